@@ -1,0 +1,48 @@
+// common.h — shared host-side helpers of the MI355X pixel-transform library.
+#pragma once
+#include <cerrno>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <hip/hip_runtime.h>
+#include "../../include/gmat_hip.h"
+
+namespace gmat {
+
+// av_log levels used by the reference filters (libavutil/log.h)
+enum { LOG_ERROR = 16, LOG_WARNING = 24, LOG_INFO = 32, LOG_VERBOSE = 40, LOG_DEBUG = 48 };
+
+void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Unlike the reference's CK_NVCV / CHECK_CU, which log and continue (vf_crop_nvcv.c:62-77,
+// swscale_cuda.c:23-25), a failed device call always aborts the operation with an error code.
+#define GMAT_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::gmat::logf(::gmat::LOG_ERROR, "HIP error %s (%d) at %s:%d: %s",            \
+                         hipGetErrorName(_e), (int)_e, __FILE__, __LINE__, #expr);       \
+            return GMAT_ERR(EIO);                                                         \
+        }                                                                                 \
+    } while (0)
+
+inline bool is_packed_rgb(int f)
+{
+    return f == GMAT_PIX_FMT_RGB24 || f == GMAT_PIX_FMT_BGR24 || f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA;
+}
+inline bool is_yuv420(int f) { return f == GMAT_PIX_FMT_NV12 || f == GMAT_PIX_FMT_YUV420P; }
+inline int  bytes_per_pixel(int f)
+{
+    switch (f) {
+    case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: return 3;
+    case GMAT_PIX_FMT_RGBA:  case GMAT_PIX_FMT_BGRA:  return 4;
+    default: return 0;
+    }
+}
+// internal accessor (gsws.cpp) used by the graph-capture helper
+int sws_src_height(const GmatSwsContext *c);
+
+inline int ceil_rshift(int a, int b) { return -((-a) >> b); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+} // namespace gmat

@@ -1,0 +1,191 @@
+// gruntime.cpp — logging, device selection, raw memory, HIP-event timers and graph capture
+// (include/gmat_hip.h §4).  The reference has av_log and nothing else here.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "common.h"
+
+namespace gmat {
+
+static gmat_log_fn g_log = nullptr;
+
+void logf(int level, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (g_log) g_log(level, buf);
+    else if (level <= LOG_ERROR) fprintf(stderr, "[gmat_hip] %s\n", buf);
+}
+
+} // namespace gmat
+
+using namespace gmat;
+
+struct GmatTimer { hipEvent_t e0, e1; };
+
+extern "C" {
+
+void gmat_set_log_callback(gmat_log_fn fn) { g_log = fn; }
+const char *gmat_version(void) { return "gmat_hip 0.1 (gfx950)"; }
+
+int gmat_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gmat_set_device(int device)
+{
+    GMAT_HIP_CHECK(hipSetDevice(device));
+    return 0;
+}
+
+int gmat_malloc(uint8_t **ptr, size_t bytes)
+{
+    if (!ptr) return GMAT_ERR(EINVAL);
+    GMAT_HIP_CHECK(hipMalloc((void **)ptr, bytes ? bytes : 1));
+    return 0;
+}
+
+int gmat_free(uint8_t *ptr)
+{
+    if (ptr) GMAT_HIP_CHECK(hipFree(ptr));
+    return 0;
+}
+
+int gmat_memcpy_h2d(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    GMAT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int gmat_memcpy_d2h(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    GMAT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int gmat_memset(uint8_t *dst, int value, size_t bytes)
+{
+    GMAT_HIP_CHECK(hipMemset(dst, value, bytes));
+    return 0;
+}
+
+int gmat_stream_create(void **stream)
+{
+    hipStream_t s;
+    GMAT_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return 0;
+}
+
+int gmat_stream_destroy(void *stream)
+{
+    if (stream) GMAT_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
+int gmat_stream_sync(void *stream)
+{
+    GMAT_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int gmat_device_sync(void)
+{
+    GMAT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
+int gmat_timer_create(void **timer)
+{
+    GmatTimer *t = new (std::nothrow) GmatTimer();
+    if (!t) return GMAT_ERR(ENOMEM);
+    if (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) {
+        delete t;
+        return GMAT_ERR(EIO);
+    }
+    *timer = t;
+    return 0;
+}
+
+int gmat_timer_begin(void *timer, void *stream)
+{
+    GMAT_HIP_CHECK(hipEventRecord(((GmatTimer *)timer)->e0, (hipStream_t)stream));
+    return 0;
+}
+
+int gmat_timer_end(void *timer, void *stream)
+{
+    GMAT_HIP_CHECK(hipEventRecord(((GmatTimer *)timer)->e1, (hipStream_t)stream));
+    return 0;
+}
+
+int gmat_timer_elapsed_ms(void *timer, float *ms)
+{
+    GmatTimer *t = (GmatTimer *)timer;
+    GMAT_HIP_CHECK(hipEventSynchronize(t->e1));
+    GMAT_HIP_CHECK(hipEventElapsedTime(ms, t->e0, t->e1));
+    return 0;
+}
+
+void gmat_timer_destroy(void *timer)
+{
+    GmatTimer *t = (GmatTimer *)timer;
+    if (!t) return;
+    (void)hipEventDestroy(t->e0);
+    (void)hipEventDestroy(t->e1);
+    delete t;
+}
+
+// Capture one gmat_sws_scale() per frame set into a graph: the per-frame kernels are a few
+// microseconds long, so replaying a captured batch removes the per-launch host cost.
+int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *src_planes, const int srcStride[],
+                          uint8_t *const *dst_planes, const int dstStride[], void *stream, void **graph_exec)
+{
+    if (!c || nframes < 1 || !graph_exec) return GMAT_ERR(EINVAL);
+    hipStream_t s = (hipStream_t)stream;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const int srcH = gmat::sws_src_height(c);
+    gmat_sws_setStream(c, stream);
+    // warm launch outside capture so lazy allocations (intermediate frame) are not captured
+    {
+        int r = gmat_sws_scale(c, src_planes, srcStride, 0, srcH, dst_planes, dstStride);
+        if (r < 0) return r;
+        GMAT_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    GMAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rr = 0;
+    for (int f = 0; f < nframes && rr >= 0; f++)
+        rr = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rr < 0 || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rr < 0 ? rr : GMAT_ERR(EIO);
+    }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return GMAT_ERR(EIO);
+    *graph_exec = (void *)exec;
+    return 0;
+}
+
+int gmat_graph_launch(void *graph_exec, void *stream)
+{
+    GMAT_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+
+void gmat_graph_destroy(void *graph_exec)
+{
+    if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
+} // extern "C"

@@ -1,0 +1,368 @@
+// gsws.cpp — libgpuscale for MI355X: the sws-style context API behind include/gmat_hip.h §1.
+//
+// Mirrors the control flow of the reference's GPU back-end (paths relative to
+// /root/reference/ffmpeg-gpu/libswscale):
+//   sws_init_context_cuda            utils.c:2026-2060   -> gmat_sws_getContext
+//   ff_get_unscaled_swscale_cuda     swscale_unscaled.c:2014-2054 (same-size converters)
+//   ff_sws_init_swscale_cuda         cuda/swscale_cuda.c:112-271  (scaled: intermediates + op)
+//   ff_swscale_cuda                  cuda/swscale_cuda.c:273-479  -> gmat_sws_scale
+//   ff_sws_free_swscale_cuda         cuda/swscale_cuda.c:86-109   -> gmat_sws_freeContext
+// Differences by design (SURVEY.md §0 defects): colour constants are per-context kernel arguments
+// (no process-global __constant__ upload on the NULL stream), the interpolation follows the flags,
+// and every device error is returned.
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "sws_tables.h"
+
+using namespace gmat;
+
+namespace {
+
+enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE };
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const void *host, size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        if (!bytes) return 0;
+        GMAT_HIP_CHECK(hipMalloc(&p, bytes));
+        GMAT_HIP_CHECK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+struct DevFilterStore {
+    DevBuf packed, pos, round;
+    int upload(const FilterBank &fb, bool vertical, DevFilter &out)
+    {
+        int r;
+        if ((r = packed.upload(fb.packed.data(), fb.packed.size() * sizeof(int32_t))) < 0) return r;
+        if ((r = pos.upload(fb.pos_even.data(), fb.pos_even.size() * sizeof(int32_t))) < 0) return r;
+        std::vector<int32_t> rnd(fb.count, 1 << 9);
+        if (vertical && fb.taps == 2) {
+            // packed_vscale's 2-tap form (vscale.c:146-160 -> yuv2rgb_full_2_c, output.c:2118-2120):
+            // no rounding constant when the two taps are a proper blend
+            for (int i = 0; i < fb.count; i++) {
+                const int f0 = fb.coef[(size_t)i * 2], f1 = fb.coef[(size_t)i * 2 + 1];
+                if (f0 + f1 == 4096 && (unsigned)f1 <= 4096u) rnd[i] = 0;
+            }
+        }
+        if ((r = round.upload(rnd.data(), rnd.size() * sizeof(int32_t))) < 0) return r;
+        out.packed = (const int32_t *)packed.p;
+        out.pos_even = (const int32_t *)pos.p;
+        out.round = (const int32_t *)round.p;
+        out.pairs = fb.pairs; out.taps = fb.taps; out.count = fb.count;
+        return 0;
+    }
+};
+
+} // namespace
+
+struct GmatSwsContext {
+    int srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags;
+    double param[2];
+    hipStream_t stream = nullptr;
+    Mode mode;
+    int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
+    Yuv2RgbConsts y2r;            // for the same-size converter (honours colourspace / range)
+    // scaler
+    ScalePlan plan;               // always an RGB24 -> dst plan (the YUV source is converted in front)
+    ScaleTiling tiling;
+    DevFilterStore dHLum, dHChr, dVLum;
+    DevBuf dColStart, dColCount, dRowStart, dRowCount;
+    ScaleArgs args;
+    int fused = 1;
+    uint8_t *inter = nullptr;     // RGB24 intermediate at source size for the two-kernel form
+    int interStride = 0;
+    const char *lastKernel = "";
+    ~GmatSwsContext() { if (inter) (void)hipFree(inter); }
+};
+
+static int init_scaler(GmatSwsContext *c)
+{
+    const bool src_yuv = is_yuv420(c->srcFormat);
+    const int planSrc = src_yuv ? GMAT_PIX_FMT_RGB24 : c->srcFormat;
+    int r = build_scale_plan(c->plan, c->srcW, c->srcH, planSrc, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
+    if (r < 0) return r;
+    if ((r = scale_pick_tiling(c->plan, c->tiling)) < 0) return r;
+    ScaleArgs &a = c->args;
+    std::memset(&a, 0, sizeof(a));
+    if ((r = c->dHLum.upload(c->plan.hLum, false, a.hLum)) < 0) return r;
+    if ((r = c->dHChr.upload(c->plan.hChr, false, a.hChr)) < 0) return r;
+    if ((r = c->dVLum.upload(c->plan.vLum, true, a.vLum)) < 0) return r;
+    const ScaleTiling &t = c->tiling;
+    if ((r = c->dColStart.upload(t.colStart.data(), t.colStart.size() * 4)) < 0) return r;
+    if ((r = c->dColCount.upload(t.colCount.data(), t.colCount.size() * 4)) < 0) return r;
+    if ((r = c->dRowStart.upload(t.rowStart.data(), t.rowStart.size() * 4)) < 0) return r;
+    if ((r = c->dRowCount.upload(t.rowCount.data(), t.rowCount.size() * 4)) < 0) return r;
+    a.colStart = (const int32_t *)c->dColStart.p; a.colCount = (const int32_t *)c->dColCount.p;
+    a.rowStart = (const int32_t *)c->dRowStart.p; a.rowCount = (const int32_t *)c->dRowCount.p;
+    a.TH = t.TH; a.ntx = t.ntx; a.nty = t.nty; a.xcdRemap = t.xcdRemap;
+    a.srcW = c->srcW; a.srcH = c->srcH; a.dstW = c->dstW; a.dstH = c->dstH;
+    a.chrHalf = c->plan.chrSrcHSub;
+    a.dstFormat = c->dstFormat;
+    // internal colour model of the generic scaler: BT.601, limited range at both RGB ends
+    a.r2y = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
+    a.y2r = make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false);
+    if (src_yuv) {
+        // the conversion stage in front uses the context's colourspace; the scaler's own output stage
+        // always uses BT.601 limited (as an RGB24->RGB libswscale context does)
+        c->y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
+    }
+    return 0;
+}
+
+namespace gmat { int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; } }
+
+extern "C" {
+
+GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
+                                    int flags, const double *param)
+{
+    if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) {
+        logf(LOG_ERROR, "gmat_sws_getContext: %dx%d -> %dx%d is an invalid scaling dimension", srcW, srcH, dstW, dstH);
+        return nullptr;
+    }
+    GmatSwsContext *c = new (std::nothrow) GmatSwsContext();
+    if (!c) return nullptr;
+    c->srcW = srcW; c->srcH = srcH; c->srcFormat = srcFormat;
+    c->dstW = dstW; c->dstH = dstH; c->dstFormat = dstFormat;
+    c->flags = flags & ~GMAT_SWS_HWACCEL;
+    c->param[0] = param ? param[0] : GMAT_SWS_PARAM_DEFAULT;
+    c->param[1] = param ? param[1] : GMAT_SWS_PARAM_DEFAULT;
+    c->y2r = make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false);
+    if (const char *e = getenv("GMAT_SWS_FUSED")) c->fused = atoi(e);
+
+    const bool same = srcW == dstW && srcH == dstH;
+    int r = 0;
+    if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat)) {
+        c->mode = MODE_YUV2RGB;
+    } else if (same && srcFormat == GMAT_PIX_FMT_NV12 && dstFormat == GMAT_PIX_FMT_RGBPF32LE) {
+        c->mode = MODE_RGBPF32;
+    } else if (same && ((srcFormat == GMAT_PIX_FMT_RGB24 && dstFormat == GMAT_PIX_FMT_BGR24) ||
+                        (srcFormat == GMAT_PIX_FMT_BGR24 && dstFormat == GMAT_PIX_FMT_RGB24))) {
+        c->mode = MODE_SWAP_RB;
+    } else if (same && srcFormat == dstFormat && is_packed_rgb(srcFormat)) {
+        c->mode = MODE_COPY;
+    } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
+               is_packed_rgb(dstFormat)) {
+        c->mode = MODE_SCALE;
+        r = init_scaler(c);
+    } else {
+        logf(LOG_ERROR, "gmat_sws_getContext: unsupported conversion %d %dx%d -> %d %dx%d", srcFormat, srcW, srcH,
+             dstFormat, dstW, dstH);
+        r = GMAT_ERR(ENOSYS);
+    }
+    if (r < 0) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void gmat_sws_setStream(GmatSwsContext *c, void *stream)
+{
+    if (c) c->stream = (hipStream_t)stream;
+}
+
+void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
+
+int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    c->colorspace = colorspace;
+    c->srcFullRange = srcFullRange;
+    c->y2r = make_yuv2rgb_consts(colorspace, srcFullRange != 0);
+    return 0;
+}
+
+int gmat_sws_setFused(GmatSwsContext *c, int fused)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    c->fused = fused;
+    return 0;
+}
+
+const char *gmat_sws_lastKernel(const GmatSwsContext *c) { return c ? c->lastKernel : ""; }
+
+int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos, int cap, int *count)
+{
+    if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
+    const FilterBank *fb;
+    switch (which) {
+    case 0: fb = &c->plan.hLum; break;
+    case 1: fb = &c->plan.hChr; break;
+    case 2: fb = &c->plan.vLum; break;
+    case 3: fb = &c->plan.vChr; break;
+    default: return GMAT_ERR(EINVAL);
+    }
+    if (count) *count = fb->count;
+    const int n = std::min(cap, fb->count);
+    if (coef) std::memcpy(coef, fb->coef.data(), (size_t)n * fb->taps * sizeof(int16_t));
+    if (pos)  std::memcpy(pos, fb->pos.data(), (size_t)n * sizeof(int32_t));
+    return fb->taps;
+}
+
+static YuvSrc yuv_src_of(int fmt, const uint8_t *const src[], const int stride[])
+{
+    YuvSrc s{};
+    s.y = src[0]; s.ys = stride[0];
+    s.u = src[1]; s.us = stride[1];
+    s.nv12 = fmt == GMAT_PIX_FMT_NV12;
+    if (!s.nv12) { s.v = src[2]; s.vs = stride[2]; }
+    return s;
+}
+
+static bool al4(const void *p, int s) { return (((uintptr_t)p | (uintptr_t)s) & 3) == 0; }
+
+int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                   int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    if (!c || !src || !dst || !srcStride || !dstStride || !src[0] || !dst[0]) {
+        logf(LOG_ERROR, "gmat_sws_scale: one of the input parameters to sws_scale() is NULL");
+        return GMAT_ERR(EINVAL);
+    }
+    // swscale.c:897-924 checks; the GPU back-end only converts whole frames (swscale_cuda.c ignores slices)
+    if (srcSliceY != 0 || srcSliceH != c->srcH) {
+        logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
+        return GMAT_ERR(EINVAL);
+    }
+    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P;
+    if (is_yuv420(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
+
+    int r = 0;
+    switch (c->mode) {
+    case MODE_YUV2RGB:
+        c->lastKernel = "yuv2rgb_kernel";
+        r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src, srcStride), dst[0], dstStride[0], c->srcW, c->srcH,
+                           c->dstFormat, c->y2r, c->stream);
+        break;
+    case MODE_RGBPF32:
+        c->lastKernel = "nv12_to_rgbpf32_kernel";
+        r = launch_nv12_to_rgbpf32(yuv_src_of(c->srcFormat, src, srcStride), dst[0], dstStride[0], c->srcW, c->srcH,
+                                   c->y2r, c->stream);
+        break;
+    case MODE_SWAP_RB:
+        c->lastKernel = "swap_rb24_kernel";
+        r = launch_swap_rb24(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, c->stream);
+        break;
+    case MODE_COPY:
+        c->lastKernel = "copy2d";
+        r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW * bytes_per_pixel(c->srcFormat),
+                          c->srcH, c->stream);
+        break;
+    case MODE_SCALE: {
+        ScaleArgs a = c->args;
+        a.dst = dst[0]; a.ds = dstStride[0];
+        const int bpp = bytes_per_pixel(c->dstFormat);
+        a.dstAligned = bpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
+        if (is_yuv420(c->srcFormat) && !c->fused) {
+            // two kernels + HBM intermediate, the reference's structure (swscale_cuda.c:352-371)
+            if (!c->inter) {
+                c->interStride = align_up(c->srcW * 3, 256);
+                GMAT_HIP_CHECK(hipMalloc((void **)&c->inter, (size_t)c->interStride * c->srcH));
+            }
+            r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src, srcStride), c->inter, c->interStride, c->srcW, c->srcH,
+                               GMAT_PIX_FMT_RGB24, c->y2r, c->stream);
+            if (r < 0) break;
+            a.srcKind = 0; a.srcBgr = 0;
+            a.src0 = c->inter; a.ss0 = c->interStride;
+            a.srcAligned = 1;
+        } else if (is_yuv420(c->srcFormat)) {
+            a.srcKind = 1;
+            a.srcNv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+            a.src0 = src[0]; a.ss0 = srcStride[0];
+            a.src1 = src[1]; a.ss1 = srcStride[1];
+            a.src2 = planarYuv ? src[2] : nullptr; a.ss2 = planarYuv ? srcStride[2] : 0;
+            a.srcAligned = al4(src[0], srcStride[0]) &&
+                           (a.srcNv12 ? al4(src[1], srcStride[1])
+                                      : ((((uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[1] |
+                                           (uintptr_t)srcStride[2]) & 1) == 0));
+            a.y2r = c->args.y2r;
+        } else {
+            a.srcKind = 0;
+            a.srcBgr = c->srcFormat == GMAT_PIX_FMT_BGR24;
+            a.src0 = src[0]; a.ss0 = srcStride[0];
+            a.srcAligned = al4(src[0], srcStride[0]);
+        }
+        if (a.srcKind == 1) {
+            // front conversion constants ride in a.y2r's closed-form fields; the output stage fields
+            // (y_coeff .. u2b) stay those of the scaler's BT.601 model
+            Yuv2RgbConsts k = c->y2r;
+            k.y_coeff = c->args.y2r.y_coeff; k.y_offset = c->args.y2r.y_offset;
+            k.v2r = c->args.y2r.v2r; k.v2g = c->args.y2r.v2g; k.u2g = c->args.y2r.u2g; k.u2b = c->args.y2r.u2b;
+            a.y2r = k;
+        }
+        c->lastKernel = scale_kernel_name(a, c->tiling);
+        r = launch_scale_rgb(a, c->tiling, c->stream);
+        break;
+    }
+    }
+    return r < 0 ? r : c->dstH;
+}
+
+// ---- plain-pointer back-end entry points under the reference's names --------------------------
+int yuv2rgb_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h,
+                 int srcFormat, int dstFormat, void *stream)
+{
+    if (!src || !dst || !is_yuv420(srcFormat)) return GMAT_ERR(EINVAL);
+    const Yuv2RgbConsts k = make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false);
+    if (dstFormat == GMAT_PIX_FMT_RGBPF32LE)
+        return launch_nv12_to_rgbpf32(yuv_src_of(srcFormat, src, srcStride), dst[0], dstStride[0], w, h, k,
+                                      (hipStream_t)stream);
+    return launch_yuv2rgb(yuv_src_of(srcFormat, src, srcStride), dst[0], dstStride[0], w, h, dstFormat, k,
+                          (hipStream_t)stream);
+}
+
+int rgb2yuv_cuda(const uint8_t *[], int[], uint8_t *[], int[], int, int, int, int, void *)
+{
+    logf(LOG_ERROR, "rgb2yuv_cuda: not implemented in this build");
+    return GMAT_ERR(ENOSYS);
+}
+
+int yuv2yuv_cuda(const uint8_t *[], int[], uint8_t *[], int[], int, int, int, int, void *)
+{
+    logf(LOG_ERROR, "yuv2yuv_cuda: not implemented in this build");
+    return GMAT_ERR(ENOSYS);
+}
+
+void rgb24tobgr24_cuda(const uint8_t *src[], uint8_t *dst[], int srcStride[], int dstStride[], int width, int height,
+                       void *stream)
+{
+    if (!src || !dst) return;
+    (void)launch_swap_rb24(src[0], srcStride[0], dst[0], dstStride[0], width, height, (hipStream_t)stream);
+}
+
+void rgb2rgb_init_cuda(void) {}
+
+// ---- metrans/app/CSwscale.c:9-40 ------------------------------------------------------------------
+GmatSwsContext *SwscaleCuda_Nv12ToRgbpf32_Init(int w, int h)
+{
+    return gmat_sws_getContext(w, h, GMAT_PIX_FMT_NV12, w, h, GMAT_PIX_FMT_RGBPF32LE, GMAT_SWS_HWACCEL, nullptr);
+}
+
+int SwscaleCuda_Nv12ToRgbpf32_Convert(GmatSwsContext *c, uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                                      int w, int h, void *stream)
+{
+    // av_image_fill_linesizes / av_image_fill_pointers for tightly packed NV12 and planar float RGB
+    // (CSwscale.c:25-28): linesize = {w, w} and {4w, 4w, 4w}; the srcStride/dstStride arguments are
+    // accepted and ignored exactly as the reference does.
+    (void)srcStride; (void)dstStride;
+    if (!c || !src || !dst) return GMAT_ERR(EINVAL);
+    const uint8_t *s[4] = {src, src + (size_t)w * h, nullptr, nullptr};
+    const int ss[4] = {w, w, 0, 0};
+    uint8_t *d[4] = {dst, dst + (size_t)4 * w * h, dst + (size_t)8 * w * h, nullptr};
+    const int dd[4] = {4 * w, 4 * w, 4 * w, 0};
+    gmat_sws_setStream(c, stream);
+    return gmat_sws_scale(c, s, ss, 0, h, d, dd);
+}
+
+void SwscaleCuda_Nv12ToRgbpf32_Delete(GmatSwsContext *c) { gmat_sws_freeContext(c); }
+
+} // extern "C"

@@ -1,0 +1,221 @@
+// k_yuv2rgb.hip — YUV 4:2:0 -> packed RGB colour conversion for gfx950 (MI355X).
+//
+// Replaces yuv2rgb_cuda -> nv122color / yuv4202color -> yuv2rgb_odd_kernel
+// (libswscale/cuda/yuv2rgb_cuda.cu:862-907,548-562,207-340) with libswscale's CPU arithmetic:
+// nearest chroma + the fixed-point tables of yuv2rgb.c, evaluated in closed form (px_math.h).
+//
+// Memory plan (HBM-bound, 4.5 B/px for rgb24): one thread converts a 4x2 pixel block.
+//   loads : 2 x dword of Y (one per row) + 1 dword of interleaved UV (or 2 x ushort for planar)
+//           -> a wave reads 256 contiguous bytes per load instruction
+//   stores: 2 x global_store_dwordx3 (12 B = 4 rgb24 pixels) -> a wave writes 768 contiguous bytes
+//           per instruction; rgba uses one dwordx4 per row.
+// No LDS: nothing is reused beyond the 2x2 chroma sharing, which lives in registers.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+enum { OUT_RGB24 = 0, OUT_BGR24 = 1, OUT_RGBA = 2, OUT_BGRA = 3 };
+
+template <int OUT>
+__device__ __forceinline__ void store_px(uint8_t *d, int r, int g, int b)
+{
+    if (OUT == OUT_RGB24)      { d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)b; }
+    else if (OUT == OUT_BGR24) { d[0] = (uint8_t)b; d[1] = (uint8_t)g; d[2] = (uint8_t)r; }
+    else if (OUT == OUT_RGBA)  { d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)b; d[3] = 255; }
+    else                       { d[0] = (uint8_t)b; d[1] = (uint8_t)g; d[2] = (uint8_t)r; d[3] = 255; }
+}
+
+// converts 4 luma samples (packed in `y4`) sharing two chroma pairs into 4 packed pixels and stores them
+template <int OUT>
+__device__ __forceinline__ void convert_row4(uint8_t *drow, unsigned y4, const ChromaTerms &c0,
+                                             const ChromaTerms &c1, int cy)
+{
+    unsigned px[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ycy = (int)((y4 >> (8 * i)) & 0xFF) * cy;
+        const ChromaTerms &c = i < 2 ? c0 : c1;
+        const unsigned r = (unsigned)luma_chan(c.r, ycy), g = (unsigned)luma_chan(c.g, ycy),
+                       b = (unsigned)luma_chan(c.b, ycy);
+        if (OUT == OUT_RGB24 || OUT == OUT_RGBA) px[i] = r | (g << 8) | (b << 16) | 0xFF000000u;
+        else                                     px[i] = b | (g << 8) | (r << 16) | 0xFF000000u;
+    }
+    if (OUT == OUT_RGBA || OUT == OUT_BGRA) {
+        *reinterpret_cast<uint4 *>(drow) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+        uint3 o;
+        o.x = (px[0] & 0xFFFFFF) | (px[1] << 24);
+        o.y = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
+        o.z = ((px[2] >> 16) & 0xFF) | (px[3] << 8);
+        *reinterpret_cast<uint3 *>(drow) = o;
+    }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void yuv2rgb_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h,
+                                                      Yuv2RgbConsts k, int aligned)
+{
+    constexpr int BPP = (OUT == OUT_RGBA || OUT == OUT_BGRA) ? 4 : 3;
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (x >= w || y >= h) return;
+
+    const uint8_t *py = s.y + (size_t)y * s.ys + x;
+    const size_t crow = (size_t)(y >> 1);
+    uint8_t *d0 = dst + (size_t)y * ds + (size_t)x * BPP;
+    const bool two_rows = y + 1 < h;
+
+    if (aligned && x + 4 <= w) {
+        const unsigned y0 = *reinterpret_cast<const unsigned *>(py);
+        const unsigned y1 = two_rows ? *reinterpret_cast<const unsigned *>(py + s.ys) : 0u;
+        int u0, v0, u1, v1;
+        if (s.nv12) {
+            const unsigned uv = *reinterpret_cast<const unsigned *>(s.u + crow * s.us + x);
+            u0 = uv & 0xFF; v0 = (uv >> 8) & 0xFF; u1 = (uv >> 16) & 0xFF; v1 = uv >> 24;
+        } else {
+            const unsigned short uu = *reinterpret_cast<const unsigned short *>(s.u + crow * s.us + (x >> 1));
+            const unsigned short vv = *reinterpret_cast<const unsigned short *>(s.v + crow * s.vs + (x >> 1));
+            u0 = uu & 0xFF; u1 = uu >> 8; v0 = vv & 0xFF; v1 = vv >> 8;
+        }
+        const ChromaTerms c0 = chroma_terms(k, u0, v0), c1 = chroma_terms(k, u1, v1);
+        convert_row4<OUT>(d0, y0, c0, c1, k.cy);
+        if (two_rows) convert_row4<OUT>(d0 + ds, y1, c0, c1, k.cy);
+        return;
+    }
+    // edge / unaligned path: byte accesses, chroma index clamped by construction (x>>1 < ceil(w/2))
+    const int nx = min(4, w - x);
+    for (int r = 0; r < (two_rows ? 2 : 1); r++) {
+        for (int i = 0; i < nx; i++) {
+            const int xx = x + i;
+            int U, V;
+            if (s.nv12) {
+                const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
+                U = p[0]; V = p[1];
+            } else {
+                U = s.u[crow * s.us + (xx >> 1)];
+                V = s.v[crow * s.vs + (xx >> 1)];
+            }
+            const ChromaTerms c = chroma_terms(k, U, V);
+            const int ycy = (int)py[(size_t)r * s.ys + i] * k.cy;
+            store_px<OUT>(d0 + (size_t)r * ds + (size_t)i * BPP, luma_chan(c.r, ycy), luma_chan(c.g, ycy),
+                          luma_chan(c.b, ycy));
+        }
+    }
+}
+
+// nv12 -> planar float RGB (AV_PIX_FMT_RGBPF32LE as GMAT defines it: three stacked planes,
+// plane k at dst + k*ds*h), value = u8 / 255.0f — the layout and normalisation of
+// nv122color_planar<RGBF32> (yuv2rgb_cuda.cu:381-545,564-570) with the integer colour stage.
+__global__ __launch_bounds__(256) void nv12_to_rgbpf32_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h,
+                                                              Yuv2RgbConsts k, int aligned)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)ds * h;
+    const size_t crow = (size_t)(y >> 1);
+    const int nx = min(4, w - x);
+    for (int r = 0; r < 2 && y + r < h; r++) {
+        float o[3][4];
+        for (int i = 0; i < 4; i++) {
+            const int xx = min(x + i, w - 1);
+            const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
+            const ChromaTerms c = chroma_terms(k, p[0], p[1]);
+            const int ycy = (int)s.y[(size_t)(y + r) * s.ys + xx] * k.cy;
+            o[0][i] = (float)luma_chan(c.r, ycy) / 255.0f;
+            o[1][i] = (float)luma_chan(c.g, ycy) / 255.0f;
+            o[2][i] = (float)luma_chan(c.b, ycy) / 255.0f;
+        }
+        for (int pl = 0; pl < 3; pl++) {
+            float *row = reinterpret_cast<float *>(dst + pl * plane + (size_t)(y + r) * ds) + x;
+            if (aligned && nx == 4) {
+                *reinterpret_cast<float4 *>(row) = make_float4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+            } else {
+                for (int i = 0; i < nx; i++) row[i] = o[pl][i];
+            }
+        }
+    }
+}
+
+// rgb24 <-> bgr24 (rgb24tobgr24_cuda, rgb2rgb_cuda_kernel.cu:7-41): 4 pixels = 3 dwords per thread
+__global__ __launch_bounds__(256) void swap_rb24_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
+                                                        int w, int h, int aligned)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *s = src + (size_t)y * ss + (size_t)x * 3;
+    uint8_t *d = dst + (size_t)y * ds + (size_t)x * 3;
+    if (aligned && x + 4 <= w) {
+        const uint3 v = *reinterpret_cast<const uint3 *>(s);
+        uint3 o;
+        // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3  ->  B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        // (written with shifts; the compiler folds the byte moves into v_perm_b32 / v_bfi_b32)
+        const unsigned b0 = (v.x >> 16) & 0xFF, g0 = (v.x >> 8) & 0xFF, r0 = v.x & 0xFF, r1 = v.x >> 24;
+        const unsigned g1 = v.y & 0xFF, b1 = (v.y >> 8) & 0xFF, r2 = (v.y >> 16) & 0xFF, g2 = v.y >> 24;
+        const unsigned b2 = v.z & 0xFF, r3 = (v.z >> 8) & 0xFF, g3 = (v.z >> 16) & 0xFF, b3 = v.z >> 24;
+        o.x = b0 | (g0 << 8) | (r0 << 16) | (b1 << 24);
+        o.y = g1 | (r1 << 8) | (b2 << 16) | (g2 << 24);
+        o.z = r2 | (b3 << 8) | (g3 << 16) | (r3 << 24);
+        *reinterpret_cast<uint3 *>(d) = o;
+        return;
+    }
+    const int nx = min(4, w - x);
+    for (int i = 0; i < nx; i++) {
+        const uint8_t r = s[3 * i], g = s[3 * i + 1], b = s[3 * i + 2];
+        d[3 * i] = b; d[3 * i + 1] = g; d[3 * i + 2] = r;
+    }
+}
+
+static inline bool aligned4(const void *p, int stride) { return (((uintptr_t)p | (uintptr_t)stride) & 3) == 0; }
+
+int launch_yuv2rgb(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, int dstFormat,
+                   const Yuv2RgbConsts &k, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int bpp = bytes_per_pixel(dstFormat);
+    if (!bpp) return GMAT_ERR(ENOSYS);
+    // vector path: 4-byte aligned luma/chroma rows and dword-aligned output groups
+    // (4 px * 3 B = 12 B keeps dword alignment; rgba needs 16 B)
+    int aligned = aligned4(s.y, s.ys) && aligned4(dst, ds);
+    if (s.nv12) aligned = aligned && aligned4(s.u, s.us);
+    else        aligned = aligned && ((((uintptr_t)s.u | (uintptr_t)s.v | (uintptr_t)s.us | (uintptr_t)s.vs) & 1) == 0);
+    if (bpp == 4) aligned = aligned && ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
+    switch (dstFormat) {
+    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(yuv2rgb_kernel<OUT_RGB24>, grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
+    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(yuv2rgb_kernel<OUT_BGR24>, grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
+    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(yuv2rgb_kernel<OUT_RGBA>,  grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
+    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(yuv2rgb_kernel<OUT_BGRA>,  grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
+    default: return GMAT_ERR(ENOSYS);
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_nv12_to_rgbpf32(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, const Yuv2RgbConsts &k,
+                           hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    if (!s.nv12) return GMAT_ERR(ENOSYS);
+    const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
+    hipLaunchKernelGGL(nv12_to_rgbpf32_kernel, grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_swap_rb24(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int aligned = aligned4(src, ss) && aligned4(dst, ds);
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4);
+    hipLaunchKernelGGL(swap_rb24_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, aligned);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

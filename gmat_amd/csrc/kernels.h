@@ -1,0 +1,78 @@
+// kernels.h — launch interface between the host layer and the HIP kernels (gfx950).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "sws_tables.h"
+
+namespace gmat {
+
+// ---- colour conversion (k_yuv2rgb.hip) ---------------------------------------------------
+struct YuvSrc {
+    const uint8_t *y, *u, *v;      // nv12: u = interleaved UV plane, v unused
+    int ys, us, vs;                // strides in bytes
+    int nv12;                      // 1: interleaved chroma
+};
+
+// nearest-chroma yuv420 -> packed rgb, libswscale fixed-point arithmetic
+int launch_yuv2rgb(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h, int dstFormat,
+                   const Yuv2RgbConsts &k, hipStream_t stream);
+// nv12 -> planar float rgb (value = u8 / 255.0f), plane stride = dstStride * h
+int launch_nv12_to_rgbpf32(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h,
+                           const Yuv2RgbConsts &k, hipStream_t stream);
+int launch_swap_rb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h,
+                     hipStream_t stream);
+
+// ---- generic scaler, packed-RGB output (k_scale.hip) ---------------------------------------
+// Device-resident copy of a FilterBank in the dword-packed form.
+struct DevFilter {
+    const int32_t *packed;    // count * pairs  (int16 pairs for v_dot2)
+    const int32_t *pos_even;  // count
+    const int32_t *round;     // count; vertical only: accumulator start value (512, or 0 for the
+                              // reference's 2-tap "packed2" form, vscale.c:146-160 / output.c:2118)
+    int pairs, taps, count;
+};
+
+// Output tiling of one context.  A block produces a TW x TH output tile; the host precomputes,
+// per tile column / tile row, the window of source columns / rows the tile's filter taps touch.
+struct ScaleTiling {
+    int TW = 0, TH = 0, ntx = 0, nty = 0;
+    int maxRows = 0, maxCols = 0;        // over all tiles (rows even, cols multiple of 4)
+    int ldsBytes = 0;
+    int xcdRemap = 1;
+    std::vector<int32_t> colStart, colCount, rowStart, rowCount;
+};
+
+struct ScaleArgs {
+    // source: packed RGB24/BGR24 (srcKind 0) or NV12/YUV420P converted on the fly (srcKind 1)
+    const uint8_t *src0, *src1, *src2;
+    int ss0, ss1, ss2;
+    int srcKind, srcNv12, srcBgr, srcAligned;
+    int srcW, srcH, dstW, dstH;
+    int chrHalf;              // chroma plane is the pairwise horizontal average (chrSrcHSubSample)
+    uint8_t *dst;
+    int ds, dstFormat, dstAligned;
+    DevFilter hLum, hChr, vLum;   // vertical chroma filter == vLum for a non-subsampled source
+    const int32_t *colStart, *colCount, *rowStart, *rowCount;   // device copies of ScaleTiling's
+    int TH, ntx, nty, xcdRemap;
+    Rgb2YuvConsts r2y;
+    Yuv2RgbConsts y2r;
+};
+
+int  scale_pick_tiling(const ScalePlan &p, ScaleTiling &t);
+int  launch_scale_rgb(const ScaleArgs &a, const ScaleTiling &t, hipStream_t stream);
+const char *scale_kernel_name(const ScaleArgs &a, const ScaleTiling &t);
+
+// ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
+int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                     int inW, int inH, int bpp, int dir, hipStream_t stream);
+int launch_flip(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                int w, int h, int bpp, int flipH, int flipV, hipStream_t stream);
+int launch_copy2d(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                  int rowBytes, int h, hipStream_t stream);
+int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                   int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream);
+int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                              int inW, int inH, int bpp, hipStream_t stream);
+
+} // namespace gmat

@@ -1,0 +1,84 @@
+// px_math.h — per-pixel fixed-point arithmetic shared by the kernels (device code, gfx950).
+//
+// Integer formulas only; every function states the libswscale expression it evaluates
+// (paths relative to /root/reference/ffmpeg-gpu/libswscale).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sws_tables.h"
+
+namespace gmat {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   // v_med3_i32
+
+// 2-way int16 dot product with int32 accumulate: v_dot2c_i32_i16 (exact integer arithmetic).
+__device__ __forceinline__ int dot2(int packed_ab, int packed_cd, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, packed_ab),
+                                  __builtin_bit_cast(short2v, packed_cd), acc, false);
+}
+
+// ---- yuv -> rgb through the closed form of the yuv2rgb.c tables ----------------------------
+// table_rV[V][Y] = y_table[offR + ((V*crv)>>16) + Y], y_table[i] = clip_u8((yb0 + i*cy + 0x8000)>>16)
+// (yuv2rgb.c:737-760, :958-971), so each channel is clip_u8((term + Y*cy) >> 16) with a per-chroma term.
+struct ChromaTerms { int r, g, b; };
+
+__device__ __forceinline__ ChromaTerms chroma_terms(const Yuv2RgbConsts &k, int U, int V)
+{
+    const int kr = k.offR + ((V * k.crv) >> 16);
+    const int kg = k.offG + ((U * k.cgu) >> 16) + ((V * k.cgv) >> 16);
+    const int kb = k.offB + ((U * k.cbu) >> 16);
+    ChromaTerms t;
+    t.r = k.base + kr * k.cy;
+    t.g = k.base + kg * k.cy;
+    t.b = k.base + kb * k.cy;
+    return t;
+}
+
+__device__ __forceinline__ int luma_chan(int term, int ycy) { return clip_u8((term + ycy) >> 16); }
+
+// ---- rgb -> 14-bit Y / U / V as the generic scaler's input stage does (input.c:795-866) -----
+__device__ __forceinline__ int rgb_to_y14(const Rgb2YuvConsts &c, int r, int g, int b)
+{
+    // rgb24ToY_c: (ry*r + gy*g + by*b + (32<<14) + (1<<8)) >> 9
+    return (c.ry * r + c.gy * g + c.by * b + (32 << 14) + (1 << 8)) >> 9;
+}
+__device__ __forceinline__ int rgb_to_u14(const Rgb2YuvConsts &c, int r, int g, int b)
+{
+    // rgb24ToUV_c: (ru*r + gu*g + bu*b + (256<<14) + (1<<8)) >> 9
+    return (c.ru * r + c.gu * g + c.bu * b + (256 << 14) + (1 << 8)) >> 9;
+}
+__device__ __forceinline__ int rgb_to_v14(const Rgb2YuvConsts &c, int r, int g, int b)
+{
+    return (c.rv * r + c.gv * g + c.bv * b + (256 << 14) + (1 << 8)) >> 9;
+}
+// rgb24ToUV_half_c on the SUM of two horizontally adjacent pixels:
+//   (ru*r + gu*g + bu*b + (256<<15) + (1<<9)) >> 10
+__device__ __forceinline__ int rgbsum_to_u14(const Rgb2YuvConsts &c, int r, int g, int b)
+{
+    return (c.ru * r + c.gu * g + c.bu * b + (256 << 15) + (1 << 9)) >> 10;
+}
+__device__ __forceinline__ int rgbsum_to_v14(const Rgb2YuvConsts &c, int r, int g, int b)
+{
+    return (c.rv * r + c.gv * g + c.bv * b + (256 << 15) + (1 << 9)) >> 10;
+}
+
+// ---- full-chroma output stage: yuv2rgb_write_full (output.c:1886-1935) ------------------------
+// Y, U, V are the vertically filtered values after their >>10.  Returns R | G<<8 | B<<16.
+__device__ __forceinline__ unsigned yuv_to_rgb_full(const Yuv2RgbConsts &k, int Y, int U, int V)
+{
+    unsigned y = (unsigned)((Y - k.y_offset) * k.y_coeff) + (1u << 21);
+    int R = (int)(y + (unsigned)(V * k.v2r));
+    int G = (int)(y + (unsigned)(V * k.v2g) + (unsigned)(U * k.u2g));
+    int B = (int)(y + (unsigned)(U * k.u2b));
+    if ((R | G | B) & 0xC0000000) {
+        // av_clip_uintp2(x, 30)
+        R = (R & ~0x3FFFFFFF) ? ((~R) >> 31) & 0x3FFFFFFF : R;
+        G = (G & ~0x3FFFFFFF) ? ((~G) >> 31) & 0x3FFFFFFF : G;
+        B = (B & ~0x3FFFFFFF) ? ((~B) >> 31) & 0x3FFFFFFF : B;
+    }
+    return (unsigned)(R >> 22) | ((unsigned)(G >> 22) << 8) | ((unsigned)(B >> 22) << 16);
+}
+
+} // namespace gmat

@@ -1,0 +1,232 @@
+/*
+ * gmat_hip.h — C ABI of the MI355X-native pixel-transform path (libgpuscale + GPU filters).
+ *
+ * Plain C, no HIP or torch types in any signature: device pointers are `uint8_t *`, streams
+ * are `void *` (a hipStream_t; the reference passes CUstream, also an opaque pointer —
+ * SURVEY.md §8b).  All work is ENQUEUED on the given stream and the call returns without
+ * synchronising, exactly like the reference (swscale_cuda.c:273-479, vf_crop_nvcv.c:209-291).
+ * Return values: >= 0 success, negative errno-style code on failure (GMAT_ERR(EINVAL) ...).
+ * Every `path:line` below is relative to /root/reference/ffmpeg-gpu/.
+ */
+#ifndef GMAT_HIP_H
+#define GMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMAT_API __attribute__((visibility("default")))
+#define GMAT_ERR(e) (-(e))
+
+/* ---- pixel formats: the integer values of enum AVPixelFormat, libavutil/pixfmt.h:65-318 ---- */
+enum GmatPixelFormat {
+    GMAT_PIX_FMT_NONE      = -1,
+    GMAT_PIX_FMT_YUV420P   = 0,
+    GMAT_PIX_FMT_RGB24     = 2,
+    GMAT_PIX_FMT_BGR24     = 3,
+    GMAT_PIX_FMT_NV12      = 23,
+    GMAT_PIX_FMT_RGBA      = 26,
+    GMAT_PIX_FMT_BGRA      = 28,
+    GMAT_PIX_FMT_HIP       = 120,   /* occupies AV_PIX_FMT_CUDA's slot: opaque device frame */
+    GMAT_PIX_FMT_RGBPF32LE = 182,   /* GMAT addition, pixfmt.h:315 */
+};
+
+/* ---- scaler flags: libswscale/swscale.h:65-95 ---- */
+#define GMAT_SWS_FAST_BILINEAR   1
+#define GMAT_SWS_BILINEAR        2
+#define GMAT_SWS_BICUBIC         4
+#define GMAT_SWS_POINT        0x10
+#define GMAT_SWS_AREA         0x20
+#define GMAT_SWS_GAUSS        0x80
+#define GMAT_SWS_SINC        0x100
+#define GMAT_SWS_LANCZOS     0x200
+#define GMAT_SWS_FULL_CHR_H_INT 0x2000
+#define GMAT_SWS_FULL_CHR_H_INP 0x4000
+#define GMAT_SWS_ACCURATE_RND  0x40000
+#define GMAT_SWS_BITEXACT      0x80000
+#define GMAT_SWS_HWACCEL      0x1000000   /* == SWS_HWACCEL_CUDA, swscale.h:95 (accepted, implied) */
+#define GMAT_SWS_PARAM_DEFAULT 123456
+
+/* colour spaces: swscale.h:99-106 */
+#define GMAT_SWS_CS_ITU709   1
+#define GMAT_SWS_CS_ITU601   5
+#define GMAT_SWS_CS_DEFAULT  5
+#define GMAT_SWS_CS_BT2020   9
+
+/* =====================================================================================
+ * 1. libgpuscale — the sws-style context API
+ *    replaces sws_getContext (libswscale/utils.c:2087) with SWS_HWACCEL_CUDA
+ *    -> sws_init_context_cuda (utils.c:2026-2060), sws_scale (swscale.c:1204),
+ *    sws_setCudaStream (swscale.h:446-448), sws_freeContext_cuda (swscale.h:170-188).
+ *
+ *    Semantics are libswscale's CPU arithmetic (SURVEY.md §0 lists why the reference GPU
+ *    arithmetic is not the parity target):
+ *      - same size, YUV -> RGB: nearest-chroma fixed-point yuv2rgb (yuv2rgb.c:346-405), bit-exact
+ *      - same size, RGB24 <-> BGR24: byte swap (rgb2rgb_template.c)
+ *      - everything else: the generic scaler (swscale.c:234-520) in integer arithmetic, bit-exact
+ *        with the portable C build (filterAlign 1); for a YUV source with a different output
+ *        size the result equals the reference's convert-then-resize order of operations
+ *        (swscale_cuda.c:352-371) with both stages in libswscale arithmetic, i.e.
+ *        POINT-convert to RGB24 at source size, then RGB24 -> RGB scale.
+ * ===================================================================================== */
+typedef struct GmatSwsContext GmatSwsContext;
+
+GMAT_API GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat,
+                                             int dstW, int dstH, int dstFormat,
+                                             int flags, const double *param /* [2] or NULL */);
+/* src[]/dst[] are device pointers in AVFrame plane order, strides in bytes.  The whole frame is
+ * processed (srcSliceY/srcSliceH are validated then ignored, as swscale_cuda.c does). */
+GMAT_API int  gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[],
+                             int srcSliceY, int srcSliceH,
+                             uint8_t *const dst[], const int dstStride[]);
+GMAT_API void gmat_sws_setStream(GmatSwsContext *c, void *stream);
+GMAT_API void gmat_sws_freeContext(GmatSwsContext *c);
+/* sws_setColorspaceDetails subset (utils.c:902): colourspace index + source range for YUV->RGB */
+GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange);
+
+/* how a scaled YUV->RGB context runs: 0 = two kernels with an HBM RGB24 intermediate owned by the
+ * context (the reference's structure, swscale_cuda.c:248-266,352-371), 1 = one fused kernel
+ * producing bit-identical output without the intermediate.  Default 1. */
+GMAT_API int  gmat_sws_setFused(GmatSwsContext *c, int fused);
+/* introspection used by tests and bench: which 0 hLum 1 hChr 2 vLum 3 vChr.  Copies up to `cap`
+ * int16 coefficients / int32 positions to HOST buffers; returns filter size, *count = rows. */
+GMAT_API int  gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos,
+                                 int cap, int *count);
+/* name of the kernel the last gmat_sws_scale() launched last (static string) */
+GMAT_API const char *gmat_sws_lastKernel(const GmatSwsContext *c);
+
+/* ---- the plain-pointer back-end entry points, under the reference's own names ----------
+ * libswscale core calls these (swscale_unscaled.c:1970-2012); CUstream == void*.          */
+GMAT_API int  yuv2rgb_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[],
+                           int w, int h, int srcFormat, int dstFormat, void *stream);   /* :1980 */
+GMAT_API int  rgb2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[],
+                           int w, int h, int srcFormat, int dstFormat, void *stream);   /* :1984 */
+GMAT_API int  yuv2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[],
+                           int w, int h, int srcFormat, int dstFormat, void *stream);   /* :1988 */
+GMAT_API void rgb24tobgr24_cuda(const uint8_t *src[], uint8_t *dst[], int srcStride[], int dstStride[],
+                                int width, int height, void *stream);                   /* :1970 */
+GMAT_API void rgb2rgb_init_cuda(void);                                 /* rgb2rgb.h:175 (no-op) */
+
+/* ---- caller of libgpuscale: metrans/app/CSwscale.c:9-40 (bound by metrans/python/swscale.py) -- */
+GMAT_API GmatSwsContext *SwscaleCuda_Nv12ToRgbpf32_Init(int w, int h);
+GMAT_API int  SwscaleCuda_Nv12ToRgbpf32_Convert(GmatSwsContext *c, uint8_t *src, int srcStride,
+                                                uint8_t *dst, int dstStride, int w, int h, void *stream);
+GMAT_API void SwscaleCuda_Nv12ToRgbpf32_Delete(GmatSwsContext *c);
+
+/* =====================================================================================
+ * 2. Frames — the AVFrame / AVHWFramesContext subset the filters touch
+ *    (libavutil/frame.h, libavutil/hwcontext.h:124-229, hwcontext_cuda.c:96-193)
+ * ===================================================================================== */
+typedef struct GmatHWFramesContext GmatHWFramesContext;
+
+typedef struct GmatFrame {
+    uint8_t *data[4];          /* device pointers (format == GMAT_PIX_FMT_HIP) or host pointers   */
+    int      linesize[4];
+    int      width, height;
+    int      format;           /* GMAT_PIX_FMT_HIP for device frames, else the sw format          */
+    int      sw_format;        /* layout of the planes                                             */
+    int64_t  pts;
+    int      colorspace;       /* AVCOL_SPC_* as carried by AVFrame.colorspace (copied by props)   */
+    GmatHWFramesContext *hw_frames_ctx;   /* owner pool, NULL for caller-owned memory              */
+    void    *buf;              /* pool bookkeeping, opaque                                          */
+} GmatFrame;
+
+/* av_hwframe_ctx_alloc + field assignment + av_hwframe_ctx_init (hwcontext.h:361,371) */
+GMAT_API GmatHWFramesContext *gmat_hwframe_ctx_create(int device, int sw_format, int width, int height,
+                                                      int initial_pool_size);
+GMAT_API void gmat_hwframe_ctx_free(GmatHWFramesContext *fc);
+GMAT_API int  gmat_hwframe_ctx_info(const GmatHWFramesContext *fc, int *device, int *sw_format,
+                                    int *width, int *height);
+/* av_hwframe_get_buffer (hwcontext.h:382): pooled hipMalloc block, plane layout per
+ * hwcontext_cuda.c:183-193 (linesize aligned to 256 B; NV12 UV directly after Y) */
+GMAT_API int  gmat_hwframe_get_buffer(GmatHWFramesContext *fc, GmatFrame *frame);
+GMAT_API GmatFrame *gmat_frame_alloc(void);                 /* av_frame_alloc  */
+GMAT_API void gmat_frame_free(GmatFrame **frame);           /* av_frame_free: returns the buffer to its pool */
+/* av_hwframe_transfer_data (hwcontext.h:413, hwcontext_cuda.c:221-279): one 2-D async copy per
+ * plane on `stream`; direction from which side has format == GMAT_PIX_FMT_HIP */
+GMAT_API int  gmat_hwframe_transfer_data(GmatFrame *dst, const GmatFrame *src, void *stream);
+/* pinned host staging (hipHostMalloc) so transfers overlap compute */
+GMAT_API int  gmat_host_frame_alloc(GmatFrame *frame, int sw_format, int width, int height);
+GMAT_API void gmat_host_frame_free(GmatFrame *frame);
+
+/* =====================================================================================
+ * 3. Filters — AVFilter-shaped: init / config_props / filter_frame / uninit
+ *    crop_hip    <- vf_crop_nvcv.c    options w,h,x,y            (:80-86)
+ *    flip_hip    <- vf_flip_nvcv.c    option  code 0|1|-1        (:77-80)
+ *    rotate_hip  <- vf_rotate_nvcv.c  options angle, interp, shift_x, shift_y (:79-88);
+ *                   multiples of 90 degrees are exact transposes (vf_transpose.c semantics,
+ *                   output w/h swapped); other angles are rejected with ENOSYS this round
+ *    transpose_hip <- vf_transpose.c  option dir 0..3 (names :374-379)
+ *    smooth_hip  <- vf_smooth_nvcv.c  options type, kw, kh, border_type, sigmaX, sigmaY (:82-105);
+ *                   3x3 "gaussian" = integer kernel 1 2 1 / 2 4 2 / 1 2 1, rdiv 1/16
+ *                   (vf_convolution.c:495-512 arithmetic and :555-569 borders)
+ *    scale_hip   <- vf_scale_cuda.c   options w,h,interp_algo,format (:586-603) on top of libgpuscale
+ *    format_hip  <- vf_format_cuda.c  option pix_fmt (:69-79)
+ *  Input sw formats accepted by the nvcv-style filters: rgb24 bgr24 rgba bgra (vf_crop_nvcv.c:90-98).
+ * ===================================================================================== */
+typedef struct GmatFilterContext GmatFilterContext;
+
+GMAT_API GmatFilterContext *gmat_filter_alloc(const char *name);
+GMAT_API int  gmat_filter_set_option(GmatFilterContext *f, const char *key, const char *value); /* AVOption */
+GMAT_API int  gmat_filter_init(GmatFilterContext *f);                                /* AVFilter.init          */
+/* config_props(outlink): derives the output size/format from the input frames context and creates
+ * the output frames context on the same device (vf_crop_nvcv.c:133-207) */
+GMAT_API int  gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frames, void *stream);
+GMAT_API GmatHWFramesContext *gmat_filter_out_frames(GmatFilterContext *f);
+/* filter_frame(inlink, in): takes ownership of `in` (frees it, also on error), returns a pooled
+ * output frame with props copied (vf_crop_nvcv.c:209-291) */
+GMAT_API int  gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out);
+GMAT_API void gmat_filter_free(GmatFilterContext *f);                                /* uninit + free */
+
+/* direct launchers behind the filters (device pointers, packed pixels of bpp bytes) */
+GMAT_API int gmat_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                            int inW, int inH, int bpp, int dir, void *stream);
+GMAT_API int gmat_flip(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                       int w, int h, int bpp, int code, void *stream);
+GMAT_API int gmat_crop(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                       int x, int y, int w, int h, int bpp, void *stream);
+GMAT_API int gmat_smooth3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                            int w, int h, int bpp, const int matrix[9], float rdiv, float bias, void *stream);
+/* rotate(90 clockwise) + horizontal flip + 3x3 smooth in ONE kernel (cfg4 fused form) */
+GMAT_API int gmat_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                                     int inW, int inH, int bpp, void *stream);
+
+/* =====================================================================================
+ * 4. Runtime helpers (logging, device, timing) — no reference counterpart beyond av_log
+ * ===================================================================================== */
+typedef void (*gmat_log_fn)(int level, const char *msg);
+GMAT_API void gmat_set_log_callback(gmat_log_fn fn);     /* default: stderr for level <= 16 (AV_LOG_ERROR) */
+GMAT_API int  gmat_device_count(void);
+GMAT_API int  gmat_set_device(int device);
+GMAT_API const char *gmat_version(void);
+GMAT_API int  gmat_malloc(uint8_t **ptr, size_t bytes);   /* hipMalloc */
+GMAT_API int  gmat_free(uint8_t *ptr);
+GMAT_API int  gmat_memcpy_h2d(uint8_t *dst, const uint8_t *src, size_t bytes);
+GMAT_API int  gmat_memcpy_d2h(uint8_t *dst, const uint8_t *src, size_t bytes);
+GMAT_API int  gmat_memset(uint8_t *dst, int value, size_t bytes);
+GMAT_API int  gmat_stream_create(void **stream);
+GMAT_API int  gmat_stream_destroy(void *stream);
+GMAT_API int  gmat_stream_sync(void *stream);
+GMAT_API int  gmat_device_sync(void);
+/* hipEvent pair timing on `stream`: begin/end bracket a region, elapsed in milliseconds */
+GMAT_API int  gmat_timer_create(void **timer);
+GMAT_API int  gmat_timer_begin(void *timer, void *stream);
+GMAT_API int  gmat_timer_end(void *timer, void *stream);
+GMAT_API int  gmat_timer_elapsed_ms(void *timer, float *ms);   /* synchronises on the end event */
+GMAT_API void gmat_timer_destroy(void *timer);
+/* capture `iters` repetitions of gmat_sws_scale over `nframes` rotating frame sets into a
+ * hipGraph and launch it `launches` times (launch-bound inner loop -> graph replay) */
+GMAT_API int  gmat_sws_graph_create(GmatSwsContext *c, int nframes,
+                                    const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
+                                    uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
+                                    void *stream, void **graph_exec);
+GMAT_API int  gmat_graph_launch(void *graph_exec, void *stream);
+GMAT_API void gmat_graph_destroy(void *graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMAT_HIP_H */

@@ -1,0 +1,148 @@
+/*
+ * oracle/orc.h — CPU restatement of the reference's pixel-transform arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gmat_amd/ (the product) may include,
+ * link, dlopen or call anything declared here; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg do.  The product path fails loudly when its HIP
+ * library is missing — it never falls back to this code.
+ *
+ * What is restated (all paths relative to /root/reference/ffmpeg-gpu):
+ *   libswscale/yuv2rgb.c      — fixed-point yuv->rgb look-up tables and the
+ *                               yuv2rgb_c_24_rgb/_bgr/_32 "fast path" converters
+ *   libswscale/utils.c        — initFilter() coefficient generator, the chroma
+ *                               sub-sampling / filter-selection logic of
+ *                               sws_init_single_context(), fill_rgb2yuv_table()
+ *   libswscale/input.c        — rgb24/bgr24 readers (ToY, ToUV, ToUV_half), nv12 reader
+ *   libswscale/swscale.c      — hScale8To15_c / hScale16To15_c, the swscale() row schedule
+ *   libswscale/output.c       — yuv2rgb_{X,2,1}_c and yuv2rgb_full_{X,2,1}_c templates,
+ *                               yuv2planeX_8_c / yuv2plane1_8_c / yuv2nv12cX_c
+ *   libavfilter/vf_transpose.c, vf_hflip.c, vf_vflip.c, vf_crop.c, vf_convolution.c
+ *
+ * PARITY PIN STATUS: the reference's libswscale cannot be
+ * built in this image without generated headers (config.h) and stand-ins for cuda.h /
+ * CV-CUDA, so no oracle/_ref exists.  The oracle is pinned by
+ *   (1) known-answer values the survey recorded from the reference run (SURVEY.md §8a
+ *       row 7, §8c item 5): filter sizes, coefficient rows and positions for
+ *       3840->1920 / 2160->1080 bicubic and the 540->1080 chroma filter;
+ *   (2) constants that are literal in the reference sources (ff_yuv2rgb_coeffs,
+ *       BT.601 rgb2yuv literals);
+ *   (3) the LUT path and the closed form being two independent restatements that must
+ *       agree over all 2^24 (Y,U,V) triples.
+ * The reference's FATE references for this path are NUT-container md5s
+ * (tests/ref/fate/filter-pixfmts-*), which cannot be reproduced without restating the
+ * muxer; they are not used.  Parity is therefore "partially pinned".
+ */
+#ifndef GMAT_ORACLE_ORC_H
+#define GMAT_ORACLE_ORC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum AVPixelFormat values, libavutil/pixfmt.h:65-... of the reference tree */
+enum {
+    ORC_PIX_YUV420P = 0,
+    ORC_PIX_RGB24   = 2,
+    ORC_PIX_BGR24   = 3,
+    ORC_PIX_NV12    = 23,
+    ORC_PIX_RGBA    = 26,
+    ORC_PIX_BGRA    = 28,
+    ORC_PIX_RGBPF32LE = 182,
+};
+
+/* libswscale/swscale.h:65-95 */
+#define ORC_SWS_FAST_BILINEAR 1
+#define ORC_SWS_BILINEAR      2
+#define ORC_SWS_BICUBIC       4
+#define ORC_SWS_POINT      0x10
+#define ORC_SWS_AREA       0x20
+#define ORC_SWS_LANCZOS   0x200
+#define ORC_SWS_FULL_CHR_H_INT 0x2000
+#define ORC_SWS_FULL_CHR_H_INP 0x4000
+#define ORC_SWS_ACCURATE_RND  0x40000
+#define ORC_SWS_BITEXACT      0x80000
+#define ORC_SWS_PARAM_DEFAULT 123456
+
+#define ORC_TABLE_HEADROOM      512   /* swscale_internal.h:45 */
+#define ORC_TABLE_LUMA_HEADROOM 512   /* swscale_internal.h:46 */
+
+/* yuv2rgb.c:774-1030 (24 bpp branch :958-971) */
+typedef struct OrcYuv2Rgb {
+    int      full_range;
+    int64_t  cy, oy, yb0;                 /* luma scale / offset / table origin       */
+    int64_t  crv, cbu, cgu, cgv;          /* chroma increments after the /cy rescale  */
+    int      yoffs;
+    int16_t  y_coeff, y_offset, v2r, v2g, u2g, u2b;   /* yuv2rgb.c:843-848 */
+    uint8_t  y_table[1024 + 2 * ORC_TABLE_LUMA_HEADROOM];
+    int32_t  off_rV[256 + 2 * ORC_TABLE_HEADROOM];    /* index offsets into y_table   */
+    int32_t  off_gU[256 + 2 * ORC_TABLE_HEADROOM];
+    int32_t  off_gV[256 + 2 * ORC_TABLE_HEADROOM];
+    int32_t  off_bU[256 + 2 * ORC_TABLE_HEADROOM];
+} OrcYuv2Rgb;
+
+int  orc_yuv2rgb_init(OrcYuv2Rgb *t, int colorspace, int full_range,
+                      int brightness, int contrast, int saturation);
+/* one pixel through the look-up tables exactly as LOADCHROMA/PUTRGB24 do */
+void orc_yuv2rgb_lut_px(const OrcYuv2Rgb *t, int Y, int U, int V, uint8_t rgb[3]);
+/* the closed form of SURVEY.md §8a row 1 — independent of the tables */
+void orc_yuv2rgb_closed_px(const OrcYuv2Rgb *t, int Y, int U, int V, uint8_t rgb[3]);
+/* returns number of mismatching triples over all 2^24 inputs */
+long orc_yuv2rgb_selfcheck(const OrcYuv2Rgb *t);
+
+/* yuv2rgb.c:346-405 fast path: nearest chroma, 2x2 quads.  src_fmt NV12 or YUV420P,
+ * dst_fmt RGB24/BGR24/RGBA/BGRA.  Handles odd w/h by clamping the chroma index
+ * (the reference requires even sizes; the GPU kernels accept odd ones the same way
+ * the reference's yuv2rgb_odd_kernel does). */
+int  orc_yuv2rgb_frame(const OrcYuv2Rgb *t, const uint8_t *const src[4], const int src_stride[4],
+                       uint8_t *dst, int dst_stride, int w, int h, int src_fmt, int dst_fmt);
+/* nv12 -> planar float rgb, value = u8 / 255.0f (yuv2rgb_cuda.cu:381-545 semantics with
+ * the integer colour stage substituted) */
+int  orc_nv12_to_rgbpf32(const OrcYuv2Rgb *t, const uint8_t *const src[4], const int src_stride[4],
+                         float *dst, int dst_stride_bytes, int w, int h);
+
+/* utils.c:367-763 */
+int  orc_init_filter(int16_t **out_filter, int32_t **filter_pos, int *out_filter_size,
+                     int x_inc, int src_w, int dst_w, int filter_align, int one,
+                     int flags, const double param[2], int src_pos, int dst_pos);
+void orc_free(void *p);
+
+/* generic scaler context (utils.c:1293-2020 + swscale.c:234-520) */
+typedef struct OrcSws OrcSws;
+OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
+                       int flags, const double param[2]);
+int   orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
+                    uint8_t *const dst[4], const int dst_stride[4]);
+/* row-sliced variant for the threaded cpu baseline: computes output rows [y0,y1) */
+int   orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
+                         uint8_t *const dst[4], const int dst_stride[4], int y0, int y1);
+void  orc_sws_free(OrcSws *c);
+/* introspection for the known-answer tests: which = 0 hLum, 1 hChr, 2 vLum, 3 vChr */
+int   orc_sws_filter(const OrcSws *c, int which, const int16_t **coef, const int32_t **pos,
+                     int *size, int *count);
+int   orc_sws_info(const OrcSws *c, int *chr_src_w, int *chr_src_h, int *chr_dst_w, int *chr_dst_h,
+                   int *flags);
+
+/* filters (libavfilter CPU counterparts) — packed pixels of `bpp` bytes */
+void orc_transpose(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                   int in_w, int in_h, int bpp, int dir);           /* vf_transpose.c:267-327 */
+void orc_hflip(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+               int w, int h, int bpp);                              /* vf_hflip.c:89-117 */
+void orc_vflip(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+               int w, int h, int bpp);                              /* vf_vflip.c:108-127 */
+void orc_crop(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+              int x, int y, int w, int h, int bpp);                 /* vf_crop.c */
+/* vf_convolution.c:495-512 + setup_3x3 :555-569 applied per channel of a packed frame */
+void orc_conv3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                 int w, int h, int bpp, const int matrix[9], float rdiv, float bias);
+void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                       int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
+
+/* deterministic synthetic planes: s = s*1664525 + 1013904223, byte = s>>24 */
+void orc_fill_lcg(uint8_t *p, long n, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,563 @@
+/*
+ * oracle/orc_sws.c — TEST INFRASTRUCTURE ONLY (see orc.h).
+ *
+ * CPU restatement of libswscale's *generic* scaler for the formats on the hot path:
+ *   src: RGB24, BGR24, NV12, YUV420P        dst: RGB24, BGR24, RGBA, BGRA, NV12, YUV420P
+ *
+ * Follows (reference tree, ffmpeg-gpu/libswscale):
+ *   sws_init_single_context   utils.c:1293-2020  chroma sub-sampling decisions :1427-1557,
+ *                                                increments :1412-1413,:1588-1589,
+ *                                                filter creation :1820-1875
+ *   get_local_pos             utils.c:338-345
+ *   fill_rgb2yuv_table        utils.c:765-858
+ *   rgb24ToY_c/ToUV_c/ToUV_half_c, bgr24 twins, nvXXtoUV_c   input.c:795-866, :675-690
+ *   hScale8To15_c / hScale16To15_c                         swscale.c:93-136
+ *   swscale() row schedule                                 swscale.c:372-389
+ *   packed_vscale selection                                vscale.c:108-170
+ *   yuv2rgb_{X,2,1}_c_template + yuv2rgb_write             output.c:1554-1828
+ *   yuv2rgb_full_{X,2,1}_c_template + yuv2rgb_write_full   output.c:1886-1935,:2037-2200
+ *   yuv2planeX_8_c / yuv2plane1_8_c / yuv2nv12cX_c         output.c:400-450
+ *   lum/chr planar vscale                                  vscale.c:30-105
+ *
+ * It models the portable C build (cpu_flags == 0, filterAlign == 1).  It always takes the
+ * generic path: the special unscaled converters (ff_get_unscaled_swscale) are restated
+ * separately (orc_yuv2rgb_frame, orc_rgb24_swap_rb).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "orc.h"
+
+struct OrcSws {
+    int src_w, src_h, dst_w, dst_h, src_fmt, dst_fmt, flags;
+    int chr_src_hsub, chr_src_vsub, chr_dst_hsub, chr_dst_vsub;
+    int chr_src_w, chr_src_h, chr_dst_w, chr_dst_h;
+    int lum_x_inc, lum_y_inc, chr_x_inc, chr_y_inc;
+    int16_t *h_lum, *h_chr, *v_lum, *v_chr;
+    int32_t *h_lum_pos, *h_chr_pos, *v_lum_pos, *v_chr_pos;
+    int h_lum_size, h_chr_size, v_lum_size, v_chr_size;
+    int src_is_rgb, dst_is_rgb;
+    int32_t ry, gy, by, ru, gu, bu, rv, gv, bv;
+    OrcYuv2Rgb y2r;
+};
+
+#define RGB2YUV_SHIFT 15    /* swscale_internal.h:452 */
+
+static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
+static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P; }
+static int ceil_rshift(int a, int b) { return -((-a) >> b); }
+static int clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+static int clip_uintp2_30(int a)
+{
+    /* av_clip_uintp2_c(a, 30), libavutil/common.h */
+    if (a & ~((1 << 30) - 1)) return (~a) >> 31 & ((1 << 30) - 1);
+    return a;
+}
+
+static int get_local_pos(int chr_subsample, int pos)
+{
+    if (pos == -1 || pos <= -513)
+        pos = (128 << chr_subsample) - 128;
+    pos += 128;
+    return pos >> chr_subsample;
+}
+
+static int64_t rounded_div(int64_t a, int64_t b)
+{
+    return a >= 0 ? (a + (b >> 1)) / b : (a - (b >> 1)) / b;
+}
+
+extern const int32_t *orc_get_coefficients(int colorspace);
+
+static void fill_rgb2yuv(OrcSws *c, int colorspace)
+{
+    const int32_t *table = orc_get_coefficients(colorspace);
+    const int32_t *def   = orc_get_coefficients(5);
+    int64_t W, V, Z, Cy, Cu, Cv;
+    int64_t vr = table[0], ub = table[1], ug = -table[2], vg = -table[3];
+    const int64_t ONE = 65536;
+    int64_t cy = ONE;
+
+    cy = cy * 255 / 219;                         /* dstRange forced to 0, utils.c:811 */
+    W = rounded_div(ONE * ONE * ug, ub);
+    V = rounded_div(ONE * ONE * vg, vr);
+    Z = ONE * ONE - W - V;
+    Cy = rounded_div(cy * Z, ONE);
+    Cu = rounded_div(ub * Z, ONE);
+    Cv = rounded_div(vr * Z, ONE);
+
+    c->ry = (int32_t)-rounded_div((1 << RGB2YUV_SHIFT) * V, Cy);
+    c->gy = (int32_t) rounded_div((1 << RGB2YUV_SHIFT) * ONE * ONE, Cy);
+    c->by = (int32_t)-rounded_div((1 << RGB2YUV_SHIFT) * W, Cy);
+    c->ru = (int32_t) rounded_div((1 << RGB2YUV_SHIFT) * V, Cu);
+    c->gu = (int32_t)-rounded_div((1 << RGB2YUV_SHIFT) * ONE * ONE, Cu);
+    c->bu = (int32_t) rounded_div((1 << RGB2YUV_SHIFT) * (Z + W), Cu);
+    c->rv = (int32_t) rounded_div((1 << RGB2YUV_SHIFT) * (V + Z), Cv);
+    c->gv = (int32_t)-rounded_div((1 << RGB2YUV_SHIFT) * ONE * ONE, Cv);
+    c->bv = (int32_t) rounded_div((1 << RGB2YUV_SHIFT) * W, Cv);
+
+    if (!memcmp(table, def, 4 * sizeof(int32_t))) {               /* utils.c:845-856 */
+        c->by =  ((int)(0.114 * 219 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->bv = (-(int)(0.081 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->bu =  ((int)(0.500 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->gy =  ((int)(0.587 * 219 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->gv = (-(int)(0.419 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->gu = (-(int)(0.331 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->ry =  ((int)(0.299 * 219 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->rv =  ((int)(0.500 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+        c->ru = (-(int)(0.169 * 224 / 255 * (1 << RGB2YUV_SHIFT) + 0.5));
+    }
+}
+
+void orc_sws_free(OrcSws *c)
+{
+    if (!c) return;
+    free(c->h_lum); free(c->h_chr); free(c->v_lum); free(c->v_chr);
+    free(c->h_lum_pos); free(c->h_chr_pos); free(c->v_lum_pos); free(c->v_chr_pos);
+    free(c);
+}
+
+OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
+                       int flags, const double param[2])
+{
+    OrcSws *c;
+    int scaler_mask = ORC_SWS_FAST_BILINEAR | ORC_SWS_BILINEAR | ORC_SWS_BICUBIC | 8 | ORC_SWS_POINT |
+                      ORC_SWS_AREA | 0x40 | 0x80 | 0x100 | ORC_SWS_LANCZOS | 0x400;
+
+    if (!(is_rgb(src_fmt) || is_yuv(src_fmt)) || !(is_rgb(dst_fmt) || is_yuv(dst_fmt)))
+        return NULL;
+    if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
+        return NULL;                                       /* 32-bit readers not restated */
+    if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
+        return NULL;
+    c = (OrcSws *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+
+    if (!(flags & scaler_mask))
+        flags |= ORC_SWS_BICUBIC;                          /* utils.c:1370-1381 */
+    c->src_w = src_w; c->src_h = src_h; c->dst_w = dst_w; c->dst_h = dst_h;
+    c->src_fmt = src_fmt; c->dst_fmt = dst_fmt;
+    c->src_is_rgb = is_rgb(src_fmt);
+    c->dst_is_rgb = is_rgb(dst_fmt);
+
+    c->lum_x_inc = (int)((((int64_t)src_w << 16) + (dst_w >> 1)) / dst_w);
+    c->lum_y_inc = (int)((((int64_t)src_h << 16) + (dst_h >> 1)) / dst_h);
+
+    c->chr_src_hsub = c->chr_src_vsub = c->src_is_rgb ? 0 : 1;
+    c->chr_dst_hsub = c->chr_dst_vsub = c->dst_is_rgb ? 0 : 1;
+
+    if (c->dst_is_rgb && !(flags & ORC_SWS_FULL_CHR_H_INT)) {      /* utils.c:1431-1448 */
+        if (dst_w & 1)
+            flags |= ORC_SWS_FULL_CHR_H_INT;
+        if (c->chr_src_hsub == 0 && c->chr_src_vsub == 0 && !(flags & ORC_SWS_FAST_BILINEAR))
+            flags |= ORC_SWS_FULL_CHR_H_INT;
+    }
+    if (!c->dst_is_rgb)
+        flags &= ~ORC_SWS_FULL_CHR_H_INT;                          /* utils.c:1483-1517 */
+    if (c->dst_is_rgb && !(flags & ORC_SWS_FULL_CHR_H_INT))
+        c->chr_dst_hsub = 1;                                       /* :1519-1520 */
+    if (c->src_is_rgb && !(flags & ORC_SWS_FULL_CHR_H_INP) &&
+        ((dst_w >> c->chr_dst_hsub) <= (src_w >> 1) || (flags & ORC_SWS_FAST_BILINEAR)))
+        c->chr_src_hsub = 1;                                       /* :1529-1545 */
+    c->flags = flags;
+
+    c->chr_src_w = ceil_rshift(src_w, c->chr_src_hsub);
+    c->chr_src_h = ceil_rshift(src_h, c->chr_src_vsub);
+    c->chr_dst_w = ceil_rshift(dst_w, c->chr_dst_hsub);
+    c->chr_dst_h = ceil_rshift(dst_h, c->chr_dst_vsub);
+    c->chr_x_inc = (int)((((int64_t)c->chr_src_w << 16) + (c->chr_dst_w >> 1)) / c->chr_dst_w);
+    c->chr_y_inc = (int)((((int64_t)c->chr_src_h << 16) + (c->chr_dst_h >> 1)) / c->chr_dst_h);
+
+    /* filters, utils.c:1820-1875; BICUBLIN (0x40) is not on the path and not restated */
+    if (orc_init_filter(&c->h_lum, &c->h_lum_pos, &c->h_lum_size, c->lum_x_inc, src_w, dst_w, 1, 1 << 14,
+                        flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
+    if (orc_init_filter(&c->h_chr, &c->h_chr_pos, &c->h_chr_size, c->chr_x_inc, c->chr_src_w, c->chr_dst_w,
+                        1, 1 << 14, flags, param,
+                        get_local_pos(c->chr_src_hsub, -513), get_local_pos(c->chr_dst_hsub, -513)) < 0) goto fail;
+    if (orc_init_filter(&c->v_lum, &c->v_lum_pos, &c->v_lum_size, c->lum_y_inc, src_h, dst_h, 1, 1 << 12,
+                        flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
+    if (orc_init_filter(&c->v_chr, &c->v_chr_pos, &c->v_chr_size, c->chr_y_inc, c->chr_src_h, c->chr_dst_h,
+                        1, 1 << 12, flags, param,
+                        get_local_pos(c->chr_src_vsub, -513), get_local_pos(c->chr_dst_vsub, -513)) < 0) goto fail;
+
+    /* colour tables: BT.601, limited range on both sides (sws_setColorspaceDetails defaults,
+     * utils.c:902-1030: RGB ends have their range forced to 0) */
+    orc_yuv2rgb_init(&c->y2r, 5, 0, 0, 1 << 16, 1 << 16);
+    fill_rgb2yuv(c, 5);
+    return c;
+fail:
+    orc_sws_free(c);
+    return NULL;
+}
+
+int orc_sws_filter(const OrcSws *c, int which, const int16_t **coef, const int32_t **pos, int *size, int *count)
+{
+    switch (which) {
+    case 0: *coef = c->h_lum; *pos = c->h_lum_pos; *size = c->h_lum_size; *count = c->dst_w;     return 0;
+    case 1: *coef = c->h_chr; *pos = c->h_chr_pos; *size = c->h_chr_size; *count = c->chr_dst_w; return 0;
+    case 2: *coef = c->v_lum; *pos = c->v_lum_pos; *size = c->v_lum_size; *count = c->dst_h;     return 0;
+    case 3: *coef = c->v_chr; *pos = c->v_chr_pos; *size = c->v_chr_size; *count = c->chr_dst_h; return 0;
+    }
+    return -1;
+}
+
+int orc_sws_info(const OrcSws *c, int *chr_src_w, int *chr_src_h, int *chr_dst_w, int *chr_dst_h, int *flags)
+{
+    *chr_src_w = c->chr_src_w; *chr_src_h = c->chr_src_h;
+    *chr_dst_w = c->chr_dst_w; *chr_dst_h = c->chr_dst_h;
+    *flags = c->flags;
+    return 0;
+}
+
+/* ---- input stage: one source row -> 15-bit horizontally scaled lines -------------------- */
+
+static void hscale8(int16_t *dst, int dst_w, const uint8_t *src, const int16_t *filter,
+                    const int32_t *pos, int fs)
+{
+    int i, j;
+    for (i = 0; i < dst_w; i++) {
+        int val = 0;
+        for (j = 0; j < fs; j++)
+            val += ((int)src[pos[i] + j]) * filter[fs * i + j];
+        val >>= 7;
+        dst[i] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+    }
+}
+
+static void hscale16(int16_t *dst, int dst_w, const uint16_t *src, const int16_t *filter,
+                     const int32_t *pos, int fs, int sh)
+{
+    int i, j;
+    for (i = 0; i < dst_w; i++) {
+        int val = 0;
+        for (j = 0; j < fs; j++)
+            val += src[pos[i] + j] * filter[fs * i + j];
+        val >>= sh;
+        dst[i] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+    }
+}
+
+static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y,
+                     int16_t *out, uint16_t *tmp)
+{
+    const uint8_t *row = src[0] + (long)y * stride[0];
+    if (c->src_is_rgb) {
+        int ro = c->src_fmt == ORC_PIX_RGB24 ? 0 : 2, bo = 2 - ro, i;
+        for (i = 0; i < c->src_w; i++) {
+            int r = row[3 * i + ro], g = row[3 * i + 1], b = row[3 * i + bo];
+            tmp[i] = (uint16_t)((c->ry * r + c->gy * g + c->by * b + (32 << (RGB2YUV_SHIFT - 1)) +
+                                 (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+        }
+        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 13);
+    } else {
+        hscale8(out, c->dst_w, row, c->h_lum, c->h_lum_pos, c->h_lum_size);
+    }
+}
+
+static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y,
+                     int16_t *out_u, int16_t *out_v, uint16_t *tmp_u, uint16_t *tmp_v)
+{
+    int i;
+    if (c->src_is_rgb) {
+        const uint8_t *row = src[0] + (long)y * stride[0];
+        int ro = c->src_fmt == ORC_PIX_RGB24 ? 0 : 2, bo = 2 - ro;
+        if (c->chr_src_hsub) {
+            for (i = 0; i < c->chr_src_w; i++) {
+                /* the reference reads pixel 2i+1 unconditionally; for odd widths that is the
+                 * padding of formatConvBuffer-less packed input, i.e. the next bytes of the row.
+                 * Odd source widths with half-chroma input are therefore not bit-defined and
+                 * the oracle clamps to the last pixel. */
+                int i1 = 2 * i + 1 < c->src_w ? 2 * i + 1 : c->src_w - 1;
+                int r = row[6 * i + ro] + row[3 * i1 + ro];
+                int g = row[6 * i + 1]  + row[3 * i1 + 1];
+                int b = row[6 * i + bo] + row[3 * i1 + bo];
+                tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << RGB2YUV_SHIFT) +
+                                       (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
+                tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << RGB2YUV_SHIFT) +
+                                       (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
+            }
+        } else {
+            for (i = 0; i < c->chr_src_w; i++) {
+                int r = row[3 * i + ro], g = row[3 * i + 1], b = row[3 * i + bo];
+                tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << (RGB2YUV_SHIFT - 1)) +
+                                       (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+                tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << (RGB2YUV_SHIFT - 1)) +
+                                       (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+            }
+        }
+        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
+        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
+    } else if (c->src_fmt == ORC_PIX_NV12) {
+        const uint8_t *row = src[1] + (long)y * stride[1];
+        uint8_t *u8 = (uint8_t *)tmp_u, *v8 = (uint8_t *)tmp_v;
+        for (i = 0; i < c->chr_src_w; i++) {
+            u8[i] = row[2 * i];
+            v8[i] = row[2 * i + 1];
+        }
+        hscale8(out_u, c->chr_dst_w, u8, c->h_chr, c->h_chr_pos, c->h_chr_size);
+        hscale8(out_v, c->chr_dst_w, v8, c->h_chr, c->h_chr_pos, c->h_chr_size);
+    } else {
+        hscale8(out_u, c->chr_dst_w, src[1] + (long)y * stride[1], c->h_chr, c->h_chr_pos, c->h_chr_size);
+        hscale8(out_v, c->chr_dst_w, src[2] + (long)y * stride[2], c->h_chr, c->h_chr_pos, c->h_chr_size);
+    }
+}
+
+/* ---- output stage ------------------------------------------------------------------------ */
+
+static void put_rgb(uint8_t *d, int fmt, int R, int G, int B)
+{
+    switch (fmt) {
+    case ORC_PIX_RGB24: d[0] = (uint8_t)R; d[1] = (uint8_t)G; d[2] = (uint8_t)B; break;
+    case ORC_PIX_BGR24: d[0] = (uint8_t)B; d[1] = (uint8_t)G; d[2] = (uint8_t)R; break;
+    case ORC_PIX_RGBA:  d[0] = (uint8_t)R; d[1] = (uint8_t)G; d[2] = (uint8_t)B; d[3] = 255; break;
+    case ORC_PIX_BGRA:  d[0] = (uint8_t)B; d[1] = (uint8_t)G; d[2] = (uint8_t)R; d[3] = 255; break;
+    }
+}
+
+static void write_full(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+{
+    /* yuv2rgb_write_full, output.c:1886-1935 */
+    int R, G, B;
+    Y -= c->y2r.y_offset;
+    Y *= c->y2r.y_coeff;
+    Y += 1 << 21;
+    R = (int)((unsigned)Y + (unsigned)(V * c->y2r.v2r));
+    G = (int)((unsigned)Y + (unsigned)(V * c->y2r.v2g) + (unsigned)(U * c->y2r.u2g));
+    B = (int)((unsigned)Y + (unsigned)(U * c->y2r.u2b));
+    if ((R | G | B) & 0xC0000000) {
+        R = clip_uintp2_30(R);
+        G = clip_uintp2_30(G);
+        B = clip_uintp2_30(B);
+    }
+    put_rgb(d, c->dst_fmt, R >> 22, G >> 22, B >> 22);
+}
+
+static void write_lut(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+{
+    /* yuv2rgb_write through table_rV/gU/gV/bU, output.c:1554-1600 */
+    const OrcYuv2Rgb *t = &c->y2r;
+    const uint8_t *r = t->y_table + t->off_rV[V + ORC_TABLE_HEADROOM];
+    const uint8_t *g = t->y_table + t->off_gU[U + ORC_TABLE_HEADROOM] + t->off_gV[V + ORC_TABLE_HEADROOM];
+    const uint8_t *b = t->y_table + t->off_bU[U + ORC_TABLE_HEADROOM];
+    put_rgb(d, c->dst_fmt, r[Y], g[Y], b[Y]);
+}
+
+/* lum[j], chr_u[j], chr_v[j] are the vertical taps' lines (already offset to the first tap) */
+static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
+                           const int16_t *const *lum, const int16_t *const *chr_u,
+                           const int16_t *const *chr_v)
+{
+    const int step = (c->dst_fmt == ORC_PIX_RGB24 || c->dst_fmt == ORC_PIX_BGR24) ? 3 : 4;
+    const int chr_y = dst_y >> c->chr_dst_vsub;
+    const int lfs = c->v_lum_size, cfs = c->v_chr_size;
+    const int16_t *lf = c->v_lum + dst_y * lfs;
+    const int16_t *cf = c->v_chr + chr_y * cfs;
+    const int full = !!(c->flags & ORC_SWS_FULL_CHR_H_INT);
+    int i, j, mode, yalpha = 0, uvalpha = 0;
+
+    /* packed_vscale(), vscale.c:135-167 */
+    if (lfs == 1 && cfs == 1) {
+        mode = 1; uvalpha = 0;
+    } else if (lfs == 1 && cfs == 2 && cf[1] + cf[0] == 4096 && (unsigned)cf[1] <= 4096U) {
+        mode = 1; uvalpha = cf[1];
+    } else if (lfs == 2 && cfs == 2 && lf[1] + lf[0] == 4096 && (unsigned)lf[1] <= 4096U &&
+               cf[1] + cf[0] == 4096 && (unsigned)cf[1] <= 4096U) {
+        mode = 2; yalpha = lf[1]; uvalpha = cf[1];
+    } else {
+        mode = 3;
+    }
+
+    if (full) {
+        for (i = 0; i < c->dst_w; i++) {
+            int Y, U, V;
+            if (mode == 1) {
+                Y = lum[0][i] * 4;
+                if (uvalpha < 2048) {
+                    U = (chr_u[0][i] - (128 << 7)) * 4;
+                    V = (chr_v[0][i] - (128 << 7)) * 4;
+                } else {
+                    U = (chr_u[0][i] + chr_u[1][i] - (128 << 8)) * 2;
+                    V = (chr_v[0][i] + chr_v[1][i] - (128 << 8)) * 2;
+                }
+            } else if (mode == 2) {
+                int yalpha1 = 4096 - yalpha, uvalpha1 = 4096 - uvalpha;
+                Y = (lum[0][i] * yalpha1 + lum[1][i] * yalpha) >> 10;
+                U = (chr_u[0][i] * uvalpha1 + chr_u[1][i] * uvalpha - (128 << 19)) >> 10;
+                V = (chr_v[0][i] * uvalpha1 + chr_v[1][i] * uvalpha - (128 << 19)) >> 10;
+            } else {
+                Y = 1 << 9;
+                U = (1 << 9) - (128 << 19);
+                V = (1 << 9) - (128 << 19);
+                for (j = 0; j < lfs; j++) Y += lum[j][i] * lf[j];
+                for (j = 0; j < cfs; j++) {
+                    U += chr_u[j][i] * cf[j];
+                    V += chr_v[j][i] * cf[j];
+                }
+                Y >>= 10; U >>= 10; V >>= 10;
+            }
+            write_full(c, dest + i * step, Y, U, V);
+        }
+    } else {
+        for (i = 0; i < ((c->dst_w + 1) >> 1); i++) {
+            int Y1, Y2, U, V;
+            if (mode == 1) {
+                Y1 = (lum[0][i * 2] + 64) >> 7;
+                Y2 = (lum[0][i * 2 + 1] + 64) >> 7;
+                if (uvalpha < 2048) {
+                    U = (chr_u[0][i] + 64) >> 7;
+                    V = (chr_v[0][i] + 64) >> 7;
+                } else {
+                    U = (chr_u[0][i] + chr_u[1][i] + 128) >> 8;
+                    V = (chr_v[0][i] + chr_v[1][i] + 128) >> 8;
+                }
+            } else if (mode == 2) {
+                int yalpha1 = 4096 - yalpha, uvalpha1 = 4096 - uvalpha;
+                Y1 = (lum[0][i * 2]     * yalpha1 + lum[1][i * 2]     * yalpha) >> 19;
+                Y2 = (lum[0][i * 2 + 1] * yalpha1 + lum[1][i * 2 + 1] * yalpha) >> 19;
+                U  = (chr_u[0][i] * uvalpha1 + chr_u[1][i] * uvalpha) >> 19;
+                V  = (chr_v[0][i] * uvalpha1 + chr_v[1][i] * uvalpha) >> 19;
+            } else {
+                Y1 = Y2 = U = V = 1 << 18;
+                for (j = 0; j < lfs; j++) {
+                    Y1 += lum[j][i * 2]     * lf[j];
+                    Y2 += lum[j][i * 2 + 1] * lf[j];
+                }
+                for (j = 0; j < cfs; j++) {
+                    U += chr_u[j][i] * cf[j];
+                    V += chr_v[j][i] * cf[j];
+                }
+                Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
+            }
+            /* non-full packed output requires an even dst_w (odd forces full chroma) */
+            write_lut(c, dest + (2 * i) * step, Y1, U, V);
+            write_lut(c, dest + (2 * i + 1) * step, Y2, U, V);
+        }
+    }
+}
+
+static void out_plane_row(uint8_t *dest, int w, const int16_t *filter, int fs,
+                          const int16_t *const *src, int offset)
+{
+    /* lum_planar_vscale / chr_planar_vscale, vscale.c:30-105: 1 tap -> yuv2plane1, else yuv2planeX;
+     * dither is the constant 64 (sws_pb_64) for 8-bit sources, swscale.c:349-351 */
+    int i, j;
+    (void)offset;
+    if (fs == 1) {
+        for (i = 0; i < w; i++)
+            dest[i] = (uint8_t)clip_u8((src[0][i] + 64) >> 7);
+    } else {
+        for (i = 0; i < w; i++) {
+            int val = 64 << 12;
+            for (j = 0; j < fs; j++)
+                val += src[j][i] * filter[j];
+            dest[i] = (uint8_t)clip_u8(val >> 19);
+        }
+    }
+}
+
+static void out_nv12_chroma_row(uint8_t *dest, int w, const int16_t *filter, int fs,
+                                const int16_t *const *su, const int16_t *const *sv)
+{
+    /* yuv2nv12cX_c, output.c:411-430 — always the X form, also for one tap (vscale.c:83-85) */
+    int i, j;
+    for (i = 0; i < w; i++) {
+        int u = 64 << 12, v = 64 << 12;
+        for (j = 0; j < fs; j++) {
+            u += su[j][i] * filter[j];
+            v += sv[j][i] * filter[j];
+        }
+        dest[2 * i]     = (uint8_t)clip_u8(u >> 19);
+        dest[2 * i + 1] = (uint8_t)clip_u8(v >> 19);
+    }
+}
+
+int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
+                       uint8_t *const dst[4], const int dst_stride[4], int y0, int y1)
+{
+    int lum_first, lum_last, chr_first, chr_last, y, j, ret = -1;
+    int cy0, cy1;
+    int16_t *lum_buf = NULL, *u_buf = NULL, *v_buf = NULL;
+    uint16_t *tmp = NULL, *tmp_u = NULL, *tmp_v = NULL;
+    const int16_t **lp = NULL, **up = NULL, **vp = NULL;
+    const int dst_w = c->dst_w, cdw = c->chr_dst_w;
+
+    if (y0 < 0) y0 = 0;
+    if (y1 > c->dst_h) y1 = c->dst_h;
+    if (y0 >= y1) return 0;
+    /* planar 4:2:0 output rows come in pairs sharing one chroma row */
+    if (!c->dst_is_rgb && (y0 & 1)) return -1;
+
+    cy0 = y0 >> c->chr_dst_vsub;
+    cy1 = ((y1 - 1) >> c->chr_dst_vsub) + 1;
+    lum_first = c->v_lum_pos[y0];
+    lum_last  = c->v_lum_pos[y1 - 1] + c->v_lum_size - 1;
+    chr_first = c->v_chr_pos[cy0];
+    chr_last  = c->v_chr_pos[cy1 - 1] + c->v_chr_size - 1;
+    if (lum_last >= c->src_h)     lum_last = c->src_h - 1;
+    if (chr_last >= c->chr_src_h) chr_last = c->chr_src_h - 1;
+
+    lum_buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)dst_w * (lum_last - lum_first + 1));
+    u_buf   = (int16_t *)malloc(sizeof(int16_t) * (size_t)cdw * (chr_last - chr_first + 1));
+    v_buf   = (int16_t *)malloc(sizeof(int16_t) * (size_t)cdw * (chr_last - chr_first + 1));
+    tmp     = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
+    tmp_u   = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
+    tmp_v   = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
+    lp = (const int16_t **)malloc(sizeof(*lp) * c->v_lum_size);
+    up = (const int16_t **)malloc(sizeof(*up) * c->v_chr_size);
+    vp = (const int16_t **)malloc(sizeof(*vp) * c->v_chr_size);
+    if (!lum_buf || !u_buf || !v_buf || !tmp || !tmp_u || !tmp_v || !lp || !up || !vp)
+        goto done;
+
+    for (y = lum_first; y <= lum_last; y++)
+        lum_line(c, src, src_stride, y, lum_buf + (size_t)(y - lum_first) * dst_w, tmp);
+    for (y = chr_first; y <= chr_last; y++)
+        chr_line(c, src, src_stride, y, u_buf + (size_t)(y - chr_first) * cdw,
+                 v_buf + (size_t)(y - chr_first) * cdw, tmp_u, tmp_v);
+
+    for (y = y0; y < y1; y++) {
+        const int chr_y = y >> c->chr_dst_vsub;
+        for (j = 0; j < c->v_lum_size; j++) {
+            int r = c->v_lum_pos[y] + j;
+            if (r >= c->src_h) r = c->src_h - 1;
+            lp[j] = lum_buf + (size_t)(r - lum_first) * dst_w;
+        }
+        for (j = 0; j < c->v_chr_size; j++) {
+            int r = c->v_chr_pos[chr_y] + j;
+            if (r >= c->chr_src_h) r = c->chr_src_h - 1;
+            up[j] = u_buf + (size_t)(r - chr_first) * cdw;
+            vp[j] = v_buf + (size_t)(r - chr_first) * cdw;
+        }
+        if (c->dst_is_rgb) {
+            out_packed_row(c, dst[0] + (long)y * dst_stride[0], y, lp, up, vp);
+        } else {
+            out_plane_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size,
+                          c->v_lum_size, lp, 0);
+            if (!(y & 1)) {
+                const int16_t *cf = c->v_chr + chr_y * c->v_chr_size;
+                if (c->dst_fmt == ORC_PIX_NV12) {
+                    out_nv12_chroma_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, vp);
+                } else {
+                    out_plane_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, 0);
+                    out_plane_row(dst[2] + (long)chr_y * dst_stride[2], cdw, cf, c->v_chr_size, vp, 3);
+                }
+            }
+        }
+    }
+    ret = y1 - y0;
+done:
+    free(lum_buf); free(u_buf); free(v_buf); free(tmp); free(tmp_u); free(tmp_v);
+    free((void *)lp); free((void *)up); free((void *)vp);
+    return ret;
+}
+
+int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
+                  uint8_t *const dst[4], const int dst_stride[4])
+{
+    /* bounded working set: process in bands of 64 output rows */
+    int y, band = 64;
+    for (y = 0; y < c->dst_h; y += band) {
+        int r = orc_sws_scale_rows(c, src, src_stride, dst, dst_stride, y,
+                                   y + band < c->dst_h ? y + band : c->dst_h);
+        if (r < 0) return r;
+    }
+    return c->dst_h;
+}
