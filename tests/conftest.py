@@ -1,0 +1,49 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def _make(directory, target):
+    if not os.path.exists(os.path.join(directory, target)):
+        subprocess.run(["make", "-C", directory], check=True, capture_output=True)
+    return os.path.join(directory, target)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (oracle/liborc.so) — the checker, never the thing under test."""
+    import harness
+    return harness.load_oracle(_make(os.path.join(ROOT, "oracle"), "liborc.so"))
+
+
+def _gpu_available():
+    try:
+        from gmat_amd.lib import load
+        return load().gmat_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session", params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    """A device back-end exposing the C ABI: 'hip' = the product library on a real GPU,
+    'emu' = the same sources compiled against tests/hipemu (kernel logic on CPU fibers)."""
+    import harness
+    from gmat_amd.lib import load
+    if request.param == "hip":
+        lib = load()            # raises loudly if the product library is missing
+        if lib.gmat_device_count() <= 0:
+            pytest.fail("-m gpu test selected but no HIP device is visible")
+        return harness.Dev(lib, "hip")
+    path = _make(os.path.join(ROOT, "tests", "hipemu"), "build/libgmat_hip_emu.so")
+    return harness.Dev(load(path), "emu")

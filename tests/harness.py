@@ -1,0 +1,230 @@
+"""Shared test plumbing: oracle binding, device-buffer helpers, synthetic frames."""
+import ctypes as C
+
+import numpy as np
+
+from gmat_amd.lib import planes, ints, PIX_FMT, SWS  # noqa: F401
+
+u8p = C.POINTER(C.c_uint8)
+
+
+def load_oracle(path):
+    L = C.CDLL(path)
+    L.orc_sws_create.restype = C.c_void_p
+    L.orc_sws_create.argtypes = [C.c_int] * 7 + [C.c_void_p]
+    L.orc_sws_scale.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_int)]
+    L.orc_sws_scale_rows.argtypes = L.orc_sws_scale.argtypes + [C.c_int, C.c_int]
+    L.orc_sws_free.argtypes = [C.c_void_p]
+    L.orc_sws_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.POINTER(C.c_int32)),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_sws_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+    L.orc_yuv2rgb_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_yuv2rgb_selfcheck.restype = C.c_long
+    L.orc_yuv2rgb_selfcheck.argtypes = [C.c_void_p]
+    L.orc_yuv2rgb_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_nv12_to_rgbpf32.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int]
+    L.orc_init_filter.argtypes = [C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_transpose.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    for n in ("orc_hflip", "orc_vflip"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_crop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
+    L.orc_conv3x3.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.POINTER(C.c_int), C.c_float, C.c_float]
+    L.orc_rgb24_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_fill_lcg.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
+    return Oracle(L)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    YUV2RGB_SIZE = 64 * 1024      # >= sizeof(OrcYuv2Rgb)
+
+    def __init__(self, L):
+        self.L = L
+        self._y2r = {}
+
+    def y2r(self, colorspace=5, full_range=0):
+        key = (colorspace, full_range)
+        if key not in self._y2r:
+            buf = C.create_string_buffer(self.YUV2RGB_SIZE)
+            self.L.orc_yuv2rgb_init(buf, colorspace, full_range, 0, 1 << 16, 1 << 16)
+            self._y2r[key] = buf
+        return self._y2r[key]
+
+    def lcg(self, shape, seed):
+        a = np.empty(shape, np.uint8)
+        self.L.orc_fill_lcg(ptr(a), a.size, seed)
+        return a
+
+    def yuv2rgb(self, src_planes, w, h, src_fmt, dst_fmt, colorspace=5, full_range=0):
+        bpp = 4 if dst_fmt in ("rgba", "bgra") else 3
+        out = np.zeros((h, w * bpp), np.uint8)
+        r = self.L.orc_yuv2rgb_frame(self.y2r(colorspace, full_range), planes([p.ctypes.data for p in src_planes]),
+                                     ints([p.strides[0] for p in src_planes]), ptr(out), out.strides[0], w, h,
+                                     PIX_FMT[src_fmt], PIX_FMT[dst_fmt])
+        assert r == 0
+        return out
+
+    def nv12_to_rgbpf32(self, src_planes, w, h):
+        out = np.zeros((3, h, w), np.float32)
+        r = self.L.orc_nv12_to_rgbpf32(self.y2r(), planes([p.ctypes.data for p in src_planes]),
+                                       ints([p.strides[0] for p in src_planes]), ptr(out), 4 * w, w, h)
+        assert r == 0
+        return out
+
+    def sws(self, src_planes, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"]):
+        c = self.L.orc_sws_create(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags, None)
+        assert c, "oracle refused the conversion"
+        try:
+            outs = alloc_planes(dst_fmt, dw, dh, tight=True)
+            r = self.L.orc_sws_scale(c, planes([p.ctypes.data for p in src_planes]),
+                                     ints([p.strides[0] for p in src_planes]),
+                                     planes([p.ctypes.data for p in outs]), ints([p.strides[0] for p in outs]))
+            assert r == dh
+            return outs
+        finally:
+            self.L.orc_sws_free(c)
+
+    def sws_filters(self, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"]):
+        c = self.L.orc_sws_create(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags, None)
+        assert c
+        res = []
+        for which in range(4):
+            coef = C.POINTER(C.c_int16)(); pos = C.POINTER(C.c_int32)(); size = C.c_int(); cnt = C.c_int()
+            self.L.orc_sws_filter(c, which, C.byref(coef), C.byref(pos), C.byref(size), C.byref(cnt))
+            n, s = cnt.value, size.value
+            res.append((np.ctypeslib.as_array(coef, (n * s,)).reshape(n, s).copy(),
+                        np.ctypeslib.as_array(pos, (n,)).copy()))
+        self.L.orc_sws_free(c)
+        return res
+
+    def chained(self, src_planes, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"]):
+        """The scaled YUV->RGB contract: nearest-chroma convert at source size, then RGB24->dst scale."""
+        rgb = self.yuv2rgb(src_planes, sw, sh, src_fmt, "rgb24")
+        return self.sws([rgb], sw, sh, "rgb24", dw, dh, dst_fmt, flags)
+
+
+def plane_shapes(fmt, w, h):
+    if fmt in ("rgb24", "bgr24"):
+        return [(h, 3 * w)]
+    if fmt in ("rgba", "bgra"):
+        return [(h, 4 * w)]
+    if fmt == "nv12":
+        return [(h, w), ((h + 1) // 2, 2 * ((w + 1) // 2))]
+    if fmt == "yuv420p":
+        return [(h, w), ((h + 1) // 2, (w + 1) // 2), ((h + 1) // 2, (w + 1) // 2)]
+    if fmt == "rgbpf32le":
+        return [(h, 4 * w)] * 3
+    raise ValueError(fmt)
+
+
+def alloc_planes(fmt, w, h, tight=True, align=64, fill=0):
+    out = []
+    for (rows, rb) in plane_shapes(fmt, w, h):
+        stride = rb if tight else (rb + align - 1) // align * align
+        buf = np.full((rows, stride), fill, np.uint8)
+        out.append(buf[:, :rb] if not tight else buf)
+    return out
+
+
+def synth_planes(orc, fmt, w, h, seed, tight=True, align=64):
+    out = alloc_planes(fmt, w, h, tight, align)
+    for i, p in enumerate(out):
+        p[...] = orc.lcg(p.shape, seed + 17 * i)
+    return out
+
+
+class DevBuf:
+    def __init__(self, dev, nbytes):
+        self.dev, self.nbytes = dev, nbytes
+        p = C.c_void_p()
+        r = dev.lib.gmat_malloc(C.byref(p), nbytes)
+        assert r == 0 and p.value
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.dev.lib.gmat_free(self.ptr)
+            self.ptr = None
+
+
+class DevPlane:
+    """A strided 2-D byte plane in device memory."""
+
+    def __init__(self, dev, rows, row_bytes, stride=None, fill=0xCD):
+        self.rows, self.row_bytes = rows, row_bytes
+        self.stride = stride or row_bytes
+        self.buf = DevBuf(dev, self.stride * rows)
+        dev.lib.gmat_memset(self.buf.ptr, fill, self.stride * rows)
+        self.dev = dev
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def upload(self, arr):
+        assert arr.shape == (self.rows, self.row_bytes)
+        host = np.full((self.rows, self.stride), 0xCD, np.uint8)
+        host[:, :self.row_bytes] = arr
+        assert self.dev.lib.gmat_memcpy_h2d(self.ptr, ptr(host), host.size) == 0
+        return self
+
+    def download(self, with_padding=False):
+        host = np.empty((self.rows, self.stride), np.uint8)
+        self.dev.lib.gmat_device_sync()
+        assert self.dev.lib.gmat_memcpy_d2h(ptr(host), self.ptr, host.size) == 0
+        return host if with_padding else host[:, :self.row_bytes].copy()
+
+    def free(self):
+        self.buf.free()
+
+
+class Dev:
+    def __init__(self, lib, kind):
+        self.lib, self.kind = lib, kind
+
+    def planes_like(self, fmt, w, h, stride_align=1, extra=0):
+        out = []
+        for (rows, rb) in plane_shapes(fmt, w, h):
+            stride = (rb + extra + stride_align - 1) // stride_align * stride_align
+            out.append(DevPlane(self, rows, rb, stride))
+        return out
+
+    def upload_planes(self, arrays, stride_align=1, extra=0):
+        out = []
+        for a in arrays:
+            rows, rb = a.shape
+            stride = (rb + extra + stride_align - 1) // stride_align * stride_align
+            out.append(DevPlane(self, rows, rb, stride).upload(np.ascontiguousarray(a)))
+        return out
+
+    def sws(self, src_dev, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"], fused=None, dst_align=1, dst_extra=0,
+            colorspace=None):
+        lib = self.lib
+        c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags | SWS["hwaccel"], None)
+        assert c, "gmat_sws_getContext failed"
+        try:
+            if fused is not None:
+                lib.gmat_sws_setFused(c, int(fused))
+            if colorspace is not None:
+                lib.gmat_sws_setColorspace(c, colorspace[0], colorspace[1])
+            dst = self.planes_like(dst_fmt, dw, dh, dst_align, dst_extra)
+            r = lib.gmat_sws_scale(c, planes([p.ptr for p in src_dev]), ints([p.stride for p in src_dev]), 0, sh,
+                                   planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+            assert r == dh, f"gmat_sws_scale returned {r}"
+            kernel = lib.gmat_sws_lastKernel(c).decode()
+            outs = [p.download() for p in dst]
+            pads = [p.download(with_padding=True)[:, p.row_bytes:] for p in dst]
+            for p in dst:
+                p.free()
+            return outs, pads, kernel
+        finally:
+            lib.gmat_sws_freeContext(c)

@@ -1,0 +1,188 @@
+// tests/hipemu/hipemu.cpp — TEST INFRASTRUCTURE: fiber scheduler and runtime stubs for
+// tests/hipemu/hip/hip_runtime.h (see the header for scope and rules).
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace hipemu {
+
+Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+
+namespace {
+enum State { READY, AT_BLOCK, AT_WAVE, DONE };
+struct Fiber {
+    ucontext_t ctx;
+    State state;
+    Idx tid;
+};
+const size_t kStack = 256 * 1024;
+std::vector<Fiber> fibers;
+std::vector<char *> stacks;
+ucontext_t sched_ctx;
+int cur = -1;
+const std::function<void()> *cur_body = nullptr;
+char *lds_ptr = nullptr;
+std::mutex big_lock;          // the emulation is single-threaded by design
+
+void trampoline()
+{
+    (*cur_body)();
+    fibers[cur].state = DONE;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+
+void yield_as(State s)
+{
+    fibers[cur].state = s;
+    const int me = cur;
+    swapcontext(&fibers[me].ctx, &sched_ctx);
+}
+
+// guard-page allocator: the END of the usable range abuts a PROT_NONE page
+struct Guarded { void *map; size_t map_len; };
+std::map<void *, Guarded> allocs;
+
+void *guarded_alloc(size_t n, size_t align)
+{
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t body = (n + align - 1) / align * align;
+    const size_t pages = (body + page - 1) / page;
+    const size_t len = (pages + 2) * page;
+    char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return nullptr;
+    mprotect(m, page, PROT_NONE);
+    mprotect(m + (pages + 1) * page, page, PROT_NONE);
+    char *p = m + (pages + 1) * page - body;     // aligned because body is a multiple of align
+    memset(p, 0xA5, body);
+    allocs[p] = {m, len};
+    return p;
+}
+
+void guarded_free(void *p)
+{
+    auto it = allocs.find(p);
+    if (it == allocs.end()) return;
+    munmap(it->second.map, it->second.map_len);
+    allocs.erase(it);
+}
+} // namespace
+
+void block_sync() { yield_as(AT_BLOCK); }
+void wave_sync() { yield_as(AT_WAVE); }
+void *dyn_lds() { return lds_ptr; }
+
+void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem)
+{
+    std::lock_guard<std::mutex> g(big_lock);
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if ((int)fibers.size() < nthreads) {
+        fibers.resize(nthreads);
+        while ((int)stacks.size() < nthreads) stacks.push_back((char *)malloc(kStack));
+    }
+    char *lds = shmem ? (char *)guarded_alloc(shmem, 16) : nullptr;
+    lds_ptr = lds;
+    cur_body = &body;
+    g_blockDim = {block.x, block.y, block.z};
+    g_gridDim = {grid.x, grid.y, grid.z};
+    const int nwaves = (nthreads + 63) / 64;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        g_blockIdx = {bx, by, bz};
+        for (int t = 0; t < nthreads; t++) {
+            Fiber &f = fibers[t];
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = stacks[t];
+            f.ctx.uc_stack.ss_size = kStack;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, trampoline, 0);
+            f.state = READY;
+            f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+        }
+        for (;;) {
+            int alive = 0;
+            for (int w = 0; w < nwaves; w++) {
+                const int lo = w * 64, hi = std::min(nthreads, lo + 64);
+                for (;;) {
+                    for (int t = lo; t < hi; t++) {
+                        if (fibers[t].state != READY) continue;
+                        cur = t;
+                        g_threadIdx = fibers[t].tid;
+                        swapcontext(&sched_ctx, &fibers[t].ctx);
+                    }
+                    int at_wave = 0, live = 0;
+                    for (int t = lo; t < hi; t++) {
+                        if (fibers[t].state == DONE) continue;
+                        live++;
+                        at_wave += fibers[t].state == AT_WAVE;
+                    }
+                    if (live && at_wave == live) {
+                        for (int t = lo; t < hi; t++) if (fibers[t].state == AT_WAVE) fibers[t].state = READY;
+                        continue;
+                    }
+                    if (at_wave) {
+                        fprintf(stderr, "hipemu: divergent wave barrier in block (%u,%u,%u)\n", bx, by, bz);
+                        abort();
+                    }
+                    alive += live;
+                    break;
+                }
+            }
+            if (!alive) break;
+            for (int t = 0; t < nthreads; t++) if (fibers[t].state == AT_BLOCK) fibers[t].state = READY;
+        }
+    }
+    cur_body = nullptr;
+    if (lds) guarded_free(lds);
+    lds_ptr = nullptr;
+}
+
+} // namespace hipemu
+
+using namespace hipemu;
+
+hipError_t hipMalloc(void **p, size_t n)
+{
+    *p = guarded_alloc(n ? n : 1, 16);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void *p) { guarded_free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t)
+{
+    for (size_t y = 0; y < h; y++) memcpy((char *)d + y * dp, (const char *)s + y * sp, w);
+    return hipSuccess;
+}
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+const char *hipGetErrorName(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emulated)"; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
+hipError_t hipEventCreate(hipEvent_t *e) { *e = new ihipEvent_t(); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *) { return hipErrorNotSupported; }
+hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorNotSupported; }
+hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }

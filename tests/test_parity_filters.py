@@ -1,0 +1,216 @@
+"""crop / flip / transpose / rotate / smooth kernels and the AVFilter-shaped layer vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, synth_planes, DevPlane
+from gmat_amd.lib import GmatFrame
+
+SIZES = [(64, 64), (200, 70), (67, 129), (5, 3), (1, 1), (130, 66)]
+
+
+def _orc_out(rows, row_bytes):
+    return np.zeros((rows, row_bytes), np.uint8)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("bpp", [3, 4])
+@pytest.mark.parametrize("dir", [0, 1, 2, 3])
+def test_transpose(dev, orc, w, h, bpp, dir):
+    src = orc.lcg((h, w * bpp), 5)
+    want = _orc_out(w, h * bpp)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, dir)
+    for align, extra in [(256, 0), (1, 1)]:
+        d = dev.upload_planes([src], align, extra)[0]
+        o = DevPlane(dev, w, h * bpp, (h * bpp + extra + align - 1) // align * align)
+        assert dev.lib.gmat_transpose(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, dir, None) == 0
+        assert (o.download() == want).all()
+        assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+        d.free(); o.free()
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(300, 5), (513, 4)])
+@pytest.mark.parametrize("bpp", [3, 4])
+@pytest.mark.parametrize("code", [0, 1, -1])
+def test_flip(dev, orc, w, h, bpp, code):
+    src = orc.lcg((h, w * bpp), 6)
+    tmp = src
+    if code != 0:
+        t = _orc_out(h, w * bpp)
+        orc.L.orc_hflip(tmp.ctypes.data, tmp.strides[0], t.ctypes.data, t.strides[0], w, h, bpp)
+        tmp = t
+    if code <= 0:
+        t = _orc_out(h, w * bpp)
+        orc.L.orc_vflip(tmp.ctypes.data, tmp.strides[0], t.ctypes.data, t.strides[0], w, h, bpp)
+        tmp = t
+    for align, extra in [(256, 0), (1, 2)]:
+        d = dev.upload_planes([src], align, extra)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + extra + align - 1) // align * align)
+        assert dev.lib.gmat_flip(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, code, None) == 0
+        assert (o.download() == tmp).all()
+        assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+        d.free(); o.free()
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("bpp", [3, 4])
+def test_smooth3x3(dev, orc, w, h, bpp):
+    src = orc.lcg((h, w * bpp), 8)
+    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+    want = _orc_out(h, w * bpp)
+    orc.L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, 1 / 16, 0.0)
+    for align, extra in [(256, 0), (1, 3)]:
+        d = dev.upload_planes([src], align, extra)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + extra + align - 1) // align * align)
+        assert dev.lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, 1 / 16, 0.0, None) == 0
+        assert (o.download() == want).all()
+        assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+        d.free(); o.free()
+
+
+def test_conv3x3_general_matrix_and_rounding(dev, orc):
+    w, h, bpp = 97, 33, 3
+    src = orc.lcg((h, w * bpp), 12)
+    m = (C.c_int * 9)(-1, -2, 3, 0, 5, -1, 2, 1, -3)
+    want = _orc_out(h, w * bpp)
+    orc.L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, 0.3, 7.25)
+    d = dev.upload_planes([src], 64)[0]
+    o = DevPlane(dev, h, w * bpp, 320)
+    assert dev.lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, 0.3, 7.25, None) == 0
+    assert (o.download() == want).all()
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (200, 70), (67, 129), (3, 2)])
+def test_rotate_flip_smooth_fused_equals_three_filters(dev, orc, w, h):
+    """cfg4: transpose(clock) -> hflip -> 3x3 smooth as three oracle filters == one fused kernel."""
+    bpp = 3
+    src = orc.lcg((h, w * bpp), 9)
+    a = _orc_out(w, h * bpp)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)
+    b = _orc_out(w, h * bpp)
+    orc.L.orc_hflip(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], h, w, bpp)
+    want = _orc_out(w, h * bpp)
+    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+    orc.L.orc_conv3x3(b.ctypes.data, b.strides[0], want.ctypes.data, want.strides[0], h, w, bpp, m, 1 / 16, 0.0)
+    d = dev.upload_planes([src], 256)[0]
+    o = DevPlane(dev, w, h * bpp, (h * bpp + 255) // 256 * 256)
+    assert dev.lib.gmat_rotate_flip_smooth(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, None) == 0
+    assert (o.download() == want).all()
+    assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+
+
+def test_crop(dev, orc):
+    w, h, bpp = 120, 50, 3
+    src = orc.lcg((h, w * bpp), 4)
+    x, y, cw, ch = 13, 7, 77, 31
+    d = dev.upload_planes([src], 64)[0]
+    o = DevPlane(dev, ch, cw * bpp, 256)
+    assert dev.lib.gmat_crop(d.ptr, d.stride, o.ptr, o.stride, x, y, cw, ch, bpp, None) == 0
+    assert (o.download() == src[y:y + ch, x * bpp:(x + cw) * bpp]).all()
+
+
+# ---- the AVFilter-shaped layer ------------------------------------------------------------------------
+def _run_filter(dev, name, opts, src, w, h, fmt="rgb24"):
+    lib = dev.lib
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT[fmt], w, h, 1)
+    assert fc
+    f = lib.gmat_filter_alloc(name.encode())
+    assert f
+    for k, v in opts.items():
+        assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0
+    assert lib.gmat_filter_init(f) == 0
+    assert lib.gmat_filter_config_props(f, fc, None) == 0
+    # hwupload: host frame -> pooled device frame
+    host = GmatFrame()
+    assert lib.gmat_host_frame_alloc(C.byref(host), PIX_FMT[fmt], w, h) == 0
+    rb = src.shape[1]
+    hv = np.ctypeslib.as_array(C.cast(host.data[0], C.POINTER(C.c_uint8)), (h, host.linesize[0]))
+    hv[:, :rb] = src
+    fin = lib.gmat_frame_alloc()
+    assert lib.gmat_hwframe_get_buffer(fc, fin) == 0
+    assert lib.gmat_hwframe_transfer_data(fin, C.byref(host), None) == 0
+    fin.contents.pts = 1234
+    out = C.POINTER(GmatFrame)()
+    r = lib.gmat_filter_frame(f, fin, C.byref(out))
+    assert r == 0 and out
+    o = out.contents
+    assert o.pts == 1234 and o.format == PIX_FMT["hip"]
+    # hwdownload
+    hout = GmatFrame()
+    assert lib.gmat_host_frame_alloc(C.byref(hout), o.sw_format, o.width, o.height) == 0
+    assert lib.gmat_hwframe_transfer_data(C.byref(hout), out, None) == 0
+    lib.gmat_device_sync()
+    bpp = 4 if o.sw_format in (PIX_FMT["rgba"], PIX_FMT["bgra"]) else 3
+    res = np.ctypeslib.as_array(C.cast(hout.data[0], C.POINTER(C.c_uint8)), (o.height, hout.linesize[0]))[:, :o.width * bpp].copy()
+    ow, oh = o.width, o.height
+    lib.gmat_frame_free(C.byref(out))
+    lib.gmat_host_frame_free(C.byref(host)); lib.gmat_host_frame_free(C.byref(hout))
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)
+    return res, ow, oh
+
+
+def test_filter_layer_crop_defaults_to_centre(dev, orc):
+    w, h = 100, 60
+    src = orc.lcg((h, w * 3), 2)
+    res, ow, oh = _run_filter(dev, "crop_hip", {"w": 40, "h": 20}, src, w, h)     # x=y=-1 -> centred
+    assert (ow, oh) == (40, 20)
+    assert (res == src[20:40, 30 * 3:70 * 3]).all()
+
+
+def test_filter_layer_rotate_swaps_dimensions(dev, orc):
+    w, h = 70, 30
+    src = orc.lcg((h, w * 3), 3)
+    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 90}, src, w, h)
+    assert (ow, oh) == (h, w)
+    want = np.zeros((w, h * 3), np.uint8)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, 3, 1)
+    assert (res == want).all()
+    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": -90}, src, w, h)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, 3, 2)
+    assert (res == want).all()
+    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 180}, src, w, h)
+    assert (res.reshape(h, w, 3) == src.reshape(h, w, 3)[::-1, ::-1]).all()
+
+
+def test_filter_layer_flip_smooth_scale_format(dev, orc):
+    w, h = 96, 40
+    src = orc.lcg((h, w * 3), 4)
+    res, _, _ = _run_filter(dev, "flip_hip", {"code": 1}, src, w, h)
+    assert (res.reshape(h, w, 3) == src.reshape(h, w, 3)[:, ::-1]).all()
+    res, _, _ = _run_filter(dev, "smooth_hip", {"type": "gaussian", "kw": 3, "kh": 3}, src, w, h)
+    want = np.zeros_like(src)
+    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+    orc.L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, 3, m, 1 / 16, 0.0)
+    assert (res == want).all()
+    res, ow, oh = _run_filter(dev, "scale_hip", {"w": 48, "h": 20, "interp_algo": "bicubic"}, src, w, h)
+    assert (ow, oh) == (48, 20)
+    assert (res == orc.sws([src], w, h, "rgb24", 48, 20, "rgb24")[0]).all()
+    res, _, _ = _run_filter(dev, "format_hip", {"pix_fmt": "bgr24"}, src, w, h)
+    assert (res.reshape(h, w, 3) == src.reshape(h, w, 3)[:, :, ::-1]).all()
+
+
+def test_filter_layer_errors(dev):
+    lib = dev.lib
+    assert not lib.gmat_filter_alloc(b"no_such_filter")
+    f = lib.gmat_filter_alloc(b"crop_hip")
+    assert lib.gmat_filter_set_option(f, b"bogus", b"1") < 0
+    assert lib.gmat_filter_init(f) < 0                       # w/h == 0 (vf_crop_nvcv.c:116-119)
+    lib.gmat_filter_free(f)
+    f = lib.gmat_filter_alloc(b"crop_hip")
+    lib.gmat_filter_set_option(f, b"w", b"500"); lib.gmat_filter_set_option(f, b"h", b"10")
+    assert lib.gmat_filter_init(f) == 0
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT["rgb24"], 100, 100, 0)
+    assert lib.gmat_filter_config_props(f, fc, None) < 0     # crop area outside the frame
+    lib.gmat_filter_free(f)
+    f = lib.gmat_filter_alloc(b"rotate_hip")
+    lib.gmat_filter_set_option(f, b"angle", b"33")
+    assert lib.gmat_filter_init(f) < 0                       # arbitrary angles: ENOSYS this round
+    lib.gmat_filter_free(f)
+    f = lib.gmat_filter_alloc(b"flip_hip")
+    assert lib.gmat_filter_init(f) == 0
+    nv = lib.gmat_hwframe_ctx_create(0, PIX_FMT["nv12"], 64, 64, 0)
+    assert lib.gmat_filter_config_props(f, nv, None) < 0     # nvcv-style filters take packed RGB only
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(nv); lib.gmat_hwframe_ctx_free(fc)

@@ -1,0 +1,80 @@
+"""The fused LDS-tiled scaler vs the oracle (bit-exact), through gmat_sws_scale."""
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, synth_planes
+
+
+def _check(dev, orc, src_fmt, sw, sh, dw, dh, dst_fmt, flags, fused=None, align=256, extra=0, seed=21):
+    src = synth_planes(orc, src_fmt, sw, sh, seed=seed)
+    if src_fmt in ("nv12", "yuv420p"):
+        want = orc.chained(src, sw, sh, src_fmt, dw, dh, dst_fmt, flags)[0]
+    else:
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, flags)[0]
+    d_src = dev.upload_planes(src, align, extra)
+    got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, flags, fused=fused, dst_align=align,
+                                dst_extra=extra)
+    for p in d_src:
+        p.free()
+    bad = np.argwhere(got[0] != want)
+    assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+    assert (pads[0] == 0xCD).all(), "kernel wrote into the row padding"
+    return kernel
+
+
+# (srcW, srcH, dstW, dstH): exact 2:1, odd sizes, upscale, anisotropic, tiny, > one tile in both axes
+GEOMS = [(256, 64, 128, 32), (200, 90, 100, 45), (131, 77, 64, 33), (96, 40, 144, 60), (300, 50, 100, 70),
+         (64, 64, 17, 9), (40, 30, 41, 31), (520, 36, 260, 18)]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_rgb24_bicubic(dev, orc, geom):
+    sw, sh, dw, dh = geom
+    k = _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
+    assert k.startswith("scale_rgb_kernel")
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area", "bicubic"])
+def test_rgb24_algorithms(dev, orc, flags):
+    _check(dev, orc, "rgb24", 192, 70, 96, 35, "rgb24", SWS[flags])
+    _check(dev, orc, "rgb24", 80, 30, 120, 50, "rgb24", SWS[flags])        # upscale: 2-tap special forms
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("bgr24", "rgb24"), ("rgb24", "bgr24"), ("rgb24", "rgba"),
+                                             ("bgr24", "bgra")])
+def test_packed_format_pairs(dev, orc, src_fmt, dst_fmt):
+    _check(dev, orc, src_fmt, 160, 48, 80, 24, dst_fmt, SWS["bicubic"])
+
+
+@pytest.mark.parametrize("align,extra", [(1, 0), (1, 3), (64, 0)])
+def test_unaligned_strides(dev, orc, align, extra):
+    _check(dev, orc, "rgb24", 136, 40, 68, 20, "rgb24", SWS["bicubic"], align=align, extra=extra)
+
+
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (130, 50, 64, 25), (96, 40, 144, 60)])
+def test_yuv_to_scaled_rgb_chained_contract(dev, orc, src_fmt, fused, geom):
+    """4K nv12 -> rgb24 -> 1080p in miniature: fused and two-kernel forms both equal the chained oracle."""
+    sw, sh, dw, dh = geom
+    k = _check(dev, orc, src_fmt, sw, sh, dw, dh, "rgb24", SWS["bicubic"], fused=fused)
+    assert ("yuv" in k) == bool(fused)
+
+
+def test_product_filter_tables_match_oracle(dev, orc):
+    import ctypes as C
+    lib = dev.lib
+    for (sw, sh, dw, dh, flags) in [(3840, 2160, 1920, 1080, "bicubic"), (1920, 1080, 1280, 720, "lanczos"),
+                                    (640, 360, 1920, 1080, "bilinear"), (1001, 777, 333, 555, "bicubic")]:
+        ofs = orc.sws_filters(sw, sh, "rgb24", dw, dh, "rgb24", SWS[flags])
+        c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["rgb24"], dw, dh, PIX_FMT["rgb24"], SWS[flags], None)
+        assert c
+        for which, (ocoef, opos) in enumerate(ofs):
+            n, taps = ocoef.shape
+            coef = np.zeros((n, taps + 4), np.int16).reshape(-1)
+            pos = np.zeros(n, np.int32)
+            cnt = C.c_int()
+            t = lib.gmat_sws_getFilter(c, which, coef.ctypes.data, pos.ctypes.data, n, C.byref(cnt))
+            assert t == taps and cnt.value == n
+            assert (coef[:n * taps].reshape(n, taps) == ocoef).all() and (pos == opos).all()
+        lib.gmat_sws_freeContext(c)
