@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the pixel-transform hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the config `metric` is quoted on): synthetic 3840x2160 NV12
+frames, device resident -> RGB24 -> 1920x1080 bicubic RGB24, through gmat_sws_scale().
+A "step" is one pass over one batch of FRAMES distinct frame pairs (the batch rotates over a working
+set larger than the 256 MiB Infinity Cache so HBM, not cache, is measured).
+
+One JSON line on rank 0.  `value` = source gigapixels per second over all ranks (weak scaling: every
+GPU converts its own independent streams, no collective in the data path).
+  roofline     : the dominant kernel of the headline implementation; achieved = algorithmic bytes per
+                 launch / average launch duration from HIP events on the launch stream.
+  chained      : the two-kernel form with the HBM RGB24 intermediate (the reference's structure),
+                 measured in the same run, with its own per-kernel rooflines.
+  cpu_baseline : the C oracle (a port of libswscale's arithmetic, oracle/) on the host cores, rank 0,
+                 on a bounded sample.  The oracle is used here only as the measured CPU baseline.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SRC_W, SRC_H, DST_W, DST_H = 3840, 2160, 1920, 1080
+PX = SRC_W * SRC_H
+BYTES_NV12 = PX * 3 // 2
+BYTES_RGB_SRC = PX * 3
+BYTES_RGB_DST = DST_W * DST_H * 3
+ALG_FUSED = BYTES_NV12 + BYTES_RGB_DST                      # 18,662,400 B  
+ALG_CONVERT = BYTES_NV12 + BYTES_RGB_SRC                    # 37,324,800 B
+ALG_SCALE = BYTES_RGB_SRC + BYTES_RGB_DST                   # 31,104,000 B
+HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=32, help="distinct frame pairs per step (working set)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    return ap.parse_args()
+
+
+class Runner:
+    """One implementation of the workload: a context, its frame set and (optionally) a graph."""
+
+    def __init__(self, lib, torch, stream, frames, fused, use_graph, seed):
+        from gmat_amd.lib import PIX_FMT, SWS, planes, ints
+        self.lib, self.stream, self.frames = lib, stream, frames
+        self.ctx = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["nv12"], DST_W, DST_H, PIX_FMT["rgb24"],
+                                           SWS["bicubic"] | SWS["hwaccel"], None)
+        if not self.ctx:
+            raise RuntimeError("gmat_sws_getContext failed")
+        lib.gmat_sws_setFused(self.ctx, int(fused))
+        lib.gmat_sws_setStream(self.ctx, stream)
+        src_ls = (SRC_W + 255) // 256 * 256                 # AVHWFramesContext row alignment
+        dst_ls = (DST_W * 3 + 255) // 256 * 256
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        self.src = [torch.randint(0, 256, (SRC_H * 3 // 2, src_ls), dtype=torch.uint8, device="cuda", generator=g)
+                    for _ in range(frames)]
+        self.dst = [torch.empty((DST_H, dst_ls), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        self.src_ls, self.dst_ls = src_ls, dst_ls
+        n = frames
+        self.sp = (C.c_void_p * (4 * n))()
+        self.dp = (C.c_void_p * (4 * n))()
+        for i in range(n):
+            base = self.src[i].data_ptr()
+            self.sp[4 * i], self.sp[4 * i + 1] = base, base + src_ls * SRC_H      # UV directly after Y
+            self.dp[4 * i] = self.dst[i].data_ptr()
+        self.ss, self.ds = ints([src_ls, src_ls]), ints([dst_ls])
+        self.graph = None
+        if use_graph:
+            ge = C.c_void_p()
+            r = lib.gmat_sws_graph_create(self.ctx, n, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
+                                          C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds, stream, C.byref(ge))
+            if r != 0:
+                raise RuntimeError(f"gmat_sws_graph_create failed: {r}")
+            self.graph = ge
+        self._planes = planes
+
+    def step(self):
+        lib = self.lib
+        if self.graph:
+            r = lib.gmat_graph_launch(self.graph, self.stream)
+            if r != 0:
+                raise RuntimeError(f"graph launch failed: {r}")
+            return
+        sp = C.cast(self.sp, C.POINTER(C.c_void_p))
+        dp = C.cast(self.dp, C.POINTER(C.c_void_p))
+        for i in range(self.frames):
+            r = lib.gmat_sws_scale(self.ctx, C.cast(C.byref(self.sp, 4 * i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p)),
+                                   self.ss, 0, SRC_H,
+                                   C.cast(C.byref(self.dp, 4 * i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p)), self.ds)
+            if r < 0:
+                raise RuntimeError(f"gmat_sws_scale failed: {r}")
+
+    def kernel(self):
+        return self.lib.gmat_sws_lastKernel(self.ctx).decode()
+
+    def close(self):
+        if self.graph:
+            self.lib.gmat_graph_destroy(self.graph)
+        self.lib.gmat_sws_freeContext(self.ctx)
+
+
+def timed(lib, torch, dist, runner, stream, steps, warmup, world):
+    """W warm-up steps, then exactly K steps between barrier+synchronize pairs; returns
+    (wall seconds MAX over ranks, device milliseconds from HIP events on the launch stream)."""
+    for _ in range(warmup):
+        runner.step()
+    lib.gmat_stream_sync(stream)
+    timer = C.c_void_p()
+    lib.gmat_timer_create(C.byref(timer))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.gmat_timer_begin(timer, stream)
+    for _ in range(steps):
+        runner.step()
+    lib.gmat_timer_end(timer, stream)
+    lib.gmat_stream_sync(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    ms = C.c_float()
+    lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
+    lib.gmat_timer_destroy(timer)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, float(ms.value)
+
+
+def time_single_kernel(lib, torch, runner_fn, stream, reps):
+    """average duration (ms) of one repeated launch function, HIP events on the launch stream"""
+    timer = C.c_void_p()
+    lib.gmat_timer_create(C.byref(timer))
+    for _ in range(3):
+        runner_fn()
+    lib.gmat_stream_sync(stream)
+    lib.gmat_timer_begin(timer, stream)
+    for _ in range(reps):
+        runner_fn()
+    lib.gmat_timer_end(timer, stream)
+    ms = C.c_float()
+    lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
+    lib.gmat_timer_destroy(timer)
+    return float(ms.value) / reps
+
+
+def cpu_baseline(nframes):
+    """The oracle on the host cores: chained convert + bicubic scale, row-sliced over all cores."""
+    import numpy as np
+    import harness
+    from concurrent.futures import ThreadPoolExecutor
+    from gmat_amd.lib import PIX_FMT, SWS, planes, ints
+    path = os.path.join(ROOT, "oracle", "liborc.so")
+    if not os.path.exists(path):
+        return None
+    orc = harness.load_oracle(path)
+    L = orc.L
+    cores = os.cpu_count() or 1
+    y = orc.lcg((SRC_H, SRC_W), 7)
+    uv = orc.lcg((SRC_H // 2, SRC_W), 8)
+    rgb = np.empty((SRC_H, SRC_W * 3), np.uint8)
+    out = np.empty((DST_H, DST_W * 3), np.uint8)
+    ctx = L.orc_sws_create(SRC_W, SRC_H, PIX_FMT["rgb24"], DST_W, DST_H, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    y2r = orc.y2r()
+    band_src = (SRC_H // cores + 1) & ~1
+    band_dst = DST_H // cores + 1
+
+    def conv(i):
+        y0 = i * band_src
+        hh = min(band_src, SRC_H - y0)
+        if hh <= 0:
+            return
+        L.orc_yuv2rgb_frame(y2r, planes([y.ctypes.data + y0 * SRC_W, uv.ctypes.data + (y0 // 2) * SRC_W]),
+                            ints([SRC_W, SRC_W]), rgb.ctypes.data + y0 * SRC_W * 3, SRC_W * 3, SRC_W, hh,
+                            PIX_FMT["nv12"], PIX_FMT["rgb24"])
+
+    def scale(i):
+        y0 = i * band_dst
+        y1 = min(DST_H, y0 + band_dst)
+        if y0 < y1:
+            L.orc_sws_scale_rows(ctx, planes([rgb.ctypes.data]), ints([SRC_W * 3]), planes([out.ctypes.data]),
+                                 ints([DST_W * 3]), y0, y1)
+
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(conv, range(cores))); list(ex.map(scale, range(cores)))          # warm
+        t0 = time.perf_counter()
+        for _ in range(nframes):
+            list(ex.map(conv, range(cores)))
+            list(ex.map(scale, range(cores)))
+        dt = time.perf_counter() - t0
+    L.orc_sws_free(ctx)
+    return {"value": round(nframes * PX / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
+            "sample": f"{nframes} frames 3840x2160 nv12->rgb24->1920x1080 bicubic, C oracle (oracle/), "
+                      f"{cores} threads row-sliced, {dt:.2f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import gmat_amd
+    lib = gmat_amd.load()                                   # raises if the HIP library is missing
+    if lib.gmat_device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible")
+    torch.cuda.set_device(local)
+    lib.gmat_set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    stream = C.c_void_p()
+    lib.gmat_stream_create(C.byref(stream))
+
+    use_graph = not a.no_graph
+    fused = Runner(lib, torch, stream, a.frames, True, use_graph, seed=1000 + rank)
+    wall, dev_ms = timed(lib, torch, dist, fused, stream, a.steps, a.warmup, world)
+    launches = a.steps * a.frames
+    gpix = world * launches * PX / wall / 1e9
+    ach = ALG_FUSED * launches / (dev_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Gpix/s (and % HBM roofline) for 4K nv12->rgb24->1080p bicubic at 1/2/4/8 GPUs",
+        "value": round(gpix, 3), "unit": "Gpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "3840x2160 nv12 -> rgb24 -> 1920x1080 bicubic rgb24 (BASELINE configs[2]), "
+                               "device-resident frames, output bit-identical to the chained libswscale oracle",
+                   "frames_per_step": a.frames, "implementation": "fused single kernel " + fused.kernel(),
+                   "launch": "hipGraph replay" if use_graph else "eager", "streams_per_gpu": 1,
+                   "parallelism": f"{world} independent streams, one per GPU, no collective"},
+        "roofline": {"bound": "hbm", "kernel": fused.kernel(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": ALG_FUSED, "avg_launch_us": round(dev_ms * 1e3 / launches, 3)},
+    }
+    fused.close()
+
+    if rank == 0 and not a.no_chained:
+        ch = Runner(lib, torch, stream, a.frames, False, use_graph, seed=2000)
+        cwall, cms = timed(lib, torch, None, ch, stream, max(3, a.steps // 3), 2, 1)
+        n = max(3, a.steps // 3) * a.frames
+        ach_c = (ALG_CONVERT + ALG_SCALE) * n / (cms * 1e-3) / 1e9
+        # per-kernel timing: each kernel alone over the rotating frame set
+        from gmat_amd.lib import PIX_FMT, planes, ints
+        rgb = [torch.empty((SRC_H, ch.src_ls * 3), dtype=torch.uint8, device="cuda") for _ in range(a.frames)]
+        cc = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["nv12"], SRC_W, SRC_H, PIX_FMT["rgb24"], 0, None)
+        sc = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["rgb24"], DST_W, DST_H, PIX_FMT["rgb24"], 4, None)
+        lib.gmat_sws_setStream(cc, stream); lib.gmat_sws_setStream(sc, stream)
+        state = {"i": 0}
+
+        def k_conv():
+            i = state["i"] = (state["i"] + 1) % a.frames
+            b = ch.src[i].data_ptr()
+            lib.gmat_sws_scale(cc, planes([b, b + ch.src_ls * SRC_H]), ints([ch.src_ls, ch.src_ls]), 0, SRC_H,
+                               planes([rgb[i].data_ptr()]), ints([ch.src_ls * 3]))
+
+        def k_scale():
+            i = state["i"] = (state["i"] + 1) % a.frames
+            lib.gmat_sws_scale(sc, planes([rgb[i].data_ptr()]), ints([ch.src_ls * 3]), 0, SRC_H,
+                               planes([ch.dst[i].data_ptr()]), ints([ch.dst_ls]))
+
+        t_conv = time_single_kernel(lib, torch, k_conv, stream, 4 * a.frames)
+        t_scale = time_single_kernel(lib, torch, k_scale, stream, 4 * a.frames)
+        out["chained"] = {
+            "value": round(n * PX / cwall / 1e9, 3), "unit": "Gpix/s",
+            "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_frame": ALG_CONVERT + ALG_SCALE,
+            "kernels": {
+                "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
+                                   "achieved_GBps": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9, 1),
+                                   "frac": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                lib.gmat_sws_lastKernel(sc).decode(): {
+                    "avg_launch_us": round(t_scale * 1e3, 3),
+                    "achieved_GBps": round(ALG_SCALE / (t_scale * 1e-3) / 1e9, 1),
+                    "frac": round(ALG_SCALE / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
+        lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
+        ch.close()
+
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_frames)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

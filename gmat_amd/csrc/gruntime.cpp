@@ -73,7 +73,9 @@ int gmat_memcpy_d2h(uint8_t *dst, const uint8_t *src, size_t bytes)
 
 int gmat_memset(uint8_t *dst, int value, size_t bytes)
 {
+    // hipMemset on device memory is asynchronous to the host; this helper is for set-up code, so wait
     GMAT_HIP_CHECK(hipMemset(dst, value, bytes));
+    GMAT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
 

@@ -36,7 +36,10 @@ __device__ __forceinline__ ChromaTerms chroma_terms(const Yuv2RgbConsts &k, int 
     return t;
 }
 
-__device__ __forceinline__ int luma_chan(int term, int ycy) { return clip_u8((term + ycy) >> 16); }
+// clip_u8(v >> 16) written as clamp-then-shift.  The shift-then-clamp form makes hipcc (ROCm 7.2) pair two
+// channels into v_ashr_pk_u8_i32, whose upper destination half is NOT cleared on gfx950 while the compiler
+// assumes it is: packed RGB came out as (R|B) in the B byte (seen on hardware, round 1).
+__device__ __forceinline__ int luma_chan(int term, int ycy) { return min(max(term + ycy, 0), 0xFFFFFF) >> 16; }
 
 // ---- rgb -> 14-bit Y / U / V as the generic scaler's input stage does (input.c:795-866) -----
 __device__ __forceinline__ int rgb_to_y14(const Rgb2YuvConsts &c, int r, int g, int b)
