@@ -75,7 +75,7 @@ struct GmatSwsContext {
     ScalePlan plan;               // always an RGB24 -> dst plan (the YUV source is converted in front)
     ScaleTiling tiling;
     DevFilterStore dHLum, dHChr, dVLum;
-    DevBuf dColStart, dColCount, dRowStart, dRowCount;
+    DevBuf dColStart, dColCount, dRowStart, dRowCount, dColMagic;
     ScaleArgs args;
     int fused = 1;
     uint8_t *inter = nullptr;     // RGB24 intermediate at source size for the two-kernel form
@@ -101,6 +101,8 @@ static int init_scaler(GmatSwsContext *c)
     if ((r = c->dColCount.upload(t.colCount.data(), t.colCount.size() * 4)) < 0) return r;
     if ((r = c->dRowStart.upload(t.rowStart.data(), t.rowStart.size() * 4)) < 0) return r;
     if ((r = c->dRowCount.upload(t.rowCount.data(), t.rowCount.size() * 4)) < 0) return r;
+    if ((r = c->dColMagic.upload(t.colMagic.data(), t.colMagic.size() * 4)) < 0) return r;
+    a.colMagic = (const int32_t *)c->dColMagic.p; a.chromaDirect = t.chromaDirect;
     a.colStart = (const int32_t *)c->dColStart.p; a.colCount = (const int32_t *)c->dColCount.p;
     a.rowStart = (const int32_t *)c->dRowStart.p; a.rowCount = (const int32_t *)c->dRowCount.p;
     a.TH = t.TH; a.ntx = t.ntx; a.nty = t.nty; a.xcdRemap = t.xcdRemap;

@@ -36,7 +36,7 @@ __device__ __forceinline__ void convert_row4(uint8_t *drow, unsigned y4, const C
     unsigned px[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int ycy = (int)((y4 >> (8 * i)) & 0xFF) * cy;
+        const int ycy = m24((int)((y4 >> (8 * i)) & 0xFF), cy);
         const ChromaTerms &c = i < 2 ? c0 : c1;
         const unsigned r = (unsigned)luma_chan(c.r, ycy), g = (unsigned)luma_chan(c.g, ycy),
                        b = (unsigned)luma_chan(c.b, ycy);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void yuv2rgb_kernel(YuvSrc s, uint8_t *dst, in
                 V = s.v[crow * s.vs + (xx >> 1)];
             }
             const ChromaTerms c = chroma_terms(k, U, V);
-            const int ycy = (int)py[(size_t)r * s.ys + i] * k.cy;
+            const int ycy = m24((int)py[(size_t)r * s.ys + i], k.cy);
             store_px<OUT>(d0 + (size_t)r * ds + (size_t)i * BPP, luma_chan(c.r, ycy), luma_chan(c.g, ycy),
                           luma_chan(c.b, ycy));
         }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void nv12_to_rgbpf32_kernel(YuvSrc s, uint8_t 
             const int xx = min(x + i, w - 1);
             const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
             const ChromaTerms c = chroma_terms(k, p[0], p[1]);
-            const int ycy = (int)s.y[(size_t)(y + r) * s.ys + xx] * k.cy;
+            const int ycy = m24((int)s.y[(size_t)(y + r) * s.ys + xx], k.cy);
             o[0][i] = (float)luma_chan(c.r, ycy) / 255.0f;
             o[1][i] = (float)luma_chan(c.g, ycy) / 255.0f;
             o[2][i] = (float)luma_chan(c.b, ycy) / 255.0f;

@@ -39,8 +39,8 @@ struct ScaleTiling {
     int TW = 0, TH = 0, ntx = 0, nty = 0;
     int maxRows = 0, maxCols = 0;        // over all tiles (rows even, cols multiple of 4)
     int ldsBytes = 0;
-    int xcdRemap = 1;
-    std::vector<int32_t> colStart, colCount, rowStart, rowCount;
+    int xcdRemap = 1, chromaDirect = 0;
+    std::vector<int32_t> colStart, colCount, rowStart, rowCount, colMagic;
 };
 
 struct ScaleArgs {
@@ -53,8 +53,8 @@ struct ScaleArgs {
     uint8_t *dst;
     int ds, dstFormat, dstAligned;
     DevFilter hLum, hChr, vLum;   // vertical chroma filter == vLum for a non-subsampled source
-    const int32_t *colStart, *colCount, *rowStart, *rowCount;   // device copies of ScaleTiling's
-    int TH, ntx, nty, xcdRemap;
+    const int32_t *colStart, *colCount, *rowStart, *rowCount, *colMagic;   // device copies of ScaleTiling's
+    int TH, ntx, nty, xcdRemap, chromaDirect;
     Rgb2YuvConsts r2y;
     Yuv2RgbConsts y2r;
 };

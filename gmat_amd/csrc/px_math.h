@@ -12,6 +12,10 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   // v_med3_i32
 
+// 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24 run at full rate; v_mul_lo_u32 does not).  Every use
+// below has |operands| < 2^23: pixel values <= 510, table constants <= 2^18.
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+
 // 2-way int16 dot product with int32 accumulate: v_dot2c_i32_i16 (exact integer arithmetic).
 __device__ __forceinline__ int dot2(int packed_ab, int packed_cd, int acc)
 {
@@ -26,13 +30,13 @@ struct ChromaTerms { int r, g, b; };
 
 __device__ __forceinline__ ChromaTerms chroma_terms(const Yuv2RgbConsts &k, int U, int V)
 {
-    const int kr = k.offR + ((V * k.crv) >> 16);
-    const int kg = k.offG + ((U * k.cgu) >> 16) + ((V * k.cgv) >> 16);
-    const int kb = k.offB + ((U * k.cbu) >> 16);
+    const int kr = k.offR + (m24(V, k.crv) >> 16);
+    const int kg = k.offG + (m24(U, k.cgu) >> 16) + (m24(V, k.cgv) >> 16);
+    const int kb = k.offB + (m24(U, k.cbu) >> 16);
     ChromaTerms t;
-    t.r = k.base + kr * k.cy;
-    t.g = k.base + kg * k.cy;
-    t.b = k.base + kb * k.cy;
+    t.r = k.base + m24(kr, k.cy);
+    t.g = k.base + m24(kg, k.cy);
+    t.b = k.base + m24(kb, k.cy);
     return t;
 }
 
@@ -45,26 +49,26 @@ __device__ __forceinline__ int luma_chan(int term, int ycy) { return min(max(ter
 __device__ __forceinline__ int rgb_to_y14(const Rgb2YuvConsts &c, int r, int g, int b)
 {
     // rgb24ToY_c: (ry*r + gy*g + by*b + (32<<14) + (1<<8)) >> 9
-    return (c.ry * r + c.gy * g + c.by * b + (32 << 14) + (1 << 8)) >> 9;
+    return (m24(c.ry, r) + m24(c.gy, g) + m24(c.by, b) + (32 << 14) + (1 << 8)) >> 9;
 }
 __device__ __forceinline__ int rgb_to_u14(const Rgb2YuvConsts &c, int r, int g, int b)
 {
     // rgb24ToUV_c: (ru*r + gu*g + bu*b + (256<<14) + (1<<8)) >> 9
-    return (c.ru * r + c.gu * g + c.bu * b + (256 << 14) + (1 << 8)) >> 9;
+    return (m24(c.ru, r) + m24(c.gu, g) + m24(c.bu, b) + (256 << 14) + (1 << 8)) >> 9;
 }
 __device__ __forceinline__ int rgb_to_v14(const Rgb2YuvConsts &c, int r, int g, int b)
 {
-    return (c.rv * r + c.gv * g + c.bv * b + (256 << 14) + (1 << 8)) >> 9;
+    return (m24(c.rv, r) + m24(c.gv, g) + m24(c.bv, b) + (256 << 14) + (1 << 8)) >> 9;
 }
 // rgb24ToUV_half_c on the SUM of two horizontally adjacent pixels:
 //   (ru*r + gu*g + bu*b + (256<<15) + (1<<9)) >> 10
 __device__ __forceinline__ int rgbsum_to_u14(const Rgb2YuvConsts &c, int r, int g, int b)
 {
-    return (c.ru * r + c.gu * g + c.bu * b + (256 << 15) + (1 << 9)) >> 10;
+    return (m24(c.ru, r) + m24(c.gu, g) + m24(c.bu, b) + (256 << 15) + (1 << 9)) >> 10;
 }
 __device__ __forceinline__ int rgbsum_to_v14(const Rgb2YuvConsts &c, int r, int g, int b)
 {
-    return (c.rv * r + c.gv * g + c.bv * b + (256 << 15) + (1 << 9)) >> 10;
+    return (m24(c.rv, r) + m24(c.gv, g) + m24(c.bv, b) + (256 << 15) + (1 << 9)) >> 10;
 }
 
 // ---- full-chroma output stage: yuv2rgb_write_full (output.c:1886-1935) ------------------------

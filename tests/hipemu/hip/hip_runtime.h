@@ -76,6 +76,8 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu::sdot2(a, b, c)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
+static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 
