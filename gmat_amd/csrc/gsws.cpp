@@ -39,6 +39,18 @@ struct DevBuf {
 
 struct DevFilterStore {
     DevBuf packed, pos, round;
+    int upload(const FilterBank &fb, const std::vector<int32_t> &rnd, DevFilter &out)
+    {
+        int r;
+        if ((r = packed.upload(fb.packed.data(), fb.packed.size() * sizeof(int32_t))) < 0) return r;
+        if ((r = pos.upload(fb.pos_even.data(), fb.pos_even.size() * sizeof(int32_t))) < 0) return r;
+        if ((r = round.upload(rnd.data(), rnd.size() * sizeof(int32_t))) < 0) return r;
+        out.packed = (const int32_t *)packed.p;
+        out.pos_even = (const int32_t *)pos.p;
+        out.round = (const int32_t *)round.p;
+        out.pairs = fb.pairs; out.taps = fb.taps; out.count = fb.count;
+        return 0;
+    }
     int upload(const FilterBank &fb, bool vertical, DevFilter &out)
     {
         int r;
@@ -77,15 +89,59 @@ struct GmatSwsContext {
     DevFilterStore dHLum, dHChr, dVLum;
     DevBuf dColStart, dColCount, dRowStart, dRowCount, dColMagic;
     ScaleArgs args;
-    int fused = 1;
+    bool rgbReady = false;
+    // YUV-source scaler with libswscale's single-context semantics (k_scale_yuv.hip)
+    ScalePlan planYuv;
+    YuvScaleTiling ytiling;
+    DevFilterStore yHLum, yHChr, yVLum, yVChr;
+    DevBuf yWin[8];
+    YuvScaleArgs yargs;
+    bool yuvReady = false;
+    // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
+    // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
+    int fused = 2;
     uint8_t *inter = nullptr;     // RGB24 intermediate at source size for the two-kernel form
     int interStride = 0;
     const char *lastKernel = "";
+    unsigned long long *prof = nullptr;
     ~GmatSwsContext() { if (inter) (void)hipFree(inter); }
 };
 
+static int init_yuv_scaler(GmatSwsContext *c)
+{
+    if (c->yuvReady) return 0;
+    int r = build_scale_plan(c->planYuv, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
+    if (r < 0) return r;
+    if ((r = yuvscale_prepare(c->planYuv, c->ytiling)) < 0) return r;
+    YuvScaleArgs &a = c->yargs;
+    std::memset(&a, 0, sizeof(a));
+    const YuvScaleTiling &t = c->ytiling;
+    const std::vector<int32_t> none(std::max(c->dstW, c->dstH), 0);
+    if ((r = c->yHLum.upload(c->planYuv.hLum, none, a.hLum)) < 0) return r;
+    if ((r = c->yHChr.upload(c->planYuv.hChr, none, a.hChr)) < 0) return r;
+    if ((r = c->yVLum.upload(c->planYuv.vLum, t.lumRound, a.vLum)) < 0) return r;
+    if ((r = c->yVChr.upload(t.vChrEff, t.chrRound, a.vChr)) < 0) return r;
+    const std::vector<int32_t> *w[8] = {&t.colStartL, &t.colCountL, &t.rowStartL, &t.rowCountL,
+                                        &t.colStartC, &t.colCountC, &t.rowStartC, &t.rowCountC};
+    const int32_t **dst[8] = {&a.colStartL, &a.colCountL, &a.rowStartL, &a.rowCountL,
+                              &a.colStartC, &a.colCountC, &a.rowStartC, &a.rowCountC};
+    for (int i = 0; i < 8; i++) {
+        if ((r = c->yWin[i].upload(w[i]->data(), w[i]->size() * 4)) < 0) return r;
+        *dst[i] = (const int32_t *)c->yWin[i].p;
+    }
+    a.TH = t.TH; a.ntx = t.ntx; a.nty = t.nty; a.xcdRemap = t.xcdRemap; a.fullChroma = t.fullChroma;
+    a.rowsL = t.rowsL; a.colsL = t.colsL; a.rowsC = t.rowsC; a.colsC = t.colsC;
+    a.srcW = c->srcW; a.srcH = c->srcH; a.chrSrcW = c->planYuv.chrSrcW; a.chrSrcH = c->planYuv.chrSrcH;
+    a.dstW = c->dstW; a.dstH = c->dstH; a.chrDstW = c->planYuv.chrDstW;
+    a.dstFormat = c->dstFormat;
+    a.nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    c->yuvReady = true;
+    return 0;
+}
+
 static int init_scaler(GmatSwsContext *c)
 {
+    if (c->rgbReady) return 0;
     const bool src_yuv = is_yuv420(c->srcFormat);
     const int planSrc = src_yuv ? GMAT_PIX_FMT_RGB24 : c->srcFormat;
     int r = build_scale_plan(c->plan, c->srcW, c->srcH, planSrc, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
@@ -117,7 +173,23 @@ static int init_scaler(GmatSwsContext *c)
         // always uses BT.601 limited (as an RGB24->RGB libswscale context does)
         c->y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
     }
+    c->rgbReady = true;
     return 0;
+}
+
+// prepares whichever scaler the current mode needs
+static int ensure_scaler(GmatSwsContext *c)
+{
+    if (is_yuv420(c->srcFormat) && c->fused == 2) {
+        int r = init_yuv_scaler(c);
+        if (r == GMAT_ERR(ENOSYS)) {
+            logf(LOG_WARNING, "gmat_sws: single-context YUV scaler unavailable for this geometry; using convert-then-scale");
+            c->fused = 1;
+            return init_scaler(c);
+        }
+        return r;
+    }
+    return init_scaler(c);
 }
 
 namespace gmat { int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; } }
@@ -155,7 +227,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
-        r = init_scaler(c);
+        r = ensure_scaler(c);
     } else {
         logf(LOG_ERROR, "gmat_sws_getContext: unsupported conversion %d %dx%d -> %d %dx%d", srcFormat, srcW, srcH,
              dstFormat, dstW, dstH);
@@ -186,8 +258,16 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 
 int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
-    if (!c) return GMAT_ERR(EINVAL);
+    if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
     c->fused = fused;
+    if (c->mode == MODE_SCALE) return ensure_scaler(c);
+    return 0;
+}
+
+int gmat_sws_setProfileBuffer(GmatSwsContext *c, uint8_t *devbuf)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    c->prof = (unsigned long long *)devbuf;
     return 0;
 }
 
@@ -197,11 +277,12 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 {
     if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
     const FilterBank *fb;
+    const ScalePlan &pl = (is_yuv420(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
     switch (which) {
-    case 0: fb = &c->plan.hLum; break;
-    case 1: fb = &c->plan.hChr; break;
-    case 2: fb = &c->plan.vLum; break;
-    case 3: fb = &c->plan.vChr; break;
+    case 0: fb = &pl.hLum; break;
+    case 1: fb = &pl.hChr; break;
+    case 2: fb = &pl.vLum; break;
+    case 3: fb = &pl.vChr; break;
     default: return GMAT_ERR(EINVAL);
     }
     if (count) *count = fb->count;
@@ -260,6 +341,25 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                           c->srcH, c->stream);
         break;
     case MODE_SCALE: {
+        if ((r = ensure_scaler(c)) < 0) break;
+        if (is_yuv420(c->srcFormat) && c->fused == 2) {
+            YuvScaleArgs ya = c->yargs;
+            ya.y = src[0]; ya.ys = srcStride[0];
+            ya.u = src[1]; ya.us = srcStride[1];
+            ya.v = planarYuv ? src[2] : nullptr; ya.vs = planarYuv ? srcStride[2] : 0;
+            ya.srcAligned = al4(src[0], srcStride[0]) &&
+                            (ya.nv12 ? al4(src[1], srcStride[1])
+                                     : ((((uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[1] |
+                                          (uintptr_t)srcStride[2]) & 1) == 0));
+            ya.dst = dst[0]; ya.ds = dstStride[0];
+            const int ybpp = bytes_per_pixel(c->dstFormat);
+            ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
+            ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
+            ya.prof = c->prof;
+            c->lastKernel = yuvscale_kernel_name(c->ytiling);
+            r = launch_scale_yuv(ya, c->ytiling, c->stream);
+            break;
+        }
         ScaleArgs a = c->args;
         a.dst = dst[0]; a.ds = dstStride[0];
         const int bpp = bytes_per_pixel(c->dstFormat);

@@ -1,0 +1,424 @@
+// k_scale_yuv.hip — libswscale's generic scaler for 8-bit YUV 4:2:0 sources (NV12, YUV420P) with
+// packed-RGB output, as one fused LDS-tiled kernel for gfx950.  Integer arithmetic, bit-exact with
+// what ONE libswscale context (sws_getContext(nv12 -> rgb24, different size)) computes on the CPU:
+//   horizontal   hScale8To15_c: min(sum(src*f) >> 7, 32767), luma and both chroma planes   swscale.c:122-136
+//   vertical+out half chroma : yuv2rgb_X_c / _2_c / _1_c + the yuv2rgb.c tables (closed form)  output.c:1680-1828
+//                full chroma : yuv2rgb_full_X_c / _2_c / _1_c + yuv2rgb_write_full             output.c:1886-2200
+//   form choice  packed_vscale                                                                  vscale.c:135-167
+// The 1-tap and 2-tap special forms are folded into per-row accumulator start values and an
+// "effective" vertical chroma filter prepared on the host (yuvscale_prepare), so the kernel runs one
+// generic loop.
+//
+// HBM traffic per 4K->1080p frame: 12.4 MB of NV12 in, 6.2 MB of RGB24 out (2.25 B per source pixel).
+// Block = 256 threads = one TW x TH output tile; phases: (1) window load, u8 -> int16 in LDS;
+// (2) horizontal v_dot2c_i32_i16 over dword pairs, two source rows per item, row-pair-interleaved
+// int16 result; (3) vertical dot2 from ds_read_b128 vectors + colour stage + 12/16-byte stores.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+constexpr int kYMaxPairs = 8;
+constexpr int kLumaBatch = 6, kChromaBatch = 3;
+
+__device__ __forceinline__ unsigned pk16(int lo, int hi) { return ((unsigned)lo & 0xFFFF) | ((unsigned)hi << 16); }
+
+template <bool FAST>
+__device__ __forceinline__ unsigned ld_y4(const YuvScaleArgs &a, int srow, int col)
+{
+    const uint8_t *row = a.y + (size_t)srow * a.ys;
+    if (FAST) return *reinterpret_cast<const unsigned *>(row + col);
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (unsigned)row[min(col + i, a.srcW - 1)] << (8 * i);
+    return v;
+}
+
+// two chroma samples starting at even chroma column cc: returns U0 | V0<<8 | U1<<16 | V1<<24
+template <bool FAST>
+__device__ __forceinline__ unsigned ld_uv2(const YuvScaleArgs &a, int crow, int cc)
+{
+    if (FAST) {
+        if (a.nv12) return *reinterpret_cast<const unsigned *>(a.u + (size_t)crow * a.us + 2 * cc);
+        const unsigned uu = *reinterpret_cast<const unsigned short *>(a.u + (size_t)crow * a.us + cc);
+        const unsigned vv = *reinterpret_cast<const unsigned short *>(a.v + (size_t)crow * a.vs + cc);
+        return (uu & 0xFF) | ((vv & 0xFF) << 8) | ((uu >> 8) << 16) | ((vv >> 8) << 24);
+    }
+    unsigned r = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = min(cc + i, a.chrSrcW - 1);
+        unsigned U, V;
+        if (a.nv12) { const uint8_t *q = a.u + (size_t)crow * a.us + 2 * c; U = q[0]; V = q[1]; }
+        else        { U = a.u[(size_t)crow * a.us + c]; V = a.v[(size_t)crow * a.vs + c]; }
+        r |= (U | (V << 8)) << (16 * i);
+    }
+    return r;
+}
+
+template <bool FASTL, bool FASTC>
+__device__ __forceinline__ void yuv_phase1(const YuvScaleArgs &a, int tid, int c0L, int ncL, int r0L, int nrL,
+                                           int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
+                                           unsigned short *lu, unsigned short *lv)
+{
+    // luma: 4 pixels per dword
+    {
+        const int ng = ncL >> 2, total = nrL * ng;
+        for (int base = tid; base < total; base += 256 * kLumaBatch) {
+            unsigned raw[kLumaBatch];
+            int off[kLumaBatch];
+#pragma unroll
+            for (int j = 0; j < kLumaBatch; j++) {
+                const int g = base + j * 256, gg = min(g, total - 1);
+                const int r = gg / ng, cg = gg - r * ng;
+                off[j] = g < total ? r * a.colsL + 4 * cg : -1;
+                raw[j] = ld_y4<FASTL>(a, min(r0L + r, a.srcH - 1), c0L + 4 * cg);
+            }
+#pragma unroll
+            for (int j = 0; j < kLumaBatch; j++) {
+                if (off[j] < 0) continue;
+                const unsigned v = raw[j];
+                *reinterpret_cast<uint2 *>(ly + off[j]) =
+                    make_uint2((v & 0xFF) | ((v & 0xFF00) << 8), ((v >> 16) & 0xFF) | ((v >> 24) << 16));
+            }
+        }
+    }
+    // chroma: 2 samples of each plane per dword (NV12) / pair of ushorts (planar)
+    {
+        const int ng = ncC >> 1, total = nrC * ng;
+        for (int base = tid; base < total; base += 256 * kChromaBatch) {
+            unsigned raw[kChromaBatch];
+            int off[kChromaBatch];
+#pragma unroll
+            for (int j = 0; j < kChromaBatch; j++) {
+                const int g = base + j * 256, gg = min(g, total - 1);
+                const int r = gg / ng, cg = gg - r * ng;
+                off[j] = g < total ? r * a.colsC + 2 * cg : -1;
+                raw[j] = ld_uv2<FASTC>(a, min(r0C + r, a.chrSrcH - 1), c0C + 2 * cg);
+            }
+#pragma unroll
+            for (int j = 0; j < kChromaBatch; j++) {
+                if (off[j] < 0) continue;
+                const unsigned v = raw[j];
+                *reinterpret_cast<unsigned *>(lu + off[j]) = (v & 0xFF) | (v & 0xFF0000);
+                *reinterpret_cast<unsigned *>(lv + off[j]) = ((v >> 8) & 0xFF) | ((v >> 8) & 0xFF0000);
+            }
+        }
+    }
+}
+
+template <int TW, bool FULL>
+__global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
+{
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    constexpr int CWD = FULL ? TW : TW / 2;            // chroma samples per output tile row
+
+    int tcol, trow;
+    {
+        const int ntiles = a.ntx * a.nty;
+        int lin = blockIdx.x;
+        if (a.xcdRemap) {
+            const int chunk = (ntiles + 7) >> 3;
+            lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        }
+        if (lin >= ntiles) return;
+        tcol = lin / a.nty;
+        trow = lin - tcol * a.nty;
+    }
+    const int tid = threadIdx.x;
+    // optional phase timestamps (tuning aid): 6 x u64 per block, written by thread 0
+    unsigned long long *prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
+#define GMAT_STAMP(i) do { if (prof && tid == 0) prof[i] = __builtin_readcyclecounter(); } while (0)
+    GMAT_STAMP(0);
+    const int tx0 = tcol * TW, ty0 = trow * a.TH;
+    const int tcx0 = FULL ? tx0 : tx0 >> 1;
+    const int c0L = a.colStartL[tcol], ncL = a.colCountL[tcol], r0L = a.rowStartL[trow], nrL = a.rowCountL[trow];
+    const int c0C = a.colStartC[tcol], ncC = a.colCountC[tcol], r0C = a.rowStartC[trow], nrC = a.rowCountC[trow];
+
+    unsigned short *ly = reinterpret_cast<unsigned short *>(lds_base);
+    unsigned short *lu = ly + a.rowsL * a.colsL;
+    unsigned short *lv = lu + a.rowsC * a.colsC;
+    int *hy = reinterpret_cast<int *>(lv + a.rowsC * a.colsC);
+    int *hu = hy + (a.rowsL >> 1) * TW;
+    int *hv = hu + (a.rowsC >> 1) * CWD;
+
+    // ---- prologue: issue the loads of every filter coefficient / position this thread will use in
+    // phases 2 and 3 NOW, so their latency overlaps the phase-1 pixel loads instead of serialising
+    // behind the barriers (measured: phases 2/3 were dominated by these small dependent loads) ----
+    const int xo2 = tid % TW, gx2 = min(tx0 + xo2, a.dstW - 1);
+    const int xc2 = tid % CWD, gc2 = min(tcx0 + xc2, a.chrDstW - 1);
+    int lc[kYMaxPairs], cc[kYMaxPairs];
+#pragma unroll
+    for (int k = 0; k < kYMaxPairs; k++) {
+        lc[k] = k < a.hLum.pairs ? a.hLum.packed[(size_t)gx2 * a.hLum.pairs + k] : 0;
+        cc[k] = k < a.hChr.pairs ? a.hChr.packed[(size_t)gc2 * a.hChr.pairs + k] : 0;
+    }
+    const int lpos = a.hLum.pos_even[gx2] - c0L;
+    const int cpos = a.hChr.pos_even[gc2] - c0C;
+    constexpr int QW = TW / 4;
+    const int q = tid % QW;
+    int yl = tid / QW;
+    int vl[kYMaxPairs], vc[kYMaxPairs], vpL = 0, vpC = 0, lr = 0, cr = 0;
+    auto load_row = [&](int yo) {
+#pragma unroll
+        for (int k = 0; k < kYMaxPairs; k++) {
+            vl[k] = k < a.vLum.pairs ? a.vLum.packed[(size_t)yo * a.vLum.pairs + k] : 0;
+            vc[k] = k < a.vChr.pairs ? a.vChr.packed[(size_t)yo * a.vChr.pairs + k] : 0;
+        }
+        vpL = (a.vLum.pos_even[yo] - r0L) >> 1;
+        vpC = (a.vChr.pos_even[yo] - r0C) >> 1;
+        lr = a.vLum.round[yo];
+        cr = a.vChr.round[yo];
+    };
+    load_row(min(ty0 + yl, a.dstH - 1));
+
+    // ================= phase 1 ================================================================
+    {
+        const bool fl = a.srcAligned && c0L + ncL <= a.srcW, fc = a.srcAligned && c0C + ncC <= a.chrSrcW;
+        if (fl && fc) yuv_phase1<true, true>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+        else          yuv_phase1<false, false>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+    }
+    GMAT_STAMP(1);
+    __syncthreads();
+    GMAT_STAMP(2);
+
+    // ================= phase 2: horizontal filters ==============================================
+    {   // luma: item = (row pair, output column)
+        const int xo = xo2;
+        for (int rp = tid / TW; rp < (nrL >> 1); rp += 256 / TW) {
+            const int *p0 = reinterpret_cast<const int *>(ly + (2 * rp) * a.colsL + lpos);
+            const int *p1 = reinterpret_cast<const int *>(ly + (2 * rp + 1) * a.colsL + lpos);
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int k = 0; k < kYMaxPairs; k++)
+                if (k < a.hLum.pairs) { s0 = dot2(p0[k], lc[k], s0); s1 = dot2(p1[k], lc[k], s1); }
+            hy[rp * TW + xo] = (int)pk16(min(s0 >> 7, 32767), min(s1 >> 7, 32767));
+        }
+    }
+    {   // chroma: item = (row pair, chroma output column), both planes
+        const int xc = xc2;
+        for (int rp = tid / CWD; rp < (nrC >> 1); rp += 256 / CWD) {
+            const int *u0 = reinterpret_cast<const int *>(lu + (2 * rp) * a.colsC + cpos);
+            const int *u1 = reinterpret_cast<const int *>(lu + (2 * rp + 1) * a.colsC + cpos);
+            const int *v0 = reinterpret_cast<const int *>(lv + (2 * rp) * a.colsC + cpos);
+            const int *v1 = reinterpret_cast<const int *>(lv + (2 * rp + 1) * a.colsC + cpos);
+            int su0 = 0, su1 = 0, sv0 = 0, sv1 = 0;
+#pragma unroll
+            for (int k = 0; k < kYMaxPairs; k++)
+                if (k < a.hChr.pairs) {
+                    su0 = dot2(u0[k], cc[k], su0); su1 = dot2(u1[k], cc[k], su1);
+                    sv0 = dot2(v0[k], cc[k], sv0); sv1 = dot2(v1[k], cc[k], sv1);
+                }
+            hu[rp * CWD + xc] = (int)pk16(min(su0 >> 7, 32767), min(su1 >> 7, 32767));
+            hv[rp * CWD + xc] = (int)pk16(min(sv0 >> 7, 32767), min(sv1 >> 7, 32767));
+        }
+    }
+    GMAT_STAMP(3);
+    __syncthreads();
+    GMAT_STAMP(4);
+
+    // ================= phase 3: vertical filters + colour stage + store =========================
+    {
+        const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+        const bool swap_rb = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
+        for (; yl < a.TH; yl += 256 / QW) {
+            const int yo = ty0 + yl, xo = tx0 + 4 * q;
+            if (yo >= a.dstH || xo >= a.dstW) continue;
+            if (yl >= 256 / QW) load_row(yo);            // later passes of tall tiles (TH > 256/QW)
+            int Y[4] = {lr, lr, lr, lr};
+#pragma unroll
+            for (int k = 0; k < kYMaxPairs; k++) {
+                if (k < a.vLum.pairs) {
+                    const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * TW + 4 * q);
+                    Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
+                    Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
+                }
+            }
+            for (int k = kYMaxPairs; k < a.vLum.pairs; k++) {       // filters longer than 15 taps
+                const int cf = a.vLum.packed[(size_t)yo * a.vLum.pairs + k];
+                const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * TW + 4 * q);
+                Y[0] = dot2(v.x, cf, Y[0]); Y[1] = dot2(v.y, cf, Y[1]);
+                Y[2] = dot2(v.z, cf, Y[2]); Y[3] = dot2(v.w, cf, Y[3]);
+            }
+            unsigned px[4];
+            if (FULL) {
+                int U[4] = {cr, cr, cr, cr}, V[4] = {cr, cr, cr, cr};
+                auto acc4 = [&](int k, int cf) {
+                    const int4 u = *reinterpret_cast<const int4 *>(hu + (vpC + k) * CWD + 4 * q);
+                    const int4 v = *reinterpret_cast<const int4 *>(hv + (vpC + k) * CWD + 4 * q);
+                    U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
+                    V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+                };
+#pragma unroll
+                for (int k = 0; k < kYMaxPairs; k++) if (k < a.vChr.pairs) acc4(k, vc[k]);
+                for (int k = kYMaxPairs; k < a.vChr.pairs; k++) acc4(k, a.vChr.packed[(size_t)yo * a.vChr.pairs + k]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) px[i] = yuv_to_rgb_full(a.y2r, Y[i] >> 10, U[i] >> 10, V[i] >> 10);
+            } else {
+                int U[2] = {cr, cr}, V[2] = {cr, cr};
+                auto acc2 = [&](int k, int cf) {
+                    const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + k) * CWD + 2 * q);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + k) * CWD + 2 * q);
+                    U[0] = dot2((int)u.x, cf, U[0]); U[1] = dot2((int)u.y, cf, U[1]);
+                    V[0] = dot2((int)v.x, cf, V[0]); V[1] = dot2((int)v.y, cf, V[1]);
+                };
+#pragma unroll
+                for (int k = 0; k < kYMaxPairs; k++) if (k < a.vChr.pairs) acc2(k, vc[k]);
+                for (int k = kYMaxPairs; k < a.vChr.pairs; k++) acc2(k, a.vChr.packed[(size_t)yo * a.vChr.pairs + k]);
+                // table_rV/gU/gV/bU are indexed with av_clip_uint8 (yuv2rgb.c:737-760)
+                const ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
+                const ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
+                    px[i]     = (unsigned)luma_chan(t0.r, ya) | ((unsigned)luma_chan(t0.g, ya) << 8) | ((unsigned)luma_chan(t0.b, ya) << 16);
+                    px[i + 2] = (unsigned)luma_chan(t1.r, yb) | ((unsigned)luma_chan(t1.g, yb) << 8) | ((unsigned)luma_chan(t1.b, yb) << 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                unsigned c = px[i];
+                if (swap_rb) c = ((c & 0xFF) << 16) | (c & 0xFF00) | ((c >> 16) & 0xFF);
+                px[i] = c | 0xFF000000u;
+            }
+            uint8_t *d = a.dst + (size_t)yo * a.ds + (size_t)xo * bpp;
+            const int nx = min(4, a.dstW - xo);
+            if (a.dstAligned && nx == 4) {
+                if (bpp == 4) {
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(px[0], px[1], px[2], px[3]);
+                } else {
+                    uint3 o3;
+                    o3.x = (px[0] & 0xFFFFFF) | (px[1] << 24);
+                    o3.y = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
+                    o3.z = ((px[2] >> 16) & 0xFF) | (px[3] << 8);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+            } else {
+                for (int i = 0; i < nx; i++) {
+                    d[i * bpp + 0] = (uint8_t)px[i];
+                    d[i * bpp + 1] = (uint8_t)(px[i] >> 8);
+                    d[i * bpp + 2] = (uint8_t)(px[i] >> 16);
+                    if (bpp == 4) d[i * bpp + 3] = 255;
+                }
+            }
+        }
+    }
+    GMAT_STAMP(5);
+#undef GMAT_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int yenv(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static void windows(const FilterBank &fb, int tile, int ntiles, int count, int align,
+                    std::vector<int32_t> &start, std::vector<int32_t> &cnt, int &mx)
+{
+    start.resize(ntiles); cnt.resize(ntiles);
+    for (int t = 0; t < ntiles; t++) {
+        int lo = INT32_MAX, hi = 0;
+        for (int i = t * tile; i < std::min((t + 1) * tile, count); i++) {
+            lo = std::min(lo, fb.pos_even[i]);
+            hi = std::max(hi, fb.pos_even[i] + 2 * fb.pairs);
+        }
+        if (lo == INT32_MAX) { lo = 0; hi = align; }       // tile beyond this plane's extent
+        lo &= ~(align - 1);
+        start[t] = lo;
+        cnt[t] = align_up(hi - lo, align);
+        mx = std::max(mx, cnt[t]);
+    }
+}
+
+int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
+{
+    if (!is_yuv420(p.srcFormat) || !is_packed_rgb(p.dstFormat)) return GMAT_ERR(ENOSYS);
+    if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
+    const int full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) ? 1 : 0;
+    if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);
+    if (p.chrDstH != p.dstH) return GMAT_ERR(ENOSYS);
+    t.fullChroma = full;
+
+    // ---- vertical special forms (vscale.c:135-167) -> per-row start values + effective chroma taps
+    const int sh_one = full ? (1 << 9) : (1 << 18);
+    const int chr_bias = full ? -(128 << 19) : 0;
+    t.lumRound.assign(p.dstH, sh_one);
+    t.chrRound.assign(p.dstH, sh_one + chr_bias);
+    t.vChrEff = p.vChr;
+    const int lfs = p.vLum.taps, cfs = p.vChr.taps;
+    for (int y = 0; y < p.dstH; y++) {
+        const int16_t *lf = &p.vLum.coef[(size_t)y * lfs];
+        int16_t *cf = &t.vChrEff.coef[(size_t)y * cfs];
+        const bool chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
+        const bool lum2 = lfs == 2 && lf[0] + lf[1] == 4096 && (unsigned)lf[1] <= 4096u;
+        if (lfs == 1 && chr2) {                      // yuv2packed1 with uvalpha = cf[1]
+            if (cf[1] < 2048) { cf[0] = 4096; cf[1] = 0; }
+            else              { cf[0] = 2048; cf[1] = 2048; }
+        } else if (lum2 && chr2) {                   // yuv2packed2: no rounding constant
+            t.lumRound[y] = 0;
+            t.chrRound[y] = chr_bias;
+        }
+    }
+    pack_filter_pairs(t.vChrEff);
+
+    const int ldsCap = yenv("GMAT_SCALE_LDS_CAP", 40 * 1024);
+    const int forceTW = yenv("GMAT_SCALE_TW", 0), forceTH = yenv("GMAT_SCALE_TH", 0);
+    const int tws[] = {64, 32};
+    for (int TW : tws) {
+        if (forceTW && TW != forceTW) continue;
+        const int cwd = full ? TW : TW / 2;
+        const int ntx = (p.dstW + TW - 1) / TW;
+        int colsL = 0, colsC = 0;
+        windows(p.hLum, TW, ntx, p.dstW, 4, t.colStartL, t.colCountL, colsL);
+        windows(p.hChr, cwd, ntx, p.chrDstW, 2, t.colStartC, t.colCountC, colsC);
+        colsL = align_up(colsL, 8); colsC = align_up(colsC, 8);
+        const int ths[] = {32, 16, 8, 4, 2, 1};
+        for (int TH : ths) {
+            if (forceTH && TH != forceTH) continue;
+            if (!forceTH && TH > 16) continue;
+            const int nty = (p.dstH + TH - 1) / TH;
+            int rowsL = 0, rowsC = 0;
+            windows(p.vLum, TH, nty, p.dstH, 2, t.rowStartL, t.rowCountL, rowsL);
+            windows(t.vChrEff, TH, nty, p.dstH, 2, t.rowStartC, t.rowCountC, rowsC);
+            const int bytes = rowsL * colsL * 2 + 2 * rowsC * colsC * 2 + (rowsL / 2) * TW * 4 + 2 * (rowsC / 2) * cwd * 4;
+            if (bytes > ldsCap && !(forceTH && bytes <= 64 * 1024)) continue;
+            t.TW = TW; t.TH = TH; t.ntx = ntx; t.nty = nty;
+            t.rowsL = rowsL; t.colsL = colsL; t.rowsC = rowsC; t.colsC = colsC; t.ldsBytes = bytes;
+            t.xcdRemap = yenv("GMAT_SCALE_XCD", 1);
+            return 0;
+        }
+    }
+    return GMAT_ERR(ENOSYS);
+}
+
+const char *yuvscale_kernel_name(const YuvScaleTiling &t)
+{
+    if (t.TW == 64) return t.fullChroma ? "scale_yuv_kernel<64,full>" : "scale_yuv_kernel<64,half>";
+    return t.fullChroma ? "scale_yuv_kernel<32,full>" : "scale_yuv_kernel<32,half>";
+}
+
+int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream)
+{
+    const int ntiles = t.ntx * t.nty;
+    if (ntiles <= 0) return 0;
+    const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
+    const size_t lds = (size_t)t.ldsBytes;
+#define GMAT_LAUNCH_YUV(TW_, FULL_) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, FULL_>), grid, block, lds, stream, a)
+    if (t.TW == 64) { if (t.fullChroma) GMAT_LAUNCH_YUV(64, true); else GMAT_LAUNCH_YUV(64, false); }
+    else if (t.TW == 32) { if (t.fullChroma) GMAT_LAUNCH_YUV(32, true); else GMAT_LAUNCH_YUV(32, false); }
+    else return GMAT_ERR(EINVAL);
+#undef GMAT_LAUNCH_YUV
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

@@ -63,6 +63,36 @@ int  scale_pick_tiling(const ScalePlan &p, ScaleTiling &t);
 int  launch_scale_rgb(const ScaleArgs &a, const ScaleTiling &t, hipStream_t stream);
 const char *scale_kernel_name(const ScaleArgs &a, const ScaleTiling &t);
 
+// ---- generic scaler for 8-bit YUV 4:2:0 sources, packed-RGB output (k_scale_yuv.hip) ---------
+// libswscale's single-context semantics: luma and chroma planes are scaled separately
+// (hScale8To15_c), vertical chroma has its own filter, output through the LUT form (half chroma,
+// yuv2rgb_X_c) or the full-chroma form (yuv2rgb_full_X_c).
+struct YuvScaleTiling {
+    int TW = 0, TH = 0, ntx = 0, nty = 0, fullChroma = 0;
+    int rowsL = 0, colsL = 0, rowsC = 0, colsC = 0, ldsBytes = 0, xcdRemap = 1;
+    std::vector<int32_t> colStartL, colCountL, rowStartL, rowCountL, colStartC, colCountC, rowStartC, rowCountC;
+    std::vector<int32_t> lumRound, chrRound;      // per output row accumulator start values
+    FilterBank vChrEff;                           // vertical chroma filter after the 1-/2-tap special forms
+};
+
+struct YuvScaleArgs {
+    const uint8_t *y, *u, *v;
+    int ys, us, vs, nv12, srcAligned;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW;
+    uint8_t *dst;
+    int ds, dstFormat, dstAligned;
+    DevFilter hLum, hChr, vLum, vChr;             // vLum.round / vChr.round = lumRound / chrRound
+    const int32_t *colStartL, *colCountL, *rowStartL, *rowCountL, *colStartC, *colCountC, *rowStartC, *rowCountC;
+    int TH, ntx, nty, xcdRemap, fullChroma;
+    int rowsL, colsL, rowsC, colsC;
+    unsigned long long *prof;                     // optional per-block phase timestamps (tuning aid)
+    Yuv2RgbConsts y2r;
+};
+
+int  yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t);
+int  launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream);
+const char *yuvscale_kernel_name(const YuvScaleTiling &t);
+
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
 int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                      int inW, int inH, int bpp, int dir, hipStream_t stream);

@@ -178,7 +178,9 @@ int support_factor(int flags, const double param[2])
     return f;
 }
 
-void pack_pairs(FilterBank &fb)
+} // namespace
+
+void pack_filter_pairs(FilterBank &fb)
 {
     bool any_odd = false;
     for (int32_t p : fb.pos) any_odd |= (p & 1) != 0;
@@ -196,8 +198,6 @@ void pack_pairs(FilterBank &fb)
                 (int32_t)((uint32_t)(uint16_t)row[2 * k] | ((uint32_t)(uint16_t)row[2 * k + 1] << 16));
     }
 }
-
-} // namespace
 
 int build_filter(FilterBank &out, int inc, int src_len, int dst_len, int one, int flags,
                  const double param_in[2], int src_pos, int dst_pos)
@@ -320,7 +320,7 @@ int build_filter(FilterBank &out, int inc, int src_len, int dst_len, int one, in
         }
         out.pos[i] = win[i].pos;
     }
-    pack_pairs(out);
+    pack_filter_pairs(out);
     return 0;
 }
 

@@ -43,6 +43,9 @@ struct FilterBank {
     std::vector<int32_t> pos_even;  // count
 };
 
+// (re)builds packed / pos_even / pairs from coef / pos
+void pack_filter_pairs(FilterBank &fb);
+
 // returns 0 or a negative errno; flags are GMAT_SWS_*; param[] as libswscale's param[2]
 int build_filter(FilterBank &out, int inc, int src_len, int dst_len, int one, int flags,
                  const double param[2], int src_pos, int dst_pos);

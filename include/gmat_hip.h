@@ -67,10 +67,9 @@ enum GmatPixelFormat {
  *      - same size, YUV -> RGB: nearest-chroma fixed-point yuv2rgb (yuv2rgb.c:346-405), bit-exact
  *      - same size, RGB24 <-> BGR24: byte swap (rgb2rgb_template.c)
  *      - everything else: the generic scaler (swscale.c:234-520) in integer arithmetic, bit-exact
- *        with the portable C build (filterAlign 1); for a YUV source with a different output
- *        size the result equals the reference's convert-then-resize order of operations
- *        (swscale_cuda.c:352-371) with both stages in libswscale arithmetic, i.e.
- *        POINT-convert to RGB24 at source size, then RGB24 -> RGB scale.
+ *        with the portable C build (filterAlign 1); a YUV source with a different output size is
+ *        scaled exactly as one CPU libswscale context would (see gmat_sws_setFused for the
+ *        convert-then-resize alternative that mirrors the reference GPU back-end's structure).
  * ===================================================================================== */
 typedef struct GmatSwsContext GmatSwsContext;
 
@@ -87,14 +86,22 @@ GMAT_API void gmat_sws_freeContext(GmatSwsContext *c);
 /* sws_setColorspaceDetails subset (utils.c:902): colourspace index + source range for YUV->RGB */
 GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange);
 
-/* how a scaled YUV->RGB context runs: 0 = two kernels with an HBM RGB24 intermediate owned by the
- * context (the reference's structure, swscale_cuda.c:248-266,352-371), 1 = one fused kernel
- * producing bit-identical output without the intermediate.  Default 1. */
+/* how a scaled YUV->RGB context computes:
+ *   2 (default) = what ONE libswscale context does for the same arguments: luma and chroma planes are
+ *       scaled separately (swscale.c:234-520), LUT colour stage — bit-exact with sws_scale() on the CPU;
+ *   1 = the reference GPU back-end's order of operations (convert at source size, then resize in RGB,
+ *       swscale_cuda.c:352-371) in libswscale arithmetic, i.e. sws(NV12->RGB24, POINT) followed by
+ *       sws(RGB24->RGB, flags), as ONE fused kernel without the full-size RGB frame in HBM;
+ *   0 = the same arithmetic as 1 as two kernels with the HBM RGB24 intermediate owned by the context
+ *       (the reference's structure, swscale_cuda.c:248-266). */
 GMAT_API int  gmat_sws_setFused(GmatSwsContext *c, int fused);
 /* introspection used by tests and bench: which 0 hLum 1 hChr 2 vLum 3 vChr.  Copies up to `cap`
  * int16 coefficients / int32 positions to HOST buffers; returns filter size, *count = rows. */
 GMAT_API int  gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos,
                                  int cap, int *count);
+/* tuning aid: device buffer of 8 x uint64 per workgroup receiving the scaler's phase timestamps
+ * (shader clock); NULL disables.  Only the single-context YUV scaler honours it. */
+GMAT_API int  gmat_sws_setProfileBuffer(GmatSwsContext *c, uint8_t *devbuf);
 /* name of the kernel the last gmat_sws_scale() launched last (static string) */
 GMAT_API const char *gmat_sws_lastKernel(const GmatSwsContext *c);
 

@@ -78,3 +78,52 @@ def test_product_filter_tables_match_oracle(dev, orc):
             assert t == taps and cnt.value == n
             assert (coef[:n * taps].reshape(n, taps) == ocoef).all() and (pos == opos).all()
         lib.gmat_sws_freeContext(c)
+
+
+# ---- YUV sources, libswscale single-context semantics (mode 2, the default) -----------------------------
+YUV_GEOMS = [(256, 64, 128, 32), (130, 50, 64, 26), (96, 40, 144, 60), (200, 90, 100, 45), (64, 64, 18, 10),
+             (128, 48, 128, 24), (128, 48, 64, 48), (66, 34, 33, 17), (40, 30, 41, 31), (520, 36, 260, 18)]
+
+
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", YUV_GEOMS)
+def test_yuv_single_context_bicubic(dev, orc, src_fmt, geom):
+    """What ONE libswscale context nv12 -> rgb24 (different size) computes: planes scaled separately,
+    LUT colour stage with half chroma (even dstW) or full chroma (odd dstW)."""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=31)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"])[0]
+    d_src = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"], dst_align=256)
+    assert kernel.startswith("scale_yuv_kernel")
+    assert ("full" in kernel) == bool(dw & 1)
+    bad = np.argwhere(got[0] != want)
+    assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+    assert (pads[0] == 0xCD).all()
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area", "fast_bilinear"])
+@pytest.mark.parametrize("geom", [(192, 70, 96, 36), (80, 30, 120, 50), (64, 32, 128, 64)])
+def test_yuv_single_context_algorithms(dev, orc, flags, geom):
+    sw, sh, dw, dh = geom
+    if flags == "fast_bilinear":
+        pytest.skip("fast_bilinear uses the x86/C hyscale_fast path, not restated")
+    src = synth_planes(orc, "nv12", sw, sh, seed=33)
+    want = orc.sws(src, sw, sh, "nv12", dw, dh, "rgb24", SWS[flags])[0]
+    d_src = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, "rgb24", SWS[flags], dst_align=64)
+    bad = np.argwhere(got[0] != want)
+    assert bad.size == 0, f"{flags}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+
+
+@pytest.mark.parametrize("dst_fmt", ["bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("full", [0, 1])
+def test_yuv_single_context_formats_and_full_chroma_flag(dev, orc, dst_fmt, full):
+    sw, sh, dw, dh = 160, 48, 80, 24
+    flags = SWS["bicubic"] | (SWS["full_chr_h_int"] if full else 0)
+    src = synth_planes(orc, "nv12", sw, sh, seed=35)
+    want = orc.sws(src, sw, sh, "nv12", dw, dh, dst_fmt, flags)[0]
+    d_src = dev.upload_planes(src, 1, 3)                      # misaligned rows
+    got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, dst_fmt, flags, dst_align=1, dst_extra=1)
+    assert ("full" in kernel) == bool(full)
+    assert (got[0] == want).all() and (pads[0] == 0xCD).all()

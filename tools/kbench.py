@@ -44,12 +44,12 @@ def ctx(src, dw, dh, dst="rgb24", flags=SWS["bicubic"], fused=1, sw=SW, sh=SH):
     return c
 
 
-def run(label, env, src, bytes_alg):
+def run(label, env, src, bytes_alg, fused=1):
     for k in list(os.environ):
         if k.startswith("GMAT_SCALE_"): del os.environ[k]
     os.environ.update(env)
     if src == "nv12":
-        c = ctx("nv12", DW, DH)
+        c = ctx("nv12", DW, DH, fused=fused)
         f = lambda i: lib.gmat_sws_scale(c, planes([nv12[i].data_ptr(), nv12[i].data_ptr() + SW * SH]), ints([SW, SW]), 0, SH,
                                          planes([out[i].data_ptr()]), ints([5888]))
     elif src == "rgb24":
@@ -70,6 +70,11 @@ ALG_F, ALG_S, ALG_C = 18662400, 31104000, 37324800
 CONFIGS = [
     ("convert 4K nv12->rgb24", {}, "conv", ALG_C),
     ("scale rgb24 default", {}, "rgb24", ALG_S),
+    ("direct nv12 (1 sws ctx)", {}, "nv12", ALG_F, 2),
+    ("direct TH8", {"GMAT_SCALE_TH": "8"}, "nv12", ALG_F, 2),
+    ("direct TH32", {"GMAT_SCALE_TH": "32"}, "nv12", ALG_F, 2),
+    ("direct TW32", {"GMAT_SCALE_TW": "32"}, "nv12", ALG_F, 2),
+    ("direct noxcd", {"GMAT_SCALE_XCD": "0"}, "nv12", ALG_F, 2),
     ("fused nv12 default", {}, "nv12", ALG_F),
     ("fused noxcd", {"GMAT_SCALE_XCD": "0"}, "nv12", ALG_F),
     ("fused TH8", {"GMAT_SCALE_TH": "8"}, "nv12", ALG_F),
