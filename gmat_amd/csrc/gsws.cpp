@@ -97,6 +97,8 @@ struct GmatSwsContext {
     DevBuf yWin[8];
     YuvScaleArgs yargs;
     bool yuvReady = false;
+    Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
+    DevBuf dHLreg, dHCreg;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
     int fused = 2;
@@ -135,6 +137,11 @@ static int init_yuv_scaler(GmatSwsContext *c)
     a.dstW = c->dstW; a.dstH = c->dstH; a.chrDstW = c->planYuv.chrDstW;
     a.dstFormat = c->dstFormat;
     a.nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
+    if (c->y2x.ok) {
+        if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
+        if ((r = c->dHCreg.upload(c->y2x.hCreg.data(), c->y2x.hCreg.size() * 4)) < 0) return r;
+    }
     c->yuvReady = true;
     return 0;
 }
@@ -356,6 +363,27 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
             ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
             ya.prof = c->prof;
+            if (c->y2x.ok && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
+                                                  (uintptr_t)srcStride[1]) & 15) == 0) &&
+                (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 &&
+                             (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0))) {
+                Yuv2xArgs xa;
+                std::memset(&xa, 0, sizeof(xa));
+                xa.y = ya.y; xa.u = ya.u; xa.v = ya.v; xa.ys = ya.ys; xa.us = ya.us; xa.vs = ya.vs; xa.nv12 = ya.nv12;
+                xa.srcW = ya.srcW; xa.srcH = ya.srcH; xa.chrSrcW = ya.chrSrcW; xa.chrSrcH = ya.chrSrcH;
+                xa.dstW = ya.dstW; xa.dstH = ya.dstH;
+                xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
+                xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
+                xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;
+                xa.vLum = ya.vLum; xa.vChr = ya.vChr;
+                xa.rowStartL = ya.rowStartL; xa.rowCountL = ya.rowCountL;
+                xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
+                xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
+                xa.prof = ya.prof; xa.y2r = ya.y2r;
+                c->lastKernel = "scale_yuv2x_kernel";
+                r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, c->stream);
+                break;
+            }
             c->lastKernel = yuvscale_kernel_name(c->ytiling);
             r = launch_scale_yuv(ya, c->ytiling, c->stream);
             break;

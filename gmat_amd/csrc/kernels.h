@@ -106,3 +106,32 @@ int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, i
                               int inW, int inH, int bpp, hipStream_t stream);
 
 } // namespace gmat
+
+// ---- 2:1 specialisation of the YUV scaler (k_scale_yuv2x.hip) -------------------------------------
+// Every horizontal filter row is re-expressed on the regular window [2x + w0, 2x + w0 + 10) (zero taps
+// trimmed; border rows keep their folded coefficients), so the kernel needs no per-output positions:
+// 16-byte pixel loads, ds_read_b64 windows shared by 4 adjacent outputs, coefficient tables in LDS.
+namespace gmat {
+struct Yuv2xTables {
+    int ok = 0;
+    int w0L = 0, w0C = 0;                       // regular window origins (multiples of 4)
+    int ntx = 0, nty = 0;
+    std::vector<int32_t> hLreg, hCreg;          // [ntx*64][5], [ntx*32][5] packed int16 pairs
+};
+struct Yuv2xArgs {
+    const uint8_t *y, *u, *v;
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
+    uint8_t *dst;
+    int ds, dstFormat, dstAligned;
+    const int32_t *hLreg, *hCreg;
+    int w0L, w0C;
+    DevFilter vLum, vChr;
+    const int32_t *rowStartL, *rowCountL, *rowStartC, *rowCountC;
+    int ntx, nty, xcdRemap;
+    unsigned long long *prof;
+    Yuv2RgbConsts y2r;
+};
+int  yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2xTables &t);
+int  launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream);
+} // namespace gmat

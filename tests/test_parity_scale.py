@@ -95,8 +95,9 @@ def test_yuv_single_context_bicubic(dev, orc, src_fmt, geom):
     want = orc.sws(src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"])[0]
     d_src = dev.upload_planes(src, 256)
     got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"], dst_align=256)
-    assert kernel.startswith("scale_yuv_kernel")
-    assert ("full" in kernel) == bool(dw & 1)
+    assert kernel.startswith("scale_yuv")
+    if kernel.startswith("scale_yuv_kernel"):
+        assert ("full" in kernel) == bool(dw & 1)
     bad = np.argwhere(got[0] != want)
     assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
     assert (pads[0] == 0xCD).all()
@@ -125,5 +126,40 @@ def test_yuv_single_context_formats_and_full_chroma_flag(dev, orc, dst_fmt, full
     want = orc.sws(src, sw, sh, "nv12", dw, dh, dst_fmt, flags)[0]
     d_src = dev.upload_planes(src, 1, 3)                      # misaligned rows
     got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, dst_fmt, flags, dst_align=1, dst_extra=1)
-    assert ("full" in kernel) == bool(full)
+    assert kernel.startswith("scale_yuv_kernel") and ("full" in kernel) == bool(full)
     assert (got[0] == want).all() and (pads[0] == 0xCD).all()
+
+
+# ---- the 2:1 horizontal specialisation (scale_yuv2x_kernel) --------------------------------------------
+X2_GEOMS = [(256, 64, 128, 32), (512, 256, 256, 128), (64, 64, 32, 32), (1024, 96, 512, 48), (128, 60, 64, 30),
+            (192, 34, 96, 17), (2048, 32, 1024, 16)]
+
+
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", X2_GEOMS)
+def test_yuv2x_specialisation_bit_exact(dev, orc, src_fmt, geom):
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=41)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"])[0]
+    d_src = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"], dst_align=256)
+    assert kernel == "scale_yuv2x_kernel", kernel
+    bad = np.argwhere(got[0] != want)
+    assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+    assert (pads[0] == 0xCD).all()
+    # the generic kernel must give the same bytes (misaligned source rows force it)
+    d_src2 = dev.upload_planes(src, 1, 2)
+    got2, _, kernel2 = dev.sws(d_src2, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"], dst_align=256)
+    assert kernel2.startswith("scale_yuv_kernel") and (got2[0] == want).all()
+
+
+@pytest.mark.parametrize("dst_fmt", ["bgr24", "rgba", "bgra"])
+def test_yuv2x_dst_formats_and_bilinear(dev, orc, dst_fmt):
+    sw, sh, dw, dh = 256, 48, 128, 24
+    src = synth_planes(orc, "nv12", sw, sh, seed=43)
+    for flags in ("bicubic", "bilinear"):
+        want = orc.sws(src, sw, sh, "nv12", dw, dh, dst_fmt, SWS[flags])[0]
+        d_src = dev.upload_planes(src, 256)
+        got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, dst_fmt, SWS[flags], dst_align=256)
+        assert kernel == "scale_yuv2x_kernel"
+        assert (got[0] == want).all() and (pads[0] == 0xCD).all()
