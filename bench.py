@@ -44,23 +44,26 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=32, help="distinct frame pairs per step (working set)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--branches", type=int, default=2,
+                    help="parallel branches inside the captured graph (independent frames overlap)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--cpu-frames", type=int, default=48)
     return ap.parse_args()
 
 
 class Runner:
     """One implementation of the workload: a context, its frame set and (optionally) a graph."""
 
-    def __init__(self, lib, torch, stream, frames, fused, use_graph, seed):
+    def __init__(self, lib, torch, stream, frames, fused, use_graph, seed, branches=1):
         from gmat_amd.lib import PIX_FMT, SWS, planes, ints
         self.lib, self.stream, self.frames = lib, stream, frames
         self.ctx = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["nv12"], DST_W, DST_H, PIX_FMT["rgb24"],
                                            SWS["bicubic"] | SWS["hwaccel"], None)
         if not self.ctx:
             raise RuntimeError("gmat_sws_getContext failed")
-        lib.gmat_sws_setFused(self.ctx, int(fused))
+        if lib.gmat_sws_setFused(self.ctx, int(fused)) != 0:
+            raise RuntimeError('gmat_sws_setFused failed')
         lib.gmat_sws_setStream(self.ctx, stream)
         src_ls = (SRC_W + 255) // 256 * 256                 # AVHWFramesContext row alignment
         dst_ls = (DST_W * 3 + 255) // 256 * 256
@@ -82,7 +85,7 @@ class Runner:
         if use_graph:
             ge = C.c_void_p()
             r = lib.gmat_sws_graph_create(self.ctx, n, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
-                                          C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds, stream, C.byref(ge))
+                                          C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds, stream, branches, C.byref(ge))
             if r != 0:
                 raise RuntimeError(f"gmat_sws_graph_create failed: {r}")
             self.graph = ge
@@ -162,7 +165,8 @@ def time_single_kernel(lib, torch, runner_fn, stream, reps):
 
 
 def cpu_baseline(nframes):
-    """The oracle on the host cores: chained convert + bicubic scale, row-sliced over all cores."""
+    """The oracle on the host cores: ONE nv12 2160p -> rgb24 1080p bicubic context (the headline's
+    semantics), output rows sliced over all cores."""
     import numpy as np
     import harness
     from concurrent.futures import ThreadPoolExecutor
@@ -175,40 +179,28 @@ def cpu_baseline(nframes):
     cores = os.cpu_count() or 1
     y = orc.lcg((SRC_H, SRC_W), 7)
     uv = orc.lcg((SRC_H // 2, SRC_W), 8)
-    rgb = np.empty((SRC_H, SRC_W * 3), np.uint8)
     out = np.empty((DST_H, DST_W * 3), np.uint8)
-    ctx = L.orc_sws_create(SRC_W, SRC_H, PIX_FMT["rgb24"], DST_W, DST_H, PIX_FMT["rgb24"], SWS["bicubic"], None)
-    y2r = orc.y2r()
-    band_src = (SRC_H // cores + 1) & ~1
-    band_dst = DST_H // cores + 1
-
-    def conv(i):
-        y0 = i * band_src
-        hh = min(band_src, SRC_H - y0)
-        if hh <= 0:
-            return
-        L.orc_yuv2rgb_frame(y2r, planes([y.ctypes.data + y0 * SRC_W, uv.ctypes.data + (y0 // 2) * SRC_W]),
-                            ints([SRC_W, SRC_W]), rgb.ctypes.data + y0 * SRC_W * 3, SRC_W * 3, SRC_W, hh,
-                            PIX_FMT["nv12"], PIX_FMT["rgb24"])
+    ctx = L.orc_sws_create(SRC_W, SRC_H, PIX_FMT["nv12"], DST_W, DST_H, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    cores = min(cores, 64)
+    band_dst = (DST_H + cores - 1) // cores
 
     def scale(i):
         y0 = i * band_dst
         y1 = min(DST_H, y0 + band_dst)
         if y0 < y1:
-            L.orc_sws_scale_rows(ctx, planes([rgb.ctypes.data]), ints([SRC_W * 3]), planes([out.ctypes.data]),
-                                 ints([DST_W * 3]), y0, y1)
+            L.orc_sws_scale_rows(ctx, planes([y.ctypes.data, uv.ctypes.data]), ints([SRC_W, SRC_W]),
+                                 planes([out.ctypes.data]), ints([DST_W * 3]), y0, y1)
 
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(conv, range(cores))); list(ex.map(scale, range(cores)))          # warm
+        list(ex.map(scale, range(cores)))                                            # warm
         t0 = time.perf_counter()
         for _ in range(nframes):
-            list(ex.map(conv, range(cores)))
             list(ex.map(scale, range(cores)))
         dt = time.perf_counter() - t0
     L.orc_sws_free(ctx)
     return {"value": round(nframes * PX / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
-            "sample": f"{nframes} frames 3840x2160 nv12->rgb24->1920x1080 bicubic, C oracle (oracle/), "
-                      f"{cores} threads row-sliced, {dt:.2f} s"}
+            "sample": f"{nframes} frames 3840x2160 nv12 -> 1920x1080 rgb24 bicubic (one context), C oracle "
+                      f"(oracle/, a port of libswscale's arithmetic), {cores} threads row-sliced, {dt:.2f} s"}
 
 
 def main():
@@ -231,29 +223,48 @@ def main():
     lib.gmat_stream_create(C.byref(stream))
 
     use_graph = not a.no_graph
-    fused = Runner(lib, torch, stream, a.frames, True, use_graph, seed=1000 + rank)
-    wall, dev_ms = timed(lib, torch, dist, fused, stream, a.steps, a.warmup, world)
+    branches = a.branches if use_graph else 1
+    # ---- headline: one libswscale-semantics context (mode 2), frames overlapped across graph branches
+    head = Runner(lib, torch, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=branches)
+    wall, dev_ms = timed(lib, torch, dist, head, stream, a.steps, a.warmup, world)
     launches = a.steps * a.frames
     gpix = world * launches * PX / wall / 1e9
-    ach = ALG_FUSED * launches / (dev_ms * 1e-3) / 1e9
+    kname = head.kernel()
+    head.close()
+    # ---- roofline of the dominant kernel: the same context, launches strictly back to back (1 branch)
+    ser = Runner(lib, torch, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=1)
+    _, ser_ms = timed(lib, torch, None, ser, stream, a.steps, a.warmup, 1)
+    ser.close()
+    ach = ALG_FUSED * launches / (ser_ms * 1e-3) / 1e9
+    ach_ovl = ALG_FUSED * launches / (dev_ms * 1e-3) / 1e9
     out = {
         "metric": "Gpix/s (and % HBM roofline) for 4K nv12->rgb24->1080p bicubic at 1/2/4/8 GPUs",
         "value": round(gpix, 3), "unit": "Gpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "3840x2160 nv12 -> rgb24 -> 1920x1080 bicubic rgb24 (BASELINE configs[2]), "
-                               "device-resident frames, output bit-identical to the chained libswscale oracle",
-                   "frames_per_step": a.frames, "implementation": "fused single kernel " + fused.kernel(),
-                   "launch": "hipGraph replay" if use_graph else "eager", "streams_per_gpu": 1,
-                   "parallelism": f"{world} independent streams, one per GPU, no collective"},
-        "roofline": {"bound": "hbm", "kernel": fused.kernel(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        "config": {"workload": "3840x2160 nv12 -> 1920x1080 rgb24 bicubic (BASELINE configs[2]), device-resident "
+                               "frames; output bit-identical to ONE libswscale context (sws_getContext nv12 2160p -> "
+                               "rgb24 1080p, SWS_BICUBIC); the convert-then-scale ('chained') forms are in `chained`",
+                   "frames_per_step": a.frames, "implementation": "single fused kernel " + kname,
+                   "launch": (f"hipGraph replay, {branches} parallel branches" if use_graph else "eager"),
+                   "parallelism": f"{world} GPU(s) x independent streams, no collective"},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": ALG_FUSED, "avg_launch_us": round(dev_ms * 1e3 / launches, 3)},
+                     "algorithmic_bytes_per_launch": ALG_FUSED,
+                     "avg_launch_us": round(ser_ms * 1e3 / launches, 3),
+                     "note": "launches back to back on one stream (HIP events); with the graph's parallel "
+                             "branches the effective rate is achieved_overlapped",
+                     "achieved_overlapped": round(ach_ovl, 1), "frac_overlapped": round(ach_ovl / HBM_PEAK_GBS, 4)},
     }
-    fused.close()
 
     if rank == 0 and not a.no_chained:
-        ch = Runner(lib, torch, stream, a.frames, False, use_graph, seed=2000)
+        # convert-then-scale semantics (the reference GPU back-end's order of operations), two forms
+        fz = Runner(lib, torch, stream, a.frames, 1, use_graph, seed=2000, branches=branches)
+        fwall, fms = timed(lib, torch, None, fz, stream, max(3, a.steps // 3), 2, 1)
+        fn = max(3, a.steps // 3) * a.frames
+        fused_kernel = fz.kernel()
+        fz.close()
+        ch = Runner(lib, torch, stream, a.frames, 0, use_graph, seed=2000)
         cwall, cms = timed(lib, torch, None, ch, stream, max(3, a.steps // 3), 2, 1)
         n = max(3, a.steps // 3) * a.frames
         ach_c = (ALG_CONVERT + ALG_SCALE) * n / (cms * 1e-3) / 1e9
@@ -279,17 +290,22 @@ def main():
         t_conv = time_single_kernel(lib, torch, k_conv, stream, 4 * a.frames)
         t_scale = time_single_kernel(lib, torch, k_scale, stream, 4 * a.frames)
         out["chained"] = {
-            "value": round(n * PX / cwall / 1e9, 3), "unit": "Gpix/s",
-            "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
-            "algorithmic_bytes_per_frame": ALG_CONVERT + ALG_SCALE,
-            "kernels": {
-                "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
-                                   "achieved_GBps": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9, 1),
-                                   "frac": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                lib.gmat_sws_lastKernel(sc).decode(): {
-                    "avg_launch_us": round(t_scale * 1e3, 3),
-                    "achieved_GBps": round(ALG_SCALE / (t_scale * 1e-3) / 1e9, 1),
-                    "frac": round(ALG_SCALE / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
+            "semantics": "sws(NV12->RGB24, POINT) then sws(RGB24->RGB24, BICUBIC), bit-exact",
+            "fused_kernel": {"kernel": fused_kernel, "value": round(fn * PX / fwall / 1e9, 3), "unit": "Gpix/s",
+                             "achieved_GBps": round(ALG_FUSED * fn / (fms * 1e-3) / 1e9, 1),
+                             "algorithmic_bytes_per_frame": ALG_FUSED},
+            "two_kernels": {
+                "value": round(n * PX / cwall / 1e9, 3), "unit": "Gpix/s",
+                "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_frame": ALG_CONVERT + ALG_SCALE,
+                "kernels": {
+                    "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
+                                       "achieved_GBps": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9, 1),
+                                       "frac": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    lib.gmat_sws_lastKernel(sc).decode(): {
+                        "avg_launch_us": round(t_scale * 1e3, 3),
+                        "achieved_GBps": round(ALG_SCALE / (t_scale * 1e-3) / 1e9, 1),
+                        "frac": round(ALG_SCALE / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}}
         lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
         ch.close()
 

@@ -149,13 +149,17 @@ void gmat_timer_destroy(void *timer)
 // Capture one gmat_sws_scale() per frame set into a graph: the per-frame kernels are a few
 // microseconds long, so replaying a captured batch removes the per-launch host cost.
 int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *src_planes, const int srcStride[],
-                          uint8_t *const *dst_planes, const int dstStride[], void *stream, void **graph_exec)
+                          uint8_t *const *dst_planes, const int dstStride[], void *stream, int nbranches,
+                          void **graph_exec)
 {
     if (!c || nframes < 1 || !graph_exec) return GMAT_ERR(EINVAL);
     hipStream_t s = (hipStream_t)stream;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const int srcH = gmat::sws_src_height(c);
+    if (nbranches < 1) nbranches = 1;
+    if (nbranches > 8) nbranches = 8;
+    if (gmat::sws_shares_intermediate(c)) nbranches = 1;
     gmat_sws_setStream(c, stream);
     // warm launch outside capture so lazy allocations (intermediate frame) are not captured
     {
@@ -163,11 +167,38 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
         if (r < 0) return r;
         GMAT_HIP_CHECK(hipStreamSynchronize(s));
     }
+    // side streams + fork/join events for the parallel branches (only needed while capturing)
+    hipStream_t side[8] = {nullptr};
+    hipEvent_t fork = nullptr, join[8] = {nullptr};
+    for (int b = 1; b < nbranches; b++) {
+        GMAT_HIP_CHECK(hipStreamCreateWithFlags(&side[b], hipStreamNonBlocking));
+        GMAT_HIP_CHECK(hipEventCreateWithFlags(&join[b], hipEventDisableTiming));
+    }
+    if (nbranches > 1) GMAT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
     GMAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rr = 0;
-    for (int f = 0; f < nframes && rr >= 0; f++)
+    hipError_t e = hipSuccess;
+    if (nbranches > 1) {
+        e = hipEventRecord(fork, s);
+        for (int b = 1; b < nbranches && e == hipSuccess; b++) e = hipStreamWaitEvent(side[b], fork, 0);
+    }
+    for (int f = 0; f < nframes && rr >= 0 && e == hipSuccess; f++) {
+        const int b = f % nbranches;
+        gmat_sws_setStream(c, b ? (void *)side[b] : stream);
         rr = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
-    hipError_t e = hipStreamEndCapture(s, &graph);
+    }
+    gmat_sws_setStream(c, stream);
+    for (int b = 1; b < nbranches && e == hipSuccess; b++) {
+        e = hipEventRecord(join[b], side[b]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, join[b], 0);
+    }
+    hipError_t e2 = hipStreamEndCapture(s, &graph);
+    for (int b = 1; b < nbranches; b++) {
+        (void)hipStreamDestroy(side[b]);
+        (void)hipEventDestroy(join[b]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    if (e == hipSuccess) e = e2;
     if (rr < 0 || e != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
         return rr < 0 ? rr : GMAT_ERR(EIO);

@@ -199,7 +199,10 @@ static int ensure_scaler(GmatSwsContext *c)
     return init_scaler(c);
 }
 
-namespace gmat { int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; } }
+namespace gmat {
+int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; }
+bool sws_shares_intermediate(const GmatSwsContext *c) { return c && c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0; }
+}
 
 extern "C" {
 

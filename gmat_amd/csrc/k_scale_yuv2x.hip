@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     unsigned long long *prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
 #define X2_STAMP(i) do { if (prof && tid == 0) prof[i] = __builtin_readcyclecounter(); } while (0)
     X2_STAMP(0);
+    if (prof && tid == 0) prof[6] = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference clock
     const int tx0 = tcol * X2_TW, ty0 = trow * X2_TH, tcx0 = tx0 >> 1;
     const int r0L = a.rowStartL[trow], nrL = a.rowCountL[trow];
     const int r0C = a.rowStartC[trow], nrC = a.rowCountC[trow];
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
         }
     }
     X2_STAMP(5);
+    if (prof && tid == 0) prof[7] = __builtin_amdgcn_s_memrealtime();
 #undef X2_STAMP
 }
 

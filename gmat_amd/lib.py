@@ -97,7 +97,7 @@ _SIGS = {
     "gmat_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "gmat_timer_destroy": (None, [C.c_void_p]),
     "gmat_sws_graph_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
-                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_void_p)]),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gmat_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gmat_graph_destroy": (None, [C.c_void_p]),
 }

@@ -224,12 +224,15 @@ GMAT_API int  gmat_timer_begin(void *timer, void *stream);
 GMAT_API int  gmat_timer_end(void *timer, void *stream);
 GMAT_API int  gmat_timer_elapsed_ms(void *timer, float *ms);   /* synchronises on the end event */
 GMAT_API void gmat_timer_destroy(void *timer);
-/* capture `iters` repetitions of gmat_sws_scale over `nframes` rotating frame sets into a
- * hipGraph and launch it `launches` times (launch-bound inner loop -> graph replay) */
+/* capture one gmat_sws_scale() per frame set (nframes independent frames) into a hipGraph: the
+ * per-frame kernels are a few microseconds long, so replaying a captured batch removes the per-launch
+ * host cost.  `nbranches` > 1 forks the capture into that many parallel branches (frame f runs on
+ * branch f % nbranches), so the tail of one frame's kernel overlaps the head of the next — frames are
+ * independent.  The two-kernel form (setFused 0) shares one intermediate and is forced to 1 branch. */
 GMAT_API int  gmat_sws_graph_create(GmatSwsContext *c, int nframes,
                                     const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
                                     uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
-                                    void *stream, void **graph_exec);
+                                    void *stream, int nbranches, void **graph_exec);
 GMAT_API int  gmat_graph_launch(void *graph_exec, void *stream);
 GMAT_API void gmat_graph_destroy(void *graph_exec);
 

@@ -78,6 +78,7 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
 static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 
@@ -107,6 +108,9 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t *e);
+enum { hipEventDisableTiming = 2 };
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
