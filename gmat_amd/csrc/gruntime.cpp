@@ -210,6 +210,22 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
     return 0;
 }
 
+int gmat_sws_scale_batch(GmatSwsContext *c, int nframes, const uint8_t *const *src_planes, const int srcStride[],
+                         uint8_t *const *dst_planes, const int dstStride[], void *const *streams, int nstreams)
+{
+    if (!c || nframes < 0 || !streams || nstreams < 1) return GMAT_ERR(EINVAL);
+    const int srcH = gmat::sws_src_height(c);
+    if (gmat::sws_shares_intermediate(c)) nstreams = 1;
+    void *saved = gmat::sws_current_stream(c);
+    int r = 0;
+    for (int f = 0; f < nframes && r >= 0; f++) {
+        gmat_sws_setStream(c, streams[f % nstreams]);
+        r = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
+    }
+    gmat_sws_setStream(c, saved);
+    return r < 0 ? r : nframes;
+}
+
 int gmat_graph_launch(void *graph_exec, void *stream)
 {
     GMAT_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));

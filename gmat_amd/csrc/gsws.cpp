@@ -98,7 +98,7 @@ struct GmatSwsContext {
     YuvScaleArgs yargs;
     bool yuvReady = false;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
-    DevBuf dHLreg, dHCreg;
+    DevBuf dHLreg, dHCreg, dVrec;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
     int fused = 2;
@@ -141,6 +141,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
         if ((r = c->dHCreg.upload(c->y2x.hCreg.data(), c->y2x.hCreg.size() * 4)) < 0) return r;
+        if ((r = c->dVrec.upload(c->y2x.vrec.data(), c->y2x.vrec.size() * 4)) < 0) return r;
     }
     c->yuvReady = true;
     return 0;
@@ -201,6 +202,7 @@ static int ensure_scaler(GmatSwsContext *c)
 
 namespace gmat {
 int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; }
+void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream : nullptr; }
 bool sws_shares_intermediate(const GmatSwsContext *c) { return c && c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0; }
 }
 
@@ -378,7 +380,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
                 xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
                 xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;
-                xa.vLum = ya.vLum; xa.vChr = ya.vChr;
+                xa.vrec = (const int32_t *)c->dVrec.p; xa.vLpairs = c->y2x.vLpairs; xa.vCpairs = c->y2x.vCpairs;
                 xa.rowStartL = ya.rowStartL; xa.rowCountL = ya.rowCountL;
                 xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
                 xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;

@@ -22,11 +22,13 @@ constexpr int X2_COLSL = 160, X2_COLSC = 80;           // LDS row lengths (int16
 
 __device__ __forceinline__ unsigned x2pk(int lo, int hi) { return ((unsigned)lo & 0xFFFF) | ((unsigned)hi << 16); }
 
-// expands 4 bytes to two dwords of int16 pairs
+// expands 4 bytes to two dwords of int16 pairs: two v_perm_b32 (selector 0x0C = constant zero byte)
 __device__ __forceinline__ uint2 x2_widen(unsigned v)
 {
-    return make_uint2((v & 0xFF) | ((v & 0xFF00) << 8), ((v >> 16) & 0xFF) | ((v >> 24) << 16));
+    return make_uint2(__builtin_amdgcn_perm(0u, v, 0x0C010C00u), __builtin_amdgcn_perm(0u, v, 0x0C030C02u));
 }
+
+typedef short x2_short2 __attribute__((ext_vector_type(2)));
 
 // 4 adjacent outputs x 2 rows from one regular window: w0/w1 hold 8 dwords of row 0 / row 1,
 // c[j*5 + k] the k-th coefficient pair of output j.  Returns 4 dwords (row0 | row1 << 16).
@@ -41,7 +43,10 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[8], const int (&w1)
             s0 = dot2(w0[j + k], c[j * X2_P + k], s0);
             s1 = dot2(w1[j + k], c[j * X2_P + k], s1);
         }
-        o[j] = x2pk(min(s0 >> 7, 32767), min(s1 >> 7, 32767));
+        // hScale8To15_c stores min(val >> 7, 32767) into an int16.  v_cvt_pk_i16_i32 saturates both ways and
+        // packs in one instruction; the lower bound cannot trigger (255 * sum of negative taps >> 7 > -32768
+        // for every kernel initFilter can emit with one == 16384).
+        o[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pk_i16(s0 >> 7, s1 >> 7));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -81,75 +86,61 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     int *hv = hu + (rowsC >> 1) * (X2_TW / 2);
     int *cL = hv + (rowsC >> 1) * (X2_TW / 2);                   // [64][5]
     int *cC = cL + X2_TW * X2_P;                                 // [32][5]
+    int *vr = cC + (X2_TW / 2) * X2_P;                           // [16][12] vertical records of the tile's rows
 
-    // ---- prologue: vertical coefficients of this thread's output row (phase 3), issued first ----
     constexpr int QW = X2_TW / 4;
-    const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one item each
-    const int yo = ty0 + yl, yoc = min(yo, a.dstH - 1);
-    int vl[X2_P], vc0, vc1;
-#pragma unroll
-    for (int k = 0; k < X2_P; k++) vl[k] = k < a.vLum.pairs ? a.vLum.packed[(size_t)yoc * a.vLum.pairs + k] : 0;
-    vc0 = a.vChr.packed[(size_t)yoc * a.vChr.pairs];
-    vc1 = a.vChr.pairs > 1 ? a.vChr.packed[(size_t)yoc * a.vChr.pairs + 1] : 0;
-    const int vpL = (a.vLum.pos_even[yoc] - r0L) >> 1, vpC = (a.vChr.pos_even[yoc] - r0C) >> 1;
-    const int lr = a.vLum.round[yoc], cr = a.vChr.round[yoc];
+    const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one phase-3 item each
+    const int yo = ty0 + yl;
 
     // ================= phase 1: 16-byte loads, whole rows per wave ===============================
     {
         // tile coefficient rows -> LDS (80 + 40 lanes x 16 B)
         if (tid < 80)       reinterpret_cast<uint4 *>(cL)[tid] = reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * X2_P)[tid];
         else if (tid < 120) reinterpret_cast<uint4 *>(cC)[tid - 80] = reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * X2_P)[tid - 80];
+        else if (tid < 168) reinterpret_cast<uint4 *>(vr)[tid - 120] = reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * 12)[tid - 120];
 
-        const int rs = lane / 10, g = lane - rs * 10;            // 6 rows x 10 groups per wave (lanes 60..63 idle)
+        const int rs = (lane * 205) >> 11, g = lane - rs * 10;   // lane / 10 for lane < 64: 6 rows x 10 groups per wave
         const bool act = lane < 60;
-        // luma: up to two passes in flight
-        {
-            const int col = min(max(c0L + 16 * g, 0), a.srcW - 16);
-            const uint8_t *base = a.y + col;
-            for (int rb = 0; rb < nrL; rb += 48) {
-                const int ra = rb + wave * 6 + rs, rb2 = ra + 24;
-                uint4 va = make_uint4(0, 0, 0, 0), vb = va;
-                if (act && ra < nrL)  va = *reinterpret_cast<const uint4 *>(base + (size_t)min(max(r0L + ra, 0), a.srcH - 1) * a.ys);
-                if (act && rb2 < nrL) vb = *reinterpret_cast<const uint4 *>(base + (size_t)min(max(r0L + rb2, 0), a.srcH - 1) * a.ys);
-                if (act && ra < nrL) {
-                    uint4 *d = reinterpret_cast<uint4 *>(ly + ra * X2_COLSL + 16 * g);
-                    const uint2 p0 = x2_widen(va.x), p1 = x2_widen(va.y), p2 = x2_widen(va.z), p3 = x2_widen(va.w);
-                    d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-                    d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
-                }
-                if (act && rb2 < nrL) {
-                    uint4 *d = reinterpret_cast<uint4 *>(ly + rb2 * X2_COLSL + 16 * g);
-                    const uint2 p0 = x2_widen(vb.x), p1 = x2_widen(vb.y), p2 = x2_widen(vb.z), p3 = x2_widen(vb.w);
-                    d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-                    d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
-                }
-            }
+        const int rowA = wave * 6 + rs, rowB = rowA + 24;        // nrL <= 48, nrC <= 24 (yuv2x_prepare)
+        // all three pixel loads are issued before anything is consumed; rows are clamped for the load and
+        // only the store is predicated
+        const unsigned colL = (unsigned)min(max(c0L + 16 * g, 0), a.srcW - 16);
+        const unsigned colC = (unsigned)min(max(c0C + 8 * g, 0), a.chrSrcW - 8);
+        const unsigned offA = (unsigned)min(max(r0L + min(rowA, nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
+        const unsigned offB = (unsigned)min(max(r0L + min(rowB, nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
+        const unsigned crow = (unsigned)min(max(r0C + min(rowA, nrC - 1), 0), a.chrSrcH - 1);
+        const uint4 va = *reinterpret_cast<const uint4 *>(a.y + offA);
+        const uint4 vb = *reinterpret_cast<const uint4 *>(a.y + offB);
+        uint4 tc;
+        if (a.nv12) {
+            tc = *reinterpret_cast<const uint4 *>(a.u + crow * (unsigned)a.us + 2 * colC);       // U0 V0 U1 V1 ...
+        } else {
+            const uint2 tu = *reinterpret_cast<const uint2 *>(a.u + crow * (unsigned)a.us + colC);
+            const uint2 tv = *reinterpret_cast<const uint2 *>(a.v + crow * (unsigned)a.vs + colC);
+            // interleave to the NV12 byte order so the rest is common
+            tc.x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); tc.y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
+            tc.z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); tc.w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
         }
-        // chroma: 8 samples of each plane per lane
-        {
-            const int cc = min(max(c0C + 8 * g, 0), a.chrSrcW - 8);
-            for (int rb = 0; rb < nrC; rb += 24) {
-                const int r = rb + wave * 6 + rs;
-                if (act && r < nrC) {
-                    const size_t crow = (size_t)min(max(r0C + r, 0), a.chrSrcH - 1);
-                    unsigned u01, u23, u45, u67, v01, v23, v45, v67;
-                    if (a.nv12) {
-                        const uint4 t = *reinterpret_cast<const uint4 *>(a.u + crow * a.us + 2 * cc);   // U0 V0 U1 V1 ...
-                        u01 = (t.x & 0xFF) | (t.x & 0xFF0000);  v01 = ((t.x >> 8) & 0xFF) | ((t.x >> 8) & 0xFF0000);
-                        u23 = (t.y & 0xFF) | (t.y & 0xFF0000);  v23 = ((t.y >> 8) & 0xFF) | ((t.y >> 8) & 0xFF0000);
-                        u45 = (t.z & 0xFF) | (t.z & 0xFF0000);  v45 = ((t.z >> 8) & 0xFF) | ((t.z >> 8) & 0xFF0000);
-                        u67 = (t.w & 0xFF) | (t.w & 0xFF0000);  v67 = ((t.w >> 8) & 0xFF) | ((t.w >> 8) & 0xFF0000);
-                    } else {
-                        const uint2 tu = *reinterpret_cast<const uint2 *>(a.u + crow * a.us + cc);
-                        const uint2 tv = *reinterpret_cast<const uint2 *>(a.v + crow * a.vs + cc);
-                        const uint2 a0 = x2_widen(tu.x), a1 = x2_widen(tu.y), b0 = x2_widen(tv.x), b1 = x2_widen(tv.y);
-                        u01 = a0.x; u23 = a0.y; u45 = a1.x; u67 = a1.y;
-                        v01 = b0.x; v23 = b0.y; v45 = b1.x; v67 = b1.y;
-                    }
-                    *reinterpret_cast<uint4 *>(lu + r * X2_COLSC + 8 * g) = make_uint4(u01, u23, u45, u67);
-                    *reinterpret_cast<uint4 *>(lv + r * X2_COLSC + 8 * g) = make_uint4(v01, v23, v45, v67);
-                }
-            }
+        if (act && rowA < nrL) {
+            uint4 *d = reinterpret_cast<uint4 *>(ly + rowA * X2_COLSL + 16 * g);
+            const uint2 p0 = x2_widen(va.x), p1 = x2_widen(va.y), p2 = x2_widen(va.z), p3 = x2_widen(va.w);
+            d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+            d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+        }
+        if (act && rowB < nrL) {
+            uint4 *d = reinterpret_cast<uint4 *>(ly + rowB * X2_COLSL + 16 * g);
+            const uint2 p0 = x2_widen(vb.x), p1 = x2_widen(vb.y), p2 = x2_widen(vb.z), p3 = x2_widen(vb.w);
+            d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+            d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+        }
+        if (act && rowA < nrC) {
+            // U samples are bytes 0 and 2 of each dword, V samples bytes 1 and 3
+            *reinterpret_cast<uint4 *>(lu + rowA * X2_COLSC + 8 * g) =
+                make_uint4(__builtin_amdgcn_perm(0u, tc.x, 0x0C020C00u), __builtin_amdgcn_perm(0u, tc.y, 0x0C020C00u),
+                           __builtin_amdgcn_perm(0u, tc.z, 0x0C020C00u), __builtin_amdgcn_perm(0u, tc.w, 0x0C020C00u));
+            *reinterpret_cast<uint4 *>(lv + rowA * X2_COLSC + 8 * g) =
+                make_uint4(__builtin_amdgcn_perm(0u, tc.x, 0x0C030C01u), __builtin_amdgcn_perm(0u, tc.y, 0x0C030C01u),
+                           __builtin_amdgcn_perm(0u, tc.z, 0x0C030C01u), __builtin_amdgcn_perm(0u, tc.w, 0x0C030C01u));
         }
     }
     X2_STAMP(1);
@@ -173,12 +164,13 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
                 rp = jj >> 3; g = jj & 7;
                 srcp = pl ? lv : lu; colsS = X2_COLSC; e = eC; cf = cC; dstp = (pl ? hv : hu) + rp * (X2_TW / 2) + 4 * g;
             }
-            const int *r0p = reinterpret_cast<const int *>(srcp + (2 * rp) * colsS) + 4 * g + e;
-            const int *r1p = reinterpret_cast<const int *>(srcp + (2 * rp + 1) * colsS) + 4 * g + e;
+            const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
+            const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
+            const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
             int w0[8], w1[8], c[20];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint2 t0 = reinterpret_cast<const uint2 *>(r0p)[i], t1 = reinterpret_cast<const uint2 *>(r1p)[i];
+                const uint2 t0 = r0p[pair0 + i], t1 = r1p[pair0 + i];
                 w0[2 * i] = (int)t0.x; w0[2 * i + 1] = (int)t0.y; w1[2 * i] = (int)t1.x; w1[2 * i + 1] = (int)t1.y;
             }
 #pragma unroll
@@ -197,10 +189,16 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     {
         const int xo = tx0 + 4 * q;
         if (yo < a.dstH && xo < a.dstW) {
+            // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
+            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * 12)[0], rb = reinterpret_cast<const int4 *>(vr + yl * 12)[1],
+                       rc = reinterpret_cast<const int4 *>(vr + yl * 12)[2];
+            const int vl[X2_P] = {ra.x, ra.y, ra.z, ra.w, rb.x};
+            const int vc0 = rb.y, vc1 = rb.z;
+            const int vpL = (rb.w - r0L) >> 1, vpC = (rc.x - r0C) >> 1, lr = rc.y, cr = rc.z;
             int Y[4] = {lr, lr, lr, lr}, U[2] = {cr, cr}, V[2] = {cr, cr};
 #pragma unroll
             for (int k = 0; k < X2_P; k++) {
-                if (k < a.vLum.pairs) {
+                if (k < a.vLpairs) {
                     const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
                     Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
                     Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
@@ -212,46 +210,57 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
                 U[0] = dot2((int)u.x, vc0, U[0]); U[1] = dot2((int)u.y, vc0, U[1]);
                 V[0] = dot2((int)v.x, vc0, V[0]); V[1] = dot2((int)v.y, vc0, V[1]);
             }
-            if (a.vChr.pairs > 1) {
+            if (a.vCpairs > 1) {
                 const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + 1) * (X2_TW / 2) + 2 * q);
                 const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + 1) * (X2_TW / 2) + 2 * q);
                 U[0] = dot2((int)u.x, vc1, U[0]); U[1] = dot2((int)u.y, vc1, U[1]);
                 V[0] = dot2((int)v.x, vc1, V[0]); V[1] = dot2((int)v.y, vc1, V[1]);
             }
-            const ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
-            const ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
-            unsigned px[4];
+            ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
+            ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
+            const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+            if (a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA) {
+                int t = t0.r; t0.r = t0.b; t0.b = t;
+                t = t1.r; t1.r = t1.b; t1.b = t;
+            }
+            // channel value = byte 2 of clamp(term + Y*cy, 0, 0xFFFFFF); bytes are gathered with v_perm_b32
+            unsigned c0[4], c1[4], c2[4];                 // first / second / third channel of the 4 pixels
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
-                px[i]     = (unsigned)luma_chan(t0.r, ya) | ((unsigned)luma_chan(t0.g, ya) << 8) | ((unsigned)luma_chan(t0.b, ya) << 16);
-                px[i + 2] = (unsigned)luma_chan(t1.r, yb) | ((unsigned)luma_chan(t1.g, yb) << 8) | ((unsigned)luma_chan(t1.b, yb) << 16);
+                c0[i] = (unsigned)min(max(t0.r + ya, 0), 0xFFFFFF); c1[i] = (unsigned)min(max(t0.g + ya, 0), 0xFFFFFF);
+                c2[i] = (unsigned)min(max(t0.b + ya, 0), 0xFFFFFF);
+                c0[i + 2] = (unsigned)min(max(t1.r + yb, 0), 0xFFFFFF); c1[i + 2] = (unsigned)min(max(t1.g + yb, 0), 0xFFFFFF);
+                c2[i + 2] = (unsigned)min(max(t1.b + yb, 0), 0xFFFFFF);
             }
-            const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
-            if (a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) px[i] = ((px[i] & 0xFF) << 16) | (px[i] & 0xFF00) | ((px[i] >> 16) & 0xFF);
-            }
+            // perm(hi, lo, sel): byte2(lo) -> byte 0, byte2(hi) -> byte 1, upper half zero
+#define X2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
             uint8_t *d = a.dst + (size_t)yo * a.ds + (size_t)xo * bpp;
             const int nx = min(4, a.dstW - xo);
             if (a.dstAligned && nx == 4) {
                 if (bpp == 4) {
-                    *reinterpret_cast<uint4 *>(d) = make_uint4(px[0] | 0xFF000000u, px[1] | 0xFF000000u, px[2] | 0xFF000000u, px[3] | 0xFF000000u);
+                    uint4 o4;
+                    o4.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                    o4.y = X2_B2PAIR(c0[1], c1[1]) | (X2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                    o4.z = X2_B2PAIR(c0[2], c1[2]) | (X2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                    o4.w = X2_B2PAIR(c0[3], c1[3]) | (X2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d) = o4;
                 } else {
-                    uint3 o3;
-                    o3.x = (px[0] & 0xFFFFFF) | (px[1] << 24);
-                    o3.y = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
-                    o3.z = ((px[2] >> 16) & 0xFF) | (px[3] << 8);
+                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    o3.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], c0[1]) << 16);
+                    o3.y = X2_B2PAIR(c1[1], c2[1]) | (X2_B2PAIR(c0[2], c1[2]) << 16);
+                    o3.z = X2_B2PAIR(c2[2], c0[3]) | (X2_B2PAIR(c1[3], c2[3]) << 16);
                     *reinterpret_cast<uint3 *>(d) = o3;
                 }
             } else {
                 for (int i = 0; i < nx; i++) {
-                    d[i * bpp + 0] = (uint8_t)px[i];
-                    d[i * bpp + 1] = (uint8_t)(px[i] >> 8);
-                    d[i * bpp + 2] = (uint8_t)(px[i] >> 16);
+                    d[i * bpp + 0] = (uint8_t)(c0[i] >> 16);
+                    d[i * bpp + 1] = (uint8_t)(c1[i] >> 16);
+                    d[i * bpp + 2] = (uint8_t)(c2[i] >> 16);
                     if (bpp == 4) d[i * bpp + 3] = 255;
                 }
             }
+#undef X2_B2PAIR
         }
     }
     X2_STAMP(5);
@@ -312,8 +321,20 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         if ((wc - (wc & ~7)) + 2 * (X2_TW / 2 - 1) + 2 * X2_P > X2_COLSC) return 0;
     }
     const int bytes = g.rowsL * X2_COLSL * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
-                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * X2_P * 4;
+                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * X2_P * 4 + X2_TH * 12 * 4;
     if (bytes > 64 * 1024) return 0;
+    if (g.rowsL > 48 || g.rowsC > 24) return 0;               // phase 1 covers 48 luma / 24 chroma rows per tile
+    // per-output-row records for phase 3 (rows past dstH repeat the last one; never stored)
+    t.vrec.assign((size_t)t.nty * X2_TH * 12, 0);
+    for (int yy = 0; yy < t.nty * X2_TH; yy++) {
+        const int y = std::min(yy, p.dstH - 1);
+        int32_t *r = &t.vrec[(size_t)yy * 12];
+        for (int k = 0; k < p.vLum.pairs; k++) r[k] = p.vLum.packed[(size_t)y * p.vLum.pairs + k];
+        for (int k = 0; k < g.vChrEff.pairs; k++) r[5 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
+        r[7] = p.vLum.pos_even[y]; r[8] = g.vChrEff.pos_even[y];
+        r[9] = g.lumRound[y]; r[10] = g.chrRound[y];
+    }
+    t.vLpairs = p.vLum.pairs; t.vCpairs = g.vChrEff.pairs;
     t.ok = bytes;
     return 0;
 }

@@ -117,6 +117,8 @@ struct Yuv2xTables {
     int w0L = 0, w0C = 0;                       // regular window origins (multiples of 4)
     int ntx = 0, nty = 0;
     std::vector<int32_t> hLreg, hCreg;          // [ntx*64][5], [ntx*32][5] packed int16 pairs
+    std::vector<int32_t> vrec;                  // [nty*16][12] per-output-row vertical record
+    int vLpairs = 0, vCpairs = 0;
 };
 struct Yuv2xArgs {
     const uint8_t *y, *u, *v;
@@ -124,9 +126,8 @@ struct Yuv2xArgs {
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
     uint8_t *dst;
     int ds, dstFormat, dstAligned;
-    const int32_t *hLreg, *hCreg;
-    int w0L, w0C;
-    DevFilter vLum, vChr;
+    const int32_t *hLreg, *hCreg, *vrec;
+    int w0L, w0C, vLpairs, vCpairs;
     const int32_t *rowStartL, *rowCountL, *rowStartC, *rowCountC;
     int ntx, nty, xcdRemap;
     unsigned long long *prof;

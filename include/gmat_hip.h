@@ -233,6 +233,12 @@ GMAT_API int  gmat_sws_graph_create(GmatSwsContext *c, int nframes,
                                     const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
                                     uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
                                     void *stream, int nbranches, void **graph_exec);
+/* enqueue nframes independent frames in one call, frame f on streams[f % nstreams] (the context's own
+ * stream is restored afterwards).  The two-kernel form uses streams[0] only. */
+GMAT_API int  gmat_sws_scale_batch(GmatSwsContext *c, int nframes,
+                                   const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
+                                   uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
+                                   void *const *streams, int nstreams);
 GMAT_API int  gmat_graph_launch(void *graph_exec, void *stream);
 GMAT_API void gmat_graph_destroy(void *graph_exec);
 
