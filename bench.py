@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=32, help="distinct frame pairs per step (working set)")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a captured hipGraph per step instead of submitting the batch eagerly from C")
     ap.add_argument("--branches", type=int, default=2,
-                    help="parallel branches inside the captured graph (independent frames overlap)")
+                    help="concurrent HIP streams (or graph branches) the independent frames of a step are spread over")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
     ap.add_argument("--cpu-frames", type=int, default=48)
@@ -82,6 +83,13 @@ class Runner:
             self.dp[4 * i] = self.dst[i].data_ptr()
         self.ss, self.ds = ints([src_ls, src_ls]), ints([dst_ls])
         self.graph = None
+        self.branches = branches
+        self.streams = (C.c_void_p * max(1, branches))()
+        self.streams[0] = stream
+        for b in range(1, branches):
+            h = C.c_void_p()
+            lib.gmat_stream_create(C.byref(h))
+            self.streams[b] = h
         if use_graph:
             ge = C.c_void_p()
             r = lib.gmat_sws_graph_create(self.ctx, n, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
@@ -91,21 +99,19 @@ class Runner:
             self.graph = ge
         self._planes = planes
 
-    def step(self):
+    def step(self, flags=0):
         lib = self.lib
         if self.graph:
             r = lib.gmat_graph_launch(self.graph, self.stream)
             if r != 0:
                 raise RuntimeError(f"graph launch failed: {r}")
             return
-        sp = C.cast(self.sp, C.POINTER(C.c_void_p))
-        dp = C.cast(self.dp, C.POINTER(C.c_void_p))
-        for i in range(self.frames):
-            r = lib.gmat_sws_scale(self.ctx, C.cast(C.byref(self.sp, 4 * i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p)),
-                                   self.ss, 0, SRC_H,
-                                   C.cast(C.byref(self.dp, 4 * i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p)), self.ds)
-            if r < 0:
-                raise RuntimeError(f"gmat_sws_scale failed: {r}")
+        # one C call enqueues the whole batch, frame f on stream f % branches (fork/join on streams[0])
+        r = lib.gmat_sws_scale_batch(self.ctx, self.frames, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
+                                     C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds,
+                                     C.cast(self.streams, C.POINTER(C.c_void_p)), self.branches, flags)
+        if r != self.frames:
+            raise RuntimeError(f"gmat_sws_scale_batch failed: {r}")
 
     def kernel(self):
         return self.lib.gmat_sws_lastKernel(self.ctx).decode()
@@ -113,6 +119,9 @@ class Runner:
     def close(self):
         if self.graph:
             self.lib.gmat_graph_destroy(self.graph)
+        self.lib.gmat_device_sync()
+        for b in range(1, self.branches):
+            self.lib.gmat_stream_destroy(self.streams[b])
         self.lib.gmat_sws_freeContext(self.ctx)
 
 
@@ -121,7 +130,7 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     (wall seconds MAX over ranks, device milliseconds from HIP events on the launch stream)."""
     for _ in range(warmup):
         runner.step()
-    lib.gmat_stream_sync(stream)
+    lib.gmat_device_sync()
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
     if world > 1:
@@ -129,8 +138,9 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     lib.gmat_timer_begin(timer, stream)
-    for _ in range(steps):
-        runner.step()
+    for i in range(steps):
+        # FORK (1): the side streams start after the begin event; JOIN (2): the end event covers them
+        runner.step((1 if i == 0 else 0) | (2 if i == steps - 1 else 0))
     lib.gmat_timer_end(timer, stream)
     lib.gmat_stream_sync(stream)
     torch.cuda.synchronize()
@@ -222,8 +232,8 @@ def main():
     stream = C.c_void_p()
     lib.gmat_stream_create(C.byref(stream))
 
-    use_graph = not a.no_graph
-    branches = a.branches if use_graph else 1
+    use_graph = a.graph
+    branches = a.branches
     # ---- headline: one libswscale-semantics context (mode 2), frames overlapped across graph branches
     head = Runner(lib, torch, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=branches)
     wall, dev_ms = timed(lib, torch, dist, head, stream, a.steps, a.warmup, world)
@@ -246,7 +256,8 @@ def main():
                                "frames; output bit-identical to ONE libswscale context (sws_getContext nv12 2160p -> "
                                "rgb24 1080p, SWS_BICUBIC); the convert-then-scale ('chained') forms are in `chained`",
                    "frames_per_step": a.frames, "implementation": "single fused kernel " + kname,
-                   "launch": (f"hipGraph replay, {branches} parallel branches" if use_graph else "eager"),
+                   "launch": (f"hipGraph replay, {branches} parallel branches" if use_graph else
+                              f"eager, one C call per step, frames spread over {branches} HIP streams"),
                    "parallelism": f"{world} GPU(s) x independent streams, no collective"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -264,7 +275,7 @@ def main():
         fn = max(3, a.steps // 3) * a.frames
         fused_kernel = fz.kernel()
         fz.close()
-        ch = Runner(lib, torch, stream, a.frames, 0, use_graph, seed=2000)
+        ch = Runner(lib, torch, stream, a.frames, 0, use_graph, seed=2000, branches=1)
         cwall, cms = timed(lib, torch, None, ch, stream, max(3, a.steps // 3), 2, 1)
         n = max(3, a.steps // 3) * a.frames
         ach_c = (ALG_CONVERT + ALG_SCALE) * n / (cms * 1e-3) / 1e9

@@ -42,7 +42,8 @@ inline int  bytes_per_pixel(int f)
 // internal accessor (gsws.cpp) used by the graph-capture helper
 int sws_src_height(const GmatSwsContext *c);
 bool sws_shares_intermediate(const GmatSwsContext *c);
-void *sws_current_stream(const GmatSwsContext *c);   // two-kernel form: frames must not overlap
+void *sws_current_stream(const GmatSwsContext *c);
+hipEvent_t *sws_batch_events(GmatSwsContext *c);           // 9 lazily created events owned by the context   // two-kernel form: frames must not overlap
 
 inline int ceil_rshift(int a, int b) { return -((-a) >> b); }
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }

@@ -211,18 +211,33 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
 }
 
 int gmat_sws_scale_batch(GmatSwsContext *c, int nframes, const uint8_t *const *src_planes, const int srcStride[],
-                         uint8_t *const *dst_planes, const int dstStride[], void *const *streams, int nstreams)
+                         uint8_t *const *dst_planes, const int dstStride[], void *const *streams, int nstreams, int flags)
 {
     if (!c || nframes < 0 || !streams || nstreams < 1) return GMAT_ERR(EINVAL);
     const int srcH = gmat::sws_src_height(c);
     if (gmat::sws_shares_intermediate(c)) nstreams = 1;
+    if (nstreams > 8) nstreams = 8;
     void *saved = gmat::sws_current_stream(c);
+    // fork from streams[0] and join back into it, so that anything ordered on streams[0] (events, later
+    // work) is ordered against the whole batch
+    const bool fork = (flags & GMAT_BATCH_FORK) && nstreams > 1, join = (flags & GMAT_BATCH_JOIN) && nstreams > 1;
+    hipEvent_t *ev = (fork || join) ? gmat::sws_batch_events(c) : nullptr;   // [0] fork, [1..8] joins
+    if (fork) {
+        if (!ev) return GMAT_ERR(ENOMEM);
+        GMAT_HIP_CHECK(hipEventRecord(ev[0], (hipStream_t)streams[0]));
+        for (int s = 1; s < nstreams; s++) GMAT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)streams[s], ev[0], 0));
+    }
     int r = 0;
     for (int f = 0; f < nframes && r >= 0; f++) {
         gmat_sws_setStream(c, streams[f % nstreams]);
         r = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
     }
     gmat_sws_setStream(c, saved);
+    if ((fork || join) && !ev) return GMAT_ERR(ENOMEM);
+    for (int s = 1; join && s < nstreams; s++) {
+        GMAT_HIP_CHECK(hipEventRecord(ev[s], (hipStream_t)streams[s]));
+        GMAT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)streams[0], ev[s], 0));
+    }
     return r < 0 ? r : nframes;
 }
 

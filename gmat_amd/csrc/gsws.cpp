@@ -106,7 +106,13 @@ struct GmatSwsContext {
     int interStride = 0;
     const char *lastKernel = "";
     unsigned long long *prof = nullptr;
-    ~GmatSwsContext() { if (inter) (void)hipFree(inter); }
+    hipEvent_t batchEv[9] = {nullptr};
+    bool batchEvReady = false;
+    ~GmatSwsContext()
+    {
+        if (inter) (void)hipFree(inter);
+        if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
+    }
 };
 
 static int init_yuv_scaler(GmatSwsContext *c)
@@ -202,6 +208,16 @@ static int ensure_scaler(GmatSwsContext *c)
 
 namespace gmat {
 int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; }
+hipEvent_t *sws_batch_events(GmatSwsContext *c)
+{
+    if (!c) return nullptr;
+    if (!c->batchEvReady) {
+        for (hipEvent_t &e : c->batchEv)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->batchEvReady = true;
+    }
+    return c->batchEv;
+}
 void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream : nullptr; }
 bool sws_shares_intermediate(const GmatSwsContext *c) { return c && c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0; }
 }

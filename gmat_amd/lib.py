@@ -99,7 +99,7 @@ _SIGS = {
     "gmat_sws_graph_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gmat_sws_scale_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
-                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int]),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "gmat_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gmat_graph_destroy": (None, [C.c_void_p]),
 }

@@ -234,11 +234,16 @@ GMAT_API int  gmat_sws_graph_create(GmatSwsContext *c, int nframes,
                                     uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
                                     void *stream, int nbranches, void **graph_exec);
 /* enqueue nframes independent frames in one call, frame f on streams[f % nstreams] (the context's own
- * stream is restored afterwards).  The two-kernel form uses streams[0] only. */
+ * stream is restored afterwards).  The two-kernel form uses streams[0] only.
+ * flags: GMAT_BATCH_FORK makes streams[1..] wait for the work already queued on streams[0];
+ *        GMAT_BATCH_JOIN makes streams[0] wait for the batch on every other stream, so an event recorded
+ *        on streams[0] afterwards covers the whole batch. */
+#define GMAT_BATCH_FORK 1
+#define GMAT_BATCH_JOIN 2
 GMAT_API int  gmat_sws_scale_batch(GmatSwsContext *c, int nframes,
                                    const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
                                    uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
-                                   void *const *streams, int nstreams);
+                                   void *const *streams, int nstreams, int flags);
 GMAT_API int  gmat_graph_launch(void *graph_exec, void *stream);
 GMAT_API void gmat_graph_destroy(void *graph_exec);
 

@@ -24,7 +24,7 @@ for S in (1, 2, 3, 4, 6, 8):
         h = C.c_void_p(); lib.gmat_stream_create(C.byref(h)); st[s] = h
     def go():
         r = lib.gmat_sws_scale_batch(c, NF * REP, C.cast(sp, C.POINTER(C.c_void_p)), ints([SW, SW]),
-                                     C.cast(dp, C.POINTER(C.c_void_p)), ints([5888]), C.cast(st, C.POINTER(C.c_void_p)), S)
+                                     C.cast(dp, C.POINTER(C.c_void_p)), ints([5888]), C.cast(st, C.POINTER(C.c_void_p)), S, 0)
         assert r == NF * REP, r
     go(); torch.cuda.synchronize()
     best = 1e9
