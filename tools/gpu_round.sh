@@ -17,5 +17,6 @@ echo "== bench eager" ; timeout 600 python bench.py --steps 20 --warmup 3 --grap
 echo "== rocprof" 
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-chained --branches 1 > $OUT/rocprof_serial.log 2>&1
 ls -R $OUT/prof | head -20
 find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -20
