@@ -133,8 +133,7 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     lib.gmat_device_sync()
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
-    if world > 1:
-        dist.barrier()
+    dist.barrier(world) if dist else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     lib.gmat_timer_begin(timer, stream)
@@ -144,16 +143,13 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     lib.gmat_timer_end(timer, stream)
     lib.gmat_stream_sync(stream)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier(world) if dist else None
     wall = time.perf_counter() - t0
     ms = C.c_float()
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    if dist and world > 1:
+        wall = dist.max_over_ranks(wall, world, device="cuda")
     return wall, float(ms.value)
 
 
@@ -215,20 +211,17 @@ def cpu_baseline(nframes):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    import torch.distributed as dist
     import gmat_amd
+    from gmat_amd import dist as gdist
+    rank, local, world = gdist.env_rank()
     lib = gmat_amd.load()                                   # raises if the HIP library is missing
     if lib.gmat_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible")
     torch.cuda.set_device(local)
     lib.gmat_set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    gdist.init("nccl")                                      # RCCL; control plane only (barrier + MAX of time)
+    dist = gdist
     stream = C.c_void_p()
     lib.gmat_stream_create(C.byref(stream))
 
@@ -324,9 +317,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.cpu_frames)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    gdist.finalize(world)
     if rank == 0:
         print(json.dumps(out))
 

@@ -12,6 +12,7 @@
 // and every device error is returned.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include "common.h"
@@ -22,7 +23,7 @@ using namespace gmat;
 
 namespace {
 
-enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE };
+enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV };
 
 struct DevBuf {
     void *p = nullptr;
@@ -97,6 +98,12 @@ struct GmatSwsContext {
     DevBuf yWin[8];
     YuvScaleArgs yargs;
     bool yuvReady = false;
+    // same-size RGB -> YUV 4:2:0 (k_rgb2yuv.hip)
+    ScalePlan planR2Y;
+    Rgb2YuvPlan r2y;
+    DevFilterStore dR2YvChr;
+    DevBuf dR2YrowStart, dR2YrowCount;
+    DevFilter r2yVChr;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
     DevBuf dHLreg, dHCreg, dVrec;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
@@ -191,6 +198,17 @@ static int init_scaler(GmatSwsContext *c)
     return 0;
 }
 
+static int init_rgb2yuv(GmatSwsContext *c)
+{
+    int r = build_scale_plan(c->planR2Y, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
+    if (r < 0) return r;
+    if ((r = rgb2yuv_prepare(c->planR2Y, c->r2y)) < 0) return r;
+    if ((r = c->dR2YvChr.upload(c->planR2Y.vChr, c->r2y.round, c->r2yVChr)) < 0) return r;
+    if ((r = c->dR2YrowStart.upload(c->r2y.rowStart.data(), c->r2y.rowStart.size() * 4)) < 0) return r;
+    if ((r = c->dR2YrowCount.upload(c->r2y.rowCount.data(), c->r2y.rowCount.size() * 4)) < 0) return r;
+    return 0;
+}
+
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
@@ -252,6 +270,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_SWAP_RB;
     } else if (same && srcFormat == dstFormat && is_packed_rgb(srcFormat)) {
         c->mode = MODE_COPY;
+    } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && is_yuv420(dstFormat)) {
+        c->mode = MODE_RGB2YUV;
+        r = init_rgb2yuv(c);
+    } else if (same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
+        c->mode = MODE_YUV2YUV;
     } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
@@ -368,6 +391,37 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW * bytes_per_pixel(c->srcFormat),
                           c->srcH, c->stream);
         break;
+    case MODE_RGB2YUV: {
+        const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+        if (!dst[1] || (!dnv12 && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+        Rgb2YuvLaunch L;
+        L.src = src[0]; L.ss = srcStride[0]; L.bgr = c->srcFormat == GMAT_PIX_FMT_BGR24;
+        L.y = dst[0]; L.ys = dstStride[0]; L.u = dst[1]; L.us = dstStride[1];
+        L.v = dnv12 ? nullptr : dst[2]; L.vs = dnv12 ? 0 : dstStride[2]; L.nv12 = dnv12;
+        L.w = c->srcW; L.h = c->srcH;
+        L.vChr = c->r2yVChr;
+        L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
+        L.maxRows = c->r2y.maxRows;
+        L.k = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
+        c->lastKernel = "rgb2yuv420_kernel";
+        r = launch_rgb2yuv420(L, c->stream);
+        break;
+    }
+    case MODE_YUV2YUV: {
+        // nv12ToPlanarWrapper / planarToNv12Wrapper / plane copies (swscale_unscaled.c): lossless re-layout
+        const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12, dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
+        const int cw = ceil_rshift(c->srcW, 1), ch = ceil_rshift(c->srcH, 1);
+        if (!dst[1] || (!dnv && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+        c->lastKernel = snv == dnv ? "copy2d" : (snv ? "uv_deinterleave_kernel" : "uv_interleave_kernel");
+        if ((r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, c->stream)) < 0) break;
+        if (snv && dnv) r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], 2 * cw, ch, c->stream);
+        else if (!snv && !dnv) {
+            if ((r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], cw, ch, c->stream)) < 0) break;
+            r = launch_copy2d(src[2], srcStride[2], dst[2], dstStride[2], cw, ch, c->stream);
+        } else if (snv) r = launch_uv_relayout(1, src[1], srcStride[1], nullptr, 0, dst[1], dstStride[1], dst[2], dstStride[2], cw, ch, c->stream);
+        else r = launch_uv_relayout(0, src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], nullptr, 0, cw, ch, c->stream);
+        break;
+    }
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
         if (is_yuv420(c->srcFormat) && c->fused == 2) {
@@ -471,16 +525,41 @@ int yuv2rgb_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstS
                           (hipStream_t)stream);
 }
 
-int rgb2yuv_cuda(const uint8_t *[], int[], uint8_t *[], int[], int, int, int, int, void *)
+// The reference's entry points are stateless; the table set-up they imply is cached per geometry.
+static int stateless_convert(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h,
+                             int srcFormat, int dstFormat, void *stream)
 {
-    logf(LOG_ERROR, "rgb2yuv_cuda: not implemented in this build");
-    return GMAT_ERR(ENOSYS);
+    struct Key { int w, h, s, d; GmatSwsContext *c; };
+    static std::mutex lock;
+    static std::vector<Key> cache;
+    if (!src || !dst || !srcStride || !dstStride) return GMAT_ERR(EINVAL);
+    std::lock_guard<std::mutex> g(lock);
+    GmatSwsContext *c = nullptr;
+    for (const Key &k : cache)
+        if (k.w == w && k.h == h && k.s == srcFormat && k.d == dstFormat) c = k.c;
+    if (!c) {
+        c = gmat_sws_getContext(w, h, srcFormat, w, h, dstFormat, GMAT_SWS_HWACCEL, nullptr);
+        if (!c) return GMAT_ERR(ENOSYS);
+        if (cache.size() >= 16) { gmat_sws_freeContext(cache.front().c); cache.erase(cache.begin()); }
+        cache.push_back({w, h, srcFormat, dstFormat, c});
+    }
+    gmat_sws_setStream(c, stream);
+    const int r = gmat_sws_scale(c, src, srcStride, 0, h, dst, dstStride);
+    return r < 0 ? r : 0;
 }
 
-int yuv2yuv_cuda(const uint8_t *[], int[], uint8_t *[], int[], int, int, int, int, void *)
+int rgb2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h, int srcFormat,
+                 int dstFormat, void *stream)
 {
-    logf(LOG_ERROR, "yuv2yuv_cuda: not implemented in this build");
-    return GMAT_ERR(ENOSYS);
+    if (!(srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) || !is_yuv420(dstFormat)) return GMAT_ERR(ENOSYS);
+    return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
+}
+
+int yuv2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h, int srcFormat,
+                 int dstFormat, void *stream)
+{
+    if (!is_yuv420(srcFormat) || !is_yuv420(dstFormat)) return GMAT_ERR(ENOSYS);
+    return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
 }
 
 void rgb24tobgr24_cuda(const uint8_t *src[], uint8_t *dst[], int srcStride[], int dstStride[], int width, int height,

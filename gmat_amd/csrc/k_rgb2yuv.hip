@@ -1,0 +1,208 @@
+// k_rgb2yuv.hip — packed RGB -> YUV 4:2:0 (same size) and NV12 <-> YUV420P re-layouts for gfx950.
+//
+// Replaces rgb2yuv_cuda -> color2nv12 / color2yuv420 (libswscale/cuda/yuv2rgb_cuda.cu:909-947,671-739) and
+// yuv2yuv_cuda (libswscale/cuda/yuv2yuv_cuda.cu:320-371; always returns -1 in the reference) with libswscale's
+// CPU arithmetic for an RGB24 -> NV12/YUV420P context of equal size (generic path):
+//   luma    rgb24ToY_c                      input.c:815-828   Y14 = (ry*r+gy*g+by*b+(32<<14)+(1<<8))>>9
+//           hScale16To15_c with one tap     swscale.c:93-119  min(2*Y14, 32767)
+//           yuv2plane1_8_c                  output.c:400-408  clip_u8((v + 64) >> 7)
+//   chroma  rgb24ToUV_half_c                input.c:849-866   pair-summed pixels, >>10
+//           vertical filter (8 taps for the default bicubic 2:1) + yuv2planeX_8_c / yuv2nv12cX_c
+//                                           output.c:385-430  clip_u8(((64<<12) + sum) >> 19)
+// One block = 128 x 32 luma pixels: phase 1 reads the 38-row source window as 12-byte groups, writes Y
+// for the 32 central rows straight to HBM and the half-resolution 15-bit chroma of all rows to LDS;
+// phase 2 runs the vertical chroma taps (v_dot2c_i32_i16 over row pairs) and stores U/V.
+// Traffic: 3 B/px in, 1.5 B/px out.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+constexpr int R2Y_TW = 128, R2Y_TH = 32, R2Y_CW = R2Y_TW / 2, R2Y_CH = R2Y_TH / 2;
+
+struct Rgb2YuvArgs {
+    const uint8_t *src; int ss, bgr, srcAligned;
+    uint8_t *y, *u, *v; int ys, us, vs, nv12;
+    int w, h, cw, ch;
+    DevFilter vChr;                      // chroma vertical filter over SOURCE rows, count = ch
+    const int32_t *rowStart, *rowCount;  // per tile row: source row window of the chroma taps (even start)
+    int maxRows;
+    Rgb2YuvConsts k;
+};
+
+__global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
+{
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    int *hu = reinterpret_cast<int *>(lds_base);            // [maxRows/2][64] row-pair interleaved int16
+    int *hv = hu + (a.maxRows >> 1) * R2Y_CW;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * R2Y_TW, y0 = blockIdx.y * R2Y_TH;
+    const int r0 = a.rowStart[blockIdx.y], nr = a.rowCount[blockIdx.y];   // chroma window rows (even r0)
+    // the luma rows [y0, y0+TH) are always inside [r0, r0+nr) for a 2:1 vertical chroma filter; when they
+    // are not (other flags) the missing rows are handled by the loop bounds below
+    const int lo = min(r0, y0), hiRow = max(r0 + nr, min(y0 + R2Y_TH, a.h));
+    const int rows = hiRow - lo;
+    short *hu16 = reinterpret_cast<short *>(hu), *hv16 = reinterpret_cast<short *>(hv);
+
+    // ---- phase 1: units of 4 pixels x 1 row; 32 groups per row ----
+    const int total = rows * 32;
+    for (int g = tid; g < total; g += 256) {
+        const int rr = g >> 5, cg = g & 31;
+        const int srow = lo + rr;
+        const int sr = min(max(srow, 0), a.h - 1);
+        const int col = x0 + 4 * cg;
+        if (col >= a.w) continue;
+        const uint8_t *row = a.src + (size_t)sr * a.ss;
+        int r[4], gg[4], b[4];
+        if (a.srcAligned && col + 4 <= a.w) {
+            const uint3 v = *reinterpret_cast<const uint3 *>(row + (size_t)col * 3);
+            r[0] = v.x & 0xFF;         gg[0] = (v.x >> 8) & 0xFF;  b[0] = (v.x >> 16) & 0xFF;
+            r[1] = v.x >> 24;          gg[1] = v.y & 0xFF;         b[1] = (v.y >> 8) & 0xFF;
+            r[2] = (v.y >> 16) & 0xFF; gg[2] = v.y >> 24;          b[2] = v.z & 0xFF;
+            r[3] = (v.z >> 8) & 0xFF;  gg[3] = (v.z >> 16) & 0xFF; b[3] = v.z >> 24;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int c = min(col + i, a.w - 1);
+                r[i] = row[3 * c]; gg[i] = row[3 * c + 1]; b[i] = row[3 * c + 2];
+            }
+        }
+        if (a.bgr) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int t = r[i]; r[i] = b[i]; b[i] = t; }
+        }
+        // luma of the tile's own rows
+        if (srow >= y0 && srow < y0 + R2Y_TH && srow < a.h && col < a.w) {
+            unsigned yb = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int y14 = rgb_to_y14(a.k, r[i], gg[i], b[i]);
+                yb |= (unsigned)clip_u8((min(2 * y14, 32767) + 64) >> 7) << (8 * i);
+            }
+            uint8_t *d = a.y + (size_t)srow * a.ys + col;
+            if (col + 4 <= a.w && ((((uintptr_t)a.y | (uintptr_t)a.ys) & 3) == 0)) *reinterpret_cast<unsigned *>(d) = yb;
+            else for (int i = 0; i < min(4, a.w - col); i++) d[i] = (uint8_t)(yb >> (8 * i));
+        }
+        // chroma of the window rows
+        const int wr = srow - r0;
+        if (wr >= 0 && wr < nr) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int rs = r[2 * i] + r[2 * i + 1], gs = gg[2 * i] + gg[2 * i + 1], bs = b[2 * i] + b[2 * i + 1];
+                const int o = (((wr >> 1) * R2Y_CW + 2 * cg + i) << 1) + (wr & 1);
+                hu16[o] = (short)min(2 * rgbsum_to_u14(a.k, rs, gs, bs), 32767);
+                hv16[o] = (short)min(2 * rgbsum_to_v14(a.k, rs, gs, bs), 32767);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: vertical chroma taps, 4 chroma samples per thread ----
+    {
+        const int q = tid & 15, yl = tid >> 4;                 // 16 groups x 16 chroma rows
+        const int cy = (y0 >> 1) + yl, cx = (x0 >> 1) + 4 * q;
+        if (cy < a.ch && cx < a.cw) {
+            const int vp = (a.vChr.pos_even[cy] - r0) >> 1;
+            int U[4], V[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) U[i] = V[i] = a.vChr.round[cy];
+            for (int k = 0; k < a.vChr.pairs; k++) {
+                const int cf = a.vChr.packed[(size_t)cy * a.vChr.pairs + k];
+                const int4 u = *reinterpret_cast<const int4 *>(hu + (vp + k) * R2Y_CW + 4 * q);
+                const int4 v = *reinterpret_cast<const int4 *>(hv + (vp + k) * R2Y_CW + 4 * q);
+                U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
+                V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+            }
+            // one tap of 4096: ((64<<12) + 4096*s) >> 19 == (s + 64) >> 7, i.e. yuv2plane1_8_c falls out of the X form
+            const int sh = 19;
+            const int n = min(4, a.cw - cx);
+            if (a.nv12) {
+                uint8_t *d = a.u + (size_t)cy * a.us + 2 * cx;
+                for (int i = 0; i < n; i++) { d[2 * i] = (uint8_t)clip_u8(U[i] >> sh); d[2 * i + 1] = (uint8_t)clip_u8(V[i] >> sh); }
+            } else {
+                uint8_t *du = a.u + (size_t)cy * a.us + cx, *dv = a.v + (size_t)cy * a.vs + cx;
+                for (int i = 0; i < n; i++) { du[i] = (uint8_t)clip_u8(U[i] >> sh); dv[i] = (uint8_t)clip_u8(V[i] >> sh); }
+            }
+        }
+    }
+}
+
+// NV12 <-> YUV420P chroma re-layout (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c)
+__global__ __launch_bounds__(256) void uv_deinterleave_kernel(const uint8_t *uv, int uvs, uint8_t *u, int us, uint8_t *v, int vs,
+                                                              int cw, int ch)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= cw || y >= ch) return;
+    const uint8_t *s = uv + (size_t)y * uvs + 2 * x;
+    u[(size_t)y * us + x] = s[0];
+    v[(size_t)y * vs + x] = s[1];
+}
+
+__global__ __launch_bounds__(256) void uv_interleave_kernel(const uint8_t *u, int us, const uint8_t *v, int vs, uint8_t *uv, int uvs,
+                                                            int cw, int ch)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= cw || y >= ch) return;
+    uint8_t *d = uv + (size_t)y * uvs + 2 * x;
+    d[0] = u[(size_t)y * us + x];
+    d[1] = v[(size_t)y * vs + x];
+}
+
+// ---------------------------------------------------------------------------------------------------
+int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t)
+{
+    // same-size RGB -> 4:2:0 only: identity horizontal filters, one-tap vertical luma
+    if (p.srcW != p.dstW || p.srcH != p.dstH) return GMAT_ERR(ENOSYS);
+    if (p.hLum.taps != 1 || p.hChr.taps != 1 || p.vLum.taps != 1 || !p.chrSrcHSub) return GMAT_ERR(ENOSYS);
+    for (int i = 0; i < p.hChr.count; i++) if (p.hChr.pos[i] != i) return GMAT_ERR(ENOSYS);
+    t.nty = (p.dstH + R2Y_TH - 1) / R2Y_TH;
+    t.ntx = (p.dstW + R2Y_TW - 1) / R2Y_TW;
+    t.rowStart.resize(t.nty); t.rowCount.resize(t.nty);
+    t.maxRows = 0;
+    for (int ty = 0; ty < t.nty; ty++) {
+        int lo = INT32_MAX, hi = 0;
+        for (int cy = ty * R2Y_CH; cy < std::min((ty + 1) * R2Y_CH, p.chrDstH); cy++) {
+            lo = std::min(lo, p.vChr.pos_even[cy]);
+            hi = std::max(hi, p.vChr.pos_even[cy] + 2 * p.vChr.pairs);
+        }
+        if (lo == INT32_MAX) { lo = 0; hi = 2; }
+        t.rowStart[ty] = lo;
+        t.rowCount[ty] = align_up(hi - lo, 2);
+        t.maxRows = std::max(t.maxRows, t.rowCount[ty]);
+    }
+    if (t.maxRows * R2Y_CW * 4 > 60 * 1024) return GMAT_ERR(ENOSYS);
+    // accumulator start: yuv2planeX_8_c / yuv2nv12cX_c dither 64<<12; the one-tap planar form adds 64 before >>7
+    t.round.assign(p.chrDstH, 64 << 12);
+    return 0;
+}
+
+int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream)
+{
+    Rgb2YuvArgs a;
+    a.src = L.src; a.ss = L.ss; a.bgr = L.bgr;
+    a.srcAligned = ((((uintptr_t)L.src | (uintptr_t)L.ss) & 3) == 0);
+    a.y = L.y; a.u = L.u; a.v = L.v; a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.nv12 = L.nv12;
+    a.w = L.w; a.h = L.h; a.cw = (L.w + 1) / 2; a.ch = (L.h + 1) / 2;
+    a.vChr = L.vChr; a.rowStart = L.rowStart; a.rowCount = L.rowCount; a.maxRows = L.maxRows; a.k = L.k;
+    const dim3 grid((L.w + R2Y_TW - 1) / R2Y_TW, (L.h + R2Y_TH - 1) / R2Y_TH), block(256);
+    const size_t lds = (size_t)L.maxRows * R2Y_CW * 4;      // two planes of (maxRows/2) x 64 dwords
+    hipLaunchKernelGGL(rgb2yuv420_kernel, grid, block, lds, stream, a);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0, uint8_t *d1,
+                       int ds1, int cw, int ch, hipStream_t stream)
+{
+    if (cw <= 0 || ch <= 0) return 0;
+    const dim3 grid((cw + 255) / 256, ch), block(256);
+    if (toPlanar) hipLaunchKernelGGL(uv_deinterleave_kernel, grid, block, 0, stream, a0, s0, d0, ds0, d1, ds1, cw, ch);
+    else          hipLaunchKernelGGL(uv_interleave_kernel, grid, block, 0, stream, a0, s0, a1, s1, d0, ds0, cw, ch);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

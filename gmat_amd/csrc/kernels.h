@@ -107,6 +107,28 @@ int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, i
 
 } // namespace gmat
 
+// ---- packed RGB -> YUV 4:2:0 at equal size, and NV12 <-> YUV420P (k_rgb2yuv.hip) ------------------
+namespace gmat {
+struct Rgb2YuvPlan {
+    int ntx = 0, nty = 0, maxRows = 0;
+    std::vector<int32_t> rowStart, rowCount, round;
+};
+struct Rgb2YuvLaunch {
+    const uint8_t *src; int ss, bgr;
+    uint8_t *y, *u, *v; int ys, us, vs, nv12;
+    int w, h;
+    DevFilter vChr;
+    const int32_t *rowStart, *rowCount;
+    int maxRows;
+    Rgb2YuvConsts k;
+};
+int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t);
+int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
+// toPlanar: (a0 = interleaved UV) -> d0 = U, d1 = V;  else (a0 = U, a1 = V) -> d0 = interleaved UV
+int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0,
+                       uint8_t *d1, int ds1, int cw, int ch, hipStream_t stream);
+} // namespace gmat
+
 // ---- 2:1 specialisation of the YUV scaler (k_scale_yuv2x.hip) -------------------------------------
 // Every horizontal filter row is re-expressed on the regular window [2x + w0, 2x + w0 + 10) (zero taps
 // trimmed; border rows keep their folded coefficients), so the kernel needs no per-output positions:

@@ -1,0 +1,49 @@
+"""The N>1 plumbing (one process per GPU, independent streams, barrier + MAX-over-ranks timing) on
+world_size-2 gloo, CPU only."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    from gmat_amd import dist as gd
+    rank, local, world = gd.init("gloo")
+    assert world == 2
+    mine = gd.shard_streams(8, rank, world)
+    gd.barrier(world)
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))            # rank 1 is the slow one
+    wall = time.perf_counter() - t0
+    value, t = gd.aggregate_throughput(1000.0, wall, world)
+    gd.finalize(world)
+    if rank == 0:
+        print(json.dumps({"value": value, "t": t, "streams0": mine, "wall0": wall}))
+""") % ROOT
+
+
+def test_two_rank_aggregate_is_sum_over_slowest(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["streams0"] == [0, 2, 4, 6]
+    assert d["t"] >= 0.1 and d["t"] >= d["wall0"]                 # MAX over ranks: the slow rank's time
+    assert abs(d["value"] - 2 * 1000.0 / d["t"]) < 1e-6            # both ranks' units over that time
+
+
+def test_single_process_path():
+    sys.path.insert(0, ROOT)
+    from gmat_amd import dist as gd
+    assert gd.shard_streams(5, 0, 1) == [0, 1, 2, 3, 4]
+    v, t = gd.aggregate_throughput(10.0, 2.0, 1)
+    assert v == 5.0 and t == 2.0

@@ -1,0 +1,74 @@
+"""RGB -> YUV 4:2:0 (same size) and NV12 <-> YUV420P vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, planes, ints, synth_planes
+
+SIZES = [(128, 32), (256, 70), (130, 34), (66, 18), (6, 4), (2, 2), (300, 66)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
+def test_rgb_to_yuv420_bit_exact(dev, orc, w, h, src_fmt, dst_fmt):
+    src = synth_planes(orc, src_fmt, w, h, seed=51)
+    want = orc.sws(src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"])
+    for align, extra in [(256, 0), (1, 1)]:
+        d_src = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
+        assert kernel == "rgb2yuv420_kernel"
+        for i, (g, wv) in enumerate(zip(got, want)):
+            bad = np.argwhere(g != wv)
+            assert bad.size == 0, f"plane {i}: {len(bad)} mismatches, first {bad[:4].tolist()} (align {align})"
+        for p in pads:
+            assert (p == 0xCD).all()
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "point", "lanczos"])
+def test_rgb_to_nv12_other_vertical_filters(dev, orc, flags):
+    w, h = 192, 40
+    src = synth_planes(orc, "rgb24", w, h, seed=53)
+    want = orc.sws(src, w, h, "rgb24", w, h, "nv12", SWS[flags])
+    d_src = dev.upload_planes(src, 64)
+    got, _, _ = dev.sws(d_src, w, h, "rgb24", w, h, "nv12", SWS[flags], dst_align=64)
+    assert all((g == wv).all() for g, wv in zip(got, want))
+
+
+def test_reference_entry_point_rgb2yuv_cuda(dev, orc):
+    w, h = 128, 36
+    src = synth_planes(orc, "rgb24", w, h, seed=55)
+    want = orc.sws(src, w, h, "rgb24", w, h, "nv12")
+    d_src = dev.upload_planes(src, 256)
+    dst = dev.planes_like("nv12", w, h, 256)
+    for _ in range(2):                                   # second call hits the cached tables
+        r = dev.lib.rgb2yuv_cuda(planes([p.ptr for p in d_src]), ints([p.stride for p in d_src]),
+                                 planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h,
+                                 PIX_FMT["rgb24"], PIX_FMT["nv12"], None)
+        assert r == 0
+    assert all((d.download() == wv).all() for d, wv in zip(dst, want))
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (5, 3)])
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12"), ("nv12", "nv12"), ("yuv420p", "yuv420p")])
+def test_yuv_relayout_lossless(dev, orc, w, h, pair):
+    s, d = pair
+    src = synth_planes(orc, s, w, h, seed=57)
+    d_src = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d_src, w, h, s, w, h, d, dst_align=64)
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    if s == "nv12":
+        u, v = src[1][:, 0::2], src[1][:, 1::2]
+    else:
+        u, v = src[1], src[2]
+    assert (got[0] == src[0]).all()
+    if d == "nv12":
+        assert (got[1][:, 0::2] == u).all() and (got[1][:, 1::2] == v).all()
+    else:
+        assert (got[1] == u).all() and (got[2] == v).all()
+    for p in pads:
+        assert (p == 0xCD).all()
+    # the reference's symbol
+    dst = dev.planes_like(d, w, h, 64)
+    r = dev.lib.yuv2yuv_cuda(planes([p.ptr for p in d_src]), ints([p.stride for p in d_src]),
+                             planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h, PIX_FMT[s], PIX_FMT[d], None)
+    assert r == 0 and all((a.download() == b).all() for a, b in zip(dst, got))
