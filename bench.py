@@ -37,6 +37,19 @@ ALG_SCALE = BYTES_RGB_SRC + BYTES_RGB_DST                   # 31,104,000 B
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed PMC collection (profiles/r01_traffic.json, produced on the GPU box
+    by tools/pmc_traffic.sh with the corrections of MI355X_MICROARCH.md); None when not collected."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        for k, v in d["kernels"].items():
+            if kernel in k:
+                return v["traffic_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,7 +266,8 @@ def main():
                               f"eager, one C call per step, frames spread over {branches} HIP streams"),
                    "parallelism": f"{world} GPU(s) x independent streams, no collective"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname),
+                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                      "algorithmic_bytes_per_launch": ALG_FUSED,
                      "avg_launch_us": round(ser_ms * 1e3 / launches, 3),
                      "note": "launches back to back on one stream (HIP events); with the graph's parallel "
