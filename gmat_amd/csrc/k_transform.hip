@@ -24,7 +24,11 @@ __device__ __forceinline__ void row_to_lds(const uint8_t *row, int rowBytes, int
         if (aligned && a >= 0 && a + 4 <= rowBytes && a >= b0 && a + 4 <= b0 + n) {
             const unsigned v = *reinterpret_cast<const unsigned *>(row + a);
             uint8_t *d = l + (a - b0);
-            d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16); d[3] = (uint8_t)(v >> 24);
+            if ((reinterpret_cast<uintptr_t>(d) & 3) == 0) {
+                *reinterpret_cast<unsigned *>(d) = v;              // one ds_write_b32
+            } else {
+                d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16); d[3] = (uint8_t)(v >> 24);
+            }
         } else {
             for (int i = 0; i < 4; i++) {
                 const int b = a + i;
@@ -43,11 +47,69 @@ __device__ __forceinline__ void lds_to_row(uint8_t *row, int b0, int n, const ui
         if (aligned && a >= b0 && a + 4 <= b0 + n) {
             const uint8_t *s = l + (a - b0);
             *reinterpret_cast<unsigned *>(row + a) =
-                (unsigned)s[0] | ((unsigned)s[1] << 8) | ((unsigned)s[2] << 16) | ((unsigned)s[3] << 24);
+                (reinterpret_cast<uintptr_t>(s) & 3) == 0
+                    ? *reinterpret_cast<const unsigned *>(s)                                   // one ds_read_b32
+                    : ((unsigned)s[0] | ((unsigned)s[1] << 8) | ((unsigned)s[2] << 16) | ((unsigned)s[3] << 24));
         } else {
             for (int i = 0; i < 4; i++) {
                 const int b = a + i;
                 if (b >= b0 && b < b0 + n) row[b] = l[b - b0];
+            }
+        }
+    }
+}
+
+// Two-phase form of row_to_lds for tiles: FETCH every dword slot of every row a wave owns first (all the
+// global loads in flight together), COMMIT them to LDS afterwards.  A row-at-a-time loop serialises one
+// HBM round trip per row (measured: 4.5 dependent latencies per block made the 3x3 smooth 5x slower).
+__device__ __forceinline__ unsigned fetch_dword(const uint8_t *row, int rowBytes, int a, bool aligned)
+{
+    if (aligned && a >= 0 && a + 4 <= rowBytes) return *reinterpret_cast<const unsigned *>(row + a);
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (unsigned)row[min(max(a + i, 0), rowBytes - 1)] << (8 * i);
+    return v;
+}
+
+__device__ __forceinline__ void commit_dword(uint8_t *l, int b0, int n, int a, unsigned v)
+{
+    uint8_t *d = l + (a - b0);
+    if (a >= b0 && a + 4 <= b0 + n && (reinterpret_cast<uintptr_t>(d) & 3) == 0) {
+        *reinterpret_cast<unsigned *>(d) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (a + i >= b0 && a + i < b0 + n) d[i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
+// Loads rows [0, nrows) of a tile (row r of the tile = source row rowOf(r)), bytes [b0, b0+n) of each, into
+// lds + r*pitch.  NRW = rows per wave (ceil(max rows / 4)), slots: up to 2 dwords per lane per row.
+template <int NRW, typename RowOf>
+__device__ __forceinline__ void tile_to_lds(const uint8_t *src, int ss, int rowBytes, int b0, int n, int nrows,
+                                            uint8_t *lds, int pitch, int lane, int wave, bool aligned, RowOf rowOf)
+{
+    const int a0 = b0 & ~3, a1 = (b0 + n + 3) & ~3;
+    const int sa = a0 + 4 * lane, sb = sa + 256;
+    constexpr int BATCH = 6;                              // rows per wave whose loads are in flight together
+    for (int k0 = 0; k0 < NRW; k0 += BATCH) {
+        unsigned va[BATCH], vb[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) {
+            const int r = wave + 4 * (k0 + k);
+            va[k] = vb[k] = 0;
+            if (k0 + k < NRW && r < nrows) {
+                const uint8_t *row = src + (size_t)rowOf(r) * ss;
+                if (sa < a1) va[k] = fetch_dword(row, rowBytes, sa, aligned);
+                if (sb < a1) vb[k] = fetch_dword(row, rowBytes, sb, aligned);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) {
+            const int r = wave + 4 * (k0 + k);
+            if (k0 + k < NRW && r < nrows) {
+                if (sa < a1) commit_dword(lds + r * pitch, b0, n, sa, va[k]);
+                if (sb < a1) commit_dword(lds + r * pitch, b0, n, sb, vb[k]);
             }
         }
     }
@@ -60,16 +122,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
 {
     constexpr int T = 64;
     constexpr int PITCH = T * BPP + 4;                  // +4 B: odd dword pitch, conflict-light columns
-    __shared__ uint8_t tile[T * PITCH];
-    __shared__ uint8_t orow[4][T * BPP];                // per-wave output row staging
+    __shared__ __attribute__((aligned(16))) uint8_t tile[T * PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t orow[4][T * BPP];                // per-wave output row staging
     // input tile: columns [ix0, ix0+T) x rows [iy0, iy0+T) of the (possibly bottom-up) source
     const int ix0 = blockIdx.x * T, iy0 = blockIdx.y * T;
     const int tw = min(T, inW - ix0), th = min(T, inH - iy0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < th; r += 4) {
-        const int sy = (dir & 1) ? inH - 1 - (iy0 + r) : iy0 + r;
-        row_to_lds(src + (size_t)sy * ss, inW * BPP, ix0 * BPP, tw * BPP, tile + r * PITCH, lane, 64, aligned);
-    }
+    tile_to_lds<T / 4>(src, ss, inW * BPP, ix0 * BPP, tw * BPP, th, tile, PITCH, lane, wave, aligned,
+                       [&](int r) { return (dir & 1) ? inH - 1 - (iy0 + r) : iy0 + r; });
     __syncthreads();
     // output: out(x = iy0 + r, y = ix0 + c) = tile[r][c]; out is inH wide, inW tall
     const int outH = inW;
@@ -89,8 +149,8 @@ __global__ __launch_bounds__(256) void flip_kernel(const uint8_t *src, int ss, u
                                                    int w, int h, int fh, int fv, int aligned)
 {
     constexpr int T = 256;                                // pixels per block row segment
-    __shared__ uint8_t seg[4][T * BPP];
-    __shared__ uint8_t out[4][T * BPP];
+    __shared__ __attribute__((aligned(16))) uint8_t seg[4][T * BPP];
+    __shared__ __attribute__((aligned(16))) uint8_t out[4][T * BPP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int y = blockIdx.y * 4 + wave;
     const int x0 = blockIdx.x * T;
@@ -111,28 +171,46 @@ __global__ __launch_bounds__(256) void flip_kernel(const uint8_t *src, int ss, u
 // ---- 3x3 convolution with vf_convolution's borders; optional transposed store ------------------
 // sum = sum_i c[i]*m[i];  out = clip_u8((int)(sum * rdiv + bias + 0.5f))   (vf_convolution.c:495-512)
 // border (setup_3x3, :555-569): index -1 -> 1 (reflect-101), index n -> n-1 (edge repeated).
-struct ConvParams { int m[9]; float rdiv, bias; };
+struct ConvParams { int m[9]; float rdiv, bias; int shift; unsigned half; };   // shift >= 0: rdiv == 2^-shift, bias == 0
+
+// gathers bytes (i0, i1, i2) of the 12-byte window {w0, w1, w2} into one dword [b(i0), b(i1), b(i2), 0]
+template <int I0, int I1, int I2>
+__device__ __forceinline__ unsigned gather3(unsigned w0, unsigned w1, unsigned w2)
+{
+    static_assert(I0 < I1 && I1 < I2 && I2 < 12, "window indices");
+    if (I2 < 8) return __builtin_amdgcn_perm(w1, w0, 0x0C000000u | (I2 << 16) | (I1 << 8) | I0);
+    if (I0 >= 4) return __builtin_amdgcn_perm(w2, w1, 0x0C000000u | ((I2 - 4) << 16) | ((I1 - 4) << 8) | (I0 - 4));
+    // spans all three dwords: first (I0, I1) from {w0,w1}, then add I2 from w2
+    const unsigned t = __builtin_amdgcn_perm(w1, w0, 0x0C0C0000u | (I1 << 8) | I0);
+    return __builtin_amdgcn_perm(w2, t, 0x0C000100u | ((I2 - 8 + 4) << 16));
+}
 
 template <int BPP, int TW, int TH, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
-                                                      int w, int h, ConvParams cp, int aligned)
+                                                      int w, int h, ConvParams cp, int aligned, int fastCoef)
 {
-    constexpr int SP = (TW + 2) * BPP + 2;                 // source tile pitch (bytes)
-    constexpr int RP = TW * BPP + (TRANSPOSED ? 4 : 0);    // result tile pitch
-    __shared__ uint8_t st[(TH + 2) * SP];
-    __shared__ uint8_t rt[TH * RP];
-    __shared__ uint8_t orow[4][(TRANSPOSED ? TH : 1) * BPP];
+    // The source tile holds pixels [x0-1, x0+TW] of rows [y0-1, y0+TH].  x0 is a multiple of 64, so the
+    // first source byte (x0-1)*BPP is 1 (mod 4) for 3-byte pixels and 0 for 4-byte pixels: SHIFT re-aligns
+    // the tile so that global dwords map to LDS dwords (one ds_write_b32 per loaded dword).
+    constexpr int SHIFT = BPP == 3 ? 1 : 0;
+    constexpr int SP = (((TW + 2) * BPP + SHIFT + 3) / 4) * 4 + 4;     // source tile pitch, odd dword count
+    constexpr int RP = ((TW * BPP + 3) / 4) * 4 + 4;                   // result tile pitch
+    static_assert((SP / 4) % 2 == 1 && (RP / 4) % 2 == 1, "odd dword pitches keep column accesses conflict-light");
+    __shared__ __attribute__((aligned(16))) uint8_t st_raw[(TH + 2) * SP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t rt[TH * RP];
+    __shared__ __attribute__((aligned(16))) uint8_t orow[4][((TRANSPOSED ? TH : 1) * BPP + 3) / 4 * 4];
+    uint8_t *st = st_raw + SHIFT;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tw = min(TW, w - x0), th = min(TH, h - y0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int r = wave; r < th + 2; r += 4) {
-        int yy = y0 + r - 1;
-        yy = yy < 0 ? -yy : yy;
-        yy = yy >= h ? 2 * h - 1 - yy : yy;
-        yy = min(max(yy, 0), h - 1);
-        row_to_lds(src + (size_t)yy * ss, w * BPP, (x0 - 1) * BPP, (tw + 2) * BPP, st + r * SP, lane, 64, aligned);
-    }
+    tile_to_lds<(TH + 2 + 3) / 4>(src, ss, w * BPP, (x0 - 1) * BPP, (tw + 2) * BPP, th + 2, st, SP, lane, wave, aligned,
+                                  [&](int r) {
+                                      int yy = y0 + r - 1;
+                                      yy = yy < 0 ? -yy : yy;
+                                      yy = yy >= h ? 2 * h - 1 - yy : yy;
+                                      return min(max(yy, 0), h - 1);
+                                  });
     __syncthreads();
     // horizontal halo fix-up for tiles touching the frame's left / right edge
     if (x0 == 0 || x0 + tw == w) {
@@ -147,16 +225,57 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < th * tw * BPP; i += 256) {
-        const int r = i / (tw * BPP), cb = i - r * (tw * BPP);
-        const uint8_t *p = st + r * SP + cb;               // top-left tap of the 3x3 window (this channel)
-        int sum = 0;
+    const int rowDwords = (tw * BPP + 3) >> 2;
+    if (fastCoef) {
+        // coefficients in [0,255]: one output DWORD (4 channel bytes) per item.  Per source row the three
+        // horizontal taps of output byte j are window bytes (SHIFT+j, SHIFT+j+BPP, SHIFT+j+2*BPP): gathered
+        // with v_perm_b32, multiplied with v_dot4_u32_u8.
+        const unsigned m0 = (unsigned)cp.m[0] | ((unsigned)cp.m[1] << 8) | ((unsigned)cp.m[2] << 16);
+        const unsigned m1 = (unsigned)cp.m[3] | ((unsigned)cp.m[4] << 8) | ((unsigned)cp.m[5] << 16);
+        const unsigned m2 = (unsigned)cp.m[6] | ((unsigned)cp.m[7] << 8) | ((unsigned)cp.m[8] << 16);
+        for (int i = threadIdx.x; i < th * rowDwords; i += 256) {
+            const int r = i / rowDwords, d = i - r * rowDwords;
+            unsigned sum[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 9; k++) sum += (int)p[(k / 3) * SP + (k % 3) * BPP] * cp.m[k];
-        // separate multiply and adds: the CPU reference does not contract them into an fma
-        const float f = __fadd_rn(__fadd_rn(__fmul_rn((float)sum, cp.rdiv), cp.bias), 0.5f);
-        const int v = (int)f;
-        rt[r * RP + cb] = (uint8_t)min(max(v, 0), 255);
+            for (int rr = 0; rr < 3; rr++) {
+                const unsigned *p = reinterpret_cast<const unsigned *>(st_raw + (r + rr) * SP) + d;
+                const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+                const unsigned mm = rr == 0 ? m0 : rr == 1 ? m1 : m2;
+                const unsigned g0 = gather3<SHIFT + 0, SHIFT + 0 + BPP, SHIFT + 0 + 2 * BPP>(w0, w1, w2);
+                sum[0] = __builtin_amdgcn_udot4(g0, mm, sum[0], false);
+                const unsigned g1 = gather3<SHIFT + 1, SHIFT + 1 + BPP, SHIFT + 1 + 2 * BPP>(w0, w1, w2);
+                sum[1] = __builtin_amdgcn_udot4(g1, mm, sum[1], false);
+                const unsigned g2 = gather3<SHIFT + 2, SHIFT + 2 + BPP, SHIFT + 2 + 2 * BPP>(w0, w1, w2);
+                sum[2] = __builtin_amdgcn_udot4(g2, mm, sum[2], false);
+                const unsigned g3 = gather3<SHIFT + 3, SHIFT + 3 + BPP, SHIFT + 3 + 2 * BPP>(w0, w1, w2);
+                sum[3] = __builtin_amdgcn_udot4(g3, mm, sum[3], false);
+            }
+            unsigned o = 0;
+            if (cp.shift >= 0) {
+                // rdiv == 2^-shift and bias == 0: (int)(sum * rdiv + 0.5f) == (sum + 2^(shift-1)) >> shift exactly
+                // (sum < 2^24 is exact in float, the product and the + 0.5f are exact too)
+#pragma unroll
+                for (int j = 0; j < 4; j++) o |= min((sum[j] + cp.half) >> cp.shift, 255u) << (8 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // separate multiply and adds: the CPU reference does not contract them into an fma
+                    const float f = __fadd_rn(__fadd_rn(__fmul_rn((float)(int)sum[j], cp.rdiv), cp.bias), 0.5f);
+                    o |= (unsigned)min(max((int)f, 0), 255) << (8 * j);
+                }
+            }
+            reinterpret_cast<unsigned *>(rt + r * RP)[d] = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < th * tw * BPP; i += 256) {
+            const int r = i / (tw * BPP), cb = i - r * (tw * BPP);
+            const uint8_t *p = st + r * SP + cb;           // top-left tap of the 3x3 window (this channel)
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) sum += (int)p[(k / 3) * SP + (k % 3) * BPP] * cp.m[k];
+            const float f = __fadd_rn(__fadd_rn(__fmul_rn((float)sum, cp.rdiv), cp.bias), 0.5f);
+            rt[r * RP + cb] = (uint8_t)min(max((int)f, 0), 255);
+        }
     }
     __syncthreads();
     if (!TRANSPOSED) {
@@ -219,12 +338,16 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
 {
     if (w <= 0 || h <= 0) return 0;
     ConvParams cp;
-    for (int i = 0; i < 9; i++) cp.m[i] = m[i];
+    int fast = 1;
+    for (int i = 0; i < 9; i++) { cp.m[i] = m[i]; fast &= m[i] >= 0 && m[i] <= 255; }
     cp.rdiv = rdiv; cp.bias = bias;
-    const dim3 grid((w + 63) / 64, (h + 15) / 16), block(256);
+    cp.shift = -1; cp.half = 0;
+    for (int k = 0; k <= 16 && fast; k++)
+        if (bias == 0.0f && rdiv == 1.0f / (float)(1 << k)) { cp.shift = k; cp.half = k ? 1u << (k - 1) : 0u; }
+    const dim3 grid((w + 63) / 64, (h + 63) / 64), block(256);
     const int aligned = al4(src, ss, dst, ds);
-    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<3, 64, 16, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<4, 64, 16, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned);
+    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<3, 64, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
+    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<4, 64, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -240,11 +363,12 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
     ConvParams cp;
     const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
     for (int i = 0; i < 9; i++) cp.m[i] = m[i];
-    cp.rdiv = 1.0f / 16.0f; cp.bias = 0.0f;
+    cp.rdiv = 1.0f / 16.0f; cp.bias = 0.0f; cp.shift = 4; cp.half = 8;
+    const int fast = 1;
     const dim3 grid((inW + 63) / 64, (inH + 63) / 64), block(256);
     const int aligned = al4(src, ss, dst, ds);
-    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<3, 64, 64, true>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, cp, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<4, 64, 64, true>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, cp, aligned);
+    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<3, 64, 64, true>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, cp, aligned, fast);
+    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<4, 64, 64, true>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, cp, aligned, fast);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -55,6 +55,11 @@ void *dyn_lds();
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 typedef short short2v __attribute__((ext_vector_type(2)));
 static inline int sdot2(short2v a, short2v b, int c) { return c + (int)a.x * (int)b.x + (int)a.y * (int)b.y; }
+static inline unsigned udot4(unsigned a, unsigned b, unsigned c)
+{
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return c;
+}
 static inline short2v cvt_pk_i16(int a, int b)
 {
     short2v r;
@@ -84,6 +89,7 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu::sdot2(a, b, c)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
 #define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu::cvt_pk_i16(a, b)
+#define __builtin_amdgcn_udot4(a, b, c, clamp) hipemu::udot4(a, b, c)
 static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
