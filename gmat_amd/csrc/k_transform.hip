@@ -168,6 +168,37 @@ __global__ __launch_bounds__(256) void flip_kernel(const uint8_t *src, int ss, u
     lds_to_row(dst + (size_t)y * ds, x0 * BPP, tw * BPP, out[wave], lane, 64, aligned);
 }
 
+// Direct (LDS-free) flips for the common aligned case (rows dword aligned, width a multiple of 4 pixels):
+// a thread moves 4 pixels; the horizontal mirror of a 4-pixel group is another aligned 4-pixel group, whose
+// pixel order is reversed in registers with v_perm_b32.  A wave reads and writes 768 (rgb24) / 1024 (rgba)
+// contiguous bytes per instruction.
+template <int BPP>
+__global__ __launch_bounds__(256) void flip_direct_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
+                                                          int w, int h, int fh, int fv)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int sy = fv ? h - 1 - y : y, sx = fh ? w - 4 - x : x;
+    const uint8_t *s = src + (size_t)sy * ss + (size_t)sx * BPP;
+    uint8_t *d = dst + (size_t)y * ds + (size_t)x * BPP;
+    if (BPP == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(s);
+        *reinterpret_cast<uint4 *>(d) = fh ? make_uint4(v.w, v.z, v.y, v.x) : v;
+    } else {
+        const uint3 v = *reinterpret_cast<const uint3 *>(s);
+        uint3 o = v;
+        if (fh) {
+            // pixels a b c d = bytes a0 a1 a2 b0 | b1 b2 c0 c1 | c2 d0 d1 d2  ->  d c b a
+            o.x = __builtin_amdgcn_perm(v.y, v.z, 0x06030201u);                       // d0 d1 d2 c0
+            const unsigned lo = __builtin_amdgcn_perm(v.z, v.y, 0x0C0C0403u);         // c1 c2
+            const unsigned hi = __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0403u);         // b0 b1
+            o.y = __builtin_amdgcn_perm(hi, lo, 0x05040100u);                         // c1 c2 b0 b1
+            o.z = __builtin_amdgcn_perm(v.y, v.x, 0x02010005u);                       // b2 a0 a1 a2
+        }
+        *reinterpret_cast<uint3 *>(d) = o;
+    }
+}
+
 // ---- 3x3 convolution with vf_convolution's borders; optional transposed store ------------------
 // sum = sum_i c[i]*m[i];  out = clip_u8((int)(sum * rdiv + bias + 0.5f))   (vf_convolution.c:495-512)
 // border (setup_3x3, :555-569): index -1 -> 1 (reflect-101), index n -> n-1 (edge repeated).
@@ -316,8 +347,16 @@ int launch_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, 
                 hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return 0;
-    const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
     const int aligned = al4(src, ss, dst, ds);
+    if (aligned && w % 4 == 0 && (bpp == 3 || ((((uintptr_t)src | (uintptr_t)ss | (uintptr_t)dst | (uintptr_t)ds) & 15) == 0))) {
+        const dim3 dgrid((w + 255) / 256, (h + 3) / 4), dblock(64, 4);
+        if (bpp == 3)      hipLaunchKernelGGL(flip_direct_kernel<3>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
+        else if (bpp == 4) hipLaunchKernelGGL(flip_direct_kernel<4>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
+        else return GMAT_ERR(ENOSYS);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
     if (bpp == 3)      hipLaunchKernelGGL(flip_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
     else if (bpp == 4) hipLaunchKernelGGL(flip_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
     else return GMAT_ERR(ENOSYS);
