@@ -62,6 +62,7 @@ def parse():
                     help="concurrent HIP streams (or graph branches) the independent frames of a step are spread over")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the pinned-host upload/compute/download leg")
     ap.add_argument("--cpu-frames", type=int, default=48)
     return ap.parse_args()
 
@@ -181,6 +182,32 @@ def time_single_kernel(lib, torch, runner_fn, stream, reps):
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
     return float(ms.value) / reps
+
+
+def host_pipeline(lib, nframes=96, depth=4):
+    """PCIe-inclusive rate: pinned host NV12 in -> HBM -> scale -> HBM -> pinned host RGB24 out, copies on their own
+    streams overlapping the kernels (gmat_amd/pipeline.py).  Never the headline `value`."""
+    from gmat_amd.pipeline import FramePipeline
+    p = FramePipeline(lib, SRC_W, SRC_H, "nv12", DST_W, DST_H, "rgb24", depth=depth)
+    import numpy as np
+    for k in range(depth):                                   # synthetic content in every ring slot
+        f = p.host_input(k)
+        for pl, rows in ((0, SRC_H), (1, SRC_H // 2)):
+            v = np.ctypeslib.as_array(C.cast(f.data[pl], C.POINTER(C.c_uint8)), (rows, f.linesize[pl]))
+            v[...] = np.random.default_rng(k * 2 + pl).integers(0, 256, v.shape, dtype=np.uint8)
+    for _ in range(2 * depth):
+        p.submit()
+    p.drain()
+    t0 = time.perf_counter()
+    for _ in range(nframes):
+        p.submit()
+    p.drain()
+    dt = time.perf_counter() - t0
+    p.close()
+    return {"value": round(nframes * PX / dt / 1e9, 3), "unit": "Gpix/s", "frames": nframes, "ring_depth": depth,
+            "pcie_GBps_in": round(nframes * BYTES_NV12 / dt / 1e9, 2), "pcie_GBps_out": round(nframes * BYTES_RGB_DST / dt / 1e9, 2),
+            "note": "pinned host frames, upload / compute / download on three streams chained by events; bounded by "
+                    "PCIe Gen5 x16 (63 GB/s spec), not by the kernels"}
 
 
 def cpu_baseline(nframes):
@@ -327,6 +354,8 @@ def main():
         lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
         ch.close()
 
+    if rank == 0 and world == 1 and not a.no_pipeline:
+        out["host_pipeline"] = host_pipeline(lib)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.cpu_frames)
     elif rank == 0:

@@ -105,6 +105,37 @@ int gmat_device_sync(void)
     return 0;
 }
 
+int gmat_event_create(void **event)
+{
+    hipEvent_t e;
+    GMAT_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *)e;
+    return 0;
+}
+
+int gmat_event_record(void *event, void *stream)
+{
+    GMAT_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return 0;
+}
+
+int gmat_stream_wait_event(void *stream, void *event)
+{
+    GMAT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
+int gmat_event_sync(void *event)
+{
+    GMAT_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+    return 0;
+}
+
+void gmat_event_destroy(void *event)
+{
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
 int gmat_timer_create(void **timer)
 {
     GmatTimer *t = new (std::nothrow) GmatTimer();

@@ -91,6 +91,11 @@ _SIGS = {
     "gmat_stream_destroy": (C.c_int, [C.c_void_p]),
     "gmat_stream_sync": (C.c_int, [C.c_void_p]),
     "gmat_device_sync": (C.c_int, []),
+    "gmat_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gmat_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gmat_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gmat_event_sync": (C.c_int, [C.c_void_p]),
+    "gmat_event_destroy": (None, [C.c_void_p]),
     "gmat_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gmat_timer_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gmat_timer_end": (C.c_int, [C.c_void_p, C.c_void_p]),

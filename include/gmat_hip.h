@@ -218,6 +218,12 @@ GMAT_API int  gmat_stream_create(void **stream);
 GMAT_API int  gmat_stream_destroy(void *stream);
 GMAT_API int  gmat_stream_sync(void *stream);
 GMAT_API int  gmat_device_sync(void);
+/* events for cross-stream ordering (upload stream -> compute stream -> download stream) */
+GMAT_API int  gmat_event_create(void **event);
+GMAT_API int  gmat_event_record(void *event, void *stream);
+GMAT_API int  gmat_stream_wait_event(void *stream, void *event);
+GMAT_API int  gmat_event_sync(void *event);
+GMAT_API void gmat_event_destroy(void *event);
 /* hipEvent pair timing on `stream`: begin/end bracket a region, elapsed in milliseconds */
 GMAT_API int  gmat_timer_create(void **timer);
 GMAT_API int  gmat_timer_begin(void *timer, void *stream);
