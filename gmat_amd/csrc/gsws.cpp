@@ -261,7 +261,15 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
 
     const bool same = srcW == dstW && srcH == dstH;
     int r = 0;
-    if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat)) {
+    if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat) && (c->flags & GMAT_SWS_ACCURATE_RND)) {
+        // libswscale takes its nearest-chroma special converter only for planar sources without
+        // SWS_ACCURATE_RND (swscale_unscaled.c:2094-2100); with the flag (and always for NV12) the CPU runs the
+        // generic path, which interpolates chroma vertically.  Opting in with the flag gives exactly that.
+        c->mode = MODE_SCALE;
+        c->fused = 2;
+        r = ensure_scaler(c);
+        if (r == 0 && c->fused != 2) r = GMAT_ERR(ENOSYS);
+    } else if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat)) {
         c->mode = MODE_YUV2RGB;
     } else if (same && srcFormat == GMAT_PIX_FMT_NV12 && dstFormat == GMAT_PIX_FMT_RGBPF32LE) {
         c->mode = MODE_RGBPF32;

@@ -64,7 +64,9 @@ enum GmatPixelFormat {
  *
  *    Semantics are libswscale's CPU arithmetic (SURVEY.md §0 lists why the reference GPU
  *    arithmetic is not the parity target):
- *      - same size, YUV -> RGB: nearest-chroma fixed-point yuv2rgb (yuv2rgb.c:346-405), bit-exact
+ *      - same size, YUV -> RGB: nearest-chroma fixed-point yuv2rgb (yuv2rgb.c:346-405), bit-exact;
+ *        with GMAT_SWS_ACCURATE_RND: libswscale's generic path instead (vertical chroma interpolation), which
+ *        is what the CPU runs for NV12 always and for planar sources with that flag (swscale_unscaled.c:2094)
  *      - same size, RGB24 <-> BGR24: byte swap (rgb2rgb_template.c)
  *      - everything else: the generic scaler (swscale.c:234-520) in integer arithmetic, bit-exact
  *        with the portable C build (filterAlign 1); a YUV source with a different output size is

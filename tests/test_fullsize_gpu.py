@@ -1,0 +1,98 @@
+"""BASELINE.json's full sizes on the GPU: bit-exact against the oracle where it finishes in seconds, plus
+size-independent properties (involutions, linearity of re-layouts, padding canaries).  GPU only: the CPU
+emulation would need minutes at these sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, synth_planes, DevPlane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gpu(dev):
+    if dev.kind != "hip":
+        pytest.skip("full-size tests run on the real GPU only")
+    return dev
+
+
+def test_cfg2_1080p_nv12_to_rgb24(gpu, orc):
+    w, h = 1920, 1080
+    src = synth_planes(orc, "nv12", w, h, seed=7)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, w, h, "nv12", w, h, "rgb24", dst_align=256)
+    assert k == "yuv2rgb_kernel" and (got[0] == orc.yuv2rgb(src, w, h, "nv12", "rgb24")).all()
+
+
+@pytest.mark.parametrize("fused,oracle", [(2, "single"), (1, "chained"), (0, "chained")])
+def test_cfg3_4k_nv12_to_1080p_rgb24_bicubic(gpu, orc, fused, oracle):
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = synth_planes(orc, "nv12", sw, sh, seed=11)
+    want = (orc.sws(src, sw, sh, "nv12", dw, dh, "rgb24") if oracle == "single"
+            else orc.chained(src, sw, sh, "nv12", dw, dh, "rgb24"))[0]
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, "rgb24", fused=fused, dst_align=256)
+    bad = np.argwhere(got[0] != want)
+    assert bad.size == 0, f"{k}: {len(bad)} mismatching bytes, first {bad[:3].tolist()}"
+    assert (pads[0] == 0xCD).all()
+    if fused == 2:
+        assert k == "scale_yuv2x_kernel"
+
+
+def test_cfg3_rgb24_4k_to_1080p_lanczos(gpu, orc):
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = synth_planes(orc, "rgb24", sw, sh, seed=13)
+    want = orc.sws(src, sw, sh, "rgb24", dw, dh, "rgb24", SWS["lanczos"])[0]
+    d = gpu.upload_planes(src, 256)
+    got, _, _ = gpu.sws(d, sw, sh, "rgb24", dw, dh, "rgb24", SWS["lanczos"], dst_align=256)
+    assert (got[0] == want).all()
+
+
+def test_cfg4_4k_rotate_flip_smooth(gpu, orc):
+    w, h, bpp = 3840, 2160, 3
+    src = orc.lcg((h, w * bpp), 17)
+    a = np.zeros((w, h * bpp), np.uint8)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)
+    b = np.zeros_like(a)
+    orc.L.orc_hflip(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], h, w, bpp)
+    want = np.zeros_like(a)
+    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+    orc.L.orc_conv3x3(b.ctypes.data, b.strides[0], want.ctypes.data, want.strides[0], h, w, bpp, m, 1 / 16, 0.0)
+    lib = gpu.lib
+    d = gpu.upload_planes([src], 256)[0]
+    s1 = DevPlane(gpu, w, h * bpp, (h * bpp + 255) // 256 * 256)
+    s2 = DevPlane(gpu, w, h * bpp, s1.stride)
+    s3 = DevPlane(gpu, w, h * bpp, s1.stride)
+    fused = DevPlane(gpu, w, h * bpp, s1.stride)
+    assert lib.gmat_transpose(d.ptr, d.stride, s1.ptr, s1.stride, w, h, bpp, 1, None) == 0
+    assert lib.gmat_flip(s1.ptr, s1.stride, s2.ptr, s2.stride, h, w, bpp, 1, None) == 0
+    assert lib.gmat_smooth3x3(s2.ptr, s2.stride, s3.ptr, s3.stride, h, w, bpp, m, 1 / 16, 0.0, None) == 0
+    assert lib.gmat_rotate_flip_smooth(d.ptr, d.stride, fused.ptr, fused.stride, w, h, bpp, None) == 0
+    assert (s3.download() == want).all(), "three-filter chain differs from the CPU filters"
+    assert (fused.download() == want).all(), "fused kernel differs from the CPU filters"
+    # involutions: transpose(clock) then transpose(cclock) and double flips give the source back
+    back = DevPlane(gpu, h, w * bpp, d.stride)
+    assert lib.gmat_transpose(s1.ptr, s1.stride, back.ptr, back.stride, h, w, bpp, 2, None) == 0
+    assert (back.download() == src).all()
+    f1 = DevPlane(gpu, h, w * bpp, d.stride); f2 = DevPlane(gpu, h, w * bpp, d.stride)
+    for code in (0, 1, -1):
+        assert lib.gmat_flip(d.ptr, d.stride, f1.ptr, f1.stride, w, h, bpp, code, None) == 0
+        assert lib.gmat_flip(f1.ptr, f1.stride, f2.ptr, f2.stride, w, h, bpp, code, None) == 0
+        assert (f2.download() == src).all()
+
+
+def test_rgb_to_nv12_4k_and_relayout_round_trip(gpu, orc):
+    w, h = 3840, 2160
+    src = synth_planes(orc, "rgb24", w, h, seed=19)
+    want = orc.sws(src, w, h, "rgb24", w, h, "nv12")
+    d = gpu.upload_planes(src, 256)
+    got, _, _ = gpu.sws(d, w, h, "rgb24", w, h, "nv12", dst_align=256)
+    assert all((g == wv).all() for g, wv in zip(got, want))
+    # nv12 -> yuv420p -> nv12 is the identity
+    dn = gpu.upload_planes(got, 256)
+    p, _, _ = gpu.sws(dn, w, h, "nv12", w, h, "yuv420p", dst_align=256)
+    dp = gpu.upload_planes(p, 256)
+    n2, _, _ = gpu.sws(dp, w, h, "yuv420p", w, h, "nv12", dst_align=256)
+    assert all((a == b).all() for a, b in zip(n2, got))

@@ -163,3 +163,18 @@ def test_yuv2x_dst_formats_and_bilinear(dev, orc, dst_fmt):
         got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, dst_fmt, SWS[flags], dst_align=256)
         assert kernel == "scale_yuv2x_kernel"
         assert (got[0] == want).all() and (pads[0] == 0xCD).all()
+
+
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("w,h", [(128, 48), (66, 34), (258, 20)])
+def test_same_size_generic_path_with_accurate_rnd(dev, orc, src_fmt, w, h):
+    """SWS_ACCURATE_RND on a same-size YUV->RGB context = libswscale's generic path (bicubic vertical chroma),
+    SURVEY.md 8f.2; without the flag the nearest-chroma converter is used."""
+    src = synth_planes(orc, src_fmt, w, h, seed=61)
+    want = orc.sws(src, w, h, src_fmt, w, h, "rgb24", SWS["bicubic"])[0]
+    d_src = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, "rgb24", SWS["bicubic"] | SWS["accurate_rnd"], dst_align=64)
+    assert kernel.startswith("scale_yuv")
+    assert (got[0] == want).all() and (pads[0] == 0xCD).all()
+    got2, _, kernel2 = dev.sws(d_src, w, h, src_fmt, w, h, "rgb24", SWS["bicubic"], dst_align=64)
+    assert kernel2 == "yuv2rgb_kernel" and (got2[0] != want).any()
