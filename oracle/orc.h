@@ -18,19 +18,27 @@
  *                               yuv2planeX_8_c / yuv2plane1_8_c / yuv2nv12cX_c
  *   libavfilter/vf_transpose.c, vf_hflip.c, vf_vflip.c, vf_crop.c, vf_convolution.c
  *
- * PARITY PIN STATUS: the reference's libswscale cannot be
- * built in this image without generated headers (config.h) and stand-ins for cuda.h /
- * CV-CUDA, so no oracle/_ref exists.  The oracle is pinned by
- *   (1) known-answer values the survey recorded from the reference run (SURVEY.md §8a
- *       row 7, §8c item 5): filter sizes, coefficient rows and positions for
- *       3840->1920 / 2160->1080 bicubic and the 540->1080 chroma filter;
- *   (2) constants that are literal in the reference sources (ff_yuv2rgb_coeffs,
- *       BT.601 rgb2yuv literals);
- *   (3) the LUT path and the closed form being two independent restatements that must
- *       agree over all 2^24 (Y,U,V) triples.
- * The reference's FATE references for this path are NUT-container md5s
- * (tests/ref/fate/filter-pixfmts-*), which cannot be reproduced without restating the
- * muxer; they are not used.  Parity is therefore "partially pinned".
+ * PARITY PIN STATUS: the reference's libswscale cannot be built in this
+ * image without generated headers (config.h) and stand-ins for cuda.h / CV-CUDA, so no
+ * oracle/_ref exists.  The oracle is pinned against the reference's OWN golden values:
+ *   (1) FATE checksums the reference tree ships (tests/ref/fate, tests/ref/pixfmt), reproduced
+ *       bit-for-bit by tests/test_oracle_fate.py from the restated vsynth1 clip (orc_vsynth.c):
+ *         filter-transpose (50 frames)    -> orc_transpose
+ *         sws-yuv-range                   -> 1-tap hScale8To15, range conversion, yuv2plane1_8
+ *         filter-scalechroma (25 frames)  -> initFilter with chroma positions, hScale8To15,
+ *                                            yuv2planeX_8 (2:1 bicubic, the headline geometry)
+ *         filter-colorlevels (50 frames)  -> yuv420p->rgb24 generic path: yuv2rgb_X_c and the
+ *                                            yuv2rgb.c tables shared with the fast path
+ *         pixfmt-rgb24 / -bgr24 / -yuv420p -> rgb24ToY/ToUV, hScale16To15, chroma up-scaling
+ *   (2) known-answer values the survey recorded from the reference (SURVEY.md §8a row 7,
+ *       §8c item 5) and constants literal in its sources (ff_yuv2rgb_coeffs, BT.601 literals);
+ *   (3) the LUT path and the closed form being two independent restatements that must agree
+ *       over all 2^24 (Y,U,V) triples.
+ * Not covered by a reference golden value (pinned only by construction from pinned parts):
+ * the yuv2rgb_full_* (FULL_CHR_H_INT) outputs, the Lanczos branch of initFilter, the nearest-
+ * chroma frame walk of yuv2rgb_c_24_* (its tables are pinned by filter-colorlevels), ToUV_half,
+ * hflip/vflip/crop/convolution (their FATE references are NUT-container md5s, which would need
+ * the muxer restated).
  */
 #ifndef GMAT_ORACLE_ORC_H
 #define GMAT_ORACLE_ORC_H
@@ -46,6 +54,7 @@ enum {
     ORC_PIX_YUV420P = 0,
     ORC_PIX_RGB24   = 2,
     ORC_PIX_BGR24   = 3,
+    ORC_PIX_YUV444P = 5,      /* oracle only: needed to reproduce the reference's FATE values */
     ORC_PIX_NV12    = 23,
     ORC_PIX_RGBA    = 26,
     ORC_PIX_BGRA    = 28,
@@ -112,6 +121,8 @@ void orc_free(void *p);
 typedef struct OrcSws OrcSws;
 OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
                        int flags, const double param[2]);
+OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
+                          int flags, const double param[2], const int chr_pos[4], int src_range, int dst_range);
 int   orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
                     uint8_t *const dst[4], const int dst_stride[4]);
 /* row-sliced variant for the threaded cpu baseline: computes output rows [y0,y1) */
@@ -138,6 +149,9 @@ void orc_conv3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_strid
                  int w, int h, int bpp, const int matrix[9], float rdiv, float bias);
 void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                        int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
+
+/* tests/videogen.c + tests/utils.c: frames [0,nframes) of the reference's vsynth1 clip, yuv420p */
+int orc_vsynth1(uint8_t *out, int w, int h, int nframes);
 
 /* deterministic synthetic planes: s = s*1664525 + 1013904223, byte = s>>24 */
 void orc_fill_lcg(uint8_t *p, long n, uint32_t seed);

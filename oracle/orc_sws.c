@@ -36,6 +36,7 @@ struct OrcSws {
     int32_t *h_lum_pos, *h_chr_pos, *v_lum_pos, *v_chr_pos;
     int h_lum_size, h_chr_size, v_lum_size, v_chr_size;
     int src_is_rgb, dst_is_rgb;
+    int range_conv;            /* 0 none, 1 limited->full (ToJpeg), 2 full->limited (FromJpeg) */
     int32_t ry, gy, by, ru, gu, bu, rv, gv, bv;
     OrcYuv2Rgb y2r;
 };
@@ -43,7 +44,8 @@ struct OrcSws {
 #define RGB2YUV_SHIFT 15    /* swscale_internal.h:452 */
 
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
-static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P; }
+static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
+static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
 static int ceil_rshift(int a, int b) { return -((-a) >> b); }
 static int clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 static int clip_uintp2_30(int a)
@@ -119,6 +121,17 @@ void orc_sws_free(OrcSws *c)
 OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
                        int flags, const double param[2])
 {
+    static const int def_pos[4] = { -513, -513, -513, -513 };
+    return orc_sws_create_ex(src_w, src_h, src_fmt, dst_w, dst_h, dst_fmt, flags, param, def_pos, 0, 0);
+}
+
+/* chr_pos = { src_h_chr_pos, src_v_chr_pos, dst_h_chr_pos, dst_v_chr_pos } (AVOptions of the same
+ * names, options.c:67-70; -513 = unset).  src_range / dst_range: 1 = full ("jpeg") range; only the
+ * yuv->yuv lum/chrConvertRange hooks are restated (swscale.c:157-187, selection :530-556), the
+ * RGB ends keep the limited-range BT.601 tables. */
+OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, int dst_fmt,
+                          int flags, const double param[2], const int chr_pos[4], int src_range, int dst_range)
+{
     OrcSws *c;
     int scaler_mask = ORC_SWS_FAST_BILINEAR | ORC_SWS_BILINEAR | ORC_SWS_BICUBIC | 8 | ORC_SWS_POINT |
                       ORC_SWS_AREA | 0x40 | 0x80 | 0x100 | ORC_SWS_LANCZOS | 0x400;
@@ -142,8 +155,12 @@ OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, 
     c->lum_x_inc = (int)((((int64_t)src_w << 16) + (dst_w >> 1)) / dst_w);
     c->lum_y_inc = (int)((((int64_t)src_h << 16) + (dst_h >> 1)) / dst_h);
 
-    c->chr_src_hsub = c->chr_src_vsub = c->src_is_rgb ? 0 : 1;
-    c->chr_dst_hsub = c->chr_dst_vsub = c->dst_is_rgb ? 0 : 1;
+    c->chr_src_hsub = c->chr_src_vsub = fmt_sub(src_fmt);
+    c->chr_dst_hsub = c->chr_dst_vsub = fmt_sub(dst_fmt);
+    if (src_range != dst_range) {
+        if (c->src_is_rgb || c->dst_is_rgb) { free(c); return NULL; }
+        c->range_conv = dst_range ? 1 : 2;
+    }
 
     if (c->dst_is_rgb && !(flags & ORC_SWS_FULL_CHR_H_INT)) {      /* utils.c:1431-1448 */
         if (dst_w & 1)
@@ -172,12 +189,12 @@ OrcSws *orc_sws_create(int src_w, int src_h, int src_fmt, int dst_w, int dst_h, 
                         flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
     if (orc_init_filter(&c->h_chr, &c->h_chr_pos, &c->h_chr_size, c->chr_x_inc, c->chr_src_w, c->chr_dst_w,
                         1, 1 << 14, flags, param,
-                        get_local_pos(c->chr_src_hsub, -513), get_local_pos(c->chr_dst_hsub, -513)) < 0) goto fail;
+                        get_local_pos(c->chr_src_hsub, chr_pos[0]), get_local_pos(c->chr_dst_hsub, chr_pos[2])) < 0) goto fail;
     if (orc_init_filter(&c->v_lum, &c->v_lum_pos, &c->v_lum_size, c->lum_y_inc, src_h, dst_h, 1, 1 << 12,
                         flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
     if (orc_init_filter(&c->v_chr, &c->v_chr_pos, &c->v_chr_size, c->chr_y_inc, c->chr_src_h, c->chr_dst_h,
                         1, 1 << 12, flags, param,
-                        get_local_pos(c->chr_src_vsub, -513), get_local_pos(c->chr_dst_vsub, -513)) < 0) goto fail;
+                        get_local_pos(c->chr_src_vsub, chr_pos[1]), get_local_pos(c->chr_dst_vsub, chr_pos[3])) < 0) goto fail;
 
     /* colour tables: BT.601, limited range on both sides (sws_setColorspaceDetails defaults,
      * utils.c:902-1030: RGB ends have their range forced to 0) */
@@ -236,6 +253,32 @@ static void hscale16(int16_t *dst, int dst_w, const uint16_t *src, const int16_t
     }
 }
 
+static int imin(int a, int b) { return a < b ? a : b; }
+
+static void range_lum(const OrcSws *c, int16_t *d, int w)
+{
+    int i;
+    if (c->range_conv == 1)       /* lumRangeToJpeg_c, swscale.c:176-181 */
+        for (i = 0; i < w; i++) d[i] = (int16_t)((imin(d[i], 30189) * 19077 - 39057361) >> 14);
+    else if (c->range_conv == 2)  /* lumRangeFromJpeg_c, :183-188 */
+        for (i = 0; i < w; i++) d[i] = (int16_t)((d[i] * 14071 + 33561947) >> 14);
+}
+
+static void range_chr(const OrcSws *c, int16_t *u, int16_t *v, int w)
+{
+    int i;
+    if (c->range_conv == 1)       /* chrRangeToJpeg_c, :157-164 */
+        for (i = 0; i < w; i++) {
+            u[i] = (int16_t)((imin(u[i], 30775) * 4663 - 9289992) >> 12);
+            v[i] = (int16_t)((imin(v[i], 30775) * 4663 - 9289992) >> 12);
+        }
+    else if (c->range_conv == 2)  /* chrRangeFromJpeg_c, :166-173 */
+        for (i = 0; i < w; i++) {
+            u[i] = (int16_t)((u[i] * 1799 + 4081085) >> 11);
+            v[i] = (int16_t)((v[i] * 1799 + 4081085) >> 11);
+        }
+}
+
 static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y,
                      int16_t *out, uint16_t *tmp)
 {
@@ -251,6 +294,7 @@ static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int str
     } else {
         hscale8(out, c->dst_w, row, c->h_lum, c->h_lum_pos, c->h_lum_size);
     }
+    range_lum(c, out, c->dst_w);               /* hscale.c:60-61 */
 }
 
 static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y,
@@ -299,6 +343,7 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
         hscale8(out_u, c->chr_dst_w, src[1] + (long)y * stride[1], c->h_chr, c->h_chr_pos, c->h_chr_size);
         hscale8(out_v, c->chr_dst_w, src[2] + (long)y * stride[2], c->h_chr, c->h_chr_pos, c->h_chr_size);
     }
+    range_chr(c, out_u, out_v, c->chr_dst_w);  /* hscale.c:193-194 */
 }
 
 /* ---- output stage ------------------------------------------------------------------------ */
@@ -484,7 +529,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     if (y1 > c->dst_h) y1 = c->dst_h;
     if (y0 >= y1) return 0;
     /* planar 4:2:0 output rows come in pairs sharing one chroma row */
-    if (!c->dst_is_rgb && (y0 & 1)) return -1;
+    if (!c->dst_is_rgb && c->chr_dst_vsub && (y0 & 1)) return -1;
 
     cy0 = y0 >> c->chr_dst_vsub;
     cy1 = ((y1 - 1) >> c->chr_dst_vsub) + 1;
@@ -531,7 +576,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
         } else {
             out_plane_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size,
                           c->v_lum_size, lp, 0);
-            if (!(y & 1)) {
+            if (!c->chr_dst_vsub || !(y & 1)) {
                 const int16_t *cf = c->v_chr + chr_y * c->v_chr_size;
                 if (c->dst_fmt == ORC_PIX_NV12) {
                     out_nv12_chroma_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, vp);
