@@ -39,6 +39,26 @@ int parse_pix_fmt(const std::string &s)
     return end && *end == 0 ? (int)v : -2;
 }
 
+// Per-plane geometry of a frame.  Packed RGB: one plane of bpp-byte pixels.  Planar / semi-planar 4:2:0
+// (an extension: the reference lists NV12 / YUV420P as intended but disabled, vf_crop_nvcv.c:91-94): the
+// geometric filters act on each plane like the CPU filters do (vf_hflip.c:89-117 per plane with the chroma
+// shifts; vf_transpose.c:267-327; vf_crop.c:300-304), the NV12 chroma plane as 2-byte samples.
+struct PlaneGeom { int bpp, w, h, sub; };
+
+int plane_geoms(int fmt, int w, int h, PlaneGeom g[3])
+{
+    if (fmt == GMAT_PIX_FMT_YUV420P) {
+        g[0] = {1, w, h, 0}; g[1] = g[2] = {1, (w + 1) >> 1, (h + 1) >> 1, 1};
+        return 3;
+    }
+    if (fmt == GMAT_PIX_FMT_NV12) {
+        g[0] = {1, w, h, 0}; g[1] = {2, (w + 1) >> 1, (h + 1) >> 1, 1};
+        return 2;
+    }
+    g[0] = {bytes_per_pixel(fmt), w, h, 0};
+    return 1;
+}
+
 } // namespace
 
 struct GmatFilterContext {
@@ -181,7 +201,7 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     f->stream = (hipStream_t)stream;
     f->out_w = f->in_w; f->out_h = f->in_h; f->out_fmt = f->in_fmt;
     const bool nvcv_style = f->kind != K_SCALE && f->kind != K_FORMAT;
-    if (nvcv_style && !is_packed_rgb(f->in_fmt)) {
+    if (nvcv_style && !is_packed_rgb(f->in_fmt) && !is_yuv420(f->in_fmt)) {
         logf(LOG_ERROR, "%s: Unsupported input format: %d", f->name.c_str(), f->in_fmt);
         return GMAT_ERR(ENOSYS);
     }
@@ -189,6 +209,10 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     case K_CROP:
         if (f->x == -1) f->x = (f->in_w - f->w) / 2;
         if (f->y == -1) f->y = (f->in_h - f->h) / 2;
+        if (is_yuv420(f->in_fmt)) {          // chroma-grid alignment, vf_crop.c:186-187,:223-224
+            f->w &= ~1; f->h &= ~1; f->x &= ~1; f->y &= ~1;
+            if (f->w <= 0 || f->h <= 0) return GMAT_ERR(EINVAL);
+        }
         if (f->x < 0 || f->y < 0 || f->w + f->x > f->in_w || f->h + f->y > f->in_h) {
             logf(LOG_ERROR, "crop_hip: The cropping area cannot fall out of the image border");
             return GMAT_ERR(EINVAL);
@@ -249,38 +273,43 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
     out = gmat_frame_alloc();
     if (!out) { r = GMAT_ERR(ENOMEM); goto fail; }
     if ((r = gmat_hwframe_get_buffer(f->out_frames, out)) < 0) goto fail;
-    {
-        const int bpp = bytes_per_pixel(f->in_fmt);
-        const uint8_t *s = in->data[0];
-        const int ss = in->linesize[0], ds = out->linesize[0];
-        uint8_t *d = out->data[0];
-        switch (f->kind) {
-        case K_CROP:
-            r = launch_copy2d(s + (size_t)f->y * ss + (size_t)f->x * bpp, ss, d, ds, f->w * bpp, f->h, f->stream);
-            break;
-        case K_FLIP:
-            r = launch_flip(s, ss, d, ds, f->in_w, f->in_h, bpp, f->code != 0, f->code <= 0, f->stream);
-            break;
-        case K_TRANSPOSE:
-            r = launch_transpose(s, ss, d, ds, f->in_w, f->in_h, bpp, f->dir, f->stream);
-            break;
-        case K_ROTATE:
-            switch (f->quarter) {
-            case 0: r = launch_copy2d(s, ss, d, ds, f->in_w * bpp, f->in_h, f->stream); break;
-            case 1: r = launch_transpose(s, ss, d, ds, f->in_w, f->in_h, bpp, 1, f->stream); break;   // clock
-            case 2: r = launch_flip(s, ss, d, ds, f->in_w, f->in_h, bpp, 1, 1, f->stream); break;
-            case 3: r = launch_transpose(s, ss, d, ds, f->in_w, f->in_h, bpp, 2, f->stream); break;   // cclock
+    if (f->kind == K_SCALE || f->kind == K_FORMAT) {
+        r = gmat_sws_scale(f->sws, in->data, in->linesize, 0, f->in_h, out->data, out->linesize);
+    } else {
+        PlaneGeom g[3];
+        const int np = plane_geoms(f->in_fmt, f->in_w, f->in_h, g);
+        r = 0;
+        for (int i = 0; i < np && r >= 0; i++) {
+            const int bpp = g[i].bpp, pw = g[i].w, ph = g[i].h, sub = g[i].sub;
+            const uint8_t *s = in->data[i];
+            const int ss = in->linesize[i], ds = out->linesize[i];
+            uint8_t *d = out->data[i];
+            switch (f->kind) {
+            case K_CROP:
+                r = launch_copy2d(s + (size_t)(f->y >> sub) * ss + (size_t)(f->x >> sub) * bpp, ss, d, ds,
+                                  ((f->w + sub) >> sub) * bpp, (f->h + sub) >> sub, f->stream);
+                break;
+            case K_FLIP:
+                r = launch_flip(s, ss, d, ds, pw, ph, bpp, f->code != 0, f->code <= 0, f->stream);
+                break;
+            case K_TRANSPOSE:
+                r = launch_transpose(s, ss, d, ds, pw, ph, bpp, f->dir, f->stream);
+                break;
+            case K_ROTATE:
+                switch (f->quarter) {
+                case 0: r = launch_copy2d(s, ss, d, ds, pw * bpp, ph, f->stream); break;
+                case 1: r = launch_transpose(s, ss, d, ds, pw, ph, bpp, 1, f->stream); break;   // clock
+                case 2: r = launch_flip(s, ss, d, ds, pw, ph, bpp, 1, 1, f->stream); break;
+                case 3: r = launch_transpose(s, ss, d, ds, pw, ph, bpp, 2, f->stream); break;   // cclock
+                }
+                break;
+            case K_SMOOTH: {
+                static const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+                r = launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
+                break;
             }
-            break;
-        case K_SMOOTH: {
-            static const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
-            r = launch_conv3x3(s, ss, d, ds, f->in_w, f->in_h, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
-            break;
-        }
-        case K_SCALE:
-        case K_FORMAT:
-            r = gmat_sws_scale(f->sws, in->data, in->linesize, 0, f->in_h, out->data, out->linesize);
-            break;
+            default: break;
+            }
         }
     }
     if (r < 0) goto fail;

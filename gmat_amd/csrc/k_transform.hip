@@ -116,11 +116,10 @@ __device__ __forceinline__ void tile_to_lds(const uint8_t *src, int ss, int rowB
 }
 
 // ---- transpose (+ optional source/destination vertical reversal = the four transpose dirs) -----
-template <int BPP>
+template <int BPP, int T>
 __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
                                                         int inW, int inH, int dir, int aligned)
 {
-    constexpr int T = 64;
     constexpr int PITCH = T * BPP + 4;                  // +4 B: odd dword pitch, conflict-light columns
     __shared__ __attribute__((aligned(16))) uint8_t tile[T * PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t orow[4][T * BPP];                // per-wave output row staging
@@ -221,9 +220,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
                                                       int w, int h, ConvParams cp, int aligned, int fastCoef)
 {
     // The source tile holds pixels [x0-1, x0+TW] of rows [y0-1, y0+TH].  x0 is a multiple of 64, so the
-    // first source byte (x0-1)*BPP is 1 (mod 4) for 3-byte pixels and 0 for 4-byte pixels: SHIFT re-aligns
-    // the tile so that global dwords map to LDS dwords (one ds_write_b32 per loaded dword).
-    constexpr int SHIFT = BPP == 3 ? 1 : 0;
+    // first source byte (x0-1)*BPP is (4-BPP) (mod 4) — 3, 2, 1, 0 for 1-, 2-, 3-, 4-byte pixels: SHIFT
+    // re-aligns the tile so that global dwords map to LDS dwords (one ds_write_b32 per loaded dword).
+    constexpr int SHIFT = (4 - BPP) & 3;
     constexpr int SP = (((TW + 2) * BPP + SHIFT + 3) / 4) * 4 + 4;     // source tile pitch, odd dword count
     constexpr int RP = ((TW * BPP + 3) / 4) * 4 + 4;                   // result tile pitch
     static_assert((SP / 4) % 2 == 1 && (RP / 4) % 2 == 1, "odd dword pitches keep column accesses conflict-light");
@@ -334,10 +333,15 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
 {
     if (inW <= 0 || inH <= 0) return 0;
     if (dir < 0 || dir > 3) return GMAT_ERR(EINVAL);
-    const dim3 grid((inW + 63) / 64, (inH + 63) / 64), block(256);
+    // 1- and 2-byte samples (the planes of planar / semi-planar YUV) use 128x128 tiles so that a tile row
+    // is still >= 128 B of contiguous HBM traffic
+    const int T = bpp <= 2 ? 128 : 64;
+    const dim3 grid((inW + T - 1) / T, (inH + T - 1) / T), block(256);
     const int aligned = al4(src, ss, dst, ds);
-    if (bpp == 3)      hipLaunchKernelGGL(transpose_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(transpose_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -348,7 +352,7 @@ int launch_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, 
 {
     if (w <= 0 || h <= 0) return 0;
     const int aligned = al4(src, ss, dst, ds);
-    if (aligned && w % 4 == 0 && (bpp == 3 || ((((uintptr_t)src | (uintptr_t)ss | (uintptr_t)dst | (uintptr_t)ds) & 15) == 0))) {
+    if (bpp >= 3 && aligned && w % 4 == 0 && (bpp == 3 || ((((uintptr_t)src | (uintptr_t)ss | (uintptr_t)dst | (uintptr_t)ds) & 15) == 0))) {
         const dim3 dgrid((w + 255) / 256, (h + 3) / 4), dblock(64, 4);
         if (bpp == 3)      hipLaunchKernelGGL(flip_direct_kernel<3>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
         else if (bpp == 4) hipLaunchKernelGGL(flip_direct_kernel<4>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
@@ -359,6 +363,8 @@ int launch_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, 
     const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
     if (bpp == 3)      hipLaunchKernelGGL(flip_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
     else if (bpp == 4) hipLaunchKernelGGL(flip_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
+    else if (bpp == 1) hipLaunchKernelGGL(flip_kernel<1>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
+    else if (bpp == 2) hipLaunchKernelGGL(flip_kernel<2>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -383,10 +389,13 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     cp.shift = -1; cp.half = 0;
     for (int k = 0; k <= 16 && fast; k++)
         if (bias == 0.0f && rdiv == 1.0f / (float)(1 << k)) { cp.shift = k; cp.half = k ? 1u << (k - 1) : 0u; }
-    const dim3 grid((w + 63) / 64, (h + 63) / 64), block(256);
+    const int TW = bpp <= 2 ? 128 : 64;
+    const dim3 grid((w + TW - 1) / TW, (h + 63) / 64), block(256);
     const int aligned = al4(src, ss, dst, ds);
     if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<3, 64, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
     else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<4, 64, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
+    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<1, 128, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
+    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_kernel<2, 128, 64, false>), grid, block, 0, stream, src, ss, dst, ds, w, h, cp, aligned, fast);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -174,7 +174,10 @@ GMAT_API void gmat_host_frame_free(GmatFrame *frame);
  *                   (vf_convolution.c:495-512 arithmetic and :555-569 borders)
  *    scale_hip   <- vf_scale_cuda.c   options w,h,interp_algo,format (:586-603) on top of libgpuscale
  *    format_hip  <- vf_format_cuda.c  option pix_fmt (:69-79)
- *  Input sw formats accepted by the nvcv-style filters: rgb24 bgr24 rgba bgra (vf_crop_nvcv.c:90-98).
+ *  Input sw formats accepted by the nvcv-style filters: rgb24 bgr24 rgba bgra (vf_crop_nvcv.c:90-98)
+ *  and — the two the reference lists but leaves commented out (:91,:94) — nv12 and yuv420p, filtered
+ *  plane by plane like the CPU filters (vf_hflip.c:89-117, vf_transpose.c:267-327; crop aligns
+ *  x,y,w,h down to the chroma grid, vf_crop.c:186-187,:223-224; nv12 chroma = 2-byte samples).
  * ===================================================================================== */
 typedef struct GmatFilterContext GmatFilterContext;
 
@@ -190,7 +193,9 @@ GMAT_API GmatHWFramesContext *gmat_filter_out_frames(GmatFilterContext *f);
 GMAT_API int  gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out);
 GMAT_API void gmat_filter_free(GmatFilterContext *f);                                /* uninit + free */
 
-/* direct launchers behind the filters (device pointers, packed pixels of bpp bytes) */
+/* direct launchers behind the filters (device pointers, packed pixels of bpp bytes; bpp 1..4, where
+ * 1 = one plane of planar YUV, 2 = the interleaved chroma plane of NV12).  gmat_rotate_flip_smooth
+ * takes bpp 3|4 only. */
 GMAT_API int gmat_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                             int inW, int inH, int bpp, int dir, void *stream);
 GMAT_API int gmat_flip(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,

@@ -15,7 +15,7 @@ def _orc_out(rows, row_bytes):
 
 
 @pytest.mark.parametrize("w,h", SIZES)
-@pytest.mark.parametrize("bpp", [3, 4])
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
 @pytest.mark.parametrize("dir", [0, 1, 2, 3])
 def test_transpose(dev, orc, w, h, bpp, dir):
     src = orc.lcg((h, w * bpp), 5)
@@ -31,7 +31,7 @@ def test_transpose(dev, orc, w, h, bpp, dir):
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(300, 5), (513, 4)])
-@pytest.mark.parametrize("bpp", [3, 4])
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
 @pytest.mark.parametrize("code", [0, 1, -1])
 def test_flip(dev, orc, w, h, bpp, code):
     src = orc.lcg((h, w * bpp), 6)
@@ -53,8 +53,8 @@ def test_flip(dev, orc, w, h, bpp, code):
         d.free(); o.free()
 
 
-@pytest.mark.parametrize("w,h", SIZES)
-@pytest.mark.parametrize("bpp", [3, 4])
+@pytest.mark.parametrize("w,h", SIZES + [(300, 5)])
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
 def test_smooth3x3(dev, orc, w, h, bpp):
     src = orc.lcg((h, w * bpp), 8)
     m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
@@ -210,7 +210,101 @@ def test_filter_layer_errors(dev):
     lib.gmat_filter_free(f)
     f = lib.gmat_filter_alloc(b"flip_hip")
     assert lib.gmat_filter_init(f) == 0
-    nv = lib.gmat_hwframe_ctx_create(0, PIX_FMT["nv12"], 64, 64, 0)
-    assert lib.gmat_filter_config_props(f, nv, None) < 0     # nvcv-style filters take packed RGB only
+    nv = lib.gmat_hwframe_ctx_create(0, PIX_FMT["rgbpf32le"], 64, 64, 0)
+    assert lib.gmat_filter_config_props(f, nv, None) < 0     # packed RGB and 8-bit 4:2:0 only
     lib.gmat_filter_free(f)
     lib.gmat_hwframe_ctx_free(nv); lib.gmat_hwframe_ctx_free(fc)
+
+
+# ---- planar / semi-planar 4:2:0 frames through the filter layer (per-plane, like the CPU filters) -----
+def _run_filter_planes(dev, name, opts, src_planes, w, h, fmt):
+    from harness import plane_shapes
+    lib = dev.lib
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT[fmt], w, h, 1)
+    f = lib.gmat_filter_alloc(name.encode())
+    assert fc and f
+    for k, v in opts.items():
+        assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0
+    assert lib.gmat_filter_init(f) == 0
+    assert lib.gmat_filter_config_props(f, fc, None) == 0
+    host = GmatFrame()
+    assert lib.gmat_host_frame_alloc(C.byref(host), PIX_FMT[fmt], w, h) == 0
+    for i, pl in enumerate(src_planes):
+        hv = np.ctypeslib.as_array(C.cast(host.data[i], C.POINTER(C.c_uint8)), (pl.shape[0], host.linesize[i]))
+        hv[:, :pl.shape[1]] = pl
+    fin = lib.gmat_frame_alloc()
+    assert lib.gmat_hwframe_get_buffer(fc, fin) == 0
+    assert lib.gmat_hwframe_transfer_data(fin, C.byref(host), None) == 0
+    out = C.POINTER(GmatFrame)()
+    assert lib.gmat_filter_frame(f, fin, C.byref(out)) == 0 and out
+    o = out.contents
+    hout = GmatFrame()
+    assert lib.gmat_host_frame_alloc(C.byref(hout), o.sw_format, o.width, o.height) == 0
+    assert lib.gmat_hwframe_transfer_data(C.byref(hout), out, None) == 0
+    lib.gmat_device_sync()
+    res = []
+    for i, (rows, rb) in enumerate(plane_shapes(fmt, o.width, o.height)):
+        res.append(np.ctypeslib.as_array(C.cast(hout.data[i], C.POINTER(C.c_uint8)), (rows, hout.linesize[i]))[:, :rb].copy())
+    ow, oh = o.width, o.height
+    lib.gmat_frame_free(C.byref(out))
+    lib.gmat_host_frame_free(C.byref(host)); lib.gmat_host_frame_free(C.byref(hout))
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)
+    return res, ow, oh
+
+
+def _plane_bpp(fmt, i):
+    return 2 if fmt == "nv12" and i == 1 else 1
+
+
+@pytest.mark.parametrize("fmt", ["yuv420p", "nv12"])
+@pytest.mark.parametrize("w,h", [(96, 40), (70, 34)])
+def test_filter_layer_planar_frames(dev, orc, fmt, w, h):
+    src = synth_planes(orc, fmt, w, h, 77)
+
+    def per_plane(fn):
+        outs = []
+        for i, pl in enumerate(src):
+            bpp = _plane_bpp(fmt, i)
+            outs.append(fn(np.ascontiguousarray(pl), pl.shape[1] // bpp, pl.shape[0], bpp))
+        return outs
+
+    def o_transpose(direction):
+        def fn(pl, pw, ph, bpp):
+            want = np.zeros((pw, ph * bpp), np.uint8)
+            orc.L.orc_transpose(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, bpp, direction)
+            return want
+        return fn
+
+    def o_hflip(pl, pw, ph, bpp):
+        want = np.zeros_like(pl)
+        orc.L.orc_hflip(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, bpp)
+        return want
+
+    def o_smooth(pl, pw, ph, bpp):
+        want = np.zeros_like(pl)
+        m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+        orc.L.orc_conv3x3(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, bpp, m, 1 / 16, 0.0)
+        return want
+
+    res, ow, oh = _run_filter_planes(dev, "transpose_hip", {"dir": "clock"}, src, w, h, fmt)
+    assert (ow, oh) == (h, w)
+    for a, b in zip(res, per_plane(o_transpose(1))):
+        assert (a == b).all()
+    res, ow, oh = _run_filter_planes(dev, "rotate_hip", {"angle": -90}, src, w, h, fmt)
+    for a, b in zip(res, per_plane(o_transpose(2))):
+        assert (a == b).all()
+    res, _, _ = _run_filter_planes(dev, "flip_hip", {"code": 1}, src, w, h, fmt)
+    for a, b in zip(res, per_plane(o_hflip)):
+        assert (a == b).all()
+    res, _, _ = _run_filter_planes(dev, "smooth_hip", {"type": "gaussian"}, src, w, h, fmt)
+    for a, b in zip(res, per_plane(o_smooth)):
+        assert (a == b).all()
+    # crop: x, y, w, h are aligned down to the chroma grid like vf_crop.c:186-187,:223-224
+    res, ow, oh = _run_filter_planes(dev, "crop_hip", {"w": 41, "h": 21, "x": 11, "y": 7}, src, w, h, fmt)
+    assert (ow, oh) == (40, 20)
+    assert (res[0] == src[0][6:26, 10:50]).all()
+    if fmt == "nv12":
+        assert (res[1] == src[1][3:13, 10:50]).all()
+    else:
+        assert (res[1] == src[1][3:13, 5:25]).all() and (res[2] == src[2][3:13, 5:25]).all()
