@@ -234,7 +234,7 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
         auto it = f->opt.find("format");
         int fmt = it == f->opt.end() ? GMAT_PIX_FMT_NONE : parse_pix_fmt(it->second);
         if (fmt == -2) return GMAT_ERR(EINVAL);
-        f->out_fmt = fmt == GMAT_PIX_FMT_NONE ? (is_yuv420(f->in_fmt) ? GMAT_PIX_FMT_RGB24 : f->in_fmt) : fmt;
+        f->out_fmt = fmt == GMAT_PIX_FMT_NONE ? f->in_fmt : fmt;      // "same" (vf_scale_cuda.c:594)
         break;
     }
     case K_FORMAT: {

@@ -132,6 +132,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
     std::memset(&a, 0, sizeof(a));
     const YuvScaleTiling &t = c->ytiling;
     const std::vector<int32_t> none(std::max(c->dstW, c->dstH), 0);
+    a.chrDstH = c->planYuv.chrDstH;
+    a.dstNv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
     if ((r = c->yHLum.upload(c->planYuv.hLum, none, a.hLum)) < 0) return r;
     if ((r = c->yHChr.upload(c->planYuv.hChr, none, a.hChr)) < 0) return r;
     if ((r = c->yVLum.upload(c->planYuv.vLum, t.lumRound, a.vLum)) < 0) return r;
@@ -212,6 +214,10 @@ static int init_rgb2yuv(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
+    if (is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) {
+        c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
+        return init_yuv_scaler(c);
+    }
     if (is_yuv420(c->srcFormat) && c->fused == 2) {
         int r = init_yuv_scaler(c);
         if (r == GMAT_ERR(ENOSYS)) {
@@ -285,6 +291,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_YUV2YUV;
     } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
                is_packed_rgb(dstFormat)) {
+        c->mode = MODE_SCALE;
+        r = ensure_scaler(c);
+    } else if (!same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
+        // scale_cuda's main job (vf_scale_cuda.c:428-501): 4:2:0 in, 4:2:0 out at another size.  Arithmetic of
+        // the CPU generic path: hScale8To15_c per plane, yuv2planeX_8_c / yuv2nv12cX_c vertically.
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
     } else {
@@ -444,9 +455,19 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             ya.dst = dst[0]; ya.ds = dstStride[0];
             const int ybpp = bytes_per_pixel(c->dstFormat);
             ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
+            if (is_yuv420(c->dstFormat)) {
+                const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
+                if (!dst[1] || (!dnv && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+                ya.dstU = dst[1]; ya.dsU = dstStride[1];
+                ya.dstV = dnv ? nullptr : dst[2]; ya.dsV = dnv ? 0 : dstStride[2];
+                // one flag for all planes: dword stores for luma and planar chroma, 8-byte stores for NV12 chroma
+                ya.dstAligned = al4(dst[0], dstStride[0]) &&
+                                (dnv ? ((((uintptr_t)dst[1] | (uintptr_t)dstStride[1]) & 7) == 0)
+                                     : (al4(dst[1], dstStride[1]) && al4(dst[2], dstStride[2])));
+            }
             ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
             ya.prof = c->prof;
-            if (c->y2x.ok && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
+            if (c->y2x.ok && !c->ytiling.yuvOut && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
                                                   (uintptr_t)srcStride[1]) & 15) == 0) &&
                 (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 &&
                              (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0))) {

@@ -111,10 +111,15 @@ __device__ __forceinline__ void yuv_phase1(const YuvScaleArgs &a, int tid, int c
     }
 }
 
-template <int TW, bool FULL>
+// MODE 0: packed RGB out, half chroma (LUT form)   1: packed RGB out, full chroma
+//      2: YUV 4:2:0 out (NV12 or YUV420P): the tile is TW x TH luma outputs plus the TW/2 x TH/2 chroma
+//         outputs under them; vChr is indexed by CHROMA row; yuv2planeX_8_c / yuv2nv12cX_c (output.c:400-450)
+template <int TW, int MODE>
 __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
+    constexpr bool FULL = MODE == 1;
+    constexpr bool YUVOUT = MODE == 2;
     constexpr int CWD = FULL ? TW : TW / 2;            // chroma samples per output tile row
 
     int tcol, trow;
@@ -167,12 +172,14 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 #pragma unroll
         for (int k = 0; k < kYMaxPairs; k++) {
             vl[k] = k < a.vLum.pairs ? a.vLum.packed[(size_t)yo * a.vLum.pairs + k] : 0;
-            vc[k] = k < a.vChr.pairs ? a.vChr.packed[(size_t)yo * a.vChr.pairs + k] : 0;
+            vc[k] = (!YUVOUT && k < a.vChr.pairs) ? a.vChr.packed[(size_t)yo * a.vChr.pairs + k] : 0;
         }
         vpL = (a.vLum.pos_even[yo] - r0L) >> 1;
-        vpC = (a.vChr.pos_even[yo] - r0C) >> 1;
         lr = a.vLum.round[yo];
-        cr = a.vChr.round[yo];
+        if (!YUVOUT) {                                   // MODE 2 indexes vChr by chroma row (phase 3)
+            vpC = (a.vChr.pos_even[yo] - r0C) >> 1;
+            cr = a.vChr.round[yo];
+        }
     };
     load_row(min(ty0 + yl, a.dstH - 1));
 
@@ -244,6 +251,16 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                 Y[0] = dot2(v.x, cf, Y[0]); Y[1] = dot2(v.y, cf, Y[1]);
                 Y[2] = dot2(v.z, cf, Y[2]); Y[3] = dot2(v.w, cf, Y[3]);
             }
+            if (YUVOUT) {
+                // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
+                uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
+                const unsigned o = (unsigned)clip_u8(Y[0] >> 19) | ((unsigned)clip_u8(Y[1] >> 19) << 8) |
+                                   ((unsigned)clip_u8(Y[2] >> 19) << 16) | ((unsigned)clip_u8(Y[3] >> 19) << 24);
+                const int nx = min(4, a.dstW - xo);
+                if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
+                else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+                continue;
+            }
             unsigned px[4];
             if (FULL) {
                 int U[4] = {cr, cr, cr, cr}, V[4] = {cr, cr, cr, cr};
@@ -307,6 +324,47 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
             }
         }
     }
+    if (YUVOUT) {
+        // chroma rows of the tile: item = (chroma row, group of 4 chroma columns), both planes
+        constexpr int QC = CWD / 4;
+        const int tcy0 = ty0 >> 1;
+        for (int it = tid; it < (a.TH >> 1) * QC; it += 256) {
+            const int cyl = it / QC, qc = it - cyl * QC;
+            const int cy = tcy0 + cyl, cx = tcx0 + 4 * qc;
+            if (cy >= a.chrDstH || cx >= a.chrDstW) continue;
+            const int vp = (a.vChr.pos_even[cy] - r0C) >> 1;
+            const int rnd = a.vChr.round[cy];
+            int U[4] = {rnd, rnd, rnd, rnd}, V[4] = {rnd, rnd, rnd, rnd};
+            for (int k = 0; k < a.vChr.pairs; k++) {
+                const int cf = a.vChr.packed[(size_t)cy * a.vChr.pairs + k];
+                const int4 u = *reinterpret_cast<const int4 *>(hu + (vp + k) * CWD + 4 * qc);
+                const int4 v = *reinterpret_cast<const int4 *>(hv + (vp + k) * CWD + 4 * qc);
+                U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
+                V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+            }
+            unsigned ub[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8(U[i] >> 19); vb[i] = (unsigned)clip_u8(V[i] >> 19); }
+            const int nx = min(4, a.chrDstW - cx);
+            if (a.dstNv12) {
+                uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
+                if (a.dstAligned && nx == 4) {
+                    *reinterpret_cast<uint2 *>(d) = make_uint2(ub[0] | (vb[0] << 8) | (ub[1] << 16) | (vb[1] << 24),
+                                                               ub[2] | (vb[2] << 8) | (ub[3] << 16) | (vb[3] << 24));
+                } else {
+                    for (int i = 0; i < nx; i++) { d[2 * i] = (uint8_t)ub[i]; d[2 * i + 1] = (uint8_t)vb[i]; }
+                }
+            } else {
+                uint8_t *du = a.dstU + (size_t)cy * a.dsU + cx, *dv = a.dstV + (size_t)cy * a.dsV + cx;
+                if (a.dstAligned && nx == 4) {
+                    *reinterpret_cast<unsigned *>(du) = ub[0] | (ub[1] << 8) | (ub[2] << 16) | (ub[3] << 24);
+                    *reinterpret_cast<unsigned *>(dv) = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
+                } else {
+                    for (int i = 0; i < nx; i++) { du[i] = (uint8_t)ub[i]; dv[i] = (uint8_t)vb[i]; }
+                }
+            }
+        }
+    }
     GMAT_STAMP(5);
 #undef GMAT_STAMP
 }
@@ -340,21 +398,23 @@ static void windows(const FilterBank &fb, int tile, int ntiles, int count, int a
 
 int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
-    if (!is_yuv420(p.srcFormat) || !is_packed_rgb(p.dstFormat)) return GMAT_ERR(ENOSYS);
+    const bool yuvOut = is_yuv420(p.dstFormat);
+    if (!is_yuv420(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
     const int full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) ? 1 : 0;
     if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);
-    if (p.chrDstH != p.dstH) return GMAT_ERR(ENOSYS);
+    if (p.chrDstH != (yuvOut ? (p.dstH + 1) / 2 : p.dstH)) return GMAT_ERR(ENOSYS);
     t.fullChroma = full;
+    t.yuvOut = yuvOut;
 
     // ---- vertical special forms (vscale.c:135-167) -> per-row start values + effective chroma taps
     const int sh_one = full ? (1 << 9) : (1 << 18);
     const int chr_bias = full ? -(128 << 19) : 0;
-    t.lumRound.assign(p.dstH, sh_one);
-    t.chrRound.assign(p.dstH, sh_one + chr_bias);
+    t.lumRound.assign(p.dstH, yuvOut ? (64 << 12) : sh_one);          // planar output: dither 64 (swscale.c:349-351)
+    t.chrRound.assign(p.chrDstH, yuvOut ? (64 << 12) : sh_one + chr_bias);
     t.vChrEff = p.vChr;
     const int lfs = p.vLum.taps, cfs = p.vChr.taps;
-    for (int y = 0; y < p.dstH; y++) {
+    for (int y = 0; y < p.dstH && !yuvOut; y++) {
         const int16_t *lf = &p.vLum.coef[(size_t)y * lfs];
         int16_t *cf = &t.vChrEff.coef[(size_t)y * cfs];
         const bool chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
@@ -384,10 +444,12 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
         for (int TH : ths) {
             if (forceTH && TH != forceTH) continue;
             if (!forceTH && TH > 16) continue;
+            if (yuvOut && (TH & 1)) continue;              // a tile holds TH/2 chroma rows
             const int nty = (p.dstH + TH - 1) / TH;
             int rowsL = 0, rowsC = 0;
             windows(p.vLum, TH, nty, p.dstH, 2, t.rowStartL, t.rowCountL, rowsL);
-            windows(t.vChrEff, TH, nty, p.dstH, 2, t.rowStartC, t.rowCountC, rowsC);
+            if (yuvOut) windows(t.vChrEff, TH / 2, nty, p.chrDstH, 2, t.rowStartC, t.rowCountC, rowsC);
+            else        windows(t.vChrEff, TH, nty, p.dstH, 2, t.rowStartC, t.rowCountC, rowsC);
             const int bytes = rowsL * colsL * 2 + 2 * rowsC * colsC * 2 + (rowsL / 2) * TW * 4 + 2 * (rowsC / 2) * cwd * 4;
             if (bytes > ldsCap && !(forceTH && bytes <= 64 * 1024)) continue;
             t.TW = TW; t.TH = TH; t.ntx = ntx; t.nty = nty;
@@ -401,6 +463,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 
 const char *yuvscale_kernel_name(const YuvScaleTiling &t)
 {
+    if (t.yuvOut) return t.TW == 64 ? "scale_yuv_kernel<64,yuv>" : "scale_yuv_kernel<32,yuv>";
     if (t.TW == 64) return t.fullChroma ? "scale_yuv_kernel<64,full>" : "scale_yuv_kernel<64,half>";
     return t.fullChroma ? "scale_yuv_kernel<32,full>" : "scale_yuv_kernel<32,half>";
 }
@@ -411,10 +474,11 @@ int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t
     if (ntiles <= 0) return 0;
     const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
     const size_t lds = (size_t)t.ldsBytes;
-#define GMAT_LAUNCH_YUV(TW_, FULL_) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, FULL_>), grid, block, lds, stream, a)
-    if (t.TW == 64) { if (t.fullChroma) GMAT_LAUNCH_YUV(64, true); else GMAT_LAUNCH_YUV(64, false); }
-    else if (t.TW == 32) { if (t.fullChroma) GMAT_LAUNCH_YUV(32, true); else GMAT_LAUNCH_YUV(32, false); }
+#define GMAT_LAUNCH_YUV(TW_, MODE_) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_>), grid, block, lds, stream, a)
+    const int mode = t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
+    if (t.TW == 64) { if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
+    else if (t.TW == 32) { if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }
     else return GMAT_ERR(EINVAL);
 #undef GMAT_LAUNCH_YUV
     GMAT_HIP_CHECK(hipGetLastError());

@@ -69,6 +69,7 @@ const char *scale_kernel_name(const ScaleArgs &a, const ScaleTiling &t);
 // yuv2rgb_X_c) or the full-chroma form (yuv2rgb_full_X_c).
 struct YuvScaleTiling {
     int TW = 0, TH = 0, ntx = 0, nty = 0, fullChroma = 0;
+    int yuvOut = 0;                               // destination is NV12 / YUV420P (vChr indexed by chroma row)
     int rowsL = 0, colsL = 0, rowsC = 0, colsC = 0, ldsBytes = 0, xcdRemap = 1;
     std::vector<int32_t> colStartL, colCountL, rowStartL, rowCountL, colStartC, colCountC, rowStartC, rowCountC;
     std::vector<int32_t> lumRound, chrRound;      // per output row accumulator start values
@@ -79,8 +80,10 @@ struct YuvScaleArgs {
     const uint8_t *y, *u, *v;
     int ys, us, vs, nv12, srcAligned;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW;
-    uint8_t *dst;
+    uint8_t *dst;                                 // packed RGB, or the Y plane for YUV output
     int ds, dstFormat, dstAligned;
+    uint8_t *dstU, *dstV;                         // YUV output: chroma planes (NV12: dstU = interleaved UV)
+    int dsU, dsV, dstNv12, chrDstH;
     DevFilter hLum, hChr, vLum, vChr;             // vLum.round / vChr.round = lumRound / chrRound
     const int32_t *colStartL, *colCountL, *rowStartL, *rowCountL, *colStartC, *colCountC, *rowStartC, *rowCountC;
     int TH, ntx, nty, xcdRemap, fullChroma;

@@ -243,7 +243,8 @@ def _run_filter_planes(dev, name, opts, src_planes, w, h, fmt):
     assert lib.gmat_hwframe_transfer_data(C.byref(hout), out, None) == 0
     lib.gmat_device_sync()
     res = []
-    for i, (rows, rb) in enumerate(plane_shapes(fmt, o.width, o.height)):
+    ofmt = {v: k for k, v in PIX_FMT.items()}[o.sw_format]
+    for i, (rows, rb) in enumerate(plane_shapes(ofmt, o.width, o.height)):
         res.append(np.ctypeslib.as_array(C.cast(hout.data[i], C.POINTER(C.c_uint8)), (rows, hout.linesize[i]))[:, :rb].copy())
     ow, oh = o.width, o.height
     lib.gmat_frame_free(C.byref(out))
@@ -308,3 +309,21 @@ def test_filter_layer_planar_frames(dev, orc, fmt, w, h):
         assert (res[1] == src[1][3:13, 10:50]).all()
     else:
         assert (res[1] == src[1][3:13, 5:25]).all() and (res[2] == src[2][3:13, 5:25]).all()
+
+
+def test_filter_layer_scale_keeps_yuv_format(dev, orc):
+    """scale_hip without a format option keeps the input format (vf_scale_cuda.c:594 "same"): nv12 in, nv12 out."""
+    from harness import SWS
+    w, h = 128, 48
+    src = synth_planes(orc, "nv12", w, h, 91)
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "interp_algo": "bicubic"}, src, w, h, "nv12")
+    assert (ow, oh) == (64, 24)
+    want = orc.sws(src, w, h, "nv12", 64, 24, "nv12", SWS["bicubic"])
+    for a, b in zip(res, want):
+        assert (a == b).all()
+    # explicit format option converts on the way
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "format": "yuv420p"}, src, w, h, "nv12")
+    want = orc.sws(src, w, h, "nv12", 64, 24, "yuv420p", SWS["bicubic"])
+    assert len(res) == 3
+    for a, b in zip(res, want):
+        assert (a == b).all()

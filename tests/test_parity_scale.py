@@ -178,3 +178,36 @@ def test_same_size_generic_path_with_accurate_rnd(dev, orc, src_fmt, w, h):
     assert (got[0] == want).all() and (pads[0] == 0xCD).all()
     got2, _, kernel2 = dev.sws(d_src, w, h, src_fmt, w, h, "rgb24", SWS["bicubic"], dst_align=64)
     assert kernel2 == "yuv2rgb_kernel" and (got2[0] != want).any()
+
+
+# ---- YUV 4:2:0 -> YUV 4:2:0 at another size (scale_cuda's job; planes scaled separately) -----------------
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("nv12", "nv12"), ("yuv420p", "yuv420p"), ("nv12", "yuv420p"),
+                                             ("yuv420p", "nv12")])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (200, 90, 100, 46), (131, 77, 65, 33), (96, 40, 144, 60),
+                                  (300, 50, 100, 70), (64, 64, 18, 10), (520, 36, 260, 18)])
+def test_yuv_to_yuv_scaled(dev, orc, src_fmt, dst_fmt, geom):
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=41)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"])
+    for align, extra in [(256, 0), (1, 1)]:
+        d_src = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=align,
+                                    dst_extra=extra)
+        for p in d_src:
+            p.free()
+        assert "yuv>" in kernel or "plane" in kernel, kernel
+        for i, (g, w) in enumerate(zip(got, want)):
+            bad = np.argwhere(g != w)
+            assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+            assert (pads[i] == 0xCD).all(), f"plane {i}: kernel wrote into the row padding"
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area"])
+def test_yuv_to_yuv_algorithms(dev, orc, flags):
+    for (sw, sh, dw, dh) in [(192, 70, 96, 36), (80, 30, 120, 50)]:
+        src = synth_planes(orc, "nv12", sw, sh, seed=43)
+        want = orc.sws(src, sw, sh, "nv12", dw, dh, "nv12", SWS[flags])
+        d_src = dev.upload_planes(src, 64)
+        got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, "nv12", SWS[flags], dst_align=64)
+        for g, w in zip(got, want):
+            assert (g == w).all(), (flags, kernel)
