@@ -105,7 +105,7 @@ struct GmatSwsContext {
     DevBuf dR2YrowStart, dR2YrowCount;
     DevFilter r2yVChr;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
-    DevBuf dHLreg, dHCreg, dVrec;
+    DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
     int fused = 2;
@@ -157,6 +157,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
         if ((r = c->dHCreg.upload(c->y2x.hCreg.data(), c->y2x.hCreg.size() * 4)) < 0) return r;
         if ((r = c->dVrec.upload(c->y2x.vrec.data(), c->y2x.vrec.size() * 4)) < 0) return r;
+        if ((r = c->dVrecC.upload(c->y2x.vrecC.data(), c->y2x.vrecC.size() * 4)) < 0) return r;
     }
     c->yuvReady = true;
     return 0;
@@ -467,7 +468,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             }
             ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
             ya.prof = c->prof;
-            if (c->y2x.ok && !c->ytiling.yuvOut && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
+            if (c->y2x.ok && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
                                                   (uintptr_t)srcStride[1]) & 15) == 0) &&
                 (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 &&
                              (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0))) {
@@ -477,6 +478,9 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 xa.srcW = ya.srcW; xa.srcH = ya.srcH; xa.chrSrcW = ya.chrSrcW; xa.chrSrcH = ya.chrSrcH;
                 xa.dstW = ya.dstW; xa.dstH = ya.dstH;
                 xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
+                xa.dstU = ya.dstU; xa.dstV = ya.dstV; xa.dsU = ya.dsU; xa.dsV = ya.dsV; xa.dstNv12 = ya.dstNv12;
+                xa.yuvOut = c->y2x.yuvOut; xa.chrDstW = ya.chrDstW; xa.chrDstH = ya.chrDstH;
+                xa.vrecC = (const int32_t *)c->dVrecC.p;
                 xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
                 xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;
                 xa.vrec = (const int32_t *)c->dVrec.p; xa.vLpairs = c->y2x.vLpairs; xa.vCpairs = c->y2x.vCpairs;
@@ -484,7 +488,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
                 xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
                 xa.prof = ya.prof; xa.y2r = ya.y2r;
-                c->lastKernel = "scale_yuv2x_kernel";
+                c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
                 r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, c->stream);
                 break;
             }

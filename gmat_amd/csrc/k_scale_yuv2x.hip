@@ -51,6 +51,10 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[8], const int (&w1)
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// YUVOUT = false: packed RGB out (colour stage fused).  true: NV12 / YUV420P out — the tile is 64 x 16 luma
+// outputs plus the 32 x 8 chroma outputs under them, vertical chroma filter indexed by chroma row
+// (yuv2planeX_8_c / yuv2nv12cX_c, output.c:400-450).
+template <bool YUVOUT>
 __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL, int rowsC)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     int *cL = hv + (rowsC >> 1) * (X2_TW / 2);                   // [64][5]
     int *cC = cL + X2_TW * X2_P;                                 // [32][5]
     int *vr = cC + (X2_TW / 2) * X2_P;                           // [16][12] vertical records of the tile's rows
+    int *vrc = vr + X2_TH * 12;                                  // YUVOUT: [8][8] records of the tile's chroma rows
 
     constexpr int QW = X2_TW / 4;
     const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one phase-3 item each
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
         if (tid < 80)       reinterpret_cast<uint4 *>(cL)[tid] = reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * X2_P)[tid];
         else if (tid < 120) reinterpret_cast<uint4 *>(cC)[tid - 80] = reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * X2_P)[tid - 80];
         else if (tid < 168) reinterpret_cast<uint4 *>(vr)[tid - 120] = reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * 12)[tid - 120];
+        else if (YUVOUT && tid < 184) reinterpret_cast<uint4 *>(vrc)[tid - 168] = reinterpret_cast<const uint4 *>(a.vrecC + (size_t)(ty0 >> 1) * 8)[tid - 168];
 
         const int rs = (lane * 205) >> 11, g = lane - rs * 10;   // lane / 10 for lane < 64: 6 rows x 10 groups per wave
         const bool act = lane < 60;
@@ -186,7 +192,69 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     X2_STAMP(4);
 
     // ================= phase 3: vertical filters + colour stage + store ==========================
-    {
+    if constexpr (YUVOUT) {
+        const int xo = tx0 + 4 * q;
+        {   // luma: 4 outputs of row yo
+            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * 12)[0], rb = reinterpret_cast<const int4 *>(vr + yl * 12)[1],
+                       rc = reinterpret_cast<const int4 *>(vr + yl * 12)[2];
+            const int vl[X2_P] = {ra.x, ra.y, ra.z, ra.w, rb.x};
+            const int vpL = (rb.w - r0L) >> 1, lr = rc.y;
+            int Y[4] = {lr, lr, lr, lr};
+#pragma unroll
+            for (int k = 0; k < X2_P; k++) {
+                if (k < a.vLpairs) {
+                    const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
+                    Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
+                    Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
+                }
+            }
+            if (yo < a.dstH && xo < a.dstW) {
+                // clip_u8(v >> 19) = byte 2 of clamp(v >> 3, 0, 0xFFFFFF)
+                const unsigned y0 = (unsigned)min(max(Y[0] >> 3, 0), 0xFFFFFF), y1 = (unsigned)min(max(Y[1] >> 3, 0), 0xFFFFFF);
+                const unsigned y2 = (unsigned)min(max(Y[2] >> 3, 0), 0xFFFFFF), y3 = (unsigned)min(max(Y[3] >> 3, 0), 0xFFFFFF);
+                const unsigned o = __builtin_amdgcn_perm(y1, y0, 0x0C0C0602u) | (__builtin_amdgcn_perm(y3, y2, 0x0C0C0602u) << 16);
+                uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
+                const int nx = min(4, a.dstW - xo);
+                if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
+                else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+            }
+        }
+        {   // chroma: thread (q, yl) computes plane (yl & 1) of chroma row yl >> 1, columns 2q and 2q + 1;
+            // the U and V halves of an NV12 dword meet through one cross-lane exchange (lanes l and l ^ 16)
+            const int pl = yl & 1, cyl = yl >> 1;
+            const int cy = (ty0 >> 1) + cyl, cx = tcx0 + 2 * q;
+            const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * 8)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * 8)[1];
+            const int vcp[X2_P] = {ca.x, ca.y, ca.z, ca.w, cb.x};
+            const int vp = (cb.y - r0C) >> 1;
+            const int *hp = pl ? hv : hu;
+            int C0 = cb.z, C1 = cb.z;
+#pragma unroll
+            for (int k = 0; k < X2_P; k++) {
+                if (k < a.vCpairs) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(hp + (vp + k) * (X2_TW / 2) + 2 * q);
+                    C0 = dot2((int)t.x, vcp[k], C0); C1 = dot2((int)t.y, vcp[k], C1);
+                }
+            }
+            const unsigned c0 = (unsigned)min(max(C0 >> 3, 0), 0xFFFFFF), c1 = (unsigned)min(max(C1 >> 3, 0), 0xFFFFFF);
+            const unsigned mine = __builtin_amdgcn_perm(c1, c0, 0x0C0C0602u);        // sample 0 | sample 1 << 8
+            const bool inside = cy < a.chrDstH && cx < a.chrDstW;
+            const int nx = min(2, a.chrDstW - cx);
+            if (a.dstNv12) {
+                const unsigned other = (unsigned)__shfl_xor((int)mine, 16);           // V pair for the U lanes
+                if (inside && pl == 0) {
+                    // U0 V0 U1 V1
+                    const unsigned o = __builtin_amdgcn_perm(other, mine, 0x05010400u);
+                    uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
+                    if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned *>(d) = o;
+                    else for (int i = 0; i < 2 * nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            } else if (inside) {
+                uint8_t *d = (pl ? a.dstV + (size_t)cy * a.dsV : a.dstU + (size_t)cy * a.dsU) + cx;
+                if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned short *>(d) = (unsigned short)mine;
+                else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(mine >> (8 * i));
+            }
+        }
+    } else {
         const int xo = tx0 + 4 * q;
         if (yo < a.dstH && xo < a.dstW) {
             // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
@@ -308,9 +376,9 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     t.ok = 0;
     const char *off = getenv("GMAT_SCALE_NO_2X");
     if (off && atoi(off)) return 0;
-    if (g.fullChroma || g.yuvOut || g.TW != X2_TW || g.TH != X2_TH) return 0;
+    if (g.fullChroma || g.TW != X2_TW || g.TH != X2_TH) return 0;
     if (p.srcW % 16 || p.chrSrcW % 8 || p.srcW < 16) return 0;
-    if (p.vLum.pairs > X2_P || g.vChrEff.pairs > 2) return 0;
+    if (p.vLum.pairs > X2_P || g.vChrEff.pairs > (g.yuvOut ? X2_P : 2)) return 0;
     t.ntx = g.ntx; t.nty = g.nty;
     if (!regularise(p.hLum, t.ntx * X2_TW, t.w0L, t.hLreg)) return 0;
     if (!regularise(p.hChr, t.ntx * (X2_TW / 2), t.w0C, t.hCreg)) return 0;
@@ -321,7 +389,8 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         if ((wc - (wc & ~7)) + 2 * (X2_TW / 2 - 1) + 2 * X2_P > X2_COLSC) return 0;
     }
     const int bytes = g.rowsL * X2_COLSL * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
-                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * X2_P * 4 + X2_TH * 12 * 4;
+                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * X2_P * 4 + X2_TH * 12 * 4 +
+                      (g.yuvOut ? (X2_TH / 2) * 8 * 4 : 0);
     if (bytes > 64 * 1024) return 0;
     if (g.rowsL > 48 || g.rowsC > 24) return 0;               // phase 1 covers 48 luma / 24 chroma rows per tile
     // per-output-row records for phase 3 (rows past dstH repeat the last one; never stored)
@@ -330,10 +399,25 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         const int y = std::min(yy, p.dstH - 1);
         int32_t *r = &t.vrec[(size_t)yy * 12];
         for (int k = 0; k < p.vLum.pairs; k++) r[k] = p.vLum.packed[(size_t)y * p.vLum.pairs + k];
+        r[7] = p.vLum.pos_even[y];
+        r[9] = g.lumRound[y];
+        if (g.yuvOut) continue;                              // chroma rows have their own records (vrecC)
         for (int k = 0; k < g.vChrEff.pairs; k++) r[5 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
-        r[7] = p.vLum.pos_even[y]; r[8] = g.vChrEff.pos_even[y];
-        r[9] = g.lumRound[y]; r[10] = g.chrRound[y];
+        r[8] = g.vChrEff.pos_even[y];
+        r[10] = g.chrRound[y];
     }
+    t.vrecC.clear();
+    if (g.yuvOut) {
+        t.vrecC.assign((size_t)t.nty * (X2_TH / 2) * 8, 0);
+        for (int cyy = 0; cyy < t.nty * (X2_TH / 2); cyy++) {
+            const int cy = std::min(cyy, p.chrDstH - 1);
+            int32_t *r = &t.vrecC[(size_t)cyy * 8];
+            for (int k = 0; k < g.vChrEff.pairs; k++) r[k] = g.vChrEff.packed[(size_t)cy * g.vChrEff.pairs + k];
+            r[5] = g.vChrEff.pos_even[cy];
+            r[6] = g.chrRound[cy];
+        }
+    }
+    t.yuvOut = g.yuvOut;
     t.vLpairs = p.vLum.pairs; t.vCpairs = g.vChrEff.pairs;
     t.ok = bytes;
     return 0;
@@ -344,7 +428,8 @@ int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, h
     const int ntiles = a.ntx * a.nty;
     if (ntiles <= 0) return 0;
     const dim3 grid(a.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
-    hipLaunchKernelGGL(scale_yuv2x_kernel, grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC);
+    if (a.yuvOut) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<true>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC);
+    else          hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<false>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -143,7 +143,8 @@ struct Yuv2xTables {
     int ntx = 0, nty = 0;
     std::vector<int32_t> hLreg, hCreg;          // [ntx*64][5], [ntx*32][5] packed int16 pairs
     std::vector<int32_t> vrec;                  // [nty*16][12] per-output-row vertical record
-    int vLpairs = 0, vCpairs = 0;
+    std::vector<int32_t> vrecC;                 // YUV output: [nty*8][8] per-chroma-row record (5 pairs, pos, round)
+    int vLpairs = 0, vCpairs = 0, yuvOut = 0;
 };
 struct Yuv2xArgs {
     const uint8_t *y, *u, *v;
@@ -151,6 +152,9 @@ struct Yuv2xArgs {
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
     uint8_t *dst;
     int ds, dstFormat, dstAligned;
+    uint8_t *dstU, *dstV;                       // YUV output (yuvOut): chroma planes, NV12: dstU = interleaved UV
+    int dsU, dsV, dstNv12, yuvOut, chrDstW, chrDstH;
+    const int32_t *vrecC;
     const int32_t *hLreg, *hCreg, *vrec;
     int w0L, w0C, vLpairs, vCpairs;
     const int32_t *rowStartL, *rowCountL, *rowStartC, *rowCountC;

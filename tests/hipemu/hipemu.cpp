@@ -75,6 +75,20 @@ void guarded_free(void *p)
 
 void block_sync() { yield_as(AT_BLOCK); }
 void wave_sync() { yield_as(AT_WAVE); }
+
+// cross-lane exchange (ds_bpermute semantics for the lanes of one wave): every live lane of the wave must
+// call it (the wave barrier inside aborts on divergence)
+static int shfl_slot[1024];
+int shfl_xor(int v, int mask)
+{
+    const int me = cur;
+    shfl_slot[me] = v;
+    wave_sync();
+    const int src = (me & ~63) | ((me ^ mask) & 63);
+    const int r = src < (int)fibers.size() ? shfl_slot[src] : 0;
+    wave_sync();
+    return r;
+}
 void *dyn_lds() { return lds_ptr; }
 
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem)

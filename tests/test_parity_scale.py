@@ -211,3 +211,35 @@ def test_yuv_to_yuv_algorithms(dev, orc, flags):
         got, pads, kernel = dev.sws(d_src, sw, sh, "nv12", dw, dh, "nv12", SWS[flags], dst_align=64)
         for g, w in zip(got, want):
             assert (g == w).all(), (flags, kernel)
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("nv12", "nv12"), ("yuv420p", "yuv420p"), ("nv12", "yuv420p"),
+                                             ("yuv420p", "nv12")])
+@pytest.mark.parametrize("geom", X2_GEOMS)
+def test_yuv2x_yuv_output_bit_exact(dev, orc, src_fmt, dst_fmt, geom):
+    """The 2:1 specialisation with 4:2:0 output (the transcoding down-scale) vs the oracle, and vs the generic kernel."""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=45)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"])
+    d_src = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=256)
+    assert kernel == "scale_yuv2x_kernel<yuv>", kernel
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (pads[i] == 0xCD).all()
+    # unaligned destination rows: byte stores, same bytes
+    got2, pads2, kernel2 = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=1, dst_extra=1)
+    assert kernel2 == "scale_yuv2x_kernel<yuv>"
+    for g, w, pd in zip(got2, want, pads2):
+        assert (g == w).all() and (pd == 0xCD).all()
+    for p in d_src:
+        p.free()
+    for flags in ("bilinear", "lanczos"):
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags])
+        d = dev.upload_planes(src, 256)
+        got, _, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=256)
+        for g, w in zip(got, want):
+            assert (g == w).all(), (flags, kernel)
+        for p in d:
+            p.free()
