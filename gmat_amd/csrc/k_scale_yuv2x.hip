@@ -155,21 +155,13 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
 
     // ================= phase 2: horizontal filters, 4 outputs x 2 rows per item ===================
     {
+        // The luma item range is padded to whole waves so that every wave iteration is entirely luma or
+        // entirely chroma: the choice is a scalar branch and each side has compile-time row lengths
+        // (the per-lane select cost ~25 VALU instructions per item before).
         const int nL = (nrL >> 1) * 16, nC = (nrC >> 1) * 8;      // luma items, chroma items per plane
-        const int total = nL + 2 * nC;
-        for (int it = tid; it < total; it += 256) {
-            const unsigned short *srcp;
-            const int *cf;
-            int *dstp;
-            int colsS, e, g, rp;
-            if (it < nL) {
-                rp = it >> 4; g = it & 15;
-                srcp = ly; colsS = X2_COLSL; e = eL; cf = cL; dstp = hy + rp * X2_TW + 4 * g;
-            } else {
-                const int j = it - nL, pl = j >= nC, jj = pl ? j - nC : j;
-                rp = jj >> 3; g = jj & 7;
-                srcp = pl ? lv : lu; colsS = X2_COLSC; e = eC; cf = cC; dstp = (pl ? hv : hu) + rp * (X2_TW / 2) + 4 * g;
-            }
+        const int nLw = (nL + 63) & ~63;
+        const int total = nLw + 2 * nC;
+        auto item = [&](const unsigned short *srcp, int colsS, int e, const int *cf, int *dstp, int rp, int g) {
             const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
             const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
             const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
@@ -185,6 +177,19 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
                 c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
             }
             *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4(w0, w1, c);
+        };
+        for (int it = tid; it < total; it += 256) {
+            const int wbase = __builtin_amdgcn_readfirstlane(it);     // tid of the wave's first lane is a multiple of 64
+            if (wbase < nLw) {
+                if (it < nL) {
+                    const int rp = it >> 4, g = it & 15;
+                    item(ly, X2_COLSL, eL, cL, hy + rp * X2_TW + 4 * g, rp, g);
+                }
+            } else {
+                const int j = it - nLw, pl = j >= nC, jj = pl ? j - nC : j;
+                const int rp = jj >> 3, g = jj & 7;
+                item(lu + pl * (rowsC * X2_COLSC), X2_COLSC, eC, cC, hu + pl * ((rowsC >> 1) * (X2_TW / 2)) + rp * (X2_TW / 2) + 4 * g, rp, g);
+            }
         }
     }
     X2_STAMP(3);

@@ -52,6 +52,7 @@ extern Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void block_sync();
 void wave_sync();
 int shfl_xor(int v, int mask);
+int readfirstlane(int v);
 void *dyn_lds();
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -88,6 +89,7 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __syncthreads() hipemu::block_sync()
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __shfl_xor(v, m) hipemu::shfl_xor((int)(v), (m))
+#define __builtin_amdgcn_readfirstlane(v) hipemu::readfirstlane((int)(v))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu::sdot2(a, b, c)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
 #define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu::cvt_pk_i16(a, b)

@@ -76,6 +76,26 @@ void guarded_free(void *p)
 void block_sync() { yield_as(AT_BLOCK); }
 void wave_sync() { yield_as(AT_WAVE); }
 
+// v_readfirstlane_b32: the value of the lowest-numbered active lane.  Fibers of a wave run in lane order
+// between barriers, so for the e-th call made by the lanes of a wave the first fiber to make it is the lowest
+// lane still executing that code; its value is recorded per (wave, call number) and returned to the others.
+// Valid for the kernels under test, where every lane of a wave makes the same sequence of calls (lanes that
+// leave a loop early just make fewer of them).  Reset at every block start.
+static std::vector<int> rfl_vals[16];
+static int rfl_calls[1024];
+static void rfl_reset()
+{
+    for (auto &v : rfl_vals) v.clear();
+    memset(rfl_calls, 0, sizeof(rfl_calls));
+}
+int readfirstlane(int v)
+{
+    const int me = cur, w = me >> 6;
+    const size_t e = (size_t)rfl_calls[me]++;
+    if (rfl_vals[w].size() <= e) rfl_vals[w].push_back(v);
+    return rfl_vals[w][e];
+}
+
 // cross-lane exchange (ds_bpermute semantics for the lanes of one wave): every live lane of the wave must
 // call it (the wave barrier inside aborts on divergence)
 static int shfl_slot[1024];
@@ -109,6 +129,7 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shm
     for (unsigned by = 0; by < grid.y; by++)
     for (unsigned bx = 0; bx < grid.x; bx++) {
         g_blockIdx = {bx, by, bz};
+        rfl_reset();
         for (int t = 0; t < nthreads; t++) {
             Fiber &f = fibers[t];
             getcontext(&f.ctx);
