@@ -75,7 +75,8 @@ struct GmatFilterContext {
     // flip
     int code = 0;
     // rotate / transpose
-    double angle = 0; int dir = 1, quarter = 0;
+    double angle = 0; int dir = 1, quarter = 0;       // quarter == -1: arbitrary angle (vf_rotate.c arithmetic)
+    int rot_bilinear = 1;
     // smooth
     int smooth_median = 0, kw = 3, kh = 3;
     // scale / format
@@ -87,6 +88,12 @@ static int opt_int(GmatFilterContext *f, const char *k, int dflt)
 {
     auto it = f->opt.find(k);
     return it == f->opt.end() ? dflt : atoi(it->second.c_str());
+}
+
+static double opt_double(GmatFilterContext *f, const char *k, double dflt)
+{
+    auto it = f->opt.find(k);
+    return it == f->opt.end() ? dflt : atof(it->second.c_str());
 }
 
 extern "C" {
@@ -147,11 +154,22 @@ int gmat_filter_init(GmatFilterContext *f)
         f->angle = it == f->opt.end() ? 0.0 : atof(it->second.c_str());
         if (f->angle < -360 || f->angle > 360) return GMAT_ERR(EINVAL);
         const double q = f->angle / 90.0;
-        if (std::fabs(q - std::round(q)) > 1e-9) {
-            logf(LOG_ERROR, "rotate_hip: only multiples of 90 degrees are implemented (angle=%g)", f->angle);
-            return GMAT_ERR(ENOSYS);
+        {
+            auto ip = f->opt.find("interp");
+            const std::string m = ip == f->opt.end() ? "linear" : ip->second;
+            if (m == "linear") f->rot_bilinear = 1;
+            else if (m == "nearest") f->rot_bilinear = 0;
+            else {
+                logf(LOG_ERROR, "rotate_hip: Interpolation '%s' not supported.", m.c_str());   // cubic / area: CV-CUDA only
+                return GMAT_ERR(ENOSYS);
+            }
+            if (std::fabs(opt_double(f, "shift_x", 0.0)) > 0 || std::fabs(opt_double(f, "shift_y", 0.0)) > 0) {
+                logf(LOG_ERROR, "rotate_hip: shift_x / shift_y are not implemented (rotation is about the centre)");
+                return GMAT_ERR(ENOSYS);
+            }
         }
-        f->quarter = (((int)std::lround(q)) % 4 + 4) % 4;     // clockwise quarter turns
+        if (std::fabs(q - std::round(q)) > 1e-9) f->quarter = -1;   // vf_rotate.c's fixed-point bilinear / nearest
+        else f->quarter = (((int)std::lround(q)) % 4 + 4) % 4;      // exact clockwise quarter turns
         break;
     }
     case K_TRANSPOSE: {
@@ -222,7 +240,7 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     case K_ROTATE:
         // quarter turns swap the dimensions, like CPU transpose (vf_transpose.c:216-217); the
         // reference's rotate_nvcv keeps w x h and loses pixels (SURVEY.md §0 defect 11)
-        if (f->quarter & 1) { f->out_w = f->in_h; f->out_h = f->in_w; }
+        if (f->quarter > 0 && (f->quarter & 1)) { f->out_w = f->in_h; f->out_h = f->in_w; }
         break;
     case K_TRANSPOSE:
         f->out_w = f->in_h; f->out_h = f->in_w;
@@ -301,6 +319,14 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
                 case 1: r = launch_transpose(s, ss, d, ds, pw, ph, bpp, 1, f->stream); break;   // clock
                 case 2: r = launch_flip(s, ss, d, ds, pw, ph, bpp, 1, 1, f->stream); break;
                 case 3: r = launch_transpose(s, ss, d, ds, pw, ph, bpp, 2, f->stream); break;   // cclock
+                default: {
+                    // out size = in size, background "black" (vf_rotate.c:102-107; ff_draw_color: RGB 0,0,0 / alpha 255,
+                    // limited-range YUV 16,128,128 — drawutils.c:159-202)
+                    uint8_t fill[4] = {0, 0, 0, 255};
+                    if (is_yuv420(f->in_fmt)) { fill[0] = i == 0 ? 16 : 128; fill[1] = 128; }
+                    r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream);
+                    break;
+                }
                 }
                 break;
             case K_SMOOTH: {
@@ -355,6 +381,13 @@ int gmat_smooth3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
                    float rdiv, float bias, void *stream)
 {
     return launch_conv3x3(src, ss, dst, ds, w, h, bpp, matrix, rdiv, bias, (hipStream_t)stream);
+}
+
+int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                double angle_rad, int bilinear, const uint8_t *fill, void *stream)
+{
+    if (!src || !dst) return GMAT_ERR(EINVAL);
+    return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, bilinear, fill, (hipStream_t)stream);
 }
 
 int gmat_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, void *stream)

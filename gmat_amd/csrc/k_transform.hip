@@ -401,6 +401,109 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     return 0;
 }
 
+// ---- arbitrary-angle rotation, vf_rotate.c's 16.16 fixed point --------------------------------------
+// Source position of output pixel (i, j): x = X0 + j*s + i*c, y = Y0 + j*c - i*s (filter_slice, vf_rotate.c:
+// 427-429,:487-492); pixels whose integer position leaves [-1, in] keep the fill colour (:463); bilinear taps as
+// interpolate_bilinear8 (:224-249) with a 64-bit final blend, or the clamped nearest sample.
+struct RotateParams { int X0, Y0, s, c, inW, inH, outW, outH, bilinear, fillEnable; unsigned fill; };
+
+template <int BPP>
+__global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
+                                                     int aligned)
+{
+    const int i0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i0 >= p.outW || j >= p.outH) return;
+    uint8_t o[4 * BPP];
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + q;
+        const int x = p.X0 + j * p.s + i * p.c, y = p.Y0 + j * p.c - i * p.s;
+        const int x1 = x >> 16, y1 = y >> 16;
+        valid[q] = x1 >= -1 && x1 <= p.inW && y1 >= -1 && y1 <= p.inH;
+        const int ix = min(max(x1, 0), p.inW - 1), iy = min(max(y1, 0), p.inH - 1);
+        if (!valid[q]) {
+#pragma unroll
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
+        } else if (p.bilinear) {
+            const int fx = x & 0xFFFF, fy = y & 0xFFFF;
+            const int ix1 = min(ix + 1, p.inW - 1), iy1 = min(iy + 1, p.inH - 1);
+            const uint8_t *r0 = src + (size_t)iy * ss, *r1 = src + (size_t)iy1 * ss;
+#pragma unroll
+            for (int k = 0; k < BPP; k++) {
+                const int s00 = r0[BPP * ix + k], s01 = r0[BPP * ix1 + k], s10 = r1[BPP * ix + k], s11 = r1[BPP * ix1 + k];
+                const int s0 = ((1 << 16) - fx) * s00 + fx * s01;
+                const int s1 = ((1 << 16) - fx) * s10 + fx * s11;
+                o[q * BPP + k] = (uint8_t)(((long long)((1 << 16) - fy) * s0 + (long long)fy * s1) >> 32);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = src[(size_t)iy * ss + BPP * ix + k];
+        }
+    }
+    uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
+    const int nx = min(4, p.outW - i0);
+    const bool all = p.fillEnable || (valid[0] && valid[1] && valid[2] && valid[3]);
+    if (aligned && nx == 4 && all) {
+        unsigned w[BPP];
+#pragma unroll
+        for (int k = 0; k < BPP; k++)
+            w[k] = (unsigned)o[4 * k] | ((unsigned)o[4 * k + 1] << 8) | ((unsigned)o[4 * k + 2] << 16) | ((unsigned)o[4 * k + 3] << 24);
+#pragma unroll
+        for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = w[k];
+    } else {
+        for (int q = 0; q < nx; q++)
+            if (p.fillEnable || valid[q])
+                for (int k = 0; k < BPP; k++) d[q * BPP + k] = o[q * BPP + k];
+    }
+}
+
+// int_sin, vf_rotate.c:198-218: input scaled by 2^20, output by 2^16
+static int64_t rot_int_sin(int64_t a)
+{
+    const int64_t PI = 3294199, F2 = 1 << 20;
+    int64_t res = 0;
+    if (a < 0) a = PI - a;
+    a %= 2 * PI;
+    if (a >= PI * 3 / 2) a -= 2 * PI;
+    if (a >= PI / 2) a = PI - a;
+    const int64_t a2 = (a * a) / F2;
+    for (int i = 2; i < 11; i += 2) {
+        res += a;
+        a = -a * a2 / (F2 * i * (i + 1));
+    }
+    return (res + 8) >> 4;
+}
+
+int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                  double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream)
+{
+    if (inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0) return 0;
+    if (bpp < 1 || bpp > 4) return GMAT_ERR(ENOSYS);
+    RotateParams p;
+    const int FIXP = 1 << 16;
+    const int angle_int = (int)(angleRad * FIXP * 16);                    // filter_frame, vf_rotate.c:520-522
+    p.s = (int)rot_int_sin(angle_int);
+    p.c = (int)rot_int_sin(angle_int + 3294199 / 2);
+    const int xi = -(outW - 1) * p.c / 2, yi = (outW - 1) * p.s / 2;      // :538-541 (C division truncates)
+    const int xprime = -(outH - 1) * p.s / 2, yprime = -(outH - 1) * p.c / 2;
+    p.X0 = xprime + xi + FIXP * (inW - 1) / 2;
+    p.Y0 = yprime + yi + FIXP * (inH - 1) / 2;
+    p.inW = inW; p.inH = inH; p.outW = outW; p.outH = outH;
+    p.bilinear = bilinear; p.fillEnable = fill != nullptr; p.fill = 0;
+    for (int k = 0; k < bpp && fill; k++) p.fill |= (unsigned)fill[k] << (8 * k);
+    const dim3 grid((outW + 255) / 256, (outH + 3) / 4), block(256);
+    const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
+    switch (bpp) {
+    case 1: hipLaunchKernelGGL(rotate_kernel<1>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
+    case 2: hipLaunchKernelGGL(rotate_kernel<2>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
+    case 3: hipLaunchKernelGGL(rotate_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
+    default: hipLaunchKernelGGL(rotate_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // rotate(90, clockwise) then horizontal flip is the plain transpose out(x, y) = in(y, x); the 3x3
 // kernel 1 2 1 / 2 4 2 / 1 2 1 is symmetric and vf_convolution's border rule is the same on both
 // axes, so smoothing commutes with the transpose: smooth the source tile, store it transposed.

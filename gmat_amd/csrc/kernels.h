@@ -107,6 +107,10 @@ int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStrid
                    int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream);
 int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                               int inW, int inH, int bpp, hipStream_t stream);
+// arbitrary angle (radians, clockwise positive) in vf_rotate.c's 16.16 fixed point; fill == nullptr leaves
+// the pixels whose source position is out of range untouched
+int launch_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int inW, int inH, int outW, int outH,
+                  int bpp, double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream);
 
 } // namespace gmat
 

@@ -77,6 +77,8 @@ _SIGS = {
     "gmat_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_smooth3x3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_int), C.c_float, C.c_float, C.c_void_p]),
+    "gmat_rotate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "gmat_rotate_flip_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_set_log_callback": (None, [C.c_void_p]),
     "gmat_device_count": (C.c_int, []),

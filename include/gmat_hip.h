@@ -167,7 +167,9 @@ GMAT_API void gmat_host_frame_free(GmatFrame *frame);
  *    flip_hip    <- vf_flip_nvcv.c    option  code 0|1|-1        (:77-80)
  *    rotate_hip  <- vf_rotate_nvcv.c  options angle, interp, shift_x, shift_y (:79-88);
  *                   multiples of 90 degrees are exact transposes (vf_transpose.c semantics,
- *                   output w/h swapped); other angles are rejected with ENOSYS this round
+ *                   output w/h swapped); other angles run the CPU rotate filter's fixed-point
+ *                   arithmetic (vf_rotate.c), interp linear|nearest, same-size output on black;
+ *                   interp cubic|area and non-zero shift_x/shift_y (CV-CUDA only) -> ENOSYS
  *    transpose_hip <- vf_transpose.c  option dir 0..3 (names :374-379)
  *    smooth_hip  <- vf_smooth_nvcv.c  options type, kw, kh, border_type, sigmaX, sigmaY (:82-105);
  *                   3x3 "gaussian" = integer kernel 1 2 1 / 2 4 2 / 1 2 1, rdiv 1/16
@@ -204,6 +206,14 @@ GMAT_API int gmat_crop(const uint8_t *src, int srcStride, uint8_t *dst, int dstS
                        int x, int y, int w, int h, int bpp, void *stream);
 GMAT_API int gmat_smooth3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                             int w, int h, int bpp, const int matrix[9], float rdiv, float bias, void *stream);
+/* Arbitrary-angle rotation about the centre, bit-exact with the CPU rotate filter's 16.16 fixed point
+ * (vf_rotate.c:198-249 int_sin + interpolate_bilinear8, :410-548 position walk).  angle_rad > 0 turns
+ * clockwise; bilinear 0 = nearest; fill = bpp bytes written where the source position is out of range,
+ * NULL = leave those pixels untouched (fillcolor=none).  rotate_hip uses it for angles that are not
+ * multiples of 90 degrees, with out size = in size and a black background like rotate_nvcv. */
+GMAT_API int gmat_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                         int inW, int inH, int outW, int outH, int bpp, double angle_rad, int bilinear,
+                         const uint8_t *fill, void *stream);
 /* rotate(90 clockwise) + horizontal flip + 3x3 smooth in ONE kernel (cfg4 fused form) */
 GMAT_API int gmat_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                                      int inW, int inH, int bpp, void *stream);

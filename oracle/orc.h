@@ -16,7 +16,7 @@
  *   libswscale/swscale.c      — hScale8To15_c / hScale16To15_c, the swscale() row schedule
  *   libswscale/output.c       — yuv2rgb_{X,2,1}_c and yuv2rgb_full_{X,2,1}_c templates,
  *                               yuv2planeX_8_c / yuv2plane1_8_c / yuv2nv12cX_c
- *   libavfilter/vf_transpose.c, vf_hflip.c, vf_vflip.c, vf_crop.c, vf_convolution.c
+ *   libavfilter/vf_transpose.c, vf_hflip.c, vf_vflip.c, vf_crop.c, vf_convolution.c, vf_rotate.c
  *
  * PARITY PIN STATUS: the reference's libswscale cannot be built in this
  * image without generated headers (config.h) and stand-ins for cuda.h / CV-CUDA, so no
@@ -147,6 +147,11 @@ void orc_crop(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
 /* vf_convolution.c:495-512 + setup_3x3 :555-569 applied per channel of a packed frame */
 void orc_conv3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                  int w, int h, int bpp, const int matrix[9], float rdiv, float bias);
+/* vf_rotate.c:198-548 — arbitrary angle (radians, clockwise positive), 16.16 fixed point; fill NULL = leave */
+void orc_rotate_sincos(double angle_rad, int *s, int *c);
+void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                int inw, int inh, int outw, int outh, int bpp, double angle_rad, int bilinear,
+                const uint8_t *fill);
 void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                        int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
 

@@ -91,3 +91,88 @@ void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst
         }
     }
 }
+
+/* ---- vf_rotate.c: arbitrary-angle rotation in 16.16 fixed point ---------------------------------
+ * int_sin                 vf_rotate.c:198-218   Taylor series on angles scaled by 2^20, result scaled by 2^16
+ * interpolate_bilinear8   vf_rotate.c:224-249
+ * filter_slice            vf_rotate.c:410-498   (general branch: the four exact quarter-turn branches are the
+ *                                                transposes/flips restated above)
+ * filter_frame            vf_rotate.c:500-548   angle_int = angle * FIXP * 16; per-plane xi / yi / xprime / yprime
+ * One plane of `bpp`-byte pixels; the caller passes plane dimensions (chroma planes: ceil-shifted sizes).
+ * fill == NULL: pixels whose source position is out of range are left untouched (fillcolor=none). */
+#define ROT_FIXP  (1 << 16)
+#define ROT_FIXP2 (1 << 20)
+#define ROT_INT_PI 3294199
+
+static int64_t rot_int_sin(int64_t a)
+{
+    int64_t a2, res = 0;
+    int i;
+    if (a < 0) a = ROT_INT_PI - a;
+    a %= 2 * ROT_INT_PI;
+    if (a >= ROT_INT_PI * 3 / 2) a -= 2 * ROT_INT_PI;
+    if (a >= ROT_INT_PI / 2) a = ROT_INT_PI - a;
+    a2 = (a * a) / ROT_FIXP2;
+    for (i = 2; i < 11; i += 2) {
+        res += a;
+        a = -a * a2 / (ROT_FIXP2 * i * (i + 1));
+    }
+    return (res + 8) >> 4;
+}
+
+void orc_rotate_sincos(double angle_rad, int *s, int *c)
+{
+    int angle_int = (int)(angle_rad * ROT_FIXP * 16);
+    *s = (int)rot_int_sin(angle_int);
+    *c = (int)rot_int_sin(angle_int + ROT_INT_PI / 2);
+}
+
+static int rot_clip(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                int inw, int inh, int outw, int outh, int bpp, double angle_rad, int bilinear,
+                const uint8_t *fill)
+{
+    int s, c, i, j, k;
+    int xi, yi, xprime, yprime;
+    orc_rotate_sincos(angle_rad, &s, &c);
+    xi = -(outw - 1) * c / 2; yi = (outw - 1) * s / 2;
+    xprime = -(outh - 1) * s / 2;
+    yprime = -(outh - 1) * c / 2;
+    if (fill)                                    /* ff_fill_rectangle over the whole output, :527-529 */
+        for (j = 0; j < outh; j++)
+            for (i = 0; i < outw; i++)
+                for (k = 0; k < bpp; k++) dst[(long)j * dst_stride + i * bpp + k] = fill[k];
+    for (j = 0; j < outh; j++) {
+        int x = xprime + xi + ROT_FIXP * (inw - 1) / 2;
+        int y = yprime + yi + ROT_FIXP * (inh - 1) / 2;
+        for (i = 0; i < outw; i++) {
+            int x1 = x >> 16, y1 = y >> 16;
+            if (x1 >= -1 && x1 <= inw && y1 >= -1 && y1 <= inh) {
+                uint8_t *pout = dst + (long)j * dst_stride + i * bpp;
+                if (bilinear) {
+                    int int_x = rot_clip(x >> 16, 0, inw - 1), int_y = rot_clip(y >> 16, 0, inh - 1);
+                    int frac_x = x & 0xFFFF, frac_y = y & 0xFFFF;
+                    int int_x1 = int_x + 1 < inw - 1 ? int_x + 1 : inw - 1;
+                    int int_y1 = int_y + 1 < inh - 1 ? int_y + 1 : inh - 1;
+                    for (k = 0; k < bpp; k++) {
+                        int s00 = src[bpp * int_x  + k + (long)src_stride * int_y];
+                        int s01 = src[bpp * int_x1 + k + (long)src_stride * int_y];
+                        int s10 = src[bpp * int_x  + k + (long)src_stride * int_y1];
+                        int s11 = src[bpp * int_x1 + k + (long)src_stride * int_y1];
+                        int s0 = ((1 << 16) - frac_x) * s00 + frac_x * s01;
+                        int s1 = ((1 << 16) - frac_x) * s10 + frac_x * s11;
+                        pout[k] = (uint8_t)(((int64_t)((1 << 16) - frac_y) * s0 + (int64_t)frac_y * s1) >> 32);
+                    }
+                } else {
+                    int x2 = rot_clip(x1, 0, inw - 1), y2 = rot_clip(y1, 0, inh - 1);
+                    for (k = 0; k < bpp; k++) pout[k] = src[(long)y2 * src_stride + x2 * bpp + k];
+                }
+            }
+            x += c;
+            y -= s;
+        }
+        xprime += s;
+        yprime += c;
+    }
+}

@@ -35,6 +35,9 @@ def load_oracle(path):
     L.orc_crop.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
     L.orc_conv3x3.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.POINTER(C.c_int), C.c_float, C.c_float]
+    L.orc_rotate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_double, C.c_int, C.c_void_p]
+    L.orc_rotate_sincos.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_rgb24_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.orc_fill_lcg.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
     return Oracle(L)

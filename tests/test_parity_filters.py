@@ -206,7 +206,9 @@ def test_filter_layer_errors(dev):
     lib.gmat_filter_free(f)
     f = lib.gmat_filter_alloc(b"rotate_hip")
     lib.gmat_filter_set_option(f, b"angle", b"33")
-    assert lib.gmat_filter_init(f) < 0                       # arbitrary angles: ENOSYS this round
+    assert lib.gmat_filter_init(f) == 0                      # arbitrary angles: vf_rotate.c fixed point
+    lib.gmat_filter_set_option(f, b"interp", b"cubic")
+    assert lib.gmat_filter_init(f) < 0                       # cubic / area: CV-CUDA only
     lib.gmat_filter_free(f)
     f = lib.gmat_filter_alloc(b"flip_hip")
     assert lib.gmat_filter_init(f) == 0
@@ -327,3 +329,69 @@ def test_filter_layer_scale_keeps_yuv_format(dev, orc):
     assert len(res) == 3
     for a, b in zip(res, want):
         assert (a == b).all()
+
+
+# ---- arbitrary-angle rotation (vf_rotate.c fixed point) ---------------------------------------------------
+import math
+
+
+def test_rotate_fixed_point_sincos_known_values(orc):
+    s, c = C.c_int(), C.c_int()
+    for deg, es, ec in [(0, 0, 65536), (90, 65536, 0), (180, 0, -65536), (30, 32768, 56756), (-45, -46341, 46341)]:
+        orc.L.orc_rotate_sincos(math.radians(deg), C.byref(s), C.byref(c))
+        assert abs(s.value - es) <= 4 and abs(c.value - ec) <= 4, (deg, s.value, c.value)   # 5-term Taylor series
+
+
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+@pytest.mark.parametrize("deg", [17.0, -33.5, 45.0, 100.0, 181.0, 359.0])
+@pytest.mark.parametrize("bilinear", [1, 0])
+def test_rotate_arbitrary_angle(dev, orc, bpp, deg, bilinear):
+    w, h = (131, 77) if bpp != 4 else (96, 40)
+    src = orc.lcg((h, w * bpp), 9)
+    fill = np.array([3, 250, 128, 255], np.uint8)
+    want = np.full((h, w * bpp), 0x11, np.uint8)
+    orc.L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp,
+                     math.radians(deg), bilinear, fill.ctypes.data)
+    for align, extra in [(256, 0), (1, 1)]:
+        d = dev.upload_planes([src], align, extra)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + extra + align - 1) // align * align)
+        assert dev.lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), bilinear,
+                                   fill.ctypes.data, None) == 0
+        got = o.download()
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+        d.free(); o.free()
+
+
+def test_rotate_without_fill_and_other_output_size(dev, orc):
+    w, h, ow, oh, bpp = 90, 50, 120, 70, 3
+    src = orc.lcg((h, w * bpp), 10)
+    want = np.full((oh, ow * bpp), 0xCD, np.uint8)            # DevPlane's initial fill: untouched pixels keep it
+    orc.L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, ow, oh, bpp,
+                     math.radians(25.0), 1, None)
+    d = dev.upload_planes([src], 64)[0]
+    o = DevPlane(dev, oh, ow * bpp, (ow * bpp + 63) // 64 * 64)
+    assert dev.lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, ow, oh, bpp, math.radians(25.0), 1, None, None) == 0
+    assert (o.download() == want).all()
+    d.free(); o.free()
+
+
+@pytest.mark.parametrize("fmt", ["rgb24", "rgba", "yuv420p", "nv12"])
+def test_filter_layer_rotate_arbitrary(dev, orc, fmt):
+    w, h = 96, 40
+    src = synth_planes(orc, fmt, w, h, 93)
+    res, ow, oh = _run_filter_planes(dev, "rotate_hip", {"angle": 30, "interp": "linear"}, src, w, h, fmt)
+    assert (ow, oh) == (w, h)
+    for i, pl in enumerate(src):
+        bpp = {"rgb24": 3, "rgba": 4}.get(fmt, _plane_bpp(fmt, i))
+        pw, ph = pl.shape[1] // bpp, pl.shape[0]
+        if fmt in ("rgb24", "rgba"):
+            fill = np.array([0, 0, 0, 255], np.uint8)
+        else:
+            fill = np.array([16 if i == 0 else 128, 128, 0, 0], np.uint8)
+        want = np.zeros_like(pl)
+        pl = np.ascontiguousarray(pl)
+        orc.L.orc_rotate(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, pw, ph, bpp,
+                         30 * math.pi / 180.0, 1, fill.ctypes.data)
+        assert (res[i] == want).all(), (fmt, i)
