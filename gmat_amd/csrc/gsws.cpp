@@ -23,7 +23,7 @@ using namespace gmat;
 
 namespace {
 
-enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV };
+enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH };
 
 struct DevBuf {
     void *p = nullptr;
@@ -290,6 +290,10 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         r = init_rgb2yuv(c);
     } else if (same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
         c->mode = MODE_YUV2YUV;
+    } else if (same && is_yuv420(srcFormat) && (dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE)) {
+        // planar8ToP01xleWrapper (swscale_unscaled.c:286-324, selected :2108-2112 for YUV420P); NV12 sources get
+        // the same sample rule (the reference GPU path yuv2yuv_cuda.cu:320-371 takes both)
+        c->mode = MODE_DEPTH;
     } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
@@ -442,6 +446,17 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         else r = launch_uv_relayout(0, src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], nullptr, 0, cw, ch, c->stream);
         break;
     }
+    case MODE_DEPTH: {
+        const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12;
+        if (!dst[1]) { r = GMAT_ERR(EINVAL); break; }
+        c->lastKernel = "widen8to16_kernel";
+        if ((r = launch_widen8to16(src[0], srcStride[0], nullptr, 0, dst[0], dstStride[0], c->srcW, c->srcH, c->stream)) < 0) break;
+        // the CPU wrapper converts srcW / 2 chroma pairs on ceil(srcH / 2) rows (:309-317)
+        const int cw = c->srcW / 2, ch = ceil_rshift(c->srcH, 1);
+        if (snv) r = launch_widen8to16(src[1], srcStride[1], nullptr, 0, dst[1], dstStride[1], 2 * cw, ch, c->stream);
+        else     r = launch_widen8to16(src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], cw, ch, c->stream);
+        break;
+    }
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
         if (is_yuv420(c->srcFormat) && c->fused == 2) {
@@ -591,7 +606,8 @@ int rgb2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstS
 int yuv2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h, int srcFormat,
                  int dstFormat, void *stream)
 {
-    if (!is_yuv420(srcFormat) || !is_yuv420(dstFormat)) return GMAT_ERR(ENOSYS);
+    if (!is_yuv420(srcFormat) || !(is_yuv420(dstFormat) || dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE))
+        return GMAT_ERR(ENOSYS);
     return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
 }
 

@@ -130,25 +130,70 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
     }
 }
 
-// NV12 <-> YUV420P chroma re-layout (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c)
+// NV12 <-> YUV420P chroma re-layout (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c).
+// A thread moves 4 chroma samples of each plane: 8 interleaved bytes <-> 4 + 4 planar bytes (v_perm_b32).
 __global__ __launch_bounds__(256) void uv_deinterleave_kernel(const uint8_t *uv, int uvs, uint8_t *u, int us, uint8_t *v, int vs,
-                                                              int cw, int ch)
+                                                              int cw, int ch, int aligned)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= cw || y >= ch) return;
     const uint8_t *s = uv + (size_t)y * uvs + 2 * x;
-    u[(size_t)y * us + x] = s[0];
-    v[(size_t)y * vs + x] = s[1];
+    uint8_t *du = u + (size_t)y * us + x, *dv = v + (size_t)y * vs + x;
+    if (aligned && x + 4 <= cw) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(s);            // U0 V0 U1 V1 | U2 V2 U3 V3
+        *reinterpret_cast<unsigned *>(du) = __builtin_amdgcn_perm(t.y, t.x, 0x06040200u);
+        *reinterpret_cast<unsigned *>(dv) = __builtin_amdgcn_perm(t.y, t.x, 0x07050301u);
+    } else {
+        for (int i = 0; i < min(4, cw - x); i++) { du[i] = s[2 * i]; dv[i] = s[2 * i + 1]; }
+    }
 }
 
 __global__ __launch_bounds__(256) void uv_interleave_kernel(const uint8_t *u, int us, const uint8_t *v, int vs, uint8_t *uv, int uvs,
-                                                            int cw, int ch)
+                                                            int cw, int ch, int aligned)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= cw || y >= ch) return;
+    const uint8_t *su = u + (size_t)y * us + x, *sv = v + (size_t)y * vs + x;
     uint8_t *d = uv + (size_t)y * uvs + 2 * x;
-    d[0] = u[(size_t)y * us + x];
-    d[1] = v[(size_t)y * vs + x];
+    if (aligned && x + 4 <= cw) {
+        const unsigned a = *reinterpret_cast<const unsigned *>(su), b = *reinterpret_cast<const unsigned *>(sv);
+        *reinterpret_cast<uint2 *>(d) = make_uint2(__builtin_amdgcn_perm(b, a, 0x05010400u), __builtin_amdgcn_perm(b, a, 0x07030602u));
+    } else {
+        for (int i = 0; i < min(4, cw - x); i++) { d[2 * i] = su[i]; d[2 * i + 1] = sv[i]; }
+    }
+}
+
+// 8 -> 16 bit expansion of planar8ToP01xleWrapper (swscale_unscaled.c:286-324): every sample t becomes the
+// little-endian 16-bit value t | t << 8 (P010LE and P016LE alike; no 10-bit mask on the CPU).  One plane
+// (b == nullptr: n bytes per row -> n words) or two planes interleaved (U, V -> U16 V16 pairs).
+__global__ __launch_bounds__(256) void widen8to16_kernel(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds,
+                                                         int n, int h, int aligned)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= n || y >= h) return;
+    const uint8_t *pa = a + (size_t)y * sa + x;
+    if (!b) {
+        uint8_t *o = d + (size_t)y * ds + 2 * x;
+        if (aligned && x + 4 <= n) {
+            const unsigned t = *reinterpret_cast<const unsigned *>(pa);
+            *reinterpret_cast<uint2 *>(o) = make_uint2(__builtin_amdgcn_perm(0u, t, 0x01010000u), __builtin_amdgcn_perm(0u, t, 0x03030202u));
+        } else {
+            for (int i = 0; i < min(4, n - x); i++) { o[2 * i] = pa[i]; o[2 * i + 1] = pa[i]; }
+        }
+    } else {
+        const uint8_t *pb = b + (size_t)y * sb + x;
+        uint8_t *o = d + (size_t)y * ds + 4 * x;
+        if (aligned && x + 4 <= n) {
+            const unsigned u = *reinterpret_cast<const unsigned *>(pa), v = *reinterpret_cast<const unsigned *>(pb);
+            *reinterpret_cast<uint4 *>(o) = make_uint4(__builtin_amdgcn_perm(v, u, 0x04040000u), __builtin_amdgcn_perm(v, u, 0x05050101u),
+                                                       __builtin_amdgcn_perm(v, u, 0x06060202u), __builtin_amdgcn_perm(v, u, 0x07070303u));
+        } else {
+            for (int i = 0; i < min(4, n - x); i++) {
+                o[4 * i] = o[4 * i + 1] = pa[i];
+                o[4 * i + 2] = o[4 * i + 3] = pb[i];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -198,9 +243,26 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
                        int ds1, int cw, int ch, hipStream_t stream)
 {
     if (cw <= 0 || ch <= 0) return 0;
-    const dim3 grid((cw + 255) / 256, ch), block(256);
-    if (toPlanar) hipLaunchKernelGGL(uv_deinterleave_kernel, grid, block, 0, stream, a0, s0, d0, ds0, d1, ds1, cw, ch);
-    else          hipLaunchKernelGGL(uv_interleave_kernel, grid, block, 0, stream, a0, s0, a1, s1, d0, ds0, cw, ch);
+    const dim3 grid((cw + 1023) / 1024, ch), block(256);
+    if (toPlanar) {
+        const int al = ((((uintptr_t)a0 | (uintptr_t)s0) & 7) == 0) && ((((uintptr_t)d0 | (uintptr_t)ds0 | (uintptr_t)d1 | (uintptr_t)ds1) & 3) == 0);
+        hipLaunchKernelGGL(uv_deinterleave_kernel, grid, block, 0, stream, a0, s0, d0, ds0, d1, ds1, cw, ch, al);
+    } else {
+        const int al = ((((uintptr_t)d0 | (uintptr_t)ds0) & 7) == 0) && ((((uintptr_t)a0 | (uintptr_t)s0 | (uintptr_t)a1 | (uintptr_t)s1) & 3) == 0);
+        hipLaunchKernelGGL(uv_interleave_kernel, grid, block, 0, stream, a0, s0, a1, s1, d0, ds0, cw, ch, al);
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds, int n, int h, hipStream_t stream)
+{
+    if (n <= 0 || h <= 0) return 0;
+    const dim3 grid((n + 1023) / 1024, h), block(256);
+    const int outAlign = b ? 15 : 7;
+    const int al = ((((uintptr_t)d | (uintptr_t)ds) & outAlign) == 0) && ((((uintptr_t)a | (uintptr_t)sa) & 3) == 0) &&
+                   (!b || (((uintptr_t)b | (uintptr_t)sb) & 3) == 0);
+    hipLaunchKernelGGL(widen8to16_kernel, grid, block, 0, stream, a, sa, b, sb, d, ds, n, h, al);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -134,6 +134,10 @@ int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
 // toPlanar: (a0 = interleaved UV) -> d0 = U, d1 = V;  else (a0 = U, a1 = V) -> d0 = interleaved UV
 int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0,
                        uint8_t *d1, int ds1, int cw, int ch, hipStream_t stream);
+// 8 -> 16 bit, t -> t | t << 8 (planar8ToP01xleWrapper): n samples per row of plane a (b == nullptr), or n
+// (a, b) sample pairs interleaved
+int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds, int n, int h,
+                      hipStream_t stream);
 } // namespace gmat
 
 // ---- 2:1 specialisation of the YUV scaler (k_scale_yuv2x.hip) -------------------------------------

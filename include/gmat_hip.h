@@ -21,7 +21,9 @@ extern "C" {
 #define GMAT_API __attribute__((visibility("default")))
 #define GMAT_ERR(e) (-(e))
 
-/* ---- pixel formats: the integer values of enum AVPixelFormat, libavutil/pixfmt.h:65-318 ---- */
+/* ---- pixel formats: the integer values of enum AVPixelFormat, libavutil/pixfmt.h:64-376, as the
+ * reference tree's preprocessor evaluates it (libavutil major 57: the FF_API_XVMC entry :263-265 is
+ * present).  A caller inside the reference tree passes its AV_PIX_FMT_* values unchanged. ---- */
 enum GmatPixelFormat {
     GMAT_PIX_FMT_NONE      = -1,
     GMAT_PIX_FMT_YUV420P   = 0,
@@ -30,8 +32,10 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_NV12      = 23,
     GMAT_PIX_FMT_RGBA      = 26,
     GMAT_PIX_FMT_BGRA      = 28,
-    GMAT_PIX_FMT_HIP       = 120,   /* occupies AV_PIX_FMT_CUDA's slot: opaque device frame */
-    GMAT_PIX_FMT_RGBPF32LE = 182,   /* GMAT addition, pixfmt.h:315 */
+    GMAT_PIX_FMT_HIP       = 117,   /* AV_PIX_FMT_CUDA's slot (pixfmt.h:225): opaque device frame */
+    GMAT_PIX_FMT_P010LE    = 159,   /* pixfmt.h:276 — like NV12, 16-bit containers, data in the high bits */
+    GMAT_PIX_FMT_P016LE    = 170,
+    GMAT_PIX_FMT_RGBPF32LE = 179,   /* GMAT addition, pixfmt.h:315 */
 };
 
 /* ---- scaler flags: libswscale/swscale.h:65-95 ---- */

@@ -58,7 +58,9 @@ enum {
     ORC_PIX_NV12    = 23,
     ORC_PIX_RGBA    = 26,
     ORC_PIX_BGRA    = 28,
-    ORC_PIX_RGBPF32LE = 182,
+    ORC_PIX_P010LE  = 159,
+    ORC_PIX_P016LE  = 170,
+    ORC_PIX_RGBPF32LE = 179,
 };
 
 /* libswscale/swscale.h:65-95 */
@@ -152,6 +154,10 @@ void orc_rotate_sincos(double angle_rad, int *s, int *c);
 void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                 int inw, int inh, int outw, int outh, int bpp, double angle_rad, int bilinear,
                 const uint8_t *fill);
+/* planar8ToP01xleWrapper, swscale_unscaled.c:286-324: 8-bit 4:2:0 -> P010LE / P016LE, t -> t | t << 8.
+ * src_nv12 != 0: the same rule applied to an NV12 source (src[1] interleaved). */
+void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
+                        const int dst_stride[4], int w, int h, int src_nv12);
 void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                        int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
 

@@ -176,3 +176,30 @@ void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride
         yprime += c;
     }
 }
+
+/* planar8ToP01xleWrapper, swscale_unscaled.c:286-324 */
+void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
+                        const int dst_stride[4], int w, int h, int src_nv12)
+{
+    int x, y;
+    for (y = 0; y < h; y++) {
+        const uint8_t *s = src[0] + (long)y * src_stride[0];
+        uint16_t *d = (uint16_t *)(dst[0] + (long)y * dst_stride[0]);
+        for (x = 0; x < w; x++) d[x] = (uint16_t)(s[x] | (s[x] << 8));
+        if (!(y & 1)) {
+            uint16_t *duv = (uint16_t *)(dst[1] + (long)(y / 2) * dst_stride[1]);
+            for (x = 0; x < w / 2; x++) {
+                int u, v;
+                if (src_nv12) {
+                    u = src[1][(long)(y / 2) * src_stride[1] + 2 * x];
+                    v = src[1][(long)(y / 2) * src_stride[1] + 2 * x + 1];
+                } else {
+                    u = src[1][(long)(y / 2) * src_stride[1] + x];
+                    v = src[2][(long)(y / 2) * src_stride[2] + x];
+                }
+                duv[2 * x]     = (uint16_t)(u | (u << 8));
+                duv[2 * x + 1] = (uint16_t)(v | (v << 8));
+            }
+        }
+    }
+}

@@ -38,6 +38,8 @@ def load_oracle(path):
     L.orc_rotate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_int, C.c_void_p]
     L.orc_rotate_sincos.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_yuv420_to_p01x.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                     C.c_int, C.c_int, C.c_int]
     L.orc_rgb24_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.orc_fill_lcg.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
     return Oracle(L)
@@ -126,6 +128,8 @@ def plane_shapes(fmt, w, h):
         return [(h, w), ((h + 1) // 2, (w + 1) // 2), ((h + 1) // 2, (w + 1) // 2)]
     if fmt == "rgbpf32le":
         return [(h, 4 * w)] * 3
+    if fmt in ("p010le", "p016le"):
+        return [(h, 2 * w), ((h + 1) // 2, 4 * ((w + 1) // 2))]
     raise ValueError(fmt)
 
 

@@ -72,3 +72,33 @@ def test_yuv_relayout_lossless(dev, orc, w, h, pair):
     r = dev.lib.yuv2yuv_cuda(planes([p.ptr for p in d_src]), ints([p.stride for p in d_src]),
                              planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h, PIX_FMT[s], PIX_FMT[d], None)
     assert r == 0 and all((a.download() == b).all() for a, b in zip(dst, got))
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (131, 35), (8, 2), (1920, 8)])
+@pytest.mark.parametrize("src_fmt", ["yuv420p", "nv12"])
+@pytest.mark.parametrize("dst_fmt", ["p010le", "p016le"])
+def test_depth_expansion_to_p01x(dev, orc, w, h, src_fmt, dst_fmt):
+    """planar8ToP01xleWrapper: t -> t | t << 8 (swscale_unscaled.c:286-324); odd widths leave the last chroma pair
+    unwritten exactly like the CPU loop (srcW / 2 pairs)."""
+    from harness import alloc_planes
+    src = synth_planes(orc, src_fmt, w, h, seed=59)
+    want = alloc_planes(dst_fmt, w, h, fill=0xCD)
+    orc.L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                             planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h,
+                             1 if src_fmt == "nv12" else 0)
+    for align, extra in [(256, 0), (2, 2)]:
+        d_src = dev.upload_planes(src, align if align > 2 else 1, extra)
+        got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, dst_fmt, dst_align=align, dst_extra=extra)
+        assert kernel == "widen8to16_kernel"
+        for g, wv, pd in zip(got, want, pads):
+            assert (g == wv).all()
+            assert (pd == 0xCD).all()
+        for p in d_src:
+            p.free()
+    # the reference's symbol
+    d_src = dev.upload_planes(src, 64)
+    dst = dev.planes_like(dst_fmt, w, h, 64)
+    r = dev.lib.yuv2yuv_cuda(planes([p.ptr for p in d_src]), ints([p.stride for p in d_src]),
+                             planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h, PIX_FMT[src_fmt],
+                             PIX_FMT[dst_fmt], None)
+    assert r == 0 and all((a.download() == b).all() for a, b in zip(dst, want))
