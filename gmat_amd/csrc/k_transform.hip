@@ -115,6 +115,73 @@ __device__ __forceinline__ void tile_to_lds(const uint8_t *src, int ss, int rowB
     }
 }
 
+// 16-byte tile loader.  Chunk c of tile row r = source bytes [a16 + 16c, a16 + 16c + 16) of row rowOf(r), stored at
+// lds + r*pitch + 16c (pitch a multiple of 4).  CL lanes span a row's chunks (n16 <= CL), 256/CL rows per pass, K
+// passes; ALL of a thread's loads are issued before its first LDS write — with the earlier dword-per-lane loader a
+// 66-row tile cost three dependent HBM round trips per wave and the load phase alone took 21 of the 3x3 smooth's
+// 37 us.  Chunks that stick out of [0, rowBytes) (tiles on the left / right frame edge) or unaligned sources are
+// assembled bytewise with the column clamped.
+template <int CL, int K, typename RowOf>
+__device__ __forceinline__ void tile_to_lds16(const uint8_t *src, int ss, int rowBytes, int a16, int n16, int nrows,
+                                              uint8_t *lds, int pitch, int tid, bool fast, RowOf rowOf)
+{
+    constexpr int RPP = 256 / CL;                          // rows per pass
+    const int c = tid % CL, rb = tid / CL;
+    const int a = a16 + 16 * c;
+    const bool inside = fast && a >= 0 && a + 16 <= rowBytes;
+    uint4 v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = rb + RPP * k;
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (c < n16 && r < nrows) {
+            const uint8_t *row = src + (size_t)rowOf(r) * ss;
+            if (inside) {
+                v[k] = *reinterpret_cast<const uint4 *>(row + a);
+            } else {
+                unsigned w[4] = {0u, 0u, 0u, 0u};
+                for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)row[min(max(a + i, 0), rowBytes - 1)] << (8 * (i & 3));
+                v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = rb + RPP * k;
+        if (c < n16 && r < nrows) {
+            unsigned *d = reinterpret_cast<unsigned *>(lds + r * pitch + 16 * c);
+            d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+    }
+}
+
+// 16-byte tile store, the mirror of tile_to_lds16: tile row r (n bytes at lds + r*pitch) goes to byte offset b0 of
+// destination row rowOf(r).  b0 is a multiple of 16 for every caller; whole chunks of 16-byte-aligned destinations
+// are written with one global_store_dwordx4, the rest bytewise.
+template <int CL, int K, typename RowOf>
+__device__ __forceinline__ void lds_to_tile16(uint8_t *dst, int ds, int b0, int n, int nrows, const uint8_t *lds, int pitch,
+                                              int tid, bool fast, RowOf rowOf)
+{
+    constexpr int RPP = 256 / CL;
+    const int c = tid % CL, rb = tid / CL;
+    const int n16 = (n + 15) >> 4;
+    if (c >= n16) return;
+    const bool whole = fast && 16 * c + 16 <= n;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int r = rb + RPP * k;
+        if (r >= nrows) break;
+        const unsigned *s = reinterpret_cast<const unsigned *>(lds + r * pitch + 16 * c);
+        uint8_t *d = dst + (size_t)rowOf(r) * ds + b0 + 16 * c;
+        if (whole) {
+            *reinterpret_cast<uint4 *>(d) = make_uint4(s[0], s[1], s[2], s[3]);
+        } else {
+            const uint8_t *sb = reinterpret_cast<const uint8_t *>(s);
+            for (int i = 0; i < min(16, n - 16 * c); i++) d[i] = sb[i];
+        }
+    }
+}
+
 // ---- transpose (+ optional source/destination vertical reversal = the four transpose dirs) -----
 template <int BPP, int T>
 __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
@@ -127,8 +194,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
     const int ix0 = blockIdx.x * T, iy0 = blockIdx.y * T;
     const int tw = min(T, inW - ix0), th = min(T, inH - iy0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    tile_to_lds<T / 4>(src, ss, inW * BPP, ix0 * BPP, tw * BPP, th, tile, PITCH, lane, wave, aligned,
-                       [&](int r) { return (dir & 1) ? inH - 1 - (iy0 + r) : iy0 + r; });
+    {
+        // ix0 * BPP is a multiple of 16 for every (BPP, T) instantiated, so tile byte 0 is chunk-aligned
+        static_assert((T * BPP) % 16 == 0 && T * BPP <= 256, "tile rows are whole 16-byte chunks");
+        constexpr int CL = T * BPP / 16 <= 8 ? 8 : 16;
+        constexpr int K = (T + 256 / CL - 1) / (256 / CL);
+        const bool fast16 = ((((uintptr_t)src | (uintptr_t)ss) & 15) == 0);
+        tile_to_lds16<CL, K>(src, ss, inW * BPP, ix0 * BPP, (tw * BPP + 15) >> 4, th, tile, PITCH, (int)threadIdx.x, fast16,
+                             [&](int r) { return (dir & 1) ? inH - 1 - (iy0 + r) : iy0 + r; });
+    }
     __syncthreads();
     // output: out(x = iy0 + r, y = ix0 + c) = tile[r][c]; out is inH wide, inW tall
     const int outH = inW;
@@ -219,28 +293,42 @@ template <int BPP, int TW, int TH, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
                                                       int w, int h, ConvParams cp, int aligned, int fastCoef)
 {
-    // The source tile holds pixels [x0-1, x0+TW] of rows [y0-1, y0+TH].  x0 is a multiple of 64, so the
-    // first source byte (x0-1)*BPP is (4-BPP) (mod 4) — 3, 2, 1, 0 for 1-, 2-, 3-, 4-byte pixels: SHIFT
-    // re-aligns the tile so that global dwords map to LDS dwords (one ds_write_b32 per loaded dword).
-    constexpr int SHIFT = (4 - BPP) & 3;
-    constexpr int SP = (((TW + 2) * BPP + SHIFT + 3) / 4) * 4 + 4;     // source tile pitch, odd dword count
+    // The source tile holds pixels [x0-1, x0+TW] of rows [y0-1, y0+TH].  x0 is a multiple of 64, so the first
+    // source byte (x0-1)*BPP is (16-BPP) (mod 16) — 15, 14, 13, 12 for 1-, 2-, 3-, 4-byte pixels: the LDS row keeps
+    // that offset (OFF16), so that 16-byte global chunks land on 16-byte LDS chunks (tile_to_lds16) and global
+    // dwords on LDS dwords (SHIFT = OFF16 mod 4 is the byte position of the first tile byte inside its dword).
+    constexpr int OFF16 = (16 - BPP) & 15;
+    constexpr int SHIFT = OFF16 & 3;
+    constexpr int N16 = (OFF16 + (TW + 2) * BPP + 15) / 16;            // 16-byte chunks per tile row
+    constexpr int SP = N16 * 16 + 16;                                  // source tile pitch (compute reads 2 dwords past)
     constexpr int RP = ((TW * BPP + 3) / 4) * 4 + 4;                   // result tile pitch
-    static_assert((SP / 4) % 2 == 1 && (RP / 4) % 2 == 1, "odd dword pitches keep column accesses conflict-light");
-    __shared__ __attribute__((aligned(16))) uint8_t st_raw[(TH + 2) * SP + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t rt[TH * RP];
-    __shared__ __attribute__((aligned(16))) uint8_t orow[4][((TRANSPOSED ? TH : 1) * BPP + 3) / 4 * 4];
-    uint8_t *st = st_raw + SHIFT;
+    static_assert((RP / 4) % 2 == 1, "odd dword pitch keeps column accesses conflict-light");
+    __shared__ __attribute__((aligned(16))) uint8_t lds16[(TH + 2) * SP];
+    uint8_t *st_raw = lds16 + (OFF16 & ~3);                            // dword base of the tile window
+    // result tile: rows of RP bytes, or — for the transposed store — one row of PT bytes per tile COLUMN
+    constexpr int PT = ((TH * BPP + 3) / 4) * 4 + 4;
+    static_assert((PT / 4) % 2 == 1, "odd dword pitch");
+    constexpr int RT_BYTES = TRANSPOSED ? TW * PT : TH * RP;
+    static_assert((TW * BPP + 3) / 4 <= 64, "one lane per dword column of the tile");
+    __shared__ __attribute__((aligned(16))) uint8_t rt[RT_BYTES];
+    uint8_t *st = st_raw + SHIFT;                                      // = lds16 + OFF16: tile byte 0 of row 0
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tw = min(TW, w - x0), th = min(TH, h - y0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    tile_to_lds<(TH + 2 + 3) / 4>(src, ss, w * BPP, (x0 - 1) * BPP, (tw + 2) * BPP, th + 2, st, SP, lane, wave, aligned,
-                                  [&](int r) {
-                                      int yy = y0 + r - 1;
-                                      yy = yy < 0 ? -yy : yy;
-                                      yy = yy >= h ? 2 * h - 1 - yy : yy;
-                                      return min(max(yy, 0), h - 1);
-                                  });
+    {
+        constexpr int CL = N16 <= 16 ? 16 : 32;
+        constexpr int K = (TH + 2 + 256 / CL - 1) / (256 / CL);
+        static_assert(N16 <= CL, "chunks per row");
+        const bool fast16 = ((((uintptr_t)src | (uintptr_t)ss) & 15) == 0);
+        const int b0 = (x0 - 1) * BPP;                                 // first tile byte; b0 - OFF16 is a multiple of 16
+        tile_to_lds16<CL, K>(src, ss, w * BPP, b0 - OFF16, (OFF16 + (tw + 2) * BPP + 15) >> 4, th + 2, lds16, SP,
+                             (int)threadIdx.x, fast16, [&](int r) {
+                                 int yy = y0 + r - 1;
+                                 yy = yy < 0 ? -yy : yy;
+                                 yy = yy >= h ? 2 * h - 1 - yy : yy;
+                                 return min(max(yy, 0), h - 1);
+                             });
+    }
     __syncthreads();
     // horizontal halo fix-up for tiles touching the frame's left / right edge
     if (x0 == 0 || x0 + tw == w) {
@@ -256,36 +344,40 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
         __syncthreads();
     }
     const int rowDwords = (tw * BPP + 3) >> 2;
+    // result byte (r, cb) -> LDS: row-major, or transposed at pixel granularity
+    auto put_dword = [&](int r, int d, unsigned o) {
+        if (!TRANSPOSED) {
+            reinterpret_cast<unsigned *>(rt + r * RP)[d] = o;
+        } else if (BPP == 4) {
+            *reinterpret_cast<unsigned *>(rt + d * PT + r * 4) = o;               // dword d is pixel d
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int cb = 4 * d + j, px = cb / BPP, b = cb - px * BPP;
+                if (cb < tw * BPP) rt[px * PT + r * BPP + b] = (uint8_t)(o >> (8 * j));
+            }
+        }
+    };
     if (fastCoef) {
-        // coefficients in [0,255]: one output DWORD (4 channel bytes) per item.  Per source row the three
-        // horizontal taps of output byte j are window bytes (SHIFT+j, SHIFT+j+BPP, SHIFT+j+2*BPP): gathered
-        // with v_perm_b32, multiplied with v_dot4_u32_u8.
+        // coefficients in [0,255].  Lane = one DWORD column of the tile (4 channel bytes), wave = TH/4 consecutive
+        // rows.  The lane walks down its column: each source row is read once (3 dwords), its horizontal tap
+        // triples are gathered once with v_perm_b32 (window bytes SHIFT+j, +BPP, +2*BPP) and multiplied with
+        // v_dot4_u32_u8 against the three matrix rows, feeding the three output rows it contributes to.
         const unsigned m0 = (unsigned)cp.m[0] | ((unsigned)cp.m[1] << 8) | ((unsigned)cp.m[2] << 16);
         const unsigned m1 = (unsigned)cp.m[3] | ((unsigned)cp.m[4] << 8) | ((unsigned)cp.m[5] << 16);
         const unsigned m2 = (unsigned)cp.m[6] | ((unsigned)cp.m[7] << 8) | ((unsigned)cp.m[8] << 16);
-        for (int i = threadIdx.x; i < th * rowDwords; i += 256) {
-            const int r = i / rowDwords, d = i - r * rowDwords;
-            unsigned sum[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int rr = 0; rr < 3; rr++) {
-                const unsigned *p = reinterpret_cast<const unsigned *>(st_raw + (r + rr) * SP) + d;
-                const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
-                const unsigned mm = rr == 0 ? m0 : rr == 1 ? m1 : m2;
-                const unsigned g0 = gather3<SHIFT + 0, SHIFT + 0 + BPP, SHIFT + 0 + 2 * BPP>(w0, w1, w2);
-                sum[0] = __builtin_amdgcn_udot4(g0, mm, sum[0], false);
-                const unsigned g1 = gather3<SHIFT + 1, SHIFT + 1 + BPP, SHIFT + 1 + 2 * BPP>(w0, w1, w2);
-                sum[1] = __builtin_amdgcn_udot4(g1, mm, sum[1], false);
-                const unsigned g2 = gather3<SHIFT + 2, SHIFT + 2 + BPP, SHIFT + 2 + 2 * BPP>(w0, w1, w2);
-                sum[2] = __builtin_amdgcn_udot4(g2, mm, sum[2], false);
-                const unsigned g3 = gather3<SHIFT + 3, SHIFT + 3 + BPP, SHIFT + 3 + 2 * BPP>(w0, w1, w2);
-                sum[3] = __builtin_amdgcn_udot4(g3, mm, sum[3], false);
-            }
+        constexpr int RPW = (TH + 3) / 4;
+        const int r0 = wave * RPW, nrows = min(RPW, th - r0);          // wave-uniform
+        const int d = lane;
+        // accumulators start at the rounding constant of the integer epilogue (0 for the float epilogue)
+        const unsigned init = cp.shift >= 0 ? cp.half : 0u;
+        auto emit = [&](int r, const unsigned (&sum)[4]) {
             unsigned o = 0;
             if (cp.shift >= 0) {
                 // rdiv == 2^-shift and bias == 0: (int)(sum * rdiv + 0.5f) == (sum + 2^(shift-1)) >> shift exactly
                 // (sum < 2^24 is exact in float, the product and the + 0.5f are exact too)
 #pragma unroll
-                for (int j = 0; j < 4; j++) o |= min((sum[j] + cp.half) >> cp.shift, 255u) << (8 * j);
+                for (int j = 0; j < 4; j++) o |= min(sum[j] >> cp.shift, 255u) << (8 * j);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -294,7 +386,36 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
                     o |= (unsigned)min(max((int)f, 0), 255) << (8 * j);
                 }
             }
-            reinterpret_cast<unsigned *>(rt + r * RP)[d] = o;
+            put_dword(r, d, o);
+        };
+        if (d < rowDwords && nrows > 0) {
+            unsigned A[4], B[4], Cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) A[j] = B[j] = Cc[j] = init;
+            // step(s): source tile row r0 + s; X = output row s-2 (gets matrix row 2, completes), Y = row s-1
+            // (matrix row 1), Z = row s (matrix row 0, starts)
+#define GMAT_CONV_STEP(s_, X, Y, Z)                                                                              \
+            if ((s_) < nrows + 2) {                                                                              \
+                const unsigned *p = reinterpret_cast<const unsigned *>(st_raw + (r0 + (s_)) * SP) + d;           \
+                const unsigned w0 = p[0], w1 = p[1], w2 = p[2];                                                  \
+                unsigned g[4];                                                                                   \
+                g[0] = gather3<SHIFT + 0, SHIFT + 0 + BPP, SHIFT + 0 + 2 * BPP>(w0, w1, w2);                     \
+                g[1] = gather3<SHIFT + 1, SHIFT + 1 + BPP, SHIFT + 1 + 2 * BPP>(w0, w1, w2);                     \
+                g[2] = gather3<SHIFT + 2, SHIFT + 2 + BPP, SHIFT + 2 + 2 * BPP>(w0, w1, w2);                     \
+                g[3] = gather3<SHIFT + 3, SHIFT + 3 + BPP, SHIFT + 3 + 2 * BPP>(w0, w1, w2);                     \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+                    X[j] = __builtin_amdgcn_udot4(g[j], m2, X[j], false);                                        \
+                    Y[j] = __builtin_amdgcn_udot4(g[j], m1, Y[j], false);                                        \
+                    Z[j] = __builtin_amdgcn_udot4(g[j], m0, init, false);                                        \
+                }                                                                                                \
+                if ((s_) >= 2) emit(r0 + (s_) - 2, X);                                                           \
+            }
+            for (int s = 0; s < nrows + 2; s += 3) {
+                GMAT_CONV_STEP(s, A, B, Cc)
+                GMAT_CONV_STEP(s + 1, B, Cc, A)
+                GMAT_CONV_STEP(s + 2, Cc, A, B)
+            }
+#undef GMAT_CONV_STEP
         }
     } else {
         for (int i = threadIdx.x; i < th * tw * BPP; i += 256) {
@@ -304,21 +425,23 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
 #pragma unroll
             for (int k = 0; k < 9; k++) sum += (int)p[(k / 3) * SP + (k % 3) * BPP] * cp.m[k];
             const float f = __fadd_rn(__fadd_rn(__fmul_rn((float)sum, cp.rdiv), cp.bias), 0.5f);
-            rt[r * RP + cb] = (uint8_t)min(max((int)f, 0), 255);
+            if (!TRANSPOSED) rt[r * RP + cb] = (uint8_t)min(max((int)f, 0), 255);
+            else { const int px = cb / BPP; rt[px * PT + r * BPP + (cb - px * BPP)] = (uint8_t)min(max((int)f, 0), 255); }
         }
     }
     __syncthreads();
-    if (!TRANSPOSED) {
-        for (int r = wave; r < th; r += 4)
-            lds_to_row(dst + (size_t)(y0 + r) * ds, x0 * BPP, tw * BPP, rt + r * RP, lane, 64, aligned);
-    } else {
-        // out(x = y0 + r, y = x0 + c) = rt[r][c]
-        for (int c = wave; c < tw; c += 4) {
-            for (int r = lane; r < th; r += 64)
-                for (int b = 0; b < BPP; b++) orow[wave][r * BPP + b] = rt[r * RP + c * BPP + b];
-            __builtin_amdgcn_wave_barrier();
-            lds_to_row(dst + (size_t)(x0 + c) * ds, y0 * BPP, th * BPP, orow[wave], lane, 64, aligned);
-            __builtin_amdgcn_wave_barrier();
+    {
+        const bool fast16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+        if (!TRANSPOSED) {
+            // x0 * BPP is a multiple of 16 (x0 is a multiple of 64)
+            constexpr int CL = (TW * BPP + 15) / 16 <= 16 ? 16 : 32;
+            constexpr int K = (TH + 256 / CL - 1) / (256 / CL);
+            lds_to_tile16<CL, K>(dst, ds, x0 * BPP, tw * BPP, th, rt, RP, (int)threadIdx.x, fast16, [&](int r) { return y0 + r; });
+        } else {
+            // out(x = y0 + r, y = x0 + c): the result tile is already stored one LDS row per tile column
+            constexpr int CL = (TH * BPP + 15) / 16 <= 16 ? 16 : 32;
+            constexpr int K = (TW + 256 / CL - 1) / (256 / CL);
+            lds_to_tile16<CL, K>(dst, ds, y0 * BPP, th * BPP, tw, rt, PT, (int)threadIdx.x, fast16, [&](int c) { return x0 + c; });
         }
     }
 }
