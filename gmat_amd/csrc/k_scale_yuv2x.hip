@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
             lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         }
         if (lin >= ntiles) return;
-        tcol = lin / a.nty;
+        // the division runs on the VALU; readfirstlane tells the compiler the result is wave-uniform, so the
+        // per-tile table look-ups below become scalar loads and the tile address arithmetic scalar code
+        tcol = __builtin_amdgcn_readfirstlane(lin / a.nty);
         trow = lin - tcol * a.nty;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     X2_STAMP(0);
     if (prof && tid == 0) prof[6] = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference clock
     const int tx0 = tcol * X2_TW, ty0 = trow * X2_TH, tcx0 = tx0 >> 1;
-    const int r0L = a.rowStartL[trow], nrL = a.rowCountL[trow];
-    const int r0C = a.rowStartC[trow], nrC = a.rowCountC[trow];
+    const int r0L = uniform_load(a.rowStartL, trow), nrL = uniform_load(a.rowCountL, trow);
+    const int r0C = uniform_load(a.rowStartC, trow), nrC = uniform_load(a.rowCountC, trow);
     const int wl = 2 * tx0 + a.w0L, wc = 2 * tcx0 + a.w0C;     // first window column (luma / chroma samples)
     const int c0L = wl & ~15, c0C = wc & ~7;                     // 16-byte aligned window starts
     const int eL = (wl - c0L) >> 1, eC = (wc - c0C) >> 1;       // window offset inside an LDS row, in dwords (even)

@@ -16,6 +16,20 @@ __device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   
 // below has |operands| < 2^23: pixel values <= 510, table constants <= 2^18.
 __device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
 
+// Load of a per-tile table entry whose index is wave-uniform.  The tables are written once at context creation
+// and never while a kernel runs, so they may be read through the constant address space: the compiler then emits
+// s_load_dword (scalar cache, result in an SGPR) instead of a vector load + v_readfirstlane, which shortens the
+// dependent-load chain at the start of every workgroup.
+__device__ __forceinline__ int uniform_load(const int32_t *p, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const int32_t *const_ptr;
+    return ((const_ptr)(unsigned long long)p)[i];
+#else
+    return p[i];
+#endif
+}
+
 // 2-way int16 dot product with int32 accumulate: v_dot2c_i32_i16 (exact integer arithmetic).
 __device__ __forceinline__ int dot2(int packed_ab, int packed_cd, int acc)
 {
