@@ -468,6 +468,9 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                             (ya.nv12 ? al4(src[1], srcStride[1])
                                      : ((((uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[1] |
                                           (uintptr_t)srcStride[2]) & 1) == 0));
+            ya.srcAligned16 = ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 15) == 0) &&
+                              (ya.nv12 ? ((((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0)
+                                       : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
             ya.dst = dst[0]; ya.ds = dstStride[0];
             const int ybpp = bytes_per_pixel(c->dstFormat);
             ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);

@@ -111,6 +111,75 @@ __device__ __forceinline__ void yuv_phase1(const YuvScaleArgs &a, int tid, int c
     }
 }
 
+// 16-byte form of phase 1 (rows and window starts 16-byte aligned, window inside the frame): a thread owns up to
+// K16 chunks of 16 source bytes, ALL of its loads are issued before the first LDS write.  The dword-per-lane form
+// above needs several dependent HBM round trips per tile (6 / 3 groups in flight), which dominated the generic
+// scalers the same way it dominated the 3x3 smooth (k_transform.hip).
+constexpr int K16L = 5, K16C = 3;
+
+__device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, int c0L, int ncL, int r0L, int nrL,
+                                              int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
+                                              unsigned short *lu, unsigned short *lv)
+{
+    const int nL = ncL >> 4, totL = nrL * nL;           // luma chunks: 16 samples
+    const int nC = ncC >> 3, totC = nrC * nC;           // chroma chunks: 8 samples of each plane
+    if (totL > 256 * K16L || totC > 256 * K16C) return false;      // block-uniform
+    uint4 vl[K16L], vc[K16C];
+    int ol[K16L], oc[K16C];
+#pragma unroll
+    for (int k = 0; k < K16L; k++) {
+        const int id = tid + 256 * k;
+        ol[k] = -1; vl[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (id < totL) {
+            const int r = id / nL, c = id - r * nL;
+            ol[k] = r * a.colsL + 16 * c;
+            vl[k] = *reinterpret_cast<const uint4 *>(a.y + (size_t)min(r0L + r, a.srcH - 1) * a.ys + c0L + 16 * c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K16C; k++) {
+        const int id = tid + 256 * k;
+        oc[k] = -1; vc[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (id < totC) {
+            const int r = id / nC, c = id - r * nC;
+            const size_t crow = (size_t)min(r0C + r, a.chrSrcH - 1);
+            oc[k] = r * a.colsC + 8 * c;
+            if (a.nv12) {
+                vc[k] = *reinterpret_cast<const uint4 *>(a.u + crow * a.us + 2 * (c0C + 8 * c));    // U0 V0 U1 V1 ...
+            } else {
+                const uint2 tu = *reinterpret_cast<const uint2 *>(a.u + crow * a.us + c0C + 8 * c);
+                const uint2 tv = *reinterpret_cast<const uint2 *>(a.v + crow * a.vs + c0C + 8 * c);
+                // interleave to the NV12 byte order so the unpacking below is common
+                vc[k].x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); vc[k].y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
+                vc[k].z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); vc[k].w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K16L; k++) {
+        if (ol[k] < 0) continue;
+        uint4 *d = reinterpret_cast<uint4 *>(ly + ol[k]);
+        const uint4 v = vl[k];
+        d[0] = make_uint4(__builtin_amdgcn_perm(0u, v.x, 0x0C010C00u), __builtin_amdgcn_perm(0u, v.x, 0x0C030C02u),
+                          __builtin_amdgcn_perm(0u, v.y, 0x0C010C00u), __builtin_amdgcn_perm(0u, v.y, 0x0C030C02u));
+        d[1] = make_uint4(__builtin_amdgcn_perm(0u, v.z, 0x0C010C00u), __builtin_amdgcn_perm(0u, v.z, 0x0C030C02u),
+                          __builtin_amdgcn_perm(0u, v.w, 0x0C010C00u), __builtin_amdgcn_perm(0u, v.w, 0x0C030C02u));
+    }
+#pragma unroll
+    for (int k = 0; k < K16C; k++) {
+        if (oc[k] < 0) continue;
+        const uint4 v = vc[k];
+        // U samples are bytes 0 and 2 of each dword, V samples bytes 1 and 3
+        *reinterpret_cast<uint4 *>(lu + oc[k]) =
+            make_uint4(__builtin_amdgcn_perm(0u, v.x, 0x0C020C00u), __builtin_amdgcn_perm(0u, v.y, 0x0C020C00u),
+                       __builtin_amdgcn_perm(0u, v.z, 0x0C020C00u), __builtin_amdgcn_perm(0u, v.w, 0x0C020C00u));
+        *reinterpret_cast<uint4 *>(lv + oc[k]) =
+            make_uint4(__builtin_amdgcn_perm(0u, v.x, 0x0C030C01u), __builtin_amdgcn_perm(0u, v.y, 0x0C030C01u),
+                       __builtin_amdgcn_perm(0u, v.z, 0x0C030C01u), __builtin_amdgcn_perm(0u, v.w, 0x0C030C01u));
+    }
+    return true;
+}
+
 // MODE 0: packed RGB out, half chroma (LUT form)   1: packed RGB out, full chroma
 //      2: YUV 4:2:0 out (NV12 or YUV420P): the tile is TW x TH luma outputs plus the TW/2 x TH/2 chroma
 //         outputs under them; vChr is indexed by CHROMA row; yuv2planeX_8_c / yuv2nv12cX_c (output.c:400-450)
@@ -186,7 +255,8 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
     // ================= phase 1 ================================================================
     {
         const bool fl = a.srcAligned && c0L + ncL <= a.srcW, fc = a.srcAligned && c0C + ncC <= a.chrSrcW;
-        if (fl && fc) yuv_phase1<true, true>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+        if (fl && fc && a.srcAligned16 && yuv_phase1_16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv)) {}
+        else if (fl && fc) yuv_phase1<true, true>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
         else          yuv_phase1<false, false>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
     }
     GMAT_STAMP(1);
@@ -437,9 +507,10 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
         const int cwd = full ? TW : TW / 2;
         const int ntx = (p.dstW + TW - 1) / TW;
         int colsL = 0, colsC = 0;
-        windows(p.hLum, TW, ntx, p.dstW, 4, t.colStartL, t.colCountL, colsL);
-        windows(p.hChr, cwd, ntx, p.chrDstW, 2, t.colStartC, t.colCountC, colsC);
-        colsL = align_up(colsL, 8); colsC = align_up(colsC, 8);
+        // window starts and lengths in whole 16-byte chunks (16 luma samples / 8 samples of each chroma plane)
+        windows(p.hLum, TW, ntx, p.dstW, 16, t.colStartL, t.colCountL, colsL);
+        windows(p.hChr, cwd, ntx, p.chrDstW, 8, t.colStartC, t.colCountC, colsC);
+        colsL = align_up(colsL, 16); colsC = align_up(colsC, 8);
         const int ths[] = {32, 16, 8, 4, 2, 1};
         for (int TH : ths) {
             if (forceTH && TH != forceTH) continue;
