@@ -119,12 +119,25 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
             // one tap of 4096: ((64<<12) + 4096*s) >> 19 == (s + 64) >> 7, i.e. yuv2plane1_8_c falls out of the X form
             const int sh = 19;
             const int n = min(4, a.cw - cx);
+            unsigned ub[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8(U[i] >> sh); vb[i] = (unsigned)clip_u8(V[i] >> sh); }
             if (a.nv12) {
                 uint8_t *d = a.u + (size_t)cy * a.us + 2 * cx;
-                for (int i = 0; i < n; i++) { d[2 * i] = (uint8_t)clip_u8(U[i] >> sh); d[2 * i + 1] = (uint8_t)clip_u8(V[i] >> sh); }
+                if (n == 4 && ((((uintptr_t)a.u | (uintptr_t)a.us) & 7) == 0)) {
+                    *reinterpret_cast<uint2 *>(d) = make_uint2(ub[0] | (vb[0] << 8) | (ub[1] << 16) | (vb[1] << 24),
+                                                               ub[2] | (vb[2] << 8) | (ub[3] << 16) | (vb[3] << 24));
+                } else {
+                    for (int i = 0; i < n; i++) { d[2 * i] = (uint8_t)ub[i]; d[2 * i + 1] = (uint8_t)vb[i]; }
+                }
             } else {
                 uint8_t *du = a.u + (size_t)cy * a.us + cx, *dv = a.v + (size_t)cy * a.vs + cx;
-                for (int i = 0; i < n; i++) { du[i] = (uint8_t)clip_u8(U[i] >> sh); dv[i] = (uint8_t)clip_u8(V[i] >> sh); }
+                if (n == 4 && ((((uintptr_t)a.u | (uintptr_t)a.us | (uintptr_t)a.v | (uintptr_t)a.vs) & 3) == 0)) {
+                    *reinterpret_cast<unsigned *>(du) = ub[0] | (ub[1] << 8) | (ub[2] << 16) | (ub[3] << 24);
+                    *reinterpret_cast<unsigned *>(dv) = vb[0] | (vb[1] << 8) | (vb[2] << 16) | (vb[3] << 24);
+                } else {
+                    for (int i = 0; i < n; i++) { du[i] = (uint8_t)ub[i]; dv[i] = (uint8_t)vb[i]; }
+                }
             }
         }
     }
