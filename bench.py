@@ -184,6 +184,54 @@ def time_single_kernel(lib, torch, runner_fn, stream, reps):
     return float(ms.value) / reps
 
 
+def other_configs(lib, torch, stream, frames=16):
+    """BASELINE configs[1] and configs[3], plus the 4:2:0 -> 4:2:0 down-scale of a transcode, each timed back to
+    back on one stream (HIP events) over a rotating frame set.  Secondary numbers; never the headline `value`."""
+    from gmat_amd.lib import PIX_FMT, planes, ints
+    res = {}
+
+    def sws_case(name, sf, sw, sh, df, dw, dh, alg_bytes):
+        src = [torch.randint(0, 256, (sw * sh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        dbytes = dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2
+        dst = [torch.empty((dbytes,), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], 4, None)
+        lib.gmat_sws_setStream(c, stream)
+        st = {"i": 0}
+
+        def run():
+            i = st["i"] = (st["i"] + 1) % frames
+            s0, d0 = src[i].data_ptr(), dst[i].data_ptr()
+            dp = [d0] if df == "rgb24" else [d0, d0 + dw * dh]
+            dl = [dw * 3] if df == "rgb24" else [dw, dw]
+            lib.gmat_sws_scale(c, planes([s0, s0 + sw * sh]), ints([sw, sw]), 0, sh, planes(dp), ints(dl))
+        ms = time_single_kernel(lib, torch, run, stream, 4 * frames)
+        res[name] = {"kernel": lib.gmat_sws_lastKernel(c).decode(), "avg_launch_us": round(ms * 1e3, 2),
+                     "Gpix/s": round(sw * sh / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg_bytes,
+                     "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                     "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        lib.gmat_sws_freeContext(c)
+
+    sws_case("configs[1]: 1080p nv12 -> rgb24", "nv12", 1920, 1080, "rgb24", 1920, 1080, 1920 * 1080 * 9 // 2)
+    sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", SRC_W, SRC_H, "nv12", DST_W, DST_H,
+             SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2)
+    # configs[3]: rotate(90) + hflip + 3x3 smooth as ONE kernel on 4K rgb24
+    w, h = SRC_W, SRC_H
+    src = [torch.randint(0, 256, (h, w * 3), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+    dst = [torch.empty((w, h * 3), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+    st = {"i": 0}
+
+    def run4():
+        i = st["i"] = (st["i"] + 1) % frames
+        lib.gmat_rotate_flip_smooth(src[i].data_ptr(), w * 3, dst[i].data_ptr(), h * 3, w, h, 3, stream)
+    ms = time_single_kernel(lib, torch, run4, stream, 4 * frames)
+    alg = 2 * w * h * 3
+    res["configs[3]: 4K rgb24 rotate(90)+flip+3x3 smooth, fused"] = {
+        "kernel": "conv3x3_kernel<3,64,64,transposed>", "avg_launch_us": round(ms * 1e3, 2),
+        "Gpix/s": round(w * h / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg,
+        "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return res
+
+
 def host_pipeline(lib, nframes=96, depth=4):
     """PCIe-inclusive rate: pinned host NV12 in -> HBM -> scale -> HBM -> pinned host RGB24 out, copies on their own
     streams overlapping the kernels (gmat_amd/pipeline.py).  Never the headline `value`."""
@@ -354,6 +402,8 @@ def main():
         lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
         ch.close()
 
+    if rank == 0 and not a.no_chained:
+        out["other_configs"] = other_configs(lib, torch, stream)
     if rank == 0 and world == 1 and not a.no_pipeline:
         out["host_pipeline"] = host_pipeline(lib)
     if rank == 0 and world == 1 and not a.no_cpu:

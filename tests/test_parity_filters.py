@@ -14,7 +14,7 @@ def _orc_out(rows, row_bytes):
     return np.zeros((rows, row_bytes), np.uint8)
 
 
-@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("w,h", SIZES + [(256, 128), (300, 140), (128, 192)])
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4])
 @pytest.mark.parametrize("dir", [0, 1, 2, 3])
 def test_transpose(dev, orc, w, h, bpp, dir):
