@@ -17,6 +17,7 @@ GPU converts its own independent streams, no collective in the data path).
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -147,6 +148,8 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     lib.gmat_device_sync()
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
+    gc.collect()
+    gc.disable()                        # no collector pauses inside the timed region
     dist.barrier(world) if dist else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -159,6 +162,7 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     torch.cuda.synchronize()
     dist.barrier(world) if dist else None
     wall = time.perf_counter() - t0
+    gc.enable()
     ms = C.c_float()
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
@@ -171,13 +175,17 @@ def time_single_kernel(lib, torch, runner_fn, stream, reps):
     """average duration (ms) of one repeated launch function, HIP events on the launch stream"""
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
-    for _ in range(3):
+    torch.cuda.synchronize()            # input tensors are filled on torch's stream, the launches go to `stream`
+    for _ in range(8):
         runner_fn()
     lib.gmat_stream_sync(stream)
+    gc.collect()
+    gc.disable()                        # a generation-2 collection inside the loop stalls the host for milliseconds
     lib.gmat_timer_begin(timer, stream)
     for _ in range(reps):
         runner_fn()
     lib.gmat_timer_end(timer, stream)
+    gc.enable()
     ms = C.c_float()
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
