@@ -23,7 +23,7 @@ using namespace gmat;
 
 namespace {
 
-enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH };
+enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32 };
 
 struct DevBuf {
     void *p = nullptr;
@@ -244,7 +244,12 @@ hipEvent_t *sws_batch_events(GmatSwsContext *c)
     return c->batchEv;
 }
 void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream : nullptr; }
-bool sws_shares_intermediate(const GmatSwsContext *c) { return c && c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0; }
+bool sws_shares_intermediate(const GmatSwsContext *c)
+{
+    if (!c) return false;
+    if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
+    return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
+}
 }
 
 extern "C" {
@@ -280,6 +285,16 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_YUV2RGB;
     } else if (same && srcFormat == GMAT_PIX_FMT_NV12 && dstFormat == GMAT_PIX_FMT_RGBPF32LE) {
         c->mode = MODE_RGBPF32;
+    } else if (same && srcFormat == GMAT_PIX_FMT_RGBPF32LE &&
+               (dstFormat == GMAT_PIX_FMT_RGB24 || dstFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(dstFormat))) {
+        // format_cuda's other direction (vf_format_cuda.c:184-217, rgbpf32_to_nv12): quantise to 8 bits, then — for
+        // 4:2:0 outputs — the RGB24 -> YUV path of this library
+        c->mode = MODE_FROM_PF32;
+        if (is_yuv420(dstFormat)) {
+            c->srcFormat = GMAT_PIX_FMT_RGB24;
+            r = init_rgb2yuv(c);
+            c->srcFormat = GMAT_PIX_FMT_RGBPF32LE;
+        }
     } else if (same && ((srcFormat == GMAT_PIX_FMT_RGB24 && dstFormat == GMAT_PIX_FMT_BGR24) ||
                         (srcFormat == GMAT_PIX_FMT_BGR24 && dstFormat == GMAT_PIX_FMT_RGB24))) {
         c->mode = MODE_SWAP_RB;
@@ -444,6 +459,33 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             r = launch_copy2d(src[2], srcStride[2], dst[2], dstStride[2], cw, ch, c->stream);
         } else if (snv) r = launch_uv_relayout(1, src[1], srcStride[1], nullptr, 0, dst[1], dstStride[1], dst[2], dstStride[2], cw, ch, c->stream);
         else r = launch_uv_relayout(0, src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], nullptr, 0, cw, ch, c->stream);
+        break;
+    }
+    case MODE_FROM_PF32: {
+        c->lastKernel = "rgbpf32_to_rgb24_kernel";
+        if (!is_yuv420(c->dstFormat)) {
+            r = launch_rgbpf32_to_rgb24(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH,
+                                        c->dstFormat == GMAT_PIX_FMT_BGR24, c->stream);
+            break;
+        }
+        const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+        if (!dst[1] || (!dnv12 && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+        if (!c->inter) {
+            c->interStride = align_up(c->srcW * 3, 256);
+            GMAT_HIP_CHECK(hipMalloc((void **)&c->inter, (size_t)c->interStride * c->srcH));
+        }
+        if ((r = launch_rgbpf32_to_rgb24(src[0], srcStride[0], c->inter, c->interStride, c->srcW, c->srcH, 0, c->stream)) < 0) break;
+        Rgb2YuvLaunch L;
+        L.src = c->inter; L.ss = c->interStride; L.bgr = 0;
+        L.y = dst[0]; L.ys = dstStride[0]; L.u = dst[1]; L.us = dstStride[1];
+        L.v = dnv12 ? nullptr : dst[2]; L.vs = dnv12 ? 0 : dstStride[2]; L.nv12 = dnv12;
+        L.w = c->srcW; L.h = c->srcH;
+        L.vChr = c->r2yVChr;
+        L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
+        L.maxRows = c->r2y.maxRows;
+        L.k = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
+        c->lastKernel = "rgbpf32_to_rgb24_kernel+rgb2yuv420_kernel";
+        r = launch_rgb2yuv420(L, c->stream);
         break;
     }
     case MODE_DEPTH: {

@@ -196,6 +196,51 @@ int launch_yuv2rgb(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, int dstF
     return 0;
 }
 
+// planar float RGB (three stacked planes, plane stride = ss * h) -> packed rgb24 / bgr24: the inverse of the
+// normalisation above, u8 = (int)(clamp(f, 0, 1) * 255 + 0.5).  A frame produced by nv12_to_rgbpf32_kernel comes
+// back to exactly the same bytes (k / 255.0f * 255 + 0.5 truncates to k for every k in 0..255).  The reference has
+// no integer definition of this direction (rgbpf32_to_nv12, format_cuda_kernel.cu:624-630, is a float matrix):
+// 4:2:0 outputs run this kernel into the context's RGB24 intermediate and then the RGB -> YUV path.
+__global__ __launch_bounds__(256) void rgbpf32_to_rgb24_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h,
+                                                               int bgr, int aligned)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)ss * h;
+    unsigned c[3][4];
+    const int nx = min(4, w - x);
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+        const float *row = reinterpret_cast<const float *>(src + pl * plane + (size_t)y * ss) + x;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (aligned && nx == 4) { const float4 v = *reinterpret_cast<const float4 *>(row); f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+        else for (int i = 0; i < nx; i++) f[i] = row[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) c[pl][i] = (unsigned)(int)(__fadd_rn(__fmul_rn(fminf(fmaxf(f[i], 0.0f), 1.0f), 255.0f), 0.5f));
+    }
+    const int r = bgr ? 2 : 0, b = 2 - r;
+    uint8_t *d = dst + (size_t)y * ds + (size_t)x * 3;
+    if (nx == 4 && ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0)) {
+        uint3 o;
+        o.x = c[r][0] | (c[1][0] << 8) | (c[b][0] << 16) | (c[r][1] << 24);
+        o.y = c[1][1] | (c[b][1] << 8) | (c[r][2] << 16) | (c[1][2] << 24);
+        o.z = c[b][2] | (c[r][3] << 8) | (c[1][3] << 16) | (c[b][3] << 24);
+        *reinterpret_cast<uint3 *>(d) = o;
+    } else {
+        for (int i = 0; i < nx; i++) { d[3 * i] = (uint8_t)c[r][i]; d[3 * i + 1] = (uint8_t)c[1][i]; d[3 * i + 2] = (uint8_t)c[b][i]; }
+    }
+}
+
+int launch_rgbpf32_to_rgb24(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bgr, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int aligned = ((((uintptr_t)src | (uintptr_t)ss) & 15) == 0);
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4);
+    hipLaunchKernelGGL(rgbpf32_to_rgb24_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, bgr, aligned);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_nv12_to_rgbpf32(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, const Yuv2RgbConsts &k,
                            hipStream_t stream)
 {

@@ -22,6 +22,9 @@ int launch_nv12_to_rgbpf32(const YuvSrc &src, uint8_t *dst, int dstStride, int w
                            const Yuv2RgbConsts &k, hipStream_t stream);
 int launch_swap_rb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h,
                      hipStream_t stream);
+// planar float rgb (plane stride = srcStride * h) -> packed rgb24 / bgr24, u8 = (int)(clamp(f, 0, 1) * 255 + 0.5)
+int launch_rgbpf32_to_rgb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bgr,
+                            hipStream_t stream);
 
 // ---- generic scaler, packed-RGB output (k_scale.hip) ---------------------------------------
 // Device-resident copy of a FilterBank in the dword-packed form.

@@ -395,3 +395,19 @@ def test_filter_layer_rotate_arbitrary(dev, orc, fmt):
         orc.L.orc_rotate(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, pw, ph, bpp,
                          30 * math.pi / 180.0, 1, fill.ctypes.data)
         assert (res[i] == want).all(), (fmt, i)
+
+
+def test_filter_layer_format_nv12_rgbpf32_round_trip(dev, orc):
+    """format_hip (vf_format_cuda.c:69-79): nv12 -> rgbpf32le and back to nv12 through the frame pool."""
+    w, h = 64, 16
+    src = synth_planes(orc, "nv12", w, h, 95)
+    pf, ow, oh = _run_filter_planes(dev, "format_hip", {"pix_fmt": "rgbpf32le"}, src, w, h, "nv12")
+    want = orc.nv12_to_rgbpf32(src, w, h)
+    assert len(pf) == 3
+    for k in range(3):
+        assert (pf[k].view(np.float32) == want[k]).all()
+    back, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": "nv12"}, pf, w, h, "rgbpf32le")
+    rgb = orc.yuv2rgb(src, w, h, "nv12", "rgb24")
+    want_nv12 = orc.sws([rgb], w, h, "rgb24", w, h, "nv12")
+    for a, b in zip(back, want_nv12):
+        assert (a == b).all()

@@ -100,3 +100,63 @@ def test_error_behaviour(dev):
                            planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
     assert r < 0                                                                    # partial slices rejected
     lib.gmat_sws_freeContext(c)
+
+
+def test_error_behaviour_newer_entry_points(dev):
+    lib = dev.lib
+    assert lib.gmat_rotate(None, 0, None, 0, 8, 8, 8, 8, 3, 0.5, 1, None, None) < 0          # NULL frames
+    src = dev.planes_like("rgb24", 8, 8)[0]
+    dst = dev.planes_like("rgb24", 8, 8)[0]
+    assert lib.gmat_rotate(src.ptr, src.stride, dst.ptr, dst.stride, 8, 8, 8, 8, 5, 0.5, 1, None, None) < 0    # bpp
+    assert lib.gmat_transpose(src.ptr, src.stride, dst.ptr, dst.stride, 8, 8, 3, 7, None) < 0                  # dir
+    # 4:2:0 -> 4:2:0 at another size needs every destination plane
+    c = lib.gmat_sws_getContext(32, 16, PIX_FMT["nv12"], 16, 8, PIX_FMT["yuv420p"], 4, None)
+    assert c
+    s = dev.planes_like("nv12", 32, 16)
+    d = dev.planes_like("yuv420p", 16, 8)
+    r = lib.gmat_sws_scale(c, planes([p.ptr for p in s]), ints([p.stride for p in s]), 0, 16,
+                           planes([d[0].ptr, d[1].ptr]), ints([d[0].stride, d[1].stride]))
+    assert r < 0
+    lib.gmat_sws_freeContext(c)
+    # depth expansion only from 8-bit 4:2:0, same size
+    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 32, 16, PIX_FMT["p010le"], 0, None)
+    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["nv12"], 16, 8, PIX_FMT["p010le"], 0, None)
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (33, 9)])
+def test_rgbpf32_back_to_8bit(dev, orc, w, h):
+    """format_hip's other direction: planar float RGB -> rgb24 / bgr24 / nv12.  A float frame made by the nv12 ->
+    rgbpf32le converter returns to exactly the 8-bit RGB the integer converter gives, and 4:2:0 outputs equal the
+    RGB24 -> YUV path applied to that frame."""
+    src = synth_planes(orc, "nv12", w, h, seed=71)
+    rgb = orc.yuv2rgb(src, w, h, "nv12", "rgb24")
+    # the float frame as the C ABI lays it out: three stacked planes in one buffer (CSwscale.c:25-28)
+    stacked = orc.nv12_to_rgbpf32(src, w, h).reshape(3 * h, w).view(np.uint8).reshape(3 * h, 4 * w)
+    d_pf = dev.upload_planes([np.ascontiguousarray(stacked)], 16)[0]
+    assert d_pf.stride == 4 * w or d_pf.stride % 16 == 0
+    # upload_planes pads rows: the plane stride is stride * h, so re-pack with that stride in mind
+    if d_pf.stride != 4 * w:
+        d_pf.free()
+        host = np.zeros((3 * h, (4 * w + 15) // 16 * 16), np.uint8)
+        host[:, :4 * w] = stacked
+        d_pf = dev.upload_planes([host], 1)[0]
+    lib = dev.lib
+    for dst_fmt in ("rgb24", "bgr24", "nv12", "yuv420p"):
+        c = lib.gmat_sws_getContext(w, h, PIX_FMT["rgbpf32le"], w, h, PIX_FMT[dst_fmt], 0, None)
+        assert c, dst_fmt
+        dst = dev.planes_like(dst_fmt, w, h, 64)
+        r = lib.gmat_sws_scale(c, planes([d_pf.ptr]), ints([d_pf.stride]), 0, h, planes([p.ptr for p in dst]),
+                               ints([p.stride for p in dst]))
+        assert r == h
+        got = [p.download() for p in dst]
+        lib.gmat_sws_freeContext(c)
+        if dst_fmt == "rgb24":
+            assert (got[0] == rgb).all()
+        elif dst_fmt == "bgr24":
+            assert (got[0].reshape(h, w, 3) == rgb.reshape(h, w, 3)[:, :, ::-1]).all()
+        else:
+            want = orc.sws([rgb], w, h, "rgb24", w, h, dst_fmt)
+            for g, wv in zip(got, want):
+                assert (g == wv).all(), dst_fmt
+        for p in dst:
+            p.free()
