@@ -83,6 +83,7 @@ struct GmatSwsContext {
     hipStream_t stream = nullptr;
     Mode mode;
     int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
+    int rangeConv = 0;            // YUV -> YUV: 1 limited->full (lum/chrRangeToJpeg), 2 full->limited
     Yuv2RgbConsts y2r;            // for the same-size converter (honours colourspace / range)
     // scaler
     ScalePlan plan;               // always an RGB24 -> dst plan (the YUV source is converted in front)
@@ -346,6 +347,27 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
     return 0;
 }
 
+int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    if (!is_yuv420(c->srcFormat) || !is_yuv420(c->dstFormat)) {
+        // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
+        // YUV -> RGB context is part of gmat_sws_setColorspace
+        return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
+    }
+    const int conv = (!!srcFullRange == !!dstFullRange) ? 0 : (dstFullRange ? 1 : 2);
+    if (conv == c->rangeConv) return 0;
+    c->rangeConv = conv;
+    // a same-size context is a plane copy only while the ranges agree (utils.c:1996-2000: the special
+    // converters are skipped when srcRange != dstRange); otherwise it runs the generic path
+    const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
+    if (same) {
+        if (conv) { c->mode = MODE_SCALE; return ensure_scaler(c); }
+        c->mode = MODE_YUV2YUV;
+    }
+    return 0;
+}
+
 int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
@@ -528,7 +550,8 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             }
             ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
             ya.prof = c->prof;
-            if (c->y2x.ok && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
+            ya.rangeConv = c->rangeConv;
+            if (c->y2x.ok && !c->rangeConv && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
                                                   (uintptr_t)srcStride[1]) & 15) == 0) &&
                 (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 &&
                              (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0))) {

@@ -273,7 +273,13 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 #pragma unroll
             for (int k = 0; k < kYMaxPairs; k++)
                 if (k < a.hLum.pairs) { s0 = dot2(p0[k], lc[k], s0); s1 = dot2(p1[k], lc[k], s1); }
-            hy[rp * TW + xo] = (int)pk16(min(s0 >> 7, 32767), min(s1 >> 7, 32767));
+            int l0 = min(s0 >> 7, 32767), l1 = min(s1 >> 7, 32767);
+            if (a.rangeConv == 1) {          // lumRangeToJpeg_c, swscale.c:176-181 (applied to the h-scaled line, hscale.c:60)
+                l0 = (m24(min(l0, 30189), 19077) - 39057361) >> 14; l1 = (m24(min(l1, 30189), 19077) - 39057361) >> 14;
+            } else if (a.rangeConv == 2) {   // lumRangeFromJpeg_c, :183-188
+                l0 = (m24(l0, 14071) + 33561947) >> 14; l1 = (m24(l1, 14071) + 33561947) >> 14;
+            }
+            hy[rp * TW + xo] = (int)pk16(l0, l1);
         }
     }
     {   // chroma: item = (row pair, chroma output column), both planes
@@ -290,8 +296,16 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                     su0 = dot2(u0[k], cc[k], su0); su1 = dot2(u1[k], cc[k], su1);
                     sv0 = dot2(v0[k], cc[k], sv0); sv1 = dot2(v1[k], cc[k], sv1);
                 }
-            hu[rp * CWD + xc] = (int)pk16(min(su0 >> 7, 32767), min(su1 >> 7, 32767));
-            hv[rp * CWD + xc] = (int)pk16(min(sv0 >> 7, 32767), min(sv1 >> 7, 32767));
+            int cu0 = min(su0 >> 7, 32767), cu1 = min(su1 >> 7, 32767), cv0 = min(sv0 >> 7, 32767), cv1 = min(sv1 >> 7, 32767);
+            if (a.rangeConv == 1) {          // chrRangeToJpeg_c, swscale.c:157-164 (hscale.c:193)
+                cu0 = (m24(min(cu0, 30775), 4663) - 9289992) >> 12; cu1 = (m24(min(cu1, 30775), 4663) - 9289992) >> 12;
+                cv0 = (m24(min(cv0, 30775), 4663) - 9289992) >> 12; cv1 = (m24(min(cv1, 30775), 4663) - 9289992) >> 12;
+            } else if (a.rangeConv == 2) {   // chrRangeFromJpeg_c, :166-173
+                cu0 = (m24(cu0, 1799) + 4081085) >> 11; cu1 = (m24(cu1, 1799) + 4081085) >> 11;
+                cv0 = (m24(cv0, 1799) + 4081085) >> 11; cv1 = (m24(cv1, 1799) + 4081085) >> 11;
+            }
+            hu[rp * CWD + xc] = (int)pk16(cu0, cu1);
+            hv[rp * CWD + xc] = (int)pk16(cv0, cv1);
         }
     }
     GMAT_STAMP(3);

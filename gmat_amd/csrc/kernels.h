@@ -83,6 +83,7 @@ struct YuvScaleArgs {
     const uint8_t *y, *u, *v;
     int ys, us, vs, nv12, srcAligned;
     int srcAligned16;                             // luma and NV12 chroma rows 16-byte, planar chroma rows 8-byte aligned
+    int rangeConv;                                // YUV out: 0 none, 1 limited -> full range, 2 full -> limited (swscale.c:157-188)
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW;
     uint8_t *dst;                                 // packed RGB, or the Y plane for YUV output
     int ds, dstFormat, dstAligned;

@@ -91,6 +91,11 @@ GMAT_API void gmat_sws_setStream(GmatSwsContext *c, void *stream);
 GMAT_API void gmat_sws_freeContext(GmatSwsContext *c);
 /* sws_setColorspaceDetails subset (utils.c:902): colourspace index + source range for YUV->RGB */
 GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange);
+/* srcRange / dstRange of sws_setColorspaceDetails for YUV -> YUV contexts (1 = full "jpeg" range): when they
+ * differ, the h-scaled lines go through lum/chrRangeToJpeg_c or ...FromJpeg_c (swscale.c:157-188, hooked in
+ * hscale.c:60,:193) and a same-size context leaves the plane-copy path for the generic one, exactly as
+ * libswscale does (utils.c:1996-2000).  Returns -ENOSYS for a non-zero range on a context with an RGB end. */
+GMAT_API int  gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange);
 
 /* how a scaled YUV->RGB context computes:
  *   2 (default) = what ONE libswscale context does for the same arguments: luma and chroma planes are

@@ -74,3 +74,32 @@ def test_product_reproduces_fate_filter_transpose(dev, clip):
         frame = np.concatenate(out)
         assert frame.size == GOLD["filter-transpose"][i]["size"]
         assert adler0(frame) == GOLD["filter-transpose"][i]["adler32"], i
+
+
+def test_product_reproduces_fate_sws_yuv_range(dev, clip):
+    """fate-sws-yuv-range (tests/fate/libswscale.mak:28-34): yuv420p limited -> full range at the same size, i.e.
+    1-tap hScale8To15, lum/chrRangeToJpeg_c, yuv2plane1_8_c — the HIP generic path with gmat_sws_setRange."""
+    from harness import PIX_FMT, planes, ints
+    lib = dev.lib
+    src = yuv420p_planes(clip[0])
+    d = dev.upload_planes(src, 64)
+    c = lib.gmat_sws_getContext(W, H, PIX_FMT["yuv420p"], W, H, PIX_FMT["yuv420p"],
+                                SWS["bicubic"] | SWS["accurate_rnd"] | SWS["bitexact"], None)
+    assert c
+    assert lib.gmat_sws_setRange(c, 0, 1) == 0
+    dst = dev.planes_like("yuv420p", W, H, 64)
+    r = lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, H,
+                           planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+    assert r == H
+    frame = np.concatenate([p.download().ravel() for p in dst])
+    assert lib.gmat_sws_lastKernel(c).decode().startswith("scale_yuv_kernel")
+    g = GOLD["sws-yuv-range"][0]
+    assert frame.size == g["size"] and adler0(frame) == g["adler32"]
+    # equal ranges again: back to the lossless plane copy
+    assert lib.gmat_sws_setRange(c, 1, 1) == 0
+    r = lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, H,
+                           planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+    assert r == H and all((a.download() == b).all() for a, b in zip(dst, src))
+    lib.gmat_sws_freeContext(c)
+    for p in d + dst:
+        p.free()

@@ -243,3 +243,35 @@ def test_yuv2x_yuv_output_bit_exact(dev, orc, src_fmt, dst_fmt, geom):
             assert (g == w).all(), (flags, kernel)
         for p in d:
             p.free()
+
+
+@pytest.mark.parametrize("ranges", [(0, 1), (1, 0)])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (96, 40, 144, 60), (130, 50, 130, 50)])
+def test_yuv_to_yuv_range_conversion(dev, orc, ranges, geom):
+    """limited <-> full range on 4:2:0 -> 4:2:0 contexts (lum/chrRangeToJpeg_c / FromJpeg_c), scaled and same-size."""
+    import ctypes as C
+    from harness import planes, ints, alloc_planes
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, "nv12", sw, sh, seed=47)
+    L = orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    oc = L.orc_sws_create_ex(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT["nv12"], SWS["bicubic"], None,
+                             (C.c_int * 4)(-513, -513, -513, -513), ranges[0], ranges[1])
+    assert oc
+    want = alloc_planes("nv12", dw, dh)
+    assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                           planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == dh
+    L.orc_sws_free(oc)
+    lib = dev.lib
+    d = dev.upload_planes(src, 256)
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT["nv12"], SWS["bicubic"], None)
+    assert c and lib.gmat_sws_setRange(c, ranges[0], ranges[1]) == 0
+    dst = dev.planes_like("nv12", dw, dh, 256)
+    assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                              planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == dh
+    for a, b in zip(dst, want):
+        assert (a.download() == b).all()
+    lib.gmat_sws_freeContext(c)
+    for p in d + dst:
+        p.free()
