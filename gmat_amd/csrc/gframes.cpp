@@ -46,6 +46,14 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
         L.offset[2] = L.offset[1] + (size_t)L.linesize[1] * ceil_rshift(h, 1);
         L.total = L.offset[2] + (size_t)L.linesize[2] * ceil_rshift(h, 1);
         return 0;
+    case GMAT_PIX_FMT_YUV444P:
+        L.planes = 3;
+        for (int i = 0; i < 3; i++) {
+            L.linesize[i] = align_up(w, align);
+            L.offset[i] = (size_t)i * L.linesize[0] * h;
+        }
+        L.total = (size_t)3 * L.linesize[0] * h;
+        return 0;
     case GMAT_PIX_FMT_RGBPF32LE:
         L.planes = 3;
         for (int i = 0; i < 3; i++) {
@@ -69,6 +77,7 @@ int plane_row_bytes(int fmt, int plane, int w)
     switch (fmt) {
     case GMAT_PIX_FMT_NV12:      return plane == 0 ? w : 2 * ceil_rshift(w, 1);
     case GMAT_PIX_FMT_YUV420P:   return plane == 0 ? w : ceil_rshift(w, 1);
+    case GMAT_PIX_FMT_YUV444P:   return w;
     case GMAT_PIX_FMT_RGBPF32LE: return 4 * w;
     default:                     return w * bytes_per_pixel(fmt);
     }

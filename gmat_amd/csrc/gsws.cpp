@@ -83,6 +83,7 @@ struct GmatSwsContext {
     hipStream_t stream = nullptr;
     Mode mode;
     int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
+    int chrPos[4] = {-513, -513, -513, -513};   // src_h / src_v / dst_h / dst_v chroma positions (options.c:67-70)
     int rangeConv = 0;            // YUV -> YUV: 1 limited->full (lum/chrRangeToJpeg), 2 full->limited
     Yuv2RgbConsts y2r;            // for the same-size converter (honours colourspace / range)
     // scaler
@@ -126,7 +127,8 @@ struct GmatSwsContext {
 static int init_yuv_scaler(GmatSwsContext *c)
 {
     if (c->yuvReady) return 0;
-    int r = build_scale_plan(c->planYuv, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
+    int r = build_scale_plan(c->planYuv, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param,
+                             c->chrPos);
     if (r < 0) return r;
     if ((r = yuvscale_prepare(c->planYuv, c->ytiling)) < 0) return r;
     YuvScaleArgs &a = c->yargs;
@@ -216,9 +218,9 @@ static int init_rgb2yuv(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
-    if (is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) {
+    if ((is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
-        return init_yuv_scaler(c);
+        return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
     if (is_yuv420(c->srcFormat) && c->fused == 2) {
         int r = init_yuv_scaler(c);
@@ -314,6 +316,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
+    } else if (srcFormat == GMAT_PIX_FMT_YUV444P && (is_packed_rgb(dstFormat) || is_yuv420(dstFormat))) {
+        // planar 4:4:4 source (scale_cuda's format list, vf_scale_cuda.c:45-54): always the generic plane scaler —
+        // even at the same size the chroma planes are filtered (2:1 for 4:2:0 outputs)
+        c->mode = MODE_SCALE;
+        r = ensure_scaler(c);
     } else if (!same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
         // scale_cuda's main job (vf_scale_cuda.c:428-501): 4:2:0 in, 4:2:0 out at another size.  Arithmetic of
         // the CPU generic path: hScale8To15_c per plane, yuv2planeX_8_c / yuv2nv12cX_c vertically.
@@ -368,9 +375,23 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     return 0;
 }
 
+int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_pos, int dst_h_chr_pos, int dst_v_chr_pos)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    if (c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat)) return GMAT_ERR(ENOSYS);
+    const int np[4] = {src_h_chr_pos, src_v_chr_pos, dst_h_chr_pos, dst_v_chr_pos};
+    for (int i = 0; i < 4; i++)
+        if (np[i] < -513 || np[i] > 512) return GMAT_ERR(EINVAL);           // option range, options.c:67-70
+    std::memcpy(c->chrPos, np, sizeof(np));
+    c->fused = 2;
+    c->yuvReady = false;                     // the chroma filter banks depend on the positions
+    return init_yuv_scaler(c);
+}
+
 int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
+    if (c->srcFormat == GMAT_PIX_FMT_YUV444P && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
     return 0;
@@ -389,7 +410,7 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 {
     if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
     const FilterBank *fb;
-    const ScalePlan &pl = (is_yuv420(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
+    const ScalePlan &pl = (is_yuv8_src(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
     switch (which) {
     case 0: fb = &pl.hLum; break;
     case 1: fb = &pl.hChr; break;
@@ -428,8 +449,8 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
         return GMAT_ERR(EINVAL);
     }
-    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P;
-    if (is_yuv420(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
+    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
+    if (is_yuv8_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
     int r = 0;
     switch (c->mode) {
@@ -523,7 +544,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     }
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
-        if (is_yuv420(c->srcFormat) && c->fused == 2) {
+        if (is_yuv8_src(c->srcFormat) && c->fused == 2) {
             YuvScaleArgs ya = c->yargs;
             ya.y = src[0]; ya.ys = srcStride[0];
             ya.u = src[1]; ya.us = srcStride[1];

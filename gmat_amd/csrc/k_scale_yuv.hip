@@ -483,7 +483,7 @@ static void windows(const FilterBank &fb, int tile, int ntiles, int count, int a
 int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
     const bool yuvOut = is_yuv420(p.dstFormat);
-    if (!is_yuv420(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    if (!is_yuv8_src(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
     const int full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) ? 1 : 0;
     if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);

@@ -384,6 +384,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     const char *off = getenv("GMAT_SCALE_NO_2X");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.TW != X2_TW || g.TH != X2_TH) return 0;
+    if (!is_yuv420(p.srcFormat)) return 0;                    // the tile geometry assumes half-size chroma planes
     if (p.srcW % 16 || p.chrSrcW % 8 || p.srcW < 16) return 0;
     if (p.vLum.pairs > X2_P || g.vChrEff.pairs > (g.yuvOut ? X2_P : 2)) return 0;
     t.ntx = g.ntx; t.nty = g.nty;

@@ -331,10 +331,13 @@ static int local_chroma_pos(int sub, int pos)      // utils.c:338-345 with the d
 }
 
 int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
-                     int flags, const double param[2])
+                     int flags, const double param[2], const int *chrPos)
 {
     const bool src_rgb = is_packed_rgb(srcFormat), dst_rgb = is_packed_rgb(dstFormat);
-    if (!(src_rgb || is_yuv420(srcFormat)) || !(dst_rgb || is_yuv420(dstFormat))) return GMAT_ERR(ENOSYS);
+    const bool src444 = srcFormat == GMAT_PIX_FMT_YUV444P;
+    if (!(src_rgb || is_yuv420(srcFormat) || src444) || !(dst_rgb || is_yuv420(dstFormat))) return GMAT_ERR(ENOSYS);
+    static const int unset[4] = {-513, -513, -513, -513};
+    if (!chrPos) chrPos = unset;
     if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) return GMAT_ERR(EINVAL);
     const int algo_mask = 0x7FF;
     if (!(flags & algo_mask)) flags |= GMAT_SWS_BICUBIC;
@@ -343,13 +346,14 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
     p.srcFormat = srcFormat; p.dstFormat = dstFormat;
     p.lumXInc = (int)((((int64_t)srcW << 16) + (dstW >> 1)) / dstW);
     p.lumYInc = (int)((((int64_t)srcH << 16) + (dstH >> 1)) / dstH);
-    p.chrSrcHSub = p.chrSrcVSub = src_rgb ? 0 : 1;
+    p.chrSrcHSub = p.chrSrcVSub = (src_rgb || src444) ? 0 : 1;
     p.chrDstHSub = p.chrDstVSub = dst_rgb ? 0 : 1;
 
     if (dst_rgb) {
         if (!(flags & GMAT_SWS_FULL_CHR_H_INT)) {
             if (dstW & 1) flags |= GMAT_SWS_FULL_CHR_H_INT;
-            if (src_rgb && !(flags & GMAT_SWS_FAST_BILINEAR)) flags |= GMAT_SWS_FULL_CHR_H_INT;
+            // non-subsampled sources force full chroma interpolation (utils.c:1439-1447)
+            if ((src_rgb || src444) && !(flags & GMAT_SWS_FAST_BILINEAR)) flags |= GMAT_SWS_FULL_CHR_H_INT;
         }
         if (!(flags & GMAT_SWS_FULL_CHR_H_INT)) p.chrDstHSub = 1;
     } else {
@@ -371,11 +375,11 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
     if ((r = build_filter(p.hLum, p.lumXInc, srcW, dstW, 1 << 14, flags, param,
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
     if ((r = build_filter(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 1 << 14, flags, param,
-                          local_chroma_pos(p.chrSrcHSub, -513), local_chroma_pos(p.chrDstHSub, -513))) < 0) return r;
+                          local_chroma_pos(p.chrSrcHSub, chrPos[0]), local_chroma_pos(p.chrDstHSub, chrPos[2]))) < 0) return r;
     if ((r = build_filter(p.vLum, p.lumYInc, srcH, dstH, 1 << 12, flags, param,
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
     if ((r = build_filter(p.vChr, p.chrYInc, p.chrSrcH, p.chrDstH, 1 << 12, flags, param,
-                          local_chroma_pos(p.chrSrcVSub, -513), local_chroma_pos(p.chrDstVSub, -513))) < 0) return r;
+                          local_chroma_pos(p.chrSrcVSub, chrPos[1]), local_chroma_pos(p.chrDstVSub, chrPos[3]))) < 0) return r;
     return 0;
 }
 

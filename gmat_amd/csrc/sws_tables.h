@@ -59,7 +59,9 @@ struct ScalePlan {
     FilterBank hLum, hChr, vLum, vChr;
 };
 
+// chrPos = { src_h_chr_pos, src_v_chr_pos, dst_h_chr_pos, dst_v_chr_pos } (the AVOptions of those names,
+// libswscale/options.c:67-70); nullptr or -513 = unset
 int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
-                     int flags, const double param[2]);
+                     int flags, const double param[2], const int *chrPos = nullptr);
 
 } // namespace gmat

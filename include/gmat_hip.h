@@ -29,6 +29,7 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_YUV420P   = 0,
     GMAT_PIX_FMT_RGB24     = 2,
     GMAT_PIX_FMT_BGR24     = 3,
+    GMAT_PIX_FMT_YUV444P   = 5,     /* source only (scale_cuda's list, vf_scale_cuda.c:45-54) */
     GMAT_PIX_FMT_NV12      = 23,
     GMAT_PIX_FMT_RGBA      = 26,
     GMAT_PIX_FMT_BGRA      = 28,
@@ -96,6 +97,11 @@ GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcF
  * hscale.c:60,:193) and a same-size context leaves the plane-copy path for the generic one, exactly as
  * libswscale does (utils.c:1996-2000).  Returns -ENOSYS for a non-zero range on a context with an RGB end. */
 GMAT_API int  gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange);
+/* the AVOptions src_h_chr_pos / src_v_chr_pos / dst_h_chr_pos / dst_v_chr_pos (options.c:67-70, used by
+ * vf_scale.c:567-578): chroma sample positions in 1/256 of a luma sample, -513 = unset.  Rebuilds the chroma
+ * filter banks (get_local_pos + initFilter, utils.c:338-345,:1838-1873).  YUV-source scaling contexts only. */
+GMAT_API int  gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_pos,
+                                    int dst_h_chr_pos, int dst_v_chr_pos);
 
 /* how a scaled YUV->RGB context computes:
  *   2 (default) = what ONE libswscale context does for the same arguments: luma and chroma planes are

@@ -103,3 +103,30 @@ def test_product_reproduces_fate_sws_yuv_range(dev, clip):
     lib.gmat_sws_freeContext(c)
     for p in d + dst:
         p.free()
+
+
+def test_product_reproduces_fate_filter_scalechroma(dev, clip):
+    """fate-filter-scalechroma (tests/fate/filter-video.mak:416-418): vsynth1.yuv read as 352x288 yuv444p, scaled to
+    yuv420p with out_v_chr_pos=33:out_h_chr_pos=151 — shifted chroma positions, 2:1 bicubic chroma in both axes."""
+    from harness import PIX_FMT, planes, ints
+    lib = dev.lib
+    frames444 = clip.reshape(25, -1)
+    c = lib.gmat_sws_getContext(W, H, PIX_FMT["yuv444p"], W, H, PIX_FMT["yuv420p"], SWS["bicubic"] | SWS["bitexact"], None)
+    assert c
+    assert lib.gmat_sws_setChromaPos(c, -513, -513, 151, 33) == 0
+    dst = dev.planes_like("yuv420p", W, H, 64)
+    for i in (range(25) if dev.kind == "hip" else (0, 12, 24)):
+        f = frames444[i]
+        src = [np.ascontiguousarray(f[k * W * H:(k + 1) * W * H].reshape(H, W)) for k in range(3)]
+        d = dev.upload_planes(src, 64)
+        r = lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, H,
+                               planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+        assert r == H
+        frame = np.concatenate([p.download().ravel() for p in dst])
+        g = GOLD["filter-scalechroma"][i]
+        assert frame.size == g["size"] and adler0(frame) == g["adler32"], i
+        for p in d:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+    for p in dst:
+        p.free()

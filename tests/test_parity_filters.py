@@ -411,3 +411,14 @@ def test_filter_layer_format_nv12_rgbpf32_round_trip(dev, orc):
     want_nv12 = orc.sws([rgb], w, h, "rgb24", w, h, "nv12")
     for a, b in zip(back, want_nv12):
         assert (a == b).all()
+
+
+def test_filter_layer_scale_from_yuv444p(dev, orc):
+    from harness import SWS
+    w, h = 128, 48
+    src = synth_planes(orc, "yuv444p", w, h, 97)
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "format": "nv12"}, src, w, h, "yuv444p")
+    assert (ow, oh) == (64, 24)
+    want = orc.sws(src, w, h, "yuv444p", 64, 24, "nv12", SWS["bicubic"])
+    for a, b in zip(res, want):
+        assert (a == b).all()

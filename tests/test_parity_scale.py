@@ -275,3 +275,22 @@ def test_yuv_to_yuv_range_conversion(dev, orc, ranges, geom):
     lib.gmat_sws_freeContext(c)
     for p in d + dst:
         p.free()
+
+
+@pytest.mark.parametrize("dst_fmt", ["yuv420p", "nv12", "rgb24", "bgra"])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (130, 50, 130, 50), (96, 40, 144, 60), (200, 90, 151, 67)])
+def test_yuv444p_source(dev, orc, dst_fmt, geom):
+    """planar 4:4:4 sources: chroma planes at full size, full chroma interpolation forced for RGB outputs
+    (utils.c:1439-1447), chroma filtered 2:1 for 4:2:0 outputs even at the same luma size."""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, "yuv444p", sw, sh, seed=49)
+    want = orc.sws(src, sw, sh, "yuv444p", dw, dh, dst_fmt, SWS["bicubic"])
+    d = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d, sw, sh, "yuv444p", dw, dh, dst_fmt, SWS["bicubic"], dst_align=64)
+    assert kernel.startswith("scale_yuv_kernel"), kernel
+    for i, (g, wv) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != wv)
+        assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+        assert (pads[i] == 0xCD).all()
+    for p in d:
+        p.free()
