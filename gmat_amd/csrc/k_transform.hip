@@ -59,62 +59,6 @@ __device__ __forceinline__ void lds_to_row(uint8_t *row, int b0, int n, const ui
     }
 }
 
-// Two-phase form of row_to_lds for tiles: FETCH every dword slot of every row a wave owns first (all the
-// global loads in flight together), COMMIT them to LDS afterwards.  A row-at-a-time loop serialises one
-// HBM round trip per row (measured: 4.5 dependent latencies per block made the 3x3 smooth 5x slower).
-__device__ __forceinline__ unsigned fetch_dword(const uint8_t *row, int rowBytes, int a, bool aligned)
-{
-    if (aligned && a >= 0 && a + 4 <= rowBytes) return *reinterpret_cast<const unsigned *>(row + a);
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) v |= (unsigned)row[min(max(a + i, 0), rowBytes - 1)] << (8 * i);
-    return v;
-}
-
-__device__ __forceinline__ void commit_dword(uint8_t *l, int b0, int n, int a, unsigned v)
-{
-    uint8_t *d = l + (a - b0);
-    if (a >= b0 && a + 4 <= b0 + n && (reinterpret_cast<uintptr_t>(d) & 3) == 0) {
-        *reinterpret_cast<unsigned *>(d) = v;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (a + i >= b0 && a + i < b0 + n) d[i] = (uint8_t)(v >> (8 * i));
-    }
-}
-
-// Loads rows [0, nrows) of a tile (row r of the tile = source row rowOf(r)), bytes [b0, b0+n) of each, into
-// lds + r*pitch.  NRW = rows per wave (ceil(max rows / 4)), slots: up to 2 dwords per lane per row.
-template <int NRW, typename RowOf>
-__device__ __forceinline__ void tile_to_lds(const uint8_t *src, int ss, int rowBytes, int b0, int n, int nrows,
-                                            uint8_t *lds, int pitch, int lane, int wave, bool aligned, RowOf rowOf)
-{
-    const int a0 = b0 & ~3, a1 = (b0 + n + 3) & ~3;
-    const int sa = a0 + 4 * lane, sb = sa + 256;
-    constexpr int BATCH = 6;                              // rows per wave whose loads are in flight together
-    for (int k0 = 0; k0 < NRW; k0 += BATCH) {
-        unsigned va[BATCH], vb[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const int r = wave + 4 * (k0 + k);
-            va[k] = vb[k] = 0;
-            if (k0 + k < NRW && r < nrows) {
-                const uint8_t *row = src + (size_t)rowOf(r) * ss;
-                if (sa < a1) va[k] = fetch_dword(row, rowBytes, sa, aligned);
-                if (sb < a1) vb[k] = fetch_dword(row, rowBytes, sb, aligned);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const int r = wave + 4 * (k0 + k);
-            if (k0 + k < NRW && r < nrows) {
-                if (sa < a1) commit_dword(lds + r * pitch, b0, n, sa, va[k]);
-                if (sb < a1) commit_dword(lds + r * pitch, b0, n, sb, vb[k]);
-            }
-        }
-    }
-}
-
 // 16-byte tile loader.  Chunk c of tile row r = source bytes [a16 + 16c, a16 + 16c + 16) of row rowOf(r), stored at
 // lds + r*pitch + 16c (pitch a multiple of 4).  CL lanes span a row's chunks (n16 <= CL), 256/CL rows per pass, K
 // passes; ALL of a thread's loads are issued before its first LDS write — with the earlier dword-per-lane loader a
