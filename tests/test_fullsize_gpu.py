@@ -96,3 +96,55 @@ def test_rgb_to_nv12_4k_and_relayout_round_trip(gpu, orc):
     dp = gpu.upload_planes(p, 256)
     n2, _, _ = gpu.sws(dp, w, h, "yuv420p", w, h, "nv12", dst_align=256)
     assert all((a == b).all() for a, b in zip(n2, got))
+
+
+def _oracle_rows(orc, src, sw, sh, src_fmt, dw, dh, dst_fmt, y0, y1, flags=SWS["bicubic"]):
+    """rows [y0, y1) of the oracle's output (orc_sws_scale_rows), full-size planes returned"""
+    from harness import alloc_planes, planes, ints
+    L = orc.L
+    c = L.orc_sws_create(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags, None)
+    assert c
+    outs = alloc_planes(dst_fmt, dw, dh)
+    r = L.orc_sws_scale_rows(c, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                             planes([p.ctypes.data for p in outs]), ints([p.strides[0] for p in outs]), y0, y1)
+    L.orc_sws_free(c)
+    assert r == y1 - y0
+    return outs
+
+
+def test_8k_nv12_to_4k_rgb24_bands(gpu, orc):
+    """maximum size of the path (8K UHD): three 32-row bands of the 2:1 scaler's output against the oracle"""
+    sw, sh, dw, dh = 7680, 4320, 3840, 2160
+    src = synth_planes(orc, "nv12", sw, sh, seed=19)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, "rgb24", dst_align=256)
+    assert k == "scale_yuv2x_kernel" and (pads[0] == 0xCD).all()
+    for y0 in (0, 1072, dh - 32):
+        want = _oracle_rows(orc, src, sw, sh, "nv12", dw, dh, "rgb24", y0, y0 + 32)[0]
+        assert (got[0][y0:y0 + 32] == want[y0:y0 + 32]).all(), y0
+
+
+def test_4k_nv12_to_1080p_nv12_transcode(gpu, orc):
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = synth_planes(orc, "nv12", sw, sh, seed=23)
+    want = orc.sws(src, sw, sh, "nv12", dw, dh, "nv12")
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, "nv12", dst_align=256)
+    assert k == "scale_yuv2x_kernel<yuv>"
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
+def test_4k_rotate_17_degrees(gpu, orc):
+    import math
+    w, h, bpp = 3840, 2160, 3
+    src = orc.lcg((h, w * bpp), 29)
+    fill = np.array([0, 0, 0, 255], np.uint8)
+    want = np.zeros((h, w * bpp), np.uint8)
+    orc.L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp,
+                     math.radians(17.0), 1, fill.ctypes.data)
+    d = gpu.upload_planes([src], 256)[0]
+    o = DevPlane(gpu, h, w * bpp, d.stride)
+    assert gpu.lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(17.0), 1,
+                               fill.ctypes.data, None) == 0
+    assert (o.download() == want).all()
