@@ -629,16 +629,38 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
             const int fx = x & 0xFFFF, fy = y & 0xFFFF;
             const int ix1 = min(ix + 1, p.inW - 1), iy1 = min(iy + 1, p.inH - 1);
             const uint8_t *r0 = src + (size_t)iy * ss, *r1 = src + (size_t)iy1 * ss;
+            // both horizontal taps of a row are 2*BPP consecutive bytes: one unaligned 8-byte load per row when
+            // they are neighbours and the 8 bytes stay inside the row (gfx950 global loads need no alignment)
+            unsigned long long t0 = 0, t1 = 0;
+            const bool pair = ix1 == ix + 1 && BPP * ix + 8 <= p.inW * BPP;
+            if (pair) {
+                __builtin_memcpy(&t0, r0 + BPP * ix, 8);
+                __builtin_memcpy(&t1, r1 + BPP * ix, 8);
+            }
 #pragma unroll
             for (int k = 0; k < BPP; k++) {
-                const int s00 = r0[BPP * ix + k], s01 = r0[BPP * ix1 + k], s10 = r1[BPP * ix + k], s11 = r1[BPP * ix1 + k];
+                int s00, s01, s10, s11;
+                if (pair) {
+                    s00 = (int)((t0 >> (8 * k)) & 0xFF); s01 = (int)((t0 >> (8 * (k + BPP))) & 0xFF);
+                    s10 = (int)((t1 >> (8 * k)) & 0xFF); s11 = (int)((t1 >> (8 * (k + BPP))) & 0xFF);
+                } else {
+                    s00 = r0[BPP * ix + k]; s01 = r0[BPP * ix1 + k]; s10 = r1[BPP * ix + k]; s11 = r1[BPP * ix1 + k];
+                }
                 const int s0 = ((1 << 16) - fx) * s00 + fx * s01;
                 const int s1 = ((1 << 16) - fx) * s10 + fx * s11;
                 o[q * BPP + k] = (uint8_t)(((long long)((1 << 16) - fy) * s0 + (long long)fy * s1) >> 32);
             }
         } else {
+            const uint8_t *ps = src + (size_t)iy * ss + BPP * ix;
+            if (BPP * ix + 4 <= p.inW * BPP) {                     // one unaligned dword covers the pixel
+                unsigned t;
+                __builtin_memcpy(&t, ps, 4);
 #pragma unroll
-            for (int k = 0; k < BPP; k++) o[q * BPP + k] = src[(size_t)iy * ss + BPP * ix + k];
+                for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(t >> (8 * k));
+            } else {
+#pragma unroll
+                for (int k = 0; k < BPP; k++) o[q * BPP + k] = ps[k];
+            }
         }
     }
     uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;

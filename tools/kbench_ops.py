@@ -100,3 +100,24 @@ plane_case("4K rgb24 hflip", "gmat_flip", 3840, 2160, 3, 1)
 m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
 plane_case("4K Y plane smooth3x3", "gmat_smooth3x3", 3840, 2160, 1, m, C.c_float(1 / 16), C.c_float(0.0))
 plane_case("4K rgb24 smooth3x3", "gmat_smooth3x3", 3840, 2160, 3, m, C.c_float(1 / 16), C.c_float(0.0))
+
+
+def rotate_case(label, w, h, bpp, deg, bilinear):
+    if ONLY and ONLY not in label: return
+    import math
+    src = [torch.randint(0, 256, (h, w * bpp), dtype=torch.uint8, device="cuda") for _ in range(NF)]
+    dst = [torch.empty((h, w * bpp), dtype=torch.uint8, device="cuda") for _ in range(NF)]
+    fill = (C.c_uint8 * 4)(0, 0, 0, 255)
+
+    def f(i):
+        r = lib.gmat_rotate(src[i].data_ptr(), w * bpp, dst[i].data_ptr(), w * bpp, w, h, w, h, bpp,
+                            C.c_double(math.radians(deg)), bilinear, fill, stream)
+        assert r == 0, r
+    us = timeit(f)
+    alg = 2 * w * h * bpp
+    print(f"{label:44s} {'gmat_rotate':28s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s ({alg / us / 1e3 / 80:4.1f}%)", flush=True)
+
+
+rotate_case("4K rgb24 rotate 17deg bilinear", 3840, 2160, 3, 17.0, 1)
+rotate_case("4K rgb24 rotate 17deg nearest", 3840, 2160, 3, 17.0, 0)
+rotate_case("4K Y plane rotate 17deg bilinear", 3840, 2160, 1, 17.0, 1)
