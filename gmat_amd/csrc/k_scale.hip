@@ -157,7 +157,8 @@ __device__ __forceinline__ void scale_phase1(const ScaleArgs &a, int tid, int tx
             for (int j = 0; j < kUnitsInFlight; j++) {
                 const int g = base + j * 256;
                 const int gg = min(g, total - 1);        // tail lanes reload the last unit (never stored)
-                const int rp = (int)__umulhi((unsigned)gg, ngMagic);
+                // gg / ng by multiplication; the 32-bit magic of ng == 1 (2^32 + 1) does not exist
+                const int rp = ng == 1 ? gg : (int)__umulhi((unsigned)gg, ngMagic);
                 const int cg = gg - rp * ng;
                 urp[j] = g < total ? rp : -1;
                 ucg[j] = cg;
