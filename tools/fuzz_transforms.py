@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the transform kernels and the remaining converter modes against the oracle.
+usage: tools/fuzz_transforms.py [ncases] [seed] [--hip]"""
+import os, sys, random, math, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import harness
+from harness import PIX_FMT, SWS, synth_planes, DevPlane, planes, ints, alloc_planes
+from gmat_amd.lib import load
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+hip = "--hip" in sys.argv
+rng = random.Random(seed)
+orc = harness.load_oracle(os.path.join(ROOT, "oracle", "liborc.so"))
+lib = load() if hip else load(os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so"))
+dev = harness.Dev(lib, "hip" if hip else "emu")
+L = orc.L
+fails = 0
+
+
+def strides(rb):
+    align, extra = rng.choice([(256, 0), (16, 0), (4, 0), (1, 1), (1, 3), (2, 2)])
+    return (rb + extra + align - 1) // align * align, align, extra
+
+
+for case in range(n):
+    op = rng.choice(["transpose", "flip", "smooth", "rotate", "fused", "chained", "rgb2yuv", "p01x", "cs"])
+    w, h = rng.randint(1, 330), rng.randint(1, 200)
+    bpp = rng.choice([1, 2, 3, 4])
+    desc = (case, op, w, h, bpp)
+    try:
+        if op in ("transpose", "flip", "smooth", "rotate", "fused"):
+            if op == "fused": bpp = rng.choice([3, 4])
+            src = orc.lcg((h, w * bpp), 500 + case)
+            tr = op in ("transpose", "fused")
+            ow, oh = (h, w) if tr else (w, h)
+            want = np.full((oh, ow * bpp), 0x5A, np.uint8)
+            st, al, ex = strides(w * bpp)
+            d = DevPlane(dev, h, w * bpp, st).upload(src)
+            so, _, _ = strides(ow * bpp)
+            o = DevPlane(dev, oh, ow * bpp, so)
+            if op == "transpose":
+                dr = rng.randint(0, 3)
+                L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, dr)
+                r = lib.gmat_transpose(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, dr, None)
+            elif op == "flip":
+                code = rng.choice([0, 1, -1]); tmp = src
+                if code != 0:
+                    t = np.zeros_like(src); L.orc_hflip(tmp.ctypes.data, tmp.strides[0], t.ctypes.data, t.strides[0], w, h, bpp); tmp = t
+                if code <= 0:
+                    t = np.zeros_like(src); L.orc_vflip(tmp.ctypes.data, tmp.strides[0], t.ctypes.data, t.strides[0], w, h, bpp); tmp = t
+                want = tmp
+                r = lib.gmat_flip(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, code, None)
+            elif op == "smooth":
+                if rng.random() < 0.5:
+                    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1); rdiv, bias = 1 / 16, 0.0
+                else:
+                    m = (C.c_int * 9)(*[rng.randint(-3, 9) for _ in range(9)]); rdiv, bias = rng.choice([1 / 8, 0.1, 1.0]), rng.choice([0.0, 3.5])
+                L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, rdiv, bias)
+                r = lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, rdiv, bias, None)
+            elif op == "rotate":
+                ang = math.radians(rng.uniform(-360, 360)); bil = rng.randint(0, 1)
+                fill = np.array([rng.randint(0, 255) for _ in range(4)], np.uint8)
+                L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, ang, bil, fill.ctypes.data)
+                r = lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, ang, bil, fill.ctypes.data, None)
+            else:
+                a = np.zeros((w, h * bpp), np.uint8); b = np.zeros_like(a)
+                L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)
+                L.orc_hflip(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], h, w, bpp)
+                m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+                L.orc_conv3x3(b.ctypes.data, b.strides[0], want.ctypes.data, want.strides[0], h, w, bpp, m, 1 / 16, 0.0)
+                r = lib.gmat_rotate_flip_smooth(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, None)
+            assert r == 0, r
+            got = o.download(); pad = o.download(True)[:, o.row_bytes:]
+            ok = (got == want).all() and (pad == 0xCD).all()
+            d.free(); o.free()
+        else:
+            w, h = max(w, 2), max(h, 2)
+            sf = rng.choice(["nv12", "yuv420p"])
+            _, al, ex = strides(w)
+            if op == "chained":
+                dw, dh = rng.randint(2, 300), rng.randint(2, 150)
+                df = rng.choice(["rgb24", "bgr24", "rgba", "bgra"]); fl = SWS[rng.choice(["bicubic", "bilinear", "lanczos", "area"])]
+                fused = rng.choice([0, 1])
+                src = synth_planes(orc, sf, w, h, seed=900 + case)
+                want = orc.chained(src, w, h, sf, dw, dh, df, fl)
+                dd = dev.upload_planes(src, al, ex)
+                got, pads, k = dev.sws(dd, w, h, sf, dw, dh, df, fl, fused=fused, dst_align=al, dst_extra=ex)
+                desc = desc + (sf, df, dw, dh, fused, k)
+            elif op == "rgb2yuv":
+                sfr = rng.choice(["rgb24", "bgr24"]); df = rng.choice(["nv12", "yuv420p"])
+                fl = SWS[rng.choice(["bicubic", "bilinear", "point"])]
+                src = synth_planes(orc, sfr, w, h, seed=900 + case)
+                want = orc.sws(src, w, h, sfr, w, h, df, fl)
+                dd = dev.upload_planes(src, al, ex)
+                got, pads, k = dev.sws(dd, w, h, sfr, w, h, df, fl, dst_align=al, dst_extra=ex)
+            elif op == "p01x":
+                df = rng.choice(["p010le", "p016le"])
+                src = synth_planes(orc, sf, w, h, seed=900 + case)
+                want = alloc_planes(df, w, h, fill=0xCD)
+                L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                     planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h, 1 if sf == "nv12" else 0)
+                a2 = max(al, 2)
+                dd = dev.upload_planes(src, al, ex)
+                got, pads, k = dev.sws(dd, w, h, sf, w, h, df, dst_align=a2 if a2 % 2 == 0 else 2, dst_extra=ex & ~1)
+            else:
+                csx = rng.choice([1, 4, 5, 6, 7, 9]); fr = rng.randint(0, 1); df = rng.choice(["rgb24", "bgra"])
+                src = synth_planes(orc, sf, w, h, seed=900 + case)
+                want = [orc.yuv2rgb(src, w, h, sf, df, colorspace=csx, full_range=fr)]
+                dd = dev.upload_planes(src, al, ex)
+                got, pads, k = dev.sws(dd, w, h, sf, w, h, df, dst_align=al, dst_extra=ex, colorspace=(csx, fr))
+            ok = all((g == wv).all() for g, wv in zip(got, want)) and all((p == 0xCD).all() for p in pads)
+            for p in dd: p.free()
+    except AssertionError as e:
+        if "getContext failed" in str(e):
+            continue                      # a geometry the kernels decline (ENOSYS): not a parity failure
+        print("ASSERT", desc, e); fails += 1; continue
+    if not ok:
+        fails += 1
+        print("MISMATCH", desc)
+print("cases", n, "failures", fails)
+sys.exit(1 if fails else 0)
