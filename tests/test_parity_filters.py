@@ -422,3 +422,20 @@ def test_filter_layer_scale_from_yuv444p(dev, orc):
     want = orc.sws(src, w, h, "yuv444p", 64, 24, "nv12", SWS["bicubic"])
     for a, b in zip(res, want):
         assert (a == b).all()
+
+
+@pytest.mark.parametrize("case", [(277, 128, 4, [5, -1, -1, 7, 0, -3, -3, 0, 3]), (241, 116, 1, [0, 6, -1, 3, 0, 6, -1, 0, -3]),
+                                  (264, 196, 3, [1, 2, -2, 2, 9, 5, -3, 5, -2]), (130, 40, 3, [1, 2, 3, 4, 5, 6, 7, 8, 9])])
+def test_conv3x3_float_epilogue_is_not_contracted(dev, orc, case):
+    """sum * rdiv + bias + 0.5f must round after the multiply and after each add like vf_convolution.c:495-512 on the
+    CPU; hipcc's default fp contraction fused them into fma and came out one ulp low on hardware (fuzzer finding)."""
+    w, h, bpp, mat = case
+    src = orc.lcg((h, w * bpp), 500 + w)
+    m = (C.c_int * 9)(*mat)
+    want = _orc_out(h, w * bpp)
+    orc.L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, 0.1, 3.5)
+    d = dev.upload_planes([src], 16)[0]
+    o = DevPlane(dev, h, w * bpp, (w * bpp + 15) // 16 * 16)
+    assert dev.lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, 0.1, 3.5, None) == 0
+    assert (o.download() == want).all()
+    d.free(); o.free()

@@ -58,6 +58,7 @@ for case in range(n):
                     m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1); rdiv, bias = 1 / 16, 0.0
                 else:
                     m = (C.c_int * 9)(*[rng.randint(-3, 9) for _ in range(9)]); rdiv, bias = rng.choice([1 / 8, 0.1, 1.0]), rng.choice([0.0, 3.5])
+                desc = desc + (list(m), rdiv, bias)
                 L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, rdiv, bias)
                 r = lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, rdiv, bias, None)
             elif op == "rotate":
@@ -75,6 +76,10 @@ for case in range(n):
             assert r == 0, r
             got = o.download(); pad = o.download(True)[:, o.row_bytes:]
             ok = (got == want).all() and (pad == 0xCD).all()
+            if not ok:
+                bad = np.argwhere(got != want)
+                desc = desc + ("stride", d.stride, o.stride, "nbad", len(bad), "first", bad[:3].tolist(),
+                               "got", got[tuple(bad[0])] if len(bad) else None, "want", want[tuple(bad[0])] if len(bad) else None)
             d.free(); o.free()
         else:
             w, h = max(w, 2), max(h, 2)
@@ -114,7 +119,7 @@ for case in range(n):
             ok = all((g == wv).all() for g, wv in zip(got, want)) and all((p == 0xCD).all() for p in pads)
             for p in dd: p.free()
     except AssertionError as e:
-        if "getContext failed" in str(e):
+        if "getContext failed" in str(e) or "returned -38" in str(e) or "oracle refused" in str(e):
             continue                      # a geometry the kernels decline (ENOSYS): not a parity failure
         print("ASSERT", desc, e); fails += 1; continue
     if not ok:
