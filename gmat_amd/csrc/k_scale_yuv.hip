@@ -273,6 +273,10 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 #pragma unroll
             for (int k = 0; k < kYMaxPairs; k++)
                 if (k < a.hLum.pairs) { s0 = dot2(p0[k], lc[k], s0); s1 = dot2(p1[k], lc[k], s1); }
+            for (int k = kYMaxPairs; k < a.hLum.pairs; k++) {         // filters longer than 16 taps (ratios beyond ~3.7:1)
+                const int cf = a.hLum.packed[(size_t)gx2 * a.hLum.pairs + k];
+                s0 = dot2(p0[k], cf, s0); s1 = dot2(p1[k], cf, s1);
+            }
             int l0 = min(s0 >> 7, 32767), l1 = min(s1 >> 7, 32767);
             if (a.rangeConv == 1) {          // lumRangeToJpeg_c, swscale.c:176-181 (applied to the h-scaled line, hscale.c:60)
                 l0 = (m24(min(l0, 30189), 19077) - 39057361) >> 14; l1 = (m24(min(l1, 30189), 19077) - 39057361) >> 14;
@@ -296,6 +300,11 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                     su0 = dot2(u0[k], cc[k], su0); su1 = dot2(u1[k], cc[k], su1);
                     sv0 = dot2(v0[k], cc[k], sv0); sv1 = dot2(v1[k], cc[k], sv1);
                 }
+            for (int k = kYMaxPairs; k < a.hChr.pairs; k++) {
+                const int cf = a.hChr.packed[(size_t)gc2 * a.hChr.pairs + k];
+                su0 = dot2(u0[k], cf, su0); su1 = dot2(u1[k], cf, su1);
+                sv0 = dot2(v0[k], cf, sv0); sv1 = dot2(v1[k], cf, sv1);
+            }
             int cu0 = min(su0 >> 7, 32767), cu1 = min(su1 >> 7, 32767), cv0 = min(sv0 >> 7, 32767), cv1 = min(sv1 >> 7, 32767);
             if (a.rangeConv == 1) {          // chrRangeToJpeg_c, swscale.c:157-164 (hscale.c:193)
                 cu0 = (m24(min(cu0, 30775), 4663) - 9289992) >> 12; cu1 = (m24(min(cu1, 30775), 4663) - 9289992) >> 12;
@@ -484,7 +493,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
     const bool yuvOut = is_yuv420(p.dstFormat);
     if (!is_yuv8_src(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
-    if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
+    if (p.hLum.pairs > 64 || p.hChr.pairs > 64) return GMAT_ERR(ENOSYS);      // 128 taps: ratios up to ~30:1 (bicubic)
     const int full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) ? 1 : 0;
     if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);
     if (p.chrDstH != (yuvOut ? (p.dstH + 1) / 2 : p.dstH)) return GMAT_ERR(ENOSYS);
@@ -513,9 +522,12 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     }
     pack_filter_pairs(t.vChrEff);
 
-    const int ldsCap = yenv("GMAT_SCALE_LDS_CAP", 40 * 1024);
     const int forceTW = yenv("GMAT_SCALE_TW", 0), forceTH = yenv("GMAT_SCALE_TH", 0);
     const int tws[] = {64, 32};
+    // first the tilings that leave room for several blocks per CU; large down-scale ratios (wide windows) may use
+    // the whole 64 KB a workgroup can address
+    const int caps[] = {yenv("GMAT_SCALE_LDS_CAP", 40 * 1024), 64 * 1024};
+    for (int ldsCap : caps)
     for (int TW : tws) {
         if (forceTW && TW != forceTW) continue;
         const int cwd = full ? TW : TW / 2;

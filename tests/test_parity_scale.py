@@ -304,3 +304,18 @@ def test_regressions_found_by_the_fuzzer(dev, orc, case):
     32-bit magic that does not exist."""
     sf, df, (sw, sh, dw, dh), flags = case
     _check(dev, orc, sf, sw, sh, dw, dh, df, flags, align=1, extra=1)
+
+
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "nv12"])
+@pytest.mark.parametrize("geom", [(207, 57, 54, 51), (512, 96, 64, 12), (640, 64, 80, 40), (300, 200, 40, 25)])
+def test_yuv_single_context_large_downscale_ratios(dev, orc, dst_fmt, geom):
+    """ratios beyond ~3.7:1 need more than 16 horizontal taps: the generic plane scaler handles them in its tail
+    loops instead of falling back to convert-then-scale semantics"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, "nv12", sw, sh, seed=51)
+    want = orc.sws(src, sw, sh, "nv12", dw, dh, dst_fmt, SWS["bicubic"])
+    d = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d, sw, sh, "nv12", dw, dh, dst_fmt, SWS["bicubic"], dst_align=64)
+    assert kernel.startswith("scale_yuv_kernel"), kernel
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
