@@ -286,6 +286,10 @@ __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideC
             for (int k = 0; k < kMaxPairs; k++) {
                 if (k < a.hLum.pairs) { s0 = dot2(py0[k], lc[k], s0); s1 = dot2(py1[k], lc[k], s1); }
             }
+            for (int k = kMaxPairs; k < a.hLum.pairs; k++) {          // filters longer than 16 taps (large ratios)
+                const int cf = a.hLum.packed[(size_t)gx * a.hLum.pairs + k];
+                s0 = dot2(py0[k], cf, s0); s1 = dot2(py1[k], cf, s1);
+            }
             hy[rp * TW + xo] = (int)pack16(min(s0 >> 13, 32767), min(s1 >> 13, 32767));
             if (!a.chromaDirect) {
                 const int *pu0 = reinterpret_cast<const int *>(lu + (2 * rp) * CW + cpos);
@@ -299,6 +303,11 @@ __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideC
                         u0 = dot2(pu0[k], cc[k], u0); u1 = dot2(pu1[k], cc[k], u1);
                         v0 = dot2(pv0[k], cc[k], v0); v1 = dot2(pv1[k], cc[k], v1);
                     }
+                }
+                for (int k = kMaxPairs; k < a.hChr.pairs; k++) {
+                    const int cf = a.hChr.packed[(size_t)gx * a.hChr.pairs + k];
+                    u0 = dot2(pu0[k], cf, u0); u1 = dot2(pu1[k], cf, u1);
+                    v0 = dot2(pv0[k], cf, v0); v1 = dot2(pv1[k], cf, v1);
                 }
                 hu[rp * TW + xo] = (int)pack16(min(u0 >> 13, 32767), min(u1 >> 13, 32767));
                 hv[rp * TW + xo] = (int)pack16(min(v0 >> 13, 32767), min(v1 >> 13, 32767));
@@ -389,7 +398,7 @@ static int env_int(const char *name, int dflt)
 
 int scale_pick_tiling(const ScalePlan &p, ScaleTiling &t)
 {
-    if (p.hLum.pairs > kMaxPairs || p.hChr.pairs > kMaxPairs) return GMAT_ERR(ENOSYS);
+    if (p.hLum.pairs > 64 || p.hChr.pairs > 64) return GMAT_ERR(ENOSYS);       // 128 taps
     if (p.chrDstW != p.dstW || p.chrDstH != p.dstH) return GMAT_ERR(ENOSYS);   // full-chroma output only
     const int half = p.chrSrcHSub;
     // identity chroma filter (one tap of 16384 at pos[i] == i): chroma needs no horizontal pass
@@ -398,8 +407,10 @@ int scale_pick_tiling(const ScalePlan &p, ScaleTiling &t)
         direct = p.hChr.pos[i] == i && p.hChr.coef[i] == 16384;
     if (env_int("GMAT_SCALE_NO_DIRECT", 0)) direct = 0;
     const int forceTW = env_int("GMAT_SCALE_TW", 0), forceTH = env_int("GMAT_SCALE_TH", 0);
-    const int ldsCap = env_int("GMAT_SCALE_LDS_CAP", 40 * 1024);
+    // first the tilings that leave room for several blocks per CU, then (large ratios) anything up to 64 KB
+    const int caps[] = {env_int("GMAT_SCALE_LDS_CAP", 40 * 1024), 64 * 1024};
     const int tws[] = {64, 32};
+    for (int ldsCap : caps)
     for (int TW : tws) {
         if (forceTW && TW != forceTW) continue;
         // column windows

@@ -319,3 +319,10 @@ def test_yuv_single_context_large_downscale_ratios(dev, orc, dst_fmt, geom):
     assert kernel.startswith("scale_yuv_kernel"), kernel
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
+
+
+@pytest.mark.parametrize("geom", [(207, 57, 54, 51), (512, 96, 64, 12), (300, 200, 40, 25)])
+def test_rgb_large_downscale_ratios(dev, orc, geom):
+    sw, sh, dw, dh = geom
+    _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
+    _check(dev, orc, "nv12", sw, sh, dw, dh, "bgra", SWS["bicubic"], fused=1)
