@@ -583,7 +583,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 xa.dstW = ya.dstW; xa.dstH = ya.dstH;
                 xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
                 xa.dstU = ya.dstU; xa.dstV = ya.dstV; xa.dsU = ya.dsU; xa.dsV = ya.dsV; xa.dstNv12 = ya.dstNv12;
-                xa.yuvOut = c->y2x.yuvOut; xa.chrDstW = ya.chrDstW; xa.chrDstH = ya.chrDstH;
+                xa.yuvOut = c->y2x.yuvOut; xa.chrDstW = ya.chrDstW; xa.chrDstH = ya.chrDstH; xa.P = c->y2x.P;
                 xa.vrecC = (const int32_t *)c->dVrecC.p;
                 xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
                 xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;

@@ -17,7 +17,8 @@
 
 namespace gmat {
 
-constexpr int X2_TW = 64, X2_TH = 16, X2_P = 5;
+constexpr int X2_TW = 64, X2_TH = 16;
+constexpr int X2_VR = 16, X2_VRC = 12;                  // ints per luma-row / chroma-row vertical record
 constexpr int X2_COLSL = 160, X2_COLSC = 80;           // LDS row lengths (int16 samples)
 
 __device__ __forceinline__ unsigned x2pk(int lo, int hi) { return ((unsigned)lo & 0xFFFF) | ((unsigned)hi << 16); }
@@ -32,16 +33,17 @@ typedef short x2_short2 __attribute__((ext_vector_type(2)));
 
 // 4 adjacent outputs x 2 rows from one regular window: w0/w1 hold 8 dwords of row 0 / row 1,
 // c[j*5 + k] the k-th coefficient pair of output j.  Returns 4 dwords (row0 | row1 << 16).
-__device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[8], const int (&w1)[8], const int (&c)[20])
+template <int P>
+__device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[(4 + P) & ~1], const int (&w1)[(4 + P) & ~1], const int (&c)[4 * P])
 {
     unsigned o[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         int s0 = 0, s1 = 0;
 #pragma unroll
-        for (int k = 0; k < X2_P; k++) {
-            s0 = dot2(w0[j + k], c[j * X2_P + k], s0);
-            s1 = dot2(w1[j + k], c[j * X2_P + k], s1);
+        for (int k = 0; k < P; k++) {
+            s0 = dot2(w0[j + k], c[j * P + k], s0);
+            s1 = dot2(w1[j + k], c[j * P + k], s1);
         }
         // hScale8To15_c stores min(val >> 7, 32767) into an int16.  v_cvt_pk_i16_i32 saturates both ways and
         // packs in one instruction; the lower bound cannot trigger (255 * sum of negative taps >> 7 > -32768
@@ -54,7 +56,9 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[8], const int (&w1)
 // YUVOUT = false: packed RGB out (colour stage fused).  true: NV12 / YUV420P out — the tile is 64 x 16 luma
 // outputs plus the 32 x 8 chroma outputs under them, vertical chroma filter indexed by chroma row
 // (yuv2planeX_8_c / yuv2nv12cX_c, output.c:400-450).
-template <bool YUVOUT>
+// P = coefficient pairs per output on the regular window of 2*P samples: 5 covers bicubic / bilinear (8 taps + the
+// parity slot), 8 covers Lanczos-3 (12 taps; the window origin is a multiple of 4 samples, which costs up to 3).
+template <bool YUVOUT, int P>
 __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL, int rowsC)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -91,9 +95,9 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     int *hu = hy + (rowsL >> 1) * X2_TW;
     int *hv = hu + (rowsC >> 1) * (X2_TW / 2);
     int *cL = hv + (rowsC >> 1) * (X2_TW / 2);                   // [64][5]
-    int *cC = cL + X2_TW * X2_P;                                 // [32][5]
-    int *vr = cC + (X2_TW / 2) * X2_P;                           // [16][12] vertical records of the tile's rows
-    int *vrc = vr + X2_TH * 12;                                  // YUVOUT: [8][8] records of the tile's chroma rows
+    int *cC = cL + X2_TW * P;                                    // [32][P]
+    int *vr = cC + (X2_TW / 2) * P;                              // [16][X2_VR] vertical records of the tile's rows
+    int *vrc = vr + X2_TH * X2_VR;                               // YUVOUT: [8][X2_VRC] records of the tile's chroma rows
 
     constexpr int QW = X2_TW / 4;
     const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one phase-3 item each
@@ -102,10 +106,22 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     // ================= phase 1: 16-byte loads, whole rows per wave ===============================
     {
         // tile coefficient rows -> LDS (80 + 40 lanes x 16 B)
-        if (tid < 80)       reinterpret_cast<uint4 *>(cL)[tid] = reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * X2_P)[tid];
-        else if (tid < 120) reinterpret_cast<uint4 *>(cC)[tid - 80] = reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * X2_P)[tid - 80];
-        else if (tid < 168) reinterpret_cast<uint4 *>(vr)[tid - 120] = reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * 12)[tid - 120];
-        else if (YUVOUT && tid < 184) reinterpret_cast<uint4 *>(vrc)[tid - 168] = reinterpret_cast<const uint4 *>(a.vrecC + (size_t)(ty0 >> 1) * 8)[tid - 168];
+        constexpr int NL = X2_TW * P / 4, NC = (X2_TW / 2) * P / 4, NV = X2_TH * X2_VR / 4, NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
+        constexpr int NT = NL + NC + NV + NVC;                   // 16-byte table chunks: one per thread, a second for
+        static_assert(NT <= 512, "two table chunks per thread");  // the first NT - 256 threads of the widest variant
+        // the table loads are ISSUED here and stored to LDS only after the pixel loads below have been issued, so
+        // the block pays one memory round trip, not two (a load -> store loop at this point cost 7 %)
+        auto tab = [&](int i, const uint4 *&sp, uint4 *&dp) {
+            if (i < NL)                { sp = reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * P) + i; dp = reinterpret_cast<uint4 *>(cL) + i; }
+            else if (i < NL + NC)      { sp = reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * P) + (i - NL); dp = reinterpret_cast<uint4 *>(cC) + (i - NL); }
+            else if (i < NL + NC + NV) { sp = reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * X2_VR) + (i - NL - NC); dp = reinterpret_cast<uint4 *>(vr) + (i - NL - NC); }
+            else                       { sp = reinterpret_cast<const uint4 *>(a.vrecC + (size_t)(ty0 >> 1) * X2_VRC) + (i - NL - NC - NV); dp = reinterpret_cast<uint4 *>(vrc) + (i - NL - NC - NV); }
+        };
+        const uint4 *ts0 = nullptr, *ts1 = nullptr;
+        uint4 *td0 = nullptr, *td1 = nullptr;
+        uint4 tv0 = make_uint4(0u, 0u, 0u, 0u), tv1 = tv0;
+        if (tid < NT) { tab(tid, ts0, td0); tv0 = *ts0; }
+        if (NT > 256 && tid + 256 < NT) { tab(tid + 256, ts1, td1); tv1 = *ts1; }
 
         const int rs = (lane * 205) >> 11, g = lane - rs * 10;   // lane / 10 for lane < 64: 6 rows x 10 groups per wave
         const bool act = lane < 60;
@@ -129,6 +145,8 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
             tc.x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); tc.y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
             tc.z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); tc.w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
         }
+        if (tid < NT) *td0 = tv0;
+        if (NT > 256 && tid + 256 < NT) *td1 = tv1;
         if (act && rowA < nrL) {
             uint4 *d = reinterpret_cast<uint4 *>(ly + rowA * X2_COLSL + 16 * g);
             const uint2 p0 = x2_widen(va.x), p1 = x2_widen(va.y), p2 = x2_widen(va.z), p3 = x2_widen(va.w);
@@ -167,18 +185,20 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
             const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
             const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
             const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
-            int w0[8], w1[8], c[20];
+            // 4 adjacent outputs share a window of 6 + 2P samples = 3 + P dwords, read as 8-byte pairs
+            constexpr int NWD = (4 + P) & ~1;
+            int w0[NWD], w1[NWD], c[4 * P];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NWD / 2; i++) {
                 const uint2 t0 = r0p[pair0 + i], t1 = r1p[pair0 + i];
                 w0[2 * i] = (int)t0.x; w0[2 * i + 1] = (int)t0.y; w1[2 * i] = (int)t1.x; w1[2 * i + 1] = (int)t1.y;
             }
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * X2_P)[i];
+            for (int i = 0; i < P; i++) {
+                const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * P)[i];
                 c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
             }
-            *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4(w0, w1, c);
+            *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4<P>(w0, w1, c);
         };
         for (int it = tid; it < total; it += 256) {
             const int wbase = __builtin_amdgcn_readfirstlane(it);     // tid of the wave's first lane is a multiple of 64
@@ -202,17 +222,17 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     if constexpr (YUVOUT) {
         const int xo = tx0 + 4 * q;
         {   // luma: 4 outputs of row yo
-            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * 12)[0], rb = reinterpret_cast<const int4 *>(vr + yl * 12)[1],
-                       rc = reinterpret_cast<const int4 *>(vr + yl * 12)[2];
-            const int vl[X2_P] = {ra.x, ra.y, ra.z, ra.w, rb.x};
-            const int vpL = (rb.w - r0L) >> 1, lr = rc.y;
+            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                       rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+            const int vl8[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            const int vpL = (rd.x - r0L) >> 1, lr = rd.z;
             int Y[4] = {lr, lr, lr, lr};
 #pragma unroll
-            for (int k = 0; k < X2_P; k++) {
+            for (int k = 0; k < P; k++) {
                 if (k < a.vLpairs) {
                     const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
-                    Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
-                    Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
+                    Y[0] = dot2(v.x, vl8[k], Y[0]); Y[1] = dot2(v.y, vl8[k], Y[1]);
+                    Y[2] = dot2(v.z, vl8[k], Y[2]); Y[3] = dot2(v.w, vl8[k], Y[3]);
                 }
             }
             if (yo < a.dstH && xo < a.dstW) {
@@ -230,13 +250,14 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
             // the U and V halves of an NV12 dword meet through one cross-lane exchange (lanes l and l ^ 16)
             const int pl = yl & 1, cyl = yl >> 1;
             const int cy = (ty0 >> 1) + cyl, cx = tcx0 + 2 * q;
-            const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * 8)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * 8)[1];
-            const int vcp[X2_P] = {ca.x, ca.y, ca.z, ca.w, cb.x};
-            const int vp = (cb.y - r0C) >> 1;
+            const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[1],
+                       cc3 = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[2];
+            const int vcp[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            const int vp = (cc3.x - r0C) >> 1;
             const int *hp = pl ? hv : hu;
-            int C0 = cb.z, C1 = cb.z;
+            int C0 = cc3.y, C1 = cc3.y;
 #pragma unroll
-            for (int k = 0; k < X2_P; k++) {
+            for (int k = 0; k < P; k++) {
                 if (k < a.vCpairs) {
                     const uint2 t = *reinterpret_cast<const uint2 *>(hp + (vp + k) * (X2_TW / 2) + 2 * q);
                     C0 = dot2((int)t.x, vcp[k], C0); C1 = dot2((int)t.y, vcp[k], C1);
@@ -265,31 +286,29 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
         const int xo = tx0 + 4 * q;
         if (yo < a.dstH && xo < a.dstW) {
             // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
-            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * 12)[0], rb = reinterpret_cast<const int4 *>(vr + yl * 12)[1],
-                       rc = reinterpret_cast<const int4 *>(vr + yl * 12)[2];
-            const int vl[X2_P] = {ra.x, ra.y, ra.z, ra.w, rb.x};
-            const int vc0 = rb.y, vc1 = rb.z;
-            const int vpL = (rb.w - r0L) >> 1, vpC = (rc.x - r0C) >> 1, lr = rc.y, cr = rc.z;
+            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                       rc = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2], rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+            const int vl[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            const int vcc[4] = {rc.x, rc.y, rc.z, rc.w};
+            const int vpL = (rd.x - r0L) >> 1, vpC = (rd.y - r0C) >> 1, lr = rd.z, cr = rd.w;
             int Y[4] = {lr, lr, lr, lr}, U[2] = {cr, cr}, V[2] = {cr, cr};
 #pragma unroll
-            for (int k = 0; k < X2_P; k++) {
+            for (int k = 0; k < P; k++) {
                 if (k < a.vLpairs) {
                     const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
                     Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
                     Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
                 }
             }
-            {
-                const uint2 u = *reinterpret_cast<const uint2 *>(hu + vpC * (X2_TW / 2) + 2 * q);
-                const uint2 v = *reinterpret_cast<const uint2 *>(hv + vpC * (X2_TW / 2) + 2 * q);
-                U[0] = dot2((int)u.x, vc0, U[0]); U[1] = dot2((int)u.y, vc0, U[1]);
-                V[0] = dot2((int)v.x, vc0, V[0]); V[1] = dot2((int)v.y, vc0, V[1]);
-            }
-            if (a.vCpairs > 1) {
-                const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + 1) * (X2_TW / 2) + 2 * q);
-                const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + 1) * (X2_TW / 2) + 2 * q);
-                U[0] = dot2((int)u.x, vc1, U[0]); U[1] = dot2((int)u.y, vc1, U[1]);
-                V[0] = dot2((int)v.x, vc1, V[0]); V[1] = dot2((int)v.y, vc1, V[1]);
+            constexpr int VCP = P == 5 ? 2 : 4;           // vertical chroma pairs the variant provides for
+#pragma unroll
+            for (int k = 0; k < VCP; k++) {
+                if (k == 0 || k < a.vCpairs) {
+                    const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + k) * (X2_TW / 2) + 2 * q);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + k) * (X2_TW / 2) + 2 * q);
+                    U[0] = dot2((int)u.x, vcc[k], U[0]); U[1] = dot2((int)u.y, vcc[k], U[1]);
+                    V[0] = dot2((int)v.x, vcc[k], V[0]); V[1] = dot2((int)v.y, vcc[k], V[1]);
+                }
             }
             ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
             ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
@@ -346,9 +365,9 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// Re-express a filter bank on the regular window [2x + w0, 2x + w0 + 2*X2_P).  Returns false when some
+// Re-express a filter bank on the regular window [2x + w0, 2x + w0 + 2*P).  Returns false when some
 // row's non-zero taps do not fit.  `padded` = number of rows to emit (rows past count repeat the last).
-static bool regularise(const FilterBank &fb, int padded, int &w0, std::vector<int32_t> &out)
+static bool regularise(const FilterBank &fb, int padded, int P, int &w0, std::vector<int32_t> &out)
 {
     int lo = INT32_MAX;
     std::vector<int> first(fb.count), last(fb.count);
@@ -362,18 +381,19 @@ static bool regularise(const FilterBank &fb, int padded, int &w0, std::vector<in
     }
     w0 = lo & ~3;                                    // floor to a multiple of 4 (also for negatives)
     for (int x = 0; x < fb.count; x++)
-        if (last[x] - 2 * x - w0 >= 2 * X2_P) return false;
-    out.assign((size_t)padded * X2_P, 0);
+        if (last[x] - 2 * x - w0 >= 2 * P) return false;
+    out.assign((size_t)padded * P, 0);
+    std::vector<int16_t> win(2 * P);
     for (int xx = 0; xx < padded; xx++) {
         const int x = std::min(xx, fb.count - 1);
-        int16_t win[2 * X2_P] = {0};
+        std::fill(win.begin(), win.end(), (int16_t)0);
         for (int j = 0; j < fb.taps; j++) {
             const int16_t cv = fb.coef[(size_t)x * fb.taps + j];
             if (!cv) continue;
             win[fb.pos[x] + j - 2 * x - w0] = cv;
         }
-        for (int k = 0; k < X2_P; k++)
-            out[(size_t)xx * X2_P + k] = (int32_t)((uint32_t)(uint16_t)win[2 * k] | ((uint32_t)(uint16_t)win[2 * k + 1] << 16));
+        for (int k = 0; k < P; k++)
+            out[(size_t)xx * P + k] = (int32_t)((uint32_t)(uint16_t)win[2 * k] | ((uint32_t)(uint16_t)win[2 * k + 1] << 16));
     }
     return true;
 }
@@ -386,46 +406,57 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     if (g.fullChroma || g.TW != X2_TW || g.TH != X2_TH) return 0;
     if (!is_yuv420(p.srcFormat)) return 0;                    // the tile geometry assumes half-size chroma planes
     if (p.srcW % 16 || p.chrSrcW % 8 || p.srcW < 16) return 0;
-    if (p.vLum.pairs > X2_P || g.vChrEff.pairs > (g.yuvOut ? X2_P : 2)) return 0;
-    t.ntx = g.ntx; t.nty = g.nty;
-    if (!regularise(p.hLum, t.ntx * X2_TW, t.w0L, t.hLreg)) return 0;
-    if (!regularise(p.hChr, t.ntx * (X2_TW / 2), t.w0C, t.hCreg)) return 0;
-    // every tile's regular window must fit the fixed LDS row lengths
-    for (int tc = 0; tc < t.ntx; tc++) {
-        const int wl = 2 * tc * X2_TW + t.w0L, wc = 2 * tc * (X2_TW / 2) + t.w0C;
-        if ((wl - (wl & ~15)) + 2 * (X2_TW - 1) + 2 * X2_P > X2_COLSL) return 0;
-        if ((wc - (wc & ~7)) + 2 * (X2_TW / 2 - 1) + 2 * X2_P > X2_COLSC) return 0;
-    }
-    const int bytes = g.rowsL * X2_COLSL * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
-                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * X2_P * 4 + X2_TH * 12 * 4 +
-                      (g.yuvOut ? (X2_TH / 2) * 8 * 4 : 0);
-    if (bytes > 64 * 1024) return 0;
     if (g.rowsL > 48 || g.rowsC > 24) return 0;               // phase 1 covers 48 luma / 24 chroma rows per tile
-    // per-output-row records for phase 3 (rows past dstH repeat the last one; never stored)
-    t.vrec.assign((size_t)t.nty * X2_TH * 12, 0);
+    t.ntx = g.ntx; t.nty = g.nty;
+    // smallest window that holds every row: 10 samples (bicubic, bilinear ...) or 16 (Lanczos-3)
+    int P = 0;
+    for (int cand : {5, 8}) {
+        if (p.vLum.pairs > cand || g.vChrEff.pairs > (g.yuvOut ? cand : (cand == 5 ? 2 : 4))) continue;
+        if (!regularise(p.hLum, t.ntx * X2_TW, cand, t.w0L, t.hLreg)) continue;
+        if (!regularise(p.hChr, t.ntx * (X2_TW / 2), cand, t.w0C, t.hCreg)) continue;
+        // every tile's regular window must fit the fixed LDS row lengths
+        bool fits = true;
+        for (int tc = 0; tc < t.ntx && fits; tc++) {
+            const int wl = 2 * tc * X2_TW + t.w0L, wc = 2 * tc * (X2_TW / 2) + t.w0C;
+            fits = (wl - (wl & ~15)) + 2 * (X2_TW - 1) + 2 * cand <= X2_COLSL &&
+                   (wc - (wc & ~7)) + 2 * (X2_TW / 2 - 1) + 2 * cand <= X2_COLSC;
+        }
+        if (fits) { P = cand; break; }
+    }
+    if (!P) return 0;
+    const int bytes = g.rowsL * X2_COLSL * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
+                      2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * P * 4 + X2_TH * X2_VR * 4 +
+                      (g.yuvOut ? (X2_TH / 2) * X2_VRC * 4 : 0);
+    if (bytes > 64 * 1024) return 0;
+    // per-output-row records for phase 3 (rows past dstH repeat the last one; never stored):
+    //   [0..6] luma pairs   [8..11] chroma pairs (RGB output)   [12] luma window row  [13] chroma window row
+    //   [14] luma accumulator start   [15] chroma accumulator start
+    t.vrec.assign((size_t)t.nty * X2_TH * X2_VR, 0);
     for (int yy = 0; yy < t.nty * X2_TH; yy++) {
         const int y = std::min(yy, p.dstH - 1);
-        int32_t *r = &t.vrec[(size_t)yy * 12];
+        int32_t *r = &t.vrec[(size_t)yy * X2_VR];
         for (int k = 0; k < p.vLum.pairs; k++) r[k] = p.vLum.packed[(size_t)y * p.vLum.pairs + k];
-        r[7] = p.vLum.pos_even[y];
-        r[9] = g.lumRound[y];
+        r[12] = p.vLum.pos_even[y];
+        r[14] = g.lumRound[y];
         if (g.yuvOut) continue;                              // chroma rows have their own records (vrecC)
-        for (int k = 0; k < g.vChrEff.pairs; k++) r[5 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
-        r[8] = g.vChrEff.pos_even[y];
-        r[10] = g.chrRound[y];
+        for (int k = 0; k < g.vChrEff.pairs; k++) r[8 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
+        r[13] = g.vChrEff.pos_even[y];
+        r[15] = g.chrRound[y];
     }
     t.vrecC.clear();
     if (g.yuvOut) {
-        t.vrecC.assign((size_t)t.nty * (X2_TH / 2) * 8, 0);
+        // [0..6] chroma pairs   [8] window row   [9] accumulator start
+        t.vrecC.assign((size_t)t.nty * (X2_TH / 2) * X2_VRC, 0);
         for (int cyy = 0; cyy < t.nty * (X2_TH / 2); cyy++) {
             const int cy = std::min(cyy, p.chrDstH - 1);
-            int32_t *r = &t.vrecC[(size_t)cyy * 8];
+            int32_t *r = &t.vrecC[(size_t)cyy * X2_VRC];
             for (int k = 0; k < g.vChrEff.pairs; k++) r[k] = g.vChrEff.packed[(size_t)cy * g.vChrEff.pairs + k];
-            r[5] = g.vChrEff.pos_even[cy];
-            r[6] = g.chrRound[cy];
+            r[8] = g.vChrEff.pos_even[cy];
+            r[9] = g.chrRound[cy];
         }
     }
     t.yuvOut = g.yuvOut;
+    t.P = P;
     t.vLpairs = p.vLum.pairs; t.vCpairs = g.vChrEff.pairs;
     t.ok = bytes;
     return 0;
@@ -436,8 +467,11 @@ int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, h
     const int ntiles = a.ntx * a.nty;
     if (ntiles <= 0) return 0;
     const dim3 grid(a.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
-    if (a.yuvOut) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<true>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC);
-    else          hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<false>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC);
+#define GMAT_X2(Y_, P_) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC)
+    if (a.P == 5)      { if (a.yuvOut) GMAT_X2(true, 5); else GMAT_X2(false, 5); }
+    else if (a.P == 8) { if (a.yuvOut) GMAT_X2(true, 8); else GMAT_X2(false, 8); }
+    else return GMAT_ERR(EINVAL);
+#undef GMAT_X2
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

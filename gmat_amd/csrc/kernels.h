@@ -158,6 +158,7 @@ struct Yuv2xTables {
     std::vector<int32_t> vrec;                  // [nty*16][12] per-output-row vertical record
     std::vector<int32_t> vrecC;                 // YUV output: [nty*8][8] per-chroma-row record (5 pairs, pos, round)
     int vLpairs = 0, vCpairs = 0, yuvOut = 0;
+    int P = 5;                                  // coefficient pairs per output: window of 2*P samples (5 or 8)
 };
 struct Yuv2xArgs {
     const uint8_t *y, *u, *v;
@@ -167,6 +168,7 @@ struct Yuv2xArgs {
     int ds, dstFormat, dstAligned;
     uint8_t *dstU, *dstV;                       // YUV output (yuvOut): chroma planes, NV12: dstU = interleaved UV
     int dsU, dsV, dstNv12, yuvOut, chrDstW, chrDstH;
+    int P;                                      // 5 or 8 (Yuv2xTables::P)
     const int32_t *vrecC;
     const int32_t *hLreg, *hCreg, *vrec;
     int w0L, w0C, vLpairs, vCpairs;

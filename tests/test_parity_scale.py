@@ -326,3 +326,21 @@ def test_rgb_large_downscale_ratios(dev, orc, geom):
     sw, sh, dw, dh = geom
     _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
     _check(dev, orc, "nv12", sw, sh, dw, dh, "bgra", SWS["bicubic"], fused=1)
+
+
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", X2_GEOMS)
+def test_yuv2x_lanczos_uses_the_14_sample_window(dev, orc, src_fmt, geom):
+    """Lanczos-3 at 2:1 has 12 taps: the 2:1 kernel's P = 7 variant (window of 14 samples, 4 vertical chroma pairs)"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=53)
+    for dst_fmt in ("rgb24", "bgra"):
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["lanczos"])[0]
+        d_src = dev.upload_planes(src, 256)
+        got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["lanczos"], dst_align=256)
+        for p in d_src:
+            p.free()
+        assert kernel == "scale_yuv2x_kernel", kernel
+        bad = np.argwhere(got[0] != want)
+        assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (pads[0] == 0xCD).all()

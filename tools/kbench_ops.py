@@ -11,7 +11,7 @@ import torch
 import gmat_amd
 from gmat_amd.lib import PIX_FMT, SWS, planes, ints
 
-lib = gmat_amd.load()
+lib = gmat_amd.load(os.environ["KBENCH_LIB"]) if os.environ.get("KBENCH_LIB") else gmat_amd.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 NF = 16
