@@ -223,7 +223,8 @@ __device__ __forceinline__ void scale_phase1(const ScaleArgs &a, int tid, int tx
         }
 }
 
-template <int TW, int SRCKIND>
+// LONG: horizontal filters longer than 2*kMaxPairs taps, compiled only into their own instantiation
+template <int TW, int SRCKIND, bool LONG>
 __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideCols, int maxRows)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideC
             for (int k = 0; k < kMaxPairs; k++) {
                 if (k < a.hLum.pairs) { s0 = dot2(py0[k], lc[k], s0); s1 = dot2(py1[k], lc[k], s1); }
             }
-            for (int k = kMaxPairs; k < a.hLum.pairs; k++) {          // filters longer than 16 taps (large ratios)
+            if (LONG) for (int k = kMaxPairs; k < a.hLum.pairs; k++) {          // filters longer than 16 taps (large ratios)
                 const int cf = a.hLum.packed[(size_t)gx * a.hLum.pairs + k];
                 s0 = dot2(py0[k], cf, s0); s1 = dot2(py1[k], cf, s1);
             }
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideC
                         v0 = dot2(pv0[k], cc[k], v0); v1 = dot2(pv1[k], cc[k], v1);
                     }
                 }
-                for (int k = kMaxPairs; k < a.hChr.pairs; k++) {
+                if (LONG) for (int k = kMaxPairs; k < a.hChr.pairs; k++) {
                     const int cf = a.hChr.packed[(size_t)gx * a.hChr.pairs + k];
                     u0 = dot2(pu0[k], cf, u0); u1 = dot2(pu1[k], cf, u1);
                     v0 = dot2(pv0[k], cf, v0); v1 = dot2(pv1[k], cf, v1);
@@ -476,9 +477,12 @@ int launch_scale_rgb(const ScaleArgs &a, const ScaleTiling &t, hipStream_t strea
     const int nblocks = t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles;
     const dim3 grid(nblocks), block(256);
     const size_t lds = (size_t)t.ldsBytes;
-#define GMAT_LAUNCH_SCALE(TW_, KIND_)                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb_kernel<TW_, KIND_>), grid, block, lds, stream, a, \
-                       t.maxCols, t.maxRows)
+    const bool longH = a.hLum.pairs > kMaxPairs || a.hChr.pairs > kMaxPairs;
+#define GMAT_LAUNCH_SCALE(TW_, KIND_)                                                                              \
+    do { if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb_kernel<TW_, KIND_, true>), grid, block, lds, stream, a, \
+                                       t.maxCols, t.maxRows);                                                          \
+         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb_kernel<TW_, KIND_, false>), grid, block, lds, stream, a, \
+                                       t.maxCols, t.maxRows); } while (0)
     if (t.TW == 64) { if (a.srcKind) GMAT_LAUNCH_SCALE(64, 1); else GMAT_LAUNCH_SCALE(64, 0); }
     else if (t.TW == 32) { if (a.srcKind) GMAT_LAUNCH_SCALE(32, 1); else GMAT_LAUNCH_SCALE(32, 0); }
     else return GMAT_ERR(EINVAL);

@@ -183,7 +183,10 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
 // MODE 0: packed RGB out, half chroma (LUT form)   1: packed RGB out, full chroma
 //      2: YUV 4:2:0 out (NV12 or YUV420P): the tile is TW x TH luma outputs plus the TW/2 x TH/2 chroma
 //         outputs under them; vChr is indexed by CHROMA row; yuv2planeX_8_c / yuv2nv12cX_c (output.c:400-450)
-template <int TW, int MODE>
+// LONG: horizontal filters longer than 2*kYMaxPairs taps (down-scale ratios beyond ~3.7:1).  A separate
+// instantiation: with the tail loops compiled into the common variant every geometry paid for them (the 2x
+// up-scale went from 38.7 to 47.3 us).
+template <int TW, int MODE, bool LONG>
 __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 #pragma unroll
             for (int k = 0; k < kYMaxPairs; k++)
                 if (k < a.hLum.pairs) { s0 = dot2(p0[k], lc[k], s0); s1 = dot2(p1[k], lc[k], s1); }
-            for (int k = kYMaxPairs; k < a.hLum.pairs; k++) {         // filters longer than 16 taps (ratios beyond ~3.7:1)
+            if (LONG) for (int k = kYMaxPairs; k < a.hLum.pairs; k++) {         // filters longer than 16 taps (ratios beyond ~3.7:1)
                 const int cf = a.hLum.packed[(size_t)gx2 * a.hLum.pairs + k];
                 s0 = dot2(p0[k], cf, s0); s1 = dot2(p1[k], cf, s1);
             }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                     su0 = dot2(u0[k], cc[k], su0); su1 = dot2(u1[k], cc[k], su1);
                     sv0 = dot2(v0[k], cc[k], sv0); sv1 = dot2(v1[k], cc[k], sv1);
                 }
-            for (int k = kYMaxPairs; k < a.hChr.pairs; k++) {
+            if (LONG) for (int k = kYMaxPairs; k < a.hChr.pairs; k++) {
                 const int cf = a.hChr.packed[(size_t)gc2 * a.hChr.pairs + k];
                 su0 = dot2(u0[k], cf, su0); su1 = dot2(u1[k], cf, su1);
                 sv0 = dot2(v0[k], cf, sv0); sv1 = dot2(v1[k], cf, sv1);
@@ -571,8 +574,10 @@ int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t
     if (ntiles <= 0) return 0;
     const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
     const size_t lds = (size_t)t.ldsBytes;
+    const bool longH = a.hLum.pairs > kYMaxPairs || a.hChr.pairs > kYMaxPairs;
 #define GMAT_LAUNCH_YUV(TW_, MODE_) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_>), grid, block, lds, stream, a)
+    do { if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true>), grid, block, lds, stream, a); \
+         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false>), grid, block, lds, stream, a); } while (0)
     const int mode = t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
     if (t.TW == 64) { if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
     else if (t.TW == 32) { if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }

@@ -82,6 +82,7 @@ def plane_case(label, fn_name, w, h, bpp, *extra):
 
 
 sws_case("4K nv12 -> 1080p rgb24 (headline)", "nv12", 3840, 2160, "rgb24", 1920, 1080)
+sws_case("4K nv12 -> 1080p rgb24 lanczos", "nv12", 3840, 2160, "rgb24", 1920, 1080, SWS["lanczos"])
 sws_case("4K nv12 -> 1080p nv12", "nv12", 3840, 2160, "nv12", 1920, 1080)
 sws_case("4K yuv420p -> 1080p yuv420p", "yuv420p", 3840, 2160, "yuv420p", 1920, 1080)
 sws_case("4K nv12 -> 720p nv12", "nv12", 3840, 2160, "nv12", 1280, 720)
