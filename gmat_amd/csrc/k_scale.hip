@@ -241,14 +241,14 @@ __global__ __launch_bounds__(256) void scale_rgb_kernel(ScaleArgs a, int strideC
             lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         }
         if (lin >= ntiles) return;
-        tcol = lin / a.nty;
+        tcol = __builtin_amdgcn_readfirstlane(lin / a.nty);     // wave-uniform: table look-ups below become scalar loads
         trow = lin - tcol * a.nty;
     }
     const int tid = threadIdx.x;
     const int tx0 = tcol * TW, ty0 = trow * a.TH;
-    const int c0 = a.colStart[tcol], nc = a.colCount[tcol];
-    const int r0 = a.rowStart[trow], nr = a.rowCount[trow];
-    const unsigned ngMagic = (unsigned)a.colMagic[tcol];
+    const int c0 = uniform_load(a.colStart, tcol), nc = uniform_load(a.colCount, tcol);
+    const int r0 = uniform_load(a.rowStart, trow), nr = uniform_load(a.rowCount, trow);
+    const unsigned ngMagic = (unsigned)uniform_load(a.colMagic, tcol);
 
     // LDS carve-up.  With chromaDirect (1-tap identity chroma filter, e.g. every 2:1 RGB down-scale) the
     // chroma planes skip the staging arrays and phase 2 entirely.

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
             lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
         }
         if (lin >= ntiles) return;
-        tcol = lin / a.nty;
+        tcol = __builtin_amdgcn_readfirstlane(lin / a.nty);     // wave-uniform: table look-ups below become scalar loads
         trow = lin - tcol * a.nty;
     }
     const int tid = threadIdx.x;
@@ -213,8 +213,10 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
     GMAT_STAMP(0);
     const int tx0 = tcol * TW, ty0 = trow * a.TH;
     const int tcx0 = FULL ? tx0 : tx0 >> 1;
-    const int c0L = a.colStartL[tcol], ncL = a.colCountL[tcol], r0L = a.rowStartL[trow], nrL = a.rowCountL[trow];
-    const int c0C = a.colStartC[tcol], ncC = a.colCountC[tcol], r0C = a.rowStartC[trow], nrC = a.rowCountC[trow];
+    const int c0L = uniform_load(a.colStartL, tcol), ncL = uniform_load(a.colCountL, tcol);
+    const int r0L = uniform_load(a.rowStartL, trow), nrL = uniform_load(a.rowCountL, trow);
+    const int c0C = uniform_load(a.colStartC, tcol), ncC = uniform_load(a.colCountC, tcol);
+    const int r0C = uniform_load(a.rowStartC, trow), nrC = uniform_load(a.rowCountC, trow);
 
     unsigned short *ly = reinterpret_cast<unsigned short *>(lds_base);
     unsigned short *lu = ly + a.rowsL * a.colsL;
