@@ -58,13 +58,16 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[(4 + P) & ~1], cons
 // (yuv2planeX_8_c / yuv2nv12cX_c, output.c:400-450).
 // P = coefficient pairs per output on the regular window of 2*P samples: 5 covers bicubic / bilinear (8 taps + the
 // parity slot), 8 covers Lanczos-3 (12 taps; the window origin is a multiple of 4 samples, which costs up to 3).
-template <bool YUVOUT, int P>
+template <bool YUVOUT, int P, int TILES>
 __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL, int rowsC)
 {
+    // TILES vertically adjacent tiles per block, software-pipelined: the pixel (and record) loads of tile t+1 are
+    // issued right after tile t's rows have been committed to LDS and stay in flight during its phases 2 and 3,
+    // so only the first tile of a block waits for HBM.
     HIP_DYNAMIC_SHARED(uint4, lds_base)
-    int tcol, trow;
+    int tcol, trow0;
     {
-        const int ntiles = a.ntx * a.nty;
+        const int ntyB = (a.nty + TILES - 1) / TILES, ntiles = a.ntx * ntyB;
         int lin = blockIdx.x;
         if (a.xcdRemap) {
             const int chunk = (ntiles + 7) >> 3;
@@ -73,17 +76,13 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
         if (lin >= ntiles) return;
         // the division runs on the VALU; readfirstlane tells the compiler the result is wave-uniform, so the
         // per-tile table look-ups below become scalar loads and the tile address arithmetic scalar code
-        tcol = __builtin_amdgcn_readfirstlane(lin / a.nty);
-        trow = lin - tcol * a.nty;
+        tcol = __builtin_amdgcn_readfirstlane(lin / ntyB);
+        trow0 = (lin - tcol * ntyB) * TILES;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long *prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
-#define X2_STAMP(i) do { if (prof && tid == 0) prof[i] = __builtin_readcyclecounter(); } while (0)
-    X2_STAMP(0);
-    if (prof && tid == 0) prof[6] = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference clock
-    const int tx0 = tcol * X2_TW, ty0 = trow * X2_TH, tcx0 = tx0 >> 1;
-    const int r0L = uniform_load(a.rowStartL, trow), nrL = uniform_load(a.rowCountL, trow);
-    const int r0C = uniform_load(a.rowStartC, trow), nrC = uniform_load(a.rowCountC, trow);
+#define X2_STAMP(i) do { if (prof && tid == 0 && tt == 0) prof[i] = __builtin_readcyclecounter(); } while (0)
+    const int tx0 = tcol * X2_TW, tcx0 = tx0 >> 1;
     const int wl = 2 * tx0 + a.w0L, wc = 2 * tcx0 + a.w0C;     // first window column (luma / chroma samples)
     const int c0L = wl & ~15, c0C = wc & ~7;                     // 16-byte aligned window starts
     const int eL = (wl - c0L) >> 1, eC = (wc - c0C) >> 1;       // window offset inside an LDS row, in dwords (even)
@@ -94,271 +93,302 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL
     int *hy = reinterpret_cast<int *>(lv + rowsC * X2_COLSC);
     int *hu = hy + (rowsL >> 1) * X2_TW;
     int *hv = hu + (rowsC >> 1) * (X2_TW / 2);
-    int *cL = hv + (rowsC >> 1) * (X2_TW / 2);                   // [64][5]
+    int *cL = hv + (rowsC >> 1) * (X2_TW / 2);                   // [64][P]
     int *cC = cL + X2_TW * P;                                    // [32][P]
     int *vr = cC + (X2_TW / 2) * P;                              // [16][X2_VR] vertical records of the tile's rows
     int *vrc = vr + X2_TH * X2_VR;                               // YUVOUT: [8][X2_VRC] records of the tile's chroma rows
 
     constexpr int QW = X2_TW / 4;
     const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one phase-3 item each
-    const int yo = ty0 + yl;
 
-    // ================= phase 1: 16-byte loads, whole rows per wave ===============================
-    {
-        // tile coefficient rows -> LDS (80 + 40 lanes x 16 B)
-        constexpr int NL = X2_TW * P / 4, NC = (X2_TW / 2) * P / 4, NV = X2_TH * X2_VR / 4, NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
-        constexpr int NT = NL + NC + NV + NVC;                   // 16-byte table chunks: one per thread, a second for
-        static_assert(NT <= 512, "two table chunks per thread");  // the first NT - 256 threads of the widest variant
-        // the table loads are ISSUED here and stored to LDS only after the pixel loads below have been issued, so
-        // the block pays one memory round trip, not two (a load -> store loop at this point cost 7 %)
-        auto tab = [&](int i, const uint4 *&sp, uint4 *&dp) {
-            if (i < NL)                { sp = reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * P) + i; dp = reinterpret_cast<uint4 *>(cL) + i; }
-            else if (i < NL + NC)      { sp = reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * P) + (i - NL); dp = reinterpret_cast<uint4 *>(cC) + (i - NL); }
-            else if (i < NL + NC + NV) { sp = reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * X2_VR) + (i - NL - NC); dp = reinterpret_cast<uint4 *>(vr) + (i - NL - NC); }
-            else                       { sp = reinterpret_cast<const uint4 *>(a.vrecC + (size_t)(ty0 >> 1) * X2_VRC) + (i - NL - NC - NV); dp = reinterpret_cast<uint4 *>(vrc) + (i - NL - NC - NV); }
-        };
-        const uint4 *ts0 = nullptr, *ts1 = nullptr;
-        uint4 *td0 = nullptr, *td1 = nullptr;
-        uint4 tv0 = make_uint4(0u, 0u, 0u, 0u), tv1 = tv0;
-        if (tid < NT) { tab(tid, ts0, td0); tv0 = *ts0; }
-        if (NT > 256 && tid + 256 < NT) { tab(tid + 256, ts1, td1); tv1 = *ts1; }
-
-        const int rs = (lane * 205) >> 11, g = lane - rs * 10;   // lane / 10 for lane < 64: 6 rows x 10 groups per wave
-        const bool act = lane < 60;
-        const int rowA = wave * 6 + rs, rowB = rowA + 24;        // nrL <= 48, nrC <= 24 (yuv2x_prepare)
-        // all three pixel loads are issued before anything is consumed; rows are clamped for the load and
-        // only the store is predicated
-        const unsigned colL = (unsigned)min(max(c0L + 16 * g, 0), a.srcW - 16);
-        const unsigned colC = (unsigned)min(max(c0C + 8 * g, 0), a.chrSrcW - 8);
-        const unsigned offA = (unsigned)min(max(r0L + min(rowA, nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
-        const unsigned offB = (unsigned)min(max(r0L + min(rowB, nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
-        const unsigned crow = (unsigned)min(max(r0C + min(rowA, nrC - 1), 0), a.chrSrcH - 1);
-        const uint4 va = *reinterpret_cast<const uint4 *>(a.y + offA);
-        const uint4 vb = *reinterpret_cast<const uint4 *>(a.y + offB);
-        uint4 tc;
+    // ---- phase 1, split in two: issue the loads of a tile into registers / commit them to LDS ----------------
+    constexpr int NL = X2_TW * P / 4, NC = (X2_TW / 2) * P / 4, NV = X2_TH * X2_VR / 4, NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
+    constexpr int NT = NL + NC + NV + NVC;                       // 16-byte table chunks: one per thread, a second for
+    static_assert(NT <= 512, "two table chunks per thread");      // the first NT - 256 threads of the widest variant
+    const int rs = (lane * 205) >> 11, g = lane - rs * 10;       // lane / 10 for lane < 64: 6 rows x 10 groups per wave
+    const bool act = lane < 60;
+    const int rowA = wave * 6 + rs, rowB = rowA + 24;            // nrL <= 48, nrC <= 24 (yuv2x_prepare)
+    const unsigned colL = (unsigned)min(max(c0L + 16 * g, 0), a.srcW - 16);
+    const unsigned colC = (unsigned)min(max(c0C + 8 * g, 0), a.chrSrcW - 8);
+    struct TileRegs { uint4 va, vb, tc, tv0, tv1; int r0L, nrL, r0C, nrC; };
+    // table chunk i of tile row `trow`: the coefficient rows (first tile of the block only) and the vertical records
+    auto tab_src = [&](int i, int trow) -> const uint4 * {
+        const int ty0 = trow * X2_TH;
+        if (i < NL)           return reinterpret_cast<const uint4 *>(a.hLreg + (size_t)tx0 * P) + i;
+        if (i < NL + NC)      return reinterpret_cast<const uint4 *>(a.hCreg + (size_t)tcx0 * P) + (i - NL);
+        if (i < NL + NC + NV) return reinterpret_cast<const uint4 *>(a.vrec + (size_t)ty0 * X2_VR) + (i - NL - NC);
+        return reinterpret_cast<const uint4 *>(a.vrecC + (size_t)(ty0 >> 1) * X2_VRC) + (i - NL - NC - NV);
+    };
+    auto tab_dst = [&](int i) -> uint4 * {
+        if (i < NL)           return reinterpret_cast<uint4 *>(cL) + i;
+        if (i < NL + NC)      return reinterpret_cast<uint4 *>(cC) + (i - NL);
+        if (i < NL + NC + NV) return reinterpret_cast<uint4 *>(vr) + (i - NL - NC);
+        return reinterpret_cast<uint4 *>(vrc) + (i - NL - NC - NV);
+    };
+    auto issue = [&](int trow, bool first) -> TileRegs {
+        TileRegs R;
+        R.r0L = uniform_load(a.rowStartL, trow); R.nrL = uniform_load(a.rowCountL, trow);
+        R.r0C = uniform_load(a.rowStartC, trow); R.nrC = uniform_load(a.rowCountC, trow);
+        // the table loads are ISSUED first and stored to LDS only after the pixel loads have been issued too, so a
+        // block pays one memory round trip, not two (a load -> store loop in this place cost 7 %)
+        R.tv0 = R.tv1 = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < NT && (first || tid >= NL + NC)) R.tv0 = *tab_src(tid, trow);
+        if (NT > 256 && tid + 256 < NT) R.tv1 = *tab_src(tid + 256, trow);
+        // all three pixel loads are issued before anything is consumed; rows are clamped for the load and only the
+        // store is predicated
+        const unsigned offA = (unsigned)min(max(R.r0L + min(rowA, R.nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
+        const unsigned offB = (unsigned)min(max(R.r0L + min(rowB, R.nrL - 1), 0), a.srcH - 1) * (unsigned)a.ys + colL;
+        const unsigned crow = (unsigned)min(max(R.r0C + min(rowA, R.nrC - 1), 0), a.chrSrcH - 1);
+        R.va = *reinterpret_cast<const uint4 *>(a.y + offA);
+        R.vb = *reinterpret_cast<const uint4 *>(a.y + offB);
         if (a.nv12) {
-            tc = *reinterpret_cast<const uint4 *>(a.u + crow * (unsigned)a.us + 2 * colC);       // U0 V0 U1 V1 ...
+            R.tc = *reinterpret_cast<const uint4 *>(a.u + crow * (unsigned)a.us + 2 * colC);       // U0 V0 U1 V1 ...
         } else {
             const uint2 tu = *reinterpret_cast<const uint2 *>(a.u + crow * (unsigned)a.us + colC);
             const uint2 tv = *reinterpret_cast<const uint2 *>(a.v + crow * (unsigned)a.vs + colC);
             // interleave to the NV12 byte order so the rest is common
-            tc.x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); tc.y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
-            tc.z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); tc.w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
+            R.tc.x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); R.tc.y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
+            R.tc.z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); R.tc.w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
         }
-        if (tid < NT) *td0 = tv0;
-        if (NT > 256 && tid + 256 < NT) *td1 = tv1;
-        if (act && rowA < nrL) {
+        return R;
+    };
+    auto commit = [&](bool first, const TileRegs &R) {
+        if (tid < NT && (first || tid >= NL + NC)) *tab_dst(tid) = R.tv0;
+        if (NT > 256 && tid + 256 < NT) *tab_dst(tid + 256) = R.tv1;
+        if (act && rowA < R.nrL) {
             uint4 *d = reinterpret_cast<uint4 *>(ly + rowA * X2_COLSL + 16 * g);
-            const uint2 p0 = x2_widen(va.x), p1 = x2_widen(va.y), p2 = x2_widen(va.z), p3 = x2_widen(va.w);
+            const uint2 p0 = x2_widen(R.va.x), p1 = x2_widen(R.va.y), p2 = x2_widen(R.va.z), p3 = x2_widen(R.va.w);
             d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
             d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
         }
-        if (act && rowB < nrL) {
+        if (act && rowB < R.nrL) {
             uint4 *d = reinterpret_cast<uint4 *>(ly + rowB * X2_COLSL + 16 * g);
-            const uint2 p0 = x2_widen(vb.x), p1 = x2_widen(vb.y), p2 = x2_widen(vb.z), p3 = x2_widen(vb.w);
+            const uint2 p0 = x2_widen(R.vb.x), p1 = x2_widen(R.vb.y), p2 = x2_widen(R.vb.z), p3 = x2_widen(R.vb.w);
             d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
             d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
         }
-        if (act && rowA < nrC) {
+        if (act && rowA < R.nrC) {
             // U samples are bytes 0 and 2 of each dword, V samples bytes 1 and 3
             *reinterpret_cast<uint4 *>(lu + rowA * X2_COLSC + 8 * g) =
-                make_uint4(__builtin_amdgcn_perm(0u, tc.x, 0x0C020C00u), __builtin_amdgcn_perm(0u, tc.y, 0x0C020C00u),
-                           __builtin_amdgcn_perm(0u, tc.z, 0x0C020C00u), __builtin_amdgcn_perm(0u, tc.w, 0x0C020C00u));
+                make_uint4(__builtin_amdgcn_perm(0u, R.tc.x, 0x0C020C00u), __builtin_amdgcn_perm(0u, R.tc.y, 0x0C020C00u),
+                           __builtin_amdgcn_perm(0u, R.tc.z, 0x0C020C00u), __builtin_amdgcn_perm(0u, R.tc.w, 0x0C020C00u));
             *reinterpret_cast<uint4 *>(lv + rowA * X2_COLSC + 8 * g) =
-                make_uint4(__builtin_amdgcn_perm(0u, tc.x, 0x0C030C01u), __builtin_amdgcn_perm(0u, tc.y, 0x0C030C01u),
-                           __builtin_amdgcn_perm(0u, tc.z, 0x0C030C01u), __builtin_amdgcn_perm(0u, tc.w, 0x0C030C01u));
+                make_uint4(__builtin_amdgcn_perm(0u, R.tc.x, 0x0C030C01u), __builtin_amdgcn_perm(0u, R.tc.y, 0x0C030C01u),
+                           __builtin_amdgcn_perm(0u, R.tc.z, 0x0C030C01u), __builtin_amdgcn_perm(0u, R.tc.w, 0x0C030C01u));
         }
-    }
-    X2_STAMP(1);
-    __syncthreads();
-    X2_STAMP(2);
+    };
 
-    // ================= phase 2: horizontal filters, 4 outputs x 2 rows per item ===================
+    TileRegs cur, nxt = TileRegs();
     {
-        // The luma item range is padded to whole waves so that every wave iteration is entirely luma or
-        // entirely chroma: the choice is a scalar branch and each side has compile-time row lengths
-        // (the per-lane select cost ~25 VALU instructions per item before).
-        const int nL = (nrL >> 1) * 16, nC = (nrC >> 1) * 8;      // luma items, chroma items per plane
-        const int nLw = (nL + 63) & ~63;
-        const int total = nLw + 2 * nC;
-        auto item = [&](const unsigned short *srcp, int colsS, int e, const int *cf, int *dstp, int rp, int g) {
-            const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
-            const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
-            const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
-            // 4 adjacent outputs share a window of 6 + 2P samples = 3 + P dwords, read as 8-byte pairs
-            constexpr int NWD = (4 + P) & ~1;
-            int w0[NWD], w1[NWD], c[4 * P];
-#pragma unroll
-            for (int i = 0; i < NWD / 2; i++) {
-                const uint2 t0 = r0p[pair0 + i], t1 = r1p[pair0 + i];
-                w0[2 * i] = (int)t0.x; w0[2 * i + 1] = (int)t0.y; w1[2 * i] = (int)t1.x; w1[2 * i + 1] = (int)t1.y;
-            }
-#pragma unroll
-            for (int i = 0; i < P; i++) {
-                const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * P)[i];
-                c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
-            }
-            *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4<P>(w0, w1, c);
-        };
-        for (int it = tid; it < total; it += 256) {
-            const int wbase = __builtin_amdgcn_readfirstlane(it);     // tid of the wave's first lane is a multiple of 64
-            if (wbase < nLw) {
-                if (it < nL) {
-                    const int rp = it >> 4, g = it & 15;
-                    item(ly, X2_COLSL, eL, cL, hy + rp * X2_TW + 4 * g, rp, g);
-                }
-            } else {
-                const int j = it - nLw, pl = j >= nC, jj = pl ? j - nC : j;
-                const int rp = jj >> 3, g = jj & 7;
-                item(lu + pl * (rowsC * X2_COLSC), X2_COLSC, eC, cC, hu + pl * ((rowsC >> 1) * (X2_TW / 2)) + rp * (X2_TW / 2) + 4 * g, rp, g);
-            }
-        }
+        const int tt = 0;
+        X2_STAMP(0);
+        if (prof && tid == 0) prof[6] = __builtin_amdgcn_s_memrealtime();     // 100 MHz reference clock
     }
-    X2_STAMP(3);
-    __syncthreads();
-    X2_STAMP(4);
+    cur = issue(trow0, true);
+#pragma unroll
+    for (int tt = 0; tt < TILES; tt++) {
+        const int trow = trow0 + tt;
+        if (trow >= a.nty) break;                                  // block-uniform
+        const int ty0 = trow * X2_TH, yo = ty0 + yl;
+        const int r0L = cur.r0L, nrL = cur.nrL, r0C = cur.r0C, nrC = cur.nrC;
+        commit(tt == 0, cur);
+        X2_STAMP(1);
+        __syncthreads();
+        X2_STAMP(2);
+        const bool more = tt + 1 < TILES && trow + 1 < a.nty;
+        if (more) nxt = issue(trow + 1, false);                    // in flight during phases 2 and 3
 
-    // ================= phase 3: vertical filters + colour stage + store ==========================
-    if constexpr (YUVOUT) {
-        const int xo = tx0 + 4 * q;
-        {   // luma: 4 outputs of row yo
-            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                       rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
-            const int vl8[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-            const int vpL = (rd.x - r0L) >> 1, lr = rd.z;
-            int Y[4] = {lr, lr, lr, lr};
-#pragma unroll
-            for (int k = 0; k < P; k++) {
-                if (k < a.vLpairs) {
-                    const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
-                    Y[0] = dot2(v.x, vl8[k], Y[0]); Y[1] = dot2(v.y, vl8[k], Y[1]);
-                    Y[2] = dot2(v.z, vl8[k], Y[2]); Y[3] = dot2(v.w, vl8[k], Y[3]);
+        // ================= phase 2: horizontal filters, 4 outputs x 2 rows per item ===================
+        {
+            // The luma item range is padded to whole waves so that every wave iteration is entirely luma or
+            // entirely chroma: the choice is a scalar branch and each side has compile-time row lengths
+            // (the per-lane select cost ~25 VALU instructions per item before).
+            const int nL = (nrL >> 1) * 16, nC = (nrC >> 1) * 8;      // luma items, chroma items per plane
+            const int nLw = (nL + 63) & ~63;
+            const int total = nLw + 2 * nC;
+            auto item = [&](const unsigned short *srcp, int colsS, int e, const int *cf, int *dstp, int rp, int g) {
+                const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
+                const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
+                const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
+                // 4 adjacent outputs share a window of 6 + 2P samples = 3 + P dwords, read as 8-byte pairs
+                constexpr int NWD = (4 + P) & ~1;
+                int w0[NWD], w1[NWD], c[4 * P];
+    #pragma unroll
+                for (int i = 0; i < NWD / 2; i++) {
+                    const uint2 t0 = r0p[pair0 + i], t1 = r1p[pair0 + i];
+                    w0[2 * i] = (int)t0.x; w0[2 * i + 1] = (int)t0.y; w1[2 * i] = (int)t1.x; w1[2 * i + 1] = (int)t1.y;
                 }
-            }
-            if (yo < a.dstH && xo < a.dstW) {
-                // clip_u8(v >> 19) = byte 2 of clamp(v >> 3, 0, 0xFFFFFF)
-                const unsigned y0 = (unsigned)min(max(Y[0] >> 3, 0), 0xFFFFFF), y1 = (unsigned)min(max(Y[1] >> 3, 0), 0xFFFFFF);
-                const unsigned y2 = (unsigned)min(max(Y[2] >> 3, 0), 0xFFFFFF), y3 = (unsigned)min(max(Y[3] >> 3, 0), 0xFFFFFF);
-                const unsigned o = __builtin_amdgcn_perm(y1, y0, 0x0C0C0602u) | (__builtin_amdgcn_perm(y3, y2, 0x0C0C0602u) << 16);
-                uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
-                const int nx = min(4, a.dstW - xo);
-                if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
-                else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
-            }
-        }
-        {   // chroma: thread (q, yl) computes plane (yl & 1) of chroma row yl >> 1, columns 2q and 2q + 1;
-            // the U and V halves of an NV12 dword meet through one cross-lane exchange (lanes l and l ^ 16)
-            const int pl = yl & 1, cyl = yl >> 1;
-            const int cy = (ty0 >> 1) + cyl, cx = tcx0 + 2 * q;
-            const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[1],
-                       cc3 = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[2];
-            const int vcp[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-            const int vp = (cc3.x - r0C) >> 1;
-            const int *hp = pl ? hv : hu;
-            int C0 = cc3.y, C1 = cc3.y;
-#pragma unroll
-            for (int k = 0; k < P; k++) {
-                if (k < a.vCpairs) {
-                    const uint2 t = *reinterpret_cast<const uint2 *>(hp + (vp + k) * (X2_TW / 2) + 2 * q);
-                    C0 = dot2((int)t.x, vcp[k], C0); C1 = dot2((int)t.y, vcp[k], C1);
+    #pragma unroll
+                for (int i = 0; i < P; i++) {
+                    const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * P)[i];
+                    c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
                 }
-            }
-            const unsigned c0 = (unsigned)min(max(C0 >> 3, 0), 0xFFFFFF), c1 = (unsigned)min(max(C1 >> 3, 0), 0xFFFFFF);
-            const unsigned mine = __builtin_amdgcn_perm(c1, c0, 0x0C0C0602u);        // sample 0 | sample 1 << 8
-            const bool inside = cy < a.chrDstH && cx < a.chrDstW;
-            const int nx = min(2, a.chrDstW - cx);
-            if (a.dstNv12) {
-                const unsigned other = (unsigned)__shfl_xor((int)mine, 16);           // V pair for the U lanes
-                if (inside && pl == 0) {
-                    // U0 V0 U1 V1
-                    const unsigned o = __builtin_amdgcn_perm(other, mine, 0x05010400u);
-                    uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
-                    if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned *>(d) = o;
-                    else for (int i = 0; i < 2 * nx; i++) d[i] = (uint8_t)(o >> (8 * i));
-                }
-            } else if (inside) {
-                uint8_t *d = (pl ? a.dstV + (size_t)cy * a.dsV : a.dstU + (size_t)cy * a.dsU) + cx;
-                if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned short *>(d) = (unsigned short)mine;
-                else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(mine >> (8 * i));
-            }
-        }
-    } else {
-        const int xo = tx0 + 4 * q;
-        if (yo < a.dstH && xo < a.dstW) {
-            // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
-            const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                       rc = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2], rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
-            const int vl[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-            const int vcc[4] = {rc.x, rc.y, rc.z, rc.w};
-            const int vpL = (rd.x - r0L) >> 1, vpC = (rd.y - r0C) >> 1, lr = rd.z, cr = rd.w;
-            int Y[4] = {lr, lr, lr, lr}, U[2] = {cr, cr}, V[2] = {cr, cr};
-#pragma unroll
-            for (int k = 0; k < P; k++) {
-                if (k < a.vLpairs) {
-                    const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
-                    Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
-                    Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
-                }
-            }
-            constexpr int VCP = P == 5 ? 2 : 4;           // vertical chroma pairs the variant provides for
-#pragma unroll
-            for (int k = 0; k < VCP; k++) {
-                if (k == 0 || k < a.vCpairs) {
-                    const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + k) * (X2_TW / 2) + 2 * q);
-                    const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + k) * (X2_TW / 2) + 2 * q);
-                    U[0] = dot2((int)u.x, vcc[k], U[0]); U[1] = dot2((int)u.y, vcc[k], U[1]);
-                    V[0] = dot2((int)v.x, vcc[k], V[0]); V[1] = dot2((int)v.y, vcc[k], V[1]);
-                }
-            }
-            ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
-            ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
-            const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
-            if (a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA) {
-                int t = t0.r; t0.r = t0.b; t0.b = t;
-                t = t1.r; t1.r = t1.b; t1.b = t;
-            }
-            // channel value = byte 2 of clamp(term + Y*cy, 0, 0xFFFFFF); bytes are gathered with v_perm_b32
-            unsigned c0[4], c1[4], c2[4];                 // first / second / third channel of the 4 pixels
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
-                c0[i] = (unsigned)min(max(t0.r + ya, 0), 0xFFFFFF); c1[i] = (unsigned)min(max(t0.g + ya, 0), 0xFFFFFF);
-                c2[i] = (unsigned)min(max(t0.b + ya, 0), 0xFFFFFF);
-                c0[i + 2] = (unsigned)min(max(t1.r + yb, 0), 0xFFFFFF); c1[i + 2] = (unsigned)min(max(t1.g + yb, 0), 0xFFFFFF);
-                c2[i + 2] = (unsigned)min(max(t1.b + yb, 0), 0xFFFFFF);
-            }
-            // perm(hi, lo, sel): byte2(lo) -> byte 0, byte2(hi) -> byte 1, upper half zero
-#define X2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
-            uint8_t *d = a.dst + (size_t)yo * a.ds + (size_t)xo * bpp;
-            const int nx = min(4, a.dstW - xo);
-            if (a.dstAligned && nx == 4) {
-                if (bpp == 4) {
-                    uint4 o4;
-                    o4.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
-                    o4.y = X2_B2PAIR(c0[1], c1[1]) | (X2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
-                    o4.z = X2_B2PAIR(c0[2], c1[2]) | (X2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
-                    o4.w = X2_B2PAIR(c0[3], c1[3]) | (X2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
-                    *reinterpret_cast<uint4 *>(d) = o4;
+                *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4<P>(w0, w1, c);
+            };
+            for (int it = tid; it < total; it += 256) {
+                const int wbase = __builtin_amdgcn_readfirstlane(it);     // tid of the wave's first lane is a multiple of 64
+                if (wbase < nLw) {
+                    if (it < nL) {
+                        const int rp = it >> 4, g = it & 15;
+                        item(ly, X2_COLSL, eL, cL, hy + rp * X2_TW + 4 * g, rp, g);
+                    }
                 } else {
-                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-                    o3.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], c0[1]) << 16);
-                    o3.y = X2_B2PAIR(c1[1], c2[1]) | (X2_B2PAIR(c0[2], c1[2]) << 16);
-                    o3.z = X2_B2PAIR(c2[2], c0[3]) | (X2_B2PAIR(c1[3], c2[3]) << 16);
-                    *reinterpret_cast<uint3 *>(d) = o3;
-                }
-            } else {
-                for (int i = 0; i < nx; i++) {
-                    d[i * bpp + 0] = (uint8_t)(c0[i] >> 16);
-                    d[i * bpp + 1] = (uint8_t)(c1[i] >> 16);
-                    d[i * bpp + 2] = (uint8_t)(c2[i] >> 16);
-                    if (bpp == 4) d[i * bpp + 3] = 255;
+                    const int j = it - nLw, pl = j >= nC, jj = pl ? j - nC : j;
+                    const int rp = jj >> 3, g = jj & 7;
+                    item(lu + pl * (rowsC * X2_COLSC), X2_COLSC, eC, cC, hu + pl * ((rowsC >> 1) * (X2_TW / 2)) + rp * (X2_TW / 2) + 4 * g, rp, g);
                 }
             }
-#undef X2_B2PAIR
+        }
+        X2_STAMP(3);
+        __syncthreads();
+        X2_STAMP(4);
+
+        // ================= phase 3: vertical filters + colour stage + store ==========================
+        if constexpr (YUVOUT) {
+            const int xo = tx0 + 4 * q;
+            {   // luma: 4 outputs of row yo
+                const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+                const int vl8[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                const int vpL = (rd.x - r0L) >> 1, lr = rd.z;
+                int Y[4] = {lr, lr, lr, lr};
+    #pragma unroll
+                for (int k = 0; k < P; k++) {
+                    if (k < a.vLpairs) {
+                        const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
+                        Y[0] = dot2(v.x, vl8[k], Y[0]); Y[1] = dot2(v.y, vl8[k], Y[1]);
+                        Y[2] = dot2(v.z, vl8[k], Y[2]); Y[3] = dot2(v.w, vl8[k], Y[3]);
+                    }
+                }
+                if (yo < a.dstH && xo < a.dstW) {
+                    // clip_u8(v >> 19) = byte 2 of clamp(v >> 3, 0, 0xFFFFFF)
+                    const unsigned y0 = (unsigned)min(max(Y[0] >> 3, 0), 0xFFFFFF), y1 = (unsigned)min(max(Y[1] >> 3, 0), 0xFFFFFF);
+                    const unsigned y2 = (unsigned)min(max(Y[2] >> 3, 0), 0xFFFFFF), y3 = (unsigned)min(max(Y[3] >> 3, 0), 0xFFFFFF);
+                    const unsigned o = __builtin_amdgcn_perm(y1, y0, 0x0C0C0602u) | (__builtin_amdgcn_perm(y3, y2, 0x0C0C0602u) << 16);
+                    uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
+                    const int nx = min(4, a.dstW - xo);
+                    if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
+                    else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+            {   // chroma: thread (q, yl) computes plane (yl & 1) of chroma row yl >> 1, columns 2q and 2q + 1;
+                // the U and V halves of an NV12 dword meet through one cross-lane exchange (lanes l and l ^ 16)
+                const int pl = yl & 1, cyl = yl >> 1;
+                const int cy = (ty0 >> 1) + cyl, cx = tcx0 + 2 * q;
+                const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[1],
+                           cc3 = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[2];
+                const int vcp[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+                const int vp = (cc3.x - r0C) >> 1;
+                const int *hp = pl ? hv : hu;
+                int C0 = cc3.y, C1 = cc3.y;
+    #pragma unroll
+                for (int k = 0; k < P; k++) {
+                    if (k < a.vCpairs) {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(hp + (vp + k) * (X2_TW / 2) + 2 * q);
+                        C0 = dot2((int)t.x, vcp[k], C0); C1 = dot2((int)t.y, vcp[k], C1);
+                    }
+                }
+                const unsigned c0 = (unsigned)min(max(C0 >> 3, 0), 0xFFFFFF), c1 = (unsigned)min(max(C1 >> 3, 0), 0xFFFFFF);
+                const unsigned mine = __builtin_amdgcn_perm(c1, c0, 0x0C0C0602u);        // sample 0 | sample 1 << 8
+                const bool inside = cy < a.chrDstH && cx < a.chrDstW;
+                const int nx = min(2, a.chrDstW - cx);
+                if (a.dstNv12) {
+                    const unsigned other = (unsigned)__shfl_xor((int)mine, 16);           // V pair for the U lanes
+                    if (inside && pl == 0) {
+                        // U0 V0 U1 V1
+                        const unsigned o = __builtin_amdgcn_perm(other, mine, 0x05010400u);
+                        uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
+                        if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned *>(d) = o;
+                        else for (int i = 0; i < 2 * nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+                    }
+                } else if (inside) {
+                    uint8_t *d = (pl ? a.dstV + (size_t)cy * a.dsV : a.dstU + (size_t)cy * a.dsU) + cx;
+                    if (a.dstAligned && nx == 2) *reinterpret_cast<unsigned short *>(d) = (unsigned short)mine;
+                    else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(mine >> (8 * i));
+                }
+            }
+        } else {
+            const int xo = tx0 + 4 * q;
+            if (yo < a.dstH && xo < a.dstW) {
+                // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
+                const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                           rc = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2], rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+                const int vl[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                const int vcc[4] = {rc.x, rc.y, rc.z, rc.w};
+                const int vpL = (rd.x - r0L) >> 1, vpC = (rd.y - r0C) >> 1, lr = rd.z, cr = rd.w;
+                int Y[4] = {lr, lr, lr, lr}, U[2] = {cr, cr}, V[2] = {cr, cr};
+    #pragma unroll
+                for (int k = 0; k < P; k++) {
+                    if (k < a.vLpairs) {
+                        const int4 v = *reinterpret_cast<const int4 *>(hy + (vpL + k) * X2_TW + 4 * q);
+                        Y[0] = dot2(v.x, vl[k], Y[0]); Y[1] = dot2(v.y, vl[k], Y[1]);
+                        Y[2] = dot2(v.z, vl[k], Y[2]); Y[3] = dot2(v.w, vl[k], Y[3]);
+                    }
+                }
+                constexpr int VCP = P == 5 ? 2 : 4;           // vertical chroma pairs the variant provides for
+    #pragma unroll
+                for (int k = 0; k < VCP; k++) {
+                    if (k == 0 || k < a.vCpairs) {
+                        const uint2 u = *reinterpret_cast<const uint2 *>(hu + (vpC + k) * (X2_TW / 2) + 2 * q);
+                        const uint2 v = *reinterpret_cast<const uint2 *>(hv + (vpC + k) * (X2_TW / 2) + 2 * q);
+                        U[0] = dot2((int)u.x, vcc[k], U[0]); U[1] = dot2((int)u.y, vcc[k], U[1]);
+                        V[0] = dot2((int)v.x, vcc[k], V[0]); V[1] = dot2((int)v.y, vcc[k], V[1]);
+                    }
+                }
+                ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
+                ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
+                const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+                if (a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA) {
+                    int t = t0.r; t0.r = t0.b; t0.b = t;
+                    t = t1.r; t1.r = t1.b; t1.b = t;
+                }
+                // channel value = byte 2 of clamp(term + Y*cy, 0, 0xFFFFFF); bytes are gathered with v_perm_b32
+                unsigned c0[4], c1[4], c2[4];                 // first / second / third channel of the 4 pixels
+    #pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
+                    c0[i] = (unsigned)min(max(t0.r + ya, 0), 0xFFFFFF); c1[i] = (unsigned)min(max(t0.g + ya, 0), 0xFFFFFF);
+                    c2[i] = (unsigned)min(max(t0.b + ya, 0), 0xFFFFFF);
+                    c0[i + 2] = (unsigned)min(max(t1.r + yb, 0), 0xFFFFFF); c1[i + 2] = (unsigned)min(max(t1.g + yb, 0), 0xFFFFFF);
+                    c2[i + 2] = (unsigned)min(max(t1.b + yb, 0), 0xFFFFFF);
+                }
+                // perm(hi, lo, sel): byte2(lo) -> byte 0, byte2(hi) -> byte 1, upper half zero
+    #define X2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+                uint8_t *d = a.dst + (size_t)yo * a.ds + (size_t)xo * bpp;
+                const int nx = min(4, a.dstW - xo);
+                if (a.dstAligned && nx == 4) {
+                    if (bpp == 4) {
+                        uint4 o4;
+                        o4.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                        o4.y = X2_B2PAIR(c0[1], c1[1]) | (X2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                        o4.z = X2_B2PAIR(c0[2], c1[2]) | (X2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                        o4.w = X2_B2PAIR(c0[3], c1[3]) | (X2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                        *reinterpret_cast<uint4 *>(d) = o4;
+                    } else {
+                        uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                        o3.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], c0[1]) << 16);
+                        o3.y = X2_B2PAIR(c1[1], c2[1]) | (X2_B2PAIR(c0[2], c1[2]) << 16);
+                        o3.z = X2_B2PAIR(c2[2], c0[3]) | (X2_B2PAIR(c1[3], c2[3]) << 16);
+                        *reinterpret_cast<uint3 *>(d) = o3;
+                    }
+                } else {
+                    for (int i = 0; i < nx; i++) {
+                        d[i * bpp + 0] = (uint8_t)(c0[i] >> 16);
+                        d[i * bpp + 1] = (uint8_t)(c1[i] >> 16);
+                        d[i * bpp + 2] = (uint8_t)(c2[i] >> 16);
+                        if (bpp == 4) d[i * bpp + 3] = 255;
+                    }
+                }
+    #undef X2_B2PAIR
+            }
+        }
+        X2_STAMP(5);
+        if (prof && tid == 0 && tt == 0) prof[7] = __builtin_amdgcn_s_memrealtime();
+        if (more) {
+            __syncthreads();                                       // phase 3 has read vr before the next commit overwrites it
+            cur = nxt;
         }
     }
-    X2_STAMP(5);
-    if (prof && tid == 0) prof[7] = __builtin_amdgcn_s_memrealtime();
 #undef X2_STAMP
 }
 
@@ -464,10 +494,17 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
 
 int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream)
 {
-    const int ntiles = a.ntx * a.nty;
+    // GMAT_SCALE_TILES=2 runs two vertically adjacent tiles per block with the second tile's loads in flight during
+    // the first tile's phases 2 and 3.  Measured on MI355X: 12.3-12.4 us against 12.1 us for one tile per block
+    // (82 VGPRs instead of 48, and five co-resident blocks per CU already overlap each other's load phases), so
+    // the default stays 1.
+    static const int tilesEnv = getenv("GMAT_SCALE_TILES") ? atoi(getenv("GMAT_SCALE_TILES")) : 1;
+    const int tilesPerBlock = tilesEnv == 2 ? 2 : 1;
+    const int ntiles = a.ntx * ((a.nty + tilesPerBlock - 1) / tilesPerBlock);
     if (ntiles <= 0) return 0;
     const dim3 grid(a.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
-#define GMAT_X2(Y_, P_) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC)
+#define GMAT_X2(Y_, P_) do { if (tilesPerBlock == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 2>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC); \
+                              else hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 1>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC); } while (0)
     if (a.P == 5)      { if (a.yuvOut) GMAT_X2(true, 5); else GMAT_X2(false, 5); }
     else if (a.P == 8) { if (a.yuvOut) GMAT_X2(true, 8); else GMAT_X2(false, 8); }
     else return GMAT_ERR(EINVAL);

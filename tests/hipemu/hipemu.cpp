@@ -76,24 +76,31 @@ void guarded_free(void *p)
 void block_sync() { yield_as(AT_BLOCK); }
 void wave_sync() { yield_as(AT_WAVE); }
 
-// v_readfirstlane_b32: the value of the lowest-numbered active lane.  Fibers of a wave run in lane order
-// between barriers, so for the e-th call made by the lanes of a wave the first fiber to make it is the lowest
-// lane still executing that code; its value is recorded per (wave, call number) and returned to the others.
-// Valid for the kernels under test, where every lane of a wave makes the same sequence of calls (lanes that
-// leave a loop early just make fewer of them).  Reset at every block start.
-static std::vector<int> rfl_vals[16];
-static int rfl_calls[1024];
+// v_readfirstlane_b32: the value of the lowest-numbered ACTIVE lane of the wave.  The callers rendezvous at a wave
+// barrier (lanes that have left the enclosing loop and are parked at a block barrier do not take part — see the
+// scheduler), the lowest participant's value is handed to all of them.  A per-wave round number tells this
+// rendezvous' participants from stale slots; the lowest participant advances it after everybody has read.
+static int rfl_slot[1024];
+static unsigned rfl_tag[1024], rfl_round[16];
 static void rfl_reset()
 {
-    for (auto &v : rfl_vals) v.clear();
-    memset(rfl_calls, 0, sizeof(rfl_calls));
+    memset(rfl_tag, 0, sizeof(rfl_tag));
+    memset(rfl_round, 0, sizeof(rfl_round));
 }
 int readfirstlane(int v)
 {
     const int me = cur, w = me >> 6;
-    const size_t e = (size_t)rfl_calls[me]++;
-    if (rfl_vals[w].size() <= e) rfl_vals[w].push_back(v);
-    return rfl_vals[w][e];
+    const unsigned round = rfl_round[w] + 1;
+    rfl_slot[me] = v;
+    rfl_tag[me] = round;
+    wave_sync();
+    int first = me;
+    for (int l = w * 64; l < w * 64 + 64 && l < (int)fibers.size(); l++)
+        if (rfl_tag[l] == round) { first = l; break; }
+    const int r = rfl_slot[first];
+    wave_sync();
+    if (me == first) rfl_round[w] = round;          // fibers resume in lane order: done before anyone's next call
+    return r;
 }
 
 // cross-lane exchange (ds_bpermute semantics for the lanes of one wave): every live lane of the wave must
@@ -151,13 +158,17 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shm
                         g_threadIdx = fibers[t].tid;
                         swapcontext(&sched_ctx, &fibers[t].ctx);
                     }
-                    int at_wave = 0, live = 0;
+                    // a wave-level rendezvous completes when every lane that is still running has arrived; lanes
+                    // that already wait at a block barrier (they left the enclosing loop / branch) are not
+                    // "active" for it, like lanes masked off in a real wave
+                    int at_wave = 0, live = 0, parked = 0;
                     for (int t = lo; t < hi; t++) {
                         if (fibers[t].state == DONE) continue;
                         live++;
                         at_wave += fibers[t].state == AT_WAVE;
+                        parked += fibers[t].state == AT_BLOCK;
                     }
-                    if (live && at_wave == live) {
+                    if (live && at_wave && at_wave + parked == live) {
                         for (int t = lo; t < hi; t++) if (fibers[t].state == AT_WAVE) fibers[t].state = READY;
                         continue;
                     }
