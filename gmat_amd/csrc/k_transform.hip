@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
     // result tile: rows of RP bytes, or — for the transposed store — one row of PT bytes per tile COLUMN
     constexpr int PT = ((TH * BPP + 3) / 4) * 4 + 4;
     static_assert((PT / 4) % 2 == 1, "odd dword pitch");
-    constexpr int RT_BYTES = TRANSPOSED ? TW * PT : TH * RP;
+    // the plain (row-major) store goes straight from registers to global memory: no result tile, one barrier less,
+    // and with 15 KB of LDS all eight tiles of a CU are resident at once
+    constexpr int RT_BYTES = TRANSPOSED ? TW * PT : 16;
     static_assert((TW * BPP + 3) / 4 <= 64, "one lane per dword column of the tile");
     __shared__ __attribute__((aligned(16))) uint8_t rt[RT_BYTES];
     uint8_t *st = st_raw + SHIFT;                                      // = lds16 + OFF16: tile byte 0 of row 0
@@ -422,7 +424,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
     // result byte (r, cb) -> LDS: row-major, or transposed at pixel granularity
     auto put_dword = [&](int r, int d, unsigned o) {
         if (!TRANSPOSED) {
-            reinterpret_cast<unsigned *>(rt + r * RP)[d] = o;
+            // x0 * BPP is a multiple of 4: dword d of the tile row is an aligned dword of the destination row
+            uint8_t *p = dst + (size_t)(y0 + r) * ds + (size_t)x0 * BPP + 4 * d;
+            if (aligned && 4 * d + 4 <= tw * BPP) *reinterpret_cast<unsigned *>(p) = o;
+            else for (int j = 0; j < 4 && 4 * d + j < tw * BPP; j++) p[j] = (uint8_t)(o >> (8 * j));
         } else if (BPP == 4) {
             *reinterpret_cast<unsigned *>(rt + d * PT + r * 4) = o;               // dword d is pixel d
         } else {
@@ -500,24 +505,17 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const uint8_t *src, int ss
 #pragma unroll
             for (int k = 0; k < 9; k++) sum += (int)p[(k / 3) * SP + (k % 3) * BPP] * cp.m[k];
             const float f = __fadd_rn(__fadd_rn(__fmul_rn((float)sum, cp.rdiv), cp.bias), 0.5f);
-            if (!TRANSPOSED) rt[r * RP + cb] = (uint8_t)min(max((int)f, 0), 255);
+            if (!TRANSPOSED) dst[(size_t)(y0 + r) * ds + (size_t)x0 * BPP + cb] = (uint8_t)min(max((int)f, 0), 255);
             else { const int px = cb / BPP; rt[px * PT + r * BPP + (cb - px * BPP)] = (uint8_t)min(max((int)f, 0), 255); }
         }
     }
-    __syncthreads();
-    {
+    if (TRANSPOSED) {
+        __syncthreads();
+        // out(x = y0 + r, y = x0 + c): the result tile is stored one LDS row per tile column
         const bool fast16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-        if (!TRANSPOSED) {
-            // x0 * BPP is a multiple of 16 (x0 is a multiple of 64)
-            constexpr int CL = (TW * BPP + 15) / 16 <= 16 ? 16 : 32;
-            constexpr int K = (TH + 256 / CL - 1) / (256 / CL);
-            lds_to_tile16<CL, K>(dst, ds, x0 * BPP, tw * BPP, th, rt, RP, (int)threadIdx.x, fast16, [&](int r) { return y0 + r; });
-        } else {
-            // out(x = y0 + r, y = x0 + c): the result tile is already stored one LDS row per tile column
-            constexpr int CL = (TH * BPP + 15) / 16 <= 16 ? 16 : 32;
-            constexpr int K = (TW + 256 / CL - 1) / (256 / CL);
-            lds_to_tile16<CL, K>(dst, ds, y0 * BPP, th * BPP, tw, rt, PT, (int)threadIdx.x, fast16, [&](int c) { return x0 + c; });
-        }
+        constexpr int CL = (TH * BPP + 15) / 16 <= 16 ? 16 : 32;
+        constexpr int K = (TW + 256 / CL - 1) / (256 / CL);
+        lds_to_tile16<CL, K>(dst, ds, y0 * BPP, th * BPP, tw, rt, PT, (int)threadIdx.x, fast16, [&](int c) { return x0 + c; });
     }
 }
 
