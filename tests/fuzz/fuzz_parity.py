@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test: the kernel sources (on the CPU emulation of HIP, or on the GPU with --hip) against
-the oracle over random geometries, formats, flags, strides.  usage: tools/fuzz_parity.py [ncases] [seed] [--hip]"""
+the oracle over random geometries, formats, flags, strides.  usage: tests/fuzz/fuzz_parity.py [ncases] [seed] [--hip]"""
 import os, sys, random, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import harness

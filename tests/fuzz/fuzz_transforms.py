@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the transform kernels and the remaining converter modes against the oracle.
-usage: tools/fuzz_transforms.py [ncases] [seed] [--hip]"""
+usage: tests/fuzz/fuzz_transforms.py [ncases] [seed] [--hip]"""
 import os, sys, random, math, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import harness

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the YUV plane scaler's options (range conversion, chroma positions, 4:4:4
-sources) against the oracle.  usage: tools/fuzz_yuvopts.py [ncases] [seed] [--hip]"""
+sources) against the oracle.  usage: tests/fuzz/fuzz_yuvopts.py [ncases] [seed] [--hip]"""
 import os, sys, random, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import harness

@@ -300,7 +300,7 @@ def test_yuv444p_source(dev, orc, dst_fmt, geom):
                                   ("bgr24", "bgr24", (6, 97, 196, 67), SWS["point"] | SWS["full_chr_h_int"]),
                                   ("rgb24", "bgra", (158, 36, 257, 49), SWS["area"])])
 def test_regressions_found_by_the_fuzzer(dev, orc, case):
-    """tools/fuzz_parity.py finds: a tile whose source window is a single 4-pixel group (ng == 1) divided by a
+    """tests/fuzz/fuzz_parity.py finds: a tile whose source window is a single 4-pixel group (ng == 1) divided by a
     32-bit magic that does not exist."""
     sf, df, (sw, sh, dw, dh), flags = case
     _check(dev, orc, sf, sw, sh, dw, dh, df, flags, align=1, extra=1)
