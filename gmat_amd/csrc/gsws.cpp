@@ -58,6 +58,14 @@ struct DevFilterStore {
         if ((r = packed.upload(fb.packed.data(), fb.packed.size() * sizeof(int32_t))) < 0) return r;
         if ((r = pos.upload(fb.pos_even.data(), fb.pos_even.size() * sizeof(int32_t))) < 0) return r;
         std::vector<int32_t> rnd(fb.count, 1 << 9);
+        if (vertical && fb.taps == 1) {
+            // packed_vscale's 1-tap form (vscale.c:135-145 -> yuv2rgb_full_1_c, output.c:2164-2200) takes the line as
+            // it is: the coefficient is never read, and for degenerate rows it is not 4096
+            FilterBank eff = fb;
+            std::fill(eff.coef.begin(), eff.coef.end(), (int16_t)4096);
+            pack_filter_pairs(eff);
+            if ((r = packed.upload(eff.packed.data(), eff.packed.size() * sizeof(int32_t))) < 0) return r;
+        }
         if (vertical && fb.taps == 2) {
             // packed_vscale's 2-tap form (vscale.c:146-160 -> yuv2rgb_full_2_c, output.c:2118-2120):
             // no rounding constant when the two taps are a proper blend
@@ -139,7 +147,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     a.dstNv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
     if ((r = c->yHLum.upload(c->planYuv.hLum, none, a.hLum)) < 0) return r;
     if ((r = c->yHChr.upload(c->planYuv.hChr, none, a.hChr)) < 0) return r;
-    if ((r = c->yVLum.upload(c->planYuv.vLum, t.lumRound, a.vLum)) < 0) return r;
+    if ((r = c->yVLum.upload(t.vLumEff, t.lumRound, a.vLum)) < 0) return r;
     if ((r = c->yVChr.upload(t.vChrEff, t.chrRound, a.vChr)) < 0) return r;
     const std::vector<int32_t> *w[8] = {&t.colStartL, &t.colCountL, &t.rowStartL, &t.rowCountL,
                                         &t.colStartC, &t.colCountC, &t.rowStartC, &t.rowCountC};

@@ -511,13 +511,17 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     t.lumRound.assign(p.dstH, yuvOut ? (64 << 12) : sh_one);          // planar output: dither 64 (swscale.c:349-351)
     t.chrRound.assign(p.chrDstH, yuvOut ? (64 << 12) : sh_one + chr_bias);
     t.vChrEff = p.vChr;
+    t.vLumEff = p.vLum;
     const int lfs = p.vLum.taps, cfs = p.vChr.taps;
     for (int y = 0; y < p.dstH && !yuvOut; y++) {
-        const int16_t *lf = &p.vLum.coef[(size_t)y * lfs];
+        int16_t *lf = &t.vLumEff.coef[(size_t)y * lfs];
         int16_t *cf = &t.vChrEff.coef[(size_t)y * cfs];
         const bool chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
         const bool lum2 = lfs == 2 && lf[0] + lf[1] == 4096 && (unsigned)lf[1] <= 4096u;
-        if (lfs == 1 && chr2) {                      // yuv2packed1 with uvalpha = cf[1]
+        if (lfs == 1 && cfs == 1) {                  // yuv2packed1, uvalpha 0: the samples themselves — the
+            lf[0] = 4096; cf[0] = 4096;              // coefficients are not read (they can be 0 for degenerate rows)
+        } else if (lfs == 1 && chr2) {               // yuv2packed1 with uvalpha = cf[1]
+            lf[0] = 4096;
             if (cf[1] < 2048) { cf[0] = 4096; cf[1] = 0; }
             else              { cf[0] = 2048; cf[1] = 2048; }
         } else if (lum2 && chr2) {                   // yuv2packed2: no rounding constant
@@ -525,7 +529,14 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
             t.chrRound[y] = chr_bias;
         }
     }
+    if (yuvOut) {
+        // planar output (vscale.c:30-105): a 1-tap filter goes through yuv2plane1_8_c, which does not read the
+        // coefficient; NV12 chroma always takes yuv2nv12cX_c, which does
+        if (lfs == 1) std::fill(t.vLumEff.coef.begin(), t.vLumEff.coef.end(), (int16_t)4096);
+        if (cfs == 1 && p.dstFormat != GMAT_PIX_FMT_NV12) std::fill(t.vChrEff.coef.begin(), t.vChrEff.coef.end(), (int16_t)4096);
+    }
     pack_filter_pairs(t.vChrEff);
+    pack_filter_pairs(t.vLumEff);
 
     const int forceTW = yenv("GMAT_SCALE_TW", 0), forceTH = yenv("GMAT_SCALE_TH", 0);
     const int tws[] = {64, 32};
@@ -549,7 +560,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
             if (yuvOut && (TH & 1)) continue;              // a tile holds TH/2 chroma rows
             const int nty = (p.dstH + TH - 1) / TH;
             int rowsL = 0, rowsC = 0;
-            windows(p.vLum, TH, nty, p.dstH, 2, t.rowStartL, t.rowCountL, rowsL);
+            windows(t.vLumEff, TH, nty, p.dstH, 2, t.rowStartL, t.rowCountL, rowsL);
             if (yuvOut) windows(t.vChrEff, TH / 2, nty, p.chrDstH, 2, t.rowStartC, t.rowCountC, rowsC);
             else        windows(t.vChrEff, TH, nty, p.dstH, 2, t.rowStartC, t.rowCountC, rowsC);
             const int bytes = rowsL * colsL * 2 + 2 * rowsC * colsC * 2 + (rowsL / 2) * TW * 4 + 2 * (rowsC / 2) * cwd * 4;

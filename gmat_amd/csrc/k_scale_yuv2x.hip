@@ -441,7 +441,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     // smallest window that holds every row: 10 samples (bicubic, bilinear ...) or 16 (Lanczos-3)
     int P = 0;
     for (int cand : {5, 8}) {
-        if (p.vLum.pairs > cand || g.vChrEff.pairs > (g.yuvOut ? cand : (cand == 5 ? 2 : 4))) continue;
+        if (g.vLumEff.pairs > cand || g.vChrEff.pairs > (g.yuvOut ? cand : (cand == 5 ? 2 : 4))) continue;
         if (!regularise(p.hLum, t.ntx * X2_TW, cand, t.w0L, t.hLreg)) continue;
         if (!regularise(p.hChr, t.ntx * (X2_TW / 2), cand, t.w0C, t.hCreg)) continue;
         // every tile's regular window must fit the fixed LDS row lengths
@@ -465,8 +465,8 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     for (int yy = 0; yy < t.nty * X2_TH; yy++) {
         const int y = std::min(yy, p.dstH - 1);
         int32_t *r = &t.vrec[(size_t)yy * X2_VR];
-        for (int k = 0; k < p.vLum.pairs; k++) r[k] = p.vLum.packed[(size_t)y * p.vLum.pairs + k];
-        r[12] = p.vLum.pos_even[y];
+        for (int k = 0; k < g.vLumEff.pairs; k++) r[k] = g.vLumEff.packed[(size_t)y * g.vLumEff.pairs + k];
+        r[12] = g.vLumEff.pos_even[y];
         r[14] = g.lumRound[y];
         if (g.yuvOut) continue;                              // chroma rows have their own records (vrecC)
         for (int k = 0; k < g.vChrEff.pairs; k++) r[8 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
@@ -487,7 +487,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     }
     t.yuvOut = g.yuvOut;
     t.P = P;
-    t.vLpairs = p.vLum.pairs; t.vCpairs = g.vChrEff.pairs;
+    t.vLpairs = g.vLumEff.pairs; t.vCpairs = g.vChrEff.pairs;
     t.ok = bytes;
     return 0;
 }

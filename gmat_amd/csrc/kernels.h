@@ -77,6 +77,7 @@ struct YuvScaleTiling {
     std::vector<int32_t> colStartL, colCountL, rowStartL, rowCountL, colStartC, colCountC, rowStartC, rowCountC;
     std::vector<int32_t> lumRound, chrRound;      // per output row accumulator start values
     FilterBank vChrEff;                           // vertical chroma filter after the 1-/2-tap special forms
+    FilterBank vLumEff;                           // vertical luma filter after them (the 1-tap forms ignore the coefficient)
 };
 
 struct YuvScaleArgs {

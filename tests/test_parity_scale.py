@@ -344,3 +344,33 @@ def test_yuv2x_lanczos_uses_the_14_sample_window(dev, orc, src_fmt, geom):
         bad = np.argwhere(got[0] != want)
         assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
         assert (pads[0] == 0xCD).all()
+
+
+def test_one_tap_vertical_forms_ignore_the_coefficient(dev, orc):
+    """yuv2packed1 / yuv2plane1 take the line as it is; for degenerate geometries (3 source rows, a shifted vertical
+    chroma position) initFilter emits 1-tap rows whose coefficient is 0, not 4096 (fuzzer finding)."""
+    import ctypes as C
+    from harness import planes, ints, alloc_planes
+    L = orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    sw, sh, dw, dh, pos = 26, 3, 100, 27, [64, 256, 0, 128]
+    src = synth_planes(orc, "yuv444p", sw, sh, seed=2130)
+    for dst_fmt in ("bgra", "rgb24", "yuv420p", "nv12"):
+        oc = L.orc_sws_create_ex(sw, sh, PIX_FMT["yuv444p"], dw, dh, PIX_FMT[dst_fmt], SWS["bilinear"], None,
+                                 (C.c_int * 4)(*pos), 0, 0)
+        want = alloc_planes(dst_fmt, dw, dh)
+        assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                               planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == dh
+        L.orc_sws_free(oc)
+        c = dev.lib.gmat_sws_getContext(sw, sh, PIX_FMT["yuv444p"], dw, dh, PIX_FMT[dst_fmt], SWS["bilinear"], None)
+        assert c and dev.lib.gmat_sws_setChromaPos(c, *pos) == 0
+        d = dev.upload_planes(src, 64)
+        dst = dev.planes_like(dst_fmt, dw, dh, 64)
+        assert dev.lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                                      planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == dh
+        for a, b in zip(dst, want):
+            assert (a.download() == b).all(), dst_fmt
+        dev.lib.gmat_sws_freeContext(c)
+        for p in d + dst:
+            p.free()
