@@ -56,6 +56,10 @@ int plane_geoms(int fmt, int w, int h, PlaneGeom g[3])
         g[0] = {1, w, h, 0}; g[1] = {2, (w + 1) >> 1, (h + 1) >> 1, 1};
         return 2;
     }
+    if (fmt == GMAT_PIX_FMT_YUV444P) {
+        g[0] = g[1] = g[2] = {1, w, h, 0};
+        return 3;
+    }
     g[0] = {bytes_per_pixel(fmt), w, h, 0};
     return 1;
 }
@@ -220,7 +224,7 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     f->stream = (hipStream_t)stream;
     f->out_w = f->in_w; f->out_h = f->in_h; f->out_fmt = f->in_fmt;
     const bool nvcv_style = f->kind != K_SCALE && f->kind != K_FORMAT;
-    if (nvcv_style && !is_packed_rgb(f->in_fmt) && !is_yuv420(f->in_fmt)) {
+    if (nvcv_style && !is_packed_rgb(f->in_fmt) && !is_yuv8_src(f->in_fmt)) {
         logf(LOG_ERROR, "%s: Unsupported input format: %d", f->name.c_str(), f->in_fmt);
         return GMAT_ERR(ENOSYS);
     }
@@ -324,7 +328,7 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
                     // out size = in size, background "black" (vf_rotate.c:102-107; ff_draw_color: RGB 0,0,0 / alpha 255,
                     // limited-range YUV 16,128,128 — drawutils.c:159-202)
                     uint8_t fill[4] = {0, 0, 0, 255};
-                    if (is_yuv420(f->in_fmt)) { fill[0] = i == 0 ? 16 : 128; fill[1] = 128; }
+                    if (is_yuv8_src(f->in_fmt)) { fill[0] = i == 0 ? 16 : 128; fill[1] = 128; }
                     r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream);
                     break;
                 }

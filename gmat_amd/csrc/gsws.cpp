@@ -23,7 +23,8 @@ using namespace gmat;
 
 namespace {
 
-enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32 };
+enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
+            MODE_RGB2YUV444, MODE_REPACK };
 
 struct DevBuf {
     void *p = nullptr;
@@ -226,7 +227,7 @@ static int init_rgb2yuv(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
-    if ((is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P) {
+    if ((is_yuv420(c->srcFormat) && is_yuv8_src(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -311,9 +312,21 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_SWAP_RB;
     } else if (same && srcFormat == dstFormat && is_packed_rgb(srcFormat)) {
         c->mode = MODE_COPY;
+    } else if (same && is_packed_rgb(srcFormat) && is_packed_rgb(dstFormat)) {
+        // the remaining packed pairs have a 32-bit end: rgbToRgbWrapper's byte moves (swscale_unscaled.c:1579-1640).
+        // With SWS_BITEXACT libswscale does not use its 24 -> 32 converters (:1571-1574) and the context runs the
+        // generic scaler; same here.
+        if (bytes_per_pixel(srcFormat) == 3 && (c->flags & GMAT_SWS_BITEXACT)) {
+            c->mode = MODE_SCALE;
+            r = ensure_scaler(c);
+        } else {
+            c->mode = MODE_REPACK;
+        }
     } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && is_yuv420(dstFormat)) {
         c->mode = MODE_RGB2YUV;
         r = init_rgb2yuv(c);
+    } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && dstFormat == GMAT_PIX_FMT_YUV444P) {
+        c->mode = MODE_RGB2YUV444;           // every filter has one tap: a per-pixel conversion
     } else if (same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
         c->mode = MODE_YUV2YUV;
     } else if (same && is_yuv420(srcFormat) && (dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE)) {
@@ -324,9 +337,13 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
-    } else if (srcFormat == GMAT_PIX_FMT_YUV444P && (is_packed_rgb(dstFormat) || is_yuv420(dstFormat))) {
+    } else if (srcFormat == GMAT_PIX_FMT_YUV444P && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
         // planar 4:4:4 source (scale_cuda's format list, vf_scale_cuda.c:45-54): always the generic plane scaler —
         // even at the same size the chroma planes are filtered (2:1 for 4:2:0 outputs)
+        c->mode = MODE_SCALE;
+        r = ensure_scaler(c);
+    } else if (is_yuv420(srcFormat) && dstFormat == GMAT_PIX_FMT_YUV444P) {
+        // 4:2:0 -> planar 4:4:4 (any size): the chroma planes go through their own 1:2 filters
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
     } else if (!same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
@@ -365,7 +382,7 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
-    if (!is_yuv420(c->srcFormat) || !is_yuv420(c->dstFormat)) {
+    if (!is_yuv8_src(c->srcFormat) || !is_yuv8_src(c->dstFormat)) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
@@ -376,7 +393,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     // a same-size context is a plane copy only while the ranges agree (utils.c:1996-2000: the special
     // converters are skipped when srcRange != dstRange); otherwise it runs the generic path
     const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
-    if (same) {
+    if (same && is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) {
         if (conv) { c->mode = MODE_SCALE; return ensure_scaler(c); }
         c->mode = MODE_YUV2YUV;
     }
@@ -497,6 +514,21 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         r = launch_rgb2yuv420(L, c->stream);
         break;
     }
+    case MODE_REPACK: {
+        const bool srcRgbOrder = c->srcFormat == GMAT_PIX_FMT_RGB24 || c->srcFormat == GMAT_PIX_FMT_RGBA;
+        const bool dstRgbOrder = c->dstFormat == GMAT_PIX_FMT_RGB24 || c->dstFormat == GMAT_PIX_FMT_RGBA;
+        c->lastKernel = "repack_rgb_kernel";
+        r = launch_repack_rgb(src[0], srcStride[0], bytes_per_pixel(c->srcFormat), dst[0], dstStride[0], bytes_per_pixel(c->dstFormat),
+                              c->srcW, c->srcH, srcRgbOrder != dstRgbOrder, c->stream);
+        break;
+    }
+    case MODE_RGB2YUV444: {
+        if (!dst[1] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
+        c->lastKernel = "rgb2yuv444_kernel";
+        r = launch_rgb2yuv444(src[0], srcStride[0], c->srcFormat == GMAT_PIX_FMT_BGR24, dst[0], dstStride[0], dst[1], dstStride[1],
+                              dst[2], dstStride[2], c->srcW, c->srcH, make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT), c->stream);
+        break;
+    }
     case MODE_YUV2YUV: {
         // nv12ToPlanarWrapper / planarToNv12Wrapper / plane copies (swscale_unscaled.c): lossless re-layout
         const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12, dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
@@ -567,7 +599,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             ya.dst = dst[0]; ya.ds = dstStride[0];
             const int ybpp = bytes_per_pixel(c->dstFormat);
             ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
-            if (is_yuv420(c->dstFormat)) {
+            if (is_yuv8_src(c->dstFormat)) {
                 const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
                 if (!dst[1] || (!dnv && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
                 ya.dstU = dst[1]; ya.dsU = dstStride[1];

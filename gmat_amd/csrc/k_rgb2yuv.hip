@@ -252,6 +252,69 @@ int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream)
     return 0;
 }
 
+// ---- packed RGB -> planar YUV 4:4:4 at equal size ------------------------------------------------------------
+// The CPU generic path of an RGB24 -> YUV444P context: no chroma subsampling at either end, so every filter has
+// one tap and each output sample depends on one pixel only:
+//   rgb24ToY_c / rgb24ToUV_c (input.c:815-847) -> hScale16To15_c with one tap: min(2 * v14, 32767)
+//   -> yuv2plane1_8_c (output.c:400-408): clip_u8((v + 64) >> 7)
+// 4 pixels per thread (12 bytes in, one dword per plane out).
+__global__ __launch_bounds__(256) void rgb2yuv444_kernel(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us,
+                                                         uint8_t *v, int vs, int w, int h, int aligned, Rgb2YuvConsts k)
+{
+    const int col = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= w || row >= h) return;
+    const uint8_t *rp = src + (size_t)row * ss;
+    int r[4], g[4], b[4];
+    const bool full = col + 4 <= w;
+    if (aligned && full) {
+        const uint3 q = *reinterpret_cast<const uint3 *>(rp + (size_t)col * 3);
+        r[0] = q.x & 0xFF;         g[0] = (q.x >> 8) & 0xFF;  b[0] = (q.x >> 16) & 0xFF;
+        r[1] = q.x >> 24;          g[1] = q.y & 0xFF;         b[1] = (q.y >> 8) & 0xFF;
+        r[2] = (q.y >> 16) & 0xFF; g[2] = q.y >> 24;          b[2] = q.z & 0xFF;
+        r[3] = (q.z >> 8) & 0xFF;  g[3] = (q.z >> 16) & 0xFF; b[3] = q.z >> 24;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = min(col + i, w - 1);
+            r[i] = rp[3 * c]; g[i] = rp[3 * c + 1]; b[i] = rp[3 * c + 2];
+        }
+    }
+    if (bgr) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int t = r[i]; r[i] = b[i]; b[i] = t; }
+    }
+    unsigned yb = 0, ub = 0, vb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        yb |= (unsigned)clip_u8((min(2 * rgb_to_y14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
+        ub |= (unsigned)clip_u8((min(2 * rgb_to_u14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
+        vb |= (unsigned)clip_u8((min(2 * rgb_to_v14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
+    }
+    uint8_t *dy = y + (size_t)row * ys + col, *du = u + (size_t)row * us + col, *dv = v + (size_t)row * vs + col;
+    if (aligned && full) {
+        *reinterpret_cast<unsigned *>(dy) = yb;
+        *reinterpret_cast<unsigned *>(du) = ub;
+        *reinterpret_cast<unsigned *>(dv) = vb;
+    } else {
+        for (int i = 0; i < min(4, w - col); i++) {
+            dy[i] = (uint8_t)(yb >> (8 * i)); du[i] = (uint8_t)(ub >> (8 * i)); dv[i] = (uint8_t)(vb >> (8 * i));
+        }
+    }
+}
+
+int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us, uint8_t *v, int vs, int w, int h,
+                      const Rgb2YuvConsts &k, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int aligned = ((((uintptr_t)src | (uintptr_t)ss | (uintptr_t)y | (uintptr_t)ys | (uintptr_t)u | (uintptr_t)us |
+                           (uintptr_t)v | (uintptr_t)vs) & 3) == 0);
+    const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
+    hipLaunchKernelGGL(rgb2yuv444_kernel, grid, block, 0, stream, src, ss, bgr, y, ys, u, us, v, vs, w, h, aligned, k);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0, uint8_t *d1,
                        int ds1, int cw, int ch, hipStream_t stream)
 {

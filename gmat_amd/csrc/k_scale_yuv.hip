@@ -183,6 +183,7 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
 // MODE 0: packed RGB out, half chroma (LUT form)   1: packed RGB out, full chroma
 //      2: YUV 4:2:0 out (NV12 or YUV420P): the tile is TW x TH luma outputs plus the TW/2 x TH/2 chroma
 //         outputs under them; vChr is indexed by CHROMA row; yuv2planeX_8_c / yuv2nv12cX_c (output.c:400-450)
+//      3: YUV 4:4:4 planar out: chroma tile = luma tile
 // LONG: horizontal filters longer than 2*kYMaxPairs taps (down-scale ratios beyond ~3.7:1).  A separate
 // instantiation: with the tail loops compiled into the common variant every geometry paid for them (the 2x
 // up-scale went from 38.7 to 47.3 us).
@@ -190,8 +191,9 @@ template <int TW, int MODE, bool LONG>
 __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
-    constexpr bool FULL = MODE == 1;
-    constexpr bool YUVOUT = MODE == 2;
+    constexpr bool FULL = MODE == 1 || MODE == 3;       // chroma at full output width
+    constexpr bool YUVOUT = MODE >= 2;
+    constexpr int CVS = MODE == 2 ? 1 : 0;              // vertical chroma subsampling of the destination
     constexpr int CWD = FULL ? TW : TW / 2;            // chroma samples per output tile row
 
     int tcol, trow;
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
     if (YUVOUT) {
         // chroma rows of the tile: item = (chroma row, group of 4 chroma columns), both planes
         constexpr int QC = CWD / 4;
-        const int tcy0 = ty0 >> 1;
-        for (int it = tid; it < (a.TH >> 1) * QC; it += 256) {
+        const int tcy0 = ty0 >> CVS;
+        for (int it = tid; it < (a.TH >> CVS) * QC; it += 256) {
             const int cyl = it / QC, qc = it - cyl * QC;
             const int cy = tcy0 + cyl, cx = tcx0 + 4 * qc;
             if (cy >= a.chrDstH || cx >= a.chrDstW) continue;
@@ -496,12 +498,13 @@ static void windows(const FilterBank &fb, int tile, int ntiles, int count, int a
 
 int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
-    const bool yuvOut = is_yuv420(p.dstFormat);
+    const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
+    const int yuvOut = is_yuv420(p.dstFormat) ? 1 : out444 ? 2 : 0;          // 1: 4:2:0   2: planar 4:4:4
     if (!is_yuv8_src(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (p.hLum.pairs > 64 || p.hChr.pairs > 64) return GMAT_ERR(ENOSYS);      // 128 taps: ratios up to ~30:1 (bicubic)
-    const int full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) ? 1 : 0;
+    const int full = ((p.flags & GMAT_SWS_FULL_CHR_H_INT) || out444) ? 1 : 0;  // chroma tile as wide as the luma tile
     if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);
-    if (p.chrDstH != (yuvOut ? (p.dstH + 1) / 2 : p.dstH)) return GMAT_ERR(ENOSYS);
+    if (p.chrDstH != (yuvOut == 1 ? (p.dstH + 1) / 2 : p.dstH)) return GMAT_ERR(ENOSYS);
     t.fullChroma = full;
     t.yuvOut = yuvOut;
 
@@ -557,11 +560,11 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
         for (int TH : ths) {
             if (forceTH && TH != forceTH) continue;
             if (!forceTH && TH > 16) continue;
-            if (yuvOut && (TH & 1)) continue;              // a tile holds TH/2 chroma rows
+            if (yuvOut == 1 && (TH & 1)) continue;         // a tile holds TH/2 chroma rows
             const int nty = (p.dstH + TH - 1) / TH;
             int rowsL = 0, rowsC = 0;
             windows(t.vLumEff, TH, nty, p.dstH, 2, t.rowStartL, t.rowCountL, rowsL);
-            if (yuvOut) windows(t.vChrEff, TH / 2, nty, p.chrDstH, 2, t.rowStartC, t.rowCountC, rowsC);
+            if (yuvOut == 1) windows(t.vChrEff, TH / 2, nty, p.chrDstH, 2, t.rowStartC, t.rowCountC, rowsC);
             else        windows(t.vChrEff, TH, nty, p.dstH, 2, t.rowStartC, t.rowCountC, rowsC);
             const int bytes = rowsL * colsL * 2 + 2 * rowsC * colsC * 2 + (rowsL / 2) * TW * 4 + 2 * (rowsC / 2) * cwd * 4;
             if (bytes > ldsCap && !(forceTH && bytes <= 64 * 1024)) continue;
@@ -576,6 +579,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 
 const char *yuvscale_kernel_name(const YuvScaleTiling &t)
 {
+    if (t.yuvOut == 2) return t.TW == 64 ? "scale_yuv_kernel<64,yuv444>" : "scale_yuv_kernel<32,yuv444>";
     if (t.yuvOut) return t.TW == 64 ? "scale_yuv_kernel<64,yuv>" : "scale_yuv_kernel<32,yuv>";
     if (t.TW == 64) return t.fullChroma ? "scale_yuv_kernel<64,full>" : "scale_yuv_kernel<64,half>";
     return t.fullChroma ? "scale_yuv_kernel<32,full>" : "scale_yuv_kernel<32,half>";
@@ -591,9 +595,9 @@ int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t
 #define GMAT_LAUNCH_YUV(TW_, MODE_) \
     do { if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true>), grid, block, lds, stream, a); \
          else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false>), grid, block, lds, stream, a); } while (0)
-    const int mode = t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
-    if (t.TW == 64) { if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
-    else if (t.TW == 32) { if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }
+    const int mode = t.yuvOut == 2 ? 3 : t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
+    if (t.TW == 64) { if (mode == 3) GMAT_LAUNCH_YUV(64, 3); else if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
+    else if (t.TW == 32) { if (mode == 3) GMAT_LAUNCH_YUV(32, 3); else if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }
     else return GMAT_ERR(EINVAL);
 #undef GMAT_LAUNCH_YUV
     GMAT_HIP_CHECK(hipGetLastError());

@@ -170,6 +170,59 @@ __global__ __launch_bounds__(256) void swap_rb24_kernel(const uint8_t *src, int 
     }
 }
 
+// RGB24/BGR24 <-> RGBA/BGRA and RGBA <-> BGRA at equal size: the byte moves of rgbToRgbWrapper
+// (swscale_unscaled.c:1579-1640; rgb24to32 / rgb24tobgr32 / rgb32to24 / rgb32tobgr24 / shuffle_bytes_2103).
+// Alpha is 255 when created, dropped when removed and kept 32 -> 32.  4 pixels per thread: 12 or 16 bytes in,
+// 12 or 16 bytes out.
+template <int SB, int DB>
+__global__ __launch_bounds__(256) void repack_rgb_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int swap,
+                                                         int aligned)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *s = src + (size_t)y * ss + (size_t)x * SB;
+    uint8_t *d = dst + (size_t)y * ds + (size_t)x * DB;
+    unsigned px[4];                                   // c0 | c1 << 8 | c2 << 16 | a << 24 per pixel
+    const bool full = aligned && x + 4 <= w;
+    const int nx = min(4, w - x);
+    if (full) {
+        if (SB == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s);
+            px[0] = v.x; px[1] = v.y; px[2] = v.z; px[3] = v.w;
+        } else {
+            const uint3 v = *reinterpret_cast<const uint3 *>(s);
+            px[0] = v.x | 0xFF000000u;
+            px[1] = (v.x >> 24) | (v.y << 8) | 0xFF000000u;
+            px[2] = (v.y >> 16) | (v.z << 16) | 0xFF000000u;
+            px[3] = (v.z >> 8) | 0xFF000000u;
+        }
+    } else {
+        for (int i = 0; i < 4; i++) {
+            const int j = min(i, nx - 1);
+            px[i] = s[SB * j] | (s[SB * j + 1] << 8) | (s[SB * j + 2] << 16) | (SB == 4 ? (unsigned)s[SB * j + 3] << 24 : 0xFF000000u);
+        }
+    }
+    if (swap) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = (px[i] & 0xFF00FF00u) | ((px[i] >> 16) & 0xFF) | ((px[i] & 0xFF) << 16);
+    }
+    if (full) {
+        if (DB == 4) {
+            *reinterpret_cast<uint4 *>(d) = make_uint4(px[0], px[1], px[2], px[3]);
+        } else {
+            uint3 o;
+            o.x = (px[0] & 0xFFFFFFu) | (px[1] << 24);
+            o.y = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
+            o.z = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
+            *reinterpret_cast<uint3 *>(d) = o;
+        }
+    } else {
+        for (int i = 0; i < nx; i++)
+            for (int b = 0; b < DB; b++) d[DB * i + b] = (uint8_t)(px[i] >> (8 * b));
+    }
+}
+
 static inline bool aligned4(const void *p, int stride) { return (((uintptr_t)p | (uintptr_t)stride) & 3) == 0; }
 
 int launch_yuv2rgb(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, int dstFormat,
@@ -249,6 +302,22 @@ int launch_nv12_to_rgbpf32(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, 
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
     const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
     hipLaunchKernelGGL(nv12_to_rgbpf32_kernel, grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_repack_rgb(const uint8_t *src, int ss, int srcBpp, uint8_t *dst, int ds, int dstBpp, int w, int h, int swapRB,
+                      hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    // dword groups for 24-bit rows, 16-byte groups for 32-bit rows
+    const int aligned = ((((uintptr_t)src | (uintptr_t)ss) & (srcBpp == 4 ? 15 : 3)) == 0) &&
+                        ((((uintptr_t)dst | (uintptr_t)ds) & (dstBpp == 4 ? 15 : 3)) == 0);
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 3) / 4);
+    if (srcBpp == 3 && dstBpp == 4)      hipLaunchKernelGGL(HIP_KERNEL_NAME(repack_rgb_kernel<3, 4>), grid, block, 0, stream, src, ss, dst, ds, w, h, swapRB, aligned);
+    else if (srcBpp == 4 && dstBpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(repack_rgb_kernel<4, 3>), grid, block, 0, stream, src, ss, dst, ds, w, h, swapRB, aligned);
+    else if (srcBpp == 4 && dstBpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(repack_rgb_kernel<4, 4>), grid, block, 0, stream, src, ss, dst, ds, w, h, swapRB, aligned);
+    else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -22,6 +22,9 @@ int launch_nv12_to_rgbpf32(const YuvSrc &src, uint8_t *dst, int dstStride, int w
                            const Yuv2RgbConsts &k, hipStream_t stream);
 int launch_swap_rb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h,
                      hipStream_t stream);
+// 24 <-> 32 bit and 32 <-> 32 bit packed RGB at equal size (rgbToRgbWrapper's byte moves); swapRB exchanges bytes 0 and 2
+int launch_repack_rgb(const uint8_t *src, int srcStride, int srcBpp, uint8_t *dst, int dstStride, int dstBpp, int w, int h,
+                      int swapRB, hipStream_t stream);
 // planar float rgb (plane stride = srcStride * h) -> packed rgb24 / bgr24, u8 = (int)(clamp(f, 0, 1) * 255 + 0.5)
 int launch_rgbpf32_to_rgb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bgr,
                             hipStream_t stream);
@@ -72,7 +75,7 @@ const char *scale_kernel_name(const ScaleArgs &a, const ScaleTiling &t);
 // yuv2rgb_X_c) or the full-chroma form (yuv2rgb_full_X_c).
 struct YuvScaleTiling {
     int TW = 0, TH = 0, ntx = 0, nty = 0, fullChroma = 0;
-    int yuvOut = 0;                               // destination is NV12 / YUV420P (vChr indexed by chroma row)
+    int yuvOut = 0;                               // 1: destination NV12 / YUV420P (vChr indexed by chroma row), 2: YUV444P
     int rowsL = 0, colsL = 0, rowsC = 0, colsC = 0, ldsBytes = 0, xcdRemap = 1;
     std::vector<int32_t> colStartL, colCountL, rowStartL, rowCountL, colStartC, colCountC, rowStartC, rowCountC;
     std::vector<int32_t> lumRound, chrRound;      // per output row accumulator start values
@@ -137,6 +140,9 @@ struct Rgb2YuvLaunch {
 };
 int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t);
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
+// packed RGB24 / BGR24 -> planar YUV 4:4:4 at equal size (one-tap filters everywhere: a per-pixel conversion)
+int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us, uint8_t *v, int vs, int w, int h,
+                      const Rgb2YuvConsts &k, hipStream_t stream);
 // toPlanar: (a0 = interleaved UV) -> d0 = U, d1 = V;  else (a0 = U, a1 = V) -> d0 = interleaved UV
 int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0,
                        uint8_t *d1, int ds1, int cw, int ch, hipStream_t stream);

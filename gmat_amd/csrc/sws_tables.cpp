@@ -335,7 +335,8 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
 {
     const bool src_rgb = is_packed_rgb(srcFormat), dst_rgb = is_packed_rgb(dstFormat);
     const bool src444 = srcFormat == GMAT_PIX_FMT_YUV444P;
-    if (!(src_rgb || is_yuv420(srcFormat) || src444) || !(dst_rgb || is_yuv420(dstFormat))) return GMAT_ERR(ENOSYS);
+    const bool dst444 = dstFormat == GMAT_PIX_FMT_YUV444P;
+    if (!(src_rgb || is_yuv420(srcFormat) || src444) || !(dst_rgb || is_yuv420(dstFormat) || dst444)) return GMAT_ERR(ENOSYS);
     static const int unset[4] = {-513, -513, -513, -513};
     if (!chrPos) chrPos = unset;
     if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) return GMAT_ERR(EINVAL);
@@ -347,7 +348,7 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
     p.lumXInc = (int)((((int64_t)srcW << 16) + (dstW >> 1)) / dstW);
     p.lumYInc = (int)((((int64_t)srcH << 16) + (dstH >> 1)) / dstH);
     p.chrSrcHSub = p.chrSrcVSub = (src_rgb || src444) ? 0 : 1;
-    p.chrDstHSub = p.chrDstVSub = dst_rgb ? 0 : 1;
+    p.chrDstHSub = p.chrDstVSub = (dst_rgb || dst444) ? 0 : 1;
 
     if (dst_rgb) {
         if (!(flags & GMAT_SWS_FULL_CHR_H_INT)) {

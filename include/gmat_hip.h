@@ -29,7 +29,8 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_YUV420P   = 0,
     GMAT_PIX_FMT_RGB24     = 2,
     GMAT_PIX_FMT_BGR24     = 3,
-    GMAT_PIX_FMT_YUV444P   = 5,     /* source only (scale_cuda's list, vf_scale_cuda.c:45-54) */
+    GMAT_PIX_FMT_YUV444P   = 5,     /* scale_cuda's list, vf_scale_cuda.c:45-54: source for every output format;
+                                       destination of 8-bit YUV sources (any size) and of RGB24/BGR24 (equal size) */
     GMAT_PIX_FMT_NV12      = 23,
     GMAT_PIX_FMT_RGBA      = 26,
     GMAT_PIX_FMT_BGRA      = 28,

@@ -54,7 +54,7 @@ enum {
     ORC_PIX_YUV420P = 0,
     ORC_PIX_RGB24   = 2,
     ORC_PIX_BGR24   = 3,
-    ORC_PIX_YUV444P = 5,      /* oracle only: needed to reproduce the reference's FATE values */
+    ORC_PIX_YUV444P = 5,
     ORC_PIX_NV12    = 23,
     ORC_PIX_RGBA    = 26,
     ORC_PIX_BGRA    = 28,
@@ -160,6 +160,10 @@ void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], ui
                         const int dst_stride[4], int w, int h, int src_nv12);
 void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                        int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
+/* rgbToRgbWrapper (swscale_unscaled.c:1579-1640): RGB24/BGR24 <-> RGBA/BGRA and RGBA <-> BGRA byte re-packing at
+ * equal size (alpha 255 when created, dropped when removed, kept for 32 -> 32); -1 for other pairs */
+int orc_rgb_repack(const uint8_t *src, int src_stride, int src_fmt, uint8_t *dst, int dst_stride, int dst_fmt,
+                   int w, int h);
 
 /* tests/videogen.c + tests/utils.c: frames [0,nframes) of the reference's vsynth1 clip, yuv420p */
 int orc_vsynth1(uint8_t *out, int w, int h, int nframes);

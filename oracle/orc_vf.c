@@ -92,6 +92,52 @@ void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst
     }
 }
 
+/* ---- packed 24/32-bit RGB re-packing at equal size -------------------------------------------------
+ * rgbToRgbWrapper (swscale_unscaled.c:1579-1640) with the converter findRgbConvFn picks (:1458-1577) on a
+ * little-endian host.  With RGB24 in the "RGB in int" class, BGR24 in the "BGR in int" class, RGBA = BGR32 and
+ * BGRA = RGB32 (pixfmt.h), the table reduces to:
+ *   same class,  24 -> 32   rgb24to32        rgb2rgb.c:170-188           d = { s[2], s[1], s[0], 255 }
+ *   other class, 24 -> 32   rgb24tobgr32_c   rgb2rgb_template.c:31-53    d = { s[0], s[1], s[2], 255 }
+ *   same class,  32 -> 24   rgb32to24        rgb2rgb.c:152-168           d = { s[2], s[1], s[0] }
+ *   other class, 32 -> 24   rgb32tobgr24_c   rgb2rgb_template.c:55-77    d = { s[0], s[1], s[2] }
+ *   RGBA <-> BGRA           shuffle_bytes_2103_c  rgb2rgb_template.c:317-329   bytes 0 and 2 exchanged, alpha kept
+ * Returns 0, or -1 for a pair that has no special converter here (equal formats are a copy, 24 <-> 24 is
+ * orc_rgb24_swap_rb).  NOTE (swscale_unscaled.c:1571-1574): with SWS_BITEXACT the 24 -> 32 converters are not
+ * used at all; such a context runs the generic scaler, i.e. orc_sws_create. */
+static int orc_rgb_in_int(int fmt) { return fmt == ORC_PIX_RGB24 || fmt == ORC_PIX_BGRA; }   /* else: BGR in int */
+
+int orc_rgb_repack(const uint8_t *src, int src_stride, int src_fmt, uint8_t *dst, int dst_stride, int dst_fmt,
+                   int w, int h)
+{
+    const int s32 = src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA;
+    const int d32 = dst_fmt == ORC_PIX_RGBA || dst_fmt == ORC_PIX_BGRA;
+    const int s24 = src_fmt == ORC_PIX_RGB24 || src_fmt == ORC_PIX_BGR24;
+    const int d24 = dst_fmt == ORC_PIX_RGB24 || dst_fmt == ORC_PIX_BGR24;
+    const int same_class = orc_rgb_in_int(src_fmt) == orc_rgb_in_int(dst_fmt);
+    int x, y;
+    if (!(s32 || s24) || !(d32 || d24) || src_fmt == dst_fmt || (s24 && d24))
+        return -1;
+    for (y = 0; y < h; y++) {
+        const uint8_t *s = src + (long)y * src_stride;
+        uint8_t *d = dst + (long)y * dst_stride;
+        for (x = 0; x < w; x++) {
+            if (s32 && d32) {                         /* shuffle_bytes_2103 */
+                d[4 * x] = s[4 * x + 2]; d[4 * x + 1] = s[4 * x + 1]; d[4 * x + 2] = s[4 * x]; d[4 * x + 3] = s[4 * x + 3];
+            } else if (s24) {                         /* rgb24to32 / rgb24tobgr32 */
+                d[4 * x]     = same_class ? s[3 * x + 2] : s[3 * x];
+                d[4 * x + 1] = s[3 * x + 1];
+                d[4 * x + 2] = same_class ? s[3 * x] : s[3 * x + 2];
+                d[4 * x + 3] = 255;
+            } else {                                  /* rgb32to24 / rgb32tobgr24 */
+                d[3 * x]     = same_class ? s[4 * x + 2] : s[4 * x];
+                d[3 * x + 1] = s[4 * x + 1];
+                d[3 * x + 2] = same_class ? s[4 * x] : s[4 * x + 2];
+            }
+        }
+    }
+    return 0;
+}
+
 /* ---- vf_rotate.c: arbitrary-angle rotation in 16.16 fixed point ---------------------------------
  * int_sin                 vf_rotate.c:198-218   Taylor series on angles scaled by 2^20, result scaled by 2^16
  * interpolate_bilinear8   vf_rotate.c:224-249

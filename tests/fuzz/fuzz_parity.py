@@ -22,15 +22,13 @@ ALGOS = ["bicubic", "bilinear", "lanczos", "point", "area"]
 fails = 0
 for case in range(n):
     sf = rng.choice(SRC)
-    dsts = ["rgb24", "bgr24", "rgba", "bgra", "nv12", "yuv420p"] if sf in ("nv12", "yuv420p", "yuv444p") else ["rgb24", "bgr24", "rgba", "bgra", "nv12", "yuv420p"]
+    dsts = ["rgb24", "bgr24", "rgba", "bgra", "nv12", "yuv420p", "yuv444p"]
     df = rng.choice(dsts)
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     same = rng.random() < 0.25
     dw, dh = (sw, sh) if same else (rng.randint(2, 300), rng.randint(2, 120))
-    if sf in ("rgb24", "bgr24") and df in ("nv12", "yuv420p") and not same:
+    if sf in ("rgb24", "bgr24") and df in ("nv12", "yuv420p", "yuv444p") and not same:
         continue                                  # scaled rgb -> yuv is not offered
-    if sf == "yuv444p" and df in ("rgb24", "bgr24", "rgba", "bgra") and same:
-        pass
     algo = rng.choice(ALGOS)
     flags = SWS[algo]
     if rng.random() < 0.2: flags |= SWS["full_chr_h_int"]

@@ -5,6 +5,8 @@ checksum the reference tree ships in tests/ref/fate (fixture tests/golden/fate_r
   filter-colorlevels  = scale,format=rgb24 of yuv420p with flags bicubic+accurate_rnd+bitexact
                         (tests/fate/filter-video.mak:423-424; colorlevels at defaults is the identity)
   filter-transpose    = transpose (cclock_flip) of each yuv420p plane (filter-video.mak:297-298)
+  pixfmt-rgb24/bgr24  = yuv420p -> rgb24|bgr24 -> yuv444p, md5 of the raw frame (tests/fate-run.sh pixfmt_conversion)
+  pixfmt-yuv420p      = yuv420p -> yuv444p
 The oracle only supplies the input clip (oracle/orc_vsynth.c restates tests/videogen.c).
 """
 import ctypes as C
@@ -18,7 +20,8 @@ import pytest
 from harness import SWS, DevPlane
 
 W, H, NFRAMES = 352, 288, 50
-GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))["framecrc"]
+_REFS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))
+GOLD, GOLD_MD5 = _REFS["framecrc"], _REFS["pixfmt_md5"]
 
 
 @pytest.fixture(scope="module")
@@ -130,3 +133,24 @@ def test_product_reproduces_fate_filter_scalechroma(dev, clip):
     lib.gmat_sws_freeContext(c)
     for p in dst:
         p.free()
+
+
+@pytest.mark.parametrize("fmt", ["rgb24", "bgr24", "yuv420p"])
+def test_product_reproduces_fate_pixfmt(dev, clip, fmt):
+    """fate-pixfmt-<fmt>: scale=...,format=<fmt> then back to yuv444p (the comparison format of the test), all
+    with flags bicubic+accurate_rnd+bitexact; the reference file holds the md5 of the one-frame result"""
+    import hashlib
+    flags = SWS["bicubic"] | SWS["accurate_rnd"] | SWS["bitexact"]
+    d = dev.upload_planes(yuv420p_planes(clip[0]))
+    if fmt == "yuv420p":
+        outs, _, kernel = dev.sws(d, W, H, "yuv420p", W, H, "yuv444p", flags)
+    else:
+        mid, _, _ = dev.sws(d, W, H, "yuv420p", W, H, fmt, flags)
+        dm = dev.upload_planes(mid)
+        outs, _, kernel = dev.sws(dm, W, H, fmt, W, H, "yuv444p", flags)
+        for p in dm:
+            p.free()
+    for p in d:
+        p.free()
+    raw = b"".join(bytes(np.ascontiguousarray(o)) for o in outs)
+    assert hashlib.md5(raw).hexdigest() == GOLD_MD5[fmt], kernel

@@ -424,6 +424,40 @@ def test_filter_layer_scale_from_yuv444p(dev, orc):
         assert (a == b).all()
 
 
+def test_filter_layer_yuv444p_frames(dev, orc):
+    """scale_hip / format_hip with a planar 4:4:4 destination, then crop + flip + transpose on those frames"""
+    from harness import SWS
+    w, h = 128, 48
+    src = synth_planes(orc, "nv12", w, h, 98)
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 96, "h": 40, "format": "yuv444p"}, src, w, h, "nv12")
+    assert (ow, oh) == (96, 40) and len(res) == 3
+    want = orc.sws(src, w, h, "nv12", 96, 40, "yuv444p", SWS["bicubic"])
+    for a, b in zip(res, want):
+        assert (a == b).all()
+    fmt, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": "yuv444p"}, src, w, h, "nv12")
+    for a, b in zip(fmt, orc.sws(src, w, h, "nv12", w, h, "yuv444p", SWS["bicubic"])):
+        assert (a == b).all()
+    t, tw, th = _run_filter_planes(dev, "transpose_hip", {"dir": "clock"}, want, 96, 40, "yuv444p")
+    assert (tw, th) == (40, 96)
+    for a, b in zip(t, want):
+        assert (a == np.rot90(b, -1)).all()
+    f, _, _ = _run_filter_planes(dev, "flip_hip", {"code": 1}, want, 96, 40, "yuv444p")
+    for a, b in zip(f, want):
+        assert (a == b[:, ::-1]).all()
+    c, cw, ch = _run_filter_planes(dev, "crop_hip", {"w": 31, "h": 17, "x": 5, "y": 3}, want, 96, 40, "yuv444p")
+    assert (cw, ch) == (31, 17)
+    for a, b in zip(c, want):
+        assert (a == b[3:20, 5:36]).all()
+    r, _, _ = _run_filter_planes(dev, "rotate_hip", {"angle": 23}, want, 96, 40, "yuv444p")
+    for i, (a, b) in enumerate(zip(r, want)):
+        fill = np.array([16 if i == 0 else 128, 128, 0, 0], np.uint8)
+        b = np.ascontiguousarray(b)
+        ref = np.zeros_like(b)
+        orc.L.orc_rotate(b.ctypes.data, b.strides[0], ref.ctypes.data, ref.strides[0], 96, 40, 96, 40, 1,
+                         23 * math.pi / 180.0, 1, fill.ctypes.data)
+        assert (a == ref).all(), i
+
+
 @pytest.mark.parametrize("case", [(277, 128, 4, [5, -1, -1, 7, 0, -3, -3, 0, 3]), (241, 116, 1, [0, 6, -1, 3, 0, 6, -1, 0, -3]),
                                   (264, 196, 3, [1, 2, -2, 2, 9, 5, -3, 5, -2]), (130, 40, 3, [1, 2, 3, 4, 5, 6, 7, 8, 9])])
 def test_conv3x3_float_epilogue_is_not_contracted(dev, orc, case):

@@ -24,6 +24,24 @@ def test_rgb_to_yuv420_bit_exact(dev, orc, w, h, src_fmt, dst_fmt):
             assert (p == 0xCD).all()
 
 
+@pytest.mark.parametrize("w,h", SIZES + [(1, 1), (257, 5), (1023, 3)])
+@pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
+def test_rgb_to_yuv444p_bit_exact(dev, orc, w, h, src_fmt):
+    """no subsampling at either end: rgb24ToY_c / rgb24ToUV_c, one-tap filters, yuv2plane1_8_c for the three planes"""
+    src = synth_planes(orc, src_fmt, w, h, seed=57)
+    for flags in ("bicubic", "point"):
+        want = orc.sws(src, w, h, src_fmt, w, h, "yuv444p", SWS[flags])
+        for align, extra in [(256, 0), (1, 1)]:
+            d_src = dev.upload_planes(src, align, extra)
+            got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, "yuv444p", SWS[flags], dst_align=align, dst_extra=extra)
+            assert kernel == "rgb2yuv444_kernel"
+            for i, (g, wv) in enumerate(zip(got, want)):
+                bad = np.argwhere(g != wv)
+                assert bad.size == 0, f"plane {i}: {len(bad)} mismatches, first {bad[:4].tolist()} (align {align})"
+            for p in pads:
+                assert (p == 0xCD).all()
+
+
 @pytest.mark.parametrize("flags", ["bilinear", "point", "lanczos"])
 def test_rgb_to_nv12_other_vertical_filters(dev, orc, flags):
     w, h = 192, 40

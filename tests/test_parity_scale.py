@@ -296,6 +296,58 @@ def test_yuv444p_source(dev, orc, dst_fmt, geom):
         p.free()
 
 
+@pytest.mark.parametrize("src_fmt", ["yuv420p", "nv12", "yuv444p"])
+@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "lanczos"])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (130, 50, 130, 50), (96, 40, 144, 60), (201, 91, 151, 67)])
+def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
+    """planar 4:4:4 destination (scale_cuda's format list, vf_scale_cuda.c:45-54): chroma planes at luma size,
+    a 4:2:0 source's chroma is up-scaled 1:2 on top of the luma ratio; yuv2planeX_8_c / yuv2plane1_8_c for all
+    three planes"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=61)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, "yuv444p", SWS[flags])
+    d = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "yuv444p", SWS[flags], dst_align=64)
+    assert kernel.startswith("scale_yuv_kernel") and "yuv444" in kernel, kernel
+    assert len(got) == 3
+    for i, (g, wv) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != wv)
+        assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
+        assert (pads[i] == 0xCD).all()
+    for p in d:
+        p.free()
+
+
+@pytest.mark.parametrize("align", [1, 64])
+def test_yuv444p_output_unaligned_and_range(dev, orc, align):
+    """odd sizes with byte-aligned planes, plus the limited -> full range conversion on the way"""
+    import ctypes as C
+    from harness import planes, ints, alloc_planes
+    L = orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    sw, sh, dw, dh = 77, 35, 93, 41
+    src = synth_planes(orc, "yuv420p", sw, sh, seed=62)
+    for sr, dr in ((0, 0), (0, 1), (1, 0)):
+        oc = L.orc_sws_create_ex(sw, sh, PIX_FMT["yuv420p"], dw, dh, PIX_FMT["yuv444p"], SWS["bicubic"], None,
+                                 (C.c_int * 4)(-513, -513, -513, -513), sr, dr)
+        want = alloc_planes("yuv444p", dw, dh)
+        assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                               planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == dh
+        L.orc_sws_free(oc)
+        c = dev.lib.gmat_sws_getContext(sw, sh, PIX_FMT["yuv420p"], dw, dh, PIX_FMT["yuv444p"], SWS["bicubic"], None)
+        assert c and dev.lib.gmat_sws_setRange(c, sr, dr) == 0
+        d = dev.upload_planes(src, align)
+        dst = dev.planes_like("yuv444p", dw, dh, align)
+        assert dev.lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                                      planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == dh
+        for a, b in zip(dst, want):
+            assert (a.download() == b).all(), (sr, dr)
+        dev.lib.gmat_sws_freeContext(c)
+        for p in d + dst:
+            p.free()
+
+
 @pytest.mark.parametrize("case", [("bgr24", "bgra", (86, 118, 66, 81), SWS["point"] | SWS["accurate_rnd"]),
                                   ("bgr24", "bgr24", (6, 97, 196, 67), SWS["point"] | SWS["full_chr_h_int"]),
                                   ("rgb24", "bgra", (158, 36, 257, 49), SWS["area"])])

@@ -65,6 +65,48 @@ def test_rgb24_bgr24_swap(dev, orc, w, h):
         assert (got[0] == want).all() and (pads[0] == 0xCD).all()
 
 
+_ORDER = {"rgb24": "rgb", "bgr24": "bgr", "rgba": "rgba", "bgra": "bgra"}
+
+
+@pytest.mark.parametrize("w,h", [(64, 8), (130, 6), (5, 3), (1, 1), (257, 2)])
+@pytest.mark.parametrize("pair", [("rgb24", "rgba"), ("rgb24", "bgra"), ("bgr24", "rgba"), ("bgr24", "bgra"),
+                                  ("rgba", "rgb24"), ("rgba", "bgr24"), ("bgra", "rgb24"), ("bgra", "bgr24"),
+                                  ("rgba", "bgra"), ("bgra", "rgba")])
+def test_packed_rgb_repack(dev, orc, w, h, pair):
+    """24 <-> 32 and 32 <-> 32 bit packed RGB at equal size: rgbToRgbWrapper's byte moves (alpha 255 when created,
+    dropped when removed, kept 32 -> 32).  Checked against the oracle's restatement and against the channel names."""
+    sf, df = pair
+    src = synth_planes(orc, sf, w, h, seed=5)
+    want = np.zeros((h, w * len(_ORDER[df])), np.uint8)
+    assert orc.L.orc_rgb_repack(src[0].ctypes.data, src[0].strides[0], PIX_FMT[sf], want.ctypes.data, want.strides[0],
+                                PIX_FMT[df], w, h) == 0
+    # the same thing said with channel names
+    spx = src[0].reshape(h, w, len(_ORDER[sf]))
+    chan = {c: spx[:, :, i] for i, c in enumerate(_ORDER[sf])}
+    chan.setdefault("a", np.full((h, w), 255, np.uint8))
+    assert (want.reshape(h, w, -1) == np.stack([chan[c] for c in _ORDER[df]], axis=2)).all()
+    for align, extra in [(256, 0), (1, 1), (4, 0)]:
+        d_src = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d_src, w, h, sf, w, h, df, dst_align=align, dst_extra=extra)
+        assert kernel == "repack_rgb_kernel"
+        assert (got[0] == want).all() and (pads[0] == 0xCD).all()
+
+
+@pytest.mark.parametrize("pair", [("rgb24", "bgra"), ("bgr24", "rgba")])
+def test_24_to_32_with_bitexact_runs_the_generic_scaler(dev, orc, pair):
+    """findRgbConvFn returns no converter for 24 -> 32 bit under SWS_BITEXACT (swscale_unscaled.c:1571-1574): the
+    context is a generic (lossy, through YUV) one even at equal size"""
+    sf, df = pair
+    w, h = 70, 22
+    flags = SWS["bicubic"] | SWS["bitexact"]
+    src = synth_planes(orc, sf, w, h, seed=6)
+    want = orc.sws(src, w, h, sf, w, h, df, flags)
+    d_src = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d_src, w, h, sf, w, h, df, flags, dst_align=64)
+    assert kernel.startswith("scale_rgb_kernel"), kernel
+    assert (got[0] == want[0]).all()
+
+
 @pytest.mark.parametrize("w,h", [(64, 8), (36, 6)])
 def test_nv12_to_rgbpf32_cswscale_shape(dev, orc, w, h):
     # metrans/app/CSwscale.c: tightly packed nv12 in, three stacked float planes out, value = u8/255
