@@ -35,13 +35,14 @@ def timeit(fn):
 
 def frame_bytes(fmt, w, h):
     return {"nv12": w * h * 3 // 2, "yuv420p": w * h * 3 // 2, "rgb24": w * h * 3, "bgr24": w * h * 3,
-            "rgba": w * h * 4, "bgra": w * h * 4}[fmt]
+            "rgba": w * h * 4, "bgra": w * h * 4, "yuv444p": w * h * 3}[fmt]
 
 
 def frame_ptrs(t, fmt, w, h):
     b = t.data_ptr()
     if fmt == "nv12": return [b, b + w * h], [w, w]
     if fmt == "yuv420p": return [b, b + w * h, b + w * h + (w // 2) * (h // 2)], [w, w // 2, w // 2]
+    if fmt == "yuv444p": return [b, b + w * h, b + 2 * w * h], [w, w, w]
     bpp = 4 if fmt in ("rgba", "bgra") else 3
     return [b], [w * bpp]
 
@@ -93,6 +94,12 @@ sws_case("4K nv12 -> 1080p nv12 bilinear", "nv12", 3840, 2160, "nv12", 1920, 108
 sws_case("4K nv12 -> rgb24 (convert)", "nv12", 3840, 2160, "rgb24", 3840, 2160)
 sws_case("4K rgb24 -> nv12", "rgb24", 3840, 2160, "nv12", 3840, 2160)
 sws_case("4K nv12 -> yuv420p (relayout)", "nv12", 3840, 2160, "yuv420p", 3840, 2160)
+sws_case("4K nv12 -> 1080p yuv444p", "nv12", 3840, 2160, "yuv444p", 1920, 1080)
+sws_case("4K nv12 -> yuv444p (chroma up)", "nv12", 3840, 2160, "yuv444p", 3840, 2160)
+sws_case("4K rgb24 -> yuv444p", "rgb24", 3840, 2160, "yuv444p", 3840, 2160)
+sws_case("4K rgb24 -> bgra (repack)", "rgb24", 3840, 2160, "bgra", 3840, 2160)
+sws_case("4K rgba -> bgr24 (repack)", "rgba", 3840, 2160, "bgr24", 3840, 2160)
+sws_case("4K rgb24 -> bgr24 (swap)", "rgb24", 3840, 2160, "bgr24", 3840, 2160)
 plane_case("4K Y plane transpose", "gmat_transpose", 3840, 2160, 1, 1)
 plane_case("4K UV plane transpose (bpp2)", "gmat_transpose", 1920, 1080, 2, 1)
 plane_case("4K rgb24 transpose", "gmat_transpose", 3840, 2160, 3, 1)
