@@ -45,6 +45,9 @@ inline int  bytes_per_pixel(int f)
 int sws_src_height(const GmatSwsContext *c);
 bool sws_shares_intermediate(const GmatSwsContext *c);
 void *sws_current_stream(const GmatSwsContext *c);
+// frames [0,n) through one launch per 32 frames when the context runs the 2:1 kernel: 1 taken, 0 not eligible, < 0 error
+int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
+                             uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream);
 hipEvent_t *sws_batch_events(GmatSwsContext *c);           // 9 lazily created events owned by the context   // two-kernel form: frames must not overlap
 
 inline int ceil_rshift(int a, int b) { return -((-a) >> b); }

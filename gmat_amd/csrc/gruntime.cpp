@@ -213,7 +213,23 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
         e = hipEventRecord(fork, s);
         for (int b = 1; b < nbranches && e == hipSuccess; b++) e = hipStreamWaitEvent(side[b], fork, 0);
     }
-    for (int f = 0; f < nframes && rr >= 0 && e == hipSuccess; f++) {
+    // contexts on the 2:1 kernel: each branch is one launch carrying a contiguous share of the frames
+    bool batched = nframes >= 2 * nbranches && e == hipSuccess;
+    for (int b = 0, f0 = 0; batched && b < nbranches && rr >= 0; b++) {
+        const int n = nframes / nbranches + (b < nframes % nbranches ? 1 : 0);
+        hipStream_t bs = b ? side[b] : s;
+        const int t = gmat::sws_scale_frames_batched(c, n, src_planes + 4 * f0, srcStride, dst_planes + 4 * f0, dstStride, bs);
+        if (t < 0) rr = t;
+        else if (t == 0) {
+            if (b == 0) { batched = false; break; }
+            for (int f = f0; f < f0 + n && rr >= 0; f++) {
+                gmat_sws_setStream(c, (void *)bs);
+                rr = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
+            }
+        }
+        f0 += n;
+    }
+    for (int f = 0; !batched && f < nframes && rr >= 0 && e == hipSuccess; f++) {
         const int b = f % nbranches;
         gmat_sws_setStream(c, b ? (void *)side[b] : stream);
         rr = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
@@ -259,7 +275,27 @@ int gmat_sws_scale_batch(GmatSwsContext *c, int nframes, const uint8_t *const *s
         for (int s = 1; s < nstreams; s++) GMAT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)streams[s], ev[0], 0));
     }
     int r = 0;
-    for (int f = 0; f < nframes && r >= 0; f++) {
+    // contexts on the 2:1 kernel: one launch per stream, each carrying a contiguous share of the frames (grid.y =
+    // frame) — no launch gaps and no half-empty last wave of blocks between frames
+    bool batched = nframes >= 2 * nstreams;
+    for (int s = 0, f0 = 0; batched && s < nstreams && r >= 0; s++) {
+        const int n = nframes / nstreams + (s < nframes % nstreams ? 1 : 0);
+        const int t = gmat::sws_scale_frames_batched(c, n, src_planes + 4 * f0, srcStride, dst_planes + 4 * f0, dstStride,
+                                                     (hipStream_t)streams[s]);
+        if (t < 0) r = t;
+        else if (t == 0) {
+            if (s > 0) {            // eligibility is a property of the context and the strides; later shares differ only in
+                for (int f = f0; f < f0 + n && r >= 0; f++) {   // pointer alignment: finish those frame by frame
+                    gmat_sws_setStream(c, streams[s]);
+                    r = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
+                }
+            } else {
+                batched = false;
+            }
+        }
+        f0 += n;
+    }
+    for (int f = 0; !batched && f < nframes && r >= 0; f++) {
         gmat_sws_setStream(c, streams[f % nstreams]);
         r = gmat_sws_scale(c, src_planes + 4 * f, srcStride, 0, srcH, dst_planes + 4 * f, dstStride);
     }

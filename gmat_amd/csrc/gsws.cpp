@@ -123,6 +123,7 @@ struct GmatSwsContext {
     uint8_t *inter = nullptr;     // RGB24 intermediate at source size for the two-kernel form
     int interStride = 0;
     const char *lastKernel = "";
+    int lastLaunchFrames = 1;
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
@@ -242,6 +243,113 @@ static int ensure_scaler(GmatSwsContext *c)
     }
     return init_scaler(c);
 }
+
+// ---- per-frame argument blocks of the single-context YUV scaler ------------------------------------------------
+static bool al4(const void *p, int s) { return (((uintptr_t)p | (uintptr_t)s) & 3) == 0; }
+
+static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], uint8_t *const dst[],
+                         const int dstStride[], YuvScaleArgs &ya)
+{
+    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
+    ya = c->yargs;
+    ya.y = src[0]; ya.ys = srcStride[0];
+    ya.u = src[1]; ya.us = srcStride[1];
+    ya.v = planarYuv ? src[2] : nullptr; ya.vs = planarYuv ? srcStride[2] : 0;
+    ya.srcAligned = al4(src[0], srcStride[0]) &&
+                    (ya.nv12 ? al4(src[1], srcStride[1])
+                             : ((((uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[1] |
+                                  (uintptr_t)srcStride[2]) & 1) == 0));
+    ya.srcAligned16 = ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 15) == 0) &&
+                      (ya.nv12 ? ((((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0)
+                               : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
+    ya.dst = dst[0]; ya.ds = dstStride[0];
+    const int ybpp = bytes_per_pixel(c->dstFormat);
+    ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
+    if (is_yuv8_src(c->dstFormat)) {
+        const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
+        if (!dst[1] || (!dnv && !dst[2])) return GMAT_ERR(EINVAL);
+        ya.dstU = dst[1]; ya.dsU = dstStride[1];
+        ya.dstV = dnv ? nullptr : dst[2]; ya.dsV = dnv ? 0 : dstStride[2];
+        // one flag for all planes: dword stores for luma and planar chroma, 8-byte stores for NV12 chroma
+        ya.dstAligned = al4(dst[0], dstStride[0]) &&
+                        (dnv ? ((((uintptr_t)dst[1] | (uintptr_t)dstStride[1]) & 7) == 0)
+                             : (al4(dst[1], dstStride[1]) && al4(dst[2], dstStride[2])));
+    }
+    ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
+    ya.prof = c->prof;
+    ya.rangeConv = c->rangeConv;
+    return 0;
+}
+
+// the 2:1 kernel reads whole 16-byte chunks: luma and NV12 chroma rows 16-byte, planar chroma rows 8-byte aligned
+static bool yuv2x_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, const uint8_t *const src[], const int srcStride[])
+{
+    return c->y2x.ok && !c->rangeConv && ya.srcAligned &&
+           ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0) &&
+           (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 && (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0));
+}
+
+static Yuv2xArgs make_yuv2x_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv2xArgs xa;
+    std::memset(&xa, 0, sizeof(xa));
+    xa.y = ya.y; xa.u = ya.u; xa.v = ya.v; xa.ys = ya.ys; xa.us = ya.us; xa.vs = ya.vs; xa.nv12 = ya.nv12;
+    xa.srcW = ya.srcW; xa.srcH = ya.srcH; xa.chrSrcW = ya.chrSrcW; xa.chrSrcH = ya.chrSrcH;
+    xa.dstW = ya.dstW; xa.dstH = ya.dstH;
+    xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
+    xa.dstU = ya.dstU; xa.dstV = ya.dstV; xa.dsU = ya.dsU; xa.dsV = ya.dsV; xa.dstNv12 = ya.dstNv12;
+    xa.yuvOut = c->y2x.yuvOut; xa.chrDstW = ya.chrDstW; xa.chrDstH = ya.chrDstH; xa.P = c->y2x.P;
+    xa.vrecC = (const int32_t *)c->dVrecC.p;
+    xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
+    xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;
+    xa.vrec = (const int32_t *)c->dVrec.p; xa.vLpairs = c->y2x.vLpairs; xa.vCpairs = c->y2x.vCpairs;
+    xa.rowStartL = ya.rowStartL; xa.rowCountL = ya.rowCountL;
+    xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
+    xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
+    xa.prof = ya.prof; xa.y2r = ya.y2r;
+    return xa;
+}
+
+namespace gmat {
+// Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
+// per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
+// caller then goes frame by frame), < 0 on error.
+int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
+                             uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
+{
+    if (!c || n < 2 || c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat) || c->fused != 2) return 0;
+    if (ensure_scaler(c) < 0 || c->fused != 2 || !c->y2x.ok || c->prof) return 0;
+    static const bool off = getenv("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
+    if (off) return 0;
+    YuvScaleArgs ya0;
+    for (int f = 0; f < n; f++) {
+        YuvScaleArgs ya;
+        if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
+        int r = prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya);
+        if (r < 0) return r;
+        if (!yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride)) return 0;
+        if (f == 0) ya0 = ya;
+        else if (ya.dstAligned != ya0.dstAligned) return 0;
+    }
+    const Yuv2xArgs xa = make_yuv2x_args(c, ya0);
+    c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+        Yuv2xFrames fr;
+        const int m = std::min(kYuv2xMaxFrames, n - f0);
+        std::memset(&fr, 0, sizeof(fr));
+        for (int i = 0; i < m; i++) {
+            const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+            uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+            fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = xa.nv12 ? nullptr : sp[2];
+            fr.dst[i] = dp[0]; fr.dstU[i] = xa.yuvOut ? dp[1] : nullptr; fr.dstV[i] = (xa.yuvOut && !xa.dstNv12) ? dp[2] : nullptr;
+        }
+        int r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m);
+        if (r < 0) return r;
+        c->lastLaunchFrames = m;
+    }
+    return 1;
+}
+} // namespace gmat
 
 namespace gmat {
 int sws_src_height(const GmatSwsContext *c) { return c ? c->srcH : 0; }
@@ -430,6 +538,7 @@ int gmat_sws_setProfileBuffer(GmatSwsContext *c, uint8_t *devbuf)
 }
 
 const char *gmat_sws_lastKernel(const GmatSwsContext *c) { return c ? c->lastKernel : ""; }
+int gmat_sws_lastLaunchFrames(const GmatSwsContext *c) { return c ? c->lastLaunchFrames : 0; }
 
 int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos, int cap, int *count)
 {
@@ -460,7 +569,6 @@ static YuvSrc yuv_src_of(int fmt, const uint8_t *const src[], const int stride[]
     return s;
 }
 
-static bool al4(const void *p, int s) { return (((uintptr_t)p | (uintptr_t)s) & 3) == 0; }
 
 int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
@@ -474,6 +582,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
         return GMAT_ERR(EINVAL);
     }
+    c->lastLaunchFrames = 1;
     const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
     if (is_yuv8_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
@@ -585,53 +694,10 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
         if (is_yuv8_src(c->srcFormat) && c->fused == 2) {
-            YuvScaleArgs ya = c->yargs;
-            ya.y = src[0]; ya.ys = srcStride[0];
-            ya.u = src[1]; ya.us = srcStride[1];
-            ya.v = planarYuv ? src[2] : nullptr; ya.vs = planarYuv ? srcStride[2] : 0;
-            ya.srcAligned = al4(src[0], srcStride[0]) &&
-                            (ya.nv12 ? al4(src[1], srcStride[1])
-                                     : ((((uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[1] |
-                                          (uintptr_t)srcStride[2]) & 1) == 0));
-            ya.srcAligned16 = ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 15) == 0) &&
-                              (ya.nv12 ? ((((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0)
-                                       : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
-            ya.dst = dst[0]; ya.ds = dstStride[0];
-            const int ybpp = bytes_per_pixel(c->dstFormat);
-            ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
-            if (is_yuv8_src(c->dstFormat)) {
-                const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
-                if (!dst[1] || (!dnv && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
-                ya.dstU = dst[1]; ya.dsU = dstStride[1];
-                ya.dstV = dnv ? nullptr : dst[2]; ya.dsV = dnv ? 0 : dstStride[2];
-                // one flag for all planes: dword stores for luma and planar chroma, 8-byte stores for NV12 chroma
-                ya.dstAligned = al4(dst[0], dstStride[0]) &&
-                                (dnv ? ((((uintptr_t)dst[1] | (uintptr_t)dstStride[1]) & 7) == 0)
-                                     : (al4(dst[1], dstStride[1]) && al4(dst[2], dstStride[2])));
-            }
-            ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
-            ya.prof = c->prof;
-            ya.rangeConv = c->rangeConv;
-            if (c->y2x.ok && !c->rangeConv && ya.srcAligned && ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] |
-                                                  (uintptr_t)srcStride[1]) & 15) == 0) &&
-                (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 &&
-                             (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0))) {
-                Yuv2xArgs xa;
-                std::memset(&xa, 0, sizeof(xa));
-                xa.y = ya.y; xa.u = ya.u; xa.v = ya.v; xa.ys = ya.ys; xa.us = ya.us; xa.vs = ya.vs; xa.nv12 = ya.nv12;
-                xa.srcW = ya.srcW; xa.srcH = ya.srcH; xa.chrSrcW = ya.chrSrcW; xa.chrSrcH = ya.chrSrcH;
-                xa.dstW = ya.dstW; xa.dstH = ya.dstH;
-                xa.dst = ya.dst; xa.ds = ya.ds; xa.dstFormat = ya.dstFormat; xa.dstAligned = ya.dstAligned;
-                xa.dstU = ya.dstU; xa.dstV = ya.dstV; xa.dsU = ya.dsU; xa.dsV = ya.dsV; xa.dstNv12 = ya.dstNv12;
-                xa.yuvOut = c->y2x.yuvOut; xa.chrDstW = ya.chrDstW; xa.chrDstH = ya.chrDstH; xa.P = c->y2x.P;
-                xa.vrecC = (const int32_t *)c->dVrecC.p;
-                xa.hLreg = (const int32_t *)c->dHLreg.p; xa.hCreg = (const int32_t *)c->dHCreg.p;
-                xa.w0L = c->y2x.w0L; xa.w0C = c->y2x.w0C;
-                xa.vrec = (const int32_t *)c->dVrec.p; xa.vLpairs = c->y2x.vLpairs; xa.vCpairs = c->y2x.vCpairs;
-                xa.rowStartL = ya.rowStartL; xa.rowCountL = ya.rowCountL;
-                xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
-                xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
-                xa.prof = ya.prof; xa.y2r = ya.y2r;
+            YuvScaleArgs ya;
+            if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
+            if (yuv2x_eligible(c, ya, src, srcStride)) {
+                const Yuv2xArgs xa = make_yuv2x_args(c, ya);
                 c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
                 r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, c->stream);
                 break;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "kernels.h"
 #include "px_math.h"
@@ -59,8 +60,14 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[(4 + P) & ~1], cons
 // P = coefficient pairs per output on the regular window of 2*P samples: 5 covers bicubic / bilinear (8 taps + the
 // parity slot), 8 covers Lanczos-3 (12 taps; the window origin is a multiple of 4 samples, which costs up to 3).
 template <bool YUVOUT, int P, int TILES>
-__global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, int rowsL, int rowsC)
+__global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFrames fr, int rowsL, int rowsC)
 {
+    // grid.y = frame of the batch: the plane pointers come from the kernel-argument segment (scalar loads)
+    {
+        const int f = blockIdx.y;
+        a.y = fr.y[f]; a.u = fr.u[f]; a.v = fr.v[f];
+        a.dst = fr.dst[f]; a.dstU = fr.dstU[f]; a.dstV = fr.dstV[f];
+    }
     // TILES vertically adjacent tiles per block, software-pipelined: the pixel (and record) loads of tile t+1 are
     // issued right after tile t's rows have been committed to LDS and stay in flight during its phases 2 and 3,
     // so only the first tile of a block waits for HBM.
@@ -492,8 +499,17 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     return 0;
 }
 
-int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream)
+int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames,
+                       int nframes)
 {
+    Yuv2xFrames one;
+    if (!frames) {
+        std::memset(&one, 0, sizeof(one));
+        one.y[0] = a.y; one.u[0] = a.u; one.v[0] = a.v; one.dst[0] = a.dst; one.dstU[0] = a.dstU; one.dstV[0] = a.dstV;
+        frames = &one; nframes = 1;
+    }
+    if (nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    const Yuv2xFrames &fr = *frames;
     // GMAT_SCALE_TILES=2 runs two vertically adjacent tiles per block with the second tile's loads in flight during
     // the first tile's phases 2 and 3.  Measured on MI355X: 12.3-12.4 us against 12.1 us for one tile per block
     // (82 VGPRs instead of 48, and five co-resident blocks per CU already overlap each other's load phases), so
@@ -502,9 +518,9 @@ int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, h
     const int tilesPerBlock = tilesEnv == 2 ? 2 : 1;
     const int ntiles = a.ntx * ((a.nty + tilesPerBlock - 1) / tilesPerBlock);
     if (ntiles <= 0) return 0;
-    const dim3 grid(a.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
-#define GMAT_X2(Y_, P_) do { if (tilesPerBlock == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 2>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC); \
-                              else hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 1>), grid, block, (size_t)ldsBytes, stream, a, rowsL, rowsC); } while (0)
+    const dim3 grid(a.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles, nframes), block(256);
+#define GMAT_X2(Y_, P_) do { if (tilesPerBlock == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 2>), grid, block, (size_t)ldsBytes, stream, a, fr, rowsL, rowsC); \
+                              else hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2x_kernel<Y_, P_, 1>), grid, block, (size_t)ldsBytes, stream, a, fr, rowsL, rowsC); } while (0)
     if (a.P == 5)      { if (a.yuvOut) GMAT_X2(true, 5); else GMAT_X2(false, 5); }
     else if (a.P == 8) { if (a.yuvOut) GMAT_X2(true, 8); else GMAT_X2(false, 8); }
     else return GMAT_ERR(EINVAL);

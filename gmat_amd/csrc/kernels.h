@@ -184,6 +184,15 @@ struct Yuv2xArgs {
     unsigned long long *prof;
     Yuv2RgbConsts y2r;
 };
+// Frames of one launch (grid.y = frame): the plane pointers travel in the kernel-argument segment, so a batch needs
+// no device-side pointer table.  Geometry, strides and alignment class are those of Yuv2xArgs for every frame.
+constexpr int kYuv2xMaxFrames = 32;
+struct Yuv2xFrames {
+    const uint8_t *y[kYuv2xMaxFrames], *u[kYuv2xMaxFrames], *v[kYuv2xMaxFrames];
+    uint8_t *dst[kYuv2xMaxFrames], *dstU[kYuv2xMaxFrames], *dstV[kYuv2xMaxFrames];
+};
 int  yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2xTables &t);
-int  launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream);
+// frames == nullptr: the one frame described by `a`
+int  launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream,
+                        const Yuv2xFrames *frames = nullptr, int nframes = 1);
 } // namespace gmat

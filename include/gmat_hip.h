@@ -122,6 +122,9 @@ GMAT_API int  gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *co
 GMAT_API int  gmat_sws_setProfileBuffer(GmatSwsContext *c, uint8_t *devbuf);
 /* name of the kernel the last gmat_sws_scale() launched last (static string) */
 GMAT_API const char *gmat_sws_lastKernel(const GmatSwsContext *c);
+/* number of frames that launch carried: 1, or up to 32 when gmat_sws_scale_batch / gmat_sws_graph_create put a
+ * stream's share of the frames into one launch of the 2:1 kernel */
+GMAT_API int  gmat_sws_lastLaunchFrames(const GmatSwsContext *c);
 
 /* ---- the plain-pointer back-end entry points, under the reference's own names ----------
  * libswscale core calls these (swscale_unscaled.c:1970-2012); CUstream == void*.          */

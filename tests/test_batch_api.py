@@ -1,0 +1,105 @@
+"""gmat_sws_scale_batch / gmat_sws_graph_create: many frames of one geometry per call.  Contexts on the 2:1 kernel send
+each stream's share of the frames as ONE launch (grid.y = frame, plane pointers in the kernel-argument segment);
+every other case goes frame by frame.  Each frame must equal what gmat_sws_scale / the oracle gives for it alone."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, ints, synth_planes
+
+
+def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, align, flags=SWS["bicubic"], graph=False):
+    lib = dev.lib
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags | SWS["hwaccel"], None)
+    assert c
+    srcs = [synth_planes(orc, src_fmt, sw, sh, seed=300 + 7 * f) for f in range(nframes)]
+    dsrc = [dev.upload_planes(s, align) for s in srcs]
+    ddst = [dev.planes_like(dst_fmt, dw, dh, align) for _ in range(nframes)]
+    sp = (C.c_void_p * (4 * nframes))()
+    dp = (C.c_void_p * (4 * nframes))()
+    for f in range(nframes):
+        for i, p in enumerate(dsrc[f]):
+            sp[4 * f + i] = p.ptr
+        for i, p in enumerate(ddst[f]):
+            dp[4 * f + i] = p.ptr
+    ss, ds = ints([p.stride for p in dsrc[0]]), ints([p.stride for p in ddst[0]])
+    streams = (C.c_void_p * nstreams)()
+    for s in range(nstreams):
+        h = C.c_void_p()
+        assert lib.gmat_stream_create(C.byref(h)) == 0
+        streams[s] = h
+    if graph:
+        ge = C.c_void_p()
+        assert lib.gmat_sws_graph_create(c, nframes, C.cast(sp, C.POINTER(C.c_void_p)), ss, C.cast(dp, C.POINTER(C.c_void_p)), ds,
+                                         streams[0], nstreams, C.byref(ge)) == 0
+        for p in ddst[0]:                                   # the warm launch wrote frame 0: make the replay prove itself
+            lib.gmat_memset(p.ptr, 0xCD, p.stride * p.rows)
+        assert lib.gmat_graph_launch(ge, streams[0]) == 0
+        lib.gmat_stream_sync(streams[0])
+        lib.gmat_graph_destroy(ge)
+    else:
+        r = lib.gmat_sws_scale_batch(c, nframes, C.cast(sp, C.POINTER(C.c_void_p)), ss, C.cast(dp, C.POINTER(C.c_void_p)), ds,
+                                     C.cast(streams, C.POINTER(C.c_void_p)), nstreams, 3)
+        assert r == nframes
+        lib.gmat_stream_sync(streams[0])
+    kernel = lib.gmat_sws_lastKernel(c).decode()
+    lib.gmat_device_sync()
+    for f in range(nframes):
+        want = orc.sws(srcs[f], sw, sh, src_fmt, dw, dh, dst_fmt, flags)
+        for i, (p, w) in enumerate(zip(ddst[f], want)):
+            assert (p.download() == w).all(), (f, i, kernel)
+            assert (p.download(with_padding=True)[:, p.row_bytes:] == 0xCD).all()
+    for s in range(nstreams):
+        lib.gmat_stream_destroy(streams[s])
+    for f in range(nframes):
+        for p in dsrc[f] + ddst[f]:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+    return kernel
+
+
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra", "nv12", "yuv420p"])
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+def test_batch_on_the_2to1_kernel(dev, orc, src_fmt, dst_fmt):
+    k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
+    assert k.startswith("scale_yuv2x_kernel"), k
+
+
+def test_batch_more_frames_than_one_launch_carries(dev, orc):
+    """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches"""
+    k = _run_batch(dev, orc, "nv12", "rgb24", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)
+    assert k.startswith("scale_yuv2x_kernel"), k
+
+
+@pytest.mark.parametrize("case", [("nv12", "rgb24", 260, 64, 130, 32, 1),       # rows not 16-byte aligned: generic kernel
+                                  ("nv12", "rgb24", 96, 40, 144, 60, 64),       # not 2:1
+                                  ("rgb24", "bgra", 96, 40, 50, 30, 64),        # RGB source
+                                  ("nv12", "rgb24", 64, 16, 64, 16, 64)])       # unscaled converter
+def test_batch_falls_back_frame_by_frame(dev, orc, case):
+    sf, df, sw, sh, dw, dh, align = case
+    if sf == "nv12" and sw == dw:
+        # the same-size converter is the nearest-chroma one: compare with gmat_sws_scale's own contract instead
+        lib = dev.lib
+        src = synth_planes(orc, sf, sw, sh, seed=300)
+        want = orc.yuv2rgb(src, sw, sh, sf, df)
+        d = dev.upload_planes(src, align)
+        got, _, _ = dev.sws(d, sw, sh, sf, dw, dh, df)
+        assert (got[0] == want).all()
+        return
+    k = _run_batch(dev, orc, sf, df, sw, sh, dw, dh, nframes=4, nstreams=2, align=align)
+    assert not k.startswith("scale_yuv2x_kernel"), k
+
+
+def test_batch_single_frame_and_more_streams_than_frames(dev, orc):
+    _run_batch(dev, orc, "nv12", "rgb24", 256, 64, 128, 32, nframes=1, nstreams=2, align=64)
+    _run_batch(dev, orc, "nv12", "rgb24", 256, 64, 128, 32, nframes=3, nstreams=4, align=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "nv12"])
+def test_graph_replay_of_a_batch(dev, orc, dst_fmt):
+    if dev.kind != "hip":
+        pytest.skip("graph capture needs the HIP runtime")
+    k = _run_batch(dev, orc, "nv12", dst_fmt, 256, 64, 128, 32, nframes=6, nstreams=2, align=64, graph=True)
+    assert k.startswith("scale_yuv2x_kernel"), k

@@ -14,7 +14,7 @@ from gmat_amd.lib import PIX_FMT, SWS, planes, ints
 lib = gmat_amd.load(os.environ["KBENCH_LIB"]) if os.environ.get("KBENCH_LIB") else gmat_amd.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
-NF = 16
+NF = int(os.environ.get('KBENCH_NF', '16'))
 stream = C.c_void_p(); lib.gmat_stream_create(C.byref(stream))
 
 
@@ -82,6 +82,37 @@ def plane_case(label, fn_name, w, h, bpp, *extra):
     print(f"{label:44s} {fn_name:28s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s ({alg / us / 1e3 / 80:4.1f}%)", flush=True)
 
 
+def batch_case(label, sf, sw, sh, df, dw, dh, nstreams, flags=SWS["bicubic"]):
+    """gmat_sws_scale_batch: NF frames per call; contexts on the 2:1 kernel put each stream's share into one launch"""
+    if ONLY and ONLY not in label: return
+    src = [torch.randint(0, 256, (frame_bytes(sf, sw, sh),), dtype=torch.uint8, device="cuda") for _ in range(NF)]
+    dst = [torch.empty((frame_bytes(df, dw, dh),), dtype=torch.uint8, device="cuda") for _ in range(NF)]
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], flags, None)
+    assert c, label
+    sp = (C.c_void_p * (4 * NF))(); dp = (C.c_void_p * (4 * NF))()
+    for i in range(NF):
+        a, ss = frame_ptrs(src[i], sf, sw, sh); b, ds = frame_ptrs(dst[i], df, dw, dh)
+        for k, v in enumerate(a): sp[4 * i + k] = v
+        for k, v in enumerate(b): dp[4 * i + k] = v
+    streams = (C.c_void_p * nstreams)(); streams[0] = stream
+    for k in range(1, nstreams):
+        h = C.c_void_p(); lib.gmat_stream_create(C.byref(h)); streams[k] = h
+
+    def f(i):
+        r = lib.gmat_sws_scale_batch(c, NF, C.cast(sp, C.POINTER(C.c_void_p)), ints(ss), C.cast(dp, C.POINTER(C.c_void_p)), ints(ds),
+                                     C.cast(streams, C.POINTER(C.c_void_p)), nstreams, 3)
+        assert r == NF, r
+    us = timeit(f) / NF
+    k = lib.gmat_sws_lastKernel(c).decode() + f" x{lib.gmat_sws_lastLaunchFrames(c)}"
+    lib.gmat_sws_freeContext(c)
+    alg = frame_bytes(sf, sw, sh) + frame_bytes(df, dw, dh)
+    print(f"{label:44s} {k:28s} {us:8.2f} us  {alg / us / 1e3:8.1f} GB/s ({alg / us / 1e3 / 80:4.1f}%)  {sw * sh / us / 1e3:7.1f} Gpix/s  per frame", flush=True)
+
+
+batch_case("4K nv12 -> 1080p rgb24, 16 frames/launch", "nv12", 3840, 2160, "rgb24", 1920, 1080, 1)
+batch_case("4K nv12 -> 1080p rgb24, 2 x 8 frames", "nv12", 3840, 2160, "rgb24", 1920, 1080, 2)
+batch_case("4K nv12 -> 1080p nv12, 16 frames/launch", "nv12", 3840, 2160, "nv12", 1920, 1080, 1)
+batch_case("4K nv12 -> 1080p rgb24 lanczos, 16 fr/launch", "nv12", 3840, 2160, "rgb24", 1920, 1080, 1, SWS["lanczos"])
 sws_case("4K nv12 -> 1080p rgb24 (headline)", "nv12", 3840, 2160, "rgb24", 1920, 1080)
 sws_case("4K nv12 -> 1080p rgb24 lanczos", "nv12", 3840, 2160, "rgb24", 1920, 1080, SWS["lanczos"])
 sws_case("4K nv12 -> 1080p nv12", "nv12", 3840, 2160, "nv12", 1920, 1080)
