@@ -19,8 +19,19 @@
 namespace gmat {
 
 constexpr int X2_TW = 64, X2_TH = 16;
-constexpr int X2_VR = 16, X2_VRC = 12;                  // ints per luma-row / chroma-row vertical record
-constexpr int X2_COLSL = 160, X2_COLSC = 80;           // LDS row lengths (int16 samples)
+constexpr int X2_VRC = 12;                              // ints per chroma-row vertical record (YUV output)
+constexpr int X2_COLSC = 80;                            // chroma LDS row length (int16 samples)
+// Per-variant sizes.  The luma LDS row holds the widest regular window, 15 + 2*63 + 2P samples: 151 for P = 5, so 152
+// (the last 16-sample chunk of a row is stored as its first half only), 160 for P = 8.  The per-output-row record is
+//   P = 5: [0..4] luma pairs  [5..6] chroma pairs  [8] luma window row  [9] chroma window row  [10],[11] start values
+//   P = 8: [0..7] luma pairs  [8..11] chroma pairs [12] ...             [13] ...               [14],[15]
+// Both exist to keep the P = 5 block at 27 136 B of LDS: hipOccupancyMaxActiveBlocksPerMultiprocessor steps from 6 to
+// 5 blocks per CU between 27 264 and 27 520 B on gfx950.  (Measured effect on the batched headline launch: none —
+// SQ_WAVE_CYCLES shows the same 4.3 resident blocks per CU on average either way)
+constexpr int x2_colsl(int P) { return P == 5 ? 152 : 160; }
+constexpr int x2_vr(int P) { return P == 5 ? 12 : 16; }
+constexpr int x2_vr_chroma(int P) { return P == 5 ? 5 : 8; }
+constexpr int x2_vr_misc(int P) { return P == 5 ? 8 : 12; }
 
 __device__ __forceinline__ unsigned x2pk(int lo, int hi) { return ((unsigned)lo & 0xFFFF) | ((unsigned)hi << 16); }
 
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
     const int eL = (wl - c0L) >> 1, eC = (wc - c0C) >> 1;       // window offset inside an LDS row, in dwords (even)
 
     unsigned short *ly = reinterpret_cast<unsigned short *>(lds_base);
+    constexpr int X2_COLSL = x2_colsl(P), X2_VR = x2_vr(P), VR_M = x2_vr_misc(P);
     unsigned short *lu = ly + rowsL * X2_COLSL;
     unsigned short *lv = lu + rowsC * X2_COLSC;
     int *hy = reinterpret_cast<int *>(lv + rowsC * X2_COLSC);
@@ -166,13 +178,13 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
             uint4 *d = reinterpret_cast<uint4 *>(ly + rowA * X2_COLSL + 16 * g);
             const uint2 p0 = x2_widen(R.va.x), p1 = x2_widen(R.va.y), p2 = x2_widen(R.va.z), p3 = x2_widen(R.va.w);
             d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-            d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+            if (X2_COLSL == 160 || g < 9) d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
         }
         if (act && rowB < R.nrL) {
             uint4 *d = reinterpret_cast<uint4 *>(ly + rowB * X2_COLSL + 16 * g);
             const uint2 p0 = x2_widen(R.vb.x), p1 = x2_widen(R.vb.y), p2 = x2_widen(R.vb.z), p3 = x2_widen(R.vb.w);
             d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
-            d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+            if (X2_COLSL == 160 || g < 9) d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
         }
         if (act && rowA < R.nrC) {
             // U samples are bytes 0 and 2 of each dword, V samples bytes 1 and 3
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
             const int xo = tx0 + 4 * q;
             {   // luma: 4 outputs of row yo
                 const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
                 const int vl8[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                 const int vpL = (rd.x - r0L) >> 1, lr = rd.z;
                 int Y[4] = {lr, lr, lr, lr};
@@ -319,7 +331,8 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
             if (yo < a.dstH && xo < a.dstW) {
                 // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
                 const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                           rc = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2], rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[3];
+                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
+                const int4 rc = P == 5 ? make_int4(rb.y, rb.z, 0, 0) : reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2];
                 const int vl[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                 const int vcc[4] = {rc.x, rc.y, rc.z, rc.w};
                 const int vpL = (rd.x - r0L) >> 1, vpC = (rd.y - r0C) >> 1, lr = rd.z, cr = rd.w;
@@ -455,30 +468,31 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         bool fits = true;
         for (int tc = 0; tc < t.ntx && fits; tc++) {
             const int wl = 2 * tc * X2_TW + t.w0L, wc = 2 * tc * (X2_TW / 2) + t.w0C;
-            fits = (wl - (wl & ~15)) + 2 * (X2_TW - 1) + 2 * cand <= X2_COLSL &&
+            fits = (wl - (wl & ~15)) + 2 * (X2_TW - 1) + 2 * cand <= x2_colsl(cand) &&
                    (wc - (wc & ~7)) + 2 * (X2_TW / 2 - 1) + 2 * cand <= X2_COLSC;
         }
         if (fits) { P = cand; break; }
     }
     if (!P) return 0;
-    const int bytes = g.rowsL * X2_COLSL * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
+    const int X2_VR = x2_vr(P), VR_C = x2_vr_chroma(P), VR_M = x2_vr_misc(P);
+    const int bytes = g.rowsL * x2_colsl(P) * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
                       2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * P * 4 + X2_TH * X2_VR * 4 +
                       (g.yuvOut ? (X2_TH / 2) * X2_VRC * 4 : 0);
     if (bytes > 64 * 1024) return 0;
     // per-output-row records for phase 3 (rows past dstH repeat the last one; never stored):
-    //   [0..6] luma pairs   [8..11] chroma pairs (RGB output)   [12] luma window row  [13] chroma window row
-    //   [14] luma accumulator start   [15] chroma accumulator start
+    // luma pairs, chroma pairs (RGB output), luma / chroma window row, luma / chroma accumulator start — at the
+    // positions x2_vr_chroma(P) / x2_vr_misc(P) give (layout at the top of this file)
     t.vrec.assign((size_t)t.nty * X2_TH * X2_VR, 0);
     for (int yy = 0; yy < t.nty * X2_TH; yy++) {
         const int y = std::min(yy, p.dstH - 1);
         int32_t *r = &t.vrec[(size_t)yy * X2_VR];
         for (int k = 0; k < g.vLumEff.pairs; k++) r[k] = g.vLumEff.packed[(size_t)y * g.vLumEff.pairs + k];
-        r[12] = g.vLumEff.pos_even[y];
-        r[14] = g.lumRound[y];
+        r[VR_M] = g.vLumEff.pos_even[y];
+        r[VR_M + 2] = g.lumRound[y];
         if (g.yuvOut) continue;                              // chroma rows have their own records (vrecC)
-        for (int k = 0; k < g.vChrEff.pairs; k++) r[8 + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
-        r[13] = g.vChrEff.pos_even[y];
-        r[15] = g.chrRound[y];
+        for (int k = 0; k < g.vChrEff.pairs; k++) r[VR_C + k] = g.vChrEff.packed[(size_t)y * g.vChrEff.pairs + k];
+        r[VR_M + 1] = g.vChrEff.pos_even[y];
+        r[VR_M + 3] = g.chrRound[y];
     }
     t.vrecC.clear();
     if (g.yuvOut) {
