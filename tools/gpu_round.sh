@@ -12,11 +12,11 @@ rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|gfx" | head -8 > $OU
 nproc > $OUT/nproc.txt
 echo "== pytest gpu" ; timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
 echo "== smoke" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
-echo "== bench" ; timeout 600 python bench.py --steps 30 --warmup 5 2>&1 | tail -3 | tee $OUT/bench.txt
-echo "== bench eager" ; timeout 600 python bench.py --steps 20 --warmup 3 --graph --no-cpu 2>&1 | tail -1 | tee $OUT/bench_eager.txt
+echo "== bench" ; timeout 600 python bench.py 2>&1 | tail -3 | tee $OUT/bench.txt
+echo "== bench eager" ; timeout 600 python bench.py --steps 50 --warmup 10 --graph --no-cpu 2>&1 | tail -1 | tee $OUT/bench_eager.txt
 echo "== rocprof" 
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/rocprof.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-chained --branches 1 > $OUT/rocprof_serial.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-chained --no-pipeline --branches 1 > $OUT/rocprof_serial.log 2>&1
 ls -R $OUT/prof | head -20
 find $OUT/prof -name "*kernel_stats*" | head -1 | xargs -r head -20
