@@ -244,6 +244,16 @@ static int ensure_scaler(GmatSwsContext *c)
     return init_scaler(c);
 }
 
+static YuvSrc yuv_src_of(int fmt, const uint8_t *const src[], const int stride[])
+{
+    YuvSrc s{};
+    s.y = src[0]; s.ys = stride[0];
+    s.u = src[1]; s.us = stride[1];
+    s.nv12 = fmt == GMAT_PIX_FMT_NV12;
+    if (!s.nv12) { s.v = src[2]; s.vs = stride[2]; }
+    return s;
+}
+
 // ---- per-frame argument blocks of the single-context YUV scaler ------------------------------------------------
 static bool al4(const void *p, int s) { return (((uintptr_t)p | (uintptr_t)s) & 3) == 0; }
 
@@ -317,10 +327,32 @@ namespace gmat {
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
 {
-    if (!c || n < 2 || c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat) || c->fused != 2) return 0;
-    if (ensure_scaler(c) < 0 || c->fused != 2 || !c->y2x.ok || c->prof) return 0;
+    if (!c || n < 2) return 0;
     static const bool off = getenv("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
     if (off) return 0;
+    if (c->mode == MODE_YUV2RGB) {
+        // the same-size converter: one launch per 32 frames, grid.z = frame
+        const bool planar = c->srcFormat == GMAT_PIX_FMT_YUV420P;
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                if (!sp[0] || !sp[1] || (planar && !sp[2]) || !dst_planes[4 * (f0 + i)]) return GMAT_ERR(EINVAL);
+                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = planar ? sp[2] : nullptr;
+                fr.dst[i] = dst_planes[4 * (f0 + i)];
+            }
+            c->lastKernel = "yuv2rgb_kernel";
+            int r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), fr.dst[0], dstStride[0], c->srcW, c->srcH,
+                                   c->dstFormat, c->y2r, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
+    if (c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat) || c->fused != 2) return 0;
+    if (ensure_scaler(c) < 0 || c->fused != 2 || !c->y2x.ok || c->prof) return 0;
     YuvScaleArgs ya0;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
@@ -557,16 +589,6 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
     if (coef) std::memcpy(coef, fb->coef.data(), (size_t)n * fb->taps * sizeof(int16_t));
     if (pos)  std::memcpy(pos, fb->pos.data(), (size_t)n * sizeof(int32_t));
     return fb->taps;
-}
-
-static YuvSrc yuv_src_of(int fmt, const uint8_t *const src[], const int stride[])
-{
-    YuvSrc s{};
-    s.y = src[0]; s.ys = stride[0];
-    s.u = src[1]; s.us = stride[1];
-    s.nv12 = fmt == GMAT_PIX_FMT_NV12;
-    if (!s.nv12) { s.v = src[2]; s.vs = stride[2]; }
-    return s;
 }
 
 

@@ -54,11 +54,17 @@ __device__ __forceinline__ void convert_row4(uint8_t *drow, unsigned y4, const C
     }
 }
 
-template <int OUT>
-__global__ __launch_bounds__(256) void yuv2rgb_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h,
+// BATCH: grid.z = frame, the plane pointers of up to 32 frames of one geometry come from the kernel-argument
+// segment (Yuv2xFrames); strides and the alignment class are shared.
+template <int OUT, bool BATCH>
+__global__ __launch_bounds__(256) void yuv2rgb_kernel(YuvSrc s, Yuv2xFrames fr, uint8_t *dst, int ds, int w, int h,
                                                       Yuv2RgbConsts k, int aligned)
 {
     constexpr int BPP = (OUT == OUT_RGBA || OUT == OUT_BGRA) ? 4 : 3;
+    if (BATCH) {
+        const int f = blockIdx.z;
+        s.y = fr.y[f]; s.u = fr.u[f]; s.v = fr.v[f]; dst = fr.dst[f];
+    }
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x >= w || y >= h) return;
@@ -226,25 +232,37 @@ __global__ __launch_bounds__(256) void repack_rgb_kernel(const uint8_t *src, int
 static inline bool aligned4(const void *p, int stride) { return (((uintptr_t)p | (uintptr_t)stride) & 3) == 0; }
 
 int launch_yuv2rgb(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, int dstFormat,
-                   const Yuv2RgbConsts &k, hipStream_t stream)
+                   const Yuv2RgbConsts &k, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (w <= 0 || h <= 0) return 0;
+    if (frames && (nframes < 1 || nframes > kYuv2xMaxFrames)) return GMAT_ERR(EINVAL);
     const int bpp = bytes_per_pixel(dstFormat);
     if (!bpp) return GMAT_ERR(ENOSYS);
     // vector path: 4-byte aligned luma/chroma rows and dword-aligned output groups
     // (4 px * 3 B = 12 B keeps dword alignment; rgba needs 16 B)
-    int aligned = aligned4(s.y, s.ys) && aligned4(dst, ds);
-    if (s.nv12) aligned = aligned && aligned4(s.u, s.us);
-    else        aligned = aligned && ((((uintptr_t)s.u | (uintptr_t)s.v | (uintptr_t)s.us | (uintptr_t)s.vs) & 1) == 0);
-    if (bpp == 4) aligned = aligned && ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
+    int aligned = 1;
+    for (int f = 0; f < (frames ? nframes : 1); f++) {
+        const uint8_t *py = frames ? frames->y[f] : s.y, *pu = frames ? frames->u[f] : s.u, *pv = frames ? frames->v[f] : s.v;
+        const uint8_t *pd = frames ? frames->dst[f] : dst;
+        int al = aligned4(py, s.ys) && aligned4(pd, ds);
+        if (s.nv12) al = al && aligned4(pu, s.us);
+        else        al = al && ((((uintptr_t)pu | (uintptr_t)pv | (uintptr_t)s.us | (uintptr_t)s.vs) & 1) == 0);
+        if (bpp == 4) al = al && ((((uintptr_t)pd | (uintptr_t)ds) & 15) == 0);
+        aligned = aligned && al;                // one class for the launch: the byte path is always correct
+    }
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8, frames ? nframes : 1);
+#define GMAT_Y2R(OUT_) do { \
+        if (frames) hipLaunchKernelGGL(HIP_KERNEL_NAME(yuv2rgb_kernel<OUT_, true>), grid, block, 0, stream, s, *frames, dst, ds, w, h, k, aligned); \
+        else { Yuv2xFrames none; none.y[0] = nullptr; \
+               hipLaunchKernelGGL(HIP_KERNEL_NAME(yuv2rgb_kernel<OUT_, false>), grid, block, 0, stream, s, none, dst, ds, w, h, k, aligned); } } while (0)
     switch (dstFormat) {
-    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(yuv2rgb_kernel<OUT_RGB24>, grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
-    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(yuv2rgb_kernel<OUT_BGR24>, grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
-    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(yuv2rgb_kernel<OUT_RGBA>,  grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
-    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(yuv2rgb_kernel<OUT_BGRA>,  grid, block, 0, stream, s, dst, ds, w, h, k, aligned); break;
+    case GMAT_PIX_FMT_RGB24: GMAT_Y2R(OUT_RGB24); break;
+    case GMAT_PIX_FMT_BGR24: GMAT_Y2R(OUT_BGR24); break;
+    case GMAT_PIX_FMT_RGBA:  GMAT_Y2R(OUT_RGBA); break;
+    case GMAT_PIX_FMT_BGRA:  GMAT_Y2R(OUT_BGRA); break;
     default: return GMAT_ERR(ENOSYS);
     }
+#undef GMAT_Y2R
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

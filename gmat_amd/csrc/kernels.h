@@ -14,9 +14,18 @@ struct YuvSrc {
     int nv12;                      // 1: interleaved chroma
 };
 
-// nearest-chroma yuv420 -> packed rgb, libswscale fixed-point arithmetic
+// Frames of one launch (one grid dimension = frame): the plane pointers travel in the kernel-argument segment, so a
+// batch needs no device-side pointer table.  Geometry, strides and alignment class are shared by every frame.
+constexpr int kYuv2xMaxFrames = 32;
+struct Yuv2xFrames {
+    const uint8_t *y[kYuv2xMaxFrames], *u[kYuv2xMaxFrames], *v[kYuv2xMaxFrames];
+    uint8_t *dst[kYuv2xMaxFrames], *dstU[kYuv2xMaxFrames], *dstV[kYuv2xMaxFrames];
+};
+
+// nearest-chroma yuv420 -> packed rgb, libswscale fixed-point arithmetic; frames != nullptr: nframes frames in one
+// launch (strides from src / dstStride, pointers from *frames)
 int launch_yuv2rgb(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h, int dstFormat,
-                   const Yuv2RgbConsts &k, hipStream_t stream);
+                   const Yuv2RgbConsts &k, hipStream_t stream, const Yuv2xFrames *frames = nullptr, int nframes = 1);
 // nv12 -> planar float rgb (value = u8 / 255.0f), plane stride = dstStride * h
 int launch_nv12_to_rgbpf32(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h,
                            const Yuv2RgbConsts &k, hipStream_t stream);
@@ -183,13 +192,6 @@ struct Yuv2xArgs {
     int ntx, nty, xcdRemap;
     unsigned long long *prof;
     Yuv2RgbConsts y2r;
-};
-// Frames of one launch (grid.y = frame): the plane pointers travel in the kernel-argument segment, so a batch needs
-// no device-side pointer table.  Geometry, strides and alignment class are those of Yuv2xArgs for every frame.
-constexpr int kYuv2xMaxFrames = 32;
-struct Yuv2xFrames {
-    const uint8_t *y[kYuv2xMaxFrames], *u[kYuv2xMaxFrames], *v[kYuv2xMaxFrames];
-    uint8_t *dst[kYuv2xMaxFrames], *dstU[kYuv2xMaxFrames], *dstV[kYuv2xMaxFrames];
 };
 int  yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2xTables &t);
 // frames == nullptr: the one frame described by `a`

@@ -275,8 +275,11 @@ GMAT_API int  gmat_sws_graph_create(GmatSwsContext *c, int nframes,
                                     const uint8_t *const *src_planes /* [nframes][4] */, const int srcStride[],
                                     uint8_t *const *dst_planes /* [nframes][4] */, const int dstStride[],
                                     void *stream, int nbranches, void **graph_exec);
-/* enqueue nframes independent frames in one call, frame f on streams[f % nstreams] (the context's own
- * stream is restored afterwards).  The two-kernel form uses streams[0] only.
+/* enqueue nframes independent frames of the context's geometry in one call (the context's own stream is restored
+ * afterwards).  A context that runs the 2:1 kernel (4:2:0 source, exact 2:1 down-scale, 16-byte aligned rows) gives
+ * each stream a contiguous share of the frames as ONE launch (grid.y = frame, at most 32 frames per launch, the
+ * plane pointers travel in the kernel arguments); every other context enqueues frame f on streams[f % nstreams].
+ * The same holds for the branches of gmat_sws_graph_create.  The two-kernel form uses streams[0] only.
  * flags: GMAT_BATCH_FORK makes streams[1..] wait for the work already queued on streams[0];
  *        GMAT_BATCH_JOIN makes streams[0] wait for the batch on every other stream, so an event recorded
  *        on streams[0] afterwards covers the whole batch. */

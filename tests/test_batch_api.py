@@ -72,21 +72,44 @@ def test_batch_more_frames_than_one_launch_carries(dev, orc):
     assert k.startswith("scale_yuv2x_kernel"), k
 
 
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra"])
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", [(64, 16, 64), (130, 34, 1), (36, 6, 4)])
+def test_batch_same_size_converter(dev, orc, src_fmt, dst_fmt, geom):
+    """the unscaled yuv -> rgb converter batches too (grid.z = frame); nearest-chroma yuv2rgb.c semantics"""
+    w, h, align = geom
+    lib = dev.lib
+    n = 5
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT[src_fmt], w, h, PIX_FMT[dst_fmt], SWS["bicubic"] | SWS["hwaccel"], None)
+    assert c
+    srcs = [synth_planes(orc, src_fmt, w, h, seed=400 + f) for f in range(n)]
+    dsrc = [dev.upload_planes(s, align) for s in srcs]
+    ddst = [dev.planes_like(dst_fmt, w, h, align) for _ in range(n)]
+    sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
+    for f in range(n):
+        for i, p in enumerate(dsrc[f]): sp[4 * f + i] = p.ptr
+        dp[4 * f] = ddst[f][0].ptr
+    st = C.c_void_p(); assert lib.gmat_stream_create(C.byref(st)) == 0
+    streams = (C.c_void_p * 1)(st)
+    r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
+                                 C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
+                                 C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
+    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n and lib.gmat_sws_lastKernel(c) == b"yuv2rgb_kernel"
+    lib.gmat_stream_sync(st)
+    for f in range(n):
+        assert (ddst[f][0].download() == orc.yuv2rgb(srcs[f], w, h, src_fmt, dst_fmt)).all(), f
+        assert (ddst[f][0].download(with_padding=True)[:, ddst[f][0].row_bytes:] == 0xCD).all()
+    lib.gmat_stream_destroy(st)
+    lib.gmat_sws_freeContext(c)
+    for f in range(n):
+        for p in dsrc[f] + ddst[f]: p.free()
+
+
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 260, 64, 130, 32, 1),       # rows not 16-byte aligned: generic kernel
                                   ("nv12", "rgb24", 96, 40, 144, 60, 64),       # not 2:1
-                                  ("rgb24", "bgra", 96, 40, 50, 30, 64),        # RGB source
-                                  ("nv12", "rgb24", 64, 16, 64, 16, 64)])       # unscaled converter
+                                  ("rgb24", "bgra", 96, 40, 50, 30, 64)])       # RGB source
 def test_batch_falls_back_frame_by_frame(dev, orc, case):
     sf, df, sw, sh, dw, dh, align = case
-    if sf == "nv12" and sw == dw:
-        # the same-size converter is the nearest-chroma one: compare with gmat_sws_scale's own contract instead
-        lib = dev.lib
-        src = synth_planes(orc, sf, sw, sh, seed=300)
-        want = orc.yuv2rgb(src, sw, sh, sf, df)
-        d = dev.upload_planes(src, align)
-        got, _, _ = dev.sws(d, sw, sh, sf, dw, dh, df)
-        assert (got[0] == want).all()
-        return
     k = _run_batch(dev, orc, sf, df, sw, sh, dw, dh, nframes=4, nstreams=2, align=align)
     assert not k.startswith("scale_yuv2x_kernel"), k
 
