@@ -33,6 +33,8 @@ inline bool is_packed_rgb(int f)
 inline bool is_yuv420(int f) { return f == GMAT_PIX_FMT_NV12 || f == GMAT_PIX_FMT_YUV420P; }
 // 8-bit YUV sources of the plane scaler: 4:2:0 and (source only) planar 4:4:4
 inline bool is_yuv8_src(int f) { return is_yuv420(f) || f == GMAT_PIX_FMT_YUV444P; }
+// 16-bit semi-planar 4:2:0 (interleaved U,V; P010: the 10 significant bits are the high ones)
+inline bool is_p01x(int f) { return f == GMAT_PIX_FMT_P010LE || f == GMAT_PIX_FMT_P016LE; }
 inline int  bytes_per_pixel(int f)
 {
     switch (f) {

@@ -37,6 +37,14 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
         L.offset[1] = (size_t)L.linesize[0] * h;
         L.total = L.offset[1] + (size_t)L.linesize[1] * ceil_rshift(h, 1);
         return 0;
+    case GMAT_PIX_FMT_P010LE:
+    case GMAT_PIX_FMT_P016LE:
+        // NV12's plane structure with 16-bit samples (hwcontext_cuda.c:38-52 lists both)
+        L.planes = 2;
+        L.linesize[0] = L.linesize[1] = align_up(2 * w, align);
+        L.offset[1] = (size_t)L.linesize[0] * h;
+        L.total = L.offset[1] + (size_t)L.linesize[1] * ceil_rshift(h, 1);
+        return 0;
     case GMAT_PIX_FMT_YUV420P:
         // hwcontext_cuda.c:188-193: linesize[1] = linesize[2] = linesize[0]/2
         L.planes = 3;
@@ -68,7 +76,7 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
 
 int plane_rows(int fmt, int plane, int h)
 {
-    if ((fmt == GMAT_PIX_FMT_NV12 || fmt == GMAT_PIX_FMT_YUV420P) && plane > 0) return ceil_rshift(h, 1);
+    if ((fmt == GMAT_PIX_FMT_NV12 || fmt == GMAT_PIX_FMT_YUV420P || is_p01x(fmt)) && plane > 0) return ceil_rshift(h, 1);
     return h;
 }
 
@@ -78,6 +86,8 @@ int plane_row_bytes(int fmt, int plane, int w)
     case GMAT_PIX_FMT_NV12:      return plane == 0 ? w : 2 * ceil_rshift(w, 1);
     case GMAT_PIX_FMT_YUV420P:   return plane == 0 ? w : ceil_rshift(w, 1);
     case GMAT_PIX_FMT_YUV444P:   return w;
+    case GMAT_PIX_FMT_P010LE:
+    case GMAT_PIX_FMT_P016LE:    return plane == 0 ? 2 * w : 4 * ceil_rshift(w, 1);
     case GMAT_PIX_FMT_RGBPF32LE: return 4 * w;
     default:                     return w * bytes_per_pixel(fmt);
     }

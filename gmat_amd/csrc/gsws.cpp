@@ -134,6 +134,9 @@ struct GmatSwsContext {
     }
 };
 
+// sources of the single-context plane scaler: 8-bit planar / semi-planar YUV and the 16-bit semi-planar P010LE / P016LE
+static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f); }
+
 static int init_yuv_scaler(GmatSwsContext *c)
 {
     if (c->yuvReady) return 0;
@@ -165,6 +168,11 @@ static int init_yuv_scaler(GmatSwsContext *c)
     a.dstW = c->dstW; a.dstH = c->dstH; a.chrDstW = c->planYuv.chrDstW;
     a.dstFormat = c->dstFormat;
     a.nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    if (is_p01x(c->srcFormat)) {
+        a.src16 = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : 16;
+        a.hShift = a.src16 - 1;                          // hScale16To15_c: sh = depth - 1 (swscale.c:93-119)
+        a.hBias = a.src16 == 16 ? (1 << 29) : 0;         // 32768 * 16384: undoes the -32768 of the P016 LDS image
+    }
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -228,7 +236,7 @@ static int init_rgb2yuv(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
-    if ((is_yuv420(c->srcFormat) && is_yuv8_src(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P) {
+    if ((is_yuv420(c->srcFormat) && is_yuv8_src(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -272,6 +280,12 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     ya.srcAligned16 = ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 15) == 0) &&
                       (ya.nv12 ? ((((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0)
                                : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
+    if (ya.src16) {
+        // 16-bit samples: rows and planes 2-byte aligned at least; dword loads when 4-byte aligned
+        if ((((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);
+        ya.srcAligned = al4(src[0], srcStride[0]) && al4(src[1], srcStride[1]);
+        ya.srcAligned16 = 0;
+    }
     ya.dst = dst[0]; ya.ds = dstStride[0];
     const int ybpp = bytes_per_pixel(c->dstFormat);
     ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
@@ -477,6 +491,12 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
+    } else if (is_p01x(srcFormat) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
+        // 16-bit semi-planar sources (scale_cuda's list, vf_scale_cuda.c:45-54) to any 8-bit destination, any size:
+        // libswscale has no special converter for them, the generic path's hScale16To15_c brings the samples to the
+        // same 15-bit lines an 8-bit source gives
+        c->mode = MODE_SCALE;
+        r = ensure_scaler(c);
     } else if (srcFormat == GMAT_PIX_FMT_YUV444P && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
         // planar 4:4:4 source (scale_cuda's format list, vf_scale_cuda.c:45-54): always the generic plane scaler —
         // even at the same size the chroma planes are filtered (2:1 for 4:2:0 outputs)
@@ -522,7 +542,7 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
-    if (!is_yuv8_src(c->srcFormat) || !is_yuv8_src(c->dstFormat)) {
+    if (!is_plane_src(c->srcFormat) || !is_yuv8_src(c->dstFormat)) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
@@ -543,7 +563,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_pos, int dst_h_chr_pos, int dst_v_chr_pos)
 {
     if (!c) return GMAT_ERR(EINVAL);
-    if (c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat)) return GMAT_ERR(ENOSYS);
+    if (c->mode != MODE_SCALE || !is_plane_src(c->srcFormat)) return GMAT_ERR(ENOSYS);
     const int np[4] = {src_h_chr_pos, src_v_chr_pos, dst_h_chr_pos, dst_v_chr_pos};
     for (int i = 0; i < 4; i++)
         if (np[i] < -513 || np[i] > 512) return GMAT_ERR(EINVAL);           // option range, options.c:67-70
@@ -556,7 +576,7 @@ int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_po
 int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
-    if (c->srcFormat == GMAT_PIX_FMT_YUV444P && fused != 2) return GMAT_ERR(ENOSYS);
+    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
     return 0;
@@ -576,7 +596,7 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 {
     if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
     const FilterBank *fb;
-    const ScalePlan &pl = (is_yuv8_src(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
+    const ScalePlan &pl = (is_plane_src(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
     switch (which) {
     case 0: fb = &pl.hLum; break;
     case 1: fb = &pl.hChr; break;
@@ -606,7 +626,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     }
     c->lastLaunchFrames = 1;
     const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
-    if (is_yuv8_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
+    if (is_plane_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
     int r = 0;
     switch (c->mode) {
@@ -715,7 +735,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     }
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
-        if (is_yuv8_src(c->srcFormat) && c->fused == 2) {
+        if (is_plane_src(c->srcFormat) && c->fused == 2) {
             YuvScaleArgs ya;
             if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
             if (yuv2x_eligible(c, ya, src, srcStride)) {

@@ -180,6 +180,56 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
     return true;
 }
 
+// phase 1 for 16-bit semi-planar sources (P010LE / P016LE): luma plane of 16-bit samples, chroma plane of interleaved
+// 16-bit (U, V) pairs.  The LDS image holds what hScale16To15_c multiplies (swscale.c:93-119):
+//   P010: sample >> 6 (p010LEToY_c / p010LEToUV_c, input.c:698-725) — 10 bits, non-negative as int16
+//   P016: the sample itself; 16 unsigned bits do not fit the signed v_dot2 operand, so the image holds sample - 32768
+//         (sample ^ 0x8000) and the horizontal accumulators start at 32768 * sum(coefficients) = 2^29 (YuvScaleArgs::hBias)
+// Two samples per dword when the rows are 4-byte aligned, else 16-bit loads; columns past the plane repeat the last one.
+__device__ __forceinline__ void yuv_phase1_src16(const YuvScaleArgs &a, int tid, int c0L, int ncL, int r0L, int nrL,
+                                                 int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
+                                                 unsigned short *lu, unsigned short *lv)
+{
+    const bool p010 = a.src16 == 10;
+    auto conv = [&](unsigned v) -> unsigned { return p010 ? (v >> 6) & 0x03FF03FFu : v ^ 0x80008000u; };   // both halves at once
+    {
+        const int ng = ncL >> 1, total = nrL * ng;           // items of 2 luma samples
+        for (int it = tid; it < total; it += 256) {
+            const int r = it / ng, cg = it - r * ng, col = c0L + 2 * cg;
+            const uint8_t *row = a.y + (size_t)min(r0L + r, a.srcH - 1) * a.ys;
+            unsigned v;
+            if (a.srcAligned && col + 2 <= a.srcW) {
+                v = *reinterpret_cast<const unsigned *>(row + 2 * col);
+            } else {
+                const unsigned s0 = *reinterpret_cast<const unsigned short *>(row + 2 * min(col, a.srcW - 1));
+                const unsigned s1 = *reinterpret_cast<const unsigned short *>(row + 2 * min(col + 1, a.srcW - 1));
+                v = s0 | (s1 << 16);
+            }
+            *reinterpret_cast<unsigned *>(ly + r * a.colsL + 2 * cg) = conv(v);
+        }
+    }
+    {
+        const int ng = ncC >> 1, total = nrC * ng;           // items of 2 chroma samples of each plane
+        for (int it = tid; it < total; it += 256) {
+            const int r = it / ng, cg = it - r * ng, cc = c0C + 2 * cg;
+            const uint8_t *row = a.u + (size_t)min(r0C + r, a.chrSrcH - 1) * a.us;
+            unsigned p0, p1;                                    // U | V << 16 of chroma samples cc, cc + 1
+            if (a.srcAligned && cc + 2 <= a.chrSrcW) {
+                const uint2 t = *reinterpret_cast<const uint2 *>(row + 4 * cc);     // 4-byte aligned: two dword loads
+                p0 = t.x; p1 = t.y;
+            } else {
+                const int k0 = min(cc, a.chrSrcW - 1), k1 = min(cc + 1, a.chrSrcW - 1);
+                const unsigned short *q0 = reinterpret_cast<const unsigned short *>(row + 4 * k0);
+                const unsigned short *q1 = reinterpret_cast<const unsigned short *>(row + 4 * k1);
+                p0 = q0[0] | ((unsigned)q0[1] << 16); p1 = q1[0] | ((unsigned)q1[1] << 16);
+            }
+            p0 = conv(p0); p1 = conv(p1);
+            *reinterpret_cast<unsigned *>(lu + r * a.colsC + 2 * cg) = (p0 & 0xFFFFu) | (p1 << 16);
+            *reinterpret_cast<unsigned *>(lv + r * a.colsC + 2 * cg) = (p0 >> 16) | (p1 & 0xFFFF0000u);
+        }
+    }
+}
+
 // MODE 0: packed RGB out, half chroma (LUT form)   1: packed RGB out, full chroma
 //      2: YUV 4:2:0 out (NV12 or YUV420P): the tile is TW x TH luma outputs plus the TW/2 x TH/2 chroma
 //         outputs under them; vChr is indexed by CHROMA row; yuv2planeX_8_c / yuv2nv12cX_c (output.c:400-450)
@@ -187,7 +237,7 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
 // LONG: horizontal filters longer than 2*kYMaxPairs taps (down-scale ratios beyond ~3.7:1).  A separate
 // instantiation: with the tail loops compiled into the common variant every geometry paid for them (the 2x
 // up-scale went from 38.7 to 47.3 us).
-template <int TW, int MODE, bool LONG>
+template <int TW, int MODE, bool LONG, bool SRC16>
 __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -262,7 +312,8 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
     // ================= phase 1 ================================================================
     {
         const bool fl = a.srcAligned && c0L + ncL <= a.srcW, fc = a.srcAligned && c0C + ncC <= a.chrSrcW;
-        if (fl && fc && a.srcAligned16 && yuv_phase1_16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv)) {}
+        if constexpr (SRC16) yuv_phase1_src16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+        else if (fl && fc && a.srcAligned16 && yuv_phase1_16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv)) {}
         else if (fl && fc) yuv_phase1<true, true>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
         else          yuv_phase1<false, false>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
     }
@@ -271,12 +322,14 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
     GMAT_STAMP(2);
 
     // ================= phase 2: horizontal filters ==============================================
+    // 8-bit sources: hScale8To15_c, sum >> 7.  16-bit sources: hScale16To15_c, (start + sum) >> (depth - 1)
+    const int HS = SRC16 ? a.hShift : 7, HB = SRC16 ? a.hBias : 0;
     {   // luma: item = (row pair, output column)
         const int xo = xo2;
         for (int rp = tid / TW; rp < (nrL >> 1); rp += 256 / TW) {
             const int *p0 = reinterpret_cast<const int *>(ly + (2 * rp) * a.colsL + lpos);
             const int *p1 = reinterpret_cast<const int *>(ly + (2 * rp + 1) * a.colsL + lpos);
-            int s0 = 0, s1 = 0;
+            int s0 = HB, s1 = HB;
 #pragma unroll
             for (int k = 0; k < kYMaxPairs; k++)
                 if (k < a.hLum.pairs) { s0 = dot2(p0[k], lc[k], s0); s1 = dot2(p1[k], lc[k], s1); }
@@ -284,7 +337,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                 const int cf = a.hLum.packed[(size_t)gx2 * a.hLum.pairs + k];
                 s0 = dot2(p0[k], cf, s0); s1 = dot2(p1[k], cf, s1);
             }
-            int l0 = min(s0 >> 7, 32767), l1 = min(s1 >> 7, 32767);
+            int l0 = min(s0 >> HS, 32767), l1 = min(s1 >> HS, 32767);
             if (a.rangeConv == 1) {          // lumRangeToJpeg_c, swscale.c:176-181 (applied to the h-scaled line, hscale.c:60)
                 l0 = (m24(min(l0, 30189), 19077) - 39057361) >> 14; l1 = (m24(min(l1, 30189), 19077) - 39057361) >> 14;
             } else if (a.rangeConv == 2) {   // lumRangeFromJpeg_c, :183-188
@@ -300,7 +353,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
             const int *u1 = reinterpret_cast<const int *>(lu + (2 * rp + 1) * a.colsC + cpos);
             const int *v0 = reinterpret_cast<const int *>(lv + (2 * rp) * a.colsC + cpos);
             const int *v1 = reinterpret_cast<const int *>(lv + (2 * rp + 1) * a.colsC + cpos);
-            int su0 = 0, su1 = 0, sv0 = 0, sv1 = 0;
+            int su0 = HB, su1 = HB, sv0 = HB, sv1 = HB;
 #pragma unroll
             for (int k = 0; k < kYMaxPairs; k++)
                 if (k < a.hChr.pairs) {
@@ -312,7 +365,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                 su0 = dot2(u0[k], cf, su0); su1 = dot2(u1[k], cf, su1);
                 sv0 = dot2(v0[k], cf, sv0); sv1 = dot2(v1[k], cf, sv1);
             }
-            int cu0 = min(su0 >> 7, 32767), cu1 = min(su1 >> 7, 32767), cv0 = min(sv0 >> 7, 32767), cv1 = min(sv1 >> 7, 32767);
+            int cu0 = min(su0 >> HS, 32767), cu1 = min(su1 >> HS, 32767), cv0 = min(sv0 >> HS, 32767), cv1 = min(sv1 >> HS, 32767);
             if (a.rangeConv == 1) {          // chrRangeToJpeg_c, swscale.c:157-164 (hscale.c:193)
                 cu0 = (m24(min(cu0, 30775), 4663) - 9289992) >> 12; cu1 = (m24(min(cu1, 30775), 4663) - 9289992) >> 12;
                 cv0 = (m24(min(cv0, 30775), 4663) - 9289992) >> 12; cv1 = (m24(min(cv1, 30775), 4663) - 9289992) >> 12;
@@ -500,7 +553,18 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
     const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
     const int yuvOut = is_yuv420(p.dstFormat) ? 1 : out444 ? 2 : 0;          // 1: 4:2:0   2: planar 4:4:4
-    if (!is_yuv8_src(p.srcFormat) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    if (is_p01x(p.srcFormat)) {
+        // the P016 image is biased by -32768, undone by a start value that assumes every horizontal row sums to
+        // 16384 (initFilter normalises exactly, utils.c:721-741); filters beyond 16 taps have no 16-bit variant
+        if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
+        for (const FilterBank *fb : {&p.hLum, &p.hChr})
+            for (int x = 0; x < fb->count; x++) {
+                int sum = 0;
+                for (int j = 0; j < fb->taps; j++) sum += fb->coef[(size_t)x * fb->taps + j];
+                if (sum != 16384) return GMAT_ERR(ENOSYS);
+            }
+    }
     if (p.hLum.pairs > 64 || p.hChr.pairs > 64) return GMAT_ERR(ENOSYS);      // 128 taps: ratios up to ~30:1 (bicubic)
     const int full = ((p.flags & GMAT_SWS_FULL_CHR_H_INT) || out444) ? 1 : 0;  // chroma tile as wide as the luma tile
     if (full ? p.chrDstW != p.dstW : p.chrDstW != (p.dstW + 1) / 2) return GMAT_ERR(ENOSYS);
@@ -592,9 +656,11 @@ int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t
     const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
     const size_t lds = (size_t)t.ldsBytes;
     const bool longH = a.hLum.pairs > kYMaxPairs || a.hChr.pairs > kYMaxPairs;
+    if (a.src16 && longH) return GMAT_ERR(ENOSYS);
 #define GMAT_LAUNCH_YUV(TW_, MODE_) \
-    do { if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true>), grid, block, lds, stream, a); \
-         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false>), grid, block, lds, stream, a); } while (0)
+    do { if (a.src16)  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, true>), grid, block, lds, stream, a); \
+         else if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true, false>), grid, block, lds, stream, a); \
+         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, false>), grid, block, lds, stream, a); } while (0)
     const int mode = t.yuvOut == 2 ? 3 : t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
     if (t.TW == 64) { if (mode == 3) GMAT_LAUNCH_YUV(64, 3); else if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
     else if (t.TW == 32) { if (mode == 3) GMAT_LAUNCH_YUV(32, 3); else if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }

@@ -37,6 +37,8 @@
  * Not covered by a reference golden value (pinned only by construction from pinned parts):
  * the yuv2rgb_full_* (FULL_CHR_H_INT) outputs, the Lanczos branch of initFilter, the nearest-
  * chroma frame walk of yuv2rgb_c_24_* (its tables are pinned by filter-colorlevels), ToUV_half,
+ * the P010LE / P016LE readers (p010LEToY_c / ToUV_c, three lines each; the hScale16To15_c they
+ * feed is pinned through the RGB sources), the 24 <-> 32 bit RGB re-packing (orc_rgb_repack),
  * hflip/vflip/crop/convolution (their FATE references are NUT-container md5s, which would need
  * the muxer restated).
  */

@@ -44,8 +44,10 @@ struct OrcSws {
 #define RGB2YUV_SHIFT 15    /* swscale_internal.h:452 */
 
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
+static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
-static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
+static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || is_p01x(f)) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
+static unsigned rl16(const uint8_t *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
 static int ceil_rshift(int a, int b) { return -((-a) >> b); }
 static int clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 static int clip_uintp2_30(int a)
@@ -136,7 +138,8 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     int scaler_mask = ORC_SWS_FAST_BILINEAR | ORC_SWS_BILINEAR | ORC_SWS_BICUBIC | 8 | ORC_SWS_POINT |
                       ORC_SWS_AREA | 0x40 | 0x80 | 0x100 | ORC_SWS_LANCZOS | 0x400;
 
-    if (!(is_rgb(src_fmt) || is_yuv(src_fmt)) || !(is_rgb(dst_fmt) || is_yuv(dst_fmt)))
+    /* P010LE / P016LE as SOURCES only (the 8-bit destinations keep the 15-bit intermediates: dstBpc <= 14) */
+    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) || !(is_rgb(dst_fmt) || is_yuv(dst_fmt)))
         return NULL;
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
@@ -291,6 +294,15 @@ static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int str
                                  (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
         }
         hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 13);
+    } else if (is_p01x(c->src_fmt)) {
+        /* p010LEToY_c (input.c:698-705): the 10 significant bits are the high ones, >> 6; P016LE has no converter
+         * on a little-endian host (input.c:1523-1528 sits under HAVE_BIGENDIAN): the 16-bit samples as they are.
+         * Then hScale16To15_c with sh = depth - 1 (swscale.c:93-119). */
+        const int p010 = c->src_fmt == ORC_PIX_P010LE;
+        int i;
+        for (i = 0; i < c->src_w; i++)
+            tmp[i] = (uint16_t)(p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i));
+        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, p010 ? 9 : 15);
     } else {
         hscale8(out, c->dst_w, row, c->h_lum, c->h_lum_pos, c->h_lum_size);
     }
@@ -330,6 +342,16 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
         }
         hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
         hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
+    } else if (is_p01x(c->src_fmt)) {
+        /* p010LEToUV_c / p016LEToUV_c (input.c:716-747): interleaved 16-bit U, V */
+        const uint8_t *row = src[1] + (long)y * stride[1];
+        const int p010 = c->src_fmt == ORC_PIX_P010LE;
+        for (i = 0; i < c->chr_src_w; i++) {
+            tmp_u[i] = (uint16_t)(p010 ? rl16(row + 4 * i) >> 6 : rl16(row + 4 * i));
+            tmp_v[i] = (uint16_t)(p010 ? rl16(row + 4 * i + 2) >> 6 : rl16(row + 4 * i + 2));
+        }
+        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, p010 ? 9 : 15);
+        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, p010 ? 9 : 15);
     } else if (c->src_fmt == ORC_PIX_NV12) {
         const uint8_t *row = src[1] + (long)y * stride[1];
         uint8_t *u8 = (uint8_t *)tmp_u, *v8 = (uint8_t *)tmp_v;

@@ -424,6 +424,26 @@ def test_filter_layer_scale_from_yuv444p(dev, orc):
         assert (a == b).all()
 
 
+@pytest.mark.parametrize("src_fmt", ["p010le", "p016le"])
+def test_filter_layer_scale_from_p01x(dev, orc, src_fmt):
+    """scale_hip on 16-bit semi-planar frames (scale_cuda's input list, vf_scale_cuda.c:45-54) to an 8-bit format,
+    and format_hip to the same; 8-bit frames go the other way through format_hip (planar8ToP01xleWrapper)"""
+    from harness import SWS
+    w, h = 128, 48
+    src = synth_planes(orc, src_fmt, w, h, 99)
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "format": "nv12"}, src, w, h, src_fmt)
+    assert (ow, oh) == (64, 24)
+    for a, b in zip(res, orc.sws(src, w, h, src_fmt, 64, 24, "nv12", SWS["bicubic"])):
+        assert (a == b).all()
+    res, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": "yuv420p"}, src, w, h, src_fmt)
+    for a, b in zip(res, orc.sws(src, w, h, src_fmt, w, h, "yuv420p", SWS["bicubic"])):
+        assert (a == b).all()
+    nv = synth_planes(orc, "nv12", w, h, 100)
+    up, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": src_fmt}, nv, w, h, "nv12")
+    assert (up[0].view(np.uint16) == nv[0].astype(np.uint16) * 257).all()
+    assert (up[1].view(np.uint16) == nv[1].astype(np.uint16) * 257).all()
+
+
 def test_filter_layer_yuv444p_frames(dev, orc):
     """scale_hip / format_hip with a planar 4:4:4 destination, then crop + flip + transpose on those frames"""
     from harness import SWS

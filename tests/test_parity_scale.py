@@ -348,6 +348,57 @@ def test_yuv444p_output_unaligned_and_range(dev, orc, align):
             p.free()
 
 
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p", "rgb24", "bgra"])
+@pytest.mark.parametrize("src_fmt", ["p010le", "p016le"])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (130, 50, 130, 50), (96, 40, 144, 60), (201, 91, 151, 67), (64, 34, 20, 11)])
+def test_p01x_sources(dev, orc, src_fmt, dst_fmt, geom):
+    """P010LE / P016LE sources (scale_cuda's list, vf_scale_cuda.c:45-54) to the 8-bit destinations, any size incl.
+    equal: p010LEToY_c / p010LEToUV_c (>> 6) or the 16-bit samples as they are, hScale16To15_c with sh = depth - 1
+    (swscale.c:93-119), then the same vertical / output stage as an 8-bit source.  Random 16-bit words: the low six
+    bits of P010 are not zero here, the high bit of P016 is exercised."""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=71)
+    for flags in ("bicubic", "bilinear"):
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags])
+        for align, extra in ((64, 0), (2, 2)):
+            d = dev.upload_planes(src, align, extra)
+            got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=align, dst_extra=extra)
+            assert kernel.startswith("scale_yuv_kernel"), kernel
+            for i, (g, wv) in enumerate(zip(got, want)):
+                bad = np.argwhere(g != wv)
+                assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel}, {flags}, align {align})"
+                assert (pads[i] == 0xCD).all()
+            for p in d:
+                p.free()
+
+
+def test_p01x_source_extremes_and_errors(dev, orc):
+    """all-ones and all-zero samples (the P016 image bias at both ends), Lanczos, range conversion; byte-aligned rows of
+    16-bit samples are refused"""
+    import ctypes as C
+    from harness import planes, ints
+    sw, sh, dw, dh = 64, 16, 48, 12
+    for fmt in ("p010le", "p016le"):
+        for val in (0x00, 0xFF):
+            src = [np.full(s, val, np.uint8) for s in [(sh, 2 * sw), (sh // 2, 2 * sw)]]
+            want = orc.sws(src, sw, sh, fmt, dw, dh, "nv12", SWS["lanczos"])
+            d = dev.upload_planes(src, 64)
+            got, _, _ = dev.sws(d, sw, sh, fmt, dw, dh, "nv12", SWS["lanczos"], dst_align=64)
+            assert all((g == w).all() for g, w in zip(got, want)), (fmt, val)
+            for p in d:
+                p.free()
+    c = dev.lib.gmat_sws_getContext(sw, sh, PIX_FMT["p010le"], dw, dh, PIX_FMT["nv12"], SWS["bicubic"], None)
+    assert c
+    s = dev.planes_like("p010le", sw, sh, 1, 1)            # odd strides
+    d = dev.planes_like("nv12", dw, dh, 64)
+    assert dev.lib.gmat_sws_scale(c, planes([p.ptr for p in s]), ints([p.stride for p in s]), 0, sh,
+                                  planes([p.ptr for p in d]), ints([p.stride for p in d])) < 0
+    assert dev.lib.gmat_sws_setFused(c, 1) < 0            # no convert-then-scale form for 16-bit sources
+    dev.lib.gmat_sws_freeContext(c)
+    for p in s + d:
+        p.free()
+
+
 @pytest.mark.parametrize("case", [("bgr24", "bgra", (86, 118, 66, 81), SWS["point"] | SWS["accurate_rnd"]),
                                   ("bgr24", "bgr24", (6, 97, 196, 67), SWS["point"] | SWS["full_chr_h_int"]),
                                   ("rgb24", "bgra", (158, 36, 257, 49), SWS["area"])])
