@@ -24,7 +24,7 @@ using namespace gmat;
 namespace {
 
 enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
-            MODE_RGB2YUV444, MODE_REPACK };
+            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY };
 
 struct DevBuf {
     void *p = nullptr;
@@ -149,7 +149,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
     const YuvScaleTiling &t = c->ytiling;
     const std::vector<int32_t> none(std::max(c->dstW, c->dstH), 0);
     a.chrDstH = c->planYuv.chrDstH;
-    a.dstNv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+    a.dstNv12 = c->dstFormat == GMAT_PIX_FMT_NV12 || c->dstFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma
+    a.dst16 = c->dstFormat == GMAT_PIX_FMT_P010LE;
     if ((r = c->yHLum.upload(c->planYuv.hLum, none, a.hLum)) < 0) return r;
     if ((r = c->yHChr.upload(c->planYuv.hChr, none, a.hChr)) < 0) return r;
     if ((r = c->yVLum.upload(t.vLumEff, t.lumRound, a.vLum)) < 0) return r;
@@ -236,7 +237,8 @@ static int init_rgb2yuv(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
-    if ((is_yuv420(c->srcFormat) && is_yuv8_src(c->dstFormat)) || c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) {
+    if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) ||
+        c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -289,7 +291,13 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     ya.dst = dst[0]; ya.ds = dstStride[0];
     const int ybpp = bytes_per_pixel(c->dstFormat);
     ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
-    if (is_yuv8_src(c->dstFormat)) {
+    if (c->dstFormat == GMAT_PIX_FMT_P010LE) {
+        if (!dst[1]) return GMAT_ERR(EINVAL);
+        if ((((uintptr_t)dst[0] | (uintptr_t)dst[1] | (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);
+        ya.dstU = dst[1]; ya.dsU = dstStride[1]; ya.dstV = nullptr; ya.dsV = 0;
+        // 8-byte luma stores, 16-byte chroma stores
+        ya.dstAligned = ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 7) == 0) && ((((uintptr_t)dst[1] | (uintptr_t)dstStride[1]) & 15) == 0);
+    } else if (is_yuv8_src(c->dstFormat)) {
         const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
         if (!dst[1] || (!dnv && !dst[2])) return GMAT_ERR(EINVAL);
         ya.dstU = dst[1]; ya.dsU = dstStride[1];
@@ -491,6 +499,13 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
+    } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
+        c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
+    } else if ((is_plane_src(srcFormat)) && dstFormat == GMAT_PIX_FMT_P010LE) {
+        // scaled (or 16-bit sourced) P010LE output: dstBpc = 10 keeps the 15-bit intermediates; yuv2p010l1_c /
+        // yuv2p010lX_c / yuv2p010cX_c (output.c:459-519).  Equal-size 8-bit 4:2:0 sources were taken above (MODE_DEPTH).
+        c->mode = MODE_SCALE;
+        r = ensure_scaler(c);
     } else if (is_p01x(srcFormat) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
         // 16-bit semi-planar sources (scale_cuda's list, vf_scale_cuda.c:45-54) to any 8-bit destination, any size:
         // libswscale has no special converter for them, the generic path's hScale16To15_c brings the samples to the
@@ -542,7 +557,7 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
-    if (!is_plane_src(c->srcFormat) || !is_yuv8_src(c->dstFormat)) {
+    if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
@@ -663,6 +678,13 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.k = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
         c->lastKernel = "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
+        break;
+    }
+    case MODE_PLANECOPY: {
+        if (!src[1] || !dst[1]) { r = GMAT_ERR(EINVAL); break; }
+        c->lastKernel = "copy2d_kernel";
+        r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], 2 * c->srcW, c->srcH, c->stream);
+        if (r >= 0) r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], 4 * ((c->srcW + 1) / 2), (c->srcH + 1) / 2, c->stream);
         break;
     }
     case MODE_REPACK: {

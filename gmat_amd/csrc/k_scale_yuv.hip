@@ -405,6 +405,17 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                 Y[2] = dot2(v.z, cf, Y[2]); Y[3] = dot2(v.w, cf, Y[3]);
             }
             if (YUVOUT) {
+                if (a.dst16) {
+                    // yuv2p010lX_c / l1_c: clip_uintp2((1 << 16 + sum) >> 17, 10) << 6; lr holds the 1 << 16
+                    unsigned short *d16 = reinterpret_cast<unsigned short *>(a.dst + (size_t)yo * a.ds) + xo;
+                    unsigned w[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) w[i] = (unsigned)min(max(Y[i] >> 17, 0), 1023) << 6;
+                    const int nx = min(4, a.dstW - xo);
+                    if (a.dstAligned && nx == 4) *reinterpret_cast<uint2 *>(d16) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+                    else for (int i = 0; i < nx; i++) d16[i] = (unsigned short)w[i];
+                    continue;
+                }
                 // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
                 uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
                 const unsigned o = (unsigned)clip_u8(Y[0] >> 19) | ((unsigned)clip_u8(Y[1] >> 19) << 8) |
@@ -495,10 +506,23 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
                 U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
                 V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
             }
+            const int nx = min(4, a.chrDstW - cx);
+            if (a.dst16) {                                          // yuv2p010cX_c: 16-bit U, V interleaved
+                unsigned w[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    w[i] = ((unsigned)min(max(U[i] >> 17, 0), 1023) << 6) | ((unsigned)min(max(V[i] >> 17, 0), 1023) << 22);
+                unsigned *d32 = reinterpret_cast<unsigned *>(a.dstU + (size_t)cy * a.dsU) + cx;
+                if (a.dstAligned && nx == 4) *reinterpret_cast<uint4 *>(d32) = make_uint4(w[0], w[1], w[2], w[3]);
+                else for (int i = 0; i < nx; i++) {
+                    unsigned short *d16 = reinterpret_cast<unsigned short *>(a.dstU + (size_t)cy * a.dsU) + 2 * (cx + i);
+                    d16[0] = (unsigned short)w[i]; d16[1] = (unsigned short)(w[i] >> 16);
+                }
+                continue;
+            }
             unsigned ub[4], vb[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8(U[i] >> 19); vb[i] = (unsigned)clip_u8(V[i] >> 19); }
-            const int nx = min(4, a.chrDstW - cx);
             if (a.dstNv12) {
                 uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
                 if (a.dstAligned && nx == 4) {
@@ -552,7 +576,8 @@ static void windows(const FilterBank &fb, int tile, int ntiles, int count, int a
 int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
     const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
-    const int yuvOut = is_yuv420(p.dstFormat) ? 1 : out444 ? 2 : 0;          // 1: 4:2:0   2: planar 4:4:4
+    const bool out10 = p.dstFormat == GMAT_PIX_FMT_P010LE;                   // 4:2:0 with 16-bit stores
+    const int yuvOut = (is_yuv420(p.dstFormat) || out10) ? 1 : out444 ? 2 : 0;   // 1: 4:2:0   2: planar 4:4:4
     if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (is_p01x(p.srcFormat)) {
         // the P016 image is biased by -32768, undone by a start value that assumes every horizontal row sums to
@@ -575,8 +600,10 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     // ---- vertical special forms (vscale.c:135-167) -> per-row start values + effective chroma taps
     const int sh_one = full ? (1 << 9) : (1 << 18);
     const int chr_bias = full ? -(128 << 19) : 0;
-    t.lumRound.assign(p.dstH, yuvOut ? (64 << 12) : sh_one);          // planar output: dither 64 (swscale.c:349-351)
-    t.chrRound.assign(p.chrDstH, yuvOut ? (64 << 12) : sh_one + chr_bias);
+    // planar 8-bit output: dither 64 (swscale.c:349-351), >> 19; P010: 1 << 16, >> 17 (output.c:481-519)
+    const int planar_one = out10 ? (1 << 16) : (64 << 12);
+    t.lumRound.assign(p.dstH, yuvOut ? planar_one : sh_one);
+    t.chrRound.assign(p.chrDstH, yuvOut ? planar_one : sh_one + chr_bias);
     t.vChrEff = p.vChr;
     t.vLumEff = p.vLum;
     const int lfs = p.vLum.taps, cfs = p.vChr.taps;
@@ -600,7 +627,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
         // planar output (vscale.c:30-105): a 1-tap filter goes through yuv2plane1_8_c, which does not read the
         // coefficient; NV12 chroma always takes yuv2nv12cX_c, which does
         if (lfs == 1) std::fill(t.vLumEff.coef.begin(), t.vLumEff.coef.end(), (int16_t)4096);
-        if (cfs == 1 && p.dstFormat != GMAT_PIX_FMT_NV12) std::fill(t.vChrEff.coef.begin(), t.vChrEff.coef.end(), (int16_t)4096);
+        if (cfs == 1 && p.dstFormat != GMAT_PIX_FMT_NV12 && !out10) std::fill(t.vChrEff.coef.begin(), t.vChrEff.coef.end(), (int16_t)4096);
     }
     pack_filter_pairs(t.vChrEff);
     pack_filter_pairs(t.vLumEff);

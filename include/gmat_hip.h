@@ -36,8 +36,11 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_BGRA      = 28,
     GMAT_PIX_FMT_HIP       = 117,   /* AV_PIX_FMT_CUDA's slot (pixfmt.h:225): opaque device frame */
     GMAT_PIX_FMT_P010LE    = 159,   /* pixfmt.h:276 — like NV12, 16-bit containers, data in the high bits */
-    GMAT_PIX_FMT_P016LE    = 170,   /* both: SOURCE for every 8-bit destination at any size (hScale16To15_c semantics);
-                                       DESTINATION of 8-bit 4:2:0 at equal size (planar8ToP01xleWrapper) */
+    GMAT_PIX_FMT_P016LE    = 170,   /* both: SOURCE for every 8-bit destination and for P010LE at any size
+                                       (hScale16To15_c semantics); DESTINATION of 8-bit 4:2:0 at equal size
+                                       (planar8ToP01xleWrapper); equal format and size: plane copy.  P010LE is also
+                                       a scaled destination of every YUV source (yuv2p010lX_c / cX_c); P016LE as a
+                                       scaled destination needs libswscale's 19-bit intermediates: -ENOSYS */
     GMAT_PIX_FMT_RGBPF32LE = 179,   /* GMAT addition, pixfmt.h:315 */
 };
 

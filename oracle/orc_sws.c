@@ -138,8 +138,10 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     int scaler_mask = ORC_SWS_FAST_BILINEAR | ORC_SWS_BILINEAR | ORC_SWS_BICUBIC | 8 | ORC_SWS_POINT |
                       ORC_SWS_AREA | 0x40 | 0x80 | 0x100 | ORC_SWS_LANCZOS | 0x400;
 
-    /* P010LE / P016LE as SOURCES only (the 8-bit destinations keep the 15-bit intermediates: dstBpc <= 14) */
-    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) || !(is_rgb(dst_fmt) || is_yuv(dst_fmt)))
+    /* P010LE / P016LE as sources; P010LE also as a destination (dstBpc = 10 <= 14 keeps the 15-bit intermediates;
+     * P016LE would need the 19-bit ones, hScale8To19_c / yuv2planeX_16_c, not restated) */
+    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) ||
+        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || dst_fmt == ORC_PIX_P010LE))
         return NULL;
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
@@ -537,6 +539,44 @@ static void out_nv12_chroma_row(uint8_t *dest, int w, const int16_t *filter, int
     }
 }
 
+/* P010 output, output.c:459-519 (output_pixel: clip to 10 bits, << 6, little endian):
+ *   yuv2p010l1_c   val = src + (1 << 4);            >> 5
+ *   yuv2p010lX_c   val = (1 << 16) + sum src*filter; >> 17
+ *   yuv2p010cX_c   the same per chroma plane, U and V interleaved — always the X form (vscale.c:83-85) */
+static void put_p010(uint8_t *d, int val, int shift)
+{
+    int v = val >> shift;
+    v = v < 0 ? 0 : v > 1023 ? 1023 : v;
+    v <<= 6;
+    d[0] = (uint8_t)(v & 0xFF); d[1] = (uint8_t)(v >> 8);
+}
+
+static void out_p010_luma_row(uint8_t *dest, int w, const int16_t *filter, int fs, const int16_t *const *src)
+{
+    int i, j;
+    if (fs == 1) {
+        for (i = 0; i < w; i++) put_p010(dest + 2 * i, src[0][i] + (1 << 4), 5);
+    } else {
+        for (i = 0; i < w; i++) {
+            int val = 1 << 16;
+            for (j = 0; j < fs; j++) val += src[j][i] * filter[j];
+            put_p010(dest + 2 * i, val, 17);
+        }
+    }
+}
+
+static void out_p010_chroma_row(uint8_t *dest, int w, const int16_t *filter, int fs,
+                                const int16_t *const *su, const int16_t *const *sv)
+{
+    int i, j;
+    for (i = 0; i < w; i++) {
+        int u = 1 << 16, v = 1 << 16;
+        for (j = 0; j < fs; j++) { u += su[j][i] * filter[j]; v += sv[j][i] * filter[j]; }
+        put_p010(dest + 4 * i, u, 17);
+        put_p010(dest + 4 * i + 2, v, 17);
+    }
+}
+
 int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
                        uint8_t *const dst[4], const int dst_stride[4], int y0, int y1)
 {
@@ -595,6 +635,11 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
         }
         if (c->dst_is_rgb) {
             out_packed_row(c, dst[0] + (long)y * dst_stride[0], y, lp, up, vp);
+        } else if (c->dst_fmt == ORC_PIX_P010LE) {
+            out_p010_luma_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size, c->v_lum_size, lp);
+            if (!(y & 1))
+                out_p010_chroma_row(dst[1] + (long)chr_y * dst_stride[1], cdw, c->v_chr + chr_y * c->v_chr_size,
+                                    c->v_chr_size, up, vp);
         } else {
             out_plane_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size,
                           c->v_lum_size, lp, 0);

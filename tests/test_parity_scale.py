@@ -372,6 +372,40 @@ def test_p01x_sources(dev, orc, src_fmt, dst_fmt, geom):
                 p.free()
 
 
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p", "yuv444p", "p010le", "p016le"])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (96, 40, 144, 60), (201, 91, 151, 67), (130, 50, 130, 50)])
+def test_p010_destination(dev, orc, src_fmt, geom):
+    """P010LE as a (scaled) destination: dstBpc = 10 keeps the 15-bit lines; yuv2p010l1_c / lX_c / cX_c
+    (output.c:459-519): clip_uintp2((1 << 16 + sum) >> 17, 10) << 6, chroma always in the X form"""
+    sw, sh, dw, dh = geom
+    if src_fmt in ("nv12", "yuv420p") and (sw, sh) == (dw, dh):
+        pytest.skip("equal-size 8-bit 4:2:0 -> P010 is the depth-expansion converter (test_parity_rgb2yuv.py)")
+    src = synth_planes(orc, src_fmt, sw, sh, seed=73)
+    for flags in ("bicubic", "point"):
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, "p010le", SWS[flags])
+        for align, extra in ((64, 0), (2, 2)):
+            if src_fmt == "p010le" and (sw, sh) == (dw, dh):
+                continue
+            d = dev.upload_planes(src, align, extra)
+            got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "p010le", SWS[flags], dst_align=align, dst_extra=extra)
+            assert kernel.startswith("scale_yuv_kernel"), kernel
+            for i, (g, wv) in enumerate(zip(got, want)):
+                bad = np.argwhere(g != wv)
+                assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel}, {flags}, align {align})"
+                assert (pads[i] == 0xCD).all()
+            for p in d:
+                p.free()
+
+
+@pytest.mark.parametrize("fmt", ["p010le", "p016le"])
+def test_p01x_equal_format_and_size_is_a_plane_copy(dev, orc, fmt):
+    w, h = 70, 22
+    src = synth_planes(orc, fmt, w, h, seed=74)
+    d = dev.upload_planes(src, 2, 2)
+    got, pads, kernel = dev.sws(d, w, h, fmt, w, h, fmt, dst_align=64)
+    assert all((g == s).all() for g, s in zip(got, src)) and all((p == 0xCD).all() for p in pads)
+
+
 def test_p01x_source_extremes_and_errors(dev, orc):
     """all-ones and all-zero samples (the P016 image bias at both ends), Lanczos, range conversion; byte-aligned rows of
     16-bit samples are refused"""
