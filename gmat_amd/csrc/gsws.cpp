@@ -373,20 +373,26 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
-    if (c->mode != MODE_SCALE || !is_yuv8_src(c->srcFormat) || c->fused != 2) return 0;
-    if (ensure_scaler(c) < 0 || c->fused != 2 || !c->y2x.ok || c->prof) return 0;
+    if (c->mode != MODE_SCALE || !is_plane_src(c->srcFormat) || c->fused != 2) return 0;
+    if (ensure_scaler(c) < 0 || c->fused != 2 || c->prof) return 0;
+    // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
+    // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
+    bool use2x = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
         int r = prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya);
         if (r < 0) return r;
-        if (!yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride)) return 0;
+        use2x = use2x && yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride);
         if (f == 0) ya0 = ya;
-        else if (ya.dstAligned != ya0.dstAligned) return 0;
+        else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
-    const Yuv2xArgs xa = make_yuv2x_args(c, ya0);
-    c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
+    const bool yuvDst = is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
+    const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
+    const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
+    c->lastKernel = !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -394,10 +400,11 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         for (int i = 0; i < m; i++) {
             const uint8_t *const *sp = src_planes + 4 * (f0 + i);
             uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-            fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = xa.nv12 ? nullptr : sp[2];
-            fr.dst[i] = dp[0]; fr.dstU[i] = xa.yuvOut ? dp[1] : nullptr; fr.dstV[i] = (xa.yuvOut && !xa.dstNv12) ? dp[2] : nullptr;
+            fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = planarSrc ? sp[2] : nullptr;
+            fr.dst[i] = dp[0]; fr.dstU[i] = yuvDst ? dp[1] : nullptr; fr.dstV[i] = planarDst ? dp[2] : nullptr;
         }
-        int r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m);
+        int r = use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
+                      : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
         c->lastLaunchFrames = m;
     }

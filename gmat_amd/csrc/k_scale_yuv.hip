@@ -238,8 +238,13 @@ __device__ __forceinline__ void yuv_phase1_src16(const YuvScaleArgs &a, int tid,
 // instantiation: with the tail loops compiled into the common variant every geometry paid for them (the 2x
 // up-scale went from 38.7 to 47.3 us).
 template <int TW, int MODE, bool LONG, bool SRC16>
-__global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a)
+__global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFrames fr)
 {
+    {   // grid.y = frame of the batch (1 for a single frame): plane pointers from the kernel-argument segment
+        const int f = blockIdx.y;
+        a.y = fr.y[f]; a.u = fr.u[f]; a.v = fr.v[f];
+        a.dst = fr.dst[f]; a.dstU = fr.dstU[f]; a.dstV = fr.dstV[f];
+    }
     HIP_DYNAMIC_SHARED(uint4, lds_base)
     constexpr bool FULL = MODE == 1 || MODE == 3;       // chroma at full output width
     constexpr bool YUVOUT = MODE >= 2;
@@ -676,18 +681,25 @@ const char *yuvscale_kernel_name(const YuvScaleTiling &t)
     return t.fullChroma ? "scale_yuv_kernel<32,full>" : "scale_yuv_kernel<32,half>";
 }
 
-int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream)
+int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     const int ntiles = t.ntx * t.nty;
     if (ntiles <= 0) return 0;
-    const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles), block(256);
+    Yuv2xFrames one;
+    if (!frames) {
+        one.y[0] = a.y; one.u[0] = a.u; one.v[0] = a.v; one.dst[0] = a.dst; one.dstU[0] = a.dstU; one.dstV[0] = a.dstV;
+        frames = &one; nframes = 1;
+    }
+    if (nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    const Yuv2xFrames &fr = *frames;
+    const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles, nframes), block(256);
     const size_t lds = (size_t)t.ldsBytes;
     const bool longH = a.hLum.pairs > kYMaxPairs || a.hChr.pairs > kYMaxPairs;
     if (a.src16 && longH) return GMAT_ERR(ENOSYS);
 #define GMAT_LAUNCH_YUV(TW_, MODE_) \
-    do { if (a.src16)  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, true>), grid, block, lds, stream, a); \
-         else if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true, false>), grid, block, lds, stream, a); \
-         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, false>), grid, block, lds, stream, a); } while (0)
+    do { if (a.src16)  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, true>), grid, block, lds, stream, a, fr); \
+         else if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true, false>), grid, block, lds, stream, a, fr); \
+         else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, false>), grid, block, lds, stream, a, fr); } while (0)
     const int mode = t.yuvOut == 2 ? 3 : t.yuvOut ? 2 : t.fullChroma ? 1 : 0;
     if (t.TW == 64) { if (mode == 3) GMAT_LAUNCH_YUV(64, 3); else if (mode == 2) GMAT_LAUNCH_YUV(64, 2); else if (mode == 1) GMAT_LAUNCH_YUV(64, 1); else GMAT_LAUNCH_YUV(64, 0); }
     else if (t.TW == 32) { if (mode == 3) GMAT_LAUNCH_YUV(32, 3); else if (mode == 2) GMAT_LAUNCH_YUV(32, 2); else if (mode == 1) GMAT_LAUNCH_YUV(32, 1); else GMAT_LAUNCH_YUV(32, 0); }

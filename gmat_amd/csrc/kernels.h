@@ -114,7 +114,9 @@ struct YuvScaleArgs {
 };
 
 int  yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t);
-int  launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream);
+// frames != nullptr: nframes frames of this geometry in one launch (grid.y = frame)
+int  launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t stream,
+                      const Yuv2xFrames *frames = nullptr, int nframes = 1);
 const char *yuvscale_kernel_name(const YuvScaleTiling &t);
 
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------

@@ -44,6 +44,7 @@ def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, al
         assert r == nframes
         lib.gmat_stream_sync(streams[0])
     kernel = lib.gmat_sws_lastKernel(c).decode()
+    _run_batch.last_frames = lib.gmat_sws_lastLaunchFrames(c)
     lib.gmat_device_sync()
     for f in range(nframes):
         want = orc.sws(srcs[f], sw, sh, src_fmt, dw, dh, dst_fmt, flags)
@@ -64,6 +65,17 @@ def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, al
 def test_batch_on_the_2to1_kernel(dev, orc, src_fmt, dst_fmt):
     k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
     assert k.startswith("scale_yuv2x_kernel"), k
+
+
+@pytest.mark.parametrize("case", [("nv12", "rgb24", 96, 40, 144, 60), ("yuv420p", "nv12", 200, 90, 80, 36),
+                                  ("yuv444p", "bgra", 64, 32, 64, 32), ("p010le", "nv12", 128, 48, 64, 24),
+                                  ("nv12", "p010le", 128, 48, 96, 40), ("nv12", "yuv444p", 64, 32, 64, 32)])
+def test_batch_on_the_generic_plane_scaler(dev, orc, case):
+    """geometries the 2:1 kernel does not take batch too: scale_yuv_kernel with grid.y = frame"""
+    sf, df, sw, sh, dw, dh = case
+    k = _run_batch(dev, orc, sf, df, sw, sh, dw, dh, nframes=5, nstreams=2, align=64)
+    assert k.startswith("scale_yuv_kernel"), k
+    assert _run_batch.last_frames == 2          # the second stream's share of 5 frames
 
 
 def test_batch_more_frames_than_one_launch_carries(dev, orc):
