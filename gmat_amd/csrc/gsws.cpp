@@ -339,6 +339,8 @@ static Yuv2xArgs make_yuv2x_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
     xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
     xa.prof = ya.prof; xa.y2r = ya.y2r;
+    static const bool noUni = getenv("GMAT_SCALE_NO_UNIFORM") != nullptr;
+    if (!noUni) xa.uni = c->y2x.uni;
     return xa;
 }
 

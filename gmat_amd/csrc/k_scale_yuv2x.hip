@@ -70,33 +70,12 @@ __device__ __forceinline__ uint4 x2_hfilter4(const int (&w0)[(4 + P) & ~1], cons
 // (yuv2planeX_8_c / yuv2nv12cX_c, output.c:400-450).
 // P = coefficient pairs per output on the regular window of 2*P samples: 5 covers bicubic / bilinear (8 taps + the
 // parity slot), 8 covers Lanczos-3 (12 taps; the window origin is a multiple of 4 samples, which costs up to 3).
-template <bool YUVOUT, int P, int TILES>
-__global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFrames fr, int rowsL, int rowsC)
+// UNI: the block's tile(s) lie in the interior of an exact 2:1 geometry (Yuv2xUniform): no coefficient tables, no
+// per-row records — the coefficients are kernel arguments (SGPR operands of the dot products), the window rows
+// closed forms.  The general path stages both in LDS.
+template <bool YUVOUT, int P, int TILES, bool UNI>
+__device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rowsC, int tcol, int trow0, uint4 *lds_base)
 {
-    // grid.y = frame of the batch: the plane pointers come from the kernel-argument segment (scalar loads)
-    {
-        const int f = blockIdx.y;
-        a.y = fr.y[f]; a.u = fr.u[f]; a.v = fr.v[f];
-        a.dst = fr.dst[f]; a.dstU = fr.dstU[f]; a.dstV = fr.dstV[f];
-    }
-    // TILES vertically adjacent tiles per block, software-pipelined: the pixel (and record) loads of tile t+1 are
-    // issued right after tile t's rows have been committed to LDS and stay in flight during its phases 2 and 3,
-    // so only the first tile of a block waits for HBM.
-    HIP_DYNAMIC_SHARED(uint4, lds_base)
-    int tcol, trow0;
-    {
-        const int ntyB = (a.nty + TILES - 1) / TILES, ntiles = a.ntx * ntyB;
-        int lin = blockIdx.x;
-        if (a.xcdRemap) {
-            const int chunk = (ntiles + 7) >> 3;
-            lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-        }
-        if (lin >= ntiles) return;
-        // the division runs on the VALU; readfirstlane tells the compiler the result is wave-uniform, so the
-        // per-tile table look-ups below become scalar loads and the tile address arithmetic scalar code
-        tcol = __builtin_amdgcn_readfirstlane(lin / ntyB);
-        trow0 = (lin - tcol * ntyB) * TILES;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long *prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
 #define X2_STAMP(i) do { if (prof && tid == 0 && tt == 0) prof[i] = __builtin_readcyclecounter(); } while (0)
@@ -121,7 +100,8 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
     const int q = tid % QW, yl = tid / QW;                        // 16 x 16 threads: one phase-3 item each
 
     // ---- phase 1, split in two: issue the loads of a tile into registers / commit them to LDS ----------------
-    constexpr int NL = X2_TW * P / 4, NC = (X2_TW / 2) * P / 4, NV = X2_TH * X2_VR / 4, NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
+    constexpr int NL = UNI ? 0 : X2_TW * P / 4, NC = UNI ? 0 : (X2_TW / 2) * P / 4, NV = UNI ? 0 : X2_TH * X2_VR / 4,
+                  NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
     constexpr int NT = NL + NC + NV + NVC;                       // 16-byte table chunks: one per thread, a second for
     static_assert(NT <= 512, "two table chunks per thread");      // the first NT - 256 threads of the widest variant
     const int rs = (lane * 205) >> 11, g = lane - rs * 10;       // lane / 10 for lane < 64: 6 rows x 10 groups per wave
@@ -225,7 +205,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
             const int nL = (nrL >> 1) * 16, nC = (nrC >> 1) * 8;      // luma items, chroma items per plane
             const int nLw = (nL + 63) & ~63;
             const int total = nLw + 2 * nC;
-            auto item = [&](const unsigned short *srcp, int colsS, int e, const int *cf, int *dstp, int rp, int g) {
+            auto item = [&](const unsigned short *srcp, int colsS, int e, const int *cf, const int *cfu, int *dstp, int rp, int g) {
                 const uint2 *r0p = reinterpret_cast<const uint2 *>(srcp + (2 * rp) * colsS);
                 const uint2 *r1p = reinterpret_cast<const uint2 *>(srcp + (2 * rp + 1) * colsS);
                 const int pair0 = 2 * g + (e >> 1);                       // 8-byte pair index of the window start
@@ -239,8 +219,12 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
                 }
     #pragma unroll
                 for (int i = 0; i < P; i++) {
-                    const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * P)[i];
-                    c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
+                    if constexpr (UNI) {
+                        c[i] = c[P + i] = c[2 * P + i] = c[3 * P + i] = cfu[i];      // the same row for the 4 outputs (SGPRs)
+                    } else {
+                        const int4 t = reinterpret_cast<const int4 *>(cf + 4 * g * P)[i];
+                        c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w;
+                    }
                 }
                 *reinterpret_cast<uint4 *>(dstp) = x2_hfilter4<P>(w0, w1, c);
             };
@@ -249,12 +233,12 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
                 if (wbase < nLw) {
                     if (it < nL) {
                         const int rp = it >> 4, g = it & 15;
-                        item(ly, X2_COLSL, eL, cL, hy + rp * X2_TW + 4 * g, rp, g);
+                        item(ly, X2_COLSL, eL, cL, a.uni.hL, hy + rp * X2_TW + 4 * g, rp, g);
                     }
                 } else {
                     const int j = it - nLw, pl = j >= nC, jj = pl ? j - nC : j;
                     const int rp = jj >> 3, g = jj & 7;
-                    item(lu + pl * (rowsC * X2_COLSC), X2_COLSC, eC, cC, hu + pl * ((rowsC >> 1) * (X2_TW / 2)) + rp * (X2_TW / 2) + 4 * g, rp, g);
+                    item(lu + pl * (rowsC * X2_COLSC), X2_COLSC, eC, cC, a.uni.hC, hu + pl * ((rowsC >> 1) * (X2_TW / 2)) + rp * (X2_TW / 2) + 4 * g, rp, g);
                 }
             }
         }
@@ -330,12 +314,24 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
             const int xo = tx0 + 4 * q;
             if (yo < a.dstH && xo < a.dstW) {
                 // this row's record: 5 luma pairs, 2 chroma pairs, window positions, accumulator start values
-                const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
-                const int4 rc = P == 5 ? make_int4(rb.y, rb.z, 0, 0) : reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2];
-                const int vl[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-                const int vcc[4] = {rc.x, rc.y, rc.z, rc.w};
-                const int vpL = (rd.x - r0L) >> 1, vpC = (rd.y - r0C) >> 1, lr = rd.z, cr = rd.w;
+                int vl[8], vcc[4], vpL, vpC, lr, cr;
+                if constexpr (UNI) {
+                    // interior rows: one vertical luma row, two chroma rows (by row parity), window rows in closed form
+    #pragma unroll
+                    for (int k = 0; k < 8; k++) vl[k] = a.uni.vL[k];
+                    const bool odd = (yo & 1) != 0;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) vcc[k] = odd ? a.uni.vC[1][k] : a.uni.vC[0][k];
+                    vpL = (2 * yo + a.uni.aL - r0L) >> 1; vpC = (((yo + a.uni.aC) & ~1) - r0C) >> 1;
+                    lr = a.uni.lr; cr = a.uni.cr;
+                } else {
+                    const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                               rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
+                    const int4 rc = P == 5 ? make_int4(rb.y, rb.z, 0, 0) : reinterpret_cast<const int4 *>(vr + yl * X2_VR)[2];
+                    vl[0] = ra.x; vl[1] = ra.y; vl[2] = ra.z; vl[3] = ra.w; vl[4] = rb.x; vl[5] = rb.y; vl[6] = rb.z; vl[7] = rb.w;
+                    vcc[0] = rc.x; vcc[1] = rc.y; vcc[2] = rc.z; vcc[3] = rc.w;
+                    vpL = (rd.x - r0L) >> 1; vpC = (rd.y - r0C) >> 1; lr = rd.z; cr = rd.w;
+                }
                 int Y[4] = {lr, lr, lr, lr}, U[2] = {cr, cr}, V[2] = {cr, cr};
     #pragma unroll
                 for (int k = 0; k < P; k++) {
@@ -410,6 +406,44 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
         }
     }
 #undef X2_STAMP
+}
+
+template <bool YUVOUT, int P, int TILES>
+__global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFrames fr, int rowsL, int rowsC)
+{
+    // grid.y = frame of the batch: the plane pointers come from the kernel-argument segment (scalar loads)
+    {
+        const int f = blockIdx.y;
+        a.y = fr.y[f]; a.u = fr.u[f]; a.v = fr.v[f];
+        a.dst = fr.dst[f]; a.dstU = fr.dstU[f]; a.dstV = fr.dstV[f];
+    }
+    // TILES vertically adjacent tiles per block, software-pipelined: the pixel (and record) loads of tile t+1 are
+    // issued right after tile t's rows have been committed to LDS and stay in flight during its phases 2 and 3,
+    // so only the first tile of a block waits for HBM.
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    int tcol, trow0;
+    {
+        const int ntyB = (a.nty + TILES - 1) / TILES, ntiles = a.ntx * ntyB;
+        int lin = blockIdx.x;
+        if (a.xcdRemap) {
+            const int chunk = (ntiles + 7) >> 3;
+            lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        }
+        if (lin >= ntiles) return;
+        // the division runs on the VALU; readfirstlane tells the compiler the result is wave-uniform, so the
+        // per-tile table look-ups below become scalar loads and the tile address arithmetic scalar code
+        tcol = __builtin_amdgcn_readfirstlane(lin / ntyB);
+        trow0 = (lin - tcol * ntyB) * TILES;
+    }
+#ifndef X2U_FORCE_GENERAL
+    if constexpr (!YUVOUT && TILES == 1) {
+        if (tcol >= a.uni.tcLo && tcol <= a.uni.tcHi && trow0 >= a.uni.trLo && trow0 <= a.uni.trHi && !a.prof) {   // block-uniform
+            x2_tiles<YUVOUT, P, TILES, true>(a, rowsL, rowsC, tcol, trow0, lds_base);
+            return;
+        }
+    }
+#endif
+    x2_tiles<YUVOUT, P, TILES, false>(a, rowsL, rowsC, tcol, trow0, lds_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,6 +539,55 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
             r[8] = g.vChrEff.pos_even[cy];
             r[9] = g.chrRound[cy];
         }
+    }
+    // ---- interior tiles with uniform coefficients (RGB output) --------------------------------------------------
+    t.uni = Yuv2xUniform();
+    if (!g.yuvOut && t.ntx >= 3 && t.nty >= 3) {
+        Yuv2xUniform u;
+        const int mc = t.ntx / 2, mr = t.nty / 2;                       // the middle tile provides the candidate rows
+        const int32_t *HL = &t.hLreg[(size_t)mc * X2_TW * P], *HC = &t.hCreg[(size_t)mc * (X2_TW / 2) * P];
+        auto col_uniform = [&](int tc) {
+            for (int x = 0; x < X2_TW; x++)
+                if (std::memcmp(&t.hLreg[((size_t)tc * X2_TW + x) * P], HL, P * 4)) return false;
+            for (int x = 0; x < X2_TW / 2; x++)
+                if (std::memcmp(&t.hCreg[((size_t)tc * (X2_TW / 2) + x) * P], HC, P * 4)) return false;
+            return true;
+        };
+        const int ym = mr * X2_TH;
+        const int lp = g.vLumEff.pairs, cp = g.vChrEff.pairs;
+        const int aL = g.vLumEff.pos_even[ym] - 2 * ym;
+        const int aC = g.vChrEff.pos_even[ym] - ym;                     // ym and pos_even are even
+        auto row_uniform = [&](int tr) {
+            for (int y = tr * X2_TH; y < (tr + 1) * X2_TH; y++) {
+                if (y >= p.dstH) return false;
+                const int yr = ym + (y & 1);                                        // reference row of the same parity
+                if (g.vLumEff.pos_even[y] != 2 * y + aL || g.vChrEff.pos_even[y] != ((y + aC) & ~1)) return false;
+                if (std::memcmp(&g.vLumEff.packed[(size_t)y * lp], &g.vLumEff.packed[(size_t)ym * lp], lp * 4)) return false;
+                if (std::memcmp(&g.vChrEff.packed[(size_t)y * cp], &g.vChrEff.packed[(size_t)yr * cp], cp * 4)) return false;
+                if (g.lumRound[y] != g.lumRound[ym] || g.chrRound[y] != g.chrRound[ym]) return false;
+            }
+            return true;
+        };
+        bool ok = lp <= 8 && cp <= 4 && col_uniform(mc) && row_uniform(mr) && (aL & 1) == 0;
+        // all four coefficient rows of a quad identical is implied by col_uniform (every column equals HL)
+        if (ok) {
+            u.tcLo = u.tcHi = mc; u.trLo = u.trHi = mr;
+            while (u.tcLo > 0 && col_uniform(u.tcLo - 1)) u.tcLo--;
+            while (u.tcHi + 1 < t.ntx && col_uniform(u.tcHi + 1)) u.tcHi++;
+            while (u.trLo > 0 && row_uniform(u.trLo - 1)) u.trLo--;
+            while (u.trHi + 1 < t.nty && row_uniform(u.trHi + 1)) u.trHi++;
+            for (int k = 0; k < P; k++) { u.hL[k] = HL[k]; u.hC[k] = HC[k]; }
+            for (int k = 0; k < lp; k++) u.vL[k] = g.vLumEff.packed[(size_t)ym * lp + k];
+            for (int k = 0; k < cp; k++) {
+                u.vC[0][k] = g.vChrEff.packed[(size_t)ym * cp + k];
+                u.vC[1][k] = g.vChrEff.packed[(size_t)(ym + 1) * cp + k];
+            }
+            u.aL = aL; u.aC = aC; u.lr = g.lumRound[ym]; u.cr = g.chrRound[ym];
+            t.uni = u;
+        }
+        if (getenv("GMAT_DEBUG_UNI"))
+            logf(LOG_ERROR, "yuv2x uniform tiles: cols [%d, %d] of %d, rows [%d, %d] of %d (P = %d)", t.uni.tcLo, t.uni.tcHi, t.ntx, t.uni.trLo,
+                 t.uni.trHi, t.nty, P);
     }
     t.yuvOut = g.yuvOut;
     t.P = P;

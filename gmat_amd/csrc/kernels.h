@@ -171,8 +171,20 @@ int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_
 // trimmed; border rows keep their folded coefficients), so the kernel needs no per-output positions:
 // 16-byte pixel loads, ds_read_b64 windows shared by 4 adjacent outputs, coefficient tables in LDS.
 namespace gmat {
+// Interior tiles of an exact 2:1 geometry: every output column has the same regular coefficient row and every output
+// row the same vertical one (borders fold differently), so a tile that touches no border needs no tables at all —
+// the coefficients travel as kernel arguments (SGPRs).  Tile columns [tcLo, tcHi] x tile rows [trLo, trHi]; empty
+// (tcLo > tcHi) when the geometry has no such structure.  RGB output only.
+struct Yuv2xUniform {
+    int tcLo = 1, tcHi = 0, trLo = 1, trHi = 0;
+    int hL[8] = {0}, hC[8] = {0};               // horizontal pairs (P used)
+    int vL[8] = {0};                            // vertical luma pairs; window row of output row y: 2 * y + aL (even)
+    int vC[2][4] = {{0}};                       // vertical chroma pairs by row parity; window row: (y + aC) & ~1
+    int aL = 0, aC = 0, lr = 0, cr = 0;         // lr / cr: accumulator start values
+};
 struct Yuv2xTables {
     int ok = 0;
+    Yuv2xUniform uni;
     int w0L = 0, w0C = 0;                       // regular window origins (multiples of 4)
     int ntx = 0, nty = 0;
     std::vector<int32_t> hLreg, hCreg;          // [ntx*64][5], [ntx*32][5] packed int16 pairs
@@ -197,6 +209,7 @@ struct Yuv2xArgs {
     int ntx, nty, xcdRemap;
     unsigned long long *prof;
     Yuv2RgbConsts y2r;
+    Yuv2xUniform uni;
 };
 int  yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2xTables &t);
 // frames == nullptr: the one frame described by `a`

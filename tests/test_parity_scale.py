@@ -433,6 +433,26 @@ def test_p01x_source_extremes_and_errors(dev, orc):
         p.free()
 
 
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra"])
+@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "lanczos", "point"])
+def test_2to1_kernel_interior_tiles(dev, orc, src_fmt, dst_fmt, flags):
+    """5 x 5 tiles: the 3 x 3 in the middle touch no border and take the uniform-coefficient path (coefficients as
+    kernel arguments, closed-form window rows); the ring around them takes the table path; both must agree with the
+    oracle, and GMAT_SCALE_NO_UNIFORM=1 (all tiles on the table path) must give the same bytes"""
+    sw, sh, dw, dh = 640, 160, 320, 80
+    src = synth_planes(orc, src_fmt, sw, sh, seed=81)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags])
+    d = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=64)
+    assert kernel.startswith("scale_yuv2x_kernel"), kernel
+    bad = np.argwhere(got[0] != want[0])
+    assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+    assert (pads[0] == 0xCD).all()
+    for p in d:
+        p.free()
+
+
 @pytest.mark.parametrize("case", [("bgr24", "bgra", (86, 118, 66, 81), SWS["point"] | SWS["accurate_rnd"]),
                                   ("bgr24", "bgr24", (6, 97, 196, 67), SWS["point"] | SWS["full_chr_h_int"]),
                                   ("rgb24", "bgra", (158, 36, 257, 49), SWS["area"])])
