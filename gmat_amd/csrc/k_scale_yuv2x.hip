@@ -126,8 +126,13 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
     };
     auto issue = [&](int trow, bool first) -> TileRegs {
         TileRegs R;
-        R.r0L = uniform_load(a.rowStartL, trow); R.nrL = uniform_load(a.rowCountL, trow);
-        R.r0C = uniform_load(a.rowStartC, trow); R.nrC = uniform_load(a.rowCountC, trow);
+        if constexpr (UNI) {           // interior tile rows: the windows step by a constant (checked on the host)
+            R.r0L = a.uni.r0L + trow * a.uni.dL; R.nrL = a.uni.nrL;
+            R.r0C = a.uni.r0C + trow * a.uni.dC; R.nrC = a.uni.nrC;
+        } else {
+            R.r0L = uniform_load(a.rowStartL, trow); R.nrL = uniform_load(a.rowCountL, trow);
+            R.r0C = uniform_load(a.rowStartC, trow); R.nrC = uniform_load(a.rowCountC, trow);
+        }
         // the table loads are ISSUED first and stored to LDS only after the pixel loads have been issued too, so a
         // block pays one memory round trip, not two (a load -> store loop in this place cost 7 %)
         R.tv0 = R.tv1 = make_uint4(0u, 0u, 0u, 0u);
@@ -583,6 +588,19 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
                 u.vC[1][k] = g.vChrEff.packed[(size_t)(ym + 1) * cp + k];
             }
             u.aL = aL; u.aC = aC; u.lr = g.lumRound[ym]; u.cr = g.chrRound[ym];
+            // row windows of the interior tile rows as r0 + trow * d (same count): shrink the row range to where that holds
+            u.dL = mr + 1 < t.nty ? g.rowStartL[mr + 1] - g.rowStartL[mr] : 0;
+            u.dC = mr + 1 < t.nty ? g.rowStartC[mr + 1] - g.rowStartC[mr] : 0;
+            u.r0L = g.rowStartL[mr] - mr * u.dL; u.r0C = g.rowStartC[mr] - mr * u.dC;
+            u.nrL = g.rowCountL[mr]; u.nrC = g.rowCountC[mr];
+            auto win_ok = [&](int tr) {
+                return g.rowStartL[tr] == u.r0L + tr * u.dL && g.rowCountL[tr] == u.nrL &&
+                       g.rowStartC[tr] == u.r0C + tr * u.dC && g.rowCountC[tr] == u.nrC;
+            };
+            int lo = mr, hi = mr;
+            while (lo > u.trLo && win_ok(lo - 1)) lo--;
+            while (hi < u.trHi && win_ok(hi + 1)) hi++;
+            u.trLo = lo; u.trHi = hi;
             t.uni = u;
         }
         if (getenv("GMAT_DEBUG_UNI"))

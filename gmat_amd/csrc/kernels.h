@@ -181,6 +181,7 @@ struct Yuv2xUniform {
     int vL[8] = {0};                            // vertical luma pairs; window row of output row y: 2 * y + aL (even)
     int vC[2][4] = {{0}};                       // vertical chroma pairs by row parity; window row: (y + aC) & ~1
     int aL = 0, aC = 0, lr = 0, cr = 0;         // lr / cr: accumulator start values
+    int r0L = 0, dL = 0, nrL = 0, r0C = 0, dC = 0, nrC = 0;   // source row window of tile row t: r0 + t * d, n rows
 };
 struct Yuv2xTables {
     int ok = 0;
