@@ -101,7 +101,7 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
 
     // ---- phase 1, split in two: issue the loads of a tile into registers / commit them to LDS ----------------
     constexpr int NL = UNI ? 0 : X2_TW * P / 4, NC = UNI ? 0 : (X2_TW / 2) * P / 4, NV = UNI ? 0 : X2_TH * X2_VR / 4,
-                  NVC = YUVOUT ? (X2_TH / 2) * X2_VRC / 4 : 0;
+                  NVC = (YUVOUT && !UNI) ? (X2_TH / 2) * X2_VRC / 4 : 0;
     constexpr int NT = NL + NC + NV + NVC;                       // 16-byte table chunks: one per thread, a second for
     static_assert(NT <= 512, "two table chunks per thread");      // the first NT - 256 threads of the widest variant
     const int rs = (lane * 205) >> 11, g = lane - rs * 10;       // lane / 10 for lane < 64: 6 rows x 10 groups per wave
@@ -255,10 +255,17 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
         if constexpr (YUVOUT) {
             const int xo = tx0 + 4 * q;
             {   // luma: 4 outputs of row yo
-                const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
-                           rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
-                const int vl8[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-                const int vpL = (rd.x - r0L) >> 1, lr = rd.z;
+                int vl8[8], vpL, lr;
+                if constexpr (UNI) {
+    #pragma unroll
+                    for (int k = 0; k < 8; k++) vl8[k] = a.uni.vL[k];
+                    vpL = (2 * yo + a.uni.aL - r0L) >> 1; lr = a.uni.lr;
+                } else {
+                    const int4 ra = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[0], rb = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[1],
+                               rd = reinterpret_cast<const int4 *>(vr + yl * X2_VR)[VR_M / 4];
+                    vl8[0] = ra.x; vl8[1] = ra.y; vl8[2] = ra.z; vl8[3] = ra.w; vl8[4] = rb.x; vl8[5] = rb.y; vl8[6] = rb.z; vl8[7] = rb.w;
+                    vpL = (rd.x - r0L) >> 1; lr = rd.z;
+                }
                 int Y[4] = {lr, lr, lr, lr};
     #pragma unroll
                 for (int k = 0; k < P; k++) {
@@ -283,12 +290,19 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
                 // the U and V halves of an NV12 dword meet through one cross-lane exchange (lanes l and l ^ 16)
                 const int pl = yl & 1, cyl = yl >> 1;
                 const int cy = (ty0 >> 1) + cyl, cx = tcx0 + 2 * q;
-                const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[1],
-                           cc3 = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[2];
-                const int vcp[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-                const int vp = (cc3.x - r0C) >> 1;
+                int vcp[8], vp, crnd;
+                if constexpr (UNI) {
+    #pragma unroll
+                    for (int k = 0; k < 8; k++) vcp[k] = a.uni.vCy[k];
+                    vp = (2 * cy + a.uni.aCy - r0C) >> 1; crnd = a.uni.cr;
+                } else {
+                    const int4 ca = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[0], cb = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[1],
+                               cc3 = reinterpret_cast<const int4 *>(vrc + cyl * X2_VRC)[2];
+                    vcp[0] = ca.x; vcp[1] = ca.y; vcp[2] = ca.z; vcp[3] = ca.w; vcp[4] = cb.x; vcp[5] = cb.y; vcp[6] = cb.z; vcp[7] = cb.w;
+                    vp = (cc3.x - r0C) >> 1; crnd = cc3.y;
+                }
                 const int *hp = pl ? hv : hu;
-                int C0 = cc3.y, C1 = cc3.y;
+                int C0 = crnd, C1 = crnd;
     #pragma unroll
                 for (int k = 0; k < P; k++) {
                     if (k < a.vCpairs) {
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(256) void scale_yuv2x_kernel(Yuv2xArgs a, Yuv2xFram
         trow0 = (lin - tcol * ntyB) * TILES;
     }
 #ifndef X2U_FORCE_GENERAL
-    if constexpr (!YUVOUT && TILES == 1) {
+    if constexpr (TILES == 1) {
         if (tcol >= a.uni.tcLo && tcol <= a.uni.tcHi && trow0 >= a.uni.trLo && trow0 <= a.uni.trHi && !a.prof) {   // block-uniform
             x2_tiles<YUVOUT, P, TILES, true>(a, rowsL, rowsC, tcol, trow0, lds_base);
             return;
@@ -547,7 +561,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     }
     // ---- interior tiles with uniform coefficients (RGB output) --------------------------------------------------
     t.uni = Yuv2xUniform();
-    if (!g.yuvOut && t.ntx >= 3 && t.nty >= 3) {
+    if (t.ntx >= 3 && t.nty >= 3) {
         Yuv2xUniform u;
         const int mc = t.ntx / 2, mr = t.nty / 2;                       // the middle tile provides the candidate rows
         const int32_t *HL = &t.hLreg[(size_t)mc * X2_TW * P], *HC = &t.hCreg[(size_t)mc * (X2_TW / 2) * P];
@@ -561,19 +575,31 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         const int ym = mr * X2_TH;
         const int lp = g.vLumEff.pairs, cp = g.vChrEff.pairs;
         const int aL = g.vLumEff.pos_even[ym] - 2 * ym;
-        const int aC = g.vChrEff.pos_even[ym] - ym;                     // ym and pos_even are even
+        // vertical chroma: indexed by OUTPUT row for RGB output (window row (y + aC) & ~1, the pair row alternates with
+        // the parity of y), by CHROMA row for 4:2:0 output (window row 2 * cy + aCy, one pair row)
+        const int cym = ym / 2;
+        const int aC = g.yuvOut ? 0 : g.vChrEff.pos_even[ym] - ym;      // ym and pos_even are even
+        const int aCy = g.yuvOut ? g.vChrEff.pos_even[cym] - 2 * cym : 0;
         auto row_uniform = [&](int tr) {
             for (int y = tr * X2_TH; y < (tr + 1) * X2_TH; y++) {
                 if (y >= p.dstH) return false;
-                const int yr = ym + (y & 1);                                        // reference row of the same parity
-                if (g.vLumEff.pos_even[y] != 2 * y + aL || g.vChrEff.pos_even[y] != ((y + aC) & ~1)) return false;
+                if (g.vLumEff.pos_even[y] != 2 * y + aL) return false;
                 if (std::memcmp(&g.vLumEff.packed[(size_t)y * lp], &g.vLumEff.packed[(size_t)ym * lp], lp * 4)) return false;
-                if (std::memcmp(&g.vChrEff.packed[(size_t)y * cp], &g.vChrEff.packed[(size_t)yr * cp], cp * 4)) return false;
-                if (g.lumRound[y] != g.lumRound[ym] || g.chrRound[y] != g.chrRound[ym]) return false;
+                if (g.lumRound[y] != g.lumRound[ym]) return false;
+                if (!g.yuvOut) {
+                    const int yr = ym + (y & 1);                                    // reference row of the same parity
+                    if (g.vChrEff.pos_even[y] != ((y + aC) & ~1) || g.chrRound[y] != g.chrRound[ym]) return false;
+                    if (std::memcmp(&g.vChrEff.packed[(size_t)y * cp], &g.vChrEff.packed[(size_t)yr * cp], cp * 4)) return false;
+                }
+            }
+            for (int cy = tr * (X2_TH / 2); g.yuvOut && cy < (tr + 1) * (X2_TH / 2); cy++) {
+                if (cy >= p.chrDstH) return false;
+                if (g.vChrEff.pos_even[cy] != 2 * cy + aCy || g.chrRound[cy] != g.chrRound[cym]) return false;
+                if (std::memcmp(&g.vChrEff.packed[(size_t)cy * cp], &g.vChrEff.packed[(size_t)cym * cp], cp * 4)) return false;
             }
             return true;
         };
-        bool ok = lp <= 8 && cp <= 4 && col_uniform(mc) && row_uniform(mr) && (aL & 1) == 0;
+        bool ok = lp <= 8 && cp <= (g.yuvOut ? 8 : 4) && col_uniform(mc) && row_uniform(mr) && (aL & 1) == 0 && (aCy & 1) == 0;
         // all four coefficient rows of a quad identical is implied by col_uniform (every column equals HL)
         if (ok) {
             u.tcLo = u.tcHi = mc; u.trLo = u.trHi = mr;
@@ -584,10 +610,14 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
             for (int k = 0; k < P; k++) { u.hL[k] = HL[k]; u.hC[k] = HC[k]; }
             for (int k = 0; k < lp; k++) u.vL[k] = g.vLumEff.packed[(size_t)ym * lp + k];
             for (int k = 0; k < cp; k++) {
-                u.vC[0][k] = g.vChrEff.packed[(size_t)ym * cp + k];
-                u.vC[1][k] = g.vChrEff.packed[(size_t)(ym + 1) * cp + k];
+                if (g.yuvOut) {
+                    u.vCy[k] = g.vChrEff.packed[(size_t)cym * cp + k];
+                } else {
+                    u.vC[0][k] = g.vChrEff.packed[(size_t)ym * cp + k];
+                    u.vC[1][k] = g.vChrEff.packed[(size_t)(ym + 1) * cp + k];
+                }
             }
-            u.aL = aL; u.aC = aC; u.lr = g.lumRound[ym]; u.cr = g.chrRound[ym];
+            u.aL = aL; u.aC = aC; u.aCy = aCy; u.lr = g.lumRound[ym]; u.cr = g.chrRound[g.yuvOut ? cym : ym];
             // row windows of the interior tile rows as r0 + trow * d (same count): shrink the row range to where that holds
             u.dL = mr + 1 < t.nty ? g.rowStartL[mr + 1] - g.rowStartL[mr] : 0;
             u.dC = mr + 1 < t.nty ? g.rowStartC[mr + 1] - g.rowStartC[mr] : 0;

@@ -174,13 +174,14 @@ namespace gmat {
 // Interior tiles of an exact 2:1 geometry: every output column has the same regular coefficient row and every output
 // row the same vertical one (borders fold differently), so a tile that touches no border needs no tables at all —
 // the coefficients travel as kernel arguments (SGPRs).  Tile columns [tcLo, tcHi] x tile rows [trLo, trHi]; empty
-// (tcLo > tcHi) when the geometry has no such structure.  RGB output only.
+// (tcLo > tcHi) when the geometry has no such structure.
 struct Yuv2xUniform {
     int tcLo = 1, tcHi = 0, trLo = 1, trHi = 0;
     int hL[8] = {0}, hC[8] = {0};               // horizontal pairs (P used)
     int vL[8] = {0};                            // vertical luma pairs; window row of output row y: 2 * y + aL (even)
-    int vC[2][4] = {{0}};                       // vertical chroma pairs by row parity; window row: (y + aC) & ~1
-    int aL = 0, aC = 0, lr = 0, cr = 0;         // lr / cr: accumulator start values
+    int vC[2][4] = {{0}};                       // RGB output: vertical chroma pairs by row parity; window row: (y + aC) & ~1
+    int vCy[8] = {0};                           // 4:2:0 output: vertical chroma pairs; window row of chroma row cy: 2 * cy + aCy
+    int aL = 0, aC = 0, aCy = 0, lr = 0, cr = 0;   // lr / cr: accumulator start values
     int r0L = 0, dL = 0, nrL = 0, r0C = 0, dC = 0, nrC = 0;   // source row window of tile row t: r0 + t * d, n rows
 };
 struct Yuv2xTables {
