@@ -39,14 +39,15 @@ PRE_WARM_MS = 40            # untimed clock-ramp load in front of the W warm-up 
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch from the committed PMC collection (profiles/r01_traffic.json, produced on the GPU box
-    by tools/pmc_traffic.sh with the corrections of MI355X_MICROARCH.md); None when not collected."""
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch from the committed PMC collection (profiles/r01k_traffic.json, produced on the GPU box by
+    tools/pmc_traffic_batched.sh over 32-frame launches with the corrections of MI355X_MICROARCH.md), scaled to the
+    number of frames a launch of this run carries; None when not collected."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01k_traffic.json")))
         for k, v in d["kernels"].items():
             if kernel in k:
-                return v["traffic_bytes"]
+                return int(v["traffic_bytes_per_frame"] * frames_per_launch)
     except Exception:
         pass
     return None
@@ -65,7 +66,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pinned-host upload/compute/download leg")
-    ap.add_argument("--cpu-frames", type=int, default=48)
+    ap.add_argument("--cpu-frames", type=int, default=128)
     return ap.parse_args()
 
 
@@ -388,8 +389,8 @@ def main():
                               f"eager, one C call per step, one launch per stream ({branches} streams), each carrying its share of the frames"),
                    "parallelism": f"{world} GPU(s) x independent streams, no collective"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname),
-                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname, fpl),
+                     "traffic_source": "profiles/r01k_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)",
                      "frames_per_launch": fpl, "algorithmic_bytes_per_launch": ALG_FUSED * fpl,
                      "avg_launch_us": round(ser_ms * 1e3 / launches * fpl, 3),
                      "note": "launches back to back on ONE stream (HIP events), each carrying frames_per_launch frames "
