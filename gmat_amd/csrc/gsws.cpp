@@ -556,7 +556,10 @@ void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
 
 int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 {
-    if (!c) return GMAT_ERR(EINVAL);
+    if (!c || colorspace < 0 || colorspace > 10) return GMAT_ERR(EINVAL);
+    // a YUV source: the matrix (and range) of its YUV -> RGB stage; an RGB source with a YUV destination: the matrix of
+    // the RGB -> YUV stage (fill_rgb2yuv_table, utils.c:765-858), limited range only
+    if (is_packed_rgb(c->srcFormat) && srcFullRange) return GMAT_ERR(ENOSYS);
     c->colorspace = colorspace;
     c->srcFullRange = srcFullRange;
     c->y2r = make_yuv2rgb_consts(colorspace, srcFullRange != 0);
@@ -684,7 +687,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.vChr = c->r2yVChr;
         L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
         L.maxRows = c->r2y.maxRows;
-        L.k = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
+        L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
         c->lastKernel = "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;
@@ -708,7 +711,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if (!dst[1] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
         c->lastKernel = "rgb2yuv444_kernel";
         r = launch_rgb2yuv444(src[0], srcStride[0], c->srcFormat == GMAT_PIX_FMT_BGR24, dst[0], dstStride[0], dst[1], dstStride[1],
-                              dst[2], dstStride[2], c->srcW, c->srcH, make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT), c->stream);
+                              dst[2], dstStride[2], c->srcW, c->srcH, make_rgb2yuv_consts(c->colorspace), c->stream);
         break;
     }
     case MODE_YUV2YUV: {
@@ -748,7 +751,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.vChr = c->r2yVChr;
         L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
         L.maxRows = c->r2y.maxRows;
-        L.k = make_rgb2yuv_consts(GMAT_SWS_CS_DEFAULT);
+        L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
         c->lastKernel = "rgbpf32_to_rgb24_kernel+rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;

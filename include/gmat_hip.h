@@ -95,7 +95,9 @@ GMAT_API int  gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], cons
                              uint8_t *const dst[], const int dstStride[]);
 GMAT_API void gmat_sws_setStream(GmatSwsContext *c, void *stream);
 GMAT_API void gmat_sws_freeContext(GmatSwsContext *c);
-/* sws_setColorspaceDetails subset (utils.c:902): colourspace index + source range for YUV->RGB */
+/* sws_setColorspaceDetails subset (utils.c:902-1030): the matrix (SWS_CS_* index, swscale.h:98-107) of the context's
+ * YUV end.  YUV source -> RGB: that source's matrix and range (ff_yuv2rgb_c_init_tables).  RGB source -> YUV: the
+ * destination's matrix (fill_rgb2yuv_table, utils.c:765-858), limited range only (srcFullRange must be 0). */
 GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange);
 /* srcRange / dstRange of sws_setColorspaceDetails for YUV -> YUV contexts (1 = full "jpeg" range): when they
  * differ, the h-scaled lines go through lum/chrRangeToJpeg_c or ...FromJpeg_c (swscale.c:157-188, hooked in

@@ -95,6 +95,9 @@ typedef struct OrcYuv2Rgb {
     int32_t  off_bU[256 + 2 * ORC_TABLE_HEADROOM];
 } OrcYuv2Rgb;
 
+/* colour matrix of the YUV end of a context (SWS_CS_* index, swscale.h:98-107); -1 for RGB -> RGB / YUV -> YUV */
+struct OrcSws;
+int  orc_sws_set_colorspace(struct OrcSws *c, int colorspace);
 int  orc_yuv2rgb_init(OrcYuv2Rgb *t, int colorspace, int full_range,
                       int brightness, int contrast, int saturation);
 /* one pixel through the look-up tables exactly as LOADCHROMA/PUTRGB24 do */

@@ -211,6 +211,18 @@ fail:
     return NULL;
 }
 
+/* sws_setColorspaceDetails (utils.c:902-1030) for the two directions that have a matrix: a YUV source uses its
+ * table for the YUV -> RGB stage (ff_yuv2rgb_c_init_tables), a YUV destination its table for the RGB -> YUV stage
+ * (fill_rgb2yuv_table, utils.c:765-858).  Limited range on the YUV side; RGB -> RGB contexts keep the defaults. */
+int orc_sws_set_colorspace(OrcSws *c, int colorspace)
+{
+    if (!c || colorspace < 0 || colorspace > 10) return -1;
+    if (c->src_is_rgb && !c->dst_is_rgb) fill_rgb2yuv(c, colorspace);
+    else if (!c->src_is_rgb && c->dst_is_rgb) orc_yuv2rgb_init(&c->y2r, colorspace, 0, 0, 1 << 16, 1 << 16);
+    else return -1;
+    return 0;
+}
+
 int orc_sws_filter(const OrcSws *c, int which, const int16_t **coef, const int32_t **pos, int *size, int *count)
 {
     switch (which) {

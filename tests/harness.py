@@ -41,6 +41,7 @@ def load_oracle(path):
     L.orc_yuv420_to_p01x.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                      C.c_int, C.c_int, C.c_int]
     L.orc_rgb24_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_sws_set_colorspace.argtypes = [C.c_void_p, C.c_int]
     L.orc_rgb_repack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_fill_lcg.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
     return Oracle(L)
@@ -86,10 +87,12 @@ class Oracle:
         assert r == 0
         return out
 
-    def sws(self, src_planes, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"]):
+    def sws(self, src_planes, sw, sh, src_fmt, dw, dh, dst_fmt, flags=SWS["bicubic"], colorspace=None):
         c = self.L.orc_sws_create(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags, None)
         assert c, "oracle refused the conversion"
         try:
+            if colorspace is not None:
+                assert self.L.orc_sws_set_colorspace(c, colorspace) == 0
             outs = alloc_planes(dst_fmt, dw, dh, tight=True)
             r = self.L.orc_sws_scale(c, planes([p.ctypes.data for p in src_planes]),
                                      ints([p.strides[0] for p in src_planes]),

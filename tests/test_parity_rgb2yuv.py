@@ -42,6 +42,23 @@ def test_rgb_to_yuv444p_bit_exact(dev, orc, w, h, src_fmt):
                 assert (p == 0xCD).all()
 
 
+@pytest.mark.parametrize("cs", [1, 4, 5, 7, 9])          # ITU709, FCC, ITU601, SMPTE240M, BT2020 (swscale.h:98-107)
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p"])
+def test_rgb_to_yuv_colorspaces(dev, orc, cs, dst_fmt):
+    """the destination's matrix: fill_rgb2yuv_table (utils.c:765-858) inverts the yuv2rgb coefficient row of the
+    colourspace (BT.601 keeps its literals); gmat_sws_setColorspace on an RGB -> YUV context selects it"""
+    w, h = 130, 34
+    src = synth_planes(orc, "rgb24", w, h, seed=59)
+    want = orc.sws(src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"], colorspace=cs)
+    d_src = dev.upload_planes(src, 64)
+    got, _, kernel = dev.sws(d_src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"], dst_align=64, colorspace=(cs, 0))
+    for i, (g, wv) in enumerate(zip(got, want)):
+        assert (g == wv).all(), (i, kernel)
+    if cs not in (5, 6):
+        base = orc.sws(src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"])
+        assert any((a != b).any() for a, b in zip(want, base))      # the matrix really changed something
+
+
 @pytest.mark.parametrize("flags", ["bilinear", "point", "lanczos"])
 def test_rgb_to_nv12_other_vertical_filters(dev, orc, flags):
     w, h = 192, 40

@@ -455,6 +455,23 @@ def test_2to1_kernel_interior_tiles(dev, orc, src_fmt, dst_fmt, flags):
         p.free()
 
 
+@pytest.mark.parametrize("cs", [1, 7, 9])
+@pytest.mark.parametrize("case", [("nv12", "rgb24", 256, 64, 128, 32, 0), ("yuv420p", "bgra", 96, 40, 144, 60, 0),
+                                  ("nv12", "rgb24", 130, 50, 63, 25, 0), ("yuv444p", "rgb24", 64, 32, 48, 20, 0),
+                                  ("nv12", "bgr24", 640, 160, 320, 80, 0)])
+def test_scaled_yuv_to_rgb_colorspaces(dev, orc, cs, case):
+    """the source's matrix in the scaled (one-context) YUV -> RGB paths: LUT form, full-chroma form (odd width / 4:4:4
+    source) and the 2:1 kernel incl. its interior tiles"""
+    sf, df, sw, sh, dw, dh, _ = case
+    src = synth_planes(orc, sf, sw, sh, seed=83)
+    want = orc.sws(src, sw, sh, sf, dw, dh, df, SWS["bicubic"], colorspace=cs)
+    d = dev.upload_planes(src, 64)
+    got, _, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS["bicubic"], dst_align=64, colorspace=(cs, 0))
+    assert (got[0] == want[0]).all(), kernel
+    for p in d:
+        p.free()
+
+
 @pytest.mark.parametrize("case", [("bgr24", "bgra", (86, 118, 66, 81), SWS["point"] | SWS["accurate_rnd"]),
                                   ("bgr24", "bgr24", (6, 97, 196, 67), SWS["point"] | SWS["full_chr_h_int"]),
                                   ("rgb24", "bgra", (158, 36, 257, 49), SWS["area"])])
