@@ -24,7 +24,7 @@ using namespace gmat;
 namespace {
 
 enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
-            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY };
+            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER };
 
 struct DevBuf {
     void *p = nullptr;
@@ -86,6 +86,8 @@ struct DevFilterStore {
 
 } // namespace
 
+extern "C" void gmat_sws_freeContext(GmatSwsContext *c);
+
 struct GmatSwsContext {
     int srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags;
     double param[2];
@@ -124,12 +126,15 @@ struct GmatSwsContext {
     int interStride = 0;
     const char *lastKernel = "";
     int lastLaunchFrames = 1;
+    // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
+    GmatSwsContext *inner = nullptr;
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
+        if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -430,6 +435,7 @@ void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
+    if (c->mode == MODE_VIA_INNER) return true;
     if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
     return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
 }
@@ -456,6 +462,17 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
 
     const bool same = srcW == dstW && srcH == dstH;
     int r = 0;
+    const bool src32 = srcFormat == GMAT_PIX_FMT_RGBA || srcFormat == GMAT_PIX_FMT_BGRA;
+    if (src32 && !(same && is_packed_rgb(dstFormat))) {
+        // 32-bit RGB sources (swscale_cuda.c:34-44 lists RGBA / BGRA): rgb32ToY / ToUV (input.c rgb16_32 templates) read
+        // the same three channels with the same coefficients as the 24-bit readers and ignore alpha, so the context is the
+        // 24-bit one behind a byte re-pack into an intermediate frame
+        c->inner = gmat_sws_getContext(srcW, srcH, srcFormat == GMAT_PIX_FMT_RGBA ? GMAT_PIX_FMT_RGB24 : GMAT_PIX_FMT_BGR24, dstW, dstH,
+                                       dstFormat, flags, param);
+        if (!c->inner) { delete c; return nullptr; }
+        c->mode = MODE_VIA_INNER;
+        return c;
+    }
     if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat) && (c->flags & GMAT_SWS_ACCURATE_RND)) {
         // libswscale takes its nearest-chroma special converter only for planar sources without
         // SWS_ACCURATE_RND (swscale_unscaled.c:2094-2100); with the flag (and always for NV12) the CPU runs the
@@ -557,6 +574,7 @@ void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
 int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 {
     if (!c || colorspace < 0 || colorspace > 10) return GMAT_ERR(EINVAL);
+    if (c->inner) return gmat_sws_setColorspace(c->inner, colorspace, srcFullRange);
     // a YUV source: the matrix (and range) of its YUV -> RGB stage; an RGB source with a YUV destination: the matrix of
     // the RGB -> YUV stage (fill_rgb2yuv_table, utils.c:765-858), limited range only
     if (is_packed_rgb(c->srcFormat) && srcFullRange) return GMAT_ERR(ENOSYS);
@@ -603,6 +621,7 @@ int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_po
 int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
+    if (c->inner) return gmat_sws_setFused(c->inner, fused);
     if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
@@ -621,6 +640,7 @@ int gmat_sws_lastLaunchFrames(const GmatSwsContext *c) { return c ? c->lastLaunc
 
 int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos, int cap, int *count)
 {
+    if (c && c->inner) return gmat_sws_getFilter(c->inner, which, coef, pos, cap, count);
     if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
     const FilterBank *fb;
     const ScalePlan &pl = (is_plane_src(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
@@ -690,6 +710,20 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
         c->lastKernel = "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
+        break;
+    }
+    case MODE_VIA_INNER: {
+        if (!c->inter) {
+            c->interStride = align_up(c->srcW * 3, 256);
+            if (hipMalloc((void **)&c->inter, (size_t)c->interStride * c->srcH) != hipSuccess) { r = GMAT_ERR(ENOMEM); break; }
+        }
+        if ((r = launch_repack_rgb(src[0], srcStride[0], 4, c->inter, c->interStride, 3, c->srcW, c->srcH, 0, c->stream)) < 0) break;
+        gmat_sws_setStream(c->inner, (void *)c->stream);
+        const uint8_t *isrc[4] = {c->inter, nullptr, nullptr, nullptr};
+        const int istr[4] = {c->interStride, 0, 0, 0};
+        r = gmat_sws_scale(c->inner, isrc, istr, 0, c->srcH, dst, dstStride);
+        c->lastKernel = c->inner->lastKernel;
+        if (r >= 0) return r;
         break;
     }
     case MODE_PLANECOPY: {

@@ -455,6 +455,28 @@ def test_2to1_kernel_interior_tiles(dev, orc, src_fmt, dst_fmt, flags):
         p.free()
 
 
+@pytest.mark.parametrize("src_fmt", ["rgba", "bgra"])
+@pytest.mark.parametrize("case", [("rgb24", 96, 40, 50, 30), ("bgra", 96, 40, 144, 60), ("nv12", 128, 32, 128, 32),
+                                  ("yuv420p", 130, 34, 130, 34), ("yuv444p", 70, 22, 70, 22), ("rgba", 131, 35, 64, 17)])
+def test_32bit_rgb_sources(dev, orc, src_fmt, case):
+    """RGBA / BGRA sources of the scaling and RGB -> YUV paths (swscale_cuda.c:34-44): rgb32ToY / ToUV read the same
+    three channels with the same coefficients as the 24-bit readers and ignore alpha, so the result must equal the
+    24-bit context's on the same pixels"""
+    df, sw, sh, dw, dh = case
+    src24 = synth_planes(orc, "rgb24" if src_fmt == "rgba" else "bgr24", sw, sh, seed=85)
+    alpha = orc.lcg((sh, sw), 86)
+    src32 = [np.ascontiguousarray(np.concatenate([src24[0].reshape(sh, sw, 3), alpha.reshape(sh, sw, 1)], axis=2).reshape(sh, 4 * sw))]
+    want = orc.sws(src24, sw, sh, "rgb24" if src_fmt == "rgba" else "bgr24", dw, dh, df, SWS["bicubic"])
+    for align in (64, 1):
+        d = dev.upload_planes(src32, align)
+        got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, df, SWS["bicubic"], dst_align=align)
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (i, kernel)
+            assert (pads[i] == 0xCD).all()
+        for p in d:
+            p.free()
+
+
 @pytest.mark.parametrize("cs", [1, 7, 9])
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 256, 64, 128, 32, 0), ("yuv420p", "bgra", 96, 40, 144, 60, 0),
                                   ("nv12", "rgb24", 130, 50, 63, 25, 0), ("yuv444p", "rgb24", 64, 32, 48, 20, 0),
