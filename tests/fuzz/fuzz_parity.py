@@ -17,7 +17,7 @@ orc = harness.load_oracle(os.path.join(ROOT, "oracle", "liborc.so"))
 lib = load() if hip else load(os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so"))
 dev = harness.Dev(lib, "hip" if hip else "emu")
 
-SRC = ["nv12", "yuv420p", "rgb24", "bgr24", "yuv444p"]
+SRC = ["nv12", "yuv420p", "rgb24", "bgr24", "yuv444p"]          # 32-bit RGB sources: tests/test_parity_scale.py (they are the 24-bit contexts)
 ALGOS = ["bicubic", "bilinear", "lanczos", "point", "area"]
 fails = 0
 for case in range(n):
