@@ -191,8 +191,8 @@ int gmat_filter_init(GmatFilterContext *f)
         const std::string t = it == f->opt.end() ? "gaussian" : it->second;
         f->smooth_median = (t == "median" || t == "1");
         f->kw = opt_int(f, "kw", 3); f->kh = opt_int(f, "kh", 3);
-        if (f->smooth_median || f->kw != 3 || f->kh != 3) {
-            logf(LOG_ERROR, "smooth_hip: only the 3x3 gaussian kernel is implemented");
+        if (f->kw != 3 || f->kh != 3) {
+            logf(LOG_ERROR, "smooth_hip: only 3x3 kernels (gaussian, median) are implemented");
             return GMAT_ERR(ENOSYS);
         }
         break;
@@ -336,7 +336,8 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
                 break;
             case K_SMOOTH: {
                 static const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
-                r = launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
+                r = f->smooth_median ? launch_median3x3(s, ss, d, ds, pw, ph, bpp, f->stream)
+                                     : launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
                 break;
             }
             default: break;
@@ -386,6 +387,11 @@ int gmat_smooth3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
                    float rdiv, float bias, void *stream)
 {
     return launch_conv3x3(src, ss, dst, ds, w, h, bpp, matrix, rdiv, bias, (hipStream_t)stream);
+}
+
+int gmat_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, void *stream)
+{
+    return launch_median3x3(src, ss, dst, ds, w, h, bpp, (hipStream_t)stream);
 }
 
 int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,

@@ -599,6 +599,74 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     return 0;
 }
 
+// ---- 3x3 median (smooth_nvcv type=median, vf_smooth_nvcv.c:82-105; semantics of the CPU median filter,
+// vf_median.c + median_template.c at radius 1, percentile 0.5: per channel the 5th smallest of the 3x3 window, rows and
+// columns clamped at the frame edges — the histogram walk there adds row max(0, y-1) / min(h-1, y+1) and column
+// max(0, x-1) / min(w-1, x+1)).  A selection, no arithmetic.  Per output byte: sort the three columns with
+// v_min3 / v_med3 / v_max3, then med3(max3(mins), med3(meds), min3(maxs)).  4 consecutive bytes of a row per thread;
+// taps are unaligned dword loads at -bpp / 0 / +bpp bytes, byte-wise with clamped columns in the first and last group.
+template <int BPP>
+__global__ __launch_bounds__(256) void median3x3_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dstAligned)
+{
+    const int rb = w * BPP;
+    const int i0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i0 >= rb || y >= h) return;
+    const uint8_t *rows[3] = {src + (size_t)max(y - 1, 0) * ss, src + (size_t)y * ss, src + (size_t)min(y + 1, h - 1) * ss};
+    unsigned t[3][3];                                     // [row][column offset -1, 0, +1]: 4 bytes each
+    const bool interior = i0 >= BPP && i0 + 4 + BPP <= rb;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        if (interior) {
+            __builtin_memcpy(&t[r][0], rows[r] + i0 - BPP, 4);
+            __builtin_memcpy(&t[r][1], rows[r] + i0, 4);
+            __builtin_memcpy(&t[r][2], rows[r] + i0 + BPP, 4);
+        } else {
+            t[r][0] = t[r][1] = t[r][2] = 0;
+            for (int b = 0; b < 4; b++) {
+                const int i = min(i0 + b, rb - 1), px = i / BPP, ch = i - px * BPP;
+                t[r][0] |= (unsigned)rows[r][max(px - 1, 0) * BPP + ch] << (8 * b);
+                t[r][1] |= (unsigned)rows[r][i] << (8 * b);
+                t[r][2] |= (unsigned)rows[r][min(px + 1, w - 1) * BPP + ch] << (8 * b);
+            }
+        }
+    }
+    unsigned o = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        unsigned lo[3], md[3], hi[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const unsigned a0 = (t[0][c] >> (8 * b)) & 0xFF, a1 = (t[1][c] >> (8 * b)) & 0xFF, a2 = (t[2][c] >> (8 * b)) & 0xFF;
+            lo[c] = min(min(a0, a1), a2); hi[c] = max(max(a0, a1), a2);
+            md[c] = max(min(a0, a1), min(max(a0, a1), a2));
+        }
+        const unsigned A = max(max(lo[0], lo[1]), lo[2]), C = min(min(hi[0], hi[1]), hi[2]);
+        const unsigned B = max(min(md[0], md[1]), min(max(md[0], md[1]), md[2]));
+        o |= max(min(A, B), min(max(A, B), C)) << (8 * b);
+    }
+    uint8_t *d = dst + (size_t)y * ds + i0;
+    if (dstAligned && i0 + 4 <= rb) *reinterpret_cast<unsigned *>(d) = o;
+    else for (int b = 0; b < min(4, rb - i0); b++) d[b] = (uint8_t)(o >> (8 * b));
+}
+
+int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    if (!src || !dst) return GMAT_ERR(EINVAL);
+    const int rb = w * bpp;
+    const dim3 grid((rb + 255) / 256, (h + 3) / 4), block(256);
+    const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
+    switch (bpp) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3_kernel<1>), grid, block, 0, stream, src, ss, dst, ds, w, h, aligned); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3_kernel<2>), grid, block, 0, stream, src, ss, dst, ds, w, h, aligned); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3_kernel<3>), grid, block, 0, stream, src, ss, dst, ds, w, h, aligned); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3_kernel<4>), grid, block, 0, stream, src, ss, dst, ds, w, h, aligned); break;
+    default: return GMAT_ERR(ENOSYS);
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---- arbitrary-angle rotation, vf_rotate.c's 16.16 fixed point --------------------------------------
 // Source position of output pixel (i, j): x = X0 + j*s + i*c, y = Y0 + j*c - i*s (filter_slice, vf_rotate.c:
 // 427-429,:487-492); pixels whose integer position leaves [-1, in] keep the fill colour (:463); bilinear taps as

@@ -128,6 +128,8 @@ int launch_copy2d(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride
                   int rowBytes, int h, hipStream_t stream);
 int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                    int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream);
+// per-channel 3x3 median, window rows / columns clamped at the edges (vf_median.c semantics at radius 1)
+int launch_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, hipStream_t stream);
 int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                               int inW, int inH, int bpp, hipStream_t stream);
 // arbitrary angle (radians, clockwise positive) in vf_rotate.c's 16.16 fixed point; fill == nullptr leaves

@@ -231,6 +231,11 @@ GMAT_API int gmat_crop(const uint8_t *src, int srcStride, uint8_t *dst, int dstS
                        int x, int y, int w, int h, int bpp, void *stream);
 GMAT_API int gmat_smooth3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                             int w, int h, int bpp, const int matrix[9], float rdiv, float bias, void *stream);
+/* smooth_nvcv type=median at kw = kh = 3 (vf_smooth_nvcv.c:82-105): per channel the median of the 3x3 window, rows
+ * and columns clamped at the frame edges — the CPU median filter's semantics at radius 1, percentile 0.5
+ * (vf_median.c:125, median_template.c:101-147).  bpp 1..4. */
+GMAT_API int gmat_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                            int w, int h, int bpp, void *stream);
 /* Arbitrary-angle rotation about the centre, bit-exact with the CPU rotate filter's 16.16 fixed point
  * (vf_rotate.c:198-249 int_sin + interpolate_bilinear8, :410-548 position walk).  angle_rad > 0 turns
  * clockwise; bilinear 0 = nearest; fill = bpp bytes written where the source position is out of range,

@@ -154,6 +154,8 @@ void orc_crop(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
 /* vf_convolution.c:495-512 + setup_3x3 :555-569 applied per channel of a packed frame */
 void orc_conv3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                  int w, int h, int bpp, const int matrix[9], float rdiv, float bias);
+/* vf_median.c / median_template.c at radius 1, percentile 0.5: per-channel 3x3 median, edges clamped */
+void orc_median3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp);
 /* vf_rotate.c:198-548 — arbitrary angle (radians, clockwise positive), 16.16 fixed point; fill NULL = leave */
 void orc_rotate_sincos(double angle_rad, int *s, int *c);
 void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,

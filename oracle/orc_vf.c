@@ -92,6 +92,35 @@ void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst
     }
 }
 
+/* ---- 3x3 median per channel -------------------------------------------------------------------------
+ * vf_median.c + median_template.c at radius = radiusV = 1, percentile 0.5 (t = 4, vf_median.c:125): the value at
+ * which the cumulative histogram of the window exceeds t, i.e. the 5th smallest of the nine; the window's rows are
+ * max(0, y-1) .. min(h-1, y+1) (median_template.c:101-111) and its columns are clamped the same way (:116-118,
+ * :133-147: column 0 is added radius extra times, column width-1 stands in past the right edge).  Packed pixels
+ * are handled per channel (the CPU filter takes planar formats only; the nvcv filter takes packed RGB). */
+void orc_median3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp)
+{
+    int x, y, ch, i, j;
+    for (y = 0; y < h; y++)
+        for (x = 0; x < w; x++)
+            for (ch = 0; ch < bpp; ch++) {
+                uint8_t v[9];
+                int n = 0;
+                for (j = -1; j <= 1; j++)
+                    for (i = -1; i <= 1; i++) {
+                        int yy = y + j < 0 ? 0 : y + j > h - 1 ? h - 1 : y + j;
+                        int xx = x + i < 0 ? 0 : x + i > w - 1 ? w - 1 : x + i;
+                        v[n++] = src[(long)yy * src_stride + (long)xx * bpp + ch];
+                    }
+                for (i = 1; i < 9; i++) {                      /* insertion sort */
+                    uint8_t k = v[i];
+                    for (j = i - 1; j >= 0 && v[j] > k; j--) v[j + 1] = v[j];
+                    v[j + 1] = k;
+                }
+                dst[(long)y * dst_stride + (long)x * bpp + ch] = v[4];
+            }
+}
+
 /* ---- packed 24/32-bit RGB re-packing at equal size -------------------------------------------------
  * rgbToRgbWrapper (swscale_unscaled.c:1579-1640) with the converter findRgbConvFn picks (:1458-1577) on a
  * little-endian host.  With RGB24 in the "RGB in int" class, BGR24 in the "BGR in int" class, RGBA = BGR32 and

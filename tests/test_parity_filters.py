@@ -448,6 +448,41 @@ def test_filter_layer_scale_from_p01x(dev, orc, src_fmt):
     assert (up[1].view(np.uint16) == nv[1].astype(np.uint16) * 257).all()
 
 
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 35), (5, 3), (1, 1), (2, 7), (259, 4)])
+def test_median3x3(dev, orc, w, h, bpp):
+    """smooth type=median at 3x3: per channel the 5th smallest of the window, edges clamped (vf_median.c at radius 1)"""
+    src = orc.lcg((h, w * bpp), 111 + bpp)
+    want = np.zeros_like(src)
+    orc.L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
+    # independent statement: numpy median over the edge-padded 3x3 neighbourhood
+    px = np.pad(src.reshape(h, w, bpp), ((1, 1), (1, 1), (0, 0)), mode="edge")
+    stack = np.stack([px[j:j + h, i:i + w] for j in range(3) for i in range(3)], axis=0)
+    assert (want.reshape(h, w, bpp) == np.sort(stack, axis=0)[4]).all()
+    for align, extra in ((64, 0), (1, 1)):
+        d = dev.upload_planes([src], align, extra)[0]
+        o = dev.planes_like("rgb24", 1, 1)[0] if False else None
+        from harness import DevPlane
+        out = DevPlane(dev, h, w * bpp, ((w * bpp + extra + align - 1) // align) * align)
+        assert dev.lib.gmat_median3x3(d.ptr, d.stride, out.ptr, out.stride, w, h, bpp, None) == 0
+        assert (out.download() == want).all()
+        assert (out.download(with_padding=True)[:, out.row_bytes:] == 0xCD).all()
+        d.free(); out.free()
+
+
+def test_filter_layer_smooth_median(dev, orc):
+    w, h = 96, 40
+    for fmt in ("rgb24", "nv12"):
+        src = synth_planes(orc, fmt, w, h, 113)
+        res, _, _ = _run_filter_planes(dev, "smooth_hip", {"type": "median"}, src, w, h, fmt)
+        for i, pl in enumerate(src):
+            bpp = 3 if fmt == "rgb24" else _plane_bpp(fmt, i)
+            pl = np.ascontiguousarray(pl)
+            want = np.zeros_like(pl)
+            orc.L.orc_median3x3(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pl.shape[1] // bpp, pl.shape[0], bpp)
+            assert (res[i] == want).all(), (fmt, i)
+
+
 def test_filter_layer_yuv444p_frames(dev, orc):
     """scale_hip / format_hip with a planar 4:4:4 destination, then crop + flip + transpose on those frames"""
     from harness import SWS

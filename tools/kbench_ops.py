@@ -144,6 +144,8 @@ plane_case("4K rgb24 hflip", "gmat_flip", 3840, 2160, 3, 1)
 m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
 plane_case("4K Y plane smooth3x3", "gmat_smooth3x3", 3840, 2160, 1, m, C.c_float(1 / 16), C.c_float(0.0))
 plane_case("4K rgb24 smooth3x3", "gmat_smooth3x3", 3840, 2160, 3, m, C.c_float(1 / 16), C.c_float(0.0))
+plane_case("4K rgb24 median3x3", "gmat_median3x3", 3840, 2160, 3)
+plane_case("4K Y plane median3x3", "gmat_median3x3", 3840, 2160, 1)
 
 
 def rotate_case(label, w, h, bpp, deg, bilinear):
