@@ -18,8 +18,10 @@
 
 // The LDS image allows at most 6 blocks per CU = 6 waves per SIMD: tell the compiler, so it budgets registers and
 // schedules for that occupancy instead of the maximum (measured: 6.50 -> 6.41 us per frame, 6.58 -> 6.40 for YUV output)
-#ifndef X2_WAVES_ATTR
+#if !defined(X2_WAVES_ATTR) && defined(__HIP__)
 #define X2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#elif !defined(X2_WAVES_ATTR)
+#define X2_WAVES_ATTR
 #endif
 
 namespace gmat {
