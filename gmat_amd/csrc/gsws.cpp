@@ -24,7 +24,7 @@ using namespace gmat;
 namespace {
 
 enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
-            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER };
+            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER, MODE_SCALE16 };
 
 struct DevBuf {
     void *p = nullptr;
@@ -35,6 +35,13 @@ struct DevBuf {
         if (!bytes) return 0;
         GMAT_HIP_CHECK(hipMalloc(&p, bytes));
         GMAT_HIP_CHECK(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+    int reserve(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        if (!bytes) return 0;
+        GMAT_HIP_CHECK(hipMalloc(&p, bytes));
         return 0;
     }
 };
@@ -128,6 +135,11 @@ struct GmatSwsContext {
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
     GmatSwsContext *inner = nullptr;
+    // 16-bit destinations (P016LE): 19-bit int32 lines in HBM between the two passes of k_scale16.hip
+    ScalePlan plan16;
+    DevFilterStore f16[4];
+    DevFilter d16[4];                 // hLum, hChr, vLum, vChr
+    DevBuf line16[3];                 // luma, U, V: srcH x dstW / chrSrcH x chrDstW int32
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
@@ -236,6 +248,26 @@ static int init_rgb2yuv(GmatSwsContext *c)
     if ((r = c->dR2YvChr.upload(c->planR2Y.vChr, c->r2y.round, c->r2yVChr)) < 0) return r;
     if ((r = c->dR2YrowStart.upload(c->r2y.rowStart.data(), c->r2y.rowStart.size() * 4)) < 0) return r;
     if ((r = c->dR2YrowCount.upload(c->r2y.rowCount.data(), c->r2y.rowCount.size() * 4)) < 0) return r;
+    return 0;
+}
+
+static int init_scale16(GmatSwsContext *c)
+{
+    int r = build_scale_plan(c->plan16, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param, c->chrPos);
+    if (r < 0) return r;
+    ScalePlan &p = c->plan16;
+    // a one-tap vertical luma filter goes through yuv2plane1_16_c, which does not read the coefficient: the X form
+    // with 4096 gives the same value; semi-planar chroma always takes the X form (vscale.c:30-105)
+    FilterBank vl = p.vLum;
+    if (vl.taps == 1) { std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl); }
+    const std::vector<int32_t> none(std::max(std::max(c->dstW, c->dstH), 1), 0);
+    if ((r = c->f16[0].upload(p.hLum, none, c->d16[0])) < 0) return r;
+    if ((r = c->f16[1].upload(p.hChr, none, c->d16[1])) < 0) return r;
+    if ((r = c->f16[2].upload(vl, none, c->d16[2])) < 0) return r;
+    if ((r = c->f16[3].upload(p.vChr, none, c->d16[3])) < 0) return r;
+    if ((r = c->line16[0].reserve((size_t)c->srcH * c->dstW * 4)) < 0) return r;
+    if ((r = c->line16[1].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
+    if ((r = c->line16[2].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
     return 0;
 }
 
@@ -435,7 +467,7 @@ void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
-    if (c->mode == MODE_VIA_INNER) return true;
+    if (c->mode == MODE_VIA_INNER || c->mode == MODE_SCALE16) return true;       // one set of intermediates per context
     if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
     return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
 }
@@ -527,6 +559,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         r = ensure_scaler(c);
     } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
+    } else if (is_plane_src(srcFormat) && dstFormat == GMAT_PIX_FMT_P016LE) {
+        // 16-bit destination: 19-bit intermediates, the two-pass path of k_scale16.hip (equal-size 8-bit 4:2:0 sources were
+        // taken above as the depth expansion, equal format as the plane copy)
+        c->mode = MODE_SCALE16;
+        r = init_scale16(c);
     } else if ((is_plane_src(srcFormat)) && dstFormat == GMAT_PIX_FMT_P010LE) {
         // scaled (or 16-bit sourced) P010LE output: dstBpc = 10 keeps the 15-bit intermediates; yuv2p010l1_c /
         // yuv2p010lX_c / yuv2p010cX_c (output.c:459-519).  Equal-size 8-bit 4:2:0 sources were taken above (MODE_DEPTH).
@@ -724,6 +761,27 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         r = gmat_sws_scale(c->inner, isrc, istr, 0, c->srcH, dst, dstStride);
         c->lastKernel = c->inner->lastKernel;
         if (r >= 0) return r;
+        break;
+    }
+    case MODE_SCALE16: {
+        if (!dst[1]) { r = GMAT_ERR(EINVAL); break; }
+        const ScalePlan &p = c->plan16;
+        const bool s16 = is_p01x(c->srcFormat);
+        const int odd = s16 ? 1 : 0;
+        if ((((uintptr_t)dst[0] | (uintptr_t)dst[1] | (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1]) & 1) != 0 ||
+            (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
+        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : c->srcFormat == GMAT_PIX_FMT_P016LE ? 16 : 0;
+        const int bps = s16 ? 2 : 1;
+        int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
+        c->lastKernel = "hscale19_kernel+vscale16_kernel";
+        if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream)) < 0) break;
+        const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || s16;           // interleaved U, V
+        const uint8_t *pu = src[1], *pv = semi ? src[1] + bps : src[2];
+        const int su = srcStride[1], sv = semi ? srcStride[1] : srcStride[2], cstep = semi ? 2 * bps : bps;
+        if ((r = launch_hscale19(pu, su, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lu, p.chrDstW, c->stream)) < 0) break;
+        if ((r = launch_hscale19(pv, sv, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lv, p.chrDstW, c->stream)) < 0) break;
+        if ((r = launch_vscale16(ly, nullptr, c->dstW, c->srcH, c->d16[2], dst[0], dstStride[0], c->dstW, c->dstH, c->stream)) < 0) break;
+        r = launch_vscale16(lu, lv, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream);
         break;
     }
     case MODE_PLANECOPY: {

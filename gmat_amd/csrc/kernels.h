@@ -119,6 +119,14 @@ int  launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_
                       const Yuv2xFrames *frames = nullptr, int nframes = 1);
 const char *yuvscale_kernel_name(const YuvScaleTiling &t);
 
+// ---- 16-bit destinations: 19-bit int32 lines, two passes (k_scale16.hip) -------------------------------------
+// kind 0: 8-bit samples; 10 / 16: 16-bit samples (P010: >> 6); step = bytes between consecutive samples of the plane
+int launch_hscale19(const uint8_t *src, int srcStride, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst,
+                    int dstW, hipStream_t stream);
+// lineB == nullptr: one plane of 16-bit samples; else U / V lines -> interleaved 16-bit pairs
+int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int lineH, const DevFilter &f, uint8_t *dst, int dstStride,
+                    int dstW, int dstH, hipStream_t stream);
+
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
 int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                      int inW, int inH, int bpp, int dir, hipStream_t stream);

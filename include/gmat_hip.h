@@ -38,9 +38,11 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_P010LE    = 159,   /* pixfmt.h:276 — like NV12, 16-bit containers, data in the high bits */
     GMAT_PIX_FMT_P016LE    = 170,   /* both: SOURCE for every 8-bit destination and for P010LE at any size
                                        (hScale16To15_c semantics); DESTINATION of 8-bit 4:2:0 at equal size
-                                       (planar8ToP01xleWrapper); equal format and size: plane copy.  P010LE is also
-                                       a scaled destination of every YUV source (yuv2p010lX_c / cX_c); P016LE as a
-                                       scaled destination needs libswscale's 19-bit intermediates: -ENOSYS */
+                                       (planar8ToP01xleWrapper); equal format and size: plane copy.  Both are also
+                                       scaled destinations of every YUV source: P010LE on the 15-bit lines
+                                       (yuv2p010lX_c / cX_c), P016LE on libswscale's 19-bit lines (hScale8To19_c,
+                                       yuv2planeX_16_c; a plain two-pass path, default chroma positions and
+                                       equal ranges only) */
     GMAT_PIX_FMT_RGBPF32LE = 179,   /* GMAT addition, pixfmt.h:315 */
 };
 

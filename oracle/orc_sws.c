@@ -138,11 +138,13 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     int scaler_mask = ORC_SWS_FAST_BILINEAR | ORC_SWS_BILINEAR | ORC_SWS_BICUBIC | 8 | ORC_SWS_POINT |
                       ORC_SWS_AREA | 0x40 | 0x80 | 0x100 | ORC_SWS_LANCZOS | 0x400;
 
-    /* P010LE / P016LE as sources; P010LE also as a destination (dstBpc = 10 <= 14 keeps the 15-bit intermediates;
-     * P016LE would need the 19-bit ones, hScale8To19_c / yuv2planeX_16_c, not restated) */
+    /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
+     * P016LE switches to the 19-bit ones (scale_to_p016 below) */
     if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) ||
-        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || dst_fmt == ORC_PIX_P010LE))
+        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt)))
         return NULL;
+    if (dst_fmt == ORC_PIX_P016LE && (is_rgb(src_fmt) || src_range != dst_range))
+        return NULL;                                       /* RGB readers / 16-bit range conversion for 19-bit lines: not restated */
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
@@ -589,6 +591,106 @@ static void out_p010_chroma_row(uint8_t *dest, int w, const int16_t *filter, int
     }
 }
 
+/* ---- 16-bit destination (P016LE): 19-bit lines held in int32 (dstBpc = 16, utils.c:1561-1570) -----------------
+ *   hScale8To19_c    swscale.c:138-153   min(sum >> 3, 2^19 - 1)
+ *   hScale16To19_c   swscale.c:63-91     min(sum >> (depth - 5), 2^19 - 1)
+ *   yuv2plane1_16_c  output.c:143-155    clip_uint16((src + 4) >> 3)
+ *   yuv2planeX_16_c  output.c:157-181    0x8000 + clip_int16(((1 << 14) - 0x40000000 + sum src * (unsigned)filter) >> 15)
+ *   yuv2nv12cX_16_c  output.c:183-211    the X form per chroma plane, interleaved, also for one tap
+ * Whole frames only. */
+static void hscale19(int32_t *dst, int dst_w, const uint16_t *src, const int16_t *filter, const int32_t *pos, int fs, int sh)
+{
+    int i, j;
+    for (i = 0; i < dst_w; i++) {
+        int val = 0;
+        for (j = 0; j < fs; j++) val += src[pos[i] + j] * filter[fs * i + j];
+        val >>= sh;
+        dst[i] = val < (1 << 19) - 1 ? val : (1 << 19) - 1;
+    }
+}
+
+static void put16(uint8_t *d, int v) { d[0] = (uint8_t)(v & 0xFF); d[1] = (uint8_t)(v >> 8); }
+
+static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, int i)
+{
+    unsigned val = (1u << 14) - 0x40000000u;
+    int j, v;
+    for (j = 0; j < fs; j++) val += (unsigned)src[j][i] * (unsigned)(int)filter[j];
+    v = (int)val >> 15;
+    v = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    return 0x8000 + v;
+}
+
+static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
+                         const int dst_stride[4])
+{
+    const int dw = c->dst_w, cdw = c->chr_dst_w, sh8 = 3;
+    const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
+    const int sh = src16 ? (p010 ? 10 : 16) - 5 : sh8;
+    int32_t *ly = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h);
+    int32_t *lu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
+    int32_t *lv = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
+    uint16_t *t0 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
+    uint16_t *t1 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
+    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(c->v_lum_size + c->v_chr_size) * 2);
+    int y, i, j, ret = -1;
+    if (!ly || !lu || !lv || !t0 || !t1 || !lp) goto done;
+    for (y = 0; y < c->src_h; y++) {
+        const uint8_t *row = src[0] + (long)y * src_stride[0];
+        for (i = 0; i < c->src_w; i++)
+            t0[i] = (uint16_t)(src16 ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
+        hscale19(ly + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
+    }
+    for (y = 0; y < c->chr_src_h; y++) {
+        for (i = 0; i < c->chr_src_w; i++) {
+            if (src16) {
+                const uint8_t *row = src[1] + (long)y * src_stride[1];
+                t0[i] = (uint16_t)(p010 ? rl16(row + 4 * i) >> 6 : rl16(row + 4 * i));
+                t1[i] = (uint16_t)(p010 ? rl16(row + 4 * i + 2) >> 6 : rl16(row + 4 * i + 2));
+            } else if (c->src_fmt == ORC_PIX_NV12) {
+                const uint8_t *row = src[1] + (long)y * src_stride[1];
+                t0[i] = row[2 * i]; t1[i] = row[2 * i + 1];
+            } else {
+                t0[i] = src[1][(long)y * src_stride[1] + i]; t1[i] = src[2][(long)y * src_stride[2] + i];
+            }
+        }
+        hscale19(lu + (size_t)y * cdw, cdw, t0, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
+        hscale19(lv + (size_t)y * cdw, cdw, t1, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
+    }
+    for (y = 0; y < c->dst_h; y++) {
+        uint8_t *d = dst[0] + (long)y * dst_stride[0];
+        for (j = 0; j < c->v_lum_size; j++) {
+            int r = c->v_lum_pos[y] + j;
+            lp[j] = ly + (size_t)(r < c->src_h ? r : c->src_h - 1) * dw;
+        }
+        for (i = 0; i < dw; i++) {
+            if (c->v_lum_size == 1) {
+                int v = (lp[0][i] + 4) >> 3;
+                put16(d + 2 * i, v < 0 ? 0 : v > 65535 ? 65535 : v);
+            } else {
+                put16(d + 2 * i, planeX16(lp, c->v_lum + y * c->v_lum_size, c->v_lum_size, i));
+            }
+        }
+    }
+    for (y = 0; y < c->chr_dst_h; y++) {
+        uint8_t *d = dst[1] + (long)y * dst_stride[1];
+        const int32_t **up = lp, **vp = lp + c->v_chr_size;
+        for (j = 0; j < c->v_chr_size; j++) {
+            int r = c->v_chr_pos[y] + j;
+            if (r >= c->chr_src_h) r = c->chr_src_h - 1;
+            up[j] = lu + (size_t)r * cdw; vp[j] = lv + (size_t)r * cdw;
+        }
+        for (i = 0; i < cdw; i++) {
+            put16(d + 4 * i, planeX16(up, c->v_chr + y * c->v_chr_size, c->v_chr_size, i));
+            put16(d + 4 * i + 2, planeX16(vp, c->v_chr + y * c->v_chr_size, c->v_chr_size, i));
+        }
+    }
+    ret = c->dst_h;
+done:
+    free(ly); free(lu); free(lv); free(t0); free(t1); free((void *)lp);
+    return ret;
+}
+
 int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_stride[4],
                        uint8_t *const dst[4], const int dst_stride[4], int y0, int y1)
 {
@@ -599,6 +701,8 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     const int16_t **lp = NULL, **up = NULL, **vp = NULL;
     const int dst_w = c->dst_w, cdw = c->chr_dst_w;
 
+    if (c->dst_fmt == ORC_PIX_P016LE)
+        return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_p016(c, src, src_stride, dst, dst_stride) : -1;
     if (y0 < 0) y0 = 0;
     if (y1 > c->dst_h) y1 = c->dst_h;
     if (y0 >= y1) return 0;
@@ -678,6 +782,8 @@ int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4
 {
     /* bounded working set: process in bands of 64 output rows */
     int y, band = 64;
+    if (c->dst_fmt == ORC_PIX_P016LE)
+        return scale_to_p016(c, src, src_stride, dst, dst_stride);
     for (y = 0; y < c->dst_h; y += band) {
         int r = orc_sws_scale_rows(c, src, src_stride, dst, dst_stride, y,
                                    y + band < c->dst_h ? y + band : c->dst_h);
