@@ -30,6 +30,11 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
         L.linesize[0] = align_up(w * bytes_per_pixel(fmt), align);
         L.total = (size_t)L.linesize[0] * h;
         return 0;
+    case GMAT_PIX_FMT_RGBA64LE: case GMAT_PIX_FMT_BGRA64LE:
+        L.planes = 1;
+        L.linesize[0] = align_up(w * 8, align);
+        L.total = (size_t)L.linesize[0] * h;
+        return 0;
     case GMAT_PIX_FMT_NV12:
         // data[1] = data[0] + linesize[0]*height (the layout yuv2rgb_cuda.cu:226 assumes)
         L.planes = 2;
@@ -89,6 +94,8 @@ int plane_row_bytes(int fmt, int plane, int w)
     case GMAT_PIX_FMT_P010LE:
     case GMAT_PIX_FMT_P016LE:    return plane == 0 ? 2 * w : 4 * ceil_rshift(w, 1);
     case GMAT_PIX_FMT_RGBPF32LE: return 4 * w;
+    case GMAT_PIX_FMT_RGBA64LE:
+    case GMAT_PIX_FMT_BGRA64LE:  return 8 * w;
     default:                     return w * bytes_per_pixel(fmt);
     }
 }

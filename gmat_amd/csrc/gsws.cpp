@@ -258,13 +258,30 @@ static int init_scale16(GmatSwsContext *c)
     ScalePlan &p = c->plan16;
     // a one-tap vertical luma filter goes through yuv2plane1_16_c, which does not read the coefficient: the X form
     // with 4096 gives the same value; semi-planar chroma always takes the X form (vscale.c:30-105)
-    FilterBank vl = p.vLum;
-    if (vl.taps == 1) { std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl); }
+    FilterBank vl = p.vLum, vc = p.vChr;
+    if (is_rgb64(c->dstFormat)) {
+        // packed_vscale's 1-tap forms (vscale.c:135-160 -> yuv2rgba64_1_c, output.c:1172-1272) do not read the
+        // coefficients: luma as it is, chroma either its first line (uvalpha < 2048) or the mean of its two lines.
+        // The 2-tap form (_2_c) and the X form are the same sums.
+        const int lfs = vl.taps, cfs = vc.taps;
+        for (int y = 0; y < c->dstH; y++) {
+            int16_t *lf = &vl.coef[(size_t)y * lfs], *cf = &vc.coef[(size_t)y * cfs];
+            const bool chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
+            if (lfs == 1 && cfs == 1) { lf[0] = 4096; cf[0] = 4096; }
+            else if (lfs == 1 && chr2) {
+                lf[0] = 4096;
+                if (cf[1] < 2048) { cf[0] = 4096; cf[1] = 0; } else { cf[0] = 2048; cf[1] = 2048; }
+            }
+        }
+        pack_filter_pairs(vl); pack_filter_pairs(vc);
+    } else if (vl.taps == 1) {
+        std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl);
+    }
     const std::vector<int32_t> none(std::max(std::max(c->dstW, c->dstH), 1), 0);
     if ((r = c->f16[0].upload(p.hLum, none, c->d16[0])) < 0) return r;
     if ((r = c->f16[1].upload(p.hChr, none, c->d16[1])) < 0) return r;
     if ((r = c->f16[2].upload(vl, none, c->d16[2])) < 0) return r;
-    if ((r = c->f16[3].upload(p.vChr, none, c->d16[3])) < 0) return r;
+    if ((r = c->f16[3].upload(vc, none, c->d16[3])) < 0) return r;
     if ((r = c->line16[0].reserve((size_t)c->srcH * c->dstW * 4)) < 0) return r;
     if ((r = c->line16[1].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
     if ((r = c->line16[2].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
@@ -559,7 +576,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         r = ensure_scaler(c);
     } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
-    } else if (is_plane_src(srcFormat) && dstFormat == GMAT_PIX_FMT_P016LE) {
+    } else if (is_plane_src(srcFormat) && (dstFormat == GMAT_PIX_FMT_P016LE || is_rgb64(dstFormat))) {
         // 16-bit destination: 19-bit intermediates, the two-pass path of k_scale16.hip (equal-size 8-bit 4:2:0 sources were
         // taken above as the depth expansion, equal format as the plane copy)
         c->mode = MODE_SCALE16;
@@ -764,11 +781,12 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         break;
     }
     case MODE_SCALE16: {
-        if (!dst[1]) { r = GMAT_ERR(EINVAL); break; }
+        const bool rgb64 = is_rgb64(c->dstFormat);
+        if (!rgb64 && !dst[1]) { r = GMAT_ERR(EINVAL); break; }
         const ScalePlan &p = c->plan16;
         const bool s16 = is_p01x(c->srcFormat);
         const int odd = s16 ? 1 : 0;
-        if ((((uintptr_t)dst[0] | (uintptr_t)dst[1] | (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1]) & 1) != 0 ||
+        if ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0] | (rgb64 ? 0 : ((uintptr_t)dst[1] | (uintptr_t)dstStride[1]))) & 1) != 0 ||
             (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
         const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : c->srcFormat == GMAT_PIX_FMT_P016LE ? 16 : 0;
         const int bps = s16 ? 2 : 1;
@@ -776,10 +794,18 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
         if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream)) < 0) break;
         const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || s16;           // interleaved U, V
+        if (!semi && !src[2]) { r = GMAT_ERR(EINVAL); break; }
         const uint8_t *pu = src[1], *pv = semi ? src[1] + bps : src[2];
         const int su = srcStride[1], sv = semi ? srcStride[1] : srcStride[2], cstep = semi ? 2 * bps : bps;
         if ((r = launch_hscale19(pu, su, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lu, p.chrDstW, c->stream)) < 0) break;
         if ((r = launch_hscale19(pv, sv, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lv, p.chrDstW, c->stream)) < 0) break;
+        if (rgb64) {
+            c->lastKernel = "hscale19_kernel+vrgba64_kernel";
+            r = launch_vrgba64(ly, lu, lv, c->dstW, c->srcH, p.chrDstW, p.chrSrcH, c->d16[2], c->d16[3], p.chrDstW == c->dstW ? 0 : 1,
+                               dst[0], dstStride[0], c->dstW, c->dstH, c->dstFormat == GMAT_PIX_FMT_BGRA64LE,
+                               make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0), c->stream);
+            break;
+        }
         if ((r = launch_vscale16(ly, nullptr, c->dstW, c->srcH, c->d16[2], dst[0], dstStride[0], c->dstW, c->dstH, c->stream)) < 0) break;
         r = launch_vscale16(lu, lv, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream);
         break;

@@ -1,4 +1,4 @@
-// k_scale16.hip — libswscale's generic scaler for 16-bit destinations (P016LE), gfx950.
+// k_scale16.hip — libswscale's generic scaler for 16-bit destinations (P016LE, RGBA64LE / BGRA64LE), gfx950.
 //
 // A 16-bit destination switches the CPU path to 19-bit intermediate lines held in int32 (dstBpc = 16, utils.c:1561-1570):
 //   horizontal   hScale8To19_c    min(sum >> 3, 2^19 - 1)                          swscale.c:138-153
@@ -67,6 +67,54 @@ __global__ __launch_bounds__(256) void vscale16_kernel(const int32_t *lineA, con
         unsigned short *d = reinterpret_cast<unsigned short *>(dst + (size_t)y * ds) + 2 * x;
         d[0] = (unsigned short)va; d[1] = (unsigned short)vb;
     }
+}
+
+// RGBA64LE / BGRA64LE from the 19-bit lines: yuv2rgba64_X_c / _full_X_c (output.c:1025-1105, :1275-1337); the 1- and
+// 2-tap forms (_1_c, _2_c) are the same values with the effective coefficients the host prepares (gsws.cpp):
+//   Y = ((-2^30 + sum lum * f) >> 14) + 2^16;  U, V = (-(128 << 23) + sum chr * f) >> 14      (32-bit wrap-around sums)
+//   Y = (Y - y_offset) * y_coeff + (1 << 13);  R = V * v2r;  G = V * v2g + U * u2g;  B = U * u2b
+//   channel = clip_uintp2(X + Y, 30) >> 14, alpha 0xFFFF
+// One pixel per thread; chrShift = 1: one chroma sample per pixel pair.
+__global__ __launch_bounds__(256) void vrgba64_kernel(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH,
+                                                      int chrW, int chrH, DevFilter fl, DevFilter fc, int chrShift, uint8_t *dst,
+                                                      int ds, int dstW, int dstH, int bgr, Yuv2RgbConsts k)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dstW || y >= dstH) return;
+    const int cx = x >> chrShift;
+    unsigned ay = (unsigned)-0x40000000, au = (unsigned)-(128 << 23), av = au;
+    const int pl = fl.pos_even[y], pc = fc.pos_even[y];
+    for (int t = 0; t < fl.pairs; t++) {
+        const int cf = fl.packed[(size_t)y * fl.pairs + t];
+        const int r0 = min(pl + 2 * t, lumH - 1), r1 = min(pl + 2 * t + 1, lumH - 1);
+        ay += (unsigned)ly[(size_t)r0 * lumW + x] * (unsigned)(int)(short)(cf & 0xFFFF) + (unsigned)ly[(size_t)r1 * lumW + x] * (unsigned)(cf >> 16);
+    }
+    for (int t = 0; t < fc.pairs; t++) {
+        const int cf = fc.packed[(size_t)y * fc.pairs + t];
+        const unsigned c0 = (unsigned)(int)(short)(cf & 0xFFFF), c1 = (unsigned)(cf >> 16);
+        const int r0 = min(pc + 2 * t, chrH - 1), r1 = min(pc + 2 * t + 1, chrH - 1);
+        au += (unsigned)lu[(size_t)r0 * chrW + cx] * c0 + (unsigned)lu[(size_t)r1 * chrW + cx] * c1;
+        av += (unsigned)lv[(size_t)r0 * chrW + cx] * c0 + (unsigned)lv[(size_t)r1 * chrW + cx] * c1;
+    }
+    int Y = ((int)ay >> 14) + 0x10000;
+    const int U = (int)au >> 14, V = (int)av >> 14;
+    Y = (Y - k.y_offset) * k.y_coeff + (1 << 13);
+    const int R = V * k.v2r, G = V * k.v2g + U * k.u2g, B = U * k.u2b;
+    auto ch = [&](int v) -> unsigned { return (unsigned)min(max(v + Y, 0), 0x3FFFFFFF) >> 14; };
+    const unsigned c0 = ch(bgr ? B : R), c1 = ch(G), c2 = ch(bgr ? R : B);
+    unsigned short *d = reinterpret_cast<unsigned short *>(dst + (size_t)y * ds) + 4 * x;
+    d[0] = (unsigned short)c0; d[1] = (unsigned short)c1; d[2] = (unsigned short)c2; d[3] = 0xFFFF;
+}
+
+int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
+                   const DevFilter &fc, int chrShift, uint8_t *dst, int ds, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,
+                   hipStream_t stream)
+{
+    if (dstW <= 0 || dstH <= 0) return 0;
+    const dim3 grid((dstW + 255) / 256, dstH), block(256);
+    hipLaunchKernelGGL(vrgba64_kernel, grid, block, 0, stream, ly, lu, lv, lumW, lumH, chrW, chrH, fl, fc, chrShift, dst, ds, dstW, dstH, bgr, k);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_hscale19(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst, int dstW,

@@ -127,6 +127,11 @@ int launch_hscale19(const uint8_t *src, int srcStride, int kind, int step, int s
 int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int lineH, const DevFilter &f, uint8_t *dst, int dstStride,
                     int dstW, int dstH, hipStream_t stream);
 
+// RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)
+int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
+                   const DevFilter &fc, int chrShift, uint8_t *dst, int dstStride, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,
+                   hipStream_t stream);
+
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
 int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                      int inW, int inH, int bpp, int dir, hipStream_t stream);

@@ -333,7 +333,7 @@ static int local_chroma_pos(int sub, int pos)      // utils.c:338-345 with the d
 int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
                      int flags, const double param[2], const int *chrPos)
 {
-    const bool src_rgb = is_packed_rgb(srcFormat), dst_rgb = is_packed_rgb(dstFormat);
+    const bool src_rgb = is_packed_rgb(srcFormat), dst_rgb = is_packed_rgb(dstFormat) || is_rgb64(dstFormat);
     const bool src444 = srcFormat == GMAT_PIX_FMT_YUV444P;
     const bool dst444 = dstFormat == GMAT_PIX_FMT_YUV444P;
     if (!(src_rgb || is_yuv420(srcFormat) || src444 || is_p01x(srcFormat)) ||

@@ -38,8 +38,8 @@
  * the yuv2rgb_full_* (FULL_CHR_H_INT) outputs, the Lanczos branch of initFilter, the nearest-
  * chroma frame walk of yuv2rgb_c_24_* (its tables are pinned by filter-colorlevels), ToUV_half,
  * the P010LE / P016LE readers (p010LEToY_c / ToUV_c, three lines each; the hScale16To15_c they
- * feed is pinned through the RGB sources), the P010LE / P016LE output stages (yuv2p010*, the 19-bit
- * hScale*To19_c / yuv2planeX_16_c family), the 24 <-> 32 bit RGB re-packing (orc_rgb_repack),
+ * feed is pinned through the RGB sources), the P010LE / P016LE / RGBA64 output stages (yuv2p010*, the 19-bit
+ * hScale*To19_c / yuv2planeX_16_c / yuv2rgba64_* family), the 24 <-> 32 bit RGB re-packing (orc_rgb_repack),
  * hflip/vflip/crop/convolution (their FATE references are NUT-container md5s, which would need
  * the muxer restated).
  */
@@ -63,6 +63,8 @@ enum {
     ORC_PIX_BGRA    = 28,
     ORC_PIX_P010LE  = 159,
     ORC_PIX_P016LE  = 170,
+    ORC_PIX_RGBA64LE = 105,
+    ORC_PIX_BGRA64LE = 107,
     ORC_PIX_RGBPF32LE = 179,
 };
 

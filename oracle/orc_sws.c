@@ -45,6 +45,7 @@ struct OrcSws {
 
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
 static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
+static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
 static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || is_p01x(f)) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
 static unsigned rl16(const uint8_t *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
@@ -141,9 +142,9 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
      * P016LE switches to the 19-bit ones (scale_to_p016 below) */
     if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) ||
-        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt)))
+        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_rgb64(dst_fmt)))
         return NULL;
-    if (dst_fmt == ORC_PIX_P016LE && (is_rgb(src_fmt) || src_range != dst_range))
+    if ((dst_fmt == ORC_PIX_P016LE || is_rgb64(dst_fmt)) && (is_rgb(src_fmt) || src_range != dst_range))
         return NULL;                                       /* RGB readers / 16-bit range conversion for 19-bit lines: not restated */
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
@@ -157,7 +158,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     c->src_w = src_w; c->src_h = src_h; c->dst_w = dst_w; c->dst_h = dst_h;
     c->src_fmt = src_fmt; c->dst_fmt = dst_fmt;
     c->src_is_rgb = is_rgb(src_fmt);
-    c->dst_is_rgb = is_rgb(dst_fmt);
+    c->dst_is_rgb = is_rgb(dst_fmt) || is_rgb64(dst_fmt);
 
     c->lum_x_inc = (int)((((int64_t)src_w << 16) + (dst_w >> 1)) / dst_w);
     c->lum_y_inc = (int)((((int64_t)src_h << 16) + (dst_h >> 1)) / dst_h);
@@ -621,8 +622,8 @@ static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, in
     return 0x8000 + v;
 }
 
-static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
-                         const int dst_stride[4])
+/* the 19-bit lines of a whole frame: luma src_h x dst_w, chroma chr_src_h x chr_dst_w per plane */
+static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], int32_t **pl, int32_t **pu, int32_t **pv)
 {
     const int dw = c->dst_w, cdw = c->chr_dst_w, sh8 = 3;
     const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
@@ -632,9 +633,8 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
     int32_t *lv = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
     uint16_t *t0 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
     uint16_t *t1 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
-    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(c->v_lum_size + c->v_chr_size) * 2);
-    int y, i, j, ret = -1;
-    if (!ly || !lu || !lv || !t0 || !t1 || !lp) goto done;
+    int y, i;
+    if (!ly || !lu || !lv || !t0 || !t1) { free(ly); free(lu); free(lv); free(t0); free(t1); return -1; }
     for (y = 0; y < c->src_h; y++) {
         const uint8_t *row = src[0] + (long)y * src_stride[0];
         for (i = 0; i < c->src_w; i++)
@@ -657,6 +657,19 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
         hscale19(lu + (size_t)y * cdw, cdw, t0, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
         hscale19(lv + (size_t)y * cdw, cdw, t1, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
     }
+    free(t0); free(t1);
+    *pl = ly; *pu = lu; *pv = lv;
+    return 0;
+}
+
+static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
+                         const int dst_stride[4])
+{
+    const int dw = c->dst_w, cdw = c->chr_dst_w;
+    int32_t *ly = NULL, *lu = NULL, *lv = NULL;
+    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(c->v_lum_size + c->v_chr_size) * 2);
+    int y, i, j, ret = -1;
+    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv) < 0) goto done;
     for (y = 0; y < c->dst_h; y++) {
         uint8_t *d = dst[0] + (long)y * dst_stride[0];
         for (j = 0; j < c->v_lum_size; j++) {
@@ -687,7 +700,92 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
     }
     ret = c->dst_h;
 done:
-    free(ly); free(lu); free(lv); free(t0); free(t1); free((void *)lp);
+    free(ly); free(lu); free(lv); free((void *)lp);
+    return ret;
+}
+
+/* ---- RGBA64LE / BGRA64LE destinations on the 19-bit lines -------------------------------------------------------
+ * packed_vscale's choice of form (vscale.c:135-167) and the three forms of each chroma mode, output.c:
+ *   yuv2rgba64_X_c :1025-1105   _2_c :1107-1170   _1_c :1172-1272   (one chroma sample per pixel PAIR)
+ *   yuv2rgba64_full_X_c :1275-1337, _full_2_c, _full_1_c             (one chroma sample per pixel)
+ * and their common colour stage: Y = (Y - y_offset) * y_coeff + (1 << 13); R = V * v2r; G = V * v2g + U * u2g;
+ * B = U * u2b; channel = clip_uintp2(X + Y, 30) >> 14; alpha 0xFFFF (no alpha plane). */
+static int clip_uintp2_30b(int a) { return (a & ~0x3FFFFFFF) ? (~a >> 31) & 0x3FFFFFFF : a; }
+
+static void put_rgba64(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+{
+    int R, G, B, o[3], k;
+    Y -= c->y2r.y_offset;
+    Y *= c->y2r.y_coeff;
+    Y += 1 << 13;
+    R = V * c->y2r.v2r;
+    G = V * c->y2r.v2g + U * c->y2r.u2g;
+    B = U * c->y2r.u2b;
+    o[0] = clip_uintp2_30b((c->dst_fmt == ORC_PIX_RGBA64LE ? R : B) + Y) >> 14;
+    o[1] = clip_uintp2_30b(G + Y) >> 14;
+    o[2] = clip_uintp2_30b((c->dst_fmt == ORC_PIX_RGBA64LE ? B : R) + Y) >> 14;
+    for (k = 0; k < 3; k++) put16(d + 2 * k, o[k]);
+    put16(d + 6, 0xFFFF);
+}
+
+static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
+                           const int dst_stride[4])
+{
+    const int dw = c->dst_w, cdw = c->chr_dst_w, full = (c->flags & ORC_SWS_FULL_CHR_H_INT) != 0;
+    const int lfs = c->v_lum_size, cfs = c->v_chr_size;
+    int32_t *ly = NULL, *lu = NULL, *lv = NULL;
+    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(lfs + 2 * cfs));
+    int y, i, j, ret = -1;
+    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv) < 0) goto done;
+    for (y = 0; y < c->dst_h; y++) {
+        uint8_t *d = dst[0] + (long)y * dst_stride[0];
+        const int16_t *lf = c->v_lum + y * lfs, *cf = c->v_chr + y * cfs;
+        const int32_t **up = lp + lfs, **vp = up + cfs;
+        const int chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
+        const int lum2 = lfs == 2 && lf[0] + lf[1] == 4096 && (unsigned)lf[1] <= 4096u;
+        for (j = 0; j < lfs; j++) {
+            int r = c->v_lum_pos[y] + j;
+            lp[j] = ly + (size_t)(r < c->src_h ? r : c->src_h - 1) * dw;
+        }
+        for (j = 0; j < cfs; j++) {
+            int r = c->v_chr_pos[y] + j;
+            if (r >= c->chr_src_h) r = c->chr_src_h - 1;
+            up[j] = lu + (size_t)r * cdw; vp[j] = lv + (size_t)r * cdw;
+        }
+        for (i = 0; i < dw; i++) {
+            const int ci = full ? i : i >> 1;
+            int Y, U, V;
+            if (lfs == 1 && (cfs == 1 || chr2)) {                         /* yuv2packed1, uvalpha = 0 or cf[1] */
+                const int uvalpha = cfs == 1 ? 0 : cf[1];
+                Y = lp[0][i] >> 2;
+                if (uvalpha < 2048) {
+                    U = (up[0][ci] - (128 << 11)) >> 2;
+                    V = (vp[0][ci] - (128 << 11)) >> 2;
+                } else {
+                    U = (up[0][ci] + up[1][ci] - (128 << 12)) >> 3;
+                    V = (vp[0][ci] + vp[1][ci] - (128 << 12)) >> 3;
+                }
+            } else if (lum2 && chr2) {                                     /* yuv2packed2 */
+                Y = (lp[0][i] * (4096 - lf[1]) + lp[1][i] * lf[1]) >> 14;
+                U = (up[0][ci] * (4096 - cf[1]) + up[1][ci] * cf[1] - (128 << 23)) >> 14;
+                V = (vp[0][ci] * (4096 - cf[1]) + vp[1][ci] * cf[1] - (128 << 23)) >> 14;
+            } else {                                                       /* yuv2packedX, 32-bit wrap-around sums */
+                unsigned ay = (unsigned)-0x40000000, au = (unsigned)-(128 << 23), av = au;
+                for (j = 0; j < lfs; j++) ay += (unsigned)lp[j][i] * (unsigned)(int)lf[j];
+                for (j = 0; j < cfs; j++) {
+                    au += (unsigned)up[j][ci] * (unsigned)(int)cf[j];
+                    av += (unsigned)vp[j][ci] * (unsigned)(int)cf[j];
+                }
+                Y = ((int)ay >> 14) + 0x10000;
+                U = (int)au >> 14;
+                V = (int)av >> 14;
+            }
+            put_rgba64(c, d + 8 * i, Y, U, V);
+        }
+    }
+    ret = c->dst_h;
+done:
+    free(ly); free(lu); free(lv); free((void *)lp);
     return ret;
 }
 
@@ -703,6 +801,8 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
 
     if (c->dst_fmt == ORC_PIX_P016LE)
         return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_p016(c, src, src_stride, dst, dst_stride) : -1;
+    if (is_rgb64(c->dst_fmt))
+        return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_rgba64(c, src, src_stride, dst, dst_stride) : -1;
     if (y0 < 0) y0 = 0;
     if (y1 > c->dst_h) y1 = c->dst_h;
     if (y0 >= y1) return 0;
@@ -784,6 +884,8 @@ int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4
     int y, band = 64;
     if (c->dst_fmt == ORC_PIX_P016LE)
         return scale_to_p016(c, src, src_stride, dst, dst_stride);
+    if (is_rgb64(c->dst_fmt))
+        return scale_to_rgba64(c, src, src_stride, dst, dst_stride);
     for (y = 0; y < c->dst_h; y += band) {
         int r = orc_sws_scale_rows(c, src, src_stride, dst, dst_stride, y,
                                    y + band < c->dst_h ? y + band : c->dst_h);

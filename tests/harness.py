@@ -127,6 +127,8 @@ def plane_shapes(fmt, w, h):
         return [(h, 3 * w)]
     if fmt in ("rgba", "bgra"):
         return [(h, 4 * w)]
+    if fmt in ("rgba64le", "bgra64le"):
+        return [(h, 8 * w)]
     if fmt == "nv12":
         return [(h, w), ((h + 1) // 2, 2 * ((w + 1) // 2))]
     if fmt == "yuv420p":

@@ -442,6 +442,8 @@ def test_filter_layer_scale_from_p01x(dev, orc, src_fmt):
     res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24}, src, w, h, src_fmt)
     for a, b in zip(res, orc.sws(src, w, h, src_fmt, 64, 24, src_fmt, SWS["bicubic"])):
         assert (a == b).all()
+    res, _, _ = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "format": "rgba64le"}, src, w, h, src_fmt)
+    assert (res[0] == orc.sws(src, w, h, src_fmt, 64, 24, "rgba64le", SWS["bicubic"])[0]).all()
     nv = synth_planes(orc, "nv12", w, h, 100)
     up, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": src_fmt}, nv, w, h, "nv12")
     assert (up[0].view(np.uint16) == nv[0].astype(np.uint16) * 257).all()
