@@ -641,6 +641,15 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
+    if (c->inner) return gmat_sws_setRange(c->inner, srcFullRange, dstFullRange);
+    if (c->mode == MODE_RGB2YUV) {
+        // an RGB source has no range of its own (forced to 0, utils.c:902-1030): a full-range destination is the
+        // limited -> full conversion of the 15-bit lines (lum/chrRangeToJpeg_c), as in the second half of libswscale's
+        // YUV -> RGB -> YUV cascade for differing matrices (utils.c:966-1036)
+        if (srcFullRange) return GMAT_ERR(ENOSYS);
+        c->rangeConv = dstFullRange ? 1 : 0;
+        return 0;
+    }
     if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
@@ -762,6 +771,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
         L.maxRows = c->r2y.maxRows;
         L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
+        L.toJpeg = c->rangeConv == 1;
         c->lastKernel = "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;

@@ -25,6 +25,7 @@ constexpr int R2Y_TW = 128, R2Y_TH = 32, R2Y_CW = R2Y_TW / 2, R2Y_CH = R2Y_TH / 
 
 struct Rgb2YuvArgs {
     const uint8_t *src; int ss, bgr, srcAligned;
+    int toJpeg;                          // lum/chrRangeToJpeg_c on the 15-bit values before the output stage
     uint8_t *y, *u, *v; int ys, us, vs, nv12;
     int w, h, cw, ch;
     DevFilter vChr;                      // chroma vertical filter over SOURCE rows, count = ch
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int y14 = rgb_to_y14(a.k, r[i], gg[i], b[i]);
-                yb |= (unsigned)clip_u8((min(2 * y14, 32767) + 64) >> 7) << (8 * i);
+                int l = min(2 * y14, 32767);
+                if (a.toJpeg) l = (m24(min(l, 30189), 19077) - 39057361) >> 14;          // lumRangeToJpeg_c, swscale.c:176-181
+                yb |= (unsigned)clip_u8((l + 64) >> 7) << (8 * i);
             }
             uint8_t *d = a.y + (size_t)srow * a.ys + col;
             if (col + 4 <= a.w && ((((uintptr_t)a.y | (uintptr_t)a.ys) & 3) == 0)) *reinterpret_cast<unsigned *>(d) = yb;
@@ -93,8 +96,12 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
             for (int i = 0; i < 2; i++) {
                 const int rs = r[2 * i] + r[2 * i + 1], gs = gg[2 * i] + gg[2 * i + 1], bs = b[2 * i] + b[2 * i + 1];
                 const int o = (((wr >> 1) * R2Y_CW + 2 * cg + i) << 1) + (wr & 1);
-                hu16[o] = (short)min(2 * rgbsum_to_u14(a.k, rs, gs, bs), 32767);
-                hv16[o] = (short)min(2 * rgbsum_to_v14(a.k, rs, gs, bs), 32767);
+                int cu = min(2 * rgbsum_to_u14(a.k, rs, gs, bs), 32767), cv = min(2 * rgbsum_to_v14(a.k, rs, gs, bs), 32767);
+                if (a.toJpeg) {                                                              // chrRangeToJpeg_c, swscale.c:157-164
+                    cu = (m24(min(cu, 30775), 4663) - 9289992) >> 12; cv = (m24(min(cv, 30775), 4663) - 9289992) >> 12;
+                }
+                hu16[o] = (short)cu;
+                hv16[o] = (short)cv;
             }
         }
     }
@@ -240,7 +247,7 @@ int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t)
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream)
 {
     Rgb2YuvArgs a;
-    a.src = L.src; a.ss = L.ss; a.bgr = L.bgr;
+    a.src = L.src; a.ss = L.ss; a.bgr = L.bgr; a.toJpeg = L.toJpeg;
     a.srcAligned = ((((uintptr_t)L.src | (uintptr_t)L.ss) & 3) == 0);
     a.y = L.y; a.u = L.u; a.v = L.v; a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.nv12 = L.nv12;
     a.w = L.w; a.h = L.h; a.cw = (L.w + 1) / 2; a.ch = (L.h + 1) / 2;

@@ -159,6 +159,7 @@ struct Rgb2YuvPlan {
     std::vector<int32_t> rowStart, rowCount, round;
 };
 struct Rgb2YuvLaunch {
+    int toJpeg = 0;                      // full-range YUV output: lum/chrRangeToJpeg_c on the 15-bit values (swscale.c:157-181)
     const uint8_t *src; int ss, bgr;
     uint8_t *y, *u, *v; int ys, us, vs, nv12;
     int w, h;

@@ -30,6 +30,8 @@
  *         filter-colorlevels (50 frames)  -> yuv420p->rgb24 generic path: yuv2rgb_X_c and the
  *                                            yuv2rgb.c tables shared with the fast path
  *         pixfmt-rgb24 / -bgr24 / -yuv420p -> rgb24ToY/ToUV, hScale16To15, chroma up-scaling
+ *         sws-yuv-colorspace              -> BT.709 yuv2rgb tables, BGR readers + BT.601 rgb2yuv literals,
+ *                                            range conversion of an RGB-sourced context (the cascade's two halves)
  *   (2) known-answer values the survey recorded from the reference (SURVEY.md §8a row 7,
  *       §8c item 5) and constants literal in its sources (ff_yuv2rgb_coeffs, BT.601 literals);
  *   (3) the LUT path and the closed form being two independent restatements that must agree

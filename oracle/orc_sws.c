@@ -166,7 +166,9 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     c->chr_src_hsub = c->chr_src_vsub = fmt_sub(src_fmt);
     c->chr_dst_hsub = c->chr_dst_vsub = fmt_sub(dst_fmt);
     if (src_range != dst_range) {
-        if (c->src_is_rgb || c->dst_is_rgb) { free(c); return NULL; }
+        /* RGB ends have their range forced to 0 (utils.c:902-1030): an RGB source with a full-range YUV destination
+         * is the limited -> full conversion of the 15-bit lines */
+        if (c->dst_is_rgb || (c->src_is_rgb && src_range)) { free(c); return NULL; }
         c->range_conv = dst_range ? 1 : 2;
     }
 

@@ -7,6 +7,7 @@ checksum the reference tree ships in tests/ref/fate (fixture tests/golden/fate_r
   filter-transpose    = transpose (cclock_flip) of each yuv420p plane (filter-video.mak:297-298)
   pixfmt-rgb24/bgr24  = yuv420p -> rgb24|bgr24 -> yuv444p, md5 of the raw frame (tests/fate-run.sh pixfmt_conversion)
   pixfmt-yuv420p      = yuv420p -> yuv444p
+  sws-yuv-colorspace  = yuv420p (bt709, limited) -> yuv420p (bt601, full): libswscale's two-context cascade through bgr24
 The oracle only supplies the input clip (oracle/orc_vsynth.c restates tests/videogen.c).
 """
 import ctypes as C
@@ -154,3 +155,30 @@ def test_product_reproduces_fate_pixfmt(dev, clip, fmt):
         p.free()
     raw = b"".join(bytes(np.ascontiguousarray(o)) for o in outs)
     assert hashlib.md5(raw).hexdigest() == GOLD_MD5[fmt], kernel
+
+
+def test_product_reproduces_fate_sws_yuv_colorspace(dev, clip):
+    """differing matrices between two YUV ends: what libswscale does internally (sws_setColorspaceDetails, utils.c:966-
+    1036) spelled out with two contexts of the C ABI — yuv420p -> bgr24 with the source's BT.709 matrix, then bgr24 ->
+    yuv420p with BT.601 and a full-range destination"""
+    from harness import planes, ints, PIX_FMT
+    lib = dev.lib
+    flags = SWS["bicubic"] | SWS["accurate_rnd"] | SWS["bitexact"]
+    src = dev.upload_planes(yuv420p_planes(clip[0]))
+    mid = dev.planes_like("bgr24", W, H)
+    dst = dev.planes_like("yuv420p", W, H)
+    c0 = lib.gmat_sws_getContext(W, H, PIX_FMT["yuv420p"], W, H, PIX_FMT["bgr24"], flags, None)
+    c1 = lib.gmat_sws_getContext(W, H, PIX_FMT["bgr24"], W, H, PIX_FMT["yuv420p"], flags, None)
+    assert c0 and c1
+    assert lib.gmat_sws_setColorspace(c0, 1, 0) == 0                       # SWS_CS_ITU709, limited-range source
+    assert lib.gmat_sws_setRange(c1, 0, 1) == 0                            # full-range destination
+    assert lib.gmat_sws_scale(c0, planes([p.ptr for p in src]), ints([p.stride for p in src]), 0, H,
+                              planes([p.ptr for p in mid]), ints([p.stride for p in mid])) == H
+    assert lib.gmat_sws_scale(c1, planes([p.ptr for p in mid]), ints([p.stride for p in mid]), 0, H,
+                              planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == H
+    out = np.concatenate([p.download().ravel() for p in dst])
+    assert out.size == GOLD["sws-yuv-colorspace"][0]["size"]
+    assert adler0(out) == GOLD["sws-yuv-colorspace"][0]["adler32"], (lib.gmat_sws_lastKernel(c0), lib.gmat_sws_lastKernel(c1))
+    lib.gmat_sws_freeContext(c0); lib.gmat_sws_freeContext(c1)
+    for p in src + mid + dst:
+        p.free()

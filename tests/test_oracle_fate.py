@@ -102,6 +102,28 @@ def test_fate_sws_yuv_range(fate):
     check_crcs("sws-yuv-range", [out])
 
 
+def test_fate_sws_yuv_colorspace(fate):
+    """scale=in_color_matrix=bt709:in_range=limited:out_color_matrix=bt601:out_range=full on yuv420p at equal size
+    (libswscale.mak:20-26).  Differing matrices between two YUV ends make libswscale cascade two contexts through an
+    8-bit BGR24 frame (sws_setColorspaceDetails, utils.c:966-1036): yuv420p -> bgr24 with the SOURCE matrix (BT.709
+    tables; generic path because of accurate_rnd), then bgr24 -> yuv420p with the DESTINATION matrix (BT.601 literals)
+    and the limited -> full conversion of its 15-bit lines (the RGB side's range is forced to 0).  The cascaded
+    contexts are fresh ones: default chroma positions."""
+    L, clip = fate
+    L.orc_sws_set_colorspace.argtypes = [C.c_void_p, C.c_int]
+    f0 = clip.reshape(NFRAMES, -1)[0]
+    flags = BICUBIC | ACCURATE_RND | BITEXACT
+    P4, I4 = C.c_void_p * 4, C.c_int * 4
+    s, mid = split(YUV420P, W, H, f0), split(BGR24, W, H)
+    c0 = L.orc_sws_create_ex(W, H, YUV420P, W, H, BGR24, flags, None, (C.c_int * 4)(-513, -513, -513, -513), 0, 0)
+    assert c0 and L.orc_sws_set_colorspace(c0, 1) == 0                       # SWS_CS_ITU709
+    assert L.orc_sws_scale(c0, P4(*[p.ctypes.data for p in s]), I4(*[p.shape[1] for p in s]),
+                           P4(*[p.ctypes.data for p in mid]), I4(*[p.shape[1] for p in mid])) == H
+    L.orc_sws_free(c0)
+    out = sws(L, mid[0].ravel(), BGR24, YUV420P, flags, src_range=0, dst_range=1)
+    check_crcs("sws-yuv-colorspace", [out])
+
+
 def test_fate_filter_scalechroma(fate):
     L, clip = fate
     # the recipe reads vsynth1.yuv as 352x288 yuv444p: 25 frames of 304128 bytes

@@ -59,6 +59,40 @@ def test_rgb_to_yuv_colorspaces(dev, orc, cs, dst_fmt):
         assert any((a != b).any() for a, b in zip(want, base))      # the matrix really changed something
 
 
+@pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
+def test_rgb_to_full_range_yuv(dev, orc, src_fmt, dst_fmt):
+    """a full-range YUV destination of an RGB source: lum/chrRangeToJpeg_c on the 15-bit lines (the RGB end's range is
+    forced to 0); gmat_sws_setRange(c, 0, 1)"""
+    import ctypes as C
+    w, h = 130, 34
+    L = orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    from harness import alloc_planes
+    src = synth_planes(orc, src_fmt, w, h, seed=61)
+    oc = L.orc_sws_create_ex(w, h, PIX_FMT[src_fmt], w, h, PIX_FMT[dst_fmt], SWS["bicubic"], None, (C.c_int * 4)(-513, -513, -513, -513), 0, 1)
+    assert oc
+    want = alloc_planes(dst_fmt, w, h)
+    assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                           planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == h
+    L.orc_sws_free(oc)
+    c = dev.lib.gmat_sws_getContext(w, h, PIX_FMT[src_fmt], w, h, PIX_FMT[dst_fmt], SWS["bicubic"], None)
+    assert c and dev.lib.gmat_sws_setRange(c, 0, 1) == 0 and dev.lib.gmat_sws_setRange(c, 1, 1) < 0
+    assert dev.lib.gmat_sws_setRange(c, 0, 1) == 0
+    d = dev.upload_planes(src, 64)
+    dst = dev.planes_like(dst_fmt, w, h, 64)
+    assert dev.lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
+                                  planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
+    for a, b in zip(dst, want):
+        assert (a.download() == b).all()
+    base = orc.sws(src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"])
+    assert (base[0] != want[0]).any()
+    dev.lib.gmat_sws_freeContext(c)
+    for p in d + dst:
+        p.free()
+
+
 @pytest.mark.parametrize("flags", ["bilinear", "point", "lanczos"])
 def test_rgb_to_nv12_other_vertical_filters(dev, orc, flags):
     w, h = 192, 40

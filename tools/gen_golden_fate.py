@@ -6,6 +6,7 @@ Run in the build container (needs /root/reference); the JSON it writes is commit
 tests/test_oracle_fate.py checks the oracle against.  Sources, all under
 /root/reference/ffmpeg-gpu/tests/ref:
   fate/sws-yuv-range       (recipe tests/fate/libswscale.mak:28-34)
+  fate/sws-yuv-colorspace  (recipe tests/fate/libswscale.mak:20-26)
   fate/filter-scalechroma  (tests/fate/filter-video.mak:416-418)
   fate/filter-colorlevels  (tests/fate/filter-video.mak:423-424; colorlevels with default options is
                             the identity, vf_colorlevels.c:405-439 -> the checksums are those of
@@ -36,7 +37,7 @@ def md5ref(name):
 def main():
     doc = {
         "_source": "ffmpeg-gpu/tests/ref/fate/* and tests/ref/pixfmt/* of the reference tree (golden values only)",
-        "framecrc": {n: framecrc(n) for n in ("sws-yuv-range", "filter-scalechroma", "filter-colorlevels",
+        "framecrc": {n: framecrc(n) for n in ("sws-yuv-range", "sws-yuv-colorspace", "filter-scalechroma", "filter-colorlevels",
                                               "filter-transpose")},
         "pixfmt_md5": {n: md5ref(n) for n in ("rgb24", "bgr24", "yuv420p")},
     }
