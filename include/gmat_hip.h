@@ -106,7 +106,10 @@ GMAT_API int  gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcF
 /* srcRange / dstRange of sws_setColorspaceDetails for YUV -> YUV contexts (1 = full "jpeg" range): when they
  * differ, the h-scaled lines go through lum/chrRangeToJpeg_c or ...FromJpeg_c (swscale.c:157-188, hooked in
  * hscale.c:60,:193) and a same-size context leaves the plane-copy path for the generic one, exactly as
- * libswscale does (utils.c:1996-2000).  Returns -ENOSYS for a non-zero range on a context with an RGB end. */
+ * libswscale does (utils.c:1996-2000).  An RGB source has no range of its own; an RGB24 / BGR24 -> 4:2:0 context of
+ * equal size accepts dstFullRange = 1 (the limited -> full conversion of its 15-bit lines — the second half of
+ * libswscale's YUV -> RGB -> YUV cascade for differing matrices, utils.c:966-1036).  Other contexts with an RGB end
+ * return -ENOSYS for a non-zero range. */
 GMAT_API int  gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange);
 /* the AVOptions src_h_chr_pos / src_v_chr_pos / dst_h_chr_pos / dst_v_chr_pos (options.c:67-70, used by
  * vf_scale.c:567-578): chroma sample positions in 1/256 of a luma sample, -513 = unset.  Rebuilds the chroma
