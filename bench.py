@@ -236,18 +236,21 @@ def other_configs(lib, torch, stream, frames=16):
     sws_case("configs[1]: 1080p nv12 -> rgb24", "nv12", 1920, 1080, "rgb24", 1920, 1080, 1920 * 1080 * 9 // 2)
 
     def batch_case(name, sf, sw, sh, df, dw, dh, alg_bytes, n=32):
-        """the same conversion through gmat_sws_scale_batch: n frames of one geometry per launch (grid.z = frame)"""
+        """the same conversion through gmat_sws_scale_batch: n frames of one geometry per launch (one grid dimension = frame)"""
         src = [torch.randint(0, 256, (sw * sh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(n)]
-        dst = [torch.empty((dw * dh * 3,), dtype=torch.uint8, device="cuda") for _ in range(n)]
+        dst = [torch.empty((dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(n)]
         c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], 4, None)
         sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
         for i in range(n):
             sp[4 * i], sp[4 * i + 1], dp[4 * i] = src[i].data_ptr(), src[i].data_ptr() + sw * sh, dst[i].data_ptr()
+            if df != "rgb24":
+                dp[4 * i + 1] = dst[i].data_ptr() + dw * dh
         streams = (C.c_void_p * 1)(stream)
+        dstr = ints([dw * 3]) if df == "rgb24" else ints([dw, dw])
 
         def run():
             r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([sw, sw]), C.cast(dp, C.POINTER(C.c_void_p)),
-                                         ints([dw * 3]), C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
+                                         dstr, C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
             assert r == n
         ms = time_single_kernel(lib, torch, run, stream, 64)
         fpl = int(lib.gmat_sws_lastLaunchFrames(c))
@@ -261,6 +264,8 @@ def other_configs(lib, torch, stream, frames=16):
     batch_case("configs[1], 32 frames per launch", "nv12", 1920, 1080, "rgb24", 1920, 1080, 1920 * 1080 * 9 // 2)
     sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", SRC_W, SRC_H, "nv12", DST_W, DST_H,
              SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2)
+    batch_case("transcode, 32 frames per launch", "nv12", SRC_W, SRC_H, "nv12", DST_W, DST_H,
+               SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2)
     # configs[3]: rotate(90) + hflip + 3x3 smooth as ONE kernel on 4K rgb24
     w, h = SRC_W, SRC_H
     src = [torch.randint(0, 256, (h, w * 3), dtype=torch.uint8, device="cuda") for _ in range(frames)]
