@@ -117,7 +117,9 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
     const int rowA = wave * 6 + rs, rowB = rowA + 24;            // nrL <= 48, nrC <= 24 (yuv2x_prepare)
     const unsigned colL = (unsigned)min(max(c0L + 16 * g, 0), a.srcW - 16);
     const unsigned colC = (unsigned)min(max(c0C + 8 * g, 0), a.chrSrcW - 8);
-    struct TileRegs { uint4 va, vb, tc, tv0, tv1; int r0L, nrL, r0C, nrC; };
+    // the Lanczos 4:2:0-output variant filters 8 chroma rows from 26-28 source rows: a second chroma slot (rows 24..47)
+    constexpr bool C2 = YUVOUT && P == 8;
+    struct TileRegs { uint4 va, vb, tc, tc2, tv0, tv1; int r0L, nrL, r0C, nrC; };
     // table chunk i of tile row `trow`: the coefficient rows (first tile of the block only) and the vertical records
     auto tab_src = [&](int i, int trow) -> const uint4 * {
         const int ty0 = trow * X2_TH;
@@ -153,6 +155,18 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
         const unsigned crow = (unsigned)min(max(R.r0C + min(rowA, R.nrC - 1), 0), a.chrSrcH - 1);
         R.va = *reinterpret_cast<const uint4 *>(a.y + offA);
         R.vb = *reinterpret_cast<const uint4 *>(a.y + offB);
+        R.tc2 = make_uint4(0u, 0u, 0u, 0u);
+        if (C2) {
+            const unsigned crow2 = (unsigned)min(max(R.r0C + min(rowB, R.nrC - 1), 0), a.chrSrcH - 1);
+            if (a.nv12) {
+                R.tc2 = *reinterpret_cast<const uint4 *>(a.u + crow2 * (unsigned)a.us + 2 * colC);
+            } else {
+                const uint2 tu = *reinterpret_cast<const uint2 *>(a.u + crow2 * (unsigned)a.us + colC);
+                const uint2 tv = *reinterpret_cast<const uint2 *>(a.v + crow2 * (unsigned)a.vs + colC);
+                R.tc2.x = __builtin_amdgcn_perm(tv.x, tu.x, 0x05010400u); R.tc2.y = __builtin_amdgcn_perm(tv.x, tu.x, 0x07030602u);
+                R.tc2.z = __builtin_amdgcn_perm(tv.y, tu.y, 0x05010400u); R.tc2.w = __builtin_amdgcn_perm(tv.y, tu.y, 0x07030602u);
+            }
+        }
         if (a.nv12) {
             R.tc = *reinterpret_cast<const uint4 *>(a.u + crow * (unsigned)a.us + 2 * colC);       // U0 V0 U1 V1 ...
         } else {
@@ -178,6 +192,14 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
             const uint2 p0 = x2_widen(R.vb.x), p1 = x2_widen(R.vb.y), p2 = x2_widen(R.vb.z), p3 = x2_widen(R.vb.w);
             d[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
             if (X2_COLSL == 160 || g < 9) d[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+        }
+        if (C2 && act && rowB < R.nrC) {
+            *reinterpret_cast<uint4 *>(lu + rowB * X2_COLSC + 8 * g) =
+                make_uint4(__builtin_amdgcn_perm(0u, R.tc2.x, 0x0C020C00u), __builtin_amdgcn_perm(0u, R.tc2.y, 0x0C020C00u),
+                           __builtin_amdgcn_perm(0u, R.tc2.z, 0x0C020C00u), __builtin_amdgcn_perm(0u, R.tc2.w, 0x0C020C00u));
+            *reinterpret_cast<uint4 *>(lv + rowB * X2_COLSC + 8 * g) =
+                make_uint4(__builtin_amdgcn_perm(0u, R.tc2.x, 0x0C030C01u), __builtin_amdgcn_perm(0u, R.tc2.y, 0x0C030C01u),
+                           __builtin_amdgcn_perm(0u, R.tc2.z, 0x0C030C01u), __builtin_amdgcn_perm(0u, R.tc2.w, 0x0C030C01u));
         }
         if (act && rowA < R.nrC) {
             // U samples are bytes 0 and 2 of each dword, V samples bytes 1 and 3
@@ -517,7 +539,8 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     if (g.fullChroma || g.yuvOut == 2 || g.TW != X2_TW || g.TH != X2_TH) return 0;
     if (!is_yuv420(p.srcFormat) || p.dstFormat == GMAT_PIX_FMT_P010LE) return 0;                    // the tile geometry assumes half-size chroma planes
     if (p.srcW % 16 || p.chrSrcW % 8 || p.srcW < 16) return 0;
-    if (g.rowsL > 48 || g.rowsC > 24) return 0;               // phase 1 covers 48 luma / 24 chroma rows per tile
+    if (g.rowsL > 48 || g.rowsC > 48) return 0;               // phase 1 covers 48 luma rows and 24 chroma rows per tile (48 in
+                                                              // the Lanczos 4:2:0-output variant, checked below)
     t.ntx = g.ntx; t.nty = g.nty;
     // smallest window that holds every row: 10 samples (bicubic, bilinear ...) or 16 (Lanczos-3)
     int P = 0;
@@ -535,6 +558,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
         if (fits) { P = cand; break; }
     }
     if (!P) return 0;
+    if (g.rowsC > 24 && !(g.yuvOut && P == 8)) return 0;
     const int X2_VR = x2_vr(P), VR_C = x2_vr_chroma(P), VR_M = x2_vr_misc(P);
     const int bytes = g.rowsL * x2_colsl(P) * 2 + 2 * g.rowsC * X2_COLSC * 2 + (g.rowsL / 2) * X2_TW * 4 +
                       2 * (g.rowsC / 2) * (X2_TW / 2) * 4 + (X2_TW + X2_TW / 2) * P * 4 + X2_TH * X2_VR * 4 +

@@ -117,6 +117,7 @@ batch_case("1080p nv12 -> rgb24 (convert), 16 fr/launch", "nv12", 1920, 1080, "r
 batch_case("4K nv12 -> 720p nv12, 16 frames/launch", "nv12", 3840, 2160, "nv12", 1280, 720, 1)
 batch_case("1080p nv12 -> 720p nv12, 16 frames/launch", "nv12", 1920, 1080, "nv12", 1280, 720, 1)
 batch_case("1080p nv12 -> 4K nv12 (up), 16 fr/launch", "nv12", 1920, 1080, "nv12", 3840, 2160, 1)
+batch_case("4K nv12 -> 1080p nv12 lanczos, 16 fr/launch", "nv12", 3840, 2160, "nv12", 1920, 1080, 1, SWS["lanczos"])
 batch_case("4K nv12 -> 1080p rgb24 lanczos, 16 fr/launch", "nv12", 3840, 2160, "rgb24", 1920, 1080, 1, SWS["lanczos"])
 sws_case("4K nv12 -> 1080p rgb24 (headline)", "nv12", 3840, 2160, "rgb24", 1920, 1080)
 sws_case("4K nv12 -> 1080p rgb24 lanczos", "nv12", 3840, 2160, "rgb24", 1920, 1080, SWS["lanczos"])
