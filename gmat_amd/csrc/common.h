@@ -28,7 +28,8 @@ void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)))
 
 inline bool is_packed_rgb(int f)
 {
-    return f == GMAT_PIX_FMT_RGB24 || f == GMAT_PIX_FMT_BGR24 || f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA;
+    return f == GMAT_PIX_FMT_RGB24 || f == GMAT_PIX_FMT_BGR24 || f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA ||
+           f == GMAT_PIX_FMT_RGB0 || f == GMAT_PIX_FMT_BGR0;      // the 0-alpha twins: gsws maps them to RGBA / BGRA on entry
 }
 // 64-bit packed RGB destinations (16 bits per channel, alpha last)
 inline bool is_rgb64(int f) { return f == GMAT_PIX_FMT_RGBA64LE || f == GMAT_PIX_FMT_BGRA64LE; }
@@ -41,7 +42,7 @@ inline int  bytes_per_pixel(int f)
 {
     switch (f) {
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: return 3;
-    case GMAT_PIX_FMT_RGBA:  case GMAT_PIX_FMT_BGRA:  return 4;
+    case GMAT_PIX_FMT_RGBA:  case GMAT_PIX_FMT_BGRA:  case GMAT_PIX_FMT_RGB0: case GMAT_PIX_FMT_BGR0: return 4;
     default: return 0;
     }
 }

@@ -25,6 +25,11 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
 {
     std::memset(&L, 0, sizeof(L));
     switch (fmt) {
+    case GMAT_PIX_FMT_RGB0: case GMAT_PIX_FMT_BGR0:
+        L.planes = 1;
+        L.linesize[0] = align_up(w * 4, align);
+        L.total = (size_t)L.linesize[0] * h;
+        return 0;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA:
         L.planes = 1;
         L.linesize[0] = align_up(w * bytes_per_pixel(fmt), align);
@@ -96,6 +101,8 @@ int plane_row_bytes(int fmt, int plane, int w)
     case GMAT_PIX_FMT_RGBPF32LE: return 4 * w;
     case GMAT_PIX_FMT_RGBA64LE:
     case GMAT_PIX_FMT_BGRA64LE:  return 8 * w;
+    case GMAT_PIX_FMT_RGB0:
+    case GMAT_PIX_FMT_BGR0:      return 4 * w;
     default:                     return w * bytes_per_pixel(fmt);
     }
 }

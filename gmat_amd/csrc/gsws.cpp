@@ -135,6 +135,7 @@ struct GmatSwsContext {
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
     GmatSwsContext *inner = nullptr;
+    bool src0 = false, dst0 = false;      // RGB0 / BGR0 ends, handled as RGBA / BGRA (handle_0alpha, utils.c:1121-1144)
     // 16-bit destinations (P016LE): 19-bit int32 lines in HBM between the two passes of k_scale16.hip
     ScalePlan plan16;
     DevFilterStore f16[4];
@@ -501,6 +502,14 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     }
     GmatSwsContext *c = new (std::nothrow) GmatSwsContext();
     if (!c) return nullptr;
+    // the 4th byte of RGB0 / BGR0 is padding: libswscale runs them as RGBA / BGRA (handle_0alpha, utils.c:1121-1144);
+    // nothing here reads alpha, and every path that creates one writes 255
+    auto alpha_twin = [](int f, bool &was0) {
+        was0 = f == GMAT_PIX_FMT_RGB0 || f == GMAT_PIX_FMT_BGR0;
+        return f == GMAT_PIX_FMT_RGB0 ? (int)GMAT_PIX_FMT_RGBA : f == GMAT_PIX_FMT_BGR0 ? (int)GMAT_PIX_FMT_BGRA : f;
+    };
+    srcFormat = alpha_twin(srcFormat, c->src0);
+    dstFormat = alpha_twin(dstFormat, c->dst0);
     c->srcW = srcW; c->srcH = srcH; c->srcFormat = srcFormat;
     c->dstW = dstW; c->dstH = dstH; c->dstFormat = dstFormat;
     c->flags = flags & ~GMAT_SWS_HWACCEL;
@@ -548,7 +557,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                         (srcFormat == GMAT_PIX_FMT_BGR24 && dstFormat == GMAT_PIX_FMT_RGB24))) {
         c->mode = MODE_SWAP_RB;
     } else if (same && srcFormat == dstFormat && is_packed_rgb(srcFormat)) {
-        c->mode = MODE_COPY;
+        c->mode = (c->src0 && !c->dst0) ? MODE_REPACK : MODE_COPY;      // padding -> alpha: the byte is set to 255 (swscale.c:959-978)
     } else if (same && is_packed_rgb(srcFormat) && is_packed_rgb(dstFormat)) {
         // the remaining packed pairs have a 32-bit end: rgbToRgbWrapper's byte moves (swscale_unscaled.c:1579-1640).
         // With SWS_BITEXACT libswscale does not use its 24 -> 32 converters (:1571-1574) and the context runs the
@@ -832,7 +841,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const bool dstRgbOrder = c->dstFormat == GMAT_PIX_FMT_RGB24 || c->dstFormat == GMAT_PIX_FMT_RGBA;
         c->lastKernel = "repack_rgb_kernel";
         r = launch_repack_rgb(src[0], srcStride[0], bytes_per_pixel(c->srcFormat), dst[0], dstStride[0], bytes_per_pixel(c->dstFormat),
-                              c->srcW, c->srcH, srcRgbOrder != dstRgbOrder, c->stream);
+                              c->srcW, c->srcH, (srcRgbOrder != dstRgbOrder ? 1 : 0) | ((c->src0 && !c->dst0) ? 2 : 0), c->stream);
         break;
     }
     case MODE_RGB2YUV444: {

@@ -209,9 +209,13 @@ __global__ __launch_bounds__(256) void repack_rgb_kernel(const uint8_t *src, int
             px[i] = s[SB * j] | (s[SB * j + 1] << 8) | (s[SB * j + 2] << 16) | (SB == 4 ? (unsigned)s[SB * j + 3] << 24 : 0xFF000000u);
         }
     }
-    if (swap) {
+    if (swap & 1) {
 #pragma unroll
         for (int i = 0; i < 4; i++) px[i] = (px[i] & 0xFF00FF00u) | ((px[i] >> 16) & 0xFF) | ((px[i] & 0xFF) << 16);
+    }
+    if (swap & 2) {                                   // a padding byte becomes a real alpha: 255 (swscale.c:959-978)
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] |= 0xFF000000u;
     }
     if (full) {
         if (DB == 4) {

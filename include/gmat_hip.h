@@ -37,6 +37,9 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_RGBA64LE  = 105,   /* destinations of every YUV source at any size (yuv2rgba64_*_c on libswscale's 19-bit */
     GMAT_PIX_FMT_BGRA64LE  = 107,   /* lines; alpha 0xFFFF) — yuv2rgb_cuda's 64-bit outputs, yuv2rgb_cuda.cu:862-907           */
     GMAT_PIX_FMT_HIP       = 117,   /* AV_PIX_FMT_CUDA's slot (pixfmt.h:225): opaque device frame */
+    GMAT_PIX_FMT_RGB0      = 119,   /* = AV_PIX_FMT_0BGR32 on little endian  } scale_cuda's 32-bit formats (vf_scale_cuda.c:45-54): */
+    GMAT_PIX_FMT_BGR0      = 121,   /* = AV_PIX_FMT_0RGB32 on little endian  } RGBA / BGRA whose 4th byte is padding — libswscale     */
+                                    /*   handles them as those (handle_0alpha, utils.c:1121-1144): read ignored, written 255          */
     GMAT_PIX_FMT_P010LE    = 159,   /* pixfmt.h:276 — like NV12, 16-bit containers, data in the high bits */
     GMAT_PIX_FMT_P016LE    = 170,   /* both: SOURCE for every 8-bit destination and for P010LE at any size
                                        (hScale16To15_c semantics); DESTINATION of 8-bit 4:2:0 at equal size

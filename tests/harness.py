@@ -125,7 +125,7 @@ class Oracle:
 def plane_shapes(fmt, w, h):
     if fmt in ("rgb24", "bgr24"):
         return [(h, 3 * w)]
-    if fmt in ("rgba", "bgra"):
+    if fmt in ("rgba", "bgra", "rgb0", "bgr0"):
         return [(h, 4 * w)]
     if fmt in ("rgba64le", "bgra64le"):
         return [(h, 8 * w)]

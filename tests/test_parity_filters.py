@@ -485,6 +485,17 @@ def test_filter_layer_smooth_median(dev, orc):
             assert (res[i] == want).all(), (fmt, i)
 
 
+def test_filter_layer_0rgb32_frames(dev, orc):
+    """the nvcv filters list 0rgb32 / 0bgr32 (vf_crop_nvcv.c:90-98): 4-byte pixels, the padding byte moves with them"""
+    w, h = 64, 24
+    src = synth_planes(orc, "rgba", w, h, 115)
+    res, _, _ = _run_filter_planes(dev, "flip_hip", {"code": 1}, src, w, h, "bgr0")
+    assert (res[0].reshape(h, w, 4) == src[0].reshape(h, w, 4)[:, ::-1]).all()
+    res, ow, oh = _run_filter_planes(dev, "scale_hip", {"w": 32, "h": 12}, src, w, h, "bgr0")
+    want = orc.sws([np.ascontiguousarray(src[0].reshape(h, w, 4)[:, :, :3].reshape(h, 3 * w))], w, h, "bgr24", 32, 12, "bgra")
+    assert (res[0] == want[0]).all()
+
+
 def test_filter_layer_yuv444p_frames(dev, orc):
     """scale_hip / format_hip with a planar 4:4:4 destination, then crop + flip + transpose on those frames"""
     from harness import SWS

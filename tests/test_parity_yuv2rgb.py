@@ -92,6 +92,37 @@ def test_packed_rgb_repack(dev, orc, w, h, pair):
         assert (got[0] == want).all() and (pads[0] == 0xCD).all()
 
 
+@pytest.mark.parametrize("x0,twin", [("rgb0", "rgba"), ("bgr0", "bgra")])
+def test_0alpha_formats_are_their_alpha_twins(dev, orc, x0, twin):
+    """RGB0 / BGR0 (scale_cuda's 0bgr32 / 0rgb32 on little endian): libswscale runs them as RGBA / BGRA (handle_0alpha,
+    utils.c:1121-1144) — the 4th byte is not read, a created one is 255, and padding that becomes a real alpha is set
+    to 255 (swscale.c:959-978)"""
+    w, h = 70, 22
+    nv = synth_planes(orc, "nv12", w, h, seed=91)
+    d = dev.upload_planes(nv, 64)
+    a, _, _ = dev.sws(d, w, h, "nv12", w, h, x0)
+    b, _, _ = dev.sws(d, w, h, "nv12", w, h, twin)
+    assert (a[0] == b[0]).all() and (a[0].reshape(h, w, 4)[:, :, 3] == 255).all()
+    a, _, _ = dev.sws(d, w, h, "nv12", 48, 20, x0)
+    b, _, _ = dev.sws(d, w, h, "nv12", 48, 20, twin)
+    assert (a[0] == b[0]).all()
+    src = synth_planes(orc, twin, w, h, seed=92)                       # random 4th byte
+    ds = dev.upload_planes(src, 64)
+    for df in ("nv12", "rgb24", "yuv444p"):
+        a, _, _ = dev.sws(ds, w, h, x0, 40, 18, df) if df == "rgb24" else dev.sws(ds, w, h, x0, w, h, df)
+        b, _, _ = dev.sws(ds, w, h, twin, 40, 18, df) if df == "rgb24" else dev.sws(ds, w, h, twin, w, h, df)
+        assert all((p == q).all() for p, q in zip(a, b)), df
+    # equal layout, padding -> alpha: the byte becomes 255; alpha -> padding and padding -> padding: plain copies
+    a, _, k = dev.sws(ds, w, h, x0, w, h, twin)
+    assert (a[0].reshape(h, w, 4)[:, :, :3] == src[0].reshape(h, w, 4)[:, :, :3]).all() and (a[0].reshape(h, w, 4)[:, :, 3] == 255).all()
+    a, _, _ = dev.sws(ds, w, h, twin, w, h, x0)
+    assert (a[0] == src[0]).all()
+    other = "bgra" if twin == "rgba" else "rgba"
+    a, _, _ = dev.sws(ds, w, h, x0, w, h, other)
+    px = src[0].reshape(h, w, 4)
+    assert (a[0].reshape(h, w, 4)[:, :, :3] == px[:, :, [2, 1, 0]]).all() and (a[0].reshape(h, w, 4)[:, :, 3] == 255).all()
+
+
 @pytest.mark.parametrize("pair", [("rgb24", "bgra"), ("bgr24", "rgba")])
 def test_24_to_32_with_bitexact_runs_the_generic_scaler(dev, orc, pair):
     """findRgbConvFn returns no converter for 24 -> 32 bit under SWS_BITEXACT (swscale_unscaled.c:1571-1574): the
