@@ -135,6 +135,7 @@ struct GmatSwsContext {
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
     GmatSwsContext *inner = nullptr;
+    bool rgbViaPlanes = false;            // RGB24 / BGR24 source scaled to a YUV destination: the plane scaler with its RGB loader
     bool src0 = false, dst0 = false;      // RGB0 / BGR0 ends, handled as RGBA / BGRA (handle_0alpha, utils.c:1121-1144)
     // 16-bit destinations (P016LE): 19-bit int32 lines in HBM between the two passes of k_scale16.hip
     ScalePlan plan16;
@@ -187,6 +188,11 @@ static int init_yuv_scaler(GmatSwsContext *c)
     a.dstW = c->dstW; a.dstH = c->dstH; a.chrDstW = c->planYuv.chrDstW;
     a.dstFormat = c->dstFormat;
     a.nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    if (c->rgbViaPlanes) {
+        a.src16 = 3; a.hShift = 13; a.hBias = 0;         // hScale16To15_c: sh = 13 for RGB sources (swscale.c:93-119)
+        a.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24; a.chrHalf = c->planYuv.chrSrcHSub;
+        a.r2y = make_rgb2yuv_consts(c->colorspace);
+    }
     if (is_p01x(c->srcFormat)) {
         a.src16 = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : 16;
         a.hShift = a.src16 - 1;                          // hScale16To15_c: sh = depth - 1 (swscale.c:93-119)
@@ -293,7 +299,7 @@ static int init_scale16(GmatSwsContext *c)
 static int ensure_scaler(GmatSwsContext *c)
 {
     if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) ||
-        c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) {
+        c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -337,7 +343,10 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     ya.srcAligned16 = ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 15) == 0) &&
                       (ya.nv12 ? ((((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0)
                                : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
-    if (ya.src16) {
+    if (ya.src16 == 3) {
+        ya.u = ya.v = nullptr; ya.us = ya.vs = 0;
+        ya.srcAligned = 0; ya.srcAligned16 = 0;
+    } else if (ya.src16) {
         // 16-bit samples: rows and planes 2-byte aligned at least; dword loads when 4-byte aligned
         if ((((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);
         ya.srcAligned = al4(src[0], srcStride[0]) && al4(src[1], srcStride[1]);
@@ -430,7 +439,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
-    if (c->mode != MODE_SCALE || !is_plane_src(c->srcFormat) || c->fused != 2) return 0;
+    if (c->mode != MODE_SCALE || !(is_plane_src(c->srcFormat) || c->rgbViaPlanes) || c->fused != 2) return 0;
     if (ensure_scaler(c) < 0 || c->fused != 2 || c->prof) return 0;
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
@@ -583,6 +592,14 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
+    } else if ((srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) &&
+               ((!same && is_yuv8_src(dstFormat)) || dstFormat == GMAT_PIX_FMT_P010LE)) {
+        // packed RGB scaled into a YUV frame (one libswscale context: rgb24ToY / ToUV(_half), hScale16To15_c, planar
+        // vertical stage): the plane scaler with its RGB loader
+        c->mode = MODE_SCALE;
+        c->rgbViaPlanes = true;
+        c->fused = 2;
+        r = ensure_scaler(c);
     } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
     } else if (is_plane_src(srcFormat) && (dstFormat == GMAT_PIX_FMT_P016LE || is_rgb64(dstFormat))) {
@@ -644,6 +661,7 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
     c->colorspace = colorspace;
     c->srcFullRange = srcFullRange;
     c->y2r = make_yuv2rgb_consts(colorspace, srcFullRange != 0);
+    if (c->rgbViaPlanes) { c->yuvReady = false; return init_yuv_scaler(c); }      // the loader's rgb2yuv constants
     return 0;
 }
 
@@ -651,7 +669,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
     if (c->inner) return gmat_sws_setRange(c->inner, srcFullRange, dstFullRange);
-    if (c->mode == MODE_RGB2YUV) {
+    if (c->mode == MODE_RGB2YUV || c->rgbViaPlanes) {
         // an RGB source has no range of its own (forced to 0, utils.c:902-1030): a full-range destination is the
         // limited -> full conversion of the 15-bit lines (lum/chrRangeToJpeg_c), as in the second half of libswscale's
         // YUV -> RGB -> YUV cascade for differing matrices (utils.c:966-1036)
@@ -694,7 +712,7 @@ int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
     if (c->inner) return gmat_sws_setFused(c->inner, fused);
-    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat)) && fused != 2) return GMAT_ERR(ENOSYS);
+    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat) || c->rgbViaPlanes) && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
     return 0;
@@ -715,7 +733,7 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
     if (c && c->inner) return gmat_sws_getFilter(c->inner, which, coef, pos, cap, count);
     if (!c || c->mode != MODE_SCALE) return GMAT_ERR(EINVAL);
     const FilterBank *fb;
-    const ScalePlan &pl = (is_plane_src(c->srcFormat) && c->fused == 2) ? c->planYuv : c->plan;
+    const ScalePlan &pl = ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) ? c->planYuv : c->plan;
     switch (which) {
     case 0: fb = &pl.hLum; break;
     case 1: fb = &pl.hChr; break;
@@ -906,7 +924,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     }
     case MODE_SCALE: {
         if ((r = ensure_scaler(c)) < 0) break;
-        if (is_plane_src(c->srcFormat) && c->fused == 2) {
+        if ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) {
             YuvScaleArgs ya;
             if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
             if (yuv2x_eligible(c, ya, src, srcStride)) {

@@ -180,6 +180,57 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
     return true;
 }
 
+// phase 1 for packed RGB24 / BGR24 sources with a YUV destination (src16 == 3): the LDS image holds what the CPU's
+// input stage hands to hScale16To15_c (sh = 13 for RGB sources, swscale.c:93-119):
+//   luma    rgb24ToY_c                     input.c:815-828   (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+//   chroma  rgb24ToUV_c / rgb24ToUV_half_c input.c:830-866   per pixel, or on the sum of a horizontal pixel pair (>> 10)
+// (the pair's second pixel is clamped to the last one for odd widths, as the oracle does).  Both chroma planes have the
+// source's height.  Two samples per item.
+__device__ __forceinline__ void yuv_phase1_rgb(const YuvScaleArgs &a, int tid, int c0L, int ncL, int r0L, int nrL,
+                                               int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
+                                               unsigned short *lu, unsigned short *lv)
+{
+    const int ro = a.rgbBgr ? 2 : 0, bo = 2 - ro;
+    {
+        const int ng = ncL >> 1, total = nrL * ng;
+        for (int it = tid; it < total; it += 256) {
+            const int r = it / ng, cg = it - r * ng, col = c0L + 2 * cg;
+            const uint8_t *row = a.y + (size_t)min(r0L + r, a.srcH - 1) * a.ys;
+            unsigned v = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint8_t *px = row + 3 * min(col + j, a.srcW - 1);
+                v |= (unsigned)rgb_to_y14(a.r2y, px[ro], px[1], px[bo]) << (16 * j);
+            }
+            *reinterpret_cast<unsigned *>(ly + r * a.colsL + 2 * cg) = v;
+        }
+    }
+    {
+        const int ng = ncC >> 1, total = nrC * ng;
+        for (int it = tid; it < total; it += 256) {
+            const int r = it / ng, cg = it - r * ng, cc = c0C + 2 * cg;
+            const uint8_t *row = a.y + (size_t)min(r0C + r, a.srcH - 1) * a.ys;
+            unsigned u = 0, v = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int ci = min(cc + j, a.chrSrcW - 1);
+                int U, V;
+                if (a.chrHalf) {
+                    const uint8_t *p0 = row + 3 * min(2 * ci, a.srcW - 1), *p1 = row + 3 * min(2 * ci + 1, a.srcW - 1);
+                    const int rs = p0[ro] + p1[ro], gs = p0[1] + p1[1], bs = p0[bo] + p1[bo];
+                    U = rgbsum_to_u14(a.r2y, rs, gs, bs); V = rgbsum_to_v14(a.r2y, rs, gs, bs);
+                } else {
+                    const uint8_t *px = row + 3 * min(ci, a.srcW - 1);
+                    U = rgb_to_u14(a.r2y, px[ro], px[1], px[bo]); V = rgb_to_v14(a.r2y, px[ro], px[1], px[bo]);
+                }
+                u |= (unsigned)U << (16 * j); v |= (unsigned)V << (16 * j);
+            }
+            *reinterpret_cast<unsigned *>(lu + r * a.colsC + 2 * cg) = u;
+            *reinterpret_cast<unsigned *>(lv + r * a.colsC + 2 * cg) = v;
+        }
+    }
+}
+
 // phase 1 for 16-bit semi-planar sources (P010LE / P016LE): luma plane of 16-bit samples, chroma plane of interleaved
 // 16-bit (U, V) pairs.  The LDS image holds what hScale16To15_c multiplies (swscale.c:93-119):
 //   P010: sample >> 6 (p010LEToY_c / p010LEToUV_c, input.c:698-725) — 10 bits, non-negative as int16
@@ -317,7 +368,10 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
     // ================= phase 1 ================================================================
     {
         const bool fl = a.srcAligned && c0L + ncL <= a.srcW, fc = a.srcAligned && c0C + ncC <= a.chrSrcW;
-        if constexpr (SRC16) yuv_phase1_src16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+        if constexpr (SRC16) {
+            if (a.src16 == 3) yuv_phase1_rgb(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+            else              yuv_phase1_src16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
+        }
         else if (fl && fc && a.srcAligned16 && yuv_phase1_16(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv)) {}
         else if (fl && fc) yuv_phase1<true, true>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
         else          yuv_phase1<false, false>(a, tid, c0L, ncL, r0L, nrL, c0C, ncC, r0C, nrC, ly, lu, lv);
@@ -583,7 +637,9 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
     const bool out10 = p.dstFormat == GMAT_PIX_FMT_P010LE;                   // 4:2:0 with 16-bit stores
     const int yuvOut = (is_yuv420(p.dstFormat) || out10) ? 1 : out444 ? 2 : 0;   // 1: 4:2:0   2: planar 4:4:4
-    if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // only towards YUV destinations
+    if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat) || (rgbSrc && yuvOut)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    if (rgbSrc && (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs)) return GMAT_ERR(ENOSYS);
     if (is_p01x(p.srcFormat)) {
         // the P016 image is biased by -32768, undone by a start value that assumes every horizontal row sums to
         // 16384 (initFilter normalises exactly, utils.c:721-741); filters beyond 16 taps have no 16-bit variant

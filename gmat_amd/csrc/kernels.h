@@ -97,6 +97,8 @@ struct YuvScaleArgs {
     int ys, us, vs, nv12, srcAligned;
     int srcAligned16;                             // luma and NV12 chroma rows 16-byte, planar chroma rows 8-byte aligned
     int rangeConv;                                // YUV out: 0 none, 1 limited -> full range, 2 full -> limited (swscale.c:157-188)
+    int rgbBgr, chrHalf;                          // src16 == 3: packed RGB24 / BGR24 source (y = pixels); rgbBgr: BGR order;
+    Rgb2YuvConsts r2y;                            // chrHalf: chroma from pixel pairs (rgb24ToUV_half_c); rgb24ToY_c constants
     int src16, hShift, hBias;                     // P010LE / P016LE source: 10 / 16 (0 = 8-bit); hScale16To15_c's shift
                                                   // (depth - 1) and the accumulator start that undoes the P016 image bias
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW;

@@ -27,8 +27,6 @@ for case in range(n):
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     same = rng.random() < 0.25
     dw, dh = (sw, sh) if same else (rng.randint(2, 300), rng.randint(2, 120))
-    if sf in ("rgb24", "bgr24") and df in ("nv12", "yuv420p", "yuv444p") and not same:
-        continue                                  # scaled rgb -> yuv is not offered
     algo = rng.choice(ALGOS)
     flags = SWS[algo]
     if rng.random() < 0.2: flags |= SWS["full_chr_h_int"]

@@ -506,8 +506,36 @@ def test_2to1_kernel_interior_tiles(dev, orc, src_fmt, dst_fmt, flags):
         p.free()
 
 
+@pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p", "p010le"])
+@pytest.mark.parametrize("geom", [(256, 64, 128, 32), (96, 40, 144, 60), (201, 91, 151, 67), (130, 51, 63, 25), (64, 34, 100, 34)])
+def test_rgb_scaled_into_yuv(dev, orc, src_fmt, dst_fmt, geom):
+    """packed RGB scaled into a YUV frame by ONE context, as libswscale does: rgb24ToY_c, rgb24ToUV_c or ToUV_half_c
+    (chrSrcHSubSample = 1 when the destination's chroma is at most half the source width, utils.c:1529-1545),
+    hScale16To15_c with sh = 13, planar vertical stage; the plane scaler's RGB loader"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, src_fmt, sw, sh, seed=87)
+    for flags in ("bicubic", "bilinear"):
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags])
+        for align, extra in ((64, 0), (2, 2)):
+            d = dev.upload_planes(src, align, extra)
+            got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=align, dst_extra=extra)
+            assert kernel.startswith("scale_yuv_kernel"), kernel
+            for i, (g, wv) in enumerate(zip(got, want)):
+                bad = np.argwhere(g != wv)
+                assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({flags}, align {align})"
+                assert (pads[i] == 0xCD).all()
+            for p in d:
+                p.free()
+    if dst_fmt == "nv12":
+        want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], colorspace=1)
+        d = dev.upload_planes(src, 64)
+        got, _, _ = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=64, colorspace=(1, 0))
+        assert all((g == wv).all() for g, wv in zip(got, want))
+
+
 @pytest.mark.parametrize("src_fmt", ["rgba", "bgra"])
-@pytest.mark.parametrize("case", [("rgb24", 96, 40, 50, 30), ("bgra", 96, 40, 144, 60), ("nv12", 128, 32, 128, 32),
+@pytest.mark.parametrize("case", [("rgb24", 96, 40, 50, 30), ("bgra", 96, 40, 144, 60), ("nv12", 128, 32, 128, 32), ("nv12", 128, 32, 64, 16),
                                   ("yuv420p", 130, 34, 130, 34), ("yuv444p", 70, 22, 70, 22), ("rgba", 131, 35, 64, 17)])
 def test_32bit_rgb_sources(dev, orc, src_fmt, case):
     """RGBA / BGRA sources of the scaling and RGB -> YUV paths (swscale_cuda.c:34-44): rgb32ToY / ToUV read the same

@@ -191,9 +191,9 @@ def test_error_behaviour_newer_entry_points(dev):
                            planes([d[0].ptr, d[1].ptr]), ints([d[0].stride, d[1].stride]))
     assert r < 0
     lib.gmat_sws_freeContext(c)
-    # 16-bit destinations: from YUV sources only
-    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 32, 16, PIX_FMT["p010le"], 0, None)
+    # the 19-bit path (P016, 64-bit RGB) has no RGB readers
     assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["p016le"], 0, None)
+    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["rgba64le"], 0, None)
 
 
 @pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (33, 9)])
