@@ -134,6 +134,7 @@ sws_case("4K nv12 -> yuv420p (relayout)", "nv12", 3840, 2160, "yuv420p", 3840, 2
 sws_case("4K nv12 -> 1080p yuv444p", "nv12", 3840, 2160, "yuv444p", 1920, 1080)
 sws_case("4K nv12 -> yuv444p (chroma up)", "nv12", 3840, 2160, "yuv444p", 3840, 2160)
 sws_case("4K rgb24 -> yuv444p", "rgb24", 3840, 2160, "yuv444p", 3840, 2160)
+sws_case("4K rgb24 -> 1080p nv12 (scaled)", "rgb24", 3840, 2160, "nv12", 1920, 1080)
 sws_case("4K rgb24 -> bgra (repack)", "rgb24", 3840, 2160, "bgra", 3840, 2160)
 sws_case("4K rgba -> bgr24 (repack)", "rgba", 3840, 2160, "bgr24", 3840, 2160)
 sws_case("4K rgb24 -> bgr24 (swap)", "rgb24", 3840, 2160, "bgr24", 3840, 2160)
