@@ -345,7 +345,7 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
                                : ((((uintptr_t)src[1] | (uintptr_t)srcStride[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0));
     if (ya.src16 == 3) {
         ya.u = ya.v = nullptr; ya.us = ya.vs = 0;
-        ya.srcAligned = 0; ya.srcAligned16 = 0;
+        ya.srcAligned = al4(src[0], srcStride[0]); ya.srcAligned16 = 0;        // 12-byte pixel groups as three dwords
     } else if (ya.src16) {
         // 16-bit samples: rows and planes 2-byte aligned at least; dword loads when 4-byte aligned
         if ((((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);

@@ -191,42 +191,69 @@ __device__ __forceinline__ void yuv_phase1_rgb(const YuvScaleArgs &a, int tid, i
                                                unsigned short *lu, unsigned short *lv)
 {
     const int ro = a.rgbBgr ? 2 : 0, bo = 2 - ro;
-    {
-        const int ng = ncL >> 1, total = nrL * ng;
-        for (int it = tid; it < total; it += 256) {
-            const int r = it / ng, cg = it - r * ng, col = c0L + 2 * cg;
-            const uint8_t *row = a.y + (size_t)min(r0L + r, a.srcH - 1) * a.ys;
-            unsigned v = 0;
+    // 4 pixels of one row: three dwords when the rows are 4-byte aligned and the group lies inside the row (window
+    // starts are multiples of 16 luma / 8 chroma samples, so groups start on 12-byte boundaries), else byte loads
+    // with the column clamped to the last pixel
+    auto load4 = [&](const uint8_t *row, int col, int (&r)[4], int (&g)[4], int (&b)[4]) {
+        if (a.srcAligned && col >= 0 && col + 4 <= a.srcW) {
+            const uint3 v = *reinterpret_cast<const uint3 *>(row + (size_t)col * 3);
+            const unsigned c0[4] = {v.x & 0xFF, v.x >> 24, (v.y >> 16) & 0xFF, (v.z >> 8) & 0xFF};
+            const unsigned c1[4] = {(v.x >> 8) & 0xFF, v.y & 0xFF, v.y >> 24, (v.z >> 16) & 0xFF};
+            const unsigned c2[4] = {(v.x >> 16) & 0xFF, (v.y >> 8) & 0xFF, v.z & 0xFF, v.z >> 24};
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const uint8_t *px = row + 3 * min(col + j, a.srcW - 1);
-                v |= (unsigned)rgb_to_y14(a.r2y, px[ro], px[1], px[bo]) << (16 * j);
+            for (int i = 0; i < 4; i++) { r[i] = (int)(a.rgbBgr ? c2[i] : c0[i]); g[i] = (int)c1[i]; b[i] = (int)(a.rgbBgr ? c0[i] : c2[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint8_t *px = row + 3 * min(max(col + i, 0), a.srcW - 1);
+                r[i] = px[ro]; g[i] = px[1]; b[i] = px[bo];
             }
-            *reinterpret_cast<unsigned *>(ly + r * a.colsL + 2 * cg) = v;
+        }
+    };
+    {
+        const int ng = ncL >> 2, total = nrL * ng;           // luma: 4 pixels per item
+        for (int it = tid; it < total; it += 256) {
+            const int rr = it / ng, cg = it - rr * ng;
+            int r[4], g[4], b[4];
+            load4(a.y + (size_t)min(r0L + rr, a.srcH - 1) * a.ys, c0L + 4 * cg, r, g, b);
+            const unsigned y0 = (unsigned)rgb_to_y14(a.r2y, r[0], g[0], b[0]), y1 = (unsigned)rgb_to_y14(a.r2y, r[1], g[1], b[1]);
+            const unsigned y2 = (unsigned)rgb_to_y14(a.r2y, r[2], g[2], b[2]), y3 = (unsigned)rgb_to_y14(a.r2y, r[3], g[3], b[3]);
+            *reinterpret_cast<uint2 *>(ly + rr * a.colsL + 4 * cg) = make_uint2(y0 | (y1 << 16), y2 | (y3 << 16));
         }
     }
-    {
-        const int ng = ncC >> 1, total = nrC * ng;
+    if (a.chrHalf) {
+        const int ng = ncC >> 1, total = nrC * ng;           // chroma from pixel pairs: 2 samples = 4 pixels per item
         for (int it = tid; it < total; it += 256) {
-            const int r = it / ng, cg = it - r * ng, cc = c0C + 2 * cg;
-            const uint8_t *row = a.y + (size_t)min(r0C + r, a.srcH - 1) * a.ys;
-            unsigned u = 0, v = 0;
+            const int rr = it / ng, cg = it - rr * ng, cc = c0C + 2 * cg;
+            int r[4], g[4], b[4];
+            // chroma sample ci takes pixels 2ci and min(2ci + 1, srcW - 1); samples past the plane repeat the last one
+            const int ci0 = min(cc, a.chrSrcW - 1), ci1 = min(cc + 1, a.chrSrcW - 1);
+            if (ci1 == cc + 1 && 2 * cc + 4 <= a.srcW) {
+                load4(a.y + (size_t)min(r0C + rr, a.srcH - 1) * a.ys, 2 * cc, r, g, b);
+            } else {
+                const uint8_t *row = a.y + (size_t)min(r0C + rr, a.srcH - 1) * a.ys;
+                const int px[4] = {2 * ci0, min(2 * ci0 + 1, a.srcW - 1), 2 * ci1, min(2 * ci1 + 1, a.srcW - 1)};
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int ci = min(cc + j, a.chrSrcW - 1);
-                int U, V;
-                if (a.chrHalf) {
-                    const uint8_t *p0 = row + 3 * min(2 * ci, a.srcW - 1), *p1 = row + 3 * min(2 * ci + 1, a.srcW - 1);
-                    const int rs = p0[ro] + p1[ro], gs = p0[1] + p1[1], bs = p0[bo] + p1[bo];
-                    U = rgbsum_to_u14(a.r2y, rs, gs, bs); V = rgbsum_to_v14(a.r2y, rs, gs, bs);
-                } else {
-                    const uint8_t *px = row + 3 * min(ci, a.srcW - 1);
-                    U = rgb_to_u14(a.r2y, px[ro], px[1], px[bo]); V = rgb_to_v14(a.r2y, px[ro], px[1], px[bo]);
-                }
-                u |= (unsigned)U << (16 * j); v |= (unsigned)V << (16 * j);
+                for (int i = 0; i < 4; i++) { const uint8_t *p = row + 3 * px[i]; r[i] = p[ro]; g[i] = p[1]; b[i] = p[bo]; }
             }
-            *reinterpret_cast<unsigned *>(lu + r * a.colsC + 2 * cg) = u;
-            *reinterpret_cast<unsigned *>(lv + r * a.colsC + 2 * cg) = v;
+            const unsigned u0 = (unsigned)rgbsum_to_u14(a.r2y, r[0] + r[1], g[0] + g[1], b[0] + b[1]);
+            const unsigned u1 = (unsigned)rgbsum_to_u14(a.r2y, r[2] + r[3], g[2] + g[3], b[2] + b[3]);
+            const unsigned v0 = (unsigned)rgbsum_to_v14(a.r2y, r[0] + r[1], g[0] + g[1], b[0] + b[1]);
+            const unsigned v1 = (unsigned)rgbsum_to_v14(a.r2y, r[2] + r[3], g[2] + g[3], b[2] + b[3]);
+            *reinterpret_cast<unsigned *>(lu + rr * a.colsC + 2 * cg) = u0 | (u1 << 16);
+            *reinterpret_cast<unsigned *>(lv + rr * a.colsC + 2 * cg) = v0 | (v1 << 16);
+        }
+    } else {
+        const int ng = ncC >> 2, total = nrC * ng;           // one chroma sample per pixel: 4 per item
+        for (int it = tid; it < total; it += 256) {
+            const int rr = it / ng, cg = it - rr * ng;
+            int r[4], g[4], b[4];
+            load4(a.y + (size_t)min(r0C + rr, a.srcH - 1) * a.ys, c0C + 4 * cg, r, g, b);
+            unsigned u[4], v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { u[i] = (unsigned)rgb_to_u14(a.r2y, r[i], g[i], b[i]); v[i] = (unsigned)rgb_to_v14(a.r2y, r[i], g[i], b[i]); }
+            *reinterpret_cast<uint2 *>(lu + rr * a.colsC + 4 * cg) = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+            *reinterpret_cast<uint2 *>(lv + rr * a.colsC + 4 * cg) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
         }
     }
 }
