@@ -148,3 +148,45 @@ def test_4k_rotate_17_degrees(gpu, orc):
     assert gpu.lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(17.0), 1,
                                fill.ctypes.data, None) == 0
     assert (o.download() == want).all()
+
+
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "nv12"])
+def test_4k_batched_launch_equals_single_launches(gpu, orc, dst_fmt):
+    """BASELINE configs[2] through gmat_sws_scale_batch: 5 frames on 2 streams (launches of 3 and 2 frames, grid.y =
+    frame) must give, frame by frame, the bytes of gmat_sws_scale on the same frame (which the tests above check
+    against the oracle)"""
+    from harness import ints
+    lib = gpu.lib
+    sw, sh, dw, dh, n = 3840, 2160, 1920, 1080, 5
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT[dst_fmt], SWS["bicubic"], None)
+    assert c
+    srcs = [synth_planes(orc, "nv12", sw, sh, seed=500 + f) for f in range(n)]
+    dsrc = [gpu.upload_planes(s, 256) for s in srcs]
+    single = []
+    for f in range(n):
+        got, _, k = gpu.sws(dsrc[f], sw, sh, "nv12", dw, dh, dst_fmt, dst_align=256)
+        assert k.startswith("scale_yuv2x_kernel")
+        single.append(got)
+    ddst = [gpu.planes_like(dst_fmt, dw, dh, 256) for _ in range(n)]
+    sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
+    for f in range(n):
+        for i, p in enumerate(dsrc[f]): sp[4 * f + i] = p.ptr
+        for i, p in enumerate(ddst[f]): dp[4 * f + i] = p.ptr
+    streams = (C.c_void_p * 2)()
+    for s in range(2):
+        h = C.c_void_p(); assert lib.gmat_stream_create(C.byref(h)) == 0; streams[s] = h
+    r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
+                                 C.cast(dp, C.POINTER(C.c_void_p)), ints([p.stride for p in ddst[0]]),
+                                 C.cast(streams, C.POINTER(C.c_void_p)), 2, 3)
+    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == 2
+    lib.gmat_stream_sync(streams[0])
+    for f in range(n):
+        for i, p in enumerate(ddst[f]):
+            assert (p.download() == single[f][i]).all(), (f, i)
+            assert (p.download(with_padding=True)[:, p.row_bytes:] == 0xCD).all()
+    for s in range(2):
+        lib.gmat_stream_destroy(streams[s])
+    lib.gmat_sws_freeContext(c)
+    for f in range(n):
+        for p in dsrc[f] + ddst[f]:
+            p.free()
