@@ -184,7 +184,8 @@ __device__ __forceinline__ bool yuv_phase1_16(const YuvScaleArgs &a, int tid, in
 // input stage hands to hScale16To15_c (sh = 13 for RGB sources, swscale.c:93-119):
 //   luma    rgb24ToY_c                     input.c:815-828   (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
 //   chroma  rgb24ToUV_c / rgb24ToUV_half_c input.c:830-866   per pixel, or on the sum of a horizontal pixel pair (>> 10)
-// (the pair's second pixel is clamped to the last one for odd widths, as the oracle does).  Both chroma planes have the
+// (the pair's second pixel is clamped to the last one for odd widths — the reference reads one pixel past the row there,
+// which is not defined).  Both chroma planes have the
 // source's height.  Two samples per item.
 __device__ __forceinline__ void yuv_phase1_rgb(const YuvScaleArgs &a, int tid, int c0L, int ncL, int r0L, int nrL,
                                                int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
