@@ -608,14 +608,17 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
 template <int BPP>
 __global__ __launch_bounds__(256) void median3x3_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dstAligned)
 {
+    // 4 consecutive bytes of TWO vertically adjacent output rows per thread: the rows y-1 .. y+2 are loaded once, and
+    // the two windows share the sorted pair (row y, row y+1) of every column
     const int rb = w * BPP;
-    const int i0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int i0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
     if (i0 >= rb || y >= h) return;
-    const uint8_t *rows[3] = {src + (size_t)max(y - 1, 0) * ss, src + (size_t)y * ss, src + (size_t)min(y + 1, h - 1) * ss};
-    unsigned t[3][3];                                     // [row][column offset -1, 0, +1]: 4 bytes each
+    const uint8_t *rows[4] = {src + (size_t)max(y - 1, 0) * ss, src + (size_t)y * ss, src + (size_t)min(y + 1, h - 1) * ss,
+                              src + (size_t)min(y + 2, h - 1) * ss};
+    unsigned t[4][3];                                     // [row][column offset -1, 0, +1]: 4 bytes each
     const bool interior = i0 >= BPP && i0 + 4 + BPP <= rb;
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < 4; r++) {
         if (interior) {
             __builtin_memcpy(&t[r][0], rows[r] + i0 - BPP, 4);
             __builtin_memcpy(&t[r][1], rows[r] + i0, 4);
@@ -630,23 +633,37 @@ __global__ __launch_bounds__(256) void median3x3_kernel(const uint8_t *src, int 
             }
         }
     }
-    unsigned o = 0;
+    unsigned o0 = 0, o1 = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-        unsigned lo[3], md[3], hi[3];
+        unsigned lo0[3], md0[3], hi0[3], lo1[3], md1[3], hi1[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const unsigned a0 = (t[0][c] >> (8 * b)) & 0xFF, a1 = (t[1][c] >> (8 * b)) & 0xFF, a2 = (t[2][c] >> (8 * b)) & 0xFF;
-            lo[c] = min(min(a0, a1), a2); hi[c] = max(max(a0, a1), a2);
-            md[c] = max(min(a0, a1), min(max(a0, a1), a2));
+            const unsigned a0 = (t[0][c] >> (8 * b)) & 0xFF, a1 = (t[1][c] >> (8 * b)) & 0xFF, a2 = (t[2][c] >> (8 * b)) & 0xFF,
+                           a3 = (t[3][c] >> (8 * b)) & 0xFF;
+            const unsigned pl = min(a1, a2), ph = max(a1, a2);               // the pair both windows contain
+            lo0[c] = min(a0, pl); hi0[c] = max(a0, ph); md0[c] = max(pl, min(a0, ph));
+            lo1[c] = min(a3, pl); hi1[c] = max(a3, ph); md1[c] = max(pl, min(a3, ph));
         }
-        const unsigned A = max(max(lo[0], lo[1]), lo[2]), C = min(min(hi[0], hi[1]), hi[2]);
-        const unsigned B = max(min(md[0], md[1]), min(max(md[0], md[1]), md[2]));
-        o |= max(min(A, B), min(max(A, B), C)) << (8 * b);
+        {
+            const unsigned A = max(max(lo0[0], lo0[1]), lo0[2]), C = min(min(hi0[0], hi0[1]), hi0[2]);
+            const unsigned B = max(min(md0[0], md0[1]), min(max(md0[0], md0[1]), md0[2]));
+            o0 |= max(min(A, B), min(max(A, B), C)) << (8 * b);
+        }
+        {
+            const unsigned A = max(max(lo1[0], lo1[1]), lo1[2]), C = min(min(hi1[0], hi1[1]), hi1[2]);
+            const unsigned B = max(min(md1[0], md1[1]), min(max(md1[0], md1[1]), md1[2]));
+            o1 |= max(min(A, B), min(max(A, B), C)) << (8 * b);
+        }
     }
-    uint8_t *d = dst + (size_t)y * ds + i0;
-    if (dstAligned && i0 + 4 <= rb) *reinterpret_cast<unsigned *>(d) = o;
-    else for (int b = 0; b < min(4, rb - i0); b++) d[b] = (uint8_t)(o >> (8 * b));
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (y + k >= h) break;
+        const unsigned o = k ? o1 : o0;
+        uint8_t *d = dst + (size_t)(y + k) * ds + i0;
+        if (dstAligned && i0 + 4 <= rb) *reinterpret_cast<unsigned *>(d) = o;
+        else for (int b = 0; b < min(4, rb - i0); b++) d[b] = (uint8_t)(o >> (8 * b));
+    }
 }
 
 int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, hipStream_t stream)
@@ -654,7 +671,7 @@ int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, in
     if (w <= 0 || h <= 0) return 0;
     if (!src || !dst) return GMAT_ERR(EINVAL);
     const int rb = w * bpp;
-    const dim3 grid((rb + 255) / 256, (h + 3) / 4), block(256);
+    const dim3 grid((rb + 255) / 256, (h + 7) / 8), block(256);          // 4 thread rows x 2 output rows per block
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
     switch (bpp) {
     case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3_kernel<1>), grid, block, 0, stream, src, ss, dst, ds, w, h, aligned); break;
