@@ -72,6 +72,14 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
         }
         L.total = (size_t)3 * L.linesize[0] * h;
         return 0;
+    case GMAT_PIX_FMT_YUV444P16LE:
+        L.planes = 3;
+        for (int i = 0; i < 3; i++) {
+            L.linesize[i] = align_up(2 * w, align);
+            L.offset[i] = (size_t)i * L.linesize[0] * h;
+        }
+        L.total = (size_t)3 * L.linesize[0] * h;
+        return 0;
     case GMAT_PIX_FMT_RGBPF32LE:
         L.planes = 3;
         for (int i = 0; i < 3; i++) {
@@ -103,6 +111,7 @@ int plane_row_bytes(int fmt, int plane, int w)
     case GMAT_PIX_FMT_BGRA64LE:  return 8 * w;
     case GMAT_PIX_FMT_RGB0:
     case GMAT_PIX_FMT_BGR0:      return 4 * w;
+    case GMAT_PIX_FMT_YUV444P16LE: return 2 * w;
     default:                     return w * bytes_per_pixel(fmt);
     }
 }

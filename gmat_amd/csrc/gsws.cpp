@@ -281,8 +281,10 @@ static int init_scale16(GmatSwsContext *c)
             }
         }
         pack_filter_pairs(vl); pack_filter_pairs(vc);
-    } else if (vl.taps == 1) {
-        std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl);
+    } else {
+        if (vl.taps == 1) { std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl); }
+        // planar chroma goes through yuv2plane1_16_c too when its filter has one tap; interleaved chroma never does
+        if (vc.taps == 1 && c->dstFormat == GMAT_PIX_FMT_YUV444P16LE) { std::fill(vc.coef.begin(), vc.coef.end(), (int16_t)4096); pack_filter_pairs(vc); }
     }
     const std::vector<int32_t> none(std::max(std::max(c->dstW, c->dstH), 1), 0);
     if ((r = c->f16[0].upload(p.hLum, none, c->d16[0])) < 0) return r;
@@ -602,7 +604,9 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         r = ensure_scaler(c);
     } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
-    } else if (is_plane_src(srcFormat) && (dstFormat == GMAT_PIX_FMT_P016LE || is_rgb64(dstFormat))) {
+    } else if (same && srcFormat == GMAT_PIX_FMT_YUV444P16LE && dstFormat == srcFormat) {
+        c->mode = MODE_PLANECOPY;
+    } else if ((is_plane_src(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV444P16LE) && is_dst16(dstFormat)) {
         // 16-bit destination: 19-bit intermediates, the two-pass path of k_scale16.hip (equal-size 8-bit 4:2:0 sources were
         // taken above as the depth expansion, equal format as the plane copy)
         c->mode = MODE_SCALE16;
@@ -821,16 +825,17 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const bool rgb64 = is_rgb64(c->dstFormat);
         if (!rgb64 && !dst[1]) { r = GMAT_ERR(EINVAL); break; }
         const ScalePlan &p = c->plan16;
-        const bool s16 = is_p01x(c->srcFormat);
+        const bool pl16 = c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
+        const bool s16 = is_p01x(c->srcFormat) || pl16;
         const int odd = s16 ? 1 : 0;
         if ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0] | (rgb64 ? 0 : ((uintptr_t)dst[1] | (uintptr_t)dstStride[1]))) & 1) != 0 ||
             (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
-        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : c->srcFormat == GMAT_PIX_FMT_P016LE ? 16 : 0;
+        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : s16 ? 16 : 0;
         const int bps = s16 ? 2 : 1;
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
         if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream)) < 0) break;
-        const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || s16;           // interleaved U, V
+        const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);           // interleaved U, V
         if (!semi && !src[2]) { r = GMAT_ERR(EINVAL); break; }
         const uint8_t *pu = src[1], *pv = semi ? src[1] + bps : src[2];
         const int su = srcStride[1], sv = semi ? srcStride[1] : srcStride[2], cstep = semi ? 2 * bps : bps;
@@ -844,6 +849,12 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             break;
         }
         if ((r = launch_vscale16(ly, nullptr, c->dstW, c->srcH, c->d16[2], dst[0], dstStride[0], c->dstW, c->dstH, c->stream)) < 0) break;
+        if (c->dstFormat == GMAT_PIX_FMT_YUV444P16LE) {
+            if (!dst[2] || (((uintptr_t)dst[2] | (uintptr_t)dstStride[2]) & 1)) { r = GMAT_ERR(EINVAL); break; }
+            if ((r = launch_vscale16(lu, nullptr, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream)) < 0) break;
+            r = launch_vscale16(lv, nullptr, p.chrDstW, p.chrSrcH, c->d16[3], dst[2], dstStride[2], p.chrDstW, p.chrDstH, c->stream);
+            break;
+        }
         r = launch_vscale16(lu, lv, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream);
         break;
     }
@@ -851,6 +862,11 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if (!src[1] || !dst[1]) { r = GMAT_ERR(EINVAL); break; }
         c->lastKernel = "copy2d_kernel";
         r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], 2 * c->srcW, c->srcH, c->stream);
+        if (c->srcFormat == GMAT_PIX_FMT_YUV444P16LE) {
+            if (!src[2] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
+            for (int i = 1; i < 3 && r >= 0; i++) r = launch_copy2d(src[i], srcStride[i], dst[i], dstStride[i], 2 * c->srcW, c->srcH, c->stream);
+            break;
+        }
         if (r >= 0) r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], 4 * ((c->srcW + 1) / 2), (c->srcH + 1) / 2, c->stream);
         break;
     }

@@ -65,6 +65,7 @@ enum {
     ORC_PIX_BGRA    = 28,
     ORC_PIX_P010LE  = 159,
     ORC_PIX_P016LE  = 170,
+    ORC_PIX_YUV444P16LE = 49,
     ORC_PIX_RGBA64LE = 105,
     ORC_PIX_BGRA64LE = 107,
     ORC_PIX_RGBPF32LE = 179,

@@ -46,6 +46,7 @@ struct OrcSws {
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
 static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
 static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
+static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || is_rgb64(f); }   /* 19-bit lines */
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
 static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || is_p01x(f)) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
 static unsigned rl16(const uint8_t *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
@@ -141,11 +142,13 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
 
     /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
      * P016LE switches to the 19-bit ones (scale_to_p016 below) */
-    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt)) ||
-        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_rgb64(dst_fmt)))
+    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || src_fmt == ORC_PIX_YUV444P16LE) ||
+        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt)))
         return NULL;
-    if ((dst_fmt == ORC_PIX_P016LE || is_rgb64(dst_fmt)) && (is_rgb(src_fmt) || src_range != dst_range))
-        return NULL;                                       /* RGB readers / 16-bit range conversion for 19-bit lines: not restated */
+    if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
+        return NULL;
+    if (src_fmt == ORC_PIX_YUV444P16LE && !is_dst16(dst_fmt))
+        return NULL;                                       /* 16-bit planar 4:4:4 source: only on the 19-bit path here */                                       /* RGB readers / 16-bit range conversion for 19-bit lines: not restated */
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
@@ -628,8 +631,9 @@ static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, in
 static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], int32_t **pl, int32_t **pu, int32_t **pv)
 {
     const int dw = c->dst_w, cdw = c->chr_dst_w, sh8 = 3;
+    const int pl16 = c->src_fmt == ORC_PIX_YUV444P16LE;      /* planar 16-bit samples, read as they are (native endian) */
     const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
-    const int sh = src16 ? (p010 ? 10 : 16) - 5 : sh8;
+    const int sh = (src16 || pl16) ? (p010 ? 10 : 16) - 5 : sh8;
     int32_t *ly = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h);
     int32_t *lu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
     int32_t *lv = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
@@ -640,12 +644,15 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
     for (y = 0; y < c->src_h; y++) {
         const uint8_t *row = src[0] + (long)y * src_stride[0];
         for (i = 0; i < c->src_w; i++)
-            t0[i] = (uint16_t)(src16 ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
+            t0[i] = (uint16_t)((src16 || pl16) ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
         hscale19(ly + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
     }
     for (y = 0; y < c->chr_src_h; y++) {
         for (i = 0; i < c->chr_src_w; i++) {
-            if (src16) {
+            if (pl16) {
+                t0[i] = (uint16_t)rl16(src[1] + (long)y * src_stride[1] + 2 * i);
+                t1[i] = (uint16_t)rl16(src[2] + (long)y * src_stride[2] + 2 * i);
+            } else if (src16) {
                 const uint8_t *row = src[1] + (long)y * src_stride[1];
                 t0[i] = (uint16_t)(p010 ? rl16(row + 4 * i) >> 6 : rl16(row + 4 * i));
                 t1[i] = (uint16_t)(p010 ? rl16(row + 4 * i + 2) >> 6 : rl16(row + 4 * i + 2));
@@ -690,6 +697,25 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
     for (y = 0; y < c->chr_dst_h; y++) {
         uint8_t *d = dst[1] + (long)y * dst_stride[1];
         const int32_t **up = lp, **vp = lp + c->v_chr_size;
+        if (c->dst_fmt == ORC_PIX_YUV444P16LE) {            /* planar chroma: yuv2plane1_16_c / yuv2planeX_16_c per plane */
+            uint8_t *dv = dst[2] + (long)y * dst_stride[2];
+            for (j = 0; j < c->v_chr_size; j++) {
+                int r = c->v_chr_pos[y] + j;
+                if (r >= c->chr_src_h) r = c->chr_src_h - 1;
+                up[j] = lu + (size_t)r * cdw; vp[j] = lv + (size_t)r * cdw;
+            }
+            for (i = 0; i < cdw; i++) {
+                if (c->v_chr_size == 1) {
+                    int a = (up[0][i] + 4) >> 3, b = (vp[0][i] + 4) >> 3;
+                    put16(d + 2 * i, a < 0 ? 0 : a > 65535 ? 65535 : a);
+                    put16(dv + 2 * i, b < 0 ? 0 : b > 65535 ? 65535 : b);
+                } else {
+                    put16(d + 2 * i, planeX16(up, c->v_chr + y * c->v_chr_size, c->v_chr_size, i));
+                    put16(dv + 2 * i, planeX16(vp, c->v_chr + y * c->v_chr_size, c->v_chr_size, i));
+                }
+            }
+            continue;
+        }
         for (j = 0; j < c->v_chr_size; j++) {
             int r = c->v_chr_pos[y] + j;
             if (r >= c->chr_src_h) r = c->chr_src_h - 1;
@@ -801,7 +827,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     const int16_t **lp = NULL, **up = NULL, **vp = NULL;
     const int dst_w = c->dst_w, cdw = c->chr_dst_w;
 
-    if (c->dst_fmt == ORC_PIX_P016LE)
+    if (c->dst_fmt == ORC_PIX_P016LE || c->dst_fmt == ORC_PIX_YUV444P16LE)
         return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_p016(c, src, src_stride, dst, dst_stride) : -1;
     if (is_rgb64(c->dst_fmt))
         return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_rgba64(c, src, src_stride, dst, dst_stride) : -1;
@@ -884,7 +910,7 @@ int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4
 {
     /* bounded working set: process in bands of 64 output rows */
     int y, band = 64;
-    if (c->dst_fmt == ORC_PIX_P016LE)
+    if (c->dst_fmt == ORC_PIX_P016LE || c->dst_fmt == ORC_PIX_YUV444P16LE)
         return scale_to_p016(c, src, src_stride, dst, dst_stride);
     if (is_rgb64(c->dst_fmt))
         return scale_to_rgba64(c, src, src_stride, dst, dst_stride);

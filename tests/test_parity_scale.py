@@ -449,6 +449,28 @@ def test_rgba64_destinations(dev, orc, src_fmt, dst_fmt, geom):
         assert (got[0] == want[0]).all()
 
 
+@pytest.mark.parametrize("pair", [("yuv444p16le", "yuv444p16le"), ("yuv444p16le", "p016le"), ("yuv444p16le", "rgba64le"),
+                                  ("nv12", "yuv444p16le"), ("p010le", "yuv444p16le"), ("yuv444p", "yuv444p16le")])
+@pytest.mark.parametrize("geom", [(128, 48, 64, 24), (96, 40, 144, 60), (101, 45, 75, 33), (70, 22, 70, 22)])
+def test_yuv444p16_on_the_19bit_path(dev, orc, pair, geom):
+    """scale_cuda's last format: planar 16-bit 4:4:4 as a source and as a destination of the 19-bit path (equal format and
+    size: plane copy)"""
+    sf, df = pair
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, sf, sw, sh, seed=79)
+    same = sf == df and (sw, sh) == (dw, dh)
+    want = src if same else orc.sws(src, sw, sh, sf, dw, dh, df, SWS["bicubic"])
+    for align, extra in ((64, 0), (2, 2)):
+        d = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS["bicubic"], dst_align=align, dst_extra=extra)
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (i, kernel)
+            assert (pads[i] == 0xCD).all()
+        for p in d:
+            p.free()
+    assert not dev.lib.gmat_sws_getContext(sw, sh, PIX_FMT["yuv444p16le"], dw, dh, PIX_FMT["nv12"], 4, None)
+
+
 @pytest.mark.parametrize("fmt", ["p010le", "p016le"])
 def test_p01x_equal_format_and_size_is_a_plane_copy(dev, orc, fmt):
     w, h = 70, 22
