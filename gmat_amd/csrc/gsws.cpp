@@ -154,7 +154,7 @@ struct GmatSwsContext {
 };
 
 // sources of the single-context plane scaler: 8-bit planar / semi-planar YUV and the 16-bit semi-planar P010LE / P016LE
-static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f); }
+static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f) || f == GMAT_PIX_FMT_YUV444P16LE; }
 
 static int init_yuv_scaler(GmatSwsContext *c)
 {
@@ -193,6 +193,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         a.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24; a.chrHalf = c->planYuv.chrSrcHSub;
         a.r2y = make_rgb2yuv_consts(c->colorspace);
     }
+    if (c->srcFormat == GMAT_PIX_FMT_YUV444P16LE) { a.src16 = 17; a.hShift = 15; a.hBias = 1 << 29; }
     if (is_p01x(c->srcFormat)) {
         a.src16 = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : 16;
         a.hShift = a.src16 - 1;                          // hScale16To15_c: sh = depth - 1 (swscale.c:93-119)
@@ -301,7 +302,7 @@ static int init_scale16(GmatSwsContext *c)
 static int ensure_scaler(GmatSwsContext *c)
 {
     if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) ||
-        c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
+        c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -348,6 +349,11 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     if (ya.src16 == 3) {
         ya.u = ya.v = nullptr; ya.us = ya.vs = 0;
         ya.srcAligned = al4(src[0], srcStride[0]); ya.srcAligned16 = 0;        // 12-byte pixel groups as three dwords
+    } else if (ya.src16 == 17) {
+        if (!src[2] || (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1] | (uintptr_t)srcStride[2]) & 1) != 0)
+            return GMAT_ERR(EINVAL);
+        ya.v = src[2]; ya.vs = srcStride[2];
+        ya.srcAligned = al4(src[0], srcStride[0]); ya.srcAligned16 = 0;
     } else if (ya.src16) {
         // 16-bit samples: rows and planes 2-byte aligned at least; dword loads when 4-byte aligned
         if ((((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);
@@ -456,7 +462,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
-    const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
+    const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
     const bool yuvDst = is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
@@ -616,7 +622,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         // yuv2p010lX_c / yuv2p010cX_c (output.c:459-519).  Equal-size 8-bit 4:2:0 sources were taken above (MODE_DEPTH).
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
-    } else if (is_p01x(srcFormat) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
+    } else if ((is_p01x(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV444P16LE) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
         // 16-bit semi-planar sources (scale_cuda's list, vf_scale_cuda.c:45-54) to any 8-bit destination, any size:
         // libswscale has no special converter for them, the generic path's hScale16To15_c brings the samples to the
         // same 15-bit lines an 8-bit source gives
@@ -716,7 +722,7 @@ int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
     if (c->inner) return gmat_sws_setFused(c->inner, fused);
-    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || is_p01x(c->srcFormat) || c->rgbViaPlanes) && fused != 2) return GMAT_ERR(ENOSYS);
+    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE || is_p01x(c->srcFormat) || c->rgbViaPlanes) && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
     return 0;
@@ -766,7 +772,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         return GMAT_ERR(EINVAL);
     }
     c->lastLaunchFrames = 1;
-    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P;
+    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
     if (is_plane_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
     int r = 0;

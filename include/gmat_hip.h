@@ -34,8 +34,8 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_NV12      = 23,
     GMAT_PIX_FMT_RGBA      = 26,
     GMAT_PIX_FMT_BGRA      = 28,
-    GMAT_PIX_FMT_YUV444P16LE = 49,  /* scale_cuda's list: source and destination on the 19-bit path (with P016LE, RGBA64LE,
-                                       BGRA64LE and itself); not offered towards / from the 8-bit formats */
+    GMAT_PIX_FMT_YUV444P16LE = 49,  /* scale_cuda's list: source for every destination at any size; destination of every
+                                       YUV source on the 19-bit path (with P016LE, RGBA64LE, BGRA64LE) */
     GMAT_PIX_FMT_RGBA64LE  = 105,   /* destinations of every YUV source at any size (yuv2rgba64_*_c on libswscale's 19-bit */
     GMAT_PIX_FMT_BGRA64LE  = 107,   /* lines; alpha 0xFFFF) — yuv2rgb_cuda's 64-bit outputs, yuv2rgb_cuda.cu:862-907           */
     GMAT_PIX_FMT_HIP       = 117,   /* AV_PIX_FMT_CUDA's slot (pixfmt.h:225): opaque device frame */

@@ -147,8 +147,6 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
         return NULL;
     if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
         return NULL;
-    if (src_fmt == ORC_PIX_YUV444P16LE && !is_dst16(dst_fmt))
-        return NULL;                                       /* 16-bit planar 4:4:4 source: only on the 19-bit path here */                                       /* RGB readers / 16-bit range conversion for 19-bit lines: not restated */
     if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
         return NULL;                                       /* 32-bit readers not restated */
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
@@ -316,6 +314,11 @@ static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int str
                                  (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
         }
         hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 13);
+    } else if (c->src_fmt == ORC_PIX_YUV444P16LE) {
+        /* native-endian 16-bit planar samples need no input converter; hScale16To15_c with sh = 15 */
+        int i;
+        for (i = 0; i < c->src_w; i++) tmp[i] = (uint16_t)rl16(row + 2 * i);
+        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 15);
     } else if (is_p01x(c->src_fmt)) {
         /* p010LEToY_c (input.c:698-705): the 10 significant bits are the high ones, >> 6; P016LE has no converter
          * on a little-endian host (input.c:1523-1528 sits under HAVE_BIGENDIAN): the 16-bit samples as they are.
@@ -364,6 +367,13 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
         }
         hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
         hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
+    } else if (c->src_fmt == ORC_PIX_YUV444P16LE) {
+        for (i = 0; i < c->chr_src_w; i++) {
+            tmp_u[i] = (uint16_t)rl16(src[1] + (long)y * stride[1] + 2 * i);
+            tmp_v[i] = (uint16_t)rl16(src[2] + (long)y * stride[2] + 2 * i);
+        }
+        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
+        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
     } else if (is_p01x(c->src_fmt)) {
         /* p010LEToUV_c / p016LEToUV_c (input.c:716-747): interleaved 16-bit U, V */
         const uint8_t *row = src[1] + (long)y * stride[1];

@@ -468,7 +468,25 @@ def test_yuv444p16_on_the_19bit_path(dev, orc, pair, geom):
             assert (pads[i] == 0xCD).all()
         for p in d:
             p.free()
-    assert not dev.lib.gmat_sws_getContext(sw, sh, PIX_FMT["yuv444p16le"], dw, dh, PIX_FMT["nv12"], 4, None)
+
+
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p", "rgb24", "bgra", "p010le"])
+@pytest.mark.parametrize("geom", [(128, 48, 64, 24), (96, 40, 144, 60), (101, 45, 75, 33), (70, 22, 70, 22)])
+def test_yuv444p16_source_to_8bit_and_p010(dev, orc, dst_fmt, geom):
+    """planar 16-bit 4:4:4 towards the 15-bit-line destinations: hScale16To15_c with sh = 15 per plane (the LDS image
+    biased like P016's), full chroma interpolation forced for RGB outputs (non-subsampled source)"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, "yuv444p16le", sw, sh, seed=80)
+    want = orc.sws(src, sw, sh, "yuv444p16le", dw, dh, dst_fmt, SWS["bicubic"])
+    for align, extra in ((64, 0), (2, 2)):
+        d = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d, sw, sh, "yuv444p16le", dw, dh, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
+        assert kernel.startswith("scale_yuv_kernel"), kernel
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (i, kernel)
+            assert (pads[i] == 0xCD).all()
+        for p in d:
+            p.free()
 
 
 @pytest.mark.parametrize("fmt", ["p010le", "p016le"])
