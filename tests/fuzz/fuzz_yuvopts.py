@@ -21,8 +21,8 @@ L.orc_sws_create_ex.restype = C.c_void_p
 L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 fails = skipped = 0
 for case in range(n):
-    sf = rng.choice(["nv12", "yuv420p", "yuv444p", "p010le", "p016le"])
-    df = rng.choice(["nv12", "yuv420p", "yuv444p", "p010le", "p016le", "rgb24", "bgra"])
+    sf = rng.choice(["nv12", "yuv420p", "yuv444p", "p010le", "p016le", "yuv444p16le"])
+    df = rng.choice(["nv12", "yuv420p", "yuv444p", "p010le", "p016le", "yuv444p16le", "rgba64le", "rgb24", "bgra"])
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     dw, dh = (sw, sh) if rng.random() < 0.3 else (rng.randint(2, 300), rng.randint(2, 120))
     flags = SWS[rng.choice(["bicubic", "bilinear", "lanczos", "point", "area"])]
@@ -30,10 +30,14 @@ for case in range(n):
     use_pos = rng.random() < 0.5
     if not use_pos: pos = [-513] * 4
     sr, dr = (rng.randint(0, 1), rng.randint(0, 1)) if df in ("nv12", "yuv420p", "yuv444p", "p010le") else (0, 0)
+    if df == "rgba64le":
+        pos = [-513] * 4; use_pos = False
     if df in ("p010le", "p016le") and (sw, sh) == (dw, dh) and sf in ("nv12", "yuv420p", df):
         continue                                   # depth-expansion converter / plane copy, covered elsewhere
-    if df == "p016le":
+    if df in ("p016le", "yuv444p16le", "rgba64le"):
         sr = dr = 0                                # 16-bit range conversion is not offered
+        if sf == df and (sw, sh) == (dw, dh):
+            continue                               # plane copy
     if sf in ("nv12", "yuv420p") and (sw, sh) == (dw, dh) and sr == dr and not use_pos and df in ("nv12", "yuv420p"):
         continue
     if sf in ("nv12", "yuv420p") and (sw, sh) == (dw, dh) and df in ("rgb24", "bgra"):
@@ -58,7 +62,7 @@ for case in range(n):
     if not ok_cfg:
         lib.gmat_sws_freeContext(c); skipped += 1; continue
     align, extra = rng.choice([(256, 0), (16, 0), (4, 0), (1, 1), (2, 2)])
-    if (sf in ("p010le", "p016le") or df in ("p010le", "p016le")) and align == 1:
+    if (sf in ("p010le", "p016le", "yuv444p16le") or df in ("p010le", "p016le", "yuv444p16le", "rgba64le")) and align == 1:
         align, extra = 2, 2                        # rows of 16-bit samples are at least 2-byte aligned
     d = dev.upload_planes(src, align, extra)
     dst = dev.planes_like(df, dw, dh, align, extra)
