@@ -434,7 +434,16 @@ __device__ __forceinline__ void x2_tiles(const Yuv2xArgs &a, int rowsL, int rows
                         o3.x = X2_B2PAIR(c0[0], c1[0]) | (X2_B2PAIR(c2[0], c0[1]) << 16);
                         o3.y = X2_B2PAIR(c1[1], c2[1]) | (X2_B2PAIR(c0[2], c1[2]) << 16);
                         o3.z = X2_B2PAIR(c2[2], c0[3]) | (X2_B2PAIR(c1[3], c2[3]) << 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+                        {   // one 12-byte store: left to the compiler, the store is tail-merged with the RGBA path's and
+                            // split into 8 + 4 bytes (two store instructions per wave; SQ_INSTS_VMEM_WR doubled)
+                            typedef unsigned x2_u32x3 __attribute__((ext_vector_type(3)));
+                            const x2_u32x3 pk = {o3.x, o3.y, o3.z};
+                            asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(d), "v"(pk) : "memory");
+                        }
+#else
                         *reinterpret_cast<uint3 *>(d) = o3;
+#endif
                     }
                 } else {
                     for (int i = 0; i < nx; i++) {
