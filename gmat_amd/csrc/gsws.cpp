@@ -125,6 +125,7 @@ struct GmatSwsContext {
     DevBuf dR2YrowStart, dR2YrowCount;
     DevFilter r2yVChr;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
+    Yuv2sTables y2s;              // strip-walking 2:1 form (k_scale_yuv2s.hip), RGB destinations
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
@@ -199,6 +200,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         a.hShift = a.src16 - 1;                          // hScale16To15_c: sh = depth - 1 (swscale.c:93-119)
         a.hBias = a.src16 == 16 ? (1 << 29) : 0;         // 32768 * 16384: undoes the -32768 of the P016 LDS image
     }
+    if ((r = yuv2s_prepare(c->planYuv, c->ytiling, c->y2s)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -416,6 +418,25 @@ static Yuv2xArgs make_yuv2x_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     return xa;
 }
 
+// the strip kernel: 4-byte aligned rows on both sides (its loads are dword-aligned at any window position)
+static bool yuv2s_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    return c->y2s.ok && !c->rangeConv && ya.srcAligned && ya.dstAligned && !ya.prof &&
+           (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
+}
+
+static Yuv2sArgs make_yuv2s_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv2sArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.ys = ya.ys; sa.us = ya.us; sa.vs = ya.vs; sa.nv12 = ya.nv12;
+    sa.srcW = ya.srcW; sa.srcH = ya.srcH; sa.chrSrcW = ya.chrSrcW; sa.chrSrcH = ya.chrSrcH;
+    sa.dstW = ya.dstW; sa.dstH = ya.dstH; sa.ds = ya.ds; sa.dstFormat = ya.dstFormat;
+    for (int k = 0; k < 4; k++) { sa.hL[k] = c->y2s.hL[k]; sa.hC[k] = c->y2s.hC[k]; sa.vL[k] = c->y2s.vL[k]; }
+    sa.lr = c->y2s.lr; sa.xcdRemap = ya.xcdRemap; sa.y2r = ya.y2r;
+    return sa;
+}
+
 namespace gmat {
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
@@ -452,13 +473,14 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true;
+    bool use2x = true, use2s = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
         int r = prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya);
         if (r < 0) return r;
         use2x = use2x && yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride);
+        use2s = use2s && yuv2s_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -466,7 +488,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const bool yuvDst = is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
-    c->lastKernel = !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
+    c->lastKernel = use2s ? "scale_yuv2s_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -477,7 +500,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = planarSrc ? sp[2] : nullptr;
             fr.dst[i] = dp[0]; fr.dstU[i] = yuvDst ? dp[1] : nullptr; fr.dstV[i] = planarDst ? dp[2] : nullptr;
         }
-        int r = use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
+        int r = use2s ? launch_scale_yuv2s(sa, stream, &fr, m)
+              : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
                       : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
         c->lastLaunchFrames = m;
@@ -949,6 +973,15 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) {
             YuvScaleArgs ya;
             if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
+            static const bool stripSingle = getenv("GMAT_STRIP_SINGLE") != nullptr;
+            if (stripSingle && yuv2s_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
+                c->lastKernel = "scale_yuv2s_kernel";
+                r = launch_scale_yuv2s(make_yuv2s_args(c, ya), c->stream, &one, 1);
+                break;
+            }
             if (yuv2x_eligible(c, ya, src, srcStride)) {
                 const Yuv2xArgs xa = make_yuv2x_args(c, ya);
                 c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";

@@ -1,0 +1,395 @@
+// k_scale_yuv2s.hip — strip-walking form of the exact 2:1 YUV 4:2:0 -> packed RGB scaler for gfx950 (the headline:
+// 4K nv12 -> 1080p rgb24 bicubic, one libswscale context: swscale.c:234-520 semantics, bit-exact).
+//
+// What the tiled 2:1 kernel (k_scale_yuv2x.hip) spends its time on is not arithmetic but movement: every 64 x 16
+// tile re-loads and re-filters a 7-row vertical halo (19 % of its horizontal work, 1.32x the compulsory HBM traffic),
+// widens every sample into LDS, reads it back, writes the horizontal result to LDS and reads it a third time.  Here
+//   * a wave owns a strip of 256 output columns and WALKS DOWN it: the horizontally filtered rows it still needs
+//     live in a 4-deep register window (16 VGPRs), so a source row is loaded and filtered once per strip segment;
+//   * pixels never pass through LDS: each lane loads the 16 source bytes its 4 outputs need straight from global
+//     memory (4-byte aligned dwordx4; neighbouring lanes overlap by 8 bytes, which the vector L1 absorbs) and
+//     widens them with v_perm_b32 onto the odd-aligned pair grid (2x-3, 2x-2) ... (2x+3, 2x+4): 4 coefficient pairs
+//     per output instead of the 5 an even-aligned window needs;
+//   * no tables: libswscale folds the taps that fall outside the frame onto the edge sample (initFilter,
+//     utils.c:601-640), which — when the host has checked it coefficient by coefficient, yuv2s_prepare — is the
+//     interior filter applied to an edge-replicated frame.  Rows are replicated by clamping the row address, columns
+//     by a byte permute in the two edge lanes, and every coefficient is a kernel argument (an SGPR operand of
+//     v_dot2c_i32_i16);
+//   * the per-chroma-sample colour terms (yuv2rgb.c's table_rV / gU / gV / bU in closed form) come from two 2 KB
+//     LDS look-up tables built once per workgroup, not from 14 VALU instructions per sample.
+// Waves of a workgroup share nothing but those tables: no barrier inside the row loop, occupancy set by VGPRs only.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <type_traits>
+#include <cstdlib>
+#include <cstring>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+constexpr int S2_STRIP = 256;                  // output columns per wave: 64 lanes x 4
+
+// ---- unaligned vector loads (4-byte aligned addresses) -----------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned s2_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned s2_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef unsigned s2_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ uint4 s2_ld16(const uint8_t *p) { const s2_u32x4 v = *reinterpret_cast<const s2_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint3 s2_ld12(const uint8_t *p) { const s2_u32x3 v = *reinterpret_cast<const s2_u32x3 *>(p); return make_uint3(v.x, v.y, v.z); }
+__device__ __forceinline__ uint2 s2_ld8(const uint8_t *p) { const s2_u32x2 v = *reinterpret_cast<const s2_u32x2 *>(p); return make_uint2(v.x, v.y); }
+#else
+static inline uint4 s2_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
+static inline uint3 s2_ld12(const uint8_t *p) { uint3 v; std::memcpy(&v, p, 12); return v; }
+static inline uint2 s2_ld8(const uint8_t *p) { uint2 v; std::memcpy(&v, p, 8); return v; }
+#endif
+
+// v_dot2_i32_i16 in its three-operand (VOP3P) form: with the clamp bit set the compiler cannot use the two-operand
+// v_dot2c, whose tied accumulator costs a v_mov per chain start (12 per row here).  The clamp saturates the int32
+// accumulate, which none of these sums (< 2^26) can reach, so the result is the same.
+#ifndef S2_DOT2_CLAMP
+#define S2_DOT2_CLAMP 1
+#endif
+__device__ __forceinline__ int s2_dot2(int packed_ab, int packed_cd, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, packed_ab), __builtin_bit_cast(short2v, packed_cd), acc, S2_DOT2_CLAMP != 0);
+}
+
+// bytes (1,2) of lo -> one int16 pair; byte 3 of lo and byte 0 of hi -> the next one (selector 0x0C = constant zero)
+__device__ __forceinline__ int s2_pair12(unsigned lo) { return (int)__builtin_amdgcn_perm(0u, lo, 0x0C020C01u); }
+__device__ __forceinline__ int s2_pair30(unsigned hi, unsigned lo) { return (int)__builtin_amdgcn_perm(hi, lo, 0x0C040C03u); }
+__device__ __forceinline__ unsigned s2_rep(unsigned v, unsigned sel) { return __builtin_amdgcn_perm(v, v, sel); }
+
+// The pixels one row-loop iteration consumes: a luma row pair (2m-1, 2m) and one chroma row
+struct S2Pix {
+    uint4 la, lb;                  // 16 luma bytes of each row, from column 8t - 4 of the strip
+    uint4 ca;                      // NV12: 8 UV pairs from chroma column 4t - 4;  planar: U bytes (x,y,z) from 4t - 4
+    uint4 cb;                      // NV12: (x,y) the next 4 UV pairs;             planar: V bytes (x,y,z)
+};
+
+// DST: 0 rgb24, 1 bgr24, 2 rgba, 3 bgra
+template <bool NV12, int DST>
+__global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    __shared__ int2 lutV[256], lutU[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- colour look-up tables: chan = byte 2 of clamp(term + Y * cy, 0, 0xFFFFFF) with
+    //      term_R = lutV[V].x, term_G = lutV[V].y + lutU[U].x, term_B = lutU[U].y  (px_math.h chroma_terms, split by sample)
+    {
+        const Yuv2RgbConsts &k = a.y2r;
+        const int i = tid;
+        lutV[i] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
+        lutU[i] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+    }
+    __syncthreads();
+
+    // ---- which strip segment ------------------------------------------------------------------------------------
+    const int nblk = a.nseg * a.nsg;
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= nblk) return;
+    const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsg);
+    const int X0 = ((lin - seg * a.nsg) * 4 + wave) * S2_STRIP;
+    if (X0 >= a.dstW) return;                                  // wave-uniform; no barrier below
+    const int y0 = seg * a.segRows;
+    const int nOut = min(a.segRows, a.dstH - y0);
+    const int nIter = nOut + 3;                                // 3 warm-up row pairs fill the vertical window
+
+    const uint8_t *py, *pu, *pv;
+    uint8_t *pd;
+    {
+        const int f = blockIdx.y;
+        py = fr.y[f]; pu = fr.u[f]; pv = fr.v[f]; pd = fr.dst[f];
+    }
+
+    // ---- per-lane constants -------------------------------------------------------------------------------------
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
+    const bool edgeWave = X0 == 0 || X0 + S2_STRIP >= a.dstW;   // wave-uniform: only these waves hold a frame-edge lane
+    // luma: bytes [2xc - 4, 2xc + 12) of the row; sources < 0 and >= srcW are the replicated edge samples
+    const int wantL = 2 * xc - 4;
+    const int offL = min(max(wantL, 0), a.srcW - 16);
+    const int shL = wantL - offL;                               // -4 at the left frame edge, +4 at the right one
+    // chroma samples [xc - 4, xc + 8) of the row
+    int offA, offB, shA, shB;
+    if (NV12) {
+        offA = max(2 * xc - 8, 0);               shA = 2 * xc - 8 - offA;        // 16 bytes: samples xc-4 .. xc+3   (-8: left edge)
+        offB = min(2 * xc + 8, 2 * a.chrSrcW - 8); shB = 2 * xc + 8 - offB;      //  8 bytes: samples xc+4 .. xc+7   (+8: right edge)
+    } else {
+        offA = min(max(xc - 4, 0), a.chrSrcW - 12); shA = xc - 4 - offA;         // 12 bytes of each plane (-4 / +4)
+        offB = 0; shB = 0;
+    }
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    // row pointers are wave-uniform (scalar unit), the lane offsets unsigned 32-bit: global_load with an SGPR base
+    const unsigned uoffL = (unsigned)offL, uoffA = (unsigned)offA, uoffB = (unsigned)offB;
+    auto load_luma = [&](int m, S2Pix &P) {
+        const int ra = min(max(2 * m - 1, 0), a.srcH - 1), rb = min(max(2 * m, 0), a.srcH - 1);
+        // one 32-bit offset per load = scalar row offset + lane offset (a plane is far below 4 GB): the frame pointer
+        // stays the SGPR base of the global_load
+        P.la = s2_ld16(py + (unsigned)((unsigned)ra * (unsigned)a.ys + uoffL));
+        P.lb = s2_ld16(py + (unsigned)((unsigned)rb * (unsigned)a.ys + uoffL));
+    };
+    auto load_chroma = [&](int cy, S2Pix &P) {
+        const int r = min(max(cy, 0), a.chrSrcH - 1);
+        if (NV12) {
+            const unsigned ro = (unsigned)r * (unsigned)a.us;
+            P.ca = s2_ld16(pu + (unsigned)(ro + uoffA));
+            const uint2 t = s2_ld8(pu + (unsigned)(ro + uoffB));
+            P.cb = make_uint4(t.x, t.y, 0u, 0u);
+        } else {
+            const uint3 tu = s2_ld12(pu + (unsigned)((unsigned)r * (unsigned)a.us + uoffA));
+            const uint3 tv = s2_ld12(pv + (unsigned)((unsigned)r * (unsigned)a.vs + uoffA));
+            P.ca = make_uint4(tu.x, tu.y, tu.z, 0u);
+            P.cb = make_uint4(tv.x, tv.y, tv.z, 0u);
+        }
+    };
+    // frame-edge lanes: shift the dwords into window position and replicate the edge sample
+    auto fix_luma = [&](uint4 L, auto edge_c) -> uint4 {
+        if (decltype(edge_c)::value) {
+            if (shL < 0) L = make_uint4(s2_rep(L.x, 0x00000000u), L.x, L.y, L.z);
+            else if (shL > 0) L = make_uint4(L.y, L.z, L.w, s2_rep(L.w, 0x03030303u));
+        }
+        return L;
+    };
+
+    // horizontal luma filter of one row: 4 outputs from 7 odd-aligned pairs
+    auto hrow = [&](const uint4 &L, int (&s)[4]) {
+        int p[7];
+        p[0] = s2_pair12(L.x); p[1] = s2_pair30(L.y, L.x); p[2] = s2_pair12(L.y); p[3] = s2_pair30(L.z, L.y);
+        p[4] = s2_pair12(L.z); p[5] = s2_pair30(L.w, L.z); p[6] = s2_pair12(L.w);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            s[j] = s2_dot2(p[j + 3], a.hL[3], s2_dot2(p[j + 2], a.hL[2], s2_dot2(p[j + 1], a.hL[1], s2_dot2(p[j], a.hL[0], 0))));
+    };
+
+    int hw[4][4];                                               // [slot][output]: (row 2m-1 | row 2m << 16) after hScale8To15_c
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hw[s][j] = 0;
+
+    S2Pix buf[2];                                               // ping-pong: iteration j consumes buf[j & 1], prefetches into the other
+    buf[0].ca = buf[0].cb = buf[1].ca = buf[1].cb = make_uint4(0u, 0u, 0u, 0u);
+    buf[1].la = buf[1].lb = make_uint4(0u, 0u, 0u, 0u);
+    load_luma(y0 - 1, buf[0]);
+
+    // EDGE: the wave holds a frame-edge lane (first / last strip).  The whole row loop exists twice so that interior
+    // waves carry none of the fix-up moves.
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;           // j & 3, static after unrolling
+        constexpr bool EDGE = decltype(edge_c)::value;
+        const S2Pix &cur = buf[SLOT & 1];
+        S2Pix &nxt = buf[(SLOT + 1) & 1];
+        // ---- prefetch the next iteration's rows ------------------------------------------------------------
+        if (j + 1 < nIter) {
+            load_luma(y0 + j, nxt);                                 // pair m = y0 - 1 + (j + 1)
+            if (j + 1 >= 3) load_chroma(y0 + j - 2, nxt);           // chroma row of output row y0 + (j + 1) - 3
+        }
+        // ---- horizontal luma of pair m = y0 - 1 + j -> slot ------------------------------------------------
+        {
+            int sa[4], sb[4];
+            hrow(fix_luma(cur.la, edge_c), sa);
+            hrow(fix_luma(cur.lb, edge_c), sb);
+#pragma unroll
+            for (int q = 0; q < 4; q++)       // hScale8To15_c: min(val >> 7, 32767); the lower bound cannot trigger
+                hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 7, sb[q] >> 7));
+        }
+        if (j >= 3) {
+            const int yo = y0 + j - 3;
+            // ---- vertical luma: pairs yo-1 .. yo+2 sit in slots SLOT+1 .. SLOT+4 (mod 4) ------------------------
+            int Y[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int acc = a.lr;
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc = s2_dot2(hw[(SLOT + 1 + k) & 3][q], a.vL[k], acc);
+                Y[q] = acc >> 19;
+            }
+            // ---- chroma of row yo: 2 outputs per plane from 5 odd-aligned pairs ---------------------------------
+            int pU[5], pV[5];
+            if (NV12) {
+                unsigned e[6] = {cur.ca.x, cur.ca.y, cur.ca.z, cur.ca.w, cur.cb.x, cur.cb.y};
+                if (EDGE) {
+                    if (shA < 0) { const unsigned r = s2_rep(e[0], 0x01000100u); e[3] = e[1]; e[2] = e[0]; e[0] = e[1] = r; }
+                    if (shB > 0) { e[4] = e[5] = s2_rep(e[5], 0x03020302u); }
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {       // samples (2k-3, 2k-2) rel. to xc: bytes 2,3 of e[k] and 0,1 of e[k+1]
+                    pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
+                    pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
+                }
+            } else {
+                unsigned fu[3] = {cur.ca.x, cur.ca.y, cur.ca.z}, fv[3] = {cur.cb.x, cur.cb.y, cur.cb.z};
+                if (EDGE) {
+                    if (shA < 0) {
+                        fu[2] = fu[1]; fu[1] = fu[0]; fu[0] = s2_rep(fu[0], 0x00000000u);
+                        fv[2] = fv[1]; fv[1] = fv[0]; fv[0] = s2_rep(fv[0], 0x00000000u);
+                    } else if (shA > 0) {
+                        fu[0] = fu[1]; fu[1] = fu[2]; fu[2] = s2_rep(fu[2], 0x03030303u);
+                        fv[0] = fv[1]; fv[1] = fv[2]; fv[2] = s2_rep(fv[2], 0x03030303u);
+                    }
+                }
+                pU[0] = s2_pair12(fu[0]); pU[1] = s2_pair30(fu[1], fu[0]); pU[2] = s2_pair12(fu[1]); pU[3] = s2_pair30(fu[2], fu[1]); pU[4] = s2_pair12(fu[2]);
+                pV[0] = s2_pair12(fv[0]); pV[1] = s2_pair30(fv[1], fv[0]); pV[2] = s2_pair12(fv[1]); pV[3] = s2_pair30(fv[2], fv[1]); pV[4] = s2_pair12(fv[2]);
+            }
+            int iU[2], iV[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                // hScale8To15_c (>> 7, min 32767), the one-tap vertical filter (1 << 18) + h * 4096, >> 19 and the table
+                // index clamp collapse into clip_u8((sum + 8192) >> 14): floor(floor(x / 128 + 64) / 128) = floor((x + 8192) / 16384)
+                const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], 8192))));
+                const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], 8192))));
+                iU[c] = clip_u8(su >> 14); iV[c] = clip_u8(sv >> 14);
+            }
+            // ---- colour stage + store ---------------------------------------------------------------------------
+            unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int2 tv = lutV[iV[c]], tu = lutU[iU[c]];
+                const int tr = BGR ? tu.y : tv.x, tg = tv.y + tu.x, tb = BGR ? tv.x : tu.y;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int q = 2 * c + h;
+                    c0[q] = (unsigned)min(max(tr + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                    c1[q] = (unsigned)min(max(tg + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                    c2[q] = (unsigned)min(max(tb + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                }
+            }
+            if (active) {
+                uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+    #define S2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = S2_B2PAIR(c0[0], c1[0]) | (S2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                    o4.y = S2_B2PAIR(c0[1], c1[1]) | (S2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                    o4.z = S2_B2PAIR(c0[2], c1[2]) | (S2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                    o4.w = S2_B2PAIR(c0[3], c1[3]) | (S2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d) = o4;
+                } else {
+                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    o3.x = S2_B2PAIR(c0[0], c1[0]) | (S2_B2PAIR(c2[0], c0[1]) << 16);
+                    o3.y = S2_B2PAIR(c1[1], c2[1]) | (S2_B2PAIR(c0[2], c1[2]) << 16);
+                    o3.z = S2_B2PAIR(c2[2], c0[3]) | (S2_B2PAIR(c1[3], c2[3]) << 16);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+    #undef S2_B2PAIR
+            }
+        }
+    };
+
+    auto run = [&](auto edge_c) {
+        for (int j0 = 0; j0 < nIter; j0 += 4) {
+            body(j0, std::integral_constant<int, 0>(), edge_c);
+            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// Is this axis "the filter row `nominal` on the window [2x - 3, 2x + 4] of an edge-replicated line" for every output x?
+static bool replicate_equivalent(const FilterBank &fb, int srcLen, int32_t (&pairs)[4])
+{
+    if (fb.count < 8 || srcLen != 2 * fb.count) return false;
+    // the middle row provides the nominal coefficients
+    const int xm = fb.count / 2;
+    int nominal[8] = {0};
+    for (int j = 0; j < fb.taps; j++) {
+        const int16_t c = fb.coef[(size_t)xm * fb.taps + j];
+        if (!c) continue;
+        const int slot = fb.pos[xm] + j - (2 * xm - 3);
+        if (slot < 0 || slot > 7) return false;
+        nominal[slot] = c;
+    }
+    std::vector<int> eff(16), tab(16);
+    for (int x = 0; x < fb.count; x++) {
+        // effective coefficient per source sample, window base 2x - 3 - 4 (room for the taps the table may hold further out)
+        const int base = 2 * x - 7;
+        std::fill(eff.begin(), eff.end(), 0); std::fill(tab.begin(), tab.end(), 0);
+        for (int k = 0; k < 8; k++) {
+            const int s = std::min(std::max(2 * x - 3 + k, 0), srcLen - 1);
+            eff[s - base] += nominal[k];
+        }
+        for (int j = 0; j < fb.taps; j++) {
+            const int16_t c = fb.coef[(size_t)x * fb.taps + j];
+            if (!c) continue;
+            const int s = fb.pos[x] + j;
+            if (s < 0 || s >= srcLen || s - base < 0 || s - base >= 16) return false;
+            tab[s - base] += c;
+        }
+        if (eff != tab) return false;
+    }
+    for (int k = 0; k < 4; k++)
+        pairs[k] = (int32_t)((uint32_t)(uint16_t)nominal[2 * k] | ((uint32_t)(uint16_t)nominal[2 * k + 1] << 16));
+    return true;
+}
+
+int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
+{
+    t = Yuv2sTables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (g.fullChroma || g.yuvOut) return 0;
+    if (!is_yuv420(p.srcFormat)) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
+          p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
+    if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 8 || p.srcW < 32 || p.dstH < 8) return 0;
+    if (p.chrSrcW != p.dstW || p.chrSrcH != p.dstH || p.chrDstW * 2 != p.dstW || p.chrDstH != p.dstH) return 0;
+    if (!replicate_equivalent(p.hLum, p.srcW, t.hL)) return 0;
+    if (!replicate_equivalent(p.hChr, p.chrSrcW, t.hC)) return 0;
+    if (!replicate_equivalent(g.vLumEff, p.srcH, t.vL)) return 0;
+    // vertical chroma: one tap of 4096 on row y, rounding 1 << 18 (the kernel folds it into the horizontal accumulator)
+    if (g.vChrEff.taps != 1) return 0;
+    for (int y = 0; y < p.dstH; y++)
+        if (g.vChrEff.pos[y] != y || g.vChrEff.coef[y] != 4096 || g.chrRound[y] != (1 << 18) || g.lumRound[y] != g.lumRound[0]) return 0;
+    t.lr = g.lumRound[0];
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv2sArgs a = a0;
+    // rows per strip segment: long segments amortise the 3 warm-up row pairs (6 halo rows), short ones give the
+    // dispatcher enough workgroups to fill 256 CUs several times over
+    const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
+    const int segEnv = segStr ? atoi(segStr) : 0;
+    const int nstrips = (a.dstW + S2_STRIP - 1) / S2_STRIP;
+    a.nsg = (nstrips + 3) / 4;
+    int seg = segEnv > 0 ? segEnv : 0;
+    if (!seg) {
+        // aim at >= 10 waves per SIMD over the launch (two rounds at the expected occupancy), segments of 16..64 rows
+        const long waves = (long)nstrips * nframes;
+        const long wantSegs = std::max(1L, (10L * 1024 + waves - 1) / waves);
+        seg = (int)std::min(64L, std::max(16L, (long)a.dstH / wantSegs));
+    }
+    a.segRows = seg;
+    a.nseg = (a.dstH + seg - 1) / seg;
+    const int nblk = a.nseg * a.nsg;
+    const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
+    const Yuv2xFrames &fr = *frames;
+#define GMAT_S2(N_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_kernel<N_, D_>), grid, block, 0, stream, a, fr)
+    const int d = a.dstFormat == GMAT_PIX_FMT_RGB24 ? 0 : a.dstFormat == GMAT_PIX_FMT_BGR24 ? 1 : a.dstFormat == GMAT_PIX_FMT_RGBA ? 2 : 3;
+    if (a.nv12) { switch (d) { case 0: GMAT_S2(true, 0); break; case 1: GMAT_S2(true, 1); break; case 2: GMAT_S2(true, 2); break; default: GMAT_S2(true, 3); } }
+    else        { switch (d) { case 0: GMAT_S2(false, 0); break; case 1: GMAT_S2(false, 1); break; case 2: GMAT_S2(false, 2); break; default: GMAT_S2(false, 3); } }
+#undef GMAT_S2
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

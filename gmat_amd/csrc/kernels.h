@@ -235,4 +235,25 @@ int  yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2xTable
 // frames == nullptr: the one frame described by `a`
 int  launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, hipStream_t stream,
                         const Yuv2xFrames *frames = nullptr, int nframes = 1);
+// ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> packed RGB scaler (k_scale_yuv2s.hip) -----------------------
+// A wave walks down a strip of 256 output columns with the horizontally filtered rows it still needs in registers; the
+// borders are the interior filter on an edge-replicated frame (checked coefficient by coefficient on the host), so
+// every coefficient is a kernel argument and there are no tables.
+struct Yuv2sTables {
+    int ok = 0;
+    int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
+    int lr = 0;                                        // vertical luma accumulator start
+};
+struct Yuv2sArgs {
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
+    int ds, dstFormat;
+    int32_t hL[4], hC[4], vL[4];
+    int lr;
+    int segRows, nseg, nsg, xcdRemap;           // filled by the launcher: rows per strip segment, segments, groups of 4 strips per row
+    Yuv2RgbConsts y2r;
+};
+int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTables &t);
+// plane pointers of the nframes frames in *frames (grid.y = frame)
+int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 } // namespace gmat

@@ -36,6 +36,8 @@ struct dim3 {
 };
 
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { return {x, y}; }
 struct uint3 { unsigned x, y, z; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(16) int4 { int x, y, z, w; };

@@ -64,7 +64,8 @@ def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, al
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
 def test_batch_on_the_2to1_kernel(dev, orc, src_fmt, dst_fmt):
     k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
-    assert k.startswith("scale_yuv2x_kernel"), k
+    # packed RGB destinations take the strip-walking form, 4:2:0 destinations the tiled one
+    assert k.startswith("scale_yuv2s_kernel" if dst_fmt in ("rgb24", "bgra") else "scale_yuv2x_kernel"), k
 
 
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 96, 40, 144, 60), ("yuv420p", "nv12", 200, 90, 80, 36),
@@ -82,6 +83,8 @@ def test_batch_on_the_generic_plane_scaler(dev, orc, case):
 def test_batch_more_frames_than_one_launch_carries(dev, orc):
     """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches"""
     k = _run_batch(dev, orc, "nv12", "rgb24", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)
+    assert k.startswith("scale_yuv2s_kernel"), k
+    k = _run_batch(dev, orc, "nv12", "nv12", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)
     assert k.startswith("scale_yuv2x_kernel"), k
 
 
@@ -124,7 +127,7 @@ def test_batch_same_size_converter(dev, orc, src_fmt, dst_fmt, geom):
 def test_batch_falls_back_frame_by_frame(dev, orc, case):
     sf, df, sw, sh, dw, dh, align = case
     k = _run_batch(dev, orc, sf, df, sw, sh, dw, dh, nframes=4, nstreams=2, align=align)
-    assert not k.startswith("scale_yuv2x_kernel"), k
+    assert not k.startswith("scale_yuv2"), k
 
 
 def test_batch_single_frame_and_more_streams_than_frames(dev, orc):
@@ -138,4 +141,4 @@ def test_graph_replay_of_a_batch(dev, orc, dst_fmt):
     if dev.kind != "hip":
         pytest.skip("graph capture needs the HIP runtime")
     k = _run_batch(dev, orc, "nv12", dst_fmt, 256, 64, 128, 32, nframes=6, nstreams=2, align=64, graph=True)
-    assert k.startswith("scale_yuv2x_kernel"), k
+    assert k.startswith("scale_yuv2s_kernel" if dst_fmt == "rgb24" else "scale_yuv2x_kernel"), k

@@ -1,0 +1,112 @@
+"""The strip-walking 2:1 scaler (k_scale_yuv2s.hip): 4:2:0 -> packed RGB at exactly half size, the headline kernel.
+Every case goes through gmat_sws_scale_batch (the entry point that selects it) and must equal, byte for byte, what ONE
+libswscale context computes (the oracle: swscale.c:234-520 with yuv2rgb_X_c output) — including the frame borders, where
+the kernel replicates edge samples instead of reading libswscale's folded coefficient rows (initFilter, utils.c:601-640)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, ints, synth_planes
+from test_batch_api import _run_batch
+
+
+@pytest.fixture
+def strip_rows():
+    """GMAT_STRIP_ROWS (rows per strip segment) is read at every launch: vary the segmentation per test"""
+    old = os.environ.get("GMAT_STRIP_ROWS")
+
+    def set_rows(n):
+        if n:
+            os.environ["GMAT_STRIP_ROWS"] = str(n)
+        else:
+            os.environ.pop("GMAT_STRIP_ROWS", None)
+    yield set_rows
+    if old is None:
+        os.environ.pop("GMAT_STRIP_ROWS", None)
+    else:
+        os.environ["GMAT_STRIP_ROWS"] = old
+
+
+# (srcW, srcH, row alignment): one partial strip, exactly one strip, strips + a partial one, two strip groups, widths that
+# are multiples of 8 only, heights that leave a short last segment
+GEOMS = [(32, 16, 4), (64, 32, 16), (512, 40, 64), (520, 24, 4), (1032, 36, 8), (2056, 20, 4), (2560, 18, 256), (4104, 16, 4)]
+
+
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_strip_kernel_bit_exact(dev, orc, strip_rows, src_fmt, dst_fmt, geom):
+    sw, sh, align = geom
+    if dst_fmt in ("rgba", "bgra"):
+        align = max(align, 16)                  # 16-byte pixel-group stores
+    strip_rows(0)
+    k = _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, sw // 2, sh // 2, nframes=2, nstreams=1, align=align)
+    assert k == "scale_yuv2s_kernel", k
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64, 1000])
+def test_strip_segmentation_does_not_change_the_result(dev, orc, strip_rows, rows):
+    """segments of any height: the 3 warm-up row pairs of every segment re-create the vertical window exactly"""
+    strip_rows(rows)
+    k = _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=4, nstreams=2, align=16)
+    assert k == "scale_yuv2s_kernel", k
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss"])
+def test_strip_kernel_filters_that_fit_the_window(dev, orc, strip_rows, flags):
+    """every filter whose taps fit [2x - 3, 2x + 4] and whose border rows are edge replication takes the strip kernel;
+    the others (lanczos: 12 taps) stay on the tiled kernel — either way the bytes are libswscale's"""
+    strip_rows(0)
+    k = _run_batch(dev, orc, "nv12", "rgb24", 320, 48, 160, 24, nframes=2, nstreams=1, align=16, flags=SWS[flags])
+    assert k.startswith("scale_yuv2"), k
+
+
+@pytest.mark.parametrize("flags", ["lanczos", "sinc"])
+def test_wide_filters_fall_back(dev, orc, strip_rows, flags):
+    strip_rows(0)
+    k = _run_batch(dev, orc, "nv12", "rgb24", 320, 48, 160, 24, nframes=2, nstreams=1, align=16, flags=SWS[flags])
+    assert k != "scale_yuv2s_kernel", k
+
+
+@pytest.mark.parametrize("cs", [1, 5, 9])
+def test_strip_kernel_colorspace(dev, orc, strip_rows, cs):
+    """the LDS colour tables are built from the context's constants: BT.709 / BT.601 / BT.2020 sources"""
+    strip_rows(0)
+    lib = dev.lib
+    sw, sh, n = 256, 32, 2
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], sw // 2, sh // 2, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    assert c and lib.gmat_sws_setColorspace(c, cs, 0) == 0
+    srcs = [synth_planes(orc, "nv12", sw, sh, seed=900 + f + cs) for f in range(n)]
+    dsrc = [dev.upload_planes(s, 16) for s in srcs]
+    ddst = [dev.planes_like("rgb24", sw // 2, sh // 2, 16) for _ in range(n)]
+    sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
+    for f in range(n):
+        for i, p in enumerate(dsrc[f]): sp[4 * f + i] = p.ptr
+        dp[4 * f] = ddst[f][0].ptr
+    st = C.c_void_p(); assert lib.gmat_stream_create(C.byref(st)) == 0
+    streams = (C.c_void_p * 1)(st)
+    r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
+                                 C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
+                                 C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
+    assert r == n and lib.gmat_sws_lastKernel(c) == b"scale_yuv2s_kernel"
+    lib.gmat_stream_sync(st)
+    for f in range(n):
+        want = orc.sws(srcs[f], sw, sh, "nv12", sw // 2, sh // 2, "rgb24", SWS["bicubic"], colorspace=cs)
+        assert (ddst[f][0].download() == want[0]).all(), (cs, f)
+    lib.gmat_stream_destroy(st)
+    lib.gmat_sws_freeContext(c)
+    for f in range(n):
+        for p in dsrc[f] + ddst[f]: p.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("nv12", "rgb24"), ("yuv420p", "bgra")])
+def test_strip_kernel_4k_full_size(dev, orc, strip_rows, src_fmt, dst_fmt):
+    """BASELINE configs[2] at full size, 3 frames in one launch, AVHWFramesContext row alignment"""
+    if dev.kind != "hip":
+        pytest.skip("full size: GPU only")
+    strip_rows(0)
+    k = _run_batch(dev, orc, src_fmt, dst_fmt, 3840, 2160, 1920, 1080, nframes=3, nstreams=1, align=256)
+    assert k == "scale_yuv2s_kernel", k

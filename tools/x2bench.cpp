@@ -1,0 +1,134 @@
+// tools/x2bench.cpp — tuning aid (not product code): times the scaled YUV -> RGB / YUV contexts of the C ABI on one GPU
+// without Python.  Frames rotate through a set larger than L2 + Infinity Cache; HIP-event timing on one stream.
+//   x2bench [frames_per_launch=32] [launches=40] [case substring]
+// Prints one line per case: kernel, microseconds per launch and per frame, algorithmic GB/s and the fraction of 8 TB/s.
+// It also cross-checks the batched launch against the one-frame-per-call path of the same context (same library, other
+// kernel when the strip kernel is active): a CRC of every output frame must agree.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/gmat_hip.h"
+
+#define CK(x) do { int _r = (x); if (_r < 0) { fprintf(stderr, "error %d at %s:%d: %s\n", _r, __FILE__, __LINE__, #x); exit(1); } } while (0)
+
+static uint32_t lcg_state = 12345;
+static void fill_lcg(std::vector<uint8_t> &v) { for (auto &b : v) { lcg_state = lcg_state * 1664525u + 1013904223u; b = (uint8_t)(lcg_state >> 24); } }
+static uint32_t adler(const uint8_t *p, size_t n)
+{
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < n; i++) { a = (a + p[i]) % 65521u; b = (b + a) % 65521u; }
+    return (b << 16) | a;
+}
+
+struct Fmt { const char *name; int id; };
+static size_t frame_bytes(int fmt, int w, int h)
+{
+    switch (fmt) {
+    case GMAT_PIX_FMT_NV12: case GMAT_PIX_FMT_YUV420P: return (size_t)w * h * 3 / 2;
+    case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: return (size_t)w * h * 3;
+    case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
+    default: return 0;
+    }
+}
+static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4])
+{
+    p[0] = p[1] = p[2] = p[3] = nullptr; s[0] = s[1] = s[2] = s[3] = 0;
+    switch (fmt) {
+    case GMAT_PIX_FMT_NV12: p[0] = b; p[1] = b + (size_t)w * h; s[0] = w; s[1] = w; break;
+    case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
+    case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: p[0] = b; s[0] = 3 * w; break;
+    default: p[0] = b; s[0] = 4 * w; break;
+    }
+}
+
+static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, int dh, int flags, int NF, int launches, int verify)
+{
+    const size_t sb = frame_bytes(sf, sw, sh), db = frame_bytes(df, dw, dh);
+    const int NSET = 2 * NF;                      // rotate two frame sets (> 256 MiB together at 4K x 32)
+    std::vector<uint8_t *> src(NSET), dst(NSET);
+    std::vector<uint8_t> host(sb);
+    for (int i = 0; i < NSET; i++) {
+        CK(gmat_malloc(&src[i], sb)); CK(gmat_malloc(&dst[i], db));
+        if (i < 4) { fill_lcg(host); CK(gmat_memcpy_h2d(src[i], host.data(), sb)); }
+        else CK(gmat_memcpy_h2d(src[i], host.data(), sb));          // same bytes; content does not matter for timing
+        CK(gmat_memset(dst[i], 0, db));
+    }
+    GmatSwsContext *c = gmat_sws_getContext(sw, sh, sf, dw, dh, df, flags, nullptr);
+    if (!c) { fprintf(stderr, "%s: no context\n", label); exit(1); }
+    void *stream = nullptr; CK(gmat_stream_create(&stream));
+    gmat_sws_setStream(c, stream);
+    std::vector<const uint8_t *> sp((size_t)NSET * 4); std::vector<uint8_t *> dp((size_t)NSET * 4);
+    int ss[4], ds[4];
+    for (int i = 0; i < NSET; i++) {
+        uint8_t *p[4];
+        frame_ptrs(src[i], sf, sw, sh, p, ss); for (int k = 0; k < 4; k++) sp[(size_t)i * 4 + k] = p[k];
+        frame_ptrs(dst[i], df, dw, dh, p, ds); for (int k = 0; k < 4; k++) dp[(size_t)i * 4 + k] = p[k];
+    }
+    void *streams[1] = {stream};
+    auto launch = [&](int set) {
+        CK(gmat_sws_scale_batch(c, NF, sp.data() + (size_t)set * NF * 4, ss, dp.data() + (size_t)set * NF * 4, ds, streams, 1, 0));
+    };
+    for (int i = 0; i < 6; i++) launch(i & 1);
+    CK(gmat_stream_sync(stream));
+    const std::string kname = gmat_sws_lastKernel(c);
+    void *timer = nullptr; CK(gmat_timer_create(&timer));
+    float best = 1e30f, sum = 0;
+    const int REPS = 3;
+    for (int r = 0; r < REPS; r++) {
+        CK(gmat_timer_begin(timer, stream));
+        for (int i = 0; i < launches; i++) launch(i & 1);
+        CK(gmat_timer_end(timer, stream));
+        float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
+        best = ms < best ? ms : best; sum += ms;
+    }
+    const double usLaunch = best * 1e3 / launches, usFrame = usLaunch / NF;
+    const double gbs = (double)(sb + db) / usFrame / 1e3;
+    printf("%-34s %-26s %8.1f us/launch %7.3f us/frame %8.1f GB/s  frac %.3f  %7.1f Gpix/s  (avg %.1f us/launch)\n", label, kname.c_str(),
+           usLaunch, usFrame, gbs, gbs / 8000.0, (double)sw * sh / usFrame / 1e3, sum / REPS * 1e3 / launches);
+    fflush(stdout);
+    if (verify) {
+        // batched result of the first 4 (distinct) frames vs one frame per call
+        std::vector<uint8_t> a(db), b(db);
+        std::vector<uint32_t> crcBatch(4);
+        launch(0); CK(gmat_stream_sync(stream));
+        for (int i = 0; i < 4; i++) { CK(gmat_memcpy_d2h(a.data(), dst[i], db)); crcBatch[i] = adler(a.data(), db); CK(gmat_memset(dst[i], 0, db)); }
+        int bad = 0;
+        for (int i = 0; i < 4; i++) {
+            int r = gmat_sws_scale(c, sp.data() + (size_t)i * 4, ss, 0, sh, dp.data() + (size_t)i * 4, ds);
+            if (r < 0) { fprintf(stderr, "single-frame call failed %d\n", r); exit(1); }
+            CK(gmat_stream_sync(stream));
+            CK(gmat_memcpy_d2h(b.data(), dst[i], db));
+            if (adler(b.data(), db) != crcBatch[i]) bad++;
+        }
+        printf("    verify vs one-frame path (%s): %s\n", gmat_sws_lastKernel(c), bad ? "MISMATCH" : "identical");
+        if (bad) exit(2);
+    }
+    gmat_timer_destroy(timer);
+    gmat_sws_freeContext(c);
+    gmat_stream_destroy(stream);
+    for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); }
+}
+
+int main(int argc, char **argv)
+{
+    const int NF = argc > 1 ? atoi(argv[1]) : 32, launches = argc > 2 ? atoi(argv[2]) : 40;
+    const char *only = argc > 3 ? argv[3] : "";
+    const int verify = getenv("X2BENCH_VERIFY") ? atoi(getenv("X2BENCH_VERIFY")) : 1;
+    if (gmat_device_count() < 1) { fprintf(stderr, "no GPU\n"); return 1; }
+    CK(gmat_set_device(0));
+    struct Case { const char *label; int sf, sw, sh, df, dw, dh, flags; };
+    const Case cases[] = {
+        {"nv12 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"yuv420p 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 4K->1080p rgba bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBA, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 4K->1080p rgb24 bilinear", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"nv12 4K->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 1080p->540p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
+    };
+    for (const Case &k : cases)
+        if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
+    return 0;
+}
