@@ -14,8 +14,10 @@ def pytest_configure(config):
 
 
 def _make(directory, target):
-    if not os.path.exists(os.path.join(directory, target)):
-        subprocess.run(["make", "-C", directory], check=True, capture_output=True)
+    """always ask make (a no-op when up to date): a stale .so must never pass for the sources"""
+    r = subprocess.run(["make", "-C", directory], capture_output=True, text=True)
+    if r.returncode != 0 and not os.path.exists(os.path.join(directory, target)):
+        raise RuntimeError(f"make -C {directory} failed:\n{r.stdout}{r.stderr}")
     return os.path.join(directory, target)
 
 
@@ -41,6 +43,8 @@ def dev(request):
     import harness
     from gmat_amd.lib import load
     if request.param == "hip":
+        if os.path.exists("/opt/rocm/bin/hipcc"):       # keep the product library in step with its sources
+            _make(os.path.join(ROOT, "gmat_amd", "csrc"), "../lib/libgmat_hip.so")
         lib = load()            # raises loudly if the product library is missing
         if lib.gmat_device_count() <= 0:
             pytest.fail("-m gpu test selected but no HIP device is visible")
