@@ -118,13 +118,33 @@ int plane_row_bytes(int fmt, int plane, int w)
 
 } // namespace
 
+// Lifetime (the reference keeps an AVHWFramesContext alive through AVBufferRef counts, hwcontext.c:236-258): the
+// context holds one reference for its owner plus one per frame handed out.  gmat_hwframe_ctx_free drops the owner's
+// and closes the pool; frames still out keep the object alive, and returning a frame to a closed pool frees its block.
 struct GmatHWFramesContext {
     int device, sw_format, width, height;
     PlaneLayout layout;
     std::mutex lock;
     std::vector<uint8_t *> free_list;   // pooled hipMalloc blocks (av_buffer_pool equivalent)
     int outstanding = 0;
+    bool closed = false;
 };
+
+// returns a frame's block to its pool; true when the context itself must be deleted (closed and last frame back)
+static bool pool_release(GmatHWFramesContext *fc, uint8_t *block)
+{
+    bool last;
+    bool free_block;
+    {
+        std::lock_guard<std::mutex> g(fc->lock);
+        free_block = fc->closed;
+        if (!free_block) fc->free_list.push_back(block);
+        fc->outstanding--;
+        last = fc->closed && fc->outstanding == 0;
+    }
+    if (free_block) (void)hipFree(block);
+    return last;
+}
 
 extern "C" {
 
@@ -151,9 +171,17 @@ GmatHWFramesContext *gmat_hwframe_ctx_create(int device, int sw_format, int widt
 void gmat_hwframe_ctx_free(GmatHWFramesContext *fc)
 {
     if (!fc) return;
-    for (uint8_t *p : fc->free_list) (void)hipFree(p);
-    if (fc->outstanding) logf(LOG_WARNING, "gmat_hwframe_ctx_free: %d frames still referenced", fc->outstanding);
-    delete fc;
+    std::vector<uint8_t *> blocks;
+    bool last;
+    {
+        std::lock_guard<std::mutex> g(fc->lock);
+        if (fc->closed) return;                              // the owner's reference is dropped once
+        fc->closed = true;
+        blocks.swap(fc->free_list);
+        last = fc->outstanding == 0;
+    }
+    for (uint8_t *p : blocks) (void)hipFree(p);
+    if (last) delete fc;                                     // else the last gmat_frame_unref / gmat_frame_free deletes it
 }
 
 int gmat_hwframe_ctx_info(const GmatHWFramesContext *fc, int *device, int *sw_format, int *width, int *height)
@@ -172,14 +200,20 @@ int gmat_hwframe_get_buffer(GmatHWFramesContext *fc, GmatFrame *f)
     uint8_t *base = nullptr;
     {
         std::lock_guard<std::mutex> g(fc->lock);
+        if (fc->closed) return GMAT_ERR(EINVAL);
         if (!fc->free_list.empty()) { base = fc->free_list.back(); fc->free_list.pop_back(); }
         fc->outstanding++;
     }
     if (!base) {
         GMAT_HIP_CHECK(hipSetDevice(fc->device));
         if (hipMalloc((void **)&base, fc->layout.total) != hipSuccess) {
-            std::lock_guard<std::mutex> g(fc->lock);
-            fc->outstanding--;
+            bool last;
+            {
+                std::lock_guard<std::mutex> g(fc->lock);
+                fc->outstanding--;
+                last = fc->closed && fc->outstanding == 0;
+            }
+            if (last) delete fc;
             return GMAT_ERR(ENOMEM);
         }
     }
@@ -202,17 +236,24 @@ GmatFrame *gmat_frame_alloc(void)
     return f;
 }
 
+void gmat_frame_unref(GmatFrame *f)
+{
+    if (!f) return;
+    if (f->hw_frames_ctx && f->buf) {
+        GmatHWFramesContext *fc = f->hw_frames_ctx;
+        if (pool_release(fc, (uint8_t *)f->buf)) delete fc;
+    }
+    std::memset(f->data, 0, sizeof(f->data));
+    std::memset(f->linesize, 0, sizeof(f->linesize));
+    f->hw_frames_ctx = nullptr; f->buf = nullptr;
+    f->format = GMAT_PIX_FMT_NONE; f->sw_format = GMAT_PIX_FMT_NONE;
+}
+
 void gmat_frame_free(GmatFrame **pf)
 {
     if (!pf || !*pf) return;
-    GmatFrame *f = *pf;
-    if (f->hw_frames_ctx && f->buf) {
-        GmatHWFramesContext *fc = f->hw_frames_ctx;
-        std::lock_guard<std::mutex> g(fc->lock);
-        fc->free_list.push_back((uint8_t *)f->buf);
-        fc->outstanding--;
-    }
-    delete f;
+    gmat_frame_unref(*pf);
+    delete *pf;
     *pf = nullptr;
 }
 

@@ -65,6 +65,7 @@ _SIGS = {
     "gmat_hwframe_get_buffer": (C.c_int, [C.c_void_p, C.POINTER(GmatFrame)]),
     "gmat_frame_alloc": (C.POINTER(GmatFrame), []),
     "gmat_frame_free": (None, [C.POINTER(C.POINTER(GmatFrame))]),
+    "gmat_frame_unref": (None, [C.POINTER(GmatFrame)]),
     "gmat_hwframe_transfer_data": (C.c_int, [C.POINTER(GmatFrame), C.POINTER(GmatFrame), C.c_void_p]),
     "gmat_host_frame_alloc": (C.c_int, [C.POINTER(GmatFrame), C.c_int, C.c_int, C.c_int]),
     "gmat_host_frame_free": (None, [C.POINTER(GmatFrame)]),
@@ -111,6 +112,13 @@ _SIGS = {
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gmat_sws_scale_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "gmat_pipeline_create": (C.c_void_p, [C.c_int] * 9),
+    "gmat_pipeline_host_input": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(GmatFrame)]),
+    "gmat_pipeline_host_output": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(GmatFrame)]),
+    "gmat_pipeline_submit": (C.c_int64, [C.c_void_p]),
+    "gmat_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gmat_pipeline_drain": (C.c_int, [C.c_void_p]),
+    "gmat_pipeline_free": (None, [C.c_void_p]),
     "gmat_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gmat_graph_destroy": (None, [C.c_void_p]),
 }

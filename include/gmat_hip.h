@@ -191,6 +191,11 @@ GMAT_API int  gmat_hwframe_ctx_info(const GmatHWFramesContext *fc, int *device, 
 GMAT_API int  gmat_hwframe_get_buffer(GmatHWFramesContext *fc, GmatFrame *frame);
 GMAT_API GmatFrame *gmat_frame_alloc(void);                 /* av_frame_alloc  */
 GMAT_API void gmat_frame_free(GmatFrame **frame);           /* av_frame_free: returns the buffer to its pool */
+/* av_frame_unref for a caller-owned GmatFrame struct filled by gmat_hwframe_get_buffer: returns the block to its pool
+ * and clears the struct.  Lifetime rule (AVBufferRef semantics, hwcontext.c:236-258): a frames context lives until
+ * gmat_hwframe_ctx_free has been called AND every frame taken from it has been unref'd / freed; frames returned after
+ * gmat_hwframe_ctx_free release their device memory at once.  gmat_hwframe_get_buffer on a freed context fails. */
+GMAT_API void gmat_frame_unref(GmatFrame *frame);
 /* av_hwframe_transfer_data (hwcontext.h:413, hwcontext_cuda.c:221-279): one 2-D async copy per
  * plane on `stream`; direction from which side has format == GMAT_PIX_FMT_HIP */
 GMAT_API int  gmat_hwframe_transfer_data(GmatFrame *dst, const GmatFrame *src, void *stream);
@@ -314,6 +319,25 @@ GMAT_API int  gmat_sws_scale_batch(GmatSwsContext *c, int nframes,
                                    void *const *streams, int nstreams, int flags);
 GMAT_API int  gmat_graph_launch(void *graph_exec, void *stream);
 GMAT_API void gmat_graph_destroy(void *graph_exec);
+
+/* =====================================================================================
+ * 5. Host pipeline — hwupload -> libgpuscale -> hwdownload with copy / compute overlap
+ *    (vf_hwupload_cuda.c:123-150, hwcontext_cuda.c:221-279 do this with pageable memory on one stream and a wait per
+ *    frame).  `depth` ring slots of PINNED host frames; three streams (upload, compute, download) chained per slot by
+ *    events.  The caller fills gmat_pipeline_host_input(seq) — the slot the NEXT submit will use, seq = number of
+ *    submits so far — calls gmat_pipeline_submit(), and reads gmat_pipeline_host_output(seq) after
+ *    gmat_pipeline_wait(seq).  submit blocks only while the slot's frame of `depth` submits ago is still downloading.
+ *    One pipeline = one device = one host thread; N GPUs run N pipelines (independent streams, no exchange).
+ * ===================================================================================== */
+typedef struct GmatPipeline GmatPipeline;
+GMAT_API GmatPipeline *gmat_pipeline_create(int device, int srcW, int srcH, int srcFormat,
+                                            int dstW, int dstH, int dstFormat, int flags, int depth);
+GMAT_API int  gmat_pipeline_host_input(GmatPipeline *p, int64_t seq, GmatFrame *view);    /* a view: do not free */
+GMAT_API int  gmat_pipeline_host_output(GmatPipeline *p, int64_t seq, GmatFrame *view);
+GMAT_API int64_t gmat_pipeline_submit(GmatPipeline *p);       /* sequence number of the frame, or < 0 */
+GMAT_API int  gmat_pipeline_wait(GmatPipeline *p, int64_t seq);
+GMAT_API int  gmat_pipeline_drain(GmatPipeline *p);
+GMAT_API void gmat_pipeline_free(GmatPipeline *p);
 
 #ifdef __cplusplus
 }
