@@ -2,24 +2,34 @@
 """bench.py — headline benchmark of the pixel-transform hot path on MI355X.
 
 Workload (BASELINE.json configs[2], the config `metric` is quoted on): synthetic 3840x2160 NV12
-frames, device resident -> RGB24 -> 1920x1080 bicubic RGB24, through gmat_sws_scale().
-A "step" is one pass over one batch of FRAMES distinct frame pairs (the batch rotates over a working
-set larger than the 256 MiB Infinity Cache so HBM, not cache, is measured).
+frames, device resident -> RGB24 -> 1920x1080 bicubic RGB24, through the C ABI (gmat_sws_scale_batch).
+A "step" is one pass over one batch of FRAMES distinct frame pairs (0.6 GB working set, larger than
+the 256 MiB Infinity Cache, so HBM is measured, not cache).
 
-One JSON line on rank 0.  `value` = source gigapixels per second over all ranks (weak scaling: every
-GPU converts its own independent streams, no collective in the data path).
-  roofline     : the dominant kernel of the headline implementation; achieved = algorithmic bytes per
-                 launch / average launch duration from HIP events on the launch stream.
-  chained      : the two-kernel form with the HBM RGB24 intermediate (the reference's structure),
-                 measured in the same run, with its own per-kernel rooflines.
-  cpu_baseline : the C oracle (a port of libswscale's arithmetic, oracle/) on the host cores, rank 0,
-                 on a bounded sample.  The oracle is used here only as the measured CPU baseline.
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torchrun environment re-launches itself as N ranks (one per GPU) under
+torch.distributed.run on 127.0.0.1; under torchrun it uses RANK / LOCAL_RANK / WORLD_SIZE as given.  Every
+rank converts its own independent streams on its own GPU (hipSetDevice(LOCAL_RANK); the reference selects the
+device per stream the same way, libavutil/hwcontext_cuda.c:395-434); RCCL carries only the start / stop barrier
+and the MAX of the wall time.  `--dry` runs the same code on the CPU-emulated build of the library with gloo and
+a tiny geometry (plumbing check in a GPU-less container; its numbers mean nothing and say so).
+
+One JSON line on rank 0.  `value` = source gigapixels per second over all ranks (weak scaling).
+  roofline      : the dominant kernel; achieved = algorithmic bytes per launch / average launch duration from
+                  HIP events on the launch stream; traffic from the committed PMC pass of this round.
+  chained       : the convert-then-scale forms (the metric's literal arrows), measured in the same run.
+  host_pipeline : pinned host frames in and out (gmat_pipeline_*), every rank at once; PCIe-bound.
+  cpu_baseline  : libswscale arithmetic on the host cores, rank 0, bounded sample: stock libswscale.so when the
+                  box has one ("reference"), else the C oracle ("port").  cpu_configs0 = BASELINE configs[0].
 """
 import argparse
 import ctypes as C
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,30 +37,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-SRC_W, SRC_H, DST_W, DST_H = 3840, 2160, 1920, 1080
-PX = SRC_W * SRC_H
-BYTES_NV12 = PX * 3 // 2
-BYTES_RGB_SRC = PX * 3
-BYTES_RGB_DST = DST_W * DST_H * 3
-ALG_FUSED = BYTES_NV12 + BYTES_RGB_DST                      # 18,662,400 B  
-ALG_CONVERT = BYTES_NV12 + BYTES_RGB_SRC                    # 37,324,800 B
-ALG_SCALE = BYTES_RGB_SRC + BYTES_RGB_DST                   # 31,104,000 B
 PRE_WARM_MS = 40            # untimed clock-ramp load in front of the W warm-up steps
-HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def measured_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch from the committed PMC collection (profiles/r01k_traffic.json, produced on the GPU box by
-    tools/pmc_traffic_batched.sh over 32-frame launches with the corrections of MI355X_MICROARCH.md), scaled to the
-    number of frames a launch of this run carries; None when not collected."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01k_traffic.json")))
-        for k, v in d["kernels"].items():
-            if kernel in k:
-                return int(v["traffic_bytes_per_frame"] * frames_per_launch)
-    except Exception:
-        pass
-    return None
+class Geo:
+    """the workload's geometry and its algorithmic byte counts"""
+
+    def __init__(self, sw, sh, dw, dh):
+        self.sw, self.sh, self.dw, self.dh = sw, sh, dw, dh
+        self.px = sw * sh
+        self.nv12 = self.px * 3 // 2
+        self.rgb_src = self.px * 3
+        self.rgb_dst = dw * dh * 3
+        self.alg_fused = self.nv12 + self.rgb_dst          # 18,662,400 B at 4K -> 1080p
+        self.alg_convert = self.nv12 + self.rgb_src        # 37,324,800 B
+        self.alg_scale = self.rgb_src + self.rgb_dst       # 31,104,000 B
 
 
 def parse():
@@ -63,41 +66,84 @@ def parse():
                     help="replay a captured hipGraph per step instead of submitting the batch eagerly from C")
     ap.add_argument("--branches", type=int, default=2,
                     help="concurrent HIP streams (or graph branches) the independent frames of a step are spread over")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-chained", action="store_true", help="skip the two-kernel comparison")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-chained", action="store_true", help="skip the convert-then-scale comparison and other_configs")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pinned-host upload/compute/download leg")
     ap.add_argument("--cpu-frames", type=int, default=128)
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU plumbing check: emulated library, gloo, tiny frames; numbers are not measurements")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: become N ranks under torch.distributed.run"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class DevMem:
+    """device frames through the C ABI (gmat_malloc); torch is not in the data path"""
+
+    def __init__(self, lib):
+        self.lib, self.blocks = lib, []
+
+    def alloc(self, nbytes, fill=None):
+        p = C.c_void_p()
+        if self.lib.gmat_malloc(C.byref(p), nbytes) != 0 or not p.value:
+            raise RuntimeError(f"gmat_malloc({nbytes}) failed")
+        self.blocks.append(p.value)
+        if fill is not None:
+            if self.lib.gmat_memcpy_h2d(p.value, fill.ctypes.data, nbytes) != 0:
+                raise RuntimeError("gmat_memcpy_h2d failed")
+        return p.value
+
+    def free(self):
+        for b in self.blocks:
+            self.lib.gmat_free(b)
+        self.blocks = []
+
+
+def random_bytes(n, seed):
+    import numpy as np
+    return np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
 
 
 class Runner:
     """One implementation of the workload: a context, its frame set and (optionally) a graph."""
 
-    def __init__(self, lib, torch, stream, frames, fused, use_graph, seed, branches=1):
-        from gmat_amd.lib import PIX_FMT, SWS, planes, ints
-        self.lib, self.stream, self.frames = lib, stream, frames
-        self.ctx = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["nv12"], DST_W, DST_H, PIX_FMT["rgb24"],
+    def __init__(self, lib, geo, stream, frames, fused, use_graph, seed, branches=1):
+        from gmat_amd.lib import PIX_FMT, SWS, ints
+        self.lib, self.stream, self.frames, self.geo = lib, stream, frames, geo
+        self.ctx = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.dw, geo.dh, PIX_FMT["rgb24"],
                                            SWS["bicubic"] | SWS["hwaccel"], None)
         if not self.ctx:
             raise RuntimeError("gmat_sws_getContext failed")
         if lib.gmat_sws_setFused(self.ctx, int(fused)) != 0:
             raise RuntimeError('gmat_sws_setFused failed')
         lib.gmat_sws_setStream(self.ctx, stream)
-        src_ls = (SRC_W + 255) // 256 * 256                 # AVHWFramesContext row alignment
-        dst_ls = (DST_W * 3 + 255) // 256 * 256
-        g = torch.Generator(device="cuda")
-        g.manual_seed(seed)
-        self.src = [torch.randint(0, 256, (SRC_H * 3 // 2, src_ls), dtype=torch.uint8, device="cuda", generator=g)
-                    for _ in range(frames)]
-        self.dst = [torch.empty((DST_H, dst_ls), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        src_ls = (geo.sw + 255) // 256 * 256                 # AVHWFramesContext row alignment
+        dst_ls = (geo.dw * 3 + 255) // 256 * 256
+        self.mem = DevMem(lib)
+        nsrc = src_ls * (geo.sh * 3 // 2)
+        self.src = [self.mem.alloc(nsrc, random_bytes(nsrc, seed * 1000 + i)) for i in range(frames)]
+        self.dst = [self.mem.alloc(dst_ls * geo.dh) for _ in range(frames)]
         self.src_ls, self.dst_ls = src_ls, dst_ls
         n = frames
         self.sp = (C.c_void_p * (4 * n))()
         self.dp = (C.c_void_p * (4 * n))()
         for i in range(n):
-            base = self.src[i].data_ptr()
-            self.sp[4 * i], self.sp[4 * i + 1] = base, base + src_ls * SRC_H      # UV directly after Y
-            self.dp[4 * i] = self.dst[i].data_ptr()
+            self.sp[4 * i], self.sp[4 * i + 1] = self.src[i], self.src[i] + src_ls * geo.sh      # UV directly after Y
+            self.dp[4 * i] = self.dst[i]
         self.ss, self.ds = ints([src_ls, src_ls]), ints([dst_ls])
         self.graph = None
         self.branches = branches
@@ -114,7 +160,6 @@ class Runner:
             if r != 0:
                 raise RuntimeError(f"gmat_sws_graph_create failed: {r}")
             self.graph = ge
-        self._planes = planes
 
     def step(self, flags=0):
         lib = self.lib
@@ -123,7 +168,7 @@ class Runner:
             if r != 0:
                 raise RuntimeError(f"graph launch failed: {r}")
             return
-        # one C call enqueues the whole batch, frame f on stream f % branches (fork/join on streams[0])
+        # one C call enqueues the whole batch: each stream gets its share of the frames as ONE launch (grid.y = frame)
         r = lib.gmat_sws_scale_batch(self.ctx, self.frames, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
                                      C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds,
                                      C.cast(self.streams, C.POINTER(C.c_void_p)), self.branches, flags)
@@ -143,29 +188,44 @@ class Runner:
         for b in range(1, self.branches):
             self.lib.gmat_stream_destroy(self.streams[b])
         self.lib.gmat_sws_freeContext(self.ctx)
+        self.mem.free()
 
 
-def timed(lib, torch, dist, runner, stream, steps, warmup, world):
+class Env:
+    """what differs between the GPU run and the dry (CPU-emulated) run"""
+
+    def __init__(self, dry, local):
+        self.dry = dry
+        if dry:
+            self.sync = None
+        else:
+            import torch
+            torch.cuda.set_device(local)
+            self.sync = torch.cuda.synchronize
+
+    def synchronize(self, lib):
+        lib.gmat_device_sync()
+        if self.sync:
+            self.sync()                # the contract's torch.cuda.synchronize(); the work itself is on gmat's streams
+
+
+def timed(lib, env, dist, runner, stream, steps, warmup, world, pre_warm_ms=PRE_WARM_MS):
     """W warm-up steps, then exactly K steps between barrier+synchronize pairs; returns
     (wall seconds MAX over ranks, device milliseconds from HIP events on the launch stream)."""
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
     gc.collect()
     gc.disable()                        # no collector pauses inside the timed region
-    # everything slow on the host happens BEFORE the warm-up: a GPU left idle for the tens of milliseconds a
-    # collection takes drops its clocks, and the first ~1 ms of the timed steps then runs at the low clock
-    # (measured: 8.1 us/frame over 30 steps against 6.7 with the collection moved here)
     # clock ramp: after the idle set-up phase the GPU needs several milliseconds of sustained load to reach its
-    # working clocks (measured: 8.4 us/frame over 30 steps after 5 warm-up steps, 6.7 once ramped).  Untimed, and in
-    # addition to the W warm-up steps; reported as config.pre_warm_ms.
+    # working clocks.  Untimed, and in addition to the W warm-up steps; reported as config.pre_warm_ms.
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < PRE_WARM_MS * 1e-3:
+    while time.perf_counter() - t_ramp < pre_warm_ms * 1e-3:
         runner.step()
         lib.gmat_stream_sync(stream)
     for _ in range(warmup):
         runner.step()
     dist.barrier(world) if dist else None
-    torch.cuda.synchronize()
+    env.synchronize(lib)
     t0 = time.perf_counter()
     lib.gmat_timer_begin(timer, stream)
     for i in range(steps):
@@ -173,7 +233,7 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
         runner.step((1 if i == 0 else 0) | (2 if i == steps - 1 else 0))
     lib.gmat_timer_end(timer, stream)
     lib.gmat_stream_sync(stream)
-    torch.cuda.synchronize()
+    env.synchronize(lib)
     dist.barrier(world) if dist else None
     wall = time.perf_counter() - t0
     gc.enable()
@@ -181,18 +241,18 @@ def timed(lib, torch, dist, runner, stream, steps, warmup, world):
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
     if dist and world > 1:
-        wall = dist.max_over_ranks(wall, world, device="cuda")
+        wall = dist.max_over_ranks(wall, world, device="cpu" if env.dry else "cuda")
     return wall, float(ms.value)
 
 
-def time_single_kernel(lib, torch, runner_fn, stream, reps):
+def time_single_kernel(lib, env, runner_fn, stream, reps):
     """average duration (ms) of one repeated launch function, HIP events on the launch stream"""
     timer = C.c_void_p()
     lib.gmat_timer_create(C.byref(timer))
-    torch.cuda.synchronize()            # input tensors are filled on torch's stream, the launches go to `stream`
+    env.synchronize(lib)
     gc.collect()
-    gc.disable()                        # a generation-2 collection inside the loop stalls the host for milliseconds
-    for _ in range(8):                  # (and one between warm-up and timing lets the idle GPU drop its clocks)
+    gc.disable()
+    for _ in range(8):
         runner_fn()
     lib.gmat_stream_sync(stream)
     lib.gmat_timer_begin(timer, stream)
@@ -206,45 +266,61 @@ def time_single_kernel(lib, torch, runner_fn, stream, reps):
     return float(ms.value) / reps
 
 
-def other_configs(lib, torch, stream, frames=16):
-    """BASELINE configs[1] and configs[3], plus the 4:2:0 -> 4:2:0 down-scale of a transcode, each timed back to
-    back on one stream (HIP events) over a rotating frame set.  Secondary numbers; never the headline `value`."""
+def measured_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch from this round's PMC collection (profiles/r02_traffic.json: rocprofv3 FETCH_SIZE and
+    WRITE_SIZE in separate passes over 32-frame launches of the same kernel, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), scaled to the frames a launch of this run carries; None when the
+    kernel has no entry."""
+    try:
+        d = json.load(open(TRAFFIC_FILE))
+        for k, v in d["kernels"].items():
+            if k in kernel or kernel in k:
+                return int(v["traffic_bytes_per_frame"] * frames_per_launch)
+    except Exception:
+        pass
+    return None
+
+
+def other_configs(lib, env, stream, geo, frames=16):
+    """BASELINE configs[1] and configs[3], plus the 4:2:0 -> 4:2:0 down-scale of a transcode: one frame per call
+    (what sws_scale / filter_frame do) and 32 frames per launch.  Secondary numbers; never the headline `value`."""
     from gmat_amd.lib import PIX_FMT, planes, ints
     res = {}
+    mem = DevMem(lib)
+
+    def frame_set(n, nbytes, seed):
+        return [mem.alloc(nbytes, random_bytes(nbytes, seed + i) if i < 4 else None) for i in range(n)]
 
     def sws_case(name, sf, sw, sh, df, dw, dh, alg_bytes):
-        src = [torch.randint(0, 256, (sw * sh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        src = frame_set(frames, sw * sh * 3 // 2, 11)
         dbytes = dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2
-        dst = [torch.empty((dbytes,), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+        dst = frame_set(frames, dbytes, 0)
         c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], 4, None)
         lib.gmat_sws_setStream(c, stream)
         st = {"i": 0}
 
         def run():
             i = st["i"] = (st["i"] + 1) % frames
-            s0, d0 = src[i].data_ptr(), dst[i].data_ptr()
+            s0, d0 = src[i], dst[i]
             dp = [d0] if df == "rgb24" else [d0, d0 + dw * dh]
             dl = [dw * 3] if df == "rgb24" else [dw, dw]
             lib.gmat_sws_scale(c, planes([s0, s0 + sw * sh]), ints([sw, sw]), 0, sh, planes(dp), ints(dl))
-        ms = time_single_kernel(lib, torch, run, stream, 4 * frames)
+        ms = time_single_kernel(lib, env, run, stream, 4 * frames)
         res[name] = {"kernel": lib.gmat_sws_lastKernel(c).decode(), "avg_launch_us": round(ms * 1e3, 2),
                      "Gpix/s": round(sw * sh / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg_bytes,
                      "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
                      "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         lib.gmat_sws_freeContext(c)
 
-    sws_case("configs[1]: 1080p nv12 -> rgb24", "nv12", 1920, 1080, "rgb24", 1920, 1080, 1920 * 1080 * 9 // 2)
-
     def batch_case(name, sf, sw, sh, df, dw, dh, alg_bytes, n=32):
-        """the same conversion through gmat_sws_scale_batch: n frames of one geometry per launch (one grid dimension = frame)"""
-        src = [torch.randint(0, 256, (sw * sh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(n)]
-        dst = [torch.empty((dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2,), dtype=torch.uint8, device="cuda") for _ in range(n)]
+        src = frame_set(n, sw * sh * 3 // 2, 21)
+        dst = frame_set(n, dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2, 0)
         c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], 4, None)
         sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
         for i in range(n):
-            sp[4 * i], sp[4 * i + 1], dp[4 * i] = src[i].data_ptr(), src[i].data_ptr() + sw * sh, dst[i].data_ptr()
+            sp[4 * i], sp[4 * i + 1], dp[4 * i] = src[i], src[i] + sw * sh, dst[i]
             if df != "rgb24":
-                dp[4 * i + 1] = dst[i].data_ptr() + dw * dh
+                dp[4 * i + 1] = dst[i] + dw * dh
         streams = (C.c_void_p * 1)(stream)
         dstr = ints([dw * 3]) if df == "rgb24" else ints([dw, dw])
 
@@ -252,7 +328,7 @@ def other_configs(lib, torch, stream, frames=16):
             r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([sw, sw]), C.cast(dp, C.POINTER(C.c_void_p)),
                                          dstr, C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
             assert r == n
-        ms = time_single_kernel(lib, torch, run, stream, 64)
+        ms = time_single_kernel(lib, env, run, stream, 64)
         fpl = int(lib.gmat_sws_lastLaunchFrames(c))
         res[name] = {"kernel": lib.gmat_sws_lastKernel(c).decode(), "frames_per_launch": fpl, "avg_launch_us": round(ms * 1e3, 2),
                      "us_per_frame": round(ms * 1e3 / n, 3), "Gpix/s": round(n * sw * sh / (ms * 1e-3) / 1e9, 1),
@@ -261,81 +337,86 @@ def other_configs(lib, torch, stream, frames=16):
                      "frac": round(alg_bytes * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         lib.gmat_sws_freeContext(c)
 
-    batch_case("configs[1], 32 frames per launch", "nv12", 1920, 1080, "rgb24", 1920, 1080, 1920 * 1080 * 9 // 2)
-    sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", SRC_W, SRC_H, "nv12", DST_W, DST_H,
-             SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2)
-    batch_case("transcode, 32 frames per launch", "nv12", SRC_W, SRC_H, "nv12", DST_W, DST_H,
-               SRC_W * SRC_H * 3 // 2 + DST_W * DST_H * 3 // 2)
+    hw, hh = geo.sw // 2, geo.sh // 2                 # 1920 x 1080 in the real run
+    sws_case("configs[1]: 1080p nv12 -> rgb24", "nv12", hw, hh, "rgb24", hw, hh, hw * hh * 9 // 2)
+    batch_case("configs[1], 32 frames per launch", "nv12", hw, hh, "rgb24", hw, hh, hw * hh * 9 // 2)
+    sws_case("configs[2], one frame per call (sws_scale)", "nv12", geo.sw, geo.sh, "rgb24", geo.dw, geo.dh, geo.alg_fused)
+    tb = geo.nv12 + geo.dw * geo.dh * 3 // 2
+    sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
+    batch_case("transcode, 32 frames per launch", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
     # configs[3]: rotate(90) + hflip + 3x3 smooth as ONE kernel on 4K rgb24
-    w, h = SRC_W, SRC_H
-    src = [torch.randint(0, 256, (h, w * 3), dtype=torch.uint8, device="cuda") for _ in range(frames)]
-    dst = [torch.empty((w, h * 3), dtype=torch.uint8, device="cuda") for _ in range(frames)]
+    w, h = geo.sw, geo.sh
+    src = frame_set(frames, w * h * 3, 31)
+    dst = frame_set(frames, w * h * 3, 0)
     st = {"i": 0}
 
     def run4():
         i = st["i"] = (st["i"] + 1) % frames
-        lib.gmat_rotate_flip_smooth(src[i].data_ptr(), w * 3, dst[i].data_ptr(), h * 3, w, h, 3, stream)
-    ms = time_single_kernel(lib, torch, run4, stream, 4 * frames)
+        lib.gmat_rotate_flip_smooth(src[i], w * 3, dst[i], h * 3, w, h, 3, stream)
+    ms = time_single_kernel(lib, env, run4, stream, 4 * frames)
     alg = 2 * w * h * 3
     res["configs[3]: 4K rgb24 rotate(90)+flip+3x3 smooth, fused"] = {
         "kernel": "conv3x3_kernel<3,64,64,transposed>", "avg_launch_us": round(ms * 1e3, 2),
         "Gpix/s": round(w * h / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg,
         "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    lib.gmat_device_sync()
+    mem.free()
     return res
 
 
-def host_pipeline(lib, nframes=96, depth=4):
+def host_pipeline(lib, geo, dist, world, device, dry, nframes=96, depth=4):
     """PCIe-inclusive rate: pinned host NV12 in -> HBM -> scale -> HBM -> pinned host RGB24 out, copies on their own
-    streams overlapping the kernels (gmat_amd/pipeline.py).  Never the headline `value`."""
-    from gmat_amd.pipeline import FramePipeline
-    p = FramePipeline(lib, SRC_W, SRC_H, "nv12", DST_W, DST_H, "rgb24", depth=depth)
+    streams overlapping the kernels (gmat_pipeline_*, one pipeline per rank, all ranks at once).  Never `value`."""
     import numpy as np
+    from gmat_amd.pipeline import FramePipeline
+    p = FramePipeline(lib, geo.sw, geo.sh, "nv12", geo.dw, geo.dh, "rgb24", depth=depth, device=device)
     for k in range(depth):                                   # synthetic content in every ring slot
         f = p.host_input(k)
-        for pl, rows in ((0, SRC_H), (1, SRC_H // 2)):
+        for pl, rows in ((0, geo.sh), (1, geo.sh // 2)):
             v = np.ctypeslib.as_array(C.cast(f.data[pl], C.POINTER(C.c_uint8)), (rows, f.linesize[pl]))
             v[...] = np.random.default_rng(k * 2 + pl).integers(0, 256, v.shape, dtype=np.uint8)
     for _ in range(2 * depth):
         p.submit()
     p.drain()
+    dist.barrier(world)
     t0 = time.perf_counter()
     for _ in range(nframes):
         p.submit()
     p.drain()
     dt = time.perf_counter() - t0
+    dt = dist.max_over_ranks(dt, world, device="cpu" if dry else "cuda")
     p.close()
-    return {"value": round(nframes * PX / dt / 1e9, 3), "unit": "Gpix/s", "frames": nframes, "ring_depth": depth,
-            "pcie_GBps_in": round(nframes * BYTES_NV12 / dt / 1e9, 2), "pcie_GBps_out": round(nframes * BYTES_RGB_DST / dt / 1e9, 2),
-            "note": "pinned host frames, upload / compute / download on three streams chained by events; bounded by "
-                    "PCIe Gen5 x16 (63 GB/s spec), not by the kernels"}
+    return {"value": round(world * nframes * geo.px / dt / 1e9, 3), "unit": "Gpix/s", "frames_per_rank": nframes, "ranks": world,
+            "ring_depth": depth, "pcie_GBps_in_per_gpu": round(nframes * geo.nv12 / dt / 1e9, 2),
+            "pcie_GBps_out_per_gpu": round(nframes * geo.rgb_dst / dt / 1e9, 2),
+            "note": "pinned host frames, upload / compute / download on three streams chained by events (C ABI "
+                    "gmat_pipeline_*), one pipeline per GPU; bounded by PCIe Gen5 x16 (63 GB/s spec), not by the kernels"}
 
 
-def cpu_baseline(nframes):
-    """The oracle on the host cores: ONE nv12 2160p -> rgb24 1080p bicubic context (the headline's
-    semantics), output rows sliced over all cores."""
+def cpu_port(geo, nframes):
+    """The C oracle (a port of libswscale's arithmetic) on the host cores: ONE nv12 -> rgb24 bicubic context (the
+    headline's semantics), output rows sliced over the cores."""
     import numpy as np
     import harness
     from concurrent.futures import ThreadPoolExecutor
     from gmat_amd.lib import PIX_FMT, SWS, planes, ints
     path = os.path.join(ROOT, "oracle", "liborc.so")
     if not os.path.exists(path):
-        return None
+        return None, None
     orc = harness.load_oracle(path)
     L = orc.L
-    cores = os.cpu_count() or 1
-    y = orc.lcg((SRC_H, SRC_W), 7)
-    uv = orc.lcg((SRC_H // 2, SRC_W), 8)
-    out = np.empty((DST_H, DST_W * 3), np.uint8)
-    ctx = L.orc_sws_create(SRC_W, SRC_H, PIX_FMT["nv12"], DST_W, DST_H, PIX_FMT["rgb24"], SWS["bicubic"], None)
-    cores = min(cores, 64)
-    band_dst = (DST_H + cores - 1) // cores
+    cores = min(os.cpu_count() or 1, 64)
+    y = orc.lcg((geo.sh, geo.sw), 7)
+    uv = orc.lcg((geo.sh // 2, geo.sw), 8)
+    out = np.empty((geo.dh, geo.dw * 3), np.uint8)
+    ctx = L.orc_sws_create(geo.sw, geo.sh, PIX_FMT["nv12"], geo.dw, geo.dh, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    band = (geo.dh + cores - 1) // cores
 
     def scale(i):
-        y0 = i * band_dst
-        y1 = min(DST_H, y0 + band_dst)
+        y0, y1 = i * band, min(geo.dh, (i + 1) * band)
         if y0 < y1:
-            L.orc_sws_scale_rows(ctx, planes([y.ctypes.data, uv.ctypes.data]), ints([SRC_W, SRC_W]),
-                                 planes([out.ctypes.data]), ints([DST_W * 3]), y0, y1)
+            L.orc_sws_scale_rows(ctx, planes([y.ctypes.data, uv.ctypes.data]), ints([geo.sw, geo.sw]),
+                                 planes([out.ctypes.data]), ints([geo.dw * 3]), y0, y1)
 
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(scale, range(cores)))                                            # warm
@@ -344,128 +425,223 @@ def cpu_baseline(nframes):
             list(ex.map(scale, range(cores)))
         dt = time.perf_counter() - t0
     L.orc_sws_free(ctx)
-    return {"value": round(nframes * PX / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
-            "sample": f"{nframes} frames 3840x2160 nv12 -> 1920x1080 rgb24 bicubic (one context), C oracle "
+    head = {"value": round(nframes * geo.px / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
+            "sample": f"{nframes} frames {geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (one context), C oracle "
                       f"(oracle/, a port of libswscale's arithmetic), {cores} threads row-sliced, {dt:.2f} s"}
+    # BASELINE configs[0]: 1080p yuv420p -> rgb24 on ONE host thread, libswscale's unscaled fast path (yuv2rgb.c:346-374)
+    w, h = geo.sw // 2, geo.sh // 2
+    src = [orc.lcg((h, w), 1), orc.lcg((h // 2, w // 2), 2), orc.lcg((h // 2, w // 2), 3)]
+    orc.yuv2rgb(src, w, h, "yuv420p", "rgb24")
+    n0 = max(4, nframes // 8)
+    t0 = time.perf_counter()
+    for _ in range(n0):
+        orc.yuv2rgb(src, w, h, "yuv420p", "rgb24")
+    d0 = time.perf_counter() - t0
+    cfg0 = {"value": round(n0 * w * h / d0 / 1e9, 4), "unit": "Gpix/s", "cores": 1, "kind": "port",
+            "sample": f"BASELINE configs[0]: {n0} frames {w}x{h} yuv420p -> rgb24, one stream, one thread, the oracle's "
+                      f"restatement of yuv2rgb_c_24_rgb (libswscale/yuv2rgb.c:346-374), {d0:.2f} s"}
+    return head, cfg0
+
+
+def cpu_reference(geo, nframes):
+    """Stock libswscale, when the box has one (dlopen("libswscale.so.*")): one context per thread on
+    independent frames.  None when no library loads — this image ships none, so the port above is the baseline."""
+    import ctypes.util
+    import glob
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    cands = [ctypes.util.find_library("swscale")] + sorted(glob.glob("/usr/lib/x86_64-linux-gnu/libswscale.so.*")) + \
+        sorted(glob.glob("/usr/local/lib/libswscale.so.*")) + sorted(glob.glob("/usr/lib64/libswscale.so.*"))
+    lib = None
+    for c in cands:
+        if not c:
+            continue
+        try:
+            lib = C.CDLL(c)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        return None
+    lib.sws_getContext.restype = C.c_void_p
+    lib.sws_getContext.argtypes = [C.c_int] * 7 + [C.c_void_p] * 3
+    lib.sws_scale.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                              C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.sws_freeContext.argtypes = [C.c_void_p]
+    from gmat_amd.lib import PIX_FMT, planes, ints
+    cores = min(os.cpu_count() or 1, 64)
+    per = max(1, nframes // cores)
+
+    def work(i):
+        rng = np.random.default_rng(i)
+        y = rng.integers(0, 256, (geo.sh, geo.sw), dtype=np.uint8)
+        uv = rng.integers(0, 256, (geo.sh // 2, geo.sw), dtype=np.uint8)
+        out = np.empty((geo.dh, geo.dw * 3), np.uint8)
+        ctx = lib.sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.dw, geo.dh, PIX_FMT["rgb24"], 4, None, None, None)
+        if not ctx:
+            return 0
+        for _ in range(per):
+            lib.sws_scale(ctx, planes([y.ctypes.data, uv.ctypes.data]), ints([geo.sw, geo.sw]), 0, geo.sh,
+                          planes([out.ctypes.data]), ints([geo.dw * 3]))
+        lib.sws_freeContext(ctx)
+        return per
+
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        done = sum(ex.map(work, range(cores)))
+        dt = time.perf_counter() - t0
+    if not done:
+        return None
+    return {"value": round(done * geo.px / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "reference",
+            "sample": f"{done} frames {geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 SWS_BICUBIC through the box's stock "
+                      f"libswscale (sws_scale), one context per thread on {cores} threads, {dt:.2f} s (context set-up included)"}
 
 
 def main():
     a = parse()
-    import torch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_as_ranks(a.gpus))
     import gmat_amd
     from gmat_amd import dist as gdist
     rank, local, world = gdist.env_rank()
-    lib = gmat_amd.load()                                   # raises if the HIP library is missing
-    if lib.gmat_device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible")
-    torch.cuda.set_device(local)
-    lib.gmat_set_device(local)
-    gdist.init("nccl")                                      # RCCL; control plane only (barrier + MAX of time)
+    if a.dry:
+        from gmat_amd.lib import load
+        emu = os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so")
+        if not os.path.exists(emu):
+            subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(emu))], check=True, capture_output=True)
+        lib = load(emu)                                         # test infrastructure: kernel sources on CPU fibers
+        geo = Geo(128, 32, 64, 16)
+        a.frames, a.steps, a.warmup = min(a.frames, 4), min(a.steps, 2), min(a.warmup, 1)
+        a.no_chained = True
+    else:
+        lib = gmat_amd.load()                                   # raises if the HIP library is missing
+        if lib.gmat_device_count() < 1:
+            raise SystemExit("bench.py: no HIP device visible (use --dry for the CPU plumbing check)")
+        geo = Geo(3840, 2160, 1920, 1080)
+    env = Env(a.dry, local)
+    lib.gmat_set_device(0 if a.dry else local)
+    gdist.init("gloo" if a.dry else "nccl")                     # RCCL; control plane only (barrier + MAX of time)
     dist = gdist
     stream = C.c_void_p()
     lib.gmat_stream_create(C.byref(stream))
+    pre_warm = 0 if a.dry else PRE_WARM_MS
 
-    use_graph = a.graph
+    use_graph = a.graph and not a.dry
     branches = a.branches
-    # ---- headline: one libswscale-semantics context (mode 2), frames overlapped across graph branches
-    head = Runner(lib, torch, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=branches)
-    wall, dev_ms = timed(lib, torch, dist, head, stream, a.steps, a.warmup, world)
+    # ---- headline: one libswscale-semantics context (mode 2), the step's frames spread over `branches` streams
+    head = Runner(lib, geo, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=branches)
+    wall, dev_ms = timed(lib, env, dist, head, stream, a.steps, a.warmup, world, pre_warm)
     launches = a.steps * a.frames
-    gpix = world * launches * PX / wall / 1e9
+    gpix = world * launches * geo.px / wall / 1e9
     kname = head.kernel()
     head.close()
-    # ---- roofline of the dominant kernel: the same context, launches strictly back to back (1 branch)
-    ser = Runner(lib, torch, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=1)
-    _, ser_ms = timed(lib, torch, None, ser, stream, a.steps, a.warmup, 1)
-    fpl = ser.frames_per_launch()         # frames one launch carries (grid.y): a stream's share of the step, <= 32
+    # ---- roofline of the dominant kernel: the same context, launches strictly back to back on ONE stream
+    ser = Runner(lib, geo, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=1)
+    _, ser_ms = timed(lib, env, None, ser, stream, a.steps, a.warmup, 1, pre_warm)
+    fpl = ser.frames_per_launch()         # frames one launch carries (grid.y): the whole step, <= 32
     ser.close()
-    ach = ALG_FUSED * launches / (ser_ms * 1e-3) / 1e9
-    ach_ovl = ALG_FUSED * launches / (dev_ms * 1e-3) / 1e9
+    ser_ms = max(ser_ms, 1e-6); dev_ms = max(dev_ms, 1e-6)
+    ach = geo.alg_fused * launches / (ser_ms * 1e-3) / 1e9
+    ach_ovl = geo.alg_fused * launches / (dev_ms * 1e-3) / 1e9
     out = {
         "metric": "Gpix/s (and % HBM roofline) for 4K nv12->rgb24->1080p bicubic at 1/2/4/8 GPUs",
         "value": round(gpix, 3), "unit": "Gpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "3840x2160 nv12 -> 1920x1080 rgb24 bicubic (BASELINE configs[2]), device-resident "
+        "config": {"workload": f"{geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (BASELINE configs[2]), device-resident "
                                "frames; output bit-identical to ONE libswscale context (sws_getContext nv12 2160p -> "
                                "rgb24 1080p, SWS_BICUBIC); the convert-then-scale ('chained') forms are in `chained`",
-                   "frames_per_step": a.frames, "pre_warm_ms": PRE_WARM_MS, "implementation": "single fused kernel " + kname,
+                   "frames_per_step": a.frames, "pre_warm_ms": pre_warm, "implementation": "single fused kernel " + kname,
                    "launch": (f"hipGraph replay, {branches} parallel branches" if use_graph else
                               f"eager, one C call per step, one launch per stream ({branches} streams), each carrying its share of the frames"),
-                   "parallelism": f"{world} GPU(s) x independent streams, no collective"},
+                   "parallelism": f"{world} GPU(s) x independent streams, one process per GPU, no collective in the data path"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname, fpl),
-                     "traffic_source": "profiles/r01k_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)",
-                     "frames_per_launch": fpl, "algorithmic_bytes_per_launch": ALG_FUSED * fpl,
+                     "traffic_source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)",
+                     "frames_per_launch": fpl, "algorithmic_bytes_per_launch": geo.alg_fused * fpl,
                      "avg_launch_us": round(ser_ms * 1e3 / launches * fpl, 3),
                      "note": "launches back to back on ONE stream (HIP events), each carrying frames_per_launch frames "
                              "(grid.y = frame); the headline `value` spreads the step over config.launch's streams: "
                              "achieved_overlapped",
                      "achieved_overlapped": round(ach_ovl, 1), "frac_overlapped": round(ach_ovl / HBM_PEAK_GBS, 4)},
     }
+    if a.dry:
+        out["dry_run"] = True
+        out["data"] = "synthetic (DRY RUN on the CPU-emulated library: plumbing only, not a measurement)"
 
     if rank == 0 and not a.no_chained:
         # convert-then-scale semantics (the reference GPU back-end's order of operations), two forms
-        fz = Runner(lib, torch, stream, a.frames, 1, use_graph, seed=2000, branches=branches)
-        fwall, fms = timed(lib, torch, None, fz, stream, max(3, a.steps // 3), 2, 1)
-        fn = max(3, a.steps // 3) * a.frames
+        k3 = max(3, a.steps // 3)
+        fz = Runner(lib, geo, stream, a.frames, 1, use_graph, seed=2000, branches=branches)
+        fwall, fms = timed(lib, env, None, fz, stream, k3, 2, 1, pre_warm)
+        fn = k3 * a.frames
         fused_kernel = fz.kernel()
         fz.close()
-        ch = Runner(lib, torch, stream, a.frames, 0, use_graph, seed=2000, branches=1)
-        cwall, cms = timed(lib, torch, None, ch, stream, max(3, a.steps // 3), 2, 1)
-        n = max(3, a.steps // 3) * a.frames
-        ach_c = (ALG_CONVERT + ALG_SCALE) * n / (cms * 1e-3) / 1e9
+        ch = Runner(lib, geo, stream, a.frames, 0, use_graph, seed=2000, branches=1)
+        cwall, cms = timed(lib, env, None, ch, stream, k3, 2, 1, pre_warm)
+        n = k3 * a.frames
+        ach_c = (geo.alg_convert + geo.alg_scale) * n / (cms * 1e-3) / 1e9
         # per-kernel timing: each kernel alone over the rotating frame set
         from gmat_amd.lib import PIX_FMT, planes, ints
-        rgb = [torch.empty((SRC_H, ch.src_ls * 3), dtype=torch.uint8, device="cuda") for _ in range(a.frames)]
-        cc = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["nv12"], SRC_W, SRC_H, PIX_FMT["rgb24"], 0, None)
-        sc = lib.gmat_sws_getContext(SRC_W, SRC_H, PIX_FMT["rgb24"], DST_W, DST_H, PIX_FMT["rgb24"], 4, None)
+        mem = DevMem(lib)
+        rgb = [mem.alloc(geo.sh * ch.src_ls * 3) for _ in range(a.frames)]
+        cc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.sw, geo.sh, PIX_FMT["rgb24"], 0, None)
+        sc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["rgb24"], geo.dw, geo.dh, PIX_FMT["rgb24"], 4, None)
         lib.gmat_sws_setStream(cc, stream); lib.gmat_sws_setStream(sc, stream)
         state = {"i": 0}
 
         def k_conv():
             i = state["i"] = (state["i"] + 1) % a.frames
-            b = ch.src[i].data_ptr()
-            lib.gmat_sws_scale(cc, planes([b, b + ch.src_ls * SRC_H]), ints([ch.src_ls, ch.src_ls]), 0, SRC_H,
-                               planes([rgb[i].data_ptr()]), ints([ch.src_ls * 3]))
+            b = ch.src[i]
+            lib.gmat_sws_scale(cc, planes([b, b + ch.src_ls * geo.sh]), ints([ch.src_ls, ch.src_ls]), 0, geo.sh,
+                               planes([rgb[i]]), ints([ch.src_ls * 3]))
 
         def k_scale():
             i = state["i"] = (state["i"] + 1) % a.frames
-            lib.gmat_sws_scale(sc, planes([rgb[i].data_ptr()]), ints([ch.src_ls * 3]), 0, SRC_H,
-                               planes([ch.dst[i].data_ptr()]), ints([ch.dst_ls]))
+            lib.gmat_sws_scale(sc, planes([rgb[i]]), ints([ch.src_ls * 3]), 0, geo.sh,
+                               planes([ch.dst[i]]), ints([ch.dst_ls]))
 
-        t_conv = time_single_kernel(lib, torch, k_conv, stream, 4 * a.frames)
-        t_scale = time_single_kernel(lib, torch, k_scale, stream, 4 * a.frames)
+        t_conv = time_single_kernel(lib, env, k_conv, stream, 4 * a.frames)
+        t_scale = time_single_kernel(lib, env, k_scale, stream, 4 * a.frames)
         out["chained"] = {
             "semantics": "sws(NV12->RGB24, POINT) then sws(RGB24->RGB24, BICUBIC), bit-exact",
-            "fused_kernel": {"kernel": fused_kernel, "value": round(fn * PX / fwall / 1e9, 3), "unit": "Gpix/s",
-                             "achieved_GBps": round(ALG_FUSED * fn / (fms * 1e-3) / 1e9, 1),
-                             "algorithmic_bytes_per_frame": ALG_FUSED},
+            "fused_kernel": {"kernel": fused_kernel, "value": round(fn * geo.px / fwall / 1e9, 3), "unit": "Gpix/s",
+                             "achieved_GBps": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9, 1),
+                             "frac": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes_per_frame": geo.alg_fused},
             "two_kernels": {
-                "value": round(n * PX / cwall / 1e9, 3), "unit": "Gpix/s",
+                "value": round(n * geo.px / cwall / 1e9, 3), "unit": "Gpix/s",
                 "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_frame": ALG_CONVERT + ALG_SCALE,
+                "algorithmic_bytes_per_frame": geo.alg_convert + geo.alg_scale,
                 "kernels": {
                     "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
-                                       "achieved_GBps": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9, 1),
-                                       "frac": round(ALG_CONVERT / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                       "achieved_GBps": round(geo.alg_convert / (t_conv * 1e-3) / 1e9, 1),
+                                       "frac": round(geo.alg_convert / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                     lib.gmat_sws_lastKernel(sc).decode(): {
                         "avg_launch_us": round(t_scale * 1e3, 3),
-                        "achieved_GBps": round(ALG_SCALE / (t_scale * 1e-3) / 1e9, 1),
-                        "frac": round(ALG_SCALE / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}}
+                        "achieved_GBps": round(geo.alg_scale / (t_scale * 1e-3) / 1e9, 1),
+                        "frac": round(geo.alg_scale / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}}
         lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
         ch.close()
+        mem.free()
+        out["other_configs"] = other_configs(lib, env, stream, geo)
 
-    if rank == 0 and not a.no_chained:
-        out["other_configs"] = other_configs(lib, torch, stream)
-    if rank == 0 and world == 1 and not a.no_pipeline:
-        out["host_pipeline"] = host_pipeline(lib)
-    if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_frames)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-    gdist.finalize(world)
+    if not a.no_pipeline:
+        hp = host_pipeline(lib, geo, dist, world, 0 if a.dry else local, a.dry, nframes=8 if a.dry else 96)
+        if rank == 0:
+            out["host_pipeline"] = hp
+    gdist.finalize(world)                                   # the other ranks are done; rank 0 goes on to the CPU legs
     if rank == 0:
+        out["cpu_baseline"] = None
+        if not a.no_cpu:
+            port, cfg0 = cpu_port(geo, 4 if a.dry else a.cpu_frames)
+            ref = cpu_reference(geo, 4 if a.dry else a.cpu_frames)
+            out["cpu_baseline"] = ref or port
+            if ref:
+                out["cpu_baseline_port"] = port
+            else:
+                out["cpu_baseline_note"] = "no libswscale.so on this box (dlopen tried: ctypes.util.find_library and the usual lib dirs)"
+            out["cpu_configs0"] = cfg0
         print(json.dumps(out))
 
 

@@ -12,6 +12,7 @@
 // and every device error is returned.
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -99,6 +100,8 @@ struct GmatSwsContext {
     int srcW, srcH, srcFormat, dstW, dstH, dstFormat, flags;
     double param[2];
     hipStream_t stream = nullptr;
+    int device = 0;               // the HIP device current at creation: the context's tables live there (hwcontext_cuda.c:395-434
+                                  // makes the stream's device current around every call; a context is used on ITS device only)
     Mode mode;
     int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
     int chrPos[4] = {-513, -513, -513, -513};   // src_h / src_v / dst_h / dst_v chroma positions (options.c:67-70)
@@ -543,6 +546,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     }
     GmatSwsContext *c = new (std::nothrow) GmatSwsContext();
     if (!c) return nullptr;
+    if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
     // the 4th byte of RGB0 / BGR0 is padding: libswscale runs them as RGBA / BGRA (handle_0alpha, utils.c:1121-1144);
     // nothing here reads alpha, and every path that creates one writes 255
     auto alpha_twin = [](int f, bool &was0) {
@@ -794,6 +798,13 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     if (srcSliceY != 0 || srcSliceH != c->srcH) {
         logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
         return GMAT_ERR(EINVAL);
+    }
+    {
+        int dev = c->device;
+        if (hipGetDevice(&dev) == hipSuccess && dev != c->device) {
+            logf(LOG_ERROR, "gmat_sws_scale: context created on device %d used while device %d is current", c->device, dev);
+            return GMAT_ERR(EINVAL);
+        }
     }
     c->lastLaunchFrames = 1;
     const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
@@ -1058,22 +1069,35 @@ int yuv2rgb_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstS
 static int stateless_convert(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h,
                              int srcFormat, int dstFormat, void *stream)
 {
-    struct Key { int w, h, s, d; GmatSwsContext *c; };
+    // keyed by geometry AND device (the context's tables live on the device current at creation).  The global lock
+    // covers look-up and insertion only; the launch holds the entry's own lock (a context is not re-entrant), so callers
+    // on other devices or geometries do not wait for it.  An evicted entry dies with its last user.
+    struct Entry {
+        int w, h, s, d, dev; GmatSwsContext *c; std::mutex use;
+        ~Entry() { if (c) gmat_sws_freeContext(c); }
+    };
     static std::mutex lock;
-    static std::vector<Key> cache;
+    static std::vector<std::shared_ptr<Entry>> cache;
     if (!src || !dst || !srcStride || !dstStride) return GMAT_ERR(EINVAL);
-    std::lock_guard<std::mutex> g(lock);
-    GmatSwsContext *c = nullptr;
-    for (const Key &k : cache)
-        if (k.w == w && k.h == h && k.s == srcFormat && k.d == dstFormat) c = k.c;
-    if (!c) {
-        c = gmat_sws_getContext(w, h, srcFormat, w, h, dstFormat, GMAT_SWS_HWACCEL, nullptr);
-        if (!c) return GMAT_ERR(ENOSYS);
-        if (cache.size() >= 16) { gmat_sws_freeContext(cache.front().c); cache.erase(cache.begin()); }
-        cache.push_back({w, h, srcFormat, dstFormat, c});
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::shared_ptr<Entry> e;
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (const auto &k : cache)
+            if (k->w == w && k->h == h && k->s == srcFormat && k->d == dstFormat && k->dev == dev) e = k;
+        if (!e) {
+            GmatSwsContext *c = gmat_sws_getContext(w, h, srcFormat, w, h, dstFormat, GMAT_SWS_HWACCEL, nullptr);
+            if (!c) return GMAT_ERR(ENOSYS);
+            e = std::make_shared<Entry>();
+            e->w = w; e->h = h; e->s = srcFormat; e->d = dstFormat; e->dev = dev; e->c = c;
+            if (cache.size() >= 32) cache.erase(cache.begin());
+            cache.push_back(e);
+        }
     }
-    gmat_sws_setStream(c, stream);
-    const int r = gmat_sws_scale(c, src, srcStride, 0, h, dst, dstStride);
+    std::lock_guard<std::mutex> u(e->use);
+    gmat_sws_setStream(e->c, stream);
+    const int r = gmat_sws_scale(e->c, src, srcStride, 0, h, dst, dstStride);
     return r < 0 ? r : 0;
 }
 

@@ -120,6 +120,7 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t st);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetLastError();
 const char *hipGetErrorName(hipError_t e);

@@ -208,8 +208,11 @@ hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t
     for (size_t y = 0; y < h; y++) memcpy((char *)d + y * dp, (const char *)s + y * sp, w);
     return hipSuccess;
 }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+// two emulated devices (one address space): enough to exercise per-device state such as the context's device check
+static thread_local int g_device = 0;
+hipError_t hipSetDevice(int d) { if (d < 0 || d > 1) return hipErrorInvalidValue; g_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = g_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = 2; return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorName(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emulated)"; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }

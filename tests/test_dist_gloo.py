@@ -47,3 +47,24 @@ def test_single_process_path():
     assert gd.shard_streams(5, 0, 1) == [0, 1, 2, 3, 4]
     v, t = gd.aggregate_throughput(10.0, 2.0, 1)
     assert v == 5.0 and t == 2.0
+
+
+def test_bench_self_launches_two_ranks_through_the_library():
+    """`python bench.py --gpus 2` from a plain shell becomes two ranks (torch.distributed.run on 127.0.0.1); each rank
+    drives the LIBRARY (here the CPU-emulated build, --dry, gloo): its own context, frames, streams and pinned-ring
+    pipeline — the multi-GPU path of BASELINE configs[4] minus the GPUs."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
+    assert d["roofline"]["kernel"] == "scale_yuv2s_kernel"
+    assert d["host_pipeline"]["ranks"] == 2 and d["host_pipeline"]["value"] > 0
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0     # rank 0 at any N
+    assert d["cpu_configs0"]["cores"] == 1
+    # value = all ranks' pixels over the slowest rank's time
+    px = 128 * 32 * d["config"]["frames_per_step"] * d["steps"] * 2
+    assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) < 2e-3
