@@ -501,6 +501,8 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_as_ranks(a.gpus))
+    if not a.dry:
+        import torch      # noqa: F401  BEFORE the library: both link libamdhip64, and torch must bring up the one it was built with
     import gmat_amd
     from gmat_amd import dist as gdist
     rank, local, world = gdist.env_rank()

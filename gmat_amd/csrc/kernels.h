@@ -143,6 +143,11 @@ int launch_copy2d(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride
                   int rowBytes, int h, hipStream_t stream);
 int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                    int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream);
+// smooth_nvcv type=gaussian in general: kw x kh (odd, <= kGaussMaxTaps), sigmaX / sigmaY (<= 0: OpenCV's default rule),
+// border 0 constant, 1 replicate, 2 reflect, 3 wrap, 4 reflect101; float32 accumulation in a stated order
+constexpr int kGaussMaxTaps = 31;
+int launch_gauss_blur(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, int kw, int kh,
+                      double sigmaX, double sigmaY, int border, hipStream_t stream);
 // per-channel 3x3 median, window rows / columns clamped at the edges (vf_median.c semantics at radius 1)
 int launch_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, hipStream_t stream);
 int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,

@@ -184,6 +184,10 @@ int orc_vsynth1(uint8_t *out, int w, int h, int nframes);
 /* deterministic synthetic planes: s = s*1664525 + 1013904223, byte = s>>24 */
 void orc_fill_lcg(uint8_t *p, long n, uint32_t seed);
 
+/* Gaussian blur, OpenCV / CV-CUDA rule (parity unpinned: vf_smooth_nvcv.c:88-105,:290-294 only names the options) */
+int  orc_gauss_blur(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp,
+                    int kw, int kh, double sigma_x, double sigma_y, int border);
+
 #ifdef __cplusplus
 }
 #endif

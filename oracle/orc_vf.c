@@ -14,6 +14,7 @@
  *   crop        libavfilter/vf_crop.c (pointer offset)
  *   3x3 smooth  libavfilter/vf_convolution.c filter_3x3 :495-512, border setup_3x3 :555-569
  */
+#include <math.h>
 #include <string.h>
 #include <stdlib.h>
 #include "orc.h"
@@ -277,4 +278,83 @@ void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], ui
             }
         }
     }
+}
+
+
+/* ---- Gaussian blur, kw x kh with sigmaX / sigmaY and OpenCV border rules -----------------------------------------
+ * What smooth_nvcv type=gaussian asks of CV-CUDA (vf_smooth_nvcv.c:88-105 options, :290-294 the operator call:
+ * kernel size, sigma, border mode).  CV-CUDA is not in the reference tree and no reference test pins its output:
+ * PARITY UNPINNED.  This restates the published OpenCV rule CV-CUDA documents itself as following:
+ *   kernel  cv::getGaussianKernel: sigma <= 0 -> 0.3*((k-1)*0.5 - 1) + 0.8, fixed tables for k = 1,3,5,7, else
+ *           exp(-x*x / (2 sigma^2)) / sum; sigmaY <= 0 -> sigmaX
+ *   border  cv::borderInterpolate: 0 constant(0) 1 replicate 2 reflect 3 wrap 4 reflect101
+ *   sum     float32, raster order over the window, term = (ky[j]*kx[i]) * pixel; out = clip((int)(sum + 0.5f)) */
+static int orc_border(int p, int len, int border)
+{
+    if (p >= 0 && p < len) return p;
+    if (border == 1) return p < 0 ? 0 : len - 1;
+    if (border == 2 || border == 4) {
+        int delta = border == 4;
+        if (len == 1) return 0;
+        while (p < 0 || p >= len) {
+            if (p < 0) p = -p - 1 + delta;
+            else p = len - 1 - (p - len) - delta;
+        }
+        return p;
+    }
+    if (border == 3) {
+        while (p < 0) p += len;
+        return p % len;
+    }
+    return -1;
+}
+
+static void orc_gauss_1d(int k, double sigma, float *out)
+{
+    static const double tab[4][7] = {{1.0}, {0.25, 0.5, 0.25}, {0.0625, 0.25, 0.375, 0.25, 0.0625},
+                                     {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125}};
+    double cf[64], total = 0, sg, s2;
+    int i;
+    if (sigma <= 0 && k <= 7) {
+        for (i = 0; i < k; i++) out[i] = (float)tab[k >> 1][i];
+        return;
+    }
+    sg = sigma > 0 ? sigma : 0.3 * ((k - 1) * 0.5 - 1) + 0.8;
+    s2 = -0.5 / (sg * sg);
+    for (i = 0; i < k; i++) {
+        double x = i - (k - 1) * 0.5;
+        cf[i] = exp(s2 * x * x);
+        total += cf[i];
+    }
+    for (i = 0; i < k; i++) out[i] = (float)(cf[i] / total);
+}
+
+int orc_gauss_blur(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp,
+                   int kw, int kh, double sigma_x, double sigma_y, int border)
+{
+    float kx[64], ky[64];
+    int x, y, ch, i, j;
+    if (kw < 1 || kh < 1 || kw > 63 || kh > 63 || !(kw & 1) || !(kh & 1) || border < 0 || border > 4) return -1;
+    orc_gauss_1d(kw, sigma_x, kx);
+    orc_gauss_1d(kh, sigma_y > 0 ? sigma_y : sigma_x, ky);
+    for (y = 0; y < h; y++)
+        for (x = 0; x < w; x++)
+            for (ch = 0; ch < bpp; ch++) {
+                volatile float sum = 0.0f;
+                int v;
+                for (j = 0; j < kh; j++) {
+                    int yy = orc_border(y + j - kh / 2, h, border);
+                    for (i = 0; i < kw; i++) {
+                        int xx = orc_border(x + i - kw / 2, w, border);
+                        volatile float wgt = ky[j] * kx[i];
+                        volatile float px = (yy < 0 || xx < 0) ? 0.0f : (float)src[(long)yy * src_stride + (long)xx * bpp + ch];
+                        volatile float term = wgt * px;
+                        sum = sum + term;
+                    }
+                }
+                sum = sum + 0.5f;
+                v = (int)sum;
+                dst[(long)y * dst_stride + (long)x * bpp + ch] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+    return 0;
 }
