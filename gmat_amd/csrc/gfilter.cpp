@@ -11,6 +11,7 @@
 //   format_hip    vf_format_cuda.c  option pix_fmt :69-79
 // filter_frame takes ownership of `in` and frees it on every path; errors are negative codes and
 // nothing continues after a failed launch (the reference's CK_NVCV only logs, vf_crop_nvcv.c:62-77).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,107 @@ int plane_geoms(int fmt, int w, int h, PlaneGeom g[3])
     return 1;
 }
 
+
+// ---- w / h expressions of scale_cuda (vf_scale_cuda.c:586-587, evaluated by scale_eval.c:57-111 through libavutil's
+// expression parser).  The subset an output size needs: numbers, + - * / ( ), unary minus, the variables of
+// scale_eval.c:27-41 and min / max / trunc / floor / ceil / round / abs.  Anything else is an error, never a default.
+struct ExprVars { double iw, ih, ow, oh, a, sar, dar, hsub, vsub, ohsub, ovsub; };
+
+struct ExprParser {
+    const char *p;
+    const ExprVars &v;
+    bool ok = true;
+    void skip() { while (*p == ' ' || *p == '\t') p++; }
+    bool eat(char c) { skip(); if (*p == c) { p++; return true; } return false; }
+    double ident()
+    {
+        const char *b = p;
+        while ((*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z') || *p == '_' || (p > b && *p >= '0' && *p <= '9')) p++;
+        const std::string n(b, p);
+        if (eat('(')) {
+            double a0 = sum(), a1 = 0;
+            const bool two = eat(',');
+            if (two) a1 = sum();
+            if (!eat(')')) ok = false;
+            if (n == "min" && two) return std::min(a0, a1);
+            if (n == "max" && two) return std::max(a0, a1);
+            if (!two) {
+                if (n == "trunc") return std::trunc(a0);
+                if (n == "floor") return std::floor(a0);
+                if (n == "ceil") return std::ceil(a0);
+                if (n == "round") return std::round(a0);
+                if (n == "abs") return std::fabs(a0);
+            }
+            ok = false;
+            return 0;
+        }
+        if (n == "in_w" || n == "iw") return v.iw;
+        if (n == "in_h" || n == "ih") return v.ih;
+        if (n == "out_w" || n == "ow") return v.ow;
+        if (n == "out_h" || n == "oh") return v.oh;
+        if (n == "a") return v.a;
+        if (n == "sar") return v.sar;
+        if (n == "dar") return v.dar;
+        if (n == "hsub") return v.hsub;
+        if (n == "vsub") return v.vsub;
+        if (n == "ohsub") return v.ohsub;
+        if (n == "ovsub") return v.ovsub;
+        ok = false;
+        return 0;
+    }
+    double atom()
+    {
+        skip();
+        if (eat('(')) { const double r = sum(); if (!eat(')')) ok = false; return r; }
+        if (eat('-')) return -atom();
+        if (eat('+')) return atom();
+        if ((*p >= '0' && *p <= '9') || *p == '.') { char *e = nullptr; const double r = strtod(p, &e); if (e == p) ok = false; p = e; return r; }
+        if ((*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z') || *p == '_') return ident();
+        ok = false;
+        return 0;
+    }
+    double term()
+    {
+        double r = atom();
+        for (;;) {
+            if (eat('*')) r *= atom();
+            else if (eat('/')) r /= atom();
+            else return r;
+        }
+    }
+    double sum()
+    {
+        double r = term();
+        for (;;) {
+            if (eat('+')) r += term();
+            else if (eat('-')) r -= term();
+            else return r;
+        }
+    }
+};
+
+// av_expr_parse_and_eval for that subset: false when the text does not parse completely
+bool eval_expr(const std::string &text, const ExprVars &v, double &res)
+{
+    ExprParser ps{text.c_str(), v};
+    res = ps.sum();
+    ps.skip();
+    return ps.ok && *ps.p == 0 && !text.empty();
+}
+
+// av_rescale(a, b, c): a * b / c rounded to nearest, halves away from zero (mathematics.c AV_ROUND_NEAR_INF)
+int64_t rescale_near(int64_t a, int64_t b, int64_t c)
+{
+    if (c <= 0) return 0;
+    const int64_t n = a * b;
+    return n >= 0 ? (n + c / 2) / c : -((-n + c / 2) / c);
+}
+
+int chroma_log2(int fmt)      // log2_chroma_w == log2_chroma_h for every format handled here
+{
+    return (fmt == GMAT_PIX_FMT_NV12 || fmt == GMAT_PIX_FMT_YUV420P || fmt == GMAT_PIX_FMT_P010LE || fmt == GMAT_PIX_FMT_P016LE) ? 1 : 0;
+}
+
 } // namespace
 
 struct GmatFilterContext {
@@ -86,9 +188,15 @@ struct GmatFilterContext {
     int rot_bilinear = 1;
     // smooth
     int smooth_median = 0, kw = 3, kh = 3;
+    int border = -1;                     // -1: not given (the 3x3 integer kernel keeps vf_convolution's borders)
+    double sigmaX = 0, sigmaY = 0;
+    bool gauss_general = false;          // any of kw / kh / sigma / border_type given: the float kernel of launch_gauss_blur
     // scale / format
     GmatSwsContext *sws = nullptr;
     int sws_flags = GMAT_SWS_BICUBIC;
+    int passthrough = 1, force_oar = 0, force_div = 1;
+    bool bypass = false;                 // passthrough && nothing to do: filter_frame hands the input frame on
+    double sws_param[2] = {GMAT_SWS_PARAM_DEFAULT, GMAT_SWS_PARAM_DEFAULT};
 };
 
 static int opt_int(GmatFilterContext *f, const char *k, int dflt)
@@ -191,11 +299,41 @@ int gmat_filter_init(GmatFilterContext *f)
     case K_SMOOTH: {
         auto it = f->opt.find("type");
         const std::string t = it == f->opt.end() ? "gaussian" : it->second;
-        f->smooth_median = (t == "median" || t == "1");
+        if (!(t == "gaussian" || t == "median" || t == "0" || t == "1" || t == "2")) return GMAT_ERR(EINVAL);
+        f->smooth_median = (t == "median" || t == "2");          // 0 default = 1 gaussian, 2 median (vf_smooth_nvcv.c:76-80)
         f->kw = opt_int(f, "kw", 3); f->kh = opt_int(f, "kh", 3);
-        if (f->kw != 3 || f->kh != 3) {
-            logf(LOG_ERROR, "smooth_hip: only 3x3 kernels (gaussian, median) are implemented");
-            return GMAT_ERR(ENOSYS);
+        f->sigmaX = opt_double(f, "sigmaX", 0.0); f->sigmaY = opt_double(f, "sigmaY", 0.0);
+        if (f->kw < 1 || f->kh < 1 || f->sigmaX < 0 || f->sigmaY < 0) return GMAT_ERR(EINVAL);
+        f->border = -1;
+        {
+            auto bt = f->opt.find("border_type");
+            if (bt != f->opt.end()) {
+                static const std::map<std::string, int> names = {{"constant", 0}, {"replicate", 1}, {"reflect", 2}, {"warp", 3},
+                                                                 {"wrap", 3}, {"reflect101", 4}, {"0", 0}, {"1", 1}, {"2", 2}, {"3", 3}, {"4", 4}};
+                auto n = names.find(bt->second);
+                if (n == names.end()) return GMAT_ERR(EINVAL);
+                f->border = n->second;
+            }
+        }
+        if (f->smooth_median) {
+            // median: kw = kh = 3 only; border_type / sigma are "only for gaussian" (vf_smooth_nvcv.c:93,:100-101) and
+            // are refused rather than ignored
+            if (f->kw != 3 || f->kh != 3) {
+                logf(LOG_ERROR, "smooth_hip: median is implemented for kw = kh = 3 only");
+                return GMAT_ERR(ENOSYS);
+            }
+            if (f->border >= 0 || f->sigmaX > 0 || f->sigmaY > 0) {
+                logf(LOG_ERROR, "smooth_hip: border_type / sigmaX / sigmaY apply to type=gaussian only");
+                return GMAT_ERR(EINVAL);
+            }
+        } else {
+            // the default 3x3 kernel with no sigma and no border rule given is the integer 1-2-1 kernel with
+            // vf_convolution's arithmetic and borders; every other request runs the float kernel
+            f->gauss_general = f->kw != 3 || f->kh != 3 || f->sigmaX > 0 || f->sigmaY > 0 || f->border >= 0;
+            if (f->gauss_general && (!(f->kw & 1) || !(f->kh & 1) || f->kw > kGaussMaxTaps || f->kh > kGaussMaxTaps)) {
+                logf(LOG_ERROR, "smooth_hip: gaussian kernels must be odd and at most %d x %d", kGaussMaxTaps, kGaussMaxTaps);
+                return GMAT_ERR(f->kw > kGaussMaxTaps || f->kh > kGaussMaxTaps ? ENOSYS : EINVAL);
+            }
         }
         break;
     }
@@ -207,6 +345,21 @@ int gmat_filter_init(GmatFilterContext *f)
         else if (a == "bicubic" || a == "3" || a == "0") f->sws_flags = GMAT_SWS_BICUBIC;
         else if (a == "lanczos" || a == "4") f->sws_flags = GMAT_SWS_LANCZOS;
         else return GMAT_ERR(EINVAL);
+        f->passthrough = opt_int(f, "passthrough", 1) != 0;
+        {
+            auto fo = f->opt.find("force_original_aspect_ratio");
+            const std::string m = fo == f->opt.end() ? "disable" : fo->second;
+            if (m == "disable" || m == "0") f->force_oar = 0;
+            else if (m == "decrease" || m == "1") f->force_oar = 1;
+            else if (m == "increase" || m == "2") f->force_oar = 2;
+            else return GMAT_ERR(EINVAL);
+        }
+        f->force_div = opt_int(f, "force_divisible_by", 1);
+        if (f->force_div < 1 || f->force_div > 256) return GMAT_ERR(EINVAL);
+        // "param": the algorithm-specific parameter (vf_scale_cuda.c:596, default SCALE_CUDA_PARAM_DEFAULT = unset).  The
+        // arithmetic here is libswscale's, so it becomes libswscale's param[0] (bicubic B, lanczos lobes, gauss sharpness:
+        // utils.c:455-530), exactly what the CPU scale filter's param0 does (vf_scale.c:897)
+        if (f->opt.find("param") != f->opt.end()) f->sws_param[0] = opt_double(f, "param", GMAT_SWS_PARAM_DEFAULT);
         break;
     }
     case K_FORMAT:
@@ -253,13 +406,55 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
         f->out_w = f->in_h; f->out_h = f->in_w;
         break;
     case K_SCALE: {
-        f->out_w = opt_int(f, "w", f->in_w); f->out_h = opt_int(f, "h", f->in_h);
-        if (f->out_w <= 0) f->out_w = f->in_w;
-        if (f->out_h <= 0) f->out_h = f->in_h;
         auto it = f->opt.find("format");
         int fmt = it == f->opt.end() ? GMAT_PIX_FMT_NONE : parse_pix_fmt(it->second);
         if (fmt == -2) return GMAT_ERR(EINVAL);
         f->out_fmt = fmt == GMAT_PIX_FMT_NONE ? f->in_fmt : fmt;      // "same" (vf_scale_cuda.c:594)
+        // ff_scale_eval_dimensions (scale_eval.c:57-111): w, then h, then w again (it may refer to oh); 0 -> input size
+        const std::string we = f->opt.count("w") ? f->opt["w"] : "iw", he = f->opt.count("h") ? f->opt["h"] : "ih";
+        ExprVars v;
+        v.iw = f->in_w; v.ih = f->in_h; v.ow = v.oh = NAN;
+        v.a = (double)f->in_w / f->in_h; v.sar = 1; v.dar = v.a;              // GmatFrame carries no sample aspect ratio
+        v.hsub = v.vsub = 1 << chroma_log2(f->in_fmt); v.ohsub = v.ovsub = 1 << chroma_log2(f->out_fmt);
+        double res = 0;
+        (void)eval_expr(we, v, res);                                         // first pass: ow / oh are still unknown
+        int w = (int)res == 0 ? f->in_w : (int)res;
+        v.ow = w;
+        if (!eval_expr(he, v, res) || std::isnan(res)) {
+            logf(LOG_ERROR, "scale_hip: Error when evaluating the expression '%s'.", he.c_str());
+            return GMAT_ERR(EINVAL);
+        }
+        int h = (int)res == 0 ? f->in_h : (int)res;
+        v.oh = h;
+        if (!eval_expr(we, v, res) || std::isnan(res)) {
+            logf(LOG_ERROR, "scale_hip: Error when evaluating the expression '%s'.", we.c_str());
+            return GMAT_ERR(EINVAL);
+        }
+        w = (int)res == 0 ? f->in_w : (int)res;
+        // ff_scale_adjust_dimensions (scale_eval.c:113-175): -1 keeps the aspect ratio, -n also rounds to a multiple of n
+        int fw = 1, fh = 1;
+        if (w < -1) fw = -w;
+        if (h < -1) fh = -h;
+        if (w < 0 && h < 0) { w = f->in_w; h = f->in_h; }
+        if (w < 0) w = (int)(rescale_near(h, f->in_w, (int64_t)f->in_h * fw) * fw);
+        if (h < 0) h = (int)(rescale_near(w, f->in_h, (int64_t)f->in_w * fh) * fh);
+        if (f->force_oar) {
+            const int tw = (int)rescale_near(h, f->in_w, f->in_h), th = (int)rescale_near(w, f->in_h, f->in_w);
+            if (f->force_oar == 1) {
+                w = std::min(tw, w); h = std::min(th, h);
+                if (f->force_div > 1) { w = w / f->force_div * f->force_div; h = h / f->force_div * f->force_div; }
+            } else {
+                w = std::max(tw, w); h = std::max(th, h);
+                if (f->force_div > 1) { w = (w + f->force_div - 1) / f->force_div * f->force_div; h = (h + f->force_div - 1) / f->force_div * f->force_div; }
+            }
+        }
+        if (w <= 0 || h <= 0) {
+            logf(LOG_ERROR, "scale_hip: invalid output size %dx%d", w, h);
+            return GMAT_ERR(EINVAL);
+        }
+        f->out_w = w; f->out_h = h;
+        // vf_scale_cuda.c:254-260,:543: with passthrough (default on) equal size and format means "do not process"
+        f->bypass = f->passthrough && w == f->in_w && h == f->in_h && f->out_fmt == f->in_fmt;
         break;
     }
     case K_FORMAT: {
@@ -273,7 +468,7 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     if (f->kind == K_SCALE || f->kind == K_FORMAT) {
         if (f->sws) gmat_sws_freeContext(f->sws);
         f->sws = gmat_sws_getContext(f->in_w, f->in_h, f->in_fmt, f->out_w, f->out_h, f->out_fmt,
-                                     f->sws_flags | GMAT_SWS_HWACCEL, nullptr);
+                                     f->sws_flags | GMAT_SWS_HWACCEL, f->kind == K_SCALE ? f->sws_param : nullptr);
         if (!f->sws) return GMAT_ERR(ENOSYS);
         gmat_sws_setStream(f->sws, stream);
     }
@@ -294,6 +489,10 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
         logf(LOG_ERROR, "%s: input frame does not match the configured link (%dx%d fmt %d)", f->name.c_str(),
              in->width, in->height, in->sw_format);
         goto fail;
+    }
+    if (f->kind == K_SCALE && f->bypass) {          // passthrough: the frame itself goes downstream (vf_scale_cuda.c:543-544)
+        *out_p = in;
+        return 0;
     }
     out = gmat_frame_alloc();
     if (!out) { r = GMAT_ERR(ENOMEM); goto fail; }
@@ -339,7 +538,9 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
             case K_SMOOTH: {
                 static const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
                 r = f->smooth_median ? launch_median3x3(s, ss, d, ds, pw, ph, bpp, f->stream)
-                                     : launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
+                    : f->gauss_general ? launch_gauss_blur(s, ss, d, ds, pw, ph, bpp, f->kw, f->kh, f->sigmaX, f->sigmaY,
+                                                           f->border < 0 ? 0 : f->border, f->stream)
+                                       : launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
                 break;
             }
             default: break;
@@ -389,6 +590,12 @@ int gmat_smooth3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
                    float rdiv, float bias, void *stream)
 {
     return launch_conv3x3(src, ss, dst, ds, w, h, bpp, matrix, rdiv, bias, (hipStream_t)stream);
+}
+
+int gmat_gauss_blur(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, double sigmaX,
+                    double sigmaY, int border_type, void *stream)
+{
+    return launch_gauss_blur(src, ss, dst, ds, w, h, bpp, kw, kh, sigmaX, sigmaY, border_type, (hipStream_t)stream);
 }
 
 int gmat_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, void *stream)

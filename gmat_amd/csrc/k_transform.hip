@@ -688,8 +688,8 @@ int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, in
 
 // ---- smooth_nvcv type=gaussian beyond the 3x3 integer kernel: kw x kh, sigmaX / sigmaY, five border rules ----------
 // The reference hands these options to CV-CUDA's Gaussian operator (vf_smooth_nvcv.c:88-105,:290-294), whose arithmetic
-// no reference test pins (SURVEY.md §8c "parity unpinned").  The rule stated here — and restated by the oracle,
-// oracle/orc_vf.c orc_gauss_blur — is OpenCV's, which CV-CUDA documents itself as following:
+// no reference test pins (SURVEY.md §8c "parity unpinned").  The rule stated here (the tests restate it
+// independently on the CPU) is OpenCV's, which CV-CUDA documents itself as following:
 //   * 1-D kernels as cv::getGaussianKernel: sigma <= 0 -> 0.3 * ((k - 1) * 0.5 - 1) + 0.8, with the fixed tables for
 //     k = 1, 3, 5, 7; otherwise exp(-x^2 / (2 sigma^2)) normalised to sum 1 (computed in double on the host, stored as
 //     float); sigmaY <= 0 -> sigmaX;

@@ -214,9 +214,15 @@ GMAT_API void gmat_host_frame_free(GmatFrame *frame);
  *                   interp cubic|area and non-zero shift_x/shift_y (CV-CUDA only) -> ENOSYS
  *    transpose_hip <- vf_transpose.c  option dir 0..3 (names :374-379)
  *    smooth_hip  <- vf_smooth_nvcv.c  options type, kw, kh, border_type, sigmaX, sigmaY (:82-105);
- *                   3x3 "gaussian" = integer kernel 1 2 1 / 2 4 2 / 1 2 1, rdiv 1/16
- *                   (vf_convolution.c:495-512 arithmetic and :555-569 borders)
- *    scale_hip   <- vf_scale_cuda.c   options w,h,interp_algo,format (:586-603) on top of libgpuscale
+ *                   the default request (3x3 gaussian, no sigma, no border_type) = integer kernel 1 2 1 / 2 4 2 / 1 2 1,
+ *                   rdiv 1/16 (vf_convolution.c:495-512 arithmetic and :555-569 borders); any of kw / kh / sigmaX /
+ *                   sigmaY / border_type given -> gmat_gauss_blur's float kernel with that border rule; median:
+ *                   kw = kh = 3 (other sizes ENOSYS), gaussian-only options refused with EINVAL
+ *    scale_hip   <- vf_scale_cuda.c   options (:586-603) on top of libgpuscale: w / h expressions (iw ih ow oh a sar dar
+ *                   hsub vsub ohsub ovsub, + - * / ( ) min max trunc floor ceil round abs; -1 / -n as scale_eval.c:113-175),
+ *                   interp_algo, format, passthrough (default 1: a frame whose size and format already match is handed on
+ *                   untouched, :254-260,:543), param (-> libswscale's param[0]), force_original_aspect_ratio,
+ *                   force_divisible_by
  *    format_hip  <- vf_format_cuda.c  option pix_fmt (:69-79)
  *  Input sw formats accepted by the nvcv-style filters: rgb24 bgr24 rgba bgra (vf_crop_nvcv.c:90-98)
  *  and — the two the reference lists but leaves commented out (:91,:94) — nv12 and yuv420p, filtered
@@ -248,6 +254,14 @@ GMAT_API int gmat_crop(const uint8_t *src, int srcStride, uint8_t *dst, int dstS
                        int x, int y, int w, int h, int bpp, void *stream);
 GMAT_API int gmat_smooth3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                             int w, int h, int bpp, const int matrix[9], float rdiv, float bias, void *stream);
+/* smooth_nvcv type=gaussian with its options (vf_smooth_nvcv.c:88-105): kw x kh odd and <= 31, sigmaX / sigmaY (<= 0:
+ * derived from the kernel size; sigmaY <= 0: sigmaX), border_type 0 constant(0) 1 replicate 2 reflect 3 wrap 4 reflect101.
+ * CV-CUDA's arithmetic is pinned by nothing in the reference; the rule is OpenCV's (cv::getGaussianKernel,
+ * cv::borderInterpolate) with float32 accumulation in raster order and out = clip((int)(sum + 0.5f)) — stated in
+ * k_transform.hip and restated by the oracle.  smooth_hip uses it whenever kw, kh, sigma or border_type is given; the
+ * default 3x3 request keeps the integer kernel above. */
+GMAT_API int gmat_gauss_blur(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp,
+                             int kw, int kh, double sigmaX, double sigmaY, int border_type, void *stream);
 /* smooth_nvcv type=median at kw = kh = 3 (vf_smooth_nvcv.c:82-105): per channel the median of the 3x3 window, rows
  * and columns clamped at the frame edges — the CPU median filter's semantics at radius 1, percentile 0.5
  * (vf_median.c:125, median_template.c:101-147).  bpp 1..4. */

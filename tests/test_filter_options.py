@@ -1,0 +1,195 @@
+"""The option contract of the AVFilter-shaped layer (option names and defaults are part of it): every
+option of vf_scale_cuda.c:586-603 and vf_smooth_nvcv.c:88-105 either has its effect or is refused — none is accepted and
+ignored."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, DevPlane
+from gmat_amd.lib import GmatFrame
+from test_parity_filters import _run_filter
+
+
+def _cfg(dev, name, opts, w, h, fmt="rgb24"):
+    """init + config_props only: returns (code of the first failing call or 0, out_w, out_h)"""
+    lib = dev.lib
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT[fmt], w, h, 0)
+    f = lib.gmat_filter_alloc(name.encode())
+    try:
+        for k, v in opts.items():
+            r = lib.gmat_filter_set_option(f, k.encode(), str(v).encode())
+            if r < 0:
+                return r, 0, 0
+        r = lib.gmat_filter_init(f)
+        if r < 0:
+            return r, 0, 0
+        r = lib.gmat_filter_config_props(f, fc, None)
+        if r < 0:
+            return r, 0, 0
+        of = lib.gmat_filter_out_frames(f)
+        ow, oh = C.c_int(), C.c_int()
+        lib.gmat_hwframe_ctx_info(of, None, None, C.byref(ow), C.byref(oh))
+        return 0, ow.value, oh.value
+    finally:
+        lib.gmat_filter_free(f)
+        lib.gmat_hwframe_ctx_free(fc)
+
+
+# ---- gaussian: kw x kh, sigma, borders ----------------------------------------------------------------------------
+@pytest.mark.parametrize("border", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("case", [(3, 3, 0.0, 0.0), (5, 5, 0.0, 0.0), (7, 3, 0.0, 0.0), (9, 9, 0.0, 0.0), (5, 11, 1.7, 0.0),
+                                  (3, 3, 2.0, 0.5), (1, 1, 0.0, 0.0), (31, 31, 6.0, 6.0), (13, 1, 0.0, 3.0)])
+@pytest.mark.parametrize("bpp", [1, 3, 4])
+def test_gauss_blur_matches_the_stated_rule(dev, orc, case, border, bpp):
+    kw, kh, sx, sy = case
+    w, h = (37, 19) if kw < 31 else (21, 9)               # frames smaller than the window too (borders fold repeatedly)
+    src = orc.lcg((h, w * bpp), 17 + kw + border)
+    d = dev.upload_planes([src], 4)[0]
+    o = DevPlane(dev, h, w * bpp, (w * bpp + 15) // 16 * 16)
+    assert dev.lib.gmat_gauss_blur(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, kw, kh, sx, sy, border, None) == 0
+    want = np.zeros_like(src)
+    assert orc.L.orc_gauss_blur(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, kw, kh, sx, sy, border) == 0
+    got = o.download()
+    assert (got == want).all(), np.argwhere(got != want)[:4]
+    assert (o.download(with_padding=True)[:, w * bpp:] == 0xCD).all()
+    d.free(); o.free()
+
+
+def test_gauss_default_kernel_is_the_integer_one_in_the_interior(dev, orc):
+    """sigma <= 0 at 3x3 is OpenCV's fixed 1/4 1/2 1/4 table: the float kernel and the integer 1-2-1 kernel agree away
+    from the border (their border rules differ: vf_convolution.c:555-569 mirrors, border_type 0 pads with 0)"""
+    w, h = 40, 20
+    src = orc.lcg((h, w * 3), 9)
+    a, _, _ = _run_filter(dev, "smooth_hip", {}, src, w, h)
+    b, _, _ = _run_filter(dev, "smooth_hip", {"border_type": "constant"}, src, w, h)
+    assert (a[1:-1, 3:-3] == b[1:-1, 3:-3]).all() and (a != b).any()
+
+
+def test_smooth_options_have_effect_or_are_refused(dev, orc):
+    w, h = 48, 24
+    src = orc.lcg((h, w * 3), 5)
+
+    def want(kw, kh, sx, sy, border):
+        o = np.zeros_like(src)
+        assert orc.L.orc_gauss_blur(src.ctypes.data, src.strides[0], o.ctypes.data, o.strides[0], w, h, 3, kw, kh, sx, sy, border) == 0
+        return o
+    res, _, _ = _run_filter(dev, "smooth_hip", {"kw": 5, "kh": 7}, src, w, h)
+    assert (res == want(5, 7, 0, 0, 0)).all()                              # border_type defaults to constant (:93)
+    res, _, _ = _run_filter(dev, "smooth_hip", {"sigmaX": 2}, src, w, h)
+    assert (res == want(3, 3, 2.0, 0, 0)).all()
+    res, _, _ = _run_filter(dev, "smooth_hip", {"kw": 9, "kh": 9, "sigmaX": 1.5, "sigmaY": 3, "border_type": "reflect101"}, src, w, h)
+    assert (res == want(9, 9, 1.5, 3.0, 4)).all()
+    res, _, _ = _run_filter(dev, "smooth_hip", {"border_type": "warp"}, src, w, h)          # the reference's spelling of wrap
+    assert (res == want(3, 3, 0, 0, 3)).all()
+    assert _cfg(dev, "smooth_hip", {"kw": 4}, w, h)[0] < 0                 # even
+    assert _cfg(dev, "smooth_hip", {"kw": 33, "kh": 33}, w, h)[0] < 0      # beyond the implemented size
+    assert _cfg(dev, "smooth_hip", {"border_type": "mirror"}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"sigmaX": -1}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 5, "kh": 5}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"type": "median", "border_type": "reflect"}, w, h)[0] < 0   # gaussian-only option
+    assert _cfg(dev, "smooth_hip", {"type": "median", "sigmaX": 1}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"type": "boxcar"}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"type": "median"}, w, h)[0] == 0
+
+
+# ---- scale: expressions, -1 / -n, aspect-ratio forcing, passthrough, param ------------------------------------------
+@pytest.mark.parametrize("opts,want", [
+    ({}, (96, 40)),                                             # defaults "iw" / "ih"
+    ({"w": "iw/2", "h": "ih/2"}, (48, 20)),
+    ({"w": "iw/2", "h": -1}, (48, 20)),
+    ({"w": -1, "h": 30}, (72, 30)),
+    ({"w": 50, "h": -2}, (50, 20)),                             # 50 * 40 / 96 = 20.83 -> multiple of 2 nearest: 20
+    ({"w": -4, "h": 30}, (72, 30)),
+    ({"w": "2*iw", "h": "oh"}, None),                           # self-reference: NaN -> error
+    ({"w": "ow", "h": 10}, None),
+    ({"w": "oh*2", "h": 16}, (32, 16)),                         # w may refer to the output height (second pass)
+    ({"w": "trunc(iw/3)", "h": "max(ih/4, 12)"}, (32, 12)),
+    ({"w": "min(iw, 64)", "h": "ih - 8"}, (64, 32)),
+    ({"w": "iw*sar/dar*a", "h": "ih/vsub*ovsub"}, (96, 40)),
+    ({"w": 0, "h": 0}, (96, 40)),                               # 0 -> input size (scale_eval.c:86,:92)
+    ({"w": "(iw", "h": 10}, None),
+    ({"w": "iw/2 foo", "h": 10}, None),
+    ({"w": "bar", "h": 10}, None),
+    ({"w": -1, "h": -1}, (96, 40)),
+    ({"w": 200, "h": 20, "force_original_aspect_ratio": "decrease"}, (48, 20)),
+    ({"w": 200, "h": 20, "force_original_aspect_ratio": "increase"}, (200, 83)),
+    ({"w": 50, "h": 50, "force_original_aspect_ratio": "decrease", "force_divisible_by": 8}, (48, 16)),
+    ({"w": 50, "h": 50, "force_original_aspect_ratio": 2, "force_divisible_by": 16}, (128, 64)),
+    ({"w": 50, "h": 50, "force_original_aspect_ratio": "sideways"}, None),
+    ({"w": 50, "h": 50, "force_divisible_by": 0}, None),
+    ({"w": -100, "h": 10}, (0, 0)),                              # rounds to a multiple of 100 -> 0: invalid size
+])
+def test_scale_size_expressions(dev, opts, want):
+    r, ow, oh = _cfg(dev, "scale_hip", opts, 96, 40)
+    if want is None or want == (0, 0):
+        assert r < 0, (opts, ow, oh)
+    else:
+        assert r == 0 and (ow, oh) == want, (opts, r, ow, oh)
+
+
+def test_scale_expression_sees_chroma_subsampling(dev):
+    r, ow, oh = _cfg(dev, "scale_hip", {"w": "iw/hsub", "h": "ih/vsub", "format": "rgb24"}, 96, 40, fmt="nv12")
+    assert r == 0 and (ow, oh) == (48, 20)
+    r, ow, oh = _cfg(dev, "scale_hip", {"w": "iw/ohsub", "h": "ih/ovsub", "format": "rgb24"}, 96, 40, fmt="nv12")
+    assert r == 0 and (ow, oh) == (96, 40)
+
+
+def test_scale_passthrough_hands_the_frame_on(dev, orc):
+    """vf_scale_cuda.c:254-260,:543: same size and format with passthrough=1 (the default) does not touch the frame"""
+    lib = dev.lib
+    w, h = 64, 16
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT["rgb24"], w, h, 1)
+    for pt, same in ((None, True), (1, True), (0, False)):
+        f = lib.gmat_filter_alloc(b"scale_hip")
+        if pt is not None:
+            assert lib.gmat_filter_set_option(f, b"passthrough", str(pt).encode()) == 0
+        assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+        fin = lib.gmat_frame_alloc()
+        assert lib.gmat_hwframe_get_buffer(fc, fin) == 0
+        src = orc.lcg((h, w * 3), 3)
+        host = np.zeros((h, fin.contents.linesize[0]), np.uint8)
+        host[:, :w * 3] = src
+        assert lib.gmat_memcpy_h2d(fin.contents.data[0], host.ctypes.data, host.size) == 0
+        in_ptr = fin.contents.data[0]
+        out = C.POINTER(GmatFrame)()
+        assert lib.gmat_filter_frame(f, fin, C.byref(out)) == 0
+        lib.gmat_device_sync()
+        assert (out.contents.data[0] == in_ptr) == same
+        back = np.zeros_like(host)
+        assert lib.gmat_memcpy_d2h(back.ctypes.data, out.contents.data[0], back.size) == 0
+        assert (back[:, :w * 3] == src).all()              # rgb24 -> rgb24 at equal size is a copy either way
+        lib.gmat_frame_free(C.byref(out))
+        lib.gmat_filter_free(f)
+    # a format change at equal size is NOT a passthrough
+    f = lib.gmat_filter_alloc(b"scale_hip")
+    assert lib.gmat_filter_set_option(f, b"format", b"bgr24") == 0
+    assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+    fin = lib.gmat_frame_alloc()
+    assert lib.gmat_hwframe_get_buffer(fc, fin) == 0
+    in_ptr = fin.contents.data[0]
+    out = C.POINTER(GmatFrame)()
+    assert lib.gmat_filter_frame(f, fin, C.byref(out)) == 0
+    assert out.contents.data[0] != in_ptr and out.contents.sw_format == PIX_FMT["bgr24"]
+    lib.gmat_device_sync()
+    lib.gmat_frame_free(C.byref(out))
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)
+
+
+@pytest.mark.parametrize("algo,param", [("bicubic", 0.5), ("bicubic", 1.0), ("lanczos", 2.0)])
+def test_scale_param_is_libswscale_param0(dev, orc, algo, param):
+    """param is not ignored: it reaches the filter generator as libswscale's param[0] (bicubic B / lanczos lobes)"""
+    w, h, dw, dh = 96, 40, 40, 24
+    src = orc.lcg((h, w * 3), 4)
+    res, ow, oh = _run_filter(dev, "scale_hip", {"w": dw, "h": dh, "interp_algo": algo, "param": param}, src, w, h)
+    pr = (C.c_double * 2)(param, 123456.0)
+    c = orc.L.orc_sws_create(w, h, PIX_FMT["rgb24"], dw, dh, PIX_FMT["rgb24"], SWS[algo], pr)
+    assert c
+    from harness import planes, ints
+    want = np.zeros((dh, dw * 3), np.uint8)
+    assert orc.L.orc_sws_scale(c, planes([src.ctypes.data]), ints([src.strides[0]]), planes([want.ctypes.data]), ints([want.strides[0]])) == dh
+    orc.L.orc_sws_free(c)
+    assert (res == want).all()
+    dflt, _, _ = _run_filter(dev, "scale_hip", {"w": dw, "h": dh, "interp_algo": algo}, src, w, h)
+    assert (dflt != res).any()                              # and it changes the picture
