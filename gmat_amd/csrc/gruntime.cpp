@@ -201,14 +201,28 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
     // side streams + fork/join events for the parallel branches (only needed while capturing)
     hipStream_t side[8] = {nullptr};
     hipEvent_t fork = nullptr, join[8] = {nullptr};
-    for (int b = 1; b < nbranches; b++) {
-        GMAT_HIP_CHECK(hipStreamCreateWithFlags(&side[b], hipStreamNonBlocking));
-        GMAT_HIP_CHECK(hipEventCreateWithFlags(&join[b], hipEventDisableTiming));
-    }
-    if (nbranches > 1) GMAT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    GMAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rr = 0;
+    auto release = [&]() {                 // every exit path gives the capture-time streams and events back
+        for (int b = 1; b < 8; b++) {
+            if (side[b]) (void)hipStreamDestroy(side[b]);
+            if (join[b]) (void)hipEventDestroy(join[b]);
+            side[b] = nullptr; join[b] = nullptr;
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
+    };
     hipError_t e = hipSuccess;
+    for (int b = 1; b < nbranches && e == hipSuccess; b++) {
+        e = hipStreamCreateWithFlags(&side[b], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&join[b], hipEventDisableTiming);
+    }
+    if (nbranches > 1 && e == hipSuccess) e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        gmat::logf(gmat::LOG_ERROR, "gmat_sws_graph_create: %s while preparing the capture", hipGetErrorName(e));
+        release();
+        return GMAT_ERR(EIO);
+    }
+    int rr = 0;
     if (nbranches > 1) {
         e = hipEventRecord(fork, s);
         for (int b = 1; b < nbranches && e == hipSuccess; b++) e = hipStreamWaitEvent(side[b], fork, 0);
@@ -240,11 +254,7 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
         if (e == hipSuccess) e = hipStreamWaitEvent(s, join[b], 0);
     }
     hipError_t e2 = hipStreamEndCapture(s, &graph);
-    for (int b = 1; b < nbranches; b++) {
-        (void)hipStreamDestroy(side[b]);
-        (void)hipEventDestroy(join[b]);
-    }
-    if (fork) (void)hipEventDestroy(fork);
+    release();
     if (e == hipSuccess) e = e2;
     if (rr < 0 || e != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);

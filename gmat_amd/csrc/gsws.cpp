@@ -103,6 +103,7 @@ struct GmatSwsContext {
     int device = 0;               // the HIP device current at creation: the context's tables live there (hwcontext_cuda.c:395-434
                                   // makes the stream's device current around every call; a context is used on ITS device only)
     Mode mode;
+    Mode unscaledMode = MODE_SCALE;   // the mode chosen at creation: gmat_sws_setRange leaves and re-enters the special converters
     int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
     int chrPos[4] = {-513, -513, -513, -513};   // src_h / src_v / dst_h / dst_v chroma positions (options.c:67-70)
     int rangeConv = 0;            // YUV -> YUV: 1 limited->full (lum/chrRangeToJpeg), 2 full->limited
@@ -679,6 +680,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         delete c;
         return nullptr;
     }
+    c->unscaledMode = c->mode;
     return c;
 }
 
@@ -715,21 +717,29 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
         c->rangeConv = dstFullRange ? 1 : 0;
         return 0;
     }
-    if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) {
+    if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || is_p01x(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_YUV444P16LE)) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
     }
     const int conv = (!!srcFullRange == !!dstFullRange) ? 0 : (dstFullRange ? 1 : 2);
     if (conv == c->rangeConv) return 0;
-    c->rangeConv = conv;
-    // a same-size context is a plane copy only while the ranges agree (utils.c:1996-2000: the special
-    // converters are skipped when srcRange != dstRange); otherwise it runs the generic path
+    // a same-size context is a plane copy / depth expansion only while the ranges agree (utils.c:1996-2000: the
+    // special converters are skipped when srcRange != dstRange); otherwise it runs the generic path, whose 15-bit
+    // lines carry the conversion (8-bit 4:2:0 and P010LE destinations).  The 19-bit path (P016LE, YUV444P16LE) has no
+    // range conversion here: those contexts refuse differing ranges instead of ignoring them.
     const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
-    if (same && is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat)) {
-        if (conv) { c->mode = MODE_SCALE; return ensure_scaler(c); }
-        c->mode = MODE_YUV2YUV;
+    const bool special = same && (c->unscaledMode == MODE_YUV2YUV || c->unscaledMode == MODE_DEPTH || c->unscaledMode == MODE_PLANECOPY);
+    if (special) {
+        const bool generic15 = is_yuv420(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
+        if (conv && !generic15) return GMAT_ERR(ENOSYS);
+        c->rangeConv = conv;
+        if (conv) { c->mode = MODE_SCALE; c->fused = 2; return ensure_scaler(c); }
+        c->mode = c->unscaledMode;
+        return 0;
     }
+    if (c->mode == MODE_SCALE16 && conv) return GMAT_ERR(ENOSYS);
+    c->rangeConv = conv;
     return 0;
 }
 

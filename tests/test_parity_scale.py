@@ -691,3 +691,64 @@ def test_one_tap_vertical_forms_ignore_the_coefficient(dev, orc):
         dev.lib.gmat_sws_freeContext(c)
         for p in d + dst:
             p.free()
+
+
+@pytest.mark.parametrize("case", [("nv12", "p010le"), ("yuv420p", "p010le"), ("p010le", "p010le"), ("nv12", "nv12")])
+@pytest.mark.parametrize("ranges", [(0, 1), (1, 0)])
+def test_same_size_special_converters_leave_for_the_generic_path_when_ranges_differ(dev, orc, case, ranges):
+    """utils.c:1996-2000: the unscaled special converters (plane copy, planar8ToP01xleWrapper) are skipped when
+    srcRange != dstRange; the context then runs the generic path with lum/chrRangeTo/FromJpeg_c on its 15-bit lines.
+    Setting equal ranges again returns to the special converter."""
+    import ctypes as C
+    from harness import alloc_planes, planes, ints
+    sf, df = case
+    w, h = 96, 40
+    L = orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    src = synth_planes(orc, sf, w, h, seed=91)
+    if sf == "p010le":
+        for p in src:                                           # 10 significant bits in the high end of each 16-bit sample
+            v = p.view(np.uint16); v &= 0xFFC0
+    lib = dev.lib
+    d = dev.upload_planes(src, 64)
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None)
+    assert c
+    for sr, dr in (ranges, (0, 0), ranges, (1, 1)):
+        want = alloc_planes(df, w, h)
+        if sr != dr:
+            oc = L.orc_sws_create_ex(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(-513, -513, -513, -513), sr, dr)
+            assert oc
+            assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                   planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == h
+            L.orc_sws_free(oc)
+        elif sf == df:                                          # equal format, size and range: the planes verbatim
+            for a, b in zip(want, src):
+                a[...] = b
+        else:                                                   # planar8ToP01xleWrapper (swscale_unscaled.c:286-324)
+            L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                 planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h, 1 if sf == "nv12" else 0)
+        assert lib.gmat_sws_setRange(c, sr, dr) == 0
+        dst = dev.planes_like(df, w, h, 64)
+        assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
+                                  planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
+        k = lib.gmat_sws_lastKernel(c).decode()
+        assert k.startswith("scale_yuv") == (sr != dr), (k, sr, dr)
+        for a, b in zip(dst, want):
+            assert (a.download() == b).all(), (sr, dr, k)
+        for p in dst:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+    for p in d:
+        p.free()
+
+
+def test_differing_ranges_are_refused_where_there_is_no_conversion(dev):
+    """the 19-bit path (P016LE / YUV444P16LE destinations) carries no range conversion: -ENOSYS, not a silent copy"""
+    lib = dev.lib
+    for sf, df in (("nv12", "p016le"), ("p016le", "p016le"), ("yuv444p16le", "yuv444p16le"), ("nv12", "yuv444p16le")):
+        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
+        assert c
+        assert lib.gmat_sws_setRange(c, 0, 0) == 0 and lib.gmat_sws_setRange(c, 1, 1) == 0
+        assert lib.gmat_sws_setRange(c, 1, 0) < 0 and lib.gmat_sws_setRange(c, 0, 1) < 0
+        lib.gmat_sws_freeContext(c)
