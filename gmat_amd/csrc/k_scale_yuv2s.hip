@@ -365,18 +365,19 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv2sArgs a = a0;
-    // rows per strip segment: long segments amortise the 3 warm-up row pairs (6 halo rows), short ones give the
-    // dispatcher enough workgroups to fill 256 CUs several times over
+    // Rows per strip segment.  A wave's run time is proportional to its segment (one dependent load -> filter -> store
+    // chain per row, ~0.5 us), so a launch cannot finish faster than one segment: small launches want SHORT segments,
+    // and the 3 warm-up row pairs they repeat are paid from the parallelism that would otherwise idle.  Large launches
+    // want the segments just long enough for every SIMD to hold one round of waves (6 per SIMD at 78 VGPRs): the
+    // measured optimum is total waves ~ 6144 (MI355X: 1024 SIMDs x 6) — 3 rows for one 4K frame, 45 for 32 frames.
     const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstrips = (a.dstW + S2_STRIP - 1) / S2_STRIP;
     a.nsg = (nstrips + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
-        // aim at >= 10 waves per SIMD over the launch (two rounds at the expected occupancy), segments of 16..64 rows
-        const long waves = (long)nstrips * nframes;
-        const long wantSegs = std::max(1L, (10L * 1024 + waves - 1) / waves);
-        seg = (int)std::min(64L, std::max(16L, (long)a.dstH / wantSegs));
+        const long rows = (long)a.dstH * nstrips * nframes;      // wave-rows of the launch
+        seg = (int)std::min(64L, std::max(3L, (rows + 6143) / 6144));
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;

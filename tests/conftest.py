@@ -51,3 +51,20 @@ def dev(request):
         return harness.Dev(lib, "hip")
     path = _make(os.path.join(ROOT, "tests", "hipemu"), "build/libgmat_hip_emu.so")
     return harness.Dev(load(path), "emu")
+
+
+@pytest.fixture(params=["strip", "tiled"])
+def kern(request):
+    """Which 2:1 kernel a 4:2:0 -> packed RGB context gets: the strip-walking one (default) or, with
+    GMAT_SCALE_NO_STRIP=1 at context creation, the tiled one it superseded (still the path of Lanczos, of filters whose
+    borders are not edge replication, and of 4:2:0 destinations).  Yields the kernel name to expect."""
+    old = os.environ.get("GMAT_SCALE_NO_STRIP")
+    if request.param == "tiled":
+        os.environ["GMAT_SCALE_NO_STRIP"] = "1"
+    else:
+        os.environ.pop("GMAT_SCALE_NO_STRIP", None)
+    yield "scale_yuv2x_kernel" if request.param == "tiled" else "scale_yuv2s_kernel"
+    if old is None:
+        os.environ.pop("GMAT_SCALE_NO_STRIP", None)
+    else:
+        os.environ["GMAT_SCALE_NO_STRIP"] = old

@@ -38,7 +38,7 @@ def test_cfg3_4k_nv12_to_1080p_rgb24_bicubic(gpu, orc, fused, oracle):
     assert bad.size == 0, f"{k}: {len(bad)} mismatching bytes, first {bad[:3].tolist()}"
     assert (pads[0] == 0xCD).all()
     if fused == 2:
-        assert k == "scale_yuv2x_kernel"
+        assert k == "scale_yuv2s_kernel"
 
 
 def test_cfg3_rgb24_4k_to_1080p_lanczos(gpu, orc):
@@ -112,13 +112,13 @@ def _oracle_rows(orc, src, sw, sh, src_fmt, dw, dh, dst_fmt, y0, y1, flags=SWS["
     return outs
 
 
-def test_8k_nv12_to_4k_rgb24_bands(gpu, orc):
+def test_8k_nv12_to_4k_rgb24_bands(gpu, orc, kern):
     """maximum size of the path (8K UHD): three 32-row bands of the 2:1 scaler's output against the oracle"""
     sw, sh, dw, dh = 7680, 4320, 3840, 2160
     src = synth_planes(orc, "nv12", sw, sh, seed=19)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, "rgb24", dst_align=256)
-    assert k == "scale_yuv2x_kernel" and (pads[0] == 0xCD).all()
+    assert k == kern and (pads[0] == 0xCD).all()
     for y0 in (0, 1072, dh - 32):
         want = _oracle_rows(orc, src, sw, sh, "nv12", dw, dh, "rgb24", y0, y0 + 32)[0]
         assert (got[0][y0:y0 + 32] == want[y0:y0 + 32]).all(), y0
@@ -165,7 +165,7 @@ def test_4k_batched_launch_equals_single_launches(gpu, orc, dst_fmt):
     single = []
     for f in range(n):
         got, _, k = gpu.sws(dsrc[f], sw, sh, "nv12", dw, dh, dst_fmt, dst_align=256)
-        assert k.startswith("scale_yuv2x_kernel")
+        assert k.startswith("scale_yuv2")
         single.append(got)
     ddst = [gpu.planes_like(dst_fmt, dw, dh, 256) for _ in range(n)]
     sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
