@@ -281,6 +281,9 @@ def measured_traffic(kernel, frames_per_launch):
     return None
 
 
+local_device = [0]
+
+
 def other_configs(lib, env, stream, geo, frames=16):
     """BASELINE configs[1] and configs[3], plus the 4:2:0 -> 4:2:0 down-scale of a transcode: one frame per call
     (what sws_scale / filter_frame do) and 32 frames per launch.  Secondary numbers; never the headline `value`."""
@@ -337,10 +340,50 @@ def other_configs(lib, env, stream, geo, frames=16):
                      "frac": round(alg_bytes * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         lib.gmat_sws_freeContext(c)
 
+    def queued_case(name, filt, opts, sf, sw, sh, alg_bytes, batch=32, nframes=256):
+        """the AVFilter-shaped layer's queued form: one send_frame / receive_frame per frame, one launch per `batch` frames"""
+        from gmat_amd.lib import GmatFrame
+        fc = lib.gmat_hwframe_ctx_create(0 if env.dry else local_device[0], PIX_FMT[sf], sw, sh, batch + 2)
+        f = lib.gmat_filter_alloc(filt.encode())
+        for k, v in dict(opts, batch=batch).items():
+            assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0
+        assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, stream) == 0
+        out = C.POINTER(GmatFrame)()
+
+        def one():
+            fr = lib.gmat_frame_alloc()
+            assert lib.gmat_hwframe_get_buffer(fc, fr) == 0         # content: whatever the pool block holds (timing only)
+            assert lib.gmat_filter_send_frame(f, fr) == 0
+            while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+                lib.gmat_frame_free(C.byref(out))
+        for _ in range(2 * batch):
+            one()
+        lib.gmat_stream_sync(stream)
+        gc.collect(); gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(nframes):
+            one()
+        lib.gmat_filter_flush(f)
+        while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+            lib.gmat_frame_free(C.byref(out))
+        lib.gmat_stream_sync(stream)
+        dt = time.perf_counter() - t0
+        gc.enable()
+        us = dt / nframes * 1e6
+        res[name] = {"api": f"gmat_filter_send_frame / receive_frame, {filt} batch={batch}", "us_per_frame": round(us, 3),
+                     "Gpix/s": round(sw * sh / us / 1e3, 1), "algorithmic_bytes": alg_bytes,
+                     "achieved_GBps": round(alg_bytes / us / 1e3, 1), "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4),
+                     "timing": "host wall clock over the frames incl. pool get/put, stream synchronised at the end"}
+        lib.gmat_filter_free(f)
+        lib.gmat_hwframe_ctx_free(fc)
+
     hw, hh = geo.sw // 2, geo.sh // 2                 # 1920 x 1080 in the real run
     sws_case("configs[1]: 1080p nv12 -> rgb24", "nv12", hw, hh, "rgb24", hw, hh, hw * hh * 9 // 2)
     batch_case("configs[1], 32 frames per launch", "nv12", hw, hh, "rgb24", hw, hh, hw * hh * 9 // 2)
     sws_case("configs[2], one frame per call (sws_scale)", "nv12", geo.sw, geo.sh, "rgb24", geo.dw, geo.dh, geo.alg_fused)
+    queued_case("configs[1], one frame per call, queued filter (batch 32)", "format_hip", {"pix_fmt": "rgb24"}, "nv12", hw, hh, hw * hh * 9 // 2)
+    queued_case("configs[2], one frame per call, queued filter (batch 32)", "scale_hip", {"w": "iw/2", "h": "ih/2", "format": "rgb24"},
+                "nv12", geo.sw, geo.sh, geo.alg_fused)
     tb = geo.nv12 + geo.dw * geo.dh * 3 // 2
     sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
     batch_case("transcode, 32 frames per launch", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
@@ -521,6 +564,7 @@ def main():
             raise SystemExit("bench.py: no HIP device visible (use --dry for the CPU plumbing check)")
         geo = Geo(3840, 2160, 1920, 1080)
     env = Env(a.dry, local)
+    local_device[0] = local
     lib.gmat_set_device(0 if a.dry else local)
     gdist.init("gloo" if a.dry else "nccl")                     # RCCL; control plane only (barrier + MAX of time)
     dist = gdist

@@ -15,7 +15,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <vector>
 #include <new>
 #include <string>
 #include "common.h"
@@ -196,6 +198,10 @@ struct GmatFilterContext {
     int sws_flags = GMAT_SWS_BICUBIC;
     int passthrough = 1, force_oar = 0, force_div = 1;
     bool bypass = false;                 // passthrough && nothing to do: filter_frame hands the input frame on
+    // queued form (gmat_filter_send_frame / receive_frame / flush)
+    int batch = 1;
+    std::vector<GmatFrame *> pending;
+    std::deque<GmatFrame *> ready;
     double sws_param[2] = {GMAT_SWS_PARAM_DEFAULT, GMAT_SWS_PARAM_DEFAULT};
 };
 
@@ -237,8 +243,8 @@ int gmat_filter_set_option(GmatFilterContext *f, const char *key, const char *va
     static const std::map<Kind, std::string> allowed = {
         {K_CROP, " w h x y "}, {K_FLIP, " code "}, {K_ROTATE, " angle interp shift_x shift_y "},
         {K_TRANSPOSE, " dir "}, {K_SMOOTH, " type kw kh border_type sigmaX sigmaY "},
-        {K_SCALE, " w h interp_algo format passthrough param force_original_aspect_ratio force_divisible_by "},
-        {K_FORMAT, " pix_fmt "}};
+        {K_SCALE, " w h interp_algo format passthrough param force_original_aspect_ratio force_divisible_by batch "},
+        {K_FORMAT, " pix_fmt batch "}};
     const std::string needle = std::string(" ") + key + " ";
     if (allowed.at(f->kind).find(needle) == std::string::npos) {
         logf(LOG_ERROR, "%s: option '%s' not found", f->name.c_str(), key);
@@ -365,6 +371,12 @@ int gmat_filter_init(GmatFilterContext *f)
     case K_FORMAT:
         if (f->opt.find("pix_fmt") == f->opt.end()) return GMAT_ERR(EINVAL);
         break;
+    }
+    // "batch" (no reference counterpart; scale_hip and format_hip): frames the queued entry points collect before they
+    // launch ONE kernel for all of them (gmat_filter_send_frame below)
+    if (f->kind == K_SCALE || f->kind == K_FORMAT) {
+        f->batch = opt_int(f, "batch", 1);
+        if (f->batch < 1 || f->batch > 256) return GMAT_ERR(EINVAL);
     }
     f->inited = true;
     return 0;
@@ -560,9 +572,98 @@ fail:
     return r;
 }
 
+// ---- queued form -------------------------------------------------------------------------------------------------
+// filter_frame launches one kernel per frame, and a 4K frame is a 4-8 us kernel behind a ~4 us launch: the per-frame
+// entry point of the reference (vf_scale_cuda.c:532-573) is launch-bound on this hardware.  A filter may also collect
+// frames and emit them later (libavfilter's activate() model: ff_inlink_consume_frame ... ff_filter_frame): with the
+// option batch=K, send_frame queues frames and every K-th call launches ONE kernel for K frames (grid.y = frame,
+// gmat_sws_scale_batch); receive_frame hands the finished frames out in order; flush launches a partial batch at EOF.
+// Filters without a batched kernel, and batch=1, process each frame at once — the three calls then behave like
+// filter_frame.
+static int run_pending(GmatFilterContext *f)
+{
+    const int n = (int)f->pending.size();
+    if (!n) return 0;
+    int r = 0;
+    std::vector<GmatFrame *> outs;
+    const bool batched = (f->kind == K_SCALE || f->kind == K_FORMAT) && !f->bypass && n > 1;
+    if (batched) {
+        std::vector<const uint8_t *> sp((size_t)n * 4, nullptr);
+        std::vector<uint8_t *> dp((size_t)n * 4, nullptr);
+        for (int i = 0; i < n && r >= 0; i++) {
+            GmatFrame *o = gmat_frame_alloc();
+            if (!o) { r = GMAT_ERR(ENOMEM); break; }
+            outs.push_back(o);
+            if ((r = gmat_hwframe_get_buffer(f->out_frames, o)) < 0) break;
+            for (int k = 0; k < 4; k++) { sp[(size_t)i * 4 + k] = f->pending[i]->data[k]; dp[(size_t)i * 4 + k] = o->data[k]; }
+            // one stride set per launch: pool frames of one context share it, caller-made frames must too
+            for (int k = 0; k < 4; k++)
+                if (f->pending[i]->linesize[k] != f->pending[0]->linesize[k] || o->linesize[k] != outs[0]->linesize[k]) r = GMAT_ERR(EINVAL);
+        }
+        if (r >= 0) {
+            void *streams[1] = {(void *)f->stream};
+            r = gmat_sws_scale_batch(f->sws, n, sp.data(), f->pending[0]->linesize, dp.data(), outs[0]->linesize, streams, 1, 0);
+        }
+        if (r >= 0) {
+            for (int i = 0; i < n; i++) {
+                outs[i]->pts = f->pending[i]->pts; outs[i]->colorspace = f->pending[i]->colorspace;    // av_frame_copy_props
+                gmat_frame_free(&f->pending[i]);
+                f->ready.push_back(outs[i]);
+            }
+            f->pending.clear();
+            return 0;
+        }
+        for (GmatFrame *&o : outs) gmat_frame_free(&o);
+    } else {
+        for (int i = 0; i < n; i++) {
+            GmatFrame *o = nullptr;
+            const int ri = gmat_filter_frame(f, f->pending[i], &o);     // frees its input on every path
+            f->pending[i] = nullptr;
+            if (ri < 0) r = ri; else f->ready.push_back(o);
+        }
+        f->pending.clear();
+        return r;
+    }
+    for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
+    f->pending.clear();
+    return r;
+}
+
+int gmat_filter_send_frame(GmatFilterContext *f, GmatFrame *in)
+{
+    if (!in) return GMAT_ERR(EINVAL);
+    if (!f || !f->configured) { gmat_frame_free(&in); return GMAT_ERR(EINVAL); }
+    if (in->format != GMAT_PIX_FMT_HIP || in->sw_format != f->in_fmt || in->width != f->in_w || in->height != f->in_h) {
+        logf(LOG_ERROR, "%s: input frame does not match the configured link (%dx%d fmt %d)", f->name.c_str(), in->width, in->height,
+             in->sw_format);
+        gmat_frame_free(&in);
+        return GMAT_ERR(EINVAL);
+    }
+    f->pending.push_back(in);
+    if ((int)f->pending.size() >= f->batch) return run_pending(f);
+    return 0;
+}
+
+int gmat_filter_receive_frame(GmatFilterContext *f, GmatFrame **out)
+{
+    if (!f || !out) return GMAT_ERR(EINVAL);
+    if (f->ready.empty()) return GMAT_ERR(EAGAIN);
+    *out = f->ready.front();
+    f->ready.pop_front();
+    return 0;
+}
+
+int gmat_filter_flush(GmatFilterContext *f)
+{
+    if (!f || !f->configured) return GMAT_ERR(EINVAL);
+    return run_pending(f);
+}
+
 void gmat_filter_free(GmatFilterContext *f)
 {
     if (!f) return;
+    for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
+    while (!f->ready.empty()) { GmatFrame *o = f->ready.front(); f->ready.pop_front(); gmat_frame_free(&o); }
     if (f->sws) gmat_sws_freeContext(f->sws);
     if (f->out_frames) gmat_hwframe_ctx_free(f->out_frames);
     delete f;

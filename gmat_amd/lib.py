@@ -76,6 +76,9 @@ _SIGS = {
     "gmat_filter_out_frames": (C.c_void_p, [C.c_void_p]),
     "gmat_filter_frame": (C.c_int, [C.c_void_p, C.POINTER(GmatFrame), C.POINTER(C.POINTER(GmatFrame))]),
     "gmat_filter_free": (None, [C.c_void_p]),
+    "gmat_filter_send_frame": (C.c_int, [C.c_void_p, C.POINTER(GmatFrame)]),
+    "gmat_filter_receive_frame": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(GmatFrame))]),
+    "gmat_filter_flush": (C.c_int, [C.c_void_p]),
     "gmat_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_flip": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -242,6 +242,14 @@ GMAT_API GmatHWFramesContext *gmat_filter_out_frames(GmatFilterContext *f);
  * output frame with props copied (vf_crop_nvcv.c:209-291) */
 GMAT_API int  gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out);
 GMAT_API void gmat_filter_free(GmatFilterContext *f);                                /* uninit + free */
+/* Queued form — libavfilter's activate() model (ff_inlink_consume_frame ... ff_filter_frame) instead of one kernel launch
+ * per filter_frame call (vf_scale_cuda.c:532-573), which is launch-bound here: a 4K frame is a 4-8 us kernel.  With the
+ * option batch=K (scale_hip, format_hip; default 1) send_frame takes ownership of `in`, queues it, and every K-th call
+ * launches ONE kernel for the K queued frames (grid.y = frame); receive_frame returns finished frames in input order or
+ * -EAGAIN when none is ready; flush launches a partial batch (EOF).  Other filters and batch=1 process at once. */
+GMAT_API int  gmat_filter_send_frame(GmatFilterContext *f, GmatFrame *in);
+GMAT_API int  gmat_filter_receive_frame(GmatFilterContext *f, GmatFrame **out);
+GMAT_API int  gmat_filter_flush(GmatFilterContext *f);
 
 /* direct launchers behind the filters (device pointers, packed pixels of bpp bytes; bpp 1..4, where
  * 1 = one plane of planar YUV, 2 = the interleaved chroma plane of NV12).  gmat_rotate_flip_smooth

@@ -193,3 +193,78 @@ def test_scale_param_is_libswscale_param0(dev, orc, algo, param):
     assert (res == want).all()
     dflt, _, _ = _run_filter(dev, "scale_hip", {"w": dw, "h": dh, "interp_algo": algo}, src, w, h)
     assert (dflt != res).any()                              # and it changes the picture
+
+
+# ---- queued form: send_frame / receive_frame / flush ----------------------------------------------------------------
+def _dev_frame(lib, fc, planes_np, pts):
+    fr = lib.gmat_frame_alloc()
+    assert lib.gmat_hwframe_get_buffer(fc, fr) == 0
+    for i, pl in enumerate(planes_np):
+        host = np.zeros((pl.shape[0], fr.contents.linesize[i]), np.uint8)
+        host[:, :pl.shape[1]] = pl
+        assert lib.gmat_memcpy_h2d(fr.contents.data[i], host.ctypes.data, host.size) == 0
+    fr.contents.pts = pts
+    return fr
+
+
+@pytest.mark.parametrize("batch,kernel", [(4, b"scale_yuv2s_kernel"), (1, None), (16, b"scale_yuv2s_kernel")])
+def test_queued_scale_batches_frames_into_one_launch(dev, orc, batch, kernel):
+    from harness import synth_planes
+    lib = dev.lib
+    sw, sh, dw, dh, n = 128, 32, 64, 16, 10
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT["nv12"], sw, sh, 2)
+    f = lib.gmat_filter_alloc(b"scale_hip")
+    for k, v in (("w", "iw/2"), ("h", "ih/2"), ("format", "rgb24"), ("batch", batch)):
+        assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0
+    assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+    srcs = [synth_planes(orc, "nv12", sw, sh, seed=700 + i) for i in range(n)]
+    outs = []
+    out = C.POINTER(GmatFrame)()
+    for i in range(n):
+        assert lib.gmat_filter_send_frame(f, _dev_frame(lib, fc, srcs[i], 100 + i)) == 0
+        got_now = 0
+        while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+            outs.append(out); out = C.POINTER(GmatFrame)(); got_now += 1
+        assert got_now == (batch if (i + 1) % batch == 0 else 0)        # nothing before the batch is full, then all of it
+    assert lib.gmat_filter_receive_frame(f, C.byref(out)) < 0            # -EAGAIN
+    assert lib.gmat_filter_flush(f) == 0                                  # the partial batch at EOF
+    while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+        outs.append(out); out = C.POINTER(GmatFrame)()
+    assert len(outs) == n
+    lib.gmat_device_sync()
+    for i, o in enumerate(outs):
+        assert o.contents.pts == 100 + i and o.contents.width == dw and o.contents.sw_format == PIX_FMT["rgb24"]
+        back = np.zeros((dh, o.contents.linesize[0]), np.uint8)
+        assert lib.gmat_memcpy_d2h(back.ctypes.data, o.contents.data[0], back.size) == 0
+        assert (back[:, :dw * 3] == orc.sws(srcs[i], sw, sh, "nv12", dw, dh, "rgb24")[0]).all(), i
+        lib.gmat_frame_free(C.byref(o))
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)
+
+
+def test_queued_form_of_an_unbatched_filter_is_immediate(dev, orc):
+    lib = dev.lib
+    w, h = 64, 16
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT["rgb24"], w, h, 1)
+    f = lib.gmat_filter_alloc(b"flip_hip")
+    assert lib.gmat_filter_set_option(f, b"code", b"0") == 0
+    assert lib.gmat_filter_set_option(f, b"batch", b"4") < 0           # scale_hip / format_hip only
+    assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+    src = orc.lcg((h, w * 3), 8)
+    assert lib.gmat_filter_send_frame(f, _dev_frame(lib, fc, [src], 5)) == 0
+    out = C.POINTER(GmatFrame)()
+    assert lib.gmat_filter_receive_frame(f, C.byref(out)) == 0 and out.contents.pts == 5
+    lib.gmat_device_sync()
+    back = np.zeros((h, out.contents.linesize[0]), np.uint8)
+    assert lib.gmat_memcpy_d2h(back.ctypes.data, out.contents.data[0], back.size) == 0
+    assert (back[:, :w * 3] == src[::-1]).all()
+    lib.gmat_frame_free(C.byref(out))
+    # frames still queued or ready when the filter goes are released with it (nothing leaks, nothing dangles)
+    f2 = lib.gmat_filter_alloc(b"format_hip")
+    assert lib.gmat_filter_set_option(f2, b"pix_fmt", b"bgr24") == 0 and lib.gmat_filter_set_option(f2, b"batch", b"8") == 0
+    assert lib.gmat_filter_init(f2) == 0 and lib.gmat_filter_config_props(f2, fc, None) == 0
+    for i in range(3):
+        assert lib.gmat_filter_send_frame(f2, _dev_frame(lib, fc, [src], i)) == 0
+    lib.gmat_filter_free(f2)
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)
