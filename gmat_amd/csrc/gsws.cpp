@@ -130,6 +130,7 @@ struct GmatSwsContext {
     DevFilter r2yVChr;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
     Yuv2sTables y2s;              // strip-walking 2:1 form (k_scale_yuv2s.hip), RGB destinations
+    Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
@@ -224,6 +225,7 @@ static int init_scaler(GmatSwsContext *c)
     int r = build_scale_plan(c->plan, c->srcW, c->srcH, planSrc, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
     if (r < 0) return r;
     if ((r = scale_pick_tiling(c->plan, c->tiling)) < 0) return r;
+    if ((r = rgb2s_prepare(c->plan, c->r2s)) < 0) return r;
     ScaleArgs &a = c->args;
     std::memset(&a, 0, sizeof(a));
     if ((r = c->dHLum.upload(c->plan.hLum, false, a.hLum)) < 0) return r;
@@ -441,6 +443,23 @@ static Yuv2sArgs make_yuv2s_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     return sa;
 }
 
+// argument block of the strip-walking packed-RGB scaler
+static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)
+{
+    Rgb2sArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.ss = srcStride; ra.srcW = c->srcW; ra.srcH = c->srcH; ra.dstW = c->dstW; ra.dstH = c->dstH; ra.ds = dstStride; ra.dstFormat = c->dstFormat;
+    for (int k = 0; k < 4; k++) { ra.hL[k] = c->r2s.hL[k]; ra.vL[k] = c->r2s.vL[k]; }
+    ra.rnd = 1 << 9;
+    const Rgb2YuvConsts &q = c->args.r2y;
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    // coefficients in the byte order of the pixels: (first, second) as an int16 pair, third alone
+    if (srcBgr) { ra.cY01 = pk(q.by, q.gy); ra.cY2 = q.ry; ra.cU01 = pk(q.bu, q.gu); ra.cU2 = q.ru; ra.cV01 = pk(q.bv, q.gv); ra.cV2 = q.rv; }
+    else        { ra.cY01 = pk(q.ry, q.gy); ra.cY2 = q.by; ra.cU01 = pk(q.ru, q.gu); ra.cU2 = q.bu; ra.cV01 = pk(q.rv, q.gv); ra.cV2 = q.bv; }
+    ra.xcdRemap = c->args.xcdRemap; ra.y2r = c->args.y2r;
+    return ra;
+}
+
 namespace gmat {
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
@@ -467,6 +486,31 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             c->lastKernel = "yuv2rgb_kernel";
             int r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), fr.dst[0], dstStride[0], c->srcW, c->srcH,
                                    c->dstFormat, c->y2r, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
+    if (c->mode == MODE_SCALE && (c->srcFormat == GMAT_PIX_FMT_RGB24 || c->srcFormat == GMAT_PIX_FMT_BGR24) && !c->rgbViaPlanes &&
+        !c->inner && is_packed_rgb(c->dstFormat)) {
+        // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames
+        if (ensure_scaler(c) < 0 || !c->r2s.ok) return 0;
+        const int bpp = bytes_per_pixel(c->dstFormat);
+        for (int f = 0; f < n; f++) {
+            const uint8_t *sp = src_planes[4 * f];
+            uint8_t *dp = dst_planes[4 * f];
+            if (!sp || !dp) return GMAT_ERR(EINVAL);
+            if (!al4(sp, srcStride[0])) return 0;
+            if (bpp == 4 ? ((((uintptr_t)dp | (uintptr_t)dstStride[0]) & 15) != 0) : !al4(dp, dstStride[0])) return 0;
+        }
+        const Rgb2sArgs ra = make_rgb2s_args(c, srcStride[0], dstStride[0], c->srcFormat == GMAT_PIX_FMT_BGR24);
+        c->lastKernel = "scale_rgb2s_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            int r = launch_scale_rgb2s(ra, stream, &fr, m);
             if (r < 0) return r;
             c->lastLaunchFrames = m;
         }
@@ -1053,6 +1097,16 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             k.y_coeff = c->args.y2r.y_coeff; k.y_offset = c->args.y2r.y_offset;
             k.v2r = c->args.y2r.v2r; k.v2g = c->args.y2r.v2g; k.u2g = c->args.y2r.u2g; k.u2b = c->args.y2r.u2b;
             a.y2r = k;
+        }
+        if (a.srcKind == 0 && c->r2s.ok && a.srcAligned && a.dstAligned) {
+            // exact 2:1 from packed RGB (also the second kernel of the two-kernel form): the strip-walking scaler
+            const Rgb2sArgs ra = make_rgb2s_args(c, a.ss0, a.ds, a.srcBgr != 0);
+            Yuv2xFrames one;
+            std::memset(&one, 0, sizeof(one));
+            one.y[0] = a.src0; one.dst[0] = a.dst;
+            c->lastKernel = "scale_rgb2s_kernel";
+            r = launch_scale_rgb2s(ra, c->stream, &one, 1);
+            break;
         }
         c->lastKernel = scale_kernel_name(a, c->tiling);
         r = launch_scale_rgb(a, c->tiling, c->stream);

@@ -1,0 +1,269 @@
+// k_scale_rgb2s.hip — strip-walking form of the exact 2:1 packed-RGB -> packed-RGB scaler for gfx950: rgb24 4K -> 1080p
+// bicubic, the second half of the metric's literal "nv12 -> rgb24 -> 1080p" chain (the reference's structure,
+// libswscale/cuda/swscale_cuda.c:352-371).  One libswscale context's arithmetic, bit-exact (same as k_scale.hip):
+//   input     rgb24ToY_c, rgb24ToUV_half_c on pixel pairs                      input.c:815-866
+//   luma      hScale16To15_c: min(sum >> 13, 32767), 8 taps at 2:1             swscale.c:93-119
+//   chroma    one tap of 16384 (half-width chroma plane -> full-width output): min(2u, 32767)
+//   vertical  yuv2rgb_full_X_c + yuv2rgb_write_full on luma AND chroma (8 taps) output.c:2037-2082,1886-1935
+// Same design as k_scale_yuv2s.hip: a wave owns 256 output columns and walks down its strip with the horizontally
+// filtered luma rows and the chroma rows it still needs in registers (48 VGPRs of window), pixels come straight from
+// global memory (three 4-byte aligned dwordx4 per row and lane: 16 pixels, of which 14 are the lane's window), borders
+// are the interior filter on an edge-replicated frame (checked on the host), every coefficient is a kernel argument.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <type_traits>
+#include <cstdlib>
+#include <cstring>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+constexpr int R2_STRIP = 256;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned r2_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint4 r2_ld16(const uint8_t *p) { const r2_u32x4 v = *reinterpret_cast<const r2_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+#else
+static inline uint4 r2_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
+#endif
+
+__device__ __forceinline__ int r2_dot2(int ab, int cd, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ab), __builtin_bit_cast(short2v, cd), acc, true);   // VOP3P form, see k_scale_yuv2s.hip
+}
+
+struct R2Row { unsigned d[12]; };              // 16 pixels = 48 bytes of one source row, from pixel 2 * xo - 4
+
+// DST: 0 rgb24, 1 bgr24, 2 rgba, 3 bgra
+template <int DST>
+__global__ __launch_bounds__(256) void scale_rgb2s_kernel(Rgb2sArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = a.nseg * a.nsg;
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= nblk) return;
+    const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsg);
+    const int X0 = ((lin - seg * a.nsg) * 4 + wave) * R2_STRIP;
+    if (X0 >= a.dstW) return;
+    const int y0 = seg * a.segRows;
+    const int nOut = min(a.segRows, a.dstH - y0);
+    const int nIter = nOut + 3;
+    const uint8_t *ps = fr.y[blockIdx.y];
+    uint8_t *pd = fr.dst[blockIdx.y];
+
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 4;
+    const bool edgeWave = X0 == 0 || X0 + R2_STRIP >= a.dstW;
+    const int want = 6 * xc - 12;                                // byte offset of pixel 2 * xc - 4
+    const int off = min(max(want, 0), 3 * a.srcW - 48);
+    const int sh = want - off;                                   // -12 left frame edge, +12 right frame edge (3 dwords)
+    const unsigned uoff = (unsigned)off;
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    auto load_row = [&](int r, R2Row &R) {
+        const unsigned ro = (unsigned)min(max(r, 0), a.srcH - 1) * (unsigned)a.ss + uoff;
+        const uint4 v0 = r2_ld16(ps + ro), v1 = r2_ld16(ps + (unsigned)(ro + 16)), v2 = r2_ld16(ps + (unsigned)(ro + 32));
+        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y; R.d[6] = v1.z; R.d[7] = v1.w;
+        R.d[8] = v2.x; R.d[9] = v2.y; R.d[10] = v2.z; R.d[11] = v2.w;
+    };
+    // frame-edge lanes: move the dwords into window position (4 pixels = 3 dwords) and replicate the edge pixel
+    auto fix_row = [&](R2Row &R) {
+        if (sh < 0) {
+            const unsigned p = R.d[0];
+#pragma unroll
+            for (int k = 11; k >= 3; k--) R.d[k] = R.d[k - 3];
+            R.d[0] = __builtin_amdgcn_perm(p, p, 0x00020100u); R.d[1] = __builtin_amdgcn_perm(p, p, 0x01000201u); R.d[2] = __builtin_amdgcn_perm(p, p, 0x02010002u);
+        } else if (sh > 0) {
+            const unsigned p = R.d[11];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R.d[k] = R.d[k + 3];
+            R.d[9] = __builtin_amdgcn_perm(p, p, 0x01030201u); R.d[10] = __builtin_amdgcn_perm(p, p, 0x02010302u); R.d[11] = __builtin_amdgcn_perm(p, p, 0x03020103u);
+        }
+    };
+
+    // One source row: 14-bit Y of the 14 window pixels as 7 odd-aligned pairs -> 4 horizontal sums; 14-bit U / V of the
+    // lane's 4 pixel pairs.  (first, second) channel pair and third channel as the bytes come: the coefficients arrive
+    // in that order, so BGR24 sources need no code.
+    auto convert_row = [&](const R2Row &R, int (&hs)[4], int (&u14)[4], int (&v14)[4]) {
+        int y[16], fs[16], th[16];
+#pragma unroll
+        for (int i = 1; i <= 14; i++) {
+            const int o = 3 * i, d = o >> 2, b = o & 3;
+            const unsigned lo = R.d[d], hi = R.d[d + 1 < 12 ? d + 1 : d];
+            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+            // rgb24ToY_c: (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+            y[i] = r2_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+        }
+        int p[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) p[k] = (int)((unsigned)y[2 * k + 1] | ((unsigned)y[2 * k + 2] << 16));      // 0 <= y < 2^15
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            hs[j] = r2_dot2(p[j + 3], a.hL[3], r2_dot2(p[j + 2], a.hL[2], r2_dot2(p[j + 1], a.hL[1], r2_dot2(p[j], a.hL[0], 0))));
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // rgb24ToUV_half_c on the sum of pixels 2c, 2c + 1 of the lane: (ru*r + gu*g + bu*b + (256 << 15) + (1 << 9)) >> 10
+            const int i0 = 4 + 2 * c;
+            const int fsum = fs[i0] + fs[i0 + 1];                   // two 9-bit sums in the halves: no carry across
+            const int tsum = th[i0] + th[i0 + 1];
+            u14[c] = r2_dot2(fsum, a.cU01, m24(tsum, a.cU2) + ((256 << 15) + (1 << 9))) >> 10;
+            v14[c] = r2_dot2(fsum, a.cV01, m24(tsum, a.cV2) + ((256 << 15) + (1 << 9))) >> 10;
+        }
+    };
+
+    int hwY[4][4], hwU[4][4], hwV[4][4];                          // [slot][output]: (row 2m-1 | row 2m << 16), 15-bit lines
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hwY[s][j] = hwU[s][j] = hwV[s][j] = 0;
+
+    R2Row bufA[2], bufB[2];                                       // ping-pong: rows 2m-1 and 2m of the current / next pair
+    load_row(2 * (y0 - 1) - 1, bufA[0]);
+    load_row(2 * (y0 - 1), bufB[0]);
+
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr bool EDGE = decltype(edge_c)::value;
+        R2Row ra = bufA[SLOT & 1], rb = bufB[SLOT & 1];
+        if (j + 1 < nIter) {
+            const int m = y0 + j;                                   // pair y0 - 1 + (j + 1)
+            load_row(2 * m - 1, bufA[(SLOT + 1) & 1]);
+            load_row(2 * m, bufB[(SLOT + 1) & 1]);
+        }
+        if (EDGE) { fix_row(ra); fix_row(rb); }
+        {
+            int sa[4], sb[4], ua[4], va[4], ub[4], vb[4];
+            convert_row(ra, sa, ua, va);
+            convert_row(rb, sb, ub, vb);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // hScale16To15_c: min(val >> 13, 32767)
+                hwY[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 13, sb[q] >> 13));
+                // the one-tap chroma filter: min((u * 16384) >> 13, 32767) = min(2u, 32767), u < 2^15
+                hwU[SLOT][q] = (int)((unsigned)min(2 * ua[q], 32767) | ((unsigned)min(2 * ub[q], 32767) << 16));
+                hwV[SLOT][q] = (int)((unsigned)min(2 * va[q], 32767) | ((unsigned)min(2 * vb[q], 32767) << 16));
+            }
+        }
+        if (j >= 3) {
+            const int yo = y0 + j - 3;
+            unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int Y = a.rnd, U = a.rnd - (128 << 19), V = a.rnd - (128 << 19);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    Y = r2_dot2(hwY[(SLOT + 1 + k) & 3][q], a.vL[k], Y);
+                    U = r2_dot2(hwU[(SLOT + 1 + k) & 3][q], a.vL[k], U);
+                    V = r2_dot2(hwV[(SLOT + 1 + k) & 3][q], a.vL[k], V);
+                }
+                Y >>= 10; U >>= 10; V >>= 10;
+                // yuv2rgb_write_full (output.c:1886-1935); every factor is below 2^23, so the 24-bit multiplier gives the
+                // same low 32 bits as the C expression, and av_clip_uintp2(x, 30) is a median with the range ends
+                const int yy = m24(Y - a.y2r.y_offset, a.y2r.y_coeff) + (1 << 21);
+                const int R = yy + m24(V, a.y2r.v2r);
+                const int G = yy + m24(V, a.y2r.v2g) + m24(U, a.y2r.u2g);
+                const int B = yy + m24(U, a.y2r.u2b);
+                const unsigned r8 = (unsigned)min(max(R, 0), 0x3FFFFFFF) >> 6, g8 = (unsigned)min(max(G, 0), 0x3FFFFFFF) >> 6,
+                               b8 = (unsigned)min(max(B, 0), 0x3FFFFFFF) >> 6;      // the byte sits in bits 16..23
+                c0[q] = BGR ? b8 : r8; c1[q] = g8; c2[q] = BGR ? r8 : b8;
+            }
+            if (active) {
+                uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+    #define R2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = R2_B2PAIR(c0[0], c1[0]) | (R2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                    o4.y = R2_B2PAIR(c0[1], c1[1]) | (R2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                    o4.z = R2_B2PAIR(c0[2], c1[2]) | (R2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                    o4.w = R2_B2PAIR(c0[3], c1[3]) | (R2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d) = o4;
+                } else {
+                    uint3 o3;
+                    o3.x = R2_B2PAIR(c0[0], c1[0]) | (R2_B2PAIR(c2[0], c0[1]) << 16);
+                    o3.y = R2_B2PAIR(c1[1], c2[1]) | (R2_B2PAIR(c0[2], c1[2]) << 16);
+                    o3.z = R2_B2PAIR(c2[2], c0[3]) | (R2_B2PAIR(c1[3], c2[3]) << 16);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+    #undef R2_B2PAIR
+            }
+        }
+    };
+    auto run = [&](auto edge_c) {
+        for (int j0 = 0; j0 < nIter; j0 += 4) {
+            body(j0, std::integral_constant<int, 0>(), edge_c);
+            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t)
+{
+    t = Rgb2sTables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
+          p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
+    if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 8 || p.srcW < 32 || p.dstH < 8) return 0;
+    // half-width chroma plane (pixel pairs) at full height, full-size chroma at the output
+    if (!p.chrSrcHSub || p.chrSrcW * 2 != p.srcW || p.chrSrcH != p.srcH || p.chrDstW != p.dstW || p.chrDstH != p.dstH) return 0;
+    // identity chroma filter: one tap of 16384 on sample x
+    if (p.hChr.taps != 1) return 0;
+    for (int x = 0; x < p.hChr.count; x++)
+        if (p.hChr.pos[x] != x || p.hChr.coef[x] != 16384) return 0;
+    if (!filter_is_edge_replication(p.hLum, p.srcW, t.hL)) return 0;
+    if (!filter_is_edge_replication(p.vLum, p.srcH, t.vL)) return 0;
+    // the vertical chroma filter of a non-subsampled source is the luma one (utils.c:1838-1873)
+    if (p.vChr.taps != p.vLum.taps || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return 0;
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Rgb2sArgs a = a0;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");
+    const int segEnv = segStr ? atoi(segStr) : 0;
+    const int nstrips = (a.dstW + R2_STRIP - 1) / R2_STRIP;
+    a.nsg = (nstrips + 3) / 4;
+    int seg = segEnv > 0 ? segEnv : 0;
+    if (!seg) {
+        // as launch_scale_yuv2s, for ~3 resident waves per SIMD (the window and the pixel buffers take ~130 VGPRs)
+        const long rows = (long)a.dstH * nstrips * nframes;
+        seg = (int)std::min(64L, std::max(3L, (rows + 3071) / 3072));
+    }
+    a.segRows = seg;
+    a.nseg = (a.dstH + seg - 1) / seg;
+    const int nblk = a.nseg * a.nsg;
+    const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
+    const Yuv2xFrames &fr = *frames;
+    switch (a.dstFormat) {
+    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<0>), grid, block, 0, stream, a, fr); break;
+    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<1>), grid, block, 0, stream, a, fr); break;
+    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<2>), grid, block, 0, stream, a, fr); break;
+    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<3>), grid, block, 0, stream, a, fr); break;
+    default: return GMAT_ERR(EINVAL);
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
 // host side
 // ---------------------------------------------------------------------------------------------
 // Is this axis "the filter row `nominal` on the window [2x - 3, 2x + 4] of an edge-replicated line" for every output x?
-static bool replicate_equivalent(const FilterBank &fb, int srcLen, int32_t (&pairs)[4])
+bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4])
 {
     if (fb.count < 8 || srcLen != 2 * fb.count) return false;
     // the middle row provides the nominal coefficients
@@ -349,9 +349,9 @@ int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
           p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
     if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 8 || p.srcW < 32 || p.dstH < 8) return 0;
     if (p.chrSrcW != p.dstW || p.chrSrcH != p.dstH || p.chrDstW * 2 != p.dstW || p.chrDstH != p.dstH) return 0;
-    if (!replicate_equivalent(p.hLum, p.srcW, t.hL)) return 0;
-    if (!replicate_equivalent(p.hChr, p.chrSrcW, t.hC)) return 0;
-    if (!replicate_equivalent(g.vLumEff, p.srcH, t.vL)) return 0;
+    if (!filter_is_edge_replication(p.hLum, p.srcW, t.hL)) return 0;
+    if (!filter_is_edge_replication(p.hChr, p.chrSrcW, t.hC)) return 0;
+    if (!filter_is_edge_replication(g.vLumEff, p.srcH, t.vL)) return 0;
     // vertical chroma: one tap of 4096 on row y, rounding 1 << 18 (the kernel folds it into the horizontal accumulator)
     if (g.vChrEff.taps != 1) return 0;
     for (int y = 0; y < p.dstH; y++)

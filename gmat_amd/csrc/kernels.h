@@ -261,4 +261,23 @@ struct Yuv2sArgs {
 int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTables &t);
 // plane pointers of the nframes frames in *frames (grid.y = frame)
 int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
+// ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
+// rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
+struct Rgb2sTables {
+    int ok = 0;
+    int32_t hL[4] = {0}, vL[4] = {0};           // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
+};
+struct Rgb2sArgs {
+    int ss, srcW, srcH, dstW, dstH, ds, dstFormat;
+    int32_t hL[4], vL[4];
+    int rnd;                                    // vertical accumulator start (1 << 9)
+    int32_t cY01, cY2, cU01, cU2, cV01, cV2;    // rgb -> yuv coefficients as (first, second) int16 pair and third, in byte order
+    int segRows, nseg, nsg, xcdRemap;           // filled by the launcher
+    Yuv2RgbConsts y2r;
+};
+bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4]);
+int  rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t);
+// frames->y[] = source frames, frames->dst[] = destination frames (grid.y = frame)
+int  launch_scale_rgb2s(const Rgb2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 } // namespace gmat

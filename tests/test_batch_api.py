@@ -80,6 +80,15 @@ def test_batch_on_the_generic_plane_scaler(dev, orc, case):
     assert _run_batch.last_frames == 2          # the second stream's share of 5 frames
 
 
+@pytest.mark.parametrize("case", [("rgb24", "rgb24"), ("bgr24", "bgra")])
+def test_batch_on_the_rgb_strip_kernel(dev, orc, case):
+    """packed RGB at exactly 2:1 batches too: scale_rgb2s_kernel with grid.y = frame"""
+    sf, df = case
+    k = _run_batch(dev, orc, sf, df, 264, 40, 132, 20, nframes=5, nstreams=2, align=16)
+    assert k == "scale_rgb2s_kernel", k
+    assert _run_batch.last_frames == 2
+
+
 def test_batch_more_frames_than_one_launch_carries(dev, orc):
     """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches"""
     k = _run_batch(dev, orc, "nv12", "rgb24", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)

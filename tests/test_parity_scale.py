@@ -28,10 +28,36 @@ GEOMS = [(256, 64, 128, 32), (200, 90, 100, 45), (131, 77, 64, 33), (96, 40, 144
 
 
 @pytest.mark.parametrize("geom", GEOMS)
-def test_rgb24_bicubic(dev, orc, geom):
+def test_rgb24_bicubic(dev, orc, kern, geom):
+    """exact 2:1 geometries take the strip-walking kernel (k_scale_rgb2s.hip) unless it is switched off; everything else,
+    and both with GMAT_SCALE_NO_STRIP=1, the tiled generic one"""
     sw, sh, dw, dh = geom
     k = _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
-    assert k.startswith("scale_rgb_kernel")
+    strip = kern == "scale_yuv2s_kernel" and sw == 2 * dw and sh == 2 * dh and sw % 8 == 0 and sw >= 32 and dh >= 8
+    assert k.startswith("scale_rgb2s_kernel" if strip else "scale_rgb_kernel"), k
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("rgb24", "rgb24"), ("bgr24", "rgb24"), ("rgb24", "bgr24"), ("bgr24", "bgra"), ("rgb24", "rgba")])
+@pytest.mark.parametrize("geom", [(32, 16, 4), (64, 32, 16), (512, 40, 64), (520, 24, 4), (1032, 36, 8), (2056, 20, 4), (2560, 18, 256)])
+def test_rgb_strip_kernel_bit_exact(dev, orc, monkeypatch, src_fmt, dst_fmt, geom):
+    """k_scale_rgb2s.hip: partial strips, several strip groups, widths that are multiples of 8 only, frame edges
+    (replicated pixels instead of libswscale's folded coefficient rows), both channel orders at both ends"""
+    sw, sh, align = geom
+    if dst_fmt in ("rgba", "bgra"):
+        align = max(align, 16)
+    for rows in (None, 1, 5):
+        if rows is None:
+            monkeypatch.delenv("GMAT_STRIP_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+        k = _check(dev, orc, src_fmt, sw, sh, sw // 2, sh // 2, dst_fmt, SWS["bicubic"], align=align)
+        assert k == "scale_rgb2s_kernel", k
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "point", "area", "gauss"])
+def test_rgb_strip_kernel_other_filters(dev, orc, flags):
+    k = _check(dev, orc, "rgb24", 320, 48, 160, 24, "rgb24", SWS[flags], align=16)
+    assert k.startswith("scale_rgb"), k
 
 
 @pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area", "bicubic"])
