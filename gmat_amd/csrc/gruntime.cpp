@@ -192,10 +192,14 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
     if (nbranches > 8) nbranches = 8;
     if (gmat::sws_shares_intermediate(c)) nbranches = 1;
     gmat_sws_setStream(c, stream);
-    // warm launch outside capture so lazy allocations (intermediate frame) are not captured
+    // warm launches outside capture so lazy allocations (the intermediate frames of the two-kernel form) are not captured
     {
         int r = gmat_sws_scale(c, src_planes, srcStride, 0, srcH, dst_planes, dstStride);
         if (r < 0) return r;
+        if (nframes >= 2 * nbranches) {
+            r = gmat::sws_scale_frames_batched(c, nframes / nbranches + (nframes % nbranches ? 1 : 0), src_planes, srcStride, dst_planes, dstStride, s);
+            if (r < 0) return r;
+        }
         GMAT_HIP_CHECK(hipStreamSynchronize(s));
     }
     // side streams + fork/join events for the parallel branches (only needed while capturing)

@@ -137,6 +137,8 @@ struct GmatSwsContext {
     int fused = 2;
     uint8_t *inter = nullptr;     // RGB24 intermediate at source size for the two-kernel form
     int interStride = 0;
+    uint8_t *interBatch = nullptr; // kYuv2xMaxFrames such intermediates for the batched two-kernel form
+    int interBatchFrames = 0;
     const char *lastKernel = "";
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
@@ -154,6 +156,7 @@ struct GmatSwsContext {
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
+        if (interBatch) (void)hipFree(interBatch);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
     }
@@ -514,6 +517,47 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             if (r < 0) return r;
             c->lastLaunchFrames = m;
         }
+        return 1;
+    }
+    if (c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0 && is_packed_rgb(c->dstFormat)) {
+        // the two-kernel form (convert at source size, then scale: the reference's structure, swscale_cuda.c:352-371) for
+        // n frames: ONE launch of the converter into n context-owned RGB24 intermediates, ONE launch of the strip scaler
+        if (ensure_scaler(c) < 0 || !c->r2s.ok) return 0;
+        const bool planar = c->srcFormat == GMAT_PIX_FMT_YUV420P;
+        const int bpp = bytes_per_pixel(c->dstFormat);
+        for (int f = 0; f < n; f++) {
+            const uint8_t *const *sp = src_planes + 4 * f;
+            uint8_t *dp = dst_planes[4 * f];
+            if (!sp[0] || !sp[1] || (planar && !sp[2]) || !dp) return GMAT_ERR(EINVAL);
+            if (bpp == 4 ? ((((uintptr_t)dp | (uintptr_t)dstStride[0]) & 15) != 0) : !al4(dp, dstStride[0])) return 0;
+        }
+        const int per = std::min(n, kYuv2xMaxFrames);
+        c->interStride = align_up(c->srcW * 3, 256);
+        const size_t frameBytes = (size_t)c->interStride * c->srcH;
+        if (c->interBatchFrames < per) {
+            if (c->interBatch) (void)hipFree(c->interBatch);
+            c->interBatch = nullptr; c->interBatchFrames = 0;
+            GMAT_HIP_CHECK(hipMalloc((void **)&c->interBatch, frameBytes * per));
+            c->interBatchFrames = per;
+        }
+        const Rgb2sArgs ra = make_rgb2s_args(c, c->interStride, dstStride[0], false);
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            Yuv2xFrames cv, sc;
+            std::memset(&cv, 0, sizeof(cv)); std::memset(&sc, 0, sizeof(sc));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                cv.y[i] = sp[0]; cv.u[i] = sp[1]; cv.v[i] = planar ? sp[2] : nullptr;
+                cv.dst[i] = c->interBatch + frameBytes * i;
+                sc.y[i] = cv.dst[i]; sc.dst[i] = dst_planes[4 * (f0 + i)];
+            }
+            int r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), cv.dst[0], c->interStride, c->srcW, c->srcH,
+                                   GMAT_PIX_FMT_RGB24, c->y2r, stream, &cv, m);
+            if (r < 0) return r;
+            if ((r = launch_scale_rgb2s(ra, stream, &sc, m)) < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        c->lastKernel = "scale_rgb2s_kernel";
         return 1;
     }
     if (c->mode != MODE_SCALE || !(is_plane_src(c->srcFormat) || c->rgbViaPlanes) || c->fused != 2) return 0;

@@ -246,9 +246,10 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nsg = (nstrips + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
-        // as launch_scale_yuv2s, for ~3 resident waves per SIMD (the window and the pixel buffers take ~130 VGPRs)
+        // as launch_scale_yuv2s; 3 waves per SIMD are resident (162 VGPRs), two rounds of them balance best (measured:
+        // 16..48 rows at 32 frames 9.05 us per frame, 64 rows 9.8)
         const long rows = (long)a.dstH * nstrips * nframes;
-        seg = (int)std::min(64L, std::max(3L, (rows + 3071) / 3072));
+        seg = (int)std::min(48L, std::max(3L, (rows + 6143) / 6144));
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;

@@ -89,6 +89,37 @@ def test_batch_on_the_rgb_strip_kernel(dev, orc, case):
     assert _run_batch.last_frames == 2
 
 
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+def test_batch_two_kernel_form(dev, orc, src_fmt):
+    """setFused(0) — convert at source size, then scale (the reference's structure) — batches as two launches for n frames:
+    the converter into n context-owned RGB24 intermediates, then the strip scaler; bytes = the chained oracle's"""
+    import ctypes as C
+    lib = dev.lib
+    sw, sh, dw, dh, n = 264, 40, 132, 20, 5
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    assert c and lib.gmat_sws_setFused(c, 0) == 0
+    srcs = [synth_planes(orc, src_fmt, sw, sh, seed=800 + f) for f in range(n)]
+    dsrc = [dev.upload_planes(s, 16) for s in srcs]
+    ddst = [dev.planes_like("rgb24", dw, dh, 16) for _ in range(n)]
+    sp = (C.c_void_p * (4 * n))(); dp = (C.c_void_p * (4 * n))()
+    for f in range(n):
+        for i, p in enumerate(dsrc[f]): sp[4 * f + i] = p.ptr
+        dp[4 * f] = ddst[f][0].ptr
+    st = C.c_void_p(); assert lib.gmat_stream_create(C.byref(st)) == 0
+    streams = (C.c_void_p * 1)(st)
+    r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
+                                 C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
+                                 C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
+    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n and lib.gmat_sws_lastKernel(c) == b"scale_rgb2s_kernel"
+    lib.gmat_stream_sync(st)
+    for f in range(n):
+        assert (ddst[f][0].download() == orc.chained(srcs[f], sw, sh, src_fmt, dw, dh, "rgb24")[0]).all(), f
+    lib.gmat_stream_destroy(st)
+    lib.gmat_sws_freeContext(c)
+    for f in range(n):
+        for p in dsrc[f] + ddst[f]: p.free()
+
+
 def test_batch_more_frames_than_one_launch_carries(dev, orc):
     """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches"""
     k = _run_batch(dev, orc, "nv12", "rgb24", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)

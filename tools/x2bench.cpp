@@ -93,10 +93,11 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         // batched result of the first 4 (distinct) frames vs one frame per call
         std::vector<uint8_t> a(db), b(db);
         std::vector<uint32_t> crcBatch(4);
+        const int nv = NF < 4 ? NF : 4;
         launch(0); CK(gmat_stream_sync(stream));
-        for (int i = 0; i < 4; i++) { CK(gmat_memcpy_d2h(a.data(), dst[i], db)); crcBatch[i] = adler(a.data(), db); CK(gmat_memset(dst[i], 0, db)); }
+        for (int i = 0; i < nv; i++) { CK(gmat_memcpy_d2h(a.data(), dst[i], db)); crcBatch[i] = adler(a.data(), db); CK(gmat_memset(dst[i], 0, db)); }
         int bad = 0;
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < nv; i++) {
             int r = gmat_sws_scale(c, sp.data() + (size_t)i * 4, ss, 0, sh, dp.data() + (size_t)i * 4, ds);
             if (r < 0) { fprintf(stderr, "single-frame call failed %d\n", r); exit(1); }
             CK(gmat_stream_sync(stream));
