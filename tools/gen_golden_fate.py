@@ -13,6 +13,10 @@ tests/test_oracle_fate.py checks the oracle against.  Sources, all under
                             scale's yuv420p->rgb24 output)
   fate/filter-transpose    (tests/fate/filter-video.mak:297-298)
   pixfmt/{rgb24,bgr24,yuv420p}  (tests/fate-run.sh:446-456 pixfmt_conversion: md5 of the yuv444p file)
+  fate/filter-{null,vflip,crop,...}      (tests/fate-run.sh:458-466 video_filter: md5 of the NUT stream of 5 raw frames;
+                                          recipes tests/fate/filter-video.mak:391-441)
+  fate/filter-pixfmts-{null,copy,hflip,vflip,crop,transpose,rotate,scale}   (tests/fate-run.sh:468-497 pixfmts: one md5 of
+                                          a 1-frame NUT stream per pixel format; recipes filter-video.mak:543-610)
 """
 import json, os, re, sys
 
@@ -34,12 +38,30 @@ def md5ref(name):
     return first[0]
 
 
+VIDEO_FILTER = ("null", "vflip", "crop", "crop_vflip", "vflip_crop", "vflip_vflip", "scale200", "scale500", "crop_scale")
+PIXFMTS_FILTERS = ("null", "copy", "hflip", "vflip", "crop", "transpose", "rotate", "scale")
+PIXFMTS = ("yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le")
+
+
+def nutmd5(name):
+    out = {}
+    for line in open(os.path.join(REF, "fate", name)):
+        f = line.split()
+        if len(f) == 2:
+            out[f[0]] = f[1]
+    return out
+
+
 def main():
     doc = {
         "_source": "ffmpeg-gpu/tests/ref/fate/* and tests/ref/pixfmt/* of the reference tree (golden values only)",
         "framecrc": {n: framecrc(n) for n in ("sws-yuv-range", "sws-yuv-colorspace", "filter-scalechroma", "filter-colorlevels",
                                               "filter-transpose")},
         "pixfmt_md5": {n: md5ref(n) for n in ("rgb24", "bgr24", "yuv420p")},
+        "nut_md5": {
+            "video_filter": {n: nutmd5("filter-" + n)[n] for n in VIDEO_FILTER},
+            "pixfmts": {f: {k: v for k, v in nutmd5("filter-pixfmts-" + f).items() if k in PIXFMTS} for f in PIXFMTS_FILTERS},
+        },
     }
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "fate_refs.json")
     with open(dst, "w") as f:
