@@ -40,6 +40,10 @@ inline bool is_yuv420(int f) { return f == GMAT_PIX_FMT_NV12 || f == GMAT_PIX_FM
 inline bool is_yuv8_src(int f) { return is_yuv420(f) || f == GMAT_PIX_FMT_YUV444P; }
 // 16-bit semi-planar 4:2:0 (interleaved U,V; P010: the 10 significant bits are the high ones)
 inline bool is_p01x(int f) { return f == GMAT_PIX_FMT_P010LE || f == GMAT_PIX_FMT_P016LE; }
+// planar YUV in 16-bit little-endian containers (sources; YUV444P16LE is a destination too): significant bits, 0 = not one.
+// The samples go to hScale16To15_c / hScale16To19_c as they are (no input converter on a little-endian host,
+// input.c:1523-1528), so the 10-bit form keeps its bits in the LOW end, unlike P010LE.
+inline int  pl16_depth(int f) { return (f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE) ? 16 : f == GMAT_PIX_FMT_YUV420P10LE ? 10 : 0; }
 inline int  bytes_per_pixel(int f)
 {
     switch (f) {

@@ -36,7 +36,7 @@ int parse_pix_fmt(const std::string &s)
         {"bgra", GMAT_PIX_FMT_BGRA}, {"nv12", GMAT_PIX_FMT_NV12}, {"yuv420p", GMAT_PIX_FMT_YUV420P},
         {"yuv444p", GMAT_PIX_FMT_YUV444P}, {"p010le", GMAT_PIX_FMT_P010LE}, {"p016le", GMAT_PIX_FMT_P016LE},
         {"rgba64le", GMAT_PIX_FMT_RGBA64LE}, {"bgra64le", GMAT_PIX_FMT_BGRA64LE},
-        {"yuv444p16le", GMAT_PIX_FMT_YUV444P16LE}, {"rgb0", GMAT_PIX_FMT_RGB0}, {"bgr0", GMAT_PIX_FMT_BGR0}, {"0bgr32", GMAT_PIX_FMT_RGB0}, {"0rgb32", GMAT_PIX_FMT_BGR0},
+        {"yuv444p16le", GMAT_PIX_FMT_YUV444P16LE}, {"yuv420p16le", GMAT_PIX_FMT_YUV420P16LE}, {"yuv420p10le", GMAT_PIX_FMT_YUV420P10LE}, {"rgb0", GMAT_PIX_FMT_RGB0}, {"bgr0", GMAT_PIX_FMT_BGR0}, {"0bgr32", GMAT_PIX_FMT_RGB0}, {"0rgb32", GMAT_PIX_FMT_BGR0},
         {"rgbpf32le", GMAT_PIX_FMT_RGBPF32LE}, {"same", GMAT_PIX_FMT_NONE}};
     auto it = m.find(s);
     if (it != m.end()) return it->second;

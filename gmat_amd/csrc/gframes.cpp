@@ -72,6 +72,15 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
         }
         L.total = (size_t)3 * L.linesize[0] * h;
         return 0;
+    case GMAT_PIX_FMT_YUV420P16LE:
+    case GMAT_PIX_FMT_YUV420P10LE:
+        L.planes = 3;
+        L.linesize[0] = align_up(2 * w, align);
+        L.linesize[1] = L.linesize[2] = align_up(2 * ceil_rshift(w, 1), align);
+        L.offset[1] = (size_t)L.linesize[0] * h;
+        L.offset[2] = L.offset[1] + (size_t)L.linesize[1] * ceil_rshift(h, 1);
+        L.total = L.offset[2] + (size_t)L.linesize[2] * ceil_rshift(h, 1);
+        return 0;
     case GMAT_PIX_FMT_YUV444P16LE:
         L.planes = 3;
         for (int i = 0; i < 3; i++) {
@@ -94,7 +103,8 @@ int layout_for(int fmt, int w, int h, int align, PlaneLayout &L)
 
 int plane_rows(int fmt, int plane, int h)
 {
-    if ((fmt == GMAT_PIX_FMT_NV12 || fmt == GMAT_PIX_FMT_YUV420P || is_p01x(fmt)) && plane > 0) return ceil_rshift(h, 1);
+    if ((fmt == GMAT_PIX_FMT_NV12 || fmt == GMAT_PIX_FMT_YUV420P || is_p01x(fmt) || fmt == GMAT_PIX_FMT_YUV420P16LE ||
+         fmt == GMAT_PIX_FMT_YUV420P10LE) && plane > 0) return ceil_rshift(h, 1);
     return h;
 }
 
@@ -112,6 +122,8 @@ int plane_row_bytes(int fmt, int plane, int w)
     case GMAT_PIX_FMT_RGB0:
     case GMAT_PIX_FMT_BGR0:      return 4 * w;
     case GMAT_PIX_FMT_YUV444P16LE: return 2 * w;
+    case GMAT_PIX_FMT_YUV420P16LE:
+    case GMAT_PIX_FMT_YUV420P10LE: return plane == 0 ? 2 * w : 2 * ceil_rshift(w, 1);
     default:                     return w * bytes_per_pixel(fmt);
     }
 }

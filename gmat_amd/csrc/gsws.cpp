@@ -163,7 +163,7 @@ struct GmatSwsContext {
 };
 
 // sources of the single-context plane scaler: 8-bit planar / semi-planar YUV and the 16-bit semi-planar P010LE / P016LE
-static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f) || f == GMAT_PIX_FMT_YUV444P16LE; }
+static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f) || pl16_depth(f); }
 
 static int init_yuv_scaler(GmatSwsContext *c)
 {
@@ -202,7 +202,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
         a.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24; a.chrHalf = c->planYuv.chrSrcHSub;
         a.r2y = make_rgb2yuv_consts(c->colorspace);
     }
-    if (c->srcFormat == GMAT_PIX_FMT_YUV444P16LE) { a.src16 = 17; a.hShift = 15; a.hBias = 1 << 29; }
+    if (pl16_depth(c->srcFormat) == 16) { a.src16 = 17; a.hShift = 15; a.hBias = 1 << 29; }     // planar, any chroma subsampling
+    if (pl16_depth(c->srcFormat) == 10) { a.src16 = 18; a.hShift = 9; a.hBias = 0; }            // 10 bits in the low end: as they are
     if (is_p01x(c->srcFormat)) {
         a.src16 = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : 16;
         a.hShift = a.src16 - 1;                          // hScale16To15_c: sh = depth - 1 (swscale.c:93-119)
@@ -313,7 +314,7 @@ static int init_scale16(GmatSwsContext *c)
 static int ensure_scaler(GmatSwsContext *c)
 {
     if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) ||
-        c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
+        c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat) || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
     }
@@ -360,7 +361,7 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     if (ya.src16 == 3) {
         ya.u = ya.v = nullptr; ya.us = ya.vs = 0;
         ya.srcAligned = al4(src[0], srcStride[0]); ya.srcAligned16 = 0;        // 12-byte pixel groups as three dwords
-    } else if (ya.src16 == 17) {
+    } else if (ya.src16 >= 17) {
         if (!src[2] || (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)src[2] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1] | (uintptr_t)srcStride[2]) & 1) != 0)
             return GMAT_ERR(EINVAL);
         ya.v = src[2]; ya.vs = srcStride[2];
@@ -576,7 +577,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
-    const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
+    const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
@@ -727,9 +728,9 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         r = ensure_scaler(c);
     } else if (same && is_p01x(srcFormat) && srcFormat == dstFormat) {
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
-    } else if (same && srcFormat == GMAT_PIX_FMT_YUV444P16LE && dstFormat == srcFormat) {
+    } else if (same && pl16_depth(srcFormat) && dstFormat == srcFormat) {
         c->mode = MODE_PLANECOPY;
-    } else if ((is_plane_src(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV444P16LE) && is_dst16(dstFormat)) {
+    } else if (is_plane_src(srcFormat) && is_dst16(dstFormat)) {
         // 16-bit destination: 19-bit intermediates, the two-pass path of k_scale16.hip (equal-size 8-bit 4:2:0 sources were
         // taken above as the depth expansion, equal format as the plane copy)
         c->mode = MODE_SCALE16;
@@ -739,7 +740,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         // yuv2p010lX_c / yuv2p010cX_c (output.c:459-519).  Equal-size 8-bit 4:2:0 sources were taken above (MODE_DEPTH).
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
-    } else if ((is_p01x(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV444P16LE) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
+    } else if ((is_p01x(srcFormat) || pl16_depth(srcFormat)) && (is_packed_rgb(dstFormat) || is_yuv8_src(dstFormat))) {
         // 16-bit semi-planar sources (scale_cuda's list, vf_scale_cuda.c:45-54) to any 8-bit destination, any size:
         // libswscale has no special converter for them, the generic path's hScale16To15_c brings the samples to the
         // same 15-bit lines an 8-bit source gives
@@ -848,7 +849,7 @@ int gmat_sws_setFused(GmatSwsContext *c, int fused)
 {
     if (!c || fused < 0 || fused > 2) return GMAT_ERR(EINVAL);
     if (c->inner) return gmat_sws_setFused(c->inner, fused);
-    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE || is_p01x(c->srcFormat) || c->rgbViaPlanes) && fused != 2) return GMAT_ERR(ENOSYS);
+    if ((c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat) || is_p01x(c->srcFormat) || c->rgbViaPlanes) && fused != 2) return GMAT_ERR(ENOSYS);
     c->fused = fused;
     if (c->mode == MODE_SCALE) return ensure_scaler(c);
     return 0;
@@ -905,7 +906,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         }
     }
     c->lastLaunchFrames = 1;
-    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
+    const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     if (is_plane_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
     int r = 0;
@@ -964,12 +965,12 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const bool rgb64 = is_rgb64(c->dstFormat);
         if (!rgb64 && !dst[1]) { r = GMAT_ERR(EINVAL); break; }
         const ScalePlan &p = c->plan16;
-        const bool pl16 = c->srcFormat == GMAT_PIX_FMT_YUV444P16LE;
+        const bool pl16 = pl16_depth(c->srcFormat) != 0;
         const bool s16 = is_p01x(c->srcFormat) || pl16;
         const int odd = s16 ? 1 : 0;
         if ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0] | (rgb64 ? 0 : ((uintptr_t)dst[1] | (uintptr_t)dstStride[1]))) & 1) != 0 ||
             (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
-        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : s16 ? 16 : 0;
+        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : pl16_depth(c->srcFormat) == 10 ? 110 : s16 ? 16 : 0;
         const int bps = s16 ? 2 : 1;
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
@@ -1001,9 +1002,11 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if (!src[1] || !dst[1]) { r = GMAT_ERR(EINVAL); break; }
         c->lastKernel = "copy2d_kernel";
         r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], 2 * c->srcW, c->srcH, c->stream);
-        if (c->srcFormat == GMAT_PIX_FMT_YUV444P16LE) {
+        if (pl16_depth(c->srcFormat)) {
             if (!src[2] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
-            for (int i = 1; i < 3 && r >= 0; i++) r = launch_copy2d(src[i], srcStride[i], dst[i], dstStride[i], 2 * c->srcW, c->srcH, c->stream);
+            const int sub = c->srcFormat == GMAT_PIX_FMT_YUV444P16LE ? 0 : 1;
+            const int cw = (c->srcW + sub) >> sub, ch = (c->srcH + sub) >> sub;
+            for (int i = 1; i < 3 && r >= 0; i++) r = launch_copy2d(src[i], srcStride[i], dst[i], dstStride[i], 2 * cw, ch, c->stream);
             break;
         }
         if (r >= 0) r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], 4 * ((c->srcW + 1) / 2), (c->srcH + 1) / 2, c->stream);

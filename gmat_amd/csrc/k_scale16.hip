@@ -18,7 +18,8 @@
 
 namespace gmat {
 
-// kind: 0 = 8-bit samples, sample stride `step` bytes; 10 / 16 = 16-bit samples (P010: >> 6), sample stride `step` bytes
+// kind: 0 = 8-bit samples, sample stride `step` bytes; 10 / 16 = 16-bit samples (P010: >> 6), sample stride `step` bytes;
+//       110 = 16-bit containers holding 10 bits in the low end (YUV420P10LE): as they are, sh of a 10-bit source
 __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH,
                                                        DevFilter f, int32_t *dst, int dstW, int sh)
 {
@@ -121,7 +122,7 @@ int launch_hscale19(const uint8_t *src, int ss, int kind, int step, int srcW, in
                     hipStream_t stream)
 {
     if (dstW <= 0 || srcH <= 0) return 0;
-    const int sh = kind == 0 ? 3 : kind - 5;                  // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4
+    const int sh = kind == 0 ? 3 : kind % 100 - 5;                  // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4
     const dim3 grid((dstW + 255) / 256, srcH), block(256);
     hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh);
     GMAT_HIP_CHECK(hipGetLastError());

@@ -269,8 +269,9 @@ __device__ __forceinline__ void yuv_phase1_src16(const YuvScaleArgs &a, int tid,
                                                  int c0C, int ncC, int r0C, int nrC, unsigned short *ly,
                                                  unsigned short *lu, unsigned short *lv)
 {
-    const bool p010 = a.src16 == 10;                         // 16 (P016LE) and 17 (YUV444P16LE): the samples as they are
-    auto conv = [&](unsigned v) -> unsigned { return p010 ? (v >> 6) & 0x03FF03FFu : v ^ 0x80008000u; };   // both halves at once
+    const bool p010 = a.src16 == 10;                         // 16 (P016LE) and 17 (planar 16-bit): the samples as they are
+    const bool pl10 = a.src16 == 18;                         // planar 10-bit (YUV420P10LE): as they are, and they fit int16
+    auto conv = [&](unsigned v) -> unsigned { return p010 ? (v >> 6) & 0x03FF03FFu : pl10 ? v : v ^ 0x80008000u; };   // both halves at once
     {
         const int ng = ncL >> 1, total = nrL * ng;           // items of 2 luma samples
         for (int it = tid; it < total; it += 256) {
@@ -293,7 +294,7 @@ __device__ __forceinline__ void yuv_phase1_src16(const YuvScaleArgs &a, int tid,
             const int r = it / ng, cg = it - r * ng, cc = c0C + 2 * cg;
             const uint8_t *row = a.u + (size_t)min(r0C + r, a.chrSrcH - 1) * a.us;
             unsigned p0, p1;                                    // U | V << 16 of chroma samples cc, cc + 1
-            if (a.src16 == 17) {                                // planar 16-bit 4:4:4: U and V planes of 16-bit samples
+            if (a.src16 >= 17) {                                // planar: U and V planes of 16-bit samples
                 const uint8_t *rowv = a.v + (size_t)min(r0C + r, a.chrSrcH - 1) * a.vs;
                 const int k0 = min(cc, a.chrSrcW - 1), k1 = min(cc + 1, a.chrSrcW - 1);
                 p0 = *reinterpret_cast<const unsigned short *>(row + 2 * k0) | ((unsigned)*reinterpret_cast<const unsigned short *>(rowv + 2 * k0) << 16);
@@ -671,7 +672,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     const bool out10 = p.dstFormat == GMAT_PIX_FMT_P010LE;                   // 4:2:0 with 16-bit stores
     const int yuvOut = (is_yuv420(p.dstFormat) || out10) ? 1 : out444 ? 2 : 0;   // 1: 4:2:0   2: planar 4:4:4
     const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // only towards YUV destinations
-    const bool pl16 = p.srcFormat == GMAT_PIX_FMT_YUV444P16LE;
+    const bool pl16 = pl16_depth(p.srcFormat) != 0;
     if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat) || pl16 || (rgbSrc && yuvOut)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (rgbSrc && (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs)) return GMAT_ERR(ENOSYS);
     if (is_p01x(p.srcFormat) || pl16) {

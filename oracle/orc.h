@@ -66,6 +66,8 @@ enum {
     ORC_PIX_P010LE  = 159,
     ORC_PIX_P016LE  = 170,
     ORC_PIX_YUV444P16LE = 49,
+    ORC_PIX_YUV420P16LE = 45,       /* planar 4:2:0, 16-bit containers: sources only (swscale_cuda.c:34-44 lists both) */
+    ORC_PIX_YUV420P10LE = 62,       /* 10 significant bits in the LOW end of each sample */
     ORC_PIX_RGBA64LE = 105,
     ORC_PIX_BGRA64LE = 107,
     ORC_PIX_RGBPF32LE = 179,

@@ -48,7 +48,10 @@ static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
 static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
 static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || is_rgb64(f); }   /* 19-bit lines */
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
-static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || is_p01x(f)) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
+/* planar YUV in 16-bit containers, native endian: no input converter (input.c:1523-1528 is HAVE_BIGENDIAN only), the
+ * samples go to hScale16To15_c / hScale16To19_c as they are with sh derived from the depth (swscale.c:93-119,:63-91) */
+static int pl16_depth(int f) { return f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE ? 16 : f == ORC_PIX_YUV420P10LE ? 10 : 0; }
+static int fmt_sub(int f) { return (f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || is_p01x(f) || f == ORC_PIX_YUV420P16LE || f == ORC_PIX_YUV420P10LE) ? 1 : 0; }   /* log2_chroma_w == log2_chroma_h here */
 static unsigned rl16(const uint8_t *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
 static int ceil_rshift(int a, int b) { return -((-a) >> b); }
 static int clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
@@ -142,7 +145,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
 
     /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
      * P016LE switches to the 19-bit ones (scale_to_p016 below) */
-    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || src_fmt == ORC_PIX_YUV444P16LE) ||
+    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
         !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt)))
         return NULL;
     if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
@@ -314,11 +317,11 @@ static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int str
                                  (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
         }
         hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 13);
-    } else if (c->src_fmt == ORC_PIX_YUV444P16LE) {
-        /* native-endian 16-bit planar samples need no input converter; hScale16To15_c with sh = 15 */
+    } else if (pl16_depth(c->src_fmt)) {
+        /* native-endian 16-bit planar samples need no input converter; hScale16To15_c with sh = depth - 1 */
         int i;
         for (i = 0; i < c->src_w; i++) tmp[i] = (uint16_t)rl16(row + 2 * i);
-        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 15);
+        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, pl16_depth(c->src_fmt) - 1);
     } else if (is_p01x(c->src_fmt)) {
         /* p010LEToY_c (input.c:698-705): the 10 significant bits are the high ones, >> 6; P016LE has no converter
          * on a little-endian host (input.c:1523-1528 sits under HAVE_BIGENDIAN): the 16-bit samples as they are.
@@ -367,13 +370,13 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
         }
         hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
         hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
-    } else if (c->src_fmt == ORC_PIX_YUV444P16LE) {
+    } else if (pl16_depth(c->src_fmt)) {
         for (i = 0; i < c->chr_src_w; i++) {
             tmp_u[i] = (uint16_t)rl16(src[1] + (long)y * stride[1] + 2 * i);
             tmp_v[i] = (uint16_t)rl16(src[2] + (long)y * stride[2] + 2 * i);
         }
-        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
-        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
+        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, pl16_depth(c->src_fmt) - 1);
+        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, pl16_depth(c->src_fmt) - 1);
     } else if (is_p01x(c->src_fmt)) {
         /* p010LEToUV_c / p016LEToUV_c (input.c:716-747): interleaved 16-bit U, V */
         const uint8_t *row = src[1] + (long)y * stride[1];
@@ -641,9 +644,9 @@ static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, in
 static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], int32_t **pl, int32_t **pu, int32_t **pv)
 {
     const int dw = c->dst_w, cdw = c->chr_dst_w, sh8 = 3;
-    const int pl16 = c->src_fmt == ORC_PIX_YUV444P16LE;      /* planar 16-bit samples, read as they are (native endian) */
+    const int pl16 = pl16_depth(c->src_fmt) != 0;            /* planar 16-bit containers, read as they are (native endian) */
     const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
-    const int sh = (src16 || pl16) ? (p010 ? 10 : 16) - 5 : sh8;
+    const int sh = pl16 ? pl16_depth(c->src_fmt) - 5 : src16 ? (p010 ? 10 : 16) - 5 : sh8;
     int32_t *ly = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h);
     int32_t *lu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
     int32_t *lv = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);

@@ -139,6 +139,8 @@ def plane_shapes(fmt, w, h):
         return [(h, w)] * 3
     if fmt == "yuv444p16le":
         return [(h, 2 * w)] * 3
+    if fmt in ("yuv420p16le", "yuv420p10le"):
+        return [(h, 2 * w)] + [((h + 1) // 2, 2 * ((w + 1) // 2))] * 2
     if fmt == "rgbpf32le":
         return [(h, 4 * w)] * 3
     if fmt in ("p010le", "p016le"):

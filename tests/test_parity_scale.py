@@ -515,6 +515,52 @@ def test_yuv444p16_source_to_8bit_and_p010(dev, orc, dst_fmt, geom):
             p.free()
 
 
+def _synth_hi420(orc, fmt, w, h, seed):
+    src = synth_planes(orc, fmt, w, h, seed=seed)
+    if fmt == "yuv420p10le":                              # valid input: 10 significant bits in the low end
+        for p in src:
+            p.view("<u2")[...] &= 0x3FF
+    return src
+
+
+@pytest.mark.parametrize("src_fmt", ["yuv420p10le", "yuv420p16le"])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p", "rgb24", "bgra", "p010le", "p016le", "yuv444p16le", "rgba64le"])
+@pytest.mark.parametrize("geom", [(128, 48, 64, 24), (96, 40, 144, 60), (101, 45, 75, 33), (70, 22, 70, 22)])
+def test_planar_high_depth_420_sources(dev, orc, src_fmt, dst_fmt, geom):
+    """swscale_cuda's planar high-depth 4:2:0 sources (swscale_cuda.c:34-44): no input converter on a little-endian host,
+    hScale16To15_c with sh = depth - 1 (15-bit lines) or hScale16To19_c with sh = depth - 5 (19-bit lines) per plane"""
+    sw, sh, dw, dh = geom
+    src = _synth_hi420(orc, src_fmt, sw, sh, 83)
+    want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"])
+    for align, extra in ((64, 0), (2, 2)):
+        d = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (i, kernel)
+            assert (pads[i] == 0xCD).all()
+        for p in d:
+            p.free()
+
+
+@pytest.mark.parametrize("fmt", ["yuv420p10le", "yuv420p16le"])
+def test_planar_high_depth_420_equal_format_and_size_is_a_plane_copy(dev, orc, fmt):
+    w, h = 71, 23
+    src = _synth_hi420(orc, fmt, w, h, 84)
+    d = dev.upload_planes(src, 2, 2)
+    got, pads, kernel = dev.sws(d, w, h, fmt, w, h, fmt, SWS["bicubic"], dst_align=2, dst_extra=2)
+    assert kernel == "copy2d_kernel"
+    for g, s_, pd in zip(got, src, pads):
+        assert (g == s_).all() and (pd == 0xCD).all()
+    for p in d:
+        p.free()
+
+
+def test_planar_high_depth_420_are_sources_only(dev):
+    for df in ("yuv420p10le", "yuv420p16le"):
+        assert not dev.lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 32, 16, PIX_FMT[df], SWS["bicubic"], None)
+        assert not dev.lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
+
+
 @pytest.mark.parametrize("fmt", ["p010le", "p016le"])
 def test_p01x_equal_format_and_size_is_a_plane_copy(dev, orc, fmt):
     w, h = 70, 22
