@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -577,6 +578,145 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
     return 0;
 }
 
+// ---- the 1 2 1 / 2 4 2 / 1 2 1 smooth without a source tile in LDS ----------------------------------------------------
+// smooth_hip's default matrix (rdiv 1/16, bias 0) is separable: out = (v121(h121(x)) + 8) >> 4, the same integer the
+// general kernel sums.  A lane owns one DWORD column of a 48-dword tile (lanes 1..48; lanes 0 and 49 carry the halo
+// dwords), a wave 16 output rows: it loads its 18 source rows straight from global memory (all loads in flight at once,
+// 200 contiguous bytes per instruction), splits every dword into its even and odd bytes as two 16-bit fields (v_perm_b32)
+// and does the arithmetic on both fields of a register at once — the sums stay below 4096, ordinary 32-bit adds never
+// carry across.  The vertical sum comes first (registers only); the horizontal neighbours of a byte sit BPP bytes away,
+// i.e. in the neighbouring lanes' registers: wave-wide DPP shifts (v_mov_b32 wave_shr:1 / wave_shl:1) and a funnel shift
+// bring them in.  vf_convolution's borders (index -1 -> 1, index n -> n-1, :555-569) are a clamp of the row index
+// (scalar) and, in the tiles on the left / right frame edge, a halo dword assembled from lanes 1, 2 / the last lane.
+// TRANSPOSED (rotate 90 + hflip, see launch_rotate_flip_smooth): results go byte-wise into a transposed LDS tile (odd
+// dword pitch), one block barrier, then rows of TH * BPP bytes leave as dwordx4 stores.  LDS 12.5 KB, <= 64 VGPRs: the
+// 2040 tiles of a 4K frame are all resident at once (8 blocks per CU).
+template <int BPP, bool TRANSPOSED, int TD>
+__global__ __launch_bounds__(256) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16)
+{
+    constexpr int TH = 64, RPW = 16, NS = RPW + 2;          // tile: TD dwords x 64 rows; rows per wave; source rows per wave
+    static_assert(TD + 2 <= 64 && (TD * 4) % BPP == 0, "tile width: whole pixels, two halo lanes");
+    constexpr int TWP = TD * 4 / BPP;                       // tile width in pixels
+    constexpr int PT = TH * BPP + 4;                        // transposed tile pitch: 49 / 65 dwords (odd)
+    static_assert(!TRANSPOSED || ((PT / 4) & 1), "odd dword pitch");
+    __shared__ __attribute__((aligned(16))) uint8_t rt[TRANSPOSED ? TWP * PT + 256 : 16];      // + the pad of the idle lanes
+    const int rowDwords = (w * BPP) >> 2;
+    int tbx, tby;
+    {   // XCD-aware tile order, as conv3x3_kernel
+        const int nbx = (rowDwords + TD - 1) / TD, nby = (h + TH - 1) / TH, ntiles = nbx * nby;
+        const int chunk = (ntiles + 7) >> 3;
+        const int t = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if (t >= ntiles) return;
+        if (TRANSPOSED) { tbx = t / nby; tby = t - tbx * nby; }
+        else            { tby = t / nbx; tbx = t - tby * nbx; }
+    }
+    const int d0 = tbx * TD, nd = min(TD, rowDwords - d0);  // first dword and dword count of the tile
+    const int y0 = tby * TH, th = min(TH, h - y0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int r0 = wave * RPW, nrows = min(RPW, th - r0);   // wave-uniform
+    const int di = lane - 1;                                // this lane's dword of the tile; -1 and nd are the halos
+    if (nrows > 0) {
+        const unsigned colOff = 4u * (unsigned)min(max(d0 + di, 0), rowDwords - 1);
+        unsigned wv[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            int yy = y0 + r0 + s - 1;
+            yy = yy < 0 ? -yy : yy;
+            yy = yy >= h ? 2 * h - 1 - yy : yy;
+            yy = min(max(yy, 0), h - 1);
+            wv[s] = *reinterpret_cast<const unsigned *>(src + ((unsigned)(yy * ss) + colOff));
+        }
+        if (d0 == 0) {                                      // pixel -1 := pixel 1
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)wv[s], 1), b = (unsigned)__builtin_amdgcn_readlane((int)wv[s], 2);
+                const unsigned halo = BPP == 1 ? a << 16 : BPP == 2 ? a : BPP == 3 ? (a >> 16) | (b << 16) : b;
+                wv[s] = lane == 0 ? halo : wv[s];
+            }
+        }
+        if (d0 + nd == rowDwords) {                         // pixel w := pixel w - 1
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)wv[s], nd);
+                wv[s] = lane == nd + 1 ? last >> (8 * (4 - BPP)) : wv[s];
+            }
+        }
+        // per-lane LDS pointers of the 4 result bytes (transposed store): pixel row * PT + channel; lanes outside the tile
+        // write into a pad behind it (one dword each: no bank conflicts, no exec masking around the stores)
+        const bool mine = di >= 0 && di < nd;
+        uint8_t *pj[4] = {rt, rt, rt, rt};
+        if (TRANSPOSED) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int cb = 4 * max(di, 0) + j, px = cb / BPP;
+                pj[j] = rt + (mine ? px * PT + (cb - px * BPP) + r0 * BPP : TWP * PT + 4 * lane);
+            }
+        }
+        auto rows = [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;    // all 16 rows of the wave exist: no per-row test
+            unsigned e0 = __builtin_amdgcn_perm(0u, wv[0], 0x0C020C00u), o0 = __builtin_amdgcn_perm(0u, wv[0], 0x0C030C01u);
+            unsigned e1 = __builtin_amdgcn_perm(0u, wv[1], 0x0C020C00u), o1 = __builtin_amdgcn_perm(0u, wv[1], 0x0C030C01u);
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const unsigned e2 = __builtin_amdgcn_perm(0u, wv[r + 2], 0x0C020C00u), o2 = __builtin_amdgcn_perm(0u, wv[r + 2], 0x0C030C01u);
+                if (FULL || r < nrows) {
+                    const unsigned ve = e0 + 2 * e1 + e2, vo = o0 + 2 * o1 + o2;
+                    // the neighbouring lanes' sums; lanes 0 / 63 have no source and read 0 (bound_ctrl), neither is `mine`
+                    const unsigned vep = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ve, 0x138, 0xF, 0xF, true);   // lane - 1
+                    const unsigned vop = (unsigned)__builtin_amdgcn_update_dpp(0, (int)vo, 0x138, 0xF, 0xF, true);
+                    const unsigned ven = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ve, 0x130, 0xF, 0xF, true);   // lane + 1
+                    const unsigned von = (unsigned)__builtin_amdgcn_update_dpp(0, (int)vo, 0x130, 0xF, 0xF, true);
+                    unsigned le, lo, re, ro;                // the fields BPP bytes to the left / right of the even / odd bytes
+                    if (BPP == 1)      { le = (vop >> 16) | (vo << 16); lo = ve;                       re = vo;                        ro = (ve >> 16) | (ven << 16); }
+                    else if (BPP == 2) { le = (vep >> 16) | (ve << 16); lo = (vop >> 16) | (vo << 16); re = (ve >> 16) | (ven << 16);  ro = (vo >> 16) | (von << 16); }
+                    else if (BPP == 3) { le = vop;                      lo = (vep >> 16) | (ve << 16); re = (vo >> 16) | (von << 16);  ro = ven; }
+                    else               { le = vep;                      lo = vop;                      re = ven;                       ro = von; }
+                    const unsigned he = (le + 2 * ve + re + 0x00080008u) >> 4, ho = (lo + 2 * vo + ro + 0x00080008u) >> 4;
+                    if (TRANSPOSED) {
+                        if (BPP == 4) {
+                            *reinterpret_cast<unsigned *>(pj[0] + r * 4) = __builtin_amdgcn_perm(ho, he, 0x06020400u);
+                        } else {
+                            pj[0][r * BPP] = (uint8_t)he; pj[2][r * BPP] = (uint8_t)(he >> 16);
+                            pj[1][r * BPP] = (uint8_t)ho; pj[3][r * BPP] = (uint8_t)(ho >> 16);
+                        }
+                    } else if (mine) {
+                        *reinterpret_cast<unsigned *>(dst + ((unsigned)((y0 + r0 + r) * ds) + 4u * (unsigned)(d0 + di))) = __builtin_amdgcn_perm(ho, he, 0x06020400u);
+                    }
+                }
+                e0 = e1; o0 = o1; e1 = e2; o1 = o2;
+            }
+        };
+        if (nrows == RPW) rows(std::true_type());
+        else              rows(std::false_type());
+    }
+    if (!TRANSPOSED) return;
+    __syncthreads();
+    // rows of the transposed tile: pixel column px of the source tile -> destination row x0 + px, bytes [y0*BPP, +th*BPP)
+    const int npx = nd * 4 / BPP, x0 = d0 * 4 / BPP, nbytes = th * BPP;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (dst16 && (nbytes & 15) == 0) {
+        const int cpr = nbytes >> 4;                        // 16-byte chunks per row (<= 16)
+        for (int px = ty; px < npx; px += 16) {
+            if (tx < cpr) {
+                const unsigned *l = reinterpret_cast<const unsigned *>(rt + px * PT + 16 * tx);
+                *reinterpret_cast<uint4 *>(dst + (size_t)(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx) = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+        }
+    } else {
+        for (int px = ty; px < npx; px += 16)
+            lds_to_row(dst + (size_t)(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, 16, (y0 * BPP & 3) == 0);
+    }
+}
+
+// the separable kernel's conditions: rows of whole dwords, dword-aligned pointers and pitches, at least 4 pixels a row
+static bool smooth121_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp)
+{
+    const bool off = getenv("GMAT_NO_SMOOTH121") != nullptr;                        // A/B switch for the benches and tests
+    return !off && bpp >= 1 && bpp <= 4 && ((w * bpp) & 3) == 0 && w >= 4 && al4(src, ss, dst, ds) && (int64_t)ss * h < (1ll << 31) &&
+           (int64_t)ds * std::max(w, h) < (1ll << 31);
+}
+
 int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, const int m[9],
                    float rdiv, float bias, hipStream_t stream)
 {
@@ -588,6 +728,20 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     cp.shift = -1; cp.half = 0;
     for (int k = 0; k <= 16 && fast; k++)
         if (bias == 0.0f && rdiv == 1.0f / (float)(1 << k)) { cp.shift = k; cp.half = k ? 1u << (k - 1) : 0u; }
+    static const int m121[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+    if (cp.shift == 4 && std::memcmp(m, m121, sizeof(m121)) == 0 && smooth121_ok(src, ss, dst, ds, w, h, bpp)) {
+        const int td = bpp == 3 ? 60 : 62;                   // tile width in dwords: whole pixels (60 dwords = 80 rgb24 pixels)
+        const int nt = ((w * bpp / 4 + td - 1) / td) * ((h + 63) / 64);
+        const dim3 g(8 * ((nt + 7) / 8)), b(256);
+        switch (bpp) {
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int TW = bpp <= 2 ? 128 : 64;
     const int ntiles = ((w + TW - 1) / TW) * ((h + 63) / 64);
     const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);
@@ -930,6 +1084,16 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
     const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
     for (int i = 0; i < 9; i++) cp.m[i] = m[i];
     cp.rdiv = 1.0f / 16.0f; cp.bias = 0.0f; cp.shift = 4; cp.half = 8;
+    if ((bpp == 3 || bpp == 4) && smooth121_ok(src, ss, dst, ds, inW, inH, bpp)) {
+        const int td = bpp == 3 ? 60 : 62;
+        const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
+        const dim3 g(8 * ((nt + 7) / 8)), b(256);
+        const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int fast = 1;
     const int ntiles = ((inW + 63) / 64) * ((inH + 63) / 64);
     const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);

@@ -55,6 +55,8 @@ void block_sync();
 void wave_sync();
 int shfl_xor(int v, int mask);
 int readfirstlane(int v);
+int lane_read(int v, int srcLane);
+int dpp_wave_shift(int old, int v, int ctrl);
 void *dyn_lds();
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -92,6 +94,8 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __shfl_xor(v, m) hipemu::shfl_xor((int)(v), (m))
 #define __builtin_amdgcn_readfirstlane(v) hipemu::readfirstlane((int)(v))
+#define __builtin_amdgcn_readlane(v, l) hipemu::lane_read((int)(v), (l))
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) hipemu::dpp_wave_shift((int)(old), (int)(v), (ctrl))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu::sdot2(a, b, c)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
 #define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu::cvt_pk_i16(a, b)

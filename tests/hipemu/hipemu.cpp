@@ -116,6 +116,30 @@ int shfl_xor(int v, int mask)
     wave_sync();
     return r;
 }
+// v_readlane_b32 and the wave-wide DPP shifts (wave_shr:1 = 0x138: lane i takes lane i-1; wave_shl:1 = 0x130: lane i takes
+// lane i+1; a lane without a source keeps `old`).  Every live lane of the wave calls it, like shfl_xor.
+int lane_read(int v, int srcLane)
+{
+    const int me = cur;
+    shfl_slot[me] = v;
+    wave_sync();
+    const int src = (me & ~63) | (srcLane & 63);
+    const int r = src < (int)fibers.size() ? shfl_slot[src] : 0;
+    wave_sync();
+    return r;
+}
+int dpp_wave_shift(int old, int v, int ctrl)
+{
+    const int me = cur, lane = me & 63;
+    shfl_slot[me] = v;
+    wave_sync();
+    int r = old;
+    if (ctrl == 0x138 && lane > 0) r = shfl_slot[me - 1];
+    else if (ctrl == 0x130 && lane < 63 && me + 1 < (int)fibers.size()) r = shfl_slot[me + 1];
+    else if (ctrl != 0x138 && ctrl != 0x130) abort();
+    wave_sync();
+    return r;
+}
 void *dyn_lds() { return lds_ptr; }
 
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem)

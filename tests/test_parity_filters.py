@@ -1,6 +1,8 @@
 """crop / flip / transpose / rotate / smooth kernels and the AVFilter-shaped layer vs the oracle."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -53,9 +55,22 @@ def test_flip(dev, orc, w, h, bpp, code):
         d.free(); o.free()
 
 
-@pytest.mark.parametrize("w,h", SIZES + [(300, 5)])
+@pytest.fixture(params=["separable", "general"])
+def smooth_kern(request):
+    """the 1 2 1 / 2 4 2 / 1 2 1 matrix on dword-aligned frames takes smooth121_kernel; GMAT_NO_SMOOTH121 keeps the general
+    conv3x3_kernel (the path of every other matrix and of unaligned frames) so both are compared with the oracle"""
+    old = os.environ.pop("GMAT_NO_SMOOTH121", None)
+    if request.param == "general":
+        os.environ["GMAT_NO_SMOOTH121"] = "1"
+    yield request.param
+    os.environ.pop("GMAT_NO_SMOOTH121", None)
+    if old is not None:
+        os.environ["GMAT_NO_SMOOTH121"] = old
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(300, 5), (256, 130), (196, 17), (4, 1), (8, 200), (52, 64)])
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4])
-def test_smooth3x3(dev, orc, w, h, bpp):
+def test_smooth3x3(dev, orc, w, h, bpp, smooth_kern):
     src = orc.lcg((h, w * bpp), 8)
     m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
     want = _orc_out(h, w * bpp)
@@ -81,10 +96,10 @@ def test_conv3x3_general_matrix_and_rounding(dev, orc):
     assert (o.download() == want).all()
 
 
-@pytest.mark.parametrize("w,h", [(64, 64), (200, 70), (67, 129), (3, 2)])
-def test_rotate_flip_smooth_fused_equals_three_filters(dev, orc, w, h):
+@pytest.mark.parametrize("w,h", [(64, 64), (200, 70), (67, 129), (3, 2), (256, 130), (196, 17), (4, 1), (8, 200), (52, 64), (128, 48)])
+@pytest.mark.parametrize("bpp", [3, 4])
+def test_rotate_flip_smooth_fused_equals_three_filters(dev, orc, w, h, bpp, smooth_kern):
     """cfg4: transpose(clock) -> hflip -> 3x3 smooth as three oracle filters == one fused kernel."""
-    bpp = 3
     src = orc.lcg((h, w * bpp), 9)
     a = _orc_out(w, h * bpp)
     orc.L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)

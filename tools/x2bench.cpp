@@ -113,6 +113,47 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
     for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); }
 }
 
+// one frame per launch of a pixel filter on packed 4K frames: BASELINE configs[3] (rotate 90 + hflip + 3x3 smooth as one kernel)
+// and its parts.  GMAT_NO_SMOOTH121=1 selects the general 3x3 kernel instead of the separable one.
+static void run_op(const char *label, int op, int w, int h, int bpp, int launches)
+{
+    const size_t nb = (size_t)w * h * bpp;
+    const int NSET = 12;
+    std::vector<uint8_t *> src(NSET), dst(NSET);
+    std::vector<uint8_t> host(nb);
+    fill_lcg(host);
+    for (int i = 0; i < NSET; i++) {
+        CK(gmat_malloc(&src[i], nb)); CK(gmat_malloc(&dst[i], nb));
+        CK(gmat_memcpy_h2d(src[i], host.data(), nb)); CK(gmat_memset(dst[i], 0, nb));
+    }
+    void *stream = nullptr; CK(gmat_stream_create(&stream));
+    const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+    auto launch = [&](int i) {
+        switch (op) {
+        case 0: CK(gmat_rotate_flip_smooth(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, stream)); break;
+        case 1: CK(gmat_smooth3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, m, 1.0f / 16, 0.0f, stream)); break;
+        case 2: CK(gmat_transpose(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, 0, stream)); break;
+        case 3: CK(gmat_flip(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, 1, stream)); break;
+        }
+    };
+    for (int i = 0; i < NSET; i++) launch(i);
+    CK(gmat_stream_sync(stream));
+    void *timer = nullptr; CK(gmat_timer_create(&timer));
+    float best = 1e30f;
+    for (int r = 0; r < 3; r++) {
+        CK(gmat_timer_begin(timer, stream));
+        for (int i = 0; i < launches; i++) launch(i % NSET);
+        CK(gmat_timer_end(timer, stream));
+        float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
+        best = ms < best ? ms : best;
+    }
+    const double us = best * 1e3 / launches, gbs = 2.0 * nb / us / 1e3;
+    printf("%-34s %8.2f us/frame %8.1f GB/s  frac %.3f\n", label, us, gbs, gbs / 8000.0);
+    fflush(stdout);
+    gmat_timer_destroy(timer); gmat_stream_destroy(stream);
+    for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); }
+}
+
 int main(int argc, char **argv)
 {
     const int NF = argc > 1 ? atoi(argv[1]) : 32, launches = argc > 2 ? atoi(argv[2]) : 40;
@@ -131,6 +172,11 @@ int main(int argc, char **argv)
         {"rgb24 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p bgra bilinear", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BILINEAR},
     };
+    struct Op { const char *label; int op, bpp; };
+    const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
+                      {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3}};
+    for (const Op &o : ops)
+        if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
     for (const Case &k : cases)
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     return 0;
