@@ -591,10 +591,10 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
 // TRANSPOSED (rotate 90 + hflip, see launch_rotate_flip_smooth): results go byte-wise into a transposed LDS tile (odd
 // dword pitch), one block barrier, then rows of TH * BPP bytes leave as dwordx4 stores.  LDS 12.5 KB, <= 64 VGPRs: the
 // 2040 tiles of a 4K frame are all resident at once (8 blocks per CU).
-template <int BPP, bool TRANSPOSED, int TD>
-__global__ __launch_bounds__(256) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16)
+template <int BPP, bool TRANSPOSED, int TD, int RPW>
+__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16)
 {
-    constexpr int TH = 64, RPW = 16, NS = RPW + 2;          // tile: TD dwords x 64 rows; rows per wave; source rows per wave
+    constexpr int TH = 64, NS = RPW + 2, NT = 64 * TH / RPW;  // tile: TD dwords x 64 rows; RPW rows per wave; source rows per wave; threads
     static_assert(TD + 2 <= 64 && (TD * 4) % BPP == 0, "tile width: whole pixels, two halo lanes");
     constexpr int TWP = TD * 4 / BPP;                       // tile width in pixels
     constexpr int PT = TH * BPP + 4;                        // transposed tile pitch: 49 / 65 dwords (odd)
@@ -697,14 +697,14 @@ __global__ __launch_bounds__(256) void smooth121_kernel(const uint8_t *src, int 
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     if (dst16 && (nbytes & 15) == 0) {
         const int cpr = nbytes >> 4;                        // 16-byte chunks per row (<= 16)
-        for (int px = ty; px < npx; px += 16) {
+        for (int px = ty; px < npx; px += NT / 16) {
             if (tx < cpr) {
                 const unsigned *l = reinterpret_cast<const unsigned *>(rt + px * PT + 16 * tx);
                 *reinterpret_cast<uint4 *>(dst + (size_t)(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx) = make_uint4(l[0], l[1], l[2], l[3]);
             }
         }
     } else {
-        for (int px = ty; px < npx; px += 16)
+        for (int px = ty; px < npx; px += NT / 16)
             lds_to_row(dst + (size_t)(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, 16, (y0 * BPP & 3) == 0);
     }
 }
@@ -734,10 +734,10 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
         const int nt = ((w * bpp / 4 + td - 1) / td) * ((h + 63) / 64);
         const dim3 g(8 * ((nt + 7) / 8)), b(256);
         switch (bpp) {
-        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
         }
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1089,8 +1089,9 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
         const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
         const dim3 g(8 * ((nt + 7) / 8)), b(256);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
-        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
+        // rgb24: 8 rows per wave (512 threads a tile) measured 2-3 % ahead of 16 (14.2 vs 14.5 us per 4K frame)
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
