@@ -407,6 +407,34 @@ def other_configs(lib, env, stream, geo, frames=16):
     return res
 
 
+def c_harness(dry):
+    """Per-call numbers from tools/bin/x2bench (C++ over the C ABI, built by __graft_entry__.build()): one frame per
+    gmat_sws_scale / filter call, timed with HIP events on the launch stream.  The Python loops above cannot issue a call
+    every few microseconds (the ctypes call costs about as much as the kernel), so their one-frame-per-call figures
+    are upper bounds of the call rate of THIS harness, not of the library; these are the library's."""
+    exe = os.path.join(ROOT, "tools", "bin", "x2bench")
+    if dry or not os.path.exists(exe):
+        return {"skipped": "dry run" if dry else "tools/bin/x2bench not built (run __graft_entry__.build())"}
+    env = dict(os.environ, X2BENCH_JSON="1", X2BENCH_VERIFY="0")
+    res = {"harness": "tools/x2bench.cpp, HIP events on the launch stream, best of 3 x 50 launches, 2 frame sets rotated"}
+    for nf, key in ((1, "one frame per call"), (32, "32 frames per launch")):
+        rows = []
+        try:
+            r = subprocess.run([exe, str(nf), "50", ""], env=env, capture_output=True, text=True, timeout=300)
+            for line in r.stdout.splitlines():
+                if line.startswith("{"):
+                    rows.append(json.loads(line))
+        except Exception as e:                               # noqa: BLE001 - a bench leg must not take the headline down
+            rows.append({"error": repr(e)})
+        res[key] = rows
+    try:
+        r = subprocess.run([exe, "1", "50", "op: "], env=env, capture_output=True, text=True, timeout=300)
+        res["filters, one 4K frame per launch"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]
+    except Exception as e:                                   # noqa: BLE001
+        res["filters, one 4K frame per launch"] = [{"error": repr(e)}]
+    return res
+
+
 def host_pipeline(lib, geo, dist, world, device, dry, nframes=96, depth=4):
     """PCIe-inclusive rate: pinned host NV12 in -> HBM -> scale -> HBM -> pinned host RGB24 out, copies on their own
     streams overlapping the kernels (gmat_pipeline_*, one pipeline per rank, all ranks at once).  Never `value`."""
@@ -671,6 +699,7 @@ def main():
         ch.close()
         mem.free()
         out["other_configs"] = other_configs(lib, env, stream, geo)
+        out["c_harness"] = c_harness(a.dry)
 
     if not a.no_pipeline:
         hp = host_pipeline(lib, geo, dist, world, 0 if a.dry else local, a.dry, nframes=8 if a.dry else 96)

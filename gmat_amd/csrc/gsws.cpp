@@ -130,6 +130,7 @@ struct GmatSwsContext {
     DevFilter r2yVChr;
     Yuv2xTables y2x;              // 2:1 horizontal specialisation (k_scale_yuv2x.hip), y2x.ok = LDS bytes
     Yuv2sTables y2s;              // strip-walking 2:1 form (k_scale_yuv2s.hip), RGB destinations
+    Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
@@ -210,6 +211,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         a.hBias = a.src16 == 16 ? (1 << 29) : 0;         // 32768 * 16384: undoes the -32768 of the P016 LDS image
     }
     if ((r = yuv2s_prepare(c->planYuv, c->ytiling, c->y2s)) < 0) return r;
+    if ((r = yuv2p_prepare(c->planYuv, c->ytiling, c->y2p)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -447,6 +449,29 @@ static Yuv2sArgs make_yuv2s_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     return sa;
 }
 
+// the plane-walking 4:2:0 -> 4:2:0 kernel: dword loads and stores on every plane
+static bool yuv2p_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    // its own destination rule, not ya.dstAligned: that flag carries the tiled kernel's 8-byte NV12 chroma stores, and a
+    // frame with 4-byte pitches would be sent to the slower kernel for no reason of this one's
+    const bool dst4 = al4(ya.dst, ya.ds) && al4(ya.dstU, ya.dsU) && (ya.nv12 || al4(ya.dstV, ya.dsV));
+    return c->y2p.ok && !c->rangeConv && ya.srcAligned && dst4 && !ya.prof &&
+           (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
+}
+
+static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv2pArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.ys = ya.ys; pa.us = ya.us; pa.vs = ya.vs; pa.nv12 = ya.nv12;
+    pa.srcW = ya.srcW; pa.srcH = ya.srcH; pa.chrSrcW = ya.chrSrcW; pa.chrSrcH = ya.chrSrcH;
+    pa.dstW = ya.dstW; pa.dstH = ya.dstH; pa.chrDstW = ya.chrDstW; pa.chrDstH = ya.chrDstH;
+    pa.ds = ya.ds; pa.dsU = ya.dsU; pa.dsV = ya.dsV;
+    for (int k = 0; k < 4; k++) { pa.hL[k] = c->y2p.hL[k]; pa.hC[k] = c->y2p.hC[k]; pa.vL[k] = c->y2p.vL[k]; pa.vC[k] = c->y2p.vC[k]; }
+    pa.lr = c->y2p.lr; pa.cr = c->y2p.cr; pa.xcdRemap = ya.xcdRemap;
+    return pa;
+}
+
 // argument block of the strip-walking packed-RGB scaler
 static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)
 {
@@ -566,7 +591,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true;
+    bool use2x = true, use2s = true, use2p = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -574,6 +599,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         if (r < 0) return r;
         use2x = use2x && yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride);
         use2s = use2s && yuv2s_eligible(c, ya);
+        use2p = use2p && yuv2p_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -582,7 +608,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
-    c->lastKernel = use2s ? "scale_yuv2s_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
+    c->lastKernel = use2s ? "scale_yuv2s_kernel" : use2p ? "scale_yuv2p_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -594,6 +621,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             fr.dst[i] = dp[0]; fr.dstU[i] = yuvDst ? dp[1] : nullptr; fr.dstV[i] = planarDst ? dp[2] : nullptr;
         }
         int r = use2s ? launch_scale_yuv2s(sa, stream, &fr, m)
+              : use2p ? launch_scale_yuv2p(pa, stream, &fr, m)
               : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
                       : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
@@ -1092,6 +1120,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
                 c->lastKernel = "scale_yuv2s_kernel";
                 r = launch_scale_yuv2s(make_yuv2s_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv2p_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_yuv2p_kernel";
+                r = launch_scale_yuv2p(make_yuv2p_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv2x_eligible(c, ya, src, srcStride)) {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
                 const int y14 = rgb_to_y14(a.k, r[i], gg[i], b[i]);
                 int l = min(2 * y14, 32767);
                 if (a.toJpeg) l = (m24(min(l, 30189), 19077) - 39057361) >> 14;          // lumRangeToJpeg_c, swscale.c:176-181
-                yb |= (unsigned)clip_u8((l + 64) >> 7) << (8 * i);
+                yb |= (unsigned)clip_u8_shr(l + 64, 7) << (8 * i);
             }
             uint8_t *d = a.y + (size_t)srow * a.ys + col;
             if (col + 4 <= a.w && ((((uintptr_t)a.y | (uintptr_t)a.ys) & 3) == 0)) *reinterpret_cast<unsigned *>(d) = yb;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
             const int n = min(4, a.cw - cx);
             unsigned ub[4], vb[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8(U[i] >> sh); vb[i] = (unsigned)clip_u8(V[i] >> sh); }
+            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8_shr(U[i], sh); vb[i] = (unsigned)clip_u8_shr(V[i], sh); }
             if (a.nv12) {
                 uint8_t *d = a.u + (size_t)cy * a.us + 2 * cx;
                 if (n == 4 && ((((uintptr_t)a.u | (uintptr_t)a.us) & 7) == 0)) {
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(256) void rgb2yuv444_kernel(const uint8_t *src, int
     unsigned yb = 0, ub = 0, vb = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        yb |= (unsigned)clip_u8((min(2 * rgb_to_y14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
-        ub |= (unsigned)clip_u8((min(2 * rgb_to_u14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
-        vb |= (unsigned)clip_u8((min(2 * rgb_to_v14(k, r[i], g[i], b[i]), 32767) + 64) >> 7) << (8 * i);
+        yb |= (unsigned)clip_u8_shr(min(2 * rgb_to_y14(k, r[i], g[i], b[i]), 32767) + 64, 7) << (8 * i);
+        ub |= (unsigned)clip_u8_shr(min(2 * rgb_to_u14(k, r[i], g[i], b[i]), 32767) + 64, 7) << (8 * i);
+        vb |= (unsigned)clip_u8_shr(min(2 * rgb_to_v14(k, r[i], g[i], b[i]), 32767) + 64, 7) << (8 * i);
     }
     uint8_t *dy = y + (size_t)row * ys + col, *du = u + (size_t)row * us + col, *dv = v + (size_t)row * vs + col;
     if (aligned && full) {

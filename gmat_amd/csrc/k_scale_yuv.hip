@@ -511,8 +511,8 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                 }
                 // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
                 uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
-                const unsigned o = (unsigned)clip_u8(Y[0] >> 19) | ((unsigned)clip_u8(Y[1] >> 19) << 8) |
-                                   ((unsigned)clip_u8(Y[2] >> 19) << 16) | ((unsigned)clip_u8(Y[3] >> 19) << 24);
+                const unsigned o = (unsigned)clip_u8_shr(Y[0], 19) | ((unsigned)clip_u8_shr(Y[1], 19) << 8) |
+                                   ((unsigned)clip_u8_shr(Y[2], 19) << 16) | ((unsigned)clip_u8_shr(Y[3], 19) << 24);
                 const int nx = min(4, a.dstW - xo);
                 if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
                 else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                 for (int k = 0; k < kYMaxPairs; k++) if (k < a.vChr.pairs) acc2(k, vc[k]);
                 for (int k = kYMaxPairs; k < a.vChr.pairs; k++) acc2(k, a.vChr.packed[(size_t)yo * a.vChr.pairs + k]);
                 // table_rV/gU/gV/bU are indexed with av_clip_uint8 (yuv2rgb.c:737-760)
-                const ChromaTerms t0 = chroma_terms(a.y2r, clip_u8(U[0] >> 19), clip_u8(V[0] >> 19));
-                const ChromaTerms t1 = chroma_terms(a.y2r, clip_u8(U[1] >> 19), clip_u8(V[1] >> 19));
+                const ChromaTerms t0 = chroma_terms(a.y2r, clip_u8_shr(U[0], 19), clip_u8_shr(V[0], 19));
+                const ChromaTerms t1 = chroma_terms(a.y2r, clip_u8_shr(U[1], 19), clip_u8_shr(V[1], 19));
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
             }
             unsigned ub[4], vb[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8(U[i] >> 19); vb[i] = (unsigned)clip_u8(V[i] >> 19); }
+            for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8_shr(U[i], 19); vb[i] = (unsigned)clip_u8_shr(V[i], 19); }
             if (a.dstNv12) {
                 uint8_t *d = a.dstU + (size_t)cy * a.dsU + 2 * cx;
                 if (a.dstAligned && nx == 4) {

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
                 // index clamp collapse into clip_u8((sum + 8192) >> 14): floor(floor(x / 128 + 64) / 128) = floor((x + 8192) / 16384)
                 const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], 8192))));
                 const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], 8192))));
-                iU[c] = clip_u8(su >> 14); iV[c] = clip_u8(sv >> 14);
+                iU[c] = clip_u8_shr(su, 14); iV[c] = clip_u8_shr(sv, 14);
             }
             // ---- colour stage + store ---------------------------------------------------------------------------
             unsigned c0[4], c1[4], c2[4];

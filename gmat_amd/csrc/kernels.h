@@ -262,6 +262,25 @@ int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTable
 // plane pointers of the nframes frames in *frames (grid.y = frame)
 int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> YUV 4:2:0 scaler (k_scale_yuv2p.hip): NV12 -> NV12 and
+// YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
+struct Yuv2pTables {
+    int ok = 0;
+    int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0}, vC[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
+    int lr = 0, cr = 0;                                             // vertical accumulator start values (dither << 12)
+};
+struct Yuv2pArgs {
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
+    int ds, dsU, dsV;
+    int32_t hL[4], hC[4], vL[4], vC[4];
+    int lr, cr;
+    // filled by the launcher: rows per strip segment, segments and groups of 4 strips per plane kind, workgroup counts
+    int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;
+};
+int  yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2pTables &t);
+int  launch_scale_yuv2p(const Yuv2pArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
 // rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
 struct Rgb2sTables {

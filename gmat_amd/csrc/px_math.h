@@ -12,6 +12,15 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   // v_med3_i32
 
+// clip_u8(v >> s), written clamp-then-shift — ALWAYS use this for a clamped shift, never clip_u8(v >> s).
+// hipcc (ROCm 7.2) turns the shift-then-clamp form of two neighbouring values into v_ashr_pk_u8_i32 and then ORs further
+// bytes onto the result as if its upper 16 bits were zero; on gfx950 the instruction leaves the destination's upper half AS IT
+// WAS.  Whether the output is right then depends on what the register allocator put there: rgb2yuv444_kernel was right by
+// accident (destination = a source holding a 15-bit value), scale_yuv2p_kernel wrote garbage into bytes 2 and 3 of every
+// output dword on hardware while the CPU emulation of the same source (plain C++ semantics) was bit-exact.
+// tests/test_isa_guard.py disassembles the shipped library and fails on any v_ashr_pk_*.
+__device__ __forceinline__ int clip_u8_shr(int v, int s) { return min(max(v, 0), (256 << s) - 1) >> s; }
+
 // 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24 run at full rate; v_mul_lo_u32 does not).  Every use
 // below has |operands| < 2^23: pixel values <= 510, table constants <= 2^18.
 __device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }

@@ -60,12 +60,33 @@ def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, al
     return kernel
 
 
+@pytest.fixture(params=["strip", "tiled"])
+def strip_or_tiled(request, monkeypatch):
+    """GMAT_SCALE_NO_STRIP at context creation keeps the tiled 2:1 kernels (the path of the frames the strip kernels
+    decline): the batched entry point is checked on both"""
+    if request.param == "tiled":
+        monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_SCALE_NO_STRIP", raising=False)
+    return request.param
+
+
+def _expected_2to1(which, src_fmt, dst_fmt):
+    """256 x 64 and 64 x 32 sources, bicubic: packed RGB -> scale_yuv2s_kernel; 4:2:0 with the same chroma layout on both sides
+    -> scale_yuv2p_kernel when the output has >= 16 rows; everything else, and everything under GMAT_SCALE_NO_STRIP, the tiled
+    kernel"""
+    if which == "strip" and dst_fmt in ("rgb24", "bgra"):
+        return "scale_yuv2s_kernel"
+    if which == "strip" and src_fmt == dst_fmt:
+        return "scale_yuv2p_kernel"
+    return "scale_yuv2x_kernel<yuv>" if dst_fmt in ("nv12", "yuv420p") else "scale_yuv2x_kernel"
+
+
 @pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra", "nv12", "yuv420p"])
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
-def test_batch_on_the_2to1_kernel(dev, orc, src_fmt, dst_fmt):
+def test_batch_on_the_2to1_kernel(dev, orc, strip_or_tiled, src_fmt, dst_fmt):
     k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
-    # packed RGB destinations take the strip-walking form, 4:2:0 destinations the tiled one
-    assert k.startswith("scale_yuv2s_kernel" if dst_fmt in ("rgb24", "bgra") else "scale_yuv2x_kernel"), k
+    assert k == _expected_2to1(strip_or_tiled, src_fmt, dst_fmt), k
 
 
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 96, 40, 144, 60), ("yuv420p", "nv12", 200, 90, 80, 36),
@@ -120,12 +141,12 @@ def test_batch_two_kernel_form(dev, orc, src_fmt):
         for p in dsrc[f] + ddst[f]: p.free()
 
 
-def test_batch_more_frames_than_one_launch_carries(dev, orc):
-    """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches"""
+def test_batch_more_frames_than_one_launch_carries(dev, orc, strip_or_tiled):
+    """kYuv2xMaxFrames = 32 per launch: 37 frames on one stream = two launches, on every 2:1 kernel"""
     k = _run_batch(dev, orc, "nv12", "rgb24", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)
-    assert k.startswith("scale_yuv2s_kernel"), k
+    assert k == _expected_2to1(strip_or_tiled, "nv12", "rgb24"), k
     k = _run_batch(dev, orc, "nv12", "nv12", 64, 32, 32, 16, nframes=37, nstreams=1, align=16)
-    assert k.startswith("scale_yuv2x_kernel"), k
+    assert k == _expected_2to1(strip_or_tiled, "nv12", "nv12"), k
 
 
 @pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra"])
@@ -177,8 +198,8 @@ def test_batch_single_frame_and_more_streams_than_frames(dev, orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dst_fmt", ["rgb24", "nv12"])
-def test_graph_replay_of_a_batch(dev, orc, dst_fmt):
+def test_graph_replay_of_a_batch(dev, orc, strip_or_tiled, dst_fmt):
     if dev.kind != "hip":
         pytest.skip("graph capture needs the HIP runtime")
     k = _run_batch(dev, orc, "nv12", dst_fmt, 256, 64, 128, 32, nframes=6, nstreams=2, align=64, graph=True)
-    assert k.startswith("scale_yuv2s_kernel" if dst_fmt == "rgb24" else "scale_yuv2x_kernel"), k
+    assert k == _expected_2to1(strip_or_tiled, "nv12", dst_fmt), k

@@ -124,13 +124,21 @@ def test_8k_nv12_to_4k_rgb24_bands(gpu, orc, kern):
         assert (got[0][y0:y0 + 32] == want[y0:y0 + 32]).all(), y0
 
 
-def test_4k_nv12_to_1080p_nv12_transcode(gpu, orc):
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("which", ["strip", "tiled"])
+def test_4k_to_1080p_transcode(gpu, orc, fmt, which, monkeypatch):
+    """the transcode down-scale at full size on BOTH kernels that serve it (the plane-walking one by default, the tiled one
+    for the frames it declines); yuv420p exercises the two separate chroma planes"""
+    if which == "tiled":
+        monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_SCALE_NO_STRIP", raising=False)
     sw, sh, dw, dh = 3840, 2160, 1920, 1080
-    src = synth_planes(orc, "nv12", sw, sh, seed=23)
-    want = orc.sws(src, sw, sh, "nv12", dw, dh, "nv12")
+    src = synth_planes(orc, fmt, sw, sh, seed=23)
+    want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
     d = gpu.upload_planes(src, 256)
-    got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, "nv12", dst_align=256)
-    assert k == "scale_yuv2x_kernel<yuv>"
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == ("scale_yuv2p_kernel" if which == "strip" else "scale_yuv2x_kernel<yuv>")
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
 

@@ -1,0 +1,84 @@
+"""Guards on the machine code of the library that ships to the GPU box (gmat_amd/lib/libgmat_hip.so), checked here without
+a GPU: the gfx950 code objects are cut out of the fat binary and disassembled with ROCm's llvm-objdump.
+
+v_ashr_pk_u8_i32 / v_ashr_pk_i8_i32: hipcc (ROCm 7.2) selects them for clip(v >> s) of two neighbouring values and then
+treats the upper 16 bits of the result as zero; on gfx950 the instruction leaves them as they were.  The CPU emulation of
+the kernels (plain C++ semantics) cannot see that, the bytes only go wrong on hardware — twice so far: packed RGB in round 1
+(px_math.h luma_chan) and every output dword of scale_yuv2p_kernel in round 2, with rgb2yuv444_kernel right only because of
+what the register allocator happened to leave in the destination.  The kernels use clip_u8_shr() (clamp, then shift), for
+which the compiler does not form the instruction; this test makes sure it stays that way for every kernel, present and future."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gmat_amd", "lib", "libgmat_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+FORBIDDEN = ("v_ashr_pk_u8_i32", "v_ashr_pk_i8_i32")
+
+
+def gfx950_code_objects(path):
+    """the entries of every __CLANG_OFFLOAD_BUNDLE__ in the file whose target is gfx950 (one bundle per .hip translation unit)"""
+    blob = open(path, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob):
+        o = m.start()
+        n, = struct.unpack_from("<Q", blob, o + 24)
+        p = o + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p:p + tl].decode()
+            p += tl
+            if "gfx950" in triple and size:
+                out.append(blob[o + off:o + off + size])
+    return out
+
+
+@pytest.fixture(scope="module")
+def disassembly():
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("no llvm-objdump in this image")
+    assert os.path.exists(LIB), "build first (__graft_entry__.build())"
+    objs = gfx950_code_objects(LIB)
+    texts = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, data in enumerate(objs):
+            f = os.path.join(d, f"co{i}.o")
+            open(f, "wb").write(data)
+            r = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", f], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-400:]
+            texts.append(r.stdout)
+    return texts
+
+
+def test_the_extraction_sees_the_kernels(disassembly):
+    """not vacuous: one code object per kernel source, and the kernels the product launches are in them"""
+    import glob
+    nsrc = len(glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "k_*.hip")))
+    assert len(disassembly) >= nsrc, (len(disassembly), nsrc)
+    allt = "\n".join(disassembly)
+    for k in ("scale_yuv2s_kernel", "scale_yuv2p_kernel", "scale_rgb2s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
+              "scale_yuv_kernel", "yuv2rgb_kernel"):
+        assert k in allt, k
+    assert allt.count("v_dot2") > 1000 and "v_perm_b32" in allt
+
+
+def test_no_packed_shift_clamp_instructions(disassembly):
+    hits = []
+    for t in disassembly:
+        func = "?"
+        for line in t.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                func = m.group(1)
+            elif any(f in line for f in FORBIDDEN):
+                hits.append(func)
+    by = {}
+    for f in hits:
+        by[f] = by.get(f, 0) + 1
+    assert not hits, f"v_ashr_pk_* (upper half of the result is NOT zero on gfx950) in: {by} — use clip_u8_shr()"

@@ -1,0 +1,141 @@
+"""The plane-walking 2:1 scaler with 4:2:0 output (k_scale_yuv2p.hip: NV12 -> NV12 and YUV420P -> YUV420P at exactly half
+size, the transcode down-scale) and the tiled kernel it supersedes for those cases (scale_yuv2x_kernel<yuv>, still the path
+of cross-layout pairs, range conversion, unaligned rows, widths that are not multiples of 16, Lanczos and
+GMAT_SCALE_NO_STRIP): BOTH are compared with the oracle on every geometry, and every test names the kernel it expects, so
+that a change of the selection rule cannot silently move a case from one kernel's coverage to the other's.
+
+Pinning: no vector the reference holds is a 2:1 4:2:0 -> 4:2:0 scale (tests/ref/fate/filter-scale200, -scale500,
+-crop_scale and filter-pixfmts-scale nv12 / yuv420p are 352x288 -> 200x200, 500x500, 400x298, 200x100).  Those pin the
+oracle's code for this path (hScale8To15_c, yuv2planeX_8_c, yuv2nv12cX_c, initFilter); at this ratio the kernels are held
+to the oracle only."""
+import os
+
+import numpy as np
+import pytest
+
+from harness import SWS, synth_planes
+from test_batch_api import _run_batch
+from test_parity_strip import strip_rows  # noqa: F401
+
+STRIP, TILED, GENERIC = "scale_yuv2p_kernel", "scale_yuv2x_kernel<yuv>", "scale_yuv_kernel<64,yuv>"
+
+
+def strip_takes(sw, sh, src_fmt, dst_fmt, flags="bicubic"):
+    """the host rule of yuv2p_prepare restated: same chroma layout on both sides, width a multiple of 16 and >= 64,
+    output height >= 16 and even (so that every plane is exactly halved), a filter that fits the 8-sample window"""
+    dh = sh // 2
+    return (src_fmt == dst_fmt and sw % 16 == 0 and sw >= 64 and sh % 4 == 0 and dh >= 16 and
+            flags in ("bicubic", "bilinear", "point", "area", "fast_bilinear", "gauss"))
+
+
+@pytest.fixture(params=["strip", "tiled"])
+def kern_yuv(request):
+    old = os.environ.pop("GMAT_SCALE_NO_STRIP", None)
+    if request.param == "tiled":
+        os.environ["GMAT_SCALE_NO_STRIP"] = "1"
+    yield request.param
+    os.environ.pop("GMAT_SCALE_NO_STRIP", None)
+    if old is not None:
+        os.environ["GMAT_SCALE_NO_STRIP"] = old
+
+
+def expect(kern_yuv, sw, sh, sf, df, flags="bicubic"):
+    """three kernels serve a bicubic 2:1 4:2:0 -> 4:2:0 context: the plane-walking one, the tiled 2:1 one (whole 16-byte
+    chunks: yuv2x_prepare wants srcW % 16 == 0) and the generic plane scaler for what both decline"""
+    if kern_yuv == "strip" and strip_takes(sw, sh, sf, df, flags):
+        return STRIP
+    return TILED if sw % 16 == 0 else GENERIC
+
+
+# (srcW, srcH): both sides of every clause of the rule — one partial strip, exactly one luma strip (512) and one UV strip
+# (256), strips + a partial one, several strip groups, widths that are multiples of 8 only (tiled), odd output heights
+# (tiled), the smallest the strip kernel takes
+GEOMS = [(64, 32), (256, 64), (512, 256), (528, 52), (1024, 96), (1040, 36), (2048, 32), (2064, 40), (4112, 32),
+         (72, 40), (520, 24), (192, 34), (128, 60), (48, 32), (64, 28)]
+
+
+def test_geometries_cover_both_kernels():
+    took = [strip_takes(w, h, "nv12", "nv12") for w, h in GEOMS]
+    assert sum(took) >= 8 and took.count(False) >= 4
+    names = {expect(k, w, h, "nv12", "nv12") for k in ("strip", "tiled") for w, h in GEOMS}
+    assert names == {STRIP, TILED, GENERIC}
+
+
+def _check(dev, orc, sf, df, sw, sh, flags="bicubic", align=256, extra=0):
+    src = synth_planes(orc, sf, sw, sh, seed=45)
+    want = orc.sws(src, sw, sh, sf, sw // 2, sh // 2, df, SWS[flags])
+    d = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d, sw, sh, sf, sw // 2, sh // 2, df, SWS[flags], dst_align=align, dst_extra=extra)
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{kernel} plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (pads[i] == 0xCD).all(), f"{kernel} plane {i}: wrote into the row padding"
+    for p in d:
+        p.free()
+    return kernel
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_same_layout_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, fmt, geom):
+    sw, sh = geom
+    strip_rows(0)
+    assert _check(dev, orc, fmt, fmt, sw, sh) == expect(kern_yuv, sw, sh, fmt, fmt)
+
+
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
+@pytest.mark.parametrize("geom", [(256, 64), (528, 52), (72, 40)])
+def test_cross_layout_pairs_never_take_the_strip_kernel(dev, orc, kern_yuv, pair, geom):
+    assert _check(dev, orc, pair[0], pair[1], *geom) == (TILED if geom[0] % 16 == 0 else GENERIC)
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+def test_unaligned_destination_rows_fall_back(dev, orc, fmt):
+    """the strip kernel stores dwords: rows that are not 4-byte aligned take the tiled kernel's byte stores"""
+    assert strip_takes(528, 52, fmt, fmt)
+    assert _check(dev, orc, fmt, fmt, 528, 52, align=1, extra=1) == TILED
+    assert _check(dev, orc, fmt, fmt, 528, 52, align=4, extra=4) == STRIP
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 8, 13, 64, 1000])
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+def test_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
+    """luma segments of `rows` rows, chroma segments of max(2, (rows + 1) / 2): the 3 warm-up row pairs of every segment
+    re-create the vertical window exactly, also where the last segment is short (26 luma / 13 chroma rows)"""
+    strip_rows(rows)
+    assert _check(dev, orc, fmt, fmt, 528, 52) == STRIP
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss", "lanczos", "sinc"])
+def test_filters(dev, orc, kern_yuv, flags):
+    k = _check(dev, orc, "nv12", "nv12", 528, 52, flags)
+    if kern_yuv == "tiled" or flags in ("lanczos", "sinc"):
+        assert k != STRIP, (flags, k)            # wide filters: the tiled 2:1 kernel or the generic plane scaler
+    else:
+        assert k == STRIP, (flags, k)
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+def test_batched_frames(dev, orc, strip_rows, kern_yuv, fmt):
+    strip_rows(0)
+    k = _run_batch(dev, orc, fmt, fmt, 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
+    assert k == expect(kern_yuv, 528, 52, fmt, fmt), k
+
+
+def test_range_conversion_is_not_the_strip_kernels(dev, orc):
+    """limited <-> full range sits between the horizontal and the vertical stage: such contexts keep the generic kernel"""
+    import ctypes as C
+    from harness import PIX_FMT, planes, ints
+    lib = dev.lib
+    sw, sh = 256, 64
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], sw // 2, sh // 2, PIX_FMT["nv12"], SWS["bicubic"], None)
+    assert c and lib.gmat_sws_setRange(c, 0, 1) == 0
+    src = synth_planes(orc, "nv12", sw, sh, seed=3)
+    d = dev.upload_planes(src, 256)
+    o = dev.planes_like("nv12", sw // 2, sh // 2, 256)
+    assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                              planes([p.ptr for p in o]), ints([p.stride for p in o])) == sh // 2
+    assert lib.gmat_sws_lastKernel(c).decode() not in (STRIP,)
+    lib.gmat_sws_freeContext(c)
+    for p in d + o:
+        p.free()

@@ -86,6 +86,11 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
     }
     const double usLaunch = best * 1e3 / launches, usFrame = usLaunch / NF;
     const double gbs = (double)(sb + db) / usFrame / 1e3;
+    if (getenv("X2BENCH_JSON"))
+        printf("{\"case\": \"%s\", \"kernel\": \"%s\", \"frames_per_launch\": %d, \"us_per_launch\": %.2f, \"us_per_frame\": %.3f, "
+               "\"algorithmic_bytes_per_frame\": %zu, \"achieved_GBps\": %.1f, \"frac\": %.4f, \"Gpix/s\": %.1f}\n",
+               label, kname.c_str(), NF, usLaunch, usFrame, sb + db, gbs, gbs / 8000.0, (double)sw * sh / usFrame / 1e3);
+    else
     printf("%-34s %-26s %8.1f us/launch %7.3f us/frame %8.1f GB/s  frac %.3f  %7.1f Gpix/s  (avg %.1f us/launch)\n", label, kname.c_str(),
            usLaunch, usFrame, gbs, gbs / 8000.0, (double)sw * sh / usFrame / 1e3, sum / REPS * 1e3 / launches);
     fflush(stdout);
@@ -148,6 +153,10 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         best = ms < best ? ms : best;
     }
     const double us = best * 1e3 / launches, gbs = 2.0 * nb / us / 1e3;
+    if (getenv("X2BENCH_JSON"))
+        printf("{\"case\": \"%s\", \"frames_per_launch\": 1, \"us_per_frame\": %.2f, \"algorithmic_bytes_per_frame\": %zu, "
+               "\"achieved_GBps\": %.1f, \"frac\": %.4f}\n", label, us, 2 * nb, gbs, gbs / 8000.0);
+    else
     printf("%-34s %8.2f us/frame %8.1f GB/s  frac %.3f\n", label, us, gbs, gbs / 8000.0);
     fflush(stdout);
     gmat_timer_destroy(timer); gmat_stream_destroy(stream);
@@ -168,9 +177,11 @@ int main(int argc, char **argv)
         {"nv12 4K->1080p rgba bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBA, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 4K->1080p rgb24 bilinear", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
         {"nv12 4K->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"yuv420p 4K->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 1080p->540p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p bgra bilinear", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"nv12 1080p->1080p rgb24 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
     };
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
