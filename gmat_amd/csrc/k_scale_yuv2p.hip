@@ -311,10 +311,12 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nsgL = (nstripsL + 3) / 4; a.nsgC = (nstripsC + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
-        // as launch_scale_yuv2s: about one round of waves over the chip (this kernel holds 8 per SIMD); the chroma
-        // planes walk half as many rows, their segments are half as long
+        // measured on 4K -> 1080p NV12 (profiles/r02c_yuv2p_rows_sweep.txt), best luma rows per segment by frames per
+        // launch: 1 -> 3, 2 -> 3, 4 -> 8, 8 -> 16, 16 -> 16, 32 -> 16..24.  Short launches want short segments (a wave's run
+        // time is its segment, and the 3 warm-up row pairs are paid from parallelism that would idle anyway); beyond 16 rows
+        // the waves get long enough for the tail of the launch to show.  wave-rows / 8640 is within 3 % of the best everywhere.
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;
-        seg = (int)std::min(64L, std::max(4L, (rows + 8191) / 8192));
+        seg = (int)std::min(16L, std::max(3L, (rows + 8639) / 8640));
     }
     a.segRowsL = seg; a.segRowsC = std::max(2, (seg + 1) / 2);
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
