@@ -8,16 +8,20 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export X2BENCH_VERIFY=0
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- $R/tools/bin/x2bench 32 6 "4K" > $OUT/$C.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- $R/tools/bin/x2bench 32 6 "4K->" > $OUT/$C.log 2>&1
+  # the filter kernels run one frame per launch: their own pass, so that their counters are never divided by 32
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/ops_$C -o p -- $R/tools/bin/x2bench 1 6 "op: " > $OUT/ops_$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
+ops = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True)):
+    into = ops if "/ops_" in f else agg
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "gmat" not in k: continue
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        into[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {"frames_per_launch": 32, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over tools/bin/x2bench 32 6; "
        "bytes = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts half of wide coalesced reads)", "kernels": {}}
 for k, d in agg.items():
@@ -28,5 +32,13 @@ for k, d in agg.items():
                              "read_bytes_per_frame": round(2 * f * 1024 / 32), "written_bytes_per_frame": round(w * 1024 / 32),
                              "traffic_bytes_per_frame": round((2 * f + w) * 1024 / 32), "launches": len(d["FETCH_SIZE"])}
     print(short, res["kernels"][short])
+res["filter_kernels_one_frame_per_launch"] = {}
+for k, d in ops.items():
+    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d: continue
+    f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+    short = k.split("(")[0].replace("void gmat::", "")
+    res["filter_kernels_one_frame_per_launch"][short] = {"read_bytes_per_launch": round(2 * f * 1024), "written_bytes_per_launch": round(w * 1024),
+                                                         "traffic_bytes_per_launch": round((2 * f + w) * 1024), "launches": len(d["FETCH_SIZE"])}
+    print(short, res["filter_kernels_one_frame_per_launch"][short])
 json.dump(res, open("$OUT/traffic.json", "w"), indent=1)
 PY
