@@ -21,10 +21,12 @@ from test_fate_product import clip, yuv420p_planes, W, H  # noqa: F401
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))["nut_md5"]
 FLAGS = SWS["bicubic"] | SWS["accurate_rnd"] | SWS["bitexact"]
-FOURCC = dict(nutmux.FOURCC, p010le=b"RGB\x0f")           # see tests/test_oracle_fate_nut.py
+FOURCC = dict(nutmux.FOURCC, p010le=b"RGB\x0f", p016le=b"RGB\x0f", rgba64le=b"RBA\x40", bgra64le=b"BRA\x40",
+              yuv444p16le=b"Y3\x00\x10")                   # see tests/test_oracle_fate_nut.py
 # (bytes per pixel of the plane, chroma shift) per plane
 LAYOUT = {"yuv420p": [(1, 0), (1, 1), (1, 1)], "yuv444p": [(1, 0)] * 3, "nv12": [(1, 0), (2, 1)], "p010le": [(2, 0), (4, 1)],
-          "rgb24": [(3, 0)], "bgr24": [(3, 0)], "rgba": [(4, 0)], "bgra": [(4, 0)]}
+          "rgb24": [(3, 0)], "bgr24": [(3, 0)], "rgba": [(4, 0)], "bgra": [(4, 0)],
+          "p016le": [(2, 0), (4, 1)], "yuv444p16le": [(2, 0)] * 3, "rgba64le": [(8, 0)], "bgra64le": [(8, 0)]}
 
 
 def sws(dev, src, sf, sw, sh, df, dw, dh):
@@ -68,7 +70,10 @@ def filt(dev, which, fmt, src, w, h, *args):
             assert lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, pw, rows, pw, rows, bpp, 0.0, 1, None, None) == 0
         else:
             o = DevPlane(dev, rows, pw * bpp, d.stride)
-            assert lib.gmat_flip(d.ptr, d.stride, o.ptr, o.stride, pw, rows, bpp, 1 if which == "hflip" else 0, None) == 0
+            # a vertical flip reverses rows whatever the pixel is (vf_vflip.c:108-127 only negates the line sizes): a row of
+            # 8-byte pixels goes in as twice as many 4-byte ones
+            fw, fb = (2 * pw, 4) if (bpp == 8 and which == "vflip") else (pw, bpp)
+            assert lib.gmat_flip(d.ptr, d.stride, o.ptr, o.stride, fw, rows, fb, 1 if which == "hflip" else 0, None) == 0
         out.append(o.download())
         d.free(); o.free()
     return out
@@ -106,7 +111,10 @@ def test_product_fate_crop_scale(dev, clip):
     assert nut(out, "yuv420p", 400, oh) == GOLD["video_filter"]["crop_scale"]
 
 
-PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le"]
+PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
+       "p016le", "yuv444p16le", "rgba64le", "bgra64le"]      # the last four: destinations of the 19-bit path (k_scale16.hip)
+NO_SRC = ("rgba64le", "bgra64le")                            # destinations only
+WIDE = ("rgba64le", "bgra64le")                              # 8-byte pixels: the pixel-permuting launchers take 1..4 bytes
 
 
 @pytest.fixture(scope="module")
@@ -126,6 +134,8 @@ def test_product_fate_pixfmts_conversion(dev, converted, fmt):
 def test_product_fate_pixfmts_filters(dev, converted, which, fmt):
     if which == "rotate" and fmt not in GOLD["pixfmts"]["rotate"]:
         pytest.skip("vf_rotate does not take this format")
+    if fmt in WIDE and which in ("hflip", "transpose", "rotate"):
+        pytest.skip("8-byte pixels: hflip / transpose / rotate launchers take 1..4-byte pixels (vflip and crop move rows and byte runs)")
     f = converted[fmt]
     if which == "crop":
         assert nut([filt(dev, "crop", fmt, f, W, H, 100, 100, 100, 100)], fmt, 100, 100) == GOLD["pixfmts"]["crop"][fmt]
@@ -135,6 +145,6 @@ def test_product_fate_pixfmts_filters(dev, converted, which, fmt):
         assert nut([filt(dev, which, fmt, f, W, H)], fmt, W, H) == GOLD["pixfmts"][which][fmt]
 
 
-@pytest.mark.parametrize("fmt", PIX)
+@pytest.mark.parametrize("fmt", [f for f in PIX if f not in NO_SRC])
 def test_product_fate_pixfmts_scale(dev, converted, fmt):
     assert nut([sws(dev, converted[fmt], fmt, W, H, fmt, 200, 100)], fmt, 200, 100) == GOLD["pixfmts"]["scale"][fmt]

@@ -24,11 +24,15 @@ from test_oracle_fate import fate, W, H, NFRAMES, BICUBIC, ACCURATE_RND, BITEXAC
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))["nut_md5"]
 FLAGS = BICUBIC | ACCURATE_RND | BITEXACT           # -sws_flags +accurate_rnd+bitexact on libswscale's default bicubic
-FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "yuv444p": 5, "nv12": 23, "rgba": 26, "bgra": 28, "p010le": 159}
+FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "yuv444p": 5, "nv12": 23, "rgba": 26, "bgra": 28, "p010le": 159,
+       "p016le": 170, "yuv444p16le": 49, "rgba64le": 105, "bgra64le": 107}
 FOURCC = dict(nutmux.FOURCC)
 # rawvideo has no fourcc for P010LE (libavcodec/raw.c), so the muxer takes av_codec_get_tag2's first RAWVIDEO entry of
 # ff_nut_video_tags (libavformat/nut.c:49) — confirmed by the reference md5s themselves
 FOURCC["p010le"] = b"RGB\x0f"
+FOURCC["p016le"] = b"RGB\x0f"                        # no tag either
+# libavcodec/raw.c:89-90,160: MKTAG('R','B','A',64), MKTAG('B','R','A',64), MKTAG('Y','3',0,16)
+FOURCC.update({"rgba64le": b"RBA\x40", "bgra64le": b"BRA\x40", "yuv444p16le": b"Y3\x00\x10"})
 
 
 def shapes(fmt, w, h):
@@ -36,7 +40,9 @@ def shapes(fmt, w, h):
     cw, ch = (w + 1) // 2, (h + 1) // 2
     return {"yuv420p": [(h, w, 1, 0), (ch, cw, 1, 1), (ch, cw, 1, 1)], "yuv444p": [(h, w, 1, 0)] * 3,
             "nv12": [(h, w, 1, 0), (ch, 2 * cw, 2, 1)], "p010le": [(h, 2 * w, 2, 0), (ch, 4 * cw, 4, 1)],
-            "rgb24": [(h, 3 * w, 3, 0)], "bgr24": [(h, 3 * w, 3, 0)], "rgba": [(h, 4 * w, 4, 0)], "bgra": [(h, 4 * w, 4, 0)]}[fmt]
+            "rgb24": [(h, 3 * w, 3, 0)], "bgr24": [(h, 3 * w, 3, 0)], "rgba": [(h, 4 * w, 4, 0)], "bgra": [(h, 4 * w, 4, 0)],
+            "p016le": [(h, 2 * w, 2, 0), (ch, 4 * cw, 4, 1)], "yuv444p16le": [(h, 2 * w, 2, 0)] * 3,
+            "rgba64le": [(h, 8 * w, 8, 0)], "bgra64le": [(h, 8 * w, 8, 0)]}[fmt]
 
 
 def planes_of(fmt, w, h, data=None):
@@ -63,7 +69,7 @@ def scale(L, src, sf, sw, sh, df, dw, dh):
         src, sf = [np.ascontiguousarray(px.reshape(sh, sw * 3))], {"rgba": "rgb24", "bgra": "bgr24"}[sf]
     dst = planes_of(df, dw, dh)
     P4, I4 = C.c_void_p * 4, C.c_int * 4
-    if sf == "yuv420p" and (sw, sh) == (dw, dh) and df == "p010le":     # planar8ToP01xleWrapper (swscale_unscaled.c:286-324)
+    if sf == "yuv420p" and (sw, sh) == (dw, dh) and df in ("p010le", "p016le"):     # planar8ToP01xleWrapper (swscale_unscaled.c:286-324)
         L.orc_yuv420_to_p01x.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         L.orc_yuv420_to_p01x(P4(*[p.ctypes.data for p in src]), I4(*[p.shape[1] for p in src]), P4(*[p.ctypes.data for p in dst]),
                              I4(*[p.shape[1] for p in dst]), sw, sh, 0)
@@ -154,7 +160,9 @@ def test_fate_filter_crop_scale(fate):
 
 
 # ---- pixfmts: scale,format=<fmt>,<filter> on the first frame ------------------------------------------------------
-PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le"]
+PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
+       "p016le", "yuv444p16le", "rgba64le", "bgra64le"]    # the last four: libswscale's 19-bit lines (yuv2planeX_16_c, yuv2rgba64_X_c)
+NO_SRC = ("rgba64le", "bgra64le")                          # destinations only (rgb64ToY_c is not restated): no fmt -> fmt scale row
 
 
 def converted(fate, fmt):
@@ -189,7 +197,7 @@ def test_fate_pixfmts_transpose(fate, fmt):
     assert nut([per_plane(L, L.orc_transpose, fmt, f, W, H, 0, swap=True)], fmt, H, W) == GOLD["pixfmts"]["transpose"][fmt]
 
 
-@pytest.mark.parametrize("fmt", [f for f in PIX if f not in ("nv12", "p010le")])
+@pytest.mark.parametrize("fmt", [f for f in PIX if f in GOLD["pixfmts"]["rotate"] and f not in NO_SRC])
 def test_fate_pixfmts_rotate(fate, fmt):
     """rotate=2*PI*n/50 on frame n = 0: angle 0 through vf_rotate's fixed-point walk with the default bilinear taps"""
     L, f = converted(fate, fmt)
@@ -201,7 +209,7 @@ def test_fate_pixfmts_rotate(fate, fmt):
     assert nut([out], fmt, W, H) == GOLD["pixfmts"]["rotate"][fmt]
 
 
-@pytest.mark.parametrize("fmt", PIX)
+@pytest.mark.parametrize("fmt", [f for f in PIX if f not in NO_SRC])
 def test_fate_pixfmts_scale(fate, fmt):
     """scale=200:100 in the converted format: the generic scaler fmt -> fmt (packed RGB through its YUV lines)"""
     L, f = converted(fate, fmt)
