@@ -34,7 +34,11 @@ inline bool is_packed_rgb(int f)
 // 64-bit packed RGB destinations (16 bits per channel, alpha last)
 inline bool is_rgb64(int f) { return f == GMAT_PIX_FMT_RGBA64LE || f == GMAT_PIX_FMT_BGRA64LE; }
 // destinations of the 19-bit path (k_scale16.hip)
-inline bool is_dst16(int f) { return f == GMAT_PIX_FMT_P016LE || f == GMAT_PIX_FMT_YUV444P16LE || is_rgb64(f); }
+inline bool is_dst16(int f) { return f == GMAT_PIX_FMT_P016LE || f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE || is_rgb64(f); }
+// ... of them, the ones with planar chroma (yuv2planeX_16_c per plane)
+inline bool is_pl16_dst(int f) { return f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE; }
+// 10-bit destinations of the 15-bit lines: P010LE (interleaved chroma, sample << 6) and planar YUV420P10LE (yuv2planeX_10_c)
+inline bool is_dst10(int f) { return f == GMAT_PIX_FMT_P010LE || f == GMAT_PIX_FMT_YUV420P10LE; }
 inline bool is_yuv420(int f) { return f == GMAT_PIX_FMT_NV12 || f == GMAT_PIX_FMT_YUV420P; }
 // 8-bit YUV sources of the plane scaler: 4:2:0 and (source only) planar 4:4:4
 inline bool is_yuv8_src(int f) { return is_yuv420(f) || f == GMAT_PIX_FMT_YUV444P; }

@@ -179,7 +179,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
     const std::vector<int32_t> none(std::max(c->dstW, c->dstH), 0);
     a.chrDstH = c->planYuv.chrDstH;
     a.dstNv12 = c->dstFormat == GMAT_PIX_FMT_NV12 || c->dstFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma
-    a.dst16 = c->dstFormat == GMAT_PIX_FMT_P010LE;
+    a.dst16 = c->dstFormat == GMAT_PIX_FMT_P010LE ? 1 : c->dstFormat == GMAT_PIX_FMT_YUV420P10LE ? 2 : 0;
+    a.dstShift = a.dst16 == 1 ? 6 : 0;
     if ((r = c->yHLum.upload(c->planYuv.hLum, none, a.hLum)) < 0) return r;
     if ((r = c->yHChr.upload(c->planYuv.hChr, none, a.hChr)) < 0) return r;
     if ((r = c->yVLum.upload(t.vLumEff, t.lumRound, a.vLum)) < 0) return r;
@@ -315,7 +316,7 @@ static int init_scale16(GmatSwsContext *c)
 // prepares whichever scaler the current mode needs
 static int ensure_scaler(GmatSwsContext *c)
 {
-    if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE)) ||
+    if ((is_yuv420(c->srcFormat) && (is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat))) ||
         c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat) || is_p01x(c->srcFormat) || c->rgbViaPlanes) {
         c->fused = 2;                        // planes are always scaled separately; there is no RGB stage to fuse
         return init_yuv_scaler(c);           // (a 4:4:4 source has no convert-then-scale form here either)
@@ -377,7 +378,14 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     ya.dst = dst[0]; ya.ds = dstStride[0];
     const int ybpp = bytes_per_pixel(c->dstFormat);
     ya.dstAligned = ybpp == 4 ? ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0]) & 15) == 0) : al4(dst[0], dstStride[0]);
-    if (c->dstFormat == GMAT_PIX_FMT_P010LE) {
+    if (c->dstFormat == GMAT_PIX_FMT_YUV420P10LE) {
+        if (!dst[1] || !dst[2]) return GMAT_ERR(EINVAL);
+        uintptr_t all = 0;
+        for (int i = 0; i < 3; i++) all |= (uintptr_t)dst[i] | (uintptr_t)dstStride[i];
+        if (all & 1) return GMAT_ERR(EINVAL);
+        ya.dstU = dst[1]; ya.dsU = dstStride[1]; ya.dstV = dst[2]; ya.dsV = dstStride[2];
+        ya.dstAligned = (all & 7) == 0;                      // 8-byte stores on every plane
+    } else if (c->dstFormat == GMAT_PIX_FMT_P010LE) {
         if (!dst[1]) return GMAT_ERR(EINVAL);
         if ((((uintptr_t)dst[0] | (uintptr_t)dst[1] | (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1]) & 1) != 0) return GMAT_ERR(EINVAL);
         ya.dstU = dst[1]; ya.dsU = dstStride[1]; ya.dstV = nullptr; ya.dsV = 0;
@@ -604,8 +612,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
-    const bool yuvDst = is_yuv8_src(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
-    const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P;
+    const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
+    const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
@@ -763,7 +771,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         // taken above as the depth expansion, equal format as the plane copy)
         c->mode = MODE_SCALE16;
         r = init_scale16(c);
-    } else if ((is_plane_src(srcFormat)) && dstFormat == GMAT_PIX_FMT_P010LE) {
+    } else if ((is_plane_src(srcFormat)) && is_dst10(dstFormat)) {
         // scaled (or 16-bit sourced) P010LE output: dstBpc = 10 keeps the 15-bit intermediates; yuv2p010l1_c /
         // yuv2p010lX_c / yuv2p010cX_c (output.c:459-519).  Equal-size 8-bit 4:2:0 sources were taken above (MODE_DEPTH).
         c->mode = MODE_SCALE;
@@ -834,7 +842,16 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
         c->rangeConv = dstFullRange ? 1 : 0;
         return 0;
     }
-    if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || is_p01x(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_YUV444P16LE)) {
+    {
+        // same-size 8-bit planar -> high-depth planar with the same subsampling is planarCopyWrapper in libswscale
+        // (swscale_unscaled.c:1789-1830), which SHIFTS limited-range samples — what the generic lines compute too — but
+        // bit-replicates the luma of a full-range source.  That form is not built: refuse it rather than shift silently.
+        const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
+        const bool pair = (c->srcFormat == GMAT_PIX_FMT_YUV420P && (c->dstFormat == GMAT_PIX_FMT_YUV420P10LE || c->dstFormat == GMAT_PIX_FMT_YUV420P16LE)) ||
+                          (c->srcFormat == GMAT_PIX_FMT_YUV444P && c->dstFormat == GMAT_PIX_FMT_YUV444P16LE);
+        if (same && pair && srcFullRange) return GMAT_ERR(ENOSYS);
+    }
+    if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || is_p01x(c->dstFormat) || pl16_depth(c->dstFormat))) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
         // YUV -> RGB context is part of gmat_sws_setColorspace
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
@@ -848,7 +865,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
     const bool special = same && (c->unscaledMode == MODE_YUV2YUV || c->unscaledMode == MODE_DEPTH || c->unscaledMode == MODE_PLANECOPY);
     if (special) {
-        const bool generic15 = is_yuv420(c->dstFormat) || c->dstFormat == GMAT_PIX_FMT_P010LE;
+        const bool generic15 = is_yuv420(c->dstFormat) || is_dst10(c->dstFormat);
         if (conv && !generic15) return GMAT_ERR(ENOSYS);
         c->rangeConv = conv;
         if (conv) { c->mode = MODE_SCALE; c->fused = 2; return ensure_scaler(c); }
@@ -1017,7 +1034,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             break;
         }
         if ((r = launch_vscale16(ly, nullptr, c->dstW, c->srcH, c->d16[2], dst[0], dstStride[0], c->dstW, c->dstH, c->stream)) < 0) break;
-        if (c->dstFormat == GMAT_PIX_FMT_YUV444P16LE) {
+        if (is_pl16_dst(c->dstFormat)) {
             if (!dst[2] || (((uintptr_t)dst[2] | (uintptr_t)dstStride[2]) & 1)) { r = GMAT_ERR(EINVAL); break; }
             if ((r = launch_vscale16(lu, nullptr, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream)) < 0) break;
             r = launch_vscale16(lv, nullptr, p.chrDstW, p.chrSrcH, c->d16[3], dst[2], dstStride[2], p.chrDstW, p.chrDstH, c->stream);

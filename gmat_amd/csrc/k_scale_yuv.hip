@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                     unsigned short *d16 = reinterpret_cast<unsigned short *>(a.dst + (size_t)yo * a.ds) + xo;
                     unsigned w[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) w[i] = (unsigned)min(max(Y[i] >> 17, 0), 1023) << 6;
+                    for (int i = 0; i < 4; i++) w[i] = (unsigned)min(max(Y[i] >> 17, 0), 1023) << a.dstShift;   // P010: << 6, planar: as it is
                     const int nx = min(4, a.dstW - xo);
                     if (a.dstAligned && nx == 4) *reinterpret_cast<uint2 *>(d16) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
                     else for (int i = 0; i < nx; i++) d16[i] = (unsigned short)w[i];
@@ -600,6 +600,18 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                 V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
             }
             const int nx = min(4, a.chrDstW - cx);
+            if (a.dst16 == 2) {                                     // YUV420P10LE: yuv2planeX_10_c on each chroma plane
+                unsigned short *du = reinterpret_cast<unsigned short *>(a.dstU + (size_t)cy * a.dsU) + cx;
+                unsigned short *dv = reinterpret_cast<unsigned short *>(a.dstV + (size_t)cy * a.dsV) + cx;
+                unsigned u[4], v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { u[i] = (unsigned)min(max(U[i] >> 17, 0), 1023); v[i] = (unsigned)min(max(V[i] >> 17, 0), 1023); }
+                if (a.dstAligned && nx == 4) {
+                    *reinterpret_cast<uint2 *>(du) = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+                    *reinterpret_cast<uint2 *>(dv) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+                } else for (int i = 0; i < nx; i++) { du[i] = (unsigned short)u[i]; dv[i] = (unsigned short)v[i]; }
+                continue;
+            }
             if (a.dst16) {                                          // yuv2p010cX_c: 16-bit U, V interleaved
                 unsigned w[4];
 #pragma unroll
@@ -669,7 +681,7 @@ static void windows(const FilterBank &fb, int tile, int ntiles, int count, int a
 int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
 {
     const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
-    const bool out10 = p.dstFormat == GMAT_PIX_FMT_P010LE;                   // 4:2:0 with 16-bit stores
+    const bool out10 = is_dst10(p.dstFormat);                                // 4:2:0 with 16-bit stores (P010LE, YUV420P10LE)
     const int yuvOut = (is_yuv420(p.dstFormat) || out10) ? 1 : out444 ? 2 : 0;   // 1: 4:2:0   2: planar 4:4:4
     const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // only towards YUV destinations
     const bool pl16 = pl16_depth(p.srcFormat) != 0;
@@ -723,7 +735,7 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
         // planar output (vscale.c:30-105): a 1-tap filter goes through yuv2plane1_8_c, which does not read the
         // coefficient; NV12 chroma always takes yuv2nv12cX_c, which does
         if (lfs == 1) std::fill(t.vLumEff.coef.begin(), t.vLumEff.coef.end(), (int16_t)4096);
-        if (cfs == 1 && p.dstFormat != GMAT_PIX_FMT_NV12 && !out10) std::fill(t.vChrEff.coef.begin(), t.vChrEff.coef.end(), (int16_t)4096);
+        if (cfs == 1 && p.dstFormat != GMAT_PIX_FMT_NV12 && p.dstFormat != GMAT_PIX_FMT_P010LE) std::fill(t.vChrEff.coef.begin(), t.vChrEff.coef.end(), (int16_t)4096);
     }
     pack_filter_pairs(t.vChrEff);
     pack_filter_pairs(t.vLumEff);

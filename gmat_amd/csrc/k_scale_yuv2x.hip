@@ -546,7 +546,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
     const char *off = getenv("GMAT_SCALE_NO_2X");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut == 2 || g.TW != X2_TW || g.TH != X2_TH) return 0;
-    if (!is_yuv420(p.srcFormat) || p.dstFormat == GMAT_PIX_FMT_P010LE) return 0;                    // the tile geometry assumes half-size chroma planes
+    if (!is_yuv420(p.srcFormat) || is_dst10(p.dstFormat)) return 0;                    // the tile geometry assumes half-size chroma planes
     if (p.srcW % 16 || p.chrSrcW % 8 || p.srcW < 16) return 0;
     if (g.rowsL > 48 || g.rowsC > 48) return 0;               // phase 1 covers 48 luma rows and 24 chroma rows per tile (48 in
                                                               // the Lanczos 4:2:0-output variant, checked below)

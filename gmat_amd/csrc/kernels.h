@@ -106,7 +106,8 @@ struct YuvScaleArgs {
     int ds, dstFormat, dstAligned;
     uint8_t *dstU, *dstV;                         // YUV output: chroma planes (NV12: dstU = interleaved UV)
     int dsU, dsV, dstNv12, chrDstH;
-    int dst16;                                    // P010LE output: 16-bit stores, clip to 10 bits << 6 (implies dstNv12)
+    int dst16;                                    // 10-bit output, 16-bit stores: 1 = P010LE (clip10 << 6, implies dstNv12), 2 = planar YUV420P10LE
+    int dstShift;                                 //   6 / 0
     DevFilter hLum, hChr, vLum, vChr;             // vLum.round / vChr.round = lumRound / chrRound
     const int32_t *colStartL, *colCountL, *rowStartL, *rowCountL, *colStartC, *colCountC, *rowStartC, *rowCountC;
     int TH, ntx, nty, xcdRemap, fullChroma;

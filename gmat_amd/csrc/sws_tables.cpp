@@ -337,7 +337,7 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
     const bool src444 = srcFormat == GMAT_PIX_FMT_YUV444P || srcFormat == GMAT_PIX_FMT_YUV444P16LE;
     const bool dst444 = dstFormat == GMAT_PIX_FMT_YUV444P || dstFormat == GMAT_PIX_FMT_YUV444P16LE;
     if (!(src_rgb || is_yuv420(srcFormat) || src444 || is_p01x(srcFormat) || pl16_depth(srcFormat)) ||
-        !(dst_rgb || is_yuv420(dstFormat) || dst444 || is_p01x(dstFormat))) return GMAT_ERR(ENOSYS);
+        !(dst_rgb || is_yuv420(dstFormat) || dst444 || is_p01x(dstFormat) || pl16_depth(dstFormat))) return GMAT_ERR(ENOSYS);
     static const int unset[4] = {-513, -513, -513, -513};
     if (!chrPos) chrPos = unset;
     if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) return GMAT_ERR(EINVAL);

@@ -34,8 +34,9 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_NV12      = 23,
     GMAT_PIX_FMT_RGBA      = 26,
     GMAT_PIX_FMT_BGRA      = 28,
-    GMAT_PIX_FMT_YUV420P16LE = 45,  /* } swscale_cuda's planar high-depth 4:2:0 sources (swscale_cuda.c:34-44): SOURCES for every 8-bit, */
-    GMAT_PIX_FMT_YUV420P10LE = 62,  /* } P010LE and 19-bit-path destination at any size; 10-bit: the bits are the LOW ones            */
+    GMAT_PIX_FMT_YUV420P16LE = 45,  /* } swscale_cuda's planar high-depth 4:2:0 formats (swscale_cuda.c:34-44): sources for every 8-bit,   */
+    GMAT_PIX_FMT_YUV420P10LE = 62,  /* } 10-bit and 19-bit-path destination at any size, and destinations of every YUV source (10-bit: on  */
+                                    /*   the 15-bit lines, yuv2planeX_10_c, bits in the LOW end; 16-bit: on the 19-bit lines)              */
     GMAT_PIX_FMT_YUV444P16LE = 49,  /* scale_cuda's list: source for every destination at any size; destination of every
                                        YUV source on the 19-bit path (with P016LE, RGBA64LE, BGRA64LE) */
     GMAT_PIX_FMT_RGBA64LE  = 105,   /* destinations of every YUV source at any size (yuv2rgba64_*_c on libswscale's 19-bit */

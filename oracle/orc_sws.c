@@ -46,7 +46,8 @@ struct OrcSws {
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
 static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
 static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
-static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || is_rgb64(f); }   /* 19-bit lines */
+static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE || is_rgb64(f); }   /* 19-bit lines */
+static int is_pl16_dst(int f) { return f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE; }          /* ... with planar chroma */
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
 /* planar YUV in 16-bit containers, native endian: no input converter (input.c:1523-1528 is HAVE_BIGENDIAN only), the
  * samples go to hScale16To15_c / hScale16To19_c as they are with sh derived from the depth (swscale.c:93-119,:63-91) */
@@ -146,7 +147,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
      * P016LE switches to the 19-bit ones (scale_to_p016 below) */
     if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
-        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt)))
+        !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt) || dst_fmt == ORC_PIX_YUV420P10LE))
         return NULL;
     if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
         return NULL;
@@ -584,6 +585,28 @@ static void put_p010(uint8_t *d, int val, int shift)
     d[0] = (uint8_t)(v & 0xFF); d[1] = (uint8_t)(v >> 8);
 }
 
+/* planar 10-bit output (YUV420P10LE): yuv2plane1_10_c / yuv2planeX_10_c (output.c:330-384) — P010's arithmetic with the
+ * sample left in the low bits; every plane, chroma included, goes through this (no dither at this depth) */
+static void put_pl10(uint8_t *d, int val, int shift)
+{
+    int v = val >> shift;
+    v = v < 0 ? 0 : v > 1023 ? 1023 : v;
+    d[0] = (uint8_t)(v & 0xFF); d[1] = (uint8_t)(v >> 8);
+}
+static void out_pl10_row(uint8_t *dest, int w, const int16_t *filter, int fs, const int16_t *const *src)
+{
+    int i, j;
+    if (fs == 1) {
+        for (i = 0; i < w; i++) put_pl10(dest + 2 * i, src[0][i] + (1 << 4), 5);
+    } else {
+        for (i = 0; i < w; i++) {
+            int val = 1 << 16;
+            for (j = 0; j < fs; j++) val += src[j][i] * filter[j];
+            put_pl10(dest + 2 * i, val, 17);
+        }
+    }
+}
+
 static void out_p010_luma_row(uint8_t *dest, int w, const int16_t *filter, int fs, const int16_t *const *src)
 {
     int i, j;
@@ -710,7 +733,7 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
     for (y = 0; y < c->chr_dst_h; y++) {
         uint8_t *d = dst[1] + (long)y * dst_stride[1];
         const int32_t **up = lp, **vp = lp + c->v_chr_size;
-        if (c->dst_fmt == ORC_PIX_YUV444P16LE) {            /* planar chroma: yuv2plane1_16_c / yuv2planeX_16_c per plane */
+        if (is_pl16_dst(c->dst_fmt)) {                      /* planar chroma: yuv2plane1_16_c / yuv2planeX_16_c per plane */
             uint8_t *dv = dst[2] + (long)y * dst_stride[2];
             for (j = 0; j < c->v_chr_size; j++) {
                 int r = c->v_chr_pos[y] + j;
@@ -840,7 +863,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     const int16_t **lp = NULL, **up = NULL, **vp = NULL;
     const int dst_w = c->dst_w, cdw = c->chr_dst_w;
 
-    if (c->dst_fmt == ORC_PIX_P016LE || c->dst_fmt == ORC_PIX_YUV444P16LE)
+    if (c->dst_fmt == ORC_PIX_P016LE || is_pl16_dst(c->dst_fmt))
         return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_p016(c, src, src_stride, dst, dst_stride) : -1;
     if (is_rgb64(c->dst_fmt))
         return (y0 <= 0 && y1 >= c->dst_h) ? scale_to_rgba64(c, src, src_stride, dst, dst_stride) : -1;
@@ -892,6 +915,12 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
         }
         if (c->dst_is_rgb) {
             out_packed_row(c, dst[0] + (long)y * dst_stride[0], y, lp, up, vp);
+        } else if (c->dst_fmt == ORC_PIX_YUV420P10LE) {
+            out_pl10_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size, c->v_lum_size, lp);
+            if (!(y & 1)) {
+                out_pl10_row(dst[1] + (long)chr_y * dst_stride[1], cdw, c->v_chr + chr_y * c->v_chr_size, c->v_chr_size, up);
+                out_pl10_row(dst[2] + (long)chr_y * dst_stride[2], cdw, c->v_chr + chr_y * c->v_chr_size, c->v_chr_size, vp);
+            }
         } else if (c->dst_fmt == ORC_PIX_P010LE) {
             out_p010_luma_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size, c->v_lum_size, lp);
             if (!(y & 1))
@@ -923,7 +952,7 @@ int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4
 {
     /* bounded working set: process in bands of 64 output rows */
     int y, band = 64;
-    if (c->dst_fmt == ORC_PIX_P016LE || c->dst_fmt == ORC_PIX_YUV444P16LE)
+    if (c->dst_fmt == ORC_PIX_P016LE || is_pl16_dst(c->dst_fmt))
         return scale_to_p016(c, src, src_stride, dst, dst_stride);
     if (is_rgb64(c->dst_fmt))
         return scale_to_rgba64(c, src, src_stride, dst, dst_stride);

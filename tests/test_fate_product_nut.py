@@ -22,11 +22,12 @@ from test_fate_product import clip, yuv420p_planes, W, H  # noqa: F401
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))["nut_md5"]
 FLAGS = SWS["bicubic"] | SWS["accurate_rnd"] | SWS["bitexact"]
 FOURCC = dict(nutmux.FOURCC, p010le=b"RGB\x0f", p016le=b"RGB\x0f", rgba64le=b"RBA\x40", bgra64le=b"BRA\x40",
-              yuv444p16le=b"Y3\x00\x10")                   # see tests/test_oracle_fate_nut.py
+              yuv444p16le=b"Y3\x00\x10", yuv420p10le=b"Y3\x0b\x0a", yuv420p16le=b"Y3\x0b\x10")   # see tests/test_oracle_fate_nut.py
 # (bytes per pixel of the plane, chroma shift) per plane
 LAYOUT = {"yuv420p": [(1, 0), (1, 1), (1, 1)], "yuv444p": [(1, 0)] * 3, "nv12": [(1, 0), (2, 1)], "p010le": [(2, 0), (4, 1)],
           "rgb24": [(3, 0)], "bgr24": [(3, 0)], "rgba": [(4, 0)], "bgra": [(4, 0)],
-          "p016le": [(2, 0), (4, 1)], "yuv444p16le": [(2, 0)] * 3, "rgba64le": [(8, 0)], "bgra64le": [(8, 0)]}
+          "p016le": [(2, 0), (4, 1)], "yuv444p16le": [(2, 0)] * 3, "rgba64le": [(8, 0)], "bgra64le": [(8, 0)],
+          "yuv420p10le": [(2, 0), (2, 1), (2, 1)], "yuv420p16le": [(2, 0), (2, 1), (2, 1)]}
 
 
 def sws(dev, src, sf, sw, sh, df, dw, dh):
@@ -112,7 +113,8 @@ def test_product_fate_crop_scale(dev, clip):
 
 
 PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
-       "p016le", "yuv444p16le", "rgba64le", "bgra64le"]      # the last four: destinations of the 19-bit path (k_scale16.hip)
+       "p016le", "yuv444p16le", "rgba64le", "bgra64le",      # these four: destinations of the 19-bit path (k_scale16.hip)
+       "yuv420p10le", "yuv420p16le"]                         # planar high-depth 4:2:0, sources and destinations
 NO_SRC = ("rgba64le", "bgra64le")                            # destinations only
 WIDE = ("rgba64le", "bgra64le")                              # 8-byte pixels: the pixel-permuting launchers take 1..4 bytes
 

@@ -25,14 +25,15 @@ from test_oracle_fate import fate, W, H, NFRAMES, BICUBIC, ACCURATE_RND, BITEXAC
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))["nut_md5"]
 FLAGS = BICUBIC | ACCURATE_RND | BITEXACT           # -sws_flags +accurate_rnd+bitexact on libswscale's default bicubic
 FMT = {"yuv420p": 0, "rgb24": 2, "bgr24": 3, "yuv444p": 5, "nv12": 23, "rgba": 26, "bgra": 28, "p010le": 159,
-       "p016le": 170, "yuv444p16le": 49, "rgba64le": 105, "bgra64le": 107}
+       "p016le": 170, "yuv444p16le": 49, "rgba64le": 105, "bgra64le": 107, "yuv420p10le": 62, "yuv420p16le": 45}
 FOURCC = dict(nutmux.FOURCC)
 # rawvideo has no fourcc for P010LE (libavcodec/raw.c), so the muxer takes av_codec_get_tag2's first RAWVIDEO entry of
 # ff_nut_video_tags (libavformat/nut.c:49) — confirmed by the reference md5s themselves
 FOURCC["p010le"] = b"RGB\x0f"
 FOURCC["p016le"] = b"RGB\x0f"                        # no tag either
 # libavcodec/raw.c:89-90,160: MKTAG('R','B','A',64), MKTAG('B','R','A',64), MKTAG('Y','3',0,16)
-FOURCC.update({"rgba64le": b"RBA\x40", "bgra64le": b"BRA\x40", "yuv444p16le": b"Y3\x00\x10"})
+FOURCC.update({"rgba64le": b"RBA\x40", "bgra64le": b"BRA\x40", "yuv444p16le": b"Y3\x00\x10",
+               "yuv420p10le": b"Y3\x0b\x0a", "yuv420p16le": b"Y3\x0b\x10"})     # raw.c:138,156: MKTAG('Y','3',11,10 | 16)
 
 
 def shapes(fmt, w, h):
@@ -42,7 +43,9 @@ def shapes(fmt, w, h):
             "nv12": [(h, w, 1, 0), (ch, 2 * cw, 2, 1)], "p010le": [(h, 2 * w, 2, 0), (ch, 4 * cw, 4, 1)],
             "rgb24": [(h, 3 * w, 3, 0)], "bgr24": [(h, 3 * w, 3, 0)], "rgba": [(h, 4 * w, 4, 0)], "bgra": [(h, 4 * w, 4, 0)],
             "p016le": [(h, 2 * w, 2, 0), (ch, 4 * cw, 4, 1)], "yuv444p16le": [(h, 2 * w, 2, 0)] * 3,
-            "rgba64le": [(h, 8 * w, 8, 0)], "bgra64le": [(h, 8 * w, 8, 0)]}[fmt]
+            "rgba64le": [(h, 8 * w, 8, 0)], "bgra64le": [(h, 8 * w, 8, 0)],
+            "yuv420p10le": [(h, 2 * w, 2, 0), (ch, 2 * cw, 2, 1), (ch, 2 * cw, 2, 1)],
+            "yuv420p16le": [(h, 2 * w, 2, 0), (ch, 2 * cw, 2, 1), (ch, 2 * cw, 2, 1)]}[fmt]
 
 
 def planes_of(fmt, w, h, data=None):
@@ -55,6 +58,7 @@ def planes_of(fmt, w, h, data=None):
 
 def scale(L, src, sf, sw, sh, df, dw, dh):
     """what vf_scale's context computes: MPEG-2 vertical chroma position 128 on every YUV420P end (vf_scale.c:563-573)"""
+    # vf_scale.c:563-573 sets the MPEG-2 vertical position for AV_PIX_FMT_YUV420P only, not for its high-depth siblings
     pos = (-513, 128 if sf == "yuv420p" else -513, -513, 128 if df == "yuv420p" else -513)
     if sf == df and (sw, sh) == (dw, dh):
         return [p.copy() for p in src]                   # vf_scale passes equal frames through
@@ -161,7 +165,8 @@ def test_fate_filter_crop_scale(fate):
 
 # ---- pixfmts: scale,format=<fmt>,<filter> on the first frame ------------------------------------------------------
 PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
-       "p016le", "yuv444p16le", "rgba64le", "bgra64le"]    # the last four: libswscale's 19-bit lines (yuv2planeX_16_c, yuv2rgba64_X_c)
+       "p016le", "yuv444p16le", "rgba64le", "bgra64le",    # these four: libswscale's 19-bit lines (yuv2planeX_16_c, yuv2rgba64_X_c)
+       "yuv420p10le", "yuv420p16le"]                       # planar high-depth 4:2:0: yuv2planeX_10_c / yuv2planeX_16_c per plane
 NO_SRC = ("rgba64le", "bgra64le")                          # destinations only (rgb64ToY_c is not restated): no fmt -> fmt scale row
 
 

@@ -564,10 +564,56 @@ def test_planar_high_depth_420_equal_format_and_size_is_a_plane_copy(dev, orc, f
         p.free()
 
 
-def test_planar_high_depth_420_are_sources_only(dev):
-    for df in ("yuv420p10le", "yuv420p16le"):
-        assert not dev.lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 32, 16, PIX_FMT[df], SWS["bicubic"], None)
-        assert not dev.lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
+@pytest.mark.parametrize("dst_fmt", ["yuv420p10le", "yuv420p16le"])
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p", "yuv444p", "p010le", "p016le", "yuv420p10le", "yuv420p16le", "yuv444p16le"])
+@pytest.mark.parametrize("geom", [(128, 48, 64, 24), (96, 40, 144, 60), (101, 45, 75, 33), (70, 22, 70, 22)])
+def test_planar_high_depth_420_destinations(dev, orc, src_fmt, dst_fmt, geom):
+    """YUV420P10LE on the 15-bit lines (yuv2plane1_10_c / yuv2planeX_10_c per plane: P010's arithmetic, sample in the low
+    bits), YUV420P16LE on the 19-bit lines (yuv2planeX_16_c per plane).  Equal format and size is the plane copy; equal size
+    from 8-bit planar is planarCopyWrapper's shift in libswscale, which the generic lines reproduce for limited range — the
+    reference's filter-pixfmts-null rows of both formats pin that (tests/test_fate_product_nut.py)"""
+    sw, sh, dw, dh = geom
+    src = _synth_hi420(orc, src_fmt, sw, sh, 85)
+    same = src_fmt == dst_fmt and (sw, sh) == (dw, dh)
+    want = src if same else orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"])
+    for align, extra in ((64, 0), (8, 0), (2, 2)):
+        d = dev.upload_planes(src, align, extra)
+        got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (i, kernel, align)
+            assert (pads[i] == 0xCD).all()
+        for p in d:
+            p.free()
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area"])
+def test_planar_high_depth_420_destinations_algorithms(dev, orc, flags):
+    for sf, df, geom in (("nv12", "yuv420p10le", (192, 70, 96, 36)), ("yuv420p10le", "yuv420p10le", (80, 30, 120, 50)),
+                         ("yuv420p", "yuv420p16le", (192, 70, 96, 36)), ("yuv420p16le", "yuv420p16le", (80, 30, 120, 50))):
+        sw, sh, dw, dh = geom
+        src = _synth_hi420(orc, sf, sw, sh, 86)
+        want = orc.sws(src, sw, sh, sf, dw, dh, df, SWS[flags])
+        d = dev.upload_planes(src, 64)
+        got, _, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS[flags], dst_align=64)
+        for g, wv in zip(got, want):
+            assert (g == wv).all(), (sf, df, flags, kernel)
+        for p in d:
+            p.free()
+
+
+def test_full_range_planar_depth_expansion_is_refused(dev):
+    """same size, 8-bit planar -> high-depth planar: libswscale's planarCopyWrapper bit-replicates the luma of a FULL-range
+    source (swscale_unscaled.c:1789-1830); the generic lines shift.  Not built: -ENOSYS instead of a silent shift."""
+    lib = dev.lib
+    for sf, df in (("yuv420p", "yuv420p10le"), ("yuv420p", "yuv420p16le"), ("yuv444p", "yuv444p16le")):
+        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
+        assert c
+        assert lib.gmat_sws_setRange(c, 1, 1) == -38 and lib.gmat_sws_setRange(c, 1, 0) == -38
+        assert lib.gmat_sws_setRange(c, 0, 0) == 0
+        lib.gmat_sws_freeContext(c)
+        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 32, 16, PIX_FMT[df], SWS["bicubic"], None)     # scaled: the generic path in libswscale too
+        assert c and lib.gmat_sws_setRange(c, 1, 1) == 0
+        lib.gmat_sws_freeContext(c)
 
 
 @pytest.mark.parametrize("fmt", ["p010le", "p016le"])

@@ -41,7 +41,8 @@ def md5ref(name):
 VIDEO_FILTER = ("null", "vflip", "crop", "crop_vflip", "vflip_crop", "vflip_vflip", "scale200", "scale500", "crop_scale")
 PIXFMTS_FILTERS = ("null", "copy", "hflip", "vflip", "crop", "transpose", "rotate", "scale")
 PIXFMTS = ("yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
-           "p016le", "yuv444p16le", "rgba64le", "bgra64le")        # the 19-bit path's destinations
+           "p016le", "yuv444p16le", "rgba64le", "bgra64le",        # the 19-bit path's destinations
+           "yuv420p10le", "yuv420p16le")                           # planar high-depth 4:2:0 (swscale_cuda.c:34-44)
 
 
 def nutmd5(name):
