@@ -82,3 +82,19 @@ def test_no_packed_shift_clamp_instructions(disassembly):
     for f in hits:
         by[f] = by.get(f, 0) + 1
     assert not hits, f"v_ashr_pk_* (upper half of the result is NOT zero on gfx950) in: {by} — use clip_u8_shr()"
+
+
+def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassembly):
+    """Audit of round 2 (all code objects): every SDWA instruction pads the unselected destination bits with zeros
+    (dst_unused:UNUSED_PAD), the d16_hi forms present are stores, and there is no v_sat_pk_* / v_cvt_pk_u8_* / d16 load.
+    Anything that MERGES into its destination is flagged here so that it gets looked at on hardware before it ships —
+    the emulator cannot tell."""
+    merging = ("UNUSED_PRESERVE", "v_sat_pk_u8_i16", "v_cvt_pk_u8_f32")
+    d16_loads = re.compile(r"\b(global|flat|buffer|ds|scratch)_(load|read)_\w*d16")
+    hits = {}
+    for t in disassembly:
+        for line in t.splitlines():
+            if any(m in line for m in merging) or d16_loads.search(line):
+                op = line.split()[0]
+                hits[op] = hits.get(op, 0) + 1
+    assert not hits, f"instructions that keep part of their destination: {hits} — verify on the GPU, then list them here"
