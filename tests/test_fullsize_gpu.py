@@ -125,6 +125,54 @@ def test_8k_nv12_to_4k_rgb24_bands(gpu, orc, kern):
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+def test_8k_to_4k_transcode_bands(gpu, orc, fmt):
+    """maximum size on the plane-walking 4:2:0 -> 4:2:0 kernel (32-bit row offsets: 4320 rows x 7680 bytes): three bands of
+    every plane against the oracle"""
+    sw, sh, dw, dh = 7680, 4320, 3840, 2160
+    src = synth_planes(orc, fmt, sw, sh, seed=29)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == "scale_yuv2p_kernel" and all((pd == 0xCD).all() for pd in pads)
+    for y0 in (0, 1072, dh - 32):                       # even starts: 4:2:0 rows come in pairs sharing a chroma row
+        want = _oracle_rows(orc, src, sw, sh, fmt, dw, dh, fmt, y0, y0 + 32)
+        assert (got[0][y0:y0 + 32] == want[0][y0:y0 + 32]).all(), y0
+        for pl in range(1, len(got)):
+            assert (got[pl][y0 // 2:y0 // 2 + 16] == want[pl][y0 // 2:y0 // 2 + 16]).all(), (pl, y0)
+
+
+def test_8k_rgb24_to_4k_bands(gpu, orc):
+    """maximum size on the packed-RGB strip kernel (99.5 MB source frame)"""
+    sw, sh, dw, dh = 7680, 4320, 3840, 2160
+    src = synth_planes(orc, "rgb24", sw, sh, seed=31)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, "rgb24", dw, dh, "bgra", dst_align=256)
+    assert k == "scale_rgb2s_kernel" and (pads[0] == 0xCD).all()
+    for y0 in (0, 1072, dh - 32):
+        want = _oracle_rows(orc, src, sw, sh, "rgb24", dw, dh, "bgra", y0, y0 + 32)[0]
+        assert (got[0][y0:y0 + 32] == want[y0:y0 + 32]).all(), y0
+
+
+@pytest.mark.parametrize("bpp", [3, 4])
+def test_8k_rotate_flip_smooth(gpu, orc, bpp):
+    """maximum size on smooth121_kernel, fused with the transpose (row offsets up to 4320 x 30720 bytes = 132 MB for rgba)"""
+    import ctypes as C
+    from harness import DevPlane
+    w, h = 7680, 4320
+    src = orc.lcg((h, w * bpp), 37)
+    a = np.zeros((w, h * bpp), np.uint8); b = np.zeros((w, h * bpp), np.uint8); want = np.zeros((w, h * bpp), np.uint8)
+    m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+    orc.L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)
+    orc.L.orc_hflip(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], h, w, bpp)
+    orc.L.orc_conv3x3(b.ctypes.data, b.strides[0], want.ctypes.data, want.strides[0], h, w, bpp, m, 1 / 16, 0.0)
+    d = gpu.upload_planes([src], 256)[0]
+    o = DevPlane(gpu, w, h * bpp, (h * bpp + 255) // 256 * 256)
+    assert gpu.lib.gmat_rotate_flip_smooth(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, None) == 0
+    assert (o.download() == want).all()
+    assert (o.download(True)[:, o.row_bytes:] == 0xCD).all()
+    d.free(); o.free()
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
 @pytest.mark.parametrize("which", ["strip", "tiled"])
 def test_4k_to_1080p_transcode(gpu, orc, fmt, which, monkeypatch):
     """the transcode down-scale at full size on BOTH kernels that serve it (the plane-walking one by default, the tiled one
