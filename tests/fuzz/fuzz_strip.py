@@ -51,11 +51,17 @@ for case in range(n):
             if rng.random() < 0.7:                              # the geometries scale_yuv2p_kernel takes
                 sw, sh = 16 * rng.randint(4, maxw // 16), 4 * rng.randint(8, 40); dw, dh = sw // 2, sh // 2
         else:            sf, df = rng.choice(RGB3), rng.choice(RGBX)
+        if fam >= 0.45 and fam < 0.8 and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
+            sf = df = rng.choice(["p010le", "yuv420p10le"])
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])
         try:
-            want = orc.sws(synth := synth_planes(orc, sf, sw, sh, seed=7000 + case), sw, sh, sf, dw, dh, df, SWS[algo], colorspace=cs)
+            synth = synth_planes(orc, sf, sw, sh, seed=7000 + case)
+            if sf == "yuv420p10le":
+                for pl in synth: pl.view("<u2")[...] &= 0x3FF        # valid input: 10 bits in the low end
+            if sf in ("p010le", "yuv420p10le") and align < 2: align, extra = 2, 2
+            want = orc.sws(synth, sw, sh, sf, dw, dh, df, SWS[algo], colorspace=cs)
         except AssertionError:
             continue
         d = dev.upload_planes(synth, align, extra)

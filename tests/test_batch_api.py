@@ -14,6 +14,10 @@ def _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, dw, dh, nframes, nstreams, al
     c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT[dst_fmt], flags | SWS["hwaccel"], None)
     assert c
     srcs = [synth_planes(orc, src_fmt, sw, sh, seed=300 + 7 * f) for f in range(nframes)]
+    if src_fmt == "yuv420p10le":                           # valid input: 10 significant bits in the low end of each sample
+        for fr in srcs:
+            for p in fr:
+                p.view("<u2")[...] &= 0x3FF
     dsrc = [dev.upload_planes(s, align) for s in srcs]
     ddst = [dev.planes_like(dst_fmt, dw, dh, align) for _ in range(nframes)]
     sp = (C.c_void_p * (4 * nframes))()

@@ -140,6 +140,22 @@ def test_8k_to_4k_transcode_bands(gpu, orc, fmt):
             assert (got[pl][y0 // 2:y0 // 2 + 16] == want[pl][y0 // 2:y0 // 2 + 16]).all(), (pl, y0)
 
 
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+def test_4k_to_1080p_10bit_transcode(gpu, orc, fmt):
+    """the HDR transcode down-scale at full size on the 10-bit plane-walking kernel: every plane against the oracle"""
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = synth_planes(orc, fmt, sw, sh, seed=41)
+    if fmt == "yuv420p10le":
+        for p in src:
+            p.view("<u2")[...] &= 0x3FF
+    want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == "scale_yuv2p16_kernel"
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 def test_8k_rgb24_to_4k_bands(gpu, orc):
     """maximum size on the packed-RGB strip kernel (99.5 MB source frame)"""
     sw, sh, dw, dh = 7680, 4320, 3840, 2160

@@ -139,3 +139,91 @@ def test_range_conversion_is_not_the_strip_kernels(dev, orc):
     lib.gmat_sws_freeContext(c)
     for p in d + o:
         p.free()
+
+
+# ---- 10 bits in 16-bit containers: P010LE -> P010LE (HDR transcode) and YUV420P10LE -> YUV420P10LE -------------------------
+STRIP16 = "scale_yuv2p16_kernel"
+
+
+def _synth10(orc, fmt, w, h, seed):
+    src = synth_planes(orc, fmt, w, h, seed=seed)         # P010: all 16 bits random — the low six must be ignored (>> 6)
+    if fmt == "yuv420p10le":
+        for p in src:
+            p.view("<u2")[...] &= 0x3FF                   # planar: 10 significant bits in the low end
+    return src
+
+
+def _check10(dev, orc, fmt, sw, sh, flags="bicubic", align=256, extra=0, seed=51):
+    src = _synth10(orc, fmt, sw, sh, seed)
+    want = orc.sws(src, sw, sh, fmt, sw // 2, sh // 2, fmt, SWS[flags])
+    d = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d, sw, sh, fmt, sw // 2, sh // 2, fmt, SWS[flags], dst_align=align, dst_extra=extra)
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{kernel} plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (pads[i] == 0xCD).all(), f"{kernel} plane {i}: wrote into the row padding"
+    for p in d:
+        p.free()
+    return kernel
+
+
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_10bit_same_layout_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, fmt, geom):
+    """the rule is the 8-bit one; what declines goes to the generic plane scaler (the tiled 2:1 kernel takes 8-bit sources only)"""
+    sw, sh = geom
+    strip_rows(0)
+    want = STRIP16 if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt) else GENERIC
+    assert _check10(dev, orc, fmt, sw, sh) == want
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 8, 13, 64, 1000])
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+def test_10bit_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
+    strip_rows(rows)
+    assert _check10(dev, orc, fmt, 528, 52) == STRIP16
+
+
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+def test_10bit_rows_that_are_not_8_byte_aligned_fall_back(dev, orc, fmt):
+    """the 10-bit twin stores 8 bytes per lane"""
+    assert _check10(dev, orc, fmt, 528, 52, align=4, extra=4) == GENERIC
+    assert _check10(dev, orc, fmt, 528, 52, align=2, extra=2) == GENERIC
+    assert _check10(dev, orc, fmt, 528, 52, align=8, extra=8) == STRIP16
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss", "lanczos"])
+def test_10bit_filters(dev, orc, kern_yuv, flags):
+    k = _check10(dev, orc, "p010le", 528, 52, flags)
+    assert (k == STRIP16) == (kern_yuv == "strip" and flags != "lanczos"), (flags, k)
+
+
+def test_10bit_saturating_content(dev, orc, strip_rows):
+    """all-maximum and checkerboard samples: hScale16To15_c's min(val >> 9, 32767) and the 10-bit output clip both trigger
+    (bicubic overshoot of 1023-valued samples exceeds 15 bits)"""
+    strip_rows(0)
+    lib = dev.lib
+    sw, sh = 528, 52
+    for fmt, hi in (("p010le", 0xFFC0), ("yuv420p10le", 0x03FF)):
+        for pattern in ("max", "checker"):
+            src = _synth10(orc, fmt, sw, sh, 3)
+            for p in src:
+                v = p.view("<u2")
+                v[...] = hi
+                if pattern == "checker":
+                    v[::2, ::2] = 0; v[1::2, 1::2] = 0
+            want = orc.sws(src, sw, sh, fmt, sw // 2, sh // 2, fmt, SWS["bicubic"])
+            d = dev.upload_planes(src, 256)
+            got, pads, kernel = dev.sws(d, sw, sh, fmt, sw // 2, sh // 2, fmt, SWS["bicubic"], dst_align=256)
+            assert kernel == STRIP16
+            for g, w in zip(got, want):
+                assert (g == w).all(), (fmt, pattern)
+            for p in d:
+                p.free()
+
+
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+def test_10bit_batched_frames(dev, orc, strip_rows, kern_yuv, fmt):
+    strip_rows(0)
+    k = _run_batch(dev, orc, fmt, fmt, 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
+    assert k == (STRIP16 if kern_yuv == "strip" else GENERIC), k

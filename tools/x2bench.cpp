@@ -28,6 +28,7 @@ static size_t frame_bytes(int fmt, int w, int h)
 {
     switch (fmt) {
     case GMAT_PIX_FMT_NV12: case GMAT_PIX_FMT_YUV420P: return (size_t)w * h * 3 / 2;
+    case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_YUV420P10LE: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
     default: return 0;
@@ -38,6 +39,8 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
     p[0] = p[1] = p[2] = p[3] = nullptr; s[0] = s[1] = s[2] = s[3] = 0;
     switch (fmt) {
     case GMAT_PIX_FMT_NV12: p[0] = b; p[1] = b + (size_t)w * h; s[0] = w; s[1] = w; break;
+    case GMAT_PIX_FMT_P010LE: p[0] = b; p[1] = b + (size_t)w * h * 2; s[0] = 2 * w; s[1] = 2 * w; break;
+    case GMAT_PIX_FMT_YUV420P10LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)(w / 2) * (h / 2) * 2; s[0] = 2 * w; s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: p[0] = b; s[0] = 3 * w; break;
     default: p[0] = b; s[0] = 4 * w; break;
@@ -181,6 +184,15 @@ int main(int argc, char **argv)
         {"nv12 1080p->540p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p bgra bilinear", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"land: p010 4K->1080p p010 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"land: yuv420p10 4K->1080p yuv420p10", GMAT_PIX_FMT_YUV420P10LE, 3840, 2160, GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"land: p010 4K->1080p nv12 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"land: nv12 4K->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
+        {"land: nv12 4K->720p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        {"land: nv12 1080p->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
+        {"land: nv12 1080p->4K nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"land: nv12 4K->1080p nv12 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_LANCZOS},
+        {"land: nv12 4K->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
         {"nv12 1080p->1080p rgb24 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
     };
     struct Op { const char *label; int op, bpp; };
@@ -188,7 +200,9 @@ int main(int argc, char **argv)
                       {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3}};
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
-    for (const Case &k : cases)
+    for (const Case &k : cases) {
+        if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
+    }
     return 0;
 }
