@@ -464,7 +464,7 @@ static bool yuv2p_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
     // frame with 4-byte pitches would be sent to the slower kernel for no reason of this one's
     // (the 10-bit twin stores 8 bytes per lane: 8-byte aligned rows there)
     const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
-    const bool dst4 = (dall & (c->y2p.depth == 10 ? 7 : 3)) == 0;
+    const bool dst4 = (dall & (c->y2p.dstDepth == 10 ? 7 : 3)) == 0;
     return c->y2p.ok && !c->rangeConv && ya.srcAligned && dst4 && !ya.prof &&
            (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
 }
@@ -475,13 +475,20 @@ static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     std::memset(&pa, 0, sizeof(pa));
     pa.ys = ya.ys; pa.us = ya.us; pa.vs = ya.vs;
     pa.nv12 = ya.nv12 || c->srcFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma on both sides
-    pa.depth = c->y2p.depth;
+    pa.srcDepth = c->y2p.srcDepth; pa.dstDepth = c->y2p.dstDepth;
     pa.srcW = ya.srcW; pa.srcH = ya.srcH; pa.chrSrcW = ya.chrSrcW; pa.chrSrcH = ya.chrSrcH;
     pa.dstW = ya.dstW; pa.dstH = ya.dstH; pa.chrDstW = ya.chrDstW; pa.chrDstH = ya.chrDstH;
     pa.ds = ya.ds; pa.dsU = ya.dsU; pa.dsV = ya.dsV;
     for (int k = 0; k < 4; k++) { pa.hL[k] = c->y2p.hL[k]; pa.hC[k] = c->y2p.hC[k]; pa.vL[k] = c->y2p.vL[k]; pa.vC[k] = c->y2p.vC[k]; }
     pa.lr = c->y2p.lr; pa.cr = c->y2p.cr; pa.xcdRemap = ya.xcdRemap;
     return pa;
+}
+
+// the name the plane-walking kernel reports by sample depths (one template, four instantiations per chroma layout)
+static const char *yuv2p_name(const GmatSwsContext *c)
+{
+    const int s = c->y2p.srcDepth, d = c->y2p.dstDepth;
+    return s == 8 ? (d == 8 ? "scale_yuv2p_kernel" : "scale_yuv2p_kernel<8to10>") : (d == 8 ? "scale_yuv2p_kernel<10to8>" : "scale_yuv2p16_kernel");
 }
 
 // argument block of the strip-walking packed-RGB scaler
@@ -621,7 +628,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
-    c->lastKernel = use2s ? "scale_yuv2s_kernel" : use2p ? (c->y2p.depth == 10 ? "scale_yuv2p16_kernel" : "scale_yuv2p_kernel") : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    c->lastKernel = use2s ? "scale_yuv2s_kernel" : use2p ? yuv2p_name(c) : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -1147,7 +1154,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 Yuv2xFrames one;
                 std::memset(&one, 0, sizeof(one));
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = c->y2p.depth == 10 ? "scale_yuv2p16_kernel" : "scale_yuv2p_kernel";
+                c->lastKernel = yuv2p_name(c);
                 r = launch_scale_yuv2p(make_yuv2p_args(c, ya), c->stream, &one, 1);
                 break;
             }

@@ -266,13 +266,13 @@ int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrame
 // ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> YUV 4:2:0 scaler (k_scale_yuv2p.hip): NV12 -> NV12 and
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
 struct Yuv2pTables {
-    int ok = 0, depth = 8;                                          // 8, or 10: P010LE / YUV420P10LE on both sides (scale_yuv2p16_kernel)
+    int ok = 0, srcDepth = 8, dstDepth = 8;                         // 10: P010LE / YUV420P10LE on that side
     int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0}, vC[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
     int lr = 0, cr = 0;                                             // vertical accumulator start values (dither << 12)
 };
 struct Yuv2pArgs {
     int ys, us, vs, nv12;                        // nv12: interleaved chroma (NV12, P010LE)
-    int depth;                                   // 8 or 10
+    int srcDepth, dstDepth;                      // 8 or 10 bits per sample on each side
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV;
     int32_t hL[4], hC[4], vL[4], vC[4];

@@ -52,7 +52,8 @@ for case in range(n):
                 sw, sh = 16 * rng.randint(4, maxw // 16), 4 * rng.randint(8, 40); dw, dh = sw // 2, sh // 2
         else:            sf, df = rng.choice(RGB3), rng.choice(RGBX)
         if fam >= 0.45 and fam < 0.8 and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
-            sf = df = rng.choice(["p010le", "yuv420p10le"])
+            sf, df = rng.choice([("p010le", "p010le"), ("yuv420p10le", "yuv420p10le"), ("nv12", "p010le"), ("p010le", "nv12"),
+                                 ("yuv420p", "yuv420p10le"), ("yuv420p10le", "yuv420p")])
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])
@@ -60,7 +61,7 @@ for case in range(n):
             synth = synth_planes(orc, sf, sw, sh, seed=7000 + case)
             if sf == "yuv420p10le":
                 for pl in synth: pl.view("<u2")[...] &= 0x3FF        # valid input: 10 bits in the low end
-            if sf in ("p010le", "yuv420p10le") and align < 2: align, extra = 2, 2
+            if (sf in ("p010le", "yuv420p10le") or df in ("p010le", "yuv420p10le")) and align < 2: align, extra = 2, 2   # 16-bit samples
             want = orc.sws(synth, sw, sh, sf, dw, dh, df, SWS[algo], colorspace=cs)
         except AssertionError:
             continue
@@ -75,7 +76,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith("scale_yuv2p") else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

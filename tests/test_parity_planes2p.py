@@ -227,3 +227,55 @@ def test_10bit_batched_frames(dev, orc, strip_rows, kern_yuv, fmt):
     strip_rows(0)
     k = _run_batch(dev, orc, fmt, fmt, 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
     assert k == (STRIP16 if kern_yuv == "strip" else GENERIC), k
+
+
+# ---- across depths: 8 -> 10 bits (an 8-bit source into a 10-bit encode) and 10 -> 8, same chroma layout -----------------------
+CROSS = {("nv12", "p010le"): "scale_yuv2p_kernel<8to10>", ("yuv420p", "yuv420p10le"): "scale_yuv2p_kernel<8to10>",
+         ("p010le", "nv12"): "scale_yuv2p_kernel<10to8>", ("yuv420p10le", "yuv420p"): "scale_yuv2p_kernel<10to8>"}
+
+
+def _check_cross(dev, orc, sf, df, sw, sh, flags="bicubic", align=256, extra=0):
+    src = _synth10(orc, sf, sw, sh, 57)
+    want = orc.sws(src, sw, sh, sf, sw // 2, sh // 2, df, SWS[flags])
+    d = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d, sw, sh, sf, sw // 2, sh // 2, df, SWS[flags], dst_align=align, dst_extra=extra)
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{kernel} plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
+        assert (pads[i] == 0xCD).all(), f"{kernel} plane {i}: wrote into the row padding"
+    for p in d:
+        p.free()
+    return kernel
+
+
+@pytest.mark.parametrize("pair", list(CROSS))
+@pytest.mark.parametrize("geom", GEOMS)
+def test_cross_depth_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, pair, geom):
+    sw, sh = geom
+    strip_rows(0)
+    sf, df = pair
+    k = _check_cross(dev, orc, sf, df, sw, sh)
+    if kern_yuv == "strip" and strip_takes(sw, sh, "nv12", "nv12"):     # the geometry rule does not depend on the depth
+        assert k == CROSS[pair], k
+    else:
+        assert k.startswith("scale_yuv_kernel"), k                      # the generic plane scaler (the tiled 2:1 kernel is 8 -> 8 only)
+
+
+@pytest.mark.parametrize("pair", list(CROSS))
+@pytest.mark.parametrize("rows", [1, 3, 5, 13, 1000])
+def test_cross_depth_segmentation(dev, orc, strip_rows, pair, rows):
+    strip_rows(rows)
+    assert _check_cross(dev, orc, pair[0], pair[1], 528, 52) == CROSS[pair]
+
+
+@pytest.mark.parametrize("pair", list(CROSS))
+def test_cross_depth_destination_alignment(dev, orc, pair):
+    """8-bit destinations store dwords, 10-bit ones 8 bytes"""
+    need = 8 if CROSS[pair].endswith("<8to10>") else 4
+    assert _check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need, extra=need) == CROSS[pair]
+    assert _check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need // 2, extra=need // 2).startswith("scale_yuv_kernel")
+
+
+def test_mixed_layouts_across_depths_stay_generic(dev, orc):
+    for sf, df in (("nv12", "yuv420p10le"), ("yuv420p", "p010le"), ("p010le", "yuv420p"), ("yuv420p10le", "nv12"), ("p010le", "yuv420p10le")):
+        assert _check_cross(dev, orc, sf, df, 528, 52).startswith("scale_yuv_kernel"), (sf, df)

@@ -186,7 +186,9 @@ int main(int argc, char **argv)
         {"rgb24 4K->1080p bgra bilinear", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BILINEAR},
         {"p010 4K->1080p p010 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"yuv420p10le 4K->1080p yuv420p10le", GMAT_PIX_FMT_YUV420P10LE, 3840, 2160, GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_SWS_BICUBIC},
-        {"land: p010 4K->1080p nv12 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 4K->1080p p010 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"p010 4K->1080p nv12 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"land: p010 4K->1080p nv12 (dup)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->720p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 1080p->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
