@@ -479,7 +479,8 @@ static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     pa.srcW = ya.srcW; pa.srcH = ya.srcH; pa.chrSrcW = ya.chrSrcW; pa.chrSrcH = ya.chrSrcH;
     pa.dstW = ya.dstW; pa.dstH = ya.dstH; pa.chrDstW = ya.chrDstW; pa.chrDstH = ya.chrDstH;
     pa.ds = ya.ds; pa.dsU = ya.dsU; pa.dsV = ya.dsV;
-    for (int k = 0; k < 4; k++) { pa.hL[k] = c->y2p.hL[k]; pa.hC[k] = c->y2p.hC[k]; pa.vL[k] = c->y2p.vL[k]; pa.vC[k] = c->y2p.vC[k]; }
+    pa.np = c->y2p.np;
+    for (int k = 0; k < 6; k++) { pa.hL[k] = c->y2p.hL[k]; pa.hC[k] = c->y2p.hC[k]; pa.vL[k] = c->y2p.vL[k]; pa.vC[k] = c->y2p.vC[k]; }
     pa.lr = c->y2p.lr; pa.cr = c->y2p.cr; pa.xcdRemap = ya.xcdRemap;
     return pa;
 }

@@ -60,22 +60,24 @@ __device__ __forceinline__ int p2_odd(unsigned hi, unsigned lo) { return (int)((
 struct P2Plane {
     const uint8_t *src; uint8_t *dst;
     int ss, ds, srcW, srcH, dstW;              // strides in bytes, widths in samples (UV plane: in UV positions)
-    const int32_t *h, *v;                      // 4 int16 pairs each on the odd-aligned window [2x - 3, 2x + 4]
+    const int32_t *h, *v;                      // NP int16 pairs each on the odd-aligned window [2x - (NP - 1), 2x + NP]
     int rnd;                                   // vertical accumulator start (8-bit: the dither term << 12; 10-bit: 1 << 16)
     int srcHi6, dstHi6;                        // P010: the 10 significant bits are the high ones (>> 6 in, << 6 out)
 };
 
-// vertical stage of 4 values + store: D16 ? 8 bytes (4 x 16 bit) : 4 bytes
-template <bool D16>
-__device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[4][4], int s1, int s2, int s3, int s4,
-                                          int32_t v0, int32_t v1, int32_t v2, int32_t v3, bool active, unsigned byteOff)
+__device__ __forceinline__ unsigned p2_ld4(const uint8_t *p) { return *reinterpret_cast<const unsigned *>(p); }
+
+// vertical stage of 4 values + store: D16 ? 8 bytes (4 x 16 bit) : 4 bytes.  Slot SLOT holds the newest row pair, the
+// oldest is SLOT + 1 (mod NP).
+template <bool D16, int NP, int SLOT>
+__device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][4], bool active, unsigned byteOff)
 {
     unsigned w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int acc = P.rnd;
-        acc = p2_dot2(hw[s1][q], v0, acc); acc = p2_dot2(hw[s2][q], v1, acc);
-        acc = p2_dot2(hw[s3][q], v2, acc); acc = p2_dot2(hw[s4][q], v3, acc);
+#pragma unroll
+        for (int k = 0; k < NP; k++) acc = p2_dot2(hw[(SLOT + 1 + k) % NP][q], P.v[k], acc);
         if (D16) {
             w[q] = (unsigned)min(max(acc, 0), (1024 << 17) - 1) >> 17;               // clamp, then shift (see clip_u8_shr)
             if (P.dstHi6) w[q] <<= 6;
@@ -88,142 +90,217 @@ __device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[4][4
     else     *reinterpret_cast<unsigned *>(P.dst + byteOff) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
 }
 
-// ---- one single-channel plane: srcW x srcH -> dstW x dstH (exactly half), rows [y0, y0 + nOut) of the strip at X0 ----
-struct P2Row { uint4 a, b; };                  // 16 samples from sample 2xc - 4 (8-bit: a only)
+// the row loop, unrolled by NP so that the slot of an iteration is a compile-time constant
+template <int NP, typename Body, typename Edge>
+__device__ __forceinline__ void p2_rows(int nIter, Body &&body, Edge edge_c)
+{
+    for (int j0 = 0; j0 < nIter; j0 += NP) {
+        body(j0, std::integral_constant<int, 0>(), edge_c);
+        if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+        if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+        if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        if constexpr (NP > 4) {
+            if (j0 + 4 < nIter) body(j0 + 4, std::integral_constant<int, 4>(), edge_c);
+            if (j0 + 5 < nIter) body(j0 + 5, std::integral_constant<int, 5>(), edge_c);
+        }
+    }
+}
 
-template <bool S16, bool D16>
+// ---- one single-channel plane: srcW x srcH -> dstW x dstH (exactly half), rows [y0, y0 + nOut) of the strip at X0 ----
+// NP = 4: 16 samples from sample 2xc - 4 (8-bit: 4 dwords, 16-bit: 8).  NP = 6 (Lanczos-3, 12 taps): 8-bit 24 samples from
+// 2xc - 8 (6 dwords), 16-bit 20 samples from 2xc - 6 (10 dwords).
+struct P2Row { unsigned d[10]; };
+
+template <bool S16, bool D16, int NP>
 __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, int nOut, int lane)
 {
+    constexpr int BL = S16 ? (NP == 4 ? 4 : 6) : (NP == 4 ? 4 : 8);      // samples between the window base and 2xc
+    constexpr int ND = S16 ? (NP == 4 ? 8 : 10) : (NP == 4 ? 4 : 6);     // dwords of the window
+    constexpr int SPD = S16 ? 2 : 4;                                     // samples per dword
+    constexpr int SHR = S16 ? 9 : 7;
     const int xo = X0 + 4 * lane;
     const bool active = xo < P.dstW;
     const int xc = active ? xo : P.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
     const bool edgeWave = X0 == 0 || X0 + P2_STRIP >= P.dstW;
-    const int want = 2 * xc - 4;                                // samples [2xc - 4, 2xc + 12) of the row
-    const int off = min(max(want, 0), P.srcW - 16);
-    const int sh = want - off;                                  // -4 at the left plane edge, +4 at the right one
+    const int want = 2 * xc - BL;                               // first sample of the window
+    const int off = min(max(want, 0), P.srcW - ND * SPD);       // NP = 4: the whole window clamped, then shifted back in registers
+    const int sh = want - off;                                  //         -4 at the left plane edge, +4 at the right one
     const unsigned uoff = (S16 ? 2u : 1u) * (unsigned)off;
-    const int nIter = nOut + 3;                                 // 3 warm-up row pairs fill the vertical window
-    const int32_t h0 = P.h[0], h1 = P.h[1], h2 = P.h[2], h3 = P.h[3];
-    const int32_t v0 = P.v[0], v1 = P.v[1], v2 = P.v[2], v3 = P.v[3];
+    const int wd0 = want / SPD - (want < 0 ? 1 : 0) * ((-want % SPD) != 0);   // dword index of the window base (want is a multiple of SPD)
+    const int lastDw = P.srcW / SPD - 1;
+    const int nIter = nOut + NP - 1;                            // NP - 1 warm-up row pairs fill the vertical window
+    const int m0 = y0 - (NP / 2 - 1);                           // row pair of iteration 0 (pair m = rows 2m - 1, 2m)
     const bool hi6 = P.srcHi6 != 0;
 
-    auto load1 = [&](int row, P2Row &r) {
-        const unsigned o = (unsigned)min(max(row, 0), P.srcH - 1) * (unsigned)P.ss + uoff;
-        r.a = p2_ld16(P.src + o);
-        if (S16) r.b = p2_ld16(P.src + (unsigned)(o + 16u));
-    };
-    auto load = [&](int m, P2Row &ra, P2Row &rb) { load1(2 * m - 1, ra); load1(2 * m, rb); };
-    // horizontal filter of one row: 4 outputs from 7 odd-aligned pairs
-    auto hrow = [&](const P2Row &R, auto edge_c, int (&s)[4]) {
-        int p[7];
-        if (S16) {
-            unsigned d[8] = {R.a.x, R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w};
-            if (hi6) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) d[k] = p2_shr6(d[k]);
+    auto load1 = [&](int row, P2Row &r, auto edge_c) {
+        const unsigned o = (unsigned)min(max(row, 0), P.srcH - 1) * (unsigned)P.ss;
+        if (NP == 4 || !decltype(edge_c)::value) {
+            const unsigned b = o + (NP == 4 ? uoff : (S16 ? 2u : 1u) * (unsigned)want);
+            const uint4 t0 = p2_ld16(P.src + b);
+            r.d[0] = t0.x; r.d[1] = t0.y; r.d[2] = t0.z; r.d[3] = t0.w;
+            if (ND > 4) {
+                if (ND >= 8) { const uint4 t1 = p2_ld16(P.src + (unsigned)(b + 16u)); r.d[4] = t1.x; r.d[5] = t1.y; r.d[6] = t1.z; r.d[7] = t1.w; }
+                if (ND == 6) { const uint2 t1 = p2_ld8(P.src + (unsigned)(b + 16u)); r.d[4] = t1.x; r.d[5] = t1.y; }
+                if (ND == 10) { const uint2 t2 = p2_ld8(P.src + (unsigned)(b + 32u)); r.d[8] = t2.x; r.d[9] = t2.y; }
             }
-            if (decltype(edge_c)::value) {
+        } else {
+            // NP = 6 in a wave that touches a plane edge: two lanes a side overlap the edge by different amounts, so every
+            // dword comes from its own clamped address (the edge sample is replicated in hrow)
+#pragma unroll
+            for (int i = 0; i < ND; i++) r.d[i] = p2_ld4(P.src + (unsigned)(o + 4u * (unsigned)min(max(wd0 + i, 0), lastDw)));
+        }
+    };
+    auto load = [&](int m, P2Row &ra, P2Row &rb, auto edge_c) { load1(2 * m - 1, ra, edge_c); load1(2 * m, rb, edge_c); };
+    // horizontal filter of one row: 4 outputs from NP + 3 odd-aligned pairs
+    auto hrow = [&](const P2Row &R, auto edge_c, int (&s)[4]) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        unsigned d[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) d[k] = R.d[k];
+        if (S16 && hi6) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) d[k] = p2_shr6(d[k]);
+        }
+        if constexpr (EDGE && NP == 4) {
+            if constexpr (S16) {
                 if (sh < 0) {                                   // 4 samples = 2 dwords to the right, first sample replicated
                     const unsigned r = p2_rep(d[0], 0x01000100u);
 #pragma unroll
-                    for (int k = 7; k >= 2; k--) d[k] = d[k - 2];
+                    for (int k = ND - 1; k >= 2; k--) d[k] = d[k - 2];
                     d[0] = d[1] = r;
                 } else if (sh > 0) {
-                    const unsigned r = p2_rep(d[7], 0x03020302u);
+                    const unsigned r = p2_rep(d[ND - 1], 0x03020302u);
 #pragma unroll
-                    for (int k = 0; k < 6; k++) d[k] = d[k + 2];
-                    d[6] = d[7] = r;
+                    for (int k = 0; k < ND - 2; k++) d[k] = d[k + 2];
+                    d[ND - 2] = d[ND - 1] = r;
                 }
+            } else {
+                if (sh < 0) { const unsigned r = p2_rep(d[0], 0x00000000u); d[3] = d[2]; d[2] = d[1]; d[1] = d[0]; d[0] = r; }
+                else if (sh > 0) { const unsigned r = p2_rep(d[3], 0x03030303u); d[0] = d[1]; d[1] = d[2]; d[2] = d[3]; d[3] = r; }
             }
+        }
+        if constexpr (EDGE && NP != 4) {
 #pragma unroll
-            for (int k = 0; k < 7; k++) p[k] = p2_odd(d[k + 1], d[k]);      // samples (2k-3, 2k-2) rel. to 2xc
-        } else {
-            uint4 L = R.a;
-            if (decltype(edge_c)::value) {
-                if (sh < 0) L = make_uint4(p2_rep(L.x, 0x00000000u), L.x, L.y, L.z);
-                else if (sh > 0) L = make_uint4(L.y, L.z, L.w, p2_rep(L.w, 0x03030303u));
+            for (int i = 0; i < ND; i++) {
+                const int idx = wd0 + i;                        // the dword this one stands for; outside the row: the edge sample
+                const unsigned lo = S16 ? p2_rep(d[i], 0x01000100u) : p2_rep(d[i], 0x00000000u);
+                const unsigned hi = S16 ? p2_rep(d[i], 0x03020302u) : p2_rep(d[i], 0x03030303u);
+                d[i] = idx < 0 ? lo : idx > lastDw ? hi : d[i];
             }
-            p[0] = p2_pair12(L.x); p[1] = p2_pair30(L.y, L.x); p[2] = p2_pair12(L.y); p[3] = p2_pair30(L.z, L.y);
-            p[4] = p2_pair12(L.z); p[5] = p2_pair30(L.w, L.z); p[6] = p2_pair12(L.w);
+        }
+        int p[NP + 3];
+        if (S16) {
+#pragma unroll
+            for (int k = 0; k < NP + 3; k++) p[k] = p2_odd(d[k + 1], d[k]);      // samples (base + 1 + 2k, + 2 + 2k)
+        } else {
+            constexpr int O0 = BL - (NP - 1);                   // byte of the first pair: 1 (NP = 4) or 3 (NP = 6)
+#pragma unroll
+            for (int k = 0; k < NP + 3; k++) {
+                const int o = O0 + 2 * k;
+                p[k] = (o & 3) == 1 ? p2_pair12(d[o >> 2]) : p2_pair30(d[(o >> 2) + 1], d[o >> 2]);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            s[j] = p2_dot2(p[j + 3], h3, p2_dot2(p[j + 2], h2, p2_dot2(p[j + 1], h1, p2_dot2(p[j], h0, 0))));
+        for (int j = 0; j < 4; j++) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) acc = p2_dot2(p[j + k], P.h[k], acc);
+            s[j] = acc;
+        }
     };
 
-    int hw[4][4];                                               // [slot][output]: (row 2m-1 | row 2m << 16), 15-bit lines
+    int hw[NP][4];                                              // [slot][output]: (row 2m-1 | row 2m << 16), 15-bit lines
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NP; s++)
 #pragma unroll
         for (int j = 0; j < 4; j++) hw[s][j] = 0;
     P2Row bufA[2], bufB[2];                                     // ping-pong: iteration j consumes [j & 1], prefetches the other
-    bufA[0].b = bufB[0].b = bufA[1].a = bufA[1].b = bufB[1].a = bufB[1].b = make_uint4(0u, 0u, 0u, 0u);
-    load(y0 - 1, bufA[0], bufB[0]);
+#pragma unroll
+    for (int i = 0; i < 10; i++) bufA[0].d[i] = bufB[0].d[i] = bufA[1].d[i] = bufB[1].d[i] = 0u;
 
     auto body = [&](const int j, auto slot_c, auto edge_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (j + 1 < nIter) load(y0 + j, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1]);
+        // with NP even the parity of j equals the parity of SLOT
+        if (j + 1 < nIter) load(m0 + j + 1, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1], edge_c);
         {
             int sa[4], sb[4];
             hrow(bufA[SLOT & 1], edge_c, sa);
             hrow(bufB[SLOT & 1], edge_c, sb);
 #pragma unroll
             for (int q = 0; q < 4; q++)                        // hScale8To15_c / hScale16To15_c: min(val >> 7 | 9, 32767)
-                hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> (S16 ? 9 : 7), sb[q] >> (S16 ? 9 : 7)));
+                hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> SHR, sb[q] >> SHR));
         }
-        if (j >= 3) {
-            const int yo = y0 + j - 3;
-            p2_vstore<D16>(P, hw, (SLOT + 1) & 3, (SLOT + 2) & 3, (SLOT + 3) & 3, SLOT & 3, v0, v1, v2, v3, active,
-                           (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
-        }
-    };
-    auto run = [&](auto edge_c) {
-        for (int j0 = 0; j0 < nIter; j0 += 4) {
-            body(j0, std::integral_constant<int, 0>(), edge_c);
-            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
-            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
-            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        if (j >= NP - 1) {
+            const int yo = y0 + j - (NP - 1);
+            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
         }
     };
-    if (edgeWave) run(std::true_type()); else run(std::false_type());
+    if (edgeWave) { load(m0, bufA[0], bufB[0], std::true_type());  p2_rows<NP>(nIter, body, std::true_type()); }
+    else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
 }
 
 // ---- the interleaved UV plane (NV12: 2 bytes a position; P010: one dword): a lane makes 2 UV outputs a row ------------
-struct P2RowUV { uint4 a, b, c; };             // 8-bit: a = 16 bytes from position 2c - 4, b.xy = 8 bytes from 2c + 4; 16-bit: 12 dwords
+// window: positions [2cc - NP, 2cc + NP + 4): 8-bit NP + 2 dwords (6 / 8), 16-bit 2 NP + 4 dwords (12 / 16)
+struct P2RowUV { unsigned d[16]; };
 
-template <bool S16, bool D16>
+template <bool S16, bool D16, int NP>
 __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int nOut, int lane)
 {
+    constexpr int ND = S16 ? 2 * NP + 4 : NP + 2;
+    constexpr int SHR = S16 ? 9 : 7;
     const int co = X0 + 2 * lane;
     const bool active = co < P.dstW;
     const int cc = active ? co : P.dstW - 2;
     const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UV >= P.dstW;
-    // 8-bit: two loads with their own clamps (bytes); 16-bit: one 48-byte window, positions [2cc - 4, 2cc + 8)
+    const int want = 2 * cc - NP;                               // first position of the window (even)
+    // NP = 4, 8-bit: two loads with their own clamps (bytes); NP = 4, 16-bit: one 48-byte window clamped as a whole
     const int offA = max(4 * cc - 8, 0), shA = 4 * cc - 8 - offA;               // -8 bytes: left edge
     const int offB = min(4 * cc + 8, 2 * P.srcW - 8), shB = 4 * cc + 8 - offB;  // +8 bytes: right edge
-    const int want = 2 * cc - 4;
     const int off16 = min(max(want, 0), P.srcW - 12);
     const int sh16 = want - off16;                              // -4 / +4 positions
-    const unsigned uoffA = S16 ? 4u * (unsigned)off16 : (unsigned)offA, uoffB = (unsigned)offB;
-    const int nIter = nOut + 3;
-    const int32_t h0 = P.h[0], h1 = P.h[1], h2 = P.h[2], h3 = P.h[3];
-    const int32_t v0 = P.v[0], v1 = P.v[1], v2 = P.v[2], v3 = P.v[3];
+    const int wd0 = S16 ? want : want / 2;                      // dword index of the window base (want even: exact, also when negative)
+    const int lastDw = (S16 ? P.srcW : P.srcW / 2) - 1;
+    const int nIter = nOut + NP - 1;
+    const int m0 = y0 - (NP / 2 - 1);
 
-    auto load1 = [&](int row, P2RowUV &r) {
+    auto load1 = [&](int row, P2RowUV &r, auto edge_c) {
         const unsigned o = (unsigned)min(max(row, 0), P.srcH - 1) * (unsigned)P.ss;
-        r.a = p2_ld16(P.src + (unsigned)(o + uoffA));
-        if (S16) { r.b = p2_ld16(P.src + (unsigned)(o + uoffA + 16u)); r.c = p2_ld16(P.src + (unsigned)(o + uoffA + 32u)); }
-        else     { const uint2 t = p2_ld8(P.src + (unsigned)(o + uoffB)); r.b = make_uint4(t.x, t.y, 0u, 0u); }
-    };
-    auto load = [&](int m, P2RowUV &ra, P2RowUV &rb) { load1(2 * m - 1, ra); load1(2 * m, rb); };
-    // horizontal filter of one row: 2 U and 2 V outputs from 5 odd-aligned pairs per channel
-    auto hrow = [&](const P2RowUV &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
-        int pU[5], pV[5];
-        if (S16) {
-            unsigned e[12] = {R.a.x, R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w, R.c.x, R.c.y, R.c.z, R.c.w};
+        if (NP == 4) {
+            if (S16) {
+                const unsigned b = o + 4u * (unsigned)off16;
+                const uint4 t0 = p2_ld16(P.src + b), t1 = p2_ld16(P.src + (unsigned)(b + 16u)), t2 = p2_ld16(P.src + (unsigned)(b + 32u));
+                r.d[0] = t0.x; r.d[1] = t0.y; r.d[2] = t0.z; r.d[3] = t0.w; r.d[4] = t1.x; r.d[5] = t1.y; r.d[6] = t1.z; r.d[7] = t1.w;
+                r.d[8] = t2.x; r.d[9] = t2.y; r.d[10] = t2.z; r.d[11] = t2.w;
+            } else {
+                const uint4 t0 = p2_ld16(P.src + (unsigned)(o + (unsigned)offA));
+                const uint2 t1 = p2_ld8(P.src + (unsigned)(o + (unsigned)offB));
+                r.d[0] = t0.x; r.d[1] = t0.y; r.d[2] = t0.z; r.d[3] = t0.w; r.d[4] = t1.x; r.d[5] = t1.y;
+            }
+        } else if (!decltype(edge_c)::value) {
+            const unsigned b = o + 4u * (unsigned)wd0;
 #pragma unroll
-            for (int k = 0; k < 12; k++) e[k] = p2_shr6(e[k]);  // p010LEToUV_c: both samples of the position >> 6
-            if (decltype(edge_c)::value) {
+            for (int i = 0; i < ND / 4; i++) {
+                const uint4 t = p2_ld16(P.src + (unsigned)(b + 16u * i));
+                r.d[4 * i] = t.x; r.d[4 * i + 1] = t.y; r.d[4 * i + 2] = t.z; r.d[4 * i + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ND; i++) r.d[i] = p2_ld4(P.src + (unsigned)(o + 4u * (unsigned)min(max(wd0 + i, 0), lastDw)));
+        }
+    };
+    auto load = [&](int m, P2RowUV &ra, P2RowUV &rb, auto edge_c) { load1(2 * m - 1, ra, edge_c); load1(2 * m, rb, edge_c); };
+    // horizontal filter of one row: 2 U and 2 V outputs from NP + 1 odd-aligned pairs per channel
+    auto hrow = [&](const P2RowUV &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        unsigned e[ND];
+#pragma unroll
+        for (int k = 0; k < ND; k++) e[k] = R.d[k];
+        if (S16) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) e[k] = p2_shr6(e[k]);  // p010LEToUV_c: both samples of the position >> 6
+        }
+        if constexpr (EDGE && NP == 4) {
+            if constexpr (S16) {
                 if (sh16 < 0) {
 #pragma unroll
                     for (int k = 11; k >= 4; k--) e[k] = e[k - 4];
@@ -233,75 +310,75 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
                     for (int k = 0; k < 8; k++) e[k] = e[k + 4];
                     e[8] = e[9] = e[10] = e[11];
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; k++) {       // positions (2k-3, 2k-2) rel. to 2cc = e[2k+1], e[2k+2]
-                pU[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x05040100u);
-                pV[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x07060302u);
-            }
-        } else {
-            unsigned e[6] = {R.a.x, R.a.y, R.a.z, R.a.w, R.b.x, R.b.y};
-            if (decltype(edge_c)::value) {
+            } else {
                 if (shA < 0) { const unsigned r = p2_rep(e[0], 0x01000100u); e[3] = e[1]; e[2] = e[0]; e[0] = e[1] = r; }
                 if (shB > 0) { e[4] = e[5] = p2_rep(e[5], 0x03020302u); }
             }
+        }
+        if constexpr (EDGE && NP != 4) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) {       // samples (2k-3, 2k-2) rel. to 2c: bytes 2,3 of e[k] and 0,1 of e[k+1]
+            for (int i = 0; i < ND; i++) {
+                const int idx = wd0 + i;
+                const unsigned lo = S16 ? e[i] : p2_rep(e[i], 0x01000100u);      // a 16-bit position is the whole dword
+                const unsigned hi = S16 ? e[i] : p2_rep(e[i], 0x03020302u);
+                e[i] = idx < 0 ? lo : idx > lastDw ? hi : e[i];
+            }
+        }
+        int pU[NP + 1], pV[NP + 1];
+#pragma unroll
+        for (int k = 0; k < NP + 1; k++) {
+            if (S16) {                          // positions (base + 1 + 2k, + 2 + 2k) = e[2k+1], e[2k+2]
+                pU[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x05040100u);
+                pV[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x07060302u);
+            } else {                            // bytes 2,3 of e[k] and 0,1 of e[k+1]
                 pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
                 pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
             }
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            su[c] = p2_dot2(pU[c + 3], h3, p2_dot2(pU[c + 2], h2, p2_dot2(pU[c + 1], h1, p2_dot2(pU[c], h0, 0))));
-            sv[c] = p2_dot2(pV[c + 3], h3, p2_dot2(pV[c + 2], h2, p2_dot2(pV[c + 1], h1, p2_dot2(pV[c], h0, 0))));
+            int au = 0, av = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) { au = p2_dot2(pU[c + k], P.h[k], au); av = p2_dot2(pV[c + k], P.h[k], av); }
+            su[c] = au; sv[c] = av;
         }
     };
 
-    int hw[4][4];                                               // [slot][U0, V0, U1, V1]: (row 2m-1 | row 2m << 16)
+    int hw[NP][4];                                              // [slot][U0, V0, U1, V1]: (row 2m-1 | row 2m << 16)
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NP; s++)
 #pragma unroll
         for (int j = 0; j < 4; j++) hw[s][j] = 0;
     P2RowUV bufA[2], bufB[2];
 #pragma unroll
-    for (int i = 0; i < 2; i++) bufA[i].a = bufA[i].b = bufA[i].c = bufB[i].a = bufB[i].b = bufB[i].c = make_uint4(0u, 0u, 0u, 0u);
-    load(y0 - 1, bufA[0], bufB[0]);
+    for (int i = 0; i < 16; i++) bufA[0].d[i] = bufB[0].d[i] = bufA[1].d[i] = bufB[1].d[i] = 0u;
 
     auto body = [&](const int j, auto slot_c, auto edge_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (j + 1 < nIter) load(y0 + j, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1]);
+        if (j + 1 < nIter) load(m0 + j + 1, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1], edge_c);
         {
             int ua[2], va[2], ub[2], vb[2];
             hrow(bufA[SLOT & 1], edge_c, ua, va);
             hrow(bufB[SLOT & 1], edge_c, ub, vb);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                hw[SLOT][2 * c + 0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c] >> (S16 ? 9 : 7), ub[c] >> (S16 ? 9 : 7)));
-                hw[SLOT][2 * c + 1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c] >> (S16 ? 9 : 7), vb[c] >> (S16 ? 9 : 7)));
+                hw[SLOT][2 * c + 0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c] >> SHR, ub[c] >> SHR));
+                hw[SLOT][2 * c + 1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c] >> SHR, vb[c] >> SHR));
             }
         }
-        if (j >= 3) {
-            const int yo = y0 + j - 3;                          // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
-            p2_vstore<D16>(P, hw, (SLOT + 1) & 3, (SLOT + 2) & 3, (SLOT + 3) & 3, SLOT & 3, v0, v1, v2, v3, active,
-                           (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+        if (j >= NP - 1) {
+            const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
+            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
         }
     };
-    auto run = [&](auto edge_c) {
-        for (int j0 = 0; j0 < nIter; j0 += 4) {
-            body(j0, std::integral_constant<int, 0>(), edge_c);
-            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
-            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
-            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
-        }
-    };
-    if (edgeWave) run(std::true_type()); else run(std::false_type());
+    if (edgeWave) { load(m0, bufA[0], bufB[0], std::true_type());  p2_rows<NP>(nIter, body, std::true_type()); }
+    else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
 }
 
 // blockIdx.x: [0, nblkL) luma workgroups (segment-major, 4 strips each), then the chroma workgroups — interleaved (NV): of the
 // UV plane, planar: of U, then of V.  blockIdx.y = frame.  S16 / D16: 10 bits in 16-bit containers on that side (interleaved:
-// P010LE, bits in the high end; planar: YUV420P10LE, low end).
-template <bool NV, bool S16, bool D16>
+// P010LE, bits in the high end; planar: YUV420P10LE, low end).  NP: coefficient pairs per filter (4: 8 taps; 6: Lanczos-3).
+template <bool NV, bool S16, bool D16, int NP>
 __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFrames fr)
 {
     const int lane = threadIdx.x & 63;
@@ -320,7 +397,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         if (X0 >= a.dstW) return;
         const int y0 = seg * a.segRowsL;
         const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, a.vL, a.lr, sHi, dHi};
-        p2_walk_plane<S16, D16>(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
+        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
         return;
     }
     lin -= a.nblkL;
@@ -330,7 +407,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         if (X0 >= a.chrDstW) return;
         const int y0 = seg * a.segRowsC;
         const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, a.vC, a.cr, sHi, dHi};
-        p2_walk_uv<S16, D16>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        p2_walk_uv<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
     } else {
         const int per = a.nsegC * a.nsgC;
         const int pl = __builtin_amdgcn_readfirstlane(lin >= per ? 1 : 0);
@@ -341,7 +418,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int y0 = seg * a.segRowsC;
         const P2Plane P = {pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
                            a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, a.vC, a.cr, 0, 0};
-        p2_walk_plane<S16, D16>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
     }
 }
 
@@ -364,10 +441,17 @@ int yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2pTables &t)
     t.dstDepth = (p.dstFormat == GMAT_PIX_FMT_P010LE || p.dstFormat == GMAT_PIX_FMT_YUV420P10LE) ? 10 : 8;
     if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 16 || p.srcW < 64 || p.dstH < 16) return 0;
     if (p.chrSrcW * 2 != p.srcW || p.chrSrcH * 2 != p.srcH || p.chrDstW * 2 != p.dstW || p.chrDstH * 2 != p.dstH) return 0;
-    if (!filter_is_edge_replication(p.hLum, p.srcW, t.hL)) return 0;
-    if (!filter_is_edge_replication(p.hChr, p.chrSrcW, t.hC)) return 0;
-    if (!filter_is_edge_replication(g.vLumEff, p.srcH, t.vL)) return 0;
-    if (!filter_is_edge_replication(g.vChrEff, p.chrSrcH, t.vC)) return 0;
+    // 8-tap filters (bicubic, bilinear, ...) on 4 coefficient pairs, else Lanczos-3's 12 taps on 6; all four filters alike
+    t.np = 0;
+    for (int np : {4, 6}) {
+        if (np == 6 && (p.srcW < 128 || p.dstH < 24)) break;   // the wider window wants planes at least 24 chroma samples across
+        if (filter_is_edge_replication_np(p.hLum, p.srcW, np, t.hL) && filter_is_edge_replication_np(p.hChr, p.chrSrcW, np, t.hC) &&
+            filter_is_edge_replication_np(g.vLumEff, p.srcH, np, t.vL) && filter_is_edge_replication_np(g.vChrEff, p.chrSrcH, np, t.vC)) {
+            t.np = np;
+            break;
+        }
+    }
+    if (!t.np) return 0;
     for (int y = 0; y < p.dstH; y++) if (g.lumRound[y] != g.lumRound[0]) return 0;
     for (int y = 0; y < p.chrDstH; y++) if (g.chrRound[y] != g.chrRound[0]) return 0;
     t.lr = g.lumRound[0]; t.cr = g.chrRound[0];
@@ -393,6 +477,9 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
         // the waves get long enough for the tail of the launch to show.  wave-rows / 8640 is within 3 % of the best everywhere.
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;
         seg = (int)std::min(16L, std::max(3L, (rows + 8639) / 8640));
+        // the 6-pair (Lanczos) form pays 5 warm-up row pairs per segment instead of 3: twice the rows (measured best 6 / 12-24 /
+        // 32 at 1 / 4 / 32 frames per launch, profiles/r02f_yuv2p_lanczos_rows_sweep.txt)
+        if (a.np == 6) seg = std::min(32, std::max(6, 2 * seg));
     }
     a.segRowsL = seg; a.segRowsC = std::max(2, (seg + 1) / 2);
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
@@ -400,15 +487,16 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nblkL = a.nsegL * a.nsgL;
     a.nblk = a.nblkL + a.nsegC * a.nsgC * nplC;
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
-#define GMAT_P2(NV_, S_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_>), grid, block, 0, stream, a, *frames)
+#define GMAT_P2N(NV_, S_, D_) do { if (a.np == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 6>), grid, block, 0, stream, a, *frames); \
+                                   else           hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 4>), grid, block, 0, stream, a, *frames); } while (0)
     const int sel = (a.nv12 ? 4 : 0) | (a.srcDepth == 10 ? 2 : 0) | (a.dstDepth == 10 ? 1 : 0);
     switch (sel) {
-    case 0: GMAT_P2(false, false, false); break; case 1: GMAT_P2(false, false, true); break;
-    case 2: GMAT_P2(false, true, false);  break; case 3: GMAT_P2(false, true, true);  break;
-    case 4: GMAT_P2(true, false, false);  break; case 5: GMAT_P2(true, false, true);  break;
-    case 6: GMAT_P2(true, true, false);   break; default: GMAT_P2(true, true, true);  break;
+    case 0: GMAT_P2N(false, false, false); break; case 1: GMAT_P2N(false, false, true); break;
+    case 2: GMAT_P2N(false, true, false);  break; case 3: GMAT_P2N(false, true, true);  break;
+    case 4: GMAT_P2N(true, false, false);  break; case 5: GMAT_P2N(true, false, true);  break;
+    case 6: GMAT_P2N(true, true, false);   break; default: GMAT_P2N(true, true, true);  break;
     }
-#undef GMAT_P2
+#undef GMAT_P2N
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -301,41 +301,48 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// Is this axis "the filter row `nominal` on the window [2x - 3, 2x + 4] of an edge-replicated line" for every output x?
-bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4])
+// Is this axis "the filter row `nominal` on the window [2x - (NP - 1), 2x + NP] of an edge-replicated line" for every output x?
+// NP coefficient pairs: 4 for the 8-tap filters of an exact 2:1 scale (bicubic, bilinear, ...), 6 for Lanczos-3's 12 taps.
+bool filter_is_edge_replication_np(const FilterBank &fb, int srcLen, int NP, int32_t *pairs)
 {
-    if (fb.count < 8 || srcLen != 2 * fb.count) return false;
+    const int W = 2 * NP, L = NP - 1;                           // window size, samples to the left of 2x
+    if (NP < 1 || NP > 8 || fb.count < W || srcLen != 2 * fb.count) return false;
     // the middle row provides the nominal coefficients
     const int xm = fb.count / 2;
-    int nominal[8] = {0};
+    int nominal[16] = {0};
     for (int j = 0; j < fb.taps; j++) {
         const int16_t c = fb.coef[(size_t)xm * fb.taps + j];
         if (!c) continue;
-        const int slot = fb.pos[xm] + j - (2 * xm - 3);
-        if (slot < 0 || slot > 7) return false;
+        const int slot = fb.pos[xm] + j - (2 * xm - L);
+        if (slot < 0 || slot >= W) return false;
         nominal[slot] = c;
     }
-    std::vector<int> eff(16), tab(16);
+    std::vector<int> eff(2 * W), tab(2 * W);
     for (int x = 0; x < fb.count; x++) {
-        // effective coefficient per source sample, window base 2x - 3 - 4 (room for the taps the table may hold further out)
-        const int base = 2 * x - 7;
+        // effective coefficient per source sample, window base 2x - L - NP (room for the taps the table may hold further out)
+        const int base = 2 * x - L - NP;
         std::fill(eff.begin(), eff.end(), 0); std::fill(tab.begin(), tab.end(), 0);
-        for (int k = 0; k < 8; k++) {
-            const int s = std::min(std::max(2 * x - 3 + k, 0), srcLen - 1);
+        for (int k = 0; k < W; k++) {
+            const int s = std::min(std::max(2 * x - L + k, 0), srcLen - 1);
+            if (s - base < 0 || s - base >= 2 * W) return false;
             eff[s - base] += nominal[k];
         }
         for (int j = 0; j < fb.taps; j++) {
             const int16_t c = fb.coef[(size_t)x * fb.taps + j];
             if (!c) continue;
             const int s = fb.pos[x] + j;
-            if (s < 0 || s >= srcLen || s - base < 0 || s - base >= 16) return false;
+            if (s < 0 || s >= srcLen || s - base < 0 || s - base >= 2 * W) return false;
             tab[s - base] += c;
         }
         if (eff != tab) return false;
     }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < NP; k++)
         pairs[k] = (int32_t)((uint32_t)(uint16_t)nominal[2 * k] | ((uint32_t)(uint16_t)nominal[2 * k + 1] << 16));
     return true;
+}
+bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4])
+{
+    return filter_is_edge_replication_np(fb, srcLen, 4, pairs);
 }
 
 int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)

@@ -267,7 +267,8 @@ int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrame
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
 struct Yuv2pTables {
     int ok = 0, srcDepth = 8, dstDepth = 8;                         // 10: P010LE / YUV420P10LE on that side
-    int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0}, vC[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
+    int np = 4;                                                     // coefficient pairs per filter: 4 (8 taps) or 6 (Lanczos-3)
+    int32_t hL[6] = {0}, hC[6] = {0}, vL[6] = {0}, vC[6] = {0};   // int16 pairs on the odd-aligned window [2x - (np - 1), 2x + np]
     int lr = 0, cr = 0;                                             // vertical accumulator start values (dither << 12)
 };
 struct Yuv2pArgs {
@@ -275,7 +276,8 @@ struct Yuv2pArgs {
     int srcDepth, dstDepth;                      // 8 or 10 bits per sample on each side
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV;
-    int32_t hL[4], hC[4], vL[4], vC[4];
+    int np;                                      // coefficient pairs per filter (4 | 6)
+    int32_t hL[6], hC[6], vL[6], vC[6];
     int lr, cr;
     // filled by the launcher: rows per strip segment, segments and groups of 4 strips per plane kind, workgroup counts
     int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;
@@ -298,6 +300,7 @@ struct Rgb2sArgs {
     Yuv2RgbConsts y2r;
 };
 bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4]);
+bool filter_is_edge_replication_np(const FilterBank &fb, int srcLen, int NP, int32_t *pairs);      // NP pairs on [2x - (NP - 1), 2x + NP]
 int  rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t);
 // frames->y[] = source frames, frames->dst[] = destination frames (grid.y = frame)
 int  launch_scale_rgb2s(const Rgb2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);

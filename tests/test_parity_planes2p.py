@@ -24,8 +24,11 @@ def strip_takes(sw, sh, src_fmt, dst_fmt, flags="bicubic"):
     """the host rule of yuv2p_prepare restated: same chroma layout on both sides, width a multiple of 16 and >= 64,
     output height >= 16 and even (so that every plane is exactly halved), a filter that fits the 8-sample window"""
     dh = sh // 2
-    return (src_fmt == dst_fmt and sw % 16 == 0 and sw >= 64 and sh % 4 == 0 and dh >= 16 and
-            flags in ("bicubic", "bilinear", "point", "area", "fast_bilinear", "gauss"))
+    if not (src_fmt == dst_fmt and sw % 16 == 0 and sw >= 64 and sh % 4 == 0 and dh >= 16):
+        return False
+    if flags == "lanczos":                               # 12 taps: the 6-pair instantiation, on planes wide and tall enough for it
+        return sw >= 128 and dh >= 24
+    return flags in ("bicubic", "bilinear", "point", "area", "fast_bilinear", "gauss")
 
 
 @pytest.fixture(params=["strip", "tiled"])
@@ -59,6 +62,9 @@ def test_geometries_cover_both_kernels():
     assert sum(took) >= 8 and took.count(False) >= 4
     names = {expect(k, w, h, "nv12", "nv12") for k in ("strip", "tiled") for w, h in GEOMS}
     assert names == {STRIP, TILED, GENERIC}
+
+
+LANCZOS_GEOMS = [(128, 48), (256, 64), (528, 52), (1040, 96), (2064, 48), (4112, 48), (64, 48), (128, 44), (520, 48)]
 
 
 def _check(dev, orc, sf, df, sw, sh, flags="bicubic", align=256, extra=0):
@@ -109,10 +115,39 @@ def test_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows
 @pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss", "lanczos", "sinc"])
 def test_filters(dev, orc, kern_yuv, flags):
     k = _check(dev, orc, "nv12", "nv12", 528, 52, flags)
-    if kern_yuv == "tiled" or flags in ("lanczos", "sinc"):
-        assert k != STRIP, (flags, k)            # wide filters: the tiled 2:1 kernel or the generic plane scaler
+    if kern_yuv == "tiled" or flags == "sinc":
+        assert k != STRIP, (flags, k)            # filters wider than 12 taps: the tiled 2:1 kernel or the generic plane scaler
     else:
-        assert k == STRIP, (flags, k)
+        assert k == STRIP, (flags, k)            # Lanczos-3 (12 taps) on the 6-pair instantiation
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", LANCZOS_GEOMS)
+def test_lanczos_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, fmt, geom):
+    """Lanczos-3 at 2:1: 12 taps on [2x - 5, 2x + 6], border rows = edge replication (the host checks it); in the waves on a
+    plane edge two lanes a side overlap the border by different amounts — every dword of their windows comes from its own
+    clamped address"""
+    sw, sh = geom
+    strip_rows(0)
+    k = _check(dev, orc, fmt, fmt, sw, sh, "lanczos")
+    if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt, "lanczos"):
+        assert k == STRIP, k
+    else:
+        assert k in (TILED, GENERIC), k
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64])
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+def test_lanczos_segmentation(dev, orc, strip_rows, fmt, rows):
+    """5 warm-up row pairs per segment re-create the 6-slot vertical window exactly"""
+    strip_rows(rows)
+    assert _check(dev, orc, fmt, fmt, 528, 52, "lanczos") == STRIP
+
+
+def test_lanczos_batched(dev, orc, strip_rows, kern_yuv):
+    strip_rows(0)
+    k = _run_batch(dev, orc, "nv12", "nv12", 528, 52, 264, 26, nframes=5, nstreams=2, align=16, flags=SWS["lanczos"])
+    assert (k == STRIP) == (kern_yuv == "strip"), k
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
@@ -195,7 +230,23 @@ def test_10bit_rows_that_are_not_8_byte_aligned_fall_back(dev, orc, fmt):
 @pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss", "lanczos"])
 def test_10bit_filters(dev, orc, kern_yuv, flags):
     k = _check10(dev, orc, "p010le", 528, 52, flags)
-    assert (k == STRIP16) == (kern_yuv == "strip" and flags != "lanczos"), (flags, k)
+    assert (k == STRIP16) == (kern_yuv == "strip"), (flags, k)
+
+
+@pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
+@pytest.mark.parametrize("geom", LANCZOS_GEOMS)
+def test_10bit_lanczos(dev, orc, strip_rows, kern_yuv, fmt, geom):
+    sw, sh = geom
+    strip_rows(0)
+    k = _check10(dev, orc, fmt, sw, sh, "lanczos")
+    assert (k == STRIP16) == (kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt, "lanczos")), k
+
+
+@pytest.mark.parametrize("pair", [("nv12", "p010le"), ("p010le", "nv12"), ("yuv420p", "yuv420p10le"), ("yuv420p10le", "yuv420p")])
+def test_cross_depth_lanczos(dev, orc, strip_rows, pair):
+    strip_rows(0)
+    for sw, sh in ((528, 52), (2064, 48)):
+        assert _check_cross(dev, orc, pair[0], pair[1], sw, sh, "lanczos") == CROSS[pair]
 
 
 def test_10bit_saturating_content(dev, orc, strip_rows):
