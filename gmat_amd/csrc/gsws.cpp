@@ -452,7 +452,8 @@ static Yuv2sArgs make_yuv2s_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     sa.ys = ya.ys; sa.us = ya.us; sa.vs = ya.vs; sa.nv12 = ya.nv12;
     sa.srcW = ya.srcW; sa.srcH = ya.srcH; sa.chrSrcW = ya.chrSrcW; sa.chrSrcH = ya.chrSrcH;
     sa.dstW = ya.dstW; sa.dstH = ya.dstH; sa.ds = ya.ds; sa.dstFormat = ya.dstFormat;
-    for (int k = 0; k < 4; k++) { sa.hL[k] = c->y2s.hL[k]; sa.hC[k] = c->y2s.hC[k]; sa.vL[k] = c->y2s.vL[k]; }
+    sa.np = c->y2s.np;
+    for (int k = 0; k < 6; k++) { sa.hL[k] = c->y2s.hL[k]; sa.hC[k] = c->y2s.hC[k]; sa.vL[k] = c->y2s.vL[k]; }
     sa.lr = c->y2s.lr; sa.xcdRemap = ya.xcdRemap; sa.y2r = ya.y2r;
     return sa;
 }
@@ -629,7 +630,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
-    c->lastKernel = use2s ? "scale_yuv2s_kernel" : use2p ? yuv2p_name(c) : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -1147,7 +1148,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 Yuv2xFrames one;
                 std::memset(&one, 0, sizeof(one));
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
-                c->lastKernel = "scale_yuv2s_kernel";
+                c->lastKernel = c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel";
                 r = launch_scale_yuv2s(make_yuv2s_args(c, ya), c->stream, &one, 1);
                 break;
             }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
     const int xo = X0 + 4 * lane;
     const bool active = xo < P.dstW;
     const int xc = active ? xo : P.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
-    const bool edgeWave = X0 == 0 || X0 + P2_STRIP >= P.dstW;
+    const bool edgeWave = X0 == 0 || X0 + P2_STRIP + (NP == 4 ? 0 : 8) >= P.dstW;     // NP = 6: the window overhangs further
     const int want = 2 * xc - BL;                               // first sample of the window
     const int off = min(max(want, 0), P.srcW - ND * SPD);       // NP = 4: the whole window clamped, then shifted back in registers
     const int sh = want - off;                                  //         -4 at the left plane edge, +4 at the right one
@@ -251,7 +251,7 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     const int co = X0 + 2 * lane;
     const bool active = co < P.dstW;
     const int cc = active ? co : P.dstW - 2;
-    const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UV >= P.dstW;
+    const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UV + (NP == 4 ? 0 : 8) >= P.dstW;
     const int want = 2 * cc - NP;                               // first position of the window (even)
     // NP = 4, 8-bit: two loads with their own clamps (bytes); NP = 4, 16-bit: one 48-byte window clamped as a whole
     const int offA = max(4 * cc - 8, 0), shA = 4 * cc - 8 - offA;               // -8 bytes: left edge

@@ -298,6 +298,372 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     if (edgeWave) run(std::true_type()); else run(std::false_type());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel written over the number of coefficient pairs NP, shipped for NP = 6 only (Lanczos-3: 12 taps on
+// [2x - 5, 2x + 6], a 6-slot vertical window, 24 luma bytes per row and lane).  The 4-pair kernel above is NOT an instantiation
+// of this template on purpose: written this way the 4-pair form compiles to a different schedule (70 instead of 78 VGPRs) that
+// measured 10 % slower on the headline (4.58 against 4.10 us per 4K frame, same box as an untouched kernel that did not move).
+// The pixels one row-loop iteration consumes: a luma row pair (2m-1, 2m) and one chroma row.
+// NP = 4 (8 taps): 16 luma bytes of each row from column 2xc - 4; NV12: 24 chroma bytes (8 + 4 UV pairs) from sample xc - 4,
+//                  planar: 12 bytes of each chroma plane from sample xc - 4.
+// NP = 6 (Lanczos-3, 12 taps): 24 luma bytes from column 2xc - 8; NV12: 32 chroma bytes from sample xc - 6; planar: 24 bytes of
+//                  each plane from sample xc - 8.
+struct S2PixN {
+    unsigned la[6], lb[6];         // luma rows 2m-1 and 2m
+    unsigned ca[8];                // NV12: UV pairs;  planar: U bytes (first 3 / 6 dwords)
+    unsigned cb[6];                // NV12 (NP = 4 only): ca continues in cb[0..1];  planar: V bytes
+};
+
+__device__ __forceinline__ unsigned s2_ld4(const uint8_t *p) { return *reinterpret_cast<const unsigned *>(p); }
+
+// DST: 0 rgb24, 1 bgr24, 2 rgba, 3 bgra.  NP: coefficient pairs per filter — 4 for the 8-tap filters of an exact 2:1 scale
+// (the headline), 6 for Lanczos-3.
+template <bool NV12, int DST, int NP>
+__global__ __launch_bounds__(256) void scale_yuv2s_np_kernel(Yuv2sArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    constexpr int NDL = NP == 4 ? 4 : 6;                        // luma dwords per row
+    constexpr int BLL = NP == 4 ? 4 : 8;                        // luma bytes between the window base and 2xc
+    constexpr int NDC = NV12 ? NP + 2 : (NP == 4 ? 3 : 6);      // chroma dwords per row (planar: per plane)
+    __shared__ int2 lutV[256], lutU[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- colour look-up tables: chan = byte 2 of clamp(term + Y * cy, 0, 0xFFFFFF) with
+    //      term_R = lutV[V].x, term_G = lutV[V].y + lutU[U].x, term_B = lutU[U].y  (px_math.h chroma_terms, split by sample)
+    {
+        const Yuv2RgbConsts &k = a.y2r;
+        const int i = tid;
+        lutV[i] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
+        lutU[i] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+    }
+    __syncthreads();
+
+    // ---- which strip segment ------------------------------------------------------------------------------------
+    const int nblk = a.nseg * a.nsg;
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= nblk) return;
+    const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsg);
+    const int X0 = ((lin - seg * a.nsg) * 4 + wave) * S2_STRIP;
+    if (X0 >= a.dstW) return;                                  // wave-uniform; no barrier below
+    const int y0 = seg * a.segRows;
+    const int nOut = min(a.segRows, a.dstH - y0);
+    const int nIter = nOut + NP - 1;                           // NP - 1 warm-up row pairs fill the vertical window
+    const int m0 = y0 - (NP / 2 - 1);                          // row pair of iteration 0 (pair m = rows 2m - 1, 2m)
+
+    const uint8_t *py, *pu, *pv;
+    uint8_t *pd;
+    {
+        const int f = blockIdx.y;
+        py = fr.y[f]; pu = fr.u[f]; pv = fr.v[f]; pd = fr.dst[f];
+    }
+
+    // ---- per-lane constants -------------------------------------------------------------------------------------
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
+    // wave-uniform: only these waves hold a lane whose window reaches past a frame edge.  The 12-tap window (NP = 6) overhangs
+    // further: the chroma loads of a lane reach sample xc + 9, so the wave BEFORE the last one is an edge wave too when fewer
+    // than 8 columns follow it
+    const bool edgeWave = X0 == 0 || X0 + S2_STRIP + (NP == 4 ? 0 : 8) >= a.dstW;
+    // luma: bytes [2xc - BLL, ...) of the row; sources < 0 and >= srcW are the replicated edge samples
+    const int wantL = 2 * xc - BLL;
+    const int offL = min(max(wantL, 0), a.srcW - 16);           // NP = 4: the window clamped as a whole, shifted back in registers
+    const int shL = wantL - offL;                               //         -4 at the left frame edge, +4 at the right one
+    const int wdL = wantL >> 2;                                 // NP = 6: dword index of the window base (wantL is a multiple of 8)
+    const int lastL = (a.srcW >> 2) - 1;
+    // chroma samples [xc - 4, xc + 8) (NP = 4) / [xc - 6 | xc - 8, ...) (NP = 6) of the row
+    int offA, offB, shA, shB;
+    if (NV12) {
+        offA = max(2 * xc - 8, 0);               shA = 2 * xc - 8 - offA;        // 16 bytes: samples xc-4 .. xc+3   (-8: left edge)
+        offB = min(2 * xc + 8, 2 * a.chrSrcW - 8); shB = 2 * xc + 8 - offB;      //  8 bytes: samples xc+4 .. xc+7   (+8: right edge)
+    } else {
+        offA = min(max(xc - 4, 0), a.chrSrcW - 12); shA = xc - 4 - offA;         // 12 bytes of each plane (-4 / +4)
+        offB = 0; shB = 0;
+    }
+    const int wdC = NV12 ? (2 * xc - 12) >> 2 : (xc - 8) >> 2;  // NP = 6: dword index of the chroma window base (arithmetic shift: floor)
+    const int lastC = ((NV12 ? 2 * a.chrSrcW : a.chrSrcW) >> 2) - 1;
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    // row pointers are wave-uniform (scalar unit), the lane offsets unsigned 32-bit: global_load with an SGPR base
+    const unsigned uoffL = (unsigned)offL, uoffA = (unsigned)offA, uoffB = (unsigned)offB;
+    auto load_luma = [&](int m, S2PixN &P, auto edge_c) {
+        const int ra = min(max(2 * m - 1, 0), a.srcH - 1), rb = min(max(2 * m, 0), a.srcH - 1);
+        // one 32-bit offset per load = scalar row offset + lane offset (a plane is far below 4 GB): the frame pointer
+        // stays the SGPR base of the global_load
+        if constexpr (NP == 4) {
+            const uint4 ta = s2_ld16(py + (unsigned)((unsigned)ra * (unsigned)a.ys + uoffL));
+            const uint4 tb = s2_ld16(py + (unsigned)((unsigned)rb * (unsigned)a.ys + uoffL));
+            P.la[0] = ta.x; P.la[1] = ta.y; P.la[2] = ta.z; P.la[3] = ta.w;
+            P.lb[0] = tb.x; P.lb[1] = tb.y; P.lb[2] = tb.z; P.lb[3] = tb.w;
+        } else if constexpr (!decltype(edge_c)::value) {
+            const unsigned oa = (unsigned)ra * (unsigned)a.ys + (unsigned)wantL, ob = (unsigned)rb * (unsigned)a.ys + (unsigned)wantL;
+            const uint4 ta = s2_ld16(py + oa); const uint2 ta2 = s2_ld8(py + (unsigned)(oa + 16u));
+            const uint4 tb = s2_ld16(py + ob); const uint2 tb2 = s2_ld8(py + (unsigned)(ob + 16u));
+            P.la[0] = ta.x; P.la[1] = ta.y; P.la[2] = ta.z; P.la[3] = ta.w; P.la[4] = ta2.x; P.la[5] = ta2.y;
+            P.lb[0] = tb.x; P.lb[1] = tb.y; P.lb[2] = tb.z; P.lb[3] = tb.w; P.lb[4] = tb2.x; P.lb[5] = tb2.y;
+        } else {
+            // a wave on a frame edge: two lanes a side overlap the edge by different amounts — every dword from its own
+            // clamped address, the edge sample replicated where the index was clamped (fix_luma)
+#pragma unroll
+            for (int i = 0; i < NDL; i++) {
+                const unsigned c = 4u * (unsigned)min(max(wdL + i, 0), lastL);
+                P.la[i] = s2_ld4(py + (unsigned)((unsigned)ra * (unsigned)a.ys + c));
+                P.lb[i] = s2_ld4(py + (unsigned)((unsigned)rb * (unsigned)a.ys + c));
+            }
+        }
+    };
+    auto load_chroma = [&](int cy, S2PixN &P, auto edge_c) {
+        const int r = min(max(cy, 0), a.chrSrcH - 1);
+        if constexpr (NP == 4) {
+            if (NV12) {
+                const unsigned ro = (unsigned)r * (unsigned)a.us;
+                const uint4 t0 = s2_ld16(pu + (unsigned)(ro + uoffA));
+                const uint2 t = s2_ld8(pu + (unsigned)(ro + uoffB));
+                P.ca[0] = t0.x; P.ca[1] = t0.y; P.ca[2] = t0.z; P.ca[3] = t0.w; P.ca[4] = t.x; P.ca[5] = t.y;
+            } else {
+                const uint3 tu = s2_ld12(pu + (unsigned)((unsigned)r * (unsigned)a.us + uoffA));
+                const uint3 tv = s2_ld12(pv + (unsigned)((unsigned)r * (unsigned)a.vs + uoffA));
+                P.ca[0] = tu.x; P.ca[1] = tu.y; P.ca[2] = tu.z;
+                P.cb[0] = tv.x; P.cb[1] = tv.y; P.cb[2] = tv.z;
+            }
+        } else if constexpr (!decltype(edge_c)::value) {
+            if (NV12) {
+                const unsigned o = (unsigned)r * (unsigned)a.us + 4u * (unsigned)wdC;
+                const uint4 t0 = s2_ld16(pu + o), t1 = s2_ld16(pu + (unsigned)(o + 16u));
+                P.ca[0] = t0.x; P.ca[1] = t0.y; P.ca[2] = t0.z; P.ca[3] = t0.w; P.ca[4] = t1.x; P.ca[5] = t1.y; P.ca[6] = t1.z; P.ca[7] = t1.w;
+            } else {
+                const unsigned ou = (unsigned)r * (unsigned)a.us + 4u * (unsigned)wdC, ov = (unsigned)r * (unsigned)a.vs + 4u * (unsigned)wdC;
+                const uint4 u0 = s2_ld16(pu + ou); const uint2 u1 = s2_ld8(pu + (unsigned)(ou + 16u));
+                const uint4 v0 = s2_ld16(pv + ov); const uint2 v1 = s2_ld8(pv + (unsigned)(ov + 16u));
+                P.ca[0] = u0.x; P.ca[1] = u0.y; P.ca[2] = u0.z; P.ca[3] = u0.w; P.ca[4] = u1.x; P.ca[5] = u1.y;
+                P.cb[0] = v0.x; P.cb[1] = v0.y; P.cb[2] = v0.z; P.cb[3] = v0.w; P.cb[4] = v1.x; P.cb[5] = v1.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NDC; i++) {
+                const unsigned c = 4u * (unsigned)min(max(wdC + i, 0), lastC);
+                P.ca[i] = s2_ld4(pu + (unsigned)((unsigned)r * (unsigned)a.us + c));
+                if (!NV12) P.cb[i] = s2_ld4(pv + (unsigned)((unsigned)r * (unsigned)a.vs + c));
+            }
+        }
+    };
+    // frame-edge lanes: shift the dwords into window position and replicate the edge sample (NP = 4); replicate where the
+    // address was clamped (NP = 6)
+    auto fix_luma = [&](const unsigned (&src)[6], unsigned (&L)[NDL], auto edge_c) {
+#pragma unroll
+        for (int i = 0; i < NDL; i++) L[i] = src[i];
+        if constexpr (decltype(edge_c)::value && NP == 4) {
+            if (shL < 0) { const unsigned r = s2_rep(L[0], 0x00000000u); L[3] = L[2]; L[2] = L[1]; L[1] = L[0]; L[0] = r; }
+            else if (shL > 0) { const unsigned r = s2_rep(L[3], 0x03030303u); L[0] = L[1]; L[1] = L[2]; L[2] = L[3]; L[3] = r; }
+        }
+        if constexpr (decltype(edge_c)::value && NP != 4) {
+#pragma unroll
+            for (int i = 0; i < NDL; i++) {
+                const int idx = wdL + i;
+                const unsigned lo = s2_rep(L[i], 0x00000000u), hi = s2_rep(L[i], 0x03030303u);
+                L[i] = idx < 0 ? lo : idx > lastL ? hi : L[i];
+            }
+        }
+    };
+
+    // horizontal luma filter of one row: 4 outputs from NP + 3 odd-aligned pairs
+    auto hrow = [&](const unsigned (&L)[NDL], int (&s)[4]) {
+        int p[NP + 3];
+        constexpr int O0 = BLL - (NP - 1);                      // byte of the first pair: 1 (NP = 4) or 3 (NP = 6)
+#pragma unroll
+        for (int k = 0; k < NP + 3; k++) {
+            const int o = O0 + 2 * k;
+            p[k] = (o & 3) == 1 ? s2_pair12(L[o >> 2]) : s2_pair30(L[(o >> 2) + 1], L[o >> 2]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if constexpr (NP == 4) {
+                s[j] = s2_dot2(p[j + 3], a.hL[3], s2_dot2(p[j + 2], a.hL[2], s2_dot2(p[j + 1], a.hL[1], s2_dot2(p[j], a.hL[0], 0))));
+            } else {
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < NP; k++) acc = s2_dot2(p[j + k], a.hL[k], acc);
+                s[j] = acc;
+            }
+        }
+    };
+
+    int hw[NP][4];                                              // [slot][output]: (row 2m-1 | row 2m << 16) after hScale8To15_c
+#pragma unroll
+    for (int s = 0; s < NP; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hw[s][j] = 0;
+
+    S2PixN buf[2];                                               // ping-pong: iteration j consumes buf[j & 1], prefetches into the other
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) buf[i].la[k] = buf[i].lb[k] = buf[i].cb[k] = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) buf[i].ca[k] = 0u;
+    }
+
+    // EDGE: the wave holds a frame-edge lane (first / last strip).  The whole row loop exists twice so that interior
+    // waves carry none of the fix-up moves.
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;           // j mod NP, static after unrolling (NP even: j & 1 == SLOT & 1)
+        constexpr bool EDGE = decltype(edge_c)::value;
+        const S2PixN &cur = buf[SLOT & 1];
+        S2PixN &nxt = buf[(SLOT + 1) & 1];
+        // ---- prefetch the next iteration's rows ------------------------------------------------------------
+        if (j + 1 < nIter) {
+            load_luma(m0 + j + 1, nxt, edge_c);                                      // row pair of iteration j + 1
+            if (j + 1 >= NP - 1) load_chroma(y0 + (j + 1) - (NP - 1), nxt, edge_c);  // chroma row of its output row
+        }
+        // ---- horizontal luma of this iteration's pair -> slot ----------------------------------------------
+        {
+            int sa[4], sb[4];
+            unsigned La[NDL], Lb[NDL];
+            fix_luma(cur.la, La, edge_c); fix_luma(cur.lb, Lb, edge_c);
+            hrow(La, sa);
+            hrow(Lb, sb);
+#pragma unroll
+            for (int q = 0; q < 4; q++)       // hScale8To15_c: min(val >> 7, 32767); the lower bound cannot trigger
+                hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 7, sb[q] >> 7));
+        }
+        if (j >= NP - 1) {
+            const int yo = y0 + j - (NP - 1);
+            // ---- vertical luma: the NP pairs of this output row sit in slots SLOT+1 .. SLOT+NP (mod NP), oldest first ------
+            int Y[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int acc = a.lr;
+#pragma unroll
+                for (int k = 0; k < NP; k++) acc = s2_dot2(hw[(SLOT + 1 + k) % NP][q], a.vL[k], acc);
+                Y[q] = acc >> 19;
+            }
+            // ---- chroma of row yo: 2 outputs per plane from NP + 1 odd-aligned pairs -----------------------------
+            int pU[NP + 1], pV[NP + 1];
+            if (NV12) {
+                unsigned e[NP + 2];
+#pragma unroll
+                for (int k = 0; k < NP + 2; k++) e[k] = cur.ca[k];
+                if constexpr (EDGE && NP == 4) {
+                    if (shA < 0) { const unsigned r = s2_rep(e[0], 0x01000100u); e[3] = e[1]; e[2] = e[0]; e[0] = e[1] = r; }
+                    if (shB > 0) { e[4] = e[5] = s2_rep(e[5], 0x03020302u); }
+                }
+                if constexpr (EDGE && NP != 4) {
+#pragma unroll
+                    for (int i = 0; i < NP + 2; i++) {
+                        const int idx = wdC + i;
+                        const unsigned lo = s2_rep(e[i], 0x01000100u), hi = s2_rep(e[i], 0x03020302u);
+                        e[i] = idx < 0 ? lo : idx > lastC ? hi : e[i];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NP + 1; k++) {  // samples (2k-(NP-1), ...) rel. to xc: bytes 2,3 of e[k] and 0,1 of e[k+1]
+                    pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
+                    pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
+                }
+            } else {
+                constexpr int NDP = NP == 4 ? 3 : 6;
+                unsigned fu[NDP], fv[NDP];
+#pragma unroll
+                for (int k = 0; k < NDP; k++) { fu[k] = cur.ca[k]; fv[k] = cur.cb[k]; }
+                if constexpr (EDGE && NP == 4) {
+                    if (shA < 0) {
+                        fu[2] = fu[1]; fu[1] = fu[0]; fu[0] = s2_rep(fu[0], 0x00000000u);
+                        fv[2] = fv[1]; fv[1] = fv[0]; fv[0] = s2_rep(fv[0], 0x00000000u);
+                    } else if (shA > 0) {
+                        fu[0] = fu[1]; fu[1] = fu[2]; fu[2] = s2_rep(fu[2], 0x03030303u);
+                        fv[0] = fv[1]; fv[1] = fv[2]; fv[2] = s2_rep(fv[2], 0x03030303u);
+                    }
+                }
+                if constexpr (EDGE && NP != 4) {
+#pragma unroll
+                    for (int i = 0; i < NDP; i++) {
+                        const int idx = wdC + i;
+                        fu[i] = idx < 0 ? s2_rep(fu[i], 0x00000000u) : idx > lastC ? s2_rep(fu[i], 0x03030303u) : fu[i];
+                        fv[i] = idx < 0 ? s2_rep(fv[i], 0x00000000u) : idx > lastC ? s2_rep(fv[i], 0x03030303u) : fv[i];
+                    }
+                }
+                // NP = 4: window from sample xc - 4, first pair at byte 1;  NP = 6: from xc - 8, first pair (xc - 5, xc - 4) at byte 3
+                constexpr int O0 = NP == 4 ? 1 : 3;
+#pragma unroll
+                for (int k = 0; k < NP + 1; k++) {
+                    const int o = O0 + 2 * k;
+                    pU[k] = (o & 3) == 1 ? s2_pair12(fu[o >> 2]) : s2_pair30(fu[(o >> 2) + 1], fu[o >> 2]);
+                    pV[k] = (o & 3) == 1 ? s2_pair12(fv[o >> 2]) : s2_pair30(fv[(o >> 2) + 1], fv[o >> 2]);
+                }
+            }
+            int iU[2], iV[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                // hScale8To15_c (>> 7, min 32767), the one-tap vertical filter (1 << 18) + h * 4096, >> 19 and the table
+                // index clamp collapse into clip_u8((sum + 8192) >> 14): floor(floor(x / 128 + 64) / 128) = floor((x + 8192) / 16384)
+                int su = 8192, sv = 8192;
+                if constexpr (NP == 4) {
+                    su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], 8192))));
+                    sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], 8192))));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NP; k++) { su = s2_dot2(pU[c + k], a.hC[k], su); sv = s2_dot2(pV[c + k], a.hC[k], sv); }
+                }
+                iU[c] = clip_u8_shr(su, 14); iV[c] = clip_u8_shr(sv, 14);
+            }
+            // ---- colour stage + store ---------------------------------------------------------------------------
+            unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int2 tv = lutV[iV[c]], tu = lutU[iU[c]];
+                const int tr = BGR ? tu.y : tv.x, tg = tv.y + tu.x, tb = BGR ? tv.x : tu.y;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int q = 2 * c + h;
+                    c0[q] = (unsigned)min(max(tr + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                    c1[q] = (unsigned)min(max(tg + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                    c2[q] = (unsigned)min(max(tb + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+                }
+            }
+            if (active) {
+                uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+    #define S2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = S2_B2PAIR(c0[0], c1[0]) | (S2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                    o4.y = S2_B2PAIR(c0[1], c1[1]) | (S2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                    o4.z = S2_B2PAIR(c0[2], c1[2]) | (S2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                    o4.w = S2_B2PAIR(c0[3], c1[3]) | (S2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d) = o4;
+                } else {
+                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    o3.x = S2_B2PAIR(c0[0], c1[0]) | (S2_B2PAIR(c2[0], c0[1]) << 16);
+                    o3.y = S2_B2PAIR(c1[1], c2[1]) | (S2_B2PAIR(c0[2], c1[2]) << 16);
+                    o3.z = S2_B2PAIR(c2[2], c0[3]) | (S2_B2PAIR(c1[3], c2[3]) << 16);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+    #undef S2_B2PAIR
+            }
+        }
+    };
+
+    auto run = [&](auto edge_c) {
+        load_luma(m0, buf[0], edge_c);
+        for (int j0 = 0; j0 < nIter; j0 += NP) {
+            body(j0, std::integral_constant<int, 0>(), edge_c);
+            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+            if constexpr (NP > 4) {
+                if (j0 + 4 < nIter) body(j0 + 4, std::integral_constant<int, 4>(), edge_c);
+                if (j0 + 5 < nIter) body(j0 + 5, std::integral_constant<int, 5>(), edge_c);
+            }
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -356,9 +722,14 @@ int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
           p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
     if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 8 || p.srcW < 32 || p.dstH < 8) return 0;
     if (p.chrSrcW != p.dstW || p.chrSrcH != p.dstH || p.chrDstW * 2 != p.dstW || p.chrDstH != p.dstH) return 0;
-    if (!filter_is_edge_replication(p.hLum, p.srcW, t.hL)) return 0;
-    if (!filter_is_edge_replication(p.hChr, p.chrSrcW, t.hC)) return 0;
-    if (!filter_is_edge_replication(g.vLumEff, p.srcH, t.vL)) return 0;
+    // 8-tap filters on 4 coefficient pairs (the headline), else Lanczos-3's 12 taps on 6
+    t.np = 0;
+    for (int np : {4, 6}) {
+        if (np == 6 && (p.srcW < 128 || p.dstH < 12)) break;    // the wider window: chroma rows of at least 32 samples
+        if (filter_is_edge_replication_np(p.hLum, p.srcW, np, t.hL) && filter_is_edge_replication_np(p.hChr, p.chrSrcW, np, t.hC) &&
+            filter_is_edge_replication_np(g.vLumEff, p.srcH, np, t.vL)) { t.np = np; break; }
+    }
+    if (!t.np) return 0;
     // vertical chroma: one tap of 4096 on row y, rounding 1 << 18 (the kernel folds it into the horizontal accumulator)
     if (g.vChrEff.taps != 1) return 0;
     for (int y = 0; y < p.dstH; y++)
@@ -385,13 +756,17 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     if (!seg) {
         const long rows = (long)a.dstH * nstrips * nframes;      // wave-rows of the launch
         seg = (int)std::min(64L, std::max(3L, (rows + 6143) / 6144));
+        // the 6-pair kernel: 5 warm-up row pairs per segment instead of 3 want longer segments, its 109 VGPRs (4 waves per SIMD)
+        // shorter ones; measured best 6 / 12 / 16 rows at 1 / 4 / 32 frames per launch (profiles/r02f_yuv2s_lanczos_rows_sweep.txt)
+        if (a.np == 6) seg = std::min(16, std::max(6, 2 * seg));
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;
     const int nblk = a.nseg * a.nsg;
     const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
-#define GMAT_S2(N_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_kernel<N_, D_>), grid, block, 0, stream, a, fr)
+#define GMAT_S2(N_, D_) do { if (a.np == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_np_kernel<N_, D_, 6>), grid, block, 0, stream, a, fr); \
+                             else           hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_kernel<N_, D_>), grid, block, 0, stream, a, fr); } while (0)
     const int d = a.dstFormat == GMAT_PIX_FMT_RGB24 ? 0 : a.dstFormat == GMAT_PIX_FMT_BGR24 ? 1 : a.dstFormat == GMAT_PIX_FMT_RGBA ? 2 : 3;
     if (a.nv12) { switch (d) { case 0: GMAT_S2(true, 0); break; case 1: GMAT_S2(true, 1); break; case 2: GMAT_S2(true, 2); break; default: GMAT_S2(true, 3); } }
     else        { switch (d) { case 0: GMAT_S2(false, 0); break; case 1: GMAT_S2(false, 1); break; case 2: GMAT_S2(false, 2); break; default: GMAT_S2(false, 3); } }

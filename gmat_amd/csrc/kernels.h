@@ -247,14 +247,16 @@ int  launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, 
 // every coefficient is a kernel argument and there are no tables.
 struct Yuv2sTables {
     int ok = 0;
-    int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4]
+    int np = 4;                                        // coefficient pairs per filter: 4 (8 taps) or 6 (Lanczos-3)
+    int32_t hL[6] = {0}, hC[6] = {0}, vL[6] = {0};   // int16 pairs on the odd-aligned window [2x - (np - 1), 2x + np]
     int lr = 0;                                        // vertical luma accumulator start
 };
 struct Yuv2sArgs {
     int ys, us, vs, nv12;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH;
     int ds, dstFormat;
-    int32_t hL[4], hC[4], vL[4];
+    int np;                                     // coefficient pairs per filter (4 | 6)
+    int32_t hL[6], hC[6], vL[6];
     int lr;
     int segRows, nseg, nsg, xcdRemap;           // filled by the launcher: rows per strip segment, segments, groups of 4 strips per row
     Yuv2RgbConsts y2r;

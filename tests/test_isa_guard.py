@@ -62,7 +62,7 @@ def test_the_extraction_sees_the_kernels(disassembly):
     nsrc = len(glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "k_*.hip")))
     assert len(disassembly) >= nsrc, (len(disassembly), nsrc)
     allt = "\n".join(disassembly)
-    for k in ("scale_yuv2s_kernel", "scale_yuv2p_kernel", "scale_rgb2s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
+    for k in ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_rgb2s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
               "scale_yuv_kernel", "yuv2rgb_kernel"):
         assert k in allt, k
     assert allt.count("v_dot2") > 1000 and "v_perm_b32" in allt

@@ -785,8 +785,10 @@ def test_rgb_large_downscale_ratios(dev, orc, geom):
 
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
 @pytest.mark.parametrize("geom", X2_GEOMS)
-def test_yuv2x_lanczos_uses_the_14_sample_window(dev, orc, src_fmt, geom):
-    """Lanczos-3 at 2:1 has 12 taps: the 2:1 kernel's P = 7 variant (window of 14 samples, 4 vertical chroma pairs)"""
+def test_yuv2x_lanczos_uses_the_14_sample_window(dev, orc, kern, src_fmt, geom):
+    """Lanczos-3 at 2:1 has 12 taps: the tiled 2:1 kernel's P = 7 variant (window of 14 samples, 4 vertical chroma pairs) — and,
+    by default on frames at least 128 wide and 24 tall, the strip kernel's 6-pair form (tests/test_parity_strip.py): both via
+    the `kern` fixture"""
     sw, sh, dw, dh = geom
     src = synth_planes(orc, src_fmt, sw, sh, seed=53)
     for dst_fmt in ("rgb24", "bgra"):
@@ -795,7 +797,8 @@ def test_yuv2x_lanczos_uses_the_14_sample_window(dev, orc, src_fmt, geom):
         got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["lanczos"], dst_align=256)
         for p in d_src:
             p.free()
-        assert kernel == "scale_yuv2x_kernel", kernel
+        strip = kern == "scale_yuv2s_kernel" and sw >= 128 and dh >= 12
+        assert kernel == ("scale_yuv2s_np_kernel<6>" if strip else "scale_yuv2x_kernel"), kernel
         bad = np.argwhere(got[0] != want)
         assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
         assert (pads[0] == 0xCD).all()

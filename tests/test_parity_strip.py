@@ -63,11 +63,61 @@ def test_strip_kernel_filters_that_fit_the_window(dev, orc, strip_rows, flags):
     assert k.startswith("scale_yuv2"), k
 
 
-@pytest.mark.parametrize("flags", ["lanczos", "sinc"])
-def test_wide_filters_fall_back(dev, orc, strip_rows, flags):
+def test_filters_wider_than_12_taps_fall_back(dev, orc, strip_rows):
     strip_rows(0)
-    k = _run_batch(dev, orc, "nv12", "rgb24", 320, 48, 160, 24, nframes=2, nstreams=1, align=16, flags=SWS[flags])
-    assert k != "scale_yuv2s_kernel", k
+    k = _run_batch(dev, orc, "nv12", "rgb24", 320, 48, 160, 24, nframes=2, nstreams=1, align=16, flags=SWS["sinc"])
+    assert not k.startswith("scale_yuv2s"), k
+
+
+# Lanczos-3 at 2:1: 12 taps on [2x - 5, 2x + 6] = the 6-pair instantiation, on frames at least 128 wide and 24 tall (12 output
+# rows); smaller ones stay on the tiled kernel.  (srcW, srcH, alignment): partial strips, two strip groups, widths that are
+# multiples of 8 only, both edge lanes of a side inside one wave (the narrow ones)
+LANCZOS_GEOMS = [(128, 24, 4), (136, 32, 8), (320, 48, 16), (520, 36, 4), (1032, 28, 8), (2056, 40, 4), (4104, 24, 4), (64, 32, 16), (128, 20, 4)]
+
+
+LZ = "scale_yuv2s_np_kernel<6>"                      # the 6-pair kernel (the 4-pair headline kernel is a separate, untouched one)
+
+
+def lanczos_takes(sw, sh):
+    return sw % 8 == 0 and sw >= 128 and sh // 2 >= 12
+
+
+@pytest.mark.parametrize("dst_fmt", ["rgb24", "bgra"])
+@pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", LANCZOS_GEOMS)
+def test_lanczos_on_the_strip_kernel(dev, orc, strip_rows, kern, src_fmt, dst_fmt, geom):
+    """both kernels (the `kern` fixture: strip / tiled) against the oracle on every geometry"""
+    sw, sh, align = geom
+    if dst_fmt == "bgra":
+        align = max(align, 16)
+    strip_rows(0)
+    k = _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, sw // 2, sh // 2, nframes=2, nstreams=1, align=align, flags=SWS["lanczos"])
+    if kern == "scale_yuv2s_kernel" and lanczos_takes(sw, sh):
+        assert k == LZ, k
+    else:
+        assert not k.startswith("scale_yuv2s"), k
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64])
+def test_lanczos_segmentation(dev, orc, strip_rows, rows):
+    """5 warm-up row pairs per segment re-create the 6-slot vertical window; the chroma row of an output row is requested one
+    iteration ahead of it, whatever the segment length"""
+    strip_rows(rows)
+    assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=3, nstreams=2, align=16, flags=SWS["lanczos"]) == LZ
+
+
+@pytest.mark.parametrize("cs", [1, 9])
+def test_lanczos_colorspace(dev, orc, strip_rows, cs):
+    strip_rows(0)
+    lib = dev.lib
+    sw, sh = 528, 52
+    src = synth_planes(orc, "yuv420p", sw, sh, seed=91)
+    want = orc.sws(src, sw, sh, "yuv420p", sw // 2, sh // 2, "rgb24", SWS["lanczos"], colorspace=cs)
+    d = dev.upload_planes(src, 64)
+    got, pads, k = dev.sws(d, sw, sh, "yuv420p", sw // 2, sh // 2, "rgb24", SWS["lanczos"], dst_align=64, colorspace=(cs, 0))
+    assert k == LZ and (got[0] == want[0]).all() and (pads[0] == 0xCD).all()
+    for p in d:
+        p.free()
 
 
 @pytest.mark.parametrize("cs", [1, 5, 9])
