@@ -475,7 +475,8 @@ static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     Yuv2pArgs pa;
     std::memset(&pa, 0, sizeof(pa));
     pa.ys = ya.ys; pa.us = ya.us; pa.vs = ya.vs;
-    pa.nv12 = ya.nv12 || c->srcFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma on both sides
+    pa.nv12 = ya.nv12 || c->srcFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma on the SOURCE side
+    pa.cross = c->y2p.cross;                                     // ... and the other layout on the destination's
     pa.srcDepth = c->y2p.srcDepth; pa.dstDepth = c->y2p.dstDepth;
     pa.srcW = ya.srcW; pa.srcH = ya.srcH; pa.chrSrcW = ya.chrSrcW; pa.chrSrcH = ya.chrSrcH;
     pa.dstW = ya.dstW; pa.dstH = ya.dstH; pa.chrDstW = ya.chrDstW; pa.chrDstH = ya.chrDstH;
@@ -490,6 +491,7 @@ static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya
 static const char *yuv2p_name(const GmatSwsContext *c)
 {
     const int s = c->y2p.srcDepth, d = c->y2p.dstDepth;
+    if (c->y2p.cross) return s == 8 ? (d == 8 ? "scale_yuv2px_kernel" : "scale_yuv2px_kernel<8to10>") : (d == 8 ? "scale_yuv2px_kernel<10to8>" : "scale_yuv2px_kernel<10to10>");
     return s == 8 ? (d == 8 ? "scale_yuv2p_kernel" : "scale_yuv2p_kernel<8to10>") : (d == 8 ? "scale_yuv2p_kernel<10to8>" : "scale_yuv2p16_kernel");
 }
 

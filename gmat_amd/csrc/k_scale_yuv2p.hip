@@ -375,6 +375,224 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
 }
 
+// ---- chroma across layouts: planar U, V planes <-> one interleaved UV plane (NV12 -> YUV420P: a hardware decoder's frames into a
+// software encoder; YUV420P -> NV12: the reverse).  The UV walker with the other side's load or store stage: a lane still makes 2
+// UV outputs a row and keeps [U0, V0, U1, V1] in its window slots.
+//   SPL: the source is planar — per plane 2 NP + 2 samples from sample 2cc - 4 (NP = 4) / 2cc - 8 | 2cc - 6 (NP = 6; 8 | 16 bit)
+//   !SPL: the source is interleaved, the destination planar: 2 bytes (16 bit: a dword) to each plane
+struct P2Cross {
+    const uint8_t *srcU, *srcV; uint8_t *dstU, *dstV;          // interleaved side: ...U is the UV plane, ...V unused
+    int ssU, ssV, dsU, dsV, srcW, srcH, dstW;                   // widths in UV positions
+    const int32_t *h, *v;
+    int rnd, srcHi6, dstHi6;
+};
+struct P2RowX { unsigned u[16], v[8]; };                        // interleaved source: u = the UV dwords
+
+template <bool S16, bool D16, int NP, bool SPL>
+__device__ __forceinline__ void p2_walk_uvx(const P2Cross &P, int X0, int y0, int nOut, int lane)
+{
+    constexpr int SHR = S16 ? 9 : 7;
+    // planar source: dwords per plane and samples between the window base and 2cc
+    constexpr int BLP = S16 ? (NP == 4 ? 4 : 6) : (NP == 4 ? 4 : 8);
+    constexpr int NDP = S16 ? (NP == 4 ? 6 : 8) : (NP == 4 ? 3 : 5);
+    constexpr int SPD = S16 ? 2 : 4;
+    // interleaved source: NP + 2 dwords (16 bit: 2 NP + 4), window base position 2cc - NP
+    constexpr int NDI = S16 ? 2 * NP + 4 : NP + 2;
+    const int co = X0 + 2 * lane;
+    const bool active = co < P.dstW;
+    const int cc = active ? co : P.dstW - 2;
+    const int want = SPL ? 2 * cc - BLP : 2 * cc - NP;          // first sample (planar) / position (interleaved) of the window
+    const int wd0 = SPL ? (want >= 0 ? want / SPD : -((-want + SPD - 1) / SPD)) : (S16 ? want : (want >= 0 ? want / 2 : -((-want + 1) / 2)));
+    const int lastDw = SPL ? P.srcW / SPD - 1 : (S16 ? P.srcW : P.srcW / 2) - 1;
+    // a wave is an edge wave when any of its windows leaves the row: every dword then comes from its own clamped address
+    const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UV + 8 >= P.dstW;
+    const int nIter = nOut + NP - 1;
+    const int m0 = y0 - (NP / 2 - 1);
+
+    auto load1 = [&](int row, P2RowX &r, auto edge_c) {
+        const int rr = min(max(row, 0), P.srcH - 1);
+        const unsigned ou = (unsigned)rr * (unsigned)P.ssU, ov = (unsigned)rr * (unsigned)P.ssV;
+        if constexpr (decltype(edge_c)::value) {
+#pragma unroll
+            for (int i = 0; i < (SPL ? NDP : NDI); i++) {
+                const unsigned c = 4u * (unsigned)min(max(wd0 + i, 0), lastDw);
+                r.u[i] = p2_ld4(P.srcU + (unsigned)(ou + c));
+                if (SPL) r.v[i] = p2_ld4(P.srcV + (unsigned)(ov + c));
+            }
+        } else if constexpr (SPL) {
+            const unsigned b = 4u * (unsigned)wd0;
+            const uint4 tu = p2_ld16(P.srcU + (unsigned)(ou + b)), tv = p2_ld16(P.srcV + (unsigned)(ov + b));   // NDP = 3: the 4th dword is not used
+            r.u[0] = tu.x; r.u[1] = tu.y; r.u[2] = tu.z; r.u[3] = tu.w; r.v[0] = tv.x; r.v[1] = tv.y; r.v[2] = tv.z; r.v[3] = tv.w;
+            if (NDP > 4) {
+                const uint4 tu2 = p2_ld16(P.srcU + (unsigned)(ou + b + 16u)), tv2 = p2_ld16(P.srcV + (unsigned)(ov + b + 16u));
+                r.u[4] = tu2.x; r.u[5] = tu2.y; r.u[6] = tu2.z; r.u[7] = tu2.w; r.v[4] = tv2.x; r.v[5] = tv2.y; r.v[6] = tv2.z; r.v[7] = tv2.w;
+            }
+        } else {
+            const unsigned b = ou + 4u * (unsigned)wd0;
+#pragma unroll
+            for (int i = 0; i < NDI / 4; i++) {
+                const uint4 t = p2_ld16(P.srcU + (unsigned)(b + 16u * i));
+                r.u[4 * i] = t.x; r.u[4 * i + 1] = t.y; r.u[4 * i + 2] = t.z; r.u[4 * i + 3] = t.w;
+            }
+            if (NDI % 4) { const uint2 t = p2_ld8(P.srcU + (unsigned)(b + 16u * (NDI / 4))); r.u[NDI - 2] = t.x; r.u[NDI - 1] = t.y; }
+        }
+    };
+    auto load = [&](int m, P2RowX &ra, P2RowX &rb, auto edge_c) { load1(2 * m - 1, ra, edge_c); load1(2 * m, rb, edge_c); };
+    auto hrow = [&](const P2RowX &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        int pU[NP + 1], pV[NP + 1];
+        if constexpr (SPL) {
+            unsigned du[NDP + 1], dv[NDP + 1];
+#pragma unroll
+            for (int k = 0; k < NDP; k++) { du[k] = R.u[k]; dv[k] = R.v[k]; }
+            du[NDP] = dv[NDP] = 0u;
+            if constexpr (EDGE) {
+#pragma unroll
+                for (int i = 0; i < NDP; i++) {
+                    const int idx = wd0 + i;
+                    const unsigned selLo = S16 ? 0x01000100u : 0x00000000u, selHi = S16 ? 0x03020302u : 0x03030303u;
+                    du[i] = idx < 0 ? p2_rep(du[i], selLo) : idx > lastDw ? p2_rep(du[i], selHi) : du[i];
+                    dv[i] = idx < 0 ? p2_rep(dv[i], selLo) : idx > lastDw ? p2_rep(dv[i], selHi) : dv[i];
+                }
+            }
+            if constexpr (S16) {
+#pragma unroll
+                for (int k = 0; k < NP + 1; k++) { pU[k] = p2_odd(du[k + 1], du[k]); pV[k] = p2_odd(dv[k + 1], dv[k]); }
+            } else {
+                constexpr int O0 = BLP - (NP - 1);              // byte of the first pair: 1 (NP = 4) or 3 (NP = 6)
+#pragma unroll
+                for (int k = 0; k < NP + 1; k++) {
+                    const int o = O0 + 2 * k;
+                    pU[k] = (o & 3) == 1 ? p2_pair12(du[o >> 2]) : p2_pair30(du[(o >> 2) + 1], du[o >> 2]);
+                    pV[k] = (o & 3) == 1 ? p2_pair12(dv[o >> 2]) : p2_pair30(dv[(o >> 2) + 1], dv[o >> 2]);
+                }
+            }
+        } else {
+            unsigned e[NDI];
+#pragma unroll
+            for (int k = 0; k < NDI; k++) e[k] = R.u[k];
+            if (S16) {
+#pragma unroll
+                for (int k = 0; k < NDI; k++) e[k] = p2_shr6(e[k]);
+            }
+            if constexpr (EDGE) {
+#pragma unroll
+                for (int i = 0; i < NDI; i++) {
+                    const int idx = wd0 + i;
+                    const unsigned lo = S16 ? e[i] : p2_rep(e[i], 0x01000100u), hi = S16 ? e[i] : p2_rep(e[i], 0x03020302u);
+                    e[i] = idx < 0 ? lo : idx > lastDw ? hi : e[i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NP + 1; k++) {
+                if (S16) {
+                    pU[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x05040100u);
+                    pV[k] = (int)__builtin_amdgcn_perm(e[2 * k + 2], e[2 * k + 1], 0x07060302u);
+                } else {
+                    pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
+                    pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int au = 0, av = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) { au = p2_dot2(pU[c + k], P.h[k], au); av = p2_dot2(pV[c + k], P.h[k], av); }
+            su[c] = au; sv[c] = av;
+        }
+    };
+
+    int hw[NP][4];                                              // [slot][U0, V0, U1, V1]: (row 2m-1 | row 2m << 16)
+#pragma unroll
+    for (int s = 0; s < NP; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hw[s][j] = 0;
+    P2RowX bufA[2], bufB[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) bufA[i].u[k] = bufB[i].u[k] = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) bufA[i].v[k] = bufB[i].v[k] = 0u;
+    }
+
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (j + 1 < nIter) load(m0 + j + 1, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1], edge_c);
+        {
+            int ua[2], va[2], ub[2], vb[2];
+            hrow(bufA[SLOT & 1], edge_c, ua, va);
+            hrow(bufB[SLOT & 1], edge_c, ub, vb);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                hw[SLOT][2 * c + 0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c] >> SHR, ub[c] >> SHR));
+                hw[SLOT][2 * c + 1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c] >> SHR, vb[c] >> SHR));
+            }
+        }
+        if (j >= NP - 1) {
+            const int yo = y0 + j - (NP - 1);
+            unsigned w[4];                                      // U0 V0 U1 V1
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int acc = P.rnd;
+#pragma unroll
+                for (int k = 0; k < NP; k++) acc = p2_dot2(hw[(SLOT + 1 + k) % NP][q], P.v[k], acc);
+                if (D16) { w[q] = (unsigned)min(max(acc, 0), (1024 << 17) - 1) >> 17; if (P.dstHi6) w[q] <<= 6; }
+                else     w[q] = (unsigned)clip_u8_shr(acc, 19);
+            }
+            if (active) {
+                if constexpr (SPL) {                            // planar in, interleaved out
+                    uint8_t *d = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 4u : 2u) * (unsigned)co);
+                    if (D16) *reinterpret_cast<uint2 *>(d) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+                    else     *reinterpret_cast<unsigned *>(d) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+                } else {                                        // interleaved in, planar out: 2 samples to each plane
+                    uint8_t *du = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 2u : 1u) * (unsigned)co);
+                    uint8_t *dv = P.dstV + (unsigned)((unsigned)yo * (unsigned)P.dsV + (D16 ? 2u : 1u) * (unsigned)co);
+                    if (D16) { *reinterpret_cast<unsigned *>(du) = w[0] | (w[2] << 16); *reinterpret_cast<unsigned *>(dv) = w[1] | (w[3] << 16); }
+                    else     { *reinterpret_cast<unsigned short *>(du) = (unsigned short)(w[0] | (w[2] << 8));
+                               *reinterpret_cast<unsigned short *>(dv) = (unsigned short)(w[1] | (w[3] << 8)); }
+                }
+            }
+        }
+    };
+    if (edgeWave) { load(m0, bufA[0], bufB[0], std::true_type());  p2_rows<NP>(nIter, body, std::true_type()); }
+    else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
+}
+
+// the kernel of the mixed-layout pairs: SNV: the SOURCE is interleaved (NV12 | P010LE) and the destination planar; !SNV: the reverse
+template <bool SNV, bool S16, bool D16, int NP>
+__global__ __launch_bounds__(256) void scale_yuv2px_kernel(Yuv2pArgs a, Yuv2xFrames fr)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int f = blockIdx.y;
+    const int sHi = (SNV && S16) ? 1 : 0, dHi = (!SNV && D16) ? 1 : 0;     // P010 is the interleaved 10-bit format
+    if (lin < a.nblkL) {
+        const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgL);
+        const int X0 = ((lin - seg * a.nsgL) * 4 + wave) * P2_STRIP;
+        if (X0 >= a.dstW) return;
+        const int y0 = seg * a.segRowsL;
+        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, a.vL, a.lr, sHi, dHi};
+        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
+        return;
+    }
+    lin -= a.nblkL;
+    const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgC);
+    const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * P2_STRIP_UV;
+    if (X0 >= a.chrDstW) return;
+    const int y0 = seg * a.segRowsC;
+    const P2Cross P = {fr.u[f], fr.v[f], fr.dstU[f], fr.dstV[f], a.us, a.vs, a.dsU, a.dsV, a.chrSrcW, a.chrSrcH, a.chrDstW,
+                       a.hC, a.vC, a.cr, sHi, dHi};
+    p2_walk_uvx<S16, D16, NP, !SNV>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+}
+
 // blockIdx.x: [0, nblkL) luma workgroups (segment-major, 4 strips each), then the chroma workgroups — interleaved (NV): of the
 // UV plane, planar: of U, then of V.  blockIdx.y = frame.  S16 / D16: 10 bits in 16-bit containers on that side (interleaved:
 // P010LE, bits in the high end; planar: YUV420P10LE, low end).  NP: coefficient pairs per filter (4: 8 taps; 6: Lanczos-3).
@@ -431,12 +649,14 @@ int yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2pTables &t)
     const char *off = getenv("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut != 1) return 0;                                 // 4:2:0 destinations only (8-bit, or 10 bits on the 15-bit lines)
-    // same chroma layout on both sides: interleaved (NV12 | P010LE) -> (NV12 | P010LE), planar (YUV420P | YUV420P10LE) -> the same
+    // 8- or 10-bit 4:2:0 on both sides, interleaved (NV12 | P010LE) or planar (YUV420P | YUV420P10LE) chroma, any pairing
     const bool sNv = p.srcFormat == GMAT_PIX_FMT_NV12 || p.srcFormat == GMAT_PIX_FMT_P010LE;
     const bool dNv = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_P010LE;
     const bool sPl = p.srcFormat == GMAT_PIX_FMT_YUV420P || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE;
     const bool dPl = p.dstFormat == GMAT_PIX_FMT_YUV420P || p.dstFormat == GMAT_PIX_FMT_YUV420P10LE;
-    if (!((sNv && dNv) || (sPl && dPl))) return 0;
+    if (!((sNv || sPl) && (dNv || dPl))) return 0;
+    t.cross = (sNv != dNv) ? 1 : 0;                              // mixed chroma layouts: scale_yuv2px_kernel
+    t.snv = sNv ? 1 : 0;
     t.srcDepth = (p.srcFormat == GMAT_PIX_FMT_P010LE || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE) ? 10 : 8;
     t.dstDepth = (p.dstFormat == GMAT_PIX_FMT_P010LE || p.dstFormat == GMAT_PIX_FMT_YUV420P10LE) ? 10 : 8;
     if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 16 || p.srcW < 64 || p.dstH < 16) return 0;
@@ -466,8 +686,9 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override, read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstripsL = (a.dstW + P2_STRIP - 1) / P2_STRIP;
-    const int nstripsC = a.nv12 ? (a.chrDstW + P2_STRIP_UV - 1) / P2_STRIP_UV : (a.chrDstW + P2_STRIP - 1) / P2_STRIP;
-    const int nplC = a.nv12 ? 1 : 2;
+    const bool uvw = a.nv12 || a.cross;                          // the chroma runs on a UV walker (2 outputs per lane, one "plane" of workgroups)
+    const int nstripsC = uvw ? (a.chrDstW + P2_STRIP_UV - 1) / P2_STRIP_UV : (a.chrDstW + P2_STRIP - 1) / P2_STRIP;
+    const int nplC = uvw ? 1 : 2;
     a.nsgL = (nstripsL + 3) / 4; a.nsgC = (nstripsC + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
@@ -489,7 +710,20 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
 #define GMAT_P2N(NV_, S_, D_) do { if (a.np == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 6>), grid, block, 0, stream, a, *frames); \
                                    else           hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 4>), grid, block, 0, stream, a, *frames); } while (0)
+#define GMAT_P2X(NV_, S_, D_) do { if (a.np == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2px_kernel<NV_, S_, D_, 6>), grid, block, 0, stream, a, *frames); \
+                                   else           hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2px_kernel<NV_, S_, D_, 4>), grid, block, 0, stream, a, *frames); } while (0)
     const int sel = (a.nv12 ? 4 : 0) | (a.srcDepth == 10 ? 2 : 0) | (a.dstDepth == 10 ? 1 : 0);
+    if (a.cross) {
+        switch (sel) {
+        case 0: GMAT_P2X(false, false, false); break; case 1: GMAT_P2X(false, false, true); break;
+        case 2: GMAT_P2X(false, true, false);  break; case 3: GMAT_P2X(false, true, true);  break;
+        case 4: GMAT_P2X(true, false, false);  break; case 5: GMAT_P2X(true, false, true);  break;
+        case 6: GMAT_P2X(true, true, false);   break; default: GMAT_P2X(true, true, true);  break;
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+#undef GMAT_P2X
     switch (sel) {
     case 0: GMAT_P2N(false, false, false); break; case 1: GMAT_P2N(false, false, true); break;
     case 2: GMAT_P2N(false, true, false);  break; case 3: GMAT_P2N(false, true, true);  break;

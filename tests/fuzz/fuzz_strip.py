@@ -52,8 +52,8 @@ for case in range(n):
                 sw, sh = 16 * rng.randint(4, maxw // 16), 4 * rng.randint(8, 40); dw, dh = sw // 2, sh // 2
         else:            sf, df = rng.choice(RGB3), rng.choice(RGBX)
         if fam >= 0.45 and fam < 0.8 and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
-            sf, df = rng.choice([("p010le", "p010le"), ("yuv420p10le", "yuv420p10le"), ("nv12", "p010le"), ("p010le", "nv12"),
-                                 ("yuv420p", "yuv420p10le"), ("yuv420p10le", "yuv420p")])
+            fam4 = ["nv12", "yuv420p", "p010le", "yuv420p10le"]                 # every pairing of chroma layout and sample depth
+            sf, df = rng.choice(fam4), rng.choice(fam4)
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])

@@ -81,8 +81,8 @@ def _expected_2to1(which, src_fmt, dst_fmt):
     kernel"""
     if which == "strip" and dst_fmt in ("rgb24", "bgra"):
         return "scale_yuv2s_kernel"
-    if which == "strip" and src_fmt == dst_fmt:
-        return "scale_yuv2p_kernel"
+    if which == "strip" and dst_fmt in ("nv12", "yuv420p"):
+        return "scale_yuv2p_kernel" if src_fmt == dst_fmt else "scale_yuv2px_kernel"     # same / mixed chroma layouts
     return "scale_yuv2x_kernel<yuv>" if dst_fmt in ("nv12", "yuv420p") else "scale_yuv2x_kernel"
 
 

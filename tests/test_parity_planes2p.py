@@ -24,7 +24,8 @@ def strip_takes(sw, sh, src_fmt, dst_fmt, flags="bicubic"):
     """the host rule of yuv2p_prepare restated: same chroma layout on both sides, width a multiple of 16 and >= 64,
     output height >= 16 and even (so that every plane is exactly halved), a filter that fits the 8-sample window"""
     dh = sh // 2
-    if not (src_fmt == dst_fmt and sw % 16 == 0 and sw >= 64 and sh % 4 == 0 and dh >= 16):
+    fam = ("nv12", "yuv420p", "p010le", "yuv420p10le")           # 8 / 10-bit 4:2:0, interleaved or planar chroma, any pairing
+    if not (src_fmt in fam and dst_fmt in fam and sw % 16 == 0 and sw >= 64 and sh % 4 == 0 and dh >= 16):
         return False
     if flags == "lanczos":                               # 12 taps: the 6-pair instantiation, on planes wide and tall enough for it
         return sw >= 128 and dh >= 24
@@ -42,11 +43,20 @@ def kern_yuv(request):
         os.environ["GMAT_SCALE_NO_STRIP"] = old
 
 
+def strip_name(sf, df):
+    """the name the plane-walking kernels report: by chroma layouts (same: scale_yuv2p, mixed: scale_yuv2px) and sample depths"""
+    inter = ("nv12", "p010le")
+    s10, d10 = sf in ("p010le", "yuv420p10le"), df in ("p010le", "yuv420p10le")
+    if (sf in inter) == (df in inter):
+        return {(0, 0): "scale_yuv2p_kernel", (0, 1): "scale_yuv2p_kernel<8to10>", (1, 0): "scale_yuv2p_kernel<10to8>", (1, 1): "scale_yuv2p16_kernel"}[(s10, d10)]
+    return {(0, 0): "scale_yuv2px_kernel", (0, 1): "scale_yuv2px_kernel<8to10>", (1, 0): "scale_yuv2px_kernel<10to8>", (1, 1): "scale_yuv2px_kernel<10to10>"}[(s10, d10)]
+
+
 def expect(kern_yuv, sw, sh, sf, df, flags="bicubic"):
     """three kernels serve a bicubic 2:1 4:2:0 -> 4:2:0 context: the plane-walking one, the tiled 2:1 one (whole 16-byte
     chunks: yuv2x_prepare wants srcW % 16 == 0) and the generic plane scaler for what both decline"""
     if kern_yuv == "strip" and strip_takes(sw, sh, sf, df, flags):
-        return STRIP
+        return strip_name(sf, df)
     return TILED if sw % 16 == 0 else GENERIC
 
 
@@ -90,9 +100,38 @@ def test_same_layout_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, f
 
 
 @pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
-@pytest.mark.parametrize("geom", [(256, 64), (528, 52), (72, 40)])
-def test_cross_layout_pairs_never_take_the_strip_kernel(dev, orc, kern_yuv, pair, geom):
-    assert _check(dev, orc, pair[0], pair[1], *geom) == (TILED if geom[0] % 16 == 0 else GENERIC)
+@pytest.mark.parametrize("geom", GEOMS)
+def test_mixed_layouts_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, pair, geom):
+    """NV12 -> YUV420P (a hardware decoder's frames into a software encoder) and the reverse: the chroma stage of
+    scale_yuv2px_kernel loads or stores the other layout; luma is the same walker"""
+    strip_rows(0)
+    assert _check(dev, orc, pair[0], pair[1], *geom) == expect(kern_yuv, geom[0], geom[1], pair[0], pair[1])
+
+
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
+@pytest.mark.parametrize("rows", [1, 3, 5, 13, 1000])
+def test_mixed_layouts_segmentation(dev, orc, strip_rows, pair, rows):
+    strip_rows(rows)
+    assert _check(dev, orc, pair[0], pair[1], 528, 52) == "scale_yuv2px_kernel"
+
+
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
+@pytest.mark.parametrize("geom", LANCZOS_GEOMS)
+def test_mixed_layouts_lanczos(dev, orc, strip_rows, kern_yuv, pair, geom):
+    strip_rows(0)
+    sw, sh = geom
+    k = _check(dev, orc, pair[0], pair[1], sw, sh, "lanczos")
+    if kern_yuv == "strip" and strip_takes(sw, sh, pair[0], pair[1], "lanczos"):
+        assert k == "scale_yuv2px_kernel", k
+    else:
+        assert k in (TILED, GENERIC), k
+
+
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
+def test_mixed_layouts_batched(dev, orc, strip_rows, kern_yuv, pair):
+    strip_rows(0)
+    k = _run_batch(dev, orc, pair[0], pair[1], 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
+    assert k == expect(kern_yuv, 528, 52, pair[0], pair[1]), k
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
@@ -327,6 +366,24 @@ def test_cross_depth_destination_alignment(dev, orc, pair):
     assert _check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need // 2, extra=need // 2).startswith("scale_yuv_kernel")
 
 
-def test_mixed_layouts_across_depths_stay_generic(dev, orc):
-    for sf, df in (("nv12", "yuv420p10le"), ("yuv420p", "p010le"), ("p010le", "yuv420p"), ("yuv420p10le", "nv12"), ("p010le", "yuv420p10le")):
-        assert _check_cross(dev, orc, sf, df, 528, 52).startswith("scale_yuv_kernel"), (sf, df)
+MIXED_DEPTH = [("nv12", "yuv420p10le"), ("yuv420p", "p010le"), ("p010le", "yuv420p"), ("yuv420p10le", "nv12"), ("p010le", "yuv420p10le"),
+               ("yuv420p10le", "p010le")]
+
+
+@pytest.mark.parametrize("pair", MIXED_DEPTH)
+@pytest.mark.parametrize("geom", [(64, 32), (528, 52), (1040, 36), (2064, 40), (4112, 32), (72, 40), (128, 60)])
+def test_mixed_layouts_across_depths(dev, orc, strip_rows, kern_yuv, pair, geom):
+    """every pairing of layout and depth: the mixed-layout kernel's four depth instantiations"""
+    strip_rows(0)
+    sw, sh = geom
+    k = _check_cross(dev, orc, pair[0], pair[1], sw, sh)
+    if kern_yuv == "strip" and strip_takes(sw, sh, pair[0], pair[1]):
+        assert k == strip_name(pair[0], pair[1]), k
+    else:
+        assert k.startswith("scale_yuv_kernel"), k
+
+
+@pytest.mark.parametrize("pair", MIXED_DEPTH[:4])
+def test_mixed_layouts_across_depths_lanczos(dev, orc, strip_rows, pair):
+    strip_rows(0)
+    assert _check_cross(dev, orc, pair[0], pair[1], 2064, 48, "lanczos") == strip_name(pair[0], pair[1])

@@ -223,9 +223,9 @@ def test_yuv_to_yuv_scaled(dev, orc, src_fmt, dst_fmt, geom):
             p.free()
         # a YUV-output kernel: the generic / tiled ones ("...yuv>"), or the plane-walking 2:1 one for the aligned pass of the
         # one geometry in this list that is exactly 2:1 with the same layout on both sides
-        from test_parity_planes2p import strip_takes
+        from test_parity_planes2p import strip_takes, strip_name
         if (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and strip_takes(sw, sh, src_fmt, dst_fmt):
-            assert kernel == "scale_yuv2p_kernel", kernel
+            assert kernel == strip_name(src_fmt, dst_fmt), kernel
         else:
             assert "yuv>" in kernel, kernel
         for i, (g, w) in enumerate(zip(got, want)):
@@ -257,8 +257,8 @@ def test_yuv2x_yuv_output_bit_exact(dev, orc, src_fmt, dst_fmt, geom):
     got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS["bicubic"], dst_align=256)
     # same-layout pairs the plane-walking kernel takes are ITS cases (tests/test_parity_planes2p.py runs this matrix on both
     # kernels); here the name must be the one the selection rule gives
-    from test_parity_planes2p import strip_takes
-    assert kernel == ("scale_yuv2p_kernel" if strip_takes(sw, sh, src_fmt, dst_fmt) else "scale_yuv2x_kernel<yuv>"), kernel
+    from test_parity_planes2p import strip_takes, strip_name
+    assert kernel == (strip_name(src_fmt, dst_fmt) if strip_takes(sw, sh, src_fmt, dst_fmt) else "scale_yuv2x_kernel<yuv>"), kernel
     for i, (g, w) in enumerate(zip(got, want)):
         bad = np.argwhere(g != w)
         assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()}"
@@ -400,10 +400,10 @@ def test_p01x_sources(dev, orc, src_fmt, dst_fmt, geom):
             got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=align, dst_extra=extra)
             # the generic plane scaler, except P010 -> NV12 at exactly half size on dword-aligned rows: the plane-walking kernel's
             # 10 -> 8 instantiation (its own matrix: tests/test_parity_planes2p.py)
-            from test_parity_planes2p import strip_takes
-            strip = ((src_fmt, dst_fmt) == ("p010le", "nv12") and (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and
-                     strip_takes(sw, sh, "nv12", "nv12", flags))
-            assert kernel == "scale_yuv2p_kernel<10to8>" if strip else kernel.startswith("scale_yuv_kernel"), kernel
+            from test_parity_planes2p import strip_takes, strip_name
+            strip = (src_fmt == "p010le" and dst_fmt in ("nv12", "yuv420p") and (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and
+                     strip_takes(sw, sh, src_fmt, dst_fmt, flags))
+            assert kernel == strip_name(src_fmt, dst_fmt) if strip else kernel.startswith("scale_yuv_kernel"), kernel
             for i, (g, wv) in enumerate(zip(got, want)):
                 bad = np.argwhere(g != wv)
                 assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel}, {flags}, align {align})"
@@ -430,10 +430,9 @@ def test_p010_destination(dev, orc, src_fmt, geom):
             got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "p010le", SWS[flags], dst_align=align, dst_extra=extra)
             # the generic plane scaler, except P010 -> P010 at exactly half size on 8-byte aligned rows: the 10-bit
             # plane-walking kernel (its own matrix: tests/test_parity_planes2p.py)
-            from test_parity_planes2p import strip_takes
-            strip = src_fmt in ("p010le", "nv12") and (dw, dh) == (sw // 2, sh // 2) and align % 8 == 0 and strip_takes(sw, sh, "nv12", "nv12", flags)
-            name = "scale_yuv2p16_kernel" if src_fmt == "p010le" else "scale_yuv2p_kernel<8to10>"
-            assert kernel == name if strip else kernel.startswith("scale_yuv_kernel"), kernel
+            from test_parity_planes2p import strip_takes, strip_name
+            strip = (dw, dh) == (sw // 2, sh // 2) and align % 8 == 0 and strip_takes(sw, sh, src_fmt, "p010le", flags)
+            assert kernel == strip_name(src_fmt, "p010le") if strip else kernel.startswith("scale_yuv_kernel"), kernel
             for i, (g, wv) in enumerate(zip(got, want)):
                 bad = np.argwhere(g != wv)
                 assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel}, {flags}, align {align})"

@@ -180,6 +180,8 @@ int main(int argc, char **argv)
         {"nv12 4K->1080p rgba bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBA, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 4K->1080p rgb24 bilinear", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
         {"nv12 4K->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 4K->1080p yuv420p bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"yuv420p 4K->1080p nv12 bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"yuv420p 4K->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 1080p->540p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
         {"rgb24 4K->1080p rgb24 bicubic", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
