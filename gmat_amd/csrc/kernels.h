@@ -289,6 +289,26 @@ struct Yuv2pArgs {
 int  yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2pTables &t);
 int  launch_scale_yuv2p(const Yuv2pArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// ---- strip-walking form of the exact 1:2 UP-scale of 8-bit YUV 4:2:0 (k_scale_yuv1x2.hip): NV12 -> NV12, YUV420P -> YUV420P ------
+// per axis: A / B = the two phases (even / odd outputs) as 2 int16 pairs, S0 / S2 = the table's own rows of outputs 0 and 2
+struct Yuv1x2Tables {
+    int ok = 0;
+    int32_t hLA[2] = {0}, hLB[2] = {0}, hLS0[2] = {0}, hLS2[2] = {0}, vLA[2] = {0}, vLB[2] = {0}, vLS0[2] = {0}, vLS2[2] = {0};
+    int32_t hCA[2] = {0}, hCB[2] = {0}, hCS0[2] = {0}, hCS2[2] = {0}, vCA[2] = {0}, vCB[2] = {0}, vCS0[2] = {0}, vCS2[2] = {0};
+    int lr = 0, cr = 0;
+};
+struct Yuv1x2Args {
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH;            // the destination is exactly twice as large in both directions
+    int ds, dsU, dsV;
+    int32_t hLA[2], hLB[2], hLS0[2], hLS2[2], vLA[2], vLB[2], vLS0[2], vLS2[2];
+    int32_t hCA[2], hCB[2], hCS0[2], hCS2[2], vCA[2], vCB[2], vCS0[2], vCS2[2];
+    int lr, cr;
+    int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (rows = OUTPUT rows)
+};
+int  yuv1x2_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv1x2Tables &t);
+int  launch_scale_yuv1x2(const Yuv1x2Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
 // rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
 struct Rgb2sTables {

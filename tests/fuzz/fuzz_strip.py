@@ -54,6 +54,11 @@ for case in range(n):
         if fam >= 0.45 and fam < 0.8 and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
             fam4 = ["nv12", "yuv420p", "p010le", "yuv420p10le"]                 # every pairing of chroma layout and sample depth
             sf, df = rng.choice(fam4), rng.choice(fam4)
+        if rng.random() < 0.12:                                 # the exact 1:2 UP-scale family (scale_yuv1x2_kernel) and near misses
+            sf = rng.choice(YUV); df = sf if rng.random() < 0.85 else rng.choice(YUV)
+            sw = rng.choice([8 * rng.randint(4, maxw // 16), 4 * rng.randint(8, maxw // 8)]); sh = rng.choice([2 * rng.randint(8, 50), rng.randint(16, 99)])
+            dw, dh = 2 * sw, 2 * sh
+            if rng.random() < 0.06: dh += 1
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])
@@ -76,7 +81,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

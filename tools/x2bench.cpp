@@ -194,7 +194,10 @@ int main(int argc, char **argv)
         {"land: nv12 4K->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->720p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 1080p->720p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
-        {"land: nv12 1080p->4K nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"nv12 1080p->4K nv12 bicubic (up)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"land: yuv420p 1080p->4K yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"land: nv12 1080p->4K nv12 bilinear", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BILINEAR},
+        {"land: (old label) nv12 1080p->4K nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
         {"land: p010 4K->1080p p010 lanczos", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_SWS_LANCZOS},
         {"land: nv12 4K->1080p nv12 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_LANCZOS},
         {"land: nv12 4K->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
