@@ -132,6 +132,7 @@ struct GmatSwsContext {
     Yuv2sTables y2s;              // strip-walking 2:1 form (k_scale_yuv2s.hip), RGB destinations
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
+    Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
@@ -215,6 +216,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv2s_prepare(c->planYuv, c->ytiling, c->y2s)) < 0) return r;
     if ((r = yuv2p_prepare(c->planYuv, c->ytiling, c->y2p)) < 0) return r;
     if ((r = yuv1x2_prepare(c->planYuv, c->ytiling, c->y1x2)) < 0) return r;
+    if ((r = yuv3x1_prepare(c->planYuv, c->ytiling, c->y3x1)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -515,6 +517,27 @@ static Yuv1x2Args make_yuv1x2_args(const GmatSwsContext *c, const YuvScaleArgs &
     return ua;
 }
 
+// the 3:1 down-scale kernel: dword loads and stores on every plane
+static bool yuv3x1_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    return c->y3x1.ok && !c->rangeConv && ya.srcAligned && (dall & 3) == 0 && !ya.prof &&
+           (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
+}
+
+static Yuv3x1Args make_yuv3x1_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv3x1Args da;
+    std::memset(&da, 0, sizeof(da));
+    const Yuv3x1Tables &t = c->y3x1;
+    da.ys = ya.ys; da.us = ya.us; da.vs = ya.vs; da.nv12 = ya.nv12;
+    da.dstW = ya.srcW / 3; da.dstH = ya.srcH / 3; da.chrDstW = ya.chrSrcW / 3; da.chrDstH = ya.chrSrcH / 3;
+    da.ds = ya.ds; da.dsU = ya.dsU; da.dsV = ya.dsV;
+    for (int k = 0; k < 6; k++) { da.hL[k] = t.hL[k]; da.hC[k] = t.hC[k]; da.vL[k] = t.vL[k]; da.vC[k] = t.vC[k]; }
+    da.lr = t.lr; da.cr = t.cr; da.xcdRemap = ya.xcdRemap;
+    return da;
+}
+
 // the name the plane-walking kernel reports by sample depths (one template, four instantiations per chroma layout)
 static const char *yuv2p_name(const GmatSwsContext *c)
 {
@@ -642,7 +665,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -652,6 +675,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use2s = use2s && yuv2s_eligible(c, ya);
         use2p = use2p && yuv2p_eligible(c, ya);
         use1x2 = use1x2 && yuv1x2_eligible(c, ya);
+        use3x1 = use3x1 && yuv3x1_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -662,7 +686,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
     const Yuv1x2Args ua = use1x2 ? make_yuv1x2_args(c, ya0) : Yuv1x2Args();
-    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const Yuv3x1Args da = use3x1 ? make_yuv3x1_args(c, ya0) : Yuv3x1Args();
+    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -676,6 +701,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         int r = use2s ? launch_scale_yuv2s(sa, stream, &fr, m)
               : use2p ? launch_scale_yuv2p(pa, stream, &fr, m)
               : use1x2 ? launch_scale_yuv1x2(ua, stream, &fr, m)
+              : use3x1 ? launch_scale_yuv3x1(da, stream, &fr, m)
               : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
                       : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
@@ -1199,6 +1225,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv1x2_kernel";
                 r = launch_scale_yuv1x2(make_yuv1x2_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv3x1_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_yuv3x1_kernel";
+                r = launch_scale_yuv3x1(make_yuv3x1_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv2x_eligible(c, ya, src, srcStride)) {

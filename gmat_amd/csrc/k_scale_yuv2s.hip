@@ -711,6 +711,44 @@ bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pair
     return filter_is_edge_replication_np(fb, srcLen, 4, pairs);
 }
 
+// The same question for an exact R:1 down-scale: is every row "the middle row on the window [R x - L, R x - L + 2 NP) of an
+// edge-replicated line"?  pairs: NP int16 pairs (a window slot without a tap: 0).
+bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, int L, int NP, int32_t *pairs)
+{
+    const int W = 2 * NP;
+    if (R < 2 || NP < 1 || NP > 8 || fb.count < 4 || srcLen != R * fb.count) return false;
+    const int xm = fb.count / 2;
+    int nominal[16] = {0};
+    for (int j = 0; j < fb.taps; j++) {
+        const int16_t c = fb.coef[(size_t)xm * fb.taps + j];
+        if (!c) continue;
+        const int slot = fb.pos[xm] + j - (R * xm - L);
+        if (slot < 0 || slot >= W) return false;
+        nominal[slot] = c;
+    }
+    std::vector<int> eff(3 * W), tab(3 * W);
+    for (int x = 0; x < fb.count; x++) {
+        const int base = R * x - L - W;
+        std::fill(eff.begin(), eff.end(), 0); std::fill(tab.begin(), tab.end(), 0);
+        for (int k = 0; k < W; k++) {
+            const int s = std::min(std::max(R * x - L + k, 0), srcLen - 1);
+            if (s - base < 0 || s - base >= 3 * W) return false;
+            eff[s - base] += nominal[k];
+        }
+        for (int j = 0; j < fb.taps; j++) {
+            const int16_t c = fb.coef[(size_t)x * fb.taps + j];
+            if (!c) continue;
+            const int s = fb.pos[x] + j;
+            if (s < 0 || s >= srcLen || s - base < 0 || s - base >= 3 * W) return false;
+            tab[s - base] += c;
+        }
+        if (eff != tab) return false;
+    }
+    for (int k = 0; k < NP; k++)
+        pairs[k] = (int32_t)((uint32_t)(uint16_t)nominal[2 * k] | ((uint32_t)(uint16_t)nominal[2 * k + 1] << 16));
+    return true;
+}
+
 int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
 {
     t = Yuv2sTables();

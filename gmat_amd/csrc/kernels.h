@@ -309,6 +309,24 @@ struct Yuv1x2Args {
 int  yuv1x2_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv1x2Tables &t);
 int  launch_scale_yuv1x2(const Yuv1x2Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// ---- strip-walking form of the exact 3:1 down-scale of 8-bit YUV 4:2:0 (k_scale_yuv3x1.hip): NV12 -> NV12, YUV420P -> YUV420P -----
+// per filter: the 11 taps on the window [3x - 4, 3x + 7] as 6 int16 pairs (the 12th coefficient is 0)
+struct Yuv3x1Tables {
+    int ok = 0;
+    int32_t hL[6] = {0}, hC[6] = {0}, vL[6] = {0}, vC[6] = {0};
+    int lr = 0, cr = 0;
+};
+struct Yuv3x1Args {
+    int ys, us, vs, nv12;
+    int dstW, dstH, chrDstW, chrDstH;            // the source is exactly three times as large in both directions
+    int ds, dsU, dsV;
+    int32_t hL[6], hC[6], vL[6], vC[6];
+    int lr, cr;
+    int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (nsg = strips per row here)
+};
+int  yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x1Tables &t);
+int  launch_scale_yuv3x1(const Yuv3x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
 // rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
 struct Rgb2sTables {
@@ -325,6 +343,7 @@ struct Rgb2sArgs {
 };
 bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4]);
 bool filter_is_edge_replication_np(const FilterBank &fb, int srcLen, int NP, int32_t *pairs);      // NP pairs on [2x - (NP - 1), 2x + NP]
+bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, int L, int NP, int32_t *pairs);   // R:1, window from R x - L
 int  rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t);
 // frames->y[] = source frames, frames->dst[] = destination frames (grid.y = frame)
 int  launch_scale_rgb2s(const Rgb2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);

@@ -59,6 +59,11 @@ for case in range(n):
             sw = rng.choice([8 * rng.randint(4, maxw // 16), 4 * rng.randint(8, maxw // 8)]); sh = rng.choice([2 * rng.randint(8, 50), rng.randint(16, 99)])
             dw, dh = 2 * sw, 2 * sh
             if rng.random() < 0.06: dh += 1
+        if rng.random() < 0.12:                                 # the exact 3:1 down-scale family (scale_yuv3x1_kernel) and near misses
+            sf = rng.choice(YUV); df = sf if rng.random() < 0.85 else rng.choice(YUV)
+            dw = rng.choice([8 * rng.randint(4, maxw // 24), 4 * rng.randint(8, maxw // 12)]); dh = rng.choice([2 * rng.randint(6, 40), rng.randint(8, 60)])
+            sw, sh = 3 * dw, 3 * dh
+            if rng.random() < 0.06: sh += 1
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])
@@ -81,7 +86,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

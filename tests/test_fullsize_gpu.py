@@ -207,6 +207,25 @@ def test_4k_to_1080p_transcode(gpu, orc, fmt, which, monkeypatch):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("which", ["strip", "generic"])
+def test_4k_to_720p_transcode(gpu, orc, fmt, which, monkeypatch):
+    """the 3:1 ladder step at full size on BOTH kernels that serve it (the 3:1 strip walker by default, the generic plane
+    scaler for the frames it declines): every plane against the oracle"""
+    if which == "generic":
+        monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_SCALE_NO_STRIP", raising=False)
+    sw, sh, dw, dh = 3840, 2160, 1280, 720
+    src = synth_planes(orc, fmt, sw, sh, seed=43)
+    want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == "scale_yuv3x1_kernel" if which == "strip" else k.startswith("scale_yuv_kernel"), k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 def test_4k_rotate_17_degrees(gpu, orc):
     import math
     w, h, bpp = 3840, 2160, 3
