@@ -64,6 +64,8 @@ __device__ __forceinline__ int d3_dot2(int packed_ab, int packed_cd, int acc)   
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, packed_ab), __builtin_bit_cast(short2v, packed_cd), acc, true);
 }
 __device__ __forceinline__ unsigned d3_rep(unsigned v, unsigned sel) { return __builtin_amdgcn_perm(v, v, sel); }
+// cond ? a : b on VALUES (see u2_blend in k_scale_yuv1x2.hip: a ?: on members of an in-memory struct selects an ADDRESS into scratch memory)
+__device__ __forceinline__ int32_t d3_blend(bool cond, int32_t a, int32_t b) { return b ^ ((a ^ b) & -(int32_t)cond); }
 
 struct D3Plane {
     const uint8_t *src; uint8_t *dst;
@@ -97,8 +99,14 @@ __device__ __forceinline__ int d3_hsum(const D3Plane &P, const unsigned (&d)[5])
 // The walk shared by both plane kinds.  NW = dwords of a lane's window per row; LOAD(row, d, edge_c) / HROW(d, edge_c, s[4]) /
 // STORE(y, w[4]) are the plane kind's.  Step s of a segment handles the source rows 3 y0 - 4 + 3 s + {0, 1, 2}; from step 3 on
 // output row y0 + s - 3 leaves.  PH = s mod 4 names the ring slots (PH * 3 + r) the step writes, PAR = s & 1 its load buffers.
+//
+// Odd segments walk UPWARD (up != 0): the same steps over the rows in descending order, the coefficient pairs taken in reverse with
+// their halves swapped (a pair is (row before | row now), and "before" is then the row below), output rows counted down.  Segment s
+// (down) and s + 1 (up) then reach their common boundary at the same time — both at the end of their walk — and s + 1 and s + 2 both
+// START at theirs: the 9 rows either side of a boundary that both segments need are read twice within a few microseconds on the
+// same XCD (L2 hits) instead of once at the start of one wave and once at the end of another (two HBM reads).
 template <int NW, typename Load, typename HRow, typename Store>
-__device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool edgeWave, Load &&load, HRow &&hrow, Store &&store)
+__device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool edgeWave, int up, Load &&load, HRow &&hrow, Store &&store)
 {
     int ring[12][4], prev[4];
 #pragma unroll
@@ -117,6 +125,14 @@ __device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool
     const int nStart = 3 * y0 - 4;
     const int nLast = 3 * (y0 + nOut - 1) + 7;                  // the last source row of the segment (before clamping into the plane)
     const int nSteps = nOut + 3;
+    const int rowBase = up ? nLast : nStart, rowDir = up ? -1 : 1, yBase = up ? y0 + nOut - 1 : y0;
+    auto rowOf = [&](int i) { return min(max(rowBase + rowDir * i, nStart), nLast); };     // i = 3 * step + r, never outside the segment's rows
+    int32_t vv[6];                                              // wave-uniform: scalar registers
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t rev = (uint32_t)P.v[5 - k];
+        vv[k] = d3_blend(up != 0, (int32_t)((rev >> 16) | (rev << 16)), P.v[k]);
+    }
 
     auto body = [&](const int s, auto ph_c, auto edge_c) {
         constexpr int PH = decltype(ph_c)::value, PAR = PH & 1;
@@ -127,7 +143,7 @@ __device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool
             // rolling prefetch: the registers just consumed receive the same row of step s + 2.  Unconditional (a branch here costs
             // the in-order vmcnt its slack: 7.2 instead of 4.8 us per frame on the UV plane), but never past the segment's last row:
             // the loads of the last two steps re-read that row (cache hits) instead of 6 rows of the neighbour's (HBM traffic)
-            load(min(nStart + 3 * (s + 2) + r, nLast), buf[PAR][r], edge_c);
+            load(rowOf(3 * (s + 2) + r), buf[PAR][r], edge_c);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int cur = hs[q] >> 7;                     // hScale8To15_c: min(val >> 7, 32767) — the pack saturates
@@ -142,22 +158,22 @@ __device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool
             unsigned w[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                int acc = d3_dot2(ring[A][q], P.v[0], P.rnd);
-                acc = d3_dot2(ring[B][q], P.v[1], acc);
-                acc = d3_dot2(ring[C][q], P.v[2], acc);
-                acc = d3_dot2(ring[D][q], P.v[3], acc);
-                acc = d3_dot2(ring[E][q], P.v[4], acc);
-                acc = d3_dot2(ring[F][q], P.v[5], acc);
+                int acc = d3_dot2(ring[A][q], vv[0], P.rnd);
+                acc = d3_dot2(ring[B][q], vv[1], acc);
+                acc = d3_dot2(ring[C][q], vv[2], acc);
+                acc = d3_dot2(ring[D][q], vv[3], acc);
+                acc = d3_dot2(ring[E][q], vv[4], acc);
+                acc = d3_dot2(ring[F][q], vv[5], acc);
                 w[q] = (unsigned)clip_u8_shr(acc, 19);
             }
-            store(y0 + s - 3, w);
+            store(yBase + rowDir * (s - 3), w);
         }
     };
     auto run = [&](auto edge_c) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) load(nStart + r, buf[0][r], edge_c);
+        for (int r = 0; r < 3; r++) load(rowOf(r), buf[0][r], edge_c);
 #pragma unroll
-        for (int r = 0; r < 3; r++) load(nStart + 3 + r, buf[1][r], edge_c);
+        for (int r = 0; r < 3; r++) load(rowOf(3 + r), buf[1][r], edge_c);
         for (int s0 = 0; s0 < nSteps; s0 += 4) {
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -172,7 +188,7 @@ __device__ __forceinline__ void d3_walk(const D3Plane &P, int y0, int nOut, bool
 }
 
 // ---- one single-channel plane: the output rows [y0, y0 + nOut) of the strip at X0 ------------------------------------------
-__device__ __forceinline__ void d3_walk_plane(const D3Plane &P, int X0, int y0, int nOut, int lane)
+__device__ __forceinline__ void d3_walk_plane(const D3Plane &P, int X0, int y0, int nOut, int up, int lane)
 {
     const int xo = X0 + 4 * lane;
     const bool active = xo < P.dstW;
@@ -209,11 +225,11 @@ __device__ __forceinline__ void d3_walk_plane(const D3Plane &P, int X0, int y0, 
     auto store = [&](int y, const unsigned (&w)[4]) {
         if (active) d3_st4(P.dst, (unsigned)y * (unsigned)P.ds + (unsigned)xo, w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24));
     };
-    d3_walk<5>(P, y0, nOut, edgeWave, load, hrow, store);
+    d3_walk<5>(P, y0, nOut, edgeWave, up, load, hrow, store);
 }
 
 // ---- NV12's interleaved UV plane: a lane makes 2 UV output positions (4 bytes) from 15 source positions (8 dwords) ------------
-__device__ __forceinline__ void d3_walk_uv(const D3Plane &P, int X0, int y0, int nOut, int lane)
+__device__ __forceinline__ void d3_walk_uv(const D3Plane &P, int X0, int y0, int nOut, int up, int lane)
 {
     const int co = X0 + 2 * lane;
     const bool active = co < P.dstW;
@@ -259,7 +275,7 @@ __device__ __forceinline__ void d3_walk_uv(const D3Plane &P, int X0, int y0, int
     auto store = [&](int y, const unsigned (&w)[4]) {
         if (active) d3_st4(P.dst, (unsigned)y * (unsigned)P.ds + 2u * (unsigned)co, w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24));
     };
-    d3_walk<8>(P, y0, nOut, edgeWave, load, hrow, store);
+    d3_walk<8>(P, y0, nOut, edgeWave, up, load, hrow, store);
 }
 
 __device__ __forceinline__ D3Plane d3_plane(const uint8_t *src, uint8_t *dst, int ss, int ds, int dstW, int srcW, int srcH,
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) D3_FOUR_WAVES void scale_yuv3x1_kernel(Yuv3x1A
         const int X0 = (unit - seg * a.nsgL) * D3_STRIP;
         const int y0 = seg * a.segRowsL;
         const D3Plane P = d3_plane(fr.y[f], fr.dst[f], a.ys, a.ds, a.dstW, 3 * a.dstW, 3 * a.dstH, a.hL, a.vL, a.lr);
-        d3_walk_plane(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
+        d3_walk_plane(P, X0, y0, min(a.segRowsL, a.dstH - y0), a.updown & seg & 1, lane);
         return;
     }
     int unit = (lin - a.nblkL) * 4 + wave;
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(256) D3_FOUR_WAVES void scale_yuv3x1_kernel(Yuv3x1A
         const int X0 = (unit - seg * a.nsgC) * D3_STRIP_UV;
         const int y0 = seg * a.segRowsC;
         const D3Plane P = d3_plane(fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrDstW, 3 * a.chrDstW, 3 * a.chrDstH, a.hC, a.vC, a.cr);
-        d3_walk_uv(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        d3_walk_uv(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), a.updown & seg & 1, lane);
     } else {
         if (unit >= 2 * per) return;
         const int pl = __builtin_amdgcn_readfirstlane(unit >= per ? 1 : 0);
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(256) D3_FOUR_WAVES void scale_yuv3x1_kernel(Yuv3x1A
         const int y0 = seg * a.segRowsC;
         const D3Plane P = d3_plane(pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
                                    a.chrDstW, 3 * a.chrDstW, 3 * a.chrDstH, a.hC, a.vC, a.cr);
-        d3_walk_plane(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        d3_walk_plane(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), a.updown & seg & 1, lane);
     }
 }
 
@@ -363,6 +379,8 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
         seg = (int)std::min(40L, std::max(6L, (rows + 6143) / 6144));
     }
+    const char *ud = getenv("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
+    a.updown = !(ud && !atoi(ud));
     a.segRowsL = seg; a.segRowsC = seg;                          // the same walk length on every plane: equal wave lifetimes, half the chroma warm-up
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
     a.nsegC = (a.chrDstH + a.segRowsC - 1) / a.segRowsC;

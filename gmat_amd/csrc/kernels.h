@@ -323,6 +323,7 @@ struct Yuv3x1Args {
     int32_t hL[6], hC[6], vL[6], vC[6];
     int lr, cr;
     int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (nsg = strips per row here)
+    int updown;                                  // 1: odd segments walk upward (shared boundary rows meet in L2)
 };
 int  yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x1Tables &t);
 int  launch_scale_yuv3x1(const Yuv3x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);

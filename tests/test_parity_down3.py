@@ -72,12 +72,20 @@ def test_down3_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_d3, fmt, geo
         assert k.startswith("scale_yuv_kernel"), k
 
 
+@pytest.mark.parametrize("updown", ["alternating", "all-down"])
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 7, 8, 13, 64])
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
-def test_down3_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
+def test_down3_segmentation_does_not_change_the_result(dev, orc, strip_rows, monkeypatch, fmt, rows, updown):
     """segments of `rows` output rows (on every plane): the three warm-up steps of every segment re-create the ring of
-    row pairs its first output row needs; every residue of the segment start modulo the ring's four steps is exercised"""
+    row pairs its first output row needs; every residue of the segment start modulo the ring's four steps is exercised.
+    Odd segments walk UPWARD by default (reversed row order, coefficient pairs reversed with swapped halves, so that both
+    neighbours of a boundary read its rows at the same time); GMAT_STRIP_UPDOWN=0 makes every segment walk downward — the
+    bytes must not depend on it"""
     strip_rows(rows)
+    if updown == "all-down":
+        monkeypatch.setenv("GMAT_STRIP_UPDOWN", "0")
+    else:
+        monkeypatch.delenv("GMAT_STRIP_UPDOWN", raising=False)
     assert _check(dev, orc, fmt, 264, 26) == D3
 
 
