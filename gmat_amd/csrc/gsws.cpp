@@ -607,7 +607,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             if (bpp == 4 ? ((((uintptr_t)dp | (uintptr_t)dstStride[0]) & 15) != 0) : !al4(dp, dstStride[0])) return 0;
         }
         const Rgb2sArgs ra = make_rgb2s_args(c, srcStride[0], dstStride[0], c->srcFormat == GMAT_PIX_FMT_BGR24);
-        c->lastKernel = "scale_rgb2s_kernel";
+        c->lastKernel = rgb2s_kernel_name();
         for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
             Yuv2xFrames fr;
             const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -657,7 +657,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             if ((r = launch_scale_rgb2s(ra, stream, &sc, m)) < 0) return r;
             c->lastLaunchFrames = m;
         }
-        c->lastKernel = "scale_rgb2s_kernel";
+        c->lastKernel = rgb2s_kernel_name();
         return 1;
     }
     if (c->mode != MODE_SCALE || !(is_plane_src(c->srcFormat) || c->rgbViaPlanes) || c->fused != 2) return 0;
@@ -1292,7 +1292,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             Yuv2xFrames one;
             std::memset(&one, 0, sizeof(one));
             one.y[0] = a.src0; one.dst[0] = a.dst;
-            c->lastKernel = "scale_rgb2s_kernel";
+            c->lastKernel = rgb2s_kernel_name();
             r = launch_scale_rgb2s(ra, c->stream, &one, 1);
             break;
         }

@@ -25,8 +25,11 @@ constexpr int R2_STRIP = 256;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned r2_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ uint4 r2_ld16(const uint8_t *p) { const r2_u32x4 v = *reinterpret_cast<const r2_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+typedef unsigned r2_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ uint2 r2_ld8(const uint8_t *p) { const r2_u32x2 v = *reinterpret_cast<const r2_u32x2 *>(p); return make_uint2(v.x, v.y); }
 #else
 static inline uint4 r2_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
+static inline uint2 r2_ld8(const uint8_t *p) { uint2 v; std::memcpy(&v, p, 8); return v; }
 #endif
 
 __device__ __forceinline__ int r2_dot2(int ab, int cd, int acc)
@@ -211,6 +214,188 @@ __global__ __launch_bounds__(256) void scale_rgb2s_kernel(Rgb2sArgs a, Yuv2xFram
 }
 
 // ---------------------------------------------------------------------------------------------
+// scale_rgb2h_kernel: the same arithmetic with the converted samples SHARED between neighbouring lanes.
+// In the kernel above a lane loads and converts its whole 14-pixel window (48 bytes, rgb24ToY_c on 14 pixels) although only 8
+// pixels are its own: its neighbours convert the other 6 again.  Here a lane loads its own 8 pixels (24 bytes: 2 loads per row
+// instead of 3, half the row buffers), converts them once, packs the 14-bit Y samples as the odd-aligned pairs (1,2) (3,4) (5,6)
+// plus (0 | 7), and takes the three samples either side of its window from the lanes beside it with four DPP wave shifts.
+// Lanes 0 and 63 only provide: a wave makes 62 x 4 = 248 output columns.  A lane's 8 pixels are entirely inside or entirely
+// outside the frame (widths are multiples of 8), so edge replication is "a lane outside presents the edge pixel's sample".
+// The chroma plane (pixel pairs, one tap) needs no neighbours.
+constexpr int H2_OUT = 248;
+
+struct H2Row { unsigned d[6]; };               // the lane's own 8 pixels = 24 bytes of one source row
+
+__device__ __forceinline__ int h2_from_left(int v)  { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }   // lane - 1 (wave_shr:1)
+__device__ __forceinline__ int h2_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }   // lane + 1 (wave_shl:1)
+
+template <int DST>
+__global__ __launch_bounds__(256) void scale_rgb2h_kernel(Rgb2sArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = a.nseg * a.nsg;
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= nblk) return;
+    const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsg);
+    const int X0 = ((lin - seg * a.nsg) * 4 + wave) * H2_OUT;
+    if (X0 >= a.dstW) return;
+    const int y0 = seg * a.segRows;
+    const int nOut = min(a.segRows, a.dstH - y0);
+    const int nIter = nOut + 3;
+    const uint8_t *ps = fr.y[blockIdx.y];
+    uint8_t *pd = fr.dst[blockIdx.y];
+
+    const int xo = X0 + 4 * (lane - 1);                          // the lane's 4 output columns; lane 0 / 63: its neighbour's halo
+    const bool stores = lane >= 1 && lane <= 62 && xo < a.dstW;
+    const bool outL = xo < 0, outR = xo >= a.dstW;               // own pixels 2 xo .. 2 xo + 7 lie outside the frame
+    const bool edgeWave = X0 == 0 || X0 + H2_OUT + 4 > a.dstW;   // wave-uniform: the wave holds an outside lane
+    const unsigned uoff = 6u * (unsigned)min(max(xo, 0), a.dstW - 4);     // outside lanes load the frame's first / last 8 pixels
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    auto load_row = [&](int r, H2Row &R) {
+        const unsigned ro = (unsigned)min(max(r, 0), a.srcH - 1) * (unsigned)a.ss + uoff;
+        const uint4 v0 = r2_ld16(ps + ro);
+        const uint2 v1 = r2_ld8(ps + (unsigned)(ro + 16));
+        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+    };
+
+    // One source row: 14-bit Y of the lane's 8 pixels -> with the neighbours' samples 7 odd-aligned pairs -> 4 horizontal sums;
+    // 14-bit U / V of the lane's 4 pixel pairs.
+    auto convert_row = [&](const H2Row &R, auto edge_c, int (&hs)[4], int (&u14)[4], int (&v14)[4]) {
+        int y[8], fs[8], th[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int o = 3 * i, d = o >> 2, b = o & 3;
+            const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
+            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+            // rgb24ToY_c: (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+            y[i] = r2_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+        }
+        if constexpr (decltype(edge_c)::value) {                  // a lane outside the frame: every sample is the edge pixel's
+            const int ye = outL ? y[0] : y[7];
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = (outL || outR) ? ye : y[i];
+        }
+        const int A0 = (int)((unsigned)y[1] | ((unsigned)y[2] << 16)), A1 = (int)((unsigned)y[3] | ((unsigned)y[4] << 16)),
+                  A2 = (int)((unsigned)y[5] | ((unsigned)y[6] << 16)), B = (int)((unsigned)y[0] | ((unsigned)y[7] << 16));     // 0 <= y < 2^15
+        const int lA2 = h2_from_left(A2), lB = h2_from_left(B), rA0 = h2_from_right(A0), rB = h2_from_right(B);
+        int p[7];
+        p[0] = lA2;                                                                      // the left lane's samples 5, 6
+        p[1] = (int)__builtin_amdgcn_perm((unsigned)B, (unsigned)lB, 0x05040302u);        // its sample 7 | own sample 0
+        p[2] = A0; p[3] = A1; p[4] = A2;
+        p[5] = (int)__builtin_amdgcn_perm((unsigned)rB, (unsigned)B, 0x05040302u);        // own sample 7 | the right lane's sample 0
+        p[6] = rA0;                                                                      // the right lane's samples 1, 2
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            hs[j] = r2_dot2(p[j + 3], a.hL[3], r2_dot2(p[j + 2], a.hL[2], r2_dot2(p[j + 1], a.hL[1], r2_dot2(p[j], a.hL[0], 0))));
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // rgb24ToUV_half_c on the sum of pixels 2c, 2c + 1 of the lane: (ru*r + gu*g + bu*b + (256 << 15) + (1 << 9)) >> 10
+            const int fsum = fs[2 * c] + fs[2 * c + 1];             // two 9-bit sums in the halves: no carry across
+            const int tsum = th[2 * c] + th[2 * c + 1];
+            u14[c] = r2_dot2(fsum, a.cU01, m24(tsum, a.cU2) + ((256 << 15) + (1 << 9))) >> 10;
+            v14[c] = r2_dot2(fsum, a.cV01, m24(tsum, a.cV2) + ((256 << 15) + (1 << 9))) >> 10;
+        }
+    };
+
+    int hwY[4][4], hwU[4][4], hwV[4][4];                          // [slot][output]: (row 2m-1 | row 2m << 16), 15-bit lines
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hwY[s][j] = hwU[s][j] = hwV[s][j] = 0;
+
+    H2Row bufA[2], bufB[2];                                       // ping-pong: rows 2m-1 and 2m of the current / next pair
+    load_row(2 * (y0 - 1) - 1, bufA[0]);
+    load_row(2 * (y0 - 1), bufB[0]);
+
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const H2Row ra = bufA[SLOT & 1], rb = bufB[SLOT & 1];
+        if (j + 1 < nIter) {
+            const int m = y0 + j;                                   // pair y0 - 1 + (j + 1)
+            load_row(2 * m - 1, bufA[(SLOT + 1) & 1]);
+            load_row(2 * m, bufB[(SLOT + 1) & 1]);
+        }
+        {
+            int sa[4], sb[4], ua[4], va[4], ub[4], vb[4];
+            convert_row(ra, edge_c, sa, ua, va);
+            convert_row(rb, edge_c, sb, ub, vb);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // hScale16To15_c: min(val >> 13, 32767)
+                hwY[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 13, sb[q] >> 13));
+                // the one-tap chroma filter: min((u * 16384) >> 13, 32767) = min(2u, 32767), u < 2^15
+                hwU[SLOT][q] = (int)((unsigned)min(2 * ua[q], 32767) | ((unsigned)min(2 * ub[q], 32767) << 16));
+                hwV[SLOT][q] = (int)((unsigned)min(2 * va[q], 32767) | ((unsigned)min(2 * vb[q], 32767) << 16));
+            }
+        }
+        if (j >= 3) {
+            const int yo = y0 + j - 3;
+            unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int Y = a.rnd, U = a.rnd - (128 << 19), V = a.rnd - (128 << 19);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    Y = r2_dot2(hwY[(SLOT + 1 + k) & 3][q], a.vL[k], Y);
+                    U = r2_dot2(hwU[(SLOT + 1 + k) & 3][q], a.vL[k], U);
+                    V = r2_dot2(hwV[(SLOT + 1 + k) & 3][q], a.vL[k], V);
+                }
+                Y >>= 10; U >>= 10; V >>= 10;
+                // yuv2rgb_write_full (output.c:1886-1935), as in the kernel above
+                const int yy = m24(Y - a.y2r.y_offset, a.y2r.y_coeff) + (1 << 21);
+                const int R = yy + m24(V, a.y2r.v2r);
+                const int G = yy + m24(V, a.y2r.v2g) + m24(U, a.y2r.u2g);
+                const int Bc = yy + m24(U, a.y2r.u2b);
+                const unsigned r8 = (unsigned)min(max(R, 0), 0x3FFFFFFF) >> 6, g8 = (unsigned)min(max(G, 0), 0x3FFFFFFF) >> 6,
+                               b8 = (unsigned)min(max(Bc, 0), 0x3FFFFFFF) >> 6;     // the byte sits in bits 16..23
+                c0[q] = BGR ? b8 : r8; c1[q] = g8; c2[q] = BGR ? r8 : b8;
+            }
+            if (stores) {
+                uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+    #define R2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = R2_B2PAIR(c0[0], c1[0]) | (R2_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                    o4.y = R2_B2PAIR(c0[1], c1[1]) | (R2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                    o4.z = R2_B2PAIR(c0[2], c1[2]) | (R2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                    o4.w = R2_B2PAIR(c0[3], c1[3]) | (R2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d) = o4;
+                } else {
+                    uint3 o3;
+                    o3.x = R2_B2PAIR(c0[0], c1[0]) | (R2_B2PAIR(c2[0], c0[1]) << 16);
+                    o3.y = R2_B2PAIR(c1[1], c2[1]) | (R2_B2PAIR(c0[2], c1[2]) << 16);
+                    o3.z = R2_B2PAIR(c2[2], c0[3]) | (R2_B2PAIR(c1[3], c2[3]) << 16);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+    #undef R2_B2PAIR
+            }
+        }
+    };
+    auto run = [&](auto edge_c) {
+        for (int j0 = 0; j0 < nIter; j0 += 4) {
+            body(j0, std::integral_constant<int, 0>(), edge_c);
+            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// which of the two kernels a launch uses (GMAT_RGB2_SHARED=0: the one that converts the whole window per lane)
+static bool rgb2_shared() { const char *e = getenv("GMAT_RGB2_SHARED"); return !(e && !atoi(e)); }
+const char *rgb2s_kernel_name() { return rgb2_shared() ? "scale_rgb2h_kernel" : "scale_rgb2s_kernel"; }
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t)
@@ -242,7 +427,8 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     Rgb2sArgs a = a0;
     const char *segStr = getenv("GMAT_STRIP_ROWS");
     const int segEnv = segStr ? atoi(segStr) : 0;
-    const int nstrips = (a.dstW + R2_STRIP - 1) / R2_STRIP;
+    const bool shared = rgb2_shared();
+    const int nstrips = shared ? (a.dstW + H2_OUT - 1) / H2_OUT : (a.dstW + R2_STRIP - 1) / R2_STRIP;
     a.nsg = (nstrips + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
@@ -256,6 +442,17 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     const int nblk = a.nseg * a.nsg;
     const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
+    if (shared) {
+        switch (a.dstFormat) {
+        case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<0>), grid, block, 0, stream, a, fr); break;
+        case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<1>), grid, block, 0, stream, a, fr); break;
+        case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<2>), grid, block, 0, stream, a, fr); break;
+        case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<3>), grid, block, 0, stream, a, fr); break;
+        default: return GMAT_ERR(EINVAL);
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     switch (a.dstFormat) {
     case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<0>), grid, block, 0, stream, a, fr); break;
     case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<1>), grid, block, 0, stream, a, fr); break;

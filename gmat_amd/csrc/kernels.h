@@ -348,4 +348,5 @@ bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, i
 int  rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t);
 // frames->y[] = source frames, frames->dst[] = destination frames (grid.y = frame)
 int  launch_scale_rgb2s(const Rgb2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+const char *rgb2s_kernel_name();            // scale_rgb2h_kernel (converted samples shared between lanes) unless GMAT_RGB2_SHARED=0
 } // namespace gmat

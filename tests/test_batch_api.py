@@ -107,10 +107,10 @@ def test_batch_on_the_generic_plane_scaler(dev, orc, case):
 
 @pytest.mark.parametrize("case", [("rgb24", "rgb24"), ("bgr24", "bgra")])
 def test_batch_on_the_rgb_strip_kernel(dev, orc, case):
-    """packed RGB at exactly 2:1 batches too: scale_rgb2s_kernel with grid.y = frame"""
+    """packed RGB at exactly 2:1 batches too: scale_rgb2h_kernel with grid.y = frame"""
     sf, df = case
     k = _run_batch(dev, orc, sf, df, 264, 40, 132, 20, nframes=5, nstreams=2, align=16)
-    assert k == "scale_rgb2s_kernel", k
+    assert k == "scale_rgb2h_kernel", k
     assert _run_batch.last_frames == 2
 
 
@@ -135,7 +135,7 @@ def test_batch_two_kernel_form(dev, orc, src_fmt):
     r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
                                  C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
                                  C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
-    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n and lib.gmat_sws_lastKernel(c) == b"scale_rgb2s_kernel"
+    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n and lib.gmat_sws_lastKernel(c) == b"scale_rgb2h_kernel"
     lib.gmat_stream_sync(st)
     for f in range(n):
         assert (ddst[f][0].download() == orc.chained(srcs[f], sw, sh, src_fmt, dw, dh, "rgb24")[0]).all(), f

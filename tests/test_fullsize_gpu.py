@@ -162,7 +162,7 @@ def test_8k_rgb24_to_4k_bands(gpu, orc):
     src = synth_planes(orc, "rgb24", sw, sh, seed=31)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, "rgb24", dw, dh, "bgra", dst_align=256)
-    assert k == "scale_rgb2s_kernel" and (pads[0] == 0xCD).all()
+    assert k == "scale_rgb2h_kernel" and (pads[0] == 0xCD).all()
     for y0 in (0, 1072, dh - 32):
         want = _oracle_rows(orc, src, sw, sh, "rgb24", dw, dh, "bgra", y0, y0 + 32)[0]
         assert (got[0][y0:y0 + 32] == want[y0:y0 + 32]).all(), y0

@@ -34,14 +34,29 @@ def test_rgb24_bicubic(dev, orc, kern, geom):
     sw, sh, dw, dh = geom
     k = _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
     strip = kern == "scale_yuv2s_kernel" and sw == 2 * dw and sh == 2 * dh and sw % 8 == 0 and sw >= 32 and dh >= 8
-    assert k.startswith("scale_rgb2s_kernel" if strip else "scale_rgb_kernel"), k
+    assert k.startswith("scale_rgb2h_kernel" if strip else "scale_rgb_kernel"), k
 
 
+@pytest.fixture(params=["shared", "per-lane"])
+def rgb2_kernel(request, monkeypatch):
+    """the two strip kernels of k_scale_rgb2s.hip: scale_rgb2h_kernel (default: every lane converts its own 8 pixels, the window's
+    other samples come from the neighbouring lanes by DPP) and scale_rgb2s_kernel (GMAT_RGB2_SHARED=0: every lane converts its
+    whole 14-pixel window)"""
+    if request.param == "per-lane":
+        monkeypatch.setenv("GMAT_RGB2_SHARED", "0")
+        return "scale_rgb2s_kernel"
+    monkeypatch.delenv("GMAT_RGB2_SHARED", raising=False)
+    return "scale_rgb2h_kernel"
+
+
+# (srcW, srcH, alignment): one partial wave, exactly the 248 / 256 output columns of one wave of either kernel and one group more,
+# several workgroups of strips, widths that are multiples of 8 only
 @pytest.mark.parametrize("src_fmt,dst_fmt", [("rgb24", "rgb24"), ("bgr24", "rgb24"), ("rgb24", "bgr24"), ("bgr24", "bgra"), ("rgb24", "rgba")])
-@pytest.mark.parametrize("geom", [(32, 16, 4), (64, 32, 16), (512, 40, 64), (520, 24, 4), (1032, 36, 8), (2056, 20, 4), (2560, 18, 256)])
-def test_rgb_strip_kernel_bit_exact(dev, orc, monkeypatch, src_fmt, dst_fmt, geom):
+@pytest.mark.parametrize("geom", [(32, 16, 4), (64, 32, 16), (496, 18, 4), (504, 18, 4), (512, 40, 64), (520, 24, 4), (1032, 36, 8), (2056, 20, 4),
+                                  (2560, 18, 256)])
+def test_rgb_strip_kernel_bit_exact(dev, orc, monkeypatch, rgb2_kernel, src_fmt, dst_fmt, geom):
     """k_scale_rgb2s.hip: partial strips, several strip groups, widths that are multiples of 8 only, frame edges
-    (replicated pixels instead of libswscale's folded coefficient rows), both channel orders at both ends"""
+    (replicated pixels instead of libswscale's folded coefficient rows), both channel orders at both ends — on both kernels"""
     sw, sh, align = geom
     if dst_fmt in ("rgba", "bgra"):
         align = max(align, 16)
@@ -51,7 +66,7 @@ def test_rgb_strip_kernel_bit_exact(dev, orc, monkeypatch, src_fmt, dst_fmt, geo
         else:
             monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
         k = _check(dev, orc, src_fmt, sw, sh, sw // 2, sh // 2, dst_fmt, SWS["bicubic"], align=align)
-        assert k == "scale_rgb2s_kernel", k
+        assert k == rgb2_kernel, k
 
 
 @pytest.mark.parametrize("flags", ["bilinear", "point", "area", "gauss"])
