@@ -563,6 +563,30 @@ static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dst
     return ra;
 }
 
+// the fused convert-then-scale form on the same kernel: a YUV 4:2:0 source converted lane by lane with the FIRST context's closed-form
+// constants (c->y2r: base, off*, c*) — the output stage fields (y_coeff .. u2b) stay those of the scaler's BT.601 model
+static Rgb2sArgs make_rgb2h_yuv_args(const GmatSwsContext *c, const int srcStride[], int dstStride)
+{
+    Rgb2sArgs ra = make_rgb2s_args(c, srcStride[0], dstStride, false);
+    const bool nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    ra.srcKind = nv12 ? 1 : 2; ra.us = srcStride[1]; ra.vs = nv12 ? 0 : srcStride[2];
+    Yuv2RgbConsts k = c->y2r;
+    k.y_coeff = c->args.y2r.y_coeff; k.y_offset = c->args.y2r.y_offset;
+    k.v2r = c->args.y2r.v2r; k.v2g = c->args.y2r.v2g; k.u2g = c->args.y2r.u2g; k.u2b = c->args.y2r.u2b;
+    ra.y2r = k;
+    return ra;
+}
+
+// dword loads of every plane (the lane offsets are multiples of 8 / 4 bytes), the packed-RGB store side as the RGB source form
+static bool rgb2h_yuv_eligible(const GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], const uint8_t *dst, int dstStride)
+{
+    if (!c->r2s.ok || !rgb2h_takes_yuv() || c->fused != 1 || !is_yuv420(c->srcFormat) || !is_packed_rgb(c->dstFormat)) return false;
+    const bool nv12 = c->srcFormat == GMAT_PIX_FMT_NV12;
+    if (!src[0] || !src[1] || (!nv12 && !src[2]) || !dst) return false;
+    if (!al4(src[0], srcStride[0]) || !al4(src[1], srcStride[1]) || (!nv12 && !al4(src[2], srcStride[2]))) return false;
+    return bytes_per_pixel(c->dstFormat) == 4 ? ((((uintptr_t)dst | (uintptr_t)dstStride) & 15) == 0) : al4(dst, dstStride);
+}
+
 namespace gmat {
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
@@ -613,6 +637,28 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             const int m = std::min(kYuv2xMaxFrames, n - f0);
             std::memset(&fr, 0, sizeof(fr));
             for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            int r = launch_scale_rgb2s(ra, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
+    if (c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 1 && is_packed_rgb(c->dstFormat)) {
+        // the fused convert-then-scale form at exactly 2:1: one launch of scale_rgb2h_kernel<.., yuv> per 32 frames
+        if (ensure_scaler(c) < 0 || c->fused != 1 || c->prof) return 0;
+        for (int f = 0; f < n; f++)
+            if (!rgb2h_yuv_eligible(c, src_planes + 4 * f, srcStride, dst_planes[4 * f], dstStride[0])) return 0;
+        const Rgb2sArgs ra = make_rgb2h_yuv_args(c, srcStride, dstStride[0]);
+        const bool planar = c->srcFormat == GMAT_PIX_FMT_YUV420P;
+        c->lastKernel = "scale_rgb2h_kernel<yuv>";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = planar ? sp[2] : nullptr; fr.dst[i] = dst_planes[4 * (f0 + i)];
+            }
             int r = launch_scale_rgb2s(ra, stream, &fr, m);
             if (r < 0) return r;
             c->lastLaunchFrames = m;
@@ -1285,6 +1331,16 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             k.y_coeff = c->args.y2r.y_coeff; k.y_offset = c->args.y2r.y_offset;
             k.v2r = c->args.y2r.v2r; k.v2g = c->args.y2r.v2g; k.u2g = c->args.y2r.u2g; k.u2b = c->args.y2r.u2b;
             a.y2r = k;
+        }
+        if (a.srcKind == 1 && !c->prof && rgb2h_yuv_eligible(c, src, srcStride, dst[0], dstStride[0])) {
+            // the fused convert-then-scale form at exactly 2:1 on the strip kernel
+            const Rgb2sArgs ra = make_rgb2h_yuv_args(c, srcStride, dstStride[0]);
+            Yuv2xFrames one;
+            std::memset(&one, 0, sizeof(one));
+            one.y[0] = src[0]; one.u[0] = src[1]; one.v[0] = planarYuv ? src[2] : nullptr; one.dst[0] = dst[0];
+            c->lastKernel = "scale_rgb2h_kernel<yuv>";
+            r = launch_scale_rgb2s(ra, c->stream, &one, 1);
+            break;
         }
         if (a.srcKind == 0 && c->r2s.ok && a.srcAligned && a.dstAligned) {
             // exact 2:1 from packed RGB (also the second kernel of the two-kernel form): the strip-walking scaler

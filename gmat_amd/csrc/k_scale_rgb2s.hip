@@ -25,11 +25,13 @@ constexpr int R2_STRIP = 256;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned r2_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ uint4 r2_ld16(const uint8_t *p) { const r2_u32x4 v = *reinterpret_cast<const r2_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ unsigned r2_ld4(const uint8_t *p) { return *reinterpret_cast<const unsigned *>(p); }
 typedef unsigned r2_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ uint2 r2_ld8(const uint8_t *p) { const r2_u32x2 v = *reinterpret_cast<const r2_u32x2 *>(p); return make_uint2(v.x, v.y); }
 #else
 static inline uint4 r2_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
 static inline uint2 r2_ld8(const uint8_t *p) { uint2 v; std::memcpy(&v, p, 8); return v; }
+static inline unsigned r2_ld4(const uint8_t *p) { unsigned v; std::memcpy(&v, p, 4); return v; }
 #endif
 
 __device__ __forceinline__ int r2_dot2(int ab, int cd, int acc)
@@ -224,18 +226,32 @@ __global__ __launch_bounds__(256) void scale_rgb2s_kernel(Rgb2sArgs a, Yuv2xFram
 // The chroma plane (pixel pairs, one tap) needs no neighbours.
 constexpr int H2_OUT = 248;
 
-struct H2Row { unsigned d[6]; };               // the lane's own 8 pixels = 24 bytes of one source row
+struct H2Row { unsigned d[6]; };               // the lane's own 8 pixels of one source row: 24 bytes of packed RGB, or 8 Y + 8 chroma bytes
 
 __device__ __forceinline__ int h2_from_left(int v)  { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }   // lane - 1 (wave_shr:1)
 __device__ __forceinline__ int h2_from_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }   // lane + 1 (wave_shl:1)
 
-template <int DST>
+//
+// SRC: 0 packed rgb24 / bgr24; 1 NV12, 2 YUV420P — the FUSED convert-then-scale form: sws(YUV -> RGB24 at the source size, the
+// unscaled converter of yuv2rgb.c with its nearest chroma) followed by sws(RGB24 -> RGB at half the size), the reference GPU
+// back-end's order of operations (swscale_cuda.c:352-371), without the 25 MB RGB24 intermediate of a 4K frame: a lane converts its
+// own 8 pixels of a row with the first context's table arithmetic (px_math.h chroma_terms / luma_chan, the chroma terms from LDS
+// tables as in k_scale_yuv2s.hip) and hands (r | g << 16), b to the second context's input stage.
+template <int DST, int SRC>
 __global__ __launch_bounds__(256) void scale_rgb2h_kernel(Rgb2sArgs a, Yuv2xFrames fr)
 {
     constexpr bool BGR = (DST & 1) != 0;
     constexpr int BPP = DST >= 2 ? 4 : 3;
+    __shared__ int2 lutV[SRC ? 256 : 1], lutU[SRC ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (SRC != 0) {
+        // term_R = lutV[V].x, term_G = lutV[V].y + lutU[U].x, term_B = lutU[U].y; channel = byte 2 of clamp(term + Y * cy, 0, 0xFFFFFF)
+        const Yuv2RgbConsts &k = a.y2r;
+        lutV[tid] = make_int2(k.base + m24(k.offR + (m24(tid, k.crv) >> 16), k.cy), m24(m24(tid, k.cgv) >> 16, k.cy));
+        lutU[tid] = make_int2(k.base + m24(k.offG + (m24(tid, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(tid, k.cbu) >> 16), k.cy));
+        __syncthreads();
+    }
     const int nblk = a.nseg * a.nsg;
     int lin = blockIdx.x;
     if (a.xcdRemap) {
@@ -256,29 +272,65 @@ __global__ __launch_bounds__(256) void scale_rgb2h_kernel(Rgb2sArgs a, Yuv2xFram
     const bool stores = lane >= 1 && lane <= 62 && xo < a.dstW;
     const bool outL = xo < 0, outR = xo >= a.dstW;               // own pixels 2 xo .. 2 xo + 7 lie outside the frame
     const bool edgeWave = X0 == 0 || X0 + H2_OUT + 4 > a.dstW;   // wave-uniform: the wave holds an outside lane
-    const unsigned uoff = 6u * (unsigned)min(max(xo, 0), a.dstW - 4);     // outside lanes load the frame's first / last 8 pixels
+    const unsigned xl = (unsigned)min(max(xo, 0), a.dstW - 4);   // outside lanes load the frame's first / last 8 pixels
+    const unsigned uoff = 6u * xl;
     const unsigned dstOff = (unsigned)xo * BPP;
+    const uint8_t *pu = fr.u[blockIdx.y], *pv = fr.v[blockIdx.y];
 
     auto load_row = [&](int r, H2Row &R) {
-        const unsigned ro = (unsigned)min(max(r, 0), a.srcH - 1) * (unsigned)a.ss + uoff;
-        const uint4 v0 = r2_ld16(ps + ro);
-        const uint2 v1 = r2_ld8(ps + (unsigned)(ro + 16));
-        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+        const int rc = min(max(r, 0), a.srcH - 1);
+        if constexpr (SRC == 0) {
+            const unsigned ro = (unsigned)rc * (unsigned)a.ss + uoff;
+            const uint4 v0 = r2_ld16(ps + ro);
+            const uint2 v1 = r2_ld8(ps + (unsigned)(ro + 16));
+            R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+        } else {
+            // 8 luma bytes of the row, the 4 chroma samples of row rc / 2 under them (the unscaled converter's nearest chroma)
+            const uint2 yv = r2_ld8(ps + (unsigned)((unsigned)rc * (unsigned)a.ss + 2u * xl));
+            R.d[0] = yv.x; R.d[1] = yv.y; R.d[4] = R.d[5] = 0u;
+            if constexpr (SRC == 1) {
+                const uint2 c = r2_ld8(pu + (unsigned)((unsigned)(rc >> 1) * (unsigned)a.us + 2u * xl));
+                R.d[2] = c.x; R.d[3] = c.y;
+            } else {
+                R.d[2] = r2_ld4(pu + (unsigned)((unsigned)(rc >> 1) * (unsigned)a.us + xl));
+                R.d[3] = r2_ld4(pv + (unsigned)((unsigned)(rc >> 1) * (unsigned)a.vs + xl));
+            }
+        }
     };
 
     // One source row: 14-bit Y of the lane's 8 pixels -> with the neighbours' samples 7 odd-aligned pairs -> 4 horizontal sums;
     // 14-bit U / V of the lane's 4 pixel pairs.
     auto convert_row = [&](const H2Row &R, auto edge_c, int (&hs)[4], int (&u14)[4], int (&v14)[4]) {
         int y[8], fs[8], th[8];
+        if constexpr (SRC == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int o = 3 * i, d = o >> 2, b = o & 3;
-            const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
-            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
-            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
-            // rgb24ToY_c: (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
-            y[i] = r2_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+            for (int i = 0; i < 8; i++) {
+                const int o = 3 * i, d = o >> 2, b = o & 3;
+                const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
+                fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+                th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {                           // chroma sample c covers the lane's pixels 2c, 2c + 1
+                unsigned U, V;
+                if constexpr (SRC == 1) { const unsigned w = R.d[2 + (c >> 1)]; U = (w >> (16 * (c & 1))) & 0xFFu; V = (w >> (16 * (c & 1) + 8)) & 0xFFu; }
+                else                    { U = (R.d[2] >> (8 * c)) & 0xFFu; V = (R.d[3] >> (8 * c)) & 0xFFu; }
+                const int2 tv = lutV[V], tu = lutU[U];
+                const int tr = tv.x, tg = tv.y + tu.x, tb = tu.y;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int i = 2 * c + h;
+                    const int ycy = m24((int)((R.d[i >> 2] >> (8 * (i & 3))) & 0xFFu), a.y2r.cy);
+                    const int r8 = luma_chan(tr, ycy), g8 = luma_chan(tg, ycy), b8 = luma_chan(tb, ycy);
+                    fs[i] = r8 | (g8 << 16);                        // the intermediate is RGB24: (r, g) and b, as the bytes would come
+                    th[i] = b8;
+                }
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 8; i++)   // rgb24ToY_c: (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+            y[i] = r2_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
         if constexpr (decltype(edge_c)::value) {                  // a lane outside the frame: every sample is the edge pixel's
             const int ye = outL ? y[0] : y[7];
 #pragma unroll
@@ -394,6 +446,7 @@ __global__ __launch_bounds__(256) void scale_rgb2h_kernel(Rgb2sArgs a, Yuv2xFram
 // which of the two kernels a launch uses (GMAT_RGB2_SHARED=0: the one that converts the whole window per lane)
 static bool rgb2_shared() { const char *e = getenv("GMAT_RGB2_SHARED"); return !(e && !atoi(e)); }
 const char *rgb2s_kernel_name() { return rgb2_shared() ? "scale_rgb2h_kernel" : "scale_rgb2s_kernel"; }
+bool rgb2h_takes_yuv() { return rgb2_shared(); }
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -442,14 +495,19 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     const int nblk = a.nseg * a.nsg;
     const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
+    if (a.srcKind != 0 && !shared) return GMAT_ERR(EINVAL);      // the YUV front end exists in the shared-conversion kernel only
     if (shared) {
+#define GMAT_H2(D, S) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<D, S>), grid, block, 0, stream, a, fr)
+#define GMAT_H2_SRC(D) do { if (a.srcKind == 0) GMAT_H2(D, 0); else if (a.srcKind == 1) GMAT_H2(D, 1); else GMAT_H2(D, 2); } while (0)
         switch (a.dstFormat) {
-        case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<0>), grid, block, 0, stream, a, fr); break;
-        case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<1>), grid, block, 0, stream, a, fr); break;
-        case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<2>), grid, block, 0, stream, a, fr); break;
-        case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2h_kernel<3>), grid, block, 0, stream, a, fr); break;
+        case GMAT_PIX_FMT_RGB24: GMAT_H2_SRC(0); break;
+        case GMAT_PIX_FMT_BGR24: GMAT_H2_SRC(1); break;
+        case GMAT_PIX_FMT_RGBA:  GMAT_H2_SRC(2); break;
+        case GMAT_PIX_FMT_BGRA:  GMAT_H2_SRC(3); break;
         default: return GMAT_ERR(EINVAL);
         }
+#undef GMAT_H2_SRC
+#undef GMAT_H2
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -336,6 +336,7 @@ struct Rgb2sTables {
 };
 struct Rgb2sArgs {
     int ss, srcW, srcH, dstW, dstH, ds, dstFormat;
+    int srcKind, us, vs;                        // 0 packed RGB (ss = its stride); 1 NV12, 2 YUV420P: ss / us / vs = plane strides (scale_rgb2h_kernel only)
     int32_t hL[4], vL[4];
     int rnd;                                    // vertical accumulator start (1 << 9)
     int32_t cY01, cY2, cU01, cU2, cV01, cV2;    // rgb -> yuv coefficients as (first, second) int16 pair and third, in byte order
@@ -348,5 +349,6 @@ bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, i
 int  rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t);
 // frames->y[] = source frames, frames->dst[] = destination frames (grid.y = frame)
 int  launch_scale_rgb2s(const Rgb2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+bool rgb2h_takes_yuv();                     // the fused convert-then-scale form rides on scale_rgb2h_kernel<.., yuv>
 const char *rgb2s_kernel_name();            // scale_rgb2h_kernel (converted samples shared between lanes) unless GMAT_RGB2_SHARED=0
 } // namespace gmat

@@ -66,18 +66,21 @@ for case in range(n):
             if rng.random() < 0.06: sh += 1
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
+        # the fused convert-then-scale form (setFused(1): scale_rgb2h_kernel<yuv> at exactly 2:1, the tiled kernel otherwise)
+        fused = 1 if (df in RGBX and sf in ("nv12", "yuv420p") and cs is None and rng.random() < 0.35) else None
         align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (8, 0), (4, 0), (4, 4), (1, 1), (2, 2)])
         try:
             synth = synth_planes(orc, sf, sw, sh, seed=7000 + case)
             if sf == "yuv420p10le":
                 for pl in synth: pl.view("<u2")[...] &= 0x3FF        # valid input: 10 bits in the low end
             if (sf in ("p010le", "yuv420p10le") or df in ("p010le", "yuv420p10le")) and align < 2: align, extra = 2, 2   # 16-bit samples
-            want = orc.sws(synth, sw, sh, sf, dw, dh, df, SWS[algo], colorspace=cs)
+            want = (orc.chained(synth, sw, sh, sf, dw, dh, df, SWS[algo]) if fused else
+                    orc.sws(synth, sw, sh, sf, dw, dh, df, SWS[algo], colorspace=cs))
         except AssertionError:
             continue
         d = dev.upload_planes(synth, align, extra)
         try:
-            got, pads, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS[algo], dst_align=align, dst_extra=extra,
+            got, pads, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS[algo], dst_align=align, dst_extra=extra, fused=fused,
                                         colorspace=None if cs is None else (cs, 0))
         except AssertionError as e:
             if "-38" in str(e) or "getContext" in str(e):
@@ -86,7 +89,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_rgb2h")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

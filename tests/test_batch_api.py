@@ -114,15 +114,17 @@ def test_batch_on_the_rgb_strip_kernel(dev, orc, case):
     assert _run_batch.last_frames == 2
 
 
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
-def test_batch_two_kernel_form(dev, orc, src_fmt):
+def test_batch_two_kernel_form(dev, orc, src_fmt, fused):
     """setFused(0) — convert at source size, then scale (the reference's structure) — batches as two launches for n frames:
-    the converter into n context-owned RGB24 intermediates, then the strip scaler; bytes = the chained oracle's"""
+    the converter into n context-owned RGB24 intermediates, then the strip scaler; setFused(1) — the same arithmetic without the
+    intermediate — as ONE launch of scale_rgb2h_kernel<yuv>; bytes = the chained oracle's either way"""
     import ctypes as C
     lib = dev.lib
     sw, sh, dw, dh, n = 264, 40, 132, 20, 5
     c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[src_fmt], dw, dh, PIX_FMT["rgb24"], SWS["bicubic"], None)
-    assert c and lib.gmat_sws_setFused(c, 0) == 0
+    assert c and lib.gmat_sws_setFused(c, fused) == 0
     srcs = [synth_planes(orc, src_fmt, sw, sh, seed=800 + f) for f in range(n)]
     dsrc = [dev.upload_planes(s, 16) for s in srcs]
     ddst = [dev.planes_like("rgb24", dw, dh, 16) for _ in range(n)]
@@ -135,7 +137,8 @@ def test_batch_two_kernel_form(dev, orc, src_fmt):
     r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
                                  C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
                                  C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
-    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n and lib.gmat_sws_lastKernel(c) == b"scale_rgb2h_kernel"
+    assert r == n and lib.gmat_sws_lastLaunchFrames(c) == n
+    assert lib.gmat_sws_lastKernel(c) == (b"scale_rgb2h_kernel<yuv>" if fused else b"scale_rgb2h_kernel")
     lib.gmat_stream_sync(st)
     for f in range(n):
         assert (ddst[f][0].download() == orc.chained(srcs[f], sw, sh, src_fmt, dw, dh, "rgb24")[0]).all(), f

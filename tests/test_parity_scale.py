@@ -100,6 +100,57 @@ def test_yuv_to_scaled_rgb_chained_contract(dev, orc, src_fmt, fused, geom):
     sw, sh, dw, dh = geom
     k = _check(dev, orc, src_fmt, sw, sh, dw, dh, "rgb24", SWS["bicubic"], fused=fused)
     assert ("yuv" in k) == bool(fused)
+    if fused and fused_strip_takes(sw, sh, dw, dh):
+        assert k == "scale_rgb2h_kernel<yuv>", k
+
+
+def fused_strip_takes(sw, sh, dw, dh):
+    """the rule of the fused convert-then-scale form on the strip kernel restated (rgb2s_prepare's geometry part): exactly 2:1,
+    source width a multiple of 8 and >= 32, at least 8 output rows"""
+    return sw == 2 * dw and sh == 2 * dh and sw % 8 == 0 and sw >= 32 and dh >= 8
+
+
+@pytest.fixture(params=["strip", "tiled"])
+def fused_kernel(request, monkeypatch):
+    """the two kernels that serve setFused(1): scale_rgb2h_kernel<yuv> (exactly 2:1) and the tiled scale_rgb_kernel<..,yuv>
+    (everything else, and everything with GMAT_RGB2_SHARED=0)"""
+    if request.param == "tiled":
+        monkeypatch.setenv("GMAT_RGB2_SHARED", "0")
+    else:
+        monkeypatch.delenv("GMAT_RGB2_SHARED", raising=False)
+    return request.param
+
+
+# (srcW, srcH): one partial wave, exactly the 248 output columns of one wave and one group more, several workgroups, widths that are
+# multiples of 8 only, odd chroma row counts at the bottom (srcH = 2 * odd); then geometries the strip form declines
+FUSED_GEOMS = [(32, 16), (64, 36), (496, 20), (504, 18), (520, 28), (1032, 20), (2056, 18), (264, 54), (36, 16), (64, 14), (130, 50)]
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", [("nv12", "rgb24"), ("yuv420p", "rgb24"), ("nv12", "bgra"), ("yuv420p", "bgr24"), ("nv12", "rgba")])
+@pytest.mark.parametrize("geom", FUSED_GEOMS)
+def test_fused_convert_then_scale_on_both_kernels(dev, orc, monkeypatch, fused_kernel, src_fmt, dst_fmt, geom):
+    """setFused(1): sws(YUV -> RGB24 at the source size) then sws(RGB24 -> RGB at half the size) in one kernel, against the chained
+    oracle: frame edges (a lane outside the frame presents the edge pixel's sample), the chroma row under the clamped luma row at
+    the top and bottom, segment boundaries, both chroma layouts, both channel orders and 4-byte pixels at the output"""
+    sw, sh = geom
+    dw, dh = sw // 2, sh // 2
+    align = 16 if dst_fmt in ("rgba", "bgra") else 4
+    for rows in (None, 1, 5):
+        if rows is None:
+            monkeypatch.delenv("GMAT_STRIP_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+        k = _check(dev, orc, src_fmt, sw, sh, dw, dh, dst_fmt, SWS["bicubic"], fused=1, align=align)
+        if fused_kernel == "strip" and fused_strip_takes(sw, sh, dw, dh):
+            assert k == "scale_rgb2h_kernel<yuv>", k
+        else:
+            assert k.startswith("scale_rgb_kernel") and "yuv" in k, k
+
+
+def test_fused_strip_form_declines_misaligned_planes(dev, orc):
+    """dword loads on every plane: a destination or source off the 4-byte grid goes to the tiled kernel, same bytes"""
+    k = _check(dev, orc, "nv12", 264, 40, 132, 20, "rgb24", SWS["bicubic"], fused=1, align=1, extra=1)
+    assert k.startswith("scale_rgb_kernel") and "yuv" in k, k
 
 
 def test_product_filter_tables_match_oracle(dev, orc):
