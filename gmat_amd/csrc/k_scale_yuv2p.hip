@@ -702,7 +702,12 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
         // 32 at 1 / 4 / 32 frames per launch, profiles/r02f_yuv2p_lanczos_rows_sweep.txt)
         if (a.np == 6) seg = std::min(32, std::max(6, 2 * seg));
     }
-    a.segRowsL = seg; a.segRowsC = std::max(2, (seg + 1) / 2);
+    // Chroma segments: as many ROWS as luma's when both sides are 8-bit (half the chroma warm-up, equal wave lifetimes: nv12 4K ->
+    // 1080p 4.12 -> 3.98 us, yuv420p 4.19 -> 3.89 us per frame), half as many for the 16-bit forms (their chroma waves are the
+    // slowest of the launch and longer ones make its tail: p010 6.5 -> 7.5 us with equal rows).  GMAT_P2_CHROMA_SEG = 0 | 1 overrides.
+    const char *cse = getenv("GMAT_P2_CHROMA_SEG");
+    const bool equalC = cse ? atoi(cse) != 0 : (a.srcDepth == 8 && a.dstDepth == 8 && !a.cross);   // the cross-layout walker: 4.23 -> 4.99 us with equal rows
+    a.segRowsL = seg; a.segRowsC = equalC ? seg : std::max(2, (seg + 1) / 2);
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
     a.nsegC = (a.chrDstH + a.segRowsC - 1) / a.segRowsC;
     a.nblkL = a.nsegL * a.nsgL;

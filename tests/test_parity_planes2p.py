@@ -142,12 +142,18 @@ def test_unaligned_destination_rows_fall_back(dev, orc, fmt):
     assert _check(dev, orc, fmt, fmt, 528, 52, align=4, extra=4) == STRIP
 
 
+@pytest.mark.parametrize("chroma_seg", ["equal", "half"])
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 8, 13, 64, 1000])
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
-def test_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
-    """luma segments of `rows` rows, chroma segments of max(2, (rows + 1) / 2): the 3 warm-up row pairs of every segment
-    re-create the vertical window exactly, also where the last segment is short (26 luma / 13 chroma rows)"""
+def test_segmentation_does_not_change_the_result(dev, orc, strip_rows, monkeypatch, fmt, rows, chroma_seg):
+    """luma segments of `rows` rows; chroma segments of as many rows (the 8-bit rule) or of max(2, (rows + 1) / 2) (the 16-bit
+    rule, forced here by GMAT_P2_CHROMA_SEG=0): the 3 warm-up row pairs of every segment re-create the vertical window exactly,
+    also where the last segment is short (26 luma / 13 chroma rows)"""
     strip_rows(rows)
+    if chroma_seg == "half":
+        monkeypatch.setenv("GMAT_P2_CHROMA_SEG", "0")
+    else:
+        monkeypatch.delenv("GMAT_P2_CHROMA_SEG", raising=False)
     assert _check(dev, orc, fmt, fmt, 528, 52) == STRIP
 
 

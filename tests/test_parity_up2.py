@@ -71,13 +71,18 @@ def test_up2_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_up, fmt, geom)
         assert k.startswith("scale_yuv_kernel"), k
 
 
+@pytest.mark.parametrize("chroma_seg", ["equal", "half"])
 @pytest.mark.parametrize("rows", [2, 4, 6, 8, 10, 16, 26, 64, 1000])
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
-def test_up2_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
-    """segments of `rows` output rows (chroma: half, at least 4): the 3 warm-up source rows of every segment re-create the four
-    filtered rows its first output rows need; a segment writes exactly its own rows (the steps at its ends also produce a
-    neighbour's row, which is dropped)"""
+def test_up2_segmentation_does_not_change_the_result(dev, orc, strip_rows, monkeypatch, fmt, rows, chroma_seg):
+    """segments of `rows` output rows (chroma: as many, or with GMAT_U2_CHROMA_SEG=0 half, at least 4): the 3 warm-up source rows
+    of every segment re-create the four filtered rows its first output rows need; a segment writes exactly its own rows (the steps
+    at its ends also produce a neighbour's row, which is dropped)"""
     strip_rows(rows)
+    if chroma_seg == "half":
+        monkeypatch.setenv("GMAT_U2_CHROMA_SEG", "0")
+    else:
+        monkeypatch.delenv("GMAT_U2_CHROMA_SEG", raising=False)
     assert _check(dev, orc, fmt, 264, 26) == UP
 
 

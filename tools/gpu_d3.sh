@@ -3,11 +3,11 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-d3}; mkdir -p $OUT; cd $R
 timeout 1200 python -m pytest tests -q -m gpu > $OUT/pytest.log 2>&1
 timeout 900 python tests/fuzz/fuzz_strip.py 5000 ${2:-1313} --hip > $OUT/fuzz_strip.log 2>&1
-for nf in 32 1; do for c in "land: nv12 4K->720p nv12 bicubic" "land: yuv420p 4K->720p" "land: nv12 1080p->360p"; do
+for nf in 32 1; do for c in "nv12 4K->720p nv12 bicubic (3:1)" "land: yuv420p 4K->720p" "land: nv12 1080p->360p"; do
   echo "== strip, $nf frames per launch" >> $OUT/x2.txt; timeout 200 tools/bin/x2bench $nf 30 "$c" | tee -a $OUT/x2.txt | grep -v "verify.*identical"
   echo "== generic, $nf frames per launch" >> $OUT/x2.txt; GMAT_SCALE_NO_STRIP=1 timeout 300 tools/bin/x2bench $nf 10 "$c" | tee -a $OUT/x2.txt | grep -v "verify.*identical"
 done; done
-python3 tools/sweep.py "land: nv12 4K->720p nv12 bicubic" --nf 1,4,32 --env GMAT_STRIP_ROWS=-,4,6,8,12,16,24,32,48 --out $OUT/rows.txt | sed 's/ kernel=.*//'
+python3 tools/sweep.py "nv12 4K->720p nv12 bicubic (3:1)" --nf 1,4,32 --env GMAT_STRIP_ROWS=-,4,6,8,12,16,24,32,48 --out $OUT/rows.txt | sed 's/ kernel=.*//'
 echo "== fuzz_strip"; grep -E "scale_yuv3x1|cases" $OUT/fuzz_strip.log
 echo "== pytest -m gpu (whole suite) — read first"; grep -E "^FAILED|^ERROR" $OUT/pytest.log | head; tail -1 $OUT/pytest.log
 grep -c MISMATCH $OUT/x2.txt | sed 's/^/x2bench batched-vs-single MISMATCH lines: /'
