@@ -133,6 +133,7 @@ struct GmatSwsContext {
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
+    Yuv3x2Tables y3x2;                   // strip-walking 3:2 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
@@ -217,6 +218,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv2p_prepare(c->planYuv, c->ytiling, c->y2p)) < 0) return r;
     if ((r = yuv1x2_prepare(c->planYuv, c->ytiling, c->y1x2)) < 0) return r;
     if ((r = yuv3x1_prepare(c->planYuv, c->ytiling, c->y3x1)) < 0) return r;
+    if ((r = yuv3x2_prepare(c->planYuv, c->ytiling, c->y3x2)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -538,6 +540,30 @@ static Yuv3x1Args make_yuv3x1_args(const GmatSwsContext *c, const YuvScaleArgs &
     return da;
 }
 
+// the 3:2 down-scale kernel: dword loads, 8-byte stores on every plane
+static bool yuv3x2_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    return c->y3x2.ok && !c->rangeConv && ya.srcAligned && (dall & 7) == 0 && !ya.prof &&
+           (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
+}
+
+static Yuv3x2Args make_yuv3x2_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv3x2Args ea;
+    std::memset(&ea, 0, sizeof(ea));
+    const Yuv3x2Tables &t = c->y3x2;
+    ea.ys = ya.ys; ea.us = ya.us; ea.vs = ya.vs; ea.nv12 = ya.nv12;
+    ea.dstW = 2 * (ya.srcW / 3); ea.dstH = 2 * (ya.srcH / 3); ea.chrDstW = 2 * (ya.chrSrcW / 3); ea.chrDstH = 2 * (ya.chrSrcH / 3);
+    ea.ds = ya.ds; ea.dsU = ya.dsU; ea.dsV = ya.dsV;
+    for (int k = 0; k < 3; k++) {
+        ea.hLA[k] = t.hLA[k]; ea.hLB[k] = t.hLB[k]; ea.hLS[k] = t.hLS[k]; ea.vLA[k] = t.vLA[k]; ea.vLB[k] = t.vLB[k]; ea.vLS[k] = t.vLS[k];
+        ea.hCA[k] = t.hCA[k]; ea.hCB[k] = t.hCB[k]; ea.hCS[k] = t.hCS[k]; ea.vCA[k] = t.vCA[k]; ea.vCB[k] = t.vCB[k]; ea.vCS[k] = t.vCS[k];
+    }
+    ea.lr = t.lr; ea.cr = t.cr; ea.xcdRemap = ya.xcdRemap;
+    return ea;
+}
+
 // the name the plane-walking kernel reports by sample depths (one template, four instantiations per chroma layout)
 static const char *yuv2p_name(const GmatSwsContext *c)
 {
@@ -711,7 +737,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -722,6 +748,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use2p = use2p && yuv2p_eligible(c, ya);
         use1x2 = use1x2 && yuv1x2_eligible(c, ya);
         use3x1 = use3x1 && yuv3x1_eligible(c, ya);
+        use3x2 = use3x2 && yuv3x2_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -733,7 +760,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
     const Yuv1x2Args ua = use1x2 ? make_yuv1x2_args(c, ya0) : Yuv1x2Args();
     const Yuv3x1Args da = use3x1 ? make_yuv3x1_args(c, ya0) : Yuv3x1Args();
-    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const Yuv3x2Args ea = use3x2 ? make_yuv3x2_args(c, ya0) : Yuv3x2Args();
+    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -748,6 +776,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
               : use2p ? launch_scale_yuv2p(pa, stream, &fr, m)
               : use1x2 ? launch_scale_yuv1x2(ua, stream, &fr, m)
               : use3x1 ? launch_scale_yuv3x1(da, stream, &fr, m)
+              : use3x2 ? launch_scale_yuv3x2(ea, stream, &fr, m)
               : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
                       : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
@@ -1279,6 +1308,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv3x1_kernel";
                 r = launch_scale_yuv3x1(make_yuv3x1_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv3x2_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_yuv3x2_kernel";
+                r = launch_scale_yuv3x2(make_yuv3x2_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv2x_eligible(c, ya, src, srcStride)) {

@@ -328,6 +328,26 @@ struct Yuv3x1Args {
 int  yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x1Tables &t);
 int  launch_scale_yuv3x1(const Yuv3x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// ---- strip-walking form of the exact 3:2 down-scale of 8-bit YUV 4:2:0 (k_scale_yuv3x2.hip): NV12 -> NV12, YUV420P -> YUV420P -----
+// per axis and plane kind: A / B = the two phases (even / odd outputs) as 3 int16 pairs, S = the table's own row of output 1
+struct Yuv3x2Tables {
+    int ok = 0;
+    int32_t hLA[3] = {0}, hLB[3] = {0}, hLS[3] = {0}, vLA[3] = {0}, vLB[3] = {0}, vLS[3] = {0};
+    int32_t hCA[3] = {0}, hCB[3] = {0}, hCS[3] = {0}, vCA[3] = {0}, vCB[3] = {0}, vCS[3] = {0};
+    int lr = 0, cr = 0;
+};
+struct Yuv3x2Args {
+    int ys, us, vs, nv12;
+    int dstW, dstH, chrDstW, chrDstH;            // the source is exactly 3/2 as large in both directions
+    int ds, dsU, dsV;
+    int32_t hLA[3], hLB[3], hLS[3], vLA[3], vLB[3], vLS[3];
+    int32_t hCA[3], hCB[3], hCS[3], vCA[3], vCB[3], vCS[3];
+    int lr, cr;
+    int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (nsg = strips per row)
+};
+int  yuv3x2_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x2Tables &t);
+int  launch_scale_yuv3x2(const Yuv3x2Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
 // rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
 struct Rgb2sTables {

@@ -225,6 +225,25 @@ def test_4k_to_720p_transcode(gpu, orc, fmt, which, monkeypatch):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
+@pytest.mark.parametrize("fmt,geom", [("nv12", (1920, 1080, 1280, 720)), ("yuv420p", (1920, 1080, 1280, 720)), ("nv12", (3840, 2160, 2560, 1440))])
+@pytest.mark.parametrize("which", ["strip", "generic"])
+def test_3_to_2_ladder_steps(gpu, orc, fmt, geom, which, monkeypatch):
+    """1080p -> 720p and 4K -> 1440p at full size on BOTH kernels that serve them (the 3:2 strip walker by default, the generic plane
+    scaler for the frames it declines): every plane against the oracle"""
+    if which == "generic":
+        monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_SCALE_NO_STRIP", raising=False)
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, fmt, sw, sh, seed=47)
+    want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == "scale_yuv3x2_kernel" if which == "strip" else k.startswith("scale_yuv_kernel"), k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 def test_4k_rotate_17_degrees(gpu, orc):
     import math
     w, h, bpp = 3840, 2160, 3
