@@ -1135,7 +1135,8 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.maxRows = c->r2y.maxRows;
         L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
         L.toJpeg = c->rangeConv == 1;
-        c->lastKernel = "rgb2yuv420_kernel";
+        L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        c->lastKernel = rgb2yuv420_strip_takes(L) ? "rgb2yuv420s_kernel" : "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;
     }
@@ -1257,7 +1258,8 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         L.rowStart = (const int32_t *)c->dR2YrowStart.p; L.rowCount = (const int32_t *)c->dR2YrowCount.p;
         L.maxRows = c->r2y.maxRows;
         L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
-        c->lastKernel = "rgbpf32_to_rgb24_kernel+rgb2yuv420_kernel";
+        L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        c->lastKernel = rgb2yuv420_strip_takes(L) ? "rgbpf32_to_rgb24_kernel+rgb2yuv420s_kernel" : "rgbpf32_to_rgb24_kernel+rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;
     }

@@ -15,6 +15,9 @@
 // Traffic: 3 B/px in, 1.5 B/px out.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "px_math.h"
@@ -150,6 +153,238 @@ __global__ __launch_bounds__(256) void rgb2yuv420_kernel(Rgb2YuvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// rgb2yuv420s_kernel: the strip-walking form of the same conversion (round 2).  The tiled kernel above re-converts the 6 halo rows
+// of every 32-row tile and passes the chroma through LDS: 14.7 us per 4K frame (0.32 of the HBM roofline).  Here a wave owns a strip
+// of 512 pixel columns and walks down the source rows in pairs; a lane loads its own 8 pixels of each row (24 bytes, two loads),
+// writes their luma at once (8 bytes) and keeps the pair-summed 15-bit chroma of the last four row pairs (2m-1 | 2m) in registers for
+// the 2:1 vertical filter (8 taps as 4 int16 pairs, kernel arguments; borders = the interior filter on an edge-replicated plane,
+// checked on the host with filter_is_edge_replication).  No horizontal filter exists on this path (identity: min(2 v, 32767)), so
+// nothing crosses lanes.  A segment of `segRows` chroma rows re-creates its vertical window with 3 warm-up row pairs whose luma
+// belongs to the neighbour and is neither computed nor written.
+constexpr int Y2S_STRIP = 512;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned y2s_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned y2s_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ uint4 y2s_ld16(const uint8_t *p) { const y2s_u32x4 v = *reinterpret_cast<const y2s_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 y2s_ld8(const uint8_t *p) { const y2s_u32x2 v = *reinterpret_cast<const y2s_u32x2 *>(p); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void y2s_st8(uint8_t *p, unsigned lo, unsigned hi) { y2s_u32x2 v; v.x = lo; v.y = hi; *reinterpret_cast<y2s_u32x2 *>(p) = v; }
+#else
+static inline uint4 y2s_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
+static inline uint2 y2s_ld8(const uint8_t *p) { uint2 v; std::memcpy(&v, p, 8); return v; }
+static inline void y2s_st8(uint8_t *p, unsigned lo, unsigned hi) { std::memcpy(p, &lo, 4); std::memcpy(p + 4, &hi, 4); }
+#endif
+__device__ __forceinline__ int y2s_dot2(int ab, int cd, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ab), __builtin_bit_cast(short2v, cd), acc, true);   // VOP3P form, see k_scale_yuv2s.hip
+}
+
+struct Rgb2YuvStripArgs {
+    const uint8_t *src; int ss, toJpeg;
+    uint8_t *y, *u, *v; int ys, us, vs;
+    int w, h;
+    int32_t cY01, cY2, cU01, cU2, cV01, cV2;     // coefficients in the byte order of the pixels: (first, second) as an int16 pair, third alone
+    int32_t vC[4];                               // the vertical chroma filter on [2y - 3, 2y + 4] as 4 int16 pairs
+    int rnd;
+    int segRows, nseg, nstrips, nblk, xcdRemap;
+};
+struct Y2sRow { unsigned d[6]; };
+
+// JPEG: full-range destination (lum / chrRangeToJpeg_c) — a template parameter: as a run-time flag the compiler made it a scalar branch
+// per PIXEL (26 branches per iteration; the first build ran at 16 us per 4K frame, slower than the tiled kernel)
+// NOSAT: the host has verified from the coefficients that no 8-bit input can reach the saturations of the limited-range path — the 14-bit
+// luma stays below 16352 and the 14-bit chroma below 16384 (true for every matrix of fill_rgb2yuv_table: the luma row sums to
+// 219/255 * 2^15) — so min(2 v, 32767) and the 8-bit clip of the one-tap luma output are dead and ((2 y + 64) >> 7) = (y + 32) >> 6.
+template <bool NV, bool JPEG, bool NOSAT>
+__global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int unit = lin * 4 + wave;                            // (segment, strip) units packed densely: the waves share nothing
+    if (unit >= a.nseg * a.nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / a.nstrips);
+    const int X0 = (unit - seg * a.nstrips) * Y2S_STRIP;
+    const int c0 = seg * a.segRows, ch = a.h >> 1;
+    const int nOut = min(a.segRows, ch - c0);
+    const int nIter = nOut + 3;                                 // 3 warm-up row pairs fill the vertical window
+
+    const int xo = X0 + 8 * lane;
+    const bool active = xo < a.w;
+    const unsigned xc = (unsigned)(active ? xo : a.w - 8);      // idle lanes shadow the last group (loads stay inside the rows)
+
+    auto load_row = [&](int r, Y2sRow &R) {
+        const uint8_t *p = a.src + ((unsigned)min(max(r, 0), a.h - 1) * (unsigned)a.ss + 3u * xc);
+        const uint4 v0 = y2s_ld16(p);
+        const uint2 v1 = y2s_ld8(p + 16);
+        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+    };
+    // one source row: luma of the 8 pixels written if the row belongs to this segment; 15-bit U / V of the 4 pixel pairs returned
+    auto convert_row = [&](const Y2sRow &R, int row, bool luma, int (&cu)[4], int (&cv)[4]) {
+        int fs[8], th[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int o = 3 * i, d = o >> 2, b = o & 3;
+            const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
+            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+        }
+        if (luma) {                                             // wave-uniform
+            unsigned yb[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                // rgb24ToY_c, hScale16To15_c with one tap, (lumRangeToJpeg_c), yuv2plane1_8_c
+                const int y14 = y2s_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+                if constexpr (NOSAT && !JPEG) {
+                    yb[i] = (unsigned)(y14 + 32) >> 6;
+                } else {
+                    int l = min(2 * y14, 32767);
+                    if constexpr (JPEG) l = (m24(min(l, 30189), 19077) - 39057361) >> 14;
+                    yb[i] = (unsigned)clip_u8_shr(l + 64, 7);
+                }
+            }
+            if (active) y2s_st8(a.y + ((unsigned)row * (unsigned)a.ys + (unsigned)xo), yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
+                                yb[4] | (yb[5] << 8) | (yb[6] << 16) | (yb[7] << 24));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // rgb24ToUV_half_c on the sum of the pair's pixels, hScale16To15_c with one tap, (chrRangeToJpeg_c)
+            const int fsum = fs[2 * c] + fs[2 * c + 1];             // two 9-bit sums in the halves: no carry across
+            const int tsum = th[2 * c] + th[2 * c + 1];
+            int u = 2 * (y2s_dot2(fsum, a.cU01, m24(tsum, a.cU2) + ((256 << 15) + (1 << 9))) >> 10);
+            int v = 2 * (y2s_dot2(fsum, a.cV01, m24(tsum, a.cV2) + ((256 << 15) + (1 << 9))) >> 10);
+            if constexpr (!NOSAT) { u = min(u, 32767); v = min(v, 32767); }
+            if constexpr (JPEG) { u = (m24(min(u, 30775), 4663) - 9289992) >> 12; v = (m24(min(v, 30775), 4663) - 9289992) >> 12; }
+            cu[c] = u; cv[c] = v;
+        }
+    };
+
+    int hwU[4][4], hwV[4][4];                                   // [slot][pixel pair]: (row 2m-1 | row 2m << 16)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) hwU[s][c] = hwV[s][c] = 0;
+    Y2sRow bufA[2], bufB[2];                                    // ping-pong: rows 2m-1 and 2m of the current / next pair
+#pragma unroll
+    for (int i = 0; i < 6; i++) bufA[1].d[i] = bufB[1].d[i] = 0u;
+    load_row(2 * (c0 - 1) - 1, bufA[0]);
+    load_row(2 * (c0 - 1), bufB[0]);
+
+    auto body = [&](const int j, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;           // j & 3, static after unrolling
+        const Y2sRow ra = bufA[SLOT & 1], rb = bufB[SLOT & 1];
+        const int m = c0 - 1 + j;                               // this iteration's pair: rows 2m - 1, 2m
+        if (j + 1 < nIter) {
+            load_row(2 * m + 1, bufA[(SLOT + 1) & 1]);
+            load_row(2 * m + 2, bufB[(SLOT + 1) & 1]);
+        }
+        {
+            // row 2m - 1 belongs to chroma row m - 1, row 2m to chroma row m: luma only for the rows of this segment
+            int ua[4], va[4], ub[4], vb[4];
+            convert_row(ra, 2 * m - 1, m - 1 >= c0 && m - 1 < c0 + nOut, ua, va);
+            convert_row(rb, 2 * m, m >= c0 && m < c0 + nOut, ub, vb);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                hwU[SLOT][c] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c], ub[c]));
+                hwV[SLOT][c] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c], vb[c]));
+            }
+        }
+        if (j >= 3) {
+            const int cy = c0 + j - 3;                          // pairs cy-1 .. cy+2 sit in slots SLOT+1 .. SLOT+4 (mod 4)
+            unsigned ub8[4], vb8[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                int U = a.rnd, V = a.rnd;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    U = y2s_dot2(hwU[(SLOT + 1 + k) & 3][c], a.vC[k], U);
+                    V = y2s_dot2(hwV[(SLOT + 1 + k) & 3][c], a.vC[k], V);
+                }
+                ub8[c] = (unsigned)clip_u8_shr(U, 19); vb8[c] = (unsigned)clip_u8_shr(V, 19);
+            }
+            if (active) {
+                if (NV) {
+                    y2s_st8(a.u + ((unsigned)cy * (unsigned)a.us + (unsigned)xo), ub8[0] | (vb8[0] << 8) | (ub8[1] << 16) | (vb8[1] << 24),
+                            ub8[2] | (vb8[2] << 8) | (ub8[3] << 16) | (vb8[3] << 24));
+                } else {
+                    *reinterpret_cast<unsigned *>(a.u + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = ub8[0] | (ub8[1] << 8) | (ub8[2] << 16) | (ub8[3] << 24);
+                    *reinterpret_cast<unsigned *>(a.v + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = vb8[0] | (vb8[1] << 8) | (vb8[2] << 16) | (vb8[3] << 24);
+                }
+            }
+        }
+    };
+    for (int j0 = 0; j0 < nIter; j0 += 4) {
+        body(j0, std::integral_constant<int, 0>());
+        if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>());
+        if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>());
+        if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>());
+    }
+}
+
+// the strip form takes a frame when the chroma taps are the replicated 8-tap window, the geometry is whole lanes and rows pair up,
+// and every plane can be moved in dwords
+bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L)
+{
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return false;
+    if (!L.stripOk || L.w % 8 || L.w < 64 || (L.h & 1) || L.h < 16) return false;
+    uintptr_t all = (uintptr_t)L.src | (uintptr_t)L.ss | (uintptr_t)L.y | (uintptr_t)L.ys | (uintptr_t)L.u | (uintptr_t)L.us;
+    if (!L.nv12) all |= (uintptr_t)L.v | (uintptr_t)L.vs;
+    return (all & 3) == 0;
+}
+
+static int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream)
+{
+    Rgb2YuvStripArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src = L.src; a.ss = L.ss; a.toJpeg = L.toJpeg;
+    a.y = L.y; a.u = L.u; a.v = L.v; a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.w = L.w; a.h = L.h;
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    const Rgb2YuvConsts &q = L.k;
+    if (L.bgr) { a.cY01 = pk(q.by, q.gy); a.cY2 = q.ry; a.cU01 = pk(q.bu, q.gu); a.cU2 = q.ru; a.cV01 = pk(q.bv, q.gv); a.cV2 = q.rv; }
+    else       { a.cY01 = pk(q.ry, q.gy); a.cY2 = q.by; a.cU01 = pk(q.ru, q.gu); a.cU2 = q.bu; a.cV01 = pk(q.rv, q.gv); a.cV2 = q.bv; }
+    for (int k = 0; k < 4; k++) a.vC[k] = L.vC[k];
+    a.rnd = 64 << 12;                                           // yuv2planeX_8_c / yuv2nv12cX_c dither
+    a.nstrips = (L.w + Y2S_STRIP - 1) / Y2S_STRIP;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override (chroma rows per segment), read per launch
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        // measured on one 4K frame per launch (profiles/r02o_rgb2yuv_strip.txt): 5 chroma rows 11.9 us, 3: 12.2, 4: 13.3, 6: 13.0, 8: 14.8
+        // — an odd count makes the iteration count (rows + 3) a multiple of the unrolled loop's period more often; 1080p: 3 rows
+        const long rows = (long)(L.h >> 1) * a.nstrips;         // wave-rows (chroma)
+        seg = (int)std::min(31L, std::max(3L, (rows + 1727) / 1728)) | 1;
+    }
+    a.segRows = seg;
+    a.nseg = ((L.h >> 1) + seg - 1) / seg;
+    a.nblk = (a.nseg * a.nstrips + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8)), block(256);
+    // can an 8-bit pixel reach a saturation?  luma: 0 <= y14 <= 16351 keeps 2 y14 + 64 below 2^15; chroma (pixel PAIRS): 0 <= u14 <= 16383
+    auto lo_hi = [](int c0, int c1, int c2, long scale, long add, int sh, long &lo, long &hi) {
+        lo = (scale * (std::min(c0, 0) + std::min(c1, 0) + std::min(c2, 0)) + add) >> sh;
+        hi = (scale * (std::max(c0, 0) + std::max(c1, 0) + std::max(c2, 0)) + add) >> sh;
+    };
+    long ylo, yhi, ulo, uhi, vlo, vhi;
+    lo_hi(q.ry, q.gy, q.by, 255, (32 << 14) + (1 << 8), 9, ylo, yhi);
+    lo_hi(q.ru, q.gu, q.bu, 510, (256L << 15) + (1 << 9), 10, ulo, uhi);
+    lo_hi(q.rv, q.gv, q.bv, 510, (256L << 15) + (1 << 9), 10, vlo, vhi);
+    const char *ns = getenv("GMAT_R2Y_NOSAT");                   // test knob: 0 = the variant that keeps every saturation
+    const bool nosat = !(ns && !atoi(ns)) && ylo >= 0 && yhi <= 16351 && ulo >= 0 && uhi <= 16383 && vlo >= 0 && vhi <= 16383;
+#define GMAT_Y2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a); \
+                               else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a); } while (0)
+    if (L.toJpeg) { if (L.nv12) GMAT_Y2S(true, true); else GMAT_Y2S(false, true); }
+    else          { if (L.nv12) GMAT_Y2S(true, false); else GMAT_Y2S(false, false); }
+#undef GMAT_Y2S
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // NV12 <-> YUV420P chroma re-layout (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c).
 // A thread moves 4 chroma samples of each plane: 8 interleaved bytes <-> 4 + 4 planar bytes (v_perm_b32).
 __global__ __launch_bounds__(256) void uv_deinterleave_kernel(const uint8_t *uv, int uvs, uint8_t *u, int us, uint8_t *v, int vs,
@@ -241,11 +476,14 @@ int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t)
     if (t.maxRows * R2Y_CW * 4 > 60 * 1024) return GMAT_ERR(ENOSYS);
     // accumulator start: yuv2planeX_8_c / yuv2nv12cX_c dither 64<<12; the one-tap planar form adds 64 before >>7
     t.round.assign(p.chrDstH, 64 << 12);
+    // the strip form: the vertical chroma filter as the replicated window [2y - 3, 2y + 4]
+    t.stripOk = (p.srcH % 2 == 0 && p.chrDstH * 2 == p.srcH && filter_is_edge_replication(p.vChr, p.srcH, t.vC)) ? 1 : 0;
     return 0;
 }
 
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream)
 {
+    if (rgb2yuv420_strip_takes(L)) return launch_rgb2yuv420s(L, stream);
     Rgb2YuvArgs a;
     a.src = L.src; a.ss = L.ss; a.bgr = L.bgr; a.toJpeg = L.toJpeg;
     a.srcAligned = ((((uintptr_t)L.src | (uintptr_t)L.ss) & 3) == 0);

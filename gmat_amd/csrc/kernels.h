@@ -165,6 +165,8 @@ namespace gmat {
 struct Rgb2YuvPlan {
     int ntx = 0, nty = 0, maxRows = 0;
     std::vector<int32_t> rowStart, rowCount, round;
+    int stripOk = 0;                     // the vertical chroma filter is the replicated 8-tap window: rgb2yuv420s_kernel may take the frame
+    int32_t vC[4] = {0, 0, 0, 0};
 };
 struct Rgb2YuvLaunch {
     int toJpeg = 0;                      // full-range YUV output: lum/chrRangeToJpeg_c on the 15-bit values (swscale.c:157-181)
@@ -175,9 +177,11 @@ struct Rgb2YuvLaunch {
     const int32_t *rowStart, *rowCount;
     int maxRows;
     Rgb2YuvConsts k;
+    int stripOk = 0; int32_t vC[4] = {0, 0, 0, 0};      // from Rgb2YuvPlan
 };
 int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t);
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
+bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L);        // the launch goes to rgb2yuv420s_kernel
 // packed RGB24 / BGR24 -> planar YUV 4:4:4 at equal size (one-tap filters everywhere: a per-pixel conversion)
 int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us, uint8_t *v, int vs, int w, int h,
                       const Rgb2YuvConsts &k, hipStream_t stream);

@@ -69,6 +69,10 @@ for case in range(n):
             dw = rng.choice([16 * rng.randint(4, maxw // 24), 8 * rng.randint(8, maxw // 12)]); dh = rng.choice([4 * rng.randint(4, 30), 2 * rng.randint(8, 60)])
             sw, sh = 3 * dw // 2, 3 * dh // 2
             if rng.random() < 0.06: sh += 2
+        if rng.random() < 0.08:                                 # same-size packed RGB -> 4:2:0 (rgb2yuv420s_kernel) and near misses
+            sf = rng.choice(RGB3); df = rng.choice(["nv12", "yuv420p"])
+            sw = rng.choice([8 * rng.randint(8, maxw // 8), 4 * rng.randint(16, maxw // 4)]); sh = rng.choice([2 * rng.randint(8, 60), rng.randint(8, 99)])
+            dw, dh = sw, sh
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         # the fused convert-then-scale form (setFused(1): scale_rgb2h_kernel<yuv> at exactly 2:1, the tiled kernel otherwise)
@@ -94,7 +98,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3x2", "scale_rgb2h")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3x2", "scale_rgb2h", "rgb2yuv420")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

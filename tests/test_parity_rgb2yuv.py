@@ -4,24 +4,93 @@ import pytest
 
 from harness import PIX_FMT, SWS, planes, ints, synth_planes
 
-SIZES = [(128, 32), (256, 70), (130, 34), (66, 18), (6, 4), (2, 2), (300, 66)]
+# one partial strip of the strip kernel (512 pixel columns per wave), exactly one, one and a bit, several workgroups of strips, widths
+# that are multiples of 8 only; then what it declines: widths off the 8-pixel grid, odd heights, tiny frames
+SIZES = [(128, 32), (256, 70), (512, 16), (520, 20), (1032, 16), (2056, 18), (2568, 16), (72, 18), (130, 34), (66, 18), (6, 4), (2, 2), (300, 66),
+         (128, 33), (128, 6), (128, 14)]
+
+
+def strip_takes(w, h, align):
+    """the rule of rgb2yuv420_strip_takes restated: whole 8-pixel lanes, at least 64 columns, rows pair up, at least 8 chroma rows
+    (the replication check compares every row of the table with its middle row, whose 8-tap window must be interior), every plane
+    movable in dwords — and the context's vertical chroma filter must be the replicated 8-tap window (true for bicubic)"""
+    return w % 8 == 0 and w >= 64 and h % 2 == 0 and h >= 16 and align % 4 == 0
+
+
+@pytest.fixture(params=["strip", "tiled"])
+def kern_r2y(request, monkeypatch):
+    if request.param == "tiled":
+        monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_SCALE_NO_STRIP", raising=False)
+    return request.param
+
+
+def test_sizes_cover_both_kernels():
+    took = [strip_takes(w, h, 256) for w, h in SIZES]
+    assert sum(took) >= 8 and took.count(False) >= 6
 
 
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
 @pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
-def test_rgb_to_yuv420_bit_exact(dev, orc, w, h, src_fmt, dst_fmt):
+def test_rgb_to_yuv420_bit_exact(dev, orc, kern_r2y, w, h, src_fmt, dst_fmt):
+    """both kernels of the same-size RGB -> 4:2:0 conversion against the oracle: the strip walker (rgb2yuv420s_kernel) where its
+    rule takes the frame, the tiled kernel everywhere else and everywhere with GMAT_SCALE_NO_STRIP=1"""
     src = synth_planes(orc, src_fmt, w, h, seed=51)
     want = orc.sws(src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"])
-    for align, extra in [(256, 0), (1, 1)]:
+    for align, extra in [(256, 0), (4, 4), (1, 1)]:
         d_src = dev.upload_planes(src, align, extra)
         got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
-        assert kernel == "rgb2yuv420_kernel"
+        assert kernel == ("rgb2yuv420s_kernel" if kern_r2y == "strip" and strip_takes(w, h, align) else "rgb2yuv420_kernel"), (kernel, align)
         for i, (g, wv) in enumerate(zip(got, want)):
             bad = np.argwhere(g != wv)
-            assert bad.size == 0, f"plane {i}: {len(bad)} mismatches, first {bad[:4].tolist()} (align {align})"
+            assert bad.size == 0, f"{kernel} plane {i}: {len(bad)} mismatches, first {bad[:4].tolist()} (align {align})"
         for p in pads:
             assert (p == 0xCD).all()
+        for p in d_src:
+            p.free()
+
+
+@pytest.mark.parametrize("sat", ["proven-dead", "kept"])
+@pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 7, 16, 1000])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
+def test_rgb_to_yuv420_strip_segmentation(dev, orc, monkeypatch, dst_fmt, rows, sat):
+    """segments of `rows` chroma rows: the 3 warm-up row pairs of every segment re-create the vertical chroma window, their luma
+    belongs to the neighbouring segment and is written exactly once.  Both instantiations: the one without the saturations the
+    host has proven dead from the coefficients (the default for every standard matrix) and, with GMAT_R2Y_NOSAT=0, the one that
+    keeps them"""
+    monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+    if sat == "kept":
+        monkeypatch.setenv("GMAT_R2Y_NOSAT", "0")
+    else:
+        monkeypatch.delenv("GMAT_R2Y_NOSAT", raising=False)
+    w, h = 520, 46
+    src = synth_planes(orc, "rgb24", w, h, seed=53)
+    want = orc.sws(src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"])
+    d_src = dev.upload_planes(src, 64)
+    got, pads, kernel = dev.sws(d_src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"], dst_align=64)
+    assert kernel == "rgb2yuv420s_kernel"
+    for g, wv, p in zip(got, want, pads):
+        assert (g == wv).all() and (p == 0xCD).all()
+
+
+@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "point", "area", "lanczos", "gauss"])
+def test_rgb_to_yuv420_other_filters(dev, orc, kern_r2y, flags):
+    """the vertical chroma filter decides: whatever is the replicated 8-tap window takes the strip kernel, the rest stays tiled;
+    the bytes are libswscale's either way"""
+    w, h = 264, 38
+    src = synth_planes(orc, "rgb24", w, h, seed=55)
+    want = orc.sws(src, w, h, "rgb24", w, h, "nv12", SWS[flags])
+    d_src = dev.upload_planes(src, 64)
+    got, _, kernel = dev.sws(d_src, w, h, "rgb24", w, h, "nv12", SWS[flags], dst_align=64)
+    assert kernel in ("rgb2yuv420s_kernel", "rgb2yuv420_kernel") or kernel.startswith("scale_yuv_kernel"), kernel
+    if kern_r2y == "tiled":
+        assert kernel != "rgb2yuv420s_kernel"
+    if flags == "bicubic" and kern_r2y == "strip":
+        assert kernel == "rgb2yuv420s_kernel"
+    for g, wv in zip(got, want):
+        assert (g == wv).all(), (flags, kernel)
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(1, 1), (257, 5), (1023, 3)])
@@ -42,30 +111,34 @@ def test_rgb_to_yuv444p_bit_exact(dev, orc, w, h, src_fmt):
                 assert (p == 0xCD).all()
 
 
+@pytest.mark.parametrize("geom", [(130, 34), (136, 34)])      # the tiled kernel's / the strip kernel's geometry
 @pytest.mark.parametrize("cs", [1, 4, 5, 7, 9])          # ITU709, FCC, ITU601, SMPTE240M, BT2020 (swscale.h:98-107)
 @pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p", "yuv444p"])
-def test_rgb_to_yuv_colorspaces(dev, orc, cs, dst_fmt):
+def test_rgb_to_yuv_colorspaces(dev, orc, cs, dst_fmt, geom):
     """the destination's matrix: fill_rgb2yuv_table (utils.c:765-858) inverts the yuv2rgb coefficient row of the
     colourspace (BT.601 keeps its literals); gmat_sws_setColorspace on an RGB -> YUV context selects it"""
-    w, h = 130, 34
+    w, h = geom
     src = synth_planes(orc, "rgb24", w, h, seed=59)
     want = orc.sws(src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"], colorspace=cs)
     d_src = dev.upload_planes(src, 64)
     got, _, kernel = dev.sws(d_src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"], dst_align=64, colorspace=(cs, 0))
     for i, (g, wv) in enumerate(zip(got, want)):
         assert (g == wv).all(), (i, kernel)
+    if dst_fmt != "yuv444p":
+        assert kernel == ("rgb2yuv420s_kernel" if strip_takes(w, h, 64) else "rgb2yuv420_kernel"), kernel
     if cs not in (5, 6):
         base = orc.sws(src, w, h, "rgb24", w, h, dst_fmt, SWS["bicubic"])
         assert any((a != b).any() for a, b in zip(want, base))      # the matrix really changed something
 
 
+@pytest.mark.parametrize("geom", [(130, 34), (136, 34)])      # the tiled kernel's / the strip kernel's geometry
 @pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24"])
 @pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
-def test_rgb_to_full_range_yuv(dev, orc, src_fmt, dst_fmt):
+def test_rgb_to_full_range_yuv(dev, orc, src_fmt, dst_fmt, geom):
     """a full-range YUV destination of an RGB source: lum/chrRangeToJpeg_c on the 15-bit lines (the RGB end's range is
     forced to 0); gmat_sws_setRange(c, 0, 1)"""
     import ctypes as C
-    w, h = 130, 34
+    w, h = geom
     L = orc.L
     L.orc_sws_create_ex.restype = C.c_void_p
     L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -86,6 +159,7 @@ def test_rgb_to_full_range_yuv(dev, orc, src_fmt, dst_fmt):
                                   planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
     for a, b in zip(dst, want):
         assert (a.download() == b).all()
+    assert dev.lib.gmat_sws_lastKernel(c) == (b"rgb2yuv420s_kernel" if strip_takes(w, h, 64) else b"rgb2yuv420_kernel")
     base = orc.sws(src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"])
     assert (base[0] != want[0]).any()
     dev.lib.gmat_sws_freeContext(c)
