@@ -644,6 +644,37 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
+    if (c->mode == MODE_RGB2YUV && !c->inner) {
+        // the same-size RGB -> 4:2:0 converter: one launch of rgb2yuv420s_kernel per 32 frames when every frame passes its rule
+        const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+        Rgb2YuvLaunch L;
+        L.ss = srcStride[0]; L.bgr = c->srcFormat == GMAT_PIX_FMT_BGR24;
+        L.ys = dstStride[0]; L.us = dstStride[1]; L.vs = dnv12 ? 0 : dstStride[2]; L.nv12 = dnv12;
+        L.w = c->srcW; L.h = c->srcH; L.maxRows = c->r2y.maxRows; L.rowStart = nullptr; L.rowCount = nullptr;
+        L.k = make_rgb2yuv_consts(c->colorspace); L.toJpeg = c->rangeConv == 1;
+        L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        for (int f = 0; f < n; f++) {
+            const uint8_t *const *sp = src_planes + 4 * f;
+            uint8_t *const *dp = dst_planes + 4 * f;
+            if (!sp[0] || !dp[0] || !dp[1] || (!dnv12 && !dp[2])) return GMAT_ERR(EINVAL);
+            L.src = sp[0]; L.y = dp[0]; L.u = dp[1]; L.v = dnv12 ? nullptr : dp[2];
+            if (!rgb2yuv420_strip_takes(L)) return 0;
+        }
+        c->lastKernel = "rgb2yuv420s_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                fr.y[i] = src_planes[4 * (f0 + i)];
+                fr.dst[i] = dst_planes[4 * (f0 + i)]; fr.dstU[i] = dst_planes[4 * (f0 + i) + 1]; fr.dstV[i] = dnv12 ? nullptr : dst_planes[4 * (f0 + i) + 2];
+            }
+            int r = launch_rgb2yuv420s(L, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (c->mode == MODE_SCALE && (c->srcFormat == GMAT_PIX_FMT_RGB24 || c->srcFormat == GMAT_PIX_FMT_BGR24) && !c->rgbViaPlanes &&
         !c->inner && is_packed_rgb(c->dstFormat)) {
         // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames

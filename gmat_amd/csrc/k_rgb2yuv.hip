@@ -180,9 +180,9 @@ __device__ __forceinline__ int y2s_dot2(int ab, int cd, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ab), __builtin_bit_cast(short2v, cd), acc, true);   // VOP3P form, see k_scale_yuv2s.hip
 }
 
-struct Rgb2YuvStripArgs {
-    const uint8_t *src; int ss, toJpeg;
-    uint8_t *y, *u, *v; int ys, us, vs;
+struct Rgb2YuvStripArgs {                        // plane pointers: Yuv2xFrames (y[] = the packed source, dst / dstU / dstV = the planes), blockIdx.y = frame
+    int ss, toJpeg;
+    int ys, us, vs;
     int w, h;
     int32_t cY01, cY2, cU01, cU2, cV01, cV2;     // coefficients in the byte order of the pixels: (first, second) as an int16 pair, third alone
     int32_t vC[4];                               // the vertical chroma filter on [2y - 3, 2y + 4] as 4 int16 pairs
@@ -197,8 +197,10 @@ struct Y2sRow { unsigned d[6]; };
 // luma stays below 16352 and the 14-bit chroma below 16384 (true for every matrix of fill_rgb2yuv_table: the luma row sums to
 // 219/255 * 2^15) — so min(2 v, 32767) and the 8-bit clip of the one-tap luma output are dead and ((2 y + 64) >> 7) = (y + 32) >> 6.
 template <bool NV, bool JPEG, bool NOSAT>
-__global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a)
+__global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yuv2xFrames fr)
 {
+    const uint8_t *psrc = fr.y[blockIdx.y];
+    uint8_t *py = fr.dst[blockIdx.y], *pu = fr.dstU[blockIdx.y], *pv = fr.dstV[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int lin = blockIdx.x;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a)
     const unsigned xc = (unsigned)(active ? xo : a.w - 8);      // idle lanes shadow the last group (loads stay inside the rows)
 
     auto load_row = [&](int r, Y2sRow &R) {
-        const uint8_t *p = a.src + ((unsigned)min(max(r, 0), a.h - 1) * (unsigned)a.ss + 3u * xc);
+        const uint8_t *p = psrc + ((unsigned)min(max(r, 0), a.h - 1) * (unsigned)a.ss + 3u * xc);
         const uint4 v0 = y2s_ld16(p);
         const uint2 v1 = y2s_ld8(p + 16);
         R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a)
                     yb[i] = (unsigned)clip_u8_shr(l + 64, 7);
                 }
             }
-            if (active) y2s_st8(a.y + ((unsigned)row * (unsigned)a.ys + (unsigned)xo), yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
+            if (active) y2s_st8(py + ((unsigned)row * (unsigned)a.ys + (unsigned)xo), yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24),
                                 yb[4] | (yb[5] << 8) | (yb[6] << 16) | (yb[7] << 24));
         }
 #pragma unroll
@@ -310,11 +312,11 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a)
             }
             if (active) {
                 if (NV) {
-                    y2s_st8(a.u + ((unsigned)cy * (unsigned)a.us + (unsigned)xo), ub8[0] | (vb8[0] << 8) | (ub8[1] << 16) | (vb8[1] << 24),
+                    y2s_st8(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)xo), ub8[0] | (vb8[0] << 8) | (ub8[1] << 16) | (vb8[1] << 24),
                             ub8[2] | (vb8[2] << 8) | (ub8[3] << 16) | (vb8[3] << 24));
                 } else {
-                    *reinterpret_cast<unsigned *>(a.u + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = ub8[0] | (ub8[1] << 8) | (ub8[2] << 16) | (ub8[3] << 24);
-                    *reinterpret_cast<unsigned *>(a.v + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = vb8[0] | (vb8[1] << 8) | (vb8[2] << 16) | (vb8[3] << 24);
+                    *reinterpret_cast<unsigned *>(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = ub8[0] | (ub8[1] << 8) | (ub8[2] << 16) | (ub8[3] << 24);
+                    *reinterpret_cast<unsigned *>(pv + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = vb8[0] | (vb8[1] << 8) | (vb8[2] << 16) | (vb8[3] << 24);
                 }
             }
         }
@@ -339,12 +341,20 @@ bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L)
     return (all & 3) == 0;
 }
 
-static int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream)
+// frames == nullptr: the one frame described by L; else nframes frames of L's geometry and strides (all of them pass rgb2yuv420_strip_takes)
+int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
+    if (nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv2xFrames one;
+    if (!frames) {
+        std::memset(&one, 0, sizeof(one));
+        one.y[0] = L.src; one.dst[0] = L.y; one.dstU[0] = L.u; one.dstV[0] = L.v;
+        frames = &one; nframes = 1;
+    }
     Rgb2YuvStripArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.src = L.src; a.ss = L.ss; a.toJpeg = L.toJpeg;
-    a.y = L.y; a.u = L.u; a.v = L.v; a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.w = L.w; a.h = L.h;
+    a.ss = L.ss; a.toJpeg = L.toJpeg;
+    a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.w = L.w; a.h = L.h;
     auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
     const Rgb2YuvConsts &q = L.k;
     if (L.bgr) { a.cY01 = pk(q.by, q.gy); a.cY2 = q.ry; a.cU01 = pk(q.bu, q.gu); a.cU2 = q.ru; a.cV01 = pk(q.bv, q.gv); a.cV2 = q.rv; }
@@ -357,14 +367,14 @@ static int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream)
     if (seg <= 0) {
         // measured on one 4K frame per launch (profiles/r02o_rgb2yuv_strip.txt): 5 chroma rows 11.9 us, 3: 12.2, 4: 13.3, 6: 13.0, 8: 14.8
         // — an odd count makes the iteration count (rows + 3) a multiple of the unrolled loop's period more often; 1080p: 3 rows
-        const long rows = (long)(L.h >> 1) * a.nstrips;         // wave-rows (chroma)
+        const long rows = (long)(L.h >> 1) * a.nstrips * nframes;   // wave-rows (chroma)
         seg = (int)std::min(31L, std::max(3L, (rows + 1727) / 1728)) | 1;
     }
     a.segRows = seg;
     a.nseg = ((L.h >> 1) + seg - 1) / seg;
     a.nblk = (a.nseg * a.nstrips + 3) / 4;
     a.xcdRemap = 1;
-    const dim3 grid(8 * ((a.nblk + 7) / 8)), block(256);
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
     // can an 8-bit pixel reach a saturation?  luma: 0 <= y14 <= 16351 keeps 2 y14 + 64 below 2^15; chroma (pixel PAIRS): 0 <= u14 <= 16383
     auto lo_hi = [](int c0, int c1, int c2, long scale, long add, int sh, long &lo, long &hi) {
         lo = (scale * (std::min(c0, 0) + std::min(c1, 0) + std::min(c2, 0)) + add) >> sh;
@@ -376,8 +386,8 @@ static int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream)
     lo_hi(q.rv, q.gv, q.bv, 510, (256L << 15) + (1 << 9), 10, vlo, vhi);
     const char *ns = getenv("GMAT_R2Y_NOSAT");                   // test knob: 0 = the variant that keeps every saturation
     const bool nosat = !(ns && !atoi(ns)) && ylo >= 0 && yhi <= 16351 && ulo >= 0 && uhi <= 16383 && vlo >= 0 && vhi <= 16383;
-#define GMAT_Y2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a); \
-                               else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a); } while (0)
+#define GMAT_Y2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a, *frames); \
+                               else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a, *frames); } while (0)
     if (L.toJpeg) { if (L.nv12) GMAT_Y2S(true, true); else GMAT_Y2S(false, true); }
     else          { if (L.nv12) GMAT_Y2S(true, false); else GMAT_Y2S(false, false); }
 #undef GMAT_Y2S
@@ -483,7 +493,7 @@ int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t)
 
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream)
 {
-    if (rgb2yuv420_strip_takes(L)) return launch_rgb2yuv420s(L, stream);
+    if (rgb2yuv420_strip_takes(L)) return launch_rgb2yuv420s(L, stream, nullptr, 1);
     Rgb2YuvArgs a;
     a.src = L.src; a.ss = L.ss; a.bgr = L.bgr; a.toJpeg = L.toJpeg;
     a.srcAligned = ((((uintptr_t)L.src | (uintptr_t)L.ss) & 3) == 0);

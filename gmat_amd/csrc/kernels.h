@@ -182,6 +182,8 @@ struct Rgb2YuvLaunch {
 int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t);
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
 bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L);        // the launch goes to rgb2yuv420s_kernel
+// frames == nullptr: the frame of L; else nframes frames (y[] = packed source, dst / dstU / dstV = planes) of L's geometry and strides
+int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 // packed RGB24 / BGR24 -> planar YUV 4:4:4 at equal size (one-tap filters everywhere: a per-pixel conversion)
 int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us, uint8_t *v, int vs, int w, int h,
                       const Rgb2YuvConsts &k, hipStream_t stream);

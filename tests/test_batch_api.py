@@ -105,6 +105,18 @@ def test_batch_on_the_generic_plane_scaler(dev, orc, case):
     assert _run_batch.last_frames == 2          # the second stream's share of 5 frames
 
 
+@pytest.mark.parametrize("case", [("rgb24", "nv12", 264, 40), ("bgr24", "yuv420p", 264, 40), ("rgb24", "nv12", 260, 40)])
+def test_batch_on_the_rgb_to_yuv_converter(dev, orc, case):
+    """the same-size RGB -> 4:2:0 converter batches as well: rgb2yuv420s_kernel with grid.y = frame when every frame passes its rule
+    (width a multiple of 8), frame by frame on the tiled kernel otherwise"""
+    sf, df, w, h = case
+    k = _run_batch(dev, orc, sf, df, w, h, w, h, nframes=5, nstreams=2, align=16)
+    if w % 8 == 0:
+        assert k == "rgb2yuv420s_kernel" and _run_batch.last_frames == 2, (k, _run_batch.last_frames)
+    else:
+        assert k == "rgb2yuv420_kernel", k
+
+
 @pytest.mark.parametrize("case", [("rgb24", "rgb24"), ("bgr24", "bgra")])
 def test_batch_on_the_rgb_strip_kernel(dev, orc, case):
     """packed RGB at exactly 2:1 batches too: scale_rgb2h_kernel with grid.y = frame"""
