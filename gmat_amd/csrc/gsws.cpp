@@ -476,6 +476,24 @@ static bool yuv2p_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
            (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
 }
 
+// 8-bit 4:2:0 -> YUV444P at exactly 2:1 with identity chroma filters: the luma walker of scale_yuv2p_kernel + a chroma re-layout
+static bool yuv2p444_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t dl = (uintptr_t)ya.dst | (uintptr_t)ya.ds;
+    return c->y2p.ok444 && !c->rangeConv && ya.srcAligned && (dl & 3) == 0 && !ya.prof && ya.dstU && ya.dstV;
+}
+
+static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya);
+// the chroma of one frame: NV12 -> two planes (uv_deinterleave_kernel) or two plane copies
+static int yuv2p444_chroma(const GmatSwsContext *c, const YuvScaleArgs &ya, const uint8_t *u, const uint8_t *v, uint8_t *dU, uint8_t *dV, hipStream_t stream)
+{
+    (void)c;
+    if (ya.nv12) return launch_uv_relayout(1, u, ya.us, nullptr, 0, dU, ya.dsU, dV, ya.dsV, ya.chrSrcW, ya.chrSrcH, stream);
+    int r = launch_copy2d(u, ya.us, dU, ya.dsU, ya.chrSrcW, ya.chrSrcH, stream);
+    return r < 0 ? r : launch_copy2d(v, ya.vs, dV, ya.dsV, ya.chrSrcW, ya.chrSrcH, stream);
+}
+static const char *yuv2p444_name(const YuvScaleArgs &ya) { return ya.nv12 ? "scale_yuv2p_kernel<luma>+uv_deinterleave_kernel" : "scale_yuv2p_kernel<luma>+copy2d"; }
+
 static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     Yuv2pArgs pa;
@@ -768,7 +786,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -780,12 +798,34 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use1x2 = use1x2 && yuv1x2_eligible(c, ya);
         use3x1 = use3x1 && yuv3x1_eligible(c, ya);
         use3x2 = use3x2 && yuv3x2_eligible(c, ya);
+        use444 = use444 && yuv2p444_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
+    if (use444) {
+        // luma of all frames in one launch per 32, the chroma re-layout frame by frame (its kernels take one frame)
+        Yuv2pArgs pa = make_yuv2p_args(c, ya0);
+        pa.lumaOnly = 1; pa.cross = 0; pa.srcDepth = pa.dstDepth = 8;
+        c->lastKernel = yuv2p444_name(ya0);
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            int r = launch_scale_yuv2p(pa, stream, &fr, m);
+            if (r < 0) return r;
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+                if ((r = yuv2p444_chroma(c, ya0, sp[1], ya0.nv12 ? nullptr : sp[2], dp[1], dp[2], stream)) < 0) return r;
+            }
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
     const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
     const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
@@ -1317,6 +1357,17 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
                 c->lastKernel = c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel";
                 r = launch_scale_yuv2s(make_yuv2s_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv2p444_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.dst[0] = ya.dst;
+                Yuv2pArgs pa = make_yuv2p_args(c, ya);
+                pa.lumaOnly = 1; pa.cross = 0; pa.srcDepth = pa.dstDepth = 8;
+                c->lastKernel = yuv2p444_name(ya);
+                if ((r = launch_scale_yuv2p(pa, c->stream, &one, 1)) < 0) break;
+                r = yuv2p444_chroma(c, ya, ya.u, ya.v, ya.dstU, ya.dstV, c->stream);
                 break;
             }
             if (yuv2p_eligible(c, ya)) {

@@ -648,6 +648,22 @@ int yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2pTables &t)
     t = Yuv2pTables();
     const char *off = getenv("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
+    if (g.yuvOut == 2) {
+        // 8-bit 4:2:0 -> planar 4:4:4 at exactly 2:1: the chroma planes keep their size, and when their filters are the identity (one
+        // tap of 16384 / 4096 on sample x: (u << 7 + 64) >> 7 = u) the chroma is a re-layout and only the luma plane is scaled
+        if (!(p.srcFormat == GMAT_PIX_FMT_NV12 || p.srcFormat == GMAT_PIX_FMT_YUV420P) || p.dstFormat != GMAT_PIX_FMT_YUV444P) return 0;
+        if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.srcW % 16 || p.srcW < 64 || p.dstH < 16) return 0;
+        if (p.chrSrcW != p.chrDstW || p.chrSrcH != p.chrDstH || p.chrDstW != p.dstW || p.chrDstH != p.dstH) return 0;
+        if (p.hChr.taps != 1 || g.vChrEff.taps != 1) return 0;
+        for (int x = 0; x < p.hChr.count; x++) if (p.hChr.pos[x] != x || p.hChr.coef[x] != 16384) return 0;
+        for (int y = 0; y < g.vChrEff.count; y++) if (g.vChrEff.pos[y] != y || g.vChrEff.coef[y] != 4096) return 0;
+        if (!filter_is_edge_replication_np(p.hLum, p.srcW, 4, t.hL) || !filter_is_edge_replication_np(g.vLumEff, p.srcH, 4, t.vL)) return 0;
+        for (int y = 0; y < p.dstH; y++) if (g.lumRound[y] != g.lumRound[0]) return 0;
+        for (int y = 0; y < p.chrDstH; y++) if (g.chrRound[y] != g.lumRound[0]) return 0;     // the same dither on every plane
+        t.np = 4; t.lr = g.lumRound[0]; t.snv = p.srcFormat == GMAT_PIX_FMT_NV12;
+        t.ok444 = 1;
+        return 0;
+    }
     if (g.yuvOut != 1) return 0;                                 // 4:2:0 destinations only (8-bit, or 10 bits on the 15-bit lines)
     // 8- or 10-bit 4:2:0 on both sides, interleaved (NV12 | P010LE) or planar (YUV420P | YUV420P10LE) chroma, any pairing
     const bool sNv = p.srcFormat == GMAT_PIX_FMT_NV12 || p.srcFormat == GMAT_PIX_FMT_P010LE;
@@ -696,7 +712,7 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
         // launch: 1 -> 3, 2 -> 3, 4 -> 8, 8 -> 16, 16 -> 16, 32 -> 16..24.  Short launches want short segments (a wave's run
         // time is its segment, and the 3 warm-up row pairs are paid from parallelism that would idle anyway); beyond 16 rows
         // the waves get long enough for the tail of the launch to show.  wave-rows / 8640 is within 3 % of the best everywhere.
-        const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;
+        const long rows = ((long)a.dstH * nstripsL + (a.lumaOnly ? 0L : (long)a.chrDstH * nstripsC * nplC)) * nframes;
         seg = (int)std::min(16L, std::max(3L, (rows + 8639) / 8640));
         // the 6-pair (Lanczos) form pays 5 warm-up row pairs per segment instead of 3: twice the rows (measured best 6 / 12-24 /
         // 32 at 1 / 4 / 32 frames per launch, profiles/r02f_yuv2p_lanczos_rows_sweep.txt)
@@ -711,7 +727,7 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
     a.nsegC = (a.chrDstH + a.segRowsC - 1) / a.segRowsC;
     a.nblkL = a.nsegL * a.nsgL;
-    a.nblk = a.nblkL + a.nsegC * a.nsgC * nplC;
+    a.nblk = a.nblkL + (a.lumaOnly ? 0 : a.nsegC * a.nsgC * nplC);
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
 #define GMAT_P2N(NV_, S_, D_) do { if (a.np == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 6>), grid, block, 0, stream, a, *frames); \
                                    else           hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2p_kernel<NV_, S_, D_, 4>), grid, block, 0, stream, a, *frames); } while (0)

@@ -275,6 +275,7 @@ int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrame
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
 struct Yuv2pTables {
     int ok = 0, srcDepth = 8, dstDepth = 8;                         // 10: P010LE / YUV420P10LE on that side
+    int ok444 = 0;                                                  // 8-bit 4:2:0 -> YUV444P at 2:1: the luma walker alone (the chroma filters are the identity: a re-layout)
     int cross = 0, snv = 0;                                         // mixed chroma layouts (interleaved <-> planar); source interleaved
     int np = 4;                                                     // coefficient pairs per filter: 4 (8 taps) or 6 (Lanczos-3)
     int32_t hL[6] = {0}, hC[6] = {0}, vL[6] = {0}, vC[6] = {0};   // int16 pairs on the odd-aligned window [2x - (np - 1), 2x + np]
@@ -284,6 +285,7 @@ struct Yuv2pArgs {
     int ys, us, vs, nv12;                        // nv12: interleaved chroma (NV12, P010LE)
     int srcDepth, dstDepth;                      // 8 or 10 bits per sample on each side
     int cross;                                   // the destination's chroma layout is the other one (nv12: the SOURCE's is interleaved)
+    int lumaOnly;                                // no chroma workgroups (YUV444P destinations: the caller re-lays the chroma out)
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV;
     int np;                                      // coefficient pairs per filter (4 | 6)

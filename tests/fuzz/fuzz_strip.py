@@ -51,7 +51,9 @@ for case in range(n):
             if rng.random() < 0.7:                              # the geometries scale_yuv2p_kernel takes
                 sw, sh = 16 * rng.randint(4, maxw // 16), 4 * rng.randint(8, 40); dw, dh = sw // 2, sh // 2
         else:            sf, df = rng.choice(RGB3), rng.choice(RGBX)
-        if fam >= 0.45 and fam < 0.8 and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
+        if fam >= 0.45 and fam < 0.8 and rng.random() < 0.12:   # 4:2:0 -> planar 4:4:4 (the luma walker + a chroma re-layout at exactly 2:1)
+            df = "yuv444p"
+        if fam >= 0.45 and fam < 0.8 and df != "yuv444p" and rng.random() < 0.35:   # the 10-bit twins of the 4:2:0 -> 4:2:0 family
             fam4 = ["nv12", "yuv420p", "p010le", "yuv420p10le"]                 # every pairing of chroma layout and sample depth
             sf, df = rng.choice(fam4), rng.choice(fam4)
         if rng.random() < 0.12:                                 # the exact 1:2 UP-scale family (scale_yuv1x2_kernel) and near misses

@@ -393,3 +393,63 @@ def test_mixed_layouts_across_depths(dev, orc, strip_rows, kern_yuv, pair, geom)
 def test_mixed_layouts_across_depths_lanczos(dev, orc, strip_rows, pair):
     strip_rows(0)
     assert _check_cross(dev, orc, pair[0], pair[1], 2064, 48, "lanczos") == strip_name(pair[0], pair[1])
+
+
+# ---- 8-bit 4:2:0 -> planar 4:4:4 at exactly 2:1: the luma walker + a chroma re-layout ----------------------------------------------
+def to444_takes(sw, sh, src_fmt, flags="bicubic"):
+    """the rule of yuv2p_prepare's 4:4:4 branch restated: an 8-bit 4:2:0 source, width a multiple of 16 and >= 64, output height >= 16,
+    a luma filter that fits the 8-sample window; the chroma planes keep their size, their filters are one tap (the identity)"""
+    return (src_fmt in ("nv12", "yuv420p") and sw % 16 == 0 and sw >= 64 and sh % 2 == 0 and sh // 2 >= 16 and
+            flags in ("bicubic", "bilinear", "point", "area", "fast_bilinear", "gauss"))
+
+
+def _check444(dev, orc, sf, sw, sh, flags="bicubic", align=256, extra=0, seed=83):
+    src = synth_planes(orc, sf, sw, sh, seed=seed)
+    want = orc.sws(src, sw, sh, sf, sw // 2, sh // 2, "yuv444p", SWS[flags])
+    d = dev.upload_planes(src, 256)
+    got, pads, kernel = dev.sws(d, sw, sh, sf, sw // 2, sh // 2, "yuv444p", SWS[flags], dst_align=align, dst_extra=extra)
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{kernel} plane {i}: {len(bad)} mismatching bytes, first at {bad[:6].tolist()}"
+        assert (pads[i] == 0xCD).all(), f"{kernel} plane {i}: wrote into the row padding"
+    for p in d:
+        p.free()
+    return kernel
+
+
+@pytest.mark.parametrize("sf", ["nv12", "yuv420p"])
+@pytest.mark.parametrize("geom", [(64, 32), (256, 40), (528, 52), (1040, 36), (2064, 32), (72, 40), (64, 30), (130, 52)])
+def test_420_to_444_at_half_size_on_both_paths(dev, orc, strip_rows, kern_yuv, sf, geom):
+    """nv12 / yuv420p -> yuv444p at exactly 2:1 (the chroma planes keep their size: libswscale's chroma filters are one tap, the
+    identity): scale_yuv2p_kernel's luma walker plus uv_deinterleave_kernel / two plane copies, and the generic plane scaler for what
+    the rule declines — both against the oracle"""
+    sw, sh = geom
+    strip_rows(0)
+    k = _check444(dev, orc, sf, sw, sh)
+    if kern_yuv == "strip" and to444_takes(sw, sh, sf):
+        assert k == ("scale_yuv2p_kernel<luma>+uv_deinterleave_kernel" if sf == "nv12" else "scale_yuv2p_kernel<luma>+copy2d"), k
+    else:
+        assert k.startswith("scale_yuv_kernel"), k
+
+
+@pytest.mark.parametrize("rows", [1, 3, 5, 16, 1000])
+def test_420_to_444_segmentation(dev, orc, strip_rows, rows):
+    strip_rows(rows)
+    assert _check444(dev, orc, "nv12", 528, 52).startswith("scale_yuv2p_kernel<luma>")
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "point", "area", "lanczos"])
+def test_420_to_444_filters(dev, orc, flags):
+    k = _check444(dev, orc, "nv12", 528, 52, flags)
+    if flags == "lanczos":
+        assert k.startswith("scale_yuv_kernel"), k
+
+
+def test_420_to_444_alignment_and_batches(dev, orc, strip_rows):
+    """luma rows off the 4-byte grid go to the generic kernel; the chroma re-layout handles any alignment itself"""
+    strip_rows(0)
+    assert _check444(dev, orc, "nv12", 528, 52, align=4, extra=4).startswith("scale_yuv2p_kernel<luma>")
+    assert _check444(dev, orc, "nv12", 528, 52, align=1, extra=1).startswith("scale_yuv_kernel")
+    for sf in ("nv12", "yuv420p"):
+        k = _run_batch(dev, orc, sf, "yuv444p", 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
+        assert k.startswith("scale_yuv2p_kernel<luma>"), k

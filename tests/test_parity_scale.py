@@ -409,7 +409,12 @@ def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
     want = orc.sws(src, sw, sh, src_fmt, dw, dh, "yuv444p", SWS[flags])
     d = dev.upload_planes(src, 64)
     got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "yuv444p", SWS[flags], dst_align=64)
-    assert kernel.startswith("scale_yuv_kernel") and "yuv444" in kernel, kernel
+    # exactly 2:1 from 8-bit 4:2:0 with a filter on the 8-sample window: the luma walker + a chroma re-layout (test_parity_planes2p.py
+    # restates that rule and runs both paths); everything else here is the generic plane scaler
+    if src_fmt in ("yuv420p", "nv12") and (sw, sh) == (2 * dw, 2 * dh) and sw % 16 == 0 and sw >= 64 and dh >= 16 and flags != "lanczos":
+        assert kernel.startswith("scale_yuv2p_kernel<luma>"), kernel
+    else:
+        assert kernel.startswith("scale_yuv_kernel") and "yuv444" in kernel, kernel
     assert len(got) == 3
     for i, (g, wv) in enumerate(zip(got, want)):
         bad = np.argwhere(g != wv)

@@ -29,7 +29,7 @@ static size_t frame_bytes(int fmt, int w, int h)
     switch (fmt) {
     case GMAT_PIX_FMT_NV12: case GMAT_PIX_FMT_YUV420P: return (size_t)w * h * 3 / 2;
     case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_YUV420P10LE: return (size_t)w * h * 3;
-    case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: return (size_t)w * h * 3;
+    case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: case GMAT_PIX_FMT_YUV444P: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
     default: return 0;
     }
@@ -42,6 +42,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
     case GMAT_PIX_FMT_P010LE: p[0] = b; p[1] = b + (size_t)w * h * 2; s[0] = 2 * w; s[1] = 2 * w; break;
     case GMAT_PIX_FMT_YUV420P10LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)(w / 2) * (h / 2) * 2; s[0] = 2 * w; s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
+    case GMAT_PIX_FMT_YUV444P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)w * h; s[0] = s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: p[0] = b; s[0] = 3 * w; break;
     default: p[0] = b; s[0] = 4 * w; break;
     }
@@ -197,6 +198,7 @@ int main(int argc, char **argv)
         {"land: p010 4K->1080p nv12 (dup)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"land: yuv420p 4K->720p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 1080p->360p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 640, 360, GMAT_SWS_BICUBIC},
+        {"land: nv12 4K->1080p yuv444p bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->720p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: yuv420p 1080p->720p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
