@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     const int xo = X0 + 4 * lane;
     const bool active = xo < a.dstW;
     const int xc = active ? xo : a.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
-    const bool edgeWave = X0 == 0 || X0 + S2_STRIP >= a.dstW;   // wave-uniform: only these waves hold a frame-edge lane
     // luma: bytes [2xc - 4, 2xc + 12) of the row; sources < 0 and >= srcW are the replicated edge samples
     const int wantL = 2 * xc - 4;
     const int offL = min(max(wantL, 0), a.srcW - 16);
@@ -129,6 +128,11 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
         offB = 0; shB = 0;
     }
     const unsigned dstOff = (unsigned)xo * BPP;
+    // which lanes sit on a frame edge, as lane masks: the edge variant of the row loop repairs their registers with SELECTS on these
+    // masks — written as `if (shL < 0) ...` the fix-ups became divergent branches (s_and_saveexec + s_cbranch around each), and the
+    // waves of the two edge strips ran 22-26 % longer per row than the others although they execute only 11 % more VALU instructions
+    // (per-wave time stamps, profiles/r02q_headline_wave_durations.txt); with one wave per slot the launch lasts as long as its slowest wave
+    const bool edgeLL = shL < 0, edgeLR = shL > 0, edgeAL = shA < 0, edgeAR = shA > 0, edgeBR = shB > 0;
 
     // row pointers are wave-uniform (scalar unit), the lane offsets unsigned 32-bit: global_load with an SGPR base
     const unsigned uoffL = (unsigned)offL, uoffA = (unsigned)offA, uoffB = (unsigned)offB;
@@ -155,9 +159,17 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     };
     // frame-edge lanes: shift the dwords into window position and replicate the edge sample
     auto fix_luma = [&](uint4 L, auto edge_c) -> uint4 {
-        if (decltype(edge_c)::value) {
-            if (shL < 0) L = make_uint4(s2_rep(L.x, 0x00000000u), L.x, L.y, L.z);
-            else if (shL > 0) L = make_uint4(L.y, L.z, L.w, s2_rep(L.w, 0x03030303u));
+        constexpr int K = decltype(edge_c)::value;              // 0 interior wave, 1 the frame's left edge, 2 its right edge, 3 both (one strip)
+        if constexpr (K == 1) {
+            const unsigned first = s2_rep(L.x, 0x00000000u);
+            L = make_uint4(edgeLL ? first : L.x, edgeLL ? L.x : L.y, edgeLL ? L.y : L.z, edgeLL ? L.z : L.w);
+        } else if constexpr (K == 2) {
+            const unsigned last = s2_rep(L.w, 0x03030303u);
+            L = make_uint4(edgeLR ? L.y : L.x, edgeLR ? L.z : L.y, edgeLR ? L.w : L.z, edgeLR ? last : L.w);
+        } else if constexpr (K == 3) {
+            const unsigned first = s2_rep(L.x, 0x00000000u), last = s2_rep(L.w, 0x03030303u);
+            L = make_uint4(edgeLL ? first : edgeLR ? L.y : L.x, edgeLL ? L.x : edgeLR ? L.z : L.y,
+                           edgeLL ? L.y : edgeLR ? L.w : L.z, edgeLL ? L.z : edgeLR ? last : L.w);
         }
         return L;
     };
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     // waves carry none of the fix-up moves.
     auto body = [&](const int j, auto slot_c, auto edge_c) {
         constexpr int SLOT = decltype(slot_c)::value;           // j & 3, static after unrolling
-        constexpr bool EDGE = decltype(edge_c)::value;
+        constexpr int EDGE = decltype(edge_c)::value;           // 0 interior, 1 left, 2 right, 3 both: see fix_luma
         const S2Pix &cur = buf[SLOT & 1];
         S2Pix &nxt = buf[(SLOT + 1) & 1];
         // ---- prefetch the next iteration's rows ------------------------------------------------------------
@@ -219,9 +231,13 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
             int pU[5], pV[5];
             if (NV12) {
                 unsigned e[6] = {cur.ca.x, cur.ca.y, cur.ca.z, cur.ca.w, cur.cb.x, cur.cb.y};
-                if (EDGE) {
-                    if (shA < 0) { const unsigned r = s2_rep(e[0], 0x01000100u); e[3] = e[1]; e[2] = e[0]; e[0] = e[1] = r; }
-                    if (shB > 0) { e[4] = e[5] = s2_rep(e[5], 0x03020302u); }
+                if constexpr ((EDGE & 1) != 0) {
+                    const unsigned r = s2_rep(e[0], 0x01000100u), e0 = e[0], e1 = e[1];
+                    e[0] = edgeAL ? r : e0; e[1] = edgeAL ? r : e1; e[2] = edgeAL ? e0 : e[2]; e[3] = edgeAL ? e1 : e[3];
+                }
+                if constexpr ((EDGE & 2) != 0) {
+                    const unsigned rr = s2_rep(e[5], 0x03020302u);
+                    e[4] = edgeBR ? rr : e[4]; e[5] = edgeBR ? rr : e[5];
                 }
 #pragma unroll
                 for (int k = 0; k < 5; k++) {       // samples (2k-3, 2k-2) rel. to xc: bytes 2,3 of e[k] and 0,1 of e[k+1]
@@ -230,13 +246,18 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
                 }
             } else {
                 unsigned fu[3] = {cur.ca.x, cur.ca.y, cur.ca.z}, fv[3] = {cur.cb.x, cur.cb.y, cur.cb.z};
-                if (EDGE) {
-                    if (shA < 0) {
-                        fu[2] = fu[1]; fu[1] = fu[0]; fu[0] = s2_rep(fu[0], 0x00000000u);
-                        fv[2] = fv[1]; fv[1] = fv[0]; fv[0] = s2_rep(fv[0], 0x00000000u);
-                    } else if (shA > 0) {
-                        fu[0] = fu[1]; fu[1] = fu[2]; fu[2] = s2_rep(fu[2], 0x03030303u);
-                        fv[0] = fv[1]; fv[1] = fv[2]; fv[2] = s2_rep(fv[2], 0x03030303u);
+                if constexpr (EDGE != 0) {
+                    const unsigned u0 = fu[0], u1 = fu[1], u2 = fu[2], v0 = fv[0], v1 = fv[1], v2 = fv[2];
+                    if constexpr (EDGE == 1) {
+                        fu[0] = edgeAL ? s2_rep(u0, 0x00000000u) : u0; fu[1] = edgeAL ? u0 : u1; fu[2] = edgeAL ? u1 : u2;
+                        fv[0] = edgeAL ? s2_rep(v0, 0x00000000u) : v0; fv[1] = edgeAL ? v0 : v1; fv[2] = edgeAL ? v1 : v2;
+                    } else if constexpr (EDGE == 2) {
+                        fu[0] = edgeAR ? u1 : u0; fu[1] = edgeAR ? u2 : u1; fu[2] = edgeAR ? s2_rep(u2, 0x03030303u) : u2;
+                        fv[0] = edgeAR ? v1 : v0; fv[1] = edgeAR ? v2 : v1; fv[2] = edgeAR ? s2_rep(v2, 0x03030303u) : v2;
+                    } else {
+                        const unsigned uf = s2_rep(u0, 0x00000000u), ul = s2_rep(u2, 0x03030303u), vf = s2_rep(v0, 0x00000000u), vl = s2_rep(v2, 0x03030303u);
+                        fu[0] = edgeAL ? uf : edgeAR ? u1 : u0; fu[1] = edgeAL ? u0 : edgeAR ? u2 : u1; fu[2] = edgeAL ? u1 : edgeAR ? ul : u2;
+                        fv[0] = edgeAL ? vf : edgeAR ? v1 : v0; fv[1] = edgeAL ? v0 : edgeAR ? v2 : v1; fv[2] = edgeAL ? v1 : edgeAR ? vl : v2;
                     }
                 }
                 pU[0] = s2_pair12(fu[0]); pU[1] = s2_pair30(fu[1], fu[0]); pU[2] = s2_pair12(fu[1]); pU[3] = s2_pair30(fu[2], fu[1]); pU[4] = s2_pair12(fu[2]);
@@ -295,7 +316,12 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
             if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
         }
     };
-    if (edgeWave) run(std::true_type()); else run(std::false_type());
+    // wave-uniform: which frame edges this wave's strip touches
+    const int edgeKind = (X0 == 0 ? 1 : 0) | (X0 + S2_STRIP >= a.dstW ? 2 : 0);
+    if (edgeKind == 0) run(std::integral_constant<int, 0>());
+    else if (edgeKind == 1) run(std::integral_constant<int, 1>());
+    else if (edgeKind == 2) run(std::integral_constant<int, 2>());
+    else run(std::integral_constant<int, 3>());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
