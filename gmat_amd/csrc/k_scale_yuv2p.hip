@@ -121,7 +121,6 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
     const int xo = X0 + 4 * lane;
     const bool active = xo < P.dstW;
     const int xc = active ? xo : P.dstW - 4;                    // idle lanes shadow the last group (loads stay inside the rows)
-    const bool edgeWave = X0 == 0 || X0 + P2_STRIP + (NP == 4 ? 0 : 8) >= P.dstW;     // NP = 6: the window overhangs further
     const int want = 2 * xc - BL;                               // first sample of the window
     const int off = min(max(want, 0), P.srcW - ND * SPD);       // NP = 4: the whole window clamped, then shifted back in registers
     const int sh = want - off;                                  //         -4 at the left plane edge, +4 at the right one
@@ -152,8 +151,13 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
     };
     auto load = [&](int m, P2Row &ra, P2Row &rb, auto edge_c) { load1(2 * m - 1, ra, edge_c); load1(2 * m, rb, edge_c); };
     // horizontal filter of one row: 4 outputs from NP + 3 odd-aligned pairs
+    // EK: 0 interior wave, 1 the plane's left edge, 2 its right edge, 3 both.  The fix-ups of the edge lanes are SELECTS on lane masks,
+    // one per dword when the wave touches one edge only: as `if (sh < 0) ...` on per-lane values they were divergent branches, and the
+    // edge strips' waves ran 22-26 % longer per row than the others (profiles/r02q_headline_wave_durations.txt)
+    const bool edgeL = sh < 0, edgeR = sh > 0;
     auto hrow = [&](const P2Row &R, auto edge_c, int (&s)[4]) {
-        constexpr bool EDGE = decltype(edge_c)::value;
+        constexpr int EK = decltype(edge_c)::value;
+        constexpr bool EDGE = EK != 0;
         unsigned d[ND];
 #pragma unroll
         for (int k = 0; k < ND; k++) d[k] = R.d[k];
@@ -162,21 +166,18 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
             for (int k = 0; k < ND; k++) d[k] = p2_shr6(d[k]);
         }
         if constexpr (EDGE && NP == 4) {
-            if constexpr (S16) {
-                if (sh < 0) {                                   // 4 samples = 2 dwords to the right, first sample replicated
-                    const unsigned r = p2_rep(d[0], 0x01000100u);
+            // the window shifted by SD dwords (4 samples) towards the plane, the edge sample replicated into the dwords that left it
+            constexpr int SD = S16 ? 2 : 1;
+            unsigned o[ND];
 #pragma unroll
-                    for (int k = ND - 1; k >= 2; k--) d[k] = d[k - 2];
-                    d[0] = d[1] = r;
-                } else if (sh > 0) {
-                    const unsigned r = p2_rep(d[ND - 1], 0x03020302u);
+            for (int k = 0; k < ND; k++) o[k] = d[k];
+            const unsigned first = p2_rep(o[0], S16 ? 0x01000100u : 0x00000000u), last = p2_rep(o[ND - 1], S16 ? 0x03020302u : 0x03030303u);
 #pragma unroll
-                    for (int k = 0; k < ND - 2; k++) d[k] = d[k + 2];
-                    d[ND - 2] = d[ND - 1] = r;
-                }
-            } else {
-                if (sh < 0) { const unsigned r = p2_rep(d[0], 0x00000000u); d[3] = d[2]; d[2] = d[1]; d[1] = d[0]; d[0] = r; }
-                else if (sh > 0) { const unsigned r = p2_rep(d[3], 0x03030303u); d[0] = d[1]; d[1] = d[2]; d[2] = d[3]; d[3] = r; }
+            for (int k = 0; k < ND; k++) {
+                const unsigned fromLeft = k < SD ? first : o[k - SD < 0 ? 0 : k - SD], fromRight = k >= ND - SD ? last : o[k + SD >= ND ? ND - 1 : k + SD];
+                if constexpr (EK == 1)      d[k] = edgeL ? fromLeft : o[k];
+                else if constexpr (EK == 2) d[k] = edgeR ? fromRight : o[k];
+                else                        d[k] = edgeL ? fromLeft : edgeR ? fromRight : o[k];
             }
         }
         if constexpr (EDGE && NP != 4) {
@@ -235,8 +236,14 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
             p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
         }
     };
-    if (edgeWave) { load(m0, bufA[0], bufB[0], std::true_type());  p2_rows<NP>(nIter, body, std::true_type()); }
-    else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
+    {
+        const int ek = (X0 == 0 ? 1 : 0) | (X0 + P2_STRIP + (NP == 4 ? 0 : 8) >= P.dstW ? 2 : 0);       // wave-uniform
+        auto go = [&](auto ec) { load(m0, bufA[0], bufB[0], ec); p2_rows<NP>(nIter, body, ec); };
+        if (ek == 0) go(std::integral_constant<int, 0>());
+        else if (ek == 1) go(std::integral_constant<int, 1>());
+        else if (ek == 2) go(std::integral_constant<int, 2>());
+        else go(std::integral_constant<int, 3>());
+    }
 }
 
 // ---- the interleaved UV plane (NV12: 2 bytes a position; P010: one dword): a lane makes 2 UV outputs a row ------------
@@ -251,7 +258,6 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     const int co = X0 + 2 * lane;
     const bool active = co < P.dstW;
     const int cc = active ? co : P.dstW - 2;
-    const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UV + (NP == 4 ? 0 : 8) >= P.dstW;
     const int want = 2 * cc - NP;                               // first position of the window (even)
     // NP = 4, 8-bit: two loads with their own clamps (bytes); NP = 4, 16-bit: one 48-byte window clamped as a whole
     const int offA = max(4 * cc - 8, 0), shA = 4 * cc - 8 - offA;               // -8 bytes: left edge
@@ -290,8 +296,10 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     };
     auto load = [&](int m, P2RowUV &ra, P2RowUV &rb, auto edge_c) { load1(2 * m - 1, ra, edge_c); load1(2 * m, rb, edge_c); };
     // horizontal filter of one row: 2 U and 2 V outputs from NP + 1 odd-aligned pairs per channel
+    const bool edge16L = sh16 < 0, edge16R = sh16 > 0, edgeAL = shA < 0, edgeBR = shB > 0;      // lane masks, see p2_walk_plane
     auto hrow = [&](const P2RowUV &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
-        constexpr bool EDGE = decltype(edge_c)::value;
+        constexpr int EK = decltype(edge_c)::value;
+        constexpr bool EDGE = EK != 0;
         unsigned e[ND];
 #pragma unroll
         for (int k = 0; k < ND; k++) e[k] = R.d[k];
@@ -301,18 +309,25 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
         }
         if constexpr (EDGE && NP == 4) {
             if constexpr (S16) {
-                if (sh16 < 0) {
+                unsigned o[12];                                     // 12 positions (one dword each) shifted by 4, the edge position replicated
 #pragma unroll
-                    for (int k = 11; k >= 4; k--) e[k] = e[k - 4];
-                    e[1] = e[2] = e[3] = e[0];
-                } else if (sh16 > 0) {
+                for (int k = 0; k < 12; k++) o[k] = e[k];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) e[k] = e[k + 4];
-                    e[8] = e[9] = e[10] = e[11];
+                for (int k = 0; k < 12; k++) {
+                    const unsigned fromLeft = k < 4 ? o[0] : o[k - 4 < 0 ? 0 : k - 4], fromRight = k >= 8 ? o[11] : o[k + 4 > 11 ? 11 : k + 4];
+                    if constexpr (EK == 1)      e[k] = edge16L ? fromLeft : o[k];
+                    else if constexpr (EK == 2) e[k] = edge16R ? fromRight : o[k];
+                    else                        e[k] = edge16L ? fromLeft : edge16R ? fromRight : o[k];
                 }
             } else {
-                if (shA < 0) { const unsigned r = p2_rep(e[0], 0x01000100u); e[3] = e[1]; e[2] = e[0]; e[0] = e[1] = r; }
-                if (shB > 0) { e[4] = e[5] = p2_rep(e[5], 0x03020302u); }
+                if constexpr ((EK & 1) != 0) {
+                    const unsigned r = p2_rep(e[0], 0x01000100u), e0 = e[0], e1 = e[1];
+                    e[0] = edgeAL ? r : e0; e[1] = edgeAL ? r : e1; e[2] = edgeAL ? e0 : e[2]; e[3] = edgeAL ? e1 : e[3];
+                }
+                if constexpr ((EK & 2) != 0) {
+                    const unsigned rr = p2_rep(e[5], 0x03020302u);
+                    e[4] = edgeBR ? rr : e[4]; e[5] = edgeBR ? rr : e[5];
+                }
             }
         }
         if constexpr (EDGE && NP != 4) {
@@ -371,8 +386,14 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
             p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
         }
     };
-    if (edgeWave) { load(m0, bufA[0], bufB[0], std::true_type());  p2_rows<NP>(nIter, body, std::true_type()); }
-    else          { load(m0, bufA[0], bufB[0], std::false_type()); p2_rows<NP>(nIter, body, std::false_type()); }
+    {
+        const int ek = (X0 == 0 ? 1 : 0) | (X0 + P2_STRIP_UV + (NP == 4 ? 0 : 8) >= P.dstW ? 2 : 0);    // wave-uniform
+        auto go = [&](auto ec) { load(m0, bufA[0], bufB[0], ec); p2_rows<NP>(nIter, body, ec); };
+        if (ek == 0) go(std::integral_constant<int, 0>());
+        else if (ek == 1) go(std::integral_constant<int, 1>());
+        else if (ek == 2) go(std::integral_constant<int, 2>());
+        else go(std::integral_constant<int, 3>());
+    }
 }
 
 // ---- chroma across layouts: planar U, V planes <-> one interleaved UV plane (NV12 -> YUV420P: a hardware decoder's frames into a
