@@ -396,6 +396,88 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     }
 }
 
+// ---- the interleaved 8-bit UV plane with SHARED loads (8 taps): a lane loads only its own 4 source positions (8 bytes, one load per row)
+// and takes the two dwords either side of them from the lanes beside it by DPP wave shifts.  p2_walk_uv's windows overlap threefold
+// between lanes and cost two loads per row; a wave-level load occupies the CU's address path ~17 cycles whatever its width
+// (tools/ubench/load_rate.hip), which put that path at ~85 % for the chroma waves of an NV12 transcode.  Lanes 0 and 63 only provide:
+// a wave makes 62 x 2 = 124 UV outputs.  A lane's 4 positions are entirely inside or entirely outside the plane (its width is even),
+// so edge replication is "a lane outside presents the edge position" (as in scale_rgb2h_kernel).
+constexpr int P2_STRIP_UVD = 124;
+
+template <bool D16>                             // instantiated for 8-bit destinations only (see the kernel)
+__device__ __forceinline__ void p2_walk_uvd(const P2Plane &P, int X0, int y0, int nOut, int lane)
+{
+    constexpr int NP = 4, SHR = 7;
+    const int co = X0 + 2 * (lane - 1);                         // the lane's 2 UV outputs; lanes 0 / 63: their neighbours' halo
+    const bool stores = lane >= 1 && lane <= 62 && co < P.dstW;
+    const bool outL = co < 0, outR = co >= P.dstW;              // own positions 2 co .. 2 co + 3 lie outside the plane
+    const bool edgeWave = X0 == 0 || X0 + P2_STRIP_UVD >= P.dstW;   // wave-uniform: the wave holds an outside lane
+    const unsigned ob = 4u * (unsigned)min(max(co, 0), P.dstW - 2);     // outside lanes load the plane's first / last 4 positions
+    const int nIter = nOut + NP - 1;
+    const int m0 = y0 - (NP / 2 - 1);
+
+    auto load = [&](int m, uint2 &ra, uint2 &rb) {
+        ra = p2_ld8(P.src + ((unsigned)min(max(2 * m - 1, 0), P.srcH - 1) * (unsigned)P.ss + ob));
+        rb = p2_ld8(P.src + ((unsigned)min(max(2 * m, 0), P.srcH - 1) * (unsigned)P.ss + ob));
+    };
+    auto hrow = [&](const uint2 &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
+        unsigned d0 = R.x, d1 = R.y;
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned first = p2_rep(d0, 0x01000100u), last = p2_rep(d1, 0x03020302u);
+            d0 = outL ? first : outR ? last : d0; d1 = outL ? first : outR ? last : d1;
+        }
+        unsigned e[6];                                          // positions 2 co - 4 .. 2 co + 7, two per dword
+        e[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0, 0x138, 0xF, 0xF, true);      // lane - 1
+        e[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1, 0x138, 0xF, 0xF, true);
+        e[2] = d0; e[3] = d1;
+        e[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d0, 0x130, 0xF, 0xF, true);      // lane + 1
+        e[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d1, 0x130, 0xF, 0xF, true);
+        int pU[NP + 1], pV[NP + 1];
+#pragma unroll
+        for (int k = 0; k < NP + 1; k++) {                      // bytes 2,3 of e[k] and 0,1 of e[k+1]
+            pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
+            pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int au = 0, av = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) { au = p2_dot2(pU[c + k], P.h[k], au); av = p2_dot2(pV[c + k], P.h[k], av); }
+            su[c] = au; sv[c] = av;
+        }
+    };
+
+    int hw[NP][4];                                              // [slot][U0, V0, U1, V1]: (row 2m-1 | row 2m << 16)
+#pragma unroll
+    for (int s = 0; s < NP; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hw[s][j] = 0;
+    uint2 bufA[2], bufB[2];
+    bufA[1] = bufB[1] = make_uint2(0u, 0u);
+    load(m0, bufA[0], bufB[0]);
+
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (j + 1 < nIter) load(m0 + j + 1, bufA[(SLOT + 1) & 1], bufB[(SLOT + 1) & 1]);
+        {
+            int ua[2], va[2], ub[2], vb[2];
+            hrow(bufA[SLOT & 1], edge_c, ua, va);
+            hrow(bufB[SLOT & 1], edge_c, ub, vb);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                hw[SLOT][2 * c + 0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c] >> SHR, ub[c] >> SHR));
+                hw[SLOT][2 * c + 1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c] >> SHR, vb[c] >> SHR));
+            }
+        }
+        if (j >= NP - 1) {
+            const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
+            p2_vstore<D16, NP, SLOT>(P, hw, stores, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+        }
+    };
+    if (edgeWave) p2_rows<NP>(nIter, body, std::true_type());
+    else          p2_rows<NP>(nIter, body, std::false_type());
+}
+
 // ---- chroma across layouts: planar U, V planes <-> one interleaved UV plane (NV12 -> YUV420P: a hardware decoder's frames into a
 // software encoder; YUV420P -> NV12: the reverse).  The UV walker with the other side's load or store stage: a lane still makes 2
 // UV outputs a row and keeps [U0, V0, U1, V1] in its window slots.
@@ -641,12 +723,15 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
     }
     lin -= a.nblkL;
     if (NV) {
+        constexpr bool UVD = !S16 && !D16 && NP == 4;           // 8-bit on both sides, 8 taps: the shared-load walker (124 outputs per wave); measured
+                                                                // 3.99 -> 3.59 us per nv12 -> nv12 frame, but 4.19 -> 4.33 for nv12 -> p010: not there
         const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgC);
-        const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * P2_STRIP_UV;
+        const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * (UVD ? P2_STRIP_UVD : P2_STRIP_UV);
         if (X0 >= a.chrDstW) return;
         const int y0 = seg * a.segRowsC;
         const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, a.vC, a.cr, sHi, dHi};
-        p2_walk_uv<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        if constexpr (UVD) p2_walk_uvd<D16>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        else               p2_walk_uv<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
     } else {
         const int per = a.nsegC * a.nsgC;
         const int pl = __builtin_amdgcn_readfirstlane(lin >= per ? 1 : 0);
@@ -724,7 +809,9 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstripsL = (a.dstW + P2_STRIP - 1) / P2_STRIP;
     const bool uvw = a.nv12 || a.cross;                          // the chroma runs on a UV walker (2 outputs per lane, one "plane" of workgroups)
-    const int nstripsC = uvw ? (a.chrDstW + P2_STRIP_UV - 1) / P2_STRIP_UV : (a.chrDstW + P2_STRIP - 1) / P2_STRIP;
+    const bool uvd = a.nv12 && !a.cross && a.srcDepth == 8 && a.dstDepth == 8 && a.np == 4;   // scale_yuv2p_kernel's shared-load UV walker: 124 outputs per wave
+    const int nstripsC = uvd ? (a.chrDstW + P2_STRIP_UVD - 1) / P2_STRIP_UVD
+                       : uvw ? (a.chrDstW + P2_STRIP_UV - 1) / P2_STRIP_UV : (a.chrDstW + P2_STRIP - 1) / P2_STRIP;
     const int nplC = uvw ? 1 : 2;
     a.nsgL = (nstripsL + 3) / 4; a.nsgC = (nstripsC + 3) / 4;
     int seg = segEnv > 0 ? segEnv : 0;
