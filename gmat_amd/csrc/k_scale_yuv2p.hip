@@ -822,6 +822,16 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
         // the waves get long enough for the tail of the launch to show.  wave-rows / 8640 is within 3 % of the best everywhere.
         const long rows = ((long)a.dstH * nstripsL + (a.lumaOnly ? 0L : (long)a.chrDstH * nstripsC * nplC)) * nframes;
         seg = (int)std::min(16L, std::max(3L, (rows + 8639) / 8640));
+        // Re-measured late in round 2 (profiles/r02u_yuv2p_rows_mod4.txt): segment lengths with rows + 3 a multiple of the row loop's
+        // unroll factor 4 (5, 9, 13, 17) are the good ones — no partial pass through the unrolled body — and short launches want LONGER
+        // segments than the rule above gave: best 5 / 9 / 13 / 17 / 17 / 17 rows at 1 / 2 / 4 / 8 / 16 / 32 frames per launch
+        // (nv12 -> nv12: 8.17 -> 7.37, 6.93 -> 5.77, 4.97 -> 4.61, 4.12 -> 3.96 us per frame).  The 16-bit forms want them longer still:
+        // p010 -> p010 best 9 / 17 / 17 rows at 1 / 4 / 32 frames (13.1 -> 11.0, 8.45 -> 7.20, 6.39 -> 6.26 us per frame).
+        if (a.np == 4) {
+            const long per = (a.srcDepth == 8 && a.dstDepth == 8) ? 2880 : 1440;
+            seg = (int)std::min(17L, std::max(5L, (rows + per - 1) / per));
+            seg = ((seg - 1 + 3) / 4) * 4 + 1;
+        }
         // the 6-pair (Lanczos) form pays 5 warm-up row pairs per segment instead of 3: twice the rows (measured best 6 / 12-24 /
         // 32 at 1 / 4 / 32 frames per launch, profiles/r02f_yuv2p_lanczos_rows_sweep.txt)
         if (a.np == 6) seg = std::min(32, std::max(6, 2 * seg));
