@@ -489,6 +489,10 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
         // 16..48 rows at 32 frames 9.05 us per frame, 64 rows 9.8)
         const long rows = (long)a.dstH * nstrips * nframes;
         seg = (int)std::min(48L, std::max(3L, (rows + 6143) / 6144));
+        // short launches want longer segments than that, of 1 (mod 4) rows (rows + 3 iterations through a loop unrolled by 4):
+        // scale_rgb2h_kernel at 1 / 4 / 8 frames per launch 15.4 -> 14.1, 10.3 -> 9.3, 9.5 -> 9.2 us per frame with 9 / 17 / 17 rows
+        // (profiles/r02u_yuv2p_rows_mod4.txt, second table)
+        if (shared) seg = std::max(seg, (int)std::min(17L, std::max(9L, (rows + 959) / 960)));
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;

@@ -377,7 +377,7 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
     if (!seg) {
         // a wave walks 3 seg + 9 source rows: the 9 warm-up rows argue for long segments, filling the chip for short ones
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
-        seg = (int)std::min(40L, std::max(6L, (rows + 6143) / 6144));
+        seg = (int)std::min(25L, std::max(6L, (rows + 6143) / 6144));    // 25 rows (28 steps: a multiple of the 4 unrolled) at 32 frames: 3.53 us, 28 rows 3.73
     }
     const char *ud = getenv("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
     a.updown = !(ud && !atoi(ud));
