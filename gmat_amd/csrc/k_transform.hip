@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
     constexpr int PITCH = T * BPP + 4;                  // +4 B: odd dword pitch, conflict-light columns
     constexpr int GENERIC_BYTES = T * PITCH + 4 * T * BPP;
     constexpr int PXP = T + 1;                          // dword-pixel tile pitch (BPP 3 / 4)
-    constexpr int FAST_BYTES = BPP >= 3 ? T * PXP * 4 : (BPP == 1 ? T * T : 0);
+    constexpr int FAST_BYTES = BPP >= 3 ? T * PXP * 4 : T * T * BPP;
     constexpr int LDS_BYTES = GENERIC_BYTES > FAST_BYTES ? GENERIC_BYTES : FAST_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
     // Tile order: workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  An output row segment of
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
     const int outH = inW;
     auto srow = [&](int r) { return (dir & 1) ? inH - 1 - (iy0 + r) : iy0 + r; };
     auto orowOf = [&](int c) { return (dir & 2) ? outH - 1 - (ix0 + c) : ix0 + c; };
-    const bool fast = BPP != 2 && tw == T && th == T && aligned &&
+    const bool fast = tw == T && th == T && aligned &&
                       ((((uintptr_t)src | (uintptr_t)ss) & 15) == 0);           // block-uniform
 
     if (BPP >= 3 && fast) {
@@ -222,31 +222,68 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
         }
         return;
     }
-    if (BPP == 1 && fast) {
-        static_assert(BPP != 1 || T == 128, "32 x 32 blocks of 4 x 4 bytes");
-        unsigned *t32 = reinterpret_cast<unsigned *>(smem);                     // [128 rows][32 dwords], row R rotated by R >> 2
+    if (BPP == 2 && fast) {
+        // 2-byte samples (a UV plane, 16-bit gray): blocks of 2 x 2 samples.  One dword of a source row holds two samples;
+        // the dwords of rows 2*rblk and 2*rblk + 1 at column q give the dwords of output rows 2*q and 2*q + 1 at byte 4*rblk,
+        // so a wave's store is one contiguous run per output row.
+        constexpr int DW = T / 2;                                               // dwords per tile row
+        constexpr int CPR = DW / 4, RPP = 256 / CPR, NPASS = T / RPP;           // 16-byte chunks per row, rows per pass, passes
+        unsigned *t32 = reinterpret_cast<unsigned *>(smem);                     // [T rows][DW dwords], row R rotated by R >> 1
         {
-            const int c = tid & 7, rb = tid >> 3;                               // 8 chunks per row, 32 rows per pass
-            uint4 v[4];
+            const int c = tid % CPR, rb = tid / CPR;
+            uint4 v[NPASS];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                v[k] = *reinterpret_cast<const uint4 *>(src + (size_t)srow(rb + 32 * k) * ss + ix0 + 16 * c);
+            for (int k = 0; k < NPASS; k++)
+                v[k] = *reinterpret_cast<const uint4 *>(src + (size_t)srow(rb + RPP * k) * ss + (size_t)ix0 * 2 + 16 * c);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int R = rb + 32 * k, rot = R >> 2;
-                unsigned *row = t32 + R * 32;
-                row[(4 * c + 0 + rot) & 31] = v[k].x; row[(4 * c + 1 + rot) & 31] = v[k].y;
-                row[(4 * c + 2 + rot) & 31] = v[k].z; row[(4 * c + 3 + rot) & 31] = v[k].w;
+            for (int k = 0; k < NPASS; k++) {
+                const int R = rb + RPP * k, rot = R >> 1;
+                unsigned *row = t32 + R * DW;
+                row[(4 * c + 0 + rot) & (DW - 1)] = v[k].x; row[(4 * c + 1 + rot) & (DW - 1)] = v[k].y;
+                row[(4 * c + 2 + rot) & (DW - 1)] = v[k].z; row[(4 * c + 3 + rot) & (DW - 1)] = v[k].w;
+            }
+        }
+        __syncthreads();
+        constexpr int NR = T / 2, QPW = 64 / NR, NIT = DW / (4 * QPW);           // row pairs; q's per wave and pass; passes
+        const int rblk = lane & (NR - 1);
+#pragma unroll 4
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 4 * QPW + wave * QPW + lane / NR;
+            const unsigned d0 = t32[(2 * rblk + 0) * DW + ((q + rblk) & (DW - 1))], d1 = t32[(2 * rblk + 1) * DW + ((q + rblk) & (DW - 1))];
+            const size_t xb = (size_t)iy0 * 2 + 4 * rblk;
+            *reinterpret_cast<unsigned *>(dst + (size_t)orowOf(2 * q + 0) * ds + xb) = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+            *reinterpret_cast<unsigned *>(dst + (size_t)orowOf(2 * q + 1) * ds + xb) = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+        }
+        return;
+    }
+    if (BPP == 1 && fast) {
+        static_assert(BPP != 1 || T == 128 || T == 64, "NB x NB blocks of 4 x 4 bytes, NB = 32 | 16");
+        constexpr int NB = T / 4;                                               // blocks (= dwords) per tile row
+        constexpr int CPR = T / 16, RPP = 256 / CPR, NPASS = T / RPP;          // 16-byte chunks per row, rows per pass of the 256 threads, passes
+        unsigned *t32 = reinterpret_cast<unsigned *>(smem);                     // [T rows][NB dwords], row R rotated by R >> 2
+        {
+            const int c = tid % CPR, rb = tid / CPR;
+            uint4 v[NPASS];
+#pragma unroll
+            for (int k = 0; k < NPASS; k++)
+                v[k] = *reinterpret_cast<const uint4 *>(src + (size_t)srow(rb + RPP * k) * ss + ix0 + 16 * c);
+#pragma unroll
+            for (int k = 0; k < NPASS; k++) {
+                const int R = rb + RPP * k, rot = R >> 2;
+                unsigned *row = t32 + R * NB;
+                row[(4 * c + 0 + rot) & (NB - 1)] = v[k].x; row[(4 * c + 1 + rot) & (NB - 1)] = v[k].y;
+                row[(4 * c + 2 + rot) & (NB - 1)] = v[k].z; row[(4 * c + 3 + rot) & (NB - 1)] = v[k].w;
             }
         }
         __syncthreads();
         // block (rblk, q): source rows 4*rblk .. +3, dword column q  ->  output rows 4*q .. +3, bytes 4*rblk .. +3
-        const int rblk = lane & 31;
+        constexpr int QPW = 64 / NB, NIT = NB / (4 * QPW);                       // q's per wave and pass; passes
+        const int rblk = lane & (NB - 1);
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int q = it * 8 + wave * 2 + (lane >> 5);
-            const unsigned d0 = t32[(4 * rblk + 0) * 32 + ((q + rblk) & 31)], d1 = t32[(4 * rblk + 1) * 32 + ((q + rblk) & 31)],
-                           d2 = t32[(4 * rblk + 2) * 32 + ((q + rblk) & 31)], d3 = t32[(4 * rblk + 3) * 32 + ((q + rblk) & 31)];
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 4 * QPW + wave * QPW + lane / NB;
+            const unsigned d0 = t32[(4 * rblk + 0) * NB + ((q + rblk) & (NB - 1))], d1 = t32[(4 * rblk + 1) * NB + ((q + rblk) & (NB - 1))],
+                           d2 = t32[(4 * rblk + 2) * NB + ((q + rblk) & (NB - 1))], d3 = t32[(4 * rblk + 3) * NB + ((q + rblk) & (NB - 1))];
             const unsigned lo01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), hi01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
             const unsigned lo23 = __builtin_amdgcn_perm(d3, d2, 0x05010400u), hi23 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
             const unsigned o0 = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u), o1 = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
@@ -534,14 +571,20 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
     if (dir < 0 || dir > 3) return GMAT_ERR(EINVAL);
     // 1- and 2-byte samples (the planes of planar / semi-planar YUV) use 128x128 tiles so that a tile row
     // is still >= 128 B of contiguous HBM traffic
-    const int T = bpp <= 2 ? 128 : 64;
+    // ... unless that leaves the chip short of workgroups (a 4K luma plane is 510 tiles of 128 x 128 on 256 CUs, each a single
+    // load -> LDS -> store pass: 12.4 us): 1- and 2-byte planes then take 64 x 64 tiles.  GMAT_TRANSPOSE_TILE = 64 | 128 overrides (measurement).
+    const char *te = getenv("GMAT_TRANSPOSE_TILE");
+    const int tiles128 = ((inW + 127) / 128) * ((inH + 127) / 128);
+    const int T = bpp <= 2 ? ((te ? atoi(te) == 64 : tiles128 < 2048) ? 64 : 128) : 64;
     const int ntiles = ((inW + T - 1) / T) * ((inH + T - 1) / T);
     const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);
     const int aligned = al4(src, ss, dst, ds);
     if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
     else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -19,7 +19,13 @@ def _orc_out(rows, row_bytes):
 @pytest.mark.parametrize("w,h", SIZES + [(256, 128), (300, 140), (128, 192)])
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4])
 @pytest.mark.parametrize("dir", [0, 1, 2, 3])
-def test_transpose(dev, orc, w, h, bpp, dir):
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_transpose(dev, orc, monkeypatch, w, h, bpp, dir, tile):
+    """tile: the 1- and 2-byte plane paths pick 64 x 64 or 128 x 128 tiles by the plane's size; GMAT_TRANSPOSE_TILE forces either"""
+    if tile:
+        if bpp > 2:
+            pytest.skip("only 1- and 2-byte planes have two tile sizes")
+        monkeypatch.setenv("GMAT_TRANSPOSE_TILE", str(tile))
     src = orc.lcg((h, w * bpp), 5)
     want = _orc_out(w, h * bpp)
     orc.L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, dir)

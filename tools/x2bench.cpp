@@ -213,7 +213,8 @@ int main(int argc, char **argv)
     };
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
-                      {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3}};
+                      {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3},
+                      {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2}};
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
     for (const Case &k : cases) {
