@@ -133,6 +133,7 @@ struct GmatSwsContext {
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
+    Rgb2yTables r2ys;                    // strip-walking 2:1 packed RGB -> 8-bit 4:2:0
     Yuv3x2Tables y3x2;                   // strip-walking 3:2 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
@@ -219,6 +220,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv1x2_prepare(c->planYuv, c->ytiling, c->y1x2)) < 0) return r;
     if ((r = yuv3x1_prepare(c->planYuv, c->ytiling, c->y3x1)) < 0) return r;
     if ((r = yuv3x2_prepare(c->planYuv, c->ytiling, c->y3x2)) < 0) return r;
+    if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -582,6 +584,30 @@ static Yuv3x2Args make_yuv3x2_args(const GmatSwsContext *c, const YuvScaleArgs &
     return ea;
 }
 
+// the 2:1 packed RGB -> 4:2:0 kernel: dword loads of the pixels, dword stores on luma and NV12 chroma (2-byte stores on planar chroma)
+static bool rgb2y_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    return c->rgbViaPlanes && c->r2ys.ok && !c->rangeConv && ya.src16 == 3 && ya.srcAligned && (dall & 3) == 0 && !ya.prof;
+}
+
+static Rgb2yArgs make_rgb2y_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Rgb2yArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const Rgb2yTables &t = c->r2ys;
+    a.ss = ya.ys; a.srcW = c->srcW; a.srcH = c->srcH; a.dstW = c->dstW; a.dstH = c->dstH;
+    a.ys = ya.ds; a.us = ya.dsU; a.vs = ya.dsV; a.nv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+    for (int k = 0; k < 4; k++) { a.hL[k] = t.hL[k]; a.hC[k] = t.hC[k]; a.vL[k] = t.vL[k]; }
+    for (int k = 0; k < 9; k++) a.vE[k] = t.vE[k];
+    a.rnd = 64 << 12;
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    const Rgb2YuvConsts &q = ya.r2y;
+    if (ya.rgbBgr) { a.cY01 = pk(q.by, q.gy); a.cY2 = q.ry; a.cU01 = pk(q.bu, q.gu); a.cU2 = q.ru; a.cV01 = pk(q.bv, q.gv); a.cV2 = q.rv; }
+    else           { a.cY01 = pk(q.ry, q.gy); a.cY2 = q.by; a.cU01 = pk(q.ru, q.gu); a.cU2 = q.bu; a.cV01 = pk(q.rv, q.gv); a.cV2 = q.bv; }
+    return a;
+}
+
 // the name the plane-walking kernel reports by sample depths (one template, four instantiations per chroma layout)
 static const char *yuv2p_name(const GmatSwsContext *c)
 {
@@ -786,7 +812,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -799,12 +825,30 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use3x1 = use3x1 && yuv3x1_eligible(c, ya);
         use3x2 = use3x2 && yuv3x2_eligible(c, ya);
         use444 = use444 && yuv2p444_eligible(c, ya);
+        useR2y = useR2y && rgb2y_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
+    if (useR2y) {
+        const Rgb2yArgs ra = make_rgb2y_args(c, ya0);
+        c->lastKernel = "scale_rgb2y_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+                fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = ra.nv12 ? nullptr : dp[2];
+            }
+            int r = launch_scale_rgb2y(ra, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (use444) {
         // luma of all frames in one launch per 32, the chroma re-layout frame by frame (its kernels take one frame)
         Yuv2pArgs pa = make_yuv2p_args(c, ya0);
@@ -1384,6 +1428,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv1x2_kernel";
                 r = launch_scale_yuv1x2(make_yuv1x2_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (rgb2y_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_rgb2y_kernel";
+                r = launch_scale_rgb2y(make_rgb2y_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv3x1_eligible(c, ya)) {

@@ -443,6 +443,211 @@ __global__ __launch_bounds__(256) void scale_rgb2h_kernel(Rgb2sArgs a, Yuv2xFram
     if (edgeWave) run(std::true_type()); else run(std::false_type());
 }
 
+// ---------------------------------------------------------------------------------------------
+// scale_rgb2y_kernel: packed RGB24 / BGR24 -> NV12 / YUV420P at exactly half the size, ONE libswscale context (rgb24ToY_c and
+// rgb24ToUV_half_c, hScale16To15_c with sh = 13 on both planes, yuv2planeX_8_c / yuv2nv12cX_c).  The front end is scale_rgb2h_kernel's:
+// a lane converts its own 8 pixels of a row, lanes 0 and 63 only provide halo samples, DPP shifts hand the neighbours' samples over.
+// Chroma here is decimated on both axes: the pixel-pair samples (4 per lane) go through the 8-tap 2:1 filter to 2 outputs per lane,
+// and the 4:1 vertical filter has 16 taps on rows [4c - 6, 4c + 9].  Rows arrive as pairs (2m - 1, 2m) — the luma window's
+// alignment — so a chroma row collects 9 row pairs m = 2c - 3 .. 2c + 5 (the first and the last half used) in running sums: five
+// chroma rows are open at any time, each pair feeds 5 / 4 of them with one v_dot2 per sample, and no 16-row window is kept.
+// ---------------------------------------------------------------------------------------------
+template <bool NV>
+__global__ __launch_bounds__(256) void scale_rgb2y_kernel(Rgb2yArgs a, Yuv2xFrames fr)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int unit = lin * 4 + wave;                             // (segment, strip) units packed densely: the waves share nothing
+    if (unit >= a.nseg * a.nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / a.nstrips);
+    const int X0 = (unit - seg * a.nstrips) * H2_OUT;
+    const int c0 = seg * a.segRowsC, chrH = a.dstH >> 1;
+    const int nC = min(a.segRowsC, chrH - c0);
+    const int nIter = 2 * nC + 7;                                // row pairs m0 .. m0 + 2 nC + 6
+    const int m0 = 2 * c0 - 3;
+    const uint8_t *ps = fr.y[blockIdx.y];
+    uint8_t *py = fr.dst[blockIdx.y], *pu = fr.dstU[blockIdx.y], *pv = fr.dstV[blockIdx.y];
+
+    const int xo = X0 + 4 * (lane - 1);                          // the lane's 4 luma / 2 chroma output columns; lane 0 / 63: halo only
+    const bool stores = lane >= 1 && lane <= 62 && xo < a.dstW;
+    const bool outL = xo < 0, outR = xo >= a.dstW;               // own pixels 2 xo .. 2 xo + 7 lie outside the frame
+    const bool edgeWave = X0 == 0 || X0 + H2_OUT + 4 > a.dstW;   // wave-uniform: the wave holds an outside lane
+    const unsigned xl = (unsigned)min(max(xo, 0), a.dstW - 4);   // outside lanes load the frame's first / last 8 pixels
+    const unsigned uoff = 6u * xl;
+
+    auto load_row = [&](int r, H2Row &R) {
+        const int rc = min(max(r, 0), a.srcH - 1);
+        const unsigned ro = (unsigned)rc * (unsigned)a.ss + uoff;
+        const uint4 v0 = r2_ld16(ps + ro);
+        const uint2 v1 = r2_ld8(ps + (unsigned)(ro + 16));
+        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+    };
+
+    // One source row: 14-bit Y of the lane's 8 pixels and 14-bit U / V of its 4 pixel pairs -> with the neighbours' samples the
+    // odd-aligned pairs of the 8-tap windows -> 4 luma and 2 + 2 chroma horizontal sums
+    auto convert_row = [&](const H2Row &R, auto edge_c, int (&hs)[4], int (&hu)[2], int (&hv)[2]) {
+        int y[8], u[4], v[4], fs[8], th[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int o = 3 * i, d = o >> 2, b = o & 3;
+            const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
+            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)   // rgb24ToY_c: (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+            y[i] = r2_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // rgb24ToUV_half_c on the sum of pixels 2c, 2c + 1 of the lane: (ru*r + gu*g + bu*b + (256 << 15) + (1 << 9)) >> 10
+            const int fsum = fs[2 * c] + fs[2 * c + 1];             // two 9-bit sums in the halves: no carry across
+            const int tsum = th[2 * c] + th[2 * c + 1];
+            u[c] = r2_dot2(fsum, a.cU01, m24(tsum, a.cU2) + ((256 << 15) + (1 << 9))) >> 10;
+            v[c] = r2_dot2(fsum, a.cV01, m24(tsum, a.cV2) + ((256 << 15) + (1 << 9))) >> 10;
+        }
+        if constexpr (decltype(edge_c)::value) {                  // a lane outside the frame: every sample is the edge sample
+            const int ye = outL ? y[0] : y[7], ue = outL ? u[0] : u[3], ve = outL ? v[0] : v[3];
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = (outL || outR) ? ye : y[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { u[i] = (outL || outR) ? ue : u[i]; v[i] = (outL || outR) ? ve : v[i]; }
+        }
+        {
+            const int A0 = (int)((unsigned)y[1] | ((unsigned)y[2] << 16)), A1 = (int)((unsigned)y[3] | ((unsigned)y[4] << 16)),
+                      A2 = (int)((unsigned)y[5] | ((unsigned)y[6] << 16)), B = (int)((unsigned)y[0] | ((unsigned)y[7] << 16));     // 0 <= y < 2^15
+            const int lA2 = h2_from_left(A2), lB = h2_from_left(B), rA0 = h2_from_right(A0), rB = h2_from_right(B);
+            int p[7];
+            p[0] = lA2;                                                                      // the left lane's samples 5, 6
+            p[1] = (int)__builtin_amdgcn_perm((unsigned)B, (unsigned)lB, 0x05040302u);        // its sample 7 | own sample 0
+            p[2] = A0; p[3] = A1; p[4] = A2;
+            p[5] = (int)__builtin_amdgcn_perm((unsigned)rB, (unsigned)B, 0x05040302u);        // own sample 7 | the right lane's sample 0
+            p[6] = rA0;                                                                      // the right lane's samples 1, 2
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                hs[j] = r2_dot2(p[j + 3], a.hL[3], r2_dot2(p[j + 2], a.hL[2], r2_dot2(p[j + 1], a.hL[1], r2_dot2(p[j], a.hL[0], 0))));
+        }
+        auto chroma_h = [&](const int (&s)[4], int (&h)[2]) {
+            // chroma output c of the lane: pair samples 2c - 3 .. 2c + 4
+            const int A = (int)((unsigned)s[1] | ((unsigned)s[2] << 16)), B = (int)((unsigned)s[0] | ((unsigned)s[3] << 16));
+            const int lA = h2_from_left(A), lB = h2_from_left(B), rA = h2_from_right(A), rB = h2_from_right(B);
+            int p[5];
+            p[0] = lA;                                                                       // the left lane's samples 1, 2
+            p[1] = (int)__builtin_amdgcn_perm((unsigned)B, (unsigned)lB, 0x05040302u);        // its sample 3 | own sample 0
+            p[2] = A;
+            p[3] = (int)__builtin_amdgcn_perm((unsigned)rB, (unsigned)B, 0x05040302u);        // own sample 3 | the right lane's sample 0
+            p[4] = rA;                                                                       // the right lane's samples 1, 2
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                h[j] = r2_dot2(p[j + 3], a.hC[3], r2_dot2(p[j + 2], a.hC[2], r2_dot2(p[j + 1], a.hC[1], r2_dot2(p[j], a.hC[0], 0))));
+        };
+        chroma_h(u, hu);
+        chroma_h(v, hv);
+    };
+
+    int hwY[4][4];                                                // [slot][output]: (row 2m-1 | row 2m << 16), 15-bit lines
+    int acc[5][4];                                                // open chroma rows x (U0, U1, V0, V1)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hwY[s][j] = 0;
+#pragma unroll
+    for (int s = 0; s < 5; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[s][j] = 0;
+
+    H2Row bufA[2], bufB[2];                                       // ping-pong: rows 2m-1 and 2m of the current / next pair
+    load_row(2 * m0 - 1, bufA[0]);
+    load_row(2 * m0, bufB[0]);
+
+    auto body = [&](const int j, auto slot_c, auto edge_c) {
+        constexpr int SLOT = decltype(slot_c)::value;             // j & 3; m = m0 + j is odd when j is even
+        const H2Row ra = bufA[SLOT & 1], rb = bufB[SLOT & 1];
+        const int m = m0 + j;
+        if (j + 1 < nIter) {
+            load_row(2 * m + 1, bufA[(SLOT + 1) & 1]);
+            load_row(2 * m + 2, bufB[(SLOT + 1) & 1]);
+        }
+        int pc[4];                                                // this pair's chroma lines (U0, U1, V0, V1)
+        {
+            int sa[4], sb[4], ua[2], va[2], ub[2], vb[2];
+            convert_row(ra, edge_c, sa, ua, va);
+            convert_row(rb, edge_c, sb, ub, vb);
+            // hScale16To15_c: min(val >> 13, 32767)
+#pragma unroll
+            for (int q = 0; q < 4; q++) hwY[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 13, sb[q] >> 13));
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                pc[q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[q] >> 13, ub[q] >> 13));
+                pc[2 + q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[q] >> 13, vb[q] >> 13));
+            }
+        }
+        if (j >= 5 && j < 5 + 2 * nC) {                           // luma row m - 2: pairs m - 3 .. m sit in slots SLOT + 1 .. SLOT + 4 (mod 4)
+            const int yo = m - 2;
+            unsigned yb[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int Y = a.rnd;
+#pragma unroll
+                for (int k = 0; k < 4; k++) Y = r2_dot2(hwY[(SLOT + 1 + k) & 3][q], a.vL[k], Y);
+                yb[q] = (unsigned)clip_u8_shr(Y, 19);
+            }
+            if (stores) *reinterpret_cast<unsigned *>(py + ((unsigned)yo * (unsigned)a.ys + (unsigned)xo)) = yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24);
+        }
+        if constexpr ((SLOT & 1) == 0) {
+            // m = 2t + 1: the pair opens chroma row t + 2 (taps -, 0), feeds t + 1 (3, 4), t (7, 8), t - 1 (11, 12) and closes t - 2 (15, -)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc[4][q] = r2_dot2(pc[q], a.vE[0], a.rnd);
+                acc[3][q] = r2_dot2(pc[q], a.vE[2], acc[3][q]);
+                acc[2][q] = r2_dot2(pc[q], a.vE[4], acc[2][q]);
+                acc[1][q] = r2_dot2(pc[q], a.vE[6], acc[1][q]);
+                acc[0][q] = r2_dot2(pc[q], a.vE[8], acc[0][q]);
+            }
+            if (j >= 8) {                                         // chroma row (m - 5) / 2 = c0 + (j - 8) / 2
+                const int cy = c0 + ((j - 8) >> 1);
+                const unsigned u0 = (unsigned)clip_u8_shr(acc[0][0], 19), u1 = (unsigned)clip_u8_shr(acc[0][1], 19),
+                               v0 = (unsigned)clip_u8_shr(acc[0][2], 19), v1 = (unsigned)clip_u8_shr(acc[0][3], 19);
+                if (stores) {
+                    if (NV) {
+                        *reinterpret_cast<unsigned *>(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)xo)) = u0 | (v0 << 8) | (u1 << 16) | (v1 << 24);
+                    } else {
+                        *reinterpret_cast<unsigned short *>(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = (unsigned short)(u0 | (u1 << 8));
+                        *reinterpret_cast<unsigned short *>(pv + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = (unsigned short)(v0 | (v1 << 8));
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[s][q] = acc[s + 1][q];
+        } else {
+            // m = 2t: feeds chroma rows t + 1 (taps 1, 2), t (5, 6), t - 1 (9, 10), t - 2 (13, 14)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc[3][q] = r2_dot2(pc[q], a.vE[1], acc[3][q]);
+                acc[2][q] = r2_dot2(pc[q], a.vE[3], acc[2][q]);
+                acc[1][q] = r2_dot2(pc[q], a.vE[5], acc[1][q]);
+                acc[0][q] = r2_dot2(pc[q], a.vE[7], acc[0][q]);
+            }
+        }
+    };
+    auto run = [&](auto edge_c) {
+        for (int j0 = 0; j0 < nIter; j0 += 4) {
+            body(j0, std::integral_constant<int, 0>(), edge_c);
+            if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
 // which of the two kernels a launch uses (GMAT_RGB2_SHARED=0: the one that converts the whole window per lane)
 static bool rgb2_shared() { const char *e = getenv("GMAT_RGB2_SHARED"); return !(e && !atoi(e)); }
 const char *rgb2s_kernel_name() { return rgb2_shared() ? "scale_rgb2h_kernel" : "scale_rgb2s_kernel"; }
@@ -522,6 +727,56 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2s_kernel<3>), grid, block, 0, stream, a, fr); break;
     default: return GMAT_ERR(EINVAL);
     }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// scale_rgb2y_kernel takes a context when all four filters are "the middle row on an edge-replicated line" with the window
+// alignments the kernel assumes, and the geometry is whole lanes
+int rgb2y_prepare(const ScalePlan &p, Rgb2yTables &t)
+{
+    t = Rgb2yTables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P)) return 0;
+    if (p.srcW != 2 * p.dstW || p.srcH != 2 * p.dstH || p.dstW % 4 || p.dstW < 64 || (p.dstH & 1) || p.dstH < 16) return 0;
+    // chroma from pixel pairs at full height, decimated to half the destination on both axes
+    if (!p.chrSrcHSub || p.chrSrcW * 2 != p.srcW || p.chrSrcH != p.srcH || p.chrDstW * 2 != p.dstW || p.chrDstH * 2 != p.dstH) return 0;
+    if (!filter_is_edge_replication(p.hLum, p.srcW, t.hL)) return 0;
+    if (!filter_is_edge_replication(p.hChr, p.chrSrcW, t.hC)) return 0;
+    if (!filter_is_edge_replication(p.vLum, p.srcH, t.vL)) return 0;
+    int32_t vc[8];
+    if (!filter_is_edge_replication_ratio(p.vChr, p.chrSrcH, 4, 6, 8, vc)) return 0;
+    // taps k = 0 .. 15 on rows 4c - 6 + k; row pairs (2m - 1, 2m): pair i of 9 holds taps (2i - 1, 2i)
+    int tap[18] = {0};
+    for (int k = 0; k < 8; k++) { tap[1 + 2 * k] = (int16_t)(vc[k] & 0xFFFF); tap[2 + 2 * k] = (int16_t)((uint32_t)vc[k] >> 16); }
+    for (int i = 0; i < 9; i++) t.vE[i] = (int32_t)((uint32_t)(uint16_t)tap[2 * i] | ((uint32_t)(uint16_t)tap[2 * i + 1] << 16));
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_rgb2y(const Rgb2yArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Rgb2yArgs a = a0;
+    a.nstrips = (a.dstW + H2_OUT - 1) / H2_OUT;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: chroma rows per segment
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        // a segment re-converts 14 source rows of warm-up (7 row pairs) on top of its 4 rows per chroma row; about 3 waves per SIMD.
+        // Measured on 4K -> 1080p (profiles/r02x_rgb2y.txt): 32 frames per launch 45 rows 7.6 us per frame (34: 7.8, 54: 8.4, 8: 8.7);
+        // 8 frames 12 rows 9.7 (8: 11.1, 27: 13.3); 1 frame 5 rows 19.5 (8: 24.7, 2: 25.7)
+        const long rows = (long)(a.dstH >> 1) * a.nstrips * nframes;
+        seg = (int)std::min(64L, std::max(5L, (rows + 3071) / 3072));
+    }
+    a.segRowsC = seg;
+    a.nseg = ((a.dstH >> 1) + seg - 1) / seg;
+    a.nblk = (a.nseg * a.nstrips + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+    if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2y_kernel<true>), grid, block, 0, stream, a, *frames);
+    else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_rgb2y_kernel<false>), grid, block, 0, stream, a, *frames);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

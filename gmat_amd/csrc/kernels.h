@@ -371,6 +371,22 @@ struct Rgb2sArgs {
     int segRows, nseg, nsg, xcdRemap;           // filled by the launcher
     Yuv2RgbConsts y2r;
 };
+// scale_rgb2y_kernel: packed RGB24 / BGR24 at 2:1 into an 8-bit 4:2:0 frame (NV12 / YUV420P), one libswscale context
+struct Rgb2yTables {
+    int ok = 0;
+    int32_t hL[4] = {0}, hC[4] = {0}, vL[4] = {0};   // int16 pairs on the odd-aligned window [2x - 3, 2x + 4] (luma; chroma on pixel PAIRS)
+    int32_t vE[9] = {0};                             // the 16 vertical chroma taps on rows [4c - 6, 4c + 9] as pairs (row 2m - 1, row 2m), m = 2c - 3 .. 2c + 5
+};
+struct Rgb2yArgs {
+    int ss, srcW, srcH, dstW, dstH, ys, us, vs, nv12;
+    int32_t hL[4], hC[4], vL[4], vE[9];
+    int rnd;                                         // 64 << 12: the dither of yuv2planeX_8_c / yuv2nv12cX_c
+    int32_t cY01, cY2, cU01, cU2, cV01, cV2;         // rgb -> yuv coefficients as (first, second) int16 pair and third, in byte order
+    int segRowsC, nseg, nstrips, nblk, xcdRemap;     // filled by the launcher: chroma rows per segment
+};
+int  rgb2y_prepare(const ScalePlan &p, Rgb2yTables &t);
+// frames->y[] = packed source frames, frames->dst / dstU / dstV = the planes (grid.y = frame)
+int  launch_scale_rgb2y(const Rgb2yArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool filter_is_edge_replication(const FilterBank &fb, int srcLen, int32_t (&pairs)[4]);
 bool filter_is_edge_replication_np(const FilterBank &fb, int srcLen, int NP, int32_t *pairs);      // NP pairs on [2x - (NP - 1), 2x + NP]
 bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, int L, int NP, int32_t *pairs);   // R:1, window from R x - L

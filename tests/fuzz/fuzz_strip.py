@@ -75,6 +75,11 @@ for case in range(n):
             sf = rng.choice(RGB3); df = rng.choice(["nv12", "yuv420p"])
             sw = rng.choice([8 * rng.randint(8, maxw // 8), 4 * rng.randint(16, maxw // 4)]); sh = rng.choice([2 * rng.randint(8, 60), rng.randint(8, 99)])
             dw, dh = sw, sh
+        if rng.random() < 0.1:                                  # packed RGB -> 4:2:0 at exactly 2:1 (scale_rgb2y_kernel) and near misses
+            sf = rng.choice(RGB3); df = rng.choice(["nv12", "yuv420p"])
+            dw = rng.choice([4 * rng.randint(16, maxw // 8), 2 * rng.randint(32, maxw // 4)]); dh = rng.choice([2 * rng.randint(8, 50), rng.randint(14, 80)])
+            sw, sh = 2 * dw, 2 * dh
+            if rng.random() < 0.06: sh += 2
         algo = rng.choice(["bicubic", "bicubic", "bilinear", "point", "area", "gauss", "fast_bilinear", "lanczos"])
         cs = rng.choice([None, None, 1, 5, 7]) if df in RGBX and sf in YUV else None
         # the fused convert-then-scale form (setFused(1): scale_rgb2h_kernel<yuv> at exactly 2:1, the tiled kernel otherwise)
@@ -100,7 +105,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3x2", "scale_rgb2h", "rgb2yuv420")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3x2", "scale_rgb2h", "scale_rgb2y", "rgb2yuv420")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

@@ -96,7 +96,7 @@ def test_batch_on_the_2to1_kernel(dev, orc, strip_or_tiled, src_fmt, dst_fmt):
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 96, 40, 144, 60), ("yuv420p", "nv12", 200, 90, 80, 36),
                                   ("yuv444p", "bgra", 64, 32, 64, 32), ("p010le", "nv12", 128, 48, 80, 24),   # (not 2:1: that is the strip kernel's)
                                   ("nv12", "p010le", 128, 48, 96, 40), ("nv12", "yuv444p", 64, 32, 64, 32),
-                                  ("rgb24", "nv12", 128, 48, 64, 24)])
+                                  ("rgb24", "nv12", 128, 48, 80, 24)])               # (at exactly 2:1: scale_rgb2y_kernel, test_parity_rgb2y.py)
 def test_batch_on_the_generic_plane_scaler(dev, orc, case):
     """geometries the 2:1 kernel does not take batch too: scale_yuv_kernel with grid.y = frame"""
     sf, df, sw, sh, dw, dh = case

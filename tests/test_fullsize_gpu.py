@@ -244,6 +244,19 @@ def test_3_to_2_ladder_steps(gpu, orc, fmt, geom, which, monkeypatch):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
+@pytest.mark.parametrize("fmts", [("rgb24", "nv12"), ("bgr24", "yuv420p")])
+def test_4k_rgb_to_1080p_420(gpu, orc, fmts):
+    """a 4K packed RGB frame into a 1080p 4:2:0 one (encoder input) at full size, every plane against the oracle"""
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    src = synth_planes(orc, fmts[0], sw, sh, seed=53)
+    want = orc.sws(src, sw, sh, fmts[0], dw, dh, fmts[1])
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmts[0], dw, dh, fmts[1], dst_align=256)
+    assert k == "scale_rgb2y_kernel", k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 def test_4k_rotate_17_degrees(gpu, orc):
     import math
     w, h, bpp = 3840, 2160, 3
