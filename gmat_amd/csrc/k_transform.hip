@@ -865,11 +865,145 @@ __global__ __launch_bounds__(256) void median3x3_kernel(const uint8_t *src, int 
     }
 }
 
+// ---- the same median without per-byte extraction (round 2) --------------------------------------------------------------
+// A strip walker: a lane owns one DWORD column of a 62-dword strip (lanes 1 .. 62; lanes 0 and 63 carry the halo dwords), a wave
+// walks down a segment of rows two output rows per iteration, its loads running two iterations ahead (the first build loaded a
+// whole 64 x 16 tile up front, as smooth121_kernel does: with every wave of the launch resident at once the chip loaded, then
+// computed, then stored; walking did not change the time, see below).  Per output row the lane splits the new row's dword into its 4
+// bytes once, sorts ITS column's three rows per byte (v_min3 / v_med3 / v_max3) and takes the sorted triples of the columns BPP bytes
+// to its left and right from its own registers or the neighbouring lanes' (DPP wave shifts), instead of extracting and sorting three
+// columns per byte: 53 full-rate instructions per 4 output bytes at 3 bytes per pixel (the kernel above: ~ 190).  The first build
+// did the sorting on two 16-bit fields per register with v_pk_min_u16 / v_pk_max_u16 (56 instructions, 34 of them packed): 19.0 us per
+// 4K rgb24 frame in either form, 7.3 cycles per instruction on average — the packed 16-bit integer min / max issue at half rate.  Borders: a clamp of the row index, and in the tiles on the frame's left / right edge a halo dword
+// holding pixel 0 / pixel w - 1.
+struct MdB { unsigned b[4]; };                               // the 4 bytes of a lane's dword, one per register
+// one instruction each, spelled out: from max(min(a, b), min(max(a, b), c)) the compiler formed v_med3_u32 in a third of the places and
+// four-instruction min / max chains in the rest (81 VALU instructions per row instead of 55)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned md_min3(unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ unsigned md_max3(unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ unsigned md_med3(unsigned a, unsigned b, unsigned c) { unsigned r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+__device__ __forceinline__ unsigned md_min3(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
+__device__ __forceinline__ unsigned md_max3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
+__device__ __forceinline__ unsigned md_med3(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }
+#endif
+// the bytes BPP to the left / right of this lane's four: its own registers renamed, or the neighbouring lane's over a DPP wave shift
+template <int BPP>
+__device__ __forceinline__ void md_sides(const MdB &v, MdB &l, MdB &r)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        l.b[k] = k - BPP >= 0 ? v.b[k - BPP >= 0 ? k - BPP : 0]
+                              : (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.b[(k - BPP + 4) & 3], 0x138, 0xF, 0xF, true);   // lane - 1
+        r.b[k] = k + BPP < 4 ? v.b[k + BPP < 4 ? k + BPP : 0]
+                             : (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.b[(k + BPP - 4) & 3], 0x130, 0xF, 0xF, true);    // lane + 1
+    }
+}
+
+constexpr int MD_TD = 62;                                    // dwords of a strip: lanes 1 .. 62 produce, lanes 0 and 63 carry the halo dwords
+constexpr int MD_Q = 2;                                      // iterations (row pairs) the loads run ahead of their use
+template <int BPP>
+__global__ __launch_bounds__(256) void median3x3s_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h,
+                                                         int segRows, int nseg, int nstrips, int nblk)
+{
+    const int rowDwords = (w * BPP) >> 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // XCD-aware order of the workgroups; (segment, strip) units packed densely, four to a workgroup: the waves share nothing
+    const int chunk = (nblk + 7) >> 3;
+    const int lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (lin >= nblk) return;
+    const int unit = lin * 4 + wave;
+    if (unit >= nseg * nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / nstrips);
+    const int d0 = (unit - seg * nstrips) * MD_TD;
+    const int nd = __builtin_amdgcn_readfirstlane(min(MD_TD, rowDwords - d0));
+    const int yb = seg * segRows, nOut = min(segRows, h - yb);
+    const int nIter = (nOut + 1) >> 1;                       // two output rows per iteration
+    const int di = lane - 1;                                 // this lane's dword of the strip; -1 and nd are the halos
+    const unsigned colOff = 4u * (unsigned)min(max(d0 + di, 0), rowDwords - 1);
+    const bool isL = d0 == 0, isR = d0 + nd == rowDwords;    // wave-uniform: the strip touches the frame's left / right edge
+    const bool mine = di >= 0 && di < nd;
+    // source row s of the segment = frame row yb - 1 + s, clamped (rows past the segment's last are loaded and never used)
+    auto load = [&](int s) { return *reinterpret_cast<const unsigned *>(src + ((unsigned)(min(max(yb - 1 + s, 0), h - 1) * ss) + colOff)); };
+    auto split = [&](unsigned x) {
+        if (isL) {                                           // pixel -1 := pixel 0: the halo dword ends with it
+            const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 1);
+            x = lane == 0 ? a << (8 * (4 - BPP)) : x;
+        }
+        if (isR) {                                           // pixel w := pixel w - 1: the halo dword starts with it
+            const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)x, nd);
+            x = lane == nd + 1 ? last >> (8 * (4 - BPP)) : x;
+        }
+        return MdB{{x & 0xFFu, (x >> 8) & 0xFFu, (x >> 16) & 0xFFu, x >> 24}};
+    };
+    // one output row: the sorted triple (lo, md, hi) of this lane's column -> with the neighbours' triples the median of nine
+    auto emit = [&](int r, bool st, const MdB &x0, const MdB &x1, const MdB &x2) {
+        MdB lo, md, hi, ll, lr, ml, mr, hl, hr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { lo.b[k] = md_min3(x0.b[k], x1.b[k], x2.b[k]); md.b[k] = md_med3(x0.b[k], x1.b[k], x2.b[k]); hi.b[k] = md_max3(x0.b[k], x1.b[k], x2.b[k]); }
+        md_sides<BPP>(lo, ll, lr);
+        md_sides<BPP>(md, ml, mr);
+        md_sides<BPP>(hi, hl, hr);
+        unsigned m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            m[k] = md_med3(md_max3(ll.b[k], lo.b[k], lr.b[k]), md_med3(ml.b[k], md.b[k], mr.b[k]), md_min3(hl.b[k], hi.b[k], hr.b[k]));
+        if (st) *reinterpret_cast<unsigned *>(dst + ((unsigned)((yb + r) * ds) + 4u * (unsigned)(d0 + di))) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+    };
+    MdB a0 = split(load(0)), a1 = split(load(1));
+    unsigned q[MD_Q][2];                                     // raw dwords of the rows 2i + 2, 2i + 3 of the next MD_Q iterations
+#pragma unroll
+    for (int k = 0; k < MD_Q; k++) { q[k][0] = load(2 * k + 2); q[k][1] = load(2 * k + 3); }
+    auto body = [&](const int i, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;         // i % MD_Q, static after unrolling
+        // output row 2i: source rows 2i .. 2i + 2; output row 2i + 1: rows 2i + 1 .. 2i + 3
+        const unsigned r2 = q[SLOT][0], r3 = q[SLOT][1];
+        q[SLOT][0] = load(2 * (i + MD_Q) + 2); q[SLOT][1] = load(2 * (i + MD_Q) + 3);
+        const MdB a2 = split(r2), a3 = split(r3);
+        emit(2 * i, mine, a0, a1, a2);
+        emit(2 * i + 1, mine && 2 * i + 1 < nOut, a1, a2, a3);
+        a0 = a2; a1 = a3;
+    };
+    static_assert(MD_Q == 2, "the loop below is unrolled by MD_Q");
+    for (int i0 = 0; i0 < nIter; i0 += MD_Q) {
+        body(i0, std::integral_constant<int, 0>());
+        if (i0 + 1 < nIter) body(i0 + 1, std::integral_constant<int, 1>());
+    }
+}
+
+// the strip form's conditions: rows of whole dwords, dword-aligned pointers and pitches, at least 4 pixels a row
+static bool median3x3s_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp)
+{
+    const bool off = getenv("GMAT_NO_MEDIAN_STRIP") != nullptr;                     // A/B switch for the benches and tests
+    return !off && bpp >= 1 && bpp <= 4 && ((w * bpp) & 3) == 0 && w >= 4 && al4(src, ss, dst, ds) && (int64_t)ss * h < (1ll << 31) &&
+           (int64_t)ds * h < (1ll << 31);
+}
+
 int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return 0;
     if (!src || !dst) return GMAT_ERR(EINVAL);
     const int rb = w * bpp;
+    if (median3x3s_ok(src, ss, dst, ds, w, h, bpp)) {
+        const int nstrips = ((rb >> 2) + MD_TD - 1) / MD_TD;
+        const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override: output rows per segment
+        int seg = segStr ? atoi(segStr) : 0;
+        // whole row pairs; measured on 4K rgb24 / gray (profiles/r02y_median.txt): 6 - 8 rows 16.4 - 16.7 / 6.9 - 7.0 us, 16 rows 17.5 / 8.2, 32 rows 19.4 / 10.6
+        if (seg <= 0) seg = (int)std::min(64L, std::max(8L, ((long)h * nstrips + 12287) / 12288)) & ~1;
+        seg = std::max(seg, 1);
+        const int nseg = (h + seg - 1) / seg, nblk = (nseg * nstrips + 3) / 4;
+        const dim3 g(8 * ((nblk + 7) / 8)), b(256);
+        switch (bpp) {
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<1>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<2>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<3>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<4>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((rb + 255) / 256, (h + 7) / 8), block(256);          // 4 thread rows x 2 output rows per block
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
     switch (bpp) {

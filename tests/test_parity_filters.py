@@ -472,9 +472,17 @@ def test_filter_layer_scale_from_p01x(dev, orc, src_fmt):
 
 
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4])
-@pytest.mark.parametrize("w,h", [(64, 16), (130, 35), (5, 3), (1, 1), (2, 7), (259, 4)])
-def test_median3x3(dev, orc, w, h, bpp):
-    """smooth type=median at 3x3: per channel the 5th smallest of the window, edges clamped (vf_median.c at radius 1)"""
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 35), (5, 3), (1, 1), (2, 7), (259, 4), (200, 70), (68, 129), (520, 9), (4, 65), (248, 3)])
+@pytest.mark.parametrize("kernel", ["strip", "bytes"])
+def test_median3x3(dev, orc, monkeypatch, w, h, bpp, kernel):
+    """smooth type=median at 3x3: per channel the 5th smallest of the window, edges clamped (vf_median.c at radius 1).  Both kernels:
+    median3x3s_kernel (rows of whole dwords on dword-aligned planes: the first alignment below) and the byte-wise median3x3_kernel
+    (everything else, and everything under GMAT_NO_MEDIAN_STRIP); the sizes cross the strip kernel's 62-dword / 64-row tiles, end
+    on a single row of a tile, and have rows shorter than a tile"""
+    if kernel == "bytes":
+        monkeypatch.setenv("GMAT_NO_MEDIAN_STRIP", "1")
+    else:
+        monkeypatch.delenv("GMAT_NO_MEDIAN_STRIP", raising=False)
     src = orc.lcg((h, w * bpp), 111 + bpp)
     want = np.zeros_like(src)
     orc.L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
@@ -491,6 +499,25 @@ def test_median3x3(dev, orc, w, h, bpp):
         assert (out.download() == want).all()
         assert (out.download(with_padding=True)[:, out.row_bytes:] == 0xCD).all()
         d.free(); out.free()
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 7, 10, 64])
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+def test_median3x3_segmentation_does_not_change_the_result(dev, orc, monkeypatch, bpp, rows):
+    """median3x3s_kernel walks segments of `rows` output rows two at a time with loads four iterations ahead: odd lengths end on
+    half a row pair, short ones finish inside the first unrolled group"""
+    from harness import DevPlane
+    monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+    w, h = 252, 37
+    src = orc.lcg((h, w * bpp), 131 + bpp)
+    want = np.zeros_like(src)
+    orc.L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
+    d = dev.upload_planes([src], 64, 0)[0]
+    out = DevPlane(dev, h, w * bpp, ((w * bpp + 63) // 64) * 64)
+    assert dev.lib.gmat_median3x3(d.ptr, d.stride, out.ptr, out.stride, w, h, bpp, None) == 0
+    assert (out.download() == want).all()
+    assert (out.download(with_padding=True)[:, out.row_bytes:] == 0xCD).all()
+    d.free(); out.free()
 
 
 def test_filter_layer_smooth_median(dev, orc):

@@ -18,7 +18,18 @@ __device__ __forceinline__ int op(int a, int b, int c)
     else if constexpr (OP == 4) return min(max(c, a), b);                           // v_med3_i32
     else if constexpr (OP == 5) return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
     else if constexpr (OP == 6) return c * a + b;                                   // v_mad / v_mul_lo
-    else return (c >> 7) ^ a;
+    else if constexpr (OP == 7) return (c >> 7) ^ a;
+    else if constexpr (OP == 8) return __builtin_amdgcn_update_dpp(0, c, 0x138, 0xF, 0xF, true) + 0 * (a + b);   // v_mov_b32_dpp wave_shr:1
+    else if constexpr (OP == 9) return __builtin_amdgcn_update_dpp(0, c, 0x130, 0xF, 0xF, true) + 0 * (a + b);   // wave_shl:1
+    else if constexpr (OP == 10) return __builtin_amdgcn_update_dpp(0, c, 0x111, 0xF, 0xF, true) + 0 * (a + b);  // row_shr:1
+    else if constexpr (OP == 11) return __builtin_amdgcn_update_dpp(0, c, 0x101, 0xF, 0xF, true) + 0 * (a + b);  // row_shl:1
+    else if constexpr (OP == 12) return __builtin_amdgcn_update_dpp(0, c, 0x13C, 0xF, 0xF, true) + 0 * (a + b);  // wave_ror:1
+    else if constexpr (OP == 13) return __builtin_amdgcn_ds_bpermute(a & 0xFC, c) + 0 * b;                       // ds_bpermute_b32
+    else if constexpr (OP == 14) {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, a))) + 0 * b;   // v_pk_min_u16
+    }
+    else return (int)min(min((unsigned)c, (unsigned)a), (unsigned)b);                                           // v_min3_u32
 }
 
 template <int OP>
@@ -75,6 +86,14 @@ int main()
         run<4>("v_max_i32 + v_min_i32 (2 instr)", w);
         run<6>("v_mul_lo + add", w);
         run<7>("v_ashr + xor (2 instr)", w);
+        run<8>("v_mov_b32_dpp wave_shr:1", w);
+        run<9>("v_mov_b32_dpp wave_shl:1", w);
+        run<10>("v_mov_b32_dpp row_shr:1", w);
+        run<11>("v_mov_b32_dpp row_shl:1", w);
+        run<12>("v_mov_b32_dpp wave_ror:1", w);
+        run<13>("ds_bpermute_b32", w);
+        run<14>("v_pk_min_u16", w);
+        run<15>("v_min3_u32", w);
     }
     return 0;
 }

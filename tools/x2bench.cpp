@@ -143,6 +143,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         case 1: CK(gmat_smooth3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, m, 1.0f / 16, 0.0f, stream)); break;
         case 2: CK(gmat_transpose(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, 0, stream)); break;
         case 3: CK(gmat_flip(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, 1, stream)); break;
+        case 4: CK(gmat_median3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, stream)); break;
         }
     };
     for (int i = 0; i < NSET; i++) launch(i);
@@ -215,7 +216,8 @@ int main(int argc, char **argv)
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
                       {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3},
-                      {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2}};
+                      {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2},
+                      {"op: median3x3 4K rgb24", 4, 3}, {"op: median3x3 4K gray", 4, 1}};
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
     for (const Case &k : cases) {
