@@ -26,13 +26,15 @@ def strides(rb):
 
 
 for case in range(n):
-    op = rng.choice(["transpose", "flip", "smooth", "rotate", "fused", "chained", "rgb2yuv", "p01x", "cs"])
+    op = rng.choice(["transpose", "flip", "smooth", "rotate", "fused", "median", "chained", "rgb2yuv", "p01x", "cs"])
     w, h = rng.randint(1, 330), rng.randint(1, 200)
     bpp = rng.choice([1, 2, 3, 4])
     desc = (case, op, w, h, bpp)
     try:
-        if op in ("transpose", "flip", "smooth", "rotate", "fused"):
+        if op in ("transpose", "flip", "smooth", "rotate", "fused", "median"):
             if op == "fused": bpp = rng.choice([3, 4])
+            if op == "median" and rng.random() < 0.7: w = 4 * rng.randint(1, 130)      # rows of whole dwords: median3x3s_kernel on aligned planes
+            if op == "transpose" and rng.random() < 0.4: w, h = 64 * rng.randint(1, 5), 64 * rng.randint(1, 4)   # whole tiles: the dword fast paths
             src = orc.lcg((h, w * bpp), 500 + case)
             tr = op in ("transpose", "fused")
             ow, oh = (h, w) if tr else (w, h)
@@ -61,6 +63,9 @@ for case in range(n):
                 desc = desc + (list(m), rdiv, bias)
                 L.orc_conv3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, m, rdiv, bias)
                 r = lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, rdiv, bias, None)
+            elif op == "median":
+                L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
+                r = lib.gmat_median3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, None)
             elif op == "rotate":
                 ang = math.radians(rng.uniform(-360, 360)); bil = rng.randint(0, 1)
                 fill = np.array([rng.randint(0, 255) for _ in range(4)], np.uint8)
