@@ -133,6 +133,7 @@ struct GmatSwsContext {
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
+    Yuv3rTables y3r;                     // strip-walking 3:1 NV12 -> packed RGB
     Rgb2yTables r2ys;                    // strip-walking 2:1 packed RGB -> 8-bit 4:2:0
     Yuv3x2Tables y3x2;                   // strip-walking 3:2 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
@@ -220,6 +221,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv1x2_prepare(c->planYuv, c->ytiling, c->y1x2)) < 0) return r;
     if ((r = yuv3x1_prepare(c->planYuv, c->ytiling, c->y3x1)) < 0) return r;
     if ((r = yuv3x2_prepare(c->planYuv, c->ytiling, c->y3x2)) < 0) return r;
+    if ((r = yuv3r_prepare(c->planYuv, c->ytiling, c->y3r)) < 0) return r;
     if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
@@ -584,6 +586,33 @@ static Yuv3x2Args make_yuv3x2_args(const GmatSwsContext *c, const YuvScaleArgs &
     return ea;
 }
 
+// the 3:1 NV12 -> packed RGB kernel: dword loads on both planes, the tiled kernel's destination rule (4- / 16-byte stores)
+static bool yuv3r_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    return c->y3r.ok && !c->rangeConv && ya.nv12 && ya.srcAligned && ya.dstAligned && !ya.prof;
+}
+
+static Yuv3rArgs make_yuv3r_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv3rArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const Yuv3rTables &t = c->y3r;
+    a.ys = ya.ys; a.us = ya.us; a.dstW = ya.dstW; a.dstH = ya.dstH; a.ds = ya.ds; a.dstFormat = ya.dstFormat;
+    for (int k = 0; k < 6; k++) { a.hL[k] = t.hL[k]; a.hC[k] = t.hC[k]; }
+    int cl[12];                                          // the 11 vertical luma taps (slot 11: 0)
+    for (int k = 0; k < 6; k++) { cl[2 * k] = (int16_t)(t.vL[k] & 0xFFFF); cl[2 * k + 1] = (int16_t)((uint32_t)t.vL[k] >> 16); }
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    a.vP[0] = pk(cl[8], cl[9]); a.vP[1] = pk(cl[5], cl[6]); a.vP[2] = pk(cl[2], cl[3]); a.vP[3] = pk(0, cl[0]);
+    a.vS[0] = cl[10]; a.vS[1] = cl[7]; a.vS[2] = cl[4]; a.vS[3] = cl[1];
+    for (int k = 0; k < 3; k++) {
+        a.cA[2 * k] = (int16_t)(t.vCA[k] & 0xFFFF); a.cA[2 * k + 1] = (int16_t)((uint32_t)t.vCA[k] >> 16);
+        a.cB[2 * k] = (int16_t)(t.vCB[k] & 0xFFFF); a.cB[2 * k + 1] = (int16_t)((uint32_t)t.vCB[k] >> 16);
+        a.cS[2 * k] = (int16_t)(t.vCS[k] & 0xFFFF); a.cS[2 * k + 1] = (int16_t)((uint32_t)t.vCS[k] >> 16);
+    }
+    a.lr = t.lr; a.cr = t.cr; a.y2r = ya.y2r;
+    return a;
+}
+
 // the 2:1 packed RGB -> 4:2:0 kernel: dword loads of the pixels, dword stores on luma and NV12 chroma (2-byte stores on planar chroma)
 static bool rgb2y_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
@@ -812,7 +841,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -826,12 +855,27 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use3x2 = use3x2 && yuv3x2_eligible(c, ya);
         use444 = use444 && yuv2p444_eligible(c, ya);
         useR2y = useR2y && rgb2y_eligible(c, ya);
+        use3r = use3r && yuv3r_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
+    if (use3r) {
+        const Yuv3rArgs ta = make_yuv3r_args(c, ya0);
+        c->lastKernel = "scale_yuv3r_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            int r = launch_scale_yuv3r(ta, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (useR2y) {
         const Rgb2yArgs ra = make_rgb2y_args(c, ya0);
         c->lastKernel = "scale_rgb2y_kernel";
@@ -1428,6 +1472,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv1x2_kernel";
                 r = launch_scale_yuv1x2(make_yuv1x2_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv3r_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.dst[0] = ya.dst;
+                c->lastKernel = "scale_yuv3r_kernel";
+                r = launch_scale_yuv3r(make_yuv3r_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (rgb2y_eligible(c, ya)) {

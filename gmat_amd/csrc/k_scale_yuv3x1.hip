@@ -337,6 +337,244 @@ __global__ __launch_bounds__(256) D3_FOUR_WAVES void scale_yuv3x1_kernel(Yuv3x1A
 }
 
 // ---------------------------------------------------------------------------------------------
+// scale_yuv3r_kernel: NV12 at a third of the size into packed RGB (4K -> 720p, 1080p -> 360p: a decoder's frame into a network's
+// input), ONE libswscale context: hScale8To15_c on both planes, yuv2rgb_X_c's vertical sums (>> 19) and table stage (output.c:1680-1731).
+// An RGB destination keeps its chroma at half the output width and full output height, so chroma is 3:1 horizontally — the lane's
+// window and filter of the UV walker above — and 3:2 vertically (k_scale_yuv3x2.hip: 6 taps, even rows [3k - 2, 3k + 3] with A, odd
+// rows [3k - 1, 3k + 4] with B, output row 1 with the table's own row S).  A lane makes 4 pixels of an output row: 4 luma sums from its
+// 20-byte window, 2 chroma pairs from its 32-byte UV window.  Both vertical filters run as RUNNING SUMS instead of rings of rows:
+// step T takes luma rows 6T - 5 .. 6T and chroma rows 3T - 2 .. 3T; a luma triple (3u - 2, 3u - 1, 3u) feeds the four open output
+// rows u - 2 .. u + 1 (the first two rows as a pair through v_dot2, the third by v_mad_i32_i24) and closes row u - 2; a chroma row
+// feeds four open rows; output rows 2T - 3 and 2T - 2 leave in the middle and at the end of the step.  Accumulator slots are static
+// after unrolling two steps.
+// ---------------------------------------------------------------------------------------------
+// GMAT_Y3R_FOUR_WAVES (a build-time A/B): bound the kernel to 128 VGPRs; it takes 160 unbounded (3 waves per SIMD, no scratch)
+#if defined(GMAT_Y3R_FOUR_WAVES)
+#define D3R_BOUND D3_FOUR_WAVES
+#else
+#define D3R_BOUND
+#endif
+template <int DST>
+__global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    __shared__ int2 lutV[256], lutU[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        // term_R = lutV[V].x, term_G = lutV[V].y + lutU[U].x, term_B = lutU[U].y; channel = byte 2 of clamp(term + Y * cy, 0, 0xFFFFFF)
+        const Yuv2RgbConsts &k = a.y2r;
+        lutV[tid] = make_int2(k.base + m24(k.offR + (m24(tid, k.crv) >> 16), k.cy), m24(m24(tid, k.cgv) >> 16, k.cy));
+        lutU[tid] = make_int2(k.base + m24(k.offG + (m24(tid, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(tid, k.cbu) >> 16), k.cy));
+        __syncthreads();
+    }
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int unit = lin * 4 + wave;                             // (segment, strip) units packed densely
+    if (unit >= a.nseg * a.nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / a.nstrips);
+    const int X0 = (unit - seg * a.nstrips) * D3_STRIP;
+    const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);          // y0 is even
+    const int T0 = y0 >> 1, nT = ((y0 + nOut + 2) >> 1) - T0 + 1;
+    const int srcW = 3 * a.dstW, srcH = 3 * a.dstH, chrH = srcH >> 1;
+    const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y];
+    uint8_t *pd = fr.dst[blockIdx.y];
+
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 4;                     // idle lanes shadow the last group
+    const bool edgeWave = X0 == 0 || 3 * (X0 + D3_STRIP) + 16 > srcW;
+    const bool isLeft = xc == 0, isRight = xc == a.dstW - 4;
+    const unsigned boL = (unsigned)(3 * xc - 4), lboL = boL + (isLeft ? 4u : 0u) - (isRight ? 4u : 0u);
+    const int cc = xc >> 1;                                      // first of the lane's two chroma positions
+    const unsigned boC = 2u * (unsigned)(3 * cc - 4), lboC = boC + (isLeft ? 8u : 0u) - (isRight ? 12u : 0u);
+    D3Plane PL, PC;                                              // only the horizontal taps are read through these
+#pragma unroll
+    for (int k = 0; k < 6; k++) { PL.h[k] = a.hL[k]; PC.h[k] = a.hC[k]; }
+
+    auto loadL = [&](int row, unsigned (&d)[5], auto edge_c) {
+        const unsigned o = (unsigned)min(max(row, 0), srcH - 1) * (unsigned)a.ys;
+        const uint8_t *p = py + (o + (decltype(edge_c)::value ? lboL : boL));
+        const uint4 t = d3_ld16(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        d[4] = d3_ld4(p + 16);
+    };
+    auto loadC = [&](int row, unsigned (&d)[8], auto edge_c) {
+        const unsigned o = (unsigned)min(max(row, 0), chrH - 1) * (unsigned)a.us;
+        const uint8_t *p = puv + (o + (decltype(edge_c)::value ? lboC : boC));
+        const uint4 t = d3_ld16(p);
+        const uint4 u = d3_ld16(p + 16);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w;
+    };
+    // hScale8To15_c of a luma row: the lane's 4 sums (before >> 7)
+    auto hrowL = [&](const unsigned (&src)[5], auto edge_c, int (&s)[4]) {
+        unsigned d[5] = {src[0], src[1], src[2], src[3], src[4]};
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned first = d3_rep(src[0], 0x00000000u), last = d3_rep(src[4], 0x03030303u);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const unsigned fromLeft = i == 0 ? first : src[i - 1], fromRight = i == 4 ? last : src[i + 1];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        s[0] = d3_hsum<0>(PL, d); s[1] = d3_hsum<1>(PL, d); s[2] = d3_hsum<2>(PL, d); s[3] = d3_hsum<3>(PL, d);
+    };
+    // ... of a chroma row: U0 V0 U1 V1 as 15-bit lines (>> 7, min 32767)
+    auto hrowC = [&](const unsigned (&src)[8], auto edge_c, int (&s)[4]) {
+        unsigned d[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = src[i];
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned first = d3_rep(src[0], 0x01000100u), last = d3_rep(src[7], 0x03020302u);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned fromLeft = i < 2 ? first : src[i - 2], fromRight = i > 4 ? last : src[i + 3];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        int u0 = 0, v0 = 0, u1 = 0, v1 = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            u0 = d3_dot2((int)__builtin_amdgcn_perm(0u, d[k], 0x0C020C00u), PC.h[k], u0);
+            v0 = d3_dot2((int)__builtin_amdgcn_perm(0u, d[k], 0x0C030C01u), PC.h[k], v0);
+            u1 = d3_dot2((int)__builtin_amdgcn_perm(d[k + 2], d[k + 1], 0x0C040C02u), PC.h[k], u1);
+            v1 = d3_dot2((int)__builtin_amdgcn_perm(d[k + 2], d[k + 1], 0x0C050C03u), PC.h[k], v1);
+        }
+        s[0] = min(u0 >> 7, 32767); s[1] = min(v0 >> 7, 32767); s[2] = min(u1 >> 7, 32767); s[3] = min(v1 >> 7, 32767);
+    };
+
+    int accL[4][4], accC[4][4];                                  // [slot][sample]: luma 4 columns; chroma U0 V0 U1 V1
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) accL[s][q] = accC[s][q] = 0;
+    unsigned bufL[2][3][5], bufC[3][8];
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    // one RGB row: yuv2rgb_X_c_template's sums (Y unclipped, U / V clamped by the tables' headroom = clip_u8) and table stage
+    auto emit = [&](int yo, const int (&YS)[4], const int (&CS)[4]) {
+        if (yo < y0 || yo >= y0 + nOut) return;                  // wave-uniform
+        const int iU[2] = {clip_u8_shr(CS[0], 19), clip_u8_shr(CS[2], 19)}, iV[2] = {clip_u8_shr(CS[1], 19), clip_u8_shr(CS[3], 19)};
+        unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int2 tv = lutV[iV[c]], tu = lutU[iU[c]];
+            const int tr = BGR ? tu.y : tv.x, tg = tv.y + tu.x, tb = BGR ? tv.x : tu.y;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int q = 2 * c + h;
+                const int yc = m24(YS[q] >> 19, a.y2r.cy);
+                c0[q] = (unsigned)min(max(tr + yc, 0), 0xFFFFFF);
+                c1[q] = (unsigned)min(max(tg + yc, 0), 0xFFFFFF);
+                c2[q] = (unsigned)min(max(tb + yc, 0), 0xFFFFFF);
+            }
+        }
+        if (active) {
+            uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+#define D3_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+            if (BPP == 4) {
+                uint4 o4;
+                o4.x = D3_B2PAIR(c0[0], c1[0]) | (D3_B2PAIR(c2[0], 0u) << 16) | 0xFF000000u;
+                o4.y = D3_B2PAIR(c0[1], c1[1]) | (D3_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
+                o4.z = D3_B2PAIR(c0[2], c1[2]) | (D3_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
+                o4.w = D3_B2PAIR(c0[3], c1[3]) | (D3_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
+                *reinterpret_cast<uint4 *>(d) = o4;
+            } else {
+                uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                o3.x = D3_B2PAIR(c0[0], c1[0]) | (D3_B2PAIR(c2[0], c0[1]) << 16);
+                o3.y = D3_B2PAIR(c1[1], c2[1]) | (D3_B2PAIR(c0[2], c1[2]) << 16);
+                o3.z = D3_B2PAIR(c2[2], c0[3]) | (D3_B2PAIR(c1[3], c2[3]) << 16);
+                *reinterpret_cast<uint3 *>(d) = o3;
+            }
+#undef D3_B2PAIR
+        }
+    };
+
+    // the luma triple of sub-step SUB of step i (rows 3u - 2 .. 3u, u = 2T - 1 + SUB): afterwards row u - 2 is complete in slot (U4 + 0) & 3
+    auto luma_triple = [&](int T, auto u4_c, auto sub_c, auto edge_c, int (&YS)[4]) {
+        constexpr int U4 = decltype(u4_c)::value, SUB = decltype(sub_c)::value;
+        int hA[4], hB[4], hC[4];
+        hrowL(bufL[SUB][0], edge_c, hA);
+        loadL(6 * (T + 1) - 5 + 3 * SUB + 0, bufL[SUB][0], edge_c);
+        hrowL(bufL[SUB][1], edge_c, hB);
+        loadL(6 * (T + 1) - 5 + 3 * SUB + 1, bufL[SUB][1], edge_c);
+        hrowL(bufL[SUB][2], edge_c, hC);
+        loadL(6 * (T + 1) - 5 + 3 * SUB + 2, bufL[SUB][2], edge_c);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // hScale8To15_c: min(val >> 7, 32767) — the pack saturates
+            const int ab = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hA[q] >> 7, hB[q] >> 7));
+            const int c = min(hC[q] >> 7, 32767);
+            accL[(U4 + 0) & 3][q] = m24(c, a.vS[0]) + d3_dot2(ab, a.vP[0], accL[(U4 + 0) & 3][q]);
+            accL[(U4 + 1) & 3][q] = m24(c, a.vS[1]) + d3_dot2(ab, a.vP[1], accL[(U4 + 1) & 3][q]);
+            accL[(U4 + 2) & 3][q] = m24(c, a.vS[2]) + d3_dot2(ab, a.vP[2], accL[(U4 + 2) & 3][q]);
+            YS[q] = accL[(U4 + 0) & 3][q];
+            accL[(U4 + 3) & 3][q] = m24(c, a.vS[3]) + d3_dot2(ab, a.vP[3], a.lr);      // row u + 1 opens
+        }
+    };
+    // one chroma row into the running sums: k0 .. k3 = the taps of the rows in slots S0 .. S3; FRESH: slot S0 opens with this row
+    auto chroma_row = [&](const int (&v)[4], auto s0_c, auto s1_c, auto s2_c, auto s3_c, auto fresh_c, int k0, int k1, int k2, int k3) {
+        constexpr int S0 = decltype(s0_c)::value, S1 = decltype(s1_c)::value, S2 = decltype(s2_c)::value, S3 = decltype(s3_c)::value;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            accC[S0][q] = m24(v[q], k0) + (decltype(fresh_c)::value ? a.cr : accC[S0][q]);
+            accC[S1][q] = m24(v[q], k1) + accC[S1][q];
+            accC[S2][q] = m24(v[q], k2) + accC[S2][q];
+            accC[S3][q] = m24(v[q], k3) + accC[S3][q];
+        }
+    };
+
+    auto body = [&](const int i, auto par_c, auto edge_c) {
+        constexpr int PAR = decltype(par_c)::value;              // i & 1: names the slots
+        const int T = T0 + i;
+        // output row 1 has its own taps (odd rows: slot of 2T - 3, 2T - 1, 2T + 1)
+        const bool s_m3 = T == 2, s_m1 = T == 1, s_p1 = T == 0;
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        // chroma slots: output row o lives in slot o & 3; with T = T0 + i the row parity pattern only depends on i & 1 (a renaming)
+        constexpr int E0 = (2 * PAR) & 3, Em2 = (2 * PAR + 2) & 3, Om1 = (2 * PAR + 3) & 3, Om3 = (2 * PAR + 1) & 3, Op1 = Om3;
+        using SE0 = std::integral_constant<int, E0>; using SEm2 = std::integral_constant<int, Em2>;
+        using SOm1 = std::integral_constant<int, Om1>; using SOm3 = std::integral_constant<int, Om3>; using SOp1 = std::integral_constant<int, Op1>;
+        int YS[4], CS[4], cv[4];
+        // ---- first half: luma rows 6T - 5 .. 6T - 3, chroma row 3T - 2 -> output row 2T - 3
+        luma_triple(T, std::integral_constant<int, (2 * PAR) & 3>(), I0(), edge_c, YS);
+        hrowC(bufC[0], edge_c, cv);
+        loadC(3 * (T + 1) - 2, bufC[0], edge_c);
+        // row 3T - 2: even 2T opens (A0), even 2T - 2 (A3), odd 2T - 1 (B2), odd 2T - 3 closes (B5)
+        chroma_row(cv, SE0(), SEm2(), SOm1(), SOm3(), std::true_type(), a.cA[0], a.cA[3], s_m1 ? a.cS[2] : a.cB[2], s_m3 ? a.cS[5] : a.cB[5]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) CS[q] = accC[Om3][q];
+        emit(2 * T - 3, YS, CS);
+        // ---- second half: luma rows 6T - 2 .. 6T, chroma rows 3T - 1, 3T -> output row 2T - 2
+        luma_triple(T, std::integral_constant<int, (2 * PAR + 1) & 3>(), I1(), edge_c, YS);
+        hrowC(bufC[1], edge_c, cv);
+        loadC(3 * (T + 1) - 1, bufC[1], edge_c);
+        // row 3T - 1: odd 2T + 1 opens (B0), even 2T (A1), even 2T - 2 (A4), odd 2T - 1 (B3)
+        chroma_row(cv, SOp1(), SE0(), SEm2(), SOm1(), std::true_type(), s_p1 ? a.cS[0] : a.cB[0], a.cA[1], a.cA[4], s_m1 ? a.cS[3] : a.cB[3]);
+        hrowC(bufC[2], edge_c, cv);
+        loadC(3 * (T + 1), bufC[2], edge_c);
+        // row 3T: odd 2T + 1 (B1), even 2T (A2), even 2T - 2 closes (A5), odd 2T - 1 (B4)
+        chroma_row(cv, SOp1(), SE0(), SEm2(), SOm1(), std::false_type(), s_p1 ? a.cS[1] : a.cB[1], a.cA[2], a.cA[5], s_m1 ? a.cS[4] : a.cB[4]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) CS[q] = accC[Em2][q];
+        emit(2 * T - 2, YS, CS);
+    };
+    auto run = [&](auto edge_c) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) { loadL(6 * T0 - 5 + r, bufL[0][r], edge_c); loadL(6 * T0 - 2 + r, bufL[1][r], edge_c); loadC(3 * T0 - 2 + r, bufC[r], edge_c); }
+        for (int i0 = 0; i0 < nT; i0 += 2) {
+            body(i0, std::integral_constant<int, 0>(), edge_c);
+            if (i0 + 1 < nT) body(i0 + 1, std::integral_constant<int, 1>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv3x1Tables &t)
@@ -389,6 +627,61 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3x1_kernel<true>), grid, block, 0, stream, a, *frames);
     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3x1_kernel<false>), grid, block, 0, stream, a, *frames);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// scale_yuv3r_kernel takes an NV12 -> packed RGB context at exactly 3:1 whose four filters have the shapes the kernel assumes
+int yuv3r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv3rTables &t)
+{
+    t = Yuv3rTables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (g.fullChroma || g.yuvOut) return 0;
+    if (p.srcFormat != GMAT_PIX_FMT_NV12) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
+          p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
+    if (p.srcW != 3 * p.dstW || p.srcH != 3 * p.dstH || p.dstW % 4 || p.dstW < 32 || p.dstH < 12 || (p.dstH & 1)) return 0;
+    // half-width chroma at the output's full height; the source's chroma is half the source on both axes
+    if (p.chrSrcW * 2 != p.srcW || p.chrSrcH * 2 != p.srcH || p.chrDstW * 2 != p.dstW || p.chrDstH != p.dstH) return 0;
+    if (!filter_is_edge_replication_ratio(p.hLum, p.srcW, 3, 4, 6, t.hL)) return 0;
+    if (!filter_is_edge_replication_ratio(p.hChr, p.chrSrcW, 3, 4, 6, t.hC)) return 0;
+    if (!filter_is_edge_replication_ratio(g.vLumEff, p.srcH, 3, 4, 6, t.vL)) return 0;
+    if (!down32_axis(g.vChrEff, p.chrSrcH, t.vCA, t.vCB, t.vCS)) return 0;
+    if ((t.hL[5] >> 16) || (t.hC[5] >> 16) || (t.vL[5] >> 16)) return 0;        // the 12th slot carries no weight
+    for (int y = 0; y < p.dstH; y++) if (g.lumRound[y] != g.lumRound[0]) return 0;
+    for (int y = 0; y < p.chrDstH; y++) if (g.chrRound[y] != g.chrRound[0]) return 0;
+    t.lr = g.lumRound[0]; t.cr = g.chrRound[0];
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuv3r(const Yuv3rArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv3rArgs a = a0;
+    a.nstrips = (a.dstW + D3_STRIP - 1) / D3_STRIP;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        // a segment of n output rows walks n / 2 + 2 steps of 6 luma + 3 chroma rows: two warm-up steps.  Measured on 4K -> 720p
+        // (profiles/r02za_down3rgb.txt): 32 frames per launch 24 - 30 rows 4.3 - 4.4 us per frame (12: 4.7, 48: 4.7); one frame 4 rows 10.7 us (8: 14.4)
+        const long rows = (long)a.dstH * a.nstrips * nframes;
+        seg = (int)std::min(48L, std::max(4L, (rows + 4095) / 4096));
+    }
+    seg = (seg + 1) & ~1;                                        // segments start on even output rows
+    a.segRows = seg;
+    a.nseg = (a.dstH + seg - 1) / seg;
+    a.nblk = (a.nseg * a.nstrips + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+    switch (a.dstFormat) {
+    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3r_kernel<0>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3r_kernel<1>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3r_kernel<2>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3r_kernel<3>), grid, block, 0, stream, a, *frames); break;
+    default: return GMAT_ERR(EINVAL);
+    }
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) E3_FOUR_WAVES void scale_yuv3x2_kernel(Yuv3x2A
 // One axis of an exact 3:2 down-scale: the table row of output x on its nominal window (x = 2k: [3k - 2, 3k + 3], x = 2k + 1:
 // [3k - 1, 3k + 4]).  Every output must equal "the middle row of its parity on an edge-replicated line", except output 1, whose table
 // row is taken as it is.  A / B / S as 3 int16 pairs each.
-static bool down32_axis(const FilterBank &fb, int srcLen, int32_t (&A)[3], int32_t (&B)[3], int32_t (&S)[3])
+bool down32_axis(const FilterBank &fb, int srcLen, int32_t (&A)[3], int32_t (&B)[3], int32_t (&S)[3])
 {
     if (fb.count < 8 || (fb.count & 1) || 2 * srcLen != 3 * fb.count) return false;
     auto window = [&](int x, int (&w)[6]) -> bool {              // the table row of x on its window; false: a tap falls outside it

@@ -334,6 +334,28 @@ struct Yuv3x1Args {
     int updown;                                  // 1: odd segments walk upward (shared boundary rows meet in L2)
 };
 int  yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x1Tables &t);
+
+// scale_yuv3r_kernel (k_scale_yuv3x1.hip): NV12 at exactly a third of the size into packed RGB, ONE libswscale context.  Luma 3:1 on
+// both axes (11 taps), chroma 3:1 horizontally (RGB destinations keep half-width chroma) and 3:2 vertically (6 taps, two phases,
+// output row 1 with its own table row: down32_axis in k_scale_yuv3x2.hip)
+struct Yuv3rTables {
+    int ok = 0;
+    int32_t hL[6] = {0}, hC[6] = {0}, vL[6] = {0};      // 11 taps on [3x - 4, 3x + 7] as int16 pairs
+    int32_t vCA[3] = {0}, vCB[3] = {0}, vCS[3] = {0};    // vertical chroma: even / odd output rows, and output row 1
+    int lr = 0, cr = 0;
+};
+struct Yuv3rArgs {
+    int ys, us, dstW, dstH, ds, dstFormat;
+    int32_t hL[6], hC[6];
+    int32_t vP[4], vS[4];                                // vertical luma: pairs (c8 c9) (c5 c6) (c2 c3) (0 c0) for rows (3u-2 | 3u-1), singles c10 c7 c4 c1 for row 3u
+    int32_t cA[6], cB[6], cS[6];                         // vertical chroma taps
+    int lr, cr;
+    int segRows, nseg, nstrips, nblk, xcdRemap;          // filled by the launcher
+    Yuv2RgbConsts y2r;
+};
+bool down32_axis(const FilterBank &fb, int srcLen, int32_t (&A)[3], int32_t (&B)[3], int32_t (&S)[3]);
+int  yuv3r_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3rTables &t);
+int  launch_scale_yuv3r(const Yuv3rArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 int  launch_scale_yuv3x1(const Yuv3x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // ---- strip-walking form of the exact 3:2 down-scale of 8-bit YUV 4:2:0 (k_scale_yuv3x2.hip): NV12 -> NV12, YUV420P -> YUV420P -----
