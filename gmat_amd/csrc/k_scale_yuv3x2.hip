@@ -327,6 +327,267 @@ __global__ __launch_bounds__(256) E3_FOUR_WAVES void scale_yuv3x2_kernel(Yuv3x2A
 }
 
 // ---------------------------------------------------------------------------------------------
+// scale_yuv32r_kernel: NV12 at two thirds of the size into packed RGB (1080p -> 720p, 4K -> 1440p), ONE libswscale context.  The lane
+// mapping and both horizontal filters are the plane walkers' above: 8 luma outputs from a 20-byte window, 4 chroma positions (an RGB
+// destination keeps half-width chroma) from a 20-byte UV window.  Vertically the luma is the 3:2 filter as RUNNING SUMS (as the
+// chroma of scale_yuv3r_kernel, k_scale_yuv3x1.hip: a row feeds the four open output rows, A / B / S taps by the row's place in step T,
+// output rows 2T - 3 and 2T - 2 close after the first and the last row of the step); the chroma — half the source's rows into all of
+// the destination's — is a 3:4 UP-scale: 4 taps, four phases, output row 4k + 2 + i on the chroma rows 3k + (0, 1, 1, 2)[i] .. + 3, rows
+// 0 and 1 with the table's own rows.  The last four chroma lines sit in a sliding window, U and V of a position packed in one register
+// (v_dot2 with the tap in one half picks the channel); two steps push three chroma rows.  Segments start on multiples of 4 output rows.
+// ---------------------------------------------------------------------------------------------
+// 171 VGPRs = two waves per SIMD.  Bounded to 168 (three waves) the allocator spills 8 - 12 bytes per lane and the kernel is no faster
+// (2.23 against 2.16 us per 1080p frame, one frame per launch 13.8 against 12.3: profiles/r02zc_down32rgb.txt)
+template <int DST>
+__global__ __launch_bounds__(256) void scale_yuv32r_kernel(Yuv32rArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    __shared__ int2 lutV[256], lutU[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const Yuv2RgbConsts &k = a.y2r;
+        lutV[tid] = make_int2(k.base + m24(k.offR + (m24(tid, k.crv) >> 16), k.cy), m24(m24(tid, k.cgv) >> 16, k.cy));
+        lutU[tid] = make_int2(k.base + m24(k.offG + (m24(tid, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(tid, k.cbu) >> 16), k.cy));
+        __syncthreads();
+    }
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int unit = lin * 4 + wave;
+    if (unit >= a.nseg * a.nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / a.nstrips);
+    const int X0 = (unit - seg * a.nstrips) * E3_STRIP;
+    const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);          // y0 is a multiple of 4
+    const int T0 = y0 >> 1, nT = ((y0 + nOut + 2) >> 1) - T0 + 1;                // T0 is even
+    const int srcW = 3 * (a.dstW >> 1), srcH = 3 * (a.dstH >> 1), chrH = srcH >> 1;
+    const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y];
+    uint8_t *pd = fr.dst[blockIdx.y];
+
+    const int xo = X0 + 8 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 8;
+    const bool edgeWave = X0 == 0 || 3 * (X0 + E3_STRIP) / 2 + 8 > srcW;
+    const bool isLeft = xc == 0, isRight = xc == a.dstW - 8;
+    const unsigned boL = (unsigned)(3 * (xc >> 1) - 4), lboL = boL + (isLeft ? 4u : 0u) - (isRight ? 4u : 0u);
+    const int cc = xc >> 1;                                      // first of the lane's four chroma positions
+    const unsigned boC = 2u * (unsigned)(3 * (cc >> 1) - 2), lboC = boC + (isLeft ? 4u : 0u) - (isRight ? 4u : 0u);
+    // output column 1 (of luma and of chroma) takes the table's own row
+    const int32_t l1a = e3_blend(isLeft, a.hLS[0], a.hLB[0]), l1b = e3_blend(isLeft, a.hLS[1], a.hLB[1]), l1c = e3_blend(isLeft, a.hLS[2], a.hLB[2]);
+    const int32_t c1a = e3_blend(isLeft, a.hCS[0], a.hCB[0]), c1b = e3_blend(isLeft, a.hCS[1], a.hCB[1]), c1c = e3_blend(isLeft, a.hCS[2], a.hCB[2]);
+
+    auto load5 = [&](const uint8_t *base, int stride, int row, int rows, unsigned off, unsigned (&d)[5]) {
+        const uint8_t *p = base + ((unsigned)min(max(row, 0), rows - 1) * (unsigned)stride + off);
+        const uint4 t = e3_ld16(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        d[4] = e3_ld4(p + 16);
+    };
+    auto loadL = [&](int row, unsigned (&d)[5], auto edge_c) { load5(py, a.ys, row, srcH, decltype(edge_c)::value ? lboL : boL, d); };
+    auto loadC = [&](int row, unsigned (&d)[5], auto edge_c) { load5(puv, a.us, row, chrH, decltype(edge_c)::value ? lboC : boC, d); };
+    // hScale8To15_c of a luma row: 8 lines (>> 7, min 32767)
+    auto hrowL = [&](const unsigned (&src)[5], auto edge_c, int (&s)[8]) {
+        unsigned d[5] = {src[0], src[1], src[2], src[3], src[4]};
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned firstS = e3_rep(src[0], 0x00000000u), lastS = e3_rep(src[4], 0x03030303u);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const unsigned fromLeft = i == 0 ? firstS : src[i - 1], fromRight = i == 4 ? lastS : src[i + 1];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        s[0] = e3_dot2(e3_pair<6>(d), a.hLA[2], e3_dot2(e3_pair<4>(d), a.hLA[1], e3_dot2(e3_pair<2>(d), a.hLA[0], 0)));
+        s[1] = e3_dot2(e3_pair<7>(d), l1c, e3_dot2(e3_pair<5>(d), l1b, e3_dot2(e3_pair<3>(d), l1a, 0)));
+        s[2] = e3_dot2(e3_pair<9>(d), a.hLA[2], e3_dot2(e3_pair<7>(d), a.hLA[1], e3_dot2(e3_pair<5>(d), a.hLA[0], 0)));
+        s[3] = e3_dot2(e3_pair<10>(d), a.hLB[2], e3_dot2(e3_pair<8>(d), a.hLB[1], e3_dot2(e3_pair<6>(d), a.hLB[0], 0)));
+        s[4] = e3_dot2(e3_pair<12>(d), a.hLA[2], e3_dot2(e3_pair<10>(d), a.hLA[1], e3_dot2(e3_pair<8>(d), a.hLA[0], 0)));
+        s[5] = e3_dot2(e3_pair<13>(d), a.hLB[2], e3_dot2(e3_pair<11>(d), a.hLB[1], e3_dot2(e3_pair<9>(d), a.hLB[0], 0)));
+        s[6] = e3_dot2(e3_pair<15>(d), a.hLA[2], e3_dot2(e3_pair<13>(d), a.hLA[1], e3_dot2(e3_pair<11>(d), a.hLA[0], 0)));
+        s[7] = e3_dot2(e3_pair<16>(d), a.hLB[2], e3_dot2(e3_pair<14>(d), a.hLB[1], e3_dot2(e3_pair<12>(d), a.hLB[0], 0)));
+#pragma unroll
+        for (int q = 0; q < 8; q++) s[q] = min(s[q] >> 7, 32767);
+    };
+    // ... of a chroma row: 4 positions, (U | V << 16) each
+    auto hrowC = [&](const unsigned (&src)[5], auto edge_c, int (&w)[4]) {
+        unsigned d[5] = {src[0], src[1], src[2], src[3], src[4]};
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned firstS = e3_rep(src[0], 0x01000100u), lastS = e3_rep(src[4], 0x03020302u);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const unsigned fromLeft = i == 0 ? firstS : src[i - 1], fromRight = i == 4 ? lastS : src[i + 1];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        int pU[9], pV[9];
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            if (p & 1) {
+                pU[p] = (int)__builtin_amdgcn_perm(d[(p + 1) >> 1], d[p >> 1], 0x0C040C02u);
+                pV[p] = (int)__builtin_amdgcn_perm(d[(p + 1) >> 1], d[p >> 1], 0x0C050C03u);
+            } else {
+                pU[p] = (int)__builtin_amdgcn_perm(0u, d[p >> 1], 0x0C020C00u);
+                pV[p] = (int)__builtin_amdgcn_perm(0u, d[p >> 1], 0x0C030C01u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = 3 * i, o = 3 * i + 1;
+            const int32_t oa = i == 0 ? c1a : a.hCB[0], ob = i == 0 ? c1b : a.hCB[1], oc = i == 0 ? c1c : a.hCB[2];
+            const int ue = e3_dot2(pU[e + 4], a.hCA[2], e3_dot2(pU[e + 2], a.hCA[1], e3_dot2(pU[e], a.hCA[0], 0)));
+            const int ve = e3_dot2(pV[e + 4], a.hCA[2], e3_dot2(pV[e + 2], a.hCA[1], e3_dot2(pV[e], a.hCA[0], 0)));
+            const int uo = e3_dot2(pU[o + 4], oc, e3_dot2(pU[o + 2], ob, e3_dot2(pU[o], oa, 0)));
+            const int vo = e3_dot2(pV[o + 4], oc, e3_dot2(pV[o + 2], ob, e3_dot2(pV[o], oa, 0)));
+            // hScale8To15_c's min(val >> 7, 32767) is the pack's saturation
+            w[2 * i + 0] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ue >> 7, ve >> 7));
+            w[2 * i + 1] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(uo >> 7, vo >> 7));
+        }
+    };
+
+    int accL[4][8];                                              // open luma rows x the lane's 8 columns
+    int win[4][4];                                               // the last four chroma lines x 4 positions, (U | V << 16)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) accL[s][q] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) win[s][q] = 0;
+    }
+    unsigned bufL[2][3][5], bufC[3][5];
+    const unsigned dstOff = (unsigned)xo * BPP;
+
+    auto push = [&](const unsigned (&raw)[5], auto edge_c) {
+        int w[4];
+        hrowC(raw, edge_c, w);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { win[0][q] = win[1][q]; win[1][q] = win[2][q]; win[2][q] = win[3][q]; win[3][q] = w[q]; }
+    };
+    // one luma row into the running sums (see chroma_row of scale_yuv3r_kernel)
+    auto luma_row = [&](const int (&v)[8], auto s0_c, auto s1_c, auto s2_c, auto s3_c, auto fresh_c, int k0, int k1, int k2, int k3) {
+        constexpr int S0 = decltype(s0_c)::value, S1 = decltype(s1_c)::value, S2 = decltype(s2_c)::value, S3 = decltype(s3_c)::value;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            accL[S0][q] = m24(v[q], k0) + (decltype(fresh_c)::value ? a.lr : accL[S0][q]);
+            accL[S1][q] = m24(v[q], k1) + accL[S1][q];
+            accL[S2][q] = m24(v[q], k2) + accL[S2][q];
+            accL[S3][q] = m24(v[q], k3) + accL[S3][q];
+        }
+    };
+    // one RGB row from the closed luma sums in slot SL and the chroma window under the taps k0 .. k3
+    auto emit = [&](int yo, auto sl_c, int k0, int k1, int k2, int k3) {
+        constexpr int SL = decltype(sl_c)::value;
+        if (yo < y0 || yo >= y0 + nOut) return;                  // wave-uniform
+        int iU[4], iV[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int U = e3_dot2(win[3][c], k3 & 0xFFFF, e3_dot2(win[2][c], k2 & 0xFFFF, e3_dot2(win[1][c], k1 & 0xFFFF, e3_dot2(win[0][c], k0 & 0xFFFF, a.cr))));
+            const int V = e3_dot2(win[3][c], k3 << 16, e3_dot2(win[2][c], k2 << 16, e3_dot2(win[1][c], k1 << 16, e3_dot2(win[0][c], k0 << 16, a.cr))));
+            iU[c] = clip_u8_shr(U, 19); iV[c] = clip_u8_shr(V, 19);
+        }
+        unsigned c0[8], c1[8], c2[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int2 tv = lutV[iV[c]], tu = lutU[iU[c]];
+            const int tr = BGR ? tu.y : tv.x, tg = tv.y + tu.x, tb = BGR ? tv.x : tu.y;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int q = 2 * c + h;
+                const int yc = m24(accL[SL][q] >> 19, a.y2r.cy);
+                c0[q] = (unsigned)min(max(tr + yc, 0), 0xFFFFFF);
+                c1[q] = (unsigned)min(max(tg + yc, 0), 0xFFFFFF);
+                c2[q] = (unsigned)min(max(tb + yc, 0), 0xFFFFFF);
+            }
+        }
+        if (active) {
+            uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+#define E3_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int b = 4 * g;
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = E3_B2PAIR(c0[b + 0], c1[b + 0]) | (E3_B2PAIR(c2[b + 0], 0u) << 16) | 0xFF000000u;
+                    o4.y = E3_B2PAIR(c0[b + 1], c1[b + 1]) | (E3_B2PAIR(c2[b + 1], 0u) << 16) | 0xFF000000u;
+                    o4.z = E3_B2PAIR(c0[b + 2], c1[b + 2]) | (E3_B2PAIR(c2[b + 2], 0u) << 16) | 0xFF000000u;
+                    o4.w = E3_B2PAIR(c0[b + 3], c1[b + 3]) | (E3_B2PAIR(c2[b + 3], 0u) << 16) | 0xFF000000u;
+                    *reinterpret_cast<uint4 *>(d + 16 * g) = o4;
+                } else {
+                    uint3 o3;
+                    o3.x = E3_B2PAIR(c0[b + 0], c1[b + 0]) | (E3_B2PAIR(c2[b + 0], c0[b + 1]) << 16);
+                    o3.y = E3_B2PAIR(c1[b + 1], c2[b + 1]) | (E3_B2PAIR(c0[b + 2], c1[b + 2]) << 16);
+                    o3.z = E3_B2PAIR(c2[b + 2], c0[b + 3]) | (E3_B2PAIR(c1[b + 3], c2[b + 3]) << 16);
+                    *reinterpret_cast<uint3 *>(d + 12 * g) = o3;
+                }
+            }
+#undef E3_B2PAIR
+        }
+    };
+
+    auto body = [&](const int i, auto par_c, auto edge_c) {
+        constexpr int PAR = decltype(par_c)::value;              // i & 1 = T & 1 (T0 is even)
+        const int T = T0 + i;
+        const bool s_m3 = T == 2, s_m1 = T == 1, s_p1 = T == 0;  // the luma taps of output row 1 (rows 2T - 3, 2T - 1, 2T + 1)
+        constexpr int E0 = (2 * PAR) & 3, Em2 = (2 * PAR + 2) & 3, Om1 = (2 * PAR + 3) & 3, Om3 = (2 * PAR + 1) & 3, Op1 = Om3;
+        using SE0 = std::integral_constant<int, E0>; using SEm2 = std::integral_constant<int, Em2>;
+        using SOm1 = std::integral_constant<int, Om1>; using SOm3 = std::integral_constant<int, Om3>; using SOp1 = std::integral_constant<int, Op1>;
+        int v[8];
+        // luma row 3T - 2: even 2T opens (A0), even 2T - 2 (A3), odd 2T - 1 (B2), odd 2T - 3 closes (B5)
+        hrowL(bufL[PAR][0], edge_c, v);
+        loadL(3 * (T + 2) - 2, bufL[PAR][0], edge_c);
+        luma_row(v, SE0(), SEm2(), SOm1(), SOm3(), std::true_type(), a.lA[0], a.lA[3], s_m1 ? a.lS[2] : a.lB[2], s_m3 ? a.lS[5] : a.lB[5]);
+        if (PAR == 0) {
+            // T = 2k: chroma row 3k - 1 -> output row 4k - 3 (phase 3; row 1 at T = 2 has its own taps)
+            const int kap = T >> 1;
+            push(bufC[0], edge_c);
+            loadC(3 * (kap + 1) - 1, bufC[0], edge_c);
+            emit(2 * T - 3, SOm3(), s_m3 ? a.cS1[0] : a.cP[3][0], s_m3 ? a.cS1[1] : a.cP[3][1], s_m3 ? a.cS1[2] : a.cP[3][2], s_m3 ? a.cS1[3] : a.cP[3][3]);
+        } else {
+            // T = 2k + 1: chroma row 3k + 1 -> output rows 4k - 1 (phase 1) and 4k (phase 2; row 0 at T = 1 has its own taps)
+            const int kap = T >> 1;
+            push(bufC[2], edge_c);
+            loadC(3 * (kap + 1) + 1, bufC[2], edge_c);
+            emit(2 * T - 3, SOm3(), a.cP[1][0], a.cP[1][1], a.cP[1][2], a.cP[1][3]);
+        }
+        // luma row 3T - 1: odd 2T + 1 opens (B0), even 2T (A1), even 2T - 2 (A4), odd 2T - 1 (B3)
+        hrowL(bufL[PAR][1], edge_c, v);
+        loadL(3 * (T + 2) - 1, bufL[PAR][1], edge_c);
+        luma_row(v, SOp1(), SE0(), SEm2(), SOm1(), std::true_type(), s_p1 ? a.lS[0] : a.lB[0], a.lA[1], a.lA[4], s_m1 ? a.lS[3] : a.lB[3]);
+        // luma row 3T: odd 2T + 1 (B1), even 2T (A2), even 2T - 2 closes (A5), odd 2T - 1 (B4)
+        hrowL(bufL[PAR][2], edge_c, v);
+        loadL(3 * (T + 2), bufL[PAR][2], edge_c);
+        luma_row(v, SOp1(), SE0(), SEm2(), SOm1(), std::false_type(), s_p1 ? a.lS[1] : a.lB[1], a.lA[2], a.lA[5], s_m1 ? a.lS[4] : a.lB[4]);
+        if (PAR == 0) {
+            // chroma row 3k -> output row 4k - 2 (phase 0)
+            const int kap = T >> 1;
+            push(bufC[1], edge_c);
+            loadC(3 * (kap + 1), bufC[1], edge_c);
+            emit(2 * T - 2, SEm2(), a.cP[0][0], a.cP[0][1], a.cP[0][2], a.cP[0][3]);
+        } else {
+            emit(2 * T - 2, SEm2(), s_m1 ? a.cS0[0] : a.cP[2][0], s_m1 ? a.cS0[1] : a.cP[2][1], s_m1 ? a.cS0[2] : a.cP[2][2], s_m1 ? a.cS0[3] : a.cP[2][3]);
+        }
+    };
+    auto run = [&](auto edge_c) {
+        const int k0 = T0 >> 1;
+        // the chroma window before step T0: rows 3 k0 - 4 .. 3 k0 - 2
+        {
+            unsigned pre[5];
+#pragma unroll
+            for (int r = 0; r < 3; r++) { loadC(3 * k0 - 4 + r, pre, edge_c); push(pre, edge_c); }
+        }
+        loadC(3 * k0 - 1, bufC[0], edge_c); loadC(3 * k0, bufC[1], edge_c); loadC(3 * k0 + 1, bufC[2], edge_c);
+#pragma unroll
+        for (int r = 0; r < 3; r++) { loadL(3 * T0 - 2 + r, bufL[0][r], edge_c); loadL(3 * (T0 + 1) - 2 + r, bufL[1][r], edge_c); }
+        for (int i0 = 0; i0 < nT; i0 += 2) {
+            body(i0, std::integral_constant<int, 0>(), edge_c);
+            if (i0 + 1 < nT) body(i0 + 1, std::integral_constant<int, 1>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // One axis of an exact 3:2 down-scale: the table row of output x on its nominal window (x = 2k: [3k - 2, 3k + 3], x = 2k + 1:
@@ -422,6 +683,102 @@ int launch_scale_yuv3x2(const Yuv3x2Args &a0, hipStream_t stream, const Yuv2xFra
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3x2_kernel<true>), grid, block, 0, stream, a, *frames);
     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv3x2_kernel<false>), grid, block, 0, stream, a, *frames);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Is this axis the 3:4 UP-scale the kernel assumes: output y = 4k + 2 + i on the window [ws, ws + 3], ws = 3k + (0, 1, 1, 2)[i], every
+// table row from row 2 on equal to its phase's middle row folded onto the clamped samples?  Rows 0 and 1 keep the table's own taps
+// (on their windows [-2, 1] and [-1, 2], whose out-of-range slots the kernel fills with row 0: a tap there must be 0).
+static bool up43_axis(const FilterBank &fb, int srcLen, int32_t (&P)[4][4], int32_t (&S0)[4], int32_t (&S1)[4])
+{
+    static const int off[4] = {0, 1, 1, 2};
+    if (fb.count < 16 || (fb.count & 3) || 3 * fb.count != 4 * srcLen) return false;
+    auto ws_of = [&](int y) { const int k = (y - 2) >> 2, i = (y - 2) & 3; return 3 * k + off[i]; };     // arithmetic shift: k = -1 for y = 0, 1
+    auto window = [&](int y, int (&w)[4]) -> bool {
+        const int ws = ws_of(y);
+        for (int k = 0; k < 4; k++) w[k] = 0;
+        for (int j = 0; j < fb.taps; j++) {
+            const int16_t c = fb.coef[(size_t)y * fb.taps + j];
+            if (!c) continue;
+            const int s = fb.pos[y] + j;
+            if (s < 0 || s >= srcLen || s - ws < 0 || s - ws > 3) return false;
+            w[s - ws] += c;
+        }
+        return true;
+    };
+    int nom[4][4];
+    const int ym = ((fb.count / 2) & ~3) + 2;
+    for (int i = 0; i < 4; i++) if (!window(ym + i, nom[i])) return false;
+    for (int y = 0; y < fb.count; y++) {
+        int w[4];
+        if (!window(y, w)) return false;
+        if (y < 2) {
+            int32_t (&S)[4] = y ? S1 : S0;
+            for (int k = 0; k < 4; k++) S[k] = w[k];
+            continue;
+        }
+        const int ws = ws_of(y), i = (y - 2) & 3;
+        int e[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) {
+            const int s = std::min(std::max(ws + k, 0), srcLen - 1);
+            if (s - ws < 0 || s - ws > 3) return false;
+            e[s - ws] += nom[i][k];
+        }
+        if (std::memcmp(w, e, sizeof(w)) != 0) return false;
+    }
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 4; k++) P[i][k] = nom[i][k];
+    return true;
+}
+
+int yuv32r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv32rTables &t)
+{
+    t = Yuv32rTables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (g.fullChroma || g.yuvOut) return 0;
+    if (p.srcFormat != GMAT_PIX_FMT_NV12) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
+          p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
+    if (2 * p.srcW != 3 * p.dstW || 2 * p.srcH != 3 * p.dstH || p.dstW % 8 || p.dstW < 64 || p.dstH % 4 || p.dstH < 16) return 0;
+    if (p.chrSrcW * 2 != p.srcW || p.chrSrcH * 2 != p.srcH || p.chrDstW * 2 != p.dstW || p.chrDstH != p.dstH) return 0;
+    if (!down32_axis(p.hLum, p.srcW, t.hLA, t.hLB, t.hLS)) return 0;
+    if (!down32_axis(p.hChr, p.chrSrcW, t.hCA, t.hCB, t.hCS)) return 0;
+    if (!down32_axis(g.vLumEff, p.srcH, t.vLA, t.vLB, t.vLS)) return 0;
+    if (!up43_axis(g.vChrEff, p.chrSrcH, t.cP, t.cS0, t.cS1)) return 0;
+    for (int y = 0; y < p.dstH; y++) if (g.lumRound[y] != g.lumRound[0]) return 0;
+    for (int y = 0; y < p.chrDstH; y++) if (g.chrRound[y] != g.chrRound[0]) return 0;
+    t.lr = g.lumRound[0]; t.cr = g.chrRound[0];
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuv32r(const Yuv32rArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv32rArgs a = a0;
+    a.nstrips = (a.dstW + E3_STRIP - 1) / E3_STRIP;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        // measured on 1080p -> 720p (profiles/r02zc_down32rgb.txt): 32 frames per launch 24 rows 2.14 us per frame (12: 2.32, 48: 2.74);
+        // one frame 4 rows 9.9 us (8: 13.8) — 1280 columns are three strips, a single frame is a few hundred waves
+        const long rows = (long)a.dstH * a.nstrips * nframes;
+        seg = (int)std::min(48L, std::max(4L, (rows + 3071) / 3072));
+    }
+    seg = (seg + 3) & ~3;                                        // segments start on multiples of 4 output rows (the chroma phases' period)
+    a.segRows = seg;
+    a.nseg = (a.dstH + seg - 1) / seg;
+    a.nblk = (a.nseg * a.nstrips + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+    switch (a.dstFormat) {
+    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv32r_kernel<0>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv32r_kernel<1>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv32r_kernel<2>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv32r_kernel<3>), grid, block, 0, stream, a, *frames); break;
+    default: return GMAT_ERR(EINVAL);
+    }
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -378,6 +378,28 @@ struct Yuv3x2Args {
 int  yuv3x2_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x2Tables &t);
 int  launch_scale_yuv3x2(const Yuv3x2Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// scale_yuv32r_kernel (k_scale_yuv3x2.hip): NV12 at exactly two thirds of the size into packed RGB (1080p -> 720p, 4K -> 1440p), ONE
+// libswscale context.  Luma 3:2 on both axes, chroma 3:2 horizontally (half-width chroma at the output) and 3:4 UP vertically: 4 taps,
+// four phases, output rows 0 and 1 with their own table rows
+struct Yuv32rTables {
+    int ok = 0;
+    int32_t hLA[3] = {0}, hLB[3] = {0}, hLS[3] = {0}, hCA[3] = {0}, hCB[3] = {0}, hCS[3] = {0};   // int16 pairs (down32_axis)
+    int32_t vLA[3] = {0}, vLB[3] = {0}, vLS[3] = {0};
+    int32_t cP[4][4] = {{0}}, cS0[4] = {0}, cS1[4] = {0};   // vertical chroma taps on the window of output row 4k + 2 + i: rows 3k + (0, 1, 1, 2)[i] .. + 3
+    int lr = 0, cr = 0;
+};
+struct Yuv32rArgs {
+    int ys, us, dstW, dstH, ds, dstFormat;
+    int32_t hLA[3], hLB[3], hLS[3], hCA[3], hCB[3], hCS[3];
+    int32_t lA[6], lB[6], lS[6];                          // vertical luma taps
+    int32_t cP[4][4], cS0[4], cS1[4];
+    int lr, cr;
+    int segRows, nseg, nstrips, nblk, xcdRemap;           // filled by the launcher
+    Yuv2RgbConsts y2r;
+};
+int  yuv32r_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv32rTables &t);
+int  launch_scale_yuv32r(const Yuv32rArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 packed RGB -> packed RGB scaler (k_scale_rgb2s.hip) -----------------------
 // rgb24 / bgr24 at 2W x 2H -> rgb24 / bgr24 / rgba / bgra at W x H, one libswscale context's arithmetic.
 struct Rgb2sTables {
