@@ -133,6 +133,7 @@ struct GmatSwsContext {
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
+    Yuv4rTables y4r;                     // strip-walking 4:1 NV12 -> packed RGB
     Yuv32rTables y32r;                   // strip-walking 3:2 NV12 -> packed RGB
     Yuv3rTables y3r;                     // strip-walking 3:1 NV12 -> packed RGB
     Rgb2yTables r2ys;                    // strip-walking 2:1 packed RGB -> 8-bit 4:2:0
@@ -224,6 +225,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv3x2_prepare(c->planYuv, c->ytiling, c->y3x2)) < 0) return r;
     if ((r = yuv3r_prepare(c->planYuv, c->ytiling, c->y3r)) < 0) return r;
     if ((r = yuv32r_prepare(c->planYuv, c->ytiling, c->y32r)) < 0) return r;
+    if ((r = yuv4r_prepare(c->planYuv, c->ytiling, c->y4r)) < 0) return r;
     if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
@@ -615,6 +617,25 @@ static Yuv3rArgs make_yuv3r_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     return a;
 }
 
+// the 4:1 NV12 -> packed RGB kernel: 16-byte loads on both planes
+static bool yuv4r_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t sall = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
+    return c->y4r.ok && !c->rangeConv && ya.nv12 && (sall & 3) == 0 && ya.dstAligned && !ya.prof;
+}
+
+static Yuv4rArgs make_yuv4r_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv4rArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const Yuv4rTables &t = c->y4r;
+    a.ys = ya.ys; a.us = ya.us; a.dstW = ya.dstW; a.dstH = ya.dstH; a.ds = ya.ds; a.dstFormat = ya.dstFormat;
+    for (int k = 0; k < 8; k++) { a.hL[k] = t.hL[k]; a.hC[k] = t.hC[k]; a.vL[k] = t.vL[k]; }
+    for (int k = 0; k < 4; k++) a.vC[k] = t.vC[k];
+    a.lr = t.lr; a.cr = t.cr; a.y2r = ya.y2r;
+    return a;
+}
+
 // the 3:2 NV12 -> packed RGB kernel
 static bool yuv32r_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
@@ -869,7 +890,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true, use32r = true;
+    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true, use32r = true, use4r = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -885,12 +906,27 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         useR2y = useR2y && rgb2y_eligible(c, ya);
         use3r = use3r && yuv3r_eligible(c, ya);
         use32r = use32r && yuv32r_eligible(c, ya);
+        use4r = use4r && yuv4r_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
+    if (use4r) {
+        const Yuv4rArgs ta = make_yuv4r_args(c, ya0);
+        c->lastKernel = "scale_yuv4r_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            int r = launch_scale_yuv4r(ta, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (use32r) {
         const Yuv32rArgs ta = make_yuv32r_args(c, ya0);
         c->lastKernel = "scale_yuv32r_kernel";
@@ -1515,6 +1551,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv1x2_kernel";
                 r = launch_scale_yuv1x2(make_yuv1x2_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv4r_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.dst[0] = ya.dst;
+                c->lastKernel = "scale_yuv4r_kernel";
+                r = launch_scale_yuv4r(make_yuv4r_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv32r_eligible(c, ya)) {

@@ -378,6 +378,23 @@ struct Yuv3x2Args {
 int  yuv3x2_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv3x2Tables &t);
 int  launch_scale_yuv3x2(const Yuv3x2Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// scale_yuv4r_kernel (k_scale_yuv4r.hip): NV12 at exactly a quarter of the size into packed RGB, ONE libswscale context.  Luma 4:1 on
+// both axes and chroma 4:1 horizontally: 16 taps on [4x - 6, 4x + 9] as 8 int16 pairs; chroma 2:1 vertically: 8 taps on [2y - 3, 2y + 4]
+struct Yuv4rTables {
+    int ok = 0;
+    int32_t hL[8] = {0}, hC[8] = {0}, vL[8] = {0}, vC[4] = {0};
+    int lr = 0, cr = 0;
+};
+struct Yuv4rArgs {
+    int ys, us, dstW, dstH, ds, dstFormat;
+    int32_t hL[8], hC[8], vL[8], vC[4];
+    int lr, cr;
+    int segRows, nseg, nstrips, nblk, xcdRemap;           // filled by the launcher
+    Yuv2RgbConsts y2r;
+};
+int  yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv4rTables &t);
+int  launch_scale_yuv4r(const Yuv4rArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // scale_yuv32r_kernel (k_scale_yuv3x2.hip): NV12 at exactly two thirds of the size into packed RGB (1080p -> 720p, 4K -> 1440p), ONE
 // libswscale context.  Luma 3:2 on both axes, chroma 3:2 horizontally (half-width chroma at the output) and 3:4 UP vertically: 4 taps,
 // four phases, output rows 0 and 1 with their own table rows

@@ -76,6 +76,11 @@ for case in range(n):
             dw = rng.choice([8 * rng.randint(8, maxw // 12), 4 * rng.randint(16, maxw // 6)]); dh = rng.choice([4 * rng.randint(4, 30), 2 * rng.randint(8, 60)])
             sw, sh = 3 * dw // 2, 3 * dh // 2
             if rng.random() < 0.06: sh += 2
+        if rng.random() < 0.06:                                 # NV12 at exactly 4:1 into packed RGB (scale_yuv4r_kernel) and near misses
+            sf = "nv12" if rng.random() < 0.85 else "yuv420p"; df = rng.choice(RGBX)
+            dw = rng.choice([4 * rng.randint(8, maxw // 16), 2 * rng.randint(16, maxw // 8)]); dh = rng.randint(6, 40)
+            sw, sh = 4 * dw, 4 * dh
+            if rng.random() < 0.06: sh += 2
         if rng.random() < 0.12:                                 # the exact 3:2 down-scale family (scale_yuv3x2_kernel) and near misses
             sf = rng.choice(YUV); df = sf if rng.random() < 0.85 else rng.choice(YUV)
             dw = rng.choice([16 * rng.randint(4, maxw // 24), 8 * rng.randint(8, maxw // 12)]); dh = rng.choice([4 * rng.randint(4, 30), 2 * rng.randint(8, 60)])
@@ -115,7 +120,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3r", "scale_yuv3x2", "scale_yuv32r", "scale_rgb2h", "scale_rgb2y", "rgb2yuv420")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3r", "scale_yuv3x2", "scale_yuv32r", "scale_yuv4r", "scale_rgb2h", "scale_rgb2y", "rgb2yuv420")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

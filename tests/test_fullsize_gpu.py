@@ -244,6 +244,19 @@ def test_3_to_2_ladder_steps(gpu, orc, fmt, geom, which, monkeypatch):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
+@pytest.mark.parametrize("geom", [(3840, 2160, 960, 540, "rgb24"), (1920, 1080, 480, 270, "bgra")])
+def test_nv12_to_a_quarter_in_rgb(gpu, orc, geom):
+    """4K -> 960x540 and 1080p -> 480x270 from NV12 into packed RGB at full size"""
+    sw, sh, dw, dh, df = geom
+    src = synth_planes(orc, "nv12", sw, sh, seed=67)
+    want = orc.sws(src, sw, sh, "nv12", dw, dh, df)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, df, dst_align=256)
+    assert k == "scale_yuv4r_kernel", k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 @pytest.mark.parametrize("geom", [(1920, 1080, 1280, 720, "rgb24"), (3840, 2160, 2560, 1440, "bgra")])
 def test_nv12_to_two_thirds_in_rgb(gpu, orc, geom):
     """1080p -> 720p and 4K -> 1440p from NV12 into packed RGB at full size"""
