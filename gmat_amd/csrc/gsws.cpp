@@ -133,6 +133,7 @@ struct GmatSwsContext {
     Yuv2pTables y2p;                     // strip-walking 4:2:0 -> 4:2:0 form (same chroma layout on both sides)
     Yuv1x2Tables y1x2;                   // strip-walking 1:2 up-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv3x1Tables y3x1;                   // strip-walking 3:1 down-scale, 8-bit 4:2:0 -> 4:2:0
+    Yuv4x1Tables y4x1;                   // strip-walking 4:1 down-scale, 8-bit 4:2:0 -> 4:2:0
     Yuv4rTables y4r;                     // strip-walking 4:1 NV12 -> packed RGB
     Yuv32rTables y32r;                   // strip-walking 3:2 NV12 -> packed RGB
     Yuv3rTables y3r;                     // strip-walking 3:1 NV12 -> packed RGB
@@ -226,6 +227,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv3r_prepare(c->planYuv, c->ytiling, c->y3r)) < 0) return r;
     if ((r = yuv32r_prepare(c->planYuv, c->ytiling, c->y32r)) < 0) return r;
     if ((r = yuv4r_prepare(c->planYuv, c->ytiling, c->y4r)) < 0) return r;
+    if ((r = yuv4x1_prepare(c->planYuv, c->ytiling, c->y4x1)) < 0) return r;
     if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
@@ -617,6 +619,27 @@ static Yuv3rArgs make_yuv3r_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     return a;
 }
 
+// the 4:1 4:2:0 -> 4:2:0 kernel: dword loads and stores on every plane
+static bool yuv4x1_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    return c->y4x1.ok && !c->rangeConv && ya.srcAligned && (dall & 3) == 0 && !ya.prof &&
+           (ya.nv12 || ((((uintptr_t)ya.u | (uintptr_t)ya.v | (uintptr_t)ya.us | (uintptr_t)ya.vs) & 3) == 0));
+}
+
+static Yuv4x1Args make_yuv4x1_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    Yuv4x1Args a;
+    std::memset(&a, 0, sizeof(a));
+    const Yuv4x1Tables &t = c->y4x1;
+    a.ys = ya.ys; a.us = ya.us; a.vs = ya.vs; a.nv12 = ya.nv12;
+    a.dstW = ya.srcW / 4; a.dstH = ya.srcH / 4; a.chrDstW = ya.chrSrcW / 4; a.chrDstH = ya.chrSrcH / 4;
+    a.ds = ya.ds; a.dsU = ya.dsU; a.dsV = ya.dsV;
+    for (int k = 0; k < 8; k++) { a.hL[k] = t.hL[k]; a.hC[k] = t.hC[k]; a.vL[k] = t.vL[k]; a.vC[k] = t.vC[k]; }
+    a.lr = t.lr; a.cr = t.cr;
+    return a;
+}
+
 // the 4:1 NV12 -> packed RGB kernel: 16-byte loads on both planes
 static bool yuv4r_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
@@ -890,6 +913,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
+    bool use4x1 = true;
     bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true, use32r = true, use4r = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
@@ -902,6 +926,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use1x2 = use1x2 && yuv1x2_eligible(c, ya);
         use3x1 = use3x1 && yuv3x1_eligible(c, ya);
         use3x2 = use3x2 && yuv3x2_eligible(c, ya);
+        use4x1 = use4x1 && yuv4x1_eligible(c, ya);
         use444 = use444 && yuv2p444_eligible(c, ya);
         useR2y = useR2y && rgb2y_eligible(c, ya);
         use3r = use3r && yuv3r_eligible(c, ya);
@@ -999,7 +1024,8 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv1x2Args ua = use1x2 ? make_yuv1x2_args(c, ya0) : Yuv1x2Args();
     const Yuv3x1Args da = use3x1 ? make_yuv3x1_args(c, ya0) : Yuv3x1Args();
     const Yuv3x2Args ea = use3x2 ? make_yuv3x2_args(c, ya0) : Yuv3x2Args();
-    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    const Yuv4x1Args qa = use4x1 ? make_yuv4x1_args(c, ya0) : Yuv4x1Args();
+    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : use4x1 ? "scale_yuv4x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -1015,6 +1041,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
               : use1x2 ? launch_scale_yuv1x2(ua, stream, &fr, m)
               : use3x1 ? launch_scale_yuv3x1(da, stream, &fr, m)
               : use3x2 ? launch_scale_yuv3x2(ea, stream, &fr, m)
+              : use4x1 ? launch_scale_yuv4x1(qa, stream, &fr, m)
               : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
                       : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
         if (r < 0) return r;
@@ -1599,6 +1626,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
                 c->lastKernel = "scale_yuv3x2_kernel";
                 r = launch_scale_yuv3x2(make_yuv3x2_args(c, ya), c->stream, &one, 1);
+                break;
+            }
+            if (yuv4x1_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_yuv4x1_kernel";
+                r = launch_scale_yuv4x1(make_yuv4x1_args(c, ya), c->stream, &one, 1);
                 break;
             }
             if (yuv2x_eligible(c, ya, src, srcStride)) {

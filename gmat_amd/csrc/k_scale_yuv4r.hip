@@ -248,6 +248,211 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
 }
 
 // ---------------------------------------------------------------------------------------------
+// scale_yuv4x1_kernel: the same ratio from 4:2:0 into 4:2:0 (NV12 -> NV12, YUV420P -> YUV420P: the 540p / 270p rungs of a transcoding
+// ladder), every plane walked on its own with the windows, pair packing and running sums of the kernel above; the chroma plane is
+// scaled 4:1 on both axes here, and yuv2planeX_8_c / yuv2nv12cX_c clip the sums to 8 bits.
+// ---------------------------------------------------------------------------------------------
+struct D4Plane {
+    const uint8_t *src; uint8_t *dst;
+    int ss, ds, dstW, dstH;                    // widths in samples (UV plane: in UV positions)
+    int32_t h[8], v[8];
+    int rnd;
+};
+
+// NW = dwords of a lane's window per row; LOAD(row, d, edge_c) / HROW(d, edge_c, s[4]) / STORE(y, w[4]) are the plane kind's
+template <int NW, typename Load, typename HRow, typename Store>
+__device__ __forceinline__ void d4_walk(const D4Plane &P, int y0, int nOut, bool edgeWave, Load &&load, HRow &&hrow, Store &&store)
+{
+    int acc[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[s][q] = 0;
+    unsigned buf[4][NW];
+    const int nSteps = nOut + 3;
+    auto body = [&](const int i, auto ph_c, auto edge_c) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr int S0 = PH & 3, S1 = (PH + 1) & 3, S2 = (PH + 2) & 3, S3 = (PH + 3) & 3;
+        const int y = y0 - 3 + i;
+        int hA[4], hB[4], hC[4], hD[4];
+        hrow(buf[0], edge_c, hA); load(4 * (y + 2) + 2, buf[0], edge_c);
+        hrow(buf[1], edge_c, hB); load(4 * (y + 2) + 3, buf[1], edge_c);
+        hrow(buf[2], edge_c, hC); load(4 * (y + 2) + 4, buf[2], edge_c);
+        hrow(buf[3], edge_c, hD); load(4 * (y + 2) + 5, buf[3], edge_c);
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ab = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hA[q], hB[q]));
+            const int cd = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hC[q], hD[q]));
+            w[q] = (unsigned)clip_u8_shr(d4_dot2(cd, P.v[7], d4_dot2(ab, P.v[6], acc[S0][q])), 19);
+            acc[S1][q] = d4_dot2(cd, P.v[5], d4_dot2(ab, P.v[4], acc[S1][q]));
+            acc[S2][q] = d4_dot2(cd, P.v[3], d4_dot2(ab, P.v[2], acc[S2][q]));
+            acc[S3][q] = d4_dot2(cd, P.v[1], d4_dot2(ab, P.v[0], P.rnd));
+        }
+        if (y >= y0) store(y, w);                                // wave-uniform
+    };
+    auto run = [&](auto edge_c) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) load(4 * (y0 - 2) + 2 + r, buf[r], edge_c);
+        for (int i0 = 0; i0 < nSteps; i0 += 4) {
+            body(i0, std::integral_constant<int, 0>(), edge_c);
+            if (i0 + 1 < nSteps) body(i0 + 1, std::integral_constant<int, 1>(), edge_c);
+            if (i0 + 2 < nSteps) body(i0 + 2, std::integral_constant<int, 2>(), edge_c);
+            if (i0 + 3 < nSteps) body(i0 + 3, std::integral_constant<int, 3>(), edge_c);
+        }
+    };
+    if (edgeWave) run(std::true_type()); else run(std::false_type());
+}
+
+// one single-channel plane: the output rows [y0, y0 + nOut) of the strip at X0
+__device__ __forceinline__ void d4_walk_plane(const D4Plane &P, int X0, int y0, int nOut, int lane)
+{
+    const int srcW = 4 * P.dstW, srcH = 4 * P.dstH;
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < P.dstW;
+    const int xc = active ? xo : P.dstW - 4;
+    const bool edgeWave = X0 == 0 || 4 * (X0 + D4_STRIP) + 8 > srcW;
+    const bool isLeft = xc == 0, isRight = xc == P.dstW - 4;
+    const unsigned bo = (unsigned)(4 * xc - 8), lbo = bo + (isLeft ? 8u : 0u) - (isRight ? 8u : 0u);
+    auto load = [&](int row, unsigned (&d)[8], auto edge_c) {
+        const uint8_t *p = P.src + ((unsigned)min(max(row, 0), srcH - 1) * (unsigned)P.ss + (decltype(edge_c)::value ? lbo : bo));
+        const uint4 t = d4_ld16(p), u = d4_ld16(p + 16);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w;
+    };
+    auto hrow = [&](const unsigned (&src)[8], auto edge_c, int (&s)[4]) {
+        unsigned d[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = src[i];
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned first = d4_rep(src[0], 0x00000000u), last = d4_rep(src[7], 0x03030303u);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned fromLeft = i < 2 ? first : src[i - 2], fromRight = i > 5 ? last : src[i + 2];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        int H[16];
+#pragma unroll
+        for (int h = 1; h < 15; h++)
+            H[h] = (int)__builtin_amdgcn_perm(0u, d[h >> 1], (h & 1) ? 0x0C030C02u : 0x0C010C00u);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int acc = 0;
+#pragma unroll
+            for (int m = 0; m < 8; m++) acc = d4_dot2(H[2 * j + 1 + m], P.h[m], acc);
+            s[j] = acc >> 7;
+        }
+    };
+    auto store = [&](int y, const unsigned (&w)[4]) {
+        if (active) *reinterpret_cast<unsigned *>(P.dst + ((unsigned)y * (unsigned)P.ds + (unsigned)xo)) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+    };
+    d4_walk<8>(P, y0, nOut, edgeWave, load, hrow, store);
+}
+
+// NV12's interleaved UV plane: a lane makes 2 UV output positions (4 bytes)
+__device__ __forceinline__ void d4_walk_uv(const D4Plane &P, int X0, int y0, int nOut, int lane)
+{
+    const int srcW = 4 * P.dstW, srcH = 4 * P.dstH;              // in UV positions
+    const int co = X0 + 2 * lane;
+    const bool active = co < P.dstW;
+    const int cc = active ? co : P.dstW - 2;
+    const bool edgeWave = X0 == 0 || 4 * (X0 + D4_STRIP / 2) + 8 > srcW;
+    const bool isLeft = cc == 0, isRight = cc == P.dstW - 2;
+    const unsigned bo = 2u * (unsigned)(4 * cc - 8), lbo = bo + (isLeft ? 16u : 0u) - (isRight ? 16u : 0u);
+    auto load = [&](int row, unsigned (&d)[12], auto edge_c) {
+        const uint8_t *p = P.src + ((unsigned)min(max(row, 0), srcH - 1) * (unsigned)P.ss + (decltype(edge_c)::value ? lbo : bo));
+        const uint4 t = d4_ld16(p), u = d4_ld16(p + 16), v = d4_ld16(p + 32);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w; d[8] = v.x; d[9] = v.y; d[10] = v.z; d[11] = v.w;
+    };
+    auto hrow = [&](const unsigned (&src)[12], auto edge_c, int (&s)[4]) {
+        unsigned d[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) d[i] = src[i];
+        if constexpr (decltype(edge_c)::value) {
+            const unsigned first = d4_rep(src[0], 0x01000100u), last = d4_rep(src[11], 0x03020302u);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const unsigned fromLeft = i < 4 ? first : src[i - 4], fromRight = i > 7 ? last : src[i + 4];
+                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+            }
+        }
+        int pU[12], pV[12];
+#pragma unroll
+        for (int i = 1; i < 11; i++) {
+            pU[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C020C00u);
+            pV[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C030C01u);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int u = 0, v = 0;
+#pragma unroll
+            for (int m = 0; m < 8; m++) { u = d4_dot2(pU[2 * i + 1 + m], P.h[m], u); v = d4_dot2(pV[2 * i + 1 + m], P.h[m], v); }
+            s[2 * i] = u >> 7; s[2 * i + 1] = v >> 7;
+        }
+    };
+    auto store = [&](int y, const unsigned (&w)[4]) {
+        if (active) *reinterpret_cast<unsigned *>(P.dst + ((unsigned)y * (unsigned)P.ds + 2u * (unsigned)co)) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+    };
+    d4_walk<12>(P, y0, nOut, edgeWave, load, hrow, store);
+}
+
+__device__ __forceinline__ D4Plane d4_plane(const uint8_t *src, uint8_t *dst, int ss, int ds, int dstW, int dstH,
+                                            const int32_t (&h)[8], const int32_t (&v)[8], int rnd)
+{
+    D4Plane P;
+    P.src = src; P.dst = dst; P.ss = ss; P.ds = ds; P.dstW = dstW; P.dstH = dstH; P.rnd = rnd;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { P.h[k] = h[k]; P.v[k] = v[k]; }
+    return P;
+}
+
+// blockIdx.x: [0, nblkL) luma workgroups, then the chroma workgroups; a wave's unit of work is one (segment, strip) pair, packed
+// densely (unit = 4 * workgroup + wave, segment-major).  blockIdx.y = frame.
+template <bool NV>
+__global__ __launch_bounds__(256) void scale_yuv4x1_kernel(Yuv4x1Args a, Yuv2xFrames fr)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int f = blockIdx.y;
+    if (lin < a.nblkL) {
+        const int unit = lin * 4 + wave;
+        if (unit >= a.nsegL * a.nsgL) return;
+        const int seg = __builtin_amdgcn_readfirstlane(unit / a.nsgL);
+        const int X0 = (unit - seg * a.nsgL) * D4_STRIP;
+        const int y0 = seg * a.segRows;
+        const D4Plane P = d4_plane(fr.y[f], fr.dst[f], a.ys, a.ds, a.dstW, a.dstH, a.hL, a.vL, a.lr);
+        d4_walk_plane(P, X0, y0, min(a.segRows, a.dstH - y0), lane);
+        return;
+    }
+    int unit = (lin - a.nblkL) * 4 + wave;
+    const int per = a.nsegC * a.nsgC;                            // units of one chroma plane
+    if (NV) {
+        if (unit >= per) return;
+        const int seg = __builtin_amdgcn_readfirstlane(unit / a.nsgC);
+        const int X0 = (unit - seg * a.nsgC) * (D4_STRIP / 2);
+        const int y0 = seg * a.segRows;
+        const D4Plane P = d4_plane(fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrDstW, a.chrDstH, a.hC, a.vC, a.cr);
+        d4_walk_uv(P, X0, y0, min(a.segRows, a.chrDstH - y0), lane);
+    } else {
+        if (unit >= 2 * per) return;
+        const int pl = __builtin_amdgcn_readfirstlane(unit >= per ? 1 : 0);
+        unit -= pl * per;
+        const int seg = __builtin_amdgcn_readfirstlane(unit / a.nsgC);
+        const int X0 = (unit - seg * a.nsgC) * D4_STRIP;
+        const int y0 = seg * a.segRows;
+        const D4Plane P = d4_plane(pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
+                                   a.chrDstW, a.chrDstH, a.hC, a.vC, a.cr);
+        d4_walk_plane(P, X0, y0, min(a.segRows, a.chrDstH - y0), lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 int yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv4rTables &t)
@@ -297,6 +502,56 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
     case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<3>), grid, block, 0, stream, a, *frames); break;
     default: return GMAT_ERR(EINVAL);
     }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int yuv4x1_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv4x1Tables &t)
+{
+    t = Yuv4x1Tables();
+    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return 0;
+    if (g.yuvOut != 1) return 0;
+    const bool nv = p.srcFormat == GMAT_PIX_FMT_NV12 && p.dstFormat == GMAT_PIX_FMT_NV12;
+    const bool pl = p.srcFormat == GMAT_PIX_FMT_YUV420P && p.dstFormat == GMAT_PIX_FMT_YUV420P;
+    if (!nv && !pl) return 0;
+    // a lane makes 4 samples of a plane (2 positions of the UV plane)
+    if (p.srcW != 4 * p.dstW || p.srcH != 4 * p.dstH || p.dstW % (nv ? 4 : 8) || p.dstW < 64 || p.dstH < 16 || (p.dstH & 1)) return 0;
+    if (p.chrDstW * 2 != p.dstW || p.chrDstH * 2 != p.dstH || p.chrSrcW != 4 * p.chrDstW || p.chrSrcH != 4 * p.chrDstH) return 0;
+    if (!filter_is_edge_replication_ratio(p.hLum, p.srcW, 4, 6, 8, t.hL)) return 0;
+    if (!filter_is_edge_replication_ratio(p.hChr, p.chrSrcW, 4, 6, 8, t.hC)) return 0;
+    if (!filter_is_edge_replication_ratio(g.vLumEff, p.srcH, 4, 6, 8, t.vL)) return 0;
+    if (!filter_is_edge_replication_ratio(g.vChrEff, p.chrSrcH, 4, 6, 8, t.vC)) return 0;
+    for (int y = 0; y < p.dstH; y++) if (g.lumRound[y] != g.lumRound[0]) return 0;
+    for (int y = 0; y < p.chrDstH; y++) if (g.chrRound[y] != g.chrRound[0]) return 0;
+    t.lr = g.lumRound[0]; t.cr = g.chrRound[0];
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuv4x1(const Yuv4x1Args &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv4x1Args a = a0;
+    const int nstripsL = (a.dstW + D4_STRIP - 1) / D4_STRIP;
+    const int nstripsC = a.nv12 ? (a.chrDstW + D4_STRIP / 2 - 1) / (D4_STRIP / 2) : (a.chrDstW + D4_STRIP - 1) / D4_STRIP;
+    const int nplC = a.nv12 ? 1 : 2;
+    a.nsgL = nstripsL; a.nsgC = nstripsC;
+    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment (every plane)
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
+        seg = (int)std::min(45L, std::max(3L, (rows + 4095) / 4096));
+    }
+    a.segRows = seg;
+    a.nsegL = (a.dstH + seg - 1) / seg;
+    a.nsegC = (a.chrDstH + seg - 1) / seg;
+    a.nblkL = (a.nsegL * a.nsgL + 3) / 4;
+    a.nblk = a.nblkL + (a.nsegC * a.nsgC * nplC + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+    if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<true>), grid, block, 0, stream, a, *frames);
+    else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<false>), grid, block, 0, stream, a, *frames);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

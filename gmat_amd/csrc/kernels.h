@@ -393,6 +393,23 @@ struct Yuv4rArgs {
     Yuv2RgbConsts y2r;
 };
 int  yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv4rTables &t);
+// scale_yuv4x1_kernel (k_scale_yuv4r.hip): the 4:1 down-scale of 8-bit 4:2:0 into the same layout (4K -> 540p, 1080p -> 270p), every plane
+// walked on its own: 16 taps on [4x - 6, 4x + 9] on every axis
+struct Yuv4x1Tables {
+    int ok = 0;
+    int32_t hL[8] = {0}, hC[8] = {0}, vL[8] = {0}, vC[8] = {0};
+    int lr = 0, cr = 0;
+};
+struct Yuv4x1Args {
+    int ys, us, vs, nv12;
+    int dstW, dstH, chrDstW, chrDstH;
+    int ds, dsU, dsV;
+    int32_t hL[8], hC[8], vL[8], vC[8];
+    int lr, cr;
+    int segRows, nsegL, nsgL, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (nsg = strips per row)
+};
+int  yuv4x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv4x1Tables &t);
+int  launch_scale_yuv4x1(const Yuv4x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 int  launch_scale_yuv4r(const Yuv4rArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // scale_yuv32r_kernel (k_scale_yuv3x2.hip): NV12 at exactly two thirds of the size into packed RGB (1080p -> 720p, 4K -> 1440p), ONE

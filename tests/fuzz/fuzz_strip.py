@@ -81,6 +81,11 @@ for case in range(n):
             dw = rng.choice([4 * rng.randint(8, maxw // 16), 2 * rng.randint(16, maxw // 8)]); dh = rng.randint(6, 40)
             sw, sh = 4 * dw, 4 * dh
             if rng.random() < 0.06: sh += 2
+        if rng.random() < 0.06:                                 # the exact 4:1 down-scale family (scale_yuv4x1_kernel) and near misses
+            sf = rng.choice(YUV); df = sf if rng.random() < 0.85 else rng.choice(YUV)
+            dw = rng.choice([8 * rng.randint(8, maxw // 32), 4 * rng.randint(16, maxw // 16)]); dh = rng.choice([2 * rng.randint(8, 30), rng.randint(12, 50)])
+            sw, sh = 4 * dw, 4 * dh
+            if rng.random() < 0.06: sh += 2
         if rng.random() < 0.12:                                 # the exact 3:2 down-scale family (scale_yuv3x2_kernel) and near misses
             sf = rng.choice(YUV); df = sf if rng.random() < 0.85 else rng.choice(YUV)
             dw = rng.choice([16 * rng.randint(4, maxw // 24), 8 * rng.randint(8, maxw // 12)]); dh = rng.choice([4 * rng.randint(4, 30), 2 * rng.randint(8, 60)])
@@ -120,7 +125,7 @@ for case in range(n):
                 continue
             raise
         for p in d: p.free()
-        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3r", "scale_yuv3x2", "scale_yuv32r", "scale_yuv4r", "scale_rgb2h", "scale_rgb2y", "rgb2yuv420")) else kernel.split("<")[0]] += 1
+        hist[kernel if kernel.startswith(("scale_yuv2p", "scale_yuv2s", "scale_yuv1x2", "scale_yuv3x1", "scale_yuv3r", "scale_yuv3x2", "scale_yuv32r", "scale_yuv4r", "scale_yuv4x1", "scale_rgb2h", "scale_rgb2y", "rgb2yuv420")) else kernel.split("<")[0]] += 1
         bad = sum(int((g != w).sum()) for g, w in zip(got, want)) + sum(int((pd != 0xCD).sum()) for pd in pads)
         if bad:
             fails += 1

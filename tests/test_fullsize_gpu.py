@@ -244,6 +244,19 @@ def test_3_to_2_ladder_steps(gpu, orc, fmt, geom, which, monkeypatch):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
+@pytest.mark.parametrize("fmt,geom", [("nv12", (3840, 2160, 960, 540)), ("yuv420p", (3840, 2160, 960, 540))])
+def test_4k_to_540p(gpu, orc, fmt, geom):
+    """the 540p rung of a ladder from a 4K frame, every plane against the oracle"""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, fmt, sw, sh, seed=71)
+    want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
+    d = gpu.upload_planes(src, 256)
+    got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
+    assert k == "scale_yuv4x1_kernel", k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all() and (pd == 0xCD).all()
+
+
 @pytest.mark.parametrize("geom", [(3840, 2160, 960, 540, "rgb24"), (1920, 1080, 480, 270, "bgra")])
 def test_nv12_to_a_quarter_in_rgb(gpu, orc, geom):
     """4K -> 960x540 and 1080p -> 480x270 from NV12 into packed RGB at full size"""

@@ -62,7 +62,7 @@ def test_the_extraction_sees_the_kernels(disassembly):
     nsrc = len(glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "k_*.hip")))
     assert len(disassembly) >= nsrc, (len(disassembly), nsrc)
     allt = "\n".join(disassembly)
-    for k in ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
+    for k in ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
               "scale_yuv_kernel", "yuv2rgb_kernel"):
         assert k in allt, k
     assert allt.count("v_dot2") > 1000 and "v_perm_b32" in allt
@@ -105,7 +105,7 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
     into the kernel-argument block, or `cond ? P.x : P.y` on members of a struct the compiler keeps in memory each put it there
     silently — scale_yuv1x2_kernel's first build copied its argument block to scratch and ran at 10.4 us per frame.
     (The round-1 tiled kernels scale_rgb_kernel / scale_yuv2x_kernel carry 20 - 188 bytes of it; they are not listed.)"""
-    strip = ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel",
+    strip = ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
              "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
     hits, seen = {}, set()
     for t in disassembly:

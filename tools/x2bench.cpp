@@ -187,6 +187,7 @@ int main(int argc, char **argv)
         {"yuv420p 4K->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 4K->720p nv12 bicubic (3:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
         {"nv12 4K->720p rgb24 bicubic (3:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        {"nv12 4K->540p nv12 bicubic (4:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 960, 540, GMAT_SWS_BICUBIC},
         {"nv12 4K->540p rgb24 bicubic (4:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
         {"nv12 1080p->720p nv12 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
         {"nv12 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
