@@ -643,8 +643,9 @@ static Yuv4x1Args make_yuv4x1_args(const GmatSwsContext *c, const YuvScaleArgs &
 // the 4:1 NV12 -> packed RGB kernel: 16-byte loads on both planes
 static bool yuv4r_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
-    const uintptr_t sall = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
-    return c->y4r.ok && !c->rangeConv && ya.nv12 && (sall & 3) == 0 && ya.dstAligned && !ya.prof;
+    uintptr_t sall = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
+    if (!ya.nv12) sall |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
+    return c->y4r.ok && !c->rangeConv && ya.src16 == 0 && (ya.nv12 || ya.v) && (sall & 3) == 0 && ya.dstAligned && !ya.prof;
 }
 
 static Yuv4rArgs make_yuv4r_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
@@ -652,7 +653,7 @@ static Yuv4rArgs make_yuv4r_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     Yuv4rArgs a;
     std::memset(&a, 0, sizeof(a));
     const Yuv4rTables &t = c->y4r;
-    a.ys = ya.ys; a.us = ya.us; a.dstW = ya.dstW; a.dstH = ya.dstH; a.ds = ya.ds; a.dstFormat = ya.dstFormat;
+    a.ys = ya.ys; a.us = ya.us; a.vs = ya.vs; a.nv12 = ya.nv12; a.dstW = ya.dstW; a.dstH = ya.dstH; a.ds = ya.ds; a.dstFormat = ya.dstFormat;
     for (int k = 0; k < 8; k++) { a.hL[k] = t.hL[k]; a.hC[k] = t.hC[k]; a.vL[k] = t.vL[k]; }
     for (int k = 0; k < 4; k++) a.vC[k] = t.vC[k];
     a.lr = t.lr; a.cr = t.cr; a.y2r = ya.y2r;
@@ -945,7 +946,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             Yuv2xFrames fr;
             const int m = std::min(kYuv2xMaxFrames, n - f0);
             std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.v[i] = ta.nv12 ? nullptr : src_planes[4 * (f0 + i) + 2]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
             int r = launch_scale_yuv4r(ta, stream, &fr, m);
             if (r < 0) return r;
             c->lastLaunchFrames = m;
@@ -1583,7 +1584,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             if (yuv4r_eligible(c, ya)) {
                 Yuv2xFrames one;
                 std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.dst[0] = ya.dst;
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
                 c->lastKernel = "scale_yuv4r_kernel";
                 r = launch_scale_yuv4r(make_yuv4r_args(c, ya), c->stream, &one, 1);
                 break;

@@ -1,4 +1,4 @@
-// k_scale_yuv4r.hip — NV12 at exactly a quarter of the size into packed RGB (4K -> 960x540, 1080p -> 480x270: a decoder's frame into a
+// k_scale_yuv4r.hip — NV12 / YUV420P at exactly a quarter of the size into packed RGB (4K -> 960x540, 1080p -> 480x270: a decoder's frame into a
 // low-resolution analysis pass), with the arithmetic of ONE libswscale context (hScale8To15_c on both planes, yuv2rgb_X_c's vertical
 // sums and table stage), bit-exact.  The generic plane scaler serves it at ~0.1 of the HBM roofline.
 //
@@ -42,7 +42,8 @@ __device__ __forceinline__ int d4_dot2(int packed_ab, int packed_cd, int acc)
 }
 __device__ __forceinline__ unsigned d4_rep(unsigned v, unsigned sel) { return __builtin_amdgcn_perm(v, v, sel); }
 
-template <int DST>
+// NV: NV12 source (interleaved UV); else YUV420P (a lane's windows on the U and V planes are the 24 bytes at position 4c - 8 of each)
+template <int DST, bool NV>
 __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFrames fr)
 {
     constexpr bool BGR = (DST & 1) != 0;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
     const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);
     const int nSteps = nOut + 3;                                 // steps y0 - 3 .. y0 + nOut - 1: three open the sums of row y0
     const int srcW = 4 * a.dstW, srcH = 4 * a.dstH, chrH = srcH >> 1;
-    const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y];
+    const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y], *pv = fr.v[blockIdx.y];
     uint8_t *pd = fr.dst[blockIdx.y];
 
     const int xo = X0 + 4 * lane;
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
     const unsigned boL = (unsigned)(4 * xc - 8), lboL = boL + (isLeft ? 8u : 0u) - (isRight ? 8u : 0u);
     // UV window: positions 2 xc - 8 .. + 23 (48 bytes); 8 positions outside at the edges: 16 bytes further in
     const unsigned boC = 2u * (unsigned)(2 * xc - 8), lboC = boC + (isLeft ? 16u : 0u) - (isRight ? 16u : 0u);
+    // planar chroma: 24 bytes of each plane at position 2 xc - 8; 8 bytes further in at the edges
+    const unsigned boP = (unsigned)(2 * xc - 8), lboP = boP + (isLeft ? 8u : 0u) - (isRight ? 8u : 0u);
     (void)srcW;
 
     auto loadL = [&](int row, unsigned (&d)[8], auto edge_c) {
@@ -90,9 +93,20 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
         d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w;
     };
     auto loadC = [&](int row, unsigned (&d)[12], auto edge_c) {
-        const uint8_t *p = puv + ((unsigned)min(max(row, 0), chrH - 1) * (unsigned)a.us + (decltype(edge_c)::value ? lboC : boC));
-        const uint4 t = d4_ld16(p), u = d4_ld16(p + 16), v = d4_ld16(p + 32);
-        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w; d[8] = v.x; d[9] = v.y; d[10] = v.z; d[11] = v.w;
+        const unsigned rc = (unsigned)min(max(row, 0), chrH - 1);
+        if constexpr (NV) {
+            const uint8_t *p = puv + (rc * (unsigned)a.us + (decltype(edge_c)::value ? lboC : boC));
+            const uint4 t = d4_ld16(p), u = d4_ld16(p + 16), v = d4_ld16(p + 32);
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w; d[8] = v.x; d[9] = v.y; d[10] = v.z; d[11] = v.w;
+        } else {
+            // d[0 .. 5]: the U window, d[6 .. 11]: the V window
+            const unsigned off = decltype(edge_c)::value ? lboP : boP;
+            const uint8_t *pu_ = puv + (rc * (unsigned)a.us + off), *pv_ = pv + (rc * (unsigned)a.vs + off);
+            const uint4 t = d4_ld16(pu_), v = d4_ld16(pv_);
+            const unsigned t4 = *reinterpret_cast<const unsigned *>(pu_ + 16), t5 = *reinterpret_cast<const unsigned *>(pu_ + 20);
+            const unsigned v4 = *reinterpret_cast<const unsigned *>(pv_ + 16), v5 = *reinterpret_cast<const unsigned *>(pv_ + 20);
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; d[4] = t4; d[5] = t5; d[6] = v.x; d[7] = v.y; d[8] = v.z; d[9] = v.w; d[10] = v4; d[11] = v5;
+        }
     };
     // hScale8To15_c of a luma row: the lane's 4 sums >> 7 (the saturation is the pack's)
     auto hrowL = [&](const unsigned (&src)[8], auto edge_c, int (&s)[4]) {
@@ -124,19 +138,38 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
         unsigned d[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) d[i] = src[i];
-        if constexpr (decltype(edge_c)::value) {
-            const unsigned first = d4_rep(src[0], 0x01000100u), last = d4_rep(src[11], 0x03020302u);
+        int pU[12], pV[12];                                      // position pairs (2i, 2i + 1) per channel; pairs 0 and 11 carry no tap
+        if constexpr (NV) {
+            if constexpr (decltype(edge_c)::value) {
+                const unsigned first = d4_rep(src[0], 0x01000100u), last = d4_rep(src[11], 0x03020302u);
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const unsigned fromLeft = i < 4 ? first : src[i - 4], fromRight = i > 7 ? last : src[i + 4];
-                d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+                for (int i = 0; i < 12; i++) {
+                    const unsigned fromLeft = i < 4 ? first : src[i - 4], fromRight = i > 7 ? last : src[i + 4];
+                    d[i] = isLeft ? fromLeft : isRight ? fromRight : src[i];
+                }
             }
-        }
-        int pU[12], pV[12];                                      // position pairs (2i, 2i + 1) per channel; dwords 0 and 11 carry no tap
 #pragma unroll
-        for (int i = 1; i < 11; i++) {
-            pU[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C020C00u);
-            pV[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C030C01u);
+            for (int i = 1; i < 11; i++) {
+                pU[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C020C00u);
+                pV[i] = (int)__builtin_amdgcn_perm(0u, d[i], 0x0C030C01u);
+            }
+        } else {
+            if constexpr (decltype(edge_c)::value) {
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const unsigned first = d4_rep(src[6 * pl], 0x00000000u), last = d4_rep(src[6 * pl + 5], 0x03030303u);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const unsigned fromLeft = i < 2 ? first : src[6 * pl + i - 2], fromRight = i > 3 ? last : src[6 * pl + i + 2];
+                        d[6 * pl + i] = isLeft ? fromLeft : isRight ? fromRight : src[6 * pl + i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 1; i < 11; i++) {                          // pair i = the half i & 1 of the plane's dword i >> 1
+                pU[i] = (int)__builtin_amdgcn_perm(0u, d[i >> 1], (i & 1) ? 0x0C030C02u : 0x0C010C00u);
+                pV[i] = (int)__builtin_amdgcn_perm(0u, d[6 + (i >> 1)], (i & 1) ? 0x0C030C02u : 0x0C010C00u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -461,7 +494,7 @@ int yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv4rTables &t)
     const char *off = getenv("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut) return 0;
-    if (p.srcFormat != GMAT_PIX_FMT_NV12) return 0;
+    if (p.srcFormat != GMAT_PIX_FMT_NV12 && p.srcFormat != GMAT_PIX_FMT_YUV420P) return 0;
     if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
           p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
     if (p.srcW != 4 * p.dstW || p.srcH != 4 * p.dstH || p.dstW % 4 || p.dstW < 32 || p.dstH < 8) return 0;
@@ -495,13 +528,16 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nblk = (a.nseg * a.nstrips + 3) / 4;
     a.xcdRemap = 1;
     const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+#define GMAT_D4R(D) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, true>), grid, block, 0, stream, a, *frames); \
+                        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, false>), grid, block, 0, stream, a, *frames); } while (0)
     switch (a.dstFormat) {
-    case GMAT_PIX_FMT_RGB24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<0>), grid, block, 0, stream, a, *frames); break;
-    case GMAT_PIX_FMT_BGR24: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<1>), grid, block, 0, stream, a, *frames); break;
-    case GMAT_PIX_FMT_RGBA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<2>), grid, block, 0, stream, a, *frames); break;
-    case GMAT_PIX_FMT_BGRA:  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<3>), grid, block, 0, stream, a, *frames); break;
+    case GMAT_PIX_FMT_RGB24: GMAT_D4R(0); break;
+    case GMAT_PIX_FMT_BGR24: GMAT_D4R(1); break;
+    case GMAT_PIX_FMT_RGBA:  GMAT_D4R(2); break;
+    case GMAT_PIX_FMT_BGRA:  GMAT_D4R(3); break;
     default: return GMAT_ERR(EINVAL);
     }
+#undef GMAT_D4R
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -386,7 +386,7 @@ struct Yuv4rTables {
     int lr = 0, cr = 0;
 };
 struct Yuv4rArgs {
-    int ys, us, dstW, dstH, ds, dstFormat;
+    int ys, us, vs, nv12, dstW, dstH, ds, dstFormat;
     int32_t hL[8], hC[8], vL[8], vC[4];
     int lr, cr;
     int segRows, nseg, nstrips, nblk, xcdRemap;           // filled by the launcher

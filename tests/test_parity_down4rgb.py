@@ -16,8 +16,8 @@ D4R = "scale_yuv4r_kernel"
 
 
 def d4r_takes(dw, dh, sf):
-    """the geometry part of yuv4r_prepare restated: NV12 source, destination width a multiple of 4 and >= 32, height >= 8"""
-    return sf == "nv12" and dw % 4 == 0 and dw >= 32 and dh >= 8
+    """the geometry part of yuv4r_prepare restated: NV12 or YUV420P source, destination width a multiple of 4 and >= 32, height >= 8"""
+    return sf in ("nv12", "yuv420p") and dw % 4 == 0 and dw >= 32 and dh >= 8
 
 
 @pytest.fixture(params=["strip", "generic"])
@@ -70,8 +70,17 @@ def test_down4rgb_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_d4r, df, 
         assert k.startswith("scale_yuv_kernel"), k
 
 
-def test_down4rgb_planar_source_stays_generic(dev, orc):
-    assert _check(dev, orc, "yuv420p", "rgb24", 264, 14).startswith("scale_yuv_kernel")
+@pytest.mark.parametrize("df", ["rgb24", "bgra"])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_down4rgb_planar_source(dev, orc, strip_rows, kern_d4r, df, geom):
+    """YUV420P sources: the windows on the U and V planes are dword-aligned at this ratio (position 4c - 8, c even)"""
+    dw, dh = geom
+    strip_rows(0)
+    k = _check(dev, orc, "yuv420p", df, dw, dh)
+    if kern_d4r == "strip" and d4r_takes(dw, dh, "yuv420p"):
+        assert k == D4R, k
+    else:
+        assert k.startswith("scale_yuv_kernel"), k
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 6, 7, 10, 64])

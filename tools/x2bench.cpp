@@ -206,6 +206,7 @@ int main(int argc, char **argv)
         {"land: nv12 1080p->360p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 640, 360, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->1080p yuv444p bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"land: yuv420p 1080p->720p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_SWS_BICUBIC},
+        {"land: yuv420p 4K->540p rgb24 bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_RGB24, 960, 540, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->1440p rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 2560, 1440, GMAT_SWS_BICUBIC},
         {"land: nv12 4K->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
         {"nv12 1080p->4K nv12 bicubic (up)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
