@@ -70,6 +70,21 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
     const int X0 = (unit - seg * a.nstrips) * D4_STRIP;
     const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);
     const int nSteps = nOut + 3;                                 // steps y0 - 3 .. y0 + nOut - 1: three open the sums of row y0
+    // Odd segments walk UPWARD (k_scale_yuv3x1.hip): the same steps over the rows in descending order — step y then takes the FIRST rows of
+    // row y's windows, 4y - 3 .. 4y - 6 and 2y - 2, 2y - 3 — with the tap pairs taken in reverse and their halves swapped.  A segment and its
+    // neighbour then reach their common boundary at the same time and the warm-up rows are read from HBM once (L2 hits for the other).
+    const int up = a.updown & seg & 1;
+    auto sw16 = [](int32_t v) { return (int32_t)(((uint32_t)v >> 16) | ((uint32_t)v << 16)); };
+    int32_t vvL[8], vvC[4];                                      // wave-uniform: scalar registers
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int32_t r = sw16(a.vL[7 - k]); vvL[k] = a.vL[k] ^ ((a.vL[k] ^ r) & -up); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int32_t r = sw16(a.vC[3 - k]); vvC[k] = a.vC[k] ^ ((a.vC[k] ^ r) & -up); }
+    const int yFirst = up ? y0 + nOut + 2 : y0 - 3, yDir = up ? -1 : 1;
+    // rows of step y: luma lumaBase(y) + yDir * r, chroma chrBase(y) + yDir * r; never outside the rows the segment needs
+    const int lLo = 4 * y0 - 6, lHi = 4 * (y0 + nOut - 1) + 9, cLo = 2 * y0 - 3, cHi = 2 * (y0 + nOut - 1) + 4;
+    auto lumaRow = [&](int y, int r) { return min(max(up ? 4 * y - 3 - r : 4 * y + 6 + r, lLo), lHi); };
+    auto chrRow = [&](int y, int r) { return min(max(up ? 2 * y - 2 - r : 2 * y + 3 + r, cLo), cHi); };
     const int srcW = 4 * a.dstW, srcH = 4 * a.dstH, chrH = srcH >> 1;
     const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y], *pv = fr.v[blockIdx.y];
     uint8_t *pd = fr.dst[blockIdx.y];
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
     const unsigned dstOff = (unsigned)xo * BPP;
 
     auto emit = [&](int yo, const int (&YS)[4], const int (&CS)[4]) {
-        if (yo < y0) return;                                     // wave-uniform: the warm-up steps
+        if (yo < y0 || yo >= y0 + nOut) return;                  // wave-uniform: the warm-up steps
         const int iU[2] = {clip_u8_shr(CS[0], 19), clip_u8_shr(CS[2], 19)}, iV[2] = {clip_u8_shr(CS[1], 19), clip_u8_shr(CS[3], 19)};
         unsigned c0[4], c1[4], c2[4];
 #pragma unroll
@@ -228,48 +243,47 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
 
     auto body = [&](const int i, auto ph_c, auto edge_c) {
         constexpr int PH = decltype(ph_c)::value;                // i & 3: names the slots
-        const int y = y0 - 3 + i;                                // the output row this step closes
-        // slots: row y in PH, y + 1 in PH + 1, y + 2 in PH + 2, y + 3 (opens here) in PH + 3 (mod 4)
+        const int y = yFirst + yDir * i;                         // the output row this step closes
+        // slots: row y in PH, the next three rows of the walk in PH + 1, PH + 2 and (opening here) PH + 3 (mod 4)
         constexpr int S0 = PH & 3, S1 = (PH + 1) & 3, S2 = (PH + 2) & 3, S3 = (PH + 3) & 3;
         int YS[4], CS[4];
         // luma quad u = y + 1: rows 4u + 2 .. 4u + 5, taps (12 + r) / (8 + r) / (4 + r) / r for the rows y, y + 1, y + 2, y + 3
         {
             int hA[4], hB[4], hC[4], hD[4];
-            hrowL(bufL[0], edge_c, hA); loadL(4 * (y + 2) + 2, bufL[0], edge_c);
-            hrowL(bufL[1], edge_c, hB); loadL(4 * (y + 2) + 3, bufL[1], edge_c);
-            hrowL(bufL[2], edge_c, hC); loadL(4 * (y + 2) + 4, bufL[2], edge_c);
-            hrowL(bufL[3], edge_c, hD); loadL(4 * (y + 2) + 5, bufL[3], edge_c);
+            hrowL(bufL[0], edge_c, hA); loadL(lumaRow(y + yDir, 0), bufL[0], edge_c);
+            hrowL(bufL[1], edge_c, hB); loadL(lumaRow(y + yDir, 1), bufL[1], edge_c);
+            hrowL(bufL[2], edge_c, hC); loadL(lumaRow(y + yDir, 2), bufL[2], edge_c);
+            hrowL(bufL[3], edge_c, hD); loadL(lumaRow(y + yDir, 3), bufL[3], edge_c);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int ab = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hA[q], hB[q]));
                 const int cd = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hC[q], hD[q]));
-                YS[q] = d4_dot2(cd, a.vL[7], d4_dot2(ab, a.vL[6], accL[S0][q]));
-                accL[S1][q] = d4_dot2(cd, a.vL[5], d4_dot2(ab, a.vL[4], accL[S1][q]));
-                accL[S2][q] = d4_dot2(cd, a.vL[3], d4_dot2(ab, a.vL[2], accL[S2][q]));
-                accL[S3][q] = d4_dot2(cd, a.vL[1], d4_dot2(ab, a.vL[0], a.lr));
+                YS[q] = d4_dot2(cd, vvL[7], d4_dot2(ab, vvL[6], accL[S0][q]));
+                accL[S1][q] = d4_dot2(cd, vvL[5], d4_dot2(ab, vvL[4], accL[S1][q]));
+                accL[S2][q] = d4_dot2(cd, vvL[3], d4_dot2(ab, vvL[2], accL[S2][q]));
+                accL[S3][q] = d4_dot2(cd, vvL[1], d4_dot2(ab, vvL[0], a.lr));
             }
         }
         // chroma pair m = y + 2: rows 2m - 1, 2m, taps (6, 7) / (4, 5) / (2, 3) / (0, 1) for the rows y, y + 1, y + 2, y + 3
         {
             int hA[4], hB[4];
-            hrowC(bufC[0], edge_c, hA); loadC(2 * (y + 3) - 1, bufC[0], edge_c);
-            hrowC(bufC[1], edge_c, hB); loadC(2 * (y + 3), bufC[1], edge_c);
+            hrowC(bufC[0], edge_c, hA); loadC(chrRow(y + yDir, 0), bufC[0], edge_c);
+            hrowC(bufC[1], edge_c, hB); loadC(chrRow(y + yDir, 1), bufC[1], edge_c);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int ab = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hA[q], hB[q]));
-                CS[q] = d4_dot2(ab, a.vC[3], accC[S0][q]);
-                accC[S1][q] = d4_dot2(ab, a.vC[2], accC[S1][q]);
-                accC[S2][q] = d4_dot2(ab, a.vC[1], accC[S2][q]);
-                accC[S3][q] = d4_dot2(ab, a.vC[0], a.cr);
+                CS[q] = d4_dot2(ab, vvC[3], accC[S0][q]);
+                accC[S1][q] = d4_dot2(ab, vvC[2], accC[S1][q]);
+                accC[S2][q] = d4_dot2(ab, vvC[1], accC[S2][q]);
+                accC[S3][q] = d4_dot2(ab, vvC[0], a.cr);
             }
         }
         emit(y, YS, CS);
     };
     auto run = [&](auto edge_c) {
-        const int ys = y0 - 3;                                   // first step
 #pragma unroll
-        for (int r = 0; r < 4; r++) loadL(4 * (ys + 1) + 2 + r, bufL[r], edge_c);
-        loadC(2 * (ys + 2) - 1, bufC[0], edge_c); loadC(2 * (ys + 2), bufC[1], edge_c);
+        for (int r = 0; r < 4; r++) loadL(lumaRow(yFirst, r), bufL[r], edge_c);
+        loadC(chrRow(yFirst, 0), bufC[0], edge_c); loadC(chrRow(yFirst, 1), bufC[1], edge_c);
         for (int i0 = 0; i0 < nSteps; i0 += 4) {
             body(i0, std::integral_constant<int, 0>(), edge_c);
             if (i0 + 1 < nSteps) body(i0 + 1, std::integral_constant<int, 1>(), edge_c);
@@ -294,8 +308,15 @@ struct D4Plane {
 
 // NW = dwords of a lane's window per row; LOAD(row, d, edge_c) / HROW(d, edge_c, s[4]) / STORE(y, w[4]) are the plane kind's
 template <int NW, typename Load, typename HRow, typename Store>
-__device__ __forceinline__ void d4_walk(const D4Plane &P, int y0, int nOut, bool edgeWave, Load &&load, HRow &&hrow, Store &&store)
+__device__ __forceinline__ void d4_walk(const D4Plane &P, int y0, int nOut, bool edgeWave, int up, Load &&load, HRow &&hrow, Store &&store)
 {
+    auto sw16 = [](int32_t v) { return (int32_t)(((uint32_t)v >> 16) | ((uint32_t)v << 16)); };
+    int32_t vv[8];                                               // upward segments: the tap pairs reversed, halves swapped (see the kernel above)
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int32_t r = sw16(P.v[7 - k]); vv[k] = P.v[k] ^ ((P.v[k] ^ r) & -up); }
+    const int yFirst = up ? y0 + nOut + 2 : y0 - 3, yDir = up ? -1 : 1;
+    const int rLo = 4 * y0 - 6, rHi = 4 * (y0 + nOut - 1) + 9;
+    auto rowOf = [&](int y, int r) { return min(max(up ? 4 * y - 3 - r : 4 * y + 6 + r, rLo), rHi); };
     int acc[4][4];
 #pragma unroll
     for (int s = 0; s < 4; s++)
@@ -306,27 +327,27 @@ __device__ __forceinline__ void d4_walk(const D4Plane &P, int y0, int nOut, bool
     auto body = [&](const int i, auto ph_c, auto edge_c) {
         constexpr int PH = decltype(ph_c)::value;
         constexpr int S0 = PH & 3, S1 = (PH + 1) & 3, S2 = (PH + 2) & 3, S3 = (PH + 3) & 3;
-        const int y = y0 - 3 + i;
+        const int y = yFirst + yDir * i;
         int hA[4], hB[4], hC[4], hD[4];
-        hrow(buf[0], edge_c, hA); load(4 * (y + 2) + 2, buf[0], edge_c);
-        hrow(buf[1], edge_c, hB); load(4 * (y + 2) + 3, buf[1], edge_c);
-        hrow(buf[2], edge_c, hC); load(4 * (y + 2) + 4, buf[2], edge_c);
-        hrow(buf[3], edge_c, hD); load(4 * (y + 2) + 5, buf[3], edge_c);
+        hrow(buf[0], edge_c, hA); load(rowOf(y + yDir, 0), buf[0], edge_c);
+        hrow(buf[1], edge_c, hB); load(rowOf(y + yDir, 1), buf[1], edge_c);
+        hrow(buf[2], edge_c, hC); load(rowOf(y + yDir, 2), buf[2], edge_c);
+        hrow(buf[3], edge_c, hD); load(rowOf(y + yDir, 3), buf[3], edge_c);
         unsigned w[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int ab = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hA[q], hB[q]));
             const int cd = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(hC[q], hD[q]));
-            w[q] = (unsigned)clip_u8_shr(d4_dot2(cd, P.v[7], d4_dot2(ab, P.v[6], acc[S0][q])), 19);
-            acc[S1][q] = d4_dot2(cd, P.v[5], d4_dot2(ab, P.v[4], acc[S1][q]));
-            acc[S2][q] = d4_dot2(cd, P.v[3], d4_dot2(ab, P.v[2], acc[S2][q]));
-            acc[S3][q] = d4_dot2(cd, P.v[1], d4_dot2(ab, P.v[0], P.rnd));
+            w[q] = (unsigned)clip_u8_shr(d4_dot2(cd, vv[7], d4_dot2(ab, vv[6], acc[S0][q])), 19);
+            acc[S1][q] = d4_dot2(cd, vv[5], d4_dot2(ab, vv[4], acc[S1][q]));
+            acc[S2][q] = d4_dot2(cd, vv[3], d4_dot2(ab, vv[2], acc[S2][q]));
+            acc[S3][q] = d4_dot2(cd, vv[1], d4_dot2(ab, vv[0], P.rnd));
         }
-        if (y >= y0) store(y, w);                                // wave-uniform
+        if (y >= y0 && y < y0 + nOut) store(y, w);               // wave-uniform
     };
     auto run = [&](auto edge_c) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) load(4 * (y0 - 2) + 2 + r, buf[r], edge_c);
+        for (int r = 0; r < 4; r++) load(rowOf(yFirst, r), buf[r], edge_c);
         for (int i0 = 0; i0 < nSteps; i0 += 4) {
             body(i0, std::integral_constant<int, 0>(), edge_c);
             if (i0 + 1 < nSteps) body(i0 + 1, std::integral_constant<int, 1>(), edge_c);
@@ -338,7 +359,7 @@ __device__ __forceinline__ void d4_walk(const D4Plane &P, int y0, int nOut, bool
 }
 
 // one single-channel plane: the output rows [y0, y0 + nOut) of the strip at X0
-__device__ __forceinline__ void d4_walk_plane(const D4Plane &P, int X0, int y0, int nOut, int lane)
+__device__ __forceinline__ void d4_walk_plane(const D4Plane &P, int X0, int y0, int nOut, int up, int lane)
 {
     const int srcW = 4 * P.dstW, srcH = 4 * P.dstH;
     const int xo = X0 + 4 * lane;
@@ -379,11 +400,11 @@ __device__ __forceinline__ void d4_walk_plane(const D4Plane &P, int X0, int y0, 
     auto store = [&](int y, const unsigned (&w)[4]) {
         if (active) *reinterpret_cast<unsigned *>(P.dst + ((unsigned)y * (unsigned)P.ds + (unsigned)xo)) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
     };
-    d4_walk<8>(P, y0, nOut, edgeWave, load, hrow, store);
+    d4_walk<8>(P, y0, nOut, edgeWave, up, load, hrow, store);
 }
 
 // NV12's interleaved UV plane: a lane makes 2 UV output positions (4 bytes)
-__device__ __forceinline__ void d4_walk_uv(const D4Plane &P, int X0, int y0, int nOut, int lane)
+__device__ __forceinline__ void d4_walk_uv(const D4Plane &P, int X0, int y0, int nOut, int up, int lane)
 {
     const int srcW = 4 * P.dstW, srcH = 4 * P.dstH;              // in UV positions
     const int co = X0 + 2 * lane;
@@ -426,7 +447,7 @@ __device__ __forceinline__ void d4_walk_uv(const D4Plane &P, int X0, int y0, int
     auto store = [&](int y, const unsigned (&w)[4]) {
         if (active) *reinterpret_cast<unsigned *>(P.dst + ((unsigned)y * (unsigned)P.ds + 2u * (unsigned)co)) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
     };
-    d4_walk<12>(P, y0, nOut, edgeWave, load, hrow, store);
+    d4_walk<12>(P, y0, nOut, edgeWave, up, load, hrow, store);
 }
 
 __device__ __forceinline__ D4Plane d4_plane(const uint8_t *src, uint8_t *dst, int ss, int ds, int dstW, int dstH,
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(256) void scale_yuv4x1_kernel(Yuv4x1Args a, Yuv2xFr
         const int X0 = (unit - seg * a.nsgL) * D4_STRIP;
         const int y0 = seg * a.segRows;
         const D4Plane P = d4_plane(fr.y[f], fr.dst[f], a.ys, a.ds, a.dstW, a.dstH, a.hL, a.vL, a.lr);
-        d4_walk_plane(P, X0, y0, min(a.segRows, a.dstH - y0), lane);
+        d4_walk_plane(P, X0, y0, min(a.segRows, a.dstH - y0), a.updown & seg & 1, lane);
         return;
     }
     int unit = (lin - a.nblkL) * 4 + wave;
@@ -471,7 +492,7 @@ __global__ __launch_bounds__(256) void scale_yuv4x1_kernel(Yuv4x1Args a, Yuv2xFr
         const int X0 = (unit - seg * a.nsgC) * (D4_STRIP / 2);
         const int y0 = seg * a.segRows;
         const D4Plane P = d4_plane(fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrDstW, a.chrDstH, a.hC, a.vC, a.cr);
-        d4_walk_uv(P, X0, y0, min(a.segRows, a.chrDstH - y0), lane);
+        d4_walk_uv(P, X0, y0, min(a.segRows, a.chrDstH - y0), a.updown & seg & 1, lane);
     } else {
         if (unit >= 2 * per) return;
         const int pl = __builtin_amdgcn_readfirstlane(unit >= per ? 1 : 0);
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(256) void scale_yuv4x1_kernel(Yuv4x1Args a, Yuv2xFr
         const int y0 = seg * a.segRows;
         const D4Plane P = d4_plane(pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
                                    a.chrDstW, a.chrDstH, a.hC, a.vC, a.cr);
-        d4_walk_plane(P, X0, y0, min(a.segRows, a.chrDstH - y0), lane);
+        d4_walk_plane(P, X0, y0, min(a.segRows, a.chrDstH - y0), a.updown & seg & 1, lane);
     }
 }
 
@@ -527,6 +548,7 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nseg = (a.dstH + seg - 1) / seg;
     a.nblk = (a.nseg * a.nstrips + 3) / 4;
     a.xcdRemap = 1;
+    { const char *ud = getenv("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }      // 0: every segment walks downward (test / measurement)
     const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
 #define GMAT_D4R(D) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, true>), grid, block, 0, stream, a, *frames); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, false>), grid, block, 0, stream, a, *frames); } while (0)
@@ -585,6 +607,7 @@ int launch_scale_yuv4x1(const Yuv4x1Args &a0, hipStream_t stream, const Yuv2xFra
     a.nblkL = (a.nsegL * a.nsgL + 3) / 4;
     a.nblk = a.nblkL + (a.nsegC * a.nsgC * nplC + 3) / 4;
     a.xcdRemap = 1;
+    { const char *ud = getenv("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }
     const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
     if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<true>), grid, block, 0, stream, a, *frames);
     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<false>), grid, block, 0, stream, a, *frames);

@@ -389,7 +389,7 @@ struct Yuv4rArgs {
     int ys, us, vs, nv12, dstW, dstH, ds, dstFormat;
     int32_t hL[8], hC[8], vL[8], vC[4];
     int lr, cr;
-    int segRows, nseg, nstrips, nblk, xcdRemap;           // filled by the launcher
+    int segRows, nseg, nstrips, nblk, xcdRemap, updown;   // filled by the launcher; updown: odd segments walk upward
     Yuv2RgbConsts y2r;
 };
 int  yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv4rTables &t);
@@ -406,7 +406,7 @@ struct Yuv4x1Args {
     int ds, dsU, dsV;
     int32_t hL[8], hC[8], vL[8], vC[8];
     int lr, cr;
-    int segRows, nsegL, nsgL, nsegC, nsgC, nblkL, nblk, xcdRemap;     // filled by the launcher (nsg = strips per row)
+    int segRows, nsegL, nsgL, nsegC, nsgC, nblkL, nblk, xcdRemap, updown;     // filled by the launcher (nsg = strips per row)
 };
 int  yuv4x1_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv4x1Tables &t);
 int  launch_scale_yuv4x1(const Yuv4x1Args &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);

@@ -70,10 +70,16 @@ def test_down3_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_d3, fmt, geo
         assert k.startswith("scale_yuv_kernel"), k
 
 
+@pytest.mark.parametrize("updown", ["alternating", "all-down"])
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 7, 8, 13, 64])
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
-def test_down3_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows):
+def test_down3_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt, rows, monkeypatch, updown):
     """segments of `rows` output rows (on every plane): the three warm-up steps of every segment rebuild the open sums of its first rows"""
+    # odd segments walk upward by default (reversed row order, tap pairs reversed with swapped halves); GMAT_STRIP_UPDOWN=0: all downward
+    if updown == "all-down":
+        monkeypatch.setenv("GMAT_STRIP_UPDOWN", "0")
+    else:
+        monkeypatch.delenv("GMAT_STRIP_UPDOWN", raising=False)
     strip_rows(rows)
     assert _check(dev, orc, fmt, 264, 26) == D3
 

@@ -83,10 +83,16 @@ def test_down4rgb_planar_source(dev, orc, strip_rows, kern_d4r, df, geom):
         assert k.startswith("scale_yuv_kernel"), k
 
 
+@pytest.mark.parametrize("updown", ["alternating", "all-down"])
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 6, 7, 10, 64])
 @pytest.mark.parametrize("df", ["rgb24", "bgra"])
-def test_down4rgb_segmentation_does_not_change_the_result(dev, orc, strip_rows, df, rows):
+def test_down4rgb_segmentation_does_not_change_the_result(dev, orc, strip_rows, df, rows, monkeypatch, updown):
     """segments of `rows` output rows: the three warm-up steps of every segment rebuild the open luma and chroma sums of its first rows"""
+    # odd segments walk upward by default (reversed row order, tap pairs reversed with swapped halves); GMAT_STRIP_UPDOWN=0: all downward
+    if updown == "all-down":
+        monkeypatch.setenv("GMAT_STRIP_UPDOWN", "0")
+    else:
+        monkeypatch.delenv("GMAT_STRIP_UPDOWN", raising=False)
     strip_rows(rows)
     assert _check(dev, orc, "nv12", df, 264, 26) == D4R
 
