@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a,
     const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);          // y0 is even
     const int T0 = y0 >> 1, nT = ((y0 + nOut + 2) >> 1) - T0 + 1;
     const int srcW = 3 * a.dstW, srcH = 3 * a.dstH, chrH = srcH >> 1;
+    const int lLast = 6 * (T0 + nT - 1), cLast = 3 * (T0 + nT - 1);        // the last rows the segment uses: nothing beyond is requested ahead
     const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y];
     uint8_t *pd = fr.dst[blockIdx.y];
 
@@ -500,11 +501,11 @@ __global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a,
         constexpr int U4 = decltype(u4_c)::value, SUB = decltype(sub_c)::value;
         int hA[4], hB[4], hC[4];
         hrowL(bufL[SUB][0], edge_c, hA);
-        loadL(6 * (T + 1) - 5 + 3 * SUB + 0, bufL[SUB][0], edge_c);
+        loadL(min(6 * (T + 1) - 5 + 3 * SUB + 0, lLast), bufL[SUB][0], edge_c);
         hrowL(bufL[SUB][1], edge_c, hB);
-        loadL(6 * (T + 1) - 5 + 3 * SUB + 1, bufL[SUB][1], edge_c);
+        loadL(min(6 * (T + 1) - 5 + 3 * SUB + 1, lLast), bufL[SUB][1], edge_c);
         hrowL(bufL[SUB][2], edge_c, hC);
-        loadL(6 * (T + 1) - 5 + 3 * SUB + 2, bufL[SUB][2], edge_c);
+        loadL(min(6 * (T + 1) - 5 + 3 * SUB + 2, lLast), bufL[SUB][2], edge_c);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             // hScale8To15_c: min(val >> 7, 32767) — the pack saturates
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a,
         // ---- first half: luma rows 6T - 5 .. 6T - 3, chroma row 3T - 2 -> output row 2T - 3
         luma_triple(T, std::integral_constant<int, (2 * PAR) & 3>(), I0(), edge_c, YS);
         hrowC(bufC[0], edge_c, cv);
-        loadC(3 * (T + 1) - 2, bufC[0], edge_c);
+        loadC(min(3 * (T + 1) - 2, cLast), bufC[0], edge_c);
         // row 3T - 2: even 2T opens (A0), even 2T - 2 (A3), odd 2T - 1 (B2), odd 2T - 3 closes (B5)
         chroma_row(cv, SE0(), SEm2(), SOm1(), SOm3(), std::true_type(), a.cA[0], a.cA[3], s_m1 ? a.cS[2] : a.cB[2], s_m3 ? a.cS[5] : a.cB[5]);
 #pragma unroll
@@ -552,11 +553,11 @@ __global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a,
         // ---- second half: luma rows 6T - 2 .. 6T, chroma rows 3T - 1, 3T -> output row 2T - 2
         luma_triple(T, std::integral_constant<int, (2 * PAR + 1) & 3>(), I1(), edge_c, YS);
         hrowC(bufC[1], edge_c, cv);
-        loadC(3 * (T + 1) - 1, bufC[1], edge_c);
+        loadC(min(3 * (T + 1) - 1, cLast), bufC[1], edge_c);
         // row 3T - 1: odd 2T + 1 opens (B0), even 2T (A1), even 2T - 2 (A4), odd 2T - 1 (B3)
         chroma_row(cv, SOp1(), SE0(), SEm2(), SOm1(), std::true_type(), s_p1 ? a.cS[0] : a.cB[0], a.cA[1], a.cA[4], s_m1 ? a.cS[3] : a.cB[3]);
         hrowC(bufC[2], edge_c, cv);
-        loadC(3 * (T + 1), bufC[2], edge_c);
+        loadC(min(3 * (T + 1), cLast), bufC[2], edge_c);
         // row 3T: odd 2T + 1 (B1), even 2T (A2), even 2T - 2 closes (A5), odd 2T - 1 (B4)
         chroma_row(cv, SOp1(), SE0(), SEm2(), SOm1(), std::false_type(), s_p1 ? a.cS[1] : a.cB[1], a.cA[2], a.cA[5], s_m1 ? a.cS[4] : a.cB[4]);
 #pragma unroll

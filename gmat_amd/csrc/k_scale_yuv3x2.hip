@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256) void scale_yuv32r_kernel(Yuv32rArgs a, Yuv2xFr
     const int X0 = (unit - seg * a.nstrips) * E3_STRIP;
     const int y0 = seg * a.segRows, nOut = min(a.segRows, a.dstH - y0);          // y0 is a multiple of 4
     const int T0 = y0 >> 1, nT = ((y0 + nOut + 2) >> 1) - T0 + 1;                // T0 is even
+    const int lLast = 3 * (T0 + nT - 1), cLast = 3 * ((T0 + nT - 1) >> 1) + 1;  // the last luma / chroma rows the segment uses: nothing beyond is requested ahead
     const int srcW = 3 * (a.dstW >> 1), srcH = 3 * (a.dstH >> 1), chrH = srcH >> 1;
     const uint8_t *py = fr.y[blockIdx.y], *puv = fr.u[blockIdx.y];
     uint8_t *pd = fr.dst[blockIdx.y];
@@ -535,34 +536,34 @@ __global__ __launch_bounds__(256) void scale_yuv32r_kernel(Yuv32rArgs a, Yuv2xFr
         int v[8];
         // luma row 3T - 2: even 2T opens (A0), even 2T - 2 (A3), odd 2T - 1 (B2), odd 2T - 3 closes (B5)
         hrowL(bufL[PAR][0], edge_c, v);
-        loadL(3 * (T + 2) - 2, bufL[PAR][0], edge_c);
+        loadL(min(3 * (T + 2) - 2, lLast), bufL[PAR][0], edge_c);
         luma_row(v, SE0(), SEm2(), SOm1(), SOm3(), std::true_type(), a.lA[0], a.lA[3], s_m1 ? a.lS[2] : a.lB[2], s_m3 ? a.lS[5] : a.lB[5]);
         if (PAR == 0) {
             // T = 2k: chroma row 3k - 1 -> output row 4k - 3 (phase 3; row 1 at T = 2 has its own taps)
             const int kap = T >> 1;
             push(bufC[0], edge_c);
-            loadC(3 * (kap + 1) - 1, bufC[0], edge_c);
+            loadC(min(3 * (kap + 1) - 1, cLast), bufC[0], edge_c);
             emit(2 * T - 3, SOm3(), s_m3 ? a.cS1[0] : a.cP[3][0], s_m3 ? a.cS1[1] : a.cP[3][1], s_m3 ? a.cS1[2] : a.cP[3][2], s_m3 ? a.cS1[3] : a.cP[3][3]);
         } else {
             // T = 2k + 1: chroma row 3k + 1 -> output rows 4k - 1 (phase 1) and 4k (phase 2; row 0 at T = 1 has its own taps)
             const int kap = T >> 1;
             push(bufC[2], edge_c);
-            loadC(3 * (kap + 1) + 1, bufC[2], edge_c);
+            loadC(min(3 * (kap + 1) + 1, cLast), bufC[2], edge_c);
             emit(2 * T - 3, SOm3(), a.cP[1][0], a.cP[1][1], a.cP[1][2], a.cP[1][3]);
         }
         // luma row 3T - 1: odd 2T + 1 opens (B0), even 2T (A1), even 2T - 2 (A4), odd 2T - 1 (B3)
         hrowL(bufL[PAR][1], edge_c, v);
-        loadL(3 * (T + 2) - 1, bufL[PAR][1], edge_c);
+        loadL(min(3 * (T + 2) - 1, lLast), bufL[PAR][1], edge_c);
         luma_row(v, SOp1(), SE0(), SEm2(), SOm1(), std::true_type(), s_p1 ? a.lS[0] : a.lB[0], a.lA[1], a.lA[4], s_m1 ? a.lS[3] : a.lB[3]);
         // luma row 3T: odd 2T + 1 (B1), even 2T (A2), even 2T - 2 closes (A5), odd 2T - 1 (B4)
         hrowL(bufL[PAR][2], edge_c, v);
-        loadL(3 * (T + 2), bufL[PAR][2], edge_c);
+        loadL(min(3 * (T + 2), lLast), bufL[PAR][2], edge_c);
         luma_row(v, SOp1(), SE0(), SEm2(), SOm1(), std::false_type(), s_p1 ? a.lS[1] : a.lB[1], a.lA[2], a.lA[5], s_m1 ? a.lS[4] : a.lB[4]);
         if (PAR == 0) {
             // chroma row 3k -> output row 4k - 2 (phase 0)
             const int kap = T >> 1;
             push(bufC[1], edge_c);
-            loadC(3 * (kap + 1), bufC[1], edge_c);
+            loadC(min(3 * (kap + 1), cLast), bufC[1], edge_c);
             emit(2 * T - 2, SEm2(), a.cP[0][0], a.cP[0][1], a.cP[0][2], a.cP[0][3]);
         } else {
             emit(2 * T - 2, SEm2(), s_m1 ? a.cS0[0] : a.cP[2][0], s_m1 ? a.cS0[1] : a.cP[2][1], s_m1 ? a.cS0[2] : a.cP[2][2], s_m1 ? a.cS0[3] : a.cP[2][3]);
