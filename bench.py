@@ -387,6 +387,16 @@ def other_configs(lib, env, stream, geo, frames=16):
     tb = geo.nv12 + geo.dw * geo.dh * 3 // 2
     sws_case("transcode: 4K nv12 -> 1080p nv12 bicubic", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
     batch_case("transcode, 32 frames per launch", "nv12", geo.sw, geo.sh, "nv12", geo.dw, geo.dh, tb)
+    # the other exact ratios between a decoder's frame and a network's input / a ladder rung (round 2's ratio walkers); batched only
+    if geo.sw % 24 == 0 and geo.sh % 24 == 0 and geo.sw // 4 >= 64:
+        for name, num, den in (("3:1", 1, 3), ("3:2", 2, 3), ("4:1", 1, 4)):
+            dw, dh = geo.sw * num // den, geo.sh * num // den
+            if dw % 8 or dh % 4:
+                continue
+            batch_case("nv12 %dx%d -> rgb24 %dx%d (%s), 32 frames per launch" % (geo.sw, geo.sh, dw, dh, name), "nv12", geo.sw, geo.sh, "rgb24", dw, dh,
+                       geo.nv12 + dw * dh * 3)
+        batch_case("nv12 %dx%d -> nv12 %dx%d (4:1), 32 frames per launch" % (geo.sw, geo.sh, geo.sw // 4, geo.sh // 4), "nv12", geo.sw, geo.sh, "nv12",
+                   geo.sw // 4, geo.sh // 4, geo.nv12 + (geo.sw // 4) * (geo.sh // 4) * 3 // 2)
     # configs[3]: rotate(90) + hflip + 3x3 smooth as ONE kernel on 4K rgb24
     w, h = geo.sw, geo.sh
     src = frame_set(frames, w * h * 3, 31)
