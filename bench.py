@@ -15,13 +15,18 @@ device per stream the same way, libavutil/hwcontext_cuda.c:395-434); RCCL carrie
 and the MAX of the wall time.  `--dry` runs the same code on the CPU-emulated build of the library with gloo and
 a tiny geometry (plumbing check in a GPU-less container; its numbers mean nothing and say so).
 
-One JSON line on rank 0.  `value` = source gigapixels per second over all ranks (weak scaling).
+Output (rank 0).  Secondary measurements are printed on EARLIER lines, one `BENCH_DETAIL {json}` line per block
+(chained, other_configs, c_harness, host_pipeline, per_rank, cpu_configs0, ...) and collected in bench_detail.json;
+the LAST stdout line is ONE compact JSON object (< 2 KB): metric / value / unit / n_gpus / steps / warmup / ms_per_step
+/ dtype / data / config{workload, ...} plus
   roofline      : the dominant kernel; achieved = algorithmic bytes per launch / average launch duration from
-                  HIP events on the launch stream; traffic from the committed PMC pass of this round.
-  chained       : the convert-then-scale forms (the metric's literal arrows), measured in the same run.
-  host_pipeline : pinned host frames in and out (gmat_pipeline_*), every rank at once; PCIe-bound.
+                  HIP events on the launch stream over the timed steps; traffic = HBM bytes per launch from a live
+                  rocprofv3 PMC pass of this run (FETCH_SIZE x2 + WRITE_SIZE, separate passes), else from the
+                  committed pass of this round (`traffic_source` says which).
   cpu_baseline  : libswscale arithmetic on the host cores, rank 0, bounded sample: stock libswscale.so when the
-                  box has one ("reference"), else the C oracle ("port").  cpu_configs0 = BASELINE configs[0].
+                  box has one ("reference"), else the C oracle ("port").
+`value` = source gigapixels per second over all ranks (weak scaling).  A step = LAUNCHES_PER_STEP launch sets of 32
+frames each over a working set of distinct frame pairs (default 256 pairs = 4.8 GB: HBM, not Infinity Cache).
 """
 import argparse
 import ctypes as C
@@ -39,7 +44,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PRE_WARM_MS = 40            # untimed clock-ramp load in front of the W warm-up steps
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")     # this round's committed PMC pass (fallback)
+LAUNCH_FRAMES = 32          # frames one launch set carries (kYuv2xMaxFrames)
+DETAIL = {}                 # secondary blocks: printed on earlier lines + bench_detail.json, never in the last line
+
+
+def detail(key, block):
+    """a secondary block: its own earlier stdout line, and bench_detail.json at the end"""
+    DETAIL[key] = block
+    print("BENCH_DETAIL " + json.dumps({key: block}), flush=True)
 
 
 class Geo:
@@ -59,16 +72,17 @@ class Geo:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=32, help="distinct frame pairs per step (working set)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph per step instead of submitting the batch eagerly from C")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=256,
+                    help="distinct frame pairs of the working set = frames per step (a multiple of 32; 256 pairs = 4.8 GB)")
     ap.add_argument("--branches", type=int, default=2,
-                    help="concurrent HIP streams (or graph branches) the independent frames of a step are spread over")
+                    help="concurrent HIP streams the independent frames of a launch set are spread over (headline `value`)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
-    ap.add_argument("--no-chained", action="store_true", help="skip the convert-then-scale comparison and other_configs")
+    ap.add_argument("--no-detail", "--no-chained", dest="no_detail", action="store_true",
+                    help="skip the secondary GPU measurements (chained forms, other configs, C harness)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pinned-host upload/compute/download leg")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the live rocprofv3 PMC traffic pass")
     ap.add_argument("--cpu-frames", type=int, default=128)
     ap.add_argument("--dry", action="store_true",
                     help="CPU plumbing check: emulated library, gloo, tiny frames; numbers are not measurements")
@@ -119,9 +133,11 @@ def random_bytes(n, seed):
 
 
 class Runner:
-    """One implementation of the workload: a context, its frame set and (optionally) a graph."""
+    """One implementation of the workload: a context and its working set of `frames` distinct frame pairs.
+    step() = one pass over the working set: frames / 32 launch sets, each ONE C call (gmat_sws_scale_batch) that hands every
+    stream its share of the set's 32 frames as one launch (grid.y = frame)."""
 
-    def __init__(self, lib, geo, stream, frames, fused, use_graph, seed, branches=1):
+    def __init__(self, lib, geo, stream, frames, fused, seed, branches=1, share=None):
         from gmat_amd.lib import PIX_FMT, SWS, ints
         self.lib, self.stream, self.frames, self.geo = lib, stream, frames, geo
         self.ctx = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.dw, geo.dh, PIX_FMT["rgb24"],
@@ -133,10 +149,15 @@ class Runner:
         lib.gmat_sws_setStream(self.ctx, stream)
         src_ls = (geo.sw + 255) // 256 * 256                 # AVHWFramesContext row alignment
         dst_ls = (geo.dw * 3 + 255) // 256 * 256
-        self.mem = DevMem(lib)
-        nsrc = src_ls * (geo.sh * 3 // 2)
-        self.src = [self.mem.alloc(nsrc, random_bytes(nsrc, seed * 1000 + i)) for i in range(frames)]
-        self.dst = [self.mem.alloc(dst_ls * geo.dh) for _ in range(frames)]
+        self.owner = share is None
+        if share is None:
+            self.mem = DevMem(lib)
+            nsrc = src_ls * (geo.sh * 3 // 2)
+            content = [random_bytes(nsrc, seed * 1000 + i) for i in range(min(frames, 8))]     # content does not affect timing
+            self.src = [self.mem.alloc(nsrc, content[i % len(content)]) for i in range(frames)]
+            self.dst = [self.mem.alloc(dst_ls * geo.dh) for _ in range(frames)]
+        else:                                                # another context over the same frames (the serial roofline run)
+            self.mem, self.src, self.dst = None, share.src[:frames], share.dst[:frames]
         self.src_ls, self.dst_ls = src_ls, dst_ls
         n = frames
         self.sp = (C.c_void_p * (4 * n))()
@@ -145,7 +166,6 @@ class Runner:
             self.sp[4 * i], self.sp[4 * i + 1] = self.src[i], self.src[i] + src_ls * geo.sh      # UV directly after Y
             self.dp[4 * i] = self.dst[i]
         self.ss, self.ds = ints([src_ls, src_ls]), ints([dst_ls])
-        self.graph = None
         self.branches = branches
         self.streams = (C.c_void_p * max(1, branches))()
         self.streams[0] = stream
@@ -153,27 +173,25 @@ class Runner:
             h = C.c_void_p()
             lib.gmat_stream_create(C.byref(h))
             self.streams[b] = h
-        if use_graph:
-            ge = C.c_void_p()
-            r = lib.gmat_sws_graph_create(self.ctx, n, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
-                                          C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds, stream, branches, C.byref(ge))
-            if r != 0:
-                raise RuntimeError(f"gmat_sws_graph_create failed: {r}")
-            self.graph = ge
+        self.per_launch = min(LAUNCH_FRAMES, n)
+        self.sets = [(f0, min(self.per_launch, n - f0)) for f0 in range(0, n, self.per_launch)]
+        vp = C.POINTER(C.c_void_p)
+        step_sz = C.sizeof(C.c_void_p) * 4
+        self.set_args = [(cnt, C.cast(C.byref(self.sp, f0 * step_sz), vp), C.cast(C.byref(self.dp, f0 * step_sz), vp))
+                         for f0, cnt in self.sets]
+        self.pstreams = C.cast(self.streams, vp)
 
     def step(self, flags=0):
-        lib = self.lib
-        if self.graph:
-            r = lib.gmat_graph_launch(self.graph, self.stream)
-            if r != 0:
-                raise RuntimeError(f"graph launch failed: {r}")
-            return
-        # one C call enqueues the whole batch: each stream gets its share of the frames as ONE launch (grid.y = frame)
-        r = lib.gmat_sws_scale_batch(self.ctx, self.frames, C.cast(self.sp, C.POINTER(C.c_void_p)), self.ss,
-                                     C.cast(self.dp, C.POINTER(C.c_void_p)), self.ds,
-                                     C.cast(self.streams, C.POINTER(C.c_void_p)), self.branches, flags)
-        if r != self.frames:
-            raise RuntimeError(f"gmat_sws_scale_batch failed: {r}")
+        """flags: GMAT_BATCH_FORK (1) on the step's first launch set, GMAT_BATCH_JOIN (2) on its last one"""
+        lib, last = self.lib, len(self.set_args) - 1
+        for k, (cnt, sp, dp) in enumerate(self.set_args):
+            fl = (flags & 1 if k == 0 else 0) | (flags & 2 if k == last else 0)
+            r = lib.gmat_sws_scale_batch(self.ctx, cnt, sp, self.ss, dp, self.ds, self.pstreams, self.branches, fl)
+            if r != cnt:
+                raise RuntimeError(f"gmat_sws_scale_batch failed: {r}")
+
+    def launches_per_step(self):
+        return len(self.set_args)
 
     def kernel(self):
         return self.lib.gmat_sws_lastKernel(self.ctx).decode()
@@ -182,13 +200,12 @@ class Runner:
         return max(1, int(self.lib.gmat_sws_lastLaunchFrames(self.ctx)))
 
     def close(self):
-        if self.graph:
-            self.lib.gmat_graph_destroy(self.graph)
         self.lib.gmat_device_sync()
         for b in range(1, self.branches):
             self.lib.gmat_stream_destroy(self.streams[b])
         self.lib.gmat_sws_freeContext(self.ctx)
-        self.mem.free()
+        if self.owner:
+            self.mem.free()
 
 
 class Env:
@@ -207,6 +224,9 @@ class Env:
         lib.gmat_device_sync()
         if self.sync:
             self.sync()                # the contract's torch.cuda.synchronize(); the work itself is on gmat's streams
+
+
+wall_local = [0.0]          # this rank's own wall time of the last timed() (its return value is the MAX over ranks)
 
 
 def timed(lib, env, dist, runner, stream, steps, warmup, world, pre_warm_ms=PRE_WARM_MS):
@@ -236,6 +256,7 @@ def timed(lib, env, dist, runner, stream, steps, warmup, world, pre_warm_ms=PRE_
     env.synchronize(lib)
     dist.barrier(world) if dist else None
     wall = time.perf_counter() - t0
+    wall_local[0] = wall
     gc.enable()
     ms = C.c_float()
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
@@ -266,19 +287,62 @@ def time_single_kernel(lib, env, runner_fn, stream, reps):
     return float(ms.value) / reps
 
 
-def measured_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch from this round's PMC collection (profiles/r02_traffic.json: rocprofv3 FETCH_SIZE and
-    WRITE_SIZE in separate passes over 32-frame launches of the same kernel, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), scaled to the frames a launch of this run carries; None when the
-    kernel has no entry."""
+def committed_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch from this round's committed PMC collection (profiles/r03_traffic.json, tools/gpu_pass.sh pmc),
+    scaled to the frames a launch of this run carries; None when the kernel has no entry."""
     try:
         d = json.load(open(TRAFFIC_FILE))
         for k, v in d["kernels"].items():
-            if k in kernel or kernel in k:
+            if k.startswith(kernel):
                 return int(v["traffic_bytes_per_frame"] * frames_per_launch)
     except Exception:
         pass
     return None
+
+
+def live_traffic(kernel, frames_per_launch, budget_s=150):
+    """HBM bytes per launch of `kernel` measured in THIS run: rocprofv3 --kernel-trace --pmc over tools/bin/x2bench's headline case
+    (the same context, 32 frames per launch), FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes;
+    FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes).  None when rocprofv3 or the
+    harness is missing or a pass fails: the caller falls back to the committed pass and says so."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "bin", "x2bench")
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof or not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="gmat_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", X2BENCH_VERIFY="0", X2BENCH_JSON="1")
+    vals = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None
+            out = os.path.join(tmp, ctr)
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                                exe, str(LAUNCH_FRAMES), "6", "nv12 4K->1080p rgb24 bicubic"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            if r.returncode != 0:
+                return None
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None
+            vals[ctr] = sum(got) / len(got)                      # KiB per launch of LAUNCH_FRAMES frames
+        per_frame = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / LAUNCH_FRAMES
+        return {"bytes_per_launch": int(per_frame * frames_per_launch), "read_bytes_per_frame": int(2 * vals["FETCH_SIZE"] * 1024 / LAUNCH_FRAMES),
+                "written_bytes_per_frame": int(vals["WRITE_SIZE"] * 1024 / LAUNCH_FRAMES), "seconds": round(time.perf_counter() - t0, 1)}
+    except Exception:                                            # noqa: BLE001 - a counter pass must not take the headline down
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 local_device = [0]
@@ -413,6 +477,63 @@ def other_configs(lib, env, stream, geo, frames=16):
         "Gpix/s": round(w * h / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg,
         "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     lib.gmat_device_sync()
+    mem.free()
+    return res
+
+
+def chained_forms(lib, env, stream, geo, k3, pre_warm, branches, frames=LAUNCH_FRAMES):
+    """convert-then-scale semantics (the reference GPU back-end's order of operations, the metric's literal arrows), two forms"""
+    from gmat_amd.lib import PIX_FMT, planes, ints
+    fz = Runner(lib, geo, stream, frames, 1, seed=2000, branches=branches)
+    fwall, fms = timed(lib, env, None, fz, stream, k3, 2, 1, pre_warm)
+    fn = k3 * frames
+    fused_kernel = fz.kernel()
+    fz.close()
+    ch = Runner(lib, geo, stream, frames, 0, seed=2000, branches=1)
+    cwall, cms = timed(lib, env, None, ch, stream, k3, 2, 1, pre_warm)
+    n = k3 * frames
+    ach_c = (geo.alg_convert + geo.alg_scale) * n / (cms * 1e-3) / 1e9
+    # per-kernel timing: each kernel alone over the rotating frame set
+    mem = DevMem(lib)
+    rgb = [mem.alloc(geo.sh * ch.src_ls * 3) for _ in range(frames)]
+    cc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.sw, geo.sh, PIX_FMT["rgb24"], 0, None)
+    sc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["rgb24"], geo.dw, geo.dh, PIX_FMT["rgb24"], 4, None)
+    lib.gmat_sws_setStream(cc, stream); lib.gmat_sws_setStream(sc, stream)
+    state = {"i": 0}
+
+    def k_conv():
+        i = state["i"] = (state["i"] + 1) % frames
+        b = ch.src[i]
+        lib.gmat_sws_scale(cc, planes([b, b + ch.src_ls * geo.sh]), ints([ch.src_ls, ch.src_ls]), 0, geo.sh,
+                           planes([rgb[i]]), ints([ch.src_ls * 3]))
+
+    def k_scale():
+        i = state["i"] = (state["i"] + 1) % frames
+        lib.gmat_sws_scale(sc, planes([rgb[i]]), ints([ch.src_ls * 3]), 0, geo.sh,
+                           planes([ch.dst[i]]), ints([ch.dst_ls]))
+
+    t_conv = time_single_kernel(lib, env, k_conv, stream, 4 * frames)
+    t_scale = time_single_kernel(lib, env, k_scale, stream, 4 * frames)
+    res = {
+        "semantics": "sws(NV12->RGB24, POINT) then sws(RGB24->RGB24, BICUBIC), bit-exact",
+        "fused_kernel": {"kernel": fused_kernel, "value": round(fn * geo.px / fwall / 1e9, 3), "unit": "Gpix/s",
+                         "achieved_GBps": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9, 1),
+                         "frac": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_frame": geo.alg_fused},
+        "two_kernels": {
+            "value": round(n * geo.px / cwall / 1e9, 3), "unit": "Gpix/s",
+            "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_frame": geo.alg_convert + geo.alg_scale,
+            "kernels": {
+                "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
+                                   "achieved_GBps": round(geo.alg_convert / (t_conv * 1e-3) / 1e9, 1),
+                                   "frac": round(geo.alg_convert / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                lib.gmat_sws_lastKernel(sc).decode(): {
+                    "avg_launch_us": round(t_scale * 1e3, 3),
+                    "achieved_GBps": round(geo.alg_scale / (t_scale * 1e-3) / 1e9, 1),
+                    "frac": round(geo.alg_scale / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}}
+    lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
+    ch.close()
     mem.free()
     return res
 
@@ -595,126 +716,88 @@ def main():
         lib = load(emu)                                         # test infrastructure: kernel sources on CPU fibers
         geo = Geo(128, 32, 64, 16)
         a.frames, a.steps, a.warmup = min(a.frames, 4), min(a.steps, 2), min(a.warmup, 1)
-        a.no_chained = True
+        a.no_detail = a.no_pmc = True
     else:
         lib = gmat_amd.load()                                   # raises if the HIP library is missing
         if lib.gmat_device_count() < 1:
             raise SystemExit("bench.py: no HIP device visible (use --dry for the CPU plumbing check)")
         geo = Geo(3840, 2160, 1920, 1080)
+        a.frames = max(LAUNCH_FRAMES, a.frames // LAUNCH_FRAMES * LAUNCH_FRAMES)
     env = Env(a.dry, local)
     local_device[0] = local
-    lib.gmat_set_device(0 if a.dry else local)
+    dev = 0 if a.dry else local
+    lib.gmat_set_device(dev)
+    # each GPU gets its own host thread and pinned staging ring — bind this rank to the host cores of its
+    # GPU's NUMA node BEFORE any pinned allocation (first touch decides where the ring lives)
+    numa = {"node": int(lib.gmat_device_numa_node(dev)), "cpus_bound": int(lib.gmat_bind_thread_to_device(dev))}
     gdist.init("gloo" if a.dry else "nccl")                     # RCCL; control plane only (barrier + MAX of time)
     dist = gdist
     stream = C.c_void_p()
     lib.gmat_stream_create(C.byref(stream))
     pre_warm = 0 if a.dry else PRE_WARM_MS
-
-    use_graph = a.graph and not a.dry
     branches = a.branches
-    # ---- headline: one libswscale-semantics context (mode 2), the step's frames spread over `branches` streams
-    head = Runner(lib, geo, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=branches)
+
+    # ---- headline: one libswscale-semantics context (mode 2); every launch set spread over `branches` streams
+    head = Runner(lib, geo, stream, a.frames, 2, seed=1000 + rank, branches=branches)
     wall, dev_ms = timed(lib, env, dist, head, stream, a.steps, a.warmup, world, pre_warm)
-    launches = a.steps * a.frames
-    gpix = world * launches * geo.px / wall / 1e9
+    nframes = a.steps * a.frames
+    gpix = world * nframes * geo.px / wall / 1e9
     kname = head.kernel()
-    head.close()
-    # ---- roofline of the dominant kernel: the same context, launches strictly back to back on ONE stream
-    ser = Runner(lib, geo, stream, a.frames, 2, use_graph, seed=1000 + rank, branches=1)
+    per_rank_wall = gdist.gather_floats(wall_local[0], world, device="cpu" if a.dry else "cuda")
+    # ---- roofline of the dominant kernel: the same frames, launches strictly back to back on ONE stream, HIP events
+    ser = Runner(lib, geo, stream, a.frames, 2, seed=0, branches=1, share=head)
     _, ser_ms = timed(lib, env, None, ser, stream, a.steps, a.warmup, 1, pre_warm)
-    fpl = ser.frames_per_launch()         # frames one launch carries (grid.y): the whole step, <= 32
+    fpl = ser.frames_per_launch()         # frames one launch carries (grid.y): <= 32
+    nlaunch = a.steps * ser.launches_per_step()
     ser.close()
     ser_ms = max(ser_ms, 1e-6); dev_ms = max(dev_ms, 1e-6)
-    ach = geo.alg_fused * launches / (ser_ms * 1e-3) / 1e9
-    ach_ovl = geo.alg_fused * launches / (dev_ms * 1e-3) / 1e9
+    ach = geo.alg_fused * nframes / (ser_ms * 1e-3) / 1e9
+    ach_ovl = geo.alg_fused * nframes / (dev_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and not a.no_pmc:
+        lt = live_traffic(kname, fpl)
+        if lt:
+            traffic, traffic_src = lt["bytes_per_launch"], "live: rocprofv3 --pmc FETCH_SIZE (x2) | WRITE_SIZE, separate passes, this run"
+            detail("traffic_live", lt)
+    if traffic is None:
+        traffic = committed_traffic(kname, fpl)
+        traffic_src = "committed pass profiles/r03_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None
     out = {
         "metric": "Gpix/s (and % HBM roofline) for 4K nv12->rgb24->1080p bicubic at 1/2/4/8 GPUs",
         "value": round(gpix, 3), "unit": "Gpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (BASELINE configs[2]), device-resident "
-                               "frames; output bit-identical to ONE libswscale context (sws_getContext nv12 2160p -> "
-                               "rgb24 1080p, SWS_BICUBIC); the convert-then-scale ('chained') forms are in `chained`",
-                   "frames_per_step": a.frames, "pre_warm_ms": pre_warm, "implementation": "single fused kernel " + kname,
-                   "launch": (f"hipGraph replay, {branches} parallel branches" if use_graph else
-                              f"eager, one C call per step, one launch per stream ({branches} streams), each carrying its share of the frames"),
-                   "parallelism": f"{world} GPU(s) x independent streams, one process per GPU, no collective in the data path"},
+        "config": {"workload": f"{geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (BASELINE configs[2]), device-resident, "
+                               "bit-identical to ONE libswscale context (nv12 2160p -> rgb24 1080p, SWS_BICUBIC)",
+                   "frames_per_step": a.frames, "launch_sets_per_step": head.launches_per_step(), "frames_per_launch_set": head.per_launch,
+                   "streams": branches, "working_set_MB": round(a.frames * (geo.nv12 + geo.rgb_dst) / 1e6),
+                   "pre_warm_ms": pre_warm, "kernel": kname,
+                   "parallelism": f"{world} GPU(s) x independent streams, one process per GPU, no collective"},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname, fpl),
-                     "traffic_source": "profiles/r02_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, per launch)",
+                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "frames_per_launch": fpl, "algorithmic_bytes_per_launch": geo.alg_fused * fpl,
-                     "avg_launch_us": round(ser_ms * 1e3 / launches * fpl, 3),
-                     "note": "launches back to back on ONE stream (HIP events), each carrying frames_per_launch frames "
-                             "(grid.y = frame); the headline `value` spreads the step over config.launch's streams: "
-                             "achieved_overlapped",
-                     "achieved_overlapped": round(ach_ovl, 1), "frac_overlapped": round(ach_ovl / HBM_PEAK_GBS, 4)},
+                     "avg_launch_us": round(ser_ms * 1e3 / nlaunch, 3), "launches_timed": nlaunch,
+                     "timing": "HIP events on the launch stream, launches back to back on ONE stream",
+                     "frac_overlapped": round(ach_ovl / HBM_PEAK_GBS, 4)},
     }
+    head.close()
     if a.dry:
         out["dry_run"] = True
         out["data"] = "synthetic (DRY RUN on the CPU-emulated library: plumbing only, not a measurement)"
+    if rank == 0:
+        detail("per_rank", {"wall_s": [round(w, 6) for w in per_rank_wall], "min": round(min(per_rank_wall), 6),
+                            "max": round(max(per_rank_wall), 6), "numa_rank0": numa})
 
-    if rank == 0 and not a.no_chained:
-        # convert-then-scale semantics (the reference GPU back-end's order of operations), two forms
-        k3 = max(3, a.steps // 3)
-        fz = Runner(lib, geo, stream, a.frames, 1, use_graph, seed=2000, branches=branches)
-        fwall, fms = timed(lib, env, None, fz, stream, k3, 2, 1, pre_warm)
-        fn = k3 * a.frames
-        fused_kernel = fz.kernel()
-        fz.close()
-        ch = Runner(lib, geo, stream, a.frames, 0, use_graph, seed=2000, branches=1)
-        cwall, cms = timed(lib, env, None, ch, stream, k3, 2, 1, pre_warm)
-        n = k3 * a.frames
-        ach_c = (geo.alg_convert + geo.alg_scale) * n / (cms * 1e-3) / 1e9
-        # per-kernel timing: each kernel alone over the rotating frame set
-        from gmat_amd.lib import PIX_FMT, planes, ints
-        mem = DevMem(lib)
-        rgb = [mem.alloc(geo.sh * ch.src_ls * 3) for _ in range(a.frames)]
-        cc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.sw, geo.sh, PIX_FMT["rgb24"], 0, None)
-        sc = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["rgb24"], geo.dw, geo.dh, PIX_FMT["rgb24"], 4, None)
-        lib.gmat_sws_setStream(cc, stream); lib.gmat_sws_setStream(sc, stream)
-        state = {"i": 0}
-
-        def k_conv():
-            i = state["i"] = (state["i"] + 1) % a.frames
-            b = ch.src[i]
-            lib.gmat_sws_scale(cc, planes([b, b + ch.src_ls * geo.sh]), ints([ch.src_ls, ch.src_ls]), 0, geo.sh,
-                               planes([rgb[i]]), ints([ch.src_ls * 3]))
-
-        def k_scale():
-            i = state["i"] = (state["i"] + 1) % a.frames
-            lib.gmat_sws_scale(sc, planes([rgb[i]]), ints([ch.src_ls * 3]), 0, geo.sh,
-                               planes([ch.dst[i]]), ints([ch.dst_ls]))
-
-        t_conv = time_single_kernel(lib, env, k_conv, stream, 4 * a.frames)
-        t_scale = time_single_kernel(lib, env, k_scale, stream, 4 * a.frames)
-        out["chained"] = {
-            "semantics": "sws(NV12->RGB24, POINT) then sws(RGB24->RGB24, BICUBIC), bit-exact",
-            "fused_kernel": {"kernel": fused_kernel, "value": round(fn * geo.px / fwall / 1e9, 3), "unit": "Gpix/s",
-                             "achieved_GBps": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9, 1),
-                             "frac": round(geo.alg_fused * fn / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "algorithmic_bytes_per_frame": geo.alg_fused},
-            "two_kernels": {
-                "value": round(n * geo.px / cwall / 1e9, 3), "unit": "Gpix/s",
-                "achieved_GBps": round(ach_c, 1), "frac": round(ach_c / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_frame": geo.alg_convert + geo.alg_scale,
-                "kernels": {
-                    "yuv2rgb_kernel": {"avg_launch_us": round(t_conv * 1e3, 3),
-                                       "achieved_GBps": round(geo.alg_convert / (t_conv * 1e-3) / 1e9, 1),
-                                       "frac": round(geo.alg_convert / (t_conv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                    lib.gmat_sws_lastKernel(sc).decode(): {
-                        "avg_launch_us": round(t_scale * 1e3, 3),
-                        "achieved_GBps": round(geo.alg_scale / (t_scale * 1e-3) / 1e9, 1),
-                        "frac": round(geo.alg_scale / (t_scale * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}}
-        lib.gmat_sws_freeContext(cc); lib.gmat_sws_freeContext(sc)
-        ch.close()
-        mem.free()
-        out["other_configs"] = other_configs(lib, env, stream, geo)
-        out["c_harness"] = c_harness(a.dry)
+    if rank == 0 and not a.no_detail:
+        detail("chained", chained_forms(lib, env, stream, geo, max(3, a.steps // 3), pre_warm, branches))
+        detail("other_configs", other_configs(lib, env, stream, geo))
+        detail("c_harness", c_harness(a.dry))
 
     if not a.no_pipeline:
-        hp = host_pipeline(lib, geo, dist, world, 0 if a.dry else local, a.dry, nframes=8 if a.dry else 96)
+        hp = host_pipeline(lib, geo, dist, world, dev, a.dry, nframes=8 if a.dry else 96)
         if rank == 0:
-            out["host_pipeline"] = hp
+            detail("host_pipeline", hp)
+            out["host_pipeline_Gpix_s"] = hp["value"]
     gdist.finalize(world)                                   # the other ranks are done; rank 0 goes on to the CPU legs
     if rank == 0:
         out["cpu_baseline"] = None
@@ -723,11 +806,16 @@ def main():
             ref = cpu_reference(geo, 4 if a.dry else a.cpu_frames)
             out["cpu_baseline"] = ref or port
             if ref:
-                out["cpu_baseline_port"] = port
-            else:
-                out["cpu_baseline_note"] = "no libswscale.so on this box (dlopen tried: ctypes.util.find_library and the usual lib dirs)"
-            out["cpu_configs0"] = cfg0
-        print(json.dumps(out))
+                detail("cpu_baseline_port", port)
+            detail("cpu_configs0", cfg0)
+        out["detail"] = "BENCH_DETAIL lines above + bench_detail.json"
+        try:
+            ddir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+            with open(os.path.join(ddir, "bench_detail.json"), "w") as f:
+                json.dump(dict(DETAIL, headline=out), f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -388,6 +388,9 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
 {
     if (!f || !f->inited || !in_frames) return GMAT_ERR(EINVAL);
     gmat_hwframe_ctx_info(in_frames, &f->device, &f->in_fmt, &f->in_w, &f->in_h);
+    // the link's device becomes current BEFORE anything is created for it (cuCtxPushCurrent in every reference filter,
+    // e.g. vf_scale_cuda.c:292-294): the scaler's tables and the output pool must live where the frames do
+    GMAT_HIP_CHECK(hipSetDevice(f->device));
     f->stream = (hipStream_t)stream;
     f->out_w = f->in_w; f->out_h = f->in_h; f->out_fmt = f->in_fmt;
     const bool nvcv_style = f->kind != K_SCALE && f->kind != K_FORMAT;
@@ -497,6 +500,7 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
     int r = GMAT_ERR(EINVAL);
     GmatFrame *out = nullptr;
     if (!f || !f->configured || !out_p) goto fail;
+    if (hipSetDevice(f->device) != hipSuccess) { r = GMAT_ERR(EIO); goto fail; }     // vf_scale_cuda.c:553 cuCtxPushCurrent
     if (in->format != GMAT_PIX_FMT_HIP || in->sw_format != f->in_fmt || in->width != f->in_w || in->height != f->in_h) {
         logf(LOG_ERROR, "%s: input frame does not match the configured link (%dx%d fmt %d)", f->name.c_str(),
              in->width, in->height, in->sw_format);
@@ -586,6 +590,11 @@ static int run_pending(GmatFilterContext *f)
     if (!n) return 0;
     int r = 0;
     std::vector<GmatFrame *> outs;
+    if (hipSetDevice(f->device) != hipSuccess) {
+        for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
+        f->pending.clear();
+        return GMAT_ERR(EIO);
+    }
     const bool batched = (f->kind == K_SCALE || f->kind == K_FORMAT) && !f->bypass && n > 1;
     if (batched) {
         std::vector<const uint8_t *> sp((size_t)n * 4, nullptr);

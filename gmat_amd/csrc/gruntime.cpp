@@ -2,9 +2,12 @@
 // (include/gmat_hip.h §4).  The reference has av_log and nothing else here.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
+#include <sched.h>
 #include "common.h"
 
 namespace gmat {
@@ -44,6 +47,61 @@ int gmat_set_device(int device)
 {
     GMAT_HIP_CHECK(hipSetDevice(device));
     return 0;
+}
+
+// ---- host placement ("each GPU gets its own host thread, pinned staging ring") ------------------------------
+// The reference selects the device per stream (libavutil/hwcontext_cuda.c:395-434) and leaves host placement to the OS.  With
+// eight streams each moving 75 GB/s over PCIe, a rank whose staging ring lives on the other socket pays the socket link on every
+// frame: these two calls let the caller put its thread (and, by first touch, the ring it allocates next) next to its GPU.
+static bool device_sysfs_dir(int device, char *out, size_t n)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess || !bus[0]) return false;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');     // sysfs spells the address in lower case
+    snprintf(out, n, "/sys/bus/pci/devices/%s", bus);
+    return true;
+}
+
+static bool read_small_file(const std::string &path, char *buf, size_t n)
+{
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const size_t got = fread(buf, 1, n - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    return got > 0;
+}
+
+int gmat_device_numa_node(int device)
+{
+    char dir[128], buf[64];
+    if (!device_sysfs_dir(device, dir, sizeof(dir)) || !read_small_file(std::string(dir) + "/numa_node", buf, sizeof(buf))) return -1;
+    return atoi(buf);                                           // -1: the platform reports no affinity
+}
+
+int gmat_bind_thread_to_device(int device)
+{
+    char dir[128], buf[4096];
+    if (!device_sysfs_dir(device, dir, sizeof(dir)) || !read_small_file(std::string(dir) + "/local_cpulist", buf, sizeof(buf))) return 0;
+    cpu_set_t want, have, both;
+    CPU_ZERO(&want);
+    // "0-15,128-143": comma-separated ranges
+    for (const char *p = buf; *p;) {
+        char *e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        p = e;
+        if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) CPU_SET((int)c, &want);
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+    }
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
+    CPU_AND(&both, &want, &have);                               // never widen what the launcher (a cgroup, taskset) allowed
+    const int n = CPU_COUNT(&both);
+    if (n < 1 || n == CPU_COUNT(&have)) return 0;               // nothing to narrow (one node, or no overlap): leave it
+    if (sched_setaffinity(0, sizeof(both), &both) != 0) return 0;
+    return n;
 }
 
 int gmat_malloc(uint8_t **ptr, size_t bytes)

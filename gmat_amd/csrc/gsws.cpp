@@ -760,6 +760,18 @@ static bool rgb2h_yuv_eligible(const GmatSwsContext *c, const uint8_t *const src
 }
 
 namespace gmat {
+// A context's tables live on the device that was current when it was created; a launch made while another device is current
+// would run there with pointers of this one (hwcontext_cuda.c:395-434 makes the stream's device current around every call).
+static int check_device(const GmatSwsContext *c, const char *who)
+{
+    int dev = c->device;
+    if (hipGetDevice(&dev) == hipSuccess && dev != c->device) {
+        logf(LOG_ERROR, "%s: context created on device %d used while device %d is current", who, c->device, dev);
+        return GMAT_ERR(EINVAL);
+    }
+    return 0;
+}
+
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
 // caller then goes frame by frame), < 0 on error.
@@ -768,7 +780,9 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
 {
     if (!c || n < 2) return 0;
     static const bool off = getenv("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
-    if (off) return 0;
+    // the common precheck of every branch below: profiling contexts (per-launch phase stamps) and cascades go frame by frame
+    if (off || c->prof) return 0;
+    if (int r = check_device(c, "gmat_sws_scale_batch"); r < 0) return r;
     if (c->mode == MODE_YUV2RGB) {
         // the same-size converter: one launch per 32 frames, grid.z = frame
         const bool planar = c->srcFormat == GMAT_PIX_FMT_YUV420P;
@@ -848,7 +862,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     }
     if (c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 1 && is_packed_rgb(c->dstFormat)) {
         // the fused convert-then-scale form at exactly 2:1: one launch of scale_rgb2h_kernel<.., yuv> per 32 frames
-        if (ensure_scaler(c) < 0 || c->fused != 1 || c->prof) return 0;
+        if (ensure_scaler(c) < 0 || c->fused != 1) return 0;
         for (int f = 0; f < n; f++)
             if (!rgb2h_yuv_eligible(c, src_planes + 4 * f, srcStride, dst_planes[4 * f], dstStride[0])) return 0;
         const Rgb2sArgs ra = make_rgb2h_yuv_args(c, srcStride, dstStride[0]);
@@ -881,15 +895,15 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             if (bpp == 4 ? ((((uintptr_t)dp | (uintptr_t)dstStride[0]) & 15) != 0) : !al4(dp, dstStride[0])) return 0;
         }
         const int per = std::min(n, kYuv2xMaxFrames);
-        c->interStride = align_up(c->srcW * 3, 256);
-        const size_t frameBytes = (size_t)c->interStride * c->srcH;
+        const int interBatchStride = align_up(c->srcW * 3, 256);     // the batch's own pitch: c->interStride belongs to the single-frame `inter`
+        const size_t frameBytes = (size_t)interBatchStride * c->srcH;
         if (c->interBatchFrames < per) {
             if (c->interBatch) (void)hipFree(c->interBatch);
             c->interBatch = nullptr; c->interBatchFrames = 0;
             GMAT_HIP_CHECK(hipMalloc((void **)&c->interBatch, frameBytes * per));
             c->interBatchFrames = per;
         }
-        const Rgb2sArgs ra = make_rgb2s_args(c, c->interStride, dstStride[0], false);
+        const Rgb2sArgs ra = make_rgb2s_args(c, interBatchStride, dstStride[0], false);
         for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
             const int m = std::min(kYuv2xMaxFrames, n - f0);
             Yuv2xFrames cv, sc;
@@ -900,7 +914,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
                 cv.dst[i] = c->interBatch + frameBytes * i;
                 sc.y[i] = cv.dst[i]; sc.dst[i] = dst_planes[4 * (f0 + i)];
             }
-            int r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), cv.dst[0], c->interStride, c->srcW, c->srcH,
+            int r = launch_yuv2rgb(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), cv.dst[0], interBatchStride, c->srcW, c->srcH,
                                    GMAT_PIX_FMT_RGB24, c->y2r, stream, &cv, m);
             if (r < 0) return r;
             if ((r = launch_scale_rgb2s(ra, stream, &sc, m)) < 0) return r;
@@ -910,7 +924,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         return 1;
     }
     if (c->mode != MODE_SCALE || !(is_plane_src(c->srcFormat) || c->rgbViaPlanes) || c->fused != 2) return 0;
-    if (ensure_scaler(c) < 0 || c->fused != 2 || c->prof) return 0;
+    if (ensure_scaler(c) < 0 || c->fused != 2) return 0;
     // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
     // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
     YuvScaleArgs ya0;
@@ -1356,13 +1370,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
         return GMAT_ERR(EINVAL);
     }
-    {
-        int dev = c->device;
-        if (hipGetDevice(&dev) == hipSuccess && dev != c->device) {
-            logf(LOG_ERROR, "gmat_sws_scale: context created on device %d used while device %d is current", c->device, dev);
-            return GMAT_ERR(EINVAL);
-        }
-    }
+    if (int r = check_device(c, "gmat_sws_scale"); r < 0) return r;
     c->lastLaunchFrames = 1;
     const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     if (is_plane_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);

@@ -41,6 +41,18 @@ def max_over_ranks(value, world, device="cpu"):
     return float(t.item())
 
 
+def gather_floats(value, world, device="cpu"):
+    """every rank's value, in rank order (per-rank min / max of the wall time for the detail file)"""
+    if world <= 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    return [float(t.item()) for t in allv]
+
+
 def shard_streams(n_streams, rank, world):
     """Round-robin assignment of independent stream ids to ranks (stream s -> rank s % world)."""
     return [s for s in range(n_streams) if s % world == rank]

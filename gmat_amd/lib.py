@@ -93,6 +93,8 @@ _SIGS = {
     "gmat_set_log_callback": (None, [C.c_void_p]),
     "gmat_device_count": (C.c_int, []),
     "gmat_set_device": (C.c_int, [C.c_int]),
+    "gmat_device_numa_node": (C.c_int, [C.c_int]),
+    "gmat_bind_thread_to_device": (C.c_int, [C.c_int]),
     "gmat_version": (C.c_char_p, []),
     "gmat_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "gmat_free": (C.c_int, [C.c_void_p]),

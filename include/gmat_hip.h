@@ -297,6 +297,13 @@ typedef void (*gmat_log_fn)(int level, const char *msg);
 GMAT_API void gmat_set_log_callback(gmat_log_fn fn);     /* default: stderr for level <= 16 (AV_LOG_ERROR) */
 GMAT_API int  gmat_device_count(void);
 GMAT_API int  gmat_set_device(int device);
+/* Host placement for one-process-per-GPU callers (BASELINE configs[4]; the reference picks the device per stream in
+ * libavutil/hwcontext_cuda.c:395-434 and has no counterpart): the NUMA node of `device` from sysfs (-1: none reported), and
+ * "bind the calling thread to the host cores local to `device`" — never beyond the affinity the process already has.
+ * Returns the number of cores bound to, 0 when nothing was changed.  Call before allocating pinned host memory
+ * (gmat_host_frame_alloc, gmat_pipeline_create): first touch decides which socket the staging ring lives on. */
+GMAT_API int  gmat_device_numa_node(int device);
+GMAT_API int  gmat_bind_thread_to_device(int device);
 GMAT_API const char *gmat_version(void);
 GMAT_API int  gmat_malloc(uint8_t **ptr, size_t bytes);   /* hipMalloc */
 GMAT_API int  gmat_free(uint8_t *ptr);

@@ -16,7 +16,7 @@ def pytest_configure(config):
 def _make(directory, target):
     """always ask make (a no-op when up to date): a stale .so must never pass for the sources"""
     r = subprocess.run(["make", "-C", directory], capture_output=True, text=True)
-    if r.returncode != 0 and not os.path.exists(os.path.join(directory, target)):
+    if r.returncode != 0:               # also when an older binary exists: the suite would pass against a stale build
         raise RuntimeError(f"make -C {directory} failed:\n{r.stdout}{r.stderr}")
     return os.path.join(directory, target)
 

@@ -126,6 +126,7 @@ hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int device);
 hipError_t hipGetLastError();
 const char *hipGetErrorName(hipError_t e);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);

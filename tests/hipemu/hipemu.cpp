@@ -237,6 +237,8 @@ static thread_local int g_device = 0;
 hipError_t hipSetDevice(int d) { if (d < 0 || d > 1) return hipErrorInvalidValue; g_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = g_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n) { *n = 2; return hipSuccess; }
+// no PCI device behind an emulated GPU: callers that look for sysfs placement find none
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int) { if (len > 0) buf[0] = 0; return hipErrorInvalidValue; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorName(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emulated)"; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(1); return hipSuccess; }

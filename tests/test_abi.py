@@ -89,3 +89,80 @@ def test_contexts_and_the_stateless_cache_are_per_device():
     lib.gmat_sws_freeContext(c)
     for p in src + dst + rgb + yuv:
         p.free()
+
+
+def test_filter_follows_its_links_device_not_the_current_one():
+    """a scale_hip configured for frames of device 1 while device 0 is current must create its scaler (tables,
+    output pool) on device 1 and make that device current around every frame — the reference pushes the frames' CUDA context at
+    the top of config_props and filter_frame (vf_scale_cuda.c:292-294, :553).  Both the per-frame and the queued batch=K entry
+    points; the batched launch refuses a foreign device instead of launching with another GPU's tables."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gmat_amd.lib import load, PIX_FMT, GmatFrame, planes, ints
+    emu = os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated build missing")
+    lib = load(emu)
+    w, h = 64, 16
+    assert lib.gmat_set_device(1) == 0
+    fc1 = lib.gmat_hwframe_ctx_create(1, PIX_FMT["nv12"], w, h, 4)
+    assert lib.gmat_set_device(0) == 0
+    fc0 = lib.gmat_hwframe_ctx_create(0, PIX_FMT["nv12"], w, h, 4)
+    assert fc0 and fc1
+
+    def make(batch):
+        f = lib.gmat_filter_alloc(b"scale_hip")
+        for k, v in (("w", "iw/2"), ("h", "ih/2"), ("format", "rgb24"), ("batch", str(batch))):
+            assert lib.gmat_filter_set_option(f, k.encode(), v.encode()) == 0
+        assert lib.gmat_filter_init(f) == 0
+        return f
+
+    # device 0 is current; the link is on device 1
+    f = make(1)
+    assert lib.gmat_filter_config_props(f, fc1, None) == 0
+    assert lib.gmat_set_device(0) == 0
+    for _ in range(2):
+        fr = lib.gmat_frame_alloc()
+        assert lib.gmat_hwframe_get_buffer(fc1, fr) == 0
+        out = C.POINTER(GmatFrame)()
+        assert lib.gmat_set_device(0) == 0                      # some other filter of the graph made device 0 current meanwhile
+        assert lib.gmat_filter_frame(f, fr, C.byref(out)) == 0
+        lib.gmat_frame_free(C.byref(out))
+    lib.gmat_filter_free(f)
+    # the queued form: batch = 2 launches ONE kernel for two frames
+    f = make(2)
+    assert lib.gmat_set_device(0) == 0
+    assert lib.gmat_filter_config_props(f, fc1, None) == 0
+    for i in range(4):
+        fr = lib.gmat_frame_alloc()
+        assert lib.gmat_hwframe_get_buffer(fc1, fr) == 0
+        assert lib.gmat_set_device(0) == 0
+        assert lib.gmat_filter_send_frame(f, fr) == 0
+        out = C.POINTER(GmatFrame)()
+        while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+            lib.gmat_frame_free(C.byref(out))
+    lib.gmat_filter_free(f)
+    # the batch entry point of a bare context checks the device like gmat_sws_scale does
+    assert lib.gmat_set_device(0) == 0
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT["nv12"], w // 2, h // 2, PIX_FMT["rgb24"], 4, None)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness
+    dev = harness.Dev(lib, "emu")
+    srcs = [dev.planes_like("nv12", w, h, 16) for _ in range(2)]
+    dsts = [dev.planes_like("rgb24", w // 2, h // 2, 16) for _ in range(2)]
+    sp = (C.c_void_p * 8)(); dp = (C.c_void_p * 8)()
+    for i in range(2):
+        sp[4 * i], sp[4 * i + 1], dp[4 * i] = srcs[i][0].ptr, srcs[i][1].ptr, dsts[i][0].ptr
+    streams = (C.c_void_p * 1)(None)
+    vp = C.POINTER(C.c_void_p)
+    call = lambda: lib.gmat_sws_scale_batch(c, 2, C.cast(sp, vp), ints([p.stride for p in srcs[0]]), C.cast(dp, vp),
+                                            ints([dsts[0][0].stride]), C.cast(streams, vp), 1, 0)
+    assert call() == 2
+    assert lib.gmat_set_device(1) == 0
+    assert call() < 0
+    assert lib.gmat_set_device(0) == 0
+    lib.gmat_sws_freeContext(c)
+    for ps in srcs + dsts:
+        for p in ps:
+            p.free()
+    lib.gmat_hwframe_ctx_free(fc0); lib.gmat_hwframe_ctx_free(fc1)

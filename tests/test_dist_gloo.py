@@ -58,13 +58,21 @@ def test_bench_self_launches_two_ranks_through_the_library():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    lines = r.stdout.splitlines()
+    line = lines[-1]                                   # the contract: the LAST stdout line is the compact JSON object
+    assert len(line) < 4096, len(line)
     d = json.loads(line)
+    det = {}
+    for l in lines[:-1]:
+        if l.startswith("BENCH_DETAIL "):
+            det.update(json.loads(l[len("BENCH_DETAIL "):]))
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
     assert d["roofline"]["kernel"] == "scale_yuv2s_kernel"
-    assert d["host_pipeline"]["ranks"] == 2 and d["host_pipeline"]["value"] > 0
+    assert det["host_pipeline"]["ranks"] == 2 and det["host_pipeline"]["value"] > 0
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0     # rank 0 at any N
-    assert d["cpu_configs0"]["cores"] == 1
+    assert det["cpu_configs0"]["cores"] == 1
+    # each rank timed its own steps on its own (emulated) device; rank order, MAX is what `value` uses
+    assert len(det["per_rank"]["wall_s"]) == 2 and det["per_rank"]["max"] >= det["per_rank"]["min"] > 0
     # value = all ranks' pixels over the slowest rank's time
     px = 128 * 32 * d["config"]["frames_per_step"] * d["steps"] * 2
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) < 2e-3
