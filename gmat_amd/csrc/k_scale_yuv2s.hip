@@ -31,6 +31,26 @@ namespace gmat {
 
 constexpr int S2_STRIP = 256;                  // output columns per wave: 64 lanes x 4
 
+// Round 3: three cuts in the headline kernel's instruction stream, each behind a build-time switch so that the A/B of
+// profiles/r03c_* can be repeated (tools/build_variant.sh): 155 -> ~140 VALU instructions per row and lane.
+//   S2_SBASE   the row base of every load / store is a scalar pointer (SALU: s_mul, s_add_u32, s_addc_u32), the lane offset a
+//              loop-invariant VGPR: no v_add_u32 per load (5 per iteration)
+//   S2_LUT512  the colour tables are indexed by (sum + 128 * 16384) >> 14 on 512 entries whose first 128 / last 128 repeat
+//              entries 0 / 255: the index clamp of yuv2rgb.c's tables (av_clip_uint8 in the chroma path) is in the table, not
+//              a v_med3 per chroma sample (4 per iteration).  The host proves the index range from the coefficients.
+//   S2_SATPK   channel = sat_u8(high half of (term + Y * cy)) packed two at a time by v_sat_pk_u8_i16 instead of a v_med3 per
+//              channel and a byte permute (21 -> 15 per rgb24 row, 28 -> 20 per rgba row)
+#ifndef S2_SBASE
+#define S2_SBASE 1
+#endif
+#ifndef S2_LUT512
+#define S2_LUT512 1
+#endif
+#ifndef S2_SATPK
+#define S2_SATPK 1
+#endif
+constexpr int S2_LUT_N = S2_LUT512 ? 512 : 256, S2_LUT_BIAS = S2_LUT512 ? 128 : 0;
+
 // ---- unaligned vector loads (4-byte aligned addresses) -----------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned s2_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -56,6 +76,47 @@ __device__ __forceinline__ int s2_dot2(int packed_ab, int packed_cd, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, packed_ab), __builtin_bit_cast(short2v, packed_cd), acc, S2_DOT2_CLAMP != 0);
 }
 
+// two signed 16-bit halves -> two unsigned bytes with saturation, in the low half of the result (the upper half is never used:
+// every caller selects bytes 0 and 1 with a v_perm_b32)
+__device__ __forceinline__ unsigned s2_sat_pk_u8_i16(unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    const int lo = (int16_t)(v & 0xFFFFu), hi = (int16_t)(v >> 16);
+    return (unsigned)std::min(std::max(lo, 0), 255) | ((unsigned)std::min(std::max(hi, 0), 255) << 8);
+#endif
+}
+
+// S2_SBASE: a plane as a raw buffer resource (four SGPRs built once per wave from the wave-uniform plane pointer): the row offset
+// travels in the instruction's scalar offset, the lane offset is a loop-invariant VGPR — no vector ALU per load or store.
+// num_records = 2^32 - 1: the kernel clamps every row and column itself, the bounds check is not relied on.
+struct S2Plane {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ explicit S2Plane(const uint8_t *p) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, 0xFFFFFFFFu, 0x00020000)) {}
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ uint4 ld16(unsigned lane, unsigned row) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane, row, 0); return make_uint4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ uint3 ld12(unsigned lane, unsigned row) const { const v3u v = __builtin_amdgcn_raw_buffer_load_b96(r, lane, row, 0); return make_uint3(v.x, v.y, v.z); }
+    __device__ __forceinline__ uint2 ld8(unsigned lane, unsigned row) const { const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane, row, 0); return make_uint2(v.x, v.y); }
+    __device__ __forceinline__ void st16(uint4 d, unsigned lane, unsigned row) const { v4u v = {d.x, d.y, d.z, d.w}; __builtin_amdgcn_raw_buffer_store_b128(v, r, lane, row, 0); }
+    __device__ __forceinline__ void st12(uint3 d, unsigned lane, unsigned row) const { v3u v = {d.x, d.y, d.z}; __builtin_amdgcn_raw_buffer_store_b96(v, r, lane, row, 0); }
+#else
+    // hipcc's host pass (never executed) and the CPU emulation of the test suite
+    uint8_t *p;
+    __host__ __device__ explicit S2Plane(const uint8_t *q) : p(const_cast<uint8_t *>(q)) {}
+    __host__ __device__ uint4 ld16(unsigned lane, unsigned row) const { uint4 v; std::memcpy(&v, p + (size_t)row + lane, 16); return v; }
+    __host__ __device__ uint3 ld12(unsigned lane, unsigned row) const { uint3 v; std::memcpy(&v, p + (size_t)row + lane, 12); return v; }
+    __host__ __device__ uint2 ld8(unsigned lane, unsigned row) const { uint2 v; std::memcpy(&v, p + (size_t)row + lane, 8); return v; }
+    __host__ __device__ void st16(uint4 d, unsigned lane, unsigned row) const { std::memcpy(p + (size_t)row + lane, &d, 16); }
+    __host__ __device__ void st12(uint3 d, unsigned lane, unsigned row) const { std::memcpy(p + (size_t)row + lane, &d, 12); }
+#endif
+};
+
 // bytes (1,2) of lo -> one int16 pair; byte 3 of lo and byte 0 of hi -> the next one (selector 0x0C = constant zero)
 __device__ __forceinline__ int s2_pair12(unsigned lo) { return (int)__builtin_amdgcn_perm(0u, lo, 0x0C020C01u); }
 __device__ __forceinline__ int s2_pair30(unsigned hi, unsigned lo) { return (int)__builtin_amdgcn_perm(hi, lo, 0x0C040C03u); }
@@ -74,17 +135,21 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
 {
     constexpr bool BGR = (DST & 1) != 0;
     constexpr int BPP = DST >= 2 ? 4 : 3;
-    __shared__ int2 lutV[256], lutU[256];
+    __shared__ int2 lutV[S2_LUT_N], lutU[S2_LUT_N];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- colour look-up tables: chan = byte 2 of clamp(term + Y * cy, 0, 0xFFFFFF) with
     //      term_R = lutV[V].x, term_G = lutV[V].y + lutU[U].x, term_B = lutU[U].y  (px_math.h chroma_terms, split by sample)
+    //      S2_LUT512: entry e holds sample clip_u8(e - 128)
     {
         const Yuv2RgbConsts &k = a.y2r;
-        const int i = tid;
-        lutV[i] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
-        lutU[i] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+#pragma unroll
+        for (int e = tid; e < S2_LUT_N; e += 256) {
+            const int i = min(max(e - S2_LUT_BIAS, 0), 255);
+            lutV[e] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
+            lutU[e] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+        }
     }
     __syncthreads();
 
@@ -102,6 +167,16 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     const int y0 = seg * a.segRows;
     const int nOut = min(a.segRows, a.dstH - y0);
     const int nIter = nOut + 3;                                // 3 warm-up row pairs fill the vertical window
+    // Odd segments walk UPWARD (a.updown): the rows two neighbouring segments both read — the 3 row pairs either side of their
+    // joint — are then read at the same time (both at the start of their walks or both at the end) instead of a wave's lifetime
+    // apart, so the second reader finds them in L2.  Iteration j handles row pair mStart + dir * j and, from j = 3 on, output row
+    // yoStart + dir * (j - 3); the window's slots then hold the pairs of an output row youngest-first instead of oldest-first,
+    // i.e. the vertical coefficient pairs are applied in reverse order (the rows inside a pair keep their order).  All scalar.
+    const bool up = a.updown && (seg & 1);
+    const int dir = up ? -1 : 1;
+    const int mStart = up ? y0 + nOut + 1 : y0 - 1;
+    const int yoStart = up ? y0 + nOut - 1 : y0;
+    const int vl0 = up ? a.vL[3] : a.vL[0], vl1 = up ? a.vL[2] : a.vL[1], vl2 = up ? a.vL[1] : a.vL[2], vl3 = up ? a.vL[0] : a.vL[3];
 
     const uint8_t *py, *pu, *pv;
     uint8_t *pd;
@@ -136,23 +211,41 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
 
     // row pointers are wave-uniform (scalar unit), the lane offsets unsigned 32-bit: global_load with an SGPR base
     const unsigned uoffL = (unsigned)offL, uoffA = (unsigned)offA, uoffB = (unsigned)offB;
+#if S2_SBASE
+    const S2Plane bY(py), bU(pu), bV(NV12 ? pu : pv), bD(pd);
+#endif
     auto load_luma = [&](int m, S2Pix &P) {
         const int ra = min(max(2 * m - 1, 0), a.srcH - 1), rb = min(max(2 * m, 0), a.srcH - 1);
         // one 32-bit offset per load = scalar row offset + lane offset (a plane is far below 4 GB): the frame pointer
         // stays the SGPR base of the global_load
+#if S2_SBASE
+        P.la = bY.ld16(uoffL, (unsigned)ra * (unsigned)a.ys);       // lane offset (loop-invariant VGPR) + scalar row offset
+        P.lb = bY.ld16(uoffL, (unsigned)rb * (unsigned)a.ys);
+#else
         P.la = s2_ld16(py + (unsigned)((unsigned)ra * (unsigned)a.ys + uoffL));
         P.lb = s2_ld16(py + (unsigned)((unsigned)rb * (unsigned)a.ys + uoffL));
+#endif
     };
     auto load_chroma = [&](int cy, S2Pix &P) {
         const int r = min(max(cy, 0), a.chrSrcH - 1);
         if (NV12) {
             const unsigned ro = (unsigned)r * (unsigned)a.us;
+#if S2_SBASE
+            P.ca = bU.ld16(uoffA, ro);
+            const uint2 t = bU.ld8(uoffB, ro);
+#else
             P.ca = s2_ld16(pu + (unsigned)(ro + uoffA));
             const uint2 t = s2_ld8(pu + (unsigned)(ro + uoffB));
+#endif
             P.cb = make_uint4(t.x, t.y, 0u, 0u);
         } else {
+#if S2_SBASE
+            const uint3 tu = bU.ld12(uoffA, (unsigned)r * (unsigned)a.us);
+            const uint3 tv = bV.ld12(uoffA, (unsigned)r * (unsigned)a.vs);
+#else
             const uint3 tu = s2_ld12(pu + (unsigned)((unsigned)r * (unsigned)a.us + uoffA));
             const uint3 tv = s2_ld12(pv + (unsigned)((unsigned)r * (unsigned)a.vs + uoffA));
+#endif
             P.ca = make_uint4(tu.x, tu.y, tu.z, 0u);
             P.cb = make_uint4(tv.x, tv.y, tv.z, 0u);
         }
@@ -193,7 +286,7 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
     S2Pix buf[2];                                               // ping-pong: iteration j consumes buf[j & 1], prefetches into the other
     buf[0].ca = buf[0].cb = buf[1].ca = buf[1].cb = make_uint4(0u, 0u, 0u, 0u);
     buf[1].la = buf[1].lb = make_uint4(0u, 0u, 0u, 0u);
-    load_luma(y0 - 1, buf[0]);
+    load_luma(mStart, buf[0]);
 
     // EDGE: the wave holds a frame-edge lane (first / last strip).  The whole row loop exists twice so that interior
     // waves carry none of the fix-up moves.
@@ -204,8 +297,8 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
         S2Pix &nxt = buf[(SLOT + 1) & 1];
         // ---- prefetch the next iteration's rows ------------------------------------------------------------
         if (j + 1 < nIter) {
-            load_luma(y0 + j, nxt);                                 // pair m = y0 - 1 + (j + 1)
-            if (j + 1 >= 3) load_chroma(y0 + j - 2, nxt);           // chroma row of output row y0 + (j + 1) - 3
+            load_luma(mStart + dir * (j + 1), nxt);                 // the row pair of iteration j + 1
+            if (j + 1 >= 3) load_chroma(yoStart + dir * (j - 2), nxt);   // chroma row of ITS output row
         }
         // ---- horizontal luma of pair m = y0 - 1 + j -> slot ------------------------------------------------
         {
@@ -217,14 +310,16 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
                 hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 7, sb[q] >> 7));
         }
         if (j >= 3) {
-            const int yo = y0 + j - 3;
-            // ---- vertical luma: pairs yo-1 .. yo+2 sit in slots SLOT+1 .. SLOT+4 (mod 4) ------------------------
+            const int yo = yoStart + dir * (j - 3);
+            // ---- vertical luma: pairs yo-1 .. yo+2 (walking up: yo+2 .. yo-1) sit in slots SLOT+1 .. SLOT+4 (mod 4) ------
             int Y[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int acc = a.lr;
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc = s2_dot2(hw[(SLOT + 1 + k) & 3][q], a.vL[k], acc);
+                acc = s2_dot2(hw[(SLOT + 1) & 3][q], vl0, acc);
+                acc = s2_dot2(hw[(SLOT + 2) & 3][q], vl1, acc);
+                acc = s2_dot2(hw[(SLOT + 3) & 3][q], vl2, acc);
+                acc = s2_dot2(hw[(SLOT + 4) & 3][q], vl3, acc);
                 Y[q] = acc >> 19;
             }
             // ---- chroma of row yo: 2 outputs per plane from 5 odd-aligned pairs ---------------------------------
@@ -268,9 +363,14 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
             for (int c = 0; c < 2; c++) {
                 // hScale8To15_c (>> 7, min 32767), the one-tap vertical filter (1 << 18) + h * 4096, >> 19 and the table
                 // index clamp collapse into clip_u8((sum + 8192) >> 14): floor(floor(x / 128 + 64) / 128) = floor((x + 8192) / 16384)
-                const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], 8192))));
-                const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], 8192))));
+                constexpr int R0 = 8192 + (S2_LUT_BIAS << 14);
+                const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], R0))));
+                const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], R0))));
+#if S2_LUT512
+                iU[c] = (su >> 14) & (S2_LUT_N - 1); iV[c] = (sv >> 14) & (S2_LUT_N - 1);     // in [0, 511] by the host's bound; the mask is free
+#else
                 iU[c] = clip_u8_shr(su, 14); iV[c] = clip_u8_shr(sv, 14);
+#endif
             }
             // ---- colour stage + store ---------------------------------------------------------------------------
             unsigned c0[4], c1[4], c2[4];
@@ -281,13 +381,51 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int q = 2 * c + h;
+#if S2_SATPK
+                    c0[q] = (unsigned)(tr + m24(Y[q], a.y2r.cy));      // |term + Y cy| < 2^27: the channel is sat_u8 of the high half
+                    c1[q] = (unsigned)(tg + m24(Y[q], a.y2r.cy));
+                    c2[q] = (unsigned)(tb + m24(Y[q], a.y2r.cy));
+#else
                     c0[q] = (unsigned)min(max(tr + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
                     c1[q] = (unsigned)min(max(tg + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
                     c2[q] = (unsigned)min(max(tb + m24(Y[q], a.y2r.cy), 0), 0xFFFFFF);
+#endif
                 }
             }
             if (active) {
+#if S2_SBASE
+                const unsigned drow = (unsigned)yo * (unsigned)a.ds;
+    #define S2_ST16(v) bD.st16((v), dstOff, drow)
+    #define S2_ST12(v) bD.st12((v), dstOff, drow)
+#else
                 uint8_t *d = pd + (unsigned)((unsigned)yo * (unsigned)a.ds + dstOff);
+    #define S2_ST16(v) (*reinterpret_cast<uint4 *>(d) = (v))
+    #define S2_ST12(v) (*reinterpret_cast<uint3 *>(d) = (v))
+#endif
+#if S2_SATPK
+    // two channels -> bytes (0, 1) of a register: the high halves side by side, then the saturating pack
+    #define S2_SAT2(x, y) s2_sat_pk_u8_i16(__builtin_amdgcn_perm((y), (x), 0x07060302u))
+    #define S2_JOIN(lo2, hi2) __builtin_amdgcn_perm((hi2), (lo2), 0x05040100u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = S2_JOIN(S2_SAT2(c0[0], c1[0]), S2_SAT2(c2[0], 0x00FF0000u));
+                    o4.y = S2_JOIN(S2_SAT2(c0[1], c1[1]), S2_SAT2(c2[1], 0x00FF0000u));
+                    o4.z = S2_JOIN(S2_SAT2(c0[2], c1[2]), S2_SAT2(c2[2], 0x00FF0000u));
+                    o4.w = S2_JOIN(S2_SAT2(c0[3], c1[3]), S2_SAT2(c2[3], 0x00FF0000u));
+                    S2_ST16(o4);
+                } else {
+                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    o3.x = S2_JOIN(S2_SAT2(c0[0], c1[0]), S2_SAT2(c2[0], c0[1]));
+                    o3.y = S2_JOIN(S2_SAT2(c1[1], c2[1]), S2_SAT2(c0[2], c1[2]));
+                    o3.z = S2_JOIN(S2_SAT2(c2[2], c0[3]), S2_SAT2(c1[3], c2[3]));
+                    S2_ST12(o3);
+                }
+    #undef S2_SAT2
+    #undef S2_JOIN
+            }
+        }
+    };
+#else
     #define S2_B2PAIR(lo, hi) __builtin_amdgcn_perm((hi), (lo), 0x0C0C0602u)
                 if (BPP == 4) {
                     uint4 o4;
@@ -295,18 +433,22 @@ __global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFram
                     o4.y = S2_B2PAIR(c0[1], c1[1]) | (S2_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
                     o4.z = S2_B2PAIR(c0[2], c1[2]) | (S2_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
                     o4.w = S2_B2PAIR(c0[3], c1[3]) | (S2_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
-                    *reinterpret_cast<uint4 *>(d) = o4;
+                    S2_ST16(o4);
                 } else {
                     uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
                     o3.x = S2_B2PAIR(c0[0], c1[0]) | (S2_B2PAIR(c2[0], c0[1]) << 16);
                     o3.y = S2_B2PAIR(c1[1], c2[1]) | (S2_B2PAIR(c0[2], c1[2]) << 16);
                     o3.z = S2_B2PAIR(c2[2], c0[3]) | (S2_B2PAIR(c1[3], c2[3]) << 16);
-                    *reinterpret_cast<uint3 *>(d) = o3;
+                    S2_ST12(o3);
                 }
     #undef S2_B2PAIR
             }
         }
     };
+#endif
+
+#undef S2_ST16
+#undef S2_ST12
 
     auto run = [&](auto edge_c) {
         for (int j0 = 0; j0 < nIter; j0 += 4) {
@@ -794,6 +936,19 @@ int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
             filter_is_edge_replication_np(g.vLumEff, p.srcH, np, t.vL)) { t.np = np; break; }
     }
     if (!t.np) return 0;
+#if S2_LUT512
+    // the 4-pair kernel indexes its 512-entry colour tables with (sum + 8192) >> 14 + 128 and no clamp: prove the range from the
+    // coefficients (bicubic: [-29, 284]); a filter with more overshoot than half of full scale stays on the tiled kernel
+    if (t.np == 4) {
+        int pos = 0, neg = 0;
+        for (int k = 0; k < 4; k++)
+            for (int h = 0; h < 2; h++) {
+                const int c = (int16_t)(((uint32_t)t.hC[k] >> (16 * h)) & 0xFFFF);
+                (c > 0 ? pos : neg) += c;
+            }
+        if (((255 * neg + 8192) >> 14) < -S2_LUT_BIAS || ((255 * pos + 8192) >> 14) > S2_LUT_N - 1 - S2_LUT_BIAS) return 0;
+    }
+#endif
     // vertical chroma: one tap of 4096 on row y, rounding 1 << 18 (the kernel folds it into the horizontal accumulator)
     if (g.vChrEff.taps != 1) return 0;
     for (int y = 0; y < p.dstH; y++)
@@ -807,11 +962,15 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv2sArgs a = a0;
-    // Rows per strip segment.  A wave's run time is proportional to its segment (one dependent load -> filter -> store
-    // chain per row, ~0.5 us), so a launch cannot finish faster than one segment: small launches want SHORT segments,
-    // and the 3 warm-up row pairs they repeat are paid from the parallelism that would otherwise idle.  Large launches
-    // want the segments just long enough for every SIMD to hold one round of waves (6 per SIMD at 78 VGPRs): the
-    // measured optimum is total waves ~ 6144 (MI355X: 1024 SIMDs x 6) — 3 rows for one 4K frame, 45 for 32 frames.
+    // Rows per strip segment.  A segment costs 3 warm-up row pairs (horizontal filter only) on top of its rows, so long segments
+    // looked right — and round 2 ran 45-row segments, one wave per wave slot for a 32-frame launch.  Round 3 measured the access
+    // pattern instead (tools/ubench/hbm_rw.hip, profiles/r03d_hbm_patterns.txt): thousands of waves each walking a long column
+    // are thousands of concurrent row streams, and a pure data-movement kernel of that shape tops out at 4.8-4.9 TB/s on this
+    // part whatever its prefetch depth or load width, while short bands swept in raster order reach 5.5 TB/s (the vertical halo
+    // re-read comes from L2).  Short segments also end the one-round tail (a launch no longer lasts as long as its slowest wave).
+    // Measured on the headline, same box: 45 rows 122.0 us, 24: 121.9, 16: 117.1, 12: 116.3, 10: 114.9, 8: 117.0, 6: 119.6 per
+    // 32-frame launch (profiles/r03f_rows_updown.txt) — 12 rows at most; small launches keep the old rule (3 rows for one frame:
+    // a launch cannot finish faster than one segment).
     const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstrips = (a.dstW + S2_STRIP - 1) / S2_STRIP;
@@ -819,13 +978,15 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
         const long rows = (long)a.dstH * nstrips * nframes;      // wave-rows of the launch
-        seg = (int)std::min(64L, std::max(3L, (rows + 6143) / 6144));
+        seg = (int)std::min(12L, std::max(3L, (rows + 6143) / 6144));
         // the 6-pair kernel: 5 warm-up row pairs per segment instead of 3 want longer segments, its 109 VGPRs (4 waves per SIMD)
         // shorter ones; measured best 6 / 12 / 16 rows at 1 / 4 / 32 frames per launch (profiles/r02f_yuv2s_lanczos_rows_sweep.txt)
         if (a.np == 6) seg = std::min(16, std::max(6, 2 * seg));
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;
+    const char *ud = getenv("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
+    a.updown = a.np == 4 && !(ud && !atoi(ud));
     const int nblk = a.nseg * a.nsg;
     const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;

@@ -265,6 +265,7 @@ struct Yuv2sArgs {
     int32_t hL[6], hC[6], vL[6];
     int lr;
     int segRows, nseg, nsg, xcdRemap;           // filled by the launcher: rows per strip segment, segments, groups of 4 strips per row
+    int updown;                                 // filled by the launcher: odd segments walk upward (the 4-pair kernel)
     Yuv2RgbConsts y2r;
 };
 int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTables &t);

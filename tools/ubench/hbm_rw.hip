@@ -1,0 +1,218 @@
+// tools/ubench/hbm_rw.hip — what does HBM deliver on THIS box for streaming kernels with the headline's read : write mix?
+// Not product code.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/hbm_rw.hip -o tools/bin/hbm_rw
+// Every kernel moves 16 bytes per lane per access; buffers are far larger than the 256 MiB Infinity Cache.
+//   copy        read N, write N                       (the guide's 6.29 TB/s reference is a float4 copy)
+//   read        read N (sum into a sink)
+//   r2w1        read 2N, write N  (the headline: 12.4 MB in, 6.2 MB out per frame)
+//   r2w1walk    the same bytes with the strip walkers' pattern: a wave reads two 1 KB row pieces + writes 768 B per step and walks
+//               down rows of a 3840-byte pitch, 48 steps per wave
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_copy(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n, int per)
+{
+    size_t i = ((size_t)blockIdx.x * per) * 256 + threadIdx.x;
+    for (int k = 0; k < per; k++, i += 256) if (i < n) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_read(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n, int per)
+{
+    size_t i = ((size_t)blockIdx.x * per) * 256 + threadIdx.x;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < per; k++, i += 256) if (i < n) { uint4 v = s[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+    if ((acc.x | acc.y | acc.z | acc.w) == 0x12345678u) d[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_r2w1(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n, int per)
+{
+    size_t i = ((size_t)blockIdx.x * per) * 256 + threadIdx.x;
+    for (int k = 0; k < per; k++, i += 256) if (i < n) { uint4 a = s[2 * i - (i & 255) + 0 * 256 + 0], b = s[2 * i - (i & 255) + 256]; d[i] = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
+}
+// wave = 64 lanes x 16 B = 1 KB per row piece; a wave walks `steps` rows down; rows of `pitch` bytes; pieces of a row side by side
+__global__ __launch_bounds__(256) void k_walk(const uint8_t *__restrict__ s, uint8_t *__restrict__ d, int pitch, int rows, int steps, int piecesPerRow)
+{
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int piece = wave % piecesPerRow, seg = wave / piecesPerRow;
+    const int frame = blockIdx.y;
+    const size_t fbase = (size_t)frame * pitch * rows;
+    const uint8_t *p = s + fbase + (size_t)seg * 2 * steps * pitch + piece * 1024 + lane * 16;
+    uint8_t *q = d + fbase / 2 + (size_t)seg * steps * pitch + piece * 1024 + lane * 16;       // half the bytes out: every second 1 KB piece row
+    if ((seg + 1) * 2 * steps > rows) return;
+    uint4 a = *(const uint4 *)p, b = *(const uint4 *)(p + pitch);
+    for (int r = 0; r < steps; r++) {
+        uint4 na = a, nb = b;
+        if (r + 1 < steps) { na = *(const uint4 *)(p + (size_t)(2 * r + 2) * pitch); nb = *(const uint4 *)(p + (size_t)(2 * r + 3) * pitch); }
+        *(uint4 *)(q + (size_t)r * pitch) = make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+        a = na; b = nb;
+    }
+}
+
+// The headline's shape with the loads a redesign would issue: a wave owns 512 source bytes of a row (8 per lane, no overlap), per step
+// it reads two luma rows and one chroma row (3 x 512 B) and writes 768 B (12 per lane); D = steps requested ahead; FILL = dependent
+// v_dot2 per step standing in for the filter arithmetic.  Frames are NV12 3840 x 2160 (pitch 3840), output pitch 5888.
+template <int D, int FILL>
+__global__ __launch_bounds__(256) void k_walk2(const uint8_t *__restrict__ s, uint8_t *__restrict__ d, int steps, int outRows)
+{
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int strip = wave & 7, seg = wave >> 3;
+    if (strip * 512 + lane * 8 >= 3840) return;
+    const int y0 = seg * (steps - 3);
+    if (y0 >= outRows) return;
+    const size_t fs = (size_t)3840 * 3240, fd = (size_t)5888 * 1080;
+    const uint8_t *py = s + blockIdx.y * fs + strip * 512 + lane * 8, *pc = py + (size_t)3840 * 2160;
+    uint8_t *q = d + blockIdx.y * fd + strip * 768 + lane * 12;
+    uint2 a[D + 1], b[D + 1], c[D + 1];
+    auto ld = [&](int j, int slot) {
+        const int m = min(max(y0 - 1 + j, 0), 1079), cr = min(max(y0 + j - 3, 0), 1079);
+        a[slot] = *(const uint2 *)(py + (size_t)min(max(2 * m - 1, 0), 2159) * 3840);
+        b[slot] = *(const uint2 *)(py + (size_t)(2 * m) * 3840);
+        c[slot] = *(const uint2 *)(pc + (size_t)cr * 3840);
+    };
+#pragma unroll
+    for (int k = 0; k < D; k++) ld(k, k);
+    int acc = 0;
+    for (int j0 = 0; j0 < steps; j0 += D + 1) {
+#pragma unroll
+        for (int u = 0; u <= D; u++) {
+            const int j = j0 + u;
+            if (j < steps) {
+                if (j + D < steps) ld(j + D, (u + D) % (D + 1));
+                unsigned x = a[u].x ^ b[u].y, y = a[u].y ^ c[u].x, z = b[u].x ^ c[u].y;
+#pragma unroll
+                for (int f = 0; f < FILL; f++) { x = __builtin_amdgcn_perm(x, y, 0x05010400u + f); y = (unsigned)__builtin_amdgcn_sdot2(__builtin_bit_cast(short __attribute__((ext_vector_type(2))), x), __builtin_bit_cast(short __attribute__((ext_vector_type(2))), z), (int)y, false); }
+                acc += (int)x;
+                if (j >= 3 && y0 + j - 3 < outRows) *(uint3 *)(q + (size_t)(y0 + j - 3) * 5888) = make_uint3(x, y, z + acc);
+            }
+        }
+    }
+}
+
+// walk2 with 16 source bytes per lane (a wave owns 1 KB of a row: 3.75 strips per 3840-byte row) and 24 output bytes per lane,
+// stored as 16 + 8 (ST = 0) or through nothing smarter — does the request width matter?
+template <int D, int ST>
+__global__ __launch_bounds__(256) void k_walk3(const uint8_t *__restrict__ s, uint8_t *__restrict__ d, int steps, int outRows)
+{
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int strip = wave & 3, seg = wave >> 2;
+    if (strip * 1024 + lane * 16 >= 3840) return;
+    const int y0 = seg * (steps - 3);
+    if (y0 >= outRows) return;
+    const size_t fs = (size_t)3840 * 3240, fd = (size_t)5888 * 1080;
+    const uint8_t *py = s + blockIdx.y * fs + strip * 1024 + lane * 16, *pc = py + (size_t)3840 * 2160;
+    uint8_t *q = d + blockIdx.y * fd + strip * 1536 + lane * 24;
+    uint4 a[D + 1], b[D + 1], c[D + 1];
+    auto ld = [&](int j, int slot) {
+        const int m = min(max(y0 - 1 + j, 0), 1079), cr = min(max(y0 + j - 3, 0), 1079);
+        a[slot] = *(const uint4 *)(py + (size_t)min(max(2 * m - 1, 0), 2159) * 3840);
+        b[slot] = *(const uint4 *)(py + (size_t)(2 * m) * 3840);
+        c[slot] = *(const uint4 *)(pc + (size_t)cr * 3840);
+    };
+#pragma unroll
+    for (int k = 0; k < D; k++) ld(k, k);
+    for (int j0 = 0; j0 < steps; j0 += D + 1) {
+#pragma unroll
+        for (int u = 0; u <= D; u++) {
+            const int j = j0 + u;
+            if (j < steps) {
+                if (j + D < steps) ld(j + D, (u + D) % (D + 1));
+                const uint4 x = make_uint4(a[u].x ^ b[u].y, a[u].y ^ c[u].x, b[u].x ^ c[u].y, a[u].z ^ b[u].w);
+                const uint2 y = make_uint2(a[u].w ^ c[u].z, b[u].z ^ c[u].w);
+                if (j >= 3 && y0 + j - 3 < outRows) {
+                    uint8_t *o = q + (size_t)(y0 + j - 3) * 5888;
+                    if (ST == 0) { *(uint4 *)o = x; *(uint2 *)(o + 16) = y; }
+                    else { *(uint2 *)o = make_uint2(x.x, x.y); *(uint2 *)(o + 8) = make_uint2(x.z, x.w); *(uint2 *)(o + 16) = y; }
+                }
+            }
+        }
+    }
+}
+
+// Raster-order bands: a workgroup (4 waves x 16 B per lane = one whole 3840-byte row) produces R output rows and reads the 2R + 6
+// luma rows and R chroma rows they need — the vertical halo is re-read by the neighbouring band (from L2 when that band runs on
+// the same XCD at about the same time).  XCD = 1: block b -> band (b % 8) * (nb / 8) + b / 8, so every XCD sweeps a contiguous
+// range of bands.  Bands of all frames form one linear sequence.
+template <int R, int XCD>
+__global__ __launch_bounds__(256) void k_band(const uint8_t *__restrict__ s, uint8_t *__restrict__ d, int nb)
+{
+    int b = blockIdx.x;
+    if (XCD) { const int chunk = nb >> 3; b = (b & 7) * chunk + (b >> 3); }
+    const int bandsPerFrame = 1080 / R, frame = b / bandsPerFrame, y0 = (b - frame * bandsPerFrame) * R;
+    const int col = threadIdx.x * 16;
+    if (col >= 3840) return;
+    const size_t fs = (size_t)3840 * 3240, fd = (size_t)5888 * 1080;
+    const uint8_t *py = s + frame * fs + col, *pc = py + (size_t)3840 * 2160;
+    uint8_t *q = d + frame * fd + threadIdx.x * 24;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint4 l[2 * R + 6], c[R];
+#pragma unroll
+    for (int r = 0; r < 2 * R + 6; r++) l[r] = *(const uint4 *)(py + (size_t)min(max(2 * y0 - 3 + r, 0), 2159) * 3840);
+#pragma unroll
+    for (int r = 0; r < R; r++) c[r] = *(const uint4 *)(pc + (size_t)(y0 + r) * 3840);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc.x ^= l[2 * r + k].x; acc.y ^= l[2 * r + k].y; acc.z ^= l[2 * r + k].z; acc.w ^= l[2 * r + k].w; }
+        uint8_t *o = q + (size_t)(y0 + r) * 5888;
+        *(uint4 *)o = make_uint4(acc.x ^ c[r].x, acc.y ^ c[r].y, acc.z, acc.w);
+        *(uint2 *)(o + 16) = make_uint2(c[r].z ^ acc.x, c[r].w ^ acc.y);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const size_t N = (size_t)1 << 26;            // 2^26 uint4 = 1 GiB per N
+    uint4 *s, *d;
+    CK(hipMalloc(&s, 2 * N * 16)); CK(hipMalloc(&d, N * 16));
+    CK(hipMemset(s, 1, 2 * N * 16)); CK(hipMemset(d, 0, N * 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char *name, double bytes, auto launch) {
+        for (int i = 0; i < 3; i++) launch();
+        CK(hipDeviceSynchronize());
+        float best = 1e9f, tot = 0;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0)); for (int i = 0; i < 4; i++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 4; best = ms < best ? ms : best; tot += ms;
+        }
+        printf("%-44s best %8.1f us  %6.2f TB/s   (avg %6.2f TB/s)\n", name, best * 1e3, bytes / (best * 1e-3) / 1e12, bytes / (tot / 5 * 1e-3) / 1e12);
+    };
+    for (int per : {1, 4, 16, 64}) {
+        const int blocks = (int)((N / 256 + per - 1) / per);
+        char nm[96];
+        snprintf(nm, sizeof nm, "copy   1 GiB -> 1 GiB, %2d x 16 B per lane", per);
+        timeit(nm, 2.0 * N * 16, [&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, s, d, N, per); });
+        snprintf(nm, sizeof nm, "read   1 GiB,          %2d x 16 B per lane", per);
+        timeit(nm, 1.0 * N * 16, [&] { hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, 0, s, d, N, per); });
+        snprintf(nm, sizeof nm, "r2w1   2 GiB -> 1 GiB, %2d x (32 B in, 16 B out)", per);
+        timeit(nm, 3.0 * N * 16, [&] { hipLaunchKernelGGL(k_r2w1, dim3(blocks), dim3(256), 0, 0, s, d, N, per); });
+    }
+    // the walkers' pattern: frames of 3840-byte pitch x 2160 rows in, half of that out; 32 / 128 frames per launch
+    for (int frames : {32, 128}) for (int steps : {12, 45}) {
+        const int pitch = 3840 + 256, rows = 2160, pieces = 3840 / 1024;          // 3 pieces of 1 KB per row (3072 of 3840 bytes)
+        const int segs = rows / (2 * steps), waves = segs * pieces, blocks = (waves + 3) / 4;
+        if ((size_t)frames * pitch * rows > 2 * N * 16) continue;
+        char nm[96];
+        snprintf(nm, sizeof nm, "walk   %3d frames, %2d steps per wave (r2w1)", frames, steps);
+        const double bytes = (double)frames * segs * pieces * steps * (2048.0 + 1024.0);
+        timeit(nm, bytes, [&] { hipLaunchKernelGGL(k_walk, dim3(blocks, frames), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, pitch, rows, steps, pieces); });
+    }
+    // headline-shaped walkers: 32 frames, 48 steps per wave (45 output rows), prefetch distance D, FILL dot2+perm pairs per step
+    {
+        const int frames = 32, steps = 48, segs = (1080 + 44) / 45, blocks = segs * 2;
+        const double bytes = (double)frames * (3840.0 * 3240 + 5760.0 * 1080);
+#define W2(D, F) timeit("walk2 D=" #D " fill=" #F " (32 frames, 8 B per lane loads)", bytes, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk2<D, F>), dim3(blocks, frames), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, steps, 1080); })
+        W2(1, 0); W2(2, 0); W2(3, 0); W2(5, 0);
+        W2(1, 60); W2(3, 60);
+#define W3(D, S) timeit("walk3 D=" #D " st=" #S " (32 frames, 16 B per lane loads, 24 B stores)", bytes, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk3<D, S>), dim3(segs, frames), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, steps, 1080); })
+        W3(1, 0); W3(2, 0); W3(1, 1);
+#define BD(R, X) timeit("band R=" #R " xcd=" #X " (32 frames; reads 2R+6 luma rows per R output rows)", bytes, [&] { const int nb = frames * 1080 / R; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_band<R, X>), dim3(nb), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, nb); })
+        BD(1, 0); BD(1, 1); BD(2, 0); BD(2, 1); BD(4, 0); BD(4, 1); BD(8, 0); BD(8, 1); BD(12, 1);
+        // shorter / longer segments with the wide loads
+        for (int st : {15, 27, 93}) {
+            const int sg = (1080 + st - 4) / (st - 3);
+            char nm[96]; snprintf(nm, sizeof nm, "walk3 D=1 st=0, %d steps per wave", st);
+            timeit(nm, bytes, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk3<1, 0>), dim3(sg, frames), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, st, 1080); });
+        }
+    }
+    return 0;
+}
