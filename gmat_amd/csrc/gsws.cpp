@@ -140,6 +140,9 @@ struct GmatSwsContext {
     Rgb2yTables r2ys;                    // strip-walking 2:1 packed RGB -> 8-bit 4:2:0
     Yuv3x2Tables y3x2;                   // strip-walking 3:2 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
+    YuvGTables yg;                // the polyphase band walker for any ratio (k_scale_yuvg.hip)
+    DevBuf dG[4 + 2 * 2 * 5];     // its device tables: hL, hC, posL, posC, then per (plane class, direction) coef / first / last / round / yLo
+    YuvGArgs gargs;
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
@@ -229,6 +232,26 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv4r_prepare(c->planYuv, c->ytiling, c->y4r)) < 0) return r;
     if ((r = yuv4x1_prepare(c->planYuv, c->ytiling, c->y4x1)) < 0) return r;
     if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
+    if (!a.src16 && !c->rgbViaPlanes && (r = yuvg_prepare(c->planYuv, c->ytiling, c->yg)) < 0) return r;
+    if (c->yg.ok) {
+        YuvGArgs &g = c->gargs;
+        std::memset(&g, 0, sizeof(g));
+        const YuvGTables &t = c->yg;
+        int k = 0;
+        auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            int rr = c->dG[k].upload(v.data(), v.size() * 4);
+            out = (const int32_t *)c->dG[k++].p;
+            return rr;
+        };
+        if ((r = up(t.hL, g.hL)) < 0 || (r = up(t.hC, g.hC)) < 0 || (r = up(t.posL, g.posL)) < 0 || (r = up(t.posC, g.posC)) < 0) return r;
+        for (int d = 0; d < 2; d++) {
+            if ((r = up(t.vL[d].coef, g.vcoefL[d])) < 0 || (r = up(t.vL[d].first, g.vfirstL[d])) < 0 || (r = up(t.vL[d].last, g.vlastL[d])) < 0 ||
+                (r = up(t.vL[d].round, g.vroundL[d])) < 0 || (r = up(t.vL[d].yLo, g.vyLoL[d])) < 0) return r;
+            if ((r = up(t.vC[d].coef, g.vcoefC[d])) < 0 || (r = up(t.vC[d].first, g.vfirstC[d])) < 0 || (r = up(t.vC[d].last, g.vlastC[d])) < 0 ||
+                (r = up(t.vC[d].round, g.vroundC[d])) < 0 || (r = up(t.vC[d].yLo, g.vyLoC[d])) < 0) return r;
+        }
+        g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
+    }
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -472,6 +495,30 @@ static Yuv2sArgs make_yuv2s_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     for (int k = 0; k < 6; k++) { sa.hL[k] = c->y2s.hL[k]; sa.hC[k] = c->y2s.hC[k]; sa.vL[k] = c->y2s.vL[k]; }
     sa.lr = c->y2s.lr; sa.xcdRemap = ya.xcdRemap; sa.y2r = ya.y2r;
     return sa;
+}
+
+// the polyphase band walker (any ratio): dword-aligned planes on both sides, planar chroma planes of one pitch
+static bool yuvg_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    if (!c->yg.ok || c->rangeConv || ya.prof) return false;
+    uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
+    if (!ya.nv12) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
+    if (c->yg.yuvOut) {
+        all |= (uintptr_t)ya.dstU | (uintptr_t)ya.dsU;
+        if (!ya.dstNv12) all |= (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    }
+    return (all & 3) == 0;
+}
+
+static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    YuvGArgs g = c->gargs;
+    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs; g.nv12 = ya.nv12;
+    g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
+    g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
+    g.ds = ya.ds; g.dsU = ya.dsU; g.dsV = ya.dsV; g.dstFormat = ya.dstFormat;
+    g.xcdRemap = ya.xcdRemap; g.y2r = ya.y2r;
+    return g;
 }
 
 // the plane-walking 4:2:0 -> 4:2:0 kernel: dword loads and stores on every plane
@@ -930,6 +977,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     YuvScaleArgs ya0;
     bool use4x1 = true;
     bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true, use32r = true, use4r = true;
+    bool useG = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
@@ -947,6 +995,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         use3r = use3r && yuv3r_eligible(c, ya);
         use32r = use32r && yuv32r_eligible(c, ya);
         use4r = use4r && yuv4r_eligible(c, ya);
+        useG = useG && yuvg_eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -1029,6 +1078,25 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
                 uint8_t *const *dp = dst_planes + 4 * (f0 + i);
                 if ((r = yuv2p444_chroma(c, ya0, sp[1], ya0.nv12 ? nullptr : sp[2], dp[1], dp[2], stream)) < 0) return r;
             }
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
+    if (useG && !(use2s || use2p || use1x2 || use3x1 || use3x2 || use4x1 || use2x)) {
+        const YuvGArgs ga = make_yuvg_args(c, ya0);
+        c->lastKernel = "scale_yuvg_kernel";
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = ga.nv12 ? nullptr : sp[2];
+                fr.dst[i] = dp[0]; fr.dstU[i] = ga.yuvOut ? dp[1] : nullptr; fr.dstV[i] = ga.yuvOut && !ga.nv12 ? dp[2] : nullptr;
+            }
+            int r = launch_scale_yuvg(ga, stream, &fr, m);
+            if (r < 0) return r;
             c->lastLaunchFrames = m;
         }
         return 1;
@@ -1649,6 +1717,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 const Yuv2xArgs xa = make_yuv2x_args(c, ya);
                 c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
                 r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, c->stream);
+                break;
+            }
+            if (yuvg_eligible(c, ya)) {
+                Yuv2xFrames one;
+                std::memset(&one, 0, sizeof(one));
+                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+                c->lastKernel = "scale_yuvg_kernel";
+                r = launch_scale_yuvg(make_yuvg_args(c, ya), c->stream, &one, 1);
                 break;
             }
             c->lastKernel = yuvscale_kernel_name(c->ytiling);

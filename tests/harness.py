@@ -50,6 +50,32 @@ def load_oracle(path):
     return Oracle(L)
 
 
+def is_generic(kernel):
+    """a kernel of the any-geometry tier behind the exact-ratio walkers: the polyphase band walker of round 3
+    (scale_yuvg_kernel: dword-aligned 8-bit 4:2:0 -> packed RGB / 4:2:0 of the same chroma layout, filters up to 20 x 18 taps) or
+    the tiled plane scaler of round 1 behind it (scale_yuv_kernel<...>).  WHICH of the two a context gets is asserted by
+    tests/test_parity_generic_walker.py clause by clause; the per-ratio test files only need "not a specialised walker"."""
+    return kernel == "scale_yuvg_kernel" or kernel.startswith("scale_yuv_kernel")
+
+
+def walker_takes(sw, sh, sf, df, dw, dh):
+    """the host rule of yuvg_prepare / yuvg_eligible restated for dword-aligned frames and bicubic-sized filters: 8-bit 4:2:0 in,
+    packed 8-bit RGB (even width: an odd one forces libswscale's full-chroma output) or 4:2:0 of the SAME chroma layout out, whole
+    dwords in every source row, at least 16 x 8 on both sides, and a DOWN-scale on both axes between about 1.15 : 1 and 4.7 : 1
+    (filters of at most 20 taps, at most 9 output rows open at once: the chroma plane of an RGB destination is an UP-scale below
+    2 : 1, which is what bounds the ratio from below).  Callers keep away from the two ends of that range."""
+    rgb = df in ("rgb24", "bgr24", "rgba", "bgra")
+    if sf not in ("nv12", "yuv420p") or not (rgb or df == sf):
+        return False
+    if sw % 4 or (sf == "yuv420p" and ((sw + 1) // 2) % 4) or (sf == "nv12" and (2 * ((sw + 1) // 2)) % 4):
+        return False
+    if rgb and dw % 2:
+        return False
+    if not (dw >= 16 and dh >= 8 and sw >= 16 and sh >= 8):
+        return False
+    return 1.15 <= sw / dw <= 4.7 and 1.15 <= sh / dh <= 4.7
+
+
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

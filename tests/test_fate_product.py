@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 import pytest
 
-from harness import SWS, DevPlane
+from harness import is_generic, SWS, DevPlane
 
 W, H, NFRAMES = 352, 288, 50
 _REFS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fate_refs.json")))
@@ -96,7 +96,7 @@ def test_product_reproduces_fate_sws_yuv_range(dev, clip):
                            planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
     assert r == H
     frame = np.concatenate([p.download().ravel() for p in dst])
-    assert lib.gmat_sws_lastKernel(c).decode().startswith("scale_yuv_kernel")
+    assert is_generic(lib.gmat_sws_lastKernel(c).decode())
     g = GOLD["sws-yuv-range"][0]
     assert frame.size == g["size"] and adler0(frame) == g["adler32"]
     # equal ranges again: back to the lossless plane copy

@@ -94,7 +94,7 @@ def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassemb
     # Verified on the GPU and listed (round 3): v_sat_pk_u8_i16 in the strip kernels' colour stage (s2_sat_pk_u8_i16, inline asm).
     # Its result's UPPER half is never consumed — every use goes straight into a v_perm_b32 that selects bytes 0 and 1 — so the
     # question "zeroed or preserved" does not arise; GPU suite bit-exact with it (profiles/r03c_valu_cuts_ab.txt, 4411 passed).
-    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel",)}
+    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuvg_rgb_kernel")}
     hits = {}
     for t in disassembly:
         func = "?"

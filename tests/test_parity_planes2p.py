@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import SWS, synth_planes
+from harness import is_generic, SWS, synth_planes
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
 
@@ -57,7 +57,10 @@ def expect(kern_yuv, sw, sh, sf, df, flags="bicubic"):
     chunks: yuv2x_prepare wants srcW % 16 == 0) and the generic plane scaler for what both decline"""
     if kern_yuv == "strip" and strip_takes(sw, sh, sf, df, flags):
         return strip_name(sf, df)
-    return TILED if sw % 16 == 0 else GENERIC
+    if sw % 16 == 0:
+        return TILED
+    from harness import walker_takes                      # round 3: the polyphase band walker in front of the generic plane scaler
+    return "scale_yuvg_kernel" if walker_takes(sw, sh, sf, df, sw // 2, sh // 2) else GENERIC
 
 
 # (srcW, srcH): both sides of every clause of the rule — one partial strip, exactly one luma strip (512) and one UV strip
@@ -71,7 +74,7 @@ def test_geometries_cover_both_kernels():
     took = [strip_takes(w, h, "nv12", "nv12") for w, h in GEOMS]
     assert sum(took) >= 8 and took.count(False) >= 4
     names = {expect(k, w, h, "nv12", "nv12") for k in ("strip", "tiled") for w, h in GEOMS}
-    assert names == {STRIP, TILED, GENERIC}
+    assert names == {STRIP, TILED, "scale_yuvg_kernel"}
 
 
 LANCZOS_GEOMS = [(128, 48), (256, 64), (528, 52), (1040, 96), (2064, 48), (4112, 48), (64, 48), (128, 44), (520, 48)]
@@ -124,7 +127,7 @@ def test_mixed_layouts_lanczos(dev, orc, strip_rows, kern_yuv, pair, geom):
     if kern_yuv == "strip" and strip_takes(sw, sh, pair[0], pair[1], "lanczos"):
         assert k == "scale_yuv2px_kernel", k
     else:
-        assert k in (TILED, GENERIC), k
+        assert k in (TILED, GENERIC, "scale_yuvg_kernel"), k
 
 
 @pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
@@ -178,7 +181,7 @@ def test_lanczos_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, fmt, 
     if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt, "lanczos"):
         assert k == STRIP, k
     else:
-        assert k in (TILED, GENERIC), k
+        assert k in (TILED, GENERIC, "scale_yuvg_kernel"), k
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64])
@@ -354,7 +357,7 @@ def test_cross_depth_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, p
     if kern_yuv == "strip" and strip_takes(sw, sh, "nv12", "nv12"):     # the geometry rule does not depend on the depth
         assert k == CROSS[pair], k
     else:
-        assert k.startswith("scale_yuv_kernel"), k                      # the generic plane scaler (the tiled 2:1 kernel is 8 -> 8 only)
+        assert is_generic(k), k                      # the generic plane scaler (the tiled 2:1 kernel is 8 -> 8 only)
 
 
 @pytest.mark.parametrize("pair", list(CROSS))
@@ -369,7 +372,7 @@ def test_cross_depth_destination_alignment(dev, orc, pair):
     """8-bit destinations store dwords, 10-bit ones 8 bytes"""
     need = 8 if CROSS[pair].endswith("<8to10>") else 4
     assert _check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need, extra=need) == CROSS[pair]
-    assert _check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need // 2, extra=need // 2).startswith("scale_yuv_kernel")
+    assert is_generic(_check_cross(dev, orc, pair[0], pair[1], 528, 52, align=need // 2, extra=need // 2))
 
 
 MIXED_DEPTH = [("nv12", "yuv420p10le"), ("yuv420p", "p010le"), ("p010le", "yuv420p"), ("yuv420p10le", "nv12"), ("p010le", "yuv420p10le"),
@@ -386,7 +389,7 @@ def test_mixed_layouts_across_depths(dev, orc, strip_rows, kern_yuv, pair, geom)
     if kern_yuv == "strip" and strip_takes(sw, sh, pair[0], pair[1]):
         assert k == strip_name(pair[0], pair[1]), k
     else:
-        assert k.startswith("scale_yuv_kernel"), k
+        assert is_generic(k), k
 
 
 @pytest.mark.parametrize("pair", MIXED_DEPTH[:4])
@@ -429,7 +432,7 @@ def test_420_to_444_at_half_size_on_both_paths(dev, orc, strip_rows, kern_yuv, s
     if kern_yuv == "strip" and to444_takes(sw, sh, sf):
         assert k == ("scale_yuv2p_kernel<luma>+uv_deinterleave_kernel" if sf == "nv12" else "scale_yuv2p_kernel<luma>+copy2d"), k
     else:
-        assert k.startswith("scale_yuv_kernel"), k
+        assert is_generic(k), k
 
 
 @pytest.mark.parametrize("rows", [1, 3, 5, 16, 1000])
@@ -442,14 +445,14 @@ def test_420_to_444_segmentation(dev, orc, strip_rows, rows):
 def test_420_to_444_filters(dev, orc, flags):
     k = _check444(dev, orc, "nv12", 528, 52, flags)
     if flags == "lanczos":
-        assert k.startswith("scale_yuv_kernel"), k
+        assert is_generic(k), k
 
 
 def test_420_to_444_alignment_and_batches(dev, orc, strip_rows):
     """luma rows off the 4-byte grid go to the generic kernel; the chroma re-layout handles any alignment itself"""
     strip_rows(0)
     assert _check444(dev, orc, "nv12", 528, 52, align=4, extra=4).startswith("scale_yuv2p_kernel<luma>")
-    assert _check444(dev, orc, "nv12", 528, 52, align=1, extra=1).startswith("scale_yuv_kernel")
+    assert is_generic(_check444(dev, orc, "nv12", 528, 52, align=1, extra=1))
     for sf in ("nv12", "yuv420p"):
         k = _run_batch(dev, orc, sf, "yuv444p", 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
         assert k.startswith("scale_yuv2p_kernel<luma>"), k

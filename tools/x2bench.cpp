@@ -232,6 +232,18 @@ int main(int argc, char **argv)
         {"land: nv12 4K->1080p nv12 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_LANCZOS},
         {"land: nv12 4K->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
         {"nv12 1080p->1080p rgb24 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        // any ratio: the polyphase band walker (scale_yuvg_kernel); "any:" cases run when the filter names them or "any"
+        {"any: nv12 4K->1600x900 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->1600x900 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1600, 900, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->1366x768 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1366, 768, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->1366x768 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1366, 768, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->854x480 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->854x480 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 854, 480, GMAT_SWS_BICUBIC},
+        {"any: nv12 1080p->768x432 rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 768, 432, GMAT_SWS_BICUBIC},
+        {"any: nv12 1080p->768x432 nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 768, 432, GMAT_SWS_BICUBIC},
+        {"any: nv12 1080p->854x480 rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
+        {"any: yuv420p 4K->1600x900 yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1600, 900, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->1600x900 rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_LANCZOS},
     };
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
@@ -242,6 +254,7 @@ int main(int argc, char **argv)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
+        if (strstr(k.label, "any:") && !strstr(only, "any")) continue;
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
     return 0;
