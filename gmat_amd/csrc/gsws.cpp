@@ -245,11 +245,11 @@ static int init_yuv_scaler(GmatSwsContext *c)
         };
         if ((r = up(t.hL, g.hL)) < 0 || (r = up(t.hC, g.hC)) < 0 || (r = up(t.posL, g.posL)) < 0 || (r = up(t.posC, g.posC)) < 0) return r;
         for (int d = 0; d < 2; d++) {
-            if ((r = up(t.vL[d].coef, g.vcoefL[d])) < 0 || (r = up(t.vL[d].first, g.vfirstL[d])) < 0 || (r = up(t.vL[d].last, g.vlastL[d])) < 0 ||
-                (r = up(t.vL[d].round, g.vroundL[d])) < 0 || (r = up(t.vL[d].yLo, g.vyLoL[d])) < 0) return r;
-            if ((r = up(t.vC[d].coef, g.vcoefC[d])) < 0 || (r = up(t.vC[d].first, g.vfirstC[d])) < 0 || (r = up(t.vC[d].last, g.vlastC[d])) < 0 ||
-                (r = up(t.vC[d].round, g.vroundC[d])) < 0 || (r = up(t.vC[d].yLo, g.vyLoC[d])) < 0) return r;
+            const YuvGQProg &m = t.yuvOut ? t.pl[d] : t.rgb[d];
+            if ((r = up(m.prog, g.prog[d])) < 0 || (r = up(m.qfirst, g.qfirst[d])) < 0 || (r = up(m.qdone, g.qdone[d])) < 0) return r;
+            if (t.yuvOut && ((r = up(t.pc[d].prog, g.progC[d])) < 0 || (r = up(t.pc[d].qfirst, g.qfirstC[d])) < 0 || (r = up(t.pc[d].qdone, g.qdoneC[d])) < 0)) return r;
         }
+        g.roundL = t.roundL; g.roundC = t.roundC;
         g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
     }
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;

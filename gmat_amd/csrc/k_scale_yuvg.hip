@@ -11,10 +11,12 @@
 //     byte pairs come out of the loaded dwords with v_perm_b32 through two per-lane selector registers (the window's byte phase
 //     pos[x] & 3 is the only thing that differs between lanes; the dword indices are static).  No LDS, no positions in the loop.
 //   * the vertical filter runs as K running sums per lane: source rows are consumed in pairs (cvt_pk = hScale8To15_c's
-//     saturation), a pair feeds each of the K open output rows with one v_dot2 whose coefficient pair is WAVE-UNIFORM (one scalar
-//     load per open row and pair from a table the host lays out per source row pair); when the first open row has seen its last
-//     source row it leaves through the output stage and the sums shift down by one.  Multi-row closes (up-scaling axes, e.g. the
-//     chroma of an RGB destination at ratios below 2:1) fall out of the loop structure: the next row is simply complete already.
+//     saturation), a pair feeds each of the K open output rows with one v_dot2 whose coefficient pair is WAVE-UNIFORM.  The host
+//     lays the whole vertical program out per QUAD — four luma rows and the two chroma rows beside them: two luma pairs, one chroma
+//     pair, their 3 K coefficient pairs, the first output row still open and the number of rows the quad completes — so the
+//     kernel's loop is static (two quads unrolled: every register of the prefetch rings has a fixed name) and only the number of
+//     rows leaving after a quad (0, 1, 2 ...) is decided at run time.  Multi-row closes (up-scaling axes, e.g. the chroma of an RGB
+//     destination below 2:1) are just a larger count.
 //   * bands are short (raster-like order, see k_scale_yuv2s.hip's launcher) and odd bands walk upward through mirrored tables.
 // Packed RGB destinations: even lanes filter the U sample of their column pair, odd lanes the V sample (the chroma plane of an
 // RGB destination has half the output width), one lane exchange per output row.  4:2:0 destinations: plane jobs of the same
@@ -34,14 +36,26 @@ namespace gmat {
 //      reads past the plane's last byte return 0 (the windows are whole dwords and may overhang the last row by up to 7 bytes)
 struct GPlane {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ GPlane(const uint8_t *p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000)) {}
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t r;
+    v4u words;                            // the same descriptor as four dwords, for the store issued from inline assembly
+    __device__ __forceinline__ GPlane(const uint8_t *p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000))
+    {
+        const unsigned long long a = (unsigned long long)p;
+        words = (v4u){(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+    }
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ void ld4(unsigned lane, unsigned row, unsigned *w) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane, row, 0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
     __device__ __forceinline__ void ld2(unsigned lane, unsigned row, unsigned *w) const { const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane, row, 0); w[0] = v.x; w[1] = v.y; }
     __device__ __forceinline__ void ld1(unsigned lane, unsigned row, unsigned *w) const { w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, lane, row, 0); }
-    __device__ __forceinline__ void st1(unsigned d, unsigned lane, unsigned row) const { __builtin_amdgcn_raw_buffer_store_b32(d, r, lane, row, 0); }
+    __device__ __forceinline__ void st1(unsigned d, unsigned lane, unsigned row) const
+    {
+        // The store is issued from inline assembly so that the compiler does not see it: with a store pending beside loads LLVM treats
+        // gfx9's shared vmcnt as out of order and waits for vmcnt(0) at every use of a loaded register — which also drains the rows
+        // requested three steps ahead.  Seen as loads only, its waits are counted ones; an unseen store in the queue makes a counted
+        // wait stricter than needed, never laxer (loads return in order; k_scale_yuv3x1.hip).
+        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(d), "v"(lane), "s"(words), "s"(row) : "memory");
+    }
 #else
     // hipcc's host pass (never executed) and the CPU emulation of the test suite
     uint8_t *p; unsigned n;
@@ -97,77 +111,105 @@ __device__ __forceinline__ int g_hsum(const unsigned (&w)[GWin<P, S2>::NW], cons
     return s;
 }
 
-// One axis-pair of a lane: horizontal window + coefficients, K vertical running sums, the vertical program of its plane class.
-template <int P, int K, bool S2>
-struct GWalk {
+// One stream of a lane: its horizontal window (selectors, coefficient pairs), the wave's share of the row loads, a ring of R
+// requested row pairs with STATIC slot names and the gathered windows of the pair consumed next.
+//
+// Where the source bytes come from.  The first build let every lane load its own window straight from global memory (NW dwords
+// per row and lane, one row pair requested ahead) in a loop whose trip counts depended on the ratio: bit-exact, 9.8 us per 4K ->
+// 900p frame (profiles/r03h_generic_walker_first.txt) — the compiler could count nothing: with dynamic loops around the loads and
+// the output stores in the same queue every use of a loaded register waited for vmcnt(0) or (1), and the address arithmetic of
+// each load was ~8 scalar instructions.  Now
+//   * a wave loads each source row's UNIQUE bytes once — one dword per lane: 256 bytes cover 64 columns up to 3.7 : 1, SD = 2 dwords
+//     per lane beyond that — R row pairs ahead into ring registers;
+//   * a pair's bytes pass through a wave-private LDS row image on their way to the lanes' overlapping windows (ds_write_b32, then
+//     NW dword reads per row at the lane's window offset).  No barrier: one wave, and the LDS executes its instructions in order;
+//   * rows past the plane are simply requested: the buffer resource returns 0 for them, and their taps are 0 in every table.
+template <int P, bool S2, int SD, int R>
+struct GStream {
     static constexpr int NW = GWin<P, S2>::NW;
+    static constexpr int IMG = 64 * SD;
     int cf[P];
-    unsigned selE, selO, voff;
-    int acc[K];
-    unsigned cur[2][NW];                 // the row pair about to be consumed (requested one step ahead)
-    int m;                               // next row pair (walking coordinates)
-    // plane + program (wave-uniform)
-    const int32_t *vcoef, *vlast, *vround;
-    int srcRows, stride, rows, up;
+    unsigned selE, selO;
+    int winDw;                           // LDS dword index of this lane's window inside a row image
+    int ldDw[SD];                        // LDS dword index this lane fills, per sub-load
+    unsigned ldOff[SD];                  // byte offset in the source row this lane loads, per sub-load
+    unsigned ring[R][2][SD];
+    unsigned win[2][NW];
+    unsigned *img;                       // this wave's two row images of this stream: img[row * IMG + dword]
+    unsigned reqOff, rowStep;            // (wave-uniform) byte offset of the next row to request, and of one row further along the walk
 
-    __device__ __forceinline__ void setup(const int32_t *hTab, const int32_t *posTab, int col, int comp)
+    // col: this lane's output column of the plane; comp: component of an interleaved row (S2); returns the window's first dword (bytes)
+    __device__ __forceinline__ int setup(const int32_t *hTab, const int32_t *posTab, int col, int comp)
     {
-        const int pos = uniform_or_lane(posTab, col);
+        const int pos = posTab[col];
         const int b0 = S2 ? 2 * pos + comp : pos;
         const unsigned o = (unsigned)b0 & 3u;
-        voff = (unsigned)b0 & ~3u;
         selE = S2 ? (0x0C000C00u | o | ((o + 2) << 16)) : (0x0C000C00u | o | ((o + 1) << 16));
         selO = 0x0C000C00u | (o + 2) | ((o + 3) << 16);
 #pragma unroll
         for (int t = 0; t < P; t++) cf[t] = hTab[(size_t)col * P + t];
+        return b0 & ~3;
     }
-    static __device__ __forceinline__ int uniform_or_lane(const int32_t *t, int i) { return t[i]; }
-
-    __device__ __forceinline__ unsigned row_off(int rw) const      // walking-coordinate source row -> byte offset of the actual row
+    // the walk starts at row pair `pair` (walking coordinates) of a plane of `rows` rows
+    __device__ __forceinline__ void start(int pair, int rows, int stride, int up)
     {
-        const int r = min(rw, srcRows - 1);
-        return (unsigned)(up ? srcRows - 1 - r : r) * (unsigned)stride;
+        rowStep = up ? 0u - (unsigned)stride : (unsigned)stride;
+        reqOff = (unsigned)(up ? rows - 1 - 2 * pair : 2 * pair) * (unsigned)stride;
     }
-    __device__ __forceinline__ void request(const GPlane &pl, int mm)
-    {
-        pl.template ld<NW>(voff, row_off(2 * mm), cur[0]);
-        pl.template ld<NW>(voff, row_off(2 * mm + 1), cur[1]);
-    }
-    __device__ __forceinline__ void init_acc(int y)
+    template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SD])
     {
 #pragma unroll
-        for (int i = 0; i < K; i++) acc[i] = y + i < rows ? uniform_load(vround, y + i) : 0;
+        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = ld(ldOff[s], reqOff + rowStep); }
+        reqOff += 2u * rowStep;
     }
-    // consume the requested pair m, request pair m + 1 (req: which plane this lane reads — a lane-parity choice for planar chroma
-    // under an RGB destination, so that only the LOADS diverge, never the arithmetic)
-    template <class Req> __device__ __forceinline__ void step(Req &&req)
+    // a row pair's bytes: registers -> row images -> this lane's windows
+    __device__ __forceinline__ void gather(const unsigned (&src)[2][SD])
     {
-        unsigned a[NW], b[NW];
+        __builtin_amdgcn_wave_barrier();         // (emulation: the lanes of a wave are fibers; on the GPU the LDS runs a wave's instructions in order)
 #pragma unroll
-        for (int i = 0; i < NW; i++) { a[i] = cur[0][i]; b[i] = cur[1][i]; }
-        const int32_t *vc = vcoef + (size_t)m * K;
-        m++;
-        req(m);
-        const int h0 = g_hsum<P, S2>(a, cf, selE, selO) >> 7, h1 = g_hsum<P, S2>(b, cf, selE, selO) >> 7;
-        const int hp = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h0, h1));      // min(., 32767) of hScale8To15_c
+        for (int r = 0; r < 2; r++)
 #pragma unroll
-        for (int i = 0; i < K; i++) acc[i] = g_dot2(hp, uniform_load(vc, i), acc[i]);
+            for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < NW; i++) win[r][i] = img[r * IMG + winDw + i];
     }
-    __device__ __forceinline__ void shift(int y)                  // row y has left: slot i now stands for row y + 1 + i
+    // pair 0 gathered, pairs 1 .. R requested: pair k + 1 in ring slot (k + 1) % R
+    template <class Ld> __device__ __forceinline__ void prime(Ld &&ld)
     {
+        unsigned first[2][SD];
+        request(ld, first);
 #pragma unroll
-        for (int i = 0; i + 1 < K; i++) acc[i] = acc[i + 1];
-        acc[K - 1] = y + K < rows ? uniform_load(vround, y + K) : 0;
+        for (int d = 1; d <= R; d++) request(ld, ring[d % R]);
+        gather(first);
+    }
+    // the gathered pair's two horizontally filtered samples of this lane's column, packed: min(sum >> 7, 32767) each (hScale8To15_c)
+    __device__ __forceinline__ int hpair() const
+    {
+        const int h0 = g_hsum<P, S2>(win[0], cf, selE, selO) >> 7, h1 = g_hsum<P, S2>(win[1], cf, selE, selO) >> 7;
+        return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h0, h1));
+    }
+    // after a pair has been consumed: the next one (in ring slot S) becomes the gathered one, its slot is requested again R pairs on
+    template <int S, class Ld> __device__ __forceinline__ void advance(Ld &&ld)
+    {
+        gather(ring[S]);
+        request(ld, ring[S]);
     }
 };
+
+constexpr int kGHead = 2;               // dwords in front of a quad's coefficient pairs: first open output row, rows it completes
 
 // ---- packed RGB destinations --------------------------------------------------------------------------------------------------
 // block = 4 waves = 4 adjacent strips of 64 output columns of one band; grid.y = frame
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
+    constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
     __shared__ int2 lutV[256], lutU[256];
     __shared__ unsigned stage[4][66];
+    __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
@@ -187,7 +229,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
     const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
     const int ya = up ? a.dstH - y1 : y0, yb = up ? a.dstH - y0 : y1;            // walking coordinates
     const int f = blockIdx.y;
-    // exact valid bytes of each plane (row bytes are multiples of 4 by the host rule): a window dword past them reads as 0
+    // exact valid bytes of each plane (row bytes are multiples of 4 by the host rule): a dword past them reads as 0
     const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW);
     const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW);
     const GPlane bU(fr.u[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb), bV(NV12 ? fr.u[f] : fr.v[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb);
@@ -196,65 +238,125 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
     const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
 
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
-    GWalk<P, K, false> L;
-    GWalk<P, K, NV12> C;
-    L.setup(a.hL, a.posL, xc, 0);
-    C.setup(a.hC, a.posC, min(xc >> 1, a.chrDstW - 1), par);
-    L.vcoef = a.vcoefL[up]; L.vlast = a.vlastL[up]; L.vround = a.vroundL[up]; L.srcRows = a.srcH; L.stride = a.ys; L.rows = a.dstH; L.up = up;
-    C.vcoef = a.vcoefC[up]; C.vlast = a.vlastC[up]; C.vround = a.vroundC[up]; C.srcRows = a.chrSrcH; C.stride = a.us; C.rows = a.dstH; C.up = up;   // planar: us == vs (host rule)
-    // the first pairs this band needs, and the first row whose sums must be tracked from their start
-    L.m = uniform_load(a.vfirstL[up], ya); C.m = uniform_load(a.vfirstC[up], ya);
-    int y = min(uniform_load(a.vyLoL[up], L.m), uniform_load(a.vyLoC[up], C.m));
-    L.init_acc(y); C.init_acc(y);
-    auto reqL = [&](int mm) { L.request(bY, mm); };
-    auto reqC = [&](int mm) { if (NV12 || par == 0) C.request(bU, mm); else C.request(bV, mm); };
-    reqL(L.m);
-    reqC(C.m);
+    GStream<P, false, SD, 4> L;
+    GStream<P, NV12, SD, 2> C;
+    {
+        // luma: the wave's row segment starts at lane 0's window; every lane fills dword `lane` (+ 64) of the row image
+        const int w0 = L.setup(a.hL, a.posL, xc, 0);
+        const int seg = __builtin_amdgcn_readfirstlane(w0);
+        L.winDw = (w0 - seg) >> 2;
+#pragma unroll
+        for (int s = 0; s < SD; s++) { L.ldDw[s] = lane + 64 * s; L.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+        L.img = image[wave][0];
+    }
+    {
+        // chroma column lane >> 1, component lane & 1.  NV12: one interleaved segment.  Planar: the U segment in the first half of
+        // the row image (filled by lanes 0 .. 31), the V segment in the second (lanes 32 .. 63); a lane READS the half of its component
+        const int w0 = C.setup(a.hC, a.posC, min(xc >> 1, a.chrDstW - 1), par);
+        const int seg = __builtin_amdgcn_readfirstlane(w0);
+        if (NV12) {
+            C.winDw = (w0 - seg) >> 2;
+#pragma unroll
+            for (int s = 0; s < SD; s++) { C.ldDw[s] = lane + 64 * s; C.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+        } else {
+            C.winDw = par * 32 * SD + ((w0 - seg) >> 2);
+#pragma unroll
+            for (int s = 0; s < SD; s++) { const int j = (lane & 31) + 32 * s; C.ldDw[s] = (lane >> 5) * 32 * SD + j; C.ldOff[s] = (unsigned)seg + 4u * (unsigned)j; }
+        }
+        C.img = image[wave][1];
+    }
+    auto ldL = [&](unsigned off, unsigned row) { unsigned v; bY.ld1(off, row, &v); return v; };
+    auto ldC = [&](unsigned off, unsigned row) {
+        unsigned v;
+        if (NV12 || lane < 32) bU.ld1(off, row, &v); else bV.ld1(off, row, &v);      // only the load diverges (planar: us == vs, host rule)
+        return v;
+    };
+    // the vertical program: quads q0 .. q1 complete the band's rows; the sums start at the first row still open before q0
+    const int32_t *prog = a.prog[up];
+    const int q0 = uniform_load(a.qfirst[up], ya), q1 = uniform_load(a.qdone[up], yb - 1);
+    int y = uniform_load(prog, q0 * QS);
+    L.start(2 * q0, a.srcH, a.ys, up);
+    C.start(q0, a.chrSrcH, a.us, up);
+    L.prime(ldL);
+    C.prime(ldC);
+    int accL[K], accC[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { accL[i] = a.roundL; accC[i] = a.roundC; }
     const unsigned dsel = (unsigned)(lane % 3 == 0 ? 0x04020100u : lane % 3 == 1 ? 0x05040201u : 0x06050402u);
     const int p0 = min((4 * lane) / 3, 62);                      // lanes >= 48 store nothing
-    for (; y < yb; y++) {
-        const int lastL = uniform_load(L.vlast, y), lastC = uniform_load(C.vlast, y);
-        while (L.m <= lastL) L.step(reqL);
-        while (C.m <= lastC) C.step(reqC);
-        if (y >= ya) {
-            const int Y = L.acc[0] >> 19;
-            const int mine = clip_u8_shr(C.acc[0], 19), other = __shfl_xor(mine, 1);
-            const int U = par ? other : mine, V = par ? mine : other;
-            const int2 tv = lutV[V], tu = lutU[U];
-            const int ycy = m24(Y, a.y2r.cy);
-            const unsigned cr = (unsigned)((bgr ? tu.y : tv.x) + ycy), cg = (unsigned)(tv.y + tu.x + ycy), cb = (unsigned)((bgr ? tv.x : tu.y) + ycy);
-            const unsigned rg = g_sat_pk_u8_i16(__builtin_amdgcn_perm(cg, cr, 0x07060302u));
-            const unsigned ba = g_sat_pk_u8_i16(__builtin_amdgcn_perm(0x00FF0000u, cb, 0x07060302u));
-            const unsigned px = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
-            const unsigned drow = (unsigned)(up ? a.dstH - 1 - y : y) * (unsigned)a.ds;
-            if (bpp == 4) {
-                if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
-            } else {
-                // 64 pixels x 3 bytes = 48 dwords: through the wave's own LDS row (no barrier: one wave, in-order LDS)
-                stage[wave][lane] = px;
-                __builtin_amdgcn_wave_barrier();
-                const unsigned d0 = stage[wave][p0], d1 = stage[wave][p0 + 1];
-                __builtin_amdgcn_wave_barrier();
-                const unsigned o = __builtin_amdgcn_perm(d1, d0, dsel);
-                const int nb = 3 * min(64, a.dstW - X0);                 // bytes of this strip's row
-                if (4 * lane + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + 4u * (unsigned)lane, drow);
-                else if (4 * lane < nb) {                                 // a width that is not a multiple of 4: the last bytes one by one
-                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + 4u * (unsigned)lane;
-                    for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
-                }
+
+    auto emit = [&](int yw) {
+        const int Y = accL[0] >> 19;
+        const int mine = clip_u8_shr(accC[0], 19), other = __shfl_xor(mine, 1);
+        const int U = par ? other : mine, V = par ? mine : other;
+        const int2 tv = lutV[V], tu = lutU[U];
+        const int ycy = m24(Y, a.y2r.cy);
+        const unsigned cr = (unsigned)((bgr ? tu.y : tv.x) + ycy), cg = (unsigned)(tv.y + tu.x + ycy), cb = (unsigned)((bgr ? tv.x : tu.y) + ycy);
+        const unsigned rg = g_sat_pk_u8_i16(__builtin_amdgcn_perm(cg, cr, 0x07060302u));
+        const unsigned ba = g_sat_pk_u8_i16(__builtin_amdgcn_perm(0x00FF0000u, cb, 0x07060302u));
+        const unsigned px = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+        const unsigned drow = (unsigned)(up ? a.dstH - 1 - yw : yw) * (unsigned)a.ds;
+        if (bpp == 4) {
+            if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
+        } else {
+            // 64 pixels x 3 bytes = 48 dwords: through the wave's own LDS row (no barrier: one wave, in-order LDS)
+            __builtin_amdgcn_wave_barrier();
+            stage[wave][lane] = px;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned d0 = stage[wave][p0], d1 = stage[wave][p0 + 1];
+            const unsigned o = __builtin_amdgcn_perm(d1, d0, dsel);
+            const int nb = 3 * min(64, a.dstW - X0);                 // bytes of this strip's row
+            if (4 * lane + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + 4u * (unsigned)lane, drow);
+            else if (4 * lane < nb) {                                 // a width that is not a multiple of 4: the last bytes one by one
+                uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + 4u * (unsigned)lane;
+                for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
             }
         }
-        L.shift(y); C.shift(y);
+    };
+    // one quad: luma pairs 2q and 2q + 1, chroma pair q, then the rows it completes.  SA / SB / SC: the ring slots holding the pairs
+    // that follow (static: quads alternate between two sets of slots)
+    auto quad = [&](int q, auto sa_c, auto sb_c, auto sc_c) {
+        constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value, SC = decltype(sc_c)::value;
+        const int32_t *pq = prog + (size_t)q * QS;
+        const int ne = uniform_load(pq, 1);
+        int hp = L.hpair();
+#pragma unroll
+        for (int i = 0; i < K; i++) accL[i] = g_dot2(hp, uniform_load(pq, kGHead + i), accL[i]);
+        L.template advance<SA>(ldL);
+        hp = L.hpair();
+#pragma unroll
+        for (int i = 0; i < K; i++) accL[i] = g_dot2(hp, uniform_load(pq, kGHead + K + i), accL[i]);
+        L.template advance<SB>(ldL);
+        hp = C.hpair();
+#pragma unroll
+        for (int i = 0; i < K; i++) accC[i] = g_dot2(hp, uniform_load(pq, kGHead + 2 * K + i), accC[i]);
+        C.template advance<SC>(ldC);
+        for (int k = 0; k < ne; k++, y++) {
+            if (y >= ya && y < yb) emit(y);
+#pragma unroll
+            for (int i = 0; i + 1 < K; i++) { accL[i] = accL[i + 1]; accC[i] = accC[i + 1]; }
+            accL[K - 1] = a.roundL; accC[K - 1] = a.roundC;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    for (int q = q0; q <= q1; q += 2) {
+        quad(q, I1(), I2(), I1());
+        if (q + 1 > q1) break;
+        quad(q + 1, I3(), I0(), I0());
     }
 }
 
 // ---- 4:2:0 destinations: plane jobs ----------------------------------------------------------------------------------------------
 // job 0: the luma plane (lane = column).  job 1: chroma — NV12 -> NV12: lane = (column, component) of the interleaved plane;
-// planar -> planar: two jobs (U, V), lane = column.  Blocks [0, nblkL) are luma, the rest chroma.
+// planar -> planar: two jobs (U, V), lane = column.  Blocks [0, nblkL) are luma, the rest chroma.  A quad of a plane job is four of
+// ITS rows (two row pairs; the third coefficient set of the program is unused).
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
+    constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
     __shared__ unsigned stage[4][16];
+    __shared__ unsigned image[4][2 * 64 * SD];                    // [wave][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lin = blockIdx.x;
@@ -280,39 +382,70 @@ __global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2
     const int srcRowBytes = job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW;
     const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes);
     const int bcol = min(B0 + lane, rowBytes - 1);
+    const int32_t *prog = job ? a.progC[up] : a.prog[up];
+    const int rnd = job ? a.roundC : a.roundL;
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
-        GWalk<P, K, S2> W;
-        W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
-        W.vcoef = job ? a.vcoefC[up] : a.vcoefL[up]; W.vlast = job ? a.vlastC[up] : a.vlastL[up]; W.vround = job ? a.vroundC[up] : a.vroundL[up];
-        W.srcRows = srcRows; W.stride = ss; W.rows = rows; W.up = up;
-        W.m = uniform_load(job ? a.vfirstC[up] : a.vfirstL[up], ya);
-        int y = uniform_load(job ? a.vyLoC[up] : a.vyLoL[up], W.m);
-        W.init_acc(y);
-        auto req = [&](int mm) { W.request(bS, mm); };
-        req(W.m);
-        for (; y < yb; y++) {
-            const int last = uniform_load(W.vlast, y);
-            while (W.m <= last) W.step(req);
-            if (y >= ya) {
-                // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the row's start value
-                const unsigned v = (unsigned)clip_u8_shr(W.acc[0], 19);
-                const unsigned drow = (unsigned)(up ? rows - 1 - y : y) * (unsigned)dstride;
-                uint8_t *sb = reinterpret_cast<uint8_t *>(stage[wave]);
-                sb[lane] = (uint8_t)v;
-                __builtin_amdgcn_wave_barrier();
-                const unsigned o = stage[wave][lane & 15];
-                __builtin_amdgcn_wave_barrier();
-                const int nb = min(64, rowBytes - B0);
-                if (lane < 16) {
-                    if (4 * lane + 4 <= nb) bD.st1(o, (unsigned)B0 + 4u * (unsigned)lane, drow);
-                    else if (4 * lane < nb) {
-                        uint8_t *d = dp + (size_t)drow + (unsigned)B0 + 4u * (unsigned)lane;
-                        for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
-                    }
+        GStream<P, S2, SD, 4> W;
+        {
+            const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
+            const int seg = __builtin_amdgcn_readfirstlane(w0);
+            W.winDw = (w0 - seg) >> 2;
+#pragma unroll
+            for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+            W.img = image[wave];
+        }
+        auto ld = [&](unsigned off, unsigned row) { unsigned v; bS.ld1(off, row, &v); return v; };
+        const int q0 = uniform_load(job ? a.qfirstC[up] : a.qfirst[up], ya), q1 = uniform_load(job ? a.qdoneC[up] : a.qdone[up], yb - 1);
+        int y = uniform_load(prog, q0 * QS);
+        W.start(2 * q0, srcRows, ss, up);
+        W.prime(ld);
+        int acc[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) acc[i] = rnd;
+        auto emit = [&](int yw) {
+            // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the sums' start value
+            const unsigned v = (unsigned)clip_u8_shr(acc[0], 19);
+            const unsigned drow = (unsigned)(up ? rows - 1 - yw : yw) * (unsigned)dstride;
+            uint8_t *sb = reinterpret_cast<uint8_t *>(stage[wave]);
+            __builtin_amdgcn_wave_barrier();
+            sb[lane] = (uint8_t)v;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned o = stage[wave][lane & 15];
+            const int nb = min(64, rowBytes - B0);
+            if (lane < 16) {
+                if (4 * lane + 4 <= nb) bD.st1(o, (unsigned)B0 + 4u * (unsigned)lane, drow);
+                else if (4 * lane < nb) {
+                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + 4u * (unsigned)lane;
+                    for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
                 }
             }
-            W.shift(y);
+        };
+        auto quad = [&](int q, auto sa_c, auto sb_c) {
+            constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value;
+            const int32_t *pq = prog + (size_t)q * QS;
+            const int ne = uniform_load(pq, 1);
+            int hp = W.hpair();
+#pragma unroll
+            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp, uniform_load(pq, kGHead + i), acc[i]);
+            W.template advance<SA>(ld);
+            hp = W.hpair();
+#pragma unroll
+            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp, uniform_load(pq, kGHead + K + i), acc[i]);
+            W.template advance<SB>(ld);
+            for (int k = 0; k < ne; k++, y++) {
+                if (y >= ya && y < yb) emit(y);
+#pragma unroll
+                for (int i = 0; i + 1 < K; i++) acc[i] = acc[i + 1];
+                acc[K - 1] = rnd;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        for (int q = q0; q <= q1; q += 2) {
+            quad(q, I1(), I2());
+            if (q + 1 > q1) break;
+            quad(q + 1, I3(), I0());
         }
     };
     if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
@@ -321,59 +454,71 @@ __global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// The vertical program of one plane class in one walking direction (up: everything mirrored, so the kernel always counts upward):
-//   first[y]    row pair in which output row y's window starts
-//   last[y]     row pair holding its last source row
-//   yLo[m]      first output row not complete before pair m (the row slot 0 of the running sums stands for while pair m is consumed)
-//   coef[m][i]  int16 pair (tap on source row 2m, tap on 2m + 1) of output row yLo[m] + i, zero outside its window
-static int build_vprog(const FilterBank &fb, const std::vector<int32_t> &round, int srcRows, bool up, YuvGVProg &v)
+// The vertical program of a plane class pair (luma + the chroma beside it; or one plane on its own, fc == nullptr: a "quad" is then
+// four rows of that plane) in one walking direction (up: everything mirrored, so that the kernel always counts upward).  Per quad q:
+//   [0]          the first output row not complete before q (the row slot 0 of the running sums stands for while q is consumed)
+//   [1]          the number of output rows complete after q
+//   [2 .. 2+K)   int16 pairs (tap on luma row 4q, tap on 4q + 1) of output rows [0] + i;  [2+K ..): rows 4q + 2, 4q + 3;
+//   [2+2K ..)    (tap on chroma row 2q, tap on 2q + 1)
+// qfirst[y] / qdone[y]: the quad in which output row y's windows start / after which it is complete.
+static bool build_qprog(const FilterBank &fl, int srcRowsL, const FilterBank *fc, int srcRowsC, bool up, YuvGQProg &v)
 {
-    const int rows = fb.count, taps = fb.taps;
-    std::vector<int> pos(rows);
-    std::vector<int16_t> cf((size_t)rows * taps);
-    for (int y = 0; y < rows; y++) {
-        const int ys = up ? rows - 1 - y : y;
-        // effective window without leading / trailing zero taps would shorten the sums' lifetime; keep the table's own window
-        pos[y] = up ? srcRows - (fb.pos[ys] + taps) : fb.pos[ys];
-        for (int t = 0; t < taps; t++) cf[(size_t)y * taps + t] = fb.coef[(size_t)ys * taps + (up ? taps - 1 - t : t)];
-        if (pos[y] < 0 || pos[y] + taps > srcRows + 1) return 0;
-    }
-    for (int y = 1; y < rows; y++) if (pos[y] < pos[y - 1]) return 0;            // the walk needs monotone windows
-    const int M = (srcRows + 1) / 2 + 1;
-    v.first.assign(rows, 0); v.last.assign(rows, 0); v.round.assign(rows, 0);
-    for (int y = 0; y < rows; y++) {
-        v.first[y] = pos[y] >> 1;
-        v.last[y] = (pos[y] + taps - 1) >> 1;
-        v.round[y] = round[up ? rows - 1 - y : y];
-    }
-    v.yLo.assign(M + 1, rows);
-    {
-        int y = 0;
-        for (int m = 0; m <= M; m++) { while (y < rows && v.last[y] < m) y++; v.yLo[m] = y; }
-    }
-    int K = 1;
-    for (int m = 0; m < M; m++) {
-        int hi = v.yLo[m] - 1;
-        for (int y = v.yLo[m]; y < rows && v.first[y] <= m; y++) hi = y;
-        K = std::max(K, hi - v.yLo[m] + 1);
-    }
-    v.K = K; v.M = M; v.rows = rows;
-    v.pos = pos; v.cf = cf; v.taps = taps;
-    return 1;
-}
-static void fill_vcoef(YuvGVProg &v, int K)
-{
-    v.coef.assign((size_t)(v.M + 1) * K, 0);
-    for (int m = 0; m < v.M; m++)
-        for (int i = 0; i < K; i++) {
-            const int y = v.yLo[m] + i;
-            if (y >= v.rows) break;
-            int lo = 0, hi = 0;
-            const int t0 = 2 * m - v.pos[y], t1 = t0 + 1;
-            if (t0 >= 0 && t0 < v.taps) lo = v.cf[(size_t)y * v.taps + t0];
-            if (t1 >= 0 && t1 < v.taps) hi = v.cf[(size_t)y * v.taps + t1];
-            v.coef[(size_t)m * K + i] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+    const int rows = fl.count;
+    if (fc && fc->count != rows) return false;
+    auto mirror = [&](const FilterBank &fb, int srcRows, std::vector<int> &pos, std::vector<int16_t> &cf) {
+        pos.resize(rows); cf.resize((size_t)rows * fb.taps);
+        for (int y = 0; y < rows; y++) {
+            const int ys = up ? rows - 1 - y : y;
+            pos[y] = up ? srcRows - (fb.pos[ys] + fb.taps) : fb.pos[ys];
+            for (int t = 0; t < fb.taps; t++) cf[(size_t)y * fb.taps + t] = fb.coef[(size_t)ys * fb.taps + (up ? fb.taps - 1 - t : t)];
+            if (pos[y] < 0 || pos[y] + fb.taps > srcRows) return false;
+            if (y && pos[y] < pos[y - 1]) return false;                      // the walk needs monotone windows
         }
+        return true;
+    };
+    std::vector<int> posL, posC;
+    std::vector<int16_t> cfL, cfC;
+    if (!mirror(fl, srcRowsL, posL, cfL)) return false;
+    if (fc && !mirror(*fc, srcRowsC, posC, cfC)) return false;
+    v.qfirst.assign(rows, 0); v.qdone.assign(rows, 0);
+    int Q = 0;
+    for (int y = 0; y < rows; y++) {
+        int s = posL[y] >> 2, d = (posL[y] + fl.taps - 1) >> 2;
+        if (fc) { s = std::min(s, posC[y] >> 1); d = std::max(d, (posC[y] + fc->taps - 1) >> 1); }
+        v.qfirst[y] = s; v.qdone[y] = d;
+        Q = std::max(Q, d + 1);
+    }
+    std::vector<int> yBase(Q + 1, rows);
+    for (int q = 0, y = 0; q <= Q; q++) { while (y < rows && v.qdone[y] < q) y++; yBase[q] = y; }
+    int K = 1;
+    for (int q = 0; q < Q; q++) {
+        int hi = yBase[q] - 1;
+        for (int y = yBase[q]; y < rows && v.qfirst[y] <= q; y++) hi = y;
+        K = std::max(K, hi - yBase[q] + 1);
+    }
+    v.K = K; v.Q = Q; v.rows = rows;
+    v.yBase = yBase; v.posL = posL; v.posC = posC; v.cfL = cfL; v.cfC = cfC; v.tapsL = fl.taps; v.tapsC = fc ? fc->taps : 0;
+    return true;
+}
+static void fill_qprog(YuvGQProg &v, int K)
+{
+    const int QS = kGHead + 3 * K;
+    v.prog.assign((size_t)(v.Q + 1) * QS, 0);
+    auto tap = [](const std::vector<int16_t> &cf, int taps, int y, int t) { return t >= 0 && t < taps ? (int)cf[(size_t)y * taps + t] : 0; };
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    for (int q = 0; q <= v.Q; q++) {
+        int32_t *r = &v.prog[(size_t)q * QS];
+        r[0] = v.yBase[q];
+        r[1] = q < v.Q ? v.yBase[q + 1] - v.yBase[q] : 0;
+        if (q == v.Q) break;
+        for (int i = 0; i < K; i++) {
+            const int y = v.yBase[q] + i;
+            if (y >= v.rows) break;
+            r[kGHead + i] = pk(tap(v.cfL, v.tapsL, y, 4 * q - v.posL[y]), tap(v.cfL, v.tapsL, y, 4 * q + 1 - v.posL[y]));
+            r[kGHead + K + i] = pk(tap(v.cfL, v.tapsL, y, 4 * q + 2 - v.posL[y]), tap(v.cfL, v.tapsL, y, 4 * q + 3 - v.posL[y]));
+            if (v.tapsC) r[kGHead + 2 * K + i] = pk(tap(v.cfC, v.tapsC, y, 2 * q - v.posC[y]), tap(v.cfC, v.tapsC, y, 2 * q + 1 - v.posC[y]));
+        }
+    }
 }
 
 static const int kGP[] = {4, 6, 8, 10}, kGK[] = {4, 6, 7, 9};
@@ -390,10 +535,15 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     if (yuvOut && g.yuvOut != 1) return 0;
     if (yuvOut && ((p.srcFormat == GMAT_PIX_FMT_NV12) != (p.dstFormat == GMAT_PIX_FMT_NV12))) return 0;   // same chroma layout on both sides
     if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
-    // whole dwords inside every source row (the windows are dword loads checked against the plane's exact size)
+    // whole dwords inside every source row (the rows are dword loads checked against the plane's exact size)
     if (p.srcW % 4 || (p.srcFormat == GMAT_PIX_FMT_NV12 ? (2 * p.chrSrcW) % 4 : p.chrSrcW % 4)) return 0;
     // RGB: one chroma sample per pixel pair and per output row (the LUT form); 4:2:0: the chroma planes of the destination
     if (rgbOut && (p.chrDstW != (p.dstW + 1) / 2 || p.chrDstH != p.dstH)) return 0;
+    // the sums start at ONE value per plane class (true of every multi-tap vertical filter; the 1- and 2-tap special forms of
+    // vscale.c:135-167 have per-row starts and stay on the tiled kernel)
+    for (int v : g.lumRound) if (v != g.lumRound[0]) return 0;
+    for (int v : g.chrRound) if (v != g.chrRound[0]) return 0;
+    t.roundL = g.lumRound[0]; t.roundC = g.chrRound[0];
     // horizontal: coefficient pairs on the table's own windows (a window may start anywhere; the last pair of an odd tap count is padded)
     auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out, int P) {
         out.assign((size_t)fb.count * P, 0);
@@ -413,18 +563,41 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     if (!P) return 0;
     if (!hpack(p.hLum, p.srcW, t.hL, P) || !hpack(p.hChr, p.chrSrcW, t.hC, P)) return 0;
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
+    int needK = 0;
     for (int up = 0; up < 2; up++) {
-        if (!build_vprog(g.vLumEff, g.lumRound, p.srcH, up != 0, t.vL[up])) return 0;
-        if (!build_vprog(g.vChrEff, g.chrRound, p.chrSrcH, up != 0, t.vC[up])) return 0;
+        if (rgbOut) {
+            if (!build_qprog(g.vLumEff, p.srcH, &g.vChrEff, p.chrSrcH, up != 0, t.rgb[up])) return 0;
+            needK = std::max(needK, t.rgb[up].K);
+        } else {
+            if (!build_qprog(g.vLumEff, p.srcH, nullptr, 0, up != 0, t.pl[up])) return 0;
+            if (!build_qprog(g.vChrEff, p.chrSrcH, nullptr, 0, up != 0, t.pc[up])) return 0;
+            needK = std::max(needK, std::max(t.pl[up].K, t.pc[up].K));
+        }
     }
-    const int needK = std::max(std::max(t.vL[0].K, t.vL[1].K), std::max(t.vC[0].K, t.vC[1].K));
     int K = 0;
     for (int c : kGK) if (c >= needK) { K = c; break; }
     if (!K) { if (getenv("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d declined: K needed %d", p.srcW, p.srcH, p.dstW, p.dstH, needK); return 0; }
-    for (int up = 0; up < 2; up++) { fill_vcoef(t.vL[up], K); fill_vcoef(t.vC[up], K); }
+    for (int up = 0; up < 2; up++) { if (rgbOut) fill_qprog(t.rgb[up], K); else { fill_qprog(t.pl[up], K); fill_qprog(t.pc[up], K); } }
+    // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
+    // consecutive columns must fit the row image of SD * 256 bytes (planar chroma halves under an RGB destination: SD * 128)
+    {
+        const int SD = P >= 8 ? 2 : 1;
+        auto fits = [&](const FilterBank &fb, int cols, bool s2, int capBytes) {
+            const int NW = s2 ? P + 1 : ((P - 1) >> 1) + 2;
+            for (int c0 = 0; c0 < fb.count; c0 += cols) {
+                const int c1 = std::min(c0 + cols, fb.count) - 1;
+                const int b0 = (s2 ? 2 * fb.pos[c0] : fb.pos[c0]) & ~3, b1 = (s2 ? 2 * fb.pos[c1] + 1 : fb.pos[c1]) & ~3;
+                if (b1 + 4 * NW - b0 > capBytes) return false;
+            }
+            return true;
+        };
+        const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
+        if (!fits(p.hLum, 64, false, 256 * SD)) return 0;
+        if (rgbOut ? !fits(p.hChr, 32, nv12, nv12 ? 256 * SD : 128 * SD) : !fits(p.hChr, nv12 ? 32 : 64, nv12, 256 * SD)) return 0;
+    }
     t.P = P; t.K = K; t.yuvOut = yuvOut;
-    if (getenv("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d (L %d/%d C %d/%d) -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
-                                          p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, t.vL[0].K, t.vL[1].K, t.vC[0].K, t.vC[1].K, K);
+    if (getenv("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
+                                          p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
     t.ok = 1;
     return 0;
 }

@@ -273,26 +273,27 @@ int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTable
 int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // ---- the polyphase band walker for ANY ratio (k_scale_yuvg.hip): 8-bit 4:2:0 -> packed RGB, and -> 4:2:0 of the same chroma layout ----
-// The vertical program of one plane class in one walking direction; see build_vprog in k_scale_yuvg.hip.
-struct YuvGVProg {
-    int K = 0, M = 0, rows = 0, taps = 0;
-    std::vector<int32_t> first, last, round, yLo, coef;       // [rows] [rows] [rows] [M + 1] [(M + 1) * K]
-    std::vector<int> pos;                                     // (host only) window starts in walking coordinates
-    std::vector<int16_t> cf;                                  // (host only) taps in walking order
+// The vertical program of a plane class (pair) in one walking direction; see build_qprog in k_scale_yuvg.hip.
+struct YuvGQProg {
+    int K = 0, Q = 0, rows = 0, tapsL = 0, tapsC = 0;
+    std::vector<int32_t> prog, qfirst, qdone;                 // [(Q + 1) * (2 + 3 K)] [rows] [rows]
+    std::vector<int> yBase, posL, posC;                       // (host only)
+    std::vector<int16_t> cfL, cfC;                            // (host only) taps in walking order
 };
 struct YuvGTables {
-    int ok = 0, P = 0, K = 0, yuvOut = 0;
+    int ok = 0, P = 0, K = 0, yuvOut = 0, roundL = 0, roundC = 0;
     std::vector<int32_t> hL, hC, posL, posC;                  // [dstW][P] / [chrDstW][P] packed coefficient pairs, window starts
-    YuvGVProg vL[2], vC[2];                                   // [0] walking down, [1] walking up (mirrored)
+    YuvGQProg rgb[2];                                         // RGB destination: luma + chroma; [0] walking down, [1] walking up (mirrored)
+    YuvGQProg pl[2], pc[2];                                   // 4:2:0 destination: the luma plane / a chroma plane on its own
 };
 struct YuvGArgs {
     int ys, us, vs, nv12;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV, dstFormat, yuvOut;
-    int P, K;
+    int P, K, roundL, roundC;
     const int32_t *hL, *hC, *posL, *posC;
-    const int32_t *vcoefL[2], *vfirstL[2], *vlastL[2], *vroundL[2], *vyLoL[2];
-    const int32_t *vcoefC[2], *vfirstC[2], *vlastC[2], *vroundC[2], *vyLoC[2];
+    const int32_t *prog[2], *qfirst[2], *qdone[2];            // RGB destination, or the luma job of a 4:2:0 destination
+    const int32_t *progC[2], *qfirstC[2], *qdoneC[2];         // the chroma jobs of a 4:2:0 destination
     // filled by the launcher: rows per band, 4-strip groups per row, blocks (luma | chroma jobs of a 4:2:0 destination)
     int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap, updown;
     Yuv2RgbConsts y2r;
