@@ -199,16 +199,32 @@ struct GStream {
     }
 };
 
+// occupancy hint: the first build allocated 120 VGPRs (4 waves per SIMD) mostly for hoisted byte-pair temporaries
+#ifndef G_WAVES
+#define G_WAVES 0
+#endif
+#if G_WAVES > 0
+#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_WAVES)))
+#else
+#define G_WAVES_ATTR
+#endif
+// G_DEFER: the rows a quad completes leave during the NEXT quad, between a gather and its consumer (A/B switch)
+#ifndef G_DEFER
+#define G_DEFER 0
+#endif
+// G_RL: luma ring slots (row pairs requested ahead): 4 = two quads ahead, 2 = one quad ahead and 4 registers fewer
+#ifndef G_RL
+#define G_RL 4
+#endif
 constexpr int kGHead = 2;               // dwords in front of a quad's coefficient pairs: first open output row, rows it completes
 
 // ---- packed RGB destinations --------------------------------------------------------------------------------------------------
 // block = 4 waves = 4 adjacent strips of 64 output columns of one band; grid.y = frame
 template <int P, int K, bool NV12>
-__global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
+__global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
     __shared__ int2 lutV[256], lutU[256];
-    __shared__ unsigned stage[4][66];
     __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
     const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
 
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
-    GStream<P, false, SD, 4> L;
+    GStream<P, false, SD, G_RL> L;
     GStream<P, NV12, SD, 2> C;
     {
         // luma: the wave's row segment starts at lane 0's window; every lane fills dword `lane` (+ 64) of the row image
@@ -282,12 +298,14 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
     int accL[K], accC[K];
 #pragma unroll
     for (int i = 0; i < K; i++) { accL[i] = a.roundL; accC[i] = a.roundC; }
-    const unsigned dsel = (unsigned)(lane % 3 == 0 ? 0x04020100u : lane % 3 == 1 ? 0x05040201u : 0x06050402u);
-    const int p0 = min((4 * lane) / 3, 62);                      // lanes >= 48 store nothing
+    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3 from (own pixel = bytes 0..3, next lane's = bytes 4..7)
+    const unsigned dsel = (unsigned)((lane & 3) == 0 ? 0x04020100u : (lane & 3) == 1 ? 0x05040201u : 0x06050402u);
 
+    // lane i of every group of four fetches lane quad_perm[i] of it: one VALU instruction, no LDS round trip
+#define GMAT_G_QUAD(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true)
     auto emit = [&](int yw) {
         const int Y = accL[0] >> 19;
-        const int mine = clip_u8_shr(accC[0], 19), other = __shfl_xor(mine, 1);
+        const int mine = clip_u8_shr(accC[0], 19), other = GMAT_G_QUAD(mine, 0xB1);          // quad_perm:[1,0,3,2]: the pair's other component
         const int U = par ? other : mine, V = par ? mine : other;
         const int2 tv = lutV[V], tu = lutU[U];
         const int ycy = m24(Y, a.y2r.cy);
@@ -299,52 +317,75 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
         if (bpp == 4) {
             if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
         } else {
-            // 64 pixels x 3 bytes = 48 dwords: through the wave's own LDS row (no barrier: one wave, in-order LDS)
-            __builtin_amdgcn_wave_barrier();
-            stage[wave][lane] = px;
-            __builtin_amdgcn_wave_barrier();
-            const unsigned d0 = stage[wave][p0], d1 = stage[wave][p0 + 1];
-            const unsigned o = __builtin_amdgcn_perm(d1, d0, dsel);
+            // four pixels = three dwords: lanes 0, 1, 2 of each group of four store one, from their own pixel and the next lane's
+            // (quad_perm:[1,2,3,3]) through a byte permute whose selector is the lane's place in the group
+            const unsigned nxt = (unsigned)GMAT_G_QUAD(px, 0xF9);
+            const unsigned o = __builtin_amdgcn_perm(nxt, px, dsel);
             const int nb = 3 * min(64, a.dstW - X0);                 // bytes of this strip's row
-            if (4 * lane + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + 4u * (unsigned)lane, drow);
-            else if (4 * lane < nb) {                                 // a width that is not a multiple of 4: the last bytes one by one
-                uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + 4u * (unsigned)lane;
-                for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
+            const int ob = 12 * (lane >> 2) + 4 * (lane & 3);        // byte offset of this lane's dword in the strip's row
+            if ((lane & 3) != 3) {
+                if (ob + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + (unsigned)ob, drow);
+                else if (ob < nb) {                                   // a width that is not a multiple of 4: the last bytes one by one
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + (unsigned)ob;
+                    for (int i = 0; i < nb - ob; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
             }
         }
     };
-    // one quad: luma pairs 2q and 2q + 1, chroma pair q, then the rows it completes.  SA / SB / SC: the ring slots holding the pairs
-    // that follow (static: quads alternate between two sets of slots)
-    auto quad = [&](int q, auto sa_c, auto sb_c, auto sc_c) {
-        constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value, SC = decltype(sc_c)::value;
-        const int32_t *pq = prog + (size_t)q * QS;
-        const int ne = uniform_load(pq, 1);
-        int hp = L.hpair();
-#pragma unroll
-        for (int i = 0; i < K; i++) accL[i] = g_dot2(hp, uniform_load(pq, kGHead + i), accL[i]);
-        L.template advance<SA>(ldL);
-        hp = L.hpair();
-#pragma unroll
-        for (int i = 0; i < K; i++) accL[i] = g_dot2(hp, uniform_load(pq, kGHead + K + i), accL[i]);
-        L.template advance<SB>(ldL);
-        hp = C.hpair();
-#pragma unroll
-        for (int i = 0; i < K; i++) accC[i] = g_dot2(hp, uniform_load(pq, kGHead + 2 * K + i), accC[i]);
-        C.template advance<SC>(ldC);
-        for (int k = 0; k < ne; k++, y++) {
+#undef GMAT_G_QUAD
+    // one quad: luma pairs 2q and 2q + 1, chroma pair q.  SA / SB / SC: the ring slots holding the pairs that follow (static: quads
+    // alternate between two sets of slots).  Order matters — the wave barriers around a gather pin it in place: a gather's LDS round
+    // trip is covered by work that does not need it (the other stream's horizontal filter, the output stage of the rows the PREVIOUS
+    // quad completed: their sums are final, and they must leave before this quad's taps are added because the program's slots are
+    // counted from the first row still open).
+    int pend = 0;                               // rows completed by the previous quad, not yet out
+    auto flush = [&]() {
+        for (int k = 0; k < pend; k++, y++) {
             if (y >= ya && y < yb) emit(y);
 #pragma unroll
             for (int i = 0; i + 1 < K; i++) { accL[i] = accL[i + 1]; accC[i] = accC[i + 1]; }
             accL[K - 1] = a.roundL; accC[K - 1] = a.roundC;
         }
     };
+    auto quad = [&](int q, auto sa_c, auto sb_c, auto sc_c) {
+        constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value, SC = decltype(sc_c)::value;
+        const int32_t *pq = prog + (size_t)q * QS;
+        int cL0[K], cL1[K], cC[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) { cL0[i] = uniform_load(pq, kGHead + i); cL1[i] = uniform_load(pq, kGHead + K + i); cC[i] = uniform_load(pq, kGHead + 2 * K + i); }
+        const int ne = uniform_load(pq, 1);
+        const int hp0 = L.hpair();
+        L.template advance<SA>(ldL);
+        const int hpc = C.hpair();
+        C.template advance<SC>(ldC);
+#if G_DEFER
+        flush();
+#endif
+#pragma unroll
+        for (int i = 0; i < K; i++) { accL[i] = g_dot2(hp0, cL0[i], accL[i]); accC[i] = g_dot2(hpc, cC[i], accC[i]); }
+        const int hp1 = L.hpair();
+        L.template advance<SB>(ldL);
+#pragma unroll
+        for (int i = 0; i < K; i++) accL[i] = g_dot2(hp1, cL1[i], accL[i]);
+        pend = ne;
+#if !G_DEFER
+        flush();
+#endif
+    };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     for (int q = q0; q <= q1; q += 2) {
+#if G_RL == 4
         quad(q, I1(), I2(), I1());
         if (q + 1 > q1) break;
         quad(q + 1, I3(), I0(), I0());
+#else
+        quad(q, I1(), I0(), I1());
+        if (q + 1 > q1) break;
+        quad(q + 1, I1(), I0(), I0());
+#endif
     }
+    flush();
 }
 
 // ---- 4:2:0 destinations: plane jobs ----------------------------------------------------------------------------------------------
@@ -352,10 +393,9 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFr
 // planar -> planar: two jobs (U, V), lane = column.  Blocks [0, nblkL) are luma, the rest chroma.  A quad of a plane job is four of
 // ITS rows (two row pairs; the third coefficient set of the program is unused).
 template <int P, int K, bool NV12>
-__global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
+__global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
-    __shared__ unsigned stage[4][16];
     __shared__ unsigned image[4][2 * 64 * SD];                    // [wave][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,38 +447,49 @@ __global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2
             // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the sums' start value
             const unsigned v = (unsigned)clip_u8_shr(acc[0], 19);
             const unsigned drow = (unsigned)(up ? rows - 1 - yw : yw) * (unsigned)dstride;
-            uint8_t *sb = reinterpret_cast<uint8_t *>(stage[wave]);
-            __builtin_amdgcn_wave_barrier();
-            sb[lane] = (uint8_t)v;
-            __builtin_amdgcn_wave_barrier();
-            const unsigned o = stage[wave][lane & 15];
+            // four lanes' bytes -> one dword in lane 0 of each group of four: two quad permutes and two shift-ors, no LDS round trip
+            const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);          // quad_perm:[1,1,3,3]
+            const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);       // quad_perm:[2,2,2,2]
             const int nb = min(64, rowBytes - B0);
-            if (lane < 16) {
-                if (4 * lane + 4 <= nb) bD.st1(o, (unsigned)B0 + 4u * (unsigned)lane, drow);
-                else if (4 * lane < nb) {
-                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + 4u * (unsigned)lane;
-                    for (int i = 0; i < nb - 4 * lane; i++) d[i] = (uint8_t)(o >> (8 * i));
+            if ((lane & 3) == 0) {
+                if (lane + 4 <= nb) bD.st1(o, (unsigned)B0 + (unsigned)lane, drow);
+                else if (lane < nb) {
+                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + (unsigned)lane;
+                    for (int i = 0; i < nb - lane; i++) d[i] = (uint8_t)(o >> (8 * i));
                 }
             }
         };
-        auto quad = [&](int q, auto sa_c, auto sb_c) {
-            constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value;
-            const int32_t *pq = prog + (size_t)q * QS;
-            const int ne = uniform_load(pq, 1);
-            int hp = W.hpair();
-#pragma unroll
-            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp, uniform_load(pq, kGHead + i), acc[i]);
-            W.template advance<SA>(ld);
-            hp = W.hpair();
-#pragma unroll
-            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp, uniform_load(pq, kGHead + K + i), acc[i]);
-            W.template advance<SB>(ld);
-            for (int k = 0; k < ne; k++, y++) {
+        int pend = 0;                           // rows completed by the previous quad, not yet out (see the RGB kernel)
+        auto flush = [&]() {
+            for (int k = 0; k < pend; k++, y++) {
                 if (y >= ya && y < yb) emit(y);
 #pragma unroll
                 for (int i = 0; i + 1 < K; i++) acc[i] = acc[i + 1];
                 acc[K - 1] = rnd;
             }
+        };
+        auto quad = [&](int q, auto sa_c, auto sb_c) {
+            constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value;
+            const int32_t *pq = prog + (size_t)q * QS;
+            int c0[K], c1[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) { c0[i] = uniform_load(pq, kGHead + i); c1[i] = uniform_load(pq, kGHead + K + i); }
+            const int ne = uniform_load(pq, 1);
+            const int hp0 = W.hpair();
+            W.template advance<SA>(ld);
+#if G_DEFER
+            flush();
+#endif
+#pragma unroll
+            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp0, c0[i], acc[i]);
+            const int hp1 = W.hpair();
+            W.template advance<SB>(ld);
+#pragma unroll
+            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp1, c1[i], acc[i]);
+            pend = ne;
+#if !G_DEFER
+            flush();
+#endif
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -447,6 +498,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2
             if (q + 1 > q1) break;
             quad(q + 1, I3(), I0());
         }
+        flush();
     };
     if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
 }
@@ -521,7 +573,7 @@ static void fill_qprog(YuvGQProg &v, int K)
     }
 }
 
-static const int kGP[] = {4, 6, 8, 10}, kGK[] = {4, 6, 7, 9};
+static const int kGP[] = {4, 5, 6, 8, 10}, kGK[] = {4, 6, 7, 9};
 
 int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
@@ -635,7 +687,7 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
         else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } } while (0)
 #define GMAT_G_P(P_) do { switch (a.K) { case 4: GMAT_G_K(P_, 4); break; case 6: GMAT_G_K(P_, 6); break; case 7: GMAT_G_K(P_, 7); break; default: GMAT_G_K(P_, 9); } } while (0)
-    switch (a.P) { case 4: GMAT_G_P(4); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
+    switch (a.P) { case 4: GMAT_G_P(4); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
 #undef GMAT_G_P
 #undef GMAT_G_K
     GMAT_HIP_CHECK(hipGetLastError());

@@ -15,7 +15,12 @@ def pytest_configure(config):
 
 def _make(directory, target):
     """always ask make (a no-op when up to date): a stale .so must never pass for the sources"""
-    r = subprocess.run(["make", "-C", directory], capture_output=True, text=True)
+    import fcntl
+    # one make per directory at a time: pytest-xdist workers all arrive here, and two makes rebuilding the same objects
+    # truncate each other's outputs (seen as 2860 errors after a source edit once failures were no longer swallowed)
+    with open(os.path.join(directory, ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-C", directory], capture_output=True, text=True)
     if r.returncode != 0:               # also when an older binary exists: the suite would pass against a stale build
         raise RuntimeError(f"make -C {directory} failed:\n{r.stdout}{r.stderr}")
     return os.path.join(directory, target)

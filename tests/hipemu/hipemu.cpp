@@ -136,6 +136,10 @@ int dpp_wave_shift(int old, int v, int ctrl)
     int r = old;
     if (ctrl == 0x138 && lane > 0) r = shfl_slot[me - 1];
     else if (ctrl == 0x130 && lane < 63 && me + 1 < (int)fibers.size()) r = shfl_slot[me + 1];
+    else if (ctrl >= 0 && ctrl < 0x100) {                   // quad_perm: lane i of each group of four reads lane (ctrl >> 2i) & 3 of it
+        const int srcl = (me & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+        if (srcl < (int)fibers.size()) r = shfl_slot[srcl];
+    }
     else if (ctrl != 0x138 && ctrl != 0x130) abort();
     wave_sync();
     return r;
