@@ -11,6 +11,7 @@
  * scale_hip and format_hip additionally implement activate(): with batch=K they collect K frames and convert them with
  * one kernel launch (gmat_sws_scale_batch) — the per-frame path is launch-bound on MI355X.
  */
+#include <float.h>                      /* DBL_MAX, FLT_MAX in the option tables */
 #include <math.h>
 #include <string.h>
 #include "libavutil/mathematics.h"        /* M_PI */
