@@ -65,6 +65,19 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream);
 hipEvent_t *sws_batch_events(GmatSwsContext *c);           // 9 lazily created events owned by the context   // two-kernel form: frames must not overlap
 
+// ---- environment knobs (tests and measurements only) ---------------------------------------------------
+// A knob is read from the environment when a context is created — gmat_sws_getContext, gmat_filter_init, and the stateless direct
+// launchers (gmat_transpose ...), which are their own one-call contexts — and NOT per launch: round 2's launchers called getenv()
+// up to three times per launch, a scan of the whole environment on the per-frame path.  knob() hands out
+// the value as of the last such creation; GMAT_KNOB("NAME") adds a per-call-site cache, so that a launch costs a compare.
+void knobs_refresh();                                  // a context is being created: the next knob() of every name re-reads it
+unsigned long long knobs_epoch();
+const char *knob_read(const char *name, unsigned long long *seen, char *buf, unsigned bufsz, int *present);
+struct KnobSite { unsigned long long seen = ~0ull; char buf[48]; int present = 0; };
+inline const char *knob_at(KnobSite &s, const char *name) { return knob_read(name, &s.seen, s.buf, sizeof(s.buf), &s.present); }
+#define GMAT_KNOB(name) (::gmat::knob_at(*([]() -> ::gmat::KnobSite * { static thread_local ::gmat::KnobSite s; return &s; }()), name))
+const char *knob(const char *name);                    // by a run-time name (no call-site cache)
+
 inline int ceil_rshift(int a, int b) { return -((-a) >> b); }
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 

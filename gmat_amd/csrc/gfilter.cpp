@@ -256,6 +256,7 @@ int gmat_filter_set_option(GmatFilterContext *f, const char *key, const char *va
 
 int gmat_filter_init(GmatFilterContext *f)
 {
+    knobs_refresh();                             // the environment knobs are read now, not per frame (common.h)
     if (!f) return GMAT_ERR(EINVAL);
     switch (f->kind) {
     case K_CROP:
@@ -681,17 +682,20 @@ void gmat_filter_free(GmatFilterContext *f)
 // ---- direct launchers ------------------------------------------------------------------------------
 int gmat_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, int dir, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     return launch_transpose(src, ss, dst, ds, inW, inH, bpp, dir, (hipStream_t)stream);
 }
 
 int gmat_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int code, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     if (code < -1 || code > 1) return GMAT_ERR(EINVAL);
     return launch_flip(src, ss, dst, ds, w, h, bpp, code != 0, code <= 0, (hipStream_t)stream);
 }
 
 int gmat_crop(const uint8_t *src, int ss, uint8_t *dst, int ds, int x, int y, int w, int h, int bpp, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     if (x < 0 || y < 0) return GMAT_ERR(EINVAL);
     return launch_copy2d(src + (size_t)y * ss + (size_t)x * bpp, ss, dst, ds, w * bpp, h, (hipStream_t)stream);
 }
@@ -699,29 +703,34 @@ int gmat_crop(const uint8_t *src, int ss, uint8_t *dst, int ds, int x, int y, in
 int gmat_smooth3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, const int matrix[9],
                    float rdiv, float bias, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     return launch_conv3x3(src, ss, dst, ds, w, h, bpp, matrix, rdiv, bias, (hipStream_t)stream);
 }
 
 int gmat_gauss_blur(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, double sigmaX,
                     double sigmaY, int border_type, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     return launch_gauss_blur(src, ss, dst, ds, w, h, bpp, kw, kh, sigmaX, sigmaY, border_type, (hipStream_t)stream);
 }
 
 int gmat_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     return launch_median3x3(src, ss, dst, ds, w, h, bpp, (hipStream_t)stream);
 }
 
 int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
                 double angle_rad, int bilinear, const uint8_t *fill, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     if (!src || !dst) return GMAT_ERR(EINVAL);
     return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, bilinear, fill, (hipStream_t)stream);
 }
 
 int gmat_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, void *stream)
 {
+    knobs_refresh();                             // a stateless call is its own context
     return launch_rotate_flip_smooth(src, ss, dst, ds, inW, inH, bpp, (hipStream_t)stream);
 }
 

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,37 @@ void logf(int level, const char *fmt, ...)
     va_end(ap);
     if (g_log) g_log(level, buf);
     else if (level <= LOG_ERROR) fprintf(stderr, "[gmat_hip] %s\n", buf);
+}
+
+static std::atomic<unsigned long long> g_knob_epoch{1};
+void knobs_refresh() { g_knob_epoch.fetch_add(1, std::memory_order_relaxed); }
+unsigned long long knobs_epoch() { return g_knob_epoch.load(std::memory_order_relaxed); }
+// the call site's cache (thread-local, so no lock): valid while no context has been created since it was filled
+const char *knob_read(const char *name, unsigned long long *seen, char *buf, unsigned bufsz, int *present)
+{
+    const unsigned long long e = knobs_epoch();
+    if (*seen != e) {
+        const char *v = getenv(name);
+        *present = v != nullptr;
+        if (v) { snprintf(buf, bufsz, "%s", v); }
+        *seen = e;
+    }
+    return *present ? buf : nullptr;
+}
+const char *knob(const char *name)
+{
+    static thread_local struct { unsigned long long seen = ~0ull; std::string name, val; int present = 0; } slots[16];
+    const unsigned long long e = knobs_epoch();
+    for (auto &s : slots) {
+        if (s.name == name) {
+            if (s.seen != e) { const char *v = getenv(name); s.present = v != nullptr; s.val = v ? v : ""; s.seen = e; }
+            return s.present ? s.val.c_str() : nullptr;
+        }
+    }
+    for (auto &s : slots) {
+        if (s.name.empty()) { s.name = name; const char *v = getenv(name); s.present = v != nullptr; s.val = v ? v : ""; s.seen = e; return s.present ? s.val.c_str() : nullptr; }
+    }
+    return getenv(name);
 }
 
 } // namespace gmat

@@ -165,12 +165,19 @@ struct GmatSwsContext {
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
+    // opt-in frame-level concurrency for per-call users (gmat_sws_setConcurrency): consecutive calls rotate over these streams
+    int lanes = 1, laneNext = 0;
+    unsigned lanePending = 0;
+    hipStream_t laneStream[4] = {nullptr};
+    hipEvent_t laneDone[4] = {nullptr}, laneFork = nullptr;
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
         if (interBatch) (void)hipFree(interBatch);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
+        for (int i = 0; i < 4; i++) { if (laneDone[i]) (void)hipEventDestroy(laneDone[i]); if (laneStream[i]) (void)hipStreamDestroy(laneStream[i]); }
+        if (laneFork) (void)hipEventDestroy(laneFork);
     }
 };
 
@@ -472,7 +479,7 @@ static Yuv2xArgs make_yuv2x_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     xa.rowStartC = ya.rowStartC; xa.rowCountC = ya.rowCountC;
     xa.ntx = ya.ntx; xa.nty = ya.nty; xa.xcdRemap = ya.xcdRemap;
     xa.prof = ya.prof; xa.y2r = ya.y2r;
-    static const bool noUni = getenv("GMAT_SCALE_NO_UNIFORM") != nullptr;
+    static const bool noUni = GMAT_KNOB("GMAT_SCALE_NO_UNIFORM") != nullptr;
     if (!noUni) xa.uni = c->y2x.uni;
     return xa;
 }
@@ -826,7 +833,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
 {
     if (!c || n < 2) return 0;
-    static const bool off = getenv("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
+    const bool off = GMAT_KNOB("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
     // the common precheck of every branch below: profiling contexts (per-launch phase stamps) and cascades go frame by frame
     if (off || c->prof) return 0;
     if (int r = check_device(c, "gmat_sws_scale_batch"); r < 0) return r;
@@ -1161,6 +1168,7 @@ extern "C" {
 GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat,
                                     int flags, const double *param)
 {
+    gmat::knobs_refresh();                       // the environment knobs are read now, not per launch (common.h)
     if (srcW < 1 || srcH < 1 || dstW < 1 || dstH < 1) {
         logf(LOG_ERROR, "gmat_sws_getContext: %dx%d -> %dx%d is an invalid scaling dimension", srcW, srcH, dstW, dstH);
         return nullptr;
@@ -1182,7 +1190,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     c->param[0] = param ? param[0] : GMAT_SWS_PARAM_DEFAULT;
     c->param[1] = param ? param[1] : GMAT_SWS_PARAM_DEFAULT;
     c->y2r = make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false);
-    if (const char *e = getenv("GMAT_SWS_FUSED")) c->fused = atoi(e);
+    if (const char *e = GMAT_KNOB("GMAT_SWS_FUSED")) c->fused = atoi(e);
 
     const bool same = srcW == dstW && srcH == dstH;
     int r = 0;
@@ -1306,10 +1314,16 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
 
 void gmat_sws_setStream(GmatSwsContext *c, void *stream)
 {
-    if (c) c->stream = (hipStream_t)stream;
+    if (!c) return;
+    if (c->lanePending && c->stream != (hipStream_t)stream) (void)gmat_sws_join(c);      // the old stream gets its frames before it is left
+    c->stream = (hipStream_t)stream;
 }
 
-void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
+void gmat_sws_freeContext(GmatSwsContext *c)
+{
+    if (c && c->lanePending) (void)gmat_sws_join(c);
+    delete c;
+}
 
 int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 {
@@ -1426,8 +1440,57 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 }
 
 
+static int sws_scale_one(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                         int srcSliceH, uint8_t *const dst[], const int dstStride[]);
+
+int gmat_sws_setConcurrency(GmatSwsContext *c, int n)
+{
+    if (!c || n < 1 || n > 4) return GMAT_ERR(EINVAL);
+    if (n > 1 && (sws_shares_intermediate(c) || c->inner)) return GMAT_ERR(ENOSYS);    // one set of intermediates: frames must not overlap
+    int r = gmat_sws_join(c);
+    if (r < 0) return r;
+    for (int i = 0; i < n && n > 1; i++) {
+        if (!c->laneStream[i]) GMAT_HIP_CHECK(hipStreamCreateWithFlags(&c->laneStream[i], hipStreamNonBlocking));
+        if (!c->laneDone[i]) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->laneDone[i], hipEventDisableTiming));
+    }
+    if (n > 1 && !c->laneFork) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->laneFork, hipEventDisableTiming));
+    c->lanes = n; c->laneNext = 0;
+    return 0;
+}
+
+int gmat_sws_join(GmatSwsContext *c)
+{
+    if (!c) return GMAT_ERR(EINVAL);
+    for (int i = 0; i < 4; i++)
+        if (c->lanePending & (1u << i)) GMAT_HIP_CHECK(hipStreamWaitEvent(c->stream, c->laneDone[i], 0));
+    c->lanePending = 0;
+    return 0;
+}
+
 int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    if (c && c->lanes > 1) {
+        // the frame runs on one of the context's own streams, ordered AFTER everything the caller's stream holds now; the caller's
+        // stream is ordered after the frame only by gmat_sws_join (or the next setStream / setConcurrency / freeContext)
+        const int lane = c->laneNext;
+        c->laneNext = lane + 1 == c->lanes ? 0 : lane + 1;
+        hipStream_t user = c->stream, s = c->laneStream[lane];
+        GMAT_HIP_CHECK(hipEventRecord(c->laneFork, user));
+        GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->laneFork, 0));
+        c->stream = s;
+        const int r = sws_scale_one(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+        c->stream = user;
+        if (r < 0) return r;
+        GMAT_HIP_CHECK(hipEventRecord(c->laneDone[lane], s));
+        c->lanePending |= 1u << lane;
+        return r;
+    }
+    return sws_scale_one(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+}
+
+static int sws_scale_one(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                         int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
     if (!c || !src || !dst || !srcStride || !dstStride || !src[0] || !dst[0]) {
         logf(LOG_ERROR, "gmat_sws_scale: one of the input parameters to sws_scale() is NULL");

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yu
 // and every plane can be moved in dwords
 bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L)
 {
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return false;
     if (!L.stripOk || L.w % 8 || L.w < 64 || (L.h & 1) || L.h < 16) return false;
     uintptr_t all = (uintptr_t)L.src | (uintptr_t)L.ss | (uintptr_t)L.y | (uintptr_t)L.ys | (uintptr_t)L.u | (uintptr_t)L.us;
@@ -362,7 +362,7 @@ int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFr
     for (int k = 0; k < 4; k++) a.vC[k] = L.vC[k];
     a.rnd = 64 << 12;                                           // yuv2planeX_8_c / yuv2nv12cX_c dither
     a.nstrips = (L.w + Y2S_STRIP - 1) / Y2S_STRIP;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override (chroma rows per segment), read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override (chroma rows per segment), read per launch
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         // measured on one 4K frame per launch (profiles/r02o_rgb2yuv_strip.txt): 5 chroma rows 11.9 us, 3: 12.2, 4: 13.3, 6: 13.0, 8: 14.8
@@ -384,7 +384,7 @@ int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFr
     lo_hi(q.ry, q.gy, q.by, 255, (32 << 14) + (1 << 8), 9, ylo, yhi);
     lo_hi(q.ru, q.gu, q.bu, 510, (256L << 15) + (1 << 9), 10, ulo, uhi);
     lo_hi(q.rv, q.gv, q.bv, 510, (256L << 15) + (1 << 9), 10, vlo, vhi);
-    const char *ns = getenv("GMAT_R2Y_NOSAT");                   // test knob: 0 = the variant that keeps every saturation
+    const char *ns = GMAT_KNOB("GMAT_R2Y_NOSAT");                   // test knob: 0 = the variant that keeps every saturation
     const bool nosat = !(ns && !atoi(ns)) && ylo >= 0 && yhi <= 16351 && ulo >= 0 && uhi <= 16383 && vlo >= 0 && vhi <= 16383;
 #define GMAT_Y2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a, *frames); \
                                else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a, *frames); } while (0)

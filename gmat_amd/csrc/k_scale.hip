@@ -393,7 +393,7 @@ static int lds_bytes_for(int TW, int rows, int cols, int chrHalf, int chromaDire
 
 static int env_int(const char *name, int dflt)
 {
-    const char *v = getenv(name);
+    const char *v = ::gmat::knob(name);
     return v && *v ? atoi(v) : dflt;
 }
 

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void scale_rgb2y_kernel(Rgb2yArgs a, Yuv2xFram
 }
 
 // which of the two kernels a launch uses (GMAT_RGB2_SHARED=0: the one that converts the whole window per lane)
-static bool rgb2_shared() { const char *e = getenv("GMAT_RGB2_SHARED"); return !(e && !atoi(e)); }
+static bool rgb2_shared() { const char *e = GMAT_KNOB("GMAT_RGB2_SHARED"); return !(e && !atoi(e)); }
 const char *rgb2s_kernel_name() { return rgb2_shared() ? "scale_rgb2h_kernel" : "scale_rgb2s_kernel"; }
 bool rgb2h_takes_yuv() { return rgb2_shared(); }
 
@@ -659,7 +659,7 @@ bool rgb2h_takes_yuv() { return rgb2_shared(); }
 int rgb2s_prepare(const ScalePlan &p, Rgb2sTables &t)
 {
     t = Rgb2sTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
     if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA ||
@@ -683,7 +683,7 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Rgb2sArgs a = a0;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");
     const int segEnv = segStr ? atoi(segStr) : 0;
     const bool shared = rgb2_shared();
     const int nstrips = shared ? (a.dstW + H2_OUT - 1) / H2_OUT : (a.dstW + R2_STRIP - 1) / R2_STRIP;
@@ -736,7 +736,7 @@ int launch_scale_rgb2s(const Rgb2sArgs &a0, hipStream_t stream, const Yuv2xFrame
 int rgb2y_prepare(const ScalePlan &p, Rgb2yTables &t)
 {
     t = Rgb2yTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
     if (!(p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P)) return 0;
@@ -761,7 +761,7 @@ int launch_scale_rgb2y(const Rgb2yArgs &a0, hipStream_t stream, const Yuv2xFrame
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Rgb2yArgs a = a0;
     a.nstrips = (a.dstW + H2_OUT - 1) / H2_OUT;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: chroma rows per segment
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override: chroma rows per segment
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         // a segment re-converts 14 source rows of warm-up (7 row pairs) on top of its 4 rows per chroma row; about 3 waves per SIMD.

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
 // ---------------------------------------------------------------------------------------------
 static int yenv(const char *name, int dflt)
 {
-    const char *v = getenv(name);
+    const char *v = ::gmat::knob(name);
     return v && *v ? atoi(v) : dflt;
 }
 

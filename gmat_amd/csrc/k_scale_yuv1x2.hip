@@ -391,7 +391,7 @@ static bool up2_axis(const FilterBank &fb, int srcLen, int32_t (&A)[2], int32_t 
 int yuv1x2_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv1x2Tables &t)
 {
     t = Yuv1x2Tables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut != 1) return 0;
     const bool nv = p.srcFormat == GMAT_PIX_FMT_NV12 && p.dstFormat == GMAT_PIX_FMT_NV12;
@@ -415,7 +415,7 @@ int launch_scale_yuv1x2(const Yuv1x2Args &a0, hipStream_t stream, const Yuv2xFra
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv1x2Args a = a0;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override (OUTPUT rows per luma segment), read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override (OUTPUT rows per luma segment), read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int dstW = 2 * a.srcW, dstH = 2 * a.srcH, cDstW = 2 * a.chrSrcW, cDstH = 2 * a.chrSrcH;
     const int nstripsL = (dstW + U2_STRIP - 1) / U2_STRIP;
@@ -431,7 +431,7 @@ int launch_scale_yuv1x2(const Yuv1x2Args &a0, hipStream_t stream, const Yuv2xFra
     seg = (seg + 1) & ~1;                                        // segments start on even output rows
     // chroma segments of as many rows as luma's (half the chroma warm-up, equal wave lifetimes: 4.81 -> 4.31 us per 1080p -> 4K
     // frame); GMAT_U2_CHROMA_SEG=0: half as many (at least 4) — the tests run both
-    const char *cse = getenv("GMAT_U2_CHROMA_SEG");
+    const char *cse = GMAT_KNOB("GMAT_U2_CHROMA_SEG");
     a.segRowsL = seg; a.segRowsC = (cse && !atoi(cse)) ? std::max(4, ((seg / 2) + 1) & ~1) : seg;
     a.nsegL = (dstH + a.segRowsL - 1) / a.segRowsL;
     a.nsegC = (cDstH + a.segRowsC - 1) / a.segRowsC;

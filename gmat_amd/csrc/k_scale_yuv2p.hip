@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
 int yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2pTables &t)
 {
     t = Yuv2pTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut == 2) {
         // 8-bit 4:2:0 -> planar 4:4:4 at exactly 2:1: the chroma planes keep their size, and when their filters are the identity (one
@@ -805,7 +805,7 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv2pArgs a = a0;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override, read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override, read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstripsL = (a.dstW + P2_STRIP - 1) / P2_STRIP;
     const bool uvw = a.nv12 || a.cross;                          // the chroma runs on a UV walker (2 outputs per lane, one "plane" of workgroups)
@@ -839,7 +839,7 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     // Chroma segments: as many ROWS as luma's when both sides are 8-bit (half the chroma warm-up, equal wave lifetimes: nv12 4K ->
     // 1080p 4.12 -> 3.98 us, yuv420p 4.19 -> 3.89 us per frame), half as many for the 16-bit forms (their chroma waves are the
     // slowest of the launch and longer ones make its tail: p010 6.5 -> 7.5 us with equal rows).  GMAT_P2_CHROMA_SEG = 0 | 1 overrides.
-    const char *cse = getenv("GMAT_P2_CHROMA_SEG");
+    const char *cse = GMAT_KNOB("GMAT_P2_CHROMA_SEG");
     const bool equalC = cse ? atoi(cse) != 0 : (a.srcDepth == 8 && a.dstDepth == 8 && !a.cross);   // the cross-layout walker: 4.23 -> 4.99 us with equal rows
     a.segRowsL = seg; a.segRowsC = equalC ? seg : std::max(2, (seg + 1) / 2);
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;

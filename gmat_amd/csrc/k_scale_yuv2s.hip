@@ -920,7 +920,7 @@ bool filter_is_edge_replication_ratio(const FilterBank &fb, int srcLen, int R, i
 int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
 {
     t = Yuv2sTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut) return 0;
     if (!is_yuv420(p.srcFormat)) return 0;
@@ -971,7 +971,7 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     // Measured on the headline, same box: 45 rows 122.0 us, 24: 121.9, 16: 117.1, 12: 116.3, 10: 114.9, 8: 117.0, 6: 119.6 per
     // 32-frame launch (profiles/r03f_rows_updown.txt) — 12 rows at most; small launches keep the old rule (3 rows for one frame:
     // a launch cannot finish faster than one segment).
-    const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstrips = (a.dstW + S2_STRIP - 1) / S2_STRIP;
     a.nsg = (nstrips + 3) / 4;
@@ -985,7 +985,7 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     }
     a.segRows = seg;
     a.nseg = (a.dstH + seg - 1) / seg;
-    const char *ud = getenv("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
+    const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
     a.updown = a.np == 4 && !(ud && !atoi(ud));
     const int nblk = a.nseg * a.nsg;
     const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);

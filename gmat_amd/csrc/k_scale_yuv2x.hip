@@ -543,7 +543,7 @@ static bool regularise(const FilterBank &fb, int padded, int P, int &w0, std::ve
 int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
 {
     t.ok = 0;
-    const char *off = getenv("GMAT_SCALE_NO_2X");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_2X");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut == 2 || g.TW != X2_TW || g.TH != X2_TH) return 0;
     if (!is_yuv420(p.srcFormat) || is_dst10(p.dstFormat)) return 0;                    // the tile geometry assumes half-size chroma planes
@@ -674,7 +674,7 @@ int yuv2x_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2xTables &t)
             u.trLo = lo; u.trHi = hi;
             t.uni = u;
         }
-        if (getenv("GMAT_DEBUG_UNI"))
+        if (GMAT_KNOB("GMAT_DEBUG_UNI"))
             logf(LOG_ERROR, "yuv2x uniform tiles: cols [%d, %d] of %d, rows [%d, %d] of %d (P = %d)", t.uni.tcLo, t.uni.tcHi, t.ntx, t.uni.trLo,
                  t.uni.trHi, t.nty, P);
     }
@@ -700,7 +700,7 @@ int launch_scale_yuv2x(const Yuv2xArgs &a, int rowsL, int rowsC, int ldsBytes, h
     // the first tile's phases 2 and 3.  Measured on MI355X: 12.3-12.4 us against 12.1 us for one tile per block
     // (82 VGPRs instead of 48, and five co-resident blocks per CU already overlap each other's load phases), so
     // the default stays 1.
-    static const int tilesEnv = getenv("GMAT_SCALE_TILES") ? atoi(getenv("GMAT_SCALE_TILES")) : 1;
+    static const int tilesEnv = GMAT_KNOB("GMAT_SCALE_TILES") ? atoi(GMAT_KNOB("GMAT_SCALE_TILES")) : 1;
     const int tilesPerBlock = tilesEnv == 2 ? 2 : 1;
     const int ntiles = a.ntx * ((a.nty + tilesPerBlock - 1) / tilesPerBlock);
     if (ntiles <= 0) return 0;

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) D3R_BOUND void scale_yuv3r_kernel(Yuv3rArgs a,
 int yuv3x1_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv3x1Tables &t)
 {
     t = Yuv3x1Tables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut != 1) return 0;
     const bool nv = p.srcFormat == GMAT_PIX_FMT_NV12 && p.dstFormat == GMAT_PIX_FMT_NV12;
@@ -606,7 +606,7 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv3x1Args a = a0;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override (output rows per luma segment), read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override (output rows per luma segment), read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstripsL = (a.dstW + D3_STRIP - 1) / D3_STRIP;
     const int nstripsC = a.nv12 ? (a.chrDstW + D3_STRIP_UV - 1) / D3_STRIP_UV : (a.chrDstW + D3_STRIP - 1) / D3_STRIP;
@@ -618,7 +618,7 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
         seg = (int)std::min(25L, std::max(6L, (rows + 6143) / 6144));    // 25 rows (28 steps: a multiple of the 4 unrolled) at 32 frames: 3.53 us, 28 rows 3.73
     }
-    const char *ud = getenv("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
+    const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN");                 // test / measurement knob: 0 = every segment walks downward
     a.updown = !(ud && !atoi(ud));
     a.segRowsL = seg; a.segRowsC = seg;                          // the same walk length on every plane: equal wave lifetimes, half the chroma warm-up
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
@@ -636,7 +636,7 @@ int launch_scale_yuv3x1(const Yuv3x1Args &a0, hipStream_t stream, const Yuv2xFra
 int yuv3r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv3rTables &t)
 {
     t = Yuv3rTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut) return 0;
     if (p.srcFormat != GMAT_PIX_FMT_NV12) return 0;
@@ -662,7 +662,7 @@ int launch_scale_yuv3r(const Yuv3rArgs &a0, hipStream_t stream, const Yuv2xFrame
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv3rArgs a = a0;
     a.nstrips = (a.dstW + D3_STRIP - 1) / D3_STRIP;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         // a segment of n output rows walks n / 2 + 2 steps of 6 luma + 3 chroma rows: two warm-up steps.  Measured on 4K -> 720p

@@ -637,7 +637,7 @@ bool down32_axis(const FilterBank &fb, int srcLen, int32_t (&A)[3], int32_t (&B)
 int yuv3x2_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv3x2Tables &t)
 {
     t = Yuv3x2Tables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut != 1) return 0;
     const bool nv = p.srcFormat == GMAT_PIX_FMT_NV12 && p.dstFormat == GMAT_PIX_FMT_NV12;
@@ -662,7 +662,7 @@ int launch_scale_yuv3x2(const Yuv3x2Args &a0, hipStream_t stream, const Yuv2xFra
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv3x2Args a = a0;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override (output rows per segment), read per launch
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override (output rows per segment), read per launch
     const int segEnv = segStr ? atoi(segStr) : 0;
     const int nstripsL = (a.dstW + E3_STRIP - 1) / E3_STRIP;
     const int nstripsC = a.nv12 ? (a.chrDstW + E3_STRIP_UV - 1) / E3_STRIP_UV : (a.chrDstW + E3_STRIP - 1) / E3_STRIP;
@@ -735,7 +735,7 @@ static bool up43_axis(const FilterBank &fb, int srcLen, int32_t (&P)[4][4], int3
 int yuv32r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv32rTables &t)
 {
     t = Yuv32rTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut) return 0;
     if (p.srcFormat != GMAT_PIX_FMT_NV12) return 0;
@@ -759,7 +759,7 @@ int launch_scale_yuv32r(const Yuv32rArgs &a0, hipStream_t stream, const Yuv2xFra
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv32rArgs a = a0;
     a.nstrips = (a.dstW + E3_STRIP - 1) / E3_STRIP;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         // measured on 1080p -> 720p (profiles/r02zc_down32rgb.txt): 32 frames per launch 24 rows 2.14 us per frame (12: 2.32, 48: 2.74);

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void scale_yuv4x1_kernel(Yuv4x1Args a, Yuv2xFr
 int yuv4r_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv4rTables &t)
 {
     t = Yuv4rTables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.fullChroma || g.yuvOut) return 0;
     if (p.srcFormat != GMAT_PIX_FMT_NV12 && p.srcFormat != GMAT_PIX_FMT_YUV420P) return 0;
@@ -536,7 +536,7 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv4rArgs a = a0;
     a.nstrips = (a.dstW + D4_STRIP - 1) / D4_STRIP;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         // a segment of n output rows walks n + 3 steps of 4 luma + 2 chroma rows.  Measured on 4K -> 960x540 (profiles/r02ze_down4rgb.txt):
@@ -548,7 +548,7 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
     a.nseg = (a.dstH + seg - 1) / seg;
     a.nblk = (a.nseg * a.nstrips + 3) / 4;
     a.xcdRemap = 1;
-    { const char *ud = getenv("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }      // 0: every segment walks downward (test / measurement)
+    { const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }      // 0: every segment walks downward (test / measurement)
     const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
 #define GMAT_D4R(D) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, true>), grid, block, 0, stream, a, *frames); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4r_kernel<D, false>), grid, block, 0, stream, a, *frames); } while (0)
@@ -567,7 +567,7 @@ int launch_scale_yuv4r(const Yuv4rArgs &a0, hipStream_t stream, const Yuv2xFrame
 int yuv4x1_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv4x1Tables &t)
 {
     t = Yuv4x1Tables();
-    const char *off = getenv("GMAT_SCALE_NO_STRIP");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
     if (off && atoi(off)) return 0;
     if (g.yuvOut != 1) return 0;
     const bool nv = p.srcFormat == GMAT_PIX_FMT_NV12 && p.dstFormat == GMAT_PIX_FMT_NV12;
@@ -595,7 +595,7 @@ int launch_scale_yuv4x1(const Yuv4x1Args &a0, hipStream_t stream, const Yuv2xFra
     const int nstripsC = a.nv12 ? (a.chrDstW + D4_STRIP / 2 - 1) / (D4_STRIP / 2) : (a.chrDstW + D4_STRIP - 1) / D4_STRIP;
     const int nplC = a.nv12 ? 1 : 2;
     a.nsgL = nstripsL; a.nsgC = nstripsC;
-    const char *segStr = getenv("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment (every plane)
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");              // tuning / test override: output rows per segment (every plane)
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
@@ -607,7 +607,7 @@ int launch_scale_yuv4x1(const Yuv4x1Args &a0, hipStream_t stream, const Yuv2xFra
     a.nblkL = (a.nsegL * a.nsgL + 3) / 4;
     a.nblk = a.nblkL + (a.nsegC * a.nsgC * nplC + 3) / 4;
     a.xcdRemap = 1;
-    { const char *ud = getenv("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }
+    { const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN"); a.updown = !(ud && !atoi(ud)); }
     const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
     if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<true>), grid, block, 0, stream, a, *frames);
     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv4x1_kernel<false>), grid, block, 0, stream, a, *frames);

@@ -578,7 +578,7 @@ static const int kGP[] = {4, 5, 6, 8, 10}, kGK[] = {4, 6, 7, 9};
 int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
     t = YuvGTables();
-    const char *off = getenv("GMAT_SCALE_NO_GENERIC_WALKER");
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_GENERIC_WALKER");
     if (off && atoi(off)) return 0;
     const bool rgbOut = p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA;
     const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P;
@@ -628,7 +628,7 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     }
     int K = 0;
     for (int c : kGK) if (c >= needK) { K = c; break; }
-    if (!K) { if (getenv("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d declined: K needed %d", p.srcW, p.srcH, p.dstW, p.dstH, needK); return 0; }
+    if (!K) { if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d declined: K needed %d", p.srcW, p.srcH, p.dstW, p.dstH, needK); return 0; }
     for (int up = 0; up < 2; up++) { if (rgbOut) fill_qprog(t.rgb[up], K); else { fill_qprog(t.pl[up], K); fill_qprog(t.pc[up], K); } }
     // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
     // consecutive columns must fit the row image of SD * 256 bytes (planar chroma halves under an RGB destination: SD * 128)
@@ -648,7 +648,7 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
         if (rgbOut ? !fits(p.hChr, 32, nv12, nv12 ? 256 * SD : 128 * SD) : !fits(p.hChr, nv12 ? 32 : 64, nv12, 256 * SD)) return 0;
     }
     t.P = P; t.K = K; t.yuvOut = yuvOut;
-    if (getenv("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
+    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
                                           p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
     t.ok = 1;
     return 0;
@@ -658,9 +658,9 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     YuvGArgs a = a0;
-    const char *rowsStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
+    const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;
-    const char *ud = getenv("GMAT_STRIP_UPDOWN");
+    const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN");
     a.updown = !(ud && !atoi(ud));
     const int nstrips = (a.dstW + 63) / 64;
     a.nsg = (nstrips + 3) / 4;

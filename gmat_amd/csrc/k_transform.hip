@@ -573,7 +573,7 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
     // is still >= 128 B of contiguous HBM traffic
     // ... unless that leaves the chip short of workgroups (a 4K luma plane is 510 tiles of 128 x 128 on 256 CUs, each a single
     // load -> LDS -> store pass: 12.4 us): 1- and 2-byte planes then take 64 x 64 tiles.  GMAT_TRANSPOSE_TILE = 64 | 128 overrides (measurement).
-    const char *te = getenv("GMAT_TRANSPOSE_TILE");
+    const char *te = GMAT_KNOB("GMAT_TRANSPOSE_TILE");
     const int tiles128 = ((inW + 127) / 128) * ((inH + 127) / 128);
     const int T = bpp <= 2 ? ((te ? atoi(te) == 64 : tiles128 < 2048) ? 64 : 128) : 64;
     const int ntiles = ((inW + T - 1) / T) * ((inH + T - 1) / T);
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
 // the separable kernel's conditions: rows of whole dwords, dword-aligned pointers and pitches, at least 4 pixels a row
 static bool smooth121_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp)
 {
-    const bool off = getenv("GMAT_NO_SMOOTH121") != nullptr;                        // A/B switch for the benches and tests
+    const bool off = GMAT_KNOB("GMAT_NO_SMOOTH121") != nullptr;                        // A/B switch for the benches and tests
     return !off && bpp >= 1 && bpp <= 4 && ((w * bpp) & 3) == 0 && w >= 4 && al4(src, ss, dst, ds) && (int64_t)ss * h < (1ll << 31) &&
            (int64_t)ds * std::max(w, h) < (1ll << 31);
 }
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void median3x3s_kernel(const uint8_t *src, int
 // the strip form's conditions: rows of whole dwords, dword-aligned pointers and pitches, at least 4 pixels a row
 static bool median3x3s_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp)
 {
-    const bool off = getenv("GMAT_NO_MEDIAN_STRIP") != nullptr;                     // A/B switch for the benches and tests
+    const bool off = GMAT_KNOB("GMAT_NO_MEDIAN_STRIP") != nullptr;                     // A/B switch for the benches and tests
     return !off && bpp >= 1 && bpp <= 4 && ((w * bpp) & 3) == 0 && w >= 4 && al4(src, ss, dst, ds) && (int64_t)ss * h < (1ll << 31) &&
            (int64_t)ds * h < (1ll << 31);
 }
@@ -988,7 +988,7 @@ int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, in
     const int rb = w * bpp;
     if (median3x3s_ok(src, ss, dst, ds, w, h, bpp)) {
         const int nstrips = ((rb >> 2) + MD_TD - 1) / MD_TD;
-        const char *segStr = getenv("GMAT_STRIP_ROWS");          // tuning / test override: output rows per segment
+        const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override: output rows per segment
         int seg = segStr ? atoi(segStr) : 0;
         // whole row pairs; measured on 4K rgb24 / gray (profiles/r02y_median.txt): 6 - 8 rows 16.4 - 16.7 / 6.9 - 7.0 us, 16 rows 17.5 / 8.2, 32 rows 19.4 / 10.6
         if (seg <= 0) seg = (int)std::min(64L, std::max(8L, ((long)h * nstrips + 12287) / 12288)) & ~1;
