@@ -558,12 +558,6 @@ def c_harness(dry):
         except Exception as e:                               # noqa: BLE001 - a bench leg must not take the headline down
             rows.append({"error": repr(e)})
         res[key] = rows
-    # the per-call entry point with the context's opt-in frame-level concurrency (gmat_sws_setConcurrency(3) + gmat_sws_join)
-    try:
-        r = subprocess.run([exe, "1", "50", "nv12"], env=dict(env, X2BENCH_LANES="3"), capture_output=True, text=True, timeout=300)
-        res["one frame per call, 3 frames in flight (gmat_sws_setConcurrency)"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    except Exception as e:                                   # noqa: BLE001
-        res["one frame per call, 3 frames in flight (gmat_sws_setConcurrency)"] = [{"error": repr(e)}]
     try:
         r = subprocess.run([exe, "1", "50", "op: "], env=env, capture_output=True, text=True, timeout=300)
         res["filters, one 4K frame per launch"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]

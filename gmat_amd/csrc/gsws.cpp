@@ -165,19 +165,12 @@ struct GmatSwsContext {
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
-    // opt-in frame-level concurrency for per-call users (gmat_sws_setConcurrency): consecutive calls rotate over these streams
-    int lanes = 1, laneNext = 0;
-    unsigned lanePending = 0;
-    hipStream_t laneStream[4] = {nullptr};
-    hipEvent_t laneDone[4] = {nullptr}, laneFork = nullptr;
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
         if (interBatch) (void)hipFree(interBatch);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
-        for (int i = 0; i < 4; i++) { if (laneDone[i]) (void)hipEventDestroy(laneDone[i]); if (laneStream[i]) (void)hipStreamDestroy(laneStream[i]); }
-        if (laneFork) (void)hipEventDestroy(laneFork);
     }
 };
 
@@ -1314,16 +1307,10 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
 
 void gmat_sws_setStream(GmatSwsContext *c, void *stream)
 {
-    if (!c) return;
-    if (c->lanePending && c->stream != (hipStream_t)stream) (void)gmat_sws_join(c);      // the old stream gets its frames before it is left
-    c->stream = (hipStream_t)stream;
+    if (c) c->stream = (hipStream_t)stream;
 }
 
-void gmat_sws_freeContext(GmatSwsContext *c)
-{
-    if (c && c->lanePending) (void)gmat_sws_join(c);
-    delete c;
-}
+void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
 
 int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 {
@@ -1440,57 +1427,8 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 }
 
 
-static int sws_scale_one(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
-                         int srcSliceH, uint8_t *const dst[], const int dstStride[]);
-
-int gmat_sws_setConcurrency(GmatSwsContext *c, int n)
-{
-    if (!c || n < 1 || n > 4) return GMAT_ERR(EINVAL);
-    if (n > 1 && (sws_shares_intermediate(c) || c->inner)) return GMAT_ERR(ENOSYS);    // one set of intermediates: frames must not overlap
-    int r = gmat_sws_join(c);
-    if (r < 0) return r;
-    for (int i = 0; i < n && n > 1; i++) {
-        if (!c->laneStream[i]) GMAT_HIP_CHECK(hipStreamCreateWithFlags(&c->laneStream[i], hipStreamNonBlocking));
-        if (!c->laneDone[i]) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->laneDone[i], hipEventDisableTiming));
-    }
-    if (n > 1 && !c->laneFork) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->laneFork, hipEventDisableTiming));
-    c->lanes = n; c->laneNext = 0;
-    return 0;
-}
-
-int gmat_sws_join(GmatSwsContext *c)
-{
-    if (!c) return GMAT_ERR(EINVAL);
-    for (int i = 0; i < 4; i++)
-        if (c->lanePending & (1u << i)) GMAT_HIP_CHECK(hipStreamWaitEvent(c->stream, c->laneDone[i], 0));
-    c->lanePending = 0;
-    return 0;
-}
-
 int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
-{
-    if (c && c->lanes > 1) {
-        // the frame runs on one of the context's own streams, ordered AFTER everything the caller's stream holds now; the caller's
-        // stream is ordered after the frame only by gmat_sws_join (or the next setStream / setConcurrency / freeContext)
-        const int lane = c->laneNext;
-        c->laneNext = lane + 1 == c->lanes ? 0 : lane + 1;
-        hipStream_t user = c->stream, s = c->laneStream[lane];
-        GMAT_HIP_CHECK(hipEventRecord(c->laneFork, user));
-        GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->laneFork, 0));
-        c->stream = s;
-        const int r = sws_scale_one(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
-        c->stream = user;
-        if (r < 0) return r;
-        GMAT_HIP_CHECK(hipEventRecord(c->laneDone[lane], s));
-        c->lanePending |= 1u << lane;
-        return r;
-    }
-    return sws_scale_one(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
-}
-
-static int sws_scale_one(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
-                         int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
     if (!c || !src || !dst || !srcStride || !dstStride || !src[0] || !dst[0]) {
         logf(LOG_ERROR, "gmat_sws_scale: one of the input parameters to sws_scale() is NULL");

@@ -41,8 +41,6 @@ _SIGS = {
     "gmat_sws_setColorspace": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gmat_sws_setRange": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gmat_sws_setChromaPos": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "gmat_sws_setConcurrency": (C.c_int, [C.c_void_p, C.c_int]),
-    "gmat_sws_join": (C.c_int, [C.c_void_p]),
     "gmat_sws_setFused": (C.c_int, [C.c_void_p, C.c_int]),
     "gmat_sws_getFilter": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gmat_sws_lastKernel": (C.c_char_p, [C.c_void_p]),

@@ -134,18 +134,6 @@ GMAT_API int  gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int sr
  *   0 = the same arithmetic as 1 as two kernels with the HBM RGB24 intermediate owned by the context
  *       (the reference's structure, swscale_cuda.c:248-266). */
 GMAT_API int  gmat_sws_setFused(GmatSwsContext *c, int fused);
-/* Frame-level concurrency for callers that convert ONE FRAME PER CALL (no reference counterpart; the reference's sws_scale
- * enqueues on the context's one stream, libswscale/cuda/swscale_cuda.c:273-479, and so does this library by default).
- * A 4K frame is a 4-6 us kernel behind a ~2-4 us launch boundary, so frames issued one call at a time on one in-order
- * stream leave the GPU idle between them.  With n > 1 consecutive gmat_sws_scale() calls rotate over n streams owned by
- * the context: each frame starts after everything the caller's stream holds at the time of the call (an event), frames
- * overlap each other, and the caller's stream is ordered after them by gmat_sws_join() — call it before anything on
- * that stream reads a destination (it enqueues event waits; it does not block the host).  gmat_sws_setStream to another
- * stream, gmat_sws_setConcurrency and gmat_sws_freeContext join by themselves.  1 <= n <= 4; -ENOSYS for contexts that
- * own one set of intermediate frames (the two-kernel form, 16-bit destinations, RGBA sources).  Destinations of the frames
- * in flight must not alias. */
-GMAT_API int  gmat_sws_setConcurrency(GmatSwsContext *c, int n);
-GMAT_API int  gmat_sws_join(GmatSwsContext *c);
 /* introspection used by tests and bench: which 0 hLum 1 hChr 2 vLum 3 vChr.  Copies up to `cap`
  * int16 coefficients / int32 positions to HOST buffers; returns filter size, *count = rows. */
 GMAT_API int  gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos,

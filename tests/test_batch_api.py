@@ -223,42 +223,3 @@ def test_graph_replay_of_a_batch(dev, orc, strip_or_tiled, dst_fmt):
     k = _run_batch(dev, orc, "nv12", dst_fmt, 256, 64, 128, 32, nframes=6, nstreams=2, align=64, graph=True)
     assert k == _expected_2to1(strip_or_tiled, "nv12", dst_fmt), k
 
-
-@pytest.mark.parametrize("case", [("nv12", 256, 64, "rgb24", 128, 32), ("nv12", 128, 64, "rgb24", 128, 64), ("nv12", 384, 216, "nv12", 160, 90)])
-@pytest.mark.parametrize("lanes", [2, 4])
-def test_frame_level_concurrency_of_per_call_users(dev, orc, case, lanes):
-    """gmat_sws_setConcurrency: consecutive gmat_sws_scale calls rotate over the context's own streams; gmat_sws_join orders the
-    caller's stream after them.  Same bytes as one stream; refused (-ENOSYS) where the context owns one set of intermediates."""
-    import ctypes as C
-    from harness import PIX_FMT, SWS, synth_planes, planes, ints
-    sf, sw, sh, df, dw, dh = case
-    lib = dev.lib
-    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS["bicubic"] | SWS["hwaccel"], None)
-    assert c
-    stream = C.c_void_p()
-    lib.gmat_stream_create(C.byref(stream))
-    lib.gmat_sws_setStream(c, stream)
-    assert lib.gmat_sws_setConcurrency(c, lanes) == 0
-    n = 7
-    srcs = [synth_planes(orc, sf, sw, sh, seed=300 + i) for i in range(n)]
-    d_src = [dev.upload_planes(s, 16) for s in srcs]
-    d_dst = [dev.planes_like(df, dw, dh, 16) for _ in range(n)]
-    for i in range(n):
-        assert lib.gmat_sws_scale(c, planes([p.ptr for p in d_src[i]]), ints([p.stride for p in d_src[i]]), 0, sh,
-                                  planes([p.ptr for p in d_dst[i]]), ints([p.stride for p in d_dst[i]])) == dh
-    assert lib.gmat_sws_join(c) == 0
-    assert lib.gmat_stream_sync(stream) == 0
-    for i in range(n):
-        want = orc.sws(srcs[i], sw, sh, sf, dw, dh, df) if (sw, sh) != (dw, dh) else [orc.yuv2rgb(srcs[i], sw, sh, sf, df)]
-        for g, w in zip([p.download() for p in d_dst[i]], want):
-            assert (g == w).all()
-    assert lib.gmat_sws_setConcurrency(c, 1) == 0 and lib.gmat_sws_setConcurrency(c, 5) < 0
-    lib.gmat_sws_freeContext(c)
-    lib.gmat_stream_destroy(stream)
-    for ps in d_src + d_dst:
-        for p in ps:
-            p.free()
-    # the two-kernel form shares one intermediate frame: refused
-    c = lib.gmat_sws_getContext(256, 64, PIX_FMT["nv12"], 128, 32, PIX_FMT["rgb24"], SWS["bicubic"], None)
-    assert lib.gmat_sws_setFused(c, 0) == 0 and lib.gmat_sws_setConcurrency(c, 2) < 0
-    lib.gmat_sws_freeContext(c)

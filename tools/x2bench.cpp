@@ -108,17 +108,7 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         frame_ptrs(dst[i], df, dw, dh, p, ds); for (int k = 0; k < 4; k++) dp[(size_t)i * 4 + k] = p[k];
     }
     void *streams[1] = {stream};
-    // X2BENCH_LANES=n with one frame per launch: the per-call entry point gmat_sws_scale with the context's opt-in frame-level
-    // concurrency (gmat_sws_setConcurrency), joined back into the timed stream before the end event
-    const int lanes = getenv("X2BENCH_LANES") && NF == 1 ? atoi(getenv("X2BENCH_LANES")) : 0;
-    if (lanes > 1 && gmat_sws_setConcurrency(c, lanes) < 0) { printf("%-34s (no frame-level concurrency for this context)\n", label); gmat_sws_freeContext(c); gmat_stream_destroy(stream); for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); } return; }
-    int rot = 0;
     auto launch = [&](int set) {
-        if (lanes > 1) {
-            const int i = set * NF + (rot++ % NF);
-            CK(gmat_sws_scale(c, sp.data() + (size_t)i * 4, ss, 0, sh, dp.data() + (size_t)i * 4, ds));
-            return;
-        }
         CK(gmat_sws_scale_batch(c, NF, sp.data() + (size_t)set * NF * 4, ss, dp.data() + (size_t)set * NF * 4, ds, streams, 1, 0));
     };
     for (int i = 0; i < 6; i++) launch(i & 1);
@@ -131,7 +121,6 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
     for (int r = 0; r < REPS; r++) {
         CK(gmat_timer_begin(timer, stream));
         for (int i = 0; i < launches; i++) launch(i & 1);
-        if (lanes > 1) CK(gmat_sws_join(c));
         CK(gmat_timer_end(timer, stream));
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
         best = ms < best ? ms : best; sum += ms;
