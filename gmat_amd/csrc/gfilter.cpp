@@ -187,7 +187,8 @@ struct GmatFilterContext {
     int code = 0;
     // rotate / transpose
     double angle = 0; int dir = 1, quarter = 0;       // quarter == -1: arbitrary angle (vf_rotate.c arithmetic)
-    int rot_bilinear = 1;
+    int rot_bilinear = 1;                 // 0 nearest, 1 linear (and area), 2 cubic
+    double rot_shift_x = 0, rot_shift_y = 0;
     // smooth
     int smooth_median = 0, kw = 3, kh = 3;
     int border = -1;                     // -1: not given (the 3x3 integer kernel keeps vf_convolution's borders)
@@ -279,18 +280,22 @@ int gmat_filter_init(GmatFilterContext *f)
         {
             auto ip = f->opt.find("interp");
             const std::string m = ip == f->opt.end() ? "linear" : ip->second;
-            if (m == "linear") f->rot_bilinear = 1;
+            // map_interpolation, vf_rotate_nvcv.c:114-135.  cubic: Catmull-Rom in integers; area: linear, as cv::warpAffine
+            // treats INTER_AREA (the rules are stated in the test suite's checker (orc_vf.c): CV-CUDA's own arithmetic is not in the reference tree)
+            if (m == "linear" || m == "area") f->rot_bilinear = 1;
             else if (m == "nearest") f->rot_bilinear = 0;
+            else if (m == "cubic") f->rot_bilinear = 2;
             else {
-                logf(LOG_ERROR, "rotate_hip: Interpolation '%s' not supported.", m.c_str());   // cubic / area: CV-CUDA only
-                return GMAT_ERR(ENOSYS);
+                logf(LOG_ERROR, "rotate_hip: Interpolation '%s' not supported.", m.c_str());
+                return GMAT_ERR(EINVAL);
             }
-            if (std::fabs(opt_double(f, "shift_x", 0.0)) > 0 || std::fabs(opt_double(f, "shift_y", 0.0)) > 0) {
-                logf(LOG_ERROR, "rotate_hip: shift_x / shift_y are not implemented (rotation is about the centre)");
-                return GMAT_ERR(ENOSYS);
-            }
+            // shift_x / shift_y (vf_rotate_nvcv.c:86-87): a translation of the rotated image in output pixels; the rotation
+            // itself stays about the centre (defect 11)
+            f->rot_shift_x = opt_double(f, "shift_x", 0.0); f->rot_shift_y = opt_double(f, "shift_y", 0.0);
+            if (!std::isfinite(f->rot_shift_x) || !std::isfinite(f->rot_shift_y) || std::fabs(f->rot_shift_x) > 32767 || std::fabs(f->rot_shift_y) > 32767)
+                return GMAT_ERR(EINVAL);
         }
-        if (std::fabs(q - std::round(q)) > 1e-9) f->quarter = -1;   // vf_rotate.c's fixed-point bilinear / nearest
+        if (std::fabs(q - std::round(q)) > 1e-9 || f->rot_shift_x != 0 || f->rot_shift_y != 0) f->quarter = -1;   // vf_rotate.c's fixed-point walk
         else f->quarter = (((int)std::lround(q)) % 4 + 4) % 4;      // exact clockwise quarter turns
         break;
     }
@@ -323,11 +328,11 @@ int gmat_filter_init(GmatFilterContext *f)
             }
         }
         if (f->smooth_median) {
-            // median: kw = kh = 3 only; border_type / sigma are "only for gaussian" (vf_smooth_nvcv.c:93,:100-101) and
-            // are refused rather than ignored
-            if (f->kw != 3 || f->kh != 3) {
-                logf(LOG_ERROR, "smooth_hip: median is implemented for kw = kh = 3 only");
-                return GMAT_ERR(ENOSYS);
+            // median: any odd kw x kh up to kGaussMaxTaps (vf_median.c's rule at radius (kw - 1) / 2, radiusV (kh - 1) / 2);
+            // border_type / sigma are "only for gaussian" (vf_smooth_nvcv.c:93,:100-101) and are refused rather than ignored
+            if (!(f->kw & 1) || !(f->kh & 1) || f->kw > kGaussMaxTaps || f->kh > kGaussMaxTaps) {
+                logf(LOG_ERROR, "smooth_hip: median wants odd kw, kh <= %d", kGaussMaxTaps);
+                return GMAT_ERR(EINVAL);
             }
             if (f->border >= 0 || f->sigmaX > 0 || f->sigmaY > 0) {
                 logf(LOG_ERROR, "smooth_hip: border_type / sigmaX / sigmaY apply to type=gaussian only");
@@ -547,14 +552,16 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
                     // limited-range YUV 16,128,128 — drawutils.c:159-202)
                     uint8_t fill[4] = {0, 0, 0, 255};
                     if (is_yuv8_src(f->in_fmt)) { fill[0] = i == 0 ? 16 : 128; fill[1] = 128; }
-                    r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream);
+                    // chroma planes of a 4:2:0 frame move by half the shift (their samples are twice as far apart)
+                    r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream,
+                                      f->rot_shift_x / (1 << sub), f->rot_shift_y / (1 << sub));
                     break;
                 }
                 }
                 break;
             case K_SMOOTH: {
                 static const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
-                r = f->smooth_median ? launch_median3x3(s, ss, d, ds, pw, ph, bpp, f->stream)
+                r = f->smooth_median ? launch_median(s, ss, d, ds, pw, ph, bpp, f->kw, f->kh, f->stream)
                     : f->gauss_general ? launch_gauss_blur(s, ss, d, ds, pw, ph, bpp, f->kw, f->kh, f->sigmaX, f->sigmaY,
                                                            f->border < 0 ? 0 : f->border, f->stream)
                                        : launch_conv3x3(s, ss, d, ds, pw, ph, bpp, m, 1.0f / 16.0f, 0.0f, f->stream);
@@ -718,6 +725,20 @@ int gmat_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
 {
     knobs_refresh();                             // a stateless call is its own context
     return launch_median3x3(src, ss, dst, ds, w, h, bpp, (hipStream_t)stream);
+}
+
+int gmat_rotate2(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                 double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, void *stream)
+{
+    knobs_refresh();
+    if (!src || !dst || interp < 0 || interp > 2) return GMAT_ERR(EINVAL);
+    return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, interp, fill, (hipStream_t)stream, shift_x, shift_y);
+}
+
+int gmat_median(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, void *stream)
+{
+    knobs_refresh();
+    return launch_median(src, ss, dst, ds, w, h, bpp, kw, kh, (hipStream_t)stream);
 }
 
 int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,

@@ -151,12 +151,15 @@ int launch_gauss_blur(const uint8_t *src, int srcStride, uint8_t *dst, int dstSt
                       double sigmaX, double sigmaY, int border, hipStream_t stream);
 // per-channel 3x3 median, window rows / columns clamped at the edges (vf_median.c semantics at radius 1)
 int launch_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, hipStream_t stream);
+// kw x kh (odd) in general: vf_median.c at radius (kw - 1) / 2, radiusV (kh - 1) / 2; 3 x 3 goes to the kernels above
+int launch_median(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, int kw, int kh, hipStream_t stream);
 int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                               int inW, int inH, int bpp, hipStream_t stream);
 // arbitrary angle (radians, clockwise positive) in vf_rotate.c's 16.16 fixed point; fill == nullptr leaves
 // the pixels whose source position is out of range untouched
+// bilinear: 0 nearest, 1 linear, 2 cubic (Catmull-Rom, integer weights); shiftX / shiftY: translation of the rotated image in output pixels
 int launch_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int inW, int inH, int outW, int outH,
-                  int bpp, double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream);
+                  int bpp, double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream, double shiftX = 0.0, double shiftY = 0.0);
 
 } // namespace gmat
 

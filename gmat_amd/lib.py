@@ -89,6 +89,9 @@ _SIGS = {
                                  C.POINTER(C.c_int), C.c_float, C.c_float, C.c_void_p]),
     "gmat_rotate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "gmat_rotate2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                               C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "gmat_median": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_rotate_flip_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_set_log_callback": (None, [C.c_void_p]),
     "gmat_device_count": (C.c_int, []),

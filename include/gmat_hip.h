@@ -286,6 +286,16 @@ GMAT_API int gmat_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int
 GMAT_API int gmat_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                          int inW, int inH, int outW, int outH, int bpp, double angle_rad, int bilinear,
                          const uint8_t *fill, void *stream);
+/* The same walk with rotate_nvcv's remaining options (vf_rotate_nvcv.c:79-88): interp 0 nearest, 1 linear (what "area" maps to,
+ * as cv::warpAffine does), 2 cubic (Catmull-Rom on the clamped 4 x 4 neighbourhood, integer weights); shift_x / shift_y translate
+ * the rotated image by that many output pixels.  CV-CUDA's own arithmetic is not in the reference tree: the rule is stated in
+ * the test suite's checker (orc_vf.c, orc_rotate2) and held bit for bit. */
+GMAT_API int gmat_rotate2(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
+                          int inW, int inH, int outW, int outH, int bpp, double angle_rad, int interp,
+                          double shift_x, double shift_y, const uint8_t *fill, void *stream);
+/* per-channel median of a kw x kh window (odd, <= 31), vf_median.c's rule at radius (kw - 1) / 2, radiusV (kh - 1) / 2 */
+GMAT_API int gmat_median(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp,
+                         int kw, int kh, void *stream);
 /* rotate(90 clockwise) + horizontal flip + 3x3 smooth in ONE kernel (cfg4 fused form) */
 GMAT_API int gmat_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                                      int inW, int inH, int bpp, void *stream);

@@ -165,6 +165,9 @@ void orc_conv3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_strid
 /* vf_median.c / median_template.c at radius 1, percentile 0.5: per-channel 3x3 median, edges clamped */
 void orc_median3x3(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp);
 /* vf_rotate.c:198-548 — arbitrary angle (radians, clockwise positive), 16.16 fixed point; fill NULL = leave */
+void orc_median(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp, int kw, int kh);
+void orc_rotate2(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int inw, int inh, int outw, int outh, int bpp,
+                 double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill);
 void orc_rotate_sincos(double angle_rad, int *s, int *c);
 void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                 int inw, int inh, int outw, int outh, int bpp, double angle_rad, int bilinear,

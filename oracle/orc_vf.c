@@ -253,6 +253,119 @@ void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride
     }
 }
 
+/* ---- rotate_nvcv's remaining options: interp = cubic | area, shift_x / shift_y (vf_rotate_nvcv.c:79-88,:114-135) ------------------
+ * The reference hands them to CV-CUDA's rotate operator, whose arithmetic no reference test pins and whose source is not in the
+ * tree (PARITY UNPINNED).  The build defines them on top of vf_rotate.c's fixed-point walk above — this is
+ * the statement of that rule, the product implements the same integers:
+ *   shift   the rotated image is translated by (shift_x, shift_y) output pixels: out(i, j) = rot(i - shift_x, j - shift_y).  With
+ *           S = llrint(shift * 65536) the walk's start moves by  x0 -= (Sx c + Sy s) >> 16,  y0 -= (Sy c - Sx s) >> 16  (64-bit
+ *           products, arithmetic shifts); the rotation stays about the centre (the reference rotates about the corner and leaves the
+ *           re-centring to the user's shift: SURVEY.md section 0, defect 11).
+ *   cubic   Catmull-Rom (a = -1/2) on the 4 x 4 neighbourhood of (x >> 16, y >> 16) with clamped indices, the fractions cut to 8
+ *           bits f = (x & 0xFFFF) >> 8.  Integer weights of 14 fractional bits:  n0 = -f^3 + 512 f^2 - 65536 f,
+ *           n1 = 3 f^3 - 1280 f^2 + 2^25, n3 = f^3 - 256 f^2;  w_k = (n_k + 1024) >> 11 for k = 0, 1, 3, w_2 = 16384 - w_0 - w_1 - w_3.
+ *           Rows first: h_r = sum_k w_x[k] p[r][k];  then  out = clip_u8((sum_r w_y[r] h_r + 2^27) >> 28)  in 64 bits.
+ *   area    = linear, as cv::warpAffine does for INTER_AREA.
+ * interp: 0 nearest, 1 linear, 2 cubic. */
+static void rot_cubic_w(int f, int w[4])
+{
+    const int64_t f2 = (int64_t)f * f, f3 = f2 * f;
+    const int64_t n0 = -f3 + 512 * f2 - 65536 * (int64_t)f, n1 = 3 * f3 - 1280 * f2 + ((int64_t)1 << 25), n3 = f3 - 256 * f2;
+    w[0] = (int)((n0 + 1024) >> 11); w[1] = (int)((n1 + 1024) >> 11); w[3] = (int)((n3 + 1024) >> 11);
+    w[2] = 16384 - w[0] - w[1] - w[3];
+}
+
+void orc_rotate2(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
+                 int inw, int inh, int outw, int outh, int bpp, double angle_rad, int interp,
+                 double shift_x, double shift_y, const uint8_t *fill)
+{
+    int s, c, i, j, k;
+    int xi, yi, xprime, yprime;
+    const int64_t Sx = llrint(shift_x * 65536.0), Sy = llrint(shift_y * 65536.0);
+    orc_rotate_sincos(angle_rad, &s, &c);
+    xi = -(outw - 1) * c / 2; yi = (outw - 1) * s / 2;
+    xprime = -(outh - 1) * s / 2;
+    yprime = -(outh - 1) * c / 2;
+    if (fill)
+        for (j = 0; j < outh; j++)
+            for (i = 0; i < outw; i++)
+                for (k = 0; k < bpp; k++) dst[(long)j * dst_stride + i * bpp + k] = fill[k];
+    for (j = 0; j < outh; j++) {
+        int x = xprime + xi + ROT_FIXP * (inw - 1) / 2 - (int)((Sx * c + Sy * s) >> 16);
+        int y = yprime + yi + ROT_FIXP * (inh - 1) / 2 - (int)((Sy * c - Sx * s) >> 16);
+        for (i = 0; i < outw; i++) {
+            int x1 = x >> 16, y1 = y >> 16;
+            if (x1 >= -1 && x1 <= inw && y1 >= -1 && y1 <= inh) {
+                uint8_t *pout = dst + (long)j * dst_stride + i * bpp;
+                if (interp == 2) {
+                    int wx[4], wy[4], r, t;
+                    rot_cubic_w((x & 0xFFFF) >> 8, wx); rot_cubic_w((y & 0xFFFF) >> 8, wy);
+                    for (k = 0; k < bpp; k++) {
+                        int64_t v = 0;
+                        for (r = 0; r < 4; r++) {
+                            const int yy = rot_clip(y1 - 1 + r, 0, inh - 1);
+                            int h = 0;
+                            for (t = 0; t < 4; t++) h += wx[t] * src[(long)yy * src_stride + rot_clip(x1 - 1 + t, 0, inw - 1) * bpp + k];
+                            v += (int64_t)wy[r] * h;
+                        }
+                        v = (v + ((int64_t)1 << 27)) >> 28;
+                        pout[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                    }
+                } else if (interp == 1) {
+                    int int_x = rot_clip(x >> 16, 0, inw - 1), int_y = rot_clip(y >> 16, 0, inh - 1);
+                    int frac_x = x & 0xFFFF, frac_y = y & 0xFFFF;
+                    int int_x1 = int_x + 1 < inw - 1 ? int_x + 1 : inw - 1;
+                    int int_y1 = int_y + 1 < inh - 1 ? int_y + 1 : inh - 1;
+                    for (k = 0; k < bpp; k++) {
+                        int s00 = src[bpp * int_x  + k + (long)src_stride * int_y];
+                        int s01 = src[bpp * int_x1 + k + (long)src_stride * int_y];
+                        int s10 = src[bpp * int_x  + k + (long)src_stride * int_y1];
+                        int s11 = src[bpp * int_x1 + k + (long)src_stride * int_y1];
+                        int s0 = ((1 << 16) - frac_x) * s00 + frac_x * s01;
+                        int s1 = ((1 << 16) - frac_x) * s10 + frac_x * s11;
+                        pout[k] = (uint8_t)(((int64_t)((1 << 16) - frac_y) * s0 + (int64_t)frac_y * s1) >> 32);
+                    }
+                } else {
+                    int x2 = rot_clip(x1, 0, inw - 1), y2 = rot_clip(y1, 0, inh - 1);
+                    for (k = 0; k < bpp; k++) pout[k] = src[(long)y2 * src_stride + x2 * bpp + k];
+                }
+            }
+            x += c;
+            y -= s;
+        }
+        xprime += s;
+        yprime += c;
+    }
+}
+
+/* ---- median of a kw x kh window per channel: vf_median.c + median_template.c at radius = (kw - 1) / 2, radiusV = (kh - 1) / 2,
+ * percentile 0.5: t = 2 r rV + r + rV (vf_median.c:125), the output is the value at which the cumulative histogram of the window
+ * exceeds t, i.e. its (t + 1)-th smallest of (2 r + 1)(2 rV + 1) samples; window rows max(0, y - rV) .. min(h - 1, y + rV)
+ * (median_template.c:97-106) and columns are clamped the same way (:110,:122,:133-147); a radius larger than the plane allows is
+ * clipped to (size - 1) / 2 first (check_params, vf_median.c:111-123). */
+void orc_median(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp, int kw, int kh)
+{
+    int r = (kw - 1) / 2, rv = (kh - 1) / 2, x, y, ch, i, j;
+    if (w < 2 * r + 1) r = (w - 1) / 2;
+    if (h < 2 * rv + 1) rv = (h - 1) / 2;
+    {
+        const int t = 2 * r * rv + r + rv;
+        for (y = 0; y < h; y++)
+            for (x = 0; x < w; x++)
+                for (ch = 0; ch < bpp; ch++) {
+                    int hist[256] = {0}, sum = 0, v;
+                    for (j = -rv; j <= rv; j++)
+                        for (i = -r; i <= r; i++) {
+                            int yy = y + j < 0 ? 0 : y + j > h - 1 ? h - 1 : y + j;
+                            int xx = x + i < 0 ? 0 : x + i > w - 1 ? w - 1 : x + i;
+                            hist[src[(long)yy * src_stride + (long)xx * bpp + ch]]++;
+                        }
+                    for (v = 0; v < 256; v++) { sum += hist[v]; if (sum > t) break; }
+                    dst[(long)y * dst_stride + (long)x * bpp + ch] = (uint8_t)v;
+                }
+    }
+}
+
 /* planar8ToP01xleWrapper, swscale_unscaled.c:286-324 */
 void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
                         const int dst_stride[4], int w, int h, int src_nv12)

@@ -37,6 +37,9 @@ def load_oracle(path):
                               C.POINTER(C.c_int), C.c_float, C.c_float]
     L.orc_rotate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_int, C.c_void_p]
+    L.orc_rotate2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                              C.c_double, C.c_double, C.c_void_p]
+    L.orc_median.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_rotate_sincos.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_yuv420_to_p01x.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                      C.c_int, C.c_int, C.c_int]

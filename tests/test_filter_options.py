@@ -86,7 +86,9 @@ def test_smooth_options_have_effect_or_are_refused(dev, orc):
     assert _cfg(dev, "smooth_hip", {"kw": 33, "kh": 33}, w, h)[0] < 0      # beyond the implemented size
     assert _cfg(dev, "smooth_hip", {"border_type": "mirror"}, w, h)[0] < 0
     assert _cfg(dev, "smooth_hip", {"sigmaX": -1}, w, h)[0] < 0
-    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 5, "kh": 5}, w, h)[0] < 0
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 5, "kh": 5}, w, h)[0] == 0    # vf_median.c's rule at radius 2 (round 3)
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 4, "kh": 5}, w, h)[0] < 0     # even
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 33, "kh": 3}, w, h)[0] < 0    # beyond the implemented size
     assert _cfg(dev, "smooth_hip", {"type": "median", "border_type": "reflect"}, w, h)[0] < 0   # gaussian-only option
     assert _cfg(dev, "smooth_hip", {"type": "median", "sigmaX": 1}, w, h)[0] < 0
     assert _cfg(dev, "smooth_hip", {"type": "boxcar"}, w, h)[0] < 0

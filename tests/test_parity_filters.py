@@ -229,7 +229,11 @@ def test_filter_layer_errors(dev):
     lib.gmat_filter_set_option(f, b"angle", b"33")
     assert lib.gmat_filter_init(f) == 0                      # arbitrary angles: vf_rotate.c fixed point
     lib.gmat_filter_set_option(f, b"interp", b"cubic")
-    assert lib.gmat_filter_init(f) < 0                       # cubic / area: CV-CUDA only
+    assert lib.gmat_filter_init(f) == 0                      # cubic: Catmull-Rom in integers (rule in oracle/orc_vf.c)
+    lib.gmat_filter_set_option(f, b"interp", b"area")
+    assert lib.gmat_filter_init(f) == 0                      # area = linear, as cv::warpAffine
+    lib.gmat_filter_set_option(f, b"interp", b"lanczos")
+    assert lib.gmat_filter_init(f) < 0                       # not one of vf_rotate_nvcv.c:114-135's four
     lib.gmat_filter_free(f)
     f = lib.gmat_filter_alloc(b"flip_hip")
     assert lib.gmat_filter_init(f) == 0
@@ -593,3 +597,87 @@ def test_conv3x3_float_epilogue_is_not_contracted(dev, orc, case):
     assert dev.lib.gmat_smooth3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, m, 0.1, 3.5, None) == 0
     assert (o.download() == want).all()
     d.free(); o.free()
+
+
+# ---- rotate_nvcv's remaining options and smooth_nvcv's median beyond 3 x 3 (missing #2) -----------------------------
+@pytest.mark.parametrize("bpp", [1, 3, 4])
+@pytest.mark.parametrize("case", [(17.0, 2, 0.0, 0.0), (17.0, 1, 5.0, -3.0), (-133.5, 2, 2.25, 7.5), (90.0, 0, 3.0, 1.0), (0.0, 2, 0.5, 0.5),
+                                  (33.0, 1, -40.0, 12.75), (271.0, 2, 0.0, 9.0)])
+def test_rotate_interp_and_shift_match_the_stated_rule(dev, orc, case, bpp):
+    """interp = cubic | linear | nearest with shift_x / shift_y: the rule of oracle/orc_vf.c (vf_rotate.c's 16.16 walk, translated;
+    Catmull-Rom in 14-bit integer weights), bit for bit, outside pixels filled"""
+    deg, interp, sx, sy = case
+    w, h = 70, 45
+    src = orc.lcg((h, w * bpp), 23 + bpp)
+    d = dev.upload_planes([src], 4)[0]
+    o = DevPlane(dev, h, w * bpp, (w * bpp + 15) // 16 * 16)
+    fill = (C.c_uint8 * 4)(9, 8, 7, 255)
+    assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fill, None) == 0
+    want = np.zeros_like(src)
+    orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fill)
+    got = o.download()
+    assert (got == want).all(), np.argwhere(got != want)[:4]
+    assert (o.download(with_padding=True)[:, w * bpp:] == 0xCD).all()
+    d.free(); o.free()
+
+
+def test_rotate_filter_honours_interp_and_shift(dev, orc):
+    """through the filter: rotate_hip angle=17:interp=cubic:shift_x=6:shift_y=-2.5 on rgb24, and on nv12 (chroma planes move by half)"""
+    w, h = 96, 40
+    src = orc.lcg((h, w * 3), 77)
+    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 17, "interp": "cubic", "shift_x": 6, "shift_y": -2.5}, src, w, h)
+    want = np.zeros_like(src)
+    fill = (C.c_uint8 * 4)(0, 0, 0, 255)
+    orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(17), 2, 6.0, -2.5, fill)
+    assert (ow, oh) == (w, h) and (res == want).all()
+    # a shift with no rotation is a translation: pixels move right / down by whole amounts, the uncovered part is the background
+    res, _, _ = _run_filter(dev, "rotate_hip", {"angle": 0, "interp": "nearest", "shift_x": 5, "shift_y": 3}, src, w, h)
+    # (vf_rotate.c's validity window reaches one sample past the frame, clamped: the row / column just before the image repeats its edge)
+    assert (res[3:, 15:] == src[:-3, :-15]).all() and (res[:2] == 0).all() and (res[:, :12] == 0).all()
+    src = synth_planes(orc, "nv12", w, h, seed=78)
+    res, _, _ = _run_filter_planes(dev, "rotate_hip", {"angle": 33, "interp": "linear", "shift_x": 8, "shift_y": 4}, src, w, h, "nv12")
+    for i, (pl, bpp, sub) in enumerate(((src[0], 1, 0), (src[1], 2, 1))):
+        pw, ph = pl.shape[1] // bpp, pl.shape[0]
+        want = np.zeros_like(pl)
+        fill = (C.c_uint8 * 4)(16 if i == 0 else 128, 128, 0, 0)
+        orc.L.orc_rotate2(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, pw, ph, bpp, math.radians(33), 1,
+                          8.0 / (1 << sub), 4.0 / (1 << sub), fill)
+        assert (res[i] == want).all()
+
+
+@pytest.mark.parametrize("bpp", [1, 3, 4])
+@pytest.mark.parametrize("k", [(5, 5), (3, 7), (7, 3), (9, 9), (1, 5), (5, 1), (15, 15), (31, 3)])
+def test_median_of_any_odd_window(dev, orc, k, bpp):
+    """vf_median.c at radius (kw - 1) / 2, radiusV (kh - 1) / 2, percentile 0.5: the (t + 1)-th smallest of the clamped window;
+    frames narrower than the window clip the radius (check_params)"""
+    kw, kh = k
+    for w, h in ((41, 23), (6, 4)):
+        src = orc.lcg((h, w * bpp), 31 + kw + kh)
+        d = dev.upload_planes([src], 4)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + 15) // 16 * 16)
+        assert dev.lib.gmat_median(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, kw, kh, None) == 0
+        want = np.zeros_like(src)
+        orc.L.orc_median(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, kw, kh)
+        got = o.download()
+        assert (got == want).all(), np.argwhere(got != want)[:4]
+        assert (o.download(with_padding=True)[:, w * bpp:] == 0xCD).all()
+        d.free(); o.free()
+    assert dev.lib.gmat_median(0, 0, 0, 0, 8, 8, 1, 4, 3, None) < 0          # even
+
+
+def test_median_3x3_rule_is_the_general_rule(dev, orc):
+    """the strip / byte-wise 3 x 3 kernels and the bisecting kernel state the same thing: orc_median at 3 x 3 == orc_median3x3"""
+    src = orc.lcg((19, 33 * 3), 5)
+    a, b = np.zeros_like(src), np.zeros_like(src)
+    orc.L.orc_median(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], 33, 19, 3, 3, 3)
+    orc.L.orc_median3x3(src.ctypes.data, src.strides[0], b.ctypes.data, b.strides[0], 33, 19, 3)
+    assert (a == b).all()
+
+
+def test_smooth_filter_median_5x5(dev, orc):
+    w, h = 64, 24
+    src = orc.lcg((h, w * 3), 91)
+    res, _, _ = _run_filter(dev, "smooth_hip", {"type": "median", "kw": 5, "kh": 7}, src, w, h)
+    want = np.zeros_like(src)
+    orc.L.orc_median(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, 3, 5, 7)
+    assert (res == want).all()
