@@ -664,9 +664,11 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     a.updown = !(ud && !atoi(ud));
     const int nstrips = (a.dstW + 63) / 64;
     a.nsg = (nstrips + 3) / 4;
-    // band height: short bands in raster order (see k_scale_yuv2s.hip's launcher); a lone small frame wants enough waves to fill the chip
+    // band height: a band pays its vertical windows' lead-in (taps / ratio output rows' worth of source rows) — far more than the
+    // exact-ratio walkers' three row pairs — so its optimum sits higher: 4K -> 900p rgb24 at 8 / 16 / 24 / 32 rows 7.4 / 6.1 / 5.9 /
+    // 5.7 us per frame (profiles/r03p_rows_sweep_all_strip_kernels.txt); a lone small frame wants enough waves to fill the chip
     const long wr = (long)a.dstH * nstrips * nframes;
-    int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(16L, std::max(4L, (wr + 6143) / 6144));
+    int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
     a.bandRows = rows;
     a.nbands = (a.dstH + rows - 1) / rows;
     a.nblkL = a.nbands * a.nsg;
