@@ -436,7 +436,11 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
         ExprVars v;
         v.iw = f->in_w; v.ih = f->in_h; v.ow = v.oh = NAN;
         v.a = (double)f->in_w / f->in_h; v.sar = 1; v.dar = v.a;              // GmatFrame carries no sample aspect ratio
-        v.hsub = v.vsub = 1 << chroma_log2(f->in_fmt); v.ohsub = v.ovsub = 1 << chroma_log2(f->out_fmt);
+        // hsub / vsub / ohsub / ovsub: ff_scale_eval_dimensions takes them from av_pix_fmt_desc_get(inlink->format) (scale_eval.c:
+        // 76-83), and the format of a hardware link is the hardware pixel format, whose descriptor has no chroma shift — so under
+        // scale_cuda they are all 1 whatever the frames' sw_format is, and integration/vf_gmat_hip.c (which calls the real
+        // function) sees the same.  Matched here so that one filter string gives one size through both doors.
+        v.hsub = v.vsub = v.ohsub = v.ovsub = 1;
         double res = 0;
         (void)eval_expr(we, v, res);                                         // first pass: ow / oh are still unknown
         int w = (int)res == 0 ? f->in_w : (int)res;

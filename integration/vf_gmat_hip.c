@@ -90,17 +90,17 @@ static av_cold int gh_init(AVFilterContext *ctx)
         return AVERROR(EINVAL);
     }
     if (s->kind == GH_ROTATE) {
-        if (strcmp(s->interp, "linear") && strcmp(s->interp, "nearest")) {
-            av_log(ctx, AV_LOG_ERROR, "Interpolation '%s' is not implemented (linear, nearest)\n", s->interp);
-            return AVERROR(ENOSYS);
-        }
-        if (s->shift_x != 0 || s->shift_y != 0) {
-            av_log(ctx, AV_LOG_ERROR, "shift_x / shift_y are not implemented (rotation is about the centre)\n");
-            return AVERROR(ENOSYS);
+        /* map_interpolation, vf_rotate_nvcv.c:114-135 */
+        if (strcmp(s->interp, "linear") && strcmp(s->interp, "nearest") && strcmp(s->interp, "cubic") && strcmp(s->interp, "area")) {
+            av_log(ctx, AV_LOG_ERROR, "Interpolation '%s' not supported (linear, nearest, cubic, area)\n", s->interp);
+            return AVERROR(EINVAL);
         }
     }
-    if (s->kind == GH_SMOOTH && s->type == 2 && (s->kw != 3 || s->kh != 3))
-        return AVERROR(ENOSYS);
+    /* every window is odd (the median's and the general gaussian's alike): say so at init, not at the first frame */
+    if (s->kind == GH_SMOOTH && (!(s->kw & 1) || !(s->kh & 1))) {
+        av_log(ctx, AV_LOG_ERROR, "kw and kh must be odd\n");
+        return AVERROR(EINVAL);
+    }
     if (s->batch < 1 || s->batch > GH_MAX_BATCH)
         s->batch = 1;
     return 0;
@@ -239,7 +239,7 @@ static int gh_run_planes(GmatHipContext *s, const AVFrame *in, AVFrame *out)
     static const int gauss3[9] = { 1, 2, 1, 2, 4, 2, 1, 2, 1 };
     const int general = s->kw != 3 || s->kh != 3 || s->sigma_x > 0 || s->sigma_y > 0 || s->border_type >= 0;
     const double q = s->angle / 90.0;
-    const int quarter = fabs(q - rint(q)) < 1e-9 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
+    const int quarter = fabs(q - rint(q)) < 1e-9 && s->shift_x == 0 && s->shift_y == 0 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
     int ret = 0;
 
     for (int p = 0; p < 3 && in->data[p] && ret >= 0; p++) {
@@ -268,13 +268,15 @@ static int gh_run_planes(GmatHipContext *s, const AVFrame *in, AVFrame *out)
             else {
                 uint8_t fill[4] = { 0, 0, 0, 255 };             /* black: RGB 0,0,0 / limited-range YUV 16,128,128 */
                 if (!(av_pix_fmt_desc_get(s->in_fmt)->flags & AV_PIX_FMT_FLAG_RGB)) { fill[0] = p ? 128 : 16; fill[1] = 128; }
-                ret = gmat_rotate(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, pw, ph, bpp,
-                                  s->angle * M_PI / 180.0, !strcmp(s->interp, "linear"), fill, s->stream);
+                /* interp: 0 nearest, 1 linear (= area, as cv::warpAffine), 2 cubic; the chroma planes of a 4:2:0 frame move by half the shift */
+                const int interp = !strcmp(s->interp, "nearest") ? 0 : !strcmp(s->interp, "cubic") ? 2 : 1;
+                ret = gmat_rotate2(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, pw, ph, bpp,
+                                   s->angle * M_PI / 180.0, interp, s->shift_x / (1 << sub), s->shift_y / (1 << sub), fill, s->stream);
             }
             break;
         case GH_SMOOTH:
             if (s->type == 2)
-                ret = gmat_median3x3(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, bpp, s->stream);
+                ret = gmat_median(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, bpp, s->kw, s->kh, s->stream);
             else if (general)
                 ret = gmat_gauss_blur(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, bpp, s->kw, s->kh,
                                       s->sigma_x, s->sigma_y, s->border_type < 0 ? 0 : s->border_type, s->stream);
@@ -334,8 +336,24 @@ static int gh_flush_queue(AVFilterContext *ctx)
         if (!outs[i]) { ret = AVERROR(ENOMEM); break; }
         for (int k = 0; k < 4; k++) { sp[4 * i + k] = s->queue[i]->data[k]; dp[4 * i + k] = outs[i]->data[k]; }
     }
-    if (ret >= 0 && gmat_sws_scale_batch(s->sws, n, sp, s->queue[0]->linesize, dp, outs[0]->linesize, streams, 1, 0) < 0)
-        ret = AVERROR_EXTERNAL;
+    /* one launch takes ONE stride set: frames of one pool share it, a frame from elsewhere (another pool, a cropped view) may
+     * not — those batches go frame by frame instead of being read and written with the first frame's pitch */
+    if (ret >= 0) {
+        int same = 1;
+        for (int i = 1; i < n && same; i++)
+            for (int k = 0; k < 4; k++)
+                if (s->queue[i]->linesize[k] != s->queue[0]->linesize[k] || outs[i]->linesize[k] != outs[0]->linesize[k])
+                    same = 0;
+        if (same) {
+            if (gmat_sws_scale_batch(s->sws, n, sp, s->queue[0]->linesize, dp, outs[0]->linesize, streams, 1, 0) < 0)
+                ret = AVERROR_EXTERNAL;
+        } else {
+            for (int i = 0; i < n && ret >= 0; i++)
+                if (gmat_sws_scale(s->sws, (const uint8_t *const *)s->queue[i]->data, s->queue[i]->linesize, 0, s->queue[i]->height,
+                                   outs[i]->data, outs[i]->linesize) < 0)
+                    ret = AVERROR_EXTERNAL;
+        }
+    }
     for (int i = 0; i < n; i++)
         av_frame_free(&s->queue[i]);
     s->nqueued = 0;
@@ -395,9 +413,9 @@ static const AVOption flip_hip_options[] = {
 };
 static const AVOption rotate_hip_options[] = {
     { "angle", "rotation angle in degrees", OFFSET(angle), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -360, 360, FLAGS },
-    { "interp", "interpolation (linear, nearest)", OFFSET(interp), AV_OPT_TYPE_STRING, { .str = "linear" }, 0, 0, FLAGS },
-    { "shift_x", "shift in x (not implemented: must be 0)", OFFSET(shift_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -DBL_MAX, DBL_MAX, FLAGS },
-    { "shift_y", "shift in y (not implemented: must be 0)", OFFSET(shift_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -DBL_MAX, DBL_MAX, FLAGS },
+    { "interp", "Interpolation algorithm (linear, nearest, cubic, area)", OFFSET(interp), AV_OPT_TYPE_STRING, { .str = "linear" }, 0, 0, FLAGS },
+    { "shift_x", "Shift of the rotated image in x, output pixels", OFFSET(shift_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
+    { "shift_y", "Shift of the rotated image in y, output pixels", OFFSET(shift_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
     { NULL }
 };
 static const AVOption transpose_hip_options[] = {

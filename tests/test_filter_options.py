@@ -130,9 +130,12 @@ def test_scale_size_expressions(dev, opts, want):
         assert r == 0 and (ow, oh) == want, (opts, r, ow, oh)
 
 
-def test_scale_expression_sees_chroma_subsampling(dev):
+def test_scale_expression_chroma_variables_are_those_of_a_hardware_link(dev):
+    """hsub / vsub / ohsub / ovsub come from the LINK's pixel format in ff_scale_eval_dimensions (scale_eval.c:76-83); for a
+    hardware link that is the hardware format, whose descriptor has no chroma shift: all four are 1 under scale_cuda, whatever the
+    sw_format — and through the AVFilter glue of integration/vf_gmat_hip.c, which calls that function"""
     r, ow, oh = _cfg(dev, "scale_hip", {"w": "iw/hsub", "h": "ih/vsub", "format": "rgb24"}, 96, 40, fmt="nv12")
-    assert r == 0 and (ow, oh) == (48, 20)
+    assert r == 0 and (ow, oh) == (96, 40)
     r, ow, oh = _cfg(dev, "scale_hip", {"w": "iw/ohsub", "h": "ih/ovsub", "format": "rgb24"}, 96, 40, fmt="nv12")
     assert r == 0 and (ow, oh) == (96, 40)
 
