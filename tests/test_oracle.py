@@ -1,6 +1,6 @@
 """Oracle pinning (CPU only): the restatement against what the reference is known to produce.
 
-Pins available without a reference build (DESIGN.md §Oracle):
+Pins available without a reference build (DESIGN.md §2):
   * known-answer filter rows the survey recorded from the reference itself
   * literal constants in the reference sources
   * LUT path == closed form over all 2^24 YUV triples (two independent restatements)
