@@ -47,7 +47,11 @@ inline bool is_p01x(int f) { return f == GMAT_PIX_FMT_P010LE || f == GMAT_PIX_FM
 // planar YUV in 16-bit little-endian containers (sources; YUV444P16LE is a destination too): significant bits, 0 = not one.
 // The samples go to hScale16To15_c / hScale16To19_c as they are (no input converter on a little-endian host,
 // input.c:1523-1528), so the 10-bit form keeps its bits in the LOW end, unlike P010LE.
-inline int  pl16_depth(int f) { return (f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE) ? 16 : f == GMAT_PIX_FMT_YUV420P10LE ? 10 : 0; }
+// library-internal source format (never accepted from a caller): the Y / U / V planes of 16-bit samples that rgb64ToY_c / ToUV_c /
+// ToUV_half_c make of an RGBA64LE / BGRA64LE frame (k_rgb64.hip) — planar 16-bit samples with an RGB source's chroma geometry
+constexpr int GMAT_PIX_FMT_PRIV_RGB64_PLANES = 0x47520064;
+inline int  pl16_depth(int f) { return (f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE || f == GMAT_PIX_FMT_PRIV_RGB64_PLANES) ? 16 : f == GMAT_PIX_FMT_YUV420P10LE ? 10 : 0; }
+inline bool has_alpha(int f) { return f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA || is_rgb64(f); }
 inline int  bytes_per_pixel(int f)
 {
     switch (f) {

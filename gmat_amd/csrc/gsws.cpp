@@ -25,7 +25,7 @@ using namespace gmat;
 namespace {
 
 enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
-            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER, MODE_SCALE16 };
+            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER, MODE_SCALE16, MODE_VIA_PLANES16, MODE_PLANE_UP };
 
 struct DevBuf {
     void *p = nullptr;
@@ -155,6 +155,17 @@ struct GmatSwsContext {
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
     GmatSwsContext *inner = nullptr;
+    // RGBA64LE / BGRA64LE sources (MODE_VIA_PLANES16): rgb64ToY / ToUV(_half) into Y / U / V planes of 16-bit samples, then `inner`
+    // — the planar-16 context with an RGB source's chroma geometry (k_rgb64.hip)
+    DevBuf planes16;
+    int p16Stride[2] = {0, 0};            // luma / chroma pitch in bytes
+    size_t p16Off[3] = {0, 0, 0};
+    // both ends carry alpha (needAlpha, utils.c:1902): the alpha plane through the LUMA filters of the context that makes the colours
+    bool needAlpha = false;
+    DevBuf alphaLines, aForm, aFirst;     // srcH x dstW int32 lines; per output row: the packed writer's form, the filter's position
+    DevFilterStore aH, aV;
+    DevFilter daH, daV;
+    const int32_t *alpha19 = nullptr;     // set on `inner` by its owner for one call: the alpha lines of an RGBA64 destination
     bool rgbViaPlanes = false;            // RGB24 / BGR24 source scaled to a YUV destination: the plane scaler with its RGB loader
     bool src0 = false, dst0 = false;      // RGB0 / BGR0 ends, handled as RGBA / BGRA (handle_0alpha, utils.c:1121-1144)
     // 16-bit destinations (P016LE): 19-bit int32 lines in HBM between the two passes of k_scale16.hip
@@ -1150,11 +1161,67 @@ void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
-    if (c->mode == MODE_VIA_INNER || c->mode == MODE_SCALE16) return true;       // one set of intermediates per context
+    if (c->mode == MODE_VIA_INNER || c->mode == MODE_SCALE16 || c->mode == MODE_VIA_PLANES16) return true;       // one set of intermediates per context
     if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
     return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
 }
 }
+
+
+// ---- alpha (needAlpha) ----------------------------------------------------------------------------------------------
+// the plan whose filters make the colours of this context's destination
+static const ScalePlan &active_plan(const GmatSwsContext *c)
+{
+    if (c->mode == MODE_SCALE16) return c->plan16;
+    return ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) ? c->planYuv : c->plan;
+}
+
+// packed_vscale's choice of writer per output row (vscale.c:135-167) as the alpha kernel's form word (k_rgb64.hip)
+static void alpha_forms(const ScalePlan &p, std::vector<int32_t> &form, std::vector<int32_t> &first)
+{
+    const int lfs = p.vLum.taps, cfs = p.vChr.taps;
+    const bool full = (p.flags & GMAT_SWS_FULL_CHR_H_INT) != 0;
+    form.assign(p.dstH, 0); first.assign(p.dstH, 0);
+    for (int y = 0; y < p.dstH; y++) {
+        const int16_t *lf = &p.vLum.coef[(size_t)y * lfs], *cf = &p.vChr.coef[(size_t)(y >> p.chrDstVSub) * cfs];
+        const bool chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
+        const bool lum2 = lfs == 2 && lf[0] + lf[1] == 4096 && (unsigned)lf[1] <= 4096u;
+        int m, ya = 0;
+        if (lfs == 1 && (cfs == 1 || chr2)) m = full ? 6 : ((cfs == 1 ? 0 : cf[1]) < 2048 ? 1 : 2);
+        else if (lum2 && chr2) { m = full ? 5 : 3; ya = lf[1]; }
+        else m = full ? 4 : 0;
+        form[y] = m | (ya << 8);
+        first[y] = p.vLum.pos[y];
+    }
+}
+
+// owner: the context the caller holds; maker: the context whose plan scales the colour channels
+static int alpha_prepare(GmatSwsContext *owner, const GmatSwsContext *maker)
+{
+    const ScalePlan &p = active_plan(maker);
+    const std::vector<int32_t> none(std::max(std::max(p.dstW, p.dstH), 1), 0);
+    int r;
+    if ((r = owner->aH.upload(p.hLum, none, owner->daH)) < 0) return r;
+    if ((r = owner->alphaLines.reserve((size_t)p.srcH * p.dstW * 4)) < 0) return r;
+    if (is_rgb64(owner->dstFormat)) return 0;             // the 64-bit writer takes the lines as an operand (vrgba64_kernel)
+    if ((r = owner->aV.upload(p.vLum, none, owner->daV)) < 0) return r;
+    std::vector<int32_t> form, first;
+    alpha_forms(p, form, first);
+    if ((r = owner->aForm.upload(form.data(), form.size() * 4)) < 0) return r;
+    return owner->aFirst.upload(first.data(), first.size() * 4);
+}
+
+// the alpha byte of every pixel of an RGBA / BGRA destination, after the colour channels were written
+static int alpha_run8(GmatSwsContext *c, const uint8_t *alpha0, int srcStride, int kind, int step, uint8_t *dst, int dstStride)
+{
+    int32_t *la = (int32_t *)c->alphaLines.p;
+    int r = launch_hscale19(alpha0, srcStride, kind, step, c->srcW, c->srcH, c->daH, la, c->dstW, c->stream, 1);
+    if (r < 0) return r;
+    return launch_alpha8_out(la, c->dstW, c->srcH, c->daV, (const int32_t *)c->aForm.p, (const int32_t *)c->aFirst.p, dst, dstStride,
+                             c->dstW, c->dstH, c->stream);
+}
+
+static thread_local bool g_privFormatOk = false;          // gmat_sws_getContext accepts the library-internal source format
 
 extern "C" {
 
@@ -1166,6 +1233,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         logf(LOG_ERROR, "gmat_sws_getContext: %dx%d -> %dx%d is an invalid scaling dimension", srcW, srcH, dstW, dstH);
         return nullptr;
     }
+    if (srcFormat == GMAT_PIX_FMT_PRIV_RGB64_PLANES && !g_privFormatOk) return nullptr;
     GmatSwsContext *c = new (std::nothrow) GmatSwsContext();
     if (!c) return nullptr;
     if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
@@ -1196,6 +1264,32 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                                        dstFormat, flags, param);
         if (!c->inner) { delete c; return nullptr; }
         c->mode = MODE_VIA_INNER;
+        // ... the colour channels; with an alpha channel at both ends libswscale scales the alpha plane too (needAlpha,
+        // utils.c:1902; rgbaToA_c, the luma filters, the packed writer's alpha)
+        c->needAlpha = has_alpha(dstFormat) && !c->src0 && !c->dst0;
+        if (c->needAlpha && alpha_prepare(c, c->inner) < 0) { delete c; return nullptr; }
+        return c;
+    }
+    if (is_rgb64(srcFormat) && !(same && srcFormat == dstFormat)) {
+        // RGBA64LE / BGRA64LE sources (swscale_cuda.c:34-44): no special converter takes them at equal size either (findRgbConvFn,
+        // swscale_unscaled.c:1458-1528, pairs them with the 48-bit formats only) — always the generic path on the 16-bit lines
+        // rgb64ToY_c / ToUV_c / ToUV_half_c make (input.c:36-121)
+        g_privFormatOk = true;
+        c->inner = gmat_sws_getContext(srcW, srcH, GMAT_PIX_FMT_PRIV_RGB64_PLANES, dstW, dstH, dstFormat, flags, param);
+        g_privFormatOk = false;
+        if (!c->inner) { delete c; return nullptr; }
+        c->mode = MODE_VIA_PLANES16;
+        const ScalePlan &p = active_plan(c->inner);
+        c->p16Stride[0] = align_up(2 * srcW, 256); c->p16Stride[1] = align_up(2 * p.chrSrcW, 256);
+        c->p16Off[1] = (size_t)c->p16Stride[0] * srcH; c->p16Off[2] = c->p16Off[1] + (size_t)c->p16Stride[1] * srcH;
+        if (c->planes16.reserve(c->p16Off[2] + (size_t)c->p16Stride[1] * srcH) < 0) { delete c; return nullptr; }
+        c->needAlpha = has_alpha(dstFormat) && !c->dst0;
+        if (c->needAlpha && alpha_prepare(c, c->inner) < 0) { delete c; return nullptr; }
+        return c;
+    }
+    if (same && is_rgb64(srcFormat)) {
+        c->mode = MODE_COPY;                 // equal format and size: the frame as it is
+        c->unscaledMode = c->mode;
         return c;
     }
     if (same && is_yuv420(srcFormat) && is_packed_rgb(dstFormat) && (c->flags & GMAT_SWS_ACCURATE_RND)) {
@@ -1315,6 +1409,12 @@ void gmat_sws_freeContext(GmatSwsContext *c) { delete c; }
 int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 {
     if (!c || colorspace < 0 || colorspace > 10) return GMAT_ERR(EINVAL);
+    if (c->mode == MODE_VIA_PLANES16) {
+        // an RGB source: the matrix belongs to the RGB -> YUV stage of a YUV destination (read per call above); no source range
+        if (srcFullRange) return GMAT_ERR(ENOSYS);
+        c->colorspace = colorspace;
+        return 0;
+    }
     if (c->inner) return gmat_sws_setColorspace(c->inner, colorspace, srcFullRange);
     // a YUV source: the matrix (and range) of its YUV -> RGB stage; an RGB source with a YUV destination: the matrix of
     // the RGB -> YUV stage (fill_rgb2yuv_table, utils.c:765-858), limited range only
@@ -1329,6 +1429,13 @@ int gmat_sws_setColorspace(GmatSwsContext *c, int colorspace, int srcFullRange)
 int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 {
     if (!c) return GMAT_ERR(EINVAL);
+    if (c->mode == MODE_VIA_PLANES16) {
+        // as for the 8-bit RGB sources: no range of its own; a full-range YUV destination is the limited -> full conversion of the
+        // 15-bit lines, which the inner context carries (its "source" is the limited-range planes)
+        if (srcFullRange) return GMAT_ERR(ENOSYS);
+        if (is_packed_rgb(c->dstFormat) || is_rgb64(c->dstFormat)) return dstFullRange ? GMAT_ERR(ENOSYS) : 0;
+        return gmat_sws_setRange(c->inner, 0, dstFullRange);
+    }
     if (c->inner) return gmat_sws_setRange(c->inner, srcFullRange, dstFullRange);
     if (c->mode == MODE_RGB2YUV || c->rgbViaPlanes) {
         // an RGB source has no range of its own (forced to 0, utils.c:902-1030): a full-range destination is the
@@ -1340,12 +1447,19 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     }
     {
         // same-size 8-bit planar -> high-depth planar with the same subsampling is planarCopyWrapper in libswscale
-        // (swscale_unscaled.c:1789-1830), which SHIFTS limited-range samples — what the generic lines compute too — but
-        // bit-replicates the luma of a full-range source.  That form is not built: refuse it rather than shift silently.
+        // (swscale_unscaled.c:1803-1862), taken when the two ranges agree (utils.c:1996-2000).  It SHIFTS chroma and limited-range
+        // luma — what the generic lines compute too, so a limited-range context stays on them — and bit-replicates the luma of a
+        // full-range source: its own little kernel.
         const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
         const bool pair = (c->srcFormat == GMAT_PIX_FMT_YUV420P && (c->dstFormat == GMAT_PIX_FMT_YUV420P10LE || c->dstFormat == GMAT_PIX_FMT_YUV420P16LE)) ||
                           (c->srcFormat == GMAT_PIX_FMT_YUV444P && c->dstFormat == GMAT_PIX_FMT_YUV444P16LE);
-        if (same && pair && srcFullRange) return GMAT_ERR(ENOSYS);
+        if (same && pair && srcFullRange && dstFullRange) {
+            if (c->mode != MODE_PLANE_UP) c->unscaledMode = c->mode;       // the generic mode to return to
+            c->mode = MODE_PLANE_UP;
+            c->rangeConv = 0;
+            return 0;
+        }
+        if (c->mode == MODE_PLANE_UP) c->mode = c->unscaledMode;           // leaving it: back on the generic lines
     }
     if (!is_plane_src(c->srcFormat) || !(is_yuv8_src(c->dstFormat) || is_p01x(c->dstFormat) || pl16_depth(c->dstFormat))) {
         // RGB ends have no range of their own (utils.c:902-1030 forces them to 0); the source range of a
@@ -1462,7 +1576,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         break;
     case MODE_COPY:
         c->lastKernel = "copy2d";
-        r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW * bytes_per_pixel(c->srcFormat),
+        r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW * (is_rgb64(c->srcFormat) ? 8 : bytes_per_pixel(c->srcFormat)),
                           c->srcH, c->stream);
         break;
     case MODE_RGB2YUV: {
@@ -1494,6 +1608,37 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const int istr[4] = {c->interStride, 0, 0, 0};
         r = gmat_sws_scale(c->inner, isrc, istr, 0, c->srcH, dst, dstStride);
         c->lastKernel = c->inner->lastKernel;
+        if (r >= 0 && c->needAlpha) {
+            const int ra = alpha_run8(c, src[0] + 3, srcStride[0], 208, 4, dst[0], dstStride[0]);
+            if (ra < 0) r = ra;
+        }
+        if (r >= 0) return r;
+        break;
+    }
+    case MODE_VIA_PLANES16: {
+        if ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 1) != 0) { r = GMAT_ERR(EINVAL); break; }
+        const ScalePlan &p = active_plan(c->inner);
+        uint8_t *pl = (uint8_t *)c->planes16.p;
+        // the RGB -> YUV stage takes the DESTINATION's matrix when that is YUV (fill_rgb2yuv_table, utils.c:765-858); an RGB
+        // destination leaves both stages at the default (as every RGB -> RGB context of this library)
+        const Rgb2YuvConsts k = make_rgb2yuv_consts(is_packed_rgb(c->dstFormat) || is_rgb64(c->dstFormat) ? GMAT_SWS_CS_DEFAULT : c->colorspace);
+        if ((r = launch_rgb64_planes(src[0], srcStride[0], c->srcW, c->srcH, p.chrSrcW, p.chrSrcHSub, c->srcFormat == GMAT_PIX_FMT_BGRA64LE, k,
+                                     pl, c->p16Stride[0], pl + c->p16Off[1], c->p16Stride[1], pl + c->p16Off[2], c->p16Stride[1], c->stream)) < 0) break;
+        const bool a64 = c->needAlpha && is_rgb64(c->dstFormat);
+        if (a64) {                           // the alpha plane's 19-bit lines, an operand of the inner context's writer
+            if ((r = launch_hscale19(src[0] + 6, srcStride[0], 16, 8, c->srcW, c->srcH, c->daH, (int32_t *)c->alphaLines.p, c->dstW, c->stream)) < 0) break;
+            c->inner->alpha19 = (const int32_t *)c->alphaLines.p;
+        }
+        gmat_sws_setStream(c->inner, (void *)c->stream);
+        const uint8_t *isrc[4] = {pl, pl + c->p16Off[1], pl + c->p16Off[2], nullptr};
+        const int istr[4] = {c->p16Stride[0], c->p16Stride[1], c->p16Stride[1], 0};
+        r = gmat_sws_scale(c->inner, isrc, istr, 0, c->srcH, dst, dstStride);
+        c->inner->alpha19 = nullptr;
+        c->lastKernel = c->inner->lastKernel;
+        if (r >= 0 && c->needAlpha && !a64) {
+            const int ra = alpha_run8(c, src[0] + 6, srcStride[0], 16, 8, dst[0], dstStride[0]);
+            if (ra < 0) r = ra;
+        }
         if (r >= 0) return r;
         break;
     }
@@ -1521,7 +1666,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             c->lastKernel = "hscale19_kernel+vrgba64_kernel";
             r = launch_vrgba64(ly, lu, lv, c->dstW, c->srcH, p.chrDstW, p.chrSrcH, c->d16[2], c->d16[3], p.chrDstW == c->dstW ? 0 : 1,
                                dst[0], dstStride[0], c->dstW, c->dstH, c->dstFormat == GMAT_PIX_FMT_BGRA64LE,
-                               make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0), c->stream);
+                               make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0), c->stream, c->alpha19);
             break;
         }
         if ((r = launch_vscale16(ly, nullptr, c->dstW, c->srcH, c->d16[2], dst[0], dstStride[0], c->dstW, c->dstH, c->stream)) < 0) break;
@@ -1532,6 +1677,18 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             break;
         }
         r = launch_vscale16(lu, lv, p.chrDstW, p.chrSrcH, c->d16[3], dst[1], dstStride[1], p.chrDstW, p.chrDstH, c->stream);
+        break;
+    }
+    case MODE_PLANE_UP: {
+        if (!src[1] || !src[2] || !dst[1] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
+        for (int i = 0; i < 3; i++)
+            if ((((uintptr_t)dst[i] | (uintptr_t)dstStride[i]) & 1) != 0) r = GMAT_ERR(EINVAL);
+        if (r < 0) break;
+        const int depth = pl16_depth(c->dstFormat), sub = c->srcFormat == GMAT_PIX_FMT_YUV444P ? 0 : 1;
+        const int cw = ceil_rshift(c->srcW, sub), ch = ceil_rshift(c->srcH, sub);
+        c->lastKernel = "plane_copy_up_kernel";
+        if ((r = launch_plane_copy_up(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, depth, 1, c->stream)) < 0) break;
+        for (int i = 1; i < 3 && r >= 0; i++) r = launch_plane_copy_up(src[i], srcStride[i], dst[i], dstStride[i], cw, ch, depth, 0, c->stream);
         break;
     }
     case MODE_PLANECOPY: {

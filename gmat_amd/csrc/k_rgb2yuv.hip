@@ -586,6 +586,29 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
     return 0;
 }
 
+// planarCopyWrapper's 8-bit -> deeper planar copy (swscale_unscaled.c:1844-1862, COPY816), one plane: v << (depth - 8), with the
+// top bits replicated into the new low bits (| v >> (16 - depth)) for the luma of a full-range source.  Four samples per thread.
+__global__ __launch_bounds__(256) void plane_copy_up_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *s = src + (size_t)y * ss + x;
+    unsigned short *d = reinterpret_cast<unsigned short *>(dst + (size_t)y * ds) + x;
+    for (int i = 0; i < min(4, w - x); i++) {
+        const unsigned v = s[i];
+        d[i] = (unsigned short)((v << (depth - 8)) | (replicate ? v >> (16 - depth) : 0u));
+    }
+}
+
+int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid((w + 1023) / 1024, h), block(256);
+    hipLaunchKernelGGL(plane_copy_up_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, depth, replicate);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds, int n, int h, hipStream_t stream)
 {
     if (n <= 0 || h <= 0) return 0;

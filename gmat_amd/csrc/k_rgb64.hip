@@ -1,0 +1,116 @@
+// k_rgb64.hip — RGBA64LE / BGRA64LE as SOURCES, and the alpha plane of contexts whose both ends carry alpha (gfx950).
+//
+// libswscale reads a 64-bit packed RGB source through rgb64ToY_c / rgb64ToUV_c / rgb64ToUV_half_c (input.c:36-121) into 16-bit
+// lines, then runs the generic scaler on them exactly as on a planar 16-bit source (hScale16To15_c / hScale16To19_c with
+// sh from the 16-bit depth, swscale.c:63-119).  So the source side is ONE conversion kernel into Y / U / V planes of 16-bit
+// samples in HBM (U, V at the chroma width the context decided: halved when chrSrcHSubSample is set, utils.c:1529-1545; never
+// halved vertically), and the context behind it is the planar-16 one that exists already.
+//
+// Alpha (needAlpha = both ends have an alpha channel, utils.c:1902): the source's alpha samples (rgbaToA_c: a << 6 | a >> 2 for
+// the 8-bit formats, rgba64leToA_c: the sample for the 64-bit ones, input.c:413-449) go through the LUMA filters — horizontally
+// in lum_h_scale's alpha leg (hscale.c:66-80), vertically inside the packed writer, each form of which has its own rounding
+// (output.c, quoted at alpha8_out_kernel).  Here: the existing one-sample-per-thread horizontal pass of k_scale16.hip into
+// int32 lines, then alpha8_out_kernel / the alpha operand of vrgba64_kernel.  Completeness paths, not fast ones.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+// One thread per chroma sample: its one (full chroma) or two (half) pixels' luma, and U / V.
+//   Y  = (ry*r + gy*g + by*b + (0x2001 << 14)) >> 15                       rgb64ToY_c_template        input.c:36-50
+//   UV = (ru*r + gu*g + bu*b + (0x10001 << 14)) >> 15                      rgb64ToUV_c_template       :52-69
+//        the same on (p0 + p1 + 1) >> 1 per channel                        rgb64ToUV_half_c_template  :71-87
+// An odd width with halved chroma reads pixel 2i+1 of the last pair past the row in the reference (not bit-defined); the last
+// pixel is used twice here, as the 8-bit readers of this library do.
+__global__ __launch_bounds__(256) void rgb64_planes_kernel(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr,
+                                                           Rgb2YuvConsts k, uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs)
+{
+    const int cx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (cx >= chrW || y >= h) return;
+    const unsigned short *row = reinterpret_cast<const unsigned short *>(src + (size_t)y * ss);
+    unsigned short *oy = reinterpret_cast<unsigned short *>(py + (size_t)y * ys);
+    const int ro = bgr ? 2 : 0, bo = 2 - ro;
+    auto luma = [&](int x) {
+        const unsigned r = row[4 * x + ro], g = row[4 * x + 1], b = row[4 * x + bo];
+        oy[x] = (unsigned short)(((unsigned)k.ry * r + (unsigned)k.gy * g + (unsigned)k.by * b + (0x2001u << 14)) >> 15);
+    };
+    int r, g, b;
+    if (half) {
+        const int x0 = 2 * cx, x1 = min(2 * cx + 1, w - 1);
+        luma(x0);
+        if (x1 != x0) luma(x1);
+        r = (int)(row[4 * x0 + ro] + row[4 * x1 + ro] + 1) >> 1;
+        g = (int)(row[4 * x0 + 1] + row[4 * x1 + 1] + 1) >> 1;
+        b = (int)(row[4 * x0 + bo] + row[4 * x1 + bo] + 1) >> 1;
+    } else {
+        luma(cx);
+        r = row[4 * cx + ro]; g = row[4 * cx + 1]; b = row[4 * cx + bo];
+    }
+    reinterpret_cast<unsigned short *>(pu + (size_t)y * us)[cx] = (unsigned short)((k.ru * r + k.gu * g + k.bu * b + (0x10001 << 14)) >> 15);
+    reinterpret_cast<unsigned short *>(pv + (size_t)y * vs)[cx] = (unsigned short)((k.rv * r + k.gv * g + k.bv * b + (0x10001 << 14)) >> 15);
+}
+
+int launch_rgb64_planes(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, const Rgb2YuvConsts &k,
+                        uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid((chrW + 255) / 256, h), block(256);
+    hipLaunchKernelGGL(rgb64_planes_kernel, grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, k, py, ys, pu, us, pv, vs);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The alpha byte of an RGBA / BGRA destination from the 15-bit alpha lines (srcH x dstW int32), one pixel per thread.  The form
+// per output row is packed_vscale's (vscale.c:135-167), chosen on the host from the luma AND chroma filters as for the colour
+// channels: form[y] = m | yalpha << 8 (yalpha = the luma filter's second coefficient), first[y] = the luma filter's position.
+//   m  writer                          output.c      alpha                                           clipped to 8 bits
+//   0  yuv2rgb_X_c                     :1709-1720    (2^18 + sum a * f) >> 19                        when bit 8 is set (*)
+//   4  yuv2rgb_full_X_c                :2069-2077    the same                                        when bit 8 is set
+//   1  yuv2rgb_1_c, uvalpha < 2048     :1794-1799    (a * 255 + 16384) >> 15                         always
+//   2  yuv2rgb_1_c, uvalpha >= 2048    :1816-1821    (a + 64) >> 7                                   always
+//   3  yuv2rgb_2_c                     :1761-1766    (a0 * (4096 - yalpha) + a1 * yalpha) >> 19      always
+//   5  yuv2rgb_full_2_c                :2117-2121    (a0 * (4096 - yalpha) + a1 * yalpha + 2^18) >> 19   when bit 8 is set
+//   6  yuv2rgb_full_1_c                :2154-2158,:2171-2175   (a + 64) >> 7                         when bit 8 is set
+// (*) the half-chroma X writer tests the OR of a pixel pair; the partner's bit can only matter for a value >= 512 without bit 8,
+// i.e. a filter row whose coefficients sum to more than 2^28 / 32767 = 2 * 4096 in absolute value, which initFilter does not make.
+__global__ __launch_bounds__(256) void alpha8_out_kernel(const int32_t *la, int lineW, int lineH, DevFilter f, const int32_t *form,
+                                                         const int32_t *first, uint8_t *dst, int ds, int dstW, int dstH)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dstW || y >= dstH) return;
+    const int m = form[y] & 0xFF, ya = form[y] >> 8;
+    int A;
+    if (m == 0 || m == 4) {
+        const int p0 = f.pos_even[y];
+        A = 1 << 18;
+        for (int k = 0; k < f.pairs; k++) {
+            const int cf = f.packed[(size_t)y * f.pairs + k];
+            const int r0 = min(p0 + 2 * k, lineH - 1), r1 = min(p0 + 2 * k + 1, lineH - 1);
+            A += la[(size_t)r0 * lineW + x] * (int)(short)(cf & 0xFFFF) + la[(size_t)r1 * lineW + x] * (cf >> 16);
+        }
+        A >>= 19;
+    } else {
+        const int r0 = min(first[y], lineH - 1), r1 = min(first[y] + 1, lineH - 1);
+        const int a0 = la[(size_t)r0 * lineW + x];
+        if (m == 1)                A = (a0 * 255 + 16384) >> 15;
+        else if (m == 2 || m == 6) A = (a0 + 64) >> 7;
+        else                       A = (a0 * (4096 - ya) + la[(size_t)r1 * lineW + x] * ya + (m == 5 ? (1 << 18) : 0)) >> 19;
+    }
+    const bool always = m >= 1 && m <= 3;
+    if (always || (A & 0x100)) A = clip_u8(A);
+    dst[(size_t)y * ds + 4 * x + 3] = (uint8_t)A;
+}
+
+int launch_alpha8_out(const int32_t *la, int lineW, int lineH, const DevFilter &f, const int32_t *form, const int32_t *first,
+                      uint8_t *dst, int ds, int dstW, int dstH, hipStream_t stream)
+{
+    if (dstW <= 0 || dstH <= 0) return 0;
+    const dim3 grid((dstW + 255) / 256, dstH), block(256);
+    hipLaunchKernelGGL(alpha8_out_kernel, grid, block, 0, stream, la, lineW, lineH, f, form, first, dst, ds, dstW, dstH);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

@@ -19,9 +19,11 @@
 namespace gmat {
 
 // kind: 0 = 8-bit samples, sample stride `step` bytes; 10 / 16 = 16-bit samples (P010: >> 6), sample stride `step` bytes;
-//       110 = 16-bit containers holding 10 bits in the low end (YUV420P10LE): as they are, sh of a 10-bit source
+//       110 = 16-bit containers holding 10 bits in the low end (YUV420P10LE): as they are, sh of a 10-bit source;
+//       208 = 8-bit alpha samples as rgbaToA_c hands them to the scaler (a << 6 | a >> 2, input.c:442-449)
+// maxv: 2^19 - 1 (hScale*To19_c) or 2^15 - 1 (hScale16To15_c, swscale.c:93-119 — the alpha lines of an 8-bit destination)
 __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH,
-                                                       DevFilter f, int32_t *dst, int dstW, int sh)
+                                                       DevFilter f, int32_t *dst, int dstW, int sh, int maxv)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dstW || y >= srcH) return;
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int s
         for (int j = 0; j < 2; j++) {
             const int i = min(p0 + 2 * k + j, srcW - 1);              // a tap past the plane has coefficient 0
             if (kind == 0) s[j] = row[(size_t)i * step];
+            else if (kind == 208) { const int a = row[(size_t)i * step]; s[j] = a << 6 | a >> 2; }
             else {
                 const unsigned v = *reinterpret_cast<const unsigned short *>(row + (size_t)i * step);
                 s[j] = kind == 10 ? (int)(v >> 6) : (int)v;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int s
         }
         val += s[0] * (int)(short)(cf & 0xFFFF) + s[1] * (cf >> 16);
     }
-    dst[(size_t)y * dstW + x] = min(val >> sh, (1 << 19) - 1);
+    dst[(size_t)y * dstW + x] = min(val >> sh, maxv);
 }
 
 // planes == 1: one plane -> 16-bit samples at dst + 2x.  planes == 2: U and V lines -> interleaved 16-bit pairs at dst + 4x.
@@ -74,21 +77,25 @@ __global__ __launch_bounds__(256) void vscale16_kernel(const int32_t *lineA, con
 // 2-tap forms (_1_c, _2_c) are the same values with the effective coefficients the host prepares (gsws.cpp):
 //   Y = ((-2^30 + sum lum * f) >> 14) + 2^16;  U, V = (-(128 << 23) + sum chr * f) >> 14      (32-bit wrap-around sums)
 //   Y = (Y - y_offset) * y_coeff + (1 << 13);  R = V * v2r;  G = V * v2g + U * u2g;  B = U * u2b
-//   channel = clip_uintp2(X + Y, 30) >> 14, alpha 0xFFFF
+//   channel = clip_uintp2(X + Y, 30) >> 14
+//   alpha: 0xFFFF without an alpha plane (la == nullptr); else the X form's ((-2^30 + sum a * f) >> 1) + 0x20002000 -> clip_uintp2(., 30)
+//   >> 14 (:1052-1064) on the same effective luma coefficients — the _2 form ((a0 * yalpha1 + a1 * yalpha) >> 1) + 2^13 (:1144-1150)
+//   and the _1 form (a << 11) + 2^13 (:1196-1202) are that value exactly (2^30 is even; one tap of 4096 is the shift by 11 and 1)
 // One pixel per thread; chrShift = 1: one chroma sample per pixel pair.
 __global__ __launch_bounds__(256) void vrgba64_kernel(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH,
                                                       int chrW, int chrH, DevFilter fl, DevFilter fc, int chrShift, uint8_t *dst,
-                                                      int ds, int dstW, int dstH, int bgr, Yuv2RgbConsts k)
+                                                      int ds, int dstW, int dstH, int bgr, Yuv2RgbConsts k, const int32_t *la)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dstW || y >= dstH) return;
     const int cx = x >> chrShift;
-    unsigned ay = (unsigned)-0x40000000, au = (unsigned)-(128 << 23), av = au;
+    unsigned ay = (unsigned)-0x40000000, au = (unsigned)-(128 << 23), av = au, aa = ay;
     const int pl = fl.pos_even[y], pc = fc.pos_even[y];
     for (int t = 0; t < fl.pairs; t++) {
         const int cf = fl.packed[(size_t)y * fl.pairs + t];
         const int r0 = min(pl + 2 * t, lumH - 1), r1 = min(pl + 2 * t + 1, lumH - 1);
         ay += (unsigned)ly[(size_t)r0 * lumW + x] * (unsigned)(int)(short)(cf & 0xFFFF) + (unsigned)ly[(size_t)r1 * lumW + x] * (unsigned)(cf >> 16);
+        if (la) aa += (unsigned)la[(size_t)r0 * lumW + x] * (unsigned)(int)(short)(cf & 0xFFFF) + (unsigned)la[(size_t)r1 * lumW + x] * (unsigned)(cf >> 16);
     }
     for (int t = 0; t < fc.pairs; t++) {
         const int cf = fc.packed[(size_t)y * fc.pairs + t];
@@ -104,27 +111,29 @@ __global__ __launch_bounds__(256) void vrgba64_kernel(const int32_t *ly, const i
     auto ch = [&](int v) -> unsigned { return (unsigned)min(max(v + Y, 0), 0x3FFFFFFF) >> 14; };
     const unsigned c0 = ch(bgr ? B : R), c1 = ch(G), c2 = ch(bgr ? R : B);
     unsigned short *d = reinterpret_cast<unsigned short *>(dst + (size_t)y * ds) + 4 * x;
-    d[0] = (unsigned short)c0; d[1] = (unsigned short)c1; d[2] = (unsigned short)c2; d[3] = 0xFFFF;
+    d[0] = (unsigned short)c0; d[1] = (unsigned short)c1; d[2] = (unsigned short)c2;
+    d[3] = la ? (unsigned short)((unsigned)min(max(((int)aa >> 1) + 0x20002000, 0), 0x3FFFFFFF) >> 14) : (unsigned short)0xFFFF;
 }
 
 int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
                    const DevFilter &fc, int chrShift, uint8_t *dst, int ds, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,
-                   hipStream_t stream)
+                   hipStream_t stream, const int32_t *la)
 {
     if (dstW <= 0 || dstH <= 0) return 0;
     const dim3 grid((dstW + 255) / 256, dstH), block(256);
-    hipLaunchKernelGGL(vrgba64_kernel, grid, block, 0, stream, ly, lu, lv, lumW, lumH, chrW, chrH, fl, fc, chrShift, dst, ds, dstW, dstH, bgr, k);
+    hipLaunchKernelGGL(vrgba64_kernel, grid, block, 0, stream, ly, lu, lv, lumW, lumH, chrW, chrH, fl, fc, chrShift, dst, ds, dstW, dstH, bgr, k, la);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_hscale19(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst, int dstW,
-                    hipStream_t stream)
+                    hipStream_t stream, int to15)
 {
     if (dstW <= 0 || srcH <= 0) return 0;
-    const int sh = kind == 0 ? 3 : kind % 100 - 5;                  // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4
+    // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4; hScale16To15_c (to15): depth - 1, 13 for the 14-bit alpha of an 8-bit format
+    const int sh = to15 ? (kind == 208 ? 13 : kind % 100 - 1) : kind == 0 ? 3 : kind % 100 - 5;
     const dim3 grid((dstW + 255) / 256, srcH), block(256);
-    hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh);
+    hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh, to15 ? (1 << 15) - 1 : (1 << 19) - 1);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -124,8 +124,9 @@ const char *yuvscale_kernel_name(const YuvScaleTiling &t);
 
 // ---- 16-bit destinations: 19-bit int32 lines, two passes (k_scale16.hip) -------------------------------------
 // kind 0: 8-bit samples; 10 / 16: 16-bit samples (P010: >> 6); step = bytes between consecutive samples of the plane
+// kind 208: 8-bit alpha samples (a << 6 | a >> 2); to15: hScale16To15_c's shift and clamp instead (the alpha lines of an 8-bit destination)
 int launch_hscale19(const uint8_t *src, int srcStride, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst,
-                    int dstW, hipStream_t stream);
+                    int dstW, hipStream_t stream, int to15 = 0);
 // lineB == nullptr: one plane of 16-bit samples; else U / V lines -> interleaved 16-bit pairs
 int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int lineH, const DevFilter &f, uint8_t *dst, int dstStride,
                     int dstW, int dstH, hipStream_t stream);
@@ -133,7 +134,15 @@ int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int l
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)
 int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
                    const DevFilter &fc, int chrShift, uint8_t *dst, int dstStride, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,
-                   hipStream_t stream);
+                   hipStream_t stream, const int32_t *la = nullptr);     // la: the alpha plane's 19-bit lines (lumH x lumW), nullptr = 0xFFFF
+
+// ---- RGBA64LE / BGRA64LE sources, alpha planes (k_rgb64.hip) -------------------------------------------------------------
+// packed 64-bit RGB -> Y / U / V planes of 16-bit samples (rgb64ToY_c / ToUV_c / ToUV_half_c); half: chroma from pixel pairs
+int launch_rgb64_planes(const uint8_t *src, int srcStride, int w, int h, int chrW, int half, int bgr, const Rgb2YuvConsts &k,
+                        uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream);
+// byte 3 of every pixel of an RGBA / BGRA frame from the 15-bit alpha lines; form / first: per output row, see alpha8_out_kernel
+int launch_alpha8_out(const int32_t *la, int lineW, int lineH, const DevFilter &f, const int32_t *form, const int32_t *first,
+                      uint8_t *dst, int dstStride, int dstW, int dstH, hipStream_t stream);
 
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
 int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
@@ -195,6 +204,8 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
                        uint8_t *d1, int ds1, int cw, int ch, hipStream_t stream);
 // 8 -> 16 bit, t -> t | t << 8 (planar8ToP01xleWrapper): n samples per row of plane a (b == nullptr), or n
 // (a, b) sample pairs interleaved
+// one plane of planarCopyWrapper's 8 -> `depth` bit copy; replicate: the luma of a full-range source (swscale_unscaled.c:1844-1862)
+int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream);
 int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds, int n, int h,
                       hipStream_t stream);
 } // namespace gmat

@@ -40,7 +40,9 @@ enum GmatPixelFormat {
     GMAT_PIX_FMT_YUV444P16LE = 49,  /* scale_cuda's list: source for every destination at any size; destination of every
                                        YUV source on the 19-bit path (with P016LE, RGBA64LE, BGRA64LE) */
     GMAT_PIX_FMT_RGBA64LE  = 105,   /* destinations of every YUV source at any size (yuv2rgba64_*_c on libswscale's 19-bit */
-    GMAT_PIX_FMT_BGRA64LE  = 107,   /* lines; alpha 0xFFFF) — yuv2rgb_cuda's 64-bit outputs, yuv2rgb_cuda.cu:862-907           */
+    GMAT_PIX_FMT_BGRA64LE  = 107,   /* lines; alpha 0xFFFF) — yuv2rgb_cuda's 64-bit outputs, yuv2rgb_cuda.cu:862-907; SOURCES   */
+                                    /* of every destination at any size (rgb64ToY_c / ToUV_c / ToUV_half_c, input.c:36-121);   */
+                                    /* with an alpha channel at both ends the alpha plane is scaled too (needAlpha)             */
     GMAT_PIX_FMT_HIP       = 117,   /* AV_PIX_FMT_CUDA's slot (pixfmt.h:225): opaque device frame */
     GMAT_PIX_FMT_RGB0      = 119,   /* = AV_PIX_FMT_0BGR32 on little endian  } scale_cuda's 32-bit formats (vf_scale_cuda.c:45-54): */
     GMAT_PIX_FMT_BGR0      = 121,   /* = AV_PIX_FMT_0RGB32 on little endian  } RGBA / BGRA whose 4th byte is padding — libswscale     */

@@ -32,6 +32,9 @@
  *         pixfmt-rgb24 / -bgr24 / -yuv420p -> rgb24ToY/ToUV, hScale16To15, chroma up-scaling
  *         sws-yuv-colorspace              -> BT.709 yuv2rgb tables, BGR readers + BT.601 rgb2yuv literals,
  *                                            range conversion of an RGB-sourced context (the cascade's two halves)
+ *       and, through tests/test_oracle_fate_nut.py (NUT md5s over the restated muxer), filter-pixfmts-scale for rgba64le /
+ *       bgra64le -> rgb64To{Y,UV_half}_c, rgba64leToA_c, the alpha leg of the 19-bit lines and of yuv2rgba64_*; for rgba /
+ *       bgra -> the 32-bit readers and rgbaToA_c with the 8-bit writers' alpha (opaque alpha in both: the vsynth clip has none);
  *   (2) known-answer values the survey recorded from the reference (SURVEY.md §8a row 7,
  *       §8c item 5) and constants literal in its sources (ff_yuv2rgb_coeffs, BT.601 literals);
  *   (3) the LUT path and the closed form being two independent restatements that must agree
@@ -176,6 +179,8 @@ void orc_rotate(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride
  * src_nv12 != 0: the same rule applied to an NV12 source (src[1] interleaved). */
 void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
                         const int dst_stride[4], int w, int h, int src_nv12);
+/* planarCopyWrapper's 8 -> `depth` bit plane copy (swscale_unscaled.c:1844-1862); shiftonly: chroma, and luma of a limited-range source */
+void orc_plane_copy_up(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int depth, int shiftonly);
 void orc_rgb24_swap_rb(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride,
                        int w, int h);                               /* rgb2rgb_template.c rgb24tobgr24 */
 /* rgbToRgbWrapper (swscale_unscaled.c:1579-1640): RGB24/BGR24 <-> RGBA/BGRA and RGBA <-> BGRA byte re-packing at

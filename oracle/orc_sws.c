@@ -2,7 +2,7 @@
  * oracle/orc_sws.c — TEST INFRASTRUCTURE ONLY (see orc.h).
  *
  * CPU restatement of libswscale's *generic* scaler for the formats on the hot path:
- *   src: RGB24, BGR24, NV12, YUV420P        dst: RGB24, BGR24, RGBA, BGRA, NV12, YUV420P
+ *   src: RGB24, BGR24, RGBA, BGRA, RGBA64LE, BGRA64LE, NV12, YUV420P, ...   dst: RGB24, BGR24, RGBA, BGRA, NV12, YUV420P, ...
  *
  * Follows (reference tree, ffmpeg-gpu/libswscale):
  *   sws_init_single_context   utils.c:1293-2020  chroma sub-sampling decisions :1427-1557,
@@ -11,6 +11,11 @@
  *   get_local_pos             utils.c:338-345
  *   fill_rgb2yuv_table        utils.c:765-858
  *   rgb24ToY_c/ToUV_c/ToUV_half_c, bgr24 twins, nvXXtoUV_c   input.c:795-866, :675-690
+ *   rgb32 / bgr32 readers (rgb16_32To{Y,UV,UV_half}_c_template, S = RGB2YUV_SHIFT + 8)   input.c:246-390: the 24-bit
+ *                                                            formulas on the same three channels (every term << 8)
+ *   rgb64To{Y,UV,UV_half}_c_template (RGBA64LE / BGRA64LE)   input.c:36-121
+ *   rgbaToA_c, rgba64leToA_c                                 input.c:413-449;  needAlpha  utils.c:1902
+ *   alpha in the packed writers                              output.c:1025-1470 (64-bit), :1685-1828, :2037-2200 (8-bit)
  *   hScale8To15_c / hScale16To15_c                         swscale.c:93-136
  *   swscale() row schedule                                 swscale.c:372-389
  *   packed_vscale selection                                vscale.c:108-170
@@ -36,6 +41,8 @@ struct OrcSws {
     int32_t *h_lum_pos, *h_chr_pos, *v_lum_pos, *v_chr_pos;
     int h_lum_size, h_chr_size, v_lum_size, v_chr_size;
     int src_is_rgb, dst_is_rgb;
+    int src_px;                /* packed RGB source: bytes per pixel (3, 4, 8) */
+    int need_alpha;            /* both ends carry alpha: the alpha plane is scaled with the luma filters (utils.c:1902) */
     int range_conv;            /* 0 none, 1 limited->full (ToJpeg), 2 full->limited (FromJpeg) */
     int32_t ry, gy, by, ru, gu, bu, rv, gv, bv;
     OrcYuv2Rgb y2r;
@@ -46,6 +53,7 @@ struct OrcSws {
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
 static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
 static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
+static int has_alpha(int f) { return f == ORC_PIX_RGBA || f == ORC_PIX_BGRA || is_rgb64(f); }
 static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE || is_rgb64(f); }   /* 19-bit lines */
 static int is_pl16_dst(int f) { return f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE; }          /* ... with planar chroma */
 static int is_yuv(int f)  { return f == ORC_PIX_NV12 || f == ORC_PIX_YUV420P || f == ORC_PIX_YUV444P; }
@@ -146,13 +154,11 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
 
     /* P010LE / P016LE as sources and as destinations: P010LE (dstBpc = 10 <= 14) keeps the 15-bit intermediates,
      * P016LE switches to the 19-bit ones (scale_to_p016 below) */
-    if (!(is_rgb(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
+    if (!(is_rgb(src_fmt) || is_rgb64(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
         !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt) || dst_fmt == ORC_PIX_YUV420P10LE))
         return NULL;
     if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
         return NULL;
-    if (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA)
-        return NULL;                                       /* 32-bit readers not restated */
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
         return NULL;
     c = (OrcSws *)calloc(1, sizeof(*c));
@@ -162,7 +168,9 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
         flags |= ORC_SWS_BICUBIC;                          /* utils.c:1370-1381 */
     c->src_w = src_w; c->src_h = src_h; c->dst_w = dst_w; c->dst_h = dst_h;
     c->src_fmt = src_fmt; c->dst_fmt = dst_fmt;
-    c->src_is_rgb = is_rgb(src_fmt);
+    c->src_is_rgb = is_rgb(src_fmt) || is_rgb64(src_fmt);
+    c->src_px = is_rgb64(src_fmt) ? 8 : (src_fmt == ORC_PIX_RGBA || src_fmt == ORC_PIX_BGRA) ? 4 : 3;
+    c->need_alpha = has_alpha(src_fmt) && has_alpha(dst_fmt);
     c->dst_is_rgb = is_rgb(dst_fmt) || is_rgb64(dst_fmt);
 
     c->lum_x_inc = (int)((((int64_t)src_w << 16) + (dst_w >> 1)) / dst_w);
@@ -306,14 +314,70 @@ static void range_chr(const OrcSws *c, int16_t *u, int16_t *v, int w)
         }
 }
 
+/* RGBA64LE / BGRA64LE readers (input.c:36-121): 16-bit channels, 16-bit results.
+ *   Y  = (ry*r + gy*g + by*b + (0x2001 << 14)) >> 15
+ *   UV = (ru*r + gu*g + bu*b + (0x10001 << 14)) >> 15, the _half form on (p0 + p1 + 1) >> 1 per channel
+ * The sums are formed in the reference's own types: unsigned for Y (its channels are unsigned int), int for U / V. */
+static void rgb64_lum(const OrcSws *c, const uint8_t *row, uint16_t *tmp)
+{
+    const int ro = c->src_fmt == ORC_PIX_RGBA64LE ? 0 : 4, bo = 4 - ro;
+    int i;
+    for (i = 0; i < c->src_w; i++) {
+        unsigned r = rl16(row + 8 * i + ro), g = rl16(row + 8 * i + 2), b = rl16(row + 8 * i + bo);
+        tmp[i] = (uint16_t)(((unsigned)c->ry * r + (unsigned)c->gy * g + (unsigned)c->by * b + (0x2001u << (RGB2YUV_SHIFT - 1))) >> RGB2YUV_SHIFT);
+    }
+}
+
+static void rgb64_chr(const OrcSws *c, const uint8_t *row, uint16_t *tmp_u, uint16_t *tmp_v)
+{
+    const int ro = c->src_fmt == ORC_PIX_RGBA64LE ? 0 : 4, bo = 4 - ro;
+    int i;
+    for (i = 0; i < c->chr_src_w; i++) {
+        int r, g, b;
+        if (c->chr_src_hsub) {
+            /* odd widths: pixel 2i+1 of the last pair is past the row in the reference; clamped here as for the 8-bit readers */
+            const int i1 = 2 * i + 1 < c->src_w ? 2 * i + 1 : c->src_w - 1;
+            r = (int)(rl16(row + 16 * i + ro) + rl16(row + 8 * i1 + ro) + 1) >> 1;
+            g = (int)(rl16(row + 16 * i + 2)  + rl16(row + 8 * i1 + 2)  + 1) >> 1;
+            b = (int)(rl16(row + 16 * i + bo) + rl16(row + 8 * i1 + bo) + 1) >> 1;
+        } else {
+            r = (int)rl16(row + 8 * i + ro); g = (int)rl16(row + 8 * i + 2); b = (int)rl16(row + 8 * i + bo);
+        }
+        tmp_u[i] = (uint16_t)((int)((unsigned)(c->ru * r) + (unsigned)(c->gu * g) + (unsigned)(c->bu * b) + (0x10001u << (RGB2YUV_SHIFT - 1))) >> RGB2YUV_SHIFT);
+        tmp_v[i] = (uint16_t)((int)((unsigned)(c->rv * r) + (unsigned)(c->gv * g) + (unsigned)(c->bv * b) + (0x10001u << (RGB2YUV_SHIFT - 1))) >> RGB2YUV_SHIFT);
+    }
+}
+
+/* the alpha samples as the horizontal scaler sees them: rgbaToA_c (a << 6 | a >> 2, input.c:442-449) for the 8-bit formats,
+ * rgba64leToA_c (the sample, :413-421) for the 64-bit ones */
+static void alpha_samples(const OrcSws *c, const uint8_t *row, uint16_t *tmp)
+{
+    int i;
+    if (is_rgb64(c->src_fmt))
+        for (i = 0; i < c->src_w; i++) tmp[i] = (uint16_t)rl16(row + 8 * i + 6);
+    else
+        for (i = 0; i < c->src_w; i++) tmp[i] = (uint16_t)(row[4 * i + 3] << 6 | row[4 * i + 3] >> 2);
+}
+
+/* lum_h_scale's alpha leg (hscale.c:66-76): the luma filter, hScale16To15_c with the source's sh; no range conversion */
+static void alpha_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y, int16_t *out, uint16_t *tmp)
+{
+    alpha_samples(c, src[0] + (long)y * stride[0], tmp);
+    hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, is_rgb64(c->src_fmt) ? 15 : 13);
+}
+
 static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int stride[4], int y,
                      int16_t *out, uint16_t *tmp)
 {
     const uint8_t *row = src[0] + (long)y * stride[0];
-    if (c->src_is_rgb) {
-        int ro = c->src_fmt == ORC_PIX_RGB24 ? 0 : 2, bo = 2 - ro, i;
+    if (is_rgb64(c->src_fmt)) {
+        rgb64_lum(c, row, tmp);
+        hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 15);      /* sh = depth - 1 (swscale.c:93-119) */
+    } else if (c->src_is_rgb) {
+        const int px = c->src_px;
+        int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro, i;
         for (i = 0; i < c->src_w; i++) {
-            int r = row[3 * i + ro], g = row[3 * i + 1], b = row[3 * i + bo];
+            int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
             tmp[i] = (uint16_t)((c->ry * r + c->gy * g + c->by * b + (32 << (RGB2YUV_SHIFT - 1)) +
                                  (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
         }
@@ -342,9 +406,14 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
                      int16_t *out_u, int16_t *out_v, uint16_t *tmp_u, uint16_t *tmp_v)
 {
     int i;
-    if (c->src_is_rgb) {
+    if (is_rgb64(c->src_fmt)) {
+        rgb64_chr(c, src[0] + (long)y * stride[0], tmp_u, tmp_v);
+        hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
+        hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
+    } else if (c->src_is_rgb) {
         const uint8_t *row = src[0] + (long)y * stride[0];
-        int ro = c->src_fmt == ORC_PIX_RGB24 ? 0 : 2, bo = 2 - ro;
+        const int px = c->src_px;
+        int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro;
         if (c->chr_src_hsub) {
             for (i = 0; i < c->chr_src_w; i++) {
                 /* the reference reads pixel 2i+1 unconditionally; for odd widths that is the
@@ -352,9 +421,9 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
                  * Odd source widths with half-chroma input are therefore not bit-defined and
                  * the oracle clamps to the last pixel. */
                 int i1 = 2 * i + 1 < c->src_w ? 2 * i + 1 : c->src_w - 1;
-                int r = row[6 * i + ro] + row[3 * i1 + ro];
-                int g = row[6 * i + 1]  + row[3 * i1 + 1];
-                int b = row[6 * i + bo] + row[3 * i1 + bo];
+                int r = row[2 * px * i + ro] + row[px * i1 + ro];
+                int g = row[2 * px * i + 1]  + row[px * i1 + 1];
+                int b = row[2 * px * i + bo] + row[px * i1 + bo];
                 tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << RGB2YUV_SHIFT) +
                                        (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
                 tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << RGB2YUV_SHIFT) +
@@ -362,7 +431,7 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
             }
         } else {
             for (i = 0; i < c->chr_src_w; i++) {
-                int r = row[3 * i + ro], g = row[3 * i + 1], b = row[3 * i + bo];
+                int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
                 tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << (RGB2YUV_SHIFT - 1)) +
                                        (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
                 tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << (RGB2YUV_SHIFT - 1)) +
@@ -406,17 +475,18 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
 
 /* ---- output stage ------------------------------------------------------------------------ */
 
-static void put_rgb(uint8_t *d, int fmt, int R, int G, int B)
+/* A: the alpha byte (255 without an alpha plane: the tables' own alpha / yuv2rgb_write_full's `hasAlpha ? A : 255`) */
+static void put_rgb(uint8_t *d, int fmt, int R, int G, int B, int A)
 {
     switch (fmt) {
     case ORC_PIX_RGB24: d[0] = (uint8_t)R; d[1] = (uint8_t)G; d[2] = (uint8_t)B; break;
     case ORC_PIX_BGR24: d[0] = (uint8_t)B; d[1] = (uint8_t)G; d[2] = (uint8_t)R; break;
-    case ORC_PIX_RGBA:  d[0] = (uint8_t)R; d[1] = (uint8_t)G; d[2] = (uint8_t)B; d[3] = 255; break;
-    case ORC_PIX_BGRA:  d[0] = (uint8_t)B; d[1] = (uint8_t)G; d[2] = (uint8_t)R; d[3] = 255; break;
+    case ORC_PIX_RGBA:  d[0] = (uint8_t)R; d[1] = (uint8_t)G; d[2] = (uint8_t)B; d[3] = (uint8_t)A; break;
+    case ORC_PIX_BGRA:  d[0] = (uint8_t)B; d[1] = (uint8_t)G; d[2] = (uint8_t)R; d[3] = (uint8_t)A; break;
     }
 }
 
-static void write_full(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+static void write_full(const OrcSws *c, uint8_t *d, int Y, int U, int V, int A)
 {
     /* yuv2rgb_write_full, output.c:1886-1935 */
     int R, G, B;
@@ -431,23 +501,29 @@ static void write_full(const OrcSws *c, uint8_t *d, int Y, int U, int V)
         G = clip_uintp2_30(G);
         B = clip_uintp2_30(B);
     }
-    put_rgb(d, c->dst_fmt, R >> 22, G >> 22, B >> 22);
+    put_rgb(d, c->dst_fmt, R >> 22, G >> 22, B >> 22, A);
 }
 
-static void write_lut(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+static void write_lut(const OrcSws *c, uint8_t *d, int Y, int U, int V, int A)
 {
     /* yuv2rgb_write through table_rV/gU/gV/bU, output.c:1554-1600 */
     const OrcYuv2Rgb *t = &c->y2r;
     const uint8_t *r = t->y_table + t->off_rV[V + ORC_TABLE_HEADROOM];
     const uint8_t *g = t->y_table + t->off_gU[U + ORC_TABLE_HEADROOM] + t->off_gV[V + ORC_TABLE_HEADROOM];
     const uint8_t *b = t->y_table + t->off_bU[U + ORC_TABLE_HEADROOM];
-    put_rgb(d, c->dst_fmt, r[Y], g[Y], b[Y]);
+    put_rgb(d, c->dst_fmt, r[Y], g[Y], b[Y], A);
 }
 
-/* lum[j], chr_u[j], chr_v[j] are the vertical taps' lines (already offset to the first tap) */
+/* lum[j], chr_u[j], chr_v[j] are the vertical taps' lines (already offset to the first tap); alp[j] the alpha lines on
+ * the luma taps, NULL without an alpha plane.  Alpha per form (output.c):
+ *   yuv2rgb_X_c :1709-1720      (2^18 + sum) >> 19, both of a pair clipped when either has bit 8 set
+ *   yuv2rgb_2_c :1761-1766      (a0 * yalpha1 + a1 * yalpha) >> 19, clipped
+ *   yuv2rgb_1_c :1794-1799      uvalpha < 2048: (a0 * 255 + 16384) >> 15;  :1816-1821 else: (a0 + 64) >> 7; clipped
+ *   yuv2rgb_full_X_c :2069-2077 (2^18 + sum) >> 19;  _full_2_c :2117-2121  (a0 * yalpha1 + a1 * yalpha + 2^18) >> 19;
+ *   yuv2rgb_full_1_c :2154-2158,:2171-2175  (a0 + 64) >> 7;  each clipped when bit 8 is set */
 static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
                            const int16_t *const *lum, const int16_t *const *chr_u,
-                           const int16_t *const *chr_v)
+                           const int16_t *const *chr_v, const int16_t *const *alp)
 {
     const int step = (c->dst_fmt == ORC_PIX_RGB24 || c->dst_fmt == ORC_PIX_BGR24) ? 3 : 4;
     const int chr_y = dst_y >> c->chr_dst_vsub;
@@ -471,7 +547,13 @@ static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
 
     if (full) {
         for (i = 0; i < c->dst_w; i++) {
-            int Y, U, V;
+            int Y, U, V, A = 255;
+            if (alp) {
+                if (mode == 1) A = (alp[0][i] + 64) >> 7;
+                else if (mode == 2) A = (alp[0][i] * (4096 - yalpha) + alp[1][i] * yalpha + (1 << 18)) >> 19;
+                else { A = 1 << 18; for (j = 0; j < lfs; j++) A += alp[j][i] * lf[j]; A >>= 19; }
+                if (A & 0x100) A = clip_u8(A);
+            }
             if (mode == 1) {
                 Y = lum[0][i] * 4;
                 if (uvalpha < 2048) {
@@ -497,11 +579,27 @@ static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
                 }
                 Y >>= 10; U >>= 10; V >>= 10;
             }
-            write_full(c, dest + i * step, Y, U, V);
+            write_full(c, dest + i * step, Y, U, V, A);
         }
     } else {
         for (i = 0; i < ((c->dst_w + 1) >> 1); i++) {
-            int Y1, Y2, U, V;
+            int Y1, Y2, U, V, A1 = 255, A2 = 255;
+            if (alp) {
+                const int16_t *a0 = alp[0];
+                if (mode == 1 && uvalpha < 2048) {
+                    A1 = clip_u8((a0[i * 2] * 255 + 16384) >> 15); A2 = clip_u8((a0[i * 2 + 1] * 255 + 16384) >> 15);
+                } else if (mode == 1) {
+                    A1 = clip_u8((a0[i * 2] + 64) >> 7); A2 = clip_u8((a0[i * 2 + 1] + 64) >> 7);
+                } else if (mode == 2) {
+                    A1 = clip_u8((a0[i * 2] * (4096 - yalpha) + alp[1][i * 2] * yalpha) >> 19);
+                    A2 = clip_u8((a0[i * 2 + 1] * (4096 - yalpha) + alp[1][i * 2 + 1] * yalpha) >> 19);
+                } else {
+                    A1 = A2 = 1 << 18;
+                    for (j = 0; j < lfs; j++) { A1 += alp[j][i * 2] * lf[j]; A2 += alp[j][i * 2 + 1] * lf[j]; }
+                    A1 >>= 19; A2 >>= 19;
+                    if ((A1 | A2) & 0x100) { A1 = clip_u8(A1); A2 = clip_u8(A2); }
+                }
+            }
             if (mode == 1) {
                 Y1 = (lum[0][i * 2] + 64) >> 7;
                 Y2 = (lum[0][i * 2 + 1] + 64) >> 7;
@@ -531,8 +629,8 @@ static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
                 Y1 >>= 19; Y2 >>= 19; U >>= 19; V >>= 19;
             }
             /* non-full packed output requires an even dst_w (odd forces full chroma) */
-            write_lut(c, dest + (2 * i) * step, Y1, U, V);
-            write_lut(c, dest + (2 * i + 1) * step, Y2, U, V);
+            write_lut(c, dest + (2 * i) * step, Y1, U, V, A1);
+            write_lut(c, dest + (2 * i + 1) * step, Y2, U, V, A2);
         }
     }
 }
@@ -664,12 +762,14 @@ static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, in
 }
 
 /* the 19-bit lines of a whole frame: luma src_h x dst_w, chroma chr_src_h x chr_dst_w per plane */
-static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], int32_t **pl, int32_t **pu, int32_t **pv)
+static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], int32_t **pl, int32_t **pu, int32_t **pv, int32_t **pa)
 {
     const int dw = c->dst_w, cdw = c->chr_dst_w, sh8 = 3;
     const int pl16 = pl16_depth(c->src_fmt) != 0;            /* planar 16-bit containers, read as they are (native endian) */
     const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
-    const int sh = pl16 ? pl16_depth(c->src_fmt) - 5 : src16 ? (p010 ? 10 : 16) - 5 : sh8;
+    const int r64 = is_rgb64(c->src_fmt);                    /* rgb64To*_c give 16-bit lines: hScale16To19_c, sh = 16 - 5 */
+    const int sh = r64 ? 11 : pl16 ? pl16_depth(c->src_fmt) - 5 : src16 ? (p010 ? 10 : 16) - 5 : sh8;
+    int32_t *la = (pa && c->need_alpha) ? (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h) : NULL;
     int32_t *ly = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h);
     int32_t *lu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
     int32_t *lv = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
@@ -677,14 +777,24 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
     uint16_t *t1 = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
     int y, i;
     if (!ly || !lu || !lv || !t0 || !t1) { free(ly); free(lu); free(lv); free(t0); free(t1); return -1; }
+    if (pa) *pa = la;
     for (y = 0; y < c->src_h; y++) {
         const uint8_t *row = src[0] + (long)y * src_stride[0];
-        for (i = 0; i < c->src_w; i++)
-            t0[i] = (uint16_t)((src16 || pl16) ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
+        if (r64) {
+            rgb64_lum(c, row, t0);
+        } else {
+            for (i = 0; i < c->src_w; i++)
+                t0[i] = (uint16_t)((src16 || pl16) ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
+        }
         hscale19(ly + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
+        if (la) {
+            alpha_samples(c, row, t0);
+            hscale19(la + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
+        }
     }
     for (y = 0; y < c->chr_src_h; y++) {
-        for (i = 0; i < c->chr_src_w; i++) {
+        if (r64) rgb64_chr(c, src[0] + (long)y * src_stride[0], t0, t1);
+        for (i = 0; i < c->chr_src_w && !r64; i++) {
             if (pl16) {
                 t0[i] = (uint16_t)rl16(src[1] + (long)y * src_stride[1] + 2 * i);
                 t1[i] = (uint16_t)rl16(src[2] + (long)y * src_stride[2] + 2 * i);
@@ -714,7 +824,7 @@ static int scale_to_p016(OrcSws *c, const uint8_t *const src[4], const int src_s
     int32_t *ly = NULL, *lu = NULL, *lv = NULL;
     const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(c->v_lum_size + c->v_chr_size) * 2);
     int y, i, j, ret = -1;
-    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv) < 0) goto done;
+    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv, NULL) < 0) goto done;
     for (y = 0; y < c->dst_h; y++) {
         uint8_t *d = dst[0] + (long)y * dst_stride[0];
         for (j = 0; j < c->v_lum_size; j++) {
@@ -773,10 +883,12 @@ done:
  *   yuv2rgba64_X_c :1025-1105   _2_c :1107-1170   _1_c :1172-1272   (one chroma sample per pixel PAIR)
  *   yuv2rgba64_full_X_c :1275-1337, _full_2_c, _full_1_c             (one chroma sample per pixel)
  * and their common colour stage: Y = (Y - y_offset) * y_coeff + (1 << 13); R = V * v2r; G = V * v2g + U * u2g;
- * B = U * u2b; channel = clip_uintp2(X + Y, 30) >> 14; alpha 0xFFFF (no alpha plane). */
+ * B = U * u2b; channel = clip_uintp2(X + Y, 30) >> 14.  Alpha: 0xFFFF << 14 without an alpha plane, else per form (the same
+ * rule in the half- and full-chroma twins): X :1052-1064 ((-2^30 + sum) >> 1) + 0x20002000; _2 :1144-1150
+ * ((a0 * yalpha1 + a1 * yalpha) >> 1) + 2^13; _1 :1196-1202,:1242-1248 (a0 << 11) + 2^13; then clip_uintp2(A, 30) >> 14. */
 static int clip_uintp2_30b(int a) { return (a & ~0x3FFFFFFF) ? (~a >> 31) & 0x3FFFFFFF : a; }
 
-static void put_rgba64(const OrcSws *c, uint8_t *d, int Y, int U, int V)
+static void put_rgba64(const OrcSws *c, uint8_t *d, int Y, int U, int V, int A)
 {
     int R, G, B, o[3], k;
     Y -= c->y2r.y_offset;
@@ -789,7 +901,7 @@ static void put_rgba64(const OrcSws *c, uint8_t *d, int Y, int U, int V)
     o[1] = clip_uintp2_30b(G + Y) >> 14;
     o[2] = clip_uintp2_30b((c->dst_fmt == ORC_PIX_RGBA64LE ? B : R) + Y) >> 14;
     for (k = 0; k < 3; k++) put16(d + 2 * k, o[k]);
-    put16(d + 6, 0xFFFF);
+    put16(d + 6, clip_uintp2_30b(A) >> 14);
 }
 
 static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
@@ -797,19 +909,20 @@ static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src
 {
     const int dw = c->dst_w, cdw = c->chr_dst_w, full = (c->flags & ORC_SWS_FULL_CHR_H_INT) != 0;
     const int lfs = c->v_lum_size, cfs = c->v_chr_size;
-    int32_t *ly = NULL, *lu = NULL, *lv = NULL;
-    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(lfs + 2 * cfs));
+    int32_t *ly = NULL, *lu = NULL, *lv = NULL, *la = NULL;
+    const int32_t **lp = (const int32_t **)malloc(sizeof(*lp) * (size_t)(2 * lfs + 2 * cfs));
     int y, i, j, ret = -1;
-    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv) < 0) goto done;
+    if (!lp || make_lines19(c, src, src_stride, &ly, &lu, &lv, &la) < 0) goto done;
     for (y = 0; y < c->dst_h; y++) {
         uint8_t *d = dst[0] + (long)y * dst_stride[0];
         const int16_t *lf = c->v_lum + y * lfs, *cf = c->v_chr + y * cfs;
-        const int32_t **up = lp + lfs, **vp = up + cfs;
+        const int32_t **up = lp + lfs, **vp = up + cfs, **ap = vp + cfs;
         const int chr2 = cfs == 2 && cf[0] + cf[1] == 4096 && (unsigned)cf[1] <= 4096u;
         const int lum2 = lfs == 2 && lf[0] + lf[1] == 4096 && (unsigned)lf[1] <= 4096u;
         for (j = 0; j < lfs; j++) {
             int r = c->v_lum_pos[y] + j;
             lp[j] = ly + (size_t)(r < c->src_h ? r : c->src_h - 1) * dw;
+            if (la) ap[j] = la + (size_t)(r < c->src_h ? r : c->src_h - 1) * dw;
         }
         for (j = 0; j < cfs; j++) {
             int r = c->v_chr_pos[y] + j;
@@ -818,10 +931,11 @@ static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src
         }
         for (i = 0; i < dw; i++) {
             const int ci = full ? i : i >> 1;
-            int Y, U, V;
+            int Y, U, V, A = 0xffff << 14;
             if (lfs == 1 && (cfs == 1 || chr2)) {                         /* yuv2packed1, uvalpha = 0 or cf[1] */
                 const int uvalpha = cfs == 1 ? 0 : cf[1];
                 Y = lp[0][i] >> 2;
+                if (la) A = (ap[0][i] << 11) + (1 << 13);
                 if (uvalpha < 2048) {
                     U = (up[0][ci] - (128 << 11)) >> 2;
                     V = (vp[0][ci] - (128 << 11)) >> 2;
@@ -831,6 +945,7 @@ static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src
                 }
             } else if (lum2 && chr2) {                                     /* yuv2packed2 */
                 Y = (lp[0][i] * (4096 - lf[1]) + lp[1][i] * lf[1]) >> 14;
+                if (la) A = ((ap[0][i] * (4096 - lf[1]) + ap[1][i] * lf[1]) >> 1) + (1 << 13);
                 U = (up[0][ci] * (4096 - cf[1]) + up[1][ci] * cf[1] - (128 << 23)) >> 14;
                 V = (vp[0][ci] * (4096 - cf[1]) + vp[1][ci] * cf[1] - (128 << 23)) >> 14;
             } else {                                                       /* yuv2packedX, 32-bit wrap-around sums */
@@ -841,15 +956,20 @@ static int scale_to_rgba64(OrcSws *c, const uint8_t *const src[4], const int src
                     av += (unsigned)vp[j][ci] * (unsigned)(int)cf[j];
                 }
                 Y = ((int)ay >> 14) + 0x10000;
+                if (la) {
+                    unsigned aa = (unsigned)-0x40000000;
+                    for (j = 0; j < lfs; j++) aa += (unsigned)ap[j][i] * (unsigned)(int)lf[j];
+                    A = ((int)aa >> 1) + 0x20002000;
+                }
                 U = (int)au >> 14;
                 V = (int)av >> 14;
             }
-            put_rgba64(c, d + 8 * i, Y, U, V);
+            put_rgba64(c, d + 8 * i, Y, U, V, A);
         }
     }
     ret = c->dst_h;
 done:
-    free(ly); free(lu); free(lv); free((void *)lp);
+    free(ly); free(lu); free(lv); free(la); free((void *)lp);
     return ret;
 }
 
@@ -858,9 +978,9 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
 {
     int lum_first, lum_last, chr_first, chr_last, y, j, ret = -1;
     int cy0, cy1;
-    int16_t *lum_buf = NULL, *u_buf = NULL, *v_buf = NULL;
+    int16_t *lum_buf = NULL, *u_buf = NULL, *v_buf = NULL, *a_buf = NULL;
     uint16_t *tmp = NULL, *tmp_u = NULL, *tmp_v = NULL;
-    const int16_t **lp = NULL, **up = NULL, **vp = NULL;
+    const int16_t **lp = NULL, **up = NULL, **vp = NULL, **ap = NULL;
     const int dst_w = c->dst_w, cdw = c->chr_dst_w;
 
     if (c->dst_fmt == ORC_PIX_P016LE || is_pl16_dst(c->dst_fmt))
@@ -883,6 +1003,8 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     if (chr_last >= c->chr_src_h) chr_last = c->chr_src_h - 1;
 
     lum_buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)dst_w * (lum_last - lum_first + 1));
+    a_buf   = (int16_t *)malloc(sizeof(int16_t) * (size_t)dst_w * (lum_last - lum_first + 1));
+    ap = (const int16_t **)malloc(sizeof(*ap) * c->v_lum_size);
     u_buf   = (int16_t *)malloc(sizeof(int16_t) * (size_t)cdw * (chr_last - chr_first + 1));
     v_buf   = (int16_t *)malloc(sizeof(int16_t) * (size_t)cdw * (chr_last - chr_first + 1));
     tmp     = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(c->src_w + 16));
@@ -891,11 +1013,13 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     lp = (const int16_t **)malloc(sizeof(*lp) * c->v_lum_size);
     up = (const int16_t **)malloc(sizeof(*up) * c->v_chr_size);
     vp = (const int16_t **)malloc(sizeof(*vp) * c->v_chr_size);
-    if (!lum_buf || !u_buf || !v_buf || !tmp || !tmp_u || !tmp_v || !lp || !up || !vp)
+    if (!lum_buf || !a_buf || !ap || !u_buf || !v_buf || !tmp || !tmp_u || !tmp_v || !lp || !up || !vp)
         goto done;
 
     for (y = lum_first; y <= lum_last; y++)
         lum_line(c, src, src_stride, y, lum_buf + (size_t)(y - lum_first) * dst_w, tmp);
+    for (y = lum_first; y <= lum_last && c->need_alpha; y++)
+        alpha_line(c, src, src_stride, y, a_buf + (size_t)(y - lum_first) * dst_w, tmp);
     for (y = chr_first; y <= chr_last; y++)
         chr_line(c, src, src_stride, y, u_buf + (size_t)(y - chr_first) * cdw,
                  v_buf + (size_t)(y - chr_first) * cdw, tmp_u, tmp_v);
@@ -906,6 +1030,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
             int r = c->v_lum_pos[y] + j;
             if (r >= c->src_h) r = c->src_h - 1;
             lp[j] = lum_buf + (size_t)(r - lum_first) * dst_w;
+            ap[j] = a_buf + (size_t)(r - lum_first) * dst_w;
         }
         for (j = 0; j < c->v_chr_size; j++) {
             int r = c->v_chr_pos[chr_y] + j;
@@ -914,7 +1039,7 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
             vp[j] = v_buf + (size_t)(r - chr_first) * cdw;
         }
         if (c->dst_is_rgb) {
-            out_packed_row(c, dst[0] + (long)y * dst_stride[0], y, lp, up, vp);
+            out_packed_row(c, dst[0] + (long)y * dst_stride[0], y, lp, up, vp, c->need_alpha ? ap : NULL);
         } else if (c->dst_fmt == ORC_PIX_YUV420P10LE) {
             out_pl10_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size, c->v_lum_size, lp);
             if (!(y & 1)) {
@@ -942,8 +1067,8 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
     }
     ret = y1 - y0;
 done:
-    free(lum_buf); free(u_buf); free(v_buf); free(tmp); free(tmp_u); free(tmp_v);
-    free((void *)lp); free((void *)up); free((void *)vp);
+    free(lum_buf); free(a_buf); free(u_buf); free(v_buf); free(tmp); free(tmp_u); free(tmp_v);
+    free((void *)lp); free((void *)up); free((void *)vp); free((void *)ap);
     return ret;
 }
 

@@ -366,6 +366,20 @@ void orc_median(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride
     }
 }
 
+/* planarCopyWrapper, 8-bit samples into a deeper planar format of the same layout (swscale_unscaled.c:1844-1862, COPY816):
+ * shiftonly = chroma planes, and luma of a limited-range source: v << (depth - 8); luma of a full-range source:
+ * v << (depth - 8) | v >> (16 - depth).  One plane per call. */
+void orc_plane_copy_up(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int depth, int shiftonly)
+{
+    int x, y;
+    for (y = 0; y < h; y++) {
+        const uint8_t *s = src + (long)y * src_stride;
+        uint16_t *d = (uint16_t *)(dst + (long)y * dst_stride);
+        for (x = 0; x < w; x++)
+            d[x] = (uint16_t)(shiftonly ? s[x] << (depth - 8) : (s[x] << (depth - 8)) | (s[x] >> (2 * 8 - depth)));
+    }
+}
+
 /* planar8ToP01xleWrapper, swscale_unscaled.c:286-324 */
 void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
                         const int dst_stride[4], int w, int h, int src_nv12)

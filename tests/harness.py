@@ -44,6 +44,8 @@ def load_oracle(path):
     L.orc_yuv420_to_p01x.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                      C.c_int, C.c_int, C.c_int]
     L.orc_rgb24_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_plane_copy_up.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_plane_copy_up.restype = None
     L.orc_gauss_blur.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_int]
     L.orc_median3x3.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -115,7 +115,6 @@ def test_product_fate_crop_scale(dev, clip):
 PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
        "p016le", "yuv444p16le", "rgba64le", "bgra64le",      # these four: destinations of the 19-bit path (k_scale16.hip)
        "yuv420p10le", "yuv420p16le"]                         # planar high-depth 4:2:0, sources and destinations
-NO_SRC = ("rgba64le", "bgra64le")                            # destinations only
 WIDE = ("rgba64le", "bgra64le")                              # 8-byte pixels: the pixel-permuting launchers take 1..4 bytes
 
 
@@ -147,6 +146,6 @@ def test_product_fate_pixfmts_filters(dev, converted, which, fmt):
         assert nut([filt(dev, which, fmt, f, W, H)], fmt, W, H) == GOLD["pixfmts"][which][fmt]
 
 
-@pytest.mark.parametrize("fmt", [f for f in PIX if f not in NO_SRC])
+@pytest.mark.parametrize("fmt", PIX)
 def test_product_fate_pixfmts_scale(dev, converted, fmt):
     assert nut([sws(dev, converted[fmt], fmt, W, H, fmt, 200, 100)], fmt, 200, 100) == GOLD["pixfmts"]["scale"][fmt]

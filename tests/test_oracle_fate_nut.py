@@ -66,11 +66,6 @@ def scale(L, src, sf, sw, sh, df, dw, dh):
         uv = np.zeros((src[1].shape[0], 2 * src[1].shape[1]), np.uint8)
         uv[:, 0::2], uv[:, 1::2] = src[1], src[2]
         return [src[0].copy(), uv]
-    if sf in ("rgba", "bgra"):
-        # rgb32ToY / rgb32ToUV read the three colour channels with the 24-bit readers' coefficients and ignore alpha
-        # (input.c:331-420 rgb16_32 templates): the same lines as the alpha-less twin gives
-        px = src[0].reshape(sh, sw, 4)[:, :, :3]
-        src, sf = [np.ascontiguousarray(px.reshape(sh, sw * 3))], {"rgba": "rgb24", "bgra": "bgr24"}[sf]
     dst = planes_of(df, dw, dh)
     P4, I4 = C.c_void_p * 4, C.c_int * 4
     if sf == "yuv420p" and (sw, sh) == (dw, dh) and df in ("p010le", "p016le"):     # planar8ToP01xleWrapper (swscale_unscaled.c:286-324)
@@ -167,7 +162,7 @@ def test_fate_filter_crop_scale(fate):
 PIX = ["yuv420p", "nv12", "rgb24", "bgr24", "rgba", "bgra", "yuv444p", "p010le",
        "p016le", "yuv444p16le", "rgba64le", "bgra64le",    # these four: libswscale's 19-bit lines (yuv2planeX_16_c, yuv2rgba64_X_c)
        "yuv420p10le", "yuv420p16le"]                       # planar high-depth 4:2:0: yuv2planeX_10_c / yuv2planeX_16_c per plane
-NO_SRC = ("rgba64le", "bgra64le")                          # destinations only (rgb64ToY_c is not restated): no fmt -> fmt scale row
+NO_SRC = ("rgba64le", "bgra64le")                          # vf_rotate has no 64-bit packed formats: no rotate row
 
 
 def converted(fate, fmt):
@@ -214,8 +209,9 @@ def test_fate_pixfmts_rotate(fate, fmt):
     assert nut([out], fmt, W, H) == GOLD["pixfmts"]["rotate"][fmt]
 
 
-@pytest.mark.parametrize("fmt", [f for f in PIX if f not in NO_SRC])
+@pytest.mark.parametrize("fmt", PIX)
 def test_fate_pixfmts_scale(fate, fmt):
-    """scale=200:100 in the converted format: the generic scaler fmt -> fmt (packed RGB through its YUV lines)"""
+    """scale=200:100 in the converted format: the generic scaler fmt -> fmt (packed RGB through its YUV lines; the formats with an
+    alpha channel — rgba, bgra, rgba64le, bgra64le — also scale their alpha plane: rgbaToA_c / rgba64leToA_c, needAlpha)"""
     L, f = converted(fate, fmt)
     assert nut([scale(L, f, fmt, W, H, fmt, 200, 100)], fmt, 200, 100) == GOLD["pixfmts"]["scale"][fmt]

@@ -681,19 +681,66 @@ def test_planar_high_depth_420_destinations_algorithms(dev, orc, flags):
             p.free()
 
 
-def test_full_range_planar_depth_expansion_is_refused(dev):
-    """same size, 8-bit planar -> high-depth planar: libswscale's planarCopyWrapper bit-replicates the luma of a FULL-range
-    source (swscale_unscaled.c:1789-1830); the generic lines shift.  Not built: -ENOSYS instead of a silent shift."""
-    lib = dev.lib
-    for sf, df in (("yuv420p", "yuv420p10le"), ("yuv420p", "yuv420p16le"), ("yuv444p", "yuv444p16le")):
-        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
-        assert c
-        assert lib.gmat_sws_setRange(c, 1, 1) == -38 and lib.gmat_sws_setRange(c, 1, 0) == -38
-        assert lib.gmat_sws_setRange(c, 0, 0) == 0
-        lib.gmat_sws_freeContext(c)
-        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 32, 16, PIX_FMT[df], SWS["bicubic"], None)     # scaled: the generic path in libswscale too
-        assert c and lib.gmat_sws_setRange(c, 1, 1) == 0
-        lib.gmat_sws_freeContext(c)
+@pytest.mark.parametrize("pair", [("yuv420p", "yuv420p10le"), ("yuv420p", "yuv420p16le"), ("yuv444p", "yuv444p16le")])
+def test_full_range_planar_depth_expansion(dev, orc, pair):
+    """same size, 8-bit planar -> high-depth planar with both ends full range: planarCopyWrapper (swscale_unscaled.c:1803-1862)
+    bit-replicates the luma (v << (d - 8) | v >> (16 - d)) and shifts the chroma; with both ends limited it shifts everything —
+    which the generic lines give too (pinned by the reference's filter-pixfmts md5s); with differing ranges libswscale leaves
+    the wrapper for the generic path (utils.c:1996-2000) and so does the context"""
+    import ctypes as C
+    from harness import alloc_planes, planes, ints
+    sf, df = pair
+    lib, w, h = dev.lib, 70, 34
+    depth = 10 if df.endswith("10le") else 16
+    orc.L.orc_sws_create_ex.restype = C.c_void_p
+    orc.L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    src = synth_planes(orc, sf, w, h, seed=77)
+    src[0][0, :16] = [0, 1, 15, 16, 17, 127, 128, 129, 200, 234, 235, 236, 253, 254, 255, 255]
+    want = alloc_planes(df, w, h)
+    for i, (s_, d_) in enumerate(zip(src, want)):
+        orc.L.orc_plane_copy_up(s_.ctypes.data, s_.strides[0], d_.ctypes.data, d_.strides[0], s_.shape[1], s_.shape[0], depth, int(i > 0))
+    shifted = [(s_.astype(np.uint16) << (depth - 8)).view(np.uint8).reshape(s_.shape[0], -1) for s_ in src]
+    assert not (want[0] == shifted[0]).all() and all((a == b).all() for a, b in zip(want[1:], shifted[1:]))
+    d = dev.upload_planes(src, 64)
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None)
+    assert c
+
+    def run():
+        dst = dev.planes_like(df, w, h, 64)
+        assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
+                                  planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
+        out = [p.download() for p in dst]
+        assert all((p.download(with_padding=True)[:, p.row_bytes:] == 0xCD).all() for p in dst)
+        for p in dst:
+            p.free()
+        return out, lib.gmat_sws_lastKernel(c).decode()
+
+    got, k0 = run()                                               # limited -> limited: the shift
+    assert all((g == wv).all() for g, wv in zip(got, shifted)) and k0 != "plane_copy_up_kernel"
+    assert lib.gmat_sws_setRange(c, 1, 1) == 0
+    got, k = run()
+    assert k == "plane_copy_up_kernel" and all((g == wv).all() for g, wv in zip(got, want))
+    if depth == 10:                                               # differing ranges: the generic lines carry the conversion
+        assert lib.gmat_sws_setRange(c, 1, 0) == 0
+        got, k = run()
+        oc = orc.L.orc_sws_create_ex(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(-513, -513, -513, -513), 1, 0)
+        assert oc
+        ow = alloc_planes(df, w, h)
+        assert orc.L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                   planes([p.ctypes.data for p in ow]), ints([p.strides[0] for p in ow])) == h
+        orc.L.orc_sws_free(oc)
+        assert k == k0 and all((g == wv).all() for g, wv in zip(got, ow))
+    else:                                                         # the 19-bit path has no range conversion: refused, not ignored
+        assert lib.gmat_sws_setRange(c, 1, 0) == -38
+    assert lib.gmat_sws_setRange(c, 0, 0) == 0
+    got, k = run()
+    assert k == k0 and all((g == wv).all() for g, wv in zip(got, shifted))
+    lib.gmat_sws_freeContext(c)
+    for p in d:
+        p.free()
+    c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 32, 16, PIX_FMT[df], SWS["bicubic"], None)     # scaled: the generic path in libswscale too
+    assert c and lib.gmat_sws_setRange(c, 1, 1) == 0 and lib.gmat_sws_lastKernel(c).decode() != "plane_copy_up_kernel"
+    lib.gmat_sws_freeContext(c)
 
 
 @pytest.mark.parametrize("fmt", ["p010le", "p016le"])
@@ -789,13 +836,20 @@ def test_rgb_scaled_into_yuv(dev, orc, src_fmt, dst_fmt, geom):
                                   ("yuv420p", 130, 34, 130, 34), ("yuv444p", 70, 22, 70, 22), ("rgba", 131, 35, 64, 17)])
 def test_32bit_rgb_sources(dev, orc, src_fmt, case):
     """RGBA / BGRA sources of the scaling and RGB -> YUV paths (swscale_cuda.c:34-44): rgb32ToY / ToUV read the same
-    three channels with the same coefficients as the 24-bit readers and ignore alpha, so the result must equal the
-    24-bit context's on the same pixels"""
+    three channels with the same coefficients as the 24-bit readers, so the colour channels must equal the 24-bit
+    context's on the same pixels; the source's alpha is dropped unless the destination has an alpha channel too, in
+    which case it is scaled as a plane of its own (needAlpha, utils.c:1902 — tests/test_parity_rgb64_src.py)"""
     df, sw, sh, dw, dh = case
     src24 = synth_planes(orc, "rgb24" if src_fmt == "rgba" else "bgr24", sw, sh, seed=85)
     alpha = orc.lcg((sh, sw), 86)
     src32 = [np.ascontiguousarray(np.concatenate([src24[0].reshape(sh, sw, 3), alpha.reshape(sh, sw, 1)], axis=2).reshape(sh, 4 * sw))]
-    want = orc.sws(src24, sw, sh, "rgb24" if src_fmt == "rgba" else "bgr24", dw, dh, df, SWS["bicubic"])
+    want24 = orc.sws(src24, sw, sh, "rgb24" if src_fmt == "rgba" else "bgr24", dw, dh, df, SWS["bicubic"])
+    want = orc.sws(src32, sw, sh, src_fmt, dw, dh, df, SWS["bicubic"])
+    if df in ("rgba", "bgra"):
+        assert (want[0].reshape(dh, dw, 4)[:, :, :3] == want24[0].reshape(dh, dw, 4)[:, :, :3]).all()
+        assert (want24[0].reshape(dh, dw, 4)[:, :, 3] == 255).all() and not (want[0].reshape(dh, dw, 4)[:, :, 3] == 255).all()
+    else:
+        assert all((a == b).all() for a, b in zip(want, want24))
     for align in (64, 1):
         d = dev.upload_planes(src32, align)
         got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, df, SWS["bicubic"], dst_align=align)
