@@ -17,12 +17,13 @@ orc = harness.load_oracle(os.path.join(ROOT, "oracle", "liborc.so"))
 lib = load() if hip else load(os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so"))
 dev = harness.Dev(lib, "hip" if hip else "emu")
 
-SRC = ["nv12", "yuv420p", "rgb24", "bgr24", "yuv444p"]          # 32-bit RGB sources: tests/test_parity_scale.py (they are the 24-bit contexts)
+SRC = ["nv12", "yuv420p", "rgb24", "bgr24", "yuv444p", "rgba", "bgra", "rgba64le", "bgra64le"]   # the four with alpha: their alpha plane is scaled into rgba / bgra / rgba64le / bgra64le
 ALGOS = ["bicubic", "bilinear", "lanczos", "point", "area"]
 fails = 0
 for case in range(n):
     sf = rng.choice(SRC)
     dsts = ["rgb24", "bgr24", "rgba", "bgra", "nv12", "yuv420p", "yuv444p"]
+    if sf in ("rgba64le", "bgra64le"): dsts += ["rgba64le", "bgra64le", "p016le", "yuv444p16le", "p010le"]
     df = rng.choice(dsts)
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     same = rng.random() < 0.25
@@ -32,6 +33,8 @@ for case in range(n):
     if rng.random() < 0.2: flags |= SWS["full_chr_h_int"]
     if rng.random() < 0.2: flags |= SWS["accurate_rnd"]
     align, extra = rng.choice([(256, 0), (64, 0), (16, 0), (4, 0), (1, 1), (1, 3), (2, 2)])
+    if ("64le" in sf or "16le" in df or "10le" in df or "64le" in df) and (align, extra) in ((1, 1), (1, 3)):
+        align, extra = 2, 2                       # 16-bit samples: rows on even addresses (anything else is -EINVAL)
     src = synth_planes(orc, sf, sw, sh, seed=1000 + case)
     c = orc.L.orc_sws_create(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], flags, None)
     if not c:
@@ -47,8 +50,10 @@ for case in range(n):
         want = [orc.yuv2rgb(src, sw, sh, sf, df)]
     elif same and sf in ("nv12", "yuv420p") and df in ("nv12", "yuv420p"):
         continue                                  # lossless re-layout, covered elsewhere
-    elif same and sf in ("rgb24", "bgr24") and df in ("rgb24", "bgr24", "rgba", "bgra"):
+    elif same and sf in ("rgb24", "bgr24", "rgba", "bgra") and df in ("rgb24", "bgr24", "rgba", "bgra"):
         continue                                  # copies / swaps, covered elsewhere
+    elif same and sf == df:
+        continue                                  # the plain copy
     else:
         want = orc.sws(src, sw, sh, sf, dw, dh, df, flags)
     d = dev.upload_planes(src, align, extra)
