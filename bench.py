@@ -563,6 +563,15 @@ def c_harness(dry):
         res["filters, one 4K frame per launch"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]
     except Exception as e:                                   # noqa: BLE001
         res["filters, one 4K frame per launch"] = [{"error": repr(e)}]
+    # the same calls with two / three frames in flight (launches round-robin over that many streams, as `value` has its launch
+    # sets): a launch boundary costs 1.6 us + the ramp of a 50 MB kernel, which a second stream hides (profiles/r03r_*)
+    for n in (2, 3):
+        key = "filters, one 4K frame per launch, %d frames in flight" % n
+        try:
+            r = subprocess.run([exe, "1", "50", "op: "], env=dict(env, X2BENCH_OP_STREAMS=str(n)), capture_output=True, text=True, timeout=300)
+            res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]
+        except Exception as e:                               # noqa: BLE001
+            res[key] = [{"error": repr(e)}]
     return res
 
 

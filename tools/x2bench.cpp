@@ -176,8 +176,14 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         CK(gmat_memcpy_h2d(src[i], host.data(), nb)); CK(gmat_memset(dst[i], 0, nb));
     }
     void *stream = nullptr; CK(gmat_stream_create(&stream));
+    // X2BENCH_OP_STREAMS=n: launches round-robin over n streams (n - 1 extra ones joined to `stream` by events around the timed
+    // region) — what a caller with n frames in flight sees; 1 (default) = filter_frame()'s one frame per call on one stream
+    const int nstreams = getenv("X2BENCH_OP_STREAMS") ? std::max(1, std::min(8, atoi(getenv("X2BENCH_OP_STREAMS")))) : 1;
+    std::vector<void *> xs(nstreams, stream);
+    for (int k = 1; k < nstreams; k++) CK(gmat_stream_create(&xs[k]));
     const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
     auto launch = [&](int i) {
+        void *stream = xs[i % nstreams];
         switch (op) {
         case 0: CK(gmat_rotate_flip_smooth(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, stream)); break;
         case 1: CK(gmat_smooth3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, m, 1.0f / 16, 0.0f, stream)); break;
@@ -186,14 +192,20 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         case 4: CK(gmat_median3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, stream)); break;
         }
     };
+    auto sync_all = [&] { for (void *x : xs) CK(gmat_stream_sync(x)); };
     for (int i = 0; i < NSET; i++) launch(i);
-    CK(gmat_stream_sync(stream));
-    prewarm([&](int i) { launch(i % NSET); }, [&] { CK(gmat_stream_sync(stream)); });
+    sync_all();
+    prewarm([&](int i) { launch(i % NSET); }, sync_all);
     void *timer = nullptr; CK(gmat_timer_create(&timer));
+    std::vector<void *> ev(nstreams, nullptr);
+    for (int k = 1; k < nstreams; k++) CK(gmat_event_create(&ev[k]));
     float best = 1e30f;
     for (int r = 0; r < 3; r++) {
+        sync_all();
         CK(gmat_timer_begin(timer, stream));
+        if (nstreams > 1) { void *e0 = nullptr; CK(gmat_event_create(&e0)); CK(gmat_event_record(e0, stream)); for (int k = 1; k < nstreams; k++) CK(gmat_stream_wait_event(xs[k], e0)); gmat_event_destroy(e0); }
         for (int i = 0; i < launches; i++) launch(i % NSET);
+        for (int k = 1; k < nstreams; k++) { CK(gmat_event_record(ev[k], xs[k])); CK(gmat_stream_wait_event(stream, ev[k])); }
         CK(gmat_timer_end(timer, stream));
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
         best = ms < best ? ms : best;
@@ -205,7 +217,9 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
     else
     printf("%-34s %8.2f us/frame %8.1f GB/s  frac %.3f\n", label, us, gbs, gbs / 8000.0);
     fflush(stdout);
-    gmat_timer_destroy(timer); gmat_stream_destroy(stream);
+    gmat_timer_destroy(timer);
+    for (int k = 1; k < nstreams; k++) { gmat_event_destroy(ev[k]); gmat_stream_destroy(xs[k]); }
+    gmat_stream_destroy(stream);
     for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); }
 }
 
