@@ -11,6 +11,7 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "px_math.h"
 
 namespace gmat {
 
@@ -1180,11 +1181,23 @@ __device__ __forceinline__ void rot_cubic_w(int f, int (&w)[4])
     w[2] = 16384 - w[0] - w[1] - w[3];
 }
 
-template <int BPP>
+// The direct form (gathers from global memory; the fallback for sources that are not dword-aligned): a wave covers a compact patch of
+// the output — LX lanes across (4 pixels each) by 64 / LX rows — so that the source pixels its lanes gather lie in a small rotated
+// rectangle instead of along a slanted line 256 pixels long that crosses 75 source rows (round 2: 49 us per 4K rgb24 frame at 17
+// degrees; so: 42).  Blocks are numbered so that each XCD walks a contiguous eighth of the tiles.
+template <int BPP, int LX, int INTERP>
 __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
-                                                     int aligned)
+                                                     int aligned, int nbx, int nby)
 {
-    const int i0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    constexpr int WR = 64 / LX;                             // rows a wave covers
+    int t = blockIdx.x;
+    {
+        const int nt = nbx * nby, chunk = (nt + 7) >> 3;
+        t = (t & 7) * chunk + (t >> 3);
+        if (t >= nt) return;
+    }
+    const int bx = t % nbx, by = t / nbx, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (bx * LX + (lane % LX)) * 4, j = (by * 4 + wave) * WR + lane / LX;
     if (i0 >= p.outW || j >= p.outH) return;
     uint8_t o[4 * BPP];
     bool valid[4];
@@ -1198,7 +1211,7 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
         if (!valid[q]) {
 #pragma unroll
             for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
-        } else if (p.bilinear == 2) {
+        } else if (INTERP == 2) {
             // 4 x 4 Catmull-Rom, clamped indices, rows first, 64-bit vertical sum
             int wx[4], wy[4];
             rot_cubic_w((x & 0xFFFF) >> 8, wx); rot_cubic_w((y & 0xFFFF) >> 8, wy);
@@ -1225,7 +1238,7 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
                 const long long r = (v[k] + (1LL << 27)) >> 28;
                 o[q * BPP + k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
             }
-        } else if (p.bilinear) {
+        } else if (INTERP == 1) {
             const int fx = x & 0xFFFF, fy = y & 0xFFFF;
             const int ix1 = min(ix + 1, p.inW - 1), iy1 = min(iy + 1, p.inH - 1);
             const uint8_t *r0 = src + (size_t)iy * ss, *r1 = src + (size_t)iy1 * ss;
@@ -1246,9 +1259,14 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
                 } else {
                     s00 = r0[BPP * ix + k]; s01 = r0[BPP * ix1 + k]; s10 = r1[BPP * ix + k]; s11 = r1[BPP * ix1 + k];
                 }
-                const int s0 = ((1 << 16) - fx) * s00 + fx * s01;
-                const int s1 = ((1 << 16) - fx) * s10 + fx * s11;
-                o[q * BPP + k] = (uint8_t)(((long long)((1 << 16) - fy) * s0 + (long long)fy * s1) >> 32);
+                // interpolate_bilinear8 (vf_rotate.c:224-249): s0 = (2^16 - fx) * s00 + fx * s01, s1 alike, out = ((2^16 - fy) * s0 + fy * s1)
+                // >> 32 in 64 bits — evaluated exactly without 64-bit arithmetic: s0 = s00 * 2^16 + fx * (s01 - s00) (a 24-bit multiply),
+                // and of the 41-bit product fy * (s1 - s0) only the part above bit 16 is needed (the low 16 bits it drops cannot carry
+                // into bit 32 of the sum): for the signed 25-bit D = s1 - s0, floor(fy * D / 2^16) = mulhi(fy << 16, D + 2^24) - fy * 2^8
+                const int s0 = (s00 << 16) + m24(fx, s01 - s00);
+                const int s1 = (s10 << 16) + m24(fx, s11 - s10);
+                const int ph = (int)__umulhi((unsigned)fy << 16, (unsigned)(s1 - s0 + (1 << 24))) - (fy << 8);
+                o[q * BPP + k] = (uint8_t)((s0 + ph) >> 16);
             }
         } else {
             const uint8_t *ps = src + (size_t)iy * ss + BPP * ix;
@@ -1261,6 +1279,155 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
 #pragma unroll
                 for (int k = 0; k < BPP; k++) o[q * BPP + k] = ps[k];
             }
+        }
+    }
+    uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
+    const int nx = min(4, p.outW - i0);
+    const bool all = p.fillEnable || (valid[0] && valid[1] && valid[2] && valid[3]);
+    if (aligned && nx == 4 && all) {
+        unsigned w[BPP];
+#pragma unroll
+        for (int k = 0; k < BPP; k++)
+            w[k] = (unsigned)o[4 * k] | ((unsigned)o[4 * k + 1] << 8) | ((unsigned)o[4 * k + 2] << 16) | ((unsigned)o[4 * k + 3] << 24);
+#pragma unroll
+        for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = w[k];
+    } else {
+        for (int q = 0; q < nx; q++)
+            if (p.fillEnable || valid[q])
+                for (int k = 0; k < BPP; k++) d[q * BPP + k] = o[q * BPP + k];
+    }
+}
+
+// ---- the same walk with the source patch staged in LDS (round 3) ------------------------------------------------------------
+// A block of 256 threads makes a 32 x 32 output tile: the source pixels its taps can touch lie in the bounding box of the tile's four
+// corners (an affine map: the extremes are at the corners), at most 48 x 48 pixels at any angle; the box is loaded row by row with
+// coalesced dword loads into LDS (dword-aligned start: `shift` bytes of lead-in, odd dword pitch) and every tap is read from there.
+// The box is computed on CLAMPED coordinates — every tap index the walk forms is clamped to the image first (vf_rotate.c:463-492) — so
+// it lies inside the image and the loads need no border case.  Arithmetic: rotate_kernel's, tap for tap.  Measured per 4K rgb24 frame
+// at 17 degrees (profiles/r03t_*): bilinear 42 -> 30 us, cubic 312 -> 77 us, nearest 22 -> 22 us.  Tried and slower: walking several
+// tiles per block with the next box requested ahead (35-48 us: the chip overlaps independent blocks better than one block overlaps
+// its own tiles), gathering aligned dwords in the direct form (45 us).
+template <int BPP, int INTERP>
+__global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
+                                                         int aligned, int nbx, int nby)
+{
+    constexpr int TW = 32, TBH = 32, BMAX = 50;
+    constexpr int PD = ((BMAX * BPP + 6) / 4) | 1;          // dwords per LDS row: 50 pixels + lead-in, odd
+    __shared__ unsigned box[BMAX * PD];
+    int t = blockIdx.x;
+    {
+        const int nt = nbx * nby, chunk = (nt + 7) >> 3;
+        t = (t & 7) * chunk + (t >> 3);
+        if (t >= nt) return;
+    }
+    const int bx = t % nbx, by = t / nbx, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iLo = bx * TW, iHi = min(iLo + TW, p.outW) - 1, jLo = by * TBH, jHi = min(jLo + TBH, p.outH) - 1;
+    int minx = 0x7FFFFFFF, maxx = -0x7FFFFFFF - 1, miny = minx, maxy = maxx;
+#pragma unroll
+    for (int cn = 0; cn < 4; cn++) {
+        const int i = (cn & 1) ? iHi : iLo, j = (cn & 2) ? jHi : jLo;
+        const int x1 = (p.X0 + j * p.s + i * p.c) >> 16, y1 = (p.Y0 + j * p.c - i * p.s) >> 16;
+        minx = min(minx, x1); maxx = max(maxx, x1); miny = min(miny, y1); maxy = max(maxy, y1);
+    }
+    // cubic taps are clamp(x1 - 1 + t), t = 0..3; the bilinear pair is clamp(x1) and min(clamp(x1) + 1, W - 1) — the clamp comes FIRST
+    // (x1 = -1 reads pixels 0 and 1), so the box ends one past the clamped maximum
+    constexpr bool cubic = INTERP == 2;
+    const int bx0 = min(max(minx - (cubic ? 1 : 0), 0), p.inW - 1), by0 = min(max(miny - (cubic ? 1 : 0), 0), p.inH - 1);
+    const int bx1 = cubic ? min(max(maxx + 2, 0), p.inW - 1) : min(min(max(maxx, 0), p.inW - 1) + 1, p.inW - 1);
+    const int by1 = cubic ? min(max(maxy + 2, 0), p.inH - 1) : min(min(max(maxy, 0), p.inH - 1) + 1, p.inH - 1);
+    const int bh = by1 - by0 + 1, shift = (bx0 * BPP) & 3, gd0 = (bx0 * BPP) >> 2;
+    const int nDw = (shift + (bx1 - bx0 + 1) * BPP + 3) >> 2, rowBytes = p.inW * BPP;
+    {   // a wave loads rows wave, wave + 4, ...: every load is issued before the first LDS store (one memory latency, not thirteen)
+        constexpr int NR = (BMAX + 3) / 4;
+        unsigned v[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = wave + 4 * k;
+            v[k] = 0;
+            if (r < bh && lane < nDw) {
+                const uint8_t *g = src + (size_t)(by0 + r) * ss + 4 * (size_t)(gd0 + lane);
+                if (4 * (gd0 + lane) + 4 <= rowBytes || by0 + r < p.inH - 1) v[k] = *reinterpret_cast<const unsigned *>(g);
+                else                                        // the last dword of the last row: no byte past the frame is touched
+                    for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) v[k] |= (unsigned)g[b] << (8 * b);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = wave + 4 * k;
+            if (r < bh && lane < nDw) box[r * PD + lane] = v[k];
+        }
+    }
+    __syncthreads();
+    const int i0 = iLo + (lane & 7) * 4, j = jLo + wave * 8 + (lane >> 3);
+    if (i0 >= p.outW || j >= p.outH) return;
+    auto bytes8 = [&](int iy, int ix) -> unsigned long long {      // the 8 bytes from pixel (ix, iy) on
+        const int bo = (ix - bx0) * BPP + shift, d = bo >> 2;
+        const unsigned *row = box + (iy - by0) * PD;
+        const unsigned w0 = row[d], w1 = row[min(d + 1, PD - 1)], w2 = row[min(d + 2, PD - 1)];
+        const int sh = 8 * (bo & 3);
+        const unsigned long long lo = ((unsigned long long)w1 << 32) | w0;
+        return sh ? (lo >> sh) | ((unsigned long long)w2 << (64 - sh)) : lo;
+    };
+    auto byte1 = [&](int iy, int ix, int k) -> int {
+        const int bo = (ix - bx0) * BPP + shift + k;
+        return (int)((box[(iy - by0) * PD + (bo >> 2)] >> (8 * (bo & 3))) & 0xFF);
+    };
+    uint8_t o[4 * BPP];
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + q;
+        const int x = p.X0 + j * p.s + i * p.c, y = p.Y0 + j * p.c - i * p.s;
+        const int x1 = x >> 16, y1 = y >> 16;
+        valid[q] = x1 >= -1 && x1 <= p.inW && y1 >= -1 && y1 <= p.inH;
+        const int ix = min(max(x1, 0), p.inW - 1), iy = min(max(y1, 0), p.inH - 1);
+        if (!valid[q] || i >= p.outW) {                     // (a pixel past the frame's last column has no taps in the box)
+#pragma unroll
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
+        } else if (INTERP == 2) {
+            int wx[4], wy[4];
+            rot_cubic_w((x & 0xFFFF) >> 8, wx); rot_cubic_w((y & 0xFFFF) >> 8, wy);
+            long long acc[BPP];
+#pragma unroll
+            for (int k = 0; k < BPP; k++) acc[k] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ry = min(max(y1 - 1 + r, 0), p.inH - 1);
+                int hsum[BPP];
+#pragma unroll
+                for (int k = 0; k < BPP; k++) hsum[k] = 0;
+#pragma unroll
+                for (int tt = 0; tt < 4; tt++) {
+                    const int rx = min(max(x1 - 1 + tt, 0), p.inW - 1);
+#pragma unroll
+                    for (int k = 0; k < BPP; k++) hsum[k] += wx[tt] * byte1(ry, rx, k);
+                }
+#pragma unroll
+                for (int k = 0; k < BPP; k++) acc[k] += (long long)wy[r] * hsum[k];
+            }
+#pragma unroll
+            for (int k = 0; k < BPP; k++) {
+                const long long r = (acc[k] + (1LL << 27)) >> 28;
+                o[q * BPP + k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+        } else if (INTERP == 1) {
+            const int fx = x & 0xFFFF, fy = y & 0xFFFF;
+            const int iy1 = min(iy + 1, p.inH - 1);
+            const bool pair = ix + 1 <= p.inW - 1;          // else the right tap is the left one again
+            const unsigned long long t0 = bytes8(iy, ix), t1 = bytes8(iy1, ix);
+#pragma unroll
+            for (int k = 0; k < BPP; k++) {
+                const int s00 = (int)((t0 >> (8 * k)) & 0xFF), s10 = (int)((t1 >> (8 * k)) & 0xFF);
+                const int s01 = pair ? (int)((t0 >> (8 * (k + BPP))) & 0xFF) : s00, s11 = pair ? (int)((t1 >> (8 * (k + BPP))) & 0xFF) : s10;
+                const int s0 = (s00 << 16) + m24(fx, s01 - s00);          // exact without 64-bit arithmetic: see rotate_kernel
+                const int s1 = (s10 << 16) + m24(fx, s11 - s10);
+                const int ph = (int)__umulhi((unsigned)fy << 16, (unsigned)(s1 - s0 + (1 << 24))) - (fy << 8);
+                o[q * BPP + k] = (uint8_t)((s0 + ph) >> 16);
+            }
+        } else {
+            const unsigned long long t0 = bytes8(iy, ix);
+#pragma unroll
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(t0 >> (8 * k));
         }
     }
     uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
@@ -1316,14 +1483,40 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     p.inW = inW; p.inH = inH; p.outW = outW; p.outH = outH;
     p.bilinear = bilinear; p.fillEnable = fill != nullptr; p.fill = 0;
     for (int k = 0; k < bpp && fill; k++) p.fill |= (unsigned)fill[k] << (8 * k);
-    const dim3 grid((outW + 255) / 256, (outH + 3) / 4), block(256);
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
-    switch (bpp) {
-    case 1: hipLaunchKernelGGL(rotate_kernel<1>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
-    case 2: hipLaunchKernelGGL(rotate_kernel<2>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
-    case 3: hipLaunchKernelGGL(rotate_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
-    default: hipLaunchKernelGGL(rotate_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, p, aligned); break;
+    // the source patch staged in LDS whenever the source rows are dword-aligned; GMAT_ROTATE_LDS=0 forces the direct form (A/B)
+    const char *el = GMAT_KNOB("GMAT_ROTATE_LDS");
+    const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && (int64_t)ss * inH < (1ll << 31);
+    if (lds) {
+        const int nbx = (outW + 31) / 32, nby = (outH + 31) / 32;
+        const dim3 grid(8 * ((nbx * nby + 7) / 8)), block(256);
+#define GMAT_ROTL(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
+                           else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
+                           else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 0>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); } while (0)
+        switch (bpp) {
+        case 1:  GMAT_ROTL(1); break;
+        case 2:  GMAT_ROTL(2); break;
+        case 3:  GMAT_ROTL(3); break;
+        default: GMAT_ROTL(4); break;
+        }
+#undef GMAT_ROTL
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
     }
+    constexpr int lx = 16;                                   // lanes across a wave's patch: 64 pixels x 4 rows
+    const int tw = 4 * lx, tbh = 4 * (64 / lx);
+    const int nbx = (outW + tw - 1) / tw, nby = (outH + tbh - 1) / tbh;
+    const dim3 grid(8 * ((nbx * nby + 7) / 8)), block(256);
+#define GMAT_ROT(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
+                          else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 1>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
+                          else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 0>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); } while (0)
+    switch (bpp) {
+    case 1: GMAT_ROT(1); break;
+    case 2: GMAT_ROT(2); break;
+    case 3: GMAT_ROT(3); break;
+    default: GMAT_ROT(4); break;
+    }
+#undef GMAT_ROT
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -621,6 +621,30 @@ def test_rotate_interp_and_shift_match_the_stated_rule(dev, orc, case, bpp):
     d.free(); o.free()
 
 
+@pytest.mark.parametrize("lds", ["0", "1"])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp):
+    """rotate_lds_kernel (source patch in LDS: shipped for cubic) and rotate_kernel (direct gathers: nearest, linear), each forced on
+    every interpolation, on frames several 32 x 32 tiles large whose rotated image leaves the source on all sides — the walk clamps a
+    tap index BEFORE it forms the neighbour's (x1 = -1 reads pixels 0 and 1, vf_rotate.c:463-492), which the patch's bounding box has to
+    follow (a 3-in-1000 fuzz find of round 3) — with sizes one off the tile grid and a source pitch that is not the row length"""
+    monkeypatch.setenv("GMAT_ROTATE_LDS", lds)
+    fill = (C.c_uint8 * 4)(1, 2, 3, 4)
+    for (w, h, bpp, deg, sx, sy) in [(113, 179, 4, 143.7, 0.0, 0.0), (283, 167, 2, 17.0, 0.0, 0.0), (258, 175, 1, -61.3, 0.0, 0.0),
+                                     (230, 130, 3, 100.9, 0.0, 0.0), (195, 69, 3, 271.25, 0.0, 0.0), (97, 65, 3, 45.0, 40.5, -20.25),
+                                     (64, 64, 4, 7.5, -3.0, 2.0), (33, 31, 1, 333.0, 0.0, 0.0)]:
+        src = orc.lcg((h, w * bpp), 60 + bpp)
+        d = dev.upload_planes([src], 4, 4)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + 19) // 4 * 4)
+        assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fill, None) == 0
+        want = np.zeros_like(src)
+        orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fill)
+        got = o.download()
+        assert (got == want).all(), ((w, h, bpp, deg), np.argwhere(got != want)[:4].tolist())
+        assert (o.download(with_padding=True)[:, w * bpp:] == 0xCD).all()
+        d.free(); o.free()
+
+
 def test_rotate_filter_honours_interp_and_shift(dev, orc):
     """through the filter: rotate_hip angle=17:interp=cubic:shift_x=6:shift_y=-2.5 on rgb24, and on nv12 (chroma planes move by half)"""
     w, h = 96, 40

@@ -190,6 +190,9 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         case 2: CK(gmat_transpose(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, 0, stream)); break;
         case 3: CK(gmat_flip(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, 1, stream)); break;
         case 4: CK(gmat_median3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, stream)); break;
+        case 5: CK(gmat_rotate(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 1, nullptr, stream)); break;
+        case 6: CK(gmat_rotate2(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 2, 0.0, 0.0, nullptr, stream)); break;
+        case 7: CK(gmat_rotate(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 0, nullptr, stream)); break;
         }
     };
     auto sync_all = [&] { for (void *x : xs) CK(gmat_stream_sync(x)); };
@@ -289,7 +292,9 @@ int main(int argc, char **argv)
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
                       {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3},
                       {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2},
-                      {"op: median3x3 4K rgb24", 4, 3}, {"op: median3x3 4K gray", 4, 1}};
+                      {"op: median3x3 4K rgb24", 4, 3}, {"op: median3x3 4K gray", 4, 1},
+                      {"op: rotate 17 deg bilinear 4K rgb24", 5, 3}, {"op: rotate 17 deg bilinear 4K gray", 5, 1},
+                      {"op: rotate 17 deg cubic 4K rgb24", 6, 3}, {"op: rotate 17 deg nearest 4K rgb24", 7, 3}};
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
     for (const Case &k : cases) {
