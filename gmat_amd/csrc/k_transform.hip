@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
                                                          int aligned, int nbx, int nby)
 {
     constexpr int TW = 32, TBH = 32, BMAX = 50;
-    constexpr int PD = ((BMAX * BPP + 6) / 4) | 1;          // dwords per LDS row: 50 pixels + lead-in, odd
+    constexpr int PD = ((BMAX * BPP + 6) / 4 + 2) | 1;      // dwords per LDS row: 50 pixels + lead-in + the two dwords an 8-byte read may run over, odd
     __shared__ unsigned box[BMAX * PD];
     int t = blockIdx.x;
     {
@@ -1339,34 +1339,38 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
     const int nDw = (shift + (bx1 - bx0 + 1) * BPP + 3) >> 2, rowBytes = p.inW * BPP;
     {   // a wave loads rows wave, wave + 4, ...: every load is issued before the first LDS store (one memory latency, not thirteen)
         constexpr int NR = (BMAX + 3) / 4;
+        // the dword that holds the frame's last bytes may reach past the last row's end: that one lane of that one row reads bytes
+        const bool tailRow = by1 == p.inH - 1 && 4 * (gd0 + nDw) > rowBytes;
+        const int nFull = tailRow ? nDw - 1 : nDw;          // block-uniform
         unsigned v[NR];
+        const uint8_t *g = src + (size_t)by0 * ss + 4 * (size_t)(gd0 + lane);
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const int r = wave + 4 * k;
             v[k] = 0;
-            if (r < bh && lane < nDw) {
-                const uint8_t *g = src + (size_t)(by0 + r) * ss + 4 * (size_t)(gd0 + lane);
-                if (4 * (gd0 + lane) + 4 <= rowBytes || by0 + r < p.inH - 1) v[k] = *reinterpret_cast<const unsigned *>(g);
-                else                                        // the last dword of the last row: no byte past the frame is touched
-                    for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) v[k] |= (unsigned)g[b] << (8 * b);
-            }
+            if (r < bh && lane < (r == bh - 1 ? nFull : nDw)) v[k] = *reinterpret_cast<const unsigned *>(g + (size_t)r * ss);
         }
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const int r = wave + 4 * k;
             if (r < bh && lane < nDw) box[r * PD + lane] = v[k];
         }
+        if (tailRow && lane == nDw - 1 && ((bh - 1) & 3) == wave) {
+            const uint8_t *gt = g + (size_t)(bh - 1) * ss;
+            unsigned t = 0;
+            for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) t |= (unsigned)gt[b] << (8 * b);
+            box[(bh - 1) * PD + lane] = t;                  // after this wave's own store of the same word (LDS keeps a wave's order)
+        }
     }
     __syncthreads();
     const int i0 = iLo + (lane & 7) * 4, j = jLo + wave * 8 + (lane >> 3);
     if (i0 >= p.outW || j >= p.outH) return;
-    auto bytes8 = [&](int iy, int ix) -> unsigned long long {      // the 8 bytes from pixel (ix, iy) on
+    auto bytes8 = [&](int iy, int ix, unsigned &lo, unsigned &hi) {     // the 8 bytes from pixel (ix, iy) on: two v_alignbyte_b32
         const int bo = (ix - bx0) * BPP + shift, d = bo >> 2;
         const unsigned *row = box + (iy - by0) * PD;
-        const unsigned w0 = row[d], w1 = row[min(d + 1, PD - 1)], w2 = row[min(d + 2, PD - 1)];
-        const int sh = 8 * (bo & 3);
-        const unsigned long long lo = ((unsigned long long)w1 << 32) | w0;
-        return sh ? (lo >> sh) | ((unsigned long long)w2 << (64 - sh)) : lo;
+        const unsigned w0 = row[d], w1 = row[d + 1], w2 = row[d + 2];
+        lo = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)bo & 3u);
+        hi = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)bo & 3u);
     };
     auto byte1 = [&](int iy, int ix, int k) -> int {
         const int bo = (ix - bx0) * BPP + shift + k;
@@ -1376,15 +1380,15 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
     bool valid[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int i = i0 + q;
+        // no branch per pixel: an invalid pixel is interpolated like any other (its clamped taps are in the box: the corners' extremes
+        // cover every pixel of the tile) and replaced by the fill colour afterwards; a pixel past the frame's last column borrows
+        // the last one's coordinates
+        const int i = min(i0 + q, iHi);
         const int x = p.X0 + j * p.s + i * p.c, y = p.Y0 + j * p.c - i * p.s;
         const int x1 = x >> 16, y1 = y >> 16;
         valid[q] = x1 >= -1 && x1 <= p.inW && y1 >= -1 && y1 <= p.inH;
         const int ix = min(max(x1, 0), p.inW - 1), iy = min(max(y1, 0), p.inH - 1);
-        if (!valid[q] || i >= p.outW) {                     // (a pixel past the frame's last column has no taps in the box)
-#pragma unroll
-            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
-        } else if (INTERP == 2) {
+        if (INTERP == 2) {
             int wx[4], wy[4];
             rot_cubic_w((x & 0xFFFF) >> 8, wx); rot_cubic_w((y & 0xFFFF) >> 8, wy);
             long long acc[BPP];
@@ -1413,21 +1417,33 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
         } else if (INTERP == 1) {
             const int fx = x & 0xFFFF, fy = y & 0xFFFF;
             const int iy1 = min(iy + 1, p.inH - 1);
-            const bool pair = ix + 1 <= p.inW - 1;          // else the right tap is the left one again
-            const unsigned long long t0 = bytes8(iy, ix), t1 = bytes8(iy1, ix);
+            unsigned a0, a1, b0, b1;
+            bytes8(iy, ix, a0, a1); bytes8(iy1, ix, b0, b1);
+            if (ix + 1 > p.inW - 1) {                       // the last column: the right tap is the left one again
+                const unsigned m = BPP == 4 ? 0u : (1u << (8 * BPP)) - 1u;
+                if (BPP == 4) { a1 = a0; b1 = b0; }
+                else { a1 = (a0 & m) >> (8 * (4 - BPP)); b1 = (b0 & m) >> (8 * (4 - BPP)); a0 = (a0 & m) | (a0 << (8 * BPP)); b0 = (b0 & m) | (b0 << (8 * BPP)); }
+            }
 #pragma unroll
             for (int k = 0; k < BPP; k++) {
-                const int s00 = (int)((t0 >> (8 * k)) & 0xFF), s10 = (int)((t1 >> (8 * k)) & 0xFF);
-                const int s01 = pair ? (int)((t0 >> (8 * (k + BPP))) & 0xFF) : s00, s11 = pair ? (int)((t1 >> (8 * (k + BPP))) & 0xFF) : s10;
+                const int k1 = k + BPP;                     // byte index of the right tap's channel
+                const int s00 = (int)((a0 >> (8 * k)) & 0xFF), s10 = (int)((b0 >> (8 * k)) & 0xFF);
+                const int s01 = (int)(((k1 < 4 ? a0 >> (8 * (k1 & 3)) : a1 >> (8 * (k1 & 3)))) & 0xFF);
+                const int s11 = (int)(((k1 < 4 ? b0 >> (8 * (k1 & 3)) : b1 >> (8 * (k1 & 3)))) & 0xFF);
                 const int s0 = (s00 << 16) + m24(fx, s01 - s00);          // exact without 64-bit arithmetic: see rotate_kernel
                 const int s1 = (s10 << 16) + m24(fx, s11 - s10);
                 const int ph = (int)__umulhi((unsigned)fy << 16, (unsigned)(s1 - s0 + (1 << 24))) - (fy << 8);
                 o[q * BPP + k] = (uint8_t)((s0 + ph) >> 16);
             }
         } else {
-            const unsigned long long t0 = bytes8(iy, ix);
+            unsigned a0, a1;
+            bytes8(iy, ix, a0, a1);
 #pragma unroll
-            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(t0 >> (8 * k));
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(a0 >> (8 * k));
+        }
+        if (!valid[q]) {
+#pragma unroll
+            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
         }
     }
     uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;

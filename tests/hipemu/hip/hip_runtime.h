@@ -101,6 +101,8 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu::cvt_pk_i16(a, b)
 #define __builtin_amdgcn_udot4(a, b, c, clamp) hipemu::udot4(a, b, c)
 static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+// v_alignbyte_b32: ({hi, lo} >> (8 * (sh & 3))) & 0xFFFFFFFF
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3))); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
