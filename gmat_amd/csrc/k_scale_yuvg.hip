@@ -199,12 +199,20 @@ struct GStream {
     }
 };
 
-// occupancy hint: the first build allocated 120 VGPRs (4 waves per SIMD) mostly for hoisted byte-pair temporaries
+// occupancy hint.  G_WAVES = -1 (default): the instances with one dword of a row per lane (P <= 6) are compiled for 5 waves a SIMD —
+// same-box A/B (profiles/r03u_waves5.txt): 4K -> 900p rgb24 0.372 -> 0.389, -> 768p 0.399 -> 0.408, 1080p -> 480p 0.295 -> 0.316, the
+// others within 1 %; the 2-12 dwords this spills sit outside the row loop.  Forcing 5 waves on the two-dword instances (Lanczos)
+// spills inside it (32 us per frame): they stay as the compiler allocates them.  G_WAVES = n > 0: n waves for every instance (A/B).
 #ifndef G_WAVES
-#define G_WAVES 0
+#define G_WAVES -1
 #endif
-#if G_WAVES > 0
+#if !defined(__HIP__)
+#define G_WAVES_ATTR                                          // (the CPU emulation of HIP compiles this file as plain C++)
+#elif G_WAVES > 0
 #define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_WAVES)))
+#elif G_WAVES < 0
+// one dword of a row per lane (P <= 6: ratios up to 3.7:1 with 4-tap algorithms): 94-100 VGPRs as compiled, 5 waves a SIMD fit in 96
+#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(P <= 6 ? 5 : 1)))
 #else
 #define G_WAVES_ATTR
 #endif
