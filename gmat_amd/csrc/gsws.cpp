@@ -224,7 +224,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if (c->rgbViaPlanes) {
         a.src16 = 3; a.hShift = 13; a.hBias = 0;         // hScale16To15_c: sh = 13 for RGB sources (swscale.c:93-119)
         a.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24; a.chrHalf = c->planYuv.chrSrcHSub;
-        a.r2y = make_rgb2yuv_consts(c->colorspace);
+        a.r2y = make_rgb2yuv_consts(is_packed_rgb(c->dstFormat) ? GMAT_SWS_CS_DEFAULT : c->colorspace);
     }
     if (pl16_depth(c->srcFormat) == 16) { a.src16 = 17; a.hShift = 15; a.hBias = 1 << 29; }     // planar, any chroma subsampling
     if (pl16_depth(c->srcFormat) == 10) { a.src16 = 18; a.hShift = 9; a.hBias = 0; }            // 10 bits in the low end: as they are
@@ -451,7 +451,8 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
                         (dnv ? ((((uintptr_t)dst[1] | (uintptr_t)dstStride[1]) & 7) == 0)
                              : (al4(dst[1], dstStride[1]) && al4(dst[2], dstStride[2])));
     }
-    ya.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
+    // (an RGB source written to an RGB destination keeps both stages at the default, as every RGB -> RGB context here)
+    ya.y2r = c->rgbViaPlanes ? make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false) : make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
     ya.prof = c->prof;
     ya.rangeConv = c->rangeConv;
     return 0;
@@ -1332,8 +1333,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && is_yuv420(dstFormat)) {
         c->mode = MODE_RGB2YUV;
         r = init_rgb2yuv(c);
-    } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && dstFormat == GMAT_PIX_FMT_YUV444P) {
-        c->mode = MODE_RGB2YUV444;           // every filter has one tap: a per-pixel conversion
+    } else if (same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) && dstFormat == GMAT_PIX_FMT_YUV444P &&
+               !(c->flags & GMAT_SWS_FAST_BILINEAR)) {
+        // every filter has one tap: a per-pixel conversion — unless SWS_FAST_BILINEAR halves the source's chroma (utils.c:1529-1545:
+        // rgb24ToUV_half_c, then a 1:2 chroma filter), which is the plane scaler's job below (a fuzz find of round 3)
+        c->mode = MODE_RGB2YUV444;
     } else if (same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
         c->mode = MODE_YUV2YUV;
     } else if (same && is_yuv420(srcFormat) && (dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE)) {
@@ -1344,8 +1348,15 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
                is_packed_rgb(dstFormat)) {
         c->mode = MODE_SCALE;
         r = ensure_scaler(c);
+        if (r == GMAT_ERR(ENOSYS) && !is_yuv420(srcFormat)) {
+            // the RGB scaler writes full chroma only; with SWS_FAST_BILINEAR an RGB source keeps the half-chroma writer
+            // (utils.c:1439-1447): the plane scaler with its RGB loader has that writer
+            c->rgbViaPlanes = true;
+            c->fused = 2;
+            r = ensure_scaler(c);
+        }
     } else if ((srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) &&
-               ((!same && is_yuv8_src(dstFormat)) || dstFormat == GMAT_PIX_FMT_P010LE)) {
+               ((!same && is_yuv8_src(dstFormat)) || dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_YUV444P)) {
         // packed RGB scaled into a YUV frame (one libswscale context: rgb24ToY / ToUV(_half), hScale16To15_c, planar
         // vertical stage): the plane scaler with its RGB loader
         c->mode = MODE_SCALE;
@@ -1437,6 +1448,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
         return gmat_sws_setRange(c->inner, 0, dstFullRange);
     }
     if (c->inner) return gmat_sws_setRange(c->inner, srcFullRange, dstFullRange);
+    if (c->rgbViaPlanes && is_packed_rgb(c->dstFormat)) return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;   // RGB ends: no range
     if (c->mode == MODE_RGB2YUV || c->rgbViaPlanes) {
         // an RGB source has no range of its own (forced to 0, utils.c:902-1030): a full-range destination is the
         // limited -> full conversion of the 15-bit lines (lum/chrRangeToJpeg_c), as in the second half of libswscale's

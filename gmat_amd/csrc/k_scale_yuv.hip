@@ -683,9 +683,9 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     const bool out444 = p.dstFormat == GMAT_PIX_FMT_YUV444P;
     const bool out10 = is_dst10(p.dstFormat);                                // 4:2:0 with 16-bit stores (P010LE, YUV420P10LE)
     const int yuvOut = (is_yuv420(p.dstFormat) || out10) ? 1 : out444 ? 2 : 0;   // 1: 4:2:0   2: planar 4:4:4
-    const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // only towards YUV destinations
+    const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // YUV destinations, and the RGB ones the RGB scaler has no writer for
     const bool pl16 = pl16_depth(p.srcFormat) != 0;
-    if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat) || pl16 || (rgbSrc && yuvOut)) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
+    if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat) || pl16 || rgbSrc) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
     if (rgbSrc && (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs)) return GMAT_ERR(ENOSYS);
     if (is_p01x(p.srcFormat) || pl16) {
         // the P016 image is biased by -32768, undone by a start value that assumes every horizontal row sums to

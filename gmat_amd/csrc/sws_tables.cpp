@@ -379,6 +379,30 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
     if ((r = build_filter(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 1 << 14, flags, param,
                           local_chroma_pos(p.chrSrcHSub, chrPos[0]), local_chroma_pos(p.chrDstHSub, chrPos[2]))) < 0) return r;
+    if ((flags & GMAT_SWS_FAST_BILINEAR) && is_yuv8_src(srcFormat) && !is_dst16(dstFormat)) {
+        // 8-bit samples into 15-bit lines with SWS_FAST_BILINEAR: libswscale leaves hScale8To15_c for ff_hyscale_fast_c /
+        // ff_hcscale_fast_c (swscale.c:566-574, hscale_fast_bilinear.c:23-55) — xpos += xInc, the two samples at xpos >> 16 blended
+        // with the 7-bit xalpha = (xpos & 0xFFFF) >> 9 (luma weights 128 - xalpha and xalpha, chroma (xalpha ^ 127) and xalpha), and
+        // src[srcW - 1] * 128 wherever (i * xInc) >> 16 reaches the last sample.  That is hScale8To15_c over this two-tap bank.
+        auto fast_bank = [](FilterBank &fb, int inc, int srcLen, int dstLen, int wsum) {
+            fb.taps = 2; fb.count = dstLen;
+            fb.coef.assign((size_t)dstLen * 2, 0); fb.pos.assign(dstLen, 0);
+            unsigned xpos = 0;
+            for (int i = 0; i < dstLen; i++, xpos += (unsigned)inc) {
+                const unsigned xx = xpos >> 16, xa = (xpos & 0xFFFF) >> 9;
+                if ((int)(((unsigned)i * (unsigned)inc) >> 16) >= srcLen - 1) {
+                    fb.pos[i] = srcLen >= 2 ? srcLen - 2 : 0;
+                    fb.coef[2 * i] = srcLen >= 2 ? 0 : 16384; fb.coef[2 * i + 1] = srcLen >= 2 ? 16384 : 0;
+                } else {
+                    fb.pos[i] = (int)xx;
+                    fb.coef[2 * i] = (int16_t)((wsum - (int)xa) << 7); fb.coef[2 * i + 1] = (int16_t)(xa << 7);
+                }
+            }
+            pack_filter_pairs(fb);
+        };
+        fast_bank(p.hLum, p.lumXInc, srcW, dstW, 128);
+        fast_bank(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 127);
+    }
     if ((r = build_filter(p.vLum, p.lumYInc, srcH, dstH, 1 << 12, flags, param,
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
     if ((r = build_filter(p.vChr, p.chrYInc, p.chrSrcH, p.chrDstH, 1 << 12, flags, param,

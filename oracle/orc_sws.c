@@ -17,6 +17,7 @@
  *   rgbaToA_c, rgba64leToA_c                                 input.c:413-449;  needAlpha  utils.c:1902
  *   alpha in the packed writers                              output.c:1025-1470 (64-bit), :1685-1828, :2037-2200 (8-bit)
  *   hScale8To15_c / hScale16To15_c                         swscale.c:93-136
+ *   ff_hyscale_fast_c / ff_hcscale_fast_c (SWS_FAST_BILINEAR on 8-bit sources, selected swscale.c:566-574)   hscale_fast_bilinear.c:23-55
  *   swscale() row schedule                                 swscale.c:372-389
  *   packed_vscale selection                                vscale.c:108-170
  *   yuv2rgb_{X,2,1}_c_template + yuv2rgb_write             output.c:1554-1828
@@ -218,6 +219,37 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     if (orc_init_filter(&c->v_chr, &c->v_chr_pos, &c->v_chr_size, c->chr_y_inc, c->chr_src_h, c->chr_dst_h,
                         1, 1 << 12, flags, param,
                         get_local_pos(c->chr_src_vsub, chr_pos[1]), get_local_pos(c->chr_dst_vsub, chr_pos[3])) < 0) goto fail;
+
+    /* SWS_FAST_BILINEAR with 8-bit samples and 15-bit lines (srcBpc == 8 && dstBpc <= 14, swscale.c:566-574; an RGB source has
+     * srcBpc 16): the horizontal scalers are ff_hyscale_fast_c / ff_hcscale_fast_c (hscale_fast_bilinear.c:23-55), which walk
+     * xpos += xInc and blend src[xx], src[xx + 1] with the 7-bit xalpha = (xpos & 0xFFFF) >> 9:
+     *     luma    (src[xx] << 7) + (src[xx + 1] - src[xx]) * xalpha   =  (src[xx] * (128 - xalpha) + src[xx + 1] * xalpha)
+     *     chroma  src[xx] * (xalpha ^ 127) + src[xx + 1] * xalpha                (weights that sum to 127, not 128)
+     *     every output with (i * xInc) >> 16 >= srcW - 1 is src[srcW - 1] * 128
+     * i.e. hScale8To15_c over a two-tap bank {w0 << 7, w1 << 7}: the banks initFilter made are replaced by that one */
+    if ((flags & ORC_SWS_FAST_BILINEAR) && !c->src_is_rgb && !is_p01x(src_fmt) && !pl16_depth(src_fmt) && !is_dst16(dst_fmt)) {
+        int pass;
+        for (pass = 0; pass < 2; pass++) {
+            const int dw = pass ? c->chr_dst_w : dst_w, sw = pass ? c->chr_src_w : src_w, inc = pass ? c->chr_x_inc : c->lum_x_inc;
+            int16_t *f = (int16_t *)malloc(sizeof(int16_t) * 2 * (size_t)dw);
+            int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw);
+            unsigned xpos = 0;
+            int i;
+            if (!f || !pos) { free(f); free(pos); goto fail; }
+            for (i = 0; i < dw; i++, xpos += (unsigned)inc) {
+                const unsigned xx = xpos >> 16, xa = (xpos & 0xFFFF) >> 9;
+                if ((int)(((unsigned)i * (unsigned)inc) >> 16) >= sw - 1) {          /* the tail rule */
+                    pos[i] = sw >= 2 ? sw - 2 : 0;
+                    f[2 * i] = sw >= 2 ? 0 : 16384; f[2 * i + 1] = sw >= 2 ? 16384 : 0;
+                } else {
+                    pos[i] = (int32_t)xx;
+                    f[2 * i] = (int16_t)(((pass ? 127 : 128) - xa) << 7); f[2 * i + 1] = (int16_t)(xa << 7);
+                }
+            }
+            if (pass) { free(c->h_chr); free(c->h_chr_pos); c->h_chr = f; c->h_chr_pos = pos; c->h_chr_size = 2; }
+            else      { free(c->h_lum); free(c->h_lum_pos); c->h_lum = f; c->h_lum_pos = pos; c->h_lum_size = 2; }
+        }
+    }
 
     /* colour tables: BT.601, limited range on both sides (sws_setColorspaceDetails defaults,
      * utils.c:902-1030: RGB ends have their range forced to 0) */

@@ -97,11 +97,11 @@ def test_destination_matrix(dev, orc, cs):
 
 @pytest.mark.parametrize("sf", ["rgba", "bgra"])
 @pytest.mark.parametrize("df", ["rgba", "bgra"])
-@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "point", SWS["bilinear"] | SWS["full_chr_h_int"], "area", "lanczos"])
+@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "point", SWS["bilinear"] | SWS["full_chr_h_int"], "area", "lanczos", "fast_bilinear"])
 def test_8bit_alpha_is_scaled(dev, orc, sf, df, flags):
     """RGBA / BGRA -> RGBA / BGRA at another size: the alpha channel is a fourth plane through the luma filters (rounds 1 and 2 wrote
-    255 — right only for opaque frames, which is all the reference's own vectors hold).  (An 8-bit packed RGB source with
-    SWS_FAST_BILINEAR — the half-chroma writer behind an RGB source — is refused by the RGB scaler as before: k_scale.hip:403.)"""
+    255 — right only for opaque frames, which is all the reference's own vectors hold).  SWS_FAST_BILINEAR keeps the half-chroma
+    writer behind an RGB source (utils.c:1439-1447): the plane scaler with its RGB loader, not the RGB scaler."""
     for geom in [(96, 40, 50, 30), (64, 24, 128, 24), (64, 24, 96, 48), (64, 24, 128, 60), (131, 35, 64, 17), (64, 24, 33, 24)]:
         _run(dev, orc, sf, df, geom, flags, seed=21)
 
@@ -128,3 +128,62 @@ def test_padding_twins_carry_no_alpha(dev, orc):
         assert (got[0] == want).all(), (sf, df)
     for p in d:
         p.free()
+
+
+@pytest.mark.parametrize("sf", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("df", ["rgb24", "bgr24", "rgba", "bgra"])
+def test_rgb_to_rgb_with_the_half_chroma_writer(dev, orc, sf, df):
+    """SWS_FAST_BILINEAR on an RGB -> RGB context: chroma from pixel pairs at the source (rgb24ToUV_half_c) AND one chroma sample per
+    pixel pair at the writer (yuv2rgb_X_c and its one- / two-tap forms) — refused through round 2; odd widths fall back to the full
+    writer as in libswscale (utils.c:1431-1437)"""
+    for geom in [(96, 40, 50, 30), (64, 24, 128, 24), (64, 24, 96, 48), (64, 24, 128, 60), (130, 36, 64, 18), (64, 24, 33, 24), (200, 16, 100, 8)]:
+        k = _run(dev, orc, sf, df, geom, "fast_bilinear", seed=41)
+        assert "scale_yuv_kernel" in k or "scale_rgb" in k, k
+
+
+@pytest.mark.parametrize("geom", [(96, 20, 50, 20), (64, 12, 150, 12), (200, 8, 78, 8), (33, 8, 32, 8), (50, 8, 100, 8)])
+def test_fast_bilinear_on_8bit_sources_is_hyscale_fast(dev, orc, geom):
+    """SWS_FAST_BILINEAR with 8-bit samples: libswscale's horizontal scalers are ff_hyscale_fast_c / ff_hcscale_fast_c
+    (hscale_fast_bilinear.c:23-55, selected swscale.c:566-574), not hScale8To15_c over initFilter's bilinear bank — rounds 1-2 ran the
+    bank.  Known answer from the functions' own text, written out here in numpy for a context that keeps the height (one vertical tap:
+    yuv2plane1_8_c / yuv2nv12cX_c give (line + 64) >> 7), then the oracle and the library against it and against each other."""
+    sw, sh, dw, dh = geom
+    src = synth_planes(orc, "yuv420p", sw, sh, seed=12)
+
+    def fast(row, n_out, inc, chroma):
+        out = np.zeros(n_out, np.int64)
+        n = len(row)
+        r = row.astype(np.int64)
+        for i in range(n_out):
+            xpos = (i * inc) & 0xFFFFFFFF
+            xx, xa = xpos >> 16, (xpos & 0xFFFF) >> 9
+            if ((i * inc) & 0xFFFFFFFF) >> 16 >= n - 1:
+                out[i] = r[n - 1] * 128
+            elif chroma:
+                out[i] = r[xx] * (xa ^ 127) + r[xx + 1] * xa
+            else:
+                out[i] = (r[xx] << 7) + (r[xx + 1] - r[xx]) * xa
+        return np.clip((out + 64) >> 7, 0, 255).astype(np.uint8)
+
+    cw_s, cw_d = (sw + 1) // 2, (dw + 1) // 2
+    inc_l = ((sw << 16) + (dw >> 1)) // dw
+    inc_c = ((cw_s << 16) + (cw_d >> 1)) // cw_d
+    want = [np.stack([fast(r, dw, inc_l, False) for r in src[0]]),
+            np.stack([fast(r, cw_d, inc_c, True) for r in src[1]]), np.stack([fast(r, cw_d, inc_c, True) for r in src[2]])]
+    got_o = orc.sws(src, sw, sh, "yuv420p", dw, dh, "yuv420p", SWS["fast_bilinear"])
+    for a, b in zip(got_o, want):
+        assert (a == b).all(), np.argwhere(a != b)[:4]
+    for sf, df in (("yuv420p", "yuv420p"), ("yuv420p", "rgb24"), ("nv12", "nv12"), ("nv12", "bgra"), ("yuv420p", "p010le")):
+        _run(dev, orc, sf, df, geom, "fast_bilinear")
+    _run(dev, orc, "nv12", "rgb24", (sw, sh, dw, 2 * sh), "fast_bilinear")                  # with a real vertical filter behind it
+    _run(dev, orc, "yuv420p", "nv12", (sw, sh, dw, sh // 2), "fast_bilinear")
+
+
+@pytest.mark.parametrize("sf", ["rgb24", "bgr24", "rgba"])
+def test_same_size_rgb_to_yuv444p_with_fast_bilinear(dev, orc, sf):
+    """SWS_FAST_BILINEAR halves an RGB source's chroma even when nothing is scaled (utils.c:1529-1545): the equal-size RGB -> YUV444P
+    context is then NOT a per-pixel conversion (rgb24ToUV_half_c and a 1:2 chroma filter) — found by the fuzzer once it drew the flag"""
+    for geom in [(92, 120, 92, 120), (11, 28, 11, 28), (177, 26, 177, 26)]:
+        k = _run(dev, orc, sf, "yuv444p", geom, "fast_bilinear", seed=17)
+        assert k != "rgb2yuv444_kernel", k
+        assert _run(dev, orc, sf, "yuv444p", geom, "bicubic", seed=17) == "rgb2yuv444_kernel"
