@@ -596,8 +596,26 @@ def host_pipeline(lib, geo, dist, world, device, dry, nframes=96, depth=4):
     p.drain()
     dt = time.perf_counter() - t0
     dt = dist.max_over_ranks(dt, world, device="cpu" if dry else "cuda")
+    # what a caller with PAGEABLE frames adds (hwupload's av_image_copy into the pinned ring, integration/vf_hwupload_hip.c:126):
+    # one 4K NV12 frame copied into a ring slot by this rank's (NUMA-bound) thread — a per-thread ceiling beside the PCIe one
+    fill = None
+    try:
+        f = p.host_input(0)
+        n0, n1 = f.linesize[0] * geo.sh, f.linesize[1] * (geo.sh // 2)
+        srcbuf = np.random.default_rng(99).integers(0, 256, n0 + n1, dtype=np.uint8)
+        reps = 2 if dry else 12
+        C.memmove(f.data[0], srcbuf.ctypes.data, n0); C.memmove(f.data[1], srcbuf.ctypes.data + n0, n1)      # touch
+        tf = time.perf_counter()
+        for _ in range(reps):
+            C.memmove(f.data[0], srcbuf.ctypes.data, n0); C.memmove(f.data[1], srcbuf.ctypes.data + n0, n1)
+        tf = (time.perf_counter() - tf) / reps
+        fill = {"ms_per_4k_nv12_frame": round(tf * 1e3, 3), "GBps": round((n0 + n1) / tf / 1e9, 2), "frames_per_s_per_thread": round(1.0 / tf, 1),
+                "Gpix_per_s_per_thread": round(geo.px / tf / 1e9, 3)}
+    except Exception as e:                                   # noqa: BLE001 - a bench leg must not take the headline down
+        fill = {"error": repr(e)}
     p.close()
     return {"value": round(world * nframes * geo.px / dt / 1e9, 3), "unit": "Gpix/s", "frames_per_rank": nframes, "ranks": world,
+            "pageable_fill_one_thread": fill,
             "ring_depth": depth, "pcie_GBps_in_per_gpu": round(nframes * geo.nv12 / dt / 1e9, 2),
             "pcie_GBps_out_per_gpu": round(nframes * geo.rgb_dst / dt / 1e9, 2),
             "note": "pinned host frames, upload / compute / download on three streams chained by events (C ABI "
@@ -734,8 +752,9 @@ def main():
         a.frames = max(LAUNCH_FRAMES, a.frames // LAUNCH_FRAMES * LAUNCH_FRAMES)
     env = Env(a.dry, local)
     local_device[0] = local
-    dev = 0 if a.dry else local
-    lib.gmat_set_device(dev)
+    dev = local % max(1, lib.gmat_device_count()) if a.dry else local      # (the emulated build has two devices)
+    if lib.gmat_set_device(dev) != 0:
+        raise SystemExit("bench.py: gmat_set_device(%d) failed" % dev)
     # each GPU gets its own host thread and pinned staging ring — bind this rank to the host cores of its
     # GPU's NUMA node BEFORE any pinned allocation (first touch decides where the ring lives)
     numa = {"node": int(lib.gmat_device_numa_node(dev)), "cpus_bound": int(lib.gmat_bind_thread_to_device(dev))}
@@ -752,7 +771,11 @@ def main():
     nframes = a.steps * a.frames
     gpix = world * nframes * geo.px / wall / 1e9
     kname = head.kernel()
-    per_rank_wall = gdist.gather_floats(wall_local[0], world, device="cpu" if a.dry else "cuda")
+    gdev = "cpu" if a.dry else "cuda"
+    per_rank_wall = gdist.gather_floats(wall_local[0], world, device=gdev)
+    per_rank_dev = [int(v) for v in gdist.gather_floats(dev, world, device=gdev)]
+    per_rank_numa = [int(v) for v in gdist.gather_floats(numa["node"], world, device=gdev)]
+    per_rank_cpus = [int(v) for v in gdist.gather_floats(numa["cpus_bound"], world, device=gdev)]
     # ---- roofline of the dominant kernel: the same frames, launches strictly back to back on ONE stream, HIP events
     ser = Runner(lib, geo, stream, a.frames, 2, seed=0, branches=1, share=head)
     _, ser_ms = timed(lib, env, None, ser, stream, a.steps, a.warmup, 1, pre_warm)
@@ -795,7 +818,8 @@ def main():
         out["data"] = "synthetic (DRY RUN on the CPU-emulated library: plumbing only, not a measurement)"
     if rank == 0:
         detail("per_rank", {"wall_s": [round(w, 6) for w in per_rank_wall], "min": round(min(per_rank_wall), 6),
-                            "max": round(max(per_rank_wall), 6), "numa_rank0": numa})
+                            "max": round(max(per_rank_wall), 6), "device": per_rank_dev, "numa_node": per_rank_numa,
+                            "cpus_bound": per_rank_cpus, "numa_rank0": numa})
 
     if rank == 0 and not a.no_detail:
         detail("chained", chained_forms(lib, env, stream, geo, max(3, a.steps // 3), pre_warm, branches))

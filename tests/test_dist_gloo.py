@@ -73,6 +73,10 @@ def test_bench_self_launches_two_ranks_through_the_library():
     assert det["cpu_configs0"]["cores"] == 1
     # each rank timed its own steps on its own (emulated) device; rank order, MAX is what `value` uses
     assert len(det["per_rank"]["wall_s"]) == 2 and det["per_rank"]["max"] >= det["per_rank"]["min"] > 0
+    # one device per rank (gmat_set_device(LOCAL_RANK); the emulated build has two), each rank bound to ITS device's host cores
+    assert det["per_rank"]["device"] == [0, 1]
+    assert len(det["per_rank"]["numa_node"]) == 2 and all(c >= 0 for c in det["per_rank"]["cpus_bound"])
+    assert det["host_pipeline"]["pageable_fill_one_thread"]["GBps"] > 0
     # value = all ranks' pixels over the slowest rank's time
     px = 128 * 32 * d["config"]["frames_per_step"] * d["steps"] * 2
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) < 2e-3
