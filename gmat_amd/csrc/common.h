@@ -50,7 +50,11 @@ inline bool is_p01x(int f) { return f == GMAT_PIX_FMT_P010LE || f == GMAT_PIX_FM
 // library-internal source format (never accepted from a caller): the Y / U / V planes of 16-bit samples that rgb64ToY_c / ToUV_c /
 // ToUV_half_c make of an RGBA64LE / BGRA64LE frame (k_rgb64.hip) — planar 16-bit samples with an RGB source's chroma geometry
 constexpr int GMAT_PIX_FMT_PRIV_RGB64_PLANES = 0x47520064;
-inline int  pl16_depth(int f) { return (f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE || f == GMAT_PIX_FMT_PRIV_RGB64_PLANES) ? 16 : f == GMAT_PIX_FMT_YUV420P10LE ? 10 : 0; }
+// ... and the 16-bit lines rgb24ToY_c / ToUV_c / ToUV_half_c make of an 8-bit packed RGB frame, for the 19-bit path only (16-bit
+// destinations): hScale16To19_c shifts them by 9, not by depth - 5 (swscale.c:74-76)
+constexpr int GMAT_PIX_FMT_PRIV_RGB8_PLANES = 0x47520008;
+inline bool is_priv_planes(int f) { return f == GMAT_PIX_FMT_PRIV_RGB64_PLANES || f == GMAT_PIX_FMT_PRIV_RGB8_PLANES; }
+inline int  pl16_depth(int f) { return (f == GMAT_PIX_FMT_YUV444P16LE || f == GMAT_PIX_FMT_YUV420P16LE || is_priv_planes(f)) ? 16 : f == GMAT_PIX_FMT_YUV420P10LE ? 10 : 0; }
 inline bool has_alpha(int f) { return f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA || is_rgb64(f); }
 inline int  bytes_per_pixel(int f)
 {

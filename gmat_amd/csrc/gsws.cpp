@@ -1234,7 +1234,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         logf(LOG_ERROR, "gmat_sws_getContext: %dx%d -> %dx%d is an invalid scaling dimension", srcW, srcH, dstW, dstH);
         return nullptr;
     }
-    if (srcFormat == GMAT_PIX_FMT_PRIV_RGB64_PLANES && !g_privFormatOk) return nullptr;
+    if (is_priv_planes(srcFormat) && !g_privFormatOk) return nullptr;
     GmatSwsContext *c = new (std::nothrow) GmatSwsContext();
     if (!c) return nullptr;
     if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
@@ -1257,6 +1257,22 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
     const bool same = srcW == dstW && srcH == dstH;
     int r = 0;
     const bool src32 = srcFormat == GMAT_PIX_FMT_RGBA || srcFormat == GMAT_PIX_FMT_BGRA;
+    if (is_packed_rgb(srcFormat) && is_dst16(dstFormat)) {
+        // 8-bit packed RGB into a 16-bit destination: the 19-bit lines of a 16-bit-lined source (an RGB source's lines are 16 bits wide
+        // whatever its depth, utils.c:1561-1570) — rgb24ToY_c / ToUV(_half)_c into planes, then the planar context of the 19-bit path
+        g_privFormatOk = true;
+        c->inner = gmat_sws_getContext(srcW, srcH, GMAT_PIX_FMT_PRIV_RGB8_PLANES, dstW, dstH, dstFormat, flags, param);
+        g_privFormatOk = false;
+        if (!c->inner) { delete c; return nullptr; }
+        c->mode = MODE_VIA_PLANES16;
+        const ScalePlan &p = active_plan(c->inner);
+        c->p16Stride[0] = align_up(2 * srcW, 256); c->p16Stride[1] = align_up(2 * p.chrSrcW, 256);
+        c->p16Off[1] = (size_t)c->p16Stride[0] * srcH; c->p16Off[2] = c->p16Off[1] + (size_t)c->p16Stride[1] * srcH;
+        if (c->planes16.reserve(c->p16Off[2] + (size_t)c->p16Stride[1] * srcH) < 0) { delete c; return nullptr; }
+        c->needAlpha = src32 && !c->src0 && is_rgb64(dstFormat);
+        if (c->needAlpha && alpha_prepare(c, c->inner) < 0) { delete c; return nullptr; }
+        return c;
+    }
     if (src32 && !(same && is_packed_rgb(dstFormat))) {
         // 32-bit RGB sources (swscale_cuda.c:34-44 lists RGBA / BGRA): rgb32ToY / ToUV (input.c rgb16_32 templates) read
         // the same three channels with the same coefficients as the 24-bit readers and ignore alpha, so the context is the
@@ -1628,17 +1644,24 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         break;
     }
     case MODE_VIA_PLANES16: {
-        if ((((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 1) != 0) { r = GMAT_ERR(EINVAL); break; }
+        if (is_rgb64(c->srcFormat) && (((uintptr_t)src[0] | (uintptr_t)srcStride[0]) & 1) != 0) { r = GMAT_ERR(EINVAL); break; }
         const ScalePlan &p = active_plan(c->inner);
         uint8_t *pl = (uint8_t *)c->planes16.p;
         // the RGB -> YUV stage takes the DESTINATION's matrix when that is YUV (fill_rgb2yuv_table, utils.c:765-858); an RGB
         // destination leaves both stages at the default (as every RGB -> RGB context of this library)
         const Rgb2YuvConsts k = make_rgb2yuv_consts(is_packed_rgb(c->dstFormat) || is_rgb64(c->dstFormat) ? GMAT_SWS_CS_DEFAULT : c->colorspace);
-        if ((r = launch_rgb64_planes(src[0], srcStride[0], c->srcW, c->srcH, p.chrSrcW, p.chrSrcHSub, c->srcFormat == GMAT_PIX_FMT_BGRA64LE, k,
-                                     pl, c->p16Stride[0], pl + c->p16Off[1], c->p16Stride[1], pl + c->p16Off[2], c->p16Stride[1], c->stream)) < 0) break;
+        const bool s64 = is_rgb64(c->srcFormat);
+        if (s64) r = launch_rgb64_planes(src[0], srcStride[0], c->srcW, c->srcH, p.chrSrcW, p.chrSrcHSub, c->srcFormat == GMAT_PIX_FMT_BGRA64LE, k,
+                                         pl, c->p16Stride[0], pl + c->p16Off[1], c->p16Stride[1], pl + c->p16Off[2], c->p16Stride[1], c->stream);
+        else     r = launch_rgb8_planes(src[0], srcStride[0], c->srcW, c->srcH, p.chrSrcW, p.chrSrcHSub,
+                                        c->srcFormat == GMAT_PIX_FMT_BGR24 || c->srcFormat == GMAT_PIX_FMT_BGRA, bytes_per_pixel(c->srcFormat), k,
+                                        pl, c->p16Stride[0], pl + c->p16Off[1], c->p16Stride[1], pl + c->p16Off[2], c->p16Stride[1], c->stream);
+        if (r < 0) break;
         const bool a64 = c->needAlpha && is_rgb64(c->dstFormat);
         if (a64) {                           // the alpha plane's 19-bit lines, an operand of the inner context's writer
-            if ((r = launch_hscale19(src[0] + 6, srcStride[0], 16, 8, c->srcW, c->srcH, c->daH, (int32_t *)c->alphaLines.p, c->dstW, c->stream)) < 0) break;
+            if (s64) r = launch_hscale19(src[0] + 6, srcStride[0], 16, 8, c->srcW, c->srcH, c->daH, (int32_t *)c->alphaLines.p, c->dstW, c->stream);
+            else     r = launch_hscale19(src[0] + 3, srcStride[0], 208, 4, c->srcW, c->srcH, c->daH, (int32_t *)c->alphaLines.p, c->dstW, c->stream);
+            if (r < 0) break;
             c->inner->alpha19 = (const int32_t *)c->alphaLines.p;
         }
         gmat_sws_setStream(c->inner, (void *)c->stream);
@@ -1663,7 +1686,8 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const int odd = s16 ? 1 : 0;
         if ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0] | (rgb64 ? 0 : ((uintptr_t)dst[1] | (uintptr_t)dstStride[1]))) & 1) != 0 ||
             (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
-        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : pl16_depth(c->srcFormat) == 10 ? 110 : s16 ? 16 : 0;
+        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : pl16_depth(c->srcFormat) == 10 ? 110 :
+                         c->srcFormat == GMAT_PIX_FMT_PRIV_RGB8_PLANES ? 14 : s16 ? 16 : 0;
         const int bps = s16 ? 2 : 1;
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";

@@ -52,6 +52,50 @@ __global__ __launch_bounds__(256) void rgb64_planes_kernel(const uint8_t *src, i
     reinterpret_cast<unsigned short *>(pv + (size_t)y * vs)[cx] = (unsigned short)((k.rv * r + k.gv * g + k.bv * b + (0x10001 << 14)) >> 15);
 }
 
+// The 8-bit packed RGB twin, for 16-bit destinations: rgb24ToY_c / ToUV_c / ToUV_half_c (input.c:795-866; the 32-bit readers are the same
+// formulas on the same three channels, :246-390) into planes of 16-bit samples — the lines hScale16To19_c then shifts by 9.
+//   Y  = (ry*r + gy*g + by*b + (32 << 14) + (1 << 8)) >> 9
+//   UV = (ru*r + gu*g + bu*b + (256 << 14) + (1 << 8)) >> 9;   half: on the SUMS of a pixel pair, (.. + (256 << 15) + (1 << 9)) >> 10
+__global__ __launch_bounds__(256) void rgb8_planes_kernel(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, int px,
+                                                          Rgb2YuvConsts k, uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs)
+{
+    const int cx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (cx >= chrW || y >= h) return;
+    const uint8_t *row = src + (size_t)y * ss;
+    unsigned short *oy = reinterpret_cast<unsigned short *>(py + (size_t)y * ys);
+    const int ro = bgr ? 2 : 0, bo = 2 - ro;
+    auto luma = [&](int x) {
+        const int r = row[px * x + ro], g = row[px * x + 1], b = row[px * x + bo];
+        oy[x] = (unsigned short)((k.ry * r + k.gy * g + k.by * b + (32 << 14) + (1 << 8)) >> 9);
+    };
+    int u, v;
+    if (half) {
+        const int x0 = 2 * cx, x1 = min(2 * cx + 1, w - 1);
+        luma(x0);
+        if (x1 != x0) luma(x1);
+        const int r = row[px * x0 + ro] + row[px * x1 + ro], g = row[px * x0 + 1] + row[px * x1 + 1], b = row[px * x0 + bo] + row[px * x1 + bo];
+        u = (k.ru * r + k.gu * g + k.bu * b + (256 << 15) + (1 << 9)) >> 10;
+        v = (k.rv * r + k.gv * g + k.bv * b + (256 << 15) + (1 << 9)) >> 10;
+    } else {
+        luma(cx);
+        const int r = row[px * cx + ro], g = row[px * cx + 1], b = row[px * cx + bo];
+        u = (k.ru * r + k.gu * g + k.bu * b + (256 << 14) + (1 << 8)) >> 9;
+        v = (k.rv * r + k.gv * g + k.bv * b + (256 << 14) + (1 << 8)) >> 9;
+    }
+    reinterpret_cast<unsigned short *>(pu + (size_t)y * us)[cx] = (unsigned short)u;
+    reinterpret_cast<unsigned short *>(pv + (size_t)y * vs)[cx] = (unsigned short)v;
+}
+
+int launch_rgb8_planes(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, int px, const Rgb2YuvConsts &k,
+                       uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid((chrW + 255) / 256, h), block(256);
+    hipLaunchKernelGGL(rgb8_planes_kernel, grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, px, k, py, ys, pu, us, pv, vs);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_rgb64_planes(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, const Rgb2YuvConsts &k,
                         uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream)
 {

@@ -20,7 +20,8 @@ namespace gmat {
 
 // kind: 0 = 8-bit samples, sample stride `step` bytes; 10 / 16 = 16-bit samples (P010: >> 6), sample stride `step` bytes;
 //       110 = 16-bit containers holding 10 bits in the low end (YUV420P10LE): as they are, sh of a 10-bit source;
-//       208 = 8-bit alpha samples as rgbaToA_c hands them to the scaler (a << 6 | a >> 2, input.c:442-449)
+//       208 = 8-bit alpha samples as rgbaToA_c hands them to the scaler (a << 6 | a >> 2, input.c:442-449);
+//       14 = the 16-bit lines of an 8-bit packed RGB source (rgb24ToY_c ...): raw 16-bit samples, hScale16To19_c's sh = 9
 // maxv: 2^19 - 1 (hScale*To19_c) or 2^15 - 1 (hScale16To15_c, swscale.c:93-119 — the alpha lines of an 8-bit destination)
 __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH,
                                                        DevFilter f, int32_t *dst, int dstW, int sh, int maxv)
@@ -131,7 +132,8 @@ int launch_hscale19(const uint8_t *src, int ss, int kind, int step, int srcW, in
 {
     if (dstW <= 0 || srcH <= 0) return 0;
     // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4; hScale16To15_c (to15): depth - 1, 13 for the 14-bit alpha of an 8-bit format
-    const int sh = to15 ? (kind == 208 ? 13 : kind % 100 - 1) : kind == 0 ? 3 : kind % 100 - 5;
+    // (an 8-bit RGB source's lines — kind 14, and its alpha, kind 208 — go to 19 bits by 9: swscale.c:74-76)
+    const int sh = to15 ? (kind == 208 ? 13 : kind % 100 - 1) : kind == 0 ? 3 : kind == 208 ? 9 : kind % 100 - 5;
     const dim3 grid((dstW + 255) / 256, srcH), block(256);
     hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh, to15 ? (1 << 15) - 1 : (1 << 19) - 1);
     GMAT_HIP_CHECK(hipGetLastError());

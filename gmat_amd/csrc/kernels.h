@@ -140,6 +140,9 @@ int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int 
 // packed 64-bit RGB -> Y / U / V planes of 16-bit samples (rgb64ToY_c / ToUV_c / ToUV_half_c); half: chroma from pixel pairs
 int launch_rgb64_planes(const uint8_t *src, int srcStride, int w, int h, int chrW, int half, int bgr, const Rgb2YuvConsts &k,
                         uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream);
+// 8-bit packed RGB (px = 3 or 4 bytes a pixel) -> the same planes, as rgb24ToY_c / ToUV_c / ToUV_half_c write their 16-bit lines
+int launch_rgb8_planes(const uint8_t *src, int srcStride, int w, int h, int chrW, int half, int bgr, int px, const Rgb2YuvConsts &k,
+                       uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream);
 // byte 3 of every pixel of an RGBA / BGRA frame from the 15-bit alpha lines; form / first: per output row, see alpha8_out_kernel
 int launch_alpha8_out(const int32_t *la, int lineW, int lineH, const DevFilter &f, const int32_t *form, const int32_t *first,
                       uint8_t *dst, int dstStride, int dstW, int dstH, hipStream_t stream);

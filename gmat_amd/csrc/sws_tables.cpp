@@ -334,7 +334,7 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
                      int flags, const double param[2], const int *chrPos)
 {
     // the planes of a 64-bit packed RGB source keep an RGB source's chroma decisions (utils.c:1427-1557 look at the format the caller gave)
-    const bool src_rgb = is_packed_rgb(srcFormat) || srcFormat == GMAT_PIX_FMT_PRIV_RGB64_PLANES, dst_rgb = is_packed_rgb(dstFormat) || is_rgb64(dstFormat);
+    const bool src_rgb = is_packed_rgb(srcFormat) || is_priv_planes(srcFormat), dst_rgb = is_packed_rgb(dstFormat) || is_rgb64(dstFormat);
     const bool src444 = srcFormat == GMAT_PIX_FMT_YUV444P || srcFormat == GMAT_PIX_FMT_YUV444P16LE;
     const bool dst444 = dstFormat == GMAT_PIX_FMT_YUV444P || dstFormat == GMAT_PIX_FMT_YUV444P16LE;
     if (!(src_rgb || is_yuv420(srcFormat) || src444 || is_p01x(srcFormat) || pl16_depth(srcFormat)) ||

@@ -158,7 +158,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     if (!(is_rgb(src_fmt) || is_rgb64(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
         !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt) || dst_fmt == ORC_PIX_YUV420P10LE))
         return NULL;
-    if (is_dst16(dst_fmt) && (is_rgb(src_fmt) || src_range != dst_range))
+    if (is_dst16(dst_fmt) && src_range != dst_range)
         return NULL;
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
         return NULL;
@@ -346,6 +346,48 @@ static void range_chr(const OrcSws *c, int16_t *u, int16_t *v, int w)
         }
 }
 
+/* the 8-bit packed RGB readers: rgb24ToY_c / ToUV_c / ToUV_half_c and their bgr / 32-bit twins (input.c:795-866, :246-390) */
+static void rgb8_lum(const OrcSws *c, const uint8_t *row, uint16_t *tmp)
+{
+    const int px = c->src_px;
+    int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro, i;
+    for (i = 0; i < c->src_w; i++) {
+        int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
+        tmp[i] = (uint16_t)((c->ry * r + c->gy * g + c->by * b + (32 << (RGB2YUV_SHIFT - 1)) +
+                             (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+    }
+}
+
+static void rgb8_chr(const OrcSws *c, const uint8_t *row, uint16_t *tmp_u, uint16_t *tmp_v)
+{
+    const int px = c->src_px;
+    int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro, i;
+    if (c->chr_src_hsub) {
+        for (i = 0; i < c->chr_src_w; i++) {
+            /* the reference reads pixel 2i+1 unconditionally; for odd widths that is the
+             * padding of formatConvBuffer-less packed input, i.e. the next bytes of the row.
+             * Odd source widths with half-chroma input are therefore not bit-defined and
+             * the oracle clamps to the last pixel. */
+            int i1 = 2 * i + 1 < c->src_w ? 2 * i + 1 : c->src_w - 1;
+            int r = row[2 * px * i + ro] + row[px * i1 + ro];
+            int g = row[2 * px * i + 1]  + row[px * i1 + 1];
+            int b = row[2 * px * i + bo] + row[px * i1 + bo];
+            tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << RGB2YUV_SHIFT) +
+                                   (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
+            tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << RGB2YUV_SHIFT) +
+                                   (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
+        }
+    } else {
+        for (i = 0; i < c->chr_src_w; i++) {
+            int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
+            tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << (RGB2YUV_SHIFT - 1)) +
+                                   (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+            tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << (RGB2YUV_SHIFT - 1)) +
+                                   (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
+        }
+    }
+}
+
 /* RGBA64LE / BGRA64LE readers (input.c:36-121): 16-bit channels, 16-bit results.
  *   Y  = (ry*r + gy*g + by*b + (0x2001 << 14)) >> 15
  *   UV = (ru*r + gu*g + bu*b + (0x10001 << 14)) >> 15, the _half form on (p0 + p1 + 1) >> 1 per channel
@@ -406,13 +448,7 @@ static void lum_line(const OrcSws *c, const uint8_t *const src[4], const int str
         rgb64_lum(c, row, tmp);
         hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 15);      /* sh = depth - 1 (swscale.c:93-119) */
     } else if (c->src_is_rgb) {
-        const int px = c->src_px;
-        int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro, i;
-        for (i = 0; i < c->src_w; i++) {
-            int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
-            tmp[i] = (uint16_t)((c->ry * r + c->gy * g + c->by * b + (32 << (RGB2YUV_SHIFT - 1)) +
-                                 (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
-        }
+        rgb8_lum(c, row, tmp);
         hscale16(out, c->dst_w, tmp, c->h_lum, c->h_lum_pos, c->h_lum_size, 13);
     } else if (pl16_depth(c->src_fmt)) {
         /* native-endian 16-bit planar samples need no input converter; hScale16To15_c with sh = depth - 1 */
@@ -443,33 +479,7 @@ static void chr_line(const OrcSws *c, const uint8_t *const src[4], const int str
         hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
         hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 15);
     } else if (c->src_is_rgb) {
-        const uint8_t *row = src[0] + (long)y * stride[0];
-        const int px = c->src_px;
-        int ro = (c->src_fmt == ORC_PIX_RGB24 || c->src_fmt == ORC_PIX_RGBA) ? 0 : 2, bo = 2 - ro;
-        if (c->chr_src_hsub) {
-            for (i = 0; i < c->chr_src_w; i++) {
-                /* the reference reads pixel 2i+1 unconditionally; for odd widths that is the
-                 * padding of formatConvBuffer-less packed input, i.e. the next bytes of the row.
-                 * Odd source widths with half-chroma input are therefore not bit-defined and
-                 * the oracle clamps to the last pixel. */
-                int i1 = 2 * i + 1 < c->src_w ? 2 * i + 1 : c->src_w - 1;
-                int r = row[2 * px * i + ro] + row[px * i1 + ro];
-                int g = row[2 * px * i + 1]  + row[px * i1 + 1];
-                int b = row[2 * px * i + bo] + row[px * i1 + bo];
-                tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << RGB2YUV_SHIFT) +
-                                       (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
-                tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << RGB2YUV_SHIFT) +
-                                       (1 << (RGB2YUV_SHIFT - 6))) >> (RGB2YUV_SHIFT - 5));
-            }
-        } else {
-            for (i = 0; i < c->chr_src_w; i++) {
-                int r = row[px * i + ro], g = row[px * i + 1], b = row[px * i + bo];
-                tmp_u[i] = (uint16_t)((c->ru * r + c->gu * g + c->bu * b + (256 << (RGB2YUV_SHIFT - 1)) +
-                                       (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
-                tmp_v[i] = (uint16_t)((c->rv * r + c->gv * g + c->bv * b + (256 << (RGB2YUV_SHIFT - 1)) +
-                                       (1 << (RGB2YUV_SHIFT - 7))) >> (RGB2YUV_SHIFT - 6));
-            }
-        }
+        rgb8_chr(c, src[0] + (long)y * stride[0], tmp_u, tmp_v);
         hscale16(out_u, c->chr_dst_w, tmp_u, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
         hscale16(out_v, c->chr_dst_w, tmp_v, c->h_chr, c->h_chr_pos, c->h_chr_size, 13);
     } else if (pl16_depth(c->src_fmt)) {
@@ -800,7 +810,8 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
     const int pl16 = pl16_depth(c->src_fmt) != 0;            /* planar 16-bit containers, read as they are (native endian) */
     const int src16 = is_p01x(c->src_fmt), p010 = c->src_fmt == ORC_PIX_P010LE;
     const int r64 = is_rgb64(c->src_fmt);                    /* rgb64To*_c give 16-bit lines: hScale16To19_c, sh = 16 - 5 */
-    const int sh = r64 ? 11 : pl16 ? pl16_depth(c->src_fmt) - 5 : src16 ? (p010 ? 10 : 16) - 5 : sh8;
+    const int r8 = c->src_is_rgb && !r64;                    /* an 8-bit RGB source's 16-bit lines: sh = 9 (swscale.c:74-76) */
+    const int sh = r8 ? 9 : r64 ? 11 : pl16 ? pl16_depth(c->src_fmt) - 5 : src16 ? (p010 ? 10 : 16) - 5 : sh8;
     int32_t *la = (pa && c->need_alpha) ? (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h) : NULL;
     int32_t *ly = (int32_t *)malloc(sizeof(int32_t) * (size_t)dw * c->src_h);
     int32_t *lu = (int32_t *)malloc(sizeof(int32_t) * (size_t)cdw * c->chr_src_h);
@@ -814,6 +825,8 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
         const uint8_t *row = src[0] + (long)y * src_stride[0];
         if (r64) {
             rgb64_lum(c, row, t0);
+        } else if (r8) {
+            rgb8_lum(c, row, t0);
         } else {
             for (i = 0; i < c->src_w; i++)
                 t0[i] = (uint16_t)((src16 || pl16) ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
@@ -826,7 +839,8 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
     }
     for (y = 0; y < c->chr_src_h; y++) {
         if (r64) rgb64_chr(c, src[0] + (long)y * src_stride[0], t0, t1);
-        for (i = 0; i < c->chr_src_w && !r64; i++) {
+        if (r8) rgb8_chr(c, src[0] + (long)y * src_stride[0], t0, t1);
+        for (i = 0; i < c->chr_src_w && !r64 && !r8; i++) {
             if (pl16) {
                 t0[i] = (uint16_t)rl16(src[1] + (long)y * src_stride[1] + 2 * i);
                 t1[i] = (uint16_t)rl16(src[2] + (long)y * src_stride[2] + 2 * i);

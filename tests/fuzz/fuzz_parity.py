@@ -24,6 +24,7 @@ for case in range(n):
     sf = rng.choice(SRC)
     dsts = ["rgb24", "bgr24", "rgba", "bgra", "nv12", "yuv420p", "yuv444p"]
     if sf in ("rgba64le", "bgra64le"): dsts += ["rgba64le", "bgra64le", "p016le", "yuv444p16le", "p010le"]
+    if sf in ("rgb24", "bgr24", "rgba", "bgra"): dsts += ["rgba64le", "bgra64le", "p016le", "yuv444p16le", "yuv420p16le"]
     df = rng.choice(dsts)
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     same = rng.random() < 0.25

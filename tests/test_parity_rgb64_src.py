@@ -187,3 +187,15 @@ def test_same_size_rgb_to_yuv444p_with_fast_bilinear(dev, orc, sf):
         k = _run(dev, orc, sf, "yuv444p", geom, "fast_bilinear", seed=17)
         assert k != "rgb2yuv444_kernel", k
         assert _run(dev, orc, sf, "yuv444p", geom, "bicubic", seed=17) == "rgb2yuv444_kernel"
+
+
+@pytest.mark.parametrize("sf", ["rgb24", "bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("df", ["p016le", "yuv444p16le", "yuv420p16le", "rgba64le", "bgra64le"])
+def test_8bit_rgb_sources_to_16bit_destinations(dev, orc, sf, df):
+    """an RGB source's lines are 16 bits wide whatever its depth (utils.c:1561-1570), so a 16-bit destination takes them to the 19-bit
+    path with hScale16To19_c's own shift for them (9, swscale.c:74-76) — refused through round 2; RGBA / BGRA into RGBA64 / BGRA64
+    scales the alpha plane as well"""
+    for geom in [(96, 40, 50, 30), (64, 24, 96, 36), (70, 22, 70, 22), (130, 36, 64, 18)]:
+        _run(dev, orc, sf, df, geom)
+    _run(dev, orc, sf, df, (64, 24, 128, 48), "bilinear")
+    _run(dev, orc, sf, df, (64, 24, 64, 24), "fast_bilinear")

@@ -191,9 +191,15 @@ def test_error_behaviour_newer_entry_points(dev):
                            planes([d[0].ptr, d[1].ptr]), ints([d[0].stride, d[1].stride]))
     assert r < 0
     lib.gmat_sws_freeContext(c)
-    # the 19-bit path (P016, 64-bit RGB) has no RGB readers
-    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["p016le"], 0, None)
-    assert not lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["rgba64le"], 0, None)
+    # (round 3: the 19-bit path has its RGB readers — tests/test_parity_rgb64_src.py; a format outside the table is still refused,
+    # and the library-internal plane formats are not accepted from a caller)
+    for c in (lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["p016le"], 0, None),
+              lib.gmat_sws_getContext(32, 16, PIX_FMT["rgb24"], 16, 8, PIX_FMT["rgba64le"], 0, None)):
+        assert c
+        lib.gmat_sws_freeContext(c)
+    assert not lib.gmat_sws_getContext(32, 16, 0x47520064, 16, 8, PIX_FMT["rgb24"], 0, None)
+    assert not lib.gmat_sws_getContext(32, 16, 0x47520008, 16, 8, PIX_FMT["p016le"], 0, None)
+    assert not lib.gmat_sws_getContext(32, 16, 1, 16, 8, PIX_FMT["rgb24"], 0, None)          # AV_PIX_FMT_YUYV422
 
 
 @pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (33, 9)])
