@@ -1498,19 +1498,19 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     if (conv == c->rangeConv) return 0;
     // a same-size context is a plane copy / depth expansion only while the ranges agree (utils.c:1996-2000: the
     // special converters are skipped when srcRange != dstRange); otherwise it runs the generic path, whose 15-bit
-    // lines carry the conversion (8-bit 4:2:0 and P010LE destinations).  The 19-bit path (P016LE, YUV444P16LE) has no
-    // range conversion here: those contexts refuse differing ranges instead of ignoring them.
+    // lines carry the conversion (8-bit 4:2:0 and P010LE destinations: lum / chrRange{To,From}Jpeg_c on the 15-bit lines; 16-bit
+    // destinations: their ...16_c twins on the 19-bit lines, swscale.c:189-226).
     const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
     const bool special = same && (c->unscaledMode == MODE_YUV2YUV || c->unscaledMode == MODE_DEPTH || c->unscaledMode == MODE_PLANECOPY);
     if (special) {
         const bool generic15 = is_yuv420(c->dstFormat) || is_dst10(c->dstFormat);
-        if (conv && !generic15) return GMAT_ERR(ENOSYS);
         c->rangeConv = conv;
+        if (conv && !generic15) { c->mode = MODE_SCALE16; return init_scale16(c); }       // 16-bit destination: the 19-bit lines
         if (conv) { c->mode = MODE_SCALE; c->fused = 2; return ensure_scaler(c); }
         c->mode = c->unscaledMode;
         return 0;
     }
-    if (c->mode == MODE_SCALE16 && conv) return GMAT_ERR(ENOSYS);
+    if (c->mode == MODE_SCALE16 && conv && is_rgb64(c->dstFormat)) return GMAT_ERR(ENOSYS);   // an RGB end has no range (swscale.c:536)
     c->rangeConv = conv;
     return 0;
 }
@@ -1691,13 +1691,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const int bps = s16 ? 2 : 1;
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
-        if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream)) < 0) break;
+        const int rcL = rgb64 ? 0 : c->rangeConv, rcC = rgb64 ? 0 : c->rangeConv ? c->rangeConv + 2 : 0;      // (swscale.c:536: not for RGB destinations)
+        if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream, 0, rcL)) < 0) break;
         const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);           // interleaved U, V
         if (!semi && !src[2]) { r = GMAT_ERR(EINVAL); break; }
         const uint8_t *pu = src[1], *pv = semi ? src[1] + bps : src[2];
         const int su = srcStride[1], sv = semi ? srcStride[1] : srcStride[2], cstep = semi ? 2 * bps : bps;
-        if ((r = launch_hscale19(pu, su, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lu, p.chrDstW, c->stream)) < 0) break;
-        if ((r = launch_hscale19(pv, sv, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lv, p.chrDstW, c->stream)) < 0) break;
+        if ((r = launch_hscale19(pu, su, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lu, p.chrDstW, c->stream, 0, rcC)) < 0) break;
+        if ((r = launch_hscale19(pv, sv, kind, cstep, p.chrSrcW, p.chrSrcH, c->d16[1], lv, p.chrDstW, c->stream, 0, rcC)) < 0) break;
         if (rgb64) {
             c->lastKernel = "hscale19_kernel+vrgba64_kernel";
             r = launch_vrgba64(ly, lu, lv, c->dstW, c->srcH, p.chrDstW, p.chrSrcH, c->d16[2], c->d16[3], p.chrDstW == c->dstW ? 0 : 1,

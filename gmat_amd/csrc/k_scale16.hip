@@ -24,7 +24,7 @@ namespace gmat {
 //       14 = the 16-bit lines of an 8-bit packed RGB source (rgb24ToY_c ...): raw 16-bit samples, hScale16To19_c's sh = 9
 // maxv: 2^19 - 1 (hScale*To19_c) or 2^15 - 1 (hScale16To15_c, swscale.c:93-119 — the alpha lines of an 8-bit destination)
 __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH,
-                                                       DevFilter f, int32_t *dst, int dstW, int sh, int maxv)
+                                                       DevFilter f, int32_t *dst, int dstW, int sh, int maxv, int rc)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dstW || y >= srcH) return;
@@ -46,7 +46,14 @@ __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int s
         }
         val += s[0] * (int)(short)(cf & 0xFFFF) + s[1] * (cf >> 16);
     }
-    dst[(size_t)y * dstW + x] = min(val >> sh, maxv);
+    int v = min(val >> sh, maxv);
+    // range conversion of a 19-bit line (lum / chrRange{To,From}Jpeg16_c, swscale.c:189-226) in the reference's 32-bit arithmetic: the
+    // chroma ToJpeg product passes 2^31 on its way, only the difference fits
+    if (rc == 1)      v = (int)((unsigned)min(v, 30189 << 4) * 4769u - (unsigned)(39057361 << 2)) >> 12;
+    else if (rc == 2) v = (int)((unsigned)v * (unsigned)(14071 / 4) + (unsigned)((33561947 << 4) / 4)) >> 12;
+    else if (rc == 3) v = (int)((unsigned)min(v, 30775 << 4) * 4663u - (unsigned)(9289992 << 4)) >> 12;
+    else if (rc == 4) v = (int)((unsigned)v * 1799u + (unsigned)(4081085 << 4)) >> 11;
+    dst[(size_t)y * dstW + x] = v;
 }
 
 // planes == 1: one plane -> 16-bit samples at dst + 2x.  planes == 2: U and V lines -> interleaved 16-bit pairs at dst + 4x.
@@ -128,14 +135,14 @@ int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int 
 }
 
 int launch_hscale19(const uint8_t *src, int ss, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst, int dstW,
-                    hipStream_t stream, int to15)
+                    hipStream_t stream, int to15, int rangeConv)
 {
     if (dstW <= 0 || srcH <= 0) return 0;
     // hScale8To19_c: 3; hScale16To19_c: depth - 1 - 4; hScale16To15_c (to15): depth - 1, 13 for the 14-bit alpha of an 8-bit format
     // (an 8-bit RGB source's lines — kind 14, and its alpha, kind 208 — go to 19 bits by 9: swscale.c:74-76)
     const int sh = to15 ? (kind == 208 ? 13 : kind % 100 - 1) : kind == 0 ? 3 : kind == 208 ? 9 : kind % 100 - 5;
     const dim3 grid((dstW + 255) / 256, srcH), block(256);
-    hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh, to15 ? (1 << 15) - 1 : (1 << 19) - 1);
+    hipLaunchKernelGGL(hscale19_kernel, grid, block, 0, stream, src, ss, kind, step, srcW, srcH, f, dst, dstW, sh, to15 ? (1 << 15) - 1 : (1 << 19) - 1, rangeConv);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

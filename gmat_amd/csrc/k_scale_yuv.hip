@@ -686,11 +686,9 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
     const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;      // YUV destinations, and the RGB ones the RGB scaler has no writer for
     const bool pl16 = pl16_depth(p.srcFormat) != 0;
     if (!(is_yuv8_src(p.srcFormat) || is_p01x(p.srcFormat) || pl16 || rgbSrc) || !(is_packed_rgb(p.dstFormat) || yuvOut)) return GMAT_ERR(ENOSYS);
-    if (rgbSrc && (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs)) return GMAT_ERR(ENOSYS);
     if (is_p01x(p.srcFormat) || pl16) {
         // the P016 image is biased by -32768, undone by a start value that assumes every horizontal row sums to
-        // 16384 (initFilter normalises exactly, utils.c:721-741); filters beyond 16 taps have no 16-bit variant
-        if (p.hLum.pairs > kYMaxPairs || p.hChr.pairs > kYMaxPairs) return GMAT_ERR(ENOSYS);
+        // 16384 (initFilter normalises exactly, utils.c:721-741)
         for (const FilterBank *fb : {&p.hLum, &p.hChr})
             for (int x = 0; x < fb->count; x++) {
                 int sum = 0;
@@ -798,9 +796,9 @@ int launch_scale_yuv(const YuvScaleArgs &a, const YuvScaleTiling &t, hipStream_t
     const dim3 grid(t.xcdRemap ? 8 * ((ntiles + 7) / 8) : ntiles, nframes), block(256);
     const size_t lds = (size_t)t.ldsBytes;
     const bool longH = a.hLum.pairs > kYMaxPairs || a.hChr.pairs > kYMaxPairs;
-    if (a.src16 && longH) return GMAT_ERR(ENOSYS);
 #define GMAT_LAUNCH_YUV(TW_, MODE_) \
-    do { if (a.src16)  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, true>), grid, block, lds, stream, a, fr); \
+    do { if (a.src16 && longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true, true>), grid, block, lds, stream, a, fr); \
+         else if (a.src16)  hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, true>), grid, block, lds, stream, a, fr); \
          else if (longH) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, true, false>), grid, block, lds, stream, a, fr); \
          else       hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv_kernel<TW_, MODE_, false, false>), grid, block, lds, stream, a, fr); } while (0)
     const int mode = t.yuvOut == 2 ? 3 : t.yuvOut ? 2 : t.fullChroma ? 1 : 0;

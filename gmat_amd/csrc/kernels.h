@@ -126,7 +126,7 @@ const char *yuvscale_kernel_name(const YuvScaleTiling &t);
 // kind 0: 8-bit samples; 10 / 16: 16-bit samples (P010: >> 6); step = bytes between consecutive samples of the plane
 // kind 208: 8-bit alpha samples (a << 6 | a >> 2); to15: hScale16To15_c's shift and clamp instead (the alpha lines of an 8-bit destination)
 int launch_hscale19(const uint8_t *src, int srcStride, int kind, int step, int srcW, int srcH, const DevFilter &f, int32_t *dst,
-                    int dstW, hipStream_t stream, int to15 = 0);
+                    int dstW, hipStream_t stream, int to15 = 0, int rangeConv = 0);   // rangeConv: 1 / 2 luma to / from full range, 3 / 4 chroma
 // lineB == nullptr: one plane of 16-bit samples; else U / V lines -> interleaved 16-bit pairs
 int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int lineH, const DevFilter &f, uint8_t *dst, int dstStride,
                     int dstW, int dstH, hipStream_t stream);

@@ -158,8 +158,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     if (!(is_rgb(src_fmt) || is_rgb64(src_fmt) || is_yuv(src_fmt) || is_p01x(src_fmt) || pl16_depth(src_fmt)) ||
         !(is_rgb(dst_fmt) || is_yuv(dst_fmt) || is_p01x(dst_fmt) || is_dst16(dst_fmt) || dst_fmt == ORC_PIX_YUV420P10LE))
         return NULL;
-    if (is_dst16(dst_fmt) && src_range != dst_range)
-        return NULL;
+
     if (src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1)
         return NULL;
     c = (OrcSws *)calloc(1, sizeof(*c));
@@ -791,6 +790,21 @@ static void hscale19(int32_t *dst, int dst_w, const uint16_t *src, const int16_t
     }
 }
 
+/* range conversion of the 19-bit lines (swscale.c:189-226, selected :545-552), in the reference's own 32-bit arithmetic — the chroma
+ * ToJpeg product passes 2^31 on its way and only the difference fits */
+static void range19(const OrcSws *c, int32_t *d, int w, int chroma)
+{
+    int i;
+    if (c->range_conv == 1 && !chroma)
+        for (i = 0; i < w; i++) d[i] = (int)((unsigned)imin(d[i], 30189 << 4) * 4769U - (unsigned)(39057361 << 2)) >> 12;
+    else if (c->range_conv == 2 && !chroma)
+        for (i = 0; i < w; i++) d[i] = (int)((unsigned)d[i] * (unsigned)(14071 / 4) + (unsigned)((33561947 << 4) / 4)) >> 12;
+    else if (c->range_conv == 1)
+        for (i = 0; i < w; i++) d[i] = (int)((unsigned)imin(d[i], 30775 << 4) * 4663U - (unsigned)(9289992 << 4)) >> 12;
+    else if (c->range_conv == 2)
+        for (i = 0; i < w; i++) d[i] = (int)((unsigned)d[i] * 1799U + (unsigned)(4081085 << 4)) >> 11;
+}
+
 static void put16(uint8_t *d, int v) { d[0] = (uint8_t)(v & 0xFF); d[1] = (uint8_t)(v >> 8); }
 
 static int planeX16(const int32_t *const *src, const int16_t *filter, int fs, int i)
@@ -832,6 +846,7 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
                 t0[i] = (uint16_t)((src16 || pl16) ? (p010 ? rl16(row + 2 * i) >> 6 : rl16(row + 2 * i)) : row[i]);
         }
         hscale19(ly + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
+        range19(c, ly + (size_t)y * dw, dw, 0);
         if (la) {
             alpha_samples(c, row, t0);
             hscale19(la + (size_t)y * dw, dw, t0, c->h_lum, c->h_lum_pos, c->h_lum_size, sh);
@@ -857,6 +872,8 @@ static int make_lines19(OrcSws *c, const uint8_t *const src[4], const int src_st
         }
         hscale19(lu + (size_t)y * cdw, cdw, t0, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
         hscale19(lv + (size_t)y * cdw, cdw, t1, c->h_chr, c->h_chr_pos, c->h_chr_size, sh);
+        range19(c, lu + (size_t)y * cdw, cdw, 1);
+        range19(c, lv + (size_t)y * cdw, cdw, 1);
     }
     free(t0); free(t1);
     *pl = ly; *pu = lu; *pv = lv;

@@ -62,9 +62,7 @@ def test_every_writer_form(dev, orc, flags, df):
     """the packed writers' one-tap, two-tap and X forms each have their own alpha rounding (output.c:1709-1821, :2069-2175; 64-bit
     :1052-1064, :1144-1150, :1196-1202): same height (one tap), bilinear up-scale (two proper taps), down-scales (X); chroma
     halved or not at the source (full_chr_h_inp, fast_bilinear) and at the writer (full_chr_h_int)"""
-    # (the 16-bit loader of the tiled plane scaler holds horizontal filters of up to 16 taps — 3.7:1 bicubic — for every 16-bit
-    # source; 96 -> 30 chroma samples with full_chr_h_inp stays inside)
-    for geom in [(64, 24, 64, 24), (64, 24, 128, 24), (64, 24, 96, 48), (64, 24, 128, 60), (96, 40, 60, 30)]:
+    for geom in [(64, 24, 64, 24), (64, 24, 128, 24), (64, 24, 96, 48), (64, 24, 128, 60), (96, 40, 50, 30)]:
         _run(dev, orc, "rgba64le", df, geom, flags)
 
 
@@ -199,3 +197,28 @@ def test_8bit_rgb_sources_to_16bit_destinations(dev, orc, sf, df):
         _run(dev, orc, sf, df, geom)
     _run(dev, orc, sf, df, (64, 24, 128, 48), "bilinear")
     _run(dev, orc, sf, df, (64, 24, 64, 24), "fast_bilinear")
+
+
+@pytest.mark.parametrize("sf", ["p010le", "p016le", "yuv420p16le", "yuv420p10le", "yuv444p16le", "rgba64le", "rgb24"])
+@pytest.mark.parametrize("df", ["nv12", "rgb24", "yuv420p", "p010le", "bgra"])
+def test_16bit_lines_with_long_horizontal_filters(dev, orc, sf, df):
+    """16-bit samples (and an 8-bit RGB source's 16-bit lines) at down-scale ratios beyond 3.7:1 — horizontal filters of more than 16
+    taps (4K P010 -> 480p ...): refused through round 2 ("no 16-bit variant" of the tiled kernel's long-filter loop); the two template
+    switches were independent all along"""
+    def valid(p):
+        if sf == "yuv420p10le":
+            v = p.view(np.uint16); v &= 0x3FF                   # a 10-bit format holds 10-bit samples
+        if sf == "p010le":
+            v = p.view(np.uint16); v &= 0xFFC0
+    for geom in [(384, 96, 80, 20), (640, 64, 100, 32), (300, 60, 50, 30), (512, 32, 64, 16)]:
+        sw, sh, dw, dh = geom
+        src = synth_planes(orc, sf, sw, sh, seed=3)
+        for p in src:
+            valid(p)
+        want = orc.sws(src, sw, sh, sf, dw, dh, df, SWS["bicubic"])
+        d = dev.upload_planes(src, 64)
+        got, pads, kernel = dev.sws(d, sw, sh, sf, dw, dh, df, SWS["bicubic"], dst_align=64)
+        for pl in d:
+            pl.free()
+        assert all((a == b).all() for a, b in zip(got, want)), (geom, kernel)
+        assert all((p == 0xCD).all() for p in pads)

@@ -720,8 +720,8 @@ def test_full_range_planar_depth_expansion(dev, orc, pair):
     assert lib.gmat_sws_setRange(c, 1, 1) == 0
     got, k = run()
     assert k == "plane_copy_up_kernel" and all((g == wv).all() for g, wv in zip(got, want))
-    if depth == 10:                                               # differing ranges: the generic lines carry the conversion
-        assert lib.gmat_sws_setRange(c, 1, 0) == 0
+    if True:                                                      # differing ranges: the generic lines carry the conversion (15-bit
+        assert lib.gmat_sws_setRange(c, 1, 0) == 0                # lines for the 10-bit destination, 19-bit lines for the 16-bit ones)
         got, k = run()
         oc = orc.L.orc_sws_create_ex(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(-513, -513, -513, -513), 1, 0)
         assert oc
@@ -730,8 +730,6 @@ def test_full_range_planar_depth_expansion(dev, orc, pair):
                                    planes([p.ctypes.data for p in ow]), ints([p.strides[0] for p in ow])) == h
         orc.L.orc_sws_free(oc)
         assert k == k0 and all((g == wv).all() for g, wv in zip(got, ow))
-    else:                                                         # the 19-bit path has no range conversion: refused, not ignored
-        assert lib.gmat_sws_setRange(c, 1, 0) == -38
     assert lib.gmat_sws_setRange(c, 0, 0) == 0
     got, k = run()
     assert k == k0 and all((g == wv).all() for g, wv in zip(got, shifted))
@@ -1010,12 +1008,46 @@ def test_same_size_special_converters_leave_for_the_generic_path_when_ranges_dif
         p.free()
 
 
-def test_differing_ranges_are_refused_where_there_is_no_conversion(dev):
-    """the 19-bit path (P016LE / YUV444P16LE destinations) carries no range conversion: -ENOSYS, not a silent copy"""
-    lib = dev.lib
-    for sf, df in (("nv12", "p016le"), ("p016le", "p016le"), ("yuv444p16le", "yuv444p16le"), ("nv12", "yuv444p16le")):
-        c = lib.gmat_sws_getContext(64, 32, PIX_FMT[sf], 64, 32, PIX_FMT[df], SWS["bicubic"], None)
-        assert c
-        assert lib.gmat_sws_setRange(c, 0, 0) == 0 and lib.gmat_sws_setRange(c, 1, 1) == 0
-        assert lib.gmat_sws_setRange(c, 1, 0) < 0 and lib.gmat_sws_setRange(c, 0, 1) < 0
+@pytest.mark.parametrize("ranges", [(0, 1), (1, 0)])
+@pytest.mark.parametrize("pair", [("nv12", "p016le"), ("p016le", "p016le"), ("yuv444p16le", "yuv444p16le"), ("nv12", "yuv444p16le"),
+                                  ("yuv420p", "yuv420p16le"), ("p010le", "p016le"), ("rgba64le", "yuv444p16le")])
+def test_range_conversion_on_the_19bit_lines(dev, orc, pair, ranges):
+    """16-bit YUV destinations with differing ranges: lum / chrRange{To,From}Jpeg16_c on the 19-bit lines (swscale.c:189-226; the
+    chroma ToJpeg product wraps past 2^31 on its way) — refused through round 2; at equal size the special converters step aside
+    (utils.c:1996-2000); an RGB destination has no range of its own (swscale.c:536)"""
+    import ctypes as C
+    from harness import alloc_planes, planes, ints
+    sf, df = pair
+    if sf == "rgba64le" and ranges[0]:
+        pytest.skip("an RGB source has no range")
+    L, lib = orc.L, dev.lib
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    for (sw, sh, dw, dh) in [(64, 32, 64, 32), (96, 40, 50, 30), (64, 24, 96, 36)]:
+        src = synth_planes(orc, sf, sw, sh, seed=44)
+        if sf == "p010le":
+            for p in src:
+                v = p.view(np.uint16); v &= 0xFFC0
+        src[0][0, :8] = [0, 0, 255, 255, 16, 0, 235, 255]            # extremes of either range, whatever the sample width
+        oc = L.orc_sws_create_ex(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(-513, -513, -513, -513), ranges[0], ranges[1])
+        assert oc
+        want = alloc_planes(df, dw, dh)
+        assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                               planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == dh
+        L.orc_sws_free(oc)
+        c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS["bicubic"], None)
+        assert c and lib.gmat_sws_setRange(c, ranges[0], ranges[1]) == 0
+        d = dev.upload_planes(src, 64)
+        dst = dev.planes_like(df, dw, dh, 64)
+        assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                                  planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == dh
+        got = [p.download() for p in dst]
+        for i, (g, wv) in enumerate(zip(got, want)):
+            assert (g == wv).all(), (pair, ranges, (sw, sh, dw, dh), i, np.argwhere(g != wv)[:3].tolist())
+        assert lib.gmat_sws_setRange(c, 0, 0) == 0
         lib.gmat_sws_freeContext(c)
+        for p in d + dst:
+            p.free()
+    c = lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 32, 16, PIX_FMT["rgba64le"], SWS["bicubic"], None)
+    assert c and lib.gmat_sws_setRange(c, 0, 1) < 0
+    lib.gmat_sws_freeContext(c)
