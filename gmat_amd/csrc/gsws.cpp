@@ -1518,11 +1518,12 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
 int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_pos, int dst_h_chr_pos, int dst_v_chr_pos)
 {
     if (!c) return GMAT_ERR(EINVAL);
-    if (c->mode != MODE_SCALE || !is_plane_src(c->srcFormat)) return GMAT_ERR(ENOSYS);
+    if ((c->mode != MODE_SCALE && c->mode != MODE_SCALE16) || !is_plane_src(c->srcFormat) || is_priv_planes(c->srcFormat)) return GMAT_ERR(ENOSYS);
     const int np[4] = {src_h_chr_pos, src_v_chr_pos, dst_h_chr_pos, dst_v_chr_pos};
     for (int i = 0; i < 4; i++)
         if (np[i] < -513 || np[i] > 512) return GMAT_ERR(EINVAL);           // option range, options.c:67-70
     std::memcpy(c->chrPos, np, sizeof(np));
+    if (c->mode == MODE_SCALE16) return init_scale16(c);                     // the 19-bit path's own filter banks
     c->fused = 2;
     c->yuvReady = false;                     // the chroma filter banks depend on the positions
     return init_yuv_scaler(c);

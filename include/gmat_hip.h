@@ -53,8 +53,7 @@ enum GmatPixelFormat {
                                        (planar8ToP01xleWrapper); equal format and size: plane copy.  Both are also
                                        scaled destinations of every YUV source: P010LE on the 15-bit lines
                                        (yuv2p010lX_c / cX_c), P016LE on libswscale's 19-bit lines (hScale8To19_c,
-                                       yuv2planeX_16_c; a plain two-pass path, default chroma positions and
-                                       equal ranges only) */
+                                       yuv2planeX_16_c; a plain two-pass path) */
     GMAT_PIX_FMT_RGBPF32LE = 179,   /* GMAT addition, pixfmt.h:315 */
 };
 

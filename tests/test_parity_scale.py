@@ -1051,3 +1051,33 @@ def test_range_conversion_on_the_19bit_lines(dev, orc, pair, ranges):
     c = lib.gmat_sws_getContext(64, 32, PIX_FMT["nv12"], 32, 16, PIX_FMT["rgba64le"], SWS["bicubic"], None)
     assert c and lib.gmat_sws_setRange(c, 0, 1) < 0
     lib.gmat_sws_freeContext(c)
+
+
+@pytest.mark.parametrize("pair", [("nv12", "p016le"), ("yuv420p", "yuv444p16le"), ("p016le", "yuv420p16le"), ("yuv444p16le", "p016le")])
+def test_chroma_positions_on_the_19bit_path(dev, orc, pair):
+    """src_h / src_v / dst_h / dst_v_chr_pos (options.c:67-70) on contexts with a 16-bit destination: the 19-bit path's own filter banks"""
+    import ctypes as C
+    from harness import alloc_planes, planes, ints
+    sf, df = pair
+    L, lib = orc.L, dev.lib
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    for pos in [(0, 128, 0, 128), (128, 0, 256, 64), (-513, 128, -513, -513), (37, -200, 511, 3)]:
+        for (sw, sh, dw, dh) in [(96, 40, 50, 30), (64, 24, 96, 36)]:
+            src = synth_planes(orc, sf, sw, sh, seed=52)
+            oc = L.orc_sws_create_ex(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(*pos), 0, 0)
+            assert oc
+            want = alloc_planes(df, dw, dh)
+            assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                   planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == dh
+            L.orc_sws_free(oc)
+            c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS["bicubic"], None)
+            assert c and lib.gmat_sws_setChromaPos(c, *pos) == 0
+            d = dev.upload_planes(src, 64)
+            dst = dev.planes_like(df, dw, dh, 64)
+            assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, sh,
+                                      planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == dh
+            assert all((p.download() == wv).all() for p, wv in zip(dst, want)), (pair, pos)
+            lib.gmat_sws_freeContext(c)
+            for p in d + dst:
+                p.free()
