@@ -69,11 +69,11 @@ __device__ __forceinline__ void lds_to_row(uint8_t *row, int b0, int n, const ui
 // 66-row tile cost three dependent HBM round trips per wave and the load phase alone took 21 of the 3x3 smooth's
 // 37 us.  Chunks that stick out of [0, rowBytes) (tiles on the left / right frame edge) or unaligned sources are
 // assembled bytewise with the column clamped.
-template <int CL, int K, typename RowOf>
+template <int CL, int K, int NTH = 256, typename RowOf>
 __device__ __forceinline__ void tile_to_lds16(const uint8_t *src, int ss, int rowBytes, int a16, int n16, int nrows,
                                               uint8_t *lds, int pitch, int tid, bool fast, RowOf rowOf)
 {
-    constexpr int RPP = 256 / CL;                          // rows per pass
+    constexpr int RPP = NTH / CL;                          // rows per pass (NTH threads a tile)
     const int c = tid % CL, rb = tid / CL;
     const int a = a16 + 16 * c;
     const bool inside = fast && a >= 0 && a + 16 <= rowBytes;
@@ -138,12 +138,14 @@ __device__ __forceinline__ void lds_to_tile16(uint8_t *dst, int ds, int b0, int 
 //   BPP 1     — the tile is cut into 4x4 byte blocks, each transposed in registers with 8 v_perm_b32; rows are
 //               rotated by (row >> 2) dwords in LDS so the four row reads of a block are conflict-free.
 // Everything else (partial tiles, unaligned frames, 2-byte samples) goes through the byte-wise path below it.
-template <int BPP, int T>
-__global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
+// NT: threads per tile.  128 x 128 tiles of 1- and 2-byte samples run with 1024 (full 128-byte lines on both sides AND as many waves in
+// flight as the 64 x 64 tiling has: with 256 threads a 4K plane's 510 tiles left the chip short of waves — 12.4 us against 7.8).
+template <int BPP, int T, int NT = 256>
+__global__ __launch_bounds__(NT) void transpose_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
                                                         int inW, int inH, int dir, int aligned)
 {
     constexpr int PITCH = T * BPP + 4;                  // +4 B: odd dword pitch, conflict-light columns
-    constexpr int GENERIC_BYTES = T * PITCH + 4 * T * BPP;
+    constexpr int GENERIC_BYTES = T * PITCH + (NT / 64) * T * BPP;
     constexpr int PXP = T + 1;                          // dword-pixel tile pitch (BPP 3 / 4)
     constexpr int FAST_BYTES = BPP >= 3 ? T * PXP * 4 : T * T * BPP;
     constexpr int LDS_BYTES = GENERIC_BYTES > FAST_BYTES ? GENERIC_BYTES : FAST_BYTES;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
         // the dwords of rows 2*rblk and 2*rblk + 1 at column q give the dwords of output rows 2*q and 2*q + 1 at byte 4*rblk,
         // so a wave's store is one contiguous run per output row.
         constexpr int DW = T / 2;                                               // dwords per tile row
-        constexpr int CPR = DW / 4, RPP = 256 / CPR, NPASS = T / RPP;           // 16-byte chunks per row, rows per pass, passes
+        constexpr int CPR = DW / 4, RPP = NT / CPR, NPASS = T / RPP;            // 16-byte chunks per row, rows per pass, passes
         unsigned *t32 = reinterpret_cast<unsigned *>(smem);                     // [T rows][DW dwords], row R rotated by R >> 1
         {
             const int c = tid % CPR, rb = tid / CPR;
@@ -245,11 +247,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
             }
         }
         __syncthreads();
-        constexpr int NR = T / 2, QPW = 64 / NR, NIT = DW / (4 * QPW);           // row pairs; q's per wave and pass; passes
+        constexpr int NW = NT / 64;
+        constexpr int NR = T / 2, QPW = 64 / NR, NIT = DW / (NW * QPW);          // row pairs; q's per wave and pass; passes
         const int rblk = lane & (NR - 1);
 #pragma unroll 4
         for (int it = 0; it < NIT; it++) {
-            const int q = it * 4 * QPW + wave * QPW + lane / NR;
+            const int q = it * NW * QPW + wave * QPW + lane / NR;
             const unsigned d0 = t32[(2 * rblk + 0) * DW + ((q + rblk) & (DW - 1))], d1 = t32[(2 * rblk + 1) * DW + ((q + rblk) & (DW - 1))];
             const size_t xb = (size_t)iy0 * 2 + 4 * rblk;
             *reinterpret_cast<unsigned *>(dst + (size_t)orowOf(2 * q + 0) * ds + xb) = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
     if (BPP == 1 && fast) {
         static_assert(BPP != 1 || T == 128 || T == 64, "NB x NB blocks of 4 x 4 bytes, NB = 32 | 16");
         constexpr int NB = T / 4;                                               // blocks (= dwords) per tile row
-        constexpr int CPR = T / 16, RPP = 256 / CPR, NPASS = T / RPP;          // 16-byte chunks per row, rows per pass of the 256 threads, passes
+        constexpr int CPR = T / 16, RPP = NT / CPR, NPASS = T / RPP;           // 16-byte chunks per row, rows per pass of the NT threads, passes
         unsigned *t32 = reinterpret_cast<unsigned *>(smem);                     // [T rows][NB dwords], row R rotated by R >> 2
         {
             const int c = tid % CPR, rb = tid / CPR;
@@ -278,11 +281,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
         }
         __syncthreads();
         // block (rblk, q): source rows 4*rblk .. +3, dword column q  ->  output rows 4*q .. +3, bytes 4*rblk .. +3
-        constexpr int QPW = 64 / NB, NIT = NB / (4 * QPW);                       // q's per wave and pass; passes
+        constexpr int NW = NT / 64;
+        constexpr int QPW = 64 / NB, NIT = NB / (NW * QPW);                      // q's per wave and pass; passes
         const int rblk = lane & (NB - 1);
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int q = it * 4 * QPW + wave * QPW + lane / NB;
+            const int q = it * NW * QPW + wave * QPW + lane / NB;
             const unsigned d0 = t32[(4 * rblk + 0) * NB + ((q + rblk) & (NB - 1))], d1 = t32[(4 * rblk + 1) * NB + ((q + rblk) & (NB - 1))],
                            d2 = t32[(4 * rblk + 2) * NB + ((q + rblk) & (NB - 1))], d3 = t32[(4 * rblk + 3) * NB + ((q + rblk) & (NB - 1))];
             const unsigned lo01 = __builtin_amdgcn_perm(d1, d0, 0x05010400u), hi01 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);
@@ -305,13 +309,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint8_t *src, int 
         // ix0 * BPP is a multiple of 16 for every (BPP, T) instantiated, so tile byte 0 is chunk-aligned
         static_assert((T * BPP) % 16 == 0 && T * BPP <= 256, "tile rows are whole 16-byte chunks");
         constexpr int CL = T * BPP / 16 <= 8 ? 8 : 16;
-        constexpr int K = (T + 256 / CL - 1) / (256 / CL);
+        constexpr int K = (T + NT / CL - 1) / (NT / CL);
         const bool fast16 = ((((uintptr_t)src | (uintptr_t)ss) & 15) == 0);
-        tile_to_lds16<CL, K>(src, ss, inW * BPP, ix0 * BPP, (tw * BPP + 15) >> 4, th, tile, PITCH, tid, fast16, srow);
+        tile_to_lds16<CL, K, NT>(src, ss, inW * BPP, ix0 * BPP, (tw * BPP + 15) >> 4, th, tile, PITCH, tid, fast16, srow);
     }
     __syncthreads();
     // output: out(x = iy0 + r, y = ix0 + c) = tile[r][c]; out is inH wide, inW tall
-    for (int c = wave; c < tw; c += 4) {
+    for (int c = wave; c < tw; c += NT / 64) {
         for (int r = lane; r < th; r += 64)
             for (int b = 0; b < BPP; b++) orow[wave][r * BPP + b] = tile[r * PITCH + c * BPP + b];
         __builtin_amdgcn_wave_barrier();
@@ -565,32 +569,6 @@ static inline int al4(const void *a, int sa, const void *b, int sb)
     return ((((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0);
 }
 
-int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, int dir,
-                     hipStream_t stream)
-{
-    if (inW <= 0 || inH <= 0) return 0;
-    if (dir < 0 || dir > 3) return GMAT_ERR(EINVAL);
-    // 1- and 2-byte samples (the planes of planar / semi-planar YUV) use 128x128 tiles so that a tile row
-    // is still >= 128 B of contiguous HBM traffic
-    // ... unless that leaves the chip short of workgroups (a 4K luma plane is 510 tiles of 128 x 128 on 256 CUs, each a single
-    // load -> LDS -> store pass: 12.4 us): 1- and 2-byte planes then take 64 x 64 tiles.  GMAT_TRANSPOSE_TILE = 64 | 128 overrides (measurement).
-    const char *te = GMAT_KNOB("GMAT_TRANSPOSE_TILE");
-    const int tiles128 = ((inW + 127) / 128) * ((inH + 127) / 128);
-    const int T = bpp <= 2 ? ((te ? atoi(te) == 64 : tiles128 < 2048) ? 64 : 128) : 64;
-    const int ntiles = ((inW + T - 1) / T) * ((inH + T - 1) / T);
-    const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);
-    const int aligned = al4(src, ss, dst, ds);
-    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else return GMAT_ERR(ENOSYS);
-    GMAT_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 int launch_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int fh, int fv,
                 hipStream_t stream)
 {
@@ -635,8 +613,11 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
 // TRANSPOSED (rotate 90 + hflip, see launch_rotate_flip_smooth): results go byte-wise into a transposed LDS tile (odd
 // dword pitch), one block barrier, then rows of TH * BPP bytes leave as dwordx4 stores.  LDS 12.5 KB, <= 64 VGPRs: the
 // 2040 tiles of a 4K frame are all resident at once (8 blocks per CU).
-template <int BPP, bool TRANSPOSED, int TD, int RPW>
-__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16)
+// IDENT: no filter — the plain transpose of 3- / 4-byte pixels through this kernel's loads and transposed tile (dir: vf_transpose's
+// four directions, bit 0 reads the source bottom-up, bit 1 writes the destination bottom-up): 13.6 us per 4K rgb24 frame against
+// transpose_kernel<3, 64>'s 16.0.
+template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false>
+__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir)
 {
     constexpr int TH = 64, NS = RPW + 2, NT = 64 * TH / RPW;  // tile: TD dwords x 64 rows; RPW rows per wave; source rows per wave; threads
     static_assert(TD + 2 <= 64 && (TD * 4) % BPP == 0, "tile width: whole pixels, two halo lanes");
@@ -669,6 +650,7 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
             yy = yy < 0 ? -yy : yy;
             yy = yy >= h ? 2 * h - 1 - yy : yy;
             yy = min(max(yy, 0), h - 1);
+            if (IDENT && (dir & 1)) yy = h - 1 - yy;
             wv[s] = *reinterpret_cast<const unsigned *>(src + ((unsigned)(yy * ss) + colOff));
         }
         if (d0 == 0) {                                      // pixel -1 := pixel 1
@@ -716,7 +698,7 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
                     else if (BPP == 2) { le = (vep >> 16) | (ve << 16); lo = (vop >> 16) | (vo << 16); re = (ve >> 16) | (ven << 16);  ro = (vo >> 16) | (von << 16); }
                     else if (BPP == 3) { le = vop;                      lo = (vep >> 16) | (ve << 16); re = (vo >> 16) | (von << 16);  ro = ven; }
                     else               { le = vep;                      lo = vop;                      re = ven;                       ro = von; }
-                    const unsigned he = (le + 2 * ve + re + 0x00080008u) >> 4, ho = (lo + 2 * vo + ro + 0x00080008u) >> 4;
+                    const unsigned he = IDENT ? e1 : (le + 2 * ve + re + 0x00080008u) >> 4, ho = IDENT ? o1 : (lo + 2 * vo + ro + 0x00080008u) >> 4;
                     if (TRANSPOSED) {
                         if (BPP == 4) {
                             *reinterpret_cast<unsigned *>(pj[0] + r * 4) = __builtin_amdgcn_perm(ho, he, 0x06020400u);
@@ -738,18 +720,19 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
     __syncthreads();
     // rows of the transposed tile: pixel column px of the source tile -> destination row x0 + px, bytes [y0*BPP, +th*BPP)
     const int npx = nd * 4 / BPP, x0 = d0 * 4 / BPP, nbytes = th * BPP;
+    auto orow = [&](int r) { return (IDENT && (dir & 2)) ? w - 1 - r : r; };       // the destination is w rows tall
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     if (dst16 && (nbytes & 15) == 0) {
         const int cpr = nbytes >> 4;                        // 16-byte chunks per row (<= 16)
         for (int px = ty; px < npx; px += NT / 16) {
             if (tx < cpr) {
                 const unsigned *l = reinterpret_cast<const unsigned *>(rt + px * PT + 16 * tx);
-                *reinterpret_cast<uint4 *>(dst + (size_t)(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx) = make_uint4(l[0], l[1], l[2], l[3]);
+                *reinterpret_cast<uint4 *>(dst + (size_t)orow(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx) = make_uint4(l[0], l[1], l[2], l[3]);
             }
         }
     } else {
         for (int px = ty; px < npx; px += NT / 16)
-            lds_to_row(dst + (size_t)(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, 16, (y0 * BPP & 3) == 0);
+            lds_to_row(dst + (size_t)orow(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, 16, (y0 * BPP & 3) == 0);
     }
 }
 
@@ -759,6 +742,48 @@ static bool smooth121_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w
     const bool off = GMAT_KNOB("GMAT_NO_SMOOTH121") != nullptr;                        // A/B switch for the benches and tests
     return !off && bpp >= 1 && bpp <= 4 && ((w * bpp) & 3) == 0 && w >= 4 && al4(src, ss, dst, ds) && (int64_t)ss * h < (1ll << 31) &&
            (int64_t)ds * std::max(w, h) < (1ll << 31);
+}
+
+int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, int dir,
+                     hipStream_t stream)
+{
+    if (inW <= 0 || inH <= 0) return 0;
+    if (dir < 0 || dir > 3) return GMAT_ERR(EINVAL);
+    // 1- and 2-byte samples (the planes of planar / semi-planar YUV) use 128 x 128 tiles so that a tile row is >= 128 B of contiguous
+    // HBM traffic on BOTH sides, with 1024 threads a tile so that the chip holds as many waves as with 64 x 64 tiles (256 threads on
+    // 128 x 128: 12.4 us per 4K luma plane; 64 x 64: 7.8 us; 128 x 128 with 1024 threads: 6.5 us).  GMAT_TRANSPOSE_TILE overrides (A/B).
+    const char *te = GMAT_KNOB("GMAT_TRANSPOSE_TILE");             // 64 | 128 (256 threads) | 1128 (128 x 128, 1024 threads): A/B
+    const int tv = te ? atoi(te) : 0;
+    const int tiles128 = ((inW + 127) / 128) * ((inH + 127) / 128);
+    const int T = bpp <= 2 ? ((tv ? tv == 64 : tiles128 < 2048) ? 64 : 128) : 64;
+    const bool big = bpp <= 2 && (tv == 1128 || tv == 0);   // default (profiles/r03x_transpose_tiles.txt: 4K gray 7.8 -> 6.5 us, 2-byte 11.2 -> 10.0)
+    const int TT = big ? 128 : T;
+    const int ntiles = ((inW + TT - 1) / TT) * ((inH + TT - 1) / TT);
+    const dim3 grid(8 * ((ntiles + 7) / 8)), block(big ? 1024 : 256);
+    const int aligned = al4(src, ss, dst, ds);
+    if ((bpp == 3 || bpp == 4) && tv == 0 && smooth121_ok(src, ss, dst, ds, inW, inH, bpp)) {
+        // packed RGB: the 3 x 3 smooth's transposed form with its filter left out (dword-per-lane row loads, byte-transposed LDS tile,
+        // 16-byte row stores)
+        const int td = bpp == 3 ? 60 : 62;
+        const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
+        const dim3 g2(8 * ((nt + 7) / 8));
+        const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8, true>), g2, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    else return GMAT_ERR(ENOSYS);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, const int m[9],
@@ -778,10 +803,10 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
         const int nt = ((w * bpp / 4 + td - 1) / td) * ((h + 63) / 64);
         const dim3 g(8 * ((nt + 7) / 8)), b(256);
         switch (bpp) {
-        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0); break;
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
         }
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1554,8 +1579,8 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
         const dim3 g(8 * ((nt + 7) / 8)), b(256);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
         // rgb24: 8 rows per wave (512 threads a tile) measured 2-3 % ahead of 16 (14.2 vs 14.5 us per 4K frame)
-        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16);
-        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16);
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, 0);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16, 0);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
