@@ -565,6 +565,14 @@ def c_harness(dry):
         res["filters, one 4K frame per launch"] = [{"error": repr(e)}]
     # the same calls with two / three frames in flight (launches round-robin over that many streams, as `value` has its launch
     # sets): a launch boundary costs 1.6 us + the ramp of a 50 MB kernel, which a second stream hides (profiles/r03r_*)
+    # the queued filter form (option batch / gmat_op_batch): N frames through ONE launch, grid dimension = frame
+    for nf in (4, 16):
+        key = "filters, %d 4K frames per launch" % nf
+        try:
+            r = subprocess.run([exe, str(nf), "30", "op: "], env=env, capture_output=True, text=True, timeout=300)
+            res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l and "rotate 17" not in l]
+        except Exception as e:                               # noqa: BLE001
+            res[key] = [{"error": repr(e)}]
     for n in (2, 3):
         key = "filters, one 4K frame per launch, %d frames in flight" % n
         try:

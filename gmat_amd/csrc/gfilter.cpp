@@ -242,8 +242,8 @@ int gmat_filter_set_option(GmatFilterContext *f, const char *key, const char *va
 {
     if (!f || !key || !value) return GMAT_ERR(EINVAL);
     static const std::map<Kind, std::string> allowed = {
-        {K_CROP, " w h x y "}, {K_FLIP, " code "}, {K_ROTATE, " angle interp shift_x shift_y "},
-        {K_TRANSPOSE, " dir "}, {K_SMOOTH, " type kw kh border_type sigmaX sigmaY "},
+        {K_CROP, " w h x y "}, {K_FLIP, " code batch "}, {K_ROTATE, " angle interp shift_x shift_y batch "},
+        {K_TRANSPOSE, " dir batch "}, {K_SMOOTH, " type kw kh border_type sigmaX sigmaY batch "},
         {K_SCALE, " w h interp_algo format passthrough param force_original_aspect_ratio force_divisible_by batch "},
         {K_FORMAT, " pix_fmt batch "}};
     const std::string needle = std::string(" ") + key + " ";
@@ -378,9 +378,10 @@ int gmat_filter_init(GmatFilterContext *f)
         if (f->opt.find("pix_fmt") == f->opt.end()) return GMAT_ERR(EINVAL);
         break;
     }
-    // "batch" (no reference counterpart; scale_hip and format_hip): frames the queued entry points collect before they
-    // launch ONE kernel for all of them (gmat_filter_send_frame below)
-    if (f->kind == K_SCALE || f->kind == K_FORMAT) {
+    // "batch" (no reference counterpart): frames the queued entry points collect before they launch ONE kernel for all of them
+    // (gmat_filter_send_frame below) — scale_hip, format_hip, and the transform filters whose kernels take a frame table (flip,
+    // transpose, rotate by k * 90 degrees, the 3 x 3 smooth and median; the others process a full queue frame by frame)
+    if (f->kind != K_CROP) {
         f->batch = opt_int(f, "batch", 1);
         if (f->batch < 1 || f->batch > 256) return GMAT_ERR(EINVAL);
     }
@@ -596,6 +597,8 @@ fail:
 // gmat_sws_scale_batch); receive_frame hands the finished frames out in order; flush launches a partial batch at EOF.
 // Filters without a batched kernel, and batch=1, process each frame at once — the three calls then behave like
 // filter_frame.
+static int op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int w, int h, int bpp, int arg, hipStream_t stream);
+
 static int run_pending(GmatFilterContext *f)
 {
     const int n = (int)f->pending.size();
@@ -606,6 +609,55 @@ static int run_pending(GmatFilterContext *f)
         for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
         f->pending.clear();
         return GMAT_ERR(EIO);
+    }
+    // flip / transpose / rotate by k * 90 degrees / the 3 x 3 smooth and median: one launch per PLANE for the whole batch
+    int top = -1, targ = 0;
+    if (f->kind == K_FLIP) { top = GMAT_OP_FLIP; targ = f->code; }
+    else if (f->kind == K_TRANSPOSE) { top = GMAT_OP_TRANSPOSE; targ = f->dir; }
+    else if (f->kind == K_ROTATE && (f->quarter == 1 || f->quarter == 3)) { top = GMAT_OP_TRANSPOSE; targ = f->quarter == 1 ? 1 : 2; }
+    else if (f->kind == K_ROTATE && f->quarter == 2) { top = GMAT_OP_FLIP; targ = -1; }
+    else if (f->kind == K_SMOOTH && f->smooth_median && f->kw == 3 && f->kh == 3) top = GMAT_OP_MEDIAN3X3;
+    else if (f->kind == K_SMOOTH && !f->smooth_median && !f->gauss_general) top = GMAT_OP_SMOOTH3X3;
+    if (top >= 0 && n > 1) {
+        std::vector<GmatFrame *> outs(n, nullptr);
+        int r = hipSetDevice(f->device) == hipSuccess ? 0 : GMAT_ERR(EIO);
+        for (int i = 0; i < n && r >= 0; i++) {
+            GmatFrame *in = f->pending[i];
+            if (in->format != GMAT_PIX_FMT_HIP || in->sw_format != f->in_fmt || in->width != f->in_w || in->height != f->in_h) { r = GMAT_ERR(EINVAL); break; }
+            outs[i] = gmat_frame_alloc();
+            if (!outs[i]) { r = GMAT_ERR(ENOMEM); break; }
+            r = gmat_hwframe_get_buffer(f->out_frames, outs[i]);
+        }
+        PlaneGeom g[3];
+        const int np = plane_geoms(f->in_fmt, f->in_w, f->in_h, g);
+        bool same = r >= 0;
+        for (int i = 1; i < n && same; i++)
+            for (int k = 0; k < np; k++)
+                same = same && f->pending[i]->linesize[k] == f->pending[0]->linesize[k] && outs[i]->linesize[k] == outs[0]->linesize[k];
+        if (r >= 0 && same) {
+            std::vector<const uint8_t *> sp(n);
+            std::vector<uint8_t *> dp(n);
+            for (int k = 0; k < np && r >= 0; k++) {
+                for (int i = 0; i < n; i++) { sp[i] = f->pending[i]->data[k]; dp[i] = outs[i]->data[k]; }
+                r = op_batch(top, n, sp.data(), f->pending[0]->linesize[k], dp.data(), outs[0]->linesize[k], g[k].w, g[k].h, g[k].bpp, targ, f->stream);
+            }
+            if (r >= 0) {
+                for (int i = 0; i < n; i++) {
+                    outs[i]->pts = f->pending[i]->pts; outs[i]->colorspace = f->pending[i]->colorspace;    // av_frame_copy_props
+                    gmat_frame_free(&f->pending[i]);
+                    f->ready.push_back(outs[i]);
+                }
+                f->pending.clear();
+                return 0;
+            }
+        }
+        for (GmatFrame *&o : outs) if (o) gmat_frame_free(&o);
+        if (r < 0) {
+            for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
+            f->pending.clear();
+            return r;
+        }
+        // frames of differing strides: one by one below
     }
     const bool batched = (f->kind == K_SCALE || f->kind == K_FORMAT) && !f->bypass && n > 1;
     if (batched) {
@@ -751,6 +803,41 @@ int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int i
     knobs_refresh();                             // a stateless call is its own context
     if (!src || !dst) return GMAT_ERR(EINVAL);
     return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, bilinear, fill, (hipStream_t)stream);
+}
+
+// one transform over n frames: kOpMaxFrames frames a launch
+static int op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int w, int h, int bpp, int arg, hipStream_t stream)
+{
+    static const int m121[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
+    for (int i0 = 0; i0 < n; i0 += kOpMaxFrames) {
+        const int m = std::min(kOpMaxFrames, n - i0);
+        OpFrames fr;
+        std::memset(&fr, 0, sizeof(fr));
+        for (int i = 0; i < m; i++) {
+            if (!src[i0 + i] || !dst[i0 + i]) return GMAT_ERR(EINVAL);
+            fr.src[i] = src[i0 + i]; fr.dst[i] = dst[i0 + i];
+        }
+        int r;
+        switch (op) {
+        case GMAT_OP_ROTATE_FLIP_SMOOTH: r = launch_rotate_flip_smooth(nullptr, ss, nullptr, ds, w, h, bpp, stream, &fr, m); break;
+        case GMAT_OP_SMOOTH3X3:          r = launch_conv3x3(nullptr, ss, nullptr, ds, w, h, bpp, m121, 1.0f / 16.0f, 0.0f, stream, &fr, m); break;
+        case GMAT_OP_TRANSPOSE:          r = launch_transpose(nullptr, ss, nullptr, ds, w, h, bpp, arg, stream, &fr, m); break;
+        case GMAT_OP_FLIP:               r = launch_flip(nullptr, ss, nullptr, ds, w, h, bpp, arg != 0, arg <= 0, stream, &fr, m); break;
+        case GMAT_OP_MEDIAN3X3:          r = launch_median3x3(nullptr, ss, nullptr, ds, w, h, bpp, stream, &fr, m); break;
+        default: return GMAT_ERR(EINVAL);
+        }
+        if (r < 0) return r;
+    }
+    return 0;
+}
+
+int gmat_op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int w, int h, int bpp, int arg, void *stream)
+{
+    knobs_refresh();                             // a stateless call is its own context
+    if (n < 0 || !src || !dst) return GMAT_ERR(EINVAL);
+    if (op == GMAT_OP_TRANSPOSE && (arg < 0 || arg > 3)) return GMAT_ERR(EINVAL);
+    if (op == GMAT_OP_FLIP && (arg < -1 || arg > 1)) return GMAT_ERR(EINVAL);
+    return op_batch(op, n, src, ss, dst, ds, w, h, bpp, arg, (hipStream_t)stream);
 }
 
 int gmat_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, void *stream)

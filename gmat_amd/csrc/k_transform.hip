@@ -142,8 +142,9 @@ __device__ __forceinline__ void lds_to_tile16(uint8_t *dst, int ds, int b0, int 
 // flight as the 64 x 64 tiling has: with 256 threads a 4K plane's 510 tiles left the chip short of waves — 12.4 us against 7.8).
 template <int BPP, int T, int NT = 256>
 __global__ __launch_bounds__(NT) void transpose_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
-                                                        int inW, int inH, int dir, int aligned)
+                                                        int inW, int inH, int dir, int aligned, OpFrames fr)
 {
+    src = fr.src[blockIdx.y]; dst = fr.dst[blockIdx.y];    // grid.y = frame
     constexpr int PITCH = T * BPP + 4;                  // +4 B: odd dword pitch, conflict-light columns
     constexpr int GENERIC_BYTES = T * PITCH + (NT / 64) * T * BPP;
     constexpr int PXP = T + 1;                          // dword-pixel tile pitch (BPP 3 / 4)
@@ -327,8 +328,9 @@ __global__ __launch_bounds__(NT) void transpose_kernel(const uint8_t *src, int s
 // ---- flips: out(x, y) = in(fh ? w-1-x : x, fv ? h-1-y : y) -------------------------------------
 template <int BPP>
 __global__ __launch_bounds__(256) void flip_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
-                                                   int w, int h, int fh, int fv, int aligned)
+                                                   int w, int h, int fh, int fv, int aligned, OpFrames fr)
 {
+    src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z];    // grid.z = frame
     constexpr int T = 256;                                // pixels per block row segment
     __shared__ __attribute__((aligned(16))) uint8_t seg[4][T * BPP];
     __shared__ __attribute__((aligned(16))) uint8_t out[4][T * BPP];
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(256) void flip_kernel(const uint8_t *src, int ss, u
 // contiguous bytes per instruction.
 template <int BPP>
 __global__ __launch_bounds__(256) void flip_direct_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds,
-                                                          int w, int h, int fh, int fv)
+                                                          int w, int h, int fh, int fv, OpFrames fr)
 {
+    src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z];    // grid.z = frame
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     const int sy = fv ? h - 1 - y : y, sx = fh ? w - 4 - x : x;
@@ -569,24 +572,47 @@ static inline int al4(const void *a, int sa, const void *b, int sb)
     return ((((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0);
 }
 
+// the frame table of a launch: the caller's, or the one frame given by pointer; `loop` = call `one` per frame (kernels without a table)
+static inline OpFrames op_frames(const uint8_t *src, uint8_t *dst, const OpFrames *frames)
+{
+    OpFrames f;
+    if (frames) return *frames;
+    std::memset(&f, 0, sizeof(f));
+    f.src[0] = src; f.dst[0] = dst;
+    return f;
+}
+template <class F> static inline int op_loop(const OpFrames *frames, int nframes, F &&one)
+{
+    for (int i = 0; i < nframes; i++) {
+        const int r = one(frames->src[i], frames->dst[i]);
+        if (r < 0) return r;
+    }
+    return 0;
+}
+
 int launch_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int fh, int fv,
-                hipStream_t stream)
+                hipStream_t stream, const OpFrames *frames, int nframes)
 {
     if (w <= 0 || h <= 0) return 0;
-    const int aligned = al4(src, ss, dst, ds);
-    if (bpp >= 3 && aligned && w % 4 == 0 && (bpp == 3 || ((((uintptr_t)src | (uintptr_t)ss | (uintptr_t)dst | (uintptr_t)ds) & 15) == 0))) {
-        const dim3 dgrid((w + 255) / 256, (h + 3) / 4), dblock(64, 4);
-        if (bpp == 3)      hipLaunchKernelGGL(flip_direct_kernel<3>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
-        else if (bpp == 4) hipLaunchKernelGGL(flip_direct_kernel<4>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv);
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
+    const OpFrames fr = op_frames(src, dst, frames);
+    unsigned all = (unsigned)ss | (unsigned)ds;
+    for (int i = 0; i < nframes; i++) all |= (unsigned)(uintptr_t)fr.src[i] | (unsigned)(uintptr_t)fr.dst[i];
+    const int aligned = (all & 3) == 0;
+    if (bpp >= 3 && aligned && w % 4 == 0 && (bpp == 3 || (all & 15) == 0)) {
+        const dim3 dgrid((w + 255) / 256, (h + 3) / 4, nframes), dblock(64, 4);
+        if (bpp == 3)      hipLaunchKernelGGL(flip_direct_kernel<3>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv, fr);
+        else if (bpp == 4) hipLaunchKernelGGL(flip_direct_kernel<4>, dgrid, dblock, 0, stream, src, ss, dst, ds, w, h, fh, fv, fr);
         else return GMAT_ERR(ENOSYS);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    const dim3 grid((w + 255) / 256, (h + 3) / 4), block(256);
-    if (bpp == 3)      hipLaunchKernelGGL(flip_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(flip_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
-    else if (bpp == 1) hipLaunchKernelGGL(flip_kernel<1>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
-    else if (bpp == 2) hipLaunchKernelGGL(flip_kernel<2>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned);
+    const dim3 grid((w + 255) / 256, (h + 3) / 4, nframes), block(256);
+    if (bpp == 3)      hipLaunchKernelGGL(flip_kernel<3>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned, fr);
+    else if (bpp == 4) hipLaunchKernelGGL(flip_kernel<4>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned, fr);
+    else if (bpp == 1) hipLaunchKernelGGL(flip_kernel<1>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned, fr);
+    else if (bpp == 2) hipLaunchKernelGGL(flip_kernel<2>, grid, block, 0, stream, src, ss, dst, ds, w, h, fh, fv, aligned, fr);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
@@ -617,8 +643,9 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
 // four directions, bit 0 reads the source bottom-up, bit 1 writes the destination bottom-up): 13.6 us per 4K rgb24 frame against
 // transpose_kernel<3, 64>'s 16.0.
 template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false>
-__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir)
+__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir, OpFrames fr)
 {
+    src = fr.src[blockIdx.y]; dst = fr.dst[blockIdx.y];    // grid.y = frame
     constexpr int TH = 64, NS = RPW + 2, NT = 64 * TH / RPW;  // tile: TD dwords x 64 rows; RPW rows per wave; source rows per wave; threads
     static_assert(TD + 2 <= 64 && (TD * 4) % BPP == 0, "tile width: whole pixels, two halo lanes");
     constexpr int TWP = TD * 4 / BPP;                       // tile width in pixels
@@ -745,9 +772,17 @@ static bool smooth121_ok(const uint8_t *src, int ss, uint8_t *dst, int ds, int w
 }
 
 int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, int dir,
-                     hipStream_t stream)
+                     hipStream_t stream, const OpFrames *frames, int nframes)
 {
     if (inW <= 0 || inH <= 0) return 0;
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) {                                            // alignment tests below see the batch's least aligned frame
+        src = frames->src[0]; dst = frames->dst[0];
+        for (int i = 1; i < nframes; i++) {
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+        }
+    }
+    const OpFrames fr = op_frames(src, dst, frames);
     if (dir < 0 || dir > 3) return GMAT_ERR(EINVAL);
     // 1- and 2-byte samples (the planes of planar / semi-planar YUV) use 128 x 128 tiles so that a tile row is >= 128 B of contiguous
     // HBM traffic on BOTH sides, with 1024 threads a tile so that the chip holds as many waves as with 64 x 64 tiles (256 threads on
@@ -759,37 +794,45 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
     const bool big = bpp <= 2 && (tv == 1128 || tv == 0);   // default (profiles/r03x_transpose_tiles.txt: 4K gray 7.8 -> 6.5 us, 2-byte 11.2 -> 10.0)
     const int TT = big ? 128 : T;
     const int ntiles = ((inW + TT - 1) / TT) * ((inH + TT - 1) / TT);
-    const dim3 grid(8 * ((ntiles + 7) / 8)), block(big ? 1024 : 256);
+    const dim3 grid(8 * ((ntiles + 7) / 8), nframes), block(big ? 1024 : 256);
     const int aligned = al4(src, ss, dst, ds);
     if ((bpp == 3 || bpp == 4) && tv == 0 && smooth121_ok(src, ss, dst, ds, inW, inH, bpp)) {
         // packed RGB: the 3 x 3 smooth's transposed form with its filter left out (dword-per-lane row loads, byte-transposed LDS tile,
         // 16-byte row stores)
         const int td = bpp == 3 ? 60 : 62;
         const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
-        const dim3 g2(8 * ((nt + 7) / 8));
+        const dim3 g2(8 * ((nt + 7) / 8), nframes);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8, true>), g2, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir);
-        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir);
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8, true>), g2, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
-    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned);
+    if (bpp == 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<3, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<4, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 1 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 2 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128, 1024>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 1 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<1, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 2 && T == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 128>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
+    else if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(transpose_kernel<2, 64>), grid, block, 0, stream, src, ss, dst, ds, inW, inH, dir, aligned, fr);
     else return GMAT_ERR(ENOSYS);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, const int m[9],
-                   float rdiv, float bias, hipStream_t stream)
+                   float rdiv, float bias, hipStream_t stream, const OpFrames *frames, int nframes)
 {
     if (w <= 0 || h <= 0) return 0;
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) {                                            // alignment tests below see the batch's least aligned frame
+        src = frames->src[0]; dst = frames->dst[0];
+        for (int i = 1; i < nframes; i++) {
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+        }
+    }
+    const OpFrames fr = op_frames(src, dst, frames);
     ConvParams cp;
     int fast = 1;
     for (int i = 0; i < 9; i++) { cp.m[i] = m[i]; fast &= m[i] >= 0 && m[i] <= 255; }
@@ -801,16 +844,19 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     if (cp.shift == 4 && std::memcmp(m, m121, sizeof(m121)) == 0 && smooth121_ok(src, ss, dst, ds, w, h, bpp)) {
         const int td = bpp == 3 ? 60 : 62;                   // tile width in dwords: whole pixels (60 dwords = 80 rgb24 pixels)
         const int nt = ((w * bpp / 4 + td - 1) / td) * ((h + 63) / 64);
-        const dim3 g(8 * ((nt + 7) / 8)), b(256);
+        const dim3 g(8 * ((nt + 7) / 8), nframes), b(256);
         switch (bpp) {
-        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
-        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
-        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0); break;
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16>), g, b, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
         }
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    if (frames && nframes > 1)                              // the general matrix has no frame table: one launch per frame
+        return op_loop(frames, nframes, [&](const uint8_t *s1, uint8_t *d1) { return launch_conv3x3(s1, ss, d1, ds, w, h, bpp, m, rdiv, bias, stream, nullptr, 1); });
+    if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
     const int TW = bpp <= 2 ? 128 : 64;
     const int ntiles = ((w + TW - 1) / TW) * ((h + 63) / 64);
     const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);
@@ -931,8 +977,9 @@ constexpr int MD_TD = 62;                                    // dwords of a stri
 constexpr int MD_Q = 2;                                      // iterations (row pairs) the loads run ahead of their use
 template <int BPP>
 __global__ __launch_bounds__(256) void median3x3s_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h,
-                                                         int segRows, int nseg, int nstrips, int nblk)
+                                                         int segRows, int nseg, int nstrips, int nblk, OpFrames fr)
 {
+    src = fr.src[blockIdx.y]; dst = fr.dst[blockIdx.y];    // grid.y = frame
     const int rowDwords = (w * BPP) >> 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1046,10 +1093,19 @@ int launch_median(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h
     return 0;
 }
 
-int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, hipStream_t stream)
+int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, hipStream_t stream,
+                     const OpFrames *frames, int nframes)
 {
     if (w <= 0 || h <= 0) return 0;
-    if (!src || !dst) return GMAT_ERR(EINVAL);
+    if (!frames && (!src || !dst)) return GMAT_ERR(EINVAL);
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) {                                            // alignment tests below see the batch's least aligned frame
+        src = frames->src[0]; dst = frames->dst[0];
+        for (int i = 1; i < nframes; i++) {
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+        }
+    }
+    const OpFrames fr = op_frames(src, dst, frames);
     const int rb = w * bpp;
     if (median3x3s_ok(src, ss, dst, ds, w, h, bpp)) {
         const int nstrips = ((rb >> 2) + MD_TD - 1) / MD_TD;
@@ -1059,16 +1115,19 @@ int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, in
         if (seg <= 0) seg = (int)std::min(64L, std::max(8L, ((long)h * nstrips + 12287) / 12288)) & ~1;
         seg = std::max(seg, 1);
         const int nseg = (h + seg - 1) / seg, nblk = (nseg * nstrips + 3) / 4;
-        const dim3 g(8 * ((nblk + 7) / 8)), b(256);
+        const dim3 g(8 * ((nblk + 7) / 8), nframes), b(256);
         switch (bpp) {
-        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<1>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
-        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<2>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
-        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<3>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<4>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk); break;
+        case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<1>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk, fr); break;
+        case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<2>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk, fr); break;
+        case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<3>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk, fr); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(median3x3s_kernel<4>), g, b, 0, stream, src, ss, dst, ds, w, h, seg, nseg, nstrips, nblk, fr); break;
         }
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    if (frames && nframes > 1)                              // the byte-wise kernel has no frame table
+        return op_loop(frames, nframes, [&](const uint8_t *s1, uint8_t *d1) { return launch_median3x3(s1, ss, d1, ds, w, h, bpp, stream, nullptr, 1); });
+    if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
     const dim3 grid((rb + 255) / 256, (h + 7) / 8), block(256);          // 4 thread rows x 2 output rows per block
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
     switch (bpp) {
@@ -1566,9 +1625,17 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
 // kernel 1 2 1 / 2 4 2 / 1 2 1 is symmetric and vf_convolution's border rule is the same on both
 // axes, so smoothing commutes with the transpose: smooth the source tile, store it transposed.
 int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp,
-                              hipStream_t stream)
+                              hipStream_t stream, const OpFrames *frames, int nframes)
 {
     if (inW <= 0 || inH <= 0) return 0;
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) {                                            // alignment tests below see the batch's least aligned frame
+        src = frames->src[0]; dst = frames->dst[0];
+        for (int i = 1; i < nframes; i++) {
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+        }
+    }
+    const OpFrames fr = op_frames(src, dst, frames);
     ConvParams cp;
     const int m[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
     for (int i = 0; i < 9; i++) cp.m[i] = m[i];
@@ -1576,14 +1643,17 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
     if ((bpp == 3 || bpp == 4) && smooth121_ok(src, ss, dst, ds, inW, inH, bpp)) {
         const int td = bpp == 3 ? 60 : 62;
         const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
-        const dim3 g(8 * ((nt + 7) / 8)), b(256);
+        const dim3 g(8 * ((nt + 7) / 8), nframes), b(256);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
         // rgb24: 8 rows per wave (512 threads a tile) measured 2-3 % ahead of 16 (14.2 vs 14.5 us per 4K frame)
-        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, 0);
-        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16, 0);
+        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, 0, fr);
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16, 0, fr);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    if (frames && nframes > 1)
+        return op_loop(frames, nframes, [&](const uint8_t *s1, uint8_t *d1) { return launch_rotate_flip_smooth(s1, ss, d1, ds, inW, inH, bpp, stream, nullptr, 1); });
+    if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
     const int fast = 1;
     const int ntiles = ((inW + 63) / 64) * ((inH + 63) / 64);
     const dim3 grid(8 * ((ntiles + 7) / 8)), block(256);

@@ -148,25 +148,32 @@ int launch_alpha8_out(const int32_t *la, int lineW, int lineH, const DevFilter &
                       uint8_t *dst, int dstStride, int dstW, int dstH, hipStream_t stream);
 
 // ---- geometric transforms and smoothing (k_transform.hip) ----------------------------------
+// Frames of one launch of a transform kernel (one more grid dimension = frame): the pointers travel in the kernel-argument segment; geometry
+// and strides are shared.  frames == nullptr: the one frame given by src / dst.  A launcher whose kernel for the case at hand takes no
+// frame table loops over the frames itself, so every launcher accepts one.
+constexpr int kOpMaxFrames = 16;
+struct OpFrames { const uint8_t *src[kOpMaxFrames]; uint8_t *dst[kOpMaxFrames]; };
 int launch_transpose(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
-                     int inW, int inH, int bpp, int dir, hipStream_t stream);
+                     int inW, int inH, int bpp, int dir, hipStream_t stream, const OpFrames *frames = nullptr, int nframes = 1);
 int launch_flip(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
-                int w, int h, int bpp, int flipH, int flipV, hipStream_t stream);
+                int w, int h, int bpp, int flipH, int flipV, hipStream_t stream, const OpFrames *frames = nullptr, int nframes = 1);
 int launch_copy2d(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                   int rowBytes, int h, hipStream_t stream);
 int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
-                   int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream);
+                   int w, int h, int bpp, const int matrix[9], float rdiv, float bias, hipStream_t stream,
+                   const OpFrames *frames = nullptr, int nframes = 1);
 // smooth_nvcv type=gaussian in general: kw x kh (odd, <= kGaussMaxTaps), sigmaX / sigmaY (<= 0: OpenCV's default rule),
 // border 0 constant, 1 replicate, 2 reflect, 3 wrap, 4 reflect101; float32 accumulation in a stated order
 constexpr int kGaussMaxTaps = 31;
 int launch_gauss_blur(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, int kw, int kh,
                       double sigmaX, double sigmaY, int border, hipStream_t stream);
 // per-channel 3x3 median, window rows / columns clamped at the edges (vf_median.c semantics at radius 1)
-int launch_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, hipStream_t stream);
+int launch_median3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, hipStream_t stream,
+                     const OpFrames *frames = nullptr, int nframes = 1);
 // kw x kh (odd) in general: vf_median.c at radius (kw - 1) / 2, radiusV (kh - 1) / 2; 3 x 3 goes to the kernels above
 int launch_median(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, int kw, int kh, hipStream_t stream);
 int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
-                              int inW, int inH, int bpp, hipStream_t stream);
+                              int inW, int inH, int bpp, hipStream_t stream, const OpFrames *frames = nullptr, int nframes = 1);
 // arbitrary angle (radians, clockwise positive) in vf_rotate.c's 16.16 fixed point; fill == nullptr leaves
 // the pixels whose source position is out of range untouched
 // bilinear: 0 nearest, 1 linear, 2 cubic (Catmull-Rom, integer weights); shiftX / shiftY: translation of the rotated image in output pixels

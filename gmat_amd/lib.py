@@ -93,6 +93,7 @@ _SIGS = {
                                C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "gmat_median": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_rotate_flip_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "gmat_op_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_set_log_callback": (None, [C.c_void_p]),
     "gmat_device_count": (C.c_int, []),
     "gmat_set_device": (C.c_int, [C.c_int]),

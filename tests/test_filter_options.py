@@ -204,6 +204,11 @@ def test_scale_param_is_libswscale_param0(dev, orc, algo, param):
 def _dev_frame(lib, fc, planes_np, pts):
     fr = lib.gmat_frame_alloc()
     assert lib.gmat_hwframe_get_buffer(fc, fr) == 0
+    # a pool hands a buffer out again as soon as its frame is released — by the filters right after they ENQUEUE the work that reads
+    # it, as libavfilter's hardware filters do: the next writer has to be ordered behind that work.  gmat_hwframe_transfer_data is
+    # (it copies on the stream); this helper's plain hipMemcpy of a few KB is not (seen on the GPU: the first frame of a batch
+    # overwritten by the upload of the next batch's), so it waits for the device first.
+    lib.gmat_device_sync()
     for i, pl in enumerate(planes_np):
         host = np.zeros((pl.shape[0], fr.contents.linesize[i]), np.uint8)
         host[:, :pl.shape[1]] = pl
@@ -253,7 +258,11 @@ def test_queued_form_of_an_unbatched_filter_is_immediate(dev, orc):
     fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT["rgb24"], w, h, 1)
     f = lib.gmat_filter_alloc(b"flip_hip")
     assert lib.gmat_filter_set_option(f, b"code", b"0") == 0
-    assert lib.gmat_filter_set_option(f, b"batch", b"4") < 0           # scale_hip / format_hip only
+    assert lib.gmat_filter_set_option(f, b"batch", b"0") == 0 and lib.gmat_filter_init(f) < 0   # out of range, refused at init
+    assert lib.gmat_filter_set_option(f, b"batch", b"1") == 0
+    fcrop = lib.gmat_filter_alloc(b"crop_hip")
+    assert lib.gmat_filter_set_option(fcrop, b"batch", b"4") < 0       # a crop is a copy: nothing to batch, no such option
+    lib.gmat_filter_free(fcrop)
     assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
     src = orc.lcg((h, w * 3), 8)
     assert lib.gmat_filter_send_frame(f, _dev_frame(lib, fc, [src], 5)) == 0
@@ -273,3 +282,108 @@ def test_queued_form_of_an_unbatched_filter_is_immediate(dev, orc):
     lib.gmat_filter_free(f2)
     lib.gmat_filter_free(f)
     lib.gmat_hwframe_ctx_free(fc)
+
+
+@pytest.mark.parametrize("case", [("flip_hip", {"code": "1"}, "rgb24"), ("flip_hip", {"code": "0"}, "nv12"), ("transpose_hip", {"dir": "1"}, "rgb24"),
+                                  ("transpose_hip", {"dir": "0"}, "yuv420p"), ("rotate_hip", {"angle": "90"}, "rgba"), ("rotate_hip", {"angle": "180"}, "nv12"),
+                                  ("rotate_hip", {"angle": "270"}, "rgb24"), ("smooth_hip", {}, "rgb24"), ("smooth_hip", {"type": "median"}, "yuv444p"),
+                                  ("smooth_hip", {"type": "gaussian", "kw": "5", "kh": "5"}, "rgb24"), ("rotate_hip", {"angle": "17"}, "rgb24")])
+@pytest.mark.parametrize("batch", [3, 16, 20])
+def test_queued_transform_filters_batch_frames_into_one_launch(dev, orc, case, batch):
+    """option batch on the transform filters: flip, transpose, rotate by k * 90 degrees, the 3 x 3 smooth and median take the whole
+    queue in ONE launch per plane (gmat_op_batch: a grid dimension = frame; more than 16 frames: more launches); a filter form without a
+    frame table (general gaussian, arbitrary angle) works through a full queue frame by frame.  Every frame must equal what
+    filter_frame gives for it, in order, with its pts."""
+    from harness import synth_planes
+    name, opts, fmt = case
+    lib = dev.lib
+    w, h, n = 96, 40, 23
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT[fmt], w, h, 2)
+
+    def make(extra):
+        f = lib.gmat_filter_alloc(name.encode())
+        for k, v in list(opts.items()) + list(extra.items()):
+            assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0, k
+        assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+        return f
+
+    def fetch(fr):
+        outs = []
+        nplanes = 1 if fmt in ("rgb24", "rgba") else 2 if fmt == "nv12" else 3
+        ow, oh = fr.contents.width, fr.contents.height
+        for k in range(nplanes):
+            rows = oh if k == 0 or fmt == "yuv444p" else (oh + 1) // 2
+            rb = {"rgb24": 3 * ow, "rgba": 4 * ow}.get(fmt, ow if k == 0 or fmt == "yuv444p" else 2 * ((ow + 1) // 2) if fmt == "nv12" else (ow + 1) // 2)
+            back = np.zeros((rows, fr.contents.linesize[k]), np.uint8)
+            assert lib.gmat_memcpy_d2h(back.ctypes.data, fr.contents.data[k], back.size) == 0
+            outs.append(back[:, :rb].copy())                     # (the row padding of a pool frame is whatever was there before)
+        return outs
+
+    srcs = [synth_planes(orc, fmt, w, h, seed=900 + i) for i in range(n)]
+    one, many = make({}), make({"batch": batch})
+    want = []
+    for i, s_ in enumerate(srcs):
+        out = C.POINTER(GmatFrame)()
+        assert lib.gmat_filter_frame(one, _dev_frame(lib, fc, s_, i), C.byref(out)) == 0
+        lib.gmat_device_sync()
+        want.append(fetch(out))
+        lib.gmat_frame_free(C.byref(out))
+    got = []
+    for i, s_ in enumerate(srcs):
+        assert lib.gmat_filter_send_frame(many, _dev_frame(lib, fc, s_, i)) == 0
+        while True:
+            out = C.POINTER(GmatFrame)()
+            if lib.gmat_filter_receive_frame(many, C.byref(out)) != 0:
+                break
+            got.append(out)
+    assert len(got) == n // batch * batch
+    assert lib.gmat_filter_flush(many) == 0
+    while True:
+        out = C.POINTER(GmatFrame)()
+        if lib.gmat_filter_receive_frame(many, C.byref(out)) != 0:
+            break
+        got.append(out)
+    assert len(got) == n
+    lib.gmat_device_sync()
+    for i, out in enumerate(got):
+        assert out.contents.pts == i
+        for a, b in zip(fetch(out), want[i]):
+            assert (a == b).all(), (case, batch, i)
+        lib.gmat_frame_free(C.byref(out))
+    lib.gmat_filter_free(one); lib.gmat_filter_free(many)
+    lib.gmat_hwframe_ctx_free(fc)
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("bpp", [1, 3, 4])
+def test_op_batch_equals_the_single_frame_calls(dev, orc, op, bpp):
+    """gmat_op_batch: n frames, one launch per 16 — byte for byte what the single-frame entry points write, padding untouched;
+    unaligned frames (the kernels without a frame table) go one by one inside the call"""
+    from harness import DevPlane
+    lib = dev.lib
+    if op == 0 and bpp == 1:
+        pytest.skip("the fused rotate + flip + smooth takes packed RGB")
+    for (w, h, align, extra) in [(96, 40, 64, 0), (131, 35, 1, 1), (64, 64, 256, 0)]:
+        n = 19
+        tr = op in (0, 2)
+        ow, oh = (h, w) if tr else (w, h)
+        srcs = [orc.lcg((h, w * bpp), 300 + i) for i in range(n)]
+        d = [dev.upload_planes([s_], align, extra)[0] for s_ in srcs]
+        ostride = (ow * bpp + extra + align - 1) // align * align
+        o1 = [DevPlane(dev, oh, ow * bpp, ostride) for _ in range(n)]
+        o2 = [DevPlane(dev, oh, ow * bpp, ostride) for _ in range(n)]
+        m = (C.c_int * 9)(1, 2, 1, 2, 4, 2, 1, 2, 1)
+        for i in range(n):
+            if op == 0: r = lib.gmat_rotate_flip_smooth(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, bpp, None)
+            elif op == 1: r = lib.gmat_smooth3x3(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, bpp, m, 1.0 / 16, 0.0, None)
+            elif op == 2: r = lib.gmat_transpose(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, bpp, 2, None)
+            elif op == 3: r = lib.gmat_flip(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, bpp, -1, None)
+            else: r = lib.gmat_median3x3(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, bpp, None)
+            assert r == 0
+        sp = (C.c_void_p * n)(*[p.ptr for p in d]); dp = (C.c_void_p * n)(*[p.ptr for p in o2])
+        assert lib.gmat_op_batch(op, n, sp, d[0].stride, dp, ostride, w, h, bpp, 2 if op == 2 else -1 if op == 3 else 0, None) == 0
+        for i in range(n):
+            assert (o1[i].download(True) == o2[i].download(True)).all(), (op, bpp, (w, h), i)
+        for p in d + o1 + o2:
+            p.free()
+    assert lib.gmat_op_batch(9, 1, sp, 4, dp, 4, 1, 1, 1, 0, None) < 0 and lib.gmat_op_batch(2, 1, sp, 4, dp, 4, 1, 1, 1, 7, None) < 0
