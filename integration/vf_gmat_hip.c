@@ -8,8 +8,9 @@
  * context's stream.  AVFrame.data[] / linesize[] of an AV_PIX_FMT_CUDA frame are device pointers and byte strides
  * (libavutil/hwcontext_cuda.c:183-193): exactly what the C ABI takes.
  *
- * scale_hip and format_hip additionally implement activate(): with batch=K they collect K frames and convert them with
- * one kernel launch (gmat_sws_scale_batch) — the per-frame path is launch-bound on MI355X.
+ * Every filter but crop_hip implements activate(): with batch=K it collects K frames and processes them with one kernel launch
+ * (scale / format: gmat_sws_scale_batch; flip, transpose, rotate by k * 90 degrees, the 3 x 3 smooth and median: gmat_op_batch per
+ * plane) — one frame per launch is bounded by the launch boundary on MI355X.
  */
 #include <float.h>                      /* DBL_MAX, FLT_MAX in the option tables */
 #include <math.h>
@@ -317,7 +318,29 @@ static int gh_filter_frame(AVFilterLink *inlink, AVFrame *in)
     return ff_filter_frame(outlink, out);
 }
 
-/* scale_hip / format_hip with batch > 1: queue frames, convert K of them with one launch (grid.y = frame) */
+/* the transform of this filter instance as a gmat_op_batch operation (its kernels take a frame table), or -1 */
+static int gh_batched_op(const GmatHipContext *s, int *arg)
+{
+    const int general = s->kw != 3 || s->kh != 3 || s->sigma_x > 0 || s->sigma_y > 0 || s->border_type >= 0;
+    const double q = s->angle / 90.0;
+    const int quarter = fabs(q - rint(q)) < 1e-9 && s->shift_x == 0 && s->shift_y == 0 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
+    *arg = 0;
+    switch (s->kind) {
+    case GH_FLIP:      *arg = s->code; return GMAT_OP_FLIP;
+    case GH_TRANSPOSE: *arg = s->dir;  return GMAT_OP_TRANSPOSE;
+    case GH_ROTATE:
+        if (quarter == 1 || quarter == 3) { *arg = quarter == 1 ? 1 : 2; return GMAT_OP_TRANSPOSE; }
+        if (quarter == 2) { *arg = -1; return GMAT_OP_FLIP; }
+        return -1;
+    case GH_SMOOTH:
+        if (s->type == 2) return s->kw == 3 && s->kh == 3 ? GMAT_OP_MEDIAN3X3 : -1;
+        return general ? -1 : GMAT_OP_SMOOTH3X3;
+    default: return -1;
+    }
+}
+
+/* batch > 1: queue frames, process K of them with one launch (a grid dimension = frame): scale_hip / format_hip through
+ * gmat_sws_scale_batch, the transform filters plane by plane through gmat_op_batch */
 static int gh_flush_queue(AVFilterContext *ctx)
 {
     AVFilterLink *outlink = ctx->outputs[0];
@@ -344,9 +367,26 @@ static int gh_flush_queue(AVFilterContext *ctx)
             for (int k = 0; k < 4; k++)
                 if (s->queue[i]->linesize[k] != s->queue[0]->linesize[k] || outs[i]->linesize[k] != outs[0]->linesize[k])
                     same = 0;
-        if (same) {
+        const int plane_wise = s->kind != GH_SCALE && s->kind != GH_FORMAT;
+        int oparg = 0;
+        const int op = plane_wise ? gh_batched_op(s, &oparg) : -1;
+        if (same && !plane_wise) {
             if (gmat_sws_scale_batch(s->sws, n, sp, s->queue[0]->linesize, dp, outs[0]->linesize, streams, 1, 0) < 0)
                 ret = AVERROR_EXTERNAL;
+        } else if (same && op >= 0) {
+            for (int p = 0; p < 3 && s->queue[0]->data[p] && ret >= 0; p++) {
+                const uint8_t *ps[GH_MAX_BATCH];
+                uint8_t *pd[GH_MAX_BATCH];
+                int pw, ph, bpp;
+                if (plane_geometry(s->in_fmt, p, s->in_w, s->in_h, &pw, &ph, &bpp) < 0)
+                    break;
+                for (int i = 0; i < n; i++) { ps[i] = s->queue[i]->data[p]; pd[i] = outs[i]->data[p]; }
+                if (gmat_op_batch(op, n, ps, s->queue[0]->linesize[p], pd, outs[0]->linesize[p], pw, ph, bpp, oparg, s->stream) < 0)
+                    ret = AVERROR_EXTERNAL;
+            }
+        } else if (plane_wise) {                            /* no frame table for this form, or mixed strides: frame by frame */
+            for (int i = 0; i < n && ret >= 0; i++)
+                ret = gh_run_planes(s, s->queue[i], outs[i]);
         } else {
             for (int i = 0; i < n && ret >= 0; i++)
                 if (gmat_sws_scale(s->sws, (const uint8_t *const *)s->queue[i]->data, s->queue[i]->linesize, 0, s->queue[i]->height,
@@ -409,6 +449,7 @@ static const AVOption crop_hip_options[] = {
 };
 static const AVOption flip_hip_options[] = {
     { "code", "0 vertical, 1 horizontal, -1 both", OFFSET(code), AV_OPT_TYPE_INT, { .i64 = 0 }, -1, 1, FLAGS },
+    { "batch", "frames processed by one kernel launch (activate-based queue)", OFFSET(batch), AV_OPT_TYPE_INT, { .i64 = 1 }, 1, GH_MAX_BATCH, FLAGS },
     { NULL }
 };
 static const AVOption rotate_hip_options[] = {
@@ -416,10 +457,12 @@ static const AVOption rotate_hip_options[] = {
     { "interp", "Interpolation algorithm (linear, nearest, cubic, area)", OFFSET(interp), AV_OPT_TYPE_STRING, { .str = "linear" }, 0, 0, FLAGS },
     { "shift_x", "Shift of the rotated image in x, output pixels", OFFSET(shift_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
     { "shift_y", "Shift of the rotated image in y, output pixels", OFFSET(shift_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
+    { "batch", "frames processed by one kernel launch (activate-based queue)", OFFSET(batch), AV_OPT_TYPE_INT, { .i64 = 1 }, 1, GH_MAX_BATCH, FLAGS },
     { NULL }
 };
 static const AVOption transpose_hip_options[] = {
     { "dir", "0 cclock_flip, 1 clock, 2 cclock, 3 clock_flip", OFFSET(dir), AV_OPT_TYPE_INT, { .i64 = 0 }, 0, 3, FLAGS },
+    { "batch", "frames processed by one kernel launch (activate-based queue)", OFFSET(batch), AV_OPT_TYPE_INT, { .i64 = 1 }, 1, GH_MAX_BATCH, FLAGS },
     { NULL }
 };
 static const AVOption smooth_hip_options[] = {
@@ -436,6 +479,7 @@ static const AVOption smooth_hip_options[] = {
         { "reflect101", NULL, 0, AV_OPT_TYPE_CONST, { .i64 = 4 }, 0, 0, FLAGS, "border_type" },
     { "sigmaX", "gaussian sigma in x", OFFSET(sigma_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0 }, 0, DBL_MAX, FLAGS },
     { "sigmaY", "gaussian sigma in y", OFFSET(sigma_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0 }, 0, DBL_MAX, FLAGS },
+    { "batch", "frames processed by one kernel launch (activate-based queue)", OFFSET(batch), AV_OPT_TYPE_INT, { .i64 = 1 }, 1, GH_MAX_BATCH, FLAGS },
     { NULL }
 };
 static const AVOption scale_hip_options[] = {
@@ -490,9 +534,9 @@ static const AVFilterPad gh_outputs[] = {
     }
 
 GH_FILTER(crop_hip,      "Crop the input video on the GPU (libgmat_hip).",                gh_inputs_frame,    NULL);
-GH_FILTER(flip_hip,      "Flip the input video on the GPU (libgmat_hip).",                gh_inputs_frame,    NULL);
-GH_FILTER(rotate_hip,    "Rotate the input video on the GPU (libgmat_hip).",              gh_inputs_frame,    NULL);
-GH_FILTER(transpose_hip, "Transpose the input video on the GPU (libgmat_hip).",           gh_inputs_frame,    NULL);
-GH_FILTER(smooth_hip,    "Smooth the input video on the GPU (libgmat_hip).",              gh_inputs_frame,    NULL);
+GH_FILTER(flip_hip,      "Flip the input video on the GPU (libgmat_hip).",                gh_inputs_activate, gh_activate);
+GH_FILTER(rotate_hip,    "Rotate the input video on the GPU (libgmat_hip).",              gh_inputs_activate, gh_activate);
+GH_FILTER(transpose_hip, "Transpose the input video on the GPU (libgmat_hip).",           gh_inputs_activate, gh_activate);
+GH_FILTER(smooth_hip,    "Smooth the input video on the GPU (libgmat_hip).",              gh_inputs_activate, gh_activate);
 GH_FILTER(scale_hip,     "GPU accelerated video resizer / converter (libgmat_hip).",      gh_inputs_activate, gh_activate);
 GH_FILTER(format_hip,    "GPU accelerated pixel format converter (libgmat_hip).",         gh_inputs_activate, gh_activate);
