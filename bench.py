@@ -558,6 +558,16 @@ def c_harness(dry):
         except Exception as e:                               # noqa: BLE001 - a bench leg must not take the headline down
             rows.append({"error": repr(e)})
         res[key] = rows
+    # a per-frame caller that alternates n streams of its own (one library call per frame, nothing added): the launch boundary of one
+    # frame hides behind the kernel of the other (profiles/r03zz_per_call_caller_streams.txt)
+    for n in (2, 3):
+        rows = []
+        try:
+            r = subprocess.run([exe, "1", "100", ""], env=dict(env, X2BENCH_CALL_STREAMS=str(n)), capture_output=True, text=True, timeout=300)
+            rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        except Exception as e:                               # noqa: BLE001
+            rows = [{"error": repr(e)}]
+        res["one frame per call, %d caller streams" % n] = rows
     try:
         r = subprocess.run([exe, "1", "50", "op: "], env=env, capture_output=True, text=True, timeout=300)
         res["filters, one 4K frame per launch"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]

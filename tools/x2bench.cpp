@@ -107,20 +107,30 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         frame_ptrs(src[i], sf, sw, sh, p, ss); for (int k = 0; k < 4; k++) sp[(size_t)i * 4 + k] = p[k];
         frame_ptrs(dst[i], df, dw, dh, p, ds); for (int k = 0; k < 4; k++) dp[(size_t)i * 4 + k] = p[k];
     }
-    void *streams[1] = {stream};
+    // X2BENCH_CALL_STREAMS=n: calls round-robin over n streams of the CALLER's (one library call per frame, nothing else added) — what
+    // a per-frame caller with n frames in flight sees; joined to `stream` by events around the timed region
+    const int ncs = getenv("X2BENCH_CALL_STREAMS") ? std::max(1, std::min(8, atoi(getenv("X2BENCH_CALL_STREAMS")))) : 1;
+    std::vector<void *> xs(ncs, stream), xev(ncs, nullptr);
+    for (int k = 1; k < ncs; k++) { CK(gmat_stream_create(&xs[k])); CK(gmat_event_create(&xev[k])); }
+    int callNo = 0;
     auto launch = [&](int set) {
+        void *streams[1] = {xs[callNo++ % ncs]};
         CK(gmat_sws_scale_batch(c, NF, sp.data() + (size_t)set * NF * 4, ss, dp.data() + (size_t)set * NF * 4, ds, streams, 1, 0));
     };
+    auto sync_all = [&] { for (void *x : xs) CK(gmat_stream_sync(x)); };
     for (int i = 0; i < 6; i++) launch(i & 1);
-    CK(gmat_stream_sync(stream));
-    prewarm([&](int i) { launch(i & 1); }, [&] { CK(gmat_stream_sync(stream)); });
+    sync_all();
+    prewarm([&](int i) { launch(i & 1); }, sync_all);
     const std::string kname = gmat_sws_lastKernel(c);
     void *timer = nullptr; CK(gmat_timer_create(&timer));
     float best = 1e30f, sum = 0;
     const int REPS = 3;
     for (int r = 0; r < REPS; r++) {
+        sync_all();
         CK(gmat_timer_begin(timer, stream));
+        if (ncs > 1) { void *e0 = nullptr; CK(gmat_event_create(&e0)); CK(gmat_event_record(e0, stream)); for (int k = 1; k < ncs; k++) CK(gmat_stream_wait_event(xs[k], e0)); gmat_event_destroy(e0); }
         for (int i = 0; i < launches; i++) launch(i & 1);
+        for (int k = 1; k < ncs; k++) { CK(gmat_event_record(xev[k], xs[k])); CK(gmat_stream_wait_event(stream, xev[k])); }
         CK(gmat_timer_end(timer, stream));
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
         best = ms < best ? ms : best; sum += ms;
@@ -143,7 +153,7 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         std::vector<uint8_t> a(db), b(db);
         std::vector<uint32_t> crcBatch(4);
         const int nv = NF < 4 ? NF : 4;
-        launch(0); CK(gmat_stream_sync(stream));
+        launch(0); sync_all();
         for (int i = 0; i < nv; i++) { CK(gmat_memcpy_d2h(a.data(), dst[i], db)); crcBatch[i] = adler(a.data(), db); CK(gmat_memset(dst[i], 0, db)); }
         int bad = 0;
         for (int i = 0; i < nv; i++) {
@@ -158,6 +168,7 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
     }
     gmat_timer_destroy(timer);
     gmat_sws_freeContext(c);
+    for (int k = 1; k < ncs; k++) { gmat_event_destroy(xev[k]); gmat_stream_destroy(xs[k]); }
     gmat_stream_destroy(stream);
     for (int i = 0; i < NSET; i++) { gmat_free(src[i]); gmat_free(dst[i]); }
 }
