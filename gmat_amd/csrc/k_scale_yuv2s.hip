@@ -130,8 +130,18 @@ struct S2Pix {
 };
 
 // DST: 0 rgb24, 1 bgr24, 2 rgba, 3 bgra
+// S2_WAVES = n > 0: compile for n waves a SIMD (A/B).  74 VGPRs as allocated = 6 waves; forcing 7 (72 VGPRs, 6 dwords spilled) measured
+// 3.87 against 3.61-3.77 us per frame, 8 (64 VGPRs) 5.3 us: occupancy is not what this kernel lacks.
+#ifndef S2_WAVES
+#define S2_WAVES 0
+#endif
+#if S2_WAVES > 0 && defined(__HIP__)
+#define S2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(S2_WAVES)))
+#else
+#define S2_WAVES_ATTR
+#endif
 template <bool NV12, int DST>
-__global__ __launch_bounds__(256) void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFrames fr)
+__global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArgs a, Yuv2xFrames fr)
 {
     constexpr bool BGR = (DST & 1) != 0;
     constexpr int BPP = DST >= 2 ? 4 : 3;
