@@ -581,7 +581,9 @@ static void fill_qprog(YuvGQProg &v, int K)
     }
 }
 
-static const int kGP[] = {4, 5, 6, 8, 10}, kGK[] = {4, 6, 7, 9};
+// K = output rows open at once.  The plane jobs have the registers for 12 and 15 as well (57-67 VGPRs at K = 9): 4:2:0 -> 4:2:0
+// UP-scales up to 2:1 (720p -> 1080p needs 10, 1080p -> 1440p 10, 1:2 14-15); an RGB destination needs 14-22 there and stays tiled.
+static const int kGP[] = {4, 5, 6, 8, 10}, kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
 
 int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
@@ -635,7 +637,8 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
         }
     }
     int K = 0;
-    for (int c : kGK) if (c >= needK) { K = c; break; }
+    if (yuvOut) { for (int c : kGKPlanes) if (c >= needK) { K = c; break; } }
+    else        { for (int c : kGK) if (c >= needK) { K = c; break; } }
     if (!K) { if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d declined: K needed %d", p.srcW, p.srcH, p.dstW, p.dstH, needK); return 0; }
     for (int up = 0; up < 2; up++) { if (rgbOut) fill_qprog(t.rgb[up], K); else { fill_qprog(t.pl[up], K); fill_qprog(t.pc[up], K); } }
     // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
@@ -691,15 +694,18 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     }
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
-#define GMAT_G_K(P_, K_) do { \
-        if (a.yuvOut) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
-                        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } \
-        else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
-                        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } } while (0)
-#define GMAT_G_P(P_) do { switch (a.K) { case 4: GMAT_G_K(P_, 4); break; case 6: GMAT_G_K(P_, 6); break; case 7: GMAT_G_K(P_, 7); break; default: GMAT_G_K(P_, 9); } } while (0)
+#define GMAT_G_PL(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
+                               else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
+#define GMAT_G_RGB(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
+                                else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
+#define GMAT_G_P(P_) do { \
+        if (a.yuvOut) switch (a.K) { case 4: GMAT_G_PL(P_, 4); break; case 6: GMAT_G_PL(P_, 6); break; case 7: GMAT_G_PL(P_, 7); break; case 9: GMAT_G_PL(P_, 9); break; \
+                                     case 12: GMAT_G_PL(P_, 12); break; default: GMAT_G_PL(P_, 15); } \
+        else          switch (a.K) { case 4: GMAT_G_RGB(P_, 4); break; case 6: GMAT_G_RGB(P_, 6); break; case 7: GMAT_G_RGB(P_, 7); break; default: GMAT_G_RGB(P_, 9); } } while (0)
     switch (a.P) { case 4: GMAT_G_P(4); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
 #undef GMAT_G_P
-#undef GMAT_G_K
+#undef GMAT_G_PL
+#undef GMAT_G_RGB
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -310,6 +310,12 @@ int main(int argc, char **argv)
         {"any: nv12 1080p->854x480 rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
         {"any: yuv420p 4K->1600x900 yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1600, 900, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->1600x900 rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_LANCZOS},
+        // up-scales into 4:2:0 (the plane jobs of the band walker hold up to 15 open output rows: to 1 : 2)
+        {"any: up nv12 720p->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: up nv12 1080p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
+        {"any: up yuv420p 720p->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: up nv12 720p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
+        {"any: up nv12 720p->1080p rgb24 bicubic (tiled)", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
     };
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
