@@ -212,7 +212,7 @@ struct GStream {
 #define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_WAVES)))
 #elif G_WAVES < 0
 // one dword of a row per lane (P <= 6: ratios up to 3.7:1 with 4-tap algorithms): 94-100 VGPRs as compiled, 5 waves a SIMD fit in 96
-#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(P <= 6 ? 5 : 1)))
+#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(P <= 6 && K <= 9 ? 5 : 1)))
 #else
 #define G_WAVES_ATTR
 #endif
@@ -639,6 +639,8 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     int K = 0;
     if (yuvOut) { for (int c : kGKPlanes) if (c >= needK) { K = c; break; } }
     else        { for (int c : kGK) if (c >= needK) { K = c; break; } }
+    // up-scales into RGB (four-tap filters: P = 4): the chroma of an RGB destination is up-scaled twice as far as its luma, 14-22 rows open
+    if (!K && rgbOut && P == 4) for (int c : {15, 18, 22}) if (c >= needK) { K = c; break; }
     if (!K) { if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d declined: K needed %d", p.srcW, p.srcH, p.dstW, p.dstH, needK); return 0; }
     for (int up = 0; up < 2; up++) { if (rgbOut) fill_qprog(t.rgb[up], K); else { fill_qprog(t.pl[up], K); fill_qprog(t.pc[up], K); } }
     // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
@@ -679,7 +681,9 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     // exact-ratio walkers' three row pairs — so its optimum sits higher: 4K -> 900p rgb24 at 8 / 16 / 24 / 32 rows 7.4 / 6.1 / 5.9 /
     // 5.7 us per frame (profiles/r03p_rows_sweep_all_strip_kernels.txt); a lone small frame wants enough waves to fill the chip
     const long wr = (long)a.dstH * nstrips * nframes;
-    int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
+    // (an up-scale's bands are cheap in source rows and dear in open sums: twice the height — 1080p -> 1440p alone 17.0 -> 14.3-15.9 us)
+    const bool upV = a.dstH > a.srcH;
+    int rows = rowsEnv > 0 ? rowsEnv : upV ? (int)std::min(32L, std::max(8L, (wr + 3071) / 3072)) : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
     a.bandRows = rows;
     a.nbands = (a.dstH + rows - 1) / rows;
     a.nblkL = a.nbands * a.nsg;
@@ -702,8 +706,12 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
         if (a.yuvOut) switch (a.K) { case 4: GMAT_G_PL(P_, 4); break; case 6: GMAT_G_PL(P_, 6); break; case 7: GMAT_G_PL(P_, 7); break; case 9: GMAT_G_PL(P_, 9); break; \
                                      case 12: GMAT_G_PL(P_, 12); break; default: GMAT_G_PL(P_, 15); } \
         else          switch (a.K) { case 4: GMAT_G_RGB(P_, 4); break; case 6: GMAT_G_RGB(P_, 6); break; case 7: GMAT_G_RGB(P_, 7); break; default: GMAT_G_RGB(P_, 9); } } while (0)
-    switch (a.P) { case 4: GMAT_G_P(4); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
+#define GMAT_G_P4() do { \
+        if (!a.yuvOut && a.K > 9) switch (a.K) { case 15: GMAT_G_RGB(4, 15); break; case 18: GMAT_G_RGB(4, 18); break; default: GMAT_G_RGB(4, 22); } \
+        else GMAT_G_P(4); } while (0)
+    switch (a.P) { case 4: GMAT_G_P4(); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
 #undef GMAT_G_P
+#undef GMAT_G_P4
 #undef GMAT_G_PL
 #undef GMAT_G_RGB
     GMAT_HIP_CHECK(hipGetLastError());

@@ -66,10 +66,9 @@ def is_generic(kernel):
 def walker_takes(sw, sh, sf, df, dw, dh):
     """the host rule of yuvg_prepare / yuvg_eligible restated for dword-aligned frames and bicubic-sized filters: 8-bit 4:2:0 in,
     packed 8-bit RGB (even width: an odd one forces libswscale's full-chroma output) or 4:2:0 of the SAME chroma layout out, whole
-    dwords in every source row, at least 16 x 8 on both sides, and a ratio on both axes of at most about 4.7 : 1 (filters of at most
-    20 taps) and at least 1.15 : 1 for an RGB destination (at most 9 output rows open at once: its chroma plane is an UP-scale below
-    2 : 1) or about 1 : 1.9 for a 4:2:0 destination (the plane jobs hold up to 15 open rows: up-scales to 1 : 2).  Callers keep away
-    from the ends of those ranges."""
+    dwords in every source row, at least 16 x 8 on both sides, and a ratio on both axes between about 4.7 : 1 (filters of at most
+    20 taps) and 1 : 1.9 (output rows open at once: up to 15 in the plane jobs of a 4:2:0 destination, up to 22 in the four-pair
+    instances of an RGB destination, whose chroma plane is up-scaled twice as far as its luma).  Callers keep away from the ends."""
     rgb = df in ("rgb24", "bgr24", "rgba", "bgra")
     if sf not in ("nv12", "yuv420p") or not (rgb or df == sf):
         return False
@@ -79,8 +78,7 @@ def walker_takes(sw, sh, sf, df, dw, dh):
         return False
     if not (dw >= 16 and dh >= 8 and sw >= 16 and sh >= 8):
         return False
-    lo = 1.15 if rgb else 0.53
-    return lo <= sw / dw <= 4.7 and lo <= sh / dh <= 4.7
+    return 0.53 <= sw / dw <= 4.7 and 0.53 <= sh / dh <= 4.7
 
 
 def ptr(a):

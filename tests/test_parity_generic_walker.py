@@ -135,8 +135,10 @@ def test_rule_clauses(dev, orc, strip_rows, monkeypatch):
     assert _check(dev, orc, "nv12", "rgb24", (48, 48, 12, 12)) != G                         # narrower than 16
     assert _check(dev, orc, "nv12", "rgb24", (64, 32, 16, 8)) == G
     assert _check(dev, orc, "nv12", "rgb24", (384, 216, 161, 90)) != G                      # odd width: libswscale's full-chroma output
-    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 136)) != G                      # up-scales into RGB are the tiled kernel's ...
-    assert _check(dev, orc, "nv12", "nv12", (160, 90, 240, 136)) == G                       # ... into 4:2:0 the walker's, up to 1 : 2
+    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 136)) == G                      # up-scales: the walker's up to 1 : 2 ...
+    assert _check(dev, orc, "nv12", "nv12", (160, 90, 240, 136)) == G
+    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 256, 144)) == G
+    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 320, 180)) != G                      # ... 1 : 2.5: more than 22 output rows open
     assert _check(dev, orc, "yuv420p", "yuv420p", (128, 72, 256, 144)) == G
     assert _check(dev, orc, "nv12", "nv12", (128, 72, 320, 180)) != G                       # 1 : 2.5: more than 15 output rows open
     assert _check(dev, orc, "nv12", "rgb24", (960, 540, 120, 60)) != G                      # 8 : 1: 33-tap filters

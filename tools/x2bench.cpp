@@ -315,7 +315,7 @@ int main(int argc, char **argv)
         {"any: up nv12 1080p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
         {"any: up yuv420p 720p->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"any: up nv12 720p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
-        {"any: up nv12 720p->1080p rgb24 bicubic (tiled)", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: up nv12 720p->1080p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
     };
     struct Op { const char *label; int op, bpp; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
