@@ -1382,168 +1382,238 @@ __global__ __launch_bounds__(256) void rotate_kernel(const uint8_t *src, int ss,
     }
 }
 
+// rows of a frame as a raw buffer resource (see S2Plane in k_scale_yuv2s.hip): the row offset travels in the instruction's scalar
+// offset — which the hardware's range check does not see, so the check is not used (num_records = 2^32 - 1)
+struct RotRows {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ explicit RotRows(const uint8_t *p) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, 0xFFFFFFFFu, 0x00020000)) {}
+    __device__ __forceinline__ unsigned ld4(unsigned lane, unsigned row) const { return __builtin_amdgcn_raw_buffer_load_b32(r, lane, row, 0); }
+#else
+    // hipcc's host pass (never executed) and the CPU emulation of the test suite
+    const uint8_t *p;
+    __host__ __device__ explicit RotRows(const uint8_t *q) : p(q) {}
+    __host__ __device__ unsigned ld4(unsigned lane, unsigned row) const { unsigned v; std::memcpy(&v, p + (size_t)row + lane, 4); return v; }
+#endif
+};
+
 // ---- the same walk with the source patch staged in LDS (round 3) ------------------------------------------------------------
 // A block of 256 threads makes a 32 x 32 output tile: the source pixels its taps can touch lie in the bounding box of the tile's four
 // corners (an affine map: the extremes are at the corners), at most 48 x 48 pixels at any angle; the box is loaded row by row with
 // coalesced dword loads into LDS (dword-aligned start: `shift` bytes of lead-in, odd dword pitch) and every tap is read from there.
 // The box is computed on CLAMPED coordinates — every tap index the walk forms is clamped to the image first (vf_rotate.c:463-492) — so
-// it lies inside the image and the loads need no border case.  Arithmetic: rotate_kernel's, tap for tap.  Measured per 4K rgb24 frame
-// at 17 degrees (profiles/r03t_*): bilinear 42 -> 30 us, cubic 312 -> 77 us, nearest 22 -> 22 us.  Tried and slower: walking several
-// tiles per block with the next box requested ahead (35-48 us: the chip overlaps independent blocks better than one block overlaps
-// its own tiles), gathering aligned dwords in the direct form (45 us).
+// it lies inside the image and the loads need no border case; the taps are clamped to the BOX, which for a pixel of the tile is the
+// same index (the clamp is monotone and the box's ends are the clamped extremes) and keeps a ragged tile's surplus lanes inside LDS.
+// Arithmetic: rotate_kernel's, tap for tap.
+// The kernel is bound by VALU issue, not by bytes (16.1 M wave instructions a 4K rgb24 frame = 26 of its 29 us in the first form,
+// profiles/r03t_*; nearest, with no arithmetic, 22 us).  This form spends the instructions on the blend only: everything that is
+// the same for the tile (corners, box, validity of the whole tile, row bases of the loads) is scalar; a load is a scalar base + the
+// lane's constant offset; the coordinates advance by additions; the last column / row is a zero weight instead of a second clamp;
+// the tile whose four corners are valid skips the fill logic altogether; results are packed with byte permutes.
+// Tried and slower: walking several tiles per block with the next box requested ahead (35-48 us: the chip overlaps independent
+// blocks better than one block overlaps its own tiles), gathering aligned dwords in the direct form (45 us).
 template <int BPP, int INTERP>
 __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
                                                          int aligned, int nbx, int nby)
 {
     constexpr int TW = 32, TBH = 32, BMAX = 50;
     constexpr int PD = ((BMAX * BPP + 6) / 4 + 2) | 1;      // dwords per LDS row: 50 pixels + lead-in + the two dwords an 8-byte read may run over, odd
-    __shared__ unsigned box[BMAX * PD];
-    int t = blockIdx.x;
-    {
-        const int nt = nbx * nby, chunk = (nt + 7) >> 3;
-        t = (t & 7) * chunk + (t >> 3);
-        if (t >= nt) return;
-    }
-    const int bx = t % nbx, by = t / nbx, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool cubic = INTERP == 2;
+    __shared__ unsigned box[(BMAX + 2) * PD];               // 52 rows: the loader's 13 rounds of 4 (rows past the box are never read), and
+                                                            // at the frame's last row the pair's lower row is read with weight 0
+    __shared__ unsigned cw[cubic ? 512 : 2];                // cubic: the four weights of each 8-bit fraction as two int16 pairs
+    // grid (8 * nbx, ceil(nby / 8)): workgroups go to the XCDs round-robin in dispatch order, so blockIdx.x & 7 IS the XCD, and XCD k
+    // walks tile rows k * gridDim.y ... — a contiguous band of the frame per L2, without a division
+    const int bx = blockIdx.x >> 3, by = (blockIdx.x & 7) * gridDim.y + blockIdx.y;
+    if (by >= nby) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int iLo = bx * TW, iHi = min(iLo + TW, p.outW) - 1, jLo = by * TBH, jHi = min(jLo + TBH, p.outH) - 1;
-    int minx = 0x7FFFFFFF, maxx = -0x7FFFFFFF - 1, miny = minx, maxy = maxx;
-#pragma unroll
-    for (int cn = 0; cn < 4; cn++) {
-        const int i = (cn & 1) ? iHi : iLo, j = (cn & 2) ? jHi : jLo;
-        const int x1 = (p.X0 + j * p.s + i * p.c) >> 16, y1 = (p.Y0 + j * p.c - i * p.s) >> 16;
-        minx = min(minx, x1); maxx = max(maxx, x1); miny = min(miny, y1); maxy = max(maxy, y1);
-    }
+    const int xb = p.X0 + jLo * p.s + iLo * p.c, yb = p.Y0 + jLo * p.c - iLo * p.s;     // the tile's first pixel
+    // extremes of x1 = x >> 16, y1 = y >> 16 over the tile: x and y are sums of a term in i and a term in j, the shift is monotone
+    const int xi = (iHi - iLo) * p.c, xj = (jHi - jLo) * p.s, yi = -(iHi - iLo) * p.s, yj = (jHi - jLo) * p.c;
+    const int minx = (xb + min(xi, 0) + min(xj, 0)) >> 16, maxx = (xb + max(xi, 0) + max(xj, 0)) >> 16;
+    const int miny = (yb + min(yi, 0) + min(yj, 0)) >> 16, maxy = (yb + max(yi, 0) + max(yj, 0)) >> 16;
+    // every pixel of the tile valid (vf_rotate.c:463): the validity region is a box and the extremes are at the corners
+    const bool allValid = minx >= -1 && maxx <= p.inW && miny >= -1 && maxy <= p.inH;
     // cubic taps are clamp(x1 - 1 + t), t = 0..3; the bilinear pair is clamp(x1) and min(clamp(x1) + 1, W - 1) — the clamp comes FIRST
     // (x1 = -1 reads pixels 0 and 1), so the box ends one past the clamped maximum
-    constexpr bool cubic = INTERP == 2;
     const int bx0 = min(max(minx - (cubic ? 1 : 0), 0), p.inW - 1), by0 = min(max(miny - (cubic ? 1 : 0), 0), p.inH - 1);
-    const int bx1 = cubic ? min(max(maxx + 2, 0), p.inW - 1) : min(min(max(maxx, 0), p.inW - 1) + 1, p.inW - 1);
-    const int by1 = cubic ? min(max(maxy + 2, 0), p.inH - 1) : min(min(max(maxy, 0), p.inH - 1) + 1, p.inH - 1);
+    const int bxm = min(max(maxx, 0), p.inW - 1), bym = min(max(maxy, 0), p.inH - 1);   // the clamped maxima of x1, y1
+    const int bx1 = cubic ? min(max(maxx + 2, 0), p.inW - 1) : min(bxm + 1, p.inW - 1);
+    const int by1 = cubic ? min(max(maxy + 2, 0), p.inH - 1) : min(bym + 1, p.inH - 1);
     const int bh = by1 - by0 + 1, shift = (bx0 * BPP) & 3, gd0 = (bx0 * BPP) >> 2;
     const int nDw = (shift + (bx1 - bx0 + 1) * BPP + 3) >> 2, rowBytes = p.inW * BPP;
-    {   // a wave loads rows wave, wave + 4, ...: every load is issued before the first LDS store (one memory latency, not thirteen)
+    {   // wave w loads rows w, w + 4, ... in 13 rounds: every load is issued before the first LDS store (one memory latency, not
+        // thirteen), with no branch — a round past the box's last row reads that row again (its line is in the L1) into an LDS row
+        // nobody reads.  The box's rows as a raw buffer resource: the row offset is the instruction's scalar offset, the lane's
+        // offset one constant register.  The dword that holds the frame's last bytes may reach past the last row's end: in the one
+        // tile that has it, that lane of that row reads bytes.
         constexpr int NR = (BMAX + 3) / 4;
-        // the dword that holds the frame's last bytes may reach past the last row's end: that one lane of that one row reads bytes
         const bool tailRow = by1 == p.inH - 1 && 4 * (gd0 + nDw) > rowBytes;
-        const int nFull = tailRow ? nDw - 1 : nDw;          // block-uniform
-        unsigned v[NR];
-        const uint8_t *g = src + (size_t)by0 * ss + 4 * (size_t)(gd0 + lane);
-#pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int r = wave + 4 * k;
-            v[k] = 0;
-            if (r < bh && lane < (r == bh - 1 ? nFull : nDw)) v[k] = *reinterpret_cast<const unsigned *>(g + (size_t)r * ss);
+        const RotRows rows(src + (size_t)by0 * ss + 4 * (size_t)gd0);
+        if (cubic) {                                        // 256 threads, 256 fractions
+            int w4[4];
+            rot_cubic_w((int)threadIdx.x, w4);
+            cw[2 * threadIdx.x] = (unsigned)(w4[0] & 0xFFFF) | ((unsigned)w4[1] << 16);
+            cw[2 * threadIdx.x + 1] = (unsigned)(w4[2] & 0xFFFF) | ((unsigned)w4[3] << 16);
         }
+        if (lane < nDw) {
+            const unsigned lo4 = 4u * (unsigned)lane, offLast = (unsigned)((bh - 1) * ss), step = 4u * (unsigned)ss;   // ss > 0 (launcher)
+            unsigned *bw = box + wave * PD + lane;
+            unsigned v[NR];
+            if (!tailRow) {
+                unsigned off = (unsigned)(wave * ss);
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int r = wave + 4 * k;
-            if (r < bh && lane < nDw) box[r * PD + lane] = v[k];
-        }
-        if (tailRow && lane == nDw - 1 && ((bh - 1) & 3) == wave) {
-            const uint8_t *gt = g + (size_t)(bh - 1) * ss;
-            unsigned t = 0;
-            for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) t |= (unsigned)gt[b] << (8 * b);
-            box[(bh - 1) * PD + lane] = t;                  // after this wave's own store of the same word (LDS keeps a wave's order)
+                for (int k = 0; k < NR; k++, off += step) v[k] = rows.ld4(lo4, min(off, offLast));
+#pragma unroll
+                for (int k = 0; k < NR; k++) bw[4 * k * PD] = v[k];
+            } else {
+                unsigned off = (unsigned)(wave * ss);
+#pragma unroll
+                for (int k = 0; k < NR; k++, off += step) {
+                    v[k] = 0;
+                    if (!(lane == nDw - 1 && off >= offLast)) v[k] = rows.ld4(lo4, min(off, offLast));
+                }
+#pragma unroll
+                for (int k = 0; k < NR; k++) bw[4 * k * PD] = v[k];
+                if (lane == nDw - 1 && ((bh - 1) & 3) == wave) {
+                    const uint8_t *gt = src + (size_t)by1 * ss + 4 * (size_t)(gd0 + lane);
+                    unsigned tl = 0;
+                    for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) tl |= (unsigned)gt[b] << (8 * b);
+                    box[(bh - 1) * PD + lane] = tl;         // after this lane's own stores (LDS keeps a wave's order)
+                }
+            }
         }
     }
     __syncthreads();
-    const int i0 = iLo + (lane & 7) * 4, j = jLo + wave * 8 + (lane >> 3);
+    const int ir = (lane & 7) * 4, jr = wave * 8 + (lane >> 3);
+    const int i0 = iLo + ir, j = jLo + jr;
     if (i0 >= p.outW || j >= p.outH) return;
-    auto bytes8 = [&](int iy, int ix, unsigned &lo, unsigned &hi) {     // the 8 bytes from pixel (ix, iy) on: two v_alignbyte_b32
-        const int bo = (ix - bx0) * BPP + shift, d = bo >> 2;
-        const unsigned *row = box + (iy - by0) * PD;
-        const unsigned w0 = row[d], w1 = row[d + 1], w2 = row[d + 2];
-        lo = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)bo & 3u);
-        hi = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)bo & 3u);
-    };
-    auto byte1 = [&](int iy, int ix, int k) -> int {
-        const int bo = (ix - bx0) * BPP + shift + k;
-        return (int)((box[(iy - by0) * PD + (bo >> 2)] >> (8 * (bo & 3))) & 0xFF);
-    };
-    uint8_t o[4 * BPP];
-    bool valid[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        // no branch per pixel: an invalid pixel is interpolated like any other (its clamped taps are in the box: the corners' extremes
-        // cover every pixel of the tile) and replaced by the fill colour afterwards; a pixel past the frame's last column borrows
-        // the last one's coordinates
-        const int i = min(i0 + q, iHi);
-        const int x = p.X0 + j * p.s + i * p.c, y = p.Y0 + j * p.c - i * p.s;
+    const int x0 = xb + m24(jr, p.s) + m24(ir, p.c), y0 = yb + m24(jr, p.c) - m24(ir, p.s);     // |s|, |c| <= 2^16
+    const int boK = shift - bx0 * BPP - by0 * PD * 4;       // byte offset in LDS of pixel (ix, iy): ix * BPP + iy * PD * 4 + boK
+    const int nx = min(4, p.outW - i0);
+    uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
+
+    // one output pixel; the result of channel k is BYTE 2 of R[k] (bilinear: the 24-bit sum before its >> 16)
+    auto pixel = [&](int q, unsigned (&R)[BPP], bool &valid) {
+        const int x = x0 + q * p.c, y = y0 - q * p.s;
         const int x1 = x >> 16, y1 = y >> 16;
-        valid[q] = x1 >= -1 && x1 <= p.inW && y1 >= -1 && y1 <= p.inH;
-        const int ix = min(max(x1, 0), p.inW - 1), iy = min(max(y1, 0), p.inH - 1);
+        valid = (unsigned)(x1 + 1) <= (unsigned)(p.inW + 1) && (unsigned)(y1 + 1) <= (unsigned)(p.inH + 1);
         if (INTERP == 2) {
-            int wx[4], wy[4];
-            rot_cubic_w((x & 0xFFFF) >> 8, wx); rot_cubic_w((y & 0xFFFF) >> 8, wy);
+            const unsigned wx01 = cw[2 * ((x >> 8) & 0xFF)], wx23 = cw[2 * ((x >> 8) & 0xFF) + 1];
+            const unsigned wy01 = cw[2 * ((y >> 8) & 0xFF)], wy23 = cw[2 * ((y >> 8) & 0xFF) + 1];
+            const int wx[4] = {(int)(short)(wx01 & 0xFFFF), (int)wx01 >> 16, (int)(short)(wx23 & 0xFFFF), (int)wx23 >> 16};
+            const int wy[4] = {(int)(short)(wy01 & 0xFFFF), (int)wy01 >> 16, (int)(short)(wy23 & 0xFFFF), (int)wy23 >> 16};
             long long acc[BPP];
 #pragma unroll
             for (int k = 0; k < BPP; k++) acc[k] = 0;
+            // interior: the four taps of a row are 4 * BPP consecutive bytes (BPP dwords after v_alignbyte_b32), the four rows consecutive
+            const bool inner = x1 - 1 >= bx0 && x1 + 2 <= bx1 && y1 - 1 >= by0 && y1 + 2 <= by1;
+            if (inner) {
+                const int bo = (x1 - 1) * BPP + boK;
+                const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (m24(y1 - 1, PD * 4) + (bo & ~3)));
+                const unsigned sh = (unsigned)bo & 3u;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ry = min(max(y1 - 1 + r, 0), p.inH - 1);
-                int hsum[BPP];
+                for (int r = 0; r < 4; r++) {
+                    unsigned c[BPP];
 #pragma unroll
-                for (int k = 0; k < BPP; k++) hsum[k] = 0;
+                    for (int n = 0; n < BPP; n++) c[n] = __builtin_amdgcn_alignbyte(w[r * PD + n + 1], w[r * PD + n], sh);
 #pragma unroll
-                for (int tt = 0; tt < 4; tt++) {
-                    const int rx = min(max(x1 - 1 + tt, 0), p.inW - 1);
+                    for (int k = 0; k < BPP; k++) {
+                        int hs = 0;
 #pragma unroll
-                    for (int k = 0; k < BPP; k++) hsum[k] += wx[tt] * byte1(ry, rx, k);
+                        for (int tt = 0; tt < 4; tt++) {
+                            const int n = tt * BPP + k;
+                            hs += m24(wx[tt], (int)((c[n >> 2] >> (8 * (n & 3))) & 0xFF));
+                        }
+                        acc[k] += (long long)wy[r] * hs;
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int k = 0; k < BPP; k++) acc[k] += (long long)wy[r] * hsum[k];
+                for (int r = 0; r < 4; r++) {
+                    const int ry = min(max(y1 - 1 + r, by0), by1);
+                    int hsum[BPP];
+#pragma unroll
+                    for (int k = 0; k < BPP; k++) hsum[k] = 0;
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) {
+                        const int bo = min(max(x1 - 1 + tt, bx0), bx1) * BPP + boK + m24(ry, PD * 4);
+#pragma unroll
+                        for (int k = 0; k < BPP; k++) hsum[k] += wx[tt] * (int)((box[(bo + k) >> 2] >> (8 * ((bo + k) & 3))) & 0xFF);
+                    }
+#pragma unroll
+                    for (int k = 0; k < BPP; k++) acc[k] += (long long)wy[r] * hsum[k];
+                }
             }
 #pragma unroll
             for (int k = 0; k < BPP; k++) {
                 const long long r = (acc[k] + (1LL << 27)) >> 28;
-                o[q * BPP + k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
-            }
-        } else if (INTERP == 1) {
-            const int fx = x & 0xFFFF, fy = y & 0xFFFF;
-            const int iy1 = min(iy + 1, p.inH - 1);
-            unsigned a0, a1, b0, b1;
-            bytes8(iy, ix, a0, a1); bytes8(iy1, ix, b0, b1);
-            if (ix + 1 > p.inW - 1) {                       // the last column: the right tap is the left one again
-                const unsigned m = BPP == 4 ? 0u : (1u << (8 * BPP)) - 1u;
-                if (BPP == 4) { a1 = a0; b1 = b0; }
-                else { a1 = (a0 & m) >> (8 * (4 - BPP)); b1 = (b0 & m) >> (8 * (4 - BPP)); a0 = (a0 & m) | (a0 << (8 * BPP)); b0 = (b0 & m) | (b0 << (8 * BPP)); }
-            }
-#pragma unroll
-            for (int k = 0; k < BPP; k++) {
-                const int k1 = k + BPP;                     // byte index of the right tap's channel
-                const int s00 = (int)((a0 >> (8 * k)) & 0xFF), s10 = (int)((b0 >> (8 * k)) & 0xFF);
-                const int s01 = (int)(((k1 < 4 ? a0 >> (8 * (k1 & 3)) : a1 >> (8 * (k1 & 3)))) & 0xFF);
-                const int s11 = (int)(((k1 < 4 ? b0 >> (8 * (k1 & 3)) : b1 >> (8 * (k1 & 3)))) & 0xFF);
-                const int s0 = (s00 << 16) + m24(fx, s01 - s00);          // exact without 64-bit arithmetic: see rotate_kernel
-                const int s1 = (s10 << 16) + m24(fx, s11 - s10);
-                const int ph = (int)__umulhi((unsigned)fy << 16, (unsigned)(s1 - s0 + (1 << 24))) - (fy << 8);
-                o[q * BPP + k] = (uint8_t)((s0 + ph) >> 16);
+                R[k] = (unsigned)(r < 0 ? 0 : r > 255 ? 255 : r) << 16;
             }
         } else {
-            unsigned a0, a1;
-            bytes8(iy, ix, a0, a1);
+            const int ix = min(max(x1, bx0), bxm), iy = min(max(y1, by0), bym);
+            const int bo = ix * BPP + boK;
+            const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (m24(iy, PD * 4) + (bo & ~3)));
+            const unsigned sh = (unsigned)bo & 3u;
+            if (INTERP == 1) {
+                // the pair's second column / row past the frame's last one is the first one again: the same as a zero weight
+                const int fx = ix == p.inW - 1 ? 0 : x & 0xFFFF, fy = iy == p.inH - 1 ? 0 : y & 0xFFFF;
+                const unsigned a0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), b0 = __builtin_amdgcn_alignbyte(w[PD + 1], w[PD], sh);
+                unsigned a1 = 0, b1 = 0;
+                if (BPP > 2) { a1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh); b1 = __builtin_amdgcn_alignbyte(w[PD + 2], w[PD + 1], sh); }
+                const unsigned fyh = (unsigned)fy << 16;
+                const int fyl = -(fy << 8);
 #pragma unroll
-            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(a0 >> (8 * k));
+                for (int k = 0; k < BPP; k++) {
+                    const int k1 = k + BPP;                 // byte index of the right tap's channel
+                    const int s00 = (int)((a0 >> (8 * k)) & 0xFF), s10 = (int)((b0 >> (8 * k)) & 0xFF);
+                    const int s01 = (int)(((k1 < 4 ? a0 >> (8 * (k1 & 3)) : a1 >> (8 * (k1 & 3)))) & 0xFF);
+                    const int s11 = (int)(((k1 < 4 ? b0 >> (8 * (k1 & 3)) : b1 >> (8 * (k1 & 3)))) & 0xFF);
+                    const int s0 = (s00 << 16) + m24(fx, s01 - s00);          // exact without 64-bit arithmetic: see rotate_kernel
+                    const int s1 = (s10 << 16) + m24(fx, s11 - s10);
+                    R[k] = (unsigned)(s0 + fyl + (int)__umulhi(fyh, (unsigned)(s1 - s0 + (1 << 24))));
+                }
+            } else {
+                const unsigned a0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+#pragma unroll
+                for (int k = 0; k < BPP; k++) R[k] = (a0 >> (8 * k)) << 16;
+            }
         }
+    };
+    // bytes 2 of four values -> one dword
+    auto pack4 = [](unsigned v0, unsigned v1, unsigned v2, unsigned v3) -> unsigned {
+        return __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) | __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
+    };
+    unsigned V[4 * BPP];
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned R[BPP];
+        pixel(q, R, valid[q]);
+#pragma unroll
+        for (int k = 0; k < BPP; k++) V[q * BPP + k] = R[k];
+    }
+    if (allValid && aligned && nx == 4) {                   // allValid is the tile's: no fill logic at all
+#pragma unroll
+        for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = pack4(V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]);
+        return;
+    }
+    if (allValid) valid[0] = valid[1] = valid[2] = valid[3] = true;       // surplus lanes of a ragged tile are not the tile's pixels
+#pragma unroll
+    for (int q = 0; q < 4; q++)
         if (!valid[q]) {
 #pragma unroll
-            for (int k = 0; k < BPP; k++) o[q * BPP + k] = (uint8_t)(p.fill >> (8 * k));
+            for (int k = 0; k < BPP; k++) V[q * BPP + k] = ((p.fill >> (8 * k)) & 0xFF) << 16;
         }
-    }
-    uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
-    const int nx = min(4, p.outW - i0);
     const bool all = p.fillEnable || (valid[0] && valid[1] && valid[2] && valid[3]);
     if (aligned && nx == 4 && all) {
-        unsigned w[BPP];
 #pragma unroll
-        for (int k = 0; k < BPP; k++)
-            w[k] = (unsigned)o[4 * k] | ((unsigned)o[4 * k + 1] << 8) | ((unsigned)o[4 * k + 2] << 16) | ((unsigned)o[4 * k + 3] << 24);
-#pragma unroll
-        for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = w[k];
+        for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = pack4(V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]);
     } else {
         for (int q = 0; q < nx; q++)
             if (p.fillEnable || valid[q])
-                for (int k = 0; k < BPP; k++) d[q * BPP + k] = o[q * BPP + k];
+                for (int k = 0; k < BPP; k++) d[q * BPP + k] = (uint8_t)(V[q * BPP + k] >> 16);
     }
 }
 
@@ -1586,10 +1656,10 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
     // the source patch staged in LDS whenever the source rows are dword-aligned; GMAT_ROTATE_LDS=0 forces the direct form (A/B)
     const char *el = GMAT_KNOB("GMAT_ROTATE_LDS");
-    const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && (int64_t)ss * inH < (1ll << 31);
+    const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && ss > 0 && (int64_t)ss * inH < (1ll << 31);
     if (lds) {
         const int nbx = (outW + 31) / 32, nby = (outH + 31) / 32;
-        const dim3 grid(8 * ((nbx * nby + 7) / 8)), block(256);
+        const dim3 grid(8 * nbx, (nby + 7) / 8), block(256);
 #define GMAT_ROTL(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
                            else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
                            else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 0>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); } while (0)
