@@ -598,6 +598,8 @@ fail:
 // Filters without a batched kernel, and batch=1, process each frame at once — the three calls then behave like
 // filter_frame.
 static int op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int w, int h, int bpp, int arg, hipStream_t stream);
+static int rotate_batch(int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                        double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, hipStream_t stream);
 
 static int run_pending(GmatFilterContext *f)
 {
@@ -610,12 +612,14 @@ static int run_pending(GmatFilterContext *f)
         f->pending.clear();
         return GMAT_ERR(EIO);
     }
-    // flip / transpose / rotate by k * 90 degrees / the 3 x 3 smooth and median: one launch per PLANE for the whole batch
+    // flip / transpose / rotate / the 3 x 3 smooth and median: one launch per PLANE for the whole batch
+    constexpr int OP_ROTATE_ANY = 100;              // vf_rotate.c's walk at an arbitrary angle (not one of gmat_op_batch's)
     int top = -1, targ = 0;
     if (f->kind == K_FLIP) { top = GMAT_OP_FLIP; targ = f->code; }
     else if (f->kind == K_TRANSPOSE) { top = GMAT_OP_TRANSPOSE; targ = f->dir; }
     else if (f->kind == K_ROTATE && (f->quarter == 1 || f->quarter == 3)) { top = GMAT_OP_TRANSPOSE; targ = f->quarter == 1 ? 1 : 2; }
     else if (f->kind == K_ROTATE && f->quarter == 2) { top = GMAT_OP_FLIP; targ = -1; }
+    else if (f->kind == K_ROTATE && f->quarter < 0) top = OP_ROTATE_ANY;
     else if (f->kind == K_SMOOTH && f->smooth_median && f->kw == 3 && f->kh == 3) top = GMAT_OP_MEDIAN3X3;
     else if (f->kind == K_SMOOTH && !f->smooth_median && !f->gauss_general) top = GMAT_OP_SMOOTH3X3;
     if (top >= 0 && n > 1) {
@@ -639,6 +643,14 @@ static int run_pending(GmatFilterContext *f)
             std::vector<uint8_t *> dp(n);
             for (int k = 0; k < np && r >= 0; k++) {
                 for (int i = 0; i < n; i++) { sp[i] = f->pending[i]->data[k]; dp[i] = outs[i]->data[k]; }
+                if (top == OP_ROTATE_ANY) {             // background and shift per plane as in gmat_filter_frame
+                    uint8_t fill[4] = {0, 0, 0, 255};
+                    if (is_yuv8_src(f->in_fmt)) { fill[0] = k == 0 ? 16 : 128; fill[1] = 128; }
+                    r = rotate_batch(n, sp.data(), f->pending[0]->linesize[k], dp.data(), outs[0]->linesize[k], g[k].w, g[k].h, g[k].w, g[k].h,
+                                     g[k].bpp, f->angle * M_PI / 180.0, f->rot_bilinear, f->rot_shift_x / (1 << g[k].sub),
+                                     f->rot_shift_y / (1 << g[k].sub), fill, f->stream);
+                    continue;
+                }
                 r = op_batch(top, n, sp.data(), f->pending[0]->linesize[k], dp.data(), outs[0]->linesize[k], g[k].w, g[k].h, g[k].bpp, targ, f->stream);
             }
             if (r >= 0) {
@@ -789,6 +801,31 @@ int gmat_rotate2(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int 
     knobs_refresh();
     if (!src || !dst || interp < 0 || interp > 2) return GMAT_ERR(EINVAL);
     return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, interp, fill, (hipStream_t)stream, shift_x, shift_y);
+}
+
+static int rotate_batch(int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                        double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, hipStream_t stream)
+{
+    for (int i0 = 0; i0 < n; i0 += kOpMaxFrames) {
+        const int m = std::min(kOpMaxFrames, n - i0);
+        OpFrames fr;
+        std::memset(&fr, 0, sizeof(fr));
+        for (int i = 0; i < m; i++) {
+            if (!src[i0 + i] || !dst[i0 + i]) return GMAT_ERR(EINVAL);
+            fr.src[i] = src[i0 + i]; fr.dst[i] = dst[i0 + i];
+        }
+        const int r = launch_rotate(nullptr, ss, nullptr, ds, inW, inH, outW, outH, bpp, angle_rad, interp, fill, stream, shift_x, shift_y, &fr, m);
+        if (r < 0) return r;
+    }
+    return 0;
+}
+
+int gmat_rotate2_batch(int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
+                       double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, void *stream)
+{
+    knobs_refresh();
+    if (n < 0 || !src || !dst || interp < 0 || interp > 2) return GMAT_ERR(EINVAL);
+    return rotate_batch(n, src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, interp, shift_x, shift_y, fill, (hipStream_t)stream);
 }
 
 int gmat_median(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, void *stream)

@@ -1412,14 +1412,16 @@ struct RotRows {
 // the tile whose four corners are valid skips the fill logic altogether; results are packed with byte permutes.
 // Tried and slower: walking several tiles per block with the next box requested ahead (35-48 us: the chip overlaps independent
 // blocks better than one block overlaps its own tiles), gathering aligned dwords in the direct form (45 us).
-template <int BPP, int INTERP>
-__global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
-                                                         int aligned, int nbx, int nby)
+template <int BPP, int INTERP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
+                                                         int aligned, int nbx, int nby, OpFrames fr)
 {
+    if (gridDim.z > 1) { src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z]; }      // a frame table: grid.z = frame
     constexpr int TW = 32, TBH = 32, BMAX = 50;
     constexpr int PD = ((BMAX * BPP + 6) / 4 + 2) | 1;      // dwords per LDS row: 50 pixels + lead-in + the two dwords an 8-byte read may run over, odd
     constexpr bool cubic = INTERP == 2;
-    __shared__ unsigned box[(BMAX + 2) * PD];               // 52 rows: the loader's 13 rounds of 4 (rows past the box are never read), and
+    constexpr int NR = (BMAX + NWV - 1) / NWV;              // loader rounds: wave w takes rows w, w + NWV, ...
+    __shared__ unsigned box[(NR * NWV + 1) * PD];           // the loader's NR rounds of NWV rows (rows past the box are never read), and
                                                             // at the frame's last row the pair's lower row is read with weight 0
     __shared__ unsigned cw[cubic ? 512 : 2];                // cubic: the four weights of each 8-bit fraction as two int16 pairs
     // grid (8 * nbx, ceil(nby / 8)): workgroups go to the XCDs round-robin in dispatch order, so blockIdx.x & 7 IS the XCD, and XCD k
@@ -1443,22 +1445,23 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
     const int by1 = cubic ? min(max(maxy + 2, 0), p.inH - 1) : min(bym + 1, p.inH - 1);
     const int bh = by1 - by0 + 1, shift = (bx0 * BPP) & 3, gd0 = (bx0 * BPP) >> 2;
     const int nDw = (shift + (bx1 - bx0 + 1) * BPP + 3) >> 2, rowBytes = p.inW * BPP;
-    {   // wave w loads rows w, w + 4, ... in 13 rounds: every load is issued before the first LDS store (one memory latency, not
-        // thirteen), with no branch — a round past the box's last row reads that row again (its line is in the L1) into an LDS row
+    {   // every load is issued before the first LDS store (one memory latency, not
+        // NR), with no branch — a round past the box's last row reads that row again (its line is in the L1) into an LDS row
         // nobody reads.  The box's rows as a raw buffer resource: the row offset is the instruction's scalar offset, the lane's
         // offset one constant register.  The dword that holds the frame's last bytes may reach past the last row's end: in the one
         // tile that has it, that lane of that row reads bytes.
-        constexpr int NR = (BMAX + 3) / 4;
         const bool tailRow = by1 == p.inH - 1 && 4 * (gd0 + nDw) > rowBytes;
         const RotRows rows(src + (size_t)by0 * ss + 4 * (size_t)gd0);
-        if (cubic) {                                        // 256 threads, 256 fractions
-            int w4[4];
-            rot_cubic_w((int)threadIdx.x, w4);
-            cw[2 * threadIdx.x] = (unsigned)(w4[0] & 0xFFFF) | ((unsigned)w4[1] << 16);
-            cw[2 * threadIdx.x + 1] = (unsigned)(w4[2] & 0xFFFF) | ((unsigned)w4[3] << 16);
+        if (cubic) {                                        // 256 fractions
+            for (int fr = threadIdx.x; fr < 256; fr += 64 * NWV) {
+                int w4[4];
+                rot_cubic_w(fr, w4);
+                cw[2 * fr] = (unsigned)(w4[0] & 0xFFFF) | ((unsigned)w4[1] << 16);
+                cw[2 * fr + 1] = (unsigned)(w4[2] & 0xFFFF) | ((unsigned)w4[3] << 16);
+            }
         }
         if (lane < nDw) {
-            const unsigned lo4 = 4u * (unsigned)lane, offLast = (unsigned)((bh - 1) * ss), step = 4u * (unsigned)ss;   // ss > 0 (launcher)
+            const unsigned lo4 = 4u * (unsigned)lane, offLast = (unsigned)((bh - 1) * ss), step = (unsigned)(NWV * ss);   // ss > 0 (launcher)
             unsigned *bw = box + wave * PD + lane;
             unsigned v[NR];
             if (!tailRow) {
@@ -1466,7 +1469,7 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
 #pragma unroll
                 for (int k = 0; k < NR; k++, off += step) v[k] = rows.ld4(lo4, min(off, offLast));
 #pragma unroll
-                for (int k = 0; k < NR; k++) bw[4 * k * PD] = v[k];
+                for (int k = 0; k < NR; k++) bw[NWV * k * PD] = v[k];
             } else {
                 unsigned off = (unsigned)(wave * ss);
 #pragma unroll
@@ -1475,8 +1478,8 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
                     if (!(lane == nDw - 1 && off >= offLast)) v[k] = rows.ld4(lo4, min(off, offLast));
                 }
 #pragma unroll
-                for (int k = 0; k < NR; k++) bw[4 * k * PD] = v[k];
-                if (lane == nDw - 1 && ((bh - 1) & 3) == wave) {
+                for (int k = 0; k < NR; k++) bw[NWV * k * PD] = v[k];
+                if (lane == nDw - 1 && (bh - 1) % NWV == wave) {
                     const uint8_t *gt = src + (size_t)by1 * ss + 4 * (size_t)(gd0 + lane);
                     unsigned tl = 0;
                     for (int b = 0; b < rowBytes - 4 * (gd0 + lane); b++) tl |= (unsigned)gt[b] << (8 * b);
@@ -1486,12 +1489,17 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
         }
     }
     __syncthreads();
-    const int ir = (lane & 7) * 4, jr = wave * 8 + (lane >> 3);
-    const int i0 = iLo + ir, j = jLo + jr;
-    if (i0 >= p.outW || j >= p.outH) return;
-    const int x0 = xb + m24(jr, p.s) + m24(ir, p.c), y0 = yb + m24(jr, p.c) - m24(ir, p.s);     // |s|, |c| <= 2^16
+    // a wave makes 8 rows of 32 pixels at a time (a lane: 4 adjacent pixels), the block's waves 8 * NWV rows a pass
+    const int ir = (lane & 7) * 4, i0 = iLo + ir;
+    if (i0 >= p.outW) return;
     const int boK = shift - bx0 * BPP - by0 * PD * 4;       // byte offset in LDS of pixel (ix, iy): ix * BPP + iy * PD * 4 + boK
+    const int hiX = (bxm << 16) | (bxm == p.inW - 1 ? 0 : 0xFFFF), hiY = (bym << 16) | (bym == p.inH - 1 ? 0 : 0xFFFF);
     const int nx = min(4, p.outW - i0);
+#pragma unroll 1
+    for (int jr = wave * 8 + (lane >> 3); jr < TBH; jr += 8 * NWV) {
+    const int j = jLo + jr;
+    if (j >= p.outH) break;
+    const int x0 = xb + m24(jr, p.s) + m24(ir, p.c), y0 = yb + m24(jr, p.c) - m24(ir, p.s);     // |s|, |c| <= 2^16
     uint8_t *d = dst + (size_t)j * ds + (size_t)i0 * BPP;
 
     // one output pixel; the result of channel k is BYTE 2 of R[k] (bilinear: the 24-bit sum before its >> 16)
@@ -1552,27 +1560,33 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
                 R[k] = (unsigned)(r < 0 ? 0 : r > 255 ? 255 : r) << 16;
             }
         } else {
-            const int ix = min(max(x1, bx0), bxm), iy = min(max(y1, by0), bym);
-            const int bo = ix * BPP + boK;
+            // the upper clamp on the 16.16 coordinate itself: past the frame's last column / row the pair's second tap is the first
+            // one again, which is a zero weight — hiX / hiY end in 0x0000 there and in 0xFFFF inside the frame (the lower clamp is
+            // on the integer part only: x1 = -1 reads pixels 0 and 1 WITH its fraction, vf_rotate.c:463-492)
+            const int xm = min(x, hiX), ym = min(y, hiY);
+            const int ix = max(xm >> 16, bx0), iy = max(ym >> 16, by0);
+            const int bo = m24(ix, BPP) + boK;
             const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (m24(iy, PD * 4) + (bo & ~3)));
             const unsigned sh = (unsigned)bo & 3u;
             if (INTERP == 1) {
-                // the pair's second column / row past the frame's last one is the first one again: the same as a zero weight
-                const int fx = ix == p.inW - 1 ? 0 : x & 0xFFFF, fy = iy == p.inH - 1 ? 0 : y & 0xFFFF;
+                const int fx = xm & 0xFFFF, fy = ym & 0xFFFF;
                 const unsigned a0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), b0 = __builtin_amdgcn_alignbyte(w[PD + 1], w[PD], sh);
                 unsigned a1 = 0, b1 = 0;
                 if (BPP > 2) { a1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh); b1 = __builtin_amdgcn_alignbyte(w[PD + 2], w[PD + 1], sh); }
-                const unsigned fyh = (unsigned)fy << 16;
-                const int fyl = -(fy << 8);
+                const unsigned fyh = (unsigned)ym << 16;
+                const int fyl = m24(fy, -256);
 #pragma unroll
                 for (int k = 0; k < BPP; k++) {
                     const int k1 = k + BPP;                 // byte index of the right tap's channel
-                    const int s00 = (int)((a0 >> (8 * k)) & 0xFF), s10 = (int)((b0 >> (8 * k)) & 0xFF);
+                    const int s00 = (int)((a0 >> (8 * k)) & 0xFF);
                     const int s01 = (int)(((k1 < 4 ? a0 >> (8 * (k1 & 3)) : a1 >> (8 * (k1 & 3)))) & 0xFF);
                     const int s11 = (int)(((k1 < 4 ? b0 >> (8 * (k1 & 3)) : b1 >> (8 * (k1 & 3)))) & 0xFF);
+                    // (s10 << 16) + 2^24 and s10 itself by one byte permute each (selector 0x0C = 0, byte 4 = the constant's 0x01)
+                    const int s10h = (int)__builtin_amdgcn_perm(1u, b0, 0x04000c0cu | ((unsigned)k << 16));
+                    const int s10 = (int)((b0 >> (8 * k)) & 0xFF);
                     const int s0 = (s00 << 16) + m24(fx, s01 - s00);          // exact without 64-bit arithmetic: see rotate_kernel
-                    const int s1 = (s10 << 16) + m24(fx, s11 - s10);
-                    R[k] = (unsigned)(s0 + fyl + (int)__umulhi(fyh, (unsigned)(s1 - s0 + (1 << 24))));
+                    const int s1h = s10h + m24(fx, s11 - s10);                // s1 + 2^24
+                    R[k] = (unsigned)(s0 + fyl + (int)__umulhi(fyh, (unsigned)(s1h - s0)));
                 }
             } else {
                 const unsigned a0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
@@ -1597,7 +1611,7 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
     if (allValid && aligned && nx == 4) {                   // allValid is the tile's: no fill logic at all
 #pragma unroll
         for (int k = 0; k < BPP; k++) reinterpret_cast<unsigned *>(d)[k] = pack4(V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]);
-        return;
+        continue;
     }
     if (allValid) valid[0] = valid[1] = valid[2] = valid[3] = true;       // surplus lanes of a ragged tile are not the tile's pixels
 #pragma unroll
@@ -1614,6 +1628,7 @@ __global__ __launch_bounds__(256) void rotate_lds_kernel(const uint8_t *src, int
         for (int q = 0; q < nx; q++)
             if (p.fillEnable || valid[q])
                 for (int k = 0; k < BPP; k++) d[q * BPP + k] = (uint8_t)(V[q * BPP + k] >> 16);
+    }
     }
 }
 
@@ -1635,10 +1650,17 @@ static int64_t rot_int_sin(int64_t a)
 }
 
 int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
-                  double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream, double shiftX, double shiftY)
+                  double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream, double shiftX, double shiftY,
+                  const OpFrames *frames, int nframes)
 {
     if (inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0) return 0;
     if (bpp < 1 || bpp > 4) return GMAT_ERR(ENOSYS);
+    if (nframes < 1 || nframes > kOpMaxFrames) return GMAT_ERR(EINVAL);
+    if (frames) {                                            // alignment tests below see the batch's least aligned frame
+        uintptr_t so = 0, dor = 0;
+        for (int i = 0; i < nframes; i++) { so |= (uintptr_t)frames->src[i]; dor |= (uintptr_t)frames->dst[i]; }
+        src = reinterpret_cast<const uint8_t *>(so); dst = reinterpret_cast<uint8_t *>(dor);     // only their low bits are looked at
+    }
     RotateParams p;
     const int FIXP = 1 << 16;
     const int angle_int = (int)(angleRad * FIXP * 16);                    // filter_frame, vf_rotate.c:520-522
@@ -1659,16 +1681,23 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && ss > 0 && (int64_t)ss * inH < (1ll << 31);
     if (lds) {
         const int nbx = (outW + 31) / 32, nby = (outH + 31) / 32;
-        const dim3 grid(8 * nbx, (nby + 7) / 8), block(256);
-#define GMAT_ROTL(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
-                           else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
-                           else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, 0>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); } while (0)
+        // four waves a block; GMAT_ROTATE_WAVES=2 (a thread: 8 pixels in two passes, the block's fixed latencies paid per 512 pixels a
+        // wave) is the A/B that showed the kernel is not bound by them: 21.0 against 20.7 us (profiles/r03zr_rotate.txt)
+        const char *ew = GMAT_KNOB("GMAT_ROTATE_WAVES");
+        const int nwv = ew && atoi(ew) == 2 ? 2 : 4;
+        const dim3 grid(8 * nbx, (nby + 7) / 8, frames ? nframes : 1), block(64 * nwv);
+        const OpFrames fr = frames ? *frames : op_frames(src, dst, nullptr);
+        if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
+#define GMAT_ROTL2(B_, I_) do { if (nwv == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, I_, 4>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby, fr); \
+                                else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_lds_kernel<B_, I_, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby, fr); } while (0)
+#define GMAT_ROTL(B_) do { if (bilinear == 2) GMAT_ROTL2(B_, 2); else if (bilinear) GMAT_ROTL2(B_, 1); else GMAT_ROTL2(B_, 0); } while (0)
         switch (bpp) {
         case 1:  GMAT_ROTL(1); break;
         case 2:  GMAT_ROTL(2); break;
         case 3:  GMAT_ROTL(3); break;
         default: GMAT_ROTL(4); break;
         }
+#undef GMAT_ROTL2
 #undef GMAT_ROTL
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1677,16 +1706,19 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     const int tw = 4 * lx, tbh = 4 * (64 / lx);
     const int nbx = (outW + tw - 1) / tw, nby = (outH + tbh - 1) / tbh;
     const dim3 grid(8 * ((nbx * nby + 7) / 8)), block(256);
+    for (int fi = 0; fi < (frames ? nframes : 1); fi++) {    // the fallback form takes a batch frame by frame
+        if (frames) { src = frames->src[fi]; dst = frames->dst[fi]; }
 #define GMAT_ROT(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 2>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
                           else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 1>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); \
                           else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_kernel<B_, lx, 0>), grid, block, 0, stream, src, ss, dst, ds, p, aligned, nbx, nby); } while (0)
-    switch (bpp) {
-    case 1: GMAT_ROT(1); break;
-    case 2: GMAT_ROT(2); break;
-    case 3: GMAT_ROT(3); break;
-    default: GMAT_ROT(4); break;
-    }
+        switch (bpp) {
+        case 1: GMAT_ROT(1); break;
+        case 2: GMAT_ROT(2); break;
+        case 3: GMAT_ROT(3); break;
+        default: GMAT_ROT(4); break;
+        }
 #undef GMAT_ROT
+    }
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -178,7 +178,8 @@ int launch_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t *dst, i
 // the pixels whose source position is out of range untouched
 // bilinear: 0 nearest, 1 linear, 2 cubic (Catmull-Rom, integer weights); shiftX / shiftY: translation of the rotated image in output pixels
 int launch_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int inW, int inH, int outW, int outH,
-                  int bpp, double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream, double shiftX = 0.0, double shiftY = 0.0);
+                  int bpp, double angleRad, int bilinear, const uint8_t *fill, hipStream_t stream, double shiftX = 0.0, double shiftY = 0.0,
+                  const OpFrames *frames = nullptr, int nframes = 1);
 
 } // namespace gmat
 

@@ -308,6 +308,10 @@ GMAT_API int gmat_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t 
 enum { GMAT_OP_ROTATE_FLIP_SMOOTH = 0, GMAT_OP_SMOOTH3X3 = 1, GMAT_OP_TRANSPOSE = 2, GMAT_OP_FLIP = 3, GMAT_OP_MEDIAN3X3 = 4 };
 GMAT_API int gmat_op_batch(int op, int n, const uint8_t *const *src, int srcStride, uint8_t *const *dst, int dstStride,
                            int w, int h, int bpp, int arg, void *stream);
+/* gmat_rotate2 over n frames of one geometry, angle and background through one launch (grid.z = frame) */
+GMAT_API int gmat_rotate2_batch(int n, const uint8_t *const *src, int srcStride, uint8_t *const *dst, int dstStride,
+                                int inW, int inH, int outW, int outH, int bpp, double angle_rad, int interp,
+                                double shift_x, double shift_y, const uint8_t *fill, void *stream);
 
 /* =====================================================================================
  * 4. Runtime helpers (logging, device, timing) — no reference counterpart beyond av_log

@@ -247,7 +247,7 @@ static int gh_run_planes(GmatHipContext *s, const AVFrame *in, AVFrame *out)
         int pw, ph, bpp;
         if (plane_geometry(s->in_fmt, p, s->in_w, s->in_h, &pw, &ph, &bpp) < 0)
             break;
-        const int sub = p ? 1 : 0;
+        const int sub = p ? av_pix_fmt_desc_get(s->in_fmt)->log2_chroma_w : 0;    /* 4:2:0: 1, 4:4:4: 0 */
         switch (s->kind) {
         case GH_CROP:
             ret = gmat_crop(in->data[p], in->linesize[p], out->data[p], out->linesize[p], s->x >> sub, s->y >> sub,
@@ -318,6 +318,8 @@ static int gh_filter_frame(AVFilterLink *inlink, AVFrame *in)
     return ff_filter_frame(outlink, out);
 }
 
+#define GH_OP_ROTATE_ANY 100     /* vf_rotate.c's walk at an arbitrary angle: gmat_rotate2_batch, not one of gmat_op_batch's */
+
 /* the transform of this filter instance as a gmat_op_batch operation (its kernels take a frame table), or -1 */
 static int gh_batched_op(const GmatHipContext *s, int *arg)
 {
@@ -331,7 +333,7 @@ static int gh_batched_op(const GmatHipContext *s, int *arg)
     case GH_ROTATE:
         if (quarter == 1 || quarter == 3) { *arg = quarter == 1 ? 1 : 2; return GMAT_OP_TRANSPOSE; }
         if (quarter == 2) { *arg = -1; return GMAT_OP_FLIP; }
-        return -1;
+        return quarter < 0 ? GH_OP_ROTATE_ANY : -1;
     case GH_SMOOTH:
         if (s->type == 2) return s->kw == 3 && s->kh == 3 ? GMAT_OP_MEDIAN3X3 : -1;
         return general ? -1 : GMAT_OP_SMOOTH3X3;
@@ -381,6 +383,16 @@ static int gh_flush_queue(AVFilterContext *ctx)
                 if (plane_geometry(s->in_fmt, p, s->in_w, s->in_h, &pw, &ph, &bpp) < 0)
                     break;
                 for (int i = 0; i < n; i++) { ps[i] = s->queue[i]->data[p]; pd[i] = outs[i]->data[p]; }
+                if (op == GH_OP_ROTATE_ANY) {               /* background and shift per plane as in gh_run_planes */
+                    const int sub = p ? av_pix_fmt_desc_get(s->in_fmt)->log2_chroma_w : 0;
+                    const int interp = !strcmp(s->interp, "nearest") ? 0 : !strcmp(s->interp, "cubic") ? 2 : 1;
+                    uint8_t fill[4] = { 0, 0, 0, 255 };
+                    if (!(av_pix_fmt_desc_get(s->in_fmt)->flags & AV_PIX_FMT_FLAG_RGB)) { fill[0] = p ? 128 : 16; fill[1] = 128; }
+                    if (gmat_rotate2_batch(n, ps, s->queue[0]->linesize[p], pd, outs[0]->linesize[p], pw, ph, pw, ph, bpp, s->angle * M_PI / 180.0,
+                                           interp, s->shift_x / (1 << sub), s->shift_y / (1 << sub), fill, s->stream) < 0)
+                        ret = AVERROR_EXTERNAL;
+                    continue;
+                }
                 if (gmat_op_batch(op, n, ps, s->queue[0]->linesize[p], pd, outs[0]->linesize[p], pw, ph, bpp, oparg, s->stream) < 0)
                     ret = AVERROR_EXTERNAL;
             }

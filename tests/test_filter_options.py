@@ -287,13 +287,15 @@ def test_queued_form_of_an_unbatched_filter_is_immediate(dev, orc):
 @pytest.mark.parametrize("case", [("flip_hip", {"code": "1"}, "rgb24"), ("flip_hip", {"code": "0"}, "nv12"), ("transpose_hip", {"dir": "1"}, "rgb24"),
                                   ("transpose_hip", {"dir": "0"}, "yuv420p"), ("rotate_hip", {"angle": "90"}, "rgba"), ("rotate_hip", {"angle": "180"}, "nv12"),
                                   ("rotate_hip", {"angle": "270"}, "rgb24"), ("smooth_hip", {}, "rgb24"), ("smooth_hip", {"type": "median"}, "yuv444p"),
-                                  ("smooth_hip", {"type": "gaussian", "kw": "5", "kh": "5"}, "rgb24"), ("rotate_hip", {"angle": "17"}, "rgb24")])
+                                  ("smooth_hip", {"type": "gaussian", "kw": "5", "kh": "5"}, "rgb24"), ("rotate_hip", {"angle": "17"}, "rgb24"),
+                                  ("rotate_hip", {"angle": "-33.5", "interp": "cubic", "shift_x": "5", "shift_y": "-3"}, "nv12"),
+                                  ("rotate_hip", {"angle": "201", "interp": "nearest"}, "yuv420p")])
 @pytest.mark.parametrize("batch", [3, 16, 20])
 def test_queued_transform_filters_batch_frames_into_one_launch(dev, orc, case, batch):
-    """option batch on the transform filters: flip, transpose, rotate by k * 90 degrees, the 3 x 3 smooth and median take the whole
-    queue in ONE launch per plane (gmat_op_batch: a grid dimension = frame; more than 16 frames: more launches); a filter form without a
-    frame table (general gaussian, arbitrary angle) works through a full queue frame by frame.  Every frame must equal what
-    filter_frame gives for it, in order, with its pts."""
+    """option batch on the transform filters: flip, transpose, rotate (quarter turns and vf_rotate.c's walk at any angle — background
+    and shift per plane), the 3 x 3 smooth and median take the whole queue in ONE launch per plane (gmat_op_batch / gmat_rotate2_batch:
+    a grid dimension = frame; more than 16 frames: more launches); a filter form without a frame table (general gaussian) works
+    through a full queue frame by frame.  Every frame must equal what filter_frame gives for it, in order, with its pts."""
     from harness import synth_planes
     name, opts, fmt = case
     lib = dev.lib
@@ -387,3 +389,31 @@ def test_op_batch_equals_the_single_frame_calls(dev, orc, op, bpp):
         for p in d + o1 + o2:
             p.free()
     assert lib.gmat_op_batch(9, 1, sp, 4, dp, 4, 1, 1, 1, 0, None) < 0 and lib.gmat_op_batch(2, 1, sp, 4, dp, 4, 1, 1, 1, 7, None) < 0
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+def test_rotate2_batch_equals_the_single_frame_calls(dev, orc, interp, bpp):
+    """gmat_rotate2_batch: n frames of one geometry and angle, one launch per 16 (grid.z = frame) — byte for byte what gmat_rotate2
+    writes frame by frame, padding untouched, with and without a background (without: pixels whose source position is out of range
+    keep what the destination held); sources that are not dword-aligned take the direct form frame by frame inside the call"""
+    import math
+    from harness import DevPlane
+    lib = dev.lib
+    fillc = (C.c_uint8 * 4)(9, 8, 7, 6)
+    for (w, h, align, extra, deg, fill) in [(96, 70, 64, 0, 17.0, fillc), (131, 35, 1, 1, -48.5, fillc), (64, 64, 256, 0, 123.0, None)]:
+        n = 19
+        srcs = [orc.lcg((h, w * bpp), 500 + i) for i in range(n)]
+        d = [dev.upload_planes([s_], align, extra)[0] for s_ in srcs]
+        ostride = (w * bpp + extra + align - 1) // align * align
+        o1 = [DevPlane(dev, h, w * bpp, ostride) for _ in range(n)]
+        o2 = [DevPlane(dev, h, w * bpp, ostride) for _ in range(n)]
+        for i in range(n):
+            assert lib.gmat_rotate2(d[i].ptr, d[i].stride, o1[i].ptr, ostride, w, h, w, h, bpp, math.radians(deg), interp, 2.5, -1.0, fill, None) == 0
+        sp = (C.c_void_p * n)(*[p.ptr for p in d]); dp = (C.c_void_p * n)(*[p.ptr for p in o2])
+        assert lib.gmat_rotate2_batch(n, sp, d[0].stride, dp, ostride, w, h, w, h, bpp, math.radians(deg), interp, 2.5, -1.0, fill, None) == 0
+        for i in range(n):
+            assert (o1[i].download(True) == o2[i].download(True)).all(), (interp, bpp, (w, h), i)
+        for p_ in d + o1 + o2:
+            p_.free()
+    assert lib.gmat_rotate2_batch(1, sp, 4, dp, 4, 1, 1, 1, 1, 1, 0.5, 3, 0.0, 0.0, None, None) < 0

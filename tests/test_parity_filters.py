@@ -621,14 +621,16 @@ def test_rotate_interp_and_shift_match_the_stated_rule(dev, orc, case, bpp):
     d.free(); o.free()
 
 
-@pytest.mark.parametrize("lds", ["0", "1"])
+@pytest.mark.parametrize("lds", ["0", "1", "1w2"])
 @pytest.mark.parametrize("interp", [0, 1, 2])
 def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp):
-    """rotate_lds_kernel (source patch in LDS: shipped for cubic) and rotate_kernel (direct gathers: nearest, linear), each forced on
-    every interpolation, on frames several 32 x 32 tiles large whose rotated image leaves the source on all sides — the walk clamps a
+    """rotate_lds_kernel (source patch in LDS: shipped whenever the source rows are dword-aligned; four waves a tile, and the two-wave
+    A/B form) and rotate_kernel (direct gathers: the fallback), each forced on every interpolation, on frames several 32 x 32 tiles large whose rotated image leaves the source on all sides — the walk clamps a
     tap index BEFORE it forms the neighbour's (x1 = -1 reads pixels 0 and 1, vf_rotate.c:463-492), which the patch's bounding box has to
     follow (a 3-in-1000 fuzz find of round 3) — with sizes one off the tile grid and a source pitch that is not the row length"""
-    monkeypatch.setenv("GMAT_ROTATE_LDS", lds)
+    monkeypatch.setenv("GMAT_ROTATE_LDS", lds[0])
+    if lds == "1w2":
+        monkeypatch.setenv("GMAT_ROTATE_WAVES", "2")
     fill = (C.c_uint8 * 4)(1, 2, 3, 4)
     for (w, h, bpp, deg, sx, sy) in [(113, 179, 4, 143.7, 0.0, 0.0), (283, 167, 2, 17.0, 0.0, 0.0), (258, 175, 1, -61.3, 0.0, 0.0),
                                      (230, 130, 3, 100.9, 0.0, 0.0), (195, 69, 3, 271.25, 0.0, 0.0), (97, 65, 3, 45.0, 40.5, -20.25),

@@ -29,6 +29,9 @@ __device__ __forceinline__ int op(int a, int b, int c)
         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, a))) + 0 * b;   // v_pk_min_u16
     }
+    else if constexpr (OP == 16) return (int)__umulhi((unsigned)c, (unsigned)a) + 0 * b;                         // v_mul_hi_u32
+    else if constexpr (OP == 17) return (int)(((unsigned long long)(unsigned)c * (unsigned)a + ((unsigned long long)(unsigned)b << 32)) >> 32);   // v_mad_u64_u32, high half
+    else if constexpr (OP == 18) return (int)((unsigned)c * (unsigned)a);                                        // v_mul_lo_u32
     else return (int)min(min((unsigned)c, (unsigned)a), (unsigned)b);                                           // v_min3_u32
 }
 
@@ -94,6 +97,9 @@ int main()
         run<13>("ds_bpermute_b32", w);
         run<14>("v_pk_min_u16", w);
         run<15>("v_min3_u32", w);
+        run<16>("v_mul_hi_u32", w);
+        run<17>("v_mad_u64_u32 (high half)", w);
+        run<18>("v_mul_lo_u32", w);
     }
     return 0;
 }

@@ -206,6 +206,13 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
             CK(gmat_op_batch(opid, NFOP, sp, w * bpp, dp, ods, w, h, bpp, op == 3 ? 1 : 0, stream));
             return;
         }
+        if (NFOP > 1) {                                      // the arbitrary-angle rotate over a frame table
+            const uint8_t *sp[16]; uint8_t *dp[16];
+            for (int k = 0; k < NFOP; k++) { sp[k] = src[(i * NFOP + k) % NSET]; dp[k] = dst[(i * NFOP + k) % NSET]; }
+            CK(gmat_rotate2_batch(NFOP, sp, w * bpp, dp, w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, op == 5 ? 1 : op == 6 ? 2 : 0, 0.0, 0.0,
+                                  nullptr, stream));
+            return;
+        }
         switch (op) {
         case 0: CK(gmat_rotate_flip_smooth(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, stream)); break;
         case 1: CK(gmat_smooth3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, m, 1.0f / 16, 0.0f, stream)); break;
@@ -235,7 +242,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
         best = ms < best ? ms : best;
     }
-    const int fpl = (NFOP > 1 && op <= 4) ? NFOP : 1;
+    const int fpl = NFOP;
     const double us = best * 1e3 / launches / fpl, gbs = 2.0 * nb / us / 1e3;
     if (getenv("X2BENCH_JSON"))
         printf("{\"case\": \"%s\", \"frames_per_launch\": %d, \"us_per_frame\": %.2f, \"algorithmic_bytes_per_frame\": %zu, "
