@@ -1389,11 +1389,14 @@ struct RotRows {
     __amdgpu_buffer_rsrc_t r;
     __device__ __forceinline__ explicit RotRows(const uint8_t *p) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, 0xFFFFFFFFu, 0x00020000)) {}
     __device__ __forceinline__ unsigned ld4(unsigned lane, unsigned row) const { return __builtin_amdgcn_raw_buffer_load_b32(r, lane, row, 0); }
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ uint4 ld16(unsigned off) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); return make_uint4(v.x, v.y, v.z, v.w); }
 #else
     // hipcc's host pass (never executed) and the CPU emulation of the test suite
     const uint8_t *p;
     __host__ __device__ explicit RotRows(const uint8_t *q) : p(q) {}
     __host__ __device__ unsigned ld4(unsigned lane, unsigned row) const { unsigned v; std::memcpy(&v, p + (size_t)row + lane, 4); return v; }
+    __host__ __device__ uint4 ld16(unsigned off) const { uint4 v; std::memcpy(&v, p + (size_t)off, 16); return v; }
 #endif
 };
 
@@ -1445,11 +1448,13 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
     const int by1 = cubic ? min(max(maxy + 2, 0), p.inH - 1) : min(bym + 1, p.inH - 1);
     const int bh = by1 - by0 + 1, shift = (bx0 * BPP) & 3, gd0 = (bx0 * BPP) >> 2;
     const int nDw = (shift + (bx1 - bx0 + 1) * BPP + 3) >> 2, rowBytes = p.inW * BPP;
-    {   // every load is issued before the first LDS store (one memory latency, not
-        // NR), with no branch — a round past the box's last row reads that row again (its line is in the L1) into an LDS row
-        // nobody reads.  The box's rows as a raw buffer resource: the row offset is the instruction's scalar offset, the lane's
-        // offset one constant register.  The dword that holds the frame's last bytes may reach past the last row's end: in the one
-        // tile that has it, that lane of that row reads bytes.
+    {   // The box's rows as a raw buffer resource.  The fast form reads 16 bytes a lane: the block's threads are laid flat over the
+        // box's (row, 16-byte piece) pairs, two or three rounds, every load issued before the first LDS store: 8 to 12 instructions of
+        // a kilobyte a tile where a wave per row issues 52 of 160 bytes.  A piece may run up to 12 bytes past the box's last dword:
+        // inside the frame's pitch everywhere but on the frame's last row — the tile that has it takes the dword form (a round past
+        // the box's last row reads that row again, no branch), whose last dword of the last row reads bytes.
+        const int ncol = (nDw + 3) >> 2, nitem = bh * ncol;
+        const bool wide = !(by1 == p.inH - 1 && 4 * gd0 + 16 * ncol > rowBytes);
         const bool tailRow = by1 == p.inH - 1 && 4 * (gd0 + nDw) > rowBytes;
         const RotRows rows(src + (size_t)by0 * ss + 4 * (size_t)gd0);
         if (cubic) {                                        // 256 fractions
@@ -1460,7 +1465,25 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
                 cw[2 * fr + 1] = (unsigned)(w4[2] & 0xFFFF) | ((unsigned)w4[3] << 16);
             }
         }
-        if (lane < nDw) {
+        if (wide) {
+            constexpr int NT = 64 * NWV, KMAX = (BMAX * (PD / 4) + NT - 1) / NT;
+            const unsigned mrcp = 65536u / (unsigned)ncol + 1u;             // item / ncol = (item * mrcp) >> 16 for item < 5000, ncol <= 13
+            uint4 v[KMAX];
+            int lo[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) {
+                const int item = (int)threadIdx.x + k * NT;
+                lo[k] = -1;
+                if (item < nitem) {
+                    const int q = (int)(((unsigned)item * mrcp) >> 16), c4 = item - m24(q, ncol);
+                    v[k] = rows.ld16((unsigned)(m24(q, ss) + 16 * c4));           // 0 < ss < 2^23 (launcher)
+                    lo[k] = q * PD + 4 * c4;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (lo[k] >= 0) { box[lo[k]] = v[k].x; box[lo[k] + 1] = v[k].y; box[lo[k] + 2] = v[k].z; box[lo[k] + 3] = v[k].w; }
+        } else if (lane < nDw) {
             const unsigned lo4 = 4u * (unsigned)lane, offLast = (unsigned)((bh - 1) * ss), step = (unsigned)(NWV * ss);   // ss > 0 (launcher)
             unsigned *bw = box + wave * PD + lane;
             unsigned v[NR];
@@ -1678,7 +1701,7 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 3) == 0);
     // the source patch staged in LDS whenever the source rows are dword-aligned; GMAT_ROTATE_LDS=0 forces the direct form (A/B)
     const char *el = GMAT_KNOB("GMAT_ROTATE_LDS");
-    const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && ss > 0 && (int64_t)ss * inH < (1ll << 31);
+    const bool lds = (el ? atoi(el) != 0 : true) && ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) && ss > 0 && ss < (1 << 23) && (int64_t)ss * inH < (1ll << 31);
     if (lds) {
         const int nbx = (outW + 31) / 32, nby = (outH + 31) / 32;
         // four waves a block; GMAT_ROTATE_WAVES=2 (a thread: 8 pixels in two passes, the block's fixed latencies paid per 512 pixels a
