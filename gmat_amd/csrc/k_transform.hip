@@ -1401,20 +1401,23 @@ struct RotRows {
 };
 
 // ---- the same walk with the source patch staged in LDS (round 3) ------------------------------------------------------------
-// A block of 256 threads makes a 32 x 32 output tile: the source pixels its taps can touch lie in the bounding box of the tile's four
-// corners (an affine map: the extremes are at the corners), at most 48 x 48 pixels at any angle; the box is loaded row by row with
-// coalesced dword loads into LDS (dword-aligned start: `shift` bytes of lead-in, odd dword pitch) and every tap is read from there.
+// A block makes a 32 x 32 output tile: the source pixels its taps can touch lie in the bounding box of the tile's four corners (an
+// affine map: the extremes are at the corners), at most 48 x 48 pixels at any angle; the box is loaded into LDS (dword-aligned
+// start: `shift` bytes of lead-in, odd dword pitch) and every tap is read from there.
 // The box is computed on CLAMPED coordinates — every tap index the walk forms is clamped to the image first (vf_rotate.c:463-492) — so
 // it lies inside the image and the loads need no border case; the taps are clamped to the BOX, which for a pixel of the tile is the
 // same index (the clamp is monotone and the box's ends are the clamped extremes) and keeps a ragged tile's surplus lanes inside LDS.
 // Arithmetic: rotate_kernel's, tap for tap.
-// The kernel is bound by VALU issue, not by bytes (16.1 M wave instructions a 4K rgb24 frame = 26 of its 29 us in the first form,
-// profiles/r03t_*; nearest, with no arithmetic, 22 us).  This form spends the instructions on the blend only: everything that is
-// the same for the tile (corners, box, validity of the whole tile, row bases of the loads) is scalar; a load is a scalar base + the
-// lane's constant offset; the coordinates advance by additions; the last column / row is a zero weight instead of a second clamp;
-// the tile whose four corners are valid skips the fill logic altogether; results are packed with byte permutes.
-// Tried and slower: walking several tiles per block with the next box requested ahead (35-48 us: the chip overlaps independent
-// blocks better than one block overlaps its own tiles), gathering aligned dwords in the direct form (45 us).
+// The first form of this kernel was bound by VALU issue (16.1 M wave instructions a 4K rgb24 frame = 26 of its 29 us, profiles/r03t_*).
+// This one spends the instructions on the blend: everything that is the same for the tile (corners, box, validity of the whole
+// tile) is scalar; the box is read 16 bytes a lane through a buffer resource; the coordinates advance by additions; the last
+// column / row is a zero weight instead of a second clamp; the tile whose four corners are valid skips the fill logic altogether;
+// results are packed with byte permutes: 8.5 M wave instructions, 20.5 us (0.30 of the roofline; 16.3 us = 0.38 at 16 frames a launch,
+// profiles/r03zr_rotate.txt).  What is left (profiles/r03zr_rotate_decomposition.txt): arithmetic and block structure 14.5 us, the
+// box's loads +3.3, the stores +3.4, added rather than overlapped.
+// Tried and not faster: two waves a tile (a thread: 8 pixels, GMAT_ROTATE_WAVES=2: 21.0 us), a block walking 2 / 4 / 8 tiles with the
+// next box requested ahead (23 / 25 / 29 us, and 35-48 us in the first form: the chip overlaps independent blocks better than one
+// block overlaps its own tiles), gathering aligned dwords in the direct form (45 us).
 template <int BPP, int INTERP, int NWV>
 __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
                                                          int aligned, int nbx, int nby, OpFrames fr)
