@@ -580,7 +580,7 @@ def c_harness(dry):
         key = "filters, %d 4K frames per launch" % nf
         try:
             r = subprocess.run([exe, str(nf), "30", "op: "], env=env, capture_output=True, text=True, timeout=300)
-            res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l and "rotate 17" not in l]
+            res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]
         except Exception as e:                               # noqa: BLE001
             res[key] = [{"error": repr(e)}]
     for n in (2, 3):
