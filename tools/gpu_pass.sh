@@ -50,7 +50,7 @@ for STEP in "$@"; do
   traffic) tools/pmc_traffic_x2.sh $TAG/traffic > $OUT/traffic.log 2>&1; cp $OUT/traffic/traffic.json $OUT/traffic.json 2>/dev/null; tail -14 $OUT/traffic.log ;;
   pmc) CASE=${A[1]}; NF=${A[2]}; P=(); for c in "${A[@]:3}"; do P+=("$(echo $c | tr ',' ' ')"); done
        tools/pmc_case.sh $TAG/pmc "$CASE" $NF "${P[@]}" | tee $OUT/pmc_$(echo $CASE | tr -c 'a-zA-Z0-9' '_').txt ;;
-  x2) timeout 600 tools/bin/x2bench ${A[1]:-32} ${A[2]:-20} "${A[3]:-}" 2>&1 | tee $OUT/x2bench_${A[1]:-32}.txt ;;
+  x2) SFX=$(echo "${A[3]:-}" | tr -c 'a-zA-Z0-9\n' '_'); timeout 600 tools/bin/x2bench ${A[1]:-32} ${A[2]:-20} "${A[3]:-}" 2>&1 | tee $OUT/x2bench_${A[1]:-32}${SFX:+_$SFX}.txt ;;
   x2env) ( for kv in $(echo ${A[1]} | tr ',' ' '); do export $kv; done; echo "== ${A[1]}"; timeout 600 tools/bin/x2bench ${A[2]:-32} ${A[3]:-20} "${A[4]:-}" 2>&1 ) | tee -a $OUT/x2env.txt ;;
   ops) echo "== filter ops, one 4K frame per launch" | tee $OUT/ops.txt; timeout 200 tools/bin/x2bench 1 50 "op: " 2>&1 | tee -a $OUT/ops.txt ;;
   fuzz) N=${A[1]:-2000}; SEED=${A[2]:-301}
