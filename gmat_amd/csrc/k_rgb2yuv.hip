@@ -169,7 +169,7 @@ typedef unsigned y2s_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned y2s_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ uint4 y2s_ld16(const uint8_t *p) { const y2s_u32x4 v = *reinterpret_cast<const y2s_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint2 y2s_ld8(const uint8_t *p) { const y2s_u32x2 v = *reinterpret_cast<const y2s_u32x2 *>(p); return make_uint2(v.x, v.y); }
-__device__ __forceinline__ void y2s_st8(uint8_t *p, unsigned lo, unsigned hi) { y2s_u32x2 v; v.x = lo; v.y = hi; *reinterpret_cast<y2s_u32x2 *>(p) = v; }
+__device__ __forceinline__ void y2s_st8(uint8_t *p, unsigned lo, unsigned hi) { st_stream(p, make_uint2(lo, hi)); }
 #else
 static inline uint4 y2s_ld16(const uint8_t *p) { uint4 v; std::memcpy(&v, p, 16); return v; }
 static inline uint2 y2s_ld8(const uint8_t *p) { uint2 v; std::memcpy(&v, p, 8); return v; }
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yu
                     y2s_st8(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)xo), ub8[0] | (vb8[0] << 8) | (ub8[1] << 16) | (vb8[1] << 24),
                             ub8[2] | (vb8[2] << 8) | (ub8[3] << 16) | (vb8[3] << 24));
                 } else {
-                    *reinterpret_cast<unsigned *>(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = ub8[0] | (ub8[1] << 8) | (ub8[2] << 16) | (ub8[3] << 24);
-                    *reinterpret_cast<unsigned *>(pv + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = vb8[0] | (vb8[1] << 8) | (vb8[2] << 16) | (vb8[3] << 24);
+                    st_stream(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1)), (unsigned)(ub8[0] | (ub8[1] << 8) | (ub8[2] << 16) | (ub8[3] << 24)));
+                    st_stream(pv + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1)), (unsigned)(vb8[0] | (vb8[1] << 8) | (vb8[2] << 16) | (vb8[3] << 24)));
                 }
             }
         }

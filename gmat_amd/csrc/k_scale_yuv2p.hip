@@ -86,8 +86,8 @@ __device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][
         }
     }
     if (!active) return;
-    if (D16) *reinterpret_cast<uint2 *>(P.dst + byteOff) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
-    else     *reinterpret_cast<unsigned *>(P.dst + byteOff) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+    if (D16) st_stream(P.dst + byteOff, make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16)));
+    else     st_stream(P.dst + byteOff, (unsigned)(w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24)));
 }
 
 // the row loop, unrolled by NP so that the slot of an iteration is a compile-time constant
@@ -647,8 +647,8 @@ __device__ __forceinline__ void p2_walk_uvx(const P2Cross &P, int X0, int y0, in
             if (active) {
                 if constexpr (SPL) {                            // planar in, interleaved out
                     uint8_t *d = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 4u : 2u) * (unsigned)co);
-                    if (D16) *reinterpret_cast<uint2 *>(d) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
-                    else     *reinterpret_cast<unsigned *>(d) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+                    if (D16) st_stream(d, make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16)));
+                    else     st_stream(d, (unsigned)(w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24)));
                 } else {                                        // interleaved in, planar out: 2 samples to each plane
                     uint8_t *du = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 2u : 1u) * (unsigned)co);
                     uint8_t *dv = P.dstV + (unsigned)((unsigned)yo * (unsigned)P.dsV + (D16 ? 2u : 1u) * (unsigned)co);

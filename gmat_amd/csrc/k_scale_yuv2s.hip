@@ -93,6 +93,16 @@ __device__ __forceinline__ unsigned s2_sat_pk_u8_i16(unsigned v)
 // S2_SBASE: a plane as a raw buffer resource (four SGPRs built once per wave from the wave-uniform plane pointer): the row offset
 // travels in the instruction's scalar offset, the lane offset is a loop-invariant VGPR — no vector ALU per load or store.
 // num_records = 2^32 - 1: the kernel clamps every row and column itself, the bounds check is not relied on.
+// S2_LD_AUX / S2_ST_AUX: the cache-policy bits of the loads / stores (1 = sc0, 2 = nt, 16 = sc1).  The stores are non-temporal: the
+// destination is written once, `nt` keeps it from displacing the source rows neighbouring bands share in the L2 — alternating runs on
+// one box 116.8 -> 113.1 us per 32-frame launch, 0.640 -> 0.660 (sc0 / sc1 on the stores +-0; on the LOADS nt -17 %, sc1 -3 %, sc0 +-0:
+// profiles/r03zs_cache_policy_ab.txt)
+#ifndef S2_LD_AUX
+#define S2_LD_AUX 0
+#endif
+#ifndef S2_ST_AUX
+#define S2_ST_AUX (GMAT_NT_STORES ? 2 : 0)
+#endif
 struct S2Plane {
 #if defined(__HIP_DEVICE_COMPILE__)
     __amdgpu_buffer_rsrc_t r;
@@ -100,11 +110,11 @@ struct S2Plane {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     typedef unsigned v3u __attribute__((ext_vector_type(3)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    __device__ __forceinline__ uint4 ld16(unsigned lane, unsigned row) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane, row, 0); return make_uint4(v.x, v.y, v.z, v.w); }
-    __device__ __forceinline__ uint3 ld12(unsigned lane, unsigned row) const { const v3u v = __builtin_amdgcn_raw_buffer_load_b96(r, lane, row, 0); return make_uint3(v.x, v.y, v.z); }
-    __device__ __forceinline__ uint2 ld8(unsigned lane, unsigned row) const { const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane, row, 0); return make_uint2(v.x, v.y); }
-    __device__ __forceinline__ void st16(uint4 d, unsigned lane, unsigned row) const { v4u v = {d.x, d.y, d.z, d.w}; __builtin_amdgcn_raw_buffer_store_b128(v, r, lane, row, 0); }
-    __device__ __forceinline__ void st12(uint3 d, unsigned lane, unsigned row) const { v3u v = {d.x, d.y, d.z}; __builtin_amdgcn_raw_buffer_store_b96(v, r, lane, row, 0); }
+    __device__ __forceinline__ uint4 ld16(unsigned lane, unsigned row) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane, row, S2_LD_AUX); return make_uint4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ uint3 ld12(unsigned lane, unsigned row) const { const v3u v = __builtin_amdgcn_raw_buffer_load_b96(r, lane, row, S2_LD_AUX); return make_uint3(v.x, v.y, v.z); }
+    __device__ __forceinline__ uint2 ld8(unsigned lane, unsigned row) const { const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, lane, row, S2_LD_AUX); return make_uint2(v.x, v.y); }
+    __device__ __forceinline__ void st16(uint4 d, unsigned lane, unsigned row) const { v4u v = {d.x, d.y, d.z, d.w}; __builtin_amdgcn_raw_buffer_store_b128(v, r, lane, row, S2_ST_AUX); }
+    __device__ __forceinline__ void st12(uint3 d, unsigned lane, unsigned row) const { v3u v = {d.x, d.y, d.z}; __builtin_amdgcn_raw_buffer_store_b96(v, r, lane, row, S2_ST_AUX); }
 #else
     // hipcc's host pass (never executed) and the CPU emulation of the test suite
     uint8_t *p;

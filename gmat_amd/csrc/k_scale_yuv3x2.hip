@@ -513,13 +513,13 @@ __global__ __launch_bounds__(256) void scale_yuv32r_kernel(Yuv32rArgs a, Yuv2xFr
                     o4.y = E3_B2PAIR(c0[b + 1], c1[b + 1]) | (E3_B2PAIR(c2[b + 1], 0u) << 16) | 0xFF000000u;
                     o4.z = E3_B2PAIR(c0[b + 2], c1[b + 2]) | (E3_B2PAIR(c2[b + 2], 0u) << 16) | 0xFF000000u;
                     o4.w = E3_B2PAIR(c0[b + 3], c1[b + 3]) | (E3_B2PAIR(c2[b + 3], 0u) << 16) | 0xFF000000u;
-                    *reinterpret_cast<uint4 *>(d + 16 * g) = o4;
+                    st_stream(d + 16 * g, o4);
                 } else {
                     uint3 o3;
                     o3.x = E3_B2PAIR(c0[b + 0], c1[b + 0]) | (E3_B2PAIR(c2[b + 0], c0[b + 1]) << 16);
                     o3.y = E3_B2PAIR(c1[b + 1], c2[b + 1]) | (E3_B2PAIR(c0[b + 2], c1[b + 2]) << 16);
                     o3.z = E3_B2PAIR(c2[b + 2], c0[b + 3]) | (E3_B2PAIR(c1[b + 3], c2[b + 3]) << 16);
-                    *reinterpret_cast<uint3 *>(d + 12 * g) = o3;
+                    st_stream(d + 12 * g, o3);
                 }
             }
 #undef E3_B2PAIR

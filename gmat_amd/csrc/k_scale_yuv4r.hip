@@ -229,13 +229,13 @@ __global__ __launch_bounds__(256) void scale_yuv4r_kernel(Yuv4rArgs a, Yuv2xFram
                 o4.y = D4_B2PAIR(c0[1], c1[1]) | (D4_B2PAIR(c2[1], 0u) << 16) | 0xFF000000u;
                 o4.z = D4_B2PAIR(c0[2], c1[2]) | (D4_B2PAIR(c2[2], 0u) << 16) | 0xFF000000u;
                 o4.w = D4_B2PAIR(c0[3], c1[3]) | (D4_B2PAIR(c2[3], 0u) << 16) | 0xFF000000u;
-                *reinterpret_cast<uint4 *>(d) = o4;
+                st_stream(d, o4);
             } else {
                 uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
                 o3.x = D4_B2PAIR(c0[0], c1[0]) | (D4_B2PAIR(c2[0], c0[1]) << 16);
                 o3.y = D4_B2PAIR(c1[1], c2[1]) | (D4_B2PAIR(c0[2], c1[2]) << 16);
                 o3.z = D4_B2PAIR(c2[2], c0[3]) | (D4_B2PAIR(c1[3], c2[3]) << 16);
-                *reinterpret_cast<uint3 *>(d) = o3;
+                st_stream(d, o3);
             }
 #undef D4_B2PAIR
         }

@@ -256,8 +256,8 @@ __global__ __launch_bounds__(NT) void transpose_kernel(const uint8_t *src, int s
             const int q = it * NW * QPW + wave * QPW + lane / NR;
             const unsigned d0 = t32[(2 * rblk + 0) * DW + ((q + rblk) & (DW - 1))], d1 = t32[(2 * rblk + 1) * DW + ((q + rblk) & (DW - 1))];
             const size_t xb = (size_t)iy0 * 2 + 4 * rblk;
-            *reinterpret_cast<unsigned *>(dst + (size_t)orowOf(2 * q + 0) * ds + xb) = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
-            *reinterpret_cast<unsigned *>(dst + (size_t)orowOf(2 * q + 1) * ds + xb) = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+            st_stream(dst + (size_t)orowOf(2 * q + 0) * ds + xb, __builtin_amdgcn_perm(d1, d0, 0x05040100u));
+            st_stream(dst + (size_t)orowOf(2 * q + 1) * ds + xb, __builtin_amdgcn_perm(d1, d0, 0x07060302u));
         }
         return;
     }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void flip_direct_kernel(const uint8_t *src, in
     uint8_t *d = dst + (size_t)y * ds + (size_t)x * BPP;
     if (BPP == 4) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s);
-        *reinterpret_cast<uint4 *>(d) = fh ? make_uint4(v.w, v.z, v.y, v.x) : v;
+        st_stream(d, fh ? make_uint4(v.w, v.z, v.y, v.x) : v);
     } else {
         const uint3 v = *reinterpret_cast<const uint3 *>(s);
         uint3 o = v;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void flip_direct_kernel(const uint8_t *src, in
             o.y = __builtin_amdgcn_perm(hi, lo, 0x05040100u);                         // c1 c2 b0 b1
             o.z = __builtin_amdgcn_perm(v.y, v.x, 0x02010005u);                       // b2 a0 a1 a2
         }
-        *reinterpret_cast<uint3 *>(d) = o;
+        st_stream(d, o);
     }
 }
 
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void median3x3s_kernel(const uint8_t *src, int
 #pragma unroll
         for (int k = 0; k < 4; k++)
             m[k] = md_med3(md_max3(ll.b[k], lo.b[k], lr.b[k]), md_med3(ml.b[k], md.b[k], mr.b[k]), md_min3(hl.b[k], hi.b[k], hr.b[k]));
-        if (st) *reinterpret_cast<unsigned *>(dst + ((unsigned)((yb + r) * ds) + 4u * (unsigned)(d0 + di))) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+        if (st) st_stream(dst + ((unsigned)((yb + r) * ds) + 4u * (unsigned)(d0 + di)), (unsigned)(m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24)));
     };
     MdB a0 = split(load(0)), a1 = split(load(1));
     unsigned q[MD_Q][2];                                     // raw dwords of the rows 2i + 2, 2i + 3 of the next MD_Q iterations

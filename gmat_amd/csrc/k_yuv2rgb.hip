@@ -44,13 +44,13 @@ __device__ __forceinline__ void convert_row4(uint8_t *drow, unsigned y4, const C
         else                                     px[i] = b | (g << 8) | (r << 16) | 0xFF000000u;
     }
     if (OUT == OUT_RGBA || OUT == OUT_BGRA) {
-        *reinterpret_cast<uint4 *>(drow) = make_uint4(px[0], px[1], px[2], px[3]);
+        st_stream(drow, make_uint4(px[0], px[1], px[2], px[3]));
     } else {
         uint3 o;
         o.x = (px[0] & 0xFFFFFF) | (px[1] << 24);
         o.y = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
         o.z = ((px[2] >> 16) & 0xFF) | (px[3] << 8);
-        *reinterpret_cast<uint3 *>(drow) = o;
+        st_stream(drow, o);
     }
 }
 

@@ -21,6 +21,32 @@ __device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   
 // tests/test_isa_guard.py disassembles the shipped library and fails on any v_ashr_pk_*.
 __device__ __forceinline__ int clip_u8_shr(int v, int s) { return min(max(v, 0), (256 << s) - 1) >> s; }
 
+// Streaming stores: a destination frame is written once and not read again by the launch; `nt` keeps its lines from displacing the
+// source rows that neighbouring bands still share in the L2.  It pays where a wave writes WHOLE lines and costs where tiles of
+// different blocks complete each other's lines in the L2 — measured per kernel, alternating builds on one box
+// (profiles/r03zs_nt_stores_ab.txt): headline 116.8 -> 113.1 us per 32-frame launch (0.640 -> 0.660; sc0 / sc1 on the stores +-0, `nt` on the
+// LOADS -17 %), 2:1 planes -1.5 ... -3 %, 3:1 / 3:2 RGB -1.9 / -4.4 %, the 1080p converter -8.4 %, hflip -8.5 %, 2-byte transpose -19 %
+// (-10 % batched), median -7 ... -10 % (+4 % batched); NOT used where it lost: `smooth121_kernel` in all its forms (+20 ... +30 % batched:
+// 60-column tiles), the 1-byte transpose (+15 % batched), the 3:1 / 3:2 plane walkers (+1.3 %), or did nothing (4:1, the band walker, the
+// RGB-source scalers, rotate).  GMAT_NT_STORES=0 (a build flag) is the A/B.
+#ifndef GMAT_NT_STORES
+#define GMAT_NT_STORES 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && GMAT_NT_STORES
+typedef unsigned nt_v2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned nt_v3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef unsigned nt_v4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void st_stream(void *p, unsigned v) { __builtin_nontemporal_store(v, reinterpret_cast<unsigned *>(p)); }
+__device__ __forceinline__ void st_stream(void *p, uint2 v) { nt_v2u t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v2u *>(p)); }
+__device__ __forceinline__ void st_stream(void *p, uint3 v) { nt_v3u t = {v.x, v.y, v.z}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v3u *>(p)); }
+__device__ __forceinline__ void st_stream(void *p, uint4 v) { nt_v4u t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v4u *>(p)); }
+#else
+__host__ __device__ __forceinline__ void st_stream(void *p, unsigned v) { *reinterpret_cast<unsigned *>(p) = v; }
+__host__ __device__ __forceinline__ void st_stream(void *p, uint2 v) { *reinterpret_cast<uint2 *>(p) = v; }
+__host__ __device__ __forceinline__ void st_stream(void *p, uint3 v) { *reinterpret_cast<uint3 *>(p) = v; }
+__host__ __device__ __forceinline__ void st_stream(void *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+#endif
+
 // 24-bit multiply (v_mul_i32_i24 / v_mad_i32_i24 run at full rate; v_mul_lo_u32 does not).  Every use
 // below has |operands| < 2^23: pixel values <= 510, table constants <= 2^18.
 __device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
