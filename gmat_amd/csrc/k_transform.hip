@@ -1520,6 +1520,8 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
     if (i0 >= p.outW) return;
     const int boK = shift - bx0 * BPP - by0 * PD * 4;       // byte offset in LDS of pixel (ix, iy): ix * BPP + iy * PD * 4 + boK
     const int hiX = (bxm << 16) | (bxm == p.inW - 1 ? 0 : 0xFFFF), hiY = (bym << 16) | (bym == p.inH - 1 ? 0 : 0xFFFF);
+    // a frame one column / row thick: its first column is its last one too (x1 = -1 lands on it WITH a fraction): the weight is masked
+    const int fxMask = p.inW == 1 ? 0 : 0xFFFF, fyMask = p.inH == 1 ? 0 : 0xFFFF;
     const int nx = min(4, p.outW - i0);
 #pragma unroll 1
     for (int jr = wave * 8 + (lane >> 3); jr < TBH; jr += 8 * NWV) {
@@ -1595,11 +1597,11 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
             const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (m24(iy, PD * 4) + (bo & ~3)));
             const unsigned sh = (unsigned)bo & 3u;
             if (INTERP == 1) {
-                const int fx = xm & 0xFFFF, fy = ym & 0xFFFF;
+                const int fx = xm & fxMask, fy = ym & fyMask;
                 const unsigned a0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), b0 = __builtin_amdgcn_alignbyte(w[PD + 1], w[PD], sh);
                 unsigned a1 = 0, b1 = 0;
                 if (BPP > 2) { a1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh); b1 = __builtin_amdgcn_alignbyte(w[PD + 2], w[PD + 1], sh); }
-                const unsigned fyh = (unsigned)ym << 16;
+                const unsigned fyh = (unsigned)fy << 16;
                 const int fyl = m24(fy, -256);
 #pragma unroll
                 for (int k = 0; k < BPP; k++) {

@@ -35,6 +35,7 @@ for case in range(n):
             if op == "fused": bpp = rng.choice([3, 4])
             if op == "median" and rng.random() < 0.7: w = 4 * rng.randint(1, 130)      # rows of whole dwords: median3x3s_kernel on aligned planes
             if op == "transpose" and rng.random() < 0.4: w, h = 64 * rng.randint(1, 5), 64 * rng.randint(1, 4)   # whole tiles: the dword fast paths
+            if op == "rotate" and rng.random() < 0.08: w, h = rng.choice([(1, h), (w, 1), (2, h), (w, 2)])         # frames one or two columns / rows thick
             src = orc.lcg((h, w * bpp), 500 + case)
             tr = op in ("transpose", "fused")
             ow, oh = (h, w) if tr else (w, h)

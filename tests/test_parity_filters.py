@@ -647,6 +647,26 @@ def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp)
         d.free(); o.free()
 
 
+@pytest.mark.parametrize("lds", ["0", "1"])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rotate_frames_one_column_or_row_thick(dev, orc, monkeypatch, lds, interp):
+    """a 1 x h or w x 1 frame: its first column / row is also its last one, so x1 = -1 — which keeps its fraction and reads pixels 0 and
+    min(1, W - 1) — pairs pixel 0 with itself (a GPU fuzz find of round 3: the LDS form's zero-weight rule for the last column only looked
+    at the upper clamp; fuzz_transforms seed 913 case 373: 1 x 24, 2 bytes per pixel)"""
+    monkeypatch.setenv("GMAT_ROTATE_LDS", lds)
+    fill = (C.c_uint8 * 4)(200, 100, 50, 25)
+    for (w, h, bpp, deg) in [(1, 24, 2, 77.3), (1, 24, 2, -160.0), (40, 1, 3, 12.5), (1, 1, 4, 33.0), (1, 70, 1, 5.0), (2, 33, 3, 91.5), (57, 2, 4, -3.0)]:
+        src = orc.lcg((h, w * bpp), 90 + bpp)
+        d = dev.upload_planes([src], 4, 4)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + 11) // 4 * 4)
+        assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), interp, 0.0, 0.0, fill, None) == 0
+        want = np.zeros_like(src)
+        orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, math.radians(deg), interp, 0.0, 0.0, fill)
+        got = o.download()
+        assert (got == want).all(), ((w, h, bpp, deg), np.argwhere(got != want)[:4].tolist())
+        d.free(); o.free()
+
+
 def test_rotate_filter_honours_interp_and_shift(dev, orc):
     """through the filter: rotate_hip angle=17:interp=cubic:shift_x=6:shift_y=-2.5 on rgb24, and on nv12 (chroma planes move by half)"""
     w, h = 96, 40
