@@ -1454,10 +1454,12 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
     {   // The box's rows as a raw buffer resource.  The fast form reads 16 bytes a lane: the block's threads are laid flat over the
         // box's (row, 16-byte piece) pairs, two or three rounds, every load issued before the first LDS store: 8 to 12 instructions of
         // a kilobyte a tile where a wave per row issues 52 of 160 bytes.  A piece may run up to 12 bytes past the box's last dword:
-        // inside the frame's pitch everywhere but on the frame's last row — the tile that has it takes the dword form (a round past
+        // inside the frame everywhere but at the frame's end — the tile that would leave it takes the dword form (a round past
         // the box's last row reads that row again, no branch), whose last dword of the last row reads bytes.
         const int ncol = (nDw + 3) >> 2, nitem = bh * ncol;
-        const bool wide = !(by1 == p.inH - 1 && 4 * gd0 + 16 * ncol > rowBytes);
+        // (with a pitch of a few bytes the piece past a row's end can leave the frame from a row above the last one: the test is on
+        // the last byte the pieces of the box's last row touch)
+        const bool wide = by1 * ss + 4 * gd0 + 16 * ncol <= (p.inH - 1) * ss + rowBytes;
         const bool tailRow = by1 == p.inH - 1 && 4 * (gd0 + nDw) > rowBytes;
         const RotRows rows(src + (size_t)by0 * ss + 4 * (size_t)gd0);
         if (cubic) {                                        // 256 fractions
