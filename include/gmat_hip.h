@@ -303,7 +303,7 @@ GMAT_API int gmat_rotate_flip_smooth(const uint8_t *src, int srcStride, uint8_t 
 
 /* n frames of ONE geometry through one launch of a transform kernel (one more grid dimension = frame; 16 frames a launch, more
  * frames more launches) — no reference counterpart: a launch boundary costs 1.6 us + the ramp of a 50 MB kernel, which bounds one 4K
- * frame per launch at 0.56 of the HBM roofline whatever the kernel.  op: GMAT_OP_*; arg: the direction of
+ * frame per launch at 0.56-0.62 of the HBM roofline whatever the kernel.  op: GMAT_OP_*; arg: the direction of
  * gmat_transpose / the code of gmat_flip, else 0.  The queued filter form (option batch) uses it. */
 enum { GMAT_OP_ROTATE_FLIP_SMOOTH = 0, GMAT_OP_SMOOTH3X3 = 1, GMAT_OP_TRANSPOSE = 2, GMAT_OP_FLIP = 3, GMAT_OP_MEDIAN3X3 = 4 };
 GMAT_API int gmat_op_batch(int op, int n, const uint8_t *const *src, int srcStride, uint8_t *const *dst, int dstStride,

@@ -3,7 +3,7 @@
 // The transform filters run one frame per launch (filter_frame()); their ceiling is not the 6.2 TB/s of a big streaming copy but what
 // a 50 MB launch gets between two kernel boundaries.  Shapes:
 //   empty      the launch-to-launch gap alone
-//   oneshot    thread = one 16-byte load + store                                           (flip_direct_kernel's shape)
+//   oneshot    thread = one 16-byte load + store                                           (flip_direct_kernel's shape); oneshot_nt: the store non-temporal
 //   loopP      thread = P 16-byte accesses, grid-stride
 //   rows4      wave = 16 rows x 240 B, a dword per lane per row: 16 loads in flight, then 16 stores   (smooth121_kernel's shape)
 //   rows16     wave = 16 rows x 1 KB, 16 bytes per lane per row
@@ -24,6 +24,13 @@ __global__ __launch_bounds__(256) void k_oneshot(Frames f)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i * 16 < FB) reinterpret_cast<uint4 *>(f.d[blockIdx.y])[i] = reinterpret_cast<const uint4 *>(f.s[blockIdx.y])[i];
+}
+// the same with a non-temporal store (round 3's last finding: px_math.h st_stream)
+__global__ __launch_bounds__(256) void k_oneshot_nt(Frames f)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i * 16 < FB) __builtin_nontemporal_store(reinterpret_cast<const v4u *>(f.s[blockIdx.y])[i], reinterpret_cast<v4u *>(f.d[blockIdx.y]) + i);
 }
 template <int P>
 __global__ __launch_bounds__(256) void k_loop(Frames f)
@@ -152,6 +159,7 @@ int main()
     timeit("empty", 1, [&](int, int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st); });
     for (int nf : {1, 2, 4, 8}) {
         timeit("oneshot", nf, [&](int i, int n) { hipLaunchKernelGGL(k_oneshot, dim3((unsigned)((FB / 16 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
+        timeit("oneshot_nt", nf, [&](int i, int n) { hipLaunchKernelGGL(k_oneshot_nt, dim3((unsigned)((FB / 16 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("loop2", nf, [&](int i, int n) { hipLaunchKernelGGL(k_loop<2>, dim3((unsigned)((FB / 16 / 2 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("loop4", nf, [&](int i, int n) { hipLaunchKernelGGL(k_loop<4>, dim3((unsigned)((FB / 16 / 4 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("loop8", nf, [&](int i, int n) { hipLaunchKernelGGL(k_loop<8>, dim3((unsigned)((FB / 16 / 8 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
