@@ -366,10 +366,10 @@ __global__ __launch_bounds__(256) void flip_direct_kernel(const uint8_t *src, in
     const uint8_t *s = src + (size_t)sy * ss + (size_t)sx * BPP;
     uint8_t *d = dst + (size_t)y * ds + (size_t)x * BPP;
     if (BPP == 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(s);
+        const uint4 v = ld_stream(s, uint4());
         st_stream(d, fh ? make_uint4(v.w, v.z, v.y, v.x) : v);
     } else {
-        const uint3 v = *reinterpret_cast<const uint3 *>(s);
+        const uint3 v = ld_stream(s, uint3());
         uint3 o = v;
         if (fh) {
             // pixels a b c d = bytes a0 a1 a2 b0 | b1 b2 c0 c1 | c2 d0 d1 d2  ->  d c b a

@@ -40,7 +40,16 @@ __device__ __forceinline__ void st_stream(void *p, unsigned v) { __builtin_nonte
 __device__ __forceinline__ void st_stream(void *p, uint2 v) { nt_v2u t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v2u *>(p)); }
 __device__ __forceinline__ void st_stream(void *p, uint3 v) { nt_v3u t = {v.x, v.y, v.z}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v3u *>(p)); }
 __device__ __forceinline__ void st_stream(void *p, uint4 v) { nt_v4u t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<nt_v4u *>(p)); }
+// ld_stream: the same bit on a LOAD — only for bytes no other thread of the launch reads: a copy with both goes 0.62 -> 0.635 (0.78 ->
+// 0.81 at 8 frames a launch), hflip 0.615 -> 0.625 (0.76 -> 0.815 at 16); the yuv -> rgb converter, one dword a lane, LOSES 3.5 % with it,
+// and the headline, whose neighbouring bands share halo rows, 17 % (profiles/r03zs_nt_stores_ab.txt, last table)
+__device__ __forceinline__ unsigned ld_stream(const void *p, unsigned) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)); }
+__device__ __forceinline__ uint3 ld_stream(const void *p, uint3) { const nt_v3u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v3u *>(p)); return make_uint3(t.x, t.y, t.z); }
+__device__ __forceinline__ uint4 ld_stream(const void *p, uint4) { const nt_v4u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u *>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
 #else
+__host__ __device__ __forceinline__ unsigned ld_stream(const void *p, unsigned) { return *reinterpret_cast<const unsigned *>(p); }
+__host__ __device__ __forceinline__ uint3 ld_stream(const void *p, uint3) { return *reinterpret_cast<const uint3 *>(p); }
+__host__ __device__ __forceinline__ uint4 ld_stream(const void *p, uint4) { return *reinterpret_cast<const uint4 *>(p); }
 __host__ __device__ __forceinline__ void st_stream(void *p, unsigned v) { *reinterpret_cast<unsigned *>(p) = v; }
 __host__ __device__ __forceinline__ void st_stream(void *p, uint2 v) { *reinterpret_cast<uint2 *>(p) = v; }
 __host__ __device__ __forceinline__ void st_stream(void *p, uint3 v) { *reinterpret_cast<uint3 *>(p) = v; }

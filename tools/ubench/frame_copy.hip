@@ -32,6 +32,13 @@ __global__ __launch_bounds__(256) void k_oneshot_nt(Frames f)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i * 16 < FB) __builtin_nontemporal_store(reinterpret_cast<const v4u *>(f.s[blockIdx.y])[i], reinterpret_cast<v4u *>(f.d[blockIdx.y]) + i);
 }
+// ... and a non-temporal load as well
+__global__ __launch_bounds__(256) void k_oneshot_nt2(Frames f)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i * 16 < FB) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const v4u *>(f.s[blockIdx.y]) + i), reinterpret_cast<v4u *>(f.d[blockIdx.y]) + i);
+}
 template <int P>
 __global__ __launch_bounds__(256) void k_loop(Frames f)
 {
@@ -159,6 +166,7 @@ int main()
     timeit("empty", 1, [&](int, int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st); });
     for (int nf : {1, 2, 4, 8}) {
         timeit("oneshot", nf, [&](int i, int n) { hipLaunchKernelGGL(k_oneshot, dim3((unsigned)((FB / 16 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
+        timeit("oneshot_nt2", nf, [&](int i, int n) { hipLaunchKernelGGL(k_oneshot_nt2, dim3((unsigned)((FB / 16 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("oneshot_nt", nf, [&](int i, int n) { hipLaunchKernelGGL(k_oneshot_nt, dim3((unsigned)((FB / 16 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("loop2", nf, [&](int i, int n) { hipLaunchKernelGGL(k_loop<2>, dim3((unsigned)((FB / 16 / 2 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
         timeit("loop4", nf, [&](int i, int n) { hipLaunchKernelGGL(k_loop<4>, dim3((unsigned)((FB / 16 / 4 + 255) / 256), n), dim3(256), 0, st, frames(i * n, n)); });
