@@ -68,10 +68,14 @@ for case in range(n):
                 L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
                 r = lib.gmat_median3x3(d.ptr, d.stride, o.ptr, o.stride, w, h, bpp, None)
             elif op == "rotate":
-                ang = math.radians(rng.uniform(-360, 360)); bil = rng.randint(0, 1)
+                ang = math.radians(rng.uniform(-360, 360)); bil = rng.choice([0, 1, 1, 2])
                 fill = np.array([rng.randint(0, 255) for _ in range(4)], np.uint8)
-                L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, ang, bil, fill.ctypes.data)
-                r = lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, ang, bil, fill.ctypes.data, None)
+                sx, sy = (rng.uniform(-40, 40), rng.uniform(-25, 25)) if rng.random() < 0.3 else (0.0, 0.0)
+                fp = fill.ctypes.data if rng.random() < 0.8 else None      # no background: out-of-range pixels keep the destination's bytes
+                if fp is None: want[:] = 0xCD
+                desc = desc + (round(math.degrees(ang), 3), bil, round(sx, 3), round(sy, 3), fp is not None)
+                L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, ang, bil, sx, sy, fp)
+                r = lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, ang, bil, sx, sy, fp, None)
             else:
                 a = np.zeros((w, h * bpp), np.uint8); b = np.zeros_like(a)
                 L.orc_transpose(src.ctypes.data, src.strides[0], a.ctypes.data, a.strides[0], w, h, bpp, 1)
