@@ -1558,12 +1558,13 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
                     for (int n = 0; n < BPP; n++) c[n] = __builtin_amdgcn_alignbyte(w[r * PD + n + 1], w[r * PD + n], sh);
 #pragma unroll
                     for (int k = 0; k < BPP; k++) {
-                        int hs = 0;
-#pragma unroll
-                        for (int tt = 0; tt < 4; tt++) {
-                            const int n = tt * BPP + k;
-                            hs += m24(wx[tt], (int)((c[n >> 2] >> (8 * (n & 3))) & 0xFF));
-                        }
+                        // taps 0, 1 and 2, 3 of channel k as int16 pairs (bytes k, k + BPP and k + 2 BPP, k + 3 BPP of the row's 4 BPP):
+                        // one byte permute a pair, one v_dot2_i32_i16 a pair against the table's packed weights
+                        constexpr unsigned Z = 0x0C000C00u;
+                        const int n0 = k, n1 = BPP + k, n2 = 2 * BPP + k, n3 = 3 * BPP + k;
+                        const unsigned p01 = __builtin_amdgcn_perm(c[n1 >> 2], c[n0 >> 2], Z | (unsigned)(n0 & 3) | ((unsigned)(4 + (n1 & 3)) << 16));
+                        const unsigned p23 = __builtin_amdgcn_perm(c[n3 >> 2], c[n2 >> 2], Z | (unsigned)(n2 & 3) | ((unsigned)(4 + (n3 & 3)) << 16));
+                        const int hs = dot2((int)p01, (int)wx01, dot2((int)p23, (int)wx23, 0));
                         acc[k] += (long long)wy[r] * hs;
                     }
                 }
