@@ -131,3 +131,36 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
                 hits[func] = hits.get(func, 0) + 1
     assert seen == set(strip), set(strip) - seen
     assert not hits, f"scratch memory in: {hits}"
+
+
+def test_streaming_stores_are_where_they_were_measured(disassembly):
+    """Non-temporal stores (px_math.h st_stream, profiles/r03zs_nt_stores_ab.txt): in the kernels where a wave writes whole lines — and NOT in
+    smooth121_kernel, whose 240-byte columns lose 20 - 30 % with them, nor on any LOAD of the headline (-17 %).  A refactoring that moves a
+    store helper from one list to the other changes a measured number silently; this pins the machine code."""
+    stores, loads = {}, {}
+    for t in disassembly:
+        func = None
+        for line in t.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                func = m.group(1)
+                continue
+            if func and re.search(r"\b(global|buffer)_store_\w+", line):
+                s = stores.setdefault(func, [0, 0])
+                s[1 if re.search(r"\bnt\b", line) else 0] += 1
+            if func and re.search(r"\b(global|buffer)_load_\w+", line) and re.search(r"\bnt\b", line):
+                loads[func] = loads.get(func, 0) + 1
+
+    def total(key):
+        plain = sum(v[0] for f, v in stores.items() if key in f)
+        nt = sum(v[1] for f, v in stores.items() if key in f)
+        return plain, nt
+    for k in ("scale_yuv2s_kernel", "scale_yuv2p_kernel", "scale_yuv3r_kernel", "scale_yuv32r_kernel", "rgb2yuv420s_kernel", "yuv2rgb_kernel",
+              "flip_direct_kernel", "median3x3s_kernel"):
+        plain, nt = total(k)
+        assert nt > 0, (k, plain, nt)
+    for k in ("smooth121_kernel", "scale_yuvg_", "rotate_lds_kernel"):
+        plain, nt = total(k)
+        assert plain > 0 and nt == 0, (k, plain, nt)
+    assert not any("scale_yuv2s" in f for f in loads), [f for f in loads if "scale_yuv2s" in f][:2]
+    assert any("flip_direct_kernel" in f for f in loads)
