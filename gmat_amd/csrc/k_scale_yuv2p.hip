@@ -63,6 +63,13 @@ struct P2Plane {
     const int32_t *h, *v;                      // NP int16 pairs each on the odd-aligned window [2x - (NP - 1), 2x + NP]
     int rnd;                                   // vertical accumulator start (8-bit: the dither term << 12; 10-bit: 1 << 16)
     int srcHi6, dstHi6;                        // P010: the 10 significant bits are the high ones (>> 6 in, << 6 out)
+    // up: the segment is walked from its LAST output row to its first (odd segments: the halo rows two neighbouring segments share
+    // are then requested at the same time, one HBM read and one L2 hit — the headline's finding).  The walker
+    // itself never knows: it walks the vertically mirrored plane downward — row r stands for row srcH - 1 - r (dstH - 1 - r), the
+    // row pair (2m - 1, 2m) is the mirrored pair H/2 - m with its halves swapped, so `v` holds the pairs reversed and swapped.
+    int dstH, up;
+    __device__ __forceinline__ int srow(int r) const { return up ? srcH - 1 - r : r; }
+    __device__ __forceinline__ int drow(int r) const { return up ? dstH - 1 - r : r; }
 };
 
 __device__ __forceinline__ unsigned p2_ld4(const uint8_t *p) { return *reinterpret_cast<const unsigned *>(p); }
@@ -132,7 +139,7 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
     const bool hi6 = P.srcHi6 != 0;
 
     auto load1 = [&](int row, P2Row &r, auto edge_c) {
-        const unsigned o = (unsigned)min(max(row, 0), P.srcH - 1) * (unsigned)P.ss;
+        const unsigned o = (unsigned)P.srow(min(max(row, 0), P.srcH - 1)) * (unsigned)P.ss;
         if (NP == 4 || !decltype(edge_c)::value) {
             const unsigned b = o + (NP == 4 ? uoff : (S16 ? 2u : 1u) * (unsigned)want);
             const uint4 t0 = p2_ld16(P.src + b);
@@ -233,7 +240,7 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);
-            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
+            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
         }
     };
     {
@@ -270,7 +277,7 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
     const int m0 = y0 - (NP / 2 - 1);
 
     auto load1 = [&](int row, P2RowUV &r, auto edge_c) {
-        const unsigned o = (unsigned)min(max(row, 0), P.srcH - 1) * (unsigned)P.ss;
+        const unsigned o = (unsigned)P.srow(min(max(row, 0), P.srcH - 1)) * (unsigned)P.ss;
         if (NP == 4) {
             if (S16) {
                 const unsigned b = o + 4u * (unsigned)off16;
@@ -383,7 +390,7 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
-            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
         }
     };
     {
@@ -417,8 +424,8 @@ __device__ __forceinline__ void p2_walk_uvd(const P2Plane &P, int X0, int y0, in
     const int m0 = y0 - (NP / 2 - 1);
 
     auto load = [&](int m, uint2 &ra, uint2 &rb) {
-        ra = p2_ld8(P.src + ((unsigned)min(max(2 * m - 1, 0), P.srcH - 1) * (unsigned)P.ss + ob));
-        rb = p2_ld8(P.src + ((unsigned)min(max(2 * m, 0), P.srcH - 1) * (unsigned)P.ss + ob));
+        ra = p2_ld8(P.src + ((unsigned)P.srow(min(max(2 * m - 1, 0), P.srcH - 1)) * (unsigned)P.ss + ob));
+        rb = p2_ld8(P.src + ((unsigned)P.srow(min(max(2 * m, 0), P.srcH - 1)) * (unsigned)P.ss + ob));
     };
     auto hrow = [&](const uint2 &R, auto edge_c, int (&su)[2], int (&sv)[2]) {
         unsigned d0 = R.x, d1 = R.y;
@@ -471,7 +478,7 @@ __device__ __forceinline__ void p2_walk_uvd(const P2Plane &P, int X0, int y0, in
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
-            p2_vstore<D16, NP, SLOT>(P, hw, stores, (unsigned)((unsigned)yo * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+            p2_vstore<D16, NP, SLOT>(P, hw, stores, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
         }
     };
     if (edgeWave) p2_rows<NP>(nIter, body, std::true_type());
@@ -681,9 +688,9 @@ __global__ __launch_bounds__(256) void scale_yuv2px_kernel(Yuv2pArgs a, Yuv2xFra
         const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgL);
         const int X0 = ((lin - seg * a.nsgL) * 4 + wave) * P2_STRIP;
         if (X0 >= a.dstW) return;
-        const int y0 = seg * a.segRowsL;
-        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, a.vL, a.lr, sHi, dHi};
-        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
+        const int y0 = seg * a.segRowsL, n = min(a.segRowsL, a.dstH - y0), up = a.updown & seg & 1;
+        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up};
+        p2_walk_plane<S16, D16, NP>(P, X0, up ? a.dstH - (y0 + n) : y0, n, lane);
         return;
     }
     lin -= a.nblkL;
@@ -716,9 +723,9 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgL);
         const int X0 = ((lin - seg * a.nsgL) * 4 + wave) * P2_STRIP;
         if (X0 >= a.dstW) return;
-        const int y0 = seg * a.segRowsL;
-        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, a.vL, a.lr, sHi, dHi};
-        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsL, a.dstH - y0), lane);
+        const int y0 = seg * a.segRowsL, n = min(a.segRowsL, a.dstH - y0), up = a.updown & seg & 1;
+        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up};
+        p2_walk_plane<S16, D16, NP>(P, X0, up ? a.dstH - (y0 + n) : y0, n, lane);
         return;
     }
     lin -= a.nblkL;
@@ -728,10 +735,10 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgC);
         const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * (UVD ? P2_STRIP_UVD : P2_STRIP_UV);
         if (X0 >= a.chrDstW) return;
-        const int y0 = seg * a.segRowsC;
-        const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, a.vC, a.cr, sHi, dHi};
-        if constexpr (UVD) p2_walk_uvd<D16>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
-        else               p2_walk_uv<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+        const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
+        const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up};
+        if constexpr (UVD) p2_walk_uvd<D16>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
+        else               p2_walk_uv<S16, D16, NP>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
     } else {
         const int per = a.nsegC * a.nsgC;
         const int pl = __builtin_amdgcn_readfirstlane(lin >= per ? 1 : 0);
@@ -739,10 +746,10 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgC);
         const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * P2_STRIP;
         if (X0 >= a.chrDstW) return;
-        const int y0 = seg * a.segRowsC;
+        const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
         const P2Plane P = {pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
-                           a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, a.vC, a.cr, 0, 0};
-        p2_walk_plane<S16, D16, NP>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+                           a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, 0, 0, a.chrDstH, up};
+        p2_walk_plane<S16, D16, NP>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
     }
 }
 
@@ -841,6 +848,13 @@ int launch_scale_yuv2p(const Yuv2pArgs &a0, hipStream_t stream, const Yuv2xFrame
     // slowest of the launch and longer ones make its tail: p010 6.5 -> 7.5 us with equal rows).  GMAT_P2_CHROMA_SEG = 0 | 1 overrides.
     const char *cse = GMAT_KNOB("GMAT_P2_CHROMA_SEG");
     const bool equalC = cse ? atoi(cse) != 0 : (a.srcDepth == 8 && a.dstDepth == 8 && !a.cross);   // the cross-layout walker: 4.23 -> 4.99 us with equal rows
+    // odd segments walk upward (GMAT_STRIP_UPDOWN=0: all downward): the mirrored plane's pairs are the plane's, reversed, halves swapped
+    const char *ud = GMAT_KNOB("GMAT_STRIP_UPDOWN");
+    a.updown = (ud ? atoi(ud) != 0 : true) && a.srcH == 2 * a.dstH && a.chrSrcH == 2 * a.chrDstH;
+    for (int k = 0; k < a.np; k++) {
+        const uint32_t l = (uint32_t)a.vL[a.np - 1 - k], c = (uint32_t)a.vC[a.np - 1 - k];
+        a.vLup[k] = (int32_t)((l >> 16) | (l << 16)); a.vCup[k] = (int32_t)((c >> 16) | (c << 16));
+    }
     a.segRowsL = seg; a.segRowsC = equalC ? seg : std::max(2, (seg + 1) / 2);
     a.nsegL = (a.dstH + a.segRowsL - 1) / a.segRowsL;
     a.nsegC = (a.chrDstH + a.segRowsC - 1) / a.segRowsC;

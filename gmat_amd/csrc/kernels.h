@@ -348,6 +348,7 @@ struct Yuv2pArgs {
     int lr, cr;
     // filled by the launcher: rows per strip segment, segments and groups of 4 strips per plane kind, workgroup counts
     int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;
+    int updown; int32_t vLup[6], vCup[6];        // odd segments walk upward: the vertical pairs of the mirrored plane
 };
 int  yuv2p_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2pTables &t);
 int  launch_scale_yuv2p(const Yuv2pArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
