@@ -495,6 +495,9 @@ struct P2Cross {
     int ssU, ssV, dsU, dsV, srcW, srcH, dstW;                   // widths in UV positions
     const int32_t *h, *v;
     int rnd, srcHi6, dstHi6;
+    int dstH, up;                                               // see P2Plane
+    __device__ __forceinline__ int srow(int r) const { return up ? srcH - 1 - r : r; }
+    __device__ __forceinline__ int drow(int r) const { return up ? dstH - 1 - r : r; }
 };
 struct P2RowX { unsigned u[16], v[8]; };                        // interleaved source: u = the UV dwords
 
@@ -520,7 +523,7 @@ __device__ __forceinline__ void p2_walk_uvx(const P2Cross &P, int X0, int y0, in
     const int m0 = y0 - (NP / 2 - 1);
 
     auto load1 = [&](int row, P2RowX &r, auto edge_c) {
-        const int rr = min(max(row, 0), P.srcH - 1);
+        const int rr = P.srow(min(max(row, 0), P.srcH - 1));
         const unsigned ou = (unsigned)rr * (unsigned)P.ssU, ov = (unsigned)rr * (unsigned)P.ssV;
         if constexpr (decltype(edge_c)::value) {
 #pragma unroll
@@ -653,12 +656,12 @@ __device__ __forceinline__ void p2_walk_uvx(const P2Cross &P, int X0, int y0, in
             }
             if (active) {
                 if constexpr (SPL) {                            // planar in, interleaved out
-                    uint8_t *d = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 4u : 2u) * (unsigned)co);
+                    uint8_t *d = P.dstU + (unsigned)((unsigned)P.drow(yo) * (unsigned)P.dsU + (D16 ? 4u : 2u) * (unsigned)co);
                     if (D16) st_stream(d, make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16)));
                     else     st_stream(d, (unsigned)(w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24)));
                 } else {                                        // interleaved in, planar out: 2 samples to each plane
-                    uint8_t *du = P.dstU + (unsigned)((unsigned)yo * (unsigned)P.dsU + (D16 ? 2u : 1u) * (unsigned)co);
-                    uint8_t *dv = P.dstV + (unsigned)((unsigned)yo * (unsigned)P.dsV + (D16 ? 2u : 1u) * (unsigned)co);
+                    uint8_t *du = P.dstU + (unsigned)((unsigned)P.drow(yo) * (unsigned)P.dsU + (D16 ? 2u : 1u) * (unsigned)co);
+                    uint8_t *dv = P.dstV + (unsigned)((unsigned)P.drow(yo) * (unsigned)P.dsV + (D16 ? 2u : 1u) * (unsigned)co);
                     if (D16) { *reinterpret_cast<unsigned *>(du) = w[0] | (w[2] << 16); *reinterpret_cast<unsigned *>(dv) = w[1] | (w[3] << 16); }
                     else     { *reinterpret_cast<unsigned short *>(du) = (unsigned short)(w[0] | (w[2] << 8));
                                *reinterpret_cast<unsigned short *>(dv) = (unsigned short)(w[1] | (w[3] << 8)); }
@@ -697,10 +700,10 @@ __global__ __launch_bounds__(256) void scale_yuv2px_kernel(Yuv2pArgs a, Yuv2xFra
     const int seg = __builtin_amdgcn_readfirstlane(lin / a.nsgC);
     const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * P2_STRIP_UV;
     if (X0 >= a.chrDstW) return;
-    const int y0 = seg * a.segRowsC;
+    const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
     const P2Cross P = {fr.u[f], fr.v[f], fr.dstU[f], fr.dstV[f], a.us, a.vs, a.dsU, a.dsV, a.chrSrcW, a.chrSrcH, a.chrDstW,
-                       a.hC, a.vC, a.cr, sHi, dHi};
-    p2_walk_uvx<S16, D16, NP, !SNV>(P, X0, y0, min(a.segRowsC, a.chrDstH - y0), lane);
+                       a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up};
+    p2_walk_uvx<S16, D16, NP, !SNV>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
 }
 
 // blockIdx.x: [0, nblkL) luma workgroups (segment-major, 4 strips each), then the chroma workgroups — interleaved (NV): of the
