@@ -131,6 +131,27 @@ def test_crop(dev, orc):
     assert (o.download() == src[y:y + ch, x * bpp:(x + cw) * bpp]).all()
 
 
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+def test_crop_offsets_of_every_alignment(dev, orc, bpp):
+    """crop = a strided copy: copy2d_kernel (16 bytes a lane from a source of any alignment, streaming stores, 16-byte aligned
+    destinations with rows of 64 bytes and more) and the runtime's 2-D copy for the rest — x offsets 0..17 (every byte alignment of
+    the source), widths that end inside a 16-byte piece, the window touching the frame's last byte, destination pitches aligned and
+    not; the padding of the destination rows stays untouched"""
+    w, h = 301, 37
+    src = orc.lcg((h, w * bpp), 40 + bpp)
+    d = dev.upload_planes([src], 4, 4)[0]
+    for x in list(range(0, 18)) + [w - 70]:
+        for (cw, ch, y) in [(70, 20, 3), (w - x, h, 0), (21, 5, h - 5), (64 // bpp + 1, 9, 1)]:
+            cw = min(cw, w - x)
+            for stride in ((cw * bpp + 15) // 16 * 16 + 16, cw * bpp + 3):
+                o = DevPlane(dev, ch, cw * bpp, stride)
+                assert dev.lib.gmat_crop(d.ptr, d.stride, o.ptr, o.stride, x, y, cw, ch, bpp, None) == 0
+                assert (o.download() == src[y:y + ch, x * bpp:(x + cw) * bpp]).all(), (bpp, x, cw, ch, stride)
+                assert (o.download(True)[:, o.row_bytes:] == 0xCD).all(), (bpp, x, cw, ch, stride)
+                o.free()
+    d.free()
+
+
 # ---- the AVFilter-shaped layer ------------------------------------------------------------------------
 def _run_filter(dev, name, opts, src, w, h, fmt="rgb24"):
     lib = dev.lib

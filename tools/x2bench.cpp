@@ -206,7 +206,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
             CK(gmat_op_batch(opid, NFOP, sp, w * bpp, dp, ods, w, h, bpp, op == 3 ? 1 : 0, stream));
             return;
         }
-        if (NFOP > 1) {                                      // the arbitrary-angle rotate over a frame table
+        if (NFOP > 1 && op <= 7) {                           // the arbitrary-angle rotate over a frame table
             const uint8_t *sp[16]; uint8_t *dp[16];
             for (int k = 0; k < NFOP; k++) { sp[k] = src[(i * NFOP + k) % NSET]; dp[k] = dst[(i * NFOP + k) % NSET]; }
             CK(gmat_rotate2_batch(NFOP, sp, w * bpp, dp, w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, op == 5 ? 1 : op == 6 ? 2 : 0, 0.0, 0.0,
@@ -222,6 +222,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         case 5: CK(gmat_rotate(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 1, nullptr, stream)); break;
         case 6: CK(gmat_rotate2(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 2, 0.0, 0.0, nullptr, stream)); break;
         case 7: CK(gmat_rotate(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 0, nullptr, stream)); break;
+        case 8: CK(gmat_crop(src[i], w * bpp, dst[i], (w - 64) * bpp, 32, 16, w - 64, h - 32, bpp, stream)); break;   // the frame less a 32 / 16 pixel border
         }
     };
     auto sync_all = [&] { for (void *x : xs) CK(gmat_stream_sync(x)); };
@@ -242,7 +243,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
         best = ms < best ? ms : best;
     }
-    const int fpl = NFOP;
+    const int fpl = op <= 7 ? NFOP : 1;                  // (a crop is a copy: one frame a call)
     const double us = best * 1e3 / launches / fpl, gbs = 2.0 * nb / us / 1e3;
     if (getenv("X2BENCH_JSON"))
         printf("{\"case\": \"%s\", \"frames_per_launch\": %d, \"us_per_frame\": %.2f, \"algorithmic_bytes_per_frame\": %zu, "
@@ -330,7 +331,8 @@ int main(int argc, char **argv)
                       {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2},
                       {"op: median3x3 4K rgb24", 4, 3}, {"op: median3x3 4K gray", 4, 1},
                       {"op: rotate 17 deg bilinear 4K rgb24", 5, 3}, {"op: rotate 17 deg bilinear 4K gray", 5, 1},
-                      {"op: rotate 17 deg cubic 4K rgb24", 6, 3}, {"op: rotate 17 deg nearest 4K rgb24", 7, 3}};
+                      {"op: rotate 17 deg cubic 4K rgb24", 6, 3}, {"op: rotate 17 deg nearest 4K rgb24", 7, 3},
+                      {"op: crop 4K rgb24 (less a 32 x 16 border)", 8, 3}, {"op: crop 4K gray (less a 32 x 16 border)", 8, 1}};
     g_op_frames = NF;
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
