@@ -667,8 +667,8 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
 // IDENT: no filter — the plain transpose of 3- / 4-byte pixels through this kernel's loads and transposed tile (dir: vf_transpose's
 // four directions, bit 0 reads the source bottom-up, bit 1 writes the destination bottom-up): 13.6 us per 4K rgb24 frame against
 // transpose_kernel<3, 64>'s 16.0.
-template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false>
-__global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir, OpFrames fr)
+template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false, int NWH = 0>
+__global__ __launch_bounds__(NWH ? 64 * NWH : 64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir, OpFrames fr)
 {
     src = fr.src[blockIdx.y]; dst = fr.dst[blockIdx.y];    // grid.y = frame
     constexpr int TH = 64, NS = RPW + 2, NT = 64 * TH / RPW;  // tile: TD dwords x 64 rows; RPW rows per wave; source rows per wave; threads
@@ -679,6 +679,16 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
     __shared__ __attribute__((aligned(16))) uint8_t rt[TRANSPOSED ? TWP * PT + 256 : 16];      // + the pad of the idle lanes
     const int rowDwords = (w * BPP) >> 2;
     int tbx, tby;
+    if constexpr (NWH > 0) {
+        // the block's waves side by side: NWH column tiles of RPW rows, so that the rows a block writes are NWH * TD dwords long
+        // (8 x 240 B = 15 whole lines) and only the block's own waves share a line
+        const int nbx = (rowDwords + TD - 1) / TD, nbxB = (nbx + NWH - 1) / NWH, nbyB = (h + RPW - 1) / RPW, ntiles = nbxB * nbyB;
+        const int chunk = (ntiles + 7) >> 3;
+        const int t = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if (t >= ntiles) return;
+        tby = t / nbxB; tbx = (t - tby * nbxB) * NWH + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (tbx >= nbx) return;
+    } else
     {   // XCD-aware tile order, as conv3x3_kernel
         const int nbx = (rowDwords + TD - 1) / TD, nby = (h + TH - 1) / TH, ntiles = nbx * nby;
         const int chunk = (ntiles + 7) >> 3;
@@ -688,9 +698,9 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
         else            { tby = t / nbx; tbx = t - tby * nbx; }
     }
     const int d0 = tbx * TD, nd = min(TD, rowDwords - d0);  // first dword and dword count of the tile
-    const int y0 = tby * TH, th = min(TH, h - y0);
+    const int y0 = NWH ? tby * RPW : tby * TH, th = min(NWH ? RPW : TH, h - y0);
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wave = NWH ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int r0 = wave * RPW, nrows = min(RPW, th - r0);   // wave-uniform
     const int di = lane - 1;                                // this lane's dword of the tile; -1 and nd are the halos
     if (nrows > 0) {
@@ -759,6 +769,7 @@ __global__ __launch_bounds__(64 * 64 / RPW) void smooth121_kernel(const uint8_t 
                             pj[1][r * BPP] = (uint8_t)ho; pj[3][r * BPP] = (uint8_t)(ho >> 16);
                         }
                     } else if (mine) {
+                        // (plain stores: with `nt` the side-by-side form loses 0 - 10 %, the stacked one 20 - 30 %)
                         *reinterpret_cast<unsigned *>(dst + ((unsigned)((y0 + r0 + r) * ds) + 4u * (unsigned)(d0 + di))) = __builtin_amdgcn_perm(ho, he, 0x06020400u);
                     }
                 }
@@ -868,6 +879,24 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     static const int m121[9] = {1, 2, 1, 2, 4, 2, 1, 2, 1};
     if (cp.shift == 4 && std::memcmp(m, m121, sizeof(m121)) == 0 && smooth121_ok(src, ss, dst, ds, w, h, bpp)) {
         const int td = bpp == 3 ? 60 : 62;                   // tile width in dwords: whole pixels (60 dwords = 80 rgb24 pixels)
+        // four waves of a block side by side (4 x 240 B a row, 16 rows): only a block's own waves share a 128-byte line.  With the waves
+        // stacked (a 240 B x 64 row tile a block) every line was completed by ANOTHER block, on another XCD as often as not, and each L2
+        // wrote its part: 16 frames a launch 10.3 -> 9.0 us rgb24, 3.0 -> 2.45 us gray (profiles/r03zu_smooth_layout.txt).
+        // GMAT_SMOOTH_STACKED=1: the stacked form (A/B)
+        const char *est = GMAT_KNOB("GMAT_SMOOTH_STACKED");
+        if (!(est && atoi(est))) {
+            constexpr int NWH = 4;
+            const int nbx = (w * bpp / 4 + td - 1) / td, ntb = ((nbx + NWH - 1) / NWH) * ((h + 15) / 16);
+            const dim3 gh(8 * ((ntb + 7) / 8), nframes), bh(64 * NWH);
+            switch (bpp) {
+            case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            }
+            GMAT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         const int nt = ((w * bpp / 4 + td - 1) / td) * ((h + 63) / 64);
         const dim3 g(8 * ((nt + 7) / 8), nframes), b(256);
         switch (bpp) {
