@@ -184,9 +184,13 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
     std::vector<uint8_t> host(nb);
     fill_lcg(host);
     for (int i = 0; i < NSET; i++) {
-        CK(gmat_malloc(&src[i], nb)); CK(gmat_malloc(&dst[i], nb));
+        CK(gmat_malloc(&src[i], nb)); CK(gmat_malloc(&dst[i], nb + (size_t)w * 512));
         CK(gmat_memcpy_h2d(src[i], host.data(), nb)); CK(gmat_memset(dst[i], 0, nb));
     }
+    // X2BENCH_OP_DST_ALIGN=n: the destination pitch of the transposing ops (h * bpp bytes: 6480 for a 4K rgb24 frame, not a multiple of a
+    // 128-byte line) rounded up to a multiple of n — what a frame of a hardware pool has
+    const int tal = getenv("X2BENCH_OP_DST_ALIGN") ? std::max(1, atoi(getenv("X2BENCH_OP_DST_ALIGN"))) : 1;
+    const int tpitch = (h * bpp + tal - 1) / tal * tal;
     void *stream = nullptr; CK(gmat_stream_create(&stream));
     // X2BENCH_OP_STREAMS=n: launches round-robin over n streams (n - 1 extra ones joined to `stream` by events around the timed
     // region) — what a caller with n frames in flight sees; 1 (default) = filter_frame()'s one frame per call on one stream
@@ -202,7 +206,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
             const uint8_t *sp[16]; uint8_t *dp[16];
             for (int k = 0; k < NFOP; k++) { sp[k] = src[(i * NFOP + k) % NSET]; dp[k] = dst[(i * NFOP + k) % NSET]; }
             const int opid = op == 0 ? GMAT_OP_ROTATE_FLIP_SMOOTH : op == 1 ? GMAT_OP_SMOOTH3X3 : op == 2 ? GMAT_OP_TRANSPOSE : op == 3 ? GMAT_OP_FLIP : GMAT_OP_MEDIAN3X3;
-            const int ods = (op == 0 || op == 2) ? h * bpp : w * bpp;
+            const int ods = (op == 0 || op == 2) ? tpitch : w * bpp;
             CK(gmat_op_batch(opid, NFOP, sp, w * bpp, dp, ods, w, h, bpp, op == 3 ? 1 : 0, stream));
             return;
         }
@@ -214,9 +218,9 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
             return;
         }
         switch (op) {
-        case 0: CK(gmat_rotate_flip_smooth(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, stream)); break;
+        case 0: CK(gmat_rotate_flip_smooth(src[i], w * bpp, dst[i], tpitch, w, h, bpp, stream)); break;
         case 1: CK(gmat_smooth3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, m, 1.0f / 16, 0.0f, stream)); break;
-        case 2: CK(gmat_transpose(src[i], w * bpp, dst[i], h * bpp, w, h, bpp, 0, stream)); break;
+        case 2: CK(gmat_transpose(src[i], w * bpp, dst[i], tpitch, w, h, bpp, 0, stream)); break;
         case 3: CK(gmat_flip(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, 1, stream)); break;
         case 4: CK(gmat_median3x3(src[i], w * bpp, dst[i], w * bpp, w, h, bpp, stream)); break;
         case 5: CK(gmat_rotate(src[i], w * bpp, dst[i], w * bpp, w, h, w, h, bpp, 17.0 * 3.14159265358979323846 / 180.0, 1, nullptr, stream)); break;
