@@ -667,11 +667,11 @@ int launch_copy2d(const uint8_t *src, int ss, uint8_t *dst, int ds, int rowBytes
 // IDENT: no filter — the plain transpose of 3- / 4-byte pixels through this kernel's loads and transposed tile (dir: vf_transpose's
 // four directions, bit 0 reads the source bottom-up, bit 1 writes the destination bottom-up): 13.6 us per 4K rgb24 frame against
 // transpose_kernel<3, 64>'s 16.0.
-template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false, int NWH = 0>
-__global__ __launch_bounds__(NWH ? 64 * NWH : 64 * 64 / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir, OpFrames fr)
+template <int BPP, bool TRANSPOSED, int TD, int RPW, bool IDENT = false, int NWH = 0, int THP = 64>
+__global__ __launch_bounds__(NWH ? 64 * NWH : 64 * THP / RPW) void smooth121_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int dst16, int dir, OpFrames fr)
 {
     src = fr.src[blockIdx.y]; dst = fr.dst[blockIdx.y];    // grid.y = frame
-    constexpr int TH = 64, NS = RPW + 2, NT = 64 * TH / RPW;  // tile: TD dwords x 64 rows; RPW rows per wave; source rows per wave; threads
+    constexpr int TH = THP, NS = RPW + 2, NT = 64 * TH / RPW; // tile: TD dwords x TH rows; RPW rows per wave; source rows per wave; threads
     static_assert(TD + 2 <= 64 && (TD * 4) % BPP == 0, "tile width: whole pixels, two halo lanes");
     constexpr int TWP = TD * 4 / BPP;                       // tile width in pixels
     constexpr int PT = TH * BPP + 4;                        // transposed tile pitch: 49 / 65 dwords (odd)
@@ -784,19 +784,29 @@ __global__ __launch_bounds__(NWH ? 64 * NWH : 64 * 64 / RPW) void smooth121_kern
     // rows of the transposed tile: pixel column px of the source tile -> destination row x0 + px, bytes [y0*BPP, +th*BPP)
     const int npx = nd * 4 / BPP, x0 = d0 * 4 / BPP, nbytes = th * BPP;
     auto orow = [&](int r) { return (IDENT && (dir & 2)) ? w - 1 - r : r; };       // the destination is w rows tall
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    if (dst16 && (nbytes & 15) == 0) {
-        const int cpr = nbytes >> 4;                        // 16-byte chunks per row (<= 16)
-        for (int px = ty; px < npx; px += NT / 16) {
+    constexpr int CW = TH * BPP / 16 <= 16 ? 16 : TH * BPP / 16 <= 32 ? 32 : 64;   // lanes across a row of the transposed tile
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    if ((dst16 & 1) && (nbytes & 15) == 0) {                  // dst16 bit 0: 16-byte aligned destination rows; bit 1: streaming stores
+        const int cpr = nbytes >> 4;                        // 16-byte chunks per row (<= CW)
+        for (int px = ty; px < npx; px += NT / CW) {
             if (tx < cpr) {
                 const unsigned *l = reinterpret_cast<const unsigned *>(rt + px * PT + 16 * tx);
-                *reinterpret_cast<uint4 *>(dst + (size_t)orow(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx) = make_uint4(l[0], l[1], l[2], l[3]);
+                uint8_t *q = dst + (size_t)orow(x0 + px) * ds + (size_t)y0 * BPP + 16 * tx;
+                if (dst16 & 2) st_stream(q, make_uint4(l[0], l[1], l[2], l[3]));
+                else *reinterpret_cast<uint4 *>(q) = make_uint4(l[0], l[1], l[2], l[3]);
             }
         }
     } else {
-        for (int px = ty; px < npx; px += NT / 16)
-            lds_to_row(dst + (size_t)orow(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, 16, (y0 * BPP & 3) == 0);
+        for (int px = ty; px < npx; px += NT / CW)
+            lds_to_row(dst + (size_t)orow(x0 + px) * ds, y0 * BPP, nbytes, rt + px * PT, tx, CW, (y0 * BPP & 3) == 0);
     }
+}
+
+// a destination whose rows start on 128-byte lines (GMAT_SMOOTH_LINE_DST=0: treat none as such, A/B)
+static bool smooth121_line_dst(const uint8_t *dst, int ds)
+{
+    const char *e = GMAT_KNOB("GMAT_SMOOTH_LINE_DST");
+    return !(e && !atoi(e)) && ((((uintptr_t)dst | (uintptr_t)ds) & 127) == 0);
 }
 
 // the separable kernel's conditions: rows of whole dwords, dword-aligned pointers and pitches, at least 4 pixels a row
@@ -815,7 +825,7 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
     if (frames) {                                            // alignment tests below see the batch's least aligned frame
         src = frames->src[0]; dst = frames->dst[0];
         for (int i = 1; i < nframes; i++) {
-            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 127));
         }
     }
     const OpFrames fr = op_frames(src, dst, frames);
@@ -839,8 +849,17 @@ int launch_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, 
         const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
         const dim3 g2(8 * ((nt + 7) / 8), nframes);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-        if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8, true>), g2, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
-        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
+        if (smooth121_line_dst(dst, ds)) {                   // whole-line pieces, streaming stores: see launch_rotate_flip_smooth
+            if (bpp == 3) {
+                const int ntt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 127) / 128);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 16, true, 0, 128>), dim3(8 * ((ntt + 7) / 8), nframes), dim3(512), 0, stream,
+                                   src, ss, dst, ds, inW, inH, dst16 | 2, dir, fr);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16 | 2, dir, fr);
+            }
+        }
+        else if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8, true>), g2, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
+        else               hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16, true>), g2, dim3(256), 0, stream, src, ss, dst, ds, inW, inH, dst16, dir, fr);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -865,7 +884,7 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
     if (frames) {                                            // alignment tests below see the batch's least aligned frame
         src = frames->src[0]; dst = frames->dst[0];
         for (int i = 1; i < nframes; i++) {
-            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 127));
         }
     }
     const OpFrames fr = op_frames(src, dst, frames);
@@ -1156,7 +1175,7 @@ int launch_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, in
     if (frames) {                                            // alignment tests below see the batch's least aligned frame
         src = frames->src[0]; dst = frames->dst[0];
         for (int i = 1; i < nframes; i++) {
-            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 127));
         }
     }
     const OpFrames fr = op_frames(src, dst, frames);
@@ -1819,7 +1838,7 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
     if (frames) {                                            // alignment tests below see the batch's least aligned frame
         src = frames->src[0]; dst = frames->dst[0];
         for (int i = 1; i < nframes; i++) {
-            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 15));
+            src = (const uint8_t *)((uintptr_t)src | ((uintptr_t)frames->src[i] & 15)); dst = (uint8_t *)((uintptr_t)dst | ((uintptr_t)frames->dst[i] & 127));
         }
     }
     const OpFrames fr = op_frames(src, dst, frames);
@@ -1832,6 +1851,21 @@ int launch_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, 
         const int nt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 63) / 64);
         const dim3 g(8 * ((nt + 7) / 8), nframes), b(256);
         const int dst16 = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
+        // A destination whose rows start on 128-byte lines (a pool frame: gframes.cpp aligns them to 256) takes pieces that ARE whole
+        // lines — rgb24: tiles of 128 source rows = 384-byte pieces, rgba: 64 rows = 256 bytes — with streaming stores: 14.2 -> 13.2 us
+        // alone, 9.5 -> 8.6 us at 16 frames a launch (0.44 -> 0.47, 0.655 -> 0.725; profiles/r03zu_smooth_layout.txt).  A dense 4K frame's
+        // transposed pitch (6480 bytes) is not such a destination and keeps the form below, where both lose.
+        if (smooth121_line_dst(dst, ds)) {
+            if (bpp == 3) {
+                const int ntt = ((inW * bpp / 4 + td - 1) / td) * ((inH + 127) / 128);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 16, false, 0, 128>), dim3(8 * ((ntt + 7) / 8), nframes), dim3(512), 0, stream,
+                                   src, ss, dst, ds, inW, inH, dst16 | 2, 0, fr);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16 | 2, 0, fr);
+            }
+            GMAT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         // rgb24: 8 rows per wave (512 threads a tile) measured 2-3 % ahead of 16 (14.2 vs 14.5 us per 4K frame)
         if (bpp == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, true, 60, 8>), g, dim3(512), 0, stream, src, ss, dst, ds, inW, inH, dst16, 0, fr);
         else          hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, true, 62, 16>), g, b, 0, stream, src, ss, dst, ds, inW, inH, dst16, 0, fr);
