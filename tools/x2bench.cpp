@@ -176,7 +176,7 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
 // one frame per launch of a pixel filter on packed 4K frames: BASELINE configs[3] (rotate 90 + hflip + 3x3 smooth as one kernel)
 // and its parts.  GMAT_NO_SMOOTH121=1 selects the general 3x3 kernel instead of the separable one.
 static int g_op_frames = 1;
-static void run_op(const char *label, int op, int w, int h, int bpp, int launches)
+static void run_op(const char *label, int op, int w, int h, int bpp, int launches, int poolPitch = 0)
 {
     const size_t nb = (size_t)w * h * bpp;
     const int NSET = 16;
@@ -189,7 +189,7 @@ static void run_op(const char *label, int op, int w, int h, int bpp, int launche
     }
     // X2BENCH_OP_DST_ALIGN=n: the destination pitch of the transposing ops (h * bpp bytes: 6480 for a 4K rgb24 frame, not a multiple of a
     // 128-byte line) rounded up to a multiple of n — what a frame of a hardware pool has
-    const int tal = getenv("X2BENCH_OP_DST_ALIGN") ? std::max(1, atoi(getenv("X2BENCH_OP_DST_ALIGN"))) : 1;
+    const int tal = poolPitch ? 256 : getenv("X2BENCH_OP_DST_ALIGN") ? std::max(1, atoi(getenv("X2BENCH_OP_DST_ALIGN"))) : 1;      // (a pool frame: rows aligned to 256, gframes.cpp)
     const int tpitch = (h * bpp + tal - 1) / tal * tal;
     void *stream = nullptr; CK(gmat_stream_create(&stream));
     // X2BENCH_OP_STREAMS=n: launches round-robin over n streams (n - 1 extra ones joined to `stream` by events around the timed
@@ -329,17 +329,20 @@ int main(int argc, char **argv)
         {"any: up nv12 720p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
         {"any: up nv12 720p->1080p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
     };
-    struct Op { const char *label; int op, bpp; };
+    struct Op { const char *label; int op, bpp, pool; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
                       {"op: smooth3x3 4K gray", 1, 1}, {"op: transpose 4K rgb24", 2, 3}, {"op: hflip 4K rgb24", 3, 3},
                       {"op: transpose 4K gray (a luma plane)", 2, 1}, {"op: transpose 4K 2 bytes per sample", 2, 2},
                       {"op: median3x3 4K rgb24", 4, 3}, {"op: median3x3 4K gray", 4, 1},
                       {"op: rotate 17 deg bilinear 4K rgb24", 5, 3}, {"op: rotate 17 deg bilinear 4K gray", 5, 1},
                       {"op: rotate 17 deg cubic 4K rgb24", 6, 3}, {"op: rotate 17 deg nearest 4K rgb24", 7, 3},
-                      {"op: crop 4K rgb24 (less a 32 x 16 border)", 8, 3}, {"op: crop 4K gray (less a 32 x 16 border)", 8, 1}};
+                      {"op: crop 4K rgb24 (less a 32 x 16 border)", 8, 3}, {"op: crop 4K gray (less a 32 x 16 border)", 8, 1},
+                      // the transposing ops into a destination with a hardware pool's pitch (rows aligned to 256 bytes instead of the dense 6480 / 8640 / 4320)
+                      {"op: rotate+flip+smooth 4K rgb24, pool pitch", 0, 3, 1}, {"op: rotate+flip+smooth 4K rgba, pool pitch", 0, 4, 1},
+                      {"op: transpose 4K rgb24, pool pitch", 2, 3, 1}, {"op: transpose 4K 2 bytes per sample, pool pitch", 2, 2, 1}};
     g_op_frames = NF;
     for (const Op &o : ops)
-        if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4);
+        if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4, o.pool);
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
         if (strstr(k.label, "any:") && !strstr(only, "any")) continue;
