@@ -57,6 +57,9 @@ __device__ __forceinline__ unsigned p2_rep(unsigned v, unsigned sel) { return __
 __device__ __forceinline__ unsigned p2_shr6(unsigned v) { return (v >> 6) & 0x03FF03FFu; }        // both halves: v_pk_lshrrev_b16
 __device__ __forceinline__ int p2_odd(unsigned hi, unsigned lo) { return (int)((lo >> 16) | (hi << 16)); }   // v_alignbit_b32
 
+#ifndef P2_UVD_STREAM
+#define P2_UVD_STREAM false      // its 248-byte strips are not whole lines: plain stores 0.8 % ahead (3.208 -> 3.183 us per nv12 frame, three alternating rounds)
+#endif
 struct P2Plane {
     const uint8_t *src; uint8_t *dst;
     int ss, ds, srcW, srcH, dstW;              // strides in bytes, widths in samples (UV plane: in UV positions)
@@ -76,7 +79,7 @@ __device__ __forceinline__ unsigned p2_ld4(const uint8_t *p) { return *reinterpr
 
 // vertical stage of 4 values + store: D16 ? 8 bytes (4 x 16 bit) : 4 bytes.  Slot SLOT holds the newest row pair, the
 // oldest is SLOT + 1 (mod NP).
-template <bool D16, int NP, int SLOT>
+template <bool D16, int NP, int SLOT, bool STREAM = true>
 __device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][4], bool active, unsigned byteOff)
 {
     unsigned w[4];
@@ -93,6 +96,11 @@ __device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][
         }
     }
     if (!active) return;
+    if (!STREAM) {                                              // a walker whose strips are not whole lines (the shared-load UV walker: 248 bytes)
+        if (D16) *reinterpret_cast<uint2 *>(P.dst + byteOff) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+        else     *reinterpret_cast<unsigned *>(P.dst + byteOff) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+        return;
+    }
     if (D16) st_stream(P.dst + byteOff, make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16)));
     else     st_stream(P.dst + byteOff, (unsigned)(w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24)));
 }
@@ -478,7 +486,7 @@ __device__ __forceinline__ void p2_walk_uvd(const P2Plane &P, int X0, int y0, in
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
-            p2_vstore<D16, NP, SLOT>(P, hw, stores, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+            p2_vstore<D16, NP, SLOT, P2_UVD_STREAM>(P, hw, stores, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
         }
     };
     if (edgeWave) p2_rows<NP>(nIter, body, std::true_type());
