@@ -476,6 +476,19 @@ def other_configs(lib, env, stream, geo, frames=16):
         "kernel": "smooth121_kernel<3,transposed,60,8>", "avg_launch_us": round(ms * 1e3, 2),
         "Gpix/s": round(w * h / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg,
         "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # the same into a destination with a hardware pool's pitch (rows aligned to 256 bytes, gframes.cpp; the dense frame's 6480 is not a multiple of
+    # a 128-byte line): 128-row tiles whose pieces are whole lines, streaming stores
+    pitch = (h * 3 + 255) // 256 * 256
+    dstp = frame_set(frames, pitch * w, 0)
+
+    def run4p():
+        i = st["i"] = (st["i"] + 1) % frames
+        lib.gmat_rotate_flip_smooth(src[i], w * 3, dstp[i], pitch, w, h, 3, stream)
+    ms = time_single_kernel(lib, env, run4p, stream, 4 * frames)
+    res["configs[3] into a pool frame's pitch (%d bytes a row)" % pitch] = {
+        "kernel": "smooth121_kernel<3,transposed,60,16,128 rows>", "avg_launch_us": round(ms * 1e3, 2),
+        "Gpix/s": round(w * h / (ms * 1e-3) / 1e9, 1), "algorithmic_bytes": alg,
+        "achieved_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     lib.gmat_device_sync()
     mem.free()
     return res
