@@ -905,13 +905,18 @@ int launch_conv3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int 
         const char *est = GMAT_KNOB("GMAT_SMOOTH_STACKED");
         if (!(est && atoi(est))) {
             constexpr int NWH = 4;
-            const int nbx = (w * bpp / 4 + td - 1) / td, ntb = ((nbx + NWH - 1) / NWH) * ((h + 15) / 16);
-            const dim3 gh(8 * ((ntb + 7) / 8), nframes), bh(64 * NWH);
+            const int nbx = (w * bpp / 4 + td - 1) / td;
+            const dim3 bh(64 * NWH);
+            // 1- and 2-byte planes: 8 rows a wave — a 4K luma plane is 2 160 waves at 16 rows, a quarter of what the chip holds (one frame
+            // per launch 6.15 -> 5.73 us, 16 frames per launch unchanged)
+            const int rpw = bpp <= 2 ? 8 : 16;
+            const int ntb2 = ((nbx + NWH - 1) / NWH) * ((h + rpw - 1) / rpw);
+            const dim3 g2(8 * ((ntb2 + 7) / 8), nframes);
             switch (bpp) {
-            case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
-            case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
-            case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16, false, NWH>), gh, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            case 1:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<1, false, 62, 8, false, NWH>), g2, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            case 2:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<2, false, 62, 8, false, NWH>), g2, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            case 3:  hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<3, false, 60, 16, false, NWH>), g2, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(smooth121_kernel<4, false, 62, 16, false, NWH>), g2, bh, 0, stream, src, ss, dst, ds, w, h, 0, 0, fr); break;
             }
             GMAT_HIP_CHECK(hipGetLastError());
             return 0;
