@@ -599,7 +599,9 @@ int launch_scale_yuv4x1(const Yuv4x1Args &a0, hipStream_t stream, const Yuv2xFra
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
         const long rows = ((long)a.dstH * nstripsL + (long)a.chrDstH * nstripsC * nplC) * nframes;      // wave-rows (output)
-        seg = (int)std::min(45L, std::max(3L, (rows + 4095) / 4096));
+        // re-swept at the end of round 3 (32 frames a launch, rows 4 / 6 / 8 / 12 / 16 / 25 / 32 / 45: 4.20 / 3.86 / 3.83 / 4.07 / 3.88 / 4.11 / 4.51 / 5.28 us
+        // per 4K -> 540p nv12 frame): short segments, as everywhere since the bands walk up and down
+        seg = (int)std::min(8L, std::max(3L, (rows + 4095) / 4096));
     }
     a.segRows = seg;
     a.nsegL = (a.dstH + seg - 1) / seg;
