@@ -250,8 +250,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     const int X0 = ((lin - band * a.nsg) * 4 + wave) * 64;
     if (X0 >= a.dstW) return;
     const int up = a.updown & band & 1;
-    // balanced: nbands bands whose heights differ by at most one row (a last band of a few rows would still pay a whole lead-in)
-    const int y0 = a.balanced ? band * a.dstH / a.nbands : band * a.bandRows, y1 = a.balanced ? (band + 1) * a.dstH / a.nbands : min(y0 + a.bandRows, a.dstH);
+    const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
     const int ya = up ? a.dstH - y1 : y0, yb = up ? a.dstH - y0 : y1;            // walking coordinates
     const int f = blockIdx.y;
     // exact valid bytes of each plane (row bytes are multiples of 4 by the host rule): a dword past them reads as 0
@@ -423,8 +422,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     const int rows = job ? a.chrDstH : a.dstH, srcRows = job ? a.chrSrcH : a.srcH;
     const int up = a.updown & band & 1;
     const int bandRows = job ? a.bandRowsC : a.bandRows;
-    const int nb = job ? a.nbandsC : a.nbands;
-    const int y0 = a.balanced ? band * rows / nb : band * bandRows, y1 = a.balanced ? (band + 1) * rows / nb : min(y0 + bandRows, rows);
+    const int y0 = band * bandRows, y1 = min(y0 + bandRows, rows);
     const int ya = up ? rows - y1 : y0, yb = up ? rows - y0 : y1;
     const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
@@ -686,18 +684,15 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     // (an up-scale's bands are cheap in source rows and dear in open sums: twice the height — 1080p -> 1440p alone 17.0 -> 14.3-15.9 us)
     const bool upV = a.dstH > a.srcH;
     int rows = rowsEnv > 0 ? rowsEnv : upV ? (int)std::min(32L, std::max(8L, (wr + 3071) / 3072)) : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
-    // the rule's own heights are balanced over the frame (900 rows in bands of 32: 28 bands and a 4-row one -> 28 of 32 or 33); a height forced by
-    // GMAT_STRIP_ROWS is taken as it is (the tests walk every remainder)
-    a.balanced = rowsEnv <= 0;
     a.bandRows = rows;
-    a.nbands = a.balanced ? std::max(1, (int)((a.dstH + rows / 2) / rows)) : (a.dstH + rows - 1) / rows;
+    a.nbands = (a.dstH + rows - 1) / rows;
     a.nblkL = a.nbands * a.nsg;
     a.nblk = a.nblkL;
     if (a.yuvOut) {
         const int cbytes = a.nv12 ? 2 * a.chrDstW : a.chrDstW;
         a.nsgC = ((cbytes + 63) / 64 + 3) / 4;
         a.bandRowsC = std::max(2, rows / 2);
-        a.nbandsC = a.balanced ? std::max(1, (int)((a.chrDstH + a.bandRowsC / 2) / a.bandRowsC)) : (a.chrDstH + a.bandRowsC - 1) / a.bandRowsC;
+        a.nbandsC = (a.chrDstH + a.bandRowsC - 1) / a.bandRowsC;
         a.nblkC = a.nbandsC * a.nsgC;
         a.nblk = a.nblkL + (a.nv12 ? 1 : 2) * a.nblkC;
     }
