@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned d3_ld4(const uint8_t *p) { return *reinterpr
 __device__ __forceinline__ void d3_st4(uint8_t *base, unsigned off, unsigned v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base));      // s_nop 4: see g_st in k_scale_yuvg.hip (VALU-written scalar operand)
 #else
     *reinterpret_cast<unsigned *>(base + off) = v;
 #endif

@@ -54,7 +54,7 @@ __device__ __forceinline__ void e3_st8(uint8_t *base, unsigned off, unsigned lo,
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef unsigned e3_u32x2 __attribute__((ext_vector_type(2)));
     const e3_u32x2 v = {lo, hi};
-    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base));    // s_nop 4: see g_st in k_scale_yuvg.hip (VALU-written scalar operand)
 #else
     std::memcpy(base + off, &lo, 4); std::memcpy(base + off + 4, &hi, 4);
 #endif

@@ -54,7 +54,9 @@ struct GPlane {
         // gfx9's shared vmcnt as out of order and waits for vmcnt(0) at every use of a loaded register — which also drains the rows
         // requested three steps ahead.  Seen as loads only, its waits are counted ones; an unseen store in the queue makes a counted
         // wait stricter than needed, never laxer (loads return in order; k_scale_yuv3x1.hip).
-        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(d), "v"(lane), "s"(words), "s"(row) : "memory");
+        // s_nop 4: a scalar operand written by a VALU instruction (v_readfirstlane_b32) may be read by a memory instruction five wait states
+        // later at the earliest; the compiler keeps that distance for its own instructions and does not look into this string
+        asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, %3 offen" :: "v"(d), "v"(lane), "s"(words), "s"(row) : "memory");
     }
 #else
     // hipcc's host pass (never executed) and the CPU emulation of the test suite
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     const int X0 = ((lin - band * a.nsg) * 4 + wave) * 64;
     if (X0 >= a.dstW) return;
     const int up = a.updown & band & 1;
-    const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
+    // bandStep: 16.16 rows a band — bands whose heights differ by at most one row when the launcher balances them (no division here), else
+    // bandRows << 16
+    const int y0 = (int)(((unsigned)band * (unsigned)a.bandStep) >> 16), y1 = band + 1 >= a.nbands ? a.dstH : (int)(((unsigned)(band + 1) * (unsigned)a.bandStep) >> 16);
     const int ya = up ? a.dstH - y1 : y0, yb = up ? a.dstH - y0 : y1;            // walking coordinates
     const int f = blockIdx.y;
     // exact valid bytes of each plane (row bytes are multiples of 4 by the host rule): a dword past them reads as 0
@@ -422,7 +426,9 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     const int rows = job ? a.chrDstH : a.dstH, srcRows = job ? a.chrSrcH : a.srcH;
     const int up = a.updown & band & 1;
     const int bandRows = job ? a.bandRowsC : a.bandRows;
-    const int y0 = band * bandRows, y1 = min(y0 + bandRows, rows);
+    const unsigned bstep = job ? (unsigned)a.bandStepC : (unsigned)a.bandStep;
+    const int y0 = (int)(((unsigned)band * bstep) >> 16), y1 = band + 1 >= (job ? a.nbandsC : a.nbands) ? rows : (int)(((unsigned)(band + 1) * bstep) >> 16);
+    (void)bandRows;
     const int ya = up ? rows - y1 : y0, yb = up ? rows - y0 : y1;
     const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
@@ -684,15 +690,20 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     // (an up-scale's bands are cheap in source rows and dear in open sums: twice the height — 1080p -> 1440p alone 17.0 -> 14.3-15.9 us)
     const bool upV = a.dstH > a.srcH;
     int rows = rowsEnv > 0 ? rowsEnv : upV ? (int)std::min(32L, std::max(8L, (wr + 3071) / 3072)) : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
+    // a full launch of down-scaling bands (the rule at its cap): BALANCED bands — round(rows / 32) of them, heights differing by at most one row (900
+    // rows: 28 bands of 32 or 33 instead of 28 x 32 and a 4-row one that pays a whole lead-in); otherwise bands of exactly `rows` rows
+    const bool balanced = rowsEnv <= 0 && !upV && rows == 32 && a.dstH >= 64 && a.dstH < 32768;
     a.bandRows = rows;
-    a.nbands = (a.dstH + rows - 1) / rows;
+    a.nbands = balanced ? (a.dstH + rows / 2) / rows : (a.dstH + rows - 1) / rows;
+    a.bandStep = balanced ? (int)(((unsigned)a.dstH << 16) / (unsigned)a.nbands) : rows << 16;
     a.nblkL = a.nbands * a.nsg;
     a.nblk = a.nblkL;
     if (a.yuvOut) {
         const int cbytes = a.nv12 ? 2 * a.chrDstW : a.chrDstW;
         a.nsgC = ((cbytes + 63) / 64 + 3) / 4;
         a.bandRowsC = std::max(2, rows / 2);
-        a.nbandsC = (a.chrDstH + a.bandRowsC - 1) / a.bandRowsC;
+        a.nbandsC = balanced ? std::max(1, (a.chrDstH + a.bandRowsC / 2) / a.bandRowsC) : (a.chrDstH + a.bandRowsC - 1) / a.bandRowsC;
+        a.bandStepC = balanced ? (int)(((unsigned)a.chrDstH << 16) / (unsigned)a.nbandsC) : a.bandRowsC << 16;
         a.nblkC = a.nbandsC * a.nsgC;
         a.nblk = a.nblkL + (a.nv12 ? 1 : 2) * a.nblkC;
     }

@@ -320,7 +320,7 @@ struct YuvGArgs {
     const int32_t *prog[2], *qfirst[2], *qdone[2];            // RGB destination, or the luma job of a 4:2:0 destination
     const int32_t *progC[2], *qfirstC[2], *qdoneC[2];         // the chroma jobs of a 4:2:0 destination
     // filled by the launcher: rows per band, 4-strip groups per row, blocks (luma | chroma jobs of a 4:2:0 destination)
-    int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap, updown;
+    int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap, updown, bandStep, bandStepC;
     Yuv2RgbConsts y2r;
 };
 int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);

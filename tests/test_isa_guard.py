@@ -173,3 +173,18 @@ def test_streaming_stores_are_where_they_were_measured(disassembly):
     assert any(re.search(r"smooth121_kernelILi\dELb1E", f) and v[1] > 0 for f, v in stores.items())
     assert not any("scale_yuv2s" in f for f in loads), [f for f in loads if "scale_yuv2s" in f][:2]
     assert any("flip_direct_kernel" in f for f in loads)
+
+
+def test_inline_asm_memory_instructions_keep_their_distance_from_valu_written_scalars():
+    """A memory instruction may read a scalar register a VALU instruction (v_readfirstlane_b32) wrote five wait states later at the earliest; the
+    compiler keeps that distance between its own instructions and does not look into an inline-asm string.  The band walker's store had none:
+    dormant in the shipped code layout, a GPU fault (no message) as soon as two lines of its kernel's prologue changed (round 3, FINDINGS.md
+    R3-walker-bands).  Every inline-asm memory instruction with a scalar operand starts with `s_nop 4`."""
+    import glob
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "*.h")):
+        for m in re.finditer(r'asm\s+volatile\s*\(\s*"((?:[^"\\]|\\.)*)"([^;]*);', open(path).read()):
+            text, operands = m.group(1), m.group(2)
+            if re.search(r"\b(global|buffer|flat)_(load|store)", text) and '"s"(' in operands and not text.startswith("s_nop 4"):
+                bad.append((os.path.basename(path), text[:60]))
+    assert not bad, bad
