@@ -12,6 +12,7 @@
 #   pmc:<case>:<nf>:<ctrs>[:<ctrs>]   counter passes of ONE x2bench case (ctrs: comma separated list per pass)
 #   x2[:nf[:launches[:case]]]         tools/bin/x2bench table (default 32 20, every case)
 #   x2env:<VAR=val,...>:<nf>:<launches>:<case>   the same with environment knobs (A/B of a switch on one box)
+#   layout                the GPU suite against every library under tools/variants/ (differently compiled builds of all kernels)
 #   ops                   filter kernels, one 4K frame per launch
 #   fuzz[:n[:seed]]       the five differential fuzzers against the oracle on the GPU
 #   sh:<command>          anything else (quoted), output -> sh_<n>.txt
@@ -52,6 +53,14 @@ for STEP in "$@"; do
        tools/pmc_case.sh $TAG/pmc "$CASE" $NF "${P[@]}" | tee $OUT/pmc_$(echo $CASE | tr -c 'a-zA-Z0-9' '_').txt ;;
   x2) SFX=$(echo "${A[3]:-}" | tr -c 'a-zA-Z0-9\n' '_'); timeout 600 tools/bin/x2bench ${A[1]:-32} ${A[2]:-20} "${A[3]:-}" 2>&1 | tee $OUT/x2bench_${A[1]:-32}${SFX:+_$SFX}.txt ;;
   x2env) ( for kv in $(echo ${A[1]} | tr ',' ' '); do export $kv; done; echo "== ${A[1]}"; timeout 600 tools/bin/x2bench ${A[2]:-32} ${A[3]:-20} "${A[4]:-}" 2>&1 ) | tee -a $OUT/x2env.txt ;;
+  layout) # the GPU suite against differently compiled builds of every kernel (built beforehand in the build container:
+          #   tools/build_variant.sh o2 all -O2; tools/build_variant.sh os all -Os): layout-dependent faults (FINDINGS.md R3-walker-bands)
+          cp gmat_amd/lib/libgmat_hip.so /tmp/libgmat_hip_shipped.so
+          for v in $(ls tools/variants 2>/dev/null); do
+            cp tools/variants/$v/libgmat_hip.so gmat_amd/lib/libgmat_hip.so
+            echo "layout $v: $(timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider 2>&1 | tail -1)" | tee -a $OUT/layout.txt
+          done
+          cp /tmp/libgmat_hip_shipped.so gmat_amd/lib/libgmat_hip.so ;;
   ops) echo "== filter ops, one 4K frame per launch" | tee $OUT/ops.txt; timeout 200 tools/bin/x2bench 1 50 "op: " 2>&1 | tee -a $OUT/ops.txt ;;
   fuzz) N=${A[1]:-2000}; SEED=${A[2]:-301}
         for f in fuzz_strip fuzz_parity fuzz_yuvopts fuzz_transforms fuzz_filters; do
