@@ -1577,11 +1577,13 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         logf(LOG_ERROR, "gmat_sws_scale: one of the input parameters to sws_scale() is NULL");
         return GMAT_ERR(EINVAL);
     }
-    // swscale.c:897-924 checks; the GPU back-end only converts whole frames (swscale_cuda.c ignores slices)
-    if (srcSliceY != 0 || srcSliceH != c->srcH) {
-        logf(LOG_ERROR, "gmat_sws_scale: slice %d+%d is not the whole %d-row frame", srcSliceY, srcSliceH, c->srcH);
+    // the core's slice check (swscale.c:902-907), then — like ff_swscale_cuda, which never reads its slice arguments
+    // (swscale_cuda.c:273-479) — the WHOLE frame is converted whatever slice was named; src[] / dst[] are the frame's planes
+    if (srcSliceY < 0 || srcSliceH < 0 || srcSliceY + srcSliceH > c->srcH) {
+        logf(LOG_ERROR, "gmat_sws_scale: Slice parameters %d, %d are invalid", srcSliceY, srcSliceH);
         return GMAT_ERR(EINVAL);
     }
+    if (srcSliceH == 0) return 0;                    // a trailing empty slice (swscale.c:927-928)
     if (int r = check_device(c, "gmat_sws_scale"); r < 0) return r;
     c->lastLaunchFrames = 1;
     const bool planarYuv = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
@@ -1997,10 +1999,16 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
 }
 
 // ---- plain-pointer back-end entry points under the reference's names --------------------------
+static int stateless_convert(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h,
+                             int srcFormat, int dstFormat, void *stream);
+
+// libswscale/cuda/yuv2rgb_cuda.cu:862-907: NV12 -> RGB24 / BGR24 / RGBA / BGRA / RGBA64 / BGRA64 / RGBPF32LE, YUV420P -> the six packed ones
 int yuv2rgb_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h,
                  int srcFormat, int dstFormat, void *stream)
 {
-    if (!src || !dst || !is_yuv420(srcFormat)) return GMAT_ERR(EINVAL);
+    if (!src || !dst || !srcStride || !dstStride || !is_yuv420(srcFormat)) return GMAT_ERR(EINVAL);
+    if (is_rgb64(dstFormat))                       // the 19-bit lines of a context (yuv2rgba64_*_c): the context API's path
+        return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
     const Yuv2RgbConsts k = make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false);
     if (dstFormat == GMAT_PIX_FMT_RGBPF32LE)
         return launch_nv12_to_rgbpf32(yuv_src_of(srcFormat, src, srcStride), dst[0], dstStride[0], w, h, k,
@@ -2045,18 +2053,25 @@ static int stateless_convert(const uint8_t *src[], int srcStride[], uint8_t *dst
     return r < 0 ? r : 0;
 }
 
+// libswscale/cuda/yuv2rgb_cuda.cu:909-947: RGB24 / BGR24 / RGBA / BGRA / RGBA64 / BGRA64 -> NV12 / YUV420P
 int rgb2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h, int srcFormat,
                  int dstFormat, void *stream)
 {
-    if (!(srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) || !is_yuv420(dstFormat)) return GMAT_ERR(ENOSYS);
+    const bool srcOk = srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || srcFormat == GMAT_PIX_FMT_RGBA ||
+                       srcFormat == GMAT_PIX_FMT_BGRA || is_rgb64(srcFormat);
+    if (!srcOk || !is_yuv420(dstFormat)) return GMAT_ERR(ENOSYS);
     return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
 }
 
+// libswscale/cuda/yuv2yuv_cuda.cu:324-366: equal formats = a copy of every plane; NV12 / YUV420P -> the other layout, P010, P016,
+// YUV420P10, YUV420P16.  (The reference's copy moves `width` bytes of `height` rows of every plane whatever the format — short for
+// 16-bit samples, tall for chroma planes; here every plane is copied at its own size.)
 int yuv2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstStride[], int w, int h, int srcFormat,
                  int dstFormat, void *stream)
 {
-    if (!is_yuv420(srcFormat) || !(is_yuv420(dstFormat) || dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE))
-        return GMAT_ERR(ENOSYS);
+    const bool yuvAny = is_yuv420(srcFormat) || is_p01x(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV420P10LE || srcFormat == GMAT_PIX_FMT_YUV420P16LE;
+    const bool dstOk = is_yuv420(dstFormat) || is_p01x(dstFormat) || dstFormat == GMAT_PIX_FMT_YUV420P10LE || dstFormat == GMAT_PIX_FMT_YUV420P16LE;
+    if (!((srcFormat == dstFormat && yuvAny) || (is_yuv420(srcFormat) && dstOk))) return GMAT_ERR(ENOSYS);
     return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
 }
 

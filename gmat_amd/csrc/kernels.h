@@ -38,6 +38,18 @@ int launch_repack_rgb(const uint8_t *src, int srcStride, int srcBpp, uint8_t *ds
 int launch_rgbpf32_to_rgb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bgr,
                             hipStream_t stream);
 
+// ---- MeTrans-only kernels (k_metrans.hip) ---------------------------------------------------
+// the reference's own NV12 bicubic (Resize_bicubic.cu:83-159): float 4 x 4, a = -0.5, coordinates clamped to [2, n - 2]; one allocation
+// per side, chroma at base + pitch * height
+int launch_scale_nv12_bicubic_ref(const uint8_t *src, int ss, int srcW, int srcH, uint8_t *dst, int ds, int dstW, int dstH, hipStream_t stream);
+// nv12 -> three stacked planes (plane stride = ds * h) of 8-bit (f32 = 0) or float = u8 / 255 samples, R,G,B or (bgr) B,G,R
+int launch_nv12_to_planar(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, const Yuv2RgbConsts &k, int f32, int bgr, hipStream_t stream);
+// 32-bit packed pixels -> three stacked planes of their first three bytes, in byte order
+int launch_split_packed32(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int f32, hipStream_t stream);
+// BitDepth.cu:15-36: dst = src << 8 / dst = src >> 8 over n samples
+int launch_widen_shift8(const uint8_t *src, uint16_t *dst, long n, hipStream_t stream);
+int launch_narrow_shift8(const uint16_t *src, uint8_t *dst, long n, hipStream_t stream);
+
 // ---- generic scaler, packed-RGB output (k_scale.hip) ---------------------------------------
 // Device-resident copy of a FilterBank in the dword-packed form.
 struct DevFilter {

@@ -194,6 +194,12 @@ int orc_vsynth1(uint8_t *out, int w, int h, int nframes);
 /* deterministic synthetic planes: s = s*1664525 + 1013904223, byte = s>>24 */
 void orc_fill_lcg(uint8_t *p, long n, uint32_t seed);
 
+/* orc_metrans.c — MeTrans kernels with in-tree arithmetic (metrans/include/NvCodec/Resize_bicubic.cu:83-159, BitDepth.cu:15-29);
+ * parity unpinned: no reference vector exists, CUDA cannot run here (header of orc_metrans.c) */
+int  orc_mt_scale_nv12_bicubic(const uint8_t *src, int src_pitch, int src_w, int src_h, uint8_t *dst, int dst_pitch, int dst_w, int dst_h);
+void orc_mt_u8_to_u16(const uint8_t *src, uint16_t *dst, long n);
+void orc_mt_u16_to_u8(const uint16_t *src, uint8_t *dst, long n);
+
 /* Gaussian blur, OpenCV / CV-CUDA rule (parity unpinned: vf_smooth_nvcv.c:88-105,:290-294 only names the options) */
 int  orc_gauss_blur(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp,
                     int kw, int kh, double sigma_x, double sigma_y, int border);

@@ -52,6 +52,11 @@ def load_oracle(path):
     L.orc_sws_set_colorspace.argtypes = [C.c_void_p, C.c_int]
     L.orc_rgb_repack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_fill_lcg.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
+    L.orc_mt_scale_nv12_bicubic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_mt_u8_to_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    L.orc_mt_u8_to_u16.restype = None
+    L.orc_mt_u16_to_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    L.orc_mt_u16_to_u8.restype = None
     return Oracle(L)
 
 
