@@ -26,6 +26,23 @@ void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)))
         }                                                                                 \
     } while (0)
 
+// cuCtxPushCurrent / cuCtxPopCurrent as the reference brackets every filter and transfer call with (vf_scale_cuda.c:292-294,:553,
+// hwcontext_cuda.c:231-276): the object's device is current inside the call and the CALLER's device is current again after it — a
+// thread that works with several devices is not left on the last filter's one.
+struct DeviceScope {
+    int saved = -1;
+    int enter(int device)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur == device) return 0;
+        if (hipSetDevice(device) != hipSuccess) return GMAT_ERR(EIO);
+        if (saved < 0) saved = cur;
+        return 0;
+    }
+    ~DeviceScope() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 inline bool is_packed_rgb(int f)
 {
     return f == GMAT_PIX_FMT_RGB24 || f == GMAT_PIX_FMT_BGR24 || f == GMAT_PIX_FMT_RGBA || f == GMAT_PIX_FMT_BGRA ||

@@ -289,8 +289,8 @@ int gmat_filter_init(GmatFilterContext *f)
                 logf(LOG_ERROR, "rotate_hip: Interpolation '%s' not supported.", m.c_str());
                 return GMAT_ERR(EINVAL);
             }
-            // shift_x / shift_y (vf_rotate_nvcv.c:86-87): a translation of the rotated image in output pixels; the rotation
-            // itself stays about the centre (defect 11)
+            // shift_x / shift_y (vf_rotate_nvcv.c:85-86,276): the reference's meaning — rotation about the origin, the shift re-centres
+            // (gmat_rotate_shift_translation); unset, the rotation is about the centre (defect 11)
             f->rot_shift_x = opt_double(f, "shift_x", 0.0); f->rot_shift_y = opt_double(f, "shift_y", 0.0);
             if (!std::isfinite(f->rot_shift_x) || !std::isfinite(f->rot_shift_y) || std::fabs(f->rot_shift_x) > 32767 || std::fabs(f->rot_shift_y) > 32767)
                 return GMAT_ERR(EINVAL);
@@ -397,7 +397,8 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     gmat_hwframe_ctx_info(in_frames, &f->device, &f->in_fmt, &f->in_w, &f->in_h);
     // the link's device becomes current BEFORE anything is created for it (cuCtxPushCurrent in every reference filter,
     // e.g. vf_scale_cuda.c:292-294): the scaler's tables and the output pool must live where the frames do
-    GMAT_HIP_CHECK(hipSetDevice(f->device));
+    DeviceScope onDevice;                        // ... and the caller's device is current again on return (cuCtxPopCurrent)
+    if (int e = onDevice.enter(f->device); e < 0) return e;
     f->stream = (hipStream_t)stream;
     f->out_w = f->in_w; f->out_h = f->in_h; f->out_fmt = f->in_fmt;
     const bool nvcv_style = f->kind != K_SCALE && f->kind != K_FORMAT;
@@ -510,8 +511,9 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
     if (!in) return GMAT_ERR(EINVAL);
     int r = GMAT_ERR(EINVAL);
     GmatFrame *out = nullptr;
+    DeviceScope onDevice;                                                            // vf_scale_cuda.c:553 cuCtxPushCurrent ... :571 PopCurrent
     if (!f || !f->configured || !out_p) goto fail;
-    if (hipSetDevice(f->device) != hipSuccess) { r = GMAT_ERR(EIO); goto fail; }     // vf_scale_cuda.c:553 cuCtxPushCurrent
+    if (onDevice.enter(f->device) < 0) { r = GMAT_ERR(EIO); goto fail; }
     if (in->format != GMAT_PIX_FMT_HIP || in->sw_format != f->in_fmt || in->width != f->in_w || in->height != f->in_h) {
         logf(LOG_ERROR, "%s: input frame does not match the configured link (%dx%d fmt %d)", f->name.c_str(),
              in->width, in->height, in->sw_format);
@@ -558,8 +560,10 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
                     uint8_t fill[4] = {0, 0, 0, 255};
                     if (is_yuv8_src(f->in_fmt)) { fill[0] = i == 0 ? 16 : 128; fill[1] = 128; }
                     // chroma planes of a 4:2:0 frame move by half the shift (their samples are twice as far apart)
-                    r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream,
-                                      f->rot_shift_x / (1 << sub), f->rot_shift_y / (1 << sub));
+                    double tx = 0, ty = 0;
+                    if (f->rot_shift_x != 0 || f->rot_shift_y != 0)
+                        gmat_rotate_shift_translation(f->angle * M_PI / 180.0, f->rot_shift_x / (1 << sub), f->rot_shift_y / (1 << sub), pw, ph, pw, ph, &tx, &ty);
+                    r = launch_rotate(s, ss, d, ds, pw, ph, pw, ph, bpp, f->angle * M_PI / 180.0, f->rot_bilinear, fill, f->stream, tx, ty);
                     break;
                 }
                 }
@@ -607,7 +611,8 @@ static int run_pending(GmatFilterContext *f)
     if (!n) return 0;
     int r = 0;
     std::vector<GmatFrame *> outs;
-    if (hipSetDevice(f->device) != hipSuccess) {
+    DeviceScope onDevice;
+    if (onDevice.enter(f->device) < 0) {
         for (GmatFrame *&p : f->pending) gmat_frame_free(&p);
         f->pending.clear();
         return GMAT_ERR(EIO);
@@ -624,7 +629,7 @@ static int run_pending(GmatFilterContext *f)
     else if (f->kind == K_SMOOTH && !f->smooth_median && !f->gauss_general) top = GMAT_OP_SMOOTH3X3;
     if (top >= 0 && n > 1) {
         std::vector<GmatFrame *> outs(n, nullptr);
-        int r = hipSetDevice(f->device) == hipSuccess ? 0 : GMAT_ERR(EIO);
+        int r = 0;                                  // (the device is current: onDevice above)
         for (int i = 0; i < n && r >= 0; i++) {
             GmatFrame *in = f->pending[i];
             if (in->format != GMAT_PIX_FMT_HIP || in->sw_format != f->in_fmt || in->width != f->in_w || in->height != f->in_h) { r = GMAT_ERR(EINVAL); break; }
@@ -646,9 +651,12 @@ static int run_pending(GmatFilterContext *f)
                 if (top == OP_ROTATE_ANY) {             // background and shift per plane as in gmat_filter_frame
                     uint8_t fill[4] = {0, 0, 0, 255};
                     if (is_yuv8_src(f->in_fmt)) { fill[0] = k == 0 ? 16 : 128; fill[1] = 128; }
+                    double tx = 0, ty = 0;
+                    if (f->rot_shift_x != 0 || f->rot_shift_y != 0)
+                        gmat_rotate_shift_translation(f->angle * M_PI / 180.0, f->rot_shift_x / (1 << g[k].sub), f->rot_shift_y / (1 << g[k].sub),
+                                                      g[k].w, g[k].h, g[k].w, g[k].h, &tx, &ty);
                     r = rotate_batch(n, sp.data(), f->pending[0]->linesize[k], dp.data(), outs[0]->linesize[k], g[k].w, g[k].h, g[k].w, g[k].h,
-                                     g[k].bpp, f->angle * M_PI / 180.0, f->rot_bilinear, f->rot_shift_x / (1 << g[k].sub),
-                                     f->rot_shift_y / (1 << g[k].sub), fill, f->stream);
+                                     g[k].bpp, f->angle * M_PI / 180.0, f->rot_bilinear, tx, ty, fill, f->stream);
                     continue;
                 }
                 r = op_batch(top, n, sp.data(), f->pending[0]->linesize[k], dp.data(), outs[0]->linesize[k], g[k].w, g[k].h, g[k].bpp, targ, f->stream);
@@ -757,20 +765,17 @@ void gmat_filter_free(GmatFilterContext *f)
 // ---- direct launchers ------------------------------------------------------------------------------
 int gmat_transpose(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, int dir, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     return launch_transpose(src, ss, dst, ds, inW, inH, bpp, dir, (hipStream_t)stream);
 }
 
 int gmat_flip(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int code, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     if (code < -1 || code > 1) return GMAT_ERR(EINVAL);
     return launch_flip(src, ss, dst, ds, w, h, bpp, code != 0, code <= 0, (hipStream_t)stream);
 }
 
 int gmat_crop(const uint8_t *src, int ss, uint8_t *dst, int ds, int x, int y, int w, int h, int bpp, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     if (x < 0 || y < 0) return GMAT_ERR(EINVAL);
     return launch_copy2d(src + (size_t)y * ss + (size_t)x * bpp, ss, dst, ds, w * bpp, h, (hipStream_t)stream);
 }
@@ -778,27 +783,33 @@ int gmat_crop(const uint8_t *src, int ss, uint8_t *dst, int ds, int x, int y, in
 int gmat_smooth3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, const int matrix[9],
                    float rdiv, float bias, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     return launch_conv3x3(src, ss, dst, ds, w, h, bpp, matrix, rdiv, bias, (hipStream_t)stream);
 }
 
 int gmat_gauss_blur(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, double sigmaX,
                     double sigmaY, int border_type, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     return launch_gauss_blur(src, ss, dst, ds, w, h, bpp, kw, kh, sigmaX, sigmaY, border_type, (hipStream_t)stream);
 }
 
 int gmat_median3x3(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     return launch_median3x3(src, ss, dst, ds, w, h, bpp, (hipStream_t)stream);
+}
+
+void gmat_rotate_shift_translation(double angle_rad, double shift_x, double shift_y, int inW, int inH, int outW, int outH, double *tx, double *ty)
+{
+    // the walk's matrix (vf_rotate.c:538-548): src = C_in + M (dst - C_out - t), M = [c s; -s c]; src = M (dst - shift) needs
+    // t = shift - C_out + M^T C_in
+    const double c = std::cos(angle_rad), s = std::sin(angle_rad);
+    const double cix = (inW - 1) / 2.0, ciy = (inH - 1) / 2.0, cox = (outW - 1) / 2.0, coy = (outH - 1) / 2.0;
+    if (tx) *tx = shift_x - cox + (c * cix - s * ciy);
+    if (ty) *ty = shift_y - coy + (s * cix + c * ciy);
 }
 
 int gmat_rotate2(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
                  double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, void *stream)
 {
-    knobs_refresh();
     if (!src || !dst || interp < 0 || interp > 2) return GMAT_ERR(EINVAL);
     return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, interp, fill, (hipStream_t)stream, shift_x, shift_y);
 }
@@ -823,21 +834,18 @@ static int rotate_batch(int n, const uint8_t *const *src, int ss, uint8_t *const
 int gmat_rotate2_batch(int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
                        double angle_rad, int interp, double shift_x, double shift_y, const uint8_t *fill, void *stream)
 {
-    knobs_refresh();
     if (n < 0 || !src || !dst || interp < 0 || interp > 2) return GMAT_ERR(EINVAL);
     return rotate_batch(n, src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, interp, shift_x, shift_y, fill, (hipStream_t)stream);
 }
 
 int gmat_median(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int bpp, int kw, int kh, void *stream)
 {
-    knobs_refresh();
     return launch_median(src, ss, dst, ds, w, h, bpp, kw, kh, (hipStream_t)stream);
 }
 
 int gmat_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int outW, int outH, int bpp,
                 double angle_rad, int bilinear, const uint8_t *fill, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     if (!src || !dst) return GMAT_ERR(EINVAL);
     return launch_rotate(src, ss, dst, ds, inW, inH, outW, outH, bpp, angle_rad, bilinear, fill, (hipStream_t)stream);
 }
@@ -870,7 +878,6 @@ static int op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *c
 
 int gmat_op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *const *dst, int ds, int w, int h, int bpp, int arg, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     if (n < 0 || !src || !dst) return GMAT_ERR(EINVAL);
     if (op == GMAT_OP_TRANSPOSE && (arg < 0 || arg > 3)) return GMAT_ERR(EINVAL);
     if (op == GMAT_OP_FLIP && (arg < -1 || arg > 1)) return GMAT_ERR(EINVAL);
@@ -879,7 +886,6 @@ int gmat_op_batch(int op, int n, const uint8_t *const *src, int ss, uint8_t *con
 
 int gmat_rotate_flip_smooth(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int inH, int bpp, void *stream)
 {
-    knobs_refresh();                             // a stateless call is its own context
     return launch_rotate_flip_smooth(src, ss, dst, ds, inW, inH, bpp, (hipStream_t)stream);
 }
 

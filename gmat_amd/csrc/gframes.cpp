@@ -171,7 +171,8 @@ GmatHWFramesContext *gmat_hwframe_ctx_create(int device, int sw_format, int widt
         delete fc;
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) { delete fc; return nullptr; }
+    DeviceScope onDevice;
+    if (onDevice.enter(device) < 0) { delete fc; return nullptr; }
     for (int i = 0; i < initial_pool_size; i++) {
         uint8_t *p = nullptr;
         if (hipMalloc((void **)&p, fc->layout.total) != hipSuccess) break;
@@ -217,7 +218,8 @@ int gmat_hwframe_get_buffer(GmatHWFramesContext *fc, GmatFrame *f)
         fc->outstanding++;
     }
     if (!base) {
-        GMAT_HIP_CHECK(hipSetDevice(fc->device));
+        DeviceScope onDevice;
+        if (int e = onDevice.enter(fc->device); e < 0) return e;
         if (hipMalloc((void **)&base, fc->layout.total) != hipSuccess) {
             bool last;
             {

@@ -37,7 +37,8 @@ extern "C" {
 void gmat_pipeline_free(GmatPipeline *p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->device);
+    DeviceScope onDevice;
+    (void)onDevice.enter(p->device);
     for (auto &s : p->slots)
         if (s.busy && s.downloaded) (void)hipEventSynchronize(s.downloaded);
     for (auto &s : p->slots) {
@@ -54,7 +55,8 @@ void gmat_pipeline_free(GmatPipeline *p)
 GmatPipeline *gmat_pipeline_create(int device, int srcW, int srcH, int srcFormat, int dstW, int dstH, int dstFormat, int flags, int depth)
 {
     if (depth < 1 || depth > 64) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    DeviceScope onDevice;
+    if (onDevice.enter(device) < 0) return nullptr;
     GmatPipeline *p = new (std::nothrow) GmatPipeline();
     if (!p) return nullptr;
     p->device = device; p->depth = depth;
@@ -94,7 +96,8 @@ int gmat_pipeline_host_output(GmatPipeline *p, int64_t seq, GmatFrame *view) { r
 int64_t gmat_pipeline_submit(GmatPipeline *p)
 {
     if (!p) return GMAT_ERR(EINVAL);
-    GMAT_HIP_CHECK(hipSetDevice(p->device));
+    DeviceScope onDevice;
+    if (int e = onDevice.enter(p->device); e < 0) return e;
     GmatPipeline::Slot &s = p->slots[(size_t)(p->next % p->depth)];
     if (s.busy) GMAT_HIP_CHECK(hipEventSynchronize(s.downloaded));      // the slot's previous frame has left the device
     int r = gmat_hwframe_transfer_data(&s.din, &s.hin, p->up);

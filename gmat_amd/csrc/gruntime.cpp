@@ -67,6 +67,7 @@ extern "C" {
 
 void gmat_set_log_callback(gmat_log_fn fn) { g_log = fn; }
 const char *gmat_version(void) { return "gmat_hip 0.1 (gfx950)"; }
+void gmat_knobs_reload(void) { knobs_refresh(); }
 
 int gmat_device_count(void)
 {

@@ -1777,10 +1777,18 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
     p.c = (int)rot_int_sin(angle_int + 3294199 / 2);
     const int xi = -(outW - 1) * p.c / 2, yi = (outW - 1) * p.s / 2;      // :538-541 (C division truncates)
     const int xprime = -(outH - 1) * p.s / 2, yprime = -(outH - 1) * p.c / 2;
-    // shift_x / shift_y: the rotated image translated by that many output pixels, out(i, j) = rot(i - sx, j - sy) (the test suite's checker (orc_vf.c))
-    const long long Sx = llrint(shiftX * 65536.0), Sy = llrint(shiftY * 65536.0);
-    p.X0 = xprime + xi + FIXP * (inW - 1) / 2 - (int)((Sx * p.c + Sy * p.s) >> 16);
-    p.Y0 = yprime + yi + FIXP * (inH - 1) / 2 - (int)((Sy * p.c - Sx * p.s) >> 16);
+    // shift_x / shift_y: the rotated image translated by that many output pixels, out(i, j) = rot(i - sx, j - sy) (the test suite's checker (orc_vf.c)).
+    // The walk is 16.16 fixed point in 32 bits: frames whose coordinates leave it are refused, a translation that pushes the whole source
+    // out of the output is an all-background frame whatever its size (one canonical start that cannot wrap).
+    if (!std::isfinite(shiftX) || !std::isfinite(shiftY)) return GMAT_ERR(EINVAL);
+    if ((long long)outW + outH + 4 >= 16384 || inW >= 32767 || inH >= 32767) return GMAT_ERR(EINVAL);
+    const double lim = 1.0e6;                                              // px; far beyond any frame, keeps llrint and the products in range
+    const long long Sx = llrint(std::min(std::max(shiftX, -lim), lim) * 65536.0), Sy = llrint(std::min(std::max(shiftY, -lim), lim) * 65536.0);
+    const long long X0 = (long long)xprime + xi + FIXP * (inW - 1) / 2 - ((Sx * p.c + Sy * p.s) >> 16);
+    const long long Y0 = (long long)yprime + yi + FIXP * (inH - 1) / 2 - ((Sy * p.c - Sx * p.s) >> 16);
+    const long long reach = ((long long)inW + inH + outW + outH + 4) * FIXP;   // |start| beyond this: no output pixel maps into the source
+    if (X0 > reach || X0 < -reach || Y0 > reach || Y0 < -reach) { p.X0 = -(outW + outH + 2) * FIXP; p.Y0 = p.X0; }
+    else { p.X0 = (int)X0; p.Y0 = (int)Y0; }
     p.inW = inW; p.inH = inH; p.outW = outW; p.outH = outH;
     p.bilinear = bilinear; p.fillEnable = fill != nullptr; p.fill = 0;
     for (int k = 0; k < bpp && fill; k++) p.fill |= (unsigned)fill[k] << (8 * k);

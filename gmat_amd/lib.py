@@ -91,12 +91,15 @@ _SIGS = {
                               C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "gmat_rotate2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "gmat_rotate_shift_translation": (None, [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gmat_median": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_rotate_flip_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_op_batch": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmat_rotate2_batch": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "gmat_set_log_callback": (None, [C.c_void_p]),
+    "gmat_knobs_reload": (None, []),
     "gmat_device_count": (C.c_int, []),
     "gmat_set_device": (C.c_int, [C.c_int]),
     "gmat_device_numa_node": (C.c_int, [C.c_int]),

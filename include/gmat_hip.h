@@ -214,8 +214,9 @@ GMAT_API void gmat_host_frame_free(GmatFrame *frame);
  *    rotate_hip  <- vf_rotate_nvcv.c  options angle, interp, shift_x, shift_y (:79-88);
  *                   multiples of 90 degrees are exact transposes (vf_transpose.c semantics,
  *                   output w/h swapped); other angles run the CPU rotate filter's fixed-point
- *                   arithmetic (vf_rotate.c), interp linear|nearest, same-size output on black;
- *                   interp cubic|area and non-zero shift_x/shift_y (CV-CUDA only) -> ENOSYS
+ *                   arithmetic (vf_rotate.c) about the centre, interp linear|nearest|cubic|area, same-size output on black;
+ *                   a non-zero shift_x / shift_y has the reference's meaning (gmat_rotate_shift_translation below) and
+ *                   always takes the arbitrary-angle walk at the input's size, also for multiples of 90 degrees
  *    transpose_hip <- vf_transpose.c  option dir 0..3 (names :374-379)
  *    smooth_hip  <- vf_smooth_nvcv.c  options type, kw, kh, border_type, sigmaX, sigmaY (:82-105);
  *                   the default request (3x3 gaussian, no sigma, no border_type) = integer kernel 1 2 1 / 2 4 2 / 1 2 1,
@@ -294,6 +295,16 @@ GMAT_API int gmat_rotate(const uint8_t *src, int srcStride, uint8_t *dst, int ds
 GMAT_API int gmat_rotate2(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                           int inW, int inH, int outW, int outH, int bpp, double angle_rad, int interp,
                           double shift_x, double shift_y, const uint8_t *fill, void *stream);
+/* rotate_nvcv's shift_x / shift_y as THE REFERENCE means them (vf_rotate_nvcv.c:85-86,276: handed to cvcudaRotate unchanged, "to move the
+ * center at the same coord after rotation"): the rotation is about the ORIGIN and the shift is what re-centres, src = R(angle) * (dst - shift).
+ * This helper turns such a shift into gmat_rotate2's translation of the centre-rotated image for one plane:
+ *   t = shift - (C_out - R^T * C_in),   C = ((w - 1) / 2, (h - 1) / 2),
+ * so the re-centring shift of an angle gives t = 0 — exactly the picture of the shift-free call.  rotate_hip applies it whenever a shift
+ * is given; with both shifts 0 (unset) it keeps vf_rotate.c's rotation about the centre, where the reference's picture would mostly leave
+ * the frame (INTEGRATION.md section 3 lists this as an incompatibility).  CV-CUDA's source is not in the
+ * reference tree: the rule is its documented one in THIS library's (vf_rotate.c's, clockwise-positive) sense of rotation — unpinned. */
+GMAT_API void gmat_rotate_shift_translation(double angle_rad, double shift_x, double shift_y, int inW, int inH, int outW, int outH,
+                                            double *tx, double *ty);
 /* per-channel median of a kw x kh window (odd, <= 31), vf_median.c's rule at radius (kw - 1) / 2, radiusV (kh - 1) / 2 */
 GMAT_API int gmat_median(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp,
                          int kw, int kh, void *stream);
@@ -328,6 +339,10 @@ GMAT_API int  gmat_set_device(int device);
 GMAT_API int  gmat_device_numa_node(int device);
 GMAT_API int  gmat_bind_thread_to_device(int device);
 GMAT_API const char *gmat_version(void);
+/* tests and A/B measurements only: re-read the GMAT_* environment knobs now.  Contexts read them when they are
+ * created (gmat_sws_getContext, gmat_filter_init); the stateless launchers (gmat_transpose ... gmat_rotate2_batch) read them on their
+ * first call and after this — never per launch, and a launch never invalidates another thread's or context's cached knobs. */
+GMAT_API void gmat_knobs_reload(void);
 GMAT_API int  gmat_malloc(uint8_t **ptr, size_t bytes);   /* hipMalloc */
 GMAT_API int  gmat_free(uint8_t *ptr);
 GMAT_API int  gmat_memcpy_h2d(uint8_t *dst, const uint8_t *src, size_t bytes);

@@ -42,6 +42,8 @@ typedef struct GmatHipContext {
     int code;
     /* rotate / transpose */
     double angle, shift_x, shift_y;
+    int quarter;                /* exact clockwise quarter turns 0..3 when angle is a multiple of 90 and no shift is given, else -1: ONE
+                                   predicate for config_props (which swaps w / h for odd quarters) and for the launches */
     char *interp;
     int dir;
     /* smooth */
@@ -95,6 +97,10 @@ static av_cold int gh_init(AVFilterContext *ctx)
         if (strcmp(s->interp, "linear") && strcmp(s->interp, "nearest") && strcmp(s->interp, "cubic") && strcmp(s->interp, "area")) {
             av_log(ctx, AV_LOG_ERROR, "Interpolation '%s' not supported (linear, nearest, cubic, area)\n", s->interp);
             return AVERROR(EINVAL);
+        }
+        {
+            const double q = s->angle / 90.0;
+            s->quarter = fabs(q - rint(q)) < 1e-9 && s->shift_x == 0 && s->shift_y == 0 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
         }
     }
     /* every window is odd (the median's and the general gaussian's alike): say so at init, not at the first frame */
@@ -160,8 +166,7 @@ static int gh_config_props(AVFilterLink *outlink)
         ow = s->w; oh = s->h;
         break;
     case GH_ROTATE: {
-        const double q = s->angle / 90.0;
-        if (fabs(q - rint(q)) < 1e-9 && ((int)lrint(q) & 1)) { ow = inlink->h; oh = inlink->w; }   /* quarter turns swap */
+        if (s->quarter > 0 && (s->quarter & 1)) { ow = inlink->h; oh = inlink->w; }   /* quarter turns swap (never with a shift) */
         break;
     }
     case GH_TRANSPOSE:
@@ -239,8 +244,7 @@ static int gh_run_planes(GmatHipContext *s, const AVFrame *in, AVFrame *out)
 {
     static const int gauss3[9] = { 1, 2, 1, 2, 4, 2, 1, 2, 1 };
     const int general = s->kw != 3 || s->kh != 3 || s->sigma_x > 0 || s->sigma_y > 0 || s->border_type >= 0;
-    const double q = s->angle / 90.0;
-    const int quarter = fabs(q - rint(q)) < 1e-9 && s->shift_x == 0 && s->shift_y == 0 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
+    const int quarter = s->quarter;
     int ret = 0;
 
     for (int p = 0; p < 3 && in->data[p] && ret >= 0; p++) {
@@ -271,8 +275,11 @@ static int gh_run_planes(GmatHipContext *s, const AVFrame *in, AVFrame *out)
                 if (!(av_pix_fmt_desc_get(s->in_fmt)->flags & AV_PIX_FMT_FLAG_RGB)) { fill[0] = p ? 128 : 16; fill[1] = 128; }
                 /* interp: 0 nearest, 1 linear (= area, as cv::warpAffine), 2 cubic; the chroma planes of a 4:2:0 frame move by half the shift */
                 const int interp = !strcmp(s->interp, "nearest") ? 0 : !strcmp(s->interp, "cubic") ? 2 : 1;
+                double tx = 0, ty = 0;                          /* a shift has the reference's meaning: rotation about the origin */
+                if (s->shift_x != 0 || s->shift_y != 0)
+                    gmat_rotate_shift_translation(s->angle * M_PI / 180.0, s->shift_x / (1 << sub), s->shift_y / (1 << sub), pw, ph, pw, ph, &tx, &ty);
                 ret = gmat_rotate2(in->data[p], in->linesize[p], out->data[p], out->linesize[p], pw, ph, pw, ph, bpp,
-                                   s->angle * M_PI / 180.0, interp, s->shift_x / (1 << sub), s->shift_y / (1 << sub), fill, s->stream);
+                                   s->angle * M_PI / 180.0, interp, tx, ty, fill, s->stream);
             }
             break;
         case GH_SMOOTH:
@@ -324,8 +331,7 @@ static int gh_filter_frame(AVFilterLink *inlink, AVFrame *in)
 static int gh_batched_op(const GmatHipContext *s, int *arg)
 {
     const int general = s->kw != 3 || s->kh != 3 || s->sigma_x > 0 || s->sigma_y > 0 || s->border_type >= 0;
-    const double q = s->angle / 90.0;
-    const int quarter = fabs(q - rint(q)) < 1e-9 && s->shift_x == 0 && s->shift_y == 0 ? (((int)lrint(q) % 4) + 4) % 4 : -1;
+    const int quarter = s->quarter;
     *arg = 0;
     switch (s->kind) {
     case GH_FLIP:      *arg = s->code; return GMAT_OP_FLIP;
@@ -388,8 +394,11 @@ static int gh_flush_queue(AVFilterContext *ctx)
                     const int interp = !strcmp(s->interp, "nearest") ? 0 : !strcmp(s->interp, "cubic") ? 2 : 1;
                     uint8_t fill[4] = { 0, 0, 0, 255 };
                     if (!(av_pix_fmt_desc_get(s->in_fmt)->flags & AV_PIX_FMT_FLAG_RGB)) { fill[0] = p ? 128 : 16; fill[1] = 128; }
+                    double tx = 0, ty = 0;
+                    if (s->shift_x != 0 || s->shift_y != 0)
+                        gmat_rotate_shift_translation(s->angle * M_PI / 180.0, s->shift_x / (1 << sub), s->shift_y / (1 << sub), pw, ph, pw, ph, &tx, &ty);
                     if (gmat_rotate2_batch(n, ps, s->queue[0]->linesize[p], pd, outs[0]->linesize[p], pw, ph, pw, ph, bpp, s->angle * M_PI / 180.0,
-                                           interp, s->shift_x / (1 << sub), s->shift_y / (1 << sub), fill, s->stream) < 0)
+                                           interp, tx, ty, fill, s->stream) < 0)
                         ret = AVERROR_EXTERNAL;
                     continue;
                 }
@@ -467,8 +476,8 @@ static const AVOption flip_hip_options[] = {
 static const AVOption rotate_hip_options[] = {
     { "angle", "rotation angle in degrees", OFFSET(angle), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -360, 360, FLAGS },
     { "interp", "Interpolation algorithm (linear, nearest, cubic, area)", OFFSET(interp), AV_OPT_TYPE_STRING, { .str = "linear" }, 0, 0, FLAGS },
-    { "shift_x", "Shift of the rotated image in x, output pixels", OFFSET(shift_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
-    { "shift_y", "Shift of the rotated image in y, output pixels", OFFSET(shift_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
+    { "shift_x", "Shift in x to move the center at the same coord after rotation (rotation about the origin when given)", OFFSET(shift_x), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
+    { "shift_y", "Shift in y to move the center at the same coord after rotation (rotation about the origin when given)", OFFSET(shift_y), AV_OPT_TYPE_DOUBLE, { .dbl = 0.0 }, -32767, 32767, FLAGS },
     { "batch", "frames processed by one kernel launch (activate-based queue)", OFFSET(batch), AV_OPT_TYPE_INT, { .i64 = 1 }, 1, GH_MAX_BATCH, FLAGS },
     { NULL }
 };

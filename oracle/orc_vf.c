@@ -281,7 +281,10 @@ void orc_rotate2(const uint8_t *src, int src_stride, uint8_t *dst, int dst_strid
 {
     int s, c, i, j, k;
     int xi, yi, xprime, yprime;
-    const int64_t Sx = llrint(shift_x * 65536.0), Sy = llrint(shift_y * 65536.0);
+    /* (a translation of more than a million pixels is the same all-background frame as one of a million) */
+    const double lim = 1.0e6;
+    const int64_t Sx = llrint(fmin(fmax(shift_x, -lim), lim) * 65536.0), Sy = llrint(fmin(fmax(shift_y, -lim), lim) * 65536.0);
+    int64_t tx, ty, reach;
     orc_rotate_sincos(angle_rad, &s, &c);
     xi = -(outw - 1) * c / 2; yi = (outw - 1) * s / 2;
     xprime = -(outh - 1) * s / 2;
@@ -290,9 +293,16 @@ void orc_rotate2(const uint8_t *src, int src_stride, uint8_t *dst, int dst_strid
         for (j = 0; j < outh; j++)
             for (i = 0; i < outw; i++)
                 for (k = 0; k < bpp; k++) dst[(long)j * dst_stride + i * bpp + k] = fill[k];
+    /* a start beyond the reach of every output pixel: nothing maps into the source (and the 32-bit walk below would wrap) */
+    tx = (Sx * c + Sy * s) >> 16; ty = (Sy * c - Sx * s) >> 16;
+    reach = ((int64_t)inw + inh + outw + outh + 4) * ROT_FIXP;
+    {
+        const int64_t X0 = (int64_t)xprime + xi + ROT_FIXP * (inw - 1) / 2 - tx, Y0 = (int64_t)yprime + yi + ROT_FIXP * (inh - 1) / 2 - ty;
+        if (X0 > reach || X0 < -reach || Y0 > reach || Y0 < -reach) return;
+    }
     for (j = 0; j < outh; j++) {
-        int x = xprime + xi + ROT_FIXP * (inw - 1) / 2 - (int)((Sx * c + Sy * s) >> 16);
-        int y = yprime + yi + ROT_FIXP * (inh - 1) / 2 - (int)((Sy * c - Sx * s) >> 16);
+        int x = xprime + xi + ROT_FIXP * (inw - 1) / 2 - (int)tx;
+        int y = yprime + yi + ROT_FIXP * (inh - 1) / 2 - (int)ty;
         for (i = 0; i < outw; i++) {
             int x1 = x >> 16, y1 = y >> 16;
             if (x1 >= -1 && x1 <= inw && y1 >= -1 && y1 <= inh) {

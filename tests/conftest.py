@@ -58,6 +58,15 @@ def dev(request):
     return harness.Dev(load(path), "emu")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_knobs(request):
+    """a test that changed a GMAT_* knob leaves the library's cached value behind (the environment itself is restored by monkeypatch):
+    every test that has a device starts from the environment as it is now"""
+    if "dev" in request.fixturenames:
+        request.getfixturevalue("dev").lib.gmat_knobs_reload()
+    yield
+
+
 @pytest.fixture(params=["strip", "tiled"])
 def kern(request):
     """Which 2:1 kernel a 4:2:0 -> packed RGB context gets: the strip-walking one (default) or, with

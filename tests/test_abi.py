@@ -166,3 +166,48 @@ def test_filter_follows_its_links_device_not_the_current_one():
         for p in ps:
             p.free()
     lib.gmat_hwframe_ctx_free(fc0); lib.gmat_hwframe_ctx_free(fc1)
+
+
+def test_filter_and_pool_calls_restore_the_callers_device():
+    """the reference pushes AND pops the frames' context around every call (vf_scale_cuda.c:292-294,:553-571,
+    hwcontext_cuda.c:231-276).  A thread on device 0 that runs a filter (and takes pool frames) of device 1 is still on device 0
+    afterwards: its own bare context of device 0 keeps working with no gmat_set_device in between."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness
+    from gmat_amd.lib import load, PIX_FMT, GmatFrame, planes, ints
+    emu = os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated build missing")
+    lib = load(emu)
+    dev = harness.Dev(lib, "emu")
+    w, h = 64, 16
+    assert lib.gmat_set_device(0) == 0
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT["nv12"], w // 2, h // 2, PIX_FMT["rgb24"], 4, None)
+    src = dev.planes_like("nv12", w, h, 16)
+    dst = dev.planes_like("rgb24", w // 2, h // 2, 16)
+    args = (planes([p.ptr for p in src]), ints([p.stride for p in src]), 0, h, planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+    fc1 = lib.gmat_hwframe_ctx_create(1, PIX_FMT["nv12"], w, h, 0)          # empty pool: get_buffer allocates on device 1
+    assert fc1 and lib.gmat_sws_scale(c, *args) == h // 2                    # still on device 0 after the pool was created
+    for batch in (1, 2):
+        f = lib.gmat_filter_alloc(b"scale_hip")
+        for k, v in (("w", "iw/2"), ("h", "ih/2"), ("format", "rgb24"), ("batch", str(batch))):
+            assert lib.gmat_filter_set_option(f, k.encode(), v.encode()) == 0
+        assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc1, None) == 0
+        assert lib.gmat_sws_scale(c, *args) == h // 2
+        for _ in range(2):
+            fr = lib.gmat_frame_alloc()
+            assert lib.gmat_hwframe_get_buffer(fc1, fr) == 0
+            assert lib.gmat_sws_scale(c, *args) == h // 2
+            assert lib.gmat_filter_send_frame(f, fr) == 0
+            assert lib.gmat_sws_scale(c, *args) == h // 2
+            out = C.POINTER(GmatFrame)()
+            while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+                lib.gmat_frame_free(C.byref(out))
+        assert lib.gmat_filter_flush(f) >= 0
+        lib.gmat_filter_free(f)
+        assert lib.gmat_sws_scale(c, *args) == h // 2
+    lib.gmat_sws_freeContext(c)
+    lib.gmat_hwframe_ctx_free(fc1)
+    for p in src + dst:
+        p.free()

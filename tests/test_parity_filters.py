@@ -26,6 +26,7 @@ def test_transpose(dev, orc, monkeypatch, w, h, bpp, dir, tile):
         if bpp > 2:
             pytest.skip("only 1- and 2-byte planes have two tile sizes")
         monkeypatch.setenv("GMAT_TRANSPOSE_TILE", str(tile))
+    dev.lib.gmat_knobs_reload()                              # the stateless launchers read the environment on request, not per call
     src = orc.lcg((h, w * bpp), 5)
     want = _orc_out(w, h * bpp)
     orc.L.orc_transpose(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp, dir)
@@ -62,12 +63,13 @@ def test_flip(dev, orc, w, h, bpp, code):
 
 
 @pytest.fixture(params=["separable", "general"])
-def smooth_kern(request):
+def smooth_kern(request, dev):
     """the 1 2 1 / 2 4 2 / 1 2 1 matrix on dword-aligned frames takes smooth121_kernel; GMAT_NO_SMOOTH121 keeps the general
     conv3x3_kernel (the path of every other matrix and of unaligned frames) so both are compared with the oracle"""
     old = os.environ.pop("GMAT_NO_SMOOTH121", None)
     if request.param == "general":
         os.environ["GMAT_NO_SMOOTH121"] = "1"
+    dev.lib.gmat_knobs_reload()
     yield request.param
     os.environ.pop("GMAT_NO_SMOOTH121", None)
     if old is not None:
@@ -508,6 +510,7 @@ def test_median3x3(dev, orc, monkeypatch, w, h, bpp, kernel):
         monkeypatch.setenv("GMAT_NO_MEDIAN_STRIP", "1")
     else:
         monkeypatch.delenv("GMAT_NO_MEDIAN_STRIP", raising=False)
+    dev.lib.gmat_knobs_reload()
     src = orc.lcg((h, w * bpp), 111 + bpp)
     want = np.zeros_like(src)
     orc.L.orc_median3x3(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, bpp)
@@ -652,6 +655,7 @@ def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp)
     monkeypatch.setenv("GMAT_ROTATE_LDS", lds[0])
     if lds == "1w2":
         monkeypatch.setenv("GMAT_ROTATE_WAVES", "2")
+    dev.lib.gmat_knobs_reload()
     fill = (C.c_uint8 * 4)(1, 2, 3, 4)
     for (w, h, bpp, deg, sx, sy) in [(113, 179, 4, 143.7, 0.0, 0.0), (283, 167, 2, 17.0, 0.0, 0.0), (258, 175, 1, -61.3, 0.0, 0.0),
                                      (230, 130, 3, 100.9, 0.0, 0.0), (195, 69, 3, 271.25, 0.0, 0.0), (97, 65, 3, 45.0, 40.5, -20.25),
@@ -675,6 +679,7 @@ def test_rotate_frames_one_column_or_row_thick(dev, orc, monkeypatch, lds, inter
     min(1, W - 1) — pairs pixel 0 with itself (a GPU fuzz find of round 3: the LDS form's zero-weight rule for the last column only looked
     at the upper clamp; fuzz_transforms seed 913 case 373: 1 x 24, 2 bytes per pixel)"""
     monkeypatch.setenv("GMAT_ROTATE_LDS", lds)
+    dev.lib.gmat_knobs_reload()
     fill = (C.c_uint8 * 4)(200, 100, 50, 25)
     for (w, h, bpp, deg) in [(1, 24, 2, 77.3), (1, 24, 2, -160.0), (40, 1, 3, 12.5), (1, 1, 4, 33.0), (1, 70, 1, 5.0), (2, 33, 3, 91.5), (57, 2, 4, -3.0)]:
         src = orc.lcg((h, w * bpp), 90 + bpp)
@@ -688,15 +693,45 @@ def test_rotate_frames_one_column_or_row_thick(dev, orc, monkeypatch, lds, inter
         d.free(); o.free()
 
 
+def _shift_translation(angle_deg, sx, sy, w, h):
+    """rotate_nvcv's shift as the reference means it — rotation about the ORIGIN, src = M (dst - shift), the shift re-centres
+    (vf_rotate_nvcv.c:85-86,276) — as gmat_rotate2's translation of the centre-rotated image: t = shift - C + M^T C with the walk's
+    M = [c s; -s c] (vf_rotate.c:538-548) and C = ((w - 1) / 2, (h - 1) / 2).  Restated here independently of the library's helper."""
+    a = math.radians(angle_deg)
+    c, s = math.cos(a), math.sin(a)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    return sx - cx + (c * cx - s * cy), sy - cy + (s * cx + c * cy)
+
+
 def test_rotate_filter_honours_interp_and_shift(dev, orc):
-    """through the filter: rotate_hip angle=17:interp=cubic:shift_x=6:shift_y=-2.5 on rgb24, and on nv12 (chroma planes move by half)"""
+    """through the filter: rotate_hip angle=17:interp=cubic:shift_x=..:shift_y=.. on rgb24, and on nv12 (the chroma planes take half
+    the shift on their own grid).  A given shift means what the reference's option means: rotation about the origin."""
     w, h = 96, 40
     src = orc.lcg((h, w * 3), 77)
-    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 17, "interp": "cubic", "shift_x": 6, "shift_y": -2.5}, src, w, h)
-    want = np.zeros_like(src)
     fill = (C.c_uint8 * 4)(0, 0, 0, 255)
-    orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(17), 2, 6.0, -2.5, fill)
+    # the shift that re-centres a 17 degree turn, moved by (6, -2.5): the centre-rotated picture translated by (6, -2.5)
+    rcx, rcy = _shift_translation(17, 0, 0, w, h)
+    sx, sy = 6 - rcx, -2.5 - rcy
+    res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 17, "interp": "cubic", "shift_x": repr(sx), "shift_y": repr(sy)}, src, w, h)
+    tx, ty = _shift_translation(17, sx, sy, w, h)
+    assert abs(tx - 6) < 1e-9 and abs(ty + 2.5) < 1e-9
+    want = np.zeros_like(src)
+    orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(17), 2, tx, ty, fill)
     assert (ow, oh) == (w, h) and (res == want).all()
+    # an arbitrary shift: the reference's rule, rotation about the origin
+    res, _, _ = _run_filter(dev, "rotate_hip", {"angle": 17, "interp": "linear", "shift_x": 11, "shift_y": -4}, src, w, h)
+    tx, ty = _shift_translation(17, 11, -4, w, h)
+    want = np.zeros_like(src)
+    orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(17), 1, tx, ty, fill)
+    assert (res == want).all()
+    # ... known answer of that rule: dst = shift is the source's ORIGIN, so the output pixel at (11, 36 - 4 ... ) — use a visible one:
+    res, _, _ = _run_filter(dev, "rotate_hip", {"angle": 17, "interp": "nearest", "shift_x": 20, "shift_y": 9}, src, w, h)
+    assert (res[9, 3 * 20:3 * 21] == src[0, 0:3]).all()
+    # the re-centring shift itself gives EXACTLY the shift-free picture (what the option is documented for)
+    res0, _, _ = _run_filter(dev, "rotate_hip", {"angle": 33, "interp": "linear"}, src, w, h)
+    rx, ry = _shift_translation(33, 0, 0, w, h)
+    res1, _, _ = _run_filter(dev, "rotate_hip", {"angle": 33, "interp": "linear", "shift_x": repr(-rx), "shift_y": repr(-ry)}, src, w, h)
+    assert (res0 == res1).all()
     # a shift with no rotation is a translation: pixels move right / down by whole amounts, the uncovered part is the background
     res, _, _ = _run_filter(dev, "rotate_hip", {"angle": 0, "interp": "nearest", "shift_x": 5, "shift_y": 3}, src, w, h)
     # (vf_rotate.c's validity window reaches one sample past the frame, clamped: the row / column just before the image repeats its edge)
@@ -707,9 +742,45 @@ def test_rotate_filter_honours_interp_and_shift(dev, orc):
         pw, ph = pl.shape[1] // bpp, pl.shape[0]
         want = np.zeros_like(pl)
         fill = (C.c_uint8 * 4)(16 if i == 0 else 128, 128, 0, 0)
-        orc.L.orc_rotate2(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, pw, ph, bpp, math.radians(33), 1,
-                          8.0 / (1 << sub), 4.0 / (1 << sub), fill)
+        tx, ty = _shift_translation(33, 8.0 / (1 << sub), 4.0 / (1 << sub), pw, ph)
+        orc.L.orc_rotate2(pl.ctypes.data, pl.strides[0], want.ctypes.data, want.strides[0], pw, ph, pw, ph, bpp, math.radians(33), 1, tx, ty, fill)
         assert (res[i] == want).all()
+
+
+def test_rotate_filter_quarter_turn_with_a_shift_keeps_the_input_size(dev, orc):
+    """ONE predicate decides both the output size and the kernel.  A quarter turn swaps width and height
+    only without a shift; with one the arbitrary-angle walk runs at the input's size — on a portrait AND a landscape frame."""
+    for w, h in ((40, 96), (96, 40)):
+        src = orc.lcg((h, w * 3), 79)
+        res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 90}, src, w, h)
+        assert (ow, oh) == (h, w)
+        res, ow, oh = _run_filter(dev, "rotate_hip", {"angle": 90, "interp": "nearest", "shift_x": 1, "shift_y": 0}, src, w, h)
+        assert (ow, oh) == (w, h) and res.shape == src.shape
+        tx, ty = _shift_translation(90, 1, 0, w, h)
+        want = np.zeros_like(src)
+        fill = (C.c_uint8 * 4)(0, 0, 0, 255)
+        orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(90), 0, tx, ty, fill)
+        assert (res == want).all()
+
+
+def test_rotate_shift_out_of_every_range(dev, orc):
+    """a translation that pushes the whole source out of the output is an all-background frame, however large
+    (the 32-bit walk must not wrap); a non-finite one is refused"""
+    w, h = 64, 48
+    src = orc.lcg((h, w * 3), 80)
+    d = dev.upload_planes([src], 64)[0]
+    o = dev.planes_like("rgb24", w, h, 64)[0]
+    fill = (C.c_uint8 * 4)(7, 8, 9, 0)
+    for sx, sy in ((30000.0, 30000.0), (-1e9, 5.0), (1e300, -1e300), (40000.0, 0.0)):
+        assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, 3, math.radians(45), 1, sx, sy, fill, None) == 0
+        got = o.download().reshape(h, w, 3)
+        assert (got == np.array([7, 8, 9], np.uint8)).all(), (sx, sy)
+        want = np.zeros_like(src)
+        orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, 3, math.radians(45), 1, sx, sy, fill)
+        assert (want.reshape(h, w, 3) == np.array([7, 8, 9], np.uint8)).all()
+    for bad in (float("nan"), float("inf")):
+        assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, 3, 0.3, 1, bad, 0.0, fill, None) < 0
+    d.free(); o.free()
 
 
 @pytest.mark.parametrize("bpp", [1, 3, 4])
