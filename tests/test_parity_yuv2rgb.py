@@ -169,9 +169,10 @@ def test_error_behaviour(dev):
     assert lib.gmat_sws_scale(c, None, None, 0, 16, None, None) < 0                # NULL parameters
     src = dev.planes_like("nv12", 16, 16)
     dst = dev.planes_like("rgb24", 16, 16)
-    r = lib.gmat_sws_scale(c, planes([p.ptr for p in src]), ints([p.stride for p in src]), 4, 8,
+    r = lib.gmat_sws_scale(c, planes([p.ptr for p in src]), ints([p.stride for p in src]), 4, 16,
                            planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
-    assert r < 0                                                                    # partial slices rejected
+    assert r < 0                                                                    # a slice beyond the frame (swscale.c:902-907);
+    # one inside it converts the whole frame like ff_swscale_cuda: tests/test_reference_entry_points.py
     lib.gmat_sws_freeContext(c)
 
 
