@@ -1120,7 +1120,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     const Yuv3x1Args da = use3x1 ? make_yuv3x1_args(c, ya0) : Yuv3x1Args();
     const Yuv3x2Args ea = use3x2 ? make_yuv3x2_args(c, ya0) : Yuv3x2Args();
     const Yuv4x1Args qa = use4x1 ? make_yuv4x1_args(c, ya0) : Yuv4x1Args();
-    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : use4x1 ? "scale_yuv4x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
+    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(sa, std::min(kYuv2xMaxFrames, n)) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : use4x1 ? "scale_yuv4x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -1824,8 +1824,9 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
                 Yuv2xFrames one;
                 std::memset(&one, 0, sizeof(one));
                 one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
-                c->lastKernel = c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : "scale_yuv2s_kernel";
-                r = launch_scale_yuv2s(make_yuv2s_args(c, ya), c->stream, &one, 1);
+                const Yuv2sArgs sa1 = make_yuv2s_args(c, ya);
+                c->lastKernel = c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(sa1, 1) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel";
+                r = launch_scale_yuv2s(sa1, c->stream, &one, 1);
                 break;
             }
             if (yuv2p444_eligible(c, ya)) {

@@ -487,6 +487,249 @@ __global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ONE FRAME PER LAUNCH (round 4): the block-cooperative form.  What sws_scale() / filter_frame() issue is one frame, and a launch of
+// one 4K -> 1080p frame is 2880 of the walker's waves for 6144 wave slots, each a CHAIN of 7 dependent memory round trips (one
+// prefetched row pair per iteration) with 3 warm-up row pairs for its 3 output rows — the launch lasts as long as that chain, 5.2 us
+// of a 6.8 us call (profiles/r04a_x2bench_1frame_baseline.txt), while the same frame inside a 32-frame launch costs 3.6 us.  Here a
+// block of four waves owns ONE strip of 256 output columns and 4 * RW output rows:
+//   * every wave issues ALL its loads at once — the RW + 1 row pairs it filters horizontally (pairs w, w + 4, ...: the 4 RW + 3 pairs of the
+//     band dealt round) and the RW chroma rows of its own output rows — so a block pays ONE memory round trip, not 4 RW + 3;
+//   * the horizontally filtered pairs (int16 pairs, 16 bytes a lane) go through LDS (1 KB a pair), one barrier, and every wave
+//     makes its RW output rows from the RW + 3 pairs they touch: the 3 warm-up pairs are filtered once per 4 RW rows, not once per 3;
+//   * the colour tables are built while the loads are in flight and share the barrier.
+// Same arithmetic, operation by operation, as scale_yuv2s_kernel (the walker keeps every launch of more than a few frames: its
+// register window moves nothing through LDS).
+template <bool NV12, int DST, int RW>
+__global__ __launch_bounds__(256) void scale_yuv2s_blk_kernel(Yuv2sArgs a, Yuv2xFrames fr)
+{
+    constexpr bool BGR = (DST & 1) != 0;
+    constexpr int BPP = DST >= 2 ? 4 : 3;
+    constexpr int R = 4 * RW, NPAIR = R + 3, PW = RW + 1;       // rows a block, row pairs it filters, pairs a wave
+    __shared__ int2 lutV[S2_LUT_N], lutU[S2_LUT_N];
+    __shared__ uint4 hwS[NPAIR][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nstrips = a.nsg;                                  // (this launcher: strips a row, not groups of four)
+    const int nblk = a.nseg * nstrips;
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= nblk) return;                                    // block-uniform
+    const int seg = lin / nstrips;
+    const int X0 = (lin - seg * nstrips) * S2_STRIP;
+    const int y0 = seg * R;
+
+    const int f = blockIdx.y;
+    const S2Plane bY(fr.y[f]), bU(fr.u[f]), bV(NV12 ? fr.u[f] : fr.v[f]), bD(fr.dst[f]);
+
+    // ---- per-lane constants: as in scale_yuv2s_kernel -------------------------------------------------------------------
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.dstW;
+    const int xc = active ? xo : a.dstW - 4;
+    const int wantL = 2 * xc - 4;
+    const int offL = min(max(wantL, 0), a.srcW - 16);
+    const int shL = wantL - offL;
+    int offA, offB, shA, shB;
+    if (NV12) {
+        offA = max(2 * xc - 8, 0);               shA = 2 * xc - 8 - offA;
+        offB = min(2 * xc + 8, 2 * a.chrSrcW - 8); shB = 2 * xc + 8 - offB;
+    } else {
+        offA = min(max(xc - 4, 0), a.chrSrcW - 12); shA = xc - 4 - offA;
+        offB = 0; shB = 0;
+    }
+    const unsigned dstOff = (unsigned)xo * BPP;
+    const bool edgeLL = shL < 0, edgeLR = shL > 0, edgeAL = shA < 0, edgeAR = shA > 0, edgeBR = shB > 0;
+    const unsigned uoffL = (unsigned)offL, uoffA = (unsigned)offA, uoffB = (unsigned)offB;
+
+    // ---- every load of this wave, back to back ------------------------------------------------------------------------------
+    uint4 la[PW], lb[PW], ca[RW], cb[RW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int m = y0 - 1 + wave + 4 * i;                    // pair m = rows 2m - 1, 2m (wave 3's last one lies past the band: unused)
+        const int ra = min(max(2 * m - 1, 0), a.srcH - 1), rb = min(max(2 * m, 0), a.srcH - 1);
+        la[i] = bY.ld16(uoffL, (unsigned)ra * (unsigned)a.ys);
+        lb[i] = bY.ld16(uoffL, (unsigned)rb * (unsigned)a.ys);
+    }
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+        const int r = min(max(y0 + RW * wave + i, 0), a.chrSrcH - 1);
+        if (NV12) {
+            const unsigned ro = (unsigned)r * (unsigned)a.us;
+            ca[i] = bU.ld16(uoffA, ro);
+            const uint2 t = bU.ld8(uoffB, ro);
+            cb[i] = make_uint4(t.x, t.y, 0u, 0u);
+        } else {
+            const uint3 tu = bU.ld12(uoffA, (unsigned)r * (unsigned)a.us);
+            const uint3 tv = bV.ld12(uoffA, (unsigned)r * (unsigned)a.vs);
+            ca[i] = make_uint4(tu.x, tu.y, tu.z, 0u);
+            cb[i] = make_uint4(tv.x, tv.y, tv.z, 0u);
+        }
+    }
+    // ---- the colour tables, while the loads are in flight (scale_yuv2s_kernel's, entry by entry) -----------------------------
+    {
+        const Yuv2RgbConsts &k = a.y2r;
+#pragma unroll
+        for (int e = tid; e < S2_LUT_N; e += 256) {
+            const int i = min(max(e - S2_LUT_BIAS, 0), 255);
+            lutV[e] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
+            lutU[e] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+        }
+    }
+
+    auto fix_luma = [&](uint4 L, auto edge_c) -> uint4 {
+        constexpr int K = decltype(edge_c)::value;
+        if constexpr (K == 1) {
+            const unsigned first = s2_rep(L.x, 0x00000000u);
+            L = make_uint4(edgeLL ? first : L.x, edgeLL ? L.x : L.y, edgeLL ? L.y : L.z, edgeLL ? L.z : L.w);
+        } else if constexpr (K == 2) {
+            const unsigned last = s2_rep(L.w, 0x03030303u);
+            L = make_uint4(edgeLR ? L.y : L.x, edgeLR ? L.z : L.y, edgeLR ? L.w : L.z, edgeLR ? last : L.w);
+        } else if constexpr (K == 3) {
+            const unsigned first = s2_rep(L.x, 0x00000000u), last = s2_rep(L.w, 0x03030303u);
+            L = make_uint4(edgeLL ? first : edgeLR ? L.y : L.x, edgeLL ? L.x : edgeLR ? L.z : L.y,
+                           edgeLL ? L.y : edgeLR ? L.w : L.z, edgeLL ? L.z : edgeLR ? last : L.w);
+        }
+        return L;
+    };
+    auto hrow = [&](const uint4 &L, int (&s)[4]) {
+        int p[7];
+        p[0] = s2_pair12(L.x); p[1] = s2_pair30(L.y, L.x); p[2] = s2_pair12(L.y); p[3] = s2_pair30(L.z, L.y);
+        p[4] = s2_pair12(L.z); p[5] = s2_pair30(L.w, L.z); p[6] = s2_pair12(L.w);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            s[j] = s2_dot2(p[j + 3], a.hL[3], s2_dot2(p[j + 2], a.hL[2], s2_dot2(p[j + 1], a.hL[1], s2_dot2(p[j], a.hL[0], 0))));
+    };
+
+    auto go = [&](auto edge_c) {
+        constexpr int EDGE = decltype(edge_c)::value;
+        // ---- horizontal luma of this wave's pairs -> LDS -------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            const int k = wave + 4 * i;
+            if (k < NPAIR) {
+                int sa[4], sb[4];
+                hrow(fix_luma(la[i], edge_c), sa);
+                hrow(fix_luma(lb[i], edge_c), sb);
+                uint4 h;
+                h.x = (unsigned)__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[0] >> 7, sb[0] >> 7));
+                h.y = (unsigned)__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[1] >> 7, sb[1] >> 7));
+                h.z = (unsigned)__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[2] >> 7, sb[2] >> 7));
+                h.w = (unsigned)__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[3] >> 7, sb[3] >> 7));
+                hwS[k][lane] = h;
+            }
+        }
+        __syncthreads();                                        // the band's pairs and the colour tables
+        // ---- this wave's output rows -----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+            const int r = RW * wave + i, yo = y0 + r;
+            if (yo >= a.dstH) break;                            // wave-uniform (the frame's last band)
+            const uint4 h0 = hwS[r][lane], h1 = hwS[r + 1][lane], h2 = hwS[r + 2][lane], h3 = hwS[r + 3][lane];
+            const unsigned q0[4] = {h0.x, h0.y, h0.z, h0.w}, q1[4] = {h1.x, h1.y, h1.z, h1.w}, q2[4] = {h2.x, h2.y, h2.z, h2.w}, q3[4] = {h3.x, h3.y, h3.z, h3.w};
+            int Y[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int acc = a.lr;
+                acc = s2_dot2((int)q0[q], a.vL[0], acc);
+                acc = s2_dot2((int)q1[q], a.vL[1], acc);
+                acc = s2_dot2((int)q2[q], a.vL[2], acc);
+                acc = s2_dot2((int)q3[q], a.vL[3], acc);
+                Y[q] = acc >> 19;
+            }
+            int pU[5], pV[5];
+            if (NV12) {
+                unsigned e[6] = {ca[i].x, ca[i].y, ca[i].z, ca[i].w, cb[i].x, cb[i].y};
+                if constexpr ((EDGE & 1) != 0) {
+                    const unsigned rr = s2_rep(e[0], 0x01000100u), e0 = e[0], e1 = e[1];
+                    e[0] = edgeAL ? rr : e0; e[1] = edgeAL ? rr : e1; e[2] = edgeAL ? e0 : e[2]; e[3] = edgeAL ? e1 : e[3];
+                }
+                if constexpr ((EDGE & 2) != 0) {
+                    const unsigned rr = s2_rep(e[5], 0x03020302u);
+                    e[4] = edgeBR ? rr : e[4]; e[5] = edgeBR ? rr : e[5];
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    pU[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C040C02u);
+                    pV[k] = (int)__builtin_amdgcn_perm(e[k + 1], e[k], 0x0C050C03u);
+                }
+            } else {
+                unsigned fu[3] = {ca[i].x, ca[i].y, ca[i].z}, fv[3] = {cb[i].x, cb[i].y, cb[i].z};
+                if constexpr (EDGE != 0) {
+                    const unsigned u0 = fu[0], u1 = fu[1], u2 = fu[2], v0 = fv[0], v1 = fv[1], v2 = fv[2];
+                    if constexpr (EDGE == 1) {
+                        fu[0] = edgeAL ? s2_rep(u0, 0x00000000u) : u0; fu[1] = edgeAL ? u0 : u1; fu[2] = edgeAL ? u1 : u2;
+                        fv[0] = edgeAL ? s2_rep(v0, 0x00000000u) : v0; fv[1] = edgeAL ? v0 : v1; fv[2] = edgeAL ? v1 : v2;
+                    } else if constexpr (EDGE == 2) {
+                        fu[0] = edgeAR ? u1 : u0; fu[1] = edgeAR ? u2 : u1; fu[2] = edgeAR ? s2_rep(u2, 0x03030303u) : u2;
+                        fv[0] = edgeAR ? v1 : v0; fv[1] = edgeAR ? v2 : v1; fv[2] = edgeAR ? s2_rep(v2, 0x03030303u) : v2;
+                    } else {
+                        const unsigned uf = s2_rep(u0, 0x00000000u), ul = s2_rep(u2, 0x03030303u), vf = s2_rep(v0, 0x00000000u), vl = s2_rep(v2, 0x03030303u);
+                        fu[0] = edgeAL ? uf : edgeAR ? u1 : u0; fu[1] = edgeAL ? u0 : edgeAR ? u2 : u1; fu[2] = edgeAL ? u1 : edgeAR ? ul : u2;
+                        fv[0] = edgeAL ? vf : edgeAR ? v1 : v0; fv[1] = edgeAL ? v0 : edgeAR ? v2 : v1; fv[2] = edgeAL ? v1 : edgeAR ? vl : v2;
+                    }
+                }
+                pU[0] = s2_pair12(fu[0]); pU[1] = s2_pair30(fu[1], fu[0]); pU[2] = s2_pair12(fu[1]); pU[3] = s2_pair30(fu[2], fu[1]); pU[4] = s2_pair12(fu[2]);
+                pV[0] = s2_pair12(fv[0]); pV[1] = s2_pair30(fv[1], fv[0]); pV[2] = s2_pair12(fv[1]); pV[3] = s2_pair30(fv[2], fv[1]); pV[4] = s2_pair12(fv[2]);
+            }
+            int iU[2], iV[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                constexpr int R0 = 8192 + (S2_LUT_BIAS << 14);
+                const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], R0))));
+                const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], R0))));
+#if S2_LUT512
+                iU[c] = (su >> 14) & (S2_LUT_N - 1); iV[c] = (sv >> 14) & (S2_LUT_N - 1);
+#else
+                iU[c] = clip_u8_shr(su, 14); iV[c] = clip_u8_shr(sv, 14);
+#endif
+            }
+            unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int2 tv = lutV[iV[c]], tu = lutU[iU[c]];
+                const int tr = BGR ? tu.y : tv.x, tg = tv.y + tu.x, tb = BGR ? tv.x : tu.y;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int q = 2 * c + h;
+                    c0[q] = (unsigned)(tr + m24(Y[q], a.y2r.cy));      // |term + Y cy| < 2^27: the channel is sat_u8 of the high half
+                    c1[q] = (unsigned)(tg + m24(Y[q], a.y2r.cy));
+                    c2[q] = (unsigned)(tb + m24(Y[q], a.y2r.cy));
+                }
+            }
+            if (active) {
+                const unsigned drow = (unsigned)yo * (unsigned)a.ds;
+    #define S2_SAT2(x, y) s2_sat_pk_u8_i16(__builtin_amdgcn_perm((y), (x), 0x07060302u))
+    #define S2_JOIN(lo2, hi2) __builtin_amdgcn_perm((hi2), (lo2), 0x05040100u)
+                if (BPP == 4) {
+                    uint4 o4;
+                    o4.x = S2_JOIN(S2_SAT2(c0[0], c1[0]), S2_SAT2(c2[0], 0x00FF0000u));
+                    o4.y = S2_JOIN(S2_SAT2(c0[1], c1[1]), S2_SAT2(c2[1], 0x00FF0000u));
+                    o4.z = S2_JOIN(S2_SAT2(c0[2], c1[2]), S2_SAT2(c2[2], 0x00FF0000u));
+                    o4.w = S2_JOIN(S2_SAT2(c0[3], c1[3]), S2_SAT2(c2[3], 0x00FF0000u));
+                    bD.st16(o4, dstOff, drow);
+                } else {
+                    uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    o3.x = S2_JOIN(S2_SAT2(c0[0], c1[0]), S2_SAT2(c2[0], c0[1]));
+                    o3.y = S2_JOIN(S2_SAT2(c1[1], c2[1]), S2_SAT2(c0[2], c1[2]));
+                    o3.z = S2_JOIN(S2_SAT2(c2[2], c0[3]), S2_SAT2(c1[3], c2[3]));
+                    bD.st12(o3, dstOff, drow);
+                }
+    #undef S2_SAT2
+    #undef S2_JOIN
+            }
+        }
+    };
+    const int edgeKind = (X0 == 0 ? 1 : 0) | (X0 + S2_STRIP >= a.dstW ? 2 : 0);      // block-uniform: every wave meets the barrier inside go()
+    if (edgeKind == 0) go(std::integral_constant<int, 0>());
+    else if (edgeKind == 1) go(std::integral_constant<int, 1>());
+    else if (edgeKind == 2) go(std::integral_constant<int, 2>());
+    else go(std::integral_constant<int, 3>());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same kernel written over the number of coefficient pairs NP, shipped for NP = 6 only (Lanczos-3: 12 taps on
 // [2x - 5, 2x + 6], a 6-slot vertical window, 24 luma bytes per row and lane).  The 4-pair kernel above is NOT an instantiation
 // of this template on purpose: written this way the 4-pair form compiles to a different schedule (70 instead of 78 VGPRs) that
@@ -978,10 +1221,63 @@ int yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &g, Yuv2sTables &t)
     return 0;
 }
 
+// wave slots of the device: CUs x 4 SIMDs x the waves a SIMD holds of a kernel with this many VGPRs (512 a lane and SIMD, allocated
+// in blocks of 8) — from hipDeviceProp, not a literal (MI355X: 256 x 4 x 6 = 6144 for the walker's 74 VGPRs)
+static int wave_slots(int vgprs)
+{
+    static thread_local int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int perSimd = std::min(8, 512 / ((vgprs + 7) / 8 * 8));
+    return cus[dev] * 4 * perSimd;
+}
+
+// which form a launch of nframes frames takes: the block-cooperative kernel up to GMAT_STRIP_BLOCK frames (default 2; 0 = never),
+// the walker beyond — and for the 6-pair filters always
+bool yuv2s_block_form(const Yuv2sArgs &a, int nframes)
+{
+    if (a.np != 4) return false;
+    const char *e = GMAT_KNOB("GMAT_STRIP_BLOCK");
+    const int upTo = e ? atoi(e) : 2;
+    return nframes <= upTo;
+}
+
+static int launch_scale_yuv2s_blk(Yuv2sArgs a, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+{
+    // rows a block: 4 waves x RW rows.  12 (RW = 3) filters 15 row pairs per 12 rows and gives a 4K -> 1080p frame 720 blocks = 2880
+    // waves; a small frame takes shorter bands so that the launch still has a few waves for every SIMD (1080p -> 540p: RW = 1,
+    // 2160 waves of one row each instead of 720 of three).  GMAT_STRIP_ROWS = 4 / 8 / 12 / 16 select RW = 1 .. 4 (A/B)
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");
+    const int segEnv = segStr ? atoi(segStr) : 0;
+    const long waveRows = (long)a.dstH * ((a.dstW + S2_STRIP - 1) / S2_STRIP) * nframes, simds = wave_slots(74) / 6;
+    const int rw = segEnv == 4 ? 1 : segEnv == 8 ? 2 : segEnv == 12 ? 3 : segEnv == 16 ? 4 : waveRows <= 3 * simds ? 1 : waveRows <= 6 * simds ? 2 : 3;
+    a.segRows = 4 * rw;
+    a.nseg = (a.dstH + a.segRows - 1) / a.segRows;
+    a.nsg = (a.dstW + S2_STRIP - 1) / S2_STRIP;                 // strips a row
+    a.updown = 0;
+    const int nblk = a.nseg * a.nsg;
+    const dim3 grid(a.xcdRemap ? 8 * ((nblk + 7) / 8) : nblk, nframes), block(256);
+#define GMAT_S2B(N_, D_) do { if (rw == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_blk_kernel<N_, D_, 1>), grid, block, 0, stream, a, fr); \
+                              else if (rw == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_blk_kernel<N_, D_, 2>), grid, block, 0, stream, a, fr); \
+                              else if (rw == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_blk_kernel<N_, D_, 4>), grid, block, 0, stream, a, fr); \
+                              else hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuv2s_blk_kernel<N_, D_, 3>), grid, block, 0, stream, a, fr); } while (0)
+    const int d = a.dstFormat == GMAT_PIX_FMT_RGB24 ? 0 : a.dstFormat == GMAT_PIX_FMT_BGR24 ? 1 : a.dstFormat == GMAT_PIX_FMT_RGBA ? 2 : 3;
+    if (a.nv12) { switch (d) { case 0: GMAT_S2B(true, 0); break; case 1: GMAT_S2B(true, 1); break; case 2: GMAT_S2B(true, 2); break; default: GMAT_S2B(true, 3); } }
+    else        { switch (d) { case 0: GMAT_S2B(false, 0); break; case 1: GMAT_S2B(false, 1); break; case 2: GMAT_S2B(false, 2); break; default: GMAT_S2B(false, 3); } }
+#undef GMAT_S2B
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     Yuv2sArgs a = a0;
+    if (yuv2s_block_form(a, nframes)) return launch_scale_yuv2s_blk(a, stream, *frames, nframes);
     // Rows per strip segment.  A segment costs 3 warm-up row pairs (horizontal filter only) on top of its rows, so long segments
     // looked right — and round 2 ran 45-row segments, one wave per wave slot for a 32-frame launch.  Round 3 measured the access
     // pattern instead (tools/ubench/hbm_rw.hip, profiles/r03d_hbm_patterns.txt): thousands of waves each walking a long column
@@ -998,7 +1294,8 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     int seg = segEnv > 0 ? segEnv : 0;
     if (!seg) {
         const long rows = (long)a.dstH * nstrips * nframes;      // wave-rows of the launch
-        seg = (int)std::min(12L, std::max(3L, (rows + 6143) / 6144));
+        const long slots = wave_slots(74);                       // the walker's 74 VGPRs: 6 waves a SIMD
+        seg = (int)std::min(12L, std::max(3L, (rows + slots - 1) / slots));
         // the 6-pair kernel: 5 warm-up row pairs per segment instead of 3 want longer segments, its 109 VGPRs (4 waves per SIMD)
         // shorter ones; measured best 6 / 12 / 16 rows at 1 / 4 / 32 frames per launch (profiles/r02f_yuv2s_lanczos_rows_sweep.txt)
         if (a.np == 6) seg = std::min(16, std::max(6, 2 * seg));

@@ -308,6 +308,8 @@ struct Yuv2sArgs {
 int  yuv2s_prepare(const ScalePlan &p, const YuvScaleTiling &generic, Yuv2sTables &t);
 // plane pointers of the nframes frames in *frames (grid.y = frame)
 int  launch_scale_yuv2s(const Yuv2sArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+// the form that launch takes: true = the block-cooperative kernel of small launches (scale_yuv2s_blk_kernel), false = the walker
+bool yuv2s_block_form(const Yuv2sArgs &a, int nframes);
 
 // ---- the polyphase band walker for ANY ratio (k_scale_yuvg.hip): 8-bit 4:2:0 -> packed RGB, and -> 4:2:0 of the same chroma layout ----
 // The vertical program of a plane class (pair) in one walking direction; see build_qprog in k_scale_yuvg.hip.

@@ -128,6 +128,8 @@ hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
+struct hipDeviceProp_t { int multiProcessorCount; int warpSize; char name[64]; };
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int device);
 hipError_t hipDeviceGetPCIBusId(char *buf, int len, int device);
 hipError_t hipGetLastError();
 const char *hipGetErrorName(hipError_t e);

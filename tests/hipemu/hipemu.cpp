@@ -241,6 +241,7 @@ static thread_local int g_device = 0;
 hipError_t hipSetDevice(int d) { if (d < 0 || d > 1) return hipErrorInvalidValue; g_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = g_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n) { *n = 2; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int) { memset(prop, 0, sizeof(*prop)); prop->multiProcessorCount = 256; prop->warpSize = 64; snprintf(prop->name, sizeof(prop->name), "emulated gfx950"); return hipSuccess; }
 // no PCI device behind an emulated GPU: callers that look for sysfs placement find none
 hipError_t hipDeviceGetPCIBusId(char *buf, int len, int) { if (len > 0) buf[0] = 0; return hipErrorInvalidValue; }
 hipError_t hipGetLastError() { return hipSuccess; }

@@ -90,7 +90,10 @@ def _expected_2to1(which, src_fmt, dst_fmt):
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
 def test_batch_on_the_2to1_kernel(dev, orc, strip_or_tiled, src_fmt, dst_fmt):
     k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
-    assert k == _expected_2to1(strip_or_tiled, src_fmt, dst_fmt), k
+    want = _expected_2to1(strip_or_tiled, src_fmt, dst_fmt)
+    if want == "scale_yuv2s_kernel":                # the second stream's share is 2 frames: a launch that small is the block form
+        want = "scale_yuv2s_blk_kernel"
+    assert k == want, k
 
 
 @pytest.mark.parametrize("case", [("nv12", "rgb24", 96, 40, 144, 60), ("yuv420p", "nv12", 200, 90, 80, 36),

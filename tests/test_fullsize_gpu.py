@@ -37,7 +37,7 @@ def test_cfg3_4k_nv12_to_1080p_rgb24_bicubic(gpu, orc, fused, oracle):
     bad = np.argwhere(got[0] != want)
     assert bad.size == 0, f"{k}: {len(bad)} mismatching bytes, first {bad[:3].tolist()}"
     assert (pads[0] == 0xCD).all()
-    assert k == {2: "scale_yuv2s_kernel", 1: "scale_rgb2h_kernel<yuv>", 0: "scale_rgb2h_kernel"}[fused], k
+    assert k == {2: "scale_yuv2s_blk_kernel", 1: "scale_rgb2h_kernel<yuv>", 0: "scale_rgb2h_kernel"}[fused], k
 
 
 def test_cfg3_rgb24_4k_to_1080p_lanczos(gpu, orc):

@@ -183,6 +183,6 @@ def test_batched_frames(dev, orc, strip_rows, which, df):
 def test_exact_ratio_walkers_keep_their_frames(dev, orc, strip_rows):
     """the walker sits BEHIND the exact-ratio kernels (2:1, 3:1, 3:2, 4:1, 1:2): where one of them takes a frame it still does"""
     strip_rows(0)
-    assert _check(dev, orc, "nv12", "rgb24", (512, 64, 256, 32)) == "scale_yuv2s_kernel"
+    assert _check(dev, orc, "nv12", "rgb24", (512, 64, 256, 32)) == "scale_yuv2s_blk_kernel"
     assert _check(dev, orc, "nv12", "nv12", (512, 64, 256, 32)) == "scale_yuv2p_kernel"
     assert _check(dev, orc, "nv12", "rgb24", (792, 78, 264, 26)) == "scale_yuv3r_kernel"

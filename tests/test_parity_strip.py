@@ -29,6 +29,21 @@ def strip_rows():
         os.environ["GMAT_STRIP_ROWS"] = old
 
 
+@pytest.fixture(params=["walk", "blk"])
+def strip_form(request):
+    """the two forms of the 4-pair strip kernel: the register-window WALKER (scale_yuv2s_kernel: every launch of more than two
+    frames) and the BLOCK-cooperative form of small launches (scale_yuv2s_blk_kernel, round 4: what one sws_scale() call gets).
+    GMAT_STRIP_BLOCK = n sends launches of up to n frames to the block form: 0 / 32 force either at every launch size.  Yields the
+    kernel name to expect."""
+    old = os.environ.get("GMAT_STRIP_BLOCK")
+    os.environ["GMAT_STRIP_BLOCK"] = "0" if request.param == "walk" else "32"
+    yield "scale_yuv2s_kernel" if request.param == "walk" else "scale_yuv2s_blk_kernel"
+    if old is None:
+        os.environ.pop("GMAT_STRIP_BLOCK", None)
+    else:
+        os.environ["GMAT_STRIP_BLOCK"] = old
+
+
 # (srcW, srcH, row alignment): one partial strip, exactly one strip, strips + a partial one, two strip groups, widths that
 # are multiples of 8 only, heights that leave a short last segment
 GEOMS = [(32, 16, 4), (64, 32, 16), (512, 40, 64), (520, 24, 4), (1032, 36, 8), (2056, 20, 4), (2560, 18, 256), (4104, 16, 4)]
@@ -37,21 +52,33 @@ GEOMS = [(32, 16, 4), (64, 32, 16), (512, 40, 64), (520, 24, 4), (1032, 36, 8), 
 @pytest.mark.parametrize("dst_fmt", ["rgb24", "bgr24", "rgba", "bgra"])
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p"])
 @pytest.mark.parametrize("geom", GEOMS)
-def test_strip_kernel_bit_exact(dev, orc, strip_rows, src_fmt, dst_fmt, geom):
+def test_strip_kernel_bit_exact(dev, orc, strip_rows, strip_form, src_fmt, dst_fmt, geom):
     sw, sh, align = geom
     if dst_fmt in ("rgba", "bgra"):
         align = max(align, 16)                  # 16-byte pixel-group stores
     strip_rows(0)
     k = _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, sw // 2, sh // 2, nframes=2, nstreams=1, align=align)
-    assert k == "scale_yuv2s_kernel", k
+    assert k == strip_form, k
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64, 1000])
-def test_strip_segmentation_does_not_change_the_result(dev, orc, strip_rows, rows):
-    """segments of any height: the 3 warm-up row pairs of every segment re-create the vertical window exactly"""
+def test_strip_segmentation_does_not_change_the_result(dev, orc, strip_rows, strip_form, rows):
+    """segments of any height: the 3 warm-up row pairs of every segment re-create the vertical window exactly (the block form
+    has three band heights: 8, 12 and 16 rows)"""
     strip_rows(rows)
     k = _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=4, nstreams=2, align=16)
-    assert k == "scale_yuv2s_kernel", k
+    assert k == strip_form, k
+    for sh in (16, 18, 34, 46, 70):                 # last bands of 1 .. 11 rows, frames shorter than a band
+        k = _run_batch(dev, orc, "yuv420p", "bgra", 264, sh, 132, sh // 2, nframes=1, nstreams=1, align=16)
+        assert k == strip_form, k
+
+
+def test_strip_form_follows_the_launch_size(dev, orc, strip_rows):
+    """the shipped rule (no knob): a launch of one or two frames is the block-cooperative kernel, a larger one the walker"""
+    strip_rows(0)
+    os.environ.pop("GMAT_STRIP_BLOCK", None)
+    for n, want in ((1, "scale_yuv2s_blk_kernel"), (2, "scale_yuv2s_blk_kernel"), (3, "scale_yuv2s_kernel"), (5, "scale_yuv2s_kernel")):
+        assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=n, nstreams=1, align=16) == want
 
 
 @pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss"])
@@ -92,7 +119,7 @@ def test_lanczos_on_the_strip_kernel(dev, orc, strip_rows, kern, src_fmt, dst_fm
         align = max(align, 16)
     strip_rows(0)
     k = _run_batch(dev, orc, src_fmt, dst_fmt, sw, sh, sw // 2, sh // 2, nframes=2, nstreams=1, align=align, flags=SWS["lanczos"])
-    if kern == "scale_yuv2s_kernel" and lanczos_takes(sw, sh):
+    if kern.startswith("scale_yuv2s") and lanczos_takes(sw, sh):
         assert k == LZ, k
     else:
         assert not k.startswith("scale_yuv2s"), k
@@ -140,7 +167,7 @@ def test_strip_kernel_colorspace(dev, orc, strip_rows, cs):
     r = lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]),
                                  C.cast(dp, C.POINTER(C.c_void_p)), ints([ddst[0][0].stride]),
                                  C.cast(streams, C.POINTER(C.c_void_p)), 1, 0)
-    assert r == n and lib.gmat_sws_lastKernel(c) == b"scale_yuv2s_kernel"
+    assert r == n and lib.gmat_sws_lastKernel(c) in (b"scale_yuv2s_kernel", b"scale_yuv2s_blk_kernel")
     lib.gmat_stream_sync(st)
     for f in range(n):
         want = orc.sws(srcs[f], sw, sh, "nv12", sw // 2, sh // 2, "rgb24", SWS["bicubic"], colorspace=cs)
