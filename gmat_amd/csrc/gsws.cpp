@@ -1356,9 +1356,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_RGB2YUV444;
     } else if (same && is_yuv420(srcFormat) && is_yuv420(dstFormat)) {
         c->mode = MODE_YUV2YUV;
-    } else if (same && is_yuv420(srcFormat) && (dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE)) {
-        // planar8ToP01xleWrapper (swscale_unscaled.c:286-324, selected :2108-2112 for YUV420P); NV12 sources get
-        // the same sample rule (the reference GPU path yuv2yuv_cuda.cu:320-371 takes both)
+    } else if (same && srcFormat == GMAT_PIX_FMT_YUV420P && (dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_P016LE)) {
+        // planar8ToP01xleWrapper (swscale_unscaled.c:286-324), which libswscale selects for PLANAR 8-bit sources only (:2108-2112).
+        // An NV12 source has no special converter on the CPU: it runs the generic lines below like any other pair (rounds 1-3 gave it
+        // the wrapper's t | t << 8 too; the reference's real core against its own CPU path showed the difference, round 4:
+        // tests/test_libswscale_core.py)
         c->mode = MODE_DEPTH;
     } else if (!same && (srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24 || is_yuv420(srcFormat)) &&
                is_packed_rgb(dstFormat)) {
@@ -1804,14 +1806,12 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         break;
     }
     case MODE_DEPTH: {
-        const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12;
         if (!dst[1]) { r = GMAT_ERR(EINVAL); break; }
         c->lastKernel = "widen8to16_kernel";
         if ((r = launch_widen8to16(src[0], srcStride[0], nullptr, 0, dst[0], dstStride[0], c->srcW, c->srcH, c->stream)) < 0) break;
-        // the CPU wrapper converts srcW / 2 chroma pairs on ceil(srcH / 2) rows (:309-317)
+        // the CPU wrapper converts srcW / 2 chroma pairs on ceil(srcH / 2) rows (:309-317); planar sources only (see gmat_sws_getContext)
         const int cw = c->srcW / 2, ch = ceil_rshift(c->srcH, 1);
-        if (snv) r = launch_widen8to16(src[1], srcStride[1], nullptr, 0, dst[1], dstStride[1], 2 * cw, ch, c->stream);
-        else     r = launch_widen8to16(src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], cw, ch, c->stream);
+        r = launch_widen8to16(src[1], srcStride[1], src[2], srcStride[2], dst[1], dstStride[1], cw, ch, c->stream);
         break;
     }
     case MODE_SCALE: {

@@ -13,6 +13,20 @@
 
 #define GMAT_CTX(c) ((GmatSwsContext *)(c)->cv_resize_handle)
 
+/* c->cspace is an enum AVColorSpace that NOTHING in the core sets (sws_alloc_context zeroes the context: 0 = AVCOL_SPC_RGB): the
+ * reference's get_constants (cuda/yuv2rgb_cuda.cu:782-815) sends every value it does not list — 0 included — to BT.601.  The codes it
+ * does list coincide with libswscale's SWS_CS_* rows (swscale.h:99-106). */
+static int cs_of_avcol(enum AVColorSpace cs)
+{
+    switch ((int)cs) {
+    case 1:  return GMAT_SWS_CS_ITU709;          /* AVCOL_SPC_BT709 */
+    case 4:  return 4;                           /* AVCOL_SPC_FCC */
+    case 7:  return 7;                           /* AVCOL_SPC_SMPTE240M */
+    case 9: case 10: return GMAT_SWS_CS_BT2020;  /* AVCOL_SPC_BT2020_NCL / _CL */
+    default: return GMAT_SWS_CS_DEFAULT;         /* BT470BG, SMPTE170M and everything unlisted: BT.601 */
+    }
+}
+
 /* utils.c:2057 calls this from sws_init_context_cuda once the formats and sizes are in the context */
 int ff_sws_init_swscale_cuda(SwsContext *c)
 {
@@ -24,6 +38,7 @@ int ff_sws_init_swscale_cuda(SwsContext *c)
     if (!isAnyRGB(c->srcFormat) && (c->srcW != c->dstW || c->srcH != c->dstH || c->srcFormat != c->dstFormat))
         gmat_sws_setChromaPos(g, c->src_h_chr_pos, c->src_v_chr_pos, c->dst_h_chr_pos, c->dst_v_chr_pos);
     c->cv_resize_handle = (void *)g;
+    ff_yuv2rgb_init_tables_cuda(c);              /* as the reference's init ends (cuda/swscale_cuda.c:268): the core never calls it for a scaling context */
     return 0;
 }
 
@@ -49,7 +64,7 @@ void ff_yuv2rgb_init_tables_cuda(SwsContext *c)
 {
     if (!GMAT_CTX(c))
         return;
-    gmat_sws_setColorspace(GMAT_CTX(c), c->cspace, c->srcRange);
+    gmat_sws_setColorspace(GMAT_CTX(c), cs_of_avcol(c->cspace), c->srcRange);
     if (!isAnyRGB(c->srcFormat) && !isAnyRGB(c->dstFormat))
         gmat_sws_setRange(GMAT_CTX(c), c->srcRange, c->dstRange);      /* lum/chrConvertRange, swscale.c:530-556 */
 }

@@ -49,7 +49,8 @@ int main(int argc, char **argv)
     c.flags = atoi(argv[7]) | GMAT_SWS_HWACCEL;                              /* SWS_HWACCEL_CUDA, swscale.h:95 */
     c.param[0] = c.param[1] = GMAT_SWS_PARAM_DEFAULT;                        /* SWS_PARAM_DEFAULT, utils.c:1292 */
     c.src_h_chr_pos = c.src_v_chr_pos = c.dst_h_chr_pos = c.dst_v_chr_pos = -513;   /* options.c:67-70 defaults */
-    c.cspace = 5; c.srcRange = 0; c.dstRange = 0;                            /* SWS_CS_DEFAULT, limited range */
+    c.cspace = 0; c.srcRange = 0; c.dstRange = 0;                            /* cspace: NOTHING in the core sets it (0 after sws_alloc_context;
+                                                                                tests/test_libswscale_core.py, the real core); limited range */
     const uint32_t seed = (uint32_t)atoi(argv[8]);
 
     int sb[4], sr[4], db[4], dr[4];

@@ -222,9 +222,25 @@ def test_yuv_relayout_lossless(dev, orc, w, h, pair):
 @pytest.mark.parametrize("dst_fmt", ["p010le", "p016le"])
 def test_depth_expansion_to_p01x(dev, orc, w, h, src_fmt, dst_fmt):
     """planar8ToP01xleWrapper: t -> t | t << 8 (swscale_unscaled.c:286-324); odd widths leave the last chroma pair
-    unwritten exactly like the CPU loop (srcW / 2 pairs)."""
+    unwritten exactly like the CPU loop (srcW / 2 pairs).  libswscale selects it for PLANAR 8-bit sources only (:2108-2112): an
+    NV12 source runs the generic lines (t << 8), as the reference's real core showed (round 4, tests/test_libswscale_core.py)."""
     from harness import alloc_planes
     src = synth_planes(orc, src_fmt, w, h, seed=59)
+    if src_fmt == "nv12":
+        want = orc.sws(src, w, h, src_fmt, w, h, dst_fmt)
+        d_src = dev.upload_planes(src, 64)
+        got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, dst_fmt, dst_align=64)
+        assert kernel != "widen8to16_kernel"
+        for g, wv in zip(got, want):
+            assert (g == wv).all()
+        assert (got[0].view("<u2") == src[0].astype(np.uint16) << 8).all()          # known answer: the sample in the high byte
+        dst = dev.planes_like(dst_fmt, w, h, 64)
+        r = dev.lib.yuv2yuv_cuda(planes([p.ptr for p in d_src]), ints([p.stride for p in d_src]),
+                                 planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h, PIX_FMT[src_fmt], PIX_FMT[dst_fmt], None)
+        assert r == 0 and all((a.download() == b).all() for a, b in zip(dst, want))
+        for p in d_src + dst:
+            p.free()
+        return
     want = alloc_planes(dst_fmt, w, h, fill=0xCD)
     orc.L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
                              planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h,

@@ -78,13 +78,14 @@ def test_reference_entry_point_yuv2yuv_cuda_every_pair(dev, orc, s_fmt, d_fmt):
     d_src = dev.upload_planes(src, 64)
     dst = dev.planes_like(d_fmt, w, h, 64)
     assert _call(dev, "yuv2yuv_cuda", d_src, s_fmt, dst, d_fmt, w, h) == 0
-    if d_fmt in ("p010le", "p016le"):
-        # planar8ToP01xleWrapper (swscale_unscaled.c:286-324), which the context API takes for these pairs too
+    if d_fmt in ("p010le", "p016le") and s_fmt == "yuv420p":
+        # planar8ToP01xleWrapper (swscale_unscaled.c:286-324): libswscale's converter for planar 8-bit sources (an NV12 source runs
+        # the generic lines, the else branch)
         from harness import alloc_planes
         want = alloc_planes(d_fmt, w, h, fill=0xCD)
         orc.L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
                                  planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h,
-                                 1 if s_fmt == "nv12" else 0)
+                                 0)
     else:
         want = orc.sws(src, w, h, s_fmt, w, h, d_fmt)
     for d, wv in zip(dst, want):
