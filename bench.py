@@ -3,8 +3,9 @@
 
 Workload (BASELINE.json configs[2], the config `metric` is quoted on): synthetic 3840x2160 NV12
 frames, device resident -> RGB24 -> 1920x1080 bicubic RGB24, through the C ABI (gmat_sws_scale_batch).
-A "step" is one pass over one batch of FRAMES distinct frame pairs (0.6 GB working set, larger than
-the 256 MiB Infinity Cache, so HBM is measured, not cache).
+A "step" is PASSES (default 12) passes over FRAMES (default 256) distinct frame pairs — 4.8 GB, larger than the 256 MiB
+Infinity Cache, so HBM is measured, not cache; 12 x 256 frames = 10.4 ms a step, so that the driver's 20 steps are a timed region
+of > 200 ms (round 3's was 17 ms: one pass a step).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -25,8 +26,11 @@ the LAST stdout line is ONE compact JSON object (< 2 KB): metric / value / unit 
                   committed pass of this round (`traffic_source` says which).
   cpu_baseline  : libswscale arithmetic on the host cores, rank 0, bounded sample: stock libswscale.so when the
                   box has one ("reference"), else the C oracle ("port").
-`value` = source gigapixels per second over all ranks (weak scaling).  A step = LAUNCHES_PER_STEP launch sets of 32
-frames each over a working set of distinct frame pairs (default 256 pairs = 4.8 GB: HBM, not Infinity Cache).
+`value` = source gigapixels per second over all ranks (weak scaling).  A step = PASSES x (FRAMES / 32) launch sets of 32
+frames each over a working set of distinct frame pairs (default 256 pairs = 4.8 GB: HBM, not Infinity Cache), every launch
+set spread over TWO streams (config.workload says so; `roofline` is the same kernel on ONE stream).
+`--same-device` (rehearsal of configs[4] on a 1-GPU box): every rank uses device 0 and the control plane is gloo (RCCL refuses
+two ranks on one device); the launcher, per-rank NUMA binding, N working sets and the compact last line run as on 8 GPUs.
 """
 import argparse
 import ctypes as C
@@ -75,7 +79,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=256,
-                    help="distinct frame pairs of the working set = frames per step (a multiple of 32; 256 pairs = 4.8 GB)")
+                    help="distinct frame pairs of the working set (a multiple of 32; 256 pairs = 4.8 GB)")
+    ap.add_argument("--passes", type=int, default=12,
+                    help="passes over the working set that make ONE step (12 x 256 frames = 10.4 ms: 20 steps > 200 ms)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal: every rank on device 0, control plane on gloo (N ranks on a 1-GPU box)")
     ap.add_argument("--branches", type=int, default=2,
                     help="concurrent HIP streams the independent frames of a launch set are spread over (headline `value`)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
@@ -137,9 +145,9 @@ class Runner:
     step() = one pass over the working set: frames / 32 launch sets, each ONE C call (gmat_sws_scale_batch) that hands every
     stream its share of the set's 32 frames as one launch (grid.y = frame)."""
 
-    def __init__(self, lib, geo, stream, frames, fused, seed, branches=1, share=None):
+    def __init__(self, lib, geo, stream, frames, fused, seed, branches=1, share=None, passes=1):
         from gmat_amd.lib import PIX_FMT, SWS, ints
-        self.lib, self.stream, self.frames, self.geo = lib, stream, frames, geo
+        self.lib, self.stream, self.frames, self.geo, self.passes = lib, stream, frames, geo, max(1, passes)
         self.ctx = lib.gmat_sws_getContext(geo.sw, geo.sh, PIX_FMT["nv12"], geo.dw, geo.dh, PIX_FMT["rgb24"],
                                            SWS["bicubic"] | SWS["hwaccel"], None)
         if not self.ctx:
@@ -184,14 +192,46 @@ class Runner:
     def step(self, flags=0):
         """flags: GMAT_BATCH_FORK (1) on the step's first launch set, GMAT_BATCH_JOIN (2) on its last one"""
         lib, last = self.lib, len(self.set_args) - 1
-        for k, (cnt, sp, dp) in enumerate(self.set_args):
-            fl = (flags & 1 if k == 0 else 0) | (flags & 2 if k == last else 0)
-            r = lib.gmat_sws_scale_batch(self.ctx, cnt, sp, self.ss, dp, self.ds, self.pstreams, self.branches, fl)
-            if r != cnt:
-                raise RuntimeError(f"gmat_sws_scale_batch failed: {r}")
+        for p in range(self.passes):
+            for k, (cnt, sp, dp) in enumerate(self.set_args):
+                fl = (flags & 1 if k == 0 and p == 0 else 0) | (flags & 2 if k == last and p == self.passes - 1 else 0)
+                r = lib.gmat_sws_scale_batch(self.ctx, cnt, sp, self.ss, dp, self.ds, self.pstreams, self.branches, fl)
+                if r != cnt:
+                    raise RuntimeError(f"gmat_sws_scale_batch failed: {r}")
 
     def launches_per_step(self):
-        return len(self.set_args)
+        return len(self.set_args) * self.passes
+
+    def frames_per_step(self):
+        return self.frames * self.passes
+
+    def per_launch_ms(self, n):
+        """n launches on streams[0], each between its OWN pair of HIP events (launches still back to back: an event is a
+        packet between two dispatches): the distribution behind roofline.frac — frac_p50 / frac_min / frac_max"""
+        lib = self.lib
+        timers = []
+        for _ in range(n):
+            t = C.c_void_p()
+            lib.gmat_timer_create(C.byref(t))
+            timers.append(t)
+        one = (C.c_void_p * 1)(self.stream)
+        ps = C.cast(one, C.POINTER(C.c_void_p))
+        k = 0
+        for t in timers:
+            cnt, sp, dp = self.set_args[k % len(self.set_args)]
+            k += 1
+            lib.gmat_timer_begin(t, self.stream)
+            if lib.gmat_sws_scale_batch(self.ctx, cnt, sp, self.ss, dp, self.ds, ps, 1, 0) != cnt:
+                raise RuntimeError("gmat_sws_scale_batch failed")
+            lib.gmat_timer_end(t, self.stream)
+        lib.gmat_stream_sync(self.stream)
+        out = []
+        for t in timers:
+            ms = C.c_float()
+            lib.gmat_timer_elapsed_ms(t, C.byref(ms))
+            lib.gmat_timer_destroy(t)
+            out.append(float(ms.value))
+        return out
 
     def kernel(self):
         return self.lib.gmat_sws_lastKernel(self.ctx).decode()
@@ -211,13 +251,13 @@ class Runner:
 class Env:
     """what differs between the GPU run and the dry (CPU-emulated) run"""
 
-    def __init__(self, dry, local):
+    def __init__(self, dry, device):
         self.dry = dry
         if dry:
             self.sync = None
         else:
             import torch
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(device)
             self.sync = torch.cuda.synchronize
 
     def synchronize(self, lib):
@@ -227,6 +267,7 @@ class Env:
 
 
 wall_local = [0.0]          # this rank's own wall time of the last timed() (its return value is the MAX over ranks)
+ctl_device = ["cpu"]        # where the control plane's tensors live: "cuda" under RCCL, "cpu" under gloo
 
 
 def timed(lib, env, dist, runner, stream, steps, warmup, world, pre_warm_ms=PRE_WARM_MS):
@@ -262,7 +303,7 @@ def timed(lib, env, dist, runner, stream, steps, warmup, world, pre_warm_ms=PRE_
     lib.gmat_timer_elapsed_ms(timer, C.byref(ms))
     lib.gmat_timer_destroy(timer)
     if dist and world > 1:
-        wall = dist.max_over_ranks(wall, world, device="cpu" if env.dry else "cuda")
+        wall = dist.max_over_ranks(wall, world, device=ctl_device[0])
     return wall, float(ms.value)
 
 
@@ -626,7 +667,7 @@ def host_pipeline(lib, geo, dist, world, device, dry, nframes=96, depth=4):
         p.submit()
     p.drain()
     dt = time.perf_counter() - t0
-    dt = dist.max_over_ranks(dt, world, device="cpu" if dry else "cuda")
+    dt = dist.max_over_ranks(dt, world, device=ctl_device[0])
     # what a caller with PAGEABLE frames adds (hwupload's av_image_copy into the pinned ring, integration/vf_hwupload_hip.c:126):
     # one 4K NV12 frame copied into a ring slot by this rank's (NUMA-bound) thread — a per-thread ceiling beside the PCIe one
     fill = None
@@ -665,7 +706,13 @@ def cpu_port(geo, nframes):
         return None, None
     orc = harness.load_oracle(path)
     L = orc.L
-    cores = min(os.cpu_count() or 1, 64)
+    # N = ALL host cores (round 3 stopped at 64, and the rank is bound to its GPU's NUMA node for the GPU
+    # legs: the binding is lifted for this one)
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     y = orc.lcg((geo.sh, geo.sw), 7)
     uv = orc.lcg((geo.sh // 2, geo.sw), 8)
     out = np.empty((geo.dh, geo.dw * 3), np.uint8)
@@ -686,8 +733,9 @@ def cpu_port(geo, nframes):
         dt = time.perf_counter() - t0
     L.orc_sws_free(ctx)
     head = {"value": round(nframes * geo.px / dt / 1e9, 4), "unit": "Gpix/s", "cores": cores, "kind": "port",
-            "sample": f"{nframes} frames {geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (one context), C oracle "
-                      f"(oracle/, a port of libswscale's arithmetic), {cores} threads row-sliced, {dt:.2f} s"}
+            "note": "scalar C port, NOT stock libswscale (no SIMD): 2-3x below a production host",
+            "sample": f"{nframes} frames {geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic, one context, the C oracle "
+                      f"row-sliced over all {cores} host cores, {dt:.2f} s"}
     # BASELINE configs[0]: 1080p yuv420p -> rgb24 on ONE host thread, libswscale's unscaled fast path (yuv2rgb.c:346-374)
     w, h = geo.sw // 2, geo.sh // 2
     src = [orc.lcg((h, w), 1), orc.lcg((h // 2, w // 2), 2), orc.lcg((h // 2, w // 2), 3)]
@@ -773,7 +821,7 @@ def main():
             subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(emu))], check=True, capture_output=True)
         lib = load(emu)                                         # test infrastructure: kernel sources on CPU fibers
         geo = Geo(128, 32, 64, 16)
-        a.frames, a.steps, a.warmup = min(a.frames, 4), min(a.steps, 2), min(a.warmup, 1)
+        a.frames, a.steps, a.warmup, a.passes = min(a.frames, 4), min(a.steps, 2), min(a.warmup, 1), min(a.passes, 2)
         a.no_detail = a.no_pmc = True
     else:
         lib = gmat_amd.load()                                   # raises if the HIP library is missing
@@ -781,15 +829,20 @@ def main():
             raise SystemExit("bench.py: no HIP device visible (use --dry for the CPU plumbing check)")
         geo = Geo(3840, 2160, 1920, 1080)
         a.frames = max(LAUNCH_FRAMES, a.frames // LAUNCH_FRAMES * LAUNCH_FRAMES)
-    env = Env(a.dry, local)
-    local_device[0] = local
-    dev = local % max(1, lib.gmat_device_count()) if a.dry else local      # (the emulated build has two devices)
+    # --same-device: the 8-GPU launch rehearsed on one GPU — every rank drives device 0
+    dev = local % max(1, lib.gmat_device_count()) if a.dry else 0 if a.same_device else local      # (the emulated build has two devices)
+    env = Env(a.dry, dev)
+    local_device[0] = dev
     if lib.gmat_set_device(dev) != 0:
         raise SystemExit("bench.py: gmat_set_device(%d) failed" % dev)
     # each GPU gets its own host thread and pinned staging ring — bind this rank to the host cores of its
     # GPU's NUMA node BEFORE any pinned allocation (first touch decides where the ring lives)
     numa = {"node": int(lib.gmat_device_numa_node(dev)), "cpus_bound": int(lib.gmat_bind_thread_to_device(dev))}
-    gdist.init("gloo" if a.dry else "nccl")                     # RCCL; control plane only (barrier + MAX of time)
+    # control plane only (a barrier and one MAX): RCCL, and gloo when RCCL cannot be brought up — it must never be what takes
+    # configs[4] down (RCCL refuses two ranks on one device: --same-device asks for gloo outright)
+    gdist.init("gloo" if (a.dry or a.same_device) else "nccl", fallback="gloo")
+    backend = gdist.backend()
+    ctl_device[0] = "cuda" if backend == "nccl" else "cpu"
     dist = gdist
     stream = C.c_void_p()
     lib.gmat_stream_create(C.byref(stream))
@@ -797,21 +850,23 @@ def main():
     branches = a.branches
 
     # ---- headline: one libswscale-semantics context (mode 2); every launch set spread over `branches` streams
-    head = Runner(lib, geo, stream, a.frames, 2, seed=1000 + rank, branches=branches)
+    head = Runner(lib, geo, stream, a.frames, 2, seed=1000 + rank, branches=branches, passes=a.passes)
     wall, dev_ms = timed(lib, env, dist, head, stream, a.steps, a.warmup, world, pre_warm)
-    nframes = a.steps * a.frames
+    nframes = a.steps * head.frames_per_step()
     gpix = world * nframes * geo.px / wall / 1e9
     kname = head.kernel()
-    gdev = "cpu" if a.dry else "cuda"
+    gdev = ctl_device[0]
     per_rank_wall = gdist.gather_floats(wall_local[0], world, device=gdev)
     per_rank_dev = [int(v) for v in gdist.gather_floats(dev, world, device=gdev)]
     per_rank_numa = [int(v) for v in gdist.gather_floats(numa["node"], world, device=gdev)]
     per_rank_cpus = [int(v) for v in gdist.gather_floats(numa["cpus_bound"], world, device=gdev)]
     # ---- roofline of the dominant kernel: the same frames, launches strictly back to back on ONE stream, HIP events
-    ser = Runner(lib, geo, stream, a.frames, 2, seed=0, branches=1, share=head)
+    ser = Runner(lib, geo, stream, a.frames, 2, seed=0, branches=1, share=head, passes=a.passes)
     _, ser_ms = timed(lib, env, None, ser, stream, a.steps, a.warmup, 1, pre_warm)
     fpl = ser.frames_per_launch()         # frames one launch carries (grid.y): <= 32
     nlaunch = a.steps * ser.launches_per_step()
+    # the distribution behind the average: every launch between its own pair of HIP events, right after the timed run (warm clocks)
+    pl_ms = sorted(ser.per_launch_ms(8 if a.dry else 512))
     ser.close()
     ser_ms = max(ser_ms, 1e-6); dev_ms = max(dev_ms, 1e-6)
     ach = geo.alg_fused * nframes / (ser_ms * 1e-3) / 1e9
@@ -820,27 +875,33 @@ def main():
     if rank == 0 and world == 1 and not a.no_pmc:
         lt = live_traffic(kname, fpl)
         if lt:
-            traffic, traffic_src = lt["bytes_per_launch"], "live: rocprofv3 --pmc FETCH_SIZE (x2) | WRITE_SIZE, separate passes, this run"
+            traffic, traffic_src = lt["bytes_per_launch"], "live rocprofv3 --pmc: FETCH_SIZE x2 | WRITE_SIZE, separate passes"
             detail("traffic_live", lt)
     if traffic is None:
         traffic = committed_traffic(kname, fpl)
-        traffic_src = "committed pass profiles/r03_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None
+        traffic_src = "committed pass profiles/r03_traffic.json" if traffic else None
     out = {
         "metric": "Gpix/s (and % HBM roofline) for 4K nv12->rgb24->1080p bicubic at 1/2/4/8 GPUs",
         "value": round(gpix, 3), "unit": "Gpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{geo.sw}x{geo.sh} nv12 -> {geo.dw}x{geo.dh} rgb24 bicubic (BASELINE configs[2]), device-resident, "
-                               "bit-identical to ONE libswscale context (nv12 2160p -> rgb24 1080p, SWS_BICUBIC)",
-                   "frames_per_step": a.frames, "launch_sets_per_step": head.launches_per_step(), "frames_per_launch_set": head.per_launch,
+                               f"= ONE libswscale context bit for bit; {head.per_launch}-frame launch sets over {branches} streams",
+                   "frames_per_step": head.frames_per_step(), "passes_per_step": a.passes, "distinct_frame_pairs": a.frames,
+                   "launch_sets_per_step": head.launches_per_step(), "frames_per_launch_set": head.per_launch,
                    "streams": branches, "working_set_MB": round(a.frames * (geo.nv12 + geo.rgb_dst) / 1e6),
-                   "pre_warm_ms": pre_warm, "kernel": kname,
-                   "parallelism": f"{world} GPU(s) x independent streams, one process per GPU, no collective"},
+                   "pre_warm_ms": pre_warm, "kernel": kname, "timed_region_s": round(wall, 4),
+                   "parallelism": f"{world} process(es), one per GPU, independent streams, no collective; control plane {backend or 'none'}"
+                                  + (", ALL RANKS ON DEVICE 0 (rehearsal)" if a.same_device else "")},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "frames_per_launch": fpl, "algorithmic_bytes_per_launch": geo.alg_fused * fpl,
                      "avg_launch_us": round(ser_ms * 1e3 / nlaunch, 3), "launches_timed": nlaunch,
-                     "timing": "HIP events on the launch stream, launches back to back on ONE stream",
+                     "timing": "HIP events, ONE stream, launches back to back",
+                     "frac_p50": round(geo.alg_fused * fpl / (pl_ms[len(pl_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "frac_min": round(geo.alg_fused * fpl / (pl_ms[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "frac_max": round(geo.alg_fused * fpl / (pl_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "per_launch_events": len(pl_ms),
                      "frac_overlapped": round(ach_ovl / HBM_PEAK_GBS, 4)},
     }
     head.close()

@@ -13,16 +13,56 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend):
-    """Initialise torch.distributed from the torchrun environment when WORLD_SIZE > 1."""
+_backend = [None]
+
+
+def backend():
+    """the torch.distributed backend init() brought up ("nccl" = RCCL, "gloo"), None for a single rank"""
+    return _backend[0]
+
+
+def init(backend, fallback=None):
+    """Initialise torch.distributed from the torchrun environment when WORLD_SIZE > 1.  Returns (rank, local_rank, world); the
+    backend in use is backend().  `fallback`: tried when `backend` cannot be brought up — the control plane here is a barrier and one MAX, it must never
+    be what takes an 8-GPU run down (RCCL needs dmabuf IPC, HSA_ENABLE_IPC_MODE_LEGACY=0, and refuses two ranks on one device).
+    Every rank takes the same decision: a rank whose first attempt failed and a rank whose attempt succeeded cannot be told apart
+    from inside, so the first backend is PROBED with a one-element all-reduce under a short timeout before it is trusted."""
     rank, local, world = env_rank()
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if not dist.is_initialized():
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    return rank, local, world
+    if world <= 1:
+        return rank, local, world
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if dist.is_initialized():
+        _backend[0] = dist.get_backend()
+        return rank, local, world
+    tries = [backend] + ([fallback] if fallback and fallback != backend else [])
+    last = None
+    for i, b in enumerate(tries):
+        try:
+            # (a second attempt rendezvouses at the same address: torch prefixes every process group's keys with its own count, and
+            # under torchrun the store belongs to the agent, which listens on MASTER_PORT only)
+            dist.init_process_group(b, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120 if b == "nccl" else 600))
+            t = torch.ones(1, device="cuda" if b == "nccl" else "cpu")
+            dist.all_reduce(t)
+            if int(t.item()) != world:
+                raise RuntimeError("control-plane probe returned %r for %d ranks" % (t.item(), world))
+            _backend[0] = b
+            return rank, local, world
+        except Exception as e:                                   # noqa: BLE001 - any failure of the first backend falls through
+            last = e
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:                                    # noqa: BLE001
+                pass
+            if rank == 0:
+                print("gmat_amd.dist: backend %s unavailable (%s)%s" % (b, str(e).splitlines()[0][:200], ", trying " + tries[i + 1] if i + 1 < len(tries) else ""),
+                      flush=True)
+    raise RuntimeError("no torch.distributed backend could be initialised: %r" % (last,))
 
 
 def barrier(world):

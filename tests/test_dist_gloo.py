@@ -80,3 +80,40 @@ def test_bench_self_launches_two_ranks_through_the_library():
     # value = all ranks' pixels over the slowest rank's time
     px = 128 * 32 * d["config"]["frames_per_step"] * d["steps"] * 2
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e9) < 2e-3
+
+
+def test_control_plane_falls_back_when_the_first_backend_cannot_start(tmp_path):
+    """gmat_amd.dist.init(backend, fallback=...): configs[4]'s control plane is a barrier and one MAX — if RCCL cannot be brought up
+    (here: "nccl" in a GPU-less container) every rank falls back to gloo instead of taking the run down, and backend() says which."""
+    import json
+    import textwrap
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        from gmat_amd import dist as gd
+        rank, local, world = gd.init("nccl", fallback="gloo")
+        v = gd.max_over_ranks(float(rank + 1), world)
+        gd.finalize(world)
+        if rank == 0:
+            print(json.dumps({"backend": gd.backend(), "max": v, "world": world}))
+    """) % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"backend": "gloo", "max": 2.0, "world": 2}
+
+
+def test_same_device_rehearsal_flag_runs_two_ranks():
+    """`bench.py --gpus 2 --same-device` (the 8-GPU launch rehearsed on a 1-GPU box: every rank on device 0, control plane gloo);
+    here on the emulated build: the flag parses, the ranks rendezvous on gloo and the last line says what it was"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--same-device", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--no-pipeline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.splitlines()[-1])
+    assert d["n_gpus"] == 2 and "control plane gloo" in d["config"]["parallelism"] and "DEVICE 0" in d["config"]["parallelism"]
