@@ -94,7 +94,9 @@ def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassemb
     # Verified on the GPU and listed (round 3): v_sat_pk_u8_i16 in the strip kernels' colour stage (s2_sat_pk_u8_i16, inline asm).
     # Its result's UPPER half is never consumed — every use goes straight into a v_perm_b32 that selects bytes 0 and 1 — so the
     # question "zeroed or preserved" does not arise; GPU suite bit-exact with it (profiles/r03c_valu_cuts_ab.txt, 4411 passed).
-    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuvg_rgb_kernel")}
+    # Round 4: scale_yuv2s_blk_kernel uses the same S2_SAT2 / S2_JOIN construction (bytes 0 and 1 only); bit-exact on the GPU in both
+    # forms at every launch size (profiles/r04d_block_form_one_frame_per_launch.txt, gpurun r04b: 1391 passed).
+    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel")}
     hits = {}
     for t in disassembly:
         func = "?"
@@ -116,7 +118,7 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
     into the kernel-argument block, or `cond ? P.x : P.y` on members of a struct the compiler keeps in memory each put it there
     silently — scale_yuv1x2_kernel's first build copied its argument block to scratch and ran at 10.4 us per frame.
     (The round-1 tiled kernels scale_rgb_kernel / scale_yuv2x_kernel carry 20 - 188 bytes of it; they are not listed.)"""
-    strip = ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
+    strip = ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
              "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
     hits, seen = {}, set()
     for t in disassembly:
@@ -155,7 +157,7 @@ def test_streaming_stores_are_where_they_were_measured(disassembly):
         plain = sum(v[0] for f, v in stores.items() if key in f)
         nt = sum(v[1] for f, v in stores.items() if key in f)
         return plain, nt
-    for k in ("scale_yuv2s_kernel", "scale_yuv2p_kernel", "scale_yuv3r_kernel", "scale_yuv32r_kernel", "rgb2yuv420s_kernel", "yuv2rgb_kernel",
+    for k in ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuv2p_kernel", "scale_yuv3r_kernel", "scale_yuv32r_kernel", "rgb2yuv420s_kernel", "yuv2rgb_kernel",
               "flip_direct_kernel", "median3x3s_kernel"):
         plain, nt = total(k)
         assert nt > 0, (k, plain, nt)
@@ -188,3 +190,72 @@ def test_inline_asm_memory_instructions_keep_their_distance_from_valu_written_sc
             if re.search(r"\b(global|buffer|flat)_(load|store)", text) and '"s"(' in operands and not text.startswith("s_nop 4"):
                 bad.append((os.path.basename(path), text[:60]))
     assert not bad, bad
+
+
+# ---- an ISA-level hazard lint (round 4): the rules the compiler cannot apply inside an inline-asm string,
+#      checked on the MACHINE CODE of every shipped code object instead of on the asm strings' text --------------------------------------
+def _lint():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_hazard_lint_finds_nothing_in_the_shipped_library(disassembly):
+    """rule A: no VMEM instruction reads an SGPR a VALU instruction wrote fewer than 5 wait states earlier; rule B: no VALU write of the
+    data VGPRs right behind a store of more than 64 bits (k_scale_yuv2x.hip's global_store_dwordx3 is issued from an asm string) — in
+    EVERY function of every gfx950 code object of libgmat_hip.so, whatever source construct made the instruction"""
+    lint = _lint()
+    bad, nvmem = [], 0
+    for t in disassembly:
+        bad += lint.lint(t)
+        nvmem += len(re.findall(r"^\s+(?:buffer|global|flat|scratch)_(?:load|store)", t, re.M))
+    assert nvmem > 5000, nvmem                          # not vacuous: the scan saw the library's memory instructions
+    assert not bad, bad[:6]
+
+
+def test_hazard_lint_rules_on_known_sequences():
+    """the lint itself, on hand-written disassembly: the wait-state count (s_nop N = N + 1), SGPR ranges, the carry-out destinations"""
+    lint = _lint().lint
+    head = "0000000000001000 <k>:\n"
+    bad = lint(head + "\tv_readfirstlane_b32 s4, v1 // 0\n\tv_mov_b32_e32 v2, v3 //\n\tbuffer_store_dword v0, v1, s[4:7], s9 offen //\n")
+    assert len(bad) == 1 and bad[0][1] == "A"
+    ok = lint(head + "\tv_readfirstlane_b32 s4, v1 //\n\ts_nop 4 //\n\tbuffer_store_dword v0, v1, s[4:7], s9 offen //\n")
+    assert not ok
+    ok = lint(head + "\tv_readfirstlane_b32 s4, v1 //\n" + "\tv_mov_b32_e32 v2, v3 //\n" * 5 + "\tglobal_load_dword v0, v1, s[4:5] //\n")
+    assert not ok
+    bad = lint(head + "\tv_readfirstlane_b32 s4, v1 //\n" + "\tv_mov_b32_e32 v2, v3 //\n" * 4 + "\tglobal_load_dword v0, v1, s[4:5] //\n")
+    assert len(bad) == 1                                # four instructions between = four wait states: one short
+    bad = lint(head + "\tv_add_co_u32_e64 v1, s[10:11], v2, v3 //\n\tglobal_store_dword v0, v1, s[10:11] //\n")
+    assert len(bad) == 1                                # the carry-out of a VOP3 add is an SGPR pair a VALU wrote
+    ok = lint(head + "\tv_readfirstlane_b32 s4, v1 //\n\tglobal_store_dword v0, v1, s[8:9] //\n")
+    assert not ok                                       # another register
+    bad = lint(head + "\tglobal_store_dwordx3 v0, v[4:6], off //\n\tv_mov_b32_e32 v5, v9 //\n")
+    assert len(bad) == 1 and bad[0][1] == "B"
+    ok = lint(head + "\tglobal_store_dwordx3 v0, v[4:6], off //\n\tv_mov_b32_e32 v7, v9 //\n")
+    assert not ok
+    ok = lint(head + "\tglobal_store_dwordx2 v0, v[4:5], off //\n\tv_mov_b32_e32 v5, v9 //\n")
+    assert not ok                                       # 64 bits: no hazard
+    bad = lint(head + "\tbuffer_store_dwordx4 v[8:11], v1, s[4:7], 0 offen //\n\tv_perm_b32 v10, v1, v2, v3 //\n")
+    assert len(bad) == 1
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_hazard_lint_catches_the_walkers_store_without_its_guard(tmp_path):
+    """Round 3's fault reproduced on the machine code: the band walker's inline-asm store with its `s_nop 4` taken out, compiled as the
+    library compiles it — in today's layout the planar-chroma RGB instances reload the buffer resource's words from a spill lane
+    (v_readlane_b32 s23) directly in front of the buffer_store that reads them: rule A, 0 wait states.  (The pre-fix source AS
+    COMMITTED, f1442d4^, lints clean: its layout happened to keep the distance — 'dormant', FINDINGS.md R3-walker-bands — which is
+    exactly why a source-string guard was not enough and the shipped code objects are linted on every run.)"""
+    src = open(os.path.join(ROOT, "gmat_amd", "csrc", "k_scale_yuvg.hip")).read()
+    assert src.count('"s_nop 4\\n\\t') == 1
+    bare = tmp_path / "k_scale_yuvg_noguard.hip"
+    bare.write_text(src.replace('"s_nop 4\\n\\t', '"'))
+    obj = tmp_path / "noguard.o"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "--offload-arch=gfx950",
+                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "gmat_amd", "csrc"),
+                        "--cuda-device-only", "-c", str(bare), "-o", str(obj)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad = _lint().lint_file(str(obj))
+    assert bad and all(b[1] == "A" and "scale_yuvg" in b[0] and "buffer_store_dword" in b[2] for b in bad), bad[:4]
