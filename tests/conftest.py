@@ -48,9 +48,12 @@ def dev(request):
     import harness
     from gmat_amd.lib import load
     if request.param == "hip":
-        if os.path.exists("/opt/rocm/bin/hipcc"):       # keep the product library in step with its sources
+        if os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("GMAT_TEST_HIP_LIBRARY"):       # keep the product library in step with its sources
             _make(os.path.join(ROOT, "gmat_amd", "csrc"), "../lib/libgmat_hip.so")
-        lib = load()            # raises loudly if the product library is missing
+        # GMAT_TEST_HIP_LIBRARY: another BUILD of the product sources under test (tests/test_layout_variants.py: the asm-bearing kernels
+        # under -O2 / -Os).  Test infrastructure; the package's own loader has no such switch.
+        alt = os.environ.get("GMAT_TEST_HIP_LIBRARY")
+        lib = load(alt) if alt else load()            # raises loudly if the product library is missing
         if lib.gmat_device_count() <= 0:
             pytest.fail("-m gpu test selected but no HIP device is visible")
         return harness.Dev(lib, "hip")
