@@ -114,9 +114,12 @@ for case in range(n):
             elif op == "p01x":
                 df = rng.choice(["p010le", "p016le"])
                 src = synth_planes(orc, sf, w, h, seed=900 + case)
-                want = alloc_planes(df, w, h, fill=0xCD)
-                L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
-                                     planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h, 1 if sf == "nv12" else 0)
+                if sf == "nv12":                     # no special converter for a semi-planar source on the CPU (swscale_unscaled.c:2108-2112): generic lines
+                    want = orc.sws(src, w, h, sf, w, h, df)
+                else:
+                    want = alloc_planes(df, w, h, fill=0xCD)
+                    L.orc_yuv420_to_p01x(planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                                         planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want]), w, h, 0)
                 a2 = max(al, 2)
                 dd = dev.upload_planes(src, al, ex)
                 got, pads, k = dev.sws(dd, w, h, sf, w, h, df, dst_align=a2 if a2 % 2 == 0 else 2, dst_extra=ex & ~1)

@@ -492,10 +492,16 @@ def test_filter_layer_scale_from_p01x(dev, orc, src_fmt):
         assert (a == b).all()
     res, _, _ = _run_filter_planes(dev, "scale_hip", {"w": 64, "h": 24, "format": "rgba64le"}, src, w, h, src_fmt)
     assert (res[0] == orc.sws(src, w, h, src_fmt, 64, 24, "rgba64le", SWS["bicubic"])[0]).all()
+    # planar 8-bit frames: libswscale's special converter t | t << 8; a semi-planar (nv12) source has none and runs the generic lines, t << 8
+    pl = synth_planes(orc, "yuv420p", w, h, 100)
+    up, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": src_fmt}, pl, w, h, "yuv420p")
+    assert (up[0].view(np.uint16) == pl[0].astype(np.uint16) * 257).all()
+    assert (up[1].view(np.uint16)[:, 0::2] == pl[1].astype(np.uint16) * 257).all()
     nv = synth_planes(orc, "nv12", w, h, 100)
     up, _, _ = _run_filter_planes(dev, "format_hip", {"pix_fmt": src_fmt}, nv, w, h, "nv12")
-    assert (up[0].view(np.uint16) == nv[0].astype(np.uint16) * 257).all()
-    assert (up[1].view(np.uint16) == nv[1].astype(np.uint16) * 257).all()
+    for a, b in zip(up, orc.sws(nv, w, h, "nv12", w, h, src_fmt, SWS["bicubic"])):
+        assert (a == b).all()
+    assert (up[0].view(np.uint16) == nv[0].astype(np.uint16) << 8).all()
 
 
 @pytest.mark.parametrize("bpp", [1, 2, 3, 4])
