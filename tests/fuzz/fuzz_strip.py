@@ -35,7 +35,12 @@ def width():
 for case in range(n):
     os.environ.pop("GMAT_STRIP_ROWS", None)
     if rng.random() < 0.6:
-        os.environ["GMAT_STRIP_ROWS"] = str(rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 31, 64]))
+        os.environ["GMAT_STRIP_ROWS"] = str(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 16, 31, 64]))
+    # both forms of the 4-pair strip kernel: one frame per call is the block-cooperative form by default (round 4); half the cases
+    # keep the walker on it (GMAT_STRIP_BLOCK=0)
+    os.environ.pop("GMAT_STRIP_BLOCK", None)
+    if rng.random() < 0.5:
+        os.environ["GMAT_STRIP_BLOCK"] = "0"
     kind = rng.random()
     if kind < 0.75:
         # ---- 2:1 scale ---------------------------------------------------------------------------------------------
@@ -130,7 +135,7 @@ for case in range(n):
         if bad:
             fails += 1
             print("MISMATCH case", case, sf, "->", df, (sw, sh, dw, dh), algo, "cs", cs, "align", (align, extra), "rows",
-                  os.environ.get("GMAT_STRIP_ROWS"), kernel, "bad bytes", bad)
+                  os.environ.get("GMAT_STRIP_ROWS"), "block", os.environ.get("GMAT_STRIP_BLOCK"), kernel, "bad bytes", bad)
     else:
         # ---- 1 2 1 smooth, plain and fused with rotate + flip -----------------------------------------------------------
         bpp = rng.choice([1, 2, 3, 4]); fused = rng.random() < 0.5 and bpp >= 3
@@ -161,6 +166,7 @@ for case in range(n):
             fails += 1
             print("MISMATCH case", case, "fused" if fused else "smooth", (w, h, bpp), "align", (align, extra), "rc", r)
 os.environ.pop("GMAT_STRIP_ROWS", None)
+os.environ.pop("GMAT_STRIP_BLOCK", None)
 for k, v in sorted(hist.items(), key=lambda kv: -kv[1]):
     print(f"   {v:6d}  {k}")
 print("cases", n, "failures", fails)
