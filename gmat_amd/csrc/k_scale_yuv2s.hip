@@ -1236,13 +1236,14 @@ static int wave_slots(int vgprs)
     return cus[dev] * 4 * perSimd;
 }
 
-// which form a launch of nframes frames takes: the block-cooperative kernel up to GMAT_STRIP_BLOCK frames (default 2; 0 = never),
-// the walker beyond — and for the 6-pair filters always
+// which form a launch of nframes frames takes: the block-cooperative kernel up to GMAT_STRIP_BLOCK frames (default 3; 0 = never),
+// the walker beyond — and for the 6-pair filters always.  Per frame, block form / walker (profiles/r04d_*): 1 frame 6.49 / 6.70 us,
+// 2: 4.90 / 5.50, 3: 4.38 / 4.74, 4: 4.08 / 4.01, 8: 3.51 / 3.42, 32: 3.70 / 3.53
 bool yuv2s_block_form(const Yuv2sArgs &a, int nframes)
 {
     if (a.np != 4) return false;
     const char *e = GMAT_KNOB("GMAT_STRIP_BLOCK");
-    const int upTo = e ? atoi(e) : 2;
+    const int upTo = e ? atoi(e) : 3;
     return nframes <= upTo;
 }
 

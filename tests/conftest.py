@@ -80,7 +80,7 @@ def kern(request):
         os.environ["GMAT_SCALE_NO_STRIP"] = "1"
     else:
         os.environ.pop("GMAT_SCALE_NO_STRIP", None)
-    # (one frame per call: the block-cooperative form of the strip kernel; launches of more than two frames take the walker,
+    # (one frame per call: the block-cooperative form of the strip kernel; launches of more than three frames take the walker,
     # scale_yuv2s_kernel — tests/test_parity_strip.py holds both forms to the oracle at every launch size)
     yield "scale_yuv2x_kernel" if request.param == "tiled" else "scale_yuv2s_blk_kernel"
     if old is None:

@@ -74,10 +74,10 @@ def test_strip_segmentation_does_not_change_the_result(dev, orc, strip_rows, str
 
 
 def test_strip_form_follows_the_launch_size(dev, orc, strip_rows):
-    """the shipped rule (no knob): a launch of one or two frames is the block-cooperative kernel, a larger one the walker"""
+    """the shipped rule (no knob): a launch of up to three frames is the block-cooperative kernel, a larger one the walker"""
     strip_rows(0)
     os.environ.pop("GMAT_STRIP_BLOCK", None)
-    for n, want in ((1, "scale_yuv2s_blk_kernel"), (2, "scale_yuv2s_blk_kernel"), (3, "scale_yuv2s_kernel"), (5, "scale_yuv2s_kernel")):
+    for n, want in ((1, "scale_yuv2s_blk_kernel"), (2, "scale_yuv2s_blk_kernel"), (3, "scale_yuv2s_blk_kernel"), (4, "scale_yuv2s_kernel"), (7, "scale_yuv2s_kernel")):
         assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=n, nstreams=1, align=16) == want
 
 
