@@ -176,7 +176,7 @@ int launch_conv3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStrid
                    const OpFrames *frames = nullptr, int nframes = 1);
 // smooth_nvcv type=gaussian in general: kw x kh (odd, <= kGaussMaxTaps), sigmaX / sigmaY (<= 0: OpenCV's default rule),
 // border 0 constant, 1 replicate, 2 reflect, 3 wrap, 4 reflect101; float32 accumulation in a stated order
-constexpr int kGaussMaxTaps = 31;
+constexpr int kGaussMaxTaps = 255;     // both axes; the weights travel in the kernel-argument segment (2 x 255 floats); vf_median.c caps its radius at 127 too
 int launch_gauss_blur(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp, int kw, int kh,
                       double sigmaX, double sigmaY, int border, hipStream_t stream);
 // per-channel 3x3 median, window rows / columns clamped at the edges (vf_median.c semantics at radius 1)

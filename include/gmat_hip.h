@@ -222,7 +222,8 @@ GMAT_API void gmat_host_frame_free(GmatFrame *frame);
  *                   the default request (3x3 gaussian, no sigma, no border_type) = integer kernel 1 2 1 / 2 4 2 / 1 2 1,
  *                   rdiv 1/16 (vf_convolution.c:495-512 arithmetic and :555-569 borders); any of kw / kh / sigmaX /
  *                   sigmaY / border_type given -> gmat_gauss_blur's float kernel with that border rule; median:
- *                   kw = kh = 3 (other sizes ENOSYS), gaussian-only options refused with EINVAL
+ *                   any odd kw x kh up to 255 (vf_median.c's rule), gaussian-only options refused with EINVAL; gaussian windows up to
+ *                   255 taps an axis (beyond: ENOSYS)
  *    scale_hip   <- vf_scale_cuda.c   options (:586-603) on top of libgpuscale: w / h expressions (iw ih ow oh a sar dar
  *                   hsub vsub ohsub ovsub, + - * / ( ) min max trunc floor ceil round abs; -1 / -n as scale_eval.c:113-175),
  *                   interp_algo, format, passthrough (default 1: a frame whose size and format already match is handed on
@@ -267,7 +268,7 @@ GMAT_API int gmat_crop(const uint8_t *src, int srcStride, uint8_t *dst, int dstS
                        int x, int y, int w, int h, int bpp, void *stream);
 GMAT_API int gmat_smooth3x3(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride,
                             int w, int h, int bpp, const int matrix[9], float rdiv, float bias, void *stream);
-/* smooth_nvcv type=gaussian with its options (vf_smooth_nvcv.c:88-105): kw x kh odd and <= 31, sigmaX / sigmaY (<= 0:
+/* smooth_nvcv type=gaussian with its options (vf_smooth_nvcv.c:88-105): kw x kh odd and <= 255 (the reference takes any int; beyond 255: -ENOSYS), sigmaX / sigmaY (<= 0:
  * derived from the kernel size; sigmaY <= 0: sigmaX), border_type 0 constant(0) 1 replicate 2 reflect 3 wrap 4 reflect101.
  * CV-CUDA's arithmetic is pinned by nothing in the reference; the rule is OpenCV's (cv::getGaussianKernel,
  * cv::borderInterpolate) with float32 accumulation in raster order and out = clip((int)(sum + 0.5f)) — stated in
@@ -305,7 +306,7 @@ GMAT_API int gmat_rotate2(const uint8_t *src, int srcStride, uint8_t *dst, int d
  * reference tree: the rule is its documented one in THIS library's (vf_rotate.c's, clockwise-positive) sense of rotation — unpinned. */
 GMAT_API void gmat_rotate_shift_translation(double angle_rad, double shift_x, double shift_y, int inW, int inH, int outW, int outH,
                                             double *tx, double *ty);
-/* per-channel median of a kw x kh window (odd, <= 31), vf_median.c's rule at radius (kw - 1) / 2, radiusV (kh - 1) / 2 */
+/* per-channel median of a kw x kh window (odd, <= 255: vf_median.c caps its radius at 127), vf_median.c's rule at radius (kw - 1) / 2, radiusV (kh - 1) / 2 */
 GMAT_API int gmat_median(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h, int bpp,
                          int kw, int kh, void *stream);
 /* rotate(90 clockwise) + horizontal flip + 3x3 smooth in ONE kernel (cfg4 fused form) */

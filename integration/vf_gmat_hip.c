@@ -490,8 +490,8 @@ static const AVOption smooth_hip_options[] = {
     { "type", "0 default = 1 gaussian, 2 median", OFFSET(type), AV_OPT_TYPE_INT, { .i64 = 0 }, 0, 2, FLAGS, "type" },
         { "gaussian", "gaussian blur", 0, AV_OPT_TYPE_CONST, { .i64 = 1 }, 0, 0, FLAGS, "type" },
         { "median",   "median blur",   0, AV_OPT_TYPE_CONST, { .i64 = 2 }, 0, 0, FLAGS, "type" },
-    { "kw", "kernel width",  OFFSET(kw), AV_OPT_TYPE_INT, { .i64 = 3 }, 1, 31, FLAGS },
-    { "kh", "kernel height", OFFSET(kh), AV_OPT_TYPE_INT, { .i64 = 3 }, 1, 31, FLAGS },
+    { "kw", "kernel width",  OFFSET(kw), AV_OPT_TYPE_INT, { .i64 = 3 }, 1, 255, FLAGS },
+    { "kh", "kernel height", OFFSET(kh), AV_OPT_TYPE_INT, { .i64 = 3 }, 1, 255, FLAGS },
     { "border_type", "border rule of the gaussian (-1: the 3x3 integer kernel's own)", OFFSET(border_type), AV_OPT_TYPE_INT, { .i64 = -1 }, -1, 4, FLAGS, "border_type" },
         { "constant",   NULL, 0, AV_OPT_TYPE_CONST, { .i64 = 0 }, 0, 0, FLAGS, "border_type" },
         { "replicate",  NULL, 0, AV_OPT_TYPE_CONST, { .i64 = 1 }, 0, 0, FLAGS, "border_type" },

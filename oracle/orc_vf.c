@@ -450,7 +450,7 @@ static void orc_gauss_1d(int k, double sigma, float *out)
 {
     static const double tab[4][7] = {{1.0}, {0.25, 0.5, 0.25}, {0.0625, 0.25, 0.375, 0.25, 0.0625},
                                      {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125}};
-    double cf[64], total = 0, sg, s2;
+    double cf[256], total = 0, sg, s2;
     int i;
     if (sigma <= 0 && k <= 7) {
         for (i = 0; i < k; i++) out[i] = (float)tab[k >> 1][i];
@@ -469,9 +469,9 @@ static void orc_gauss_1d(int k, double sigma, float *out)
 int orc_gauss_blur(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int bpp,
                    int kw, int kh, double sigma_x, double sigma_y, int border)
 {
-    float kx[64], ky[64];
+    float kx[256], ky[256];
     int x, y, ch, i, j;
-    if (kw < 1 || kh < 1 || kw > 63 || kh > 63 || !(kw & 1) || !(kh & 1) || border < 0 || border > 4) return -1;
+    if (kw < 1 || kh < 1 || kw > 255 || kh > 255 || !(kw & 1) || !(kh & 1) || border < 0 || border > 4) return -1;
     orc_gauss_1d(kw, sigma_x, kx);
     orc_gauss_1d(kh, sigma_y > 0 ? sigma_y : sigma_x, ky);
     for (y = 0; y < h; y++)

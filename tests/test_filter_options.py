@@ -39,7 +39,8 @@ def _cfg(dev, name, opts, w, h, fmt="rgb24"):
 # ---- gaussian: kw x kh, sigma, borders ----------------------------------------------------------------------------
 @pytest.mark.parametrize("border", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", [(3, 3, 0.0, 0.0), (5, 5, 0.0, 0.0), (7, 3, 0.0, 0.0), (9, 9, 0.0, 0.0), (5, 11, 1.7, 0.0),
-                                  (3, 3, 2.0, 0.5), (1, 1, 0.0, 0.0), (31, 31, 6.0, 6.0), (13, 1, 0.0, 3.0)])
+                                  (3, 3, 2.0, 0.5), (1, 1, 0.0, 0.0), (31, 31, 6.0, 6.0), (13, 1, 0.0, 3.0),
+                                  (63, 5, 0.0, 0.0), (3, 101, 20.0, 0.0), (255, 1, 40.0, 0.0)])       # round 4: windows up to 255 taps an axis
 @pytest.mark.parametrize("bpp", [1, 3, 4])
 def test_gauss_blur_matches_the_stated_rule(dev, orc, case, border, bpp):
     kw, kh, sx, sy = case
@@ -83,12 +84,14 @@ def test_smooth_options_have_effect_or_are_refused(dev, orc):
     res, _, _ = _run_filter(dev, "smooth_hip", {"border_type": "warp"}, src, w, h)          # the reference's spelling of wrap
     assert (res == want(3, 3, 0, 0, 3)).all()
     assert _cfg(dev, "smooth_hip", {"kw": 4}, w, h)[0] < 0                 # even
-    assert _cfg(dev, "smooth_hip", {"kw": 33, "kh": 33}, w, h)[0] < 0      # beyond the implemented size
+    assert _cfg(dev, "smooth_hip", {"kw": 33, "kh": 33}, w, h)[0] == 0     # (round 4: up to 255 taps an axis)
+    assert _cfg(dev, "smooth_hip", {"kw": 257, "kh": 3}, w, h)[0] < 0      # beyond the implemented size
     assert _cfg(dev, "smooth_hip", {"border_type": "mirror"}, w, h)[0] < 0
     assert _cfg(dev, "smooth_hip", {"sigmaX": -1}, w, h)[0] < 0
     assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 5, "kh": 5}, w, h)[0] == 0    # vf_median.c's rule at radius 2 (round 3)
     assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 4, "kh": 5}, w, h)[0] < 0     # even
-    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 33, "kh": 3}, w, h)[0] < 0    # beyond the implemented size
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 33, "kh": 3}, w, h)[0] == 0
+    assert _cfg(dev, "smooth_hip", {"type": "median", "kw": 257, "kh": 3}, w, h)[0] < 0   # vf_median.c's radius ends at 127
     assert _cfg(dev, "smooth_hip", {"type": "median", "border_type": "reflect"}, w, h)[0] < 0   # gaussian-only option
     assert _cfg(dev, "smooth_hip", {"type": "median", "sigmaX": 1}, w, h)[0] < 0
     assert _cfg(dev, "smooth_hip", {"type": "boxcar"}, w, h)[0] < 0
