@@ -70,7 +70,7 @@ struct GPlane {
 #endif
     template <int NW> __device__ __forceinline__ void ld(unsigned lane, unsigned row, unsigned (&w)[NW]) const
     {
-        static_assert(NW >= 2 && NW <= 12, "window dwords");
+        static_assert(NW >= 2 && NW <= 16, "window dwords");
         int i = 0;
 #pragma unroll
         for (; i + 4 <= NW; i += 4) ld4(lane + 4u * i, row, w + i);
@@ -589,7 +589,8 @@ static void fill_qprog(YuvGQProg &v, int K)
 
 // K = output rows open at once.  The plane jobs have the registers for 12 and 15 as well (57-67 VGPRs at K = 9): 4:2:0 -> 4:2:0
 // UP-scales up to 2:1 (720p -> 1080p needs 10, 1080p -> 1440p 10, 1:2 14-15); an RGB destination needs 14-22 there and stays tiled.
-static const int kGP[] = {4, 5, 6, 8, 10}, kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
+// P = 13 (round 4): 26 taps — bicubic down to 6.2 : 1 (4K -> 360p), bilinear / area twice as far
+static const int kGP[] = {4, 5, 6, 8, 10, 13}, kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
 
 int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
@@ -720,7 +721,7 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
 #define GMAT_G_P4() do { \
         if (!a.yuvOut && a.K > 9) switch (a.K) { case 15: GMAT_G_RGB(4, 15); break; case 18: GMAT_G_RGB(4, 18); break; default: GMAT_G_RGB(4, 22); } \
         else GMAT_G_P(4); } while (0)
-    switch (a.P) { case 4: GMAT_G_P4(); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; default: GMAT_G_P(10); }
+    switch (a.P) { case 4: GMAT_G_P4(); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; case 10: GMAT_G_P(10); break; default: GMAT_G_P(13); }
 #undef GMAT_G_P
 #undef GMAT_G_P4
 #undef GMAT_G_PL

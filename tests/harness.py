@@ -71,7 +71,7 @@ def is_generic(kernel):
 def walker_takes(sw, sh, sf, df, dw, dh):
     """the host rule of yuvg_prepare / yuvg_eligible restated for dword-aligned frames and bicubic-sized filters: 8-bit 4:2:0 in,
     packed 8-bit RGB (even width: an odd one forces libswscale's full-chroma output) or 4:2:0 of the SAME chroma layout out, whole
-    dwords in every source row, at least 16 x 8 on both sides, and a ratio on both axes between about 4.7 : 1 (filters of at most
+    dwords in every source row, at least 16 x 8 on both sides, and a ratio on both axes between about 6.1 : 1 (round 4: filters of at most 26 taps on 13 coefficient pairs; round 3 ended at 4.7 : 1,
     20 taps) and 1 : 1.9 (output rows open at once: up to 15 in the plane jobs of a 4:2:0 destination, up to 22 in the four-pair
     instances of an RGB destination, whose chroma plane is up-scaled twice as far as its luma).  Callers keep away from the ends."""
     rgb = df in ("rgb24", "bgr24", "rgba", "bgra")
@@ -83,7 +83,7 @@ def walker_takes(sw, sh, sf, df, dw, dh):
         return False
     if not (dw >= 16 and dh >= 8 and sw >= 16 and sh >= 8):
         return False
-    return 0.53 <= sw / dw <= 4.7 and 0.53 <= sh / dh <= 4.7
+    return 0.53 <= sw / dw <= 6.1 and 0.53 <= sh / dh <= 6.1
 
 
 def ptr(a):

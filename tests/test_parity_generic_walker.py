@@ -19,7 +19,7 @@ G = "scale_yuvg_kernel"
 GEOMS = [(384, 216, 160, 90), (768, 432, 273, 153), (960, 540, 214, 120), (480, 272, 192, 108), (480, 270, 214, 120),
          (640, 360, 200, 150), (160, 90, 240, 136), (128, 72, 320, 180), (400, 100, 100, 240), (200, 120, 67, 41),
          (264, 64, 64, 24), (264, 64, 66, 22), (264, 64, 130, 31), (128, 48, 16, 8), (520, 36, 173, 12),
-         (1920, 108, 768, 44)]
+         (1920, 108, 768, 44), (768, 432, 128, 72), (1280, 360, 240, 64), (600, 300, 100, 56)]       # (round 4: 5.3 - 6 : 1, P = 13)
 RGB = ["rgb24", "bgr24", "rgba", "bgra"]
 
 

@@ -317,6 +317,8 @@ int main(int argc, char **argv)
         {"any: nv12 4K->1366x768 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1366, 768, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->854x480 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->854x480 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 854, 480, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->640x360 rgb24 bicubic (6:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 640, 360, GMAT_SWS_BICUBIC},
+        {"any: nv12 4K->640x360 nv12 bicubic (6:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 640, 360, GMAT_SWS_BICUBIC},
         {"any: nv12 1080p->768x432 rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 768, 432, GMAT_SWS_BICUBIC},
         {"any: nv12 1080p->768x432 nv12 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 768, 432, GMAT_SWS_BICUBIC},
         {"any: nv12 1080p->854x480 rgb24 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
