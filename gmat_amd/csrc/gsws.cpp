@@ -459,11 +459,11 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
 }
 
 // the 2:1 kernel reads whole 16-byte chunks: luma and NV12 chroma rows 16-byte, planar chroma rows 8-byte aligned
-static bool yuv2x_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, const uint8_t *const src[], const int srcStride[])
+static bool yuv2x_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     return c->y2x.ok && !c->rangeConv && ya.srcAligned &&
-           ((((uintptr_t)src[0] | (uintptr_t)srcStride[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 15) == 0) &&
-           (ya.nv12 || ((((uintptr_t)src[2] | (uintptr_t)srcStride[2]) & 7) == 0 && (((uintptr_t)src[1] | (uintptr_t)srcStride[1]) & 7) == 0));
+           ((((uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us) & 15) == 0) &&
+           (ya.nv12 || ((((uintptr_t)ya.v | (uintptr_t)ya.vs) & 7) == 0 && (((uintptr_t)ya.u | (uintptr_t)ya.us) & 7) == 0));
 }
 
 static Yuv2xArgs make_yuv2x_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
@@ -777,6 +777,73 @@ static const char *yuv2p_name(const GmatSwsContext *c)
     return s == 8 ? (d == 8 ? "scale_yuv2p_kernel" : "scale_yuv2p_kernel<8to10>") : (d == 8 ? "scale_yuv2p_kernel<10to8>" : "scale_yuv2p16_kernel");
 }
 
+// ---- the kernels of the single-context plane scaler, ONE record each, in priority order (round 4: rounds 2-3 spelled this list out
+// twice — a 110-line if-chain in gmat_sws_scale and 13 use* flags with their own launch loops in sws_scale_frames_batched) -----------------
+// eligible: this context / this frame's pointers and pitches satisfy the kernel's rule (a batch: every frame must).  launch: n frames
+// of the table through one launch (n = 1: what sws_scale() issues).  The exact-ratio walkers' geometries are disjoint, so the order
+// only matters inside a ratio (2:1: strip walker / 4:4:4 luma walker / plane walker before the tiled kernel) and for the two catch-alls.
+struct PlaneKernel {
+    bool (*eligible)(const GmatSwsContext *c, const YuvScaleArgs &ya);
+    const char *(*name)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);
+    int (*launch)(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t stream, const Yuv2xFrames &fr, int n);
+};
+static const PlaneKernel kPlaneKernels[] = {
+    {yuv2s_eligible,
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
+         return c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(make_yuv2s_args(c, ya), n) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv2s(make_yuv2s_args(c, ya), st, &fr, n); }},
+    {yuv2p444_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return yuv2p444_name(ya); },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         // luma of all frames in one launch, the chroma re-layout frame by frame (its kernels take one frame)
+         Yuv2pArgs pa = make_yuv2p_args(c, ya);
+         pa.lumaOnly = 1; pa.cross = 0; pa.srcDepth = pa.dstDepth = 8;
+         int r = launch_scale_yuv2p(pa, st, &fr, n);
+         for (int i = 0; i < n && r >= 0; i++) r = yuv2p444_chroma(c, ya, fr.u[i], ya.nv12 ? nullptr : fr.v[i], fr.dstU[i], fr.dstV[i], st);
+         return r; }},
+    {yuv2p_eligible,
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuv2p_name(c); },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv2p(make_yuv2p_args(c, ya), st, &fr, n); }},
+    {yuv1x2_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv1x2_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv1x2(make_yuv1x2_args(c, ya), st, &fr, n); }},
+    {yuv4r_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv4r_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv4r(make_yuv4r_args(c, ya), st, &fr, n); }},
+    {yuv32r_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv32r_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv32r(make_yuv32r_args(c, ya), st, &fr, n); }},
+    {yuv3r_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3r_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3r(make_yuv3r_args(c, ya), st, &fr, n); }},
+    {rgb2y_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_rgb2y_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_rgb2y(make_rgb2y_args(c, ya), st, &fr, n); }},
+    {yuv3x1_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3x1_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3x1(make_yuv3x1_args(c, ya), st, &fr, n); }},
+    {yuv3x2_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3x2_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3x2(make_yuv3x2_args(c, ya), st, &fr, n); }},
+    {yuv4x1_eligible,
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv4x1_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv4x1(make_yuv4x1_args(c, ya), st, &fr, n); }},
+    {yuv2x_eligible,                                   // the tiled 2:1 kernel of round 1: behind every 2:1 walker
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return c->y2x.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         const Yuv2xArgs xa = make_yuv2x_args(c, ya);
+         return n == 1 ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st)      // (one frame: the pointers of the argument block)
+                       : launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st, &fr, n); }},
+    {yuvg_eligible,                                    // any ratio: the polyphase band walker
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvg_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
+    {[](const GmatSwsContext *, const YuvScaleArgs &) { return true; },      // everything else: the tiled plane scaler
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
+};
+constexpr int kNumPlaneKernels = (int)(sizeof(kPlaneKernels) / sizeof(kPlaneKernels[0]));
+
 // argument block of the strip-walking packed-RGB scaler
 static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)
 {
@@ -984,143 +1051,26 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     }
     if (c->mode != MODE_SCALE || !(is_plane_src(c->srcFormat) || c->rgbViaPlanes) || c->fused != 2) return 0;
     if (ensure_scaler(c) < 0 || c->fused != 2) return 0;
-    // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch);
-    // the 2:1 kernel when all of them are eligible for it, else the generic plane scaler
+    // every frame must fall in the same alignment class (the flags select vector or byte paths for the whole launch), and the
+    // kernel is the first of the table that takes EVERY frame
     YuvScaleArgs ya0;
-    bool use4x1 = true;
-    bool use2x = true, use2s = true, use2p = true, use1x2 = true, use3x1 = true, use3x2 = true, use444 = true, useR2y = true, use3r = true, use32r = true, use4r = true;
-    bool useG = true;
+    bool can[kNumPlaneKernels];
+    for (int k = 0; k < kNumPlaneKernels; k++) can[k] = true;
     for (int f = 0; f < n; f++) {
         YuvScaleArgs ya;
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
         int r = prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya);
         if (r < 0) return r;
-        use2x = use2x && yuv2x_eligible(c, ya, src_planes + 4 * f, srcStride);
-        use2s = use2s && yuv2s_eligible(c, ya);
-        use2p = use2p && yuv2p_eligible(c, ya);
-        use1x2 = use1x2 && yuv1x2_eligible(c, ya);
-        use3x1 = use3x1 && yuv3x1_eligible(c, ya);
-        use3x2 = use3x2 && yuv3x2_eligible(c, ya);
-        use4x1 = use4x1 && yuv4x1_eligible(c, ya);
-        use444 = use444 && yuv2p444_eligible(c, ya);
-        useR2y = useR2y && rgb2y_eligible(c, ya);
-        use3r = use3r && yuv3r_eligible(c, ya);
-        use32r = use32r && yuv32r_eligible(c, ya);
-        use4r = use4r && yuv4r_eligible(c, ya);
-        useG = useG && yuvg_eligible(c, ya);
+        for (int k = 0; k < kNumPlaneKernels; k++) can[k] = can[k] && kPlaneKernels[k].eligible(c, ya);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
+    int pick = 0;
+    while (!can[pick]) pick++;                         // (the last record takes everything)
+    const PlaneKernel &K = kPlaneKernels[pick];
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
     const bool planarDst = c->dstFormat == GMAT_PIX_FMT_YUV420P || c->dstFormat == GMAT_PIX_FMT_YUV444P || c->dstFormat == GMAT_PIX_FMT_YUV420P10LE;
-    if (use4r) {
-        const Yuv4rArgs ta = make_yuv4r_args(c, ya0);
-        c->lastKernel = "scale_yuv4r_kernel";
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.v[i] = ta.nv12 ? nullptr : src_planes[4 * (f0 + i) + 2]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
-            int r = launch_scale_yuv4r(ta, stream, &fr, m);
-            if (r < 0) return r;
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    if (use32r) {
-        const Yuv32rArgs ta = make_yuv32r_args(c, ya0);
-        c->lastKernel = "scale_yuv32r_kernel";
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
-            int r = launch_scale_yuv32r(ta, stream, &fr, m);
-            if (r < 0) return r;
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    if (use3r) {
-        const Yuv3rArgs ta = make_yuv3r_args(c, ya0);
-        c->lastKernel = "scale_yuv3r_kernel";
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.u[i] = src_planes[4 * (f0 + i) + 1]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
-            int r = launch_scale_yuv3r(ta, stream, &fr, m);
-            if (r < 0) return r;
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    if (useR2y) {
-        const Rgb2yArgs ra = make_rgb2y_args(c, ya0);
-        c->lastKernel = "scale_rgb2y_kernel";
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) {
-                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-                fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = ra.nv12 ? nullptr : dp[2];
-            }
-            int r = launch_scale_rgb2y(ra, stream, &fr, m);
-            if (r < 0) return r;
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    if (use444) {
-        // luma of all frames in one launch per 32, the chroma re-layout frame by frame (its kernels take one frame)
-        Yuv2pArgs pa = make_yuv2p_args(c, ya0);
-        pa.lumaOnly = 1; pa.cross = 0; pa.srcDepth = pa.dstDepth = 8;
-        c->lastKernel = yuv2p444_name(ya0);
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
-            int r = launch_scale_yuv2p(pa, stream, &fr, m);
-            if (r < 0) return r;
-            for (int i = 0; i < m; i++) {
-                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
-                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-                if ((r = yuv2p444_chroma(c, ya0, sp[1], ya0.nv12 ? nullptr : sp[2], dp[1], dp[2], stream)) < 0) return r;
-            }
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    if (useG && !(use2s || use2p || use1x2 || use3x1 || use3x2 || use4x1 || use2x)) {
-        const YuvGArgs ga = make_yuvg_args(c, ya0);
-        c->lastKernel = "scale_yuvg_kernel";
-        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
-            Yuv2xFrames fr;
-            const int m = std::min(kYuv2xMaxFrames, n - f0);
-            std::memset(&fr, 0, sizeof(fr));
-            for (int i = 0; i < m; i++) {
-                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
-                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = ga.nv12 ? nullptr : sp[2];
-                fr.dst[i] = dp[0]; fr.dstU[i] = ga.yuvOut ? dp[1] : nullptr; fr.dstV[i] = ga.yuvOut && !ga.nv12 ? dp[2] : nullptr;
-            }
-            int r = launch_scale_yuvg(ga, stream, &fr, m);
-            if (r < 0) return r;
-            c->lastLaunchFrames = m;
-        }
-        return 1;
-    }
-    const Yuv2xArgs xa = use2x ? make_yuv2x_args(c, ya0) : Yuv2xArgs();
-    const Yuv2sArgs sa = use2s ? make_yuv2s_args(c, ya0) : Yuv2sArgs();
-    const Yuv2pArgs pa = use2p ? make_yuv2p_args(c, ya0) : Yuv2pArgs();
-    const Yuv1x2Args ua = use1x2 ? make_yuv1x2_args(c, ya0) : Yuv1x2Args();
-    const Yuv3x1Args da = use3x1 ? make_yuv3x1_args(c, ya0) : Yuv3x1Args();
-    const Yuv3x2Args ea = use3x2 ? make_yuv3x2_args(c, ya0) : Yuv3x2Args();
-    const Yuv4x1Args qa = use4x1 ? make_yuv4x1_args(c, ya0) : Yuv4x1Args();
-    c->lastKernel = use2s ? (c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(sa, std::min(kYuv2xMaxFrames, n)) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel") : use2p ? yuv2p_name(c) : use1x2 ? "scale_yuv1x2_kernel" : use3x1 ? "scale_yuv3x1_kernel" : use3x2 ? "scale_yuv3x2_kernel" : use4x1 ? "scale_yuv4x1_kernel" : !use2x ? yuvscale_kernel_name(c->ytiling) : xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         Yuv2xFrames fr;
         const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -1128,17 +1078,11 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         for (int i = 0; i < m; i++) {
             const uint8_t *const *sp = src_planes + 4 * (f0 + i);
             uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-            fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = planarSrc ? sp[2] : nullptr;
+            fr.y[i] = sp[0]; fr.u[i] = c->rgbViaPlanes ? nullptr : sp[1]; fr.v[i] = planarSrc ? sp[2] : nullptr;
             fr.dst[i] = dp[0]; fr.dstU[i] = yuvDst ? dp[1] : nullptr; fr.dstV[i] = planarDst ? dp[2] : nullptr;
         }
-        int r = use2s ? launch_scale_yuv2s(sa, stream, &fr, m)
-              : use2p ? launch_scale_yuv2p(pa, stream, &fr, m)
-              : use1x2 ? launch_scale_yuv1x2(ua, stream, &fr, m)
-              : use3x1 ? launch_scale_yuv3x1(da, stream, &fr, m)
-              : use3x2 ? launch_scale_yuv3x2(ea, stream, &fr, m)
-              : use4x1 ? launch_scale_yuv4x1(qa, stream, &fr, m)
-              : use2x ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, stream, &fr, m)
-                      : launch_scale_yuv(ya0, c->ytiling, stream, &fr, m);
+        c->lastKernel = K.name(c, ya0, m);
+        int r = K.launch(c, ya0, stream, fr, m);
         if (r < 0) return r;
         c->lastLaunchFrames = m;
     }
@@ -1819,115 +1763,14 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) {
             YuvScaleArgs ya;
             if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
-            // one frame per call: the strip kernel with short segments (7.5 us per 4K frame against 10.2 us for the tiled one)
-            if (yuv2s_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
-                const Yuv2sArgs sa1 = make_yuv2s_args(c, ya);
-                c->lastKernel = c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(sa1, 1) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel";
-                r = launch_scale_yuv2s(sa1, c->stream, &one, 1);
-                break;
-            }
-            if (yuv2p444_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.dst[0] = ya.dst;
-                Yuv2pArgs pa = make_yuv2p_args(c, ya);
-                pa.lumaOnly = 1; pa.cross = 0; pa.srcDepth = pa.dstDepth = 8;
-                c->lastKernel = yuv2p444_name(ya);
-                if ((r = launch_scale_yuv2p(pa, c->stream, &one, 1)) < 0) break;
-                r = yuv2p444_chroma(c, ya, ya.u, ya.v, ya.dstU, ya.dstV, c->stream);
-                break;
-            }
-            if (yuv2p_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = yuv2p_name(c);
-                r = launch_scale_yuv2p(make_yuv2p_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv1x2_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_yuv1x2_kernel";
-                r = launch_scale_yuv1x2(make_yuv1x2_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv4r_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst;
-                c->lastKernel = "scale_yuv4r_kernel";
-                r = launch_scale_yuv4r(make_yuv4r_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv32r_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.dst[0] = ya.dst;
-                c->lastKernel = "scale_yuv32r_kernel";
-                r = launch_scale_yuv32r(make_yuv32r_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv3r_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.dst[0] = ya.dst;
-                c->lastKernel = "scale_yuv3r_kernel";
-                r = launch_scale_yuv3r(make_yuv3r_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (rgb2y_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_rgb2y_kernel";
-                r = launch_scale_rgb2y(make_rgb2y_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv3x1_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_yuv3x1_kernel";
-                r = launch_scale_yuv3x1(make_yuv3x1_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv3x2_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_yuv3x2_kernel";
-                r = launch_scale_yuv3x2(make_yuv3x2_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv4x1_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_yuv4x1_kernel";
-                r = launch_scale_yuv4x1(make_yuv4x1_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            if (yuv2x_eligible(c, ya, src, srcStride)) {
-                const Yuv2xArgs xa = make_yuv2x_args(c, ya);
-                c->lastKernel = xa.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel";
-                r = launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, c->stream);
-                break;
-            }
-            if (yuvg_eligible(c, ya)) {
-                Yuv2xFrames one;
-                std::memset(&one, 0, sizeof(one));
-                one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
-                c->lastKernel = "scale_yuvg_kernel";
-                r = launch_scale_yuvg(make_yuvg_args(c, ya), c->stream, &one, 1);
-                break;
-            }
-            c->lastKernel = yuvscale_kernel_name(c->ytiling);
-            r = launch_scale_yuv(ya, c->ytiling, c->stream);
+            // one frame per call: the first kernel of the table that takes this frame (kPlaneKernels)
+            Yuv2xFrames one;
+            std::memset(&one, 0, sizeof(one));
+            one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
+            int pick = 0;
+            while (!kPlaneKernels[pick].eligible(c, ya)) pick++;
+            c->lastKernel = kPlaneKernels[pick].name(c, ya, 1);
+            r = kPlaneKernels[pick].launch(c, ya, c->stream, one, 1);
             break;
         }
         ScaleArgs a = c->args;
