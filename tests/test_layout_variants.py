@@ -20,6 +20,9 @@ def test_layout_variants_exist_where_they_can_be_built():
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc here")
     assert len(VARIANTS) >= 2, "run tools/build_layout_variants.sh (__graft_entry__.build() does)"
+    newest = max(os.path.getmtime(f) for f in glob.glob(os.path.join(ROOT, "gmat_amd", "csrc", "*")) if os.path.isfile(f))
+    for v in VARIANTS:                                  # a variant older than the sources tests yesterday's kernels
+        assert os.path.getmtime(v) >= newest, "%s is older than gmat_amd/csrc: run tools/build_layout_variants.sh" % v
 
 
 @pytest.mark.parametrize("lib", VARIANTS, ids=lambda p: os.path.basename(os.path.dirname(p)))
