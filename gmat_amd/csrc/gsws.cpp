@@ -260,6 +260,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
             if ((r = up(m.prog, g.prog[d])) < 0 || (r = up(m.qfirst, g.qfirst[d])) < 0 || (r = up(m.qdone, g.qdone[d])) < 0) return r;
             if (t.yuvOut && ((r = up(t.pc[d].prog, g.progC[d])) < 0 || (r = up(t.pc[d].qfirst, g.qfirstC[d])) < 0 || (r = up(t.pc[d].qdone, g.qdoneC[d])) < 0)) return r;
         }
+        if ((r = up(t.vtL, g.vtL)) < 0 || (r = up(t.vtC, g.vtC)) < 0) return r;
+        g.n4L = t.n4L; g.n4C = t.n4C; g.blkRows = t.blkRows; g.blkRowsC = t.blkRowsC;
         g.roundL = t.roundL; g.roundC = t.roundC;
         g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
     }
@@ -779,20 +781,21 @@ static const char *yuv2p_name(const GmatSwsContext *c)
 
 // ---- the kernels of the single-context plane scaler, ONE record each, in priority order (round 4: rounds 2-3 spelled this list out
 // twice — a 110-line if-chain in gmat_sws_scale and 13 use* flags with their own launch loops in sws_scale_frames_batched) -----------------
-// eligible: this context / this frame's pointers and pitches satisfy the kernel's rule (a batch: every frame must).  launch: n frames
+// eligible: this context / this frame's pointers and pitches satisfy the kernel's rule (a batch: every frame must; n = the frames of
+// the call — only the one-frame form in front of the exact-ratio walkers looks at it).  launch: n frames
 // of the table through one launch (n = 1: what sws_scale() issues).  The exact-ratio walkers' geometries are disjoint, so the order
 // only matters inside a ratio (2:1: strip walker / 4:4:4 luma walker / plane walker before the tiled kernel) and for the two catch-alls.
 struct PlaneKernel {
-    bool (*eligible)(const GmatSwsContext *c, const YuvScaleArgs &ya);
+    bool (*eligible)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);      // n: frames of the whole call
     const char *(*name)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);
     int (*launch)(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t stream, const Yuv2xFrames &fr, int n);
 };
 static const PlaneKernel kPlaneKernels[] = {
-    {yuv2s_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv2s_eligible(c, ya); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
          return c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(make_yuv2s_args(c, ya), n) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv2s(make_yuv2s_args(c, ya), st, &fr, n); }},
-    {yuv2p444_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv2p444_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return yuv2p444_name(ya); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          // luma of all frames in one launch, the chroma re-layout frame by frame (its kernels take one frame)
@@ -801,43 +804,56 @@ static const PlaneKernel kPlaneKernels[] = {
          int r = launch_scale_yuv2p(pa, st, &fr, n);
          for (int i = 0; i < n && r >= 0; i++) r = yuv2p444_chroma(c, ya, fr.u[i], ya.nv12 ? nullptr : fr.v[i], fr.dstU[i], fr.dstV[i], st);
          return r; }},
-    {yuv2p_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv2p_eligible(c, ya); },
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuv2p_name(c); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv2p(make_yuv2p_args(c, ya), st, &fr, n); }},
-    {yuv1x2_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv1x2_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv1x2_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv1x2(make_yuv1x2_args(c, ya), st, &fr, n); }},
-    {yuv4r_eligible,
+    // a call of few frames (what sws_scale() / filter_frame() issue): the band walker's block-cooperative form IN FRONT of the exact-ratio
+    // walkers it beats at that launch size (measured, profiles/r04p_blk_vs_ratio_kernels.txt: per-ratio kernel / block form, us a launch) —
+    // 4:1 at one to three frames (-> nv12 11.2 / 8.6, 16.6 / 12.6, 20.1 / 16.5; -> rgb24 10.2 / 9.1, 16.0 / 15.4, 21.4 / 18.6), 3:1 and 3:2 to
+    // packed RGB at ONE frame (9.9 / 9.1, 8.7 / 7.8; at two and three frames the exact-ratio walkers are level or ahead).  The 3:1 / 3:2 plane
+    // walkers keep their frames at every size (7.4 against 8.8, 5.1 against 6.6).  GMAT_BLOCK_FIRST=0: never in front
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) {
+         if (!yuvg_eligible(c, ya) || yuv3x1_eligible(c, ya) || yuv3x2_eligible(c, ya)) return false;
+         const bool four = yuv4r_eligible(c, ya) || yuv4x1_eligible(c, ya), threeRgb = yuv32r_eligible(c, ya) || yuv3r_eligible(c, ya);
+         if (!(four || (threeRgb && n == 1))) return false;          // (every other context reaches the form in the band walker's own place)
+         const char *bf = GMAT_KNOB("GMAT_BLOCK_FIRST");
+         return !(bf && !atoi(bf)) && yuvg_block_form(make_yuvg_args(c, ya), n); },
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvg_blk_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv4r_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv4r_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv4r(make_yuv4r_args(c, ya), st, &fr, n); }},
-    {yuv32r_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv32r_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv32r_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv32r(make_yuv32r_args(c, ya), st, &fr, n); }},
-    {yuv3r_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv3r_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3r_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3r(make_yuv3r_args(c, ya), st, &fr, n); }},
-    {rgb2y_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return rgb2y_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_rgb2y_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_rgb2y(make_rgb2y_args(c, ya), st, &fr, n); }},
-    {yuv3x1_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv3x1_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3x1_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3x1(make_yuv3x1_args(c, ya), st, &fr, n); }},
-    {yuv3x2_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv3x2_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv3x2_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv3x2(make_yuv3x2_args(c, ya), st, &fr, n); }},
-    {yuv4x1_eligible,
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv4x1_eligible(c, ya); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuv4x1_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuv4x1(make_yuv4x1_args(c, ya), st, &fr, n); }},
-    {yuv2x_eligible,                                   // the tiled 2:1 kernel of round 1: behind every 2:1 walker
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv2x_eligible(c, ya); },                                   // the tiled 2:1 kernel of round 1: behind every 2:1 walker
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return c->y2x.yuvOut ? "scale_yuv2x_kernel<yuv>" : "scale_yuv2x_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          const Yuv2xArgs xa = make_yuv2x_args(c, ya);
          return n == 1 ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st)      // (one frame: the pointers of the argument block)
                        : launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st, &fr, n); }},
-    {yuvg_eligible,                                    // any ratio: the polyphase band walker
-     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvg_kernel"; },
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
-    {[](const GmatSwsContext *, const YuvScaleArgs &) { return true; },      // everything else: the tiled plane scaler
+    {[](const GmatSwsContext *, const YuvScaleArgs &, int) { return true; },      // everything else: the tiled plane scaler
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
@@ -1061,7 +1077,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
         int r = prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya);
         if (r < 0) return r;
-        for (int k = 0; k < kNumPlaneKernels; k++) can[k] = can[k] && kPlaneKernels[k].eligible(c, ya);
+        for (int k = 0; k < kNumPlaneKernels; k++) can[k] = can[k] && kPlaneKernels[k].eligible(c, ya, n);
         if (f == 0) ya0 = ya;
         else if (ya.dstAligned != ya0.dstAligned || ya.srcAligned != ya0.srcAligned || ya.srcAligned16 != ya0.srcAligned16) return 0;
     }
@@ -1768,7 +1784,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             std::memset(&one, 0, sizeof(one));
             one.y[0] = ya.y; one.u[0] = ya.u; one.v[0] = ya.v; one.dst[0] = ya.dst; one.dstU[0] = ya.dstU; one.dstV[0] = ya.dstV;
             int pick = 0;
-            while (!kPlaneKernels[pick].eligible(c, ya)) pick++;
+            while (!kPlaneKernels[pick].eligible(c, ya, 1)) pick++;
             c->lastKernel = kPlaneKernels[pick].name(c, ya, 1);
             r = kPlaneKernels[pick].launch(c, ya, c->stream, one, 1);
             break;

@@ -517,6 +517,232 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
 }
 
+// ---- the block-cooperative form: a launch of ONE frame (or a few) --------------------------------------------------------------------
+// What sws_scale() / filter_frame() issue is one frame, and a band walker is the wrong shape for it: too few waves to fill the chip
+// unless the bands are short, and every short band pays its vertical windows' lead-in again, row after row in one wave's dependent
+// chain (4K -> 720p rgb24 alone: 9.9 us a frame on the 3:1 walker against 3.5 batched).  Here a BLOCK owns 64 output columns of a
+// band of rows and its four waves share the work twice:
+//   1. horizontally — the band's source row pairs are dealt round the waves (pair i to wave i & 3); a wave requests ALL of its pairs
+//      at once (J pairs of registers: no ring, nothing waits for anything but the data), filters each through its wave-private row
+//      image exactly as the walker does (GStream::gather / hpair) and leaves the packed pair of 15-bit samples in LDS;
+//   2. one barrier;
+//   3. vertically — output row y0 + i belongs to wave i & 3: its taps are dot products over the LDS column of filtered pairs,
+//      coefficient pairs by OUTPUT row from the host (wave-uniform: scalar loads, four pairs a group), then the walker's output stage.
+// Every filtered row is computed once per band (the lead-in is still per band, but in parallel), no running sums, no program of quads.
+// Same arithmetic as the walker operation by operation: hScale8To15_c's sums in tap order, the vertical sum from the same start value
+// over the same taps (integer adds commute), the same colour stage.
+constexpr int kGBlkJL = 8, kGBlkJC = 5;  // row pairs a wave requests at once: luma / the chroma of an RGB destination
+constexpr int kGBlkPad = 16;             // LDS pair slots past the band's own: a row's last group of four may reach there (its taps are 0)
+constexpr int kGBlkHead = 2;             // dwords in front of an output row's coefficient pairs: first row pair, last row pair
+
+// all of a wave's row pairs requested, filtered and left in hs[pair slot][lane]; the band's pairs are [pa, pb], this wave's pa + wave + 4 j
+template <int P, bool S2, int SD, int J, class Ld>
+__device__ __forceinline__ void g_blk_hpass(GStream<P, S2, SD, J> &W, Ld &&ld, int pa, int pb, int wave, int lane, unsigned stride, int (*hs)[64])
+{
+    // every slot is requested, the ones past the band's last pair as that pair again (a cache hit): with no load under a branch the
+    // compiler counts its waits, and the first pair is filtered while the others are still on their way
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const unsigned off = (unsigned)(2 * min(pa + wave + 4 * j, pb)) * stride;
+#pragma unroll
+        for (int s = 0; s < SD; s++) { W.ring[j][0][s] = ld(W.ldOff[s], off); W.ring[j][1][s] = ld(W.ldOff[s], off + stride); }
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++)
+        if (pa + wave + 4 * j <= pb) {
+            W.gather(W.ring[j]);
+            hs[wave + 4 * j][lane] = W.hpair();
+        }
+}
+// one output row's vertical sum of this lane's column: n4 groups of four coefficient pairs from row pair slot `base` on
+__device__ __forceinline__ int g_blk_vsum(const int32_t *row, int n4, const int (*hs)[64], int base, int lane, int start)
+{
+    int acc = start;
+    for (int g = 0; g < n4; g++) {
+        const int c0 = uniform_load(row, kGBlkHead + 4 * g), c1 = uniform_load(row, kGBlkHead + 4 * g + 1);
+        const int c2 = uniform_load(row, kGBlkHead + 4 * g + 2), c3 = uniform_load(row, kGBlkHead + 4 * g + 3);
+        const int (*h)[64] = hs + base + 4 * g;
+        acc = g_dot2(h[0][lane], c0, acc); acc = g_dot2(h[1][lane], c1, acc);
+        acc = g_dot2(h[2][lane], c2, acc); acc = g_dot2(h[3][lane], c3, acc);
+    }
+    return acc;
+}
+
+// packed RGB destinations: block = 64 output columns x a.bandRows output rows; grid.y = frame
+template <int P, bool NV12>
+__global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
+{
+    constexpr int SD = P >= 8 ? 2 : 1, JL = kGBlkJL, JC = kGBlkJC;
+    __shared__ int2 lutV[256], lutU[256];
+    __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
+    __shared__ int hLs[4 * JL + kGBlkPad][64], hCs[4 * JC + kGBlkPad][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const Yuv2RgbConsts &k = a.y2r;
+        const int i = tid;
+        lutV[i] = make_int2(k.base + m24(k.offR + (m24(i, k.crv) >> 16), k.cy), m24(m24(i, k.cgv) >> 16, k.cy));
+        lutU[i] = make_int2(k.base + m24(k.offG + (m24(i, k.cgu) >> 16), k.cy), k.base + m24(k.offB + (m24(i, k.cbu) >> 16), k.cy));
+    }
+    int lin = blockIdx.x;
+    if (a.xcdRemap) { const int chunk = (a.nblk + 7) >> 3; lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3); }
+    if (lin >= a.nblk) return;
+    const int band = lin / a.nsg;                                     // (a.nsg: 64-column strips per row of blocks in this form)
+    const int X0 = (lin - band * a.nsg) * 64;
+    const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
+    const int f = blockIdx.y;
+    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW);
+    const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW);
+    const GPlane bU(fr.u[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb), bV(NV12 ? fr.u[f] : fr.v[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb);
+    const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+    const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
+    const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
+
+    const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
+    GStream<P, false, SD, JL> L;
+    GStream<P, NV12, SD, JC> C;
+    {
+        // (the lane mapping of scale_yuvg_rgb_kernel; the row segment's start — lane 0's window — from a SCALAR load, so that the row
+        // requests do not wait for the lanes' own table entries)
+        const int w0 = L.setup(a.hL, a.posL, xc, 0);
+        const int seg = uniform_load(a.posL, X0) & ~3;
+        L.winDw = (w0 - seg) >> 2;
+#pragma unroll
+        for (int s = 0; s < SD; s++) { L.ldDw[s] = lane + 64 * s; L.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+        L.img = image[wave][0];
+    }
+    {
+        const int w0 = C.setup(a.hC, a.posC, min(xc >> 1, a.chrDstW - 1), par);
+        const int pos0 = uniform_load(a.posC, min(X0 >> 1, a.chrDstW - 1));
+        const int seg = (NV12 ? 2 * pos0 : pos0) & ~3;
+        if (NV12) {
+            C.winDw = (w0 - seg) >> 2;
+#pragma unroll
+            for (int s = 0; s < SD; s++) { C.ldDw[s] = lane + 64 * s; C.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+        } else {
+            C.winDw = par * 32 * SD + ((w0 - seg) >> 2);
+#pragma unroll
+            for (int s = 0; s < SD; s++) { const int j = (lane & 31) + 32 * s; C.ldDw[s] = (lane >> 5) * 32 * SD + j; C.ldOff[s] = (unsigned)seg + 4u * (unsigned)j; }
+        }
+        C.img = image[wave][1];
+    }
+    auto ldL = [&](unsigned off, unsigned row) { unsigned v; bY.ld1(off, row, &v); return v; };
+    auto ldC = [&](unsigned off, unsigned row) {
+        unsigned v;
+        if (NV12 || lane < 32) bU.ld1(off, row, &v); else bV.ld1(off, row, &v);
+        return v;
+    };
+    const int sL = kGBlkHead + 4 * a.n4L, sC = kGBlkHead + 4 * a.n4C;
+    const int paL = uniform_load(a.vtL, y0 * sL), pbL = uniform_load(a.vtL, (y1 - 1) * sL + 1);
+    const int paC = uniform_load(a.vtC, y0 * sC), pbC = uniform_load(a.vtC, (y1 - 1) * sC + 1);
+    g_blk_hpass(L, ldL, paL, pbL, wave, lane, (unsigned)a.ys, hLs);
+    g_blk_hpass(C, ldC, paC, pbC, wave, lane, (unsigned)a.us, hCs);
+    __syncthreads();
+
+    const unsigned dsel = (unsigned)((lane & 3) == 0 ? 0x04020100u : (lane & 3) == 1 ? 0x05040201u : 0x06050402u);
+#define GMAT_G_QUAD(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true)
+    for (int y = y0 + wave; y < y1; y += 4) {
+        const int32_t *rl = a.vtL + (size_t)y * sL, *rc = a.vtC + (size_t)y * sC;
+        const int accL = g_blk_vsum(rl, a.n4L, hLs, uniform_load(rl, 0) - paL, lane, a.roundL);
+        const int accC = g_blk_vsum(rc, a.n4C, hCs, uniform_load(rc, 0) - paC, lane, a.roundC);
+        // the colour stage and the store of scale_yuvg_rgb_kernel's emit()
+        const int Y = accL >> 19;
+        const int mine = clip_u8_shr(accC, 19), other = GMAT_G_QUAD(mine, 0xB1);
+        const int U = par ? other : mine, V = par ? mine : other;
+        const int2 tv = lutV[V], tu = lutU[U];
+        const int ycy = m24(Y, a.y2r.cy);
+        const unsigned cr = (unsigned)((bgr ? tu.y : tv.x) + ycy), cg = (unsigned)(tv.y + tu.x + ycy), cb = (unsigned)((bgr ? tv.x : tu.y) + ycy);
+        const unsigned rg = g_sat_pk_u8_i16(__builtin_amdgcn_perm(cg, cr, 0x07060302u));
+        const unsigned ba = g_sat_pk_u8_i16(__builtin_amdgcn_perm(0x00FF0000u, cb, 0x07060302u));
+        const unsigned px = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+        const unsigned drow = (unsigned)y * (unsigned)a.ds;
+        if (bpp == 4) {
+            if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
+        } else {
+            const unsigned nxt = (unsigned)GMAT_G_QUAD(px, 0xF9);
+            const unsigned o = __builtin_amdgcn_perm(nxt, px, dsel);
+            const int nb = 3 * min(64, a.dstW - X0);
+            const int ob = 12 * (lane >> 2) + 4 * (lane & 3);
+            if ((lane & 3) != 3) {
+                if (ob + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + (unsigned)ob, drow);
+                else if (ob < nb) {
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + (unsigned)ob;
+                    for (int i = 0; i < nb - ob; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+        }
+    }
+#undef GMAT_G_QUAD
+}
+
+// 4:2:0 destinations: block = 64 byte columns x a band of rows of ONE plane job (luma | interleaved chroma | U | V, as scale_yuvg_planes_kernel)
+template <int P, bool NV12>
+__global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
+{
+    constexpr int SD = P >= 8 ? 2 : 1, J = kGBlkJL;
+    __shared__ unsigned image[4][2 * 64 * SD];
+    __shared__ int hS[4 * J + kGBlkPad][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) { const int chunk = (a.nblk + 7) >> 3; lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3); }
+    if (lin >= a.nblk) return;
+    const int f = blockIdx.y;
+    int job = 0, rel = lin;
+    if (lin >= a.nblkL) { rel = lin - a.nblkL; job = 1; if (!NV12 && rel >= a.nblkC) { rel -= a.nblkC; job = 2; } }
+    const int nsg = job ? a.nsgC : a.nsg;
+    const int band = rel / nsg;
+    const int B0 = (rel - band * nsg) * 64;                         // first BYTE column of this block in the destination plane row
+    const int rowBytes = job == 0 ? a.dstW : NV12 ? 2 * a.chrDstW : a.chrDstW;
+    const int rows = job ? a.chrDstH : a.dstH, srcRows = job ? a.chrSrcH : a.srcH;
+    const int bandRows = job ? a.bandRowsC : a.bandRows;
+    const int y0 = band * bandRows, y1 = min(y0 + bandRows, rows);
+    const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
+    uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
+    const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
+    const int srcRowBytes = job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW;
+    const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes);
+    const int bcol = min(B0 + lane, rowBytes - 1);
+    const int32_t *vt = job ? a.vtC : a.vtL;
+    const int n4 = job ? a.n4C : a.n4L, sV = kGBlkHead + 4 * n4;
+    const int rnd = job ? a.roundC : a.roundL;
+    auto run = [&](auto s2_c) {
+        constexpr bool S2 = decltype(s2_c)::value;
+        GStream<P, S2, SD, J> W;
+        {
+            const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
+            const int pos0 = uniform_load(job ? a.posC : a.posL, S2 ? B0 >> 1 : B0);      // lane 0's window (B0 is even), by a scalar load
+            const int seg = (S2 ? 2 * pos0 : pos0) & ~3;
+            W.winDw = (w0 - seg) >> 2;
+#pragma unroll
+            for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+            W.img = image[wave];
+        }
+        auto ld = [&](unsigned off, unsigned row) { unsigned v; bS.ld1(off, row, &v); return v; };
+        const int pa = uniform_load(vt, y0 * sV), pb = uniform_load(vt, (y1 - 1) * sV + 1);
+        g_blk_hpass(W, ld, pa, pb, wave, lane, (unsigned)ss, hS);
+        __syncthreads();
+        for (int y = y0 + wave; y < y1; y += 4) {
+            const int32_t *rv = vt + (size_t)y * sV;
+            const int acc = g_blk_vsum(rv, n4, hS, uniform_load(rv, 0) - pa, lane, rnd);
+            // the output stage of scale_yuvg_planes_kernel's emit()
+            const unsigned v = (unsigned)clip_u8_shr(acc, 19);
+            const unsigned drow = (unsigned)y * (unsigned)dstride;
+            const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);          // quad_perm:[1,1,3,3]
+            const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);       // quad_perm:[2,2,2,2]
+            const int nb = min(64, rowBytes - B0);
+            if ((lane & 3) == 0) {
+                if (lane + 4 <= nb) bD.st1(o, (unsigned)B0 + (unsigned)lane, drow);
+                else if (lane < nb) {
+                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + (unsigned)lane;
+                    for (int i = 0; i < nb - lane; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+        }
+    };
+    if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -668,15 +894,108 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
         if (rgbOut ? !fits(p.hChr, 32, nv12, nv12 ? 256 * SD : 128 * SD) : !fits(p.hChr, nv12 ? 32 : 64, nv12, 256 * SD)) return 0;
     }
     t.P = P; t.K = K; t.yuvOut = yuvOut;
+    // the block-cooperative form's vertical tables (by output row, walking down) and the tallest band whose row pairs fit a block:
+    // checked for EVERY start row, so that the launcher may cut bands of any height up to it anywhere
+    {
+        auto vtab = [&](const FilterBank &fb, std::vector<int32_t> &out, int &n4) {
+            const int npv = fb.taps / 2 + 1;                          // row pairs a window can touch (it may start on an odd row)
+            n4 = (npv + 3) / 4;
+            const int stride = kGBlkHead + 4 * n4;
+            out.assign((size_t)fb.count * stride, 0);
+            for (int y = 0; y < fb.count; y++) {
+                const int pos = fb.pos[y], p0 = pos >> 1;
+                int32_t *r = &out[(size_t)y * stride];
+                r[0] = p0; r[1] = (pos + fb.taps - 1) >> 1;
+                for (int k = 0; k < 4 * n4; k++) {
+                    const int t0 = 2 * (p0 + k) - pos, t1 = t0 + 1;
+                    const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)y * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)y * fb.taps + t1] : 0;
+                    r[kGBlkHead + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+                }
+            }
+        };
+        // the tallest band (rows, <= cap) that fits J pairs a wave from any start row
+        auto tallest = [&](const std::vector<int32_t> &vt, int n4, int count, int J, int cap) {
+            const int stride = kGBlkHead + 4 * n4;
+            int best = cap;
+            for (int y0 = 0; y0 < count && best > 0; y0++) {
+                const int pa = vt[(size_t)y0 * stride];
+                int fit = 0;
+                for (int y = y0; y < std::min(count, y0 + best); y++) {
+                    const int p0 = vt[(size_t)y * stride], pl = vt[(size_t)y * stride + 1];
+                    if (pl - pa + 1 > 4 * J || p0 - pa + 4 * n4 > 4 * J + kGBlkPad) break;
+                    fit = y - y0 + 1;
+                }
+                if (y0 + fit < count || fit == best) best = std::min(best, fit);      // (a band cut short by the plane's end fits whatever its nominal height)
+            }
+            return best;
+        };
+        vtab(g.vLumEff, t.vtL, t.n4L);
+        vtab(g.vChrEff, t.vtC, t.n4C);
+        if (rgbOut) {
+            const int rows = std::min(tallest(t.vtL, t.n4L, g.vLumEff.count, kGBlkJL, 32), tallest(t.vtC, t.n4C, g.vChrEff.count, kGBlkJC, 32)) & ~3;
+            t.blkRows = rows; t.blkRowsC = 0;
+        } else {
+            const int rl = tallest(t.vtL, t.n4L, g.vLumEff.count, kGBlkJL, 32) & ~3, rc = tallest(t.vtC, t.n4C, g.vChrEff.count, kGBlkJL, 16) & ~1;
+            t.blkRows = std::min(rl, 2 * rc) & ~3; t.blkRowsC = t.blkRows / 2;
+        }
+        if (t.n4L > 4 || t.n4C > 4) t.blkRows = 0;                    // (windows of more than 16 row pairs: the walker alone)
+    }
     if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
                                           p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
     t.ok = 1;
     return 0;
 }
 
+// a launch of few frames takes the block-cooperative form (GMAT_STRIP_BLOCK=n: launches of up to n frames, default 3; 0: never)
+bool yuvg_block_form(const YuvGArgs &a, int nframes)
+{
+    if (a.blkRows < 4 || !a.vtL || !a.vtC) return false;
+    const char *bs = GMAT_KNOB("GMAT_STRIP_BLOCK");
+    return nframes <= (bs ? atoi(bs) : 3);
+}
+
+static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+{
+    YuvGArgs a = a0;
+    const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override: output rows per band
+    const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;
+    a.nsg = (a.dstW + 63) / 64;
+    // band height: tall bands pay the vertical windows' lead-in less often, short ones fill the chip — a block per CU and SIMD pair at least
+    int rows = a.blkRows;
+    if (rowsEnv > 0) rows = std::min(a.blkRows, std::max(4, rowsEnv & ~3));
+    else {
+        // measured, one frame a launch (profiles/r04n_blk_rows_sweep.txt): the tallest band that still leaves four blocks a CU
+        const int jobs = a.yuvOut ? 2 : 1;                           // (a 4:2:0 destination's chroma jobs: as many blocks again, half as tall)
+        while (rows > 8 && (long)a.nsg * ((a.dstH + rows - 1) / rows) * nframes * jobs < 1024) rows -= 4;
+    }
+    a.bandRows = rows;
+    a.nbands = (a.dstH + rows - 1) / rows;
+    a.nblkL = a.nbands * a.nsg;
+    a.nblk = a.nblkL;
+    if (a.yuvOut) {
+        const int cbytes = a.nv12 ? 2 * a.chrDstW : a.chrDstW;
+        a.nsgC = (cbytes + 63) / 64;
+        a.bandRowsC = rows / 2;
+        a.nbandsC = (a.chrDstH + a.bandRowsC - 1) / a.bandRowsC;
+        a.nblkC = a.nbandsC * a.nsgC;
+        a.nblk = a.nblkL + (a.nv12 ? 1 : 2) * a.nblkC;
+    }
+    const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
+#define GMAT_GB(P_) do { \
+        if (a.yuvOut) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true>), grid, block, 0, stream, a, fr); \
+                        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false>), grid, block, 0, stream, a, fr); } \
+        else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, true>), grid, block, 0, stream, a, fr); \
+                        else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, false>), grid, block, 0, stream, a, fr); } } while (0)
+    switch (a.P) { case 4: GMAT_GB(4); break; case 5: GMAT_GB(5); break; case 6: GMAT_GB(6); break; case 8: GMAT_GB(8); break; case 10: GMAT_GB(10); break; default: GMAT_GB(13); }
+#undef GMAT_GB
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    if (yuvg_block_form(a0, nframes)) return launch_scale_yuvg_blk(a0, stream, *frames, nframes);
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;

@@ -324,6 +324,10 @@ struct YuvGTables {
     std::vector<int32_t> hL, hC, posL, posC;                  // [dstW][P] / [chrDstW][P] packed coefficient pairs, window starts
     YuvGQProg rgb[2];                                         // RGB destination: luma + chroma; [0] walking down, [1] walking up (mirrored)
     YuvGQProg pl[2], pc[2];                                   // 4:2:0 destination: the luma plane / a chroma plane on its own
+    // the block-cooperative form (a launch of few frames): per output row [first row pair, last row pair, 4 n4 coefficient pairs on the
+    // row pairs from the first one on]; blkRows: the tallest band (output rows, a multiple of 4) whose row pairs fit a block at ANY start row
+    std::vector<int32_t> vtL, vtC;
+    int n4L = 0, n4C = 0, blkRows = 0, blkRowsC = 0;
 };
 struct YuvGArgs {
     int ys, us, vs, nv12;
@@ -335,10 +339,14 @@ struct YuvGArgs {
     const int32_t *progC[2], *qfirstC[2], *qdoneC[2];         // the chroma jobs of a 4:2:0 destination
     // filled by the launcher: rows per band, 4-strip groups per row, blocks (luma | chroma jobs of a 4:2:0 destination)
     int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap, updown, bandStep, bandStepC;
+    // the block-cooperative form: vertical tables by output row, groups of 4 coefficient pairs a row, the tallest bands that fit
+    const int32_t *vtL, *vtC;
+    int n4L, n4C, blkRows, blkRowsC;
     Yuv2RgbConsts y2r;
 };
 int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
 int  launch_scale_yuvg(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launch of nframes frames takes scale_yuvg_blk_*_kernel
 
 // ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> YUV 4:2:0 scaler (k_scale_yuv2p.hip): NV12 -> NV12 and
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------

@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from gmat_amd.lib import planes, ints, PIX_FMT, SWS  # noqa: F401
 
@@ -65,7 +66,15 @@ def is_generic(kernel):
     (scale_yuvg_kernel: dword-aligned 8-bit 4:2:0 -> packed RGB / 4:2:0 of the same chroma layout, filters up to 20 x 18 taps) or
     the tiled plane scaler of round 1 behind it (scale_yuv_kernel<...>).  WHICH of the two a context gets is asserted by
     tests/test_parity_generic_walker.py clause by clause; the per-ratio test files only need "not a specialised walker"."""
-    return kernel == "scale_yuvg_kernel" or kernel.startswith("scale_yuv_kernel")
+    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel") or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4)
+
+
+@pytest.fixture(autouse=True)
+def ratio_kernels_keep_single_frames(monkeypatch):
+    """round 4: a call of one frame (4:1: up to three) takes the band walker's block-cooperative form IN FRONT of the 4:1 walkers and of the
+    3:1 / 3:2 -> RGB walkers (gsws.cpp kPlaneKernels; tests/test_parity_generic_walker.py::test_block_form_in_front_of_the_ratio_walkers holds
+    the rule).  The per-ratio parity files import this fixture to keep every launch size on the kernel they are about."""
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0")
 
 
 def walker_takes(sw, sh, sf, df, dw, dh):

@@ -369,11 +369,15 @@ def test_4k_batched_launch_equals_single_launches(gpu, orc, dst_fmt):
 @pytest.mark.parametrize("which", ["walker", "tiled"])
 @pytest.mark.parametrize("df", ["rgb24", "nv12"])
 @pytest.mark.parametrize("geom", [(3840, 2160, 1600, 900), (3840, 2160, 1366, 768), (3840, 2160, 854, 480), (1920, 1080, 768, 432)])
-def test_any_ratio_full_size(gpu, orc, monkeypatch, which, df, geom):
+@pytest.mark.parametrize("form", ["walk", "blk"])
+def test_any_ratio_full_size(gpu, orc, monkeypatch, which, df, geom, form):
     """4K -> 1600x900 / 1366x768 / 854x480 and 1080p -> 768x432, to nv12 and to rgb24, on the polyphase
     band walker (scale_yuvg_kernel) and on the tiled plane scaler behind it — both bit-exact with one libswscale context"""
     if which == "tiled":
+        if form == "blk":
+            pytest.skip("one tiled kernel")
         monkeypatch.setenv("GMAT_SCALE_NO_GENERIC_WALKER", "1")
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "0" if form == "walk" else "3")      # a single frame: the walker / its block-cooperative form (round 4)
     sw, sh, dw, dh = geom
     src = synth_planes(orc, "nv12", sw, sh, seed=61)
     want = orc.sws(src, sw, sh, "nv12", dw, dh, df)
@@ -383,6 +387,6 @@ def test_any_ratio_full_size(gpu, orc, monkeypatch, which, df, geom):
         bad = np.argwhere(g != w)
         assert bad.size == 0, f"{k} plane {i}: {len(bad)} mismatching bytes, first {bad[:3].tolist()}"
         assert (pads[i] == 0xCD).all()
-    assert (k == "scale_yuvg_kernel") == (which == "walker"), k
+    assert (k == ("scale_yuvg_kernel" if form == "walk" else "scale_yuvg_blk_kernel")) == (which == "walker"), k
     for p in d:
         p.free()

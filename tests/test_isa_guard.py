@@ -96,7 +96,9 @@ def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassemb
     # question "zeroed or preserved" does not arise; GPU suite bit-exact with it (profiles/r03c_valu_cuts_ab.txt, 4411 passed).
     # Round 4: scale_yuv2s_blk_kernel uses the same S2_SAT2 / S2_JOIN construction (bytes 0 and 1 only); bit-exact on the GPU in both
     # forms at every launch size (profiles/r04d_block_form_one_frame_per_launch.txt, gpurun r04b: 1391 passed).
-    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel")}
+    # scale_yuvg_blk_rgb_kernel: the band walker's colour stage, same construction (g_sat_pk_u8_i16 -> v_perm_b32 of bytes 0 and 1); bit-exact
+    # on the GPU (gpurun r04m / r04o: tests/test_parity_generic_walker.py in both forms, 518 passed).
+    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel", "scale_yuvg_blk_rgb_kernel")}
     hits = {}
     for t in disassembly:
         func = "?"
@@ -119,7 +121,7 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
     silently — scale_yuv1x2_kernel's first build copied its argument block to scratch and ran at 10.4 us per frame.
     (The round-1 tiled kernels scale_rgb_kernel / scale_yuv2x_kernel carry 20 - 188 bytes of it; they are not listed.)"""
     strip = ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
-             "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
+             "scale_yuvg_blk_rgb_kernel", "scale_yuvg_blk_planes_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
     hits, seen = {}, set()
     for t in disassembly:
         func = None

@@ -12,6 +12,7 @@ import pytest
 from harness import is_generic, SWS, synth_planes
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
+from harness import ratio_kernels_keep_single_frames  # noqa: F401  (autouse: this file is about the exact-ratio kernel at every launch size)
 
 D32R = "scale_yuv32r_kernel"
 

@@ -11,6 +11,7 @@ import pytest
 from harness import is_generic, SWS, synth_planes
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
+from harness import ratio_kernels_keep_single_frames  # noqa: F401  (autouse: this file is about the exact-ratio kernel at every launch size)
 
 D4R = "scale_yuv4r_kernel"
 

@@ -11,7 +11,36 @@ from harness import SWS, synth_planes, walker_takes, is_generic
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
 
-G = "scale_yuvg_kernel"
+import os
+
+GW, GB = "scale_yuvg_kernel", "scale_yuvg_blk_kernel"
+
+
+class _Form:
+    """the name the band walker reports: its block-cooperative form (round 4: a launch of up to GMAT_STRIP_BLOCK frames, default 3 — what
+    one sws_scale() call gets) or the walker itself.  Compares equal to the name the current setting of the knob asks for."""
+    def _want(self):
+        return GB if os.environ.get("GMAT_STRIP_BLOCK", "3") != "0" else GW
+
+    def __eq__(self, k):
+        return k == self._want()
+
+    def __ne__(self, k):
+        return k != self._want()
+
+    def __repr__(self):
+        return self._want()
+
+
+G = _Form()
+
+
+@pytest.fixture(autouse=True, params=["walk", "blk"])
+def form(request, monkeypatch):
+    """every test of this file twice: single-frame launches on the walker (GMAT_STRIP_BLOCK=0) and on the block-cooperative form"""
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "0" if request.param == "walk" else "3")
+    return request.param
+
 
 # (srcW, srcH, dstW, dstH): the ratios of 4K -> 900p (2.4), -> 768p (2.81), -> 480p (4.5: 19-tap filters), 1080p -> 432p (2.5),
 # 1080p -> 480p (2.25 / 2.25), anamorphic, up-scales (1:1.5, 1:2.5: several output rows close per source row pair), mixed
@@ -63,7 +92,7 @@ def test_any_ratio_to_rgb(dev, orc, strip_rows, which, sf, df, geom):
     strip_rows(0)
     k = _check(dev, orc, sf, df, geom)
     e = _expect(which, sf, df, geom)
-    assert k == e if e else (is_generic(k) and k != G), (k, e)
+    assert k == e if e else (is_generic(k) and k not in (GW, GB)), (k, e)
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
@@ -75,7 +104,7 @@ def test_any_ratio_to_420(dev, orc, strip_rows, which, fmt, geom):
         pytest.skip("4:2:0 destinations of odd size are test_parity_scale.py's (the tiled kernel)")
     k = _check(dev, orc, fmt, fmt, geom)
     e = _expect(which, fmt, fmt, geom)
-    assert k == e if e else (is_generic(k) and k != G), (k, e)
+    assert k == e if e else (is_generic(k) and k not in (GW, GB)), (k, e)
 
 
 @pytest.mark.parametrize("df", ["bgr24", "rgba"])
@@ -108,7 +137,7 @@ def test_every_algorithm(dev, orc, strip_rows, which, flags):
         k = _check(dev, orc, "nv12", "rgb24", geom, flags)
         assert is_generic(k), k
         if which == "tiled":
-            assert k != G
+            assert k not in (GW, GB)
         k = _check(dev, orc, "nv12", "nv12", geom, flags)
         assert is_generic(k) or "yuv>" in k, k
     if which == "walker":
@@ -176,13 +205,35 @@ def test_colour_matrices(dev, orc, strip_rows, monkeypatch, cs):
 def test_batched_frames(dev, orc, strip_rows, which, df):
     """grid.y = frame through gmat_sws_scale_batch, two streams"""
     strip_rows(0)
-    k = _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=5, nstreams=2, align=16)
+    k = _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=9, nstreams=2, align=16)
+    assert (k == GW) == (which == "walker"), k                  # four and five frames a launch: the walker under either setting
+    k = _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=2, nstreams=1, align=16)
     assert (k == G) == (which == "walker"), k
 
 
 def test_exact_ratio_walkers_keep_their_frames(dev, orc, strip_rows):
     """the walker sits BEHIND the exact-ratio kernels (2:1, 3:1, 3:2, 4:1, 1:2): where one of them takes a frame it still does"""
     strip_rows(0)
-    assert _check(dev, orc, "nv12", "rgb24", (512, 64, 256, 32)) == "scale_yuv2s_blk_kernel"
+    assert _check(dev, orc, "nv12", "rgb24", (512, 64, 256, 32)) in ("scale_yuv2s_blk_kernel", "scale_yuv2s_kernel")
     assert _check(dev, orc, "nv12", "nv12", (512, 64, 256, 32)) == "scale_yuv2p_kernel"
-    assert _check(dev, orc, "nv12", "rgb24", (792, 78, 264, 26)) == "scale_yuv3r_kernel"
+    assert _check(dev, orc, "nv12", "nv12", (792, 78, 264, 26)) == "scale_yuv3x1_kernel"      # (-> rgb24 at ONE frame: test_block_form_in_front_of_the_ratio_walkers)
+
+
+def test_block_form_in_front_of_the_ratio_walkers(dev, orc, strip_rows, monkeypatch):
+    """the shipped rule (gsws.cpp kPlaneKernels, measured in profiles/r04p_blk_vs_ratio_kernels.txt): a call of ONE frame at 3:1 / 3:2 into
+    packed RGB, and of up to three frames at 4:1 into either destination kind, takes the band walker's block-cooperative form; the 3:1 / 3:2
+    PLANE walkers keep their frames at every size; larger launches stay on the exact-ratio walkers; GMAT_BLOCK_FIRST=0 switches it off.
+    Bytes against the oracle in every case (inside _run_batch)."""
+    strip_rows(0)
+    monkeypatch.delenv("GMAT_STRIP_BLOCK", raising=False)
+    monkeypatch.delenv("GMAT_BLOCK_FIRST", raising=False)
+    cases = [  # (destination, srcW, srcH, dstW, dstH, exact-ratio kernel, the largest launch the block form takes)
+        ("rgb24", 1056, 96, 264, 24, "scale_yuv4r_kernel", 3), ("nv12", 1056, 96, 264, 24, "scale_yuv4x1_kernel", 3),
+        ("rgb24", 792, 78, 264, 26, "scale_yuv3r_kernel", 1), ("rgb24", 768, 72, 512, 48, "scale_yuv32r_kernel", 1),
+        ("nv12", 792, 72, 264, 24, "scale_yuv3x1_kernel", 0), ("nv12", 768, 72, 512, 48, "scale_yuv3x2_kernel", 0)]
+    for df, sw, sh, dw, dh, ratio_kernel, upto in cases:
+        for n in (1, 2, 3, 4):
+            k = _run_batch(dev, orc, "nv12", df, sw, sh, dw, dh, nframes=n, nstreams=1, align=16)
+            assert k == (GB if n <= upto else ratio_kernel), (df, sw, dw, n, k)
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0")
+    assert _run_batch(dev, orc, "nv12", "rgb24", 1056, 96, 264, 24, nframes=1, nstreams=1, align=16) == "scale_yuv4r_kernel"

@@ -60,7 +60,7 @@ def expect(kern_yuv, sw, sh, sf, df, flags="bicubic"):
     if sw % 16 == 0:
         return TILED
     from harness import walker_takes                      # round 3: the polyphase band walker in front of the generic plane scaler
-    return "scale_yuvg_kernel" if walker_takes(sw, sh, sf, df, sw // 2, sh // 2) else GENERIC
+    return "scale_yuvg_blk_kernel" if walker_takes(sw, sh, sf, df, sw // 2, sh // 2) else GENERIC      # (single-frame calls: its block-cooperative form)
 
 
 # (srcW, srcH): both sides of every clause of the rule — one partial strip, exactly one luma strip (512) and one UV strip
@@ -74,7 +74,7 @@ def test_geometries_cover_both_kernels():
     took = [strip_takes(w, h, "nv12", "nv12") for w, h in GEOMS]
     assert sum(took) >= 8 and took.count(False) >= 4
     names = {expect(k, w, h, "nv12", "nv12") for k in ("strip", "tiled") for w, h in GEOMS}
-    assert names == {STRIP, TILED, "scale_yuvg_kernel"}
+    assert names == {STRIP, TILED, "scale_yuvg_blk_kernel"}
 
 
 LANCZOS_GEOMS = [(128, 48), (256, 64), (528, 52), (1040, 96), (2064, 48), (4112, 48), (64, 48), (128, 44), (520, 48)]
@@ -127,7 +127,7 @@ def test_mixed_layouts_lanczos(dev, orc, strip_rows, kern_yuv, pair, geom):
     if kern_yuv == "strip" and strip_takes(sw, sh, pair[0], pair[1], "lanczos"):
         assert k == "scale_yuv2px_kernel", k
     else:
-        assert k in (TILED, GENERIC, "scale_yuvg_kernel"), k
+        assert k in (TILED, GENERIC, "scale_yuvg_kernel", "scale_yuvg_blk_kernel"), k
 
 
 @pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
@@ -189,7 +189,7 @@ def test_lanczos_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_yuv, fmt, 
     if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt, "lanczos"):
         assert k == STRIP, k
     else:
-        assert k in (TILED, GENERIC, "scale_yuvg_kernel"), k
+        assert k in (TILED, GENERIC, "scale_yuvg_kernel", "scale_yuvg_blk_kernel"), k
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 5, 8, 13, 64])

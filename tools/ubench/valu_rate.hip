@@ -32,6 +32,8 @@ __device__ __forceinline__ int op(int a, int b, int c)
     else if constexpr (OP == 16) return (int)__umulhi((unsigned)c, (unsigned)a) + 0 * b;                         // v_mul_hi_u32
     else if constexpr (OP == 17) return (int)(((unsigned long long)(unsigned)c * (unsigned)a + ((unsigned long long)(unsigned)b << 32)) >> 32);   // v_mad_u64_u32, high half
     else if constexpr (OP == 18) return (int)((unsigned)c * (unsigned)a);                                        // v_mul_lo_u32
+    else if constexpr (OP == 19) return __builtin_amdgcn_sdot4(a, b, c, false);                                  // v_dot4_i32_i8
+    else if constexpr (OP == 20) return (int)__builtin_amdgcn_udot4((unsigned)a, (unsigned)b, (unsigned)c, false); // v_dot4_u32_u8
     else return (int)min(min((unsigned)c, (unsigned)a), (unsigned)b);                                           // v_min3_u32
 }
 
@@ -98,6 +100,8 @@ int main()
         run<14>("v_pk_min_u16", w);
         run<15>("v_min3_u32", w);
         run<16>("v_mul_hi_u32", w);
+        run<19>("v_dot4_i32_i8", w);
+        run<20>("v_dot4_u32_u8", w);
         run<17>("v_mad_u64_u32 (high half)", w);
         run<18>("v_mul_lo_u32", w);
     }
