@@ -51,6 +51,11 @@ for case in range(n):
         algo = "bicubic"
     nframes = rng.choice([1, 1, 1, 2, 3, 4, 5])
     align = rng.choice([4, 8, 16, 64, 256])
+    ctx = lib.gmat_sws_getContext(sw, sh, harness.PIX_FMT[sf], dw, dh, harness.PIX_FMT[df], SWS[algo] | SWS["hwaccel"], None)
+    if not ctx:
+        hist["(declined: -ENOSYS)"] += 1              # filters beyond what any kernel takes (sinc / spline at high ratios): not a parity failure
+        continue
+    lib.gmat_sws_freeContext(ctx)
     try:
         k = _run_batch(dev, orc, sf, df, sw, sh, dw, dh, nframes=nframes, nstreams=rng.choice([1, 2]), align=align, flags=SWS[algo])
         hist[k] += 1
