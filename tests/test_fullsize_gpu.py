@@ -245,53 +245,65 @@ def test_3_to_2_ladder_steps(gpu, orc, fmt, geom, which, monkeypatch):
 
 
 @pytest.mark.parametrize("fmt,geom", [("nv12", (3840, 2160, 960, 540)), ("yuv420p", (3840, 2160, 960, 540))])
-def test_4k_to_540p(gpu, orc, fmt, geom):
+@pytest.mark.parametrize("first", ["ratio", "blk"])
+def test_4k_to_540p(gpu, orc, monkeypatch, first, fmt, geom):
     """the 540p rung of a ladder from a 4K frame, every plane against the oracle"""
+    # one frame per call: the exact-ratio walker (GMAT_BLOCK_FIRST=0) and the band walker's block-cooperative form the shipped rule puts in front of it
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0" if first == "ratio" else "1")
     sw, sh, dw, dh = geom
     src = synth_planes(orc, fmt, sw, sh, seed=71)
     want = orc.sws(src, sw, sh, fmt, dw, dh, fmt)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, fmt, dw, dh, fmt, dst_align=256)
-    assert k == "scale_yuv4x1_kernel", k
+    assert k == ("scale_yuv4x1_kernel" if first == "ratio" else "scale_yuvg_blk_kernel"), k
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
 @pytest.mark.parametrize("geom", [(3840, 2160, 960, 540, "rgb24"), (1920, 1080, 480, 270, "bgra")])
-def test_nv12_to_a_quarter_in_rgb(gpu, orc, geom):
+@pytest.mark.parametrize("first", ["ratio", "blk"])
+def test_nv12_to_a_quarter_in_rgb(gpu, orc, monkeypatch, first, geom):
     """4K -> 960x540 and 1080p -> 480x270 from NV12 into packed RGB at full size"""
+    # one frame per call: the exact-ratio walker (GMAT_BLOCK_FIRST=0) and the band walker's block-cooperative form the shipped rule puts in front of it
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0" if first == "ratio" else "1")
     sw, sh, dw, dh, df = geom
     src = synth_planes(orc, "nv12", sw, sh, seed=67)
     want = orc.sws(src, sw, sh, "nv12", dw, dh, df)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, df, dst_align=256)
-    assert k == "scale_yuv4r_kernel", k
+    assert k == ("scale_yuv4r_kernel" if first == "ratio" else "scale_yuvg_blk_kernel"), k
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
 @pytest.mark.parametrize("geom", [(1920, 1080, 1280, 720, "rgb24"), (3840, 2160, 2560, 1440, "bgra")])
-def test_nv12_to_two_thirds_in_rgb(gpu, orc, geom):
+@pytest.mark.parametrize("first", ["ratio", "blk"])
+def test_nv12_to_two_thirds_in_rgb(gpu, orc, monkeypatch, first, geom):
     """1080p -> 720p and 4K -> 1440p from NV12 into packed RGB at full size"""
+    # one frame per call: the exact-ratio walker (GMAT_BLOCK_FIRST=0) and the band walker's block-cooperative form the shipped rule puts in front of it
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0" if first == "ratio" else "1")
     sw, sh, dw, dh, df = geom
     src = synth_planes(orc, "nv12", sw, sh, seed=61)
     want = orc.sws(src, sw, sh, "nv12", dw, dh, df)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, df, dst_align=256)
-    assert k == "scale_yuv32r_kernel", k
+    assert k == ("scale_yuv32r_kernel" if first == "ratio" else "scale_yuvg_blk_kernel"), k
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
 
 
 @pytest.mark.parametrize("geom", [(3840, 2160, 1280, 720, "rgb24"), (1920, 1080, 640, 360, "bgra")])
-def test_nv12_to_a_third_in_rgb(gpu, orc, geom):
+@pytest.mark.parametrize("first", ["ratio", "blk"])
+def test_nv12_to_a_third_in_rgb(gpu, orc, monkeypatch, first, geom):
     """4K -> 720p and 1080p -> 360p from NV12 into packed RGB (a decoder's frame into a network's input) at full size"""
+    # one frame per call: the exact-ratio walker (GMAT_BLOCK_FIRST=0) and the band walker's block-cooperative form the shipped rule puts in front of it
+    monkeypatch.setenv("GMAT_BLOCK_FIRST", "0" if first == "ratio" else "1")
     sw, sh, dw, dh, df = geom
     src = synth_planes(orc, "nv12", sw, sh, seed=59)
     want = orc.sws(src, sw, sh, "nv12", dw, dh, df)
     d = gpu.upload_planes(src, 256)
     got, pads, k = gpu.sws(d, sw, sh, "nv12", dw, dh, df, dst_align=256)
-    assert k == "scale_yuv3r_kernel", k
+    assert k == ("scale_yuv3r_kernel" if first == "ratio" else "scale_yuvg_blk_kernel"), k
     for g, wv, pd in zip(got, want, pads):
         assert (g == wv).all() and (pd == 0xCD).all()
 
