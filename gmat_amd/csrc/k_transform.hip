@@ -1478,6 +1478,39 @@ struct RotRows {
 #endif
 };
 
+// ---- interpolate_bilinear8 in single precision (round 4; FINDINGS R4-rotate, tools/ubench/rot_probe.hip) ------------------------
+// vf_rotate.c:224-249 is floor(((2^16 - fy) * s0 + fy * s1) / 2^32) with s0 = (2^16 - fx) * s00 + fx * s01 in 64-bit integers.  Divided by
+// 2^16, s0' = s00 + fx' * (s01 - s00) with fx' = fx / 2^16 has 8 + 16 bits: it IS a float, and the fused multiply-add that forms it is exact.
+// The vertical step v = s0' + fy' * (s1' - s0') has 40 bits — but only floor(v) is wanted, and v >= 0: ONE fused multiply-add rounded TOWARD
+// ZERO gives RZ(v) <= v, and floor(v) <= v is a float itself, so floor(v) <= RZ(v): floor(RZ(v)) == floor(v), exactly.  The wave runs with
+// MODE.fp_round = toward zero (set at the kernel's first instruction; every other float operation here is exact, so the mode touches nothing
+// else) and v_cvt_pk_u8_f32 — which converts under the same mode — drops the byte into its place in the output dword: 2^24 random blends and
+// the corner cases against the integer form, 0 differences (and 8.4 M with the default mode).  v_pk_fma_f32 / v_pk_add_f32 do two values an
+// instruction; v_cvt_f32_ubyteN takes a byte of a dword straight to a float: 8 instructions a sample where the integer form needs 14.
+typedef float rotf2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void rot_round_toward_zero() { __builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 3); }      // hwreg(HW_REG_MODE, 0, 2)
+__device__ __forceinline__ rotf2 rot_fma2(rotf2 a, rotf2 b, rotf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ unsigned rot_put_u8(float v, unsigned byte, unsigned acc) { return __builtin_amdgcn_cvt_pk_u8_f32(v, byte, acc); }
+#else
+// the CPU emulation of the test suite: the same two operations under the same rounding (the products and sums here are exact in double)
+__host__ __device__ static inline void rot_round_toward_zero() {}
+__host__ __device__ static inline float rot_fma_rz1(float a, float b, float c)
+{
+    const double t = (double)a * (double)b + (double)c;
+    float r = (float)t;
+    if (std::fabs((double)r) > std::fabs(t)) r = std::nextafterf(r, 0.0f);
+    return r;
+}
+__host__ __device__ static inline rotf2 rot_fma2(rotf2 a, rotf2 b, rotf2 c) { rotf2 r; r.x = rot_fma_rz1(a.x, b.x, c.x); r.y = rot_fma_rz1(a.y, b.y, c.y); return r; }
+__host__ __device__ static inline unsigned rot_put_u8(float v, unsigned byte, unsigned acc)
+{
+    const int t = v <= 0.0f ? 0 : v >= 255.0f ? 255 : (int)v;
+    return (acc & ~(0xFFu << (8 * byte))) | ((unsigned)t << (8 * byte));
+}
+#endif
+__device__ __forceinline__ float rot_byte_f(unsigned w, int n) { return (float)((w >> (8 * n)) & 0xFFu); }              // v_cvt_f32_ubyteN
+
 // ---- the same walk with the source patch staged in LDS (round 3) ------------------------------------------------------------
 // A block makes a 32 x 32 output tile: the source pixels its taps can touch lie in the bounding box of the tile's four corners (an
 // affine map: the extremes are at the corners), at most 48 x 48 pixels at any angle; the box is loaded into LDS (dword-aligned
@@ -1496,22 +1529,32 @@ struct RotRows {
 // Tried and not faster: two waves a tile (a thread: 8 pixels, GMAT_ROTATE_WAVES=2: 21.0 us), a block walking 2 / 4 / 8 tiles with the
 // next box requested ahead (23 / 25 / 29 us, and 35-48 us in the first form: the chip overlaps independent blocks better than one
 // block overlaps its own tiles), gathering aligned dwords in the direct form (45 us).
+// tools/ubench/rot_phase.hip builds this file with GMAT_ROT_PHASE: every wave leaves its clock at the ends of its phases
+#if defined(GMAT_ROT_PHASE)
+__device__ unsigned long long g_rot_phase[(1 << 16) * 8];
+#define ROT_PH(i) do { if ((threadIdx.x & 63) == 0) { const unsigned wid_ = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if (wid_ < (1u << 16)) g_rot_phase[wid_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define ROT_PH(i) do { } while (0)
+#endif
 template <int BPP, int INTERP, int NWV>
-__global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
-                                                         int aligned, int nbx, int nby, OpFrames fr)
+struct RotTile {                                            // the 32 x 32 tile's LDS geometry
+    static constexpr int TW = 32, TBH = 32, BMAX = 50;
+    static constexpr int PD = ((BMAX * BPP + 6) / 4 + 2) | 1;      // dwords per LDS row: 50 pixels + lead-in + the two dwords an 8-byte read may run over, odd
+    static constexpr int NR = (BMAX + NWV - 1) / NWV;              // loader rounds: wave w takes rows w, w + NWV, ...
+    static constexpr int BOX = (NR * NWV + 1) * PD;                // the loader's NR rounds of NWV rows (rows past the box are never read), and
+                                                                   // at the frame's last row the pair's lower row is read with weight 0
+    static constexpr int CW = INTERP == 2 ? 512 : 2;               // cubic: the four weights of each 8-bit fraction as two int16 pairs
+};
+
+// one 32 x 32 tile (bx, by) by the block's NWV waves: box -> LDS, one barrier, the integer walk
+template <int BPP, int INTERP, int NWV>
+__device__ __forceinline__ void rot_tile_general(const uint8_t *src, int ss, uint8_t *dst, int ds, const RotateParams &p, int aligned, int bx, int by,
+                                                 unsigned *box, unsigned *cw)
 {
-    if (gridDim.z > 1) { src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z]; }      // a frame table: grid.z = frame
-    constexpr int TW = 32, TBH = 32, BMAX = 50;
-    constexpr int PD = ((BMAX * BPP + 6) / 4 + 2) | 1;      // dwords per LDS row: 50 pixels + lead-in + the two dwords an 8-byte read may run over, odd
+    constexpr int TW = RotTile<BPP, INTERP, NWV>::TW, TBH = RotTile<BPP, INTERP, NWV>::TBH, BMAX = RotTile<BPP, INTERP, NWV>::BMAX;
+    constexpr int PD = RotTile<BPP, INTERP, NWV>::PD, NR = RotTile<BPP, INTERP, NWV>::NR;
     constexpr bool cubic = INTERP == 2;
-    constexpr int NR = (BMAX + NWV - 1) / NWV;              // loader rounds: wave w takes rows w, w + NWV, ...
-    __shared__ unsigned box[(NR * NWV + 1) * PD];           // the loader's NR rounds of NWV rows (rows past the box are never read), and
-                                                            // at the frame's last row the pair's lower row is read with weight 0
-    __shared__ unsigned cw[cubic ? 512 : 2];                // cubic: the four weights of each 8-bit fraction as two int16 pairs
-    // grid (8 * nbx, ceil(nby / 8)): workgroups go to the XCDs round-robin in dispatch order, so blockIdx.x & 7 IS the XCD, and XCD k
-    // walks tile rows k * gridDim.y ... — a contiguous band of the frame per L2, without a division
-    const int bx = blockIdx.x >> 3, by = (blockIdx.x & 7) * gridDim.y + blockIdx.y;
-    if (by >= nby) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int iLo = bx * TW, iHi = min(iLo + TW, p.outW) - 1, jLo = by * TBH, jHi = min(jLo + TBH, p.outH) - 1;
     const int xb = p.X0 + jLo * p.s + iLo * p.c, yb = p.Y0 + jLo * p.c - iLo * p.s;     // the tile's first pixel
@@ -1563,7 +1606,7 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
                     lo[k] = q * PD + 4 * c4;
                 }
             }
-#pragma unroll
+    #pragma unroll
             for (int k = 0; k < KMAX; k++)
                 if (lo[k] >= 0) { box[lo[k]] = v[k].x; box[lo[k] + 1] = v[k].y; box[lo[k] + 2] = v[k].z; box[lo[k] + 3] = v[k].w; }
         } else if (lane < nDw) {
@@ -1741,6 +1784,163 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
     }
 }
 
+template <int BPP, int INTERP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p,
+                                                         int aligned, int nbx, int nby, OpFrames fr)
+{
+    if (gridDim.z > 1) { src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z]; }      // a frame table: grid.z = frame
+    __shared__ unsigned box[RotTile<BPP, INTERP, NWV>::BOX];
+    __shared__ unsigned cw[RotTile<BPP, INTERP, NWV>::CW];
+    // grid (8 * nbx, ceil(nby / 8)): workgroups go to the XCDs round-robin in dispatch order, so blockIdx.x & 7 IS the XCD, and XCD k
+    // walks tile rows k * gridDim.y ... — a contiguous band of the frame per L2, without a division
+    const int bx = blockIdx.x >> 3, by = (blockIdx.x & 7) * gridDim.y + blockIdx.y;
+    if (by >= nby) return;
+    rot_tile_general<BPP, INTERP, NWV>(src, ss, dst, ds, p, aligned, bx, by, box, cw);
+}
+
+// ---- the macro-tile form (round 4): 64 x 32 outputs a block, the whole interior tile on a lean path --------------------------------------
+// tools/ubench/rot_phase.hip put clocks into rotate_lds_kernel's waves (profiles/r04t_rotate_phases.txt): of a wave's life the blend is 23 %;
+// 32 % goes before the first load leaves (170 scalar instructions a wave — corners, clamps, the loader's division — four waves a tile each
+// redoing them, 5.6 M a 4K frame on scalar units that issue one a cycle a CU: 9 us of the frame's 20 by themselves), 20 % into issuing
+// the loads, 10 % into the barrier.  Making the blend cheaper (single precision, above: 262 -> 190 instructions a wave) moved nothing.
+// So: tiles twice as large (half the waves, each with two passes of work behind one preamble and one barrier); whatever is the same for
+// every whole tile comes from the host (RotMT: the extremes of the coordinate offsets over 64 x 32 outputs); a tile that is whole, all valid
+// and whose box met no clamp knows its box from four additions; the loader is laid out by rows (LPR threads a row of 16-byte pieces, no
+// division) and stores 16 bytes an LDS instruction (the pitch is a multiple of 4 dwords, = 4 mod 8); coordinates are relative to the box;
+// no fill logic, no clamp, no zero-weight rule.  Everything else — the frame's rim, ragged tiles, unaligned destinations — is the integer
+// walk above on the macro tile's two halves.
+// Tried on top of this and dropped (FINDINGS R4-rotate): persistent blocks that request the next tile's box before blending this one (28 us
+// where one tile a block takes 20: a tile's blend is far shorter than a load's way, eight short-lived blocks a CU overlap better, and the
+// registers of a box in flight halve the occupancy); one pixel a dword in LDS for 3 / 4 bytes a pixel (no v_alignbyte, but 73 VGPRs and a
+// loader of byte permutes: 21.9 against 20.5 us); reads at their own byte address (35 us).
+struct RotMT { int dxLo, dxHi, dyLo, dyHi; };               // extremes of the coordinate offsets over 64 x 32 outputs
+
+template <int BPP> struct RotMTGeom {
+    static constexpr int MW = 64, MH = 32, BM = 74;        // the box of 64 x 32 outputs: |extent| <= hypot(63, 31) = 70.3, + 1 (floors) + 1 (the pair) + 1
+    static constexpr int NCOL = (((3 + BM * BPP + 3) / 4) + 3) / 4;                     // 16-byte pieces a row, at most
+    static constexpr int PD = (4 * NCOL) % 8 == 4 ? 4 * NCOL : 4 * NCOL + 4;            // dwords a row: whole pieces, = 4 mod 8
+    static constexpr int LPR = NCOL <= 8 ? 8 : NCOL <= 16 ? 16 : 32, RPR = 256 / LPR, KMAX = (BM + RPR - 1) / RPR;     // loader: LPR threads a row
+    static constexpr int BOX = BM * PD;
+};
+
+template <int BPP, int INTERP>
+__global__ __launch_bounds__(256) void rotate_mt_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, RotateParams p, RotMT mt,
+                                                        int aligned, int nbx, int nby, OpFrames fr)
+{
+    ROT_PH(0);
+    typedef RotMTGeom<BPP> G;
+    typedef RotTile<BPP, INTERP, 4> T;
+    constexpr int PD = G::PD;
+    if (INTERP == 1) rot_round_toward_zero();               // the single-precision blend below; nothing else in this kernel rounds
+    if (gridDim.z > 1) { src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z]; }      // a frame table: grid.z = frame
+    __shared__ __attribute__((aligned(16))) unsigned box[G::BOX > T::BOX ? G::BOX : T::BOX];
+    __shared__ unsigned cw[T::CW];
+    // grid (8 * macro columns, ceil(nby / 8)): blockIdx.x & 7 is the XCD (see rotate_lds_kernel).  (Bands balanced to a row — XCD k walks
+    // [k * nby / 8, (k + 1) * nby / 8) — cost 3 % for the two multiplies in front of everything else: the makespan is the same 9 rows at 4K.)
+    const int bxM = blockIdx.x >> 3, by = (blockIdx.x & 7) * gridDim.y + blockIdx.y;
+    if (by >= nby) return;
+    ROT_PH(7);
+    const int iLo = bxM * G::MW, jLo = by * G::MH;
+    const int xb = p.X0 + jLo * p.s + iLo * p.c, yb = p.Y0 + jLo * p.c - iLo * p.s;     // the tile's first pixel
+    const int minx = (xb + mt.dxLo) >> 16, maxx = (xb + mt.dxHi) >> 16, miny = (yb + mt.dyLo) >> 16, maxy = (yb + mt.dyHi) >> 16;
+    const int bw = maxx + 2 - minx, bh = maxy + 2 - miny;   // pairs: x1, x1 + 1 on rows y1, y1 + 1
+    const int gd0 = (minx * BPP) >> 2, shift = (minx * BPP) & 3, ncol = (((shift + bw * BPP + 3) >> 2) + 3) >> 2;
+    const bool fast = aligned && iLo + G::MW <= p.outW && jLo + G::MH <= p.outH && minx >= 0 && maxx + 1 <= p.inW - 1 && miny >= 0 && maxy + 1 <= p.inH - 1 &&
+                      bw <= G::BM && bh <= G::BM &&
+                      (maxy + 1) * ss + 4 * gd0 + 16 * ncol <= (p.inH - 1) * ss + p.inW * BPP;     // the last row's 16-byte pieces end inside the frame
+    if (!fast) {
+        // the frame's rim, ragged tiles, unaligned destinations: the integer walk on the macro tile's two halves
+#pragma unroll                                               // (as a loop: 4 % slower on the WHOLE tiles — the code's layout, not its work)
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();                       // the second half's box goes where the first one's is still being read
+            if (2 * bxM + half < nbx) rot_tile_general<BPP, INTERP, 4>(src, ss, dst, ds, p, aligned, 2 * bxM + half, by, box, cw);
+        }
+        return;
+    }
+    ROT_PH(1);
+    {
+        const RotRows rows(src + (size_t)miny * ss + 4 * (size_t)gd0);
+        const int lrow = (int)threadIdx.x / G::LPR, lcol = (int)threadIdx.x & (G::LPR - 1);
+        const unsigned off = (unsigned)(m24(lrow, ss) + 16 * lcol), step = (unsigned)(G::RPR * ss);
+        uint4 v[G::KMAX];
+#pragma unroll
+        for (int k = 0; k < G::KMAX; k++)
+            if (lcol < ncol && lrow + k * G::RPR < bh) v[k] = rows.ld16(off + (unsigned)k * step);
+        ROT_PH(2);
+#pragma unroll
+        for (int k = 0; k < G::KMAX; k++)
+            if (lcol < ncol && lrow + k * G::RPR < bh) *reinterpret_cast<uint4 *>(&box[(lrow + k * G::RPR) * PD + 4 * lcol]) = v[k];
+    }
+    ROT_PH(3);
+    __syncthreads();
+    ROT_PH(4);
+    // a wave makes 4 rows of 64 pixels a pass (a lane: 4 adjacent pixels), the block 16 rows a pass
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ir = (lane & 15) * 4;
+    const int xl = xb - (minx << 16) + m24(ir, p.c), yl = yb - (miny << 16) - m24(ir, p.s);     // relative to the box, this lane's column
+    constexpr float K16 = 1.0f / 65536.0f;
+#pragma unroll 1
+    for (int jr = wave * 4 + (lane >> 4); jr < G::MH; jr += 16) {
+        const int x0 = xl + m24(jr, p.s), y0 = yl + m24(jr, p.c);
+        unsigned TT[4][2], UU[4][2];                         // per pixel: the pair of the upper row and of the lower one, 2 BPP bytes each
+        float FX[4], FY[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = x0 + q * p.c, y = y0 - q * p.s;    // >= 0: relative to the box
+            const int bo = m24(y >> 16, PD * 4) + m24(x >> 16, BPP) + shift;
+            TT[q][1] = UU[q][1] = 0; UU[q][0] = 0;
+            if (BPP == 1) {
+                // one byte a read, four reads off one address: the LDS unit does what v_alignbyte, the two masks and the byte picks did
+                // (97 -> 69 VALU instructions a pass; it then is the LDS unit that is busy: 13.9 against 14.5 us)
+                const uint8_t *pb = reinterpret_cast<const uint8_t *>(box) + bo;
+                TT[q][0] = pb[0];
+                if (INTERP) { TT[q][0] |= (unsigned)pb[1] << 8; UU[q][0] = (unsigned)pb[PD * 4] | ((unsigned)pb[PD * 4 + 1] << 8); }
+            } else {
+                // aligned dwords and a byte shift: a read at its own byte address is legal on gfx950 (the compiler emits it for a memcpy)
+                // but is served a lane at a time — 35 us a 4K frame where this form takes 20 (profiles/r04r_*)
+                const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (bo & ~3));
+                const unsigned sh = (unsigned)bo & 3u;
+                if (BPP == 4) { TT[q][0] = w[0]; if (INTERP) { TT[q][1] = w[1]; UU[q][0] = w[PD]; UU[q][1] = w[PD + 1]; } }
+                else {
+                    TT[q][0] = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+                    if (INTERP) {
+                        UU[q][0] = __builtin_amdgcn_alignbyte(w[PD + 1], w[PD], sh);
+                        if (BPP == 3) { TT[q][1] = __builtin_amdgcn_alignbyte(w[2], w[1], sh); UU[q][1] = __builtin_amdgcn_alignbyte(w[PD + 2], w[PD + 1], sh); }
+                    }
+                }
+            }
+            FX[q] = (float)(x & 0xFFFF) * K16; FY[q] = (float)(y & 0xFFFF) * K16;
+        }
+        unsigned W[BPP];
+#pragma unroll
+        for (int k = 0; k < BPP; k++) W[k] = 0;
+        if (INTERP == 1) {
+            // the lane's 4 BPP samples two at a time (v_pk_*_f32): sample n = channel n % BPP of pixel n / BPP = byte n of the output
+#pragma unroll
+            for (int m = 0; m < 2 * BPP; m++) {
+                const int na = 2 * m, nb = 2 * m + 1, qa = na / BPP, qb = nb / BPP, ka = na % BPP, kb = nb % BPP, ka1 = ka + BPP, kb1 = kb + BPP;
+                const rotf2 fx = {FX[qa], FX[qb]}, fy = {FY[qa], FY[qb]};
+                const rotf2 t0 = {rot_byte_f(TT[qa][0], ka), rot_byte_f(TT[qb][0], kb)};
+                const rotf2 t1 = {rot_byte_f(TT[qa][ka1 >> 2], ka1 & 3), rot_byte_f(TT[qb][kb1 >> 2], kb1 & 3)};
+                const rotf2 u0 = {rot_byte_f(UU[qa][0], ka), rot_byte_f(UU[qb][0], kb)};
+                const rotf2 u1 = {rot_byte_f(UU[qa][ka1 >> 2], ka1 & 3), rot_byte_f(UU[qb][kb1 >> 2], kb1 & 3)};
+                const rotf2 s0 = rot_fma2(fx, t1 - t0, t0), s1 = rot_fma2(fx, u1 - u0, u0);      // exact
+                const rotf2 v = rot_fma2(fy, s1 - s0, s0);                                       // toward zero: floor(v) is the integer form's result
+                W[na >> 2] = rot_put_u8(v.x, na & 3, W[na >> 2]);
+                W[nb >> 2] = rot_put_u8(v.y, nb & 3, W[nb >> 2]);
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4 * BPP; n++) W[n >> 2] |= ((TT[n / BPP][0] >> (8 * (n % BPP))) & 0xFFu) << (8 * (n & 3));
+        }
+        unsigned *d = reinterpret_cast<unsigned *>(dst + (size_t)(jLo + jr) * ds + (size_t)(iLo + ir) * BPP);
+        ROT_PH(5);
+#pragma unroll
+        for (int k = 0; k < BPP; k++) d[k] = W[k];
+        ROT_PH(6);
+    }
+}
+
 // int_sin, vf_rotate.c:198-218: input scaled by 2^20, output by 2^16
 static int64_t rot_int_sin(int64_t a)
 {
@@ -1802,6 +2002,29 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
         // wave) is the A/B that showed the kernel is not bound by them: 21.0 against 20.7 us (profiles/r03zr_rotate.txt)
         const char *ew = GMAT_KNOB("GMAT_ROTATE_WAVES");
         const int nwv = ew && atoi(ew) == 2 ? 2 : 4;
+        // nearest and bilinear: 64 x 32 macro tiles (rotate_mt_kernel); GMAT_ROTATE_MT=0 keeps the 32 x 32 form (A/B, and the tests' way to it)
+        const char *em = GMAT_KNOB("GMAT_ROTATE_MT");
+        if (bilinear != 2 && nwv == 4 && (em ? atoi(em) != 0 : true)) {
+            const int nbxM = (outW + 63) / 64;
+            const dim3 grid(8 * nbxM, (nby + 7) / 8, frames ? nframes : 1), block(256);
+            const OpFrames fr = frames ? *frames : op_frames(src, dst, nullptr);
+            if (frames) { src = frames->src[0]; dst = frames->dst[0]; }
+            RotMT mt;                                        // extremes of the coordinate offsets over 64 x 32 outputs (see rot_tile_general)
+            const int xi = 63 * p.c, xj = 31 * p.s, yi = -63 * p.s, yj = 31 * p.c;
+            mt.dxLo = std::min(xi, 0) + std::min(xj, 0); mt.dxHi = std::max(xi, 0) + std::max(xj, 0);
+            mt.dyLo = std::min(yi, 0) + std::min(yj, 0); mt.dyHi = std::max(yi, 0) + std::max(yj, 0);
+#define GMAT_ROTM(B_) do { if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); \
+                           else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 0>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); } while (0)
+            switch (bpp) {
+            case 1:  GMAT_ROTM(1); break;
+            case 2:  GMAT_ROTM(2); break;
+            case 3:  GMAT_ROTM(3); break;
+            default: GMAT_ROTM(4); break;
+            }
+#undef GMAT_ROTM
+            GMAT_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         const dim3 grid(8 * nbx, (nby + 7) / 8, frames ? nframes : 1), block(64 * nwv);
         const OpFrames fr = frames ? *frames : op_frames(src, dst, nullptr);
         if (frames) { src = frames->src[0]; dst = frames->dst[0]; }

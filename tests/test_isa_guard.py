@@ -98,7 +98,12 @@ def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassemb
     # forms at every launch size (profiles/r04d_block_form_one_frame_per_launch.txt, gpurun r04b: 1391 passed).
     # scale_yuvg_blk_rgb_kernel: the band walker's colour stage, same construction (g_sat_pk_u8_i16 -> v_perm_b32 of bytes 0 and 1); bit-exact
     # on the GPU (gpurun r04m / r04o: tests/test_parity_generic_walker.py in both forms, 518 passed).
-    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel", "scale_yuvg_blk_rgb_kernel")}
+    # rotate_mt_kernel: v_cvt_pk_u8_f32 is USED for its merge — it converts under MODE.fp_round (toward zero there) and drops the byte into
+    # byte S1 of S2, the output dword being assembled (k_transform.hip rot_put_u8); the first of a dword's four starts from 0.  On the GPU:
+    # tools/ubench/rot_probe.hip (2^24 blends against the 64-bit integer form, 0 differences), tests -k rotate 168 passed, 1500 fuzz cases
+    # (profiles/r04_rotate.txt).
+    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel", "scale_yuvg_blk_rgb_kernel"),
+                "v_cvt_pk_u8_f32": ("rotate_mt_kernel",)}
     hits = {}
     for t in disassembly:
         func = "?"

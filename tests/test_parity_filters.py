@@ -651,7 +651,7 @@ def test_rotate_interp_and_shift_match_the_stated_rule(dev, orc, case, bpp):
     d.free(); o.free()
 
 
-@pytest.mark.parametrize("lds", ["0", "1", "1w2"])
+@pytest.mark.parametrize("lds", ["0", "1", "1w2", "1m0"])
 @pytest.mark.parametrize("interp", [0, 1, 2])
 def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp):
     """rotate_lds_kernel (source patch in LDS: shipped whenever the source rows are dword-aligned; four waves a tile, and the two-wave
@@ -661,6 +661,8 @@ def test_rotate_both_kernels_over_tile_edges(dev, orc, monkeypatch, lds, interp)
     monkeypatch.setenv("GMAT_ROTATE_LDS", lds[0])
     if lds == "1w2":
         monkeypatch.setenv("GMAT_ROTATE_WAVES", "2")
+    if lds == "1m0":                                          # the 32 x 32 form behind the macro tiles (nearest / bilinear; cubic always runs it)
+        monkeypatch.setenv("GMAT_ROTATE_MT", "0")
     dev.lib.gmat_knobs_reload()
     fill = (C.c_uint8 * 4)(1, 2, 3, 4)
     for (w, h, bpp, deg, sx, sy) in [(113, 179, 4, 143.7, 0.0, 0.0), (283, 167, 2, 17.0, 0.0, 0.0), (258, 175, 1, -61.3, 0.0, 0.0),
@@ -825,3 +827,26 @@ def test_smooth_filter_median_5x5(dev, orc):
     want = np.zeros_like(src)
     orc.L.orc_median(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, 3, 5, 7)
     assert (res == want).all()
+
+
+@pytest.mark.parametrize("bpp", [1, 2, 3, 4])
+def test_rotate_bilinear_interior_tiles(dev, orc, bpp):
+    """the single-precision form of interpolate_bilinear8 (round 4: whole 64 x 32 macro tiles whose source box met no clamp — one fused
+    multiply-add rounded toward zero per sample, k_transform.hip rot_fma2 / rot_put_u8) against the 64-bit integer rule of vf_rotate.c:224-249
+    on frames that are mostly such tiles, a flat-ish source (long runs of equal neighbours: differences of 0), a noisy one and the
+    extremes 0 / 255 next to each other (the blend's largest differences)"""
+    w, h = 352, 256
+    rng = np.random.default_rng(40 + bpp)
+    srcs = [orc.lcg((h, w * bpp), 70 + bpp), (rng.integers(0, 2, (h, w * bpp)) * 255).astype(np.uint8),
+            np.repeat(rng.integers(0, 256, (h, w * bpp // 8), dtype=np.uint8), 8, axis=1)]
+    for src, deg, interp in zip(srcs * 3, [17.0, -3.25, 45.0, 91.0, 200.5, 0.01, 17.0, 135.0, -60.0], [1, 1, 1, 1, 1, 1, 0, 0, 0]):
+        src = np.ascontiguousarray(src)
+        want = np.zeros_like(src)
+        orc.L.orc_rotate(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, math.radians(deg), interp, None)
+        d = dev.upload_planes([src], 256, 0)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + 255) // 256 * 256)
+        o.upload(np.zeros((h, w * bpp), np.uint8))
+        assert dev.lib.gmat_rotate(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), interp, None, None) == 0
+        got = o.download()
+        assert (got == want).all(), ((bpp, deg, interp), np.argwhere(got != want)[:4].tolist())
+        d.free(); o.free()
