@@ -1509,6 +1509,17 @@ __host__ __device__ static inline unsigned rot_put_u8(float v, unsigned byte, un
     return (acc & ~(0xFFu << (8 * byte))) | ((unsigned)t << (8 * byte));
 }
 #endif
+// v_dot2_i32_i16 with a literal 0 to add to (the builtin's first use of an accumulator becomes v_dot2c_i32_i16 behind a v_mov_b32 0)
+__device__ __forceinline__ int dot2z(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return dot2(a, b, 0);
+#endif
+}
 __device__ __forceinline__ float rot_byte_f(unsigned w, int n) { return (float)((w >> (8 * n)) & 0xFFu); }              // v_cvt_f32_ubyteN
 
 // ---- the same walk with the source patch staged in LDS (round 3) ------------------------------------------------------------
@@ -1663,9 +1674,11 @@ __device__ __forceinline__ void rot_tile_general(const uint8_t *src, int ss, uin
             const unsigned wy01 = cw[2 * ((y >> 8) & 0xFF)], wy23 = cw[2 * ((y >> 8) & 0xFF) + 1];
             const int wx[4] = {(int)(short)(wx01 & 0xFFFF), (int)wx01 >> 16, (int)(short)(wx23 & 0xFFFF), (int)wx23 >> 16};
             const int wy[4] = {(int)(short)(wy01 & 0xFFFF), (int)wy01 >> 16, (int)(short)(wy23 & 0xFFFF), (int)wy23 >> 16};
-            long long acc[BPP];
+            // the 38-bit vertical sum in doubles (exact; v_fma_f64 is full rate on gfx950), see rotate_mt_kernel
+            const double wyd[4] = {(double)wy[0], (double)wy[1], (double)wy[2], (double)wy[3]};
+            double acc[BPP];
 #pragma unroll
-            for (int k = 0; k < BPP; k++) acc[k] = 0;
+            for (int k = 0; k < BPP; k++) acc[k] = 134217728.0;         // 2^27
             // interior: the four taps of a row are 4 * BPP consecutive bytes (BPP dwords after v_alignbyte_b32), the four rows consecutive
             const bool inner = x1 - 1 >= bx0 && x1 + 2 <= bx1 && y1 - 1 >= by0 && y1 + 2 <= by1;
             if (inner) {
@@ -1685,8 +1698,8 @@ __device__ __forceinline__ void rot_tile_general(const uint8_t *src, int ss, uin
                         const int n0 = k, n1 = BPP + k, n2 = 2 * BPP + k, n3 = 3 * BPP + k;
                         const unsigned p01 = __builtin_amdgcn_perm(c[n1 >> 2], c[n0 >> 2], Z | (unsigned)(n0 & 3) | ((unsigned)(4 + (n1 & 3)) << 16));
                         const unsigned p23 = __builtin_amdgcn_perm(c[n3 >> 2], c[n2 >> 2], Z | (unsigned)(n2 & 3) | ((unsigned)(4 + (n3 & 3)) << 16));
-                        const int hs = dot2((int)p01, (int)wx01, dot2((int)p23, (int)wx23, 0));
-                        acc[k] += (long long)wy[r] * hs;
+                        const int hs = dot2((int)p01, (int)wx01, dot2z((int)p23, (int)wx23));
+                        acc[k] = __builtin_fma(wyd[r], (double)hs, acc[k]);
                     }
                 }
             } else {
@@ -1703,14 +1716,12 @@ __device__ __forceinline__ void rot_tile_general(const uint8_t *src, int ss, uin
                         for (int k = 0; k < BPP; k++) hsum[k] += wx[tt] * (int)((box[(bo + k) >> 2] >> (8 * ((bo + k) & 3))) & 0xFF);
                     }
 #pragma unroll
-                    for (int k = 0; k < BPP; k++) acc[k] += (long long)wy[r] * hsum[k];
+                    for (int k = 0; k < BPP; k++) acc[k] = __builtin_fma(wyd[r], (double)hsum[k], acc[k]);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < BPP; k++) {
-                const long long r = (acc[k] + (1LL << 27)) >> 28;
-                R[k] = (unsigned)(r < 0 ? 0 : r > 255 ? 255 : r) << 16;
-            }
+            for (int k = 0; k < BPP; k++)           // floor and truncation differ below zero only, where the clamp gives 0 either way
+                R[k] = (unsigned)min(max((int)(acc[k] * (1.0 / 268435456.0)), 0), 255) << 16;
         } else {
             // the upper clamp on the 16.16 coordinate itself: past the frame's last column / row the pair's second tap is the first
             // one again, which is a zero weight — hiX / hiY end in 0x0000 there and in 0xFFFF inside the frame (the lower clamp is
@@ -1815,8 +1826,8 @@ __global__ __launch_bounds__(64 * NWV) void rotate_lds_kernel(const uint8_t *src
 // loader of byte permutes: 21.9 against 20.5 us); reads at their own byte address (35 us).
 struct RotMT { int dxLo, dxHi, dyLo, dyHi; };               // extremes of the coordinate offsets over 64 x 32 outputs
 
-template <int BPP> struct RotMTGeom {
-    static constexpr int MW = 64, MH = 32, BM = 74;        // the box of 64 x 32 outputs: |extent| <= hypot(63, 31) = 70.3, + 1 (floors) + 1 (the pair) + 1
+template <int BPP, int MRG = 0> struct RotMTGeom {      // MRG: the cubic's extra column / row on every side
+    static constexpr int MW = 64, MH = 32, BM = 74 + 2 * MRG;  // the box of 64 x 32 outputs: |extent| <= hypot(63, 31) = 70.3, + 1 (floors) + 1 (the pair) + 1
     static constexpr int NCOL = (((3 + BM * BPP + 3) / 4) + 3) / 4;                     // 16-byte pieces a row, at most
     static constexpr int PD = (4 * NCOL) % 8 == 4 ? 4 * NCOL : 4 * NCOL + 4;            // dwords a row: whole pieces, = 4 mod 8
     static constexpr int LPR = NCOL <= 8 ? 8 : NCOL <= 16 ? 16 : 32, RPR = 256 / LPR, KMAX = (BM + RPR - 1) / RPR;     // loader: LPR threads a row
@@ -1828,12 +1839,13 @@ __global__ __launch_bounds__(256) void rotate_mt_kernel(const uint8_t *src, int 
                                                         int aligned, int nbx, int nby, OpFrames fr)
 {
     ROT_PH(0);
-    typedef RotMTGeom<BPP> G;
+    constexpr int MRG = INTERP == 2 ? 1 : 0;                // cubic: taps x1 - 1 .. x1 + 2 on rows y1 - 1 .. y1 + 2
+    typedef RotMTGeom<BPP, MRG> G;
     typedef RotTile<BPP, INTERP, 4> T;
     constexpr int PD = G::PD;
     if (INTERP == 1) rot_round_toward_zero();               // the single-precision blend below; nothing else in this kernel rounds
     if (gridDim.z > 1) { src = fr.src[blockIdx.z]; dst = fr.dst[blockIdx.z]; }      // a frame table: grid.z = frame
-    __shared__ __attribute__((aligned(16))) unsigned box[G::BOX > T::BOX ? G::BOX : T::BOX];
+    __shared__ __attribute__((aligned(16))) unsigned box[(G::BOX > T::BOX ? G::BOX : T::BOX) + 4];    // + the dword a shifted read's upper half may name
     __shared__ unsigned cw[T::CW];
     // grid (8 * macro columns, ceil(nby / 8)): blockIdx.x & 7 is the XCD (see rotate_lds_kernel).  (Bands balanced to a row — XCD k walks
     // [k * nby / 8, (k + 1) * nby / 8) — cost 3 % for the two multiplies in front of everything else: the makespan is the same 9 rows at 4K.)
@@ -1842,12 +1854,38 @@ __global__ __launch_bounds__(256) void rotate_mt_kernel(const uint8_t *src, int 
     ROT_PH(7);
     const int iLo = bxM * G::MW, jLo = by * G::MH;
     const int xb = p.X0 + jLo * p.s + iLo * p.c, yb = p.Y0 + jLo * p.c - iLo * p.s;     // the tile's first pixel
-    const int minx = (xb + mt.dxLo) >> 16, maxx = (xb + mt.dxHi) >> 16, miny = (yb + mt.dyLo) >> 16, maxy = (yb + mt.dyHi) >> 16;
-    const int bw = maxx + 2 - minx, bh = maxy + 2 - miny;   // pairs: x1, x1 + 1 on rows y1, y1 + 1
+    // the box: columns minx .. maxx + 1 (pairs: x1, x1 + 1), rows alike; the cubic one more on every side
+    const int minx = ((xb + mt.dxLo) >> 16) - MRG, maxx = ((xb + mt.dxHi) >> 16) + 1 + MRG, miny = ((yb + mt.dyLo) >> 16) - MRG, maxy = ((yb + mt.dyHi) >> 16) + 1 + MRG;
+    const int bw = maxx + 1 - minx, bh = maxy + 1 - miny;
     const int gd0 = (minx * BPP) >> 2, shift = (minx * BPP) & 3, ncol = (((shift + bw * BPP + 3) >> 2) + 3) >> 2;
-    const bool fast = aligned && iLo + G::MW <= p.outW && jLo + G::MH <= p.outH && minx >= 0 && maxx + 1 <= p.inW - 1 && miny >= 0 && maxy + 1 <= p.inH - 1 &&
+    const bool fast = aligned && iLo + G::MW <= p.outW && jLo + G::MH <= p.outH && minx >= 0 && maxx <= p.inW - 1 && miny >= 0 && maxy <= p.inH - 1 &&
                       bw <= G::BM && bh <= G::BM &&
-                      (maxy + 1) * ss + 4 * gd0 + 16 * ncol <= (p.inH - 1) * ss + p.inW * BPP;     // the last row's 16-byte pieces end inside the frame
+                      maxy * ss + 4 * gd0 + 16 * ncol <= (p.inH - 1) * ss + p.inW * BPP;           // the last row's 16-byte pieces end inside the frame
+    // every pixel of the tile invalid (its source position outside [-1, in]: the box of the tile's positions misses that range in x or in y — at 17
+    // degrees a tenth of a 4K frame's tiles): the fill colour, or nothing
+    {
+        const int tx0 = (xb + mt.dxLo) >> 16, tx1 = (xb + mt.dxHi) >> 16, ty0 = (yb + mt.dyLo) >> 16, ty1 = (yb + mt.dyHi) >> 16;
+        if ((tx1 < -1 || tx0 > p.inW || ty1 < -1 || ty0 > p.inH) && iLo + G::MW <= p.outW && jLo + G::MH <= p.outH) {
+            if (!p.fillEnable) return;
+            if (aligned) {
+                // the tile's rows are 16 * BPP dwords: pixel (4 n + q)'s channel k is byte (q * BPP + k) & 3 of dword (q * BPP + k) >> 2 of every 4-pixel group
+                unsigned F[BPP];
+#pragma unroll
+                for (int n = 0; n < BPP; n++) {
+                    F[n] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) F[n] |= ((p.fill >> (8 * ((4 * n + b) % BPP))) & 0xFFu) << (8 * b);
+                }
+                const int li = threadIdx.x & 15;
+                for (int jr = (int)threadIdx.x >> 4; jr < G::MH; jr += 16) {
+                    unsigned *d = reinterpret_cast<unsigned *>(dst + (size_t)(jLo + jr) * ds + (size_t)(iLo + 4 * li) * BPP);
+#pragma unroll
+                    for (int k = 0; k < BPP; k++) d[k] = F[k];
+                }
+                return;
+            }
+        }
+    }
     if (!fast) {
         // the frame's rim, ragged tiles, unaligned destinations: the integer walk on the macro tile's two halves
 #pragma unroll                                               // (as a loop: 4 % slower on the WHOLE tiles — the code's layout, not its work)
@@ -1858,6 +1896,12 @@ __global__ __launch_bounds__(256) void rotate_mt_kernel(const uint8_t *src, int 
         return;
     }
     ROT_PH(1);
+    if (INTERP == 2) {                                      // the four weights of each 8-bit fraction as two int16 pairs: a thread, a fraction
+        int w4[4];
+        rot_cubic_w((int)threadIdx.x, w4);
+        cw[2 * threadIdx.x] = (unsigned)(w4[0] & 0xFFFF) | ((unsigned)w4[1] << 16);
+        cw[2 * threadIdx.x + 1] = (unsigned)(w4[2] & 0xFFFF) | ((unsigned)w4[3] << 16);
+    }
     {
         const RotRows rows(src + (size_t)miny * ss + 4 * (size_t)gd0);
         const int lrow = (int)threadIdx.x / G::LPR, lcol = (int)threadIdx.x & (G::LPR - 1);
@@ -1879,6 +1923,60 @@ __global__ __launch_bounds__(256) void rotate_mt_kernel(const uint8_t *src, int 
     const int ir = (lane & 15) * 4;
     const int xl = xb - (minx << 16) + m24(ir, p.c), yl = yb - (miny << 16) - m24(ir, p.s);     // relative to the box, this lane's column
     constexpr float K16 = 1.0f / 65536.0f;
+    if (INTERP == 2) {
+        // The cubic of the test suite's checker (orc_vf.c; rotate_nvcv's has no integer reference): rows first, 14-bit weights, out = clamp((sum_r wy[r]
+        // * hs[r] + 2^27) >> 28).  The kernel is bound by VALU issue (27 M instructions a 4K frame in the round-3 form, profiles/r04_rotate.txt):
+        // a row's four taps of a channel are two v_perm_b32 + two v_dot2_i32_i16 against the table's packed weights as before; the 38-bit
+        // vertical sum — four 64-bit multiply-adds, a 64-bit shift and a clamp a channel — is four v_fma_f64 on exact doubles (full rate on
+        // gfx950: 4.7 cycles, tools/ubench/rot_probe.hip), a scale by 2^-28, a conversion that truncates and one v_med3 (what truncation does
+        // to a negative sum the clamp to 0 hides); no border case, no clamped indices in the whole tile.
+#pragma unroll 1
+        for (int jr = wave * 4 + (lane >> 4); jr < G::MH; jr += 16) {
+            const int x0 = xl + m24(jr, p.s), y0 = yl + m24(jr, p.c);
+            unsigned W[BPP];
+#pragma unroll
+            for (int k = 0; k < BPP; k++) W[k] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int x = x0 + q * p.c, y = y0 - q * p.s;            // relative to the box: x >> 16 >= 1
+                const unsigned wx01 = cw[2 * ((x >> 8) & 0xFF)], wx23 = cw[2 * ((x >> 8) & 0xFF) + 1];
+                const unsigned wy01 = cw[2 * ((y >> 8) & 0xFF)], wy23 = cw[2 * ((y >> 8) & 0xFF) + 1];
+                const double wy[4] = {(double)(int)(short)(wy01 & 0xFFFF), (double)((int)wy01 >> 16), (double)(int)(short)(wy23 & 0xFFFF), (double)((int)wy23 >> 16)};
+                const int bo = m24((y >> 16) - 1, PD * 4) + m24((x >> 16) - 1, BPP) + shift;
+                const unsigned *w = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(box) + (bo & ~3));
+                const unsigned sh = (unsigned)bo & 3u;
+                double acc[BPP];
+#pragma unroll
+                for (int k = 0; k < BPP; k++) acc[k] = 134217728.0;     // 2^27
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    unsigned c[BPP];                         // the row's four taps: 4 BPP consecutive bytes
+#pragma unroll
+                    for (int n = 0; n < BPP; n++) c[n] = BPP == 4 ? w[r * PD + n] : __builtin_amdgcn_alignbyte(w[r * PD + n + 1], w[r * PD + n], sh);
+#pragma unroll
+                    for (int k = 0; k < BPP; k++) {
+                        // taps 0, 1 and 2, 3 of channel k as int16 pairs (bytes k, k + BPP and k + 2 BPP, k + 3 BPP of the row's 4 BPP)
+                        constexpr unsigned Z = 0x0C000C00u;
+                        const int n0 = k, n1 = BPP + k, n2 = 2 * BPP + k, n3 = 3 * BPP + k;
+                        const unsigned p01 = __builtin_amdgcn_perm(c[n1 >> 2], c[n0 >> 2], Z | (unsigned)(n0 & 3) | ((unsigned)(4 + (n1 & 3)) << 16));
+                        const unsigned p23 = __builtin_amdgcn_perm(c[n3 >> 2], c[n2 >> 2], Z | (unsigned)(n2 & 3) | ((unsigned)(4 + (n3 & 3)) << 16));
+                        const int hs = dot2((int)p01, (int)wx01, dot2z((int)p23, (int)wx23));
+                        acc[k] = __builtin_fma(wy[r], (double)hs, acc[k]);          // exact: |sum| < 2^40
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < BPP; k++) {
+                    const int o = min(max((int)(acc[k] * (1.0 / 268435456.0)), 0), 255);
+                    const int n = q * BPP + k;
+                    W[n >> 2] |= (unsigned)o << (8 * (n & 3));
+                }
+            }
+            unsigned *d = reinterpret_cast<unsigned *>(dst + (size_t)(jLo + jr) * ds + (size_t)(iLo + ir) * BPP);
+#pragma unroll
+            for (int k = 0; k < BPP; k++) d[k] = W[k];
+        }
+        return;
+    }
 #pragma unroll 1
     for (int jr = wave * 4 + (lane >> 4); jr < G::MH; jr += 16) {
         const int x0 = xl + m24(jr, p.s), y0 = yl + m24(jr, p.c);
@@ -2002,9 +2100,9 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
         // wave) is the A/B that showed the kernel is not bound by them: 21.0 against 20.7 us (profiles/r03zr_rotate.txt)
         const char *ew = GMAT_KNOB("GMAT_ROTATE_WAVES");
         const int nwv = ew && atoi(ew) == 2 ? 2 : 4;
-        // nearest and bilinear: 64 x 32 macro tiles (rotate_mt_kernel); GMAT_ROTATE_MT=0 keeps the 32 x 32 form (A/B, and the tests' way to it)
+        // 64 x 32 macro tiles (rotate_mt_kernel); GMAT_ROTATE_MT=0 keeps the 32 x 32 form (A/B, and the tests' way to it)
         const char *em = GMAT_KNOB("GMAT_ROTATE_MT");
-        if (bilinear != 2 && nwv == 4 && (em ? atoi(em) != 0 : true)) {
+        if (nwv == 4 && (em ? atoi(em) != 0 : true)) {
             const int nbxM = (outW + 63) / 64;
             const dim3 grid(8 * nbxM, (nby + 7) / 8, frames ? nframes : 1), block(256);
             const OpFrames fr = frames ? *frames : op_frames(src, dst, nullptr);
@@ -2013,7 +2111,8 @@ int launch_rotate(const uint8_t *src, int ss, uint8_t *dst, int ds, int inW, int
             const int xi = 63 * p.c, xj = 31 * p.s, yi = -63 * p.s, yj = 31 * p.c;
             mt.dxLo = std::min(xi, 0) + std::min(xj, 0); mt.dxHi = std::max(xi, 0) + std::max(xj, 0);
             mt.dyLo = std::min(yi, 0) + std::min(yj, 0); mt.dyHi = std::max(yi, 0) + std::max(yj, 0);
-#define GMAT_ROTM(B_) do { if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); \
+#define GMAT_ROTM(B_) do { if (bilinear == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 2>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); \
+                           else if (bilinear) hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 1>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); \
                            else hipLaunchKernelGGL(HIP_KERNEL_NAME(rotate_mt_kernel<B_, 0>), grid, block, 0, stream, src, ss, dst, ds, p, mt, aligned, nbx, nby, fr); } while (0)
             switch (bpp) {
             case 1:  GMAT_ROTM(1); break;

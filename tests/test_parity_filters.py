@@ -850,3 +850,25 @@ def test_rotate_bilinear_interior_tiles(dev, orc, bpp):
         got = o.download()
         assert (got == want).all(), ((bpp, deg, interp), np.argwhere(got != want)[:4].tolist())
         d.free(); o.free()
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+@pytest.mark.parametrize("bpp", [1, 3, 4])
+def test_rotate_tiles_outside_the_source(dev, orc, interp, bpp):
+    """whole 64 x 32 tiles none of whose pixels maps into the source (a shift pushes the picture out of most of the frame): the fill
+    colour, or the destination as it was — the tile-level short cut of rotate_mt_kernel next to tiles that cross the source's rim"""
+    w, h = 384, 224
+    src = orc.lcg((h, w * bpp), 55 + bpp)
+    for deg, sx, sy, fill in [(17.0, 210.0, 120.0, (9, 8, 7, 6)), (-40.0, -260.0, 90.0, None), (3.0, 0.0, -190.0, (255, 0, 1, 254))]:
+        fp = (C.c_uint8 * 4)(*fill) if fill else None
+        before = orc.lcg((h, w * bpp), 77)
+        want = before.copy()
+        orc.L.orc_rotate2(src.ctypes.data, src.strides[0], want.ctypes.data, want.strides[0], w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fp)
+        d = dev.upload_planes([src], 256, 0)[0]
+        o = DevPlane(dev, h, w * bpp, (w * bpp + 255) // 256 * 256)
+        o.upload(before)
+        assert dev.lib.gmat_rotate2(d.ptr, d.stride, o.ptr, o.stride, w, h, w, h, bpp, math.radians(deg), interp, sx, sy, fp, None) == 0
+        got = o.download()
+        assert (got == want).all(), ((bpp, deg, interp), np.argwhere(got != want)[:4].tolist())
+        assert (o.download(with_padding=True)[:, w * bpp:] == 0xCD).all()
+        d.free(); o.free()
