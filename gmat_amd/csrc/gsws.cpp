@@ -143,6 +143,9 @@ struct GmatSwsContext {
     YuvGTables yg;                // the polyphase band walker for any ratio (k_scale_yuvg.hip)
     DevBuf dG[4 + 2 * 2 * 5];     // its device tables: hL, hC, posL, posC, then per (plane class, direction) coef / first / last / round / yLo
     YuvGArgs gargs;
+    YuvUTables yu;                // the quad-lane walker: up-scales of any factor, short filters (k_scale_yuvu.hip)
+    DevBuf dU[12];                // its device tables
+    YuvUArgs uargs;
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
@@ -264,6 +267,22 @@ static int init_yuv_scaler(GmatSwsContext *c)
         g.n4L = t.n4L; g.n4C = t.n4C; g.blkRows = t.blkRows; g.blkRowsC = t.blkRowsC;
         g.roundL = t.roundL; g.roundC = t.roundC;
         g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
+    }
+    if (!a.src16 && !c->rgbViaPlanes && (r = yuvu_prepare(c->planYuv, c->ytiling, c->yu)) < 0) return r;
+    if (c->yu.ok) {
+        YuvUArgs &u = c->uargs;
+        std::memset(&u, 0, sizeof(u));
+        const YuvUTables &t = c->yu;
+        int k = 0;
+        auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            int rr = c->dU[k].upload(v.data(), v.size() * 4);
+            out = (const int32_t *)c->dU[k++].p;
+            return rr;
+        };
+        if ((r = up(t.hL, u.hL)) < 0 || (r = up(t.hC, u.hC)) < 0 || (r = up(t.posL, u.posL)) < 0 || (r = up(t.posC, u.posC)) < 0 ||
+            (r = up(t.vtL, u.vtL)) < 0 || (r = up(t.vtC, u.vtC)) < 0 || (r = up(t.endL, u.endL)) < 0 || (r = up(t.endC, u.endC)) < 0 ||
+            (r = up(t.firstL, u.firstL)) < 0 || (r = up(t.firstC, u.firstC)) < 0 || (r = up(t.lastL, u.lastL)) < 0 || (r = up(t.lastC, u.lastC)) < 0) return r;
+        u.P = t.P; u.SD = t.SD; u.RL = t.RL; u.RC = t.RC; u.roundL = t.roundL; u.roundC = t.roundC; u.yuvOut = t.yuvOut;
     }
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
@@ -527,6 +546,35 @@ static bool yuvg_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     YuvGArgs g = c->gargs;
+    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs; g.nv12 = ya.nv12;
+    g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
+    g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
+    g.ds = ya.ds; g.dsU = ya.dsU; g.dsV = ya.dsV; g.dstFormat = ya.dstFormat;
+    g.xcdRemap = ya.xcdRemap; g.y2r = ya.y2r;
+    return g;
+}
+
+// the quad-lane walker (up-scales of any factor, short filters): the band walker's pointer rule (dword-aligned planes on both sides, planar
+// chroma planes of one pitch); RGBA destinations store 16 bytes a lane.  Which contexts take it: up-scales on the vertical axis — where
+// the band walker keeps 12 - 22 running sums or declines — unless GMAT_QUAD_WALKER says otherwise (0: never, 2: wherever it is eligible)
+static bool yuvu_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    if (!c->yu.ok || c->rangeConv || ya.prof) return false;
+    const char *qw = GMAT_KNOB("GMAT_QUAD_WALKER");
+    const int mode = qw ? atoi(qw) : 1;
+    if (mode == 0 || (mode == 1 && !(ya.dstH > ya.srcH))) return false;
+    uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
+    if (!ya.nv12) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
+    if (c->yu.yuvOut) {
+        all |= (uintptr_t)ya.dstU | (uintptr_t)ya.dsU;
+        if (!ya.dstNv12) all |= (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
+    }
+    return (all & 3) == 0;
+}
+
+static YuvUArgs make_yuvu_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    YuvUArgs g = c->uargs;
     g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs; g.nv12 = ya.nv12;
     g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
     g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
@@ -850,6 +898,9 @@ static const PlaneKernel kPlaneKernels[] = {
          const Yuv2xArgs xa = make_yuv2x_args(c, ya);
          return n == 1 ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st)      // (one frame: the pointers of the argument block)
                        : launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st, &fr, n); }},
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvu_eligible(c, ya); },                                    // up-scales of any factor: the quad-lane walker
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvu_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},

@@ -348,6 +348,32 @@ int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables 
 int  launch_scale_yuvg(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launch of nframes frames takes scale_yuvg_blk_*_kernel
 
+// ---- the quad-lane polyphase walker (k_scale_yuvu.hip, round 4): a lane owns FOUR adjacent outputs of a row, the vertical filter is a
+// GATHER over a short register ring of horizontally filtered row pairs (coefficients by output row, relative to the newest pair) — no
+// running sums, so the number of output rows open at once does not matter: UP-scales of any factor (and down-scales up to 2 : 1) ------
+struct YuvUTables {
+    int ok = 0, P = 0, SD = 1, yuvOut = 0, roundL = 0, roundC = 0;
+    int RL = 0, RC = 0;                                       // ring depth: 4:2:0 destination: luma job / chroma jobs; RGB: luma / chroma stream
+    std::vector<int32_t> hL, hC, posL, posC;                  // [dstW][P] / [chrDstW][P] packed coefficient pairs, window starts
+    // a STEP is a row pair of the plane (4:2:0 destination) or a quad = two luma row pairs + the chroma row pair beside them (RGB).
+    // vt*: per output row the coefficient pairs on the ring, newest pair first, as of the step that completes the row (RGB: vtL holds
+    // RL luma + RC chroma pairs a row); end*[s]: output rows complete after step s; first* / last*: a row's first / last step
+    std::vector<int32_t> vtL, vtC, endL, endC, firstL, firstC, lastL, lastC;
+};
+struct YuvUArgs {
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
+    int ds, dsU, dsV, dstFormat, yuvOut;
+    int P, SD, RL, RC, roundL, roundC;
+    const int32_t *hL, *hC, *posL, *posC;
+    const int32_t *vtL, *vtC, *endL, *endC, *firstL, *firstC, *lastL, *lastC;
+    // filled by the launcher: rows per band, groups of four 256-byte strips per row, blocks (luma | chroma jobs of a 4:2:0 destination)
+    int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap;
+    Yuv2RgbConsts y2r;
+};
+int  yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvUTables &t);
+int  launch_scale_yuvu(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> YUV 4:2:0 scaler (k_scale_yuv2p.hip): NV12 -> NV12 and
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
 struct Yuv2pTables {
