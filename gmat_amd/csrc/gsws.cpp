@@ -282,7 +282,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         if ((r = up(t.hL, u.hL)) < 0 || (r = up(t.hC, u.hC)) < 0 || (r = up(t.posL, u.posL)) < 0 || (r = up(t.posC, u.posC)) < 0 ||
             (r = up(t.vtL, u.vtL)) < 0 || (r = up(t.vtC, u.vtC)) < 0 || (r = up(t.endL, u.endL)) < 0 || (r = up(t.endC, u.endC)) < 0 ||
             (r = up(t.firstL, u.firstL)) < 0 || (r = up(t.firstC, u.firstC)) < 0 || (r = up(t.lastL, u.lastL)) < 0 || (r = up(t.lastC, u.lastC)) < 0) return r;
-        u.P = t.P; u.SD = t.SD; u.RL = t.RL; u.RC = t.RC; u.roundL = t.roundL; u.roundC = t.roundC; u.yuvOut = t.yuvOut;
+        u.P = t.P; u.SD = t.SD; u.RL = t.RL; u.RC = t.RC; u.lead = t.lead; u.roundL = t.roundL; u.roundC = t.roundC; u.yuvOut = t.yuvOut;
     }
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {

@@ -109,7 +109,7 @@ struct UStream {
     unsigned ring[RR][2][SD];
     unsigned win[NC][2][NW];
     unsigned *img;                       // this wave's two row images of this stream
-    unsigned reqOff, rowStep;            // (wave-uniform) byte offset of the next row to request; one row
+    int reqOff, rowStep, lastOff;        // (wave-uniform) byte offset of the next row to request; one row; the plane's last row
 
     // column c of this lane is output column `col` of the plane; returns the first byte of its window (dword aligned)
     __device__ __forceinline__ int setup_col(int c, const int32_t *hTab, const int32_t *posTab, int col)
@@ -122,16 +122,21 @@ struct UStream {
         for (int t = 0; t < P; t++) cf[c][t] = hTab[(size_t)col * P + t];
         return b0 & ~3;
     }
-    __device__ __forceinline__ void start(int pair, int stride)
+    // the walk starts at row pair `pair` (it may lie in front of the plane: an RGB destination's luma stream runs behind its chroma stream)
+    __device__ __forceinline__ void start(int pair, int stride, int rows)
     {
-        rowStep = (unsigned)stride;
-        reqOff = (unsigned)(2 * pair) * (unsigned)stride;
+        rowStep = stride;
+        reqOff = 2 * pair * stride;
+        lastOff = (rows - 1) * stride;
     }
+    // rows in front of the plane and behind it are requested as its first / last row: no tap falls on them (scalar clamps: the resource's
+    // own range check is not relied on)
     template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SD])
     {
+        const unsigned o0 = (unsigned)min(max(reqOff, 0), lastOff), o1 = (unsigned)min(max(reqOff + rowStep, 0), lastOff);
 #pragma unroll
-        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = ld(ldOff[s], reqOff + rowStep); }
-        reqOff += 2u * rowStep;
+        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], o0); dst[1][s] = ld(ldOff[s], o1); }
+        reqOff += 2 * rowStep;
     }
     // a row pair's bytes: registers -> row images -> every column's windows
     __device__ __forceinline__ void gather(const unsigned (&src)[2][SD])
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
         }
         auto ld = [&](unsigned off, unsigned row) { return bS.ld1(off, row); };
         const int pa = uniform_load(firstT, ya), pb = uniform_load(lastT, yb - 1);
-        W.start(pa, ss);
+        W.start(pa, ss, srcRows);
         W.prime(ld);
         int hr[R][4];                                               // the ring: hr[j] = the pair j steps before the newest
 #pragma unroll
@@ -268,28 +273,11 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
 #pragma unroll
             for (int o = 0; o < 4; o++) hr[j][o] = 0;
         int y = ya;
-        int c0[R], c1[R];                                           // coefficient pairs of rows y and y + 1, requested ahead of their use
-        u_load_row<R>(vt, y, c0);
-        u_load_row<R>(vt, min(y + 1, rows - 1), c1);
+        // coefficient pairs of the next row to leave: requested as soon as the previous row's sums are done, so that the scalar loads'
+        // way is covered by that row's packing and store (one set of scalar registers, redefined in place: no copies)
+        int cv[R];
+        u_load_row<R>(vt, y, cv);
 
-        auto emit = [&](int yo, const int (&c)[R]) {
-            // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the sums' start value
-            unsigned v[4];
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                int acc = rnd;
-#pragma unroll
-                for (int j = 0; j < R; j++) acc = u_dot2(hr[j][o], c[j], acc);
-                v[o] = (unsigned)clip_u8_shr(acc, 19);
-            }
-            const unsigned d = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-            const unsigned drow = (unsigned)yo * (unsigned)dstride;
-            if (b0 + 4 <= rowBytes) bD.st1(d, (unsigned)b0, drow);
-            else if (b0 < rowBytes) {                                // a row that is not whole dwords: its last bytes one by one
-                uint8_t *q = dp + (size_t)drow + (unsigned)b0;
-                for (int i = 0; i < rowBytes - b0; i++) q[i] = (uint8_t)(d >> (8 * i));
-            }
-        };
         auto step = [&](int p, auto slot_c) {
             constexpr int SLOT = decltype(slot_c)::value;
             const int ye = min(uniform_load(endT, p), yb);         // output rows complete after this pair
@@ -303,11 +291,24 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
 #pragma unroll
             for (int o = 0; o < 4; o++) hr[0][o] = hp[o];
             while (y < ye) {
-                int c[R];
+                // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the sums' start value
+                int acc[4];
 #pragma unroll
-                for (int j = 0; j < R; j++) { c[j] = c0[j]; c0[j] = c1[j]; }
-                u_load_row<R>(vt, min(y + 2, rows - 1), c1);
-                emit(y, c);
+                for (int o = 0; o < 4; o++) {
+                    acc[o] = rnd;
+#pragma unroll
+                    for (int j = 0; j < R; j++) acc[o] = u_dot2(hr[j][o], cv[j], acc[o]);
+                }
+                u_load_row<R>(vt, min(y + 1, rows - 1), cv);
+                const unsigned v0 = (unsigned)clip_u8_shr(acc[0], 19), v1 = (unsigned)clip_u8_shr(acc[1], 19);
+                const unsigned v2 = (unsigned)clip_u8_shr(acc[2], 19), v3 = (unsigned)clip_u8_shr(acc[3], 19);
+                const unsigned d = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+                const unsigned drow = (unsigned)y * (unsigned)dstride;
+                if (b0 + 4 <= rowBytes) bD.st1(d, (unsigned)b0, drow);
+                else if (b0 < rowBytes) {                            // a row that is not whole dwords: its last bytes one by one
+                    uint8_t *q = dp + (size_t)drow + (unsigned)b0;
+                    for (int i = 0; i < rowBytes - b0; i++) q[i] = (uint8_t)(d >> (8 * i));
+                }
                 y++;
             }
         };
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
 // ---- packed RGB destinations -----------------------------------------------------------------------------------------------------------
 // block = 4 waves = 4 adjacent strips of 256 pixels of one band; grid.y = frame.  A lane: 4 pixels = 4 luma columns + the 2 chroma
 // columns under them (RGB destinations keep the chroma plane at half the output width, one sample a pixel pair: yuv2rgb_X_c_template).
-// A step is a QUAD: luma row pairs 2q, 2q + 1 and chroma row pair q; RL / RC = ring depths, counted from pair 2q + 1 / q.
+// A step: two luma row pairs and one chroma row pair (below); RL / RC = ring depths, counted from the step's newest pair of each stream.
 template <int P, int RL, int RC, int SD, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFrames fr)
 {
@@ -407,9 +408,13 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
         if (NV12 || lane < 32) v = bU.ld1(off, row); else v = bV.ld1(off, row);      // only the load diverges (planar: us == vs, host rule)
         return v;
     };
+    // a step s: luma row pairs 2 (s - lead), 2 (s - lead) + 1 and chroma row pair s.  lead: the luma stream runs that many steps behind the
+    // chroma stream (the host's choice, 0 .. 2): the chroma of an RGB destination is up-scaled twice as far as its luma, its windows end
+    // later, and with the streams side by side every luma window would have to be kept a step longer (deeper rings, more dot products a
+    // row).  Luma pairs in front of the plane (a band at the frame's top) read as 0 and carry no taps.
     const int q0 = uniform_load(a.firstL, ya), q1 = uniform_load(a.lastL, yb - 1);
-    L.start(2 * q0, a.ys);
-    C.start(q0, a.us);
+    L.start(2 * (q0 - a.lead), a.ys, a.srcH);
+    C.start(q0, a.us, a.chrSrcH);
     L.prime(ldL);
     C.prime(ldC);
     int hL[RL][4], hC[RC][4];                                      // the rings, newest pair first
@@ -422,74 +427,16 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
 #pragma unroll
         for (int o = 0; o < 4; o++) hC[j][o] = 0;
     int y = ya;
-    int c0[RV], c1[RV];                                            // RL luma + RC chroma coefficient pairs of rows y and y + 1
-    u_load_row<RV>(a.vtL, y, c0);
-    u_load_row<RV>(a.vtL, min(y + 1, a.dstH - 1), c1);
+    // RL luma + RC chroma coefficient pairs of the next row to leave: requested as soon as the previous row's sums are done, so that the
+    // scalar loads' way is covered by that row's colour stage (one set of scalar registers, redefined in place: no copies)
+    int cv[RV];
+    u_load_row<RV>(a.vtL, y, cv);
     const int npx = a.dstW - x0;                                   // pixels this lane really has (>= 4: all four)
 
-    auto emit = [&](int yo, const int (&c)[RV]) {
-        int Y[4], iU[2], iV[2];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            int acc = a.roundL;
-#pragma unroll
-            for (int j = 0; j < RL; j++) acc = u_dot2(hL[j][o], c[j], acc);
-            Y[o] = acc >> 19;
-        }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            int acc = a.roundC;
-#pragma unroll
-            for (int j = 0; j < RC; j++) acc = u_dot2(hC[j][o], c[RL + j], acc);
-            const int v = clip_u8_shr(acc, 19);
-            // NV12: (U, V) of column 0, then of column 1;  planar: U of columns 0, 1, then V
-            if (NV12) { if (o & 1) iV[o >> 1] = v; else iU[o >> 1] = v; }
-            else      { if (o & 2) iV[o & 1] = v; else iU[o & 1] = v; }
-        }
-        unsigned k0[4], k1[4], k2[4];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int2 tv = lutV[iV[h]], tu = lutU[iU[h]];
-            const int tr = bgr ? tu.y : tv.x, tg = tv.y + tu.x, tb = bgr ? tv.x : tu.y;
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int q = 2 * h + e;
-                const int ycy = m24(Y[q], a.y2r.cy);
-                k0[q] = (unsigned)(tr + ycy); k1[q] = (unsigned)(tg + ycy); k2[q] = (unsigned)(tb + ycy);   // |term + Y cy| < 2^27: the channel is sat_u8 of the high half
-            }
-        }
-        const unsigned drow = (unsigned)yo * (unsigned)a.ds;
-        // two channels -> bytes (0, 1) of a register: the high halves side by side, then the saturating pack
-    #define U_SAT2(x, y) u_sat_pk_u8_i16(__builtin_amdgcn_perm((y), (x), 0x07060302u))
-    #define U_JOIN(lo2, hi2) __builtin_amdgcn_perm((hi2), (lo2), 0x05040100u)
-        if (bpp == 4) {
-            uint4 o4;
-            o4.x = U_JOIN(U_SAT2(k0[0], k1[0]), U_SAT2(k2[0], 0x00FF0000u));
-            o4.y = U_JOIN(U_SAT2(k0[1], k1[1]), U_SAT2(k2[1], 0x00FF0000u));
-            o4.z = U_JOIN(U_SAT2(k0[2], k1[2]), U_SAT2(k2[2], 0x00FF0000u));
-            o4.w = U_JOIN(U_SAT2(k0[3], k1[3]), U_SAT2(k2[3], 0x00FF0000u));
-            if (npx >= 4) bD.st4(o4, 4u * (unsigned)x0, drow);
-            else if (npx > 0) {
-                const unsigned w[4] = {o4.x, o4.y, o4.z, o4.w};
-                uint8_t *d = fr.dst[f] + (size_t)drow + 4u * (unsigned)x0;
-                for (int i = 0; i < npx; i++) std::memcpy(d + 4 * i, &w[i], 4);
-            }
-        } else {
-            uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-            o3.x = U_JOIN(U_SAT2(k0[0], k1[0]), U_SAT2(k2[0], k0[1]));
-            o3.y = U_JOIN(U_SAT2(k1[1], k2[1]), U_SAT2(k0[2], k1[2]));
-            o3.z = U_JOIN(U_SAT2(k2[2], k0[3]), U_SAT2(k1[3], k2[3]));
-            if (npx >= 4) bD.st3(o3, 3u * (unsigned)x0, drow);
-            else if (npx > 0) {
-                const unsigned w[3] = {o3.x, o3.y, o3.z};
-                uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)x0;
-                for (int i = 0; i < 3 * npx; i++) d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
-            }
-        }
-    #undef U_SAT2
-    #undef U_JOIN
-    };
-    // one quad.  SA / SB / SC: the ring slots holding the pairs that follow (static: quads alternate between two sets of slots).  A
+    // two channels -> bytes (0, 1) of a register: the high halves side by side, then the saturating pack
+#define U_SAT2(x, y) u_sat_pk_u8_i16(__builtin_amdgcn_perm((y), (x), 0x07060302u))
+#define U_JOIN(lo2, hi2) __builtin_amdgcn_perm((hi2), (lo2), 0x05040100u)
+    // one step.  SA / SB / SC: the ring slots holding the pairs that follow (static: steps alternate between two sets of slots).  A
     // gather's LDS round trip is covered by work that does not need it: the other stream's horizontal filter, the rows leaving.
     auto quad = [&](int q, auto sa_c, auto sb_c, auto sc_c) {
         constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value, SC = decltype(sc_c)::value;
@@ -514,11 +461,59 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
 #pragma unroll
         for (int o = 0; o < 4; o++) hC[0][o] = hpc[o];
         while (y < ye) {
-            int c[RV];
+            int aL[4], aC[4];
 #pragma unroll
-            for (int j = 0; j < RV; j++) { c[j] = c0[j]; c0[j] = c1[j]; }
-            u_load_row<RV>(a.vtL, min(y + 2, a.dstH - 1), c1);
-            emit(y, c);
+            for (int o = 0; o < 4; o++) {
+                aL[o] = a.roundL; aC[o] = a.roundC;
+#pragma unroll
+                for (int j = 0; j < RL; j++) aL[o] = u_dot2(hL[j][o], cv[j], aL[o]);
+#pragma unroll
+                for (int j = 0; j < RC; j++) aC[o] = u_dot2(hC[j][o], cv[RL + j], aC[o]);
+            }
+            u_load_row<RV>(a.vtL, min(y + 1, a.dstH - 1), cv);
+            // chroma samples: NV12: (U, V) of column 0, then of column 1;  planar: U of columns 0, 1, then V
+            int iU[2], iV[2];
+            iU[0] = clip_u8_shr(aC[0], 19);
+            iV[0] = clip_u8_shr(aC[NV12 ? 1 : 2], 19);
+            iU[1] = clip_u8_shr(aC[NV12 ? 2 : 1], 19);
+            iV[1] = clip_u8_shr(aC[3], 19);
+            unsigned k0[4], k1[4], k2[4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int2 tv = lutV[iV[h]], tu = lutU[iU[h]];
+                const int tr = bgr ? tu.y : tv.x, tg = tv.y + tu.x, tb = bgr ? tv.x : tu.y;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int q4 = 2 * h + e;
+                    const int ycy = m24(aL[q4] >> 19, a.y2r.cy);
+                    k0[q4] = (unsigned)(tr + ycy); k1[q4] = (unsigned)(tg + ycy); k2[q4] = (unsigned)(tb + ycy);   // |term + Y cy| < 2^27: the channel is sat_u8 of the high half
+                }
+            }
+            const unsigned drow = (unsigned)y * (unsigned)a.ds;
+            if (bpp == 4) {
+                uint4 o4;
+                o4.x = U_JOIN(U_SAT2(k0[0], k1[0]), U_SAT2(k2[0], 0x00FF0000u));
+                o4.y = U_JOIN(U_SAT2(k0[1], k1[1]), U_SAT2(k2[1], 0x00FF0000u));
+                o4.z = U_JOIN(U_SAT2(k0[2], k1[2]), U_SAT2(k2[2], 0x00FF0000u));
+                o4.w = U_JOIN(U_SAT2(k0[3], k1[3]), U_SAT2(k2[3], 0x00FF0000u));
+                if (npx >= 4) bD.st4(o4, 4u * (unsigned)x0, drow);
+                else if (npx > 0) {
+                    const unsigned w[4] = {o4.x, o4.y, o4.z, o4.w};
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 4u * (unsigned)x0;
+                    for (int i = 0; i < 4 * npx; i++) d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+                }
+            } else {
+                uint3 o3;           // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                o3.x = U_JOIN(U_SAT2(k0[0], k1[0]), U_SAT2(k2[0], k0[1]));
+                o3.y = U_JOIN(U_SAT2(k1[1], k2[1]), U_SAT2(k0[2], k1[2]));
+                o3.z = U_JOIN(U_SAT2(k2[2], k0[3]), U_SAT2(k1[3], k2[3]));
+                if (npx >= 4) bD.st3(o3, 3u * (unsigned)x0, drow);
+                else if (npx > 0) {
+                    const unsigned w[3] = {o3.x, o3.y, o3.z};
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)x0;
+                    for (int i = 0; i < 3 * npx; i++) d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+                }
+            }
             y++;
         }
     };
@@ -529,6 +524,8 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
         if (q + 1 > q1) break;
         quad(q + 1, I3(), I0(), I0());
     }
+#undef U_SAT2
+#undef U_JOIN
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -536,7 +533,7 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
 // ---------------------------------------------------------------------------------------------
 // ring depths the kernels are instantiated for: 4:2:0 destinations R (4-tap filters need 3, 8-tap ones 5), RGB (RL, RC)
 static const int kUP[] = {2, 3, 4}, kUR[] = {3, 5};
-static const int kURgb[][2] = {{4, 3}, {6, 4}, {8, 5}};
+static const int kURgb[][2] = {{4, 3}, {4, 4}, {6, 4}, {8, 5}};      // (bilinear: 4 / 3; bicubic: 4 / 4 with the luma stream a step behind; Lanczos-3: 6 / 4)
 
 int yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
 {
@@ -646,40 +643,49 @@ int yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
         fill(g.vChrEff, t.lastC, t.vtC, t.endC);
         t.RL = t.RC = R;
     } else {
-        // a step = a quad: luma rows 4q .. 4q + 3 (pairs 2q, 2q + 1), chroma rows 2q, 2q + 1 (pair q)
+        // a step s = luma row pairs 2 (s - lead), 2 (s - lead) + 1 and chroma row pair s.  lead = 0 .. 2, whichever needs the shallowest rings
         const FilterBank &fl = g.vLumEff, &fc = g.vChrEff;
         const int rows = p.dstH;
-        t.firstL.resize(rows); t.lastL.resize(rows);
-        int needL = 1, needC = 1;
-        for (int y = 0; y < rows; y++) {
-            t.firstL[y] = std::min(fl.pos[y] >> 2, fc.pos[y] >> 1);
-            t.lastL[y] = std::max((fl.pos[y] + fl.taps - 1) >> 2, (fc.pos[y] + fc.taps - 1) >> 1);
-            if (y && t.lastL[y] < t.lastL[y - 1]) return 0;
-            if (y && t.firstL[y] < t.firstL[y - 1]) return 0;
-            needL = std::max(needL, 2 * t.lastL[y] + 1 - (fl.pos[y] >> 1) + 1);
-            needC = std::max(needC, t.lastL[y] - (fc.pos[y] >> 1) + 1);
+        int RL = 0, RC = 0, lead = 0;
+        std::vector<int32_t> first(rows), last(rows);
+        for (int ld = 0; ld <= 2; ld++) {
+            int needL = 1, needC = 1;
+            bool ok = true;
+            for (int y = 0; y < rows && ok; y++) {
+                first[y] = std::min((fl.pos[y] >> 2) + ld, fc.pos[y] >> 1);
+                last[y] = std::max(((fl.pos[y] + fl.taps - 1) >> 2) + ld, (fc.pos[y] + fc.taps - 1) >> 1);
+                if (y && (last[y] < last[y - 1] || first[y] < first[y - 1])) ok = false;
+                needL = std::max(needL, 2 * (last[y] - ld) + 1 - (fl.pos[y] >> 1) + 1);
+                needC = std::max(needC, last[y] - (fc.pos[y] >> 1) + 1);
+            }
+            if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvu: lead %d: rings needed %d / %d%s", ld, needL, needC, ok ? "" : " (not monotone)");
+            if (!ok) continue;
+            for (const auto &rc : kURgb)
+                if (rc[0] >= needL && rc[1] >= needC) {
+                    if (!RL || rc[0] + rc[1] < RL + RC) { RL = rc[0]; RC = rc[1]; lead = ld; t.firstL = first; t.lastL = last; }
+                    break;
+                }
         }
-        int RL = 0, RC = 0;
-        for (const auto &rc : kURgb) if (rc[0] >= needL && rc[1] >= needC) { RL = rc[0]; RC = rc[1]; break; }
-        if (!RL) { if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvu: %dx%d -> %dx%d declined: rings needed %d / %d", p.srcW, p.srcH, p.dstW, p.dstH, needL, needC); return 0; }
+        if (!RL) { if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvu: %dx%d -> %dx%d declined: rings", p.srcW, p.srcH, p.dstW, p.dstH); return 0; }
         const int RV = RL + RC;
         t.vtL.assign((size_t)rows * RV, 0);
         const int steps = t.lastL.back() + 1;
         t.endL.assign(steps + 1, 0);
         for (int y = 0; y < rows; y++) {
             const int q = t.lastL[y];
-            for (int j = 0; j < RL; j++) { const int pp = 2 * q + 1 - j; t.vtL[(size_t)y * RV + j] = pk(tap(fl, y, 2 * pp), tap(fl, y, 2 * pp + 1)); }
+            for (int j = 0; j < RL; j++) { const int pp = 2 * (q - lead) + 1 - j; t.vtL[(size_t)y * RV + j] = pk(tap(fl, y, 2 * pp), tap(fl, y, 2 * pp + 1)); }
             for (int j = 0; j < RC; j++) { const int pp = q - j; t.vtL[(size_t)y * RV + RL + j] = pk(tap(fc, y, 2 * pp), tap(fc, y, 2 * pp + 1)); }
             t.endL[q] = y + 1;
         }
         for (int s = 1; s <= steps; s++) t.endL[s] = std::max(t.endL[s], t.endL[s - 1]);
+        t.lead = lead;
         t.RL = RL; t.RC = RC;
         // (the 4:2:0 tables are not used: one-element placeholders keep the uploads uniform)
         t.vtC.assign(1, 0); t.endC.assign(1, 0); t.firstC.assign(1, 0); t.lastC.assign(1, 0);
     }
     t.P = P; t.SD = SD; t.yuvOut = yuvOut;
-    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvu: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, SD %d, rings %d / %d", p.srcW, p.srcH, p.dstW, p.dstH,
-                                          p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, SD, t.RL, t.RC);
+    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvu: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, SD %d, rings %d / %d, lead %d", p.srcW, p.srcH, p.dstW, p.dstH,
+                                          p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, SD, t.RL, t.RC, t.lead);
     t.ok = 1;
     return 0;
 }
@@ -716,7 +722,7 @@ int launch_scale_yuvu(const YuvUArgs &a0, hipStream_t stream, const Yuv2xFrames 
                                            else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvu_rgb_kernel<P_, RL_, RC_, SD_, false>), grid, block, 0, stream, a, fr); } while (0)
 #define GMAT_U_SD(P_, SD_) do { \
         if (a.yuvOut) { if (a.RL <= 3) GMAT_U_PL(P_, 3, SD_); else GMAT_U_PL(P_, 5, SD_); } \
-        else          { if (a.RL <= 4) GMAT_U_RGB(P_, 4, 3, SD_); else if (a.RL <= 6) GMAT_U_RGB(P_, 6, 4, SD_); else GMAT_U_RGB(P_, 8, 5, SD_); } } while (0)
+        else          { if (a.RL <= 4 && a.RC <= 3) GMAT_U_RGB(P_, 4, 3, SD_); else if (a.RL <= 4) GMAT_U_RGB(P_, 4, 4, SD_); else if (a.RL <= 6) GMAT_U_RGB(P_, 6, 4, SD_); else GMAT_U_RGB(P_, 8, 5, SD_); } } while (0)
 #define GMAT_U_P(P_) do { if (a.SD == 1) GMAT_U_SD(P_, 1); else GMAT_U_SD(P_, 2); } while (0)
     switch (a.P) { case 2: GMAT_U_P(2); break; case 3: GMAT_U_P(3); break; default: GMAT_U_P(4); }
 #undef GMAT_U_P

@@ -354,6 +354,7 @@ bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launc
 struct YuvUTables {
     int ok = 0, P = 0, SD = 1, yuvOut = 0, roundL = 0, roundC = 0;
     int RL = 0, RC = 0;                                       // ring depth: 4:2:0 destination: luma job / chroma jobs; RGB: luma / chroma stream
+    int lead = 0;                                             // RGB: steps the luma stream runs behind the chroma stream
     std::vector<int32_t> hL, hC, posL, posC;                  // [dstW][P] / [chrDstW][P] packed coefficient pairs, window starts
     // a STEP is a row pair of the plane (4:2:0 destination) or a quad = two luma row pairs + the chroma row pair beside them (RGB).
     // vt*: per output row the coefficient pairs on the ring, newest pair first, as of the step that completes the row (RGB: vtL holds
@@ -364,7 +365,7 @@ struct YuvUArgs {
     int ys, us, vs, nv12;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV, dstFormat, yuvOut;
-    int P, SD, RL, RC, roundL, roundC;
+    int P, SD, RL, RC, lead, roundL, roundC;
     const int32_t *hL, *hC, *posL, *posC;
     const int32_t *vtL, *vtC, *endL, *endC, *firstL, *firstC, *lastL, *lastC;
     // filled by the launcher: rows per band, groups of four 256-byte strips per row, blocks (luma | chroma jobs of a 4:2:0 destination)
