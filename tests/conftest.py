@@ -20,6 +20,10 @@ def pytest_cmdline_main(config):
     GMAT_TEST_SERIAL=1), the run is spread over pytest-xdist workers — what the option `-n 8` would do.  With a GPU in sight nothing is touched:
     one process per GPU."""
     opt = config.option
+    # never inside a worker: xdist runs this hook there too with numprocesses reset to None — without this line every worker spread
+    # itself over eight more (550 processes within 25 s of `pytest tests/test_abi.py`, the container out of memory within minutes)
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
     if not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", None) is not None or getattr(opt, "dist", "no") != "no":
         return None
     if os.environ.get("GMAT_TEST_SERIAL") or os.path.exists("/dev/kfd") or getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
