@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential test aimed at the any-ratio band walker (k_scale_yuvg.hip) in BOTH forms — the register-window walker
+"""Randomised differential test aimed at the quad-lane walker of up-scales (k_scale_yuvu.hip, scale_yuvu_kernel: ratios down to 1 : 6.5, GMAT_QUAD_WALKER
+0 / 1 / 2) and at the any-ratio band walker (k_scale_yuvg.hip) in BOTH forms — the register-window walker
 (scale_yuvg_kernel) and the block-cooperative form of small launches (scale_yuvg_blk_kernel, round 4) — against the oracle: random
 ratios between 1 : 1.9 and 6 : 1 on each axis independently (anamorphic included), every SWS algorithm, both source layouts, packed RGB
 and 4:2:0 destinations, random band heights (GMAT_STRIP_ROWS), random launch sizes through gmat_sws_scale_batch (1 .. 5 frames), widths
@@ -27,8 +28,11 @@ maxw, maxh = (2600, 400) if hip else (900, 160)
 ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline"]
 
 for case in range(n):
-    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST"):
+    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER"):
         os.environ.pop(k, None)
+    q = rng.random()
+    if q < 0.15:   os.environ["GMAT_QUAD_WALKER"] = "0"          # up-scales on the band walker / the tiled kernel
+    elif q < 0.45: os.environ["GMAT_QUAD_WALKER"] = "2"          # the quad-lane walker wherever it is eligible (short-filter down-scales too)
     if rng.random() < 0.5:
         os.environ["GMAT_STRIP_ROWS"] = str(rng.choice([1, 3, 4, 5, 8, 12, 13, 16, 20, 24, 31, 32, 64]))
     r = rng.random()
@@ -42,8 +46,8 @@ for case in range(n):
     dh = 2 * rng.randint(4, maxh // 6)
     if rng.random() < 0.3:
         dw = 64 * rng.randint(1, 8) + rng.choice([0, 0, 2, 62])   # on / just past / just short of the strips
-    rx = rng.choice([rng.uniform(0.55, 1.0), rng.uniform(1.0, 3.0), rng.uniform(1.0, 3.0), rng.uniform(3.0, 6.0)])
-    ry = rx * rng.uniform(0.8, 1.25) if rng.random() < 0.7 else rng.choice([rng.uniform(0.55, 1.0), rng.uniform(1.0, 6.0)])
+    rx = rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 2.0), rng.uniform(1.0, 3.0), rng.uniform(3.0, 6.0)])
+    ry = rx * rng.uniform(0.8, 1.25) if rng.random() < 0.7 else rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 6.0)])
     sw = max(16, min(maxw, 4 * int(dw * rx / 4)))
     sh = max(8, min(maxh, 2 * int(dh * ry / 2)))
     algo = rng.choice(ALGOS)
@@ -62,7 +66,7 @@ for case in range(n):
     except AssertionError as e:
         fails += 1
         print("MISMATCH case", case, sf, "->", df, (sw, sh, dw, dh), algo, "frames", nframes, "align", align,
-              {k: os.environ.get(k) for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP")}, "->", str(e)[:300])
+              {k: os.environ.get(k) for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_QUAD_WALKER")}, "->", str(e)[:300])
 for k, v in hist.most_common():
     print("%6d  %s" % (v, k))
 print("cases", n, "failures", fails)

@@ -1,4 +1,5 @@
 """Shared test plumbing: oracle binding, device-buffer helpers, synthetic frames."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -66,7 +67,7 @@ def is_generic(kernel):
     (scale_yuvg_kernel: dword-aligned 8-bit 4:2:0 -> packed RGB / 4:2:0 of the same chroma layout, filters up to 20 x 18 taps) or
     the tiled plane scaler of round 1 behind it (scale_yuv_kernel<...>).  WHICH of the two a context gets is asserted by
     tests/test_parity_generic_walker.py clause by clause; the per-ratio test files only need "not a specialised walker"."""
-    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel") or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4)
+    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", QUAD) or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4; QUAD: the quad-lane walker of up-scales, round 4)
 
 
 @pytest.fixture(autouse=True)
@@ -75,6 +76,31 @@ def ratio_kernels_keep_single_frames(monkeypatch):
     3:1 / 3:2 -> RGB walkers (gsws.cpp kPlaneKernels; tests/test_parity_generic_walker.py::test_block_form_in_front_of_the_ratio_walkers holds
     the rule).  The per-ratio parity files import this fixture to keep every launch size on the kernel they are about."""
     monkeypatch.setenv("GMAT_BLOCK_FIRST", "0")
+
+
+QUAD = "scale_yuvu_kernel"
+
+
+def quad_takes(sw, sh, sf, df, dw, dh, flags="bicubic"):
+    """the host rule of yuvu_prepare / yuvu_eligible (k_scale_yuvu.hip, the quad-lane walker) restated for dword-aligned frames: the band
+    walker's format rule (8-bit 4:2:0 in; packed 8-bit RGB of even width or 4:2:0 of the SAME chroma layout out; whole dwords in every source
+    row; at least 16 x 8 on both sides), an UP-scale on the vertical axis (the default of GMAT_QUAD_WALKER) and horizontal filters of at most
+    8 taps: any up-scale, a down-scale up to about 1.7 : 1 with the four-tap algorithms.  The algorithms whose windows grow past that on an
+    up-scale (sinc, gauss, spline: 8 - 20 taps) stay where they were.  No limit on the up-scale factor: the vertical filter is a gather."""
+    rgb = df in ("rgb24", "bgr24", "rgba", "bgra")
+    if os.environ.get("GMAT_SCALE_NO_QUAD_WALKER", "0") not in ("", "0") or os.environ.get("GMAT_QUAD_WALKER", "1") == "0":
+        return False
+    if sf not in ("nv12", "yuv420p") or not (rgb or df == sf):
+        return False
+    if sw % 4 or (sf == "yuv420p" and ((sw + 1) // 2) % 4) or (sf == "nv12" and (2 * ((sw + 1) // 2)) % 4):
+        return False
+    if rgb and dw % 2:
+        return False
+    if not (dw >= 16 and dh >= 8 and sw >= 16 and sh >= 8):
+        return False
+    if flags not in ("bicubic", "bilinear", "fast_bilinear", "lanczos", "area", "point"):
+        return False
+    return dh > sh and sw / dw <= (1.7 if flags != "lanczos" else 1.2)
 
 
 def walker_takes(sw, sh, sf, df, dw, dh):

@@ -63,7 +63,7 @@ def test_the_extraction_sees_the_kernels(disassembly):
     assert len(disassembly) >= nsrc, (len(disassembly), nsrc)
     allt = "\n".join(disassembly)
     for k in ("scale_yuv2s_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "rgb2yuv444_kernel", "smooth121_kernel",
-              "scale_yuv_kernel", "yuv2rgb_kernel"):
+              "scale_yuv_kernel", "yuv2rgb_kernel", "scale_yuvu_rgb_kernel", "scale_yuvu_planes_kernel"):
         assert k in allt, k
     assert allt.count("v_dot2") > 1000 and "v_perm_b32" in allt
 
@@ -102,7 +102,9 @@ def test_no_other_instruction_leaves_part_of_its_destination_untouched(disassemb
     # byte S1 of S2, the output dword being assembled (k_transform.hip rot_put_u8); the first of a dword's four starts from 0.  On the GPU:
     # tools/ubench/rot_probe.hip (2^24 blends against the 64-bit integer form, 0 differences), tests -k rotate 168 passed, 1500 fuzz cases
     # (profiles/r04_rotate.txt).
-    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel", "scale_yuvg_blk_rgb_kernel"),
+    # scale_yuvu_rgb_kernel (the quad-lane walker): the headline's colour stage (U_SAT2 -> U_JOIN: bytes 0 and 1 only); bit-exact on the GPU
+    # (gpurun r04r / r04t: tools/probe/probe_yuvu.py, 162 cases; tests/test_parity_quad_walker.py).
+    verified = {"v_sat_pk_u8_i16": ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuvg_rgb_kernel", "scale_yuvg_blk_rgb_kernel", "scale_yuvu_rgb_kernel"),
                 "v_cvt_pk_u8_f32": ("rotate_mt_kernel",)}
     hits = {}
     for t in disassembly:
@@ -126,7 +128,7 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
     silently — scale_yuv1x2_kernel's first build copied its argument block to scratch and ran at 10.4 us per frame.
     (The round-1 tiled kernels scale_rgb_kernel / scale_yuv2x_kernel carry 20 - 188 bytes of it; they are not listed.)"""
     strip = ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
-             "scale_yuvg_blk_rgb_kernel", "scale_yuvg_blk_planes_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
+             "scale_yuvg_blk_rgb_kernel", "scale_yuvg_blk_planes_kernel", "scale_yuvu_rgb_kernel", "scale_yuvu_planes_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel")
     hits, seen = {}, set()
     for t in disassembly:
         func = None
@@ -168,7 +170,7 @@ def test_streaming_stores_are_where_they_were_measured(disassembly):
               "flip_direct_kernel", "median3x3s_kernel"):
         plain, nt = total(k)
         assert nt > 0, (k, plain, nt)
-    for k in ("scale_yuvg_", "rotate_lds_kernel"):
+    for k in ("scale_yuvg_", "scale_yuvu_", "rotate_lds_kernel"):
         plain, nt = total(k)
         assert plain > 0 and nt == 0, (k, plain, nt)
     # smooth121_kernel<BPP, TRANSPOSED, ...>: the plain smooth (TRANSPOSED = false) never streams; the transposed forms do behind a flag,

@@ -7,7 +7,7 @@ under the same oracle."""
 import numpy as np
 import pytest
 
-from harness import SWS, synth_planes, walker_takes, is_generic
+from harness import SWS, synth_planes, walker_takes, quad_takes, is_generic, QUAD
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
 
@@ -57,8 +57,10 @@ def which(request, monkeypatch):
     monkeypatch.setenv("GMAT_SCALE_NO_STRIP", "1")           # the exact-ratio walkers out of the way: this file is about the tier behind them
     if request.param == "tiled":
         monkeypatch.setenv("GMAT_SCALE_NO_GENERIC_WALKER", "1")
+        monkeypatch.setenv("GMAT_SCALE_NO_QUAD_WALKER", "1")     # (the quad-lane walker of up-scales out of the way as well)
     else:
         monkeypatch.delenv("GMAT_SCALE_NO_GENERIC_WALKER", raising=False)
+        monkeypatch.delenv("GMAT_SCALE_NO_QUAD_WALKER", raising=False)
     return request.param
 
 
@@ -81,8 +83,12 @@ def _check(dev, orc, sf, df, geom, flags="bicubic", align=256, extra=0, seed=91,
 
 
 def _expect(which, sf, df, geom):
+    """the kernel the selection rule must pick: the quad-lane walker (k_scale_yuvu.hip, round 4) where the vertical axis is an up-scale and the
+    horizontal filters are short, the band walker in the rest of its range, neither under `tiled`"""
     sw, sh, dw, dh = geom
-    return G if which == "walker" and walker_takes(sw, sh, sf, df, dw, dh) else None
+    if which != "walker":
+        return None
+    return QUAD if quad_takes(sw, sh, sf, df, dw, dh) else G if walker_takes(sw, sh, sf, df, dw, dh) else None
 
 
 @pytest.mark.parametrize("sf", ["nv12", "yuv420p"])
@@ -92,7 +98,7 @@ def test_any_ratio_to_rgb(dev, orc, strip_rows, which, sf, df, geom):
     strip_rows(0)
     k = _check(dev, orc, sf, df, geom)
     e = _expect(which, sf, df, geom)
-    assert k == e if e else (is_generic(k) and k not in (GW, GB)), (k, e)
+    assert k == e if e else (is_generic(k) and k not in (GW, GB, QUAD)), (k, e)
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "yuv420p"])
@@ -104,7 +110,7 @@ def test_any_ratio_to_420(dev, orc, strip_rows, which, fmt, geom):
         pytest.skip("4:2:0 destinations of odd size are test_parity_scale.py's (the tiled kernel)")
     k = _check(dev, orc, fmt, fmt, geom)
     e = _expect(which, fmt, fmt, geom)
-    assert k == e if e else (is_generic(k) and k not in (GW, GB)), (k, e)
+    assert k == e if e else (is_generic(k) and k not in (GW, GB, QUAD)), (k, e)
 
 
 @pytest.mark.parametrize("df", ["bgr24", "rgba"])
@@ -137,10 +143,12 @@ def test_every_algorithm(dev, orc, strip_rows, which, flags):
         k = _check(dev, orc, "nv12", "rgb24", geom, flags)
         assert is_generic(k), k
         if which == "tiled":
-            assert k not in (GW, GB)
+            assert k not in (GW, GB, QUAD)
         k = _check(dev, orc, "nv12", "nv12", geom, flags)
         assert is_generic(k) or "yuv>" in k, k
     if which == "walker":
+        assert _check(dev, orc, "nv12", "rgb24", (200, 120, 300, 180), "bicubic") == QUAD         # the up-scale: the quad-lane walker's
+        assert _check(dev, orc, "nv12", "nv12", (200, 120, 300, 180), "lanczos") == QUAD
         assert _check(dev, orc, "nv12", "rgb24", (384, 216, 160, 90), "bicubic") == G
         assert _check(dev, orc, "nv12", "rgb24", (384, 216, 160, 90), "lanczos") == G
 
@@ -164,12 +172,26 @@ def test_rule_clauses(dev, orc, strip_rows, monkeypatch):
     assert _check(dev, orc, "nv12", "rgb24", (48, 48, 12, 12)) != G                         # narrower than 16
     assert _check(dev, orc, "nv12", "rgb24", (64, 32, 16, 8)) == G
     assert _check(dev, orc, "nv12", "rgb24", (384, 216, 161, 90)) != G                      # odd width: libswscale's full-chroma output
-    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 136)) == G                      # up-scales: the walker's up to 1 : 2 ...
+    # up-scales: the quad-lane walker's at any factor (round 4) ...
+    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 136)) == QUAD
+    assert _check(dev, orc, "nv12", "nv12", (160, 90, 240, 136)) == QUAD
+    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 256, 144)) == QUAD
+    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 320, 180)) == QUAD
+    assert _check(dev, orc, "nv12", "nv12", (128, 72, 640, 360)) == QUAD                    # 1 : 5
+    assert _check(dev, orc, "nv12", "rgb24", (480, 72, 320, 180)) == QUAD                   # 3 : 2 down horizontally (8 taps), up vertically
+    assert _check(dev, orc, "nv12", "rgb24", (800, 72, 320, 180)) != QUAD                   # 2.5 : 1 down horizontally: 11-tap filters
+    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 90)) == G                       # not an up-scale on the vertical axis: the band walker
+    monkeypatch.setenv("GMAT_QUAD_WALKER", "0")                                             # ... and without it the band walker's up to 1 : 2
+    assert _check(dev, orc, "nv12", "rgb24", (160, 90, 240, 136)) == G
     assert _check(dev, orc, "nv12", "nv12", (160, 90, 240, 136)) == G
     assert _check(dev, orc, "nv12", "rgb24", (128, 72, 256, 144)) == G
-    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 320, 180)) != G                      # ... 1 : 2.5: more than 22 output rows open
+    assert _check(dev, orc, "nv12", "rgb24", (128, 72, 320, 180)) != G                      # 1 : 2.5: more than 22 output rows open
     assert _check(dev, orc, "yuv420p", "yuv420p", (128, 72, 256, 144)) == G
     assert _check(dev, orc, "nv12", "nv12", (128, 72, 320, 180)) != G                       # 1 : 2.5: more than 15 output rows open
+    monkeypatch.setenv("GMAT_QUAD_WALKER", "2")                                             # wherever it is eligible: a down-scale with 8-tap filters
+    assert _check(dev, orc, "nv12", "rgb24", (384, 216, 256, 144)) == QUAD
+    assert _check(dev, orc, "nv12", "nv12", (384, 216, 256, 144)) == QUAD
+    monkeypatch.delenv("GMAT_QUAD_WALKER")
     assert _check(dev, orc, "nv12", "rgb24", (960, 540, 120, 60)) != G                      # 8 : 1: 33-tap filters
 
 

@@ -293,7 +293,7 @@ def test_yuv_to_yuv_scaled(dev, orc, src_fmt, dst_fmt, geom):
         if (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and strip_takes(sw, sh, src_fmt, dst_fmt):
             assert kernel == strip_name(src_fmt, dst_fmt), kernel
         else:
-            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel"), kernel
+            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", "scale_yuvu_kernel"), kernel
         for i, (g, w) in enumerate(zip(got, want)):
             bad = np.argwhere(g != w)
             assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
