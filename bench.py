@@ -502,6 +502,11 @@ def other_configs(lib, env, stream, geo, frames=16):
                        geo.nv12 + dw * dh * 3)
         batch_case("nv12 %dx%d -> nv12 %dx%d (4:1), 32 frames per launch" % (geo.sw, geo.sh, geo.sw // 4, geo.sh // 4), "nv12", geo.sw, geo.sh, "nv12",
                    geo.sw // 4, geo.sh // 4, geo.nv12 + (geo.sw // 4) * (geo.sh // 4) * 3 // 2)
+    # up-scales (round 4: the quad-lane walker, k_scale_yuvu.hip — any factor; the tiled kernel's beyond 1 : 2 before it)
+    if geo.sw == 3840 and geo.sh == 2160:
+        for name, sw, sh, dw, dh, df in (("720p -> 1080p nv12 (1:1.5)", 1280, 720, 1920, 1080, "nv12"), ("720p -> 1080p rgb24 (1:1.5)", 1280, 720, 1920, 1080, "rgb24"),
+                                         ("720p -> 4K nv12 (1:3)", 1280, 720, 3840, 2160, "nv12"), ("1080p -> 4K rgb24 (1:2)", 1920, 1080, 3840, 2160, "rgb24")):
+            batch_case("up-scale nv12 %s, 32 frames per launch" % name, "nv12", sw, sh, df, dw, dh, sw * sh * 3 // 2 + (dw * dh * 3 if df == "rgb24" else dw * dh * 3 // 2))
     # configs[3]: rotate(90) + hflip + 3x3 smooth as ONE kernel on 4K rgb24
     w, h = geo.sw, geo.sh
     src = frame_set(frames, w * h * 3, 31)

@@ -556,13 +556,16 @@ static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 
 // the quad-lane walker (up-scales of any factor, short filters): the band walker's pointer rule (dword-aligned planes on both sides, planar
 // chroma planes of one pitch); RGBA destinations store 16 bytes a lane.  Which contexts take it: up-scales on the vertical axis — where
-// the band walker keeps 12 - 22 running sums or declines — unless GMAT_QUAD_WALKER says otherwise (0: never, 2: wherever it is eligible)
-static bool yuvu_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+// the band walker keeps 12 - 22 running sums or declines — at every launch size, and the short-filter down-scales it is eligible for (up to
+// 1.75 : 1) in launches of more than three frames (measured, profiles/r04v_*: 32 frames a launch, band walker / this kernel: 1440p -> 1080p nv12
+// 5.00 / 3.23 us, rgb24 5.09 / 4.33, 1080p -> 900p rgb24 3.67 / 3.58; ONE frame: the band walker's block form 10.0 / 11.6 / 9.5 against 10.5 /
+// 14.1 / 10.6) — unless GMAT_QUAD_WALKER says otherwise (0: never, 2: wherever it is eligible)
+static bool yuvu_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n)
 {
     if (!c->yu.ok || c->rangeConv || ya.prof) return false;
     const char *qw = GMAT_KNOB("GMAT_QUAD_WALKER");
     const int mode = qw ? atoi(qw) : 1;
-    if (mode == 0 || (mode == 1 && !(ya.dstH > ya.srcH))) return false;
+    if (mode == 0 || (mode == 1 && !(ya.dstH > ya.srcH || n > 3))) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
     if (!ya.nv12) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
     if (c->yu.yuvOut) {
@@ -898,7 +901,7 @@ static const PlaneKernel kPlaneKernels[] = {
          const Yuv2xArgs xa = make_yuv2x_args(c, ya);
          return n == 1 ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st)      // (one frame: the pointers of the argument block)
                        : launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st, &fr, n); }},
-    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvu_eligible(c, ya); },                                    // up-scales of any factor: the quad-lane walker
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvu_eligible(c, ya, n); },                                    // up-scales of any factor: the quad-lane walker
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvu_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker

@@ -163,3 +163,14 @@ def test_batched_frames(dev, orc, strip_rows, df):
     assert _run_batch(dev, orc, "nv12", df, 160, 90, 240, 136, nframes=9, nstreams=2, align=16) == QUAD
     assert _run_batch(dev, orc, "nv12", df, 160, 90, 240, 136, nframes=2, nstreams=1, align=16) == QUAD
     assert _run_batch(dev, orc, "yuv420p", "yuv420p" if df == "nv12" else df, 128, 72, 320, 180, nframes=3, nstreams=1, align=64) == QUAD
+
+
+@pytest.mark.parametrize("df", ["rgb24", "nv12"])
+def test_short_filter_down_scales_in_launches_of_more_than_three_frames(dev, orc, strip_rows, df):
+    """the shipped rule (gsws.cpp yuvu_eligible, measured in profiles/r04v_*): a down-scale with filters of at most 8 taps takes this kernel when
+    a launch holds more than three frames (1440p -> 1080p: 5.0 -> 3.2 us a frame against the band walker), the band walker's forms below that"""
+    strip_rows(0)
+    assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=9, nstreams=2, align=16) == QUAD         # four and five frames a launch
+    assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=4, nstreams=1, align=16) == QUAD
+    assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=3, nstreams=1, align=16) in ("scale_yuvg_blk_kernel", "scale_yuvg_kernel")
+    assert _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=5, nstreams=1, align=16) == "scale_yuvg_kernel"      # 2.4 : 1: 11-tap filters

@@ -330,6 +330,18 @@ int main(int argc, char **argv)
         {"any: up yuv420p 720p->1080p yuv420p bicubic", GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_PIX_FMT_YUV420P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"any: up nv12 720p->1440p nv12 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_SWS_BICUBIC},
         {"any: up nv12 720p->1080p rgb24 bicubic", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        // (round 4) beyond 1 : 2 — the tiled kernel's until the quad-lane walker — and an RGB destination at exactly 1 : 2
+        {"any: up nv12 720p->4K nv12 bicubic (1:3)", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"any: up nv12 720p->4K rgb24 bicubic (1:3)", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"any: up nv12 1080p->4K rgb24 bicubic (1:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"any: up nv12 640x480->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 640, 480, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: up nv12 720p->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
+        // short-filter down-scales (8 taps): the band walker's by default, the quad-lane walker's behind GMAT_QUAD_WALKER=2
+        {"any: short nv12 1440p->1080p nv12 bicubic (4:3)", GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: short nv12 1440p->1080p rgb24 bicubic (4:3)", GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"any: short nv12 1080p->1600x900 rgb24 bicubic (1.2:1)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
+        {"any: short nv12 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        {"any: short nv12 1080p->720p nv12 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
     };
     struct Op { const char *label; int op, bpp, pool; };
     const Op ops[] = {{"op: rotate+flip+smooth 4K rgb24", 0, 3}, {"op: rotate+flip+smooth 4K rgba", 0, 4}, {"op: smooth3x3 4K rgb24", 1, 3},
@@ -347,7 +359,7 @@ int main(int argc, char **argv)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4, o.pool);
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
-        if (strstr(k.label, "any:") && !strstr(only, "any")) continue;
+        if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
     return 0;
