@@ -49,7 +49,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PRE_WARM_MS = 40            # untimed clock-ramp load in front of the W warm-up steps
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")     # this round's committed PMC pass (fallback)
-LAUNCH_FRAMES = 32          # frames one launch set carries (kYuv2xMaxFrames)
+LAUNCH_FRAMES = int(os.environ.get("GMAT_BENCH_LAUNCH_FRAMES", "32"))          # frames one launch set carries (kYuv2xMaxFrames; the variable: experiments only)
 DETAIL = {}                 # secondary blocks: printed on earlier lines + bench_detail.json, never in the last line
 
 
