@@ -50,6 +50,9 @@ for case in range(n):
     ry = rx * rng.uniform(0.8, 1.25) if rng.random() < 0.7 else rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 6.0)])
     sw = max(16, min(maxw, 4 * int(dw * rx / 4)))
     sh = max(8, min(maxh, 2 * int(dh * ry / 2)))
+    if (sw, sh) == (dw, dh):
+        hist["(same size: the converter's semantics, tests/test_parity_yuv2rgb.py)"] += 1    # nearest-chroma yuv2rgb.c by design, not orc.sws's generic lines
+        continue
     algo = rng.choice(ALGOS)
     if algo not in SWS:
         algo = "bicubic"
