@@ -1000,6 +1000,25 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
+    if (c->mode == MODE_RGBPF32) {
+        // nv12 -> planar float RGB (the tensor a network reads): one launch per 32 frames, grid.z = frame
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                if (!sp[0] || !sp[1] || !dst_planes[4 * (f0 + i)]) return GMAT_ERR(EINVAL);
+                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.dst[i] = dst_planes[4 * (f0 + i)];
+            }
+            c->lastKernel = "nv12_to_rgbpf32_kernel";
+            int r = launch_nv12_to_rgbpf32(yuv_src_of(c->srcFormat, src_planes + 4 * f0, srcStride), fr.dst[0], dstStride[0], c->srcW, c->srcH,
+                                           c->y2r, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (c->mode == MODE_RGB2YUV && !c->inner) {
         // the same-size RGB -> 4:2:0 converter: one launch of rgb2yuv420s_kernel per 32 frames when every frame passes its rule
         const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;

@@ -115,30 +115,61 @@ __global__ __launch_bounds__(256) void yuv2rgb_kernel(YuvSrc s, Yuv2xFrames fr, 
 // nv12 -> planar float RGB (AV_PIX_FMT_RGBPF32LE as GMAT defines it: three stacked planes,
 // plane k at dst + k*ds*h), value = u8 / 255.0f — the layout and normalisation of
 // nv122color_planar<RGBF32> (yuv2rgb_cuda.cu:381-545,564-570) with the integer colour stage.
-__global__ __launch_bounds__(256) void nv12_to_rgbpf32_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h,
+// This is the tensor a network reads (format_cuda -> tensorrt in the reference's graphs; CSwscale.c): 12 bytes WRITTEN per pixel against 1.5 read,
+// so the kernel is a streaming writer.  Round 4: a lane makes 4 pixels of 2 rows from three dword loads; the chroma terms once per sample pair
+// (not per pixel and row); u8 / 255.0f comes from a 256-entry table in LDS built with the same IEEE division (24 divisions a lane were 60 % of
+// the kernel's instructions); the 16-byte stores are non-temporal (a frame of floats is written once and read by the next kernel at the
+// earliest); FRAMES: grid.z = frame.  1080p 8.4 -> see profiles/r04_rgbpf32.txt
+template <bool FRAMES>
+__global__ __launch_bounds__(256) void nv12_to_rgbpf32_kernel(YuvSrc s, Yuv2xFrames fr, uint8_t *dst, int ds, int w, int h,
                                                               Yuv2RgbConsts k, int aligned)
 {
+    __shared__ float unit[256];
+    {
+        const int i = threadIdx.y * 64 + threadIdx.x;
+        unit[i] = (float)i / 255.0f;
+    }
+    __syncthreads();
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x >= w || y >= h) return;
+    const uint8_t *py = s.y, *pu = s.u;
+    if (FRAMES) { const int f = blockIdx.z; py = fr.y[f]; pu = fr.u[f]; dst = fr.dst[f]; }
     const size_t plane = (size_t)ds * h;
-    const size_t crow = (size_t)(y >> 1);
     const int nx = min(4, w - x);
-    for (int r = 0; r < 2 && y + r < h; r++) {
-        float o[3][4];
-        for (int i = 0; i < 4; i++) {
-            const int xx = min(x + i, w - 1);
-            const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
-            const ChromaTerms c = chroma_terms(k, p[0], p[1]);
-            const int ycy = m24((int)s.y[(size_t)(y + r) * s.ys + xx], k.cy);
-            o[0][i] = (float)luma_chan(c.r, ycy) / 255.0f;
-            o[1][i] = (float)luma_chan(c.g, ycy) / 255.0f;
-            o[2][i] = (float)luma_chan(c.b, ycy) / 255.0f;
+    // the two chroma pairs of these 4 columns: one dword (U0 V0 U1 V1) where the row allows it
+    unsigned uv;
+    {
+        const uint8_t *p = pu + (size_t)(y >> 1) * s.us + x;      // x is even: column x / 2 of the interleaved row
+        if (aligned && nx == 4) uv = *reinterpret_cast<const unsigned *>(p);
+        else {
+            const int x1 = min(x + 2, ((w + 1) & ~1) - 2);         // the last pair again when the row ends here
+            uv = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)pu[(size_t)(y >> 1) * s.us + x1] << 16) | ((unsigned)pu[(size_t)(y >> 1) * s.us + x1 + 1] << 24);
         }
+    }
+    const ChromaTerms c0 = chroma_terms(k, (int)(uv & 0xFF), (int)((uv >> 8) & 0xFF)), c1 = chroma_terms(k, (int)((uv >> 16) & 0xFF), (int)(uv >> 24));
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (y + r >= h) break;
+        unsigned yy;
+        const uint8_t *prow = py + (size_t)(y + r) * s.ys + x;
+        if (aligned && nx == 4) yy = *reinterpret_cast<const unsigned *>(prow);
+        else { yy = 0; for (int i = 0; i < nx; i++) yy |= (unsigned)prow[i] << (8 * i); }
+        float o[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const ChromaTerms &c = i < 2 ? c0 : c1;
+            const int ycy = m24((int)((yy >> (8 * i)) & 0xFF), k.cy);
+            o[0][i] = unit[luma_chan(c.r, ycy)];
+            o[1][i] = unit[luma_chan(c.g, ycy)];
+            o[2][i] = unit[luma_chan(c.b, ycy)];
+        }
+#pragma unroll
         for (int pl = 0; pl < 3; pl++) {
             float *row = reinterpret_cast<float *>(dst + pl * plane + (size_t)(y + r) * ds) + x;
             if (aligned && nx == 4) {
-                *reinterpret_cast<float4 *>(row) = make_float4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+                st_stream(row, make_uint4(__builtin_bit_cast(unsigned, o[pl][0]), __builtin_bit_cast(unsigned, o[pl][1]),
+                                          __builtin_bit_cast(unsigned, o[pl][2]), __builtin_bit_cast(unsigned, o[pl][3])));
             } else {
                 for (int i = 0; i < nx; i++) row[i] = o[pl][i];
             }
@@ -317,13 +348,21 @@ int launch_rgbpf32_to_rgb24(const uint8_t *src, int ss, uint8_t *dst, int ds, in
 }
 
 int launch_nv12_to_rgbpf32(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, const Yuv2RgbConsts &k,
-                           hipStream_t stream)
+                           hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (w <= 0 || h <= 0) return 0;
     if (!s.nv12) return GMAT_ERR(ENOSYS);
-    const int aligned = ((((uintptr_t)dst | (uintptr_t)ds) & 15) == 0);
-    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
-    hipLaunchKernelGGL(nv12_to_rgbpf32_kernel, grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
+    if (frames && (nframes < 1 || nframes > kYuv2xMaxFrames)) return GMAT_ERR(EINVAL);
+    // vector path: dword-aligned luma / chroma rows, 16-byte aligned float rows, for every frame of the launch (the byte path is always correct)
+    int aligned = (w % 2) == 0;
+    for (int f = 0; f < (frames ? nframes : 1); f++) {
+        const uint8_t *py = frames ? frames->y[f] : s.y, *pu = frames ? frames->u[f] : s.u, *pd = frames ? frames->dst[f] : dst;
+        aligned = aligned && aligned4(py, s.ys) && aligned4(pu, s.us) && ((((uintptr_t)pd | (uintptr_t)ds) & 15) == 0);
+    }
+    const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8, frames ? nframes : 1);
+    if (frames) hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_rgbpf32_kernel<true>), grid, block, 0, stream, s, *frames, dst, ds, w, h, k, aligned);
+    else { Yuv2xFrames none; none.y[0] = nullptr;
+           hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_rgbpf32_kernel<false>), grid, block, 0, stream, s, none, dst, ds, w, h, k, aligned); }
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -28,7 +28,7 @@ int launch_yuv2rgb(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h,
                    const Yuv2RgbConsts &k, hipStream_t stream, const Yuv2xFrames *frames = nullptr, int nframes = 1);
 // nv12 -> planar float rgb (value = u8 / 255.0f), plane stride = dstStride * h
 int launch_nv12_to_rgbpf32(const YuvSrc &src, uint8_t *dst, int dstStride, int w, int h,
-                           const Yuv2RgbConsts &k, hipStream_t stream);
+                           const Yuv2RgbConsts &k, hipStream_t stream, const Yuv2xFrames *frames = nullptr, int nframes = 1);
 int launch_swap_rb24(const uint8_t *src, int srcStride, uint8_t *dst, int dstStride, int w, int h,
                      hipStream_t stream);
 // 24 <-> 32 bit and 32 <-> 32 bit packed RGB at equal size (rgbToRgbWrapper's byte moves); swapRB exchanges bytes 0 and 2

@@ -240,3 +240,52 @@ def test_rgbpf32_back_to_8bit(dev, orc, w, h):
                 assert (g == wv).all(), dst_fmt
         for p in dst:
             p.free()
+
+
+@pytest.mark.parametrize("w,h", [(64, 8), (36, 6), (38, 7), (37, 9), (130, 10), (260, 12), (16, 2), (514, 4)])
+@pytest.mark.parametrize("pitch", ["tight", "lines", "odd"])
+def test_nv12_to_rgbpf32_every_shape_single_and_batched(dev, orc, w, h, pitch):
+    """nv12 -> planar float RGB (format_cuda's / CSwscale's tensor; k_yuv2rgb.hip nv12_to_rgbpf32_kernel, round 4: dword loads, the chroma terms
+    once per sample pair, u8 / 255 from an LDS table, streaming 16-byte stores, grid.z = frame): widths on and off the four-pixel groups, odd
+    widths and heights (the last chroma pair and row shared), float rows on 16-byte lines and off them (the per-float path), one call and a
+    batch of three frames through gmat_sws_scale_batch — bit-identical floats, nothing written past a row"""
+    from harness import DevPlane, ptr
+    lib = dev.lib
+    fstride = {"tight": 4 * w, "lines": (4 * w + 63) // 64 * 64, "odd": 4 * w + 4}[pitch]
+    nf = 3
+    srcs, wants, ins, outs = [], [], [], []
+    for f in range(nf):
+        src = synth_planes(orc, "nv12", w, h, seed=40 + f)
+        srcs.append(src)
+        wants.append(orc.nv12_to_rgbpf32(src, w, h))
+        ins.append(dev.upload_planes(src, 4 if pitch != "odd" else 1, 0 if pitch != "odd" else 1))
+        outs.append(DevPlane(dev, 3 * h, 4 * w, fstride))
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT["nv12"], w, h, PIX_FMT["rgbpf32le"], SWS["hwaccel"], None)
+    assert c
+
+    def check(f):
+        got = outs[f].download().view(np.float32).reshape(3, h, w)
+        assert (got.view(np.uint32) == wants[f].view(np.uint32)).all(), (w, h, pitch, f)
+        assert (outs[f].download(with_padding=True)[:, 4 * w:] == 0xCD).all()
+    r = lib.gmat_sws_scale(c, planes([p.ptr for p in ins[0]]), ints([p.stride for p in ins[0]]), 0, h, planes([outs[0].ptr]), ints([fstride]))
+    assert r == h
+    lib.gmat_device_sync()
+    assert lib.gmat_sws_lastKernel(c).decode() == "nv12_to_rgbpf32_kernel"
+    check(0)
+    lib.gmat_memset(outs[0].ptr, 0xCD, 3 * h * fstride)
+    sp = (C.c_void_p * (4 * nf))(); dp = (C.c_void_p * (4 * nf))()
+    for f in range(nf):
+        sp[4 * f], sp[4 * f + 1], dp[4 * f] = ins[f][0].ptr, ins[f][1].ptr, outs[f].ptr
+    r = lib.gmat_sws_scale_batch(c, nf, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in ins[0]]), C.cast(dp, C.POINTER(C.c_void_p)),
+                                 ints([fstride]), C.cast((C.c_void_p * 1)(None), C.POINTER(C.c_void_p)), 1, 0)
+    assert r == nf, r
+    lib.gmat_device_sync()
+    assert int(lib.gmat_sws_lastLaunchFrames(c)) == nf
+    for f in range(nf):
+        check(f)
+    lib.gmat_sws_freeContext(c)
+    for p in outs:
+        p.buf.free()
+    for pl in ins:
+        for p in pl:
+            p.free()

@@ -57,6 +57,7 @@ static size_t frame_bytes(int fmt, int w, int h)
     case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_YUV420P10LE: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: case GMAT_PIX_FMT_YUV444P: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
+    case GMAT_PIX_FMT_RGBPF32LE: return (size_t)w * h * 12;        // three stacked planes of floats
     default: return 0;
     }
 }
@@ -310,6 +311,9 @@ int main(int argc, char **argv)
         {"land: nv12 4K->1080p nv12 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_LANCZOS},
         {"land: nv12 4K->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
         {"nv12 1080p->1080p rgb24 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        // format_cuda / CSwscale's pair (the tensor a network reads): nv12 -> planar float RGB, value = u8 / 255
+        {"nv12 1080p->1080p rgbpf32 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBPF32LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"nv12 4K->4K rgbpf32 convert", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBPF32LE, 3840, 2160, GMAT_SWS_BICUBIC},
         // any ratio: the polyphase band walker (scale_yuvg_kernel); "any:" cases run when the filter names them or "any"
         {"any: nv12 4K->1600x900 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->1600x900 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1600, 900, GMAT_SWS_BICUBIC},
