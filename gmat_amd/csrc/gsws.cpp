@@ -1019,6 +1019,38 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
+    if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) {
+        // planar float RGB -> 4:2:0 (a network's output on its way to the encoder): one launch of pf32_to_yuv420s_kernel per 32 frames when every
+        // frame passes its rule
+        const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
+        Rgb2YuvLaunch L;
+        L.ss = srcStride[0]; L.bgr = 0;
+        L.ys = dstStride[0]; L.us = dstStride[1]; L.vs = dnv12 ? 0 : dstStride[2]; L.nv12 = dnv12;
+        L.w = c->srcW; L.h = c->srcH; L.maxRows = c->r2y.maxRows; L.rowStart = nullptr; L.rowCount = nullptr;
+        L.k = make_rgb2yuv_consts(c->colorspace);
+        L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        for (int f = 0; f < n; f++) {
+            const uint8_t *const *sp = src_planes + 4 * f;
+            uint8_t *const *dp = dst_planes + 4 * f;
+            if (!sp[0] || !dp[0] || !dp[1] || (!dnv12 && !dp[2])) return GMAT_ERR(EINVAL);
+            L.src = sp[0]; L.y = dp[0]; L.u = dp[1]; L.v = dnv12 ? nullptr : dp[2];
+            if (!pf32_to_yuv420_strip_takes(L)) return 0;
+        }
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                fr.y[i] = src_planes[4 * (f0 + i)];
+                fr.dst[i] = dst_planes[4 * (f0 + i)]; fr.dstU[i] = dst_planes[4 * (f0 + i) + 1]; fr.dstV[i] = dnv12 ? nullptr : dst_planes[4 * (f0 + i) + 2];
+            }
+            c->lastKernel = "pf32_to_yuv420s_kernel";
+            int r = launch_pf32_to_yuv420s(L, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (c->mode == MODE_RGB2YUV && !c->inner) {
         // the same-size RGB -> 4:2:0 converter: one launch of rgb2yuv420s_kernel per 32 frames when every frame passes its rule
         const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
@@ -1819,6 +1851,21 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         }
         const bool dnv12 = c->dstFormat == GMAT_PIX_FMT_NV12;
         if (!dst[1] || (!dnv12 && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+        {
+            // round 4: one kernel from the floats to the 4:2:0 planes where the strip converter's rule holds (no RGB24 intermediate)
+            Rgb2YuvLaunch F;
+            F.src = src[0]; F.ss = srcStride[0]; F.bgr = 0;
+            F.y = dst[0]; F.ys = dstStride[0]; F.u = dst[1]; F.us = dstStride[1];
+            F.v = dnv12 ? nullptr : dst[2]; F.vs = dnv12 ? 0 : dstStride[2]; F.nv12 = dnv12;
+            F.w = c->srcW; F.h = c->srcH; F.vChr = c->r2yVChr; F.rowStart = nullptr; F.rowCount = nullptr; F.maxRows = c->r2y.maxRows;
+            F.k = make_rgb2yuv_consts(c->colorspace);
+            F.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) F.vC[k] = c->r2y.vC[k];
+            if (pf32_to_yuv420_strip_takes(F)) {
+                c->lastKernel = "pf32_to_yuv420s_kernel";
+                r = launch_pf32_to_yuv420s(F, c->stream, nullptr, 1);
+                break;
+            }
+        }
         if (!c->inter) {
             c->interStride = align_up(c->srcW * 3, 256);
             GMAT_HIP_CHECK(hipMalloc((void **)&c->inter, (size_t)c->interStride * c->srcH));

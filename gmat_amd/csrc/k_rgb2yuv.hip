@@ -395,6 +395,204 @@ int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFr
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// planar float RGB (rgbpf32le: three stacked planes, value = u8 / 255) -> 8-bit 4:2:0 in ONE kernel (round 4).  format_cuda's way back from a
+// network's output tensor (vf_format_cuda.c:184-217: ... tensorrt, format_cuda=nv12, encode).  Rounds 1-3 quantised the floats into the
+// context's RGB24 intermediate (rgbpf32_to_rgb24_kernel) and ran the RGB -> 4:2:0 converter behind it: 162 MB of traffic for a 4K frame whose
+// compulsory bytes are 112 MB, two launches, 25.8 us for a 1080p frame.  Here rgb2yuv420s_kernel's walk with the quantisation in its load
+// stage: a wave owns a strip of 256 pixel columns, a lane 4 pixels of a row — one 16-byte load per plane, u8 = (int)(clamp(f, 0, 1) * 255 + 0.5)
+// exactly as rgbpf32_to_rgb24_kernel computes it, then rgb24ToY_c / rgb24ToUV_half_c and the 8-tap vertical chroma filter operation by operation.
+constexpr int F2S_STRIP = 256;
+struct F2sRow { float4 p[3]; };
+__device__ __forceinline__ int f2s_quant(float f) { return (int)(__fadd_rn(__fmul_rn(fminf(fmaxf(f, 0.0f), 1.0f), 255.0f), 0.5f)); }
+
+template <bool NV, bool JPEG, bool NOSAT>
+__global__ __launch_bounds__(256) void pf32_to_yuv420s_kernel(Rgb2YuvStripArgs a, Yuv2xFrames fr)
+{
+    const uint8_t *psrc = fr.y[blockIdx.y];
+    uint8_t *py = fr.dst[blockIdx.y], *pu = fr.dstU[blockIdx.y], *pv = fr.dstV[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) {
+        const int chunk = (a.nblk + 7) >> 3;
+        lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    }
+    if (lin >= a.nblk) return;
+    const int unit = lin * 4 + wave;
+    if (unit >= a.nseg * a.nstrips) return;
+    const int seg = __builtin_amdgcn_readfirstlane(unit / a.nstrips);
+    const int X0 = (unit - seg * a.nstrips) * F2S_STRIP;
+    const int c0 = seg * a.segRows, ch = a.h >> 1;
+    const int nOut = min(a.segRows, ch - c0);
+    const int nIter = nOut + 3;                                 // 3 warm-up row pairs fill the vertical window
+    const int xo = X0 + 4 * lane;
+    const bool active = xo < a.w;
+    const unsigned xc = (unsigned)(active ? xo : a.w - 4);      // idle lanes shadow the last group
+    const size_t plane = (size_t)a.ss * a.h;
+
+    auto load_row = [&](int r, F2sRow &R) {
+        const uint8_t *p = psrc + ((size_t)min(max(r, 0), a.h - 1) * (unsigned)a.ss + 4u * xc);
+#pragma unroll
+        for (int k = 0; k < 3; k++) R.p[k] = *reinterpret_cast<const float4 *>(p + k * plane);
+    };
+    // one source row: luma of the 4 pixels written if the row belongs to this segment; 15-bit U / V of the 2 pixel pairs returned
+    auto convert_row = [&](const F2sRow &R, int row, bool luma, int (&cu)[2], int (&cv)[2]) {
+        const float f0[4] = {R.p[0].x, R.p[0].y, R.p[0].z, R.p[0].w}, f1[4] = {R.p[1].x, R.p[1].y, R.p[1].z, R.p[1].w}, f2[4] = {R.p[2].x, R.p[2].y, R.p[2].z, R.p[2].w};
+        int fs[4], th[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { fs[i] = f2s_quant(f0[i]) | (f2s_quant(f1[i]) << 16); th[i] = f2s_quant(f2[i]); }
+        if (luma) {                                             // wave-uniform
+            unsigned yb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // rgb24ToY_c, hScale16To15_c with one tap, (lumRangeToJpeg_c), yuv2plane1_8_c
+                const int y14 = y2s_dot2(fs[i], a.cY01, m24(th[i], a.cY2) + ((32 << 14) + (1 << 8))) >> 9;
+                if constexpr (NOSAT && !JPEG) {
+                    yb[i] = (unsigned)(y14 + 32) >> 6;
+                } else {
+                    int l = min(2 * y14, 32767);
+                    if constexpr (JPEG) l = (m24(min(l, 30189), 19077) - 39057361) >> 14;
+                    yb[i] = (unsigned)clip_u8_shr(l + 64, 7);
+                }
+            }
+            if (active) st_stream(py + ((unsigned)row * (unsigned)a.ys + (unsigned)xo), (unsigned)(yb[0] | (yb[1] << 8) | (yb[2] << 16) | (yb[3] << 24)));
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            // rgb24ToUV_half_c on the sum of the pair's pixels, hScale16To15_c with one tap, (chrRangeToJpeg_c)
+            const int fsum = fs[2 * c] + fs[2 * c + 1];             // two 9-bit sums in the halves: no carry across
+            const int tsum = th[2 * c] + th[2 * c + 1];
+            int u = 2 * (y2s_dot2(fsum, a.cU01, m24(tsum, a.cU2) + ((256 << 15) + (1 << 9))) >> 10);
+            int v = 2 * (y2s_dot2(fsum, a.cV01, m24(tsum, a.cV2) + ((256 << 15) + (1 << 9))) >> 10);
+            if constexpr (!NOSAT) { u = min(u, 32767); v = min(v, 32767); }
+            if constexpr (JPEG) { u = (m24(min(u, 30775), 4663) - 9289992) >> 12; v = (m24(min(v, 30775), 4663) - 9289992) >> 12; }
+            cu[c] = u; cv[c] = v;
+        }
+    };
+
+    int hwU[4][2], hwV[4][2];                                   // [slot][pixel pair]: (row 2m-1 | row 2m << 16)
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) hwU[s][c] = hwV[s][c] = 0;
+    F2sRow bufA[2], bufB[2];                                    // ping-pong: rows 2m-1 and 2m of the current / next pair
+#pragma unroll
+    for (int k = 0; k < 3; k++) bufA[1].p[k] = bufB[1].p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_row(2 * (c0 - 1) - 1, bufA[0]);
+    load_row(2 * (c0 - 1), bufB[0]);
+
+    auto body = [&](const int j, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;           // j & 3, static after unrolling
+        const F2sRow ra = bufA[SLOT & 1], rb = bufB[SLOT & 1];
+        const int m = c0 - 1 + j;                               // this iteration's pair: rows 2m - 1, 2m
+        if (j + 1 < nIter) {
+            load_row(2 * m + 1, bufA[(SLOT + 1) & 1]);
+            load_row(2 * m + 2, bufB[(SLOT + 1) & 1]);
+        }
+        {
+            int ua[2], va[2], ub[2], vb[2];
+            convert_row(ra, 2 * m - 1, m - 1 >= c0 && m - 1 < c0 + nOut, ua, va);
+            convert_row(rb, 2 * m, m >= c0 && m < c0 + nOut, ub, vb);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                hwU[SLOT][c] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(ua[c], ub[c]));
+                hwV[SLOT][c] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(va[c], vb[c]));
+            }
+        }
+        if (j >= 3) {
+            const int cy = c0 + j - 3;                          // pairs cy-1 .. cy+2 sit in slots SLOT+1 .. SLOT+4 (mod 4)
+            unsigned ub8[2], vb8[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                int U = a.rnd, V = a.rnd;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    U = y2s_dot2(hwU[(SLOT + 1 + k) & 3][c], a.vC[k], U);
+                    V = y2s_dot2(hwV[(SLOT + 1 + k) & 3][c], a.vC[k], V);
+                }
+                ub8[c] = (unsigned)clip_u8_shr(U, 19); vb8[c] = (unsigned)clip_u8_shr(V, 19);
+            }
+            if (active) {
+                if (NV) {
+                    st_stream(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)xo), (unsigned)(ub8[0] | (vb8[0] << 8) | (ub8[1] << 16) | (vb8[1] << 24)));
+                } else {
+                    *reinterpret_cast<uint16_t *>(pu + ((unsigned)cy * (unsigned)a.us + (unsigned)(xo >> 1))) = (uint16_t)(ub8[0] | (ub8[1] << 8));
+                    *reinterpret_cast<uint16_t *>(pv + ((unsigned)cy * (unsigned)a.vs + (unsigned)(xo >> 1))) = (uint16_t)(vb8[0] | (vb8[1] << 8));
+                }
+            }
+        }
+    };
+    for (int j0 = 0; j0 < nIter; j0 += 4) {
+        body(j0, std::integral_constant<int, 0>());
+        if (j0 + 1 < nIter) body(j0 + 1, std::integral_constant<int, 1>());
+        if (j0 + 2 < nIter) body(j0 + 2, std::integral_constant<int, 2>());
+        if (j0 + 3 < nIter) body(j0 + 3, std::integral_constant<int, 3>());
+    }
+}
+
+// the fused form takes a frame when the strip converter would (replicated 8-tap chroma window, rows pair up) and the float rows can be read 16
+// bytes at a time; L.src = the first float plane, L.ss = a float row's pitch in bytes (the planes are L.ss * L.h apart)
+bool pf32_to_yuv420_strip_takes(const Rgb2YuvLaunch &L)
+{
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_STRIP");
+    if (off && atoi(off)) return false;
+    if (!L.stripOk || L.w % 4 || L.w < 64 || (L.h & 1) || L.h < 16) return false;
+    if ((((uintptr_t)L.src | (uintptr_t)L.ss) & 15) != 0) return false;
+    uintptr_t all = (uintptr_t)L.y | (uintptr_t)L.ys | (uintptr_t)L.u | (uintptr_t)L.us;
+    if (!L.nv12) return (all & 3) == 0 && ((((uintptr_t)L.u | (uintptr_t)L.us | (uintptr_t)L.v | (uintptr_t)L.vs) & 1) == 0);
+    return (all & 3) == 0;
+}
+
+int launch_pf32_to_yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    Yuv2xFrames one;
+    if (!frames) {
+        std::memset(&one, 0, sizeof(one));
+        one.y[0] = L.src; one.dst[0] = L.y; one.dstU[0] = L.u; one.dstV[0] = L.v;
+        frames = &one; nframes = 1;
+    }
+    Rgb2YuvStripArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ss = L.ss; a.toJpeg = L.toJpeg;
+    a.ys = L.ys; a.us = L.us; a.vs = L.vs; a.w = L.w; a.h = L.h;
+    auto pk = [](int lo, int hi) { return (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16)); };
+    const Rgb2YuvConsts &q = L.k;
+    a.cY01 = pk(q.ry, q.gy); a.cY2 = q.by; a.cU01 = pk(q.ru, q.gu); a.cU2 = q.bu; a.cV01 = pk(q.rv, q.gv); a.cV2 = q.bv;      // planes in R, G, B order
+    for (int k = 0; k < 4; k++) a.vC[k] = L.vC[k];
+    a.rnd = 64 << 12;                                           // yuv2planeX_8_c / yuv2nv12cX_c dither
+    a.nstrips = (L.w + F2S_STRIP - 1) / F2S_STRIP;
+    const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");
+    int seg = segStr ? atoi(segStr) : 0;
+    if (seg <= 0) {
+        const long rows = (long)(L.h >> 1) * a.nstrips * nframes;   // wave-rows (chroma)
+        seg = (int)std::min(31L, std::max(3L, (rows + 3455) / 3456)) | 1;
+    }
+    a.segRows = seg;
+    a.nseg = ((L.h >> 1) + seg - 1) / seg;
+    a.nblk = (a.nseg * a.nstrips + 3) / 4;
+    a.xcdRemap = 1;
+    const dim3 grid(8 * ((a.nblk + 7) / 8), nframes), block(256);
+    auto lo_hi = [](int c0, int c1, int c2, long scale, long add, int sh, long &lo, long &hi) {
+        lo = (scale * (std::min(c0, 0) + std::min(c1, 0) + std::min(c2, 0)) + add) >> sh;
+        hi = (scale * (std::max(c0, 0) + std::max(c1, 0) + std::max(c2, 0)) + add) >> sh;
+    };
+    long ylo, yhi, ulo, uhi, vlo, vhi;
+    lo_hi(q.ry, q.gy, q.by, 255, (32 << 14) + (1 << 8), 9, ylo, yhi);
+    lo_hi(q.ru, q.gu, q.bu, 510, (256L << 15) + (1 << 9), 10, ulo, uhi);
+    lo_hi(q.rv, q.gv, q.bv, 510, (256L << 15) + (1 << 9), 10, vlo, vhi);
+    const char *ns = GMAT_KNOB("GMAT_R2Y_NOSAT");
+    const bool nosat = !(ns && !atoi(ns)) && ylo >= 0 && yhi <= 16351 && ulo >= 0 && uhi <= 16383 && vlo >= 0 && vhi <= 16383;
+#define GMAT_F2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(pf32_to_yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a, *frames); \
+                               else       hipLaunchKernelGGL(HIP_KERNEL_NAME(pf32_to_yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a, *frames); } while (0)
+    if (L.toJpeg) { if (L.nv12) GMAT_F2S(true, true); else GMAT_F2S(false, true); }
+    else          { if (L.nv12) GMAT_F2S(true, false); else GMAT_F2S(false, false); }
+#undef GMAT_F2S
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // NV12 <-> YUV420P chroma re-layout (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c).
 // A thread moves 4 chroma samples of each plane: 8 interleaved bytes <-> 4 + 4 planar bytes (v_perm_b32).
 __global__ __launch_bounds__(256) void uv_deinterleave_kernel(const uint8_t *uv, int uvs, uint8_t *u, int us, uint8_t *v, int vs,

@@ -219,6 +219,9 @@ int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
 bool rgb2yuv420_strip_takes(const Rgb2YuvLaunch &L);        // the launch goes to rgb2yuv420s_kernel
 // frames == nullptr: the frame of L; else nframes frames (y[] = packed source, dst / dstU / dstV = planes) of L's geometry and strides
 int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+// planar float RGB (L.src = the first plane, L.ss = a float row's pitch, planes L.ss * L.h apart) -> 8-bit 4:2:0 in one kernel (round 4)
+bool pf32_to_yuv420_strip_takes(const Rgb2YuvLaunch &L);
+int launch_pf32_to_yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 // packed RGB24 / BGR24 -> planar YUV 4:4:4 at equal size (one-tap filters everywhere: a per-pixel conversion)
 int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, uint8_t *u, int us, uint8_t *v, int vs, int w, int h,
                       const Rgb2YuvConsts &k, hipStream_t stream);

@@ -203,7 +203,7 @@ def test_error_behaviour_newer_entry_points(dev):
     assert not lib.gmat_sws_getContext(32, 16, 1, 16, 8, PIX_FMT["rgb24"], 0, None)          # AV_PIX_FMT_YUYV422
 
 
-@pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (33, 9)])
+@pytest.mark.parametrize("w,h", [(64, 16), (130, 34), (33, 9), (256, 32), (260, 18), (516, 40), (68, 16)])
 def test_rgbpf32_back_to_8bit(dev, orc, w, h):
     """format_hip's other direction: planar float RGB -> rgb24 / bgr24 / nv12.  A float frame made by the nv12 ->
     rgbpf32le converter returns to exactly the 8-bit RGB the integer converter gives, and 4:2:0 outputs equal the
@@ -229,7 +229,10 @@ def test_rgbpf32_back_to_8bit(dev, orc, w, h):
                                ints([p.stride for p in dst]))
         assert r == h
         got = [p.download() for p in dst]
+        kernel = lib.gmat_sws_lastKernel(c).decode()
         lib.gmat_sws_freeContext(c)
+        if dst_fmt in ("nv12", "yuv420p"):      # round 4: ONE kernel from the floats to the planes where the strip converter's rule holds
+            assert (kernel == "pf32_to_yuv420s_kernel") == (w % 4 == 0 and w >= 64 and h % 2 == 0 and h >= 16), (kernel, w, h)
         if dst_fmt == "rgb24":
             assert (got[0] == rgb).all()
         elif dst_fmt == "bgr24":
@@ -289,3 +292,46 @@ def test_nv12_to_rgbpf32_every_shape_single_and_batched(dev, orc, w, h, pitch):
     for pl in ins:
         for p in pl:
             p.free()
+
+
+@pytest.mark.parametrize("w,h", [(64, 16), (256, 32), (260, 18), (772, 22)])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
+def test_rgbpf32_any_floats_to_420(dev, orc, w, h, dst_fmt):
+    """the fused float -> 4:2:0 kernel (k_rgb2yuv.hip pf32_to_yuv420s_kernel) on floats a network may hand back: below 0, above 1, NaN,
+    values between the 8-bit steps.  Expected: u8 = (int)(clamp(f, 0, 1) * 255 + 0.5) in single precision (NaN -> 0: fmaxf), then libswscale's
+    RGB24 -> 4:2:0 lines (the oracle's) — and the same bytes as the two-kernel path it replaces (GMAT_SCALE_NO_STRIP=1)."""
+    import os
+    rng = np.random.default_rng(5 + w)
+    f = rng.uniform(-0.3, 1.3, (3, h, w)).astype(np.float32)
+    f[:, ::7, ::5] = np.float32(np.nan)
+    f[:, 1::9, 2::11] = (rng.integers(0, 256, f[:, 1::9, 2::11].shape) / np.float32(255.0)).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        cl = np.minimum(np.maximum(np.where(np.isnan(f), np.float32(0), f), np.float32(0)), np.float32(1))
+        q = (cl * np.float32(255.0) + np.float32(0.5)).astype(np.int32).astype(np.uint8)
+    rgb = np.ascontiguousarray(q.transpose(1, 2, 0).reshape(h, 3 * w))
+    want = orc.sws([rgb], w, h, "rgb24", w, h, dst_fmt)
+    host = np.ascontiguousarray(f.reshape(3 * h, w)).view(np.uint8).reshape(3 * h, 4 * w)
+    d_pf = dev.upload_planes([host], 1)[0]
+    lib = dev.lib
+    names = []
+    for no_strip in ("0", "1"):
+        os.environ["GMAT_SCALE_NO_STRIP"] = no_strip
+        try:
+            c = lib.gmat_sws_getContext(w, h, PIX_FMT["rgbpf32le"], w, h, PIX_FMT[dst_fmt], 0, None)
+            assert c
+            dst = dev.planes_like(dst_fmt, w, h, 64)
+            r = lib.gmat_sws_scale(c, planes([d_pf.ptr]), ints([d_pf.stride]), 0, h, planes([p.ptr for p in dst]), ints([p.stride for p in dst]))
+            assert r == h
+            got = [p.download() for p in dst]
+            pads = [p.download(with_padding=True)[:, p.row_bytes:] for p in dst]
+            names.append(lib.gmat_sws_lastKernel(c).decode())
+            lib.gmat_sws_freeContext(c)
+            for g, wv, pd in zip(got, want, pads):
+                assert (g == wv).all(), (dst_fmt, names[-1])
+                assert (pd == 0xCD).all()
+            for p in dst:
+                p.free()
+        finally:
+            os.environ.pop("GMAT_SCALE_NO_STRIP", None)
+    assert names[0] == "pf32_to_yuv420s_kernel" and names[1] != names[0], names
+    d_pf.free()

@@ -314,6 +314,16 @@ int main(int argc, char **argv)
         // format_cuda / CSwscale's pair (the tensor a network reads): nv12 -> planar float RGB, value = u8 / 255
         {"nv12 1080p->1080p rgbpf32 convert", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBPF32LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"nv12 4K->4K rgbpf32 convert", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBPF32LE, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"rgbpf32 1080p->1080p nv12 convert", GMAT_PIX_FMT_RGBPF32LE, 1920, 1080, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbpf32 4K->4K nv12 convert", GMAT_PIX_FMT_RGBPF32LE, 3840, 2160, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        // the lossless re-layouts of SURVEY 8a row 16 (run on request: "relayout")
+        {"relayout: nv12 4K->yuv420p", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: yuv420p 4K->nv12", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: rgb24 4K->bgr24", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_BGR24, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: rgb24 4K->rgba", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGBA, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: rgba 4K->rgb24", GMAT_PIX_FMT_RGBA, 3840, 2160, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: nv12 4K->p010", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"relayout: nv12 4K->yuv444p", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_SWS_BICUBIC},
         // any ratio: the polyphase band walker (scale_yuvg_kernel); "any:" cases run when the filter names them or "any"
         {"any: nv12 4K->1600x900 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->1600x900 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1600, 900, GMAT_SWS_BICUBIC},
@@ -363,7 +373,8 @@ int main(int argc, char **argv)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4, o.pool);
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
-        if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
+        if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;
+        if (strstr(k.label, "relayout:") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
     return 0;
