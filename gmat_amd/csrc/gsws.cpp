@@ -1000,6 +1000,49 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
         }
         return 1;
     }
+    if ((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
+        c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv && !(GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8")))) {
+        // NV12 -> P010LE / P016LE at equal size: t << 8 of every sample (gmat_sws_scale's rule), frame by frame — the kernel is a copy
+        for (int f = 0; f < n; f++) {
+            const uint8_t *const *sp = src_planes + 4 * f;
+            uint8_t *const *dp = dst_planes + 4 * f;
+            if (!sp[0] || !sp[1] || !dp[0] || !dp[1]) return GMAT_ERR(EINVAL);
+            c->lastKernel = "nv12_shift8_kernel";
+            int r = launch_nv12_shift8(sp[0], srcStride[0], sp[1], srcStride[1], dp[0], dstStride[0], dp[1], dstStride[1], c->srcW, c->srcH, stream);
+            if (r < 0) return r;
+        }
+        c->lastLaunchFrames = 1;
+        return 1;
+    }
+    if (c->mode == MODE_YUV2YUV && (c->srcFormat == GMAT_PIX_FMT_NV12) != (c->dstFormat == GMAT_PIX_FMT_NV12) &&
+        !(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED") && atoi(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED")))) {
+        // NV12 <-> YUV420P: one launch per 32 frames (grid.z = frame) when every frame's planes move 16 / 8 bytes at a time
+        const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12;
+        for (int f = 0; f < n; f++) {
+            const uint8_t *const *sp = src_planes + 4 * f;
+            uint8_t *const *dp = dst_planes + 4 * f;
+            if (!sp[0] || !sp[1] || (!snv && !sp[2]) || !dp[0] || !dp[1] || (snv && !dp[2])) return GMAT_ERR(EINVAL);
+            if (!yuv420_relayout_takes(snv, sp[0], srcStride[0], sp[1], srcStride[1], snv ? nullptr : sp[2], snv ? 0 : srcStride[2],
+                                       dp[0], dstStride[0], dp[1], dstStride[1], snv ? dp[2] : nullptr, snv ? dstStride[2] : 0)) return 0;
+        }
+        for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+            Yuv2xFrames fr;
+            const int m = std::min(kYuv2xMaxFrames, n - f0);
+            std::memset(&fr, 0, sizeof(fr));
+            for (int i = 0; i < m; i++) {
+                const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+                uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+                fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = snv ? nullptr : sp[2];
+                fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = snv ? dp[2] : nullptr;
+            }
+            c->lastKernel = "yuv420_relayout_kernel";
+            int r = launch_yuv420_relayout(snv, fr.y[0], srcStride[0], fr.u[0], srcStride[1], fr.v[0], snv ? 0 : srcStride[2],
+                                           fr.dst[0], dstStride[0], fr.dstU[0], dstStride[1], fr.dstV[0], snv ? dstStride[2] : 0, c->srcW, c->srcH, stream, &fr, m);
+            if (r < 0) return r;
+            c->lastLaunchFrames = m;
+        }
+        return 1;
+    }
     if (c->mode == MODE_RGBPF32) {
         // nv12 -> planar float RGB (the tensor a network reads): one launch per 32 frames, grid.z = frame
         for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
@@ -1657,6 +1700,15 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
     if (is_plane_src(c->srcFormat) && (!src[1] || (planarYuv && !src[2]))) return GMAT_ERR(EINVAL);
 
     int r = 0;
+    // NV12 -> P010LE / P016LE at equal size: the generic lines with one-tap filters make t << 8 of every sample (see nv12_shift8_kernel); a range
+    // conversion, the only thing that changes the lines' values here, keeps the plane scaler
+    if ((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
+        c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv && !(GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8")))) {
+        if (!dst[1]) return GMAT_ERR(EINVAL);
+        c->lastKernel = "nv12_shift8_kernel";
+        r = launch_nv12_shift8(src[0], srcStride[0], src[1], srcStride[1], dst[0], dstStride[0], dst[1], dstStride[1], c->srcW, c->srcH, c->stream);
+        return r < 0 ? r : c->dstH;
+    }
     switch (c->mode) {
     case MODE_YUV2RGB:
         c->lastKernel = "yuv2rgb_kernel";
@@ -1832,6 +1884,15 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12, dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
         const int cw = ceil_rshift(c->srcW, 1), ch = ceil_rshift(c->srcH, 1);
         if (!dst[1] || (!dnv && !dst[2])) { r = GMAT_ERR(EINVAL); break; }
+        if (snv != dnv && !(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED") && atoi(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED"))) &&
+            yuv420_relayout_takes(snv, src[0], srcStride[0], src[1], srcStride[1], snv ? nullptr : src[2], snv ? 0 : srcStride[2],
+                                  dst[0], dstStride[0], dst[1], dstStride[1], dnv ? nullptr : dst[2], dnv ? 0 : dstStride[2])) {
+            // round 4: luma copy and chroma (de)interleave in one launch
+            c->lastKernel = "yuv420_relayout_kernel";
+            r = launch_yuv420_relayout(snv, src[0], srcStride[0], src[1], srcStride[1], snv ? nullptr : src[2], snv ? 0 : srcStride[2],
+                                       dst[0], dstStride[0], dst[1], dstStride[1], dnv ? nullptr : dst[2], dnv ? 0 : dstStride[2], c->srcW, c->srcH, c->stream);
+            break;
+        }
         c->lastKernel = snv == dnv ? "copy2d" : (snv ? "uv_deinterleave_kernel" : "uv_interleave_kernel");
         if ((r = launch_copy2d(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, c->stream)) < 0) break;
         if (snv && dnv) r = launch_copy2d(src[1], srcStride[1], dst[1], dstStride[1], 2 * cw, ch, c->stream);

@@ -566,8 +566,10 @@ int launch_pf32_to_yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv
     const char *segStr = GMAT_KNOB("GMAT_STRIP_ROWS");
     int seg = segStr ? atoi(segStr) : 0;
     if (seg <= 0) {
+        // measured, 8 frames a launch (profiles/r04_rgbpf32.txt): 3 chroma rows 29.4 us a 4K frame, 5: 24.7, 7: 23.5, 11: 24.6, 15: 24.8, 23: 24.2,
+        // 31: 25.1 — short segments sweep the three float planes in raster order; 7 rows at most
         const long rows = (long)(L.h >> 1) * a.nstrips * nframes;   // wave-rows (chroma)
-        seg = (int)std::min(31L, std::max(3L, (rows + 3455) / 3456)) | 1;
+        seg = (int)std::min(7L, std::max(3L, (rows + 3455) / 3456)) | 1;
     }
     a.segRows = seg;
     a.nseg = ((L.h >> 1) + seg - 1) / seg;
@@ -768,6 +770,79 @@ int launch_rgb2yuv444(const uint8_t *src, int ss, int bgr, uint8_t *y, int ys, u
     return 0;
 }
 
+// NV12 <-> YUV420P in ONE launch (round 4): rows [0, h) copy the luma plane, rows [h, h + ch) (de)interleave the chroma — 16 bytes a lane each way,
+// every byte read once and written once (streaming loads and stores), grid.z = frame.  Rounds 1-3: a 2-D copy and a chroma kernel, 7.2 / 6.3 us
+// for a 4K frame; this is what nvdec's NV12 meets in front of every planar consumer (scale_cuda=format=yuv420p).
+template <bool TO_PLANAR, bool FRAMES>
+__global__ __launch_bounds__(256) void yuv420_relayout_kernel(const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
+                                                              uint8_t *dy, int dys, uint8_t *d0, int ds0, uint8_t *d1, int ds1, int w, int h, int cw, int ch,
+                                                              Yuv2xFrames fr)
+{
+    if (FRAMES) {
+        const int f = blockIdx.z;
+        y = fr.y[f]; a0 = fr.u[f]; a1 = fr.v[f]; dy = fr.dst[f]; d0 = fr.dstU[f]; d1 = fr.dstV[f];
+    }
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16, r = blockIdx.y;
+    if (r < h) {
+        if (x >= w) return;
+        const uint8_t *s = y + (size_t)r * ys + x;
+        uint8_t *d = dy + (size_t)r * dys + x;
+        if (x + 16 <= w) st_stream(d, ld_stream(s, uint4()));
+        else for (int i = 0; i < w - x; i++) d[i] = s[i];
+        return;
+    }
+    const int cr = r - h;
+    if (cr >= ch) return;
+    if (TO_PLANAR) {                                    // 16 interleaved bytes -> 8 + 8 planar bytes; x counts interleaved bytes
+        if (x >= 2 * cw) return;
+        const uint8_t *s = a0 + (size_t)cr * s0 + x;
+        uint8_t *du = d0 + (size_t)cr * ds0 + (x >> 1), *dv = d1 + (size_t)cr * ds1 + (x >> 1);
+        if (x + 16 <= 2 * cw) {
+            const uint4 t = ld_stream(s, uint4());          // U0 V0 U1 V1 | U2 V2 U3 V3 | ...
+            st_stream(du, make_uint2(__builtin_amdgcn_perm(t.y, t.x, 0x06040200u), __builtin_amdgcn_perm(t.w, t.z, 0x06040200u)));
+            st_stream(dv, make_uint2(__builtin_amdgcn_perm(t.y, t.x, 0x07050301u), __builtin_amdgcn_perm(t.w, t.z, 0x07050301u)));
+        } else for (int i = 0; i < cw - (x >> 1); i++) { du[i] = s[2 * i]; dv[i] = s[2 * i + 1]; }
+    } else {                                            // 8 + 8 planar bytes -> 16 interleaved bytes
+        if (x >= 2 * cw) return;
+        const uint8_t *su = a0 + (size_t)cr * s0 + (x >> 1), *sv = a1 + (size_t)cr * s1 + (x >> 1);
+        uint8_t *d = d0 + (size_t)cr * ds0 + x;
+        if (x + 16 <= 2 * cw) {
+            const uint2 a = ld_stream(su, uint2()), b = ld_stream(sv, uint2());
+            st_stream(d, make_uint4(__builtin_amdgcn_perm(b.x, a.x, 0x05010400u), __builtin_amdgcn_perm(b.x, a.x, 0x07030602u),
+                                    __builtin_amdgcn_perm(b.y, a.y, 0x05010400u), __builtin_amdgcn_perm(b.y, a.y, 0x07030602u)));
+        } else for (int i = 0; i < cw - (x >> 1); i++) { d[2 * i] = su[i]; d[2 * i + 1] = sv[i]; }
+    }
+}
+
+// every plane pointer and pitch of every frame can be moved 16 (interleaved side, luma) / 8 (planar chroma) bytes at a time
+bool yuv420_relayout_takes(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
+                           const uint8_t *dy, int dys, const uint8_t *d0, int ds0, const uint8_t *d1, int ds1)
+{
+    uintptr_t wide = (uintptr_t)y | (uintptr_t)ys | (uintptr_t)dy | (uintptr_t)dys, narrow;
+    if (toPlanar) { wide |= (uintptr_t)a0 | (uintptr_t)s0; narrow = (uintptr_t)d0 | (uintptr_t)ds0 | (uintptr_t)d1 | (uintptr_t)ds1; }
+    else          { wide |= (uintptr_t)d0 | (uintptr_t)ds0; narrow = (uintptr_t)a0 | (uintptr_t)s0 | (uintptr_t)a1 | (uintptr_t)s1; }
+    return (wide & 15) == 0 && (narrow & 7) == 0;
+}
+
+// one frame (frames == nullptr) or nframes frames of this geometry and these pitches (y / u / v = the source planes, dst / dstU / dstV the destination's)
+int launch_yuv420_relayout(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
+                           uint8_t *dy, int dys, uint8_t *d0, int ds0, uint8_t *d1, int ds1, int w, int h, hipStream_t stream,
+                           const Yuv2xFrames *frames, int nframes)
+{
+    if (w <= 0 || h <= 0) return 0;
+    if (frames && (nframes < 1 || nframes > kYuv2xMaxFrames)) return GMAT_ERR(EINVAL);
+    const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+    const int rowBytes = std::max(w, 2 * cw);
+    const dim3 grid((rowBytes + 4095) / 4096, h + ch, frames ? nframes : 1), block(256);
+    Yuv2xFrames none; none.y[0] = nullptr;
+#define GMAT_RL(TP_) do { if (frames) hipLaunchKernelGGL(HIP_KERNEL_NAME(yuv420_relayout_kernel<TP_, true>), grid, block, 0, stream, y, ys, a0, s0, a1, s1, dy, dys, d0, ds0, d1, ds1, w, h, cw, ch, *frames); \
+                            else        hipLaunchKernelGGL(HIP_KERNEL_NAME(yuv420_relayout_kernel<TP_, false>), grid, block, 0, stream, y, ys, a0, s0, a1, s1, dy, dys, d0, ds0, d1, ds1, w, h, cw, ch, none); } while (0)
+    if (toPlanar) GMAT_RL(true); else GMAT_RL(false);
+#undef GMAT_RL
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a1, int s1, uint8_t *d0, int ds0, uint8_t *d1,
                        int ds1, int cw, int ch, hipStream_t stream)
 {
@@ -803,6 +878,45 @@ int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w
     if (w <= 0 || h <= 0) return 0;
     const dim3 grid((w + 1023) / 1024, h), block(256);
     hipLaunchKernelGGL(plane_copy_up_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, depth, replicate);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// NV12 -> P010LE / P016LE at equal size (round 4).  libswscale has no special converter for a semi-planar 8-bit source (planar8ToP01xleWrapper takes
+// PLANAR ones only, swscale_unscaled.c:2108-2112): the generic lines run with one-tap filters — hScale8To15_c t << 7 then yuv2p010l1_c
+// ((t << 7) + 16 >> 5) << 6, or hScale8To19_c t << 11 then yuv2p016 ((t << 11) + 4 >> 3) — every sample of BOTH planes becomes t << 8, and the
+// chroma keeps its interleaving.  Rounds 1-3 ran the tiled plane scaler for it (35 us a 4K frame, 0.13 of the roofline); this is the copy it is:
+// a lane turns 8 bytes into 8 words, rows [0, h) from the luma plane and [h, h + ch) from the chroma plane (both w bytes wide).
+__global__ __launch_bounds__(256) void nv12_shift8_kernel(const uint8_t *y, int ys, const uint8_t *uv, int uvs, uint8_t *dy, int dys, uint8_t *duv, int duvs,
+                                                          int w, int h, int ch, int aligned)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y;
+    if (x >= w || r >= h + ch) return;
+    const uint8_t *s = r < h ? y + (size_t)r * ys + x : uv + (size_t)(r - h) * uvs + x;
+    uint8_t *d = r < h ? dy + (size_t)r * dys + 2 * x : duv + (size_t)(r - h) * duvs + 2 * x;
+    if (aligned && x + 8 <= w) {
+        const uint2 t = ld_stream(s, uint2());                          // (each byte is read once and each word written once: streaming both ways)
+        st_stream(d, make_uint4(__builtin_amdgcn_perm(0u, t.x, 0x010C000Cu), __builtin_amdgcn_perm(0u, t.x, 0x030C020Cu),
+                                __builtin_amdgcn_perm(0u, t.y, 0x010C000Cu), __builtin_amdgcn_perm(0u, t.y, 0x030C020Cu)));
+    } else {
+        for (int i = 0; i < min(8, w - x); i++) { d[2 * i] = 0; d[2 * i + 1] = s[i]; }
+    }
+}
+
+int launch_nv12_shift8(const uint8_t *y, int ys, const uint8_t *uv, int uvs, uint8_t *dy, int dys, uint8_t *duv, int duvs, int w, int h, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int ch = (h + 1) / 2, wb = 2 * ((w + 1) / 2);                // the chroma row's bytes (an odd width: one more than the luma row's)
+    const int al = ((((uintptr_t)y | (uintptr_t)ys | (uintptr_t)uv | (uintptr_t)uvs) & 7) == 0) &&
+                   ((((uintptr_t)dy | (uintptr_t)dys | (uintptr_t)duv | (uintptr_t)duvs) & 15) == 0) && w == wb;
+    if (w != wb) {                                                      // odd width: the two planes differ in width — two launches of the one-plane form
+        const dim3 g1((w + 2047) / 2048, h), g2((wb + 2047) / 2048, ch), block(256);
+        hipLaunchKernelGGL(nv12_shift8_kernel, g1, block, 0, stream, y, ys, uv, uvs, dy, dys, duv, duvs, w, h, 0, 0);
+        hipLaunchKernelGGL(nv12_shift8_kernel, g2, block, 0, stream, uv, uvs, uv, uvs, duv, duvs, duv, duvs, wb, ch, 0, 0);
+    } else {
+        const dim3 grid((w + 2047) / 2048, h + ch), block(256);
+        hipLaunchKernelGGL(nv12_shift8_kernel, grid, block, 0, stream, y, ys, uv, uvs, dy, dys, duv, duvs, w, h, ch, al);
+    }
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -232,6 +232,14 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
 // (a, b) sample pairs interleaved
 // one plane of planarCopyWrapper's 8 -> `depth` bit copy; replicate: the luma of a full-range source (swscale_unscaled.c:1844-1862)
 int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream);
+// NV12 <-> YUV420P in one launch (luma copy + chroma (de)interleave, streaming both ways; frames: grid.z) where every plane moves in 16 / 8 bytes
+bool yuv420_relayout_takes(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
+                           const uint8_t *dy, int dys, const uint8_t *d0, int ds0, const uint8_t *d1, int ds1);
+int launch_yuv420_relayout(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
+                           uint8_t *dy, int dys, uint8_t *d0, int ds0, uint8_t *d1, int ds1, int w, int h, hipStream_t stream,
+                           const Yuv2xFrames *frames = nullptr, int nframes = 1);
+// NV12 -> P010LE / P016LE at equal size: every sample of both planes t << 8 (the generic lines' result, round 4)
+int launch_nv12_shift8(const uint8_t *y, int ys, const uint8_t *uv, int uvs, uint8_t *dy, int dys, uint8_t *duv, int duvs, int w, int h, hipStream_t stream);
 int launch_widen8to16(const uint8_t *a, int sa, const uint8_t *b, int sb, uint8_t *d, int ds, int n, int h,
                       hipStream_t stream);
 } // namespace gmat

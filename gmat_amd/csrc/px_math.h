@@ -44,10 +44,12 @@ __device__ __forceinline__ void st_stream(void *p, uint4 v) { nt_v4u t = {v.x, v
 // 0.81 at 8 frames a launch), hflip 0.615 -> 0.625 (0.76 -> 0.815 at 16); the yuv -> rgb converter, one dword a lane, LOSES 3.5 % with it,
 // and the headline, whose neighbouring bands share halo rows, 17 % (profiles/r03zs_nt_stores_ab.txt, last table)
 __device__ __forceinline__ unsigned ld_stream(const void *p, unsigned) { return __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)); }
+__device__ __forceinline__ uint2 ld_stream(const void *p, uint2) { const nt_v2u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v2u *>(p)); return make_uint2(t.x, t.y); }
 __device__ __forceinline__ uint3 ld_stream(const void *p, uint3) { const nt_v3u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v3u *>(p)); return make_uint3(t.x, t.y, t.z); }
 __device__ __forceinline__ uint4 ld_stream(const void *p, uint4) { const nt_v4u t = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u *>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
 #else
 __host__ __device__ __forceinline__ unsigned ld_stream(const void *p, unsigned) { return *reinterpret_cast<const unsigned *>(p); }
+__host__ __device__ __forceinline__ uint2 ld_stream(const void *p, uint2) { return *reinterpret_cast<const uint2 *>(p); }
 __host__ __device__ __forceinline__ uint3 ld_stream(const void *p, uint3) { return *reinterpret_cast<const uint3 *>(p); }
 __host__ __device__ __forceinline__ uint4 ld_stream(const void *p, uint4) { return *reinterpret_cast<const uint4 *>(p); }
 __host__ __device__ __forceinline__ void st_stream(void *p, unsigned v) { *reinterpret_cast<unsigned *>(p) = v; }

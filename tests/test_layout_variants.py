@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = sorted(glob.glob(os.path.join(ROOT, "tools", "variants", "layout_*", "libgmat_hip.so")))
-SUBSET = ["tests/test_parity_generic_walker.py", "tests/test_parity_down3.py", "tests/test_parity_down32.py",
+SUBSET = ["tests/test_parity_generic_walker.py", "tests/test_parity_quad_walker.py", "tests/test_parity_down3.py", "tests/test_parity_down32.py",
           "tests/test_parity_scale.py::test_yuv_single_context_bicubic"]
 
 

@@ -1000,7 +1000,9 @@ def test_same_size_special_converters_leave_for_the_generic_path_when_ranges_dif
         assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
                                   planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
         k = lib.gmat_sws_lastKernel(c).decode()
-        assert k.startswith("scale_yuv") == (sr != dr or (sf, df) == ("nv12", "p010le")), (k, sr, dr)
+        assert k.startswith("scale_yuv") == (sr != dr), (k, sr, dr)
+        if (sf, df) == ("nv12", "p010le") and sr == dr:        # round 4: the generic lines' t << 8 as the copy it is (k_rgb2yuv.hip nv12_shift8_kernel)
+            assert k == "nv12_shift8_kernel", k
         for a, b in zip(dst, want):
             assert (a.download() == b).all(), (sr, dr, k)
         for p in dst:
@@ -1083,3 +1085,72 @@ def test_chroma_positions_on_the_19bit_path(dev, orc, pair):
             lib.gmat_sws_freeContext(c)
             for p in d + dst:
                 p.free()
+
+
+@pytest.mark.parametrize("df", ["p010le", "p016le"])
+@pytest.mark.parametrize("w,h", [(96, 40), (64, 8), (130, 34), (37, 9), (520, 16), (16, 2)])
+@pytest.mark.parametrize("align", [64, 16, 2])
+def test_nv12_to_p01x_at_equal_size_is_a_shift(dev, orc, df, w, h, align):
+    """NV12 -> P010LE / P016LE at equal size: libswscale's generic lines with one-tap filters (no special converter for a semi-planar 8-bit
+    source, swscale_unscaled.c:2108-2112) give t << 8 for every sample of both planes; round 4 runs that as a streaming copy
+    (nv12_shift8_kernel) instead of the tiled plane scaler (35 -> see profiles/r04_relayouts.txt).  Against the oracle's generic lines, over
+    widths on and off the 8-byte groups, odd sizes, pitches the vector path takes and declines; GMAT_NO_SHIFT8=1 keeps the plane scaler."""
+    src = synth_planes(orc, "nv12", w, h, seed=17)
+    want = orc.sws(src, w, h, "nv12", w, h, df)
+    for p, q in zip(want, src):
+        assert (p.view(np.uint16) == (q.astype(np.uint16) << 8)).all()              # the statement itself, on the oracle
+    d = dev.upload_planes(src, 8 if align != 2 else 1)
+    got, pads, k = dev.sws(d, w, h, "nv12", w, h, df, dst_align=align)
+    assert k == "nv12_shift8_kernel", k
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all()
+        assert (pd == 0xCD).all()
+    for p in d:
+        p.free()
+
+
+def test_nv12_to_p01x_knob_keeps_the_plane_scaler(dev, orc, monkeypatch):
+    monkeypatch.setenv("GMAT_NO_SHIFT8", "1")
+    src = synth_planes(orc, "nv12", 96, 40, seed=18)
+    d = dev.upload_planes(src, 64)
+    for df in ("p010le", "p016le"):
+        got, _, k = dev.sws(d, 96, 40, "nv12", 96, 40, df, dst_align=64)
+        assert k != "nv12_shift8_kernel"
+        for g, wv in zip(got, orc.sws(src, 96, 40, "nv12", 96, 40, df)):
+            assert (g == wv).all()
+    for p in d:
+        p.free()
+
+
+@pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
+@pytest.mark.parametrize("w,h", [(96, 40), (64, 8), (130, 34), (37, 9), (4128, 6), (32, 2)])
+@pytest.mark.parametrize("align", [64, 16, 4])
+def test_yuv420_relayout_in_one_launch(dev, orc, pair, w, h, align, monkeypatch):
+    """NV12 <-> YUV420P (nv12ToPlanarWrapper / planarToNv12Wrapper, swscale_unscaled.c): lossless; round 4 moves the luma plane and (de)interleaves
+    the chroma in ONE launch (yuv420_relayout_kernel: 16 bytes a lane, streaming both ways, grid.z = frame) where every plane moves 16 / 8 bytes at a
+    time, the 2-D copy + chroma kernel of rounds 1-3 elsewhere — widths on and off the 16-byte groups, odd sizes, a batch of three frames"""
+    from test_batch_api import _run_batch
+    sf, df = pair
+    src = synth_planes(orc, sf, w, h, seed=23)
+    want = orc.sws(src, w, h, sf, w, h, df)
+    d = dev.upload_planes(src, align)
+    got, pads, k = dev.sws(d, w, h, sf, w, h, df, dst_align=align)
+    up = lambda v: (v + align - 1) // align * align                  # the pitches the harness gives the planes (their bases are 256-byte aligned)
+    cw = (w + 1) // 2
+    fused = up(w) % 16 == 0 and up(2 * cw) % 16 == 0 and up(cw) % 8 == 0
+    assert (k == "yuv420_relayout_kernel") == fused, (k, align)
+    for g, wv, pd in zip(got, want, pads):
+        assert (g == wv).all()
+        assert (pd == 0xCD).all()
+    for p in d:
+        p.free()
+    k = _run_batch(dev, orc, sf, df, w, h, w, h, nframes=3, nstreams=1, align=align)
+    assert (k == "yuv420_relayout_kernel") == fused, (k, align)
+    monkeypatch.setenv("GMAT_NO_RELAYOUT_FUSED", "1")
+    d = dev.upload_planes(src, align)
+    got, _, k = dev.sws(d, w, h, sf, w, h, df, dst_align=align)
+    assert k != "yuv420_relayout_kernel"
+    for g, wv in zip(got, want):
+        assert (g == wv).all()
+    for p in d:
+        p.free()

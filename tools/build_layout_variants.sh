@@ -6,7 +6,7 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/gmat_amd/csrc
 make -C $C -j8 > /dev/null
-FILES="k_scale_yuvg k_scale_yuv3x1 k_scale_yuv3x2 k_scale_yuv2x"
+FILES="k_scale_yuvg k_scale_yuvu k_scale_yuv3x1 k_scale_yuv3x2 k_scale_yuv2x"
 for V in o2:-O2 os:-Os; do
   N=layout_${V%%:*}; F=${V##*:}; O=$R/tools/variants/$N; mkdir -p $O
   OBJS=$(ls $C/build/*.o)
