@@ -179,10 +179,19 @@ struct GmatSwsContext {
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
+    // NV12 <-> YUV420P SCALED (round 4): no walker but the 2:1 one writes the other chroma layout, so such a context fell to the tiled kernel of
+    // round 1 (0.04 - 0.14 of the roofline) — nvdec's NV12 scaled for a planar consumer, the commonest ladder step there is.  `cross` is the same
+    // context in the SOURCE's layout (every walker applies), created on first use with this context's positions and ranges and dropped when
+    // they change; its output lands in `crossBuf` (a frame of the destination's size) and yuv420_relayout_kernel moves it into the destination
+    GmatSwsContext *cross = nullptr;
+    uint8_t *crossBuf = nullptr;
+    int crossPitch = 0, crossFrames = 0;
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
         if (interBatch) (void)hipFree(interBatch);
+        if (cross) gmat_sws_freeContext(cross);
+        if (crossBuf) (void)hipFree(crossBuf);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
     }
@@ -971,6 +980,52 @@ static int check_device(const GmatSwsContext *c, const char *who)
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
 // caller then goes frame by frame), < 0 on error.
+// NV12 <-> YUV420P scaled: whether this call takes the cascade (scale in the source's layout, re-layout the result) — a context of the plane
+// scaler between the two 8-bit 4:2:0 layouts whose own table would end at the tiled catch-all, destination planes the re-layout kernel can move
+static bool cross_layout_cascade(GmatSwsContext *c, const YuvScaleArgs &ya, int n)
+{
+    if (!is_yuv420(c->srcFormat) || !is_yuv420(c->dstFormat) || c->srcFormat == c->dstFormat || c->prof) return false;
+    const char *off = GMAT_KNOB("GMAT_NO_CROSS_CASCADE");
+    if (off && atoi(off)) return false;
+    int pick = 0;
+    while (!kPlaneKernels[pick].eligible(c, ya, n)) pick++;
+    if (pick != kNumPlaneKernels - 1) return false;              // a walker of this context's own takes the frame (2:1)
+    const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
+    return yuv420_relayout_takes(!dnv, nullptr, 256, nullptr, 256, nullptr, dnv ? 256 : 0, ya.dst, ya.ds, ya.dstU, ya.dsU, dnv ? nullptr : ya.dstV, dnv ? 0 : ya.dsV);
+}
+
+static size_t cross_frame_bytes(const GmatSwsContext *c) { return (size_t)align_up(c->dstW + 1, 256) * (c->dstH + 2 * ceil_rshift(c->dstH, 1)); }
+
+// the sibling context and its frames; 0 or a negative error
+static int cross_prepare(GmatSwsContext *c, int nframes)
+{
+    if (!c->cross) {
+        c->cross = gmat_sws_getContext(c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->srcFormat, c->flags, c->param);
+        if (!c->cross) return GMAT_ERR(ENOSYS);
+        int r = 0;
+        if (c->chrPos[0] != -513 || c->chrPos[1] != -513 || c->chrPos[2] != -513 || c->chrPos[3] != -513)
+            r = gmat_sws_setChromaPos(c->cross, c->chrPos[0], c->chrPos[1], c->chrPos[2], c->chrPos[3]);
+        if (r >= 0 && c->rangeConv) r = gmat_sws_setRange(c->cross, c->rangeConv == 2, c->rangeConv == 1);
+        if (r < 0) { gmat_sws_freeContext(c->cross); c->cross = nullptr; return r; }
+    }
+    if (c->crossFrames < nframes) {
+        if (c->crossBuf) { (void)hipFree(c->crossBuf); c->crossBuf = nullptr; c->crossFrames = 0; }
+        c->crossPitch = align_up(c->dstW + 1, 256);
+        GMAT_HIP_CHECK(hipMalloc((void **)&c->crossBuf, cross_frame_bytes(c) * nframes));
+        c->crossFrames = nframes;
+    }
+    return 0;
+}
+
+// the planes of the sibling's output frame inside crossBuf (the SOURCE's layout at the destination's size)
+static void cross_planes(const GmatSwsContext *c, uint8_t *base, uint8_t *pl[4], int st[4])
+{
+    const int ch = ceil_rshift(c->dstH, 1);
+    pl[0] = base; pl[1] = base + (size_t)c->crossPitch * c->dstH; pl[2] = pl[3] = nullptr;
+    st[0] = st[1] = c->crossPitch; st[2] = st[3] = 0;
+    if (c->srcFormat == GMAT_PIX_FMT_YUV420P) { st[1] = st[2] = c->crossPitch / 2; pl[2] = pl[1] + (size_t)st[1] * ch; }
+}
+
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
 {
@@ -1231,6 +1286,47 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
     }
     int pick = 0;
     while (!can[pick]) pick++;                         // (the last record takes everything)
+    if (pick == kNumPlaneKernels - 1 && cross_layout_cascade(c, ya0, n)) {
+        // NV12 <-> YUV420P scaled (gmat_sws_scale's rule), every frame's destination movable by the re-layout kernel: the sibling context's own
+        // batch into crossBuf, then one re-layout launch per 32 frames
+        bool all = true;
+        for (int f = 1; f < n && all; f++) {
+            YuvScaleArgs ya;
+            if (prep_yuv_args(c, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride, ya) < 0) return GMAT_ERR(EINVAL);
+            all = cross_layout_cascade(c, ya, n);
+        }
+        if (all) {
+            const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12;
+            for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+                const int m = std::min(kYuv2xMaxFrames, n - f0);
+                if (int r = cross_prepare(c, m); r < 0) return r;
+                std::vector<uint8_t *> ip((size_t)4 * m);
+                int st[4] = {0, 0, 0, 0};
+                Yuv2xFrames fr;
+                std::memset(&fr, 0, sizeof(fr));
+                for (int i = 0; i < m; i++) {
+                    uint8_t *pl[4];
+                    cross_planes(c, c->crossBuf + cross_frame_bytes(c) * i, pl, st);
+                    for (int q = 0; q < 4; q++) ip[(size_t)4 * i + q] = pl[q];
+                    uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+                    fr.y[i] = pl[0]; fr.u[i] = pl[1]; fr.v[i] = pl[2];
+                    fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = snv ? dp[2] : nullptr;
+                }
+                gmat_sws_setStream(c->cross, (void *)stream);
+                int r = m > 1 ? sws_scale_frames_batched(c->cross, m, src_planes + 4 * f0, srcStride, ip.data(), st, stream) : 0;
+                if (r < 0) return r;
+                if (r == 0)
+                    for (int i = 0; i < m; i++)
+                        if ((r = gmat_sws_scale(c->cross, src_planes + 4 * (f0 + i), srcStride, 0, c->srcH, ip.data() + 4 * i, st)) < 0) return r;
+                r = launch_yuv420_relayout(snv, fr.y[0], st[0], fr.u[0], st[1], fr.v[0], st[2], fr.dst[0], dstStride[0], fr.dstU[0], dstStride[1],
+                                           fr.dstV[0], snv ? dstStride[2] : 0, c->dstW, c->dstH, stream, &fr, m);
+                if (r < 0) return r;
+                c->lastKernel = c->cross->lastKernel;
+                c->lastLaunchFrames = c->cross->lastLaunchFrames;
+            }
+            return 1;
+        }
+    }
     const PlaneKernel &K = kPlaneKernels[pick];
     const bool planarSrc = c->srcFormat == GMAT_PIX_FMT_YUV420P || c->srcFormat == GMAT_PIX_FMT_YUV444P || pl16_depth(c->srcFormat);
     const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
@@ -1606,6 +1702,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     }
     const int conv = (!!srcFullRange == !!dstFullRange) ? 0 : (dstFullRange ? 1 : 2);
     if (conv == c->rangeConv) return 0;
+    if (c->cross) { gmat_sws_freeContext(c->cross); c->cross = nullptr; }
     // a same-size context is a plane copy / depth expansion only while the ranges agree (utils.c:1996-2000: the
     // special converters are skipped when srcRange != dstRange); otherwise it runs the generic path, whose 15-bit
     // lines carry the conversion (8-bit 4:2:0 and P010LE destinations: lum / chrRange{To,From}Jpeg_c on the 15-bit lines; 16-bit
@@ -1633,6 +1730,7 @@ int gmat_sws_setChromaPos(GmatSwsContext *c, int src_h_chr_pos, int src_v_chr_po
     for (int i = 0; i < 4; i++)
         if (np[i] < -513 || np[i] > 512) return GMAT_ERR(EINVAL);           // option range, options.c:67-70
     std::memcpy(c->chrPos, np, sizeof(np));
+    if (c->cross) { gmat_sws_freeContext(c->cross); c->cross = nullptr; }
     if (c->mode == MODE_SCALE16) return init_scale16(c);                     // the 19-bit path's own filter banks
     c->fused = 2;
     c->yuvReady = false;                     // the chroma filter banks depend on the positions
@@ -1960,6 +2058,19 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
         if ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) {
             YuvScaleArgs ya;
             if ((r = prep_yuv_args(c, src, srcStride, dst, dstStride, ya)) < 0) break;
+            if (cross_layout_cascade(c, ya, 1)) {
+                // NV12 <-> YUV420P scaled: the sibling context in the source's layout, then the re-layout of its (destination-size) frame
+                if ((r = cross_prepare(c, 1)) < 0) break;
+                uint8_t *pl[4]; int st[4];
+                cross_planes(c, c->crossBuf, pl, st);
+                gmat_sws_setStream(c->cross, (void *)c->stream);
+                if ((r = gmat_sws_scale(c->cross, src, srcStride, 0, c->srcH, pl, st)) < 0) break;
+                const bool snv = c->srcFormat == GMAT_PIX_FMT_NV12;
+                r = launch_yuv420_relayout(snv, pl[0], st[0], pl[1], st[1], pl[2], st[2], dst[0], dstStride[0], dst[1], dstStride[1],
+                                           snv ? dst[2] : nullptr, snv ? dstStride[2] : 0, c->dstW, c->dstH, c->stream);
+                c->lastKernel = c->cross->lastKernel;
+                break;
+            }
             // one frame per call: the first kernel of the table that takes this frame (kPlaneKernels)
             Yuv2xFrames one;
             std::memset(&one, 0, sizeof(one));

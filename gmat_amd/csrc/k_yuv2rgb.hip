@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void swap_rb24_kernel(const uint8_t *src, int 
     const uint8_t *s = src + (size_t)y * ss + (size_t)x * 3;
     uint8_t *d = dst + (size_t)y * ds + (size_t)x * 3;
     if (aligned && x + 4 <= w) {
-        const uint3 v = *reinterpret_cast<const uint3 *>(s);
+        const uint3 v = ld_stream(s, uint3());          // (round 4: every byte read once and written once — streaming both ways)
         uint3 o;
         // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3  ->  B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
         // (written with shifts; the compiler folds the byte moves into v_perm_b32 / v_bfi_b32)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void swap_rb24_kernel(const uint8_t *src, int 
         o.x = b0 | (g0 << 8) | (r0 << 16) | (b1 << 24);
         o.y = g1 | (r1 << 8) | (b2 << 16) | (g2 << 24);
         o.z = r2 | (b3 << 8) | (g3 << 16) | (r3 << 24);
-        *reinterpret_cast<uint3 *>(d) = o;
+        st_stream(d, o);
         return;
     }
     const int nx = min(4, w - x);
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(256) void repack_rgb_kernel(const uint8_t *src, int
     const int nx = min(4, w - x);
     if (full) {
         if (SB == 4) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(s);
+            const uint4 v = ld_stream(s, uint4());
             px[0] = v.x; px[1] = v.y; px[2] = v.z; px[3] = v.w;
         } else {
-            const uint3 v = *reinterpret_cast<const uint3 *>(s);
+            const uint3 v = ld_stream(s, uint3());
             px[0] = v.x | 0xFF000000u;
             px[1] = (v.x >> 24) | (v.y << 8) | 0xFF000000u;
             px[2] = (v.y >> 16) | (v.z << 16) | 0xFF000000u;
@@ -250,13 +250,13 @@ __global__ __launch_bounds__(256) void repack_rgb_kernel(const uint8_t *src, int
     }
     if (full) {
         if (DB == 4) {
-            *reinterpret_cast<uint4 *>(d) = make_uint4(px[0], px[1], px[2], px[3]);
+            st_stream(d, make_uint4(px[0], px[1], px[2], px[3]));
         } else {
             uint3 o;
             o.x = (px[0] & 0xFFFFFFu) | (px[1] << 24);
             o.y = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
             o.z = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
-            *reinterpret_cast<uint3 *>(d) = o;
+            st_stream(d, o);
         }
     } else {
         for (int i = 0; i < nx; i++)

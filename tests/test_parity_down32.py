@@ -175,7 +175,8 @@ def test_down32_batched_frames(dev, orc, strip_rows, kern_e3, fmt):
     assert (k == E3) == (kern_e3 == "strip"), k
 
 
-def test_down32_mixed_layouts_and_depths_stay_generic(dev, orc):
+def test_down32_mixed_layouts_and_depths_stay_generic(dev, orc, monkeypatch):
+    monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")          # (round 4: mixed layouts run the same-layout walker + a re-layout, tests/test_parity_cross_layout.py; this test is about the tier behind)
     for sf, df in (("nv12", "yuv420p"), ("yuv420p", "nv12"), ("p010le", "p010le")):
         src = synth_planes(orc, sf, 408, 42, seed=7)
         want = orc.sws(src, 408, 42, sf, 272, 28, df, SWS["bicubic"])

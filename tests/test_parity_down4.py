@@ -162,7 +162,8 @@ def test_down3_batched_frames(dev, orc, strip_rows, kern_d3, fmt):
     assert (k == D3) == (kern_d3 == "strip"), k
 
 
-def test_down3_mixed_layouts_and_depths_stay_generic(dev, orc):
+def test_down3_mixed_layouts_and_depths_stay_generic(dev, orc, monkeypatch):
+    monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")          # (round 4: mixed layouts run the same-layout walker + a re-layout, tests/test_parity_cross_layout.py; this test is about the tier behind)
     for sf, df in (("nv12", "yuv420p"), ("yuv420p", "nv12"), ("p010le", "p010le")):
         src = synth_planes(orc, sf, 1056, 64, seed=7)
         want = orc.sws(src, 1056, 64, sf, 264, 16, df, SWS["bicubic"])

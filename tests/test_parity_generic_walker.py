@@ -168,7 +168,10 @@ def test_rule_clauses(dev, orc, strip_rows, monkeypatch):
     assert _check(dev, orc, "nv12", "rgb24", (386, 216, 160, 90)) != G                      # 386 bytes: not whole dwords
     assert _check(dev, orc, "yuv420p", "rgb24", (388, 216, 160, 90)) != G                   # planar chroma rows of 194 bytes
     assert _check(dev, orc, "nv12", "rgb24", (388, 216, 160, 90)) == G                      # interleaved chroma rows of 388 bytes
-    assert _check(dev, orc, "nv12", "yuv420p", g) != G and _check(dev, orc, "yuv420p", "nv12", g) != G
+    assert _check(dev, orc, "nv12", "yuv420p", g) == G and _check(dev, orc, "yuv420p", "nv12", g) == G      # round 4: the walker in the source's layout + a re-layout
+    monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")
+    assert _check(dev, orc, "nv12", "yuv420p", g) != G and _check(dev, orc, "yuv420p", "nv12", g) != G      # ... its own rule: one chroma layout
+    monkeypatch.delenv("GMAT_NO_CROSS_CASCADE")
     assert _check(dev, orc, "nv12", "rgb24", (48, 48, 12, 12)) != G                         # narrower than 16
     assert _check(dev, orc, "nv12", "rgb24", (64, 32, 16, 8)) == G
     assert _check(dev, orc, "nv12", "rgb24", (384, 216, 161, 90)) != G                      # odd width: libswscale's full-chroma output

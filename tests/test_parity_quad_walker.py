@@ -103,7 +103,10 @@ def test_rule_clauses(dev, orc, strip_rows, monkeypatch):
     assert _check(dev, orc, "nv12", "rgb24", (162, 90, 240, 136)) != QUAD                   # 162 bytes: not whole dwords
     assert _check(dev, orc, "yuv420p", "rgb24", (164, 90, 240, 136)) != QUAD                # planar chroma rows of 82 bytes
     assert _check(dev, orc, "nv12", "rgb24", (164, 90, 240, 136)) == QUAD                   # interleaved chroma rows of 164 bytes
-    assert _check(dev, orc, "nv12", "yuv420p", g) != QUAD and _check(dev, orc, "yuv420p", "nv12", g) != QUAD
+    assert _check(dev, orc, "nv12", "yuv420p", g) == QUAD and _check(dev, orc, "yuv420p", "nv12", g) == QUAD      # the kernel in the source's layout + a re-layout (the cascade)
+    monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")
+    assert _check(dev, orc, "nv12", "yuv420p", g) != QUAD and _check(dev, orc, "yuv420p", "nv12", g) != QUAD      # ... its own rule: one chroma layout
+    monkeypatch.delenv("GMAT_NO_CROSS_CASCADE")
     assert _check(dev, orc, "nv12", "rgb24", (160, 90, 241, 136)) != QUAD                   # odd width: libswscale's full-chroma output
     assert _check(dev, orc, "nv12", "rgb24", (12, 8, 24, 16)) != QUAD                       # narrower than 16
     assert _check(dev, orc, "nv12", "rgb24", (16, 8, 32, 16)) == QUAD

@@ -153,7 +153,8 @@ def test_up2_batched_frames(dev, orc, strip_rows, kern_up, fmt):
     assert (k == UP) == (kern_up == "strip"), k
 
 
-def test_up2_mixed_layouts_and_depths_stay_generic(dev, orc):
+def test_up2_mixed_layouts_and_depths_stay_generic(dev, orc, monkeypatch):
+    monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")          # (round 4: mixed layouts run the same-layout walker + a re-layout, tests/test_parity_cross_layout.py; this test is about the tier behind)
     for sf, df in (("nv12", "yuv420p"), ("yuv420p", "nv12")):
         src = synth_planes(orc, sf, 264, 26, seed=7)
         want = orc.sws(src, 264, 26, sf, 528, 52, df, SWS["bicubic"])
