@@ -350,6 +350,11 @@ int main(int argc, char **argv)
         {"any: up nv12 1080p->4K rgb24 bicubic (1:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
         {"any: up nv12 640x480->1080p nv12 bicubic", GMAT_PIX_FMT_NV12, 640, 480, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"any: up nv12 720p->1080p rgb24 lanczos", GMAT_PIX_FMT_NV12, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_LANCZOS},
+        // between the chroma layouts, scaled (nvdec's NV12 for a planar consumer): rounds 1-3 the tiled kernel, round 4 the same-layout walker + a re-layout
+        {"any: cross nv12 1080p->720p yuv420p bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_SWS_BICUBIC},
+        {"any: cross nv12 4K->720p yuv420p bicubic (3:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_SWS_BICUBIC},
+        {"any: cross nv12 4K->1600x900 yuv420p bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV420P, 1600, 900, GMAT_SWS_BICUBIC},
+        {"any: cross yuv420p 720p->1080p nv12 bicubic", GMAT_PIX_FMT_YUV420P, 1280, 720, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         // short-filter down-scales (8 taps): the band walker's by default, the quad-lane walker's behind GMAT_QUAD_WALKER=2
         {"any: short nv12 1440p->1080p nv12 bicubic (4:3)", GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"any: short nv12 1440p->1080p rgb24 bicubic (4:3)", GMAT_PIX_FMT_NV12, 2560, 1440, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
