@@ -149,8 +149,16 @@ int launch_scale_nv12_bicubic_ref(const uint8_t *src, int ss, int srcW, int srcH
 // ---- NV12 -> three stacked planes (plane k at dst + k * ds * h), 8-bit or float = u8 / 255 ----------------------------------------
 // 4 x 2 pixels per thread like yuv2rgb_kernel: two dwords of luma, one of chroma; per plane and row one dword (8-bit) or 16 bytes (float)
 template <bool F32, bool BGR>
-__global__ __launch_bounds__(256) void nv12_to_planar_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h, Yuv2RgbConsts k, int aligned)
+__global__ __launch_bounds__(256) void nv12_to_planar_kernel(YuvSrc s, uint8_t *dst, int ds, int w, int h, Yuv2RgbConsts k, int aligned, int srcAligned)
 {
+    // round 4 (as nv12_to_rgbpf32_kernel, k_yuv2rgb.hip): u8 / 255.0f from a 256-entry LDS table built with the same IEEE division (12 divisions a
+    // row and lane were most of the float form's instructions), dword loads where the rows allow them, streaming stores
+    __shared__ float unit[256];
+    if (F32) {
+        const int i = threadIdx.y * 64 + threadIdx.x;
+        unit[i] = (float)i / 255.0f;
+        __syncthreads();
+    }
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x >= w || y >= h) return;
@@ -158,16 +166,25 @@ __global__ __launch_bounds__(256) void nv12_to_planar_kernel(YuvSrc s, uint8_t *
     const size_t crow = (size_t)(y >> 1);
     const int nx = min(4, w - x);
     ChromaTerms c[2];
-    for (int i = 0; i < 2; i++) {
-        const int xx = min(x + 2 * i, w - 1);
-        const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
-        c[i] = chroma_terms(k, p[0], p[1]);
+    if (srcAligned && nx == 4) {
+        const unsigned uv = *reinterpret_cast<const unsigned *>(s.u + crow * s.us + x);      // U0 V0 U1 V1 (x is a multiple of 4: pair x / 2 at byte x)
+        c[0] = chroma_terms(k, (int)(uv & 0xFF), (int)((uv >> 8) & 0xFF));
+        c[1] = chroma_terms(k, (int)((uv >> 16) & 0xFF), (int)(uv >> 24));
+    } else {
+        for (int i = 0; i < 2; i++) {
+            const int xx = min(x + 2 * i, w - 1);
+            const uint8_t *p = s.u + crow * s.us + 2 * (xx >> 1);
+            c[i] = chroma_terms(k, p[0], p[1]);
+        }
     }
     for (int r = 0; r < 2 && y + r < h; r++) {
+        unsigned yy = 0;
+        const uint8_t *prow = s.y + (size_t)(y + r) * s.ys + x;
+        if (srcAligned && nx == 4) yy = *reinterpret_cast<const unsigned *>(prow);
+        else for (int i = 0; i < 4; i++) yy |= (unsigned)prow[min(i, nx - 1)] << (8 * i);
         int o[3][4];
         for (int i = 0; i < 4; i++) {
-            const int xx = min(x + i, w - 1);
-            const int ycy = m24((int)s.y[(size_t)(y + r) * s.ys + xx], k.cy);
+            const int ycy = m24((int)((yy >> (8 * i)) & 0xFF), k.cy);
             const ChromaTerms &q = c[i >> 1];
             o[BGR ? 2 : 0][i] = luma_chan(q.r, ycy);
             o[1][i] = luma_chan(q.g, ycy);
@@ -177,10 +194,11 @@ __global__ __launch_bounds__(256) void nv12_to_planar_kernel(YuvSrc s, uint8_t *
             uint8_t *row = dst + pl * plane + (size_t)(y + r) * ds;
             if (F32) {
                 float *f = reinterpret_cast<float *>(row) + x;
-                if (aligned && nx == 4) *reinterpret_cast<float4 *>(f) = make_float4((float)o[pl][0] / 255.0f, (float)o[pl][1] / 255.0f, (float)o[pl][2] / 255.0f, (float)o[pl][3] / 255.0f);
-                else for (int i = 0; i < nx; i++) f[i] = (float)o[pl][i] / 255.0f;
+                if (aligned && nx == 4) st_stream(f, make_uint4(__builtin_bit_cast(unsigned, unit[o[pl][0]]), __builtin_bit_cast(unsigned, unit[o[pl][1]]),
+                                                                __builtin_bit_cast(unsigned, unit[o[pl][2]]), __builtin_bit_cast(unsigned, unit[o[pl][3]])));
+                else for (int i = 0; i < nx; i++) f[i] = unit[o[pl][i]];
             } else {
-                if (aligned && nx == 4) *reinterpret_cast<unsigned *>(row + x) = (unsigned)o[pl][0] | ((unsigned)o[pl][1] << 8) | ((unsigned)o[pl][2] << 16) | ((unsigned)o[pl][3] << 24);
+                if (aligned && nx == 4) st_stream(row + x, (unsigned)((unsigned)o[pl][0] | ((unsigned)o[pl][1] << 8) | ((unsigned)o[pl][2] << 16) | ((unsigned)o[pl][3] << 24)));
                 else for (int i = 0; i < nx; i++) row[x + i] = (uint8_t)o[pl][i];
             }
         }
@@ -193,11 +211,12 @@ int launch_nv12_to_planar(const YuvSrc &s, uint8_t *dst, int ds, int w, int h, c
     if (!s.nv12 || !dst) return GMAT_ERR(EINVAL);
     const size_t plane = (size_t)ds * h;
     const int aligned = ((((uintptr_t)dst | (uintptr_t)ds | plane) & (f32 ? 15 : 3)) == 0);
+    const int srcAligned = ((((uintptr_t)s.y | (uintptr_t)s.ys | (uintptr_t)s.u | (uintptr_t)s.us) & 3) == 0) && (w % 2) == 0;
     const dim3 block(64, 4), grid((w + 255) / 256, (h + 7) / 8);
-    if (f32 && bgr)       hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<true, true>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
-    else if (f32)         hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<true, false>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
-    else if (bgr)         hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<false, true>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
-    else                  hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<false, false>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned);
+    if (f32 && bgr)       hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<true, true>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned, srcAligned);
+    else if (f32)         hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<true, false>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned, srcAligned);
+    else if (bgr)         hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<false, true>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned, srcAligned);
+    else                  hipLaunchKernelGGL(HIP_KERNEL_NAME(nv12_to_planar_kernel<false, false>), grid, block, 0, stream, s, dst, ds, w, h, k, aligned, srcAligned);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
