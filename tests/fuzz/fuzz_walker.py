@@ -41,7 +41,10 @@ for case in range(n):
     if rng.random() < 0.7:
         os.environ["GMAT_SCALE_NO_STRIP"] = "1"                  # exact ratios reach the walker too
     sf = rng.choice(["nv12", "yuv420p"])
-    df = rng.choice(["rgb24", "bgr24", "rgba", "bgra", sf, sf])
+    df = rng.choice(["rgb24", "bgr24", "rgba", "bgra", sf, sf, "yuv420p" if sf == "nv12" else "nv12"])      # (the other chroma layout: round 4's cascade, GMAT_NO_CROSS_CASCADE)
+    os.environ.pop("GMAT_NO_CROSS_CASCADE", None)
+    if rng.random() < 0.2:
+        os.environ["GMAT_NO_CROSS_CASCADE"] = "1"
     dw = 2 * rng.randint(8, maxw // 8)
     dh = 2 * rng.randint(4, maxh // 6)
     if rng.random() < 0.3:
