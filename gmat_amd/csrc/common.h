@@ -84,6 +84,7 @@ inline int  bytes_per_pixel(int f)
 // internal accessor (gsws.cpp) used by the graph-capture helper
 int sws_src_height(const GmatSwsContext *c);
 bool sws_shares_intermediate(const GmatSwsContext *c);
+bool sws_owns_intermediates(const GmatSwsContext *c);   // ... or may (NV12 <-> YUV420P scaled: the cascade's frame)
 void *sws_current_stream(const GmatSwsContext *c);
 // frames [0,n) through one launch per 32 frames when the context runs the 2:1 kernel: 1 taken, 0 not eligible, < 0 error
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],

@@ -281,7 +281,7 @@ int gmat_sws_graph_create(GmatSwsContext *c, int nframes, const uint8_t *const *
     const int srcH = gmat::sws_src_height(c);
     if (nbranches < 1) nbranches = 1;
     if (nbranches > 8) nbranches = 8;
-    if (gmat::sws_shares_intermediate(c)) nbranches = 1;
+    if (gmat::sws_owns_intermediates(c)) nbranches = 1;     // captured work is ordered by its graph alone (stream_handoff_*, gsws.cpp)
     gmat_sws_setStream(c, stream);
     // warm launches outside capture so lazy allocations (the intermediate frames of the two-kernel form) are not captured
     {

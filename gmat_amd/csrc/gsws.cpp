@@ -186,12 +186,21 @@ struct GmatSwsContext {
     GmatSwsContext *cross = nullptr;
     uint8_t *crossBuf = nullptr;
     int crossPitch = 0, crossFrames = 0;
+    // A context owns ONE set of intermediates (crossBuf, inter / interBatch, the 16-bit lines, an inner context's): a call on a stream other than
+    // the one that used them last is ordered behind that use by an event (stream_handoff_*) — gmat_sws_scale_batch hands a context's frames to
+    // several streams, and a per-frame caller may alternate streams of its own.  The reference has one set of cv_* buffers per context and leaves
+    // the ordering to its caller (swscale_cuda.c:86-109, 248-266).
+    hipEvent_t interEv = nullptr;
+    hipStream_t interStream = nullptr;
+    bool interUsed = false, interTouched = false;
+    int handoffs = 0;
     ~GmatSwsContext()
     {
         if (inter) (void)hipFree(inter);
         if (interBatch) (void)hipFree(interBatch);
         if (cross) gmat_sws_freeContext(cross);
         if (crossBuf) (void)hipFree(crossBuf);
+        if (interEv) (void)hipEventDestroy(interEv);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
     }
@@ -977,6 +986,39 @@ static int check_device(const GmatSwsContext *c, const char *who)
     return 0;
 }
 
+// ---- one set of intermediates per context: ordering between streams ---------------------------------------------------------------------
+static bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+// contexts whose calls may write a buffer the context owns: the modes with an intermediate, and NV12 <-> YUV420P scaled (the cascade's crossBuf)
+static bool owns_intermediates(const GmatSwsContext *c)
+{
+    return sws_shares_intermediate(c) ||
+           (c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat) && c->srcFormat != c->dstFormat);
+}
+// before a call's first launch: `s` waits for the last use of the intermediates if that was on another stream.  Captured work is ordered by its
+// graph (gmat_sws_graph_create keeps such contexts on one branch and synchronises before it captures).
+static int stream_handoff_acquire(GmatSwsContext *c, hipStream_t s)
+{
+    c->interTouched = false;
+    if (!c->interUsed || c->interStream == s || stream_is_capturing(s)) return 0;
+    GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->interEv, 0));
+    c->handoffs++;
+    return 0;
+}
+// after a call's last launch, when it used the intermediates
+static int stream_handoff_release(GmatSwsContext *c, hipStream_t s)
+{
+    if (stream_is_capturing(s)) return 0;
+    if (!c->interEv) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->interEv, hipEventDisableTiming));
+    GMAT_HIP_CHECK(hipEventRecord(c->interEv, s));
+    c->interStream = s;
+    c->interUsed = true;
+    return 0;
+}
+
 // Frames [0, n) of one geometry (plane pointers 4 per frame, shared strides) through ONE launch of the 2:1 kernel
 // per kYuv2xMaxFrames frames.  Returns 1 when taken, 0 when this context / these frames are not eligible (the
 // caller then goes frame by frame), < 0 on error.
@@ -1026,8 +1068,22 @@ static void cross_planes(const GmatSwsContext *c, uint8_t *base, uint8_t *pl[4],
     if (c->srcFormat == GMAT_PIX_FMT_YUV420P) { st[1] = st[2] = c->crossPitch / 2; pl[2] = pl[1] + (size_t)st[1] * ch; }
 }
 
+static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
+                                         uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream);
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
+{
+    if (!c || n < 2) return 0;
+    const bool own = owns_intermediates(c);
+    if (own)
+        if (int r = stream_handoff_acquire(c, stream); r < 0) return r;
+    const int t = sws_scale_frames_batched_impl(c, n, src_planes, srcStride, dst_planes, dstStride, stream);
+    if (own && t > 0 && (c->interTouched || sws_shares_intermediate(c)))
+        if (int r = stream_handoff_release(c, stream); r < 0) return r;
+    return t;
+}
+static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
+                                         uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
 {
     if (!c || n < 2) return 0;
     const bool off = GMAT_KNOB("GMAT_SWS_NO_BATCH_KERNEL") != nullptr;
@@ -1300,6 +1356,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
             for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
                 const int m = std::min(kYuv2xMaxFrames, n - f0);
                 if (int r = cross_prepare(c, m); r < 0) return r;
+                c->interTouched = true;
                 std::vector<uint8_t *> ip((size_t)4 * m);
                 int st[4] = {0, 0, 0, 0};
                 Yuv2xFrames fr;
@@ -1363,6 +1420,7 @@ hipEvent_t *sws_batch_events(GmatSwsContext *c)
     return c->batchEv;
 }
 void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream : nullptr; }
+bool sws_owns_intermediates(const GmatSwsContext *c) { return c && owns_intermediates(c); }
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
@@ -1756,6 +1814,7 @@ int gmat_sws_setProfileBuffer(GmatSwsContext *c, uint8_t *devbuf)
 
 const char *gmat_sws_lastKernel(const GmatSwsContext *c) { return c ? c->lastKernel : ""; }
 int gmat_sws_lastLaunchFrames(const GmatSwsContext *c) { return c ? c->lastLaunchFrames : 0; }
+int gmat_sws_streamHandoffs(const GmatSwsContext *c) { return c ? c->handoffs : 0; }
 
 int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_t *pos, int cap, int *count)
 {
@@ -1778,8 +1837,20 @@ int gmat_sws_getFilter(const GmatSwsContext *c, int which, int16_t *coef, int32_
 }
 
 
+static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                          int srcSliceH, uint8_t *const dst[], const int dstStride[]);
 int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
+{
+    if (!c || !owns_intermediates(c)) return sws_scale_impl(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    if (int r = stream_handoff_acquire(c, c->stream); r < 0) return r;
+    const int h = sws_scale_impl(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
+    if (h > 0 && (c->interTouched || sws_shares_intermediate(c)))
+        if (int r = stream_handoff_release(c, c->stream); r < 0) return r;
+    return h;
+}
+static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
+                          int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
     if (!c || !src || !dst || !srcStride || !dstStride || !src[0] || !dst[0]) {
         logf(LOG_ERROR, "gmat_sws_scale: one of the input parameters to sws_scale() is NULL");
@@ -2061,6 +2132,7 @@ int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcS
             if (cross_layout_cascade(c, ya, 1)) {
                 // NV12 <-> YUV420P scaled: the sibling context in the source's layout, then the re-layout of its (destination-size) frame
                 if ((r = cross_prepare(c, 1)) < 0) break;
+                c->interTouched = true;
                 uint8_t *pl[4]; int st[4];
                 cross_planes(c, c->crossBuf, pl, st);
                 gmat_sws_setStream(c->cross, (void *)c->stream);

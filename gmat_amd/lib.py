@@ -45,6 +45,7 @@ _SIGS = {
     "gmat_sws_getFilter": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gmat_sws_lastKernel": (C.c_char_p, [C.c_void_p]),
     "gmat_sws_lastLaunchFrames": (C.c_int, [C.c_void_p]),
+    "gmat_sws_streamHandoffs": (C.c_int, [C.c_void_p]),
     "gmat_sws_setProfileBuffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "yuv2rgb_cuda": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -147,6 +147,11 @@ GMAT_API const char *gmat_sws_lastKernel(const GmatSwsContext *c);
 /* number of frames that launch carried: 1, or up to 32 when gmat_sws_scale_batch / gmat_sws_graph_create put a
  * stream's share of the frames into one launch of the 2:1 kernel */
 GMAT_API int  gmat_sws_lastLaunchFrames(const GmatSwsContext *c);
+/* A context owns ONE set of intermediates (the two-kernel forms, the 16-bit paths, NV12 <-> YUV420P scaled); like the reference's cv_* buffers
+ * (swscale_cuda.c:248-266) they are shared by every call.  A call on a stream other than the one that used them last is ordered behind that use
+ * by an event inside the library, so alternating streams (gmat_sws_setStream, gmat_sws_scale_batch) is always safe; contexts without
+ * intermediates (the fused kernels, every same-size converter) overlap freely.  Returns how often that ordering was needed (tests). */
+GMAT_API int  gmat_sws_streamHandoffs(const GmatSwsContext *c);
 
 /* ---- the plain-pointer back-end entry points, under the reference's own names ----------
  * libswscale core calls these (swscale_unscaled.c:1970-2012); CUstream == void*.          */

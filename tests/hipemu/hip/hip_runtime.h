@@ -145,6 +145,8 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus *st);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t *g);
 hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t);

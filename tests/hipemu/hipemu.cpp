@@ -262,6 +262,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *) { return hipErrorNotSupported; }
 hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorNotSupported; }

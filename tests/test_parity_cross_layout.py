@@ -90,3 +90,77 @@ def test_positions_and_ranges_reach_the_sibling(dev, orc):
     lib.gmat_sws_freeContext(c)
     for p in d:
         p.free()
+
+
+def _alternating_streams(dev, orc, sf, df, geom, nframes, nstreams, fused=None, flags="bicubic"):
+    """one gmat_sws_scale per frame, the caller alternating `nstreams` streams of its own (gmat_sws_setStream before each call) — what
+    gmat_sws_scale_batch does with fewer than two frames a stream; returns the kernel and how often the context ordered one stream behind another"""
+    import ctypes as C
+    from harness import PIX_FMT, planes, ints
+    lib = dev.lib
+    sw, sh, dw, dh = geom
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT[sf], dw, dh, PIX_FMT[df], SWS[flags] | SWS["hwaccel"], None)
+    assert c
+    if fused is not None:
+        assert lib.gmat_sws_setFused(c, fused) == 0
+    srcs = [synth_planes(orc, sf, sw, sh, seed=900 + 11 * f) for f in range(nframes)]
+    dsrc = [dev.upload_planes(s, 64) for s in srcs]
+    ddst = [dev.planes_like(df, dw, dh, 64) for _ in range(nframes)]
+    streams = []
+    for _ in range(nstreams):
+        h = C.c_void_p()
+        assert lib.gmat_stream_create(C.byref(h)) == 0
+        streams.append(h)
+    for f in range(nframes):
+        lib.gmat_sws_setStream(c, streams[f % nstreams])
+        r = lib.gmat_sws_scale(c, planes([p.ptr for p in dsrc[f]]), ints([p.stride for p in dsrc[f]]), 0, sh,
+                               planes([p.ptr for p in ddst[f]]), ints([p.stride for p in ddst[f]]))
+        assert r == dh
+    lib.gmat_device_sync()
+    kernel, handoffs = lib.gmat_sws_lastKernel(c).decode(), lib.gmat_sws_streamHandoffs(c)
+    for f in range(nframes):
+        if (sw, sh) == (dw, dh) and df == "rgb24":
+            want = [orc.yuv2rgb(srcs[f], sw, sh, sf, df)]                                                    # the same-size converter's rule
+        else:
+            want = (orc.chained if fused == 0 else orc.sws)(srcs[f], sw, sh, sf, dw, dh, df, SWS[flags])     # fused = 0: the reference's order of operations
+        for i, (p, w) in enumerate(zip(ddst[f], want)):
+            assert (p.download() == w).all(), (f, i, kernel)
+    for h in streams:
+        lib.gmat_stream_destroy(h)
+    for f in range(nframes):
+        for p in dsrc[f] + ddst[f]:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+    return kernel, handoffs
+
+
+@pytest.mark.parametrize("pair", PAIRS)
+def test_streams_share_the_cascade_frame(dev, orc, strip_rows, pair):
+    """The cascade's frame (crossBuf) is ONE per context: calls on alternating streams are ordered behind each other by the context
+    (stream_handoff_*, gsws.cpp).  Found by fuzz_walker on the GPU (two frames over two streams: the second frame's scale overwrote the frame
+    the first one's re-layout was reading); the emulator runs a stream's work at once, so there it is the count of hand-offs that proves the rule."""
+    strip_rows(0)
+    geom = (1428, 248, 272, 58) if dev.kind == "hip" else (384, 216, 160, 90)
+    for nstreams, nframes in ((2, 6), (3, 7)):
+        kernel, handoffs = _alternating_streams(dev, orc, pair[0], pair[1], geom, nframes, nstreams)
+        assert handoffs == nframes - 1, kernel                  # (the kernel named is the sibling's, whichever its table picks: the frame is shared either way)
+    # through the batch entry point: fewer than two frames a stream (frame by frame over the streams), and shares of several frames
+    for nframes, nstreams in ((2, 2), (3, 2), (5, 2), (9, 4)):
+        _run_batch(dev, orc, pair[0], pair[1], *geom, nframes=nframes, nstreams=nstreams, align=64)
+    # a context whose own table serves the pair (2:1) owns no frame: nothing to order
+    kernel, handoffs = _alternating_streams(dev, orc, pair[0], pair[1], (528, 52, 264, 26), 4, 2)
+    assert (kernel, handoffs) == ("scale_yuv2px_kernel", 0)
+
+
+def test_streams_share_the_two_kernel_forms_intermediate(dev, orc, strip_rows):
+    """the same rule for every context with an intermediate: the two-kernel form of a scaled yuv -> rgb context (fused = 0), a 16-bit path;
+    the fused kernels and the same-size converters own nothing and are never ordered"""
+    strip_rows(0)
+    kernel, handoffs = _alternating_streams(dev, orc, "nv12", "rgb24", (384, 216, 192, 108), 5, 2, fused=0)
+    assert handoffs == 4, kernel
+    kernel, handoffs = _alternating_streams(dev, orc, "nv12", "rgb24", (384, 216, 192, 108), 5, 2, fused=2)
+    assert handoffs == 0, kernel
+    kernel, handoffs = _alternating_streams(dev, orc, "nv12", "rgb24", (384, 216, 384, 216), 5, 2)
+    assert (kernel, handoffs) == ("yuv2rgb_kernel", 0)
+    kernel, handoffs = _alternating_streams(dev, orc, "rgba", "nv12", (384, 216, 160, 90), 4, 2)
+    assert handoffs in (0, 3), kernel
