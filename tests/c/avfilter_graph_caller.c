@@ -1,0 +1,190 @@
+/* tests/c/avfilter_graph_caller.c — TEST INFRASTRUCTURE (build container only: needs /root/reference).
+ *
+ * The reference's REAL libavfilter + libavutil drive the reference-side sources of this repository: compiled against the reference's own
+ * headers and linked with its libavfilter.a / libavutil.a / libswscale.a (tools/build_ref_avfilter.sh), with
+ *     integration/hwcontext_hip.c   as libavutil's ff_hwcontext_type_cuda                (hwcontext.c:36-38)
+ *     integration/vf_gmat_hip.c     the seven GPU filters, integration/vf_hwupload_hip.c  (const AVFilter ff_vf_*)
+ * and the library under test behind them.  It does what an application (fftools/ffmpeg_filter.c) does with libavfilter's public API:
+ *     av_hwdevice_ctx_create(AV_HWDEVICE_TYPE_CUDA, "0")        libavutil/hwcontext.c:610 -> HWContextType.device_create
+ *     avfilter_graph_alloc_filter / avfilter_init_str / avfilter_link / avfilter_graph_config      (format negotiation, config_props,
+ *                                                              av_hwframe_ctx_alloc / _init inside the filters: hwcontext.c:247,333)
+ *     av_buffersrc_add_frame -> ... -> av_buffersink_get_frame  (filter_frame / activate() scheduling, frame pools, av_hwframe_transfer_data)
+ * on TWO graphs over the same software frames —
+ *     buffer -> <gpu chain, e.g. hwupload_hip,scale_hip=w=160:h=90:format=rgb24,hwdownload> -> buffersink
+ *     buffer -> <cpu chain, e.g. scale=160:90:flags=bicubic,format=rgb24>                   -> buffersink
+ * — and compares every byte of every frame.  Exit code 0: identical.
+ *   avfilter_graph_caller <w> <h> <pix_fmt> <nframes> "<gpu chain>" "<cpu chain>" [seed]
+ * A chain is `name=args,name=args,...` (no quoting: ',' only between filters); names ending in _hip are this repository's.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "libavfilter/avfilter.h"
+#include "libavfilter/buffersink.h"
+#include "libavfilter/buffersrc.h"
+#include "libavutil/frame.h"
+#include "libavutil/hwcontext.h"
+#include "libavutil/imgutils.h"
+#include "libavutil/pixdesc.h"
+
+extern const AVFilter ff_vf_crop_hip, ff_vf_flip_hip, ff_vf_rotate_hip, ff_vf_transpose_hip, ff_vf_smooth_hip, ff_vf_scale_hip,
+                      ff_vf_format_hip, ff_vf_hwupload_hip;
+static const AVFilter *const ours[] = { &ff_vf_crop_hip, &ff_vf_flip_hip, &ff_vf_rotate_hip, &ff_vf_transpose_hip, &ff_vf_smooth_hip,
+                                        &ff_vf_scale_hip, &ff_vf_format_hip, &ff_vf_hwupload_hip };
+
+static const AVFilter *find_filter(const char *name)
+{
+    for (size_t i = 0; i < sizeof(ours) / sizeof(ours[0]); i++)
+        if (!strcmp(ours[i]->name, name))
+            return ours[i];
+    return avfilter_get_by_name(name);
+}
+
+#define CK(x) do { int r_ = (x); if (r_ < 0) { char e_[128]; av_strerror(r_, e_, sizeof(e_)); \
+                   fprintf(stderr, "%s failed: %d (%s)\n", #x, r_, e_); return r_; } } while (0)
+
+typedef struct Graph {
+    AVFilterGraph *g;
+    AVFilterContext *src, *sink;
+} Graph;
+
+static int build(Graph *G, const char *chain, int w, int h, enum AVPixelFormat fmt, AVBufferRef *device)
+{
+    char args[256], *copy = strdup(chain), *save = NULL;
+    AVFilterContext *last;
+    int n = 0;
+
+    G->g = avfilter_graph_alloc();
+    if (!G->g || !copy)
+        return AVERROR(ENOMEM);
+    snprintf(args, sizeof(args), "video_size=%dx%d:pix_fmt=%d:time_base=1/25:pixel_aspect=1/1", w, h, (int)fmt);
+    CK(avfilter_graph_create_filter(&G->src, avfilter_get_by_name("buffer"), "in", args, NULL, G->g));
+    last = G->src;
+    for (char *tok = strtok_r(copy, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
+        char *eq = strchr(tok, '='), inst[32];
+        const AVFilter *f;
+        AVFilterContext *ctx;
+        if (eq)
+            *eq = 0;
+        f = find_filter(tok);
+        if (!f) { fprintf(stderr, "no filter '%s'\n", tok); return AVERROR_FILTER_NOT_FOUND; }
+        snprintf(inst, sizeof(inst), "f%d_%s", n++, tok);
+        ctx = avfilter_graph_alloc_filter(G->g, f, inst);
+        if (!ctx)
+            return AVERROR(ENOMEM);
+        if (device && !strcmp(tok, "hwupload"))                  /* libavfilter's generic uploader takes the device from the application (ffmpeg_filter.c) */
+            ctx->hw_device_ctx = av_buffer_ref(device);
+        CK(avfilter_init_str(ctx, eq ? eq + 1 : NULL));
+        CK(avfilter_link(last, 0, ctx, 0));
+        last = ctx;
+    }
+    CK(avfilter_graph_create_filter(&G->sink, avfilter_get_by_name("buffersink"), "out", NULL, NULL, G->g));
+    CK(avfilter_link(last, 0, G->sink, 0));
+    CK(avfilter_graph_config(G->g, NULL));
+    free(copy);
+    return 0;
+}
+
+static AVFrame *make_frame(int w, int h, enum AVPixelFormat fmt, uint32_t seed, int64_t pts)
+{
+    AVFrame *f = av_frame_alloc();
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fmt);
+    uint32_t s = seed;
+    if (!f)
+        return NULL;
+    f->format = fmt; f->width = w; f->height = h; f->pts = pts;
+    if (av_frame_get_buffer(f, 0) < 0) { av_frame_free(&f); return NULL; }
+    for (int p = 0; p < 4 && f->data[p]; p++) {
+        const int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(h, d->log2_chroma_h) : h;
+        const int bytes = av_image_get_linesize(fmt, w, p);
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < bytes; x++) {
+                s = s * 1664525u + 1013904223u;
+                /* smooth-ish content with noise on top: gradients exercise the filters' rounding, noise their clipping */
+                f->data[p][(size_t)y * f->linesize[p] + x] = (uint8_t)(((x * 3 + y * 5) & 0xFF) / 2 + (s >> 25));
+            }
+    }
+    return f;
+}
+
+static long compare(const AVFrame *a, const AVFrame *b, int frame_no)
+{
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(a->format);
+    long bad = 0;
+    if (a->format != b->format || a->width != b->width || a->height != b->height) {
+        fprintf(stderr, "frame %d: %s %dx%d against %s %dx%d\n", frame_no, av_get_pix_fmt_name(a->format), a->width, a->height,
+                av_get_pix_fmt_name(b->format), b->width, b->height);
+        return 1 << 30;
+    }
+    for (int p = 0; p < 4 && a->data[p]; p++) {
+        const int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(a->height, d->log2_chroma_h) : a->height;
+        const int bytes = av_image_get_linesize(a->format, a->width, p);
+        for (int y = 0; y < rows; y++) {
+            const uint8_t *ra = a->data[p] + (ptrdiff_t)y * a->linesize[p], *rb = b->data[p] + (ptrdiff_t)y * b->linesize[p];
+            for (int x = 0; x < bytes; x++)
+                if (ra[x] != rb[x]) {
+                    if (bad < 6)
+                        fprintf(stderr, "frame %d plane %d (%d, %d): gpu %d cpu %d\n", frame_no, p, x, y, ra[x], rb[x]);
+                    bad++;
+                }
+        }
+    }
+    return bad;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: avfilter_graph_caller w h pix_fmt nframes \"gpu chain\" \"cpu chain\" [seed]\n"); return 1; }
+    const int w = atoi(argv[1]), h = atoi(argv[2]), nframes = atoi(argv[4]);
+    const enum AVPixelFormat fmt = av_get_pix_fmt(argv[3]);
+    const uint32_t seed = argc > 7 ? (uint32_t)atoi(argv[7]) : 2026u;
+    AVBufferRef *device = NULL;
+    Graph gpu = {0}, cpu = {0};
+    long bad = 0;
+    int got = 0;
+
+    if (fmt == AV_PIX_FMT_NONE || nframes < 1 || nframes > 64) { fprintf(stderr, "bad arguments\n"); return 1; }
+    av_log_set_level(AV_LOG_WARNING);
+    CK(av_hwdevice_ctx_create(&device, AV_HWDEVICE_TYPE_CUDA, "0", NULL, 0));
+    CK(build(&gpu, argv[5], w, h, fmt, device));
+    CK(build(&cpu, argv[6], w, h, fmt, NULL));
+
+    AVFrame *outs_gpu[64] = {0}, *outs_cpu[64] = {0};
+    int ng = 0, nc = 0;
+    for (int i = 0; i <= nframes; i++) {
+        /* frame i into both graphs (i == nframes: EOF, which flushes a partial batch of the queued filters), then whatever has come out */
+        for (int k = 0; k < 2; k++) {
+            Graph *G = k ? &cpu : &gpu;
+            AVFrame *in = i < nframes ? make_frame(w, h, fmt, seed + 977u * i, i) : NULL;
+            if (i < nframes && !in)
+                return 2;
+            CK(av_buffersrc_add_frame_flags(G->src, in, AV_BUFFERSRC_FLAG_PUSH));
+            av_frame_free(&in);
+            for (;;) {
+                AVFrame *out = av_frame_alloc();
+                int r = av_buffersink_get_frame(G->sink, out);
+                if (r == AVERROR(EAGAIN) || r == AVERROR_EOF) { av_frame_free(&out); break; }
+                CK(r);
+                if ((k ? nc : ng) >= 64) return 2;
+                if (k) outs_cpu[nc++] = out; else outs_gpu[ng++] = out;
+            }
+        }
+    }
+    if (ng != nframes || nc != nframes) {
+        fprintf(stderr, "%d frames in, %d out of the gpu graph, %d out of the cpu graph\n", nframes, ng, nc);
+        return 3;
+    }
+    for (int i = 0; i < nframes; i++) {
+        if (outs_gpu[i]->pts != outs_cpu[i]->pts) { fprintf(stderr, "frame %d: pts %ld against %ld\n", i, (long)outs_gpu[i]->pts, (long)outs_cpu[i]->pts); bad++; }
+        bad += compare(outs_gpu[i], outs_cpu[i], i);
+        got++;
+    }
+    printf("%s %dx%d x%d  [%s]  ==  [%s]  ->  %s %dx%d: %ld mismatching bytes\n", argv[3], w, h, nframes, argv[5], argv[6],
+           av_get_pix_fmt_name(outs_gpu[0]->format), outs_gpu[0]->width, outs_gpu[0]->height, bad);
+    for (int i = 0; i < nframes; i++) { av_frame_free(&outs_gpu[i]); av_frame_free(&outs_cpu[i]); }
+    avfilter_graph_free(&gpu.g);
+    avfilter_graph_free(&cpu.g);
+    av_buffer_unref(&device);
+    return bad ? 4 : (got == nframes ? 0 : 3);
+}

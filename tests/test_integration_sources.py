@@ -26,7 +26,7 @@ def test_integration_source_type_checks(name):
 def test_integration_sources_call_only_exported_abi():
     from gmat_amd.lib import ABI_SYMBOLS
     used = set()
-    for name in SRC:
+    for name in SRC + ["hwcontext_hip.c"]:
         used |= set(re.findall(r"\b(gmat_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "integration", name)).read()))
     assert used and used <= set(ABI_SYMBOLS), sorted(used - set(ABI_SYMBOLS))
     so = os.path.join(ROOT, "gmat_amd", "lib", "libgmat_hip.so")
@@ -74,13 +74,15 @@ def ref_headers(tmp_path_factory):
     return str(d), str(shim)
 
 
-@pytest.mark.parametrize("name", SRC)
+@pytest.mark.parametrize("name", SRC + ["hwcontext_hip.c"])
 def test_integration_source_compiles_against_the_reference_headers(ref_headers, name):
     """vf_gmat_hip.c used DBL_MAX / FLT_MAX without <float.h> and only the compat headers (whose
     common.h happened to include it) ever saw the file.  The three sources against the real libav* headers."""
     cfg, shim = ref_headers
     inc = ["-I" + cfg, "-I" + REF, "-I" + shim, "-I" + os.path.join(ROOT, "include")]
-    if name != "swscale_hip_adapter.c":
+    if name == "hwcontext_hip.c":
+        inc.append("-I" + os.path.join(REF, "libavutil"))                     # a libavutil source: "hwcontext_internal.h" ... like hwcontext_cuda.c (tests/test_libavfilter_core.py links and RUNS it)
+    elif name != "swscale_hip_adapter.c":
         inc.append("-I" + os.path.join(REF, "libavfilter"))                   # the filters include "avfilter.h" ... like the reference's do
     cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
            "-Werror=int-conversion", "-DHAVE_AV_CONFIG_H", "-D_ISOC11_SOURCE", "-D_DEFAULT_SOURCE"] + inc + [os.path.join(ROOT, "integration", name)]
