@@ -25,7 +25,7 @@ using namespace gmat;
 namespace {
 
 enum Mode { MODE_YUV2RGB, MODE_RGBPF32, MODE_SWAP_RB, MODE_COPY, MODE_SCALE, MODE_RGB2YUV, MODE_YUV2YUV, MODE_DEPTH, MODE_FROM_PF32,
-            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER, MODE_SCALE16, MODE_VIA_PLANES16, MODE_PLANE_UP };
+            MODE_RGB2YUV444, MODE_REPACK, MODE_PLANECOPY, MODE_VIA_INNER, MODE_SCALE16, MODE_VIA_PLANES16, MODE_PLANE_UP, MODE_PLANE_DOWN };
 
 struct DevBuf {
     void *p = nullptr;
@@ -107,6 +107,7 @@ struct GmatSwsContext {
     int colorspace = GMAT_SWS_CS_DEFAULT, srcFullRange = 0;
     int chrPos[4] = {-513, -513, -513, -513};   // src_h / src_v / dst_h / dst_v chroma positions (options.c:67-70)
     int rangeConv = 0;            // YUV -> YUV: 1 limited->full (lum/chrRangeToJpeg), 2 full->limited
+    bool planeDownFull = false;   // MODE_PLANE_DOWN with both ranges full: the luma's (v - (v >> 8) + d) >> shift
     Yuv2RgbConsts y2r;            // for the same-size converter (honours colourspace / range)
     // scaler
     ScalePlan plan;               // always an RGB24 -> dst plan (the YUV source is converted in front)
@@ -494,6 +495,8 @@ static int prep_yuv_args(const GmatSwsContext *c, const uint8_t *const src[], co
     ya.y2r = c->rgbViaPlanes ? make_yuv2rgb_consts(GMAT_SWS_CS_DEFAULT, false) : make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
     ya.prof = c->prof;
     ya.rangeConv = c->rangeConv;
+    // swscale.c:263-264, 482-485 (should_dither): 8-bit planar output of a source deeper than 8 bits is dithered with ff_dither_8x8_128
+    ya.dither8 = is_yuv8_src(c->dstFormat) && c->srcFormat != GMAT_PIX_FMT_PRIV_RGB8_PLANES && (is_p01x(c->srcFormat) || pl16_depth(c->srcFormat) != 0);
     return 0;
 }
 
@@ -641,7 +644,7 @@ static Yuv2pArgs make_yuv2p_args(const GmatSwsContext *c, const YuvScaleArgs &ya
     pa.ys = ya.ys; pa.us = ya.us; pa.vs = ya.vs;
     pa.nv12 = ya.nv12 || c->srcFormat == GMAT_PIX_FMT_P010LE;   // interleaved chroma on the SOURCE side
     pa.cross = c->y2p.cross;                                     // ... and the other layout on the destination's
-    pa.srcDepth = c->y2p.srcDepth; pa.dstDepth = c->y2p.dstDepth;
+    pa.srcDepth = c->y2p.srcDepth; pa.dstDepth = c->y2p.dstDepth; pa.dither8 = ya.dither8;
     pa.srcW = ya.srcW; pa.srcH = ya.srcH; pa.chrSrcW = ya.chrSrcW; pa.chrSrcH = ya.chrSrcH;
     pa.dstW = ya.dstW; pa.dstH = ya.dstH; pa.chrDstW = ya.chrDstW; pa.chrDstH = ya.chrDstH;
     pa.ds = ya.ds; pa.dsU = ya.dsU; pa.dsV = ya.dsV;
@@ -1647,6 +1650,11 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
         c->mode = MODE_PLANECOPY;            // equal format and size: libswscale copies the planes verbatim
     } else if (same && pl16_depth(srcFormat) && dstFormat == srcFormat) {
         c->mode = MODE_PLANECOPY;
+    } else if (same && ((pl16_depth(srcFormat) && !is_priv_planes(srcFormat) && srcFormat != GMAT_PIX_FMT_YUV444P16LE && dstFormat == GMAT_PIX_FMT_YUV420P) ||
+                        (srcFormat == GMAT_PIX_FMT_YUV444P16LE && dstFormat == GMAT_PIX_FMT_YUV444P))) {
+        // equal size, a deeper planar format into the 8-bit one of the SAME layout: planarCopyWrapper with its own dither tables
+        // (swscale_unscaled.c:1743-1800, 2293-2309) while the two ranges agree; gmat_sws_setRange moves it onto the generic lines when they do not
+        c->mode = MODE_PLANE_DOWN;
     } else if (is_plane_src(srcFormat) && is_dst16(dstFormat)) {
         // 16-bit destination: 19-bit intermediates, the two-pass path of k_scale16.hip (equal-size 8-bit 4:2:0 sources were
         // taken above as the depth expansion, equal format as the plane copy)
@@ -1759,6 +1767,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
         return (srcFullRange || dstFullRange) ? GMAT_ERR(ENOSYS) : 0;
     }
     const int conv = (!!srcFullRange == !!dstFullRange) ? 0 : (dstFullRange ? 1 : 2);
+    if (c->unscaledMode == MODE_PLANE_DOWN) c->planeDownFull = srcFullRange && dstFullRange;     // planarCopyWrapper's luma rule follows srcRange
     if (conv == c->rangeConv) return 0;
     if (c->cross) { gmat_sws_freeContext(c->cross); c->cross = nullptr; }
     // a same-size context is a plane copy / depth expansion only while the ranges agree (utils.c:1996-2000: the
@@ -1766,9 +1775,9 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     // lines carry the conversion (8-bit 4:2:0 and P010LE destinations: lum / chrRange{To,From}Jpeg_c on the 15-bit lines; 16-bit
     // destinations: their ...16_c twins on the 19-bit lines, swscale.c:189-226).
     const bool same = c->srcW == c->dstW && c->srcH == c->dstH;
-    const bool special = same && (c->unscaledMode == MODE_YUV2YUV || c->unscaledMode == MODE_DEPTH || c->unscaledMode == MODE_PLANECOPY);
+    const bool special = same && (c->unscaledMode == MODE_YUV2YUV || c->unscaledMode == MODE_DEPTH || c->unscaledMode == MODE_PLANECOPY || c->unscaledMode == MODE_PLANE_DOWN);
     if (special) {
-        const bool generic15 = is_yuv420(c->dstFormat) || is_dst10(c->dstFormat);
+        const bool generic15 = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
         c->rangeConv = conv;
         if (conv && !generic15) { c->mode = MODE_SCALE16; return init_scale16(c); }       // 16-bit destination: the 19-bit lines
         if (conv) { c->mode = MODE_SCALE; c->fused = 2; return ensure_scaler(c); }
@@ -2017,6 +2026,18 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         c->lastKernel = "plane_copy_up_kernel";
         if ((r = launch_plane_copy_up(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, depth, 1, c->stream)) < 0) break;
         for (int i = 1; i < 3 && r >= 0; i++) r = launch_plane_copy_up(src[i], srcStride[i], dst[i], dstStride[i], cw, ch, depth, 0, c->stream);
+        break;
+    }
+    case MODE_PLANE_DOWN: {
+        if (!src[1] || !src[2] || !dst[1] || !dst[2]) { r = GMAT_ERR(EINVAL); break; }
+        for (int i = 0; i < 3; i++)
+            if ((((uintptr_t)src[i] | (uintptr_t)srcStride[i]) & 1) != 0) r = GMAT_ERR(EINVAL);
+        if (r < 0) break;
+        const int depth = pl16_depth(c->srcFormat), sub = c->srcFormat == GMAT_PIX_FMT_YUV444P16LE ? 0 : 1;
+        const int cw = ceil_rshift(c->srcW, sub), ch = ceil_rshift(c->srcH, sub);
+        c->lastKernel = "plane_copy_down_kernel";
+        if ((r = launch_plane_copy_down(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, depth, c->planeDownFull ? 0 : 1, c->stream)) < 0) break;
+        for (int i = 1; i < 3 && r >= 0; i++) r = launch_plane_copy_down(src[i], srcStride[i], dst[i], dstStride[i], cw, ch, depth, 1, c->stream);
         break;
     }
     case MODE_PLANECOPY: {

@@ -873,6 +873,35 @@ __global__ __launch_bounds__(256) void plane_copy_up_kernel(const uint8_t *src, 
     }
 }
 
+// planarCopyWrapper's deeper -> 8-bit planar copy (swscale_unscaled.c:1743-1800, DITHER_COPY), one plane: shift = depth - 8 and
+// d = dithers[shift - 1][y & 7][x & 7] (:40-113) — shift 2: 1 2 / 3 0 alternating, shift 8: ff_dither_8x8_128's values (dither_8x8_128).
+// shiftonly (chroma, luma of a limited-range source): t = (v + d) >> shift, t - (t >> 8); else (v - (v >> 8) + d) >> shift.  Four samples a thread.
+__global__ __launch_bounds__(256) void plane_copy_down_kernel(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int shiftonly)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const unsigned short *s = reinterpret_cast<const unsigned short *>(src + (size_t)y * ss) + x;
+    uint8_t *d = dst + (size_t)y * ds + x;
+    const int shift = depth - 8;
+    for (int i = 0; i < min(4, w - x); i++) {
+        const unsigned v = s[i];
+        const unsigned dith = shift == 2 ? (unsigned)(((y & 1) ? 3 : 1) ^ (((x + i) & 1) ? 3 : 0)) : (unsigned)dither_8x8_128(x + i, y);
+        unsigned t;
+        if (shiftonly) { t = (v + dith) >> shift; t -= t >> 8; }
+        else           { t = (v - (v >> 8) + dith) >> shift; }
+        d[i] = (uint8_t)t;
+    }
+}
+
+int launch_plane_copy_down(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int shiftonly, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid((w + 1023) / 1024, h), block(256);
+    hipLaunchKernelGGL(plane_copy_down_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, depth, shiftonly);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return 0;

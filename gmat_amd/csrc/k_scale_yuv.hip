@@ -509,7 +509,11 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                     else for (int i = 0; i < nx; i++) d16[i] = (unsigned short)w[i];
                     continue;
                 }
-                // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
+                // yuv2planeX_8_c: clip_u8((dither << 12 + sum) >> 19); lr holds the 64 << 12 of an 8-bit source
+                if (a.dither8) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) Y[i] += dither_delta(xo + i, yo);
+                }
                 uint8_t *d = a.dst + (size_t)yo * a.ds + xo;
                 const unsigned o = (unsigned)clip_u8_shr(Y[0], 19) | ((unsigned)clip_u8_shr(Y[1], 19) << 8) |
                                    ((unsigned)clip_u8_shr(Y[2], 19) << 16) | ((unsigned)clip_u8_shr(Y[3], 19) << 24);
@@ -626,6 +630,10 @@ __global__ __launch_bounds__(256) void scale_yuv_kernel(YuvScaleArgs a, Yuv2xFra
                 continue;
             }
             unsigned ub[4], vb[4];
+            if (a.dither8) {                                        // chrDither8 = row chrDstY & 7; V three columns on (vscale.c:98,101, output.c:433-434)
+#pragma unroll
+                for (int i = 0; i < 4; i++) { U[i] += dither_delta(cx + i, cy); V[i] += dither_delta(cx + i + 3, cy); }
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) { ub[i] = (unsigned)clip_u8_shr(U[i], 19); vb[i] = (unsigned)clip_u8_shr(V[i], 19); }
             if (a.dstNv12) {

@@ -71,21 +71,30 @@ struct P2Plane {
     // itself never knows: it walks the vertically mirrored plane downward — row r stands for row srcH - 1 - r (dstH - 1 - r), the
     // row pair (2m - 1, 2m) is the mirrored pair H/2 - m with its halves swapped, so `v` holds the pairs reversed and swapped.
     int dstH, up;
+    int dither;                                // 8-bit out of a deeper source (S16 && !D16): 0 the constant in rnd, 1 this plane's own columns (luma, U),
+                                               // 2 three columns on (V), 3 interleaved U0 V0 U1 V1 (U: its column, V: three on) — dither_8x8_128
     __device__ __forceinline__ int srow(int r) const { return up ? srcH - 1 - r : r; }
     __device__ __forceinline__ int drow(int r) const { return up ? dstH - 1 - r : r; }
 };
+// value q of a lane's four (single plane: samples x + q; interleaved: U(x), V(x), U(x + 1), V(x + 1)) on destination row y
+__device__ __forceinline__ int p2_dither(int mode, int x, int y, int q)
+{
+    const int col = mode == 3 ? x + (q >> 1) + 3 * (q & 1) : x + q + (mode == 2 ? 3 : 0);
+    return dither_delta(col, y);
+}
 
 __device__ __forceinline__ unsigned p2_ld4(const uint8_t *p) { return *reinterpret_cast<const unsigned *>(p); }
 
 // vertical stage of 4 values + store: D16 ? 8 bytes (4 x 16 bit) : 4 bytes.  Slot SLOT holds the newest row pair, the
 // oldest is SLOT + 1 (mod NP).
-template <bool D16, int NP, int SLOT, bool STREAM = true>
-__device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][4], bool active, unsigned byteOff)
+template <bool D16, int NP, int SLOT, bool STREAM = true, bool DITH = false>
+__device__ __forceinline__ void p2_vstore(const P2Plane &P, const int (&hw)[NP][4], bool active, unsigned byteOff, int x = 0, int y = 0)
 {
     unsigned w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         int acc = P.rnd;
+        if constexpr (DITH) { if (P.dither) acc += p2_dither(P.dither, x, y, q); }
 #pragma unroll
         for (int k = 0; k < NP; k++) acc = p2_dot2(hw[(SLOT + 1 + k) % NP][q], P.v[k], acc);
         if (D16) {
@@ -248,7 +257,7 @@ __device__ __forceinline__ void p2_walk_plane(const P2Plane &P, int X0, int y0, 
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);
-            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo));
+            p2_vstore<D16, NP, SLOT, true, S16 && !D16>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 2u : 1u) * (unsigned)xo), xo, P.drow(yo));
         }
     };
     {
@@ -398,7 +407,7 @@ __device__ __forceinline__ void p2_walk_uv(const P2Plane &P, int X0, int y0, int
         }
         if (j >= NP - 1) {
             const int yo = y0 + j - (NP - 1);                   // yuv2nv12cX_c / yuv2p010cX_c: U0 V0 U1 V1
-            p2_vstore<D16, NP, SLOT>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co));
+            p2_vstore<D16, NP, SLOT, true, S16 && !D16>(P, hw, active, (unsigned)((unsigned)P.drow(yo) * (unsigned)P.ds + (D16 ? 4u : 2u) * (unsigned)co), co, P.drow(yo));
         }
     };
     {
@@ -504,6 +513,7 @@ struct P2Cross {
     const int32_t *h, *v;
     int rnd, srcHi6, dstHi6;
     int dstH, up;                                               // see P2Plane
+    int dither;                                                 // != 0: U0 V0 U1 V1 dithered (P2Plane::dither mode 3)
     __device__ __forceinline__ int srow(int r) const { return up ? srcH - 1 - r : r; }
     __device__ __forceinline__ int drow(int r) const { return up ? dstH - 1 - r : r; }
 };
@@ -657,6 +667,7 @@ __device__ __forceinline__ void p2_walk_uvx(const P2Cross &P, int X0, int y0, in
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int acc = P.rnd;
+                if constexpr (S16 && !D16) { if (P.dither) acc += p2_dither(3, co, P.drow(yo), q); }
 #pragma unroll
                 for (int k = 0; k < NP; k++) acc = p2_dot2(hw[(SLOT + 1 + k) % NP][q], P.v[k], acc);
                 if (D16) { w[q] = (unsigned)min(max(acc, 0), (1024 << 17) - 1) >> 17; if (P.dstHi6) w[q] <<= 6; }
@@ -700,7 +711,7 @@ __global__ __launch_bounds__(256) void scale_yuv2px_kernel(Yuv2pArgs a, Yuv2xFra
         const int X0 = ((lin - seg * a.nsgL) * 4 + wave) * P2_STRIP;
         if (X0 >= a.dstW) return;
         const int y0 = seg * a.segRowsL, n = min(a.segRowsL, a.dstH - y0), up = a.updown & seg & 1;
-        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up};
+        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up, a.dither8 ? 1 : 0};
         p2_walk_plane<S16, D16, NP>(P, X0, up ? a.dstH - (y0 + n) : y0, n, lane);
         return;
     }
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(256) void scale_yuv2px_kernel(Yuv2pArgs a, Yuv2xFra
     if (X0 >= a.chrDstW) return;
     const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
     const P2Cross P = {fr.u[f], fr.v[f], fr.dstU[f], fr.dstV[f], a.us, a.vs, a.dsU, a.dsV, a.chrSrcW, a.chrSrcH, a.chrDstW,
-                       a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up};
+                       a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up, a.dither8};
     p2_walk_uvx<S16, D16, NP, !SNV>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
 }
 
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int X0 = ((lin - seg * a.nsgL) * 4 + wave) * P2_STRIP;
         if (X0 >= a.dstW) return;
         const int y0 = seg * a.segRowsL, n = min(a.segRowsL, a.dstH - y0), up = a.updown & seg & 1;
-        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up};
+        const P2Plane P = {fr.y[f], fr.dst[f], a.ys, a.ds, a.srcW, a.srcH, a.dstW, a.hL, up ? a.vLup : a.vL, a.lr, sHi, dHi, a.dstH, up, a.dither8 ? 1 : 0};
         p2_walk_plane<S16, D16, NP>(P, X0, up ? a.dstH - (y0 + n) : y0, n, lane);
         return;
     }
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         const int X0 = ((lin - seg * a.nsgC) * 4 + wave) * (UVD ? P2_STRIP_UVD : P2_STRIP_UV);
         if (X0 >= a.chrDstW) return;
         const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
-        const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up};
+        const P2Plane P = {fr.u[f], fr.dstU[f], a.us, a.dsU, a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, sHi, dHi, a.chrDstH, up, a.dither8 ? 3 : 0};
         if constexpr (UVD) p2_walk_uvd<D16>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
         else               p2_walk_uv<S16, D16, NP>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
     } else {
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(256) void scale_yuv2p_kernel(Yuv2pArgs a, Yuv2xFram
         if (X0 >= a.chrDstW) return;
         const int y0 = seg * a.segRowsC, n = min(a.segRowsC, a.chrDstH - y0), up = a.updown & seg & 1;
         const P2Plane P = {pl ? fr.v[f] : fr.u[f], pl ? fr.dstV[f] : fr.dstU[f], pl ? a.vs : a.us, pl ? a.dsV : a.dsU,
-                           a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, 0, 0, a.chrDstH, up};
+                           a.chrSrcW, a.chrSrcH, a.chrDstW, a.hC, up ? a.vCup : a.vC, a.cr, 0, 0, a.chrDstH, up, a.dither8 ? (pl ? 2 : 1) : 0};
         p2_walk_plane<S16, D16, NP>(P, X0, up ? a.chrDstH - (y0 + n) : y0, n, lane);
     }
 }

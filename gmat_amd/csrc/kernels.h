@@ -109,6 +109,7 @@ struct YuvScaleArgs {
     int ys, us, vs, nv12, srcAligned;
     int srcAligned16;                             // luma and NV12 chroma rows 16-byte, planar chroma rows 8-byte aligned
     int rangeConv;                                // YUV out: 0 none, 1 limited -> full range, 2 full -> limited (swscale.c:157-188)
+    int dither8;                                  // 8-bit YUV out of a source deeper than 8 bits: ff_dither_8x8_128 instead of the constant 64 (px_math.h dither_8x8_128)
     int rgbBgr, chrHalf;                          // src16 == 3: packed RGB24 / BGR24 source (y = pixels); rgbBgr: BGR order;
     Rgb2YuvConsts r2y;                            // chrHalf: chroma from pixel pairs (rgb24ToUV_half_c); rgb24ToY_c constants
     int src16, hShift, hBias;                     // P010LE / P016LE source: 10 / 16 (0 = 8-bit); hScale16To15_c's shift
@@ -232,6 +233,7 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
 // (a, b) sample pairs interleaved
 // one plane of planarCopyWrapper's 8 -> `depth` bit copy; replicate: the luma of a full-range source (swscale_unscaled.c:1844-1862)
 int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream);
+int launch_plane_copy_down(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int shiftonly, hipStream_t stream);
 // NV12 <-> YUV420P in one launch (luma copy + chroma (de)interleave, streaming both ways; frames: grid.z) where every plane moves in 16 / 8 bytes
 bool yuv420_relayout_takes(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
                            const uint8_t *dy, int dys, const uint8_t *d0, int ds0, const uint8_t *d1, int ds1);
@@ -406,6 +408,7 @@ struct Yuv2pArgs {
     int np;                                      // coefficient pairs per filter (4 | 6)
     int32_t hL[6], hC[6], vL[6], vC[6];
     int lr, cr;
+    int dither8;                                 // see YuvScaleArgs::dither8 (the <10to8> instances only)
     // filled by the launcher: rows per strip segment, segments and groups of 4 strips per plane kind, workgroup counts
     int segRowsL, nsegL, nsgL, segRowsC, nsegC, nsgC, nblkL, nblk, xcdRemap;
     int updown; int32_t vLup[6], vCup[6];        // odd segments walk upward: the vertical pairs of the mirrored plane

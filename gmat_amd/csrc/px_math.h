@@ -20,6 +20,16 @@ __device__ __forceinline__ int clip_u8(int v) { return min(max(v, 0), 255); }   
 // output dword on hardware while the CPU emulation of the same source (plain C++ semantics) was bit-exact.
 // tests/test_isa_guard.py disassembles the shipped library and fails on any v_ashr_pk_*.
 __device__ __forceinline__ int clip_u8_shr(int v, int s) { return min(max(v, 0), (256 << s) - 1) >> s; }
+// ff_dither_8x8_128[y & 7][x & 7] (swscale.c:36-46), the ordered dither libswscale gives 8-bit planar output when the SOURCE has more than
+// 8 bits (should_dither, swscale.c:263-264, 482-485; 8-bit sources: the constant 64).  The table is affine over GF(2): 36 with x0 flipping
+// 0x60, x1 0x18, x2 0x06, y0 0x40, y1 0x10, y2 0x04 — no memory (tests/test_parity_dither.py holds it against the table itself).
+__host__ __device__ __forceinline__ int dither_8x8_128(int x, int y)
+{
+    return 36 ^ ((x & 1) * 0x60) ^ ((x & 2) * 0xC) ^ ((x & 4) + ((x & 4) >> 1)) ^ ((y & 1) * 0x40) ^ ((y & 2) * 8) ^ (y & 4);
+}
+// what the dither adds to a vertical accumulator that started at 64 << 12 (yuv2planeX_8_c / yuv2nv12cX_c: dither << 12)
+__host__ __device__ __forceinline__ int dither_delta(int x, int y) { return (dither_8x8_128(x, y) - 64) << 12; }
+
 
 // Streaming stores: a destination frame is written once and not read again by the launch; `nt` keeps its lines from displacing the
 // source rows that neighbouring bands still share in the L2.  It pays where a wave writes WHOLE lines and costs where tiles of

@@ -22,6 +22,7 @@ enum AVPixelFormat {
     AV_PIX_FMT_NONE = -1, AV_PIX_FMT_YUV420P = 0, AV_PIX_FMT_RGB24 = 2, AV_PIX_FMT_BGR24 = 3, AV_PIX_FMT_YUV444P = 5,
     AV_PIX_FMT_NV12 = 23, AV_PIX_FMT_RGBA = 26, AV_PIX_FMT_BGRA = 28, AV_PIX_FMT_YUV444P16 = 49, AV_PIX_FMT_CUDA = 117,
     AV_PIX_FMT_0BGR32 = 119, AV_PIX_FMT_0RGB32 = 121, AV_PIX_FMT_P010 = 159, AV_PIX_FMT_P016 = 170,
+    AV_PIX_FMT_YUV420P16 = 45, AV_PIX_FMT_YUV420P10 = 62, AV_PIX_FMT_RGBA64 = 105, AV_PIX_FMT_BGRA64 = 107, AV_PIX_FMT_RGBPF32LE = 179,
 };
 enum AVColorSpace { AVCOL_SPC_UNSPECIFIED = 2 };
 typedef struct AVClass AVClass;

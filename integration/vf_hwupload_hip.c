@@ -59,8 +59,12 @@ static av_cold void hipupload_uninit(AVFilterContext *ctx)
 static int hipupload_query_formats(AVFilterContext *ctx)
 {
     static const enum AVPixelFormat in_fmts[] = {
+        /* vf_hwupload_cuda.c:59-67's list + the packed RGB the nvcv filters take (defect 10) + the planar 10 / 16-bit and
+         * 64-bit RGB formats libgpuscale lists (swscale_cuda.c:34-44): everything integration/hwcontext_hip.c pools */
         AV_PIX_FMT_NV12, AV_PIX_FMT_YUV420P, AV_PIX_FMT_YUV444P, AV_PIX_FMT_P010, AV_PIX_FMT_P016, AV_PIX_FMT_YUV444P16,
-        AV_PIX_FMT_RGB24, AV_PIX_FMT_BGR24, AV_PIX_FMT_RGBA, AV_PIX_FMT_BGRA, AV_PIX_FMT_0RGB32, AV_PIX_FMT_0BGR32, AV_PIX_FMT_NONE,
+        AV_PIX_FMT_YUV420P10, AV_PIX_FMT_YUV420P16,
+        AV_PIX_FMT_RGB24, AV_PIX_FMT_BGR24, AV_PIX_FMT_RGBA, AV_PIX_FMT_BGRA, AV_PIX_FMT_0RGB32, AV_PIX_FMT_0BGR32,
+        AV_PIX_FMT_RGBA64, AV_PIX_FMT_BGRA64, AV_PIX_FMT_RGBPF32LE, AV_PIX_FMT_NONE,
     };
     static const enum AVPixelFormat out_fmts[] = { AV_PIX_FMT_CUDA, AV_PIX_FMT_NONE };
     int ret = ff_formats_ref(ff_make_format_list((const int *)in_fmts), &ctx->inputs[0]->outcfg.formats);

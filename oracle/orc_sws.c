@@ -35,6 +35,7 @@
 
 struct OrcSws {
     int src_w, src_h, dst_w, dst_h, src_fmt, dst_fmt, flags;
+    int src_full_range;                       /* planarCopyWrapper's luma rule (orc_sws_scale) */
     int chr_src_hsub, chr_src_vsub, chr_dst_hsub, chr_dst_vsub;
     int chr_src_w, chr_src_h, chr_dst_w, chr_dst_h;
     int lum_x_inc, lum_y_inc, chr_x_inc, chr_y_inc;
@@ -53,6 +54,7 @@ struct OrcSws {
 
 static int is_rgb(int f)  { return f == ORC_PIX_RGB24 || f == ORC_PIX_BGR24 || f == ORC_PIX_RGBA || f == ORC_PIX_BGRA; }
 static int is_p01x(int f) { return f == ORC_PIX_P010LE || f == ORC_PIX_P016LE; }
+void orc_plane_copy_down(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int depth, int shiftonly);   /* orc_vf.c */
 static int is_rgb64(int f) { return f == ORC_PIX_RGBA64LE || f == ORC_PIX_BGRA64LE; }
 static int has_alpha(int f) { return f == ORC_PIX_RGBA || f == ORC_PIX_BGRA || is_rgb64(f); }
 static int is_dst16(int f) { return f == ORC_PIX_P016LE || f == ORC_PIX_YUV444P16LE || f == ORC_PIX_YUV420P16LE || is_rgb64(f); }   /* 19-bit lines */
@@ -178,6 +180,7 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
 
     c->chr_src_hsub = c->chr_src_vsub = fmt_sub(src_fmt);
     c->chr_dst_hsub = c->chr_dst_vsub = fmt_sub(dst_fmt);
+    c->src_full_range = src_range;
     if (src_range != dst_range) {
         /* RGB ends have their range forced to 0 (utils.c:902-1030): an RGB source with a full-range YUV destination
          * is the limited -> full conversion of the 15-bit lines */
@@ -676,19 +679,33 @@ static void out_packed_row(const OrcSws *c, uint8_t *dest, int dst_y,
     }
 }
 
+/* swscale.c:36-46: the ordered dither of 8-bit planar output for sources deeper than 8 bits (row 8 repeats row 0 and is never indexed here) */
+static const uint8_t orc_dither_8x8_128[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 },
+    {  52, 84,  44, 76,  50, 82,  42, 74 }, { 116, 20, 108, 12, 114, 18, 106, 10 },
+    {  32, 64,  56, 88,  38, 70,  62, 94 }, {  96,  0, 120, 24, 102,  6, 126, 30 },
+    {  48, 80,  40, 72,  54, 86,  46, 78 }, { 112, 16, 104,  8, 118, 22, 110, 14 },
+};
+static const uint8_t orc_pb_64[8] = { 64, 64, 64, 64, 64, 64, 64, 64 };     /* sws_pb_64, swscale.c:48-50 */
+
+/* swscale.c:263-264, 349-351, 482-485: should_dither = isNBPS(src) || is16BPS(src) — a source of 9 .. 16 bits (P010 / P016, planar 10 / 16 bit,
+ * RGBA64 / BGRA64) dithers its 8-bit planar output with row dstY & 7 (luma) / chrDstY & 7 (chroma) of the table; an 8-bit source uses the constant 64.
+ * Round 4: rounds 1-3 used 64 for every source — found by running the reference's real libswscale core (tests/fuzz/fuzz_ref_core.py). */
+static int should_dither(const OrcSws *c) { return is_p01x(c->src_fmt) || pl16_depth(c->src_fmt) != 0 || is_rgb64(c->src_fmt); }
+static const uint8_t *dither_row(const OrcSws *c, int y) { return should_dither(c) ? orc_dither_8x8_128[y & 7] : orc_pb_64; }
+
 static void out_plane_row(uint8_t *dest, int w, const int16_t *filter, int fs,
-                          const int16_t *const *src, int offset)
+                          const int16_t *const *src, const uint8_t *dither, int offset)
 {
-    /* lum_planar_vscale / chr_planar_vscale, vscale.c:30-105: 1 tap -> yuv2plane1, else yuv2planeX;
-     * dither is the constant 64 (sws_pb_64) for 8-bit sources, swscale.c:349-351 */
+    /* lum_planar_vscale / chr_planar_vscale, vscale.c:30-105: 1 tap -> yuv2plane1_8_c (output.c:415-423), else yuv2planeX_8_c (:400-413);
+     * the V plane's dither is offset by 3 (vscale.c:98,101) */
     int i, j;
-    (void)offset;
     if (fs == 1) {
         for (i = 0; i < w; i++)
-            dest[i] = (uint8_t)clip_u8((src[0][i] + 64) >> 7);
+            dest[i] = (uint8_t)clip_u8((src[0][i] + dither[(i + offset) & 7]) >> 7);
     } else {
         for (i = 0; i < w; i++) {
-            int val = 64 << 12;
+            int val = dither[(i + offset) & 7] << 12;
             for (j = 0; j < fs; j++)
                 val += src[j][i] * filter[j];
             dest[i] = (uint8_t)clip_u8(val >> 19);
@@ -697,12 +714,12 @@ static void out_plane_row(uint8_t *dest, int w, const int16_t *filter, int fs,
 }
 
 static void out_nv12_chroma_row(uint8_t *dest, int w, const int16_t *filter, int fs,
-                                const int16_t *const *su, const int16_t *const *sv)
+                                const int16_t *const *su, const int16_t *const *sv, const uint8_t *dither)
 {
-    /* yuv2nv12cX_c, output.c:411-430 — always the X form, also for one tap (vscale.c:83-85) */
+    /* yuv2nv12cX_c, output.c:425-458 — always the X form, also for one tap (vscale.c:83-85) */
     int i, j;
     for (i = 0; i < w; i++) {
-        int u = 64 << 12, v = 64 << 12;
+        int u = dither[i & 7] << 12, v = dither[(i + 3) & 7] << 12;
         for (j = 0; j < fs; j++) {
             u += su[j][i] * filter[j];
             v += sv[j][i] * filter[j];
@@ -1116,14 +1133,14 @@ int orc_sws_scale_rows(OrcSws *c, const uint8_t *const src[4], const int src_str
                                     c->v_chr_size, up, vp);
         } else {
             out_plane_row(dst[0] + (long)y * dst_stride[0], dst_w, c->v_lum + y * c->v_lum_size,
-                          c->v_lum_size, lp, 0);
+                          c->v_lum_size, lp, dither_row(c, y), 0);
             if (!c->chr_dst_vsub || !(y & 1)) {
                 const int16_t *cf = c->v_chr + chr_y * c->v_chr_size;
                 if (c->dst_fmt == ORC_PIX_NV12) {
-                    out_nv12_chroma_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, vp);
+                    out_nv12_chroma_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, vp, dither_row(c, chr_y));
                 } else {
-                    out_plane_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, 0);
-                    out_plane_row(dst[2] + (long)chr_y * dst_stride[2], cdw, cf, c->v_chr_size, vp, 3);
+                    out_plane_row(dst[1] + (long)chr_y * dst_stride[1], cdw, cf, c->v_chr_size, up, dither_row(c, chr_y), 0);
+                    out_plane_row(dst[2] + (long)chr_y * dst_stride[2], cdw, cf, c->v_chr_size, vp, dither_row(c, chr_y), 3);
                 }
             }
         }
@@ -1140,6 +1157,19 @@ int orc_sws_scale(OrcSws *c, const uint8_t *const src[4], const int src_stride[4
 {
     /* bounded working set: process in bands of 64 output rows */
     int y, band = 64;
+    /* the one unscaled special converter a context of THIS entry point takes by itself (the others are the callers' choice: orc_plane_copy_up,
+     * orc_yuv420_to_p01x, orc_yuv2rgb): equal size, a deeper planar format into the 8-bit one of the same layout, ranges equal (utils.c:1996-2000,
+     * swscale_unscaled.c:2293-2309) -> planarCopyWrapper's dithered copy, luma rule by the source's range */
+    if (c->src_w == c->dst_w && c->src_h == c->dst_h && !c->range_conv &&
+        (((c->src_fmt == ORC_PIX_YUV420P10LE || c->src_fmt == ORC_PIX_YUV420P16LE) && c->dst_fmt == ORC_PIX_YUV420P) ||
+         (c->src_fmt == ORC_PIX_YUV444P16LE && c->dst_fmt == ORC_PIX_YUV444P))) {
+        const int depth = pl16_depth(c->src_fmt), sub = c->src_fmt == ORC_PIX_YUV444P16LE ? 0 : 1;
+        const int cw = (c->src_w + sub) >> sub, ch = (c->src_h + sub) >> sub;
+        orc_plane_copy_down(src[0], src_stride[0], dst[0], dst_stride[0], c->src_w, c->src_h, depth, !c->src_full_range);
+        orc_plane_copy_down(src[1], src_stride[1], dst[1], dst_stride[1], cw, ch, depth, 1);
+        orc_plane_copy_down(src[2], src_stride[2], dst[2], dst_stride[2], cw, ch, depth, 1);
+        return c->dst_h;
+    }
     if (c->dst_fmt == ORC_PIX_P016LE || is_pl16_dst(c->dst_fmt))
         return scale_to_p016(c, src, src_stride, dst, dst_stride);
     if (is_rgb64(c->dst_fmt))

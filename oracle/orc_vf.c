@@ -390,6 +390,33 @@ void orc_plane_copy_up(const uint8_t *src, int src_stride, uint8_t *dst, int dst
     }
 }
 
+/* planarCopyWrapper, a deeper planar format into the 8-bit one of the same layout (swscale_unscaled.c:1743-1800 DITHER_COPY, dithers :40-113):
+ * shift = depth - 8, d = dithers[shift - 1][row & 7][x & 7];  shiftonly (chroma planes, luma of a limited-range source):
+ * t = (v + d) >> shift, out = t - (t >> 8);  luma of a full-range source: out = (v - (v >> 8) + d) >> shift.  Only the two tables the
+ * served formats reach are restated: shift 2 (10 bits) and shift 8 (16 bits: the same values as ff_dither_8x8_128).  One plane per call;
+ * taken at equal size when the two ranges agree (utils.c:1996-2000, swscale_unscaled.c:2293-2309). */
+static const uint8_t orc_dithers_2[2][2] = { { 1, 2 }, { 3, 0 } };                         /* dithers[1]: rows / columns alternate */
+static const uint8_t orc_dithers_8[8][8] = {
+    {  36, 68,  60, 92,  34, 66,  58, 90 }, { 100,  4, 124, 28,  98,  2, 122, 26 }, {  52, 84,  44, 76,  50, 82,  42, 74 },
+    { 116, 20, 108, 12, 114, 18, 106, 10 }, {  32, 64,  56, 88,  38, 70,  62, 94 }, {  96,  0, 120, 24, 102,  6, 126, 30 },
+    {  48, 80,  40, 72,  54, 86,  46, 78 }, { 112, 16, 104,  8, 118, 22, 110, 14 },
+};
+void orc_plane_copy_down(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int w, int h, int depth, int shiftonly)
+{
+    const int shift = depth - 8;
+    int x, y;
+    for (y = 0; y < h; y++) {
+        const uint16_t *s = (const uint16_t *)(src + (long)y * src_stride);
+        uint8_t *d = dst + (long)y * dst_stride;
+        for (x = 0; x < w; x++) {
+            const unsigned dith = shift == 2 ? orc_dithers_2[y & 1][x & 1] : orc_dithers_8[y & 7][x & 7];
+            unsigned t;
+            if (shiftonly) { t = (s[x] + dith) >> shift; d[x] = (uint8_t)(t - (t >> 8)); }
+            else           { t = s[x]; d[x] = (uint8_t)((t - (t >> 8) + dith) >> shift); }
+        }
+    }
+}
+
 /* planar8ToP01xleWrapper, swscale_unscaled.c:286-324 */
 void orc_yuv420_to_p01x(const uint8_t *const src[4], const int src_stride[4], uint8_t *const dst[4],
                         const int dst_stride[4], int w, int h, int src_nv12)

@@ -58,6 +58,9 @@ static int build(Graph *G, const char *chain, int w, int h, enum AVPixelFormat f
     G->g = avfilter_graph_alloc();
     if (!G->g || !copy)
         return AVERROR(ENOMEM);
+    /* one thread: libswscale's slice threads give planarCopyWrapper's dither a phase per SLICE (the row counter of DITHER_COPY restarts in every
+     * slice, swscale_unscaled.c:1764-1765), so a 10 -> 8 bit copy depends on the thread count; the whole-frame result is the reference */
+    G->g->nb_threads = 1;
     snprintf(args, sizeof(args), "video_size=%dx%d:pix_fmt=%d:time_base=1/25:pixel_aspect=1/1", w, h, (int)fmt);
     CK(avfilter_graph_create_filter(&G->src, avfilter_get_by_name("buffer"), "in", args, NULL, G->g));
     last = G->src;
@@ -104,6 +107,13 @@ static AVFrame *make_frame(int w, int h, enum AVPixelFormat fmt, uint32_t seed, 
                 /* smooth-ish content with noise on top: gradients exercise the filters' rounding, noise their clipping */
                 f->data[p][(size_t)y * f->linesize[p] + x] = (uint8_t)(((x * 3 + y * 5) & 0xFF) / 2 + (s >> 25));
             }
+        if (d->comp[0].depth > 8 && d->comp[0].depth < 16)     /* valid input: `depth` significant bits where the format keeps them (P010: high, planar 10-bit: low) */
+            for (int y = 0; y < rows; y++)
+                for (int x = 0; x + 1 < bytes; x += 2) {
+                    uint8_t *q = f->data[p] + (size_t)y * f->linesize[p] + x;
+                    const unsigned v = (q[0] | q[1] << 8) >> (16 - d->comp[0].depth) << d->comp[0].shift;
+                    q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8);
+                }
     }
     return f;
 }

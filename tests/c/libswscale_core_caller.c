@@ -55,6 +55,11 @@ int main(int argc, char **argv)
         const long n = (long)ss[i] * plane_rows(sd, i, sh);
         hs[i] = malloc(n);
         fill_lcg(hs[i], n, seed + 17u * i);
+        if (sd->comp[0].depth > 8 && sd->comp[0].depth < 16)          /* valid input: `depth` significant bits where the format keeps them (P010: high, planar 10-bit: low) */
+            for (long k = 0; k + 1 < n; k += 2) {
+                const unsigned v = (hs[i][k] | hs[i][k + 1] << 8) >> (16 - sd->comp[0].depth) << sd->comp[0].shift;
+                hs[i][k] = (uint8_t)v; hs[i][k + 1] = (uint8_t)(v >> 8);
+            }
         CK(gmat_malloc(&gsrc[i], n)); CK(gmat_memcpy_h2d(gsrc[i], hs[i], n));
     }
     for (int i = 0; i < 4 && ds[i]; i++) {

@@ -65,6 +65,17 @@ CASES = [
     (320, 180, "rgb24", 2, "scale_hip=w=160:h=90:format=nv12", "scale=160:90:flags=bicubic", "nv12"),
     (320, 180, "nv12", 2, "format_hip=pix_fmt=yuv420p", "scale=flags=bicubic", "yuv420p"),                                            # re-layout
     (320, 180, "p010le", 2, "scale_hip=w=160:h=90", "scale=160:90:flags=bicubic", "p010le"),
+    # sources deeper than 8 bits into 8-bit planar frames: ff_dither_8x8_128 (round 4: found by this test's fuzzer, tests/test_parity_dither.py)
+    (640, 360, "p010le", 2, "scale_hip=w=320:h=180:format=nv12", "scale=320:180:flags=bicubic", "nv12"),                             # the 2:1 walker <10to8>
+    (640, 360, "yuv420p10le", 2, "scale_hip=w=320:h=180:format=yuv420p:interp_algo=lanczos", "scale=320:180:flags=lanczos", "yuv420p"),
+    (640, 360, "yuv420p10le", 2, "scale_hip=w=320:h=180:format=nv12", "scale=320:180:flags=bicubic", "nv12"),                        # ... and the other chroma layout
+    (320, 180, "p010le", 2, "scale_hip=w=212:h=120:format=yuv420p", "scale=212:120:flags=bicubic", "yuv420p"),
+    (320, 180, "p010le", 2, "scale_hip=format=nv12", "scale=flags=bicubic", "nv12"),                                                 # equal size, generic lines
+    (320, 180, "rgba64le", 2, "scale_hip=w=160:h=90:format=nv12", "scale=160:90:flags=bicubic", "nv12"),
+    (320, 180, "yuv444p16le", 2, "scale_hip=w=160:h=90:format=yuv420p", "scale=160:90:flags=bicubic", "yuv420p"),
+    (320, 180, "yuv420p10le", 2, "scale_hip=format=yuv420p", "scale=flags=bicubic", "yuv420p"),                                      # equal size AND layout: planarCopyWrapper's own tables
+    (321, 181, "yuv420p16le", 2, "scale_hip=format=yuv420p", "scale=flags=bicubic", "yuv420p"),
+    (321, 181, "yuv444p16le", 2, "scale_hip=format=yuv444p", "scale=flags=bicubic", "yuv444p"),
     (320, 180, "nv12", 6, "scale_hip=w=160:h=90:format=rgb24:batch=4", "scale=160:90:flags=bicubic", "rgb24"),                        # activate(): a full queue, then EOF flushes two
     (320, 180, "nv12", 3, "scale_hip=w=160:h=90,scale_hip=w=80:h=44:format=rgb24", "scale=160:90:flags=bicubic,scale=80:44:flags=bicubic", "rgb24"),   # frames contexts from filter to filter
     # the pixel filters (cfg4's operations), against the CPU filters SURVEY.md 8a row 14 names
@@ -103,7 +114,7 @@ def test_real_libavfilter_drives_the_gpu_filters(graph_caller, case):
     assert "0 mismatching bytes" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("fmt", ["nv12", "yuv420p", "rgb24", "bgra", "p010le", "yuv444p"])
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p", "rgb24", "bgra", "p010le", "yuv444p", "yuv420p10le", "rgba64le"])
 def test_libavfilters_own_hwupload_and_hwdownload_round_trip(graph_caller, fmt):
     """libavfilter's generic hwupload (vf_hwupload.c: the device from the application, av_hwframe_ctx_alloc / _init, av_hwframe_get_buffer,
     av_hwframe_transfer_data) and hwdownload over integration/hwcontext_hip.c alone: pool layout (YUV420P: V before U, chroma pitch = luma
