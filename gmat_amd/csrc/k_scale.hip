@@ -401,6 +401,9 @@ int scale_pick_tiling(const ScalePlan &p, ScaleTiling &t)
 {
     if (p.hLum.pairs > 64 || p.hChr.pairs > 64) return GMAT_ERR(ENOSYS);       // 128 taps
     if (p.chrDstW != p.dstW || p.chrDstH != p.dstH) return GMAT_ERR(ENOSYS);   // full-chroma output only
+    // the kernel walks ONE vertical bank for the three lines of a pixel: the chroma bank must be the luma bank (it is for every algorithm
+    // but SWS_BICUBLIN, whose chroma banks are bilinear: the plane scaler with its RGB loader takes those contexts)
+    if (p.vChr.taps != p.vLum.taps || p.vChr.count != p.vLum.count || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return GMAT_ERR(ENOSYS);
     const int half = p.chrSrcHSub;
     // identity chroma filter (one tap of 16384 at pos[i] == i): chroma needs no horizontal pass
     int direct = p.hChr.taps == 1 && p.hChr.pairs == 1;

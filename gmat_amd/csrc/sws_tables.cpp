@@ -140,6 +140,12 @@ int64_t kernel_weight(int flags, const double param[2], int64_t d, int inc, int6
         }
         return w / ((1LL << 54) / fone);
     }
+    if (flags & GMAT_SWS_X) {                                     // "experimental", utils.c:497-508: a raised-cosine lobe, sharpened by param[0]
+        const double A = p0 ? param[0] : 1.0;
+        double c = fd < 1.0 ? std::cos(fd * M_PI) : -1.0;
+        c = c < 0.0 ? -std::pow(-c, A) : std::pow(c, A);
+        return (int64_t)((c * 0.5 + 0.5) * fone);
+    }
     if (flags & GMAT_SWS_AREA) {
         const int64_t d2 = d - (1 << 29);
         int64_t w;
@@ -159,20 +165,33 @@ int64_t kernel_weight(int flags, const double param[2], int64_t d, int inc, int6
         if (fd > p) return 0;
         return (int64_t)((d ? std::sin(fd * M_PI) * std::sin(fd * M_PI / p) / (fd * fd * M_PI * M_PI / p) : 1.0) * fone);
     }
-    // bilinear
-    int64_t w = (1 << 30) - d;
-    if (w < 0) w = 0;
-    return w * (fone >> 30);
+    if (flags & GMAT_SWS_BILINEAR) {
+        int64_t w = (1 << 30) - d;
+        if (w < 0) w = 0;
+        return w * (fone >> 30);
+    }
+    // SWS_SPLINE, utils.c:322-334, 535-537: the natural cubic spline's kernel, one polynomial piece per unit of distance, each
+    // piece's coefficients derived from the previous one's (getSplineCoeff's recursion, written as the loop it is)
+    double a = 1.0, b = 0.0, c = -2.196152422706632, e = -c - 1.0, dist = fd;
+    while (dist > 1.0) {
+        const double nb = b + 2.0 * c + 3.0 * e, nc = c + 3.0 * e, ne = -b - 3.0 * c - 6.0 * e;
+        a = 0.0; b = nb; c = nc; e = ne;
+        dist -= 1.0;
+    }
+    return (int64_t)((((e * dist + c) * dist + b) * dist + a) * fone);
 }
 
 int support_factor(int flags, const double param[2])
 {
     int f = -1;
+    // scale_algorithms[] in its own order (utils.c:353-365), the first entry with a factor: BICUBLIN, FAST_BILINEAR, POINT, LANCZOS carry none
     if      (flags & GMAT_SWS_AREA)     f = 1;
     else if (flags & GMAT_SWS_BICUBIC)  f = 4;
     else if (flags & GMAT_SWS_BILINEAR) f = 2;
     else if (flags & GMAT_SWS_GAUSS)    f = 8;
     else if (flags & GMAT_SWS_SINC)     f = 20;
+    else if (flags & GMAT_SWS_SPLINE)   f = 20;
+    else if (flags & GMAT_SWS_X)        f = 8;
     if (flags & GMAT_SWS_LANCZOS)
         f = param[0] != GMAT_SWS_PARAM_DEFAULT ? (int)std::ceil(2 * param[0]) : 6;
     return f;
@@ -375,9 +394,12 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
     p.chrYInc = (int)((((int64_t)p.chrSrcH << 16) + (p.chrDstH >> 1)) / p.chrDstH);
 
     int r;
-    if ((r = build_filter(p.hLum, p.lumXInc, srcW, dstW, 1 << 14, flags, param,
+    // SWS_BICUBLIN: bicubic luma banks, bilinear chroma banks (utils.c:1830, 1841, 1860, 1869)
+    const int lflags = (flags & GMAT_SWS_BICUBLIN) ? (flags | GMAT_SWS_BICUBIC) : flags;
+    const int cflags = (flags & GMAT_SWS_BICUBLIN) ? (flags | GMAT_SWS_BILINEAR) : flags;
+    if ((r = build_filter(p.hLum, p.lumXInc, srcW, dstW, 1 << 14, lflags, param,
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
-    if ((r = build_filter(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 1 << 14, flags, param,
+    if ((r = build_filter(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 1 << 14, cflags, param,
                           local_chroma_pos(p.chrSrcHSub, chrPos[0]), local_chroma_pos(p.chrDstHSub, chrPos[2]))) < 0) return r;
     if ((flags & GMAT_SWS_FAST_BILINEAR) && is_yuv8_src(srcFormat) && !is_dst16(dstFormat)) {
         // 8-bit samples into 15-bit lines with SWS_FAST_BILINEAR: libswscale leaves hScale8To15_c for ff_hyscale_fast_c /
@@ -403,9 +425,9 @@ int build_scale_plan(ScalePlan &p, int srcW, int srcH, int srcFormat, int dstW, 
         fast_bank(p.hLum, p.lumXInc, srcW, dstW, 128);
         fast_bank(p.hChr, p.chrXInc, p.chrSrcW, p.chrDstW, 127);
     }
-    if ((r = build_filter(p.vLum, p.lumYInc, srcH, dstH, 1 << 12, flags, param,
+    if ((r = build_filter(p.vLum, p.lumYInc, srcH, dstH, 1 << 12, lflags, param,
                           local_chroma_pos(0, 0), local_chroma_pos(0, 0))) < 0) return r;
-    if ((r = build_filter(p.vChr, p.chrYInc, p.chrSrcH, p.chrDstH, 1 << 12, flags, param,
+    if ((r = build_filter(p.vChr, p.chrYInc, p.chrSrcH, p.chrDstH, 1 << 12, cflags, param,
                           local_chroma_pos(p.chrSrcVSub, chrPos[1]), local_chroma_pos(p.chrDstVSub, chrPos[3]))) < 0) return r;
     return 0;
 }

@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 PIX_FMT = dict(yuv420p=0, rgb24=2, bgr24=3, yuv444p=5, nv12=23, yuv444p16le=49, yuv420p16le=45, yuv420p10le=62, rgba=26, bgra=28, rgba64le=105, bgra64le=107, hip=117, rgb0=119, bgr0=121, p010le=159, p016le=170, rgbpf32le=179)
-SWS = dict(fast_bilinear=1, bilinear=2, bicubic=4, point=0x10, area=0x20, gauss=0x80, sinc=0x100,
-           lanczos=0x200, full_chr_h_int=0x2000, full_chr_h_inp=0x4000, accurate_rnd=0x40000,
+SWS = dict(fast_bilinear=1, bilinear=2, bicubic=4, x=8, point=0x10, area=0x20, bicublin=0x40, gauss=0x80, sinc=0x100,
+           lanczos=0x200, spline=0x400, full_chr_h_int=0x2000, full_chr_h_inp=0x4000, accurate_rnd=0x40000,
            bitexact=0x80000, hwaccel=0x1000000)
 
 

@@ -61,11 +61,14 @@ enum GmatPixelFormat {
 #define GMAT_SWS_FAST_BILINEAR   1
 #define GMAT_SWS_BILINEAR        2
 #define GMAT_SWS_BICUBIC         4
+#define GMAT_SWS_X               8   /* "experimental" (swscale.h:68) */
 #define GMAT_SWS_POINT        0x10
 #define GMAT_SWS_AREA         0x20
+#define GMAT_SWS_BICUBLIN     0x40   /* bicubic luma, bilinear chroma */
 #define GMAT_SWS_GAUSS        0x80
 #define GMAT_SWS_SINC        0x100
 #define GMAT_SWS_LANCZOS     0x200
+#define GMAT_SWS_SPLINE      0x400
 #define GMAT_SWS_FULL_CHR_H_INT 0x2000
 #define GMAT_SWS_FULL_CHR_H_INP 0x4000
 #define GMAT_SWS_ACCURATE_RND  0x40000

@@ -35,6 +35,14 @@ static int64_t rounded_div(int64_t a, int64_t b)
     return a >= 0 ? (a + (b >> 1)) / b : (a - (b >> 1)) / b;
 }
 
+/* getSplineCoeff, utils.c:322-334 */
+static double spline_coeff(double a, double b, double c, double d, double dist)
+{
+    if (dist <= 1.0)
+        return ((d * dist + c) * dist + b) * dist + a;
+    return spline_coeff(0.0, b + 2.0 * c + 3.0 * d, c + 3.0 * d, -b - 3.0 * c - 6.0 * d, dist - 1.0);
+}
+
 int orc_init_filter(int16_t **out_filter, int32_t **filter_pos, int *out_filter_size,
                     int x_inc, int src_w, int dst_w, int filter_align, int one,
                     int flags, const double param_in[2], int src_pos, int dst_pos)
@@ -102,6 +110,8 @@ int orc_init_filter(int16_t **out_filter, int32_t **filter_pos, int *out_filter_
         else if (flags & ORC_SWS_BILINEAR) size_factor = 2;
         else if (flags & 0x80)             size_factor = 8;    /* GAUSS  */
         else if (flags & 0x100)            size_factor = 20;   /* SINC   */
+        else if (flags & 0x400)            size_factor = 20;   /* SPLINE */
+        else if (flags & 8)                size_factor = 8;    /* X      */
         if (flags & ORC_SWS_LANCZOS)
             size_factor = param[0] != ORC_SWS_PARAM_DEFAULT ? (int)ceil(2 * param[0]) : 6;
         if (size_factor <= 0) goto fail;
@@ -147,6 +157,14 @@ int orc_init_filter(int16_t **out_filter, int32_t **filter_pos, int *out_filter_
                                       (8 * B + 24 * C) * (1 << 30);
                     }
                     coeff /= (1LL << 54) / fone;
+                } else if (flags & 8) {                          /* SWS_X, :497-508 */
+                    double A = param[0] != ORC_SWS_PARAM_DEFAULT ? param[0] : 1.0;
+                    double cc;
+                    if (floatd < 1.0) cc = cos(floatd * M_PI);
+                    else              cc = -1.0;
+                    if (cc < 0.0) cc = -pow(-cc, A);
+                    else          cc = pow(cc, A);
+                    coeff = (int64_t)((cc * 0.5 + 0.5) * fone);
                 } else if (flags & ORC_SWS_AREA) {
                     int64_t d2 = d - (1 << 29);
                     if (d2 * x_inc < -(1LL << (29 + 16)))
@@ -171,6 +189,9 @@ int orc_init_filter(int16_t **out_filter, int32_t **filter_pos, int *out_filter_
                     coeff = (1 << 30) - d;
                     if (coeff < 0) coeff = 0;
                     coeff *= fone >> 30;
+                } else if (flags & 0x400) {                      /* SWS_SPLINE, :535-537 */
+                    double p = -2.196152422706632;
+                    coeff = (int64_t)(spline_coeff(1.0, 0.0, p, -p - 1.0, floatd) * fone);
                 } else {
                     goto fail;
                 }

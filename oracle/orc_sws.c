@@ -210,16 +210,17 @@ OrcSws *orc_sws_create_ex(int src_w, int src_h, int src_fmt, int dst_w, int dst_
     c->chr_x_inc = (int)((((int64_t)c->chr_src_w << 16) + (c->chr_dst_w >> 1)) / c->chr_dst_w);
     c->chr_y_inc = (int)((((int64_t)c->chr_src_h << 16) + (c->chr_dst_h >> 1)) / c->chr_dst_h);
 
-    /* filters, utils.c:1820-1875; BICUBLIN (0x40) is not on the path and not restated */
+    /* filters, utils.c:1820-1875; SWS_BICUBLIN (0x40): bicubic luma banks, bilinear chroma banks (:1830, 1841, 1860, 1869) */
+    const int lflags = (flags & 0x40) ? (flags | ORC_SWS_BICUBIC) : flags, cflags = (flags & 0x40) ? (flags | ORC_SWS_BILINEAR) : flags;
     if (orc_init_filter(&c->h_lum, &c->h_lum_pos, &c->h_lum_size, c->lum_x_inc, src_w, dst_w, 1, 1 << 14,
-                        flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
+                        lflags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
     if (orc_init_filter(&c->h_chr, &c->h_chr_pos, &c->h_chr_size, c->chr_x_inc, c->chr_src_w, c->chr_dst_w,
-                        1, 1 << 14, flags, param,
+                        1, 1 << 14, cflags, param,
                         get_local_pos(c->chr_src_hsub, chr_pos[0]), get_local_pos(c->chr_dst_hsub, chr_pos[2])) < 0) goto fail;
     if (orc_init_filter(&c->v_lum, &c->v_lum_pos, &c->v_lum_size, c->lum_y_inc, src_h, dst_h, 1, 1 << 12,
-                        flags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
+                        lflags, param, get_local_pos(0, 0), get_local_pos(0, 0)) < 0) goto fail;
     if (orc_init_filter(&c->v_chr, &c->v_chr_pos, &c->v_chr_size, c->chr_y_inc, c->chr_src_h, c->chr_dst_h,
-                        1, 1 << 12, flags, param,
+                        1, 1 << 12, cflags, param,
                         get_local_pos(c->chr_src_vsub, chr_pos[1]), get_local_pos(c->chr_dst_vsub, chr_pos[3])) < 0) goto fail;
 
     /* SWS_FAST_BILINEAR with 8-bit samples and 15-bit lines (srcBpc == 8 && dstBpc <= 14, swscale.c:566-574; an RGB source has

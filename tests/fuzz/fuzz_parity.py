@@ -18,7 +18,7 @@ lib = load() if hip else load(os.path.join(ROOT, "tests", "hipemu", "build", "li
 dev = harness.Dev(lib, "hip" if hip else "emu")
 
 SRC = ["nv12", "yuv420p", "rgb24", "bgr24", "yuv444p", "rgba", "bgra", "rgba64le", "bgra64le"]   # the four with alpha: their alpha plane is scaled into rgba / bgra / rgba64le / bgra64le
-ALGOS = ["bicubic", "bilinear", "lanczos", "point", "area", "fast_bilinear"]
+ALGOS = ["bicubic", "bilinear", "lanczos", "point", "area", "fast_bilinear", "bicublin", "x", "gauss"]
 fails = 0
 for case in range(n):
     sf = rng.choice(SRC)

@@ -28,7 +28,7 @@ for name, script in (("sws", "build_ref_swscale.sh"), ("avf", "build_ref_avfilte
 rng = random.Random(seed)
 hist, fails = collections.Counter(), 0
 
-ALGOS = {"fast_bilinear": 1, "bilinear": 2, "bicubic": 4, "point": 0x10, "area": 0x20, "bicublin": 0x40, "gauss": 0x80, "sinc": 0x100,
+ALGOS = {"fast_bilinear": 1, "bilinear": 2, "bicubic": 4, "x": 8, "point": 0x10, "area": 0x20, "bicublin": 0x40, "gauss": 0x80, "sinc": 0x100,
          "lanczos": 0x200, "spline": 0x400}
 YUV8 = ["nv12", "yuv420p"]
 RGB = ["rgb24", "bgr24", "rgba", "bgra"]
@@ -76,9 +76,13 @@ for case in range(n):
         algo = rng.choice(list(ALGOS) + ["bicubic", "bicubic", "bilinear", "lanczos"])
         if (sw, sh) == (dw, dh):
             continue
-        cmd = [os.path.join(dirs["sws"], "libswscale_core_caller"), str(sw), str(sh), sf, str(dw), str(dh), df, str(ALGOS[algo]), str(ALGOS[algo]),
+        fl = ALGOS[algo]
+        for bit in (0x2000, 0x4000, 0x40000, 0x80000):             # SWS_FULL_CHR_H_INT / _INP, SWS_ACCURATE_RND, SWS_BITEXACT (swscale.h:84-90)
+            if rng.random() < 0.2:
+                fl |= bit
+        cmd = [os.path.join(dirs["sws"], "libswscale_core_caller"), str(sw), str(sh), sf, str(dw), str(dh), df, str(fl), str(fl),
                str(rng.randint(1, 1 << 20))]
-        what = "core %s %dx%d -> %s %dx%d %s" % (sf, sw, sh, df, dw, dh, algo)
+        what = "core %s %dx%d -> %s %dx%d %s flags 0x%x" % (sf, sw, sh, df, dw, dh, algo, fl)
         key = "core %s -> %s" % ("yuv" if sf in YUV8 else "rgb" if sf in RGB else "hi", "yuv" if df in YUV8 else "rgb" if df in RGB else "hi")
     else:
         # ---- part B: the filter graph ----
@@ -149,6 +153,8 @@ for case in range(n):
         hist[key] += 1
     elif "sws_getContext(SWS_HWACCEL_CUDA) failed" in r.stderr:
         hist["(declined) " + key] += 1
+        if "--verbose" in sys.argv:
+            print("declined:", what)
     else:
         fails += 1
         print("MISMATCH case", case, what, "->", (r.stdout + r.stderr).strip()[-400:].replace("\n", " | "))

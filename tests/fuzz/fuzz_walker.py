@@ -25,7 +25,7 @@ dev = harness.Dev(lib, "hip" if hip else "emu")
 hist = collections.Counter()
 fails = 0
 maxw, maxh = (2600, 400) if hip else (900, 160)
-ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline"]
+ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline", "bicublin", "x"]
 
 for case in range(n):
     for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER"):

@@ -62,6 +62,18 @@ CASES = [
     (120, 48, "rgb24", 60, 24, "rgb24", BICUBIC, BICUBIC),     # scaled, packed RGB at both ends
     (128, 64, "nv12", 64, 32, "nv12", BICUBIC, BICUBIC),       # scale_cuda's job through libswscale
     (120, 48, "rgb24", 60, 24, "nv12", BICUBIC, BICUBIC),
+    # round 4, found by tests/fuzz/fuzz_ref_core.py over this caller: sources deeper than 8 bits dither their 8-bit planar output (swscale.c:263-264)
+    (256, 144, "p010le", 128, 72, "nv12", BICUBIC, BICUBIC),
+    (234, 122, "yuv420p10le", 124, 70, "nv12", 1, 1),
+    (216, 40, "p016le", 100, 22, "yuv420p", BICUBIC, BICUBIC),
+    (216, 40, "rgba64le", 100, 22, "yuv420p", BICUBIC, BICUBIC),
+    (216, 40, "yuv444p16le", 100, 22, "nv12", LANCZOS, LANCZOS),
+    # ... and the three algorithms of scale_algorithms[] rounds 1-3 refused: SWS_X, SWS_BICUBLIN, SWS_SPLINE
+    (256, 144, "nv12", 128, 72, "rgb24", 8, 8),
+    (200, 120, "yuv420p", 68, 42, "bgra", 0x40, 0x40),
+    (116, 32, "rgb24", 142, 44, "rgb24", 0x40, 0x40),            # RGB -> RGB: the chroma banks differ from the luma banks (the plane scaler, not scale_rgb_kernel)
+    (160, 90, "nv12", 240, 136, "nv12", 0x400, 0x400),
+    (164, 68, "rgba", 92, 50, "nv12", 0x400 | 0x40000, 0x400 | 0x40000),
 ]
 
 
