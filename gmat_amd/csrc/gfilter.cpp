@@ -196,6 +196,7 @@ struct GmatFilterContext {
     bool gauss_general = false;          // any of kw / kh / sigma / border_type given: the float kernel of launch_gauss_blur
     // scale / format
     GmatSwsContext *sws = nullptr;
+    int cur_cs = GMAT_SWS_CS_DEFAULT;            // the colourspace row the sws context was last set to (follow_frame_colour)
     int sws_flags = GMAT_SWS_BICUBIC;
     int passthrough = 1, force_oar = 0, force_div = 1;
     bool bypass = false;                 // passthrough && nothing to do: filter_frame hands the input frame on
@@ -506,6 +507,30 @@ int gmat_filter_config_props(GmatFilterContext *f, GmatHWFramesContext *in_frame
     return 0;
 }
 
+// A frame's own colour description drives the conversion (vf_format_cuda.c:184-217: in->colorspace goes to SetMatYuv2Rgb / SetMatRgb2Yuv per frame;
+// libavfilter's `scale` does the same with in_color_matrix=auto, vf_scale.c:793-824).  GmatFrame carries the colourspace only (no range: limited).
+// AVCOL_SPC_* -> the SWS_CS_* row as cuda/yuv2rgb_cuda.cu:782-815 get_constants maps them: unlisted values are BT.601.
+static int follow_frame_colour(GmatFilterContext *f, const GmatFrame *in)
+{
+    int cs = GMAT_SWS_CS_DEFAULT;
+    switch (in->colorspace) {
+    case 1: cs = GMAT_SWS_CS_ITU709; break;          // AVCOL_SPC_BT709
+    case 4: cs = 4; break;                           // AVCOL_SPC_FCC
+    case 7: cs = 7; break;                           // AVCOL_SPC_SMPTE240M
+    case 9: case 10: cs = GMAT_SWS_CS_BT2020; break; // AVCOL_SPC_BT2020_NCL / _CL
+    default: break;
+    }
+    if (!f->sws || cs == f->cur_cs) return 0;
+    const bool src_rgb = is_packed_rgb(f->in_fmt) || is_rgb64(f->in_fmt) || f->in_fmt == GMAT_PIX_FMT_RGBPF32LE;
+    const bool dst_rgb = is_packed_rgb(f->out_fmt) || is_rgb64(f->out_fmt) || f->out_fmt == GMAT_PIX_FMT_RGBPF32LE;
+    if (src_rgb != dst_rgb) {
+        const int r = gmat_sws_setColorspace(f->sws, cs, 0);
+        if (r < 0) return r;
+    }
+    f->cur_cs = cs;
+    return 0;
+}
+
 int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
 {
     if (!in) return GMAT_ERR(EINVAL);
@@ -527,7 +552,8 @@ int gmat_filter_frame(GmatFilterContext *f, GmatFrame *in, GmatFrame **out_p)
     if (!out) { r = GMAT_ERR(ENOMEM); goto fail; }
     if ((r = gmat_hwframe_get_buffer(f->out_frames, out)) < 0) goto fail;
     if (f->kind == K_SCALE || f->kind == K_FORMAT) {
-        r = gmat_sws_scale(f->sws, in->data, in->linesize, 0, f->in_h, out->data, out->linesize);
+        if ((r = follow_frame_colour(f, in)) >= 0)
+            r = gmat_sws_scale(f->sws, in->data, in->linesize, 0, f->in_h, out->data, out->linesize);
     } else {
         PlaneGeom g[3];
         const int np = plane_geoms(f->in_fmt, f->in_w, f->in_h, g);
@@ -679,7 +705,9 @@ static int run_pending(GmatFilterContext *f)
         }
         // frames of differing strides: one by one below
     }
-    const bool batched = (f->kind == K_SCALE || f->kind == K_FORMAT) && !f->bypass && n > 1;
+    bool one_colour = true;                                    // a launch carries one colour description (follow_frame_colour): mixed queues go frame by frame
+    for (int i = 1; i < n; i++) one_colour = one_colour && f->pending[i]->colorspace == f->pending[0]->colorspace;
+    const bool batched = (f->kind == K_SCALE || f->kind == K_FORMAT) && !f->bypass && n > 1 && one_colour;
     if (batched) {
         std::vector<const uint8_t *> sp((size_t)n * 4, nullptr);
         std::vector<uint8_t *> dp((size_t)n * 4, nullptr);
@@ -693,6 +721,7 @@ static int run_pending(GmatFilterContext *f)
             for (int k = 0; k < 4; k++)
                 if (f->pending[i]->linesize[k] != f->pending[0]->linesize[k] || o->linesize[k] != outs[0]->linesize[k]) r = GMAT_ERR(EINVAL);
         }
+        if (r >= 0) r = follow_frame_colour(f, f->pending[0]);
         if (r >= 0) {
             void *streams[1] = {(void *)f->stream};
             r = gmat_sws_scale_batch(f->sws, n, sp.data(), f->pending[0]->linesize, dp.data(), outs[0]->linesize, streams, 1, 0);

@@ -24,7 +24,9 @@ enum AVPixelFormat {
     AV_PIX_FMT_0BGR32 = 119, AV_PIX_FMT_0RGB32 = 121, AV_PIX_FMT_P010 = 159, AV_PIX_FMT_P016 = 170,
     AV_PIX_FMT_YUV420P16 = 45, AV_PIX_FMT_YUV420P10 = 62, AV_PIX_FMT_RGBA64 = 105, AV_PIX_FMT_BGRA64 = 107, AV_PIX_FMT_RGBPF32LE = 179,
 };
-enum AVColorSpace { AVCOL_SPC_UNSPECIFIED = 2 };
+enum AVColorSpace { AVCOL_SPC_RGB = 0, AVCOL_SPC_BT709 = 1, AVCOL_SPC_UNSPECIFIED = 2, AVCOL_SPC_FCC = 4, AVCOL_SPC_BT470BG = 5, AVCOL_SPC_SMPTE170M = 6,
+                    AVCOL_SPC_SMPTE240M = 7, AVCOL_SPC_BT2020_NCL = 9, AVCOL_SPC_BT2020_CL = 10 };
+enum AVColorRange { AVCOL_RANGE_UNSPECIFIED = 0, AVCOL_RANGE_MPEG = 1, AVCOL_RANGE_JPEG = 2 };
 typedef struct AVClass AVClass;
 typedef struct AVBufferRef { uint8_t *data; size_t size; } AVBufferRef;
 AVBufferRef *av_buffer_ref(const AVBufferRef *buf);
@@ -34,6 +36,8 @@ typedef struct AVFrame {
     int linesize[8];
     int width, height, format;
     int64_t pts;
+    enum AVColorRange color_range;
+    enum AVColorSpace colorspace;
     AVBufferRef *hw_frames_ctx;
 } AVFrame;
 AVFrame *av_frame_alloc(void);

@@ -60,9 +60,46 @@ typedef struct GmatHipContext {
     AVBufferRef *frames_ref;
     void *stream;
     GmatSwsContext *sws;
+    int cur_cs, cur_full;       /* AVFrame.colorspace / full range the sws context was last set to (-1: its defaults) */
     AVFrame *queue[GH_MAX_BATCH];
     int nqueued;
 } GmatHipContext;
+
+/* A frame's own colour description drives the conversion, frame by frame:
+ *   format_hip  vf_format_cuda.c:184-217 hands in->colorspace to nv12_to_rgbpf32 / rgbpf32_to_nv12 (SetMatYuv2Rgb / SetMatRgb2Yuv)
+ *   scale_hip   vf_scale_cuda.c has no matrix (YUV -> YUV only); where it converts it follows libavfilter's `scale` with its default
+ *               in_color_matrix=auto (vf_scale.c:793-824): the matrix of in->colorspace on both sides, the source range of in->color_range,
+ *               a limited-range output
+ * AVCOL_SPC_* -> the SWS_CS_* row (libswscale/utils.c parse_yuv_type / cuda/yuv2rgb_cuda.cu:782-815 get_constants: unlisted values are BT.601) */
+static int gh_sws_cs(enum AVColorSpace cs)
+{
+    switch ((int)cs) {
+    case AVCOL_SPC_BT709:                               return GMAT_SWS_CS_ITU709;
+    case AVCOL_SPC_FCC:                                 return 4;
+    case AVCOL_SPC_SMPTE240M:                           return 7;
+    case AVCOL_SPC_BT2020_NCL: case AVCOL_SPC_BT2020_CL: return GMAT_SWS_CS_BT2020;
+    default:                                            return GMAT_SWS_CS_DEFAULT;
+    }
+}
+
+static int gh_follow_frame_colour(GmatHipContext *s, const AVFrame *in)
+{
+    const int cs = gh_sws_cs(in->colorspace), full = in->color_range == AVCOL_RANGE_JPEG;
+    const AVPixFmtDescriptor *si = av_pix_fmt_desc_get(s->in_fmt), *so = av_pix_fmt_desc_get(s->out_fmt);
+    const int src_rgb = !!(si->flags & AV_PIX_FMT_FLAG_RGB), dst_rgb = !!(so->flags & AV_PIX_FMT_FLAG_RGB);
+    int ret = 0;
+
+    if (!s->sws || (cs == s->cur_cs && full == s->cur_full))
+        return 0;
+    if (src_rgb != dst_rgb)                             /* a matrix is involved: YUV -> RGB (with the source's range) or RGB -> YUV */
+        ret = gmat_sws_setColorspace(s->sws, cs, src_rgb ? 0 : full);
+    else if (!src_rgb && full != (s->cur_full > 0))     /* YUV -> YUV: a full-range source into the limited-range output `scale` makes of it */
+        ret = gmat_sws_setRange(s->sws, full, 0);
+    if (ret < 0)
+        return AVERROR(ENOSYS);
+    s->cur_cs = cs; s->cur_full = full;
+    return 0;
+}
 
 static int plane_geometry(enum AVPixelFormat fmt, int plane, int w, int h, int *pw, int *ph, int *bpp)
 {
@@ -206,6 +243,7 @@ static int gh_config_props(AVFilterLink *outlink)
             return AVERROR(ENOSYS);
         }
         gmat_sws_setStream(s->sws, s->stream);
+        s->cur_cs = GMAT_SWS_CS_DEFAULT; s->cur_full = 0;       /* a new context's defaults: BT.601, limited range */
     }
 
     av_buffer_unref(&s->frames_ref);
@@ -312,8 +350,10 @@ static int gh_filter_frame(AVFilterLink *inlink, AVFrame *in)
         return AVERROR(ENOMEM);
     }
     if (s->kind == GH_SCALE || s->kind == GH_FORMAT) {
-        ret = gmat_sws_scale(s->sws, (const uint8_t *const *)in->data, in->linesize, 0, in->height, out->data, out->linesize);
-        ret = ret < 0 ? AVERROR_EXTERNAL : 0;
+        if ((ret = gh_follow_frame_colour(s, in)) >= 0) {
+            ret = gmat_sws_scale(s->sws, (const uint8_t *const *)in->data, in->linesize, 0, in->height, out->data, out->linesize);
+            ret = ret < 0 ? AVERROR_EXTERNAL : 0;
+        }
     } else {
         ret = gh_run_planes(s, in, out);
     }
@@ -378,8 +418,13 @@ static int gh_flush_queue(AVFilterContext *ctx)
         const int plane_wise = s->kind != GH_SCALE && s->kind != GH_FORMAT;
         int oparg = 0;
         const int op = plane_wise ? gh_batched_op(s, &oparg) : -1;
+        for (int i = 1; i < n && same && !plane_wise; i++)      /* ... and ONE colour description (gh_follow_frame_colour) */
+            if (s->queue[i]->colorspace != s->queue[0]->colorspace || s->queue[i]->color_range != s->queue[0]->color_range)
+                same = 0;
         if (same && !plane_wise) {
-            if (gmat_sws_scale_batch(s->sws, n, sp, s->queue[0]->linesize, dp, outs[0]->linesize, streams, 1, 0) < 0)
+            if ((ret = gh_follow_frame_colour(s, s->queue[0])) < 0)
+                ;
+            else if (gmat_sws_scale_batch(s->sws, n, sp, s->queue[0]->linesize, dp, outs[0]->linesize, streams, 1, 0) < 0)
                 ret = AVERROR_EXTERNAL;
         } else if (same && op >= 0) {
             for (int p = 0; p < 3 && s->queue[0]->data[p] && ret >= 0; p++) {
@@ -410,7 +455,8 @@ static int gh_flush_queue(AVFilterContext *ctx)
                 ret = gh_run_planes(s, s->queue[i], outs[i]);
         } else {
             for (int i = 0; i < n && ret >= 0; i++)
-                if (gmat_sws_scale(s->sws, (const uint8_t *const *)s->queue[i]->data, s->queue[i]->linesize, 0, s->queue[i]->height,
+                if ((ret = gh_follow_frame_colour(s, s->queue[i])) >= 0 &&
+                    gmat_sws_scale(s->sws, (const uint8_t *const *)s->queue[i]->data, s->queue[i]->linesize, 0, s->queue[i]->height,
                                    outs[i]->data, outs[i]->linesize) < 0)
                     ret = AVERROR_EXTERNAL;
         }

@@ -13,7 +13,7 @@
  *     buffer -> <gpu chain, e.g. hwupload_hip,scale_hip=w=160:h=90:format=rgb24,hwdownload> -> buffersink
  *     buffer -> <cpu chain, e.g. scale=160:90:flags=bicubic,format=rgb24>                   -> buffersink
  * — and compares every byte of every frame.  Exit code 0: identical.
- *   avfilter_graph_caller <w> <h> <pix_fmt> <nframes> "<gpu chain>" "<cpu chain>" [seed]
+ *   avfilter_graph_caller <w> <h> <pix_fmt> <nframes> "<gpu chain>" "<cpu chain>" [seed [AVCOL_SPC [AVCOL_RANGE]]]   (tags of the source frames)
  * A chain is `name=args,name=args,...` (no quoting: ',' only between filters); names ending in _hip are this repository's.
  */
 #include <stdint.h>
@@ -89,6 +89,8 @@ static int build(Graph *G, const char *chain, int w, int h, enum AVPixelFormat f
     return 0;
 }
 
+static int g_colorspace = AVCOL_SPC_UNSPECIFIED, g_range = AVCOL_RANGE_UNSPECIFIED;   /* tags of every source frame (argv[8], argv[9]) */
+
 static AVFrame *make_frame(int w, int h, enum AVPixelFormat fmt, uint32_t seed, int64_t pts)
 {
     AVFrame *f = av_frame_alloc();
@@ -97,6 +99,7 @@ static AVFrame *make_frame(int w, int h, enum AVPixelFormat fmt, uint32_t seed, 
     if (!f)
         return NULL;
     f->format = fmt; f->width = w; f->height = h; f->pts = pts;
+    f->colorspace = (enum AVColorSpace)g_colorspace; f->color_range = (enum AVColorRange)g_range;
     if (av_frame_get_buffer(f, 0) < 0) { av_frame_free(&f); return NULL; }
     for (int p = 0; p < 4 && f->data[p]; p++) {
         const int rows = (p == 1 || p == 2) ? AV_CEIL_RSHIFT(h, d->log2_chroma_h) : h;
@@ -149,6 +152,8 @@ int main(int argc, char **argv)
     const int w = atoi(argv[1]), h = atoi(argv[2]), nframes = atoi(argv[4]);
     const enum AVPixelFormat fmt = av_get_pix_fmt(argv[3]);
     const uint32_t seed = argc > 7 ? (uint32_t)atoi(argv[7]) : 2026u;
+    if (argc > 8) g_colorspace = atoi(argv[8]);             /* AVCOL_SPC_*: 1 bt709, 5 bt470bg, 6 smpte170m, 7 smpte240m, 9 bt2020nc */
+    if (argc > 9) g_range = atoi(argv[9]);                  /* AVCOL_RANGE_*: 1 limited (mpeg), 2 full (jpeg) */
     AVBufferRef *device = NULL;
     Graph gpu = {0}, cpu = {0};
     long bad = 0;

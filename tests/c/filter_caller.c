@@ -71,7 +71,7 @@ void av_frame_free(AVFrame **f)
     av_buffer_unref(&(*f)->hw_frames_ctx);
     free(*f); *f = NULL;
 }
-int av_frame_copy_props(AVFrame *dst, const AVFrame *src) { dst->pts = src->pts; return 0; }
+int av_frame_copy_props(AVFrame *dst, const AVFrame *src) { dst->pts = src->pts; dst->colorspace = src->colorspace; dst->color_range = src->color_range; return 0; }
 
 AVBufferRef *av_hwframe_ctx_alloc(AVBufferRef *device_ref)
 {

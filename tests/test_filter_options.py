@@ -420,3 +420,49 @@ def test_rotate2_batch_equals_the_single_frame_calls(dev, orc, interp, bpp):
         for p_ in d + o1 + o2:
             p_.free()
     assert lib.gmat_rotate2_batch(1, sp, 4, dp, 4, 1, 1, 1, 1, 1, 0.5, 3, 0.0, 0.0, None, None) < 0
+
+
+# ---- a frame's own colour description drives the conversion (vf_format_cuda.c:184-217, vf_scale.c:793-824) ---------------------------
+@pytest.mark.parametrize("filt,opts", [("format_hip", {"pix_fmt": "rgb24"}), ("scale_hip", {"w": "iw/2", "h": "ih/2", "format": "bgra"}),
+                                       ("scale_hip", {"w": "iw/2", "h": "ih/2", "format": "rgb24", "batch": 3})])
+def test_frame_colourspace_selects_the_matrix(dev, orc, filt, opts):
+    """frames tagged BT.709, BT.601, untagged, BT.2020, SMPTE 240M in ONE stream (the queued form's batches hold mixed tags): each comes out in the matrix
+    of its own tag, as the reference's format_cuda converts it (in->colorspace per frame) and as libavfilter's `scale` does (in_color_matrix=auto);
+    tests/test_libavfilter_core.py holds the same against the reference's CPU filter with tagged frames"""
+    from harness import synth_planes
+    lib = dev.lib
+    sw, sh = 128, 32
+    sf = "yuv420p" if filt == "format_hip" else "nv12"
+    df = {"rgb24": "rgb24", "bgra": "bgra"}[opts.get("pix_fmt", opts.get("format"))]
+    dw, dh = (sw, sh) if filt == "format_hip" else (sw // 2, sh // 2)
+    fc = lib.gmat_hwframe_ctx_create(0, PIX_FMT[sf], sw, sh, 2)
+    f = lib.gmat_filter_alloc(filt.encode())
+    for k, v in opts.items():
+        assert lib.gmat_filter_set_option(f, k.encode(), str(v).encode()) == 0
+    assert lib.gmat_filter_init(f) == 0 and lib.gmat_filter_config_props(f, fc, None) == 0
+    tags = [1, 6, 2, 9, 7, 1, 1, 5]                       # AVCOL_SPC_*: bt709, smpte170m, unspecified, bt2020nc, smpte240m, ..., bt470bg
+    row = {1: 1, 9: 9, 7: 7}                              # -> SWS_CS_* (the others: 5 = BT.601)
+    srcs = [synth_planes(orc, sf, sw, sh, seed=900 + i) for i in range(len(tags))]
+    outs, out = [], C.POINTER(GmatFrame)()
+    for i, t in enumerate(tags):
+        fr = _dev_frame(lib, fc, srcs[i], i)
+        fr.contents.colorspace = t
+        assert lib.gmat_filter_send_frame(f, fr) == 0
+        while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+            outs.append(out); out = C.POINTER(GmatFrame)()
+    assert lib.gmat_filter_flush(f) == 0
+    while lib.gmat_filter_receive_frame(f, C.byref(out)) == 0:
+        outs.append(out); out = C.POINTER(GmatFrame)()
+    assert len(outs) == len(tags)
+    lib.gmat_device_sync()
+    bpp = 3 if df == "rgb24" else 4
+    for i, o in enumerate(outs):
+        assert o.contents.pts == i and o.contents.colorspace == tags[i]
+        back = np.zeros((dh, o.contents.linesize[0]), np.uint8)
+        assert lib.gmat_memcpy_d2h(back.ctypes.data, o.contents.data[0], back.size) == 0
+        cs = row.get(tags[i], 5)
+        want = [orc.yuv2rgb(srcs[i], sw, sh, sf, df, colorspace=cs)] if filt == "format_hip" else orc.sws(srcs[i], sw, sh, sf, dw, dh, df, colorspace=cs)
+        assert (back[:, :dw * bpp] == want[0]).all(), (i, tags[i])
+        lib.gmat_frame_free(C.byref(o))
+    lib.gmat_filter_free(f)
+    lib.gmat_hwframe_ctx_free(fc)

@@ -103,12 +103,26 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: ("%s_%dx%d_%s" % (c[2], c[0], c[1], c[4])).replace(" ", "_")[:80])
+# frames that carry their own colour description (AVFrame.colorspace / color_range): format_cuda converts with in->colorspace (vf_format_cuda.c:184-217),
+# `scale` with in_color_matrix=auto takes matrix and source range from the frame and writes limited range (vf_scale.c:793-824); (AVCOL_SPC, AVCOL_RANGE)
+TAGGED = [
+    (320, 180, "nv12", 2, "scale_hip=w=160:h=90:format=rgb24", "scale=160:90:flags=bicubic", "rgb24", 1, 1),              # BT.709, limited
+    (320, 180, "nv12", 2, "scale_hip=w=160:h=90:format=rgb24", "scale=160:90:flags=bicubic", "rgb24", 1, 2),              # BT.709, full-range source
+    (320, 180, "yuv420p", 2, "format_hip=pix_fmt=bgra", "scale=flags=bicubic", "bgra", 9, 1),                             # BT.2020
+    (320, 180, "yuv420p", 2, "format_hip=pix_fmt=rgb24", "scale=flags=bicubic", "rgb24", 7, 2),                           # SMPTE 240M, full range
+    (320, 180, "nv12", 2, "scale_hip=w=160:h=90", "scale=160:90:flags=bicubic", "nv12", 1, 2),                            # YUV -> YUV: full -> limited range conversion
+    (320, 180, "rgb24", 2, "scale_hip=w=160:h=90:format=nv12", "scale=160:90:flags=bicubic", "nv12", 1, 1),               # RGB -> YUV: the tag's matrix on the way out
+    (320, 180, "nv12", 5, "scale_hip=w=160:h=90:format=rgb24:batch=2", "scale=160:90:flags=bicubic", "rgb24", 1, 2),      # ... through the queue
+]
+
+
+@pytest.mark.parametrize("case", CASES + TAGGED, ids=lambda c: ("%s_%dx%d_%s%s" % (c[2], c[0], c[1], c[4], "_cs%d_r%d" % c[7:9] if len(c) > 7 else "")).replace(" ", "_")[:90])
 def test_real_libavfilter_drives_the_gpu_filters(graph_caller, case):
-    w, h, fmt, n, gpu, cpu, out = case
+    w, h, fmt, n, gpu, cpu, out = case[:7]
     gpu_chain = "hwupload_hip,%s,hwdownload,format=%s" % (gpu, out)
     cpu_chain = "%s,format=%s" % (cpu, out)
-    r = subprocess.run([os.path.join(graph_caller, "avfilter_graph_caller"), str(w), str(h), fmt, str(n), gpu_chain, cpu_chain],
+    tags = ["2026", str(case[7]), str(case[8])] if len(case) > 7 else []
+    r = subprocess.run([os.path.join(graph_caller, "avfilter_graph_caller"), str(w), str(h), fmt, str(n), gpu_chain, cpu_chain] + tags,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2500:]
     assert "0 mismatching bytes" in r.stdout, r.stdout
