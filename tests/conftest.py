@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
+    # a sanitizer build of the emulated library (GMAT_TEST_EMU_LIBRARY) reports on file descriptor 2, which pytest captures and xdist drops:
+    # GMAT_SANITIZER_LOG=<prefix> sends each process's descriptor 2 to <prefix>.<pid>
+    if os.environ.get("GMAT_SANITIZER_LOG"):
+        os.dup2(os.open("%s.%d" % (os.environ["GMAT_SANITIZER_LOG"], os.getpid()), os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644), 2)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
@@ -78,7 +82,9 @@ def dev(request):
         if lib.gmat_device_count() <= 0:
             pytest.fail("-m gpu test selected but no HIP device is visible")
         return harness.Dev(lib, "hip")
-    path = _make(os.path.join(ROOT, "tests", "hipemu"), "build/libgmat_hip_emu.so")
+    # GMAT_TEST_EMU_LIBRARY: another BUILD of the emulated library (tools/ubsan_emu.sh: every kernel and the host code under
+    # -fsanitize=undefined — sanitizers run on the CPU build only)
+    path = os.environ.get("GMAT_TEST_EMU_LIBRARY") or _make(os.path.join(ROOT, "tests", "hipemu"), "build/libgmat_hip_emu.so")
     return harness.Dev(load(path), "emu")
 
 

@@ -17,7 +17,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 hip = "--hip" in sys.argv
 rng = random.Random(seed)
 orc = harness.load_oracle(os.path.join(ROOT, "oracle", "liborc.so"))
-lib = load() if hip else load(os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so"))
+lib = load() if hip else load(os.environ.get("GMAT_TEST_EMU_LIBRARY") or os.path.join(ROOT, "tests", "hipemu", "build", "libgmat_hip_emu.so"))
 dev = harness.Dev(lib, "hip" if hip else "emu")
 hist = collections.Counter()
 fails = 0
