@@ -32,7 +32,7 @@ ALGOS = {"fast_bilinear": 1, "bilinear": 2, "bicubic": 4, "x": 8, "point": 0x10,
          "lanczos": 0x200, "spline": 0x400}
 YUV8 = ["nv12", "yuv420p"]
 RGB = ["rgb24", "bgr24", "rgba", "bgra"]
-HI = ["p010le", "yuv420p10le"]
+HI = ["p010le", "yuv420p10le", "p016le", "yuv420p16le", "yuv444p16le", "rgba64le", "bgra64le", "yuv444p"]     # (yuv444p rides here: 8 bits, no chroma subsampling)
 
 
 def geometry(maxw=420, maxh=240):
@@ -67,10 +67,12 @@ for case in range(n):
         elif sf in RGB:
             df = rng.choice(RGB + YUV8 * 2)
         else:
-            df = rng.choice([sf, sf, "nv12", "rgb24"])
-        if (sf in ("nv12", "p010le") or df in ("nv12", "p010le")) and ((sw | dw) & 1):
+            df = rng.choice([sf, sf, "nv12", "rgb24", "yuv420p", "bgra", rng.choice(HI)])
+        if rng.random() < 0.15:
+            df = rng.choice(HI)                                    # ... and the deep / 4:4:4 formats as destinations of everything
+        if (sf in ("nv12", "p010le", "p016le") or df in ("nv12", "p010le", "p016le")) and ((sw | dw) & 1):
             sw, dw = sw & ~1, dw & ~1                              # semi-planar rows are pairs
-        if sf in RGB and (sw & 1):
+        if (sf in RGB or sf in ("rgba64le", "bgra64le")) and (sw & 1):
             sw += 1                                               # rgb24ToUV_half_c reads pixel 2i + 1 of the last pair of an odd row: whatever follows it in memory
                                                                   # (input.c:849-866; oracle/orc_sws.c rgb8_chr states the clamp the library uses instead)
         algo = rng.choice(list(ALGOS) + ["bicubic", "bicubic", "bilinear", "lanczos"])

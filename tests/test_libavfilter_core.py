@@ -14,6 +14,7 @@ buffer -> the reference's own CPU filters -> buffersink — feeds both the same 
 through the reference's format negotiation, config_props order, frame pools, activate() scheduling and EOF handling.
 Nothing of this travels to the GPU box (no reference tree there)."""
 import os
+import sys
 import subprocess
 
 import pytest
@@ -151,3 +152,14 @@ def test_error_paths_of_the_real_graph(graph_caller):
     assert r.returncode != 0 and "avfilter_graph_config" in r.stderr
     r = subprocess.run([exe, "320", "180", "rgb24", "1", "hwupload_hip,smooth_hip=kw=4,hwdownload,format=rgb24", "null"], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_reference_fuzz_smoke(tmp_path):
+    """tests/fuzz/fuzz_ref_core.py over both harnesses (the real libswscale core + the real libavfilter): 60 random cases against the reference's own
+    compiled CPU code — geometries incl. the exact ratios no reference vector holds, all eleven SWS algorithms and four flag bits, 8 / 10 / 16-bit and
+    64-bit RGB formats, rotate / crop / median / smooth / transpose graphs.  Larger runs are recorded in profiles/r04_fuzz_ref_core.txt."""
+    if not os.path.exists(os.path.join(REF, "configure")):
+        pytest.skip("the reference tree is not present (GPU box)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_ref_core.py"), "60", "20261001", "--keep", str(tmp_path)],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "failures 0" in r.stdout, (r.stdout + r.stderr)[-3000:]
