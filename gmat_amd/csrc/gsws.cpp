@@ -147,6 +147,11 @@ struct GmatSwsContext {
     YuvUTables yu;                // the quad-lane walker: up-scales of any factor, short filters (k_scale_yuvu.hip)
     DevBuf dU[12];                // its device tables
     YuvUArgs uargs;
+    YuvLTables yl;                // the lines form: two launches through a frame of 15-bit lines (k_scale_yuvl.hip)
+    DevBuf dL[4];                 // its device tables: hL, hC, offL, offC
+    YuvLArgs largs;
+    int32_t *linesBuf = nullptr;  // linesFrames lines frames (an intermediate the context owns: stream_handoff_*)
+    int linesFrames = 0;
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
     // 1 the same arithmetic in one fused kernel, 2 one libswscale context (planes scaled separately)
@@ -201,6 +206,7 @@ struct GmatSwsContext {
         if (interBatch) (void)hipFree(interBatch);
         if (cross) gmat_sws_freeContext(cross);
         if (crossBuf) (void)hipFree(crossBuf);
+        if (linesBuf) (void)hipFree(linesBuf);
         if (interEv) (void)hipEventDestroy(interEv);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
@@ -303,6 +309,23 @@ static int init_yuv_scaler(GmatSwsContext *c)
             (r = up(t.firstL, u.firstL)) < 0 || (r = up(t.firstC, u.firstC)) < 0 || (r = up(t.lastL, u.lastL)) < 0 || (r = up(t.lastC, u.lastC)) < 0) return r;
         u.P = t.P; u.SD = t.SD; u.RL = t.RL; u.RC = t.RC; u.lead = t.lead; u.roundL = t.roundL; u.roundC = t.roundC; u.yuvOut = t.yuvOut;
     }
+    if (!a.src16 && !c->rgbViaPlanes && (r = yuvl_prepare(c->planYuv, c->ytiling, c->yl)) < 0) return r;
+    if (c->yl.ok) {
+        YuvLArgs &l = c->largs;
+        std::memset(&l, 0, sizeof(l));
+        const YuvLTables &t = c->yl;
+        int k = 0;
+        auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            int rr = c->dL[k].upload(v.data(), v.size() * 4);
+            out = (const int32_t *)c->dL[k++].p;
+            return rr;
+        };
+        if ((r = up(t.hL, l.hL)) < 0 || (r = up(t.hC, l.hC)) < 0 || (r = up(t.offL, l.offL)) < 0 || (r = up(t.offC, l.offC)) < 0) return r;
+        l.P = t.P; l.yuvOut = t.yuvOut; l.fullChroma = t.fullChroma;
+        l.pitchL = t.pitchL; l.pitchC = t.pitchC; l.pairRowsL = t.pairRowsL; l.pairRowsC = t.pairRowsC;
+        l.baseU = t.baseU; l.baseV = t.baseV; l.frameInts = t.frameInts;
+    }
+    if (c->ytiling.TW == 0 && !c->yl.ok) return GMAT_ERR(ENOSYS);     // no tiling fits a workgroup's LDS and the lines form does not serve the formats
     if ((r = yuv2x_prepare(c->planYuv, c->ytiling, c->y2x)) < 0) return r;
     if (c->y2x.ok) {
         if ((r = c->dHLreg.upload(c->y2x.hLreg.data(), c->y2x.hLreg.size() * 4)) < 0) return r;
@@ -857,6 +880,54 @@ static const char *yuv2p_name(const GmatSwsContext *c)
 // the call — only the one-frame form in front of the exact-ratio walkers looks at it).  launch: n frames
 // of the table through one launch (n = 1: what sws_scale() issues).  The exact-ratio walkers' geometries are disjoint, so the order
 // only matters inside a ratio (2:1: strip walker / 4:4:4 luma walker / plane walker before the tiled kernel) and for the two catch-alls.
+// the lines form (k_scale_yuvl.hip).  Context level: which contexts MAY take it — the ones no walker of the table serves (a ratio beyond the
+// band walker's 6.1 : 1, range conversion, filters its tables do not hold, a 4:4:4 end, full-chroma RGB) and whose horizontal axis shrinks
+// by two at least (the lines frame is srcH x dstW samples; measured against the tiled kernel, profiles/r04_lines.txt), or every context the
+// tiled kernel has no tiling for.  GMAT_LINES=0: never, 2: wherever the table reaches it.  Such a context owns its lines frame.
+static bool lines_context(const GmatSwsContext *c)
+{
+    if (c->mode != MODE_SCALE || !c->yuvReady || !c->yl.ok || c->fused != 2) return false;
+    if (c->ytiling.TW == 0) return true;
+    const char *kn = GMAT_KNOB("GMAT_LINES");
+    const int mode = kn ? atoi(kn) : 1;
+    if (mode != 1) return mode == 2;
+    const bool walker = !c->rangeConv && (c->y2s.ok || c->y2p.ok || c->y2p.ok444 || c->y1x2.ok || c->y3x1.ok || c->y3x2.ok || c->y3r.ok || c->y32r.ok ||
+                                          c->y4r.ok || c->y4x1.ok || c->y2x.ok || c->yg.ok || c->yu.ok);
+    // NV12 <-> YUV420P within the band walker's range: the cascade (a sibling context in the source's layout on a walker + the re-layout) keeps it
+    const bool crossWalk = is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat) && c->srcFormat != c->dstFormat && !c->rangeConv &&
+                           10 * c->srcW <= 61 * c->dstW && 10 * c->srcH <= 61 * c->dstH;
+    return !walker && !crossWalk && c->srcW >= 2 * c->dstW;
+}
+// frame level: dword-aligned source planes (the windows are read as aligned dwords), 8-bit destinations
+static bool yuvl_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    if (!lines_context(c) || ya.prof || ya.src16 || ya.dst16 || ya.dither8) return false;
+    uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
+    if (!ya.nv12) all |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
+    return (all & 3) == 0;
+}
+static int lines_prepare(GmatSwsContext *c, int nframes)
+{
+    if (c->linesFrames < nframes) {
+        if (c->linesBuf) { (void)hipFree(c->linesBuf); c->linesBuf = nullptr; c->linesFrames = 0; }
+        GMAT_HIP_CHECK(hipMalloc((void **)&c->linesBuf, c->yl.frameInts * sizeof(int32_t) * nframes));
+        c->linesFrames = nframes;
+    }
+    return 0;
+}
+static YuvLArgs make_yuvl_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    YuvLArgs l = c->largs;
+    l.ys = ya.ys; l.us = ya.us; l.vs = ya.vs; l.nv12 = ya.nv12;
+    l.srcW = ya.srcW; l.srcH = ya.srcH; l.chrSrcW = ya.chrSrcW; l.chrSrcH = ya.chrSrcH;
+    l.dstW = ya.dstW; l.dstH = ya.dstH; l.chrDstW = ya.chrDstW; l.chrDstH = c->planYuv.chrDstH;
+    l.ds = ya.ds; l.dsU = ya.dsU; l.dsV = ya.dsV; l.dstFormat = ya.dstFormat; l.dstAligned = ya.dstAligned; l.dstNv12 = ya.dstNv12;
+    l.rangeConv = ya.rangeConv;
+    l.vLum = ya.vLum; l.vChr = ya.vChr; l.y2r = ya.y2r;
+    l.inter = c->linesBuf;
+    return l;
+}
+
 struct PlaneKernel {
     bool (*eligible)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);      // n: frames of the whole call
     const char *(*name)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);
@@ -928,9 +999,17 @@ static const PlaneKernel kPlaneKernels[] = {
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvl_eligible(c, ya); },                                    // what no walker takes: the lines form
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         GmatSwsContext *m = const_cast<GmatSwsContext *>(c);             // (the lines frame is allocated on first use and grows with the launch)
+         if (int r = lines_prepare(m, n); r < 0) return r;
+         m->interTouched = true;
+         return launch_scale_yuvl(make_yuvl_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *, const YuvScaleArgs &, int) { return true; },      // everything else: the tiled plane scaler
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         if (c->ytiling.TW == 0) return GMAT_ERR(ENOSYS);                 // no tiling fits the LDS and this frame's planes are not the lines form's
          return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
 };
 constexpr int kNumPlaneKernels = (int)(sizeof(kPlaneKernels) / sizeof(kPlaneKernels[0]));
@@ -998,8 +1077,13 @@ static bool stream_is_capturing(hipStream_t s)
 // contexts whose calls may write a buffer the context owns: the modes with an intermediate, and NV12 <-> YUV420P scaled (the cascade's crossBuf)
 static bool owns_intermediates(const GmatSwsContext *c)
 {
-    return sws_shares_intermediate(c) ||
+    return sws_shares_intermediate(c) || lines_context(c) ||
            (c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat) && c->srcFormat != c->dstFormat);
+}
+// lines_context() reads tables the first call builds: they are built before the ownership question is asked
+static void lines_ready(GmatSwsContext *c)
+{
+    if (c && c->mode == MODE_SCALE && !c->yuvReady && is_yuv8_src(c->srcFormat) && (c->fused == 2 || !is_yuv420(c->srcFormat))) (void)ensure_scaler(c);
 }
 // before a call's first launch: `s` waits for the last use of the intermediates if that was on another stream.  Captured work is ordered by its
 // graph (gmat_sws_graph_create keeps such contexts on one branch and synchronises before it captures).
@@ -1077,6 +1161,7 @@ int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src
                              uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream)
 {
     if (!c || n < 2) return 0;
+    lines_ready(c);
     const bool own = owns_intermediates(c);
     if (own)
         if (int r = stream_handoff_acquire(c, stream); r < 0) return r;
@@ -1423,7 +1508,7 @@ hipEvent_t *sws_batch_events(GmatSwsContext *c)
     return c->batchEv;
 }
 void *sws_current_stream(const GmatSwsContext *c) { return c ? (void *)c->stream : nullptr; }
-bool sws_owns_intermediates(const GmatSwsContext *c) { return c && owns_intermediates(c); }
+bool sws_owns_intermediates(const GmatSwsContext *c) { lines_ready(const_cast<GmatSwsContext *>(c)); return c && owns_intermediates(c); }
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
@@ -1851,6 +1936,7 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
 int gmat_sws_scale(GmatSwsContext *c, const uint8_t *const src[], const int srcStride[], int srcSliceY,
                    int srcSliceH, uint8_t *const dst[], const int dstStride[])
 {
+    lines_ready(c);
     if (!c || !owns_intermediates(c)) return sws_scale_impl(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);
     if (int r = stream_handoff_acquire(c, c->stream); r < 0) return r;
     const int h = sws_scale_impl(c, src, srcStride, srcSliceY, srcSliceH, dst, dstStride);

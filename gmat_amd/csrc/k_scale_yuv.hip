@@ -779,7 +779,10 @@ int yuvscale_prepare(const ScalePlan &p, YuvScaleTiling &t)
             return 0;
         }
     }
-    return GMAT_ERR(ENOSYS);
+    // no tile's window fits a workgroup's LDS (a one-row tile beyond ~ 20 : 1): TW = 0 — the context lives if the lines form (k_scale_yuvl.hip)
+    // serves it (init_yuv_scaler), and the tiled kernel's place in the table answers ENOSYS
+    t.TW = 0; t.TH = 0; t.ntx = 0; t.nty = 0; t.ldsBytes = 0;
+    return 0;
 }
 
 const char *yuvscale_kernel_name(const YuvScaleTiling &t)

@@ -1,0 +1,398 @@
+// k_scale_yuvl.hip — the LINES form of libswscale's generic scaler for 8-bit YUV sources (NV12, YUV420P, YUV444P): two launches through a
+// frame of horizontally filtered 15-bit lines.  Round 4.  Integer arithmetic, bit-exact with ONE libswscale context:
+//   pass H   hScale8To15_c: min(sum(src * f) >> 7, 32767) of EVERY source row of the three planes          swscale.c:122-136
+//            (+ lum / chrRangeTo / FromJpeg_c on the lines, as hscale.c:60,193 applies them)                 swscale.c:157-188
+//   pass V   the vertical filters + the output stage of k_scale_yuv.hip's phase 3, the same expressions:
+//            yuv2rgb_X_c / _2_c / _1_c + the yuv2rgb.c tables' closed form, yuv2rgb_full_X_c + yuv2rgb_write_full,
+//            yuv2planeX_8_c / yuv2nv12cX_c                                                                  output.c:400-450,1680-2200
+// What it is for: the down-scales no walker takes — beyond 6.1 : 1 (a 4K frame to a thumbnail: 4 r taps an axis at r : 1), filters the band
+// walker's tables do not hold, range conversion — which the LDS-tiled kernel serves at 0.03 - 0.1 of the roofline because a tile's window
+// grows with the ratio on BOTH axes (4K -> 640 x 360 rgb24: 63 us a frame), and which it REFUSED once a one-row tile's window passed 64 KB
+// (beyond ~ 20 : 1).  A large down-scale is a reduction: the work is the horizontal pass (4 multiply-adds per SOURCE byte whatever the
+// ratio) and its output is small (srcH x dstW samples), so the lines go through HBM / the L2 instead of LDS:
+//   pass H   a lane owns ONE output column for a run of source row pairs: its coefficient pairs stay in registers (re-based on the host to
+//            the 4-byte aligned window start, so the bytes -> int16 pairs step is two v_perm_b32 a dword and nothing else), the window is
+//            read straight from the row (adjacent lanes' windows overlap 4 x: L1 hits), two rows at a time, one packed (row 2p, row 2p + 1)
+//            dword out;
+//   pass V   a lane owns four adjacent outputs of one row; the vertical coefficients are wave-uniform scalar loads, the lines 16-byte loads.
+// HBM per 4K -> 480 x 270 rgb24 frame: 12.4 MB in, 0.4 MB out, 3.1 MB of lines written once and read ~ 4 x from the L2.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+namespace gmat {
+
+__device__ __forceinline__ unsigned l_pk16(int lo, int hi) { return ((unsigned)lo & 0xFFFF) | ((unsigned)hi << 16); }
+
+// bytes 0,1 / 2,3 of a dword as an int16 pair; the U / V samples of two interleaved chroma pairs
+__device__ __forceinline__ int pair_lo(unsigned d) { return (int)__builtin_amdgcn_perm(0u, d, 0x0c010c00u); }
+__device__ __forceinline__ int pair_hi(unsigned d) { return (int)__builtin_amdgcn_perm(0u, d, 0x0c030c02u); }
+__device__ __forceinline__ int pair_u(unsigned d)  { return (int)__builtin_amdgcn_perm(0u, d, 0x0c020c00u); }
+__device__ __forceinline__ int pair_v(unsigned d)  { return (int)__builtin_amdgcn_perm(0u, d, 0x0c030c01u); }
+
+__device__ __forceinline__ int l_lum_range(int v, int rc)
+{
+    if (rc == 1) return (m24(min(v, 30189), 19077) - 39057361) >> 14;      // lumRangeToJpeg_c, swscale.c:176-181
+    if (rc == 2) return (m24(v, 14071) + 33561947) >> 14;                  // lumRangeFromJpeg_c, :183-188
+    return v;
+}
+__device__ __forceinline__ int l_chr_range(int v, int rc)
+{
+    if (rc == 1) return (m24(min(v, 30775), 4663) - 9289992) >> 12;        // chrRangeToJpeg_c, swscale.c:157-164
+    if (rc == 2) return (m24(v, 1799) + 4081085) >> 11;                    // chrRangeFromJpeg_c, :166-173
+    return v;
+}
+
+// ---- pass H ----------------------------------------------------------------------------------------------------------------------------
+// A plane as a raw buffer resource: the lane's window offset in a loop-invariant VGPR, the dword index in the instruction's offset field, the
+// row offset in its scalar offset — no vector ALU per load — and a dword past the plane's last one reads as 0 (a window re-based to a 4-byte
+// aligned start may overhang the row's last whole dword by its padding taps, whose coefficients are zero).
+struct LPlane {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ LPlane(const uint8_t *p, unsigned bytes, unsigned) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000)) {}
+    __device__ __forceinline__ unsigned ld(unsigned off, unsigned row) const { return __builtin_amdgcn_raw_buffer_load_b32(r, off, row, 0); }
+#else
+    // hipcc's host pass (never executed) and the CPU emulation of the test suite: the descriptor's range check restated
+    const uint8_t *p; unsigned n;
+    __host__ __device__ LPlane(const uint8_t *q, unsigned bytes, unsigned) : p(q), n(bytes) {}
+    __host__ __device__ unsigned ld(unsigned off, unsigned row) const { unsigned v = 0; if ((size_t)row + off + 4 <= n) std::memcpy(&v, p + (size_t)row + off, 4); return v; }
+#endif
+};
+
+// One wave = one ITEM: 64 output columns of a plane x `rp` source row pairs.  Items of a frame, in order: luma [0, nItemL), then the chroma
+// planes — interleaved chroma: [nItemL, nItemL + nItemC) makes U and V lines together; planar: U items, then V items.
+// P = coefficient pairs a lane holds (the context's longest re-based filter, rounded up to an instance).
+template <int P>
+__device__ __forceinline__ void hline_bytes(const LPlane &pl, unsigned row0, unsigned row1, unsigned off, const int (&cf)[P], int &s0, int &s1)
+{
+    unsigned d0[P / 2], d1[P / 2];
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) { d0[j] = pl.ld(off + 4u * j, row0); d1[j] = pl.ld(off + 4u * j, row1); }
+    s0 = 0; s1 = 0;
+#pragma unroll
+    for (int j = 0; j < P / 2; j++) {
+        s0 = dot2(pair_lo(d0[j]), cf[2 * j], s0); s0 = dot2(pair_hi(d0[j]), cf[2 * j + 1], s0);
+        s1 = dot2(pair_lo(d1[j]), cf[2 * j], s1); s1 = dot2(pair_hi(d1[j]), cf[2 * j + 1], s1);
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void hline_uv(const LPlane &pl, unsigned row, unsigned off, const int (&cf)[P], int &su, int &sv)
+{
+    unsigned d[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) d[j] = pl.ld(off + 4u * j, row);
+    su = 0; sv = 0;
+#pragma unroll
+    for (int j = 0; j < P; j++) { su = dot2(pair_u(d[j]), cf[j], su); sv = dot2(pair_v(d[j]), cf[j], sv); }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void scale_yuvl_h_kernel(YuvLArgs a, Yuv2xFrames fr)
+{
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (item >= a.nItem) return;
+    int32_t *inter = a.inter + (size_t)f * a.frameInts;
+    const bool lumaJob = item < a.nItemL;
+    const int  cjob = lumaJob ? 0 : item - a.nItemL;
+    const bool vPlane = !lumaJob && !a.nv12 && cjob >= a.nItemC;              // planar chroma: the V plane's items
+    const int  it = lumaJob ? item : vPlane ? cjob - a.nItemC : cjob;
+    const int  ncol = lumaJob ? a.nColL : a.nColC;
+    const int  chunk = it / ncol, cg = it - chunk * ncol;
+    const int  W = lumaJob ? a.dstW : a.chrDstW, H = lumaJob ? a.srcH : a.chrSrcH;
+    const int  pitch = lumaJob ? a.pitchL : a.pitchC, pairRows = lumaJob ? a.pairRowsL : a.pairRowsC;
+    const int  gx = min(cg * 64 + lane, W - 1);
+    const int32_t *tab = lumaJob ? a.hL : a.hC;
+    const unsigned off = (unsigned)(lumaJob ? a.offL : a.offC)[gx];
+    int cf[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) cf[k] = tab[(size_t)gx * P + k];
+    const int p0 = chunk * a.rp, p1 = min(p0 + a.rp, pairRows);
+    const int rc = a.rangeConv;
+    const bool bytePlane = lumaJob || !a.nv12;
+    const uint8_t *plane = lumaJob ? fr.y[f] : vPlane ? fr.v[f] : fr.u[f];
+    const unsigned stride = (unsigned)(lumaJob ? a.ys : vPlane ? a.vs : a.us);
+    const unsigned rowBytes = (unsigned)(lumaJob ? a.srcW : a.nv12 ? 2 * a.chrSrcW : a.chrSrcW);
+    const unsigned lastDw = (rowBytes - 1) & ~3u;
+    const LPlane pl(plane, (unsigned)(H - 1) * stride + lastDw + 4u, lastDw);
+
+    if (bytePlane) {
+        int32_t *out = inter + (lumaJob ? 0 : vPlane ? a.baseV : a.baseU) + cg * 64 + lane;
+        for (int p = p0; p < p1; p++) {
+            int s0, s1;
+            hline_bytes<P>(pl, (unsigned)(2 * p) * stride, (unsigned)min(2 * p + 1, H - 1) * stride, off, cf, s0, s1);
+            int l0 = min(s0 >> 7, 32767), l1 = min(s1 >> 7, 32767);
+            if (rc) {
+                if (lumaJob) { l0 = l_lum_range(l0, rc); l1 = l_lum_range(l1, rc); }
+                else         { l0 = l_chr_range(l0, rc); l1 = l_chr_range(l1, rc); }
+            }
+            out[(size_t)p * pitch] = (int)l_pk16(l0, l1);
+        }
+    } else {
+        int32_t *outU = inter + a.baseU + cg * 64 + lane, *outV = inter + a.baseV + cg * 64 + lane;
+        for (int p = p0; p < p1; p++) {
+            int u0, v0, u1, v1;
+            hline_uv<P>(pl, (unsigned)(2 * p) * stride, off, cf, u0, v0);
+            hline_uv<P>(pl, (unsigned)min(2 * p + 1, H - 1) * stride, off, cf, u1, v1);
+            u0 = min(u0 >> 7, 32767); u1 = min(u1 >> 7, 32767); v0 = min(v0 >> 7, 32767); v1 = min(v1 >> 7, 32767);
+            if (rc) { u0 = l_chr_range(u0, rc); u1 = l_chr_range(u1, rc); v0 = l_chr_range(v0, rc); v1 = l_chr_range(v1, rc); }
+            outU[(size_t)p * pitch] = (int)l_pk16(u0, u1);
+            outV[(size_t)p * pitch] = (int)l_pk16(v0, v1);
+        }
+    }
+}
+
+// ---- pass V ----------------------------------------------------------------------------------------------------------------------------
+// MODE 0: packed RGB, half chroma (LUT form)   1: packed RGB, full chroma   2: YUV 4:2:0 (NV12 / YUV420P)   3: planar YUV 4:4:4
+// A block = 4 output rows x 256 columns (a wave a row, a lane four adjacent outputs); MODE 2: its 2 chroma rows x 128 columns after them,
+// a thread a column.
+template <int MODE>
+__global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFrames fr)
+{
+    constexpr bool FULL = MODE == 1 || MODE == 3;
+    constexpr bool YUVOUT = MODE >= 2;
+    const int f = blockIdx.y;
+    const int32_t *inter = a.inter + (size_t)f * a.frameInts;
+    const int32_t *hy = inter, *hu = inter + a.baseU, *hv = inter + a.baseV;
+    uint8_t *dst = fr.dst[f], *dstU = fr.dstU[f], *dstV = fr.dstV[f];
+    const int brow = blockIdx.x / a.nColV, bcol = blockIdx.x - brow * a.nColV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int yo = __builtin_amdgcn_readfirstlane(brow * 4 + wave);
+    const int xo = bcol * 256 + 4 * lane;
+    const DevFilter &VL = a.vLum, &VC = a.vChr;
+
+    if (yo < a.dstH && xo < a.dstW) {
+        const int vpL = uniform_load(VL.pos_even, yo) >> 1, lr = uniform_load(VL.round, yo);
+        int Y[4] = {lr, lr, lr, lr};
+        const int32_t *ly = hy + (size_t)vpL * a.pitchL + xo;
+#pragma unroll 4
+        for (int k = 0; k < VL.pairs; k++) {
+            const int cf = uniform_load(VL.packed, yo * VL.pairs + k);
+            const int4 v = *reinterpret_cast<const int4 *>(ly + (size_t)k * a.pitchL);
+            Y[0] = dot2(v.x, cf, Y[0]); Y[1] = dot2(v.y, cf, Y[1]); Y[2] = dot2(v.z, cf, Y[2]); Y[3] = dot2(v.w, cf, Y[3]);
+        }
+        const int nx = min(4, a.dstW - xo);
+        if (YUVOUT) {
+            // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
+            uint8_t *d = dst + (size_t)yo * a.ds + xo;
+            const unsigned o = (unsigned)clip_u8_shr(Y[0], 19) | ((unsigned)clip_u8_shr(Y[1], 19) << 8) |
+                               ((unsigned)clip_u8_shr(Y[2], 19) << 16) | ((unsigned)clip_u8_shr(Y[3], 19) << 24);
+            if (a.dstAligned && nx == 4) *reinterpret_cast<unsigned *>(d) = o;
+            else for (int i = 0; i < nx; i++) d[i] = (uint8_t)(o >> (8 * i));
+        } else {
+            const int vpC = uniform_load(VC.pos_even, yo) >> 1, cr = uniform_load(VC.round, yo);
+            unsigned px[4];
+            if (FULL) {
+                int U[4] = {cr, cr, cr, cr}, V[4] = {cr, cr, cr, cr};
+                const int32_t *lu = hu + (size_t)vpC * a.pitchC + xo, *lv = hv + (size_t)vpC * a.pitchC + xo;
+#pragma unroll 4
+            for (int k = 0; k < VC.pairs; k++) {
+                    const int cf = uniform_load(VC.packed, yo * VC.pairs + k);
+                    const int4 u = *reinterpret_cast<const int4 *>(lu + (size_t)k * a.pitchC);
+                    const int4 v = *reinterpret_cast<const int4 *>(lv + (size_t)k * a.pitchC);
+                    U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
+                    V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) px[i] = yuv_to_rgb_full(a.y2r, Y[i] >> 10, U[i] >> 10, V[i] >> 10);
+            } else {
+                int U[2] = {cr, cr}, V[2] = {cr, cr};
+                const int32_t *lu = hu + (size_t)vpC * a.pitchC + (xo >> 1), *lv = hv + (size_t)vpC * a.pitchC + (xo >> 1);
+#pragma unroll 4
+            for (int k = 0; k < VC.pairs; k++) {
+                    const int cf = uniform_load(VC.packed, yo * VC.pairs + k);
+                    const uint2 u = *reinterpret_cast<const uint2 *>(lu + (size_t)k * a.pitchC);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(lv + (size_t)k * a.pitchC);
+                    U[0] = dot2((int)u.x, cf, U[0]); U[1] = dot2((int)u.y, cf, U[1]);
+                    V[0] = dot2((int)v.x, cf, V[0]); V[1] = dot2((int)v.y, cf, V[1]);
+                }
+                // table_rV / gU / gV / bU are indexed with av_clip_uint8 (yuv2rgb.c:737-760)
+                const ChromaTerms t0 = chroma_terms(a.y2r, clip_u8_shr(U[0], 19), clip_u8_shr(V[0], 19));
+                const ChromaTerms t1 = chroma_terms(a.y2r, clip_u8_shr(U[1], 19), clip_u8_shr(V[1], 19));
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int ya = m24(Y[i] >> 19, a.y2r.cy), yb = m24(Y[i + 2] >> 19, a.y2r.cy);
+                    px[i]     = (unsigned)luma_chan(t0.r, ya) | ((unsigned)luma_chan(t0.g, ya) << 8) | ((unsigned)luma_chan(t0.b, ya) << 16);
+                    px[i + 2] = (unsigned)luma_chan(t1.r, yb) | ((unsigned)luma_chan(t1.g, yb) << 8) | ((unsigned)luma_chan(t1.b, yb) << 16);
+                }
+            }
+            const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+            const bool swap_rb = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                unsigned c = px[i];
+                if (swap_rb) c = ((c & 0xFF) << 16) | (c & 0xFF00) | ((c >> 16) & 0xFF);
+                px[i] = c | 0xFF000000u;
+            }
+            uint8_t *d = dst + (size_t)yo * a.ds + (size_t)xo * bpp;
+            if (a.dstAligned && nx == 4) {
+                if (bpp == 4) *reinterpret_cast<uint4 *>(d) = make_uint4(px[0], px[1], px[2], px[3]);
+                else {
+                    uint3 o3;
+                    o3.x = (px[0] & 0xFFFFFF) | (px[1] << 24);
+                    o3.y = ((px[1] >> 8) & 0xFFFF) | (px[2] << 16);
+                    o3.z = ((px[2] >> 16) & 0xFF) | (px[3] << 8);
+                    *reinterpret_cast<uint3 *>(d) = o3;
+                }
+            } else {
+                for (int i = 0; i < nx; i++) {
+                    d[i * bpp + 0] = (uint8_t)px[i]; d[i * bpp + 1] = (uint8_t)(px[i] >> 8); d[i * bpp + 2] = (uint8_t)(px[i] >> 16);
+                    if (bpp == 4) d[i * bpp + 3] = 255;
+                }
+            }
+        }
+    }
+    if (YUVOUT) {
+        // chroma: MODE 2: rows brow * 2 + (wave >> 1), 128 columns a row, a thread a column; MODE 3: the luma rows' own geometry, a thread 4 columns
+        constexpr int CVS = MODE == 2 ? 1 : 0;
+        const int cy = __builtin_amdgcn_readfirstlane(CVS ? brow * 2 + (wave >> 1) : brow * 4 + wave);
+        if (cy >= a.chrDstH) return;
+        const int vp = uniform_load(VC.pos_even, cy) >> 1, rnd = uniform_load(VC.round, cy);
+        if (CVS) {
+            const int cx = bcol * 128 + (threadIdx.x & 127);
+            if (cx >= a.chrDstW) return;
+            int U = rnd, V = rnd;
+            const int32_t *lu = hu + (size_t)vp * a.pitchC + cx, *lv = hv + (size_t)vp * a.pitchC + cx;
+#pragma unroll 4
+            for (int k = 0; k < VC.pairs; k++) {
+                const int cf = uniform_load(VC.packed, cy * VC.pairs + k);
+                U = dot2(lu[(size_t)k * a.pitchC], cf, U);
+                V = dot2(lv[(size_t)k * a.pitchC], cf, V);
+            }
+            const unsigned ub = (unsigned)clip_u8_shr(U, 19), vb = (unsigned)clip_u8_shr(V, 19);
+            if (a.dstNv12) {
+                uint8_t *d = dstU + (size_t)cy * a.dsU + 2 * cx;
+                if (a.dstAligned) *reinterpret_cast<unsigned short *>(d) = (unsigned short)(ub | (vb << 8));
+                else { d[0] = (uint8_t)ub; d[1] = (uint8_t)vb; }
+            } else {
+                dstU[(size_t)cy * a.dsU + cx] = (uint8_t)ub;
+                dstV[(size_t)cy * a.dsV + cx] = (uint8_t)vb;
+            }
+        } else {
+            if (xo >= a.chrDstW) return;
+            int U[4] = {rnd, rnd, rnd, rnd}, V[4] = {rnd, rnd, rnd, rnd};
+            const int32_t *lu = hu + (size_t)vp * a.pitchC + xo, *lv = hv + (size_t)vp * a.pitchC + xo;
+#pragma unroll 4
+            for (int k = 0; k < VC.pairs; k++) {
+                const int cf = uniform_load(VC.packed, cy * VC.pairs + k);
+                const int4 u = *reinterpret_cast<const int4 *>(lu + (size_t)k * a.pitchC);
+                const int4 v = *reinterpret_cast<const int4 *>(lv + (size_t)k * a.pitchC);
+                U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
+                V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+            }
+            const int nx = min(4, a.chrDstW - xo);
+            uint8_t *du = dstU + (size_t)cy * a.dsU + xo, *dv = dstV + (size_t)cy * a.dsV + xo;
+            const unsigned ou = (unsigned)clip_u8_shr(U[0], 19) | ((unsigned)clip_u8_shr(U[1], 19) << 8) | ((unsigned)clip_u8_shr(U[2], 19) << 16) | ((unsigned)clip_u8_shr(U[3], 19) << 24);
+            const unsigned ov = (unsigned)clip_u8_shr(V[0], 19) | ((unsigned)clip_u8_shr(V[1], 19) << 8) | ((unsigned)clip_u8_shr(V[2], 19) << 16) | ((unsigned)clip_u8_shr(V[3], 19) << 24);
+            if (a.dstAligned && nx == 4) { *reinterpret_cast<unsigned *>(du) = ou; *reinterpret_cast<unsigned *>(dv) = ov; }
+            else for (int i = 0; i < nx; i++) { du[i] = (uint8_t)(ou >> (8 * i)); dv[i] = (uint8_t)(ov >> (8 * i)); }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static const int kLineInstances[] = {8, 12, 16, 20, 24, 32, 40, 48, 56, 68};
+
+// coefficient pairs of a byte plane's filter re-based to the 4-byte aligned window start pos & ~3 (up to three leading zero taps)
+static void rebase4(const FilterBank &fb, int P, std::vector<int32_t> &tab, std::vector<int32_t> &off)
+{
+    tab.assign((size_t)fb.count * P, 0);
+    off.resize(fb.count);
+    for (int i = 0; i < fb.count; i++) {
+        const int lead = fb.pos[i] & 3;
+        off[i] = fb.pos[i] & ~3;
+        int16_t w[2 * 68] = {0};
+        for (int t = 0; t < fb.taps; t++) w[lead + t] = fb.coef[(size_t)i * fb.taps + t];
+        for (int k = 0; k < P; k++) tab[(size_t)i * P + k] = (int32_t)(((uint32_t)(uint16_t)w[2 * k]) | ((uint32_t)(uint16_t)w[2 * k + 1] << 16));
+    }
+}
+
+int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
+{
+    t = YuvLTables();
+    if (!is_yuv8_src(p.srcFormat)) return 0;
+    if (!(is_packed_rgb(p.dstFormat) || is_yuv420(p.dstFormat) || p.dstFormat == GMAT_PIX_FMT_YUV444P)) return 0;
+    if (p.hLum.taps > 128 || p.hChr.taps > 128) return 0;
+    const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
+    // pairs a lane holds: byte planes on their 4-byte aligned windows, interleaved chroma on its pos_even windows (as FilterBank::packed)
+    int need = (p.hLum.taps + 3 + 1) / 2;
+    need = std::max(need, nv12 ? p.hChr.pairs : (p.hChr.taps + 3 + 1) / 2);
+    int P = 0;
+    for (int v : kLineInstances) if (v >= need) { P = v; break; }
+    if (!P) return 0;
+    t.P = P;
+    rebase4(p.hLum, P, t.hL, t.offL);
+    if (nv12) {
+        t.hC.assign((size_t)p.hChr.count * P, 0);
+        t.offC.resize(p.hChr.count);
+        for (int i = 0; i < p.hChr.count; i++) {
+            t.offC[i] = 2 * p.hChr.pos_even[i];                   // bytes into the interleaved row
+            for (int k = 0; k < p.hChr.pairs; k++) t.hC[(size_t)i * P + k] = p.hChr.packed[(size_t)i * p.hChr.pairs + k];
+        }
+    } else rebase4(p.hChr, P, t.hC, t.offC);
+    // windows start in column order (the kernel's edge test reads the wave's last lane)
+    for (size_t i = 1; i < t.offL.size(); i++) if (t.offL[i] < t.offL[i - 1]) return 0;
+    for (size_t i = 1; i < t.offC.size(); i++) if (t.offC[i] < t.offC[i - 1]) return 0;
+    t.yuvOut = g.yuvOut; t.fullChroma = g.fullChroma;
+    t.pitchL = align_up(p.dstW, 64); t.pitchC = align_up(p.chrDstW, 64);
+    t.pairRowsL = (p.srcH + 1) / 2; t.pairRowsC = (p.chrSrcH + 1) / 2;
+    // rows the frame holds: a vertical window's padded pairs may end one row pair past the plane (zero coefficients: the rows are never written)
+    int rowsL = t.pairRowsL, rowsC = t.pairRowsC;
+    for (int i = 0; i < g.vLumEff.count; i++) rowsL = std::max(rowsL, g.vLumEff.pos_even[i] / 2 + g.vLumEff.pairs);
+    for (int i = 0; i < g.vChrEff.count; i++) rowsC = std::max(rowsC, g.vChrEff.pos_even[i] / 2 + g.vChrEff.pairs);
+    t.baseU = (size_t)rowsL * t.pitchL;
+    t.baseV = t.baseU + (size_t)rowsC * t.pitchC;
+    t.frameInts = t.baseV + (size_t)rowsC * t.pitchC;
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || !a0.inter) return GMAT_ERR(EINVAL);
+    YuvLArgs a = a0;
+    const Yuv2xFrames &fr = *frames;
+    a.nColL = a.pitchL / 64; a.nColC = a.pitchC / 64;
+    // row pairs a wave: long runs amortise the lane's coefficient loads, short ones fill the chip
+    const char *rpStr = GMAT_KNOB("GMAT_LINES_RP");
+    int rp = rpStr ? std::max(1, atoi(rpStr)) : 8;
+    if (!rpStr) while (rp > 2 && (long)a.nColL * ((a.pairRowsL + rp - 1) / rp) * nframes < 2048) rp >>= 1;
+    a.rp = rp;
+    a.nItemL = a.nColL * ((a.pairRowsL + rp - 1) / rp);
+    a.nItemC = a.nColC * ((a.pairRowsC + rp - 1) / rp);
+    a.nItem = a.nItemL + (a.nv12 ? 1 : 2) * a.nItemC;
+    {
+        const dim3 grid((a.nItem + 3) / 4, nframes), block(256);
+        switch (a.P) {
+#define GMAT_LH(P_) case P_: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_>), grid, block, 0, stream, a, fr); break
+        GMAT_LH(8); GMAT_LH(12); GMAT_LH(16); GMAT_LH(20); GMAT_LH(24); GMAT_LH(32); GMAT_LH(40); GMAT_LH(48); GMAT_LH(56); GMAT_LH(68);
+#undef GMAT_LH
+        default: return GMAT_ERR(EINVAL);
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+    }
+    {
+        a.nColV = (a.dstW + 255) / 256;
+        const dim3 grid(a.nColV * ((a.dstH + 3) / 4), nframes), block(256);
+        const int mode = a.yuvOut == 2 ? 3 : a.yuvOut ? 2 : a.fullChroma ? 1 : 0;
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_v_kernel<0>), grid, block, 0, stream, a, fr); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_v_kernel<1>), grid, block, 0, stream, a, fr); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_v_kernel<2>), grid, block, 0, stream, a, fr); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_v_kernel<3>), grid, block, 0, stream, a, fr); break;
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+} // namespace gmat

@@ -388,6 +388,33 @@ struct YuvUArgs {
 int  yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvUTables &t);
 int  launch_scale_yuvu(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
+// ---- the LINES form (k_scale_yuvl.hip, round 4): two launches through a frame of horizontally filtered 15-bit lines in HBM — the down-scales
+// no walker takes (beyond 6.1 : 1, range conversion, filters the band walker's tables do not hold), which the tiled kernel served at 0.03 - 0.1 of
+// the roofline and refused beyond ~ 20 : 1.  8-bit YUV sources (NV12, YUV420P, YUV444P) -> packed RGB (half / full chroma), 8-bit 4:2:0, YUV444P.
+struct YuvLTables {
+    int ok = 0, P = 0, yuvOut = 0, fullChroma = 0;
+    std::vector<int32_t> hL, hC;                              // [dstW][P] / [chrDstW][P] coefficient pairs on the window that starts at off*
+    std::vector<int32_t> offL, offC;                          // byte offset of a column's window in its source row (a multiple of 4)
+    int pitchL = 0, pitchC = 0, pairRowsL = 0, pairRowsC = 0; // the lines frame: dwords a row (a dword = rows 2p and 2p + 1 of one column), rows
+    size_t baseU = 0, baseV = 0, frameInts = 0;               // dword offsets of the U / V lines, dwords a frame
+};
+struct YuvLArgs {
+    int ys, us, vs, nv12;
+    int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
+    int ds, dsU, dsV, dstFormat, dstAligned, dstNv12, yuvOut, fullChroma, rangeConv;
+    int P;
+    const int32_t *hL, *hC, *offL, *offC;
+    int pitchL, pitchC, pairRowsL, pairRowsC;
+    size_t baseU, baseV, frameInts;
+    int32_t *inter;                                           // nframes lines frames
+    DevFilter vLum, vChr;                                     // the tiled kernel's: effective taps, per-row start values
+    // filled by the launcher
+    int nColL, nColC, rp, nItemL, nItemC, nItem, nColV;
+    Yuv2RgbConsts y2r;
+};
+int  yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvLTables &t);
+int  launch_scale_yuvl(const YuvLArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // ---- strip-walking form of the exact 2:1 YUV 4:2:0 -> YUV 4:2:0 scaler (k_scale_yuv2p.hip): NV12 -> NV12 and
 // YUV420P -> YUV420P, every plane walked on its own -------------------------------------------------------------------
 struct Yuv2pTables {

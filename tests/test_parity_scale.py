@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from harness import is_generic, PIX_FMT, SWS, synth_planes
+from harness import LINES
 
 
 def _check(dev, orc, src_fmt, sw, sh, dw, dh, dst_fmt, flags, fused=None, align=256, extra=0, seed=21):
@@ -188,7 +189,7 @@ def test_yuv_single_context_bicubic(dev, orc, src_fmt, geom):
     d_src = dev.upload_planes(src, 256)
     got, pads, kernel = dev.sws(d_src, sw, sh, src_fmt, dw, dh, "rgb24", SWS["bicubic"], dst_align=256)
     assert kernel.startswith("scale_yuv")
-    if is_generic(kernel):
+    if is_generic(kernel) and kernel != LINES:              # (the lines form's name does not carry its chroma form)
         assert ("full" in kernel) == bool(dw & 1)
     bad = np.argwhere(got[0] != want)
     assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
@@ -293,7 +294,7 @@ def test_yuv_to_yuv_scaled(dev, orc, src_fmt, dst_fmt, geom):
         if (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and strip_takes(sw, sh, src_fmt, dst_fmt):
             assert kernel == strip_name(src_fmt, dst_fmt), kernel
         else:
-            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", "scale_yuvu_kernel"), kernel
+            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", "scale_yuvu_kernel", LINES), kernel
         for i, (g, w) in enumerate(zip(got, want)):
             bad = np.argwhere(g != w)
             assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
@@ -414,7 +415,7 @@ def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
     if src_fmt in ("yuv420p", "nv12") and (sw, sh) == (2 * dw, 2 * dh) and sw % 16 == 0 and sw >= 64 and dh >= 16 and flags != "lanczos":
         assert kernel.startswith("scale_yuv2p_kernel<luma>"), kernel
     else:
-        assert is_generic(kernel) and "yuv444" in kernel, kernel
+        assert is_generic(kernel) and ("yuv444" in kernel or kernel == LINES), kernel
     assert len(got) == 3
     for i, (g, wv) in enumerate(zip(got, want)):
         bad = np.argwhere(g != wv)

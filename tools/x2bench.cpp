@@ -324,6 +324,20 @@ int main(int argc, char **argv)
         {"relayout: rgba 4K->rgb24", GMAT_PIX_FMT_RGBA, 3840, 2160, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
         {"relayout: nv12 4K->p010", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_SWS_BICUBIC},
         {"relayout: nv12 4K->yuv444p", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_SWS_BICUBIC},
+        // beyond every walker: the lines form (k_scale_yuvl.hip, round 4); "thumb:" cases run when the filter names them ("thumb")
+        {"thumb: nv12 4K->480x270 rgb24 bicubic (8:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 480, 270, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->480x270 nv12 bicubic (8:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 480, 270, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->320x180 rgb24 bicubic (12:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 320, 180, GMAT_SWS_BICUBIC},
+        {"thumb: yuv420p 4K->320x180 yuv420p bicubic (12:1)", GMAT_PIX_FMT_YUV420P, 3840, 2160, GMAT_PIX_FMT_YUV420P, 320, 180, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->160x90 rgb24 bicubic (24:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 160, 90, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->640x360 rgb24 bicubic (6:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 640, 360, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->854x480 rgb24 bicubic (4.5:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->1600x900 rgb24 bicubic (2.4:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 4K->1600x900 rgb24 lanczos (2.4:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_LANCZOS},
+        {"thumb: nv12 4K->854x480 rgb24 lanczos (4.5:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 854, 480, GMAT_SWS_LANCZOS},
+        {"thumb: nv12 1080p->240x136 rgb24 bicubic (8:1)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 240, 136, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 1080p->320x180 nv12 bicubic (6:1)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 320, 180, GMAT_SWS_BICUBIC},
+        {"thumb: nv12 1080p->1280x720 rgb24 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         // any ratio: the polyphase band walker (scale_yuvg_kernel); "any:" cases run when the filter names them or "any"
         {"any: nv12 4K->1600x900 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->1600x900 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1600, 900, GMAT_SWS_BICUBIC},
@@ -379,7 +393,8 @@ int main(int argc, char **argv)
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
         if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;
-        if (strstr(k.label, "relayout:") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
+        if (strstr(k.label, "relayout:") && !(*only && strstr(k.label, only))) continue;
+        if (strstr(k.label, "thumb:") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
     return 0;
