@@ -48,56 +48,61 @@ __device__ __forceinline__ int l_chr_range(int v, int rc)
 }
 
 // ---- pass H ----------------------------------------------------------------------------------------------------------------------------
-// A plane as a raw buffer resource: the lane's window offset in a loop-invariant VGPR, the dword index in the instruction's offset field, the
-// row offset in its scalar offset — no vector ALU per load — and a dword past the plane's last one reads as 0 (a window re-based to a 4-byte
-// aligned start may overhang the row's last whole dword by its padding taps, whose coefficients are zero).
+// A plane as a raw buffer resource: lane offset in a VGPR, row offset in the instruction's scalar offset, and a dword past the plane's last
+// one reads as 0 (a window re-based to a 4-byte aligned start may overhang the row's last whole dword by its padding taps, whose coefficients
+// are zero; the last lanes of a segment's 16-byte pieces overhang by more).
 struct LPlane {
 #if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ LPlane(const uint8_t *p, unsigned bytes, unsigned) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000)) {}
-    __device__ __forceinline__ unsigned ld(unsigned off, unsigned row) const { return __builtin_amdgcn_raw_buffer_load_b32(r, off, row, 0); }
+    __device__ __forceinline__ LPlane(const uint8_t *p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000)) {}
+    __device__ __forceinline__ uint4 ld16(unsigned off, unsigned row) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, row, 0); return make_uint4(v.x, v.y, v.z, v.w); }
 #else
     // hipcc's host pass (never executed) and the CPU emulation of the test suite: the descriptor's range check restated
     const uint8_t *p; unsigned n;
-    __host__ __device__ LPlane(const uint8_t *q, unsigned bytes, unsigned) : p(q), n(bytes) {}
-    __host__ __device__ unsigned ld(unsigned off, unsigned row) const { unsigned v = 0; if ((size_t)row + off + 4 <= n) std::memcpy(&v, p + (size_t)row + off, 4); return v; }
+    __host__ __device__ LPlane(const uint8_t *q, unsigned bytes) : p(q), n(bytes) {}
+    __host__ __device__ unsigned dw(size_t o) const { unsigned v = 0; if (o + 4 <= n) std::memcpy(&v, p + o, 4); return v; }
+    __host__ __device__ uint4 ld16(unsigned off, unsigned row) const { const size_t o = (size_t)row + off; return make_uint4(dw(o), dw(o + 4), dw(o + 8), dw(o + 12)); }
 #endif
 };
 
 // One wave = one ITEM: 64 output columns of a plane x `rp` source row pairs.  Items of a frame, in order: luma [0, nItemL), then the chroma
 // planes — interleaved chroma: [nItemL, nItemL + nItemC) makes U and V lines together; planar: U items, then V items.
-// P = coefficient pairs a lane holds (the context's longest re-based filter, rounded up to an instance).
-template <int P>
-__device__ __forceinline__ void hline_bytes(const LPlane &pl, unsigned row0, unsigned row1, unsigned off, const int (&cf)[P], int &s0, int &s1)
+// Per row pair: the wave reads the bytes its 64 windows span ONCE, 16 bytes a lane (kLineNld pieces of 1 KB at most; the first version read
+// every window dword by dword straight from the row: lanes r bytes apart, a quarter of the L1's rate — 12.4 us a 4K frame), through a
+// wave-private LDS image (no barrier: one wave, and the LDS runs a wave's instructions in order), the next pair's bytes in flight during this
+// pair's arithmetic.  P = coefficient pairs a lane holds (the context's longest re-based filter, rounded up to an instance).
+constexpr int kLineNld = 5;
+
+// N dwords of a window image, R dwords a read (the image address is a multiple of 4 R bytes: the host re-based the window so)
+template <int N, int R>
+__device__ __forceinline__ void read_window(const unsigned *w, unsigned (&d)[N])
 {
-    unsigned d0[P / 2], d1[P / 2];
+    static_assert(N % R == 0, "window dwords");
+    if constexpr (R == 4) {
 #pragma unroll
-    for (int j = 0; j < P / 2; j++) { d0[j] = pl.ld(off + 4u * j, row0); d1[j] = pl.ld(off + 4u * j, row1); }
-    s0 = 0; s1 = 0;
+        for (int j = 0; j < N / 4; j++) { const uint4 v = reinterpret_cast<const uint4 *>(w)[j]; d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+    } else if constexpr (R == 2) {
 #pragma unroll
-    for (int j = 0; j < P / 2; j++) {
-        s0 = dot2(pair_lo(d0[j]), cf[2 * j], s0); s0 = dot2(pair_hi(d0[j]), cf[2 * j + 1], s0);
-        s1 = dot2(pair_lo(d1[j]), cf[2 * j], s1); s1 = dot2(pair_hi(d1[j]), cf[2 * j + 1], s1);
+        for (int j = 0; j < N / 2; j++) { const uint2 v = reinterpret_cast<const uint2 *>(w)[j]; d[2 * j] = v.x; d[2 * j + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++) d[j] = w[j];
     }
 }
 
-template <int P>
-__device__ __forceinline__ void hline_uv(const LPlane &pl, unsigned row, unsigned off, const int (&cf)[P], int &su, int &sv)
-{
-    unsigned d[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) d[j] = pl.ld(off + 4u * j, row);
-    su = 0; sv = 0;
-#pragma unroll
-    for (int j = 0; j < P; j++) { su = dot2(pair_u(d[j]), cf[j], su); sv = dot2(pair_v(d[j]), cf[j], sv); }
-}
-
-template <int P>
+// RW: dwords a lane reads from the image at once in a byte plane's items (1 | 2 | 4: the windows start on 4 RW-byte boundaries; the interleaved
+// chroma items, whose lanes are twice as far apart, read 2 | 4 | 4) — a lane stride of r bytes read dword by dword is a 2-way bank conflict from
+// r = 8 on (measured: the LDS busy 62 % of the kernel, half of it conflicts); NLD: 1 KB pieces a row at most.
+template <int P, int RW, int NLD>
 __global__ __launch_bounds__(256) void scale_yuvl_h_kernel(YuvLArgs a, Yuv2xFrames fr)
 {
+    constexpr int RB = (P / 2) % RW == 0 ? RW : 1;                // byte planes: P / 2 dwords a row
+    constexpr int RU = RW == 1 ? 2 : (P % 4 == 0 ? 4 : 2);       // interleaved chroma: P dwords a row
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
     const int f = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
     if (item >= a.nItem) return;
     int32_t *inter = a.inter + (size_t)f * a.frameInts;
     const bool lumaJob = item < a.nItemL;
@@ -113,38 +118,82 @@ __global__ __launch_bounds__(256) void scale_yuvl_h_kernel(YuvLArgs a, Yuv2xFram
     const unsigned off = (unsigned)(lumaJob ? a.offL : a.offC)[gx];
     int cf[P];
 #pragma unroll
-    for (int k = 0; k < P; k++) cf[k] = tab[(size_t)gx * P + k];
+    for (int k = 0; k < P; k++) cf[k] = tab[(size_t)k * pitch + cg * 64 + lane];        // (pair k of every column: coalesced)
     const int p0 = chunk * a.rp, p1 = min(p0 + a.rp, pairRows);
     const int rc = a.rangeConv;
     const bool bytePlane = lumaJob || !a.nv12;
     const uint8_t *plane = lumaJob ? fr.y[f] : vPlane ? fr.v[f] : fr.u[f];
     const unsigned stride = (unsigned)(lumaJob ? a.ys : vPlane ? a.vs : a.us);
     const unsigned rowBytes = (unsigned)(lumaJob ? a.srcW : a.nv12 ? 2 * a.chrSrcW : a.chrSrcW);
-    const unsigned lastDw = (rowBytes - 1) & ~3u;
-    const LPlane pl(plane, (unsigned)(H - 1) * stride + lastDw + 4u, lastDw);
+    const LPlane pl(plane, (unsigned)(H - 1) * stride + ((rowBytes + 3u) & ~3u));
+    // the segment of a row the wave's windows span (they start in column order): [seg0, segEnd), seg0 on a 16-byte boundary of the row
+    const unsigned seg0 = (unsigned)__builtin_amdgcn_readlane((int)off, 0) & ~15u;
+    const unsigned segEnd = (unsigned)__builtin_amdgcn_readlane((int)off, 63) + (bytePlane ? 2u * P : 4u * P);
+    const int nld = __builtin_amdgcn_readfirstlane((int)((segEnd - seg0 + 1023u) >> 10));          // <= a.nld <= NLD (the host's maximum)
+    const unsigned rowDw = (unsigned)a.nld * 256u;
+    unsigned *img = reinterpret_cast<unsigned *>(lds_base) + (unsigned)wave * 2u * rowDw;
+    const unsigned lo = seg0 + 16u * lane;
+    // the window's place in the image, opaque per role: seen as ONE address in both roles' branches the compiler hoists the reads they share
+    // above the branch dword by dword, and the wide reads are gone
+    auto window = [&]() {
+        unsigned wo = (off - seg0) >> 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(wo));
+#endif
+        return (const unsigned *)(img + wo);
+    };
 
-    if (bytePlane) {
-        int32_t *out = inter + (lumaJob ? 0 : vPlane ? a.baseV : a.baseU) + cg * 64 + lane;
-        for (int p = p0; p < p1; p++) {
-            int s0, s1;
-            hline_bytes<P>(pl, (unsigned)(2 * p) * stride, (unsigned)min(2 * p + 1, H - 1) * stride, off, cf, s0, s1);
+    uint4 raw[2][NLD];
+    auto request = [&](int p) {
+        const unsigned r0 = (unsigned)(2 * p) * stride, r1 = (unsigned)min(2 * p + 1, H - 1) * stride;
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (i < nld && lo + 1024u * i < segEnd) { raw[0][i] = pl.ld16(lo + 1024u * i, r0); raw[1][i] = pl.ld16(lo + 1024u * i, r1); }
+    };
+    if (p0 < p1) request(p0);
+    for (int p = p0; p < p1; p++) {
+        __builtin_amdgcn_wave_barrier();         // (emulation: the lanes of a wave are fibers; on the GPU the LDS runs a wave's instructions in order)
+#pragma unroll
+        for (int i = 0; i < NLD; i++)
+            if (i < nld && lo + 1024u * i < segEnd) {
+                *reinterpret_cast<uint4 *>(img + 256 * i + 4 * lane) = raw[0][i];
+                *reinterpret_cast<uint4 *>(img + rowDw + 256 * i + 4 * lane) = raw[1][i];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (p + 1 < p1) request(p + 1);
+        if (bytePlane) {
+            const unsigned *win = window();
+            unsigned d0[P / 2], d1[P / 2];
+            read_window<P / 2, RB>(win, d0);
+            read_window<P / 2, RB>(win + rowDw, d1);
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int j = 0; j < P / 2; j++) {
+                s0 = dot2(pair_lo(d0[j]), cf[2 * j], s0); s0 = dot2(pair_hi(d0[j]), cf[2 * j + 1], s0);
+                s1 = dot2(pair_lo(d1[j]), cf[2 * j], s1); s1 = dot2(pair_hi(d1[j]), cf[2 * j + 1], s1);
+            }
             int l0 = min(s0 >> 7, 32767), l1 = min(s1 >> 7, 32767);
             if (rc) {
                 if (lumaJob) { l0 = l_lum_range(l0, rc); l1 = l_lum_range(l1, rc); }
                 else         { l0 = l_chr_range(l0, rc); l1 = l_chr_range(l1, rc); }
             }
-            out[(size_t)p * pitch] = (int)l_pk16(l0, l1);
-        }
-    } else {
-        int32_t *outU = inter + a.baseU + cg * 64 + lane, *outV = inter + a.baseV + cg * 64 + lane;
-        for (int p = p0; p < p1; p++) {
-            int u0, v0, u1, v1;
-            hline_uv<P>(pl, (unsigned)(2 * p) * stride, off, cf, u0, v0);
-            hline_uv<P>(pl, (unsigned)min(2 * p + 1, H - 1) * stride, off, cf, u1, v1);
-            u0 = min(u0 >> 7, 32767); u1 = min(u1 >> 7, 32767); v0 = min(v0 >> 7, 32767); v1 = min(v1 >> 7, 32767);
-            if (rc) { u0 = l_chr_range(u0, rc); u1 = l_chr_range(u1, rc); v0 = l_chr_range(v0, rc); v1 = l_chr_range(v1, rc); }
-            outU[(size_t)p * pitch] = (int)l_pk16(u0, u1);
-            outV[(size_t)p * pitch] = (int)l_pk16(v0, v1);
+            inter[(lumaJob ? 0 : vPlane ? a.baseV : a.baseU) + (size_t)p * pitch + cg * 64 + lane] = (int)l_pk16(l0, l1);
+        } else {
+            const unsigned *win = window();
+            int uv[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {                        // a row at a time: P dwords of window
+                unsigned d[P];
+                read_window<P, RU>(win + r * rowDw, d);
+                int u = 0, v = 0;
+#pragma unroll
+                for (int j = 0; j < P; j++) { u = dot2(pair_u(d[j]), cf[j], u); v = dot2(pair_v(d[j]), cf[j], v); }
+                u = min(u >> 7, 32767); v = min(v >> 7, 32767);
+                if (rc) { u = l_chr_range(u, rc); v = l_chr_range(v, rc); }
+                uv[r][0] = u; uv[r][1] = v;
+            }
+            inter[a.baseU + (size_t)p * pitch + cg * 64 + lane] = (int)l_pk16(uv[0][0], uv[1][0]);
+            inter[a.baseV + (size_t)p * pitch + cg * 64 + lane] = (int)l_pk16(uv[0][1], uv[1][1]);
         }
     }
 }
@@ -300,19 +349,20 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static const int kLineInstances[] = {8, 12, 16, 20, 24, 32, 40, 48, 56, 68};
+static const int kLineInstances[] = {8, 12, 16, 20, 24, 32, 40, 48, 56, 72};
 
-// coefficient pairs of a byte plane's filter re-based to the 4-byte aligned window start pos & ~3 (up to three leading zero taps)
-static void rebase4(const FilterBank &fb, int P, std::vector<int32_t> &tab, std::vector<int32_t> &off)
+// coefficient pairs of a filter re-based to a window that starts on a multiple of `align` SAMPLES (up to align - 1 leading zero taps);
+// tab[k][column]: pair k of every column side by side (pitch = the lines frame's); off: the window's byte offset in the row
+static void rebase(const FilterBank &fb, int P, int pitch, int align, int bytesPerSample, std::vector<int32_t> &tab, std::vector<int32_t> &off)
 {
-    tab.assign((size_t)fb.count * P, 0);
+    tab.assign((size_t)P * pitch, 0);
     off.resize(fb.count);
     for (int i = 0; i < fb.count; i++) {
-        const int lead = fb.pos[i] & 3;
-        off[i] = fb.pos[i] & ~3;
-        int16_t w[2 * 68] = {0};
+        const int lead = fb.pos[i] & (align - 1);
+        off[i] = (fb.pos[i] - lead) * bytesPerSample;
+        int16_t w[2 * 72 + 2] = {0};
         for (int t = 0; t < fb.taps; t++) w[lead + t] = fb.coef[(size_t)i * fb.taps + t];
-        for (int k = 0; k < P; k++) tab[(size_t)i * P + k] = (int32_t)(((uint32_t)(uint16_t)w[2 * k]) | ((uint32_t)(uint16_t)w[2 * k + 1] << 16));
+        for (int k = 0; k < P; k++) tab[(size_t)k * pitch + i] = (int32_t)(((uint32_t)(uint16_t)w[2 * k]) | ((uint32_t)(uint16_t)w[2 * k + 1] << 16));
     }
 }
 
@@ -323,27 +373,35 @@ int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
     if (!(is_packed_rgb(p.dstFormat) || is_yuv420(p.dstFormat) || p.dstFormat == GMAT_PIX_FMT_YUV444P)) return 0;
     if (p.hLum.taps > 128 || p.hChr.taps > 128) return 0;
     const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
-    // pairs a lane holds: byte planes on their 4-byte aligned windows, interleaved chroma on its pos_even windows (as FilterBank::packed)
-    int need = (p.hLum.taps + 3 + 1) / 2;
-    need = std::max(need, nv12 ? p.hChr.pairs : (p.hChr.taps + 3 + 1) / 2);
+    // dwords a lane reads from a row's image at once: as many as its neighbour's window starts further on (a byte plane's lanes are srcW / dstW
+    // bytes apart); the windows start on that boundary: samples 4 RW of a byte plane, 2 RU of the interleaved chroma plane (two bytes a sample)
+    const int RW = p.srcW >= 16 * p.dstW ? 4 : p.srcW >= 8 * p.dstW ? 2 : 1, RU = RW == 1 ? 2 : 4;
+    const int alignB = 4 * RW, alignU = 2 * RU;
+    int need = (p.hLum.taps + alignB - 1 + 1) / 2;
+    need = std::max(need, (p.hChr.taps + (nv12 ? alignU : alignB) - 1 + 1) / 2);
     int P = 0;
-    for (int v : kLineInstances) if (v >= need) { P = v; break; }
+    for (int v : kLineInstances) if (v >= need && (v / 2) % RW == 0) { P = v; break; }
     if (!P) return 0;
-    t.P = P;
-    rebase4(p.hLum, P, t.hL, t.offL);
-    if (nv12) {
-        t.hC.assign((size_t)p.hChr.count * P, 0);
-        t.offC.resize(p.hChr.count);
-        for (int i = 0; i < p.hChr.count; i++) {
-            t.offC[i] = 2 * p.hChr.pos_even[i];                   // bytes into the interleaved row
-            for (int k = 0; k < p.hChr.pairs; k++) t.hC[(size_t)i * P + k] = p.hChr.packed[(size_t)i * p.hChr.pairs + k];
-        }
-    } else rebase4(p.hChr, P, t.hC, t.offC);
+    t.P = P; t.RW = RW;
+    t.pitchL = align_up(p.dstW, 64); t.pitchC = align_up(p.chrDstW, 64);
+    rebase(p.hLum, P, t.pitchL, alignB, 1, t.hL, t.offL);
+    if (nv12) rebase(p.hChr, P, t.pitchC, alignU, 2, t.hC, t.offC);
+    else      rebase(p.hChr, P, t.pitchC, alignB, 1, t.hC, t.offC);
     // windows start in column order (the kernel's edge test reads the wave's last lane)
     for (size_t i = 1; i < t.offL.size(); i++) if (t.offL[i] < t.offL[i - 1]) return 0;
     for (size_t i = 1; i < t.offC.size(); i++) if (t.offC[i] < t.offC[i - 1]) return 0;
+    // 1 KB pieces of a row a wave's 64 windows span, at most (LDS: two rows of them a wave)
+    auto pieces = [&](const std::vector<int32_t> &off, int winBytes) {
+        int n = 1;
+        for (size_t c0 = 0; c0 < off.size(); c0 += 64) {
+            const size_t c1 = std::min(off.size(), c0 + 64) - 1;
+            n = std::max(n, (int)(((unsigned)off[c1] + winBytes - ((unsigned)off[c0] & ~15u) + 1023u) >> 10));
+        }
+        return n;
+    };
+    t.nld = std::max(pieces(t.offL, 2 * P), pieces(t.offC, nv12 ? 4 * P : 2 * P));
+    if (t.nld > (RW == 1 ? 2 : RW == 2 ? 3 : kLineNld)) return 0;     // (the instances: RW 1 | 2 | 4 with 2 | 3 | 5 pieces)
     t.yuvOut = g.yuvOut; t.fullChroma = g.fullChroma;
-    t.pitchL = align_up(p.dstW, 64); t.pitchC = align_up(p.chrDstW, 64);
     t.pairRowsL = (p.srcH + 1) / 2; t.pairRowsC = (p.chrSrcH + 1) / 2;
     // rows the frame holds: a vertical window's padded pairs may end one row pair past the plane (zero coefficients: the rows are never written)
     int rowsL = t.pairRowsL, rowsC = t.pairRowsC;
@@ -358,7 +416,7 @@ int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
 
 int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
-    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || !a0.inter) return GMAT_ERR(EINVAL);
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || !a0.inter || a0.nld < 1 || a0.nld > (a0.RW == 1 ? 2 : a0.RW == 2 ? 3 : kLineNld)) return GMAT_ERR(EINVAL);
     YuvLArgs a = a0;
     const Yuv2xFrames &fr = *frames;
     a.nColL = a.pitchL / 64; a.nColC = a.pitchC / 64;
@@ -372,12 +430,15 @@ int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames 
     a.nItem = a.nItemL + (a.nv12 ? 1 : 2) * a.nItemC;
     {
         const dim3 grid((a.nItem + 3) / 4, nframes), block(256);
+        const size_t lds = (size_t)4 * 2 * a.nld * 1024;
+#define GMAT_LH(P_) case P_: if (a.RW == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_, 1, 2>), grid, block, lds, stream, a, fr); \
+                     else if (a.RW == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_, 2, 3>), grid, block, lds, stream, a, fr); \
+                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_, 4, kLineNld>), grid, block, lds, stream, a, fr); break
         switch (a.P) {
-#define GMAT_LH(P_) case P_: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_>), grid, block, 0, stream, a, fr); break
-        GMAT_LH(8); GMAT_LH(12); GMAT_LH(16); GMAT_LH(20); GMAT_LH(24); GMAT_LH(32); GMAT_LH(40); GMAT_LH(48); GMAT_LH(56); GMAT_LH(68);
-#undef GMAT_LH
+        GMAT_LH(8); GMAT_LH(12); GMAT_LH(16); GMAT_LH(20); GMAT_LH(24); GMAT_LH(32); GMAT_LH(40); GMAT_LH(48); GMAT_LH(56); GMAT_LH(72);
         default: return GMAT_ERR(EINVAL);
         }
+#undef GMAT_LH
         GMAT_HIP_CHECK(hipGetLastError());
     }
     {

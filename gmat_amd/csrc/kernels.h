@@ -393,6 +393,8 @@ int  launch_scale_yuvu(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames 
 // the roofline and refused beyond ~ 20 : 1.  8-bit YUV sources (NV12, YUV420P, YUV444P) -> packed RGB (half / full chroma), 8-bit 4:2:0, YUV444P.
 struct YuvLTables {
     int ok = 0, P = 0, yuvOut = 0, fullChroma = 0;
+    int nld = 0;                                              // 1 KB pieces of a source row a wave's 64 windows span, at most
+    int RW = 1;                                               // dwords a lane reads from a byte plane's row image at once (the windows' alignment / 4)
     std::vector<int32_t> hL, hC;                              // [dstW][P] / [chrDstW][P] coefficient pairs on the window that starts at off*
     std::vector<int32_t> offL, offC;                          // byte offset of a column's window in its source row (a multiple of 4)
     int pitchL = 0, pitchC = 0, pairRowsL = 0, pairRowsC = 0; // the lines frame: dwords a row (a dword = rows 2p and 2p + 1 of one column), rows
@@ -402,7 +404,7 @@ struct YuvLArgs {
     int ys, us, vs, nv12;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV, dstFormat, dstAligned, dstNv12, yuvOut, fullChroma, rangeConv;
-    int P;
+    int P, nld, RW;
     const int32_t *hL, *hC, *offL, *offC;
     int pitchL, pitchC, pairRowsL, pairRowsC;
     size_t baseU, baseV, frameInts;

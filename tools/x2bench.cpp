@@ -86,7 +86,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
 
 static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, int dh, int flags, int NF, int launches, int verify)
 {
-    g_align = strncmp(label, "any:", 4) == 0 ? 256 : 1;
+    g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0) ? 256 : 1;
     const size_t sb = frame_bytes(sf, sw, sh), db = frame_bytes(df, dw, dh);
     const int NSET = 2 * NF;                      // rotate two frame sets (> 256 MiB together at 4K x 32)
     std::vector<uint8_t *> src(NSET), dst(NSET);
