@@ -881,27 +881,35 @@ static const char *yuv2p_name(const GmatSwsContext *c)
 // of the table through one launch (n = 1: what sws_scale() issues).  The exact-ratio walkers' geometries are disjoint, so the order
 // only matters inside a ratio (2:1: strip walker / 4:4:4 luma walker / plane walker before the tiled kernel) and for the two catch-alls.
 // the lines form (k_scale_yuvl.hip).  Context level: which contexts MAY take it — the ones no walker of the table serves (a ratio beyond the
-// band walker's 6.1 : 1, range conversion, filters its tables do not hold, a 4:4:4 end, full-chroma RGB) and whose horizontal axis shrinks
-// by two at least (the lines frame is srcH x dstW samples; measured against the tiled kernel, profiles/r04_lines.txt), or every context the
-// tiled kernel has no tiling for.  GMAT_LINES=0: never, 2: wherever the table reaches it.  Such a context owns its lines frame.
+// band walker's 6.1 : 1, range conversion, filters its tables do not hold, a 4:4:4 end, full-chroma RGB), or every context the tiled kernel
+// has no tiling for.  GMAT_LINES=0: never, 2: wherever the table reaches it.  Such a context owns its lines frames (stream_handoff_*).
+static int lines_mode()
+{
+    const char *kn = GMAT_KNOB("GMAT_LINES");
+    return kn ? atoi(kn) : 1;
+}
 static bool lines_context(const GmatSwsContext *c)
 {
     if (c->mode != MODE_SCALE || !c->yuvReady || !c->yl.ok || c->fused != 2) return false;
     if (c->ytiling.TW == 0) return true;
-    const char *kn = GMAT_KNOB("GMAT_LINES");
-    const int mode = kn ? atoi(kn) : 1;
+    const int mode = lines_mode();
     if (mode != 1) return mode == 2;
     const bool walker = !c->rangeConv && (c->y2s.ok || c->y2p.ok || c->y2p.ok444 || c->y1x2.ok || c->y3x1.ok || c->y3x2.ok || c->y3r.ok || c->y32r.ok ||
                                           c->y4r.ok || c->y4x1.ok || c->y2x.ok || c->yg.ok || c->yu.ok);
     // NV12 <-> YUV420P within the band walker's range: the cascade (a sibling context in the source's layout on a walker + the re-layout) keeps it
     const bool crossWalk = is_yuv420(c->srcFormat) && is_yuv420(c->dstFormat) && c->srcFormat != c->dstFormat && !c->rangeConv &&
                            10 * c->srcW <= 61 * c->dstW && 10 * c->srcH <= 61 * c->dstH;
-    return !walker && !crossWalk && c->srcW >= 2 * c->dstW;
+    return !walker && !crossWalk;
 }
-// frame level: dword-aligned source planes (the windows are read as aligned dwords), 8-bit destinations
-static bool yuvl_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+// frame level: dword-aligned source planes (the rows are read as aligned 16-byte pieces of a buffer resource), 8-bit destinations; and the
+// launch's size — measured against the tiled kernel with every walker switched off (profiles/r04_lines.txt, us a frame, lines / tiled): 32 frames
+// a launch the lines form wins at EVERY ratio (4K -> 480 x 270 4.8 / 28.1, -> 1600 x 900 12.6 / 15.2, 1080p -> 720p 5.2 / 6.8, 1440p -> 1080p
+// 10.8 / 11.8, 720p -> 1080p 6.3 / 9.4); ONE frame a launch pays two launches and a lines frame through memory: from 2 : 1 on (4.5 : 1 20.2 / 25.4,
+// 2.4 : 1 24.0 / 23.5, 3 : 2 18.9 / 12.3, 720p -> 1080p 18.5 / 14.0)
+static bool yuvl_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n)
 {
     if (!lines_context(c) || ya.prof || ya.src16 || ya.dst16 || ya.dither8) return false;
+    if (c->ytiling.TW != 0 && lines_mode() == 1 && !(n > 3 || c->srcW >= 2 * c->dstW)) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
     if (!ya.nv12) all |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
     return (all & 3) == 0;
@@ -999,7 +1007,7 @@ static const PlaneKernel kPlaneKernels[] = {
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
-    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvl_eligible(c, ya); },                                    // what no walker takes: the lines form
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvl_eligible(c, ya, n); },                                    // what no walker takes: the lines form
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          GmatSwsContext *m = const_cast<GmatSwsContext *>(c);             // (the lines frame is allocated on first use and grows with the launch)

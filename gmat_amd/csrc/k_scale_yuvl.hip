@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
         const int vpL = uniform_load(VL.pos_even, yo) >> 1, lr = uniform_load(VL.round, yo);
         int Y[4] = {lr, lr, lr, lr};
         const int32_t *ly = hy + (size_t)vpL * a.pitchL + xo;
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k < VL.pairs; k++) {
             const int cf = uniform_load(VL.packed, yo * VL.pairs + k);
             const int4 v = *reinterpret_cast<const int4 *>(ly + (size_t)k * a.pitchL);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
             if (FULL) {
                 int U[4] = {cr, cr, cr, cr}, V[4] = {cr, cr, cr, cr};
                 const int32_t *lu = hu + (size_t)vpC * a.pitchC + xo, *lv = hv + (size_t)vpC * a.pitchC + xo;
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < VC.pairs; k++) {
                     const int cf = uniform_load(VC.packed, yo * VC.pairs + k);
                     const int4 u = *reinterpret_cast<const int4 *>(lu + (size_t)k * a.pitchC);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
             } else {
                 int U[2] = {cr, cr}, V[2] = {cr, cr};
                 const int32_t *lu = hu + (size_t)vpC * a.pitchC + (xo >> 1), *lv = hv + (size_t)vpC * a.pitchC + (xo >> 1);
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < VC.pairs; k++) {
                     const int cf = uniform_load(VC.packed, yo * VC.pairs + k);
                     const uint2 u = *reinterpret_cast<const uint2 *>(lu + (size_t)k * a.pitchC);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
             if (cx >= a.chrDstW) return;
             int U = rnd, V = rnd;
             const int32_t *lu = hu + (size_t)vp * a.pitchC + cx, *lv = hv + (size_t)vp * a.pitchC + cx;
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < VC.pairs; k++) {
                 const int cf = uniform_load(VC.packed, cy * VC.pairs + k);
                 U = dot2(lu[(size_t)k * a.pitchC], cf, U);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
             if (xo >= a.chrDstW) return;
             int U[4] = {rnd, rnd, rnd, rnd}, V[4] = {rnd, rnd, rnd, rnd};
             const int32_t *lu = hu + (size_t)vp * a.pitchC + xo, *lv = hv + (size_t)vp * a.pitchC + xo;
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < VC.pairs; k++) {
                 const int cf = uniform_load(VC.packed, cy * VC.pairs + k);
                 const int4 u = *reinterpret_cast<const int4 *>(lu + (size_t)k * a.pitchC);
@@ -423,7 +423,8 @@ int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames 
     // row pairs a wave: long runs amortise the lane's coefficient loads, short ones fill the chip
     const char *rpStr = GMAT_KNOB("GMAT_LINES_RP");
     int rp = rpStr ? std::max(1, atoi(rpStr)) : 8;
-    if (!rpStr) while (rp > 2 && (long)a.nColL * ((a.pairRowsL + rp - 1) / rp) * nframes < 2048) rp >>= 1;
+    // (measured, profiles/r04_lines.txt: 32 frames a launch 8 / 16 / 32 pairs 5.0 / 5.2 / 5.7 us a 4K frame; one frame a launch 1 / 2 / 4 / 8 pairs 21.0 / 21.5 / 21.7 / 25.1)
+    if (!rpStr) while (rp > 1 && (long)(a.nColL + a.nColC) * ((a.pairRowsL + rp - 1) / rp) * nframes < 8192) rp >>= 1;
     a.rp = rp;
     a.nItemL = a.nColL * ((a.pairRowsL + rp - 1) / rp);
     a.nItemC = a.nColC * ((a.pairRowsC + rp - 1) / rp);
