@@ -309,7 +309,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
             (r = up(t.firstL, u.firstL)) < 0 || (r = up(t.firstC, u.firstC)) < 0 || (r = up(t.lastL, u.lastL)) < 0 || (r = up(t.lastC, u.lastC)) < 0) return r;
         u.P = t.P; u.SD = t.SD; u.RL = t.RL; u.RC = t.RC; u.lead = t.lead; u.roundL = t.roundL; u.roundC = t.roundC; u.yuvOut = t.yuvOut;
     }
-    if (!a.src16 && !c->rgbViaPlanes && (r = yuvl_prepare(c->planYuv, c->ytiling, c->yl)) < 0) return r;
+    if (!c->rgbViaPlanes && (r = yuvl_prepare(c->planYuv, c->ytiling, c->yl)) < 0) return r;
     if (c->yl.ok) {
         YuvLArgs &l = c->largs;
         std::memset(&l, 0, sizeof(l));
@@ -908,8 +908,12 @@ static bool lines_context(const GmatSwsContext *c)
 // 2.4 : 1 24.0 / 23.5, 3 : 2 18.9 / 12.3, 720p -> 1080p 18.5 / 14.0)
 static bool yuvl_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n)
 {
-    if (!lines_context(c) || ya.prof || ya.src16 || ya.dst16 || ya.dither8) return false;
-    if (c->ytiling.TW != 0 && lines_mode() == 1 && !(n > 3 || c->srcW >= 2 * c->dstW)) return false;
+    if (!lines_context(c) || ya.prof || ya.src16 == 3) return false;
+    // 16-bit samples in (scale_yuvl_h16_kernel, a row at a time) or 10-bit samples out: from 2 : 1 on whatever the launch (profiles/r04_lines_deep.txt,
+    // lines / tiled: 32 frames a launch P010 4K -> 1600 x 900 18.2 / 28.9, -> 854 x 480 11.5 / 68.7, 3 : 2 and 2 : 3 a tie; one frame 29.5 / 35.8,
+    // 24.7 / 70.2, 3 : 2 22.8 / 13.1)
+    const bool deep = ya.src16 || ya.dst16 || ya.dither8;
+    if (c->ytiling.TW != 0 && lines_mode() == 1 && !((n > 3 && !deep) || c->srcW >= 2 * c->dstW)) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
     if (!ya.nv12) all |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
     return (all & 3) == 0;
@@ -931,6 +935,7 @@ static YuvLArgs make_yuvl_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
     l.dstW = ya.dstW; l.dstH = ya.dstH; l.chrDstW = ya.chrDstW; l.chrDstH = c->planYuv.chrDstH;
     l.ds = ya.ds; l.dsU = ya.dsU; l.dsV = ya.dsV; l.dstFormat = ya.dstFormat; l.dstAligned = ya.dstAligned; l.dstNv12 = ya.dstNv12;
     l.rangeConv = ya.rangeConv;
+    l.src16 = ya.src16; l.hShift = ya.hShift; l.hBias = ya.hBias; l.dst16 = ya.dst16; l.dstShift = ya.dstShift; l.dither8 = ya.dither8;
     l.vLum = ya.vLum; l.vChr = ya.vChr; l.y2r = ya.y2r;
     l.inter = c->linesBuf;
     return l;
@@ -1008,7 +1013,7 @@ static const PlaneKernel kPlaneKernels[] = {
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvl_eligible(c, ya, n); },                                    // what no walker takes: the lines form
-     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
+     [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return ya.src16 ? "scale_yuvl_h16_kernel+scale_yuvl_v_kernel" : "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          GmatSwsContext *m = const_cast<GmatSwsContext *>(c);             // (the lines frame is allocated on first use and grows with the launch)
          if (int r = lines_prepare(m, n); r < 0) return r;

@@ -198,6 +198,103 @@ __global__ __launch_bounds__(256) void scale_yuvl_h_kernel(YuvLArgs a, Yuv2xFram
     }
 }
 
+// ---- pass H for 16-bit samples (P010LE / P016LE: a luma plane and a plane of interleaved (U, V) pairs; planar 10 / 16 bit) ------------------
+// hScale16To15_c (swscale.c:93-119): min((sum(src * f)) >> sh, 32767), sh = depth - 1.  What the taps multiply is k_scale_yuv.hip's 16-bit image
+// (yuv_phase1_src16): P010 sample >> 6; planar 10 bit as it is; 16 bits as sample - 32768 (the signed v_dot2 operand) with the accumulator
+// started at 32768 * 16384 (hBias; the host checks that every filter row sums to 16384).  A dword of a plane is one coefficient pair; of the
+// interleaved plane two dwords make a U pair and a V pair.  Same structure as the 8-bit kernel, a ROW at a time (a lane stride of 2 r or 4 r
+// bytes: up to kLineNld16 pieces a row), the window in groups of eight dwords.  Not tuned: it is what serves these sources beyond the tiled
+// kernel's reach (refused from ~ 10 : 1 before).
+constexpr int kLineNld16 = 9;
+
+template <int P>
+__global__ __launch_bounds__(256) void scale_yuvl_h16_kernel(YuvLArgs a, Yuv2xFrames fr)
+{
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    if (item >= a.nItem) return;
+    int32_t *inter = a.inter + (size_t)f * a.frameInts;
+    const bool semi = a.src16 < 17;                                            // P010 / P016: interleaved chroma
+    const bool lumaJob = item < a.nItemL;
+    const int  cjob = lumaJob ? 0 : item - a.nItemL;
+    const bool vPlane = !lumaJob && !semi && cjob >= a.nItemC;
+    const int  it = lumaJob ? item : vPlane ? cjob - a.nItemC : cjob;
+    const int  ncol = lumaJob ? a.nColL : a.nColC;
+    const int  chunk = it / ncol, cg = it - chunk * ncol;
+    const int  W = lumaJob ? a.dstW : a.chrDstW, H = lumaJob ? a.srcH : a.chrSrcH;
+    const int  pitch = lumaJob ? a.pitchL : a.pitchC, pairRows = lumaJob ? a.pairRowsL : a.pairRowsC;
+    const int  gx = min(cg * 64 + lane, W - 1);
+    const int32_t *tab = lumaJob ? a.hL : a.hC;
+    const unsigned off = (unsigned)(lumaJob ? a.offL : a.offC)[gx];
+    int cf[P];
+#pragma unroll
+    for (int k = 0; k < P; k++) cf[k] = tab[(size_t)k * pitch + cg * 64 + lane];
+    const int p0 = chunk * a.rp, p1 = min(p0 + a.rp, pairRows);
+    const int rc = a.rangeConv;
+    const bool uvJob = !lumaJob && semi;
+    const uint8_t *plane = lumaJob ? fr.y[f] : vPlane ? fr.v[f] : fr.u[f];
+    const unsigned stride = (unsigned)(lumaJob ? a.ys : vPlane ? a.vs : a.us);
+    const unsigned rowBytes = 2u * (unsigned)(lumaJob ? a.srcW : semi ? 2 * a.chrSrcW : a.chrSrcW);
+    const LPlane pl(plane, (unsigned)(H - 1) * stride + ((rowBytes + 3u) & ~3u));
+    const unsigned seg0 = (unsigned)__builtin_amdgcn_readlane((int)off, 0) & ~15u;
+    const unsigned segEnd = (unsigned)__builtin_amdgcn_readlane((int)off, 63) + (uvJob ? 8u * P : 4u * P);
+    const int nld = __builtin_amdgcn_readfirstlane((int)((segEnd - seg0 + 1023u) >> 10));
+    unsigned *img = reinterpret_cast<unsigned *>(lds_base) + (unsigned)wave * (unsigned)a.nld * 256u;
+    const unsigned *win = img + ((off - seg0) >> 2);                           // (a multiple of 8 bytes: the host re-based the windows so)
+    const unsigned lo = seg0 + 16u * lane;
+    const int kind = a.src16, sh = a.hShift, bias = a.hBias;
+    auto conv = [&](unsigned v) -> int { return (int)(kind == 10 ? (v >> 6) & 0x03FF03FFu : kind == 18 ? v : v ^ 0x80008000u); };
+
+    for (int p = p0; p < p1; p++) {
+        int out[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const unsigned rowOff = (unsigned)min(2 * p + r, H - 1) * stride;
+            uint4 raw[kLineNld16];
+#pragma unroll
+            for (int i = 0; i < kLineNld16; i++)
+                if (i < nld && lo + 1024u * i < segEnd) raw[i] = pl.ld16(lo + 1024u * i, rowOff);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < kLineNld16; i++)
+                if (i < nld && lo + 1024u * i < segEnd) *reinterpret_cast<uint4 *>(img + 256 * i + 4 * lane) = raw[i];
+            __builtin_amdgcn_wave_barrier();
+            int s0 = bias, s1 = bias;
+            if (!uvJob) {
+#pragma unroll
+                for (int j0 = 0; j0 < P; j0 += 8) {
+                    unsigned d[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) if (j0 + j < P) { const uint2 t = *reinterpret_cast<const uint2 *>(win + j0 + j); d[j] = t.x; d[j + 1] = t.y; }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (j0 + j < P) s0 = dot2(conv(d[j]), cf[j0 + j], s0);
+                }
+            } else {
+#pragma unroll
+                for (int j0 = 0; j0 < P; j0 += 4) {
+                    unsigned d[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (j0 + j < P) { const uint2 t = *reinterpret_cast<const uint2 *>(win + 2 * (j0 + j)); d[2 * j] = t.x; d[2 * j + 1] = t.y; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (j0 + j < P) {
+                            s0 = dot2(conv(__builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x05040100u)), cf[j0 + j], s0);       // U of two samples
+                            s1 = dot2(conv(__builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x07060302u)), cf[j0 + j], s1);       // V
+                        }
+                }
+            }
+            int v0 = min(s0 >> sh, 32767), v1 = min(s1 >> sh, 32767);
+            if (rc) { v0 = lumaJob ? l_lum_range(v0, rc) : l_chr_range(v0, rc); v1 = l_chr_range(v1, rc); }
+            out[r][0] = v0; out[r][1] = v1;
+        }
+        const size_t o = (size_t)p * pitch + cg * 64 + lane;
+        if (!uvJob) inter[(lumaJob ? 0 : vPlane ? a.baseV : a.baseU) + o] = (int)l_pk16(out[0][0], out[1][0]);
+        else { inter[a.baseU + o] = (int)l_pk16(out[0][0], out[1][0]); inter[a.baseV + o] = (int)l_pk16(out[0][1], out[1][1]); }
+    }
+}
+
 // ---- pass V ----------------------------------------------------------------------------------------------------------------------------
 // MODE 0: packed RGB, half chroma (LUT form)   1: packed RGB, full chroma   2: YUV 4:2:0 (NV12 / YUV420P)   3: planar YUV 4:4:4
 // A block = 4 output rows x 256 columns (a wave a row, a lane four adjacent outputs); MODE 2: its 2 chroma rows x 128 columns after them,
@@ -228,8 +325,20 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
             Y[0] = dot2(v.x, cf, Y[0]); Y[1] = dot2(v.y, cf, Y[1]); Y[2] = dot2(v.z, cf, Y[2]); Y[3] = dot2(v.w, cf, Y[3]);
         }
         const int nx = min(4, a.dstW - xo);
-        if (YUVOUT) {
-            // yuv2planeX_8_c: clip_u8((64 << 12 + sum) >> 19); lr holds the 64 << 12
+        if (YUVOUT && a.dst16) {
+            // yuv2p010lX_c / yuv2planeX_10_c: clip_uintp2((1 << 16 + sum) >> 17, 10) (P010: << 6); lr holds the 1 << 16
+            unsigned short *d16 = reinterpret_cast<unsigned short *>(dst + (size_t)yo * a.ds) + xo;
+            unsigned w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = (unsigned)min(max(Y[i] >> 17, 0), 1023) << a.dstShift;
+            if (a.dstAligned && nx == 4) *reinterpret_cast<uint2 *>(d16) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+            else for (int i = 0; i < nx; i++) d16[i] = (unsigned short)w[i];
+        } else if (YUVOUT) {
+            // yuv2planeX_8_c: clip_u8((dither << 12 + sum) >> 19); lr holds the 64 << 12 of an 8-bit source, a deeper one's ordered dither on top
+            if (a.dither8) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) Y[i] += dither_delta(xo + i, yo);
+            }
             uint8_t *d = dst + (size_t)yo * a.ds + xo;
             const unsigned o = (unsigned)clip_u8_shr(Y[0], 19) | ((unsigned)clip_u8_shr(Y[1], 19) << 8) |
                                ((unsigned)clip_u8_shr(Y[2], 19) << 16) | ((unsigned)clip_u8_shr(Y[3], 19) << 24);
@@ -315,6 +424,16 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
                 U = dot2(lu[(size_t)k * a.pitchC], cf, U);
                 V = dot2(lv[(size_t)k * a.pitchC], cf, V);
             }
+            if (a.dst16) {                                          // yuv2p010cX_c (interleaved, << 6) / yuv2planeX_10_c per plane
+                const unsigned u10 = (unsigned)min(max(U >> 17, 0), 1023), v10 = (unsigned)min(max(V >> 17, 0), 1023);
+                if (a.dst16 == 1) reinterpret_cast<unsigned *>(dstU + (size_t)cy * a.dsU)[cx] = (u10 << 6) | (v10 << 22);
+                else {
+                    reinterpret_cast<unsigned short *>(dstU + (size_t)cy * a.dsU)[cx] = (unsigned short)u10;
+                    reinterpret_cast<unsigned short *>(dstV + (size_t)cy * a.dsV)[cx] = (unsigned short)v10;
+                }
+                return;
+            }
+            if (a.dither8) { U += dither_delta(cx, cy); V += dither_delta(cx + 3, cy); }       // chrDither8: V three columns on (vscale.c:98,101, output.c:433-434)
             const unsigned ub = (unsigned)clip_u8_shr(U, 19), vb = (unsigned)clip_u8_shr(V, 19);
             if (a.dstNv12) {
                 uint8_t *d = dstU + (size_t)cy * a.dsU + 2 * cx;
@@ -335,6 +454,10 @@ __global__ __launch_bounds__(256) void scale_yuvl_v_kernel(YuvLArgs a, Yuv2xFram
                 const int4 v = *reinterpret_cast<const int4 *>(lv + (size_t)k * a.pitchC);
                 U[0] = dot2(u.x, cf, U[0]); U[1] = dot2(u.y, cf, U[1]); U[2] = dot2(u.z, cf, U[2]); U[3] = dot2(u.w, cf, U[3]);
                 V[0] = dot2(v.x, cf, V[0]); V[1] = dot2(v.y, cf, V[1]); V[2] = dot2(v.z, cf, V[2]); V[3] = dot2(v.w, cf, V[3]);
+            }
+            if (a.dither8) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { U[i] += dither_delta(xo + i, cy); V[i] += dither_delta(xo + i + 3, cy); }
             }
             const int nx = min(4, a.chrDstW - xo);
             uint8_t *du = dstU + (size_t)cy * a.dsU + xo, *dv = dstV + (size_t)cy * a.dsV + xo;
@@ -369,9 +492,35 @@ static void rebase(const FilterBank &fb, int P, int pitch, int align, int bytesP
 int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
 {
     t = YuvLTables();
-    if (!is_yuv8_src(p.srcFormat)) return 0;
-    if (!(is_packed_rgb(p.dstFormat) || is_yuv420(p.dstFormat) || p.dstFormat == GMAT_PIX_FMT_YUV444P)) return 0;
+    const bool semi16 = is_p01x(p.srcFormat);                                   // 16-bit samples, interleaved chroma
+    const bool pl16 = pl16_depth(p.srcFormat) != 0 && p.srcFormat != GMAT_PIX_FMT_PRIV_RGB8_PLANES;      // ... planar (incl. the planes of an RGBA64 frame)
+    if (!(is_yuv8_src(p.srcFormat) || semi16 || pl16)) return 0;
+    if (!(is_packed_rgb(p.dstFormat) || is_yuv420(p.dstFormat) || p.dstFormat == GMAT_PIX_FMT_YUV444P || is_dst10(p.dstFormat))) return 0;
     if (p.hLum.taps > 128 || p.hChr.taps > 128) return 0;
+    if (semi16 || pl16) {
+        // windows on 8-byte boundaries: 4 samples of a plane, 2 (U, V) pairs of the interleaved plane; a row at a time, up to kLineNld16 pieces
+        const int need = std::max((p.hLum.taps + 3 + 1) / 2, (p.hChr.taps + (semi16 ? 1 : 3) + 1) / 2);
+        int P = 0;
+        for (int v : kLineInstances) if (v >= need) { P = v; break; }
+        if (!P) return 0;
+        t.P = P; t.RW = 2; t.wide = 1;
+        t.pitchL = align_up(p.dstW, 64); t.pitchC = align_up(p.chrDstW, 64);
+        rebase(p.hLum, P, t.pitchL, 4, 2, t.hL, t.offL);
+        if (semi16) rebase(p.hChr, P, t.pitchC, 2, 4, t.hC, t.offC);
+        else        rebase(p.hChr, P, t.pitchC, 4, 2, t.hC, t.offC);
+        for (size_t i = 1; i < t.offL.size(); i++) if (t.offL[i] < t.offL[i - 1]) return 0;
+        for (size_t i = 1; i < t.offC.size(); i++) if (t.offC[i] < t.offC[i - 1]) return 0;
+        auto pieces16 = [&](const std::vector<int32_t> &off, int winBytes) {
+            int n = 1;
+            for (size_t c0 = 0; c0 < off.size(); c0 += 64) {
+                const size_t c1 = std::min(off.size(), c0 + 64) - 1;
+                n = std::max(n, (int)(((unsigned)off[c1] + winBytes - ((unsigned)off[c0] & ~15u) + 1023u) >> 10));
+            }
+            return n;
+        };
+        t.nld = std::max(pieces16(t.offL, 4 * P), pieces16(t.offC, semi16 ? 8 * P : 4 * P));
+        if (t.nld > 9) return 0;
+    } else {
     const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
     // dwords a lane reads from a row's image at once: as many as its neighbour's window starts further on (a byte plane's lanes are srcW / dstW
     // bytes apart); the windows start on that boundary: samples 4 RW of a byte plane, 2 RU of the interleaved chroma plane (two bytes a sample)
@@ -401,6 +550,7 @@ int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
     };
     t.nld = std::max(pieces(t.offL, 2 * P), pieces(t.offC, nv12 ? 4 * P : 2 * P));
     if (t.nld > (RW == 1 ? 2 : RW == 2 ? 3 : kLineNld)) return 0;     // (the instances: RW 1 | 2 | 4 with 2 | 3 | 5 pieces)
+    }
     t.yuvOut = g.yuvOut; t.fullChroma = g.fullChroma;
     t.pairRowsL = (p.srcH + 1) / 2; t.pairRowsC = (p.chrSrcH + 1) / 2;
     // rows the frame holds: a vertical window's padded pairs may end one row pair past the plane (zero coefficients: the rows are never written)
@@ -416,7 +566,7 @@ int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
 
 int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
-    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || !a0.inter || a0.nld < 1 || a0.nld > (a0.RW == 1 ? 2 : a0.RW == 2 ? 3 : kLineNld)) return GMAT_ERR(EINVAL);
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || !a0.inter || a0.nld < 1 || a0.nld > (a0.src16 ? kLineNld16 : a0.RW == 1 ? 2 : a0.RW == 2 ? 3 : kLineNld)) return GMAT_ERR(EINVAL);
     YuvLArgs a = a0;
     const Yuv2xFrames &fr = *frames;
     a.nColL = a.pitchL / 64; a.nColC = a.pitchC / 64;
@@ -428,8 +578,18 @@ int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames 
     a.rp = rp;
     a.nItemL = a.nColL * ((a.pairRowsL + rp - 1) / rp);
     a.nItemC = a.nColC * ((a.pairRowsC + rp - 1) / rp);
-    a.nItem = a.nItemL + (a.nv12 ? 1 : 2) * a.nItemC;
-    {
+    a.nItem = a.nItemL + ((a.src16 ? a.src16 < 17 : a.nv12) ? 1 : 2) * a.nItemC;
+    if (a.src16) {
+        const dim3 grid((a.nItem + 3) / 4, nframes), block(256);
+        const size_t lds = (size_t)4 * a.nld * 1024;
+        switch (a.P) {
+#define GMAT_LH16(P_) case P_: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h16_kernel<P_>), grid, block, lds, stream, a, fr); break
+        GMAT_LH16(8); GMAT_LH16(12); GMAT_LH16(16); GMAT_LH16(20); GMAT_LH16(24); GMAT_LH16(32); GMAT_LH16(40); GMAT_LH16(48); GMAT_LH16(56); GMAT_LH16(72);
+#undef GMAT_LH16
+        default: return GMAT_ERR(EINVAL);
+        }
+        GMAT_HIP_CHECK(hipGetLastError());
+    } else {
         const dim3 grid((a.nItem + 3) / 4, nframes), block(256);
         const size_t lds = (size_t)4 * 2 * a.nld * 1024;
 #define GMAT_LH(P_) case P_: if (a.RW == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvl_h_kernel<P_, 1, 2>), grid, block, lds, stream, a, fr); \

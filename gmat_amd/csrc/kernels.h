@@ -394,6 +394,7 @@ int  launch_scale_yuvu(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames 
 struct YuvLTables {
     int ok = 0, P = 0, yuvOut = 0, fullChroma = 0;
     int nld = 0;                                              // 1 KB pieces of a source row a wave's 64 windows span, at most
+    int wide = 0;                                             // 16-bit samples (scale_yuvl_h16_kernel)
     int RW = 1;                                               // dwords a lane reads from a byte plane's row image at once (the windows' alignment / 4)
     std::vector<int32_t> hL, hC;                              // [dstW][P] / [chrDstW][P] coefficient pairs on the window that starts at off*
     std::vector<int32_t> offL, offC;                          // byte offset of a column's window in its source row (a multiple of 4)
@@ -404,6 +405,8 @@ struct YuvLArgs {
     int ys, us, vs, nv12;
     int srcW, srcH, chrSrcW, chrSrcH, dstW, dstH, chrDstW, chrDstH;
     int ds, dsU, dsV, dstFormat, dstAligned, dstNv12, yuvOut, fullChroma, rangeConv;
+    int src16, hShift, hBias;                                 // 16-bit samples: YuvScaleArgs' kind (10 | 16 semi-planar, 17 | 18 planar), hScale16To15_c's shift, accumulator start
+    int dst16, dstShift, dither8;                             // 10-bit 4:2:0 destinations; 8-bit planar output of a deeper source (YuvScaleArgs')
     int P, nld, RW;
     const int32_t *hL, *hC, *offL, *offC;
     int pitchL, pitchC, pairRowsL, pairRowsC;

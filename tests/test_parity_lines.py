@@ -164,6 +164,44 @@ def test_range_conversion_on_the_lines(dev, orc, ranges, fmts, geom):
     assert k == LINES, k
 
 
+# ---- 16-bit sources, 10-bit destinations (round 4: refused from ~ 10 : 1 before: no tile's window fits the LDS) ---------------------------
+def _deep(orc, fmt, sw, sh, seed):
+    src = synth_planes(orc, fmt, sw, sh, seed=seed)
+    if fmt == "yuv420p10le":                               # valid input: 10 significant bits in the low end
+        for p in src:
+            p.view("<u2")[...] &= 0x3FF
+    if fmt == "p010le":                                    # ... in the high end
+        for p in src:
+            p.view("<u2")[...] &= 0xFFC0
+    return src
+
+
+@pytest.mark.parametrize("sf,df", [("p010le", "nv12"), ("p010le", "p010le"), ("p010le", "rgb24"), ("p016le", "yuv420p"), ("p016le", "bgra"),
+                                   ("yuv420p10le", "rgb24"), ("yuv420p10le", "yuv420p10le"), ("yuv420p10le", "nv12"), ("yuv420p16le", "yuv420p"),
+                                   ("yuv444p16le", "rgb24"), ("yuv444p16le", "yuv444p"), ("nv12", "p010le"), ("yuv420p", "yuv420p10le"), ("nv12", "yuv420p10le")])
+@pytest.mark.parametrize("geom", [(768, 432, 64, 36), (1536, 96, 64, 4), (520, 100, 66, 12)])
+def test_lines_deep_sources_and_destinations(dev, orc, sf, df, geom):
+    """hScale16To15_c on P010 (sample >> 6) / P016 and planar 16 bit (biased by 32768) / planar 10 bit samples, interleaved 16-bit chroma; 8-bit planar
+    output of a deeper source takes ff_dither_8x8_128 (swscale.c:263-264), 10-bit output yuv2p010lX_c / yuv2planeX_10_c"""
+    sw, sh, dw, dh = geom
+    src = _deep(orc, sf, sw, sh, 23)
+    want = orc.sws(src, sw, sh, sf, dw, dh, df, SWS["bicubic"])
+    d = dev.upload_planes(src, 256)
+    got, pads, k = dev.sws(d, sw, sh, sf, dw, dh, df, SWS["bicubic"], dst_align=256)
+    for p in d:
+        p.free()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert (g == w).all(), (k, i, int((g != w).sum()))
+        assert (pads[i] == 0xCD).all()
+    deep_src = sf not in ("nv12", "yuv420p")
+    assert k == ("scale_yuvl_h16_kernel+scale_yuvl_v_kernel" if deep_src else LINES), k
+
+
+def test_lines_deep_source_batch_and_moderate_ratio(dev, orc, forced):
+    for sf, df in (("p010le", "nv12"), ("yuv420p10le", "rgb24"), ("p016le", "p010le")):
+        assert _run_batch(dev, orc, sf, df, 480, 128, 120, 32, 5, 2, 256) == "scale_yuvl_h16_kernel+scale_yuvl_v_kernel"
+
+
 # ---- many frames, several streams, graphs ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("sf,df", [("nv12", "rgb24"), ("yuv420p", "yuv420p"), ("nv12", "yuv420p")])
 def test_lines_batches(dev, orc, sf, df):

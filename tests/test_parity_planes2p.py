@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import is_generic, SWS, synth_planes
+from harness import is_generic, SWS, synth_planes, LINES16
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
 
@@ -265,7 +265,7 @@ def test_10bit_same_layout_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_
     """the rule is the 8-bit one; what declines goes to the generic plane scaler (the tiled 2:1 kernel takes 8-bit sources only)"""
     sw, sh = geom
     strip_rows(0)
-    want = STRIP16 if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt) else GENERIC
+    want = STRIP16 if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt) else LINES16      # (round 4: a context the strip kernel declines is the lines form's from 2 : 1 on)
     assert _check10(dev, orc, fmt, sw, sh) == want
 
 
@@ -334,7 +334,7 @@ def test_10bit_saturating_content(dev, orc, strip_rows):
 def test_10bit_batched_frames(dev, orc, strip_rows, kern_yuv, fmt):
     strip_rows(0)
     k = _run_batch(dev, orc, fmt, fmt, 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
-    assert k == (STRIP16 if kern_yuv == "strip" else GENERIC), k
+    assert k == (STRIP16 if kern_yuv == "strip" else LINES16), k
 
 
 # ---- across depths: 8 -> 10 bits (an 8-bit source into a 10-bit encode) and 10 -> 8, same chroma layout -----------------------

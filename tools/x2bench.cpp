@@ -86,7 +86,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
 
 static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, int dh, int flags, int NF, int launches, int verify)
 {
-    g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0) ? 256 : 1;
+    g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0 || strncmp(label, "deep:", 5) == 0) ? 256 : 1;
     const size_t sb = frame_bytes(sf, sw, sh), db = frame_bytes(df, dw, dh);
     const int NSET = 2 * NF;                      // rotate two frame sets (> 256 MiB together at 4K x 32)
     std::vector<uint8_t *> src(NSET), dst(NSET);
@@ -338,6 +338,17 @@ int main(int argc, char **argv)
         {"thumb: nv12 1080p->240x136 rgb24 bicubic (8:1)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 240, 136, GMAT_SWS_BICUBIC},
         {"thumb: nv12 1080p->320x180 nv12 bicubic (6:1)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_NV12, 320, 180, GMAT_SWS_BICUBIC},
         {"thumb: nv12 1080p->1280x720 rgb24 bicubic (3:2)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        // deep samples on the lines form (scale_yuvl_h16_kernel, round 4); "deep:" cases run when the filter names them ("deep")
+        {"deep: p010 4K->1600x900 p010 bicubic (2.4:1)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 1600, 900, GMAT_SWS_BICUBIC},
+        {"deep: p010 4K->1280x720 nv12 bicubic (3:1)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
+        {"deep: p010 4K->854x480 nv12 bicubic (4.5:1)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_NV12, 854, 480, GMAT_SWS_BICUBIC},
+        {"deep: p010 4K->480x270 rgb24 bicubic (8:1)", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_RGB24, 480, 270, GMAT_SWS_BICUBIC},
+        {"deep: yuv420p10le 4K->480x270 yuv420p10le bicubic (8:1)", GMAT_PIX_FMT_YUV420P10LE, 3840, 2160, GMAT_PIX_FMT_YUV420P10LE, 480, 270, GMAT_SWS_BICUBIC},
+        {"deep: yuv420p10le 1080p->1280x720 yuv420p10le bicubic (3:2)", GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_PIX_FMT_YUV420P10LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"deep: p010 1080p->1280x720 rgb24 bicubic (3:2)", GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        {"deep: nv12 4K->1600x900 p010 bicubic (2.4:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 1600, 900, GMAT_SWS_BICUBIC},
+        {"deep: nv12 4K->480x270 p010 bicubic (8:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 480, 270, GMAT_SWS_BICUBIC},
+        {"deep: p010 720p->1080p p010 bicubic (2:3 up)", GMAT_PIX_FMT_P010LE, 1280, 720, GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_SWS_BICUBIC},
         // any ratio: the polyphase band walker (scale_yuvg_kernel); "any:" cases run when the filter names them or "any"
         {"any: nv12 4K->1600x900 rgb24 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
         {"any: nv12 4K->1600x900 nv12 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 1600, 900, GMAT_SWS_BICUBIC},
@@ -394,6 +405,7 @@ int main(int argc, char **argv)
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
         if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;
         if (strstr(k.label, "relayout:") && !(*only && strstr(k.label, only))) continue;
+        if (strstr(k.label, "deep:") && !(*only && strstr(k.label, only))) continue;
         if (strstr(k.label, "thumb:") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
