@@ -247,20 +247,25 @@ __global__ __launch_bounds__(256) void scale_yuvl_h16_kernel(YuvLArgs a, Yuv2xFr
     const int kind = a.src16, sh = a.hShift, bias = a.hBias;
     auto conv = [&](unsigned v) -> int { return (int)(kind == 10 ? (v >> 6) & 0x03FF03FFu : kind == 18 ? v : v ^ 0x80008000u); };
 
+    // the next ROW's bytes in flight during this row's arithmetic (as the 8-bit kernel's next pair)
+    uint4 raw[kLineNld16];
+    auto request = [&](int q) {
+        const unsigned rowOff = (unsigned)min(q, H - 1) * stride;
+#pragma unroll
+        for (int i = 0; i < kLineNld16; i++)
+            if (i < nld && lo + 1024u * i < segEnd) raw[i] = pl.ld16(lo + 1024u * i, rowOff);
+    };
+    if (p0 < p1) request(2 * p0);
     for (int p = p0; p < p1; p++) {
         int out[2][2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const unsigned rowOff = (unsigned)min(2 * p + r, H - 1) * stride;
-            uint4 raw[kLineNld16];
-#pragma unroll
-            for (int i = 0; i < kLineNld16; i++)
-                if (i < nld && lo + 1024u * i < segEnd) raw[i] = pl.ld16(lo + 1024u * i, rowOff);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < kLineNld16; i++)
                 if (i < nld && lo + 1024u * i < segEnd) *reinterpret_cast<uint4 *>(img + 256 * i + 4 * lane) = raw[i];
             __builtin_amdgcn_wave_barrier();
+            if (2 * p + r + 1 < 2 * p1) request(2 * p + r + 1);
             int s0 = bias, s1 = bias;
             if (!uvJob) {
 #pragma unroll
