@@ -579,7 +579,8 @@ int launch_scale_yuvl(const YuvLArgs &a0, hipStream_t stream, const Yuv2xFrames 
     const char *rpStr = GMAT_KNOB("GMAT_LINES_RP");
     int rp = rpStr ? std::max(1, atoi(rpStr)) : 8;
     // (measured, profiles/r04_lines.txt: 32 frames a launch 8 / 16 / 32 pairs 5.0 / 5.2 / 5.7 us a 4K frame; one frame a launch 1 / 2 / 4 / 8 pairs 21.0 / 21.5 / 21.7 / 25.1)
-    if (!rpStr) while (rp > 1 && (long)(a.nColL + a.nColC) * ((a.pairRowsL + rp - 1) / rp) * nframes < 8192) rp >>= 1;
+    // (round 4, after the per-call event was gone: one 4K frame -> 480 x 270 at 1 / 2 / 3 / 4 / 8 pairs 14.1 / 13.6 / 13.5 / 14.2 / 17.1, -> 160 x 90 16.9 / 17.1 / 16.8 / 18.4 / 23.5)
+    if (!rpStr) while (rp > 1 && (long)(a.nColL + a.nColC) * ((a.pairRowsL + rp - 1) / rp) * nframes < 4096) rp >>= 1;
     a.rp = rp;
     a.nItemL = a.nColL * ((a.pairRowsL + rp - 1) / rp);
     a.nItemC = a.nColC * ((a.pairRowsC + rp - 1) / rp);
