@@ -153,7 +153,9 @@ GMAT_API int  gmat_sws_lastLaunchFrames(const GmatSwsContext *c);
 /* A context owns ONE set of intermediates (the two-kernel forms, the 16-bit paths, NV12 <-> YUV420P scaled); like the reference's cv_* buffers
  * (swscale_cuda.c:248-266) they are shared by every call.  A call on a stream other than the one that used them last is ordered behind that use
  * by an event inside the library, so alternating streams (gmat_sws_setStream, gmat_sws_scale_batch) is always safe; contexts without
- * intermediates (the fused kernels, every same-size converter) overlap freely.  Returns how often that ordering was needed (tests). */
+ * intermediates (the fused kernels, every same-size converter) overlap freely.  A context that only ever sees ONE stream records nothing (an
+ * event record per call kept the next call's first launch waiting ~ 4 us); the first call on a second stream synchronises the device once
+ * (blocking the host), and from then on every call records its last use.  Returns how often that ordering was needed (tests). */
 GMAT_API int  gmat_sws_streamHandoffs(const GmatSwsContext *c);
 
 /* ---- the plain-pointer back-end entry points, under the reference's own names ----------
