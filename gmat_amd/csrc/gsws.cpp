@@ -1109,7 +1109,12 @@ static int stream_handoff_acquire(GmatSwsContext *c, hipStream_t s)
     c->interTouched = false;
     if (!c->interUsed || c->interStream == s || stream_is_capturing(s)) return 0;
     if (!c->interMulti) {
-        GMAT_HIP_CHECK(hipDeviceSynchronize());
+        if (hipDeviceSynchronize() != hipSuccess) {           // (refused while another thread captures in global mode: order the two streams by an event instead)
+            (void)hipGetLastError();
+            if (!c->interEv) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->interEv, hipEventDisableTiming));
+            GMAT_HIP_CHECK(hipEventRecord(c->interEv, c->interStream));
+            GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->interEv, 0));
+        }
         c->interMulti = true;
     } else {
         GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->interEv, 0));
