@@ -368,7 +368,8 @@ int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFr
         // measured on one 4K frame per launch (profiles/r02o_rgb2yuv_strip.txt): 5 chroma rows 11.9 us, 3: 12.2, 4: 13.3, 6: 13.0, 8: 14.8
         // — an odd count makes the iteration count (rows + 3) a multiple of the unrolled loop's period more often; 1080p: 3 rows
         const long rows = (long)(L.h >> 1) * a.nstrips * nframes;   // wave-rows (chroma)
-        seg = (int)std::min(31L, std::max(3L, (rows + 1727) / 1728)) | 1;
+        // (round 4, 32 frames a launch, 4K: 6 ... 12 rows 219-222 us a launch, 14: 226, 16: 229, 24: 237, 31 — the old cap — 232: profiles/r04_rows_all.txt)
+        seg = (int)std::min(9L, std::max(3L, (rows + 1727) / 1728)) | 1;      // (1080p: 9 rows 60.5 us a 32-frame launch, 11: 64, 31: 67)
     }
     a.segRows = seg;
     a.nseg = ((L.h >> 1) + seg - 1) / seg;

@@ -1296,7 +1296,11 @@ int launch_scale_yuv2s(const Yuv2sArgs &a0, hipStream_t stream, const Yuv2xFrame
     if (!seg) {
         const long rows = (long)a.dstH * nstrips * nframes;      // wave-rows of the launch
         const long slots = wave_slots(74);                       // the walker's 74 VGPRs: 6 waves a SIMD
-        seg = (int)std::min(12L, std::max(3L, (rows + slots - 1) / slots));
+        // (round 4, re-swept with non-temporal stores, same box, three alternating repeats: 32 frames a launch 12 / 10 / 9 rows 0.639-0.644 / 0.658-0.660 /
+        // 0.654-0.659 of the roofline, 16 frames 0.603-0.606 / 0.616-0.617 / 0.622-0.623: profiles/r04_headline_rows.txt)
+        // — for launches of several rounds of such bands; a launch of ONE round of 12-row bands keeps them (1080p -> 540p, 32 frames: 10 / 12 / 14 rows 28.1 / 27.7 / 27.3 us)
+        const long natural = std::max(3L, (rows + slots - 1) / slots);
+        seg = (int)(natural > 12 ? (nframes >= 24 ? 10L : 9L) : natural);
         // the 6-pair kernel: 5 warm-up row pairs per segment instead of 3 want longer segments, its 109 VGPRs (4 waves per SIMD)
         // shorter ones; measured best 6 / 12 / 16 rows at 1 / 4 / 32 frames per launch (profiles/r02f_yuv2s_lanczos_rows_sweep.txt)
         if (a.np == 6) seg = std::min(16, std::max(6, 2 * seg));
