@@ -88,7 +88,10 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
 {
     g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0 || strncmp(label, "deep:", 5) == 0) ? 256 : 1;
     const size_t sb = frame_bytes(sf, sw, sh), db = frame_bytes(df, dw, dh);
-    const int NSET = 2 * NF;                      // rotate two frame sets (> 256 MiB together at 4K x 32)
+    // rotate NSETS frame sets (two: > 256 MiB together at 4K x 32, yet a third of the source set can stay in the 256 MB Infinity Cache between
+    // launches; X2BENCH_SETS=8 is bench.py's regime, every frame from HBM — the headline's band-height A/B came out differently in the two, FINDINGS R4-rows)
+    const int NSETS = getenv("X2BENCH_SETS") ? std::max(2, std::min(16, atoi(getenv("X2BENCH_SETS")))) : 2;
+    const int NSET = NSETS * NF;
     std::vector<uint8_t *> src(NSET), dst(NSET);
     std::vector<uint8_t> host(sb);
     for (int i = 0; i < NSET; i++) {
@@ -119,9 +122,9 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         CK(gmat_sws_scale_batch(c, NF, sp.data() + (size_t)set * NF * 4, ss, dp.data() + (size_t)set * NF * 4, ds, streams, 1, 0));
     };
     auto sync_all = [&] { for (void *x : xs) CK(gmat_stream_sync(x)); };
-    for (int i = 0; i < 6; i++) launch(i & 1);
+    for (int i = 0; i < 3 * NSETS; i++) launch(i % NSETS);
     sync_all();
-    prewarm([&](int i) { launch(i & 1); }, sync_all);
+    prewarm([&](int i) { launch(i % NSETS); }, sync_all);
     const std::string kname = gmat_sws_lastKernel(c);
     void *timer = nullptr; CK(gmat_timer_create(&timer));
     float best = 1e30f, sum = 0;
@@ -130,7 +133,7 @@ static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, 
         sync_all();
         CK(gmat_timer_begin(timer, stream));
         if (ncs > 1) { void *e0 = nullptr; CK(gmat_event_create(&e0)); CK(gmat_event_record(e0, stream)); for (int k = 1; k < ncs; k++) CK(gmat_stream_wait_event(xs[k], e0)); gmat_event_destroy(e0); }
-        for (int i = 0; i < launches; i++) launch(i & 1);
+        for (int i = 0; i < launches; i++) launch(i % NSETS);
         for (int k = 1; k < ncs; k++) { CK(gmat_event_record(xev[k], xs[k])); CK(gmat_stream_wait_event(stream, xev[k])); }
         CK(gmat_timer_end(timer, stream));
         float ms = 0; CK(gmat_timer_elapsed_ms(timer, &ms));
