@@ -524,7 +524,7 @@ int yuvl_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvLTables &t)
             return n;
         };
         t.nld = std::max(pieces16(t.offL, 4 * P), pieces16(t.offC, semi16 ? 8 * P : 4 * P));
-        if (t.nld > 9) return 0;
+        if (t.nld > kLineNld16) return 0;
     } else {
     const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
     // dwords a lane reads from a row's image at once: as many as its neighbour's window starts further on (a byte plane's lanes are srcW / dstW
