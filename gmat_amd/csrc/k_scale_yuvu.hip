@@ -700,7 +700,11 @@ int launch_scale_yuvu(const YuvUArgs &a0, hipStream_t stream, const Yuv2xFrames 
     a.nsg = (nstrips + 3) / 4;
     // band height: a band pays its ring's lead-in (R - 1 row pairs filtered for rows above it); a lone small frame wants enough waves
     const long wr = (long)a.dstH * nstrips * nframes * (a.yuvOut ? 2 : 1);
-    int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(32L, std::max(4L, (wr + 4095) / 4096));
+    // (round 4's last sweep, 32 frames a launch, 32 / 48 / 64 rows: 720p -> 1080p rgb24 81.3 / 78.4 / 84.2 us a launch, lanczos 100 / 94.8 / 102.5, 720p -> 4K rgb24 280 / 266.6 /
+    // 264.4, nv12 177.6 / 167.8 / 167.4, 1080p -> 4K rgb24 292.8 / 281.5 / 274.6, 1080p -> 1440p nv12 105.6 / 102.6 / 107; 4:2:0 destinations of up to 1080 rows lose 1 % at 48:
+    // profiles/r04_rows_all.txt)
+    const long cap = (!a.yuvOut || a.dstH > 1080) ? 48 : 32;
+    int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(cap, std::max(4L, (wr + 4095) / 4096));
     if (a.yuvOut) rows = std::max(2, rows & ~1);
     a.bandRows = rows;
     a.nbands = (a.dstH + rows - 1) / rows;
