@@ -1009,10 +1009,13 @@ int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames 
     const long wr = (long)a.dstH * nstrips * nframes;
     // (an up-scale's bands are cheap in source rows and dear in open sums: twice the height — 1080p -> 1440p alone 17.0 -> 14.3-15.9 us)
     const bool upV = a.dstH > a.srcH;
-    int rows = rowsEnv > 0 ? rowsEnv : upV ? (int)std::min(32L, std::max(8L, (wr + 3071) / 3072)) : (int)std::min(32L, std::max(4L, (wr + 6143) / 6144));
+    // (round 4's last sweep, 32 frames a launch, 32 / 48 rows: an RGB destination 4K -> 900p 181 / 175 us a launch, lanczos 256 / 247.6, -> 640 x 360 142.3 / 127.5; a 4:2:0
+    // destination -> 900p 173.5 / 178, -> 640 x 360 147.7 / 159: profiles/r04_rows_all.txt)
+    const long cap = a.yuvOut ? 32 : 48;
+    int rows = rowsEnv > 0 ? rowsEnv : upV ? (int)std::min(32L, std::max(8L, (wr + 3071) / 3072)) : (int)std::min(cap, std::max(4L, (wr + 6143) / 6144));
     // a full launch of down-scaling bands (the rule at its cap): BALANCED bands — round(rows / 32) of them, heights differing by at most one row (900
     // rows: 28 bands of 32 or 33 instead of 28 x 32 and a 4-row one that pays a whole lead-in); otherwise bands of exactly `rows` rows
-    const bool balanced = rowsEnv <= 0 && !upV && rows == 32 && a.dstH >= 64 && a.dstH < 32768;
+    const bool balanced = rowsEnv <= 0 && !upV && rows == (int)cap && a.dstH >= 2 * cap && a.dstH < 32768;
     a.bandRows = rows;
     a.nbands = balanced ? (a.dstH + rows / 2) / rows : (a.dstH + rows - 1) / rows;
     a.bandStep = balanced ? (int)(((unsigned)a.dstH << 16) / (unsigned)a.nbands) : rows << 16;
