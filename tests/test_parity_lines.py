@@ -263,3 +263,42 @@ def test_lines_frame_is_handed_between_streams(dev, orc):
         for p in f:
             p.free()
     lib.gmat_sws_freeContext(c)
+
+
+def test_lines_one_stream_needs_no_ordering_and_a_destroyed_stream_is_never_touched(dev, orc, forced):
+    """round 4 (FINDINGS R4-gaps): a context that only ever sees one stream records no event per call (the record cost the next call's first launch
+    ~ 4 us); the first call on a second stream orders itself behind everything (once), and the FIRST stream may be gone by then"""
+    lib = dev.lib
+    sw, sh, dw, dh = 512, 128, 64, 16
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    assert c
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.gmat_stream_create(C.byref(a)) == 0 and lib.gmat_stream_create(C.byref(b)) == 0
+    frames = [synth_planes(orc, "nv12", sw, sh, seed=80 + i) for i in range(5)]
+    dsrc = [dev.upload_planes(f, 256) for f in frames]
+    ddst = [dev.planes_like("rgb24", dw, dh, 256) for _ in frames]
+
+    def call(i, stream):
+        lib.gmat_sws_setStream(c, stream)
+        assert lib.gmat_sws_scale(c, planes([p.ptr for p in dsrc[i]]), ints([p.stride for p in dsrc[i]]), 0, sh,
+                                  planes([p.ptr for p in ddst[i]]), ints([p.stride for p in ddst[i]])) == dh
+
+    for i in range(3):
+        call(i, a)
+    assert lib.gmat_sws_lastKernel(c).decode() == LINES
+    assert lib.gmat_sws_streamHandoffs(c) == 0
+    assert lib.gmat_stream_sync(a) == 0
+    lib.gmat_stream_destroy(a)                             # the first stream is gone before the second one shows up
+    call(3, b)
+    assert lib.gmat_sws_streamHandoffs(c) == 1
+    call(4, b)
+    assert lib.gmat_sws_streamHandoffs(c) == 1
+    lib.gmat_device_sync()
+    for i, f in enumerate(frames):
+        want = orc.sws(f, sw, sh, "nv12", dw, dh, "rgb24", SWS["bicubic"])
+        assert (ddst[i][0].download() == want[0]).all(), i
+    lib.gmat_stream_destroy(b)
+    for f in dsrc + ddst:
+        for p in f:
+            p.free()
+    lib.gmat_sws_freeContext(c)
