@@ -321,7 +321,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
             return rr;
         };
         if ((r = up(t.hL, l.hL)) < 0 || (r = up(t.hC, l.hC)) < 0 || (r = up(t.offL, l.offL)) < 0 || (r = up(t.offC, l.offC)) < 0) return r;
-        l.P = t.P; l.nld = t.nld; l.RW = t.RW; l.yuvOut = t.yuvOut; l.fullChroma = t.fullChroma;
+        l.P = t.P; l.nld = t.nld; l.RW = t.RW; l.yuvOut = t.yuvOut; l.fullChroma = t.fullChroma; l.dot4L = t.dot4L; l.dot4C = t.dot4C;
         l.pitchL = t.pitchL; l.pitchC = t.pitchC; l.pairRowsL = t.pairRowsL; l.pairRowsC = t.pairRowsC;
         l.baseU = t.baseU; l.baseV = t.baseV; l.frameInts = t.frameInts;
     }

@@ -395,6 +395,7 @@ struct YuvLTables {
     int ok = 0, P = 0, yuvOut = 0, fullChroma = 0;
     int nld = 0;                                              // 1 KB pieces of a source row a wave's 64 windows span, at most
     int wide = 0;                                             // 16-bit samples (scale_yuvl_h16_kernel)
+    int dot4L = 0, dot4C = 0;                                 // a byte plane's table in the signed-byte form (k_scale_yuvl.hip): [P + 1][pitch]
     int RW = 1;                                               // dwords a lane reads from a byte plane's row image at once (the windows' alignment / 4)
     std::vector<int32_t> hL, hC;                              // [dstW][P] / [chrDstW][P] coefficient pairs on the window that starts at off*
     std::vector<int32_t> offL, offC;                          // byte offset of a column's window in its source row (a multiple of 4)
@@ -407,7 +408,7 @@ struct YuvLArgs {
     int ds, dsU, dsV, dstFormat, dstAligned, dstNv12, yuvOut, fullChroma, rangeConv;
     int src16, hShift, hBias;                                 // 16-bit samples: YuvScaleArgs' kind (10 | 16 semi-planar, 17 | 18 planar), hScale16To15_c's shift, accumulator start
     int dst16, dstShift, dither8;                             // 10-bit 4:2:0 destinations; 8-bit planar output of a deeper source (YuvScaleArgs')
-    int P, nld, RW;
+    int P, nld, RW, dot4L, dot4C;
     const int32_t *hL, *hC, *offL, *offC;
     int pitchL, pitchC, pairRowsL, pairRowsC;
     size_t baseU, baseV, frameInts;

@@ -93,6 +93,12 @@ __device__ __forceinline__ int dot2(int packed_ab, int packed_cd, int acc)
                                   __builtin_bit_cast(short2v, packed_cd), acc, false);
 }
 
+// 4-way signed-byte dot product with int32 accumulate: v_dot4c_i32_i8 (exact integer arithmetic).
+__device__ __forceinline__ int dot4s(int bytes_a, int bytes_b, int acc)
+{
+    return __builtin_amdgcn_sdot4(bytes_a, bytes_b, acc, false);
+}
+
 // ---- yuv -> rgb through the closed form of the yuv2rgb.c tables ----------------------------
 // table_rV[V][Y] = y_table[offR + ((V*crv)>>16) + Y], y_table[i] = clip_u8((yb0 + i*cy + 0x8000)>>16)
 // (yuv2rgb.c:737-760, :958-971), so each channel is clip_u8((term + Y*cy) >> 16) with a per-chroma term.

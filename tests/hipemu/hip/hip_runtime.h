@@ -61,6 +61,7 @@ void *dyn_lds();
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 typedef short short2v __attribute__((ext_vector_type(2)));
 static inline int sdot2(short2v a, short2v b, int c) { return c + (int)a.x * (int)b.x + (int)a.y * (int)b.y; }
+static inline int sdot4(int a, int b, int c) { for (int i = 0; i < 4; i++) c += (int)(signed char)(a >> (8 * i)) * (int)(signed char)(b >> (8 * i)); return c; }
 static inline unsigned udot4(unsigned a, unsigned b, unsigned c)
 {
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
@@ -97,6 +98,7 @@ static inline unsigned perm(unsigned hi, unsigned lo, unsigned sel)
 #define __builtin_amdgcn_readlane(v, l) hipemu::lane_read((int)(v), (l))
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) hipemu::dpp_wave_shift((int)(old), (int)(v), (ctrl))
 #define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu::sdot2(a, b, c)
+#define __builtin_amdgcn_sdot4(a, b, c, clamp) hipemu::sdot4(a, b, c)
 #define __builtin_amdgcn_perm(hi, lo, sel) hipemu::perm(hi, lo, sel)
 #define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu::cvt_pk_i16(a, b)
 #define __builtin_amdgcn_udot4(a, b, c, clamp) hipemu::udot4(a, b, c)

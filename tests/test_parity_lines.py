@@ -302,3 +302,16 @@ def test_lines_one_stream_needs_no_ordering_and_a_destroyed_stream_is_never_touc
         for p in f:
             p.free()
     lib.gmat_sws_freeContext(c)
+
+
+@pytest.mark.parametrize("dot4", ["0", "1"])
+@pytest.mark.parametrize("sf,df", [("nv12", "rgb24"), ("yuv420p", "yuv420p"), ("yuv420p", "bgra"), ("nv12", "yuv444p")])
+@pytest.mark.parametrize("geom", [(768, 432, 64, 36), (1536, 96, 64, 4), (520, 100, 66, 12), (384, 216, 160, 90)])
+def test_lines_byte_planes_in_both_table_forms(dev, orc, forced, monkeypatch, dot4, sf, df, geom):
+    """pass H's byte planes: int16 coefficient pairs (v_perm_b32 + v_dot2) and the signed-byte form (samples - 128 in the row image, c = 256 ch + cl,
+    two v_dot4c_i32_i8 a dword; the shipped rule takes it from 40 pairs on) — the same sums, bit for bit"""
+    monkeypatch.setenv("GMAT_LINES_DOT4", dot4)
+    dev.lib.gmat_knobs_reload()
+    assert _check(dev, orc, sf, df, geom) == LINES
+    if geom[0] <= 12 * geom[2]:                            # (Lanczos at 24 : 1 is 144 taps: beyond the form's 128)
+        assert _check(dev, orc, sf, df, geom, flags="lanczos", seed=19) == LINES
