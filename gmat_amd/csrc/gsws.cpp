@@ -151,6 +151,7 @@ struct GmatSwsContext {
     DevBuf dL[4];                 // its device tables: hL, hC, offL, offC
     YuvLArgs largs;
     int32_t *linesBuf = nullptr;  // linesFrames lines frames (an intermediate the context owns: stream_handoff_*)
+    uint8_t *linesStage = nullptr; size_t linesStageBytes = 0;     // dword-aligned copies of source planes that are not (lines_stage)
     int linesFrames = 0;
     DevBuf dHLreg, dHCreg, dVrec, dVrecC;
     // how a scaled YUV->RGB context runs: 0 two kernels (convert, scale) with an HBM intermediate,
@@ -206,7 +207,7 @@ struct GmatSwsContext {
         if (interBatch) (void)hipFree(interBatch);
         if (cross) gmat_sws_freeContext(cross);
         if (crossBuf) (void)hipFree(crossBuf);
-        if (linesBuf) (void)hipFree(linesBuf);
+        if (linesBuf) (void)hipFree(linesBuf); if (linesStage) (void)hipFree(linesStage);
         if (interEv) (void)hipEventDestroy(interEv);
         if (inner) gmat_sws_freeContext(inner);
         if (batchEvReady) for (hipEvent_t e : batchEv) if (e) (void)hipEventDestroy(e);
@@ -916,7 +917,10 @@ static bool yuvl_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n
     if (c->ytiling.TW != 0 && lines_mode() == 1 && !((n > 3 && !deep) || c->srcW >= 2 * c->dstW)) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
     if (!ya.nv12) all |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
-    return (all & 3) == 0;
+    // planes that are not dword-aligned go to the tiled kernel — where there is one: a context it has no tiling for (a ratio or a filter beyond a tile's
+    // LDS) was accepted on the strength of this form and must not fail frame by frame (found by fuzz_ref_core: yuv420p 321 x 432 -> 81 x 108 sinc, chroma
+    // rows of 161 bytes, -ENOSYS from sws_scale); the launch then reads dword-aligned copies of the planes (lines_stage)
+    return (all & 3) == 0 || c->ytiling.TW == 0;
 }
 static int lines_prepare(GmatSwsContext *c, int nframes)
 {
@@ -925,6 +929,30 @@ static int lines_prepare(GmatSwsContext *c, int nframes)
         GMAT_HIP_CHECK(hipMalloc((void **)&c->linesBuf, c->yl.frameInts * sizeof(int32_t) * nframes));
         c->linesFrames = nframes;
     }
+    return 0;
+}
+// source planes that are not dword-aligned, in a context the tiled kernel has no tiling for: the launch reads dword-aligned COPIES (pitch a multiple of 256,
+// device-to-device on the call's stream) — pass H reads a row as aligned 16-byte pieces of a buffer resource whose range ends on a dword
+static int lines_stage(GmatSwsContext *c, YuvScaleArgs &ya, hipStream_t st, Yuv2xFrames &fr, int n)
+{
+    const int bps = ya.src16 ? 2 : 1;
+    const bool semi = ya.src16 ? ya.src16 < 17 : ya.nv12 != 0;              // interleaved chroma
+    const size_t rowL = (size_t)ya.srcW * bps, rowC = (size_t)(semi ? 2 * ya.chrSrcW : ya.chrSrcW) * bps;
+    const size_t pitchL = (rowL + 255) & ~(size_t)255, pitchC = (rowC + 255) & ~(size_t)255;
+    const size_t bytesL = pitchL * ya.srcH, bytesC = pitchC * ya.chrSrcH, frame = bytesL + (semi ? 1 : 2) * bytesC;
+    if (c->linesStageBytes < frame * n) {
+        if (c->linesStage) { (void)hipFree(c->linesStage); c->linesStage = nullptr; c->linesStageBytes = 0; }
+        GMAT_HIP_CHECK(hipMalloc((void **)&c->linesStage, frame * n));
+        c->linesStageBytes = frame * n;
+    }
+    for (int i = 0; i < n; i++) {
+        uint8_t *b = c->linesStage + frame * i;
+        GMAT_HIP_CHECK(hipMemcpy2DAsync(b, pitchL, fr.y[i], ya.ys, rowL, ya.srcH, hipMemcpyDeviceToDevice, st));
+        GMAT_HIP_CHECK(hipMemcpy2DAsync(b + bytesL, pitchC, fr.u[i], ya.us, rowC, ya.chrSrcH, hipMemcpyDeviceToDevice, st));
+        if (!semi) GMAT_HIP_CHECK(hipMemcpy2DAsync(b + bytesL + bytesC, pitchC, fr.v[i], ya.vs, rowC, ya.chrSrcH, hipMemcpyDeviceToDevice, st));
+        fr.y[i] = b; fr.u[i] = b + bytesL; fr.v[i] = semi ? nullptr : b + bytesL + bytesC;
+    }
+    ya.ys = (int)pitchL; ya.us = (int)pitchC; ya.vs = (int)pitchC;
     return 0;
 }
 static YuvLArgs make_yuvl_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
@@ -1018,6 +1046,14 @@ static const PlaneKernel kPlaneKernels[] = {
          GmatSwsContext *m = const_cast<GmatSwsContext *>(c);             // (the lines frame is allocated on first use and grows with the launch)
          if (int r = lines_prepare(m, n); r < 0) return r;
          m->interTouched = true;
+         uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us;
+         if (!ya.nv12) all |= (uintptr_t)ya.v | (uintptr_t)ya.vs;
+         for (int i = 0; i < n; i++) all |= (uintptr_t)fr.y[i] | (uintptr_t)fr.u[i] | (ya.nv12 ? 0 : (uintptr_t)fr.v[i]);
+         if (all & 3) {                                                    // (only where the tiled kernel has no tiling: yuvl_eligible)
+             YuvScaleArgs ya2 = ya; Yuv2xFrames fr2 = fr;
+             if (int r = lines_stage(m, ya2, st, fr2, n); r < 0) return r;
+             return launch_scale_yuvl(make_yuvl_args(c, ya2), st, &fr2, n);
+         }
          return launch_scale_yuvl(make_yuvl_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *, const YuvScaleArgs &, int) { return true; },      // everything else: the tiled plane scaler
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },

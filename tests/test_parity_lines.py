@@ -315,3 +315,16 @@ def test_lines_byte_planes_in_both_table_forms(dev, orc, forced, monkeypatch, do
     assert _check(dev, orc, sf, df, geom) == LINES
     if geom[0] <= 12 * geom[2]:                            # (Lanczos at 24 : 1 is 144 taps: beyond the form's 128)
         assert _check(dev, orc, sf, df, geom, flags="lanczos", seed=19) == LINES
+
+
+@pytest.mark.parametrize("sf,df,geom,flags", [("yuv420p", "rgb24", (321, 432, 81, 108), "sinc"), ("nv12", "rgb24", (1538, 98, 64, 4), "bicubic"),
+                                              ("yuv420p", "yuv420p", (1001, 120, 40, 6), "bicubic"), ("nv12", "nv12", (1538, 98, 64, 4), "bicubic"),
+                                              ("p010le", "nv12", (1538, 98, 64, 4), "bicubic"), ("yuv420p16le", "rgb24", (1610, 96, 66, 4), "bicubic")])
+@pytest.mark.parametrize("src_align,src_extra", [(1, 0), (1, 1), (2, 2)])
+def test_lines_serve_unaligned_planes_where_no_tile_fits(dev, orc, sf, df, geom, flags, src_align, src_extra):
+    """a context the tiled kernel has no tiling for was accepted on the strength of the lines form: it must serve source planes of any alignment
+    (fuzz_ref_core: yuv420p 321 x 432 -> 81 x 108 sinc, chroma rows of 161 bytes — gmat_sws_scale returned -ENOSYS frame by frame)"""
+    if sf in ("p010le", "yuv420p16le") and src_align == 1:
+        src_align, src_extra = 2, 6                        # (rows of 16-bit samples are at least 2-byte aligned)
+    k = _check(dev, orc, sf, df, geom, flags=flags, src_align=src_align, src_extra=src_extra)
+    assert k == (LINES if sf in ("nv12", "yuv420p") else "scale_yuvl_h16_kernel+scale_yuvl_v_kernel"), k
