@@ -297,7 +297,10 @@ int gmat_hwframe_transfer_data(GmatFrame *dst, const GmatFrame *src, void *strea
     if (!dst || !src) return GMAT_ERR(EINVAL);
     const bool up = dst->format == GMAT_PIX_FMT_HIP && src->format != GMAT_PIX_FMT_HIP;
     const bool down = src->format == GMAT_PIX_FMT_HIP && dst->format != GMAT_PIX_FMT_HIP;
-    if (!up && !down) return GMAT_ERR(EINVAL);
+    // both frames on the device: cuda_transfer_data copies whatever memory types the two sides have (hwcontext_cuda.c:239-252: srcMemoryType /
+    // dstMemoryType by hw_frames_ctx), and av_hwframe_transfer_data reaches it for two hardware frames (hwcontext.c:448-467)
+    const bool d2d = dst->format == GMAT_PIX_FMT_HIP && src->format == GMAT_PIX_FMT_HIP;
+    if (!up && !down && !d2d) return GMAT_ERR(EINVAL);
     const int fmt = up ? dst->sw_format : src->sw_format;
     if ((up ? src->sw_format : dst->sw_format) != fmt || src->width != dst->width || src->height != dst->height)
         return GMAT_ERR(EINVAL);
@@ -307,7 +310,7 @@ int gmat_hwframe_transfer_data(GmatFrame *dst, const GmatFrame *src, void *strea
     for (int i = 0; i < L.planes; i++) {
         GMAT_HIP_CHECK(hipMemcpy2DAsync(dst->data[i], (size_t)dst->linesize[i], src->data[i], (size_t)src->linesize[i],
                                         (size_t)plane_row_bytes(fmt, i, src->width), (size_t)plane_rows(fmt, i, src->height),
-                                        up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
+                                        d2d ? hipMemcpyDeviceToDevice : up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
     }
     dst->pts = src->pts;
     dst->colorspace = src->colorspace;

@@ -1104,6 +1104,8 @@ static bool rgb2h_yuv_eligible(const GmatSwsContext *c, const uint8_t *const src
     return bytes_per_pixel(c->dstFormat) == 4 ? ((((uintptr_t)dst | (uintptr_t)dstStride) & 15) == 0) : al4(dst, dstStride);
 }
 
+static bool shift8_shortcut(const GmatSwsContext *c);          // (defined with active_plan below)
+
 namespace gmat {
 // A context's tables live on the device that was current when it was created; a launch made while another device is current
 // would run there with pointers of this one (hwcontext_cuda.c:395-434 makes the stream's device current around every call).
@@ -1151,8 +1153,11 @@ static int stream_handoff_acquire(GmatSwsContext *c, hipStream_t s)
             GMAT_HIP_CHECK(hipEventRecord(c->interEv, c->interStream));
             GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->interEv, 0));
         }
+        // the event exists from here on: a call that does not touch the intermediates records nothing (no release), and the next call on yet another
+        // stream waits on it — a wait on a never-recorded event is a no-op, a wait on a null handle an error that stuck
+        if (!c->interEv) GMAT_HIP_CHECK(hipEventCreateWithFlags(&c->interEv, hipEventDisableTiming));
         c->interMulti = true;
-    } else {
+    } else if (c->interEv) {
         GMAT_HIP_CHECK(hipStreamWaitEvent(s, c->interEv, 0));
     }
     c->handoffs++;
@@ -1264,8 +1269,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         }
         return 1;
     }
-    if ((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
-        c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv && !(GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8")))) {
+    if (shift8_shortcut(c)) {
         // NV12 -> P010LE / P016LE at equal size: t << 8 of every sample (gmat_sws_scale's rule), frame by frame — the kernel is a copy
         for (int f = 0; f < n; f++) {
             const uint8_t *const *sp = src_planes + 4 * f;
@@ -1590,6 +1594,30 @@ static const ScalePlan &active_plan(const GmatSwsContext *c)
 {
     if (c->mode == MODE_SCALE16) return c->plan16;
     return ((is_plane_src(c->srcFormat) || c->rgbViaPlanes) && c->fused == 2) ? c->planYuv : c->plan;
+}
+
+// every output of the bank is its own source sample: one non-zero coefficient (= the bank's unit, the rows are normalised) at source index i
+static bool bank_is_identity(const FilterBank &fb)
+{
+    if (fb.count <= 0 || fb.taps <= 0) return false;
+    for (int i = 0; i < fb.count; i++) {
+        const int k = i - fb.pos[i];
+        if (k < 0 || k >= fb.taps) return false;
+        for (int t = 0; t < fb.taps; t++)
+            if ((fb.coef[(size_t)i * fb.taps + t] != 0) != (t == k)) return false;
+    }
+    return true;
+}
+
+// NV12 -> P010LE / P016LE at equal size is t << 8 of every sample only while all four filter banks are one-tap identities: chroma positions that differ
+// between the ends (gmat_sws_setChromaPos) make the chroma banks real filters at equal size too
+static bool shift8_shortcut(const GmatSwsContext *c)
+{
+    if (!((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
+          c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv)) return false;
+    if (GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8"))) return false;
+    const ScalePlan &p = active_plan(c);
+    return bank_is_identity(p.hLum) && bank_is_identity(p.vLum) && bank_is_identity(p.hChr) && bank_is_identity(p.vChr);
 }
 
 // packed_vscale's choice of writer per output row (vscale.c:135-167) as the alpha kernel's form word (k_rgb64.hip)
@@ -2031,8 +2059,7 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
     int r = 0;
     // NV12 -> P010LE / P016LE at equal size: the generic lines with one-tap filters make t << 8 of every sample (see nv12_shift8_kernel); a range
     // conversion, the only thing that changes the lines' values here, keeps the plane scaler
-    if ((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
-        c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv && !(GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8")))) {
+    if (shift8_shortcut(c)) {
         if (!dst[1]) return GMAT_ERR(EINVAL);
         c->lastKernel = "nv12_shift8_kernel";
         r = launch_nv12_shift8(src[0], srcStride[0], src[1], srcStride[1], dst[0], dstStride[0], dst[1], dstStride[1], c->srcW, c->srcH, c->stream);

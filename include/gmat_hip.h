@@ -211,7 +211,8 @@ GMAT_API void gmat_frame_free(GmatFrame **frame);           /* av_frame_free: re
  * gmat_hwframe_ctx_free release their device memory at once.  gmat_hwframe_get_buffer on a freed context fails. */
 GMAT_API void gmat_frame_unref(GmatFrame *frame);
 /* av_hwframe_transfer_data (hwcontext.h:413, hwcontext_cuda.c:221-279): one 2-D async copy per
- * plane on `stream`; direction from which side has format == GMAT_PIX_FMT_HIP */
+ * plane on `stream`; direction from which side has format == GMAT_PIX_FMT_HIP (both: device to device, as cuda_transfer_data
+ * copies between two hardware frames) */
 GMAT_API int  gmat_hwframe_transfer_data(GmatFrame *dst, const GmatFrame *src, void *stream);
 /* pinned host staging (hipHostMalloc) so transfers overlap compute */
 GMAT_API int  gmat_host_frame_alloc(GmatFrame *frame, int sw_format, int width, int height);

@@ -269,7 +269,11 @@ static int hip_transfer_data(AVHWFramesContext *ctx, AVFrame *dst, const AVFrame
     const int dst_dev = dst->hw_frames_ctx != NULL, src_dev = src->hw_frames_ctx != NULL;
 
     if ((src_dev && ((AVHWFramesContext *)src->hw_frames_ctx->data)->format != AV_PIX_FMT_CUDA) ||
-        (dst_dev && ((AVHWFramesContext *)dst->hw_frames_ctx->data)->format != AV_PIX_FMT_CUDA) || dst_dev == src_dev)
+        (dst_dev && ((AVHWFramesContext *)dst->hw_frames_ctx->data)->format != AV_PIX_FMT_CUDA) || (!dst_dev && !src_dev))
+        return AVERROR(ENOSYS);
+    /* two hardware frames: cuda_transfer_data copies device to device (both sides CU_MEMORYTYPE_DEVICE, hwcontext_cuda.c:239-252) — reached through
+     * av_hwframe_transfer_data's transfer_data_from, then transfer_data_to (hwcontext.c:448-467); the two pools hold one sw_format or the copy is refused */
+    if (dst_dev && src_dev && ((AVHWFramesContext *)dst->hw_frames_ctx->data)->sw_format != ((AVHWFramesContext *)src->hw_frames_ctx->data)->sw_format)
         return AVERROR(ENOSYS);
     if (hip_make_current(ctx->device_ctx) < 0)
         return AVERROR_EXTERNAL;

@@ -101,6 +101,22 @@ static int gh_follow_frame_colour(GmatHipContext *s, const AVFrame *in)
     return 0;
 }
 
+/* ... and the output frame says what its samples are (vf_scale.c:783-786,:831): av_frame_copy_props carried the INPUT's tags over, but a
+ * full-range YUV source has just been compressed to limited range and a matrix applied or removed.  Without this a downstream filter sees
+ * limited-range samples tagged AVCOL_RANGE_JPEG, and a second scale_hip compresses them again.  The passthrough of an untouched frame
+ * (gh_filter_frame's bypass, vf_scale_cuda.c:543-544) converts nothing and keeps its tags: samples and tags agree on both routes. */
+static void gh_tag_output(const GmatHipContext *s, const AVFrame *in, AVFrame *out)
+{
+    if (av_pix_fmt_desc_get(s->out_fmt)->flags & AV_PIX_FMT_FLAG_RGB)
+        out->colorspace = AVCOL_SPC_RGB;
+    else if (out->colorspace == AVCOL_SPC_RGB)
+        out->colorspace = AVCOL_SPC_UNSPECIFIED;
+    /* no out_range option here: the destination range is libswscale's default — limited for YUV, and sws_getColorspaceDetails reports an RGB
+     * end as full (utils.c:1074-1075), which is what vf_scale.c:831 writes into the frame */
+    if (in->color_range != AVCOL_RANGE_UNSPECIFIED)
+        out->color_range = (av_pix_fmt_desc_get(s->out_fmt)->flags & AV_PIX_FMT_FLAG_RGB) ? AVCOL_RANGE_JPEG : AVCOL_RANGE_MPEG;
+}
+
 static int plane_geometry(enum AVPixelFormat fmt, int plane, int w, int h, int *pw, int *ph, int *bpp)
 {
     const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(fmt);
@@ -353,6 +369,7 @@ static int gh_filter_frame(AVFilterLink *inlink, AVFrame *in)
         if ((ret = gh_follow_frame_colour(s, in)) >= 0) {
             ret = gmat_sws_scale(s->sws, (const uint8_t *const *)in->data, in->linesize, 0, in->height, out->data, out->linesize);
             ret = ret < 0 ? AVERROR_EXTERNAL : 0;
+            gh_tag_output(s, in, out);
         }
     } else {
         ret = gh_run_planes(s, in, out);
@@ -461,6 +478,10 @@ static int gh_flush_queue(AVFilterContext *ctx)
                     ret = AVERROR_EXTERNAL;
         }
     }
+    if (s->kind == GH_SCALE || s->kind == GH_FORMAT)
+        for (int i = 0; i < n; i++)
+            if (outs[i])
+                gh_tag_output(s, s->queue[i], outs[i]);
     for (int i = 0; i < n; i++)
         av_frame_free(&s->queue[i]);
     s->nqueued = 0;

@@ -146,6 +146,37 @@ static long compare(const AVFrame *a, const AVFrame *b, int frame_no)
     return bad;
 }
 
+/* av_hwframe_transfer_data between two HARDWARE frames of two pools (hwcontext.c:448-467: transfer_data_from of the source's context, then
+ * transfer_data_to of the destination's): up, device to device, down — the bytes that went in (ENOSYS where cuda_transfer_data copies) */
+static int d2d_check(AVBufferRef *device, int w, int h, enum AVPixelFormat fmt, uint32_t seed)
+{
+    AVBufferRef *pool[2] = { NULL, NULL };
+    AVFrame *hw[2] = { av_frame_alloc(), av_frame_alloc() }, *in = make_frame(w, h, fmt, seed, 0), *back = av_frame_alloc();
+    long bad;
+    if (!hw[0] || !hw[1] || !in || !back)
+        return AVERROR(ENOMEM);
+    for (int i = 0; i < 2; i++) {
+        AVHWFramesContext *fc;
+        pool[i] = av_hwframe_ctx_alloc(device);
+        if (!pool[i])
+            return AVERROR(ENOMEM);
+        fc = (AVHWFramesContext *)pool[i]->data;
+        fc->format = AV_PIX_FMT_CUDA; fc->sw_format = fmt; fc->width = w; fc->height = h;
+        CK(av_hwframe_ctx_init(pool[i]));
+        CK(av_hwframe_get_buffer(pool[i], hw[i], 0));
+    }
+    CK(av_hwframe_transfer_data(hw[0], in, 0));
+    CK(av_hwframe_transfer_data(hw[1], hw[0], 0));
+    back->format = fmt;
+    CK(av_hwframe_transfer_data(back, hw[1], 0));
+    back->width = w; back->height = h;
+    bad = compare(back, in, 0);
+    printf("%s %dx%d  upload, device to device, download: %ld mismatching bytes\n", av_get_pix_fmt_name(fmt), w, h, bad);
+    av_frame_free(&hw[0]); av_frame_free(&hw[1]); av_frame_free(&in); av_frame_free(&back);
+    av_buffer_unref(&pool[0]); av_buffer_unref(&pool[1]);
+    return bad ? 4 : 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 7) { fprintf(stderr, "usage: avfilter_graph_caller w h pix_fmt nframes \"gpu chain\" \"cpu chain\" [seed]\n"); return 1; }
@@ -162,6 +193,11 @@ int main(int argc, char **argv)
     if (fmt == AV_PIX_FMT_NONE || nframes < 1 || nframes > 64) { fprintf(stderr, "bad arguments\n"); return 1; }
     av_log_set_level(AV_LOG_WARNING);
     CK(av_hwdevice_ctx_create(&device, AV_HWDEVICE_TYPE_CUDA, "0", NULL, 0));
+    if (!strcmp(argv[5], "d2d")) {
+        int r = d2d_check(device, w, h, fmt, seed);
+        av_buffer_unref(&device);
+        return r;
+    }
     CK(build(&gpu, argv[5], w, h, fmt, device));
     CK(build(&cpu, argv[6], w, h, fmt, NULL));
 
@@ -192,6 +228,12 @@ int main(int argc, char **argv)
     }
     for (int i = 0; i < nframes; i++) {
         if (outs_gpu[i]->pts != outs_cpu[i]->pts) { fprintf(stderr, "frame %d: pts %ld against %ld\n", i, (long)outs_gpu[i]->pts, (long)outs_cpu[i]->pts); bad++; }
+        /* the tags a downstream filter would act on: a frame must say what its samples are (vf_scale.c:783-786,:831) */
+        if (argc > 9 && (outs_gpu[i]->color_range != outs_cpu[i]->color_range || outs_gpu[i]->colorspace != outs_cpu[i]->colorspace)) {   /* (tagged runs: scale_hip / format_hip against `scale`) */
+            fprintf(stderr, "frame %d: color_range %d colorspace %d against %d %d\n", i, outs_gpu[i]->color_range, outs_gpu[i]->colorspace,
+                    outs_cpu[i]->color_range, outs_cpu[i]->colorspace);
+            bad++;
+        }
         bad += compare(outs_gpu[i], outs_cpu[i], i);
         got++;
     }

@@ -111,7 +111,7 @@ static inline float __fmul_rn(float a, float b) { volatile float r = a * b; retu
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 
 // ---- runtime API subset -------------------------------------------------------------------------
-typedef enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
+typedef enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidHandle = 400, hipErrorNotSupported = 801 } hipError_t;
 typedef struct ihipStream_t *hipStream_t;
 typedef struct ihipEvent_t *hipEvent_t;
 typedef struct ihipGraph *hipGraph_t;

@@ -253,7 +253,7 @@ hipError_t hipDeviceSynchronize() { return hipSuccess; }
 struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new ihipEvent_t(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new ihipEvent_t(); return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return e ? hipSuccess : hipErrorInvalidHandle; }   // (the runtime refuses a null event: ADVICE r4)
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -114,6 +114,11 @@ TAGGED = [
     (320, 180, "nv12", 2, "scale_hip=w=160:h=90", "scale=160:90:flags=bicubic", "nv12", 1, 2),                            # YUV -> YUV: full -> limited range conversion
     (320, 180, "rgb24", 2, "scale_hip=w=160:h=90:format=nv12", "scale=160:90:flags=bicubic", "nv12", 1, 1),               # RGB -> YUV: the tag's matrix on the way out
     (320, 180, "nv12", 5, "scale_hip=w=160:h=90:format=rgb24:batch=2", "scale=160:90:flags=bicubic", "rgb24", 1, 2),      # ... through the queue
+    # the output frame says what its samples are — a full-range source leaves the first scale_hip as LIMITED range tagged so, and a second
+    # scale_hip (or a converter) must not compress it again; the caller also compares every output frame's color_range / colorspace with `scale`'s
+    (320, 180, "nv12", 2, "scale_hip=w=240:h=136,scale_hip=w=160:h=90", "scale=240:136:flags=bicubic,scale=160:90:flags=bicubic", "nv12", 1, 2),
+    (320, 180, "nv12", 5, "scale_hip=w=240:h=136:batch=2,scale_hip=w=160:h=90:format=rgb24:batch=3", "scale=240:136:flags=bicubic,scale=160:90:flags=bicubic", "rgb24", 1, 2),
+    (320, 180, "yuv420p", 2, "scale_hip=w=160:h=90,format_hip=pix_fmt=rgb24", "scale=160:90:flags=bicubic,scale=flags=bicubic", "rgb24", 5, 2),
 ]
 
 
@@ -140,6 +145,15 @@ def test_libavfilters_own_hwupload_and_hwdownload_round_trip(graph_caller, fmt):
         r = subprocess.run([os.path.join(graph_caller, "avfilter_graph_caller"), str(w), str(h), fmt, "3",
                             "hwupload,hwdownload,format=%s" % fmt, "null"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "0 mismatching bytes" in r.stdout, (w, h, (r.stdout + r.stderr)[-2000:])
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "yuv420p", "rgb24", "p010le"])
+def test_transfer_between_two_hardware_frames(graph_caller, fmt):
+    """av_hwframe_transfer_data with a hardware frame on BOTH sides (hwcontext.c:448-467) — cuda_transfer_data copies device to device
+    (hwcontext_cuda.c:239-252); hip_transfer_data answered ENOSYS.  Upload, pool-to-pool copy, download: the bytes that went in."""
+    for w, h in ((320, 180), (162, 90)):
+        r = subprocess.run([os.path.join(graph_caller, "avfilter_graph_caller"), str(w), str(h), fmt, "1", "d2d", "null"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and " 0 mismatching bytes" in r.stdout, (w, h, (r.stdout + r.stderr)[-2000:])
 
 
 def test_error_paths_of_the_real_graph(graph_caller):

@@ -304,6 +304,52 @@ def test_lines_one_stream_needs_no_ordering_and_a_destroyed_stream_is_never_touc
     lib.gmat_sws_freeContext(c)
 
 
+def test_a_call_that_leaves_the_lines_frame_alone_on_a_second_stream(dev, orc):
+    """the first call on a second stream that does NOT touch the intermediates (below 2 : 1 a launch of fewer than four frames is the
+    tiled kernel's) records nothing — the context must still own an event afterwards, or the next call that does touch them waits on a null handle
+    (hipErrorInvalidHandle from then on).  Touched on a, untouched on b, touched on b, touched on a, untouched on a third stream, touched there."""
+    lib = dev.lib
+    sw, sh, dw, dh = 480, 270, 320, 180
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT["yuv444p"], SWS["bicubic"], None)
+    assert c
+    st = []
+    for _ in range(3):
+        h = C.c_void_p()
+        assert lib.gmat_stream_create(C.byref(h)) == 0
+        st.append(h)
+    plan = [(5, 0), (1, 1), (5, 1), (4, 0), (2, 2), (6, 2), (1, 0)]          # (frames in the call, stream)
+    nf = sum(n for n, _ in plan)
+    frames = [synth_planes(orc, "nv12", sw, sh, seed=140 + i) for i in range(nf)]
+    dsrc = [dev.upload_planes(f, 256) for f in frames]
+    ddst = [dev.planes_like("yuv444p", dw, dh, 256) for _ in frames]
+    ss, ds = ints([p.stride for p in dsrc[0]]), ints([p.stride for p in ddst[0]])
+    f0, kernels = 0, []
+    for n, si in plan:
+        sp, dp = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))()
+        for f in range(n):
+            for i, p in enumerate(dsrc[f0 + f]):
+                sp[4 * f + i] = p.ptr
+            for i, p in enumerate(ddst[f0 + f]):
+                dp[4 * f + i] = p.ptr
+        one = (C.c_void_p * 1)(st[si])
+        assert lib.gmat_sws_scale_batch(c, n, C.cast(sp, C.POINTER(C.c_void_p)), ss, C.cast(dp, C.POINTER(C.c_void_p)), ds,
+                                        C.cast(one, C.POINTER(C.c_void_p)), 1, 3) == n, (n, si, kernels)
+        kernels.append(lib.gmat_sws_lastKernel(c).decode())
+        f0 += n
+    assert [k == LINES for k in kernels] == [True, False, True, True, False, True, False], kernels
+    lib.gmat_device_sync()
+    for i, f in enumerate(frames):
+        want = orc.sws(f, sw, sh, "nv12", dw, dh, "yuv444p", SWS["bicubic"])
+        for a, b in zip(ddst[i], want):
+            assert (a.download() == b).all(), i
+    for s in st:
+        lib.gmat_stream_destroy(s)
+    for f in dsrc + ddst:
+        for p in f:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+
+
 @pytest.mark.parametrize("dot4", ["0", "1"])
 @pytest.mark.parametrize("sf,df", [("nv12", "rgb24"), ("yuv420p", "yuv420p"), ("yuv420p", "bgra"), ("nv12", "yuv444p")])
 @pytest.mark.parametrize("geom", [(768, 432, 64, 36), (1536, 96, 64, 4), (520, 100, 66, 12), (384, 216, 160, 90)])

@@ -1126,6 +1126,60 @@ def test_nv12_to_p01x_knob_keeps_the_plane_scaler(dev, orc, monkeypatch):
         p.free()
 
 
+@pytest.mark.parametrize("df", ["p010le", "p016le"])
+@pytest.mark.parametrize("pos", [(0, 0, 256, 256), (0, 128, 0, 128), (128, 128, 128, 128), (-513, 0, -513, 256)])
+def test_nv12_to_p01x_with_chroma_positions_that_differ_is_not_a_shift(dev, orc, df, pos):
+    """gmat_sws_setChromaPos succeeds on these contexts, and positions that differ between the ends make the chroma banks real filters at
+    equal size — the t << 8 shortcut must step aside (it is taken only while all four banks are one-tap identities); one frame and a batch of three"""
+    import ctypes as C
+    from harness import PIX_FMT, planes, ints, alloc_planes
+    lib, L = dev.lib, orc.L
+    L.orc_sws_create_ex.restype = C.c_void_p
+    L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    w, h, nf = 96, 40, 3
+    srcs = [synth_planes(orc, "nv12", w, h, seed=19 + f) for f in range(nf)]
+    wants = []
+    oc = L.orc_sws_create_ex(w, h, PIX_FMT["nv12"], w, h, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(*pos), 0, 0)
+    assert oc
+    for src in srcs:
+        want = alloc_planes(df, w, h)
+        assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
+                               planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == h
+        wants.append(want)
+    L.orc_sws_free(oc)
+    same = pos[0] == pos[2] and pos[1] == pos[3]
+    shifted = (wants[0][1].view(np.uint16) == (srcs[0][1].astype(np.uint16) << 8)).all()
+    assert shifted == same                                           # the oracle: a pure shift exactly when the positions agree
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT["nv12"], w, h, PIX_FMT[df], SWS["bicubic"], None)
+    assert c
+    assert lib.gmat_sws_setChromaPos(c, *pos) == 0
+    dsrc = [dev.upload_planes(s_, 64) for s_ in srcs]
+    ddst = [dev.planes_like(df, w, h, 64) for _ in srcs]
+    assert lib.gmat_sws_scale(c, planes([p.ptr for p in dsrc[0]]), ints([p.stride for p in dsrc[0]]), 0, h,
+                              planes([p.ptr for p in ddst[0]]), ints([p.stride for p in ddst[0]])) == h
+    assert (lib.gmat_sws_lastKernel(c).decode() == "nv12_shift8_kernel") == same
+    for a, b in zip(ddst[0], wants[0]):
+        assert (a.download() == b).all(), lib.gmat_sws_lastKernel(c).decode()
+        lib.gmat_memset(a.ptr, 0xCD, a.stride * a.rows)
+    sp, dp = (C.c_void_p * (4 * nf))(), (C.c_void_p * (4 * nf))()
+    for f in range(nf):
+        for i, p in enumerate(dsrc[f]):
+            sp[4 * f + i] = p.ptr
+        for i, p in enumerate(ddst[f]):
+            dp[4 * f + i] = p.ptr
+    assert lib.gmat_sws_scale_batch(c, nf, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]), C.cast(dp, C.POINTER(C.c_void_p)),
+                                    ints([p.stride for p in ddst[0]]), C.cast((C.c_void_p * 1)(None), C.POINTER(C.c_void_p)), 1, 3) == nf
+    lib.gmat_device_sync()
+    assert (lib.gmat_sws_lastKernel(c).decode() == "nv12_shift8_kernel") == same
+    for f in range(nf):
+        for a, b in zip(ddst[f], wants[f]):
+            assert (a.download() == b).all(), (f, lib.gmat_sws_lastKernel(c).decode())
+    for f in dsrc + ddst:
+        for p in f:
+            p.free()
+    lib.gmat_sws_freeContext(c)
+
+
 @pytest.mark.parametrize("pair", [("nv12", "yuv420p"), ("yuv420p", "nv12")])
 @pytest.mark.parametrize("w,h", [(96, 40), (64, 8), (130, 34), (37, 9), (4128, 6), (32, 2)])
 @pytest.mark.parametrize("align", [64, 16, 4])
