@@ -1002,7 +1002,7 @@ static const PlaneKernel kPlaneKernels[] = {
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) {
          if (!yuvg_eligible(c, ya) || yuv3x1_eligible(c, ya) || yuv3x2_eligible(c, ya)) return false;
          const bool four = yuv4r_eligible(c, ya) || yuv4x1_eligible(c, ya), threeRgb = yuv32r_eligible(c, ya) || yuv3r_eligible(c, ya);
-         if (!(four || (threeRgb && n == 1))) return false;          // (every other context reaches the form in the band walker's own place)
+         if (!((four && n <= 3) || (threeRgb && n == 1))) return false;   // (every other context reaches the form in the band walker's own place)
          const char *bf = GMAT_KNOB("GMAT_BLOCK_FIRST");
          return !(bf && !atoi(bf)) && yuvg_block_form(make_yuvg_args(c, ya), n); },
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvg_blk_kernel"; },

@@ -50,6 +50,12 @@ constexpr int S2_STRIP = 256;                  // output columns per wave: 64 la
 #define S2_SATPK 1
 #endif
 constexpr int S2_LUT_N = S2_LUT512 ? 512 : 256, S2_LUT_BIAS = S2_LUT512 ? 128 : 0;
+// S2_PROBE (measurement builds only, tools/build_variant.sh — the results are WRONG pixels): what the walker's time is made of.  Bit 0: no horizontal
+// chroma filter (-26 VALU a row), bit 1: no vertical luma filter (-16), bit 2: the pair's second luma row is not filtered (-23), bit 3: the second luma row
+// is not LOADED either (a third of the read bytes gone, with bit 2).  profiles/r05b_headline_probes.txt
+#ifndef S2_PROBE
+#define S2_PROBE 0
+#endif
 
 // ---- unaligned vector loads (4-byte aligned addresses) -----------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArg
         // stays the SGPR base of the global_load
 #if S2_SBASE
         P.la = bY.ld16(uoffL, (unsigned)ra * (unsigned)a.ys);       // lane offset (loop-invariant VGPR) + scalar row offset
-        P.lb = bY.ld16(uoffL, (unsigned)rb * (unsigned)a.ys);
+        if ((S2_PROBE & 8) == 0) P.lb = bY.ld16(uoffL, (unsigned)rb * (unsigned)a.ys); else P.lb = P.la;
 #else
         P.la = s2_ld16(py + (unsigned)((unsigned)ra * (unsigned)a.ys + uoffL));
         P.lb = s2_ld16(py + (unsigned)((unsigned)rb * (unsigned)a.ys + uoffL));
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArg
         {
             int sa[4], sb[4];
             hrow(fix_luma(cur.la, edge_c), sa);
-            hrow(fix_luma(cur.lb, edge_c), sb);
+            if ((S2_PROBE & 4) == 0) hrow(fix_luma(cur.lb, edge_c), sb);
+            else { for (int q = 0; q < 4; q++) sb[q] = sa[q] ^ (int)cur.lb.x; }
 #pragma unroll
             for (int q = 0; q < 4; q++)       // hScale8To15_c: min(val >> 7, 32767); the lower bound cannot trigger
                 hw[SLOT][q] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(sa[q] >> 7, sb[q] >> 7));
@@ -336,9 +343,11 @@ __global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArg
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int acc = a.lr;
+                if ((S2_PROBE & 2) == 0) {
                 acc = s2_dot2(hw[(SLOT + 1) & 3][q], vl0, acc);
                 acc = s2_dot2(hw[(SLOT + 2) & 3][q], vl1, acc);
                 acc = s2_dot2(hw[(SLOT + 3) & 3][q], vl2, acc);
+                }
                 acc = s2_dot2(hw[(SLOT + 4) & 3][q], vl3, acc);
                 Y[q] = acc >> 19;
             }
@@ -384,8 +393,12 @@ __global__ __launch_bounds__(256) S2_WAVES_ATTR void scale_yuv2s_kernel(Yuv2sArg
                 // hScale8To15_c (>> 7, min 32767), the one-tap vertical filter (1 << 18) + h * 4096, >> 19 and the table
                 // index clamp collapse into clip_u8((sum + 8192) >> 14): floor(floor(x / 128 + 64) / 128) = floor((x + 8192) / 16384)
                 constexpr int R0 = 8192 + (S2_LUT_BIAS << 14);
+#if (S2_PROBE & 1)
+                const int su = s2_dot2(pU[c + 1], a.hC[1], R0), sv = s2_dot2(pV[c + 1], a.hC[1], R0);
+#else
                 const int su = s2_dot2(pU[c + 3], a.hC[3], s2_dot2(pU[c + 2], a.hC[2], s2_dot2(pU[c + 1], a.hC[1], s2_dot2(pU[c], a.hC[0], R0))));
                 const int sv = s2_dot2(pV[c + 3], a.hC[3], s2_dot2(pV[c + 2], a.hC[2], s2_dot2(pV[c + 1], a.hC[1], s2_dot2(pV[c], a.hC[0], R0))));
+#endif
 #if S2_LUT512
                 iU[c] = (su >> 14) & (S2_LUT_N - 1); iV[c] = (sv >> 14) & (S2_LUT_N - 1);     // in [0, 511] by the host's bound; the mask is free
 #else
@@ -1236,15 +1249,20 @@ static int wave_slots(int vgprs)
     return cus[dev] * 4 * perSimd;
 }
 
-// which form a launch of nframes frames takes: the block-cooperative kernel up to GMAT_STRIP_BLOCK frames (default 3; 0 = never),
-// the walker beyond — and for the 6-pair filters always.  Per frame, block form / walker (profiles/r04d_*): 1 frame 6.49 / 6.70 us,
-// 2: 4.90 / 5.50, 3: 4.38 / 4.74, 4: 4.08 / 4.01, 8: 3.51 / 3.42, 32: 3.70 / 3.53
+// which form a launch of nframes frames takes: the block-cooperative kernel while the launch is short — up to 17 wave-rows (256 output columns of
+// one row) per wave slot: twelve 4K -> 1080p frames, every launch of 1080p -> 540p frames — the walker beyond, and for the 6-pair filters always.
+// GMAT_STRIP_BLOCK = n: up to n frames instead (0 = never).  Round 4 drew the line at 3 frames from x2bench's default rotation of 64 frame pairs
+// (1.2 GB: partly served by the 256 MB Infinity Cache), where the two forms tie from 4 frames on; with every frame from HBM (X2BENCH_SETS = 8, bench.py's
+// regime) the block form is ahead up to 12 frames — per frame, block form / walker, 4K -> 1080p: 3 frames 4.70 / 5.13 us, 4: 4.33 / 4.63, 6: 3.98 / 4.35,
+// 8: 3.83 / 4.18, 12: 3.75 / 3.88, 16: 3.74 / 3.70, 32: 3.68 / 3.52; 1080p -> 540p: 8 frames 1.31 / 1.48, 32: 0.97 / 1.06 — and never behind in the cached
+// regime (profiles/r05f_blk_frames.txt, r05g_blk_frames_small.txt).  Its blocks live for one memory round trip: short launches keep every CU
+// fed where the walker's 13-iteration waves leave a tail.
 bool yuv2s_block_form(const Yuv2sArgs &a, int nframes)
 {
     if (a.np != 4) return false;
-    const char *e = GMAT_KNOB("GMAT_STRIP_BLOCK");
-    const int upTo = e ? atoi(e) : 3;
-    return nframes <= upTo;
+    if (const char *e = GMAT_KNOB("GMAT_STRIP_BLOCK")) return nframes <= atoi(e);
+    const long waveRows = (long)a.dstH * ((a.dstW + S2_STRIP - 1) / S2_STRIP) * nframes;
+    return waveRows <= 17L * wave_slots(74);
 }
 
 static int launch_scale_yuv2s_blk(Yuv2sArgs a, hipStream_t stream, const Yuv2xFrames &fr, int nframes)

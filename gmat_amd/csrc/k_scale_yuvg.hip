@@ -946,12 +946,14 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     return 0;
 }
 
-// a launch of few frames takes the block-cooperative form (GMAT_STRIP_BLOCK=n: launches of up to n frames, default 3; 0: never)
+// a short launch takes the block-cooperative form: up to 3 frames, or — small outputs — up to 2.8 M output pixels (round 5, every frame from HBM,
+// walker / block form, us a launch: 4K -> 854 x 480 rgb24 4 frames 33.1 / 29.6, 8: 50.6 / 53.3; 1080p -> 768 x 432 4 frames 13.9 / 11.5, 8: 19.8 / 18.5,
+// 16: 30.4 / 31.6; 4K -> 900p 4 frames 30.5 / 32.9: profiles/r05h_yuvg_blk_frames.txt).  GMAT_STRIP_BLOCK=n: launches of up to n frames; 0: never
 bool yuvg_block_form(const YuvGArgs &a, int nframes)
 {
     if (a.blkRows < 4 || !a.vtL || !a.vtC) return false;
-    const char *bs = GMAT_KNOB("GMAT_STRIP_BLOCK");
-    return nframes <= (bs ? atoi(bs) : 3);
+    if (const char *bs = GMAT_KNOB("GMAT_STRIP_BLOCK")) return nframes <= atoi(bs);
+    return nframes <= 3 || (long)a.dstW * a.dstH * nframes <= 2800000L;
 }
 
 static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)

@@ -80,7 +80,7 @@ def _expected_2to1(which, src_fmt, dst_fmt):
     -> scale_yuv2p_kernel when the output has >= 16 rows; everything else, and everything under GMAT_SCALE_NO_STRIP, the tiled
     kernel"""
     if which == "strip" and dst_fmt in ("rgb24", "bgra"):
-        return "scale_yuv2s_kernel"
+        return "scale_yuv2s_blk_kernel"              # (frames this small: every launch is the block form, k_scale_yuv2s.hip yuv2s_block_form)
     if which == "strip" and dst_fmt in ("nv12", "yuv420p"):
         return "scale_yuv2p_kernel" if src_fmt == dst_fmt else "scale_yuv2px_kernel"     # same / mixed chroma layouts
     return "scale_yuv2x_kernel<yuv>" if dst_fmt in ("nv12", "yuv420p") else "scale_yuv2x_kernel"
@@ -91,8 +91,6 @@ def _expected_2to1(which, src_fmt, dst_fmt):
 def test_batch_on_the_2to1_kernel(dev, orc, strip_or_tiled, src_fmt, dst_fmt):
     k = _run_batch(dev, orc, src_fmt, dst_fmt, 256, 64, 128, 32, nframes=5, nstreams=2, align=64)
     want = _expected_2to1(strip_or_tiled, src_fmt, dst_fmt)
-    if want == "scale_yuv2s_kernel":                # the second stream's share is 2 frames: a launch that small is the block form
-        want = "scale_yuv2s_blk_kernel"
     assert k == want, k
 
 

@@ -220,7 +220,7 @@ def _dev_frame(lib, fc, planes_np, pts):
     return fr
 
 
-@pytest.mark.parametrize("batch,kernel", [(4, b"scale_yuv2s_kernel"), (1, None), (16, b"scale_yuv2s_kernel")])
+@pytest.mark.parametrize("batch,kernel", [(4, b"scale_yuv2s_blk_kernel"), (1, None), (16, b"scale_yuv2s_blk_kernel")])   # (frames this small: the block form at every launch size)
 def test_queued_scale_batches_frames_into_one_launch(dev, orc, batch, kernel):
     from harness import synth_planes
     lib = dev.lib

@@ -40,6 +40,39 @@ def test_cfg3_4k_nv12_to_1080p_rgb24_bicubic(gpu, orc, fused, oracle):
     assert k == {2: "scale_yuv2s_blk_kernel", 1: "scale_rgb2h_kernel<yuv>", 0: "scale_rgb2h_kernel"}[fused], k
 
 
+@pytest.mark.parametrize("nframes,kernel", [(12, "scale_yuv2s_blk_kernel"), (13, "scale_yuv2s_kernel")])
+def test_cfg3_launch_size_rule_at_full_size(gpu, orc, nframes, kernel, monkeypatch):
+    """round 5: launches of up to twelve 4K -> 1080p frames take the block-cooperative form (17 wave-rows a wave slot), larger ones the walker
+    (k_scale_yuv2s.hip yuv2s_block_form; profiles/r05f_blk_frames.txt) — two distinct frames repeated through ONE launch, every output against the oracle"""
+    monkeypatch.delenv("GMAT_STRIP_BLOCK", raising=False)
+    monkeypatch.delenv("GMAT_STRIP_ROWS", raising=False)
+    from harness import ints
+    lib = gpu.lib
+    sw, sh, dw, dh = 3840, 2160, 1920, 1080
+    srcs = [synth_planes(orc, "nv12", sw, sh, seed=21 + i) for i in range(2)]
+    wants = [orc.sws(s, sw, sh, "nv12", dw, dh, "rgb24")[0] for s in srcs]
+    dsrc = [gpu.upload_planes(s, 256) for s in srcs]
+    ddst = [gpu.planes_like("rgb24", dw, dh, 256) for _ in range(nframes)]
+    c = lib.gmat_sws_getContext(sw, sh, PIX_FMT["nv12"], dw, dh, PIX_FMT["rgb24"], SWS["bicubic"], None)
+    assert c
+    sp, dp = (C.c_void_p * (4 * nframes))(), (C.c_void_p * (4 * nframes))()
+    for f in range(nframes):
+        for i, p in enumerate(dsrc[f & 1]):
+            sp[4 * f + i] = p.ptr
+        dp[4 * f] = ddst[f][0].ptr
+    st = (C.c_void_p * 1)(None)
+    assert lib.gmat_sws_scale_batch(c, nframes, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]), C.cast(dp, C.POINTER(C.c_void_p)),
+                                    ints([ddst[0][0].stride]), C.cast(st, C.POINTER(C.c_void_p)), 1, 0) == nframes
+    lib.gmat_device_sync()
+    assert lib.gmat_sws_lastKernel(c).decode() == kernel and lib.gmat_sws_lastLaunchFrames(c) == nframes
+    for f in range(nframes):
+        assert (ddst[f][0].download() == wants[f & 1]).all(), f
+    lib.gmat_sws_freeContext(c)
+    for fr in dsrc + ddst:
+        for p in fr:
+            p.free()
+
+
 def test_cfg3_rgb24_4k_to_1080p_lanczos(gpu, orc):
     sw, sh, dw, dh = 3840, 2160, 1920, 1080
     src = synth_planes(orc, "rgb24", sw, sh, seed=13)

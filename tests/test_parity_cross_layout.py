@@ -34,8 +34,9 @@ def _check(dev, orc, sf, df, geom, flags="bicubic", align=64, src_align=256):
 
 @pytest.mark.parametrize("pair", PAIRS)
 @pytest.mark.parametrize("case", CASES)
-def test_scaled_between_the_layouts(dev, orc, strip_rows, pair, case):
+def test_scaled_between_the_layouts(dev, orc, strip_rows, pair, case, monkeypatch):
     strip_rows(0)
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "3")           # the block forms by FRAMES (frames this small take them at every launch size under the shipped rule, round 5): five frames = the walkers
     geom, one, five = case
     assert _check(dev, orc, pair[0], pair[1], geom) == one
     k = _run_batch(dev, orc, pair[0], pair[1], *geom, nframes=5, nstreams=1, align=64)

@@ -6,6 +6,8 @@ ring depths (4:2:0: 3 / 5 pairs; RGB: 4 / 3, 4 / 4 with the luma stream a step b
 horizontal window (2 / 3 / 4) and of the row-image size (one / two dwords a lane) is reached here by a geometry chosen for it, and the test
 says which one through GMAT_DEBUG_WALKER's line where it matters.  Kernel names are asserted on both sides of the rule."""
 import numpy as np
+import os
+
 import pytest
 
 from harness import SWS, synth_planes, quad_takes, QUAD
@@ -176,4 +178,9 @@ def test_short_filter_down_scales_in_launches_of_more_than_three_frames(dev, orc
     assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=9, nstreams=2, align=16) == QUAD         # four and five frames a launch
     assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=4, nstreams=1, align=16) == QUAD
     assert _run_batch(dev, orc, "nv12", df, 384, 216, 288, 162, nframes=3, nstreams=1, align=16) in ("scale_yuvg_blk_kernel", "scale_yuvg_kernel")
-    assert _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=5, nstreams=1, align=16) == "scale_yuvg_kernel"      # 2.4 : 1: 11-tap filters
+    assert _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=5, nstreams=1, align=16) == "scale_yuvg_blk_kernel"  # 2.4 : 1: 11-tap filters — the band walker's (a launch this small: its block form, round 5)
+    os.environ["GMAT_STRIP_BLOCK"] = "3"
+    try:
+        assert _run_batch(dev, orc, "nv12", df, 384, 216, 160, 90, nframes=5, nstreams=1, align=16) == "scale_yuvg_kernel"
+    finally:
+        os.environ.pop("GMAT_STRIP_BLOCK", None)

@@ -74,11 +74,20 @@ def test_strip_segmentation_does_not_change_the_result(dev, orc, strip_rows, str
 
 
 def test_strip_form_follows_the_launch_size(dev, orc, strip_rows):
-    """the shipped rule (no knob): a launch of up to three frames is the block-cooperative kernel, a larger one the walker"""
+    """the shipped rule (no knob, round 5): the block-cooperative kernel while the launch has at most 17 wave-rows a wave slot — every launch of frames
+    this small — the walker beyond (4K -> 1080p: from 13 frames on, tests/test_fullsize_gpu.py); GMAT_STRIP_BLOCK = n draws the line at n FRAMES"""
     strip_rows(0)
-    os.environ.pop("GMAT_STRIP_BLOCK", None)
-    for n, want in ((1, "scale_yuv2s_blk_kernel"), (2, "scale_yuv2s_blk_kernel"), (3, "scale_yuv2s_blk_kernel"), (4, "scale_yuv2s_kernel"), (7, "scale_yuv2s_kernel")):
-        assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=n, nstreams=1, align=16) == want
+    old = os.environ.pop("GMAT_STRIP_BLOCK", None)
+    try:
+        for n in (1, 3, 4, 7, 33):
+            assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=n, nstreams=1, align=16) == "scale_yuv2s_blk_kernel"
+        os.environ["GMAT_STRIP_BLOCK"] = "3"
+        for n, want in ((3, "scale_yuv2s_blk_kernel"), (4, "scale_yuv2s_kernel"), (7, "scale_yuv2s_kernel")):
+            assert _run_batch(dev, orc, "nv12", "rgb24", 528, 52, 264, 26, nframes=n, nstreams=1, align=16) == want
+    finally:
+        os.environ.pop("GMAT_STRIP_BLOCK", None)
+        if old is not None:
+            os.environ["GMAT_STRIP_BLOCK"] = old
 
 
 @pytest.mark.parametrize("flags", ["bilinear", "bicubic", "point", "area", "fast_bilinear", "gauss"])

@@ -207,6 +207,15 @@ int main(int argc, char **argv)
         W3(1, 0); W3(2, 0); W3(1, 1);
 #define BD(R, X) timeit("band R=" #R " xcd=" #X " (32 frames; reads 2R+6 luma rows per R output rows)", bytes, [&] { const int nb = frames * 1080 / R; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_band<R, X>), dim3(nb), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, nb); })
         BD(1, 0); BD(1, 1); BD(2, 0); BD(2, 1); BD(4, 0); BD(4, 1); BD(8, 0); BD(8, 1); BD(12, 1);
+        // (round 5) the same bands over 128 frames = 1.6 GB in + 0.8 GB out: every byte from HBM (32 frames = 600 MB sit partly in the 256 MB Infinity Cache)
+        {
+            const int frames = 128;
+            const double bytes = (double)frames * (3840.0 * 3240 + 5760.0 * 1080);
+#define BD128(R, X) timeit("band R=" #R " xcd=" #X " (128 frames: all HBM)", bytes, [&] { const int nb = frames * 1080 / R; hipLaunchKernelGGL(HIP_KERNEL_NAME(k_band<R, X>), dim3(nb), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, nb); })
+            BD128(2, 1); BD128(4, 0); BD128(4, 1); BD128(8, 0); BD128(8, 1);
+            const int steps = 13, sg = (1080 + steps - 4) / (steps - 3);
+            timeit("walk3 D=1 st=0, 13 steps per wave (128 frames: all HBM)", bytes, [&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk3<1, 0>), dim3(sg, frames), dim3(256), 0, 0, (const uint8_t *)s, (uint8_t *)d, steps, 1080); });
+        }
         // shorter / longer segments with the wide loads
         for (int st : {15, 27, 93}) {
             const int sg = (1080 + st - 4) / (st - 3);
