@@ -273,9 +273,13 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if ((r = yuv4x1_prepare(c->planYuv, c->ytiling, c->y4x1)) < 0) return r;
     if (c->rgbViaPlanes && (r = rgb2y_prepare(c->planYuv, c->r2ys)) < 0) return r;
     if (!a.src16 && !c->rgbViaPlanes && (r = yuvg_prepare(c->planYuv, c->ytiling, c->yg)) < 0) return r;
+    // (round 5) the same walker over 16-bit samples: P010LE / P016LE / planar 10- and 16-bit 4:2:0 sources (k_scale_yuvg16.hip) — one set of tables a context
+    if (a.src16 >= 10 && !c->rgbViaPlanes && (r = yuvg_prepare16(c->planYuv, c->ytiling, c->yg)) < 0) return r;
     if (c->yg.ok) {
         YuvGArgs &g = c->gargs;
         std::memset(&g, 0, sizeof(g));
+        g.src16 = a.src16 >= 10 ? a.src16 : 0; g.hShift = a.src16 >= 10 ? a.hShift : 7; g.hBias = a.src16 >= 10 ? a.hBias : 0;
+        g.dst16 = a.dst16; g.dstShift = a.dstShift;
         const YuvGTables &t = c->yg;
         int k = 0;
         auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
@@ -580,7 +584,8 @@ static bool yuvg_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     if (!c->yg.ok || c->rangeConv || ya.prof) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
-    if (!ya.nv12) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
+    const bool semi = c->gargs.src16 ? (c->gargs.src16 == 10 || c->gargs.src16 == 16) : ya.nv12 != 0;
+    if (!semi) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
     if (c->yg.yuvOut) {
         all |= (uintptr_t)ya.dstU | (uintptr_t)ya.dsU;
         if (!ya.dstNv12) all |= (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
@@ -591,7 +596,9 @@ static bool yuvg_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     YuvGArgs g = c->gargs;
-    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs; g.nv12 = ya.nv12;
+    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs;
+    g.nv12 = g.src16 ? (g.src16 == 10 || g.src16 == 16) : ya.nv12;        // interleaved chroma (P010LE / P016LE: YuvScaleArgs' kinds 10 and 16)
+    g.dither8 = ya.dither8;
     g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
     g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
     g.ds = ya.ds; g.dsU = ya.dsU; g.dsV = ya.dsV; g.dstFormat = ya.dstFormat;
@@ -1000,7 +1007,7 @@ static const PlaneKernel kPlaneKernels[] = {
     // packed RGB at ONE frame (9.9 / 9.1, 8.7 / 7.8; at two and three frames the exact-ratio walkers are level or ahead).  The 3:1 / 3:2 plane
     // walkers keep their frames at every size (7.4 against 8.8, 5.1 against 6.6).  GMAT_BLOCK_FIRST=0: never in front
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) {
-         if (!yuvg_eligible(c, ya) || yuv3x1_eligible(c, ya) || yuv3x2_eligible(c, ya)) return false;
+         if (c->gargs.src16 || !yuvg_eligible(c, ya) || yuv3x1_eligible(c, ya) || yuv3x2_eligible(c, ya)) return false;
          const bool four = yuv4r_eligible(c, ya) || yuv4x1_eligible(c, ya), threeRgb = yuv32r_eligible(c, ya) || yuv3r_eligible(c, ya);
          if (!((four && n <= 3) || (threeRgb && n == 1))) return false;   // (every other context reaches the form in the band walker's own place)
          const char *bf = GMAT_KNOB("GMAT_BLOCK_FIRST");
@@ -1038,8 +1045,11 @@ static const PlaneKernel kPlaneKernels[] = {
      [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvu_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
-     [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * { return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
-     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
+         if (c->gargs.src16) return yuvg_block_form16(make_yuvg_args(c, ya), n) ? "scale_yuvg16_blk_kernel" : "scale_yuvg16_kernel";      // (16-bit samples: k_scale_yuvg16.hip)
+         return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         return c->gargs.src16 ? launch_scale_yuvg16(make_yuvg_args(c, ya), st, &fr, n) : launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvl_eligible(c, ya, n); },                                    // what no walker takes: the lines form
      [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return ya.src16 ? "scale_yuvl_h16_kernel+scale_yuvl_v_kernel" : "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {

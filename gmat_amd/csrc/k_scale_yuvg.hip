@@ -30,7 +30,24 @@
 #include "kernels.h"
 #include "px_math.h"
 
+// G_BPS: bytes per SOURCE sample.  This file compiles twice: as it is (8-bit sources: NV12 / YUV420P), and from k_scale_yuvg16.hip with G_BPS = 2
+// (round 5: P010LE / P016LE / YUV420P10LE / YUV420P16LE — hScale16To15_c, swscale.c:93-119, in front of the same vertical program and output stages;
+// those sources sat on the lines form's two passes or the tiled kernel at 0.12-0.24 of the roofline).  What changes with the sample width is the
+// horizontal stage alone — which bytes a coefficient pair meets (GWin, g_hsum, GStream::setup), how many dwords of a row a lane loads (SD), what the
+// row image holds (g_conv) — and the output stage's 10-bit and dithered 8-bit forms; the 16-bit build lives in namespace gmat::g16.
+#ifndef G_BPS
+#define G_BPS 1
+#endif
+#if G_BPS == 2
+#define G_NAME(n) n##16
+#else
+#define G_NAME(n) n
+#endif
+
 namespace gmat {
+#if G_BPS == 2
+namespace g16 {
+#endif
 
 // ---- a plane as a raw buffer resource: lane offset in a loop-invariant VGPR, row offset in the instruction's scalar offset,
 //      reads past the plane's last byte return 0 (the windows are whole dwords and may overhang the last row by up to 7 bytes)
@@ -41,8 +58,11 @@ struct GPlane {
     v4u words;                            // the same descriptor as four dwords, for the store issued from inline assembly
     __device__ __forceinline__ GPlane(const uint8_t *p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000))
     {
+        // (readfirstlane: the descriptor is an "s" operand of the inline-assembly store below — a wave-uniform value the compiler chose to compute on the
+        // vector ALU, e.g. a size that is a product of kernel arguments, reaches the assembler as v[n:n+3], "invalid operand for instruction")
         const unsigned long long a = (unsigned long long)p;
-        words = (v4u){(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+        words = (v4u){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
     }
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ void ld4(unsigned lane, unsigned row, unsigned *w) const { const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, lane, row, 0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
@@ -96,22 +116,46 @@ __device__ __forceinline__ unsigned g_sat_pk_u8_i16(unsigned v)
 }
 
 // window dwords of a lane: component stride 1 (a luma or planar chroma row): byte pairs (o + 2t, o + 2t + 1), t < P, o = pos & 3;
-// component stride 2 (one component of NV12's UV row): (o + 4t, o + 4t + 2), o = (2 pos + comp) & 3
+// component stride 2 (one component of NV12's UV row): (o + 4t, o + 4t + 2), o = (2 pos + comp) & 3.
+// 16-bit samples (G_BPS = 2): a pair is two whole samples — stride 1: the dword at sample pos + 2t (pos even) or the halves either side of a dword
+// boundary (pos odd: one selector per lane); stride 2 (P010's (U, V) dwords): the component's half of dwords 2t and 2t + 1, always aligned
+#if G_BPS == 2
+template <int P, bool S2> struct GWin { static constexpr int NW = S2 ? 2 * P : P + 1; };
+#else
 template <int P, bool S2> struct GWin { static constexpr int NW = S2 ? P + 1 : ((P - 1) >> 1) + 2; };
+#endif
 
-// one horizontally filtered sample of this lane's column: hScale8To15_c's sum (before its >> 7)
+// one horizontally filtered sample of this lane's column: hScale8To15_c's / hScale16To15_c's sum (before its shift), from `start`
 template <int P, bool S2>
-__device__ __forceinline__ int g_hsum(const unsigned (&w)[GWin<P, S2>::NW], const int (&cf)[P], unsigned selE, unsigned selO)
+__device__ __forceinline__ int g_hsum(const unsigned (&w)[GWin<P, S2>::NW], const int (&cf)[P], unsigned selE, unsigned selO, int start)
 {
-    int s = 0;
+    int s = start;
 #pragma unroll
     for (int t = 0; t < P; t++) {
+#if G_BPS == 2
+        const int pr = S2 ? (int)__builtin_amdgcn_perm(w[2 * t + 1], w[2 * t], selE) : (int)__builtin_amdgcn_perm(w[t + 1], w[t], selE);
+#else
         const int pr = S2 ? (int)__builtin_amdgcn_perm(w[t + 1], w[t], selE)
                           : (int)__builtin_amdgcn_perm(w[(t >> 1) + 1], w[t >> 1], (t & 1) ? selO : selE);
+#endif
         s = g_dot2(pr, cf[t], s);
     }
     return s;
 }
+
+// what a row image holds of the dwords as loaded (G_BPS = 2, YuvScaleArgs' kinds): P010 (10): sample >> 6; planar 10 bit (18): as it is; 16 bits (16
+// semi-planar, 17 planar): sample - 32768 — the signed operand of v_dot2 — with the sums started at 32768 * 16384 (hBias; every filter row sums to 16384,
+// checked on the host).  One or two VALU instructions per LOADED dword, not per window
+struct GConv { int kind, sh, bias; };
+// branch-free over the (wave-uniform) kind: both samples of the dword shifted right by 6 or 0 (one v_pk_lshrrev_b16), bit 15 flipped or not
+typedef unsigned short g_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned g_conv(unsigned shr, unsigned flip, unsigned v)
+{
+    const g_us2 s = __builtin_bit_cast(g_us2, v) >> (g_us2){(unsigned short)shr, (unsigned short)shr};
+    return __builtin_bit_cast(unsigned, s) ^ flip;
+}
+// first byte of the window of output column `pos` (component `comp` of an interleaved row)
+template <bool S2> __device__ __host__ __forceinline__ int g_win_byte(int pos, int comp) { return G_BPS == 2 ? (S2 ? 4 * pos + 2 * comp : 2 * pos) : (S2 ? 2 * pos + comp : pos); }
 
 // One stream of a lane: its horizontal window (selectors, coefficient pairs), the wave's share of the row loads, a ring of R
 // requested row pairs with STATIC slot names and the gathered windows of the pair consumed next.
@@ -139,15 +183,27 @@ struct GStream {
     unsigned win[2][NW];
     unsigned *img;                       // this wave's two row images of this stream: img[row * IMG + dword]
     unsigned reqOff, rowStep;            // (wave-uniform) byte offset of the next row to request, and of one row further along the walk
+#if G_BPS == 2
+    unsigned cvShr, cvFlip;              // 16-bit samples: what the image holds (see g_conv) ...
+    int cvSh, cvBias;                    // ... hScale16To15_c's shift and the sums' start (8 bit: >> 7 from 0)
+    __device__ __forceinline__ void set_conv(const GConv &c) { cvShr = c.kind == 10 ? 6u : 0u; cvFlip = (c.kind == 10 || c.kind == 18) ? 0u : 0x80008000u; cvSh = c.sh; cvBias = c.bias; }
+#else
+    __device__ __forceinline__ void set_conv(const GConv &) {}
+#endif
 
     // col: this lane's output column of the plane; comp: component of an interleaved row (S2); returns the window's first dword (bytes)
     __device__ __forceinline__ int setup(const int32_t *hTab, const int32_t *posTab, int col, int comp)
     {
         const int pos = posTab[col];
-        const int b0 = S2 ? 2 * pos + comp : pos;
+        const int b0 = g_win_byte<S2>(pos, comp);
         const unsigned o = (unsigned)b0 & 3u;
+#if G_BPS == 2
+        selE = S2 ? (comp ? 0x07060302u : 0x05040100u) : (o ? 0x05040302u : 0x03020100u);
+        selO = 0u;
+#else
         selE = S2 ? (0x0C000C00u | o | ((o + 2) << 16)) : (0x0C000C00u | o | ((o + 1) << 16));
         selO = 0x0C000C00u | (o + 2) | ((o + 3) << 16);
+#endif
 #pragma unroll
         for (int t = 0; t < P; t++) cf[t] = hTab[(size_t)col * P + t];
         return b0 & ~3;
@@ -171,7 +227,11 @@ struct GStream {
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
+#if G_BPS == 2
+            for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = g_conv(cvShr, cvFlip, src[r][s]);
+#else
             for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
+#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -190,7 +250,11 @@ struct GStream {
     // the gathered pair's two horizontally filtered samples of this lane's column, packed: min(sum >> 7, 32767) each (hScale8To15_c)
     __device__ __forceinline__ int hpair() const
     {
-        const int h0 = g_hsum<P, S2>(win[0], cf, selE, selO) >> 7, h1 = g_hsum<P, S2>(win[1], cf, selE, selO) >> 7;
+#if G_BPS == 2
+        const int h0 = g_hsum<P, S2>(win[0], cf, selE, selO, cvBias) >> cvSh, h1 = g_hsum<P, S2>(win[1], cf, selE, selO, cvBias) >> cvSh;
+#else
+        const int h0 = g_hsum<P, S2>(win[0], cf, selE, selO, 0) >> 7, h1 = g_hsum<P, S2>(win[1], cf, selE, selO, 0) >> 7;
+#endif
         return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h0, h1));
     }
     // after a pair has been consumed: the next one (in ring slot S) becomes the gathered one, its slot is requested again R pairs on
@@ -214,7 +278,7 @@ struct GStream {
 #define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_WAVES)))
 #elif G_WAVES < 0
 // one dword of a row per lane (P <= 6: ratios up to 3.7:1 with 4-tap algorithms): 94-100 VGPRs as compiled, 5 waves a SIMD fit in 96
-#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(P <= 6 && K <= 9 ? 5 : 1)))
+#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_BPS == 1 && P <= 6 && K <= 9 ? 5 : 1)))      // (16-bit samples: wider windows and rings — as the compiler allocates them)
 #else
 #define G_WAVES_ATTR
 #endif
@@ -233,7 +297,7 @@ constexpr int kGHead = 2;               // dwords in front of a quad's coefficie
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
+    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
     __shared__ int2 lutV[256], lutU[256];
     __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -258,8 +322,8 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     const int ya = up ? a.dstH - y1 : y0, yb = up ? a.dstH - y0 : y1;            // walking coordinates
     const int f = blockIdx.y;
     // exact valid bytes of each plane (row bytes are multiples of 4 by the host rule): a dword past them reads as 0
-    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW);
-    const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW);
+    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW * G_BPS);
     const GPlane bU(fr.u[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb), bV(NV12 ? fr.u[f] : fr.v[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb);
     const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
     const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
@@ -268,6 +332,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
     GStream<P, false, SD, G_RL> L;
     GStream<P, NV12, SD, 2> C;
+    L.set_conv(GConv{a.src16, a.hShift, a.hBias}); C.set_conv(GConv{a.src16, a.hShift, a.hBias});
     {
         // luma: the wave's row segment starts at lane 0's window; every lane fills dword `lane` (+ 64) of the row image
         const int w0 = L.setup(a.hL, a.posL, xc, 0);
@@ -400,6 +465,41 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     flush();
 }
 
+// The output stage of a plane job: the lane's vertical sum -> its sample of the plane row -> the wave's dwords.  elem: the lane's element of the row
+// (a luma / planar chroma sample, or a component of the interleaved row), e0 the wave's first, n the row's elements; dx: the lane's half of the
+// ordered dither (8-bit output of a deeper source: dither_8x8_128 is affine over GF(2), px_math.h), y the REAL output row
+struct GPlaneOut {
+    int dst16, dstShift, dither8, xpart;
+    __device__ __forceinline__ void set(const YuvGArgs &a, int col) { dst16 = a.dst16; dstShift = a.dstShift; dither8 = a.dither8; xpart = dither_8x8_128(col, 0); }
+    __device__ __forceinline__ void store(const GPlane &bD, uint8_t *dp, int acc, int e0, int lane, int n, unsigned drow, int y) const
+    {
+        const int nb = min(64, n - e0);
+        if (__builtin_amdgcn_readfirstlane(dst16)) {
+            // yuv2p010l1_c / lX_c / cX_c, yuv2planeX_10_c (output.c:459-519): clip_uintp2((1 << 16 + sum) >> 17, 10), P010: << 6 — two lanes a dword
+            const unsigned v = (unsigned)min(max(acc >> 17, 0), 1023) << dstShift;
+            const unsigned o = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 16);                 // quad_perm:[1,1,3,3]
+            if ((lane & 1) == 0) {
+                if (lane + 2 <= nb) bD.st1(o, 2u * (unsigned)(e0 + lane), drow);
+                else if (lane < nb) *reinterpret_cast<unsigned short *>(dp + (size_t)drow + 2u * (unsigned)(e0 + lane)) = (unsigned short)v;
+            }
+            return;
+        }
+        // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19); the sums started at 64 << 12, a deeper source's ordered dither on top
+        if (G_BPS == 2 && __builtin_amdgcn_readfirstlane(dither8)) acc += ((xpart ^ dither_8x8_128(0, y) ^ 36) - 64) << 12;
+        const unsigned v = (unsigned)clip_u8_shr(acc, 19);
+        // four lanes' bytes -> one dword in lane 0 of each group of four: two quad permutes and two shift-ors, no LDS round trip
+        const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);          // quad_perm:[1,1,3,3]
+        const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);       // quad_perm:[2,2,2,2]
+        if ((lane & 3) == 0) {
+            if (lane + 4 <= nb) bD.st1(o, (unsigned)e0 + (unsigned)lane, drow);
+            else if (lane < nb) {
+                uint8_t *d = dp + (size_t)drow + (unsigned)e0 + (unsigned)lane;
+                for (int i = 0; i < nb - lane; i++) d[i] = (uint8_t)(o >> (8 * i));
+            }
+        }
+    }
+};
+
 // ---- 4:2:0 destinations: plane jobs ----------------------------------------------------------------------------------------------
 // job 0: the luma plane (lane = column).  job 1: chroma — NV12 -> NV12: lane = (column, component) of the interleaved plane;
 // planar -> planar: two jobs (U, V), lane = column.  Blocks [0, nblkL) are luma, the rest chroma.  A quad of a plane job is four of
@@ -407,7 +507,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = P >= 8 ? 2 : 1, QS = kGHead + 3 * K;
+    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
     __shared__ unsigned image[4][2 * 64 * SD];                    // [wave][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,14 +533,17 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
     const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
-    const int srcRowBytes = job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW;
-    const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes);
+    const int srcRowBytes = (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes * (a.dst16 ? 2u : 1u));
     const int bcol = min(B0 + lane, rowBytes - 1);
+    GPlaneOut out;                                                 // (the dither's column: a chroma sample's own, V three columns on — vscale.c:98,101, output.c:433-434)
+    out.set(a, job == 0 ? bcol : NV12 ? (bcol >> 1) + 3 * (bcol & 1) : bcol + (job == 2 ? 3 : 0));
     const int32_t *prog = job ? a.progC[up] : a.prog[up];
     const int rnd = job ? a.roundC : a.roundL;
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
         GStream<P, S2, SD, 4> W;
+        W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
             const int seg = __builtin_amdgcn_readfirstlane(w0);
@@ -458,20 +561,8 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
 #pragma unroll
         for (int i = 0; i < K; i++) acc[i] = rnd;
         auto emit = [&](int yw) {
-            // yuv2planeX_8_c / yuv2nv12cX_c: clip_u8((dither << 12 + sum) >> 19), the dither in the sums' start value
-            const unsigned v = (unsigned)clip_u8_shr(acc[0], 19);
-            const unsigned drow = (unsigned)(up ? rows - 1 - yw : yw) * (unsigned)dstride;
-            // four lanes' bytes -> one dword in lane 0 of each group of four: two quad permutes and two shift-ors, no LDS round trip
-            const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);          // quad_perm:[1,1,3,3]
-            const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);       // quad_perm:[2,2,2,2]
-            const int nb = min(64, rowBytes - B0);
-            if ((lane & 3) == 0) {
-                if (lane + 4 <= nb) bD.st1(o, (unsigned)B0 + (unsigned)lane, drow);
-                else if (lane < nb) {
-                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + (unsigned)lane;
-                    for (int i = 0; i < nb - lane; i++) d[i] = (uint8_t)(o >> (8 * i));
-                }
-            }
+            const int yr = up ? rows - 1 - yw : yw;
+            out.store(bD, dp, acc[0], B0, lane, rowBytes, (unsigned)yr * (unsigned)dstride, yr);
         };
         int pend = 0;                           // rows completed by the previous quad, not yet out (see the RGB kernel)
         auto flush = [&]() {
@@ -572,7 +663,7 @@ __device__ __forceinline__ int g_blk_vsum(const int32_t *row, int n4, const int 
 template <int P, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = P >= 8 ? 2 : 1, JL = kGBlkJL, JC = kGBlkJC;
+    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), JL = kGBlkJL, JC = kGBlkJC;
     __shared__ int2 lutV[256], lutU[256];
     __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     __shared__ int hLs[4 * JL + kGBlkPad][64], hCs[4 * JC + kGBlkPad][64];
@@ -591,8 +682,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
     const int X0 = (lin - band * a.nsg) * 64;
     const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
     const int f = blockIdx.y;
-    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW);
-    const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW);
+    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const GPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW * G_BPS);
     const GPlane bU(fr.u[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb), bV(NV12 ? fr.u[f] : fr.v[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb);
     const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
     const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
@@ -601,11 +692,12 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
     GStream<P, false, SD, JL> L;
     GStream<P, NV12, SD, JC> C;
+    L.set_conv(GConv{a.src16, a.hShift, a.hBias}); C.set_conv(GConv{a.src16, a.hShift, a.hBias});
     {
         // (the lane mapping of scale_yuvg_rgb_kernel; the row segment's start — lane 0's window — from a SCALAR load, so that the row
         // requests do not wait for the lanes' own table entries)
         const int w0 = L.setup(a.hL, a.posL, xc, 0);
-        const int seg = uniform_load(a.posL, X0) & ~3;
+        const int seg = g_win_byte<false>(uniform_load(a.posL, X0), 0) & ~3;
         L.winDw = (w0 - seg) >> 2;
 #pragma unroll
         for (int s = 0; s < SD; s++) { L.ldDw[s] = lane + 64 * s; L.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
@@ -614,7 +706,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
     {
         const int w0 = C.setup(a.hC, a.posC, min(xc >> 1, a.chrDstW - 1), par);
         const int pos0 = uniform_load(a.posC, min(X0 >> 1, a.chrDstW - 1));
-        const int seg = (NV12 ? 2 * pos0 : pos0) & ~3;
+        const int seg = g_win_byte<NV12>(pos0, 0) & ~3;
         if (NV12) {
             C.winDw = (w0 - seg) >> 2;
 #pragma unroll
@@ -679,7 +771,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
 template <int P, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = P >= 8 ? 2 : 1, J = kGBlkJL;
+    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), J = kGBlkJL;
     __shared__ unsigned image[4][2 * 64 * SD];
     __shared__ int hS[4 * J + kGBlkPad][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -700,19 +792,22 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
     const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
     const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
-    const int srcRowBytes = job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW;
-    const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes);
+    const int srcRowBytes = (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes * (a.dst16 ? 2u : 1u));
     const int bcol = min(B0 + lane, rowBytes - 1);
+    GPlaneOut out;
+    out.set(a, job == 0 ? bcol : NV12 ? (bcol >> 1) + 3 * (bcol & 1) : bcol + (job == 2 ? 3 : 0));
     const int32_t *vt = job ? a.vtC : a.vtL;
     const int n4 = job ? a.n4C : a.n4L, sV = kGBlkHead + 4 * n4;
     const int rnd = job ? a.roundC : a.roundL;
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
         GStream<P, S2, SD, J> W;
+        W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
             const int pos0 = uniform_load(job ? a.posC : a.posL, S2 ? B0 >> 1 : B0);      // lane 0's window (B0 is even), by a scalar load
-            const int seg = (S2 ? 2 * pos0 : pos0) & ~3;
+            const int seg = g_win_byte<S2>(pos0, 0) & ~3;
             W.winDw = (w0 - seg) >> 2;
 #pragma unroll
             for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
@@ -725,23 +820,16 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
         for (int y = y0 + wave; y < y1; y += 4) {
             const int32_t *rv = vt + (size_t)y * sV;
             const int acc = g_blk_vsum(rv, n4, hS, uniform_load(rv, 0) - pa, lane, rnd);
-            // the output stage of scale_yuvg_planes_kernel's emit()
-            const unsigned v = (unsigned)clip_u8_shr(acc, 19);
-            const unsigned drow = (unsigned)y * (unsigned)dstride;
-            const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);          // quad_perm:[1,1,3,3]
-            const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);       // quad_perm:[2,2,2,2]
-            const int nb = min(64, rowBytes - B0);
-            if ((lane & 3) == 0) {
-                if (lane + 4 <= nb) bD.st1(o, (unsigned)B0 + (unsigned)lane, drow);
-                else if (lane < nb) {
-                    uint8_t *d = dp + (size_t)drow + (unsigned)B0 + (unsigned)lane;
-                    for (int i = 0; i < nb - lane; i++) d[i] = (uint8_t)(o >> (8 * i));
-                }
-            }
+            out.store(bD, dp, acc, B0, lane, rowBytes, (unsigned)y * (unsigned)dstride, y);       // (the output stage of scale_yuvg_planes_kernel's emit())
         }
     };
     if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
 }
+
+#if G_BPS == 2
+} // namespace g16
+using namespace g16;
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -818,20 +906,36 @@ static void fill_qprog(YuvGQProg &v, int K)
 // P = 13 (round 4): 26 taps — bicubic down to 6.2 : 1 (4K -> 360p), bilinear / area twice as far
 static const int kGP[] = {4, 5, 6, 8, 10, 13}, kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
 
-int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
+int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
     t = YuvGTables();
     const char *off = GMAT_KNOB("GMAT_SCALE_NO_GENERIC_WALKER");
     if (off && atoi(off)) return 0;
     const bool rgbOut = p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA;
-    const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P;
+    // 4:2:0 destinations: 8 bits, or (round 5) 10 bits in 16-bit stores — P010LE / YUV420P10LE: the same 15-bit lines, yuv2p010lX_c / yuv2planeX_10_c's shift
+    const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P || is_dst10(p.dstFormat);
+    const bool semiDst = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_P010LE;
+#if G_BPS == 2
+    const bool semiSrc = is_p01x(p.srcFormat);
+    if (!(semiSrc || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE || p.srcFormat == GMAT_PIX_FMT_YUV420P16LE) || !(rgbOut || yuvOut)) return 0;
+    if (const char *o16 = GMAT_KNOB("GMAT_SCALE_NO_WALKER16")) if (atoi(o16)) return 0;
+    // the 16-bit image is biased by -32768 and the sums start at 32768 * 16384: every horizontal row sums to 16384 (initFilter normalises exactly)
+    for (const FilterBank *fb : {&p.hLum, &p.hChr})
+        for (int x = 0; x < fb->count; x++) {
+            int sum = 0;
+            for (int j = 0; j < fb->taps; j++) sum += fb->coef[(size_t)x * fb->taps + j];
+            if (sum != 16384) return 0;
+        }
+#else
+    const bool semiSrc = p.srcFormat == GMAT_PIX_FMT_NV12;
     if (!(p.srcFormat == GMAT_PIX_FMT_NV12 || p.srcFormat == GMAT_PIX_FMT_YUV420P) || !(rgbOut || yuvOut)) return 0;
+#endif
     if (rgbOut && (g.fullChroma || g.yuvOut)) return 0;
     if (yuvOut && g.yuvOut != 1) return 0;
-    if (yuvOut && ((p.srcFormat == GMAT_PIX_FMT_NV12) != (p.dstFormat == GMAT_PIX_FMT_NV12))) return 0;   // same chroma layout on both sides
+    if (yuvOut && semiSrc != semiDst) return 0;                           // same chroma layout on both sides
     if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
     // whole dwords inside every source row (the rows are dword loads checked against the plane's exact size)
-    if (p.srcW % 4 || (p.srcFormat == GMAT_PIX_FMT_NV12 ? (2 * p.chrSrcW) % 4 : p.chrSrcW % 4)) return 0;
+    if ((p.srcW * G_BPS) % 4 || ((semiSrc ? 2 * p.chrSrcW : p.chrSrcW) * G_BPS) % 4) return 0;
     // RGB: one chroma sample per pixel pair and per output row (the LUT form); 4:2:0: the chroma planes of the destination
     if (rgbOut && (p.chrDstW != (p.dstW + 1) / 2 || p.chrDstH != p.dstH)) return 0;
     // the sums start at ONE value per plane class (true of every multi-tap vertical filter; the 1- and 2-tap special forms of
@@ -879,17 +983,18 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
     // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
     // consecutive columns must fit the row image of SD * 256 bytes (planar chroma halves under an RGB destination: SD * 128)
     {
-        const int SD = P >= 8 ? 2 : 1;
+        const int SD = G_BPS * (P >= 8 ? 2 : 1);
         auto fits = [&](const FilterBank &fb, int cols, bool s2, int capBytes) {
-            const int NW = s2 ? P + 1 : ((P - 1) >> 1) + 2;
+            const int NW = G_BPS == 2 ? (s2 ? 2 * P : P + 1) : (s2 ? P + 1 : ((P - 1) >> 1) + 2);
             for (int c0 = 0; c0 < fb.count; c0 += cols) {
                 const int c1 = std::min(c0 + cols, fb.count) - 1;
-                const int b0 = (s2 ? 2 * fb.pos[c0] : fb.pos[c0]) & ~3, b1 = (s2 ? 2 * fb.pos[c1] + 1 : fb.pos[c1]) & ~3;
+                const int b0 = (s2 ? g_win_byte<true>(fb.pos[c0], 0) : g_win_byte<false>(fb.pos[c0], 0)) & ~3;
+                const int b1 = (s2 ? g_win_byte<true>(fb.pos[c1], 1) : g_win_byte<false>(fb.pos[c1], 0)) & ~3;
                 if (b1 + 4 * NW - b0 > capBytes) return false;
             }
             return true;
         };
-        const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
+        const bool nv12 = semiSrc;
         if (!fits(p.hLum, 64, false, 256 * SD)) return 0;
         if (rgbOut ? !fits(p.hChr, 32, nv12, nv12 ? 256 * SD : 128 * SD) : !fits(p.hChr, nv12 ? 32 : 64, nv12, 256 * SD)) return 0;
     }
@@ -939,6 +1044,7 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
             t.blkRows = std::min(rl, 2 * rc) & ~3; t.blkRowsC = t.blkRows / 2;
         }
         if (t.n4L > 4 || t.n4C > 4) t.blkRows = 0;                    // (windows of more than 16 row pairs: the walker alone)
+        if (G_BPS == 2 && P >= 8) t.blkRows = 0;                      // (16-bit samples, four dwords of a row per lane: 64 registers of requested pairs)
     }
     if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
                                           p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
@@ -949,7 +1055,7 @@ int yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 // a short launch takes the block-cooperative form: up to 3 frames, or — small outputs — up to 2.8 M output pixels (round 5, every frame from HBM,
 // walker / block form, us a launch: 4K -> 854 x 480 rgb24 4 frames 33.1 / 29.6, 8: 50.6 / 53.3; 1080p -> 768 x 432 4 frames 13.9 / 11.5, 8: 19.8 / 18.5,
 // 16: 30.4 / 31.6; 4K -> 900p 4 frames 30.5 / 32.9: profiles/r05h_yuvg_blk_frames.txt).  GMAT_STRIP_BLOCK=n: launches of up to n frames; 0: never
-bool yuvg_block_form(const YuvGArgs &a, int nframes)
+bool G_NAME(yuvg_block_form)(const YuvGArgs &a, int nframes)
 {
     if (a.blkRows < 4 || !a.vtL || !a.vtC) return false;
     if (const char *bs = GMAT_KNOB("GMAT_STRIP_BLOCK")) return nframes <= atoi(bs);
@@ -994,10 +1100,10 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
     return 0;
 }
 
-int launch_scale_yuvg(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
-    if (yuvg_block_form(a0, nframes)) return launch_scale_yuvg_blk(a0, stream, *frames, nframes);
+    if (G_NAME(yuvg_block_form)(a0, nframes)) return launch_scale_yuvg_blk(a0, stream, *frames, nframes);
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override, read per launch
     const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;

@@ -355,11 +355,18 @@ struct YuvGArgs {
     // the block-cooperative form: vertical tables by output row, groups of 4 coefficient pairs a row, the tallest bands that fit
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
+    // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
+    // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
+    int src16, hShift, hBias, dst16, dstShift, dither8;
     Yuv2RgbConsts y2r;
 };
 int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
 int  launch_scale_yuvg(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launch of nframes frames takes scale_yuvg_blk_*_kernel
+// the same walker over 16-bit samples (k_scale_yuvg16.hip = k_scale_yuvg.hip compiled with G_BPS = 2): P010LE / P016LE / planar 10- and 16-bit sources
+int  yuvg_prepare16(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
+int  launch_scale_yuvg16(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+bool yuvg_block_form16(const YuvGArgs &a, int nframes);
 
 // ---- the quad-lane polyphase walker (k_scale_yuvu.hip, round 4): a lane owns FOUR adjacent outputs of a row, the vertical filter is a
 // GATHER over a short register ring of horizontally filtered row pairs (coefficients by output row, relative to the newest pair) — no

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from harness import is_generic, SWS, synth_planes, LINES16
+from harness import is_generic, SWS, synth_planes, LINES16, WALK16
 from test_batch_api import _run_batch
 from test_parity_strip import strip_rows  # noqa: F401
 
@@ -265,8 +265,11 @@ def test_10bit_same_layout_bit_exact_on_both_kernels(dev, orc, strip_rows, kern_
     """the rule is the 8-bit one; what declines goes to the generic plane scaler (the tiled 2:1 kernel takes 8-bit sources only)"""
     sw, sh = geom
     strip_rows(0)
-    want = STRIP16 if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt) else LINES16      # (round 4: a context the strip kernel declines is the lines form's from 2 : 1 on)
-    assert _check10(dev, orc, fmt, sw, sh) == want
+    k = _check10(dev, orc, fmt, sw, sh)
+    if kern_yuv == "strip" and strip_takes(sw, sh, fmt, fmt):
+        assert k == STRIP16, k
+    else:
+        assert k in WALK16 + (LINES16,), k      # (a context the strip kernel declines: the band walker over 16-bit samples since round 5, the lines form where it declines too)
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 4, 5, 8, 13, 64, 1000])
@@ -278,8 +281,8 @@ def test_10bit_segmentation_does_not_change_the_result(dev, orc, strip_rows, fmt
 
 @pytest.mark.parametrize("fmt", ["p010le", "yuv420p10le"])
 def test_10bit_rows_that_are_not_8_byte_aligned_fall_back(dev, orc, fmt):
-    """the 10-bit twin stores 8 bytes per lane"""
-    assert _check10(dev, orc, fmt, 528, 52, align=4, extra=4) == GENERIC
+    """the 10-bit twin stores 8 bytes per lane; rows of dwords are the band walker's (16-bit samples, round 5), anything less the tiled kernel's"""
+    assert _check10(dev, orc, fmt, 528, 52, align=4, extra=4) in WALK16
     assert _check10(dev, orc, fmt, 528, 52, align=2, extra=2) == GENERIC
     assert _check10(dev, orc, fmt, 528, 52, align=8, extra=8) == STRIP16
 
@@ -334,7 +337,7 @@ def test_10bit_saturating_content(dev, orc, strip_rows):
 def test_10bit_batched_frames(dev, orc, strip_rows, kern_yuv, fmt):
     strip_rows(0)
     k = _run_batch(dev, orc, fmt, fmt, 528, 52, 264, 26, nframes=5, nstreams=2, align=16)
-    assert k == (STRIP16 if kern_yuv == "strip" else LINES16), k
+    assert k == STRIP16 if kern_yuv == "strip" else k in WALK16 + (LINES16,), k
 
 
 # ---- across depths: 8 -> 10 bits (an 8-bit source into a 10-bit encode) and 10 -> 8, same chroma layout -----------------------

@@ -1,0 +1,121 @@
+"""The polyphase band walker over 16-BIT SAMPLES (k_scale_yuvg16.hip = k_scale_yuvg.hip compiled with two bytes a sample; round 5): P010LE / P016LE /
+YUV420P10LE / YUV420P16LE sources at the walker's ratios into packed RGB, 8-bit 4:2:0 (libswscale's ordered dither of a deeper source) and 10-bit
+4:2:0 of the same chroma layout — and the 8-bit walker's new 10-bit destinations (NV12 -> P010LE, YUV420P -> YUV420P10LE).  Against ONE libswscale
+context (the oracle: hScale16To15_c swscale.c:93-119, yuv2planeX_8_c with ff_dither_8x8_128 swscale.c:263-264 / 482-485, yuv2p010lX_c / cX_c and
+yuv2planeX_10_c output.c:459-519) bit for bit; before it these contexts ran the lines form's two passes or the tiled kernel (0.12 - 0.24 of the roofline)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from harness import PIX_FMT, SWS, ints, planes, synth_planes
+from test_batch_api import _run_batch
+
+W16 = ("scale_yuvg16_kernel", "scale_yuvg16_blk_kernel")
+W8 = ("scale_yuvg_kernel", "scale_yuvg_blk_kernel")
+
+
+def _deep(orc, fmt, sw, sh, seed, valid=True):
+    src = synth_planes(orc, fmt, sw, sh, seed=seed)
+    if valid and fmt == "yuv420p10le":                     # valid input: 10 significant bits in the low end
+        for p in src:
+            p.view("<u2")[...] &= 0x3FF
+    if valid and fmt == "p010le":                          # ... in the high end
+        for p in src:
+            p.view("<u2")[...] &= 0xFFC0
+    return src
+
+
+def _check(dev, orc, sf, df, geom, flags="bicubic", align=256, seed=23, valid=True, src_align=256):
+    sw, sh, dw, dh = geom
+    src = _deep(orc, sf, sw, sh, seed, valid)
+    want = orc.sws(src, sw, sh, sf, dw, dh, df, SWS[flags])
+    d = dev.upload_planes(src, src_align)
+    got, pads, k = dev.sws(d, sw, sh, sf, dw, dh, df, SWS[flags], dst_align=align)
+    for p in d:
+        p.free()
+    for i, (g, w) in enumerate(zip(got, want)):
+        bad = np.argwhere(g != w)
+        assert bad.size == 0, f"{k} {sf}->{df} {geom} plane {i}: {len(bad)} mismatching bytes, first at {bad[:6].tolist()}"
+        assert (pads[i] == 0xCD).all(), f"{k} plane {i}: wrote into the row padding"
+    return k
+
+
+@pytest.fixture(params=["walk", "blk"])
+def form(request, monkeypatch):
+    """both forms of the walker at every launch size: the band walker proper and the block-cooperative form of short launches"""
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "0" if request.param == "walk" else "32")
+    return request.param
+
+
+PAIRS16 = [("p010le", "p010le"), ("p010le", "nv12"), ("p010le", "rgb24"), ("p010le", "bgra"), ("p016le", "nv12"), ("p016le", "p010le"), ("p016le", "bgr24"),
+           ("yuv420p10le", "yuv420p10le"), ("yuv420p10le", "yuv420p"), ("yuv420p10le", "rgb24"), ("yuv420p16le", "yuv420p"), ("yuv420p16le", "yuv420p10le"),
+           ("yuv420p16le", "rgba")]
+# 2.4 : 1 (11 taps), 3 : 1, 3 : 2, 4 : 1, 1.3 : 1, 6 : 1 (26 taps), anamorphic, odd destination sizes, several 64-column strips with a partial last one
+GEOMS = [(384, 216, 160, 90), (768, 96, 256, 32), (384, 216, 256, 144), (1024, 64, 256, 16), (400, 240, 308, 184), (1536, 96, 256, 16), (640, 96, 200, 64),
+         (520, 100, 173, 41), (2048, 40, 700, 16)]
+
+
+@pytest.mark.parametrize("pair", PAIRS16, ids=lambda p: "%s-%s" % p)
+@pytest.mark.parametrize("geom", GEOMS, ids=lambda g: "%dx%d-%dx%d" % g)
+def test_walker16_every_layout(dev, orc, form, pair, geom):
+    k = _check(dev, orc, pair[0], pair[1], geom)
+    if (geom[2] & 1) and pair[1] in ("rgb24", "bgr24", "rgba", "bgra"):
+        assert k.startswith("scale_yuv"), k              # an RGB destination of odd width is not the walker's (8 bits or 16): whatever serves it, the bytes
+    elif form == "walk":
+        assert k == "scale_yuvg16_kernel", k
+    else:
+        assert k in W16, k                               # (a context whose bands fit no block keeps the walker)
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "bicubic", "lanczos", "area", "gauss", "spline", "point", "sinc"])
+@pytest.mark.parametrize("pair", [("p010le", "p010le"), ("yuv420p10le", "rgb24"), ("p016le", "nv12")], ids=lambda p: "%s-%s" % p)
+def test_walker16_every_algorithm(dev, orc, form, pair, flags):
+    """every SWS algorithm whose tables fit the walker (the others: whatever serves them — the bytes either way)"""
+    for geom in ((384, 216, 160, 90), (640, 128, 420, 84)):
+        _check(dev, orc, pair[0], pair[1], geom, flags)
+
+
+def test_walker16_garbage_in_the_unused_bits(dev, orc, form):
+    """libswscale shifts a P010 sample right by 6 whatever its low bits hold: frames that break the format's promise (random low bits) still come out as
+    one libswscale context makes them.  (A planar 10-bit sample with high bits set is read as the 16 bits it is and overflows hScale16To15_c's int: no
+    kernel here follows that.)"""
+    for pair in (("p010le", "p010le"), ("p010le", "rgb24"), ("p010le", "nv12")):
+        assert _check(dev, orc, pair[0], pair[1], (384, 216, 160, 90), valid=False) in W16
+
+
+@pytest.mark.parametrize("pair", [("nv12", "p010le"), ("yuv420p", "yuv420p10le")], ids=lambda p: "%s-%s" % p)
+@pytest.mark.parametrize("geom", [(384, 216, 160, 90), (768, 96, 256, 32), (384, 216, 256, 144), (520, 100, 173, 41)], ids=lambda g: "%dx%d-%dx%d" % g)
+def test_walker8_writes_ten_bit_destinations(dev, orc, form, pair, geom):
+    """the 8-bit walker's output stage in its 10-bit form: NV12 -> P010LE (a hardware decoder's frame for a 10-bit encoder), YUV420P -> YUV420P10LE"""
+    assert _check(dev, orc, pair[0], pair[1], geom) in W8
+
+
+@pytest.mark.parametrize("pair", [("p010le", "p010le"), ("p010le", "nv12"), ("yuv420p10le", "rgb24"), ("p016le", "bgra")], ids=lambda p: "%s-%s" % p)
+def test_walker16_batches_and_streams(dev, orc, pair, monkeypatch):
+    """n frames = one launch (grid.y = frame), shares of a batch on two streams; both forms by launch size"""
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "3")
+    assert _run_batch(dev, orc, pair[0], pair[1], 384, 216, 160, 90, nframes=5, nstreams=1, align=256) == "scale_yuvg16_kernel"
+    assert _run_batch.last_frames == 5
+    assert _run_batch(dev, orc, pair[0], pair[1], 384, 216, 160, 90, nframes=3, nstreams=1, align=256) == "scale_yuvg16_blk_kernel"
+    assert _run_batch(dev, orc, pair[0], pair[1], 384, 216, 160, 90, nframes=9, nstreams=2, align=256) == "scale_yuvg16_kernel"
+
+
+def test_walker16_pitches_and_band_heights(dev, orc, monkeypatch):
+    """destination pitches that are multiples of 4 only, source pitches of 64; bands of 4 ... 40 rows (GMAT_STRIP_ROWS) walking down and up"""
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "0")
+    for rows in (4, 7, 16, 40):
+        monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+        for pair in (("p010le", "p010le"), ("yuv420p10le", "yuv420p"), ("p016le", "rgb24")):
+            assert _check(dev, orc, pair[0], pair[1], (520, 200, 172, 66), align=4, src_align=64) == "scale_yuvg16_kernel"
+    monkeypatch.setenv("GMAT_STRIP_UPDOWN", "0")
+    assert _check(dev, orc, "p010le", "nv12", (520, 200, 172, 66)) == "scale_yuvg16_kernel"
+
+
+def test_walker16_knob_and_what_it_leaves_alone(dev, orc, monkeypatch):
+    """GMAT_SCALE_NO_WALKER16=1: the lines form / tiled kernel as before; 2 : 1 keeps its own kernel; a range conversion and 4:4:4 ends are not the walker's"""
+    assert _check(dev, orc, "p010le", "p010le", (384, 216, 192, 108)).startswith("scale_yuv2p")
+    monkeypatch.setenv("GMAT_SCALE_NO_WALKER16", "1")
+    k = _check(dev, orc, "p010le", "p010le", (384, 216, 160, 90))
+    assert k not in W16 and k.startswith("scale_yuv"), k
