@@ -117,10 +117,13 @@ __device__ __forceinline__ unsigned g_sat_pk_u8_i16(unsigned v)
 
 // window dwords of a lane: component stride 1 (a luma or planar chroma row): byte pairs (o + 2t, o + 2t + 1), t < P, o = pos & 3;
 // component stride 2 (one component of NV12's UV row): (o + 4t, o + 4t + 2), o = (2 pos + comp) & 3.
-// 16-bit samples (G_BPS = 2): a pair is two whole samples — stride 1: the dword at sample pos + 2t (pos even) or the halves either side of a dword
-// boundary (pos odd: one selector per lane); stride 2 (P010's (U, V) dwords): the component's half of dwords 2t and 2t + 1, always aligned
+// 16-bit samples (G_BPS = 2): the host re-bases every window to an 8-BYTE boundary of the row (leading zero taps: up to three samples of a plane,
+// one (U, V) position of P010's interleaved row) — a coefficient pair of a plane then meets one ALIGNED dword as it was loaded: no v_perm_b32, no
+// selector, and the window is read two dwords at a time (ds_read_b64).  Dword by dword at the lanes' own offsets the same windows were a 2-way bank
+// conflict (lanes 1.2 dwords apart at 2.4 : 1: SQ_LDS_BANK_CONFLICT 37.7 M cycles a 32-frame launch against 0 in the 8-bit build, SQ_WAIT_INST_LDS
+// 63 M against 8 M: profiles/r05k_walker16_pmc.txt).  Stride 2: the component's half of dwords 2t and 2t + 1 (one v_perm_b32 a pair).
 #if G_BPS == 2
-template <int P, bool S2> struct GWin { static constexpr int NW = S2 ? 2 * P : P + 1; };
+template <int P, bool S2> struct GWin { static constexpr int NW = S2 ? 2 * P : (P + 1) & ~1; };
 #else
 template <int P, bool S2> struct GWin { static constexpr int NW = S2 ? P + 1 : ((P - 1) >> 1) + 2; };
 #endif
@@ -133,7 +136,7 @@ __device__ __forceinline__ int g_hsum(const unsigned (&w)[GWin<P, S2>::NW], cons
 #pragma unroll
     for (int t = 0; t < P; t++) {
 #if G_BPS == 2
-        const int pr = S2 ? (int)__builtin_amdgcn_perm(w[2 * t + 1], w[2 * t], selE) : (int)__builtin_amdgcn_perm(w[t + 1], w[t], selE);
+        const int pr = S2 ? (int)__builtin_amdgcn_perm(w[2 * t + 1], w[2 * t], selE) : (int)w[t];
 #else
         const int pr = S2 ? (int)__builtin_amdgcn_perm(w[t + 1], w[t], selE)
                           : (int)__builtin_amdgcn_perm(w[(t >> 1) + 1], w[t >> 1], (t & 1) ? selO : selE);
@@ -154,8 +157,12 @@ __device__ __forceinline__ unsigned g_conv(unsigned shr, unsigned flip, unsigned
     const g_us2 s = __builtin_bit_cast(g_us2, v) >> (g_us2){(unsigned short)shr, (unsigned short)shr};
     return __builtin_bit_cast(unsigned, s) ^ flip;
 }
-// first byte of the window of output column `pos` (component `comp` of an interleaved row)
+// first byte of the window of output column `pos` (component `comp` of an interleaved row) / of the aligned dwords the lane reads for it
 template <bool S2> __device__ __host__ __forceinline__ int g_win_byte(int pos, int comp) { return G_BPS == 2 ? (S2 ? 4 * pos + 2 * comp : 2 * pos) : (S2 ? 2 * pos + comp : pos); }
+template <bool S2> __device__ __host__ __forceinline__ int g_win_base(int pos, int comp) { return g_win_byte<S2>(pos, comp) & (G_BPS == 2 ? ~7 : ~3); }
+// coefficient pairs of a stream in a kernel instantiated for P: 16-bit samples of an interleaved row lead with at most one position where a plane leads
+// with three samples, so the same taps fit one pair fewer (and every pair there costs a v_perm_b32 besides its v_dot2)
+template <int P, bool S2> struct GPairs { static constexpr int N = (G_BPS == 2 && S2) ? P - 1 : P; };
 
 // One stream of a lane: its horizontal window (selectors, coefficient pairs), the wave's share of the row loads, a ring of R
 // requested row pairs with STATIC slot names and the gathered windows of the pair consumed next.
@@ -198,15 +205,16 @@ struct GStream {
         const int b0 = g_win_byte<S2>(pos, comp);
         const unsigned o = (unsigned)b0 & 3u;
 #if G_BPS == 2
-        selE = S2 ? (comp ? 0x07060302u : 0x05040100u) : (o ? 0x05040302u : 0x03020100u);
+        selE = comp ? 0x07060302u : 0x05040100u;           // (stride 2 only)
         selO = 0u;
+        (void)o;
 #else
         selE = S2 ? (0x0C000C00u | o | ((o + 2) << 16)) : (0x0C000C00u | o | ((o + 1) << 16));
         selO = 0x0C000C00u | (o + 2) | ((o + 3) << 16);
 #endif
 #pragma unroll
         for (int t = 0; t < P; t++) cf[t] = hTab[(size_t)col * P + t];
-        return b0 & ~3;
+        return g_win_base<S2>(pos, comp);
     }
     // the walk starts at row pair `pair` (walking coordinates) of a plane of `rows` rows
     __device__ __forceinline__ void start(int pair, int rows, int stride, int up)
@@ -233,10 +241,20 @@ struct GStream {
             for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
 #endif
         __builtin_amdgcn_wave_barrier();
+#if G_BPS == 2
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < NW; i += 2) {                // (winDw is even, the images 8-byte aligned: ds_read_b64)
+                const uint2 t = *reinterpret_cast<const uint2 *>(img + r * IMG + winDw + i);
+                win[r][i] = t.x; win[r][i + 1] = t.y;
+            }
+#else
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
             for (int i = 0; i < NW; i++) win[r][i] = img[r * IMG + winDw + i];
+#endif
     }
     // pair 0 gathered, pairs 1 .. R requested: pair k + 1 in ring slot (k + 1) % R
     template <class Ld> __device__ __forceinline__ void prime(Ld &&ld)
@@ -278,7 +296,11 @@ struct GStream {
 #define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_WAVES)))
 #elif G_WAVES < 0
 // one dword of a row per lane (P <= 6: ratios up to 3.7:1 with 4-tap algorithms): 94-100 VGPRs as compiled, 5 waves a SIMD fit in 96
-#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_BPS == 1 && P <= 6 && K <= 9 ? 5 : 1)))      // (16-bit samples: wider windows and rings — as the compiler allocates them)
+// (16-bit samples: wider windows and rings — as the compiler allocates them: 98 VGPRs in the plane jobs at P = 6, 148 under an RGB destination; G_WAVES16 = n: A/B)
+#ifndef G_WAVES16
+#define G_WAVES16 1
+#endif
+#define G_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(G_BPS == 1 ? (P <= 6 && K <= 9 ? 5 : 1) : (P <= 6 && K <= 9 ? G_WAVES16 : 1))))
 #else
 #define G_WAVES_ATTR
 #endif
@@ -290,6 +312,11 @@ struct GStream {
 #ifndef G_RL
 #define G_RL 4
 #endif
+// G_RP: ring slots of a plane job (row pairs requested ahead): 4 = two quads ahead, 2 = one quad ahead and 4 SD registers fewer (A/B)
+// (16-bit samples: 2 — one quad ahead is as fast or 1-2 % faster, 8 % on an up-scale, and eight registers fewer: profiles/r05n_w16_ring.txt)
+#ifndef G_RP
+#define G_RP (G_BPS == 2 ? 2 : 4)
+#endif
 constexpr int kGHead = 2;               // dwords in front of a quad's coefficient pairs: first open output row, rows it completes
 
 // ---- packed RGB destinations --------------------------------------------------------------------------------------------------
@@ -297,9 +324,9 @@ constexpr int kGHead = 2;               // dwords in front of a quad's coefficie
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
+    constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
     __shared__ int2 lutV[256], lutU[256];
-    __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
+    __shared__ __attribute__((aligned(16))) unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
 
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
     GStream<P, false, SD, G_RL> L;
-    GStream<P, NV12, SD, 2> C;
+    GStream<GPairs<P, NV12>::N, NV12, SD, 2> C;
     L.set_conv(GConv{a.src16, a.hShift, a.hBias}); C.set_conv(GConv{a.src16, a.hShift, a.hBias});
     {
         // luma: the wave's row segment starts at lane 0's window; every lane fills dword `lane` (+ 64) of the row image
@@ -507,8 +534,8 @@ struct GPlaneOut {
 template <int P, int K, bool NV12>
 __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
-    __shared__ unsigned image[4][2 * 64 * SD];                    // [wave][two row images]
+    constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
+    __shared__ __attribute__((aligned(16))) unsigned image[4][2 * 64 * SD];                    // [wave][two row images]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lin = blockIdx.x;
@@ -542,7 +569,7 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     const int rnd = job ? a.roundC : a.roundL;
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
-        GStream<P, S2, SD, 4> W;
+        GStream<GPairs<P, S2>::N, S2, SD, G_RP> W;
         W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
@@ -599,9 +626,15 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         for (int q = q0; q <= q1; q += 2) {
+#if G_RP == 4
             quad(q, I1(), I2());
             if (q + 1 > q1) break;
             quad(q + 1, I3(), I0());
+#else
+            quad(q, I1(), I0());
+            if (q + 1 > q1) break;
+            quad(q + 1, I1(), I0());
+#endif
         }
         flush();
     };
@@ -663,9 +696,9 @@ __device__ __forceinline__ int g_blk_vsum(const int32_t *row, int n4, const int 
 template <int P, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), JL = kGBlkJL, JC = kGBlkJC;
+    constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), JL = kGBlkJL, JC = kGBlkJC;
     __shared__ int2 lutV[256], lutU[256];
-    __shared__ unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
+    __shared__ __attribute__((aligned(16))) unsigned image[4][2][2 * 64 * SD];                 // [wave][luma | chroma][two row images]
     __shared__ int hLs[4 * JL + kGBlkPad][64], hCs[4 * JC + kGBlkPad][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -691,13 +724,13 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
 
     const int x = X0 + lane, xc = min(x, a.dstW - 1), par = lane & 1;
     GStream<P, false, SD, JL> L;
-    GStream<P, NV12, SD, JC> C;
+    GStream<GPairs<P, NV12>::N, NV12, SD, JC> C;
     L.set_conv(GConv{a.src16, a.hShift, a.hBias}); C.set_conv(GConv{a.src16, a.hShift, a.hBias});
     {
         // (the lane mapping of scale_yuvg_rgb_kernel; the row segment's start — lane 0's window — from a SCALAR load, so that the row
         // requests do not wait for the lanes' own table entries)
         const int w0 = L.setup(a.hL, a.posL, xc, 0);
-        const int seg = g_win_byte<false>(uniform_load(a.posL, X0), 0) & ~3;
+        const int seg = g_win_base<false>(uniform_load(a.posL, X0), 0);
         L.winDw = (w0 - seg) >> 2;
 #pragma unroll
         for (int s = 0; s < SD; s++) { L.ldDw[s] = lane + 64 * s; L.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
@@ -706,7 +739,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
     {
         const int w0 = C.setup(a.hC, a.posC, min(xc >> 1, a.chrDstW - 1), par);
         const int pos0 = uniform_load(a.posC, min(X0 >> 1, a.chrDstW - 1));
-        const int seg = g_win_byte<NV12>(pos0, 0) & ~3;
+        const int seg = g_win_base<NV12>(pos0, 0);
         if (NV12) {
             C.winDw = (w0 - seg) >> 2;
 #pragma unroll
@@ -771,8 +804,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
 template <int P, bool NV12>
 __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
-    constexpr int SD = G_BPS * (P >= 8 ? 2 : 1), J = kGBlkJL;
-    __shared__ unsigned image[4][2 * 64 * SD];
+    constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), J = kGBlkJL;
+    __shared__ __attribute__((aligned(16))) unsigned image[4][2 * 64 * SD];
     __shared__ int hS[4 * J + kGBlkPad][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -802,12 +835,12 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
     const int rnd = job ? a.roundC : a.roundL;
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
-        GStream<P, S2, SD, J> W;
+        GStream<GPairs<P, S2>::N, S2, SD, J> W;
         W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
             const int pos0 = uniform_load(job ? a.posC : a.posL, S2 ? B0 >> 1 : B0);      // lane 0's window (B0 is even), by a scalar load
-            const int seg = g_win_byte<S2>(pos0, 0) & ~3;
+            const int seg = g_win_base<S2>(pos0, 0);
             W.winDw = (w0 - seg) >> 2;
 #pragma unroll
             for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
@@ -904,7 +937,12 @@ static void fill_qprog(YuvGQProg &v, int K)
 // K = output rows open at once.  The plane jobs have the registers for 12 and 15 as well (57-67 VGPRs at K = 9): 4:2:0 -> 4:2:0
 // UP-scales up to 2:1 (720p -> 1080p needs 10, 1080p -> 1440p 10, 1:2 14-15); an RGB destination needs 14-22 there and stays tiled.
 // P = 13 (round 4): 26 taps — bicubic down to 6.2 : 1 (4K -> 360p), bilinear / area twice as far
-static const int kGP[] = {4, 5, 6, 8, 10, 13}, kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
+#if G_BPS == 2
+static const int kGP[] = {4, 5, 6, 7, 8, 10, 13};           // (7: the 10 / 11 taps of 2.2 - 2.5 : 1 behind three leading zeros)
+#else
+static const int kGP[] = {4, 5, 6, 8, 10, 13};
+#endif
+static const int kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
 
 int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
@@ -944,23 +982,32 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     for (int v : g.chrRound) if (v != g.chrRound[0]) return 0;
     t.roundL = g.lumRound[0]; t.roundC = g.chrRound[0];
     // horizontal: coefficient pairs on the table's own windows (a window may start anywhere; the last pair of an odd tap count is padded)
-    auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out, int P) {
+    // (16-bit samples: the windows re-based to 8-byte boundaries — `lead` zero taps in front: pos & 3 samples of a plane, pos & 1 positions of an interleaved row)
+    auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out, int P, bool s2) {
         out.assign((size_t)fb.count * P, 0);
         for (int x = 0; x < fb.count; x++) {
             if (fb.pos[x] < 0 || fb.pos[x] + fb.taps > srcLen) return false;
+            const int lead = G_BPS == 2 ? (s2 ? fb.pos[x] & 1 : fb.pos[x] & 3) : 0;
+            if (lead + fb.taps > 2 * P) return false;
             for (int k = 0; k < P; k++) {
-                const int t0 = 2 * k, t1 = t0 + 1;
-                const int lo = t0 < fb.taps ? fb.coef[(size_t)x * fb.taps + t0] : 0, hi = t1 < fb.taps ? fb.coef[(size_t)x * fb.taps + t1] : 0;
+                const int t0 = 2 * k - lead, t1 = t0 + 1;
+                const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)x * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)x * fb.taps + t1] : 0;
                 out[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
             }
         }
         return true;
     };
-    const int needP = (std::max(p.hLum.taps, p.hChr.taps) + 1) / 2;
+    auto pairs_needed = [&](const FilterBank &fb, bool s2) {
+        int m = 0;
+        for (int x = 0; x < fb.count; x++) m = std::max(m, (G_BPS == 2 ? (s2 ? fb.pos[x] & 1 : fb.pos[x] & 3) : 0) + fb.taps);
+        return (m + 1) / 2;
+    };
+    // (the chroma stream of an interleaved 16-bit row runs on one pair fewer than the instance's P: GPairs)
+    const int needP = std::max(pairs_needed(p.hLum, false), pairs_needed(p.hChr, semiSrc) + (G_BPS == 2 && semiSrc ? 1 : 0));
     int P = 0;
     for (int c : kGP) if (c >= needP) { P = c; break; }
     if (!P) return 0;
-    if (!hpack(p.hLum, p.srcW, t.hL, P) || !hpack(p.hChr, p.chrSrcW, t.hC, P)) return 0;
+    if (!hpack(p.hLum, p.srcW, t.hL, P, false) || !hpack(p.hChr, p.chrSrcW, t.hC, G_BPS == 2 && semiSrc ? P - 1 : P, semiSrc)) return 0;
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
     int needK = 0;
     for (int up = 0; up < 2; up++) {
@@ -983,13 +1030,13 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     // the row segments: a wave's 64 (luma, planar chroma plane) or 32 (the chroma of an RGB destination, NV12's interleaved chroma)
     // consecutive columns must fit the row image of SD * 256 bytes (planar chroma halves under an RGB destination: SD * 128)
     {
-        const int SD = G_BPS * (P >= 8 ? 2 : 1);
+        const int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1);     // (16-bit samples: eight pairs hold the 13 taps of 3 : 1 behind three leading zeros — 416 bytes a row)
         auto fits = [&](const FilterBank &fb, int cols, bool s2, int capBytes) {
-            const int NW = G_BPS == 2 ? (s2 ? 2 * P : P + 1) : (s2 ? P + 1 : ((P - 1) >> 1) + 2);
+            const int NW = G_BPS == 2 ? (s2 ? 2 * (P - 1) : (P + 1) & ~1) : (s2 ? P + 1 : ((P - 1) >> 1) + 2);
             for (int c0 = 0; c0 < fb.count; c0 += cols) {
                 const int c1 = std::min(c0 + cols, fb.count) - 1;
-                const int b0 = (s2 ? g_win_byte<true>(fb.pos[c0], 0) : g_win_byte<false>(fb.pos[c0], 0)) & ~3;
-                const int b1 = (s2 ? g_win_byte<true>(fb.pos[c1], 1) : g_win_byte<false>(fb.pos[c1], 0)) & ~3;
+                const int b0 = s2 ? g_win_base<true>(fb.pos[c0], 0) : g_win_base<false>(fb.pos[c0], 0);
+                const int b1 = s2 ? g_win_base<true>(fb.pos[c1], 1) : g_win_base<false>(fb.pos[c1], 0);
                 if (b1 + 4 * NW - b0 > capBytes) return false;
             }
             return true;
@@ -1044,7 +1091,7 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
             t.blkRows = std::min(rl, 2 * rc) & ~3; t.blkRowsC = t.blkRows / 2;
         }
         if (t.n4L > 4 || t.n4C > 4) t.blkRows = 0;                    // (windows of more than 16 row pairs: the walker alone)
-        if (G_BPS == 2 && P >= 8) t.blkRows = 0;                      // (16-bit samples, four dwords of a row per lane: 64 registers of requested pairs)
+        if (G_BPS == 2 && P >= 10) t.blkRows = 0;                     // (16-bit samples, four dwords of a row per lane: 64 registers of requested pairs)
     }
     if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
                                           p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
@@ -1094,6 +1141,9 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false>), grid, block, 0, stream, a, fr); } \
         else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, false>), grid, block, 0, stream, a, fr); } } while (0)
+#if G_BPS == 2
+    if (a.P == 7) { GMAT_GB(7); } else
+#endif
     switch (a.P) { case 4: GMAT_GB(4); break; case 5: GMAT_GB(5); break; case 6: GMAT_GB(6); break; case 8: GMAT_GB(8); break; case 10: GMAT_GB(10); break; default: GMAT_GB(13); }
 #undef GMAT_GB
     GMAT_HIP_CHECK(hipGetLastError());
@@ -1151,6 +1201,9 @@ int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2
 #define GMAT_G_P4() do { \
         if (!a.yuvOut && a.K > 9) switch (a.K) { case 15: GMAT_G_RGB(4, 15); break; case 18: GMAT_G_RGB(4, 18); break; default: GMAT_G_RGB(4, 22); } \
         else GMAT_G_P(4); } while (0)
+#if G_BPS == 2
+    if (a.P == 7) { GMAT_G_P(7); } else
+#endif
     switch (a.P) { case 4: GMAT_G_P4(); break; case 5: GMAT_G_P(5); break; case 6: GMAT_G_P(6); break; case 8: GMAT_G_P(8); break; case 10: GMAT_G_P(10); break; default: GMAT_G_P(13); }
 #undef GMAT_G_P
 #undef GMAT_G_P4

@@ -52,8 +52,8 @@ def form(request, monkeypatch):
 PAIRS16 = [("p010le", "p010le"), ("p010le", "nv12"), ("p010le", "rgb24"), ("p010le", "bgra"), ("p016le", "nv12"), ("p016le", "p010le"), ("p016le", "bgr24"),
            ("yuv420p10le", "yuv420p10le"), ("yuv420p10le", "yuv420p"), ("yuv420p10le", "rgb24"), ("yuv420p16le", "yuv420p"), ("yuv420p16le", "yuv420p10le"),
            ("yuv420p16le", "rgba")]
-# 2.4 : 1 (11 taps), 3 : 1, 3 : 2, 4 : 1, 1.3 : 1, 6 : 1 (26 taps), anamorphic, odd destination sizes, several 64-column strips with a partial last one
-GEOMS = [(384, 216, 160, 90), (768, 96, 256, 32), (384, 216, 256, 144), (1024, 64, 256, 16), (400, 240, 308, 184), (1536, 96, 256, 16), (640, 96, 200, 64),
+# 2.4 : 1 (11 taps), 3 : 1, 3 : 2, 4 : 1, 1.3 : 1, 5 : 1 (21 taps behind up to three leading zeros: 12 of the 13 pairs), anamorphic, odd destination sizes, several 64-column strips with a partial last one
+GEOMS = [(384, 216, 160, 90), (768, 96, 256, 32), (384, 216, 256, 144), (1024, 64, 256, 16), (400, 240, 308, 184), (1280, 96, 256, 16), (640, 96, 200, 64),
          (520, 100, 173, 41), (2048, 40, 700, 16)]
 
 
