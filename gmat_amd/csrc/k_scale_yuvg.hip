@@ -38,6 +38,11 @@
 #ifndef G_BPS
 #define G_BPS 1
 #endif
+// G_PROBE (measurement builds only — WRONG pixels): bit 0: half the horizontal taps, bit 1: a pair's second row is not loaded (half the read bytes),
+// bit 2: no vertical taps but a sum's first.  profiles/r05o_walker_probes.txt
+#ifndef G_PROBE
+#define G_PROBE 0
+#endif
 #if G_BPS == 2
 #define G_NAME(n) n##16
 #else
@@ -134,7 +139,7 @@ __device__ __forceinline__ int g_hsum(const unsigned (&w)[GWin<P, S2>::NW], cons
 {
     int s = start;
 #pragma unroll
-    for (int t = 0; t < P; t++) {
+    for (int t = 0; t < ((G_PROBE & 1) ? (P + 1) / 2 : P); t++) {
 #if G_BPS == 2
         const int pr = S2 ? (int)__builtin_amdgcn_perm(w[2 * t + 1], w[2 * t], selE) : (int)w[t];
 #else
@@ -225,7 +230,7 @@ struct GStream {
     template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SD])
     {
 #pragma unroll
-        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = ld(ldOff[s], reqOff + rowStep); }
+        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = (G_PROBE & 2) ? dst[0][s] : ld(ldOff[s], reqOff + rowStep); }
         reqOff += 2u * rowStep;
     }
     // a row pair's bytes: registers -> row images -> this lane's windows
@@ -613,11 +618,11 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
             flush();
 #endif
 #pragma unroll
-            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp0, c0[i], acc[i]);
+            for (int i = 0; i < ((G_PROBE & 4) ? 1 : K); i++) acc[i] = g_dot2(hp0, c0[i], acc[i]);
             const int hp1 = W.hpair();
             W.template advance<SB>(ld);
 #pragma unroll
-            for (int i = 0; i < K; i++) acc[i] = g_dot2(hp1, c1[i], acc[i]);
+            for (int i = 0; i < ((G_PROBE & 4) ? 1 : K); i++) acc[i] = g_dot2(hp1, c1[i], acc[i]);
             pend = ne;
 #if !G_DEFER
             flush();

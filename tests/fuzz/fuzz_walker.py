@@ -28,7 +28,7 @@ maxw, maxh = (2600, 400) if hip else (900, 160)
 ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline", "bicublin", "x"]
 
 for case in range(n):
-    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER"):
+    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER", "GMAT_SCALE_NO_WALKER16"):
         os.environ.pop(k, None)
     q = rng.random()
     if q < 0.15:   os.environ["GMAT_QUAD_WALKER"] = "0"          # up-scales on the band walker / the tiled kernel
@@ -42,6 +42,16 @@ for case in range(n):
         os.environ["GMAT_SCALE_NO_STRIP"] = "1"                  # exact ratios reach the walker too
     sf = rng.choice(["nv12", "yuv420p"])
     df = rng.choice(["rgb24", "bgr24", "rgba", "bgra", sf, sf, "yuv420p" if sf == "nv12" else "nv12"])      # (the other chroma layout: round 4's cascade, GMAT_NO_CROSS_CASCADE)
+    if rng.random() < 0.3:
+        # round 5: 16-bit samples in (the band walker of k_scale_yuvg16.hip), 10-bit samples out (its output stage, the 8-bit walker's too)
+        semi = rng.random() < 0.5
+        if rng.random() < 0.75:
+            sf = rng.choice(["p010le", "p010le", "p016le"] if semi else ["yuv420p10le", "yuv420p10le", "yuv420p16le"])
+        else:
+            sf = "nv12" if semi else "yuv420p"
+        df = rng.choice(["rgb24", "bgr24", "rgba", "bgra"] + 3 * ["nv12" if semi else "yuv420p"] + 3 * ["p010le" if semi else "yuv420p10le"])
+        if rng.random() < 0.15:
+            os.environ["GMAT_SCALE_NO_WALKER16"] = "1"
     os.environ.pop("GMAT_NO_CROSS_CASCADE", None)
     if rng.random() < 0.2:
         os.environ["GMAT_NO_CROSS_CASCADE"] = "1"
@@ -51,7 +61,7 @@ for case in range(n):
         dw = 64 * rng.randint(1, 8) + rng.choice([0, 0, 2, 62])   # on / just past / just short of the strips
     rx = rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 2.0), rng.uniform(1.0, 3.0), rng.uniform(3.0, 6.0)])
     ry = rx * rng.uniform(0.8, 1.25) if rng.random() < 0.7 else rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 6.0)])
-    sw = max(16, min(maxw, 4 * int(dw * rx / 4)))
+    sw = max(16, min(maxw if len(sf) <= 7 else maxw // 2, 4 * int(dw * rx / 4)))       # (16-bit samples: half the width for the same oracle time)
     sh = max(8, min(maxh, 2 * int(dh * ry / 2)))
     if (sw, sh) == (dw, dh):
         hist["(same size: the converter's semantics, tests/test_parity_yuv2rgb.py)"] += 1    # nearest-chroma yuv2rgb.c by design, not orc.sws's generic lines
