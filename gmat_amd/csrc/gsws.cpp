@@ -275,10 +275,13 @@ static int init_yuv_scaler(GmatSwsContext *c)
     if (!a.src16 && !c->rgbViaPlanes && (r = yuvg_prepare(c->planYuv, c->ytiling, c->yg)) < 0) return r;
     // (round 5) the same walker over 16-bit samples: P010LE / P016LE / planar 10- and 16-bit 4:2:0 sources (k_scale_yuvg16.hip) — one set of tables a context
     if (a.src16 >= 10 && !c->rgbViaPlanes && (r = yuvg_prepare16(c->planYuv, c->ytiling, c->yg)) < 0) return r;
+    // ... and over a packed RGB24 / BGR24 source into a 4:2:0 frame (its own converter in front of the same 16-bit lines: hScale16To15_c with sh = 13)
+    if (a.src16 == 3 && c->rgbViaPlanes && (r = yuvg_prepare16(c->planYuv, c->ytiling, c->yg)) < 0) return r;
     if (c->yg.ok) {
         YuvGArgs &g = c->gargs;
         std::memset(&g, 0, sizeof(g));
-        g.src16 = a.src16 >= 10 ? a.src16 : 0; g.hShift = a.src16 >= 10 ? a.hShift : 7; g.hBias = a.src16 >= 10 ? a.hBias : 0;
+        g.src16 = (a.src16 >= 10 || a.src16 == 3) ? a.src16 : 0; g.hShift = g.src16 ? a.hShift : 7; g.hBias = g.src16 ? a.hBias : 0;
+        g.r2y = a.r2y; g.rgbBgr = a.rgbBgr;
         g.dst16 = a.dst16; g.dstShift = a.dstShift;
         const YuvGTables &t = c->yg;
         int k = 0;
@@ -585,7 +588,8 @@ static bool yuvg_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
     if (!c->yg.ok || c->rangeConv || ya.prof) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
     const bool semi = c->gargs.src16 ? (c->gargs.src16 == 10 || c->gargs.src16 == 16) : ya.nv12 != 0;
-    if (!semi) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
+    if (c->gargs.src16 == 3) all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.dst | (uintptr_t)ya.ds;      // (a packed RGB source: one plane)
+    else if (!semi) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
     if (c->yg.yuvOut) {
         all |= (uintptr_t)ya.dstU | (uintptr_t)ya.dsU;
         if (!ya.dstNv12) all |= (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
@@ -597,7 +601,7 @@ static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     YuvGArgs g = c->gargs;
     g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs;
-    g.nv12 = g.src16 ? (g.src16 == 10 || g.src16 == 16) : ya.nv12;        // interleaved chroma (P010LE / P016LE: YuvScaleArgs' kinds 10 and 16)
+    g.nv12 = g.src16 == 3 ? ya.dstNv12 : g.src16 ? (g.src16 == 10 || g.src16 == 16) : ya.nv12;        // interleaved chroma (P010LE / P016LE: YuvScaleArgs' kinds 10 and 16; an RGB source: the destination's layout)
     g.dither8 = ya.dither8;
     g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
     g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;

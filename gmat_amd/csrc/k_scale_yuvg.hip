@@ -182,16 +182,22 @@ template <int P, bool S2> struct GPairs { static constexpr int N = (G_BPS == 2 &
 //   * a pair's bytes pass through a wave-private LDS row image on their way to the lanes' overlapping windows (ds_write_b32, then
 //     NW dword reads per row at the lane's window offset).  No barrier: one wave, and the LDS executes its instructions in order;
 //   * rows past the plane are simply requested: the buffer resource returns 0 for them, and their taps are 0 in every table.
-template <int P, bool S2, int SD, int R>
+// LK (16-bit build, round 5): what a lane loads.  0: SD dwords of the plane's row, 256 bytes apart.  1 / 2 / 3: a PACKED RGB24 / BGR24 source — the image
+// holds what libswscale's input stage hands to hScale16To15_c (sh = 13): rgb24ToY_c's 14-bit luma (1: four pixels = three raw dwords -> two image
+// dwords), rgb24ToUV_half_c's chroma of pixel PAIRS as one plane's line (2: eight pixels = six raw dwords -> two image dwords) or as (U, V) dwords like
+// P010's interleaved row (3: four pixels -> two image dwords) — input.c:815-866; a lane then fills SD ADJACENT image dwords from 4 SDL contiguous bytes.
+template <int P, bool S2, int SD, int R, int LK = 0>
 struct GStream {
     static constexpr int NW = GWin<P, S2>::NW;
     static constexpr int IMG = 64 * SD;
+    static constexpr int SDL = LK == 0 ? SD : LK == 2 ? 3 * SD : (3 * SD) / 2;      // raw dwords of a row a lane
     int cf[P];
     unsigned selE, selO;
     int winDw;                           // LDS dword index of this lane's window inside a row image
-    int ldDw[SD];                        // LDS dword index this lane fills, per sub-load
-    unsigned ldOff[SD];                  // byte offset in the source row this lane loads, per sub-load
-    unsigned ring[R][2][SD];
+    int ldDw[SD];                        // LDS dword index this lane fills, per sub-load (LK != 0: ldDw[0] + s)
+    unsigned ldOff[SDL];                 // byte offset in the source row this lane loads, per sub-load
+    unsigned ring[R][2][SDL];
+    int rc01, rc2, rk01, rk2;            // LK != 0: the converter's coefficients — bytes (0, 1) as an int16 pair and byte 2: luma or the plane's component (rc), V beside U (rk, LK = 3)
     unsigned win[2][NW];
     unsigned *img;                       // this wave's two row images of this stream: img[row * IMG + dword]
     unsigned reqOff, rowStep;            // (wave-uniform) byte offset of the next row to request, and of one row further along the walk
@@ -227,24 +233,70 @@ struct GStream {
         rowStep = up ? 0u - (unsigned)stride : (unsigned)stride;
         reqOff = (unsigned)(up ? rows - 1 - 2 * pair : 2 * pair) * (unsigned)stride;
     }
-    template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SD])
+    template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SDL])
     {
 #pragma unroll
-        for (int s = 0; s < SD; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = (G_PROBE & 2) ? dst[0][s] : ld(ldOff[s], reqOff + rowStep); }
+        for (int s = 0; s < SDL; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = (G_PROBE & 2) ? dst[0][s] : ld(ldOff[s], reqOff + rowStep); }
         reqOff += 2u * rowStep;
     }
+    // four packed pixels (three dwords): bytes (0, 1) of each as an int16 pair, byte 2 on its own (k_scale_rgb2s.hip's unpacking)
+    static __device__ __forceinline__ void rgb4(const unsigned *d, int (&fs)[4], int (&th)[4])
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int o = 3 * i, dw = o >> 2, b = o & 3;
+            const unsigned lo = d[dw], hi = d[dw + 1 < 3 ? dw + 1 : dw];
+            fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
+            th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
+        }
+    }
     // a row pair's bytes: registers -> row images -> this lane's windows
-    __device__ __forceinline__ void gather(const unsigned (&src)[2][SD])
+    __device__ __forceinline__ void gather(const unsigned (&src)[2][SDL])
     {
         __builtin_amdgcn_wave_barrier();         // (emulation: the lanes of a wave are fibers; on the GPU the LDS runs a wave's instructions in order)
+        if constexpr (LK == 0) {
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+            for (int r = 0; r < 2; r++)
 #pragma unroll
 #if G_BPS == 2
-            for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = g_conv(cvShr, cvFlip, src[r][s]);
+                for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = g_conv(cvShr, cvFlip, src[r][s]);
 #else
-            for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
+                for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
 #endif
+        } else {
+            constexpr int KY = (32 << 14) + (1 << 8), KC = (256 << 15) + (1 << 9);      // rgb24ToY_c: >> 9; rgb24ToUV_half_c on a pair's sums: >> 10
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int g = 0; g < SD / 2; g++) {
+                    unsigned o0, o1;
+                    if constexpr (LK == 1) {
+                        int fs[4], th[4], y[4];
+                        rgb4(&src[r][3 * g], fs, th);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) y[i] = g_dot2(fs[i], rc01, m24(th[i], rc2) + KY) >> 9;
+                        o0 = (unsigned)y[0] | ((unsigned)y[1] << 16); o1 = (unsigned)y[2] | ((unsigned)y[3] << 16);
+                    } else if constexpr (LK == 2) {
+                        int c[4];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            int fs[4], th[4];
+                            rgb4(&src[r][6 * g + 3 * h], fs, th);
+#pragma unroll
+                            for (int q = 0; q < 2; q++)          // (two 9-bit sums in the halves: no carry across)
+                                c[2 * h + q] = g_dot2(fs[2 * q] + fs[2 * q + 1], rc01, m24(th[2 * q] + th[2 * q + 1], rc2) + KC) >> 10;
+                        }
+                        o0 = (unsigned)c[0] | ((unsigned)c[1] << 16); o1 = (unsigned)c[2] | ((unsigned)c[3] << 16);
+                    } else {
+                        int fs[4], th[4];
+                        rgb4(&src[r][3 * g], fs, th);
+                        const int f0 = fs[0] + fs[1], t0 = th[0] + th[1], f1 = fs[2] + fs[3], t1 = th[2] + th[3];
+                        o0 = (unsigned)(g_dot2(f0, rc01, m24(t0, rc2) + KC) >> 10) | ((unsigned)(g_dot2(f0, rk01, m24(t0, rk2) + KC) >> 10) << 16);
+                        o1 = (unsigned)(g_dot2(f1, rc01, m24(t1, rc2) + KC) >> 10) | ((unsigned)(g_dot2(f1, rk01, m24(t1, rk2) + KC) >> 10) << 16);
+                    }
+                    *reinterpret_cast<uint2 *>(img + r * IMG + ldDw[0] + 2 * g) = make_uint2(o0, o1);
+                }
+        }
         __builtin_amdgcn_wave_barrier();
 #if G_BPS == 2
 #pragma unroll
@@ -264,7 +316,7 @@ struct GStream {
     // pair 0 gathered, pairs 1 .. R requested: pair k + 1 in ring slot (k + 1) % R
     template <class Ld> __device__ __forceinline__ void prime(Ld &&ld)
     {
-        unsigned first[2][SD];
+        unsigned first[2][SDL];
         request(ld, first);
 #pragma unroll
         for (int d = 1; d <= R; d++) request(ld, ring[d % R]);
@@ -497,6 +549,31 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_rgb_kernel(YuvGAr
     flush();
 }
 
+// which bytes of its row a lane loads and which image dwords it fills: a plane's row (LK = 0: dword `lane` of the wave's segment and the ones 256
+// bytes on) or packed RGB pixels (LK != 0: SD adjacent image dwords from 4 SDL contiguous bytes; seg = the segment's first image BYTE, a multiple of 8).
+// job / semi pick the converter's coefficients: luma, one chroma plane's component, or U beside V
+template <class Stream>
+__device__ __forceinline__ void g_stream_loads(Stream &W, int seg, int lane, bool s2, const YuvGArgs &a, int job)
+{
+    constexpr int SD = Stream::IMG / 64, SDL = Stream::SDL;
+    if constexpr (SDL == SD) {
+#pragma unroll
+        for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+    } else {
+        const int e0 = s2 ? seg >> 2 : seg >> 1;                      // first sample (chroma position) of the segment
+        const unsigned raw = (unsigned)((2 * SDL == 3 * SD && !s2) ? 3 * e0 : 6 * e0);      // luma: 3 bytes a sample; chroma of pixel pairs: 6
+#pragma unroll
+        for (int s = 0; s < SD; s++) W.ldDw[s] = lane * SD + s;
+#pragma unroll
+        for (int s = 0; s < SDL; s++) W.ldOff[s] = raw + 4u * (unsigned)(lane * SDL + s);
+        const Rgb2YuvConsts &k = a.r2y;
+        auto pk = [](int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); };
+        const int c0 = job == 0 ? k.ry : (job == 2 ? k.rv : k.ru), c1 = job == 0 ? k.gy : (job == 2 ? k.gv : k.gu), c2 = job == 0 ? k.by : (job == 2 ? k.bv : k.bu);
+        W.rc01 = a.rgbBgr ? pk(c2, c1) : pk(c0, c1); W.rc2 = a.rgbBgr ? c0 : c2;
+        W.rk01 = a.rgbBgr ? pk(k.bv, k.gv) : pk(k.rv, k.gv); W.rk2 = a.rgbBgr ? k.rv : k.bv;
+    }
+}
+
 // The output stage of a plane job: the lane's vertical sum -> its sample of the plane row -> the wave's dwords.  elem: the lane's element of the row
 // (a luma / planar chroma sample, or a component of the interleaved row), e0 the wave's first, n the row's elements; dx: the lane's half of the
 // ordered dither (8-bit output of a deeper source: dither_8x8_128 is affine over GF(2), px_math.h), y the REAL output row
@@ -536,7 +613,10 @@ struct GPlaneOut {
 // job 0: the luma plane (lane = column).  job 1: chroma — NV12 -> NV12: lane = (column, component) of the interleaved plane;
 // planar -> planar: two jobs (U, V), lane = column.  Blocks [0, nblkL) are luma, the rest chroma.  A quad of a plane job is four of
 // ITS rows (two row pairs; the third coefficient set of the program is unused).
-template <int P, int K, bool NV12>
+// SRC = 1 (16-bit build): the source is ONE plane of packed RGB24 / BGR24 pixels (libswscale's generic path for an RGB source into a 4:2:0 frame,
+// down-scaling: luma from every pixel, chroma from horizontal pixel PAIRS at full height — chrSrcHSubSample = 1, chrSrcVSubSample = 0, utils.c:1529-1545);
+// every job reads that plane through its own converter (GStream's LK); NV12 then names the DESTINATION's chroma layout
+template <int P, int K, bool NV12, int SRC = 0>
 __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), QS = kGHead + 3 * K;
@@ -562,26 +642,26 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
     const int y0 = (int)(((unsigned)band * bstep) >> 16), y1 = band + 1 >= (job ? a.nbandsC : a.nbands) ? rows : (int)(((unsigned)(band + 1) * bstep) >> 16);
     (void)bandRows;
     const int ya = up ? rows - y1 : y0, yb = up ? rows - y0 : y1;
-    const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
+    const uint8_t *sp = (SRC || job == 0) ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
-    const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
-    const int srcRowBytes = (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const int ss = (SRC || job == 0) ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
+    const int srcRowBytes = SRC ? 3 * a.srcW : (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
     const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes * (a.dst16 ? 2u : 1u));
     const int bcol = min(B0 + lane, rowBytes - 1);
     GPlaneOut out;                                                 // (the dither's column: a chroma sample's own, V three columns on — vscale.c:98,101, output.c:433-434)
     out.set(a, job == 0 ? bcol : NV12 ? (bcol >> 1) + 3 * (bcol & 1) : bcol + (job == 2 ? 3 : 0));
     const int32_t *prog = job ? a.progC[up] : a.prog[up];
     const int rnd = job ? a.roundC : a.roundL;
-    auto run = [&](auto s2_c) {
+    auto run = [&](auto s2_c, auto lk_c) {
         constexpr bool S2 = decltype(s2_c)::value;
-        GStream<GPairs<P, S2>::N, S2, SD, G_RP> W;
+        constexpr int LK = decltype(lk_c)::value;
+        GStream<GPairs<P, S2>::N, S2, SD, G_RP, LK> W;
         W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
             const int seg = __builtin_amdgcn_readfirstlane(w0);
             W.winDw = (w0 - seg) >> 2;
-#pragma unroll
-            for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+            g_stream_loads(W, seg, lane, S2, a, job);
             W.img = image[wave];
         }
         auto ld = [&](unsigned off, unsigned row) { unsigned v; bS.ld1(off, row, &v); return v; };
@@ -643,7 +723,15 @@ __global__ __launch_bounds__(256) G_WAVES_ATTR void scale_yuvg_planes_kernel(Yuv
         }
         flush();
     };
-    if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
+    using LK0 = std::integral_constant<int, 0>;
+#if G_BPS == 2
+    if constexpr (SRC != 0) {
+        if (job == 0) run(std::false_type(), std::integral_constant<int, 1>());
+        else if (NV12) run(std::true_type(), std::integral_constant<int, 3>());
+        else run(std::false_type(), std::integral_constant<int, 2>());
+    } else
+#endif
+    if (NV12 && job == 1) run(std::true_type(), LK0()); else run(std::false_type(), LK0());
 }
 
 // ---- the block-cooperative form: a launch of ONE frame (or a few) --------------------------------------------------------------------
@@ -665,8 +753,8 @@ constexpr int kGBlkPad = 16;             // LDS pair slots past the band's own: 
 constexpr int kGBlkHead = 2;             // dwords in front of an output row's coefficient pairs: first row pair, last row pair
 
 // all of a wave's row pairs requested, filtered and left in hs[pair slot][lane]; the band's pairs are [pa, pb], this wave's pa + wave + 4 j
-template <int P, bool S2, int SD, int J, class Ld>
-__device__ __forceinline__ void g_blk_hpass(GStream<P, S2, SD, J> &W, Ld &&ld, int pa, int pb, int wave, int lane, unsigned stride, int (*hs)[64])
+template <int P, bool S2, int SD, int J, int LK, class Ld>
+__device__ __forceinline__ void g_blk_hpass(GStream<P, S2, SD, J, LK> &W, Ld &&ld, int pa, int pb, int wave, int lane, unsigned stride, int (*hs)[64])
 {
     // every slot is requested, the ones past the band's last pair as that pair again (a cache hit): with no load under a branch the
     // compiler counts its waits, and the first pair is filtered while the others are still on their way
@@ -674,7 +762,7 @@ __device__ __forceinline__ void g_blk_hpass(GStream<P, S2, SD, J> &W, Ld &&ld, i
     for (int j = 0; j < J; j++) {
         const unsigned off = (unsigned)(2 * min(pa + wave + 4 * j, pb)) * stride;
 #pragma unroll
-        for (int s = 0; s < SD; s++) { W.ring[j][0][s] = ld(W.ldOff[s], off); W.ring[j][1][s] = ld(W.ldOff[s], off + stride); }
+        for (int s = 0; s < GStream<P, S2, SD, J, LK>::SDL; s++) { W.ring[j][0][s] = ld(W.ldOff[s], off); W.ring[j][1][s] = ld(W.ldOff[s], off + stride); }
     }
 #pragma unroll
     for (int j = 0; j < J; j++)
@@ -806,7 +894,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_rgb_kernel(YuvGArgs a, Yuv
 }
 
 // 4:2:0 destinations: block = 64 byte columns x a band of rows of ONE plane job (luma | interleaved chroma | U | V, as scale_yuvg_planes_kernel)
-template <int P, bool NV12>
+template <int P, bool NV12, int SRC = 0>
 __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     constexpr int SD = G_BPS == 2 ? (P >= 10 ? 4 : 2) : (P >= 8 ? 2 : 1), J = kGBlkJL;
@@ -827,10 +915,10 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
     const int rows = job ? a.chrDstH : a.dstH, srcRows = job ? a.chrSrcH : a.srcH;
     const int bandRows = job ? a.bandRowsC : a.bandRows;
     const int y0 = band * bandRows, y1 = min(y0 + bandRows, rows);
-    const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
+    const uint8_t *sp = (SRC || job == 0) ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
-    const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
-    const int srcRowBytes = (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
+    const int ss = (SRC || job == 0) ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
+    const int srcRowBytes = SRC ? 3 * a.srcW : (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * G_BPS;
     const GPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes * (a.dst16 ? 2u : 1u));
     const int bcol = min(B0 + lane, rowBytes - 1);
     GPlaneOut out;
@@ -838,17 +926,17 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
     const int32_t *vt = job ? a.vtC : a.vtL;
     const int n4 = job ? a.n4C : a.n4L, sV = kGBlkHead + 4 * n4;
     const int rnd = job ? a.roundC : a.roundL;
-    auto run = [&](auto s2_c) {
+    auto run = [&](auto s2_c, auto lk_c) {
         constexpr bool S2 = decltype(s2_c)::value;
-        GStream<GPairs<P, S2>::N, S2, SD, J> W;
+        constexpr int LK = decltype(lk_c)::value;
+        GStream<GPairs<P, S2>::N, S2, SD, J, LK> W;
         W.set_conv(GConv{a.src16, a.hShift, a.hBias});
         {
             const int w0 = W.setup(job ? a.hC : a.hL, job ? a.posC : a.posL, S2 ? bcol >> 1 : bcol, S2 ? bcol & 1 : 0);
             const int pos0 = uniform_load(job ? a.posC : a.posL, S2 ? B0 >> 1 : B0);      // lane 0's window (B0 is even), by a scalar load
             const int seg = g_win_base<S2>(pos0, 0);
             W.winDw = (w0 - seg) >> 2;
-#pragma unroll
-            for (int s = 0; s < SD; s++) { W.ldDw[s] = lane + 64 * s; W.ldOff[s] = (unsigned)seg + 4u * (unsigned)(lane + 64 * s); }
+            g_stream_loads(W, seg, lane, S2, a, job);
             W.img = image[wave];
         }
         auto ld = [&](unsigned off, unsigned row) { unsigned v; bS.ld1(off, row, &v); return v; };
@@ -861,7 +949,15 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
             out.store(bD, dp, acc, B0, lane, rowBytes, (unsigned)y * (unsigned)dstride, y);       // (the output stage of scale_yuvg_planes_kernel's emit())
         }
     };
-    if (NV12 && job == 1) run(std::true_type()); else run(std::false_type());
+    using LK0 = std::integral_constant<int, 0>;
+#if G_BPS == 2
+    if constexpr (SRC != 0) {
+        if (job == 0) run(std::false_type(), std::integral_constant<int, 1>());
+        else if (NV12) run(std::true_type(), std::integral_constant<int, 3>());
+        else run(std::false_type(), std::integral_constant<int, 2>());
+    } else
+#endif
+    if (NV12 && job == 1) run(std::true_type(), LK0()); else run(std::false_type(), LK0());
 }
 
 #if G_BPS == 2
@@ -959,8 +1055,12 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P || is_dst10(p.dstFormat);
     const bool semiDst = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_P010LE;
 #if G_BPS == 2
-    const bool semiSrc = is_p01x(p.srcFormat);
-    if (!(semiSrc || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE || p.srcFormat == GMAT_PIX_FMT_YUV420P16LE) || !(rgbOut || yuvOut)) return 0;
+    // a packed RGB24 / BGR24 source into a 4:2:0 frame (the walker's own converter: GStream LK): the chroma of pixel PAIRS at full height — what libswscale
+    // gives every such context that does not up-scale (utils.c:1529-1545); the jobs synthesise the DESTINATION's chroma layout, so "semi" follows it
+    const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;
+    if (rgbSrc && (!yuvOut || !p.chrSrcHSub || p.chrSrcVSub || p.chrSrcW * 2 != p.srcW || p.chrSrcH != p.srcH || (p.srcW & 3))) return 0;
+    const bool semiSrc = rgbSrc ? semiDst : is_p01x(p.srcFormat);
+    if (!(rgbSrc || semiSrc || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE || p.srcFormat == GMAT_PIX_FMT_YUV420P16LE) || !(rgbOut || yuvOut)) return 0;
     if (const char *o16 = GMAT_KNOB("GMAT_SCALE_NO_WALKER16")) if (atoi(o16)) return 0;
     // the 16-bit image is biased by -32768 and the sums start at 32768 * 16384: every horizontal row sums to 16384 (initFilter normalises exactly)
     for (const FilterBank *fb : {&p.hLum, &p.hChr})
@@ -1141,8 +1241,15 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
         a.nblk = a.nblkL + (a.nv12 ? 1 : 2) * a.nblkC;
     }
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
+#if G_BPS == 2
+#define GMAT_GB_RGBSRC(P_) if (a.src16 == 3) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true, 1>), grid, block, 0, stream, a, fr); \
+                                               else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false, 1>), grid, block, 0, stream, a, fr); } else
+#else
+#define GMAT_GB_RGBSRC(P_)
+#endif
 #define GMAT_GB(P_) do { \
-        if (a.yuvOut) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true>), grid, block, 0, stream, a, fr); \
+        if (a.yuvOut) { GMAT_GB_RGBSRC(P_) \
+                        if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false>), grid, block, 0, stream, a, fr); } \
         else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, false>), grid, block, 0, stream, a, fr); } } while (0)
@@ -1195,7 +1302,14 @@ int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2
     }
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
-#define GMAT_G_PL(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
+#if G_BPS == 2
+#define GMAT_G_PL_RGBSRC(P_, K_) if (a.src16 == 3) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true, 1>), grid, block, 0, stream, a, fr); \
+                                                     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false, 1>), grid, block, 0, stream, a, fr); } else
+#else
+#define GMAT_G_PL_RGBSRC(P_, K_)
+#endif
+#define GMAT_G_PL(P_, K_) do { GMAT_G_PL_RGBSRC(P_, K_) \
+                               if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
                                else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
 #define GMAT_G_RGB(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)

@@ -358,6 +358,7 @@ struct YuvGArgs {
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
     int src16, hShift, hBias, dst16, dstShift, dither8;
+    Rgb2YuvConsts r2y; int rgbBgr;                            // src16 == 3: a packed RGB24 / BGR24 source (the walker's own converter, GStream LK)
     Yuv2RgbConsts y2r;
 };
 int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);

@@ -119,3 +119,43 @@ def test_walker16_knob_and_what_it_leaves_alone(dev, orc, monkeypatch):
     monkeypatch.setenv("GMAT_SCALE_NO_WALKER16", "1")
     k = _check(dev, orc, "p010le", "p010le", (384, 216, 160, 90))
     assert k not in W16 and k.startswith("scale_yuv"), k
+
+
+# ---- packed RGB sources into 4:2:0 frames: the walker's own converter in front of the same 16-bit lines (round 5) -----------------------------------
+RGBSRC_GEOMS = [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (640, 128, 420, 84), (1024, 64, 256, 16), (520, 100, 172, 40), (2048, 40, 700, 16),
+                (384, 216, 380, 212)]
+
+
+@pytest.mark.parametrize("sf", ["rgb24", "bgr24"])
+@pytest.mark.parametrize("df", ["nv12", "yuv420p", "p010le"])
+@pytest.mark.parametrize("geom", RGBSRC_GEOMS, ids=lambda g: "%dx%d-%dx%d" % g)
+def test_walker16_packed_rgb_sources(dev, orc, form, sf, df, geom):
+    """RGB24 / BGR24 -> NV12 / YUV420P (and their 10-bit twins) at the walker's down-scale ratios — the frames a network writes, scaled for an encoder.  One
+    libswscale context: rgb24ToY_c on every pixel, rgb24ToUV_half_c on horizontal pixel pairs at full height (input.c:815-866), hScale16To15_c with sh = 13,
+    the planar vertical stage.  These contexts ran the tiled kernel at 0.07 - 0.12 of the roofline (rgb24 4K -> 720p nv12: 42 us a frame)."""
+    k = _check(dev, orc, sf, df, geom)
+    assert k in W16, k
+    if form == "walk":
+        assert k == "scale_yuvg16_kernel", k
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "point"])
+def test_walker16_packed_rgb_sources_algorithms(dev, orc, form, flags):
+    for df in ("nv12", "yuv420p"):
+        _check(dev, orc, "rgb24", df, (640, 128, 420, 84), flags)
+        _check(dev, orc, "bgr24", df, (384, 216, 160, 90), flags)
+
+
+def test_walker16_packed_rgb_what_it_leaves_alone(dev, orc, form):
+    """up-scales (chroma from every pixel, not from pairs), widths that are not multiples of four, 2 : 1 (its own kernel), RGB destinations: not this form"""
+    assert _check(dev, orc, "rgb24", "nv12", (256, 144, 384, 216)) not in W16
+    assert _check(dev, orc, "rgb24", "nv12", (386, 216, 160, 90)) not in W16
+    assert _check(dev, orc, "rgb24", "nv12", (512, 64, 256, 32)) == "scale_rgb2y_kernel"
+    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 160, 90)) not in W16
+
+
+def test_walker16_packed_rgb_batches(dev, orc, monkeypatch):
+    monkeypatch.setenv("GMAT_STRIP_BLOCK", "3")
+    for df in ("nv12", "yuv420p"):
+        assert _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=5, nstreams=2, align=256) in W16
+        assert _run_batch(dev, orc, "bgr24", df, 384, 216, 256, 144, nframes=6, nstreams=1, align=64) == "scale_yuvg16_kernel"

@@ -86,7 +86,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
 
 static void run_case(const char *label, int sf, int sw, int sh, int df, int dw, int dh, int flags, int NF, int launches, int verify)
 {
-    g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0 || strncmp(label, "deep:", 5) == 0) ? 256 : 1;
+    g_align = (strncmp(label, "any:", 4) == 0 || strncmp(label, "thumb:", 6) == 0 || strncmp(label, "deep:", 5) == 0 || strncmp(label, "rgbsrc:", 7) == 0) ? 256 : 1;
     const size_t sb = frame_bytes(sf, sw, sh), db = frame_bytes(df, dw, dh);
     // rotate NSETS frame sets (two: > 256 MiB together at 4K x 32, yet a third of the source set can stay in the 256 MB Infinity Cache between
     // launches; X2BENCH_SETS=8 is bench.py's regime, every frame from HBM — the headline's band-height A/B came out differently in the two, FINDINGS R4-rows)
@@ -327,6 +327,18 @@ int main(int argc, char **argv)
         {"relayout: rgba 4K->rgb24", GMAT_PIX_FMT_RGBA, 3840, 2160, GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_SWS_BICUBIC},
         {"relayout: nv12 4K->p010", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_SWS_BICUBIC},
         {"relayout: nv12 4K->yuv444p", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_SWS_BICUBIC},
+        // packed-RGB sources away from 2 : 1 (the frames a network writes, scaled for an encoder or a display): "rgbsrc:" cases run when the filter names them
+        {"rgbsrc: rgb24 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 1080p->720p nv12 bicubic (3:2)", GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 4K->720p nv12 bicubic (3:1)", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 4K->1600x900 rgb24 bicubic (2.4:1)", GMAT_PIX_FMT_RGB24, 3840, 2160, GMAT_PIX_FMT_RGB24, 1600, 900, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 720p->1080p rgb24 bicubic (2:3 up)", GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 720p->1080p nv12 bicubic (2:3 up)", GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbsrc: bgra 1080p->720p bgra bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_BGRA, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: rgb24 640x640->1080p rgb24 bilinear (up)", GMAT_PIX_FMT_RGB24, 640, 640, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
+        {"rgbsrc: nv12 4K->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
+        {"rgbsrc: nv12 1080p->224x224 rgb24 bilinear (a classifier's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 224, 224, GMAT_SWS_BILINEAR},
         // beyond every walker: the lines form (k_scale_yuvl.hip, round 4); "thumb:" cases run when the filter names them ("thumb")
         {"thumb: nv12 4K->480x270 rgb24 bicubic (8:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 480, 270, GMAT_SWS_BICUBIC},
         {"thumb: nv12 4K->480x270 nv12 bicubic (8:1)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_NV12, 480, 270, GMAT_SWS_BICUBIC},
@@ -410,6 +422,7 @@ int main(int argc, char **argv)
         if (strstr(k.label, "relayout:") && !(*only && strstr(k.label, only))) continue;
         if (strstr(k.label, "deep:") && !(*only && strstr(k.label, only))) continue;
         if (strstr(k.label, "thumb:") && !(*only && strstr(k.label, only))) continue;      // (or when the filter names them otherwise: "up nv12")
+        if (strstr(k.label, "rgbsrc:") && !(*only && strstr(k.label, only))) continue;
         if (strstr(k.label, only)) run_case(k.label, k.sf, k.sw, k.sh, k.df, k.dw, k.dh, k.flags, NF, launches, verify);
     }
     return 0;
