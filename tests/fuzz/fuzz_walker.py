@@ -52,6 +52,10 @@ for case in range(n):
         df = rng.choice(["rgb24", "bgr24", "rgba", "bgra"] + 3 * ["nv12" if semi else "yuv420p"] + 3 * ["p010le" if semi else "yuv420p10le"])
         if rng.random() < 0.15:
             os.environ["GMAT_SCALE_NO_WALKER16"] = "1"
+    elif rng.random() < 0.12:
+        # round 5: a packed RGB source into a 4:2:0 frame (the 16-bit walker's converter; up-scales and odd widths: whatever serves them)
+        sf = rng.choice(["rgb24", "bgr24"])
+        df = rng.choice(["nv12", "yuv420p", "nv12", "yuv420p", "p010le"])
     os.environ.pop("GMAT_NO_CROSS_CASCADE", None)
     if rng.random() < 0.2:
         os.environ["GMAT_NO_CROSS_CASCADE"] = "1"
@@ -61,7 +65,7 @@ for case in range(n):
         dw = 64 * rng.randint(1, 8) + rng.choice([0, 0, 2, 62])   # on / just past / just short of the strips
     rx = rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 2.0), rng.uniform(1.0, 3.0), rng.uniform(3.0, 6.0)])
     ry = rx * rng.uniform(0.8, 1.25) if rng.random() < 0.7 else rng.choice([rng.uniform(0.55, 1.0), rng.uniform(0.15, 1.0), rng.uniform(1.0, 6.0)])
-    sw = max(16, min(maxw if len(sf) <= 7 else maxw // 2, 4 * int(dw * rx / 4)))       # (16-bit samples: half the width for the same oracle time)
+    sw = max(16, min(maxw if sf in ("nv12", "yuv420p") else maxw // 2, 4 * int(dw * rx / 4)))       # (16-bit samples, packed pixels: half the width for the same oracle time)
     sh = max(8, min(maxh, 2 * int(dh * ry / 2)))
     if (sw, sh) == (dw, dh):
         hist["(same size: the converter's semantics, tests/test_parity_yuv2rgb.py)"] += 1    # nearest-chroma yuv2rgb.c by design, not orc.sws's generic lines
