@@ -141,6 +141,9 @@ struct GmatSwsContext {
     Rgb2yTables r2ys;                    // strip-walking 2:1 packed RGB -> 8-bit 4:2:0
     Yuv3x2Tables y3x2;                   // strip-walking 3:2 down-scale, 8-bit 4:2:0 -> 4:2:0
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
+    YuvGTables rg;                // (round 5) any other ratio the band walker reaches: scale_yuvg_rgbsrc_kernel (k_scale_yuvg16.hip) ...
+    YuvGArgs rgargs;              // ... its arguments but the call's pointers and pitches ...
+    DevBuf dRG[7];                // ... and device tables: hL, hC, posL, posC, prog, qfirst, qdone
     YuvGTables yg;                // the polyphase band walker for any ratio (k_scale_yuvg.hip)
     DevBuf dG[4 + 2 * 2 * 5];     // its device tables: hL, hC, posL, posC, then per (plane class, direction) coef / first / last / round / yLo
     YuvGArgs gargs;
@@ -354,6 +357,24 @@ static int init_scaler(GmatSwsContext *c)
     if (r < 0) return r;
     if ((r = scale_pick_tiling(c->plan, c->tiling)) < 0) return r;
     if ((r = rgb2s_prepare(c->plan, c->r2s)) < 0) return r;
+    if (!src_yuv && (r = yuvg_rgbsrc_prepare(c->plan, c->rg)) < 0) return r;
+    if (c->rg.ok) {
+        YuvGArgs &g = c->rgargs;
+        std::memset(&g, 0, sizeof(g));
+        const YuvGTables &t = c->rg;
+        int k = 0;
+        auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            int rr = c->dRG[k].upload(v.data(), v.size() * 4);
+            out = (const int32_t *)c->dRG[k++].p;
+            return rr;
+        };
+        if ((r = up(t.hL, g.hL)) < 0 || (r = up(t.hC, g.hC)) < 0 || (r = up(t.posL, g.posL)) < 0 || (r = up(t.posC, g.posC)) < 0 ||
+            (r = up(t.rgb[0].prog, g.prog[0])) < 0 || (r = up(t.rgb[0].qfirst, g.qfirst[0])) < 0 || (r = up(t.rgb[0].qdone, g.qdone[0])) < 0) return r;
+        g.P = t.P; g.K = t.K; g.roundL = t.roundL; g.roundC = t.roundC; g.src16 = 3; g.hShift = 13;
+        g.srcW = c->srcW; g.srcH = c->srcH; g.chrSrcW = c->plan.chrSrcW; g.chrSrcH = c->plan.chrSrcH;
+        g.dstW = c->dstW; g.dstH = c->dstH; g.chrDstW = c->dstW; g.chrDstH = c->dstH; g.dstFormat = c->dstFormat;
+        g.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24;
+    }
     ScaleArgs &a = c->args;
     std::memset(&a, 0, sizeof(a));
     if ((r = c->dHLum.upload(c->plan.hLum, false, a.hLum)) < 0) return r;
@@ -1094,6 +1115,15 @@ static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dst
     return ra;
 }
 
+// packed RGB -> packed RGB on the band walker (scale_yuvg_rgbsrc_kernel): the context's tables + the call's pitches; the scaler's own colour model at both ends
+static YuvGArgs make_rg_args(const GmatSwsContext *c, int srcStride, int dstStride)
+{
+    YuvGArgs g = c->rgargs;
+    g.ys = srcStride; g.ds = dstStride;
+    g.r2y = c->args.r2y; g.y2r = c->args.y2r; g.xcdRemap = c->args.xcdRemap;
+    return g;
+}
+
 // the fused convert-then-scale form on the same kernel: a YUV 4:2:0 source converted lane by lane with the FIRST context's closed-form
 // constants (c->y2r: base, off*, c*) — the output stage fields (y_coeff .. u2b) stay those of the scaler's BT.601 model
 static Rgb2sArgs make_rgb2h_yuv_args(const GmatSwsContext *c, const int srcStride[], int dstStride)
@@ -1409,8 +1439,32 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
     }
     if (c->mode == MODE_SCALE && (c->srcFormat == GMAT_PIX_FMT_RGB24 || c->srcFormat == GMAT_PIX_FMT_BGR24) && !c->rgbViaPlanes &&
         !c->inner && is_packed_rgb(c->dstFormat)) {
-        // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames
-        if (ensure_scaler(c) < 0 || !c->r2s.ok) return 0;
+        // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames; at the band walker's other ratios: its RGB-source form
+        if (ensure_scaler(c) < 0 || !(c->r2s.ok || c->rg.ok)) return 0;
+        if (!c->r2s.ok) {
+            // (32 frames a launch: rgb24 1080p -> 720p 14.2 -> 6.6 us a frame, 4K -> 900p 30.1 -> 22.0, 720p -> 1080p 14.8 -> 9.3; below four frames the tiled kernel)
+            const char *rw = GMAT_KNOB("GMAT_RGBSRC_WALKER");
+            const int mode = rw ? atoi(rw) : 1;
+            if (mode == 0 || (mode == 1 && n < 4)) return 0;
+            for (int f = 0; f < n; f++) {
+                const uint8_t *sp = src_planes[4 * f];
+                uint8_t *dp = dst_planes[4 * f];
+                if (!sp || !dp) return GMAT_ERR(EINVAL);
+                if (!al4(sp, srcStride[0]) || !al4(dp, dstStride[0])) return 0;
+            }
+            const YuvGArgs ga = make_rg_args(c, srcStride[0], dstStride[0]);
+            c->lastKernel = "scale_yuvg_rgbsrc_kernel";
+            for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+                Yuv2xFrames fr;
+                const int m = std::min(kYuv2xMaxFrames, n - f0);
+                std::memset(&fr, 0, sizeof(fr));
+                for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
+                int r = launch_scale_yuvg_rgbsrc(ga, stream, &fr, m);
+                if (r < 0) return r;
+                c->lastLaunchFrames = m;
+            }
+            return 1;
+        }
         const int bpp = bytes_per_pixel(c->dstFormat);
         for (int f = 0; f < n; f++) {
             const uint8_t *sp = src_planes[4 * f];
@@ -2425,6 +2479,17 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             one.y[0] = a.src0; one.dst[0] = a.dst;
             c->lastKernel = rgb2s_kernel_name();
             r = launch_scale_rgb2s(ra, c->stream, &one, 1);
+            break;
+        }
+        if (a.srcKind == 0 && c->rg.ok && a.srcAligned && al4(dst[0], dstStride[0]) && !c->prof && GMAT_KNOB("GMAT_RGBSRC_WALKER") && atoi(GMAT_KNOB("GMAT_RGBSRC_WALKER")) == 2) {
+            // any other ratio the band walker reaches (round 5): one column a lane, the three lines from one load of the pixels — in launches of four
+            // frames or more (sws_scale_frames_batched_impl); ONE frame stays on the tiled kernel, which is faster alone (1080p -> 720p 13.0 against
+            // 17.2 us, 4K -> 900p 27 against 48: profiles/r05s_rgbrgb_walker.txt).  GMAT_RGBSRC_WALKER=2: here too (tests, A/B)
+            Yuv2xFrames one;
+            std::memset(&one, 0, sizeof(one));
+            one.y[0] = a.src0; one.dst[0] = a.dst;
+            c->lastKernel = "scale_yuvg_rgbsrc_kernel";
+            r = launch_scale_yuvg_rgbsrc(make_rg_args(c, a.ss0, a.ds), c->stream, &one, 1);
             break;
         }
         c->lastKernel = scale_kernel_name(a, c->tiling);

@@ -961,6 +961,232 @@ __global__ __launch_bounds__(256) void scale_yuvg_blk_planes_kernel(YuvGArgs a, 
 }
 
 #if G_BPS == 2
+// ---- packed RGB -> packed RGB at any ratio the walker reaches (round 5) -----------------------------------------------------------------------------------
+// libswscale's generic path for an RGB source into an RGB frame (the BASELINE's literal second stage, rgb24 -> rgb24, away from its exact 2 : 1):
+// rgb24ToY_c per pixel, rgb24ToUV_c per pixel or rgb24ToUV_half_c per pixel pair (chrSrcHSubSample = 1 from 2 : 1 on), both at FULL height; hScale16To15_c
+// (sh = 13) of the three lines; yuv2rgb_full_X_c over them — full-chroma output is forced for a non-subsampled source (utils.c:1439-1447) and the vertical
+// chroma filter is the luma one (utils.c:1838-1873) — and yuv2rgb_write_full (output.c:1886-1935, 2037-2082).  A lane owns one output column of a band;
+// its U and V lines come from ONE stream: the raw pixels are loaded once and the converter fills two row images.
+// HALF: chroma from pixel pairs (eight pixels = six raw dwords -> two image dwords a plane) instead of from every pixel (four pixels = three raw dwords)
+template <int P, int SD, int R, bool HALF>
+struct GStreamUV {
+    static constexpr int NW = (P + 1) & ~1, IMG = 64 * SD, SDL = HALF ? 3 * SD : (3 * SD) / 2;
+    int cf[P];
+    int winDw, ldDw0;
+    unsigned ldOff[SDL];
+    unsigned ring[R][2][SDL];
+    unsigned win[2][2][NW];              // [U | V][row of the pair][window dword]
+    unsigned *img;                       // [U | V][row][IMG]
+    unsigned reqOff, rowStep;
+    int u01, u2, v01, v2;
+    __device__ __forceinline__ int setup(const int32_t *hTab, const int32_t *posTab, int col)
+    {
+#pragma unroll
+        for (int t = 0; t < P; t++) cf[t] = hTab[(size_t)col * P + t];
+        return g_win_base<false>(posTab[col], 0);
+    }
+    __device__ __forceinline__ void start(int pair, int stride) { rowStep = (unsigned)stride; reqOff = (unsigned)(2 * pair) * (unsigned)stride; }
+    template <class Ld> __device__ __forceinline__ void request(Ld &&ld, unsigned (&dst)[2][SDL])
+    {
+#pragma unroll
+        for (int s = 0; s < SDL; s++) { dst[0][s] = ld(ldOff[s], reqOff); dst[1][s] = ld(ldOff[s], reqOff + rowStep); }
+        reqOff += 2u * rowStep;
+    }
+    __device__ __forceinline__ void gather(const unsigned (&src)[2][SDL])
+    {
+        typedef GStream<P, false, SD, R, 1> G1;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int g = 0; g < SD / 2; g++) {
+                int cu[4], cv[4];
+                if constexpr (HALF) {
+                    constexpr int KC = (256 << 15) + (1 << 9);          // rgb24ToUV_half_c on a pair's sums: >> 10
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        int fs[4], th[4];
+                        G1::rgb4(&src[r][6 * g + 3 * h], fs, th);
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const int f = fs[2 * q] + fs[2 * q + 1], t = th[2 * q] + th[2 * q + 1];
+                            cu[2 * h + q] = g_dot2(f, u01, m24(t, u2) + KC) >> 10;
+                            cv[2 * h + q] = g_dot2(f, v01, m24(t, v2) + KC) >> 10;
+                        }
+                    }
+                } else {
+                    constexpr int KC = (256 << 14) + (1 << 8);          // rgb24ToUV_c: >> 9
+                    int fs[4], th[4];
+                    G1::rgb4(&src[r][3 * g], fs, th);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { cu[i] = g_dot2(fs[i], u01, m24(th[i], u2) + KC) >> 9; cv[i] = g_dot2(fs[i], v01, m24(th[i], v2) + KC) >> 9; }
+                }
+                *reinterpret_cast<uint2 *>(img + r * IMG + ldDw0 + 2 * g) = make_uint2((unsigned)cu[0] | ((unsigned)cu[1] << 16), (unsigned)cu[2] | ((unsigned)cu[3] << 16));
+                *reinterpret_cast<uint2 *>(img + (2 + r) * IMG + ldDw0 + 2 * g) = make_uint2((unsigned)cv[0] | ((unsigned)cv[1] << 16), (unsigned)cv[2] | ((unsigned)cv[3] << 16));
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < NW; i += 2) {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(img + (2 * c + r) * IMG + winDw + i);
+                    win[c][r][i] = t.x; win[c][r][i + 1] = t.y;
+                }
+    }
+    template <class Ld> __device__ __forceinline__ void prime(Ld &&ld)
+    {
+        unsigned first[2][SDL];
+        request(ld, first);
+#pragma unroll
+        for (int d = 1; d <= R; d++) request(ld, ring[d % R]);
+        gather(first);
+    }
+    // the gathered pair's horizontally filtered U and V samples of this lane's column, packed by rows: min(sum >> 13, 32767) (hScale16To15_c)
+    __device__ __forceinline__ void hpairs(int &hu, int &hv) const
+    {
+        int h[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int sum = 0;
+#pragma unroll
+                for (int t = 0; t < P; t++) sum = g_dot2((int)win[c][r][t], cf[t], sum);
+                h[c][r] = sum >> 13;
+            }
+        hu = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0][0], h[0][1]));
+        hv = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[1][0], h[1][1]));
+    }
+    template <int S, class Ld> __device__ __forceinline__ void advance(Ld &&ld) { gather(ring[S]); request(ld, ring[S]); }
+};
+
+// block = 4 waves = 4 adjacent strips of 64 output columns of one band; grid.y = frame.  Bands walk downward.  a.prog[0] is the program of ONE plane (a quad =
+// four source rows = two row pairs), shared by the three lines
+template <int P, int K, bool HALF>
+__global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_kernel(YuvGArgs a, Yuv2xFrames fr)
+{
+    constexpr int PC = HALF ? P : P, SD = P >= 10 ? 4 : 2, QS = kGHead + 3 * K;
+    __shared__ __attribute__((aligned(16))) unsigned imageY[4][2 * 64 * SD];
+    __shared__ __attribute__((aligned(16))) unsigned imageC[4][4 * 64 * SD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) { const int chunk = (a.nblk + 7) >> 3; lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3); }
+    if (lin >= a.nblk) return;
+    const int band = __builtin_amdgcn_readfirstlane(lin / a.nsg);
+    const int X0 = ((lin - band * a.nsg) * 4 + wave) * 64;
+    if (X0 >= a.dstW) return;
+    const int ya = (int)(((unsigned)band * (unsigned)a.bandStep) >> 16), yb = band + 1 >= a.nbands ? a.dstH : (int)(((unsigned)(band + 1) * (unsigned)a.bandStep) >> 16);
+    const int f = blockIdx.y;
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + 3u * (unsigned)a.srcW);
+    const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+    const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
+    const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
+    const int x = X0 + lane, xc = min(x, a.dstW - 1);
+
+    GStream<P, false, SD, 2, 1> L;
+    GStreamUV<PC, SD, 2, HALF> C;
+    L.set_conv(GConv{18, 13, 0});
+    {
+        const int w0 = L.setup(a.hL, a.posL, xc, 0);
+        const int seg = __builtin_amdgcn_readfirstlane(w0);
+        L.winDw = (w0 - seg) >> 2;
+        g_stream_loads(L, seg, lane, false, a, 0);
+        L.img = imageY[wave];
+    }
+    {
+        const int w0 = C.setup(a.hC, a.posC, HALF ? min(xc, a.dstW - 1) : xc);
+        const int seg = __builtin_amdgcn_readfirstlane(w0);
+        C.winDw = (w0 - seg) >> 2;
+        const int e0 = seg >> 1;                                      // first chroma sample of the segment
+        C.ldDw0 = lane * SD;
+#pragma unroll
+        for (int s2 = 0; s2 < GStreamUV<PC, SD, 2, HALF>::SDL; s2++)
+            C.ldOff[s2] = (unsigned)((HALF ? 6 : 3) * e0) + 4u * (unsigned)(lane * GStreamUV<PC, SD, 2, HALF>::SDL + s2);
+        const Rgb2YuvConsts &k = a.r2y;
+        auto pk = [](int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); };
+        C.u01 = a.rgbBgr ? pk(k.bu, k.gu) : pk(k.ru, k.gu); C.u2 = a.rgbBgr ? k.ru : k.bu;
+        C.v01 = a.rgbBgr ? pk(k.bv, k.gv) : pk(k.rv, k.gv); C.v2 = a.rgbBgr ? k.rv : k.bv;
+        C.img = imageC[wave];
+    }
+    auto ld = [&](unsigned off, unsigned row) { unsigned v; bS.ld1(off, row, &v); return v; };
+    const int32_t *prog = a.prog[0];
+    const int q0 = uniform_load(a.qfirst[0], ya), q1 = uniform_load(a.qdone[0], yb - 1);
+    int y = uniform_load(prog, q0 * QS);
+    L.start(2 * q0, a.srcH, a.ys, 0);
+    C.start(2 * q0, a.ys);
+    L.prime(ld);
+    C.prime(ld);
+    int accY[K], accU[K], accV[K];
+    // yuv2rgb_full_X_c: Y from 1 << 9, U and V from (1 << 9) - (128 << 19); >> 10
+#pragma unroll
+    for (int i = 0; i < K; i++) { accY[i] = a.roundL; accU[i] = accV[i] = a.roundC; }
+    const unsigned dsel = (unsigned)((lane & 3) == 0 ? 0x04020100u : (lane & 3) == 1 ? 0x05040201u : 0x06050402u);
+#define GMAT_G_QUAD(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true)
+    auto emit = [&](int yw) {
+        const int Y = accY[0] >> 10, U = accU[0] >> 10, V = accV[0] >> 10;
+        // yuv2rgb_write_full (output.c:1886-1935): every factor below 2^23 (the 24-bit multiplier gives the C expression's low 32 bits), av_clip_uintp2(x, 30)
+        const int yy = m24(Y - a.y2r.y_offset, a.y2r.y_coeff) + (1 << 21);
+        const int R = yy + m24(V, a.y2r.v2r), G = yy + m24(V, a.y2r.v2g) + m24(U, a.y2r.u2g), B = yy + m24(U, a.y2r.u2b);
+        const unsigned r8 = (unsigned)min(max(R, 0), 0x3FFFFFFF) >> 22, g8 = (unsigned)min(max(G, 0), 0x3FFFFFFF) >> 22, b8 = (unsigned)min(max(B, 0), 0x3FFFFFFF) >> 22;
+        const unsigned px = (bgr ? b8 : r8) | (g8 << 8) | ((bgr ? r8 : b8) << 16) | 0xFF000000u;
+        const unsigned drow = (unsigned)yw * (unsigned)a.ds;
+        if (bpp == 4) {
+            if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
+        } else {
+            const unsigned nxt = (unsigned)GMAT_G_QUAD(px, 0xF9);
+            const unsigned o = __builtin_amdgcn_perm(nxt, px, dsel);
+            const int nb = 3 * min(64, a.dstW - X0);
+            const int ob = 12 * (lane >> 2) + 4 * (lane & 3);
+            if ((lane & 3) != 3) {
+                if (ob + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + (unsigned)ob, drow);
+                else if (ob < nb) {
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + (unsigned)ob;
+                    for (int i = 0; i < nb - ob; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+        }
+    };
+#undef GMAT_G_QUAD
+    int pend = 0;
+    auto flush = [&]() {
+        for (int k = 0; k < pend; k++, y++) {
+            if (y >= ya && y < yb) emit(y);
+#pragma unroll
+            for (int i = 0; i + 1 < K; i++) { accY[i] = accY[i + 1]; accU[i] = accU[i + 1]; accV[i] = accV[i + 1]; }
+            accY[K - 1] = a.roundL; accU[K - 1] = accV[K - 1] = a.roundC;
+        }
+    };
+    auto quad = [&](int q) {
+        const int32_t *pq = prog + (size_t)q * QS;
+        int c0[K], c1[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) { c0[i] = uniform_load(pq, kGHead + i); c1[i] = uniform_load(pq, kGHead + K + i); }
+        const int ne = uniform_load(pq, 1);
+        int hu, hv;
+        const int hy0 = L.hpair();
+        L.template advance<1>(ld);
+        C.hpairs(hu, hv);
+        C.template advance<1>(ld);
+#pragma unroll
+        for (int i = 0; i < K; i++) { accY[i] = g_dot2(hy0, c0[i], accY[i]); accU[i] = g_dot2(hu, c0[i], accU[i]); accV[i] = g_dot2(hv, c0[i], accV[i]); }
+        const int hy1 = L.hpair();
+        L.template advance<0>(ld);
+        C.hpairs(hu, hv);
+        C.template advance<0>(ld);
+#pragma unroll
+        for (int i = 0; i < K; i++) { accY[i] = g_dot2(hy1, c1[i], accY[i]); accU[i] = g_dot2(hu, c1[i], accU[i]); accV[i] = g_dot2(hv, c1[i], accV[i]); }
+        pend = ne;
+        flush();
+    };
+    for (int q = q0; q <= q1; q++) quad(q);
+    flush();
+}
+#endif
+
+#if G_BPS == 2
 } // namespace g16
 using namespace g16;
 #endif
@@ -1331,5 +1557,99 @@ int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+#if G_BPS == 2
+// ---- packed RGB -> packed RGB (scale_yuvg_rgbsrc_kernel) ---------------------------------------------------------------------------------------------------
+// p: the RGB scaler's plan (gsws.cpp init_scaler: full-chroma output, the chroma lines at full height and full or half width)
+int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
+{
+    t = YuvGTables();
+    const char *off = GMAT_KNOB("GMAT_SCALE_NO_GENERIC_WALKER");
+    if (off && atoi(off)) return 0;
+    if (const char *o16 = GMAT_KNOB("GMAT_SCALE_NO_WALKER16")) if (atoi(o16)) return 0;
+    if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
+    if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
+    if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8 || (p.srcW & 3)) return 0;
+    if (p.srcW == 2 * p.dstW && p.srcH == 2 * p.dstH) return 0;                              // (exactly 2 : 1 has its own strip walker, k_scale_rgb2s.hip)
+    // full-chroma output (forced for this source), chroma lines of the source's height and of its width or half of it
+    if (p.chrDstW != p.dstW || p.chrDstH != p.dstH || p.chrSrcVSub || p.chrSrcH != p.srcH) return 0;
+    if (!(p.chrSrcHSub == 0 ? p.chrSrcW == p.srcW : (p.chrSrcW * 2 == p.srcW && !(p.srcW & 7)))) return 0;
+    // yuv2rgb_full_X_c proper (the one- and two-tap special forms of vscale.c:135-167 stay on the tiled kernel); the chroma's vertical filter is the luma's
+    if (p.vLum.taps < 3 || p.vChr.taps != p.vLum.taps || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return 0;
+    if (p.hLum.count != p.dstW || p.hChr.count != p.dstW) return 0;
+    auto lead = [](const FilterBank &fb, int x) { return fb.pos[x] & 3; };
+    auto pairs_needed = [&](const FilterBank &fb) { int m = 0; for (int x = 0; x < fb.count; x++) m = std::max(m, lead(fb, x) + fb.taps); return (m + 1) / 2; };
+    const int needP = std::max(pairs_needed(p.hLum), pairs_needed(p.hChr));
+    int P = 0;
+    for (int c : kGP) if (c >= needP) { P = c; break; }
+    if (!P) return 0;
+    auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out) {
+        out.assign((size_t)fb.count * P, 0);
+        for (int x = 0; x < fb.count; x++) {
+            if (fb.pos[x] < 0 || fb.pos[x] + fb.taps > srcLen) return false;
+            const int ld = lead(fb, x);
+            for (int k = 0; k < P; k++) {
+                const int t0 = 2 * k - ld, t1 = t0 + 1;
+                const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)x * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)x * fb.taps + t1] : 0;
+                out[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+            }
+        }
+        return true;
+    };
+    if (!hpack(p.hLum, p.srcW, t.hL) || !hpack(p.hChr, p.chrSrcW, t.hC)) return 0;
+    t.posL = p.hLum.pos; t.posC = p.hChr.pos;
+    if (!build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) return 0;
+    int K = 0;
+    for (int c : kGK) if (c >= t.rgb[0].K) { K = c; break; }
+    if (!K && t.rgb[0].K <= 12 && P <= 8) K = 12;          // (ratios near 1 and up-scales: ten or eleven rows open over a quad of four source rows)
+    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg rgbsrc: %dx%d -> %dx%d taps h %d/%d v %d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
+                                          p.hLum.taps, p.hChr.taps, p.vLum.taps, P, t.rgb[0].K, K);
+    if (!K) return 0;
+    fill_qprog(t.rgb[0], K);
+    // a wave's 64 columns inside the row image its lanes fill (16-bit samples, windows re-based to 8 bytes)
+    const int SD = P >= 10 ? 4 : 2, NW = (P + 1) & ~1;
+    for (const FilterBank *fb : {&p.hLum, &p.hChr})
+        for (int c0 = 0; c0 < fb->count; c0 += 64) {
+            const int c1 = std::min(c0 + 64, fb->count) - 1;
+            if (g_win_base<false>(fb->pos[c1], 0) + 4 * NW - g_win_base<false>(fb->pos[c0], 0) > 256 * SD) return 0;
+        }
+    t.roundL = 1 << 9; t.roundC = (1 << 9) - (128 << 19);          // yuv2rgb_full_X_c (output.c:2037-2082)
+    t.P = P; t.K = K; t.yuvOut = 0;
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale_yuvg_rgbsrc(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    YuvGArgs a = a0;
+    const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
+    const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;
+    const int nstrips = (a.dstW + 63) / 64;
+    a.nsg = (nstrips + 3) / 4;
+    const long wr = (long)a.dstH * nstrips * nframes;
+    const int rows = rowsEnv > 0 ? rowsEnv : (int)std::min(48L, std::max(4L, (wr + 6143) / 6144));     // (the band walker's rule for an RGB destination)
+    const bool balanced = rowsEnv <= 0 && rows == 48 && a.dstH >= 96 && a.dstH < 32768;
+    a.bandRows = rows;
+    a.nbands = balanced ? (a.dstH + rows / 2) / rows : (a.dstH + rows - 1) / rows;
+    a.bandStep = balanced ? (int)(((unsigned)a.dstH << 16) / (unsigned)a.nbands) : rows << 16;
+    a.nblkL = a.nbands * a.nsg;
+    a.nblk = a.nblkL;
+    const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
+    const Yuv2xFrames &fr = *frames;
+    const bool half = a.chrSrcW != a.srcW;
+#define GMAT_RS(P_, K_) do { if (half) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
+                             else      hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
+#define GMAT_RS_P(P_) do { switch (a.K) { case 4: GMAT_RS(P_, 4); break; case 6: GMAT_RS(P_, 6); break; case 7: GMAT_RS(P_, 7); break; default: GMAT_RS(P_, 9); } } while (0)
+#define GMAT_RS_P12(P_) do { if (a.K == 12) GMAT_RS(P_, 12); else GMAT_RS_P(P_); } while (0)
+    switch (a.P) { case 4: GMAT_RS_P12(4); break; case 5: GMAT_RS_P12(5); break; case 6: GMAT_RS_P12(6); break; case 7: GMAT_RS_P12(7); break; case 8: GMAT_RS_P12(8); break;
+                   case 10: GMAT_RS_P(10); break; default: GMAT_RS_P(13); }
+#undef GMAT_RS_P12
+#undef GMAT_RS_P
+#undef GMAT_RS
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#endif
 
 } // namespace gmat

@@ -368,6 +368,9 @@ bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launc
 int  yuvg_prepare16(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
 int  launch_scale_yuvg16(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool yuvg_block_form16(const YuvGArgs &a, int nframes);
+// packed RGB24 / BGR24 -> packed RGB at the walker's ratios (scale_yuvg_rgbsrc_kernel in k_scale_yuvg16.hip): p = the RGB scaler's plan
+int  yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t);
+int  launch_scale_yuvg_rgbsrc(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // ---- the quad-lane polyphase walker (k_scale_yuvu.hip, round 4): a lane owns FOUR adjacent outputs of a row, the vertical filter is a
 // GATHER over a short register ring of horizontally filtered row pairs (coefficients by output row, relative to the newest pair) — no

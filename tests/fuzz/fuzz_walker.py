@@ -28,7 +28,7 @@ maxw, maxh = (2600, 400) if hip else (900, 160)
 ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline", "bicublin", "x"]
 
 for case in range(n):
-    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER", "GMAT_SCALE_NO_WALKER16"):
+    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER", "GMAT_SCALE_NO_WALKER16", "GMAT_RGBSRC_WALKER"):
         os.environ.pop(k, None)
     q = rng.random()
     if q < 0.15:   os.environ["GMAT_QUAD_WALKER"] = "0"          # up-scales on the band walker / the tiled kernel
@@ -55,7 +55,9 @@ for case in range(n):
     elif rng.random() < 0.12:
         # round 5: a packed RGB source into a 4:2:0 frame (the 16-bit walker's converter; up-scales and odd widths: whatever serves them)
         sf = rng.choice(["rgb24", "bgr24"])
-        df = rng.choice(["nv12", "yuv420p", "nv12", "yuv420p", "p010le"])
+        df = rng.choice(["nv12", "yuv420p", "nv12", "yuv420p", "p010le", "rgb24", "bgr24", "rgba", "bgra"])     # (RGB -> RGB: scale_yuvg_rgbsrc_kernel from four frames a launch on)
+        if rng.random() < 0.5:
+            os.environ["GMAT_RGBSRC_WALKER"] = "2"                # ... or at every launch size
     os.environ.pop("GMAT_NO_CROSS_CASCADE", None)
     if rng.random() < 0.2:
         os.environ["GMAT_NO_CROSS_CASCADE"] = "1"
