@@ -627,6 +627,13 @@ def c_harness(dry):
         except Exception as e:                               # noqa: BLE001
             rows = [{"error": repr(e)}]
         res["one frame per call, %d caller streams" % n] = rows
+    # round 5: 16-bit samples and packed-RGB sources away from 2 : 1 (the band walker of k_scale_yuvg16.hip; the lines form / tiled kernels before)
+    for flt, key in (("deep:", "10- / 16-bit sources and 10-bit destinations, 32 frames per launch"), ("rgbsrc: rgb24", "packed-RGB sources away from 2:1, 32 frames per launch")):
+        try:
+            r = subprocess.run([exe, "32", "10", flt], env=dict(env, X2BENCH_SETS="4"), capture_output=True, text=True, timeout=300)
+            res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        except Exception as e:                               # noqa: BLE001
+            res[key] = [{"error": repr(e)}]
     try:
         r = subprocess.run([exe, "1", "50", "op: "], env=env, capture_output=True, text=True, timeout=300)
         res["filters, one 4K frame per launch"] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "op: " in l]

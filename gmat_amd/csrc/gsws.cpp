@@ -305,9 +305,12 @@ static int init_yuv_scaler(GmatSwsContext *c)
         g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
     }
     if (!a.src16 && !c->rgbViaPlanes && (r = yuvu_prepare(c->planYuv, c->ytiling, c->yu)) < 0) return r;
+    if (a.src16 >= 10 && !c->rgbViaPlanes && (r = yuvu_prepare16(c->planYuv, c->ytiling, c->yu)) < 0) return r;      // (round 5: k_scale_yuvu16.hip)
     if (c->yu.ok) {
         YuvUArgs &u = c->uargs;
         std::memset(&u, 0, sizeof(u));
+        u.src16 = a.src16 >= 10 ? a.src16 : 0; u.hShift = u.src16 ? a.hShift : 7; u.hBias = u.src16 ? a.hBias : 0;
+        u.dst16 = a.dst16; u.dstShift = a.dstShift;
         const YuvUTables &t = c->yu;
         int k = 0;
         auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
@@ -642,9 +645,12 @@ static bool yuvu_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n
     if (!c->yu.ok || c->rangeConv || ya.prof) return false;
     const char *qw = GMAT_KNOB("GMAT_QUAD_WALKER");
     const int mode = qw ? atoi(qw) : 1;
-    if (mode == 0 || (mode == 1 && !(ya.dstH > ya.srcH || n > 3))) return false;
+    // (16-bit samples, round 5: up-scales only — its six-pair instance loses the short-filter down-scales to the band walker: yuv420p10le 1080p -> 720p 4.96
+    // against 3.2 us a frame, P010 -> rgb24 6.4 against 2.9: profiles/r05t_quad16.txt)
+    if (mode == 0 || (mode == 1 && !(ya.dstH > ya.srcH || (n > 3 && !c->uargs.src16)))) return false;
     uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
-    if (!ya.nv12) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
+    const bool semiU = c->uargs.src16 ? (c->uargs.src16 == 10 || c->uargs.src16 == 16) : ya.nv12 != 0;
+    if (!semiU) { all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; if (ya.us != ya.vs) return false; }
     if (c->yu.yuvOut) {
         all |= (uintptr_t)ya.dstU | (uintptr_t)ya.dsU;
         if (!ya.dstNv12) all |= (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
@@ -655,7 +661,9 @@ static bool yuvu_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya, int n
 static YuvUArgs make_yuvu_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     YuvUArgs g = c->uargs;
-    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs; g.nv12 = ya.nv12;
+    g.ys = ya.ys; g.us = ya.us; g.vs = ya.vs;
+    g.nv12 = g.src16 ? (g.src16 == 10 || g.src16 == 16) : ya.nv12;        // interleaved chroma (P010LE / P016LE: YuvScaleArgs' kinds 10 and 16)
+    g.dither8 = ya.dither8;
     g.srcW = ya.srcW; g.srcH = ya.srcH; g.chrSrcW = ya.chrSrcW; g.chrSrcH = ya.chrSrcH;
     g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
     g.ds = ya.ds; g.dsU = ya.dsU; g.dsV = ya.dsV; g.dstFormat = ya.dstFormat;
@@ -1067,8 +1075,9 @@ static const PlaneKernel kPlaneKernels[] = {
          return n == 1 ? launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st)      // (one frame: the pointers of the argument block)
                        : launch_scale_yuv2x(xa, c->ytiling.rowsL, c->ytiling.rowsC, c->y2x.ok, st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvu_eligible(c, ya, n); },                                    // up-scales of any factor: the quad-lane walker
-     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale_yuvu_kernel"; },
-     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return c->uargs.src16 ? "scale_yuvu16_kernel" : "scale_yuvu_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
+         return c->uargs.src16 ? launch_scale_yuvu16(make_yuvu_args(c, ya), st, &fr, n) : launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
          if (c->gargs.src16) return yuvg_block_form16(make_yuvg_args(c, ya), n) ? "scale_yuvg16_blk_kernel" : "scale_yuvg16_kernel";      // (16-bit samples: k_scale_yuvg16.hip)

@@ -28,7 +28,23 @@
 #include "kernels.h"
 #include "px_math.h"
 
+// U_BPS: bytes per SOURCE sample.  This file compiles twice (round 5, as k_scale_yuvg.hip does): as it is for NV12 / YUV420P, and from k_scale_yuvu16.hip with
+// U_BPS = 2 for P010LE / P016LE / YUV420P10LE / YUV420P16LE (hScale16To15_c in front of the same rings and output stages; namespace gmat::u16, entry points *16).
+// With 16-bit samples the host re-bases every window to an 8-byte boundary of the row: a plane's coefficient pair is an aligned dword as loaded (no
+// v_perm_b32), windows are read with ds_read_b64, the interleaved chroma runs on one pair fewer (k_scale_yuvg.hip).
+#ifndef U_BPS
+#define U_BPS 1
+#endif
+#if U_BPS == 2
+#define U_NAME(n) n##16
+#else
+#define U_NAME(n) n
+#endif
+
 namespace gmat {
+#if U_BPS == 2
+namespace u16 {
+#endif
 
 // ---- a plane as a raw buffer resource (k_scale_yuvg.hip's GPlane with 12- and 16-byte stores): reads past the plane's last byte return
 //      0, the stores are issued from inline assembly so that the compiler's wait counts see loads only (FINDINGS.md R3-walker)
@@ -40,10 +56,18 @@ struct UPlane {
     v4u words;
     __device__ __forceinline__ UPlane(const uint8_t *p, unsigned bytes) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, bytes, 0x00020000))
     {
+        // (readfirstlane: an "s" operand of the inline-assembly stores must not be a value the compiler chose to compute on the vector ALU: k_scale_yuvg.hip GPlane)
         const unsigned long long a = (unsigned long long)p;
-        words = (v4u){(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+        words = (v4u){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
     }
     __device__ __forceinline__ unsigned ld1(unsigned lane, unsigned row) const { return __builtin_amdgcn_raw_buffer_load_b32(r, lane, row, 0); }
+    __device__ __forceinline__ void st2(uint2 d, unsigned lane, unsigned row) const
+    {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u v = {d.x, d.y};
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(lane), "s"(words), "s"(row) : "memory");
+    }
     // s_nop 4: a scalar operand written by a VALU instruction may be read by a memory instruction five wait states later at the earliest
     // (tests/test_isa_guard.py); s_nop 0 behind the wide stores: their data registers must not be overwritten by the next VALU instruction
     __device__ __forceinline__ void st1(unsigned d, unsigned lane, unsigned row) const
@@ -66,6 +90,7 @@ struct UPlane {
     __host__ __device__ UPlane(const uint8_t *q, unsigned bytes) : p(const_cast<uint8_t *>(q)), n(bytes) {}
     __host__ __device__ unsigned ld1(unsigned lane, unsigned row) const { unsigned v = 0; if ((size_t)row + lane + 4 <= n) std::memcpy(&v, p + (size_t)row + lane, 4); return v; }
     __host__ __device__ void st1(unsigned d, unsigned lane, unsigned row) const { if ((size_t)row + lane + 4 <= n) std::memcpy(p + (size_t)row + lane, &d, 4); }
+    __host__ __device__ void st2(uint2 d, unsigned lane, unsigned row) const { if ((size_t)row + lane + 8 <= n) std::memcpy(p + (size_t)row + lane, &d, 8); }
     __host__ __device__ void st3(uint3 d, unsigned lane, unsigned row) const { if ((size_t)row + lane + 12 <= n) std::memcpy(p + (size_t)row + lane, &d, 12); }
     __host__ __device__ void st4(uint4 d, unsigned lane, unsigned row) const { if ((size_t)row + lane + 16 <= n) std::memcpy(p + (size_t)row + lane, &d, 16); }
 #endif
@@ -96,9 +121,19 @@ constexpr int kUStrip = 256;             // output bytes (4:2:0 destination) / p
 // o = pos & 3; S2 = both components of NV12's interleaved row: (o + 4t, o + 4t + 2) for U and one byte further for V, o = 2 pos & 3),
 // the wave's share of the row loads, a ring of RR requested row pairs with static slot names, the gathered windows of the pair consumed
 // next.  NOUT horizontally filtered samples leave per pair: NC (stride 1) or 2 NC (S2: U, V of column 0, U, V of column 1).
+// first byte of the window of output column `pos`, and of the aligned dwords read for it (16-bit samples: 8-byte boundaries)
+template <bool S2> __device__ __host__ __forceinline__ int u_win_base(int pos) { return U_BPS == 2 ? ((S2 ? 4 * pos : 2 * pos) & ~7) : ((S2 ? 2 * pos : pos) & ~3); }
+typedef unsigned short u_us2 __attribute__((ext_vector_type(2)));
 template <int P, bool S2, int NC, int SD, int RR>
 struct UStream {
+#if U_BPS == 2
+    static constexpr int NW = S2 ? 2 * P : (P + 1) & ~1;
+    unsigned cvShr, cvFlip; int cvSh, cvBias;     // what the row image holds (k_scale_yuvg.hip g_conv), hScale16To15_c's shift, the sums' start
+    __device__ __forceinline__ void set_conv(int kind, int sh, int bias) { cvShr = kind == 10 ? 6u : 0u; cvFlip = (kind == 10 || kind == 18) ? 0u : 0x80008000u; cvSh = sh; cvBias = bias; }
+#else
     static constexpr int NW = S2 ? P + 1 : ((P - 1) >> 1) + 2;
+    __device__ __forceinline__ void set_conv(int, int, int) {}
+#endif
     static constexpr int NOUT = S2 ? 2 * NC : NC;
     static constexpr int IMG = 64 * SD + kUPad;
     int cf[NC][P];
@@ -115,12 +150,16 @@ struct UStream {
     __device__ __forceinline__ int setup_col(int c, const int32_t *hTab, const int32_t *posTab, int col)
     {
         const int pos = posTab[col];
+#if U_BPS == 2
+        sel[c] = 0u;
+#else
         const int b0 = S2 ? 2 * pos : pos;
         const unsigned o = (unsigned)b0 & 3u;
         sel[c] = S2 ? (0x0C000C00u | o | ((o + 2) << 16)) : (0x0C000C00u | o | ((o + 1) << 16));
+#endif
 #pragma unroll
         for (int t = 0; t < P; t++) cf[c][t] = hTab[(size_t)col * P + t];
-        return b0 & ~3;
+        return u_win_base<S2>(pos);
     }
     // the walk starts at row pair `pair` (it may lie in front of the plane: an RGB destination's luma stream runs behind its chroma stream)
     __device__ __forceinline__ void start(int pair, int stride, int rows)
@@ -145,14 +184,29 @@ struct UStream {
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
+#if U_BPS == 2
+            for (int s = 0; s < SD; s++) {
+                const u_us2 h = __builtin_bit_cast(u_us2, src[r][s]) >> (u_us2){(unsigned short)cvShr, (unsigned short)cvShr};
+                img[r * IMG + ldDw[s]] = __builtin_bit_cast(unsigned, h) ^ cvFlip;
+            }
+#else
             for (int s = 0; s < SD; s++) img[r * IMG + ldDw[s]] = src[r][s];
+#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int r = 0; r < 2; r++)
+#if U_BPS == 2
+#pragma unroll
+                for (int i = 0; i < NW; i += 2) {            // (window bases are 8-byte aligned, IMG is even: ds_read_b64)
+                    const uint2 t = *reinterpret_cast<const uint2 *>(img + r * IMG + winDw[c] + i);
+                    win[c][r][i] = t.x; win[c][r][i + 1] = t.y;
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < NW; i++) win[c][r][i] = img[r * IMG + winDw[c] + i];
+#endif
     }
     // pair 0 gathered, pairs 1 .. RR requested: pair k + 1 in ring slot (k + 1) % RR
     template <class Ld> __device__ __forceinline__ void prime(Ld &&ld)
@@ -171,8 +225,18 @@ struct UStream {
             if constexpr (S2) {
 #pragma unroll
                 for (int comp = 0; comp < 2; comp++) {
-                    const unsigned sc = sel[c] + (comp ? 0x00010001u : 0u);
                     int h[2];
+#if U_BPS == 2
+                    const unsigned sc = comp ? 0x07060302u : 0x05040100u;        // the component's half of the (U, V) dwords 2t and 2t + 1
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        int s = cvBias;
+#pragma unroll
+                        for (int t = 0; t < P; t++) s = u_dot2((int)__builtin_amdgcn_perm(win[c][r][2 * t + 1], win[c][r][2 * t], sc), cf[c][t], s);
+                        h[r] = s >> cvSh;
+                    }
+#else
+                    const unsigned sc = sel[c] + (comp ? 0x00010001u : 0u);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         int s = 0;
@@ -180,11 +244,21 @@ struct UStream {
                         for (int t = 0; t < P; t++) s = u_dot2((int)__builtin_amdgcn_perm(win[c][r][t + 1], win[c][r][t], sc), cf[c][t], s);
                         h[r] = s >> 7;
                     }
+#endif
                     out[2 * c + comp] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0], h[1]));
                 }
             } else {
-                const unsigned se = sel[c], so = sel[c] + 0x00020002u;
                 int h[2];
+#if U_BPS == 2
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    int s = cvBias;
+#pragma unroll
+                    for (int t = 0; t < P; t++) s = u_dot2((int)win[c][r][t], cf[c][t], s);      // an aligned dword as loaded IS the pair
+                    h[r] = s >> cvSh;
+                }
+#else
+                const unsigned se = sel[c], so = sel[c] + 0x00020002u;
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     int s = 0;
@@ -193,6 +267,7 @@ struct UStream {
                         s = u_dot2((int)__builtin_amdgcn_perm(win[c][r][(t >> 1) + 1], win[c][r][t >> 1], (t & 1) ? so : se), cf[c][t], s);
                     h[r] = s >> 7;
                 }
+#endif
                 out[c] = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0], h[1]));
             }
         }
@@ -204,6 +279,10 @@ struct UStream {
         request(ld, ring[S]);
     }
 };
+
+// coefficient pairs of a stream in a kernel instantiated for P: 16-bit samples of an interleaved row lead with at most one position where a plane leads with
+// three samples (k_scale_yuvg.hip GPairs)
+template <int P, bool S2> struct UPairs { static constexpr int N = (U_BPS == 2 && S2) ? P - 1 : P; };
 
 // R coefficient pairs of output row y (wave-uniform: scalar loads)
 template <int R> __device__ __forceinline__ void u_load_row(const int32_t *vt, int y, int (&c)[R])
@@ -240,8 +319,8 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
     const uint8_t *sp = job == 0 ? fr.y[f] : job == 1 ? fr.u[f] : fr.v[f];
     uint8_t *dp = job == 0 ? fr.dst[f] : job == 1 ? fr.dstU[f] : fr.dstV[f];
     const int ss = job == 0 ? a.ys : job == 1 ? a.us : a.vs, dstride = job == 0 ? a.ds : job == 1 ? a.dsU : a.dsV;
-    const int srcRowBytes = job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW;
-    const UPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes);
+    const int srcRowBytes = (job == 0 ? a.srcW : NV12 ? 2 * a.chrSrcW : a.chrSrcW) * U_BPS;
+    const UPlane bS(sp, (unsigned)ss * (unsigned)(srcRows - 1) + (unsigned)srcRowBytes), bD(dp, (unsigned)dstride * (unsigned)(rows - 1) + (unsigned)rowBytes * (a.dst16 ? 2u : 1u));
     const int32_t *vt = job ? a.vtC : a.vtL, *endT = job ? a.endC : a.endL, *firstT = job ? a.firstC : a.firstL, *lastT = job ? a.lastC : a.lastL;
     const int rnd = job ? a.roundC : a.roundL;
     const int b0 = B0 + 4 * lane;                                   // this lane's first byte column
@@ -249,7 +328,8 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
     auto run = [&](auto s2_c) {
         constexpr bool S2 = decltype(s2_c)::value;
         constexpr int NC = S2 ? 2 : 4;
-        UStream<P, S2, NC, SD, 4> W;
+        UStream<UPairs<P, S2>::N, S2, NC, SD, 4> W;
+        W.set_conv(a.src16, a.hShift, a.hBias);
         {
             const int32_t *hTab = job ? a.hC : a.hL, *posTab = job ? a.posC : a.posL;
             const int ncols = S2 ? a.chrDstW : rowBytes;
@@ -300,10 +380,32 @@ __global__ __launch_bounds__(256) void scale_yuvu_planes_kernel(YuvUArgs a, Yuv2
                     for (int j = 0; j < R; j++) acc[o] = u_dot2(hr[j][o], cv[j], acc[o]);
                 }
                 u_load_row<R>(vt, min(y + 1, rows - 1), cv);
+                const unsigned drow = (unsigned)y * (unsigned)dstride;
+                if (__builtin_amdgcn_readfirstlane(a.dst16)) {
+                    // yuv2p010l1_c / lX_c / cX_c, yuv2planeX_10_c (output.c:459-519): clip_uintp2((1 << 16 + sum) >> 17, 10), P010: << 6 — four samples = two dwords
+                    unsigned w[4];
+#pragma unroll
+                    for (int o = 0; o < 4; o++) w[o] = (unsigned)min(max(acc[o] >> 17, 0), 1023) << a.dstShift;
+                    if (b0 + 4 <= rowBytes) bD.st2(make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16)), 2u * (unsigned)b0, drow);
+                    else if (b0 < rowBytes) {
+                        unsigned short *q = reinterpret_cast<unsigned short *>(dp + (size_t)drow) + b0;
+                        for (int i = 0; i < rowBytes - b0; i++) q[i] = (unsigned short)w[i];
+                    }
+                    y++;
+                    continue;
+                }
+                if (U_BPS == 2 && __builtin_amdgcn_readfirstlane(a.dither8)) {
+                    // 8-bit planar output of a deeper source: ff_dither_8x8_128 (swscale.c:263-264, 482-485) on top of the 64 << 12 the sums started at; the dither's
+                    // column: a sample's own, V three columns on (vscale.c:98,101, output.c:433-434)
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        const int col = job == 0 ? b0 + o : NV12 ? ((b0 + o) >> 1) + 3 * ((b0 + o) & 1) : b0 + o + (job == 2 ? 3 : 0);
+                        acc[o] += dither_delta(col, y);
+                    }
+                }
                 const unsigned v0 = (unsigned)clip_u8_shr(acc[0], 19), v1 = (unsigned)clip_u8_shr(acc[1], 19);
                 const unsigned v2 = (unsigned)clip_u8_shr(acc[2], 19), v3 = (unsigned)clip_u8_shr(acc[3], 19);
                 const unsigned d = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-                const unsigned drow = (unsigned)y * (unsigned)dstride;
                 if (b0 + 4 <= rowBytes) bD.st1(d, (unsigned)b0, drow);
                 else if (b0 < rowBytes) {                            // a row that is not whole dwords: its last bytes one by one
                     uint8_t *q = dp + (size_t)drow + (unsigned)b0;
@@ -356,8 +458,8 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
     if (X0 >= a.dstW) return;
     const int ya = band * a.bandRows, yb = min(ya + a.bandRows, a.dstH);
     const int f = blockIdx.y;
-    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW);
-    const UPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW);
+    const unsigned crb = (unsigned)(NV12 ? 2 * a.chrSrcW : a.chrSrcW) * U_BPS;
+    const UPlane bY(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)a.srcW * U_BPS);
     const UPlane bU(fr.u[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb), bV(NV12 ? fr.u[f] : fr.v[f], (unsigned)a.us * (unsigned)(a.chrSrcH - 1) + crb);
     const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
     const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
@@ -367,7 +469,8 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
     UStream<P, false, 4, SD, 4> L;
     // chroma: NV12: 2 columns x (U, V) of the interleaved row.  Planar: 4 "columns" = (U, column 0), (U, 1), (V, 0), (V, 1); the U segment
     // in the first half of the row image (filled by lanes 0 .. 31), the V segment in the second (lanes 32 .. 63)
-    UStream<P, NV12, NV12 ? 2 : 4, SD, 2> C;
+    UStream<UPairs<P, NV12>::N, NV12, NV12 ? 2 : 4, SD, 2> C;
+    L.set_conv(a.src16, a.hShift, a.hBias); C.set_conv(a.src16, a.hShift, a.hBias);
     {
         int w0[4];
 #pragma unroll
@@ -528,28 +631,52 @@ __global__ __launch_bounds__(256) void scale_yuvu_rgb_kernel(YuvUArgs a, Yuv2xFr
 #undef U_JOIN
 }
 
+#if U_BPS == 2
+} // namespace u16
+using namespace u16;
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // ring depths the kernels are instantiated for: 4:2:0 destinations R (4-tap filters need 3, 8-tap ones 5), RGB (RL, RC)
-static const int kUP[] = {2, 3, 4}, kUR[] = {3, 5};
+#if U_BPS == 2
+static const int kUP[] = {4, 6};              // (16-bit samples: up to three leading zero taps in front of the 2 / 4 / 6 / 8 taps)
+#else
+static const int kUP[] = {2, 3, 4};
+#endif
+static const int kUR[] = {3, 5};
 static const int kURgb[][2] = {{4, 3}, {4, 4}, {6, 4}, {8, 5}};      // (bilinear: 4 / 3; bicubic: 4 / 4 with the luma stream a step behind; Lanczos-3: 6 / 4)
 
-int yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
+int U_NAME(yuvu_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
 {
     t = YuvUTables();
     const char *off = GMAT_KNOB("GMAT_SCALE_NO_QUAD_WALKER");
     if (off && atoi(off)) return 0;
     const bool rgbOut = p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA;
-    const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P;
+    // 4:2:0 destinations: 8 bits, or (round 5) 10 bits in 16-bit stores (P010LE / YUV420P10LE: the same 15-bit lines, another shift)
+    const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P || is_dst10(p.dstFormat);
+    const bool semiDst = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_P010LE;
+#if U_BPS == 2
+    const bool nv12 = is_p01x(p.srcFormat);                                                 // (interleaved chroma)
+    if (!(nv12 || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE || p.srcFormat == GMAT_PIX_FMT_YUV420P16LE) || !(rgbOut || yuvOut)) return 0;
+    if (const char *o16 = GMAT_KNOB("GMAT_SCALE_NO_WALKER16")) if (atoi(o16)) return 0;
+    for (const FilterBank *fb : {&p.hLum, &p.hChr})                                         // (the 16-bit image's bias: every row sums to 16384)
+        for (int x = 0; x < fb->count; x++) {
+            int sum = 0;
+            for (int j = 0; j < fb->taps; j++) sum += fb->coef[(size_t)x * fb->taps + j];
+            if (sum != 16384) return 0;
+        }
+#else
     const bool nv12 = p.srcFormat == GMAT_PIX_FMT_NV12;
     if (!(nv12 || p.srcFormat == GMAT_PIX_FMT_YUV420P) || !(rgbOut || yuvOut)) return 0;
+#endif
     if (rgbOut && (g.fullChroma || g.yuvOut)) return 0;
     if (yuvOut && g.yuvOut != 1) return 0;
-    if (yuvOut && (nv12 != (p.dstFormat == GMAT_PIX_FMT_NV12))) return 0;                   // same chroma layout on both sides
+    if (yuvOut && nv12 != semiDst) return 0;                                                // same chroma layout on both sides
     if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
     // whole dwords inside every source row (the rows are dword loads checked against the plane's exact size)
-    if (p.srcW % 4 || (nv12 ? (2 * p.chrSrcW) % 4 : p.chrSrcW % 4)) return 0;
+    if ((p.srcW * U_BPS) % 4 || ((nv12 ? 2 * p.chrSrcW : p.chrSrcW) * U_BPS) % 4) return 0;
     if (rgbOut && (p.chrDstW != (p.dstW + 1) / 2 || p.chrDstH != p.dstH || p.dstW % 2)) return 0;
     if (yuvOut && (p.chrDstW != (p.dstW + 1) / 2 || p.chrDstH != (p.dstH + 1) / 2)) return 0;
     // the sums start at ONE value per plane class (the 1- and 2-tap special forms of vscale.c:135-167 have per-row starts)
@@ -559,40 +686,46 @@ int yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
     if (g.vLumEff.count != p.dstH || g.vChrEff.count != (rgbOut ? p.dstH : p.chrDstH)) return 0;
 
     // ---- horizontal: coefficient pairs on the table's own windows -------------------------------------------------------------------
-    const int needP = (std::max(p.hLum.taps, p.hChr.taps) + 1) / 2;
+    // (16-bit samples: windows re-based to 8-byte boundaries — `lead` zero taps in front: pos & 3 samples of a plane, pos & 1 positions of an interleaved row —
+    // and the interleaved chroma stream on one pair fewer than the instance's P: UPairs)
+    auto lead = [&](const FilterBank &fb, int x, bool s2) { return U_BPS == 2 ? (s2 ? fb.pos[x] & 1 : fb.pos[x] & 3) : 0; };
+    auto pairs_needed = [&](const FilterBank &fb, bool s2) { int m = 0; for (int x = 0; x < fb.count; x++) m = std::max(m, lead(fb, x, s2) + fb.taps); return (m + 1) / 2; };
+    const int needP = std::max(pairs_needed(p.hLum, false), pairs_needed(p.hChr, nv12) + (U_BPS == 2 && nv12 ? 1 : 0));
     int P = 0;
     for (int c : kUP) if (c >= needP) { P = c; break; }
     if (!P) return 0;
-    auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out) {
-        out.assign((size_t)fb.count * P, 0);
+    auto hpack = [&](const FilterBank &fb, int srcLen, std::vector<int32_t> &out, int PP, bool s2) {
+        out.assign((size_t)fb.count * PP, 0);
         for (int x = 0; x < fb.count; x++) {
             if (fb.pos[x] < 0 || fb.pos[x] + fb.taps > srcLen) return false;
             if (x && fb.pos[x] < fb.pos[x - 1]) return false;                               // lane 0 holds a wave's first window
-            for (int k = 0; k < P; k++) {
-                const int t0 = 2 * k, t1 = t0 + 1;
-                const int lo = t0 < fb.taps ? fb.coef[(size_t)x * fb.taps + t0] : 0, hi = t1 < fb.taps ? fb.coef[(size_t)x * fb.taps + t1] : 0;
-                out[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+            const int ld = lead(fb, x, s2);
+            for (int k = 0; k < PP; k++) {
+                const int t0 = 2 * k - ld, t1 = t0 + 1;
+                const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)x * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)x * fb.taps + t1] : 0;
+                out[(size_t)x * PP + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
             }
         }
         return true;
     };
     if (p.hLum.count != p.dstW || p.hChr.count != p.chrDstW) return 0;
-    if (!hpack(p.hLum, p.srcW, t.hL) || !hpack(p.hChr, p.chrSrcW, t.hC)) return 0;
+    if (!hpack(p.hLum, p.srcW, t.hL, P, false) || !hpack(p.hChr, p.chrSrcW, t.hC, U_BPS == 2 && nv12 ? P - 1 : P, nv12)) return 0;
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
     // the row segments: the windows of a wave's columns lie inside the capDw dwords its lanes load (+ the pad for dwords whose taps are 0)
     auto fits = [&](const FilterBank &fb, int cols, bool s2, int capDw) {
-        const int NW = s2 ? P + 1 : ((P - 1) >> 1) + 2;
+        const int NW = U_BPS == 2 ? (s2 ? 2 * (P - 1) : (P + 1) & ~1) : (s2 ? P + 1 : ((P - 1) >> 1) + 2);
         for (int c0 = 0; c0 < fb.count; c0 += cols) {
             const int c1 = std::min(c0 + cols, fb.count) - 1;
-            const int b0 = (s2 ? 2 * fb.pos[c0] : fb.pos[c0]) & ~3, b1 = (s2 ? 2 * fb.pos[c1] : fb.pos[c1]) & ~3;
+            const int b0 = s2 ? u_win_base<true>(fb.pos[c0]) : u_win_base<false>(fb.pos[c0]), b1 = s2 ? u_win_base<true>(fb.pos[c1]) : u_win_base<false>(fb.pos[c1]);
             if (((b1 - b0) >> 2) + NW > capDw + kUPad) return false;
-            const int lastTap = s2 ? 2 * (fb.pos[c1] + fb.taps - 1) + 1 : fb.pos[c1] + fb.taps - 1;     // the last byte with a real tap
+            const int lastSample = fb.pos[c1] + fb.taps - 1;                                                  // the last byte with a real tap
+            const int lastTap = U_BPS == 2 ? (s2 ? 4 * lastSample + 3 : 2 * lastSample + 1) : (s2 ? 2 * lastSample + 1 : lastSample);
             if (lastTap >= b0 + 4 * capDw) return false;
         }
         return true;
     };
     int SD = 0;
-    for (int sd : {1, 2}) {
+    for (int sd : {1 * U_BPS, 2 * U_BPS}) {
         bool ok = fits(p.hLum, kUStrip, false, 64 * sd);
         if (rgbOut) ok = ok && fits(p.hChr, kUStrip / 2, nv12, nv12 ? 64 * sd : 32 * sd);
         else        ok = ok && fits(p.hChr, nv12 ? kUStrip / 2 : kUStrip, nv12, 64 * sd);
@@ -690,7 +823,7 @@ int yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &g, YuvUTables &t)
     return 0;
 }
 
-int launch_scale_yuvu(const YuvUArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+int U_NAME(launch_scale_yuvu)(const YuvUArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
     YuvUArgs a = a0;
@@ -727,8 +860,12 @@ int launch_scale_yuvu(const YuvUArgs &a0, hipStream_t stream, const Yuv2xFrames 
 #define GMAT_U_SD(P_, SD_) do { \
         if (a.yuvOut) { if (a.RL <= 3) GMAT_U_PL(P_, 3, SD_); else GMAT_U_PL(P_, 5, SD_); } \
         else          { if (a.RL <= 4 && a.RC <= 3) GMAT_U_RGB(P_, 4, 3, SD_); else if (a.RL <= 4) GMAT_U_RGB(P_, 4, 4, SD_); else if (a.RL <= 6) GMAT_U_RGB(P_, 6, 4, SD_); else GMAT_U_RGB(P_, 8, 5, SD_); } } while (0)
-#define GMAT_U_P(P_) do { if (a.SD == 1) GMAT_U_SD(P_, 1); else GMAT_U_SD(P_, 2); } while (0)
+#define GMAT_U_P(P_) do { if (a.SD == 1 * U_BPS) GMAT_U_SD(P_, 1 * U_BPS); else GMAT_U_SD(P_, 2 * U_BPS); } while (0)
+#if U_BPS == 2
+    if (a.P == 4) GMAT_U_P(4); else GMAT_U_P(6);
+#else
     switch (a.P) { case 2: GMAT_U_P(2); break; case 3: GMAT_U_P(3); break; default: GMAT_U_P(4); }
+#endif
 #undef GMAT_U_P
 #undef GMAT_U_SD
 #undef GMAT_U_RGB

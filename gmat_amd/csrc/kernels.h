@@ -394,10 +394,14 @@ struct YuvUArgs {
     const int32_t *vtL, *vtC, *endL, *endC, *firstL, *firstC, *lastL, *lastC;
     // filled by the launcher: rows per band, groups of four 256-byte strips per row, blocks (luma | chroma jobs of a 4:2:0 destination)
     int bandRows, nbands, nsg, bandRowsC, nbandsC, nsgC, nblkL, nblkC, nblk, xcdRemap;
+    int src16, hShift, hBias, dst16, dstShift, dither8;       // (round 5) 16-bit samples in (k_scale_yuvu16.hip), 10-bit samples out, the dither of a deeper source: as YuvGArgs'
     Yuv2RgbConsts y2r;
 };
 int  yuvu_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvUTables &t);
 int  launch_scale_yuvu(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+// the same walker over 16-bit samples (k_scale_yuvu16.hip = k_scale_yuvu.hip compiled with U_BPS = 2)
+int  yuvu_prepare16(const ScalePlan &p, const YuvScaleTiling &generic, YuvUTables &t);
+int  launch_scale_yuvu16(const YuvUArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // ---- the LINES form (k_scale_yuvl.hip, round 4): two launches through a frame of horizontally filtered 15-bit lines in HBM — the down-scales
 // no walker takes (beyond 6.1 : 1, range conversion, filters the band walker's tables do not hold), which the tiled kernel served at 0.03 - 0.1 of

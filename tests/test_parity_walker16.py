@@ -205,3 +205,42 @@ def test_rgb_to_rgb_batches_and_bands(dev, orc, monkeypatch):
     for rows in (4, 7, 40):
         monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
         assert _check(dev, orc, "rgb24", "bgr24", (520, 200, 172, 66), align=4, src_align=64) == RGBRGB
+
+
+# ---- the quad-lane walker over 16-bit samples (k_scale_yuvu16.hip, round 5): up-scales of any factor, short-filter down-scales ------------------------------
+QUAD16 = "scale_yuvu16_kernel"
+UP_GEOMS = [(160, 90, 240, 136), (128, 72, 384, 216), (320, 180, 384, 216), (200, 120, 600, 330), (256, 64, 1024, 256), (132, 76, 200, 114)]
+
+
+@pytest.mark.parametrize("pair", PAIRS16, ids=lambda p: "%s-%s" % p)
+@pytest.mark.parametrize("geom", UP_GEOMS, ids=lambda g: "%dx%d-%dx%d" % g)
+def test_quad16_up_scales(dev, orc, pair, geom):
+    """P010 / P016 / planar 10- and 16-bit 4:2:0 sources up-scaled by any factor: a lane owns four adjacent outputs, the vertical filter is a gather over a register
+    ring (k_scale_yuvu.hip's structure), the horizontal stage reads 8-byte aligned windows of 16-bit samples (no v_perm_b32 for a plane)"""
+    k = _check(dev, orc, pair[0], pair[1], geom)
+    assert k == QUAD16 or ((geom[2] & 1) and pair[1] in ("rgb24", "bgr24", "rgba", "bgra")), k
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "point", "area", "gauss", "spline"])
+def test_quad16_algorithms(dev, orc, flags):
+    for pair in (("p010le", "p010le"), ("yuv420p10le", "rgb24"), ("p016le", "nv12")):
+        _check(dev, orc, pair[0], pair[1], (160, 90, 240, 136), flags)
+        _check(dev, orc, pair[0], pair[1], (128, 72, 384, 216), flags)
+
+
+@pytest.mark.parametrize("pair", [("nv12", "p010le"), ("yuv420p", "yuv420p10le")], ids=lambda p: "%s-%s" % p)
+def test_quad8_writes_ten_bit_destinations(dev, orc, pair):
+    for geom in UP_GEOMS[:4]:
+        assert _check(dev, orc, pair[0], pair[1], geom) == "scale_yuvu_kernel"
+
+
+def test_quad16_short_filter_down_scales_and_batches(dev, orc, monkeypatch):
+    """the shipped rule: up-scales on the vertical axis (the short-filter down-scales the 8-bit kernel takes in launches of more than three frames stay on the band
+    walker here: measured slower, profiles/r05t_quad16.txt); GMAT_QUAD_WALKER=2: wherever it is eligible"""
+    assert _run_batch(dev, orc, "p010le", "p010le", 384, 216, 288, 162, nframes=5, nstreams=1, align=256) in W16
+    monkeypatch.setenv("GMAT_QUAD_WALKER", "2")
+    assert _run_batch(dev, orc, "p010le", "p010le", 384, 216, 288, 162, nframes=5, nstreams=1, align=256) == QUAD16
+    monkeypatch.delenv("GMAT_QUAD_WALKER")
+    assert _run_batch(dev, orc, "yuv420p10le", "yuv420p", 160, 90, 240, 136, nframes=9, nstreams=2, align=64) == QUAD16
+    monkeypatch.setenv("GMAT_QUAD_WALKER", "0")
+    assert _check(dev, orc, "p010le", "p010le", (160, 90, 240, 136)) in W16
