@@ -79,7 +79,7 @@ def ratio_kernels_keep_single_frames(monkeypatch):
 
 
 QUAD = "scale_yuvu_kernel"
-WALK16 = ("scale_yuvg16_kernel", "scale_yuvg16_blk_kernel")   # the band walker over 16-bit samples (k_scale_yuvg16.hip, round 5): P010 / P016 / planar 10- and 16-bit 4:2:0 sources
+WALK16 = ("scale_yuvg16_kernel", "scale_yuvg16_blk_kernel", "scale_yuvu16_kernel")   # the band walker over 16-bit samples (k_scale_yuvg16.hip, round 5): P010 / P016 / planar 10- and 16-bit 4:2:0 sources; the quad-lane walker of their up-scales (k_scale_yuvu16.hip)
 LINES16 = "scale_yuvl_h16_kernel+scale_yuvl_v_kernel"  # ... its pass H for 16-bit samples (P010 / P016 / planar 10 / 16 bit sources)
 LINES = "scale_yuvl_h_kernel+scale_yuvl_v_kernel"     # the lines form (k_scale_yuvl.hip, round 4): what no walker takes, from 2 : 1 on the horizontal axis
 
