@@ -143,7 +143,7 @@ struct GmatSwsContext {
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     YuvGTables rg;                // (round 5) any other ratio the band walker reaches: scale_yuvg_rgbsrc_kernel (k_scale_yuvg16.hip) ...
     YuvGArgs rgargs;              // ... its arguments but the call's pointers and pitches ...
-    DevBuf dRG[7];                // ... and device tables: hL, hC, posL, posC, prog, qfirst, qdone
+    DevBuf dRG[8];                // ... and device tables: hL, hC, posL, posC, prog, qfirst, qdone, vtL (the block-cooperative form's)
     YuvGTables yg;                // the polyphase band walker for any ratio (k_scale_yuvg.hip)
     DevBuf dG[4 + 2 * 2 * 5];     // its device tables: hL, hC, posL, posC, then per (plane class, direction) coef / first / last / round / yLo
     YuvGArgs gargs;
@@ -367,13 +367,17 @@ static int init_scaler(GmatSwsContext *c)
         const YuvGTables &t = c->rg;
         int k = 0;
         auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            if (v.empty()) { out = nullptr; k++; return 0; }
             int rr = c->dRG[k].upload(v.data(), v.size() * 4);
             out = (const int32_t *)c->dRG[k++].p;
             return rr;
         };
+        static const std::vector<int32_t> none;
         if ((r = up(t.hL, g.hL)) < 0 || (r = up(t.hC, g.hC)) < 0 || (r = up(t.posL, g.posL)) < 0 || (r = up(t.posC, g.posC)) < 0 ||
-            (r = up(t.rgb[0].prog, g.prog[0])) < 0 || (r = up(t.rgb[0].qfirst, g.qfirst[0])) < 0 || (r = up(t.rgb[0].qdone, g.qdone[0])) < 0) return r;
+            (r = up(t.walkOk ? t.rgb[0].prog : none, g.prog[0])) < 0 || (r = up(t.walkOk ? t.rgb[0].qfirst : none, g.qfirst[0])) < 0 ||
+            (r = up(t.walkOk ? t.rgb[0].qdone : none, g.qdone[0])) < 0 || (r = up(t.blkRows ? t.vtL : none, g.vtL)) < 0) return r;
         g.P = t.P; g.K = t.K; g.roundL = t.roundL; g.roundC = t.roundC; g.src16 = 3; g.hShift = 13;
+        g.n4L = t.n4L; g.blkRows = t.blkRows; g.blkRows4 = t.blkRows4; g.blkPPL = t.blkPPL;
         g.srcW = c->srcW; g.srcH = c->srcH; g.chrSrcW = c->plan.chrSrcW; g.chrSrcH = c->plan.chrSrcH;
         g.dstW = c->dstW; g.dstH = c->dstH; g.chrDstW = c->dstW; g.chrDstH = c->dstH; g.dstFormat = c->dstFormat;
         g.rgbBgr = c->srcFormat == GMAT_PIX_FMT_BGR24;
@@ -1452,9 +1456,12 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         if (ensure_scaler(c) < 0 || !(c->r2s.ok || c->rg.ok)) return 0;
         if (!c->r2s.ok) {
             // (32 frames a launch: rgb24 1080p -> 720p 14.2 -> 6.6 us a frame, 4K -> 900p 30.1 -> 22.0, 720p -> 1080p 14.8 -> 9.3; below four frames the tiled kernel)
+            // (round 5, later: ONE to three frames a launch — and every launch the walker has no instance for: up-scales beyond its open rows — take the
+            // block-cooperative form, scale_yuvg_rgbsrc_blk_kernel)
             const char *rw = GMAT_KNOB("GMAT_RGBSRC_WALKER");
             const int mode = rw ? atoi(rw) : 1;
-            if (mode == 0 || (mode == 1 && n < 4)) return 0;
+            const bool blk = yuvg_rgbsrc_block_form(c->rgargs, std::min(n, kYuv2xMaxFrames));
+            if (mode == 0 || !(blk || (c->rgargs.K && (mode == 2 || n >= 4)))) return 0;
             for (int f = 0; f < n; f++) {
                 const uint8_t *sp = src_planes[4 * f];
                 uint8_t *dp = dst_planes[4 * f];
@@ -1462,7 +1469,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
                 if (!al4(sp, srcStride[0]) || !al4(dp, dstStride[0])) return 0;
             }
             const YuvGArgs ga = make_rg_args(c, srcStride[0], dstStride[0]);
-            c->lastKernel = "scale_yuvg_rgbsrc_kernel";
+            c->lastKernel = blk ? "scale_yuvg_rgbsrc_blk_kernel" : "scale_yuvg_rgbsrc_kernel";
             for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
                 Yuv2xFrames fr;
                 const int m = std::min(kYuv2xMaxFrames, n - f0);
@@ -2490,14 +2497,16 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             r = launch_scale_rgb2s(ra, c->stream, &one, 1);
             break;
         }
-        if (a.srcKind == 0 && c->rg.ok && a.srcAligned && al4(dst[0], dstStride[0]) && !c->prof && GMAT_KNOB("GMAT_RGBSRC_WALKER") && atoi(GMAT_KNOB("GMAT_RGBSRC_WALKER")) == 2) {
+        const char *rgw = GMAT_KNOB("GMAT_RGBSRC_WALKER");
+        if (a.srcKind == 0 && c->rg.ok && a.srcAligned && al4(dst[0], dstStride[0]) && !c->prof && !(rgw && !atoi(rgw)) &&
+            (yuvg_rgbsrc_block_form(c->rgargs, 1) || (c->rgargs.K && rgw && atoi(rgw) == 2))) {
             // any other ratio the band walker reaches (round 5): one column a lane, the three lines from one load of the pixels — in launches of four
             // frames or more (sws_scale_frames_batched_impl); ONE frame stays on the tiled kernel, which is faster alone (1080p -> 720p 13.0 against
             // 17.2 us, 4K -> 900p 27 against 48: profiles/r05s_rgbrgb_walker.txt).  GMAT_RGBSRC_WALKER=2: here too (tests, A/B)
             Yuv2xFrames one;
             std::memset(&one, 0, sizeof(one));
             one.y[0] = a.src0; one.dst[0] = a.dst;
-            c->lastKernel = "scale_yuvg_rgbsrc_kernel";
+            c->lastKernel = yuvg_rgbsrc_block_form(c->rgargs, 1) ? "scale_yuvg_rgbsrc_blk_kernel" : "scale_yuvg_rgbsrc_kernel";
             r = launch_scale_yuvg_rgbsrc(make_rg_args(c, a.ss0, a.ds), c->stream, &one, 1);
             break;
         }

@@ -1184,6 +1184,166 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_kernel(YuvGArgs a, Yuv2
     for (int q = q0; q <= q1; q++) quad(q);
     flush();
 }
+
+// ---- the same conversion, block-cooperative: a launch of few frames, up-scales, windows of any height (round 5) ---------------------------------------------
+// block = 64 output columns x a.bandRows output rows; grid.y = frame.  scale_yuvg_blk_rgb_kernel's two phases with THREE lines behind one load of the pixels:
+// (1) the band's source row pairs are dealt round the waves.  The two rows of a pair are converted SIDE BY SIDE — lanes 0-31 take row 2p, lanes 32-63 row
+//     2p + 1, PPL pixels a lane (3 PPL / 4 raw dwords) — into the wave's row images of Y, U and V: half the loads and half the converter instructions of
+//     the band walker's streams, which convert 256 samples of BOTH rows in every lane.  Then every lane filters its column of the two rows of the three lines
+//     (8-byte aligned windows, ds_read_b64, one v_dot2 a coefficient pair) and leaves three packed pairs of 15-bit samples in LDS;
+// (2) one barrier; output row y0 + i belongs to wave i & 3: ONE set of coefficient pairs (the chroma's vertical filter is the luma's) down three LDS columns,
+//     yuv2rgb_full_X_c's shifts, yuv2rgb_write_full.
+// HALF: chroma from pixel pairs (2 : 1 and beyond).  PPL = 4 where every block's segment fits 128 pixels, 8 otherwise (HALF: always 8).  J: row pairs a wave
+// requests at once.  The filtered pairs sit in dynamic LDS: 3 x a.blkSlots x 64 dwords.
+template <int P, bool HALF, int PPL, int J>
+__global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, Yuv2xFrames fr)
+{
+    static_assert(PPL == 4 || PPL == 8, "pixels a lane");
+    static_assert(!HALF || PPL == 8, "pixel pairs: eight pixels a lane");
+    constexpr int NW = (P + 1) & ~1;                         // window dwords
+    constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY;    // dwords of a row image: 32 lanes x PPL samples (chroma of pixel pairs: half of them)
+    constexpr int RD = (3 * PPL) / 4;                        // raw dwords a lane
+    __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC];
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    int (*hY)[64] = reinterpret_cast<int (*)[64]>(lds_base);
+    int (*hU)[64] = hY + a.blkSlots, (*hV)[64] = hU + a.blkSlots;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) { const int chunk = (a.nblk + 7) >> 3; lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3); }
+    if (lin >= a.nblk) return;
+    const int band = lin / a.nsg;
+    const int X0 = (lin - band * a.nsg) * 64;
+    const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
+    const int f = blockIdx.y;
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + 3u * (unsigned)a.srcW);
+    const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
+    const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
+    const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
+    const int x = X0 + lane, xc = min(x, a.dstW - 1);
+
+    // this lane's column: coefficient pairs and windows (in samples, multiples of 4); the block's first pixel from SCALAR loads of lane 0's windows
+    int cfY[P], cfC[P];
+#pragma unroll
+    for (int t = 0; t < P; t++) { cfY[t] = a.hL[(size_t)xc * P + t]; cfC[t] = a.hC[(size_t)xc * P + t]; }
+    const int sy0 = uniform_load(a.posL, X0) & ~3, sc0 = uniform_load(a.posC, X0) & ~3;
+    const int px0 = HALF ? min(sy0 & ~7, 2 * sc0) : min(sy0, sc0);
+    const int winY = ((a.posL[xc] & ~3) - px0) >> 1, winC = ((a.posC[xc] & ~3) - (HALF ? px0 >> 1 : px0)) >> 1;
+    const int half = lane >> 5, grp = lane & 31;
+    const unsigned lbase = 3u * (unsigned)px0 + (unsigned)(3 * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
+    auto pk = [](int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); };
+    const Rgb2YuvConsts &k = a.r2y;
+    const int y01 = a.rgbBgr ? pk(k.by, k.gy) : pk(k.ry, k.gy), y2 = a.rgbBgr ? k.ry : k.by;
+    const int u01 = a.rgbBgr ? pk(k.bu, k.gu) : pk(k.ru, k.gu), u2 = a.rgbBgr ? k.ru : k.bu;
+    const int v01 = a.rgbBgr ? pk(k.bv, k.gv) : pk(k.rv, k.gv), v2 = a.rgbBgr ? k.rv : k.bv;
+    unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0];
+    typedef GStream<P, false, 2, 1, 1> G1;
+
+    const int sV = kGBlkHead + 4 * a.n4L;
+    const int pa = uniform_load(a.vtL, y0 * sV), pb = uniform_load(a.vtL, (y1 - 1) * sV + 1);
+    // (1) every slot is requested (the ones past the band's last pair as that pair again: no load under a branch)
+    unsigned ring[J][RD];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const unsigned off = (unsigned)(2 * min(pa + wave + 4 * j, pb)) * (unsigned)a.ys;
+#pragma unroll
+        for (int s = 0; s < RD; s++) bS.ld1(lbase + 4u * (unsigned)s, off, &ring[j][s]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++)
+        if (pa + wave + 4 * j <= pb) {
+            constexpr int KY = (32 << 14) + (1 << 8);                    // rgb24ToY_c: >> 9
+            int ys[PPL], us[HALF ? PPL / 2 : PPL], vs[HALF ? PPL / 2 : PPL];
+#pragma unroll
+            for (int h = 0; h < PPL / 4; h++) {
+                int fs[4], th[4];
+                G1::rgb4(&ring[j][3 * h], fs, th);
+#pragma unroll
+                for (int i = 0; i < 4; i++) ys[4 * h + i] = g_dot2(fs[i], y01, m24(th[i], y2) + KY) >> 9;
+                if constexpr (HALF) {
+                    constexpr int KC = (256 << 15) + (1 << 9);           // rgb24ToUV_half_c on a pair's sums: >> 10
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int fq = fs[2 * q] + fs[2 * q + 1], tq = th[2 * q] + th[2 * q + 1];       // (two 9-bit sums in the halves: no carry across)
+                        us[2 * h + q] = g_dot2(fq, u01, m24(tq, u2) + KC) >> 10;
+                        vs[2 * h + q] = g_dot2(fq, v01, m24(tq, v2) + KC) >> 10;
+                    }
+                } else {
+                    constexpr int KC = (256 << 14) + (1 << 8);           // rgb24ToUV_c: >> 9
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { us[4 * h + i] = g_dot2(fs[i], u01, m24(th[i], u2) + KC) >> 9; vs[4 * h + i] = g_dot2(fs[i], v01, m24(th[i], v2) + KC) >> 9; }
+                }
+            }
+            auto put = [&](unsigned *img, int pitch, const int *v, int n) {      // n samples of this lane's row into its image
+                unsigned *d = img + half * pitch + (n / 2) * grp;
+                if (n == 8) *reinterpret_cast<uint4 *>(d) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                                                        (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                else        *reinterpret_cast<uint2 *>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+            };
+            __builtin_amdgcn_wave_barrier();
+            put(iy, IY, ys, PPL); put(iu, IC, us, HALF ? PPL / 2 : PPL); put(iv, IC, vs, HALF ? PPL / 2 : PPL);
+            __builtin_amdgcn_wave_barrier();
+            auto hfilt = [&](const unsigned *img, int pitch, int win, const int (&cf)[P]) {
+                int h[2];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    int sum = 0;
+#pragma unroll
+                    for (int i = 0; i < NW; i += 2) {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(img + r * pitch + win + i);
+                        sum = g_dot2((int)t.x, cf[i], sum);
+                        if (i + 1 < P) sum = g_dot2((int)t.y, cf[i + 1], sum);
+                    }
+                    h[r] = sum >> 13;                                    // hScale16To15_c, sh = 13; the pack saturates at 32767
+                }
+                return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0], h[1]));
+            };
+            const int slot = wave + 4 * j;
+            hY[slot][lane] = hfilt(iy, IY, winY, cfY);
+            hU[slot][lane] = hfilt(iu, IC, winC, cfC);
+            hV[slot][lane] = hfilt(iv, IC, winC, cfC);
+        }
+    __syncthreads();
+
+    // (2)
+    const unsigned dsel = (unsigned)((lane & 3) == 0 ? 0x04020100u : (lane & 3) == 1 ? 0x05040201u : 0x06050402u);
+#define GMAT_G_QUAD(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true)
+    for (int y = y0 + wave; y < y1; y += 4) {
+        const int32_t *rv = a.vtL + (size_t)y * sV;
+        const int base = uniform_load(rv, 0) - pa;
+        int accY = a.roundL, accU = a.roundC, accV = a.roundC;
+        for (int g = 0; g < a.n4L; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int c = uniform_load(rv, kGBlkHead + 4 * g + i), s = base + 4 * g + i;
+                accY = g_dot2(hY[s][lane], c, accY); accU = g_dot2(hU[s][lane], c, accU); accV = g_dot2(hV[s][lane], c, accV);
+            }
+        }
+        const int Y = accY >> 10, U = accU >> 10, V = accV >> 10;
+        // yuv2rgb_write_full (output.c:1886-1935): scale_yuvg_rgbsrc_kernel's emit()
+        const int yy = m24(Y - a.y2r.y_offset, a.y2r.y_coeff) + (1 << 21);
+        const int R = yy + m24(V, a.y2r.v2r), G = yy + m24(V, a.y2r.v2g) + m24(U, a.y2r.u2g), B = yy + m24(U, a.y2r.u2b);
+        const unsigned r8 = (unsigned)min(max(R, 0), 0x3FFFFFFF) >> 22, g8 = (unsigned)min(max(G, 0), 0x3FFFFFFF) >> 22, b8 = (unsigned)min(max(B, 0), 0x3FFFFFFF) >> 22;
+        const unsigned px = (bgr ? b8 : r8) | (g8 << 8) | ((bgr ? r8 : b8) << 16) | 0xFF000000u;
+        const unsigned drow = (unsigned)y * (unsigned)a.ds;
+        if (bpp == 4) {
+            if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
+        } else {
+            const unsigned nxt = (unsigned)GMAT_G_QUAD(px, 0xF9);
+            const unsigned o = __builtin_amdgcn_perm(nxt, px, dsel);
+            const int nb = 3 * min(64, a.dstW - X0);
+            const int ob = 12 * (lane >> 2) + 4 * (lane & 3);
+            if ((lane & 3) != 3) {
+                if (ob + 4 <= nb) bD.st1(o, 3u * (unsigned)X0 + (unsigned)ob, drow);
+                else if (ob < nb) {
+                    uint8_t *d = fr.dst[f] + (size_t)drow + 3u * (unsigned)X0 + (unsigned)ob;
+                    for (int i = 0; i < nb - ob; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+        }
+    }
+#undef GMAT_G_QUAD
+}
 #endif
 
 #if G_BPS == 2
@@ -1264,6 +1424,43 @@ static void fill_qprog(YuvGQProg &v, int K)
 // K = output rows open at once.  The plane jobs have the registers for 12 and 15 as well (57-67 VGPRs at K = 9): 4:2:0 -> 4:2:0
 // UP-scales up to 2:1 (720p -> 1080p needs 10, 1080p -> 1440p 10, 1:2 14-15); an RGB destination needs 14-22 there and stays tiled.
 // P = 13 (round 4): 26 taps — bicubic down to 6.2 : 1 (4K -> 360p), bilinear / area twice as far
+// the block-cooperative form's vertical table of a plane class (by output row, walking down): [first row pair, last row pair, 4 n4 coefficient pairs on
+// the row pairs from the first one on]
+static void g_blk_vtab(const FilterBank &fb, std::vector<int32_t> &out, int &n4)
+{
+    const int npv = fb.taps / 2 + 1;                          // row pairs a window can touch (it may start on an odd row)
+    n4 = (npv + 3) / 4;
+    const int stride = kGBlkHead + 4 * n4;
+    out.assign((size_t)fb.count * stride, 0);
+    for (int y = 0; y < fb.count; y++) {
+        const int pos = fb.pos[y], p0 = pos >> 1;
+        int32_t *r = &out[(size_t)y * stride];
+        r[0] = p0; r[1] = (pos + fb.taps - 1) >> 1;
+        for (int k = 0; k < 4 * n4; k++) {
+            const int t0 = 2 * (p0 + k) - pos, t1 = t0 + 1;
+            const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)y * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)y * fb.taps + t1] : 0;
+            r[kGBlkHead + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+        }
+    }
+}
+// the tallest band (rows, <= cap) that fits J pairs a wave from ANY start row (slots: LDS pair slots behind the 4 J of the band's own)
+static int g_blk_tallest(const std::vector<int32_t> &vt, int n4, int count, int J, int cap, int pad)
+{
+    const int stride = kGBlkHead + 4 * n4;
+    int best = cap;
+    for (int y0 = 0; y0 < count && best > 0; y0++) {
+        const int pa = vt[(size_t)y0 * stride];
+        int fit = 0;
+        for (int y = y0; y < std::min(count, y0 + best); y++) {
+            const int p0 = vt[(size_t)y * stride], pl = vt[(size_t)y * stride + 1];
+            if (pl - pa + 1 > 4 * J || p0 - pa + 4 * n4 > 4 * J + pad) break;
+            fit = y - y0 + 1;
+        }
+        if (y0 + fit < count || fit == best) best = std::min(best, fit);      // (a band cut short by the plane's end fits whatever its nominal height)
+    }
+    return best;
+}
+
 #if G_BPS == 2
 static const int kGP[] = {4, 5, 6, 7, 8, 10, 13};           // (7: the 10 / 11 taps of 2.2 - 2.5 : 1 behind three leading zeros)
 #else
@@ -1380,38 +1577,8 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     // the block-cooperative form's vertical tables (by output row, walking down) and the tallest band whose row pairs fit a block:
     // checked for EVERY start row, so that the launcher may cut bands of any height up to it anywhere
     {
-        auto vtab = [&](const FilterBank &fb, std::vector<int32_t> &out, int &n4) {
-            const int npv = fb.taps / 2 + 1;                          // row pairs a window can touch (it may start on an odd row)
-            n4 = (npv + 3) / 4;
-            const int stride = kGBlkHead + 4 * n4;
-            out.assign((size_t)fb.count * stride, 0);
-            for (int y = 0; y < fb.count; y++) {
-                const int pos = fb.pos[y], p0 = pos >> 1;
-                int32_t *r = &out[(size_t)y * stride];
-                r[0] = p0; r[1] = (pos + fb.taps - 1) >> 1;
-                for (int k = 0; k < 4 * n4; k++) {
-                    const int t0 = 2 * (p0 + k) - pos, t1 = t0 + 1;
-                    const int lo = t0 >= 0 && t0 < fb.taps ? fb.coef[(size_t)y * fb.taps + t0] : 0, hi = t1 >= 0 && t1 < fb.taps ? fb.coef[(size_t)y * fb.taps + t1] : 0;
-                    r[kGBlkHead + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
-                }
-            }
-        };
-        // the tallest band (rows, <= cap) that fits J pairs a wave from any start row
-        auto tallest = [&](const std::vector<int32_t> &vt, int n4, int count, int J, int cap) {
-            const int stride = kGBlkHead + 4 * n4;
-            int best = cap;
-            for (int y0 = 0; y0 < count && best > 0; y0++) {
-                const int pa = vt[(size_t)y0 * stride];
-                int fit = 0;
-                for (int y = y0; y < std::min(count, y0 + best); y++) {
-                    const int p0 = vt[(size_t)y * stride], pl = vt[(size_t)y * stride + 1];
-                    if (pl - pa + 1 > 4 * J || p0 - pa + 4 * n4 > 4 * J + kGBlkPad) break;
-                    fit = y - y0 + 1;
-                }
-                if (y0 + fit < count || fit == best) best = std::min(best, fit);      // (a band cut short by the plane's end fits whatever its nominal height)
-            }
-            return best;
-        };
+        auto vtab = [&](const FilterBank &fb, std::vector<int32_t> &out, int &n4) { g_blk_vtab(fb, out, n4); };
+        auto tallest = [&](const std::vector<int32_t> &vt, int n4, int count, int J, int cap) { return g_blk_tallest(vt, n4, count, J, cap, kGBlkPad); };
         vtab(g.vLumEff, t.vtL, t.n4L);
         vtab(g.vChrEff, t.vtC, t.n4C);
         if (rgbOut) {
@@ -1598,30 +1765,101 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     };
     if (!hpack(p.hLum, p.srcW, t.hL) || !hpack(p.hChr, p.chrSrcW, t.hC)) return 0;
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
-    if (!build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) return 0;
+    // the band walker's form (scale_yuvg_rgbsrc_kernel): the running sums of one plane's program, a wave's 64 columns inside the row image its lanes fill
     int K = 0;
-    for (int c : kGK) if (c >= t.rgb[0].K) { K = c; break; }
-    if (!K && t.rgb[0].K <= 12 && P <= 8) K = 12;          // (ratios near 1 and up-scales: ten or eleven rows open over a quad of four source rows)
-    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg rgbsrc: %dx%d -> %dx%d taps h %d/%d v %d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
-                                          p.hLum.taps, p.hChr.taps, p.vLum.taps, P, t.rgb[0].K, K);
-    if (!K) return 0;
-    fill_qprog(t.rgb[0], K);
-    // a wave's 64 columns inside the row image its lanes fill (16-bit samples, windows re-based to 8 bytes)
-    const int SD = P >= 10 ? 4 : 2, NW = (P + 1) & ~1;
-    for (const FilterBank *fb : {&p.hLum, &p.hChr})
-        for (int c0 = 0; c0 < fb->count; c0 += 64) {
-            const int c1 = std::min(c0 + 64, fb->count) - 1;
-            if (g_win_base<false>(fb->pos[c1], 0) + 4 * NW - g_win_base<false>(fb->pos[c0], 0) > 256 * SD) return 0;
+    if (build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) {
+        for (int c : kGK) if (c >= t.rgb[0].K) { K = c; break; }
+        if (!K && t.rgb[0].K <= 12 && P <= 8) K = 12;          // (ratios near 1 and up-scales: ten or eleven rows open over a quad of four source rows)
+        const int SD = P >= 10 ? 4 : 2, NW = (P + 1) & ~1;
+        for (const FilterBank *fb : {&p.hLum, &p.hChr})
+            for (int c0 = 0; c0 < fb->count; c0 += 64) {
+                const int c1 = std::min(c0 + 64, fb->count) - 1;
+                if (g_win_base<false>(fb->pos[c1], 0) + 4 * NW - g_win_base<false>(fb->pos[c0], 0) > 256 * SD) K = 0;
+            }
+        if (K) fill_qprog(t.rgb[0], K);
+    }
+    // the block-cooperative form (scale_yuvg_rgbsrc_blk_kernel): windows of up to 16 row pairs, any number of rows open at once (up-scales); a block's
+    // 64 columns inside 32 lanes x PPL pixels of a row, from the block's first pixel (the kernel's px0) on
+    if (P <= 8 && !(GMAT_KNOB("GMAT_RGBSRC_NO_BLOCK") && atoi(GMAT_KNOB("GMAT_RGBSRC_NO_BLOCK")))) {
+        g_blk_vtab(p.vLum, t.vtL, t.n4L);
+        const bool half = p.chrSrcHSub != 0;
+        const int NW = (P + 1) & ~1;
+        int ppl = half ? 8 : 4;
+        for (int c0 = 0; c0 < p.dstW && ppl <= 8; c0 += 64) {
+            const int c1 = std::min(c0 + 64, p.dstW) - 1;
+            const int sy0 = p.hLum.pos[c0] & ~3, sc0 = p.hChr.pos[c0] & ~3;
+            const int px0 = half ? std::min(sy0 & ~7, 2 * sc0) : std::min(sy0, sc0);
+            int endY = 0, endC = 0;                                   // (window starts need not be monotonic at the borders: every column)
+            bool before = false;
+            for (int x = c0; x <= c1; x++) {
+                endY = std::max(endY, (p.hLum.pos[x] & ~3) + 2 * NW - px0);
+                endC = std::max(endC, (p.hChr.pos[x] & ~3) + 2 * NW - (half ? px0 / 2 : px0));
+                before = before || (p.hLum.pos[x] & ~3) < px0 || (p.hChr.pos[x] & ~3) < (half ? px0 / 2 : px0);
+            }
+            if (before) { ppl = 16; break; }
+            while (ppl <= 8 && (endY > 32 * ppl || endC > (half ? 16 : 32) * ppl)) ppl *= 2;
         }
+        if (ppl <= 8 && t.n4L <= 4) {
+            const int cap = p.dstH > p.srcH ? 64 : 32;
+            t.blkRows = g_blk_tallest(t.vtL, t.n4L, p.vLum.count, 8, cap, 4 * t.n4L) & ~3;
+            t.blkRows4 = g_blk_tallest(t.vtL, t.n4L, p.vLum.count, 4, cap, 4 * t.n4L) & ~3;
+            t.blkPPL = ppl;
+            if (t.blkRows < 4) t.blkRows = t.blkRows4 = 0;
+        }
+    }
+    if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg rgbsrc: %dx%d -> %dx%d taps h %d/%d v %d -> P %d, K needed %d -> %d; block form rows %d / %d, %d pixels a lane",
+                                          p.srcW, p.srcH, p.dstW, p.dstH, p.hLum.taps, p.hChr.taps, p.vLum.taps, P, t.rgb[0].K, K, t.blkRows, t.blkRows4, t.blkPPL);
+    if (!K && !t.blkRows) return 0;
     t.roundL = 1 << 9; t.roundC = (1 << 9) - (128 << 19);          // yuv2rgb_full_X_c (output.c:2037-2082)
-    t.P = P; t.K = K; t.yuvOut = 0;
+    t.P = P; t.K = K; t.walkOk = K > 0; t.yuvOut = 0;
     t.ok = 1;
+    return 0;
+}
+
+// a launch of nframes frames on the block-cooperative form: wherever it has an instance — it is in front of the tiled kernel AND of the walker's form at
+// every launch size (us a frame, tiled or walker / this form: rgb24 1080p -> 720p alone 13.1 / 8.2, 32 frames a launch 6.55 / 4.20; 4K -> 900p 27.4 / 19.4,
+// 22.0 / 12.6; 720p -> 1080p 13.7 / 10.4, 9.25 / 5.47: profiles/r05u_rgbrgb_block_form.txt).  GMAT_RGBSRC_BLOCK=n: launches of up to n frames where the
+// walker has an instance too (0: never there; tests, A/B)
+bool yuvg_rgbsrc_block_form(const YuvGArgs &a, int nframes)
+{
+    if (a.blkRows < 4 || !a.vtL) return false;
+    if (!a.K) return true;
+    if (const char *bs = GMAT_KNOB("GMAT_RGBSRC_BLOCK")) return nframes <= atoi(bs);
+    return true;
+}
+
+static int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+{
+    YuvGArgs a = a0;
+    const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
+    const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;
+    a.nsg = (a.dstW + 63) / 64;
+    int rows = a.blkRows;
+    if (rowsEnv > 0) rows = std::min(a.blkRows, std::max(4, rowsEnv & ~3));
+    else while (rows > 8 && (long)a.nsg * ((a.dstH + rows - 1) / rows) * nframes < 1024) rows -= 4;      // (four blocks a CU, as launch_scale_yuvg_blk)
+    a.bandRows = rows;
+    a.nbands = (a.dstH + rows - 1) / rows;
+    a.nblkL = a.nblk = a.nbands * a.nsg;
+    const int J = rows <= a.blkRows4 ? 4 : 8;
+    a.blkSlots = 4 * J + 4 * a.n4L;
+    const size_t lds = (size_t)3 * a.blkSlots * 64 * 4;
+    const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
+    const bool half = a.chrSrcW != a.srcW;
+#define GMAT_RB(P_, H_, L_) do { if (J == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, 4>), grid, block, lds, stream, a, fr); \
+                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, 8>), grid, block, lds, stream, a, fr); } while (0)
+#define GMAT_RB_P(P_) do { if (half) GMAT_RB(P_, true, 8); else if (a.blkPPL == 4) GMAT_RB(P_, false, 4); else GMAT_RB(P_, false, 8); } while (0)
+    switch (a.P) { case 4: GMAT_RB_P(4); break; case 5: GMAT_RB_P(5); break; case 6: GMAT_RB_P(6); break; case 7: GMAT_RB_P(7); break; default: GMAT_RB_P(8); }
+#undef GMAT_RB_P
+#undef GMAT_RB
+    GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_scale_yuvg_rgbsrc(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+    if (yuvg_rgbsrc_block_form(a0, nframes)) return launch_scale_yuvg_rgbsrc_blk(a0, stream, *frames, nframes);
+    if (!a0.K) return GMAT_ERR(ENOSYS);
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
     const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;

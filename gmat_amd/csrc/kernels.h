@@ -341,6 +341,9 @@ struct YuvGTables {
     // row pairs from the first one on]; blkRows: the tallest band (output rows, a multiple of 4) whose row pairs fit a block at ANY start row
     std::vector<int32_t> vtL, vtC;
     int n4L = 0, n4C = 0, blkRows = 0, blkRowsC = 0;
+    // packed RGB -> packed RGB, block-cooperative (scale_yuvg_rgbsrc_blk_kernel): the walker's form available at all (K), pixels a lane converts, the
+    // tallest band on four row pairs a wave (blkRows: on eight)
+    int walkOk = 0, blkPPL = 0, blkRows4 = 0;
 };
 struct YuvGArgs {
     int ys, us, vs, nv12;
@@ -355,6 +358,7 @@ struct YuvGArgs {
     // the block-cooperative form: vertical tables by output row, groups of 4 coefficient pairs a row, the tallest bands that fit
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
+    int blkPPL, blkRows4, blkSlots;                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
     int src16, hShift, hBias, dst16, dstShift, dither8;
@@ -371,6 +375,7 @@ bool yuvg_block_form16(const YuvGArgs &a, int nframes);
 // packed RGB24 / BGR24 -> packed RGB at the walker's ratios (scale_yuvg_rgbsrc_kernel in k_scale_yuvg16.hip): p = the RGB scaler's plan
 int  yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t);
 int  launch_scale_yuvg_rgbsrc(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+bool yuvg_rgbsrc_block_form(const YuvGArgs &a, int nframes);  // whether a launch of nframes frames takes scale_yuvg_rgbsrc_blk_kernel (a.K == 0: always)
 
 // ---- the quad-lane polyphase walker (k_scale_yuvu.hip, round 4): a lane owns FOUR adjacent outputs of a row, the vertical filter is a
 // GATHER over a short register ring of horizontally filtered row pairs (coefficients by output row, relative to the newest pair) — no

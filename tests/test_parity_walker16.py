@@ -161,45 +161,80 @@ def test_walker16_packed_rgb_batches(dev, orc, monkeypatch):
         assert _run_batch(dev, orc, "bgr24", df, 384, 216, 256, 144, nframes=6, nstreams=1, align=64) == "scale_yuvg16_kernel"
 
 
-# ---- packed RGB -> packed RGB away from 2 : 1 (scale_yuvg_rgbsrc_kernel, round 5): the BASELINE's literal second stage at any ratio -------------------------
+# ---- packed RGB -> packed RGB away from 2 : 1 (round 5): the BASELINE's literal second stage at any ratio -----------------------------------------------------
+# scale_yuvg_rgbsrc_blk_kernel: the block-cooperative form — every launch size, up-scales of any factor, filters up to 16 coefficient pairs (3.3 : 1);
+# scale_yuvg_rgbsrc_kernel: the band walker's form behind it (ratios up to 6 : 1 from four frames a launch on)
 RGBRGB = "scale_yuvg_rgbsrc_kernel"
+RGBBLK = "scale_yuvg_rgbsrc_blk_kernel"
+RGB_GEOMS = [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (640, 128, 420, 84), (1024, 64, 256, 16), (520, 100, 172, 40),
+             (256, 144, 384, 216), (400, 100, 380, 96), (2048, 40, 700, 16), (384, 216, 161, 91)]
+
+
+@pytest.fixture(params=["walk", "blk"])
+def rgbform(request, monkeypatch):
+    """both forms at every launch size (the shipped rule: the block form wherever it has an instance)"""
+    if request.param == "walk":
+        monkeypatch.setenv("GMAT_RGBSRC_WALKER", "2")
+        monkeypatch.setenv("GMAT_RGBSRC_BLOCK", "0")
+    return request.param
 
 
 @pytest.mark.parametrize("sf", ["rgb24", "bgr24"])
 @pytest.mark.parametrize("df", ["rgb24", "bgr24", "rgba", "bgra"])
-@pytest.mark.parametrize("geom", [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (640, 128, 420, 84), (1024, 64, 256, 16), (520, 100, 172, 40),
-                                  (256, 144, 384, 216), (400, 100, 380, 96), (2048, 40, 700, 16), (384, 216, 161, 91)], ids=lambda g: "%dx%d-%dx%d" % g)
-def test_rgb_to_rgb_any_ratio(dev, orc, sf, df, geom, monkeypatch):
+@pytest.mark.parametrize("geom", RGB_GEOMS, ids=lambda g: "%dx%d-%dx%d" % g)
+def test_rgb_to_rgb_any_ratio(dev, orc, rgbform, sf, df, geom):
     """rgb24ToY_c + rgb24ToUV_c / rgb24ToUV_half_c (from 2 : 1 on), hScale16To15_c (sh = 13) of the three lines, yuv2rgb_full_X_c + yuv2rgb_write_full: one
-    libswscale context, bit for bit, down- and up-scales, odd destination sizes; before: the tiled kernel of round 1 (rgb24 1080p -> 720p 14 us a frame, 0.08).
-    (GMAT_RGBSRC_WALKER=2: the form at every launch size; the shipped rule takes it from four frames a launch on)"""
-    monkeypatch.setenv("GMAT_RGBSRC_WALKER", "2")
-    assert _check(dev, orc, sf, df, geom) == RGBRGB
+    libswscale context, bit for bit, down- and up-scales, odd destination sizes; before: the tiled kernel of round 1 (rgb24 1080p -> 720p 14 us a frame, 0.08)."""
+    k = _check(dev, orc, sf, df, geom)
+    if rgbform == "blk" and geom == (1024, 64, 256, 16):       # (4 : 1 needs ten coefficient pairs: the walker's form only, from four frames a launch on)
+        assert k.startswith("scale_rgb_kernel"), k
+    else:
+        assert k == (RGBRGB if rgbform == "walk" else RGBBLK), k
 
 
-@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "spline"])
-def test_rgb_to_rgb_algorithms(dev, orc, flags, monkeypatch):
-    monkeypatch.setenv("GMAT_RGBSRC_WALKER", "2")
+@pytest.mark.parametrize("geom", [(128, 72, 384, 216), (160, 90, 640, 360), (96, 64, 700, 500), (200, 120, 260, 150), (1280, 40, 1600, 50), (644, 60, 1284, 90)],
+                         ids=lambda g: "%dx%d-%dx%d" % g)
+def test_rgb_to_rgb_block_form_up_scales(dev, orc, geom):
+    """up-scales of any factor: every output row is a gather down the LDS columns of filtered row pairs, so the number of rows open at once (the walker's
+    limit: 12) does not matter; several 64-column blocks with a partial last one, bands cut by the plane's end"""
+    for sf, df in (("rgb24", "rgb24"), ("bgr24", "rgba")):
+        assert _check(dev, orc, sf, df, geom) == RGBBLK
+    assert _check(dev, orc, "rgb24", "bgr24", geom, "lanczos") == RGBBLK
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "spline", "sinc", "bicublin", "x"])
+def test_rgb_to_rgb_algorithms(dev, orc, rgbform, flags):
     for geom in ((640, 128, 420, 84), (384, 216, 160, 90)):
         _check(dev, orc, "rgb24", "rgb24", geom, flags)
 
 
-def test_rgb_to_rgb_what_it_leaves_alone(dev, orc, monkeypatch):
-    """exactly 2 : 1 (its own strip walker), widths that are not multiples of four, two-tap vertical filters (yuv2rgb_full_2_c: bilinear up-scales), the knob"""
-    monkeypatch.setenv("GMAT_RGBSRC_WALKER", "2")
+def test_rgb_to_rgb_what_it_leaves_alone(dev, orc, rgbform, monkeypatch):
+    """exactly 2 : 1 (its own strip walker), widths that are not multiples of four, two-tap vertical filters (yuv2rgb_full_2_c: bilinear up-scales), the knobs"""
+    both = (RGBRGB, RGBBLK)
     assert _check(dev, orc, "rgb24", "rgb24", (512, 64, 256, 32)).startswith("scale_rgb2")
-    assert _check(dev, orc, "rgb24", "rgb24", (386, 216, 160, 90)) != RGBRGB
-    assert _check(dev, orc, "rgb24", "rgb24", (256, 144, 384, 216), "bilinear") != RGBRGB
+    assert _check(dev, orc, "rgb24", "rgb24", (386, 216, 160, 90)) not in both
+    assert _check(dev, orc, "rgb24", "rgb24", (256, 144, 384, 216), "bilinear") not in both
     monkeypatch.setenv("GMAT_SCALE_NO_WALKER16", "1")
+    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144)).startswith("scale_rgb_kernel")
+    monkeypatch.delenv("GMAT_SCALE_NO_WALKER16")
+    monkeypatch.setenv("GMAT_RGBSRC_WALKER", "0")
     assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144)).startswith("scale_rgb_kernel")
 
 
 def test_rgb_to_rgb_batches_and_bands(dev, orc, monkeypatch):
-    """the shipped rule: launches of four frames or more (alone the tiled kernel is faster: 13 against 17 us for a 1080p -> 720p frame)"""
-    assert _run_batch(dev, orc, "rgb24", "rgb24", 384, 216, 256, 144, nframes=3, nstreams=1, align=256).startswith("scale_rgb_kernel")
-    assert _run_batch(dev, orc, "rgb24", "rgb24", 384, 216, 256, 144, nframes=4, nstreams=1, align=256) == RGBRGB
-    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144)).startswith("scale_rgb_kernel")
+    """the shipped rule: the block form at every launch size; the walker's form where the block form has no instance (4 : 1: ten coefficient pairs) from
+    four frames a launch on, the tiled kernel below"""
+    for n in (1, 3, 4, 35):
+        assert _run_batch(dev, orc, "rgb24", "rgb24", 384, 216, 256, 144, nframes=n, nstreams=1, align=256) == RGBBLK
+    assert _run_batch(dev, orc, "bgr24", "bgra", 384, 216, 160, 90, nframes=5, nstreams=2, align=64) == RGBBLK
+    assert _run_batch(dev, orc, "rgb24", "rgb24", 1024, 64, 256, 16, nframes=3, nstreams=1, align=256).startswith("scale_rgb_kernel")
+    assert _run_batch(dev, orc, "rgb24", "rgb24", 1024, 64, 256, 16, nframes=4, nstreams=1, align=256) == RGBRGB
+    for rows in (4, 7, 12, 40):
+        monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+        assert _check(dev, orc, "rgb24", "bgr24", (520, 200, 172, 66), align=4, src_align=64) == RGBBLK
+        assert _check(dev, orc, "rgb24", "rgba", (200, 120, 520, 310), align=4, src_align=64) == RGBBLK
     monkeypatch.setenv("GMAT_RGBSRC_WALKER", "2")
+    monkeypatch.setenv("GMAT_RGBSRC_BLOCK", "0")
     assert _run_batch(dev, orc, "rgb24", "rgb24", 384, 216, 256, 144, nframes=5, nstreams=2, align=256) == RGBRGB
     assert _run_batch(dev, orc, "bgr24", "bgra", 384, 216, 160, 90, nframes=35, nstreams=1, align=64) == RGBRGB
     for rows in (4, 7, 40):
