@@ -289,6 +289,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
         const YuvGTables &t = c->yg;
         int k = 0;
         auto up = [&](const std::vector<int32_t> &v, const int32_t *&out) {
+            if (v.empty()) { out = nullptr; k++; return 0; }      // (an RGB up-scale has the fused block form only: no walker programs)
             int rr = c->dG[k].upload(v.data(), v.size() * 4);
             out = (const int32_t *)c->dG[k++].p;
             return rr;
@@ -300,6 +301,8 @@ static int init_yuv_scaler(GmatSwsContext *c)
             if (t.yuvOut && ((r = up(t.pc[d].prog, g.progC[d])) < 0 || (r = up(t.pc[d].qfirst, g.qfirstC[d])) < 0 || (r = up(t.pc[d].qdone, g.qdoneC[d])) < 0)) return r;
         }
         if ((r = up(t.vtL, g.vtL)) < 0 || (r = up(t.vtC, g.vtC)) < 0) return r;
+        if (!t.hCp.empty() && (r = up(t.hCp, g.hCp)) < 0) return r;      // (the fused block form of an RGB source: scale_yuvg_rgb2p_blk_kernel)
+        g.f2PPL = t.f2PPL; std::memcpy(g.f2Pairs, t.f2Pairs, sizeof(g.f2Pairs));
         g.n4L = t.n4L; g.n4C = t.n4C; g.blkRows = t.blkRows; g.blkRowsC = t.blkRowsC;
         g.roundL = t.roundL; g.roundC = t.roundC;
         g.P = t.P; g.K = t.K; g.yuvOut = t.yuvOut;
@@ -1084,6 +1087,7 @@ static const PlaneKernel kPlaneKernels[] = {
          return c->uargs.src16 ? launch_scale_yuvu16(make_yuvu_args(c, ya), st, &fr, n) : launch_scale_yuvu(make_yuvu_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuvg_eligible(c, ya); },                                    // any ratio: the polyphase band walker
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
+         if (c->gargs.src16 == 3 && yuvg_rgb2p_fused(make_yuvg_args(c, ya), n)) return "scale_yuvg_rgb2p_blk_kernel";       // (an RGB source: the fused block form)
          if (c->gargs.src16) return yuvg_block_form16(make_yuvg_args(c, ya), n) ? "scale_yuvg16_blk_kernel" : "scale_yuvg16_kernel";      // (16-bit samples: k_scale_yuvg16.hip)
          return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {

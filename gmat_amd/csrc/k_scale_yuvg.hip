@@ -1185,6 +1185,80 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_kernel(YuvGArgs a, Yuv2
     flush();
 }
 
+// ---- the converter of the block-cooperative RGB-source kernels: the two rows of a pair side by side in the wave's halves ------------------------------------
+// rgb24ToY_c / rgb24ToUV_c / rgb24ToUV_half_c's coefficients for a lane's byte order: bytes (0, 1) of a pixel as an int16 pair, byte 2 on its own
+struct GRgbConv {
+    int y01, y2, u01, u2, v01, v2;
+    __device__ __forceinline__ GRgbConv(const Rgb2YuvConsts &k, int bgr)
+    {
+        auto pk = [](int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); };
+        y01 = bgr ? pk(k.by, k.gy) : pk(k.ry, k.gy); y2 = bgr ? k.ry : k.by;
+        u01 = bgr ? pk(k.bu, k.gu) : pk(k.ru, k.gu); u2 = bgr ? k.ru : k.bu;
+        v01 = bgr ? pk(k.bv, k.gv) : pk(k.rv, k.gv); v2 = bgr ? k.rv : k.bv;
+    }
+};
+// PPL pixels of ONE row (raw: 3 PPL / 4 dwords) -> PPL luma samples and PPL (HALF: PPL / 2, of pixel pairs) samples of U and of V, into row `half` of the
+// wave's images at the lane's group of samples.  wantY / wantC (wave-uniform): lines nobody reads are not made
+template <bool HALF, int PPL>
+__device__ __forceinline__ void g_rgb_rows(const unsigned *raw, const GRgbConv &cv, unsigned *iy, unsigned *iu, unsigned *iv, int half, int grp, bool wantY, bool wantC)
+{
+    typedef GStream<4, false, 2, 1, 1> G1;
+    constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, NC = HALF ? PPL / 2 : PPL;
+    constexpr int KY = (32 << 14) + (1 << 8);                            // rgb24ToY_c: >> 9
+    int ys[PPL], us[NC], vs[NC];
+#pragma unroll
+    for (int h = 0; h < PPL / 4; h++) {
+        int fs[4], th[4];
+        G1::rgb4(raw + 3 * h, fs, th);
+        if (wantY) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) ys[4 * h + i] = g_dot2(fs[i], cv.y01, m24(th[i], cv.y2) + KY) >> 9;
+        }
+        if (wantC) {
+            if constexpr (HALF) {
+                constexpr int KC = (256 << 15) + (1 << 9);               // rgb24ToUV_half_c on a pair's sums: >> 10
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int fq = fs[2 * q] + fs[2 * q + 1], tq = th[2 * q] + th[2 * q + 1];           // (two 9-bit sums in the halves: no carry across)
+                    us[2 * h + q] = g_dot2(fq, cv.u01, m24(tq, cv.u2) + KC) >> 10;
+                    vs[2 * h + q] = g_dot2(fq, cv.v01, m24(tq, cv.v2) + KC) >> 10;
+                }
+            } else {
+                constexpr int KC = (256 << 14) + (1 << 8);               // rgb24ToUV_c: >> 9
+#pragma unroll
+                for (int i = 0; i < 4; i++) { us[4 * h + i] = g_dot2(fs[i], cv.u01, m24(th[i], cv.u2) + KC) >> 9; vs[4 * h + i] = g_dot2(fs[i], cv.v01, m24(th[i], cv.v2) + KC) >> 9; }
+            }
+        }
+    }
+    auto put = [&](unsigned *img, int pitch, const int *v, int n) {      // n samples of this lane's row into its image
+        unsigned *d = img + half * pitch + (n / 2) * grp;
+        if (n == 8) *reinterpret_cast<uint4 *>(d) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                                                (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+        else        *reinterpret_cast<uint2 *>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+    };
+    if (wantY) put(iy, IY, ys, PPL);
+    if (wantC) { put(iu, IC, us, NC); put(iv, IC, vs, NC); }
+}
+// a lane's column of the two rows of an image: hScale16To15_c (sh = 13) over 8-byte aligned windows, the two samples packed (the pack saturates at 32767)
+template <int P>
+__device__ __forceinline__ int g_rgb_hfilt(const unsigned *img, int pitch, int win, const int (&cf)[P])
+{
+    constexpr int NW = (P + 1) & ~1;
+    int h[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i += 2) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(img + r * pitch + win + i);
+            sum = g_dot2((int)t.x, cf[i], sum);
+            if (i + 1 < P) sum = g_dot2((int)t.y, cf[i + 1], sum);
+        }
+        h[r] = sum >> 13;
+    }
+    return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0], h[1]));
+}
+
 // ---- the same conversion, block-cooperative: a launch of few frames, up-scales, windows of any height (round 5) ---------------------------------------------
 // block = 64 output columns x a.bandRows output rows; grid.y = frame.  scale_yuvg_blk_rgb_kernel's two phases with THREE lines behind one load of the pixels:
 // (1) the band's source row pairs are dealt round the waves.  The two rows of a pair are converted SIDE BY SIDE — lanes 0-31 take row 2p, lanes 32-63 row
@@ -1231,13 +1305,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     const int winY = ((a.posL[xc] & ~3) - px0) >> 1, winC = ((a.posC[xc] & ~3) - (HALF ? px0 >> 1 : px0)) >> 1;
     const int half = lane >> 5, grp = lane & 31;
     const unsigned lbase = 3u * (unsigned)px0 + (unsigned)(3 * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
-    auto pk = [](int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); };
-    const Rgb2YuvConsts &k = a.r2y;
-    const int y01 = a.rgbBgr ? pk(k.by, k.gy) : pk(k.ry, k.gy), y2 = a.rgbBgr ? k.ry : k.by;
-    const int u01 = a.rgbBgr ? pk(k.bu, k.gu) : pk(k.ru, k.gu), u2 = a.rgbBgr ? k.ru : k.bu;
-    const int v01 = a.rgbBgr ? pk(k.bv, k.gv) : pk(k.rv, k.gv), v2 = a.rgbBgr ? k.rv : k.bv;
+    const GRgbConv cv(a.r2y, a.rgbBgr);
     unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0];
-    typedef GStream<P, false, 2, 1, 1> G1;
 
     const int sV = kGBlkHead + 4 * a.n4L;
     const int pa = uniform_load(a.vtL, y0 * sV), pb = uniform_load(a.vtL, (y1 - 1) * sV + 1);
@@ -1252,56 +1321,13 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
 #pragma unroll
     for (int j = 0; j < J; j++)
         if (pa + wave + 4 * j <= pb) {
-            constexpr int KY = (32 << 14) + (1 << 8);                    // rgb24ToY_c: >> 9
-            int ys[PPL], us[HALF ? PPL / 2 : PPL], vs[HALF ? PPL / 2 : PPL];
-#pragma unroll
-            for (int h = 0; h < PPL / 4; h++) {
-                int fs[4], th[4];
-                G1::rgb4(&ring[j][3 * h], fs, th);
-#pragma unroll
-                for (int i = 0; i < 4; i++) ys[4 * h + i] = g_dot2(fs[i], y01, m24(th[i], y2) + KY) >> 9;
-                if constexpr (HALF) {
-                    constexpr int KC = (256 << 15) + (1 << 9);           // rgb24ToUV_half_c on a pair's sums: >> 10
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int fq = fs[2 * q] + fs[2 * q + 1], tq = th[2 * q] + th[2 * q + 1];       // (two 9-bit sums in the halves: no carry across)
-                        us[2 * h + q] = g_dot2(fq, u01, m24(tq, u2) + KC) >> 10;
-                        vs[2 * h + q] = g_dot2(fq, v01, m24(tq, v2) + KC) >> 10;
-                    }
-                } else {
-                    constexpr int KC = (256 << 14) + (1 << 8);           // rgb24ToUV_c: >> 9
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { us[4 * h + i] = g_dot2(fs[i], u01, m24(th[i], u2) + KC) >> 9; vs[4 * h + i] = g_dot2(fs[i], v01, m24(th[i], v2) + KC) >> 9; }
-                }
-            }
-            auto put = [&](unsigned *img, int pitch, const int *v, int n) {      // n samples of this lane's row into its image
-                unsigned *d = img + half * pitch + (n / 2) * grp;
-                if (n == 8) *reinterpret_cast<uint4 *>(d) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
-                                                                        (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
-                else        *reinterpret_cast<uint2 *>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
-            };
             __builtin_amdgcn_wave_barrier();
-            put(iy, IY, ys, PPL); put(iu, IC, us, HALF ? PPL / 2 : PPL); put(iv, IC, vs, HALF ? PPL / 2 : PPL);
+            g_rgb_rows<HALF, PPL>(ring[j], cv, iy, iu, iv, half, grp, true, true);
             __builtin_amdgcn_wave_barrier();
-            auto hfilt = [&](const unsigned *img, int pitch, int win, const int (&cf)[P]) {
-                int h[2];
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    int sum = 0;
-#pragma unroll
-                    for (int i = 0; i < NW; i += 2) {
-                        const uint2 t = *reinterpret_cast<const uint2 *>(img + r * pitch + win + i);
-                        sum = g_dot2((int)t.x, cf[i], sum);
-                        if (i + 1 < P) sum = g_dot2((int)t.y, cf[i + 1], sum);
-                    }
-                    h[r] = sum >> 13;                                    // hScale16To15_c, sh = 13; the pack saturates at 32767
-                }
-                return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(h[0], h[1]));
-            };
             const int slot = wave + 4 * j;
-            hY[slot][lane] = hfilt(iy, IY, winY, cfY);
-            hU[slot][lane] = hfilt(iu, IC, winC, cfC);
-            hV[slot][lane] = hfilt(iv, IC, winC, cfC);
+            hY[slot][lane] = g_rgb_hfilt<P>(iy, IY, winY, cfY);
+            hU[slot][lane] = g_rgb_hfilt<P>(iu, IC, winC, cfC);
+            hV[slot][lane] = g_rgb_hfilt<P>(iv, IC, winC, cfC);
         }
     __syncthreads();
 
@@ -1343,6 +1369,119 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
         }
     }
 #undef GMAT_G_QUAD
+}
+// ---- packed RGB -> 4:2:0, block-cooperative and fused (round 5) -------------------------------------------------------------------------------------------------
+// scale_yuvg_blk_planes_kernel<.., SRC = 1> gives an RGB source three kinds of blocks — luma, U, V (or the interleaved chroma) — and every one of them loads
+// and unpacks the pixels for itself, both rows of a pair in every lane.  Here a block owns 64 luma columns x a.bandRows luma rows AND the chroma beside them
+// (32 columns x half the rows of U and of V): one load of the band's pixels, the converter of scale_yuvg_rgbsrc_blk_kernel (a pair's rows side by side in the
+// wave's halves), then lanes 0-63 filter the luma line's columns and — NV12: even / odd lanes, planar: the wave's halves — the U / V lines' columns; the
+// filtered pairs of both sit in LDS, one barrier, and the waves deal out the band's luma rows, then its chroma rows (each its own vertical table and
+// output stage: yuv2planeX_8_c / yuv2nv12cX_c).  The band's row pairs are the union of its luma and chroma windows; a pair outside one of them skips that line.
+template <int P, bool HALF, int PPL, int J>
+__global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Yuv2xFrames fr)
+{
+    static_assert(PPL == 4 || PPL == 8, "pixels a lane");
+    static_assert(!HALF || PPL == 8, "pixel pairs: eight pixels a lane");
+    constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, RD = (3 * PPL) / 4;
+    __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC];
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    int (*hY)[64] = reinterpret_cast<int (*)[64]>(lds_base);
+    int (*hC)[64] = hY + a.blkSlots;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lin = blockIdx.x;
+    if (a.xcdRemap) { const int chunk = (a.nblk + 7) >> 3; lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3); }
+    if (lin >= a.nblk) return;
+    const int band = lin / a.nsg;
+    const int X0 = (lin - band * a.nsg) * 64, C0 = X0 >> 1;
+    const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
+    const int cy0 = y0 >> 1, cy1 = min((y1 + 1) >> 1, a.chrDstH);
+    const int f = blockIdx.y;
+    const bool nv12 = a.nv12 != 0;
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + 3u * (unsigned)a.srcW);
+    const GPlane bY(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)a.dstW);
+    const int crow = nv12 ? 2 * a.chrDstW : a.chrDstW;
+    const GPlane bU(fr.dstU[f], (unsigned)a.dsU * (unsigned)(a.chrDstH - 1) + (unsigned)crow);
+    const GPlane bV(nv12 ? fr.dstU[f] : fr.dstV[f], (unsigned)(nv12 ? a.dsU : a.dsV) * (unsigned)(a.chrDstH - 1) + (unsigned)crow);
+
+    // this lane's luma column and its chroma column (NV12: component = lane & 1 of column lane >> 1; planar: component = lane >> 5 of column lane & 31)
+    const int xc = min(X0 + lane, a.dstW - 1);
+    const int comp = nv12 ? lane & 1 : lane >> 5;
+    const int cc = min(C0 + (nv12 ? lane >> 1 : lane & 31), a.chrDstW - 1);
+    int cfY[P], cfC[P];
+#pragma unroll
+    for (int t = 0; t < P; t++) { cfY[t] = a.hL[(size_t)xc * P + t]; cfC[t] = a.hCp[(size_t)cc * P + t]; }
+    const int sy0 = uniform_load(a.posL, X0) & ~3, sc0 = uniform_load(a.posC, min(C0, a.chrDstW - 1)) & ~3;
+    const int px0 = HALF ? min(sy0 & ~7, 2 * sc0) : min(sy0, sc0);
+    const int winY = ((a.posL[xc] & ~3) - px0) >> 1, winC = ((a.posC[cc] & ~3) - (HALF ? px0 >> 1 : px0)) >> 1;
+    const int half = lane >> 5, grp = lane & 31;
+    const unsigned lbase = 3u * (unsigned)px0 + (unsigned)(3 * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
+    const GRgbConv cv(a.r2y, a.rgbBgr);
+    unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0];
+    const unsigned *const ic = comp ? iv : iu;
+
+    const int sL = kGBlkHead + 4 * a.n4L, sC = kGBlkHead + 4 * a.n4C;
+    const int paL = uniform_load(a.vtL, y0 * sL), pbL = uniform_load(a.vtL, (y1 - 1) * sL + 1);
+    const bool anyC = cy1 > cy0;
+    const int paC = anyC ? uniform_load(a.vtC, cy0 * sC) : paL, pbC = anyC ? uniform_load(a.vtC, (cy1 - 1) * sC + 1) : paL - 1;
+    const int pa = min(paL, paC), pb = max(pbL, pbC);
+    unsigned ring[J][RD];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const unsigned off = (unsigned)(2 * min(pa + wave + 4 * j, pb)) * (unsigned)a.ys;
+#pragma unroll
+        for (int s = 0; s < RD; s++) bS.ld1(lbase + 4u * (unsigned)s, off, &ring[j][s]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int pair = pa + wave + 4 * j;
+        if (pair <= pb) {
+            const bool wantY = pair >= paL && pair <= pbL, wantC = pair >= paC && pair <= pbC;
+            __builtin_amdgcn_wave_barrier();
+            g_rgb_rows<HALF, PPL>(ring[j], cv, iy, iu, iv, half, grp, wantY, wantC);
+            __builtin_amdgcn_wave_barrier();
+            const int slot = wave + 4 * j;
+            if (wantY) hY[slot][lane] = g_rgb_hfilt<P>(iy, IY, winY, cfY);
+            if (wantC) hC[slot][lane] = g_rgb_hfilt<P>(ic, IC, winC, cfC);
+        }
+    }
+    __syncthreads();
+
+    // luma rows
+    {
+        GPlaneOut out;
+        out.set(a, xc);
+        for (int y = y0 + wave; y < y1; y += 4) {
+            const int32_t *rv = a.vtL + (size_t)y * sL;
+            const int acc = g_blk_vsum(rv, a.n4L, hY, uniform_load(rv, 0) - pa, lane, a.roundL);
+            out.store(bY, fr.dst[f], acc, X0, lane, a.dstW, (unsigned)y * (unsigned)a.ds, y);
+        }
+    }
+    // chroma rows
+    {
+        const int bcol = min(X0 + lane, crow - 1);
+        GPlaneOut out;
+        out.set(a, nv12 ? (bcol >> 1) + 3 * (bcol & 1) : cc + 3 * comp);
+        for (int y = cy0 + wave; y < cy1; y += 4) {
+            const int32_t *rv = a.vtC + (size_t)y * sC;
+            int acc = g_blk_vsum(rv, a.n4C, hC, uniform_load(rv, 0) - pa, lane, a.roundC);
+            if (nv12) { out.store(bU, fr.dstU[f], acc, X0, lane, crow, (unsigned)y * (unsigned)a.dsU, y); continue; }
+            // planar: GPlaneOut::store's 8-bit stage, lanes 0-31 into U's row, lanes 32-63 into V's
+            if (__builtin_amdgcn_readfirstlane(out.dither8)) acc += ((out.xpart ^ dither_8x8_128(0, y) ^ 36) - 64) << 12;
+            const unsigned v = (unsigned)clip_u8_shr(acc, 19);
+            const unsigned pr = v | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xF, 0xF, true) << 8);
+            const unsigned o = pr | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)pr, 0xAA, 0xF, 0xF, true) << 16);
+            const int l5 = lane & 31, nb = min(32, a.chrDstW - C0);
+            if ((lane & 3) == 0 && l5 < nb) {
+                const unsigned drowU = (unsigned)y * (unsigned)a.dsU, drowV = (unsigned)y * (unsigned)a.dsV;      // (wave-uniform: the store's scalar offset)
+                if (l5 + 4 <= nb) { if (comp) bV.st1(o, (unsigned)(C0 + l5), drowV); else bU.st1(o, (unsigned)(C0 + l5), drowU); }
+                else {
+                    uint8_t *d = (comp ? fr.dstV[f] + (size_t)drowV : fr.dstU[f] + (size_t)drowU) + (unsigned)(C0 + l5);
+                    for (int i = 0; i < nb - l5; i++) d[i] = (uint8_t)(o >> (8 * i));
+                }
+            }
+        }
+    }
 }
 #endif
 
@@ -1468,6 +1607,54 @@ static const int kGP[] = {4, 5, 6, 8, 10, 13};
 #endif
 static const int kGK[] = {4, 6, 7, 9}, kGKPlanes[] = {4, 6, 7, 9, 12, 15};
 
+#if G_BPS == 2
+// the fused block form of an RGB source into an 8-bit 4:2:0 frame (scale_yuvg_rgb2p_blk_kernel): the chroma's pairs on a PLANE's aligned windows, a
+// block's luma and chroma windows inside 32 lanes x PPL pixels from its first pixel on, and per band height the row pairs its windows span together.
+// t.vtL / t.vtC (g_blk_vtab) are there already
+static void g_rgb2p_tables(const ScalePlan &p, int P, YuvGTables &t)
+{
+    if (GMAT_KNOB("GMAT_RGBSRC_NO_FUSED") && atoi(GMAT_KNOB("GMAT_RGBSRC_NO_FUSED"))) return;
+    const int NW = (P + 1) & ~1;
+    const bool half = p.chrSrcHSub != 0;
+    bool ok = true;
+    t.hCp.assign((size_t)p.hChr.count * P, 0);
+    for (int x = 0; x < p.hChr.count && ok; x++) {
+        const int lead = p.hChr.pos[x] & 3;
+        if (p.hChr.pos[x] < 0 || p.hChr.pos[x] + p.hChr.taps > p.chrSrcW || lead + p.hChr.taps > 2 * P) ok = false;
+        for (int k = 0; k < P && ok; k++) {
+            const int t0 = 2 * k - lead, t1 = t0 + 1;
+            const int lo = t0 >= 0 && t0 < p.hChr.taps ? p.hChr.coef[(size_t)x * p.hChr.taps + t0] : 0, hi = t1 >= 0 && t1 < p.hChr.taps ? p.hChr.coef[(size_t)x * p.hChr.taps + t1] : 0;
+            t.hCp[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+        }
+    }
+    int ppl = half ? 8 : 4;
+    for (int c0 = 0; c0 < p.dstW && ok; c0 += 64) {
+        const int c1 = std::min(c0 + 64, p.dstW) - 1, k0 = std::min(c0 >> 1, p.chrDstW - 1), k1 = std::min((c0 >> 1) + 31, p.chrDstW - 1);
+        const int sy0 = p.hLum.pos[c0] & ~3, sc0 = p.hChr.pos[k0] & ~3;
+        const int px0 = half ? std::min(sy0 & ~7, 2 * sc0) : std::min(sy0, sc0), pc0 = half ? px0 / 2 : px0;
+        int endY = 0, endC = 0;
+        for (int x = c0; x <= c1 && ok; x++) { const int b = p.hLum.pos[x] & ~3; ok = b >= px0; endY = std::max(endY, b + 2 * NW - px0); }
+        for (int x = k0; x <= k1 && ok; x++) { const int b = p.hChr.pos[x] & ~3; ok = b >= pc0; endC = std::max(endC, b + 2 * NW - pc0); }
+        while (ppl <= 8 && (endY > 32 * ppl || endC > (half ? 16 : 32) * ppl)) ppl *= 2;
+        if (ppl > 8) ok = false;
+    }
+    if (!ok) { t.hCp.clear(); return; }
+    const int sL = kGBlkHead + 4 * t.n4L, sC = kGBlkHead + 4 * t.n4C;
+    for (int i = 1; i <= 16; i++) {
+        const int B = 4 * i;
+        int most = 0;
+        for (int y0 = 0; y0 < p.dstH; y0 += B) {
+            const int y1 = std::min(y0 + B, p.dstH), cy0 = y0 >> 1, cy1 = std::min((y1 + 1) >> 1, p.chrDstH);
+            int pa = t.vtL[(size_t)y0 * sL], pb = t.vtL[(size_t)(y1 - 1) * sL + 1];
+            if (cy1 > cy0) { pa = std::min(pa, t.vtC[(size_t)cy0 * sC]); pb = std::max(pb, t.vtC[(size_t)(cy1 - 1) * sC + 1]); }
+            most = std::max(most, pb - pa + 1);
+        }
+        t.f2Pairs[i] = most;
+    }
+    t.f2PPL = ppl;
+}
+#endif
+
 int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
     t = YuvGTables();
@@ -1481,6 +1668,39 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     // a packed RGB24 / BGR24 source into a 4:2:0 frame (the walker's own converter: GStream LK): the chroma of pixel PAIRS at full height — what libswscale
     // gives every such context that does not up-scale (utils.c:1529-1545); the jobs synthesise the DESTINATION's chroma layout, so "semi" follows it
     const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;
+    if (rgbSrc && yuvOut && !is_dst10(p.dstFormat) && !p.chrSrcHSub && !p.chrSrcVSub && p.chrSrcW == p.srcW && p.chrSrcH == p.srcH && !(p.srcW & 3) &&
+        g.yuvOut == 1 && p.dstW >= 16 && p.dstH >= 8 && p.srcW >= 16 && p.srcH >= 8) {
+        // an UP-scale (chroma from every pixel, utils.c:1529-1545): the fused block form alone — no walker instance (t.K = 0), no plane jobs
+        for (int v : g.lumRound) if (v != g.lumRound[0]) return 0;
+        for (int v : g.chrRound) if (v != g.chrRound[0]) return 0;
+        int need = 0;
+        for (const FilterBank *fb : {&p.hLum, &p.hChr})
+            for (int x = 0; x < fb->count; x++) {
+                if (fb->pos[x] < 0 || fb->pos[x] + fb->taps > p.srcW) return 0;
+                need = std::max(need, ((fb->pos[x] & 3) + fb->taps + 1) / 2);
+            }
+        if (need > 8) return 0;
+        const int P = std::max(need, 4);
+        t.hL.assign((size_t)p.hLum.count * P, 0);
+        for (int x = 0; x < p.hLum.count; x++) {
+            const int lead = p.hLum.pos[x] & 3;
+            for (int k = 0; k < P; k++) {
+                const int t0 = 2 * k - lead, t1 = t0 + 1;
+                const int lo = t0 >= 0 && t0 < p.hLum.taps ? p.hLum.coef[(size_t)x * p.hLum.taps + t0] : 0, hi = t1 >= 0 && t1 < p.hLum.taps ? p.hLum.coef[(size_t)x * p.hLum.taps + t1] : 0;
+                t.hL[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
+            }
+        }
+        t.posL = p.hLum.pos; t.posC = p.hChr.pos;
+        t.roundL = g.lumRound[0]; t.roundC = g.chrRound[0];
+        g_blk_vtab(g.vLumEff, t.vtL, t.n4L);
+        g_blk_vtab(g.vChrEff, t.vtC, t.n4C);
+        g_rgb2p_tables(p, P, t);
+        if (!t.f2PPL || t.f2Pairs[2] > 32) { t = YuvGTables(); return 0; }
+        t.hC = t.hCp;                                                  // (the walker's table slot: never read without an instance of it)
+        t.P = P; t.K = 0; t.yuvOut = 1;
+        t.ok = 1;
+        return 0;
+    }
     if (rgbSrc && (!yuvOut || !p.chrSrcHSub || p.chrSrcVSub || p.chrSrcW * 2 != p.srcW || p.chrSrcH != p.srcH || (p.srcW & 3))) return 0;
     const bool semiSrc = rgbSrc ? semiDst : is_p01x(p.srcFormat);
     if (!(rgbSrc || semiSrc || p.srcFormat == GMAT_PIX_FMT_YUV420P10LE || p.srcFormat == GMAT_PIX_FMT_YUV420P16LE) || !(rgbOut || yuvOut)) return 0;
@@ -1591,6 +1811,9 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
         if (t.n4L > 4 || t.n4C > 4) t.blkRows = 0;                    // (windows of more than 16 row pairs: the walker alone)
         if (G_BPS == 2 && P >= 10) t.blkRows = 0;                     // (16-bit samples, four dwords of a row per lane: 64 registers of requested pairs)
     }
+#if G_BPS == 2
+    if (rgbSrc && yuvOut && !is_dst10(p.dstFormat) && P <= 8) g_rgb2p_tables(p, P, t);
+#endif
     if (GMAT_KNOB("GMAT_DEBUG_WALKER")) logf(LOG_ERROR, "yuvg: %dx%d -> %dx%d taps h %d/%d v %d/%d -> P %d, K needed %d -> %d", p.srcW, p.srcH, p.dstW, p.dstH,
                                           p.hLum.taps, p.hChr.taps, g.vLumEff.taps, g.vChrEff.taps, P, needK, K);
     t.ok = 1;
@@ -1655,9 +1878,55 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
     return 0;
 }
 
+#if G_BPS == 2
+// a packed RGB source into an 8-bit 4:2:0 frame on the fused block form: an up-scale always (no other form), a down-scale from four frames a launch on — us a
+// frame, plane jobs (walker or its block form) / fused, rgb24 1080p -> 720p nv12: one frame 10.3 / 10.5, three 6.4 / 6.9, four 8.5 / 6.7, eight 6.4 / 5.2,
+// 32: 5.84 / 4.39; 4K -> 720p 17.4 / 18.5, 13.6 / 13.3, 15.8 / 12.3, 14.5 / 12.0, 12.3 / 11.25 (profiles/r05v_rgb2p_fused.txt): alone, three kinds of smaller
+// blocks fill the chip better than one.  GMAT_RGBSRC_FUSED=n: from n frames a launch on (1: always, 0: never)
+bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes)
+{
+    if (a.src16 != 3 || !a.yuvOut || !a.f2PPL || !a.hCp || !a.vtL || !a.vtC || a.f2Pairs[2] > 32) return false;
+    if (!a.K) return true;                                              // (an up-scale: no other form)
+    if (const char *fs = GMAT_KNOB("GMAT_RGBSRC_FUSED")) return atoi(fs) > 0 && nframes >= atoi(fs);
+    return nframes >= 4;
+}
+
+static int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+{
+    YuvGArgs a = a0;
+    const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
+    const int rowsEnv = rowsStr ? atoi(rowsStr) : 0;
+    a.nsg = (a.dstW + 63) / 64;
+    // the tallest band whose row pairs fit (32), then shorter ones until the launch has four blocks a CU (never below 8 rows)
+    int rows = 8;
+    for (int i = 16; i >= 2; i--) if (a.f2Pairs[i] <= 32) { rows = 4 * i; break; }
+    if (rowsEnv > 0) rows = std::min(rows, std::max(8, rowsEnv & ~3));
+    else while (rows > 8 && (long)a.nsg * ((a.dstH + rows - 1) / rows) * nframes < 1024) rows -= 4;
+    a.bandRows = rows;
+    a.nbands = (a.dstH + rows - 1) / rows;
+    a.nblkL = a.nblk = a.nbands * a.nsg;
+    const int J = a.f2Pairs[rows / 4] <= 16 ? 4 : 8;
+    a.blkSlots = 4 * J + 4 * std::max(a.n4L, a.n4C);
+    const size_t lds = (size_t)2 * a.blkSlots * 64 * 4;
+    const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
+    const bool half = a.chrSrcW != a.srcW;
+#define GMAT_R2(P_, H_, L_) do { if (J == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 4>), grid, block, lds, stream, a, fr); \
+                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 8>), grid, block, lds, stream, a, fr); } while (0)
+#define GMAT_R2P(P_) do { if (half) GMAT_R2(P_, true, 8); else if (a.f2PPL == 4) GMAT_R2(P_, false, 4); else GMAT_R2(P_, false, 8); } while (0)
+    switch (a.P) { case 4: GMAT_R2P(4); break; case 5: GMAT_R2P(5); break; case 6: GMAT_R2P(6); break; case 7: GMAT_R2P(7); break; default: GMAT_R2P(8); }
+#undef GMAT_R2P
+#undef GMAT_R2
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#endif
+
 int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
+#if G_BPS == 2
+    if (yuvg_rgb2p_fused(a0, nframes)) return launch_scale_yuvg_rgb2p(a0, stream, *frames, nframes);
+#endif
     if (G_NAME(yuvg_block_form)(a0, nframes)) return launch_scale_yuvg_blk(a0, stream, *frames, nframes);
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");          // tuning / test override, read per launch

@@ -344,6 +344,11 @@ struct YuvGTables {
     // packed RGB -> packed RGB, block-cooperative (scale_yuvg_rgbsrc_blk_kernel): the walker's form available at all (K), pixels a lane converts, the
     // tallest band on four row pairs a wave (blkRows: on eight)
     int walkOk = 0, blkPPL = 0, blkRows4 = 0;
+    // packed RGB -> 4:2:0, block-cooperative and FUSED (scale_yuvg_rgb2p_blk_kernel: luma and chroma of a band behind one load of the pixels): the chroma's
+    // coefficient pairs on 8-byte aligned windows of a PLANE's line whatever the destination's layout, pixels a lane converts (0: no instance), and per band
+    // height 4 i the most row pairs a band needs (luma and chroma windows together)
+    std::vector<int32_t> hCp;
+    int f2PPL = 0, f2Pairs[17] = {0};
 };
 struct YuvGArgs {
     int ys, us, vs, nv12;
@@ -358,6 +363,7 @@ struct YuvGArgs {
     // the block-cooperative form: vertical tables by output row, groups of 4 coefficient pairs a row, the tallest bands that fit
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
+    const int32_t *hCp; int f2PPL, f2Pairs[17];               // scale_yuvg_rgb2p_blk_kernel (YuvGTables')
     int blkPPL, blkRows4, blkSlots;                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
@@ -372,6 +378,7 @@ bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launc
 int  yuvg_prepare16(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
 int  launch_scale_yuvg16(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool yuvg_block_form16(const YuvGArgs &a, int nframes);
+bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes);        // a packed RGB source into a 4:2:0 frame: whether the launch takes scale_yuvg_rgb2p_blk_kernel
 // packed RGB24 / BGR24 -> packed RGB at the walker's ratios (scale_yuvg_rgbsrc_kernel in k_scale_yuvg16.hip): p = the RGB scaler's plan
 int  yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t);
 int  launch_scale_yuvg_rgbsrc(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);

@@ -67,7 +67,7 @@ def is_generic(kernel):
     (scale_yuvg_kernel: dword-aligned 8-bit 4:2:0 -> packed RGB / 4:2:0 of the same chroma layout, filters up to 20 x 18 taps) or
     the tiled plane scaler of round 1 behind it (scale_yuv_kernel<...>).  WHICH of the two a context gets is asserted by
     tests/test_parity_generic_walker.py clause by clause; the per-ratio test files only need "not a specialised walker"."""
-    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", QUAD, LINES, LINES16) + WALK16 or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4; QUAD: the quad-lane walker of up-scales, round 4)
+    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", QUAD, LINES, LINES16, RGB2P) + WALK16 or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4; QUAD: the quad-lane walker of up-scales, round 4)
 
 
 @pytest.fixture(autouse=True)
@@ -79,6 +79,7 @@ def ratio_kernels_keep_single_frames(monkeypatch):
 
 
 QUAD = "scale_yuvu_kernel"
+RGB2P = "scale_yuvg_rgb2p_blk_kernel"                     # a packed RGB source into an 8-bit 4:2:0 frame, block-cooperative and fused (k_scale_yuvg16.hip, round 5): up-scales, launches of four frames or more
 WALK16 = ("scale_yuvg16_kernel", "scale_yuvg16_blk_kernel", "scale_yuvu16_kernel")   # the band walker over 16-bit samples (k_scale_yuvg16.hip, round 5): P010 / P016 / planar 10- and 16-bit 4:2:0 sources; the quad-lane walker of their up-scales (k_scale_yuvu16.hip)
 LINES16 = "scale_yuvl_h16_kernel+scale_yuvl_v_kernel"  # ... its pass H for 16-bit samples (P010 / P016 / planar 10 / 16 bit sources)
 LINES = "scale_yuvl_h_kernel+scale_yuvl_v_kernel"     # the lines form (k_scale_yuvl.hip, round 4): what no walker takes, from 2 : 1 on the horizontal axis

@@ -126,35 +126,95 @@ RGBSRC_GEOMS = [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (
                 (384, 216, 380, 212)]
 
 
+FUSED = "scale_yuvg_rgb2p_blk_kernel"     # luma and chroma of a band behind ONE load of the pixels, a pair's rows converted side by side: the rule for 8-bit 4:2:0 frames
+
+
+@pytest.fixture(params=["walk", "blk", "fused"])
+def rgbp(request, monkeypatch):
+    """the three forms an RGB source into a 4:2:0 frame has, each at every launch size: the band walker's plane jobs, their block-cooperative form, and the
+    fused block form (8-bit destinations, filters of up to 16 coefficient pairs: the shipped rule from four frames a launch on, and for every up-scale)"""
+    if request.param != "fused":
+        monkeypatch.setenv("GMAT_RGBSRC_FUSED", "0")
+        monkeypatch.setenv("GMAT_STRIP_BLOCK", "0" if request.param == "walk" else "32")
+    else:
+        monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")       # (the shipped rule: from four frames a launch on)
+    return request.param
+
+
+def _rgbp_name(rgbp, df, geom):
+    if rgbp == "fused" and df != "p010le" and geom != (1024, 64, 256, 16):       # (4 : 1: ten coefficient pairs)
+        return (FUSED,)
+    return ("scale_yuvg16_kernel",) if rgbp == "walk" else W16
+
+
 @pytest.mark.parametrize("sf", ["rgb24", "bgr24"])
 @pytest.mark.parametrize("df", ["nv12", "yuv420p", "p010le"])
 @pytest.mark.parametrize("geom", RGBSRC_GEOMS, ids=lambda g: "%dx%d-%dx%d" % g)
-def test_walker16_packed_rgb_sources(dev, orc, form, sf, df, geom):
+def test_walker16_packed_rgb_sources(dev, orc, rgbp, sf, df, geom):
     """RGB24 / BGR24 -> NV12 / YUV420P (and their 10-bit twins) at the walker's down-scale ratios — the frames a network writes, scaled for an encoder.  One
     libswscale context: rgb24ToY_c on every pixel, rgb24ToUV_half_c on horizontal pixel pairs at full height (input.c:815-866), hScale16To15_c with sh = 13,
     the planar vertical stage.  These contexts ran the tiled kernel at 0.07 - 0.12 of the roofline (rgb24 4K -> 720p nv12: 42 us a frame)."""
     k = _check(dev, orc, sf, df, geom)
-    assert k in W16, k
-    if form == "walk":
-        assert k == "scale_yuvg16_kernel", k
+    assert k in _rgbp_name(rgbp, df, geom), k
 
 
-@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "point"])
-def test_walker16_packed_rgb_sources_algorithms(dev, orc, form, flags):
+@pytest.mark.parametrize("geom", [(384, 216, 258, 146), (520, 100, 174, 42), (1280, 40, 1000, 30), (644, 60, 322, 40), (388, 216, 130, 70), (640, 128, 422, 85)],
+                         ids=lambda g: "%dx%d-%dx%d" % g)
+def test_rgb_to_420_fused_edges(dev, orc, geom, monkeypatch):
+    """the fused block form at the edges: partial last blocks (luma and chroma), odd chroma sizes, widths that are multiples of four but not of eight, odd
+    destination heights (a last band whose chroma rows end first), rows at pitches that are not multiples of 64"""
+    monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")
+    for sf, df in (("rgb24", "nv12"), ("bgr24", "yuv420p")):
+        assert _check(dev, orc, sf, df, geom) == FUSED
+        assert _check(dev, orc, sf, df, geom, align=4, src_align=4) == FUSED
+
+
+@pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "point", "spline", "sinc"])
+def test_walker16_packed_rgb_sources_algorithms(dev, orc, rgbp, flags):
     for df in ("nv12", "yuv420p"):
         _check(dev, orc, "rgb24", df, (640, 128, 420, 84), flags)
         _check(dev, orc, "bgr24", df, (384, 216, 160, 90), flags)
 
 
-def test_walker16_packed_rgb_what_it_leaves_alone(dev, orc, form):
-    """up-scales (chroma from every pixel, not from pairs), widths that are not multiples of four, 2 : 1 (its own kernel), RGB destinations: not this form"""
-    assert _check(dev, orc, "rgb24", "nv12", (256, 144, 384, 216)) not in W16
-    assert _check(dev, orc, "rgb24", "nv12", (386, 216, 160, 90)) not in W16
+UP_RGB = [(256, 144, 384, 216), (128, 72, 384, 216), (160, 90, 640, 360), (96, 64, 700, 500), (200, 120, 260, 150), (1280, 40, 1600, 50), (644, 60, 1284, 90),
+          (132, 76, 200, 115)]
+
+
+@pytest.mark.parametrize("geom", UP_RGB, ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("flags", ["bicubic", "bilinear", "lanczos"])
+def test_rgb_to_420_up_scales(dev, orc, geom, flags):
+    """UP-scales of an RGB source into NV12 / YUV420P: the chroma of every pixel (rgb24ToUV_c: chrSrcHSubSample stays 0 once the destination's chroma is wider
+    than half the source, utils.c:1529-1545), any factor — the fused block form alone (no walker instance); before: the tiled kernel (720p -> 1080p 9.8 us)"""
+    for sf, df in (("rgb24", "nv12"), ("bgr24", "yuv420p")):
+        assert _check(dev, orc, sf, df, geom, flags) == FUSED
+    assert _check(dev, orc, "rgb24", "yuv420p", geom, flags, align=4, src_align=4) == FUSED
+
+
+def test_walker16_packed_rgb_what_it_leaves_alone(dev, orc, rgbp):
+    """up-scales into 10-bit frames, widths that are not multiples of four, 2 : 1 (its own kernel), RGB destinations: not these forms"""
+    ours = W16 + (FUSED,)
+    assert _check(dev, orc, "rgb24", "p010le", (256, 144, 384, 216)) not in ours
+    assert _check(dev, orc, "rgb24", "nv12", (256, 144, 384, 216)) == FUSED          # (whatever the knobs say: an up-scale has no other form here)
+    assert _check(dev, orc, "rgb24", "nv12", (386, 216, 160, 90)) not in ours
     assert _check(dev, orc, "rgb24", "nv12", (512, 64, 256, 32)) == "scale_rgb2y_kernel"
-    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 160, 90)) not in W16
+    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 160, 90)) not in ours
 
 
 def test_walker16_packed_rgb_batches(dev, orc, monkeypatch):
+    """the shipped rule: plane jobs (their block form) up to three frames a launch, the fused block form from four on; an up-scale: the fused form always"""
+    for df in ("nv12", "yuv420p"):
+        for n in (1, 3, 4, 5, 36):
+            k = _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=n, nstreams=1, align=256)
+            assert k == (FUSED if n >= 4 else "scale_yuvg16_blk_kernel"), (n, k)
+        assert _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=9, nstreams=2, align=64) == FUSED      # (launches of five and four frames)
+        assert _run_batch(dev, orc, "bgr24", df, 160, 90, 384, 216, nframes=2, nstreams=1, align=64) == FUSED
+    monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")
+    for rows in (4, 8, 12, 20, 64):
+        monkeypatch.setenv("GMAT_STRIP_ROWS", str(rows))
+        assert _check(dev, orc, "rgb24", "nv12", (520, 200, 172, 66), align=4, src_align=64) == FUSED
+        assert _check(dev, orc, "bgr24", "yuv420p", (520, 200, 300, 134), align=4, src_align=64) == FUSED
+    monkeypatch.delenv("GMAT_STRIP_ROWS")
+    monkeypatch.setenv("GMAT_RGBSRC_FUSED", "0")
     monkeypatch.setenv("GMAT_STRIP_BLOCK", "3")
     for df in ("nv12", "yuv420p"):
         assert _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=5, nstreams=2, align=256) in W16
