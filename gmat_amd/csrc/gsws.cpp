@@ -143,7 +143,7 @@ struct GmatSwsContext {
     Rgb2sTables r2s;              // strip-walking 2:1 form of the packed-RGB source scaler (k_scale_rgb2s.hip)
     YuvGTables rg;                // (round 5) any other ratio the band walker reaches: scale_yuvg_rgbsrc_kernel (k_scale_yuvg16.hip) ...
     YuvGArgs rgargs;              // ... its arguments but the call's pointers and pitches ...
-    DevBuf dRG[8];                // ... and device tables: hL, hC, posL, posC, prog, qfirst, qdone, vtL (the block-cooperative form's)
+    DevBuf dRG[9];                // ... and device tables: hL, hC, posL, posC, prog, qfirst, qdone, vtL (the block-cooperative form's)
     YuvGTables yg;                // the polyphase band walker for any ratio (k_scale_yuvg.hip)
     DevBuf dG[4 + 2 * 2 * 5];     // its device tables: hL, hC, posL, posC, then per (plane class, direction) coef / first / last / round / yLo
     YuvGArgs gargs;
@@ -378,7 +378,8 @@ static int init_scaler(GmatSwsContext *c)
         static const std::vector<int32_t> none;
         if ((r = up(t.hL, g.hL)) < 0 || (r = up(t.hC, g.hC)) < 0 || (r = up(t.posL, g.posL)) < 0 || (r = up(t.posC, g.posC)) < 0 ||
             (r = up(t.walkOk ? t.rgb[0].prog : none, g.prog[0])) < 0 || (r = up(t.walkOk ? t.rgb[0].qfirst : none, g.qfirst[0])) < 0 ||
-            (r = up(t.walkOk ? t.rgb[0].qdone : none, g.qdone[0])) < 0 || (r = up(t.blkRows ? t.vtL : none, g.vtL)) < 0) return r;
+            (r = up(t.walkOk ? t.rgb[0].qdone : none, g.qdone[0])) < 0 || (r = up(t.blkRows ? t.vtL : none, g.vtL)) < 0 ||
+            (r = up(t.blkRows ? t.vtRnd : none, g.vtRnd)) < 0) return r;
         g.P = t.P; g.K = t.K; g.roundL = t.roundL; g.roundC = t.roundC; g.src16 = 3; g.hShift = 13;
         g.n4L = t.n4L; g.blkRows = t.blkRows; g.blkRows4 = t.blkRows4; g.blkPPL = t.blkPPL;
         g.srcW = c->srcW; g.srcH = c->srcH; g.chrSrcW = c->plan.chrSrcW; g.chrSrcH = c->plan.chrSrcH;

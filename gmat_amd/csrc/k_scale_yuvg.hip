@@ -1337,7 +1337,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     for (int y = y0 + wave; y < y1; y += 4) {
         const int32_t *rv = a.vtL + (size_t)y * sV;
         const int base = uniform_load(rv, 0) - pa;
-        int accY = a.roundL, accU = a.roundC, accV = a.roundC;
+        const int rnd = uniform_load(a.vtRnd, y);                          // (1 << 9, or 0 in a row of yuv2rgb_full_2_c)
+        int accY = rnd, accU = rnd - (128 << 19), accV = accU;
         for (int g = 0; g < a.n4L; g++) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2011,7 +2012,8 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     if (p.chrDstW != p.dstW || p.chrDstH != p.dstH || p.chrSrcVSub || p.chrSrcH != p.srcH) return 0;
     if (!(p.chrSrcHSub == 0 ? p.chrSrcW == p.srcW : (p.chrSrcW * 2 == p.srcW && !(p.srcW & 7)))) return 0;
     // yuv2rgb_full_X_c proper (the one- and two-tap special forms of vscale.c:135-167 stay on the tiled kernel); the chroma's vertical filter is the luma's
-    if (p.vLum.taps < 3 || p.vChr.taps != p.vLum.taps || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return 0;
+    // (round 5, later: the block form takes those too — packed_vscale's forms differ from yuv2rgb_full_X_c in the sums' start alone, which it reads per output row)
+    if (p.vLum.taps < 1 || p.vChr.taps != p.vLum.taps || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return 0;
     if (p.hLum.count != p.dstW || p.hChr.count != p.dstW) return 0;
     auto lead = [](const FilterBank &fb, int x) { return fb.pos[x] & 3; };
     auto pairs_needed = [&](const FilterBank &fb) { int m = 0; for (int x = 0; x < fb.count; x++) m = std::max(m, lead(fb, x) + fb.taps); return (m + 1) / 2; };
@@ -2036,7 +2038,7 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
     // the band walker's form (scale_yuvg_rgbsrc_kernel): the running sums of one plane's program, a wave's 64 columns inside the row image its lanes fill
     int K = 0;
-    if (build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) {
+    if (p.vLum.taps >= 3 && build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) {
         for (int c : kGK) if (c >= t.rgb[0].K) { K = c; break; }
         if (!K && t.rgb[0].K <= 12 && P <= 8) K = 12;          // (ratios near 1 and up-scales: ten or eleven rows open over a quad of four source rows)
         const int SD = P >= 10 ? 4 : 2, NW = (P + 1) & ~1;
@@ -2050,7 +2052,18 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     // the block-cooperative form (scale_yuvg_rgbsrc_blk_kernel): windows of up to 16 row pairs, any number of rows open at once (up-scales); a block's
     // 64 columns inside 32 lanes x PPL pixels of a row, from the block's first pixel (the kernel's px0) on
     if (P <= 8 && !(GMAT_KNOB("GMAT_RGBSRC_NO_BLOCK") && atoi(GMAT_KNOB("GMAT_RGBSRC_NO_BLOCK")))) {
-        g_blk_vtab(p.vLum, t.vtL, t.n4L);
+        // packed_vscale's forms (vscale.c:135-160): one tap — the line as it is (yuv2rgb_full_1_c: the coefficient is never read: 4096 here, and the X form's
+        // rounding constant drops out of the shift); two taps that are a proper blend — yuv2rgb_full_2_c, no rounding constant (output.c:2118-2120);
+        // everything else yuv2rgb_full_X_c from 1 << 9.  The sums' start by output row: DevFilterStore::upload's rule for the tiled kernel (gsws.cpp)
+        FilterBank vb = p.vLum;
+        if (vb.taps == 1) std::fill(vb.coef.begin(), vb.coef.end(), (int16_t)4096);
+        t.vtRnd.assign(vb.count, 1 << 9);
+        if (vb.taps == 2)
+            for (int y = 0; y < vb.count; y++) {
+                const int f0 = vb.coef[(size_t)y * 2], f1 = vb.coef[(size_t)y * 2 + 1];
+                if (f0 + f1 == 4096 && (unsigned)f1 <= 4096u) t.vtRnd[y] = 0;
+            }
+        g_blk_vtab(vb, t.vtL, t.n4L);
         const bool half = p.chrSrcHSub != 0;
         const int NW = (P + 1) & ~1;
         int ppl = half ? 8 : 4;

@@ -344,6 +344,7 @@ struct YuvGTables {
     // packed RGB -> packed RGB, block-cooperative (scale_yuvg_rgbsrc_blk_kernel): the walker's form available at all (K), pixels a lane converts, the
     // tallest band on four row pairs a wave (blkRows: on eight)
     int walkOk = 0, blkPPL = 0, blkRows4 = 0;
+    std::vector<int32_t> vtRnd;                               // ... and the sums' start by output row (packed_vscale's one- and two-tap forms)
     // packed RGB -> 4:2:0, block-cooperative and FUSED (scale_yuvg_rgb2p_blk_kernel: luma and chroma of a band behind one load of the pixels): the chroma's
     // coefficient pairs on 8-byte aligned windows of a PLANE's line whatever the destination's layout, pixels a lane converts (0: no instance), and per band
     // height 4 i the most row pairs a band needs (luma and chroma windows together)
@@ -364,7 +365,7 @@ struct YuvGArgs {
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
     const int32_t *hCp; int f2PPL, f2Pairs[17];               // scale_yuvg_rgb2p_blk_kernel (YuvGTables')
-    int blkPPL, blkRows4, blkSlots;                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
+    int blkPPL, blkRows4, blkSlots; const int32_t *vtRnd;                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
     int src16, hShift, hBias, dst16, dstShift, dither8;

@@ -262,6 +262,17 @@ def test_rgb_to_rgb_block_form_up_scales(dev, orc, geom):
     assert _check(dev, orc, "rgb24", "bgr24", geom, "lanczos") == RGBBLK
 
 
+@pytest.mark.parametrize("geom", [(256, 144, 384, 216), (160, 90, 640, 360), (640, 640, 1920, 1080), (384, 216, 256, 216), (256, 100, 384, 100), (384, 216, 160, 90)],
+                         ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("flags", ["bilinear", "point", "area"])
+def test_rgb_to_rgb_one_and_two_tap_vertical_filters(dev, orc, geom, flags):
+    """packed_vscale's special forms (vscale.c:135-160): ONE vertical tap — equal heights, SWS_POINT: yuv2rgb_full_1_c takes the line as it is; TWO taps that
+    are a proper blend — bilinear up-scales: yuv2rgb_full_2_c, no rounding constant (output.c:2118-2120).  They differ from yuv2rgb_full_X_c in the sums'
+    start alone; the block form reads it per output row (the walker's form needs three taps or more: running sums from one start)"""
+    assert _check(dev, orc, "rgb24", "bgra", geom, flags) == RGBBLK
+    assert _check(dev, orc, "bgr24", "rgb24", geom, flags, align=4, src_align=4) == RGBBLK
+
+
 @pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "spline", "sinc", "bicublin", "x"])
 def test_rgb_to_rgb_algorithms(dev, orc, rgbform, flags):
     for geom in ((640, 128, 420, 84), (384, 216, 160, 90)):
@@ -269,11 +280,13 @@ def test_rgb_to_rgb_algorithms(dev, orc, rgbform, flags):
 
 
 def test_rgb_to_rgb_what_it_leaves_alone(dev, orc, rgbform, monkeypatch):
-    """exactly 2 : 1 (its own strip walker), widths that are not multiples of four, two-tap vertical filters (yuv2rgb_full_2_c: bilinear up-scales), the knobs"""
+    """exactly 2 : 1 (its own strip walker), widths that are not multiples of four, SWS_FAST_BILINEAR (an RGB source keeps its halved chroma: the plane
+    scaler), two-tap vertical filters on the walker's form, the knobs"""
     both = (RGBRGB, RGBBLK)
     assert _check(dev, orc, "rgb24", "rgb24", (512, 64, 256, 32)).startswith("scale_rgb2")
     assert _check(dev, orc, "rgb24", "rgb24", (386, 216, 160, 90)) not in both
-    assert _check(dev, orc, "rgb24", "rgb24", (256, 144, 384, 216), "bilinear") not in both
+    assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144), "fast_bilinear") not in both
+    assert _check(dev, orc, "rgb24", "rgb24", (256, 144, 384, 216), "bilinear") == RGBBLK         # (whatever the knobs say: the walker's form has no instance)
     monkeypatch.setenv("GMAT_SCALE_NO_WALKER16", "1")
     assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144)).startswith("scale_rgb_kernel")
     monkeypatch.delenv("GMAT_SCALE_NO_WALKER16")
