@@ -48,6 +48,11 @@
 #else
 #define G_NAME(n) n
 #endif
+// G_PART (the 16-bit build is TWO translation units, so that its kernels compile side by side — k_scale_yuvg16.hip and k_scale_yuvg16b.hip): 0 = everything;
+// 1 = everything but the launchers of the block-cooperative RGB-source kernels (whose instances are the launchers' alone); 2 = those launchers alone
+#ifndef G_PART
+#define G_PART 0
+#endif
 
 namespace gmat {
 #if G_BPS == 2
@@ -1656,6 +1661,32 @@ static void g_rgb2p_tables(const ScalePlan &p, int P, YuvGTables &t)
 }
 #endif
 
+#if G_BPS == 2
+// the plane jobs of a packed RGB source (scale_yuvg_planes_kernel / scale_yuvg_blk_planes_kernel with SRC = 1): launched for launch_scale_yuvg16 with its
+// arguments and grid as they are; the instances live in the second translation unit
+int launch_yuvg_planes_rgbsrc(const YuvGArgs &a, dim3 grid, hipStream_t stream, const Yuv2xFrames &fr, bool blk);
+#if G_PART != 1
+int launch_yuvg_planes_rgbsrc(const YuvGArgs &a, dim3 grid, hipStream_t stream, const Yuv2xFrames &fr, bool blk)
+{
+    const dim3 block(256);
+#define GMAT_PB(P_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true, 1>), grid, block, 0, stream, a, fr); \
+                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false, 1>), grid, block, 0, stream, a, fr); } while (0)
+#define GMAT_PL(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true, 1>), grid, block, 0, stream, a, fr); \
+                             else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false, 1>), grid, block, 0, stream, a, fr); } while (0)
+#define GMAT_PP(P_) do { if (blk) GMAT_PB(P_); else switch (a.K) { case 4: GMAT_PL(P_, 4); break; case 6: GMAT_PL(P_, 6); break; case 7: GMAT_PL(P_, 7); break; \
+                                                                   case 9: GMAT_PL(P_, 9); break; case 12: GMAT_PL(P_, 12); break; default: GMAT_PL(P_, 15); } } while (0)
+    switch (a.P) { case 4: GMAT_PP(4); break; case 5: GMAT_PP(5); break; case 6: GMAT_PP(6); break; case 7: GMAT_PP(7); break; case 8: GMAT_PP(8); break;
+                   case 10: GMAT_PP(10); break; default: GMAT_PP(13); }
+#undef GMAT_PP
+#undef GMAT_PL
+#undef GMAT_PB
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+#endif
+#endif
+
+#if G_PART != 2
 int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables &t)
 {
     t = YuvGTables();
@@ -1859,14 +1890,10 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
     }
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
 #if G_BPS == 2
-#define GMAT_GB_RGBSRC(P_) if (a.src16 == 3) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true, 1>), grid, block, 0, stream, a, fr); \
-                                               else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false, 1>), grid, block, 0, stream, a, fr); } else
-#else
-#define GMAT_GB_RGBSRC(P_)
+    if (a.yuvOut && a.src16 == 3) return launch_yuvg_planes_rgbsrc(a, grid, stream, fr, true);        // (their instances: k_scale_yuvg16b.hip)
 #endif
 #define GMAT_GB(P_) do { \
-        if (a.yuvOut) { GMAT_GB_RGBSRC(P_) \
-                        if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true>), grid, block, 0, stream, a, fr); \
+        if (a.yuvOut) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_planes_kernel<P_, false>), grid, block, 0, stream, a, fr); } \
         else          { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, true>), grid, block, 0, stream, a, fr); \
                         else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_blk_rgb_kernel<P_, false>), grid, block, 0, stream, a, fr); } } while (0)
@@ -1879,11 +1906,13 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
     return 0;
 }
 
+#endif  // G_PART != 2
 #if G_BPS == 2
 // a packed RGB source into an 8-bit 4:2:0 frame on the fused block form: an up-scale always (no other form), a down-scale from four frames a launch on — us a
 // frame, plane jobs (walker or its block form) / fused, rgb24 1080p -> 720p nv12: one frame 10.3 / 10.5, three 6.4 / 6.9, four 8.5 / 6.7, eight 6.4 / 5.2,
 // 32: 5.84 / 4.39; 4K -> 720p 17.4 / 18.5, 13.6 / 13.3, 15.8 / 12.3, 14.5 / 12.0, 12.3 / 11.25 (profiles/r05v_rgb2p_fused.txt): alone, three kinds of smaller
 // blocks fill the chip better than one.  GMAT_RGBSRC_FUSED=n: from n frames a launch on (1: always, 0: never)
+#if G_PART != 2
 bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes)
 {
     if (a.src16 != 3 || !a.yuvOut || !a.f2PPL || !a.hCp || !a.vtL || !a.vtC || a.f2Pairs[2] > 32) return false;
@@ -1891,8 +1920,10 @@ bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes)
     if (const char *fs = GMAT_KNOB("GMAT_RGBSRC_FUSED")) return atoi(fs) > 0 && nframes >= atoi(fs);
     return nframes >= 4;
 }
-
-static int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+#endif
+int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes);
+#if G_PART != 1
+int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
 {
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
@@ -1920,8 +1951,10 @@ static int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
+#endif  // G_PART != 1
 #endif
 
+#if G_PART != 2
 int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
@@ -1966,13 +1999,9 @@ int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     const Yuv2xFrames &fr = *frames;
 #if G_BPS == 2
-#define GMAT_G_PL_RGBSRC(P_, K_) if (a.src16 == 3) { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true, 1>), grid, block, 0, stream, a, fr); \
-                                                     else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false, 1>), grid, block, 0, stream, a, fr); } else
-#else
-#define GMAT_G_PL_RGBSRC(P_, K_)
+    if (a.yuvOut && a.src16 == 3) return launch_yuvg_planes_rgbsrc(a, grid, stream, fr, false);       // (their instances: k_scale_yuvg16b.hip)
 #endif
-#define GMAT_G_PL(P_, K_) do { GMAT_G_PL_RGBSRC(P_, K_) \
-                               if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
+#define GMAT_G_PL(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
                                else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_planes_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
 #define GMAT_G_RGB(P_, K_) do { if (a.nv12) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, true>), grid, block, 0, stream, a, fr); \
                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb_kernel<P_, K_, false>), grid, block, 0, stream, a, fr); } while (0)
@@ -1995,9 +2024,12 @@ int G_NAME(launch_scale_yuvg)(const YuvGArgs &a0, hipStream_t stream, const Yuv2
     return 0;
 }
 
+#endif  // G_PART != 2
+
 #if G_BPS == 2
 // ---- packed RGB -> packed RGB (scale_yuvg_rgbsrc_kernel) ---------------------------------------------------------------------------------------------------
 // p: the RGB scaler's plan (gsws.cpp init_scaler: full-chroma output, the chroma lines at full height and full or half width)
+#if G_PART != 2
 int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
 {
     t = YuvGTables();
@@ -2109,8 +2141,10 @@ bool yuvg_rgbsrc_block_form(const YuvGArgs &a, int nframes)
     if (const char *bs = GMAT_KNOB("GMAT_RGBSRC_BLOCK")) return nframes <= atoi(bs);
     return true;
 }
-
-static int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
+#endif
+int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes);
+#if G_PART != 1
+int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes)
 {
     YuvGArgs a = a0;
     const char *rowsStr = GMAT_KNOB("GMAT_STRIP_ROWS");
@@ -2136,7 +2170,9 @@ static int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, 
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
+#endif  // G_PART != 1
 
+#if G_PART != 2
 int launch_scale_yuvg_rgbsrc(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames) return GMAT_ERR(EINVAL);
@@ -2170,6 +2206,7 @@ int launch_scale_yuvg_rgbsrc(const YuvGArgs &a0, hipStream_t stream, const Yuv2x
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
+#endif  // G_PART != 2
 #endif
 
 } // namespace gmat

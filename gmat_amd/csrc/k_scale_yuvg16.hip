@@ -6,4 +6,5 @@
 // instruction for instruction — this file IS that file, compiled with two bytes a sample (namespace gmat::g16, entry points *16).
 // Before it these contexts ran the lines form's two passes (k_scale_yuvl.hip: P010 4K -> 900p 18 us a frame, 1080p -> 720p 7.9) or the tiled kernel.
 #define G_BPS 2
+#define G_PART 1            // (the block-cooperative RGB-source kernels' launchers: k_scale_yuvg16b.hip)
 #include "k_scale_yuvg.hip"
