@@ -1239,7 +1239,8 @@ __device__ __forceinline__ void g_rgb_rows(const unsigned *raw, const GRgbConv &
         unsigned *d = img + half * pitch + (n / 2) * grp;
         if (n == 8) *reinterpret_cast<uint4 *>(d) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
                                                                 (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
-        else        *reinterpret_cast<uint2 *>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+        else if (n == 4) *reinterpret_cast<uint2 *>(d) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+        else        *d = (unsigned)v[0] | ((unsigned)v[1] << 16);
     };
     if (wantY) put(iy, IY, ys, PPL);
     if (wantC) { put(iu, IC, us, NC); put(iv, IC, vs, NC); }
@@ -1387,7 +1388,7 @@ template <int P, bool HALF, int PPL, int J>
 __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     static_assert(PPL == 4 || PPL == 8, "pixels a lane");
-    static_assert(!HALF || PPL == 8, "pixel pairs: eight pixels a lane");
+    // (pixel pairs at four pixels a lane: two chroma samples, one image dword — ratios below 1.75 : 1, whose 64 columns span fewer than 128 pixels)
     constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, RD = (3 * PPL) / 4;
     __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC];
     HIP_DYNAMIC_SHARED(uint4, lds_base)
@@ -1633,7 +1634,7 @@ static void g_rgb2p_tables(const ScalePlan &p, int P, YuvGTables &t)
             t.hCp[(size_t)x * P + k] = (int32_t)((uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16));
         }
     }
-    int ppl = half ? 8 : 4;
+    int ppl = 4;
     for (int c0 = 0; c0 < p.dstW && ok; c0 += 64) {
         const int c1 = std::min(c0 + 64, p.dstW) - 1, k0 = std::min(c0 >> 1, p.chrDstW - 1), k1 = std::min((c0 >> 1) + 31, p.chrDstW - 1);
         const int sy0 = p.hLum.pos[c0] & ~3, sc0 = p.hChr.pos[k0] & ~3;
@@ -1908,17 +1909,18 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
 
 #endif  // G_PART != 2
 #if G_BPS == 2
-// a packed RGB source into an 8-bit 4:2:0 frame on the fused block form: an up-scale always (no other form), a down-scale from four frames a launch on — us a
-// frame, plane jobs (walker or its block form) / fused, rgb24 1080p -> 720p nv12: one frame 10.3 / 10.5, three 6.4 / 6.9, four 8.5 / 6.7, eight 6.4 / 5.2,
-// 32: 5.84 / 4.39; 4K -> 720p 17.4 / 18.5, 13.6 / 13.3, 15.8 / 12.3, 14.5 / 12.0, 12.3 / 11.25 (profiles/r05v_rgb2p_fused.txt): alone, three kinds of smaller
-// blocks fill the chip better than one.  GMAT_RGBSRC_FUSED=n: from n frames a launch on (1: always, 0: never)
+// a packed RGB source into an 8-bit 4:2:0 frame on the fused block form: an up-scale always (no other form); a down-scale below 1.75 : 1 (four pixels a lane:
+// a block's 64 columns span fewer than 128 pixels) always too — us a frame, plane jobs (walker or its block form) / fused, rgb24 1080p -> 720p nv12: one frame 10.2 /
+// 8.7, two 7.7 / 7.1, four 8.6 / 5.7, 32: 5.84 / 3.46; beyond (eight pixels a lane) from three frames a launch on — 4K -> 720p: one 17.5 / 18.4, two 14.5 / 14.6,
+// three 13.5 / 13.3, four 15.7 / 12.3, 32: 12.2 / 11.26 (profiles/r05v_rgb2p_fused.txt): alone, three kinds of smaller blocks fill the chip better than one whose
+// chroma window is 40 % of its row pairs.  GMAT_RGBSRC_FUSED=n: from n frames a launch on (1: always, 0: never)
 #if G_PART != 2
 bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes)
 {
     if (a.src16 != 3 || !a.yuvOut || !a.f2PPL || !a.hCp || !a.vtL || !a.vtC || a.f2Pairs[2] > 32) return false;
     if (!a.K) return true;                                              // (an up-scale: no other form)
     if (const char *fs = GMAT_KNOB("GMAT_RGBSRC_FUSED")) return atoi(fs) > 0 && nframes >= atoi(fs);
-    return nframes >= 4;
+    return a.f2PPL == 4 || nframes >= 3;
 }
 #endif
 int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xFrames &fr, int nframes);
@@ -1944,7 +1946,8 @@ int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xF
     const bool half = a.chrSrcW != a.srcW;
 #define GMAT_R2(P_, H_, L_) do { if (J == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 4>), grid, block, lds, stream, a, fr); \
                                  else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 8>), grid, block, lds, stream, a, fr); } while (0)
-#define GMAT_R2P(P_) do { if (half) GMAT_R2(P_, true, 8); else if (a.f2PPL == 4) GMAT_R2(P_, false, 4); else GMAT_R2(P_, false, 8); } while (0)
+#define GMAT_R2P(P_) do { if (half) { if (a.f2PPL == 4) GMAT_R2(P_, true, 4); else GMAT_R2(P_, true, 8); } \
+                          else      { if (a.f2PPL == 4) GMAT_R2(P_, false, 4); else GMAT_R2(P_, false, 8); } } while (0)
     switch (a.P) { case 4: GMAT_R2P(4); break; case 5: GMAT_R2P(5); break; case 6: GMAT_R2P(6); break; case 7: GMAT_R2P(7); break; default: GMAT_R2P(8); }
 #undef GMAT_R2P
 #undef GMAT_R2

@@ -52,7 +52,7 @@ for case in range(n):
         df = rng.choice(["rgb24", "bgr24", "rgba", "bgra"] + 3 * ["nv12" if semi else "yuv420p"] + 3 * ["p010le" if semi else "yuv420p10le"])
         if rng.random() < 0.15:
             os.environ["GMAT_SCALE_NO_WALKER16"] = "1"
-    elif rng.random() < 0.12:
+    elif rng.random() < (0.8 if "--rgbsrc" in sys.argv else 0.12):      # (--rgbsrc: mostly packed RGB sources — the block-cooperative kernels of round 5's second half)
         # round 5: a packed RGB source into a 4:2:0 frame (the 16-bit walker's converter; up-scales and odd widths: whatever serves them)
         sf = rng.choice(["rgb24", "bgr24"])
         df = rng.choice(["nv12", "yuv420p", "nv12", "yuv420p", "p010le", "rgb24", "bgr24", "rgba", "bgra"])     # (RGB -> RGB: scale_yuvg_rgbsrc_kernel from four frames a launch on)

@@ -132,12 +132,12 @@ FUSED = "scale_yuvg_rgb2p_blk_kernel"     # luma and chroma of a band behind ONE
 @pytest.fixture(params=["walk", "blk", "fused"])
 def rgbp(request, monkeypatch):
     """the three forms an RGB source into a 4:2:0 frame has, each at every launch size: the band walker's plane jobs, their block-cooperative form, and the
-    fused block form (8-bit destinations, filters of up to 16 coefficient pairs: the shipped rule from four frames a launch on, and for every up-scale)"""
+    fused block form (8-bit destinations, filters of up to 16 coefficient pairs: the shipped rule below 1.75 : 1, from three frames a launch on, and for every up-scale)"""
     if request.param != "fused":
         monkeypatch.setenv("GMAT_RGBSRC_FUSED", "0")
         monkeypatch.setenv("GMAT_STRIP_BLOCK", "0" if request.param == "walk" else "32")
     else:
-        monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")       # (the shipped rule: from four frames a launch on)
+        monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")       # (the shipped rule: from three frames a launch on beyond 1.75 : 1)
     return request.param
 
 
@@ -201,12 +201,15 @@ def test_walker16_packed_rgb_what_it_leaves_alone(dev, orc, rgbp):
 
 
 def test_walker16_packed_rgb_batches(dev, orc, monkeypatch):
-    """the shipped rule: plane jobs (their block form) up to three frames a launch, the fused block form from four on; an up-scale: the fused form always"""
+    """the shipped rule: below 1.75 : 1 (four pixels a lane) and for every up-scale the fused block form always; beyond (eight pixels a lane) from three
+    frames a launch on, plane jobs (their block form) below"""
     for df in ("nv12", "yuv420p"):
-        for n in (1, 3, 4, 5, 36):
+        for n in (1, 2, 3, 5, 35):
             k = _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=n, nstreams=1, align=256)
-            assert k == (FUSED if n >= 4 else "scale_yuvg16_blk_kernel"), (n, k)
-        assert _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=9, nstreams=2, align=64) == FUSED      # (launches of five and four frames)
+            assert k == (FUSED if n >= 3 else "scale_yuvg16_blk_kernel"), (n, k)
+        assert _run_batch(dev, orc, "rgb24", df, 384, 216, 160, 90, nframes=7, nstreams=2, align=64) == FUSED      # (launches of four and three frames)
+        for n in (1, 2, 4):
+            assert _run_batch(dev, orc, "bgr24", df, 384, 216, 256, 144, nframes=n, nstreams=1, align=256) == FUSED
         assert _run_batch(dev, orc, "bgr24", df, 160, 90, 384, 216, nframes=2, nstreams=1, align=64) == FUSED
     monkeypatch.setenv("GMAT_RGBSRC_FUSED", "1")
     for rows in (4, 8, 12, 20, 64):
