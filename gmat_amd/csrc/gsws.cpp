@@ -168,6 +168,7 @@ struct GmatSwsContext {
     int lastLaunchFrames = 1;
     // RGBA / BGRA sources of the scaling / RGB -> YUV paths: alpha dropped into `inter` (RGB24 / BGR24), then `inner`
     GmatSwsContext *inner = nullptr;
+    int px4 = 0, px4Alpha = 0;    // (set around ONE call by the RGBA / BGRA context in front of this one: the source pixels are four bytes wide — scale_yuvg_rgbsrc_blk_kernel reads them as they are)
     // RGBA64LE / BGRA64LE sources (MODE_VIA_PLANES16): rgb64ToY / ToUV(_half) into Y / U / V planes of 16-bit samples, then `inner`
     // — the planar-16 context with an RGB source's chroma geometry (k_rgb64.hip)
     DevBuf planes16;
@@ -639,6 +640,7 @@ static YuvGArgs make_yuvg_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
     g.dstW = ya.dstW; g.dstH = ya.dstH; g.chrDstW = ya.chrDstW; g.chrDstH = c->planYuv.chrDstH;
     g.ds = ya.ds; g.dsU = ya.dsU; g.dsV = ya.dsV; g.dstFormat = ya.dstFormat;
     g.xcdRemap = ya.xcdRemap; g.y2r = ya.y2r;
+    g.srcPx = c->px4 ? 4 : 3;
     return g;
 }
 
@@ -1139,7 +1141,20 @@ static YuvGArgs make_rg_args(const GmatSwsContext *c, int srcStride, int dstStri
     YuvGArgs g = c->rgargs;
     g.ys = srcStride; g.ds = dstStride;
     g.r2y = c->args.r2y; g.y2r = c->args.y2r; g.xcdRemap = c->args.xcdRemap;
+    g.srcPx = c->px4 ? 4 : 3; g.srcAlpha = c->px4 ? c->px4Alpha : 0;
     return g;
+}
+
+// an RGBA / BGRA source in front of this (24-bit) context: whether a call of n frames lands on the block-cooperative RGB -> RGB kernel, which reads four-byte
+// pixels as they are (and scales their alpha channel as a fourth line) — the 32 -> 24-bit pass and the alpha passes of MODE_VIA_INNER are then not run
+static bool rg_block_takes_px4(GmatSwsContext *in, int n, const uint8_t *src, int ss, const uint8_t *dst, int ds)
+{
+    if (!in || in->mode != MODE_SCALE || in->prof || in->inner || in->rgbViaPlanes) return false;
+    if (!(in->srcFormat == GMAT_PIX_FMT_RGB24 || in->srcFormat == GMAT_PIX_FMT_BGR24) || !is_packed_rgb(in->dstFormat)) return false;
+    if (const char *k = GMAT_KNOB("GMAT_RGBSRC_NO_PX4")) if (atoi(k)) return false;
+    if (const char *rw = GMAT_KNOB("GMAT_RGBSRC_WALKER")) if (!atoi(rw)) return false;
+    if (ensure_scaler(in) < 0 || in->r2s.ok || !in->rg.ok) return false;
+    return al4(src, ss) && al4(dst, ds) && yuvg_rgbsrc_block_form(in->rgargs, std::min(n, kYuv2xMaxFrames));
 }
 
 // the fused convert-then-scale form on the same kernel: a YUV 4:2:0 source converted lane by lane with the FIRST context's closed-form
@@ -1287,6 +1302,22 @@ static void cross_planes(const GmatSwsContext *c, uint8_t *base, uint8_t *pl[4],
     if (c->srcFormat == GMAT_PIX_FMT_YUV420P) { st[1] = st[2] = c->crossPitch / 2; pl[2] = pl[1] + (size_t)st[1] * ch; }
 }
 
+// ... or, into a 4:2:0 frame, on the fused block form of the plane scaler's table (scale_yuvg_rgb2p_blk_kernel: the one entry that reads four-byte pixels)
+static bool planes_fused_takes_px4(GmatSwsContext *in, int n, const uint8_t *const src[], const int srcStride[], uint8_t *const dst[], const int dstStride[])
+{
+    if (!in || in->mode != MODE_SCALE || in->prof || in->inner || !in->rgbViaPlanes || in->fused != 2) return false;
+    if (const char *k = GMAT_KNOB("GMAT_RGBSRC_NO_PX4")) if (atoi(k)) return false;
+    if (ensure_scaler(in) < 0 || in->fused != 2) return false;
+    YuvScaleArgs ya;
+    if (prep_yuv_args(in, src, srcStride, dst, dstStride, ya) < 0) return false;
+    in->px4 = 1;
+    int pick = 0;
+    while (!kPlaneKernels[pick].eligible(in, ya, n)) pick++;
+    const bool ok = !std::strcmp(kPlaneKernels[pick].name(in, ya, n), "scale_yuvg_rgb2p_blk_kernel");
+    in->px4 = 0;
+    return ok;
+}
+
 static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
                                          uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream);
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
@@ -1310,6 +1341,19 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
     // the common precheck of every branch below: profiling contexts (per-launch phase stamps) and cascades go frame by frame
     if (off || c->prof) return 0;
     if (int r = check_device(c, "gmat_sws_scale_batch"); r < 0) return r;
+    if (c->mode == MODE_VIA_INNER && c->inner) {
+        // an RGBA / BGRA source whose 24-bit context lands on the block-cooperative RGB -> RGB kernel: that context's launches, reading the pixels as they are
+        for (int f = 0; f < n; f++) {
+            if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
+            if (!rg_block_takes_px4(c->inner, n, src_planes[4 * f], srcStride[0], dst_planes[4 * f], dstStride[0]) &&
+                !planes_fused_takes_px4(c->inner, n, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride)) return 0;
+        }
+        c->inner->px4 = 1; c->inner->px4Alpha = c->needAlpha;
+        const int t = sws_scale_frames_batched_impl(c->inner, n, src_planes, srcStride, dst_planes, dstStride, stream);
+        c->inner->px4 = 0; c->inner->px4Alpha = 0;
+        c->lastKernel = c->inner->lastKernel; c->lastLaunchFrames = c->inner->lastLaunchFrames;
+        return t;
+    }
     if (c->mode == MODE_YUV2RGB) {
         // the same-size converter: one launch per 32 frames, grid.z = frame
         const bool planar = c->srcFormat == GMAT_PIX_FMT_YUV420P;
@@ -1645,6 +1689,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
             fr.dst[i] = dp[0]; fr.dstU[i] = yuvDst ? dp[1] : nullptr; fr.dstV[i] = planarDst ? dp[2] : nullptr;
         }
         c->lastKernel = K.name(c, ya0, m);
+        if (c->px4 && std::strcmp(c->lastKernel, "scale_yuvg_rgb2p_blk_kernel")) return GMAT_ERR(EINVAL);
         int r = K.launch(c, ya0, stream, fr, m);
         if (r < 0) return r;
         c->lastLaunchFrames = m;
@@ -2193,6 +2238,15 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         break;
     }
     case MODE_VIA_INNER: {
+        if (rg_block_takes_px4(c->inner, 1, src[0], srcStride[0], dst[0], dstStride[0]) || planes_fused_takes_px4(c->inner, 1, src, srcStride, dst, dstStride)) {
+            gmat_sws_setStream(c->inner, (void *)c->stream);
+            c->inner->px4 = 1; c->inner->px4Alpha = c->needAlpha;
+            r = gmat_sws_scale(c->inner, src, srcStride, 0, c->srcH, dst, dstStride);
+            c->inner->px4 = 0; c->inner->px4Alpha = 0;
+            c->lastKernel = c->inner->lastKernel;
+            if (r >= 0) return r;
+            break;
+        }
         if (!c->inter) {
             c->interStride = align_up(c->srcW * 3, 256);
             if (hipMalloc((void **)&c->inter, (size_t)c->interStride * c->srcH) != hipSuccess) { r = GMAT_ERR(ENOMEM); break; }
@@ -2438,6 +2492,7 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             int pick = 0;
             while (!kPlaneKernels[pick].eligible(c, ya, 1)) pick++;
             c->lastKernel = kPlaneKernels[pick].name(c, ya, 1);
+            if (c->px4 && std::strcmp(c->lastKernel, "scale_yuvg_rgb2p_blk_kernel")) { r = GMAT_ERR(EINVAL); break; }      // (four-byte pixels were promised the kernel that reads them)
             r = kPlaneKernels[pick].launch(c, ya, c->stream, one, 1);
             break;
         }
@@ -2515,6 +2570,7 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             r = launch_scale_yuvg_rgbsrc(make_rg_args(c, a.ss0, a.ds), c->stream, &one, 1);
             break;
         }
+        if (c->px4) { r = GMAT_ERR(EINVAL); break; }              // (four-byte pixels were promised a kernel that reads them)
         c->lastKernel = scale_kernel_name(a, c->tiling);
         r = launch_scale_rgb(a, c->tiling, c->stream);
         break;

@@ -1204,17 +1204,29 @@ struct GRgbConv {
 };
 // PPL pixels of ONE row (raw: 3 PPL / 4 dwords) -> PPL luma samples and PPL (HALF: PPL / 2, of pixel pairs) samples of U and of V, into row `half` of the
 // wave's images at the lane's group of samples.  wantY / wantC (wave-uniform): lines nobody reads are not made
-template <bool HALF, int PPL>
-__device__ __forceinline__ void g_rgb_rows(const unsigned *raw, const GRgbConv &cv, unsigned *iy, unsigned *iu, unsigned *iv, int half, int grp, bool wantY, bool wantC)
+// BPX = 4: RGBA / BGRA pixels (rgb32ToY / ToUV read the same three channels with the same coefficients and ignore the fourth byte, input.c rgb16_32
+// templates); ia != nullptr: the alpha line too — rgbaToA_c's a << 6 | a >> 2 (input.c:442-449), filtered like the luma line
+template <bool HALF, int PPL, int BPX = 3>
+__device__ __forceinline__ void g_rgb_rows(const unsigned *raw, const GRgbConv &cv, unsigned *iy, unsigned *iu, unsigned *iv, int half, int grp, bool wantY, bool wantC,
+                                           unsigned *ia = nullptr)
 {
     typedef GStream<4, false, 2, 1, 1> G1;
     constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, NC = HALF ? PPL / 2 : PPL;
     constexpr int KY = (32 << 14) + (1 << 8);                            // rgb24ToY_c: >> 9
-    int ys[PPL], us[NC], vs[NC];
+    int ys[PPL], us[NC], vs[NC], as[PPL];
 #pragma unroll
     for (int h = 0; h < PPL / 4; h++) {
         int fs[4], th[4];
-        G1::rgb4(raw + 3 * h, fs, th);
+        if constexpr (BPX == 3) G1::rgb4(raw + 3 * h, fs, th);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned d = raw[4 * h + i];
+                fs[i] = (int)__builtin_amdgcn_perm(d, d, 0x0C010C00u);
+                th[i] = (int)__builtin_amdgcn_perm(d, d, 0x0C0C0C02u);
+                as[4 * h + i] = (int)(((d >> 18) & 0x3FC0u) | (d >> 26));                       // a << 6 | a >> 2
+            }
+        }
         if (wantY) {
 #pragma unroll
             for (int i = 0; i < 4; i++) ys[4 * h + i] = g_dot2(fs[i], cv.y01, m24(th[i], cv.y2) + KY) >> 9;
@@ -1244,6 +1256,7 @@ __device__ __forceinline__ void g_rgb_rows(const unsigned *raw, const GRgbConv &
     };
     if (wantY) put(iy, IY, ys, PPL);
     if (wantC) { put(iu, IC, us, NC); put(iv, IC, vs, NC); }
+    if constexpr (BPX == 4) { if (ia) put(ia, IY, as, PPL); }
 }
 // a lane's column of the two rows of an image: hScale16To15_c (sh = 13) over 8-byte aligned windows, the two samples packed (the pack saturates at 32767)
 template <int P>
@@ -1275,18 +1288,20 @@ __device__ __forceinline__ int g_rgb_hfilt(const unsigned *img, int pitch, int w
 //     yuv2rgb_full_X_c's shifts, yuv2rgb_write_full.
 // HALF: chroma from pixel pairs (2 : 1 and beyond).  PPL = 4 where every block's segment fits 128 pixels, 8 otherwise (HALF: always 8).  J: row pairs a wave
 // requests at once.  The filtered pairs sit in dynamic LDS: 3 x a.blkSlots x 64 dwords.
-template <int P, bool HALF, int PPL, int J>
+// BPX = 4: an RGBA / BGRA source read as it is (no 32 -> 24-bit pass in front); ALPHA: its fourth byte is a fourth line — with an alpha channel at both ends
+// libswscale scales the alpha plane through the luma filters (needAlpha, utils.c:1902) and yuv2rgb_full_X_c writes (2^18 + sum) >> 19 (output.c:2069-2077)
+template <int P, bool HALF, int PPL, int J, int BPX = 3, bool ALPHA = false>
 __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     static_assert(PPL == 4 || PPL == 8, "pixels a lane");
     static_assert(!HALF || PPL == 8, "pixel pairs: eight pixels a lane");
-    constexpr int NW = (P + 1) & ~1;                         // window dwords
+    static_assert(!ALPHA || BPX == 4, "an alpha line: four bytes a pixel");
     constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY;    // dwords of a row image: 32 lanes x PPL samples (chroma of pixel pairs: half of them)
-    constexpr int RD = (3 * PPL) / 4;                        // raw dwords a lane
-    __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC];
+    constexpr int RD = (BPX * PPL) / 4;                      // raw dwords a lane
+    __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC], imgA[ALPHA ? 4 : 1][2][ALPHA ? IY : 2];
     HIP_DYNAMIC_SHARED(uint4, lds_base)
     int (*hY)[64] = reinterpret_cast<int (*)[64]>(lds_base);
-    int (*hU)[64] = hY + a.blkSlots, (*hV)[64] = hU + a.blkSlots;
+    int (*hU)[64] = hY + a.blkSlots, (*hV)[64] = hU + a.blkSlots, (*hA)[64] = hV + a.blkSlots;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lin = blockIdx.x;
@@ -1296,7 +1311,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     const int X0 = (lin - band * a.nsg) * 64;
     const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
     const int f = blockIdx.y;
-    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + 3u * (unsigned)a.srcW);
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)BPX * (unsigned)a.srcW);
     const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
     const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
     const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
@@ -1310,9 +1325,9 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     const int px0 = HALF ? min(sy0 & ~7, 2 * sc0) : min(sy0, sc0);
     const int winY = ((a.posL[xc] & ~3) - px0) >> 1, winC = ((a.posC[xc] & ~3) - (HALF ? px0 >> 1 : px0)) >> 1;
     const int half = lane >> 5, grp = lane & 31;
-    const unsigned lbase = 3u * (unsigned)px0 + (unsigned)(3 * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
+    const unsigned lbase = (unsigned)BPX * (unsigned)px0 + (unsigned)(BPX * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
     const GRgbConv cv(a.r2y, a.rgbBgr);
-    unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0];
+    unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0], *const ia = ALPHA ? imgA[ALPHA ? wave : 0][0] : nullptr;
 
     const int sV = kGBlkHead + 4 * a.n4L;
     const int pa = uniform_load(a.vtL, y0 * sV), pb = uniform_load(a.vtL, (y1 - 1) * sV + 1);
@@ -1328,12 +1343,13 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     for (int j = 0; j < J; j++)
         if (pa + wave + 4 * j <= pb) {
             __builtin_amdgcn_wave_barrier();
-            g_rgb_rows<HALF, PPL>(ring[j], cv, iy, iu, iv, half, grp, true, true);
+            g_rgb_rows<HALF, PPL, BPX>(ring[j], cv, iy, iu, iv, half, grp, true, true, ia);
             __builtin_amdgcn_wave_barrier();
             const int slot = wave + 4 * j;
             hY[slot][lane] = g_rgb_hfilt<P>(iy, IY, winY, cfY);
             hU[slot][lane] = g_rgb_hfilt<P>(iu, IC, winC, cfC);
             hV[slot][lane] = g_rgb_hfilt<P>(iv, IC, winC, cfC);
+            if constexpr (ALPHA) hA[slot][lane] = g_rgb_hfilt<P>(ia, IY, winY, cfY);
         }
     __syncthreads();
 
@@ -1344,20 +1360,23 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
         const int32_t *rv = a.vtL + (size_t)y * sV;
         const int base = uniform_load(rv, 0) - pa;
         const int rnd = uniform_load(a.vtRnd, y);                          // (1 << 9, or 0 in a row of yuv2rgb_full_2_c)
-        int accY = rnd, accU = rnd - (128 << 19), accV = accU;
+        int accY = rnd, accU = rnd - (128 << 19), accV = accU, accA = 1 << 18;
         for (int g = 0; g < a.n4L; g++) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int c = uniform_load(rv, kGBlkHead + 4 * g + i), s = base + 4 * g + i;
                 accY = g_dot2(hY[s][lane], c, accY); accU = g_dot2(hU[s][lane], c, accU); accV = g_dot2(hV[s][lane], c, accV);
+                if constexpr (ALPHA) accA = g_dot2(hA[s][lane], c, accA);
             }
         }
+        unsigned a8 = 255u;
+        if constexpr (ALPHA) { int A = accA >> 19; if (A & 0x100) A = min(max(A, 0), 255); a8 = (unsigned)A & 0xFFu; }       // (clipped when bit 8 is set, as the writer does)
         const int Y = accY >> 10, U = accU >> 10, V = accV >> 10;
         // yuv2rgb_write_full (output.c:1886-1935): scale_yuvg_rgbsrc_kernel's emit()
         const int yy = m24(Y - a.y2r.y_offset, a.y2r.y_coeff) + (1 << 21);
         const int R = yy + m24(V, a.y2r.v2r), G = yy + m24(V, a.y2r.v2g) + m24(U, a.y2r.u2g), B = yy + m24(U, a.y2r.u2b);
         const unsigned r8 = (unsigned)min(max(R, 0), 0x3FFFFFFF) >> 22, g8 = (unsigned)min(max(G, 0), 0x3FFFFFFF) >> 22, b8 = (unsigned)min(max(B, 0), 0x3FFFFFFF) >> 22;
-        const unsigned px = (bgr ? b8 : r8) | (g8 << 8) | ((bgr ? r8 : b8) << 16) | 0xFF000000u;
+        const unsigned px = (bgr ? b8 : r8) | (g8 << 8) | ((bgr ? r8 : b8) << 16) | (a8 << 24);
         const unsigned drow = (unsigned)y * (unsigned)a.ds;
         if (bpp == 4) {
             if (x < a.dstW) bD.st1(px, 4u * (unsigned)x, drow);
@@ -1384,12 +1403,13 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
 // wave's halves), then lanes 0-63 filter the luma line's columns and — NV12: even / odd lanes, planar: the wave's halves — the U / V lines' columns; the
 // filtered pairs of both sit in LDS, one barrier, and the waves deal out the band's luma rows, then its chroma rows (each its own vertical table and
 // output stage: yuv2planeX_8_c / yuv2nv12cX_c).  The band's row pairs are the union of its luma and chroma windows; a pair outside one of them skips that line.
-template <int P, bool HALF, int PPL, int J>
+// BPX = 4: an RGBA / BGRA source read as it is (its fourth byte ignored)
+template <int P, bool HALF, int PPL, int J, int BPX = 3>
 __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Yuv2xFrames fr)
 {
     static_assert(PPL == 4 || PPL == 8, "pixels a lane");
     // (pixel pairs at four pixels a lane: two chroma samples, one image dword — ratios below 1.75 : 1, whose 64 columns span fewer than 128 pixels)
-    constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, RD = (3 * PPL) / 4;
+    constexpr int IY = 16 * PPL, IC = HALF ? IY / 2 : IY, RD = (BPX * PPL) / 4;
     __shared__ __attribute__((aligned(16))) unsigned imgY[4][2][IY], imgU[4][2][IC], imgV[4][2][IC];
     HIP_DYNAMIC_SHARED(uint4, lds_base)
     int (*hY)[64] = reinterpret_cast<int (*)[64]>(lds_base);
@@ -1405,7 +1425,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Y
     const int cy0 = y0 >> 1, cy1 = min((y1 + 1) >> 1, a.chrDstH);
     const int f = blockIdx.y;
     const bool nv12 = a.nv12 != 0;
-    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + 3u * (unsigned)a.srcW);
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)BPX * (unsigned)a.srcW);
     const GPlane bY(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)a.dstW);
     const int crow = nv12 ? 2 * a.chrDstW : a.chrDstW;
     const GPlane bU(fr.dstU[f], (unsigned)a.dsU * (unsigned)(a.chrDstH - 1) + (unsigned)crow);
@@ -1422,7 +1442,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Y
     const int px0 = HALF ? min(sy0 & ~7, 2 * sc0) : min(sy0, sc0);
     const int winY = ((a.posL[xc] & ~3) - px0) >> 1, winC = ((a.posC[cc] & ~3) - (HALF ? px0 >> 1 : px0)) >> 1;
     const int half = lane >> 5, grp = lane & 31;
-    const unsigned lbase = 3u * (unsigned)px0 + (unsigned)(3 * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
+    const unsigned lbase = (unsigned)BPX * (unsigned)px0 + (unsigned)(BPX * PPL) * (unsigned)grp + (unsigned)half * (unsigned)a.ys;
     const GRgbConv cv(a.r2y, a.rgbBgr);
     unsigned *const iy = imgY[wave][0], *const iu = imgU[wave][0], *const iv = imgV[wave][0];
     const unsigned *const ic = comp ? iv : iu;
@@ -1445,7 +1465,7 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Y
         if (pair <= pb) {
             const bool wantY = pair >= paL && pair <= pbL, wantC = pair >= paC && pair <= pbC;
             __builtin_amdgcn_wave_barrier();
-            g_rgb_rows<HALF, PPL>(ring[j], cv, iy, iu, iv, half, grp, wantY, wantC);
+            g_rgb_rows<HALF, PPL, BPX>(ring[j], cv, iy, iu, iv, half, grp, wantY, wantC);
             __builtin_amdgcn_wave_barrier();
             const int slot = wave + 4 * j;
             if (wantY) hY[slot][lane] = g_rgb_hfilt<P>(iy, IY, winY, cfY);
@@ -1918,7 +1938,7 @@ static int launch_scale_yuvg_blk(const YuvGArgs &a0, hipStream_t stream, const Y
 bool yuvg_rgb2p_fused(const YuvGArgs &a, int nframes)
 {
     if (a.src16 != 3 || !a.yuvOut || !a.f2PPL || !a.hCp || !a.vtL || !a.vtC || a.f2Pairs[2] > 32) return false;
-    if (!a.K) return true;                                              // (an up-scale: no other form)
+    if (!a.K || a.srcPx == 4) return true;                              // (an up-scale: no other form; four-byte pixels: no other form reads them)
     if (const char *fs = GMAT_KNOB("GMAT_RGBSRC_FUSED")) return atoi(fs) > 0 && nframes >= atoi(fs);
     return a.f2PPL == 4 || nframes >= 3;
 }
@@ -1944,13 +1964,16 @@ int launch_scale_yuvg_rgb2p(const YuvGArgs &a0, hipStream_t stream, const Yuv2xF
     const size_t lds = (size_t)2 * a.blkSlots * 64 * 4;
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     const bool half = a.chrSrcW != a.srcW;
-#define GMAT_R2(P_, H_, L_) do { if (J == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 4>), grid, block, lds, stream, a, fr); \
-                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, 8>), grid, block, lds, stream, a, fr); } while (0)
+    const bool px4 = a.srcPx == 4;
+#define GMAT_R2J(P_, H_, L_, J_) do { if (px4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, J_, 4>), grid, block, lds, stream, a, fr); \
+                                      else     hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgb2p_blk_kernel<P_, H_, L_, J_>), grid, block, lds, stream, a, fr); } while (0)
+#define GMAT_R2(P_, H_, L_) do { if (J == 4) GMAT_R2J(P_, H_, L_, 4); else GMAT_R2J(P_, H_, L_, 8); } while (0)
 #define GMAT_R2P(P_) do { if (half) { if (a.f2PPL == 4) GMAT_R2(P_, true, 4); else GMAT_R2(P_, true, 8); } \
                           else      { if (a.f2PPL == 4) GMAT_R2(P_, false, 4); else GMAT_R2(P_, false, 8); } } while (0)
     switch (a.P) { case 4: GMAT_R2P(4); break; case 5: GMAT_R2P(5); break; case 6: GMAT_R2P(6); break; case 7: GMAT_R2P(7); break; default: GMAT_R2P(8); }
 #undef GMAT_R2P
 #undef GMAT_R2
+#undef GMAT_R2J
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2161,15 +2184,20 @@ int launch_scale_yuvg_rgbsrc_blk(const YuvGArgs &a0, hipStream_t stream, const Y
     a.nblkL = a.nblk = a.nbands * a.nsg;
     const int J = rows <= a.blkRows4 ? 4 : 8;
     a.blkSlots = 4 * J + 4 * a.n4L;
-    const size_t lds = (size_t)3 * a.blkSlots * 64 * 4;
+    const bool px4 = a.srcPx == 4, alpha = px4 && a.srcAlpha;
+    const size_t lds = (size_t)(alpha ? 4 : 3) * a.blkSlots * 64 * 4;
     const dim3 grid(a.xcdRemap ? 8 * ((a.nblk + 7) / 8) : a.nblk, nframes), block(256);
     const bool half = a.chrSrcW != a.srcW;
-#define GMAT_RB(P_, H_, L_) do { if (J == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, 4>), grid, block, lds, stream, a, fr); \
-                                 else        hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, 8>), grid, block, lds, stream, a, fr); } while (0)
+#define GMAT_RBJ(P_, H_, L_, J_) do { \
+        if (alpha)    hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, J_, 4, true>), grid, block, lds, stream, a, fr); \
+        else if (px4) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, J_, 4, false>), grid, block, lds, stream, a, fr); \
+        else          hipLaunchKernelGGL(HIP_KERNEL_NAME(scale_yuvg_rgbsrc_blk_kernel<P_, H_, L_, J_>), grid, block, lds, stream, a, fr); } while (0)
+#define GMAT_RB(P_, H_, L_) do { if (J == 4) GMAT_RBJ(P_, H_, L_, 4); else GMAT_RBJ(P_, H_, L_, 8); } while (0)
 #define GMAT_RB_P(P_) do { if (half) GMAT_RB(P_, true, 8); else if (a.blkPPL == 4) GMAT_RB(P_, false, 4); else GMAT_RB(P_, false, 8); } while (0)
     switch (a.P) { case 4: GMAT_RB_P(4); break; case 5: GMAT_RB_P(5); break; case 6: GMAT_RB_P(6); break; case 7: GMAT_RB_P(7); break; default: GMAT_RB_P(8); }
 #undef GMAT_RB_P
 #undef GMAT_RB
+#undef GMAT_RBJ
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

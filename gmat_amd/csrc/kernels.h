@@ -365,7 +365,8 @@ struct YuvGArgs {
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
     const int32_t *hCp; int f2PPL, f2Pairs[17];               // scale_yuvg_rgb2p_blk_kernel (YuvGTables')
-    int blkPPL, blkRows4, blkSlots; const int32_t *vtRnd;                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
+    int blkPPL, blkRows4, blkSlots; const int32_t *vtRnd;
+    int srcPx, srcAlpha;                                      // ... (per call) 4: the source is RGBA / BGRA pixels read as they are; its alpha channel is a fourth line                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
     int src16, hShift, hBias, dst16, dstShift, dither8;

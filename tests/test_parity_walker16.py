@@ -276,6 +276,43 @@ def test_rgb_to_rgb_one_and_two_tap_vertical_filters(dev, orc, geom, flags):
     assert _check(dev, orc, "bgr24", "rgb24", geom, flags, align=4, src_align=4) == RGBBLK
 
 
+@pytest.mark.parametrize("geom", [(384, 216, 256, 144), (384, 216, 160, 90), (256, 144, 384, 216), (520, 100, 172, 40), (200, 120, 260, 150), (384, 216, 161, 91),
+                                  (256, 100, 384, 100)], ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("pair", [("rgba", "rgb24"), ("bgra", "bgra"), ("rgba", "bgra"), ("bgra", "bgr24")], ids=lambda p: "%s-%s" % p)
+def test_rgba_sources_are_read_as_they_are(dev, orc, pair, geom, monkeypatch):
+    """RGBA / BGRA sources (rgb32ToY / ToUV: the 24-bit readers' coefficients on the same three channels): the block form reads four-byte pixels itself — no
+    32 -> 24-bit pass in front — and, with an alpha channel at both ends, scales alpha as a FOURTH line (rgbaToA_c's a << 6 | a >> 2, the luma filters on both
+    axes, yuv2rgb_full_X_c's (2^18 + sum) >> 19: needAlpha, utils.c:1902) instead of two more passes behind.  The same bytes with GMAT_RGBSRC_NO_PX4=1"""
+    sf, df = pair
+    assert _check(dev, orc, sf, df, geom) == RGBBLK
+    assert _check(dev, orc, sf, df, geom, "bilinear" if geom[0] >= 2 * geom[2] else "lanczos", align=4, src_align=4) == RGBBLK
+    monkeypatch.setenv("GMAT_RGBSRC_NO_PX4", "1")
+    _check(dev, orc, sf, df, geom)
+
+
+@pytest.mark.parametrize("geom", [(384, 216, 256, 144), (384, 216, 160, 90), (256, 144, 384, 216), (520, 100, 172, 40), (388, 216, 130, 70), (640, 128, 422, 85)],
+                         ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("pair", [("rgba", "nv12"), ("bgra", "yuv420p"), ("bgra", "nv12")], ids=lambda p: "%s-%s" % p)
+def test_rgba_sources_into_420_are_read_as_they_are(dev, orc, pair, geom, monkeypatch):
+    """... and into NV12 / YUV420P: the fused block form reads the four-byte pixels (at every launch size: no other entry of the plane scaler's table does)"""
+    sf, df = pair
+    assert _check(dev, orc, sf, df, geom) == FUSED
+    assert _check(dev, orc, sf, df, geom, "bilinear", align=4, src_align=4) == FUSED
+    monkeypatch.setenv("GMAT_RGBSRC_NO_PX4", "1")
+    _check(dev, orc, sf, df, geom)
+
+
+def test_rgba_sources_batches(dev, orc):
+    for n in (2, 5, 34):
+        assert _run_batch(dev, orc, "bgra", "nv12", 384, 216, 160, 90, nframes=n, nstreams=1, align=256) == FUSED
+    assert _run_batch(dev, orc, "rgba", "yuv420p", 256, 144, 384, 216, nframes=3, nstreams=2, align=64) == FUSED
+
+    for n in (2, 5, 35):
+        assert _run_batch(dev, orc, "bgra", "bgra", 384, 216, 256, 144, nframes=n, nstreams=1, align=256) == RGBBLK
+    assert _run_batch(dev, orc, "rgba", "rgb24", 384, 216, 160, 90, nframes=5, nstreams=2, align=64) == RGBBLK
+    assert _run_batch(dev, orc, "rgba", "bgra", 256, 144, 384, 216, nframes=3, nstreams=1, align=64) == RGBBLK
+
+
 @pytest.mark.parametrize("flags", ["bilinear", "lanczos", "area", "gauss", "spline", "sinc", "bicublin", "x"])
 def test_rgb_to_rgb_algorithms(dev, orc, rgbform, flags):
     for geom in ((640, 128, 420, 84), (384, 216, 160, 90)):
