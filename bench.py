@@ -628,7 +628,8 @@ def c_harness(dry):
             rows = [{"error": repr(e)}]
         res["one frame per call, %d caller streams" % n] = rows
     # round 5: 16-bit samples and packed-RGB sources away from 2 : 1 (the band walker of k_scale_yuvg16.hip; the lines form / tiled kernels before)
-    for flt, key in (("deep:", "10- / 16-bit sources and 10-bit destinations, 32 frames per launch"), ("rgbsrc: rgb24", "packed-RGB sources away from 2:1, 32 frames per launch")):
+    for flt, key in (("deep:", "10- / 16-bit sources and 10-bit destinations, 32 frames per launch"), ("rgbsrc: rgb24", "packed-RGB sources away from 2:1, 32 frames per launch"),
+                     ("rgbsrc: bgra", "RGBA sources (read as they are; alpha scaled as a fourth line), 32 frames per call")):
         try:
             r = subprocess.run([exe, "32", "10", flt], env=dict(env, X2BENCH_SETS="4"), capture_output=True, text=True, timeout=300)
             res[key] = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
