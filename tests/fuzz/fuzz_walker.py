@@ -28,7 +28,7 @@ maxw, maxh = (2600, 400) if hip else (900, 160)
 ALGOS = ["bicubic", "bicubic", "bicubic", "bilinear", "lanczos", "point", "area", "gauss", "fast_bilinear", "sinc", "spline", "bicublin", "x"]
 
 for case in range(n):
-    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER", "GMAT_SCALE_NO_WALKER16", "GMAT_RGBSRC_WALKER", "GMAT_RGBSRC_BLOCK", "GMAT_RGBSRC_FUSED"):
+    for k in ("GMAT_STRIP_ROWS", "GMAT_STRIP_BLOCK", "GMAT_SCALE_NO_STRIP", "GMAT_BLOCK_FIRST", "GMAT_QUAD_WALKER", "GMAT_SCALE_NO_WALKER16", "GMAT_RGBSRC_WALKER", "GMAT_RGBSRC_BLOCK", "GMAT_RGBSRC_FUSED", "GMAT_RGBSRC_NO_PX4"):
         os.environ.pop(k, None)
     q = rng.random()
     if q < 0.15:   os.environ["GMAT_QUAD_WALKER"] = "0"          # up-scales on the band walker / the tiled kernel
@@ -54,12 +54,14 @@ for case in range(n):
             os.environ["GMAT_SCALE_NO_WALKER16"] = "1"
     elif rng.random() < (0.8 if "--rgbsrc" in sys.argv else 0.12):      # (--rgbsrc: mostly packed RGB sources — the block-cooperative kernels of round 5's second half)
         # round 5: a packed RGB source into a 4:2:0 frame (the 16-bit walker's converter; up-scales and odd widths: whatever serves them)
-        sf = rng.choice(["rgb24", "bgr24"])
+        sf = rng.choice(["rgb24", "bgr24", "rgb24", "bgr24", "rgba", "bgra"])      # (RGBA / BGRA: read as they are by the block-cooperative kernels, alpha -> alpha as a fourth line)
         df = rng.choice(["nv12", "yuv420p", "nv12", "yuv420p", "p010le", "rgb24", "bgr24", "rgba", "bgra"])     # (RGB -> RGB: scale_yuvg_rgbsrc_kernel from four frames a launch on)
         if rng.random() < 0.5:
             os.environ["GMAT_RGBSRC_WALKER"] = "2"                # ... or at every launch size
         if rng.random() < 0.6:
             os.environ["GMAT_RGBSRC_FUSED"] = rng.choice(["0", "1", "1"])    # an RGB source into a 4:2:0 frame: never / always on the fused block form (the rule: from four frames a launch on, up-scales always)
+        if rng.random() < 0.15:
+            os.environ["GMAT_RGBSRC_NO_PX4"] = "1"                # (RGBA sources through the 32 -> 24-bit pass, as before round 5)
         if rng.random() < 0.4:
             os.environ["GMAT_RGBSRC_BLOCK"] = "0"                 # (the block-cooperative form, scale_yuvg_rgbsrc_blk_kernel, is the rule wherever it has an instance: without it)
     os.environ.pop("GMAT_NO_CROSS_CASCADE", None)
