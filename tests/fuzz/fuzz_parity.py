@@ -29,6 +29,7 @@ for case in range(n):
     sw, sh = rng.randint(2, 300), rng.randint(2, 120)
     same = rng.random() < 0.25
     dw, dh = (sw, sh) if same else (rng.randint(2, 300), rng.randint(2, 120))
+    same = same or (dw, dh) == (sw, sh)           # (the draw can hit the source's size by itself — seed 9300 case 1606: libswscale's unscaled converters apply, not orc.sws's generic lines)
     algo = rng.choice(ALGOS)
     flags = SWS[algo]
     if rng.random() < 0.2: flags |= SWS["full_chr_h_int"]
