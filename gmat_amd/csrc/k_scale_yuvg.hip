@@ -1311,7 +1311,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgbsrc_blk_kernel(YuvGArgs a, 
     const int X0 = (lin - band * a.nsg) * 64;
     const int y0 = band * a.bandRows, y1 = min(y0 + a.bandRows, a.dstH);
     const int f = blockIdx.y;
-    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)BPX * (unsigned)a.srcW);
+    // (rounded up to a whole dword: a width that is not a multiple of four ends its last row inside one — the same page as the row's last byte)
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (((unsigned)BPX * (unsigned)a.srcW + 3u) & ~3u));
     const int bpp = (a.dstFormat == GMAT_PIX_FMT_RGBA || a.dstFormat == GMAT_PIX_FMT_BGRA) ? 4 : 3;
     const bool bgr = a.dstFormat == GMAT_PIX_FMT_BGR24 || a.dstFormat == GMAT_PIX_FMT_BGRA;
     const GPlane bD(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)(a.dstW * bpp));
@@ -1425,7 +1426,8 @@ __global__ __launch_bounds__(256) void scale_yuvg_rgb2p_blk_kernel(YuvGArgs a, Y
     const int cy0 = y0 >> 1, cy1 = min((y1 + 1) >> 1, a.chrDstH);
     const int f = blockIdx.y;
     const bool nv12 = a.nv12 != 0;
-    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (unsigned)BPX * (unsigned)a.srcW);
+    // (rounded up to a whole dword: a width that is not a multiple of four ends its last row inside one — the same page as the row's last byte)
+    const GPlane bS(fr.y[f], (unsigned)a.ys * (unsigned)(a.srcH - 1) + (((unsigned)BPX * (unsigned)a.srcW + 3u) & ~3u));
     const GPlane bY(fr.dst[f], (unsigned)a.ds * (unsigned)(a.dstH - 1) + (unsigned)a.dstW);
     const int crow = nv12 ? 2 * a.chrDstW : a.chrDstW;
     const GPlane bU(fr.dstU[f], (unsigned)a.dsU * (unsigned)(a.chrDstH - 1) + (unsigned)crow);
@@ -1721,15 +1723,16 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     // a packed RGB24 / BGR24 source into a 4:2:0 frame (the walker's own converter: GStream LK): the chroma of pixel PAIRS at full height — what libswscale
     // gives every such context that does not up-scale (utils.c:1529-1545); the jobs synthesise the DESTINATION's chroma layout, so "semi" follows it
     const bool rgbSrc = p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24;
-    if (rgbSrc && yuvOut && !is_dst10(p.dstFormat) && !p.chrSrcHSub && !p.chrSrcVSub && p.chrSrcW == p.srcW && p.chrSrcH == p.srcH && !(p.srcW & 3) &&
-        g.yuvOut == 1 && p.dstW >= 16 && p.dstH >= 8 && p.srcW >= 16 && p.srcH >= 8) {
-        // an UP-scale (chroma from every pixel, utils.c:1529-1545): the fused block form alone — no walker instance (t.K = 0), no plane jobs
+    if (rgbSrc && yuvOut && !is_dst10(p.dstFormat) && !p.chrSrcVSub && p.chrSrcH == p.srcH && g.yuvOut == 1 && p.dstW >= 16 && p.dstH >= 8 && p.srcW >= 16 && p.srcH >= 8 &&
+        (p.chrSrcHSub ? (p.chrSrcW * 2 == p.srcW && (p.srcW & 3)) : p.chrSrcW == p.srcW)) {
+        // an UP-scale (chroma from every pixel, utils.c:1529-1545), or a down-scale of a width that is not a multiple of four (the walker's streams load whole
+        // groups of four pixels): the fused block form alone — no walker instance (t.K = 0), no plane jobs
         for (int v : g.lumRound) if (v != g.lumRound[0]) return 0;
         for (int v : g.chrRound) if (v != g.chrRound[0]) return 0;
         int need = 0;
         for (const FilterBank *fb : {&p.hLum, &p.hChr})
             for (int x = 0; x < fb->count; x++) {
-                if (fb->pos[x] < 0 || fb->pos[x] + fb->taps > p.srcW) return 0;
+                if (fb->pos[x] < 0 || fb->pos[x] + fb->taps > (fb == &p.hLum ? p.srcW : p.chrSrcW)) return 0;
                 need = std::max(need, ((fb->pos[x] & 3) + fb->taps + 1) / 2);
             }
         if (need > 8) return 0;
@@ -2064,11 +2067,13 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     if (const char *o16 = GMAT_KNOB("GMAT_SCALE_NO_WALKER16")) if (atoi(o16)) return 0;
     if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
     if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
-    if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8 || (p.srcW & 3)) return 0;
+    if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
     if (p.srcW == 2 * p.dstW && p.srcH == 2 * p.dstH) return 0;                              // (exactly 2 : 1 has its own strip walker, k_scale_rgb2s.hip)
     // full-chroma output (forced for this source), chroma lines of the source's height and of its width or half of it
     if (p.chrDstW != p.dstW || p.chrDstH != p.dstH || p.chrSrcVSub || p.chrSrcH != p.srcH) return 0;
-    if (!(p.chrSrcHSub == 0 ? p.chrSrcW == p.srcW : (p.chrSrcW * 2 == p.srcW && !(p.srcW & 7)))) return 0;
+    // (any width, an even one where the chroma comes from pixel pairs: the block form; the walker's form wants whole groups of four / eight pixels a row)
+    if (!(p.chrSrcHSub == 0 ? p.chrSrcW == p.srcW : p.chrSrcW * 2 == p.srcW)) return 0;
+    const bool walkW = !(p.srcW & (p.chrSrcHSub ? 7 : 3));
     // yuv2rgb_full_X_c proper (the one- and two-tap special forms of vscale.c:135-167 stay on the tiled kernel); the chroma's vertical filter is the luma's
     // (round 5, later: the block form takes those too — packed_vscale's forms differ from yuv2rgb_full_X_c in the sums' start alone, which it reads per output row)
     if (p.vLum.taps < 1 || p.vChr.taps != p.vLum.taps || p.vChr.pos != p.vLum.pos || p.vChr.coef != p.vLum.coef) return 0;
@@ -2096,7 +2101,7 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     t.posL = p.hLum.pos; t.posC = p.hChr.pos;
     // the band walker's form (scale_yuvg_rgbsrc_kernel): the running sums of one plane's program, a wave's 64 columns inside the row image its lanes fill
     int K = 0;
-    if (p.vLum.taps >= 3 && build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) {
+    if (walkW && p.vLum.taps >= 3 && build_qprog(p.vLum, p.srcH, nullptr, 0, false, t.rgb[0])) {
         for (int c : kGK) if (c >= t.rgb[0].K) { K = c; break; }
         if (!K && t.rgb[0].K <= 12 && P <= 8) K = 12;          // (ratios near 1 and up-scales: ten or eleven rows open over a quad of four source rows)
         const int SD = P >= 10 ? 4 : 2, NW = (P + 1) & ~1;

@@ -37,7 +37,7 @@ def test_rgb24_bicubic(dev, orc, kern, geom):
     strip = kern.startswith("scale_yuv2s") and sw == 2 * dw and sh == 2 * dh and sw % 8 == 0 and sw >= 32 and dh >= 8
     # (round 5: away from 2 : 1, widths that are multiples of four, filters of three vertical taps or more: the block-cooperative RGB-source form,
     # tests/test_parity_walker16.py; GMAT_SCALE_NO_STRIP leaves it alone)
-    blk = geom in ((96, 40, 144, 60), (40, 30, 41, 31))      # (300 -> 100: pixel pairs want a width that is a multiple of eight; 64 -> 17: ten coefficient pairs)
+    blk = geom in ((96, 40, 144, 60), (40, 30, 41, 31), (300, 50, 100, 70))      # (64 -> 17: ten coefficient pairs; the odd widths: pixel pairs)
     assert k.startswith("scale_rgb2h_kernel" if strip else "scale_yuvg_rgbsrc_blk_kernel" if blk else "scale_rgb_kernel"), k
 
 

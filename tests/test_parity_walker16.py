@@ -191,11 +191,12 @@ def test_rgb_to_420_up_scales(dev, orc, geom, flags):
 
 
 def test_walker16_packed_rgb_what_it_leaves_alone(dev, orc, rgbp):
-    """up-scales into 10-bit frames, widths that are not multiples of four, 2 : 1 (its own kernel), RGB destinations: not these forms"""
+    """up-scales into 10-bit frames, odd widths, 2 : 1 (its own kernel), RGB destinations: not these forms"""
     ours = W16 + (FUSED,)
     assert _check(dev, orc, "rgb24", "p010le", (256, 144, 384, 216)) not in ours
     assert _check(dev, orc, "rgb24", "nv12", (256, 144, 384, 216)) == FUSED          # (whatever the knobs say: an up-scale has no other form here)
-    assert _check(dev, orc, "rgb24", "nv12", (386, 216, 160, 90)) not in ours
+    assert _check(dev, orc, "rgb24", "nv12", (386, 216, 160, 90)) == FUSED               # (a width that is not a multiple of four: the fused block form alone)
+    assert _check(dev, orc, "rgb24", "nv12", (385, 216, 160, 90)) not in ours
     assert _check(dev, orc, "rgb24", "nv12", (512, 64, 256, 32)) == "scale_rgb2y_kernel"
     assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 160, 90)) not in ours
 
@@ -302,6 +303,19 @@ def test_rgba_sources_into_420_are_read_as_they_are(dev, orc, pair, geom, monkey
     _check(dev, orc, sf, df, geom)
 
 
+@pytest.mark.parametrize("geom", [(386, 216, 256, 144), (1366, 76, 640, 36), (854, 48, 426, 24), (426, 60, 854, 120), (390, 100, 172, 40), (202, 120, 260, 150),
+                                  (342, 60, 1284, 90), (394, 216, 161, 91), (385, 60, 500, 80)], ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("trio", [("rgb24", "bgr24", RGBBLK), ("bgr24", "nv12", FUSED), ("rgb24", "yuv420p", FUSED), ("bgra", "bgra", RGBBLK), ("rgba", "nv12", FUSED)],
+                         ids=lambda t: "%s-%s" % t[:2])
+def test_rgb_sources_of_any_width(dev, orc, trio, geom):
+    """source widths that are not multiples of four (1366, 854, 426 ...; odd ones where the chroma comes from every pixel): the block-cooperative kernels read
+    whole dwords of a row through a buffer resource whose size is rounded up to a dword — the last pixels' dword lies in the page of the row's last byte —
+    and every sample past the row's end meets a zero coefficient.  The walker's streams (groups of four / eight pixels checked against the exact size) decline"""
+    sf, df, k = trio
+    assert _check(dev, orc, sf, df, geom) == k
+    assert _check(dev, orc, sf, df, geom, "bilinear", align=4, src_align=4) == k
+
+
 def test_rgba_sources_batches(dev, orc):
     for n in (2, 5, 34):
         assert _run_batch(dev, orc, "bgra", "nv12", 384, 216, 160, 90, nframes=n, nstreams=1, align=256) == FUSED
@@ -320,11 +334,12 @@ def test_rgb_to_rgb_algorithms(dev, orc, rgbform, flags):
 
 
 def test_rgb_to_rgb_what_it_leaves_alone(dev, orc, rgbform, monkeypatch):
-    """exactly 2 : 1 (its own strip walker), widths that are not multiples of four, SWS_FAST_BILINEAR (an RGB source keeps its halved chroma: the plane
+    """exactly 2 : 1 (its own strip walker), odd widths under pixel pairs, SWS_FAST_BILINEAR (an RGB source keeps its halved chroma: the plane
     scaler), two-tap vertical filters on the walker's form, the knobs"""
     both = (RGBRGB, RGBBLK)
     assert _check(dev, orc, "rgb24", "rgb24", (512, 64, 256, 32)).startswith("scale_rgb2")
-    assert _check(dev, orc, "rgb24", "rgb24", (386, 216, 160, 90)) not in both
+    assert _check(dev, orc, "rgb24", "rgb24", (386, 216, 160, 90)) == RGBBLK            # (a width that is not a multiple of four: the block form alone)
+    assert _check(dev, orc, "rgb24", "rgb24", (385, 216, 160, 90)) not in both           # (pixel pairs of an odd width: the tiled kernel)
     assert _check(dev, orc, "rgb24", "rgb24", (384, 216, 256, 144), "fast_bilinear") not in both
     assert _check(dev, orc, "rgb24", "rgb24", (256, 144, 384, 216), "bilinear") == RGBBLK         # (whatever the knobs say: the walker's form has no instance)
     monkeypatch.setenv("GMAT_SCALE_NO_WALKER16", "1")
