@@ -897,7 +897,8 @@ static Yuv32rArgs make_yuv32r_args(const GmatSwsContext *c, const YuvScaleArgs &
 static bool rgb2y_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
 {
     const uintptr_t dall = (uintptr_t)ya.dst | (uintptr_t)ya.ds | (uintptr_t)ya.dstU | (uintptr_t)ya.dsU | (uintptr_t)ya.dstV | (uintptr_t)ya.dsV;
-    return c->rgbViaPlanes && c->r2ys.ok && !c->rangeConv && ya.src16 == 3 && ya.srcAligned && (dall & 3) == 0 && !ya.prof;
+    return c->rgbViaPlanes && c->r2ys.ok && !c->rangeConv && ya.src16 == 3 && ya.srcAligned && (dall & 3) == 0 && !ya.prof &&
+           !c->px4;           // (four-byte pixels, read as they are: the fused block form behind it in the table)
 }
 
 static Rgb2yArgs make_rgb2y_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
@@ -1153,7 +1154,7 @@ static bool rg_block_takes_px4(GmatSwsContext *in, int n, const uint8_t *src, in
     if (!(in->srcFormat == GMAT_PIX_FMT_RGB24 || in->srcFormat == GMAT_PIX_FMT_BGR24) || !is_packed_rgb(in->dstFormat)) return false;
     if (const char *k = GMAT_KNOB("GMAT_RGBSRC_NO_PX4")) if (atoi(k)) return false;
     if (const char *rw = GMAT_KNOB("GMAT_RGBSRC_WALKER")) if (!atoi(rw)) return false;
-    if (ensure_scaler(in) < 0 || in->r2s.ok || !in->rg.ok) return false;
+    if (ensure_scaler(in) < 0 || !in->rg.ok) return false;      // (exactly 2 : 1 included: the strip kernel of the 24-bit context reads three-byte pixels)
     return al4(src, ss) && al4(dst, ds) && yuvg_rgbsrc_block_form(in->rgargs, std::min(n, kYuv2xMaxFrames));
 }
 
@@ -1503,7 +1504,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         !c->inner && is_packed_rgb(c->dstFormat)) {
         // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames; at the band walker's other ratios: its RGB-source form
         if (ensure_scaler(c) < 0 || !(c->r2s.ok || c->rg.ok)) return 0;
-        if (!c->r2s.ok) {
+        if (!c->r2s.ok || (c->px4 && c->rg.ok)) {                 // (four-byte pixels at exactly 2 : 1 too: the strip kernel reads three)
             // (32 frames a launch: rgb24 1080p -> 720p 14.2 -> 6.6 us a frame, 4K -> 900p 30.1 -> 22.0, 720p -> 1080p 14.8 -> 9.3; below four frames the tiled kernel)
             // (round 5, later: ONE to three frames a launch — and every launch the walker has no instance for: up-scales beyond its open rows — take the
             // block-cooperative form, scale_yuvg_rgbsrc_blk_kernel)
@@ -2547,7 +2548,7 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             r = launch_scale_rgb2s(ra, c->stream, &one, 1);
             break;
         }
-        if (a.srcKind == 0 && c->r2s.ok && a.srcAligned && a.dstAligned) {
+        if (a.srcKind == 0 && c->r2s.ok && a.srcAligned && a.dstAligned && !c->px4) {
             // exact 2:1 from packed RGB (also the second kernel of the two-kernel form): the strip-walking scaler
             const Rgb2sArgs ra = make_rgb2s_args(c, a.ss0, a.ds, a.srcBgr != 0);
             Yuv2xFrames one;

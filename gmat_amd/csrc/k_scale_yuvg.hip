@@ -2068,7 +2068,7 @@ int yuvg_rgbsrc_prepare(const ScalePlan &p, YuvGTables &t)
     if (!(p.srcFormat == GMAT_PIX_FMT_RGB24 || p.srcFormat == GMAT_PIX_FMT_BGR24)) return 0;
     if (!(p.dstFormat == GMAT_PIX_FMT_RGB24 || p.dstFormat == GMAT_PIX_FMT_BGR24 || p.dstFormat == GMAT_PIX_FMT_RGBA || p.dstFormat == GMAT_PIX_FMT_BGRA)) return 0;
     if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
-    if (p.srcW == 2 * p.dstW && p.srcH == 2 * p.dstH) return 0;                              // (exactly 2 : 1 has its own strip walker, k_scale_rgb2s.hip)
+    // (exactly 2 : 1 has its own strip walker, k_scale_rgb2s.hip, in front of these forms wherever it takes the frame: dword-aligned planes of three-byte pixels)
     // full-chroma output (forced for this source), chroma lines of the source's height and of its width or half of it
     if (p.chrDstW != p.dstW || p.chrDstH != p.dstH || p.chrSrcVSub || p.chrSrcH != p.srcH) return 0;
     // (any width, an even one where the chroma comes from pixel pairs: the block form; the walker's form wants whole groups of four / eight pixels a row)

@@ -316,6 +316,21 @@ def test_rgb_sources_of_any_width(dev, orc, trio, geom):
     assert _check(dev, orc, sf, df, geom, "bilinear", align=4, src_align=4) == k
 
 
+@pytest.mark.parametrize("geom", [(512, 64, 256, 32), (384, 216, 192, 108), (520, 100, 260, 50), (640, 40, 320, 20)], ids=lambda g: "%dx%d-%dx%d" % g)
+@pytest.mark.parametrize("trio", [("bgra", "bgra", RGBBLK), ("rgba", "rgb24", RGBBLK), ("bgra", "nv12", FUSED), ("rgba", "yuv420p", FUSED)], ids=lambda t: "%s-%s" % t[:2])
+def test_rgba_sources_at_exactly_two_to_one(dev, orc, trio, geom):
+    """exactly 2 : 1 belongs to the strip kernels of k_scale_rgb2s.hip — which read three-byte pixels; an RGBA / BGRA source takes the block-cooperative kernels there
+    too rather than a 32 -> 24-bit pass in front of them (and a batch of such frames stays a batch); rgb24 / bgr24 keep the strip kernels"""
+    sf, df, k = trio
+    assert _check(dev, orc, sf, df, geom) == k
+    assert _check(dev, orc, sf, df, geom, "bilinear", align=16, src_align=16) == k
+    if geom == (512, 64, 256, 32):
+        assert _check(dev, orc, "rgb24", "rgb24", geom).startswith("scale_rgb2")
+        assert _check(dev, orc, "rgb24", "nv12", geom) == "scale_rgb2y_kernel"
+        assert _run_batch(dev, orc, sf, df, *geom, nframes=5, nstreams=1, align=256) == k
+        assert _run_batch(dev, orc, "rgb24", "rgb24", *geom, nframes=5, nstreams=1, align=256).startswith("scale_rgb2")
+
+
 def test_rgba_sources_batches(dev, orc):
     for n in (2, 5, 34):
         assert _run_batch(dev, orc, "bgra", "nv12", 384, 216, 160, 90, nframes=n, nstreams=1, align=256) == FUSED

@@ -338,6 +338,8 @@ int main(int argc, char **argv)
         {"rgbsrc: rgb24 720p->1080p nv12 bicubic (2:3 up)", GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: rgb24 1366x768->1080p rgb24 bicubic (a width that is not a multiple of four, up)", GMAT_PIX_FMT_RGB24, 1366, 768, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: rgb24 1366x768->854x480 nv12 bicubic (widths that are not multiples of four)", GMAT_PIX_FMT_RGB24, 1366, 768, GMAT_PIX_FMT_NV12, 854, 480, GMAT_SWS_BICUBIC},
+        {"rgbsrc: bgra 4K->1080p bgra bicubic (2:1)", GMAT_PIX_FMT_BGRA, 3840, 2160, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbsrc: bgra 4K->1080p nv12 bicubic (2:1)", GMAT_PIX_FMT_BGRA, 3840, 2160, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p nv12 bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_NV12, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p bgra bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_BGRA, 1280, 720, GMAT_SWS_BICUBIC},
