@@ -331,6 +331,14 @@ def test_rgba_sources_at_exactly_two_to_one(dev, orc, trio, geom):
         assert _run_batch(dev, orc, "rgb24", "rgb24", *geom, nframes=5, nstreams=1, align=256).startswith("scale_rgb2")
 
 
+def test_rgba_to_rgba_at_the_largest_block(dev, orc):
+    """the block form's largest footprint: four lines (alpha), chroma from every pixel at eight pixels a lane (1.9 : 1), eight row pairs a wave and 16-pair vertical
+    windows (7 : 1) — 16 KB of row images + 48 KB of filtered pairs = the 64 KB a workgroup may hold; a taller window is declined"""
+    assert _check(dev, orc, "bgra", "bgra", (760, 700, 400, 100)) == RGBBLK
+    assert _check(dev, orc, "rgba", "bgra", (760, 350, 400, 50)) == RGBBLK
+    assert _check(dev, orc, "bgra", "bgra", (764, 720, 400, 90)).startswith("scale_rgb_kernel")
+
+
 def test_rgba_sources_batches(dev, orc):
     for n in (2, 5, 34):
         assert _run_batch(dev, orc, "bgra", "nv12", 384, 216, 160, 90, nframes=n, nstreams=1, align=256) == FUSED
