@@ -31,13 +31,15 @@ GEOMS = [(256, 64, 128, 32), (200, 90, 100, 45), (131, 77, 64, 33), (96, 40, 144
 @pytest.mark.parametrize("geom", GEOMS)
 def test_rgb24_bicubic(dev, orc, kern, geom):
     """exact 2:1 geometries take the strip-walking kernel (k_scale_rgb2s.hip) unless it is switched off; everything else,
-    and both with GMAT_SCALE_NO_STRIP=1, the tiled generic one"""
+    and both with GMAT_SCALE_NO_STRIP=1, the block-cooperative form of round 5 where it has an instance, the tiled generic kernel where not"""
     sw, sh, dw, dh = geom
     k = _check(dev, orc, "rgb24", sw, sh, dw, dh, "rgb24", SWS["bicubic"])
     strip = kern.startswith("scale_yuv2s") and sw == 2 * dw and sh == 2 * dh and sw % 8 == 0 and sw >= 32 and dh >= 8
     # (round 5: away from 2 : 1, widths that are multiples of four, filters of three vertical taps or more: the block-cooperative RGB-source form,
     # tests/test_parity_walker16.py; GMAT_SCALE_NO_STRIP leaves it alone)
-    blk = geom in ((96, 40, 144, 60), (40, 30, 41, 31), (300, 50, 100, 70))      # (64 -> 17: ten coefficient pairs; the odd widths: pixel pairs)
+    # (... and exactly 2 : 1 wherever the strip kernel does not take the frame: switched off, or a width that is not a multiple of eight)
+    blk = geom in ((96, 40, 144, 60), (40, 30, 41, 31), (300, 50, 100, 70)) or (not strip and geom in ((256, 64, 128, 32), (200, 90, 100, 45), (520, 36, 260, 18)))
+    # (64 -> 17: ten coefficient pairs; the odd widths: pixel pairs)
     assert k.startswith("scale_rgb2h_kernel" if strip else "scale_yuvg_rgbsrc_blk_kernel" if blk else "scale_rgb_kernel"), k
 
 
