@@ -344,6 +344,8 @@ int main(int argc, char **argv)
         {"rgbsrc: bgra 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p bgra bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_BGRA, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: rgb24 640x640->1080p rgb24 bilinear (up)", GMAT_PIX_FMT_RGB24, 640, 640, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"rgbsrc: yuv444p 1080p->720p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_PIX_FMT_YUV444P, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: yuv444p 4K->1080p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
         {"rgbsrc: nv12 4K->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
         {"rgbsrc: nv12 1080p->224x224 rgb24 bilinear (a classifier's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 224, 224, GMAT_SWS_BILINEAR},
