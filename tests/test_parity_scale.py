@@ -420,7 +420,8 @@ def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
     if src_fmt in ("yuv420p", "nv12") and (sw, sh) == (2 * dw, 2 * dh) and sw % 16 == 0 and sw >= 64 and dh >= 16 and flags != "lanczos":
         assert kernel.startswith("scale_yuv2p_kernel<luma>"), kernel
     else:
-        assert is_generic(kernel) and ("yuv444" in kernel or kernel == LINES), kernel
+        # (round 5: 4:4:4 at BOTH ends is three plane jobs of the band walker where it has an instance, tests/test_parity_walker16.py)
+        assert is_generic(kernel) and ("yuv444" in kernel or kernel == LINES or (src_fmt == "yuv444p" and kernel.startswith("scale_yuvg_"))), kernel
     assert len(got) == 3
     for i, (g, wv) in enumerate(zip(got, want)):
         bad = np.argwhere(g != wv)

@@ -121,6 +121,21 @@ def test_walker16_knob_and_what_it_leaves_alone(dev, orc, monkeypatch):
     assert k not in W16 and k.startswith("scale_yuv"), k
 
 
+# ---- YUV444P -> YUV444P on the 8-bit band walker (round 5, last): three plane jobs whose chroma tables are the full-size ones ------------------------------------
+@pytest.mark.parametrize("geom", GEOMS + [(384, 216, 192, 108), (256, 144, 384, 216), (200, 120, 260, 150)], ids=lambda g: "%dx%d-%dx%d" % g)
+def test_walker8_planar_444_at_both_ends(dev, orc, form, geom):
+    """a format of scale_cuda's list (vf_scale_cuda.c:45-54): it ran the lines form's two passes (0.12 of the roofline: 1080p -> 720p 9.5 us a frame) or, alone, the
+    tiled kernel (14 us); the walker's plane jobs take sizes and tables as they come, so 4:4:4 is an acceptance rule, not a kernel"""
+    up = geom[2] > geom[0]
+    for flags in ("bicubic", "bilinear", "lanczos"):
+        k = _check(dev, orc, "yuv444p", "yuv444p", geom, flags)
+        if not up and (flags == "bicubic" or geom[0] < 4 * geom[2]):      # (from 4 : 1 on the short filters' 64 columns do not fit one dword a lane, Lanczos' taps its pairs: the lines form)
+            assert k in W8, (flags, k)
+    if not up:
+        assert _check(dev, orc, "yuv444p", "yuv444p", geom, align=4, src_align=4) in W8
+        assert _run_batch(dev, orc, "yuv444p", "yuv444p", *geom, nframes=5, nstreams=1, align=256) in W8
+
+
 # ---- packed RGB sources into 4:2:0 frames: the walker's own converter in front of the same 16-bit lines (round 5) -----------------------------------
 RGBSRC_GEOMS = [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (640, 128, 420, 84), (1024, 64, 256, 16), (520, 100, 172, 40), (2048, 40, 700, 16),
                 (384, 216, 380, 212)]
