@@ -58,6 +58,8 @@ static size_t frame_bytes(int fmt, int w, int h)
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: case GMAT_PIX_FMT_YUV444P: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
     case GMAT_PIX_FMT_RGBPF32LE: return (size_t)w * h * 12;        // three stacked planes of floats
+    case GMAT_PIX_FMT_YUV444P16LE: return (size_t)w * h * 6;
+    case GMAT_PIX_FMT_P016LE: return (size_t)w * h * 3;
     default: return 0;
     }
 }
@@ -75,7 +77,8 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
     }
     switch (fmt) {
     case GMAT_PIX_FMT_NV12: p[0] = b; p[1] = b + (size_t)w * h; s[0] = w; s[1] = w; break;
-    case GMAT_PIX_FMT_P010LE: p[0] = b; p[1] = b + (size_t)w * h * 2; s[0] = 2 * w; s[1] = 2 * w; break;
+    case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_P016LE: p[0] = b; p[1] = b + (size_t)w * h * 2; s[0] = 2 * w; s[1] = 2 * w; break;
+    case GMAT_PIX_FMT_YUV444P16LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)w * h * 2; s[0] = s[1] = s[2] = 2 * w; break;
     case GMAT_PIX_FMT_YUV420P10LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)(w / 2) * (h / 2) * 2; s[0] = 2 * w; s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
     case GMAT_PIX_FMT_YUV444P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)w * h; s[0] = s[1] = s[2] = w; break;
@@ -344,6 +347,10 @@ int main(int argc, char **argv)
         {"rgbsrc: bgra 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p bgra bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_BGRA, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: rgb24 640x640->1080p rgb24 bilinear (up)", GMAT_PIX_FMT_RGB24, 640, 640, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
+        {"rgbsrc: yuv444p16le 1080p->720p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_PIX_FMT_YUV444P16LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"rgbsrc: yuv444p16le 4K->1080p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 3840, 2160, GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbsrc: p016 4K->1080p p016 bicubic", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"rgbsrc: p016 1080p->720p p016 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 1080p->720p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_PIX_FMT_YUV444P, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 4K->1080p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
