@@ -1505,9 +1505,9 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         // packed RGB at exactly 2:1: the strip-walking scaler, one launch per 32 frames; at the band walker's other ratios: its RGB-source form
         if (ensure_scaler(c) < 0 || !(c->r2s.ok || c->rg.ok)) return 0;
         if (!c->r2s.ok || (c->px4 && c->rg.ok)) {                 // (four-byte pixels at exactly 2 : 1 too: the strip kernel reads three)
-            // (32 frames a launch: rgb24 1080p -> 720p 14.2 -> 6.6 us a frame, 4K -> 900p 30.1 -> 22.0, 720p -> 1080p 14.8 -> 9.3; below four frames the tiled kernel)
-            // (round 5, later: ONE to three frames a launch — and every launch the walker has no instance for: up-scales beyond its open rows — take the
-            // block-cooperative form, scale_yuvg_rgbsrc_blk_kernel)
+            // (the walker's form, 32 frames a launch: rgb24 1080p -> 720p 14.2 -> 6.6 us a frame, 4K -> 900p 30.1 -> 22.0, 720p -> 1080p 14.8 -> 9.3 — from four frames a
+            // launch on, and only where the block-cooperative form, scale_yuvg_rgbsrc_blk_kernel, has no instance: that one is the rule at every launch size
+            // (4.2 / 12.6 / 5.5 us a frame batched, 8.2 / 19.4 / 10.4 alone; k_scale_yuvg.hip yuvg_rgbsrc_block_form))
             const char *rw = GMAT_KNOB("GMAT_RGBSRC_WALKER");
             const int mode = rw ? atoi(rw) : 1;
             const bool blk = yuvg_rgbsrc_block_form(c->rgargs, std::min(n, kYuv2xMaxFrames));
@@ -2561,9 +2561,9 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         const char *rgw = GMAT_KNOB("GMAT_RGBSRC_WALKER");
         if (a.srcKind == 0 && c->rg.ok && a.srcAligned && al4(dst[0], dstStride[0]) && !c->prof && !(rgw && !atoi(rgw)) &&
             (yuvg_rgbsrc_block_form(c->rgargs, 1) || (c->rgargs.K && rgw && atoi(rgw) == 2))) {
-            // any other ratio the band walker reaches (round 5): one column a lane, the three lines from one load of the pixels — in launches of four
-            // frames or more (sws_scale_frames_batched_impl); ONE frame stays on the tiled kernel, which is faster alone (1080p -> 720p 13.0 against
-            // 17.2 us, 4K -> 900p 27 against 48: profiles/r05s_rgbrgb_walker.txt).  GMAT_RGBSRC_WALKER=2: here too (tests, A/B)
+            // away from the strip kernel's exact 2 : 1 (round 5): the block-cooperative form wherever it has an instance — every launch size, up-scales of any factor,
+            // RGBA sources read as they are (c->px4) — and the walker's form (one column a lane, running sums) behind it, alone in a launch only with
+            // GMAT_RGBSRC_WALKER=2 (tests, A/B: 17.2 against the tiled kernel's 13.0 us for a 1080p -> 720p frame; profiles/r05s_rgbrgb_walker.txt)
             Yuv2xFrames one;
             std::memset(&one, 0, sizeof(one));
             one.y[0] = a.src0; one.dst[0] = a.dst;
