@@ -30,22 +30,36 @@ __global__ __launch_bounds__(256) void hscale19_kernel(const uint8_t *src, int s
     if (x >= dstW || y >= srcH) return;
     const uint8_t *row = src + (size_t)y * ss;
     const int p0 = f.pos_even[x];
+    auto sample = [&](int i) -> int {                                 // a tap past the plane has coefficient 0
+        i = min(i, srcW - 1);
+        if (kind == 0) return row[(size_t)i * step];
+        if (kind == 208) { const int a = row[(size_t)i * step]; return a << 6 | a >> 2; }
+        const unsigned v = *reinterpret_cast<const unsigned short *>(row + (size_t)i * step);
+        return kind == 10 ? (int)(v >> 6) : (int)v;
+    };
+    // (round 5, last hour: measured for the first time — P016 1080p -> 720p 41 us a frame, 70 % of it here — and latency-bound: a loop over f.pairs waits for every
+    // pair's loads before it asks for the next.  Up to eight pairs: all of a thread's loads are issued together — NP >= f.pairs of them, the pairs past the
+    // filter's own with coefficient 0 on a clamped, valid sample — then summed in the same order)
     int val = 0;
-    for (int k = 0; k < f.pairs; k++) {
-        const int cf = f.packed[(size_t)x * f.pairs + k];
-        int s[2];
+    auto taps = [&](auto np_c) {
+        constexpr int NP = decltype(np_c)::value;
+        int cf[NP], s0[NP], s1[NP];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i = min(p0 + 2 * k + j, srcW - 1);              // a tap past the plane has coefficient 0
-            if (kind == 0) s[j] = row[(size_t)i * step];
-            else if (kind == 208) { const int a = row[(size_t)i * step]; s[j] = a << 6 | a >> 2; }
-            else {
-                const unsigned v = *reinterpret_cast<const unsigned short *>(row + (size_t)i * step);
-                s[j] = kind == 10 ? (int)(v >> 6) : (int)v;
-            }
+        for (int k = 0; k < NP; k++) cf[k] = k < f.pairs ? f.packed[(size_t)x * f.pairs + k] : 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) { s0[k] = sample(p0 + 2 * k); s1[k] = sample(p0 + 2 * k + 1); }
+#pragma unroll
+        for (int k = 0; k < NP; k++) val += s0[k] * (int)(short)(cf[k] & 0xFFFF) + s1[k] * (cf[k] >> 16);
+    };
+    if (f.pairs <= 2)      taps(std::integral_constant<int, 2>());
+    else if (f.pairs <= 4) taps(std::integral_constant<int, 4>());
+    else if (f.pairs <= 6) taps(std::integral_constant<int, 6>());
+    else if (f.pairs <= 8) taps(std::integral_constant<int, 8>());
+    else
+        for (int k = 0; k < f.pairs; k++) {
+            const int cf = f.packed[(size_t)x * f.pairs + k];
+            val += sample(p0 + 2 * k) * (int)(short)(cf & 0xFFFF) + sample(p0 + 2 * k + 1) * (cf >> 16);
         }
-        val += s[0] * (int)(short)(cf & 0xFFFF) + s[1] * (cf >> 16);
-    }
     int v = min(val >> sh, maxv);
     // range conversion of a 19-bit line (lum / chrRange{To,From}Jpeg16_c, swscale.c:189-226) in the reference's 32-bit arithmetic: the
     // chroma ToJpeg product passes 2^31 on its way, only the difference fits
@@ -64,13 +78,38 @@ __global__ __launch_bounds__(256) void vscale16_kernel(const int32_t *lineA, con
     if (x >= dstW || y >= dstH) return;
     const int p0 = f.pos_even[y];
     unsigned a = (1u << 14) - 0x40000000u, b = a;
-    for (int k = 0; k < f.pairs; k++) {
-        const int cf = f.packed[(size_t)y * f.pairs + k];
-        const unsigned c0 = (unsigned)(int)(short)(cf & 0xFFFF), c1 = (unsigned)(cf >> 16);
-        const int r0 = min(p0 + 2 * k, lineH - 1), r1 = min(p0 + 2 * k + 1, lineH - 1);
-        a += (unsigned)lineA[(size_t)r0 * lineW + x] * c0 + (unsigned)lineA[(size_t)r1 * lineW + x] * c1;
-        if (planes == 2) b += (unsigned)lineB[(size_t)r0 * lineW + x] * c0 + (unsigned)lineB[(size_t)r1 * lineW + x] * c1;
-    }
+    // (as hscale19_kernel: up to eight pairs a thread asks for all of its lines' samples at once — the loop waited for each pair)
+    auto taps = [&](auto np_c) {
+        constexpr int NP = decltype(np_c)::value;
+        int cf[NP];
+        unsigned a0[NP], a1[NP], b0[NP], b1[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) cf[k] = k < f.pairs ? f.packed[(size_t)y * f.pairs + k] : 0;     // (the coefficient of a row: wave-uniform)
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int r0 = min(p0 + 2 * k, lineH - 1), r1 = min(p0 + 2 * k + 1, lineH - 1);
+            a0[k] = (unsigned)lineA[(size_t)r0 * lineW + x]; a1[k] = (unsigned)lineA[(size_t)r1 * lineW + x];
+            if (planes == 2) { b0[k] = (unsigned)lineB[(size_t)r0 * lineW + x]; b1[k] = (unsigned)lineB[(size_t)r1 * lineW + x]; } else b0[k] = b1[k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const unsigned c0 = (unsigned)(int)(short)(cf[k] & 0xFFFF), c1 = (unsigned)(cf[k] >> 16);
+            a += a0[k] * c0 + a1[k] * c1;
+            b += b0[k] * c0 + b1[k] * c1;
+        }
+    };
+    if (f.pairs <= 2)      taps(std::integral_constant<int, 2>());
+    else if (f.pairs <= 4) taps(std::integral_constant<int, 4>());
+    else if (f.pairs <= 6) taps(std::integral_constant<int, 6>());
+    else if (f.pairs <= 8) taps(std::integral_constant<int, 8>());
+    else
+        for (int k = 0; k < f.pairs; k++) {
+            const int cf = f.packed[(size_t)y * f.pairs + k];
+            const unsigned c0 = (unsigned)(int)(short)(cf & 0xFFFF), c1 = (unsigned)(cf >> 16);
+            const int r0 = min(p0 + 2 * k, lineH - 1), r1 = min(p0 + 2 * k + 1, lineH - 1);
+            a += (unsigned)lineA[(size_t)r0 * lineW + x] * c0 + (unsigned)lineA[(size_t)r1 * lineW + x] * c1;
+            if (planes == 2) b += (unsigned)lineB[(size_t)r0 * lineW + x] * c0 + (unsigned)lineB[(size_t)r1 * lineW + x] * c1;
+        }
     const int va = min(max((int)a >> 15, -32768), 32767) + 0x8000;
     if (planes == 1) {
         reinterpret_cast<unsigned short *>(dst + (size_t)y * ds)[x] = (unsigned short)va;
