@@ -187,6 +187,8 @@ struct GmatSwsContext {
     DevFilterStore f16[4];
     DevFilter d16[4];                 // hLum, hChr, vLum, vChr
     DevBuf line16[3];                 // luma, U, V: srcH x dstW / chrSrcH x chrDstW int32
+    S19Tables s19;                    // (round 6) 16-bit YUV destinations in one launch, the lines of a tile in LDS (k_scale19.hip); s19.ok = 0: the two passes
+    DevBuf dS19[6];                   // its tables: per job the tile columns' first bytes, the tile rows' first source rows and their counts
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
@@ -428,6 +430,13 @@ static int init_rgb2yuv(GmatSwsContext *c)
     return 0;
 }
 
+// hscale19_kernel's sample kind of a plane source of the 19-bit path
+static int scale16_kind(int srcFormat)
+{
+    const bool s16 = is_p01x(srcFormat) || pl16_depth(srcFormat) != 0;
+    return srcFormat == GMAT_PIX_FMT_P010LE ? 10 : pl16_depth(srcFormat) == 10 ? 110 : srcFormat == GMAT_PIX_FMT_PRIV_RGB8_PLANES ? 14 : s16 ? 16 : 0;
+}
+
 static int init_scale16(GmatSwsContext *c)
 {
     int r = build_scale_plan(c->plan16, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param, c->chrPos);
@@ -461,6 +470,27 @@ static int init_scale16(GmatSwsContext *c)
     if ((r = c->f16[1].upload(p.hChr, none, c->d16[1])) < 0) return r;
     if ((r = c->f16[2].upload(vl, none, c->d16[2])) < 0) return r;
     if ((r = c->f16[3].upload(vc, none, c->d16[3])) < 0) return r;
+    // (round 6) YUV destinations: one launch a frame, the 19-bit lines of a tile in LDS (k_scale19.hip; GMAT_S19=0: the two passes through HBM)
+    c->s19.ok = 0;
+    const char *ks19 = GMAT_KNOB("GMAT_S19");
+    if (!is_rgb64(c->dstFormat) && !(ks19 && atoi(ks19) == 0)) {
+        const bool s16 = is_p01x(c->srcFormat) || pl16_depth(c->srcFormat) != 0;
+        const bool srcSemi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);
+        r = s19_prepare(p, vl, vc, s16 ? 2 : 1, scale16_kind(c->srcFormat), srcSemi ? 1 : 0, c->dstFormat == GMAT_PIX_FMT_P016LE ? 1 : 0, c->s19);
+        if (r < 0 && r != GMAT_ERR(ENOSYS)) return r;
+        if (c->s19.ok) {
+            for (int j = 0; j < 2; j++) {
+                S19Job &J = c->s19.job[j];
+                if ((r = c->dS19[3 * j].upload(c->s19.colStart[j].data(), c->s19.colStart[j].size() * 4)) < 0) return r;
+                if ((r = c->dS19[3 * j + 1].upload(c->s19.rowStart[j].data(), c->s19.rowStart[j].size() * 4)) < 0) return r;
+                if ((r = c->dS19[3 * j + 2].upload(c->s19.rowCount[j].data(), c->s19.rowCount[j].size() * 4)) < 0) return r;
+                J.colStart = (const int32_t *)c->dS19[3 * j].p; J.rowStart = (const int32_t *)c->dS19[3 * j + 1].p; J.rowCount = (const int32_t *)c->dS19[3 * j + 2].p;
+                J.h = c->d16[j]; J.v = c->d16[2 + j];
+            }
+            for (int i = 0; i < 3; i++) if ((r = c->line16[i].reserve(0)) < 0) return r;
+            return 0;
+        }
+    }
     if ((r = c->line16[0].reserve((size_t)c->srcH * c->dstW * 4)) < 0) return r;
     if ((r = c->line16[1].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
     if ((r = c->line16[2].reserve((size_t)p.chrSrcH * p.chrDstW * 4)) < 0) return r;
@@ -1319,6 +1349,44 @@ static bool planes_fused_takes_px4(GmatSwsContext *in, int n, const uint8_t *con
     return ok;
 }
 
+// MODE_SCALE16 with a YUV destination on scale19_kernel: frames [0, n) of the context's geometry, up to 32 a launch
+static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[], uint8_t *const *dst_planes,
+                          const int dstStride[], hipStream_t stream)
+{
+    const bool semiS = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat), semiD = c->dstFormat == GMAT_PIX_FMT_P016LE;
+    const bool s16 = is_p01x(c->srcFormat) || pl16_depth(c->srcFormat) != 0;
+    S19Args a;
+    a.job[0] = c->s19.job[0]; a.job[1] = c->s19.job[1];
+    a.job[0].rawStride[0] = srcStride[0]; a.job[0].rawStride[1] = 0;
+    a.job[1].rawStride[0] = srcStride[1]; a.job[1].rawStride[1] = semiS ? 0 : srcStride[2];
+    a.job[0].ds[0] = dstStride[0]; a.job[0].ds[1] = 0;
+    a.job[1].ds[0] = dstStride[1]; a.job[1].ds[1] = semiD ? dstStride[1] : dstStride[2];
+    a.job[0].rc = c->rangeConv; a.job[1].rc = c->rangeConv ? c->rangeConv + 2 : 0;
+    uintptr_t sAl = (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1] | (semiS ? 0 : (uintptr_t)srcStride[2]);
+    uintptr_t dAl = (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1] | (semiD ? 0 : (uintptr_t)dstStride[2]);
+    for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
+        const int m = std::min(kYuv2xMaxFrames, n - f0);
+        Yuv2xFrames fr;
+        std::memset(&fr, 0, sizeof(fr));
+        uintptr_t sA = sAl, dA = dAl;
+        for (int i = 0; i < m; i++) {
+            const uint8_t *const *sp = src_planes + 4 * (f0 + i);
+            uint8_t *const *dp = dst_planes + 4 * (f0 + i);
+            if (!sp[0] || !sp[1] || (!semiS && !sp[2]) || !dp[0] || !dp[1] || (!semiD && !dp[2])) return GMAT_ERR(EINVAL);
+            fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = semiS ? nullptr : sp[2];
+            fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = semiD ? nullptr : dp[2];
+            sA |= (uintptr_t)sp[0] | (uintptr_t)sp[1] | (semiS ? 0 : (uintptr_t)sp[2]);
+            dA |= (uintptr_t)dp[0] | (uintptr_t)dp[1] | (semiD ? 0 : (uintptr_t)dp[2]);
+        }
+        if ((dA & 1) || (s16 && (sA & 1))) return GMAT_ERR(EINVAL);              // 16-bit samples sit on even addresses
+        a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
+        c->lastKernel = "scale19_kernel";
+        if (int r = launch_scale19(a, c->s19.np, c->s19.ldsBytes, stream, &fr, m); r < 0) return r;
+        c->lastLaunchFrames = m;
+    }
+    return 0;
+}
+
 static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
                                          uint8_t *const *dst_planes, const int dstStride[], hipStream_t stream);
 int sws_scale_frames_batched(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[],
@@ -1388,6 +1456,10 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         }
         c->lastLaunchFrames = 1;
         return 1;
+    }
+    if (c->mode == MODE_SCALE16 && c->s19.ok) {
+        const int r = scale19_frames(c, n, src_planes, srcStride, dst_planes, dstStride, stream);
+        return r < 0 ? r : 1;
     }
     if (c->mode == MODE_YUV2YUV && (c->srcFormat == GMAT_PIX_FMT_NV12) != (c->dstFormat == GMAT_PIX_FMT_NV12) &&
         !(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED") && atoi(GMAT_KNOB("GMAT_NO_RELAYOUT_FUSED")))) {
@@ -1716,6 +1788,7 @@ bool sws_owns_intermediates(const GmatSwsContext *c) { lines_ready(const_cast<Gm
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
+    if (c->mode == MODE_SCALE16 && c->s19.ok) return false;                                                      // (round 6: the lines of a tile live in LDS)
     if (c->mode == MODE_VIA_INNER || c->mode == MODE_SCALE16 || c->mode == MODE_VIA_PLANES16) return true;       // one set of intermediates per context
     if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
     return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
@@ -2308,12 +2381,18 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         const int odd = s16 ? 1 : 0;
         if ((((uintptr_t)dst[0] | (uintptr_t)dstStride[0] | (rgb64 ? 0 : ((uintptr_t)dst[1] | (uintptr_t)dstStride[1]))) & 1) != 0 ||
             (odd && (((uintptr_t)src[0] | (uintptr_t)src[1] | (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1]) & 1) != 0)) { r = GMAT_ERR(EINVAL); break; }
-        const int kind = c->srcFormat == GMAT_PIX_FMT_P010LE ? 10 : pl16_depth(c->srcFormat) == 10 ? 110 :
-                         c->srcFormat == GMAT_PIX_FMT_PRIV_RGB8_PLANES ? 14 : s16 ? 16 : 0;
+        const int kind = scale16_kind(c->srcFormat);
         const int bps = s16 ? 2 : 1;
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
         const int rcL = rgb64 ? 0 : c->rangeConv, rcC = rgb64 ? 0 : c->rangeConv ? c->rangeConv + 2 : 0;      // (swscale.c:536: not for RGB destinations)
+        if (c->s19.ok) {
+            const bool semiS = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);
+            const uint8_t *const sp[4] = {src[0], src[1], semiS ? nullptr : src[2], nullptr};
+            uint8_t *const dp[4] = {dst[0], dst[1], c->dstFormat == GMAT_PIX_FMT_P016LE ? nullptr : dst[2], nullptr};
+            r = scale19_frames(c, 1, sp, srcStride, dp, dstStride, c->stream);
+            break;
+        }
         if ((r = launch_hscale19(src[0], srcStride[0], kind, bps, c->srcW, c->srcH, c->d16[0], ly, c->dstW, c->stream, 0, rcL)) < 0) break;
         const bool semi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);           // interleaved U, V
         if (!semi && !src[2]) { r = GMAT_ERR(EINVAL); break; }

@@ -1,0 +1,537 @@
+// k_scale19.hip — libswscale's generic scaler for 16-bit YUV destinations (P016LE, YUV420P16LE, YUV444P16LE) in ONE launch, gfx950.
+//
+// The arithmetic is k_scale16.hip's (dstBpc = 16, utils.c:1561-1570): 19-bit lines held in int32,
+//   horizontal   hScale8To19_c    min(sum >> 3, 2^19 - 1)                          swscale.c:138-153
+//                hScale16To19_c   min(sum >> (depth - 5), 2^19 - 1)                swscale.c:63-91
+//   vertical     yuv2planeX_16_c  0x8000 + clip_int16(((1 << 14) - 0x40000000 + sum src * (unsigned)filter) >> 15)
+//                                 in 32-bit wrap-around arithmetic                 output.c:157-181
+//                yuv2nv12cX_16_c  the X form per chroma plane, interleaved         output.c:183-211
+// Round 5's last hour timed that two-pass path for the first time: P016LE 1080p -> 720p 35-41 us a frame, 0.03 of the roofline — five or
+// six launches a frame, two-byte gathers through the vector cache, the int32 lines of a whole frame through HBM.  Here a block owns a tile
+// of 64 output columns x TH output rows of a plane (or of both chroma planes):
+//   stage   the source rows the tile's vertical taps span, the samples its horizontal windows span, global -> LDS; whatever the source is
+//           (8- or 16-bit samples, interleaved or planar chroma, P010's shift) a staged row is a plane's row of 16-bit sample PAIRS, one
+//           dword a pair, 16-bit samples biased by -2^15 so that v_dot2_i32_i16 takes them (the bias returns as 2^15 sum(c) a column);
+//   pass H  a lane owns a column (its coefficient pairs stay in registers), a wave walks the staged rows four at a time: a pair of taps is
+//           one ds_read_b32 and one v_dot2_i32_i16; the 19-bit line values go to LDS;
+//   pass V  a thread owns four columns of an output row (two of each chroma plane where the destination interleaves them): ds_read_b128 of
+//           the lines, v_mad_i32_i24 (a 19-bit line x a 13-bit coefficient: the low 32 bits of the product ARE the 32-bit wrap-around
+//           product), the row's coefficients unpacked once a tile in LDS; four samples stored.
+// The lines never leave the CU; a frame is one launch, a batch of frames one launch too (grid.y).  First form of this file (profiles/r06a,
+// r06b): sample-by-sample LDS reads and v_mul_i32_i24 in pass H, column pairs in pass V — 45 + 35 VALU instructions an output, 9.0 us a
+// 1080p -> 720p frame batched: bound by instruction issue (a wave64 VALU instruction is 4 cycles on a SIMD here).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "px_math.h"
+
+// measurement builds (tools/build_variant.sh s19pN k_scale19.hip -DS19_PROBE=N; wrong pixels): 1 no staging, 2 no pass H, 3 no pass V (stores stay)
+#ifndef S19_PROBE
+#define S19_PROBE 0
+#endif
+
+namespace gmat {
+
+namespace {
+
+// lum / chrRange{To,From}Jpeg16_c on a 19-bit line value (swscale.c:189-226), as hscale19_kernel states them
+__device__ __forceinline__ int s19_range(int v, int rc)
+{
+    if (rc == 1)      v = (int)((unsigned)min(v, 30189 << 4) * 4769u - (unsigned)(39057361 << 2)) >> 12;
+    else if (rc == 2) v = (int)((unsigned)v * (unsigned)(14071 / 4) + (unsigned)((33561947 << 4) / 4)) >> 12;
+    else if (rc == 3) v = (int)((unsigned)min(v, 30775 << 4) * 4663u - (unsigned)(9289992 << 4)) >> 12;
+    else if (rc == 4) v = (int)((unsigned)v * 1799u + (unsigned)(4081085 << 4)) >> 11;
+    return v;
+}
+
+__device__ __forceinline__ int s19_dot2(unsigned samples, int coefs, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, samples), __builtin_bit_cast(short2v, coefs), acc, false);
+}
+
+// four samples of every component a source row image carries (one staging unit) -> sample pairs, 16-bit samples as v_dot2_i32_i16 takes them.
+// LAYOUT 0: 8-bit planar (4 bytes -> two pairs); 1: 8-bit interleaved (8 bytes -> two pairs each of A and B); 2: 16-bit planar (8 bytes);
+// 3: 16-bit interleaved (16 bytes)
+template <int LAYOUT>
+__device__ __forceinline__ void s19_pairs(const unsigned *v, unsigned xorv, bool shr6, unsigned &a0, unsigned &a1, unsigned &b0, unsigned &b1)
+{
+    b0 = b1 = 0;
+    if (LAYOUT == 0) {
+        a0 = (v[0] & 0xFFu) | (v[0] & 0xFF00u) << 8; a1 = (v[0] >> 16 & 0xFFu) | (v[0] >> 24) << 16;
+    } else if (LAYOUT == 1) {                                                   // u0 v0 u1 v1 | u2 v2 u3 v3
+        a0 = v[0] & 0x00FF00FFu; b0 = v[0] >> 8 & 0x00FF00FFu;
+        a1 = v[1] & 0x00FF00FFu; b1 = v[1] >> 8 & 0x00FF00FFu;
+    } else if (LAYOUT == 2) {
+        a0 = v[0]; a1 = v[1];
+    } else {                                                                    // (u0 v0) (u1 v1) (u2 v2) (u3 v3)
+        a0 = (v[0] & 0xFFFFu) | v[1] << 16; b0 = v[0] >> 16 | (v[1] & 0xFFFF0000u);
+        a1 = (v[2] & 0xFFFFu) | v[3] << 16; b1 = v[2] >> 16 | (v[3] & 0xFFFF0000u);
+    }
+    if (LAYOUT >= 2) {
+        if (shr6) { a0 = a0 >> 6 & 0x03FF03FFu; a1 = a1 >> 6 & 0x03FF03FFu; b0 = b0 >> 6 & 0x03FF03FFu; b1 = b1 >> 6 & 0x03FF03FFu; }
+        a0 ^= xorv; a1 ^= xorv; b0 ^= xorv; b1 ^= xorv;
+    }
+}
+
+// Staging: rows [0, gn) of one source row image -> staged rows.  sp: the image's row r0 + g0; B0: byte offset of the tile's first staged
+// sample group; out0 / out1: the staged rows of the component(s) the image carries, PP dwords a row; nunit units a row.
+// The fast form (every row address a multiple of 4, a row holds at least one unit) is split in two so that a group's loads are in flight while
+// the block filters the group before it: s19_issue asks for EVERY unit of the group at once — a lane takes unit (lane mod LPR) of rows
+// (lane / LPR) + 4 RPW u, u < U, CP column passes when a row has more than 64 units; SLOTS = CP U register slots of NDW dwords — with no branch
+// between the loads (a row past the group's last, a unit past the row's last repeat the last one: the same dwords are stored twice; a unit
+// past the row's last WHOLE one reads that one and stores zeros); s19_commit turns the registers into sample pairs in LDS.  The ONE unit that
+// straddles a row's end is patched byte by byte afterwards, a thread a row.  32-bit offsets from sp: a plane spans less than 4 GB.
+template <int LAYOUT, int SLOTS, int CP, int pfBase>
+__device__ __forceinline__ void s19_issue(const uint8_t *sp, unsigned stride, int rowBytes, int B0, int gn, int nunit, int lshift,
+                                          unsigned (&pf)[16], int tid)
+{
+    constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, UB = 4 * NDW, U = SLOTS / CP;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int LPR = 1 << lshift, RPW = 64 >> lshift;
+    const int ul = lane & (LPR - 1), row0 = wave * RPW + (lane >> lshift);
+    const int offLast = (rowBytes / UB - 1) * UB;                               // the last whole unit of a row from its start
+    const unsigned gstep = (unsigned)(4 * RPW) * stride;
+#pragma unroll
+    for (int cp = 0; cp < CP; cp++) {
+        const int u0 = min(ul + cp * LPR, nunit - 1);
+        const unsigned offc = (unsigned)min(B0 + u0 * UB, offLast);
+        const unsigned gLast = (unsigned)(gn - 1) * stride + offc, g = (unsigned)row0 * stride + offc;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned *gp = reinterpret_cast<const unsigned *>(sp + min(g + u * gstep, gLast));
+#pragma unroll
+            for (int i = 0; i < NDW; i++) pf[pfBase + (cp * U + u) * NDW + i] = gp[i];
+        }
+    }
+}
+
+template <int LAYOUT, int SLOTS, int CP, int pfBase>
+__device__ __forceinline__ void s19_commit(int rowBytes, int B0, int gn, int nunit, int lshift, unsigned xorv, bool shr6,
+                                           unsigned *out0, unsigned *out1, int PP, const unsigned (&pf)[16], int tid)
+{
+    constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, UB = 4 * NDW, U = SLOTS / CP;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int LPR = 1 << lshift, RPW = 64 >> lshift;
+    const int ul = lane & (LPR - 1), row0 = wave * RPW + (lane >> lshift);
+    const unsigned lstep = (unsigned)(4 * RPW * PP);
+#pragma unroll
+    for (int cp = 0; cp < CP; cp++) {
+        const int u0 = min(ul + cp * LPR, nunit - 1);
+        const bool whole = B0 + u0 * UB + UB <= rowBytes;
+        const unsigned lLast = (unsigned)((gn - 1) * PP + 2 * u0), l = (unsigned)(row0 * PP + 2 * u0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            unsigned a0, a1, b0, b1, z[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; i++) z[i] = whole ? pf[pfBase + (cp * U + u) * NDW + i] : 0u;
+            s19_pairs<LAYOUT>(z, xorv, shr6, a0, a1, b0, b1);
+            const unsigned lo = min(l + u * lstep, lLast);
+            *reinterpret_cast<uint2 *>(out0 + lo) = make_uint2(a0, a1);
+            if (LAYOUT == 1 || LAYOUT == 3) *reinterpret_cast<uint2 *>(out1 + lo) = make_uint2(b0, b1);
+        }
+    }
+}
+
+// the byte-by-byte forms: one unit of every row (the fast form's straddling unit: unit >= 0), or every unit (any alignment: unit < 0)
+template <int LAYOUT>
+__device__ __forceinline__ void s19_stage_bytes(const uint8_t *sp, int stride, int rowBytes, int B0, int gn, int nunit, int unit, unsigned xorv, bool shr6,
+                                                unsigned *out0, unsigned *out1, int PP, int tid)
+{
+    constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, UB = 4 * NDW;
+    const int per = unit >= 0 ? 1 : nunit;
+    for (int it = tid; it < gn * per; it += 256) {
+        const int rr = it / per, u0 = unit >= 0 ? unit : it - rr * per;
+        unsigned z[NDW], a0, a1, b0, b1;
+        const uint8_t *rowp = sp + (size_t)rr * stride;
+        for (int i = 0; i < NDW; i++) {
+            z[i] = 0;
+            for (int q = 0; q < 4; q++)
+                if (B0 + u0 * UB + 4 * i + q < rowBytes) z[i] |= (unsigned)rowp[B0 + u0 * UB + 4 * i + q] << (8 * q);   // (past the row: zero — those taps' coefficients are)
+        }
+        s19_pairs<LAYOUT>(z, xorv, shr6, a0, a1, b0, b1);
+        *reinterpret_cast<uint2 *>(out0 + (size_t)rr * PP + 2 * u0) = make_uint2(a0, a1);
+        if (LAYOUT == 1 || LAYOUT == 3) *reinterpret_cast<uint2 *>(out1 + (size_t)rr * PP + 2 * u0) = make_uint2(b0, b1);
+    }
+}
+
+// the instance of a (layout, images) pair: 16 register dwords a lane in all
+#define S19_FOR_LAYOUT(CALL)                                                      \
+    do {                                                                          \
+        if (J.layout == 0) { if (J.nraw == 1) { CALL(0, 16) } else { CALL(0, 8) } } \
+        else if (J.layout == 1) { CALL(1, 8) }                                    \
+        else if (J.layout == 2) { if (J.nraw == 1) { CALL(2, 8) } else { CALL(2, 4) } } \
+        else { CALL(3, 4) }                                                       \
+    } while (0)
+
+// pass H of four staged rows (rows past the group's last repeat it) for the lane's column; rc0: the lane's window in the group's first row
+template <int NP, bool RC>
+__device__ __forceinline__ void s19_hrows(const unsigned *rc0, int PP, int rb, int gn, const int *cf, const int32_t *cfg, int hp, unsigned bias,
+                                          int sh, int maxv, int rc, int32_t *lrow, int lane)
+{
+    int acc[4] = {0, 0, 0, 0};
+    int ro[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) ro[u] = min(rb + 4 * u, gn - 1);
+    if (NP > 0) {
+        unsigned s[4][NP > 0 ? NP : 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int k = 0; k < (NP > 0 ? NP : 1); k++) s[u][k] = rc0[ro[u] * PP + k];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int k = 0; k < (NP > 0 ? NP : 1); k++) acc[u] = s19_dot2(s[u][k], cf[k], acc[u]);
+    } else {
+        for (int k = 0; k < hp; k++) {
+            const int cc = cfg[k];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] = s19_dot2(rc0[ro[u] * PP + k], cc, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int v = min((int)((unsigned)acc[u] + bias) >> sh, maxv);       // (the sums start at 0: a biased sum stays inside 2^31 while sum |c| < 2^16, plan_job)
+        if (RC) v = s19_range(v, rc);
+        lrow[ro[u] * kS19TW + lane] = v;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
+{
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_base);
+    // workgroups go round the eight XCDs in launch order (observed, MI355X_MICROARCH.md): each XCD takes one contiguous range of (frame, tile)
+    // items, so that the tiles that share source lines — neighbours across, the rows two tile rows overlap in — meet in ONE L2
+    int item = blockIdx.x;
+    if (a.xcdRemap) {
+        const int per = (int)gridDim.x >> 3;
+        if (item < per * 8) item = (item & 7) * per + (item >> 3);
+    }
+    const int nb = a.job[0].nblk + a.job[1].nblk;
+    const int f = item / nb;
+    int b = item - f * nb;
+    const int ji = b >= a.job[0].nblk ? 1 : 0;
+    if (ji) b -= a.job[0].nblk;
+    const S19Job &J = a.job[ji];
+    const int tx = b % J.ntx, ty = b / J.ntx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = tx * kS19TW, y0 = ty * J.TH;
+    const int r0 = J.rowStart[ty], nr = J.rowCount[ty], c0 = J.colStart[tx];
+    // LDS: the tile rows' vertical tables (window start, then 2 vp coefficients a row), the staged rows (ncomp x G x PP dwords), the lines
+    const int vp = J.v.pairs, PP = J.PP;
+    int32_t *vtab = reinterpret_cast<int32_t *>(lds);
+    unsigned *raw = reinterpret_cast<unsigned *>(lds + J.vtBytes);
+    int32_t *lines = reinterpret_cast<int32_t *>(raw + (size_t)J.ncomp * J.G * PP);
+    auto src_ptr = [&](int sel) -> const uint8_t * { return sel == 0 ? fr.y[f] : sel == 1 ? fr.u[f] : fr.v[f]; };
+    auto dst_ptr = [&](int sel) -> uint8_t * { return sel == 0 ? fr.dst[f] : sel == 1 ? fr.dstU[f] : fr.dstV[f]; };
+
+    const int nunit = PP >> 1;
+    const int sgb = J.layout == 0 ? 1 : J.layout == 3 ? 4 : 2;                  // bytes a sample group (a sample of every component of the row image)
+    const int B0 = c0 * sgb, UBrt = 4 * sgb;
+    const bool fast = a.srcAl4 != 0 && J.rowBytes >= UBrt;
+    const bool shr6 = J.kind == 10;
+    // the unit that straddles the row's end (fast form only; block-uniform)
+    const int upart = (J.rowBytes > B0 && (J.rowBytes - B0) % UBrt != 0 && (J.rowBytes - B0) / UBrt < nunit) ? (J.rowBytes - B0) / UBrt : -1;
+    unsigned pf[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) pf[i] = 0;
+    // (the two row images of planar chroma take register slots 0-7 and 8-15: the slot base is a template argument — a run-time base made
+    // the compiler index the register file through M0)
+    auto issue = [&](int g0) {
+        const int gn = min(J.G, nr - g0);
+        {
+            const uint8_t *sp = src_ptr(J.rawSel[0]) + (size_t)(r0 + g0) * J.rawStride[0];
+#define S19_ISSUE(L_, S_) if (J.cp2) s19_issue<L_, S_, 2, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); \
+                          else       s19_issue<L_, S_, 1, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
+            S19_FOR_LAYOUT(S19_ISSUE);
+#undef S19_ISSUE
+        }
+        if (J.nraw == 2) {
+            const uint8_t *sp = src_ptr(J.rawSel[1]) + (size_t)(r0 + g0) * J.rawStride[1];
+            if (J.layout == 0) { if (J.cp2) s19_issue<0, 8, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
+                                 else       s19_issue<0, 8, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); }
+            else               { if (J.cp2) s19_issue<2, 4, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
+                                 else       s19_issue<2, 4, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); }
+        }
+    };
+    if (fast && S19_PROBE != 1) issue(0);                                     // the first group's rows: asked for before anything else is
+
+    // the lane's column: first pair of its window in a staged row, coefficient pairs, the bias the staged samples carry
+    const int hp = J.h.pairs;
+    const int x = x0 + lane;
+    const bool xin = x < J.dstW;
+    const int q0 = xin ? (J.h.pos_even[x] - c0) >> 1 : 0;
+    const int32_t *cfg = J.h.packed + (size_t)(xin ? x : 0) * hp;
+    int cf[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int k = 0; k < (NP > 0 ? NP : 1); k++) cf[k] = (NP > 0 && xin && k < hp) ? cfg[k] : 0;
+    unsigned bias = 0;
+    if (J.xorv) {
+        int sum = 0;
+        if (NP > 0) {
+#pragma unroll
+            for (int k = 0; k < (NP > 0 ? NP : 1); k++) sum += (int)(short)(cf[k] & 0xFFFF) + (cf[k] >> 16);
+        } else if (xin)
+            for (int k = 0; k < hp; k++) sum += (int)(short)(cfg[k] & 0xFFFF) + (cfg[k] >> 16);
+        bias = (unsigned)sum << 15;
+    }
+    {   // the vertical tables of the tile's rows (read back in pass V, two barriers from here)
+        const int nrow = min(J.TH, J.dstH - y0);
+        for (int i = tid; i < nrow * vp; i += 256) {
+            const int c = J.v.packed[(size_t)y0 * vp + i];
+            vtab[J.TH + 2 * i] = (int)(short)(c & 0xFFFF); vtab[J.TH + 2 * i + 1] = c >> 16;
+        }
+        if (tid < nrow) vtab[tid] = J.v.pos_even[y0 + tid];
+    }
+
+    for (int g0 = 0; g0 < nr; g0 += J.G) {
+        const int gn = min(J.G, nr - g0);
+        if (g0) __syncthreads();                                               // the previous group's windows have been read
+        if (S19_PROBE != 1 && fast) {
+            unsigned *o0 = raw, *o1 = raw + (size_t)J.G * PP;
+#define S19_COMMIT(L_, S_) if (J.cp2) s19_commit<L_, S_, 2, 0>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o0, o1, PP, pf, tid); \
+                           else       s19_commit<L_, S_, 1, 0>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o0, o1, PP, pf, tid);
+            S19_FOR_LAYOUT(S19_COMMIT);
+#undef S19_COMMIT
+            if (J.nraw == 2) {
+                if (J.layout == 0) { if (J.cp2) s19_commit<0, 8, 2, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid);
+                                     else       s19_commit<0, 8, 1, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid); }
+                else               { if (J.cp2) s19_commit<2, 4, 2, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid);
+                                     else       s19_commit<2, 4, 1, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid); }
+            }
+        }
+        if (S19_PROBE != 1 && (!fast || upart >= 0)) {
+            if (fast) __syncthreads();                                          // after the zeros the fast form left in the straddling unit
+            for (int i = 0; i < J.nraw; i++) {
+                unsigned *o0 = raw + (size_t)i * J.G * PP, *o1 = raw + (size_t)J.G * PP;
+                const uint8_t *sp = src_ptr(J.rawSel[i]) + (size_t)(r0 + g0) * J.rawStride[i];
+#define S19_BYTES(L_, S_) s19_stage_bytes<L_>(sp, J.rawStride[i], J.rowBytes, B0, gn, nunit, fast ? upart : -1, J.xorv, shr6, o0, o1, PP, tid);
+                S19_FOR_LAYOUT(S19_BYTES);
+#undef S19_BYTES
+            }
+        }
+        __syncthreads();
+        if (fast && S19_PROBE != 1 && g0 + J.G < nr) issue(g0 + J.G);          // in flight while this group is filtered
+        // pass H: four staged rows a wave at a time (their window reads in flight together)
+        for (int c = 0; c < (S19_PROBE == 2 ? 0 : J.ncomp); c++) {
+            const unsigned *rc0 = raw + (size_t)c * J.G * PP + q0;
+            int32_t *lrow = lines + (size_t)(c * J.nrLines + g0) * kS19TW;
+            if (J.rc == 0) for (int rb = wave; rb < gn; rb += 16) s19_hrows<NP, false>(rc0, PP, rb, gn, cf, cfg, xin ? hp : 0, bias, J.sh, J.maxv, 0, lrow, lane);
+            else           for (int rb = wave; rb < gn; rb += 16) s19_hrows<NP, true>(rc0, PP, rb, gn, cf, cfg, xin ? hp : 0, bias, J.sh, J.maxv, J.rc, lrow, lane);
+        }
+    }
+    __syncthreads();
+
+    // pass V.  The rows of `lines` from nr on (a window's padded taps past the plane) hold whatever the LDS held: their coefficients are zero
+    // and v_mul_i32_i24 of anything by zero is zero.
+    const int yEnd = min(y0 + J.TH, J.dstH);
+    const unsigned k0 = (1u << 14) - 0x40000000u;
+    auto out16 = [](unsigned acc) -> unsigned { return (unsigned)(min(max((int)acc >> 15, -32768), 32767) + 0x8000); };
+    if (J.ileave) {
+        // a thread: columns (2 cp, 2 cp + 1) of both chroma planes, 32 pairs a row, 8 rows a step; (U, V) dwords stored
+        const int cp = tid & 31, xo = x0 + 2 * cp;
+        if (xo < J.dstW)
+            for (int y = y0 + (tid >> 5); y < yEnd; y += 8) {
+                const int32_t *la = lines + (size_t)(vtab[y - y0] - r0) * kS19TW + 2 * cp, *lb = la + (size_t)J.nrLines * kS19TW;
+                const int32_t *vc = vtab + J.TH + (y - y0) * 2 * vp;
+                unsigned u0 = k0, u1 = k0, v0 = k0, v1 = k0;
+#pragma unroll 2
+                for (int k = 0; k < (S19_PROBE == 3 ? 0 : vp); k++) {
+                    const int2 cc = *reinterpret_cast<const int2 *>(vc + 2 * k);
+                    const int2 a0 = *reinterpret_cast<const int2 *>(la + (2 * k) * kS19TW), a1 = *reinterpret_cast<const int2 *>(la + (2 * k + 1) * kS19TW);
+                    const int2 b0 = *reinterpret_cast<const int2 *>(lb + (2 * k) * kS19TW), b1 = *reinterpret_cast<const int2 *>(lb + (2 * k + 1) * kS19TW);
+                    u0 += (unsigned)__mul24(a0.x, cc.x) + (unsigned)__mul24(a1.x, cc.y); u1 += (unsigned)__mul24(a0.y, cc.x) + (unsigned)__mul24(a1.y, cc.y);
+                    v0 += (unsigned)__mul24(b0.x, cc.x) + (unsigned)__mul24(b1.x, cc.y); v1 += (unsigned)__mul24(b0.y, cc.x) + (unsigned)__mul24(b1.y, cc.y);
+                }
+                const unsigned d0 = out16(u0) | out16(v0) << 16, d1 = out16(u1) | out16(v1) << 16;
+                uint8_t *d = dst_ptr(J.dstSel[0]) + J.dstOff[0] + (size_t)y * J.ds[0] + 4 * (size_t)xo;
+                const bool two = xo + 1 < J.dstW;
+                if (a.dstAl4) {
+                    reinterpret_cast<unsigned *>(d)[0] = d0;
+                    if (two) reinterpret_cast<unsigned *>(d)[1] = d1;
+                } else {
+                    unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+                    d16[0] = (unsigned short)d0; d16[1] = (unsigned short)(d0 >> 16);
+                    if (two) { d16[2] = (unsigned short)d1; d16[3] = (unsigned short)(d1 >> 16); }
+                }
+            }
+    } else {
+        // a thread: columns 4 q .. 4 q + 3 of a plane, 16 quads a row, 16 rows a step
+        const int q = tid & 15, xo = x0 + 4 * q;
+        if (xo < J.dstW)
+            for (int y = y0 + (tid >> 4); y < yEnd; y += 16) {
+                const int32_t *vc = vtab + J.TH + (y - y0) * 2 * vp;
+                const int p0 = vtab[y - y0] - r0;
+                for (int c = 0; c < J.ncomp; c++) {
+                    const int32_t *la = lines + (size_t)(c * J.nrLines + p0) * kS19TW + 4 * q;
+                    unsigned o0 = k0, o1 = k0, o2 = k0, o3 = k0;
+#pragma unroll 2
+                    for (int k = 0; k < (S19_PROBE == 3 ? 0 : vp); k++) {
+                        const int2 cc = *reinterpret_cast<const int2 *>(vc + 2 * k);
+                        const int4 a0 = *reinterpret_cast<const int4 *>(la + (2 * k) * kS19TW), a1 = *reinterpret_cast<const int4 *>(la + (2 * k + 1) * kS19TW);
+                        o0 += (unsigned)__mul24(a0.x, cc.x) + (unsigned)__mul24(a1.x, cc.y); o1 += (unsigned)__mul24(a0.y, cc.x) + (unsigned)__mul24(a1.y, cc.y);
+                        o2 += (unsigned)__mul24(a0.z, cc.x) + (unsigned)__mul24(a1.z, cc.y); o3 += (unsigned)__mul24(a0.w, cc.x) + (unsigned)__mul24(a1.w, cc.y);
+                    }
+                    const unsigned d0 = out16(o0) | out16(o1) << 16, d1 = out16(o2) | out16(o3) << 16;
+                    uint8_t *d = dst_ptr(J.dstSel[c]) + J.dstOff[c] + (size_t)y * J.ds[c] + 2 * (size_t)xo;
+                    const int n = min(4, J.dstW - xo);
+                    if (a.dstAl4 && n == 4) { reinterpret_cast<unsigned *>(d)[0] = d0; reinterpret_cast<unsigned *>(d)[1] = d1; }
+                    else {
+                        unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+                        d16[0] = (unsigned short)d0;
+                        if (n > 1) d16[1] = (unsigned short)(d0 >> 16);
+                        if (n > 2) d16[2] = (unsigned short)d1;
+                        if (n > 3) d16[3] = (unsigned short)(d1 >> 16);
+                    }
+                }
+            }
+    }
+}
+
+// the tiles of one job: windows across (sample pairs of a staged row), windows down (source rows) for the tallest tile the LDS budget holds.
+// Refuses (ENOSYS: the two passes take the context) a bank whose padded taps past the plane are not all zero or whose coefficients could
+// carry a biased sum past 2^31.
+int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int dstW, int dstH, int ncomp, int nraw, int layout, int hpairs, int budget, int thCap,
+             S19Job &J, std::vector<int32_t> &colStart, std::vector<int32_t> &rowStart, std::vector<int32_t> &rowCount)
+{
+    if (h.count != dstW || v.count != dstH || h.pairs < 1 || v.pairs < 1) return GMAT_ERR(EINVAL);
+    for (int x = 0; x < dstW; x++) {
+        long sumAbs = 0;
+        for (int k = 0; k < h.pairs; k++) {
+            const int32_t c = h.packed[(size_t)x * h.pairs + k];
+            const int c0 = (int16_t)(c & 0xFFFF), c1 = c >> 16;
+            sumAbs += std::abs(c0) + std::abs(c1);
+            if ((c0 && h.pos_even[x] + 2 * k >= srcW) || (c1 && h.pos_even[x] + 2 * k + 1 >= srcW)) return GMAT_ERR(ENOSYS);
+        }
+        if (sumAbs > 65535 || h.pos_even[x] < 0 || (h.pos_even[x] & 1)) return GMAT_ERR(ENOSYS);
+    }
+    for (int y = 0; y < dstH; y++)
+        for (int k = 0; k < v.pairs; k++) {
+            const int32_t c = v.packed[(size_t)y * v.pairs + k];
+            if (((c & 0xFFFF) && v.pos_even[y] + 2 * k >= srcH) || ((c >> 16) && v.pos_even[y] + 2 * k + 1 >= srcH)) return GMAT_ERR(ENOSYS);
+        }
+    J.ntx = (dstW + kS19TW - 1) / kS19TW;
+    colStart.assign(J.ntx, 0);
+    long PP = 4;
+    for (int tx = 0; tx < J.ntx; tx++) {
+        long lo = LONG_MAX, hi = 0;
+        for (int x = tx * kS19TW; x < std::min(dstW, (tx + 1) * kS19TW); x++) {
+            lo = std::min(lo, (long)h.pos_even[x]);
+            hi = std::max(hi, (long)h.pos_even[x] + 2 * hpairs);
+        }
+        const long c0 = lo & ~3L;
+        colStart[tx] = (int32_t)c0;
+        PP = std::max(PP, ((hi - c0 + 7) >> 3) * 4);                           // whole units of four samples = two pairs; rows of whole 16 bytes
+    }
+    if (PP > 4096) return GMAT_ERR(ENOSYS);
+    J.PP = (int)PP;
+    if (PP / 2 > 128) return GMAT_ERR(ENOSYS);                                 // (a lane stages at most two units of a row)
+    J.lshift = 0;
+    while ((1 << J.lshift) < PP / 2 && J.lshift < 6) J.lshift++;              // lanes a staged row's units take (a power of two)
+    J.cp2 = PP / 2 > 64;
+    // rows one s19_issue covers: 16 register dwords a lane = slots of a unit, over the row images and the column passes
+    const int ndw = layout == 0 ? 1 : layout == 3 ? 4 : 2;
+    const int gcap = 4 * (64 >> J.lshift) * std::max(1, 16 / (ndw * nraw) / (J.cp2 ? 2 : 1));
+    static const int kTH[] = {64, 48, 40, 32, 24, 16, 12, 8, 4, 2, 1};
+    for (int TH : kTH) {
+        if (TH > thCap) continue;
+        const int nty = (dstH + TH - 1) / TH;
+        std::vector<int32_t> rs(nty), rc(nty);
+        int nrMax = 1, nrLines = 1;
+        for (int ty = 0; ty < nty; ty++) {
+            int lo = INT_MAX, hi = 0;
+            for (int y = ty * TH; y < std::min(dstH, (ty + 1) * TH); y++) {
+                lo = std::min(lo, v.pos_even[y]);
+                hi = std::max(hi, v.pos_even[y] + 2 * v.pairs);
+            }
+            if (lo < 0 || lo >= srcH) return GMAT_ERR(EINVAL);
+            nrLines = std::max(nrLines, hi - lo);
+            hi = std::min(hi, srcH);
+            rs[ty] = lo; rc[ty] = hi - lo;
+            nrMax = std::max(nrMax, hi - lo);
+        }
+        const long linesBytes = (long)ncomp * nrLines * kS19TW * 4, vtBytes = ((long)TH * (2 * v.pairs + 1) * 4 + 15) & ~15L;
+        // rows staged at once: all of a tile's when they fit a third of the budget (at least 4 KB), else as many (a multiple of 4, the waves)
+        const long rawBudget = std::max(4096L, (long)budget / 3), rowB = (long)ncomp * PP * 4;
+        int G = (int)std::min<long>(std::min(nrMax, gcap), rawBudget / rowB);
+        if (G < nrMax && G >= 4) G &= ~3;
+        if (G < 1) { if (TH == 1) return GMAT_ERR(ENOSYS); continue; }
+        const long total = vtBytes + G * rowB + linesBytes;
+        if (total > budget && TH > 1) continue;
+        if (total > 65536) return GMAT_ERR(ENOSYS);
+        J.TH = TH; J.nty = nty; J.nblk = J.ntx * nty; J.nrMax = nrMax; J.nrLines = nrLines; J.G = G; J.vtBytes = (int)vtBytes;
+        rowStart.swap(rs); rowCount.swap(rc);
+        return (int)((total + 15) & ~15L);
+    }
+    return GMAT_ERR(ENOSYS);
+}
+
+} // namespace
+
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, S19Tables &t)
+{
+    t.ok = 0;
+    // (measured: DESIGN 4.8) LDS a block may take, output rows a tile at most
+    const char *ks = GMAT_KNOB("GMAT_S19_LDS"), *kr = GMAT_KNOB("GMAT_S19_ROWS");
+    const int budget = ks ? std::min(std::max(atoi(ks), 4096), 65536) : 32768;
+    const int thCap = kr ? std::max(1, atoi(kr)) : 64;
+    const int sh = kind == 0 ? 3 : kind % 100 - 5;                                // hScale8To19_c: 3; hScale16To19_c: depth - 5 (kind 14: 9)
+    const unsigned xorv = (bps == 2 && kind != 10) ? 0x80008000u : 0u;            // 16-bit samples as v_dot2_i32_i16 takes them (P010's ten bits fit as they are)
+    S19Job &L = t.job[0], &C = t.job[1];
+    std::memset(&L, 0, sizeof(L)); std::memset(&C, 0, sizeof(C));
+    L.ncomp = 1; L.nraw = 1; L.ileave = 0; L.layout = bps == 2 ? 2 : 0;
+    L.rawSel[0] = 0;
+    L.kind = kind; L.xorv = xorv; L.rowBytes = p.srcW * bps;
+    L.srcW = p.srcW; L.srcH = p.srcH; L.dstW = p.dstW; L.dstH = p.dstH;
+    L.dstSel[0] = 0; L.dstOff[0] = 0;
+    L.sh = sh; L.maxv = (1 << 19) - 1;
+    const int hp = std::max(p.hLum.pairs, p.hChr.pairs);
+    t.np = hp <= 4 ? 4 : hp <= 8 ? 8 : 0;
+    int r = plan_job(p.hLum, vl, p.srcW, p.srcH, p.dstW, p.dstH, 1, 1, L.layout, t.np ? t.np : p.hLum.pairs, budget, thCap, L, t.colStart[0], t.rowStart[0], t.rowCount[0]);
+    if (r < 0) return r;
+    int lds = r;
+    C.ncomp = 2; C.nraw = srcSemi ? 1 : 2; C.ileave = dstSemi ? 1 : 0; C.layout = (bps == 2 ? 2 : 0) + (srcSemi ? 1 : 0);
+    C.rawSel[0] = 1; C.rawSel[1] = 2;
+    C.kind = kind; C.xorv = xorv; C.rowBytes = p.chrSrcW * bps * (srcSemi ? 2 : 1);
+    C.srcW = p.chrSrcW; C.srcH = p.chrSrcH; C.dstW = p.chrDstW; C.dstH = p.chrDstH;
+    C.dstSel[0] = 1; C.dstSel[1] = dstSemi ? 1 : 2;
+    C.dstOff[0] = 0; C.dstOff[1] = dstSemi ? 2 : 0;
+    C.sh = sh; C.maxv = (1 << 19) - 1;
+    r = plan_job(p.hChr, vc, p.chrSrcW, p.chrSrcH, p.chrDstW, p.chrDstH, 2, C.nraw, C.layout, t.np ? t.np : p.hChr.pairs, budget, thCap, C, t.colStart[1], t.rowStart[1], t.rowCount[1]);
+    if (r < 0) return r;
+    lds = std::max(lds, r);
+    t.ldsBytes = lds;
+    if (GMAT_KNOB("GMAT_S19_DEBUG"))
+        for (int j = 0; j < 2; j++)
+            fprintf(stderr, "s19 job %d: %d x %d -> %d x %d layout %d np %d vp %d TH %d tiles %d x %d nrMax %d nrLines %d PP %d G %d lshift %d lds %d\n", j, t.job[j].srcW, t.job[j].srcH,
+                    t.job[j].dstW, t.job[j].dstH, t.job[j].layout, t.np, j ? vc.pairs : vl.pairs, t.job[j].TH, t.job[j].ntx, t.job[j].nty, t.job[j].nrMax, t.job[j].nrLines, t.job[j].PP, t.job[j].G, t.job[j].lshift, lds);
+    t.ok = 1;
+    return 0;
+}
+
+int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || ldsBytes < 1 || ldsBytes > 65536) return GMAT_ERR(EINVAL);
+    S19Args a = a0;
+    const dim3 grid((a.job[0].nblk + a.job[1].nblk) * nframes), block(256);
+    const Yuv2xFrames &fr = *frames;
+    const char *kx = GMAT_KNOB("GMAT_SCALE_XCD");
+    a.xcdRemap = kx ? atoi(kx) != 0 : 1;
+    switch (np) {
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<4>), grid, block, ldsBytes, stream, a, fr); break;
+    case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<8>), grid, block, ldsBytes, stream, a, fr); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<0>), grid, block, ldsBytes, stream, a, fr); break;
+    }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+} // namespace gmat

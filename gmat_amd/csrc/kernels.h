@@ -144,6 +144,36 @@ int launch_hscale19(const uint8_t *src, int srcStride, int kind, int step, int s
 int launch_vscale16(const int32_t *lineA, const int32_t *lineB, int lineW, int lineH, const DevFilter &f, uint8_t *dst, int dstStride,
                     int dstW, int dstH, hipStream_t stream);
 
+// ---- 16-bit YUV destinations in ONE launch (k_scale19.hip, round 6): the two passes above with the 19-bit lines of a tile in LDS ----
+// A job = the 64-column tiles of the luma plane (one component) or of the two chroma planes side by side (two components: one staged row
+// image when the source interleaves them, one dword a sample pair stored when the destination does).
+constexpr int kS19TW = 64;
+struct S19Job {
+    int ncomp, nraw, ileave;              // components (1: the luma plane, 2: the chroma planes); source row images (1: interleaved chroma); interleaved destination
+    int layout;                           // 0: 8-bit planar samples, 1: 8-bit interleaved, 2: 16-bit planar, 3: 16-bit interleaved
+    int rawSel[2], rawStride[2];          // source row image i: the frame's source pointer (0 y, 1 u, 2 v); (per call) its pitch
+    int rowBytes;                         // valid bytes of a source row
+    int kind; unsigned xorv;              // 10: P010's >> 6; what a staged pair of 16-bit samples is XORed with (the bias v_dot2_i32_i16 needs)
+    int srcW, srcH, dstW, dstH;
+    int dstSel[2], dstOff[2], ds[2];      // component c: the frame's destination pointer (0 dst, 1 dstU, 2 dstV) + a byte offset; (per call) its pitch
+    DevFilter h, v;
+    int sh, maxv, rc;                     // hScale*To19_c's shift and clamp; (per call) range conversion of the lines (hscale19_kernel's codes)
+    int TH, ntx, nty, nblk;               // output rows a tile, tiles across / down
+    int lshift, cp2;                      // log2 of the lanes that share a staged row's units; a row has more than 64 units (a lane stages two)
+    int nrMax, nrLines, PP, G, vtBytes;   // most source rows a tile's taps span (inside the plane / with the padded taps); dwords (sample pairs) a staged row; rows staged at once; bytes of a tile's vertical tables
+    const int32_t *colStart;              // [ntx] first staged sample of a tile column's rows (a multiple of 4)
+    const int32_t *rowStart, *rowCount;   // [nty] source rows a tile row's taps span
+};
+struct S19Tables {
+    int ok = 0, np = 0, ldsBytes = 0;     // np: 4 | 8 horizontal pairs in registers, 0 = any number (coefficients read in the loop)
+    S19Job job[2];                        // luma, chroma (device pointers left null: the caller uploads col / row tables and fills them in)
+    std::vector<int32_t> colStart[2], rowStart[2], rowCount[2];
+};
+struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; };
+// hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, S19Tables &t);
+int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)
 int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
                    const DevFilter &fc, int chrShift, uint8_t *dst, int dstStride, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,

@@ -519,13 +519,16 @@ def test_p010_destination(dev, orc, src_fmt, geom):
                 p.free()
 
 
+@pytest.mark.parametrize("form", ["tile", "passes"])
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p", "yuv444p", "p010le", "p016le"])
 @pytest.mark.parametrize("geom", [(256, 64, 128, 32), (96, 40, 144, 60), (201, 91, 151, 67), (130, 50, 130, 50)])
-def test_p016_destination(dev, orc, src_fmt, geom):
+def test_p016_destination(dev, orc, src_fmt, geom, form, monkeypatch):
     """P016LE as a (scaled) destination: dstBpc = 16 switches to 19-bit int32 lines — hScale8To19_c / hScale16To19_c,
-    yuv2plane1_16_c / yuv2planeX_16_c / yuv2nv12cX_16_c (32-bit wrap-around accumulation, output.c:143-211); the
-    two-pass path of k_scale16.hip"""
+    yuv2plane1_16_c / yuv2planeX_16_c / yuv2nv12cX_16_c (32-bit wrap-around accumulation, output.c:143-211); in one launch with a tile's
+    lines in LDS (k_scale19.hip, round 6) and as the two passes of k_scale16.hip behind GMAT_S19=0"""
     sw, sh, dw, dh = geom
+    if form == "passes":
+        monkeypatch.setenv("GMAT_S19", "0")
     if (sw, sh) == (dw, dh) and src_fmt in ("nv12", "yuv420p", "p016le"):
         pytest.skip("equal-size 8-bit 4:2:0 -> P016 is the depth-expansion converter, P016 -> P016 a plane copy")
     src = synth_planes(orc, src_fmt, sw, sh, seed=75)
@@ -534,7 +537,7 @@ def test_p016_destination(dev, orc, src_fmt, geom):
         for align, extra in ((64, 0), (2, 2)):
             d = dev.upload_planes(src, align, extra)
             got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "p016le", SWS[flags], dst_align=align, dst_extra=extra)
-            assert "vscale16" in kernel, kernel
+            assert kernel == ("scale19_kernel" if form == "tile" else "hscale19_kernel+vscale16_kernel"), kernel
             for i, (g, wv) in enumerate(zip(got, want)):
                 bad = np.argwhere(g != wv)
                 assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({flags}, align {align})"

@@ -351,6 +351,10 @@ int main(int argc, char **argv)
         {"rgbsrc: yuv444p16le 4K->1080p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 3840, 2160, GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: p016 4K->1080p p016 bicubic", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: p016 1080p->720p p016 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"dst16: nv12 1080p->720p p016 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"dst16: p010 4K->1080p p016 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: p016 720p->1080p p016 bicubic (up)", GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: p016 4K->720p p016 lanczos (3:1)", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_LANCZOS},
         {"rgbsrc: yuv444p 1080p->720p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_PIX_FMT_YUV444P, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 4K->1080p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
