@@ -112,6 +112,13 @@ int gmat_device_numa_node(int device)
     return atoi(buf);                                           // -1: the platform reports no affinity
 }
 
+int gmat_device_compute_units(int device)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GMAT_ERR(EINVAL);
+    return prop.multiProcessorCount;
+}
+
 int gmat_bind_thread_to_device(int device)
 {
     char dir[128], buf[4096];

@@ -187,6 +187,7 @@ struct GmatSwsContext {
     DevFilterStore f16[4];
     DevFilter d16[4];                 // hLum, hChr, vLum, vChr
     DevBuf line16[3];                 // luma, U, V: srcH x dstW / chrSrcH x chrDstW int32
+    mutable int shift8Ident = -1;     // shift8_shortcut's answer about the active plan's four banks (-1: not asked since the plan was last built)
     S19Tables s19;                    // (round 6) 16-bit YUV destinations in one launch, the lines of a tile in LDS (k_scale19.hip); s19.ok = 0: the two passes
     DevBuf dS19[6];                   // its tables: per job the tile columns' first bytes, the tile rows' first source rows and their counts
     unsigned long long *prof = nullptr;
@@ -226,6 +227,7 @@ static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f) || 
 static int init_yuv_scaler(GmatSwsContext *c)
 {
     if (c->yuvReady) return 0;
+    c->shift8Ident = -1;
     int r = build_scale_plan(c->planYuv, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param,
                              c->chrPos);
     if (r < 0) return r;
@@ -362,6 +364,7 @@ static int init_scaler(GmatSwsContext *c)
     if (c->rgbReady) return 0;
     const bool src_yuv = is_yuv420(c->srcFormat);
     const int planSrc = src_yuv ? GMAT_PIX_FMT_RGB24 : c->srcFormat;
+    c->shift8Ident = -1;
     int r = build_scale_plan(c->plan, c->srcW, c->srcH, planSrc, c->dstW, c->dstH, c->dstFormat, c->flags, c->param);
     if (r < 0) return r;
     if ((r = scale_pick_tiling(c->plan, c->tiling)) < 0) return r;
@@ -439,6 +442,7 @@ static int scale16_kind(int srcFormat)
 
 static int init_scale16(GmatSwsContext *c)
 {
+    c->shift8Ident = -1;
     int r = build_scale_plan(c->plan16, c->srcW, c->srcH, c->srcFormat, c->dstW, c->dstH, c->dstFormat, c->flags, c->param, c->chrPos);
     if (r < 0) return r;
     ScalePlan &p = c->plan16;
@@ -1421,7 +1425,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         const int t = sws_scale_frames_batched_impl(c->inner, n, src_planes, srcStride, dst_planes, dstStride, stream);
         c->inner->px4 = 0; c->inner->px4Alpha = 0;
         c->lastKernel = c->inner->lastKernel; c->lastLaunchFrames = c->inner->lastLaunchFrames;
-        return t;
+        return t == GMAT_ERR(EINVAL) ? 0 : t;       // (a promise the inner context does not keep is "not taken" — the frames go one by one, through the pass that drops the alpha)
     }
     if (c->mode == MODE_YUV2RGB) {
         // the same-size converter: one launch per 32 frames, grid.z = frame
@@ -1599,6 +1603,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
                 for (int i = 0; i < m; i++) { fr.y[i] = src_planes[4 * (f0 + i)]; fr.dst[i] = dst_planes[4 * (f0 + i)]; }
                 int r = launch_scale_yuvg_rgbsrc(ga, stream, &fr, m);
                 if (r < 0) return r;
+                c->lastKernel = yuvg_rgbsrc_block_form(ga, m) ? "scale_yuvg_rgbsrc_blk_kernel" : "scale_yuvg_rgbsrc_kernel";   // (the form of THIS chunk — the launcher decides per launch)
                 c->lastLaunchFrames = m;
             }
             return 1;
@@ -1824,8 +1829,12 @@ static bool shift8_shortcut(const GmatSwsContext *c)
     if (!((c->mode == MODE_SCALE || c->mode == MODE_SCALE16) && c->srcFormat == GMAT_PIX_FMT_NV12 && is_p01x(c->dstFormat) &&
           c->srcW == c->dstW && c->srcH == c->dstH && !c->rangeConv)) return false;
     if (GMAT_KNOB("GMAT_NO_SHIFT8") && atoi(GMAT_KNOB("GMAT_NO_SHIFT8"))) return false;
-    const ScalePlan &p = active_plan(c);
-    return bank_is_identity(p.hLum) && bank_is_identity(p.vLum) && bank_is_identity(p.hChr) && bank_is_identity(p.vChr);
+    // (the four banks are walked once a plan, not once a call — the plan changes where it is built: init, setChromaPos, setRange)
+    if (c->shift8Ident < 0) {
+        const ScalePlan &p = active_plan(c);
+        c->shift8Ident = bank_is_identity(p.hLum) && bank_is_identity(p.vLum) && bank_is_identity(p.hChr) && bank_is_identity(p.vChr);
+    }
+    return c->shift8Ident != 0;
 }
 
 // packed_vscale's choice of writer per output row (vscale.c:135-167) as the alpha kernel's form word (k_rgb64.hip)
@@ -2165,6 +2174,7 @@ int gmat_sws_setRange(GmatSwsContext *c, int srcFullRange, int dstFullRange)
     if (special) {
         const bool generic15 = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
         c->rangeConv = conv;
+        c->shift8Ident = -1;
         if (conv && !generic15) { c->mode = MODE_SCALE16; return init_scale16(c); }       // 16-bit destination: the 19-bit lines
         if (conv) { c->mode = MODE_SCALE; c->fused = 2; return ensure_scaler(c); }
         c->mode = c->unscaledMode;
@@ -2319,7 +2329,9 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
             c->inner->px4 = 0; c->inner->px4Alpha = 0;
             c->lastKernel = c->inner->lastKernel;
             if (r >= 0) return r;
-            break;
+            //  the inner context answers EINVAL before it launches anything when the kernel that reads four-byte pixels is not the one
+            // its own rules pick after all: the 32 -> 24-bit pass below still serves the call (a caller's own EINVAL comes back from there too)
+            if (r != GMAT_ERR(EINVAL)) break;
         }
         if (!c->inter) {
             c->interStride = align_up(c->srcW * 3, 256);

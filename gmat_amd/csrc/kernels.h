@@ -170,6 +170,7 @@ struct S19Tables {
     std::vector<int32_t> colStart[2], rowStart[2], rowCount[2];
 };
 struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; };
+static_assert(sizeof(S19Args) + sizeof(Yuv2xFrames) <= 4096, "S19Args + Yuv2xFrames exceed the kernel-argument segment");
 // hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
 int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, S19Tables &t);
 int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
@@ -395,14 +396,16 @@ struct YuvGArgs {
     const int32_t *vtL, *vtC;
     int n4L, n4C, blkRows, blkRowsC;
     const int32_t *hCp; int f2PPL, f2Pairs[17];               // scale_yuvg_rgb2p_blk_kernel (YuvGTables')
-    int blkPPL, blkRows4, blkSlots; const int32_t *vtRnd;
-    int srcPx, srcAlpha;                                      // ... (per call) 4: the source is RGBA / BGRA pixels read as they are; its alpha channel is a fourth line                           // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
+    int blkPPL, blkRows4, blkSlots; const int32_t *vtRnd;     // scale_yuvg_rgbsrc_blk_kernel: pixels a lane, the tallest band on four pairs a wave; (launcher) LDS pair slots a line
+    int srcPx, srcAlpha;                                      // ... (per call) 4: the source is RGBA / BGRA pixels read as they are; its alpha channel is a fourth line
     // (round 5) 16-bit samples in (k_scale_yuvg16.hip: YuvScaleArgs' kind, hScale16To15_c's shift, the sums' start), 10-bit samples out, and the
     // ordered dither of 8-bit planar output of a deeper source (YuvScaleArgs')
     int src16, hShift, hBias, dst16, dstShift, dither8;
     Rgb2YuvConsts r2y; int rgbBgr;                            // src16 == 3: a packed RGB24 / BGR24 source (the walker's own converter, GStream LK)
     Yuv2RgbConsts y2r;
 };
+// both structs travel by value in one launch's kernel-argument segment (4 KB)
+static_assert(sizeof(YuvGArgs) + sizeof(Yuv2xFrames) <= 4096, "YuvGArgs + Yuv2xFrames exceed the kernel-argument segment");
 int  yuvg_prepare(const ScalePlan &p, const YuvScaleTiling &generic, YuvGTables &t);
 int  launch_scale_yuvg(const YuvGArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 bool yuvg_block_form(const YuvGArgs &a, int nframes);         // whether a launch of nframes frames takes scale_yuvg_blk_*_kernel

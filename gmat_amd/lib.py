@@ -104,6 +104,7 @@ _SIGS = {
     "gmat_device_count": (C.c_int, []),
     "gmat_set_device": (C.c_int, [C.c_int]),
     "gmat_device_numa_node": (C.c_int, [C.c_int]),
+    "gmat_device_compute_units": (C.c_int, [C.c_int]),
     "gmat_bind_thread_to_device": (C.c_int, [C.c_int]),
     "gmat_version": (C.c_char_p, []),
     "gmat_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),

@@ -349,6 +349,8 @@ GMAT_API int  gmat_set_device(int device);
  * Returns the number of cores bound to, 0 when nothing was changed.  Call before allocating pinned host memory
  * (gmat_host_frame_alloc, gmat_pipeline_create): first touch decides which socket the staging ring lives on. */
 GMAT_API int  gmat_device_numa_node(int device);
+/* compute units of `device` (hipDeviceProp_t.multiProcessorCount; MI355X: 256) — the launch-size rules scale with it; < 0: error */
+GMAT_API int  gmat_device_compute_units(int device);
 GMAT_API int  gmat_bind_thread_to_device(int device);
 GMAT_API const char *gmat_version(void);
 /* tests and A/B measurements only: re-read the GMAT_* environment knobs now.  Contexts read them when they are
