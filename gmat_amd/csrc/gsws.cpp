@@ -477,10 +477,12 @@ static int init_scale16(GmatSwsContext *c)
     // (round 6) YUV destinations: one launch a frame, the 19-bit lines of a tile in LDS (k_scale19.hip; GMAT_S19=0: the two passes through HBM)
     c->s19.ok = 0;
     const char *ks19 = GMAT_KNOB("GMAT_S19");
-    if (!is_rgb64(c->dstFormat) && !(ks19 && atoi(ks19) == 0)) {
+    if (!(ks19 && atoi(ks19) == 0)) {
         const bool s16 = is_p01x(c->srcFormat) || pl16_depth(c->srcFormat) != 0;
         const bool srcSemi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);
-        r = s19_prepare(p, vl, vc, s16 ? 2 : 1, scale16_kind(c->srcFormat), srcSemi ? 1 : 0, c->dstFormat == GMAT_PIX_FMT_P016LE ? 1 : 0, c->s19);
+        const int rgb64 = c->dstFormat == GMAT_PIX_FMT_RGBA64LE ? 1 : c->dstFormat == GMAT_PIX_FMT_BGRA64LE ? 2 : 0;
+        r = s19_prepare(p, vl, vc, s16 ? 2 : 1, scale16_kind(c->srcFormat), srcSemi ? 1 : 0, c->dstFormat == GMAT_PIX_FMT_P016LE ? 1 : 0,
+                        rgb64, p.chrDstW == c->dstW ? 0 : 1, c->s19);
         if (r < 0 && r != GMAT_ERR(ENOSYS)) return r;
         if (c->s19.ok) {
             for (int j = 0; j < 2; j++) {
@@ -491,8 +493,10 @@ static int init_scale16(GmatSwsContext *c)
                 J.colStart = (const int32_t *)c->dS19[3 * j].p; J.rowStart = (const int32_t *)c->dS19[3 * j + 1].p; J.rowCount = (const int32_t *)c->dS19[3 * j + 2].p;
                 J.h = c->d16[j]; J.v = c->d16[2 + j];
             }
-            for (int i = 0; i < 3; i++) if ((r = c->line16[i].reserve(0)) < 0) return r;
-            return 0;
+            if (!rgb64) {                    // (a 64-bit destination keeps the two passes' lines: the alpha plane of an RGBA source rides on them)
+                for (int i = 0; i < 3; i++) if ((r = c->line16[i].reserve(0)) < 0) return r;
+                return 0;
+            }
         }
     }
     if ((r = c->line16[0].reserve((size_t)c->srcH * c->dstW * 4)) < 0) return r;
@@ -1359,15 +1363,19 @@ static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_pl
 {
     const bool semiS = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat), semiD = c->dstFormat == GMAT_PIX_FMT_P016LE;
     const bool s16 = is_p01x(c->srcFormat) || pl16_depth(c->srcFormat) != 0;
+    const bool rgb64 = c->s19.rgb64 != 0;
     S19Args a;
+    std::memset(&a, 0, sizeof(a));
     a.job[0] = c->s19.job[0]; a.job[1] = c->s19.job[1];
     a.job[0].rawStride[0] = srcStride[0]; a.job[0].rawStride[1] = 0;
     a.job[1].rawStride[0] = srcStride[1]; a.job[1].rawStride[1] = semiS ? 0 : srcStride[2];
     a.job[0].ds[0] = dstStride[0]; a.job[0].ds[1] = 0;
-    a.job[1].ds[0] = dstStride[1]; a.job[1].ds[1] = semiD ? dstStride[1] : dstStride[2];
-    a.job[0].rc = c->rangeConv; a.job[1].rc = c->rangeConv ? c->rangeConv + 2 : 0;
+    a.job[1].ds[0] = rgb64 ? 0 : dstStride[1]; a.job[1].ds[1] = rgb64 ? 0 : semiD ? dstStride[1] : dstStride[2];
+    a.job[0].rc = rgb64 ? 0 : c->rangeConv; a.job[1].rc = rgb64 ? 0 : c->rangeConv ? c->rangeConv + 2 : 0;      // (swscale.c:536: not for RGB destinations)
+    a.rgb64 = c->s19.rgb64; a.chrShift = c->s19.chrShift; a.linesOff = c->s19.linesOff;
+    if (rgb64) a.y2r = make_yuv2rgb_consts(c->colorspace, c->srcFullRange != 0);
     uintptr_t sAl = (uintptr_t)srcStride[0] | (uintptr_t)srcStride[1] | (semiS ? 0 : (uintptr_t)srcStride[2]);
-    uintptr_t dAl = (uintptr_t)dstStride[0] | (uintptr_t)dstStride[1] | (semiD ? 0 : (uintptr_t)dstStride[2]);
+    uintptr_t dAl = (uintptr_t)dstStride[0] | (rgb64 ? 0 : (uintptr_t)dstStride[1] | (semiD ? 0 : (uintptr_t)dstStride[2]));
     for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
         const int m = std::min(kYuv2xMaxFrames, n - f0);
         Yuv2xFrames fr;
@@ -1376,11 +1384,11 @@ static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_pl
         for (int i = 0; i < m; i++) {
             const uint8_t *const *sp = src_planes + 4 * (f0 + i);
             uint8_t *const *dp = dst_planes + 4 * (f0 + i);
-            if (!sp[0] || !sp[1] || (!semiS && !sp[2]) || !dp[0] || !dp[1] || (!semiD && !dp[2])) return GMAT_ERR(EINVAL);
+            if (!sp[0] || !sp[1] || (!semiS && !sp[2]) || !dp[0] || (!rgb64 && (!dp[1] || (!semiD && !dp[2])))) return GMAT_ERR(EINVAL);
             fr.y[i] = sp[0]; fr.u[i] = sp[1]; fr.v[i] = semiS ? nullptr : sp[2];
-            fr.dst[i] = dp[0]; fr.dstU[i] = dp[1]; fr.dstV[i] = semiD ? nullptr : dp[2];
+            fr.dst[i] = dp[0]; fr.dstU[i] = rgb64 ? nullptr : dp[1]; fr.dstV[i] = (rgb64 || semiD) ? nullptr : dp[2];
             sA |= (uintptr_t)sp[0] | (uintptr_t)sp[1] | (semiS ? 0 : (uintptr_t)sp[2]);
-            dA |= (uintptr_t)dp[0] | (uintptr_t)dp[1] | (semiD ? 0 : (uintptr_t)dp[2]);
+            dA |= (uintptr_t)dp[0] | (rgb64 ? 0 : (uintptr_t)dp[1] | (semiD ? 0 : (uintptr_t)dp[2]));
         }
         if ((dA & 1) || (s16 && (sA & 1))) return GMAT_ERR(EINVAL);              // 16-bit samples sit on even addresses
         a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
@@ -1461,7 +1469,7 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         c->lastLaunchFrames = 1;
         return 1;
     }
-    if (c->mode == MODE_SCALE16 && c->s19.ok) {
+    if (c->mode == MODE_SCALE16 && c->s19.ok && !c->alpha19) {
         const int r = scale19_frames(c, n, src_planes, srcStride, dst_planes, dstStride, stream);
         return r < 0 ? r : 1;
     }
@@ -1793,7 +1801,7 @@ bool sws_owns_intermediates(const GmatSwsContext *c) { lines_ready(const_cast<Gm
 bool sws_shares_intermediate(const GmatSwsContext *c)
 {
     if (!c) return false;
-    if (c->mode == MODE_SCALE16 && c->s19.ok) return false;                                                      // (round 6: the lines of a tile live in LDS)
+    if (c->mode == MODE_SCALE16 && c->s19.ok && !is_rgb64(c->dstFormat)) return false;                           // (round 6: the lines of a tile live in LDS; a 64-bit destination may still take the two passes — an RGBA source's alpha lines)
     if (c->mode == MODE_VIA_INNER || c->mode == MODE_SCALE16 || c->mode == MODE_VIA_PLANES16) return true;       // one set of intermediates per context
     if (c->mode == MODE_FROM_PF32 && is_yuv420(c->dstFormat)) return true;
     return c->mode == MODE_SCALE && is_yuv420(c->srcFormat) && c->fused == 0;
@@ -2398,10 +2406,10 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         int32_t *ly = (int32_t *)c->line16[0].p, *lu = (int32_t *)c->line16[1].p, *lv = (int32_t *)c->line16[2].p;
         c->lastKernel = "hscale19_kernel+vscale16_kernel";
         const int rcL = rgb64 ? 0 : c->rangeConv, rcC = rgb64 ? 0 : c->rangeConv ? c->rangeConv + 2 : 0;      // (swscale.c:536: not for RGB destinations)
-        if (c->s19.ok) {
+        if (c->s19.ok && !(rgb64 && c->alpha19)) {                            // (the alpha lines of an RGBA source: vrgba64_kernel's operand)
             const bool semiS = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);
             const uint8_t *const sp[4] = {src[0], src[1], semiS ? nullptr : src[2], nullptr};
-            uint8_t *const dp[4] = {dst[0], dst[1], c->dstFormat == GMAT_PIX_FMT_P016LE ? nullptr : dst[2], nullptr};
+            uint8_t *const dp[4] = {dst[0], rgb64 ? nullptr : dst[1], (rgb64 || c->dstFormat == GMAT_PIX_FMT_P016LE) ? nullptr : dst[2], nullptr};
             r = scale19_frames(c, 1, sp, srcStride, dp, dstStride, c->stream);
             break;
         }

@@ -203,35 +203,21 @@ __device__ __forceinline__ void s19_hrows(const unsigned *rc0, int PP, int rb, i
     }
 }
 
+// the plane pointers of the item's frame, read from the frame table in the kernel's own body (handing the table itself to the functions below
+// by reference made the compiler copy its 1.5 KB into every lane's scratch: 98 KB written a wave, the kernel seven times slower — r06l): src0 / src1 =
+// the job's source row images, dst0 / dst1 = its components' destinations, by value
+
+// stage + pass H of ONE job's tile (tx, ty): the tile rows' vertical tables into `vtab`, the 19-bit lines of its components into `lines`
+// (kS19TW ints a row, component c from row c * nrLines on); `raw`: the staged rows.  Ends behind a barrier.
 template <int NP>
-__global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
+__device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_t *src0, const uint8_t *src1, int tx, int ty,
+                                          int32_t *vtab, unsigned *raw, int32_t *lines)
 {
-    HIP_DYNAMIC_SHARED(uint4, lds_base)
-    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_base);
-    // workgroups go round the eight XCDs in launch order (observed, MI355X_MICROARCH.md): each XCD takes one contiguous range of (frame, tile)
-    // items, so that the tiles that share source lines — neighbours across, the rows two tile rows overlap in — meet in ONE L2
-    int item = blockIdx.x;
-    if (a.xcdRemap) {
-        const int per = (int)gridDim.x >> 3;
-        if (item < per * 8) item = (item & 7) * per + (item >> 3);
-    }
-    const int nb = a.job[0].nblk + a.job[1].nblk;
-    const int f = item / nb;
-    int b = item - f * nb;
-    const int ji = b >= a.job[0].nblk ? 1 : 0;
-    if (ji) b -= a.job[0].nblk;
-    const S19Job &J = a.job[ji];
-    const int tx = b % J.ntx, ty = b / J.ntx;
+    const S19Job &J = a.job[jx];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = tx * kS19TW, y0 = ty * J.TH;
+    const int x0 = tx * J.TW, y0 = ty * J.TH;
     const int r0 = J.rowStart[ty], nr = J.rowCount[ty], c0 = J.colStart[tx];
-    // LDS: the tile rows' vertical tables (window start, then 2 vp coefficients a row), the staged rows (ncomp x G x PP dwords), the lines
     const int vp = J.v.pairs, PP = J.PP;
-    int32_t *vtab = reinterpret_cast<int32_t *>(lds);
-    unsigned *raw = reinterpret_cast<unsigned *>(lds + J.vtBytes);
-    int32_t *lines = reinterpret_cast<int32_t *>(raw + (size_t)J.ncomp * J.G * PP);
-    auto src_ptr = [&](int sel) -> const uint8_t * { return sel == 0 ? fr.y[f] : sel == 1 ? fr.u[f] : fr.v[f]; };
-    auto dst_ptr = [&](int sel) -> uint8_t * { return sel == 0 ? fr.dst[f] : sel == 1 ? fr.dstU[f] : fr.dstV[f]; };
 
     const int nunit = PP >> 1;
     const int sgb = J.layout == 0 ? 1 : J.layout == 3 ? 4 : 2;                  // bytes a sample group (a sample of every component of the row image)
@@ -248,14 +234,14 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
     auto issue = [&](int g0) {
         const int gn = min(J.G, nr - g0);
         {
-            const uint8_t *sp = src_ptr(J.rawSel[0]) + (size_t)(r0 + g0) * J.rawStride[0];
+            const uint8_t *sp = src0 + (size_t)(r0 + g0) * J.rawStride[0];
 #define S19_ISSUE(L_, S_) if (J.cp2) s19_issue<L_, S_, 2, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); \
                           else       s19_issue<L_, S_, 1, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
             S19_FOR_LAYOUT(S19_ISSUE);
 #undef S19_ISSUE
         }
         if (J.nraw == 2) {
-            const uint8_t *sp = src_ptr(J.rawSel[1]) + (size_t)(r0 + g0) * J.rawStride[1];
+            const uint8_t *sp = src1 + (size_t)(r0 + g0) * J.rawStride[1];
             if (J.layout == 0) { if (J.cp2) s19_issue<0, 8, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
                                  else       s19_issue<0, 8, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); }
             else               { if (J.cp2) s19_issue<2, 4, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
@@ -267,7 +253,7 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
     // the lane's column: first pair of its window in a staged row, coefficient pairs, the bias the staged samples carry
     const int hp = J.h.pairs;
     const int x = x0 + lane;
-    const bool xin = x < J.dstW;
+    const bool xin = lane < J.TW && x < J.dstW;
     const int q0 = xin ? (J.h.pos_even[x] - c0) >> 1 : 0;
     const int32_t *cfg = J.h.packed + (size_t)(xin ? x : 0) * hp;
     int cf[NP > 0 ? NP : 1];
@@ -312,7 +298,7 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
             if (fast) __syncthreads();                                          // after the zeros the fast form left in the straddling unit
             for (int i = 0; i < J.nraw; i++) {
                 unsigned *o0 = raw + (size_t)i * J.G * PP, *o1 = raw + (size_t)J.G * PP;
-                const uint8_t *sp = src_ptr(J.rawSel[i]) + (size_t)(r0 + g0) * J.rawStride[i];
+                const uint8_t *sp = (i ? src1 : src0) + (size_t)(r0 + g0) * J.rawStride[i];
 #define S19_BYTES(L_, S_) s19_stage_bytes<L_>(sp, J.rawStride[i], J.rowBytes, B0, gn, nunit, fast ? upart : -1, J.xorv, shr6, o0, o1, PP, tid);
                 S19_FOR_LAYOUT(S19_BYTES);
 #undef S19_BYTES
@@ -329,7 +315,15 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
         }
     }
     __syncthreads();
+}
 
+// pass V of a YUV destination's job: the tile's output rows from its lines
+__device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *dst0, uint8_t *dst1, int tx, int ty,
+                                           const int32_t *vtab, const int32_t *lines)
+{
+    const S19Job &J = a.job[jx];
+    const int tid = threadIdx.x;
+    const int x0 = tx * J.TW, y0 = ty * J.TH, r0 = J.rowStart[ty], vp = J.v.pairs;
     // pass V.  The rows of `lines` from nr on (a window's padded taps past the plane) hold whatever the LDS held: their coefficients are zero
     // and v_mul_i32_i24 of anything by zero is zero.
     const int yEnd = min(y0 + J.TH, J.dstH);
@@ -352,7 +346,7 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
                     v0 += (unsigned)__mul24(b0.x, cc.x) + (unsigned)__mul24(b1.x, cc.y); v1 += (unsigned)__mul24(b0.y, cc.x) + (unsigned)__mul24(b1.y, cc.y);
                 }
                 const unsigned d0 = out16(u0) | out16(v0) << 16, d1 = out16(u1) | out16(v1) << 16;
-                uint8_t *d = dst_ptr(J.dstSel[0]) + J.dstOff[0] + (size_t)y * J.ds[0] + 4 * (size_t)xo;
+                uint8_t *d = dst0 + J.dstOff[0] + (size_t)y * J.ds[0] + 4 * (size_t)xo;
                 const bool two = xo + 1 < J.dstW;
                 if (a.dstAl4) {
                     reinterpret_cast<unsigned *>(d)[0] = d0;
@@ -381,7 +375,7 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
                         o2 += (unsigned)__mul24(a0.z, cc.x) + (unsigned)__mul24(a1.z, cc.y); o3 += (unsigned)__mul24(a0.w, cc.x) + (unsigned)__mul24(a1.w, cc.y);
                     }
                     const unsigned d0 = out16(o0) | out16(o1) << 16, d1 = out16(o2) | out16(o3) << 16;
-                    uint8_t *d = dst_ptr(J.dstSel[c]) + J.dstOff[c] + (size_t)y * J.ds[c] + 2 * (size_t)xo;
+                    uint8_t *d = (c ? dst1 : dst0) + J.dstOff[c] + (size_t)y * J.ds[c] + 2 * (size_t)xo;
                     const int n = min(4, J.dstW - xo);
                     if (a.dstAl4 && n == 4) { reinterpret_cast<unsigned *>(d)[0] = d0; reinterpret_cast<unsigned *>(d)[1] = d1; }
                     else {
@@ -396,11 +390,117 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
     }
 }
 
-// the tiles of one job: windows across (sample pairs of a staged row), windows down (source rows) for the tallest tile the LDS budget holds.
+// pass V + colour stage of an RGBA64LE / BGRA64LE destination: yuv2rgba64_X_c / _full_X_c (output.c:1025-1105, :1275-1337; the 1- and 2-tap forms are
+// the same sums on the effective coefficients, as vrgba64_kernel states them):
+//   Y = ((-2^30 + sum lum f) >> 14) + 2^16;  U, V = (-(128 << 23) + sum chr f) >> 14     (32-bit wrap-around sums)
+//   Y = (Y - y_offset) y_coeff + 2^13;  R = V v2r;  G = V v2g + U u2g;  B = U u2b;  channel = clip_uintp2(X + Y, 30) >> 14;  alpha 0xFFFF
+// A thread: pixels (2 cp, 2 cp + 1) of an output row, 32 pairs a row, 8 rows a step; sixteen bytes stored.  vtL / vtC, linesY / linesC: the luma
+// job's and the chroma job's tables and lines (chroma columns: x >> chrShift from the chroma tile's first one)
+__device__ __forceinline__ void s19_rgb64(const S19Args &a, uint8_t *dst0, int tx, int ty, const int32_t *vtL, const int32_t *vtC,
+                                          const int32_t *linesY, const int32_t *linesC)
+{
+    const S19Job &L = a.job[0], &C = a.job[1];
+    const int tid = threadIdx.x, cp = tid & 31;
+    const int x0 = tx * L.TW, y0 = ty * L.TH, xo = x0 + 2 * cp;
+    const int r0L = L.rowStart[ty], r0C = C.rowStart[ty], vpL = L.v.pairs, vpC = C.v.pairs;
+    const int yEnd = min(y0 + L.TH, L.dstH);
+    const int cs = a.chrShift, cx = cs ? cp : 2 * cp;                            // the pair's (first) chroma column in the chroma tile
+    const Yuv2RgbConsts &k = a.y2r;
+    if (xo >= L.dstW) return;
+    for (int y = y0 + (tid >> 5); y < yEnd; y += 8) {
+        const int32_t *ly = linesY + (vtL[y - y0] - r0L) * kS19TW + 2 * cp;
+        const int32_t *lu = linesC + (vtC[y - y0] - r0C) * kS19TW + cx, *lv = lu + C.nrLines * kS19TW;
+        const int32_t *cl = vtL + L.TH + (y - y0) * 2 * vpL, *cc = vtC + C.TH + (y - y0) * 2 * vpC;
+        unsigned ay0 = (unsigned)-0x40000000, ay1 = ay0, au0 = (unsigned)-(128 << 23), au1 = au0, av0 = au0, av1 = au0;
+#pragma unroll 2
+        for (int t = 0; t < vpL; t++) {
+            const int2 c2 = *reinterpret_cast<const int2 *>(cl + 2 * t);
+            const int2 p0 = *reinterpret_cast<const int2 *>(ly + (2 * t) * kS19TW), p1 = *reinterpret_cast<const int2 *>(ly + (2 * t + 1) * kS19TW);
+            ay0 += (unsigned)__mul24(p0.x, c2.x) + (unsigned)__mul24(p1.x, c2.y); ay1 += (unsigned)__mul24(p0.y, c2.x) + (unsigned)__mul24(p1.y, c2.y);
+        }
+        if (cs) {
+#pragma unroll 2
+            for (int t = 0; t < vpC; t++) {
+                const int2 c2 = *reinterpret_cast<const int2 *>(cc + 2 * t);
+                au0 += (unsigned)__mul24(lu[(2 * t) * kS19TW], c2.x) + (unsigned)__mul24(lu[(2 * t + 1) * kS19TW], c2.y);
+                av0 += (unsigned)__mul24(lv[(2 * t) * kS19TW], c2.x) + (unsigned)__mul24(lv[(2 * t + 1) * kS19TW], c2.y);
+            }
+            au1 = au0; av1 = av0;
+        } else {
+#pragma unroll 2
+            for (int t = 0; t < vpC; t++) {
+                const int2 c2 = *reinterpret_cast<const int2 *>(cc + 2 * t);
+                const int2 u0 = *reinterpret_cast<const int2 *>(lu + (2 * t) * kS19TW), u1 = *reinterpret_cast<const int2 *>(lu + (2 * t + 1) * kS19TW);
+                const int2 v0 = *reinterpret_cast<const int2 *>(lv + (2 * t) * kS19TW), v1 = *reinterpret_cast<const int2 *>(lv + (2 * t + 1) * kS19TW);
+                au0 += (unsigned)__mul24(u0.x, c2.x) + (unsigned)__mul24(u1.x, c2.y); au1 += (unsigned)__mul24(u0.y, c2.x) + (unsigned)__mul24(u1.y, c2.y);
+                av0 += (unsigned)__mul24(v0.x, c2.x) + (unsigned)__mul24(v1.x, c2.y); av1 += (unsigned)__mul24(v0.y, c2.x) + (unsigned)__mul24(v1.y, c2.y);
+            }
+        }
+        auto pixel = [&](unsigned ay, unsigned au, unsigned av, unsigned &lo, unsigned &hi) {
+            int Y = ((int)ay >> 14) + 0x10000;
+            const int U = (int)au >> 14, V = (int)av >> 14;
+            Y = (int)((unsigned)(Y - k.y_offset) * (unsigned)k.y_coeff) + (1 << 13);
+            const int R = (int)((unsigned)V * (unsigned)k.v2r), G = (int)((unsigned)V * (unsigned)k.v2g + (unsigned)U * (unsigned)k.u2g), B = (int)((unsigned)U * (unsigned)k.u2b);
+            auto ch = [&](int v) -> unsigned { return (unsigned)min(max((int)((unsigned)v + (unsigned)Y), 0), 0x3FFFFFFF) >> 14; };
+            const unsigned c0 = ch(a.rgb64 == 2 ? B : R), c1 = ch(G), c2 = ch(a.rgb64 == 2 ? R : B);
+            lo = c0 | c1 << 16; hi = c2 | 0xFFFF0000u;
+        };
+        unsigned d[4];
+        pixel(ay0, au0, av0, d[0], d[1]);
+        pixel(ay1, au1, av1, d[2], d[3]);
+        uint8_t *dp = dst0 + (size_t)y * L.ds[0] + 8 * (size_t)xo;
+        const bool two = xo + 1 < L.dstW;
+        if (a.dstAl4) {
+            reinterpret_cast<unsigned *>(dp)[0] = d[0]; reinterpret_cast<unsigned *>(dp)[1] = d[1];
+            if (two) { reinterpret_cast<unsigned *>(dp)[2] = d[2]; reinterpret_cast<unsigned *>(dp)[3] = d[3]; }
+        } else {
+            unsigned short *d16 = reinterpret_cast<unsigned short *>(dp);
+            for (int i = 0; i < (two ? 4 : 2); i++) { d16[2 * i] = (unsigned short)d[i]; d16[2 * i + 1] = (unsigned short)(d[i] >> 16); }
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
+{
+    HIP_DYNAMIC_SHARED(uint4, lds_base)
+    uint8_t *lds = reinterpret_cast<uint8_t *>(lds_base);
+    // workgroups go round the eight XCDs in launch order (observed, MI355X_MICROARCH.md): each XCD takes one contiguous range of (frame, tile)
+    // items, so that the tiles that share source lines — neighbours across, the rows two tile rows overlap in — meet in ONE L2
+    int item = blockIdx.x;
+    if (a.xcdRemap) {
+        const int per = (int)gridDim.x >> 3;
+        if (item < per * 8) item = (item & 7) * per + (item >> 3);
+    }
+    // a YUV destination: the item is a tile of ONE job (the luma plane's, or the two chroma planes').  A packed 64-bit destination: the item is a tile
+    // of pixels — the luma job's lines, then the chroma job's (their staged rows share LDS), then the colour stage.  ONE inlined copy of s19_lines
+    // serves both (three copies: 171 VGPRs and 1.5 KB of scratch)
+    const int nb = a.rgb64 ? a.job[0].nblk : a.job[0].nblk + a.job[1].nblk;
+    const int f = item / nb;
+    int b = item - f * nb;
+    int ji = 0;
+    if (!a.rgb64 && b >= a.job[0].nblk) { ji = 1; b -= a.job[0].nblk; }
+    const int ntx = a.job[ji].ntx;
+    const int tx = b % ntx, ty = b / ntx;
+    // LDS: the tile rows' vertical tables (window start, then 2 vp coefficients a row) of the job(s), the staged rows (ncomp x G x PP dwords), the lines
+    const int vt0 = a.job[ji].vtBytes;
+    int32_t *vtab0 = reinterpret_cast<int32_t *>(lds), *vtab1 = reinterpret_cast<int32_t *>(lds + vt0);
+    unsigned *raw = reinterpret_cast<unsigned *>(lds + vt0 + (a.rgb64 ? a.job[1].vtBytes : 0));
+    int32_t *lines0 = a.rgb64 ? reinterpret_cast<int32_t *>(lds + a.linesOff) : reinterpret_cast<int32_t *>(raw + (size_t)a.job[ji].ncomp * a.job[ji].G * a.job[ji].PP);
+    int32_t *lines1 = lines0 + a.job[0].nrLines * kS19TW;
+    auto src_ptr = [&](int sel) -> const uint8_t * { return sel == 0 ? fr.y[f] : sel == 1 ? fr.u[f] : fr.v[f]; };
+    auto dst_ptr = [&](int sel) -> uint8_t * { return sel == 0 ? fr.dst[f] : sel == 1 ? fr.dstU[f] : fr.dstV[f]; };
+    const int nj = a.rgb64 ? 2 : 1;
+    for (int j = 0; j < nj; j++)
+        s19_lines<NP>(a, ji + j, src_ptr(a.job[ji + j].rawSel[0]), src_ptr(a.job[ji + j].rawSel[1]), tx, ty, j ? vtab1 : vtab0, raw, j ? lines1 : lines0);
+    if (a.rgb64) s19_rgb64(a, fr.dst[f], tx, ty, vtab0, vtab1, lines0, lines1);
+    else         s19_planes(a, ji, dst_ptr(a.job[ji].dstSel[0]), dst_ptr(a.job[ji].dstSel[1]), tx, ty, vtab0, lines0);
+}
+
+// ---- the planner (host) ---------------------------------------------------------------------------------------------------------------------
 // Refuses (ENOSYS: the two passes take the context) a bank whose padded taps past the plane are not all zero or whose coefficients could
-// carry a biased sum past 2^31.
-int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int dstW, int dstH, int ncomp, int nraw, int layout, int hpairs, int budget, int thCap,
-             S19Job &J, std::vector<int32_t> &colStart, std::vector<int32_t> &rowStart, std::vector<int32_t> &rowCount)
+// carry a biased sum past 2^31, and rows of more than 128 staging units.
+int check_banks(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int dstW, int dstH)
 {
     if (h.count != dstW || v.count != dstH || h.pairs < 1 || v.pairs < 1) return GMAT_ERR(EINVAL);
     for (int x = 0; x < dstW; x++) {
@@ -413,17 +513,27 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
         }
         if (sumAbs > 65535 || h.pos_even[x] < 0 || (h.pos_even[x] & 1)) return GMAT_ERR(ENOSYS);
     }
-    for (int y = 0; y < dstH; y++)
+    for (int y = 0; y < dstH; y++) {
+        if (v.pos_even[y] < 0 || v.pos_even[y] >= srcH) return GMAT_ERR(EINVAL);
         for (int k = 0; k < v.pairs; k++) {
             const int32_t c = v.packed[(size_t)y * v.pairs + k];
             if (((c & 0xFFFF) && v.pos_even[y] + 2 * k >= srcH) || ((c >> 16) && v.pos_even[y] + 2 * k + 1 >= srcH)) return GMAT_ERR(ENOSYS);
         }
-    J.ntx = (dstW + kS19TW - 1) / kS19TW;
+    }
+    return 0;
+}
+
+// the tile columns of a job (TW output columns a tile): the first staged sample of each, the sample pairs a staged row holds, how the stage's
+// lanes share a row; returns the rows one s19_issue covers
+int plan_cols(const FilterBank &h, int dstW, int TW, int nraw, int layout, int hpairs, S19Job &J, std::vector<int32_t> &colStart)
+{
+    J.TW = TW;
+    J.ntx = (dstW + TW - 1) / TW;
     colStart.assign(J.ntx, 0);
     long PP = 4;
     for (int tx = 0; tx < J.ntx; tx++) {
         long lo = LONG_MAX, hi = 0;
-        for (int x = tx * kS19TW; x < std::min(dstW, (tx + 1) * kS19TW); x++) {
+        for (int x = tx * TW; x < std::min(dstW, (tx + 1) * TW); x++) {
             lo = std::min(lo, (long)h.pos_even[x]);
             hi = std::max(hi, (long)h.pos_even[x] + 2 * hpairs);
         }
@@ -431,43 +541,65 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
         colStart[tx] = (int32_t)c0;
         PP = std::max(PP, ((hi - c0 + 7) >> 3) * 4);                           // whole units of four samples = two pairs; rows of whole 16 bytes
     }
-    if (PP > 4096) return GMAT_ERR(ENOSYS);
-    J.PP = (int)PP;
     if (PP / 2 > 128) return GMAT_ERR(ENOSYS);                                 // (a lane stages at most two units of a row)
+    J.PP = (int)PP;
     J.lshift = 0;
     while ((1 << J.lshift) < PP / 2 && J.lshift < 6) J.lshift++;              // lanes a staged row's units take (a power of two)
     J.cp2 = PP / 2 > 64;
     // rows one s19_issue covers: 16 register dwords a lane = slots of a unit, over the row images and the column passes
     const int ndw = layout == 0 ? 1 : layout == 3 ? 4 : 2;
-    const int gcap = 4 * (64 >> J.lshift) * std::max(1, 16 / (ndw * nraw) / (J.cp2 ? 2 : 1));
-    static const int kTH[] = {64, 48, 40, 32, 24, 16, 12, 8, 4, 2, 1};
-    for (int TH : kTH) {
-        if (TH > thCap) continue;
-        const int nty = (dstH + TH - 1) / TH;
-        std::vector<int32_t> rs(nty), rc(nty);
-        int nrMax = 1, nrLines = 1;
-        for (int ty = 0; ty < nty; ty++) {
-            int lo = INT_MAX, hi = 0;
-            for (int y = ty * TH; y < std::min(dstH, (ty + 1) * TH); y++) {
-                lo = std::min(lo, v.pos_even[y]);
-                hi = std::max(hi, v.pos_even[y] + 2 * v.pairs);
-            }
-            if (lo < 0 || lo >= srcH) return GMAT_ERR(EINVAL);
-            nrLines = std::max(nrLines, hi - lo);
-            hi = std::min(hi, srcH);
-            rs[ty] = lo; rc[ty] = hi - lo;
-            nrMax = std::max(nrMax, hi - lo);
+    return 4 * (64 >> J.lshift) * std::max(1, 16 / (ndw * nraw) / (J.cp2 ? 2 : 1));
+}
+
+// the tile rows of a job at TH output rows a tile
+void plan_rows(const FilterBank &v, int srcH, int dstH, int TH, std::vector<int32_t> &rs, std::vector<int32_t> &rc, int &nrMax, int &nrLines)
+{
+    const int nty = (dstH + TH - 1) / TH;
+    rs.assign(nty, 0); rc.assign(nty, 0);
+    nrMax = 1; nrLines = 1;
+    for (int ty = 0; ty < nty; ty++) {
+        int lo = INT_MAX, hi = 0;
+        for (int y = ty * TH; y < std::min(dstH, (ty + 1) * TH); y++) {
+            lo = std::min(lo, v.pos_even[y]);
+            hi = std::max(hi, v.pos_even[y] + 2 * v.pairs);
         }
+        nrLines = std::max(nrLines, hi - lo);
+        hi = std::min(hi, srcH);
+        rs[ty] = lo; rc[ty] = hi - lo;
+        nrMax = std::max(nrMax, hi - lo);
+    }
+}
+
+// rows staged at once: all of a tile's when they fit a third of the budget (at least 4 KB) and one s19_issue, else as many (a multiple of 4, the waves)
+int plan_group(const S19Job &J, int ncomp, int nrMax, int gcap, int budget)
+{
+    const long rawBudget = std::max(4096L, (long)budget / 3), rowB = (long)ncomp * J.PP * 4;
+    int G = (int)std::min<long>(std::min(nrMax, gcap), rawBudget / rowB);
+    if (G < nrMax && G >= 4) G &= ~3;
+    return G;
+}
+
+static const int kS19TH[] = {64, 48, 40, 32, 24, 16, 12, 8, 4, 2, 1};
+
+// one job of a YUV destination on its own: the tallest tile the LDS budget holds; returns its LDS bytes
+int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int dstW, int dstH, int ncomp, int nraw, int layout, int hpairs, int budget, int thCap,
+             S19Job &J, std::vector<int32_t> &colStart, std::vector<int32_t> &rowStart, std::vector<int32_t> &rowCount)
+{
+    if (int r = check_banks(h, v, srcW, srcH, dstW, dstH); r < 0) return r;
+    const int gcap = plan_cols(h, dstW, kS19TW, nraw, layout, hpairs, J, colStart);
+    if (gcap < 0) return gcap;
+    for (int TH : kS19TH) {
+        if (TH > thCap) continue;
+        std::vector<int32_t> rs, rc;
+        int nrMax, nrLines;
+        plan_rows(v, srcH, dstH, TH, rs, rc, nrMax, nrLines);
         const long linesBytes = (long)ncomp * nrLines * kS19TW * 4, vtBytes = ((long)TH * (2 * v.pairs + 1) * 4 + 15) & ~15L;
-        // rows staged at once: all of a tile's when they fit a third of the budget (at least 4 KB), else as many (a multiple of 4, the waves)
-        const long rawBudget = std::max(4096L, (long)budget / 3), rowB = (long)ncomp * PP * 4;
-        int G = (int)std::min<long>(std::min(nrMax, gcap), rawBudget / rowB);
-        if (G < nrMax && G >= 4) G &= ~3;
+        const int G = plan_group(J, ncomp, nrMax, gcap, budget);
         if (G < 1) { if (TH == 1) return GMAT_ERR(ENOSYS); continue; }
-        const long total = vtBytes + G * rowB + linesBytes;
+        const long total = vtBytes + (long)G * ncomp * J.PP * 4 + linesBytes;
         if (total > budget && TH > 1) continue;
         if (total > 65536) return GMAT_ERR(ENOSYS);
-        J.TH = TH; J.nty = nty; J.nblk = J.ntx * nty; J.nrMax = nrMax; J.nrLines = nrLines; J.G = G; J.vtBytes = (int)vtBytes;
+        J.TH = TH; J.nty = (int)rs.size(); J.nblk = J.ntx * J.nty; J.nrMax = nrMax; J.nrLines = nrLines; J.G = G; J.vtBytes = (int)vtBytes;
         rowStart.swap(rs); rowCount.swap(rc);
         return (int)((total + 15) & ~15L);
     }
@@ -476,7 +608,9 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
 
 } // namespace
 
-int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, S19Tables &t)
+// rgb64: 0 a YUV destination (two jobs of their own tiles); 1 RGBA64LE, 2 BGRA64LE (one grid of 64-column tiles: the luma job's lines, then the chroma job's —
+// 64 >> chrShift columns — behind the same staged-row LDS, then the colour stage); chrShift: 1 = one chroma sample a pixel pair (ignored for YUV destinations)
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t)
 {
     t.ok = 0;
     // (measured: DESIGN 4.8) LDS a block may take, output rows a tile at most
@@ -493,11 +627,6 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
     L.srcW = p.srcW; L.srcH = p.srcH; L.dstW = p.dstW; L.dstH = p.dstH;
     L.dstSel[0] = 0; L.dstOff[0] = 0;
     L.sh = sh; L.maxv = (1 << 19) - 1;
-    const int hp = std::max(p.hLum.pairs, p.hChr.pairs);
-    t.np = hp <= 4 ? 4 : hp <= 8 ? 8 : 0;
-    int r = plan_job(p.hLum, vl, p.srcW, p.srcH, p.dstW, p.dstH, 1, 1, L.layout, t.np ? t.np : p.hLum.pairs, budget, thCap, L, t.colStart[0], t.rowStart[0], t.rowCount[0]);
-    if (r < 0) return r;
-    int lds = r;
     C.ncomp = 2; C.nraw = srcSemi ? 1 : 2; C.ileave = dstSemi ? 1 : 0; C.layout = (bps == 2 ? 2 : 0) + (srcSemi ? 1 : 0);
     C.rawSel[0] = 1; C.rawSel[1] = 2;
     C.kind = kind; C.xorv = xorv; C.rowBytes = p.chrSrcW * bps * (srcSemi ? 2 : 1);
@@ -505,14 +634,57 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
     C.dstSel[0] = 1; C.dstSel[1] = dstSemi ? 1 : 2;
     C.dstOff[0] = 0; C.dstOff[1] = dstSemi ? 2 : 0;
     C.sh = sh; C.maxv = (1 << 19) - 1;
-    r = plan_job(p.hChr, vc, p.chrSrcW, p.chrSrcH, p.chrDstW, p.chrDstH, 2, C.nraw, C.layout, t.np ? t.np : p.hChr.pairs, budget, thCap, C, t.colStart[1], t.rowStart[1], t.rowCount[1]);
-    if (r < 0) return r;
-    lds = std::max(lds, r);
-    t.ldsBytes = lds;
+    const int hp = std::max(p.hLum.pairs, p.hChr.pairs);
+    t.np = hp <= 4 ? 4 : hp <= 8 ? 8 : 0;
+    const int hpL = t.np ? t.np : p.hLum.pairs, hpC = t.np ? t.np : p.hChr.pairs;
+    t.rgb64 = rgb64; t.chrShift = chrShift; t.linesOff = 0;
+    if (!rgb64) {
+        int r = plan_job(p.hLum, vl, p.srcW, p.srcH, p.dstW, p.dstH, 1, 1, L.layout, hpL, budget, thCap, L, t.colStart[0], t.rowStart[0], t.rowCount[0]);
+        if (r < 0) return r;
+        int lds = r;
+        r = plan_job(p.hChr, vc, p.chrSrcW, p.chrSrcH, p.chrDstW, p.chrDstH, 2, C.nraw, C.layout, hpC, budget, thCap, C, t.colStart[1], t.rowStart[1], t.rowCount[1]);
+        if (r < 0) return r;
+        t.ldsBytes = std::max(lds, r);
+    } else {
+        // one grid of tiles: 64 pixels across, the chroma job's tile 64 >> chrShift of ITS columns; the vertical chroma bank has a row an output row
+        if (vc.count != p.dstH || p.chrDstW != ((p.dstW + (1 << chrShift) - 1) >> chrShift)) return GMAT_ERR(ENOSYS);
+        C.dstH = p.dstH;
+        if (int r = check_banks(p.hLum, vl, p.srcW, p.srcH, p.dstW, p.dstH); r < 0) return r;
+        if (int r = check_banks(p.hChr, vc, p.chrSrcW, p.chrSrcH, p.chrDstW, p.dstH); r < 0) return r;
+        const int gcapL = plan_cols(p.hLum, p.dstW, kS19TW, 1, L.layout, hpL, L, t.colStart[0]);
+        const int gcapC = plan_cols(p.hChr, p.chrDstW, kS19TW >> chrShift, C.nraw, C.layout, hpC, C, t.colStart[1]);
+        if (gcapL < 0) return gcapL;
+        if (gcapC < 0) return gcapC;
+        if (L.ntx != C.ntx) return GMAT_ERR(ENOSYS);
+        bool done = false;
+        for (int TH : kS19TH) {
+            if (TH > thCap) continue;
+            std::vector<int32_t> rsL, rcL, rsC, rcC;
+            int nrL, nlL, nrC, nlC;
+            plan_rows(vl, p.srcH, p.dstH, TH, rsL, rcL, nrL, nlL);
+            plan_rows(vc, p.chrSrcH, p.dstH, TH, rsC, rcC, nrC, nlC);
+            const int GL = plan_group(L, 1, nrL, gcapL, budget), GC = plan_group(C, 2, nrC, gcapC, budget);
+            if (GL < 1 || GC < 1) { if (TH == 1) return GMAT_ERR(ENOSYS); continue; }
+            const long vtL = ((long)TH * (2 * vl.pairs + 1) * 4 + 15) & ~15L, vtC = ((long)TH * (2 * vc.pairs + 1) * 4 + 15) & ~15L;
+            const long rawB = std::max((long)GL * L.PP * 4, (long)GC * 2 * C.PP * 4);
+            const long total = vtL + vtC + rawB + ((long)nlL + 2L * nlC) * kS19TW * 4;
+            if (total > budget && TH > 1) continue;
+            if (total > 65536) return GMAT_ERR(ENOSYS);
+            L.TH = C.TH = TH; L.nty = C.nty = (int)rsL.size(); L.nblk = C.nblk = L.ntx * L.nty;
+            L.nrMax = nrL; L.nrLines = nlL; L.G = GL; L.vtBytes = (int)vtL;
+            C.nrMax = nrC; C.nrLines = nlC; C.G = GC; C.vtBytes = (int)vtC;
+            t.rowStart[0].swap(rsL); t.rowCount[0].swap(rcL); t.rowStart[1].swap(rsC); t.rowCount[1].swap(rcC);
+            t.linesOff = (int)(vtL + vtC + rawB);
+            t.ldsBytes = (int)((total + 15) & ~15L);
+            done = true;
+            break;
+        }
+        if (!done) return GMAT_ERR(ENOSYS);
+    }
     if (GMAT_KNOB("GMAT_S19_DEBUG"))
         for (int j = 0; j < 2; j++)
-            fprintf(stderr, "s19 job %d: %d x %d -> %d x %d layout %d np %d vp %d TH %d tiles %d x %d nrMax %d nrLines %d PP %d G %d lshift %d lds %d\n", j, t.job[j].srcW, t.job[j].srcH,
-                    t.job[j].dstW, t.job[j].dstH, t.job[j].layout, t.np, j ? vc.pairs : vl.pairs, t.job[j].TH, t.job[j].ntx, t.job[j].nty, t.job[j].nrMax, t.job[j].nrLines, t.job[j].PP, t.job[j].G, t.job[j].lshift, lds);
+            fprintf(stderr, "s19 job %d: %d x %d -> %d x %d layout %d np %d vp %d TW %d TH %d tiles %d x %d nrMax %d nrLines %d PP %d G %d lshift %d lds %d rgb64 %d\n", j, t.job[j].srcW, t.job[j].srcH,
+                    t.job[j].dstW, t.job[j].dstH, t.job[j].layout, t.np, j ? vc.pairs : vl.pairs, t.job[j].TW, t.job[j].TH, t.job[j].ntx, t.job[j].nty, t.job[j].nrMax, t.job[j].nrLines, t.job[j].PP, t.job[j].G, t.job[j].lshift, t.ldsBytes, rgb64);
     t.ok = 1;
     return 0;
 }
@@ -521,7 +693,7 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || ldsBytes < 1 || ldsBytes > 65536) return GMAT_ERR(EINVAL);
     S19Args a = a0;
-    const dim3 grid((a.job[0].nblk + a.job[1].nblk) * nframes), block(256);
+    const dim3 grid((a.rgb64 ? a.job[0].nblk : a.job[0].nblk + a.job[1].nblk) * nframes), block(256);
     const Yuv2xFrames &fr = *frames;
     const char *kx = GMAT_KNOB("GMAT_SCALE_XCD");
     a.xcdRemap = kx ? atoi(kx) != 0 : 1;

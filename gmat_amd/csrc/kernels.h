@@ -158,7 +158,7 @@ struct S19Job {
     int dstSel[2], dstOff[2], ds[2];      // component c: the frame's destination pointer (0 dst, 1 dstU, 2 dstV) + a byte offset; (per call) its pitch
     DevFilter h, v;
     int sh, maxv, rc;                     // hScale*To19_c's shift and clamp; (per call) range conversion of the lines (hscale19_kernel's codes)
-    int TH, ntx, nty, nblk;               // output rows a tile, tiles across / down
+    int TW, TH, ntx, nty, nblk;           // output columns (64; 32: the half-width chroma of a packed 64-bit destination) and rows a tile, tiles across / down
     int lshift, cp2;                      // log2 of the lanes that share a staged row's units; a row has more than 64 units (a lane stages two)
     int nrMax, nrLines, PP, G, vtBytes;   // most source rows a tile's taps span (inside the plane / with the padded taps); dwords (sample pairs) a staged row; rows staged at once; bytes of a tile's vertical tables
     const int32_t *colStart;              // [ntx] first staged sample of a tile column's rows (a multiple of 4)
@@ -166,13 +166,14 @@ struct S19Job {
 };
 struct S19Tables {
     int ok = 0, np = 0, ldsBytes = 0;     // np: 4 | 8 horizontal pairs in registers, 0 = any number (coefficients read in the loop)
+    int rgb64 = 0, chrShift = 0, linesOff = 0;   // a packed 64-bit destination (1 RGBA64LE, 2 BGRA64LE): chroma columns = pixel columns >> chrShift; byte offset of the lines in LDS
     S19Job job[2];                        // luma, chroma (device pointers left null: the caller uploads col / row tables and fills them in)
     std::vector<int32_t> colStart[2], rowStart[2], rowCount[2];
 };
-struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; };
+struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; int rgb64, chrShift, linesOff; Yuv2RgbConsts y2r; };
 static_assert(sizeof(S19Args) + sizeof(Yuv2xFrames) <= 4096, "S19Args + Yuv2xFrames exceed the kernel-argument segment");
 // hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
-int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, S19Tables &t);
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t);
 int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)

@@ -546,22 +546,26 @@ def test_p016_destination(dev, orc, src_fmt, geom, form, monkeypatch):
                 p.free()
 
 
+@pytest.mark.parametrize("form", ["tile", "passes"])
 @pytest.mark.parametrize("dst_fmt", ["rgba64le", "bgra64le"])
 @pytest.mark.parametrize("src_fmt", ["nv12", "yuv420p", "yuv444p", "p010le", "p016le"])
 @pytest.mark.parametrize("geom", [(256, 64, 128, 32), (96, 40, 144, 60), (201, 91, 151, 67), (130, 50, 130, 50), (64, 34, 64, 17)])
-def test_rgba64_destinations(dev, orc, src_fmt, dst_fmt, geom):
+def test_rgba64_destinations(dev, orc, src_fmt, dst_fmt, geom, form, monkeypatch):
     """RGBA64LE / BGRA64LE (yuv2rgb_cuda's 64-bit outputs) with libswscale's semantics: 19-bit lines, then
     yuv2rgba64_X_c / _2_c / _1_c or their full-chroma twins as packed_vscale picks them (vscale.c:135-167); the oracle
     restates the forms one by one, the HIP path runs the X form with the effective coefficients.  Geometries cover the
-    1-tap luma with 1- and 2-tap chroma (equal size / equal height), full chroma (odd width, 4:4:4 source) and the X form."""
+    1-tap luma with 1- and 2-tap chroma (equal size / equal height), full chroma (odd width, 4:4:4 source) and the X form.  In one launch behind a
+    tile's lines in LDS (scale19_kernel's colour stage, round 6) and as the two passes of k_scale16.hip behind GMAT_S19=0."""
     sw, sh, dw, dh = geom
+    if form == "passes":
+        monkeypatch.setenv("GMAT_S19", "0")
     src = synth_planes(orc, src_fmt, sw, sh, seed=77)
     for flags in ("bicubic", "bilinear", "point"):
         want = orc.sws(src, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags])
         for align, extra in ((64, 0), (2, 2)):
             d = dev.upload_planes(src, align, extra)
             got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, dst_fmt, SWS[flags], dst_align=align, dst_extra=extra)
-            assert "vrgba64" in kernel, kernel
+            assert kernel == ("scale19_kernel" if form == "tile" else "hscale19_kernel+vrgba64_kernel"), kernel
             bad = np.argwhere(got[0] != want[0])
             assert bad.size == 0, f"{len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({flags}, align {align})"
             assert (pads[0] == 0xCD).all()

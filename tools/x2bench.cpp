@@ -60,6 +60,7 @@ static size_t frame_bytes(int fmt, int w, int h)
     case GMAT_PIX_FMT_RGBPF32LE: return (size_t)w * h * 12;        // three stacked planes of floats
     case GMAT_PIX_FMT_YUV444P16LE: return (size_t)w * h * 6;
     case GMAT_PIX_FMT_P016LE: return (size_t)w * h * 3;
+    case GMAT_PIX_FMT_RGBA64LE: case GMAT_PIX_FMT_BGRA64LE: return (size_t)w * h * 8;
     default: return 0;
     }
 }
@@ -83,6 +84,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
     case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
     case GMAT_PIX_FMT_YUV444P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)w * h; s[0] = s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: p[0] = b; s[0] = 3 * w; break;
+    case GMAT_PIX_FMT_RGBA64LE: case GMAT_PIX_FMT_BGRA64LE: p[0] = b; s[0] = 8 * w; break;
     default: p[0] = b; s[0] = 4 * w; break;
     }
 }
@@ -352,6 +354,10 @@ int main(int argc, char **argv)
         {"rgbsrc: p016 4K->1080p p016 bicubic", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: p016 1080p->720p p016 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
         {"dst16: nv12 1080p->720p p016 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"dst16: nv12 1080p->1080p rgba64 convert (yuv2rgb_cuda's 64-bit output)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBA64LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: nv12 1080p->1080p rgba64 convert, point", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBA64LE, 1920, 1080, GMAT_SWS_POINT},
+        {"dst16: nv12 4K->1080p rgba64 bicubic", GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_PIX_FMT_RGBA64LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: p016 1080p->720p bgra64 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_BGRA64LE, 1280, 720, GMAT_SWS_BICUBIC},
         {"dst16: p010 4K->1080p p016 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"dst16: p016 720p->1080p p016 bicubic (up)", GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"dst16: p016 4K->720p p016 lanczos (3:1)", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_LANCZOS},
