@@ -1357,6 +1357,21 @@ static bool planes_fused_takes_px4(GmatSwsContext *in, int n, const uint8_t *con
     return ok;
 }
 
+// ... and the equal-size converter (round 6): rgb2yuv420s_kernel reads four-byte pixels itself where its rule takes the frame
+static bool r2y_strip_takes_px4(const GmatSwsContext *in, const uint8_t *const src[], const int srcStride[], uint8_t *const dst[], const int dstStride[])
+{
+    if (!in || in->mode != MODE_RGB2YUV || in->inner) return false;
+    if (GMAT_KNOB("GMAT_RGBSRC_NO_PX4") && atoi(GMAT_KNOB("GMAT_RGBSRC_NO_PX4"))) return false;
+    const bool dnv12 = in->dstFormat == GMAT_PIX_FMT_NV12;
+    if (!src[0] || !dst[0] || !dst[1] || (!dnv12 && !dst[2])) return false;
+    Rgb2YuvLaunch L;
+    L.src = src[0]; L.ss = srcStride[0]; L.bgr = 0;
+    L.y = dst[0]; L.ys = dstStride[0]; L.u = dst[1]; L.us = dstStride[1]; L.v = dnv12 ? nullptr : dst[2]; L.vs = dnv12 ? 0 : dstStride[2]; L.nv12 = dnv12;
+    L.w = in->srcW; L.h = in->srcH; L.maxRows = 0; L.rowStart = nullptr; L.rowCount = nullptr;
+    L.stripOk = in->r2y.stripOk;
+    return rgb2yuv420_strip_takes(L);
+}
+
 // MODE_SCALE16 with a YUV destination on scale19_kernel: frames [0, n) of the context's geometry, up to 32 a launch
 static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_planes, const int srcStride[], uint8_t *const *dst_planes,
                           const int dstStride[], hipStream_t stream)
@@ -1427,7 +1442,8 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         for (int f = 0; f < n; f++) {
             if (!src_planes[4 * f] || !dst_planes[4 * f]) return GMAT_ERR(EINVAL);
             if (!rg_block_takes_px4(c->inner, n, src_planes[4 * f], srcStride[0], dst_planes[4 * f], dstStride[0]) &&
-                !planes_fused_takes_px4(c->inner, n, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride)) return 0;
+                !planes_fused_takes_px4(c->inner, n, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride) &&
+                !r2y_strip_takes_px4(c->inner, src_planes + 4 * f, srcStride, dst_planes + 4 * f, dstStride)) return 0;
         }
         c->inner->px4 = 1; c->inner->px4Alpha = c->needAlpha;
         const int t = sws_scale_frames_batched_impl(c->inner, n, src_planes, srcStride, dst_planes, dstStride, stream);
@@ -1562,12 +1578,13 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
         L.w = c->srcW; L.h = c->srcH; L.maxRows = c->r2y.maxRows; L.rowStart = nullptr; L.rowCount = nullptr;
         L.k = make_rgb2yuv_consts(c->colorspace); L.toJpeg = c->rangeConv == 1;
         L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        L.px = c->px4 ? 4 : 3;
         for (int f = 0; f < n; f++) {
             const uint8_t *const *sp = src_planes + 4 * f;
             uint8_t *const *dp = dst_planes + 4 * f;
             if (!sp[0] || !dp[0] || !dp[1] || (!dnv12 && !dp[2])) return GMAT_ERR(EINVAL);
             L.src = sp[0]; L.y = dp[0]; L.u = dp[1]; L.v = dnv12 ? nullptr : dp[2];
-            if (!rgb2yuv420_strip_takes(L)) return 0;
+            if (!rgb2yuv420_strip_takes(L)) return c->px4 ? GMAT_ERR(EINVAL) : 0;       // (four-byte pixels were promised the kernel that reads them)
         }
         c->lastKernel = "rgb2yuv420s_kernel";
         for (int f0 = 0; f0 < n; f0 += kYuv2xMaxFrames) {
@@ -2042,7 +2059,7 @@ GmatSwsContext *gmat_sws_getContext(int srcW, int srcH, int srcFormat, int dstW,
             r = ensure_scaler(c);
         }
     } else if ((srcFormat == GMAT_PIX_FMT_RGB24 || srcFormat == GMAT_PIX_FMT_BGR24) &&
-               ((!same && is_yuv8_src(dstFormat)) || dstFormat == GMAT_PIX_FMT_P010LE || dstFormat == GMAT_PIX_FMT_YUV444P)) {
+               ((!same && is_yuv8_src(dstFormat)) || is_dst10(dstFormat) || dstFormat == GMAT_PIX_FMT_YUV444P)) {       // (round 6: planar YUV420P10LE too — swscale_cuda.c:34-44 lists it; the format sweep found the pair refused)
         // packed RGB scaled into a YUV frame (one libswscale context: rgb24ToY / ToUV(_half), hScale16To15_c, planar
         // vertical stage): the plane scaler with its RGB loader
         c->mode = MODE_SCALE;
@@ -2325,12 +2342,15 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         L.k = make_rgb2yuv_consts(c->colorspace);      // the destination's matrix (fill_rgb2yuv_table, utils.c:765-858)
         L.toJpeg = c->rangeConv == 1;
         L.stripOk = c->r2y.stripOk; for (int k = 0; k < 4; k++) L.vC[k] = c->r2y.vC[k];
+        L.px = c->px4 ? 4 : 3;
+        if (c->px4 && !rgb2yuv420_strip_takes(L)) { r = GMAT_ERR(EINVAL); break; }      // (four-byte pixels were promised the kernel that reads them)
         c->lastKernel = rgb2yuv420_strip_takes(L) ? "rgb2yuv420s_kernel" : "rgb2yuv420_kernel";
         r = launch_rgb2yuv420(L, c->stream);
         break;
     }
     case MODE_VIA_INNER: {
-        if (rg_block_takes_px4(c->inner, 1, src[0], srcStride[0], dst[0], dstStride[0]) || planes_fused_takes_px4(c->inner, 1, src, srcStride, dst, dstStride)) {
+        if (rg_block_takes_px4(c->inner, 1, src[0], srcStride[0], dst[0], dstStride[0]) || planes_fused_takes_px4(c->inner, 1, src, srcStride, dst, dstStride) ||
+            r2y_strip_takes_px4(c->inner, src, srcStride, dst, dstStride)) {
             gmat_sws_setStream(c->inner, (void *)c->stream);
             c->inner->px4 = 1; c->inner->px4Alpha = c->needAlpha;
             r = gmat_sws_scale(c->inner, src, srcStride, 0, c->srcH, dst, dstStride);
@@ -2456,9 +2476,12 @@ static int sws_scale_impl(GmatSwsContext *c, const uint8_t *const src[], const i
         if (r < 0) break;
         const int depth = pl16_depth(c->srcFormat), sub = c->srcFormat == GMAT_PIX_FMT_YUV444P16LE ? 0 : 1;
         const int cw = ceil_rshift(c->srcW, sub), ch = ceil_rshift(c->srcH, sub);
-        c->lastKernel = "plane_copy_down_kernel";
-        if ((r = launch_plane_copy_down(src[0], srcStride[0], dst[0], dstStride[0], c->srcW, c->srcH, depth, c->planeDownFull ? 0 : 1, c->stream)) < 0) break;
-        for (int i = 1; i < 3 && r >= 0; i++) r = launch_plane_copy_down(src[i], srcStride[i], dst[i], dstStride[i], cw, ch, depth, 1, c->stream);
+        c->lastKernel = "plane_copy_down3_kernel";
+        {
+            const uint8_t *const sp[3] = {src[0], src[1], src[2]};
+            uint8_t *const dp[3] = {dst[0], dst[1], dst[2]};
+            r = launch_planes_copy_down(sp, srcStride, dp, dstStride, c->srcW, c->srcH, cw, ch, depth, c->planeDownFull ? 0 : 1, c->stream);
+        }
         break;
     }
     case MODE_PLANECOPY: {

@@ -189,14 +189,16 @@ struct Rgb2YuvStripArgs {                        // plane pointers: Yuv2xFrames 
     int rnd;
     int segRows, nseg, nstrips, nblk, xcdRemap;
 };
-struct Y2sRow { unsigned d[6]; };
+struct Y2sRow { unsigned d[8]; };                 // eight pixels: 24 bytes (six dwords) or — PX = 4, RGBA / BGRA read as they are (round 6) — 32
 
 // JPEG: full-range destination (lum / chrRangeToJpeg_c) — a template parameter: as a run-time flag the compiler made it a scalar branch
 // per PIXEL (26 branches per iteration; the first build ran at 16 us per 4K frame, slower than the tiled kernel)
 // NOSAT: the host has verified from the coefficients that no 8-bit input can reach the saturations of the limited-range path — the 14-bit
 // luma stays below 16352 and the 14-bit chroma below 16384 (true for every matrix of fill_rgb2yuv_table: the luma row sums to
 // 219/255 * 2^15) — so min(2 v, 32767) and the 8-bit clip of the one-tap luma output are dead and ((2 y + 64) >> 7) = (y + 32) >> 6.
-template <bool NV, bool JPEG, bool NOSAT>
+// PX: bytes a source pixel (3; 4: RGBA / BGRA sources, rgb32ToY / ToUV read the same three channels — round 6: such a context ran a 32 -> 24-bit pass in
+// front of this kernel, two launches a frame and no batches: 13.1 us a 1080p frame where RGB24 takes 2.2, profiles/r06_sweep_before.txt)
+template <bool NV, bool JPEG, bool NOSAT, int PX>
 __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yuv2xFrames fr)
 {
     const uint8_t *psrc = fr.y[blockIdx.y];
@@ -222,18 +224,19 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yu
     const unsigned xc = (unsigned)(active ? xo : a.w - 8);      // idle lanes shadow the last group (loads stay inside the rows)
 
     auto load_row = [&](int r, Y2sRow &R) {
-        const uint8_t *p = psrc + ((unsigned)min(max(r, 0), a.h - 1) * (unsigned)a.ss + 3u * xc);
+        const uint8_t *p = psrc + ((unsigned)min(max(r, 0), a.h - 1) * (unsigned)a.ss + (unsigned)PX * xc);
         const uint4 v0 = y2s_ld16(p);
-        const uint2 v1 = y2s_ld8(p + 16);
-        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w; R.d[4] = v1.x; R.d[5] = v1.y;
+        R.d[0] = v0.x; R.d[1] = v0.y; R.d[2] = v0.z; R.d[3] = v0.w;
+        if (PX == 4) { const uint4 v1 = y2s_ld16(p + 16); R.d[4] = v1.x; R.d[5] = v1.y; R.d[6] = v1.z; R.d[7] = v1.w; }
+        else         { const uint2 v1 = y2s_ld8(p + 16); R.d[4] = v1.x; R.d[5] = v1.y; }
     };
     // one source row: luma of the 8 pixels written if the row belongs to this segment; 15-bit U / V of the 4 pixel pairs returned
     auto convert_row = [&](const Y2sRow &R, int row, bool luma, int (&cu)[4], int (&cv)[4]) {
         int fs[8], th[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int o = 3 * i, d = o >> 2, b = o & 3;
-            const unsigned lo = R.d[d], hi = R.d[d + 1 < 6 ? d + 1 : d];
+            const int o = PX * i, d = o >> 2, b = o & 3;
+            const unsigned lo = R.d[d], hi = R.d[PX == 4 ? d : d + 1 < 6 ? d + 1 : d];
             fs[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (unsigned)b | ((unsigned)(b + 1) << 16));
             th[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (unsigned)(b + 2));
         }
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void rgb2yuv420s_kernel(Rgb2YuvStripArgs a, Yu
         for (int c = 0; c < 4; c++) hwU[s][c] = hwV[s][c] = 0;
     Y2sRow bufA[2], bufB[2];                                    // ping-pong: rows 2m-1 and 2m of the current / next pair
 #pragma unroll
-    for (int i = 0; i < 6; i++) bufA[1].d[i] = bufB[1].d[i] = 0u;
+    for (int i = 0; i < 8; i++) bufA[1].d[i] = bufB[1].d[i] = 0u;
     load_row(2 * (c0 - 1) - 1, bufA[0]);
     load_row(2 * (c0 - 1), bufB[0]);
 
@@ -387,8 +390,10 @@ int launch_rgb2yuv420s(const Rgb2YuvLaunch &L, hipStream_t stream, const Yuv2xFr
     lo_hi(q.rv, q.gv, q.bv, 510, (256L << 15) + (1 << 9), 10, vlo, vhi);
     const char *ns = GMAT_KNOB("GMAT_R2Y_NOSAT");                   // test knob: 0 = the variant that keeps every saturation
     const bool nosat = !(ns && !atoi(ns)) && ylo >= 0 && yhi <= 16351 && ulo >= 0 && uhi <= 16383 && vlo >= 0 && vhi <= 16383;
-#define GMAT_Y2S(NV_, J_) do { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true>), grid, block, 0, stream, a, *frames); \
-                               else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false>), grid, block, 0, stream, a, *frames); } while (0)
+#define GMAT_Y2S(NV_, J_) do { if (L.px == 4) { if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true, 4>), grid, block, 0, stream, a, *frames); \
+                                                 else       hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false, 4>), grid, block, 0, stream, a, *frames); } \
+                               else if (nosat) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, true, 3>), grid, block, 0, stream, a, *frames); \
+                               else            hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb2yuv420s_kernel<NV_, J_, false, 3>), grid, block, 0, stream, a, *frames); } while (0)
     if (L.toJpeg) { if (L.nv12) GMAT_Y2S(true, true); else GMAT_Y2S(false, true); }
     else          { if (L.nv12) GMAT_Y2S(true, false); else GMAT_Y2S(false, false); }
 #undef GMAT_Y2S
@@ -899,6 +904,57 @@ int launch_plane_copy_down(const uint8_t *src, int ss, uint8_t *dst, int ds, int
     if (w <= 0 || h <= 0) return 0;
     const dim3 grid((w + 1023) / 1024, h), block(256);
     hipLaunchKernelGGL(plane_copy_down_kernel, grid, block, 0, stream, src, ss, dst, ds, w, h, depth, shiftonly);
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// (round 6) the three planes of a frame in ONE launch (three launches of four samples a thread before: yuv420p10le -> yuv420p at 1080p 9.7 us a frame, 0.12 of the
+// roofline, most of it the gaps between six-microsecond-class launches — profiles/r06_sweep_before.txt): rows [0, h) of the luma plane, then the two chroma
+// planes' (cw x ch each); a lane: eight samples — sixteen bytes in, eight out — where the rows allow (al: source rows on 16-byte, destination rows on 8-byte addresses)
+struct PlaneDown3 { const uint8_t *src[3]; uint8_t *dst[3]; int ss[3], ds[3]; };
+__global__ __launch_bounds__(256) void plane_copy_down3_kernel(PlaneDown3 P, int w, int h, int cw, int ch, int depth, int shiftonlyY, int al)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 8;
+    int r = blockIdx.y;
+    const int pl = r < h ? 0 : r < h + ch ? 1 : 2;
+    if (pl == 1) r -= h; else if (pl == 2) r -= h + ch;
+    const int pw = pl ? cw : w;
+    if (x >= pw) return;
+    const uint8_t *srow = (pl == 0 ? P.src[0] : pl == 1 ? P.src[1] : P.src[2]) + (size_t)r * (pl == 0 ? P.ss[0] : pl == 1 ? P.ss[1] : P.ss[2]);
+    uint8_t *drow = (pl == 0 ? P.dst[0] : pl == 1 ? P.dst[1] : P.dst[2]) + (size_t)r * (pl == 0 ? P.ds[0] : pl == 1 ? P.ds[1] : P.ds[2]);
+    const int shift = depth - 8, shiftonly = pl ? 1 : shiftonlyY;
+    auto one = [&](unsigned v, int xx) -> unsigned {
+        const unsigned dith = shift == 2 ? (unsigned)(((r & 1) ? 3 : 1) ^ ((xx & 1) ? 3 : 0)) : (unsigned)dither_8x8_128(xx, r);
+        unsigned t;
+        if (shiftonly) { t = (v + dith) >> shift; t -= t >> 8; }
+        else           { t = (v - (v >> 8) + dith) >> shift; }
+        return t & 0xFFu;
+    };
+    if (al && x + 8 <= pw) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(srow + 2 * (size_t)x);
+        const unsigned q[4] = {v.x, v.y, v.z, v.w};
+        unsigned o[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o[i >> 1] |= one(q[i] & 0xFFFFu, x + 2 * i) << (16 * (i & 1));
+            o[i >> 1] |= one(q[i] >> 16, x + 2 * i + 1) << (16 * (i & 1) + 8);
+        }
+        *reinterpret_cast<uint2 *>(drow + x) = make_uint2(o[0], o[1]);
+    } else {
+        const unsigned short *s16 = reinterpret_cast<const unsigned short *>(srow);
+        for (int i = 0; i < min(8, pw - x); i++) drow[x + i] = (uint8_t)one(s16[x + i], x + i);
+    }
+}
+
+int launch_planes_copy_down(const uint8_t *const src[3], const int ss[3], uint8_t *const dst[3], const int ds[3], int w, int h, int cw, int ch, int depth,
+                            int shiftonlyY, hipStream_t stream)
+{
+    if (w <= 0 || h <= 0) return 0;
+    PlaneDown3 P;
+    uintptr_t sa = 0, da = 0;
+    for (int i = 0; i < 3; i++) { P.src[i] = src[i]; P.dst[i] = dst[i]; P.ss[i] = ss[i]; P.ds[i] = ds[i]; sa |= (uintptr_t)src[i] | (uintptr_t)ss[i]; da |= (uintptr_t)dst[i] | (uintptr_t)ds[i]; }
+    const dim3 grid((w + 2047) / 2048, h + 2 * ch), block(256);
+    hipLaunchKernelGGL(plane_copy_down3_kernel, grid, block, 0, stream, P, w, h, cw, ch, depth, shiftonlyY, ((sa & 15) == 0 && (da & 7) == 0) ? 1 : 0);
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

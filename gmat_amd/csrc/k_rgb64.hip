@@ -12,6 +12,7 @@
 // (output.c, quoted at alpha8_out_kernel).  Here: the existing one-sample-per-thread horizontal pass of k_scale16.hip into
 // int32 lines, then alpha8_out_kernel / the alpha operand of vrgba64_kernel.  Completeness paths, not fast ones.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "px_math.h"
@@ -86,10 +87,116 @@ __global__ __launch_bounds__(256) void rgb8_planes_kernel(const uint8_t *src, in
     reinterpret_cast<unsigned short *>(pv + (size_t)y * vs)[cx] = (unsigned short)v;
 }
 
+// (round 6) both kernels above four pixels a thread: the format sweep (profiles/r06_sweep_before.txt) found every context behind them — packed RGB into
+// 16-bit YUV / RGBA64, RGBA64 sources — at 25-38 us a 1080p frame with the scaler behind them at 6-10: a thread a chroma sample, byte and 16-bit loads, 16-bit stores.
+// Here: 12 / 16 / 32 source bytes a thread in dwords where the row allows (al4: rows on 4-byte addresses; else bytes), eight luma bytes and four or eight chroma
+// bytes stored at once (the planes are the context's own: rows on 256-byte addresses).  The ragged last group of a row takes the formulas pixel by pixel.
+// BPS 1: rgb8_planes_kernel's arithmetic (PX 3 | 4 bytes a pixel); BPS 2: rgb64_planes_kernel's (8 bytes a pixel)
+template <int BPS, int PX>
+__global__ __launch_bounds__(256) void rgb_planes4_kernel(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, int al4,
+                                                          Rgb2YuvConsts k, uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *row = src + (size_t)y * ss;
+    unsigned short *oy = reinterpret_cast<unsigned short *>(py + (size_t)y * ys);
+    unsigned short *ou = reinterpret_cast<unsigned short *>(pu + (size_t)y * us), *ov = reinterpret_cast<unsigned short *>(pv + (size_t)y * vs);
+    const int ro = bgr ? 2 : 0, bo = 2 - ro;
+    auto sample = [&](int xx, int ch) -> int {
+        if (BPS == 2) return reinterpret_cast<const unsigned short *>(row)[4 * xx + ch];
+        return row[PX * xx + ch];
+    };
+    // (v_mul_i32_i24: samples below 2^16 x coefficients below 2^15 — the low 32 bits of the product, full rate; v_mul_lo_u32 is a quarter of it)
+    auto lum = [&](int r, int g, int b) -> unsigned {
+        const unsigned acc = (unsigned)__mul24(k.ry, r) + (unsigned)__mul24(k.gy, g) + (unsigned)__mul24(k.by, b);
+        if (BPS == 2) return (acc + (0x2001u << 14)) >> 15;
+        return (unsigned)((int)(acc + (unsigned)((32 << 14) + (1 << 8))) >> 9);
+    };
+    // chroma of one pixel (full) or of a pixel pair (half): the 8-bit readers work on the pair's SUMS, the 16-bit ones on its rounded means
+    auto chr = [&](int r0, int g0, int b0, int r1, int g1, int b1, bool pair, unsigned &u, unsigned &v) {
+        int r, g, b, add, sh;
+        if (BPS == 2)  { r = pair ? (r0 + r1 + 1) >> 1 : r0; g = pair ? (g0 + g1 + 1) >> 1 : g0; b = pair ? (b0 + b1 + 1) >> 1 : b0; add = 0x10001 << 14; sh = 15; }
+        else if (pair) { r = r0 + r1; g = g0 + g1; b = b0 + b1; add = (256 << 15) + (1 << 9); sh = 10; }
+        else           { r = r0; g = g0; b = b0; add = (256 << 14) + (1 << 8); sh = 9; }
+        u = (unsigned)((int)((unsigned)__mul24(k.ru, r) + (unsigned)__mul24(k.gu, g) + (unsigned)__mul24(k.bu, b) + (unsigned)add) >> sh) & 0xFFFFu;
+        v = (unsigned)((int)((unsigned)__mul24(k.rv, r) + (unsigned)__mul24(k.gv, g) + (unsigned)__mul24(k.bv, b) + (unsigned)add) >> sh) & 0xFFFFu;
+    };
+    if (x + 4 <= w) {
+        int c[4][3];                                                            // [pixel][r, g, b]
+        if (al4) {
+            constexpr int NDW = BPS == 2 ? 8 : PX;                             // dwords of four pixels: 8 (64-bit), 3 (24-bit), 4 (32-bit)
+            unsigned d[NDW];
+            const unsigned *p = reinterpret_cast<const unsigned *>(row + (size_t)x * (BPS == 2 ? 8 : PX));
+#pragma unroll
+            for (int i = 0; i < NDW; i++) d[i] = p[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    if (BPS == 2) { const int hw = 4 * i + ch; c[i][ch] = (int)(d[hw >> 1] >> (16 * (hw & 1)) & 0xFFFFu); }
+                    else          { const int bt = PX * i + ch; c[i][ch] = (int)(d[bt >> 2] >> (8 * (bt & 3)) & 0xFFu); }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) c[i][ch] = sample(x + i, ch);
+        }
+        // (red and blue by a select, not by an index: `c[i][ro]` with a run-time ro put the array into scratch — 24.6 -> 43.4 us a frame on the first try, r06o)
+        int R[4], G[4], B[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { R[i] = bgr ? c[i][2] : c[i][0]; G[i] = c[i][1]; B[i] = bgr ? c[i][0] : c[i][2]; }
+        unsigned yy[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) yy[i] = lum(R[i], G[i], B[i]) & 0xFFFFu;
+        *reinterpret_cast<uint2 *>(oy + x) = make_uint2(yy[0] | yy[1] << 16, yy[2] | yy[3] << 16);
+        if (half) {
+            unsigned u0, v0, u1, v1;
+            chr(R[0], G[0], B[0], R[1], G[1], B[1], true, u0, v0);
+            chr(R[2], G[2], B[2], R[3], G[3], B[3], true, u1, v1);
+            *reinterpret_cast<unsigned *>(ou + (x >> 1)) = u0 | u1 << 16;
+            *reinterpret_cast<unsigned *>(ov + (x >> 1)) = v0 | v1 << 16;
+        } else {
+            unsigned u[4], v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) chr(R[i], G[i], B[i], 0, 0, 0, false, u[i], v[i]);
+            *reinterpret_cast<uint2 *>(ou + x) = make_uint2(u[0] | u[1] << 16, u[2] | u[3] << 16);
+            *reinterpret_cast<uint2 *>(ov + x) = make_uint2(v[0] | v[1] << 16, v[2] | v[3] << 16);
+        }
+    } else {
+        // the row's ragged end: one to three pixels, as the kernels above (an odd width with halved chroma uses the last pixel twice)
+        for (int xx = x; xx < w; xx++) oy[xx] = (unsigned short)lum(sample(xx, ro), sample(xx, 1), sample(xx, bo));
+        if (half) {
+            for (int cx = x >> 1; cx < chrW; cx++) {
+                const int x0 = 2 * cx, x1 = min(2 * cx + 1, w - 1);
+                unsigned u, v;
+                chr(sample(x0, ro), sample(x0, 1), sample(x0, bo), sample(x1, ro), sample(x1, 1), sample(x1, bo), true, u, v);
+                ou[cx] = (unsigned short)u; ov[cx] = (unsigned short)v;
+            }
+        } else {
+            for (int xx = x; xx < w; xx++) {
+                unsigned u, v;
+                chr(sample(xx, ro), sample(xx, 1), sample(xx, bo), 0, 0, 0, false, u, v);
+                ou[xx] = (unsigned short)u; ov[xx] = (unsigned short)v;
+            }
+        }
+    }
+}
+
 int launch_rgb8_planes(const uint8_t *src, int ss, int w, int h, int chrW, int half, int bgr, int px, const Rgb2YuvConsts &k,
                        uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return 0;
+    const bool planesAl = ((((uintptr_t)py | (uintptr_t)ys | (uintptr_t)pu | (uintptr_t)us | (uintptr_t)pv | (uintptr_t)vs) & 7) == 0);
+    const char *kq = GMAT_KNOB("GMAT_RGB_PLANES4");
+    if (planesAl && (px == 3 || px == 4) && !(kq && atoi(kq) == 0)) {
+        const dim3 grid((w + 1023) / 1024, h), block(256);
+        const int al4 = ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) ? 1 : 0;
+        if (px == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb_planes4_kernel<1, 3>), grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, al4, k, py, ys, pu, us, pv, vs);
+        else         hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb_planes4_kernel<1, 4>), grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, al4, k, py, ys, pu, us, pv, vs);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((chrW + 255) / 256, h), block(256);
     hipLaunchKernelGGL(rgb8_planes_kernel, grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, px, k, py, ys, pu, us, pv, vs);
     GMAT_HIP_CHECK(hipGetLastError());
@@ -100,6 +207,15 @@ int launch_rgb64_planes(const uint8_t *src, int ss, int w, int h, int chrW, int 
                         uint8_t *py, int ys, uint8_t *pu, int us, uint8_t *pv, int vs, hipStream_t stream)
 {
     if (w <= 0 || h <= 0) return 0;
+    const bool planesAl = ((((uintptr_t)py | (uintptr_t)ys | (uintptr_t)pu | (uintptr_t)us | (uintptr_t)pv | (uintptr_t)vs) & 7) == 0);
+    const char *kq = GMAT_KNOB("GMAT_RGB_PLANES4");
+    if (planesAl && !(kq && atoi(kq) == 0)) {
+        const dim3 grid((w + 1023) / 1024, h), block(256);
+        const int al4 = ((((uintptr_t)src | (uintptr_t)ss) & 3) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rgb_planes4_kernel<2, 4>), grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, al4, k, py, ys, pu, us, pv, vs);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((chrW + 255) / 256, h), block(256);
     hipLaunchKernelGGL(rgb64_planes_kernel, grid, block, 0, stream, src, ss, w, h, chrW, half, bgr, k, py, ys, pu, us, pv, vs);
     GMAT_HIP_CHECK(hipGetLastError());

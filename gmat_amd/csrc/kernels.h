@@ -246,6 +246,7 @@ struct Rgb2YuvLaunch {
     int maxRows;
     Rgb2YuvConsts k;
     int stripOk = 0; int32_t vC[4] = {0, 0, 0, 0};      // from Rgb2YuvPlan
+    int px = 3;                          // bytes a source pixel: 4 = RGBA / BGRA read as they are (rgb2yuv420s_kernel only)
 };
 int rgb2yuv_prepare(const ScalePlan &p, Rgb2YuvPlan &t);
 int launch_rgb2yuv420(const Rgb2YuvLaunch &L, hipStream_t stream);
@@ -266,6 +267,9 @@ int launch_uv_relayout(int toPlanar, const uint8_t *a0, int s0, const uint8_t *a
 // one plane of planarCopyWrapper's 8 -> `depth` bit copy; replicate: the luma of a full-range source (swscale_unscaled.c:1844-1862)
 int launch_plane_copy_up(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int replicate, hipStream_t stream);
 int launch_plane_copy_down(const uint8_t *src, int ss, uint8_t *dst, int ds, int w, int h, int depth, int shiftonly, hipStream_t stream);
+// the three planes of a frame in one launch (luma w x h, chroma cw x ch each); shiftonlyY: the luma's form (the chroma's is always the shift-only one)
+int launch_planes_copy_down(const uint8_t *const src[3], const int ss[3], uint8_t *const dst[3], const int ds[3], int w, int h, int cw, int ch, int depth,
+                            int shiftonlyY, hipStream_t stream);
 // NV12 <-> YUV420P in one launch (luma copy + chroma (de)interleave, streaming both ways; frames: grid.z) where every plane moves in 16 / 8 bytes
 bool yuv420_relayout_takes(int toPlanar, const uint8_t *y, int ys, const uint8_t *a0, int s0, const uint8_t *a1, int s1,
                            const uint8_t *dy, int dys, const uint8_t *d0, int ds0, const uint8_t *d1, int ds1);

@@ -121,7 +121,7 @@ def test_plane_copy_down(dev, orc, case, full):
         assert lib.gmat_sws_setRange(c, 1, 1) == 0
     dst = dev.planes_like(df, w, h, 64)
     assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h, planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
-    assert lib.gmat_sws_lastKernel(c).decode() == "plane_copy_down_kernel"
+    assert lib.gmat_sws_lastKernel(c).decode() == "plane_copy_down3_kernel"
     got = [p.download() for p in dst]
     shift = depth - 8
     for i, g in enumerate(got):
@@ -148,7 +148,7 @@ def test_plane_copy_down(dev, orc, case, full):
     # ranges that differ: the generic lines carry the conversion (utils.c:1996-2000), their own dither
     assert lib.gmat_sws_setRange(c, 0, 1) == 0
     assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h, planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
-    assert lib.gmat_sws_lastKernel(c).decode() != "plane_copy_down_kernel"
+    assert lib.gmat_sws_lastKernel(c).decode() != "plane_copy_down3_kernel"
     lib.gmat_sws_freeContext(c)
     for p in d + dst:
         p.free()

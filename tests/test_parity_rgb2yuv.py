@@ -261,3 +261,55 @@ def test_depth_expansion_to_p01x(dev, orc, w, h, src_fmt, dst_fmt):
                              planes([p.ptr for p in dst]), ints([p.stride for p in dst]), w, h, PIX_FMT[src_fmt],
                              PIX_FMT[dst_fmt], None)
     assert r == 0 and all((a.download() == b).all() for a, b in zip(dst, want))
+
+
+@pytest.mark.parametrize("w,h", [(128, 32), (520, 20), (1032, 16), (72, 18), (130, 34), (300, 66), (128, 33)])
+@pytest.mark.parametrize("src_fmt", ["rgba", "bgra"])
+@pytest.mark.parametrize("dst_fmt", ["nv12", "yuv420p"])
+def test_rgba_to_yuv420_reads_the_pixels_as_they_are(dev, orc, w, h, src_fmt, dst_fmt, monkeypatch):
+    """rgb2yuv_cuda's RGBA / BGRA sources (libswscale/cuda/yuv2rgb_cuda.cu:909-947) at equal size: rgb32ToY / ToUV read the same three channels, so the strip
+    kernel's <PX = 4> instances take the frame where its rule does (round 6: a 32 -> 24-bit pass ran in front — two launches a frame, batches frame by frame); the
+    pass stays behind GMAT_RGBSRC_NO_PX4=1 and for the frames the rule declines.  Single calls, a batch (one launch), the full-range destination"""
+    import ctypes as C
+    lib = dev.lib
+    src = synth_planes(orc, src_fmt, w, h, seed=57)
+    want = orc.sws(src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"])
+    for knob in ("", "1"):
+        monkeypatch.setenv("GMAT_RGBSRC_NO_PX4", knob) if knob else monkeypatch.delenv("GMAT_RGBSRC_NO_PX4", raising=False)
+        for align, extra in [(256, 0), (4, 4)]:
+            d_src = dev.upload_planes(src, align, extra)
+            got, pads, kernel = dev.sws(d_src, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
+            assert kernel == ("rgb2yuv420s_kernel" if strip_takes(w, h, align) else "rgb2yuv420_kernel"), (kernel, align)
+            for i, (g, wv) in enumerate(zip(got, want)):
+                assert (g == wv).all(), (kernel, knob, align, i, np.argwhere(g != wv)[:3].tolist())
+            for p in pads:
+                assert (p == 0xCD).all()
+            for p in d_src:
+                p.free()
+    monkeypatch.delenv("GMAT_RGBSRC_NO_PX4", raising=False)
+    # a batch of three frames through gmat_sws_scale_batch: one launch where the strip rule takes the frames
+    nf = 3
+    srcs = [synth_planes(orc, src_fmt, w, h, seed=60 + f) for f in range(nf)]
+    wants = [orc.sws(s_, w, h, src_fmt, w, h, dst_fmt, SWS["bicubic"]) for s_ in srcs]
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT[src_fmt], w, h, PIX_FMT[dst_fmt], SWS["bicubic"], None)
+    assert c
+    dsrc = [dev.upload_planes(s_, 256) for s_ in srcs]
+    ddst = [dev.planes_like(dst_fmt, w, h, 256) for _ in srcs]
+    sp, dp = (C.c_void_p * (4 * nf))(), (C.c_void_p * (4 * nf))()
+    for f in range(nf):
+        for i, p in enumerate(dsrc[f]):
+            sp[4 * f + i] = p.ptr
+        for i, p in enumerate(ddst[f]):
+            dp[4 * f + i] = p.ptr
+    assert lib.gmat_sws_scale_batch(c, nf, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]), C.cast(dp, C.POINTER(C.c_void_p)),
+                                    ints([p.stride for p in ddst[0]]), C.cast((C.c_void_p * 1)(None), C.POINTER(C.c_void_p)), 1, 3) == nf
+    lib.gmat_device_sync()
+    if strip_takes(w, h, 256):
+        assert lib.gmat_sws_lastKernel(c).decode() == "rgb2yuv420s_kernel" and lib.gmat_sws_lastLaunchFrames(c) == nf
+    for f in range(nf):
+        for a, b in zip(ddst[f], wants[f]):
+            assert (a.download() == b).all(), (f, lib.gmat_sws_lastKernel(c).decode())
+    lib.gmat_sws_freeContext(c)
+    for fr in dsrc + ddst:
+        for p in fr:
+            p.free()

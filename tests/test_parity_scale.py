@@ -611,7 +611,7 @@ def test_yuv444p16_source_to_8bit_and_p010(dev, orc, dst_fmt, geom):
         d = dev.upload_planes(src, align, extra)
         got, pads, kernel = dev.sws(d, sw, sh, "yuv444p16le", dw, dh, dst_fmt, SWS["bicubic"], dst_align=align, dst_extra=extra)
         if (sw, sh) == (dw, dh) and dst_fmt == "yuv444p":                    # equal size and layout: planarCopyWrapper (tests/test_parity_dither.py)
-            assert kernel == "plane_copy_down_kernel"
+            assert kernel == "plane_copy_down3_kernel"
         else:
             assert is_generic(kernel), kernel
         for i, (g, wv) in enumerate(zip(got, want)):
@@ -1225,3 +1225,21 @@ def test_yuv420_relayout_in_one_launch(dev, orc, pair, w, h, align, monkeypatch)
         assert (g == wv).all()
     for p in d:
         p.free()
+
+
+@pytest.mark.parametrize("src_fmt", ["rgb24", "bgr24", "rgba", "bgra"])
+def test_packed_rgb_to_planar_10bit(dev, orc, src_fmt):
+    """packed RGB into YUV420P10LE (swscale_cuda.c:34-44 lists the format; round 6's format sweep — tools/x2bench sweep: — found the pair REFUSED while P010LE, the same
+    samples interleaved, was served): the plane scaler with its RGB loader and the planar 10-bit output stage (yuv2planeX_10_c), equal size and scaled"""
+    for geom in ((128, 72, 128, 72), (192, 108, 128, 72), (96, 40, 144, 60), (101, 45, 75, 33)):
+        sw, sh, dw, dh = geom
+        for flags in ("bicubic", "bilinear", "fast_bilinear"):
+            src = synth_planes(orc, src_fmt, sw, sh, seed=4)
+            want = orc.sws(src, sw, sh, src_fmt, dw, dh, "yuv420p10le", SWS[flags])
+            d = dev.upload_planes(src, 64)
+            got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "yuv420p10le", SWS[flags], dst_align=64)
+            for i, (g, wv) in enumerate(zip(got, want)):
+                assert (g == wv).all(), (src_fmt, geom, flags, i, kernel)
+                assert (pads[i] == 0xCD).all()
+            for p in d:
+                p.free()

@@ -54,7 +54,7 @@ static size_t frame_bytes(int fmt, int w, int h)
     }
     switch (fmt) {
     case GMAT_PIX_FMT_NV12: case GMAT_PIX_FMT_YUV420P: return (size_t)w * h * 3 / 2;
-    case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_YUV420P10LE: return (size_t)w * h * 3;
+    case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_YUV420P10LE: case GMAT_PIX_FMT_YUV420P16LE: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: case GMAT_PIX_FMT_YUV444P: return (size_t)w * h * 3;
     case GMAT_PIX_FMT_RGBA: case GMAT_PIX_FMT_BGRA: return (size_t)w * h * 4;
     case GMAT_PIX_FMT_RGBPF32LE: return (size_t)w * h * 12;        // three stacked planes of floats
@@ -80,7 +80,7 @@ static void frame_ptrs(uint8_t *b, int fmt, int w, int h, uint8_t *p[4], int s[4
     case GMAT_PIX_FMT_NV12: p[0] = b; p[1] = b + (size_t)w * h; s[0] = w; s[1] = w; break;
     case GMAT_PIX_FMT_P010LE: case GMAT_PIX_FMT_P016LE: p[0] = b; p[1] = b + (size_t)w * h * 2; s[0] = 2 * w; s[1] = 2 * w; break;
     case GMAT_PIX_FMT_YUV444P16LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)w * h * 2; s[0] = s[1] = s[2] = 2 * w; break;
-    case GMAT_PIX_FMT_YUV420P10LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)(w / 2) * (h / 2) * 2; s[0] = 2 * w; s[1] = s[2] = w; break;
+    case GMAT_PIX_FMT_YUV420P10LE: case GMAT_PIX_FMT_YUV420P16LE: p[0] = b; p[1] = b + (size_t)w * h * 2; p[2] = p[1] + (size_t)(w / 2) * (h / 2) * 2; s[0] = 2 * w; s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_YUV420P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)(w / 2) * (h / 2); s[0] = w; s[1] = s[2] = w / 2; break;
     case GMAT_PIX_FMT_YUV444P: p[0] = b; p[1] = b + (size_t)w * h; p[2] = p[1] + (size_t)w * h; s[0] = s[1] = s[2] = w; break;
     case GMAT_PIX_FMT_RGB24: case GMAT_PIX_FMT_BGR24: p[0] = b; s[0] = 3 * w; break;
@@ -443,6 +443,29 @@ int main(int argc, char **argv)
     g_op_frames = NF;
     for (const Op &o : ops)
         if (*only && strstr(o.label, only)) run_op(o.label, o.op, 3840, 2160, o.bpp, launches * 4, o.pool);
+    // "sweep:<w>x<h>-<w>x<h>": every pair of swscale_cuda's format list (libswscale/cuda/swscale_cuda.c:34-44; RGB32 / BGR32 are BGRA / RGBA on a little-endian host)
+    // at that geometry, bicubic — the table that finds the pairs nobody has timed (round 5's method; round 6: profiles/r06_sweep_*.txt)
+    if (strncmp(only, "sweep:", 6) == 0) {
+        int sw = 1920, sh = 1080, dw = 1280, dh = 720;
+        sscanf(only + 6, "%dx%d-%dx%d", &sw, &sh, &dw, &dh);
+        struct F { const char *n; int f; };
+        const F fm[] = {{"yuv420p", GMAT_PIX_FMT_YUV420P}, {"nv12", GMAT_PIX_FMT_NV12}, {"yuv420p10", GMAT_PIX_FMT_YUV420P10LE}, {"yuv420p16", GMAT_PIX_FMT_YUV420P16LE},
+                        {"p010", GMAT_PIX_FMT_P010LE}, {"p016", GMAT_PIX_FMT_P016LE}, {"yuv444p", GMAT_PIX_FMT_YUV444P}, {"rgba", GMAT_PIX_FMT_RGBA}, {"rgb24", GMAT_PIX_FMT_RGB24},
+                        {"rgba64", GMAT_PIX_FMT_RGBA64LE}, {"yuv444p16", GMAT_PIX_FMT_YUV444P16LE}};
+        static char lab[128][64];
+        int nl = 0;
+        for (const F &a : fm)
+            for (const F &b : fm) {
+                if (a.f == b.f && sw == dw && sh == dh) continue;
+                GmatSwsContext *probe = gmat_sws_getContext(sw, sh, a.f, dw, dh, b.f, GMAT_SWS_BICUBIC, nullptr);
+                if (!probe) { printf("sweep: %s -> %s: no context\n", a.n, b.n); continue; }
+                gmat_sws_freeContext(probe);
+                snprintf(lab[nl], sizeof(lab[nl]), "sweep: %-9s -> %-9s", a.n, b.n);
+                run_case(lab[nl], a.f, sw, sh, b.f, dw, dh, GMAT_SWS_BICUBIC, NF, launches, 0);
+                nl++;
+            }
+        return 0;
+    }
     for (const Case &k : cases) {
         if (strstr(k.label, "land:") && !strstr(only, "land")) continue;      // the landscape cases run on request only
         if (strstr(k.label, "any:") && !strstr(only, "any") && !(*only && strstr(k.label, only))) continue;
