@@ -1719,7 +1719,10 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     // 4:2:0 destinations: 8 bits, or (round 5) 10 bits in 16-bit stores — P010LE / YUV420P10LE: the same 15-bit lines, yuv2p010lX_c / yuv2planeX_10_c's shift
     // (round 5, last: YUV444P -> YUV444P — a format of scale_cuda's list, vf_scale_cuda.c:45-54 — is three plane jobs like any planar frame: the chroma jobs' tables and
     // sizes simply are the full-size ones; it ran the lines form's two passes at 0.12 of the roofline)
-    const bool p444 = G_BPS == 1 && p.srcFormat == GMAT_PIX_FMT_YUV444P && p.dstFormat == GMAT_PIX_FMT_YUV444P;
+    // (round 6: the other planar pairs with a 4:4:4 end — YUV444P -> YUV420P, YUV420P -> YUV444P — are three plane jobs too, the chroma jobs' source and destination
+    // sizes whatever the plan says; the format sweep found them on the lines form's two launches, 0.11-0.13 of the roofline)
+    const bool pl8s = p.srcFormat == GMAT_PIX_FMT_YUV420P || p.srcFormat == GMAT_PIX_FMT_YUV444P, pl8d = p.dstFormat == GMAT_PIX_FMT_YUV420P || p.dstFormat == GMAT_PIX_FMT_YUV444P;
+    const bool p444 = G_BPS == 1 && pl8s && pl8d && (p.srcFormat == GMAT_PIX_FMT_YUV444P || p.dstFormat == GMAT_PIX_FMT_YUV444P);
     const bool yuvOut = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_YUV420P || is_dst10(p.dstFormat) || p444;
     const bool semiDst = p.dstFormat == GMAT_PIX_FMT_NV12 || p.dstFormat == GMAT_PIX_FMT_P010LE;
 #if G_BPS == 2
@@ -1777,7 +1780,7 @@ int G_NAME(yuvg_prepare)(const ScalePlan &p, const YuvScaleTiling &g, YuvGTables
     if ((p.srcFormat == GMAT_PIX_FMT_YUV444P) != p444) return 0;
 #endif
     if (rgbOut && (g.fullChroma || g.yuvOut)) return 0;
-    if (yuvOut && g.yuvOut != (p444 ? 2 : 1)) return 0;
+    if (yuvOut && g.yuvOut != (p.dstFormat == GMAT_PIX_FMT_YUV444P ? 2 : 1)) return 0;
     if (yuvOut && semiSrc != semiDst) return 0;                           // same chroma layout on both sides
     if (p.dstW < 16 || p.dstH < 8 || p.srcW < 16 || p.srcH < 8) return 0;
     // whole dwords inside every source row (the rows are dword loads checked against the plane's exact size)

@@ -136,6 +136,23 @@ def test_walker8_planar_444_at_both_ends(dev, orc, form, geom):
         assert _run_batch(dev, orc, "yuv444p", "yuv444p", *geom, nframes=5, nstreams=1, align=256) in W8
 
 
+# ---- YUV444P -> YUV420P on the same plane jobs (round 6): the chroma jobs' source planes are the full-size ones, their destinations the halved ones -----------------------
+@pytest.mark.parametrize("geom", [(384, 216, 256, 144), (384, 216, 192, 108), (640, 128, 420, 84), (520, 100, 300, 60), (384, 216, 384, 216)], ids=lambda g: "%dx%d-%dx%d" % g)
+def test_walker8_planar_444_into_420(dev, orc, form, geom):
+    """swscale_cuda's YUV444P source into YUV420P (swscale_cuda.c:34-44): the format sweep (profiles/r06_sweep_before.txt) found it on the lines form's two launches, 0.126 of
+    the roofline; the luma job at the frame's ratio, the chroma jobs at twice it — an acceptance rule.  (Semi-planar ends and 4:2:0 -> 4:4:4, whose chroma is an UP-scale
+    beside a luma down-scale, stay where they were.)"""
+    for flags in ("bicubic", "bilinear"):
+        k = _check(dev, orc, "yuv444p", "yuv420p", geom, flags)
+        if flags == "bicubic" or geom[0] < 2 * geom[2]:             # (the chroma jobs run at twice the frame's ratio: from 4 : 1 on the short filters' 64 columns do not fit one dword a lane — the lines form)
+            assert k in W8, (flags, k)
+    assert _check(dev, orc, "yuv444p", "yuv420p", geom, "lanczos") is not None
+    assert _check(dev, orc, "yuv444p", "yuv420p", geom, align=4, src_align=4) in W8
+    assert _run_batch(dev, orc, "yuv444p", "yuv420p", *geom, nframes=5, nstreams=1, align=256) in W8
+    for other in (("yuv420p", "yuv444p"), ("yuv444p", "nv12"), ("nv12", "yuv444p")):           # bit-exact wherever they land
+        assert _check(dev, orc, other[0], other[1], geom) is not None
+
+
 # ---- packed RGB sources into 4:2:0 frames: the walker's own converter in front of the same 16-bit lines (round 5) -----------------------------------
 RGBSRC_GEOMS = [(384, 216, 256, 144), (768, 96, 256, 32), (384, 216, 160, 90), (640, 128, 420, 84), (1024, 64, 256, 16), (520, 100, 172, 40), (2048, 40, 700, 16),
                 (384, 216, 380, 212)]
