@@ -190,6 +190,9 @@ struct GmatSwsContext {
     mutable int shift8Ident = -1;     // shift8_shortcut's answer about the active plan's four banks (-1: not asked since the plan was last built)
     S19Tables s19;                    // (round 6) 16-bit YUV destinations in one launch, the lines of a tile in LDS (k_scale19.hip); s19.ok = 0: the two passes
     DevBuf dS19[6];                   // its tables: per job the tile columns' first bytes, the tile rows' first source rows and their counts
+    S19Tables t15;                    // (round 6) the same tile kernel on the 15-bit lines (8- and 10-bit YUV destinations): the pairs no walker serves — a layout change, a 4:4:4 end
+    DevBuf dT15[6];
+    bool t15Mixed = false;            // ... semi-planar <-> planar, or 4:4:4 at one end: in front of the lines form below 4 : 1
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
@@ -224,6 +227,7 @@ struct GmatSwsContext {
 // sources of the single-context plane scaler: 8-bit planar / semi-planar YUV and the 16-bit semi-planar P010LE / P016LE
 static inline bool is_plane_src(int f) { return is_yuv8_src(f) || is_p01x(f) || pl16_depth(f); }
 
+static int scale16_kind(int srcFormat);
 static int init_yuv_scaler(GmatSwsContext *c)
 {
     if (c->yuvReady) return 0;
@@ -354,6 +358,35 @@ static int init_yuv_scaler(GmatSwsContext *c)
         if ((r = c->dHCreg.upload(c->y2x.hCreg.data(), c->y2x.hCreg.size() * 4)) < 0) return r;
         if ((r = c->dVrec.upload(c->y2x.vrec.data(), c->y2x.vrec.size() * 4)) < 0) return r;
         if ((r = c->dVrecC.upload(c->y2x.vrecC.data(), c->y2x.vrecC.size() * 4)) < 0) return r;
+    }
+    // (round 6) the tile kernel of k_scale19.hip on the 15-bit lines: any plane layout and depth in, 8- or 10-bit YUV out (kPlaneKernels: behind every walker, in front
+    // of the tiled catch-all; in front of the lines form where the layouts differ and the ratio is below 4 : 1).  GMAT_T15=0: never
+    c->t15.ok = 0; c->t15Mixed = false;
+    {
+        const char *k15 = GMAT_KNOB("GMAT_T15");
+        const bool yuvDst = is_yuv8_src(c->dstFormat) || is_dst10(c->dstFormat);
+        if (!(k15 && atoi(k15) == 0) && !c->rgbViaPlanes && yuvDst && is_plane_src(c->srcFormat) && !is_priv_planes(c->srcFormat)) {
+            const bool srcSemi = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat);
+            const bool src444 = c->srcFormat == GMAT_PIX_FMT_YUV444P || c->srcFormat == GMAT_PIX_FMT_YUV444P16LE, dst444 = c->dstFormat == GMAT_PIX_FMT_YUV444P;
+            r = s19_prepare(c->planYuv, t.vLumEff, t.vChrEff, a.src16 ? 2 : 1, scale16_kind(c->srcFormat), srcSemi ? 1 : 0, a.dstNv12 ? 1 : 0, 0, 0, c->t15,
+                            a.dst16 ? 2 : 1, a.dstShift, a.src16 ? a.hShift : 7);
+            if (r < 0 && r != GMAT_ERR(ENOSYS) && r != GMAT_ERR(EINVAL)) return r;
+            // (measured, profiles/r06_sweep_tile15.txt: an 8-bit source whose two jobs need different pair counts — YUV444P into 4:2:0: four luma pairs, seven at the chroma's
+            // 3 : 1 — runs the larger instance for both and loses to the tiled kernel, 11.3 against 7.7 us a frame; 16-bit sources win either way)
+            auto np_of = [](int pairs) { return pairs <= 4 ? 4 : pairs <= 8 ? 8 : 0; };
+            if (c->t15.ok && !a.src16 && np_of(c->planYuv.hLum.pairs) != np_of(c->planYuv.hChr.pairs)) c->t15.ok = 0;
+            if (c->t15.ok) {
+                for (int j = 0; j < 2; j++) {
+                    S19Job &J = c->t15.job[j];
+                    if ((r = c->dT15[3 * j].upload(c->t15.colStart[j].data(), c->t15.colStart[j].size() * 4)) < 0) return r;
+                    if ((r = c->dT15[3 * j + 1].upload(c->t15.rowStart[j].data(), c->t15.rowStart[j].size() * 4)) < 0) return r;
+                    if ((r = c->dT15[3 * j + 2].upload(c->t15.rowCount[j].data(), c->t15.rowCount[j].size() * 4)) < 0) return r;
+                    J.colStart = (const int32_t *)c->dT15[3 * j].p; J.rowStart = (const int32_t *)c->dT15[3 * j + 1].p; J.rowCount = (const int32_t *)c->dT15[3 * j + 2].p;
+                    J.h = j ? a.hChr : a.hLum; J.v = j ? a.vChr : a.vLum;
+                }
+                c->t15Mixed = (srcSemi != (a.dstNv12 != 0)) || src444 || dst444;
+            }
+        }
     }
     c->yuvReady = true;
     return 0;
@@ -1058,6 +1091,27 @@ static YuvLArgs make_yuvl_args(const GmatSwsContext *c, const YuvScaleArgs &ya)
     return l;
 }
 
+// the tile kernel on the 15-bit lines: n frames of the context's geometry (kPlaneKernels)
+static int launch_tile15(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n)
+{
+    const bool semiS = c->srcFormat == GMAT_PIX_FMT_NV12 || is_p01x(c->srcFormat), semiD = ya.dstNv12 != 0;
+    S19Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.job[0] = c->t15.job[0]; a.job[1] = c->t15.job[1];
+    a.job[0].rawStride[0] = ya.ys; a.job[1].rawStride[0] = ya.us; a.job[1].rawStride[1] = semiS ? 0 : ya.vs;
+    a.job[0].ds[0] = ya.ds; a.job[1].ds[0] = ya.dsU; a.job[1].ds[1] = semiD ? ya.dsU : ya.dsV;
+    a.job[0].rc = ya.rangeConv ? 4 + ya.rangeConv : 0; a.job[1].rc = ya.rangeConv ? 6 + ya.rangeConv : 0;     // (s19_range: 5 / 6 luma to / from full range, 7 / 8 chroma)
+    a.job[0].dither8 = a.job[1].dither8 = ya.dither8;
+    uintptr_t sA = (uintptr_t)ya.ys | (uintptr_t)ya.us | (semiS ? 0 : (uintptr_t)ya.vs), dA = (uintptr_t)ya.ds | (uintptr_t)ya.dsU | (semiD ? 0 : (uintptr_t)ya.dsV);
+    for (int i = 0; i < n; i++) {
+        sA |= (uintptr_t)fr.y[i] | (uintptr_t)fr.u[i] | (semiS ? 0 : (uintptr_t)fr.v[i]);
+        dA |= (uintptr_t)fr.dst[i] | (uintptr_t)fr.dstU[i] | (semiD ? 0 : (uintptr_t)fr.dstV[i]);
+    }
+    if ((ya.src16 && (sA & 1)) || (ya.dst16 && (dA & 1))) return GMAT_ERR(EINVAL);        // 16-bit samples sit on even addresses
+    a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
+    return launch_scale19(a, c->t15.np, c->t15.ldsBytes, st, &fr, n);
+}
+
 struct PlaneKernel {
     bool (*eligible)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);      // n: frames of the whole call
     const char *(*name)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);
@@ -1134,6 +1188,14 @@ static const PlaneKernel kPlaneKernels[] = {
          return yuvg_block_form(make_yuvg_args(c, ya), n) ? "scale_yuvg_blk_kernel" : "scale_yuvg_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
          return c->gargs.src16 ? launch_scale_yuvg16(make_yuvg_args(c, ya), st, &fr, n) : launch_scale_yuvg(make_yuvg_args(c, ya), st, &fr, n); }},
+    // (round 6) the tile kernel on the 15-bit lines where the two ends' plane layouts differ (semi-planar <-> planar, a 4:4:4 end) below 4 : 1: in front of the lines form's
+    // two launches (profiles/r06_sweep_*.txt: 6.7-9.1 us a 1080p -> 720p frame there, 8-12 on the tiled kernel behind it)
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) {
+         // (8-bit ends keep the lines form: 6.7 against 7.8-11 us a 1080p -> 720p frame batched, profiles/r06_sweep_tile15.txt; the deep ones — 16-bit samples in, 10-bit out,
+         // the dithered 8-bit output — ran its untuned 16-bit pass or fell through to the tiled kernel)
+         return c->t15.ok && c->t15Mixed && !ya.prof && (ya.src16 || ya.dst16 || ya.dither8) && c->srcW < 4 * c->dstW && c->srcH < 4 * c->dstH; },
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale19_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_tile15(c, ya, st, fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvl_eligible(c, ya, n); },                                    // what no walker takes: the lines form
      [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return ya.src16 ? "scale_yuvl_h16_kernel+scale_yuvl_v_kernel" : "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
@@ -1149,6 +1211,9 @@ static const PlaneKernel kPlaneKernels[] = {
              return launch_scale_yuvl(make_yuvl_args(c, ya2), st, &fr2, n);
          }
          return launch_scale_yuvl(make_yuvl_args(c, ya), st, &fr, n); }},
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return c->t15.ok && !ya.prof; },       // ... and in front of the tiled catch-all wherever it has a plan
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale19_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_tile15(c, ya, st, fr, n); }},
     {[](const GmatSwsContext *, const YuvScaleArgs &, int) { return true; },      // everything else: the tiled plane scaler
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) {
@@ -1156,6 +1221,8 @@ static const PlaneKernel kPlaneKernels[] = {
          return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
 };
 constexpr int kNumPlaneKernels = (int)(sizeof(kPlaneKernels) / sizeof(kPlaneKernels[0]));
+// the two records of the tile kernel on the 15-bit lines (launch_tile15): the second and the fourth from the end
+static bool plane_record_is_tile(int k) { return k == kNumPlaneKernels - 2 || k == kNumPlaneKernels - 4; }
 
 // argument block of the strip-walking packed-RGB scaler
 static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)
@@ -1302,8 +1369,10 @@ static bool cross_layout_cascade(GmatSwsContext *c, const YuvScaleArgs &ya, int 
     if (!is_yuv420(c->srcFormat) || !is_yuv420(c->dstFormat) || c->srcFormat == c->dstFormat || c->prof) return false;
     const char *off = GMAT_KNOB("GMAT_NO_CROSS_CASCADE");
     if (off && atoi(off)) return false;
+    // (the tile kernel's two records stand in front of the tiled catch-all since round 6: the cascade — a walker in the source's layout, then a copy — keeps the
+    // frames it had, the ones whose pick is the catch-all once those two are set aside)
     int pick = 0;
-    while (!kPlaneKernels[pick].eligible(c, ya, n)) pick++;
+    while (plane_record_is_tile(pick) || !kPlaneKernels[pick].eligible(c, ya, n)) pick++;
     if (pick != kNumPlaneKernels - 1) return false;              // a walker of this context's own takes the frame (2:1)
     const bool dnv = c->dstFormat == GMAT_PIX_FMT_NV12;
     return yuv420_relayout_takes(!dnv, nullptr, 256, nullptr, 256, nullptr, dnv ? 256 : 0, ya.dst, ya.ds, ya.dstU, ya.dsU, dnv ? nullptr : ya.dstV, dnv ? 0 : ya.dsV);
@@ -1735,7 +1804,9 @@ static int sws_scale_frames_batched_impl(GmatSwsContext *c, int n, const uint8_t
     }
     int pick = 0;
     while (!can[pick]) pick++;                         // (the last record takes everything)
-    if (pick == kNumPlaneKernels - 1 && cross_layout_cascade(c, ya0, n)) {
+    int pickNoTile = 0;
+    while (plane_record_is_tile(pickNoTile) || !can[pickNoTile]) pickNoTile++;
+    if (pickNoTile == kNumPlaneKernels - 1 && cross_layout_cascade(c, ya0, n)) {
         // NV12 <-> YUV420P scaled (gmat_sws_scale's rule), every frame's destination movable by the re-layout kernel: the sibling context's own
         // batch into crossBuf, then one re-layout launch per 32 frames
         bool all = true;

@@ -47,6 +47,11 @@ __device__ __forceinline__ int s19_range(int v, int rc)
     else if (rc == 2) v = (int)((unsigned)v * (unsigned)(14071 / 4) + (unsigned)((33561947 << 4) / 4)) >> 12;
     else if (rc == 3) v = (int)((unsigned)min(v, 30775 << 4) * 4663u - (unsigned)(9289992 << 4)) >> 12;
     else if (rc == 4) v = (int)((unsigned)v * 1799u + (unsigned)(4081085 << 4)) >> 11;
+    // the 15-bit lines' forms (lum / chrRange{To,From}Jpeg_c, swscale.c:157-188, as scale_yuv_kernel states them)
+    else if (rc == 5) v = (__mul24(min(v, 30189), 19077) - 39057361) >> 14;
+    else if (rc == 6) v = (__mul24(v, 14071) + 33561947) >> 14;
+    else if (rc == 7) v = (__mul24(min(v, 30775), 4663) - 9289992) >> 12;
+    else if (rc == 8) v = (__mul24(v, 1799) + 4081085) >> 11;
     return v;
 }
 
@@ -78,6 +83,15 @@ __device__ __forceinline__ void s19_pairs(const unsigned *v, unsigned xorv, bool
         a0 ^= xorv; a1 ^= xorv; b0 ^= xorv; b1 ^= xorv;
     }
 }
+
+// acc + a b on 24-bit operands as ONE v_mad_i32_i24 (the low 32 bits of the product: the wrap-around 32-bit multiply-add for a 19-bit line and a 13-bit
+// coefficient).  Written as `acc += __mul24(..) + __mul24(..)` the compiler makes two v_mul_i32_i24 and a v_add3_u32 of a tap pair — 12 instructions a pair and
+// column quad where 8 do (profiles/r06_scale19_history.txt r06r)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ unsigned s19_mad(int a, int b, unsigned acc) { unsigned r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc)); return r; }
+#else
+__device__ __forceinline__ unsigned s19_mad(int a, int b, unsigned acc) { return acc + (unsigned)__mul24(a, b); }      // (the emulator, and hipcc's host pass)
+#endif
 
 // Staging: rows [0, gn) of one source row image -> staged rows.  sp: the image's row r0 + g0; B0: byte offset of the tile's first staged
 // sample group; out0 / out1: the staged rows of the component(s) the image carries, PP dwords a row; nunit units a row.
@@ -256,6 +270,7 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
     const bool xin = lane < J.TW && x < J.dstW;
     const int q0 = xin ? (J.h.pos_even[x] - c0) >> 1 : 0;
     const int32_t *cfg = J.h.packed + (size_t)(xin ? x : 0) * hp;
+    // (ONE number of register pairs a launch — the larger job's: per-job instances inside one kernel were tried, r06s: 102 VGPRs against 74, every case 10-20 % slower)
     int cf[NP > 0 ? NP : 1];
 #pragma unroll
     for (int k = 0; k < (NP > 0 ? NP : 1); k++) cf[k] = (NP > 0 && xin && k < hp) ? cfg[k] : 0;
@@ -273,9 +288,11 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
         const int nrow = min(J.TH, J.dstH - y0);
         for (int i = tid; i < nrow * vp; i += 256) {
             const int c = J.v.packed[(size_t)y0 * vp + i];
-            vtab[J.TH + 2 * i] = (int)(short)(c & 0xFFFF); vtab[J.TH + 2 * i + 1] = c >> 16;
+            vtab[2 * J.TH + 2 * i] = (int)(short)(c & 0xFFFF); vtab[2 * J.TH + 2 * i + 1] = c >> 16;
         }
-        if (tid < nrow) vtab[tid] = J.v.pos_even[y0 + tid];
+        // a row's window start and its sums' start value: yuv2planeX_16_c's constant, or (15-bit lines) the bank's own — the dither of
+        // yuv2planeX_8_c << 12, 2^16 for the 10-bit writers, the one- and two-tap forms' (YuvScaleTiling::lumRound / chrRound)
+        if (tid < nrow) { vtab[tid] = J.v.pos_even[y0 + tid]; vtab[J.TH + tid] = J.outMode ? J.v.round[y0 + tid] : (int)((1u << 14) - 0x40000000u); }
     }
 
     for (int g0 = 0; g0 < nr; g0 += J.G) {
@@ -317,44 +334,63 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
     __syncthreads();
 }
 
-// pass V of a YUV destination's job: the tile's output rows from its lines
+// pass V of a YUV destination's job: the tile's output rows from its lines.  outMode 0: 16-bit samples (yuv2planeX_16_c / yuv2nv12cX_16_c); the 15-bit
+// lines' writers (round 6, second half: the pairs no walker serves — planar <-> semi-planar with a deep end, 4 : 4 : 4 <-> 4 : 2 : 0): 1: 8-bit samples,
+// clip_u8((start + sum + dither) >> 19) — yuv2planeX_8_c / yuv2nv12cX_c, the dither of a deep source ff_dither_8x8_128 by (x, y), the V plane's three columns on
+// (output.c:400-450, vscale.c:98-101) —, 2: 10-bit samples in 16-bit stores, clip_uintp2((start + sum) >> 17, 10) << outShift (yuv2planeX_10_c; P010: << 6,
+// yuv2p010lX_c / cX_c, output.c:459-519)
 __device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *dst0, uint8_t *dst1, int tx, int ty,
                                            const int32_t *vtab, const int32_t *lines)
 {
     const S19Job &J = a.job[jx];
     const int tid = threadIdx.x;
     const int x0 = tx * J.TW, y0 = ty * J.TH, r0 = J.rowStart[ty], vp = J.v.pairs;
-    // pass V.  The rows of `lines` from nr on (a window's padded taps past the plane) hold whatever the LDS held: their coefficients are zero
-    // and v_mul_i32_i24 of anything by zero is zero.
+    // The rows of `lines` from nr on (a window's padded taps past the plane) hold whatever the LDS held: their coefficients are zero
+    // and v_mad_i32_i24 of anything by zero adds zero.
     const int yEnd = min(y0 + J.TH, J.dstH);
-    const unsigned k0 = (1u << 14) - 0x40000000u;
-    auto out16 = [](unsigned acc) -> unsigned { return (unsigned)(min(max((int)acc >> 15, -32768), 32767) + 0x8000); };
+    const int mode = J.outMode, osh = J.outShift, dith = J.dither8;
+    // one sample from its sum; (xx, yy): its place in the plane (the dither's), vplane: the V plane's three columns
+    auto outv = [&](unsigned acc, int xx, int yy, int vplane) -> unsigned {
+        if (mode == 0) return (unsigned)(min(max((int)acc >> 15, -32768), 32767) + 0x8000);
+        if (mode == 2) return (unsigned)min(max((int)acc >> 17, 0), 1023) << osh;
+        int v = (int)acc;
+        if (dith) v += dither_delta(xx + 3 * vplane, yy);
+        return (unsigned)clip_u8_shr(v, 19);
+    };
     if (J.ileave) {
-        // a thread: columns (2 cp, 2 cp + 1) of both chroma planes, 32 pairs a row, 8 rows a step; (U, V) dwords stored
+        // a thread: columns (2 cp, 2 cp + 1) of both chroma planes, 32 pairs a row, 8 rows a step; (U, V) pairs stored
         const int cp = tid & 31, xo = x0 + 2 * cp;
         if (xo < J.dstW)
             for (int y = y0 + (tid >> 5); y < yEnd; y += 8) {
                 const int32_t *la = lines + (size_t)(vtab[y - y0] - r0) * kS19TW + 2 * cp, *lb = la + (size_t)J.nrLines * kS19TW;
-                const int32_t *vc = vtab + J.TH + (y - y0) * 2 * vp;
+                const int32_t *vc = vtab + 2 * J.TH + (y - y0) * 2 * vp;
+                const unsigned k0 = (unsigned)vtab[J.TH + (y - y0)];
                 unsigned u0 = k0, u1 = k0, v0 = k0, v1 = k0;
 #pragma unroll 2
                 for (int k = 0; k < (S19_PROBE == 3 ? 0 : vp); k++) {
                     const int2 cc = *reinterpret_cast<const int2 *>(vc + 2 * k);
                     const int2 a0 = *reinterpret_cast<const int2 *>(la + (2 * k) * kS19TW), a1 = *reinterpret_cast<const int2 *>(la + (2 * k + 1) * kS19TW);
                     const int2 b0 = *reinterpret_cast<const int2 *>(lb + (2 * k) * kS19TW), b1 = *reinterpret_cast<const int2 *>(lb + (2 * k + 1) * kS19TW);
-                    u0 += (unsigned)__mul24(a0.x, cc.x) + (unsigned)__mul24(a1.x, cc.y); u1 += (unsigned)__mul24(a0.y, cc.x) + (unsigned)__mul24(a1.y, cc.y);
-                    v0 += (unsigned)__mul24(b0.x, cc.x) + (unsigned)__mul24(b1.x, cc.y); v1 += (unsigned)__mul24(b0.y, cc.x) + (unsigned)__mul24(b1.y, cc.y);
+                    u0 = s19_mad(a1.x, cc.y, s19_mad(a0.x, cc.x, u0)); u1 = s19_mad(a1.y, cc.y, s19_mad(a0.y, cc.x, u1));
+                    v0 = s19_mad(b1.x, cc.y, s19_mad(b0.x, cc.x, v0)); v1 = s19_mad(b1.y, cc.y, s19_mad(b0.y, cc.x, v1));
                 }
-                const unsigned d0 = out16(u0) | out16(v0) << 16, d1 = out16(u1) | out16(v1) << 16;
-                uint8_t *d = dst0 + J.dstOff[0] + (size_t)y * J.ds[0] + 4 * (size_t)xo;
+                const unsigned pu0 = outv(u0, xo, y, 0), pv0 = outv(v0, xo, y, 1), pu1 = outv(u1, xo + 1, y, 0), pv1 = outv(v1, xo + 1, y, 1);
                 const bool two = xo + 1 < J.dstW;
-                if (a.dstAl4) {
-                    reinterpret_cast<unsigned *>(d)[0] = d0;
-                    if (two) reinterpret_cast<unsigned *>(d)[1] = d1;
+                if (mode == 1) {
+                    uint8_t *d = dst0 + J.dstOff[0] + (size_t)y * J.ds[0] + 2 * (size_t)xo;
+                    if (a.dstAl4 && two) *reinterpret_cast<unsigned *>(d) = pu0 | pv0 << 8 | pu1 << 16 | pv1 << 24;
+                    else { d[0] = (uint8_t)pu0; d[1] = (uint8_t)pv0; if (two) { d[2] = (uint8_t)pu1; d[3] = (uint8_t)pv1; } }
                 } else {
-                    unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
-                    d16[0] = (unsigned short)d0; d16[1] = (unsigned short)(d0 >> 16);
-                    if (two) { d16[2] = (unsigned short)d1; d16[3] = (unsigned short)(d1 >> 16); }
+                    const unsigned d0 = pu0 | pv0 << 16, d1 = pu1 | pv1 << 16;
+                    uint8_t *d = dst0 + J.dstOff[0] + (size_t)y * J.ds[0] + 4 * (size_t)xo;
+                    if (a.dstAl4) {
+                        reinterpret_cast<unsigned *>(d)[0] = d0;
+                        if (two) reinterpret_cast<unsigned *>(d)[1] = d1;
+                    } else {
+                        unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+                        d16[0] = (unsigned short)d0; d16[1] = (unsigned short)(d0 >> 16);
+                        if (two) { d16[2] = (unsigned short)d1; d16[3] = (unsigned short)(d1 >> 16); }
+                    }
                 }
             }
     } else {
@@ -362,8 +398,9 @@ __device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *ds
         const int q = tid & 15, xo = x0 + 4 * q;
         if (xo < J.dstW)
             for (int y = y0 + (tid >> 4); y < yEnd; y += 16) {
-                const int32_t *vc = vtab + J.TH + (y - y0) * 2 * vp;
+                const int32_t *vc = vtab + 2 * J.TH + (y - y0) * 2 * vp;
                 const int p0 = vtab[y - y0] - r0;
+                const unsigned k0 = (unsigned)vtab[J.TH + (y - y0)];
                 for (int c = 0; c < J.ncomp; c++) {
                     const int32_t *la = lines + (size_t)(c * J.nrLines + p0) * kS19TW + 4 * q;
                     unsigned o0 = k0, o1 = k0, o2 = k0, o3 = k0;
@@ -371,19 +408,26 @@ __device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *ds
                     for (int k = 0; k < (S19_PROBE == 3 ? 0 : vp); k++) {
                         const int2 cc = *reinterpret_cast<const int2 *>(vc + 2 * k);
                         const int4 a0 = *reinterpret_cast<const int4 *>(la + (2 * k) * kS19TW), a1 = *reinterpret_cast<const int4 *>(la + (2 * k + 1) * kS19TW);
-                        o0 += (unsigned)__mul24(a0.x, cc.x) + (unsigned)__mul24(a1.x, cc.y); o1 += (unsigned)__mul24(a0.y, cc.x) + (unsigned)__mul24(a1.y, cc.y);
-                        o2 += (unsigned)__mul24(a0.z, cc.x) + (unsigned)__mul24(a1.z, cc.y); o3 += (unsigned)__mul24(a0.w, cc.x) + (unsigned)__mul24(a1.w, cc.y);
+                        o0 = s19_mad(a1.x, cc.y, s19_mad(a0.x, cc.x, o0)); o1 = s19_mad(a1.y, cc.y, s19_mad(a0.y, cc.x, o1));
+                        o2 = s19_mad(a1.z, cc.y, s19_mad(a0.z, cc.x, o2)); o3 = s19_mad(a1.w, cc.y, s19_mad(a0.w, cc.x, o3));
                     }
-                    const unsigned d0 = out16(o0) | out16(o1) << 16, d1 = out16(o2) | out16(o3) << 16;
-                    uint8_t *d = (c ? dst1 : dst0) + J.dstOff[c] + (size_t)y * J.ds[c] + 2 * (size_t)xo;
+                    const unsigned w0 = outv(o0, xo, y, c), w1 = outv(o1, xo + 1, y, c), w2 = outv(o2, xo + 2, y, c), w3 = outv(o3, xo + 3, y, c);
                     const int n = min(4, J.dstW - xo);
-                    if (a.dstAl4 && n == 4) { reinterpret_cast<unsigned *>(d)[0] = d0; reinterpret_cast<unsigned *>(d)[1] = d1; }
-                    else {
-                        unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
-                        d16[0] = (unsigned short)d0;
-                        if (n > 1) d16[1] = (unsigned short)(d0 >> 16);
-                        if (n > 2) d16[2] = (unsigned short)d1;
-                        if (n > 3) d16[3] = (unsigned short)(d1 >> 16);
+                    if (mode == 1) {
+                        uint8_t *d = (c ? dst1 : dst0) + J.dstOff[c] + (size_t)y * J.ds[c] + (size_t)xo;
+                        if (a.dstAl4 && n == 4) *reinterpret_cast<unsigned *>(d) = w0 | w1 << 8 | w2 << 16 | w3 << 24;
+                        else { d[0] = (uint8_t)w0; if (n > 1) d[1] = (uint8_t)w1; if (n > 2) d[2] = (uint8_t)w2; if (n > 3) d[3] = (uint8_t)w3; }
+                    } else {
+                        const unsigned d0 = w0 | w1 << 16, d1 = w2 | w3 << 16;
+                        uint8_t *d = (c ? dst1 : dst0) + J.dstOff[c] + (size_t)y * J.ds[c] + 2 * (size_t)xo;
+                        if (a.dstAl4 && n == 4) { reinterpret_cast<unsigned *>(d)[0] = d0; reinterpret_cast<unsigned *>(d)[1] = d1; }
+                        else {
+                            unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+                            d16[0] = (unsigned short)d0;
+                            if (n > 1) d16[1] = (unsigned short)(d0 >> 16);
+                            if (n > 2) d16[2] = (unsigned short)d1;
+                            if (n > 3) d16[3] = (unsigned short)(d1 >> 16);
+                        }
                     }
                 }
             }
@@ -410,20 +454,20 @@ __device__ __forceinline__ void s19_rgb64(const S19Args &a, uint8_t *dst0, int t
     for (int y = y0 + (tid >> 5); y < yEnd; y += 8) {
         const int32_t *ly = linesY + (vtL[y - y0] - r0L) * kS19TW + 2 * cp;
         const int32_t *lu = linesC + (vtC[y - y0] - r0C) * kS19TW + cx, *lv = lu + C.nrLines * kS19TW;
-        const int32_t *cl = vtL + L.TH + (y - y0) * 2 * vpL, *cc = vtC + C.TH + (y - y0) * 2 * vpC;
+        const int32_t *cl = vtL + 2 * L.TH + (y - y0) * 2 * vpL, *cc = vtC + 2 * C.TH + (y - y0) * 2 * vpC;
         unsigned ay0 = (unsigned)-0x40000000, ay1 = ay0, au0 = (unsigned)-(128 << 23), au1 = au0, av0 = au0, av1 = au0;
 #pragma unroll 2
         for (int t = 0; t < vpL; t++) {
             const int2 c2 = *reinterpret_cast<const int2 *>(cl + 2 * t);
             const int2 p0 = *reinterpret_cast<const int2 *>(ly + (2 * t) * kS19TW), p1 = *reinterpret_cast<const int2 *>(ly + (2 * t + 1) * kS19TW);
-            ay0 += (unsigned)__mul24(p0.x, c2.x) + (unsigned)__mul24(p1.x, c2.y); ay1 += (unsigned)__mul24(p0.y, c2.x) + (unsigned)__mul24(p1.y, c2.y);
+            ay0 = s19_mad(p1.x, c2.y, s19_mad(p0.x, c2.x, ay0)); ay1 = s19_mad(p1.y, c2.y, s19_mad(p0.y, c2.x, ay1));
         }
         if (cs) {
 #pragma unroll 2
             for (int t = 0; t < vpC; t++) {
                 const int2 c2 = *reinterpret_cast<const int2 *>(cc + 2 * t);
-                au0 += (unsigned)__mul24(lu[(2 * t) * kS19TW], c2.x) + (unsigned)__mul24(lu[(2 * t + 1) * kS19TW], c2.y);
-                av0 += (unsigned)__mul24(lv[(2 * t) * kS19TW], c2.x) + (unsigned)__mul24(lv[(2 * t + 1) * kS19TW], c2.y);
+                au0 = s19_mad(lu[(2 * t + 1) * kS19TW], c2.y, s19_mad(lu[(2 * t) * kS19TW], c2.x, au0));
+                av0 = s19_mad(lv[(2 * t + 1) * kS19TW], c2.y, s19_mad(lv[(2 * t) * kS19TW], c2.x, av0));
             }
             au1 = au0; av1 = av0;
         } else {
@@ -432,8 +476,8 @@ __device__ __forceinline__ void s19_rgb64(const S19Args &a, uint8_t *dst0, int t
                 const int2 c2 = *reinterpret_cast<const int2 *>(cc + 2 * t);
                 const int2 u0 = *reinterpret_cast<const int2 *>(lu + (2 * t) * kS19TW), u1 = *reinterpret_cast<const int2 *>(lu + (2 * t + 1) * kS19TW);
                 const int2 v0 = *reinterpret_cast<const int2 *>(lv + (2 * t) * kS19TW), v1 = *reinterpret_cast<const int2 *>(lv + (2 * t + 1) * kS19TW);
-                au0 += (unsigned)__mul24(u0.x, c2.x) + (unsigned)__mul24(u1.x, c2.y); au1 += (unsigned)__mul24(u0.y, c2.x) + (unsigned)__mul24(u1.y, c2.y);
-                av0 += (unsigned)__mul24(v0.x, c2.x) + (unsigned)__mul24(v1.x, c2.y); av1 += (unsigned)__mul24(v0.y, c2.x) + (unsigned)__mul24(v1.y, c2.y);
+                au0 = s19_mad(u1.x, c2.y, s19_mad(u0.x, c2.x, au0)); au1 = s19_mad(u1.y, c2.y, s19_mad(u0.y, c2.x, au1));
+                av0 = s19_mad(v1.x, c2.y, s19_mad(v0.x, c2.x, av0)); av1 = s19_mad(v1.y, c2.y, s19_mad(v0.y, c2.x, av1));
             }
         }
         auto pixel = [&](unsigned ay, unsigned au, unsigned av, unsigned &lo, unsigned &hi) {
@@ -593,7 +637,7 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
         std::vector<int32_t> rs, rc;
         int nrMax, nrLines;
         plan_rows(v, srcH, dstH, TH, rs, rc, nrMax, nrLines);
-        const long linesBytes = (long)ncomp * nrLines * kS19TW * 4, vtBytes = ((long)TH * (2 * v.pairs + 1) * 4 + 15) & ~15L;
+        const long linesBytes = (long)ncomp * nrLines * kS19TW * 4, vtBytes = ((long)TH * (2 * v.pairs + 2) * 4 + 15) & ~15L;
         const int G = plan_group(J, ncomp, nrMax, gcap, budget);
         if (G < 1) { if (TH == 1) return GMAT_ERR(ENOSYS); continue; }
         const long total = vtBytes + (long)G * ncomp * J.PP * 4 + linesBytes;
@@ -610,14 +654,16 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
 
 // rgb64: 0 a YUV destination (two jobs of their own tiles); 1 RGBA64LE, 2 BGRA64LE (one grid of 64-column tiles: the luma job's lines, then the chroma job's —
 // 64 >> chrShift columns — behind the same staged-row LDS, then the colour stage); chrShift: 1 = one chroma sample a pixel pair (ignored for YUV destinations)
-int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t)
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
+                int outMode, int outShift, int hsh)
 {
     t.ok = 0;
     // (measured: DESIGN 4.8) LDS a block may take, output rows a tile at most
     const char *ks = GMAT_KNOB("GMAT_S19_LDS"), *kr = GMAT_KNOB("GMAT_S19_ROWS");
     const int budget = ks ? std::min(std::max(atoi(ks), 4096), 65536) : 32768;
     const int thCap = kr ? std::max(1, atoi(kr)) : 64;
-    const int sh = kind == 0 ? 3 : kind % 100 - 5;                                // hScale8To19_c: 3; hScale16To19_c: depth - 5 (kind 14: 9)
+    // hScale8To19_c: 3; hScale16To19_c: depth - 5 (kind 14: 9); the 15-bit lines (outMode != 0): hScale8To15_c's 7 / hScale16To15_c's depth - 1, the caller's
+    const int sh = outMode ? hsh : kind == 0 ? 3 : kind % 100 - 5;
     const unsigned xorv = (bps == 2 && kind != 10) ? 0x80008000u : 0u;            // 16-bit samples as v_dot2_i32_i16 takes them (P010's ten bits fit as they are)
     S19Job &L = t.job[0], &C = t.job[1];
     std::memset(&L, 0, sizeof(L)); std::memset(&C, 0, sizeof(C));
@@ -626,16 +672,17 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
     L.kind = kind; L.xorv = xorv; L.rowBytes = p.srcW * bps;
     L.srcW = p.srcW; L.srcH = p.srcH; L.dstW = p.dstW; L.dstH = p.dstH;
     L.dstSel[0] = 0; L.dstOff[0] = 0;
-    L.sh = sh; L.maxv = (1 << 19) - 1;
+    L.sh = sh; L.maxv = outMode ? 32767 : (1 << 19) - 1; L.outMode = outMode; L.outShift = outShift;
     C.ncomp = 2; C.nraw = srcSemi ? 1 : 2; C.ileave = dstSemi ? 1 : 0; C.layout = (bps == 2 ? 2 : 0) + (srcSemi ? 1 : 0);
     C.rawSel[0] = 1; C.rawSel[1] = 2;
     C.kind = kind; C.xorv = xorv; C.rowBytes = p.chrSrcW * bps * (srcSemi ? 2 : 1);
     C.srcW = p.chrSrcW; C.srcH = p.chrSrcH; C.dstW = p.chrDstW; C.dstH = p.chrDstH;
     C.dstSel[0] = 1; C.dstSel[1] = dstSemi ? 1 : 2;
-    C.dstOff[0] = 0; C.dstOff[1] = dstSemi ? 2 : 0;
-    C.sh = sh; C.maxv = (1 << 19) - 1;
+    C.dstOff[0] = 0; C.dstOff[1] = dstSemi ? (outMode == 1 ? 1 : 2) : 0;
+    C.sh = sh; C.maxv = outMode ? 32767 : (1 << 19) - 1; C.outMode = outMode; C.outShift = outShift;
     const int hp = std::max(p.hLum.pairs, p.hChr.pairs);
     t.np = hp <= 4 ? 4 : hp <= 8 ? 8 : 0;
+    L.np = C.np = t.np;
     const int hpL = t.np ? t.np : p.hLum.pairs, hpC = t.np ? t.np : p.hChr.pairs;
     t.rgb64 = rgb64; t.chrShift = chrShift; t.linesOff = 0;
     if (!rgb64) {
@@ -665,7 +712,7 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
             plan_rows(vc, p.chrSrcH, p.dstH, TH, rsC, rcC, nrC, nlC);
             const int GL = plan_group(L, 1, nrL, gcapL, budget), GC = plan_group(C, 2, nrC, gcapC, budget);
             if (GL < 1 || GC < 1) { if (TH == 1) return GMAT_ERR(ENOSYS); continue; }
-            const long vtL = ((long)TH * (2 * vl.pairs + 1) * 4 + 15) & ~15L, vtC = ((long)TH * (2 * vc.pairs + 1) * 4 + 15) & ~15L;
+            const long vtL = ((long)TH * (2 * vl.pairs + 2) * 4 + 15) & ~15L, vtC = ((long)TH * (2 * vc.pairs + 2) * 4 + 15) & ~15L;
             const long rawB = std::max((long)GL * L.PP * 4, (long)GC * 2 * C.PP * 4);
             const long total = vtL + vtC + rawB + ((long)nlL + 2L * nlC) * kS19TW * 4;
             if (total > budget && TH > 1) continue;

@@ -157,8 +157,10 @@ struct S19Job {
     int srcW, srcH, dstW, dstH;
     int dstSel[2], dstOff[2], ds[2];      // component c: the frame's destination pointer (0 dst, 1 dstU, 2 dstV) + a byte offset; (per call) its pitch
     DevFilter h, v;
-    int sh, maxv, rc;                     // hScale*To19_c's shift and clamp; (per call) range conversion of the lines (hscale19_kernel's codes)
+    int sh, maxv, rc;                     // hScale*To19_c's (To15_c's) shift and clamp; (per call) range conversion of the lines (hscale19_kernel's codes; 5-8: the 15-bit lines')
+    int outMode, outShift, dither8;       // 0: 16-bit samples out; 1: 8-bit, 2: 10-bit << outShift (the 15-bit lines' writers); (per call) 8-bit output of a deep source: ff_dither_8x8_128
     int TW, TH, ntx, nty, nblk;           // output columns (64; 32: the half-width chroma of a packed 64-bit destination) and rows a tile, tiles across / down
+    int np;                               // horizontal pairs the job keeps in registers: 4 | 8, 0 = any number (read in the loop)
     int lshift, cp2;                      // log2 of the lanes that share a staged row's units; a row has more than 64 units (a lane stages two)
     int nrMax, nrLines, PP, G, vtBytes;   // most source rows a tile's taps span (inside the plane / with the padded taps); dwords (sample pairs) a staged row; rows staged at once; bytes of a tile's vertical tables
     const int32_t *colStart;              // [ntx] first staged sample of a tile column's rows (a multiple of 4)
@@ -173,7 +175,9 @@ struct S19Tables {
 struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; int rgb64, chrShift, linesOff; Yuv2RgbConsts y2r; };
 static_assert(sizeof(S19Args) + sizeof(Yuv2xFrames) <= 4096, "S19Args + Yuv2xFrames exceed the kernel-argument segment");
 // hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
-int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t);
+// outMode / outShift: S19Job's; hsh: the horizontal shift of the 15-bit lines (outMode != 0)
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
+                int outMode = 0, int outShift = 0, int hsh = 0);
 int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
 
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)

@@ -50,13 +50,15 @@ def test_rule_clauses(dev, orc, strip_rows, pair, monkeypatch):
     strip_rows(0)
     sf, df = pair
     assert _check(dev, orc, sf, df, (528, 52, 264, 26)) == "scale_yuv2px_kernel"
-    assert _check(dev, orc, sf, df, (384, 216, 164, 90), align=4).startswith("scale_yuv_kernel")          # 164-byte luma rows: not 16-byte lines
+    assert _check(dev, orc, sf, df, (384, 216, 164, 90), align=4) == "scale19_kernel"                      # 164-byte luma rows: not 16-byte lines (round 6: the tile kernel on the 15-bit lines, in front of the tiled one)
     assert _check(dev, orc, sf, df, (384, 216, 162, 90), align=64) == "scale_yuvg_blk_kernel"                # an odd chroma width
-    assert _check(dev, orc, sf, df, (384, 216, 161, 91), align=64).startswith("scale_yuv")                   # odd sizes: whatever serves them, the bytes
+    assert _check(dev, orc, sf, df, (384, 216, 161, 91), align=64).startswith(("scale_yuv", "scale19"))     # odd sizes: whatever serves them, the bytes
     for flags in ("bilinear", "lanczos", "area", "point", "gauss"):
         _check(dev, orc, sf, df, (384, 216, 160, 90), flags)
         _check(dev, orc, sf, df, (160, 90, 240, 136), flags)
     monkeypatch.setenv("GMAT_NO_CROSS_CASCADE", "1")
+    assert _check(dev, orc, sf, df, (384, 216, 160, 90)) == "scale19_kernel"
+    monkeypatch.setenv("GMAT_T15", "0")
     assert _check(dev, orc, sf, df, (384, 216, 160, 90)).startswith("scale_yuv_kernel")
 
 

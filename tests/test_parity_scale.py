@@ -299,7 +299,7 @@ def test_yuv_to_yuv_scaled(dev, orc, src_fmt, dst_fmt, geom):
         if (dw, dh) == (sw // 2, sh // 2) and align % 4 == 0 and strip_takes(sw, sh, src_fmt, dst_fmt):
             assert kernel == strip_name(src_fmt, dst_fmt), kernel
         else:
-            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", "scale_yuvu_kernel", LINES), kernel
+            assert "yuv>" in kernel or kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", "scale_yuvu_kernel", LINES, "scale19_kernel"), kernel      # (scale19_kernel: the tile kernel on the 15-bit lines, round 6 — the cross-layout pairs)
         for i, (g, w) in enumerate(zip(got, want)):
             bad = np.argwhere(g != w)
             assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({kernel})"
@@ -421,7 +421,7 @@ def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
         assert kernel.startswith("scale_yuv2p_kernel<luma>"), kernel
     else:
         # (round 5: 4:4:4 at BOTH ends is three plane jobs of the band walker where it has an instance, tests/test_parity_walker16.py)
-        assert is_generic(kernel) and ("yuv444" in kernel or kernel == LINES or (src_fmt == "yuv444p" and kernel.startswith("scale_yuvg_"))), kernel
+        assert is_generic(kernel) and ("yuv444" in kernel or kernel in (LINES, "scale19_kernel") or (src_fmt == "yuv444p" and kernel.startswith("scale_yuvg_"))), kernel
     assert len(got) == 3
     for i, (g, wv) in enumerate(zip(got, want)):
         bad = np.argwhere(g != wv)
@@ -1017,7 +1017,7 @@ def test_same_size_special_converters_leave_for_the_generic_path_when_ranges_dif
         assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
                                   planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
         k = lib.gmat_sws_lastKernel(c).decode()
-        assert k.startswith("scale_yuv") == (sr != dr), (k, sr, dr)
+        assert (k.startswith("scale_yuv") or k == "scale19_kernel") == (sr != dr), (k, sr, dr)
         if (sf, df) == ("nv12", "p010le") and sr == dr:        # round 4: the generic lines' t << 8 as the copy it is (k_rgb2yuv.hip nv12_shift8_kernel)
             assert k == "nv12_shift8_kernel", k
         for a, b in zip(dst, want):
