@@ -158,6 +158,6 @@ def test_the_rule(dev, orc, monkeypatch):
 def test_full_size(dev, orc):
     if dev.kind != "hip":
         pytest.skip("full-size frames run on the real GPU only")
-    for sf, df, geom in (("nv12", "yuv420p10le", (1920, 1080, 1280, 720)), ("p010le", "yuv420p", (3840, 2160, 1920, 1088)), ("yuv444p", "nv12", (1920, 1080, 1280, 720)),
+    for sf, df, geom in (("nv12", "yuv420p10le", (1920, 1080, 1280, 720)), ("p010le", "yuv420p", (3840, 2160, 1920, 1088)), ("yuv444p16le", "nv12", (1920, 1080, 1280, 720)),
                          ("nv12", "yuv444p", (1920, 1080, 1920, 1080))):
         assert _check(dev, orc, sf, df, geom, "bicubic", 256, 0, seed=3) == "scale19_kernel"
