@@ -349,10 +349,10 @@ int main(int argc, char **argv)
         {"rgbsrc: bgra 1080p->720p rgb24 bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_RGB24, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: bgra 1080p->720p bgra bicubic (3:2)", GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_PIX_FMT_BGRA, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: rgb24 640x640->1080p rgb24 bilinear (up)", GMAT_PIX_FMT_RGB24, 640, 640, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BILINEAR},
-        {"rgbsrc: yuv444p16le 1080p->720p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_PIX_FMT_YUV444P16LE, 1280, 720, GMAT_SWS_BICUBIC},
-        {"rgbsrc: yuv444p16le 4K->1080p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 3840, 2160, GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_SWS_BICUBIC},
-        {"rgbsrc: p016 4K->1080p p016 bicubic", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
-        {"rgbsrc: p016 1080p->720p p016 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"dst16: yuv444p16le 1080p->720p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_PIX_FMT_YUV444P16LE, 1280, 720, GMAT_SWS_BICUBIC},
+        {"dst16: yuv444p16le 4K->1080p yuv444p16le bicubic (16-bit 4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P16LE, 3840, 2160, GMAT_PIX_FMT_YUV444P16LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: p016 4K->1080p p016 bicubic", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"dst16: p016 1080p->720p p016 bicubic", GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
         {"dst16: nv12 1080p->720p p016 bicubic", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_BICUBIC},
         {"dst16: nv12 1080p->1080p rgba64 convert (yuv2rgb_cuda's 64-bit output)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBA64LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"dst16: nv12 1080p->1080p rgba64 convert, point", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGBA64LE, 1920, 1080, GMAT_SWS_POINT},
