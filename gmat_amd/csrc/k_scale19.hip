@@ -63,8 +63,8 @@ __device__ __forceinline__ int s19_dot2(unsigned samples, int coefs, int acc)
 // four samples of every component a source row image carries (one staging unit) -> sample pairs, 16-bit samples as v_dot2_i32_i16 takes them.
 // LAYOUT 0: 8-bit planar (4 bytes -> two pairs); 1: 8-bit interleaved (8 bytes -> two pairs each of A and B); 2: 16-bit planar (8 bytes);
 // 3: 16-bit interleaved (16 bytes)
-template <int LAYOUT>
-__device__ __forceinline__ void s19_pairs(const unsigned *v, unsigned xorv, bool shr6, unsigned &a0, unsigned &a1, unsigned &b0, unsigned &b1)
+template <int LAYOUT, bool SHR6>
+__device__ __forceinline__ void s19_pairs_t(const unsigned *v, unsigned xorv, unsigned &a0, unsigned &a1, unsigned &b0, unsigned &b1)
 {
     b0 = b1 = 0;
     if (LAYOUT == 0) {
@@ -79,10 +79,26 @@ __device__ __forceinline__ void s19_pairs(const unsigned *v, unsigned xorv, bool
         a1 = (v[2] & 0xFFFFu) | v[3] << 16; b1 = v[2] >> 16 | (v[3] & 0xFFFF0000u);
     }
     if (LAYOUT >= 2) {
-        if (shr6) { a0 = a0 >> 6 & 0x03FF03FFu; a1 = a1 >> 6 & 0x03FF03FFu; b0 = b0 >> 6 & 0x03FF03FFu; b1 = b1 >> 6 & 0x03FF03FFu; }
-        a0 ^= xorv; a1 ^= xorv; b0 ^= xorv; b1 ^= xorv;
+        // (P010's ten bits, kind 10: xorv is 0 there — a template argument: as a run-time flag the shift cost two selects a dword in the commit, r06v)
+        if (SHR6) { a0 = a0 >> 6 & 0x03FF03FFu; a1 = a1 >> 6 & 0x03FF03FFu; b0 = b0 >> 6 & 0x03FF03FFu; b1 = b1 >> 6 & 0x03FF03FFu; }
+        else      { a0 ^= xorv; a1 ^= xorv; b0 ^= xorv; b1 ^= xorv; }
     }
 }
+
+template <int LAYOUT>
+__device__ __forceinline__ void s19_pairs(const unsigned *v, unsigned xorv, bool shr6, unsigned &a0, unsigned &a1, unsigned &b0, unsigned &b1)
+{
+    if (LAYOUT >= 2 && shr6) s19_pairs_t<LAYOUT, true>(v, xorv, a0, a1, b0, b1);
+    else                     s19_pairs_t<LAYOUT, false>(v, xorv, a0, a1, b0, b1);
+}
+
+// keeps an offset that advances by a constant a step as ONE v_add a step: left alone the compiler re-derives every step's offset as (row + step rows) x stride,
+// a v_mad_u64_u32 each (r06v)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define S19_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define S19_OPAQUE(v) ((void)0)
+#endif
 
 // acc + a b on 24-bit operands as ONE v_mad_i32_i24 (the low 32 bits of the product: the wrap-around 32-bit multiply-add for a 19-bit line and a 13-bit
 // coefficient).  Written as `acc += __mul24(..) + __mul24(..)` the compiler makes two v_mul_i32_i24 and a v_add3_u32 of a tap pair — 12 instructions a pair and
@@ -103,10 +119,9 @@ __device__ __forceinline__ unsigned s19_mad(int a, int b, unsigned acc) { return
 // straddles a row's end is patched byte by byte afterwards, a thread a row.  32-bit offsets from sp: a plane spans less than 4 GB.
 template <int LAYOUT, int SLOTS, int CP, int pfBase>
 __device__ __forceinline__ void s19_issue(const uint8_t *sp, unsigned stride, int rowBytes, int B0, int gn, int nunit, int lshift,
-                                          unsigned (&pf)[16], int tid)
+                                          unsigned (&pf)[16], int lane, int wave)
 {
     constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, UB = 4 * NDW, U = SLOTS / CP;
-    const int lane = tid & 63, wave = tid >> 6;
     const int LPR = 1 << lshift, RPW = 64 >> lshift;
     const int ul = lane & (LPR - 1), row0 = wave * RPW + (lane >> lshift);
     const int offLast = (rowBytes / UB - 1) * UB;                               // the last whole unit of a row from its start
@@ -115,39 +130,45 @@ __device__ __forceinline__ void s19_issue(const uint8_t *sp, unsigned stride, in
     for (int cp = 0; cp < CP; cp++) {
         const int u0 = min(ul + cp * LPR, nunit - 1);
         const unsigned offc = (unsigned)min(B0 + u0 * UB, offLast);
-        const unsigned gLast = (unsigned)(gn - 1) * stride + offc, g = (unsigned)row0 * stride + offc;
+        const unsigned gLast = (unsigned)(gn - 1) * stride + offc;
+        unsigned g = (unsigned)row0 * stride + offc;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const unsigned *gp = reinterpret_cast<const unsigned *>(sp + min(g + u * gstep, gLast));
+            S19_OPAQUE(g);
+            const unsigned *gp = reinterpret_cast<const unsigned *>(sp + min(g, gLast));
 #pragma unroll
             for (int i = 0; i < NDW; i++) pf[pfBase + (cp * U + u) * NDW + i] = gp[i];
+            g += gstep;
         }
     }
 }
 
-template <int LAYOUT, int SLOTS, int CP, int pfBase>
-__device__ __forceinline__ void s19_commit(int rowBytes, int B0, int gn, int nunit, int lshift, unsigned xorv, bool shr6,
-                                           unsigned *out0, unsigned *out1, int PP, const unsigned (&pf)[16], int tid)
+// (a unit past the row's last whole one is stored as it was read — the last whole one's samples, where round 6's first form stored zeros at two selects a slot: every
+// tap there has a zero coefficient, check_banks, and the straddling unit is rewritten by the patch pass)
+template <int LAYOUT, int SLOTS, int CP, int pfBase, bool SHR6>
+__device__ __forceinline__ void s19_commit(int gn, int nunit, int lshift, unsigned xorv,
+                                           unsigned *out0, unsigned *out1, int PP, const unsigned (&pf)[16], int lane, int wave)
 {
-    constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, UB = 4 * NDW, U = SLOTS / CP;
-    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NDW = LAYOUT == 0 ? 1 : LAYOUT == 3 ? 4 : 2, U = SLOTS / CP;
     const int LPR = 1 << lshift, RPW = 64 >> lshift;
     const int ul = lane & (LPR - 1), row0 = wave * RPW + (lane >> lshift);
     const unsigned lstep = (unsigned)(4 * RPW * PP);
 #pragma unroll
     for (int cp = 0; cp < CP; cp++) {
         const int u0 = min(ul + cp * LPR, nunit - 1);
-        const bool whole = B0 + u0 * UB + UB <= rowBytes;
-        const unsigned lLast = (unsigned)((gn - 1) * PP + 2 * u0), l = (unsigned)(row0 * PP + 2 * u0);
+        const unsigned lLast = (unsigned)((gn - 1) * PP + 2 * u0);
+        unsigned l = (unsigned)(row0 * PP + 2 * u0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            S19_OPAQUE(l);
             unsigned a0, a1, b0, b1, z[NDW];
 #pragma unroll
-            for (int i = 0; i < NDW; i++) z[i] = whole ? pf[pfBase + (cp * U + u) * NDW + i] : 0u;
-            s19_pairs<LAYOUT>(z, xorv, shr6, a0, a1, b0, b1);
-            const unsigned lo = min(l + u * lstep, lLast);
+            for (int i = 0; i < NDW; i++) z[i] = pf[pfBase + (cp * U + u) * NDW + i];
+            s19_pairs_t<LAYOUT, SHR6>(z, xorv, a0, a1, b0, b1);
+            const unsigned lo = min(l, lLast);
             *reinterpret_cast<uint2 *>(out0 + lo) = make_uint2(a0, a1);
             if (LAYOUT == 1 || LAYOUT == 3) *reinterpret_cast<uint2 *>(out1 + lo) = make_uint2(b0, b1);
+            l += lstep;
         }
     }
 }
@@ -228,7 +249,9 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
                                           int32_t *vtab, unsigned *raw, int32_t *lines)
 {
     const S19Job &J = a.job[jx];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave's number as a scalar: as tid >> 6 it is a vector register to the compiler, and pass H's row indices, their v_mul_lo_u32 by the row pitch and the
+    // loop's bounds were vector work — 35 of 51 VALU instructions a row quad, r06v)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx * J.TW, y0 = ty * J.TH;
     const int r0 = J.rowStart[ty], nr = J.rowCount[ty], c0 = J.colStart[tx];
     const int vp = J.v.pairs, PP = J.PP;
@@ -249,17 +272,17 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
         const int gn = min(J.G, nr - g0);
         {
             const uint8_t *sp = src0 + (size_t)(r0 + g0) * J.rawStride[0];
-#define S19_ISSUE(L_, S_) if (J.cp2) s19_issue<L_, S_, 2, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); \
-                          else       s19_issue<L_, S_, 1, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
+#define S19_ISSUE(L_, S_) if (J.cp2) s19_issue<L_, S_, 2, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave); \
+                          else       s19_issue<L_, S_, 1, 0>(sp, (unsigned)J.rawStride[0], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave);
             S19_FOR_LAYOUT(S19_ISSUE);
 #undef S19_ISSUE
         }
         if (J.nraw == 2) {
             const uint8_t *sp = src1 + (size_t)(r0 + g0) * J.rawStride[1];
-            if (J.layout == 0) { if (J.cp2) s19_issue<0, 8, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
-                                 else       s19_issue<0, 8, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); }
-            else               { if (J.cp2) s19_issue<2, 4, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid);
-                                 else       s19_issue<2, 4, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, tid); }
+            if (J.layout == 0) { if (J.cp2) s19_issue<0, 8, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave);
+                                 else       s19_issue<0, 8, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave); }
+            else               { if (J.cp2) s19_issue<2, 4, 2, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave);
+                                 else       s19_issue<2, 4, 1, 8>(sp, (unsigned)J.rawStride[1], J.rowBytes, B0, gn, nunit, J.lshift, pf, lane, wave); }
         }
     };
     if (fast && S19_PROBE != 1) issue(0);                                     // the first group's rows: asked for before anything else is
@@ -300,16 +323,16 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
         if (g0) __syncthreads();                                               // the previous group's windows have been read
         if (S19_PROBE != 1 && fast) {
             unsigned *o0 = raw, *o1 = raw + (size_t)J.G * PP;
-#define S19_COMMIT(L_, S_) if (J.cp2) s19_commit<L_, S_, 2, 0>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o0, o1, PP, pf, tid); \
-                           else       s19_commit<L_, S_, 1, 0>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o0, o1, PP, pf, tid);
+#define S19_COMMIT_(L_, S_, C_, B_, O0_, O1_) do { if (L_ >= 2 && shr6) s19_commit<L_, S_, C_, B_, true>(gn, nunit, J.lshift, J.xorv, O0_, O1_, PP, pf, lane, wave); \
+                                                 else                  s19_commit<L_, S_, C_, B_, false>(gn, nunit, J.lshift, J.xorv, O0_, O1_, PP, pf, lane, wave); } while (0)
+#define S19_COMMIT(L_, S_) if (J.cp2) S19_COMMIT_(L_, S_, 2, 0, o0, o1); else S19_COMMIT_(L_, S_, 1, 0, o0, o1);
             S19_FOR_LAYOUT(S19_COMMIT);
 #undef S19_COMMIT
             if (J.nraw == 2) {
-                if (J.layout == 0) { if (J.cp2) s19_commit<0, 8, 2, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid);
-                                     else       s19_commit<0, 8, 1, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid); }
-                else               { if (J.cp2) s19_commit<2, 4, 2, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid);
-                                     else       s19_commit<2, 4, 1, 8>(J.rowBytes, B0, gn, nunit, J.lshift, J.xorv, shr6, o1, o1, PP, pf, tid); }
+                if (J.layout == 0) { if (J.cp2) S19_COMMIT_(0, 8, 2, 8, o1, o1); else S19_COMMIT_(0, 8, 1, 8, o1, o1); }
+                else               { if (J.cp2) S19_COMMIT_(2, 4, 2, 8, o1, o1); else S19_COMMIT_(2, 4, 1, 8, o1, o1); }
             }
+#undef S19_COMMIT_
         }
         if (S19_PROBE != 1 && (!fast || upart >= 0)) {
             if (fast) __syncthreads();                                          // after the zeros the fast form left in the straddling unit
