@@ -677,14 +677,10 @@ int plan_job(const FilterBank &h, const FilterBank &v, int srcW, int srcH, int d
 
 // rgb64: 0 a YUV destination (two jobs of their own tiles); 1 RGBA64LE, 2 BGRA64LE (one grid of 64-column tiles: the luma job's lines, then the chroma job's —
 // 64 >> chrShift columns — behind the same staged-row LDS, then the colour stage); chrShift: 1 = one chroma sample a pixel pair (ignored for YUV destinations)
-int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
-                int outMode, int outShift, int hsh)
+static int s19_prepare_budget(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
+                              int outMode, int outShift, int hsh, int budget, int thCap)
 {
     t.ok = 0;
-    // (measured: DESIGN 4.8) LDS a block may take, output rows a tile at most
-    const char *ks = GMAT_KNOB("GMAT_S19_LDS"), *kr = GMAT_KNOB("GMAT_S19_ROWS");
-    const int budget = ks ? std::min(std::max(atoi(ks), 4096), 65536) : 32768;
-    const int thCap = kr ? std::max(1, atoi(kr)) : 64;
     // hScale8To19_c: 3; hScale16To19_c: depth - 5 (kind 14: 9); the 15-bit lines (outMode != 0): hScale8To15_c's 7 / hScale16To15_c's depth - 1, the caller's
     const int sh = outMode ? hsh : kind == 0 ? 3 : kind % 100 - 5;
     const unsigned xorv = (bps == 2 && kind != 10) ? 0x80008000u : 0u;            // 16-bit samples as v_dot2_i32_i16 takes them (P010's ten bits fit as they are)
@@ -757,6 +753,30 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
                     t.job[j].dstW, t.job[j].dstH, t.job[j].layout, t.np, j ? vc.pairs : vl.pairs, t.job[j].TW, t.job[j].TH, t.job[j].ntx, t.job[j].nty, t.job[j].nrMax, t.job[j].nrLines, t.job[j].PP, t.job[j].G, t.job[j].lshift, t.ldsBytes, rgb64);
     t.ok = 1;
     return 0;
+}
+
+// The LDS a block may take (measured, profiles/r06_scale19_history.txt r06v: 16 ... 48 KB over the twelve dst16 cases): 32 KB — five blocks a CU — wherever a tile
+// of that size spends at least 85 % of its staged rows on rows of its own (tile rows x the vertical ratio / the rows its windows span): every 1.5 : 1 and 2 : 1
+// bicubic case is flat or best there.  A tile that does not — long vertical windows: 3 : 1 lanczos 23.9 us a frame at 32 KB, 20.0 at 40, 19.5 at 48; a 64-bit
+// destination's three line sets, 4K -> 1080p 23.1 / 20.5 / 21.5 — takes 40, then 48 KB.  GMAT_S19_LDS pins the number.
+int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
+                int outMode, int outShift, int hsh)
+{
+    const char *ks = GMAT_KNOB("GMAT_S19_LDS"), *kr = GMAT_KNOB("GMAT_S19_ROWS");
+    const int thCap = kr ? std::max(1, atoi(kr)) : 64;
+    t.ok = 0;
+    if (ks) return s19_prepare_budget(p, vl, vc, bps, kind, srcSemi, dstSemi, rgb64, chrShift, t, outMode, outShift, hsh, std::min(std::max(atoi(ks), 4096), 65536), thCap);
+    int r = GMAT_ERR(ENOSYS);
+    for (int budget : {32768, 40960, 49152}) {
+        S19Tables cand;
+        const int rc = s19_prepare_budget(p, vl, vc, bps, kind, srcSemi, dstSemi, rgb64, chrShift, cand, outMode, outShift, hsh, budget, thCap);
+        if (rc < 0) { if (!t.ok) r = rc; continue; }
+        const S19Job &L = cand.job[0];
+        const bool full = (long)L.TH * L.srcH * 100 >= 85L * L.nrMax * L.dstH || L.nty == 1;
+        t = std::move(cand); r = 0;
+        if (full) break;
+    }
+    return r;
 }
 
 int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes)

@@ -76,6 +76,23 @@ def test_tile_plans(dev, orc, pair, knobs, monkeypatch):
             assert _check(dev, orc, sf, df, geom, flags, 64, 0, seed=5) == "scale19_kernel"
 
 
+@pytest.mark.parametrize("pair", [("p016le", "p016le"), ("nv12", "rgba64le"), ("yuv444p16le", "yuv420p16le")])
+def test_long_windows_take_more_lds(dev, orc, pair, monkeypatch, capfd):
+    """a tile whose vertical windows leave it under 85 % of its staged rows at 32 KB of LDS is planned with 40, then 48 KB (s19_prepare: 3 : 1 lanczos
+    23.9 -> 19.5 us a 4K frame); the plan is read from the GMAT_S19_DEBUG line, the pixels held to the oracle as everywhere"""
+    import re
+    monkeypatch.setenv("GMAT_S19_DEBUG", "1")
+    sf, df = pair
+    seen = []
+    for geom, flags in (((72, 900, 66, 300), "lanczos"), ((96, 1024, 40, 256), "bicubic"), ((64, 600, 64, 400), "bicubic")):
+        capfd.readouterr()
+        assert _check(dev, orc, sf, df, geom, flags, 64, 0, seed=23) == "scale19_kernel"
+        m = re.findall(r"s19 job 0: .* lds (\d+) ", capfd.readouterr().err)
+        assert m, "no plan line"
+        seen.append(int(m[-1]))
+    assert seen[0] > 32768 and seen[1] > 32768 and seen[2] <= 32768, seen
+
+
 @pytest.mark.parametrize("df", ["rgba64le", "bgra64le"])
 @pytest.mark.parametrize("sf", ["nv12", "yuv420p", "yuv444p", "p016le", "yuv420p10le"])
 def test_rgba64_forms(dev, orc, sf, df):
