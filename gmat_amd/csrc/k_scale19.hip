@@ -31,7 +31,7 @@
 #include "kernels.h"
 #include "px_math.h"
 
-// measurement builds (tools/build_variant.sh s19pN k_scale19.hip -DS19_PROBE=N; wrong pixels): 1 no staging, 2 no pass H, 3 no pass V (stores stay)
+// measurement builds (tools/build_variant.sh s19pN k_scale19.hip -DS19_PROBE=N; wrong pixels): 1 no staging, 2 no pass H, 3 no pass V (stores stay), 4 nothing (the launch's floor)
 #ifndef S19_PROBE
 #define S19_PROBE 0
 #endif
@@ -532,6 +532,7 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
 {
     HIP_DYNAMIC_SHARED(uint4, lds_base)
     uint8_t *lds = reinterpret_cast<uint8_t *>(lds_base);
+    if (S19_PROBE == 4) return;
     // workgroups go round the eight XCDs in launch order (observed, MI355X_MICROARCH.md): each XCD takes one contiguous range of (frame, tile)
     // items, so that the tiles that share source lines — neighbours across, the rows two tile rows overlap in — meet in ONE L2
     int item = blockIdx.x;
