@@ -375,6 +375,7 @@ static int init_yuv_scaler(GmatSwsContext *c)
             // 3 : 1 — runs the larger instance for both and loses to the tiled kernel, 11.3 against 7.7 us a frame; 16-bit sources win either way)
             auto np_of = [](int pairs) { return pairs <= 4 ? 4 : pairs <= 8 ? 8 : 0; };
             if (c->t15.ok && !a.src16 && np_of(c->planYuv.hLum.pairs) != np_of(c->planYuv.hChr.pairs)) c->t15.ok = 0;
+            s19_unit_plan(c->planYuv, t.vLumEff, t.vChrEff, t.lumRound.data(), t.chrRound.data(), c->t15);
             if (c->t15.ok) {
                 for (int j = 0; j < 2; j++) {
                     S19Job &J = c->t15.job[j];
@@ -517,6 +518,7 @@ static int init_scale16(GmatSwsContext *c)
         r = s19_prepare(p, vl, vc, s16 ? 2 : 1, scale16_kind(c->srcFormat), srcSemi ? 1 : 0, c->dstFormat == GMAT_PIX_FMT_P016LE ? 1 : 0,
                         rgb64, p.chrDstW == c->dstW ? 0 : 1, c->s19);
         if (r < 0 && r != GMAT_ERR(ENOSYS)) return r;
+        s19_unit_plan(p, vl, vc, nullptr, nullptr, c->s19);              // (equal size, one-tap identity banks: the launch is scale19_unit_kernel's)
         if (c->s19.ok) {
             for (int j = 0; j < 2; j++) {
                 S19Job &J = c->s19.job[j];
@@ -1109,6 +1111,7 @@ static int launch_tile15(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStr
     }
     if ((ya.src16 && (sA & 1)) || (ya.dst16 && (dA & 1))) return GMAT_ERR(EINVAL);        // 16-bit samples sit on even addresses
     a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
+    a.unit = c->t15.unit; a.srcAl16 = (sA & 15) == 0; a.dstAl16 = (dA & 15) == 0;
     return launch_scale19(a, c->t15.np, c->t15.ldsBytes, st, &fr, n);
 }
 
@@ -1118,6 +1121,11 @@ struct PlaneKernel {
     int (*launch)(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t stream, const Yuv2xFrames &fr, int n);
 };
 static const PlaneKernel kPlaneKernels[] = {
+    // (round 6, last third) equal size with one-tap identity banks — yuv2yuv_cuda's same-size conversions between depths and layouts that libswscale runs through its
+    // generic scaler: the tile kernel's unit form, a sample a multiply and a shift (in front of every walker: they took 5.2-6.5 us a 1080p frame for what is a copy's bytes)
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return c->t15.ok && c->t15.unit && !ya.prof; },
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale19_unit_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_tile15(c, ya, st, fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return yuv2s_eligible(c, ya); },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) -> const char * {
          return c->y2s.np == 6 ? "scale_yuv2s_np_kernel<6>" : yuv2s_block_form(make_yuv2s_args(c, ya), n) ? "scale_yuv2s_blk_kernel" : "scale_yuv2s_kernel"; },
@@ -1194,7 +1202,7 @@ static const PlaneKernel kPlaneKernels[] = {
          // (8-bit ends keep the lines form: 6.7 against 7.8-11 us a 1080p -> 720p frame batched, profiles/r06_sweep_tile15.txt; the deep ones — 16-bit samples in, 10-bit out,
          // the dithered 8-bit output — ran its untuned 16-bit pass or fell through to the tiled kernel)
          return c->t15.ok && c->t15Mixed && !ya.prof && (ya.src16 || ya.dst16 || ya.dither8) && c->srcW < 4 * c->dstW && c->srcH < 4 * c->dstH; },
-     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale19_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return c->t15.unit ? "scale19_unit_kernel" : "scale19_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_tile15(c, ya, st, fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int n) { return yuvl_eligible(c, ya, n); },                                    // what no walker takes: the lines form
      [](const GmatSwsContext *, const YuvScaleArgs &ya, int) -> const char * { return ya.src16 ? "scale_yuvl_h16_kernel+scale_yuvl_v_kernel" : "scale_yuvl_h_kernel+scale_yuvl_v_kernel"; },
@@ -1212,7 +1220,7 @@ static const PlaneKernel kPlaneKernels[] = {
          }
          return launch_scale_yuvl(make_yuvl_args(c, ya), st, &fr, n); }},
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return c->t15.ok && !ya.prof; },       // ... and in front of the tiled catch-all wherever it has a plan
-     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "scale19_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return c->t15.unit ? "scale19_unit_kernel" : "scale19_kernel"; },
      [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_tile15(c, ya, st, fr, n); }},
     {[](const GmatSwsContext *, const YuvScaleArgs &, int) { return true; },      // everything else: the tiled plane scaler
      [](const GmatSwsContext *c, const YuvScaleArgs &, int) -> const char * { return yuvscale_kernel_name(c->ytiling); },
@@ -1221,8 +1229,8 @@ static const PlaneKernel kPlaneKernels[] = {
          return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
 };
 constexpr int kNumPlaneKernels = (int)(sizeof(kPlaneKernels) / sizeof(kPlaneKernels[0]));
-// the two records of the tile kernel on the 15-bit lines (launch_tile15): the second and the fourth from the end
-static bool plane_record_is_tile(int k) { return k == kNumPlaneKernels - 2 || k == kNumPlaneKernels - 4; }
+// the three records of the tile kernel on the 15-bit lines (launch_tile15): the first (its unit form), the second and the fourth from the end
+static bool plane_record_is_tile(int k) { return k == 0 || k == kNumPlaneKernels - 2 || k == kNumPlaneKernels - 4; }
 
 // argument block of the strip-walking packed-RGB scaler
 static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)
@@ -1476,7 +1484,8 @@ static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_pl
         }
         if ((dA & 1) || (s16 && (sA & 1))) return GMAT_ERR(EINVAL);              // 16-bit samples sit on even addresses
         a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
-        c->lastKernel = "scale19_kernel";
+        a.unit = c->s19.unit; a.srcAl16 = (sA & 15) == 0; a.dstAl16 = (dA & 15) == 0;
+        c->lastKernel = c->s19.unit ? "scale19_unit_kernel" : "scale19_kernel";
         if (int r = launch_scale19(a, c->s19.np, c->s19.ldsBytes, stream, &fr, m); r < 0) return r;
         c->lastLaunchFrames = m;
     }

@@ -357,6 +357,16 @@ __device__ __forceinline__ void s19_lines(const S19Args &a, int jx, const uint8_
     __syncthreads();
 }
 
+// one sample from its sum: s19_planes' writers (outMode 0: 16-bit, 1: 8-bit with the deep sources' dither, 2: 10-bit << outShift)
+__device__ __forceinline__ unsigned s19_outv(int mode, int osh, int dith, unsigned acc, int xx, int yy, int vplane)
+{
+    if (mode == 0) return (unsigned)(min(max((int)acc >> 15, -32768), 32767) + 0x8000);
+    if (mode == 2) return (unsigned)min(max((int)acc >> 17, 0), 1023) << osh;
+    int v = (int)acc;
+    if (dith) v += dither_delta(xx + 3 * vplane, yy);
+    return (unsigned)clip_u8_shr(v, 19);
+}
+
 // pass V of a YUV destination's job: the tile's output rows from its lines.  outMode 0: 16-bit samples (yuv2planeX_16_c / yuv2nv12cX_16_c); the 15-bit
 // lines' writers (round 6, second half: the pairs no walker serves — planar <-> semi-planar with a deep end, 4 : 4 : 4 <-> 4 : 2 : 0): 1: 8-bit samples,
 // clip_u8((start + sum + dither) >> 19) — yuv2planeX_8_c / yuv2nv12cX_c, the dither of a deep source ff_dither_8x8_128 by (x, y), the V plane's three columns on
@@ -373,13 +383,7 @@ __device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *ds
     const int yEnd = min(y0 + J.TH, J.dstH);
     const int mode = J.outMode, osh = J.outShift, dith = J.dither8;
     // one sample from its sum; (xx, yy): its place in the plane (the dither's), vplane: the V plane's three columns
-    auto outv = [&](unsigned acc, int xx, int yy, int vplane) -> unsigned {
-        if (mode == 0) return (unsigned)(min(max((int)acc >> 15, -32768), 32767) + 0x8000);
-        if (mode == 2) return (unsigned)min(max((int)acc >> 17, 0), 1023) << osh;
-        int v = (int)acc;
-        if (dith) v += dither_delta(xx + 3 * vplane, yy);
-        return (unsigned)clip_u8_shr(v, 19);
-    };
+    auto outv = [&](unsigned acc, int xx, int yy, int vplane) -> unsigned { return s19_outv(mode, osh, dith, acc, xx, yy, vplane); };
     if (J.ileave) {
         // a thread: columns (2 cp, 2 cp + 1) of both chroma planes, 32 pairs a row, 8 rows a step; (U, V) pairs stored
         const int cp = tid & 31, xo = x0 + 2 * cp;
@@ -563,6 +567,151 @@ __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
         s19_lines<NP>(a, ji + j, src_ptr(a.job[ji + j].rawSel[0]), src_ptr(a.job[ji + j].rawSel[1]), tx, ty, j ? vtab1 : vtab0, raw, j ? lines1 : lines0);
     if (a.rgb64) s19_rgb64(a, fr.dst[f], tx, ty, vtab0, vtab1, lines0, lines1);
     else         s19_planes(a, ji, dst_ptr(a.job[ji].dstSel[0]), dst_ptr(a.job[ji].dstSel[1]), tx, ty, vtab0, lines0);
+}
+
+// ---- the unit form: equal size, every bank a one-tap identity --------------------------------------------------------------------------------
+// yuv2yuv_cuda's space (libswscale/cuda/yuv2yuv_cuda.cu:324-366: same-size conversions between the 4:2:0 / 4:4:4 layouts and depths) wherever libswscale
+// has no unscaled special converter and runs its generic scaler with one-tap filters: a sample's 15- / 19-bit line value is min(s 2^14 >> sh, maxv), the
+// range conversion, then the writer's one product and shift — no neighbour, no LDS.  A thread: eight samples of a row of the luma plane, or of both chroma
+// planes; 8 / 16 / 32-byte loads and stores where the planes sit on 16-byte addresses and pitches, sample by sample elsewhere and on a row's ragged end.
+// S19Job is the tile form's (layouts, plane selectors, pitches, shift / clamp / range / writer); unitCoef / unitRound: the vertical bank's one coefficient and the
+// sums' start value (the same for every row: s19_unit_plan checks).
+template <int LAYOUT>
+__device__ __forceinline__ void s19u_load(const uint8_t *p0, const uint8_t *p1, bool fast, int n, bool shr6, int (&sa)[8], int (&sb)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) sa[i] = sb[i] = 0;
+    if (fast) {
+        if (LAYOUT == 0) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p0);
+            const unsigned w[2] = {v.x, v.y};
+#pragma unroll
+            for (int i = 0; i < 8; i++) sa[i] = (int)(w[i >> 2] >> (8 * (i & 3)) & 0xFFu);
+            if (p1) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(p1);
+                const unsigned z[2] = {q.x, q.y};
+#pragma unroll
+                for (int i = 0; i < 8; i++) sb[i] = (int)(z[i >> 2] >> (8 * (i & 3)) & 0xFFu);
+            }
+        } else if (LAYOUT == 1) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p0);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sa[i] = (int)(w[i >> 1] >> (16 * (i & 1)) & 0xFFu); sb[i] = (int)(w[i >> 1] >> (16 * (i & 1) + 8) & 0xFFu); }
+        } else if (LAYOUT == 2) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p0);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) sa[i] = (int)(w[i >> 1] >> (16 * (i & 1)) & 0xFFFFu);
+            if (p1) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(p1);
+                const unsigned z[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) sb[i] = (int)(z[i >> 1] >> (16 * (i & 1)) & 0xFFFFu);
+            }
+        } else {
+            const uint4 v0 = reinterpret_cast<const uint4 *>(p0)[0], v1 = reinterpret_cast<const uint4 *>(p0)[1];
+            const unsigned w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sa[i] = (int)(w[i] & 0xFFFFu); sb[i] = (int)(w[i] >> 16); }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (i < n) {                                                        // (unrolled: a run-time index into the arrays would put them in scratch)
+                if (LAYOUT == 0)      { sa[i] = p0[i]; if (p1) sb[i] = p1[i]; }
+                else if (LAYOUT == 1) { sa[i] = p0[2 * i]; sb[i] = p0[2 * i + 1]; }
+                else if (LAYOUT == 2) { sa[i] = reinterpret_cast<const unsigned short *>(p0)[i]; if (p1) sb[i] = reinterpret_cast<const unsigned short *>(p1)[i]; }
+                else                  { sa[i] = reinterpret_cast<const unsigned short *>(p0)[2 * i]; sb[i] = reinterpret_cast<const unsigned short *>(p0)[2 * i + 1]; }
+            }
+    }
+    if (LAYOUT >= 2 && shr6) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { sa[i] >>= 6; sb[i] >>= 6; }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrames fr)
+{
+    const int nb = a.unitBlk[0] + a.unitBlk[1];
+    const int f = blockIdx.x / nb;
+    int b = blockIdx.x - f * nb, ji = 0;
+    if (b >= a.unitBlk[0]) { ji = 1; b -= a.unitBlk[0]; }
+    const S19Job &J = a.job[ji];
+    const int upr = (J.dstW + 7) >> 3;
+    const int idx = b * 256 + (int)threadIdx.x;
+    const int y = idx / upr, x0 = (idx - y * upr) * 8;
+    if (y >= J.dstH) return;
+    const int n = min(8, J.dstW - x0);
+    auto src_ptr = [&](int sel) -> const uint8_t * { return sel == 0 ? fr.y[f] : sel == 1 ? fr.u[f] : fr.v[f]; };
+    auto dst_ptr = [&](int sel) -> uint8_t * { return sel == 0 ? fr.dst[f] : sel == 1 ? fr.dstU[f] : fr.dstV[f]; };
+    const int sgb = J.layout == 0 ? 1 : J.layout == 3 ? 4 : 2;                  // bytes a sample group of a source row image
+    const uint8_t *p0 = src_ptr(J.rawSel[0]) + (size_t)y * J.rawStride[0] + (size_t)x0 * sgb;
+    const uint8_t *p1 = (J.ncomp == 2 && J.nraw == 2) ? src_ptr(J.rawSel[1]) + (size_t)y * J.rawStride[1] + (size_t)x0 * sgb : nullptr;
+    const bool fastS = a.srcAl16 && n == 8, fastD = a.dstAl16 && n == 8;
+    int sa[8], sb[8];
+    if (J.layout == 0)      s19u_load<0>(p0, p1, fastS, n, false, sa, sb);
+    else if (J.layout == 1) s19u_load<1>(p0, p1, fastS, n, false, sa, sb);
+    else if (J.layout == 2) s19u_load<2>(p0, p1, fastS, n, J.kind == 10, sa, sb);
+    else                    s19u_load<3>(p0, p1, fastS, n, J.kind == 10, sa, sb);
+    const int mode = J.outMode, osh = J.outShift, dith = J.dither8;
+    unsigned oa[8], ob[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int la = min((int)((unsigned)sa[i] << 14) >> J.sh, J.maxv);
+        if (J.rc) la = s19_range(la, J.rc);
+        oa[i] = s19_outv(mode, osh, dith, s19_mad(la, J.unitCoef, (unsigned)J.unitRound), x0 + i, y, 0);
+        ob[i] = 0;
+        if (J.ncomp == 2) {
+            int lb = min((int)((unsigned)sb[i] << 14) >> J.sh, J.maxv);
+            if (J.rc) lb = s19_range(lb, J.rc);
+            ob[i] = s19_outv(mode, osh, dith, s19_mad(lb, J.unitCoef, (unsigned)J.unitRound), x0 + i, y, 1);
+        }
+    }
+    const int ob8 = mode == 1 ? 1 : 2;                                           // bytes an output sample
+    if (J.ileave) {
+        uint8_t *d = dst_ptr(J.dstSel[0]) + J.dstOff[0] + (size_t)y * J.ds[0] + (size_t)x0 * 2 * ob8;
+        if (mode == 1) {
+            if (fastD) {
+                unsigned w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = oa[2 * k] | ob[2 * k] << 8 | oa[2 * k + 1] << 16 | ob[2 * k + 1] << 24;
+                *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (i < n) { d[2 * i] = (uint8_t)oa[i]; d[2 * i + 1] = (uint8_t)ob[i]; }
+            }
+        } else {
+            if (fastD) {
+                reinterpret_cast<uint4 *>(d)[0] = make_uint4(oa[0] | ob[0] << 16, oa[1] | ob[1] << 16, oa[2] | ob[2] << 16, oa[3] | ob[3] << 16);
+                reinterpret_cast<uint4 *>(d)[1] = make_uint4(oa[4] | ob[4] << 16, oa[5] | ob[5] << 16, oa[6] | ob[6] << 16, oa[7] | ob[7] << 16);
+            } else {
+                unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (i < n) { d16[2 * i] = (unsigned short)oa[i]; d16[2 * i + 1] = (unsigned short)ob[i]; }
+            }
+        }
+    } else {
+        auto store = [&](int c, const unsigned (&o)[8]) {
+            uint8_t *d = dst_ptr(J.dstSel[c]) + J.dstOff[c] + (size_t)y * J.ds[c] + (size_t)x0 * ob8;
+            if (mode == 1) {
+                if (fastD) *reinterpret_cast<uint2 *>(d) = make_uint2(o[0] | o[1] << 8 | o[2] << 16 | o[3] << 24, o[4] | o[5] << 8 | o[6] << 16 | o[7] << 24);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) if (i < n) d[i] = (uint8_t)o[i];
+                }
+            } else {
+                if (fastD) *reinterpret_cast<uint4 *>(d) = make_uint4(o[0] | o[1] << 16, o[2] | o[3] << 16, o[4] | o[5] << 16, o[6] | o[7] << 16);
+                else {
+                    unsigned short *d16 = reinterpret_cast<unsigned short *>(d);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) if (i < n) d16[i] = (unsigned short)o[i];
+                }
+            }
+        };
+        store(0, oa);
+        if (J.ncomp == 2) store(1, ob);
+    }
 }
 
 // ---- the planner (host) ---------------------------------------------------------------------------------------------------------------------
@@ -780,10 +929,57 @@ int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, 
     return r;
 }
 
+// the bank's one coefficient when output i is source sample i and nothing else, for every i, with the same coefficient; 0 otherwise
+static int s19_identity_coef(const FilterBank &fb, int n)
+{
+    if (fb.count != n || fb.pairs < 1) return 0;
+    int coef = 0;
+    for (int i = 0; i < n; i++) {
+        const int k = i - fb.pos_even[i];
+        if (k < 0 || k >= 2 * fb.pairs) return 0;
+        for (int t = 0; t < 2 * fb.pairs; t++) {
+            const int32_t pk = fb.packed[(size_t)i * fb.pairs + (t >> 1)];
+            const int c = (t & 1) ? pk >> 16 : (int)(int16_t)(pk & 0xFFFF);
+            if ((c != 0) != (t == k)) return 0;
+            if (t == k) { if (coef && c != coef) return 0; coef = c; }
+        }
+    }
+    return coef;
+}
+
+void s19_unit_plan(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, const int32_t *lumRound, const int32_t *chrRound, S19Tables &t)
+{
+    t.unit = 0;
+    const char *ku = GMAT_KNOB("GMAT_S19_UNIT");
+    if (!t.ok || t.rgb64 || (ku && atoi(ku) == 0)) return;
+    for (int j = 0; j < 2; j++) {
+        S19Job &J = t.job[j];
+        if (J.srcW != J.dstW || J.srcH != J.dstH) return;
+        if (s19_identity_coef(j ? p.hChr : p.hLum, J.dstW) != 16384) return;
+        const int cv = s19_identity_coef(j ? vc : vl, J.dstH);
+        if (cv <= 0 || cv >= (1 << 15)) return;
+        const int32_t *rnd = j ? chrRound : lumRound;
+        int k0 = (int)((1u << 14) - 0x40000000u);                               // yuv2planeX_16_c's constant (s19_lines)
+        if (J.outMode) {
+            if (!rnd) return;
+            k0 = rnd[0];
+            for (int y = 1; y < J.dstH; y++) if (rnd[y] != k0) return;
+        }
+        J.unitCoef = cv; J.unitRound = k0;
+    }
+    t.unit = 1;
+}
+
 int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || ldsBytes < 1 || ldsBytes > 65536) return GMAT_ERR(EINVAL);
     S19Args a = a0;
+    if (a.unit) {
+        for (int j = 0; j < 2; j++) a.unitBlk[j] = (int)((((long)(a.job[j].dstW + 7) >> 3) * a.job[j].dstH + 255) / 256);
+        hipLaunchKernelGGL(scale19_unit_kernel, dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
+        GMAT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((a.rgb64 ? a.job[0].nblk : a.job[0].nblk + a.job[1].nblk) * nframes), block(256);
     const Yuv2xFrames &fr = *frames;
     const char *kx = GMAT_KNOB("GMAT_SCALE_XCD");

@@ -165,20 +165,26 @@ struct S19Job {
     int nrMax, nrLines, PP, G, vtBytes;   // most source rows a tile's taps span (inside the plane / with the padded taps); dwords (sample pairs) a staged row; rows staged at once; bytes of a tile's vertical tables
     const int32_t *colStart;              // [ntx] first staged sample of a tile column's rows (a multiple of 4)
     const int32_t *rowStart, *rowCount;   // [nty] source rows a tile row's taps span
+    int unitCoef, unitRound;              // the unit form (equal size, one-tap identity banks: scale19_unit_kernel): the vertical bank's one coefficient, the sums' start value
 };
 struct S19Tables {
     int ok = 0, np = 0, ldsBytes = 0;     // np: 4 | 8 horizontal pairs in registers, 0 = any number (coefficients read in the loop)
+    int unit = 0;                         // every bank of both jobs a one-tap identity at equal size: the launch takes scale19_unit_kernel (s19_unit_plan)
     int rgb64 = 0, chrShift = 0, linesOff = 0;   // a packed 64-bit destination (1 RGBA64LE, 2 BGRA64LE): chroma columns = pixel columns >> chrShift; byte offset of the lines in LDS
     S19Job job[2];                        // luma, chroma (device pointers left null: the caller uploads col / row tables and fills them in)
     std::vector<int32_t> colStart[2], rowStart[2], rowCount[2];
 };
-struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; int rgb64, chrShift, linesOff; Yuv2RgbConsts y2r; };
+struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; int rgb64, chrShift, linesOff; Yuv2RgbConsts y2r;
+                 int unit, srcAl16, dstAl16, unitBlk[2]; };   // the unit form: planes and pitches on 16-byte addresses; blocks a frame's luma / chroma job takes
 static_assert(sizeof(S19Args) + sizeof(Yuv2xFrames) <= 4096, "S19Args + Yuv2xFrames exceed the kernel-argument segment");
 // hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
 // outMode / outShift: S19Job's; hsh: the horizontal shift of the 15-bit lines (outMode != 0)
 int s19_prepare(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, int bps, int kind, int srcSemi, int dstSemi, int rgb64, int chrShift, S19Tables &t,
                 int outMode = 0, int outShift = 0, int hsh = 0);
 int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+// after s19_prepare: t.unit = 1 (and the jobs' unitCoef / unitRound) when the plan is an equal-size one whose four banks are one-tap identities with ONE vertical
+// coefficient and start value for every row.  lumRound / chrRound: the 15-bit writers' start values a row (YuvScaleTiling's), nullptr for the 16-bit writers' constant
+void s19_unit_plan(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, const int32_t *lumRound, const int32_t *chrRound, S19Tables &t);
 
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)
 int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,

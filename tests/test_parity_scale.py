@@ -421,7 +421,7 @@ def test_yuv444p_output(dev, orc, src_fmt, flags, geom):
         assert kernel.startswith("scale_yuv2p_kernel<luma>"), kernel
     else:
         # (round 5: 4:4:4 at BOTH ends is three plane jobs of the band walker where it has an instance, tests/test_parity_walker16.py)
-        assert is_generic(kernel) and ("yuv444" in kernel or kernel in (LINES, "scale19_kernel") or (src_fmt == "yuv444p" and kernel.startswith("scale_yuvg_"))), kernel
+        assert is_generic(kernel) and ("yuv444" in kernel or kernel in (LINES, "scale19_kernel", "scale19_unit_kernel") or (src_fmt == "yuv444p" and kernel.startswith("scale_yuvg_"))), kernel
     assert len(got) == 3
     for i, (g, wv) in enumerate(zip(got, want)):
         bad = np.argwhere(g != wv)
@@ -537,7 +537,7 @@ def test_p016_destination(dev, orc, src_fmt, geom, form, monkeypatch):
         for align, extra in ((64, 0), (2, 2)):
             d = dev.upload_planes(src, align, extra)
             got, pads, kernel = dev.sws(d, sw, sh, src_fmt, dw, dh, "p016le", SWS[flags], dst_align=align, dst_extra=extra)
-            assert kernel == ("scale19_kernel" if form == "tile" else "hscale19_kernel+vscale16_kernel"), kernel
+            assert kernel == (("scale19_unit_kernel" if (sw, sh) == (dw, dh) and "444" not in src_fmt else "scale19_kernel") if form == "tile" else "hscale19_kernel+vscale16_kernel"), kernel      # (equal size, 4:2:0 at both ends: the tile kernel's unit form)
             for i, (g, wv) in enumerate(zip(got, want)):
                 bad = np.argwhere(g != wv)
                 assert bad.size == 0, f"plane {i}: {len(bad)} mismatching bytes, first at {bad[:4].tolist()} ({flags}, align {align})"
@@ -1017,7 +1017,7 @@ def test_same_size_special_converters_leave_for_the_generic_path_when_ranges_dif
         assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h,
                                   planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
         k = lib.gmat_sws_lastKernel(c).decode()
-        assert (k.startswith("scale_yuv") or k == "scale19_kernel") == (sr != dr), (k, sr, dr)
+        assert (k.startswith("scale_yuv") or k in ("scale19_kernel", "scale19_unit_kernel")) == (sr != dr), (k, sr, dr)
         if (sf, df) == ("nv12", "p010le") and sr == dr:        # round 4: the generic lines' t << 8 as the copy it is (k_rgb2yuv.hip nv12_shift8_kernel)
             assert k == "nv12_shift8_kernel", k
         for a, b in zip(dst, want):
