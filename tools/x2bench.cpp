@@ -361,6 +361,11 @@ int main(int argc, char **argv)
         {"dst16: p010 4K->1080p p016 bicubic", GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"dst16: p016 720p->1080p p016 bicubic (up)", GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_PIX_FMT_P016LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"dst16: p016 4K->720p p016 lanczos (3:1)", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_P016LE, 1280, 720, GMAT_SWS_LANCZOS},
+        // same-size conversions between depths and layouts (yuv2yuv_cuda's space; libswscale: the generic scaler with one-tap filters): the tile kernel's unit form
+        {"yuv2yuv: p010 1080p->1080p nv12 (10 -> 8 bits, dithered)", GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"yuv2yuv: nv12 1080p->1080p yuv420p10le", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"yuv2yuv: yuv420p10le 4K->4K p010", GMAT_PIX_FMT_YUV420P10LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_SWS_BICUBIC},
+        {"yuv2yuv: p016 4K->4K nv12 (16 -> 8 bits, dithered)", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 1080p->720p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_PIX_FMT_YUV444P, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 4K->1080p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
