@@ -660,14 +660,16 @@ __global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrame
     const S19Job &J = a.job[ji];
     const int upr = (J.dstW + 7) >> 3;
     const int idx = b * 256 + (int)threadIdx.x;
-    const int y = idx / upr, x0 = (idx - y * upr) * 8;
+    // idx / upr by the host's multiplier (exact for idx < 2^31: launch_scale19): the compiler's division is thirty instructions of a thread that has a hundred
+    const int y = upr == 1 ? idx : (int)(__umulhi((unsigned)idx, a.unitMul[ji]) >> a.unitShr[ji]), x0 = (idx - y * upr) * 8;
     if (y >= J.dstH) return;
     const int n = min(8, J.dstW - x0);
     auto src_ptr = [&](int sel) -> const uint8_t * { return sel == 0 ? fr.y[f] : sel == 1 ? fr.u[f] : fr.v[f]; };
     auto dst_ptr = [&](int sel) -> uint8_t * { return sel == 0 ? fr.dst[f] : sel == 1 ? fr.dstU[f] : fr.dstV[f]; };
     const int sgb = J.layout == 0 ? 1 : J.layout == 3 ? 4 : 2;                  // bytes a sample group of a source row image
-    const uint8_t *p0 = src_ptr(J.rawSel[0]) + (size_t)y * J.rawStride[0] + (size_t)x0 * sgb;
-    const uint8_t *p1 = (J.ncomp == 2 && J.nraw == 2) ? src_ptr(J.rawSel[1]) + (size_t)y * J.rawStride[1] + (size_t)x0 * sgb : nullptr;
+    // (32-bit offsets from the plane pointers: a plane spans less than 4 GB)
+    const uint8_t *p0 = src_ptr(J.rawSel[0]) + ((unsigned)y * (unsigned)J.rawStride[0] + (unsigned)(x0 * sgb));
+    const uint8_t *p1 = (J.ncomp == 2 && J.nraw == 2) ? src_ptr(J.rawSel[1]) + ((unsigned)y * (unsigned)J.rawStride[1] + (unsigned)(x0 * sgb)) : nullptr;
     const bool fastS = a.srcAl16 && n == 8, fastD = a.dstAl16 && n == 8;
     int sa[8], sb[8];
     if (J.layout == 0)      s19u_load<0>(p0, p1, fastS, n, false, sa, sb);
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrame
 #undef S19U_SAMPLES
     const int ob8 = mode == 1 ? 1 : 2;                                           // bytes an output sample
     if (J.ileave) {
-        uint8_t *d = dst_ptr(J.dstSel[0]) + J.dstOff[0] + (size_t)y * J.ds[0] + (size_t)x0 * 2 * ob8;
+        uint8_t *d = dst_ptr(J.dstSel[0]) + ((unsigned)J.dstOff[0] + (unsigned)y * (unsigned)J.ds[0] + (unsigned)(x0 * 2 * ob8));
         if (mode == 1) {
             if (fastD) {
                 unsigned w[4];
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrame
         }
     } else {
         auto store = [&](int c, const unsigned (&o)[8]) {
-            uint8_t *d = dst_ptr(J.dstSel[c]) + J.dstOff[c] + (size_t)y * J.ds[c] + (size_t)x0 * ob8;
+            uint8_t *d = dst_ptr(J.dstSel[c]) + ((unsigned)J.dstOff[c] + (unsigned)y * (unsigned)J.ds[c] + (unsigned)(x0 * ob8));
             if (mode == 1) {
                 if (fastD) *reinterpret_cast<uint2 *>(d) = make_uint2(o[0] | o[1] << 8 | o[2] << 16 | o[3] << 24, o[4] | o[5] << 8 | o[6] << 16 | o[7] << 24);
                 else {
@@ -989,7 +991,16 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || ldsBytes < 1 || ldsBytes > 65536) return GMAT_ERR(EINVAL);
     S19Args a = a0;
     if (a.unit) {
-        for (int j = 0; j < 2; j++) a.unitBlk[j] = (int)((((long)(a.job[j].dstW + 7) >> 3) * a.job[j].dstH + 255) / 256);
+        for (int j = 0; j < 2; j++) {
+            const long upr = ((long)a.job[j].dstW + 7) >> 3;
+            a.unitBlk[j] = (int)((upr * a.job[j].dstH + 255) / 256);
+            if ((long)a.unitBlk[j] * 256 >= (1L << 31)) return GMAT_ERR(EINVAL);
+            // n / upr = (n m) >> (31 + L), L = ceil(log2 upr), m = floor(2^(31 + L) / upr) + 1 < 2^32: exact for n < 2^31 (the excess n e / (upr 2^(31 + L)) < 2^-L <= 1 / upr)
+            int L = 0;
+            while ((1L << L) < upr) L++;
+            a.unitMul[j] = upr > 1 ? (unsigned)(((1ULL << (31 + L)) / (unsigned long long)upr) + 1) : 0u;
+            a.unitShr[j] = upr > 1 ? L - 1 : 0;
+        }
         hipLaunchKernelGGL(scale19_unit_kernel, dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;

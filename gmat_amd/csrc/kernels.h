@@ -175,7 +175,7 @@ struct S19Tables {
     std::vector<int32_t> colStart[2], rowStart[2], rowCount[2];
 };
 struct S19Args { S19Job job[2]; int srcAl4, dstAl4, xcdRemap; int rgb64, chrShift, linesOff; Yuv2RgbConsts y2r;
-                 int unit, srcAl16, dstAl16, unitBlk[2]; };   // the unit form: planes and pitches on 16-byte addresses; blocks a frame's luma / chroma job takes
+                 int unit, srcAl16, dstAl16, unitBlk[2]; unsigned unitMul[2]; int unitShr[2]; };   // the unit form: planes and pitches on 16-byte addresses; blocks a frame's luma / chroma job takes; n / (units a row) = umulhi(n, unitMul) >> unitShr
 static_assert(sizeof(S19Args) + sizeof(Yuv2xFrames) <= 4096, "S19Args + Yuv2xFrames exceed the kernel-argument segment");
 // hl / hc / vl / vc: the 19-bit path's banks (the vertical ones after the one-tap forms' substitution); srcSemi / dstSemi: interleaved chroma
 // outMode / outShift: S19Job's; hsh: the horizontal shift of the 15-bit lines (outMode != 0)

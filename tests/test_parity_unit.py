@@ -57,7 +57,7 @@ def test_same_size_conversions(dev, orc, pair):
     and on odd-ish (2 + 2) addresses — the vector and the sample-by-sample forms of the loads and the stores"""
     sf, df = pair
     kernels = set()
-    for (w, h) in ((64, 16), (200, 37), (66, 10), (18, 7)):
+    for (w, h) in ((64, 16), (200, 37), (66, 10), (18, 7), (8, 6)):
         for align, extra in ((64, 0), (2, 2)):
             kernels.add(_run(dev, orc, sf, df, w, h, align, extra))
     if "scale19_unit_kernel" in kernels:
