@@ -1485,7 +1485,7 @@ static int scale19_frames(GmatSwsContext *c, int n, const uint8_t *const *src_pl
         if ((dA & 1) || (s16 && (sA & 1))) return GMAT_ERR(EINVAL);              // 16-bit samples sit on even addresses
         a.srcAl4 = (sA & 3) == 0; a.dstAl4 = (dA & 3) == 0;
         a.unit = c->s19.unit; a.srcAl16 = (sA & 15) == 0; a.dstAl16 = (dA & 15) == 0;
-        c->lastKernel = c->s19.unit ? "scale19_unit_kernel" : "scale19_kernel";
+        c->lastKernel = c->s19.unit == 1 ? "scale19_unit_kernel" : (c->s19.unit == 2 && a.srcAl16 && a.dstAl16) ? "scale19_unit64_kernel" : "scale19_kernel";
         if (int r = launch_scale19(a, c->s19.np, c->s19.ldsBytes, stream, &fr, m); r < 0) return r;
         c->lastLaunchFrames = m;
     }

@@ -461,6 +461,19 @@ __device__ __forceinline__ void s19_planes(const S19Args &a, int jx, uint8_t *ds
     }
 }
 
+// yuv2rgba64_X_c's colour stage from the three sums (output.c:1062-1100), one pixel: two dwords.  The five products are 24-bit ones (v_mul_i32_i24 / v_mad_i32_i24, full
+// rate; v_mul_lo_u32 is a quarter of it and was 20 of a pixel's 50 issue slots, r06y5): Y, U, V are sums >> 14 — within 2^18 — and the coefficients 16-bit values, so the low 32
+// bits of the 24-bit product ARE the 32-bit wrap-around product libswscale computes
+__device__ __forceinline__ void s19_rgb64_pixel(const Yuv2RgbConsts &k, int bgr, unsigned ay, unsigned au, unsigned av, unsigned &lo, unsigned &hi)
+{
+    const int U = (int)au >> 14, V = (int)av >> 14;
+    const unsigned Y = s19_mad(((int)ay >> 14) + 0x10000 - k.y_offset, k.y_coeff, 1u << 13);
+    const unsigned R = s19_mad(V, k.v2r, Y), G = s19_mad(U, k.u2g, s19_mad(V, k.v2g, Y)), B = s19_mad(U, k.u2b, Y);
+    auto ch = [&](unsigned v) -> unsigned { return (unsigned)min(max((int)v, 0), 0x3FFFFFFF) >> 14; };
+    const unsigned c0 = ch(bgr ? B : R), c1 = ch(G), c2 = ch(bgr ? R : B);
+    lo = c0 | c1 << 16; hi = c2 | 0xFFFF0000u;
+}
+
 // pass V + colour stage of an RGBA64LE / BGRA64LE destination: yuv2rgba64_X_c / _full_X_c (output.c:1025-1105, :1275-1337; the 1- and 2-tap forms are
 // the same sums on the effective coefficients, as vrgba64_kernel states them):
 //   Y = ((-2^30 + sum lum f) >> 14) + 2^16;  U, V = (-(128 << 23) + sum chr f) >> 14     (32-bit wrap-around sums)
@@ -507,15 +520,7 @@ __device__ __forceinline__ void s19_rgb64(const S19Args &a, uint8_t *dst0, int t
                 av0 = s19_mad(v1.x, c2.y, s19_mad(v0.x, c2.x, av0)); av1 = s19_mad(v1.y, c2.y, s19_mad(v0.y, c2.x, av1));
             }
         }
-        auto pixel = [&](unsigned ay, unsigned au, unsigned av, unsigned &lo, unsigned &hi) {
-            int Y = ((int)ay >> 14) + 0x10000;
-            const int U = (int)au >> 14, V = (int)av >> 14;
-            Y = (int)((unsigned)(Y - k.y_offset) * (unsigned)k.y_coeff) + (1 << 13);
-            const int R = (int)((unsigned)V * (unsigned)k.v2r), G = (int)((unsigned)V * (unsigned)k.v2g + (unsigned)U * (unsigned)k.u2g), B = (int)((unsigned)U * (unsigned)k.u2b);
-            auto ch = [&](int v) -> unsigned { return (unsigned)min(max((int)((unsigned)v + (unsigned)Y), 0), 0x3FFFFFFF) >> 14; };
-            const unsigned c0 = ch(a.rgb64 == 2 ? B : R), c1 = ch(G), c2 = ch(a.rgb64 == 2 ? R : B);
-            lo = c0 | c1 << 16; hi = c2 | 0xFFFF0000u;
-        };
+        auto pixel = [&](unsigned ay, unsigned au, unsigned av, unsigned &lo, unsigned &hi) { s19_rgb64_pixel(k, a.rgb64 == 2, ay, au, av, lo, hi); };
         unsigned d[4];
         pixel(ay0, au0, av0, d[0], d[1]);
         pixel(ay1, au1, av1, d[2], d[3]);
@@ -727,6 +732,118 @@ __global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrame
         };
         store(0, oa);
         if (J.ncomp == 2) store(1, ob);
+    }
+}
+
+// ---- the unit form of a packed 64-bit destination: yuv2rgb_cuda's RGBA64 / BGRA64 outputs at equal size (yuv2rgb_cuda.cu:862-907) ---------------------------
+// libswscale has no unscaled converter into the 64-bit formats: the generic path with identity horizontal banks, an identity vertical luma bank and the chroma's
+// vertical filter (4 : 2 : 0 rows interpolated: four taps under bicubic, one under point).  A thread: eight pixels of a row — their luma samples, per chroma tap
+// the four (4 : 4 : 4: eight) chroma samples under them straight from the tap's row, yuv2rgba64_X_c's sums and colour stage as s19_rgb64 states them, 64 bytes
+// stored.  Only for planes and pitches on 16-byte addresses and widths of whole units (launch_scale19: anything else is the tile form's).
+// LC: the chroma job's layout (0 / 2: planar 8- / 16-bit, 1 / 3: interleaved); CS: chroma columns = pixel columns >> CS
+template <int LC, int CS>
+__device__ __forceinline__ void s19u64_thread(const S19Args &a, const uint8_t *sy, const uint8_t *su, const uint8_t *sv, int x0, int y, unsigned (&d)[16])
+{
+    const S19Job &L = a.job[0], &C = a.job[1];
+    constexpr int NC = CS ? 4 : 8;                                              // chroma samples of a component under the thread's pixels
+    const bool shr6 = L.kind == 10;
+    const int shl = L.sh <= 14 ? 14 - L.sh : 0, shr = L.sh > 14 ? L.sh - 14 : 0, maxv = L.maxv;
+    // luma: eight samples, one line value each
+    unsigned ay[8];
+    {
+        int sa[8], sb[8];
+        if (L.layout == 0) s19u_load<0>(sy + ((unsigned)y * (unsigned)L.rawStride[0] + (unsigned)x0), nullptr, true, 8, false, sa, sb);
+        else               s19u_load<2>(sy + ((unsigned)y * (unsigned)L.rawStride[0] + (unsigned)(2 * x0)), nullptr, true, 8, shr6, sa, sb);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ay[i] = s19_mad(min((sa[i] << shl) >> shr, maxv), L.unitCoef, (unsigned)-0x40000000);
+    }
+    // chroma: the row's taps
+    unsigned au[NC], av[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) au[j] = av[j] = (unsigned)-(128 << 23);
+    const int vp = C.v.pairs, pos = C.v.pos_even[y];
+    const int cx = CS ? x0 >> 1 : x0;
+    constexpr int csb = LC == 0 ? 1 : LC == 3 ? 4 : 2;                          // bytes a chroma sample group
+    for (int t = 0; t < 2 * vp; t++) {
+        const int pk = C.v.packed[(size_t)y * vp + (t >> 1)];
+        const int cf = (t & 1) ? pk >> 16 : (int)(short)(pk & 0xFFFF);
+        const int rc = min(pos + t, C.srcH - 1);                                // (a padded tap past the plane: its coefficient is zero)
+        int cu[8], cv[8];
+        if (CS) {
+            // four samples a component: half a unit — 4 / 8 / 8 / 16 bytes
+            unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            if (LC == 0)      { r0 = *reinterpret_cast<const unsigned *>(su + ((unsigned)rc * (unsigned)C.rawStride[0] + (unsigned)cx));
+                                r1 = *reinterpret_cast<const unsigned *>(sv + ((unsigned)rc * (unsigned)C.rawStride[1] + (unsigned)cx)); }
+            else if (LC == 1) { const uint2 q = *reinterpret_cast<const uint2 *>(su + ((unsigned)rc * (unsigned)C.rawStride[0] + (unsigned)(2 * cx))); r0 = q.x; r1 = q.y; }
+            else if (LC == 2) { const uint2 q = *reinterpret_cast<const uint2 *>(su + ((unsigned)rc * (unsigned)C.rawStride[0] + (unsigned)(2 * cx)));
+                                const uint2 w = *reinterpret_cast<const uint2 *>(sv + ((unsigned)rc * (unsigned)C.rawStride[1] + (unsigned)(2 * cx))); r0 = q.x; r1 = q.y; r2 = w.x; r3 = w.y; }
+            else              { const uint4 q = *reinterpret_cast<const uint4 *>(su + ((unsigned)rc * (unsigned)C.rawStride[0] + (unsigned)(4 * cx))); r0 = q.x; r1 = q.y; r2 = q.z; r3 = q.w; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (LC == 0)      { cu[j] = (int)(r0 >> (8 * j) & 0xFFu); cv[j] = (int)(r1 >> (8 * j) & 0xFFu); }
+                else if (LC == 1) { const unsigned w = j < 2 ? r0 : r1; cu[j] = (int)(w >> (16 * (j & 1)) & 0xFFu); cv[j] = (int)(w >> (16 * (j & 1) + 8) & 0xFFu); }
+                else if (LC == 2) { cu[j] = (int)((j < 2 ? r0 : r1) >> (16 * (j & 1)) & 0xFFFFu); cv[j] = (int)((j < 2 ? r2 : r3) >> (16 * (j & 1)) & 0xFFFFu); }
+                else              { const unsigned w = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3; cu[j] = (int)(w & 0xFFFFu); cv[j] = (int)(w >> 16); }
+                if (LC >= 2 && shr6) { cu[j] >>= 6; cv[j] >>= 6; }
+            }
+        } else {
+            s19u_load<LC>(su + ((unsigned)rc * (unsigned)C.rawStride[0] + (unsigned)(cx * csb)), sv + ((unsigned)rc * (unsigned)C.rawStride[1] + (unsigned)(cx * csb)), true, 8,
+                          LC >= 2 && shr6, cu, cv);
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            au[j] = s19_mad(min((cu[j] << shl) >> shr, maxv), cf, au[j]);
+            av[j] = s19_mad(min((cv[j] << shl) >> shr, maxv), cf, av[j]);
+        }
+    }
+    const Yuv2RgbConsts &k = a.y2r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int j = CS ? i >> 1 : i;
+        s19_rgb64_pixel(k, a.rgb64 == 2, ay[i], au[j], av[j], d[2 * i], d[2 * i + 1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale19_unit64_kernel(S19Args a, Yuv2xFrames fr)
+{
+    // a thread's eight pixels are 64 bytes: stored as they are, a wave's store instruction would write 16 bytes of every 64 over 4 KB (7.1 us a 1080p frame, 0.35 of the
+    // roofline, whatever the arithmetic cost: r06y5 / r06y6).  The pixels go through LDS instead, and store q of a wave writes dwords [256 q, 256 q + 256) of the wave's
+    // 4 KB — whole lines; the units of a wave are consecutive ones of the frame, their rows found again per store
+    __shared__ uint4 xch[256 * 4];
+    const int nb = a.unitBlk[0];
+    const int f = blockIdx.x / nb, b = blockIdx.x - f * nb;
+    const S19Job &L = a.job[0], &C = a.job[1];
+    const int upr = L.dstW >> 3;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = b * 256 + tid;
+    auto row_of = [&](int i) -> int { return upr == 1 ? i : (int)(__umulhi((unsigned)i, a.unitMul[0]) >> a.unitShr[0]); };
+    const int y = row_of(idx), x0 = (idx - y * upr) * 8;
+    unsigned d[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = 0;
+    if (y < L.dstH) {
+        const uint8_t *sy = fr.y[f], *su = fr.u[f], *sv = fr.v[f];
+        if (a.chrShift) {
+            if (C.layout == 0)      s19u64_thread<0, 1>(a, sy, su, sv, x0, y, d);
+            else if (C.layout == 1) s19u64_thread<1, 1>(a, sy, su, sv, x0, y, d);
+            else if (C.layout == 2) s19u64_thread<2, 1>(a, sy, su, sv, x0, y, d);
+            else                    s19u64_thread<3, 1>(a, sy, su, sv, x0, y, d);
+        } else {
+            if (C.layout == 0)      s19u64_thread<0, 0>(a, sy, su, sv, x0, y, d);
+            else if (C.layout == 2) s19u64_thread<2, 0>(a, sy, su, sv, x0, y, d);
+        }
+    }
+    uint4 *mine = xch + wave * 256;
+#pragma unroll
+    for (int q = 0; q < 4; q++) mine[lane * 4 + q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+    __syncthreads();
+    uint8_t *dst = fr.dst[f];
+    const int wbase = b * 256 + wave * 64;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int e = q * 64 + lane, ts = e >> 2, slot = e & 3;               // the wave's dword-quad e: unit ts of the wave, its pixels 2 slot, 2 slot + 1
+        const int is = wbase + ts, ys = row_of(is), xs = (is - ys * upr) * 8;
+        if (ys < L.dstH) *reinterpret_cast<uint4 *>(dst + ((unsigned)ys * (unsigned)L.ds[0] + (unsigned)(8 * xs + 16 * slot))) = mine[e];
     }
 }
 
@@ -967,7 +1084,20 @@ void s19_unit_plan(const ScalePlan &p, const FilterBank &vl, const FilterBank &v
 {
     t.unit = 0;
     const char *ku = GMAT_KNOB("GMAT_S19_UNIT");
-    if (!t.ok || t.rgb64 || (ku && atoi(ku) == 0)) return;
+    if (!t.ok || (ku && atoi(ku) == 0)) return;
+    if (t.rgb64) {
+        // a packed 64-bit destination: identity horizontal banks, an identity vertical luma bank; the chroma's vertical bank is whatever it is (scale19_unit64_kernel);
+        // planar 4 : 4 : 4 or any 4 : 2 : 0 layout, rows of whole units
+        S19Job &L = t.job[0], &C = t.job[1];
+        if (L.srcW != L.dstW || L.srcH != L.dstH || C.srcW != C.dstW || (L.dstW & 7)) return;
+        if (C.dstW != (t.chrShift ? (L.dstW + 1) >> 1 : L.dstW) || (!t.chrShift && (C.layout & 1))) return;
+        if (s19_identity_coef(p.hLum, L.dstW) != 16384 || s19_identity_coef(p.hChr, C.dstW) != 16384) return;
+        const int cv = s19_identity_coef(vl, L.dstH);
+        if (cv <= 0 || cv >= (1 << 15) || vc.count != L.dstH || vc.pairs < 1) return;
+        L.unitCoef = cv; L.unitRound = 0;
+        t.unit = 2;
+        return;
+    }
     for (int j = 0; j < 2; j++) {
         S19Job &J = t.job[j];
         if (J.srcW != J.dstW || J.srcH != J.dstH) return;
@@ -990,7 +1120,9 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
 {
     if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || ldsBytes < 1 || ldsBytes > 65536) return GMAT_ERR(EINVAL);
     S19Args a = a0;
+    if (a.unit == 2 && !(a.srcAl16 && a.dstAl16)) a.unit = 0;                   // (the 64-bit unit form has no sample-by-sample path: the tile form takes odd planes)
     if (a.unit) {
+        if (a.unit == 2) a.job[1].dstW = 0, a.job[1].dstH = 0;                   // (one grid of pixel units: no blocks of the chroma job's own)
         for (int j = 0; j < 2; j++) {
             const long upr = ((long)a.job[j].dstW + 7) >> 3;
             a.unitBlk[j] = (int)((upr * a.job[j].dstH + 255) / 256);
@@ -1001,7 +1133,11 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
             a.unitMul[j] = upr > 1 ? (unsigned)(((1ULL << (31 + L)) / (unsigned long long)upr) + 1) : 0u;
             a.unitShr[j] = upr > 1 ? L - 1 : 0;
         }
-        hipLaunchKernelGGL(scale19_unit_kernel, dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
+        if (a.unit == 2) {
+            a.job[1].dstW = a0.job[1].dstW; a.job[1].dstH = a0.job[1].dstH;
+            hipLaunchKernelGGL(scale19_unit64_kernel, dim3(a.unitBlk[0] * nframes), dim3(256), 0, stream, a, *frames);
+        } else
+            hipLaunchKernelGGL(scale19_unit_kernel, dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }

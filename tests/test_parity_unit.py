@@ -154,3 +154,45 @@ def test_batch_is_one_launch(dev, orc, pair):
 def test_full_size(dev, orc, pair):
     sf, df = pair
     assert _run(dev, orc, sf, df, 1920, 1080, 64, 0) == "scale19_unit_kernel"
+
+
+SRC64 = ["nv12", "yuv420p", "p010le", "p016le", "yuv420p10le", "yuv420p16le", "yuv444p", "yuv444p16le"]
+
+
+@pytest.mark.parametrize("df", ["rgba64le", "bgra64le"])
+@pytest.mark.parametrize("sf", SRC64)
+def test_rgba64_at_equal_size(dev, orc, sf, df):
+    """yuv2rgb_cuda's 64-bit outputs (libswscale/cuda/yuv2rgb_cuda.cu:862-907) at equal size: identity horizontal banks, an identity vertical luma bank, the chroma's
+    vertical filter as it is (four taps under bicubic, two under bilinear, one under point) — scale19_unit64_kernel where the planes sit on 16-byte addresses and
+    the width is a multiple of 8, the tile form elsewhere; yuv2rgba64_X_c / _2_c / _1_c (output.c:1025-1270) in the oracle"""
+    for flags in ("bicubic", "bilinear", "point"):
+        assert _run(dev, orc, sf, df, 64, 18, 64, 0, flags=flags) == "scale19_unit64_kernel", (sf, df, flags)
+        assert _run(dev, orc, sf, df, 136, 11, 16, 0, flags=flags) == "scale19_unit64_kernel", (sf, df, flags)
+    assert _run(dev, orc, sf, df, 64, 18, 2, 2) == "scale19_kernel"                  # planes off 16-byte addresses
+    assert _run(dev, orc, sf, df, 68, 10, 64, 0) == "scale19_kernel"                 # a width that is not whole units
+
+
+def test_rgba64_unit_form_colourspaces_and_the_knob(dev, orc, monkeypatch):
+    lib = dev.lib
+    for sf, cs in (("nv12", 1), ("p010le", 9), ("yuv444p", 5)):
+        w, h = 72, 14
+        src = _synth(orc, sf, w, h, 77)
+        want = orc.sws(src, w, h, sf, w, h, "rgba64le", SWS["bicubic"], colorspace=cs)
+        c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT["rgba64le"], SWS["bicubic"], None)
+        assert c and lib.gmat_sws_setColorspace(c, cs, 0) == 0
+        d = dev.upload_planes(src, 64)
+        dst = dev.planes_like("rgba64le", w, h, 64)
+        assert lib.gmat_sws_scale(c, planes([p.ptr for p in d]), ints([p.stride for p in d]), 0, h, planes([p.ptr for p in dst]), ints([p.stride for p in dst])) == h
+        assert lib.gmat_sws_lastKernel(c).decode() == "scale19_unit64_kernel"
+        assert (dst[0].download() == want[0]).all(), (sf, cs)
+        lib.gmat_sws_freeContext(c)
+        for p in d + dst:
+            p.free()
+    monkeypatch.setenv("GMAT_S19_UNIT", "0")
+    assert _run(dev, orc, "nv12", "rgba64le", 64, 18, 64, 0) == "scale19_kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [("nv12", "rgba64le"), ("p010le", "bgra64le"), ("yuv444p16le", "rgba64le")], ids=lambda p: f"{p[0]}-{p[1]}")
+def test_rgba64_full_size(dev, orc, pair):
+    assert _run(dev, orc, pair[0], pair[1], 1920, 1080, 64, 0) == "scale19_unit64_kernel"
