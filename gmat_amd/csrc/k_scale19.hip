@@ -536,6 +536,13 @@ __device__ __forceinline__ void s19_rgb64(const S19Args &a, uint8_t *dst0, int t
     }
 }
 
+// the frame table of a ONE-frame launch of the unit forms: 48 bytes of kernel arguments instead of 1.5 KB (what sws_scale() / filter_frame() send: P010 -> NV12 1080p alone
+// 5.4 -> 5.0 us, r06y8)
+struct S19Frame1 {
+    const uint8_t *y[1], *u[1], *v[1];
+    uint8_t *dst[1], *dstU[1], *dstV[1];
+};
+
 template <int NP>
 __global__ __launch_bounds__(256) void scale19_kernel(S19Args a, Yuv2xFrames fr)
 {
@@ -656,7 +663,8 @@ __device__ __forceinline__ void s19u_samples(const S19Job &J, const int (&s)[8],
     }
 }
 
-__global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, Yuv2xFrames fr)
+template <class FR>
+__global__ __launch_bounds__(256) void scale19_unit_kernel(S19Args a, FR fr)
 {
     const int nb = a.unitBlk[0] + a.unitBlk[1];
     const int f = blockIdx.x / nb;
@@ -804,7 +812,8 @@ __device__ __forceinline__ void s19u64_thread(const S19Args &a, const uint8_t *s
     }
 }
 
-__global__ __launch_bounds__(256) void scale19_unit64_kernel(S19Args a, Yuv2xFrames fr)
+template <class FR>
+__global__ __launch_bounds__(256) void scale19_unit64_kernel(S19Args a, FR fr)
 {
     // a thread's eight pixels are 64 bytes: stored as they are, a wave's store instruction would write 16 bytes of every 64 over 4 KB (7.1 us a 1080p frame, 0.35 of the
     // roofline, whatever the arithmetic cost: r06y5 / r06y6).  The pixels go through LDS instead, and store q of a wave writes dwords [256 q, 256 q + 256) of the wave's
@@ -1133,11 +1142,16 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
             a.unitMul[j] = upr > 1 ? (unsigned)(((1ULL << (31 + L)) / (unsigned long long)upr) + 1) : 0u;
             a.unitShr[j] = upr > 1 ? L - 1 : 0;
         }
+        S19Frame1 f1;
+        f1.y[0] = frames->y[0]; f1.u[0] = frames->u[0]; f1.v[0] = frames->v[0]; f1.dst[0] = frames->dst[0]; f1.dstU[0] = frames->dstU[0]; f1.dstV[0] = frames->dstV[0];
         if (a.unit == 2) {
             a.job[1].dstW = a0.job[1].dstW; a.job[1].dstH = a0.job[1].dstH;
-            hipLaunchKernelGGL(scale19_unit64_kernel, dim3(a.unitBlk[0] * nframes), dim3(256), 0, stream, a, *frames);
-        } else
-            hipLaunchKernelGGL(scale19_unit_kernel, dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
+            if (nframes == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_unit64_kernel<S19Frame1>), dim3(a.unitBlk[0]), dim3(256), 0, stream, a, f1);
+            else              hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_unit64_kernel<Yuv2xFrames>), dim3(a.unitBlk[0] * nframes), dim3(256), 0, stream, a, *frames);
+        } else {
+            if (nframes == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_unit_kernel<S19Frame1>), dim3(a.unitBlk[0] + a.unitBlk[1]), dim3(256), 0, stream, a, f1);
+            else              hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_unit_kernel<Yuv2xFrames>), dim3((a.unitBlk[0] + a.unitBlk[1]) * nframes), dim3(256), 0, stream, a, *frames);
+        }
         GMAT_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1145,6 +1159,7 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
     const Yuv2xFrames &fr = *frames;
     const char *kx = GMAT_KNOB("GMAT_SCALE_XCD");
     a.xcdRemap = kx ? atoi(kx) != 0 : 1;
+    // (a 48-byte frame table for one-frame launches of THIS kernel was measured, r06y8: nothing — its one-frame time is the blocks' latency chains)
     switch (np) {
     case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<4>), grid, block, ldsBytes, stream, a, fr); break;
     case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<8>), grid, block, ldsBytes, stream, a, fr); break;
