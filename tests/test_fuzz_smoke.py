@@ -8,7 +8,7 @@ import sys
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FUZZERS = ["fuzz_parity.py", "fuzz_transforms.py", "fuzz_yuvopts.py", "fuzz_filters.py", "fuzz_strip.py", "fuzz_walker.py"]
+FUZZERS = ["fuzz_parity.py", "fuzz_transforms.py", "fuzz_yuvopts.py", "fuzz_unit.py", "fuzz_filters.py", "fuzz_strip.py", "fuzz_walker.py"]
 
 
 def _run(name, ncases, seed, hip):

@@ -63,7 +63,7 @@ for STEP in "$@"; do
           cp /tmp/libgmat_hip_shipped.so gmat_amd/lib/libgmat_hip.so ;;
   ops) echo "== filter ops, one 4K frame per launch" | tee $OUT/ops.txt; timeout 200 tools/bin/x2bench 1 50 "op: " 2>&1 | tee -a $OUT/ops.txt ;;
   fuzz) N=${A[1]:-2000}; SEED=${A[2]:-301}
-        for f in fuzz_strip fuzz_walker fuzz_parity fuzz_yuvopts fuzz_transforms fuzz_filters; do
+        for f in fuzz_strip fuzz_walker fuzz_parity fuzz_yuvopts fuzz_unit fuzz_transforms fuzz_filters; do
           timeout 1500 python tests/fuzz/$f.py $N $SEED --hip > $OUT/$f.log 2>&1; echo "$f seed $SEED n $N: rc=$? $(tail -1 $OUT/$f.log)"
           { [ $f = fuzz_strip ] || [ $f = fuzz_walker ]; } && tail -24 $OUT/$f.log | head -23
         done | tee $OUT/fuzz.txt ;;

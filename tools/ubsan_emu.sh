@@ -28,7 +28,7 @@ for l in open("/proc/self/maps"):
 sys.argv = [sys.argv[1]] + sys.argv[2:]
 runpy.run_path(sys.argv[0], run_name="__main__")
 PY
-for f in fuzz_parity fuzz_strip fuzz_walker fuzz_yuvopts fuzz_transforms fuzz_filters; do
+for f in fuzz_parity fuzz_strip fuzz_walker fuzz_yuvopts fuzz_unit fuzz_transforms fuzz_filters; do
   python $OUT/run.py $R/tests/fuzz/$f.py $N 4321 2> $OUT/err_$f.txt | tail -1 | sed "s/^/$f: /"
 done
 python3 - $OUT <<'PY'
