@@ -501,7 +501,9 @@ static int init_scale16(GmatSwsContext *c)
     } else {
         if (vl.taps == 1) { std::fill(vl.coef.begin(), vl.coef.end(), (int16_t)4096); pack_filter_pairs(vl); }
         // planar chroma goes through yuv2plane1_16_c too when its filter has one tap; interleaved chroma never does
-        if (vc.taps == 1 && c->dstFormat == GMAT_PIX_FMT_YUV444P16LE) { std::fill(vc.coef.begin(), vc.coef.end(), (int16_t)4096); pack_filter_pairs(vc); }
+        // (every planar 16-bit destination: round 6's fuzz_unit found YUV420P16LE left out — a one-tap chroma bank whose coefficient is not 4096, which extreme chroma
+        // positions produce at a plane's first row, wrote zeros where libswscale writes the line)
+        if (vc.taps == 1 && is_pl16_dst(c->dstFormat)) { std::fill(vc.coef.begin(), vc.coef.end(), (int16_t)4096); pack_filter_pairs(vc); }
     }
     const std::vector<int32_t> none(std::max(std::max(c->dstW, c->dstH), 1), 0);
     if ((r = c->f16[0].upload(p.hLum, none, c->d16[0])) < 0) return r;

@@ -75,19 +75,19 @@ def test_unit_form_is_taken_and_agrees_with_the_tile_form(dev, orc, pair, monkey
     assert _run(dev, orc, sf, df, 136, 22, 64, 0) != "scale19_unit_kernel"
 
 
-def _ex(dev, orc, sf, df, w, h, ranges, pos, seed):
+def _ex(dev, orc, sf, df, w, h, ranges, pos, seed, flags="bicubic"):
     """one call with ranges and chroma positions set at both ends: the library's planes and kernel against the oracle's"""
     L, lib = orc.L, dev.lib
     L.orc_sws_create_ex.restype = C.c_void_p
     L.orc_sws_create_ex.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     src = _synth(orc, sf, w, h, seed)
-    oc = L.orc_sws_create_ex(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None, (C.c_int * 4)(*pos), ranges[0], ranges[1])
+    oc = L.orc_sws_create_ex(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS[flags], None, (C.c_int * 4)(*pos), ranges[0], ranges[1])
     assert oc
     want = alloc_planes(df, w, h)
     assert L.orc_sws_scale(oc, planes([p.ctypes.data for p in src]), ints([p.strides[0] for p in src]),
                            planes([p.ctypes.data for p in want]), ints([p.strides[0] for p in want])) == h
     L.orc_sws_free(oc)
-    c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS["bicubic"], None)
+    c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT[df], SWS[flags], None)
     assert c and lib.gmat_sws_setRange(c, ranges[0], ranges[1]) == 0 and lib.gmat_sws_setChromaPos(c, *pos) == 0
     d = dev.upload_planes(src, 64)
     dst = dev.planes_like(df, w, h, 64)
@@ -115,6 +115,19 @@ def test_differing_chroma_positions_are_filters(dev, orc):
     for sf, df in (("p010le", "nv12"), ("nv12", "yuv420p16le")):
         assert _ex(dev, orc, sf, df, 96, 20, (0, 0), (0, 128, 128, 128), 3) != "scale19_unit_kernel"
         assert _ex(dev, orc, sf, df, 96, 20, (0, 0), (128, 0, 128, 0), 3) == "scale19_unit_kernel"          # (the same at both ends: identities)
+
+
+@pytest.mark.parametrize("df", ["yuv420p16le", "yuv444p16le", "p016le", "yuv420p10le"])
+def test_one_tap_chroma_bank_whose_coefficient_is_not_the_unit(dev, orc, df):
+    """found by tests/fuzz/fuzz_unit.py (seed 72001, case 757): a destination chroma position far above the plane makes initFilter's one-tap vertical chroma bank carry the
+    coefficient 0 at the first row; yuv2plane1_* does not read the coefficient (vscale.c:30-105) and writes the line, the X form with the bank as it is writes the sums' floor —
+    YUV420P16LE was left out of the planar 16-bit destinations' substitution (init_scale16) since round 4"""
+    for sf in ("nv12", "yuv420p", "p010le"):
+        if sf == df or (sf == "yuv420p" and df in ("p016le",)):
+            continue
+        for ranges in ((1, 0), (0, 0)):
+            _ex(dev, orc, sf, df, 278, 6, ranges, (192, 256, 192, -263), 2757, flags="bilinear")
+            _ex(dev, orc, sf, df, 64, 9, ranges, (-513, -513, 0, -400), 11, flags="point")
 
 
 @pytest.mark.parametrize("pair", [("p010le", "nv12"), ("nv12", "yuv420p16le"), ("yuv420p10le", "p016le")], ids=lambda p: f"{p[0]}-{p[1]}")
