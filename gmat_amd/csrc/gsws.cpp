@@ -193,6 +193,7 @@ struct GmatSwsContext {
     S19Tables t15;                    // (round 6) the same tile kernel on the 15-bit lines (8- and 10-bit YUV destinations): the pairs no walker serves — a layout change, a 4:4:4 end
     DevBuf dT15[6];
     bool t15Mixed = false;            // ... semi-planar <-> planar, or 4:4:4 at one end: in front of the lines form below 4 : 1
+    UnitRgbPlan urgb;                 // (round 6) 16-bit 4:2:0 sources into packed 8-bit RGB at equal size: unit_rgb_kernel (k_scale19.hip)
     unsigned long long *prof = nullptr;
     hipEvent_t batchEv[9] = {nullptr};
     bool batchEvReady = false;
@@ -361,6 +362,9 @@ static int init_yuv_scaler(GmatSwsContext *c)
     }
     // (round 6) the tile kernel of k_scale19.hip on the 15-bit lines: any plane layout and depth in, 8- or 10-bit YUV out (kPlaneKernels: behind every walker, in front
     // of the tiled catch-all; in front of the lines form where the layouts differ and the ratio is below 4 : 1).  GMAT_T15=0: never
+    c->urgb.ok = 0;
+    if ((a.src16 == 10 || a.src16 == 16 || a.src16 == 17 || a.src16 == 18) && is_packed_rgb(c->dstFormat) && !c->rgbViaPlanes && is_plane_src(c->srcFormat) && !is_priv_planes(c->srcFormat))
+        unit_rgb_plan(c->planYuv, t.vLumEff, t.lumRound.data(), t.fullChroma, c->urgb);
     c->t15.ok = 0; c->t15Mixed = false;
     {
         const char *k15 = GMAT_KNOB("GMAT_T15");
@@ -1122,7 +1126,37 @@ struct PlaneKernel {
     const char *(*name)(const GmatSwsContext *c, const YuvScaleArgs &ya, int n);
     int (*launch)(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t stream, const Yuv2xFrames &fr, int n);
 };
+// 16-bit 4:2:0 sources into packed 8-bit RGB at equal size: this call's planes and pitches on 16-byte addresses (unit_rgb_kernel's loads and 8-byte pieces)
+static bool unit_rgb_eligible(const GmatSwsContext *c, const YuvScaleArgs &ya)
+{
+    // (src16: 10 P010LE, 16 P016LE — interleaved chroma —, 17 / 18 planar 16- / 10-bit)
+    if (!c->urgb.ok || ya.prof || !(ya.src16 == 10 || ya.src16 == 16 || ya.src16 == 17 || ya.src16 == 18)) return false;
+    const bool semi = ya.src16 == 10 || ya.src16 == 16;
+    uintptr_t all = (uintptr_t)ya.y | (uintptr_t)ya.ys | (uintptr_t)ya.u | (uintptr_t)ya.us | (uintptr_t)ya.dst | (uintptr_t)ya.ds;
+    if (!semi) { if (!ya.v) return false; all |= (uintptr_t)ya.v | (uintptr_t)ya.vs; }
+    return (all & 15) == 0;
+}
+static int launch_unit_rgb_frames(const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n)
+{
+    UnitRgbArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.w = ya.dstW; a.h = ya.dstH; a.chrH = ya.chrSrcH;
+    a.semi = (ya.src16 == 10 || ya.src16 == 16) ? 1 : 0; a.shr6 = ya.src16 == 10 ? 1 : 0;       // (P010LE: ten bits in the high end)
+    a.ys = ya.ys; a.us = ya.us; a.vs = a.semi ? 0 : ya.vs; a.ds = ya.ds;
+    a.shl = ya.hShift <= 14 ? 14 - ya.hShift : 0; a.shr = ya.hShift > 14 ? ya.hShift - 14 : 0; a.maxv = 32767;      // hScale16To15_c with one coefficient of 2^14
+    a.coefL = c->urgb.coefL; a.roundL = c->urgb.roundL;
+    a.vChr = ya.vChr;
+    a.px = bytes_per_pixel(c->dstFormat); a.bgr = (c->dstFormat == GMAT_PIX_FMT_BGR24 || c->dstFormat == GMAT_PIX_FMT_BGRA) ? 1 : 0;
+    a.y2r = ya.y2r;
+    return launch_unit_rgb(a, st, &fr, n);
+}
+
 static const PlaneKernel kPlaneKernels[] = {
+    // (round 6, last hours) P010 / P016 / planar 10- / 16-bit 4:2:0 into packed 8-bit RGB at equal size — no unscaled converter in libswscale, 7.3-9.5 us a 1080p frame on the
+    // 16-bit walker: the unit form of the RGB writer
+    {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return unit_rgb_eligible(c, ya); },
+     [](const GmatSwsContext *, const YuvScaleArgs &, int) -> const char * { return "unit_rgb_kernel"; },
+     [](const GmatSwsContext *c, const YuvScaleArgs &ya, hipStream_t st, const Yuv2xFrames &fr, int n) { return launch_unit_rgb_frames(c, ya, st, fr, n); }},
     // (round 6, last third) equal size with one-tap identity banks — yuv2yuv_cuda's same-size conversions between depths and layouts that libswscale runs through its
     // generic scaler: the tile kernel's unit form, a sample a multiply and a shift (in front of every walker: they took 5.2-6.5 us a 1080p frame for what is a copy's bytes)
     {[](const GmatSwsContext *c, const YuvScaleArgs &ya, int) { return c->t15.ok && c->t15.unit && !ya.prof; },
@@ -1231,8 +1265,8 @@ static const PlaneKernel kPlaneKernels[] = {
          return n == 1 ? launch_scale_yuv(ya, c->ytiling, st) : launch_scale_yuv(ya, c->ytiling, st, &fr, n); }},
 };
 constexpr int kNumPlaneKernels = (int)(sizeof(kPlaneKernels) / sizeof(kPlaneKernels[0]));
-// the three records of the tile kernel on the 15-bit lines (launch_tile15): the first (its unit form), the second and the fourth from the end
-static bool plane_record_is_tile(int k) { return k == 0 || k == kNumPlaneKernels - 2 || k == kNumPlaneKernels - 4; }
+// the records that are not walkers of the context's own (the cascade's rule): the two unit forms in front, the tile kernel on the 15-bit lines second and fourth from the end
+static bool plane_record_is_tile(int k) { return k == 0 || k == 1 || k == kNumPlaneKernels - 2 || k == kNumPlaneKernels - 4; }
 
 // argument block of the strip-walking packed-RGB scaler
 static Rgb2sArgs make_rgb2s_args(const GmatSwsContext *c, int srcStride, int dstStride, bool srcBgr)

@@ -856,6 +856,92 @@ __global__ __launch_bounds__(256) void scale19_unit64_kernel(S19Args a, FR fr)
     }
 }
 
+// ---- 16-bit 4:2:0 sources into packed 8-bit RGB at equal size (kernels.h UnitRgbArgs) -------------------------------------------------------------------------
+// A thread: eight pixels of a row.  Luma: Y = (roundL + line coefL) >> 19; chroma: per tap of the row's vertical bank the four (U, V) samples under the pixels from
+// the tap's row, U / V = clip_u8((round + sum) >> 19); the pixel from yuv2rgb.c's tables in closed form (chroma_terms / luma_chan).  PX bytes a pixel; the wave's
+// pixels go through LDS and leave as 8-byte pieces in address order (whole lines a store, as scale19_unit64_kernel's)
+// SRC: 0 planar chroma, 1 interleaved (P016LE), 2 interleaved with ten bits in the high end (P010LE) — template arguments: as run-time flags their branches sat around every
+// tap and sample (P010 6.6 us a 1080p frame against the planar sources' 5.4, r06y10)
+template <int PX, int SRC, class FR>
+__global__ __launch_bounds__(256) void unit_rgb_kernel(UnitRgbArgs a, FR fr)
+{
+    __shared__ uint2 xch[256 * PX];
+    const int f = blockIdx.x / a.blocks, b = blockIdx.x - f * a.blocks;
+    const int upr = a.w >> 3;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = b * 256 + tid;
+    auto row_of = [&](int i) -> int { return upr == 1 ? i : (int)(__umulhi((unsigned)i, a.rowMul) >> a.rowShr); };
+    const int y = row_of(idx), x0 = (idx - y * upr) * 8;
+    unsigned d[2 * PX];
+#pragma unroll
+    for (int i = 0; i < 2 * PX; i++) d[i] = 0;
+    if (y < a.h) {
+        const uint8_t *sy = fr.y[f], *su = fr.u[f], *sv = fr.v[f];
+        int ly[8];
+        {
+            int sb[8];
+            s19u_load<2>(sy + ((unsigned)y * (unsigned)a.ys + (unsigned)(2 * x0)), nullptr, true, 8, SRC == 2, ly, sb);
+        }
+        int U[4], V[4];
+        const int vp = a.vChr.pairs, pos = a.vChr.pos_even[y], rnd = a.vChr.round[y];
+#pragma unroll
+        for (int j = 0; j < 4; j++) U[j] = V[j] = rnd;
+        const int cx = x0 >> 1;
+        for (int t = 0; t < 2 * vp; t++) {
+            const int pk = a.vChr.packed[(size_t)y * vp + (t >> 1)];
+            const int cf = (t & 1) ? pk >> 16 : (int)(short)(pk & 0xFFFF);
+            if (cf == 0) continue;                                              // (the pairs' padding, a bank's zero taps: a third of a bicubic bank's slots at equal size)
+            const int rc = min(pos + t, a.chrH - 1);                            // (a padded tap past the plane: its coefficient is zero)
+            unsigned r0, r1, r2, r3;
+            if (SRC) { const uint4 q = *reinterpret_cast<const uint4 *>(su + ((unsigned)rc * (unsigned)a.us + (unsigned)(4 * cx))); r0 = q.x; r1 = q.y; r2 = q.z; r3 = q.w; }
+            else { const uint2 q = *reinterpret_cast<const uint2 *>(su + ((unsigned)rc * (unsigned)a.us + (unsigned)(2 * cx)));
+                   const uint2 w = *reinterpret_cast<const uint2 *>(sv + ((unsigned)rc * (unsigned)a.vs + (unsigned)(2 * cx))); r0 = q.x; r1 = q.y; r2 = w.x; r3 = w.y; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int cu, cv;
+                if (SRC) { const unsigned w = j == 0 ? r0 : j == 1 ? r1 : j == 2 ? r2 : r3; cu = (int)(w & 0xFFFFu); cv = (int)(w >> 16); }
+                else        { cu = (int)((j < 2 ? r0 : r1) >> (16 * (j & 1)) & 0xFFFFu); cv = (int)((j < 2 ? r2 : r3) >> (16 * (j & 1)) & 0xFFFFu); }
+                if (SRC == 2) { cu >>= 6; cv >>= 6; }
+                U[j] = (int)s19_mad(min((cu << a.shl) >> a.shr, a.maxv), cf, (unsigned)U[j]);
+                V[j] = (int)s19_mad(min((cv << a.shl) >> a.shr, a.maxv), cf, (unsigned)V[j]);
+            }
+        }
+        unsigned px[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // table_rV / gU / gV / bU are indexed with av_clip_uint8 (yuv2rgb.c:737-760)
+            const ChromaTerms t = chroma_terms(a.y2r, clip_u8_shr(U[j], 19), clip_u8_shr(V[j], 19));
+#pragma unroll
+            for (int i = 2 * j; i < 2 * j + 2; i++) {
+                const int Y = (int)s19_mad(min((ly[i] << a.shl) >> a.shr, a.maxv), a.coefL, (unsigned)a.roundL) >> 19;
+                const int ya = m24(Y, a.y2r.cy);
+                const unsigned r = (unsigned)luma_chan(t.r, ya), g = (unsigned)luma_chan(t.g, ya), bl = (unsigned)luma_chan(t.b, ya);
+                px[i] = a.bgr ? (bl | g << 8 | r << 16) : (r | g << 8 | bl << 16);
+            }
+        }
+        if (PX == 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = px[i] | 0xFF000000u;
+        } else {
+            // eight 3-byte pixels in six dwords
+            d[0] = px[0] | px[1] << 24;          d[1] = px[1] >> 8 | px[2] << 16;     d[2] = px[2] >> 16 | px[3] << 8;
+            d[3] = px[4] | px[5] << 24;          d[4] = px[5] >> 8 | px[6] << 16;     d[5] = px[6] >> 16 | px[7] << 8;
+        }
+    }
+    uint2 *mine = xch + wave * 64 * PX;
+#pragma unroll
+    for (int q = 0; q < PX; q++) mine[lane * PX + q] = make_uint2(d[2 * q], d[2 * q + 1]);
+    __syncthreads();
+    uint8_t *dst = fr.dst[f];
+    const int wbase = b * 256 + wave * 64;
+#pragma unroll
+    for (int q = 0; q < PX; q++) {
+        const int e = q * 64 + lane, ts = e / PX, slot = e - ts * PX;          // the wave's 8-byte piece e: unit ts of the wave, its piece `slot`
+        const int is = wbase + ts, ys = row_of(is), xs = (is - ys * upr) * 8;
+        if (ys < a.h) *reinterpret_cast<uint2 *>(dst + ((unsigned)ys * (unsigned)a.ds + (unsigned)(PX * xs + 8 * slot))) = mine[e];
+    }
+}
+
 // ---- the planner (host) ---------------------------------------------------------------------------------------------------------------------
 // Refuses (ENOSYS: the two passes take the context) a bank whose padded taps past the plane are not all zero or whose coefficients could
 // carry a biased sum past 2^31, and rows of more than 128 staging units.
@@ -1165,6 +1251,41 @@ int launch_scale19(const S19Args &a0, int np, int ldsBytes, hipStream_t stream, 
     case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<8>), grid, block, ldsBytes, stream, a, fr); break;
     default: hipLaunchKernelGGL(HIP_KERNEL_NAME(scale19_kernel<0>), grid, block, ldsBytes, stream, a, fr); break;
     }
+    GMAT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+void unit_rgb_plan(const ScalePlan &p, const FilterBank &vl, const int32_t *lumRound, int fullChroma, UnitRgbPlan &u)
+{
+    u.ok = 0;
+    const char *ku = GMAT_KNOB("GMAT_S19_UNIT");
+    if ((ku && atoi(ku) == 0) || fullChroma || !lumRound) return;
+    if (p.srcW != p.dstW || p.srcH != p.dstH || (p.dstW & 7) || p.chrDstW != (p.dstW + 1) / 2 || p.chrSrcW != p.chrDstW) return;
+    if (s19_identity_coef(p.hLum, p.dstW) != 16384 || s19_identity_coef(p.hChr, p.chrDstW) != 16384) return;
+    const int cv = s19_identity_coef(vl, p.dstH);
+    if (cv <= 0 || cv >= (1 << 15)) return;
+    for (int y = 1; y < p.dstH; y++) if (lumRound[y] != lumRound[0]) return;
+    u.coefL = cv; u.roundL = lumRound[0];
+    u.ok = 1;
+}
+
+int launch_unit_rgb(const UnitRgbArgs &a0, hipStream_t stream, const Yuv2xFrames *frames, int nframes)
+{
+    if (!frames || nframes < 1 || nframes > kYuv2xMaxFrames || (a0.w & 7) || a0.w < 8 || a0.h < 1 || (a0.px != 3 && a0.px != 4)) return GMAT_ERR(EINVAL);
+    UnitRgbArgs a = a0;
+    const long upr = a.w >> 3;
+    a.blocks = (int)((upr * a.h + 255) / 256);
+    if ((long)a.blocks * 256 >= (1L << 31)) return GMAT_ERR(EINVAL);
+    int L = 0;
+    while ((1L << L) < upr) L++;
+    a.rowMul = upr > 1 ? (unsigned)(((1ULL << (31 + L)) / (unsigned long long)upr) + 1) : 0u;     // (launch_scale19's multiplier)
+    a.rowShr = upr > 1 ? L - 1 : 0;
+    const dim3 grid(a.blocks * nframes), block(256);
+    const int srck = a.semi ? (a.shr6 ? 2 : 1) : 0;
+#define URGB_LAUNCH(PX_, S_) hipLaunchKernelGGL(HIP_KERNEL_NAME(unit_rgb_kernel<PX_, S_, Yuv2xFrames>), grid, block, 0, stream, a, *frames)
+    if (a.px == 3) { if (srck == 0) URGB_LAUNCH(3, 0); else if (srck == 1) URGB_LAUNCH(3, 1); else URGB_LAUNCH(3, 2); }
+    else           { if (srck == 0) URGB_LAUNCH(4, 0); else if (srck == 1) URGB_LAUNCH(4, 1); else URGB_LAUNCH(4, 2); }
+#undef URGB_LAUNCH
     GMAT_HIP_CHECK(hipGetLastError());
     return 0;
 }

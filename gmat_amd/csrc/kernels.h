@@ -186,6 +186,24 @@ int launch_scale19(const S19Args &a, int np, int ldsBytes, hipStream_t stream, c
 // coefficient and start value for every row.  lumRound / chrRound: the 15-bit writers' start values a row (YuvScaleTiling's), nullptr for the 16-bit writers' constant
 void s19_unit_plan(const ScalePlan &p, const FilterBank &vl, const FilterBank &vc, const int32_t *lumRound, const int32_t *chrRound, S19Tables &t);
 
+// ---- 16-bit 4:2:0 sources into packed 8-bit RGB at equal size: the unit form of the 15-bit lines' RGB writer (unit_rgb_kernel, k_scale19.hip) -------------
+// P010 / P016 / planar 10- / 16-bit sources have no unscaled converter in libswscale: identity horizontal banks, an identity vertical luma bank, the chroma's
+// vertical filter, yuv2rgb_X_c's table arithmetic in closed form (px_math.h).  Host: unit_rgb_plan; per call: planes and pitches on 16-byte addresses.
+struct UnitRgbArgs {
+    int w, h, chrH;                       // pixels (w a multiple of 8), chroma rows of the source
+    int ys, us, vs, ds;                   // pitches: luma, chroma (us only where interleaved), destination
+    int semi, shr6, shl, shr, maxv;       // interleaved chroma; P010's >> 6; a line value = min((s << shl) >> shr, maxv)
+    int coefL, roundL;                    // the vertical luma bank's one coefficient, the luma sums' start value
+    DevFilter vChr;                       // the chroma's vertical bank (packed pairs, pos_even, round: device pointers)
+    int px, bgr;                          // bytes a pixel (3 | 4); blue first
+    Yuv2RgbConsts y2r;
+    int blocks; unsigned rowMul; int rowShr;     // blocks a frame; idx / (units a row) = umulhi(idx, rowMul) >> rowShr
+};
+struct UnitRgbPlan { int ok = 0, coefL = 0, roundL = 0; };
+// ok = 1 when the plan is an equal-size one with identity horizontal banks and an identity vertical luma bank of ONE start value (vl: the effective bank, lumRound: its rows')
+void unit_rgb_plan(const ScalePlan &p, const FilterBank &vl, const int32_t *lumRound, int fullChroma, UnitRgbPlan &u);
+int launch_unit_rgb(const UnitRgbArgs &a, hipStream_t stream, const Yuv2xFrames *frames, int nframes);
+
 // RGBA64LE / BGRA64LE from the 19-bit lines; chrShift 1: one chroma sample per pixel pair, 0: per pixel (full chroma)
 int launch_vrgba64(const int32_t *ly, const int32_t *lu, const int32_t *lv, int lumW, int lumH, int chrW, int chrH, const DevFilter &fl,
                    const DevFilter &fc, int chrShift, uint8_t *dst, int dstStride, int dstW, int dstH, int bgr, const Yuv2RgbConsts &k,

@@ -67,7 +67,7 @@ def is_generic(kernel):
     (scale_yuvg_kernel: dword-aligned 8-bit 4:2:0 -> packed RGB / 4:2:0 of the same chroma layout, filters up to 20 x 18 taps) or
     the tiled plane scaler of round 1 behind it (scale_yuv_kernel<...>).  WHICH of the two a context gets is asserted by
     tests/test_parity_generic_walker.py clause by clause; the per-ratio test files only need "not a specialised walker"."""
-    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", QUAD, LINES, LINES16, RGB2P, "scale19_kernel", "scale19_unit_kernel", "scale19_unit64_kernel") + WALK16 or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4; QUAD: the quad-lane walker of up-scales, round 4)
+    return kernel in ("scale_yuvg_kernel", "scale_yuvg_blk_kernel", QUAD, LINES, LINES16, RGB2P, "scale19_kernel", "scale19_unit_kernel", "scale19_unit64_kernel", "unit_rgb_kernel") + WALK16 or kernel.startswith("scale_yuv_kernel")      # (_blk_: the walker's one-frame form, round 4; QUAD: the quad-lane walker of up-scales, round 4)
 
 
 @pytest.fixture(autouse=True)

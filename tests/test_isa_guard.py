@@ -129,7 +129,7 @@ def test_strip_kernels_use_no_scratch_memory(disassembly):
     (The round-1 tiled kernels scale_rgb_kernel / scale_yuv2x_kernel carry 20 - 188 bytes of it; they are not listed.)"""
     strip = ("scale_yuv2s_kernel", "scale_yuv2s_blk_kernel", "scale_yuv2s_np_kernel", "scale_yuv2p_kernel", "scale_yuv2px_kernel", "scale_yuv1x2_kernel", "scale_yuv3x1_kernel", "scale_yuv3r_kernel", "scale_yuv3x2_kernel", "scale_yuv32r_kernel", "scale_yuv4r_kernel", "scale_yuv4x1_kernel",
              "scale_yuvg_blk_rgb_kernel", "scale_yuvg_blk_planes_kernel", "scale_yuvu_rgb_kernel", "scale_yuvu_planes_kernel", "scale_rgb2s_kernel", "scale_rgb2h_kernel", "scale_rgb2y_kernel", "rgb2yuv420s_kernel", "smooth121_kernel",
-             "scale19_kernel", "scale19_unit_kernel", "scale19_unit64_kernel")          # (round 6: handing the frame table to its device functions by reference copied 1.5 KB into every lane's scratch — seven times slower, profiles/r06_scale19_history.txt r06l)
+             "scale19_kernel", "scale19_unit_kernel", "scale19_unit64_kernel", "unit_rgb_kernel")          # (round 6: handing the frame table to its device functions by reference copied 1.5 KB into every lane's scratch — seven times slower, profiles/r06_scale19_history.txt r06l)
     hits, seen = {}, set()
     for t in disassembly:
         func = None

@@ -209,3 +209,52 @@ def test_rgba64_unit_form_colourspaces_and_the_knob(dev, orc, monkeypatch):
 @pytest.mark.parametrize("pair", [("nv12", "rgba64le"), ("p010le", "bgra64le"), ("yuv444p16le", "rgba64le")], ids=lambda p: f"{p[0]}-{p[1]}")
 def test_rgba64_full_size(dev, orc, pair):
     assert _run(dev, orc, pair[0], pair[1], 1920, 1080, 64, 0) == "scale19_unit64_kernel"
+
+
+@pytest.mark.parametrize("df", ["rgb24", "bgr24", "rgba", "bgra"])
+@pytest.mark.parametrize("sf", ["p010le", "p016le", "yuv420p10le", "yuv420p16le"])
+def test_deep_sources_into_rgb_at_equal_size(dev, orc, sf, df):
+    """P010 / P016 / planar 10- and 16-bit 4:2:0 into packed 8-bit RGB at equal size: no unscaled converter in libswscale — hScale16To15_c with one coefficient, the chroma's
+    vertical filter, yuv2rgb_X_c / _2_c / _1_c by the filter family (output.c:1600-1800) — unit_rgb_kernel where the planes sit on 16-byte addresses and the width is a multiple
+    of 8, the walkers elsewhere"""
+    for flags in ("bicubic", "bilinear", "point"):
+        assert _run(dev, orc, sf, df, 64, 18, 64, 0, flags=flags) == "unit_rgb_kernel", (sf, df, flags)
+        assert _run(dev, orc, sf, df, 136, 11, 16, 0, flags=flags) == "unit_rgb_kernel", (sf, df, flags)
+    assert _run(dev, orc, sf, df, 64, 18, 2, 2) != "unit_rgb_kernel"                  # planes off 16-byte addresses
+    assert _run(dev, orc, sf, df, 68, 10, 64, 0) != "unit_rgb_kernel"                 # a width that is not whole units
+
+
+def test_deep_sources_into_rgb_colourspaces_batches_and_the_knob(dev, orc, monkeypatch):
+    lib = dev.lib
+    for sf, cs in (("p010le", 1), ("yuv420p16le", 9), ("p016le", 5)):
+        w, h, nf = 72, 14, 3
+        srcs = [_synth(orc, sf, w, h, 90 + f) for f in range(nf)]
+        wants = [orc.sws(s_, w, h, sf, w, h, "bgra", SWS["bicubic"], colorspace=cs) for s_ in srcs]
+        c = lib.gmat_sws_getContext(w, h, PIX_FMT[sf], w, h, PIX_FMT["bgra"], SWS["bicubic"], None)
+        assert c and lib.gmat_sws_setColorspace(c, cs, 0) == 0
+        dsrc = [dev.upload_planes(s_, 64) for s_ in srcs]
+        ddst = [dev.planes_like("bgra", w, h, 64) for _ in srcs]
+        sp, dp = (C.c_void_p * (4 * nf))(), (C.c_void_p * (4 * nf))()
+        for f in range(nf):
+            for i, p in enumerate(dsrc[f]):
+                sp[4 * f + i] = p.ptr
+            for i, p in enumerate(ddst[f]):
+                dp[4 * f + i] = p.ptr
+        assert lib.gmat_sws_scale_batch(c, nf, C.cast(sp, C.POINTER(C.c_void_p)), ints([p.stride for p in dsrc[0]]), C.cast(dp, C.POINTER(C.c_void_p)),
+                                        ints([p.stride for p in ddst[0]]), C.cast((C.c_void_p * 1)(None), C.POINTER(C.c_void_p)), 1, 3) == nf
+        lib.gmat_device_sync()
+        assert lib.gmat_sws_lastKernel(c).decode() == "unit_rgb_kernel" and lib.gmat_sws_lastLaunchFrames(c) == nf
+        for f in range(nf):
+            assert (ddst[f][0].download() == wants[f][0]).all(), (sf, cs, f)
+        lib.gmat_sws_freeContext(c)
+        for fr in dsrc + ddst:
+            for p in fr:
+                p.free()
+    monkeypatch.setenv("GMAT_S19_UNIT", "0")
+    assert _run(dev, orc, "p010le", "rgb24", 64, 18, 64, 0) != "unit_rgb_kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", [("p010le", "rgb24"), ("yuv420p10le", "bgra"), ("p016le", "rgba")], ids=lambda p: f"{p[0]}-{p[1]}")
+def test_deep_sources_into_rgb_full_size(dev, orc, pair):
+    assert _run(dev, orc, pair[0], pair[1], 1920, 1080, 64, 0) == "unit_rgb_kernel"
