@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the SAME-SIZE conversions between the YUV depths and layouts and into RGBA64 / BGRA64 (the tile kernel's unit forms,
-k_scale19.hip: scale19_unit_kernel, scale19_unit64_kernel — and whatever takes the draws they refuse: differing chroma positions, odd planes, ragged widths)
-against the oracle: every format pair, range conversions, chroma positions, plane alignments, filter families.
+k_scale19.hip: scale19_unit_kernel, scale19_unit64_kernel, unit_rgb_kernel — and whatever takes the draws they refuse: differing chroma positions, odd planes, ragged widths)
+against the oracle: every format pair (deep 4:2:0 sources into packed 8-bit RGB too), range conversions, chroma positions, plane alignments, filter families.
 usage: tests/fuzz/fuzz_unit.py [ncases] [seed] [--hip]"""
 import os, sys, random, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ YUV = ["nv12", "yuv420p", "p010le", "p016le", "yuv420p10le", "yuv420p16le", "yuv
 DEEP = ("p010le", "p016le", "yuv420p10le", "yuv420p16le", "yuv444p16le", "rgba64le", "bgra64le")
 for case in range(n):
     sf = rng.choice(YUV)
-    df = rng.choice(YUV + ["rgba64le", "bgra64le", "rgba64le"])
+    df = rng.choice(YUV + ["rgba64le", "bgra64le", "rgba64le"] + (["rgb24", "bgr24", "rgba", "bgra"] if sf in ("p010le", "p016le", "yuv420p10le", "yuv420p16le") else []))
     sw = rng.choice([rng.randint(2, 400), 8 * rng.randint(1, 50)])
     sh = rng.randint(2, 90)
     dw, dh = sw, sh
