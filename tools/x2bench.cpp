@@ -366,6 +366,9 @@ int main(int argc, char **argv)
         {"yuv2yuv: nv12 1080p->1080p yuv420p10le", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_SWS_BICUBIC},
         {"yuv2yuv: yuv420p10le 4K->4K p010", GMAT_PIX_FMT_YUV420P10LE, 3840, 2160, GMAT_PIX_FMT_P010LE, 3840, 2160, GMAT_SWS_BICUBIC},
         {"yuv2yuv: p016 4K->4K nv12 (16 -> 8 bits, dithered)", GMAT_PIX_FMT_P016LE, 3840, 2160, GMAT_PIX_FMT_NV12, 3840, 2160, GMAT_SWS_BICUBIC},
+        // 16-bit 4:2:0 sources into packed 8-bit RGB at equal size (no unscaled converter in libswscale): unit_rgb_kernel
+        {"deep2rgb: p010 1080p->1080p rgb24 convert", GMAT_PIX_FMT_P010LE, 1920, 1080, GMAT_PIX_FMT_RGB24, 1920, 1080, GMAT_SWS_BICUBIC},
+        {"deep2rgb: yuv420p10le 1080p->1080p bgra convert", GMAT_PIX_FMT_YUV420P10LE, 1920, 1080, GMAT_PIX_FMT_BGRA, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 1080p->720p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_PIX_FMT_YUV444P, 1280, 720, GMAT_SWS_BICUBIC},
         {"rgbsrc: yuv444p 4K->1080p yuv444p bicubic (4:4:4 at both ends)", GMAT_PIX_FMT_YUV444P, 3840, 2160, GMAT_PIX_FMT_YUV444P, 1920, 1080, GMAT_SWS_BICUBIC},
         {"rgbsrc: nv12 1080p->640x640 rgb24 bilinear (a network's input)", GMAT_PIX_FMT_NV12, 1920, 1080, GMAT_PIX_FMT_RGB24, 640, 640, GMAT_SWS_BILINEAR},
