@@ -2891,7 +2891,11 @@ int yuv2yuv_cuda(const uint8_t *src[], int srcStride[], uint8_t *dst[], int dstS
 {
     const bool yuvAny = is_yuv420(srcFormat) || is_p01x(srcFormat) || srcFormat == GMAT_PIX_FMT_YUV420P10LE || srcFormat == GMAT_PIX_FMT_YUV420P16LE;
     const bool dstOk = is_yuv420(dstFormat) || is_p01x(dstFormat) || dstFormat == GMAT_PIX_FMT_YUV420P10LE || dstFormat == GMAT_PIX_FMT_YUV420P16LE;
-    if (!((srcFormat == dstFormat && yuvAny) || (is_yuv420(srcFormat) && dstOk))) return GMAT_ERR(ENOSYS);
+    // The reference's switch (yuv2yuv_cuda.cu:324-366) has arms for equal formats and for NV12 / YUV420P sources only — a P010 / P016 / 10- or 16-bit planar source into
+    // another format of the list falls through it and writes NOTHING (found with the reference's own core, round 6: sws_scale() of a same-size P010 -> NV12
+    // SWS_HWACCEL_CUDA context leaves the destination untouched).  This symbol serves every pair of the list — what the CPU context of the same libswscale computes
+    // (the generic lines with one-tap filters: scale19_unit_kernel) — so that the core's convert_unscaled path has no silent hole here.
+    if (!(yuvAny && dstOk)) return GMAT_ERR(ENOSYS);
     return stateless_convert(src, srcStride, dst, dstStride, w, h, srcFormat, dstFormat, stream);
 }
 

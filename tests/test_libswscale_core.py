@@ -74,6 +74,14 @@ CASES = [
     (116, 32, "rgb24", 142, 44, "rgb24", 0x40, 0x40),            # RGB -> RGB: the chroma banks differ from the luma banks (the plane scaler, not scale_rgb_kernel)
     (160, 90, "nv12", 240, 136, "nv12", 0x400, 0x400),
     (164, 68, "rgba", 92, 50, "nv12", 0x400 | 0x40000, 0x400 | 0x40000),
+    # round 6: SAME size with a deep source — the core's convert_unscaled calls yuv2yuv_cuda, whose reference switch has no arm for P010 / P016 sources and
+    # writes nothing (yuv2yuv_cuda.cu:324-366); this library's symbol serves every pair of the list with what the CPU context computes (scale19_unit_kernel)
+    (64, 18, "p010le", 64, 18, "nv12", BICUBIC, BICUBIC),
+    (136, 22, "p016le", 136, 22, "p010le", BICUBIC, BICUBIC),
+    (66, 10, "p010le", 66, 10, "yuv420p", BICUBIC, BICUBIC),
+    (64, 18, "p016le", 64, 18, "nv12", BILINEAR, BILINEAR),
+    (64, 18, "yuv420p", 64, 18, "p016le", BICUBIC, BICUBIC),
+    (64, 18, "nv12", 64, 18, "rgba64le", BICUBIC, BICUBIC),      # ... and yuv2rgb_cuda's 64-bit output at equal size (scale19_unit64_kernel)
 ]
 
 
